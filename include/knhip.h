@@ -1,0 +1,203 @@
+/* include/knhip.h -- the drop-in boundary: C ABI between the C++ host IndexNode and the
+ * hand-written HIP (gfx950) Search() kernels.
+ *
+ * Plain pointers and sizes only; no C++/torch types; never throws; every entry point
+ * returns 0 on success or a negative knhip_status, with the message available from
+ * knhip_last_error() (thread-local).  One knhip_index lives on ONE device (one process per
+ * GPU); multi-GPU list sharding is done by giving each rank's index only the inverted lists
+ * it owns (all other lists empty) and merging the per-rank partial top-k with
+ * knhip_merge_topk_device after an RCCL all-gather.
+ *
+ * What each entry point replaces in the reference (/root/reference):
+ *   knhip_index_create / set_* / add_*   the state GpuCuvsIndexNode::Train builds on device
+ *                                        (src/index/gpu_cuvs/gpu_cuvs.h:88-119) and the faiss
+ *                                        objects IvfIndexNode::Train/Add fill
+ *                                        (src/index/ivf/ivf.cc:547-844): IndexFlat centroids,
+ *                                        ProductQuantizer::centroids, ScalarQuantizer::trained,
+ *                                        ArrayInvertedLists codes/ids
+ *                                        (thirdparty/faiss/faiss/invlists/InvertedLists.h:264-266)
+ *   knhip_search                         IvfIndexNode::Search (src/index/ivf/ivf.cc:889-1168),
+ *                                        FlatIndexNode::Search (src/index/flat/flat.cc:76-148),
+ *                                        BruteForce::Search (src/common/comp/brute_force.cc:258-392),
+ *                                        cuvs_knowhere_index::search
+ *                                        (src/common/cuvs/integration/cuvs_knowhere_index.cuh:507-633)
+ *   knhip_search_device                  same, inputs/outputs already resident in HBM
+ *   knhip_coarse_search_device           quantizer->search (thirdparty/faiss/faiss/IndexIVF.cpp:336-342)
+ *   knhip_merge_topk_*                   merge_knn_results (thirdparty/faiss/faiss/utils/Heap.h:636),
+ *                                        IndexShards (thirdparty/faiss/faiss/IndexShards.cpp:247-256)
+ *   knhip_fvec_* / knhip_int8_*          the src/simd hook table (src/simd/hook.h:33-139),
+ *                                        scalar semantics of src/simd/distances_ref.cc
+ *
+ * Numeric contract ("exact" mode, the default): every distance is computed with the
+ * reference's scalar operation order, one IEEE rounding per operation (no FMA contraction),
+ * so returned distances are bit-equal to the scalar reference; returned ids are the k best
+ * in canonical order (L2: distance asc, id asc; IP: distance desc, id desc -- the order
+ * heap_reorder produces, thirdparty/faiss/faiss/utils/Heap.h:427-457).  The only licensed
+ * deviation: among candidates whose distance EQUALS the k-th distance bit-for-bit, the
+ * reference keeps first-scanned, this library keeps canonical-first.
+ */
+#ifndef KNHIP_H
+#define KNHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KNHIP_ABI_VERSION 1
+
+typedef struct knhip_index knhip_index;
+
+typedef enum knhip_kind {
+    KNHIP_BRUTE_FORCE = 0, /* FLAT / BruteForce */
+    KNHIP_IVF_FLAT = 1,
+    KNHIP_IVF_PQ = 2,
+    KNHIP_IVF_SQ8 = 3
+} knhip_kind;
+
+typedef enum knhip_metric { KNHIP_L2 = 0, KNHIP_IP = 1 } knhip_metric;
+/* COSINE is handled above the ABI exactly as the reference does: base normalised at
+ * train/add, query copied+normalised per search, metric mapped to IP
+ * (src/index/ivf/ivf.cc:559-565, 1068-1071; src/common/metric.h:30). */
+
+typedef enum knhip_status {
+    KNHIP_OK = 0,
+    KNHIP_ERR_INVALID_ARGS = -1,    /* Status::invalid_args */
+    KNHIP_ERR_NOT_TRAINED = -2,     /* Status::index_not_trained */
+    KNHIP_ERR_EMPTY_INDEX = -3,     /* Status::empty_index */
+    KNHIP_ERR_NOT_IMPLEMENTED = -4, /* Status::not_implemented */
+    KNHIP_ERR_HIP_RUNTIME = -5,     /* Status::cuda_runtime_error (reused for HIP) */
+    KNHIP_ERR_OUT_OF_MEMORY = -6    /* Status::malloc_error */
+} knhip_status;
+
+typedef struct knhip_desc {
+    int32_t kind;   /* knhip_kind */
+    int32_t metric; /* knhip_metric */
+    int32_t dim;
+    int32_t device;   /* HIP device ordinal */
+    int64_t nlist;    /* IVF kinds */
+    int32_t pq_m;     /* IVF_PQ: sub-quantizers (must divide dim) */
+    int32_t pq_nbits; /* IVF_PQ: 8 */
+    /* IVF_PQ + L2: precomputed term-2 table limit in bytes; 0 = the reference default 2 GiB
+     * (thirdparty/faiss/faiss/IndexIVFPQ.cpp:375).  Above it the residual-table form is used,
+     * as the reference does (:441-456). */
+    int64_t precomputed_table_max_bytes;
+} knhip_desc;
+
+/* ---- library ---- */
+int knhip_abi_version(void);
+int knhip_device_count(void);
+const char* knhip_last_error(void);
+
+/* ---- index lifetime and contents (all pointers below are HOST pointers) ---- */
+int knhip_index_create(const knhip_desc* desc, knhip_index** out);
+void knhip_index_destroy(knhip_index* idx);
+
+/* coarse centroids [nlist][dim] fp32 (IndexFlat xb of the quantizer) */
+int knhip_index_set_coarse(knhip_index* idx, const float* centroids);
+/* PQ codebooks [M][ksub][dsub] fp32 (ProductQuantizer::centroids) */
+int knhip_index_set_pq(knhip_index* idx, const float* codebooks);
+/* SQ8 trained params: vmin[dim], vdiff[dim] (ScalarQuantizer::trained) */
+int knhip_index_set_sq(knhip_index* idx, const float* vmin, const float* vdiff);
+/* inverted lists in faiss ArrayInvertedLists layout: list_sizes[nlist],
+ * codes[l] -> uint8[len][code_size] (IVF_FLAT: the fp32 rows), ids[l] -> int64[len].
+ * Replaces any previous content.  codes[l]/ids[l] may be NULL when list_sizes[l] == 0. */
+int knhip_index_add_lists(knhip_index* idx, const int64_t* list_sizes, const uint8_t* const* codes,
+                          const int64_t* const* ids);
+/* BRUTE_FORCE base vectors [n][dim] fp32; ids NULL => 0..n-1 (+ id_offset, cf. tensor begin id
+ * include/knowhere/dataset.h:412) */
+int knhip_index_add_vectors(knhip_index* idx, int64_t n, const float* x, const int64_t* ids,
+                            int64_t id_offset);
+
+/* Device-resident bulk variants (GPU build path; pointers are DEVICE pointers on idx's
+ * device, consumed before the call returns): entries sorted by list, ids ascending inside
+ * each list; list_offsets is a HOST array [nlist+1]. */
+int knhip_index_set_coarse_device(knhip_index* idx, const float* d_centroids);
+int knhip_index_set_lists_device(knhip_index* idx, const int64_t* list_offsets,
+                                 const uint8_t* d_codes, const int64_t* d_ids);
+int knhip_index_add_vectors_device(knhip_index* idx, int64_t n, const float* d_x,
+                                   const int64_t* d_ids, int64_t id_offset);
+
+int64_t knhip_index_count(const knhip_index* idx);         /* stored vectors */
+int64_t knhip_index_device_bytes(const knhip_index* idx);  /* HBM held by the index */
+int knhip_index_uses_precomputed_table(const knhip_index* idx);
+
+/* ---- search ---- */
+/* Host boundary (what the IndexNode calls): queries [nq][dim] host fp32; bitset host bytes
+ * LSB-first, bit set => id filtered OUT (include/knowhere/bitsetview_idselector.h:20-31),
+ * NULL => none; out_ids[nq*k] int64 / out_dist[nq*k] fp32 host, best-first; missing results
+ * id = -1, dist = +FLT_MAX (L2) / -FLT_MAX (IP) (thirdparty/faiss/faiss/utils/Heap.h:338-341).
+ * nprobe is clamped to nlist (thirdparty/faiss/faiss/IndexIVF.cpp:321-322); ignored for
+ * BRUTE_FORCE.  Thread-safe for concurrent calls on one index. */
+int knhip_search(const knhip_index* idx, const float* queries, int64_t nq, int32_t k,
+                 int32_t nprobe, const uint8_t* bitset, int64_t bitset_nbits, int64_t* out_ids,
+                 float* out_dist);
+/* Same with every buffer already in HBM; enqueued on `stream` (hipStream_t, NULL = default
+ * stream) and NOT synchronised. */
+int knhip_search_device(const knhip_index* idx, const float* d_queries, int64_t nq, int32_t k,
+                        int32_t nprobe, const uint8_t* d_bitset, int64_t bitset_nbits,
+                        int64_t* d_out_ids, float* d_out_dist, void* stream);
+/* Coarse quantizer only: top-nprobe centroids per query, best-first. */
+int knhip_coarse_search_device(const knhip_index* idx, const float* d_queries, int64_t nq,
+                               int32_t nprobe, int64_t* d_out_keys, float* d_out_dist,
+                               void* stream);
+
+/* ---- multi-GPU: merge of per-shard partial top-k ----
+ * parts laid out [nshard][nq][k]; ids < 0 are empty slots. */
+int knhip_merge_topk_device(int32_t metric, int64_t nq, int32_t k, int32_t nshard,
+                            const float* d_dist_parts, const int64_t* d_ids_parts, float* d_out_dist,
+                            int64_t* d_out_ids, void* stream);
+int knhip_merge_topk_host(int32_t metric, int64_t nq, int32_t k, int32_t nshard,
+                          const float* dist_parts, const int64_t* ids_parts, float* out_dist,
+                          int64_t* out_ids);
+
+/* ---- src/simd distance primitives, HIP equivalents (device pointers, exact scalar order) ---- */
+/* dis[i] = ||x - y_i||^2, y row-major [ny][d]          (fvec_L2sqr_ny,        hook.h:60) */
+int knhip_fvec_L2sqr_ny(float* d_dis, const float* d_x, const float* d_y, int64_t d, int64_t ny,
+                        void* stream);
+/* ip[i] = <x, y_i>                                     (fvec_inner_products_ny, hook.h:63) */
+int knhip_fvec_inner_products_ny(float* d_ip, const float* d_x, const float* d_y, int64_t d,
+                                 int64_t ny, void* stream);
+/* out[i] = ||x_i||^2 for n rows                        (fvec_norm_L2sqr,       hook.h:39) */
+int knhip_fvec_norms_L2sqr(float* d_out, const float* d_x, int64_t d, int64_t n, void* stream);
+/* c = a + bf * b                                       (fvec_madd,             hook.h:66) */
+int knhip_fvec_madd(int64_t n, const float* d_a, float bf, const float* d_b, float* d_c,
+                    void* stream);
+/* int8 rows: int32 accumulate then cast                (int8_vec_L2sqr / _inner_product,
+ *                                                       distances_ref.cc:386-404)       */
+int knhip_int8_vec_L2sqr_ny(float* d_dis, const int8_t* d_x, const int8_t* d_y, int64_t d,
+                            int64_t ny, void* stream);
+int knhip_int8_vec_inner_products_ny(float* d_ip, const int8_t* d_x, const int8_t* d_y, int64_t d,
+                                     int64_t ny, void* stream);
+
+/* ---- profiling hooks (bench.py / rocprof cross-check) ---- */
+#define KNHIP_NSTAGE 8
+typedef struct knhip_stage_times {
+    /* accumulated HIP-event milliseconds per stage since the last reset, and launch counts */
+    float ms[KNHIP_NSTAGE];
+    int64_t launches[KNHIP_NSTAGE];
+    /* algorithmic bytes / flops of the last search (SURVEY.md section 8d definitions) */
+    double scan_bytes;    /* sum over (query, probe) of len(list) * code_size */
+    double coarse_flops;  /* 2 * nq * nlist * dim */
+    int64_t scan_items;   /* work items launched by the scan kernel */
+} knhip_stage_times;
+/* stage indices */
+enum {
+    KNHIP_STAGE_COARSE = 0,   /* query x centroid distances + top-nprobe */
+    KNHIP_STAGE_GROUP = 1,    /* (query,probe) -> per-list work table */
+    KNHIP_STAGE_LUT = 2,      /* PQ query tables */
+    KNHIP_STAGE_SCAN = 3,     /* per-list code scan (ADC / flat / SQ8) -- the dominant kernel */
+    KNHIP_STAGE_MERGE = 4,    /* per-query merge of per-probe partial top-k */
+    KNHIP_STAGE_OTHER = 5
+};
+int knhip_profile_enable(knhip_index* idx, int on);
+int knhip_profile_reset(knhip_index* idx);
+int knhip_profile_get(const knhip_index* idx, knhip_stage_times* out);
+const char* knhip_stage_kernel_name(int stage, int kind);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KNHIP_H */

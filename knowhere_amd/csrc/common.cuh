@@ -1,0 +1,226 @@
+// knowhere_amd/csrc/common.cuh -- shared device/host helpers for the gfx950 kernels.
+//
+// Conventions used by every kernel in this directory:
+//  * wave = 64 lanes, hard-coded (CDNA4); block sizes are multiples of 64.
+//  * "exact" arithmetic: the reference's scalar operation order with one IEEE rounding per
+//    operation.  The translation units are built with -ffp-contract=off and the helpers
+//    below use the _rn intrinsics, so no mul+add is ever fused behind our back.
+//  * canonical result order (what heap_reorder produces in the reference,
+//    thirdparty/faiss/faiss/utils/Heap.h:427-457 with the comparators of
+//    utils/ordered_key_value.h:43-83):  L2: (dist asc, id asc);  IP: (dist desc, id desc).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <float.h>
+#include "kernels.h"
+
+#define KN_WAVE 64
+
+// ---- exact (never contracted) fp32 ops -----------------------------------------------------
+__device__ __forceinline__ float fadd_x(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ float fsub_x(float a, float b) { return __fsub_rn(a, b); }
+__device__ __forceinline__ float fmul_x(float a, float b) { return __fmul_rn(a, b); }
+
+// res += (x - y)^2 with the reference's three roundings (src/simd/distances_ref.cc:30-37)
+__device__ __forceinline__ float l2_step(float res, float x, float y) {
+    const float t = fsub_x(x, y);
+    return fadd_x(res, fmul_x(t, t));
+}
+// res += x * y (src/simd/distances_ref.cc:21-28)
+__device__ __forceinline__ float ip_step(float res, float x, float y) {
+    return fadd_x(res, fmul_x(x, y));
+}
+
+// ---- canonical ordering ----------------------------------------------------------------------
+// IS_L2: "a is better than b"  <=>  (da < db) || (da == db && ia < ib)
+// IP   :                         (da > db) || (da == db && ia > ib)
+template <bool IS_L2>
+__device__ __forceinline__ bool better(float da, int64_t ia, float db, int64_t ib) {
+    if (IS_L2) {
+        return (da < db) || (da == db && ia < ib);
+    }
+    return (da > db) || (da == db && ia > ib);
+}
+template <bool IS_L2>
+__device__ __forceinline__ bool better_or_equal_dist(float da, float db) {
+    return IS_L2 ? (da <= db) : (da >= db);
+}
+template <bool IS_L2>
+__device__ __forceinline__ float worst_dist() {
+    // C::neutral(): +FLT_MAX for the max-heap (L2), lowest() for the min-heap (IP)
+    return IS_L2 ? FLT_MAX : -FLT_MAX;
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (KN_WAVE - 1); }
+
+// 64-bit shuffle helpers (ds_bpermute based; used only on slow paths)
+__device__ __forceinline__ int64_t shfl_i64(int64_t v, int src) {
+    int lo = __shfl((int)(v & 0xffffffffll), src, KN_WAVE);
+    int hi = __shfl((int)(v >> 32), src, KN_WAVE);
+    return ((int64_t)hi << 32) | (uint32_t)lo;
+}
+
+// ---- WaveTopK: a wave-resident sorted list of the K best (dist, idx) ---------------------------
+// Element e (0 = best) lives in lane e % 64, register e / 64.  R = registers per lane, capacity
+// 64*R >= k.  All methods must be called by the full wave with wave-uniform arguments unless
+// noted.  `idx` is whatever the caller orders ties by (list offset, row number or id) -- it is
+// compared as a signed 64-bit integer in the canonical direction.
+template <bool IS_L2, int R>
+struct WaveTopK {
+    float d[R];
+    int64_t i[R];
+    int k;
+
+    __device__ __forceinline__ void init(int k_) {
+        k = k_;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            d[r] = worst_dist<IS_L2>();
+            i[r] = -1;
+        }
+    }
+
+    // distance of the current k-th element (wave-uniform)
+    __device__ __forceinline__ float kth_dist() const {
+        const int e = k - 1;
+        float v = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if (r == e / KN_WAVE) {
+                v = __shfl(d[r], e % KN_WAVE, KN_WAVE);
+            }
+        }
+        return v;
+    }
+    __device__ __forceinline__ int64_t kth_idx() const {
+        const int e = k - 1;
+        int64_t v = -1;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if (r == e / KN_WAVE) {
+                v = shfl_i64(i[r], e % KN_WAVE);
+            }
+        }
+        return v;
+    }
+
+    // would (dist, idx) enter the list?  Empty slots have idx -1 and the neutral distance: a real
+    // candidate whose distance equals the neutral value is rejected, as the reference's strict
+    // heap admission does (thirdparty/faiss/faiss/impl/ResultHandler.h:271-278).
+    __device__ __forceinline__ bool admits(float dist, int64_t idx, float kd, int64_t ki) const {
+        if (ki < 0) {
+            return IS_L2 ? (dist < kd) : (dist > kd);
+        }
+        return better<IS_L2>(dist, idx, kd, ki);
+    }
+
+    // insert a wave-uniform candidate that is known to be admissible
+    __device__ __forceinline__ void insert(float dist, int64_t idx) {
+        const int lane = lane_id();
+        // position = number of stored elements strictly better than the candidate
+        int pos = 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const bool b = (i[r] >= 0) && better<IS_L2>(d[r], i[r], dist, idx);
+            pos += __popcll(__ballot(b));
+        }
+        // shift elements [pos, k-2] one place towards the tail, highest register first
+        float carry_d_prev = 0.f;
+        int64_t carry_i_prev = 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            // value coming into lane 0 of register r is lane 63 of register r-1 (pre-shift)
+            const float last_d = __shfl(d[r], KN_WAVE - 1, KN_WAVE);
+            const int64_t last_i = shfl_i64(i[r], KN_WAVE - 1);
+            float up_d = __shfl_up(d[r], 1, KN_WAVE);
+            int64_t up_i;
+            {
+                int lo = __shfl_up((int)(i[r] & 0xffffffffll), 1, KN_WAVE);
+                int hi = __shfl_up((int)(i[r] >> 32), 1, KN_WAVE);
+                up_i = ((int64_t)hi << 32) | (uint32_t)lo;
+            }
+            if (lane == 0) {
+                up_d = carry_d_prev;
+                up_i = carry_i_prev;
+            }
+            const int e = r * KN_WAVE + lane;
+            if (e > pos) {
+                d[r] = up_d;
+                i[r] = up_i;
+            } else if (e == pos) {
+                d[r] = dist;
+                i[r] = idx;
+            }
+            carry_d_prev = last_d;
+            carry_i_prev = last_i;
+        }
+        // elements beyond k-1 are garbage by construction; re-neutralise them so kth/merge
+        // never see them
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int e = r * KN_WAVE + lane;
+            if (e >= k) {
+                d[r] = worst_dist<IS_L2>();
+                i[r] = -1;
+            }
+        }
+    }
+
+    // write the k elements (best first) to dst arrays (global or LDS), one per lane-slot
+    template <class TD, class TI>
+    __device__ __forceinline__ void store(TD* dd, TI* ii) const {
+        const int lane = lane_id();
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int e = r * KN_WAVE + lane;
+            if (e < k) {
+                dd[e] = d[r];
+                ii[e] = i[r];
+            }
+        }
+    }
+};
+
+// runtime k -> compile-time R dispatch (k <= 1024)
+#define KN_MAX_K 1024
+#define KN_DISPATCH_R(k, ...)                \
+    do {                                     \
+        if ((k) <= 64) {                     \
+            constexpr int R_ = 1;            \
+            __VA_ARGS__                      \
+        } else if ((k) <= 128) {             \
+            constexpr int R_ = 2;            \
+            __VA_ARGS__                      \
+        } else if ((k) <= 256) {             \
+            constexpr int R_ = 4;            \
+            __VA_ARGS__                      \
+        } else if ((k) <= 512) {             \
+            constexpr int R_ = 8;            \
+            __VA_ARGS__                      \
+        } else {                             \
+            constexpr int R_ = 16;           \
+            __VA_ARGS__                      \
+        }                                    \
+    } while (0)
+
+// ---- bitset (bit set => filtered out, LSB first; include/knowhere/bitsetview_idselector.h) ---
+__device__ __forceinline__ bool bitset_filtered(const uint8_t* bitset, int64_t nbits, int64_t id) {
+    if (bitset == nullptr || id < 0 || id >= nbits) {
+        return false;
+    }
+    return (bitset[id >> 3] >> (id & 7)) & 1;
+}
+
+// ---- XCD-aware work mapping --------------------------------------------------------------------
+// Consecutive work items share an inverted list; the dispatcher places block b on XCD b % 8
+// (speed only, never correctness), so give each XCD a contiguous run of items and its private
+// L2 sees every list once.
+__device__ __forceinline__ int64_t xcd_item(int64_t b, int64_t nitems) {
+    const int64_t per = (nitems + 7) / 8;
+    return (b % 8) * per + (b / 8);
+}
+
+// ---- per-(query,slot) partial result layout -----------------------------------------------------
+// partial_d/partial_i : [nq][nslot][k], slot = probe rank (IVF) or base chunk (brute force)
+

@@ -1,0 +1,183 @@
+// knowhere_amd/csrc/kernels.h -- host-side launch interface between knhip_api.hip and the
+// kernel translation units.  Everything here is internal to libknhip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <algorithm>
+
+namespace knhip {
+
+// ---- work item table ------------------------------------------------------------------------------
+struct KnItem {
+    int32_t list;   // inverted list (or base chunk) to scan
+    int32_t npair;  // number of (query, slot) pairs in this item, 1..QG
+    int64_t pair0;  // first entry in the sorted pair array
+};
+// sorted pair entry: query index and slot (probe rank) packed
+struct KnPair {
+    int32_t q;
+    int32_t slot;
+};
+
+struct FlatScanArgs {
+    // rows
+    const float4* rows;          // interleaved blocks
+    const int64_t* list_blk_off; // [nlist] first block of each list (TABLE) / nullptr (DENSE)
+    const int64_t* list_len;     // [nlist] rows in each list (TABLE)
+    const int64_t* list_row_off; // [nlist] first entry in ids[] of each list (TABLE)
+    const int64_t* ids;          // [ntotal] (TABLE) or nullptr (DENSE: id = row + id_offset)
+    int64_t nrows;               // DENSE: total rows
+    int64_t chunk_rows;          // DENSE: rows per chunk (multiple of 64)
+    int64_t id_offset;           // DENSE
+    int32_t d;
+    int32_t nchunk;              // ceil(d/4)
+    // queries
+    const float* queries;        // [nq][d]
+    int64_t nq;
+    // work
+    const KnItem* items;         // TABLE
+    const KnPair* pairs;         // TABLE
+    const int64_t* nitems_dev;   // TABLE: device scalar
+    int64_t nitems_dense;        // DENSE: nchunks * ngroups
+    int64_t ngroups;             // DENSE
+    // filter
+    const uint8_t* bitset;
+    int64_t bitset_nbits;
+    // output
+    float* partial_d;            // [nq][nslot][k]
+    int64_t* partial_i;
+    int32_t nslot;
+    int32_t k;
+};
+
+enum PqLutMode { PQ_LUT_PRECOMP = 0, PQ_LUT_IP = 1, PQ_LUT_RESIDUAL = 2 };
+
+struct PqScanArgs {
+    // index
+    const uint4* codes_skew;       // skewed code blocks
+    const int64_t* list_sblk_off;  // [nlist+1] first skew block of each list
+    const int64_t* list_len;       // [nlist]
+    const int64_t* list_row_off;   // [nlist] offset into ids[]
+    const int64_t* ids;            // [ntotal] sorted by list, ascending inside a list
+    const float* precomp_t;        // [nlist][256][M]   (PRECOMP)
+    const float* cb;               // [M][256][dsub]    (RESIDUAL)
+    const float* centroids;        // [nlist][d]        (RESIDUAL)
+    int32_t d;
+    int32_t lut_mode;
+    // per search
+    const float* queries;          // [nq][d]           (RESIDUAL)
+    const float* t2t;              // [nq][256][M]      (PRECOMP, IP)
+    const float* coarse_dis;       // [nq][nprobe]
+    const KnItem* items;
+    const KnPair* pairs;
+    const int64_t* nitems_dev;
+    const uint8_t* bitset;
+    int64_t bitset_nbits;
+    float* partial_d;              // [nq][nslot][k]
+    int64_t* partial_i;
+    int32_t nslot;                 // = nprobe
+    int32_t k;
+};
+
+
+struct SqScanArgs {
+    const uint4* rows;           // interleaved blocks: [nchunk16][64 rows][16 code bytes]
+    const int64_t* list_blk_off; // [nlist]
+    const int64_t* list_len;     // [nlist]
+    const int64_t* list_row_off; // [nlist]
+    const int64_t* ids;          // [ntotal]
+    const float* trained;        // vmin[d], vdiff[d]
+    const float* centroids;      // [nlist][d]  (L2: query residual)
+    int32_t d;
+    int32_t nchunk16;            // ceil(d/16)
+    const float* queries;        // [nq][d]
+    const float* coarse_dis;     // [nq][nprobe] (IP: accu0)
+    const KnItem* items;
+    const KnPair* pairs;
+    const int64_t* nitems_dev;
+    const uint8_t* bitset;
+    int64_t bitset_nbits;
+    float* partial_d;            // [nq][nslot][k]
+    int64_t* partial_i;
+    int32_t nslot;
+    int32_t k;
+};
+
+// ---- flat_scan.hip ----
+int flat_scan_qg(int k);
+hipError_t launch_flat_scan(const FlatScanArgs& a, bool is_l2, bool dense, int64_t grid, hipStream_t s);
+hipError_t launch_flat_full(const FlatScanArgs& a, bool is_l2, float* out, const int32_t* q_subset,
+                            int64_t nq_subset, hipStream_t s);
+hipError_t launch_interleave_rows(const float* src, int64_t n, int d, float4* dst, int64_t dst_blk0,
+                                  hipStream_t s);
+hipError_t launch_interleave_lists(const float* src, const int64_t* list_row_off,
+                                   const int64_t* list_len, const int64_t* list_blk_off, int64_t nlist,
+                                   int d, float4* dst, hipStream_t s);
+
+// ---- pq_scan.hip ----
+int pq_scan_supported_m(int M);
+int pq_scan_qg(int M);
+int64_t pq_skew_blocks(int64_t len, int M);
+hipError_t launch_pq_scan(const PqScanArgs& a, bool is_l2, int M, int64_t grid, hipStream_t s);
+hipError_t launch_pq_query_table(const float* queries, const float* cb, int d, int M, int64_t nq,
+                                 float* t2t, hipStream_t s);
+hipError_t launch_pq_precomp_table(const float* centroids, const float* cb, int d, int M,
+                                   int64_t nlist, float* pt, hipStream_t s);
+hipError_t launch_pq_skew_codes(const uint8_t* codes, const int64_t* list_row_off,
+                                const int64_t* list_len, const int64_t* list_sblk_off, int64_t nlist,
+                                int M, uint4* out, hipStream_t s);
+
+// ---- sq_scan.hip ----
+hipError_t launch_sq_scan(const SqScanArgs& a, bool is_l2, int64_t grid, hipStream_t s);
+hipError_t launch_sq_interleave(const uint8_t* codes, const int64_t* list_row_off,
+                                const int64_t* list_len, const int64_t* list_blk_off, int64_t nlist,
+                                int d, uint4* out, hipStream_t s);
+
+// ---- worktable.hip: (query, probe) pairs -> per-list work items ----
+struct WorkTable {
+    // device buffers sized by the caller
+    int32_t* list_count;   // [nlist]
+    int64_t* list_pair_off;// [nlist+1]
+    int64_t* list_item_off;// [nlist+1]
+    int32_t* list_cursor;  // [nlist]
+    KnPair* pairs;         // [nq*nprobe]
+    KnItem* items;         // [nq*nprobe/qg + nlist]
+    int64_t* nitems;       // [1]
+    double* scan_bytes;    // [1] sum over pairs of len(list)*code_size
+};
+hipError_t launch_build_worktable(const int64_t* keys, int64_t nq, int nprobe, int64_t nlist, int qg,
+                                  const int64_t* list_len, int64_t code_size, const WorkTable& wt,
+                                  hipStream_t s);
+
+// ---- topk.hip: selection kernels ----
+// per query: k best of nslot sorted partial lists -> out (canonical order, sentinel padded);
+// list (q, slot) starts at q * q_stride + slot * slot_stride (elements)
+hipError_t launch_merge_partials(const float* partial_d, const int64_t* partial_i, int64_t nq,
+                                 int nslot, int k, int64_t q_stride, int64_t slot_stride, bool is_l2,
+                                 float* out_d, int64_t* out_i, hipStream_t s);
+// per row: the k best of n values (index = column), canonical order; out_keys int64, out_d float
+hipError_t launch_row_select(const float* vals, int64_t nrows, int64_t n, int k, bool is_l2,
+                             int64_t* out_keys, float* out_d, hipStream_t s);
+size_t row_select_max_k();
+
+// ---- coarse_gemm.hip: fp32 MFMA prefilter for the coarse quantizer ----
+hipError_t launch_row_norms(const float* x, int64_t n, int d, float* out, hipStream_t s);
+hipError_t launch_coarse_gemm(const float* q, const float* qnorm, const float* c, const float* cnorm,
+                              int64_t nq, int64_t nlist, int d, bool is_l2, float* out, hipStream_t s);
+hipError_t launch_coarse_rerank(const float* queries, const float* centroids, int d, int64_t nq,
+                                int64_t nlist, int ncand, const int64_t* cand_keys,
+                                const float* cand_approx, int nprobe, bool is_l2, const float* qnorm,
+                                float cnorm_max, int64_t* out_keys, float* out_d, int32_t* fail_flags,
+                                hipStream_t s);
+
+// ---- prims.hip ----
+hipError_t launch_fvec_ny(float* out, const float* x, const float* y, int64_t d, int64_t ny,
+                          bool is_l2, hipStream_t s);
+hipError_t launch_fvec_norms(float* out, const float* x, int64_t d, int64_t n, hipStream_t s);
+hipError_t launch_fvec_madd(int64_t n, const float* a, float bf, const float* b, float* c,
+                            hipStream_t s);
+hipError_t launch_int8_ny(float* out, const int8_t* x, const int8_t* y, int64_t d, int64_t ny,
+                          bool is_l2, hipStream_t s);
+
+} // namespace knhip

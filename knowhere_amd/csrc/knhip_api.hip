@@ -1,0 +1,1107 @@
+// knowhere_amd/csrc/knhip_api.hip -- the C ABI of libknhip.so (include/knhip.h): index object,
+// HBM layouts, and the Search() orchestration over the kernels in this directory.
+//
+// Search() on the device, IVF kinds (mirrors faiss::IndexIVF::search,
+// reference thirdparty/faiss/faiss/IndexIVF.cpp:305-399, driven per batch instead of per query):
+//   1. coarse   : exact query x centroid distances (flat_full) + per-row top-nprobe (row_select)
+//                 == quantizer->search(n, x, nprobe)                    IndexIVF.cpp:336-342
+//   2. group    : (query, probe) -> list-major work items                worktable.hip
+//   3. tables   : PQ query tables <q_m, cb[m][c]>                        IVFPQ_QueryTables.cpp:56-67
+//   4. scan     : per-list code scan with per-(query, probe) top-k      search_preassigned :625-671
+//   5. merge    : per query, k best of its nprobe partial lists          heap_reorder :665
+// BRUTE_FORCE is steps 4-5 with base chunks in place of lists.
+// Nothing in this path touches the host between the first and the last kernel.
+#include "../../include/knhip.h"
+#include "common.cuh"
+#include "kernels.h"
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <numeric>
+#include <string>
+#include <vector>
+
+using namespace knhip;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            return fail(e_ == hipErrorOutOfMemory ? KNHIP_ERR_OUT_OF_MEMORY : KNHIP_ERR_HIP_RUNTIME, \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                        \
+        }                                                                                          \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) {
+            (void)hipFree(p);
+        }
+        p = nullptr;
+        bytes = 0;
+    }
+    hipError_t alloc(size_t n) {
+        release();
+        if (n == 0) {
+            n = 16;
+        }
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) {
+            bytes = n;
+        } else {
+            p = nullptr;
+        }
+        return e;
+    }
+    // grow-only
+    hipError_t reserve(size_t n) {
+        if (n <= bytes) {
+            return hipSuccess;
+        }
+        return alloc(n);
+    }
+    template <class T>
+    T* as() const {
+        return static_cast<T*>(p);
+    }
+};
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        (void)hipGetDevice(&prev);
+        if (prev != dev) {
+            (void)hipSetDevice(dev);
+        }
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) {
+            (void)hipSetDevice(prev);
+        }
+    }
+};
+
+// per-stream scratch; stream order makes reuse by consecutive searches on one stream safe
+struct Workspace {
+    DevBuf coarse_full;  // [qb][nlist] exact distances
+    DevBuf keys;         // [qb][nprobe] int64
+    DevBuf cdis;         // [qb][nprobe] float
+    DevBuf t2t;          // [qb][256][M]
+    DevBuf partial_d;    // [qb][nslot][k]
+    DevBuf partial_i;
+    DevBuf list_count, list_pair_off, list_item_off, list_cursor, pairs, items, nitems;
+    // host-boundary staging
+    DevBuf h_queries, h_bitset, h_out_d, h_out_i;
+    bool busy = false;
+};
+
+struct PendingEvent {
+    int stage;
+    hipEvent_t e0, e1;
+};
+
+} // namespace
+
+struct knhip_index {
+    knhip_desc desc{};
+    bool is_l2 = true;
+    int64_t nlist = 0;
+    int d = 0;
+    // coarse quantizer
+    bool has_coarse = false;
+    DevBuf centroids;     // [nlist][d] row major
+    DevBuf centroids_il;  // interleaved 64-row blocks
+    // PQ
+    bool has_pq = false;
+    DevBuf cb;            // [M][256][dsub]
+    DevBuf precomp_t;     // [nlist][256][M]
+    int use_precomp = 0;
+    // SQ
+    bool has_sq = false;
+    DevBuf sq_trained;    // vmin[d], vdiff[d]
+    // lists / base
+    bool has_data = false;
+    int64_t ntotal = 0;
+    int64_t code_size = 0;
+    int64_t id_offset = 0;
+    std::vector<int64_t> h_list_len, h_list_row_off;
+    DevBuf d_list_len, d_list_row_off, d_list_blk_off;
+    DevBuf ids;
+    DevBuf rows;          // kind specific layout
+    // scratch
+    mutable std::mutex mu;
+    mutable std::map<void*, std::unique_ptr<Workspace>> ws_by_stream;
+    mutable std::vector<std::unique_ptr<Workspace>> ws_free;
+    // profiling
+    bool prof = false;
+    mutable std::vector<PendingEvent> pending;
+    mutable knhip_stage_times times{};
+    DevBuf scan_bytes_dev; // double accumulator
+    mutable double coarse_flops = 0;
+    mutable int64_t last_items_bound = 0;
+
+    int64_t device_bytes() const {
+        const DevBuf* all[] = {&centroids, &centroids_il, &cb, &precomp_t, &sq_trained, &d_list_len,
+                               &d_list_row_off, &d_list_blk_off, &ids, &rows};
+        int64_t t = 0;
+        for (auto* b : all) {
+            t += (int64_t)b->bytes;
+        }
+        return t;
+    }
+};
+
+namespace {
+
+struct StageTimer {
+    const knhip_index* idx;
+    hipStream_t s;
+    int stage;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    StageTimer(const knhip_index* i, hipStream_t st, int stg) : idx(i), s(st), stage(stg) {
+        if (idx->prof) {
+            (void)hipEventCreate(&e0);
+            (void)hipEventCreate(&e1);
+            (void)hipEventRecord(e0, s);
+        }
+    }
+    ~StageTimer() {
+        if (idx->prof) {
+            (void)hipEventRecord(e1, s);
+            std::lock_guard<std::mutex> lk(idx->mu);
+            idx->pending.push_back({stage, e0, e1});
+        }
+    }
+};
+
+int check_index(const knhip_index* idx) {
+    if (!idx) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "null index");
+    }
+    return KNHIP_OK;
+}
+
+int64_t round_up(int64_t a, int64_t b) {
+    return (a + b - 1) / b * b;
+}
+
+// upload helpers ---------------------------------------------------------------------------------
+int upload(DevBuf& dst, const void* src, size_t bytes) {
+    HIP_TRY(dst.alloc(bytes));
+    if (bytes) {
+        HIP_TRY(hipMemcpy(dst.p, src, bytes, hipMemcpyHostToDevice));
+    }
+    return KNHIP_OK;
+}
+
+int build_coarse_layout(knhip_index* idx) {
+    const int nchunk = (idx->d + 3) / 4;
+    const int64_t nblk = (idx->nlist + 63) / 64;
+    HIP_TRY(idx->centroids_il.alloc((size_t)nblk * nchunk * 64 * sizeof(float4)));
+    HIP_TRY(launch_interleave_rows(idx->centroids.as<float>(), idx->nlist, idx->d,
+                                   idx->centroids_il.as<float4>(), 0, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    return KNHIP_OK;
+}
+
+int maybe_build_precomp(knhip_index* idx) {
+    // reference thirdparty/faiss/faiss/IndexIVFPQ.cpp:428-456: L2 + by_residual, table within limit
+    idx->use_precomp = 0;
+    idx->precomp_t.release();
+    if (idx->desc.kind != KNHIP_IVF_PQ || !idx->has_coarse || !idx->has_pq || !idx->is_l2) {
+        return KNHIP_OK;
+    }
+    const size_t limit = idx->desc.precomputed_table_max_bytes > 0
+            ? (size_t)idx->desc.precomputed_table_max_bytes
+            : ((size_t)1 << 31);
+    const size_t table = (size_t)idx->nlist * 256 * idx->desc.pq_m * sizeof(float);
+    if (table > limit) {
+        return KNHIP_OK;
+    }
+    HIP_TRY(idx->precomp_t.alloc(table));
+    HIP_TRY(launch_pq_precomp_table(idx->centroids.as<float>(), idx->cb.as<float>(), idx->d,
+                                    idx->desc.pq_m, idx->nlist, idx->precomp_t.as<float>(), nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    idx->use_precomp = 1;
+    return KNHIP_OK;
+}
+
+// lay the lists out from device-resident, list-sorted AoS codes + ids
+int build_list_layout(knhip_index* idx, const std::vector<int64_t>& list_off, const uint8_t* d_codes,
+                      const int64_t* d_ids) {
+    const int64_t nlist = idx->nlist;
+    const int64_t ntotal = list_off[nlist];
+    idx->ntotal = ntotal;
+    idx->h_list_len.resize(nlist);
+    idx->h_list_row_off.assign(list_off.begin(), list_off.begin() + nlist);
+    for (int64_t l = 0; l < nlist; l++) {
+        idx->h_list_len[l] = list_off[l + 1] - list_off[l];
+        if (idx->h_list_len[l] < 0) {
+            return fail(KNHIP_ERR_INVALID_ARGS, "list offsets must be non-decreasing");
+        }
+    }
+    std::vector<int64_t> blk_off(nlist + 1, 0);
+    const int kind = idx->desc.kind;
+    for (int64_t l = 0; l < nlist; l++) {
+        int64_t nb;
+        if (kind == KNHIP_IVF_PQ) {
+            nb = pq_skew_blocks(idx->h_list_len[l], idx->desc.pq_m);
+        } else {
+            nb = (idx->h_list_len[l] + 63) / 64;
+        }
+        blk_off[l + 1] = blk_off[l] + nb;
+    }
+    int rc;
+    if ((rc = upload(idx->d_list_len, idx->h_list_len.data(), nlist * sizeof(int64_t)))) return rc;
+    if ((rc = upload(idx->d_list_row_off, idx->h_list_row_off.data(), nlist * sizeof(int64_t)))) return rc;
+    if ((rc = upload(idx->d_list_blk_off, blk_off.data(), (nlist + 1) * sizeof(int64_t)))) return rc;
+    HIP_TRY(idx->ids.alloc((size_t)ntotal * sizeof(int64_t)));
+    if (ntotal) {
+        HIP_TRY(hipMemcpy(idx->ids.p, d_ids, (size_t)ntotal * sizeof(int64_t), hipMemcpyDeviceToDevice));
+    }
+    const int64_t total_blk = blk_off[nlist];
+    if (kind == KNHIP_IVF_FLAT) {
+        const int nchunk = (idx->d + 3) / 4;
+        HIP_TRY(idx->rows.alloc((size_t)total_blk * nchunk * 64 * sizeof(float4)));
+        HIP_TRY(launch_interleave_lists(reinterpret_cast<const float*>(d_codes),
+                                        idx->d_list_row_off.as<int64_t>(), idx->d_list_len.as<int64_t>(),
+                                        idx->d_list_blk_off.as<int64_t>(), nlist, idx->d,
+                                        idx->rows.as<float4>(), nullptr));
+    } else if (kind == KNHIP_IVF_PQ) {
+        const int M = idx->desc.pq_m;
+        HIP_TRY(idx->rows.alloc((size_t)total_blk * M * sizeof(uint4)));
+        HIP_TRY(launch_pq_skew_codes(d_codes, idx->d_list_row_off.as<int64_t>(),
+                                     idx->d_list_len.as<int64_t>(), idx->d_list_blk_off.as<int64_t>(),
+                                     nlist, M, idx->rows.as<uint4>(), nullptr));
+    } else if (kind == KNHIP_IVF_SQ8) {
+        const int nchunk16 = (idx->d + 15) / 16;
+        HIP_TRY(idx->rows.alloc((size_t)total_blk * nchunk16 * 64 * sizeof(uint4)));
+        HIP_TRY(launch_sq_interleave(d_codes, idx->d_list_row_off.as<int64_t>(),
+                                     idx->d_list_len.as<int64_t>(), idx->d_list_blk_off.as<int64_t>(),
+                                     nlist, idx->d, idx->rows.as<uint4>(), nullptr));
+    } else {
+        return fail(KNHIP_ERR_INVALID_ARGS, "lists on a brute-force index");
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    idx->has_data = true;
+    return KNHIP_OK;
+}
+
+Workspace* acquire_ws(const knhip_index* idx, void* stream_key, bool pooled_by_stream) {
+    std::lock_guard<std::mutex> lk(idx->mu);
+    if (pooled_by_stream) {
+        auto& slot = idx->ws_by_stream[stream_key];
+        if (!slot) {
+            slot.reset(new Workspace());
+        }
+        return slot.get();
+    }
+    if (!idx->ws_free.empty()) {
+        Workspace* w = idx->ws_free.back().release();
+        idx->ws_free.pop_back();
+        return w;
+    }
+    return new Workspace();
+}
+
+void release_ws(const knhip_index* idx, Workspace* w) {
+    std::lock_guard<std::mutex> lk(idx->mu);
+    idx->ws_free.emplace_back(w);
+}
+
+// ---- one batch of queries, everything on the device ------------------------------------------------
+int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_t nq, int k, int nprobe,
+                 const uint8_t* d_bitset, int64_t nbits, int64_t* d_out_i, float* d_out_d,
+                 hipStream_t s) {
+    const int kind = idx->desc.kind;
+    const int d = idx->d;
+    const bool is_l2 = idx->is_l2;
+
+    if (kind == KNHIP_BRUTE_FORCE) {
+        const int64_t nb = idx->ntotal;
+        int64_t chunk_rows = std::max<int64_t>(1024, round_up((nb + 511) / 512, 64));
+        const int64_t nchunks = (nb + chunk_rows - 1) / chunk_rows;
+        const int qg = flat_scan_qg(k);
+        const int64_t ngroups = (nq + qg - 1) / qg;
+        HIP_TRY(ws->partial_d.reserve((size_t)nq * nchunks * k * sizeof(float)));
+        HIP_TRY(ws->partial_i.reserve((size_t)nq * nchunks * k * sizeof(int64_t)));
+        FlatScanArgs a{};
+        a.rows = idx->rows.as<float4>();
+        a.nrows = nb;
+        a.chunk_rows = chunk_rows;
+        a.id_offset = idx->id_offset;
+        a.d = d;
+        a.nchunk = (d + 3) / 4;
+        a.queries = d_q;
+        a.nq = nq;
+        a.nitems_dense = nchunks * ngroups;
+        a.ngroups = ngroups;
+        a.bitset = d_bitset;
+        a.bitset_nbits = nbits;
+        a.partial_d = ws->partial_d.as<float>();
+        a.partial_i = ws->partial_i.as<int64_t>();
+        a.nslot = (int)nchunks;
+        a.k = k;
+        {
+            StageTimer t(idx, s, KNHIP_STAGE_SCAN);
+            HIP_TRY(launch_flat_scan(a, is_l2, true, a.nitems_dense, s));
+        }
+        {
+            StageTimer t(idx, s, KNHIP_STAGE_MERGE);
+            HIP_TRY(launch_merge_partials(a.partial_d, a.partial_i, nq, (int)nchunks, k, nchunks * k, k,
+                                          is_l2, d_out_d, d_out_i, s));
+        }
+        return KNHIP_OK;
+    }
+
+    // ---- IVF kinds ----
+    const int64_t nlist = idx->nlist;
+    // 1. coarse
+    HIP_TRY(ws->coarse_full.reserve((size_t)nq * nlist * sizeof(float)));
+    HIP_TRY(ws->keys.reserve((size_t)nq * nprobe * sizeof(int64_t)));
+    HIP_TRY(ws->cdis.reserve((size_t)nq * nprobe * sizeof(float)));
+    {
+        StageTimer t(idx, s, KNHIP_STAGE_COARSE);
+        FlatScanArgs c{};
+        c.rows = idx->centroids_il.as<float4>();
+        c.nrows = nlist;
+        c.chunk_rows = 1024;
+        c.d = d;
+        c.nchunk = (d + 3) / 4;
+        c.queries = d_q;
+        c.nq = nq;
+        HIP_TRY(launch_flat_full(c, is_l2, ws->coarse_full.as<float>(), nullptr, 0, s));
+        HIP_TRY(launch_row_select(ws->coarse_full.as<float>(), nq, nlist, nprobe, is_l2,
+                                  ws->keys.as<int64_t>(), ws->cdis.as<float>(), s));
+    }
+    // 2. group
+    const int qg = (kind == KNHIP_IVF_PQ) ? pq_scan_qg(idx->desc.pq_m)
+                 : (kind == KNHIP_IVF_SQ8) ? 8
+                                           : flat_scan_qg(k);
+    const int64_t npairs = nq * nprobe;
+    const int64_t items_bound = round_up(npairs / qg + std::min<int64_t>(nlist, npairs) + 1, 8);
+    HIP_TRY(ws->list_count.reserve((size_t)nlist * sizeof(int32_t)));
+    HIP_TRY(ws->list_cursor.reserve((size_t)nlist * sizeof(int32_t)));
+    HIP_TRY(ws->list_pair_off.reserve((size_t)(nlist + 1) * sizeof(int64_t)));
+    HIP_TRY(ws->list_item_off.reserve((size_t)(nlist + 1) * sizeof(int64_t)));
+    HIP_TRY(ws->pairs.reserve((size_t)npairs * sizeof(KnPair)));
+    HIP_TRY(ws->items.reserve((size_t)items_bound * sizeof(KnItem)));
+    HIP_TRY(ws->nitems.reserve(sizeof(int64_t)));
+    WorkTable wt{};
+    wt.list_count = ws->list_count.as<int32_t>();
+    wt.list_cursor = ws->list_cursor.as<int32_t>();
+    wt.list_pair_off = ws->list_pair_off.as<int64_t>();
+    wt.list_item_off = ws->list_item_off.as<int64_t>();
+    wt.pairs = ws->pairs.as<KnPair>();
+    wt.items = ws->items.as<KnItem>();
+    wt.nitems = ws->nitems.as<int64_t>();
+    wt.scan_bytes = idx->scan_bytes_dev.as<double>();
+    {
+        StageTimer t(idx, s, KNHIP_STAGE_GROUP);
+        HIP_TRY(launch_build_worktable(ws->keys.as<int64_t>(), nq, nprobe, nlist, qg,
+                                       idx->d_list_len.as<int64_t>(), idx->code_size, wt, s));
+    }
+    HIP_TRY(ws->partial_d.reserve((size_t)npairs * k * sizeof(float)));
+    HIP_TRY(ws->partial_i.reserve((size_t)npairs * k * sizeof(int64_t)));
+    idx->last_items_bound = items_bound;
+
+    if (kind == KNHIP_IVF_FLAT) {
+        FlatScanArgs a{};
+        a.rows = idx->rows.as<float4>();
+        a.list_blk_off = idx->d_list_blk_off.as<int64_t>();
+        a.list_len = idx->d_list_len.as<int64_t>();
+        a.list_row_off = idx->d_list_row_off.as<int64_t>();
+        a.ids = idx->ids.as<int64_t>();
+        a.d = d;
+        a.nchunk = (d + 3) / 4;
+        a.queries = d_q;
+        a.nq = nq;
+        a.items = wt.items;
+        a.pairs = wt.pairs;
+        a.nitems_dev = wt.nitems;
+        a.bitset = d_bitset;
+        a.bitset_nbits = nbits;
+        a.partial_d = ws->partial_d.as<float>();
+        a.partial_i = ws->partial_i.as<int64_t>();
+        a.nslot = nprobe;
+        a.k = k;
+        StageTimer t(idx, s, KNHIP_STAGE_SCAN);
+        HIP_TRY(launch_flat_scan(a, is_l2, false, items_bound, s));
+    } else if (kind == KNHIP_IVF_PQ) {
+        const int M = idx->desc.pq_m;
+        const int mode = !is_l2 ? PQ_LUT_IP : (idx->use_precomp ? PQ_LUT_PRECOMP : PQ_LUT_RESIDUAL);
+        if (mode != PQ_LUT_RESIDUAL) {
+            HIP_TRY(ws->t2t.reserve((size_t)nq * 256 * M * sizeof(float)));
+            StageTimer t(idx, s, KNHIP_STAGE_LUT);
+            HIP_TRY(launch_pq_query_table(d_q, idx->cb.as<float>(), d, M, nq, ws->t2t.as<float>(), s));
+        }
+        PqScanArgs a{};
+        a.codes_skew = idx->rows.as<uint4>();
+        a.list_sblk_off = idx->d_list_blk_off.as<int64_t>();
+        a.list_len = idx->d_list_len.as<int64_t>();
+        a.list_row_off = idx->d_list_row_off.as<int64_t>();
+        a.ids = idx->ids.as<int64_t>();
+        a.precomp_t = idx->precomp_t.as<float>();
+        a.cb = idx->cb.as<float>();
+        a.centroids = idx->centroids.as<float>();
+        a.d = d;
+        a.lut_mode = mode;
+        a.queries = d_q;
+        a.t2t = ws->t2t.as<float>();
+        a.coarse_dis = ws->cdis.as<float>();
+        a.items = wt.items;
+        a.pairs = wt.pairs;
+        a.nitems_dev = wt.nitems;
+        a.bitset = d_bitset;
+        a.bitset_nbits = nbits;
+        a.partial_d = ws->partial_d.as<float>();
+        a.partial_i = ws->partial_i.as<int64_t>();
+        a.nslot = nprobe;
+        a.k = k;
+        StageTimer t(idx, s, KNHIP_STAGE_SCAN);
+        HIP_TRY(launch_pq_scan(a, is_l2, M, items_bound, s));
+    } else { // IVF_SQ8
+        SqScanArgs a{};
+        a.rows = idx->rows.as<uint4>();
+        a.list_blk_off = idx->d_list_blk_off.as<int64_t>();
+        a.list_len = idx->d_list_len.as<int64_t>();
+        a.list_row_off = idx->d_list_row_off.as<int64_t>();
+        a.ids = idx->ids.as<int64_t>();
+        a.trained = idx->sq_trained.as<float>();
+        a.centroids = idx->centroids.as<float>();
+        a.d = d;
+        a.nchunk16 = (d + 15) / 16;
+        a.queries = d_q;
+        a.coarse_dis = ws->cdis.as<float>();
+        a.items = wt.items;
+        a.pairs = wt.pairs;
+        a.nitems_dev = wt.nitems;
+        a.bitset = d_bitset;
+        a.bitset_nbits = nbits;
+        a.partial_d = ws->partial_d.as<float>();
+        a.partial_i = ws->partial_i.as<int64_t>();
+        a.nslot = nprobe;
+        a.k = k;
+        StageTimer t(idx, s, KNHIP_STAGE_SCAN);
+        HIP_TRY(launch_sq_scan(a, is_l2, items_bound, s));
+    }
+    {
+        StageTimer t(idx, s, KNHIP_STAGE_MERGE);
+        HIP_TRY(launch_merge_partials(ws->partial_d.as<float>(), ws->partial_i.as<int64_t>(), nq, nprobe, k,
+                                      (int64_t)nprobe * k, k, is_l2, d_out_d, d_out_i, s));
+    }
+    return KNHIP_OK;
+}
+
+int validate_search(const knhip_index* idx, int64_t nq, int32_t k, int32_t& nprobe) {
+    if (nq < 0 || k <= 0) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "nq must be >= 0 and k > 0");
+    }
+    if (k > KN_MAX_K) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "k > 1024 is not supported");
+    }
+    const int kind = idx->desc.kind;
+    if (kind == KNHIP_BRUTE_FORCE) {
+        if (!idx->has_data) {
+            return fail(KNHIP_ERR_EMPTY_INDEX, "brute-force index holds no vectors");
+        }
+        return KNHIP_OK;
+    }
+    if (!idx->has_coarse) {
+        return fail(KNHIP_ERR_NOT_TRAINED, "coarse centroids not set");
+    }
+    if (kind == KNHIP_IVF_PQ && !idx->has_pq) {
+        return fail(KNHIP_ERR_NOT_TRAINED, "PQ codebooks not set");
+    }
+    if (kind == KNHIP_IVF_SQ8 && !idx->has_sq) {
+        return fail(KNHIP_ERR_NOT_TRAINED, "SQ parameters not set");
+    }
+    if (!idx->has_data) {
+        return fail(KNHIP_ERR_EMPTY_INDEX, "inverted lists not set");
+    }
+    if (nprobe <= 0) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "nprobe must be > 0");
+    }
+    if (nprobe > idx->nlist) {
+        nprobe = (int32_t)idx->nlist; // IndexIVF.cpp:321-322
+    }
+    if ((size_t)nprobe > row_select_max_k()) {
+        return fail(KNHIP_ERR_NOT_IMPLEMENTED, "nprobe > 4096 is not supported yet");
+    }
+    if (kind == KNHIP_IVF_SQ8 && k > 128) {
+        return fail(KNHIP_ERR_NOT_IMPLEMENTED, "IVF_SQ8 supports k <= 128");
+    }
+    return KNHIP_OK;
+}
+
+// how many queries per batch so the scratch stays within ~8 GiB
+int64_t query_batch(const knhip_index* idx, int64_t nq, int k, int nprobe) {
+    double per_q;
+    if (idx->desc.kind == KNHIP_BRUTE_FORCE) {
+        const int64_t nb = idx->ntotal;
+        int64_t chunk_rows = std::max<int64_t>(1024, round_up((nb + 511) / 512, 64));
+        const int64_t nchunks = (nb + chunk_rows - 1) / chunk_rows;
+        per_q = (double)nchunks * k * 12.0;
+    } else {
+        per_q = (double)idx->nlist * 4.0 + (double)nprobe * (12.0 + 8.0 + (double)k * 12.0);
+        if (idx->desc.kind == KNHIP_IVF_PQ) {
+            per_q += 256.0 * idx->desc.pq_m * 4.0;
+        }
+    }
+    const double budget = 8.0 * 1024 * 1024 * 1024;
+    int64_t qb = (int64_t)(budget / std::max(per_q, 1.0));
+    qb = std::max<int64_t>(qb, 8);
+    qb = std::min<int64_t>(qb, 65536 * 16);
+    return std::min(qb, std::max<int64_t>(nq, 1));
+}
+
+} // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+int knhip_abi_version(void) {
+    return KNHIP_ABI_VERSION;
+}
+
+int knhip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        return 0;
+    }
+    return n;
+}
+
+const char* knhip_last_error(void) {
+    return g_last_error.c_str();
+}
+
+int knhip_index_create(const knhip_desc* desc, knhip_index** out) {
+    if (!desc || !out) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "null argument");
+    }
+    *out = nullptr;
+    if (desc->kind < KNHIP_BRUTE_FORCE || desc->kind > KNHIP_IVF_SQ8) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "unknown index kind");
+    }
+    if (desc->metric != KNHIP_L2 && desc->metric != KNHIP_IP) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "metric must be L2 or IP (cosine is normalised IP)");
+    }
+    if (desc->dim <= 0 || desc->dim > 32768) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "dim out of range");
+    }
+    if (desc->kind != KNHIP_BRUTE_FORCE && (desc->nlist <= 0 || desc->nlist > (1 << 24))) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "nlist out of range");
+    }
+    if (desc->kind == KNHIP_IVF_PQ) {
+        if (desc->pq_nbits != 8) {
+            return fail(KNHIP_ERR_NOT_IMPLEMENTED, "only 8-bit PQ codes are supported");
+        }
+        if (desc->pq_m <= 0 || desc->dim % desc->pq_m != 0) {
+            return fail(KNHIP_ERR_INVALID_ARGS, "pq_m must divide dim");
+        }
+        if (!pq_scan_supported_m(desc->pq_m)) {
+            return fail(KNHIP_ERR_NOT_IMPLEMENTED, "pq_m must be one of 8, 16, 32, 64");
+        }
+    }
+    int ndev = knhip_device_count();
+    if (ndev <= 0) {
+        return fail(KNHIP_ERR_HIP_RUNTIME, "no HIP device visible");
+    }
+    if (desc->device < 0 || desc->device >= ndev) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "device ordinal out of range");
+    }
+    std::unique_ptr<knhip_index> idx(new knhip_index());
+    idx->desc = *desc;
+    idx->is_l2 = desc->metric == KNHIP_L2;
+    idx->d = desc->dim;
+    idx->nlist = desc->kind == KNHIP_BRUTE_FORCE ? 0 : desc->nlist;
+    switch (desc->kind) {
+        case KNHIP_BRUTE_FORCE:
+        case KNHIP_IVF_FLAT:
+            idx->code_size = (int64_t)desc->dim * 4;
+            break;
+        case KNHIP_IVF_PQ:
+            idx->code_size = desc->pq_m;
+            break;
+        default:
+            idx->code_size = desc->dim;
+    }
+    DeviceGuard g(desc->device);
+    HIP_TRY(idx->scan_bytes_dev.alloc(sizeof(double)));
+    HIP_TRY(hipMemset(idx->scan_bytes_dev.p, 0, sizeof(double)));
+    *out = idx.release();
+    return KNHIP_OK;
+}
+
+void knhip_index_destroy(knhip_index* idx) {
+    if (!idx) {
+        return;
+    }
+    DeviceGuard g(idx->desc.device);
+    (void)hipDeviceSynchronize();
+    for (auto& p : idx->pending) {
+        (void)hipEventDestroy(p.e0);
+        (void)hipEventDestroy(p.e1);
+    }
+    delete idx;
+}
+
+int knhip_index_set_coarse(knhip_index* idx, const float* centroids) {
+    if (int rc = check_index(idx)) return rc;
+    if (!centroids || idx->desc.kind == KNHIP_BRUTE_FORCE) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "set_coarse: bad arguments");
+    }
+    DeviceGuard g(idx->desc.device);
+    if (int rc = upload(idx->centroids, centroids, (size_t)idx->nlist * idx->d * sizeof(float))) return rc;
+    if (int rc = build_coarse_layout(idx)) return rc;
+    idx->has_coarse = true;
+    return maybe_build_precomp(idx);
+}
+
+int knhip_index_set_coarse_device(knhip_index* idx, const float* d_centroids) {
+    if (int rc = check_index(idx)) return rc;
+    if (!d_centroids || idx->desc.kind == KNHIP_BRUTE_FORCE) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "set_coarse_device: bad arguments");
+    }
+    DeviceGuard g(idx->desc.device);
+    const size_t bytes = (size_t)idx->nlist * idx->d * sizeof(float);
+    HIP_TRY(idx->centroids.alloc(bytes));
+    HIP_TRY(hipMemcpy(idx->centroids.p, d_centroids, bytes, hipMemcpyDeviceToDevice));
+    if (int rc = build_coarse_layout(idx)) return rc;
+    idx->has_coarse = true;
+    return maybe_build_precomp(idx);
+}
+
+int knhip_index_set_pq(knhip_index* idx, const float* codebooks) {
+    if (int rc = check_index(idx)) return rc;
+    if (!codebooks || idx->desc.kind != KNHIP_IVF_PQ) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "set_pq: not an IVF_PQ index");
+    }
+    DeviceGuard g(idx->desc.device);
+    if (int rc = upload(idx->cb, codebooks, (size_t)256 * idx->d * sizeof(float))) return rc;
+    idx->has_pq = true;
+    return maybe_build_precomp(idx);
+}
+
+int knhip_index_set_sq(knhip_index* idx, const float* vmin, const float* vdiff) {
+    if (int rc = check_index(idx)) return rc;
+    if (!vmin || !vdiff || idx->desc.kind != KNHIP_IVF_SQ8) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "set_sq: not an IVF_SQ8 index");
+    }
+    DeviceGuard g(idx->desc.device);
+    std::vector<float> t(2 * (size_t)idx->d);
+    std::memcpy(t.data(), vmin, sizeof(float) * idx->d);
+    std::memcpy(t.data() + idx->d, vdiff, sizeof(float) * idx->d);
+    if (int rc = upload(idx->sq_trained, t.data(), t.size() * sizeof(float))) return rc;
+    idx->has_sq = true;
+    return KNHIP_OK;
+}
+
+int knhip_index_add_lists(knhip_index* idx, const int64_t* list_sizes, const uint8_t* const* codes,
+                          const int64_t* const* ids) {
+    if (int rc = check_index(idx)) return rc;
+    if (!list_sizes || !codes || !ids || idx->desc.kind == KNHIP_BRUTE_FORCE) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "add_lists: bad arguments");
+    }
+    DeviceGuard g(idx->desc.device);
+    const int64_t nlist = idx->nlist;
+    const int64_t cs = idx->code_size;
+    std::vector<int64_t> off(nlist + 1, 0);
+    for (int64_t l = 0; l < nlist; l++) {
+        if (list_sizes[l] < 0 || (list_sizes[l] > 0 && (!codes[l] || !ids[l]))) {
+            return fail(KNHIP_ERR_INVALID_ARGS, "add_lists: negative size or null list pointer");
+        }
+        off[l + 1] = off[l] + list_sizes[l];
+    }
+    const int64_t ntotal = off[nlist];
+    // concatenate on the host, each list sorted by id (ties inside the kernels are broken by
+    // storage position, which must therefore be the id order)
+    std::vector<uint8_t> hc((size_t)ntotal * cs);
+    std::vector<int64_t> hi((size_t)ntotal);
+    std::vector<int64_t> perm;
+    for (int64_t l = 0; l < nlist; l++) {
+        const int64_t n = list_sizes[l];
+        if (n == 0) {
+            continue;
+        }
+        bool sorted = true;
+        for (int64_t j = 1; j < n; j++) {
+            if (ids[l][j] < ids[l][j - 1]) {
+                sorted = false;
+                break;
+            }
+        }
+        if (sorted) {
+            std::memcpy(hc.data() + (size_t)off[l] * cs, codes[l], (size_t)n * cs);
+            std::memcpy(hi.data() + off[l], ids[l], (size_t)n * sizeof(int64_t));
+        } else {
+            perm.resize(n);
+            std::iota(perm.begin(), perm.end(), 0);
+            const int64_t* lid = ids[l];
+            std::stable_sort(perm.begin(), perm.end(), [lid](int64_t a, int64_t b) { return lid[a] < lid[b]; });
+            for (int64_t j = 0; j < n; j++) {
+                std::memcpy(hc.data() + (size_t)(off[l] + j) * cs, codes[l] + (size_t)perm[j] * cs, (size_t)cs);
+                hi[off[l] + j] = lid[perm[j]];
+            }
+        }
+    }
+    DevBuf dc, di;
+    if (int rc = upload(dc, hc.data(), hc.size())) return rc;
+    if (int rc = upload(di, hi.data(), hi.size() * sizeof(int64_t))) return rc;
+    return build_list_layout(idx, off, dc.as<uint8_t>(), di.as<int64_t>());
+}
+
+int knhip_index_set_lists_device(knhip_index* idx, const int64_t* list_offsets, const uint8_t* d_codes,
+                                 const int64_t* d_ids) {
+    if (int rc = check_index(idx)) return rc;
+    if (!list_offsets || idx->desc.kind == KNHIP_BRUTE_FORCE) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "set_lists_device: bad arguments");
+    }
+    DeviceGuard g(idx->desc.device);
+    std::vector<int64_t> off(list_offsets, list_offsets + idx->nlist + 1);
+    if (off[0] != 0) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "list_offsets[0] must be 0");
+    }
+    return build_list_layout(idx, off, d_codes, d_ids);
+}
+
+static int add_vectors_common(knhip_index* idx, int64_t n, const float* d_x, const int64_t* /*d_ids*/,
+                              int64_t id_offset) {
+    const int nchunk = (idx->d + 3) / 4;
+    const int64_t nblk = (n + 63) / 64;
+    HIP_TRY(idx->rows.alloc((size_t)nblk * nchunk * 64 * sizeof(float4)));
+    HIP_TRY(launch_interleave_rows(d_x, n, idx->d, idx->rows.as<float4>(), 0, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    idx->ntotal = n;
+    idx->id_offset = id_offset;
+    idx->has_data = n > 0;
+    return KNHIP_OK;
+}
+
+int knhip_index_add_vectors(knhip_index* idx, int64_t n, const float* x, const int64_t* ids,
+                            int64_t id_offset) {
+    if (int rc = check_index(idx)) return rc;
+    if (idx->desc.kind != KNHIP_BRUTE_FORCE || n < 0 || (n > 0 && !x)) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "add_vectors: bad arguments");
+    }
+    if (ids) {
+        return fail(KNHIP_ERR_NOT_IMPLEMENTED,
+                    "explicit ids on a brute-force index: use id_offset (ids are row + offset)");
+    }
+    DeviceGuard g(idx->desc.device);
+    DevBuf dx;
+    if (int rc = upload(dx, x, (size_t)n * idx->d * sizeof(float))) return rc;
+    return add_vectors_common(idx, n, dx.as<float>(), nullptr, id_offset);
+}
+
+int knhip_index_add_vectors_device(knhip_index* idx, int64_t n, const float* d_x, const int64_t* d_ids,
+                                   int64_t id_offset) {
+    if (int rc = check_index(idx)) return rc;
+    if (idx->desc.kind != KNHIP_BRUTE_FORCE || n < 0 || (n > 0 && !d_x) || d_ids) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "add_vectors_device: bad arguments");
+    }
+    DeviceGuard g(idx->desc.device);
+    return add_vectors_common(idx, n, d_x, nullptr, id_offset);
+}
+
+int64_t knhip_index_count(const knhip_index* idx) {
+    return idx ? idx->ntotal : 0;
+}
+
+int64_t knhip_index_device_bytes(const knhip_index* idx) {
+    return idx ? idx->device_bytes() : 0;
+}
+
+int knhip_index_uses_precomputed_table(const knhip_index* idx) {
+    return idx ? idx->use_precomp : 0;
+}
+
+int knhip_search_device(const knhip_index* idx, const float* d_queries, int64_t nq, int32_t k,
+                        int32_t nprobe, const uint8_t* d_bitset, int64_t bitset_nbits,
+                        int64_t* d_out_ids, float* d_out_dist, void* stream) {
+    if (int rc = check_index(idx)) return rc;
+    if (int rc = validate_search(idx, nq, k, nprobe)) return rc;
+    if (nq == 0) {
+        return KNHIP_OK;
+    }
+    if (!d_queries || !d_out_ids || !d_out_dist) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "null query/output pointer");
+    }
+    DeviceGuard g(idx->desc.device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Workspace* ws = acquire_ws(idx, stream, true);
+    const int64_t qb = query_batch(idx, nq, k, nprobe);
+    if (idx->desc.kind != KNHIP_BRUTE_FORCE) {
+        idx->coarse_flops += 2.0 * (double)nq * (double)idx->nlist * (double)idx->d;
+    }
+    for (int64_t q0 = 0; q0 < nq; q0 += qb) {
+        const int64_t n = std::min(qb, nq - q0);
+        if (int rc = search_batch(idx, ws, d_queries + q0 * idx->d, n, k, nprobe, d_bitset, bitset_nbits,
+                                  d_out_ids + q0 * k, d_out_dist + q0 * k, s)) {
+            return rc;
+        }
+    }
+    return KNHIP_OK;
+}
+
+int knhip_search(const knhip_index* idx, const float* queries, int64_t nq, int32_t k, int32_t nprobe,
+                 const uint8_t* bitset, int64_t bitset_nbits, int64_t* out_ids, float* out_dist) {
+    if (int rc = check_index(idx)) return rc;
+    if (int rc = validate_search(idx, nq, k, nprobe)) return rc;
+    if (nq == 0) {
+        return KNHIP_OK;
+    }
+    if (!queries || !out_ids || !out_dist) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "null query/output pointer");
+    }
+    DeviceGuard g(idx->desc.device);
+    hipStream_t s = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    Workspace* ws = acquire_ws(idx, nullptr, false);
+    int rc = KNHIP_OK;
+    auto run = [&]() -> int {
+        const size_t qbytes = (size_t)nq * idx->d * sizeof(float);
+        HIP_TRY(ws->h_queries.reserve(qbytes));
+        HIP_TRY(ws->h_out_d.reserve((size_t)nq * k * sizeof(float)));
+        HIP_TRY(ws->h_out_i.reserve((size_t)nq * k * sizeof(int64_t)));
+        HIP_TRY(hipMemcpyAsync(ws->h_queries.p, queries, qbytes, hipMemcpyHostToDevice, s));
+        const uint8_t* d_bitset = nullptr;
+        if (bitset && bitset_nbits > 0) {
+            const size_t bb = (size_t)((bitset_nbits + 7) / 8);
+            HIP_TRY(ws->h_bitset.reserve(bb));
+            HIP_TRY(hipMemcpyAsync(ws->h_bitset.p, bitset, bb, hipMemcpyHostToDevice, s));
+            d_bitset = ws->h_bitset.as<uint8_t>();
+        }
+        const int64_t qb = query_batch(idx, nq, k, nprobe);
+        if (idx->desc.kind != KNHIP_BRUTE_FORCE) {
+            idx->coarse_flops += 2.0 * (double)nq * (double)idx->nlist * (double)idx->d;
+        }
+        for (int64_t q0 = 0; q0 < nq; q0 += qb) {
+            const int64_t n = std::min(qb, nq - q0);
+            if (int r = search_batch(idx, ws, ws->h_queries.as<float>() + q0 * idx->d, n, k, nprobe, d_bitset,
+                                     bitset_nbits, ws->h_out_i.as<int64_t>() + q0 * k,
+                                     ws->h_out_d.as<float>() + q0 * k, s)) {
+                return r;
+            }
+        }
+        HIP_TRY(hipMemcpyAsync(out_dist, ws->h_out_d.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(out_ids, ws->h_out_i.p, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        return KNHIP_OK;
+    };
+    rc = run();
+    if (rc != KNHIP_OK) {
+        (void)hipStreamSynchronize(s);
+    }
+    release_ws(idx, ws);
+    (void)hipStreamDestroy(s);
+    return rc;
+}
+
+int knhip_coarse_search_device(const knhip_index* idx, const float* d_queries, int64_t nq,
+                               int32_t nprobe, int64_t* d_out_keys, float* d_out_dist, void* stream) {
+    if (int rc = check_index(idx)) return rc;
+    if (idx->desc.kind == KNHIP_BRUTE_FORCE || !idx->has_coarse) {
+        return fail(KNHIP_ERR_NOT_TRAINED, "coarse centroids not set");
+    }
+    if (nq <= 0 || nprobe <= 0 || !d_queries || !d_out_keys || !d_out_dist) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "coarse_search: bad arguments");
+    }
+    if (nprobe > idx->nlist || (size_t)nprobe > row_select_max_k()) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "coarse_search: nprobe out of range");
+    }
+    DeviceGuard g(idx->desc.device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Workspace* ws = acquire_ws(idx, stream, true);
+    const int64_t qb = std::max<int64_t>(1, std::min<int64_t>(nq, (int64_t)((4.0 * 1024 * 1024 * 1024) / (idx->nlist * 4.0))));
+    for (int64_t q0 = 0; q0 < nq; q0 += qb) {
+        const int64_t n = std::min(qb, nq - q0);
+        HIP_TRY(ws->coarse_full.reserve((size_t)n * idx->nlist * sizeof(float)));
+        FlatScanArgs c{};
+        c.rows = idx->centroids_il.as<float4>();
+        c.nrows = idx->nlist;
+        c.chunk_rows = 1024;
+        c.d = idx->d;
+        c.nchunk = (idx->d + 3) / 4;
+        c.queries = d_queries + q0 * idx->d;
+        c.nq = n;
+        HIP_TRY(launch_flat_full(c, idx->is_l2, ws->coarse_full.as<float>(), nullptr, 0, s));
+        HIP_TRY(launch_row_select(ws->coarse_full.as<float>(), n, idx->nlist, nprobe, idx->is_l2,
+                                  d_out_keys + q0 * nprobe, d_out_dist + q0 * nprobe, s));
+    }
+    return KNHIP_OK;
+}
+
+int knhip_merge_topk_device(int32_t metric, int64_t nq, int32_t k, int32_t nshard,
+                            const float* d_dist_parts, const int64_t* d_ids_parts, float* d_out_dist,
+                            int64_t* d_out_ids, void* stream) {
+    if (nq < 0 || k <= 0 || k > KN_MAX_K || nshard <= 0 || !d_dist_parts || !d_ids_parts || !d_out_dist ||
+        !d_out_ids) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "merge_topk: bad arguments");
+    }
+    // parts are [nshard][nq][k]: list (q, shard) starts at q * k + shard * nq * k
+    HIP_TRY(launch_merge_partials(d_dist_parts, d_ids_parts, nq, nshard, k, k, nq * (int64_t)k,
+                                  metric == KNHIP_L2, d_out_dist, d_out_ids,
+                                  static_cast<hipStream_t>(stream)));
+    return KNHIP_OK;
+}
+
+int knhip_merge_topk_host(int32_t metric, int64_t nq, int32_t k, int32_t nshard, const float* dist_parts,
+                          const int64_t* ids_parts, float* out_dist, int64_t* out_ids) {
+    if (nq < 0 || k <= 0 || nshard <= 0 || !dist_parts || !ids_parts || !out_dist || !out_ids) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "merge_topk_host: bad arguments");
+    }
+    const bool l2 = metric == KNHIP_L2;
+    std::vector<std::pair<float, int64_t>> c;
+    c.reserve((size_t)nshard * k);
+    for (int64_t q = 0; q < nq; q++) {
+        c.clear();
+        for (int sh = 0; sh < nshard; sh++) {
+            const float* dp = dist_parts + ((size_t)sh * nq + q) * k;
+            const int64_t* ip = ids_parts + ((size_t)sh * nq + q) * k;
+            for (int j = 0; j < k; j++) {
+                if (ip[j] >= 0) {
+                    c.emplace_back(dp[j], ip[j]);
+                }
+            }
+        }
+        // canonical order: L2 (dist asc, id asc); IP (dist desc, id desc)
+        std::sort(c.begin(), c.end(), [l2](const std::pair<float, int64_t>& a, const std::pair<float, int64_t>& b) {
+            if (l2) {
+                return a.first < b.first || (a.first == b.first && a.second < b.second);
+            }
+            return a.first > b.first || (a.first == b.first && a.second > b.second);
+        });
+        for (int j = 0; j < k; j++) {
+            if ((size_t)j < c.size()) {
+                out_dist[q * k + j] = c[j].first;
+                out_ids[q * k + j] = c[j].second;
+            } else {
+                out_dist[q * k + j] = l2 ? FLT_MAX : -FLT_MAX;
+                out_ids[q * k + j] = -1;
+            }
+        }
+    }
+    return KNHIP_OK;
+}
+
+// ---- primitives ------------------------------------------------------------------------------------
+int knhip_fvec_L2sqr_ny(float* d_dis, const float* d_x, const float* d_y, int64_t d, int64_t ny, void* stream) {
+    HIP_TRY(launch_fvec_ny(d_dis, d_x, d_y, d, ny, true, static_cast<hipStream_t>(stream)));
+    return KNHIP_OK;
+}
+int knhip_fvec_inner_products_ny(float* d_ip, const float* d_x, const float* d_y, int64_t d, int64_t ny,
+                                 void* stream) {
+    HIP_TRY(launch_fvec_ny(d_ip, d_x, d_y, d, ny, false, static_cast<hipStream_t>(stream)));
+    return KNHIP_OK;
+}
+int knhip_fvec_norms_L2sqr(float* d_out, const float* d_x, int64_t d, int64_t n, void* stream) {
+    HIP_TRY(launch_fvec_norms(d_out, d_x, d, n, static_cast<hipStream_t>(stream)));
+    return KNHIP_OK;
+}
+int knhip_fvec_madd(int64_t n, const float* d_a, float bf, const float* d_b, float* d_c, void* stream) {
+    HIP_TRY(launch_fvec_madd(n, d_a, bf, d_b, d_c, static_cast<hipStream_t>(stream)));
+    return KNHIP_OK;
+}
+int knhip_int8_vec_L2sqr_ny(float* d_dis, const int8_t* d_x, const int8_t* d_y, int64_t d, int64_t ny,
+                            void* stream) {
+    HIP_TRY(launch_int8_ny(d_dis, d_x, d_y, d, ny, true, static_cast<hipStream_t>(stream)));
+    return KNHIP_OK;
+}
+int knhip_int8_vec_inner_products_ny(float* d_ip, const int8_t* d_x, const int8_t* d_y, int64_t d, int64_t ny,
+                                     void* stream) {
+    HIP_TRY(launch_int8_ny(d_ip, d_x, d_y, d, ny, false, static_cast<hipStream_t>(stream)));
+    return KNHIP_OK;
+}
+
+// ---- profiling -------------------------------------------------------------------------------------
+int knhip_profile_enable(knhip_index* idx, int on) {
+    if (int rc = check_index(idx)) return rc;
+    idx->prof = on != 0;
+    return KNHIP_OK;
+}
+
+static void drain_pending(const knhip_index* idx) {
+    std::vector<PendingEvent> p;
+    {
+        std::lock_guard<std::mutex> lk(idx->mu);
+        p.swap(idx->pending);
+    }
+    for (auto& e : p) {
+        float ms = 0.f;
+        if (hipEventSynchronize(e.e1) == hipSuccess && hipEventElapsedTime(&ms, e.e0, e.e1) == hipSuccess) {
+            idx->times.ms[e.stage] += ms;
+            idx->times.launches[e.stage] += 1;
+        }
+        (void)hipEventDestroy(e.e0);
+        (void)hipEventDestroy(e.e1);
+    }
+}
+
+int knhip_profile_reset(knhip_index* idx) {
+    if (int rc = check_index(idx)) return rc;
+    DeviceGuard g(idx->desc.device);
+    drain_pending(idx);
+    std::memset(&idx->times, 0, sizeof(idx->times));
+    idx->coarse_flops = 0;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(idx->scan_bytes_dev.p, 0, sizeof(double)));
+    return KNHIP_OK;
+}
+
+int knhip_profile_get(const knhip_index* idx, knhip_stage_times* out) {
+    if (int rc = check_index(idx)) return rc;
+    if (!out) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "null output");
+    }
+    DeviceGuard g(idx->desc.device);
+    HIP_TRY(hipDeviceSynchronize());
+    drain_pending(idx);
+    double sb = 0;
+    HIP_TRY(hipMemcpy(&sb, idx->scan_bytes_dev.p, sizeof(double), hipMemcpyDeviceToHost));
+    *out = idx->times;
+    out->scan_bytes = sb;
+    out->coarse_flops = idx->coarse_flops;
+    out->scan_items = idx->last_items_bound;
+    return KNHIP_OK;
+}
+
+const char* knhip_stage_kernel_name(int stage, int kind) {
+    switch (stage) {
+        case KNHIP_STAGE_COARSE:
+            return "flat_full_kernel+row_select_kernel";
+        case KNHIP_STAGE_GROUP:
+            return "wt_*_kernel";
+        case KNHIP_STAGE_LUT:
+            return "pq_query_table_kernel";
+        case KNHIP_STAGE_SCAN:
+            return kind == KNHIP_IVF_PQ ? "pq_scan_kernel" : kind == KNHIP_IVF_SQ8 ? "sq_scan_kernel" : "flat_scan_kernel";
+        case KNHIP_STAGE_MERGE:
+            return "merge_partials_kernel";
+        default:
+            return "other";
+    }
+}
+
+} // extern "C"

@@ -1,0 +1,277 @@
+// knowhere_amd/csrc/topk.hip -- k-selection kernels for gfx950 (wave64).
+//
+//   merge_partials : per query, the k best of nslot sorted partial lists
+//                    == the effect of the reference's single per-query heap visited probe by
+//                    probe (thirdparty/faiss/faiss/IndexIVF.cpp:499-508, 642-665) and of
+//                    merge_knn_results over shards (utils/Heap.h:636).
+//   row_select     : per row, the k best of n values with the column index as id -- the
+//                    coarse quantizer's top-nprobe (IndexFlat::search over the centroids,
+//                    thirdparty/faiss/faiss/utils/distances.cpp:834-875).
+// Both return the canonical order of heap_reorder (L2: dist asc, id asc; IP: dist desc, id desc)
+// and pad missing results with id -1 / the neutral distance (utils/Heap.h:338-341).
+#include "common.cuh"
+#include "kernels.h"
+
+namespace knhip {
+
+// ---------------------------------------------------------------------------------------------
+// merge_partials: one wave per query
+// ---------------------------------------------------------------------------------------------
+template <bool IS_L2, int R>
+__global__ __launch_bounds__(256) void merge_partials_kernel(const float* __restrict__ pd,
+                                                             const int64_t* __restrict__ pi,
+                                                             int64_t nq, int nslot, int k,
+                                                             int64_t q_stride, int64_t slot_stride,
+                                                             float* __restrict__ out_d,
+                                                             int64_t* __restrict__ out_i) {
+    const int lane = lane_id();
+    const int64_t q = (int64_t)blockIdx.x * (blockDim.x / KN_WAVE) + threadIdx.x / KN_WAVE;
+    if (q >= nq) {
+        return;
+    }
+    WaveTopK<IS_L2, R> top;
+    top.init(k);
+    float kd = worst_dist<IS_L2>();
+    int64_t ki = -1;
+    const float* qd = pd + q * q_stride;
+    const int64_t* qi = pi + q * q_stride;
+    for (int r = 0; r < k; r++) {
+        bool any = false;
+        for (int s0 = 0; s0 < nslot; s0 += KN_WAVE) {
+            const int s = s0 + lane;
+            float cd = worst_dist<IS_L2>();
+            int64_t ci = -1;
+            if (s < nslot) {
+                cd = qd[(int64_t)s * slot_stride + r];
+                ci = qi[(int64_t)s * slot_stride + r];
+            }
+            const bool pass = (ci >= 0) && top.admits(cd, ci, kd, ki);
+            unsigned long long m = __ballot(pass);
+            any |= (m != 0);
+            while (m) {
+                const int l = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const float xd = __shfl(cd, l, KN_WAVE);
+                const int64_t xi = shfl_i64(ci, l);
+                if (top.admits(xd, xi, kd, ki)) {
+                    top.insert(xd, xi);
+                    kd = top.kth_dist();
+                    ki = top.kth_idx();
+                }
+            }
+        }
+        if (!any) {
+            break; // every slot is sorted best-first: deeper ranks cannot enter either
+        }
+    }
+    top.store(out_d + q * k, out_i + q * k);
+}
+
+hipError_t launch_merge_partials(const float* partial_d, const int64_t* partial_i, int64_t nq,
+                                 int nslot, int k, int64_t q_stride, int64_t slot_stride, bool is_l2,
+                                 float* out_d, int64_t* out_i, hipStream_t s) {
+    if (nq <= 0) {
+        return hipSuccess;
+    }
+    const unsigned grid = (unsigned)((nq + 3) / 4);
+    KN_DISPATCH_R(k, {
+        if (is_l2) {
+            hipLaunchKernelGGL((merge_partials_kernel<true, R_>), dim3(grid), dim3(256), 0, s,
+                               partial_d, partial_i, nq, nslot, k, q_stride, slot_stride, out_d, out_i);
+        } else {
+            hipLaunchKernelGGL((merge_partials_kernel<false, R_>), dim3(grid), dim3(256), 0, s,
+                               partial_d, partial_i, nq, nslot, k, q_stride, slot_stride, out_d, out_i);
+        }
+    });
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// row_select: one 256-thread workgroup per row; radix select (4 x 8-bit digits, LDS histogram)
+// for the k-th key, gather, bitonic sort of the survivors in LDS.
+// ---------------------------------------------------------------------------------------------
+constexpr int RS_THREADS = 256;
+constexpr int RS_MAX_K = 4096;
+
+// order-preserving map float -> uint32 such that "better" == smaller key
+template <bool IS_L2>
+__device__ __forceinline__ uint32_t rs_key(float f) {
+    uint32_t b = __float_as_uint(f);
+    uint32_t asc = (b & 0x80000000u) ? ~b : (b | 0x80000000u); // ascending in f
+    return IS_L2 ? asc : ~asc;
+}
+template <bool IS_L2>
+__device__ __forceinline__ float rs_unkey(uint32_t key) {
+    uint32_t asc = IS_L2 ? key : ~key;
+    uint32_t b = (asc & 0x80000000u) ? (asc & 0x7fffffffu) : ~asc;
+    return __uint_as_float(b);
+}
+
+template <bool IS_L2>
+__global__ __launch_bounds__(RS_THREADS) void row_select_kernel(const float* __restrict__ vals,
+                                                                int64_t n, int k, int kp,
+                                                                int64_t* __restrict__ out_keys,
+                                                                float* __restrict__ out_d) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned long long* cand = reinterpret_cast<unsigned long long*>(smem); // [kp]
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t s_prefix, s_need, s_count, s_wave_tot[RS_THREADS / KN_WAVE], s_taken;
+    const int tid = threadIdx.x;
+    const float* row = vals + (int64_t)blockIdx.x * n;
+    const int keff = (int)min((int64_t)k, n);
+
+    // ---- radix select: find key T with count(key < T) < keff <= count(key <= T) ----
+    uint32_t prefix = 0, prefix_mask = 0;
+    uint32_t need = (uint32_t)keff; // rank (1-based) of the wanted key among keys matching prefix
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        hist[tid] = 0;
+        __syncthreads();
+        for (int64_t i = tid; i < n; i += RS_THREADS) {
+            const uint32_t key = rs_key<IS_L2>(row[i]);
+            if ((key & prefix_mask) == prefix) {
+                atomicAdd(&hist[(key >> shift) & 0xff], 1u);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t acc = 0;
+            int b = 0;
+            for (; b < 256; b++) {
+                if (acc + hist[b] >= need) {
+                    break;
+                }
+                acc += hist[b];
+            }
+            s_prefix = prefix | ((uint32_t)b << shift);
+            s_need = need - acc;
+        }
+        __syncthreads();
+        prefix = s_prefix;
+        need = s_need;
+        prefix_mask |= 0xffu << shift;
+        __syncthreads();
+    }
+    const uint32_t T = prefix; // the keff-th best key; `need` of the elements equal to T are wanted
+
+    // ---- gather: everything better than T, then the `need` lowest/highest-index ties at T ----
+    if (tid == 0) {
+        s_count = 0;
+        s_taken = 0;
+    }
+    for (int i = tid; i < kp; i += RS_THREADS) {
+        cand[i] = ~0ull;
+    }
+    __syncthreads();
+    for (int64_t i = tid; i < n; i += RS_THREADS) {
+        const uint32_t key = rs_key<IS_L2>(row[i]);
+        if (key < T) {
+            const uint32_t pos = atomicAdd(&s_count, 1u);
+            const uint32_t tie = IS_L2 ? (uint32_t)i : ~(uint32_t)i;
+            cand[pos] = ((unsigned long long)key << 32) | tie;
+        }
+    }
+    __syncthreads();
+    const uint32_t base = s_count;
+    // ties at T in canonical index order (L2: ascending index, IP: descending index)
+    const int lane = tid & (KN_WAVE - 1), wave = tid / KN_WAVE;
+    const int64_t ntile = (n + RS_THREADS - 1) / RS_THREADS;
+    for (int64_t tile = 0; tile < ntile; tile++) {
+        if (s_taken >= need) {
+            break;
+        }
+        const int64_t pos_in_order = tile * RS_THREADS + tid;
+        const int64_t i = IS_L2 ? pos_in_order : (n - 1 - pos_in_order);
+        bool flag = false;
+        if (pos_in_order < n) {
+            flag = rs_key<IS_L2>(row[i]) == T;
+        }
+        const unsigned long long bal = __ballot(flag);
+        const uint32_t before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) {
+            s_wave_tot[wave] = __popcll(bal);
+        }
+        __syncthreads();
+        uint32_t woff = 0, tot = 0;
+        for (int w = 0; w < RS_THREADS / KN_WAVE; w++) {
+            if (w < wave) {
+                woff += s_wave_tot[w];
+            }
+            tot += s_wave_tot[w];
+        }
+        const uint32_t taken = s_taken;
+        if (flag) {
+            const uint32_t ord = taken + woff + before;
+            if (ord < need) {
+                const uint32_t tie = IS_L2 ? (uint32_t)i : ~(uint32_t)i;
+                cand[base + ord] = ((unsigned long long)T << 32) | tie;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            s_taken = taken + tot;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+
+    // ---- bitonic sort of cand[0..kp) ascending (composite key: better first) ----
+    for (int size = 2; size <= kp; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < kp / 2; t += RS_THREADS) {
+                const int lo = (t / stride) * stride * 2 + (t % stride);
+                const int hi = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const unsigned long long a = cand[lo], b = cand[hi];
+                if ((a > b) == up) {
+                    cand[lo] = b;
+                    cand[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- emit ----
+    int64_t* ok = out_keys + (int64_t)blockIdx.x * k;
+    float* od = out_d + (int64_t)blockIdx.x * k;
+    for (int e = tid; e < k; e += RS_THREADS) {
+        if (e < keff) {
+            const unsigned long long c = cand[e];
+            const uint32_t key = (uint32_t)(c >> 32);
+            const uint32_t tie = (uint32_t)c;
+            ok[e] = IS_L2 ? (int64_t)tie : (int64_t)(~tie);
+            od[e] = rs_unkey<IS_L2>(key);
+        } else {
+            ok[e] = -1;
+            od[e] = worst_dist<IS_L2>();
+        }
+    }
+}
+
+size_t row_select_max_k() {
+    return RS_MAX_K;
+}
+
+hipError_t launch_row_select(const float* vals, int64_t nrows, int64_t n, int k, bool is_l2,
+                             int64_t* out_keys, float* out_d, hipStream_t s) {
+    if (nrows <= 0 || k <= 0) {
+        return hipSuccess;
+    }
+    if (k > RS_MAX_K || n > 0xffffffffll) {
+        return hipErrorInvalidValue;
+    }
+    int kp = 2;
+    while (kp < k) {
+        kp <<= 1;
+    }
+    const size_t sm = (size_t)kp * 8;
+    if (is_l2) {
+        hipLaunchKernelGGL((row_select_kernel<true>), dim3((unsigned)nrows), dim3(RS_THREADS), sm, s,
+                           vals, n, k, kp, out_keys, out_d);
+    } else {
+        hipLaunchKernelGGL((row_select_kernel<false>), dim3((unsigned)nrows), dim3(RS_THREADS), sm, s,
+                           vals, n, k, kp, out_keys, out_d);
+    }
+    return hipGetLastError();
+}
+
+} // namespace knhip

@@ -1,0 +1,162 @@
+// knowhere_amd/csrc/worktable.hip -- turn the coarse quantizer's (query, probe-rank) -> list
+// assignment into list-major work items.
+//
+// The reference walks probes query by query (thirdparty/faiss/faiss/IndexIVF.cpp:642-662: for
+// each query, for ik in 0..nprobe: scan_one_list(keys[i*nprobe+ik], ...)).  On the GPU the same
+// (query, list) scans are regrouped by LIST: all queries of the batch that probe list l become
+// ceil(count_l / qg) work items of up to qg queries each, consecutive in the item array, so that
+// a list's codes are fetched from HBM once and then served from L2 / shared between the qg
+// queries of an item.  The per-(query, probe) results are written back to slot `ik` of the
+// query's partial-result row, so the final merge is independent of this regrouping.
+//
+// Everything stays on the device: no host synchronisation between coarse search and scan.
+#include "common.cuh"
+#include "kernels.h"
+
+namespace knhip {
+
+__global__ void wt_zero_kernel(int32_t* list_count, int32_t* list_cursor, int64_t nlist,
+                               double* scan_bytes, int64_t* nitems) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nlist) {
+        list_count[t] = 0;
+        list_cursor[t] = 0;
+    }
+    if (t == 0) {
+        *nitems = 0;
+    }
+    (void)scan_bytes;
+}
+
+__global__ void wt_count_kernel(const int64_t* __restrict__ keys, int64_t npairs, int64_t nlist,
+                                int32_t* list_count) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= npairs) {
+        return;
+    }
+    const int64_t key = keys[t];
+    if (key >= 0 && key < nlist) {
+        atomicAdd(&list_count[key], 1);
+    }
+}
+
+// single workgroup: exclusive scans of pair counts and item counts over the lists
+constexpr int WT_SCAN_THREADS = 1024;
+__global__ __launch_bounds__(WT_SCAN_THREADS) void wt_scan_kernel(
+        const int32_t* __restrict__ list_count, const int64_t* __restrict__ list_len, int64_t nlist,
+        int qg, int64_t code_size, int64_t* list_pair_off, int64_t* list_item_off, int64_t* nitems,
+        double* scan_bytes) {
+    __shared__ int64_t s_pairs[WT_SCAN_THREADS];
+    __shared__ int64_t s_items[WT_SCAN_THREADS];
+    __shared__ double s_bytes[WT_SCAN_THREADS];
+    const int tid = threadIdx.x;
+    const int64_t per = (nlist + WT_SCAN_THREADS - 1) / WT_SCAN_THREADS;
+    const int64_t l0 = (int64_t)tid * per;
+    const int64_t l1 = min(l0 + per, nlist);
+    int64_t np = 0, ni = 0;
+    double nb = 0.0;
+    for (int64_t l = l0; l < l1; l++) {
+        const int64_t c = list_count[l];
+        np += c;
+        ni += (c + qg - 1) / qg;
+        nb += (double)c * (double)list_len[l] * (double)code_size;
+    }
+    s_pairs[tid] = np;
+    s_items[tid] = ni;
+    s_bytes[tid] = nb;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over the 1024 per-thread totals
+    for (int off = 1; off < WT_SCAN_THREADS; off <<= 1) {
+        int64_t a = 0, b = 0;
+        double c = 0.0;
+        if (tid >= off) {
+            a = s_pairs[tid - off];
+            b = s_items[tid - off];
+            c = s_bytes[tid - off];
+        }
+        __syncthreads();
+        s_pairs[tid] += a;
+        s_items[tid] += b;
+        s_bytes[tid] += c;
+        __syncthreads();
+    }
+    int64_t pp = s_pairs[tid] - np; // exclusive prefix
+    int64_t ii = s_items[tid] - ni;
+    for (int64_t l = l0; l < l1; l++) {
+        const int64_t c = list_count[l];
+        list_pair_off[l] = pp;
+        list_item_off[l] = ii;
+        pp += c;
+        ii += (c + qg - 1) / qg;
+    }
+    if (tid == WT_SCAN_THREADS - 1) {
+        list_pair_off[nlist] = s_pairs[tid];
+        list_item_off[nlist] = s_items[tid];
+        *nitems = s_items[tid];
+        *scan_bytes += s_bytes[tid]; // accumulated across query batches; reset by the host
+    }
+}
+
+__global__ void wt_scatter_kernel(const int64_t* __restrict__ keys, int64_t npairs, int nprobe,
+                                  int64_t nlist, const int64_t* __restrict__ list_pair_off,
+                                  int32_t* list_cursor, KnPair* pairs) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= npairs) {
+        return;
+    }
+    const int64_t key = keys[t];
+    if (key < 0 || key >= nlist) {
+        return;
+    }
+    const int64_t pos = list_pair_off[key] + atomicAdd(&list_cursor[key], 1);
+    KnPair p;
+    p.q = (int32_t)(t / nprobe);
+    p.slot = (int32_t)(t % nprobe);
+    pairs[pos] = p;
+}
+
+__global__ void wt_items_kernel(const int32_t* __restrict__ list_count,
+                                const int64_t* __restrict__ list_pair_off,
+                                const int64_t* __restrict__ list_item_off, int64_t nlist, int qg,
+                                KnItem* items) {
+    const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= nlist) {
+        return;
+    }
+    const int64_t c = list_count[l];
+    const int64_t p0 = list_pair_off[l];
+    int64_t it = list_item_off[l];
+    for (int64_t i = 0; i < c; i += qg, it++) {
+        KnItem x;
+        x.list = (int32_t)l;
+        x.npair = (int32_t)min((int64_t)qg, c - i);
+        x.pair0 = p0 + i;
+        items[it] = x;
+    }
+}
+
+hipError_t launch_build_worktable(const int64_t* keys, int64_t nq, int nprobe, int64_t nlist, int qg,
+                                  const int64_t* list_len, int64_t code_size, const WorkTable& wt,
+                                  hipStream_t s) {
+    const int64_t npairs = nq * nprobe;
+    const unsigned gl = (unsigned)((nlist + 255) / 256);
+    const unsigned gp = (unsigned)((npairs + 255) / 256);
+    hipLaunchKernelGGL(wt_zero_kernel, dim3(gl), dim3(256), 0, s, wt.list_count, wt.list_cursor, nlist,
+                       wt.scan_bytes, wt.nitems);
+    if (npairs > 0) {
+        hipLaunchKernelGGL(wt_count_kernel, dim3(gp), dim3(256), 0, s, keys, npairs, nlist,
+                           wt.list_count);
+    }
+    hipLaunchKernelGGL(wt_scan_kernel, dim3(1), dim3(WT_SCAN_THREADS), 0, s, wt.list_count, list_len,
+                       nlist, qg, code_size, wt.list_pair_off, wt.list_item_off, wt.nitems,
+                       wt.scan_bytes);
+    if (npairs > 0) {
+        hipLaunchKernelGGL(wt_scatter_kernel, dim3(gp), dim3(256), 0, s, keys, npairs, nprobe, nlist,
+                           wt.list_pair_off, wt.list_cursor, wt.pairs);
+    }
+    hipLaunchKernelGGL(wt_items_kernel, dim3(gl), dim3(256), 0, s, wt.list_count, wt.list_pair_off,
+                       wt.list_item_off, nlist, qg, wt.items);
+    return hipGetLastError();
+}
+
+} // namespace knhip

@@ -1,0 +1,393 @@
+"""oracle/binding.py -- ctypes bindings for the CHECKERS (test infrastructure only).
+
+  * ``Port``  : oracle/liboracle.so, the plain-C restatement (oracle.c).
+  * ``Ref``   : oracle/_ref/libknowhere_ref.so, the reference's own FAISS sources compiled in
+                place (only present when /root/reference was available at build time).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+The product package (knowhere_amd/) must never import it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+FLAT, IVF_FLAT, IVF_PQ, IVF_SQ8 = 0, 1, 2, 3
+L2, IP = 0, 1
+
+_f32p = C.POINTER(C.c_float)
+_i64p = C.POINTER(C.c_int64)
+_u8p = C.POINTER(C.c_uint8)
+
+
+def _p(a, t):
+    if a is None:
+        return None
+    return a.ctypes.data_as(t)
+
+
+def build(ref=True):
+    """(Re)build liboracle.so and, when the reference tree is present, _ref."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "port"])
+    if ref and os.path.isdir("/root/reference/thirdparty/faiss/faiss"):
+        subprocess.check_call(["make", "-s", "-j8", "-C", _HERE, "ref"])
+
+
+class _OrcIndex(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("metric", C.c_int32), ("d", C.c_int32), ("M", C.c_int32),
+        ("nbits", C.c_int32), ("use_precomputed_table", C.c_int32),
+        ("nlist", C.c_int64), ("code_size", C.c_int64),
+        ("centroids", _f32p), ("pq_centroids", _f32p), ("precomputed_table", _f32p),
+        ("sq_trained", _f32p), ("list_sizes", _i64p),
+        ("list_codes", C.POINTER(_u8p)), ("list_ids", C.POINTER(_i64p)),
+    ]
+
+
+class IndexData:
+    """A trained + populated index as plain numpy arrays: the bytes shared by oracle and GPU."""
+
+    def __init__(self, kind, metric, d, nlist=0, M=0, nbits=8):
+        self.kind, self.metric, self.d, self.nlist, self.M, self.nbits = kind, metric, d, nlist, M, nbits
+        self.centroids = None        # [nlist, d] f32
+        self.pq_centroids = None     # [M, ksub, dsub] f32
+        self.sq_trained = None       # [2d] f32
+        self.precomputed_table = None
+        self.use_precomputed_table = 0
+        self.list_codes = []         # per list uint8 [len, code_size]
+        self.list_ids = []           # per list int64 [len]
+        self.base = None             # FLAT: [n, d] f32
+
+    @property
+    def code_size(self):
+        return {FLAT: self.d * 4, IVF_FLAT: self.d * 4, IVF_PQ: self.M, IVF_SQ8: self.d}[self.kind]
+
+    @property
+    def ntotal(self):
+        if self.kind == FLAT:
+            return 0 if self.base is None else self.base.shape[0]
+        return int(sum(len(i) for i in self.list_ids))
+
+
+class Port:
+    """oracle.c through ctypes."""
+
+    def __init__(self, path=None):
+        path = path or os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build(ref=False)
+        self.lib = L = C.CDLL(path)
+        L.orc_fvec_L2sqr.restype = C.c_float
+        L.orc_fvec_inner_product.restype = C.c_float
+        L.orc_fvec_norm_L2sqr.restype = C.c_float
+        L.orc_ivfpq_list_table.restype = C.c_float
+        L.orc_int8_vec_inner_product.restype = C.c_int32
+        L.orc_int8_vec_L2sqr.restype = C.c_int32
+        L.orc_heap_reorder.restype = C.c_size_t
+
+    # -- primitives --
+    def fvec_L2sqr(self, x, y):
+        return float(self.lib.orc_fvec_L2sqr(_p(x, _f32p), _p(y, _f32p), C.c_size_t(x.size)))
+
+    def fvec_inner_product(self, x, y):
+        return float(self.lib.orc_fvec_inner_product(_p(x, _f32p), _p(y, _f32p), C.c_size_t(x.size)))
+
+    def fvec_norm_L2sqr(self, x):
+        return float(self.lib.orc_fvec_norm_L2sqr(_p(x, _f32p), C.c_size_t(x.size)))
+
+    def fvec_L2sqr_ny(self, x, y):
+        ny, d = y.shape
+        out = np.empty(ny, np.float32)
+        self.lib.orc_fvec_L2sqr_ny(_p(out, _f32p), _p(x, _f32p), _p(y, _f32p), C.c_size_t(d), C.c_size_t(ny))
+        return out
+
+    def fvec_inner_products_ny(self, x, y):
+        ny, d = y.shape
+        out = np.empty(ny, np.float32)
+        self.lib.orc_fvec_inner_products_ny(_p(out, _f32p), _p(x, _f32p), _p(y, _f32p), C.c_size_t(d), C.c_size_t(ny))
+        return out
+
+    def fvec_madd(self, a, bf, b):
+        c = np.empty_like(a)
+        self.lib.orc_fvec_madd(C.c_size_t(a.size), _p(a, _f32p), C.c_float(bf), _p(b, _f32p), _p(c, _f32p))
+        return c
+
+    def int8_ny(self, x, y, metric):
+        fn = self.lib.orc_int8_vec_L2sqr if metric == L2 else self.lib.orc_int8_vec_inner_product
+        i8p = C.POINTER(C.c_int8)
+        return np.array([float(fn(_p(x, i8p), _p(np.ascontiguousarray(r), i8p), C.c_size_t(x.size))) for r in y],
+                        np.float32)
+
+    # -- index marshalling --
+    def _marshal(self, ix):
+        s = _OrcIndex()
+        keep = []
+        s.kind, s.metric, s.d, s.M, s.nbits = ix.kind, ix.metric, ix.d, ix.M, ix.nbits
+        s.use_precomputed_table = ix.use_precomputed_table
+        s.nlist, s.code_size = ix.nlist, ix.code_size
+        s.centroids = _p(ix.centroids, _f32p)
+        s.pq_centroids = _p(ix.pq_centroids, _f32p)
+        s.precomputed_table = _p(ix.precomputed_table, _f32p)
+        s.sq_trained = _p(ix.sq_trained, _f32p)
+        sizes = np.array([len(i) for i in ix.list_ids], np.int64)
+        codes = (_u8p * ix.nlist)()
+        ids = (_i64p * ix.nlist)()
+        for l in range(ix.nlist):
+            c = np.ascontiguousarray(ix.list_codes[l], np.uint8)
+            i = np.ascontiguousarray(ix.list_ids[l], np.int64)
+            keep += [c, i]
+            codes[l] = _p(c, _u8p) if c.size else None
+            ids[l] = _p(i, _i64p) if i.size else None
+        s.list_sizes = _p(sizes, _i64p)
+        s.list_codes = codes
+        s.list_ids = ids
+        keep += [sizes, codes, ids]
+        return s, keep
+
+    # -- searches --
+    def flat_search(self, metric, xb, xq, k, bitset=None):
+        xb = np.ascontiguousarray(xb, np.float32)
+        xq = np.ascontiguousarray(xq, np.float32)
+        nb, d = xb.shape
+        nq = xq.shape[0]
+        D = np.empty((nq, k), np.float32)
+        I = np.empty((nq, k), np.int64)
+        self.lib.orc_flat_search(C.c_int(metric), C.c_int(d), C.c_int64(nb), _p(xb, _f32p), C.c_int64(nq),
+                                 _p(xq, _f32p), C.c_int64(k), _p(bitset, _u8p),
+                                 C.c_int64(0 if bitset is None else nb), _p(D, _f32p), _p(I, _i64p))
+        return D, I
+
+    def coarse_search(self, ix, xq, nprobe):
+        xq = np.ascontiguousarray(xq, np.float32)
+        s, keep = self._marshal(ix)
+        nq = xq.shape[0]
+        D = np.empty((nq, nprobe), np.float32)
+        I = np.empty((nq, nprobe), np.int64)
+        self.lib.orc_coarse_search(C.byref(s), C.c_int64(nq), _p(xq, _f32p), C.c_int64(nprobe), _p(D, _f32p), _p(I, _i64p))
+        return D, I
+
+    def ivf_search(self, ix, xq, k, nprobe, bitset=None, nbits=0):
+        xq = np.ascontiguousarray(xq, np.float32)
+        s, keep = self._marshal(ix)
+        nq = xq.shape[0]
+        D = np.empty((nq, k), np.float32)
+        I = np.empty((nq, k), np.int64)
+        rc = self.lib.orc_ivf_search(C.byref(s), C.c_int64(nq), _p(xq, _f32p), C.c_int64(k), C.c_int64(nprobe),
+                                     _p(bitset, _u8p), C.c_int64(nbits), _p(D, _f32p), _p(I, _i64p))
+        assert rc == 0
+        return D, I
+
+    def search(self, ix, xq, k, nprobe=1, bitset=None, nbits=0):
+        if ix.kind == FLAT:
+            return self.flat_search(ix.metric, ix.base, xq, k, bitset)
+        return self.ivf_search(ix, xq, k, nprobe, bitset, nbits)
+
+    def merge_topk(self, metric, D_parts, I_parts):
+        nshard, nq, k = D_parts.shape
+        D = np.empty((nq, k), np.float32)
+        I = np.empty((nq, k), np.int64)
+        Dp = np.ascontiguousarray(D_parts, np.float32)
+        Ip = np.ascontiguousarray(I_parts, np.int64)
+        self.lib.orc_merge_topk(C.c_int(metric), C.c_int64(nq), C.c_int64(k), C.c_int(nshard), _p(Dp, _f32p),
+                                _p(Ip, _i64p), _p(D, _f32p), _p(I, _i64p))
+        return D, I
+
+    def pq_precompute_table(self, d, M, nbits, centroids, cb):
+        nlist = centroids.shape[0]
+        out = np.empty((nlist, M * (1 << nbits)), np.float32)
+        self.lib.orc_pq_precompute_table(C.c_int(d), C.c_int(M), C.c_int(nbits), C.c_int64(nlist),
+                                         _p(centroids, _f32p), _p(cb, _f32p), _p(out, _f32p))
+        return out
+
+    # -- build helpers (restated add path) --
+    def assign(self, metric, centroids, x):
+        out = np.empty(x.shape[0], np.int64)
+        self.lib.orc_assign(C.c_int(metric), C.c_int(x.shape[1]), C.c_int64(centroids.shape[0]),
+                            _p(centroids, _f32p), C.c_int64(x.shape[0]), _p(x, _f32p), _p(out, _i64p))
+        return out
+
+    def pq_encode(self, d, M, nbits, cb, x):
+        codes = np.empty((x.shape[0], M), np.uint8)
+        for i in range(x.shape[0]):
+            self.lib.orc_pq_compute_code(C.c_int(d), C.c_int(M), C.c_int(nbits), _p(cb, _f32p),
+                                         _p(np.ascontiguousarray(x[i]), _f32p),
+                                         codes[i].ctypes.data_as(_u8p))
+        return codes
+
+    def sq8_encode(self, trained, x):
+        d = x.shape[1]
+        codes = np.empty((x.shape[0], d), np.uint8)
+        for i in range(x.shape[0]):
+            self.lib.orc_sq8_encode(C.c_int(d), _p(trained, _f32p), _p(np.ascontiguousarray(x[i]), _f32p),
+                                    codes[i].ctypes.data_as(_u8p))
+        return codes
+
+
+def make_index(port, kind, metric, xb, nlist=16, M=8, nbits=8, seed=123, ids=None):
+    """Build a VALID (not good) index without any training library: centroids / codebooks are
+    samples of the data, SQ ranges are min/max; assignment and encoding use the restated add
+    path.  Parity of Search() only needs both sides to hold the same index bytes."""
+    xb = np.ascontiguousarray(xb, np.float32)
+    n, d = xb.shape
+    rng = np.random.default_rng(seed)
+    ix = IndexData(kind, metric, d, nlist if kind != FLAT else 0, M if kind == IVF_PQ else 0, nbits)
+    if kind == FLAT:
+        ix.base = xb
+        return ix
+    ids = np.arange(n, dtype=np.int64) if ids is None else np.asarray(ids, np.int64)
+    ix.centroids = np.ascontiguousarray(xb[rng.choice(n, nlist, replace=False)])
+    assign = port.assign(metric, ix.centroids, xb)
+    resid = xb - ix.centroids[assign]
+    if kind == IVF_FLAT:
+        codes = xb.view(np.uint8).reshape(n, d * 4)
+    elif kind == IVF_PQ:
+        ksub, dsub = 1 << nbits, d // M
+        pick = rng.choice(n, ksub, replace=n < ksub)
+        ix.pq_centroids = np.ascontiguousarray(
+            resid[pick].reshape(ksub, M, dsub).transpose(1, 0, 2)).astype(np.float32)
+        codes = port.pq_encode(d, M, nbits, ix.pq_centroids, np.ascontiguousarray(resid))
+        if metric == L2:
+            ix.precomputed_table = port.pq_precompute_table(d, M, nbits, ix.centroids, ix.pq_centroids)
+            ix.use_precomputed_table = 1
+    elif kind == IVF_SQ8:
+        vmin = resid.min(0)
+        vdiff = resid.max(0) - vmin
+        ix.sq_trained = np.concatenate([vmin, vdiff]).astype(np.float32)
+        codes = port.sq8_encode(ix.sq_trained, np.ascontiguousarray(resid))
+    else:
+        raise ValueError(kind)
+    for l in range(nlist):
+        sel = np.nonzero(assign == l)[0]
+        ix.list_codes.append(np.ascontiguousarray(codes[sel]))
+        ix.list_ids.append(np.ascontiguousarray(ids[sel]))
+    return ix
+
+
+class Ref:
+    """oracle/_ref/libknowhere_ref.so -- the reference's own FAISS, driven Knowhere-style."""
+
+    @staticmethod
+    def path():
+        return os.path.join(_HERE, "_ref", "libknowhere_ref.so")
+
+    @staticmethod
+    def available():
+        if not os.path.exists(Ref.path()):
+            return False
+        try:
+            Ref()
+            return True
+        except OSError:
+            return False
+
+    def __init__(self):
+        # libmkl_rt picks its threading layer at load time
+        os.environ.setdefault("MKL_THREADING_LAYER", "GNU")
+        self.lib = L = C.CDLL(Ref.path(), mode=C.RTLD_GLOBAL)
+        L.ref_create.restype = C.c_void_p
+        L.ref_last_error.restype = C.c_char_p
+        for f in ("ref_ntotal", "ref_nlist", "ref_code_size", "ref_list_size", "ref_get_precomputed_table"):
+            getattr(L, f).restype = C.c_int64
+        L.ref_fvec_L2sqr.restype = C.c_float
+        L.ref_fvec_inner_product.restype = C.c_float
+        L.ref_fvec_norm_L2sqr.restype = C.c_float
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise RuntimeError(self.lib.ref_last_error().decode())
+
+    def create(self, kind, metric, d, nlist=0, M=0, nbits=8):
+        h = self.lib.ref_create(kind, metric, d, nlist, M, nbits)
+        if not h:
+            raise RuntimeError(self.lib.ref_last_error().decode())
+        return C.c_void_p(h)
+
+    def destroy(self, h):
+        self.lib.ref_destroy(h)
+
+    def train_add(self, h, xb, ids=None):
+        xb = np.ascontiguousarray(xb, np.float32)
+        self._chk(self.lib.ref_train(h, C.c_int64(xb.shape[0]), _p(xb, _f32p)))
+        self._chk(self.lib.ref_add(h, C.c_int64(xb.shape[0]), _p(xb, _f32p), _p(ids, _i64p)))
+
+    def export(self, h, kind, metric, d, nlist=0, M=0, nbits=8, base=None):
+        """reference-trained index -> IndexData (plain arrays)"""
+        ix = IndexData(kind, metric, d, nlist, M, nbits)
+        if kind == FLAT:
+            n = self.lib.ref_ntotal(h)
+            ix.base = np.empty((n, d), np.float32)
+            self._chk(self.lib.ref_get_flat_vectors(h, _p(ix.base, _f32p)))
+            return ix
+        ix.centroids = np.empty((nlist, d), np.float32)
+        self._chk(self.lib.ref_get_centroids(h, _p(ix.centroids, _f32p)))
+        cs = self.lib.ref_code_size(h)
+        if kind == IVF_PQ:
+            ksub = 1 << nbits
+            ix.pq_centroids = np.empty((M, ksub, d // M), np.float32)
+            self._chk(self.lib.ref_get_pq_centroids(h, _p(ix.pq_centroids, _f32p)))
+            ix.use_precomputed_table = self.lib.ref_use_precomputed_table(h)
+            n = self.lib.ref_get_precomputed_table(h, None)
+            if n > 0:
+                ix.precomputed_table = np.empty(n, np.float32)
+                self.lib.ref_get_precomputed_table(h, _p(ix.precomputed_table, _f32p))
+        if kind == IVF_SQ8:
+            ix.sq_trained = np.empty(2 * d, np.float32)
+            self._chk(self.lib.ref_get_sq_trained(h, _p(ix.sq_trained, _f32p)))
+        for l in range(nlist):
+            n = self.lib.ref_list_size(h, C.c_int64(l))
+            c = np.empty((n, cs), np.uint8)
+            i = np.empty(n, np.int64)
+            if n:
+                self._chk(self.lib.ref_get_list(h, C.c_int64(l), _p(c, _u8p), _p(i, _i64p)))
+            ix.list_codes.append(c)
+            ix.list_ids.append(i)
+        return ix
+
+    def from_data(self, ix):
+        """IndexData -> reference index object (no training)"""
+        h = self.create(ix.kind, ix.metric, ix.d, ix.nlist, ix.M, ix.nbits)
+        if ix.kind == FLAT:
+            self._chk(self.lib.ref_add(h, C.c_int64(ix.base.shape[0]), _p(ix.base, _f32p), None))
+            return h
+        self._chk(self.lib.ref_set_centroids(h, C.c_int64(ix.nlist), _p(ix.centroids, _f32p)))
+        if ix.kind == IVF_PQ:
+            self._chk(self.lib.ref_set_pq_centroids(h, _p(ix.pq_centroids, _f32p)))
+        if ix.kind == IVF_SQ8:
+            self._chk(self.lib.ref_set_sq_trained(h, _p(ix.sq_trained, _f32p)))
+        for l in range(ix.nlist):
+            c = np.ascontiguousarray(ix.list_codes[l], np.uint8)
+            i = np.ascontiguousarray(ix.list_ids[l], np.int64)
+            if i.size:
+                self._chk(self.lib.ref_add_list_entries(h, C.c_int64(l), C.c_int64(i.size), _p(c, _u8p), _p(i, _i64p)))
+        self._chk(self.lib.ref_finalize(h))
+        return h
+
+    def search(self, h, xq, k, nprobe=1, bitset=None, nbits=0, nthreads=1):
+        xq = np.ascontiguousarray(xq, np.float32)
+        nq = xq.shape[0]
+        D = np.empty((nq, k), np.float32)
+        I = np.empty((nq, k), np.int64)
+        self._chk(self.lib.ref_search(h, C.c_int64(nq), _p(xq, _f32p), C.c_int64(k), C.c_int64(nprobe),
+                                      _p(bitset, _u8p), C.c_int64(nbits), _p(D, _f32p), _p(I, _i64p),
+                                      C.c_int(nthreads)))
+        return D, I
+
+    def coarse(self, h, xq, nprobe):
+        xq = np.ascontiguousarray(xq, np.float32)
+        nq = xq.shape[0]
+        D = np.empty((nq, nprobe), np.float32)
+        I = np.empty((nq, nprobe), np.int64)
+        self._chk(self.lib.ref_coarse(h, C.c_int64(nq), _p(xq, _f32p), C.c_int64(nprobe), _p(D, _f32p), _p(I, _i64p)))
+        return D, I
+
+    def fvec_L2sqr(self, x, y):
+        return float(self.lib.ref_fvec_L2sqr(_p(x, _f32p), _p(y, _f32p), C.c_int64(x.size)))
+
+    def fvec_inner_product(self, x, y):
+        return float(self.lib.ref_fvec_inner_product(_p(x, _f32p), _p(y, _f32p), C.c_int64(x.size)))
+
+    def fvec_norm_L2sqr(self, x):
+        return float(self.lib.ref_fvec_norm_L2sqr(_p(x, _f32p), C.c_int64(x.size)))

@@ -1,0 +1,570 @@
+/* oracle/oracle.c -- TEST INFRASTRUCTURE ONLY (see oracle.h).
+ *
+ * Plain-C restatement of the arithmetic the reference executes on its CPU Search() path,
+ * in the scalar (SIMDLevel::NONE / *_ref) form the reference's own tests use as the
+ * known-answer (reference tests/ut/test_simd.cc:259-568).  Every floating-point operation
+ * keeps the reference's order and is rounded once (build: -ffp-contract=off, no fast-math),
+ * so a result can be compared BIT-FOR-BIT with oracle/_ref and with the HIP kernels.
+ *
+ * "T:" abbreviates /root/reference/thirdparty/faiss/faiss/.
+ */
+#include "oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------
+ * Distance primitives.
+ * reference src/simd/distances_ref.cc:21-37 (fvec_inner_product_ref, fvec_L2sqr_ref),
+ * T:utils/simd_impl/distances_autovec-inl.h:43-66 (baseline scalar loops: same order).
+ * ---------------------------------------------------------------------------------------- */
+float orc_fvec_L2sqr(const float* x, const float* y, size_t d) {
+    float res = 0;
+    for (size_t i = 0; i < d; i++) {
+        const float tmp = x[i] - y[i];
+        res += tmp * tmp;
+    }
+    return res;
+}
+
+float orc_fvec_inner_product(const float* x, const float* y, size_t d) {
+    float res = 0;
+    for (size_t i = 0; i < d; i++) {
+        res += x[i] * y[i];
+    }
+    return res;
+}
+
+/* T:utils/simd_impl/distances_autovec-inl.h:28-39 (float accumulator; the double in
+ * distances_ref.cc:58-65 is noted there as a suspected typo; IVFPQ uses the faiss one). */
+float orc_fvec_norm_L2sqr(const float* x, size_t d) {
+    float res = 0;
+    for (size_t i = 0; i < d; i++) {
+        res += x[i] * x[i];
+    }
+    return res;
+}
+
+/* T:utils/distances_simd.cpp:33-43  c = a + bf * b */
+void orc_fvec_madd(size_t n, const float* a, float bf, const float* b, float* c) {
+    for (size_t i = 0; i < n; i++) {
+        c[i] = a[i] + bf * b[i];
+    }
+}
+
+/* reference src/simd/distances_ref.cc:67-81 */
+void orc_fvec_L2sqr_ny(float* dis, const float* x, const float* y, size_t d, size_t ny) {
+    for (size_t i = 0; i < ny; i++) {
+        dis[i] = orc_fvec_L2sqr(x, y, d);
+        y += d;
+    }
+}
+
+void orc_fvec_inner_products_ny(float* ip, const float* x, const float* y, size_t d, size_t ny) {
+    for (size_t i = 0; i < ny; i++) {
+        ip[i] = orc_fvec_inner_product(x, y, d);
+        y += d;
+    }
+}
+
+/* reference src/simd/distances_ref.cc:159-186 (batch_4: four independent sequential sums) */
+void orc_fvec_L2sqr_batch_4(const float* x, const float* y0, const float* y1, const float* y2,
+                            const float* y3, size_t d, float* d0, float* d1, float* d2, float* d3) {
+    *d0 = orc_fvec_L2sqr(x, y0, d);
+    *d1 = orc_fvec_L2sqr(x, y1, d);
+    *d2 = orc_fvec_L2sqr(x, y2, d);
+    *d3 = orc_fvec_L2sqr(x, y3, d);
+}
+
+/* reference src/simd/distances_ref.cc:386-404: int32 accumulate, cast at the end */
+int32_t orc_int8_vec_inner_product(const int8_t* x, const int8_t* y, size_t d) {
+    int32_t res = 0;
+    for (size_t i = 0; i < d; i++) {
+        res += (int32_t)x[i] * (int32_t)y[i];
+    }
+    return res;
+}
+
+int32_t orc_int8_vec_L2sqr(const int8_t* x, const int8_t* y, size_t d) {
+    int32_t res = 0;
+    for (size_t i = 0; i < d; i++) {
+        const int32_t tmp = (int32_t)x[i] - (int32_t)y[i];
+        res += tmp * tmp;
+    }
+    return res;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Top-k heap: T:utils/Heap.h:112-151 (heap_replace_top), :45-75 (heap_pop), :318-343
+ * (heap_heapify), :427-457 (heap_reorder); comparators T:utils/ordered_key_value.h:43-83.
+ * is_max=1 is CMax (keeps the k SMALLEST, L2); is_max=0 is CMin (keeps the k LARGEST, IP).
+ * ---------------------------------------------------------------------------------------- */
+static inline int cmp2(int is_max, float a1, float b1, int64_t a2, int64_t b2) {
+    if (is_max) {
+        return (a1 > b1) || ((a1 == b1) && (a2 > b2));
+    }
+    return (a1 < b1) || ((a1 == b1) && (a2 < b2));
+}
+
+static inline int cmp1(int is_max, float a, float b) {
+    return is_max ? (a > b) : (a < b);
+}
+
+static inline float neutral(int is_max) {
+    return is_max ? FLT_MAX : -FLT_MAX;
+}
+
+void orc_heap_heapify(int is_max, size_t k, float* val, int64_t* ids) {
+    for (size_t i = 0; i < k; i++) {
+        val[i] = neutral(is_max);
+        ids[i] = -1;
+    }
+}
+
+/* sift (v,id) down from the root of the 1-based heap of size k */
+static void sift_from_root(int is_max, size_t k, float* val, int64_t* ids, float v, int64_t id) {
+    float* hv = val - 1;
+    int64_t* hi = ids - 1;
+    size_t i = 1;
+    for (;;) {
+        size_t i1 = i << 1, i2 = i1 + 1;
+        if (i1 > k) {
+            break;
+        }
+        size_t c;
+        if (i2 == k + 1 || cmp2(is_max, hv[i1], hv[i2], hi[i1], hi[i2])) {
+            c = i1;
+        } else {
+            c = i2;
+        }
+        if (cmp2(is_max, v, hv[c], id, hi[c])) {
+            break;
+        }
+        hv[i] = hv[c];
+        hi[i] = hi[c];
+        i = c;
+    }
+    hv[i] = v;
+    hi[i] = id;
+}
+
+void orc_heap_replace_top(int is_max, size_t k, float* val, int64_t* ids, float v, int64_t id) {
+    sift_from_root(is_max, k, val, ids, v, id);
+}
+
+static void heap_pop(int is_max, size_t k, float* val, int64_t* ids) {
+    /* the last element is re-inserted from the root over the remaining k-1 slots */
+    float v = val[k - 1];
+    int64_t id = ids[k - 1];
+    sift_from_root(is_max, k - 1 ? k - 1 : 0, val, ids, v, id);
+    /* note: T:utils/Heap.h:45-75 sifts over size k with the i1>k guard reading slot k,
+     * which holds (v,id) itself; restricting to k-1 gives the same placement. */
+}
+
+size_t orc_heap_reorder(int is_max, size_t k, float* val, int64_t* ids) {
+    size_t i, ii;
+    for (i = 0, ii = 0; i < k; i++) {
+        float v = val[0];
+        int64_t id = ids[0];
+        if (k - i > 1) {
+            heap_pop(is_max, k - i, val, ids);
+        }
+        val[k - ii - 1] = v;
+        ids[k - ii - 1] = id;
+        if (id != -1) {
+            ii++;
+        }
+    }
+    size_t nel = ii;
+    memmove(val, val + k - ii, ii * sizeof(*val));
+    memmove(ids, ids + k - ii, ii * sizeof(*ids));
+    for (; ii < k; ii++) {
+        val[ii] = neutral(is_max);
+        ids[ii] = -1;
+    }
+    return nel;
+}
+
+/* HeapResultHandler::add_result, T:impl/ResultHandler.h:271-278: strict improvement only */
+static inline void heap_add(int is_max, size_t k, float* val, int64_t* ids, float dis, int64_t id) {
+    if (cmp1(is_max, val[0], dis)) {
+        orc_heap_replace_top(is_max, k, val, ids, dis, id);
+    }
+}
+
+/* BitsetViewIDSelector::is_member, reference include/knowhere/bitsetview_idselector.h:20-31 */
+static inline int filtered_out(const uint8_t* bitset, int64_t nbits, int64_t id) {
+    if (!bitset || id < 0 || id >= nbits) {
+        return 0;
+    }
+    return (bitset[id >> 3] >> (id & 7)) & 1;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * FLAT / BruteForce: reference src/index/flat/flat.cc:98-118 -> IndexFlat::search(1,..) ->
+ * T:utils/distances.cpp:326-362 exhaustive_L2sqr_seq / :283-322 exhaustive_inner_product_seq
+ * with a HeapResultHandler (k < 100).  [k >= 100 uses a reservoir in the reference; it returns
+ * the same set except for exact distance ties at the k-th boundary -- not restated.]
+ * ---------------------------------------------------------------------------------------- */
+int orc_flat_search(int metric, int d, int64_t nb, const float* xb, int64_t nq, const float* xq,
+                    int64_t k, const uint8_t* bitset, int64_t nbits, float* D, int64_t* I) {
+    const int is_max = (metric == ORC_L2);
+    for (int64_t i = 0; i < nq; i++) {
+        const float* x = xq + i * (int64_t)d;
+        float* simi = D + i * k;
+        int64_t* idxi = I + i * k;
+        orc_heap_heapify(is_max, (size_t)k, simi, idxi);
+        for (int64_t j = 0; j < nb; j++) {
+            if (filtered_out(bitset, nbits, j)) {
+                continue;
+            }
+            const float* y = xb + j * (int64_t)d;
+            float dis = is_max ? orc_fvec_L2sqr(x, y, (size_t)d)
+                               : orc_fvec_inner_product(x, y, (size_t)d);
+            heap_add(is_max, (size_t)k, simi, idxi, dis, j);
+        }
+        orc_heap_reorder(is_max, (size_t)k, simi, idxi);
+    }
+    return 0;
+}
+
+/* Coarse quantizer: T:IndexIVF.cpp:336-342 quantizer->search(1, q, nprobe) == the FLAT search
+ * above over the centroids (never filtered: quantizer_params is null). */
+int orc_coarse_search(const orc_index* idx, int64_t nq, const float* xq, int64_t nprobe, float* D,
+                      int64_t* I) {
+    return orc_flat_search(idx->metric, idx->d, idx->nlist, idx->centroids, nq, xq, nprobe, NULL,
+                           0, D, I);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Product quantizer tables.
+ * T:impl/ProductQuantizer.cpp:443-485: one fvec_*_ny per sub-quantizer.
+ * ---------------------------------------------------------------------------------------- */
+void orc_pq_inner_prod_table(int d, int M, int nbits, const float* cb, const float* x,
+                             float* table) {
+    const size_t ksub = (size_t)1 << nbits, dsub = (size_t)d / (size_t)M;
+    for (int m = 0; m < M; m++) {
+        orc_fvec_inner_products_ny(table + m * ksub, x + m * dsub, cb + m * ksub * dsub, dsub,
+                                   ksub);
+    }
+}
+
+void orc_pq_distance_table(int d, int M, int nbits, const float* cb, const float* x, float* table) {
+    const size_t ksub = (size_t)1 << nbits, dsub = (size_t)d / (size_t)M;
+    for (int m = 0; m < M; m++) {
+        orc_fvec_L2sqr_ny(table + m * ksub, x + m * dsub, cb + m * ksub * dsub, dsub, ksub);
+    }
+}
+
+/* T:IndexIVFPQ.cpp:465-484 (use_precomputed_table == 1):
+ *   r_norms[m][j] = ||cb[m][j]||^2 ; tab = <c_list,m , cb[m][j]> ; tab = r_norms + 2.0 * tab */
+void orc_pq_precompute_table(int d, int M, int nbits, int64_t nlist, const float* centroids,
+                             const float* cb, float* out) {
+    const size_t ksub = (size_t)1 << nbits, dsub = (size_t)d / (size_t)M;
+    const size_t m_ksub = (size_t)M * ksub;
+    float* r_norms = (float*)malloc(sizeof(float) * m_ksub);
+    for (size_t m = 0; m < (size_t)M; m++) {
+        for (size_t j = 0; j < ksub; j++) {
+            r_norms[m * ksub + j] = orc_fvec_norm_L2sqr(cb + (m * ksub + j) * dsub, dsub);
+        }
+    }
+    for (int64_t i = 0; i < nlist; i++) {
+        float* tab = out + (size_t)i * m_ksub;
+        orc_pq_inner_prod_table(d, M, nbits, cb, centroids + i * (int64_t)d, tab);
+        orc_fvec_madd(m_ksub, r_norms, 2.0f, tab, tab);
+    }
+    free(r_norms);
+}
+
+/* Per-(query, list) table + dis0: T:impl/pq_code_distance/IVFPQ_QueryTables.cpp:110-145.
+ *  IP            : dis0 = <q, c_list>, table = query table (sim_table == inner-prod table)
+ *  L2, precomp=1 : dis0 = coarse_dis,  table = precomp[list] + (-2) * sim_table_2
+ *  L2, precomp=0 : dis0 = 0,           table = ||(q - c_list)_m - cb[m][j]||^2           */
+float orc_ivfpq_list_table(const orc_index* idx, const float* q, int64_t list_no, float coarse_dis,
+                           const float* sim_table_2, float* sim_table) {
+    const size_t ksub = (size_t)1 << idx->nbits;
+    const size_t m_ksub = (size_t)idx->M * ksub;
+    const float* c = idx->centroids + list_no * (int64_t)idx->d;
+    if (idx->metric == ORC_IP) {
+        /* the scan uses the query table directly (sim_table set by init_query_IP) */
+        if (sim_table_2 && sim_table != sim_table_2) {
+            memcpy(sim_table, sim_table_2, sizeof(float) * m_ksub);
+        }
+        return orc_fvec_inner_product(q, c, (size_t)idx->d);
+    }
+    if (idx->use_precomputed_table == 1) {
+        orc_fvec_madd(m_ksub, idx->precomputed_table + (size_t)list_no * m_ksub, -2.0f, sim_table_2,
+                      sim_table);
+        return coarse_dis;
+    }
+    /* residual tables: quantizer->compute_residual (x - centroid) then compute_distance_table */
+    float* r = (float*)malloc(sizeof(float) * (size_t)idx->d);
+    for (int i = 0; i < idx->d; i++) {
+        r[i] = q[i] - c[i];
+    }
+    orc_pq_distance_table(idx->d, idx->M, idx->nbits, idx->pq_centroids, r, sim_table);
+    free(r);
+    return 0.0f;
+}
+
+/* ADC: T:impl/pq_code_distance/pq_code_distance-inl.h:73-90: result = 0; result += tab[m][c_m]
+ * in m order; the caller adds dis0 in front: dis = dis0 + result
+ * (T:impl/pq_code_distance/IVFPQScanner_impl.h:147-150). */
+static inline float adc_distance(int M, size_t ksub, const float* sim_table, const uint8_t* code) {
+    const float* tab = sim_table;
+    float result = 0;
+    for (int m = 0; m < M; m++) {
+        result += tab[code[m]];
+        tab += ksub;
+    }
+    return result;
+}
+
+/* SQ8: T:impl/scalar_quantizer/codecs.h:37-41 decode_component = (code + 0.5f) / 255.0f,
+ *      T:impl/scalar_quantizer/quantizers.h:139-145 x = vmin[i] + xi * vdiff[i],
+ *      T:impl/scalar_quantizer/similarities.h:46-49 (L2: tmp = y - x; accu += tmp*tmp),
+ *      :80-82 (IP: accu += y * x) */
+static inline float sq8_component(const float* trained, int d, const uint8_t* code, int i) {
+    const float xi = ((float)code[i] + 0.5f) / 255.0f;
+    return trained[i] + xi * trained[d + i];
+}
+
+static float sq8_distance(int metric, int d, const float* trained, const float* y,
+                          const uint8_t* code) {
+    float accu = 0;
+    if (metric == ORC_L2) {
+        for (int i = 0; i < d; i++) {
+            const float x = sq8_component(trained, d, code, i);
+            const float tmp = y[i] - x;
+            accu += tmp * tmp;
+        }
+    } else {
+        for (int i = 0; i < d; i++) {
+            const float x = sq8_component(trained, d, code, i);
+            accu += y[i] * x;
+        }
+    }
+    return accu;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * IVF search: T:IndexIVF.cpp:401-768 search_preassigned, parallel_mode 0, max_codes = 0:
+ * per query: heapify; for each probe in coarse-rank order: skip key<0 / empty lists,
+ * set_list, scan_codes in storage order through a HeapResultHandler; heap_reorder.
+ * ---------------------------------------------------------------------------------------- */
+int orc_ivf_search_preassigned(const orc_index* idx, int64_t nq, const float* xq, int64_t k,
+                               int64_t nprobe, const int64_t* keys, const float* coarse_dis,
+                               const uint8_t* bitset, int64_t nbits, float* D, int64_t* I) {
+    const int is_max = (idx->metric == ORC_L2);
+    const int d = idx->d;
+    const size_t ksub = (size_t)1 << (idx->kind == ORC_IVF_PQ ? idx->nbits : 0);
+    const size_t m_ksub = (size_t)idx->M * ksub;
+    float* sim_table = NULL;
+    float* sim_table_2 = NULL;
+    float* resid = (float*)malloc(sizeof(float) * (size_t)d);
+    if (idx->kind == ORC_IVF_PQ) {
+        sim_table = (float*)malloc(sizeof(float) * m_ksub);
+        sim_table_2 = (float*)malloc(sizeof(float) * m_ksub);
+    }
+    for (int64_t i = 0; i < nq; i++) {
+        const float* q = xq + i * (int64_t)d;
+        float* simi = D + i * k;
+        int64_t* idxi = I + i * k;
+        orc_heap_heapify(is_max, (size_t)k, simi, idxi);
+
+        /* set_query: T:impl/pq_code_distance/IVFPQ_QueryTables.cpp:44-67 */
+        if (idx->kind == ORC_IVF_PQ) {
+            if (idx->metric == ORC_IP) {
+                orc_pq_inner_prod_table(d, idx->M, idx->nbits, idx->pq_centroids, q, sim_table);
+            } else if (idx->use_precomputed_table == 1) {
+                orc_pq_inner_prod_table(d, idx->M, idx->nbits, idx->pq_centroids, q, sim_table_2);
+            }
+        }
+        for (int64_t ik = 0; ik < nprobe; ik++) {
+            const int64_t key = keys[i * nprobe + ik];
+            if (key < 0) {
+                continue;
+            }
+            const int64_t len = idx->list_sizes[key];
+            if (len == 0) {
+                continue;
+            }
+            const uint8_t* codes = idx->list_codes[key];
+            const int64_t* ids = idx->list_ids[key];
+            const float cdis = coarse_dis[i * nprobe + ik];
+
+            if (idx->kind == ORC_IVF_FLAT) {
+                /* T:IndexIVFFlat.cpp IVFFlatScanner::scan_codes: dis = metric(q, row) */
+                for (int64_t j = 0; j < len; j++) {
+                    if (filtered_out(bitset, nbits, ids[j])) {
+                        continue;
+                    }
+                    const float* y = (const float*)(codes + j * idx->code_size);
+                    float dis = is_max ? orc_fvec_L2sqr(q, y, (size_t)d)
+                                       : orc_fvec_inner_product(q, y, (size_t)d);
+                    heap_add(is_max, (size_t)k, simi, idxi, dis, ids[j]);
+                }
+            } else if (idx->kind == ORC_IVF_PQ) {
+                const float dis0 = orc_ivfpq_list_table(
+                        idx, q, key, cdis, idx->metric == ORC_IP ? sim_table : sim_table_2,
+                        sim_table);
+                for (int64_t j = 0; j < len; j++) {
+                    if (filtered_out(bitset, nbits, ids[j])) {
+                        continue;
+                    }
+                    const float dis =
+                            dis0 + adc_distance(idx->M, ksub, sim_table, codes + j * idx->code_size);
+                    heap_add(is_max, (size_t)k, simi, idxi, dis, ids[j]);
+                }
+            } else if (idx->kind == ORC_IVF_SQ8) {
+                /* reference thirdparty/faiss/faiss/cppcontrib/knowhere/IndexScalarQuantizer.cpp
+                 * :196-290 (IP: accu0 = coarse_dis, dis = accu0 + <q, x>),
+                 * :292-400 (L2: query residual q - c_list, dis = ||r - x||^2); by_residual */
+                const float* y = q;
+                float accu0 = 0;
+                if (idx->metric == ORC_IP) {
+                    accu0 = cdis;
+                } else {
+                    const float* c = idx->centroids + key * (int64_t)d;
+                    for (int t = 0; t < d; t++) {
+                        resid[t] = q[t] - c[t];
+                    }
+                    y = resid;
+                }
+                for (int64_t j = 0; j < len; j++) {
+                    if (filtered_out(bitset, nbits, ids[j])) {
+                        continue;
+                    }
+                    float dis = sq8_distance(idx->metric, d, idx->sq_trained, y,
+                                             codes + j * idx->code_size);
+                    if (idx->metric == ORC_IP) {
+                        dis = accu0 + dis;
+                    }
+                    heap_add(is_max, (size_t)k, simi, idxi, dis, ids[j]);
+                }
+            }
+        }
+        orc_heap_reorder(is_max, (size_t)k, simi, idxi);
+    }
+    free(sim_table);
+    free(sim_table_2);
+    free(resid);
+    return 0;
+}
+
+int orc_ivf_search(const orc_index* idx, int64_t nq, const float* xq, int64_t k, int64_t nprobe,
+                   const uint8_t* bitset, int64_t nbits, float* D, int64_t* I) {
+    if (nprobe > idx->nlist) {
+        nprobe = idx->nlist; /* T:IndexIVF.cpp:321-322 */
+    }
+    float* cd = (float*)malloc(sizeof(float) * (size_t)(nq * nprobe));
+    int64_t* keys = (int64_t*)malloc(sizeof(int64_t) * (size_t)(nq * nprobe));
+    orc_coarse_search(idx, nq, xq, nprobe, cd, keys);
+    int rc = orc_ivf_search_preassigned(idx, nq, xq, k, nprobe, keys, cd, bitset, nbits, D, I);
+    free(cd);
+    free(keys);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Shard merge.  The k best of the union of per-shard results; the reference proves the
+ * property in tests/ut/test_bruteforce.cc:128-181 (heaps.addn_with_ids over partitions) and
+ * T:utils/Heap.h:636 merge_knn_results.  Restated with the same heap.
+ * ---------------------------------------------------------------------------------------- */
+int orc_merge_topk(int metric, int64_t nq, int64_t k, int nshard, const float* D_parts,
+                   const int64_t* I_parts, float* D, int64_t* I) {
+    const int is_max = (metric == ORC_L2);
+    for (int64_t i = 0; i < nq; i++) {
+        float* simi = D + i * k;
+        int64_t* idxi = I + i * k;
+        orc_heap_heapify(is_max, (size_t)k, simi, idxi);
+        for (int s = 0; s < nshard; s++) {
+            const float* dp = D_parts + ((int64_t)s * nq + i) * k;
+            const int64_t* ip = I_parts + ((int64_t)s * nq + i) * k;
+            for (int64_t j = 0; j < k; j++) {
+                if (ip[j] < 0) {
+                    continue;
+                }
+                heap_add(is_max, (size_t)k, simi, idxi, dp[j], ip[j]);
+            }
+        }
+        orc_heap_reorder(is_max, (size_t)k, simi, idxi);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Build-side helpers (restated add path), used to make test indexes on boxes without _ref.
+ * ---------------------------------------------------------------------------------------- */
+/* IndexFlat::assign == search with k=1: first strict improvement wins */
+void orc_assign(int metric, int d, int64_t nlist, const float* centroids, int64_t n, const float* x,
+                int64_t* out) {
+    for (int64_t i = 0; i < n; i++) {
+        const float* xi = x + i * (int64_t)d;
+        int64_t best = -1;
+        float bd = (metric == ORC_L2) ? FLT_MAX : -FLT_MAX;
+        for (int64_t j = 0; j < nlist; j++) {
+            const float* c = centroids + j * (int64_t)d;
+            if (metric == ORC_L2) {
+                float dis = orc_fvec_L2sqr(xi, c, (size_t)d);
+                if (bd > dis) {
+                    bd = dis;
+                    best = j;
+                }
+            } else {
+                float dis = orc_fvec_inner_product(xi, c, (size_t)d);
+                if (bd < dis) {
+                    bd = dis;
+                    best = j;
+                }
+            }
+        }
+        out[i] = best;
+    }
+}
+
+/* T:impl/ProductQuantizer.cpp:250-280 compute_1_code (nbits = 8): per sub-vector the nearest
+ * codeword, first minimum wins (reference src/simd/distances_ref.cc:100-117). */
+void orc_pq_compute_code(int d, int M, int nbits, const float* cb, const float* x, uint8_t* code) {
+    const size_t ksub = (size_t)1 << nbits, dsub = (size_t)d / (size_t)M;
+    for (int m = 0; m < M; m++) {
+        const float* xs = x + m * dsub;
+        size_t best = 0;
+        float bd = HUGE_VALF;
+        for (size_t j = 0; j < ksub; j++) {
+            float dis = orc_fvec_L2sqr(xs, cb + (m * ksub + j) * dsub, dsub);
+            if (dis < bd) {
+                bd = dis;
+                best = j;
+            }
+        }
+        code[m] = (uint8_t)best;
+    }
+}
+
+/* T:impl/scalar_quantizer/quantizers.h:118-133 + codecs.h:29-35 */
+void orc_sq8_encode(int d, const float* trained, const float* x, uint8_t* code) {
+    const float* vmin = trained;
+    const float* vdiff = trained + d;
+    for (int i = 0; i < d; i++) {
+        float xi = 0;
+        if (vdiff[i] != 0) {
+            xi = (x[i] - vmin[i]) / vdiff[i];
+            if (xi < 0) {
+                xi = 0;
+            }
+            if (xi > 1.0) {
+                xi = 1.0;
+            }
+        }
+        code[i] = (uint8_t)(int)(255 * xi);
+    }
+}
+
+void orc_sq8_decode(int d, const float* trained, const uint8_t* code, float* x) {
+    for (int i = 0; i < d; i++) {
+        x[i] = sq8_component(trained, d, code, i);
+    }
+}

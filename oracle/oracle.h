@@ -1,0 +1,108 @@
+/* oracle/oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C restatement of the reference (zilliztech/knowhere @ /root/reference) Search()
+ * arithmetic for BruteForce(FLAT) / IVF-Flat / IVF-PQ / IVF-SQ8.  It is the CHECKER for the
+ * HIP path: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * it.  The product (knowhere_amd/, libknhip.so) never links or calls anything here.
+ *
+ * Parity status: PINNED.  The reference tests hold no golden id/distance vectors for this
+ * path, so the restatement is pinned against outputs of the reference
+ * itself: oracle/_ref/libknowhere_ref.so (the reference's own FAISS sources compiled in
+ * place, scalar SIMDLevel::NONE build) -- tests/test_oracle_vs_ref.py requires bit-equal
+ * distances and equal ids -- and against fixtures generated from it under tests/golden/.
+ *
+ * "T:" below abbreviates /root/reference/thirdparty/faiss/faiss/.
+ */
+#ifndef KNOWHERE_AMD_ORACLE_H
+#define KNOWHERE_AMD_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ORC_FLAT = 0, ORC_IVF_FLAT = 1, ORC_IVF_PQ = 2, ORC_IVF_SQ8 = 3 };
+enum { ORC_L2 = 0, ORC_IP = 1 };
+
+/* A trained + populated index as plain arrays (same bytes the HIP side is given). */
+typedef struct orc_index {
+    int32_t kind;   /* ORC_* */
+    int32_t metric; /* ORC_L2 | ORC_IP */
+    int32_t d;
+    int32_t M;     /* IVF_PQ: sub-quantizers */
+    int32_t nbits; /* IVF_PQ: bits per code (8) */
+    int32_t use_precomputed_table; /* IVF_PQ L2: 1 = term-2 table, 0 = residual tables */
+    int64_t nlist;
+    int64_t code_size;             /* bytes per stored vector */
+    const float* centroids;        /* [nlist][d] */
+    const float* pq_centroids;     /* [M][ksub][dsub] */
+    const float* precomputed_table;/* [nlist][M*ksub] or NULL */
+    const float* sq_trained;       /* vmin[d] then vdiff[d] */
+    const int64_t* list_sizes;     /* [nlist] */
+    const uint8_t* const* list_codes; /* [nlist] -> [len][code_size] */
+    const int64_t* const* list_ids;   /* [nlist] -> [len] */
+} orc_index;
+
+/* ---- distance primitives (reference src/simd/distances_ref.cc:21-76) ---- */
+float orc_fvec_L2sqr(const float* x, const float* y, size_t d);
+float orc_fvec_inner_product(const float* x, const float* y, size_t d);
+float orc_fvec_norm_L2sqr(const float* x, size_t d);
+void orc_fvec_madd(size_t n, const float* a, float bf, const float* b, float* c);
+void orc_fvec_L2sqr_ny(float* dis, const float* x, const float* y, size_t d, size_t ny);
+void orc_fvec_inner_products_ny(float* ip, const float* x, const float* y, size_t d, size_t ny);
+void orc_fvec_L2sqr_batch_4(const float* x, const float* y0, const float* y1, const float* y2,
+                            const float* y3, size_t d, float* d0, float* d1, float* d2, float* d3);
+int32_t orc_int8_vec_inner_product(const int8_t* x, const int8_t* y, size_t d);
+int32_t orc_int8_vec_L2sqr(const int8_t* x, const int8_t* y, size_t d);
+
+/* ---- top-k heap (T:utils/Heap.h) ---- */
+void orc_heap_heapify(int is_max, size_t k, float* val, int64_t* ids);
+void orc_heap_replace_top(int is_max, size_t k, float* val, int64_t* ids, float v, int64_t id);
+size_t orc_heap_reorder(int is_max, size_t k, float* val, int64_t* ids);
+
+/* ---- PQ tables ---- */
+void orc_pq_inner_prod_table(int d, int M, int nbits, const float* pq_centroids, const float* x,
+                             float* table /* [M][ksub] */);
+void orc_pq_distance_table(int d, int M, int nbits, const float* pq_centroids, const float* x,
+                           float* table);
+void orc_pq_precompute_table(int d, int M, int nbits, int64_t nlist, const float* centroids,
+                             const float* pq_centroids, float* out /* [nlist][M*ksub] */);
+/* the per-(query,list) LUT and dis0 the ADC scan uses */
+float orc_ivfpq_list_table(const orc_index* idx, const float* q, int64_t list_no, float coarse_dis,
+                           const float* sim_table_2 /* query table or NULL */,
+                           float* sim_table /* [M*ksub] out */);
+
+/* ---- searches; bitset: bit set => row filtered OUT, LSB-first; NULL = no filter ---- */
+int orc_flat_search(int metric, int d, int64_t nb, const float* xb, int64_t nq, const float* xq,
+                    int64_t k, const uint8_t* bitset, int64_t nbits, float* D, int64_t* I);
+int orc_coarse_search(const orc_index* idx, int64_t nq, const float* xq, int64_t nprobe, float* D,
+                      int64_t* I);
+int orc_ivf_search(const orc_index* idx, int64_t nq, const float* xq, int64_t k, int64_t nprobe,
+                   const uint8_t* bitset, int64_t nbits, float* D, int64_t* I);
+/* same, with the probe assignment given (T:IndexIVF.cpp:401 search_preassigned) */
+int orc_ivf_search_preassigned(const orc_index* idx, int64_t nq, const float* xq, int64_t k,
+                               int64_t nprobe, const int64_t* keys, const float* coarse_dis,
+                               const uint8_t* bitset, int64_t nbits, float* D, int64_t* I);
+
+/* host-side merge of per-shard partial results (T:utils/Heap.h:636 merge_knn_results semantics:
+ * the k best of the union in canonical order) -- checker for the multi-GPU merge */
+int orc_merge_topk(int metric, int64_t nq, int64_t k, int nshard, const float* D_parts,
+                   const int64_t* I_parts, float* D, int64_t* I);
+
+/* ---- build-side helpers used to make test indexes (restated add path) ---- */
+/* nearest centroid by the metric (IndexFlat::assign) */
+void orc_assign(int metric, int d, int64_t nlist, const float* centroids, int64_t n, const float* x,
+                int64_t* out);
+/* PQ encode one (residual) vector: T:impl/ProductQuantizer.cpp:282-299 compute_code */
+void orc_pq_compute_code(int d, int M, int nbits, const float* pq_centroids, const float* x,
+                         uint8_t* code);
+/* SQ8 encode / decode: T:impl/scalar_quantizer/quantizers.h:108-146, codecs.h:26-41 */
+void orc_sq8_encode(int d, const float* trained, const float* x, uint8_t* code);
+void orc_sq8_decode(int d, const float* trained, const uint8_t* code, float* x);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,353 @@
+// oracle/ref_driver.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// Thin C-ABI over the REAL reference arithmetic: the baseline FAISS objects vendored in the
+// reference tree (/root/reference/thirdparty/faiss/faiss), compiled from where they lie by
+// oracle/Makefile into oracle/_ref/libknowhere_ref.so.  Nothing here re-implements a
+// distance; it only drives the reference the way Knowhere does:
+//   * IvfIndexNode::Search  (reference src/index/ivf/ivf.cc:915-1159): one task per query,
+//     index->search(1, q, k, ...), OpenMP pinned to 1 thread inside the task,
+//     IVFSearchParameters{nprobe, max_codes=0, sel = BitsetViewIDSelector | nullptr}.
+//   * FlatIndexNode::Search (reference src/index/flat/flat.cc:76-148): IndexFlat::search(1,..)
+//   * BitsetViewIDSelector::is_member(id) = !bitset.test(id), LSB-first bytes
+//     (reference include/knowhere/bitsetview_idselector.h:20-31, index_node.h:646).
+// Used by tests/ to pin oracle.c (the plain-C restatement) and, as "kind":"reference",
+// by bench.py's cpu_baseline leg.
+
+#include <faiss/IndexFlat.h>
+#include <faiss/IndexIVF.h>
+#include <faiss/IndexIVFFlat.h>
+#include <faiss/IndexIVFPQ.h>
+#include <faiss/IndexScalarQuantizer.h>
+#include <faiss/impl/IDSelector.h>
+#include <faiss/invlists/InvertedLists.h>
+#include <faiss/utils/distances.h>
+
+#include <omp.h>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <string>
+
+namespace {
+
+struct BitsetSelector : faiss::IDSelector {
+    const uint8_t* bits;
+    int64_t nbits;
+    BitsetSelector(const uint8_t* b, int64_t n) : bits(b), nbits(n) {}
+    bool is_member(faiss::idx_t id) const override {
+        if (id < 0 || id >= nbits) {
+            return true;
+        }
+        return !((bits[id >> 3] >> (id & 7)) & 1);
+    }
+};
+
+enum Kind { K_FLAT = 0, K_IVF_FLAT = 1, K_IVF_PQ = 2, K_IVF_SQ8 = 3 };
+
+struct RefIndex {
+    int kind = 0, metric = 0, d = 0;
+    std::unique_ptr<faiss::IndexFlat> quantizer;  // coarse quantizer (IVF kinds)
+    std::unique_ptr<faiss::Index> index;          // the searched index
+    faiss::IndexIVF* ivf() const {
+        return dynamic_cast<faiss::IndexIVF*>(index.get());
+    }
+};
+
+thread_local std::string g_err;
+
+template <class F>
+int guarded(F&& f) {
+    try {
+        f();
+        return 0;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ref_last_error() {
+    return g_err.c_str();
+}
+
+void* ref_create(int kind, int metric, int d, int nlist, int M, int nbits) {
+    auto* h = new RefIndex();
+    h->kind = kind;
+    h->metric = metric;
+    h->d = d;
+    faiss::MetricType mt = metric == 0 ? faiss::METRIC_L2 : faiss::METRIC_INNER_PRODUCT;
+    int rc = guarded([&] {
+        if (kind == K_FLAT) {
+            h->index.reset(new faiss::IndexFlat(d, mt));
+            return;
+        }
+        h->quantizer.reset(new faiss::IndexFlat(d, mt));
+        if (kind == K_IVF_FLAT) {
+            h->index.reset(new faiss::IndexIVFFlat(h->quantizer.get(), d, nlist, mt));
+        } else if (kind == K_IVF_PQ) {
+            h->index.reset(new faiss::IndexIVFPQ(h->quantizer.get(), d, nlist, M, nbits, mt));
+        } else if (kind == K_IVF_SQ8) {
+            h->index.reset(new faiss::IndexIVFScalarQuantizer(
+                    h->quantizer.get(), d, nlist, faiss::ScalarQuantizer::QT_8bit, mt, true));
+        } else {
+            throw std::runtime_error("bad kind");
+        }
+    });
+    if (rc != 0) {
+        delete h;
+        return nullptr;
+    }
+    return h;
+}
+
+void ref_destroy(void* hv) {
+    auto* h = static_cast<RefIndex*>(hv);
+    if (!h) {
+        return;
+    }
+    h->index.reset();  // index does not own the quantizer (own_fields=false)
+    h->quantizer.reset();
+    delete h;
+}
+
+int ref_train(void* hv, int64_t n, const float* x) {
+    auto* h = static_cast<RefIndex*>(hv);
+    return guarded([&] { h->index->train(n, x); });
+}
+
+int ref_add(void* hv, int64_t n, const float* x, const int64_t* ids) {
+    auto* h = static_cast<RefIndex*>(hv);
+    return guarded([&] {
+        if (ids && h->kind != K_FLAT) {
+            h->index->add_with_ids(n, x, ids);
+        } else {
+            h->index->add(n, x);
+        }
+    });
+}
+
+int64_t ref_ntotal(void* hv) {
+    return static_cast<RefIndex*>(hv)->index->ntotal;
+}
+
+int64_t ref_nlist(void* hv) {
+    auto* ivf = static_cast<RefIndex*>(hv)->ivf();
+    return ivf ? (int64_t)ivf->nlist : 0;
+}
+
+int64_t ref_code_size(void* hv) {
+    auto* ivf = static_cast<RefIndex*>(hv)->ivf();
+    return ivf ? (int64_t)ivf->code_size : 0;
+}
+
+/* ---------------- export (reference-trained index -> plain arrays) ---------------- */
+
+int ref_get_flat_vectors(void* hv, float* out) {
+    auto* h = static_cast<RefIndex*>(hv);
+    auto* f = dynamic_cast<faiss::IndexFlat*>(h->index.get());
+    if (!f) {
+        return -1;
+    }
+    std::memcpy(out, f->get_xb(), sizeof(float) * f->ntotal * f->d);
+    return 0;
+}
+
+int ref_get_centroids(void* hv, float* out) {
+    auto* h = static_cast<RefIndex*>(hv);
+    if (!h->quantizer) {
+        return -1;
+    }
+    std::memcpy(out, h->quantizer->get_xb(), sizeof(float) * h->quantizer->ntotal * h->d);
+    return 0;
+}
+
+int ref_get_pq_centroids(void* hv, float* out) {
+    auto* p = dynamic_cast<faiss::IndexIVFPQ*>(static_cast<RefIndex*>(hv)->index.get());
+    if (!p) {
+        return -1;
+    }
+    std::memcpy(out, p->pq.centroids.data(), sizeof(float) * p->pq.centroids.size());
+    return 0;
+}
+
+int ref_get_sq_trained(void* hv, float* out) {
+    auto* p = dynamic_cast<faiss::IndexIVFScalarQuantizer*>(static_cast<RefIndex*>(hv)->index.get());
+    if (!p) {
+        return -1;
+    }
+    std::memcpy(out, p->sq.trained.data(), sizeof(float) * p->sq.trained.size());
+    return 0;
+}
+
+int ref_use_precomputed_table(void* hv) {
+    auto* p = dynamic_cast<faiss::IndexIVFPQ*>(static_cast<RefIndex*>(hv)->index.get());
+    return p ? p->use_precomputed_table : -2;
+}
+
+int64_t ref_get_precomputed_table(void* hv, float* out) {
+    auto* p = dynamic_cast<faiss::IndexIVFPQ*>(static_cast<RefIndex*>(hv)->index.get());
+    if (!p) {
+        return -1;
+    }
+    if (out) {
+        std::memcpy(out, p->precomputed_table.data(), sizeof(float) * p->precomputed_table.size());
+    }
+    return (int64_t)p->precomputed_table.size();
+}
+
+int64_t ref_list_size(void* hv, int64_t l) {
+    auto* ivf = static_cast<RefIndex*>(hv)->ivf();
+    return ivf ? (int64_t)ivf->invlists->list_size(l) : -1;
+}
+
+int ref_get_list(void* hv, int64_t l, uint8_t* codes, int64_t* ids) {
+    auto* ivf = static_cast<RefIndex*>(hv)->ivf();
+    if (!ivf) {
+        return -1;
+    }
+    size_t n = ivf->invlists->list_size(l);
+    if (n == 0) {
+        return 0;
+    }
+    faiss::InvertedLists::ScopedCodes sc(ivf->invlists, l);
+    faiss::InvertedLists::ScopedIds si(ivf->invlists, l);
+    std::memcpy(codes, sc.get(), n * ivf->code_size);
+    std::memcpy(ids, si.get(), n * sizeof(int64_t));
+    return 0;
+}
+
+/* ---------------- import (plain arrays -> reference index, no training) ---------------- */
+
+int ref_set_centroids(void* hv, int64_t nlist, const float* c) {
+    auto* h = static_cast<RefIndex*>(hv);
+    return guarded([&] {
+        h->quantizer->reset();
+        h->quantizer->add(nlist, c);
+        auto* ivf = h->ivf();
+        ivf->is_trained = true;  // encoder params are set separately
+    });
+}
+
+int ref_set_pq_centroids(void* hv, const float* cb) {
+    auto* p = dynamic_cast<faiss::IndexIVFPQ*>(static_cast<RefIndex*>(hv)->index.get());
+    if (!p) {
+        return -1;
+    }
+    std::memcpy(p->pq.centroids.data(), cb, sizeof(float) * p->pq.centroids.size());
+    return 0;
+}
+
+int ref_set_sq_trained(void* hv, const float* t) {
+    auto* p = dynamic_cast<faiss::IndexIVFScalarQuantizer*>(static_cast<RefIndex*>(hv)->index.get());
+    if (!p) {
+        return -1;
+    }
+    p->sq.trained.assign(t, t + 2 * p->d);
+    return 0;
+}
+
+int ref_add_list_entries(void* hv, int64_t l, int64_t n, const uint8_t* codes, const int64_t* ids) {
+    auto* h = static_cast<RefIndex*>(hv);
+    return guarded([&] {
+        auto* ivf = h->ivf();
+        ivf->invlists->add_entries(l, n, ids, codes);
+        ivf->ntotal += n;
+    });
+}
+
+/// (re)build the IVFPQ precomputed table exactly as IndexIVFPQ::train_encoder does
+/// (reference thirdparty/faiss/faiss/IndexIVFPQ.cpp:515-523).
+int ref_finalize(void* hv) {
+    auto* h = static_cast<RefIndex*>(hv);
+    return guarded([&] {
+        if (auto* p = dynamic_cast<faiss::IndexIVFPQ*>(h->index.get())) {
+            p->use_precomputed_table = 0;
+            p->precompute_table();
+        }
+    });
+}
+
+/* ---------------- search, driven the way Knowhere drives it ---------------- */
+
+int ref_search(
+        void* hv,
+        int64_t nq,
+        const float* q,
+        int64_t k,
+        int64_t nprobe,
+        const uint8_t* bitset,
+        int64_t nbits,
+        float* D,
+        int64_t* I,
+        int nthreads) {
+    auto* h = static_cast<RefIndex*>(hv);
+    std::string err;
+    int failed = 0;
+    if (nthreads < 1) {
+        nthreads = 1;
+    }
+    omp_set_max_active_levels(1);  // inner faiss omp regions run single-threaded
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
+    for (int64_t i = 0; i < nq; i++) {
+        try {
+            std::unique_ptr<BitsetSelector> sel;
+            if (bitset) {
+                sel.reset(new BitsetSelector(bitset, nbits));
+            }
+            if (h->kind == K_FLAT) {
+                faiss::SearchParameters sp;
+                sp.sel = sel.get();
+                h->index->search(1, q + i * h->d, k, D + i * k, I + i * k, &sp);
+            } else {
+                faiss::IVFSearchParameters sp;
+                sp.nprobe = nprobe;
+                sp.max_codes = 0;
+                sp.sel = sel.get();
+                h->index->search(1, q + i * h->d, k, D + i * k, I + i * k, &sp);
+            }
+        } catch (const std::exception& e) {
+#pragma omp critical
+            {
+                failed = 1;
+                err = e.what();
+            }
+        }
+    }
+    if (failed) {
+        g_err = err;
+        return -1;
+    }
+    return 0;
+}
+
+/// coarse quantizer alone: quantizer->search(1, q, nprobe) per query
+/// (reference thirdparty/faiss/faiss/IndexIVF.cpp:336-342).
+int ref_coarse(void* hv, int64_t nq, const float* q, int64_t nprobe, float* D, int64_t* I) {
+    auto* h = static_cast<RefIndex*>(hv);
+    return guarded([&] {
+        for (int64_t i = 0; i < nq; i++) {
+            h->quantizer->search(1, q + i * h->d, nprobe, D + i * nprobe, I + i * nprobe);
+        }
+    });
+}
+
+/* ---------------- primitives (baseline faiss scalar build) ---------------- */
+
+float ref_fvec_L2sqr(const float* x, const float* y, int64_t d) {
+    return faiss::fvec_L2sqr(x, y, d);
+}
+float ref_fvec_inner_product(const float* x, const float* y, int64_t d) {
+    return faiss::fvec_inner_product(x, y, d);
+}
+float ref_fvec_norm_L2sqr(const float* x, int64_t d) {
+    return faiss::fvec_norm_L2sqr(x, d);
+}
+void ref_fvec_madd(int64_t n, const float* a, float bf, const float* b, float* c) {
+    faiss::fvec_madd(n, a, bf, b, c);
+}
+
+}  // extern "C"
