@@ -1,0 +1,102 @@
+"""knowhere_amd/_lib.py -- ctypes binding of libknhip.so (include/knhip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C knowhere_amd/csrc``.
+There is NO fallback: if the shared object is missing or a HIP call fails, this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libknhip.so")
+
+BRUTE_FORCE, IVF_FLAT, IVF_PQ, IVF_SQ8 = 0, 1, 2, 3
+L2, IP = 0, 1
+NSTAGE = 8
+STAGE_COARSE, STAGE_GROUP, STAGE_LUT, STAGE_SCAN, STAGE_MERGE, STAGE_OTHER = range(6)
+
+
+class KnhipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"knhip error {code}: {msg}")
+        self.code = code
+
+
+class Desc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("metric", C.c_int32), ("dim", C.c_int32), ("device", C.c_int32),
+                ("nlist", C.c_int64), ("pq_m", C.c_int32), ("pq_nbits", C.c_int32),
+                ("precomputed_table_max_bytes", C.c_int64)]
+
+
+class StageTimes(C.Structure):
+    _fields_ = [("ms", C.c_float * NSTAGE), ("launches", C.c_int64 * NSTAGE), ("scan_bytes", C.c_double),
+                ("coarse_flops", C.c_double), ("scan_items", C.c_int64)]
+
+
+# every symbol include/knhip.h declares (tests check the .so exports all of them)
+SYMBOLS = [
+    "knhip_abi_version", "knhip_device_count", "knhip_last_error", "knhip_index_create",
+    "knhip_index_destroy", "knhip_index_set_coarse", "knhip_index_set_pq", "knhip_index_set_sq",
+    "knhip_index_add_lists", "knhip_index_add_vectors", "knhip_index_set_coarse_device",
+    "knhip_index_set_lists_device", "knhip_index_add_vectors_device", "knhip_index_count",
+    "knhip_index_device_bytes", "knhip_index_uses_precomputed_table", "knhip_search",
+    "knhip_search_device", "knhip_coarse_search_device", "knhip_merge_topk_device",
+    "knhip_merge_topk_host", "knhip_fvec_L2sqr_ny", "knhip_fvec_inner_products_ny",
+    "knhip_fvec_norms_L2sqr", "knhip_fvec_madd", "knhip_int8_vec_L2sqr_ny",
+    "knhip_int8_vec_inner_products_ny", "knhip_profile_enable", "knhip_profile_reset",
+    "knhip_profile_get", "knhip_stage_kernel_name",
+]
+
+_lib = None
+
+
+def load():
+    """Load libknhip.so; raises if it has not been built (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C knowhere_amd/csrc). "
+            "knowhere_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int32
+    L.knhip_last_error.restype = C.c_char_p
+    L.knhip_stage_kernel_name.restype = C.c_char_p
+    L.knhip_index_count.restype = i64
+    L.knhip_index_device_bytes.restype = i64
+    L.knhip_index_create.argtypes = [C.POINTER(Desc), C.POINTER(vp)]
+    L.knhip_index_destroy.argtypes = [vp]
+    L.knhip_index_destroy.restype = None
+    L.knhip_index_set_coarse.argtypes = [vp, vp]
+    L.knhip_index_set_coarse_device.argtypes = [vp, vp]
+    L.knhip_index_set_pq.argtypes = [vp, vp]
+    L.knhip_index_set_sq.argtypes = [vp, vp, vp]
+    L.knhip_index_add_lists.argtypes = [vp, vp, vp, vp]
+    L.knhip_index_set_lists_device.argtypes = [vp, vp, vp, vp]
+    L.knhip_index_add_vectors.argtypes = [vp, i64, vp, vp, i64]
+    L.knhip_index_add_vectors_device.argtypes = [vp, i64, vp, vp, i64]
+    L.knhip_index_count.argtypes = [vp]
+    L.knhip_index_device_bytes.argtypes = [vp]
+    L.knhip_index_uses_precomputed_table.argtypes = [vp]
+    L.knhip_search.argtypes = [vp, vp, i64, i32, i32, vp, i64, vp, vp]
+    L.knhip_search_device.argtypes = [vp, vp, i64, i32, i32, vp, i64, vp, vp, vp]
+    L.knhip_coarse_search_device.argtypes = [vp, vp, i64, i32, vp, vp, vp]
+    L.knhip_merge_topk_device.argtypes = [i32, i64, i32, i32, vp, vp, vp, vp, vp]
+    L.knhip_merge_topk_host.argtypes = [i32, i64, i32, i32, vp, vp, vp, vp]
+    for f in ("knhip_fvec_L2sqr_ny", "knhip_fvec_inner_products_ny", "knhip_int8_vec_L2sqr_ny",
+              "knhip_int8_vec_inner_products_ny"):
+        getattr(L, f).argtypes = [vp, vp, vp, i64, i64, vp]
+    L.knhip_fvec_norms_L2sqr.argtypes = [vp, vp, i64, i64, vp]
+    L.knhip_fvec_madd.argtypes = [i64, vp, C.c_float, vp, vp, vp]
+    L.knhip_profile_enable.argtypes = [vp, C.c_int]
+    L.knhip_profile_reset.argtypes = [vp]
+    L.knhip_profile_get.argtypes = [vp, C.POINTER(StageTimes)]
+    L.knhip_stage_kernel_name.argtypes = [C.c_int, C.c_int]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise KnhipError(rc, load().knhip_last_error().decode(errors="replace"))

@@ -1,0 +1,195 @@
+"""knowhere_amd/index.py -- Python handle over a ``knhip_index`` (one device, one process).
+
+Mirrors the C ABI one-to-one; numpy arrays cross the host boundary (``search``), torch tensors
+the device boundary (``search_device``).  No arithmetic happens here.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import KnhipError, check  # noqa: F401
+
+BRUTE_FORCE, IVF_FLAT, IVF_PQ, IVF_SQ8 = _lib.BRUTE_FORCE, _lib.IVF_FLAT, _lib.IVF_PQ, _lib.IVF_SQ8
+L2, IP = _lib.L2, _lib.IP
+
+KIND_NAMES = {"GPU_HIP_BRUTE_FORCE": BRUTE_FORCE, "GPU_HIP_IVF_FLAT": IVF_FLAT, "GPU_HIP_IVF_PQ": IVF_PQ,
+              "GPU_HIP_IVF_SQ8": IVF_SQ8}
+
+
+def _np_ptr(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+def _t_ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class GpuIndex:
+    def __init__(self, kind, metric, dim, nlist=0, pq_m=0, pq_nbits=8, device=0,
+                 precomputed_table_max_bytes=0):
+        self.L = _lib.load()
+        self.kind, self.metric, self.dim, self.nlist, self.pq_m = kind, metric, dim, nlist, pq_m
+        self.device = device
+        d = _lib.Desc(kind, metric, dim, device, nlist, pq_m, pq_nbits, precomputed_table_max_bytes)
+        h = C.c_void_p()
+        check(self.L.knhip_index_create(C.byref(d), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.knhip_index_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- contents (host) ----
+    def set_coarse(self, centroids):
+        c = np.ascontiguousarray(centroids, np.float32)
+        assert c.shape == (self.nlist, self.dim)
+        check(self.L.knhip_index_set_coarse(self.h, _np_ptr(c)))
+
+    def set_pq(self, codebooks):
+        c = np.ascontiguousarray(codebooks, np.float32)
+        assert c.size == 256 * self.dim
+        check(self.L.knhip_index_set_pq(self.h, _np_ptr(c)))
+
+    def set_sq(self, vmin, vdiff):
+        a = np.ascontiguousarray(vmin, np.float32)
+        b = np.ascontiguousarray(vdiff, np.float32)
+        check(self.L.knhip_index_set_sq(self.h, _np_ptr(a), _np_ptr(b)))
+
+    def add_lists(self, list_codes, list_ids):
+        nlist = self.nlist
+        sizes = np.array([len(i) for i in list_ids], np.int64)
+        keep = []
+        cp = (C.c_void_p * nlist)()
+        ip = (C.c_void_p * nlist)()
+        for l in range(nlist):
+            c = np.ascontiguousarray(list_codes[l], np.uint8)
+            i = np.ascontiguousarray(list_ids[l], np.int64)
+            keep += [c, i]
+            cp[l] = c.ctypes.data if i.size else None
+            ip[l] = i.ctypes.data if i.size else None
+        check(self.L.knhip_index_add_lists(self.h, _np_ptr(sizes), C.cast(cp, C.c_void_p), C.cast(ip, C.c_void_p)))
+
+    def add_vectors(self, x, id_offset=0):
+        x = np.ascontiguousarray(x, np.float32)
+        check(self.L.knhip_index_add_vectors(self.h, x.shape[0], _np_ptr(x), None, id_offset))
+
+    @classmethod
+    def from_data(cls, ix, device=0, precomputed_table_max_bytes=0):
+        """ix: any object with the fields of oracle.binding.IndexData (duck typed; the product does
+        not import the oracle)."""
+        kind = {0: BRUTE_FORCE, 1: IVF_FLAT, 2: IVF_PQ, 3: IVF_SQ8}[ix.kind]
+        g = cls(kind, ix.metric, ix.d, ix.nlist, ix.M, ix.nbits, device, precomputed_table_max_bytes)
+        if kind == BRUTE_FORCE:
+            g.add_vectors(ix.base)
+            return g
+        g.set_coarse(ix.centroids)
+        if kind == IVF_PQ:
+            g.set_pq(ix.pq_centroids)
+        if kind == IVF_SQ8:
+            g.set_sq(ix.sq_trained[:ix.d], ix.sq_trained[ix.d:])
+        g.add_lists(ix.list_codes, ix.list_ids)
+        return g
+
+    # ---- contents (device tensors, GPU build path) ----
+    def set_coarse_device(self, centroids_t):
+        assert centroids_t.is_cuda and centroids_t.is_contiguous()
+        check(self.L.knhip_index_set_coarse_device(self.h, _t_ptr(centroids_t)))
+
+    def set_lists_device(self, list_offsets, codes_t, ids_t):
+        off = np.ascontiguousarray(list_offsets, np.int64)
+        assert off.size == self.nlist + 1
+        check(self.L.knhip_index_set_lists_device(self.h, _np_ptr(off), _t_ptr(codes_t), _t_ptr(ids_t)))
+
+    def add_vectors_device(self, x_t, id_offset=0):
+        assert x_t.is_cuda and x_t.is_contiguous()
+        check(self.L.knhip_index_add_vectors_device(self.h, x_t.shape[0], _t_ptr(x_t), None, id_offset))
+
+    # ---- info ----
+    @property
+    def count(self):
+        return int(self.L.knhip_index_count(self.h))
+
+    @property
+    def device_bytes(self):
+        return int(self.L.knhip_index_device_bytes(self.h))
+
+    @property
+    def uses_precomputed_table(self):
+        return int(self.L.knhip_index_uses_precomputed_table(self.h))
+
+    # ---- search ----
+    def search(self, xq, k, nprobe=1, bitset=None, nbits=0):
+        xq = np.ascontiguousarray(xq, np.float32)
+        nq = xq.shape[0]
+        D = np.empty((nq, k), np.float32)
+        I = np.empty((nq, k), np.int64)
+        bs = None if bitset is None else np.ascontiguousarray(bitset, np.uint8)
+        check(self.L.knhip_search(self.h, _np_ptr(xq), nq, k, nprobe, _np_ptr(bs), nbits, _np_ptr(I), _np_ptr(D)))
+        return D, I
+
+    def search_device(self, xq_t, k, nprobe=1, bitset_t=None, nbits=0, out=None, stream=None):
+        import torch
+        nq = xq_t.shape[0]
+        if out is None:
+            D = torch.empty((nq, k), dtype=torch.float32, device=xq_t.device)
+            I = torch.empty((nq, k), dtype=torch.int64, device=xq_t.device)
+        else:
+            D, I = out
+        s = torch.cuda.current_stream(xq_t.device).cuda_stream if stream is None else stream
+        check(self.L.knhip_search_device(self.h, _t_ptr(xq_t), nq, k, nprobe, _t_ptr(bitset_t), nbits,
+                                         _t_ptr(I), _t_ptr(D), C.c_void_p(s)))
+        return D, I
+
+    def coarse_search_device(self, xq_t, nprobe, stream=None):
+        import torch
+        nq = xq_t.shape[0]
+        D = torch.empty((nq, nprobe), dtype=torch.float32, device=xq_t.device)
+        I = torch.empty((nq, nprobe), dtype=torch.int64, device=xq_t.device)
+        s = torch.cuda.current_stream(xq_t.device).cuda_stream if stream is None else stream
+        check(self.L.knhip_coarse_search_device(self.h, _t_ptr(xq_t), nq, nprobe, _t_ptr(I), _t_ptr(D), C.c_void_p(s)))
+        return D, I
+
+    # ---- profiling ----
+    def profile_enable(self, on=True):
+        check(self.L.knhip_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        check(self.L.knhip_profile_reset(self.h))
+
+    def profile_get(self):
+        st = _lib.StageTimes()
+        check(self.L.knhip_profile_get(self.h, C.byref(st)))
+        return {"ms": list(st.ms), "launches": list(st.launches), "scan_bytes": st.scan_bytes,
+                "coarse_flops": st.coarse_flops, "scan_items": st.scan_items}
+
+
+def merge_topk_host(metric, D_parts, I_parts):
+    """[nshard, nq, k] partial results -> [nq, k] (host path of the shard merge)."""
+    L = _lib.load()
+    Dp = np.ascontiguousarray(D_parts, np.float32)
+    Ip = np.ascontiguousarray(I_parts, np.int64)
+    nshard, nq, k = Dp.shape
+    D = np.empty((nq, k), np.float32)
+    I = np.empty((nq, k), np.int64)
+    check(L.knhip_merge_topk_host(metric, nq, k, nshard, _np_ptr(Dp), _np_ptr(Ip), _np_ptr(D), _np_ptr(I)))
+    return D, I
+
+
+def merge_topk_device(metric, D_parts_t, I_parts_t, stream=None):
+    import torch
+    L = _lib.load()
+    nshard, nq, k = D_parts_t.shape
+    D = torch.empty((nq, k), dtype=torch.float32, device=D_parts_t.device)
+    I = torch.empty((nq, k), dtype=torch.int64, device=D_parts_t.device)
+    s = torch.cuda.current_stream(D_parts_t.device).cuda_stream if stream is None else stream
+    check(L.knhip_merge_topk_device(metric, nq, k, nshard, _t_ptr(D_parts_t), _t_ptr(I_parts_t), _t_ptr(D),
+                                    _t_ptr(I), C.c_void_p(s)))
+    return D, I

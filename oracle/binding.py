@@ -286,6 +286,13 @@ class Ref:
     def __init__(self):
         # libmkl_rt picks its threading layer at load time
         os.environ.setdefault("MKL_THREADING_LAYER", "GNU")
+        # the .so was linked against MKL by full path (oracle/Makefile); preload it the same way so
+        # no LD_LIBRARY_PATH is needed (adding /opt/conda/lib to the search path would also drag in
+        # conda's older libstdc++)
+        for mkl in ("/opt/conda/lib/libmkl_rt.so.1", "/opt/conda/lib/libmkl_rt.so"):
+            if os.path.exists(mkl):
+                C.CDLL(mkl, mode=C.RTLD_GLOBAL)
+                break
         self.lib = L = C.CDLL(Ref.path(), mode=C.RTLD_GLOBAL)
         L.ref_create.restype = C.c_void_p
         L.ref_last_error.restype = C.c_char_p

@@ -1,0 +1,61 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def port():
+    from oracle import binding as ob
+    return ob.Port()
+
+
+@pytest.fixture(scope="session")
+def ref():
+    from oracle import binding as ob
+    if not ob.Ref.available():
+        pytest.skip("oracle/_ref/libknowhere_ref.so not built (needs /root/reference)")
+    return ob.Ref()
+
+
+def gen_data(n, d, seed, lo=0.0, hi=100.0):
+    """reference fixture: tests/ut/utils.h:41-50 GenDataSet = uniform_real(0, 100), seeded"""
+    r = np.random.default_rng(seed)
+    return (r.random((n, d), dtype=np.float32) * (hi - lo) + lo).astype(np.float32)
+
+
+def assert_parity(Do, Io, Dg, Ig, metric, what=""):
+    """Parity bar (BASELINE.json north_star): distances bit-equal (tolerance 0 -- far inside the
+    1e-4 relative bound), ids equal in canonical order.  The only licensed difference: entries whose
+    distance equals the query's k-th distance bit-for-bit (exact ties at the boundary: the
+    reference keeps first-scanned, the GPU keeps canonical-first; include/knhip.h)."""
+    Do, Dg = np.asarray(Do, np.float32), np.asarray(Dg, np.float32)
+    Io, Ig = np.asarray(Io, np.int64), np.asarray(Ig, np.int64)
+    assert Do.shape == Dg.shape and Io.shape == Ig.shape, what
+    db = Do.view(np.uint32) != Dg.view(np.uint32)
+    assert not db.any(), (f"{what}: {db.sum()} distances differ bitwise; first at {np.argwhere(db)[0]}: "
+                          f"oracle {Do[db][0]!r} gpu {Dg[db][0]!r}")
+    bad = Io != Ig
+    if bad.any():
+        kth = Do[:, -1:]
+        licensed = bad & (Do == kth)
+        # within a run of equal distances the same id multiset must appear unless it touches the k-th
+        assert (bad == licensed).all(), (f"{what}: {int((bad & ~licensed).sum())} id mismatches that are not "
+                                         f"k-th-boundary ties; first at {np.argwhere(bad & ~licensed)[0]}")
+
+
+def recall(I_true, I, k=None):
+    k = k or I.shape[1]
+    hit = 0
+    for a, b in zip(I_true[:, :k], I[:, :k]):
+        hit += len(set(a.tolist()) & set(b.tolist()))
+    return hit / (I.shape[0] * k)

@@ -1,0 +1,45 @@
+"""tests/helpers.py -- fixture loading shared by CPU and GPU tests."""
+import glob
+import os
+
+import numpy as np
+
+from oracle import binding as ob
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_files():
+    return sorted(glob.glob(os.path.join(GOLDEN, "*.npz")))
+
+
+def load_golden(path):
+    z = np.load(path)
+    kind, metric, d = int(z["kind"]), int(z["metric"]), int(z["d"])
+    ix = ob.IndexData(kind, metric, d, int(z["nlist"]), int(z["M"]), int(z["nbits"]))
+    ix.use_precomputed_table = int(z["use_precomputed_table"])
+    if kind == ob.FLAT:
+        ix.base = z["base"]
+    else:
+        ix.centroids = z["centroids"]
+        sizes = z["list_sizes"]
+        off = np.concatenate([[0], np.cumsum(sizes)])
+        codes, ids = z["codes"], z["ids"]
+        ix.list_codes = [np.ascontiguousarray(codes[off[l]:off[l + 1]]) for l in range(ix.nlist)]
+        ix.list_ids = [np.ascontiguousarray(ids[off[l]:off[l + 1]]) for l in range(ix.nlist)]
+        if kind == ob.IVF_PQ:
+            ix.pq_centroids = z["pq_centroids"]
+        if kind == ob.IVF_SQ8:
+            ix.sq_trained = z["sq_trained"]
+    cases = []
+    for ci, (k, nprobe, use_bs) in enumerate(z["cases"]):
+        cases.append(dict(k=int(k), nprobe=int(nprobe), bitset=z["bitset"] if use_bs else None,
+                          nbits=int(z["nb"]) if use_bs else 0, D=z[f"D{ci}"], I=z[f"I{ci}"]))
+    return ix, z["xq"], cases
+
+
+def finish_ivfpq(port, ix):
+    """the precomputed term-2 table is derived data: recompute it with the restated formula"""
+    if ix.kind == ob.IVF_PQ and ix.metric == ob.L2 and ix.use_precomputed_table == 1 and ix.precomputed_table is None:
+        ix.precomputed_table = port.pq_precompute_table(ix.d, ix.M, ix.nbits, ix.centroids, ix.pq_centroids)
+    return ix

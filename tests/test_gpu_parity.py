@@ -1,0 +1,265 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the oracle on the
+same seeded inputs and against the committed golden fixtures.  Bar: distances bit-equal, ids
+equal in canonical order (licensed: exact ties at the k-th boundary) -- see conftest.assert_parity.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import assert_parity, gen_data
+from helpers import finish_ivfpq, golden_files, load_golden
+from oracle import binding as ob
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    return torch
+
+
+def _gpu(ix, **kw):
+    from knowhere_amd import GpuIndex
+    return GpuIndex.from_data(ix, device=0, **kw)
+
+
+def _bitset(n, frac, seed):
+    filt = np.random.default_rng(seed).random(n) < frac
+    bs = np.zeros((n + 7) // 8, np.uint8)
+    for i in np.nonzero(filt)[0]:
+        bs[i >> 3] |= 1 << (i & 7)
+    return bs
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("path", golden_files(), ids=lambda p: os.path.basename(p)[:-4])
+def test_golden(torch_cuda, port, path):
+    ix, xq, cases = load_golden(path)
+    g = _gpu(ix)
+    for c in cases:
+        D, I = g.search(xq, c["k"], c["nprobe"], c["bitset"], c["nbits"])
+        assert_parity(c["D"], c["I"], D, I, ix.metric, f"{os.path.basename(path)} k={c['k']} nprobe={c['nprobe']}")
+    g.close()
+
+
+@pytest.mark.parametrize("metric", [ob.L2, ob.IP])
+@pytest.mark.parametrize("nb,d", [(5000, 32), (20000, 128), (777, 30), (64, 4), (65, 5)])
+def test_brute_force(torch_cuda, port, metric, nb, d):
+    xb, xq = gen_data(nb, d, 42), gen_data(37, d, 44)
+    ix = ob.make_index(port, ob.FLAT, metric, xb)
+    g = _gpu(ix)
+    for k in (1, 10, 64, 100, 300):
+        k = min(k, 1024)
+        Do, Io = port.search(ix, xq, k)
+        D, I = g.search(xq, k)
+        assert_parity(Do, Io, D, I, metric, f"BF nb={nb} d={d} k={k}")
+    bs = _bitset(nb, 0.4, 1)
+    Do, Io = port.search(ix, xq, 10, bitset=bs)
+    D, I = g.search(xq, 10, bitset=bs, nbits=nb)
+    assert_parity(Do, Io, D, I, metric, "BF bitset")
+    g.close()
+
+
+def test_brute_force_self_hit(torch_cuda):
+    # reference tests/ut/test_bruteforce.cc:70-76 and test_gpu_search.cc:83-86
+    xb = gen_data(10000, 128, 42)
+    from knowhere_amd import GpuIndex
+    g = GpuIndex(0, ob.L2, 128)
+    g.add_vectors(xb)
+    D, I = g.search(xb[:1000], 5)
+    assert (I[:, 0] == np.arange(1000)).all()
+    assert (D[:, 0] == 0).all()
+    g.close()
+
+
+@pytest.mark.parametrize("metric", [ob.L2, ob.IP])
+def test_coarse(torch_cuda, port, metric):
+    torch = torch_cuda
+    xb, xq = gen_data(6000, 64, 42), gen_data(50, 64, 44)
+    ix = ob.make_index(port, ob.IVF_FLAT, metric, xb, nlist=300)
+    g = _gpu(ix)
+    for nprobe in (1, 7, 64, 128, 300):
+        Do, Io = port.coarse_search(ix, xq, nprobe)
+        D, I = g.coarse_search_device(torch.from_numpy(xq).cuda(), nprobe)
+        torch.cuda.synchronize()
+        assert_parity(Do, Io, D.cpu().numpy(), I.cpu().numpy(), metric, f"coarse nprobe={nprobe}")
+    g.close()
+
+
+KINDS = [(ob.IVF_FLAT, 0), (ob.IVF_PQ, 8), (ob.IVF_PQ, 16), (ob.IVF_PQ, 32), (ob.IVF_PQ, 64), (ob.IVF_SQ8, 0)]
+
+
+@pytest.mark.parametrize("kind,M", KINDS, ids=lambda v: str(v))
+@pytest.mark.parametrize("metric", [ob.L2, ob.IP])
+def test_ivf(torch_cuda, port, kind, M, metric):
+    nb, d, nlist = 12000, 64, 40
+    xb, xq = gen_data(nb, d, 42), gen_data(45, d, 44)
+    ix = ob.make_index(port, kind, metric, xb, nlist=nlist, M=max(M, 1))
+    g = _gpu(ix)
+    ks = (1, 10, 100) if kind == ob.IVF_SQ8 else (1, 10, 100, 200)
+    for k in ks:
+        for nprobe in (1, 8, nlist):
+            Do, Io = port.search(ix, xq, k, nprobe)
+            D, I = g.search(xq, k, nprobe)
+            assert_parity(Do, Io, D, I, metric, f"kind={kind} M={M} k={k} nprobe={nprobe}")
+    bs = _bitset(nb, 0.4, 1)
+    Do, Io = port.search(ix, xq, 10, 8, bs, nb)
+    D, I = g.search(xq, 10, 8, bs, nb)
+    assert_parity(Do, Io, D, I, metric, "bitset 40%")
+    bs = _bitset(nb, 0.98, 2)
+    Do, Io = port.search(ix, xq, 10, nlist, bs, nb)
+    D, I = g.search(xq, 10, nlist, bs, nb)
+    assert_parity(Do, Io, D, I, metric, "bitset 98%")
+    g.close()
+
+
+def test_ivfpq_residual_tables(torch_cuda, port):
+    # precomputed table over the limit -> reference falls back to per-list residual tables
+    # (thirdparty/faiss/faiss/IndexIVFPQ.cpp:441-456)
+    nb, d = 8000, 64
+    xb, xq = gen_data(nb, d, 42), gen_data(20, d, 44)
+    ix = ob.make_index(port, ob.IVF_PQ, ob.L2, xb, nlist=32, M=16)
+    ix.use_precomputed_table = 0
+    ix.precomputed_table = None
+    g = _gpu(ix, precomputed_table_max_bytes=1024)
+    assert g.uses_precomputed_table == 0
+    for k, nprobe in ((10, 8), (1, 32)):
+        Do, Io = port.search(ix, xq, k, nprobe)
+        D, I = g.search(xq, k, nprobe)
+        assert_parity(Do, Io, D, I, ob.L2, "residual tables")
+    g.close()
+
+
+def test_ivfpq_long_lists_headline_shape(torch_cuda, port):
+    # d=128, m=32: the headline configuration's shape at a size the oracle finishes in seconds;
+    # lists of ~3000 codes exercise many pipeline blocks per pipe
+    nb, d = 200000, 128
+    xb, xq = gen_data(nb, d, 42), gen_data(200, d, 44)
+    ix = ob.make_index(port, ob.IVF_PQ, ob.L2, xb, nlist=64, M=32)
+    g = _gpu(ix)
+    Do, Io = port.search(ix, xq, 10, 16)
+    D, I = g.search(xq, 10, 16)
+    assert_parity(Do, Io, D, I, ob.L2, "headline shape")
+    g.close()
+
+
+def test_edge_cases(torch_cuda, port):
+    d = 32
+    xb = gen_data(300, d, 42)
+    xb[100:140] = xb[5]  # exact duplicates: distance ties
+    xq = gen_data(9, d, 44)
+    xq[0] = xb[5]
+    for kind in (ob.IVF_FLAT, ob.IVF_PQ, ob.IVF_SQ8):
+        # nlist close to n -> many empty and tiny lists; custom non-monotone ids
+        ids = np.random.default_rng(5).permutation(300).astype(np.int64) * 3 + 1
+        ix = ob.make_index(port, kind, ob.L2, xb, nlist=64, M=8, ids=ids)
+        g = _gpu(ix)
+        for k, nprobe in ((10, 64), (128 if kind != ob.IVF_SQ8 else 100, 64), (3, 1)):
+            Do, Io = port.search(ix, xq, k, nprobe)
+            D, I = g.search(xq, k, nprobe)
+            assert_parity(Do, Io, D, I, ob.L2, f"edge kind={kind} k={k} nprobe={nprobe}")
+        # k larger than everything reachable: sentinel tail id -1 / FLT_MAX
+        D, I = g.search(xq, 400, 2)
+        Do, Io = port.search(ix, xq, 400, 2)
+        assert_parity(Do, Io, D, I, ob.L2, "k > candidates")
+        assert (I[:, -1] == -1).all() and (D[:, -1] == np.finfo(np.float32).max).all()
+        # single query, and nq == 0
+        D, I = g.search(xq[:1], 5, 4)
+        Do, Io = port.search(ix, xq[:1], 5, 4)
+        assert_parity(Do, Io, D, I, ob.L2, "nq=1")
+        D, I = g.search(xq[:0], 5, 4)
+        assert D.shape == (0, 5)
+        g.close()
+
+
+def test_error_convention(torch_cuda):
+    from knowhere_amd import GpuIndex, KnhipError
+    g = GpuIndex(2, ob.L2, 64, nlist=8, pq_m=8)
+    with pytest.raises(KnhipError) as e:
+        g.search(np.zeros((1, 64), np.float32), 5, 2)
+    assert e.value.code == -2  # index_not_trained
+    with pytest.raises(KnhipError):
+        GpuIndex(2, ob.L2, 64, nlist=8, pq_m=7)  # m must divide dim
+    with pytest.raises(KnhipError):
+        GpuIndex(2, 5, 64, nlist=8, pq_m=8)  # bad metric
+    g.close()
+
+
+def test_device_boundary_and_determinism(torch_cuda, port):
+    torch = torch_cuda
+    xb, xq = gen_data(30000, 64, 42), gen_data(128, 64, 44)
+    ix = ob.make_index(port, ob.IVF_PQ, ob.L2, xb, nlist=64, M=32)
+    g = _gpu(ix)
+    q = torch.from_numpy(xq).cuda()
+    D0, I0 = g.search_device(q, 10, 16)
+    torch.cuda.synchronize()
+    for _ in range(3):  # work-item grouping uses atomics; results must not depend on it
+        D1, I1 = g.search_device(q, 10, 16)
+        torch.cuda.synchronize()
+        assert torch.equal(D0, D1) and torch.equal(I0, I1)
+    Do, Io = port.search(ix, xq, 10, 16)
+    assert_parity(Do, Io, D0.cpu().numpy(), I0.cpu().numpy(), ob.L2, "device boundary")
+    # shard merge on device == oracle merge
+    from knowhere_amd.index import merge_topk_device
+    halves = []
+    for part in range(2):
+        sub = ob.IndexData(ix.kind, ix.metric, ix.d, ix.nlist, ix.M, ix.nbits)
+        sub.centroids, sub.pq_centroids = ix.centroids, ix.pq_centroids
+        sub.precomputed_table, sub.use_precomputed_table = ix.precomputed_table, 1
+        sub.list_codes = [c if l % 2 == part else c[:0] for l, c in enumerate(ix.list_codes)]
+        sub.list_ids = [i if l % 2 == part else i[:0] for l, i in enumerate(ix.list_ids)]
+        gs = _gpu(sub)
+        halves.append(gs.search_device(q, 10, 16))
+        torch.cuda.synchronize()
+        gs.close()
+    Dp = torch.stack([h[0] for h in halves])
+    Ip = torch.stack([h[1] for h in halves])
+    Dm, Im = merge_topk_device(ob.L2, Dp, Ip)
+    torch.cuda.synchronize()
+    assert_parity(Do, Io, Dm.cpu().numpy(), Im.cpu().numpy(), ob.L2, "list-sharded search + merge == monolithic")
+    g.close()
+
+
+def test_primitives(torch_cuda, port):
+    torch = torch_cuda
+    import ctypes as C
+    from knowhere_amd import _lib
+    L = _lib.load()
+    r = np.random.default_rng(9)
+    for d in (1, 3, 4, 17, 64, 100, 128, 256, 768):
+        ny = 333
+        x = (r.random(d, dtype=np.float32) * 100).astype(np.float32)
+        y = (r.random((ny, d), dtype=np.float32) * 100).astype(np.float32)
+        xt, yt = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+        out = torch.empty(ny, dtype=torch.float32, device="cuda")
+        p = lambda t: C.c_void_p(t.data_ptr())
+        _lib.check(L.knhip_fvec_L2sqr_ny(p(out), p(xt), p(yt), d, ny, None))
+        torch.cuda.synchronize()
+        assert out.cpu().numpy().tobytes() == port.fvec_L2sqr_ny(x, y).tobytes(), f"L2sqr_ny d={d}"
+        _lib.check(L.knhip_fvec_inner_products_ny(p(out), p(xt), p(yt), d, ny, None))
+        torch.cuda.synchronize()
+        assert out.cpu().numpy().tobytes() == port.fvec_inner_products_ny(x, y).tobytes(), f"ip_ny d={d}"
+        _lib.check(L.knhip_fvec_norms_L2sqr(p(out), p(yt), d, ny, None))
+        torch.cuda.synchronize()
+        nr = np.array([port.fvec_norm_L2sqr(np.ascontiguousarray(v)) for v in y], np.float32)
+        assert out.cpu().numpy().tobytes() == nr.tobytes(), f"norms d={d}"
+        xi = r.integers(-128, 128, d, dtype=np.int8)
+        yi = r.integers(-128, 128, (ny, d), dtype=np.int8)
+        xit, yit = torch.from_numpy(xi).cuda(), torch.from_numpy(yi).cuda()
+        _lib.check(L.knhip_int8_vec_L2sqr_ny(p(out), p(xit), p(yit), d, ny, None))
+        torch.cuda.synchronize()
+        assert out.cpu().numpy().tobytes() == port.int8_ny(xi, yi, ob.L2).tobytes()
+        _lib.check(L.knhip_int8_vec_inner_products_ny(p(out), p(xit), p(yit), d, ny, None))
+        torch.cuda.synchronize()
+        assert out.cpu().numpy().tobytes() == port.int8_ny(xi, yi, ob.IP).tobytes()
+    a = (r.random(5000, dtype=np.float32) * 10).astype(np.float32)
+    b = (r.random(5000, dtype=np.float32) * 10).astype(np.float32)
+    at, bt = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    ct = torch.empty_like(at)
+    _lib.check(L.knhip_fvec_madd(5000, C.c_void_p(at.data_ptr()), -2.0, C.c_void_p(bt.data_ptr()),
+                                 C.c_void_p(ct.data_ptr()), None))
+    torch.cuda.synchronize()
+    assert ct.cpu().numpy().tobytes() == port.fvec_madd(a, -2.0, b).tobytes()
