@@ -61,11 +61,26 @@ __device__ __forceinline__ int64_t shfl_i64(int64_t v, int src) {
     return ((int64_t)hi << 32) | (uint32_t)lo;
 }
 
+// ---- cross-lane helpers that stay in the VALU (no LDS round trip) -------------------------------
+__device__ __forceinline__ float readlane_f(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ int64_t readlane_i64(int64_t v, int l) {
+    const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffll), l);
+    const int hi = __builtin_amdgcn_readlane((int)(v >> 32), l);
+    return ((int64_t)hi << 32) | (uint32_t)lo;
+}
+// value of lane-1 (lane 0 keeps its own value): DPP wave_shr:1
+__device__ __forceinline__ int wave_shr1(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false);
+}
+
 // ---- WaveTopK: a wave-resident sorted list of the K best (dist, idx) ---------------------------
 // Element e (0 = best) lives in lane e % 64, register e / 64.  R = registers per lane, capacity
 // 64*R >= k.  All methods must be called by the full wave with wave-uniform arguments unless
 // noted.  `idx` is whatever the caller orders ties by (list offset, row number or id) -- it is
-// compared as a signed 64-bit integer in the canonical direction.
+// compared as a signed 64-bit integer in the canonical direction.  Insertion is one compare +
+// ballot per register to find the position, then a DPP shift of the tail: no LDS traffic.
 template <bool IS_L2, int R>
 struct WaveTopK {
     float d[R];
@@ -81,14 +96,14 @@ struct WaveTopK {
         }
     }
 
-    // distance of the current k-th element (wave-uniform)
+    // distance / idx of the current k-th element (wave-uniform)
     __device__ __forceinline__ float kth_dist() const {
         const int e = k - 1;
         float v = 0.f;
 #pragma unroll
         for (int r = 0; r < R; r++) {
             if (r == e / KN_WAVE) {
-                v = __shfl(d[r], e % KN_WAVE, KN_WAVE);
+                v = readlane_f(d[r], e % KN_WAVE);
             }
         }
         return v;
@@ -99,7 +114,7 @@ struct WaveTopK {
 #pragma unroll
         for (int r = 0; r < R; r++) {
             if (r == e / KN_WAVE) {
-                v = shfl_i64(i[r], e % KN_WAVE);
+                v = readlane_i64(i[r], e % KN_WAVE);
             }
         }
         return v;
@@ -125,24 +140,21 @@ struct WaveTopK {
             const bool b = (i[r] >= 0) && better<IS_L2>(d[r], i[r], dist, idx);
             pos += __popcll(__ballot(b));
         }
-        // shift elements [pos, k-2] one place towards the tail, highest register first
-        float carry_d_prev = 0.f;
-        int64_t carry_i_prev = 0;
+        // shift elements [pos, k-2] one place towards the tail
+        float carry_d = 0.f;
+        int64_t carry_i = 0;
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            // value coming into lane 0 of register r is lane 63 of register r-1 (pre-shift)
-            const float last_d = __shfl(d[r], KN_WAVE - 1, KN_WAVE);
-            const int64_t last_i = shfl_i64(i[r], KN_WAVE - 1);
-            float up_d = __shfl_up(d[r], 1, KN_WAVE);
-            int64_t up_i;
-            {
-                int lo = __shfl_up((int)(i[r] & 0xffffffffll), 1, KN_WAVE);
-                int hi = __shfl_up((int)(i[r] >> 32), 1, KN_WAVE);
-                up_i = ((int64_t)hi << 32) | (uint32_t)lo;
-            }
-            if (lane == 0) {
-                up_d = carry_d_prev;
-                up_i = carry_i_prev;
+            // pre-shift value of this register's last lane feeds lane 0 of the next register
+            const float last_d = (R > 1) ? readlane_f(d[r], KN_WAVE - 1) : 0.f;
+            const int64_t last_i = (R > 1) ? readlane_i64(i[r], KN_WAVE - 1) : 0;
+            float up_d = __builtin_bit_cast(float, wave_shr1(__builtin_bit_cast(int, d[r])));
+            const int lo = wave_shr1((int)(i[r] & 0xffffffffll));
+            const int hi = wave_shr1((int)(i[r] >> 32));
+            int64_t up_i = ((int64_t)hi << 32) | (uint32_t)lo;
+            if (R > 1 && lane == 0) {
+                up_d = carry_d;
+                up_i = carry_i;
             }
             const int e = r * KN_WAVE + lane;
             if (e > pos) {
@@ -152,8 +164,8 @@ struct WaveTopK {
                 d[r] = dist;
                 i[r] = idx;
             }
-            carry_d_prev = last_d;
-            carry_i_prev = last_i;
+            carry_d = last_d;
+            carry_i = last_i;
         }
         // elements beyond k-1 are garbage by construction; re-neutralise them so kth/merge
         // never see them
@@ -181,6 +193,41 @@ struct WaveTopK {
         }
     }
 };
+
+// ---- per-query global threshold, shared by every wave that scans for the query -------------------
+// Any wave whose local list is full holds k real candidates, so its k-th distance bounds the final
+// k-th distance from the losing side; publishing the best such bound lets every other wave drop
+// candidates that cannot make the final top-k.  Candidates EQUAL to the bound are kept (they may
+// win the canonical id tie-break).  Stale reads only make the bound looser: never incorrect.
+template <bool IS_L2>
+__device__ __forceinline__ float gthr_load(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool IS_L2>
+__device__ __forceinline__ void gthr_publish(float* p, float v) {
+    // called by one lane; CAS loop on the bit pattern (rare: only when a local list tightens)
+    unsigned int* up = reinterpret_cast<unsigned int*>(p);
+    unsigned int old = __hip_atomic_load(up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (true) {
+        const float cur = __uint_as_float(old);
+        if (IS_L2 ? !(v < cur) : !(v > cur)) {
+            return;
+        }
+        const unsigned int want = __float_as_uint(v);
+        if (__hip_atomic_compare_exchange_strong(up, &old, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT)) {
+            return;
+        }
+    }
+}
+template <bool IS_L2>
+__device__ __forceinline__ bool within_gthr(float dist, float g) {
+    return IS_L2 ? (dist <= g) : (dist >= g);
+}
+template <bool IS_L2>
+__device__ __forceinline__ float tighter(float a, float b) {
+    return IS_L2 ? fminf(a, b) : fmaxf(a, b);
+}
 
 // runtime k -> compile-time R dispatch (k <= 1024)
 #define KN_MAX_K 1024

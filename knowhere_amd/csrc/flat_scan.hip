@@ -89,18 +89,23 @@ __global__ __launch_bounds__(FS_THREADS) void flat_scan_kernel(FlatScanArgs a) {
     __syncthreads();
 
     WaveTopK<IS_L2, R> top[QG];
-    float kd[QG];
+    float kd[QG], gt[QG];
     int64_t ki[QG];
 #pragma unroll
     for (int j = 0; j < QG; j++) {
         top[j].init(a.k);
         kd[j] = worst_dist<IS_L2>();
         ki[j] = -1;
+        gt[j] = worst_dist<IS_L2>();
     }
 
     const int64_t nblk = (len + 63) / 64;
     for (int64_t b = wave; b < nblk; b += FS_WAVES) {
         const int64_t row = b * 64 + lane; // row inside the list / chunk
+#pragma unroll
+        for (int j = 0; j < QG; j++) {
+            gt[j] = gthr_load<IS_L2>(a.gthr + q_of[j]);
+        }
         bool valid = row < len;
         int64_t id_for_filter = -1;
         if (a.bitset != nullptr && valid) {
@@ -137,18 +142,24 @@ __global__ __launch_bounds__(FS_THREADS) void flat_scan_kernel(FlatScanArgs a) {
 #pragma unroll
         for (int j = 0; j < QG; j++) {
             if (j < npair) {
-                bool pass = valid && top[j].admits(acc[j], row, kd[j], ki[j]);
+                bool pass = valid && within_gthr<IS_L2>(acc[j], gt[j]) &&
+                            top[j].admits(acc[j], row, kd[j], ki[j]);
                 unsigned long long m = __ballot(pass);
+                bool tightened = false;
                 while (m) {
                     const int l = __ffsll((long long)m) - 1;
                     m &= m - 1;
-                    const float cd = __shfl(acc[j], l, KN_WAVE);
+                    const float cd = readlane_f(acc[j], l);
                     const int64_t ci = b * 64 + l;
                     if (top[j].admits(cd, ci, kd[j], ki[j])) {
                         top[j].insert(cd, ci);
                         kd[j] = top[j].kth_dist();
                         ki[j] = top[j].kth_idx();
+                        tightened = true;
                     }
+                }
+                if (tightened && ki[j] >= 0 && lane == 0) {
+                    gthr_publish<IS_L2>(a.gthr + q_of[j], kd[j]);
                 }
             }
         }

@@ -47,6 +47,7 @@ struct FlatScanArgs {
     // output
     float* partial_d;            // [nq][nslot][k]
     int64_t* partial_i;
+    float* gthr;                 // [nq] shared per-query threshold (see common.cuh gthr_*)
     int32_t nslot;
     int32_t k;
 };
@@ -76,6 +77,7 @@ struct PqScanArgs {
     int64_t bitset_nbits;
     float* partial_d;              // [nq][nslot][k]
     int64_t* partial_i;
+    float* gthr;                   // [nq] shared per-query threshold
     int32_t nslot;                 // = nprobe
     int32_t k;
 };
@@ -100,6 +102,7 @@ struct SqScanArgs {
     int64_t bitset_nbits;
     float* partial_d;            // [nq][nslot][k]
     int64_t* partial_i;
+    float* gthr;                 // [nq] shared per-query threshold (see common.cuh gthr_*)
     int32_t nslot;
     int32_t k;
 };
@@ -136,19 +139,20 @@ hipError_t launch_sq_interleave(const uint8_t* codes, const int64_t* list_row_of
 
 // ---- worktable.hip: (query, probe) pairs -> per-list work items ----
 struct WorkTable {
-    // device buffers sized by the caller
-    int32_t* list_count;   // [nlist]
-    int64_t* list_pair_off;// [nlist+1]
-    int64_t* list_item_off;// [nlist+1]
-    int32_t* list_cursor;  // [nlist]
+    // device buffers sized by the caller; "virtual lists" = 2 * nlist (rank-0 probes first)
+    int32_t* list_count;   // [2*nlist]
+    int64_t* list_pair_off;// [2*nlist+1]
+    int64_t* list_item_off;// [2*nlist+1]
+    int32_t* list_cursor;  // [2*nlist]
     KnPair* pairs;         // [nq*nprobe]
-    KnItem* items;         // [nq*nprobe/qg + nlist]
+    KnItem* items;         // [nq*nprobe/qg + 2*nlist]
     int64_t* nitems;       // [1]
     double* scan_bytes;    // [1] sum over pairs of len(list)*code_size
 };
 hipError_t launch_build_worktable(const int64_t* keys, int64_t nq, int nprobe, int64_t nlist, int qg,
                                   const int64_t* list_len, int64_t code_size, const WorkTable& wt,
                                   hipStream_t s);
+hipError_t launch_fill_f32(float* p, int64_t n, float v, hipStream_t s);
 
 // ---- topk.hip: selection kernels ----
 // per query: k best of nslot sorted partial lists -> out (canonical order, sentinel padded);

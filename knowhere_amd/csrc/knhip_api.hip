@@ -107,6 +107,7 @@ struct Workspace {
     DevBuf t2t;          // [qb][256][M]
     DevBuf partial_d;    // [qb][nslot][k]
     DevBuf partial_i;
+    DevBuf gthr;         // [qb] shared per-query thresholds
     DevBuf list_count, list_pair_off, list_item_off, list_cursor, pairs, items, nitems;
     // host-boundary staging
     DevBuf h_queries, h_bitset, h_out_d, h_out_i;
@@ -334,6 +335,8 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
     const int kind = idx->desc.kind;
     const int d = idx->d;
     const bool is_l2 = idx->is_l2;
+    HIP_TRY(ws->gthr.reserve((size_t)nq * sizeof(float)));
+    HIP_TRY(launch_fill_f32(ws->gthr.as<float>(), nq, is_l2 ? FLT_MAX : -FLT_MAX, s));
 
     if (kind == KNHIP_BRUTE_FORCE) {
         const int64_t nb = idx->ntotal;
@@ -358,6 +361,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         a.bitset_nbits = nbits;
         a.partial_d = ws->partial_d.as<float>();
         a.partial_i = ws->partial_i.as<int64_t>();
+        a.gthr = ws->gthr.as<float>();
         a.nslot = (int)nchunks;
         a.k = k;
         {
@@ -397,11 +401,11 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
                  : (kind == KNHIP_IVF_SQ8) ? 8
                                            : flat_scan_qg(k);
     const int64_t npairs = nq * nprobe;
-    const int64_t items_bound = round_up(npairs / qg + std::min<int64_t>(nlist, npairs) + 1, 8);
-    HIP_TRY(ws->list_count.reserve((size_t)nlist * sizeof(int32_t)));
-    HIP_TRY(ws->list_cursor.reserve((size_t)nlist * sizeof(int32_t)));
-    HIP_TRY(ws->list_pair_off.reserve((size_t)(nlist + 1) * sizeof(int64_t)));
-    HIP_TRY(ws->list_item_off.reserve((size_t)(nlist + 1) * sizeof(int64_t)));
+    const int64_t items_bound = round_up(npairs / qg + std::min<int64_t>(2 * nlist, npairs) + 1, 8);
+    HIP_TRY(ws->list_count.reserve((size_t)2 * nlist * sizeof(int32_t)));
+    HIP_TRY(ws->list_cursor.reserve((size_t)2 * nlist * sizeof(int32_t)));
+    HIP_TRY(ws->list_pair_off.reserve((size_t)(2 * nlist + 1) * sizeof(int64_t)));
+    HIP_TRY(ws->list_item_off.reserve((size_t)(2 * nlist + 1) * sizeof(int64_t)));
     HIP_TRY(ws->pairs.reserve((size_t)npairs * sizeof(KnPair)));
     HIP_TRY(ws->items.reserve((size_t)items_bound * sizeof(KnItem)));
     HIP_TRY(ws->nitems.reserve(sizeof(int64_t)));
@@ -441,6 +445,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         a.bitset_nbits = nbits;
         a.partial_d = ws->partial_d.as<float>();
         a.partial_i = ws->partial_i.as<int64_t>();
+        a.gthr = ws->gthr.as<float>();
         a.nslot = nprobe;
         a.k = k;
         StageTimer t(idx, s, KNHIP_STAGE_SCAN);
@@ -474,6 +479,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         a.bitset_nbits = nbits;
         a.partial_d = ws->partial_d.as<float>();
         a.partial_i = ws->partial_i.as<int64_t>();
+        a.gthr = ws->gthr.as<float>();
         a.nslot = nprobe;
         a.k = k;
         StageTimer t(idx, s, KNHIP_STAGE_SCAN);
@@ -498,6 +504,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         a.bitset_nbits = nbits;
         a.partial_d = ws->partial_d.as<float>();
         a.partial_i = ws->partial_i.as<int64_t>();
+        a.gthr = ws->gthr.as<float>();
         a.nslot = nprobe;
         a.k = k;
         StageTimer t(idx, s, KNHIP_STAGE_SCAN);

@@ -303,14 +303,15 @@ __global__ __launch_bounds__(PQ_THREADS) void pq_scan_kernel(PqScanArgs a) {
     }
 
     WaveTopK<IS_L2, R> top[QG];
-    float kd[QG], pre[QG];
+    float kd[QG], pre[QG], gt[QG];
     int64_t ki[QG];
 #pragma unroll
     for (int j = 0; j < QG; j++) {
         top[j].init(a.k);
         kd[j] = worst_dist<IS_L2>();
         ki[j] = -1;
-        pre[j] = prefilter_bound<IS_L2>(kd[j], dis0[j]);
+        gt[j] = gthr_load<IS_L2>(a.gthr + q_of[j]);
+        pre[j] = prefilter_bound<IS_L2>(tighter<IS_L2>(kd[j], gt[j]), dis0[j]);
     }
 
     float accA = 0.f, accB = 0.f;
@@ -375,6 +376,11 @@ __global__ __launch_bounds__(PQ_THREADS) void pq_scan_kernel(PqScanArgs a) {
         // ---- rare path: some finished sum may enter a top-k ----------------------------------
         if (live && (hit & outmask)) {
 #pragma unroll
+            for (int qi = 0; qi < QG; qi++) { // pick up thresholds published by other waves
+                gt[qi] = gthr_load<IS_L2>(a.gthr + q_of[qi]);
+                pre[qi] = prefilter_bound<IS_L2>(tighter<IS_L2>(kd[qi], gt[qi]), dis0[qi]);
+            }
+#pragma unroll
             for (int j = 0; j < 16; j++) {
 #pragma unroll
                 for (int qi = 0; qi < QG; qi++) {
@@ -392,9 +398,9 @@ __global__ __launch_bounds__(PQ_THREADS) void pq_scan_kernel(PqScanArgs a) {
                         if (t < RUNUP || v >= vend || qi >= npair) {
                             continue;
                         }
-                        const float acc = __shfl(o, l, KN_WAVE);
+                        const float acc = readlane_f(o, l);
                         const float dis = fadd_x(dis0[qi], acc);
-                        if (!top[qi].admits(dis, v, kd[qi], ki[qi])) {
+                        if (!within_gthr<IS_L2>(dis, gt[qi]) || !top[qi].admits(dis, v, kd[qi], ki[qi])) {
                             continue;
                         }
                         if (a.bitset != nullptr &&
@@ -404,7 +410,10 @@ __global__ __launch_bounds__(PQ_THREADS) void pq_scan_kernel(PqScanArgs a) {
                         top[qi].insert(dis, v);
                         kd[qi] = top[qi].kth_dist();
                         ki[qi] = top[qi].kth_idx();
-                        pre[qi] = prefilter_bound<IS_L2>(kd[qi], dis0[qi]);
+                        pre[qi] = prefilter_bound<IS_L2>(tighter<IS_L2>(kd[qi], gt[qi]), dis0[qi]);
+                        if (ki[qi] >= 0 && lane == 0) {
+                            gthr_publish<IS_L2>(a.gthr + q_of[qi], kd[qi]);
+                        }
                     }
                 }
             }

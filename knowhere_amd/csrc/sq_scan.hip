@@ -86,18 +86,23 @@ __global__ __launch_bounds__(SQ_THREADS) void sq_scan_kernel(SqScanArgs a) {
     __syncthreads();
 
     WaveTopK<IS_L2, R> top[QG];
-    float kd[QG];
+    float kd[QG], gt[QG];
     int64_t ki[QG];
 #pragma unroll
     for (int j = 0; j < QG; j++) {
         top[j].init(a.k);
         kd[j] = worst_dist<IS_L2>();
         ki[j] = -1;
+        gt[j] = worst_dist<IS_L2>();
     }
 
     const int64_t nblk = (len + 63) / 64;
     for (int64_t b = wave; b < nblk; b += SQ_WAVES) {
         const int64_t row = b * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < QG; j++) {
+            gt[j] = gthr_load<IS_L2>(a.gthr + q_of[j]);
+        }
         bool valid = row < len;
         if (a.bitset != nullptr && valid) {
             valid = !bitset_filtered(a.bitset, a.bitset_nbits, a.ids[row_off + row]);
@@ -132,18 +137,24 @@ __global__ __launch_bounds__(SQ_THREADS) void sq_scan_kernel(SqScanArgs a) {
         for (int j = 0; j < QG; j++) {
             if (j < npair) {
                 const float dis = IS_L2 ? acc[j] : fadd_x(accu0[j], acc[j]);
-                const bool pass = valid && top[j].admits(dis, row, kd[j], ki[j]);
+                const bool pass = valid && within_gthr<IS_L2>(dis, gt[j]) &&
+                                  top[j].admits(dis, row, kd[j], ki[j]);
                 unsigned long long m = __ballot(pass);
+                bool tightened = false;
                 while (m) {
                     const int l = __ffsll((long long)m) - 1;
                     m &= m - 1;
-                    const float cd = __shfl(dis, l, KN_WAVE);
+                    const float cd = readlane_f(dis, l);
                     const int64_t ci = b * 64 + l;
                     if (top[j].admits(cd, ci, kd[j], ki[j])) {
                         top[j].insert(cd, ci);
                         kd[j] = top[j].kth_dist();
                         ki[j] = top[j].kth_idx();
+                        tightened = true;
                     }
+                }
+                if (tightened && ki[j] >= 0 && lane == 0) {
+                    gthr_publish<IS_L2>(a.gthr + q_of[j], kd[j]);
                 }
             }
         }

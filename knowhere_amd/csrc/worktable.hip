@@ -28,15 +28,24 @@ __global__ void wt_zero_kernel(int32_t* list_count, int32_t* list_cursor, int64_
     (void)scan_bytes;
 }
 
-__global__ void wt_count_kernel(const int64_t* __restrict__ keys, int64_t npairs, int64_t nlist,
-                                int32_t* list_count) {
+// Virtual list id: the rank-0 probe of every query (its closest list) goes to virtual lists
+// [0, nlist), all other probes to [nlist, 2*nlist).  Items are emitted in virtual-list order, so
+// the scans most likely to contain a query's true neighbours are dispatched first and publish a
+// tight per-query threshold (common.cuh gthr_*) before the bulk of the probes run.  Pure
+// scheduling: results do not depend on it.
+__device__ __forceinline__ int64_t wt_vlist(int64_t key, int64_t slot, int64_t nlist) {
+    return key + (slot != 0 ? nlist : 0);
+}
+
+__global__ void wt_count_kernel(const int64_t* __restrict__ keys, int64_t npairs, int nprobe,
+                                int64_t nlist, int32_t* list_count) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= npairs) {
         return;
     }
     const int64_t key = keys[t];
     if (key >= 0 && key < nlist) {
-        atomicAdd(&list_count[key], 1);
+        atomicAdd(&list_count[wt_vlist(key, t % nprobe, nlist)], 1);
     }
 }
 
@@ -44,8 +53,8 @@ __global__ void wt_count_kernel(const int64_t* __restrict__ keys, int64_t npairs
 constexpr int WT_SCAN_THREADS = 1024;
 __global__ __launch_bounds__(WT_SCAN_THREADS) void wt_scan_kernel(
         const int32_t* __restrict__ list_count, const int64_t* __restrict__ list_len, int64_t nlist,
-        int qg, int64_t code_size, int64_t* list_pair_off, int64_t* list_item_off, int64_t* nitems,
-        double* scan_bytes) {
+        int64_t nreal, int qg, int64_t code_size, int64_t* list_pair_off, int64_t* list_item_off,
+        int64_t* nitems, double* scan_bytes) {
     __shared__ int64_t s_pairs[WT_SCAN_THREADS];
     __shared__ int64_t s_items[WT_SCAN_THREADS];
     __shared__ double s_bytes[WT_SCAN_THREADS];
@@ -59,7 +68,7 @@ __global__ __launch_bounds__(WT_SCAN_THREADS) void wt_scan_kernel(
         const int64_t c = list_count[l];
         np += c;
         ni += (c + qg - 1) / qg;
-        nb += (double)c * (double)list_len[l] * (double)code_size;
+        nb += (double)c * (double)list_len[l % nreal] * (double)code_size;
     }
     s_pairs[tid] = np;
     s_items[tid] = ni;
@@ -108,7 +117,8 @@ __global__ void wt_scatter_kernel(const int64_t* __restrict__ keys, int64_t npai
     if (key < 0 || key >= nlist) {
         return;
     }
-    const int64_t pos = list_pair_off[key] + atomicAdd(&list_cursor[key], 1);
+    const int64_t vl = wt_vlist(key, t % nprobe, nlist);
+    const int64_t pos = list_pair_off[vl] + atomicAdd(&list_cursor[vl], 1);
     KnPair p;
     p.q = (int32_t)(t / nprobe);
     p.slot = (int32_t)(t % nprobe);
@@ -117,8 +127,8 @@ __global__ void wt_scatter_kernel(const int64_t* __restrict__ keys, int64_t npai
 
 __global__ void wt_items_kernel(const int32_t* __restrict__ list_count,
                                 const int64_t* __restrict__ list_pair_off,
-                                const int64_t* __restrict__ list_item_off, int64_t nlist, int qg,
-                                KnItem* items) {
+                                const int64_t* __restrict__ list_item_off, int64_t nlist,
+                                int64_t nreal, int qg, KnItem* items) {
     const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= nlist) {
         return;
@@ -128,7 +138,7 @@ __global__ void wt_items_kernel(const int32_t* __restrict__ list_count,
     int64_t it = list_item_off[l];
     for (int64_t i = 0; i < c; i += qg, it++) {
         KnItem x;
-        x.list = (int32_t)l;
+        x.list = (int32_t)(l % nreal);
         x.npair = (int32_t)min((int64_t)qg, c - i);
         x.pair0 = p0 + i;
         items[it] = x;
@@ -139,23 +149,39 @@ hipError_t launch_build_worktable(const int64_t* keys, int64_t nq, int nprobe, i
                                   const int64_t* list_len, int64_t code_size, const WorkTable& wt,
                                   hipStream_t s) {
     const int64_t npairs = nq * nprobe;
-    const unsigned gl = (unsigned)((nlist + 255) / 256);
+    const int64_t nvl = 2 * nlist; // virtual lists, see wt_vlist
+    const unsigned gl = (unsigned)((nvl + 255) / 256);
     const unsigned gp = (unsigned)((npairs + 255) / 256);
-    hipLaunchKernelGGL(wt_zero_kernel, dim3(gl), dim3(256), 0, s, wt.list_count, wt.list_cursor, nlist,
+    hipLaunchKernelGGL(wt_zero_kernel, dim3(gl), dim3(256), 0, s, wt.list_count, wt.list_cursor, nvl,
                        wt.scan_bytes, wt.nitems);
     if (npairs > 0) {
-        hipLaunchKernelGGL(wt_count_kernel, dim3(gp), dim3(256), 0, s, keys, npairs, nlist,
+        hipLaunchKernelGGL(wt_count_kernel, dim3(gp), dim3(256), 0, s, keys, npairs, nprobe, nlist,
                            wt.list_count);
     }
     hipLaunchKernelGGL(wt_scan_kernel, dim3(1), dim3(WT_SCAN_THREADS), 0, s, wt.list_count, list_len,
-                       nlist, qg, code_size, wt.list_pair_off, wt.list_item_off, wt.nitems,
+                       nvl, nlist, qg, code_size, wt.list_pair_off, wt.list_item_off, wt.nitems,
                        wt.scan_bytes);
     if (npairs > 0) {
         hipLaunchKernelGGL(wt_scatter_kernel, dim3(gp), dim3(256), 0, s, keys, npairs, nprobe, nlist,
                            wt.list_pair_off, wt.list_cursor, wt.pairs);
     }
     hipLaunchKernelGGL(wt_items_kernel, dim3(gl), dim3(256), 0, s, wt.list_count, wt.list_pair_off,
-                       wt.list_item_off, nlist, qg, wt.items);
+                       wt.list_item_off, nvl, nlist, qg, wt.items);
+    return hipGetLastError();
+}
+
+__global__ void fill_f32_kernel(float* p, int64_t n, float v) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) {
+        p[t] = v;
+    }
+}
+
+hipError_t launch_fill_f32(float* p, int64_t n, float v, hipStream_t s) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(fill_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n, v);
     return hipGetLastError();
 }
 
