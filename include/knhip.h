@@ -144,6 +144,15 @@ int knhip_coarse_search_device(const knhip_index* idx, const float* d_queries, i
                                int32_t nprobe, int64_t* d_out_keys, float* d_out_dist,
                                void* stream);
 
+/* ---- refine: exact re-rank of candidate ids against raw fp32 vectors resident in HBM ----
+ * Replaces the second stage of faiss::IndexRefine::search
+ * (thirdparty/faiss/faiss/IndexRefine.cpp:104-140; Knowhere's `refine` / `refine_k`,
+ * src/index/ivf/ivf.cc:1073-1103).  d_base is row-major [nbase][dim], row r holds id id_base + r.
+ * cand ids [nq][k_base] as returned by knhip_search_device with k = k_base (a -1 ends a row). */
+int knhip_refine_device(int32_t metric, int32_t dim, const float* d_base, int64_t nbase,
+                        int64_t id_base, const float* d_queries, int64_t nq, const int64_t* d_cand_ids,
+                        int32_t k_base, int32_t k, float* d_out_dist, int64_t* d_out_ids, void* stream);
+
 /* ---- multi-GPU: merge of per-shard partial top-k ----
  * parts laid out [nshard][nq][k]; ids < 0 are empty slots. */
 int knhip_merge_topk_device(int32_t metric, int64_t nq, int32_t k, int32_t nshard,

@@ -40,7 +40,7 @@ SYMBOLS = [
     "knhip_index_set_lists_device", "knhip_index_add_vectors_device", "knhip_index_count",
     "knhip_index_device_bytes", "knhip_index_uses_precomputed_table", "knhip_search",
     "knhip_search_device", "knhip_coarse_search_device", "knhip_merge_topk_device",
-    "knhip_merge_topk_host", "knhip_fvec_L2sqr_ny", "knhip_fvec_inner_products_ny",
+    "knhip_merge_topk_host", "knhip_refine_device", "knhip_fvec_L2sqr_ny", "knhip_fvec_inner_products_ny",
     "knhip_fvec_norms_L2sqr", "knhip_fvec_madd", "knhip_int8_vec_L2sqr_ny",
     "knhip_int8_vec_inner_products_ny", "knhip_profile_enable", "knhip_profile_reset",
     "knhip_profile_get", "knhip_stage_kernel_name",
@@ -84,6 +84,7 @@ def load():
     L.knhip_coarse_search_device.argtypes = [vp, vp, i64, i32, vp, vp, vp]
     L.knhip_merge_topk_device.argtypes = [i32, i64, i32, i32, vp, vp, vp, vp, vp]
     L.knhip_merge_topk_host.argtypes = [i32, i64, i32, i32, vp, vp, vp, vp]
+    L.knhip_refine_device.argtypes = [i32, i32, vp, i64, i64, vp, i64, vp, i32, i32, vp, vp, vp]
     for f in ("knhip_fvec_L2sqr_ny", "knhip_fvec_inner_products_ny", "knhip_int8_vec_L2sqr_ny",
               "knhip_int8_vec_inner_products_ny"):
         getattr(L, f).argtypes = [vp, vp, vp, i64, i64, vp]

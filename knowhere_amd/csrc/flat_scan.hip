@@ -200,6 +200,11 @@ __global__ __launch_bounds__(FS_THREADS) void flat_scan_kernel(FlatScanArgs a) {
                     }
                 }
                 // row position -> id, write the (query, slot) partial
+                // the merged list bounds the query's final k-th with the whole list behind it: far
+                // tighter than any single wave's slice (matters most for large k)
+                if (ki[j] >= 0 && lane == 0) {
+                    gthr_publish<IS_L2>(a.gthr + q_of[j], kd[j]);
+                }
                 float* pd = a.partial_d + ((int64_t)q_of[j] * a.nslot + slot_of[j]) * k;
                 int64_t* pi = a.partial_i + ((int64_t)q_of[j] * a.nslot + slot_of[j]) * k;
 #pragma unroll

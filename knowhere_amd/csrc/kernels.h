@@ -175,6 +175,11 @@ hipError_t launch_coarse_rerank(const float* queries, const float* centroids, in
                                 float cnorm_max, int64_t* out_keys, float* out_d, int32_t* fail_flags,
                                 hipStream_t s);
 
+// ---- refine.hip ----
+hipError_t launch_refine(const float* base, int64_t nbase, int64_t id_base, int d, const float* queries,
+                         int64_t nq, const int64_t* cand, int kbase, int k, bool is_l2, float* out_d,
+                         int64_t* out_i, hipStream_t s);
+
 // ---- prims.hip ----
 hipError_t launch_fvec_ny(float* out, const float* x, const float* y, int64_t d, int64_t ny,
                           bool is_l2, hipStream_t s);

@@ -1013,6 +1013,18 @@ int knhip_merge_topk_host(int32_t metric, int64_t nq, int32_t k, int32_t nshard,
     return KNHIP_OK;
 }
 
+int knhip_refine_device(int32_t metric, int32_t dim, const float* d_base, int64_t nbase, int64_t id_base,
+                        const float* d_queries, int64_t nq, const int64_t* d_cand_ids, int32_t k_base,
+                        int32_t k, float* d_out_dist, int64_t* d_out_ids, void* stream) {
+    if (dim <= 0 || nbase < 0 || nq < 0 || k <= 0 || k > KN_MAX_K || k_base < k || !d_base || !d_queries ||
+        !d_cand_ids || !d_out_dist || !d_out_ids || (metric != KNHIP_L2 && metric != KNHIP_IP)) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "refine: bad arguments");
+    }
+    HIP_TRY(launch_refine(d_base, nbase, id_base, dim, d_queries, nq, d_cand_ids, k_base, k, metric == KNHIP_L2,
+                          d_out_dist, d_out_ids, static_cast<hipStream_t>(stream)));
+    return KNHIP_OK;
+}
+
 // ---- primitives ------------------------------------------------------------------------------------
 int knhip_fvec_L2sqr_ny(float* d_dis, const float* d_x, const float* d_y, int64_t d, int64_t ny, void* stream) {
     HIP_TRY(launch_fvec_ny(d_dis, d_x, d_y, d, ny, true, static_cast<hipStream_t>(stream)));

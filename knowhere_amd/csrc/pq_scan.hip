@@ -45,10 +45,10 @@
 #include "common.cuh"
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace knhip {
 
-constexpr int PQ_WAVES = 4;
-constexpr int PQ_THREADS = PQ_WAVES * KN_WAVE;
 constexpr int PQ_KSUB = 256;
 
 #ifndef KN_PQ_M
@@ -187,8 +187,13 @@ __device__ __forceinline__ float prefilter_bound(float kd, float dis0) {
     return IS_L2 ? (kd - dis0) + slack : (kd - dis0) - slack;
 }
 
-template <bool IS_L2, int M, int QG, int R>
-__global__ __launch_bounds__(PQ_THREADS) void pq_scan_kernel(PqScanArgs a) {
+// PQ_WAVES waves share one LUT.  The LUT (64 KB) caps a CU at two workgroups, so the waves per
+// SIMD -- what hides the latency of the dependent fmac chain -- are set by the workgroup size:
+// 4 waves -> 2 per SIMD, 8 -> 4, 16 -> 8.  More waves also means more pipes per list, i.e. more
+// run-up steps (M-1 per pipe): measured trade-off in DESIGN.md.
+template <bool IS_L2, int M, int QG, int R, int PQ_WAVES>
+__global__ __launch_bounds__(PQ_WAVES * 64) void pq_scan_kernel(PqScanArgs a) {
+    constexpr int PQ_THREADS = PQ_WAVES * KN_WAVE;
     static_assert(64 % M == 0, "M must divide the wave");
     static_assert(QG == 1 || QG == 2, "");
     static_assert(!(M == 64 && QG == 2), "M=64 tables take the whole LUT budget");
@@ -468,6 +473,11 @@ __global__ __launch_bounds__(PQ_THREADS) void pq_scan_kernel(PqScanArgs a) {
                     ki[qi] = top[qi].kth_idx();
                 }
             }
+            // the merged list bounds the query's final k-th with the whole list behind it: far
+            // tighter than any single wave's slice (matters most for large k)
+            if (ki[qi] >= 0 && lane == 0) {
+                gthr_publish<IS_L2>(a.gthr + q_of[qi], kd[qi]);
+            }
             float* pd = a.partial_d + ((int64_t)q_of[qi] * a.nslot + slot_of[qi]) * k;
             int64_t* pi = a.partial_i + ((int64_t)q_of[qi] * a.nslot + slot_of[qi]) * k;
 #pragma unroll
@@ -488,29 +498,46 @@ __global__ __launch_bounds__(PQ_THREADS) void pq_scan_kernel(PqScanArgs a) {
 // (-DKN_PQ_M=8|16|32|64, see the Makefile) so the four instantiation sets build in parallel;
 // the TU built without KN_PQ_M holds the small kernels and the dispatcher.
 // ---------------------------------------------------------------------------------------------
-template <bool IS_L2, int M, int QG>
-static hipError_t launch_pq_scan_m(const PqScanArgs& a, int64_t grid, hipStream_t s) {
+template <bool IS_L2, int M, int QG, int R, int PQ_WAVES>
+static hipError_t launch_pq_scan_rw(const PqScanArgs& a, int64_t grid, hipStream_t s) {
+    constexpr int PQ_THREADS = PQ_WAVES * KN_WAVE;
     const size_t lut_bytes = (size_t)PQ_KSUB * 256;
     const int k = a.k;
     const size_t merge_bytes = (((size_t)QG * PQ_WAVES * k * 4 + 7) & ~(size_t)7) + (size_t)QG * PQ_WAVES * k * 8;
     const size_t sm = std::max(lut_bytes, merge_bytes);
-#define PQ_LAUNCH(R_)                                                                              \
-    do {                                                                                           \
-        auto kern = pq_scan_kernel<IS_L2, M, QG, R_>;                                              \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                    \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);   \
-        if (e != hipSuccess) return e;                                                             \
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(PQ_THREADS), sm, s, a);                \
-    } while (0)
-    if (k <= 64) {
-        PQ_LAUNCH(1);
-    } else if (k <= 128) {
-        PQ_LAUNCH(2);
-    } else {
-        PQ_LAUNCH(16);
+    auto kern = pq_scan_kernel<IS_L2, M, QG, R, PQ_WAVES>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    if (e != hipSuccess) {
+        return e;
     }
-#undef PQ_LAUNCH
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(PQ_THREADS), sm, s, a);
     return hipGetLastError();
+}
+
+// Variant choice.  k <= 128 keeps the wave-resident top-k small (R = 1 or 2) and uses 8 waves per
+// workgroup (KNHIP_PQ_WAVES=4|8|16 overrides it for M = 32: tuning knob).  Larger k (<= 1024) uses
+// R = 16 with 4 waves so the cross-wave merge area (QG * waves * k * 12 B) still fits the LDS.
+template <bool IS_L2, int M, int QG>
+static hipError_t launch_pq_scan_m(const PqScanArgs& a, int64_t grid, hipStream_t s) {
+    static const int waves = [] {
+        const char* e = getenv("KNHIP_PQ_WAVES");
+        return e ? atoi(e) : 8;
+    }();
+    const int k = a.k;
+    if (k > 128) {
+        return launch_pq_scan_rw<IS_L2, M, QG, 16, 4>(a, grid, s);
+    }
+    if (M == 32 && waves == 4) {
+        return k <= 64 ? launch_pq_scan_rw<IS_L2, M, QG, 1, (M == 32 ? 4 : 8)>(a, grid, s)
+                       : launch_pq_scan_rw<IS_L2, M, QG, 2, (M == 32 ? 4 : 8)>(a, grid, s);
+    }
+    if (M == 32 && waves == 16) {
+        return k <= 64 ? launch_pq_scan_rw<IS_L2, M, QG, 1, (M == 32 ? 16 : 8)>(a, grid, s)
+                       : launch_pq_scan_rw<IS_L2, M, QG, 2, (M == 32 ? 16 : 8)>(a, grid, s);
+    }
+    return k <= 64 ? launch_pq_scan_rw<IS_L2, M, QG, 1, 8>(a, grid, s)
+                   : launch_pq_scan_rw<IS_L2, M, QG, 2, 8>(a, grid, s);
 }
 
 #ifdef KN_PQ_M

@@ -192,6 +192,11 @@ __global__ __launch_bounds__(SQ_THREADS) void sq_scan_kernel(SqScanArgs a) {
                         ki[j] = top[j].kth_idx();
                     }
                 }
+                // the merged list bounds the query's final k-th with the whole list behind it: far
+                // tighter than any single wave's slice (matters most for large k)
+                if (ki[j] >= 0 && lane == 0) {
+                    gthr_publish<IS_L2>(a.gthr + q_of[j], kd[j]);
+                }
                 float* pd = a.partial_d + ((int64_t)q_of[j] * a.nslot + slot_of[j]) * k;
                 int64_t* pi = a.partial_i + ((int64_t)q_of[j] * a.nslot + slot_of[j]) * k;
 #pragma unroll

@@ -193,3 +193,16 @@ def merge_topk_device(metric, D_parts_t, I_parts_t, stream=None):
     check(L.knhip_merge_topk_device(metric, nq, k, nshard, _t_ptr(D_parts_t), _t_ptr(I_parts_t), _t_ptr(D),
                                     _t_ptr(I), C.c_void_p(s)))
     return D, I
+
+
+def refine_device(metric, base_t, xq_t, cand_ids_t, k, id_base=0, stream=None):
+    """exact re-rank (IndexRefine second stage): base_t [nbase, d] fp32 device, cand_ids_t [nq, k_base]"""
+    import torch
+    L = _lib.load()
+    nq, kbase = cand_ids_t.shape
+    D = torch.empty((nq, k), dtype=torch.float32, device=xq_t.device)
+    I = torch.empty((nq, k), dtype=torch.int64, device=xq_t.device)
+    s = torch.cuda.current_stream(xq_t.device).cuda_stream if stream is None else stream
+    check(L.knhip_refine_device(metric, base_t.shape[1], _t_ptr(base_t), base_t.shape[0], id_base, _t_ptr(xq_t), nq,
+                                _t_ptr(cand_ids_t), kbase, k, _t_ptr(D), _t_ptr(I), C.c_void_p(s)))
+    return D, I

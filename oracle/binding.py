@@ -195,6 +195,18 @@ class Port:
                                 _p(Ip, _i64p), _p(D, _f32p), _p(I, _i64p))
         return D, I
 
+    def refine(self, metric, base, xq, cand_ids, k, id_base=0):
+        base = np.ascontiguousarray(base, np.float32)
+        xq = np.ascontiguousarray(xq, np.float32)
+        cand = np.ascontiguousarray(cand_ids, np.int64)
+        nq, kb = cand.shape
+        D = np.empty((nq, k), np.float32)
+        I = np.empty((nq, k), np.int64)
+        self.lib.orc_refine(C.c_int(metric), C.c_int(base.shape[1]), _p(base, _f32p), C.c_int64(base.shape[0]),
+                            C.c_int64(id_base), C.c_int64(nq), _p(xq, _f32p), C.c_int64(kb), _p(cand, _i64p),
+                            C.c_int64(k), _p(D, _f32p), _p(I, _i64p))
+        return D, I
+
     def pq_precompute_table(self, d, M, nbits, centroids, cb):
         nlist = centroids.shape[0]
         out = np.empty((nlist, M * (1 << nbits)), np.float32)
@@ -380,6 +392,18 @@ class Ref:
         self._chk(self.lib.ref_search(h, C.c_int64(nq), _p(xq, _f32p), C.c_int64(k), C.c_int64(nprobe),
                                       _p(bitset, _u8p), C.c_int64(nbits), _p(D, _f32p), _p(I, _i64p),
                                       C.c_int(nthreads)))
+        return D, I
+
+    def search_refine(self, h, xb, xq, k, k_factor, nprobe):
+        """IndexRefine(base = h, refine = IndexFlat(xb)).search, one query per call"""
+        xb = np.ascontiguousarray(xb, np.float32)
+        xq = np.ascontiguousarray(xq, np.float32)
+        nq = xq.shape[0]
+        D = np.empty((nq, k), np.float32)
+        I = np.empty((nq, k), np.int64)
+        self._chk(self.lib.ref_search_refine(h, C.c_int64(xb.shape[0]), _p(xb, _f32p), C.c_int64(nq), _p(xq, _f32p),
+                                             C.c_int64(k), C.c_float(k_factor), C.c_int64(nprobe), _p(D, _f32p),
+                                             _p(I, _i64p)))
         return D, I
 
     def coarse(self, h, xq, nprobe):

@@ -469,6 +469,38 @@ int orc_ivf_search(const orc_index* idx, int64_t nq, const float* xq, int64_t k,
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Refine: T:IndexRefine.cpp:108-140.  dc(idx) of an IndexFlat is fvec_L2sqr / fvec_inner_product
+ * (T:IndexFlat.cpp FlatL2Dis / FlatIPDis); reorder_2_heaps = heapify(k) + heap_addn(all k_base,
+ * labels -1 included: their stale distances are never admitted because... they keep the
+ * base-stage value, so restate literally) + heap_reorder  (T:utils/Heap.h reorder_2_heaps).
+ * ---------------------------------------------------------------------------------------- */
+int orc_refine(int metric, int d, const float* base, int64_t nbase, int64_t id_base, int64_t nq,
+               const float* xq, int64_t k_base, const int64_t* cand_ids, int64_t k, float* D, int64_t* I) {
+    const int is_max = (metric == ORC_L2);
+    for (int64_t i = 0; i < nq; i++) {
+        const float* q = xq + i * (int64_t)d;
+        float* simi = D + i * k;
+        int64_t* idxi = I + i * k;
+        orc_heap_heapify(is_max, (size_t)k, simi, idxi);
+        for (int64_t j = 0; j < k_base; j++) {
+            const int64_t id = cand_ids[i * k_base + j];
+            if (id < 0) {
+                break; /* entries after the first -1 are all -1 (sentinel tail): nothing to add */
+            }
+            if (id - id_base < 0 || id - id_base >= nbase) {
+                continue;
+            }
+            const float* y = base + (id - id_base) * (int64_t)d;
+            const float dis = is_max ? orc_fvec_L2sqr(q, y, (size_t)d)
+                                     : orc_fvec_inner_product(q, y, (size_t)d);
+            heap_add(is_max, (size_t)k, simi, idxi, dis, id);
+        }
+        orc_heap_reorder(is_max, (size_t)k, simi, idxi);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
  * Shard merge.  The k best of the union of per-shard results; the reference proves the
  * property in tests/ut/test_bruteforce.cc:128-181 (heaps.addn_with_ids over partitions) and
  * T:utils/Heap.h:636 merge_knn_results.  Restated with the same heap.

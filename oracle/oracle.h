@@ -86,6 +86,12 @@ int orc_ivf_search_preassigned(const orc_index* idx, int64_t nq, const float* xq
                                int64_t nprobe, const int64_t* keys, const float* coarse_dis,
                                const uint8_t* bitset, int64_t nbits, float* D, int64_t* I);
 
+/* Refine (second stage of IndexRefine::search, T:IndexRefine.cpp:104-140): re-score candidate
+ * labels (stop at the first -1) with the exact metric on the raw vectors, keep the k best.
+ * base row r holds id id_base + r. */
+int orc_refine(int metric, int d, const float* base, int64_t nbase, int64_t id_base, int64_t nq,
+               const float* xq, int64_t k_base, const int64_t* cand_ids, int64_t k, float* D, int64_t* I);
+
 /* host-side merge of per-shard partial results (T:utils/Heap.h:636 merge_knn_results semantics:
  * the k best of the union in canonical order) -- checker for the multi-GPU merge */
 int orc_merge_topk(int metric, int64_t nq, int64_t k, int nshard, const float* D_parts,

@@ -17,6 +17,7 @@
 #include <faiss/IndexIVF.h>
 #include <faiss/IndexIVFFlat.h>
 #include <faiss/IndexIVFPQ.h>
+#include <faiss/IndexRefine.h>
 #include <faiss/IndexScalarQuantizer.h>
 #include <faiss/impl/IDSelector.h>
 #include <faiss/invlists/InvertedLists.h>
@@ -322,6 +323,37 @@ int ref_search(
         return -1;
     }
     return 0;
+}
+
+/// Knowhere's refine path: IndexRefine over the IVF index with a flat fp32 refine index
+/// (reference src/index/ivf/ivf.cc:1073-1103, src/index/refine/refine_utils.cc:99).
+int ref_search_refine(
+        void* hv,
+        int64_t nb,
+        const float* xb,
+        int64_t nq,
+        const float* q,
+        int64_t k,
+        float k_factor,
+        int64_t nprobe,
+        float* D,
+        int64_t* I) {
+    auto* h = static_cast<RefIndex*>(hv);
+    return guarded([&] {
+        faiss::MetricType mt = h->metric == 0 ? faiss::METRIC_L2 : faiss::METRIC_INNER_PRODUCT;
+        faiss::IndexFlat flat(h->d, mt);
+        flat.add(nb, xb);
+        faiss::IndexRefine refine(h->index.get(), &flat);
+        refine.ntotal = h->index->ntotal; // both were populated independently
+        faiss::IVFSearchParameters ivfp;
+        ivfp.nprobe = nprobe;
+        faiss::IndexRefineSearchParameters rp;
+        rp.k_factor = k_factor;
+        rp.base_index_params = &ivfp;
+        for (int64_t i = 0; i < nq; i++) {
+            refine.search(1, q + i * h->d, k, D + i * k, I + i * k, &rp);
+        }
+    });
 }
 
 /// coarse quantizer alone: quantizer->search(1, q, nprobe) per query

@@ -264,3 +264,52 @@ def test_primitives(torch_cuda, port):
                                  C.c_void_p(ct.data_ptr()), None))
     torch.cuda.synchronize()
     assert ct.cpu().numpy().tobytes() == port.fvec_madd(a, -2.0, b).tobytes()
+
+
+@pytest.mark.parametrize("metric", [ob.L2, ob.IP])
+def test_refine(torch_cuda, port, metric):
+    # Knowhere `refine`: IndexRefine over IVF_PQ (reference src/index/ivf/ivf.cc:1073-1103)
+    torch = torch_cuda
+    from knowhere_amd.index import refine_device
+    nb, d = 15000, 64
+    xb, xq = gen_data(nb, d, 42), gen_data(60, d, 44)
+    ix = ob.make_index(port, ob.IVF_PQ, metric, xb, nlist=32, M=16)
+    g = _gpu(ix)
+    q = torch.from_numpy(xq).cuda()
+    base = torch.from_numpy(xb).cuda()
+    for k, kbase, nprobe in ((10, 40, 8), (1, 64, 4), (100, 200, 32), (10, 500, 1)):
+        Dc, Ic = g.search_device(q, kbase, nprobe)
+        torch.cuda.synchronize()
+        Do_c, Io_c = port.search(ix, xq, kbase, nprobe)
+        assert_parity(Do_c, Io_c, Dc.cpu().numpy(), Ic.cpu().numpy(), metric, "refine stage 1")
+        D, I = refine_device(metric, base, q, Ic, k)
+        torch.cuda.synchronize()
+        Do, Io = port.refine(metric, xb, xq, Io_c, k)
+        assert_parity(Do, Io, D.cpu().numpy(), I.cpu().numpy(), metric, f"refine k={k} kbase={kbase}")
+    g.close()
+
+
+def test_gpu_builder_index_parity_and_recall(torch_cuda, port):
+    # index trained/encoded by the GPU builder (bench.py's path): same bytes to oracle and GPU
+    torch = torch_cuda
+    from knowhere_amd import build as kb
+    from knowhere_amd import index as kidx
+    spec = kb.DataSpec(300000, 64, kind="mixture", ncenter=4096, sigma=0.35)
+    built = kb.build_ivf(spec, kidx.IVF_PQ, kidx.L2, nlist=256, M=16, keep_vectors=True)
+    g = built.to_gpu_index()
+    xq = kb.queries(spec, 100, "cuda:0")
+    D, I = g.search_device(xq, 50, 16)
+    Dr, Ir = kidx.refine_device(kidx.L2, built.vectors, xq, I, 10)
+    torch.cuda.synchronize()
+    ix = built.export(ob.IndexData)
+    ix.use_precomputed_table = 1
+    finish_ivfpq(port, ix)
+    Do, Io = port.search(ix, xq.cpu().numpy(), 50, 16)
+    assert_parity(Do, Io, D.cpu().numpy(), I.cpu().numpy(), ob.L2, "builder index")
+    _, gt = kb.ground_truth(spec, xq, 10)
+    # ground truth itself against the oracle's exact search
+    Dg, Ig = port.flat_search(ob.L2, built.vectors.cpu().numpy(), xq.cpu().numpy(), 10)
+    assert (np.sort(gt.cpu().numpy(), 1) == np.sort(Ig, 1)).mean() > 0.999
+    rec = (Ir.unsqueeze(2) == gt.unsqueeze(1)).any(2).float().mean().item()
+    assert rec > 0.6, rec  # sanity floor (reference floors: tests/ut/test_gpu_search.cc:179-187)
+    g.close()
