@@ -191,8 +191,10 @@ __device__ __forceinline__ float prefilter_bound(float kd, float dis0) {
 // SIMD -- what hides the latency of the dependent fmac chain -- are set by the workgroup size:
 // 4 waves -> 2 per SIMD, 8 -> 4, 16 -> 8.  More waves also means more pipes per list, i.e. more
 // run-up steps (M-1 per pipe): measured trade-off in DESIGN.md.
+// second launch-bounds argument = waves per SIMD the register allocator must leave room for:
+// two workgroups per CU (the LDS limit) = 2 * PQ_WAVES / 4 waves per SIMD, capped at 4 (128 VGPRs)
 template <bool IS_L2, int M, int QG, int R, int PQ_WAVES>
-__global__ __launch_bounds__(PQ_WAVES * 64) void pq_scan_kernel(PqScanArgs a) {
+__global__ __launch_bounds__(PQ_WAVES * 64, (PQ_WAVES >= 8 ? 4 : 2)) void pq_scan_kernel(PqScanArgs a) {
     constexpr int PQ_THREADS = PQ_WAVES * KN_WAVE;
     static_assert(64 % M == 0, "M must divide the wave");
     static_assert(QG == 1 || QG == 2, "");
