@@ -1,0 +1,76 @@
+"""CPU tests of the multi-GPU plumbing (world_size 2, gloo): list partition, all-gather + merge of
+per-shard partial top-k == monolithic search (reference property: tests/ut/test_bruteforce.cc:128-181).
+The per-shard searches are played by the oracle here (no GPU); what is under test is the
+partitioning, the collective and the product's host merge (knhip_merge_topk_host)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, assert_parity, gen_data
+
+
+def _worker(rank, world, port_no, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port_no)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from knowhere_amd import sharded
+    from oracle import binding as ob
+    port = ob.Port()
+    xb, xq = gen_data(6000, 32, 42), gen_data(40, 32, 44)
+    ix = ob.make_index(port, ob.IVF_PQ, ob.L2, xb, nlist=24, M=8)
+    sizes = np.array([len(i) for i in ix.list_ids])
+    masks = sharded.partition_lists(sizes, world)
+    # every list owned exactly once, loads balanced
+    assert (np.sum(masks, axis=0) == 1).all()
+    loads = [int(sizes[m].sum()) for m in masks]
+    assert max(loads) - min(loads) <= sizes.max()
+    sub = ob.IndexData(ix.kind, ix.metric, ix.d, ix.nlist, ix.M, ix.nbits)
+    sub.centroids, sub.pq_centroids = ix.centroids, ix.pq_centroids
+    sub.precomputed_table, sub.use_precomputed_table = ix.precomputed_table, 1
+    sub.list_codes = [c if masks[rank][l] else c[:0] for l, c in enumerate(ix.list_codes)]
+    sub.list_ids = [i if masks[rank][l] else i[:0] for l, i in enumerate(ix.list_ids)]
+    Dl, Il = port.search(sub, xq, 10, 8)  # this rank's partial top-k (its own lists only)
+    comm = sharded.Comm()
+    D, I = comm.allgather_merge(ob.L2, torch.from_numpy(Dl), torch.from_numpy(Il))
+    D0, I0 = port.search(ix, xq, 10, 8)
+    assert_parity(D0, I0, D.numpy(), I.numpy(), ob.L2, f"rank {rank}: sharded == monolithic")
+    t = comm.max_float(float(rank))
+    assert t == world - 1
+    b = torch.full((3,), float(rank))
+    comm.broadcast(b, 0)
+    assert (b == 0).all()
+    # refine ownership masking: -1 ends a row, unowned -> -2
+    own = torch.zeros(10, dtype=torch.bool)
+    own[[1, 3]] = True
+    m = sharded.mask_unowned(torch.tensor([[1, 2, 3, -1]]), own)
+    assert m.tolist() == [[1, -2, 3, -1]]
+    dist.barrier()
+    dist.destroy_process_group()
+    ret[rank] = 1
+
+
+def test_list_sharding_allgather_merge_world2():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port_no = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port_no, ret), nprocs=world, join=True)
+    assert len(ret) == world
+
+
+def test_partition_is_deterministic_and_balanced():
+    from knowhere_amd import sharded
+    r = np.random.default_rng(0)
+    sizes = r.gamma(2.0, 3000, 16384).astype(np.int64)
+    for world in (2, 4, 8):
+        m1 = sharded.partition_lists(sizes, world)
+        m2 = sharded.partition_lists(sizes.copy(), world)
+        assert all((a == b).all() for a, b in zip(m1, m2))
+        loads = np.array([sizes[m].sum() for m in m1], np.float64)
+        assert loads.max() / loads.mean() < 1.001
