@@ -96,7 +96,7 @@ def main():
     if world > 1:
         # rank 0 trains; centroids and codebooks are broadcast so every shard quantises identically
         if rank == 0:
-            tmp = kb.build_ivf(spec, kidx.IVF_PQ, kidx.L2, a.nlist, a.m, device=str(dev), row_range=(0, 0),
+            tmp = kb.build_ivf(spec, kidx.IVF_PQ, kidx.L2, a.nlist, a.m, device=str(dev), train_only=True,
                                verbose=a.verbose)
             cen, cb = tmp.centroids, tmp.codebooks
         else:

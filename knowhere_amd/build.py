@@ -229,7 +229,7 @@ class BuiltIndex:
 
 def build_ivf(spec, kind, metric, nlist, M=32, device="cuda:0", train_per_centroid=64, niter=10,
               pq_train=1 << 20, centroids=None, codebooks=None, row_range=None, verbose=False,
-              keep_vectors=False):
+              keep_vectors=False, train_only=False):
     """Train (unless centroids/codebooks are given, e.g. broadcast from rank 0) and encode
     rows [row_range) of the synthetic data set.  Returns a BuiltIndex on `device`."""
     import time
@@ -264,6 +264,8 @@ def build_ivf(spec, kind, metric, nlist, M=32, device="cuda:0", train_per_centro
         del xt, a, r
     torch.cuda.synchronize(dev)
     out.timings["train_codec_s"] = time.time() - t0
+    if train_only:
+        return out
     t0 = time.time()
     lo, hi = row_range if row_range is not None else (0, spec.n)
     assign_parts, code_parts = [], []

@@ -184,7 +184,9 @@ class HipIndexNode : public IndexNode {
         if (nlist_ * 39 > rows) nlist_ = std::max<int64_t>(1, rows / 39);
         if (kind_ == KNHIP_IVF_PQ) {
             if (cfg_.nbits != 8) return Status::invalid_args;
-            m_ = cfg_.m == 0 ? std::min<int64_t>(32, dim_) : cfg_.m;  // m = 0: let the backend pick
+            // m = 0: let the backend pick, as cuVS does for pq_dim = 0 (about dim / 2): the largest
+            // supported m that leaves sub-vectors of at least 2 dims
+            m_ = cfg_.m == 0 ? std::min<int64_t>(64, dim_ / 2) : cfg_.m;
             while (m_ > 1 && (dim_ % m_ != 0 || !(m_ == 8 || m_ == 16 || m_ == 32 || m_ == 64))) m_--;
             if (dim_ % m_ != 0 || !(m_ == 8 || m_ == 16 || m_ == 32 || m_ == 64)) return Status::invalid_args;
         }
