@@ -191,6 +191,7 @@ typedef struct knhip_stage_times {
     double scan_bytes;    /* sum over (query, probe) of len(list) * code_size */
     double coarse_flops;  /* 2 * nq * nlist * dim */
     int64_t scan_items;   /* work items launched by the scan kernel */
+    int64_t coarse_fallback_queries; /* queries whose MFMA-prefilter certificate failed (exact redo) */
 } knhip_stage_times;
 /* stage indices */
 enum {

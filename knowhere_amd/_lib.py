@@ -29,7 +29,7 @@ class Desc(C.Structure):
 
 class StageTimes(C.Structure):
     _fields_ = [("ms", C.c_float * NSTAGE), ("launches", C.c_int64 * NSTAGE), ("scan_bytes", C.c_double),
-                ("coarse_flops", C.c_double), ("scan_items", C.c_int64)]
+                ("coarse_flops", C.c_double), ("scan_items", C.c_int64), ("coarse_fallback_queries", C.c_int64)]
 
 
 # every symbol include/knhip.h declares (tests check the .so exports all of them)

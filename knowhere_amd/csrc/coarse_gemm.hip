@@ -62,16 +62,15 @@ __global__ __launch_bounds__(256) void coarse_gemm_kernel(const float* __restric
                                                           const float* __restrict__ Cm,
                                                           const float* __restrict__ cn, int64_t nq,
                                                           int64_t nlist, int d, int64_t tiles_n,
-                                                          float* __restrict__ out) {
+                                                          int64_t ntiles, float* __restrict__ out) {
     __shared__ float sA[CG_BK * CG_LD];
     __shared__ float sB[CG_BK * CG_LD];
     // XCD-aware tile order: consecutive tile ids share the query panel; give each XCD a run
-    const int64_t ntiles = (int64_t)gridDim.x;
+    // (grid is rounded up to a multiple of 8; ids beyond the last tile exit)
     const int64_t per = (ntiles + 7) / 8;
-    int64_t tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    const int64_t tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
     if (tile >= ntiles) {
-        // grid not a multiple of 8: the overflow ids map back onto the unused tail
-        tile = blockIdx.x;
+        return;
     }
     const int64_t tm = tile / tiles_n, tn = tile % tiles_n;
     const int64_t q0 = tm * CG_BM, c0 = tn * CG_BN;
@@ -185,7 +184,7 @@ __global__ __launch_bounds__(256) void coarse_rerank_kernel(
         const float* __restrict__ queries, const float* __restrict__ centroids, int d, int64_t nlist,
         int ncand, int kp, const int64_t* __restrict__ cand_keys, const float* __restrict__ cand_approx,
         int nprobe, const float* __restrict__ qnorm, float cnorm_max, int64_t* __restrict__ out_keys,
-        float* __restrict__ out_d, int32_t* __restrict__ fail_flags) {
+        float* __restrict__ out_d, int32_t* __restrict__ fail_flags, unsigned long long* __restrict__ nfail) {
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(smem); // [kp]
     float* sq = reinterpret_cast<float*>(smem + (size_t)kp * 8);           // [d]
@@ -257,6 +256,9 @@ __global__ __launch_bounds__(256) void coarse_rerank_kernel(
             }
         }
         fail_flags[q] = fail;
+        if (fail && nfail != nullptr) {
+            atomicAdd(nfail, 1ull);
+        }
     }
 }
 
@@ -275,12 +277,13 @@ hipError_t launch_coarse_gemm(const float* q, const float* qnorm, const float* c
     }
     const int64_t tm = (nq + CG_BM - 1) / CG_BM, tn = (nlist + CG_BN - 1) / CG_BN;
     const int64_t ntiles = tm * tn;
+    const unsigned grid = (unsigned)(((ntiles + 7) / 8) * 8);
     if (is_l2) {
-        hipLaunchKernelGGL((coarse_gemm_kernel<true>), dim3((unsigned)ntiles), dim3(256), 0, s, q, qnorm,
-                           c, cnorm, nq, nlist, d, tn, out);
+        hipLaunchKernelGGL((coarse_gemm_kernel<true>), dim3(grid), dim3(256), 0, s, q, qnorm, c, cnorm, nq,
+                           nlist, d, tn, ntiles, out);
     } else {
-        hipLaunchKernelGGL((coarse_gemm_kernel<false>), dim3((unsigned)ntiles), dim3(256), 0, s, q, qnorm,
-                           c, cnorm, nq, nlist, d, tn, out);
+        hipLaunchKernelGGL((coarse_gemm_kernel<false>), dim3(grid), dim3(256), 0, s, q, qnorm, c, cnorm, nq,
+                           nlist, d, tn, ntiles, out);
     }
     return hipGetLastError();
 }
@@ -289,7 +292,7 @@ hipError_t launch_coarse_rerank(const float* queries, const float* centroids, in
                                 int64_t nlist, int ncand, const int64_t* cand_keys,
                                 const float* cand_approx, int nprobe, bool is_l2, const float* qnorm,
                                 float cnorm_max, int64_t* out_keys, float* out_d, int32_t* fail_flags,
-                                hipStream_t s) {
+                                unsigned long long* nfail, hipStream_t s) {
     if (nq <= 0) {
         return hipSuccess;
     }
@@ -307,7 +310,7 @@ hipError_t launch_coarse_rerank(const float* queries, const float* centroids, in
         }
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nq), dim3(256), sm, s, queries, centroids, d, nlist, ncand, kp,
-                       cand_keys, cand_approx, nprobe, qnorm, cnorm_max, out_keys, out_d, fail_flags);
+                       cand_keys, cand_approx, nprobe, qnorm, cnorm_max, out_keys, out_d, fail_flags, nfail);
     return hipGetLastError();
 }
 

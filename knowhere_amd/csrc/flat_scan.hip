@@ -231,7 +231,8 @@ __global__ __launch_bounds__(FS_THREADS) void flat_scan_kernel(FlatScanArgs a) {
 template <bool IS_L2, int QG>
 __global__ __launch_bounds__(FS_THREADS) void flat_full_kernel(FlatScanArgs a, float* out,
                                                                const int32_t* q_subset,
-                                                               int64_t nq_subset) {
+                                                               int64_t nq_subset,
+                                                               const int32_t* row_flags) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = lane_id();
     const int wave = threadIdx.x / KN_WAVE;
@@ -249,6 +250,17 @@ __global__ __launch_bounds__(FS_THREADS) void flat_full_kernel(FlatScanArgs a, f
     for (int j = 0; j < QG; j++) {
         const int64_t qi = min(g * QG + j, nq - 1);
         q_of[j] = q_subset ? q_subset[qi] : (int32_t)qi;
+    }
+    if (row_flags != nullptr) {
+        // exact fallback of the MFMA prefilter: only queries whose certificate failed are recomputed
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < QG; j++) {
+            any |= (j < npair) && row_flags[q_of[j]] != 0;
+        }
+        if (!any) {
+            return;
+        }
     }
     float* sq = reinterpret_cast<float*>(smem);
     for (int t = threadIdx.x; t < QG * dpad; t += FS_THREADS) {
@@ -287,7 +299,7 @@ __global__ __launch_bounds__(FS_THREADS) void flat_full_kernel(FlatScanArgs a, f
         if (row < len) {
 #pragma unroll
             for (int j = 0; j < QG; j++) {
-                if (j < npair) {
+                if (j < npair && (row_flags == nullptr || row_flags[q_of[j]] != 0)) {
                     out[(int64_t)q_of[j] * a.nrows + row_base + row] = acc[j];
                 }
             }
@@ -413,7 +425,7 @@ hipError_t launch_flat_scan(const FlatScanArgs& a, bool is_l2, bool dense, int64
 }
 
 hipError_t launch_flat_full(const FlatScanArgs& a, bool is_l2, float* out, const int32_t* q_subset,
-                            int64_t nq_subset, hipStream_t s) {
+                            int64_t nq_subset, const int32_t* row_flags, hipStream_t s) {
     constexpr int QG = 8;
     const int64_t nq = q_subset ? nq_subset : a.nq;
     if (nq <= 0 || a.nrows <= 0) {
@@ -429,7 +441,7 @@ hipError_t launch_flat_full(const FlatScanArgs& a, bool is_l2, float* out, const
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)(ngroups * nchunks)), dim3(FS_THREADS), sm, s, a, out,
-                       q_subset, nq_subset);
+                       q_subset, nq_subset, row_flags);
     return hipGetLastError();
 }
 

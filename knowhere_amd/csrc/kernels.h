@@ -111,7 +111,7 @@ struct SqScanArgs {
 int flat_scan_qg(int k);
 hipError_t launch_flat_scan(const FlatScanArgs& a, bool is_l2, bool dense, int64_t grid, hipStream_t s);
 hipError_t launch_flat_full(const FlatScanArgs& a, bool is_l2, float* out, const int32_t* q_subset,
-                            int64_t nq_subset, hipStream_t s);
+                            int64_t nq_subset, const int32_t* row_flags, hipStream_t s);
 hipError_t launch_interleave_rows(const float* src, int64_t n, int d, float4* dst, int64_t dst_blk0,
                                   hipStream_t s);
 hipError_t launch_interleave_lists(const float* src, const int64_t* list_row_off,
@@ -162,7 +162,7 @@ hipError_t launch_merge_partials(const float* partial_d, const int64_t* partial_
                                  float* out_d, int64_t* out_i, hipStream_t s);
 // per row: the k best of n values (index = column), canonical order; out_keys int64, out_d float
 hipError_t launch_row_select(const float* vals, int64_t nrows, int64_t n, int k, bool is_l2,
-                             int64_t* out_keys, float* out_d, hipStream_t s);
+                             int64_t* out_keys, float* out_d, const int32_t* row_flags, hipStream_t s);
 size_t row_select_max_k();
 
 // ---- coarse_gemm.hip: fp32 MFMA prefilter for the coarse quantizer ----
@@ -173,7 +173,7 @@ hipError_t launch_coarse_rerank(const float* queries, const float* centroids, in
                                 int64_t nlist, int ncand, const int64_t* cand_keys,
                                 const float* cand_approx, int nprobe, bool is_l2, const float* qnorm,
                                 float cnorm_max, int64_t* out_keys, float* out_d, int32_t* fail_flags,
-                                hipStream_t s);
+                                unsigned long long* nfail, hipStream_t s);
 
 // ---- refine.hip ----
 hipError_t launch_refine(const float* base, int64_t nbase, int64_t id_base, int d, const float* queries,

@@ -16,6 +16,7 @@
 #include "kernels.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -108,6 +109,10 @@ struct Workspace {
     DevBuf partial_d;    // [qb][nslot][k]
     DevBuf partial_i;
     DevBuf gthr;         // [qb] shared per-query thresholds
+    DevBuf qnorm;        // [qb] ||q||^2 (MFMA coarse prefilter)
+    DevBuf cand_keys;    // [qb][ncand]
+    DevBuf cand_approx;  // [qb][ncand]
+    DevBuf fail_flags;   // [qb] coarse certificate failed -> exact fallback
     DevBuf list_count, list_pair_off, list_item_off, list_cursor, pairs, items, nitems;
     // host-boundary staging
     DevBuf h_queries, h_bitset, h_out_d, h_out_i;
@@ -130,6 +135,10 @@ struct knhip_index {
     bool has_coarse = false;
     DevBuf centroids;     // [nlist][d] row major
     DevBuf centroids_il;  // interleaved 64-row blocks
+    DevBuf cnorm;         // [nlist] ||c||^2
+    float cnorm_max = 0.f;
+    bool coarse_gemm = true;  // KNHIP_COARSE=exact switches the MFMA prefilter off
+    DevBuf coarse_fail_dev;   // unsigned long long: queries that took the exact fallback
     // PQ
     bool has_pq = false;
     DevBuf cb;            // [M][256][dsub]
@@ -219,7 +228,56 @@ int build_coarse_layout(knhip_index* idx) {
     HIP_TRY(idx->centroids_il.alloc((size_t)nblk * nchunk * 64 * sizeof(float4)));
     HIP_TRY(launch_interleave_rows(idx->centroids.as<float>(), idx->nlist, idx->d,
                                    idx->centroids_il.as<float4>(), 0, nullptr));
+    HIP_TRY(idx->cnorm.alloc((size_t)idx->nlist * sizeof(float)));
+    HIP_TRY(launch_row_norms(idx->centroids.as<float>(), idx->nlist, idx->d, idx->cnorm.as<float>(), nullptr));
     HIP_TRY(hipDeviceSynchronize());
+    std::vector<float> cn((size_t)idx->nlist);
+    HIP_TRY(hipMemcpy(cn.data(), idx->cnorm.p, cn.size() * sizeof(float), hipMemcpyDeviceToHost));
+    idx->cnorm_max = cn.empty() ? 0.f : *std::max_element(cn.begin(), cn.end());
+    const char* e = getenv("KNHIP_COARSE");
+    idx->coarse_gemm = !(e && std::string(e) == "exact");
+    return KNHIP_OK;
+}
+
+// Coarse quantizer for one batch: keys/cdis [nq][nprobe], best-first, bit-equal to the exact search.
+int coarse_stage(const knhip_index* idx, Workspace* ws, const float* d_q, int64_t nq, int nprobe,
+                 int64_t* keys, float* cdis, hipStream_t s) {
+    const int64_t nlist = idx->nlist;
+    const int d = idx->d;
+    const bool is_l2 = idx->is_l2;
+    HIP_TRY(ws->coarse_full.reserve((size_t)nq * nlist * sizeof(float)));
+    FlatScanArgs c{};
+    c.rows = idx->centroids_il.as<float4>();
+    c.nrows = nlist;
+    c.chunk_rows = 1024;
+    c.d = d;
+    c.nchunk = (d + 3) / 4;
+    c.queries = d_q;
+    c.nq = nq;
+    const int margin = std::max(32, nprobe / 4);
+    const int64_t ncand = (int64_t)nprobe + margin;
+    if (!idx->coarse_gemm || ncand >= nlist || (size_t)ncand > row_select_max_k()) {
+        HIP_TRY(launch_flat_full(c, is_l2, ws->coarse_full.as<float>(), nullptr, 0, nullptr, s));
+        HIP_TRY(launch_row_select(ws->coarse_full.as<float>(), nq, nlist, nprobe, is_l2, keys, cdis, nullptr, s));
+        return KNHIP_OK;
+    }
+    HIP_TRY(ws->qnorm.reserve((size_t)nq * sizeof(float)));
+    HIP_TRY(ws->cand_keys.reserve((size_t)nq * ncand * sizeof(int64_t)));
+    HIP_TRY(ws->cand_approx.reserve((size_t)nq * ncand * sizeof(float)));
+    HIP_TRY(ws->fail_flags.reserve((size_t)nq * sizeof(int32_t)));
+    HIP_TRY(launch_row_norms(d_q, nq, d, ws->qnorm.as<float>(), s));
+    HIP_TRY(launch_coarse_gemm(d_q, ws->qnorm.as<float>(), idx->centroids.as<float>(), idx->cnorm.as<float>(), nq,
+                               nlist, d, is_l2, ws->coarse_full.as<float>(), s));
+    HIP_TRY(launch_row_select(ws->coarse_full.as<float>(), nq, nlist, (int)ncand, is_l2,
+                              ws->cand_keys.as<int64_t>(), ws->cand_approx.as<float>(), nullptr, s));
+    HIP_TRY(launch_coarse_rerank(d_q, idx->centroids.as<float>(), d, nq, nlist, (int)ncand,
+                                 ws->cand_keys.as<int64_t>(), ws->cand_approx.as<float>(), nprobe, is_l2,
+                                 ws->qnorm.as<float>(), idx->cnorm_max, keys, cdis, ws->fail_flags.as<int32_t>(),
+                                 idx->coarse_fail_dev.as<unsigned long long>(), s));
+    // exact fallback, restricted on the device to the flagged queries (normally none)
+    HIP_TRY(launch_flat_full(c, is_l2, ws->coarse_full.as<float>(), nullptr, 0, ws->fail_flags.as<int32_t>(), s));
+    HIP_TRY(launch_row_select(ws->coarse_full.as<float>(), nq, nlist, nprobe, is_l2, keys, cdis,
+                              ws->fail_flags.as<int32_t>(), s));
     return KNHIP_OK;
 }
 
@@ -379,22 +437,13 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
     // ---- IVF kinds ----
     const int64_t nlist = idx->nlist;
     // 1. coarse
-    HIP_TRY(ws->coarse_full.reserve((size_t)nq * nlist * sizeof(float)));
     HIP_TRY(ws->keys.reserve((size_t)nq * nprobe * sizeof(int64_t)));
     HIP_TRY(ws->cdis.reserve((size_t)nq * nprobe * sizeof(float)));
     {
         StageTimer t(idx, s, KNHIP_STAGE_COARSE);
-        FlatScanArgs c{};
-        c.rows = idx->centroids_il.as<float4>();
-        c.nrows = nlist;
-        c.chunk_rows = 1024;
-        c.d = d;
-        c.nchunk = (d + 3) / 4;
-        c.queries = d_q;
-        c.nq = nq;
-        HIP_TRY(launch_flat_full(c, is_l2, ws->coarse_full.as<float>(), nullptr, 0, s));
-        HIP_TRY(launch_row_select(ws->coarse_full.as<float>(), nq, nlist, nprobe, is_l2,
-                                  ws->keys.as<int64_t>(), ws->cdis.as<float>(), s));
+        if (int rc = coarse_stage(idx, ws, d_q, nq, nprobe, ws->keys.as<int64_t>(), ws->cdis.as<float>(), s)) {
+            return rc;
+        }
     }
     // 2. group
     const int qg = (kind == KNHIP_IVF_PQ) ? pq_scan_qg(idx->desc.pq_m)
@@ -657,6 +706,8 @@ int knhip_index_create(const knhip_desc* desc, knhip_index** out) {
     DeviceGuard g(desc->device);
     HIP_TRY(idx->scan_bytes_dev.alloc(sizeof(double)));
     HIP_TRY(hipMemset(idx->scan_bytes_dev.p, 0, sizeof(double)));
+    HIP_TRY(idx->coarse_fail_dev.alloc(sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(idx->coarse_fail_dev.p, 0, sizeof(unsigned long long)));
     *out = idx.release();
     return KNHIP_OK;
 }
@@ -944,18 +995,10 @@ int knhip_coarse_search_device(const knhip_index* idx, const float* d_queries, i
     const int64_t qb = std::max<int64_t>(1, std::min<int64_t>(nq, (int64_t)((4.0 * 1024 * 1024 * 1024) / (idx->nlist * 4.0))));
     for (int64_t q0 = 0; q0 < nq; q0 += qb) {
         const int64_t n = std::min(qb, nq - q0);
-        HIP_TRY(ws->coarse_full.reserve((size_t)n * idx->nlist * sizeof(float)));
-        FlatScanArgs c{};
-        c.rows = idx->centroids_il.as<float4>();
-        c.nrows = idx->nlist;
-        c.chunk_rows = 1024;
-        c.d = idx->d;
-        c.nchunk = (idx->d + 3) / 4;
-        c.queries = d_queries + q0 * idx->d;
-        c.nq = n;
-        HIP_TRY(launch_flat_full(c, idx->is_l2, ws->coarse_full.as<float>(), nullptr, 0, s));
-        HIP_TRY(launch_row_select(ws->coarse_full.as<float>(), n, idx->nlist, nprobe, idx->is_l2,
-                                  d_out_keys + q0 * nprobe, d_out_dist + q0 * nprobe, s));
+        if (int rc = coarse_stage(idx, ws, d_queries + q0 * idx->d, n, nprobe, d_out_keys + q0 * nprobe,
+                                  d_out_dist + q0 * nprobe, s)) {
+            return rc;
+        }
     }
     return KNHIP_OK;
 }
@@ -1086,6 +1129,7 @@ int knhip_profile_reset(knhip_index* idx) {
     idx->coarse_flops = 0;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemset(idx->scan_bytes_dev.p, 0, sizeof(double)));
+    HIP_TRY(hipMemset(idx->coarse_fail_dev.p, 0, sizeof(unsigned long long)));
     return KNHIP_OK;
 }
 
@@ -1103,13 +1147,16 @@ int knhip_profile_get(const knhip_index* idx, knhip_stage_times* out) {
     out->scan_bytes = sb;
     out->coarse_flops = idx->coarse_flops;
     out->scan_items = idx->last_items_bound;
+    unsigned long long nf = 0;
+    HIP_TRY(hipMemcpy(&nf, idx->coarse_fail_dev.p, sizeof(nf), hipMemcpyDeviceToHost));
+    out->coarse_fallback_queries = (int64_t)nf;
     return KNHIP_OK;
 }
 
 const char* knhip_stage_kernel_name(int stage, int kind) {
     switch (stage) {
         case KNHIP_STAGE_COARSE:
-            return "flat_full_kernel+row_select_kernel";
+            return "coarse_gemm_kernel+row_select_kernel+coarse_rerank_kernel";
         case KNHIP_STAGE_GROUP:
             return "wt_*_kernel";
         case KNHIP_STAGE_LUT:

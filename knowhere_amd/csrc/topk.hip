@@ -111,8 +111,12 @@ template <bool IS_L2>
 __global__ __launch_bounds__(RS_THREADS) void row_select_kernel(const float* __restrict__ vals,
                                                                 int64_t n, int k, int kp,
                                                                 int64_t* __restrict__ out_keys,
-                                                                float* __restrict__ out_d) {
+                                                                float* __restrict__ out_d,
+                                                                const int32_t* __restrict__ row_flags) {
     extern __shared__ __align__(16) unsigned char smem[];
+    if (row_flags != nullptr && row_flags[blockIdx.x] == 0) {
+        return; // only rows flagged by the coarse certificate are re-selected
+    }
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(smem); // [kp]
     __shared__ uint32_t hist[256];
     __shared__ uint32_t s_prefix, s_need, s_count, s_wave_tot[RS_THREADS / KN_WAVE], s_taken;
@@ -252,7 +256,7 @@ size_t row_select_max_k() {
 }
 
 hipError_t launch_row_select(const float* vals, int64_t nrows, int64_t n, int k, bool is_l2,
-                             int64_t* out_keys, float* out_d, hipStream_t s) {
+                             int64_t* out_keys, float* out_d, const int32_t* row_flags, hipStream_t s) {
     if (nrows <= 0 || k <= 0) {
         return hipSuccess;
     }
@@ -266,10 +270,10 @@ hipError_t launch_row_select(const float* vals, int64_t nrows, int64_t n, int k,
     const size_t sm = (size_t)kp * 8;
     if (is_l2) {
         hipLaunchKernelGGL((row_select_kernel<true>), dim3((unsigned)nrows), dim3(RS_THREADS), sm, s,
-                           vals, n, k, kp, out_keys, out_d);
+                           vals, n, k, kp, out_keys, out_d, row_flags);
     } else {
         hipLaunchKernelGGL((row_select_kernel<false>), dim3((unsigned)nrows), dim3(RS_THREADS), sm, s,
-                           vals, n, k, kp, out_keys, out_d);
+                           vals, n, k, kp, out_keys, out_d, row_flags);
     }
     return hipGetLastError();
 }

@@ -168,7 +168,8 @@ class GpuIndex:
         st = _lib.StageTimes()
         check(self.L.knhip_profile_get(self.h, C.byref(st)))
         return {"ms": list(st.ms), "launches": list(st.launches), "scan_bytes": st.scan_bytes,
-                "coarse_flops": st.coarse_flops, "scan_items": st.scan_items}
+                "coarse_flops": st.coarse_flops, "scan_items": st.scan_items,
+                "coarse_fallback_queries": st.coarse_fallback_queries}
 
 
 def merge_topk_host(metric, D_parts, I_parts):

@@ -88,7 +88,7 @@ def main():
                stage_ms=dict(coarse=round(ms[0], 3), group=round(ms[1], 3), lut=round(ms[2], 3),
                              scan=round(ms[3], 3), merge=round(ms[4], 3)),
                scan_bytes=scan_bytes, scan_algo_GBps=round(scan_bytes / (ms[3] * 1e-3) / 1e9, 1) if ms[3] > 0 else None,
-               device_GB=round(g.device_bytes / 1e9, 2), valid_ids=int((I >= 0).sum().item()))
+               device_GB=round(g.device_bytes / 1e9, 2), coarse_fallback_queries=p["coarse_fallback_queries"], valid_ids=int((I >= 0).sum().item()))
     print(json.dumps(res))
 
 
