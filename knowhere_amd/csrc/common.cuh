@@ -81,10 +81,34 @@ __device__ __forceinline__ int wave_shr1(int v) {
 // noted.  `idx` is whatever the caller orders ties by (list offset, row number or id) -- it is
 // compared as a signed 64-bit integer in the canonical direction.  Insertion is one compare +
 // ballot per register to find the position, then a DPP shift of the tail: no LDS traffic.
-template <bool IS_L2, int R>
+template <class T>
+__device__ __forceinline__ T readlane_idx(T v, int l);
+template <>
+__device__ __forceinline__ int64_t readlane_idx<int64_t>(int64_t v, int l) {
+    return readlane_i64(v, l);
+}
+template <>
+__device__ __forceinline__ int32_t readlane_idx<int32_t>(int32_t v, int l) {
+    return __builtin_amdgcn_readlane(v, l);
+}
+template <class T>
+__device__ __forceinline__ T wave_shr1_idx(T v);
+template <>
+__device__ __forceinline__ int64_t wave_shr1_idx<int64_t>(int64_t v) {
+    const int lo = wave_shr1((int)(v & 0xffffffffll));
+    const int hi = wave_shr1((int)(v >> 32));
+    return ((int64_t)hi << 32) | (uint32_t)lo;
+}
+template <>
+__device__ __forceinline__ int32_t wave_shr1_idx<int32_t>(int32_t v) {
+    return wave_shr1(v);
+}
+
+// IdxT = int32_t where the tie-break index is a list offset (saves a VGPR per register)
+template <bool IS_L2, int R, class IdxT = int64_t>
 struct WaveTopK {
     float d[R];
-    int64_t i[R];
+    IdxT i[R];
     int k;
 
     __device__ __forceinline__ void init(int k_) {
@@ -108,13 +132,13 @@ struct WaveTopK {
         }
         return v;
     }
-    __device__ __forceinline__ int64_t kth_idx() const {
+    __device__ __forceinline__ IdxT kth_idx() const {
         const int e = k - 1;
-        int64_t v = -1;
+        IdxT v = -1;
 #pragma unroll
         for (int r = 0; r < R; r++) {
             if (r == e / KN_WAVE) {
-                v = readlane_i64(i[r], e % KN_WAVE);
+                v = readlane_idx<IdxT>(i[r], e % KN_WAVE);
             }
         }
         return v;
@@ -123,7 +147,7 @@ struct WaveTopK {
     // would (dist, idx) enter the list?  Empty slots have idx -1 and the neutral distance: a real
     // candidate whose distance equals the neutral value is rejected, as the reference's strict
     // heap admission does (thirdparty/faiss/faiss/impl/ResultHandler.h:271-278).
-    __device__ __forceinline__ bool admits(float dist, int64_t idx, float kd, int64_t ki) const {
+    __device__ __forceinline__ bool admits(float dist, IdxT idx, float kd, IdxT ki) const {
         if (ki < 0) {
             return IS_L2 ? (dist < kd) : (dist > kd);
         }
@@ -131,7 +155,7 @@ struct WaveTopK {
     }
 
     // insert a wave-uniform candidate that is known to be admissible
-    __device__ __forceinline__ void insert(float dist, int64_t idx) {
+    __device__ __forceinline__ void insert(float dist, IdxT idx) {
         const int lane = lane_id();
         // position = number of stored elements strictly better than the candidate
         int pos = 0;
@@ -142,16 +166,14 @@ struct WaveTopK {
         }
         // shift elements [pos, k-2] one place towards the tail
         float carry_d = 0.f;
-        int64_t carry_i = 0;
+        IdxT carry_i = 0;
 #pragma unroll
         for (int r = 0; r < R; r++) {
             // pre-shift value of this register's last lane feeds lane 0 of the next register
             const float last_d = (R > 1) ? readlane_f(d[r], KN_WAVE - 1) : 0.f;
-            const int64_t last_i = (R > 1) ? readlane_i64(i[r], KN_WAVE - 1) : 0;
+            const IdxT last_i = (R > 1) ? readlane_idx<IdxT>(i[r], KN_WAVE - 1) : 0;
             float up_d = __builtin_bit_cast(float, wave_shr1(__builtin_bit_cast(int, d[r])));
-            const int lo = wave_shr1((int)(i[r] & 0xffffffffll));
-            const int hi = wave_shr1((int)(i[r] >> 32));
-            int64_t up_i = ((int64_t)hi << 32) | (uint32_t)lo;
+            IdxT up_i = wave_shr1_idx<IdxT>(i[r]);
             if (R > 1 && lane == 0) {
                 up_d = carry_d;
                 up_i = carry_i;

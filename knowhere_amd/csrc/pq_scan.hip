@@ -309,9 +309,9 @@ __global__ __launch_bounds__(PQ_WAVES * 64, (PQ_WAVES >= 8 ? 4 : 2)) void pq_sca
         outmask |= 1ull << (p * M + M - 1);
     }
 
-    WaveTopK<IS_L2, R> top[QG];
+    WaveTopK<IS_L2, R, int32_t> top[QG]; // ordered by the offset inside the list (< 2^31)
     float kd[QG], pre[QG], gt[QG];
-    int64_t ki[QG];
+    int32_t ki[QG];
 #pragma unroll
     for (int j = 0; j < QG; j++) {
         top[j].init(a.k);
@@ -400,11 +400,12 @@ __global__ __launch_bounds__(PQ_WAVES * 64, (PQ_WAVES >= 8 ? 4 : 2)) void pq_sca
                         const int p = l / M;
                         const int64_t pv0 = ((int64_t)wave * P + p) * per_pipe;
                         const int64_t t = rb * 16 + j;
-                        const int64_t v = pv0 + t - RUNUP;
+                        const int64_t v64 = pv0 + t - RUNUP;
                         const int64_t vend = min(pv0 + per_pipe, len);
-                        if (t < RUNUP || v >= vend || qi >= npair) {
+                        if (t < RUNUP || v64 >= vend || qi >= npair) {
                             continue;
                         }
+                        const int32_t v = (int32_t)v64;
                         const float acc = readlane_f(o, l);
                         const float dis = fadd_x(dis0[qi], acc);
                         if (!within_gthr<IS_L2>(dis, gt[qi]) || !top[qi].admits(dis, v, kd[qi], ki[qi])) {
@@ -466,7 +467,7 @@ __global__ __launch_bounds__(PQ_WAVES * 64, (PQ_WAVES >= 8 ? 4 : 2)) void pq_sca
                 const int64_t* oi = mi + (qi * PQ_WAVES + ow) * k;
                 for (int e = 0; e < k; e++) {
                     const float cd = od[e];
-                    const int64_t ci = oi[e];
+                    const int32_t ci = (int32_t)oi[e];
                     if (ci < 0 || !top[qi].admits(cd, ci, kd[qi], ki[qi])) {
                         break;
                     }
@@ -486,7 +487,7 @@ __global__ __launch_bounds__(PQ_WAVES * 64, (PQ_WAVES >= 8 ? 4 : 2)) void pq_sca
             for (int r = 0; r < R; r++) {
                 const int e = r * KN_WAVE + lane;
                 if (e < k) {
-                    const int64_t pos = top[qi].i[r];
+                    const int64_t pos = (int64_t)top[qi].i[r];
                     pd[e] = top[qi].d[r];
                     pi[e] = pos >= 0 ? a.ids[row_off + pos] : -1;
                 }
