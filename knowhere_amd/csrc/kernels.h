@@ -131,6 +131,13 @@ hipError_t launch_pq_skew_codes(const uint8_t* codes, const int64_t* list_row_of
                                 const int64_t* list_len, const int64_t* list_sblk_off, int64_t nlist,
                                 int M, uint4* out, hipStream_t s);
 
+// ---- pq_scan_v2.hip (M = 32, k <= 128: lane-stationary staggered ADC on the stream16 layout) ----
+bool pq_scan_v2_supports(int M, int k);
+int64_t pq_stream16_blocks(int64_t len);
+hipError_t launch_pq_scan_v2(const PqScanArgs& a, bool is_l2, int64_t grid, hipStream_t s);
+hipError_t launch_pq_stream16(const uint8_t* codes, const int64_t* list_row_off, const int64_t* list_len,
+                              const int64_t* list_sblk_off, int64_t nlist, uint4* out, hipStream_t s);
+
 // ---- sq_scan.hip ----
 hipError_t launch_sq_scan(const SqScanArgs& a, bool is_l2, int64_t grid, hipStream_t s);
 hipError_t launch_sq_interleave(const uint8_t* codes, const int64_t* list_row_off,

@@ -156,6 +156,9 @@ struct knhip_index {
     DevBuf d_list_len, d_list_row_off, d_list_blk_off;
     DevBuf ids;
     DevBuf rows;          // kind specific layout
+    DevBuf rows2;         // IVF_PQ m=32: stream16 layout for the staggered scan (pq_scan_v2.hip)
+    DevBuf d_list_blk_off2;
+    bool pq_v2 = false;
     // scratch
     mutable std::mutex mu;
     mutable std::map<void*, std::unique_ptr<Workspace>> ws_by_stream;
@@ -170,7 +173,7 @@ struct knhip_index {
 
     int64_t device_bytes() const {
         const DevBuf* all[] = {&centroids, &centroids_il, &cb, &precomp_t, &sq_trained, &d_list_len,
-                               &d_list_row_off, &d_list_blk_off, &ids, &rows};
+                               &d_list_row_off, &d_list_blk_off, &ids, &rows, &rows2, &d_list_blk_off2};
         int64_t t = 0;
         for (auto* b : all) {
             t += (int64_t)b->bytes;
@@ -350,6 +353,18 @@ int build_list_layout(knhip_index* idx, const std::vector<int64_t>& list_off, co
         HIP_TRY(launch_pq_skew_codes(d_codes, idx->d_list_row_off.as<int64_t>(),
                                      idx->d_list_len.as<int64_t>(), idx->d_list_blk_off.as<int64_t>(),
                                      nlist, M, idx->rows.as<uint4>(), nullptr));
+        const char* v1 = getenv("KNHIP_PQ_V1");
+        idx->pq_v2 = (M == 32) && !(v1 && v1[0] == '1');
+        if (idx->pq_v2) {
+            std::vector<int64_t> off2(nlist + 1, 0);
+            for (int64_t l = 0; l < nlist; l++) {
+                off2[l + 1] = off2[l] + pq_stream16_blocks(idx->h_list_len[l]);
+            }
+            if ((rc = upload(idx->d_list_blk_off2, off2.data(), (nlist + 1) * sizeof(int64_t)))) return rc;
+            HIP_TRY(idx->rows2.alloc((size_t)off2[nlist] * 64 * sizeof(uint4)));
+            HIP_TRY(launch_pq_stream16(d_codes, idx->d_list_row_off.as<int64_t>(), idx->d_list_len.as<int64_t>(),
+                                       idx->d_list_blk_off2.as<int64_t>(), nlist, idx->rows2.as<uint4>(), nullptr));
+        }
     } else if (kind == KNHIP_IVF_SQ8) {
         const int nchunk16 = (idx->d + 15) / 16;
         HIP_TRY(idx->rows.alloc((size_t)total_blk * nchunk16 * 64 * sizeof(uint4)));
@@ -532,7 +547,13 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         a.nslot = nprobe;
         a.k = k;
         StageTimer t(idx, s, KNHIP_STAGE_SCAN);
-        HIP_TRY(launch_pq_scan(a, is_l2, M, items_bound, s));
+        if (idx->pq_v2 && pq_scan_v2_supports(M, k)) {
+            a.codes_skew = idx->rows2.as<uint4>();
+            a.list_sblk_off = idx->d_list_blk_off2.as<int64_t>();
+            HIP_TRY(launch_pq_scan_v2(a, is_l2, items_bound, s));
+        } else {
+            HIP_TRY(launch_pq_scan(a, is_l2, M, items_bound, s));
+        }
     } else { // IVF_SQ8
         SqScanArgs a{};
         a.rows = idx->rows.as<uint4>();

@@ -1,0 +1,432 @@
+// knowhere_amd/csrc/pq_scan_v2.hip -- IVF-PQ ADC scan, M = 32, "lane-stationary staggered" form.
+//
+// Same contract and arithmetic as pq_scan.hip (dis = dis0 + (((0 + LUT[0][c0]) + LUT[1][c1]) ...) in m
+// order, bit-equal to PQCodeDistanceScalar, reference
+// thirdparty/faiss/faiss/impl/pq_code_distance/pq_code_distance-inl.h:69-90 and
+// IVFPQScanner_impl.h:147-150) but re-shaped around what the gfx950 issue rates actually are
+// (tools/ubench/valu_rates.hip, measured on MI355X): a VOP2 v_add_f32 issues every ~2 cycles per SIMD,
+// v_pk_add_f32 every ~4 (two adds), while the systolic kernel's DPP v_fmac (3.9), v_perm_b32 (3.6) and
+// v_cmp_e64 (3.6) made it VALU-issue bound at ~26 cycles per 128 lookups (rocprof: SQ_INSTS_VALU 6.5 per
+// step, VALU ~88 % busy).
+//
+// Here every lane OWNS one vector at a time and walks its 32 sub-quantizers in order m = 0..31, one per
+// step, accumulating privately -- nothing crosses lanes.  Lane l of a 32-lane half starts its vector l
+// steps late, so at any step the 32 lanes sit on 32 different m: with the LUT stored LUT[code][m][query]
+// (8-byte entries) they hit 32 different bank pairs -> still zero LDS bank conflicts.  In a 32-step window
+// lanes l <= j are already on the window's new vector, lanes l > j still finish the previous one; two
+// accumulator pairs (new / old) and an EXEC mask per step select which one receives the LUT pair:
+//     s_mov exec, {l <= j}   ; v_pk_add_f32 acc_new, acc_new, lut      (both queries in one instruction)
+//     s_not exec, exec       ; v_pk_add_f32 acc_old, acc_old, lut
+// At the end of a window acc_old holds a FINISHED sum in all 64 lanes (64 vectors x 2 queries): one
+// compare per query per window, candidates handled wave-parallel.  The LDS address of each lookup
+// (code << 8 | m << 3) depends only on (lane, step), so it is baked into the code stream at index build
+// time as a 16-bit value: the per-step address "computation" is one v_and / v_lshr.
+//
+// HBM layout of a list ("stream16"): the list is cut into groups of 64 vectors; lane L's stream is
+//   S_L[T] = (code[64 * e + L][m] << 8) | (m << 3),  e = (T - l) / 32,  m = (T - l) mod 32,  l = L mod 32
+// (zero before T = l and for vectors past the end), stored as blocks of 8 steps [T/8][64 lanes][8 x u16]:
+// one fully contiguous 1 KiB global_load_dwordx4 per wave per 8 steps.  A wave that owns groups [G0, G1)
+// runs windows G0 .. G1 (one extra window drains the stagger); the first window's "old" sums belong to
+// the previous wave and are ignored.
+//
+// Per-step budget (2 queries, 128 lookups): 1 VOP2 (address) + 2 v_pk_add_f32 + 1 ds_read_b64 (+3 SALU)
+// = ~10 VALU-issue cycles per SIMD and 2 LDS cycles per wave -- both near their limits at 4 waves/SIMD.
+#include "common.cuh"
+#include "kernels.h"
+
+#include <cstdlib>
+
+namespace knhip {
+
+constexpr int P2_KSUB = 256;
+constexpr int P2_M = 32;
+constexpr int P2_WAVES = 8;
+constexpr int P2_THREADS = P2_WAVES * KN_WAVE;
+
+typedef float p2_f32x2 __attribute__((ext_vector_type(2)));
+
+// ---- AoS codes [len][32] -> stream16 blocks ------------------------------------------------------
+// blocks of 8 steps: uint4 out[blk][lane]; block count per list = stream_blocks(len)
+__global__ void pq_stream16_kernel(const uint8_t* __restrict__ codes, const int64_t* __restrict__ list_row_off,
+                                   const int64_t* __restrict__ list_len,
+                                   const int64_t* __restrict__ list_sblk_off, int64_t nlist,
+                                   uint4* __restrict__ out) {
+    const int64_t l = blockIdx.y + (int64_t)blockIdx.z * gridDim.y;
+    if (l >= nlist) {
+        return;
+    }
+    const int64_t len = list_len[l];
+    const int64_t nblk = list_sblk_off[l + 1] - list_sblk_off[l];
+    const int64_t row_off = list_row_off[l];
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nblk * 64;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t blk = t / 64;
+        const int L = (int)(t % 64);
+        const int lo = L & 31;
+        uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            const int64_t T = blk * 8 + s;
+            uint32_t val = 0;
+            if (T >= lo) {
+                const int64_t e = (T - lo) / 32;
+                const int m = (int)((T - lo) % 32);
+                const int64_t v = e * 64 + L;
+                uint32_t code = 0;
+                if (v < len) {
+                    code = codes[(row_off + v) * P2_M + m];
+                }
+                val = (code << 8) | ((uint32_t)m << 3);
+            }
+            w[s >> 1] |= val << (16 * (s & 1));
+        }
+        out[(list_sblk_off[l] + blk) * 64 + L] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+int64_t pq_stream16_blocks(int64_t len) {
+    // 32 steps per group of 64 vectors + 31 stagger steps, in blocks of 8 steps, + one window of slack so
+    // that every wave's drain window and the prefetch of the window after it stay inside the list
+    const int64_t ngroups = (len + 63) / 64;
+    return (ngroups * 32 + 32) / 8 + 8;
+}
+
+// ---- 8 steps of accumulate, J0 = index of the first step inside the 32-step window ------------------
+// EXEC is restored to all-ones before the block ends; the compiler never sees it changed.
+#define P2_STEP(J, LUT)                                                   \
+    "s_mov_b32 exec_lo, " #J "\n\t"                                       \
+    "s_mov_b32 exec_hi, " #J "\n\t"                                       \
+    "v_pk_add_f32 %0, %0, " LUT "\n\t"                                    \
+    "s_not_b64 exec, exec\n\t"                                            \
+    "v_pk_add_f32 %1, %1, " LUT "\n\t"
+
+template <int Q>
+__device__ __forceinline__ void p2_accum8(p2_f32x2& an, p2_f32x2& ao, const p2_f32x2 (&v)[8]);
+
+template <>
+__device__ __forceinline__ void p2_accum8<0>(p2_f32x2& an, p2_f32x2& ao, const p2_f32x2 (&v)[8]) {
+    asm volatile(P2_STEP(0x1, "%2") P2_STEP(0x3, "%3") P2_STEP(0x7, "%4") P2_STEP(0xf, "%5")
+                 P2_STEP(0x1f, "%6") P2_STEP(0x3f, "%7") P2_STEP(0x7f, "%8") P2_STEP(0xff, "%9")
+                 "s_mov_b64 exec, -1\n\t"
+                 : "+v"(an), "+v"(ao)
+                 : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+}
+template <>
+__device__ __forceinline__ void p2_accum8<1>(p2_f32x2& an, p2_f32x2& ao, const p2_f32x2 (&v)[8]) {
+    asm volatile(P2_STEP(0x1ff, "%2") P2_STEP(0x3ff, "%3") P2_STEP(0x7ff, "%4") P2_STEP(0xfff, "%5")
+                 P2_STEP(0x1fff, "%6") P2_STEP(0x3fff, "%7") P2_STEP(0x7fff, "%8") P2_STEP(0xffff, "%9")
+                 "s_mov_b64 exec, -1\n\t"
+                 : "+v"(an), "+v"(ao)
+                 : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+}
+template <>
+__device__ __forceinline__ void p2_accum8<2>(p2_f32x2& an, p2_f32x2& ao, const p2_f32x2 (&v)[8]) {
+    asm volatile(P2_STEP(0x1ffff, "%2") P2_STEP(0x3ffff, "%3") P2_STEP(0x7ffff, "%4") P2_STEP(0xfffff, "%5")
+                 P2_STEP(0x1fffff, "%6") P2_STEP(0x3fffff, "%7") P2_STEP(0x7fffff, "%8") P2_STEP(0xffffff, "%9")
+                 "s_mov_b64 exec, -1\n\t"
+                 : "+v"(an), "+v"(ao)
+                 : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+}
+template <>
+__device__ __forceinline__ void p2_accum8<3>(p2_f32x2& an, p2_f32x2& ao, const p2_f32x2 (&v)[8]) {
+    asm volatile(P2_STEP(0x1ffffff, "%2") P2_STEP(0x3ffffff, "%3") P2_STEP(0x7ffffff, "%4")
+                 P2_STEP(0xfffffff, "%5") P2_STEP(0x1fffffff, "%6") P2_STEP(0x3fffffff, "%7")
+                 P2_STEP(0x7fffffff, "%8")
+                 // step 31: every lane is on the new vector
+                 "s_mov_b64 exec, -1\n\t"
+                 "v_pk_add_f32 %0, %0, %9\n\t"
+                 : "+v"(an), "+v"(ao)
+                 : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+}
+
+template <bool IS_L2>
+__device__ __forceinline__ float p2_prefilter(float kd, float dis0) {
+    const float slack = (fabsf(kd) + fabsf(dis0)) * 4.8e-7f + 1e-30f;
+    return IS_L2 ? (kd - dis0) + slack : (kd - dis0) - slack;
+}
+
+template <bool IS_L2, int R>
+__global__ __launch_bounds__(P2_THREADS, 4) void pq_scan_v2_kernel(PqScanArgs a) {
+    constexpr int QG = 2;
+    extern __shared__ __align__(16) unsigned char smem[];
+    float* lut = reinterpret_cast<float*>(smem); // [256][32][2]
+    const int lane = lane_id();
+    const int wave = threadIdx.x / KN_WAVE;
+
+    const int64_t nitems = *a.nitems_dev;
+    if ((int64_t)blockIdx.x >= ((nitems + 7) / 8) * 8) {
+        return;
+    }
+    const int64_t item = xcd_item(blockIdx.x, nitems);
+    if (item >= nitems) {
+        return;
+    }
+    const KnItem it = a.items[item];
+    const int npair = it.npair < QG ? it.npair : QG;
+    const int64_t list = it.list;
+    const int64_t len = a.list_len[list];
+    const int64_t sblk0 = a.list_sblk_off[list];
+    const int64_t row_off = a.list_row_off[list];
+    int32_t q_of[QG], slot_of[QG];
+    float dis0[QG];
+#pragma unroll
+    for (int j = 0; j < QG; j++) {
+        const KnPair p = a.pairs[it.pair0 + (j < npair ? j : npair - 1)];
+        q_of[j] = p.q;
+        slot_of[j] = p.slot;
+        dis0[j] = (a.lut_mode == PQ_LUT_RESIDUAL) ? 0.f : a.coarse_dis[(int64_t)p.q * a.nslot + p.slot];
+    }
+
+    // ---- LUT[code][m][query] in LDS -------------------------------------------------------------
+    if (a.lut_mode == PQ_LUT_RESIDUAL) {
+        const int dsub = a.d / P2_M;
+        const float* cl = a.centroids + list * a.d;
+        for (int e = threadIdx.x; e < P2_KSUB * P2_M; e += P2_THREADS) {
+            const int c = e / P2_M, m = e % P2_M;
+            const float* y = a.cb + ((int64_t)m * P2_KSUB + c) * dsub;
+#pragma unroll
+            for (int j = 0; j < QG; j++) {
+                const float* x = a.queries + (int64_t)q_of[j] * a.d + m * dsub;
+                float res = 0.f;
+                for (int i = 0; i < dsub; i++) {
+                    res = l2_step(res, fsub_x(x[i], cl[m * dsub + i]), y[i]);
+                }
+                lut[e * QG + j] = res;
+            }
+        }
+    } else {
+        // 2048 float4 slots, 512 threads: 4 per thread, all 12 loads issued before the first use
+        const bool pre = a.lut_mode == PQ_LUT_PRECOMP;
+        const float4* pt = reinterpret_cast<const float4*>(a.precomp_t + (pre ? list * (int64_t)(P2_KSUB * P2_M) : 0));
+        const float4* ta = reinterpret_cast<const float4*>(a.t2t + (int64_t)q_of[0] * (P2_KSUB * P2_M));
+        const float4* tb = reinterpret_cast<const float4*>(a.t2t + (int64_t)q_of[1] * (P2_KSUB * P2_M));
+        float4 xa[4], xb[4], pp[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int e4 = threadIdx.x + u * P2_THREADS;
+            xa[u] = ta[e4];
+            xb[u] = tb[e4];
+            pp[u] = pre ? pt[e4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float4* l4 = reinterpret_cast<float4*>(lut);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int e4 = threadIdx.x + u * P2_THREADS;
+            float4 A = xa[u], B = xb[u];
+            if (pre) {
+                const float4 p = pp[u];
+                A.x = fadd_x(p.x, fmul_x(-2.0f, A.x)); B.x = fadd_x(p.x, fmul_x(-2.0f, B.x));
+                A.y = fadd_x(p.y, fmul_x(-2.0f, A.y)); B.y = fadd_x(p.y, fmul_x(-2.0f, B.y));
+                A.z = fadd_x(p.z, fmul_x(-2.0f, A.z)); B.z = fadd_x(p.z, fmul_x(-2.0f, B.z));
+                A.w = fadd_x(p.w, fmul_x(-2.0f, A.w)); B.w = fadd_x(p.w, fmul_x(-2.0f, B.w));
+            }
+            l4[e4 * 2 + 0] = make_float4(A.x, B.x, A.y, B.y);
+            l4[e4 * 2 + 1] = make_float4(A.z, B.z, A.w, B.w);
+        }
+    }
+    __syncthreads();
+    if ((uint32_t)(size_t)((__attribute__((address_space(3))) unsigned char*)smem) != 0u) {
+        __builtin_trap(); // the baked 16-bit addresses assume the LUT at LDS offset 0
+    }
+
+    // ---- this wave's groups --------------------------------------------------------------------------
+    const int64_t ngroups = (len + 63) / 64;
+    const int64_t gpw = (ngroups + P2_WAVES - 1) / P2_WAVES;
+    const int64_t G0 = (int64_t)wave * gpw;
+    const int64_t G1 = min(G0 + gpw, ngroups);
+    const int64_t nwin = G1 > G0 ? (G1 - G0 + 1) : 0; // one extra window drains the stagger
+
+    WaveTopK<IS_L2, R, int32_t> top[QG];
+    float kd[QG], pre[QG], gt[QG];
+    int32_t ki[QG];
+#pragma unroll
+    for (int j = 0; j < QG; j++) {
+        top[j].init(a.k);
+        kd[j] = worst_dist<IS_L2>();
+        ki[j] = -1;
+        gt[j] = gthr_load<IS_L2>(a.gthr + q_of[j]);
+        pre[j] = p2_prefilter<IS_L2>(tighter<IS_L2>(kd[j], gt[j]), dis0[j]);
+    }
+
+    typedef __attribute__((address_space(3))) const p2_f32x2 lds_f2;
+    auto lut_read = [&](uint32_t word, int half) -> p2_f32x2 {
+        const uint32_t addr = half ? (word >> 16) : (word & 0xffffu);
+        return *reinterpret_cast<lds_f2*>(addr);
+    };
+    // 8 lookups of one code block (uint4 = 8 x u16 addresses)
+    auto issue8 = [&](const uint4 w, p2_f32x2 (&v)[8]) {
+        v[0] = lut_read(w.x, 0); v[1] = lut_read(w.x, 1);
+        v[2] = lut_read(w.y, 0); v[3] = lut_read(w.y, 1);
+        v[4] = lut_read(w.z, 0); v[5] = lut_read(w.z, 1);
+        v[6] = lut_read(w.w, 0); v[7] = lut_read(w.w, 1);
+    };
+
+    if (nwin > 0) {
+        const uint4* cbase = a.codes_skew + (sblk0 + G0 * 4) * 64 + lane; // 4 blocks of 8 steps per window
+        auto load_blk = [&](int64_t b) { return cbase[b * 64]; };      // past-the-end blocks exist (slack)
+        p2_f32x2 an = {0.f, 0.f}, ao = {0.f, 0.f};
+        p2_f32x2 va[8], vb[8];
+        uint4 c0 = load_blk(0), c1 = load_blk(1), c2 = load_blk(2), c3 = load_blk(3);
+        issue8(c0, va);
+        for (int64_t w = 0; w < nwin; w++) {
+            // thresholds published by other waves meanwhile (consumed at the end of this window)
+            float gnext[QG];
+#pragma unroll
+            for (int qi = 0; qi < QG; qi++) {
+                gnext[qi] = gthr_load<IS_L2>(a.gthr + q_of[qi]);
+            }
+            // code blocks of the next window (requested 32 steps before their first lookup)
+            const uint4 n0 = load_blk(4 * w + 4), n1 = load_blk(4 * w + 5), n2 = load_blk(4 * w + 6),
+                        n3 = load_blk(4 * w + 7);
+            issue8(c1, vb);
+            __builtin_amdgcn_sched_barrier(0);
+            p2_accum8<0>(an, ao, va);
+            __builtin_amdgcn_sched_barrier(0);
+            issue8(c2, va);
+            __builtin_amdgcn_sched_barrier(0);
+            p2_accum8<1>(an, ao, vb);
+            __builtin_amdgcn_sched_barrier(0);
+            issue8(c3, vb);
+            __builtin_amdgcn_sched_barrier(0);
+            p2_accum8<2>(an, ao, va);
+            __builtin_amdgcn_sched_barrier(0);
+            issue8(n0, va); // first block of the next window
+            __builtin_amdgcn_sched_barrier(0);
+            p2_accum8<3>(an, ao, vb);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- window end: ao = finished sums of group G0 + w - 1 in every lane ------------------
+#pragma unroll
+            for (int qi = 0; qi < QG; qi++) {
+                gt[qi] = tighter<IS_L2>(gt[qi], gnext[qi]);
+                pre[qi] = p2_prefilter<IS_L2>(tighter<IS_L2>(kd[qi], gt[qi]), dis0[qi]);
+            }
+            if (w > 0) {
+                const int64_t vbase = (G0 + w - 1) * 64;
+                const bool valid = vbase + lane < len;
+#pragma unroll
+                for (int qi = 0; qi < QG; qi++) {
+                    const float o = qi == 0 ? ao.x : ao.y;
+                    unsigned long long mm = __ballot(valid && (IS_L2 ? (o <= pre[qi]) : (o >= pre[qi])));
+                    if (mm != 0 && qi < npair) {
+                        bool tightened = false;
+                        while (mm) {
+                            const int l = __ffsll((long long)mm) - 1;
+                            mm &= mm - 1;
+                            const int32_t v = (int32_t)(vbase + l);
+                            const float dis = fadd_x(dis0[qi], readlane_f(o, l));
+                            if (!within_gthr<IS_L2>(dis, gt[qi]) || !top[qi].admits(dis, v, kd[qi], ki[qi])) {
+                                continue;
+                            }
+                            if (a.bitset != nullptr &&
+                                bitset_filtered(a.bitset, a.bitset_nbits, a.ids[row_off + v])) {
+                                continue;
+                            }
+                            top[qi].insert(dis, v);
+                            kd[qi] = top[qi].kth_dist();
+                            ki[qi] = top[qi].kth_idx();
+                            tightened = true;
+                        }
+                        if (tightened && ki[qi] >= 0 && lane == 0) {
+                            gthr_publish<IS_L2>(a.gthr + q_of[qi], kd[qi]);
+                        }
+                        pre[qi] = p2_prefilter<IS_L2>(tighter<IS_L2>(kd[qi], gt[qi]), dis0[qi]);
+                    }
+                }
+            }
+            ao = an;
+            an = p2_f32x2{0.f, 0.f};
+            c1 = n1;
+            c2 = n2;
+            c3 = n3;
+        }
+    }
+
+    // ---- merge the waves' lists; wave qi finishes query qi ---------------------------------------------
+    __syncthreads(); // LUT is dead
+    const int k = a.k;
+    float* md = reinterpret_cast<float*>(smem);
+    int64_t* mi = reinterpret_cast<int64_t*>(smem + (((size_t)QG * P2_WAVES * k * 4 + 7) & ~(size_t)7));
+#pragma unroll
+    for (int qi = 0; qi < QG; qi++) {
+        top[qi].store(md + (qi * P2_WAVES + wave) * k, mi + (qi * P2_WAVES + wave) * k);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int qi = 0; qi < QG; qi++) {
+        if (qi < npair && wave == qi) {
+            for (int w = 1; w < P2_WAVES; w++) {
+                const int ow = (wave + w) % P2_WAVES;
+                const float* od = md + (qi * P2_WAVES + ow) * k;
+                const int64_t* oi = mi + (qi * P2_WAVES + ow) * k;
+                for (int e = 0; e < k; e++) {
+                    const float cd = od[e];
+                    const int32_t ci = (int32_t)oi[e];
+                    if (ci < 0 || !top[qi].admits(cd, ci, kd[qi], ki[qi])) {
+                        break;
+                    }
+                    top[qi].insert(cd, ci);
+                    kd[qi] = top[qi].kth_dist();
+                    ki[qi] = top[qi].kth_idx();
+                }
+            }
+            if (ki[qi] >= 0 && lane == 0) {
+                gthr_publish<IS_L2>(a.gthr + q_of[qi], kd[qi]);
+            }
+            float* pd = a.partial_d + ((int64_t)q_of[qi] * a.nslot + slot_of[qi]) * k;
+            int64_t* pi = a.partial_i + ((int64_t)q_of[qi] * a.nslot + slot_of[qi]) * k;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int e = r * KN_WAVE + lane;
+                if (e < k) {
+                    const int64_t pos = (int64_t)top[qi].i[r];
+                    pd[e] = top[qi].d[r];
+                    pi[e] = pos >= 0 ? a.ids[row_off + pos] : -1;
+                }
+            }
+        }
+    }
+}
+
+template <bool IS_L2, int R>
+static hipError_t launch_v2_r(const PqScanArgs& a, int64_t grid, hipStream_t s) {
+    const size_t lut_bytes = (size_t)P2_KSUB * 256;
+    const size_t merge_bytes = (((size_t)2 * P2_WAVES * a.k * 4 + 7) & ~(size_t)7) + (size_t)2 * P2_WAVES * a.k * 8;
+    const size_t sm = std::max(lut_bytes, merge_bytes);
+    auto kern = pq_scan_v2_kernel<IS_L2, R>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)sm);
+    if (e != hipSuccess) {
+        return e;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(P2_THREADS), sm, s, a);
+    return hipGetLastError();
+}
+
+// k <= 128 only (R = 1, 2); larger k stays on the systolic kernel and its layout
+bool pq_scan_v2_supports(int M, int k) {
+    return M == P2_M && k <= 128;
+}
+
+hipError_t launch_pq_scan_v2(const PqScanArgs& a, bool is_l2, int64_t grid, hipStream_t s) {
+    if (grid <= 0) {
+        return hipSuccess;
+    }
+    if (a.k <= 64) {
+        return is_l2 ? launch_v2_r<true, 1>(a, grid, s) : launch_v2_r<false, 1>(a, grid, s);
+    }
+    return is_l2 ? launch_v2_r<true, 2>(a, grid, s) : launch_v2_r<false, 2>(a, grid, s);
+}
+
+hipError_t launch_pq_stream16(const uint8_t* codes, const int64_t* list_row_off, const int64_t* list_len,
+                              const int64_t* list_sblk_off, int64_t nlist, uint4* out, hipStream_t s) {
+    if (nlist <= 0) {
+        return hipSuccess;
+    }
+    const unsigned gy = (unsigned)std::min<int64_t>(nlist, 32768);
+    const unsigned gz = (unsigned)((nlist + gy - 1) / gy);
+    hipLaunchKernelGGL(pq_stream16_kernel, dim3(8, gy, gz), dim3(256), 0, s, codes, list_row_off, list_len,
+                       list_sblk_off, nlist, out);
+    return hipGetLastError();
+}
+
+} // namespace knhip
