@@ -177,7 +177,7 @@ def main():
     achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     roofline = {"bound": "hbm", "kernel": "pq_scan_kernel<L2,M=32,QG=2>", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "traffic": None,  # PMC FETCH_SIZE pass: see profiles/ (rocprofv3 --pmc, separate run)
+                "traffic": pmc_traffic(a, world),
                 "algorithmic_bytes_per_launch": scan_bytes, "ms_per_launch": round(scan_ms, 3),
                 "stage_ms_per_step": {n: round(prof["ms"][i] / a.steps, 3) for i, n in
                                       enumerate(["coarse", "group", "lut", "scan", "merge"])}}
@@ -206,6 +206,19 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(a, world):
+    """HBM bytes per launch of the scan kernel from the PMC counters.  Counters cannot be collected
+    inside a timed run: they come from separate rocprofv3 --pmc passes of this same command
+    (tools/profile_bench.sh), stored under profiles/; returned only if the workload matches."""
+    path = os.path.join(ROOT, "profiles", "bench_pmc_traffic.json")
+    try:
+        t = json.load(open(path))
+    except Exception:
+        return None
+    key = f"nb={a.nb},nlist={a.nlist},nprobe={a.nprobe},nq={a.nq},m={a.m},refine_k={a.refine_k},gpus={world}"
+    return t.get(key, {}).get("hbm_bytes_per_launch")
 
 
 def cpu_baseline(a, built, vectors, xq, I_gpu, log):

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libknhip.so")
+LIB_PATH = os.environ.get("KNHIP_LIB") or os.path.join(_HERE, "libknhip.so")  # KNHIP_LIB: experiments only
 
 BRUTE_FORCE, IVF_FLAT, IVF_PQ, IVF_SQ8 = 0, 1, 2, 3
 L2, IP = 0, 1

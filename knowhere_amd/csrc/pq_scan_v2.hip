@@ -93,12 +93,21 @@ int64_t pq_stream16_blocks(int64_t len) {
 
 // ---- 8 steps of accumulate, J0 = index of the first step inside the 32-step window ------------------
 // EXEC is restored to all-ones before the block ends; the compiler never sees it changed.
+#ifndef P2_ABLATE
+#define P2_ABLATE 0
+#endif
+#if P2_ABLATE == 1 /* timing experiment only (wrong results): no EXEC flips */
+#define P2_STEP(J, LUT)                                                   \
+    "v_pk_add_f32 %0, %0, " LUT "\n\t"                                    \
+    "v_pk_add_f32 %1, %1, " LUT "\n\t"
+#else
 #define P2_STEP(J, LUT)                                                   \
     "s_mov_b32 exec_lo, " #J "\n\t"                                       \
     "s_mov_b32 exec_hi, " #J "\n\t"                                       \
     "v_pk_add_f32 %0, %0, " LUT "\n\t"                                    \
     "s_not_b64 exec, exec\n\t"                                            \
     "v_pk_add_f32 %1, %1, " LUT "\n\t"
+#endif
 
 template <int Q>
 __device__ __forceinline__ void p2_accum8(p2_f32x2& an, p2_f32x2& ao, const p2_f32x2 (&v)[8]);
@@ -251,7 +260,11 @@ __global__ __launch_bounds__(P2_THREADS, 4) void pq_scan_v2_kernel(PqScanArgs a)
     typedef __attribute__((address_space(3))) const p2_f32x2 lds_f2;
     auto lut_read = [&](uint32_t word, int half) -> p2_f32x2 {
         const uint32_t addr = half ? (word >> 16) : (word & 0xffffu);
+#if P2_ABLATE == 2 /* timing experiment only (wrong results): no LDS lookups */
+        return p2_f32x2{__uint_as_float(addr), __uint_as_float(addr + 1)};
+#else
         return *reinterpret_cast<lds_f2*>(addr);
+#endif
     };
     // 8 lookups of one code block (uint4 = 8 x u16 addresses)
     auto issue8 = [&](const uint4 w, p2_f32x2 (&v)[8]) {

@@ -313,3 +313,70 @@ def test_gpu_builder_index_parity_and_recall(torch_cuda, port):
     rec = (Ir.unsqueeze(2) == gt.unsqueeze(1)).any(2).float().mean().item()
     assert rec > 0.6, rec  # sanity floor (reference floors: tests/ut/test_gpu_search.cc:179-187)
     g.close()
+
+
+def test_config_shapes_ivfsq8_ip_d768_and_ivfflat_d128(torch_cuda, port):
+    # BASELINE.json configs[4] (IVF-SQ8 IP, d=768) and configs[1] (IVF-Flat L2, d=128) at sizes the
+    # oracle finishes in seconds; "int8" inputs in Knowhere are converted to fp32 and SQ8-trained
+    # (reference include/knowhere/index/index_factory.h:144-145, index_node_data_mock_wrapper.cc:55-61)
+    r = np.random.default_rng(5)
+    xb = r.integers(-128, 128, (6000, 768)).astype(np.float32)
+    xq = r.integers(-128, 128, (25, 768)).astype(np.float32)
+    ix = ob.make_index(port, ob.IVF_SQ8, ob.IP, xb, nlist=48)
+    g = _gpu(ix)
+    for k, nprobe in ((10, 16), (100, 48)):
+        Do, Io = port.search(ix, xq, k, nprobe)
+        D, I = g.search(xq, k, nprobe)
+        assert_parity(Do, Io, D, I, ob.IP, f"SQ8 IP d=768 k={k}")
+    g.close()
+    xb, xq = gen_data(60000, 128, 42), gen_data(64, 128, 44)
+    ix = ob.make_index(port, ob.IVF_FLAT, ob.L2, xb, nlist=128)
+    g = _gpu(ix)
+    Do, Io = port.search(ix, xq, 10, 64)
+    D, I = g.search(xq, 10, 64)
+    assert_parity(Do, Io, D, I, ob.L2, "IVF-Flat L2 d=128 nprobe=64")
+    g.close()
+
+
+def test_scale_properties_ivfpq_1m(torch_cuda):
+    # size-independent properties at a size the oracle cannot run (1M x 128, nlist 1024):
+    # (1) list-sharded search + merge == monolithic, bit for bit; (2) results sorted and ids unique;
+    # (3) a bitset that removes the current top-1 makes the old top-2 the new top-1
+    torch = torch_cuda
+    from knowhere_amd import build as kb
+    from knowhere_amd import index as kidx
+    from knowhere_amd.index import merge_topk_device
+    spec = kb.DataSpec(1_000_000, 128, ncenter=8192)
+    built = kb.build_ivf(spec, kidx.IVF_PQ, kidx.L2, nlist=1024, M=32)
+    xq = kb.queries(spec, 2000, "cuda:0")
+    g = built.to_gpu_index()
+    D, I = g.search_device(xq, 10, 32)
+    torch.cuda.synchronize()
+    assert (D[:, 1:] >= D[:, :-1]).all()
+    assert all(len(set(r.tolist())) == 10 for r in I[:200].cpu())
+    parts = []
+    for r in range(3):
+        own = (np.arange(1024) % 3) == r
+        gs = built.to_gpu_index(owned_lists=own)
+        parts.append(gs.search_device(xq, 10, 32))
+        torch.cuda.synchronize()
+        gs.close()
+    Dm, Im = merge_topk_device(kidx.L2, torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
+    torch.cuda.synchronize()
+    assert torch.equal(Dm, D) and torch.equal(Im, I)
+    nbits = 1_000_000
+    top1 = I[:, 0].clone()
+    bsh = np.zeros((nbits + 7) // 8, np.uint8)
+    for t in top1.cpu().numpy():
+        bsh[t >> 3] |= 1 << (t & 7)
+    D2, I2 = g.search_device(xq, 10, 32, bitset_t=torch.from_numpy(bsh).cuda(), nbits=nbits)
+    torch.cuda.synchronize()
+    removed = set(top1.cpu().numpy().tolist())
+    I2c = I2.cpu().numpy()
+    assert not any(int(i) in removed for i in I2c.ravel() if i >= 0)
+    Ic = I.cpu().numpy()
+    for q in range(0, 2000, 97):  # first surviving old result is the new top-1
+        surv = [i for i in Ic[q] if int(i) not in removed]
+        if surv:
+            assert I2c[q, 0] == surv[0]
+    g.close()
