@@ -80,6 +80,12 @@ struct PqScanArgs {
     float* gthr;                   // [nq] shared per-query threshold
     int32_t nslot;                 // = nprobe
     int32_t k;
+    // work-item range [*item_lo, *item_hi) of this launch (device scalars; item_lo may be null = 0)
+    const int64_t* item_lo;
+    const int64_t* item_hi;
+    // rank-0 "dump" phase (pq_scan_v2.hip): every finished distance goes to dump[q * dump_stride + offset]
+    float* dump;
+    int64_t dump_stride;
 };
 
 
@@ -134,7 +140,12 @@ hipError_t launch_pq_skew_codes(const uint8_t* codes, const int64_t* list_row_of
 // ---- pq_scan_v2.hip (M = 32, k <= 128: lane-stationary staggered ADC on the stream16 layout) ----
 bool pq_scan_v2_supports(int M, int k);
 int64_t pq_stream16_blocks(int64_t len);
-hipError_t launch_pq_scan_v2(const PqScanArgs& a, bool is_l2, int64_t grid, hipStream_t s);
+hipError_t launch_pq_scan_v2(const PqScanArgs& a, bool is_l2, bool dump, int64_t grid, hipStream_t s);
+// rank-0 phase epilogue: per query, top-k of its dumped closest list -> partial slot 0 + shared threshold
+hipError_t launch_rank0_select(const float* dump, int64_t dump_stride, const int64_t* keys, int nprobe,
+                               const int64_t* list_len, const int64_t* list_row_off, const int64_t* ids,
+                               int64_t nq, int k, bool is_l2, float* partial_d, int64_t* partial_i, float* gthr,
+                               int64_t* tmp_keys, float* tmp_d, hipStream_t s);
 hipError_t launch_pq_stream16(const uint8_t* codes, const int64_t* list_row_off, const int64_t* list_len,
                               const int64_t* list_sblk_off, int64_t nlist, uint4* out, hipStream_t s);
 
@@ -170,6 +181,10 @@ hipError_t launch_merge_partials(const float* partial_d, const int64_t* partial_
 // per row: the k best of n values (index = column), canonical order; out_keys int64, out_d float
 hipError_t launch_row_select(const float* vals, int64_t nrows, int64_t n, int k, bool is_l2,
                              int64_t* out_keys, float* out_d, const int32_t* row_flags, hipStream_t s);
+// rows of different length: row r has n = list_len[keys[r * key_stride]] values at vals + r * stride
+hipError_t launch_row_select_var(const float* vals, int64_t stride, const int64_t* keys, int key_stride,
+                                 const int64_t* list_len, int64_t nrows, int k, bool is_l2, int64_t* out_keys,
+                                 float* out_d, hipStream_t s);
 size_t row_select_max_k();
 
 // ---- coarse_gemm.hip: fp32 MFMA prefilter for the coarse quantizer ----

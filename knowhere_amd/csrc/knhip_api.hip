@@ -113,6 +113,9 @@ struct Workspace {
     DevBuf cand_keys;    // [qb][ncand]
     DevBuf cand_approx;  // [qb][ncand]
     DevBuf fail_flags;   // [qb] coarse certificate failed -> exact fallback
+    DevBuf dump;         // [qb][max list len] rank-0 phase distances (pq_scan_v2 DUMP)
+    DevBuf sel_keys;     // [qb][k]
+    DevBuf sel_d;        // [qb][k]
     DevBuf list_count, list_pair_off, list_item_off, list_cursor, pairs, items, nitems;
     // host-boundary staging
     DevBuf h_queries, h_bitset, h_out_d, h_out_i;
@@ -159,6 +162,8 @@ struct knhip_index {
     DevBuf rows2;         // IVF_PQ m=32: stream16 layout for the staggered scan (pq_scan_v2.hip)
     DevBuf d_list_blk_off2;
     bool pq_v2 = false;
+    bool rank0_select = true;  // KNHIP_RANK0=0 switches the dump + radix-select phase off
+    int64_t max_list_len = 0;
     // scratch
     mutable std::mutex mu;
     mutable std::map<void*, std::unique_ptr<Workspace>> ws_by_stream;
@@ -314,8 +319,14 @@ int build_list_layout(knhip_index* idx, const std::vector<int64_t>& list_off, co
     idx->ntotal = ntotal;
     idx->h_list_len.resize(nlist);
     idx->h_list_row_off.assign(list_off.begin(), list_off.begin() + nlist);
+    idx->max_list_len = 0;
+    {
+        const char* e = getenv("KNHIP_RANK0");
+        idx->rank0_select = !(e && e[0] == '0');
+    }
     for (int64_t l = 0; l < nlist; l++) {
         idx->h_list_len[l] = list_off[l + 1] - list_off[l];
+        idx->max_list_len = std::max(idx->max_list_len, idx->h_list_len[l]);
         if (idx->h_list_len[l] < 0) {
             return fail(KNHIP_ERR_INVALID_ARGS, "list offsets must be non-decreasing");
         }
@@ -550,7 +561,29 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         if (idx->pq_v2 && pq_scan_v2_supports(M, k)) {
             a.codes_skew = idx->rows2.as<uint4>();
             a.list_sblk_off = idx->d_list_blk_off2.as<int64_t>();
-            HIP_TRY(launch_pq_scan_v2(a, is_l2, items_bound, s));
+            a.item_hi = wt.nitems;
+            const int64_t stride = round_up(std::max<int64_t>(idx->max_list_len, 64), 64);
+            if (idx->rank0_select && (double)nq * stride * 4.0 <= 6.0e9) {
+                // phase A: the rank-0 probe of every query (work items of virtual lists [0, nlist) come
+                // first: worktable.hip) in dump mode, then radix select -> partial slot 0 + thresholds
+                HIP_TRY(ws->dump.reserve((size_t)nq * stride * sizeof(float)));
+                HIP_TRY(ws->sel_keys.reserve((size_t)nq * k * sizeof(int64_t)));
+                HIP_TRY(ws->sel_d.reserve((size_t)nq * k * sizeof(float)));
+                a.dump = ws->dump.as<float>();
+                a.dump_stride = stride;
+                a.item_lo = nullptr;
+                a.item_hi = wt.list_item_off + nlist; // items of the rank-0 virtual lists
+                const int64_t boundA = round_up(nq / qg + std::min<int64_t>(nlist, nq) + 1, 8);
+                HIP_TRY(launch_pq_scan_v2(a, is_l2, true, boundA, s));
+                HIP_TRY(launch_rank0_select(a.dump, stride, ws->keys.as<int64_t>(), nprobe,
+                                            idx->d_list_len.as<int64_t>(), idx->d_list_row_off.as<int64_t>(),
+                                            idx->ids.as<int64_t>(), nq, k, is_l2, a.partial_d, a.partial_i, a.gthr,
+                                            ws->sel_keys.as<int64_t>(), ws->sel_d.as<float>(), s));
+                // phase B: every other probe
+                a.item_lo = wt.list_item_off + nlist;
+                a.item_hi = wt.nitems;
+            }
+            HIP_TRY(launch_pq_scan_v2(a, is_l2, false, items_bound, s));
         } else {
             HIP_TRY(launch_pq_scan(a, is_l2, M, items_bound, s));
         }

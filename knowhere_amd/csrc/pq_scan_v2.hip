@@ -40,7 +40,10 @@ namespace knhip {
 
 constexpr int P2_KSUB = 256;
 constexpr int P2_M = 32;
-constexpr int P2_WAVES = 8;
+#ifndef P2_NWAVES
+#define P2_NWAVES 8
+#endif
+constexpr int P2_WAVES = P2_NWAVES;
 constexpr int P2_THREADS = P2_WAVES * KN_WAVE;
 
 typedef float p2_f32x2 __attribute__((ext_vector_type(2)));
@@ -154,23 +157,29 @@ __device__ __forceinline__ float p2_prefilter(float kd, float dis0) {
     return IS_L2 ? (kd - dis0) + slack : (kd - dis0) - slack;
 }
 
-template <bool IS_L2, int R>
-__global__ __launch_bounds__(P2_THREADS, 4) void pq_scan_v2_kernel(PqScanArgs a) {
+// DUMP = true: rank-0 phase.  No top-k is kept: every finished distance of the list is written to
+// a.dump (row = query, column = offset inside the list) and a radix select picks the k best afterwards
+// (launch_rank0_select) -- selecting k of a whole list by sorted insertion is what made k = 100 cost
+// twice k = 10 (tools ablation).  The selection also seeds the shared threshold before
+// the bulk scan of the remaining probes starts.
+template <bool IS_L2, int R, bool DUMP>
+__global__ __launch_bounds__(P2_THREADS, (P2_NWAVES >= 8 ? 4 : 2)) void pq_scan_v2_kernel(PqScanArgs a) {
     constexpr int QG = 2;
     extern __shared__ __align__(16) unsigned char smem[];
     float* lut = reinterpret_cast<float*>(smem); // [256][32][2]
     const int lane = lane_id();
     const int wave = threadIdx.x / KN_WAVE;
 
-    const int64_t nitems = *a.nitems_dev;
+    const int64_t item_lo = a.item_lo ? *a.item_lo : 0;
+    const int64_t nitems = *a.item_hi - item_lo;
     if ((int64_t)blockIdx.x >= ((nitems + 7) / 8) * 8) {
         return;
     }
-    const int64_t item = xcd_item(blockIdx.x, nitems);
-    if (item >= nitems) {
+    const int64_t item_rel = xcd_item(blockIdx.x, nitems);
+    if (item_rel >= nitems) {
         return;
     }
-    const KnItem it = a.items[item];
+    const KnItem it = a.items[item_lo + item_rel];
     const int npair = it.npair < QG ? it.npair : QG;
     const int64_t list = it.list;
     const int64_t len = a.list_len[list];
@@ -209,17 +218,22 @@ __global__ __launch_bounds__(P2_THREADS, 4) void pq_scan_v2_kernel(PqScanArgs a)
         const float4* pt = reinterpret_cast<const float4*>(a.precomp_t + (pre ? list * (int64_t)(P2_KSUB * P2_M) : 0));
         const float4* ta = reinterpret_cast<const float4*>(a.t2t + (int64_t)q_of[0] * (P2_KSUB * P2_M));
         const float4* tb = reinterpret_cast<const float4*>(a.t2t + (int64_t)q_of[1] * (P2_KSUB * P2_M));
-        float4 xa[4], xb[4], pp[4];
+        constexpr int NU = (P2_KSUB * P2_M / 4) / P2_THREADS;
+        float4 xa[NU], xb[NU], pp[NU];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < NU; u++) {
             const int e4 = threadIdx.x + u * P2_THREADS;
+#if P2_ABLATE == 4 /* timing experiment only: no table loads */
+            xa[u] = xb[u] = pp[u] = make_float4(1.f, 2.f, 3.f, (float)e4);
+#else
             xa[u] = ta[e4];
             xb[u] = tb[e4];
             pp[u] = pre ? pt[e4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
         }
         float4* l4 = reinterpret_cast<float4*>(lut);
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < NU; u++) {
             const int e4 = threadIdx.x + u * P2_THREADS;
             float4 A = xa[u], B = xb[u];
             if (pre) {
@@ -313,7 +327,23 @@ __global__ __launch_bounds__(P2_THREADS, 4) void pq_scan_v2_kernel(PqScanArgs a)
                 gt[qi] = tighter<IS_L2>(gt[qi], gnext[qi]);
                 pre[qi] = p2_prefilter<IS_L2>(tighter<IS_L2>(kd[qi], gt[qi]), dis0[qi]);
             }
-            if (w > 0) {
+            if (DUMP) {
+                if (w > 0) {
+                    const int64_t vbase = (G0 + w - 1) * 64;
+                    if (vbase + lane < len) {
+                        const bool filt = a.bitset != nullptr &&
+                                bitset_filtered(a.bitset, a.bitset_nbits, a.ids[row_off + vbase + lane]);
+#pragma unroll
+                        for (int qi = 0; qi < QG; qi++) {
+                            if (qi < npair) {
+                                const float o = qi == 0 ? ao.x : ao.y;
+                                a.dump[(int64_t)q_of[qi] * a.dump_stride + vbase + lane] =
+                                        filt ? worst_dist<IS_L2>() : fadd_x(dis0[qi], o);
+                            }
+                        }
+                    }
+                }
+            } else if (w > 0 && P2_ABLATE != 3) {
                 const int64_t vbase = (G0 + w - 1) * 64;
                 const bool valid = vbase + lane < len;
 #pragma unroll
@@ -354,6 +384,9 @@ __global__ __launch_bounds__(P2_THREADS, 4) void pq_scan_v2_kernel(PqScanArgs a)
         }
     }
 
+    if (DUMP) {
+        return;
+    }
     // ---- merge the waves' lists; wave qi finishes query qi ---------------------------------------------
     __syncthreads(); // LUT is dead
     const int k = a.k;
@@ -400,12 +433,12 @@ __global__ __launch_bounds__(P2_THREADS, 4) void pq_scan_v2_kernel(PqScanArgs a)
     }
 }
 
-template <bool IS_L2, int R>
+template <bool IS_L2, int R, bool DUMP>
 static hipError_t launch_v2_r(const PqScanArgs& a, int64_t grid, hipStream_t s) {
     const size_t lut_bytes = (size_t)P2_KSUB * 256;
     const size_t merge_bytes = (((size_t)2 * P2_WAVES * a.k * 4 + 7) & ~(size_t)7) + (size_t)2 * P2_WAVES * a.k * 8;
-    const size_t sm = std::max(lut_bytes, merge_bytes);
-    auto kern = pq_scan_v2_kernel<IS_L2, R>;
+    const size_t sm = DUMP ? lut_bytes : std::max(lut_bytes, merge_bytes);
+    auto kern = pq_scan_v2_kernel<IS_L2, R, DUMP>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)sm);
     if (e != hipSuccess) {
@@ -420,14 +453,67 @@ bool pq_scan_v2_supports(int M, int k) {
     return M == P2_M && k <= 128;
 }
 
-hipError_t launch_pq_scan_v2(const PqScanArgs& a, bool is_l2, int64_t grid, hipStream_t s) {
+hipError_t launch_pq_scan_v2(const PqScanArgs& a, bool is_l2, bool dump, int64_t grid, hipStream_t s) {
     if (grid <= 0) {
         return hipSuccess;
     }
-    if (a.k <= 64) {
-        return is_l2 ? launch_v2_r<true, 1>(a, grid, s) : launch_v2_r<false, 1>(a, grid, s);
+    if (dump) {
+        return is_l2 ? launch_v2_r<true, 1, true>(a, grid, s) : launch_v2_r<false, 1, true>(a, grid, s);
     }
-    return is_l2 ? launch_v2_r<true, 2>(a, grid, s) : launch_v2_r<false, 2>(a, grid, s);
+    if (a.k <= 64) {
+        return is_l2 ? launch_v2_r<true, 1, false>(a, grid, s) : launch_v2_r<false, 1, false>(a, grid, s);
+    }
+    return is_l2 ? launch_v2_r<true, 2, false>(a, grid, s) : launch_v2_r<false, 2, false>(a, grid, s);
+}
+
+// ---- rank-0 epilogue: list offsets -> ids, partial slot 0, shared threshold -------------------------------
+template <bool IS_L2>
+__global__ void rank0_finalize_kernel(const int64_t* __restrict__ sel_off, const float* __restrict__ sel_d,
+                                      const int64_t* __restrict__ keys, int nprobe,
+                                      const int64_t* __restrict__ list_row_off, const int64_t* __restrict__ ids,
+                                      int64_t nq, int k, float* __restrict__ partial_d,
+                                      int64_t* __restrict__ partial_i, float* __restrict__ gthr) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nq * k) {
+        return;
+    }
+    const int64_t q = t / k;
+    const int e = (int)(t % k);
+    const int64_t key = keys[q * nprobe];
+    int64_t off = sel_off[t];
+    float d = sel_d[t];
+    // a dumped sentinel (filtered vector) must not surface as a result
+    if (off >= 0 && (IS_L2 ? !(d < worst_dist<IS_L2>()) : !(d > worst_dist<IS_L2>()))) {
+        off = -1;
+    }
+    const int64_t id = (off >= 0 && key >= 0) ? ids[list_row_off[key] + off] : -1;
+    partial_d[(q * nprobe + 0) * k + e] = id >= 0 ? d : worst_dist<IS_L2>();
+    partial_i[(q * nprobe + 0) * k + e] = id;
+    if (e == k - 1 && id >= 0) {
+        gthr[q] = d; // k real candidates: their k-th distance bounds the final k-th (before the bulk scan starts)
+    }
+}
+
+hipError_t launch_rank0_select(const float* dump, int64_t dump_stride, const int64_t* keys, int nprobe,
+                               const int64_t* list_len, const int64_t* list_row_off, const int64_t* ids,
+                               int64_t nq, int k, bool is_l2, float* partial_d, int64_t* partial_i, float* gthr,
+                               int64_t* tmp_keys, float* tmp_d, hipStream_t s) {
+    if (nq <= 0) {
+        return hipSuccess;
+    }
+    hipError_t e = launch_row_select_var(dump, dump_stride, keys, nprobe, list_len, nq, k, is_l2, tmp_keys, tmp_d, s);
+    if (e != hipSuccess) {
+        return e;
+    }
+    const unsigned grid = (unsigned)((nq * k + 255) / 256);
+    if (is_l2) {
+        hipLaunchKernelGGL((rank0_finalize_kernel<true>), dim3(grid), dim3(256), 0, s, tmp_keys, tmp_d, keys, nprobe,
+                           list_row_off, ids, nq, k, partial_d, partial_i, gthr);
+    } else {
+        hipLaunchKernelGGL((rank0_finalize_kernel<false>), dim3(grid), dim3(256), 0, s, tmp_keys, tmp_d, keys, nprobe,
+                           list_row_off, ids, nq, k, partial_d, partial_i, gthr);
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_pq_stream16(const uint8_t* codes, const int64_t* list_row_off, const int64_t* list_len,

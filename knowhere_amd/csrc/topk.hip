@@ -109,21 +109,37 @@ __device__ __forceinline__ float rs_unkey(uint32_t key) {
 
 template <bool IS_L2>
 __global__ __launch_bounds__(RS_THREADS) void row_select_kernel(const float* __restrict__ vals,
-                                                                int64_t n, int k, int kp,
+                                                                int64_t n_fixed, int k, int kp,
                                                                 int64_t* __restrict__ out_keys,
                                                                 float* __restrict__ out_d,
-                                                                const int32_t* __restrict__ row_flags) {
+                                                                const int32_t* __restrict__ row_flags,
+                                                                int64_t stride,
+                                                                const int64_t* __restrict__ var_keys,
+                                                                int key_stride,
+                                                                const int64_t* __restrict__ var_len) {
     extern __shared__ __align__(16) unsigned char smem[];
+    int64_t n = n_fixed;
     if (row_flags != nullptr && row_flags[blockIdx.x] == 0) {
         return; // only rows flagged by the coarse certificate are re-selected
+    }
+    if (var_keys != nullptr) { // variable-length rows (rank-0 list dumps)
+        const int64_t key = var_keys[(int64_t)blockIdx.x * key_stride];
+        n = key >= 0 ? var_len[key] : 0;
     }
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(smem); // [kp]
     __shared__ uint32_t hist[256];
     __shared__ uint32_t s_prefix, s_need, s_count, s_wave_tot[RS_THREADS / KN_WAVE], s_taken;
     const int tid = threadIdx.x;
-    const float* row = vals + (int64_t)blockIdx.x * n;
+    const float* row = vals + (int64_t)blockIdx.x * (stride > 0 ? stride : n);
     const int keff = (int)min((int64_t)k, n);
 
+    if (keff == 0) { // empty row: all sentinels
+        for (int e = tid; e < k; e += RS_THREADS) {
+            out_keys[(int64_t)blockIdx.x * k + e] = -1;
+            out_d[(int64_t)blockIdx.x * k + e] = worst_dist<IS_L2>();
+        }
+        return;
+    }
     // ---- radix select: find key T with count(key < T) < keff <= count(key <= T) ----
     uint32_t prefix = 0, prefix_mask = 0;
     uint32_t need = (uint32_t)keff; // rank (1-based) of the wanted key among keys matching prefix
@@ -270,10 +286,34 @@ hipError_t launch_row_select(const float* vals, int64_t nrows, int64_t n, int k,
     const size_t sm = (size_t)kp * 8;
     if (is_l2) {
         hipLaunchKernelGGL((row_select_kernel<true>), dim3((unsigned)nrows), dim3(RS_THREADS), sm, s,
-                           vals, n, k, kp, out_keys, out_d, row_flags);
+                           vals, n, k, kp, out_keys, out_d, row_flags, (int64_t)0, nullptr, 0, nullptr);
     } else {
         hipLaunchKernelGGL((row_select_kernel<false>), dim3((unsigned)nrows), dim3(RS_THREADS), sm, s,
-                           vals, n, k, kp, out_keys, out_d, row_flags);
+                           vals, n, k, kp, out_keys, out_d, row_flags, (int64_t)0, nullptr, 0, nullptr);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_row_select_var(const float* vals, int64_t stride, const int64_t* keys, int key_stride,
+                                 const int64_t* list_len, int64_t nrows, int k, bool is_l2, int64_t* out_keys,
+                                 float* out_d, hipStream_t s) {
+    if (nrows <= 0 || k <= 0) {
+        return hipSuccess;
+    }
+    if (k > RS_MAX_K) {
+        return hipErrorInvalidValue;
+    }
+    int kp = 2;
+    while (kp < k) {
+        kp <<= 1;
+    }
+    const size_t sm = (size_t)kp * 8;
+    if (is_l2) {
+        hipLaunchKernelGGL((row_select_kernel<true>), dim3((unsigned)nrows), dim3(RS_THREADS), sm, s, vals,
+                           (int64_t)0, k, kp, out_keys, out_d, nullptr, stride, keys, key_stride, list_len);
+    } else {
+        hipLaunchKernelGGL((row_select_kernel<false>), dim3((unsigned)nrows), dim3(RS_THREADS), sm, s, vals,
+                           (int64_t)0, k, kp, out_keys, out_d, nullptr, stride, keys, key_stride, list_len);
     }
     return hipGetLastError();
 }
