@@ -563,7 +563,8 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             a.list_sblk_off = idx->d_list_blk_off2.as<int64_t>();
             a.item_hi = wt.nitems;
             const int64_t stride = round_up(std::max<int64_t>(idx->max_list_len, 64), 64);
-            if (idx->rank0_select && (double)nq * stride * 4.0 <= 6.0e9) {
+            // (worth it once k is large enough that sorted insertion dominates: measured k >= 32)
+            if (idx->rank0_select && k >= 32 && nprobe > 1 && (double)nq * stride * 4.0 <= 6.0e9) {
                 // phase A: the rank-0 probe of every query (work items of virtual lists [0, nlist) come
                 // first: worktable.hip) in dump mode, then radix select -> partial slot 0 + thresholds
                 HIP_TRY(ws->dump.reserve((size_t)nq * stride * sizeof(float)));

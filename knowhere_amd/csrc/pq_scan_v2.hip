@@ -290,11 +290,18 @@ __global__ __launch_bounds__(P2_THREADS, (P2_NWAVES >= 8 ? 4 : 2)) void pq_scan_
 
     if (nwin > 0) {
         const uint4* cbase = a.codes_skew + (sblk0 + G0 * 4) * 64 + lane; // 4 blocks of 8 steps per window
+#if P2_ABLATE == 5 /* timing experiment only: every code load hits the same (L1-resident) block */
+        auto load_blk = [&](int64_t b) { return cbase[(b & 3) * 64]; };
+#else
         auto load_blk = [&](int64_t b) { return cbase[b * 64]; };      // past-the-end blocks exist (slack)
+#endif
         p2_f32x2 an = {0.f, 0.f}, ao = {0.f, 0.f};
-        p2_f32x2 va[8], vb[8];
+        // LUT reads run TWO blocks (16 steps) ahead of the accumulate that consumes them: four value
+        // buffers rotate so that the loop-carried names line up (va/vb hold blocks 0/1 of the window)
+        p2_f32x2 va[8], vb[8], vc[8], vd[8];
         uint4 c0 = load_blk(0), c1 = load_blk(1), c2 = load_blk(2), c3 = load_blk(3);
         issue8(c0, va);
+        issue8(c1, vb);
         for (int64_t w = 0; w < nwin; w++) {
             // thresholds published by other waves meanwhile (consumed at the end of this window)
             float gnext[QG];
@@ -305,21 +312,21 @@ __global__ __launch_bounds__(P2_THREADS, (P2_NWAVES >= 8 ? 4 : 2)) void pq_scan_
             // code blocks of the next window (requested 32 steps before their first lookup)
             const uint4 n0 = load_blk(4 * w + 4), n1 = load_blk(4 * w + 5), n2 = load_blk(4 * w + 6),
                         n3 = load_blk(4 * w + 7);
-            issue8(c1, vb);
+            issue8(c2, vc);
             __builtin_amdgcn_sched_barrier(0);
             p2_accum8<0>(an, ao, va);
             __builtin_amdgcn_sched_barrier(0);
-            issue8(c2, va);
+            issue8(c3, vd);
             __builtin_amdgcn_sched_barrier(0);
             p2_accum8<1>(an, ao, vb);
             __builtin_amdgcn_sched_barrier(0);
-            issue8(c3, vb);
+            issue8(n0, va); // blocks 0 / 1 of the next window
             __builtin_amdgcn_sched_barrier(0);
-            p2_accum8<2>(an, ao, va);
+            p2_accum8<2>(an, ao, vc);
             __builtin_amdgcn_sched_barrier(0);
-            issue8(n0, va); // first block of the next window
+            issue8(n1, vb);
             __builtin_amdgcn_sched_barrier(0);
-            p2_accum8<3>(an, ao, vb);
+            p2_accum8<3>(an, ao, vd);
             __builtin_amdgcn_sched_barrier(0);
             // ---- window end: ao = finished sums of group G0 + w - 1 in every lane ------------------
 #pragma unroll
@@ -378,7 +385,6 @@ __global__ __launch_bounds__(P2_THREADS, (P2_NWAVES >= 8 ? 4 : 2)) void pq_scan_
             }
             ao = an;
             an = p2_f32x2{0.f, 0.f};
-            c1 = n1;
             c2 = n2;
             c3 = n3;
         }

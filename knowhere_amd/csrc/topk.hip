@@ -35,13 +35,27 @@ __global__ __launch_bounds__(256) void merge_partials_kernel(const float* __rest
     int64_t ki = -1;
     const float* qd = pd + q * q_stride;
     const int64_t* qi = pi + q * q_stride;
+    // Slot 0 (the closest list / first shard) usually supplies a large share of the result and is already
+    // sorted best-first with its empty entries at the tail: load it straight into the wave-resident list
+    // (element e -> lane e % 64, register e / 64) so that the rank loop below can stop early.
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int e = r * KN_WAVE + lane;
+        if (e < k) {
+            const int64_t id0 = qi[e];
+            top.d[r] = id0 >= 0 ? qd[e] : worst_dist<IS_L2>();
+            top.i[r] = id0 >= 0 ? id0 : -1;
+        }
+    }
+    kd = top.kth_dist();
+    ki = top.kth_idx();
     for (int r = 0; r < k; r++) {
         bool any = false;
         for (int s0 = 0; s0 < nslot; s0 += KN_WAVE) {
             const int s = s0 + lane;
             float cd = worst_dist<IS_L2>();
             int64_t ci = -1;
-            if (s < nslot) {
+            if (s < nslot && s > 0) {
                 cd = qd[(int64_t)s * slot_stride + r];
                 ci = qi[(int64_t)s * slot_stride + r];
             }
