@@ -9,13 +9,14 @@ ap.add_argument("--nb", type=int, default=10_000_000); ap.add_argument("--nlist"
 ap.add_argument("--nprobe", type=int, default=64); ap.add_argument("--nq", type=int, default=10000)
 ap.add_argument("--ncenter", type=int, default=0); ap.add_argument("--latents", default="0")
 ap.add_argument("--rks", default="10,16,32,48,64,100"); ap.add_argument("--ngt", type=int, default=1000)
+ap.add_argument("--niter", type=int, default=10); ap.add_argument("--tpc", type=int, default=64)
 a = ap.parse_args()
 dev = "cuda:0"
 ncenter = a.ncenter or 1 << int(round(np.log2(a.nb / 160.0)))
 for latent in [int(x) for x in a.latents.split(",")]:
     spec = kb.DataSpec(a.nb, 128, ncenter=ncenter, sigma=0.35, latent=latent)
     t0 = time.time()
-    built = kb.build_ivf(spec, kidx.IVF_PQ, kidx.L2, a.nlist, 32, keep_vectors=True)
+    built = kb.build_ivf(spec, kidx.IVF_PQ, kidx.L2, a.nlist, 32, keep_vectors=True, niter=a.niter, train_per_centroid=a.tpc)
     g = built.to_gpu_index()
     xq = kb.queries(spec, a.nq, dev)
     sizes = built.list_offsets[1:] - built.list_offsets[:-1]
