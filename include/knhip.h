@@ -192,6 +192,7 @@ typedef struct knhip_stage_times {
     double coarse_flops;  /* 2 * nq * nlist * dim */
     int64_t scan_items;   /* work items launched by the scan kernel */
     int64_t coarse_fallback_queries; /* queries whose MFMA-prefilter certificate failed (exact redo) */
+    double scan_bytes_rank0; /* part of scan_bytes handled by the rank-0 (dump + select) phase */
 } knhip_stage_times;
 /* stage indices */
 enum {
@@ -200,7 +201,8 @@ enum {
     KNHIP_STAGE_LUT = 2,      /* PQ query tables */
     KNHIP_STAGE_SCAN = 3,     /* per-list code scan (ADC / flat / SQ8) -- the dominant kernel */
     KNHIP_STAGE_MERGE = 4,    /* per-query merge of per-probe partial top-k */
-    KNHIP_STAGE_OTHER = 5
+    KNHIP_STAGE_OTHER = 5,
+    KNHIP_STAGE_SCAN_RANK0 = 6 /* IVF_PQ: rank-0 probes in dump mode + radix select (pq_scan_v2.hip) */
 };
 int knhip_profile_enable(knhip_index* idx, int on);
 int knhip_profile_reset(knhip_index* idx);

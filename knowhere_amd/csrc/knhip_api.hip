@@ -163,6 +163,7 @@ struct knhip_index {
     DevBuf d_list_blk_off2;
     bool pq_v2 = false;
     bool rank0_select = true;  // KNHIP_RANK0=0 switches the dump + radix-select phase off
+    mutable bool rank0_phase_used = false;
     int64_t max_list_len = 0;
     // scratch
     mutable std::mutex mu;
@@ -557,7 +558,6 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         a.gthr = ws->gthr.as<float>();
         a.nslot = nprobe;
         a.k = k;
-        StageTimer t(idx, s, KNHIP_STAGE_SCAN);
         if (idx->pq_v2 && pq_scan_v2_supports(M, k)) {
             a.codes_skew = idx->rows2.as<uint4>();
             a.list_sblk_off = idx->d_list_blk_off2.as<int64_t>();
@@ -575,17 +575,26 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
                 a.item_lo = nullptr;
                 a.item_hi = wt.list_item_off + nlist; // items of the rank-0 virtual lists
                 const int64_t boundA = round_up(nq / qg + std::min<int64_t>(nlist, nq) + 1, 8);
-                HIP_TRY(launch_pq_scan_v2(a, is_l2, true, boundA, s));
-                HIP_TRY(launch_rank0_select(a.dump, stride, ws->keys.as<int64_t>(), nprobe,
-                                            idx->d_list_len.as<int64_t>(), idx->d_list_row_off.as<int64_t>(),
-                                            idx->ids.as<int64_t>(), nq, k, is_l2, a.partial_d, a.partial_i, a.gthr,
-                                            ws->sel_keys.as<int64_t>(), ws->sel_d.as<float>(), s));
+                {
+                    StageTimer t(idx, s, KNHIP_STAGE_SCAN_RANK0);
+                    HIP_TRY(launch_pq_scan_v2(a, is_l2, true, boundA, s));
+                    HIP_TRY(launch_rank0_select(a.dump, stride, ws->keys.as<int64_t>(), nprobe,
+                                                idx->d_list_len.as<int64_t>(), idx->d_list_row_off.as<int64_t>(),
+                                                idx->ids.as<int64_t>(), nq, k, is_l2, a.partial_d, a.partial_i,
+                                                a.gthr, ws->sel_keys.as<int64_t>(), ws->sel_d.as<float>(), s));
+                }
+                idx->rank0_phase_used = true;
                 // phase B: every other probe
                 a.item_lo = wt.list_item_off + nlist;
                 a.item_hi = wt.nitems;
+            } else {
+                idx->rank0_phase_used = false;
             }
+            StageTimer t(idx, s, KNHIP_STAGE_SCAN);
             HIP_TRY(launch_pq_scan_v2(a, is_l2, false, items_bound, s));
         } else {
+            idx->rank0_phase_used = false;
+            StageTimer t(idx, s, KNHIP_STAGE_SCAN);
             HIP_TRY(launch_pq_scan(a, is_l2, M, items_bound, s));
         }
     } else { // IVF_SQ8
@@ -759,8 +768,8 @@ int knhip_index_create(const knhip_desc* desc, knhip_index** out) {
             idx->code_size = desc->dim;
     }
     DeviceGuard g(desc->device);
-    HIP_TRY(idx->scan_bytes_dev.alloc(sizeof(double)));
-    HIP_TRY(hipMemset(idx->scan_bytes_dev.p, 0, sizeof(double)));
+    HIP_TRY(idx->scan_bytes_dev.alloc(2 * sizeof(double)));
+    HIP_TRY(hipMemset(idx->scan_bytes_dev.p, 0, 2 * sizeof(double)));
     HIP_TRY(idx->coarse_fail_dev.alloc(sizeof(unsigned long long)));
     HIP_TRY(hipMemset(idx->coarse_fail_dev.p, 0, sizeof(unsigned long long)));
     *out = idx.release();
@@ -1183,7 +1192,7 @@ int knhip_profile_reset(knhip_index* idx) {
     std::memset(&idx->times, 0, sizeof(idx->times));
     idx->coarse_flops = 0;
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemset(idx->scan_bytes_dev.p, 0, sizeof(double)));
+    HIP_TRY(hipMemset(idx->scan_bytes_dev.p, 0, 2 * sizeof(double)));
     HIP_TRY(hipMemset(idx->coarse_fail_dev.p, 0, sizeof(unsigned long long)));
     return KNHIP_OK;
 }
@@ -1196,10 +1205,11 @@ int knhip_profile_get(const knhip_index* idx, knhip_stage_times* out) {
     DeviceGuard g(idx->desc.device);
     HIP_TRY(hipDeviceSynchronize());
     drain_pending(idx);
-    double sb = 0;
-    HIP_TRY(hipMemcpy(&sb, idx->scan_bytes_dev.p, sizeof(double), hipMemcpyDeviceToHost));
+    double sb[2] = {0, 0};
+    HIP_TRY(hipMemcpy(sb, idx->scan_bytes_dev.p, 2 * sizeof(double), hipMemcpyDeviceToHost));
     *out = idx->times;
-    out->scan_bytes = sb;
+    out->scan_bytes = sb[0];
+    out->scan_bytes_rank0 = idx->rank0_phase_used ? sb[1] : 0.0;
     out->coarse_flops = idx->coarse_flops;
     out->scan_items = idx->last_items_bound;
     unsigned long long nf = 0;
@@ -1216,8 +1226,10 @@ const char* knhip_stage_kernel_name(int stage, int kind) {
             return "wt_*_kernel";
         case KNHIP_STAGE_LUT:
             return "pq_query_table_kernel";
+        case KNHIP_STAGE_SCAN_RANK0:
+            return "pq_scan_v2_kernel<DUMP>+row_select_kernel+rank0_finalize_kernel";
         case KNHIP_STAGE_SCAN:
-            return kind == KNHIP_IVF_PQ ? "pq_scan_kernel" : kind == KNHIP_IVF_SQ8 ? "sq_scan_kernel" : "flat_scan_kernel";
+            return kind == KNHIP_IVF_PQ ? "pq_scan_v2_kernel (m=32, k<=128) | pq_scan_kernel" : kind == KNHIP_IVF_SQ8 ? "sq_scan_kernel" : "flat_scan_kernel";
         case KNHIP_STAGE_MERGE:
             return "merge_partials_kernel";
         default:

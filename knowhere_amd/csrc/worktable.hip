@@ -62,14 +62,20 @@ __global__ __launch_bounds__(WT_SCAN_THREADS) void wt_scan_kernel(
     const int64_t per = (nlist + WT_SCAN_THREADS - 1) / WT_SCAN_THREADS;
     const int64_t l0 = (int64_t)tid * per;
     const int64_t l1 = min(l0 + per, nlist);
+    __shared__ double s_bytes0[WT_SCAN_THREADS];
     int64_t np = 0, ni = 0;
-    double nb = 0.0;
+    double nb = 0.0, nb0 = 0.0;
     for (int64_t l = l0; l < l1; l++) {
         const int64_t c = list_count[l];
         np += c;
         ni += (c + qg - 1) / qg;
-        nb += (double)c * (double)list_len[l % nreal] * (double)code_size;
+        const double b = (double)c * (double)list_len[l % nreal] * (double)code_size;
+        nb += b;
+        if (l < nreal) {
+            nb0 += b; // rank-0 probes (virtual lists [0, nreal))
+        }
     }
+    s_bytes0[tid] = nb0;
     s_pairs[tid] = np;
     s_items[tid] = ni;
     s_bytes[tid] = nb;
@@ -103,6 +109,11 @@ __global__ __launch_bounds__(WT_SCAN_THREADS) void wt_scan_kernel(
         list_item_off[nlist] = s_items[tid];
         *nitems = s_items[tid];
         *scan_bytes += s_bytes[tid]; // accumulated across query batches; reset by the host
+        double t0 = 0.0;
+        for (int i = 0; i < WT_SCAN_THREADS; i++) {
+            t0 += s_bytes0[i];
+        }
+        scan_bytes[1] += t0;
     }
 }
 

@@ -169,7 +169,7 @@ class GpuIndex:
         check(self.L.knhip_profile_get(self.h, C.byref(st)))
         return {"ms": list(st.ms), "launches": list(st.launches), "scan_bytes": st.scan_bytes,
                 "coarse_flops": st.coarse_flops, "scan_items": st.scan_items,
-                "coarse_fallback_queries": st.coarse_fallback_queries}
+                "coarse_fallback_queries": st.coarse_fallback_queries, "scan_bytes_rank0": st.scan_bytes_rank0}
 
 
 def merge_topk_host(metric, D_parts, I_parts):
