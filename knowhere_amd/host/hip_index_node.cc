@@ -18,10 +18,13 @@
 //   RangeSearch / GetIndexMeta: not_implemented, as the cuVS node (gpu_cuvs.h:192-201).
 //   COSINE  base normalised at Train/Add, query copied + normalised per Search, metric -> IP
 //           (ivf.cc:559-565, 1068-1071).
-//   Serialize / Deserialize: one named blob (Type()) in a BinarySet (ivf.cc:1717-1834).  The blob
-//           is this backend's own little-endian layout of the same objects; faiss-compatible
-//           IwPQ/IwFl/IwSq is a "next" row.
+//   Serialize / Deserialize: one named blob (Type()) in a BinarySet (ivf.cc:1717-1834) in the FAISS
+//           byte format the CPU nodes write (IxF2/IxFI, IwFl, IwSq, IwPQ, IxRF around the latter two
+//           when built with `refine`; faiss_io.h), so a CPU-built index loads here unchanged and back.
+//   refine  build-time `refine` keeps the fp32 rows (IndexRefineFlat, ivf.cc:673-700); search-time
+//           `refine_k` re-ranks only if they are there (ivf.cc:1073-1103).
 #include "knowhere_shim.h"
+#include "faiss_io.h"
 
 #include "../../include/knhip.h"
 
@@ -223,6 +226,7 @@ class HipIndexNode : public IndexNode {
                 sq_trained_[dim_ + t] = hi - lo;
             }
         }
+        has_refine_ = cfg_.refine && (kind_ == KNHIP_IVF_PQ || kind_ == KNHIP_IVF_SQ8);
         trained_ = true;
         return Status::success;
     }
@@ -291,7 +295,9 @@ class HipIndexNode : public IndexNode {
             lc.insert(lc.end(), codes.begin() + i * cs, codes.begin() + (i + 1) * cs);
             list_ids_[a[i]].push_back(i);
         }
-        return Upload();
+        s = Upload();
+        if (!has_refine_ && (kind_ == KNHIP_IVF_PQ || kind_ == KNHIP_IVF_SQ8)) std::vector<float>().swap(raw_);
+        return s;
     }
 
     expected<DataSetPtr> Search(const DataSetPtr dataset, const Json& cfg, const BitsetView& bitset) const override {
@@ -319,7 +325,8 @@ class HipIndexNode : public IndexNode {
             std::fill(dis, dis + nq * k, std::numeric_limits<float>::infinity());
             return GenResultDataSet(nq, k, ids, dis);
         }
-        const bool refine = c.refine && kind_ != KNHIP_BRUTE_FORCE && kind_ != KNHIP_IVF_FLAT;
+        // use_refine = the index carries a refine index; enabled by a search-time refine_k (ivf.cc:1080-1092)
+        const bool refine = has_refine_ && cfg.contains(indexparam::REFINE_K);
         const int64_t kbase = refine ? std::min<int64_t>(1024, std::max<int64_t>(k, c.refine_k > 0 ? c.refine_k : k)) : k;
         std::unique_ptr<int64_t[]> ids(new int64_t[nq * kbase]);
         std::unique_ptr<float[]> dis(new float[nq * kbase]);
@@ -342,7 +349,8 @@ class HipIndexNode : public IndexNode {
         return expected<DataSetPtr>::Err(Status::not_implemented, "RangeSearch not implemented");
     }
     expected<DataSetPtr> GetVectorByIds(const DataSetPtr dataset) const override {
-        if (!HasRawData(cfg_.metric)) return expected<DataSetPtr>::Err(Status::not_implemented, "no raw data");
+        if (!HasRawData(cfg_.metric) || raw_.empty())
+            return expected<DataSetPtr>::Err(Status::not_implemented, "no raw data");
         const int64_t n = dataset->GetRows();
         const int64_t* ids = dataset->GetIds();
         auto* out = new float[n * dim_];
@@ -365,57 +373,133 @@ class HipIndexNode : public IndexNode {
         return expected<DataSetPtr>::Err(Status::not_implemented, "GetIndexMeta not implemented");
     }
 
+    // One named blob in the BinarySet (ivf.cc:1717-1744), holding the FAISS byte format the CPU nodes
+    // write (faiss_io.h): IxF2/IxFI, IwFl, IwSq, IwPQ, wrapped in IxRF when built with refine.
     Status Serialize(BinarySet& binset) const override {
         if (!idx_) return Status::empty_index;
-        std::vector<uint8_t> buf;
-        auto put = [&](const void* p, size_t n) { buf.insert(buf.end(), (const uint8_t*)p, (const uint8_t*)p + n); };
-        auto put_i = [&](int64_t v) { put(&v, sizeof(v)); };
-        const char magic[8] = {'K', 'N', 'H', 'I', 'P', '0', '0', '1'};
-        put(magic, 8);
-        put_i(kind_); put_i(metric_); put_i(cosine_); put_i(dim_); put_i(nlist_); put_i(m_); put_i(count_);
-        put_i((int64_t)centroids_.size()); put(centroids_.data(), centroids_.size() * 4);
-        put_i((int64_t)codebooks_.size()); put(codebooks_.data(), codebooks_.size() * 4);
-        put_i((int64_t)sq_trained_.size()); put(sq_trained_.data(), sq_trained_.size() * 4);
-        put_i((int64_t)raw_.size()); put(raw_.data(), raw_.size() * 4);
-        for (int64_t l = 0; l < nlist_; l++) {
-            put_i((int64_t)list_ids_[l].size());
-            put(list_ids_[l].data(), list_ids_[l].size() * 8);
-            put(list_codes_[l].data(), list_codes_[l].size());
+        using namespace knhip_host;
+        FaissIndexData x;
+        auto fill_hdr = [&](FaissHeader& h, int64_t ntotal) {
+            h.d = (int32_t)dim_;
+            h.ntotal = ntotal;
+            h.dummy[0] = cosine_ ? 1 : 0;  // Knowhere's is_cosine byte (cppcontrib/knowhere/impl/index_write.cpp:84-88)
+            h.is_trained = true;
+            h.metric = metric_ == KNHIP_L2 ? 1 : 0;
+        };
+        const uint32_t flat_cc = metric_ == KNHIP_L2 ? FourCC("IxF2") : FourCC("IxFI");
+        fill_hdr(x.hdr, count_);
+        if (kind_ == KNHIP_BRUTE_FORCE) {
+            x.fourcc = flat_cc;
+            x.xb = raw_;
+        } else {
+            x.fourcc = kind_ == KNHIP_IVF_FLAT ? FourCC("IwFl") : kind_ == KNHIP_IVF_PQ ? FourCC("IwPQ") : FourCC("IwSq");
+            x.nlist = (uint64_t)nlist_;
+            x.nprobe = (uint64_t)cfg_.nprobe;
+            x.quantizer.fourcc = flat_cc;
+            fill_hdr(x.quantizer.hdr, nlist_);
+            x.quantizer.hdr.dummy[0] = 0;
+            x.quantizer.xb = centroids_;
+            x.by_residual = true;
+            x.code_size = (uint64_t)CodeSize();
+            if (kind_ == KNHIP_IVF_PQ) {
+                x.pq_d = (uint64_t)dim_; x.pq_M = (uint64_t)m_; x.pq_nbits = 8;
+                x.pq_centroids = codebooks_;
+            } else if (kind_ == KNHIP_IVF_SQ8) {
+                x.sq_qtype = 0;      // ScalarQuantizer::QT_8bit
+                x.sq_rangestat = 0;  // RS_minmax
+                x.sq_d = (uint64_t)dim_; x.sq_code_size = (uint64_t)dim_;
+                x.sq_trained = sq_trained_;
+            }
+            x.codes = list_codes_;
+            x.ids = list_ids_;
+            size_t non0 = 0;
+            for (auto& l : list_ids_) non0 += !l.empty();
+            x.lists_sparse = !(non0 > (size_t)nlist_ / 2);  // index_write.cpp:309-316
+            if (kind_ == KNHIP_IVF_FLAT && cosine_) {       // Knowhere cosine IVF-Flat carries the row norms
+                x.with_norm = true;
+                x.norms.assign(nlist_, {});
+                for (int64_t l = 0; l < nlist_; l++)
+                    for (size_t i = 0; i < list_ids_[l].size(); i++) {
+                        const float* v = (const float*)&list_codes_[l][i * dim_ * 4];
+                        float s = 0;
+                        for (int64_t t = 0; t < dim_; t++) s += v[t] * v[t];
+                        x.norms[l].push_back(std::sqrt(s));
+                    }
+            }
+            if (has_refine_) {  // IndexRefineFlat (ivf.cc:673-700)
+                x.has_refine = true;
+                fill_hdr(x.refine_hdr, count_);
+                x.refine_index.fourcc = flat_cc;
+                fill_hdr(x.refine_index.hdr, count_);
+                x.refine_index.hdr.dummy[0] = 0;
+                x.refine_index.xb = raw_;
+                x.k_factor = 1.f;
+            }
         }
+        std::vector<uint8_t> buf;
+        std::string err;
+        if (!WriteFaissIndex(x, &buf, &err)) return Status::faiss_inner_error;
         std::shared_ptr<uint8_t[]> data(new uint8_t[buf.size()]);
         std::memcpy(data.get(), buf.data(), buf.size());
         binset.Append(Type(), data, (int64_t)buf.size());
         return Status::success;
     }
 
-    Status Deserialize(const BinarySet& binset, const Json& /*cfg*/) override {
-        auto b = binset.GetByName(Type());
+    // Accepts the blob of this node AND of the CPU node of the same kind (FLAT / IVF_FLAT / IVF_PQ /
+    // IVF_SQ8, or the knowhere-1.x name "IVF", ivf.cc:1750-1757): same bytes.
+    Status Deserialize(const BinarySet& binset, const Json& cfg) override {
+        using namespace knhip_host;
+        static const char* cpu_names[] = {"FLAT", "IVF_FLAT", "IVF_PQ", "IVF_SQ8"};
+        BinaryPtr b = binset.GetByName(Type());
+        if (!b) b = binset.GetByName(cpu_names[kind_ == KNHIP_BRUTE_FORCE ? 0 : kind_ == KNHIP_IVF_FLAT ? 1
+                                               : kind_ == KNHIP_IVF_PQ    ? 2 : 3]);
+        if (!b && kind_ != KNHIP_BRUTE_FORCE) b = binset.GetByName("IVF");
         if (!b) return Status::invalid_binary_set;
-        const uint8_t* p = b->data.get();
-        const uint8_t* end = p + b->size;
-        auto get = [&](void* dst, size_t n) {
-            if (p + n > end) throw std::runtime_error("truncated blob");
-            std::memcpy(dst, p, n);
-            p += n;
-        };
-        auto get_i = [&]() { int64_t v; get(&v, 8); return v; };
-        char magic[8];
-        get(magic, 8);
-        if (std::memcmp(magic, "KNHIP001", 8) != 0) return Status::invalid_serialized_index_type;
-        if (get_i() != kind_) return Status::invalid_serialized_index_type;
-        metric_ = (int)get_i(); cosine_ = get_i() != 0; dim_ = get_i(); nlist_ = get_i(); m_ = get_i(); count_ = get_i();
+        FaissIndexData x;
+        std::string err;
+        if (!ParseFaissIndex(b->data.get(), (size_t)b->size, &x, &err)) return Status::invalid_serialized_index_type;
+        const bool flat = x.fourcc == FourCC("IxF2") || x.fourcc == FourCC("IxFI");
+        const bool kind_ok = (kind_ == KNHIP_BRUTE_FORCE && flat) || (kind_ == KNHIP_IVF_FLAT && x.fourcc == FourCC("IwFl")) ||
+                             (kind_ == KNHIP_IVF_PQ && x.fourcc == FourCC("IwPQ")) ||
+                             (kind_ == KNHIP_IVF_SQ8 && x.fourcc == FourCC("IwSq"));
+        if (!kind_ok) return Status::invalid_serialized_index_type;
+        if (x.hdr.metric != 0 && x.hdr.metric != 1) return Status::invalid_metric_type;
+        if (!flat && x.quantizer.hdr.metric != x.hdr.metric) return Status::not_implemented;
+        if (kind_ == KNHIP_IVF_PQ &&
+            (x.pq_nbits != 8 || !x.by_residual || !(x.pq_M == 8 || x.pq_M == 16 || x.pq_M == 32 || x.pq_M == 64)))
+            return Status::not_implemented;
+        if (kind_ == KNHIP_IVF_SQ8 && (x.sq_qtype != 0 || !x.by_residual || x.sq_trained.size() != 2 * (size_t)x.hdr.d))
+            return Status::not_implemented;
+        metric_ = x.hdr.metric == 1 ? KNHIP_L2 : KNHIP_IP;
+        cosine_ = x.hdr.is_cosine();
+        if (cfg.contains(meta::METRIC_TYPE) && cfg.at(meta::METRIC_TYPE).is_string())
+            cosine_ = cosine_ || cfg.at(meta::METRIC_TYPE).as_string() == metric::COSINE;
         cfg_.metric = cosine_ ? metric::COSINE : (metric_ == KNHIP_L2 ? metric::L2 : metric::IP);
-        centroids_.resize(get_i()); get(centroids_.data(), centroids_.size() * 4);
-        codebooks_.resize(get_i()); get(codebooks_.data(), codebooks_.size() * 4);
-        sq_trained_.resize(get_i()); get(sq_trained_.data(), sq_trained_.size() * 4);
-        raw_.resize(get_i()); get(raw_.data(), raw_.size() * 4);
-        const int64_t cs = kind_ == KNHIP_IVF_FLAT ? dim_ * 4 : (kind_ == KNHIP_IVF_PQ ? m_ : dim_);
-        list_ids_.assign(nlist_, {});
-        list_codes_.assign(nlist_, {});
-        for (int64_t l = 0; l < nlist_; l++) {
-            const int64_t n = get_i();
-            list_ids_[l].resize(n); get(list_ids_[l].data(), n * 8);
-            list_codes_[l].resize(n * cs); get(list_codes_[l].data(), n * cs);
+        dim_ = x.hdr.d;
+        count_ = x.hdr.ntotal;
+        nlist_ = (int64_t)x.nlist;
+        if (x.nprobe >= 1 && x.nprobe <= 65536) cfg_.nprobe = (int64_t)x.nprobe;  // the index's default nprobe
+        m_ = (int64_t)x.pq_M;
+        centroids_ = std::move(x.quantizer.xb);
+        codebooks_ = std::move(x.pq_centroids);
+        sq_trained_ = std::move(x.sq_trained);
+        list_codes_ = std::move(x.codes);
+        list_ids_ = std::move(x.ids);
+        has_refine_ = x.has_refine;
+        raw_.clear();
+        if (kind_ == KNHIP_BRUTE_FORCE) {
+            raw_ = std::move(x.xb);
+        } else if (x.has_refine) {
+            if (x.refine_index.hdr.ntotal != count_) return Status::invalid_serialized_index_type;
+            raw_ = std::move(x.refine_index.xb);
+        } else if (kind_ == KNHIP_IVF_FLAT) {  // raw rows back in id order (make_direct_map, ivf.cc:1815-1828)
+            raw_.assign((size_t)count_ * dim_, 0.f);
+            for (int64_t l = 0; l < nlist_; l++)
+                for (size_t i = 0; i < list_ids_[l].size(); i++) {
+                    const int64_t id = list_ids_[l][i];
+                    if (id < 0 || id >= count_) { raw_.clear(); l = nlist_; break; }
+                    std::memcpy(&raw_[id * dim_], &list_codes_[l][i * dim_ * 4], sizeof(float) * dim_);
+                }
         }
         knhip_index_destroy(idx_);
         idx_ = nullptr;
@@ -445,6 +529,8 @@ class HipIndexNode : public IndexNode {
     }
 
  private:
+    int64_t CodeSize() const { return kind_ == KNHIP_IVF_FLAT ? dim_ * 4 : (kind_ == KNHIP_IVF_PQ ? m_ : dim_); }
+
     Status Upload() {
         int rc = knhip_index_set_coarse(idx_, centroids_.data());
         if (rc) return ToStatus(rc);
@@ -499,7 +585,7 @@ class HipIndexNode : public IndexNode {
 
     int kind_;
     int metric_ = KNHIP_L2;
-    bool cosine_ = false, trained_ = false;
+    bool cosine_ = false, trained_ = false, has_refine_ = false;
     int64_t dim_ = 0, nlist_ = 0, m_ = 0, count_ = 0;
     HipConfig cfg_;
     knhip_index* idx_ = nullptr;

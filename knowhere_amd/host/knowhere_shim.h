@@ -42,6 +42,7 @@ enum class Status {
     not_implemented = 7,
     index_not_trained = 8,
     index_already_trained = 9,
+    faiss_inner_error = 10,
     malloc_error = 13,
     invalid_value_in_json = 16,
     invalid_binary_set = 19,
@@ -56,6 +57,7 @@ inline std::string Status2String(Status s) {
     switch (s) {
         case Status::success: return "success";
         case Status::invalid_args: return "invalid args";
+        case Status::faiss_inner_error: return "faiss inner error";
         case Status::invalid_param_in_json: return "invalid param in json";
         case Status::out_of_range_in_json: return "out of range in json";
         case Status::type_conflict_in_json: return "type conflict in json";

@@ -307,6 +307,8 @@ class Ref:
                 break
         self.lib = L = C.CDLL(Ref.path(), mode=C.RTLD_GLOBAL)
         L.ref_create.restype = C.c_void_p
+        L.ref_deserialize.restype = C.c_void_p
+        L.ref_serialize.restype = C.c_int64
         L.ref_last_error.restype = C.c_char_p
         for f in ("ref_ntotal", "ref_nlist", "ref_code_size", "ref_list_size", "ref_get_precomputed_table"):
             getattr(L, f).restype = C.c_int64
@@ -393,6 +395,36 @@ class Ref:
                                       _p(bitset, _u8p), C.c_int64(nbits), _p(D, _f32p), _p(I, _i64p),
                                       C.c_int(nthreads)))
         return D, I
+
+    def serialize(self, h, xb_refine=None):
+        """faiss::write_index bytes of the index (wrapped in IndexRefine(base, IndexFlat(xb_refine)) if given)"""
+        nbr, pr = 0, None
+        if xb_refine is not None:
+            xb_refine = np.ascontiguousarray(xb_refine, np.float32)
+            nbr, pr = xb_refine.shape[0], _p(xb_refine, _f32p)
+        n = self.lib.ref_serialize(h, C.c_int64(nbr), pr, None, C.c_int64(0))
+        if n < 0:
+            raise RuntimeError(self.lib.ref_last_error().decode())
+        out = np.empty(n, np.uint8)
+        n2 = self.lib.ref_serialize(h, C.c_int64(nbr), pr, _p(out, _u8p), C.c_int64(n))
+        assert n2 == n
+        return out
+
+    def deserialize(self, blob, d=None):
+        """faiss::read_index; returns (handle of the base index, refine vectors or None)"""
+        blob = np.ascontiguousarray(blob, np.uint8)
+        nbr = C.c_int64(0)
+        h = self.lib.ref_deserialize(_p(blob, _u8p), C.c_int64(blob.size), C.byref(nbr), None)
+        if not h:
+            raise RuntimeError(self.lib.ref_last_error().decode())
+        h = C.c_void_p(h)
+        if nbr.value == 0:
+            return h, None
+        self.lib.ref_destroy(h)
+        assert d is not None, "pass d to receive the refine vectors"
+        xb = np.empty((nbr.value, d), np.float32)
+        h = C.c_void_p(self.lib.ref_deserialize(_p(blob, _u8p), C.c_int64(blob.size), C.byref(nbr), _p(xb, _f32p)))
+        return h, xb
 
     def search_refine(self, h, xb, xq, k, k_factor, nprobe):
         """IndexRefine(base = h, refine = IndexFlat(xb)).search, one query per call"""

@@ -20,6 +20,8 @@
 #include <faiss/IndexRefine.h>
 #include <faiss/IndexScalarQuantizer.h>
 #include <faiss/impl/IDSelector.h>
+#include <faiss/impl/io.h>
+#include <faiss/index_io.h>
 #include <faiss/invlists/InvertedLists.h>
 #include <faiss/utils/distances.h>
 
@@ -354,6 +356,85 @@ int ref_search_refine(
             refine.search(1, q + i * h->d, k, D + i * k, I + i * k, &rp);
         }
     });
+}
+
+/// faiss::write_index into memory -- the bytes IvfIndexNode::SerializeImpl puts into the BinarySet
+/// (reference src/index/ivf/ivf.cc:1717-1744).  With nb_refine > 0 the index is first wrapped the
+/// way Knowhere's `refine` build option does: IndexRefine(base, IndexFlat(raw vectors))
+/// (ivf.cc:673-700).  Returns the byte count (also when cap is too small), -1 on error.
+int64_t ref_serialize(void* hv, int64_t nb_refine, const float* xb_refine, uint8_t* out, int64_t cap) {
+    auto* h = static_cast<RefIndex*>(hv);
+    int64_t n = -1;
+    int rc = guarded([&] {
+        faiss::VectorIOWriter w;
+        if (nb_refine > 0) {
+            faiss::MetricType mt = h->metric == 0 ? faiss::METRIC_L2 : faiss::METRIC_INNER_PRODUCT;
+            faiss::IndexFlat flat(h->d, mt);
+            flat.add(nb_refine, xb_refine);
+            faiss::IndexRefine refine(h->index.get(), &flat);
+            refine.ntotal = h->index->ntotal;
+            faiss::write_index(&refine, &w);
+        } else {
+            faiss::write_index(h->index.get(), &w);
+        }
+        n = (int64_t)w.data.size();
+        if (n <= cap) {
+            std::memcpy(out, w.data.data(), w.data.size());
+        }
+    });
+    return rc == 0 ? n : -1;
+}
+
+/// faiss::read_index from memory (IvfIndexNode::Deserialize, ivf.cc:1750-1834).  An IndexRefine
+/// wrapper is unwrapped to its base index; *nb_refine / xb_refine (if non-null, capacity ntotal*d)
+/// receive the refine index's vectors.  Returns a handle usable with ref_search / ref_destroy.
+void* ref_deserialize(const uint8_t* data, int64_t size, int64_t* nb_refine, float* xb_refine) {
+    auto* h = new RefIndex();
+    int rc = guarded([&] {
+        faiss::VectorIOReader r;
+        r.data.assign(data, data + size);
+        std::unique_ptr<faiss::Index> idx(faiss::read_index(&r));
+        if (nb_refine) {
+            *nb_refine = 0;
+        }
+        if (auto* rf = dynamic_cast<faiss::IndexRefine*>(idx.get())) {
+            auto* flat = dynamic_cast<faiss::IndexFlat*>(rf->refine_index);
+            if (!flat) {
+                throw std::runtime_error("refine index is not flat");
+            }
+            if (nb_refine) {
+                *nb_refine = flat->ntotal;
+            }
+            if (xb_refine) {
+                std::memcpy(xb_refine, flat->get_xb(), sizeof(float) * flat->ntotal * flat->d);
+            }
+            faiss::Index* base = rf->base_index;
+            rf->base_index = nullptr;  // keep the base, drop wrapper + refine index
+            delete rf->refine_index;
+            rf->refine_index = nullptr;
+            rf->own_fields = false;
+            idx.reset(base);
+        }
+        h->d = idx->d;
+        h->metric = idx->metric_type == faiss::METRIC_L2 ? 0 : 1;
+        if (dynamic_cast<faiss::IndexIVFPQ*>(idx.get())) {
+            h->kind = K_IVF_PQ;
+        } else if (dynamic_cast<faiss::IndexIVFScalarQuantizer*>(idx.get())) {
+            h->kind = K_IVF_SQ8;
+        } else if (dynamic_cast<faiss::IndexIVFFlat*>(idx.get())) {
+            h->kind = K_IVF_FLAT;
+        } else if (dynamic_cast<faiss::IndexFlat*>(idx.get())) {
+            h->kind = K_FLAT;
+        } else {
+            throw std::runtime_error("deserialized index kind not on the path");
+        }
+        h->index = std::move(idx);  // an IVF index read from bytes owns its quantizer (own_fields)
+    });
+    if (rc != 0) {
+        delete h;
+        return nullptr;
+    }
+    return h;
 }
 
 /// coarse quantizer alone: quantizer->search(1, q, nprobe) per query

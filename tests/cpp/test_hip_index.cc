@@ -8,6 +8,7 @@
 // :70-76 (self-hit distance exactly 0).  Catch2 is absent from this image, hence the tiny harness.
 #include <algorithm>
 #include <cstdio>
+#include <cstring>
 #include <random>
 #include <set>
 
@@ -170,24 +171,52 @@ int main() {
             auto r = idx.Search(query_ds, c.cfg, BitsetView(bits.data(), nb));
             REQUIRE(r.has_value() && r.value()->GetIds()[0] == -1);
         }
-        // 5. refine (IVF_PQ / IVF_SQ8): ivf.cc:1073-1103
+        // 5. refine (IVF_PQ / IVF_SQ8): a build-time `refine` keeps the fp32 rows (ivf.cc:673-700), a
+        //    search-time `refine_k` re-ranks with them (ivf.cc:1073-1103); without the former the latter
+        //    is a no-op
         if (std::string(c.name) == IndexEnum::INDEX_HIP_IVFPQ) {
             Json cfg = c.cfg;
             cfg[meta::TOPK] = 10;
             auto plain = idx.Search(query_ds, cfg, nullptr);
-            cfg[indexparam::REFINE] = true;
-            cfg[indexparam::REFINE_K] = 100;
-            auto refined = idx.Search(query_ds, cfg, nullptr);
+            Json scfg = cfg;
+            scfg[indexparam::REFINE_K] = 100;
+            auto noop = idx.Search(query_ds, scfg, nullptr);
+            REQUIRE(plain.has_value() && noop.has_value());
+            int diff = 0;
+            for (int64_t i = 0; i < nq * 10; i++) diff += plain.value()->GetIds()[i] != noop.value()->GetIds()[i];
+            REQUIRE(diff == 0);
+            Json bcfg = c.cfg;
+            bcfg[indexparam::REFINE] = true;
+            auto ridx = IndexFactory::Instance().Create<fp32>(c.name, version).value();
+            REQUIRE(ridx.Build(train_ds, bcfg) == Status::success);
+            auto refined = ridx.Search(query_ds, scfg, nullptr);
             auto g = BruteForce::Search<fp32>(train_ds, query_ds, cfg, nullptr);
-            REQUIRE(plain.has_value() && refined.has_value());
+            REQUIRE(refined.has_value() && g.has_value());
             float r0 = GetKNNRecall(*g.value(), *plain.value()), r1 = GetKNNRecall(*g.value(), *refined.value());
             std::printf("   recall@10 plain %.4f refined(100) %.4f\n", r0, r1);
             REQUIRE(r1 > r0 && r1 > 0.9f);
+            // the refine index travels with the blob ("IxRF" wrapper) and keeps working after a reload
+            BinarySet rbs;
+            REQUIRE(ridx.Serialize(rbs) == Status::success);
+            REQUIRE(std::memcmp(rbs.GetByName(c.name)->data.get(), "IxRF", 4) == 0);
+            auto ridx2 = IndexFactory::Instance().Create<fp32>(c.name, version).value();
+            REQUIRE(ridx2.Deserialize(rbs) == Status::success);
+            auto refined2 = ridx2.Search(query_ds, scfg, nullptr);
+            REQUIRE(refined2.has_value());
+            diff = 0;
+            for (int64_t i = 0; i < nq * 10; i++) diff += refined.value()->GetIds()[i] != refined2.value()->GetIds()[i];
+            REQUIRE(diff == 0);
         }
         // 6. serialize round trip (test_gpu_search.cc:280-314)
         BinarySet bs;
         REQUIRE(idx.Serialize(bs) == Status::success);
         REQUIRE(bs.Contains(c.name));
+        {   // the blob is the FAISS byte format of the CPU node of the same kind (index_write.cpp fourccs)
+            const char* cc = std::string(c.name) == IndexEnum::INDEX_HIP_BRUTEFORCE ? "IxF2"
+                             : std::string(c.name) == IndexEnum::INDEX_HIP_IVFFLAT  ? "IwFl"
+                             : std::string(c.name) == IndexEnum::INDEX_HIP_IVFPQ    ? "IwPQ" : "IwSq";
+            REQUIRE(std::memcmp(bs.GetByName(c.name)->data.get(), cc, 4) == 0);
+        }
         auto idx2 = IndexFactory::Instance().Create<fp32>(c.name, version).value();
         REQUIRE(idx2.Deserialize(bs) == Status::success);
         auto r2 = idx2.Search(query_ds, c.cfg, nullptr);

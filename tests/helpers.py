@@ -10,7 +10,12 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def golden_files():
-    return sorted(glob.glob(os.path.join(GOLDEN, "*.npz")))
+    return sorted(p for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if not os.path.basename(p).startswith("blob_"))
+
+
+def golden_blobs():
+    """index bytes written by the reference's faiss::write_index (tests/golden/make_golden_blobs.py)"""
+    return sorted(glob.glob(os.path.join(GOLDEN, "blob_*.npz")))
 
 
 def load_golden(path):

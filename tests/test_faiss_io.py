@@ -1,0 +1,190 @@
+"""Wire format: the HIP node reads and writes the FAISS index bytes the CPU nodes
+put into the BinarySet (reference src/index/ivf/ivf.cc:1717-1834 -> faiss::write_index / read_index).
+
+CPU: knowhere_amd/host/faiss_io.cc parses the reference's own bytes (committed fixtures
+tests/golden/blob_*.npz, and live oracle/_ref output where present) and re-emits them BYTE-IDENTICALLY;
+malformed blobs are rejected.  GPU: a CPU-built index loads into the node and returns the
+reference's results bit-exactly; a node-built index is read back by the reference's faiss::read_index
+and returns the node's results."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, assert_parity, gen_data
+from helpers import golden_blobs
+from oracle import binding as ob
+
+NODE_SO = os.path.join(ROOT, "knowhere_amd", "libknowhere_hip_node.so")
+CPU_NAME = {ob.FLAT: "FLAT", ob.IVF_FLAT: "IVF_FLAT", ob.IVF_PQ: "IVF_PQ", ob.IVF_SQ8: "IVF_SQ8"}
+GPU_NAME = {ob.FLAT: "GPU_HIP_BRUTE_FORCE", ob.IVF_FLAT: "GPU_HIP_IVF_FLAT", ob.IVF_PQ: "GPU_HIP_IVF_PQ",
+            ob.IVF_SQ8: "GPU_HIP_IVF_SQ8"}
+
+
+@pytest.fixture(scope="module")
+def node():
+    assert os.path.exists(NODE_SO), "build with __graft_entry__.build()"
+    L = C.CDLL(NODE_SO)
+    L.knhip_host_faiss_roundtrip.restype = C.c_int64
+    L.knhip_node_create.restype = C.c_void_p
+    L.knhip_node_serialize.restype = C.c_int64
+    L.knhip_node_last_error.restype = C.c_char_p
+    L.knhip_node_count.restype = C.c_int64
+    return L
+
+
+def _u8(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def roundtrip(L, blob):
+    blob = np.ascontiguousarray(blob, np.uint8)
+    err = C.create_string_buffer(256)
+    out = np.empty(blob.size + 64, np.uint8)
+    n = L.knhip_host_faiss_roundtrip(_u8(blob), C.c_int64(blob.size), _u8(out), C.c_int64(out.size), err, C.c_int64(256))
+    if n < 0:
+        raise ValueError(err.value.decode())
+    return out[:n]
+
+
+def info(L, blob):
+    blob = np.ascontiguousarray(blob, np.uint8)
+    err = C.create_string_buffer(256)
+    v = np.zeros(10, np.int64)
+    rc = L.knhip_host_faiss_info(_u8(blob), C.c_int64(blob.size), v.ctypes.data_as(C.POINTER(C.c_int64)), err,
+                                 C.c_int64(256))
+    if rc != 0:
+        raise ValueError(err.value.decode())
+    return dict(fourcc=int(v[0]).to_bytes(4, "little").decode(), d=int(v[1]), ntotal=int(v[2]), metric=int(v[3]),
+                nlist=int(v[4]), code_size=int(v[5]), pq_M=int(v[6]), has_refine=bool(v[7]), is_cosine=bool(v[8]),
+                list_total=int(v[9]))
+
+
+@pytest.mark.parametrize("path", golden_blobs(), ids=lambda p: os.path.basename(p)[5:-4])
+def test_reference_bytes_roundtrip_identically(node, path):
+    z = np.load(path)
+    blob = z["blob"]
+    out = roundtrip(node, blob)
+    assert out.size == blob.size and np.array_equal(out, blob)
+    i = info(node, blob)
+    kind, metric = int(z["kind"]), int(z["metric"])
+    assert i["d"] == int(z["d"]) and i["ntotal"] == int(z["nb"]) and i["metric"] == (1 if metric == ob.L2 else 0)
+    assert i["has_refine"] == path.endswith("_refine.npz") and not i["is_cosine"]
+    if kind == ob.FLAT:
+        assert i["fourcc"] == ("IxF2" if metric == ob.L2 else "IxFI")
+    else:
+        assert i["fourcc"] == {ob.IVF_FLAT: "IwFl", ob.IVF_PQ: "IwPQ", ob.IVF_SQ8: "IwSq"}[kind]
+        assert i["nlist"] == int(z["nlist"]) and i["list_total"] == int(z["nb"])
+        assert i["code_size"] == {ob.IVF_FLAT: 4 * int(z["d"]), ob.IVF_PQ: int(z["M"]), ob.IVF_SQ8: int(z["d"])}[kind]
+
+
+def test_live_reference_bytes_roundtrip(node, ref):
+    """fresh indexes from the reference (incl. mostly-empty lists -> the sparse size table, custom ids)"""
+    d = 8
+    xb = gen_data(400, d, 5)
+    for kind in (ob.IVF_FLAT, ob.IVF_PQ, ob.IVF_SQ8):
+        for nlist, nadd in ((4, 400), (10, 3)):  # 3 rows over 10 lists: <= nlist/2 non-empty -> "sprs"
+            h = ref.create(kind, ob.L2, d, nlist, 4, 8)
+            ref._chk(ref.lib.ref_train(h, C.c_int64(400), xb.ctypes.data_as(C.POINTER(C.c_float))))
+            ids = np.arange(nadd, dtype=np.int64) * 7 + 100
+            ref._chk(ref.lib.ref_add(h, C.c_int64(nadd), xb.ctypes.data_as(C.POINTER(C.c_float)),
+                                     ids.ctypes.data_as(C.POINTER(C.c_int64))))
+            blob = ref.serialize(h)
+            assert np.array_equal(roundtrip(node, blob), blob)
+            assert info(node, blob)["list_total"] == nadd
+            ref.destroy(h)
+
+
+def test_malformed_blobs_are_rejected(node):
+    blob = np.load(golden_blobs()[0])["blob"]
+    pq = np.load([p for p in golden_blobs() if "ivfpq_l2.npz" in p][0])["blob"]
+    for bad in (pq[:100], pq[:-1], np.concatenate([pq, np.zeros(3, np.uint8)]), blob[:3]):
+        with pytest.raises(ValueError):
+            roundtrip(node, bad)
+    unknown = pq.copy()
+    unknown[:4] = np.frombuffer(b"IHNf", np.uint8)  # an index type that is not on the path
+    with pytest.raises(ValueError, match="not on the HIP"):
+        roundtrip(node, unknown)
+    huge = pq.copy()
+    huge[4 + 4 + 8 + 16 + 1 + 4: 4 + 4 + 8 + 16 + 1 + 4 + 8] = 255  # nlist = 2^64-1
+    with pytest.raises(ValueError):
+        roundtrip(node, huge)
+
+
+# ------------------------------------------------------------------------------------------ GPU
+def _search(L, h, xq, cfg, k):
+    nq, d = xq.shape
+    I = np.empty((nq, k), np.int64)
+    D = np.empty((nq, k), np.float32)
+    rc = L.knhip_node_search(C.c_void_p(h), xq.ctypes.data_as(C.POINTER(C.c_float)), C.c_int64(nq), C.c_int64(d),
+                             cfg.encode(), None, C.c_int64(0), C.c_int64(k), I.ctypes.data_as(C.POINTER(C.c_int64)),
+                             D.ctypes.data_as(C.POINTER(C.c_float)))
+    assert rc == 0, L.knhip_node_last_error().decode()
+    return D, I
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", golden_blobs(), ids=lambda p: os.path.basename(p)[5:-4])
+def test_cpu_built_index_loads_into_the_hip_node(node, path):
+    """the bytes of a CPU IVF_PQ / IVF_FLAT / IVF_SQ8 / FLAT index, under the CPU node's BinarySet key"""
+    z = np.load(path)
+    kind, metric, k, nprobe = int(z["kind"]), int(z["metric"]), int(z["k"]), int(z["nprobe"])
+    blob, xq = np.ascontiguousarray(z["blob"]), np.ascontiguousarray(z["xq"])
+    h = node.knhip_node_create(GPU_NAME[kind].encode())
+    assert h
+    try:
+        rc = node.knhip_node_deserialize(C.c_void_p(h), CPU_NAME[kind].encode(), _u8(blob), C.c_int64(blob.size), b"")
+        assert rc == 0
+        assert node.knhip_node_count(C.c_void_p(h)) == int(z["nb"])
+        D, I = _search(node, h, xq, f"k={k};nprobe={nprobe}", k)
+        assert_parity(z["D"], z["I"], D, I, metric, "cpu blob -> hip node")
+        if "Dr" in z.files:  # IndexRefine, k_factor 4 (refine_k = 4k)
+            D, I = _search(node, h, xq, f"k={k};nprobe={nprobe};refine_k={4 * k}", k)
+            assert_parity(z["Dr"], z["Ir"], D, I, metric, "cpu blob -> hip node, refine")
+        # and the node writes the same kind of bytes back: identical up to the 16 reserved header bytes
+        n = node.knhip_node_serialize(C.c_void_p(h), None, C.c_int64(0))
+        out = np.empty(n, np.uint8)
+        assert node.knhip_node_serialize(C.c_void_p(h), _u8(out), C.c_int64(n)) == n
+        assert n == blob.size
+        diff = np.nonzero(out != blob)[0]
+        assert bytes(out[:4]) == bytes(blob[:4])
+        # baseline faiss writes 1 << 20 into the two reserved int64 of every header, Knowhere zeros
+        assert len(diff) <= 2 * (3 if "Dr" in z.files else 1) * 2 and all(blob[i] == 0x10 for i in diff)
+    finally:
+        node.knhip_node_destroy(C.c_void_p(h))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", [ob.FLAT, ob.IVF_FLAT, ob.IVF_PQ, ob.IVF_SQ8], ids=["flat", "ivfflat", "ivfpq", "ivfsq8"])
+@pytest.mark.parametrize("metric", ["L2", "IP"])
+def test_hip_built_index_is_read_by_the_reference(node, ref, kind, metric):
+    """Build through the plugin API on the GPU, Serialize, faiss::read_index the bytes with the
+    reference, search there: same results."""
+    nb, nq, d, k, nprobe = 4000, 32, 32, 10, 8
+    xb, xq = gen_data(nb, d, 42), gen_data(nq, d, 44)
+    h = node.knhip_node_create(GPU_NAME[kind].encode())
+    try:
+        refine = kind in (ob.IVF_PQ, ob.IVF_SQ8)
+        cfg = f"metric_type={metric};nlist=32;m=8;nbits=8" + (";refine=true" if refine else "")
+        rc = node.knhip_node_build(C.c_void_p(h), xb.ctypes.data_as(C.POINTER(C.c_float)), C.c_int64(nb), C.c_int64(d),
+                                   cfg.encode())
+        assert rc == 0
+        D, I = _search(node, h, xq, f"k={k};nprobe={nprobe}", k)
+        n = node.knhip_node_serialize(C.c_void_p(h), None, C.c_int64(0))
+        blob = np.empty(n, np.uint8)
+        assert node.knhip_node_serialize(C.c_void_p(h), _u8(blob), C.c_int64(n)) == n
+        assert bytes(blob[:4]) == (b"IxRF" if refine else {ob.FLAT: b"IxF2" if metric == "L2" else b"IxFI",
+                                                           ob.IVF_FLAT: b"IwFl"}[kind])
+        h2, raw = ref.deserialize(blob, d)
+        m = ob.L2 if metric == "L2" else ob.IP
+        Dr, Ir = ref.search(h2, xq, k, nprobe)
+        assert_parity(Dr, Ir, D, I, m, "hip blob -> reference")
+        if refine:
+            assert np.array_equal(raw, xb)
+            D2, I2 = _search(node, h, xq, f"k={k};nprobe={nprobe};refine_k={4 * k}", k)
+            Dr2, Ir2 = ref.search_refine(h2, raw, xq, k, 4.0, nprobe)
+            assert_parity(Dr2, Ir2, D2, I2, m, "hip blob -> reference, refine")
+        ref.destroy(h2)
+    finally:
+        node.knhip_node_destroy(C.c_void_p(h))
