@@ -88,10 +88,10 @@ __global__ void pq_stream16_kernel(const uint8_t* __restrict__ codes, const int6
 }
 
 int64_t pq_stream16_blocks(int64_t len) {
-    // 32 steps per group of 64 vectors + 31 stagger steps, in blocks of 8 steps, + one window of slack so
-    // that every wave's drain window and the prefetch of the window after it stay inside the list
+    // 32 steps per group of 64 vectors + 31 stagger steps, in blocks of 8 steps, + slack so that every
+    // wave's drain window and its code prefetch (two windows + one block ahead) stay inside the list
     const int64_t ngroups = (len + 63) / 64;
-    return (ngroups * 32 + 32) / 8 + 8;
+    return (ngroups * 32 + 32) / 8 + 16;
 }
 
 // ---- 8 steps of accumulate, J0 = index of the first step inside the 32-step window ------------------
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(P2_THREADS, (P2_NWAVES >= 8 ? 4 : 2)) void pq_scan_
     extern __shared__ __align__(16) unsigned char smem[];
     float* lut = reinterpret_cast<float*>(smem); // [256][32][2]
     const int lane = lane_id();
-    const int wave = threadIdx.x / KN_WAVE;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / KN_WAVE); // wave-uniform: scalar loop control
 
     const int64_t item_lo = a.item_lo ? *a.item_lo : 0;
     const int64_t nitems = *a.item_hi - item_lo;
@@ -296,44 +296,53 @@ __global__ __launch_bounds__(P2_THREADS, (P2_NWAVES >= 8 ? 4 : 2)) void pq_scan_
         auto load_blk = [&](int64_t b) { return cbase[b * 64]; };      // past-the-end blocks exist (slack)
 #endif
         p2_f32x2 an = {0.f, 0.f}, ao = {0.f, 0.f};
-        // LUT reads run TWO blocks (16 steps) ahead of the accumulate that consumes them: four value
-        // buffers rotate so that the loop-carried names line up (va/vb hold blocks 0/1 of the window)
-        p2_f32x2 va[8], vb[8], vc[8], vd[8];
-        uint4 c0 = load_blk(0), c1 = load_blk(1), c2 = load_blk(2), c3 = load_blk(3);
-        issue8(c0, va);
-        issue8(c1, vb);
-        for (int64_t w = 0; w < nwin; w++) {
+        // LUT reads run one block (8 steps) ahead of the accumulate that consumes them (two value
+        // buffers); the code stream runs TWO WINDOWS ahead of its first use (three register sets of
+        // four blocks, T_w = blocks 4w+1 .. 4w+4 = what window w turns into LUT reads), so that a block
+        // that misses L2 has ~64 steps to arrive from HBM.
+        p2_f32x2 va[8], vb[8];
+        const uint4 b0 = load_blk(0);
+        uint4 A0 = load_blk(1), A1 = load_blk(2), A2 = load_blk(3), A3 = load_blk(4);
+        uint4 B0 = load_blk(5), B1 = load_blk(6), B2 = load_blk(7), B3 = load_blk(8);
+        uint4 C0, C1, C2, C3;
+        issue8(b0, va);
+        const int64_t last_group = (len + 63) / 64 - 1;
+        const unsigned long long tail_mask = (len & 63) ? ((1ull << (len & 63)) - 1ull) : ~0ull;
+
+        // One 32-step window: an accumulates the window's new vectors, ao finishes the previous window's
+        // (ao = finished sums of group G0 + w - 1 in every lane at the end).  u0..u3 = T_w, l0..l3
+        // receive T_{w+2}.  Called three times per loop trip with the register sets rotated, so no code
+        // word is ever copied.
+        auto window = [&](const int64_t w, const uint4& u0, const uint4& u1, const uint4& u2, const uint4& u3,
+                          uint4& l0, uint4& l1, uint4& l2, uint4& l3) {
             // thresholds published by other waves meanwhile (consumed at the end of this window)
             float gnext[QG];
 #pragma unroll
             for (int qi = 0; qi < QG; qi++) {
                 gnext[qi] = gthr_load<IS_L2>(a.gthr + q_of[qi]);
             }
-            // code blocks of the next window (requested 32 steps before their first lookup)
-            const uint4 n0 = load_blk(4 * w + 4), n1 = load_blk(4 * w + 5), n2 = load_blk(4 * w + 6),
-                        n3 = load_blk(4 * w + 7);
-            issue8(c2, vc);
+            l0 = load_blk(4 * w + 9);
+            l1 = load_blk(4 * w + 10);
+            l2 = load_blk(4 * w + 11);
+            l3 = load_blk(4 * w + 12);
+            issue8(u0, vb);
             __builtin_amdgcn_sched_barrier(0);
             p2_accum8<0>(an, ao, va);
             __builtin_amdgcn_sched_barrier(0);
-            issue8(c3, vd);
+            issue8(u1, va);
             __builtin_amdgcn_sched_barrier(0);
             p2_accum8<1>(an, ao, vb);
             __builtin_amdgcn_sched_barrier(0);
-            issue8(n0, va); // blocks 0 / 1 of the next window
+            issue8(u2, vb);
             __builtin_amdgcn_sched_barrier(0);
-            p2_accum8<2>(an, ao, vc);
+            p2_accum8<2>(an, ao, va);
             __builtin_amdgcn_sched_barrier(0);
-            issue8(n1, vb);
+            issue8(u3, va); // block 0 of the next window
             __builtin_amdgcn_sched_barrier(0);
-            p2_accum8<3>(an, ao, vd);
+            p2_accum8<3>(an, ao, vb);
             __builtin_amdgcn_sched_barrier(0);
-            // ---- window end: ao = finished sums of group G0 + w - 1 in every lane ------------------
-#pragma unroll
-            for (int qi = 0; qi < QG; qi++) {
-                gt[qi] = tighter<IS_L2>(gt[qi], gnext[qi]);
-                pre[qi] = p2_prefilter<IS_L2>(tighter<IS_L2>(kd[qi], gt[qi]), dis0[qi]);
-            }
+            p2_f32x2& Y = ao;
+            // ---- window end --------------------------------------------------------------------------
             if (DUMP) {
                 if (w > 0) {
                     const int64_t vbase = (G0 + w - 1) * 64;
@@ -343,7 +352,7 @@ __global__ __launch_bounds__(P2_THREADS, (P2_NWAVES >= 8 ? 4 : 2)) void pq_scan_
 #pragma unroll
                         for (int qi = 0; qi < QG; qi++) {
                             if (qi < npair) {
-                                const float o = qi == 0 ? ao.x : ao.y;
+                                const float o = qi == 0 ? Y.x : Y.y;
                                 a.dump[(int64_t)q_of[qi] * a.dump_stride + vbase + lane] =
                                         filt ? worst_dist<IS_L2>() : fadd_x(dis0[qi], o);
                             }
@@ -351,42 +360,62 @@ __global__ __launch_bounds__(P2_THREADS, (P2_NWAVES >= 8 ? 4 : 2)) void pq_scan_
                     }
                 }
             } else if (w > 0 && P2_ABLATE != 3) {
-                const int64_t vbase = (G0 + w - 1) * 64;
-                const bool valid = vbase + lane < len;
+                // fast path: two compares against the (possibly stale, i.e. looser) prefilter and one
+                // "did a shared threshold move" test; everything else only when one of them fires
+                const unsigned long long vmask = (G0 + w - 1 == last_group) ? tail_mask : ~0ull;
+                const unsigned long long f0 = __ballot(IS_L2 ? (Y.x <= pre[0]) : (Y.x >= pre[0])) & vmask;
+                const unsigned long long f1 = __ballot(IS_L2 ? (Y.y <= pre[1]) : (Y.y >= pre[1])) & vmask;
+                const unsigned long long moved =
+                        __ballot(IS_L2 ? (gnext[0] < gt[0] || gnext[1] < gt[1]) : (gnext[0] > gt[0] || gnext[1] > gt[1]));
+                if ((f0 | f1 | moved) != 0) {
+                    const int64_t vbase = (G0 + w - 1) * 64;
 #pragma unroll
-                for (int qi = 0; qi < QG; qi++) {
-                    const float o = qi == 0 ? ao.x : ao.y;
-                    unsigned long long mm = __ballot(valid && (IS_L2 ? (o <= pre[qi]) : (o >= pre[qi])));
-                    if (mm != 0 && qi < npair) {
-                        bool tightened = false;
-                        while (mm) {
-                            const int l = __ffsll((long long)mm) - 1;
-                            mm &= mm - 1;
-                            const int32_t v = (int32_t)(vbase + l);
-                            const float dis = fadd_x(dis0[qi], readlane_f(o, l));
-                            if (!within_gthr<IS_L2>(dis, gt[qi]) || !top[qi].admits(dis, v, kd[qi], ki[qi])) {
-                                continue;
-                            }
-                            if (a.bitset != nullptr &&
-                                bitset_filtered(a.bitset, a.bitset_nbits, a.ids[row_off + v])) {
-                                continue;
-                            }
-                            top[qi].insert(dis, v);
-                            kd[qi] = top[qi].kth_dist();
-                            ki[qi] = top[qi].kth_idx();
-                            tightened = true;
-                        }
-                        if (tightened && ki[qi] >= 0 && lane == 0) {
-                            gthr_publish<IS_L2>(a.gthr + q_of[qi], kd[qi]);
-                        }
+                    for (int qi = 0; qi < QG; qi++) {
+                        gt[qi] = tighter<IS_L2>(gt[qi], gnext[qi]);
                         pre[qi] = p2_prefilter<IS_L2>(tighter<IS_L2>(kd[qi], gt[qi]), dis0[qi]);
+                        const float o = qi == 0 ? Y.x : Y.y;
+                        unsigned long long mm = __ballot(IS_L2 ? (o <= pre[qi]) : (o >= pre[qi])) & vmask;
+                        if (mm != 0 && qi < npair) {
+                            bool tightened = false;
+                            while (mm) {
+                                const int l = __ffsll((long long)mm) - 1;
+                                mm &= mm - 1;
+                                const int32_t v = (int32_t)(vbase + l);
+                                const float dis = fadd_x(dis0[qi], readlane_f(o, l));
+                                if (!within_gthr<IS_L2>(dis, gt[qi]) || !top[qi].admits(dis, v, kd[qi], ki[qi])) {
+                                    continue;
+                                }
+                                if (a.bitset != nullptr &&
+                                    bitset_filtered(a.bitset, a.bitset_nbits, a.ids[row_off + v])) {
+                                    continue;
+                                }
+                                top[qi].insert(dis, v);
+                                kd[qi] = top[qi].kth_dist();
+                                ki[qi] = top[qi].kth_idx();
+                                tightened = true;
+                            }
+                            if (tightened && ki[qi] >= 0 && lane == 0) {
+                                gthr_publish<IS_L2>(a.gthr + q_of[qi], kd[qi]);
+                            }
+                            pre[qi] = p2_prefilter<IS_L2>(tighter<IS_L2>(kd[qi], gt[qi]), dis0[qi]);
+                        }
                     }
                 }
             }
             ao = an;
             an = p2_f32x2{0.f, 0.f};
-            c2 = n2;
-            c3 = n3;
+        };
+
+        for (int64_t w = 0; w < nwin; w += 3) {
+            window(w, A0, A1, A2, A3, C0, C1, C2, C3);
+            if (w + 1 >= nwin) {
+                break;
+            }
+            window(w + 1, B0, B1, B2, B3, A0, A1, A2, A3);
+            if (w + 2 >= nwin) {
+                break;
+            }
+            window(w + 2, C0, C1, C2, C3, B0, B1, B2, B3);
         }
     }
 
