@@ -44,6 +44,12 @@ constexpr int P2_M = 32;
 #define P2_NWAVES 8
 #endif
 constexpr int P2_WAVES = P2_NWAVES;
+// lanes l and l ^ 1 share a stagger phase when P2_PHASE_SHIFT = 1: 16 phases instead of 32, so only the
+// first 15 steps of a window have lanes on two different vectors (EXEC flips + second accumulate), at the
+// price of a 2-way LDS bank conflict on every lookup
+#ifndef P2_PHASE_SHIFT
+#define P2_PHASE_SHIFT 1
+#endif
 constexpr int P2_THREADS = P2_WAVES * KN_WAVE;
 
 typedef float p2_f32x2 __attribute__((ext_vector_type(2)));
@@ -65,7 +71,7 @@ __global__ void pq_stream16_kernel(const uint8_t* __restrict__ codes, const int6
          t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t blk = t / 64;
         const int L = (int)(t % 64);
-        const int lo = L & 31;
+        const int lo = (L & 31) >> P2_PHASE_SHIFT;
         uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int s = 0; s < 8; s++) {
@@ -112,9 +118,42 @@ int64_t pq_stream16_blocks(int64_t len) {
     "v_pk_add_f32 %1, %1, " LUT "\n\t"
 #endif
 
+#define P2_PLAIN(LUT) "v_pk_add_f32 %0, %0, " LUT "\n\t"
+
 template <int Q>
 __device__ __forceinline__ void p2_accum8(p2_f32x2& an, p2_f32x2& ao, const p2_f32x2 (&v)[8]);
 
+#if P2_PHASE_SHIFT == 1
+// 16 phases: lanes with (l & 31) >> 1 <= j are on the new vector at step j -> mask 4^(j+1) - 1; from step 15
+// on every lane is
+template <>
+__device__ __forceinline__ void p2_accum8<0>(p2_f32x2& an, p2_f32x2& ao, const p2_f32x2 (&v)[8]) {
+    asm volatile(P2_STEP(0x3, "%2") P2_STEP(0xf, "%3") P2_STEP(0x3f, "%4") P2_STEP(0xff, "%5")
+                 P2_STEP(0x3ff, "%6") P2_STEP(0xfff, "%7") P2_STEP(0x3fff, "%8") P2_STEP(0xffff, "%9")
+                 "s_mov_b64 exec, -1\n\t"
+                 : "+v"(an), "+v"(ao)
+                 : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+}
+template <>
+__device__ __forceinline__ void p2_accum8<1>(p2_f32x2& an, p2_f32x2& ao, const p2_f32x2 (&v)[8]) {
+    asm volatile(P2_STEP(0x3ffff, "%2") P2_STEP(0xfffff, "%3") P2_STEP(0x3fffff, "%4") P2_STEP(0xffffff, "%5")
+                 P2_STEP(0x3ffffff, "%6") P2_STEP(0xfffffff, "%7") P2_STEP(0x3fffffff, "%8")
+                 "s_mov_b64 exec, -1\n\t" P2_PLAIN("%9")
+                 : "+v"(an), "+v"(ao)
+                 : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+}
+template <>
+__device__ __forceinline__ void p2_accum8<2>(p2_f32x2& an, p2_f32x2& ao, const p2_f32x2 (&v)[8]) {
+    asm volatile(P2_PLAIN("%2") P2_PLAIN("%3") P2_PLAIN("%4") P2_PLAIN("%5") P2_PLAIN("%6") P2_PLAIN("%7")
+                 P2_PLAIN("%8") P2_PLAIN("%9")
+                 : "+v"(an), "+v"(ao)
+                 : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+}
+template <>
+__device__ __forceinline__ void p2_accum8<3>(p2_f32x2& an, p2_f32x2& ao, const p2_f32x2 (&v)[8]) {
+    p2_accum8<2>(an, ao, v);
+}
+#else
 template <>
 __device__ __forceinline__ void p2_accum8<0>(p2_f32x2& an, p2_f32x2& ao, const p2_f32x2 (&v)[8]) {
     asm volatile(P2_STEP(0x1, "%2") P2_STEP(0x3, "%3") P2_STEP(0x7, "%4") P2_STEP(0xf, "%5")
@@ -151,6 +190,8 @@ __device__ __forceinline__ void p2_accum8<3>(p2_f32x2& an, p2_f32x2& ao, const p
                  : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
 }
 
+#endif
+
 template <bool IS_L2>
 __device__ __forceinline__ float p2_prefilter(float kd, float dis0) {
     const float slack = (fabsf(kd) + fabsf(dis0)) * 4.8e-7f + 1e-30f;
@@ -163,7 +204,7 @@ __device__ __forceinline__ float p2_prefilter(float kd, float dis0) {
 // twice k = 10 (tools ablation).  The selection also seeds the shared threshold before
 // the bulk scan of the remaining probes starts.
 template <bool IS_L2, int R, bool DUMP>
-__global__ __launch_bounds__(P2_THREADS, (P2_NWAVES >= 8 ? 4 : 2)) void pq_scan_v2_kernel(PqScanArgs a) {
+__global__ __launch_bounds__(P2_THREADS, (P2_NWAVES >= 10 ? 5 : P2_NWAVES >= 8 ? 4 : 2)) void pq_scan_v2_kernel(PqScanArgs a) {
     constexpr int QG = 2;
     extern __shared__ __align__(16) unsigned char smem[];
     float* lut = reinterpret_cast<float*>(smem); // [256][32][2]
@@ -218,7 +259,8 @@ __global__ __launch_bounds__(P2_THREADS, (P2_NWAVES >= 8 ? 4 : 2)) void pq_scan_
         const float4* pt = reinterpret_cast<const float4*>(a.precomp_t + (pre ? list * (int64_t)(P2_KSUB * P2_M) : 0));
         const float4* ta = reinterpret_cast<const float4*>(a.t2t + (int64_t)q_of[0] * (P2_KSUB * P2_M));
         const float4* tb = reinterpret_cast<const float4*>(a.t2t + (int64_t)q_of[1] * (P2_KSUB * P2_M));
-        constexpr int NU = (P2_KSUB * P2_M / 4) / P2_THREADS;
+        constexpr int NSLOT4 = P2_KSUB * P2_M / 4;
+        constexpr int NU = (NSLOT4 + P2_THREADS - 1) / P2_THREADS;
         float4 xa[NU], xb[NU], pp[NU];
 #pragma unroll
         for (int u = 0; u < NU; u++) {
@@ -226,9 +268,10 @@ __global__ __launch_bounds__(P2_THREADS, (P2_NWAVES >= 8 ? 4 : 2)) void pq_scan_
 #if P2_ABLATE == 4 /* timing experiment only: no table loads */
             xa[u] = xb[u] = pp[u] = make_float4(1.f, 2.f, 3.f, (float)e4);
 #else
-            xa[u] = ta[e4];
-            xb[u] = tb[e4];
-            pp[u] = pre ? pt[e4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool in = (NSLOT4 % P2_THREADS == 0) || e4 < NSLOT4;
+            xa[u] = in ? ta[e4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            xb[u] = in ? tb[e4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            pp[u] = (pre && in) ? pt[e4] : make_float4(0.f, 0.f, 0.f, 0.f);
 #endif
         }
         float4* l4 = reinterpret_cast<float4*>(lut);
@@ -243,8 +286,10 @@ __global__ __launch_bounds__(P2_THREADS, (P2_NWAVES >= 8 ? 4 : 2)) void pq_scan_
                 A.z = fadd_x(p.z, fmul_x(-2.0f, A.z)); B.z = fadd_x(p.z, fmul_x(-2.0f, B.z));
                 A.w = fadd_x(p.w, fmul_x(-2.0f, A.w)); B.w = fadd_x(p.w, fmul_x(-2.0f, B.w));
             }
-            l4[e4 * 2 + 0] = make_float4(A.x, B.x, A.y, B.y);
-            l4[e4 * 2 + 1] = make_float4(A.z, B.z, A.w, B.w);
+            if ((NSLOT4 % P2_THREADS == 0) || e4 < NSLOT4) {
+                l4[e4 * 2 + 0] = make_float4(A.x, B.x, A.y, B.y);
+                l4[e4 * 2 + 1] = make_float4(A.z, B.z, A.w, B.w);
+            }
         }
     }
     __syncthreads();
