@@ -251,6 +251,34 @@ __device__ __forceinline__ float tighter(float a, float b) {
     return IS_L2 ? fminf(a, b) : fmaxf(a, b);
 }
 
+// ---- order-preserving integer keys for distances (smaller key = better candidate) ------------------
+// used by the per-query candidate histogram (pq_scan_v2.hip): binning in the integer key domain has no
+// rounding, so "every distance in bins <= b is <= bound(b)" holds exactly
+__device__ __forceinline__ uint32_t okey_f32(float d) {
+    const uint32_t b = __float_as_uint(d);
+    return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+}
+__device__ __forceinline__ float okey_inv_f32(uint32_t k) {
+    return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
+}
+template <bool IS_L2>
+__device__ __forceinline__ uint32_t dist_key(float d) {
+    return IS_L2 ? okey_f32(d) : ~okey_f32(d);
+}
+template <bool IS_L2>
+__device__ __forceinline__ float dist_key_inv(uint32_t k) {
+    return okey_inv_f32(IS_L2 ? k : ~k);
+}
+constexpr int KN_HIST_BINS = 64;
+constexpr uint32_t KN_HIST_OFF = 0xffu; // meta.y: histogram disabled for this query
+__device__ __forceinline__ uint32_t hist_bin(uint32_t key, uint32_t lo, uint32_t shift) {
+    if (key <= lo) {
+        return 0u;
+    }
+    const uint32_t b = (key - lo) >> shift;
+    return b < (uint32_t)(KN_HIST_BINS - 1) ? b : (uint32_t)(KN_HIST_BINS - 1);
+}
+
 // runtime k -> compile-time R dispatch (k <= 1024)
 #define KN_MAX_K 1024
 #define KN_DISPATCH_R(k, ...)                \

@@ -86,6 +86,10 @@ struct PqScanArgs {
     // rank-0 "dump" phase (pq_scan_v2.hip): every finished distance goes to dump[q * dump_stride + offset]
     float* dump;
     int64_t dump_stride;
+    // per-query candidate histogram (pq_scan_v2 after a rank-0 phase; null = off): ghist[q][64] counts the
+    // vectors seen so far per distance bin, gmeta[q] = {key of the first bin, bin shift | KN_HIST_OFF}
+    uint32_t* ghist;
+    const uint2* gmeta;
 };
 
 
@@ -145,7 +149,7 @@ hipError_t launch_pq_scan_v2(const PqScanArgs& a, bool is_l2, bool dump, int64_t
 hipError_t launch_rank0_select(const float* dump, int64_t dump_stride, const int64_t* keys, int nprobe,
                                const int64_t* list_len, const int64_t* list_row_off, const int64_t* ids,
                                int64_t nq, int k, bool is_l2, float* partial_d, int64_t* partial_i, float* gthr,
-                               int64_t* tmp_keys, float* tmp_d, hipStream_t s);
+                               int64_t* tmp_keys, float* tmp_d, uint32_t* ghist, uint2* gmeta, hipStream_t s);
 hipError_t launch_pq_stream16(const uint8_t* codes, const int64_t* list_row_off, const int64_t* list_len,
                               const int64_t* list_sblk_off, int64_t nlist, uint4* out, hipStream_t s);
 

@@ -116,6 +116,8 @@ struct Workspace {
     DevBuf dump;         // [qb][max list len] rank-0 phase distances (pq_scan_v2 DUMP)
     DevBuf sel_keys;     // [qb][k]
     DevBuf sel_d;        // [qb][k]
+    DevBuf ghist;        // [qb][64] per-query candidate histogram (pq_scan_v2 after a rank-0 phase)
+    DevBuf gmeta;        // [qb] {first-bin key, shift}
     DevBuf list_count, list_pair_off, list_item_off, list_cursor, pairs, items, nitems;
     // host-boundary staging
     DevBuf h_queries, h_bitset, h_out_d, h_out_i;
@@ -163,6 +165,7 @@ struct knhip_index {
     DevBuf d_list_blk_off2;
     bool pq_v2 = false;
     bool rank0_select = true;  // KNHIP_RANK0=0 switches the dump + radix-select phase off
+    bool cand_hist = true;     // KNHIP_HIST=0 switches the per-query candidate histogram off
     mutable bool rank0_phase_used = false;
     int64_t max_list_len = 0;
     // scratch
@@ -324,6 +327,8 @@ int build_list_layout(knhip_index* idx, const std::vector<int64_t>& list_off, co
     {
         const char* e = getenv("KNHIP_RANK0");
         idx->rank0_select = !(e && e[0] == '0');
+        const char* h = getenv("KNHIP_HIST");
+        idx->cand_hist = !(h && h[0] == '0');
     }
     for (int64_t l = 0; l < nlist; l++) {
         idx->h_list_len[l] = list_off[l + 1] - list_off[l];
@@ -570,6 +575,8 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
                 HIP_TRY(ws->dump.reserve((size_t)nq * stride * sizeof(float)));
                 HIP_TRY(ws->sel_keys.reserve((size_t)nq * k * sizeof(int64_t)));
                 HIP_TRY(ws->sel_d.reserve((size_t)nq * k * sizeof(float)));
+                HIP_TRY(ws->ghist.reserve((size_t)nq * 64 * sizeof(uint32_t)));
+                HIP_TRY(ws->gmeta.reserve((size_t)nq * sizeof(uint2)));
                 a.dump = ws->dump.as<float>();
                 a.dump_stride = stride;
                 a.item_lo = nullptr;
@@ -581,7 +588,13 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
                     HIP_TRY(launch_rank0_select(a.dump, stride, ws->keys.as<int64_t>(), nprobe,
                                                 idx->d_list_len.as<int64_t>(), idx->d_list_row_off.as<int64_t>(),
                                                 idx->ids.as<int64_t>(), nq, k, is_l2, a.partial_d, a.partial_i,
-                                                a.gthr, ws->sel_keys.as<int64_t>(), ws->sel_d.as<float>(), s));
+                                                a.gthr, ws->sel_keys.as<int64_t>(), ws->sel_d.as<float>(),
+                                                idx->cand_hist ? ws->ghist.as<uint32_t>() : nullptr,
+                                                ws->gmeta.as<uint2>(), s));
+                }
+                if (idx->cand_hist) {
+                    a.ghist = ws->ghist.as<uint32_t>();
+                    a.gmeta = ws->gmeta.as<uint2>();
                 }
                 idx->rank0_phase_used = true;
                 // phase B: every other probe

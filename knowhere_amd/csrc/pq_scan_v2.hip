@@ -236,6 +236,29 @@ __global__ __launch_bounds__(P2_THREADS, (P2_NWAVES >= 10 ? 5 : P2_NWAVES >= 8 ?
         dis0[j] = (a.lut_mode == PQ_LUT_RESIDUAL) ? 0.f : a.coarse_dis[(int64_t)p.q * a.nslot + p.slot];
     }
 
+    // candidate histogram of this item's queries: wave j refreshes query j's bound from it; the row is
+    // requested here so that its latency hides behind the table loads of the LUT build
+    uint32_t h_lo[QG], h_shift[QG];
+#pragma unroll
+    for (int j = 0; j < QG; j++) {
+        h_lo[j] = 0;
+        h_shift[j] = KN_HIST_OFF;
+        if (!DUMP && a.ghist != nullptr) {
+            const uint2 mt = a.gmeta[q_of[j]];
+            h_lo[j] = mt.x;
+            h_shift[j] = mt.y;
+        }
+    }
+    uint32_t h_cnt = 0;
+    const bool h_one = wave == 1; // (selects instead of register-array indexing)
+    const int32_t h_q = h_one ? q_of[1] : q_of[0];
+    const uint32_t h_lo_w = h_one ? h_lo[1] : h_lo[0], h_shift_w = h_one ? h_shift[1] : h_shift[0];
+    const bool h_mine = !DUMP && wave < npair && h_shift_w != KN_HIST_OFF;
+    if (h_mine) {
+        h_cnt = __hip_atomic_load(a.ghist + (int64_t)h_q * KN_HIST_BINS + lane, __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_AGENT);
+    }
+
     // ---- LUT[code][m][query] in LDS -------------------------------------------------------------
     if (a.lut_mode == PQ_LUT_RESIDUAL) {
         const int dsub = a.d / P2_M;
@@ -314,6 +337,36 @@ __global__ __launch_bounds__(P2_THREADS, (P2_NWAVES >= 10 ? 5 : P2_NWAVES >= 8 ?
         ki[j] = -1;
         gt[j] = gthr_load<IS_L2>(a.gthr + q_of[j]);
         pre[j] = p2_prefilter<IS_L2>(tighter<IS_L2>(kd[j], gt[j]), dis0[j]);
+    }
+
+    if (h_mine) {
+        // inclusive prefix sum of the 64 bins across the wave; first bin where k vectors are reached
+        uint32_t cum = h_cnt;
+#pragma unroll
+        for (int dlt = 1; dlt < KN_WAVE; dlt <<= 1) {
+            const uint32_t up = __shfl_up(cum, dlt, KN_WAVE);
+            cum += lane >= dlt ? up : 0u;
+        }
+        const unsigned long long reach = __ballot(cum >= (uint32_t)a.k);
+        const int b = reach ? __ffsll((long long)reach) - 1 : KN_HIST_BINS;
+        if (b < KN_HIST_BINS - 1) { // (the last bin also collects everything beyond the range)
+            const unsigned long long edge = (unsigned long long)h_lo_w + (((unsigned long long)b + 1ull) << h_shift_w) - 1ull;
+            if (edge < 0xffffffffull) {
+                const float bound = dist_key_inv<IS_L2>((uint32_t)edge);
+                if (bound == bound && fabsf(bound) < FLT_MAX) {
+#pragma unroll
+                    for (int j = 0; j < QG; j++) {
+                        if (j == (h_one ? 1 : 0)) {
+                            gt[j] = tighter<IS_L2>(gt[j], bound);
+                            pre[j] = p2_prefilter<IS_L2>(tighter<IS_L2>(kd[j], gt[j]), dis0[j]);
+                        }
+                    }
+                    if (lane == 0) {
+                        gthr_publish<IS_L2>(a.gthr + h_q, bound);
+                    }
+                }
+            }
+        }
     }
 
     typedef __attribute__((address_space(3))) const p2_f32x2 lds_f2;
@@ -438,6 +491,10 @@ __global__ __launch_bounds__(P2_THREADS, (P2_NWAVES >= 10 ? 5 : P2_NWAVES >= 8 ?
                                 kd[qi] = top[qi].kth_dist();
                                 ki[qi] = top[qi].kth_idx();
                                 tightened = true;
+                                if (h_shift[qi] != KN_HIST_OFF && lane == 0) { // one more vector at this distance
+                                    atomicAdd(a.ghist + (int64_t)q_of[qi] * KN_HIST_BINS +
+                                                      hist_bin(dist_key<IS_L2>(dis), h_lo[qi], h_shift[qi]), 1u);
+                                }
                             }
                             if (tightened && ki[qi] >= 0 && lane == 0) {
                                 gthr_publish<IS_L2>(a.gthr + q_of[qi], kd[qi]);
@@ -574,10 +631,47 @@ __global__ void rank0_finalize_kernel(const int64_t* __restrict__ sel_off, const
     }
 }
 
+// ---- rank-0 epilogue 2: seed the per-query candidate histogram ---------------------------------------------
+// One wave per query.  The k selected distances of the closest list span [best, k-th]; 64 bins over that key
+// range (bin = (key - key(best)) >> shift).  A later reader that finds cum(bins <= b) >= k knows that k
+// vectors are at least as good as the upper edge of bin b: a valid, ever tightening bound on the final k-th
+// distance long before any single workgroup has k candidates of its own.
+template <bool IS_L2>
+__global__ __launch_bounds__(64) void rank0_hist_kernel(const int64_t* __restrict__ sel_off,
+                                                        const float* __restrict__ sel_d, int64_t nq, int k,
+                                                        uint32_t* __restrict__ ghist, uint2* __restrict__ gmeta) {
+    __shared__ uint32_t h[KN_HIST_BINS];
+    const int64_t q = blockIdx.x;
+    const int lane = threadIdx.x;
+    h[lane] = 0;
+    __syncthreads();
+    auto valid = [&](int e) {
+        const float d = sel_d[q * k + e];
+        return sel_off[q * k + e] >= 0 && (IS_L2 ? (d < worst_dist<IS_L2>()) : (d > worst_dist<IS_L2>()));
+    };
+    uint32_t lo = 0, shift = KN_HIST_OFF;
+    if (valid(k - 1)) { // the list is sorted best-first: k real candidates
+        lo = dist_key<IS_L2>(sel_d[q * k]);
+        const uint32_t range = dist_key<IS_L2>(sel_d[q * k + k - 1]) - lo;
+        shift = 0;
+        while ((range >> shift) >= (uint32_t)(KN_HIST_BINS - 1)) {
+            shift++;
+        }
+        for (int e = lane; e < k; e += 64) {
+            atomicAdd(&h[hist_bin(dist_key<IS_L2>(sel_d[q * k + e]), lo, shift)], 1u);
+        }
+    }
+    __syncthreads();
+    ghist[q * KN_HIST_BINS + lane] = h[lane];
+    if (lane == 0) {
+        gmeta[q] = make_uint2(lo, shift);
+    }
+}
+
 hipError_t launch_rank0_select(const float* dump, int64_t dump_stride, const int64_t* keys, int nprobe,
                                const int64_t* list_len, const int64_t* list_row_off, const int64_t* ids,
                                int64_t nq, int k, bool is_l2, float* partial_d, int64_t* partial_i, float* gthr,
-                               int64_t* tmp_keys, float* tmp_d, hipStream_t s) {
+                               int64_t* tmp_keys, float* tmp_d, uint32_t* ghist, uint2* gmeta, hipStream_t s) {
     if (nq <= 0) {
         return hipSuccess;
     }
@@ -592,6 +686,15 @@ hipError_t launch_rank0_select(const float* dump, int64_t dump_stride, const int
     } else {
         hipLaunchKernelGGL((rank0_finalize_kernel<false>), dim3(grid), dim3(256), 0, s, tmp_keys, tmp_d, keys, nprobe,
                            list_row_off, ids, nq, k, partial_d, partial_i, gthr);
+    }
+    if (ghist != nullptr) {
+        if (is_l2) {
+            hipLaunchKernelGGL((rank0_hist_kernel<true>), dim3((unsigned)nq), dim3(64), 0, s, tmp_keys, tmp_d, nq, k,
+                               ghist, gmeta);
+        } else {
+            hipLaunchKernelGGL((rank0_hist_kernel<false>), dim3((unsigned)nq), dim3(64), 0, s, tmp_keys, tmp_d, nq, k,
+                               ghist, gmeta);
+        }
     }
     return hipGetLastError();
 }
