@@ -185,6 +185,34 @@ class Port:
             return self.flat_search(ix.metric, ix.base, xq, k, bitset)
         return self.ivf_search(ix, xq, k, nprobe, bitset, nbits)
 
+    def _collect(self, lims, pi, pd, free):
+        n = int(lims[-1])
+        ids = np.ctypeslib.as_array(pi, shape=(max(n, 1),))[:n].copy() if n else np.empty(0, np.int64)
+        dis = np.ctypeslib.as_array(pd, shape=(max(n, 1),))[:n].copy() if n else np.empty(0, np.float32)
+        free(pi)
+        free(pd)
+        return lims, ids, dis
+
+    def range_search(self, ix, xq, radius, max_empty=2, bitset=None, nbits=0):
+        """-> (lims[nq+1], ids, distances): FLAT or IVF range search, results in the reference's emission order"""
+        xq = np.ascontiguousarray(xq, np.float32)
+        nq = xq.shape[0]
+        lims = np.zeros(nq + 1, np.int64)
+        pi, pd = _i64p(), _f32p()
+        L = self.lib
+        if ix.kind == FLAT:
+            base = np.ascontiguousarray(ix.base, np.float32)
+            rc = L.orc_flat_range_search(C.c_int(ix.metric), C.c_int(ix.d), C.c_int64(base.shape[0]), _p(base, _f32p),
+                                         C.c_int64(nq), _p(xq, _f32p), C.c_float(radius), _p(bitset, _u8p),
+                                         C.c_int64(nbits), _p(lims, _i64p), C.byref(pi), C.byref(pd))
+        else:
+            m, keep = self._marshal(ix)
+            rc = L.orc_ivf_range_search(C.byref(m), C.c_int64(nq), _p(xq, _f32p), C.c_float(radius),
+                                        C.c_int64(max_empty), _p(bitset, _u8p), C.c_int64(nbits), _p(lims, _i64p),
+                                        C.byref(pi), C.byref(pd))
+        assert rc == 0
+        return self._collect(lims, pi, pd, L.orc_free)
+
     def merge_topk(self, metric, D_parts, I_parts):
         nshard, nq, k = D_parts.shape
         D = np.empty((nq, k), np.float32)
@@ -425,6 +453,21 @@ class Ref:
         xb = np.empty((nbr.value, d), np.float32)
         h = C.c_void_p(self.lib.ref_deserialize(_p(blob, _u8p), C.c_int64(blob.size), C.byref(nbr), _p(xb, _f32p)))
         return h, xb
+
+    def range_search(self, h, xq, radius, max_empty=2, bitset=None, nbits=0):
+        xq = np.ascontiguousarray(xq, np.float32)
+        nq = xq.shape[0]
+        lims = np.zeros(nq + 1, np.int64)
+        pi, pd = _i64p(), _f32p()
+        self._chk(self.lib.ref_range_search(h, C.c_int64(nq), _p(xq, _f32p), C.c_float(radius), C.c_int64(max_empty),
+                                            _p(bitset, _u8p), C.c_int64(nbits), _p(lims, _i64p), C.byref(pi),
+                                            C.byref(pd)))
+        n = int(lims[-1])
+        ids = np.ctypeslib.as_array(pi, shape=(max(n, 1),))[:n].copy() if n else np.empty(0, np.int64)
+        dis = np.ctypeslib.as_array(pd, shape=(max(n, 1),))[:n].copy() if n else np.empty(0, np.float32)
+        self.lib.ref_free(pi)
+        self.lib.ref_free(pd)
+        return lims, ids, dis
 
     def search_refine(self, h, xb, xq, k, k_factor, nprobe):
         """IndexRefine(base = h, refine = IndexFlat(xb)).search, one query per call"""

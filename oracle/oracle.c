@@ -194,6 +194,42 @@ static inline void heap_add(int is_max, size_t k, float* val, int64_t* ids, floa
     }
 }
 
+/* Result sink of a list scan: top-k heap (HeapResultHandler) or range collector
+ * (RangeQueryResult::add, T:impl/AuxIndexStructures.h; admission C::cmp(radius, dis), i.e. strictly
+ * inside the radius: L2 dis < radius, IP dis > radius -- T:IndexIVFFlat.cpp scan_codes_range,
+ * IVFPQScanner_impl.h scan_codes_range, utils/distances.cpp range_search_L2sqr). */
+typedef struct orc_sink {
+    int is_max;
+    /* top-k */
+    size_t k;
+    float* val;
+    int64_t* ids;
+    /* range (k == 0) */
+    float radius;
+    size_t n, cap;
+    float* rdis;
+    int64_t* rids;
+} orc_sink;
+
+static inline void sink_add(orc_sink* s, float dis, int64_t id) {
+    if (s->k > 0) {
+        if (cmp1(s->is_max, s->val[0], dis)) {
+            orc_heap_replace_top(s->is_max, s->k, s->val, s->ids, dis, id);
+        }
+        return;
+    }
+    if (cmp1(s->is_max, s->radius, dis)) {
+        if (s->n == s->cap) {
+            s->cap = s->cap ? s->cap * 2 : 256;
+            s->rdis = (float*)realloc(s->rdis, sizeof(float) * s->cap);
+            s->rids = (int64_t*)realloc(s->rids, sizeof(int64_t) * s->cap);
+        }
+        s->rdis[s->n] = dis;
+        s->rids[s->n] = id;
+        s->n++;
+    }
+}
+
 /* BitsetViewIDSelector::is_member, reference include/knowhere/bitsetview_idselector.h:20-31 */
 static inline int filtered_out(const uint8_t* bitset, int64_t nbits, int64_t id) {
     if (!bitset || id < 0 || id >= nbits) {
@@ -354,103 +390,125 @@ static float sq8_distance(int metric, int d, const float* trained, const float* 
  * per query: heapify; for each probe in coarse-rank order: skip key<0 / empty lists,
  * set_list, scan_codes in storage order through a HeapResultHandler; heap_reorder.
  * ---------------------------------------------------------------------------------------- */
+typedef struct orc_scan_state {
+    float* sim_table;
+    float* sim_table_2;
+    float* resid;
+} orc_scan_state;
+
+static void scan_state_init(const orc_index* idx, orc_scan_state* st) {
+    const size_t ksub = (size_t)1 << (idx->kind == ORC_IVF_PQ ? idx->nbits : 0);
+    const size_t m_ksub = (size_t)idx->M * ksub;
+    st->sim_table = st->sim_table_2 = NULL;
+    st->resid = (float*)malloc(sizeof(float) * (size_t)idx->d);
+    if (idx->kind == ORC_IVF_PQ) {
+        st->sim_table = (float*)malloc(sizeof(float) * m_ksub);
+        st->sim_table_2 = (float*)malloc(sizeof(float) * m_ksub);
+    }
+}
+
+static void scan_state_free(orc_scan_state* st) {
+    free(st->sim_table);
+    free(st->sim_table_2);
+    free(st->resid);
+}
+
+/* set_query: T:impl/pq_code_distance/IVFPQ_QueryTables.cpp:44-67 */
+static void scan_set_query(const orc_index* idx, orc_scan_state* st, const float* q) {
+    if (idx->kind == ORC_IVF_PQ) {
+        if (idx->metric == ORC_IP) {
+            orc_pq_inner_prod_table(idx->d, idx->M, idx->nbits, idx->pq_centroids, q, st->sim_table);
+        } else if (idx->use_precomputed_table == 1) {
+            orc_pq_inner_prod_table(idx->d, idx->M, idx->nbits, idx->pq_centroids, q, st->sim_table_2);
+        }
+    }
+}
+
+/* set_list + scan_codes of one inverted list in storage order into the sink */
+static void scan_one_list(const orc_index* idx, orc_scan_state* st, const float* q, int64_t key, float cdis,
+                          const uint8_t* bitset, int64_t nbits, orc_sink* sk) {
+    const int is_max = (idx->metric == ORC_L2);
+    const int d = idx->d;
+    const size_t ksub = (size_t)1 << (idx->kind == ORC_IVF_PQ ? idx->nbits : 0);
+    const int64_t len = idx->list_sizes[key];
+    const uint8_t* codes = idx->list_codes[key];
+    const int64_t* ids = idx->list_ids[key];
+    if (idx->kind == ORC_IVF_FLAT) {
+        /* T:IndexIVFFlat.cpp IVFFlatScanner::scan_codes: dis = metric(q, row) */
+        for (int64_t j = 0; j < len; j++) {
+            if (filtered_out(bitset, nbits, ids[j])) {
+                continue;
+            }
+            const float* y = (const float*)(codes + j * idx->code_size);
+            float dis = is_max ? orc_fvec_L2sqr(q, y, (size_t)d) : orc_fvec_inner_product(q, y, (size_t)d);
+            sink_add(sk, dis, ids[j]);
+        }
+    } else if (idx->kind == ORC_IVF_PQ) {
+        const float dis0 = orc_ivfpq_list_table(idx, q, key, cdis,
+                                                idx->metric == ORC_IP ? st->sim_table : st->sim_table_2,
+                                                st->sim_table);
+        for (int64_t j = 0; j < len; j++) {
+            if (filtered_out(bitset, nbits, ids[j])) {
+                continue;
+            }
+            const float dis = dis0 + adc_distance(idx->M, ksub, st->sim_table, codes + j * idx->code_size);
+            sink_add(sk, dis, ids[j]);
+        }
+    } else if (idx->kind == ORC_IVF_SQ8) {
+        /* reference thirdparty/faiss/faiss/cppcontrib/knowhere/IndexScalarQuantizer.cpp
+         * :196-290 (IP: accu0 = coarse_dis, dis = accu0 + <q, x>),
+         * :292-400 (L2: query residual q - c_list, dis = ||r - x||^2); by_residual */
+        const float* y = q;
+        float accu0 = 0;
+        if (idx->metric == ORC_IP) {
+            accu0 = cdis;
+        } else {
+            const float* c = idx->centroids + key * (int64_t)d;
+            for (int t = 0; t < d; t++) {
+                st->resid[t] = q[t] - c[t];
+            }
+            y = st->resid;
+        }
+        for (int64_t j = 0; j < len; j++) {
+            if (filtered_out(bitset, nbits, ids[j])) {
+                continue;
+            }
+            float dis = sq8_distance(idx->metric, d, idx->sq_trained, y, codes + j * idx->code_size);
+            if (idx->metric == ORC_IP) {
+                dis = accu0 + dis;
+            }
+            sink_add(sk, dis, ids[j]);
+        }
+    }
+}
+
 int orc_ivf_search_preassigned(const orc_index* idx, int64_t nq, const float* xq, int64_t k,
                                int64_t nprobe, const int64_t* keys, const float* coarse_dis,
                                const uint8_t* bitset, int64_t nbits, float* D, int64_t* I) {
     const int is_max = (idx->metric == ORC_L2);
     const int d = idx->d;
-    const size_t ksub = (size_t)1 << (idx->kind == ORC_IVF_PQ ? idx->nbits : 0);
-    const size_t m_ksub = (size_t)idx->M * ksub;
-    float* sim_table = NULL;
-    float* sim_table_2 = NULL;
-    float* resid = (float*)malloc(sizeof(float) * (size_t)d);
-    if (idx->kind == ORC_IVF_PQ) {
-        sim_table = (float*)malloc(sizeof(float) * m_ksub);
-        sim_table_2 = (float*)malloc(sizeof(float) * m_ksub);
-    }
+    orc_scan_state st;
+    scan_state_init(idx, &st);
     for (int64_t i = 0; i < nq; i++) {
         const float* q = xq + i * (int64_t)d;
-        float* simi = D + i * k;
-        int64_t* idxi = I + i * k;
-        orc_heap_heapify(is_max, (size_t)k, simi, idxi);
-
-        /* set_query: T:impl/pq_code_distance/IVFPQ_QueryTables.cpp:44-67 */
-        if (idx->kind == ORC_IVF_PQ) {
-            if (idx->metric == ORC_IP) {
-                orc_pq_inner_prod_table(d, idx->M, idx->nbits, idx->pq_centroids, q, sim_table);
-            } else if (idx->use_precomputed_table == 1) {
-                orc_pq_inner_prod_table(d, idx->M, idx->nbits, idx->pq_centroids, q, sim_table_2);
-            }
-        }
+        orc_sink sk;
+        memset(&sk, 0, sizeof(sk));
+        sk.is_max = is_max;
+        sk.k = (size_t)k;
+        sk.val = D + i * k;
+        sk.ids = I + i * k;
+        orc_heap_heapify(is_max, (size_t)k, sk.val, sk.ids);
+        scan_set_query(idx, &st, q);
         for (int64_t ik = 0; ik < nprobe; ik++) {
             const int64_t key = keys[i * nprobe + ik];
-            if (key < 0) {
+            if (key < 0 || idx->list_sizes[key] == 0) {
                 continue;
             }
-            const int64_t len = idx->list_sizes[key];
-            if (len == 0) {
-                continue;
-            }
-            const uint8_t* codes = idx->list_codes[key];
-            const int64_t* ids = idx->list_ids[key];
-            const float cdis = coarse_dis[i * nprobe + ik];
-
-            if (idx->kind == ORC_IVF_FLAT) {
-                /* T:IndexIVFFlat.cpp IVFFlatScanner::scan_codes: dis = metric(q, row) */
-                for (int64_t j = 0; j < len; j++) {
-                    if (filtered_out(bitset, nbits, ids[j])) {
-                        continue;
-                    }
-                    const float* y = (const float*)(codes + j * idx->code_size);
-                    float dis = is_max ? orc_fvec_L2sqr(q, y, (size_t)d)
-                                       : orc_fvec_inner_product(q, y, (size_t)d);
-                    heap_add(is_max, (size_t)k, simi, idxi, dis, ids[j]);
-                }
-            } else if (idx->kind == ORC_IVF_PQ) {
-                const float dis0 = orc_ivfpq_list_table(
-                        idx, q, key, cdis, idx->metric == ORC_IP ? sim_table : sim_table_2,
-                        sim_table);
-                for (int64_t j = 0; j < len; j++) {
-                    if (filtered_out(bitset, nbits, ids[j])) {
-                        continue;
-                    }
-                    const float dis =
-                            dis0 + adc_distance(idx->M, ksub, sim_table, codes + j * idx->code_size);
-                    heap_add(is_max, (size_t)k, simi, idxi, dis, ids[j]);
-                }
-            } else if (idx->kind == ORC_IVF_SQ8) {
-                /* reference thirdparty/faiss/faiss/cppcontrib/knowhere/IndexScalarQuantizer.cpp
-                 * :196-290 (IP: accu0 = coarse_dis, dis = accu0 + <q, x>),
-                 * :292-400 (L2: query residual q - c_list, dis = ||r - x||^2); by_residual */
-                const float* y = q;
-                float accu0 = 0;
-                if (idx->metric == ORC_IP) {
-                    accu0 = cdis;
-                } else {
-                    const float* c = idx->centroids + key * (int64_t)d;
-                    for (int t = 0; t < d; t++) {
-                        resid[t] = q[t] - c[t];
-                    }
-                    y = resid;
-                }
-                for (int64_t j = 0; j < len; j++) {
-                    if (filtered_out(bitset, nbits, ids[j])) {
-                        continue;
-                    }
-                    float dis = sq8_distance(idx->metric, d, idx->sq_trained, y,
-                                             codes + j * idx->code_size);
-                    if (idx->metric == ORC_IP) {
-                        dis = accu0 + dis;
-                    }
-                    heap_add(is_max, (size_t)k, simi, idxi, dis, ids[j]);
-                }
-            }
+            scan_one_list(idx, &st, q, key, coarse_dis[i * nprobe + ik], bitset, nbits, &sk);
         }
-        orc_heap_reorder(is_max, (size_t)k, simi, idxi);
+        orc_heap_reorder(is_max, (size_t)k, sk.val, sk.ids);
     }
-    free(sim_table);
-    free(sim_table_2);
-    free(resid);
+    scan_state_free(&st);
     return 0;
 }
 
@@ -466,6 +524,109 @@ int orc_ivf_search(const orc_index* idx, int64_t nq, const float* xq, int64_t k,
     free(cd);
     free(keys);
     return rc;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Range search.
+ *   IVF: IvfIndexNode::RangeSearch (reference src/index/ivf/ivf.cc:1231-1420) drives
+ *   index->range_search(1, q, radius, res, params{nprobe = nlist, max_empty_result_buckets, sel}) ->
+ *   T:IndexIVF.cpp:774-990 range_search_preassigned, parallel_mode 0: lists in coarse order, each
+ *   scanned in storage order; after a list the counter of consecutive lists that added nothing is
+ *   bumped or reset and the loop stops when it reaches max_empty_result_buckets (> 0); empty lists
+ *   and key < 0 count as "added nothing".
+ *   FLAT: IndexFlat::range_search -> T:utils/distances.cpp range_search_L2sqr / _inner_product:
+ *   every unfiltered row strictly inside the radius, in storage order.
+ * Results: lims[nq + 1], and malloc'ed ids / distances (release with orc_free).
+ * ---------------------------------------------------------------------------------------- */
+static void range_flush(orc_sink* sk, int64_t i, int64_t* lims, int64_t** out_ids, float** out_dis, size_t* total,
+                        size_t* cap) {
+    if (*total + sk->n > *cap) {
+        *cap = (*total + sk->n) * 2 + 256;
+        *out_ids = (int64_t*)realloc(*out_ids, sizeof(int64_t) * *cap);
+        *out_dis = (float*)realloc(*out_dis, sizeof(float) * *cap);
+    }
+    if (sk->n) {
+        memcpy(*out_ids + *total, sk->rids, sizeof(int64_t) * sk->n);
+        memcpy(*out_dis + *total, sk->rdis, sizeof(float) * sk->n);
+    }
+    *total += sk->n;
+    lims[i + 1] = (int64_t)*total;
+    free(sk->rids);
+    free(sk->rdis);
+}
+
+int orc_ivf_range_search(const orc_index* idx, int64_t nq, const float* xq, float radius,
+                         int64_t max_empty_result_buckets, const uint8_t* bitset, int64_t nbits, int64_t* lims,
+                         int64_t** out_ids, float** out_dis) {
+    const int is_max = (idx->metric == ORC_L2);
+    const int d = idx->d;
+    const int64_t nprobe = idx->nlist; /* ivf.cc:1290 / :1391: every list is a candidate */
+    float* cd = (float*)malloc(sizeof(float) * (size_t)nprobe);
+    int64_t* keys = (int64_t*)malloc(sizeof(int64_t) * (size_t)nprobe);
+    orc_scan_state st;
+    scan_state_init(idx, &st);
+    size_t total = 0, cap = 0;
+    *out_ids = NULL;
+    *out_dis = NULL;
+    lims[0] = 0;
+    for (int64_t i = 0; i < nq; i++) {
+        const float* q = xq + i * (int64_t)d;
+        orc_coarse_search(idx, 1, q, nprobe, cd, keys);
+        orc_sink sk;
+        memset(&sk, 0, sizeof(sk));
+        sk.is_max = is_max;
+        sk.radius = radius;
+        scan_set_query(idx, &st, q);
+        size_t prev = 0;
+        int64_t ndup = 0;
+        for (int64_t ik = 0; ik < nprobe; ik++) {
+            const int64_t key = keys[ik];
+            if (key >= 0 && idx->list_sizes[key] != 0) {
+                scan_one_list(idx, &st, q, key, cd[ik], bitset, nbits, &sk);
+            }
+            if (max_empty_result_buckets > 0) {
+                ndup = (sk.n == prev) ? ndup + 1 : 0;
+                if (ndup >= max_empty_result_buckets) {
+                    break;
+                }
+                prev = sk.n;
+            }
+        }
+        range_flush(&sk, i, lims, out_ids, out_dis, &total, &cap);
+    }
+    scan_state_free(&st);
+    free(cd);
+    free(keys);
+    return 0;
+}
+
+int orc_flat_range_search(int metric, int d, int64_t nb, const float* xb, int64_t nq, const float* xq, float radius,
+                          const uint8_t* bitset, int64_t nbits, int64_t* lims, int64_t** out_ids, float** out_dis) {
+    const int is_max = (metric == ORC_L2);
+    size_t total = 0, cap = 0;
+    *out_ids = NULL;
+    *out_dis = NULL;
+    lims[0] = 0;
+    for (int64_t i = 0; i < nq; i++) {
+        const float* x = xq + i * (int64_t)d;
+        orc_sink sk;
+        memset(&sk, 0, sizeof(sk));
+        sk.is_max = is_max;
+        sk.radius = radius;
+        for (int64_t j = 0; j < nb; j++) {
+            if (filtered_out(bitset, nbits, j)) {
+                continue;
+            }
+            const float* y = xb + j * (int64_t)d;
+            sink_add(&sk, is_max ? orc_fvec_L2sqr(x, y, (size_t)d) : orc_fvec_inner_product(x, y, (size_t)d), j);
+        }
+        range_flush(&sk, i, lims, out_ids, out_dis, &total, &cap);
+    }
+    return 0;
+}
+
+void orc_free(void* p) {
+    free(p);
 }
 
 /* ------------------------------------------------------------------------------------------

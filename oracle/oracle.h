@@ -89,6 +89,14 @@ int orc_ivf_search_preassigned(const orc_index* idx, int64_t nq, const float* xq
 /* Refine (second stage of IndexRefine::search, T:IndexRefine.cpp:104-140): re-score candidate
  * labels (stop at the first -1) with the exact metric on the raw vectors, keep the k best.
  * base row r holds id id_base + r. */
+/* range search (results malloc'ed, release with orc_free) */
+int orc_ivf_range_search(const orc_index* idx, int64_t nq, const float* xq, float radius,
+                         int64_t max_empty_result_buckets, const uint8_t* bitset, int64_t nbits, int64_t* lims,
+                         int64_t** out_ids, float** out_dis);
+int orc_flat_range_search(int metric, int d, int64_t nb, const float* xb, int64_t nq, const float* xq, float radius,
+                          const uint8_t* bitset, int64_t nbits, int64_t* lims, int64_t** out_ids, float** out_dis);
+void orc_free(void* p);
+
 int orc_refine(int metric, int d, const float* base, int64_t nbase, int64_t id_base, int64_t nq,
                const float* xq, int64_t k_base, const int64_t* cand_ids, int64_t k, float* D, int64_t* I);
 

@@ -30,6 +30,8 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <vector>
+#include <cstdlib>
 
 namespace {
 
@@ -435,6 +437,60 @@ void* ref_deserialize(const uint8_t* data, int64_t size, int64_t* nb_refine, flo
         return nullptr;
     }
     return h;
+}
+
+/// Range search driven the way IvfIndexNode::RangeSearch / FlatIndexNode::RangeSearch do (reference
+/// src/index/ivf/ivf.cc:1231-1420): one query per faiss::RangeSearchResult(1),
+/// IVFSearchParameters{nprobe = nlist, max_codes = 0, max_empty_result_buckets, sel}.
+/// lims[nq + 1]; *out_ids / *out_dis are malloc'ed (release with ref_free).
+int ref_range_search(
+        void* hv,
+        int64_t nq,
+        const float* q,
+        float radius,
+        int64_t max_empty_result_buckets,
+        const uint8_t* bitset,
+        int64_t nbits,
+        int64_t* lims,
+        int64_t** out_ids,
+        float** out_dis) {
+    auto* h = static_cast<RefIndex*>(hv);
+    return guarded([&] {
+        std::vector<int64_t> ids;
+        std::vector<float> dis;
+        lims[0] = 0;
+        for (int64_t i = 0; i < nq; i++) {
+            faiss::RangeSearchResult res(1);
+            std::unique_ptr<BitsetSelector> sel;
+            if (bitset) {
+                sel.reset(new BitsetSelector(bitset, nbits));
+            }
+            if (h->kind == K_FLAT) {
+                faiss::SearchParameters sp;
+                sp.sel = sel.get();
+                h->index->range_search(1, q + i * h->d, radius, &res, &sp);
+            } else {
+                faiss::IVFSearchParameters sp;
+                sp.nprobe = h->ivf()->nlist;
+                sp.max_codes = 0;
+                sp.max_empty_result_buckets = (size_t)max_empty_result_buckets;
+                sp.sel = sel.get();
+                h->index->range_search(1, q + i * h->d, radius, &res, &sp);
+            }
+            const size_t n = res.lims[1];
+            ids.insert(ids.end(), res.labels, res.labels + n);
+            dis.insert(dis.end(), res.distances, res.distances + n);
+            lims[i + 1] = (int64_t)ids.size();
+        }
+        *out_ids = (int64_t*)malloc(sizeof(int64_t) * (ids.size() + 1));
+        *out_dis = (float*)malloc(sizeof(float) * (dis.size() + 1));
+        std::memcpy(*out_ids, ids.data(), sizeof(int64_t) * ids.size());
+        std::memcpy(*out_dis, dis.data(), sizeof(float) * dis.size());
+    });
+}
+
+void ref_free(void* p) {
+    free(p);
 }
 
 /// coarse quantizer alone: quantizer->search(1, q, nprobe) per query
