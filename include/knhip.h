@@ -124,6 +124,24 @@ int64_t knhip_index_count(const knhip_index* idx);         /* stored vectors */
 int64_t knhip_index_device_bytes(const knhip_index* idx);  /* HBM held by the index */
 int knhip_index_uses_precomputed_table(const knhip_index* idx);
 
+/* Range search: every vector strictly inside the radius (L2: dist < radius, IP: dist > radius) among the
+ * lists visited in coarse order, with the reference's early stop after `max_empty_result_buckets`
+ * consecutive lists without a hit (0 = visit every list).  Replaces IvfIndexNode::RangeSearch (reference
+ * src/index/ivf/ivf.cc:1231-1420: nprobe = nlist, IVFSearchParameters::max_empty_result_buckets, default 2)
+ * -> IndexIVF::range_search_preassigned (thirdparty/faiss/faiss/IndexIVF.cpp:812-990, parallel_mode 0) and,
+ * for KNHIP_BRUTE_FORCE, IndexFlat::range_search (thirdparty/faiss/faiss/utils/distances.cpp
+ * range_search_L2sqr / range_search_inner_product; no early stop).  The caller applies `range_filter`
+ * (reference src/common/range_util.cc:27-48).
+ * Host pointers.  lims[nq + 1] receives the per-query offsets; *out_ids / *out_dist receive malloc'ed arrays
+ * of lims[nq] entries (release with knhip_free) in the reference's emission order: list by list in coarse
+ * order, storage order inside a list.  Distances are bit-equal to the scalar reference.
+ * Supported: KNHIP_BRUTE_FORCE, KNHIP_IVF_FLAT, KNHIP_IVF_PQ with m = 32; nlist <= 4096.  Others return
+ * KNHIP_ERR_NOT_IMPLEMENTED. */
+int knhip_range_search(const knhip_index* idx, const float* queries, int64_t nq, float radius,
+                       int32_t max_empty_result_buckets, const uint8_t* bitset, int64_t bitset_nbits, int64_t* lims,
+                       int64_t** out_ids, float** out_dist);
+void knhip_free(void* p);
+
 /* ---- search ---- */
 /* Host boundary (what the IndexNode calls): queries [nq][dim] host fp32; bitset host bytes
  * LSB-first, bit set => id filtered OUT (include/knowhere/bitsetview_idselector.h:20-31),

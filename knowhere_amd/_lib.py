@@ -43,7 +43,7 @@ SYMBOLS = [
     "knhip_merge_topk_host", "knhip_refine_device", "knhip_fvec_L2sqr_ny", "knhip_fvec_inner_products_ny",
     "knhip_fvec_norms_L2sqr", "knhip_fvec_madd", "knhip_int8_vec_L2sqr_ny",
     "knhip_int8_vec_inner_products_ny", "knhip_profile_enable", "knhip_profile_reset",
-    "knhip_profile_get", "knhip_stage_kernel_name",
+    "knhip_profile_get", "knhip_stage_kernel_name", "knhip_range_search", "knhip_free",
 ]
 
 _lib = None
@@ -68,6 +68,10 @@ def load():
     L.knhip_index_create.argtypes = [C.POINTER(Desc), C.POINTER(vp)]
     L.knhip_index_destroy.argtypes = [vp]
     L.knhip_index_destroy.restype = None
+    L.knhip_range_search.argtypes = [vp, vp, i64, C.c_float, i32, vp, i64, vp, C.POINTER(C.POINTER(C.c_int64)),
+                                     C.POINTER(C.POINTER(C.c_float))]
+    L.knhip_free.argtypes = [vp]
+    L.knhip_free.restype = None
     L.knhip_index_set_coarse.argtypes = [vp, vp]
     L.knhip_index_set_coarse_device.argtypes = [vp, vp]
     L.knhip_index_set_pq.argtypes = [vp, vp]

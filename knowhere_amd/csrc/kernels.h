@@ -86,6 +86,7 @@ struct PqScanArgs {
     // rank-0 "dump" phase (pq_scan_v2.hip): every finished distance goes to dump[q * dump_stride + offset]
     float* dump;
     int64_t dump_stride;
+    int32_t dump_by_row;           // 1: column = storage position of the vector (list_row_off + offset), range search
     // per-query candidate histogram (pq_scan_v2 after a rank-0 phase; null = off): ghist[q][64] counts the
     // vectors seen so far per distance bin, gmeta[q] = {key of the first bin, bin shift | KN_HIST_OFF}
     uint32_t* ghist;
@@ -175,6 +176,27 @@ hipError_t launch_build_worktable(const int64_t* keys, int64_t nq, int nprobe, i
                                   const int64_t* list_len, int64_t code_size, const WorkTable& wt,
                                   hipStream_t s);
 hipError_t launch_fill_f32(float* p, int64_t n, float v, hipStream_t s);
+
+// ---- range.hip: range search epilogue over a dumped distance matrix ----
+struct RangeArgs {
+    const float* dist;        // [nq][ncol] every distance of every probed list (scan kernels, dump mode)
+    int64_t ncol;
+    const int64_t* seg_col;   // [nseg] first column of each list / row segment
+    const int64_t* seg_idpos; // [nseg] first entry in ids[] (or first row number when ids == nullptr)
+    const int64_t* seg_len;   // [nseg]
+    const int64_t* ids;       // storage-order ids, or nullptr: id = position + id_offset
+    int64_t id_offset;
+    const int64_t* order;     // [nq][nprobe] segment visited at each rank (coarse order), nullptr: rank == segment
+    int32_t nprobe;
+    float radius;
+    const uint8_t* bitset;
+    int64_t bitset_nbits;
+};
+hipError_t launch_range_count(const RangeArgs& a, int64_t nq, bool is_l2, int32_t* cnt, hipStream_t s);
+hipError_t launch_range_plan(const int32_t* cnt, int64_t nq, int nprobe, int max_empty, int64_t* off, int64_t* total,
+                             hipStream_t s);
+hipError_t launch_range_emit(const RangeArgs& a, int64_t nq, bool is_l2, const int64_t* off, const int64_t* qbase,
+                             int64_t* out_ids, float* out_dis, hipStream_t s);
 
 // ---- topk.hip: selection kernels ----
 // per query: k best of nslot sorted partial lists -> out (canonical order, sentinel padded);

@@ -116,6 +116,7 @@ struct Workspace {
     DevBuf dump;         // [qb][max list len] rank-0 phase distances (pq_scan_v2 DUMP)
     DevBuf sel_keys;     // [qb][k]
     DevBuf sel_d;        // [qb][k]
+    DevBuf rg_seg, rg_cnt, rg_off, rg_tot, rg_out_i, rg_out_d;  // range search scratch
     DevBuf ghist;        // [qb][64] per-query candidate histogram (pq_scan_v2 after a rank-0 phase)
     DevBuf gmeta;        // [qb] {first-bin key, shift}
     DevBuf list_count, list_pair_off, list_item_off, list_cursor, pairs, items, nitems;
@@ -1052,6 +1053,264 @@ int knhip_search(const knhip_index* idx, const float* queries, int64_t nq, int32
     release_ws(idx, ws);
     (void)hipStreamDestroy(s);
     return rc;
+}
+
+// ---- range search ----------------------------------------------------------------------------------------
+// Every probed list is scanned in dump mode (all distances -> dist[q][column]); range.hip then counts the
+// hits per (query, probe rank), applies the reference's early stop and compacts the survivors in the
+// reference's emission order.  One batch of queries (device pointers); results appended to host vectors.
+static int range_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_t nq, float radius,
+                       int max_empty, const uint8_t* d_bitset, int64_t nbits, const int64_t* d_seg /*3 x nseg*/,
+                       int64_t nseg, int64_t ncol, int64_t* h_lims /*nq + 1, relative*/, std::vector<int64_t>& out_i,
+                       std::vector<float>& out_d, hipStream_t s) {
+    const int kind = idx->desc.kind;
+    const bool is_l2 = idx->is_l2;
+    const int d = idx->d;
+    const int nprobe = (int)nseg;
+    HIP_TRY(ws->dump.reserve((size_t)nq * ncol * sizeof(float)));
+    RangeArgs r{};
+    r.dist = ws->dump.as<float>();
+    r.ncol = ncol;
+    r.seg_col = d_seg;
+    r.seg_idpos = d_seg + nseg;
+    r.seg_len = d_seg + 2 * nseg;
+    r.nprobe = nprobe;
+    r.radius = radius;
+    r.bitset = d_bitset;
+    r.bitset_nbits = nbits;
+    if (kind == KNHIP_BRUTE_FORCE || kind == KNHIP_IVF_FLAT) {
+        FlatScanArgs c{};
+        c.rows = idx->rows.as<float4>();
+        c.nrows = ncol;
+        c.chunk_rows = std::max<int64_t>(1024, round_up((ncol + 1023) / 1024, 64));
+        c.d = d;
+        c.nchunk = (d + 3) / 4;
+        c.queries = d_q;
+        c.nq = nq;
+        HIP_TRY(launch_flat_full(c, is_l2, ws->dump.as<float>(), nullptr, 0, nullptr, s));
+    }
+    if (kind == KNHIP_BRUTE_FORCE) {
+        r.ids = nullptr;
+        r.id_offset = idx->id_offset;
+        r.order = nullptr;
+        max_empty = 0; // IndexFlat::range_search has no early stop
+    } else {
+        HIP_TRY(ws->keys.reserve((size_t)nq * nprobe * sizeof(int64_t)));
+        HIP_TRY(ws->cdis.reserve((size_t)nq * nprobe * sizeof(float)));
+        if (int rc = coarse_stage(idx, ws, d_q, nq, nprobe, ws->keys.as<int64_t>(), ws->cdis.as<float>(), s)) {
+            return rc;
+        }
+        r.ids = idx->ids.as<int64_t>();
+        r.order = ws->keys.as<int64_t>();
+    }
+    if (kind == KNHIP_IVF_PQ) {
+        const int M = idx->desc.pq_m;
+        const int mode = !is_l2 ? PQ_LUT_IP : (idx->use_precomp ? PQ_LUT_PRECOMP : PQ_LUT_RESIDUAL);
+        if (mode != PQ_LUT_RESIDUAL) {
+            HIP_TRY(ws->t2t.reserve((size_t)nq * 256 * M * sizeof(float)));
+            HIP_TRY(launch_pq_query_table(d_q, idx->cb.as<float>(), d, M, nq, ws->t2t.as<float>(), s));
+        }
+        const int qg = pq_scan_qg(M);
+        const int64_t nlist = idx->nlist;
+        const int64_t npairs = nq * nprobe;
+        const int64_t items_bound = round_up(npairs / qg + std::min<int64_t>(2 * nlist, npairs) + 1, 8);
+        HIP_TRY(ws->list_count.reserve((size_t)2 * nlist * sizeof(int32_t)));
+        HIP_TRY(ws->list_cursor.reserve((size_t)2 * nlist * sizeof(int32_t)));
+        HIP_TRY(ws->list_pair_off.reserve((size_t)(2 * nlist + 1) * sizeof(int64_t)));
+        HIP_TRY(ws->list_item_off.reserve((size_t)(2 * nlist + 1) * sizeof(int64_t)));
+        HIP_TRY(ws->pairs.reserve((size_t)npairs * sizeof(KnPair)));
+        HIP_TRY(ws->items.reserve((size_t)items_bound * sizeof(KnItem)));
+        HIP_TRY(ws->nitems.reserve(sizeof(int64_t)));
+        HIP_TRY(ws->gthr.reserve((size_t)nq * sizeof(float)));
+        HIP_TRY(launch_fill_f32(ws->gthr.as<float>(), nq, is_l2 ? FLT_MAX : -FLT_MAX, s));
+        WorkTable wt{};
+        wt.list_count = ws->list_count.as<int32_t>();
+        wt.list_cursor = ws->list_cursor.as<int32_t>();
+        wt.list_pair_off = ws->list_pair_off.as<int64_t>();
+        wt.list_item_off = ws->list_item_off.as<int64_t>();
+        wt.pairs = ws->pairs.as<KnPair>();
+        wt.items = ws->items.as<KnItem>();
+        wt.nitems = ws->nitems.as<int64_t>();
+        wt.scan_bytes = idx->scan_bytes_dev.as<double>();
+        HIP_TRY(launch_build_worktable(ws->keys.as<int64_t>(), nq, nprobe, nlist, qg, idx->d_list_len.as<int64_t>(),
+                                       idx->code_size, wt, s));
+        PqScanArgs a{};
+        a.codes_skew = idx->rows2.as<uint4>();
+        a.list_sblk_off = idx->d_list_blk_off2.as<int64_t>();
+        a.list_len = idx->d_list_len.as<int64_t>();
+        a.list_row_off = idx->d_list_row_off.as<int64_t>();
+        a.ids = idx->ids.as<int64_t>();
+        a.precomp_t = idx->precomp_t.as<float>();
+        a.cb = idx->cb.as<float>();
+        a.centroids = idx->centroids.as<float>();
+        a.d = d;
+        a.lut_mode = mode;
+        a.queries = d_q;
+        a.t2t = ws->t2t.as<float>();
+        a.coarse_dis = ws->cdis.as<float>();
+        a.items = wt.items;
+        a.pairs = wt.pairs;
+        a.nitems_dev = wt.nitems;
+        a.bitset = d_bitset;
+        a.bitset_nbits = nbits;
+        a.gthr = ws->gthr.as<float>();
+        a.nslot = nprobe;
+        a.k = 1;
+        a.item_lo = nullptr;
+        a.item_hi = wt.nitems;
+        a.dump = ws->dump.as<float>();
+        a.dump_stride = ncol;
+        a.dump_by_row = 1;
+        HIP_TRY(launch_pq_scan_v2(a, is_l2, true, items_bound, s));
+    }
+    // count -> plan -> (host: totals, bases) -> emit
+    HIP_TRY(ws->rg_cnt.reserve((size_t)nq * nprobe * sizeof(int32_t)));
+    HIP_TRY(ws->rg_off.reserve((size_t)nq * nprobe * sizeof(int64_t)));
+    HIP_TRY(ws->rg_tot.reserve((size_t)nq * 2 * sizeof(int64_t)));
+    HIP_TRY(launch_range_count(r, nq, is_l2, ws->rg_cnt.as<int32_t>(), s));
+    HIP_TRY(launch_range_plan(ws->rg_cnt.as<int32_t>(), nq, nprobe, max_empty, ws->rg_off.as<int64_t>(),
+                              ws->rg_tot.as<int64_t>(), s));
+    std::vector<int64_t> tot((size_t)nq), base((size_t)nq);
+    HIP_TRY(hipMemcpyAsync(tot.data(), ws->rg_tot.p, (size_t)nq * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    int64_t run = 0;
+    h_lims[0] = 0;
+    for (int64_t i = 0; i < nq; i++) {
+        base[i] = run;
+        run += tot[i];
+        h_lims[i + 1] = run;
+    }
+    if (run > 0) {
+        HIP_TRY(hipMemcpyAsync(ws->rg_tot.as<int64_t>() + nq, base.data(), (size_t)nq * sizeof(int64_t),
+                               hipMemcpyHostToDevice, s));
+        HIP_TRY(ws->rg_out_i.reserve((size_t)run * sizeof(int64_t)));
+        HIP_TRY(ws->rg_out_d.reserve((size_t)run * sizeof(float)));
+        HIP_TRY(launch_range_emit(r, nq, is_l2, ws->rg_off.as<int64_t>(), ws->rg_tot.as<int64_t>() + nq,
+                                  ws->rg_out_i.as<int64_t>(), ws->rg_out_d.as<float>(), s));
+        const size_t o = out_i.size();
+        out_i.resize(o + (size_t)run);
+        out_d.resize(o + (size_t)run);
+        HIP_TRY(hipMemcpyAsync(out_i.data() + o, ws->rg_out_i.p, (size_t)run * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(out_d.data() + o, ws->rg_out_d.p, (size_t)run * sizeof(float), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    return KNHIP_OK;
+}
+
+int knhip_range_search(const knhip_index* idx, const float* queries, int64_t nq, float radius,
+                       int32_t max_empty_result_buckets, const uint8_t* bitset, int64_t bitset_nbits, int64_t* lims,
+                       int64_t** out_ids, float** out_dist) {
+    if (int rc = check_index(idx)) return rc;
+    if (nq < 0 || max_empty_result_buckets < 0 || !lims || !out_ids || !out_dist) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "bad range search arguments");
+    }
+    *out_ids = nullptr;
+    *out_dist = nullptr;
+    lims[0] = 0;
+    if (nq == 0) {
+        return KNHIP_OK;
+    }
+    if (!queries) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "null query pointer");
+    }
+    if (!idx->has_data) {
+        return fail(KNHIP_ERR_EMPTY_INDEX, "index holds no vectors");
+    }
+    const int kind = idx->desc.kind;
+    if (kind == KNHIP_IVF_SQ8) {
+        return fail(KNHIP_ERR_NOT_IMPLEMENTED, "range search on IVF_SQ8 is not supported yet");
+    }
+    if (kind == KNHIP_IVF_PQ && !(idx->pq_v2 && idx->desc.pq_m == 32)) {
+        return fail(KNHIP_ERR_NOT_IMPLEMENTED, "range search on IVF_PQ needs m = 32 (stream16 layout)");
+    }
+    if (kind != KNHIP_BRUTE_FORCE && (size_t)idx->nlist > row_select_max_k()) {
+        return fail(KNHIP_ERR_NOT_IMPLEMENTED, "range search probes every list: nlist > 4096 is not supported yet");
+    }
+    DeviceGuard g(idx->desc.device);
+    hipStream_t s = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    Workspace* ws = acquire_ws(idx, nullptr, false);
+    std::vector<int64_t> res_i;
+    std::vector<float> res_d;
+    auto run = [&]() -> int {
+        // segments: column of the first row, position of the first id, length
+        std::vector<int64_t> seg;
+        int64_t nseg = 0, ncol = 0;
+        if (kind == KNHIP_BRUTE_FORCE) {
+            const int64_t SEG = 8192;
+            ncol = idx->ntotal;
+            nseg = (ncol + SEG - 1) / SEG;
+            seg.resize((size_t)3 * nseg);
+            for (int64_t i = 0; i < nseg; i++) {
+                seg[i] = seg[nseg + i] = i * SEG;
+                seg[2 * nseg + i] = std::min(SEG, ncol - i * SEG);
+            }
+        } else {
+            nseg = idx->nlist;
+            seg.resize((size_t)3 * nseg);
+            int64_t blk = 0;
+            for (int64_t l = 0; l < nseg; l++) {
+                seg[l] = kind == KNHIP_IVF_FLAT ? blk * 64 : idx->h_list_row_off[l];
+                seg[nseg + l] = idx->h_list_row_off[l];
+                seg[2 * nseg + l] = idx->h_list_len[l];
+                blk += (idx->h_list_len[l] + 63) / 64;
+            }
+            ncol = kind == KNHIP_IVF_FLAT ? blk * 64 : idx->ntotal;
+        }
+        HIP_TRY(ws->rg_seg.reserve(seg.size() * sizeof(int64_t)));
+        HIP_TRY(hipMemcpyAsync(ws->rg_seg.p, seg.data(), seg.size() * sizeof(int64_t), hipMemcpyHostToDevice, s));
+        const size_t qbytes = (size_t)nq * idx->d * sizeof(float);
+        HIP_TRY(ws->h_queries.reserve(qbytes));
+        HIP_TRY(hipMemcpyAsync(ws->h_queries.p, queries, qbytes, hipMemcpyHostToDevice, s));
+        const uint8_t* d_bitset = nullptr;
+        if (bitset && bitset_nbits > 0) {
+            const size_t bb = (size_t)((bitset_nbits + 7) / 8);
+            HIP_TRY(ws->h_bitset.reserve(bb));
+            HIP_TRY(hipMemcpyAsync(ws->h_bitset.p, bitset, bb, hipMemcpyHostToDevice, s));
+            d_bitset = ws->h_bitset.as<uint8_t>();
+        }
+        // queries per batch: the distance matrix stays below 2 GiB
+        const int64_t qb = std::max<int64_t>(1, std::min<int64_t>(nq, (int64_t)((2ull << 30) / ((size_t)std::max<int64_t>(ncol, 1) * 4))));
+        std::vector<int64_t> rel((size_t)qb + 1);
+        for (int64_t q0 = 0; q0 < nq; q0 += qb) {
+            const int64_t n = std::min(qb, nq - q0);
+            if (int r = range_batch(idx, ws, ws->h_queries.as<float>() + q0 * idx->d, n, radius, max_empty_result_buckets,
+                                    d_bitset, bitset_nbits, ws->rg_seg.as<int64_t>(), nseg, ncol, rel.data(), res_i,
+                                    res_d, s)) {
+                return r;
+            }
+            for (int64_t i = 0; i < n; i++) {
+                lims[q0 + i + 1] = lims[q0] + rel[i + 1];
+            }
+        }
+        return KNHIP_OK;
+    };
+    int rc = run();
+    if (rc != KNHIP_OK) {
+        (void)hipStreamSynchronize(s);
+    }
+    release_ws(idx, ws);
+    (void)hipStreamDestroy(s);
+    if (rc != KNHIP_OK) {
+        return rc;
+    }
+    const size_t n = res_i.size();
+    *out_ids = static_cast<int64_t*>(std::malloc(sizeof(int64_t) * (n + 1)));
+    *out_dist = static_cast<float*>(std::malloc(sizeof(float) * (n + 1)));
+    if (!*out_ids || !*out_dist) {
+        std::free(*out_ids);
+        std::free(*out_dist);
+        *out_ids = nullptr;
+        *out_dist = nullptr;
+        return fail(KNHIP_ERR_OUT_OF_MEMORY, "host allocation of the range result failed");
+    }
+    std::memcpy(*out_ids, res_i.data(), sizeof(int64_t) * n);
+    std::memcpy(*out_dist, res_d.data(), sizeof(float) * n);
+    return KNHIP_OK;
+}
+
+void knhip_free(void* p) {
+    std::free(p);
 }
 
 int knhip_coarse_search_device(const knhip_index* idx, const float* d_queries, int64_t nq,

@@ -451,7 +451,7 @@ __global__ __launch_bounds__(P2_THREADS, (P2_NWAVES >= 10 ? 5 : P2_NWAVES >= 8 ?
                         for (int qi = 0; qi < QG; qi++) {
                             if (qi < npair) {
                                 const float o = qi == 0 ? Y.x : Y.y;
-                                a.dump[(int64_t)q_of[qi] * a.dump_stride + vbase + lane] =
+                                a.dump[(int64_t)q_of[qi] * a.dump_stride + (a.dump_by_row ? row_off : 0) + vbase + lane] =
                                         filt ? worst_dist<IS_L2>() : fadd_x(dis0[qi], o);
                             }
                         }

@@ -1,0 +1,189 @@
+// knowhere_amd/csrc/range.hip -- range search epilogue: distance matrix -> (lims, ids, distances).
+//
+// Reference semantics (IvfIndexNode::RangeSearch, src/index/ivf/ivf.cc:1231-1420 ->
+// IndexIVF::range_search_preassigned, thirdparty/faiss/faiss/IndexIVF.cpp:812-990, parallel_mode 0):
+// lists are visited in coarse order; a vector is reported when C::cmp(radius, dis) (L2: dis < radius, IP:
+// dis > radius) and the id selector admits it; after each list the count of consecutive lists that added
+// nothing is bumped or reset, and the loop stops once it reaches max_empty_result_buckets (> 0).  Results
+// of one query are emitted list by list in that order, storage order inside a list.
+//
+// The scan kernels (flat_full / pq_scan_v2 dump mode) have already written every distance of every probed
+// list to dist[q][column]; what is left is data-parallel bookkeeping:
+//   range_count  : hits per (query, probe rank)                      one workgroup per pair
+//   range_plan   : early-stop cut + running offsets per query       one thread per query (nprobe steps)
+//   range_emit   : ordered compaction of the surviving lists         one workgroup per pair
+#include "common.cuh"
+#include "kernels.h"
+
+namespace knhip {
+
+constexpr int RG_THREADS = 256;
+
+template <bool IS_L2>
+__device__ __forceinline__ bool range_hit(const RangeArgs& a, int64_t q, int64_t col, int64_t id_pos, float* dis) {
+    const float v = a.dist[q * a.ncol + col];
+    *dis = v;
+    if (!(IS_L2 ? (v < a.radius) : (v > a.radius))) {
+        return false;
+    }
+    const int64_t id = a.ids ? a.ids[id_pos] : id_pos + a.id_offset;
+    return !bitset_filtered(a.bitset, a.bitset_nbits, id);
+}
+
+// segment of (q, rank): columns [col0, col0 + len), ids at [idp0, idp0 + len)
+__device__ __forceinline__ bool range_segment(const RangeArgs& a, int64_t q, int rank, int64_t* col0, int64_t* idp0,
+                                              int64_t* len) {
+    const int64_t key = a.order ? a.order[q * a.nprobe + rank] : rank;
+    if (key < 0) {
+        return false;
+    }
+    *col0 = a.seg_col[key];
+    *idp0 = a.seg_idpos[key];
+    *len = a.seg_len[key];
+    return *len > 0;
+}
+
+template <bool IS_L2>
+__global__ __launch_bounds__(RG_THREADS) void range_count_kernel(RangeArgs a, int32_t* __restrict__ cnt) {
+    const int64_t q = blockIdx.x / a.nprobe;
+    const int rank = (int)(blockIdx.x % a.nprobe);
+    __shared__ int s_tot;
+    if (threadIdx.x == 0) {
+        s_tot = 0;
+    }
+    __syncthreads();
+    int64_t col0, idp0, len;
+    int mine = 0;
+    if (range_segment(a, q, rank, &col0, &idp0, &len)) {
+        for (int64_t i = threadIdx.x; i < len; i += RG_THREADS) {
+            float dis;
+            mine += range_hit<IS_L2>(a, q, col0 + i, idp0 + i, &dis) ? 1 : 0;
+        }
+    }
+    // wave reduce, then one LDS atomic per wave
+    for (int off = KN_WAVE / 2; off > 0; off >>= 1) {
+        mine += __shfl_down(mine, off, KN_WAVE);
+    }
+    if (lane_id() == 0 && mine) {
+        atomicAdd(&s_tot, mine);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        cnt[blockIdx.x] = s_tot;
+    }
+}
+
+// off[q][rank] = running offset of the rank's hits inside the query's result, or -1 behind the early stop
+__global__ void range_plan_kernel(const int32_t* __restrict__ cnt, int64_t nq, int nprobe, int max_empty,
+                                  int64_t* __restrict__ off, int64_t* __restrict__ total) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) {
+        return;
+    }
+    int64_t run = 0;
+    int ndup = 0;
+    bool stopped = false;
+    for (int r = 0; r < nprobe; r++) {
+        if (stopped) {
+            off[q * nprobe + r] = -1;
+            continue;
+        }
+        const int c = cnt[q * nprobe + r];
+        off[q * nprobe + r] = run;
+        run += c;
+        if (max_empty > 0) {
+            ndup = c == 0 ? ndup + 1 : 0;
+            stopped = ndup >= max_empty;
+        }
+    }
+    total[q] = run;
+}
+
+template <bool IS_L2>
+__global__ __launch_bounds__(RG_THREADS) void range_emit_kernel(RangeArgs a, const int64_t* __restrict__ off,
+                                                                const int64_t* __restrict__ qbase,
+                                                                int64_t* __restrict__ out_ids,
+                                                                float* __restrict__ out_dis) {
+    const int64_t q = blockIdx.x / a.nprobe;
+    const int rank = (int)(blockIdx.x % a.nprobe);
+    const int64_t o = off[blockIdx.x];
+    int64_t col0, idp0, len;
+    if (o < 0 || !range_segment(a, q, rank, &col0, &idp0, &len)) {
+        return;
+    }
+    __shared__ int s_wave[RG_THREADS / KN_WAVE];
+    __shared__ int64_t s_base;
+    const int lane = lane_id(), wave = threadIdx.x / KN_WAVE;
+    if (threadIdx.x == 0) {
+        s_base = qbase[q] + o;
+    }
+    __syncthreads();
+    for (int64_t i0 = 0; i0 < len; i0 += RG_THREADS) {
+        const int64_t i = i0 + threadIdx.x;
+        float dis = 0.f;
+        const bool hit = i < len && range_hit<IS_L2>(a, q, col0 + i, idp0 + i, &dis);
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0) {
+            s_wave[wave] = __popcll(m);
+        }
+        __syncthreads();
+        int before = __popcll(m & ((1ull << lane) - 1ull)), tot = 0;
+        for (int w = 0; w < RG_THREADS / KN_WAVE; w++) {
+            if (w < wave) {
+                before += s_wave[w];
+            }
+            tot += s_wave[w];
+        }
+        const int64_t base = s_base;
+        if (hit) {
+            out_ids[base + before] = a.ids ? a.ids[idp0 + i] : idp0 + i + a.id_offset;
+            out_dis[base + before] = dis;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s_base = base + tot;
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_range_count(const RangeArgs& a, int64_t nq, bool is_l2, int32_t* cnt, hipStream_t s) {
+    if (nq <= 0 || a.nprobe <= 0) {
+        return hipSuccess;
+    }
+    const unsigned grid = (unsigned)(nq * a.nprobe);
+    if (is_l2) {
+        hipLaunchKernelGGL((range_count_kernel<true>), dim3(grid), dim3(RG_THREADS), 0, s, a, cnt);
+    } else {
+        hipLaunchKernelGGL((range_count_kernel<false>), dim3(grid), dim3(RG_THREADS), 0, s, a, cnt);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_range_plan(const int32_t* cnt, int64_t nq, int nprobe, int max_empty, int64_t* off, int64_t* total,
+                             hipStream_t s) {
+    if (nq <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(range_plan_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, s, cnt, nq, nprobe, max_empty,
+                       off, total);
+    return hipGetLastError();
+}
+
+hipError_t launch_range_emit(const RangeArgs& a, int64_t nq, bool is_l2, const int64_t* off, const int64_t* qbase,
+                             int64_t* out_ids, float* out_dis, hipStream_t s) {
+    if (nq <= 0 || a.nprobe <= 0) {
+        return hipSuccess;
+    }
+    const unsigned grid = (unsigned)(nq * a.nprobe);
+    if (is_l2) {
+        hipLaunchKernelGGL((range_emit_kernel<true>), dim3(grid), dim3(RG_THREADS), 0, s, a, off, qbase, out_ids,
+                           out_dis);
+    } else {
+        hipLaunchKernelGGL((range_emit_kernel<false>), dim3(grid), dim3(RG_THREADS), 0, s, a, off, qbase, out_ids,
+                           out_dis);
+    }
+    return hipGetLastError();
+}
+
+} // namespace knhip

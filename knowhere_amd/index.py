@@ -135,6 +135,22 @@ class GpuIndex:
         check(self.L.knhip_search(self.h, _np_ptr(xq), nq, k, nprobe, _np_ptr(bs), nbits, _np_ptr(I), _np_ptr(D)))
         return D, I
 
+    def range_search(self, xq, radius, max_empty_result_buckets=2, bitset=None, nbits=0):
+        """-> (lims[nq + 1], ids, distances) in the reference's emission order (include/knhip.h)"""
+        xq = np.ascontiguousarray(xq, np.float32)
+        nq = xq.shape[0]
+        lims = np.zeros(nq + 1, np.int64)
+        pi, pd = C.POINTER(C.c_int64)(), C.POINTER(C.c_float)()
+        bs = None if bitset is None else np.ascontiguousarray(bitset, np.uint8)
+        check(self.L.knhip_range_search(self.h, _np_ptr(xq), nq, float(radius), int(max_empty_result_buckets),
+                                        _np_ptr(bs), nbits, _np_ptr(lims), C.byref(pi), C.byref(pd)))
+        n = int(lims[-1])
+        ids = np.ctypeslib.as_array(pi, shape=(n,)).copy() if n else np.empty(0, np.int64)
+        dis = np.ctypeslib.as_array(pd, shape=(n,)).copy() if n else np.empty(0, np.float32)
+        self.L.knhip_free(pi)  # (NULL when there were no queries)
+        self.L.knhip_free(pd)
+        return lims, ids, dis
+
     def search_device(self, xq_t, k, nprobe=1, bitset_t=None, nbits=0, out=None, stream=None):
         import torch
         nq = xq_t.shape[0]

@@ -1,0 +1,111 @@
+"""Range search: knhip_range_search against the oracle's restatement of
+IndexIVF::range_search_preassigned / IndexFlat::range_search (itself pinned to the reference's FAISS in
+tests/test_oracle.py), through the C ABI.  Bar: lims equal, ids equal IN THE REFERENCE'S EMISSION ORDER (lists
+in coarse order, storage order inside a list), distances bit-equal -- for every early-stop setting, with and
+without a bitset."""
+import numpy as np
+import pytest
+
+from conftest import gen_data
+from helpers import finish_ivfpq
+from oracle import binding as ob
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu(ix):
+    from knowhere_amd import GpuIndex
+    return GpuIndex.from_data(ix, device=0)
+
+
+def _bitset(n, frac, seed):
+    filt = np.random.default_rng(seed).random(n) < frac
+    bs = np.zeros((n + 7) // 8, np.uint8)
+    for i in np.nonzero(filt)[0]:
+        bs[i >> 3] |= 1 << (i & 7)
+    return bs
+
+
+def _same(a, b, what):
+    assert np.array_equal(a[0], b[0]), f"{what}: lims differ"
+    assert np.array_equal(a[1], b[1]), f"{what}: ids differ (or are in a different order)"
+    assert np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32)), f"{what}: distances differ bitwise"
+
+
+def _radii(port, ix, xq, metric, nprobe):
+    """radii that give empty, sparse and dense results"""
+    D, _ = port.search(ix, xq, 40, nprobe)
+    col = np.sort(D[:, [0, 5, 39]].reshape(-1))
+    if metric == ob.L2:
+        return [float(col[0]) * 0.5, float(np.median(D[:, 5])), float(np.median(D[:, 39]))]
+    return [float(col[-1]) * 2.0 + 1.0, float(np.median(D[:, 5])), float(np.median(D[:, 39]))]
+
+
+@pytest.mark.parametrize("metric", [ob.L2, ob.IP], ids=["l2", "ip"])
+def test_brute_force_range(port, metric):
+    nb, nq, d = 20000, 33, 24  # > 2 segments of 8192 rows, ragged last one
+    xb, xq = gen_data(nb, d, 42), gen_data(nq, d, 44)
+    ix = ob.IndexData(ob.FLAT, metric, d)
+    ix.base = xb
+    g = _gpu(ix)
+    bs = _bitset(nb, 0.4, 7)
+    for radius in _radii(port, ix, xq, metric, 1):
+        for bitset in (None, bs):
+            exp = port.range_search(ix, xq, radius, 0, bitset, nb if bitset is not None else 0)
+            got = g.range_search(xq, radius, 0, bitset, nb if bitset is not None else 0)
+            _same(exp, got, f"flat radius={radius}")
+
+
+@pytest.mark.parametrize("kind,M,d", [(ob.IVF_FLAT, 0, 20), (ob.IVF_PQ, 32, 64), (ob.IVF_PQ, 32, 128)],
+                         ids=["ivfflat", "ivfpq32_d64", "ivfpq32_d128"])
+@pytest.mark.parametrize("metric", [ob.L2, ob.IP], ids=["l2", "ip"])
+def test_ivf_range(port, kind, M, d, metric):
+    nb, nq, nlist = 12000, 40, 48
+    xb, xq = gen_data(nb, d, 42), gen_data(nq, d, 44)
+    ix = finish_ivfpq(port, ob.make_index(port, kind, metric, xb, nlist=nlist, M=max(M, 1), nbits=8))
+    g = _gpu(ix)
+    bs = _bitset(nb, 0.4, 7)
+    total = 0
+    for radius in _radii(port, ix, xq, metric, nlist):
+        for max_empty in (0, 1, 2, 5):
+            for bitset in (None, bs):
+                exp = port.range_search(ix, xq, radius, max_empty, bitset, nb if bitset is not None else 0)
+                got = g.range_search(xq, radius, max_empty, bitset, nb if bitset is not None else 0)
+                _same(exp, got, f"kind={kind} radius={radius} max_empty={max_empty} bitset={bitset is not None}")
+                total += int(exp[0][-1])
+    assert total > 0
+
+
+def test_ivf_range_early_stop_changes_the_result(port):
+    """the heuristic is real: stopping after one empty list must lose hits that scanning every list finds"""
+    nb, nq, d, nlist = 12000, 40, 20, 48
+    xb, xq = gen_data(nb, d, 42), gen_data(nq, d, 44)
+    ix = ob.make_index(port, ob.IVF_FLAT, ob.L2, xb, nlist=nlist)
+    g = _gpu(ix)
+    D, _ = port.search(ix, xq, 40, nlist)
+    radius = float(np.median(D[:, 39]))
+    full = g.range_search(xq, radius, 0)
+    one = g.range_search(xq, radius, 1)
+    assert one[0][-1] < full[0][-1]
+    for q in range(nq):
+        assert set(one[1][one[0][q]:one[0][q + 1]].tolist()) <= set(full[1][full[0][q]:full[0][q + 1]].tolist())
+
+
+def test_range_unsupported_and_edge_cases(port):
+    from knowhere_amd import KnhipError
+    nb, d = 3000, 16
+    xb, xq = gen_data(nb, d, 1), gen_data(5, d, 2)
+    sq = ob.make_index(port, ob.IVF_SQ8, ob.L2, xb, nlist=8)
+    with pytest.raises(KnhipError):
+        _gpu(sq).range_search(xq, 1.0)
+    pq8 = finish_ivfpq(port, ob.make_index(port, ob.IVF_PQ, ob.L2, xb, nlist=8, M=8))
+    with pytest.raises(KnhipError):
+        _gpu(pq8).range_search(xq, 1.0)
+    fl = ob.make_index(port, ob.IVF_FLAT, ob.L2, xb, nlist=8)
+    g = _gpu(fl)
+    lims, ids, dis = g.range_search(xq[:0], 1.0)  # no queries
+    assert lims.tolist() == [0] and ids.size == 0
+    lims, ids, dis = g.range_search(xq, -1.0)  # nothing is inside a negative L2 radius
+    assert lims.tolist() == [0] * 6 and ids.size == 0
+    lims, ids, dis = g.range_search(xq, 3.0e38, 0)  # everything is
+    assert lims[-1] == 5 * nb
