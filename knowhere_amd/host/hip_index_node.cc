@@ -15,7 +15,9 @@
 //   Search  GpuCuvsIndexNode::Search (gpu_cuvs.h:121-190): config -> knhip_search -> GenResultDataSet
 //           (takes ownership of two new[] arrays) ; `refine` / `refine_k` as IvfIndexNode::Search
 //           does with IndexRefine (ivf.cc:1073-1103).
-//   RangeSearch / GetIndexMeta: not_implemented, as the cuVS node (gpu_cuvs.h:192-201).
+//   RangeSearch  IvfIndexNode::RangeSearch (ivf.cc:1231-1497) -> knhip_range_search (brute force, IVF_FLAT,
+//           IVF_PQ m = 32; IVF_SQ8 and nlist > 4096 report not_implemented).  GetIndexMeta: not_implemented,
+//           as the cuVS node (gpu_cuvs.h:192-201).
 //   COSINE  base normalised at Train/Add, query copied + normalised per Search, metric -> IP
 //           (ivf.cc:559-565, 1068-1071).
 //   Serialize / Deserialize: one named blob (Type()) in a BinarySet (ivf.cc:1717-1834) in the FAISS
@@ -345,8 +347,68 @@ class HipIndexNode : public IndexNode {
         return GenResultDataSet(nq, k, ids.release(), dis.release());
     }
 
-    expected<DataSetPtr> RangeSearch(const DataSetPtr, const Json&, const BitsetView&) const override {
-        return expected<DataSetPtr>::Err(Status::not_implemented, "RangeSearch not implemented");
+    // IvfIndexNode::RangeSearch (ivf.cc:1231-1497): radius / range_filter / max_empty_result_buckets from the
+    // config, every list a candidate, results filtered to [range_filter, radius) (L2) or (radius, range_filter]
+    // (IP, COSINE) (range_util.h:22-25) and returned as lims + flat arrays.
+    expected<DataSetPtr> RangeSearch(const DataSetPtr dataset, const Json& cfg, const BitsetView& bitset) const override {
+        if (!idx_) return expected<DataSetPtr>::Err(Status::empty_index, "index not built");
+        if (!dataset || !dataset->GetTensor()) return expected<DataSetPtr>::Err(Status::invalid_args, "null dataset");
+        if (dataset->GetDim() != dim_) return expected<DataSetPtr>::Err(Status::invalid_args, "dim mismatch");
+        auto get_f = [&](const char* key, float dflt, float& dst) -> bool {
+            dst = dflt;
+            if (!cfg.contains(key)) return true;
+            if (!cfg.at(key).is_number()) return false;
+            dst = (float)cfg.at(key).as_double();
+            return true;
+        };
+        float radius = 0.f, range_filter = 0.f;
+        const float default_range_filter = std::numeric_limits<float>::infinity();  // config.h:583
+        if (!get_f(meta::RADIUS, 0.0f, radius) || !get_f(meta::RANGE_FILTER, default_range_filter, range_filter))
+            return expected<DataSetPtr>::Err(Status::type_conflict_in_json, "radius / range_filter must be numbers");
+        int64_t max_empty = 2;  // ivf_config.h:53-59
+        if (cfg.contains(indexparam::MAX_EMPTY_RESULT_BUCKETS)) {
+            if (!cfg.at(indexparam::MAX_EMPTY_RESULT_BUCKETS).is_number())
+                return expected<DataSetPtr>::Err(Status::type_conflict_in_json, "max_empty_result_buckets");
+            max_empty = cfg.at(indexparam::MAX_EMPTY_RESULT_BUCKETS).as_int();
+            if (max_empty < 0 || max_empty > 65536)
+                return expected<DataSetPtr>::Err(Status::out_of_range_in_json, "max_empty_result_buckets");
+        }
+        const int64_t nq = dataset->GetRows();
+        const float* q = (const float*)dataset->GetTensor();
+        std::vector<float> qn;
+        if (cosine_) {
+            qn.assign(q, q + nq * dim_);
+            NormalizeRows(qn.data(), nq, dim_);
+            q = qn.data();
+        }
+        std::vector<int64_t> lims(nq + 1);
+        int64_t* ids = nullptr;
+        float* dis = nullptr;
+        int rc = knhip_range_search(idx_, q, nq, radius, (int32_t)max_empty, bitset.empty() ? nullptr : bitset.data(),
+                                    (int64_t)bitset.size(), lims.data(), &ids, &dis);
+        if (rc) return expected<DataSetPtr>::Err(ToStatus(rc), knhip_last_error());
+        const bool is_ip = metric_ != KNHIP_L2;
+        auto* out_lims = new size_t[nq + 1];
+        auto* out_ids = new int64_t[std::max<int64_t>(lims[nq], 1)];
+        auto* out_dis = new float[std::max<int64_t>(lims[nq], 1)];
+        size_t n = 0;
+        out_lims[0] = 0;
+        for (int64_t i = 0; i < nq; i++) {
+            for (int64_t j = lims[i]; j < lims[i + 1]; j++) {
+                const float v = dis[j];
+                const bool keep = range_filter == default_range_filter ||
+                                  (is_ip ? (radius < v && v <= range_filter) : (range_filter <= v && v < radius));
+                if (keep) {
+                    out_ids[n] = ids[j];
+                    out_dis[n] = v;
+                    n++;
+                }
+            }
+            out_lims[i + 1] = n;
+        }
+        knhip_free(ids);
+        knhip_free(dis);
+        return GenRangeResultDataSet(nq, out_lims, out_ids, out_dis);
     }
     expected<DataSetPtr> GetVectorByIds(const DataSetPtr dataset) const override {
         if (!HasRawData(cfg_.metric) || raw_.empty())

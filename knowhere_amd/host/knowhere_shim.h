@@ -116,6 +116,7 @@ constexpr const char* RANGE_FILTER = "range_filter";
 }  // namespace meta
 namespace indexparam {
 constexpr const char* NPROBE = "nprobe";
+constexpr const char* MAX_EMPTY_RESULT_BUCKETS = "max_empty_result_buckets";
 constexpr const char* NLIST = "nlist";
 constexpr const char* NBITS = "nbits";
 constexpr const char* M = "m";
@@ -210,6 +211,7 @@ class DataSet {
             delete[] static_cast<const char*>(tensor_);
             delete[] ids_;
             delete[] dist_;
+            delete[] lims_;
         }
     }
     void SetRows(int64_t r) { rows_ = r; }
@@ -218,6 +220,8 @@ class DataSet {
     void SetIds(const int64_t* i) { ids_ = i; }
     void SetDistance(const float* d) { dist_ = d; }
     void SetIsOwner(bool o) { owner_ = o; }
+    void SetLims(const size_t* l) { lims_ = l; }
+    const size_t* GetLims() const { return lims_; }
     void SetTensorBeginId(int64_t b) { begin_id_ = b; }
     int64_t GetRows() const { return rows_; }
     int64_t GetDim() const { return dim_; }
@@ -231,6 +235,7 @@ class DataSet {
     const void* tensor_ = nullptr;
     const int64_t* ids_ = nullptr;
     const float* dist_ = nullptr;
+    const size_t* lims_ = nullptr;
     bool owner_ = true;
 };
 using DataSetPtr = std::shared_ptr<DataSet>;
@@ -249,6 +254,18 @@ inline DataSetPtr GenResultDataSet(int64_t nq, int64_t topk, const int64_t* ids,
     auto ds = std::make_shared<DataSet>();
     ds->SetRows(nq);
     ds->SetDim(topk);
+    ds->SetIds(ids);
+    ds->SetDistance(distance);
+    ds->SetIsOwner(true);
+    return ds;
+}
+
+/// range search result (include/knowhere/dataset.h GenResultDataSet(nq, RangeSearchResult)): lims[nq + 1] +
+/// flat ids / distances; takes ownership of three new[]-allocated arrays
+inline DataSetPtr GenRangeResultDataSet(int64_t nq, const size_t* lims, const int64_t* ids, const float* distance) {
+    auto ds = std::make_shared<DataSet>();
+    ds->SetRows(nq);
+    ds->SetLims(lims);
     ds->SetIds(ids);
     ds->SetDistance(distance);
     ds->SetIsOwner(true);

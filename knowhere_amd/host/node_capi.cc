@@ -103,6 +103,26 @@ int knhip_node_deserialize(void* h, const char* key, const uint8_t* data, int64_
     return (int)static_cast<Handle*>(h)->idx.Deserialize(bs, ParseConfig(cfg));
 }
 
+// Index::RangeSearch: lims[nq + 1]; *ids / *dist are malloc'ed copies (release with free())
+int knhip_node_range_search(void* h, const float* q, int64_t nq, int64_t dim, const char* cfg, const uint8_t* bitset,
+                            int64_t nbits, int64_t* lims, int64_t** ids, float** dist) {
+    auto ds = GenDataSet(nq, dim, q);
+    auto r = static_cast<Handle*>(h)->idx.RangeSearch(ds, ParseConfig(cfg),
+                                                      bitset ? BitsetView(bitset, (size_t)nbits) : BitsetView());
+    if (!r.has_value()) {
+        g_err = r.what();
+        return (int)r.error();
+    }
+    const size_t* l = r.value()->GetLims();
+    for (int64_t i = 0; i <= nq; i++) lims[i] = (int64_t)l[i];
+    const size_t n = l[nq];
+    *ids = static_cast<int64_t*>(std::malloc(sizeof(int64_t) * (n + 1)));
+    *dist = static_cast<float*>(std::malloc(sizeof(float) * (n + 1)));
+    std::memcpy(*ids, r.value()->GetIds(), sizeof(int64_t) * n);
+    std::memcpy(*dist, r.value()->GetDistance(), sizeof(float) * n);
+    return 0;
+}
+
 int64_t knhip_node_count(void* h) { return static_cast<Handle*>(h)->idx.Count(); }
 int64_t knhip_node_dim(void* h) { return static_cast<Handle*>(h)->idx.Dim(); }
 

@@ -103,6 +103,42 @@ int main() {
     REQUIRE(!IndexFactory::Instance().Create<fp32>("NO_SUCH_INDEX", version).has_value());
     REQUIRE(IndexFactory::Instance().Create<fp32>("NO_SUCH_INDEX", version).error() == Status::invalid_index_error);
 
+    // range search check (tests/ut/test_search.cc range sections): every result inside [range_filter, radius), and
+    // with the early stop off the top-1 neighbour is never missed
+    auto check_range = [&](Index<IndexNode>& idx, const Json& base_cfg) {
+        Json rcfg = base_cfg;
+        auto top = idx.Search(query_ds, rcfg, nullptr);  // k = 1 distances give a sensible radius
+        REQUIRE(top.has_value());
+        std::vector<float> d1(top.value()->GetDistance(), top.value()->GetDistance() + nq);
+        std::nth_element(d1.begin(), d1.begin() + nq / 2, d1.end());
+        const float radius = d1[nq / 2] * 1.5f;
+        rcfg[meta::RADIUS] = radius;
+        rcfg[meta::RANGE_FILTER] = 0.0f;
+        rcfg[indexparam::MAX_EMPTY_RESULT_BUCKETS] = 0;
+        auto rr = idx.RangeSearch(query_ds, rcfg, nullptr);
+        REQUIRE(rr.has_value());
+        if (rr.has_value()) {
+            const size_t* lims = rr.value()->GetLims();
+            int out_of_range = 0, missed = 0;
+            for (int64_t i = 0; i < nq; i++) {
+                bool has_top = false;
+                for (size_t j = lims[i]; j < lims[i + 1]; j++) {
+                    const float v = rr.value()->GetDistance()[j];
+                    out_of_range += !(v >= 0.0f && v < radius);
+                    has_top |= rr.value()->GetIds()[j] == top.value()->GetIds()[i];
+                }
+                missed += (top.value()->GetDistance()[i] < radius) && !has_top;
+            }
+            REQUIRE(lims[nq] > 0);
+            REQUIRE(out_of_range == 0);
+            REQUIRE(missed == 0);
+            std::printf("   range search: %zu results inside radius %.3f\n", lims[nq], radius);
+        }
+        Json bad = rcfg;
+        bad[meta::RADIUS] = "far";
+        REQUIRE(idx.RangeSearch(query_ds, bad, nullptr).error() == Status::type_conflict_in_json);
+    };
+
     for (auto& c : cases) {
         std::printf("== %s\n", c.name);
         auto idx = IndexFactory::Instance().Create<fp32>(c.name, version).value();
@@ -226,8 +262,12 @@ int main() {
             for (int64_t i = 0; i < nq; i++) diff += r2.value()->GetIds()[i] != results.value()->GetIds()[i];
             REQUIRE(diff == 0);
         }
-        // 7. contract: not implemented where the cuVS node is not either
-        REQUIRE(idx.RangeSearch(query_ds, c.cfg, nullptr).error() == Status::not_implemented);
+        // 7. range search: brute force and IVF_FLAT here, IVF_PQ (m = 32) below; IVF_SQ8 / other m: not_implemented
+        if (std::string(c.name) == IndexEnum::INDEX_HIP_IVFSQ8 || std::string(c.name) == IndexEnum::INDEX_HIP_IVFPQ) {
+            REQUIRE(idx.RangeSearch(query_ds, c.cfg, nullptr).error() == Status::not_implemented);
+        } else {
+            check_range(idx, c.cfg);
+        }
         // config validation
         Json bad = c.cfg;
         bad[meta::TOPK] = 100000;
@@ -235,6 +275,14 @@ int main() {
         bad = c.cfg;
         bad[meta::METRIC_TYPE] = "HAMMING";
         REQUIRE(idx.Search(query_ds, bad, nullptr).error() == Status::invalid_metric_type);
+    }
+
+    {   // IVF_PQ with m = 32: the range search path of the headline kernel
+        Json cfg = ivfpq_gen();
+        cfg[indexparam::M] = 32;
+        auto idx = IndexFactory::Instance().Create<fp32>(IndexEnum::INDEX_HIP_IVFPQ, version).value();
+        REQUIRE(idx.Build(train_ds, cfg) == Status::success);
+        check_range(idx, cfg);
     }
 
     {   // COSINE == normalised IP

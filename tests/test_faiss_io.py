@@ -188,3 +188,46 @@ def test_hip_built_index_is_read_by_the_reference(node, ref, kind, metric):
         ref.destroy(h2)
     finally:
         node.knhip_node_destroy(C.c_void_p(h))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", [ob.FLAT, ob.IVF_FLAT, ob.IVF_PQ], ids=["flat", "ivfflat", "ivfpq32"])
+def test_node_range_search_equals_the_reference_on_the_same_bytes(node, ref, kind):
+    """IndexNode::RangeSearch on a HIP-built index == faiss range_search of the reference on the index read back
+    from the node's own bytes: same lims, same ids in the same order, bit-equal distances; range_filter applied."""
+    nb, nq, d, k = 4000, 32, 64, 10
+    xb, xq = gen_data(nb, d, 42), gen_data(nq, d, 44)
+    node.knhip_node_range_search.restype = C.c_int
+    h = node.knhip_node_create(GPU_NAME[kind].encode())
+    try:
+        cfg = "metric_type=L2;nlist=32;m=32;nbits=8"
+        assert node.knhip_node_build(C.c_void_p(h), xb.ctypes.data_as(C.POINTER(C.c_float)), C.c_int64(nb), C.c_int64(d),
+                                     cfg.encode()) == 0
+        D, _ = _search(node, h, xq, f"k={k};nprobe=32", k)
+        radius = float(np.median(D[:, k - 1]))
+        n = node.knhip_node_serialize(C.c_void_p(h), None, C.c_int64(0))
+        blob = np.empty(n, np.uint8)
+        assert node.knhip_node_serialize(C.c_void_p(h), _u8(blob), C.c_int64(n)) == n
+        h2, _ = ref.deserialize(blob, d)
+        for max_empty, range_filter in ((2, None), (0, None), (2, radius * 0.5)):
+            lims = np.zeros(nq + 1, np.int64)
+            pi, pd = C.POINTER(C.c_int64)(), C.POINTER(C.c_float)()
+            c = f"radius={radius!r};max_empty_result_buckets={max_empty}" + (
+                f";range_filter={range_filter!r}" if range_filter is not None else "")
+            rc = node.knhip_node_range_search(C.c_void_p(h), xq.ctypes.data_as(C.POINTER(C.c_float)), C.c_int64(nq),
+                                              C.c_int64(d), c.encode(), None, C.c_int64(0),
+                                              lims.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(pi), C.byref(pd))
+            assert rc == 0, node.knhip_node_last_error().decode()
+            tot = int(lims[-1])
+            ids = np.ctypeslib.as_array(pi, shape=(max(tot, 1),))[:tot].copy()
+            dis = np.ctypeslib.as_array(pd, shape=(max(tot, 1),))[:tot].copy()
+            el, ei, ed = ref.range_search(h2, xq, np.float32(radius), max_empty)
+            if range_filter is not None:  # [range_filter, radius), reference src/common/range_util.cc:27-48
+                keep = ed >= np.float32(range_filter)
+                cnt = np.array([keep[el[i]:el[i + 1]].sum() for i in range(nq)])
+                el, ei, ed = np.concatenate([[0], np.cumsum(cnt)]), ei[keep], ed[keep]
+            assert tot > 0 and np.array_equal(lims, el) and np.array_equal(ids, ei)
+            assert np.array_equal(dis.view(np.uint32), ed.view(np.uint32))
+        ref.destroy(h2)
+    finally:
+        node.knhip_node_destroy(C.c_void_p(h))
