@@ -116,6 +116,9 @@ struct SqScanArgs {
     float* gthr;                 // [nq] shared per-query threshold (see common.cuh gthr_*)
     int32_t nslot;
     int32_t k;
+    // range search: non-null = write every distance to dump[q * dump_stride + storage position], no top-k
+    float* dump;
+    int64_t dump_stride;
 };
 
 // ---- flat_scan.hip ----

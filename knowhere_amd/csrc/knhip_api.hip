@@ -1163,6 +1163,55 @@ static int range_batch(const knhip_index* idx, Workspace* ws, const float* d_q, 
         a.dump_by_row = 1;
         HIP_TRY(launch_pq_scan_v2(a, is_l2, true, items_bound, s));
     }
+    if (kind == KNHIP_IVF_SQ8) {
+        const int qg = 8;
+        const int64_t nlist = idx->nlist;
+        const int64_t npairs = nq * nprobe;
+        const int64_t items_bound = round_up(npairs / qg + std::min<int64_t>(2 * nlist, npairs) + 1, 8);
+        HIP_TRY(ws->list_count.reserve((size_t)2 * nlist * sizeof(int32_t)));
+        HIP_TRY(ws->list_cursor.reserve((size_t)2 * nlist * sizeof(int32_t)));
+        HIP_TRY(ws->list_pair_off.reserve((size_t)(2 * nlist + 1) * sizeof(int64_t)));
+        HIP_TRY(ws->list_item_off.reserve((size_t)(2 * nlist + 1) * sizeof(int64_t)));
+        HIP_TRY(ws->pairs.reserve((size_t)npairs * sizeof(KnPair)));
+        HIP_TRY(ws->items.reserve((size_t)items_bound * sizeof(KnItem)));
+        HIP_TRY(ws->nitems.reserve(sizeof(int64_t)));
+        HIP_TRY(ws->gthr.reserve((size_t)nq * sizeof(float)));
+        HIP_TRY(launch_fill_f32(ws->gthr.as<float>(), nq, is_l2 ? FLT_MAX : -FLT_MAX, s));
+        WorkTable wt{};
+        wt.list_count = ws->list_count.as<int32_t>();
+        wt.list_cursor = ws->list_cursor.as<int32_t>();
+        wt.list_pair_off = ws->list_pair_off.as<int64_t>();
+        wt.list_item_off = ws->list_item_off.as<int64_t>();
+        wt.pairs = ws->pairs.as<KnPair>();
+        wt.items = ws->items.as<KnItem>();
+        wt.nitems = ws->nitems.as<int64_t>();
+        wt.scan_bytes = idx->scan_bytes_dev.as<double>();
+        HIP_TRY(launch_build_worktable(ws->keys.as<int64_t>(), nq, nprobe, nlist, qg, idx->d_list_len.as<int64_t>(),
+                                       idx->code_size, wt, s));
+        SqScanArgs a{};
+        a.rows = idx->rows.as<uint4>();
+        a.list_blk_off = idx->d_list_blk_off.as<int64_t>();
+        a.list_len = idx->d_list_len.as<int64_t>();
+        a.list_row_off = idx->d_list_row_off.as<int64_t>();
+        a.ids = idx->ids.as<int64_t>();
+        a.trained = idx->sq_trained.as<float>();
+        a.centroids = idx->centroids.as<float>();
+        a.d = d;
+        a.nchunk16 = (d + 15) / 16;
+        a.queries = d_q;
+        a.coarse_dis = ws->cdis.as<float>();
+        a.items = wt.items;
+        a.pairs = wt.pairs;
+        a.nitems_dev = wt.nitems;
+        a.bitset = d_bitset;
+        a.bitset_nbits = nbits;
+        a.gthr = ws->gthr.as<float>();
+        a.nslot = nprobe;
+        a.k = 1;
+        a.dump = ws->dump.as<float>();
+        a.dump_stride = ncol;
+        HIP_TRY(launch_sq_scan(a, is_l2, items_bound, s));
+    }
     // count -> plan -> (host: totals, bases) -> emit
     HIP_TRY(ws->rg_cnt.reserve((size_t)nq * nprobe * sizeof(int32_t)));
     HIP_TRY(ws->rg_off.reserve((size_t)nq * nprobe * sizeof(int64_t)));
@@ -1217,9 +1266,6 @@ int knhip_range_search(const knhip_index* idx, const float* queries, int64_t nq,
         return fail(KNHIP_ERR_EMPTY_INDEX, "index holds no vectors");
     }
     const int kind = idx->desc.kind;
-    if (kind == KNHIP_IVF_SQ8) {
-        return fail(KNHIP_ERR_NOT_IMPLEMENTED, "range search on IVF_SQ8 is not supported yet");
-    }
     if (kind == KNHIP_IVF_PQ && !(idx->pq_v2 && idx->desc.pq_m == 32)) {
         return fail(KNHIP_ERR_NOT_IMPLEMENTED, "range search on IVF_PQ needs m = 32 (stream16 layout)");
     }

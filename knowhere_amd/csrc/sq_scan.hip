@@ -135,7 +135,13 @@ __global__ __launch_bounds__(SQ_THREADS) void sq_scan_kernel(SqScanArgs a) {
         }
 #pragma unroll
         for (int j = 0; j < QG; j++) {
-            if (j < npair) {
+            if (j < npair && a.dump != nullptr) {
+                // range search: every distance of the list, filtered rows as the sentinel
+                if (row < len) {
+                    const float dis = IS_L2 ? acc[j] : fadd_x(accu0[j], acc[j]);
+                    a.dump[(int64_t)q_of[j] * a.dump_stride + row_off + row] = valid ? dis : worst_dist<IS_L2>();
+                }
+            } else if (j < npair) {
                 const float dis = IS_L2 ? acc[j] : fadd_x(accu0[j], acc[j]);
                 const bool pass = valid && within_gthr<IS_L2>(dis, gt[j]) &&
                                   top[j].admits(dis, row, kd[j], ki[j]);
@@ -160,6 +166,9 @@ __global__ __launch_bounds__(SQ_THREADS) void sq_scan_kernel(SqScanArgs a) {
         }
     }
 
+    if (a.dump != nullptr) {
+        return;
+    }
     // ---- merge waves (same scheme as flat_scan) ----
     __syncthreads();
     const int k = a.k;

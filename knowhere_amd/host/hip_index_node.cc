@@ -16,7 +16,7 @@
 //           (takes ownership of two new[] arrays) ; `refine` / `refine_k` as IvfIndexNode::Search
 //           does with IndexRefine (ivf.cc:1073-1103).
 //   RangeSearch  IvfIndexNode::RangeSearch (ivf.cc:1231-1497) -> knhip_range_search (brute force, IVF_FLAT,
-//           IVF_PQ m = 32; IVF_SQ8 and nlist > 4096 report not_implemented).  GetIndexMeta: not_implemented,
+//           IVF_SQ8, IVF_PQ m = 32; other m and nlist > 4096 report not_implemented).  GetIndexMeta: not_implemented,
 //           as the cuVS node (gpu_cuvs.h:192-201).
 //   COSINE  base normalised at Train/Add, query copied + normalised per Search, metric -> IP
 //           (ivf.cc:559-565, 1068-1071).

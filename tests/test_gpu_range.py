@@ -56,8 +56,9 @@ def test_brute_force_range(port, metric):
             _same(exp, got, f"flat radius={radius}")
 
 
-@pytest.mark.parametrize("kind,M,d", [(ob.IVF_FLAT, 0, 20), (ob.IVF_PQ, 32, 64), (ob.IVF_PQ, 32, 128)],
-                         ids=["ivfflat", "ivfpq32_d64", "ivfpq32_d128"])
+@pytest.mark.parametrize("kind,M,d", [(ob.IVF_FLAT, 0, 20), (ob.IVF_SQ8, 0, 40), (ob.IVF_PQ, 32, 64),
+                                      (ob.IVF_PQ, 32, 128)],
+                         ids=["ivfflat", "ivfsq8", "ivfpq32_d64", "ivfpq32_d128"])
 @pytest.mark.parametrize("metric", [ob.L2, ob.IP], ids=["l2", "ip"])
 def test_ivf_range(port, kind, M, d, metric):
     nb, nq, nlist = 12000, 40, 48
@@ -95,9 +96,6 @@ def test_range_unsupported_and_edge_cases(port):
     from knowhere_amd import KnhipError
     nb, d = 3000, 16
     xb, xq = gen_data(nb, d, 1), gen_data(5, d, 2)
-    sq = ob.make_index(port, ob.IVF_SQ8, ob.L2, xb, nlist=8)
-    with pytest.raises(KnhipError):
-        _gpu(sq).range_search(xq, 1.0)
     pq8 = finish_ivfpq(port, ob.make_index(port, ob.IVF_PQ, ob.L2, xb, nlist=8, M=8))
     with pytest.raises(KnhipError):
         _gpu(pq8).range_search(xq, 1.0)
