@@ -330,6 +330,7 @@ __global__ __launch_bounds__(P2_THREADS, (P2_NWAVES >= 10 ? 5 : P2_NWAVES >= 8 ?
     WaveTopK<IS_L2, R, int32_t> top[QG];
     float kd[QG], pre[QG], gt[QG];
     int32_t ki[QG];
+    int ncand[QG] = {0, 0}; // insertions into this wave's lists (an empty list is the common case in the bulk phase)
 #pragma unroll
     for (int j = 0; j < QG; j++) {
         top[j].init(a.k);
@@ -488,6 +489,7 @@ __global__ __launch_bounds__(P2_THREADS, (P2_NWAVES >= 10 ? 5 : P2_NWAVES >= 8 ?
                                     continue;
                                 }
                                 top[qi].insert(dis, v);
+                                ncand[qi]++;
                                 kd[qi] = top[qi].kth_dist();
                                 ki[qi] = top[qi].kth_idx();
                                 tightened = true;
@@ -525,13 +527,23 @@ __global__ __launch_bounds__(P2_THREADS, (P2_NWAVES >= 10 ? 5 : P2_NWAVES >= 8 ?
         return;
     }
     // ---- merge the waves' lists; wave qi finishes query qi ---------------------------------------------
+    // Partial lists are written SENTINEL-TERMINATED: entries [0, n) and, if n < k, one id = -1 behind them
+    // (merge_partials never reads past the first sentinel of a slot).  In the bulk phase most (query, list)
+    // pairs contribute nothing: that case costs one barrier pair, eight LDS counters and one 8-byte store.
     __syncthreads(); // LUT is dead
     const int k = a.k;
-    float* md = reinterpret_cast<float*>(smem);
-    int64_t* mi = reinterpret_cast<int64_t*>(smem + (((size_t)QG * P2_WAVES * k * 4 + 7) & ~(size_t)7));
+    int* s_cnt = reinterpret_cast<int*>(smem); // [QG][P2_WAVES]
+    float* md = reinterpret_cast<float*>(smem + 64);
+    int64_t* mi = reinterpret_cast<int64_t*>(smem + 64 + (((size_t)QG * P2_WAVES * k * 4 + 7) & ~(size_t)7));
 #pragma unroll
     for (int qi = 0; qi < QG; qi++) {
-        top[qi].store(md + (qi * P2_WAVES + wave) * k, mi + (qi * P2_WAVES + wave) * k);
+        const int n = ncand[qi] < k ? ncand[qi] : k;
+        if (lane == 0) {
+            s_cnt[qi * P2_WAVES + wave] = n;
+        }
+        if (n > 0) {
+            top[qi].store(md + (qi * P2_WAVES + wave) * k, mi + (qi * P2_WAVES + wave) * k);
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -539,9 +551,10 @@ __global__ __launch_bounds__(P2_THREADS, (P2_NWAVES >= 10 ? 5 : P2_NWAVES >= 8 ?
         if (qi < npair && wave == qi) {
             for (int w = 1; w < P2_WAVES; w++) {
                 const int ow = (wave + w) % P2_WAVES;
+                const int on = s_cnt[qi * P2_WAVES + ow];
                 const float* od = md + (qi * P2_WAVES + ow) * k;
                 const int64_t* oi = mi + (qi * P2_WAVES + ow) * k;
-                for (int e = 0; e < k; e++) {
+                for (int e = 0; e < on; e++) {
                     const float cd = od[e];
                     const int32_t ci = (int32_t)oi[e];
                     if (ci < 0 || !top[qi].admits(cd, ci, kd[qi], ki[qi])) {
@@ -555,15 +568,22 @@ __global__ __launch_bounds__(P2_THREADS, (P2_NWAVES >= 10 ? 5 : P2_NWAVES >= 8 ?
             if (ki[qi] >= 0 && lane == 0) {
                 gthr_publish<IS_L2>(a.gthr + q_of[qi], kd[qi]);
             }
+            int nvalid = 0; // the list is sorted with its empty entries at the tail
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                nvalid += __popcll(__ballot(r * KN_WAVE + lane < k && top[qi].i[r] >= 0));
+            }
             float* pd = a.partial_d + ((int64_t)q_of[qi] * a.nslot + slot_of[qi]) * k;
             int64_t* pi = a.partial_i + ((int64_t)q_of[qi] * a.nslot + slot_of[qi]) * k;
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 const int e = r * KN_WAVE + lane;
-                if (e < k) {
-                    const int64_t pos = (int64_t)top[qi].i[r];
+                if (e < nvalid) {
                     pd[e] = top[qi].d[r];
-                    pi[e] = pos >= 0 ? a.ids[row_off + pos] : -1;
+                    pi[e] = a.ids[row_off + (int64_t)top[qi].i[r]];
+                } else if (e == nvalid && e < k) {
+                    pd[e] = worst_dist<IS_L2>();
+                    pi[e] = -1;
                 }
             }
         }
@@ -573,7 +593,7 @@ __global__ __launch_bounds__(P2_THREADS, (P2_NWAVES >= 10 ? 5 : P2_NWAVES >= 8 ?
 template <bool IS_L2, int R, bool DUMP>
 static hipError_t launch_v2_r(const PqScanArgs& a, int64_t grid, hipStream_t s) {
     const size_t lut_bytes = (size_t)P2_KSUB * 256;
-    const size_t merge_bytes = (((size_t)2 * P2_WAVES * a.k * 4 + 7) & ~(size_t)7) + (size_t)2 * P2_WAVES * a.k * 8;
+    const size_t merge_bytes = 64 + (((size_t)2 * P2_WAVES * a.k * 4 + 7) & ~(size_t)7) + (size_t)2 * P2_WAVES * a.k * 8;
     const size_t sm = DUMP ? lut_bytes : std::max(lut_bytes, merge_bytes);
     auto kern = pq_scan_v2_kernel<IS_L2, R, DUMP>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,

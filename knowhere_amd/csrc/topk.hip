@@ -35,31 +35,54 @@ __global__ __launch_bounds__(256) void merge_partials_kernel(const float* __rest
     int64_t ki = -1;
     const float* qd = pd + q * q_stride;
     const int64_t* qi = pi + q * q_stride;
-    // Slot 0 (the closest list / first shard) usually supplies a large share of the result and is already
-    // sorted best-first with its empty entries at the tail: load it straight into the wave-resident list
-    // (element e -> lane e % 64, register e / 64) so that the rank loop below can stop early.
+    // Slot lists are sorted best-first and SENTINEL-TERMINATED: nothing behind the first id < 0 of a slot is
+    // defined (the scan kernels stop writing there).
+    // Slot 0 (the closest list / first shard) usually supplies a large share of the result: load it straight
+    // into the wave-resident list (element e -> lane e % 64, register e / 64) so that the rank loop below can
+    // stop early.
+    int first_end = k;
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int e = r * KN_WAVE + lane;
-        if (e < k) {
-            const int64_t id0 = qi[e];
-            top.d[r] = id0 >= 0 ? qd[e] : worst_dist<IS_L2>();
-            top.i[r] = id0 >= 0 ? id0 : -1;
+        int64_t id0 = -1;
+        float d0 = worst_dist<IS_L2>();
+        if (e < k && e < first_end) {
+            id0 = qi[e];
+            if (id0 >= 0) {
+                d0 = qd[e];
+            }
         }
+        const unsigned long long endm = __ballot(e < k && e < first_end && id0 < 0);
+        if (endm) {
+            first_end = min(first_end, r * KN_WAVE + __ffsll((long long)endm) - 1);
+        }
+        const bool ok = e < first_end && id0 >= 0;
+        top.d[r] = ok ? d0 : worst_dist<IS_L2>();
+        top.i[r] = ok ? id0 : -1;
     }
     kd = top.kth_dist();
     ki = top.kth_idx();
+    // per lane: bit g set = slot g * 64 + lane is exhausted (sentinel seen, or an entry that could not enter:
+    // every later one of that slot is worse and the bound only tightens)
+    unsigned long long done = 0;
     for (int r = 0; r < k; r++) {
         bool any = false;
-        for (int s0 = 0; s0 < nslot; s0 += KN_WAVE) {
+        int g = 0;
+        for (int s0 = 0; s0 < nslot; s0 += KN_WAVE, g++) {
             const int s = s0 + lane;
             float cd = worst_dist<IS_L2>();
             int64_t ci = -1;
-            if (s < nslot && s > 0) {
-                cd = qd[(int64_t)s * slot_stride + r];
+            const bool live = s < nslot && s > 0 && !((done >> g) & 1ull);
+            if (live) {
                 ci = qi[(int64_t)s * slot_stride + r];
+                if (ci >= 0) {
+                    cd = qd[(int64_t)s * slot_stride + r];
+                }
             }
             const bool pass = (ci >= 0) && top.admits(cd, ci, kd, ki);
+            if (!pass) {
+                done |= 1ull << g;
+            }
             unsigned long long m = __ballot(pass);
             any |= (m != 0);
             while (m) {
