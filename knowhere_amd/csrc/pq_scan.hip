@@ -56,23 +56,30 @@ constexpr int PQ_KSUB = 256;
 __global__ __launch_bounds__(256) void pq_query_table_kernel(const float* __restrict__ queries,
                                                              const float* __restrict__ cb, int d,
                                                              int M, float* __restrict__ t2t) {
-    extern __shared__ float sqv[];
+    // codebook reads in its own [m][c][dsub] order (a wave covers whole rows), results staged in LDS as
+    // [c][M + 1] (padded: conflict-free) and written out [c][m] fully coalesced
+    extern __shared__ float sqv[]; // [d] query, then [256][M + 1] staging
+    float* stage = sqv + d;
     const int64_t q = blockIdx.x;
     const int dsub = d / M;
     for (int i = threadIdx.x; i < d; i += blockDim.x) {
         sqv[i] = queries[q * d + i];
     }
     __syncthreads();
-    float* out = t2t + q * (int64_t)(PQ_KSUB * M);
     for (int e = threadIdx.x; e < PQ_KSUB * M; e += blockDim.x) {
-        const int c = e / M, m = e % M;
+        const int m = e / PQ_KSUB, c = e % PQ_KSUB;
         const float* y = cb + ((int64_t)m * PQ_KSUB + c) * dsub;
         const float* x = sqv + m * dsub;
         float res = 0.f;
         for (int i = 0; i < dsub; i++) {
             res = ip_step(res, x[i], y[i]);
         }
-        out[e] = res;
+        stage[c * (M + 1) + m] = res;
+    }
+    __syncthreads();
+    float* out = t2t + q * (int64_t)(PQ_KSUB * M);
+    for (int e = threadIdx.x; e < PQ_KSUB * M; e += blockDim.x) {
+        out[e] = stage[(e / M) * (M + 1) + (e % M)];
     }
 }
 
@@ -592,8 +599,15 @@ hipError_t launch_pq_query_table(const float* queries, const float* cb, int d, i
     if (nq <= 0) {
         return hipSuccess;
     }
-    hipLaunchKernelGGL(pq_query_table_kernel, dim3((unsigned)nq), dim3(256), (size_t)d * 4, s, queries,
-                       cb, d, M, t2t);
+    const size_t sm = ((size_t)d + (size_t)PQ_KSUB * (M + 1)) * 4;
+    if (sm > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pq_query_table_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        if (e != hipSuccess) {
+            return e;
+        }
+    }
+    hipLaunchKernelGGL(pq_query_table_kernel, dim3((unsigned)nq), dim3(256), sm, s, queries, cb, d, M, t2t);
     return hipGetLastError();
 }
 
