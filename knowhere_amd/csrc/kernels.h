@@ -174,6 +174,10 @@ struct WorkTable {
     KnItem* items;         // [nq*nprobe/qg + 2*nlist]
     int64_t* nitems;       // [1]
     double* scan_bytes;    // [1] sum over pairs of len(list)*code_size
+    // pairs of empty lists get no work item; if non-null, entry 0 of their partial list (partial_i + t * k,
+    // t = q * nprobe + slot) is set to -1 instead
+    int64_t* empty_mark;
+    int32_t k;
 };
 hipError_t launch_build_worktable(const int64_t* keys, int64_t nq, int nprobe, int64_t nlist, int qg,
                                   const int64_t* list_len, int64_t code_size, const WorkTable& wt,

@@ -500,13 +500,15 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
     wt.items = ws->items.as<KnItem>();
     wt.nitems = ws->nitems.as<int64_t>();
     wt.scan_bytes = idx->scan_bytes_dev.as<double>();
+    HIP_TRY(ws->partial_d.reserve((size_t)npairs * k * sizeof(float)));
+    HIP_TRY(ws->partial_i.reserve((size_t)npairs * k * sizeof(int64_t)));
+    wt.empty_mark = ws->partial_i.as<int64_t>();
+    wt.k = k;
     {
         StageTimer t(idx, s, KNHIP_STAGE_GROUP);
         HIP_TRY(launch_build_worktable(ws->keys.as<int64_t>(), nq, nprobe, nlist, qg,
                                        idx->d_list_len.as<int64_t>(), idx->code_size, wt, s));
     }
-    HIP_TRY(ws->partial_d.reserve((size_t)npairs * k * sizeof(float)));
-    HIP_TRY(ws->partial_i.reserve((size_t)npairs * k * sizeof(int64_t)));
     idx->last_items_bound = items_bound;
 
     if (kind == KNHIP_IVF_FLAT) {

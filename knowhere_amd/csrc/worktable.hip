@@ -37,14 +37,16 @@ __device__ __forceinline__ int64_t wt_vlist(int64_t key, int64_t slot, int64_t n
     return key + (slot != 0 ? nlist : 0);
 }
 
+// Pairs whose list is empty on this device (always the case for the lists another rank owns when the index
+// is list-sharded) produce no work item at all: their partial slot is just marked empty by wt_scatter_kernel.
 __global__ void wt_count_kernel(const int64_t* __restrict__ keys, int64_t npairs, int nprobe,
-                                int64_t nlist, int32_t* list_count) {
+                                int64_t nlist, const int64_t* __restrict__ list_len, int32_t* list_count) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= npairs) {
         return;
     }
     const int64_t key = keys[t];
-    if (key >= 0 && key < nlist) {
+    if (key >= 0 && key < nlist && list_len[key] > 0) {
         atomicAdd(&list_count[wt_vlist(key, t % nprobe, nlist)], 1);
     }
 }
@@ -118,14 +120,18 @@ __global__ __launch_bounds__(WT_SCAN_THREADS) void wt_scan_kernel(
 }
 
 __global__ void wt_scatter_kernel(const int64_t* __restrict__ keys, int64_t npairs, int nprobe,
-                                  int64_t nlist, const int64_t* __restrict__ list_pair_off,
-                                  int32_t* list_cursor, KnPair* pairs) {
+                                  int64_t nlist, const int64_t* __restrict__ list_len,
+                                  const int64_t* __restrict__ list_pair_off, int32_t* list_cursor, KnPair* pairs,
+                                  int64_t* empty_mark, int k) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= npairs) {
         return;
     }
     const int64_t key = keys[t];
-    if (key < 0 || key >= nlist) {
+    if (key < 0 || key >= nlist || list_len[key] == 0) {
+        if (empty_mark != nullptr) {
+            empty_mark[t * k] = -1; // sentinel-terminated partial list of (query, slot) t: empty
+        }
         return;
     }
     const int64_t vl = wt_vlist(key, t % nprobe, nlist);
@@ -166,15 +172,15 @@ hipError_t launch_build_worktable(const int64_t* keys, int64_t nq, int nprobe, i
     hipLaunchKernelGGL(wt_zero_kernel, dim3(gl), dim3(256), 0, s, wt.list_count, wt.list_cursor, nvl,
                        wt.scan_bytes, wt.nitems);
     if (npairs > 0) {
-        hipLaunchKernelGGL(wt_count_kernel, dim3(gp), dim3(256), 0, s, keys, npairs, nprobe, nlist,
+        hipLaunchKernelGGL(wt_count_kernel, dim3(gp), dim3(256), 0, s, keys, npairs, nprobe, nlist, list_len,
                            wt.list_count);
     }
     hipLaunchKernelGGL(wt_scan_kernel, dim3(1), dim3(WT_SCAN_THREADS), 0, s, wt.list_count, list_len,
                        nvl, nlist, qg, code_size, wt.list_pair_off, wt.list_item_off, wt.nitems,
                        wt.scan_bytes);
     if (npairs > 0) {
-        hipLaunchKernelGGL(wt_scatter_kernel, dim3(gp), dim3(256), 0, s, keys, npairs, nprobe, nlist,
-                           wt.list_pair_off, wt.list_cursor, wt.pairs);
+        hipLaunchKernelGGL(wt_scatter_kernel, dim3(gp), dim3(256), 0, s, keys, npairs, nprobe, nlist, list_len,
+                           wt.list_pair_off, wt.list_cursor, wt.pairs, wt.empty_mark, wt.k);
     }
     hipLaunchKernelGGL(wt_items_kernel, dim3(gl), dim3(256), 0, s, wt.list_count, wt.list_pair_off,
                        wt.list_item_off, nvl, nlist, qg, wt.items);
