@@ -56,6 +56,18 @@ def main():
                 arrs[f"D{ci}"], arrs[f"I{ci}"] = D, I
                 cases.append((k, nprobe, int(use_bs)))
             arrs["cases"] = np.array(cases, np.int64)
+            # range search cases (reference: IvfIndexNode::RangeSearch semantics, oracle/ref_driver.cpp
+            # ref_range_search): radius = median 10th-best distance; (max_empty_result_buckets, bitset?)
+            D10, _ = ref.search(h, xq, 10, ix.nlist if kind != ob.FLAT else 1)
+            radius = np.float32(np.median(D10[:, 9]))
+            arrs["range_radius"] = radius
+            rcases = []
+            for ri, (max_empty, use_bs) in enumerate(((2, False), (0, False), (1, True))):
+                lims, rids, rdis = ref.range_search(h, xq, radius, max_empty, bitset if use_bs else None,
+                                                    nb if use_bs else 0)
+                arrs[f"RL{ri}"], arrs[f"RI{ri}"], arrs[f"RD{ri}"] = lims, rids, rdis
+                rcases.append((max_empty, int(use_bs)))
+            arrs["range_cases"] = np.array(rcases, np.int64)
             np.savez_compressed(os.path.join(OUT, f"{name}_{mname}.npz"), **arrs)
             ref.destroy(h)
             print("wrote", name, mname)

@@ -43,6 +43,16 @@ def load_golden(path):
     return ix, z["xq"], cases
 
 
+def load_golden_range(path):
+    """range-search cases of a golden fixture: (radius, [dict(max_empty, bitset, nbits, lims, ids, dis)])"""
+    z = np.load(path)
+    out = []
+    for ri, (max_empty, use_bs) in enumerate(z["range_cases"]):
+        out.append(dict(max_empty=int(max_empty), bitset=z["bitset"] if use_bs else None,
+                        nbits=int(z["nb"]) if use_bs else 0, lims=z[f"RL{ri}"], ids=z[f"RI{ri}"], dis=z[f"RD{ri}"]))
+    return float(z["range_radius"]), out
+
+
 def finish_ivfpq(port, ix):
     """the precomputed term-2 table is derived data: recompute it with the restated formula"""
     if ix.kind == ob.IVF_PQ and ix.metric == ob.L2 and ix.use_precomputed_table == 1 and ix.precomputed_table is None:

@@ -32,6 +32,20 @@ def _same(a, b, what):
     assert np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32)), f"{what}: distances differ bitwise"
 
 
+@pytest.mark.parametrize("path", [p for p in __import__("helpers").golden_files() if "ivfpq" not in p],
+                         ids=lambda p: __import__("os").path.basename(p)[:-4])
+def test_golden_range(path):
+    """the committed range results of the reference's own FAISS (tests/golden/make_golden.py); the golden IVF-PQ
+    index has m = 8, outside the range path"""
+    from helpers import load_golden, load_golden_range
+    ix, xq, _ = load_golden(path)
+    g = _gpu(ix)
+    radius, cases = load_golden_range(path)
+    for c in cases:
+        got = g.range_search(xq, np.float32(radius), c["max_empty"], c["bitset"], c["nbits"])
+        _same((c["lims"], c["ids"], c["dis"]), got, f"golden range max_empty={c['max_empty']}")
+
+
 def _radii(port, ix, xq, metric, nprobe):
     """radii that give empty, sparse and dense results"""
     D, _ = port.search(ix, xq, 40, nprobe)
