@@ -190,17 +190,25 @@ __global__ __launch_bounds__(RS_THREADS) void row_select_kernel(const float* __r
             }
         }
         __syncthreads();
-        if (tid == 0) {
-            uint32_t acc = 0;
-            int b = 0;
-            for (; b < 256; b++) {
-                if (acc + hist[b] >= need) {
-                    break;
-                }
-                acc += hist[b];
+        {   // parallel scan of the 256 bins (one per thread): the bin where the running count reaches `need`
+            const uint32_t h = hist[tid];
+            uint32_t c = h;
+#pragma unroll
+            for (int dlt = 1; dlt < KN_WAVE; dlt <<= 1) {
+                const uint32_t up = __shfl_up(c, dlt, KN_WAVE);
+                c += (tid & (KN_WAVE - 1)) >= dlt ? up : 0u;
             }
-            s_prefix = prefix | ((uint32_t)b << shift);
-            s_need = need - acc;
+            if ((tid & (KN_WAVE - 1)) == KN_WAVE - 1) {
+                s_wave_tot[tid / KN_WAVE] = c;
+            }
+            __syncthreads();
+            for (int w = 0; w < tid / KN_WAVE; w++) {
+                c += s_wave_tot[w];
+            }
+            if (c >= need && c - h < need) {
+                s_prefix = prefix | ((uint32_t)tid << shift);
+                s_need = need - (c - h);
+            }
         }
         __syncthreads();
         prefix = s_prefix;
