@@ -183,10 +183,30 @@ __global__ __launch_bounds__(RS_THREADS) void row_select_kernel(const float* __r
     for (int shift = 24; shift >= 0; shift -= 8) {
         hist[tid] = 0;
         __syncthreads();
-        for (int64_t i = tid; i < n; i += RS_THREADS) {
-            const uint32_t key = rs_key<IS_L2>(row[i]);
-            if ((key & prefix_mask) == prefix) {
-                atomicAdd(&hist[(key >> shift) & 0xff], 1u);
+        if (shift == 24) {
+            // top digit = sign + exponent bits: a whole row falls into two or three bins, so the counts are
+            // combined per wave (one atomic per distinct digit) instead of 64 atomics on the same address
+            for (int64_t i0 = 0; i0 < n; i0 += RS_THREADS) {
+                const int64_t i = i0 + tid;
+                const bool act = i < n;
+                const uint32_t dg = act ? (rs_key<IS_L2>(row[i]) >> 24) : 0xffffffffu;
+                unsigned long long rem = __ballot(act);
+                while (rem) {
+                    const int l = __ffsll((long long)rem) - 1;
+                    const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)dg, l);
+                    const unsigned long long m = __ballot(act && dg == d0);
+                    if ((tid & (KN_WAVE - 1)) == l) {
+                        atomicAdd(&hist[d0], (uint32_t)__popcll(m));
+                    }
+                    rem &= ~m;
+                }
+            }
+        } else {
+            for (int64_t i = tid; i < n; i += RS_THREADS) {
+                const uint32_t key = rs_key<IS_L2>(row[i]);
+                if ((key & prefix_mask) == prefix) {
+                    atomicAdd(&hist[(key >> shift) & 0xff], 1u);
+                }
             }
         }
         __syncthreads();
