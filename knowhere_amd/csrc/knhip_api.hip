@@ -1318,7 +1318,9 @@ int knhip_range_search(const knhip_index* idx, const float* queries, int64_t nq,
             d_bitset = ws->h_bitset.as<uint8_t>();
         }
         // queries per batch: the distance matrix stays below 2 GiB
-        const int64_t qb = std::max<int64_t>(1, std::min<int64_t>(nq, (int64_t)((2ull << 30) / ((size_t)std::max<int64_t>(ncol, 1) * 4))));
+        // (and one workgroup per (query, segment) must fit a launch)
+        int64_t qb = std::max<int64_t>(1, std::min<int64_t>(nq, (int64_t)((2ull << 30) / ((size_t)std::max<int64_t>(ncol, 1) * 4))));
+        qb = std::max<int64_t>(1, std::min<int64_t>(qb, (int64_t)0x7fffffff / std::max<int64_t>(nseg, 1)));
         std::vector<int64_t> rel((size_t)qb + 1);
         for (int64_t q0 = 0; q0 < nq; q0 += qb) {
             const int64_t n = std::min(qb, nq - q0);
