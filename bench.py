@@ -122,10 +122,25 @@ def main():
 
     kbase = a.refine_k if a.refine_k > 0 else a.k
 
+    # N > 1: the coarse quantizer is sharded by QUERIES (each rank assigns nq / N of them, one all-gather of the
+    # (nq, nprobe) assignment), the scan by LISTS (knhip_search_preassigned_device = IndexIVF::search_preassigned)
+    q_per = (a.nq + world - 1) // world
+    q_lo, q_hi = min(a.nq, rank * q_per), min(a.nq, (rank + 1) * q_per)
+
     def step():
-        Dp, Ip = g.search_device(xq, kbase, a.nprobe)
         if world > 1:
+            keys_loc = torch.full((q_per, a.nprobe), -1, dtype=torch.int64, device=dev)
+            cdis_loc = torch.zeros((q_per, a.nprobe), dtype=torch.float32, device=dev)
+            if q_hi > q_lo:
+                cd, ck = g.coarse_search_device(xq[q_lo:q_hi], a.nprobe)
+                keys_loc[:q_hi - q_lo] = ck
+                cdis_loc[:q_hi - q_lo] = cd
+            keys = comm.allgather(keys_loc).reshape(-1, a.nprobe)[:a.nq].contiguous()
+            cdis = comm.allgather(cdis_loc).reshape(-1, a.nprobe)[:a.nq].contiguous()
+            Dp, Ip = g.search_preassigned_device(xq, kbase, keys, cdis)
             Dp, Ip = comm.allgather_merge(kidx.L2, Dp, Ip)
+        else:
+            Dp, Ip = g.search_device(xq, kbase, a.nprobe)
         if a.refine_k > 0:
             cand = Ip if own_row is None else sharded.mask_unowned(Ip, own_row)
             D, I = kidx.refine_device(kidx.L2, vectors, xq, cand, a.k)

@@ -157,6 +157,16 @@ int knhip_search(const knhip_index* idx, const float* queries, int64_t nq, int32
 int knhip_search_device(const knhip_index* idx, const float* d_queries, int64_t nq, int32_t k,
                         int32_t nprobe, const uint8_t* d_bitset, int64_t bitset_nbits,
                         int64_t* d_out_ids, float* d_out_dist, void* stream);
+/* Search with a GIVEN coarse assignment: d_keys / d_coarse_dis [nq][nprobe] as knhip_coarse_search_device
+ * returns them (best-first; key < 0 = no list).  Replaces IndexIVF::search_preassigned
+ * (thirdparty/faiss/faiss/IndexIVF.cpp:401-768), which is what IndexIVF::search calls after its coarse
+ * quantizer step (:336-350).  Lets a list-sharded deployment run the coarse quantizer once per query instead
+ * of once per rank: every rank assigns its slice of the batch, the assignments are all-gathered, every rank
+ * scans the lists it owns.  nprobe must be <= nlist.  Same results as knhip_search_device. */
+int knhip_search_preassigned_device(const knhip_index* idx, const float* d_queries, int64_t nq, int32_t k,
+                                    int32_t nprobe, const int64_t* d_keys, const float* d_coarse_dis,
+                                    const uint8_t* d_bitset, int64_t bitset_nbits, int64_t* d_out_ids,
+                                    float* d_out_dist, void* stream);
 /* Coarse quantizer only: top-nprobe centroids per query, best-first. */
 int knhip_coarse_search_device(const knhip_index* idx, const float* d_queries, int64_t nq,
                                int32_t nprobe, int64_t* d_out_keys, float* d_out_dist,

@@ -43,7 +43,7 @@ SYMBOLS = [
     "knhip_merge_topk_host", "knhip_refine_device", "knhip_fvec_L2sqr_ny", "knhip_fvec_inner_products_ny",
     "knhip_fvec_norms_L2sqr", "knhip_fvec_madd", "knhip_int8_vec_L2sqr_ny",
     "knhip_int8_vec_inner_products_ny", "knhip_profile_enable", "knhip_profile_reset",
-    "knhip_profile_get", "knhip_stage_kernel_name", "knhip_range_search", "knhip_free",
+    "knhip_profile_get", "knhip_stage_kernel_name", "knhip_range_search", "knhip_free", "knhip_search_preassigned_device",
 ]
 
 _lib = None
@@ -86,6 +86,7 @@ def load():
     L.knhip_search.argtypes = [vp, vp, i64, i32, i32, vp, i64, vp, vp]
     L.knhip_search_device.argtypes = [vp, vp, i64, i32, i32, vp, i64, vp, vp, vp]
     L.knhip_coarse_search_device.argtypes = [vp, vp, i64, i32, vp, vp, vp]
+    L.knhip_search_preassigned_device.argtypes = [vp, vp, i64, i32, i32, vp, vp, vp, i64, vp, vp, vp]
     L.knhip_merge_topk_device.argtypes = [i32, i64, i32, i32, vp, vp, vp, vp, vp]
     L.knhip_merge_topk_host.argtypes = [i32, i64, i32, i32, vp, vp, vp, vp]
     L.knhip_refine_device.argtypes = [i32, i32, vp, i64, i64, vp, i64, vp, i32, i32, vp, vp, vp]

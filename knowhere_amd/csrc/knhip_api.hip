@@ -420,9 +420,10 @@ void release_ws(const knhip_index* idx, Workspace* w) {
 }
 
 // ---- one batch of queries, everything on the device ------------------------------------------------
+// pre_keys / pre_cdis non-null: the coarse assignment is given (IndexIVF::search_preassigned), [nq][nprobe]
 int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_t nq, int k, int nprobe,
                  const uint8_t* d_bitset, int64_t nbits, int64_t* d_out_i, float* d_out_d,
-                 hipStream_t s) {
+                 hipStream_t s, const int64_t* pre_keys = nullptr, const float* pre_cdis = nullptr) {
     const int kind = idx->desc.kind;
     const int d = idx->d;
     const bool is_l2 = idx->is_l2;
@@ -470,13 +471,17 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
     // ---- IVF kinds ----
     const int64_t nlist = idx->nlist;
     // 1. coarse
-    HIP_TRY(ws->keys.reserve((size_t)nq * nprobe * sizeof(int64_t)));
-    HIP_TRY(ws->cdis.reserve((size_t)nq * nprobe * sizeof(float)));
-    {
+    const int64_t* keys_p = pre_keys;
+    const float* cdis_p = pre_cdis;
+    if (pre_keys == nullptr) {
+        HIP_TRY(ws->keys.reserve((size_t)nq * nprobe * sizeof(int64_t)));
+        HIP_TRY(ws->cdis.reserve((size_t)nq * nprobe * sizeof(float)));
         StageTimer t(idx, s, KNHIP_STAGE_COARSE);
         if (int rc = coarse_stage(idx, ws, d_q, nq, nprobe, ws->keys.as<int64_t>(), ws->cdis.as<float>(), s)) {
             return rc;
         }
+        keys_p = ws->keys.as<int64_t>();
+        cdis_p = ws->cdis.as<float>();
     }
     // 2. group
     const int qg = (kind == KNHIP_IVF_PQ) ? pq_scan_qg(idx->desc.pq_m)
@@ -506,7 +511,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
     wt.k = k;
     {
         StageTimer t(idx, s, KNHIP_STAGE_GROUP);
-        HIP_TRY(launch_build_worktable(ws->keys.as<int64_t>(), nq, nprobe, nlist, qg,
+        HIP_TRY(launch_build_worktable(keys_p, nq, nprobe, nlist, qg,
                                        idx->d_list_len.as<int64_t>(), idx->code_size, wt, s));
     }
     idx->last_items_bound = items_bound;
@@ -555,7 +560,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         a.lut_mode = mode;
         a.queries = d_q;
         a.t2t = ws->t2t.as<float>();
-        a.coarse_dis = ws->cdis.as<float>();
+        a.coarse_dis = cdis_p;
         a.items = wt.items;
         a.pairs = wt.pairs;
         a.nitems_dev = wt.nitems;
@@ -588,7 +593,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
                 {
                     StageTimer t(idx, s, KNHIP_STAGE_SCAN_RANK0);
                     HIP_TRY(launch_pq_scan_v2(a, is_l2, true, boundA, s));
-                    HIP_TRY(launch_rank0_select(a.dump, stride, ws->keys.as<int64_t>(), nprobe,
+                    HIP_TRY(launch_rank0_select(a.dump, stride, keys_p, nprobe,
                                                 idx->d_list_len.as<int64_t>(), idx->d_list_row_off.as<int64_t>(),
                                                 idx->ids.as<int64_t>(), nq, k, is_l2, a.partial_d, a.partial_i,
                                                 a.gthr, ws->sel_keys.as<int64_t>(), ws->sel_d.as<float>(),
@@ -625,7 +630,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         a.d = d;
         a.nchunk16 = (d + 15) / 16;
         a.queries = d_q;
-        a.coarse_dis = ws->cdis.as<float>();
+        a.coarse_dis = cdis_p;
         a.items = wt.items;
         a.pairs = wt.pairs;
         a.nitems_dev = wt.nitems;
@@ -997,6 +1002,40 @@ int knhip_search_device(const knhip_index* idx, const float* d_queries, int64_t 
         const int64_t n = std::min(qb, nq - q0);
         if (int rc = search_batch(idx, ws, d_queries + q0 * idx->d, n, k, nprobe, d_bitset, bitset_nbits,
                                   d_out_ids + q0 * k, d_out_dist + q0 * k, s)) {
+            return rc;
+        }
+    }
+    return KNHIP_OK;
+}
+
+int knhip_search_preassigned_device(const knhip_index* idx, const float* d_queries, int64_t nq, int32_t k,
+                                    int32_t nprobe, const int64_t* d_keys, const float* d_coarse_dis,
+                                    const uint8_t* d_bitset, int64_t bitset_nbits, int64_t* d_out_ids,
+                                    float* d_out_dist, void* stream) {
+    if (int rc = check_index(idx)) return rc;
+    if (idx->desc.kind == KNHIP_BRUTE_FORCE) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "search_preassigned needs an IVF index");
+    }
+    const int32_t nprobe_in = nprobe;
+    if (int rc = validate_search(idx, nq, k, nprobe)) return rc;
+    if (nprobe != nprobe_in) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "search_preassigned: nprobe must not exceed nlist (keys are [nq][nprobe])");
+    }
+    if (nq == 0) {
+        return KNHIP_OK;
+    }
+    if (!d_queries || !d_out_ids || !d_out_dist || !d_keys || !d_coarse_dis) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "null query/assignment/output pointer");
+    }
+    DeviceGuard g(idx->desc.device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Workspace* ws = acquire_ws(idx, stream, true);
+    const int64_t qb = query_batch(idx, nq, k, nprobe);
+    for (int64_t q0 = 0; q0 < nq; q0 += qb) {
+        const int64_t n = std::min(qb, nq - q0);
+        if (int rc = search_batch(idx, ws, d_queries + q0 * idx->d, n, k, nprobe, d_bitset, bitset_nbits,
+                                  d_out_ids + q0 * k, d_out_dist + q0 * k, s, d_keys + q0 * nprobe,
+                                  d_coarse_dis + q0 * nprobe)) {
             return rc;
         }
     }

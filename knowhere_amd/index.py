@@ -164,6 +164,18 @@ class GpuIndex:
                                          _t_ptr(I), _t_ptr(D), C.c_void_p(s)))
         return D, I
 
+    def search_preassigned_device(self, xq_t, k, keys_t, cdis_t, bitset_t=None, nbits=0, stream=None):
+        """search with a given coarse assignment (keys_t / cdis_t: [nq][nprobe] from coarse_search_device)"""
+        import torch
+        nq, nprobe = keys_t.shape
+        assert xq_t.shape[0] == nq and keys_t.is_contiguous() and cdis_t.is_contiguous()
+        D = torch.empty((nq, k), dtype=torch.float32, device=xq_t.device)
+        I = torch.empty((nq, k), dtype=torch.int64, device=xq_t.device)
+        s = torch.cuda.current_stream(xq_t.device).cuda_stream if stream is None else stream
+        check(self.L.knhip_search_preassigned_device(self.h, _t_ptr(xq_t), nq, k, nprobe, _t_ptr(keys_t), _t_ptr(cdis_t),
+                                                     _t_ptr(bitset_t), nbits, _t_ptr(I), _t_ptr(D), C.c_void_p(s)))
+        return D, I
+
     def coarse_search_device(self, xq_t, nprobe, stream=None):
         import torch
         nq = xq_t.shape[0]

@@ -380,3 +380,30 @@ def test_scale_properties_ivfpq_1m(torch_cuda):
         if surv:
             assert I2c[q, 0] == surv[0]
     g.close()
+
+
+@pytest.mark.parametrize("kind,M", [(ob.IVF_FLAT, 0), (ob.IVF_PQ, 32), (ob.IVF_PQ, 16), (ob.IVF_SQ8, 0)],
+                         ids=["ivfflat", "ivfpq32", "ivfpq16", "ivfsq8"])
+def test_search_preassigned_equals_search(torch_cuda, port, kind, M):
+    """IndexIVF::search == quantizer search + search_preassigned (IndexIVF.cpp:336-350): the split entry point
+    used by the list-sharded deployment returns exactly what knhip_search_device returns"""
+    torch = torch_cuda
+    nb, nq, d, nlist, nprobe = 20000, 77, 64, 64, 12
+    xb, xq = gen_data(nb, d, 42), gen_data(nq, d, 44)
+    ix = finish_ivfpq(port, ob.make_index(port, kind, ob.L2, xb, nlist=nlist, M=max(M, 1), nbits=8))
+    g = _gpu(ix)
+    xq_t = torch.from_numpy(xq).cuda()
+    for k in (10, 100):
+        D, I = g.search_device(xq_t, k, nprobe)
+        cd, ck = g.coarse_search_device(xq_t, nprobe)
+        D2, I2 = g.search_preassigned_device(xq_t, k, ck, cd)
+        torch.cuda.synchronize()
+        assert torch.equal(I, I2) and torch.equal(D.view(torch.int32), D2.view(torch.int32))
+    # a dropped probe (key = -1) is simply not scanned
+    cd, ck = g.coarse_search_device(xq_t, nprobe)
+    ck2 = ck.clone()
+    ck2[:, 1:] = -1
+    D1, I1 = g.search_device(xq_t, 10, 1)
+    D3, I3 = g.search_preassigned_device(xq_t, 10, ck2, cd)
+    torch.cuda.synchronize()
+    assert torch.equal(I1, I3)
