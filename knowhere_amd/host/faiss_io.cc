@@ -85,6 +85,7 @@ void ReadInvertedLists(Reader& r, FaissIndexData& x) {
     const uint64_t nlist = r.one<uint64_t>();
     const uint64_t cs = r.one<uint64_t>();
     if (nlist != x.nlist) throw std::runtime_error("inverted lists: nlist mismatch");
+    if (nlist > (uint64_t)(r.end - r.p)) throw std::runtime_error("inverted lists: nlist exceeds blob");
     if (x.code_size == 0) x.code_size = cs;
     if (cs != x.code_size) throw std::runtime_error("inverted lists: code_size mismatch");
     const uint32_t lt = r.one<uint32_t>();
@@ -110,7 +111,7 @@ void ReadInvertedLists(Reader& r, FaissIndexData& x) {
     x.norms.assign(x.with_norm ? nlist : 0, {});
     for (uint64_t l = 0; l < nlist; l++) {
         if (n[l] == 0) continue;
-        if (n[l] > (uint64_t)(r.end - r.p)) throw std::runtime_error("inverted lists: list length exceeds blob");
+        if (cs == 0 || n[l] > (uint64_t)(r.end - r.p) / cs) throw std::runtime_error("inverted lists: list length exceeds blob");
         x.codes[l].resize(n[l] * cs);
         r.raw(x.codes[l].data(), n[l] * cs);
         x.ids[l].resize(n[l]);
@@ -151,6 +152,7 @@ void ReadIvfHeader(Reader& r, FaissIndexData& x) {
     ReadHeader(r, x.hdr);
     x.nlist = r.one<uint64_t>();
     x.nprobe = r.one<uint64_t>();
+    if (x.nlist == 0 || x.nlist > (uint64_t)(r.end - r.p)) throw std::runtime_error("bad nlist");
     x.quantizer.fourcc = r.one<uint32_t>();
     if (!IsFlat(x.quantizer.fourcc)) throw std::runtime_error("coarse quantizer is not a flat index");
     ReadFlatBody(r, x.quantizer);

@@ -112,6 +112,29 @@ def test_malformed_blobs_are_rejected(node):
         roundtrip(node, huge)
 
 
+def test_corrupted_blobs_never_crash_the_parser(node):
+    """random byte / length-field corruption: the parser either round-trips or reports an error -- no crash,
+    no runaway allocation (every length is checked against the bytes that are left)"""
+    rng = np.random.default_rng(11)
+    blobs = [np.load(p)["blob"] for p in golden_blobs() if "ivfpq_l2" in p or "ivfflat_l2" in p or "ivfsq8_l2_refine" in p]
+    outcomes = {"ok": 0, "rejected": 0}
+    for blob in blobs:
+        for _ in range(150):
+            b = blob.copy()
+            for _ in range(int(rng.integers(1, 4))):
+                pos = int(rng.integers(0, min(b.size, 400)))  # headers and size tables live at the front
+                if rng.random() < 0.5:
+                    b[pos] = rng.integers(0, 256)
+                else:
+                    b[pos:pos + 8] = 255
+            try:
+                roundtrip(node, b)
+                outcomes["ok"] += 1
+            except ValueError:
+                outcomes["rejected"] += 1
+    assert outcomes["rejected"] > 50 and outcomes["ok"] + outcomes["rejected"] == 150 * len(blobs)
+
+
 # ------------------------------------------------------------------------------------------ GPU
 def _search(L, h, xq, cfg, k):
     nq, d = xq.shape
