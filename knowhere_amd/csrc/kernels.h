@@ -20,6 +20,19 @@ struct KnPair {
     int32_t slot;
 };
 
+// flat work record of the persistent variant of the lane-stationary PQ scan (pq_scan_v2.hip)
+struct P2Rec {
+    int32_t list;
+    int32_t npair;
+    int32_t q[2];
+    int32_t slot[2];
+    float dis0[2];
+    int64_t len;
+    int64_t sblk0;
+    int64_t row_off;
+    int64_t pad;
+};
+
 struct FlatScanArgs {
     // rows
     const float4* rows;          // interleaved blocks
@@ -91,6 +104,8 @@ struct PqScanArgs {
     // vectors seen so far per distance bin, gmeta[q] = {key of the first bin, bin shift | KN_HIST_OFF}
     uint32_t* ghist;
     const uint2* gmeta;
+    // persistent variant of the bulk launch (experimental): [item bound] flat records; nullptr = one workgroup per item
+    P2Rec* recs;
 };
 
 

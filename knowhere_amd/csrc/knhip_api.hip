@@ -117,6 +117,7 @@ struct Workspace {
     DevBuf sel_keys;     // [qb][k]
     DevBuf sel_d;        // [qb][k]
     DevBuf rg_seg, rg_cnt, rg_off, rg_tot, rg_out_i, rg_out_d;  // range search scratch
+    DevBuf recs;         // [items] flat work records (persistent bulk scan, experimental)
     DevBuf ghist;        // [qb][64] per-query candidate histogram (pq_scan_v2 after a rank-0 phase)
     DevBuf gmeta;        // [qb] {first-bin key, shift}
     DevBuf list_count, list_pair_off, list_item_off, list_cursor, pairs, items, nitems;
@@ -167,6 +168,7 @@ struct knhip_index {
     bool pq_v2 = false;
     bool rank0_select = true;  // KNHIP_RANK0=0 switches the dump + radix-select phase off
     bool cand_hist = true;     // KNHIP_HIST=0 switches the per-query candidate histogram off
+    bool persistent_scan = false; // KNHIP_PERSISTENT=1: persistent workgroups in the bulk scan (experimental)
     mutable bool rank0_phase_used = false;
     int64_t max_list_len = 0;
     // scratch
@@ -330,6 +332,8 @@ int build_list_layout(knhip_index* idx, const std::vector<int64_t>& list_off, co
         idx->rank0_select = !(e && e[0] == '0');
         const char* h = getenv("KNHIP_HIST");
         idx->cand_hist = !(h && h[0] == '0');
+        const char* pe = getenv("KNHIP_PERSISTENT");
+        idx->persistent_scan = pe && pe[0] == '1';
     }
     for (int64_t l = 0; l < nlist; l++) {
         idx->h_list_len[l] = list_off[l + 1] - list_off[l];
@@ -610,6 +614,10 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
                 a.item_hi = wt.nitems;
             } else {
                 idx->rank0_phase_used = false;
+            }
+            if (idx->persistent_scan) {
+                HIP_TRY(ws->recs.reserve((size_t)items_bound * sizeof(P2Rec)));
+                a.recs = ws->recs.as<P2Rec>();
             }
             StageTimer t(idx, s, KNHIP_STAGE_SCAN);
             HIP_TRY(launch_pq_scan_v2(a, is_l2, false, items_bound, s));

@@ -203,38 +203,14 @@ __device__ __forceinline__ float p2_prefilter(float kd, float dis0) {
 // (launch_rank0_select) -- selecting k of a whole list by sorted insertion is what made k = 100 cost
 // twice k = 10 (tools ablation).  The selection also seeds the shared threshold before
 // the bulk scan of the remaining probes starts.
+// One work item = (list, up to two (query, probe) pairs): LUT build, staggered scan, end-of-item merge.
 template <bool IS_L2, int R, bool DUMP>
-__global__ __launch_bounds__(P2_THREADS, (P2_NWAVES >= 10 ? 5 : P2_NWAVES >= 8 ? 4 : 2)) void pq_scan_v2_kernel(PqScanArgs a) {
+__device__ __forceinline__ void p2_process_item(const PqScanArgs& a, unsigned char* smem, const int lane, const int wave,
+                                                const int tid, const int npair, const int64_t list, const int64_t len,
+                                                const int64_t sblk0, const int64_t row_off, const int32_t (&q_of)[2],
+                                                const int32_t (&slot_of)[2], const float (&dis0)[2]) {
     constexpr int QG = 2;
-    extern __shared__ __align__(16) unsigned char smem[];
     float* lut = reinterpret_cast<float*>(smem); // [256][32][2]
-    const int lane = lane_id();
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / KN_WAVE); // wave-uniform: scalar loop control
-
-    const int64_t item_lo = a.item_lo ? *a.item_lo : 0;
-    const int64_t nitems = *a.item_hi - item_lo;
-    if ((int64_t)blockIdx.x >= ((nitems + 7) / 8) * 8) {
-        return;
-    }
-    const int64_t item_rel = xcd_item(blockIdx.x, nitems);
-    if (item_rel >= nitems) {
-        return;
-    }
-    const KnItem it = a.items[item_lo + item_rel];
-    const int npair = it.npair < QG ? it.npair : QG;
-    const int64_t list = it.list;
-    const int64_t len = a.list_len[list];
-    const int64_t sblk0 = a.list_sblk_off[list];
-    const int64_t row_off = a.list_row_off[list];
-    int32_t q_of[QG], slot_of[QG];
-    float dis0[QG];
-#pragma unroll
-    for (int j = 0; j < QG; j++) {
-        const KnPair p = a.pairs[it.pair0 + (j < npair ? j : npair - 1)];
-        q_of[j] = p.q;
-        slot_of[j] = p.slot;
-        dis0[j] = (a.lut_mode == PQ_LUT_RESIDUAL) ? 0.f : a.coarse_dis[(int64_t)p.q * a.nslot + p.slot];
-    }
 
     // candidate histogram of this item's queries: wave j refreshes query j's bound from it; the row is
     // requested here so that its latency hides behind the table loads of the LUT build
@@ -263,7 +239,7 @@ __global__ __launch_bounds__(P2_THREADS, (P2_NWAVES >= 10 ? 5 : P2_NWAVES >= 8 ?
     if (a.lut_mode == PQ_LUT_RESIDUAL) {
         const int dsub = a.d / P2_M;
         const float* cl = a.centroids + list * a.d;
-        for (int e = threadIdx.x; e < P2_KSUB * P2_M; e += P2_THREADS) {
+        for (int e = tid; e < P2_KSUB * P2_M; e += P2_THREADS) {
             const int c = e / P2_M, m = e % P2_M;
             const float* y = a.cb + ((int64_t)m * P2_KSUB + c) * dsub;
 #pragma unroll
@@ -287,7 +263,7 @@ __global__ __launch_bounds__(P2_THREADS, (P2_NWAVES >= 10 ? 5 : P2_NWAVES >= 8 ?
         float4 xa[NU], xb[NU], pp[NU];
 #pragma unroll
         for (int u = 0; u < NU; u++) {
-            const int e4 = threadIdx.x + u * P2_THREADS;
+            const int e4 = tid + u * P2_THREADS;
 #if P2_ABLATE == 4 /* timing experiment only: no table loads */
             xa[u] = xb[u] = pp[u] = make_float4(1.f, 2.f, 3.f, (float)e4);
 #else
@@ -300,7 +276,7 @@ __global__ __launch_bounds__(P2_THREADS, (P2_NWAVES >= 10 ? 5 : P2_NWAVES >= 8 ?
         float4* l4 = reinterpret_cast<float4*>(lut);
 #pragma unroll
         for (int u = 0; u < NU; u++) {
-            const int e4 = threadIdx.x + u * P2_THREADS;
+            const int e4 = tid + u * P2_THREADS;
             float4 A = xa[u], B = xb[u];
             if (pre) {
                 const float4 p = pp[u];
@@ -590,6 +566,110 @@ __global__ __launch_bounds__(P2_THREADS, (P2_NWAVES >= 10 ? 5 : P2_NWAVES >= 8 ?
     }
 }
 
+// ---- one workgroup per work item (grid = item bound), XCD-aware block -> item mapping ---------------------
+template <bool IS_L2, int R, bool DUMP>
+__global__ __launch_bounds__(P2_THREADS, (P2_NWAVES >= 10 ? 5 : P2_NWAVES >= 8 ? 4 : 2)) void pq_scan_v2_kernel(PqScanArgs a) {
+    constexpr int QG = 2;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / KN_WAVE); // wave-uniform: scalar loop control
+
+    const int64_t item_lo = a.item_lo ? *a.item_lo : 0;
+    const int64_t nitems = *a.item_hi - item_lo;
+    if ((int64_t)blockIdx.x >= ((nitems + 7) / 8) * 8) {
+        return;
+    }
+    const int64_t item_rel = xcd_item(blockIdx.x, nitems);
+    if (item_rel >= nitems) {
+        return;
+    }
+    const KnItem it = a.items[item_lo + item_rel];
+    const int npair = it.npair < QG ? it.npair : QG;
+    const int64_t list = it.list;
+    const int64_t len = a.list_len[list];
+    const int64_t sblk0 = a.list_sblk_off[list];
+    const int64_t row_off = a.list_row_off[list];
+    int32_t q_of[QG], slot_of[QG];
+    float dis0[QG];
+#pragma unroll
+    for (int j = 0; j < QG; j++) {
+        const KnPair p = a.pairs[it.pair0 + (j < npair ? j : npair - 1)];
+        q_of[j] = p.q;
+        slot_of[j] = p.slot;
+        dis0[j] = (a.lut_mode == PQ_LUT_RESIDUAL) ? 0.f : a.coarse_dis[(int64_t)p.q * a.nslot + p.slot];
+    }
+    p2_process_item<IS_L2, R, DUMP>(a, smem, lane, wave, (int)threadIdx.x, npair, list, len, sblk0, row_off, q_of, slot_of,
+                                    dis0);
+}
+
+// ---- PERSISTENT variant (experimental, KNHIP_PERSISTENT=1): the grid is the number of co-resident workgroups;
+// workgroup b walks the items (b % 8) * per + (b / 8), + gridDim / 8, ... of "its" XCD's contiguous eighth, reading
+// one flat 64-byte record per item (p2_prepare_kernel) instead of the item -> pair -> list-metadata chain.
+__global__ void p2_prepare_kernel(PqScanArgs a, int64_t nrec) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrec) {
+        return;
+    }
+    P2Rec rec{};
+    const int64_t item_lo = a.item_lo ? *a.item_lo : 0;
+    const int64_t nitems = *a.item_hi - item_lo;
+    if (r < nitems) {
+        const KnItem it = a.items[item_lo + r];
+        const int npair = it.npair < 2 ? it.npair : 2;
+        rec.list = it.list;
+        rec.npair = npair;
+        rec.len = a.list_len[it.list];
+        rec.sblk0 = a.list_sblk_off[it.list];
+        rec.row_off = a.list_row_off[it.list];
+        for (int j = 0; j < 2; j++) {
+            const KnPair p = a.pairs[it.pair0 + (j < npair ? j : npair - 1)];
+            rec.q[j] = p.q;
+            rec.slot[j] = p.slot;
+            rec.dis0[j] = (a.lut_mode == PQ_LUT_RESIDUAL) ? 0.f : a.coarse_dis[(int64_t)p.q * a.nslot + p.slot];
+        }
+    }
+    a.recs[r] = rec;
+}
+
+template <bool IS_L2, int R>
+__global__ __launch_bounds__(P2_THREADS, 4) void pq_scan_v2_persistent_kernel(PqScanArgs a) {
+    constexpr int QG = 2;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / KN_WAVE);
+    const int64_t item_lo = a.item_lo ? *a.item_lo : 0;
+    const int64_t nitems = *a.item_hi - item_lo;
+    const int64_t per = (nitems + 7) / 8;
+    const int64_t xcd = blockIdx.x % 8, wg_in_xcd = blockIdx.x / 8, wgs_per_xcd = gridDim.x / 8;
+    for (int64_t n = 0;; n++) {
+        const int64_t local = n * wgs_per_xcd + wg_in_xcd;
+        const int64_t idx = xcd * per + local;
+        if (local >= per || idx >= nitems) {
+            break;
+        }
+        // opaque per iteration: nothing derived from the lane / thread id is hoisted out of the item loop (the
+        // hoisted addresses cost 26 VGPRs and a spill otherwise)
+        int lane_i = lane, tid_i = (int)threadIdx.x;
+        asm volatile("" : "+v"(lane_i), "+v"(tid_i));
+        // every field is wave-uniform; say so (readfirstlane), or lengths and offsets live in VGPRs and the window
+        // loop control turns into EXEC-masked vector code
+        const P2Rec rec = a.recs[idx];
+        auto sc32 = [](int32_t v) { return __builtin_amdgcn_readfirstlane(v); };
+        auto sc64 = [](int64_t v) {
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(uint32_t)v);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(uint32_t)((uint64_t)v >> 32));
+            return (int64_t)(((uint64_t)hi << 32) | lo);
+        };
+        auto scf = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+        const int32_t q_of[QG] = {sc32(rec.q[0]), sc32(rec.q[1])};
+        const int32_t slot_of[QG] = {sc32(rec.slot[0]), sc32(rec.slot[1])};
+        const float dis0[QG] = {scf(rec.dis0[0]), scf(rec.dis0[1])};
+        p2_process_item<IS_L2, R, false>(a, smem, lane_i, wave, tid_i, sc32(rec.npair), sc32(rec.list), sc64(rec.len),
+                                         sc64(rec.sblk0), sc64(rec.row_off), q_of, slot_of, dis0);
+        __syncthreads(); // the merge scratch aliases the next item's LUT
+    }
+}
+
 template <bool IS_L2, int R, bool DUMP>
 static hipError_t launch_v2_r(const PqScanArgs& a, int64_t grid, hipStream_t s) {
     const size_t lut_bytes = (size_t)P2_KSUB * 256;
@@ -600,6 +680,19 @@ static hipError_t launch_v2_r(const PqScanArgs& a, int64_t grid, hipStream_t s) 
                                        (int)sm);
     if (e != hipSuccess) {
         return e;
+    }
+    if (!DUMP && a.recs != nullptr) {
+        auto pk = pq_scan_v2_persistent_kernel<IS_L2, R>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        if (e != hipSuccess) {
+            return e;
+        }
+        hipLaunchKernelGGL(p2_prepare_kernel, dim3((unsigned)((grid + 255) / 256)), dim3(256), 0, s, a, grid);
+        // a few workgroups per resident slot (2 slots per CU): semi-persistent, independent of how the runtime
+        // counts compute units, still ~300 items per workgroup at the contract shape
+        const int64_t wgs = std::max<int64_t>(8, std::min<int64_t>(2048, ((grid + 7) / 8) * 8));
+        hipLaunchKernelGGL(pk, dim3((unsigned)wgs), dim3(P2_THREADS), sm, s, a);
+        return hipGetLastError();
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(P2_THREADS), sm, s, a);
     return hipGetLastError();

@@ -407,3 +407,17 @@ def test_search_preassigned_equals_search(torch_cuda, port, kind, M):
     D3, I3 = g.search_preassigned_device(xq_t, 10, ck2, cd)
     torch.cuda.synchronize()
     assert torch.equal(I1, I3)
+
+
+def test_persistent_scan_variant_matches(torch_cuda, port, monkeypatch):
+    """KNHIP_PERSISTENT=1 (experimental persistent-workgroup form of the bulk IVF-PQ scan) returns
+    exactly what the default one-workgroup-per-item launch returns"""
+    nb, nq, d, nlist, nprobe, k = 60000, 200, 128, 128, 32, 100
+    xb, xq = gen_data(nb, d, 42), gen_data(nq, d, 44)
+    ix = finish_ivfpq(port, ob.make_index(port, ob.IVF_PQ, ob.L2, xb, nlist=nlist, M=32, nbits=8))
+    D0, I0 = _gpu(ix).search(xq, k, nprobe)
+    monkeypatch.setenv("KNHIP_PERSISTENT", "1")  # read when the lists are attached
+    D1, I1 = _gpu(ix).search(xq, k, nprobe)
+    assert np.array_equal(I0, I1) and np.array_equal(D0.view(np.uint32), D1.view(np.uint32))
+    Do, Io = port.search(ix, xq, k, nprobe)
+    assert_parity(Do, Io, D1, I1, ob.L2, "persistent variant vs oracle")
