@@ -124,19 +124,10 @@ def main():
 
     # N > 1: the coarse quantizer is sharded by QUERIES (each rank assigns nq / N of them, one all-gather of the
     # (nq, nprobe) assignment), the scan by LISTS (knhip_search_preassigned_device = IndexIVF::search_preassigned)
-    q_per = (a.nq + world - 1) // world
-    q_lo, q_hi = min(a.nq, rank * q_per), min(a.nq, (rank + 1) * q_per)
-
     def step():
         if world > 1:
-            keys_loc = torch.full((q_per, a.nprobe), -1, dtype=torch.int64, device=dev)
-            cdis_loc = torch.zeros((q_per, a.nprobe), dtype=torch.float32, device=dev)
-            if q_hi > q_lo:
-                cd, ck = g.coarse_search_device(xq[q_lo:q_hi], a.nprobe)
-                keys_loc[:q_hi - q_lo] = ck
-                cdis_loc[:q_hi - q_lo] = cd
-            keys = comm.allgather(keys_loc).reshape(-1, a.nprobe)[:a.nq].contiguous()
-            cdis = comm.allgather(cdis_loc).reshape(-1, a.nprobe)[:a.nq].contiguous()
+            keys, cdis = sharded.sharded_coarse(comm, lambda lo, hi: g.coarse_search_device(xq[lo:hi], a.nprobe),
+                                                a.nq, a.nprobe, device=dev)
             Dp, Ip = g.search_preassigned_device(xq, kbase, keys, cdis)
             Dp, Ip = comm.allgather_merge(kidx.L2, Dp, Ip)
         else:

@@ -98,3 +98,21 @@ class Comm:
             return kidx.merge_topk_device(metric, Dp, Ip)
         Dm, Im = kidx.merge_topk_host(metric, Dp.numpy(), Ip.numpy())
         return torch.from_numpy(Dm), torch.from_numpy(Im)
+
+
+def sharded_coarse(comm, coarse_fn, nq, nprobe, device=None):
+    """Coarse quantizer sharded by QUERIES: rank r assigns queries [r * per, (r + 1) * per), one all-gather each of the
+    keys and the coarse distances gives every rank the full (nq, nprobe) assignment for
+    knhip_search_preassigned_device (= IndexIVF::search_preassigned).
+    coarse_fn(lo, hi) -> (coarse_dis [hi - lo, nprobe] float32, keys [hi - lo, nprobe] int64) tensors."""
+    per = (nq + comm.world - 1) // comm.world
+    lo, hi = min(nq, comm.rank * per), min(nq, (comm.rank + 1) * per)
+    keys_loc = torch.full((per, nprobe), -1, dtype=torch.int64, device=device)
+    cdis_loc = torch.zeros((per, nprobe), dtype=torch.float32, device=device)
+    if hi > lo:
+        cd, ck = coarse_fn(lo, hi)
+        keys_loc[:hi - lo] = ck
+        cdis_loc[:hi - lo] = cd
+    keys = comm.allgather(keys_loc).reshape(-1, nprobe)[:nq].contiguous()
+    cdis = comm.allgather(cdis_loc).reshape(-1, nprobe)[:nq].contiguous()
+    return keys, cdis

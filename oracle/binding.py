@@ -180,6 +180,21 @@ class Port:
         assert rc == 0
         return D, I
 
+    def ivf_search_preassigned(self, ix, xq, k, keys, cdis, bitset=None, nbits=0):
+        """IndexIVF::search_preassigned: the scan half of ivf_search with a given coarse assignment"""
+        xq = np.ascontiguousarray(xq, np.float32)
+        keys = np.ascontiguousarray(keys, np.int64)
+        cdis = np.ascontiguousarray(cdis, np.float32)
+        nq, nprobe = keys.shape
+        m, keep = self._marshal(ix)
+        D = np.empty((nq, k), np.float32)
+        I = np.empty((nq, k), np.int64)
+        rc = self.lib.orc_ivf_search_preassigned(C.byref(m), C.c_int64(nq), _p(xq, _f32p), C.c_int64(k),
+                                                 C.c_int64(nprobe), _p(keys, _i64p), _p(cdis, _f32p),
+                                                 _p(bitset, _u8p), C.c_int64(nbits), _p(D, _f32p), _p(I, _i64p))
+        assert rc == 0
+        return D, I
+
     def search(self, ix, xq, k, nprobe=1, bitset=None, nbits=0):
         if ix.kind == FLAT:
             return self.flat_search(ix.metric, ix.base, xq, k, bitset)

@@ -40,6 +40,21 @@ def _worker(rank, world, port_no, ret):
     D, I = comm.allgather_merge(ob.L2, torch.from_numpy(Dl), torch.from_numpy(Il))
     D0, I0 = port.search(ix, xq, 10, 8)
     assert_parity(D0, I0, D.numpy(), I.numpy(), ob.L2, f"rank {rank}: sharded == monolithic")
+    # the coarse quantizer sharded by queries + search_preassigned over the owned lists (bench.py's N > 1 step):
+    # 41 queries over 2 ranks exercises the padded last slice
+    xq2 = gen_data(41, 32, 45)
+
+    def coarse(lo, hi):
+        cd, ck = port.coarse_search(ix, xq2[lo:hi], 8)
+        return torch.from_numpy(cd), torch.from_numpy(ck)
+
+    keys, cdis = sharded.sharded_coarse(comm, coarse, 41, 8)
+    cd0, ck0 = port.coarse_search(ix, xq2, 8)
+    assert np.array_equal(keys.numpy(), ck0) and np.array_equal(cdis.numpy().view(np.uint32), cd0.view(np.uint32))
+    Dl2, Il2 = port.ivf_search_preassigned(sub, xq2, 10, keys.numpy(), cdis.numpy())
+    D2, I2 = comm.allgather_merge(ob.L2, torch.from_numpy(Dl2), torch.from_numpy(Il2))
+    D20, I20 = port.search(ix, xq2, 10, 8)
+    assert_parity(D20, I20, D2.numpy(), I2.numpy(), ob.L2, f"rank {rank}: query-sharded coarse + list-sharded scan")
     t = comm.max_float(float(rank))
     assert t == world - 1
     b = torch.full((3,), float(rank))
