@@ -22,7 +22,7 @@
 //   4. queries whose certificate fails are recomputed with the exact all-pairs kernel
 //      (flat_full + row_select restricted to flagged rows): rare, and exactness never depends
 //      on the margin being "big enough".
-#include "common.cuh"
+#include "common.h"
 #include "kernels.h"
 
 namespace knhip {

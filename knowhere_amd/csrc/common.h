@@ -1,4 +1,4 @@
-// knowhere_amd/csrc/common.cuh -- shared device/host helpers for the gfx950 kernels.
+// knowhere_amd/csrc/common.h -- shared device/host helpers for the gfx950 kernels.
 //
 // Conventions used by every kernel in this directory:
 //  * wave = 64 lanes, hard-coded (CDNA4); block sizes are multiples of 64.

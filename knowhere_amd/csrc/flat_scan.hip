@@ -19,7 +19,7 @@
 //
 // Roofline: algorithmic bytes per item = rows * d * 4 * npair (SURVEY.md 8d counts every
 // (query, probe) pair's list bytes, no credit for reuse).
-#include "common.cuh"
+#include "common.h"
 #include "kernels.h"
 
 namespace knhip {

@@ -20,18 +20,43 @@ struct KnPair {
     int32_t slot;
 };
 
-// flat work record of the persistent variant of the lane-stationary PQ scan (pq_scan_v2.hip)
-struct P2Rec {
+// ---- stream16 code layout of the staggered PQ scans (pq_scan_v2.hip, pq_scan_q4.hip) -----------------
+// Lane L of a wave starts its vector pq_stream_phase(L) steps late.  16 phases, chosen so that every lane
+// group an LDS gather is serviced in sees each phase equally often:
+//   ds_read_b128 (pq_scan_q4): four 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32)  -> each
+//     phase once per group; with LUT[code][m][4 queries] (16-B entries, bank quad = m mod 16) the 16 lanes
+//     of a group sit on 16 consecutive m: no bank conflict for any code values.  The map is also
+//     conflict-free should the groups be the contiguous sixteenths {0-15}, {16-31}.
+//   ds_read_b64 (pq_scan_v2): two 32-lane groups -> each phase twice: the 2-way conflict that kernel accepts.
+__host__ __device__ constexpr int pq_stream_phase(int lane) {
+    const int l = lane & 31;
+    return l < 4 ? l : l < 12 ? l + 4 : l < 16 ? l - 8 : l < 20 ? l - 16 : l < 28 ? l - 12 : l - 24;
+}
+constexpr int PQ_STREAM_PHASES = 16;
+// lanes (of one 32-lane half; both halves are alike) that are already on the window's NEW vector at step j
+__host__ __device__ constexpr uint32_t pq_stream_mask(int j) {
+    uint32_t m = 0;
+    for (int l = 0; l < 32; l++) {
+        if (pq_stream_phase(l) <= j) {
+            m |= 1u << l;
+        }
+    }
+    return m;
+}
+
+// flat work record of the persistent 4-query scan (pq_scan_q4.hip), one per work item
+struct P4Rec {
     int32_t list;
     int32_t npair;
-    int32_t q[2];
-    int32_t slot[2];
-    float dis0[2];
+    int32_t q[4];
+    int32_t slot[4];
+    float dis0[4];
     int64_t len;
     int64_t sblk0;
     int64_t row_off;
-    int64_t pad;
+    int64_t pad[2];
 };
+static_assert(sizeof(P4Rec) == 96, "P4Rec layout");
 
 struct FlatScanArgs {
     // rows
@@ -60,7 +85,7 @@ struct FlatScanArgs {
     // output
     float* partial_d;            // [nq][nslot][k]
     int64_t* partial_i;
-    float* gthr;                 // [nq] shared per-query threshold (see common.cuh gthr_*)
+    float* gthr;                 // [nq] shared per-query threshold (see common.h gthr_*)
     int32_t nslot;
     int32_t k;
 };
@@ -104,8 +129,10 @@ struct PqScanArgs {
     // vectors seen so far per distance bin, gmeta[q] = {key of the first bin, bin shift | KN_HIST_OFF}
     uint32_t* ghist;
     const uint2* gmeta;
-    // persistent variant of the bulk launch (experimental): [item bound] flat records; nullptr = one workgroup per item
-    P2Rec* recs;
+    // pq_scan_q4 (persistent, 4 queries per item): flat records, per-XCD item counters, c-major codebook
+    P4Rec* recs4;                  // [item bound]
+    int32_t* q4_ctr;               // [8 * 16] one counter per XCD, 64 B apart (zeroed by the launcher)
+    const float4* cb_t;            // [256][M] float4: cb_t[c][m] = codebook entry (m, c), dsub = 4
 };
 
 
@@ -128,7 +155,7 @@ struct SqScanArgs {
     int64_t bitset_nbits;
     float* partial_d;            // [nq][nslot][k]
     int64_t* partial_i;
-    float* gthr;                 // [nq] shared per-query threshold (see common.cuh gthr_*)
+    float* gthr;                 // [nq] shared per-query threshold (see common.h gthr_*)
     int32_t nslot;
     int32_t k;
     // range search: non-null = write every distance to dump[q * dump_stride + storage position], no top-k
@@ -172,6 +199,11 @@ hipError_t launch_rank0_select(const float* dump, int64_t dump_stride, const int
 hipError_t launch_pq_stream16(const uint8_t* codes, const int64_t* list_row_off, const int64_t* list_len,
                               const int64_t* list_sblk_off, int64_t nlist, uint4* out, hipStream_t s);
 
+// ---- pq_scan_q4.hip (M = 32, dsub = 4, k <= 128: persistent 4-query staggered ADC, LUT built in-kernel) ----
+bool pq_scan_q4_supports(int M, int d, int k);
+hipError_t launch_pq_scan_q4(const PqScanArgs& a, bool is_l2, int64_t items_bound, hipStream_t s);
+hipError_t launch_pq_cb_transpose(const float* cb, int M, int dsub, float4* cb_t, hipStream_t s);
+
 // ---- sq_scan.hip ----
 hipError_t launch_sq_scan(const SqScanArgs& a, bool is_l2, int64_t grid, hipStream_t s);
 hipError_t launch_sq_interleave(const uint8_t* codes, const int64_t* list_row_off,
@@ -194,7 +226,7 @@ struct WorkTable {
     int64_t* empty_mark;
     int32_t k;
 };
-hipError_t launch_build_worktable(const int64_t* keys, int64_t nq, int nprobe, int64_t nlist, int qg,
+hipError_t launch_build_worktable(const int64_t* keys, int64_t nq, int nprobe, int64_t nlist, int qg0, int qg1,
                                   const int64_t* list_len, int64_t code_size, const WorkTable& wt,
                                   hipStream_t s);
 hipError_t launch_fill_f32(float* p, int64_t n, float v, hipStream_t s);

@@ -12,7 +12,7 @@
 // BRUTE_FORCE is steps 4-5 with base chunks in place of lists.
 // Nothing in this path touches the host between the first and the last kernel.
 #include "../../include/knhip.h"
-#include "common.cuh"
+#include "common.h"
 #include "kernels.h"
 
 #include <cstdio>
@@ -117,7 +117,8 @@ struct Workspace {
     DevBuf sel_keys;     // [qb][k]
     DevBuf sel_d;        // [qb][k]
     DevBuf rg_seg, rg_cnt, rg_off, rg_tot, rg_out_i, rg_out_d;  // range search scratch
-    DevBuf recs;         // [items] flat work records (persistent bulk scan, experimental)
+    DevBuf recs4;        // [items] flat work records of the persistent 4-query scan (pq_scan_q4)
+    DevBuf q4_ctr;       // [8 * 16] per-XCD item counters
     DevBuf ghist;        // [qb][64] per-query candidate histogram (pq_scan_v2 after a rank-0 phase)
     DevBuf gmeta;        // [qb] {first-bin key, shift}
     DevBuf list_count, list_pair_off, list_item_off, list_cursor, pairs, items, nitems;
@@ -150,6 +151,7 @@ struct knhip_index {
     bool has_pq = false;
     DevBuf cb;            // [M][256][dsub]
     DevBuf precomp_t;     // [nlist][256][M]
+    DevBuf cb_t;          // [256][M] float4, c-major codebook (pq_scan_q4: M = 32, dsub = 4)
     int use_precomp = 0;
     // SQ
     bool has_sq = false;
@@ -166,9 +168,9 @@ struct knhip_index {
     DevBuf rows2;         // IVF_PQ m=32: stream16 layout for the staggered scan (pq_scan_v2.hip)
     DevBuf d_list_blk_off2;
     bool pq_v2 = false;
+    int pq_q4 = 2;             // KNHIP_Q4 = 0: never, 1: whenever the shape allows, 2 (default): when lists are shared by enough queries
     bool rank0_select = true;  // KNHIP_RANK0=0 switches the dump + radix-select phase off
     bool cand_hist = true;     // KNHIP_HIST=0 switches the per-query candidate histogram off
-    bool persistent_scan = false; // KNHIP_PERSISTENT=1: persistent workgroups in the bulk scan (experimental)
     mutable bool rank0_phase_used = false;
     int64_t max_list_len = 0;
     // scratch
@@ -185,7 +187,7 @@ struct knhip_index {
 
     int64_t device_bytes() const {
         const DevBuf* all[] = {&centroids, &centroids_il, &cb, &precomp_t, &sq_trained, &d_list_len,
-                               &d_list_row_off, &d_list_blk_off, &ids, &rows, &rows2, &d_list_blk_off2};
+                               &d_list_row_off, &d_list_blk_off, &ids, &rows, &rows2, &d_list_blk_off2, &cb_t};
         int64_t t = 0;
         for (auto* b : all) {
             t += (int64_t)b->bytes;
@@ -332,8 +334,8 @@ int build_list_layout(knhip_index* idx, const std::vector<int64_t>& list_off, co
         idx->rank0_select = !(e && e[0] == '0');
         const char* h = getenv("KNHIP_HIST");
         idx->cand_hist = !(h && h[0] == '0');
-        const char* pe = getenv("KNHIP_PERSISTENT");
-        idx->persistent_scan = pe && pe[0] == '1';
+        const char* q4 = getenv("KNHIP_Q4");
+        idx->pq_q4 = (q4 && q4[0] >= '0' && q4[0] <= '2') ? q4[0] - '0' : 2;
     }
     for (int64_t l = 0; l < nlist; l++) {
         idx->h_list_len[l] = list_off[l + 1] - list_off[l];
@@ -492,7 +494,25 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
                  : (kind == KNHIP_IVF_SQ8) ? 8
                                            : flat_scan_qg(k);
     const int64_t npairs = nq * nprobe;
-    const int64_t items_bound = round_up(npairs / qg + std::min<int64_t>(2 * nlist, npairs) + 1, 8);
+    // IVF-PQ m = 32: which kernels run the two phases (rank-0 dump + select, bulk) and how many queries they
+    // take per work item
+    bool pq_use_v2 = false, pq_rank0 = false, pq_use_q4 = false;
+    int qg_rank0 = qg, qg_bulk = qg;
+    if (kind == KNHIP_IVF_PQ && idx->pq_v2 && pq_scan_v2_supports(idx->desc.pq_m, k)) {
+        pq_use_v2 = true;
+        const int64_t stride = round_up(std::max<int64_t>(idx->max_list_len, 64), 64);
+        // (worth it once k is large enough that sorted insertion dominates: measured k >= 32)
+        pq_rank0 = idx->rank0_select && k >= 32 && nprobe > 1 && (double)nq * stride * 4.0 <= 6.0e9;
+        // the 4-query kernel pays when the lists are shared by enough (query, probe) pairs of the batch
+        pq_use_q4 = idx->cb_t.p != nullptr && pq_scan_q4_supports(idx->desc.pq_m, d, k) &&
+                (idx->pq_q4 == 1 || (idx->pq_q4 == 2 && npairs >= 6 * nlist));
+        if (pq_use_q4) {
+            qg_bulk = 4;
+            qg_rank0 = pq_rank0 ? qg : 4;
+        }
+    }
+    const int64_t items_bound =
+            round_up(npairs / std::min(qg_rank0, qg_bulk) + std::min<int64_t>(2 * nlist, npairs) + 1, 8);
     HIP_TRY(ws->list_count.reserve((size_t)2 * nlist * sizeof(int32_t)));
     HIP_TRY(ws->list_cursor.reserve((size_t)2 * nlist * sizeof(int32_t)));
     HIP_TRY(ws->list_pair_off.reserve((size_t)(2 * nlist + 1) * sizeof(int64_t)));
@@ -515,7 +535,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
     wt.k = k;
     {
         StageTimer t(idx, s, KNHIP_STAGE_GROUP);
-        HIP_TRY(launch_build_worktable(keys_p, nq, nprobe, nlist, qg,
+        HIP_TRY(launch_build_worktable(keys_p, nq, nprobe, nlist, qg_rank0, qg_bulk,
                                        idx->d_list_len.as<int64_t>(), idx->code_size, wt, s));
     }
     idx->last_items_bound = items_bound;
@@ -546,7 +566,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
     } else if (kind == KNHIP_IVF_PQ) {
         const int M = idx->desc.pq_m;
         const int mode = !is_l2 ? PQ_LUT_IP : (idx->use_precomp ? PQ_LUT_PRECOMP : PQ_LUT_RESIDUAL);
-        if (mode != PQ_LUT_RESIDUAL) {
+        if (mode != PQ_LUT_RESIDUAL && !(pq_use_q4 && !pq_rank0)) { // (pq_scan_q4 computes its tables from the codebook)
             HIP_TRY(ws->t2t.reserve((size_t)nq * 256 * M * sizeof(float)));
             StageTimer t(idx, s, KNHIP_STAGE_LUT);
             HIP_TRY(launch_pq_query_table(d_q, idx->cb.as<float>(), d, M, nq, ws->t2t.as<float>(), s));
@@ -575,13 +595,12 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         a.gthr = ws->gthr.as<float>();
         a.nslot = nprobe;
         a.k = k;
-        if (idx->pq_v2 && pq_scan_v2_supports(M, k)) {
+        if (pq_use_v2) {
             a.codes_skew = idx->rows2.as<uint4>();
             a.list_sblk_off = idx->d_list_blk_off2.as<int64_t>();
             a.item_hi = wt.nitems;
             const int64_t stride = round_up(std::max<int64_t>(idx->max_list_len, 64), 64);
-            // (worth it once k is large enough that sorted insertion dominates: measured k >= 32)
-            if (idx->rank0_select && k >= 32 && nprobe > 1 && (double)nq * stride * 4.0 <= 6.0e9) {
+            if (pq_rank0) {
                 // phase A: the rank-0 probe of every query (work items of virtual lists [0, nlist) come
                 // first: worktable.hip) in dump mode, then radix select -> partial slot 0 + thresholds
                 HIP_TRY(ws->dump.reserve((size_t)nq * stride * sizeof(float)));
@@ -593,7 +612,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
                 a.dump_stride = stride;
                 a.item_lo = nullptr;
                 a.item_hi = wt.list_item_off + nlist; // items of the rank-0 virtual lists
-                const int64_t boundA = round_up(nq / qg + std::min<int64_t>(nlist, nq) + 1, 8);
+                const int64_t boundA = round_up(nq / qg_rank0 + std::min<int64_t>(nlist, nq) + 1, 8);
                 {
                     StageTimer t(idx, s, KNHIP_STAGE_SCAN_RANK0);
                     HIP_TRY(launch_pq_scan_v2(a, is_l2, true, boundA, s));
@@ -615,12 +634,17 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             } else {
                 idx->rank0_phase_used = false;
             }
-            if (idx->persistent_scan) {
-                HIP_TRY(ws->recs.reserve((size_t)items_bound * sizeof(P2Rec)));
-                a.recs = ws->recs.as<P2Rec>();
-            }
             StageTimer t(idx, s, KNHIP_STAGE_SCAN);
-            HIP_TRY(launch_pq_scan_v2(a, is_l2, false, items_bound, s));
+            if (pq_use_q4) {
+                HIP_TRY(ws->recs4.reserve((size_t)items_bound * sizeof(P4Rec)));
+                HIP_TRY(ws->q4_ctr.reserve(8 * 16 * sizeof(int32_t)));
+                a.recs4 = ws->recs4.as<P4Rec>();
+                a.q4_ctr = ws->q4_ctr.as<int32_t>();
+                a.cb_t = idx->cb_t.as<float4>();
+                HIP_TRY(launch_pq_scan_q4(a, is_l2, items_bound, s));
+            } else {
+                HIP_TRY(launch_pq_scan_v2(a, is_l2, false, items_bound, s));
+            }
         } else {
             idx->rank0_phase_used = false;
             StageTimer t(idx, s, KNHIP_STAGE_SCAN);
@@ -852,6 +876,13 @@ int knhip_index_set_pq(knhip_index* idx, const float* codebooks) {
     DeviceGuard g(idx->desc.device);
     if (int rc = upload(idx->cb, codebooks, (size_t)256 * idx->d * sizeof(float))) return rc;
     idx->has_pq = true;
+    idx->cb_t.release();
+    if (pq_scan_q4_supports(idx->desc.pq_m, idx->d, 1)) {
+        HIP_TRY(idx->cb_t.alloc((size_t)256 * idx->desc.pq_m * sizeof(float4)));
+        HIP_TRY(launch_pq_cb_transpose(idx->cb.as<float>(), idx->desc.pq_m, idx->d / idx->desc.pq_m,
+                                       idx->cb_t.as<float4>(), nullptr));
+        HIP_TRY(hipDeviceSynchronize());
+    }
     return maybe_build_precomp(idx);
 }
 
@@ -1181,7 +1212,7 @@ static int range_batch(const knhip_index* idx, Workspace* ws, const float* d_q, 
         wt.items = ws->items.as<KnItem>();
         wt.nitems = ws->nitems.as<int64_t>();
         wt.scan_bytes = idx->scan_bytes_dev.as<double>();
-        HIP_TRY(launch_build_worktable(ws->keys.as<int64_t>(), nq, nprobe, nlist, qg, idx->d_list_len.as<int64_t>(),
+        HIP_TRY(launch_build_worktable(ws->keys.as<int64_t>(), nq, nprobe, nlist, qg, qg, idx->d_list_len.as<int64_t>(),
                                        idx->code_size, wt, s));
         PqScanArgs a{};
         a.codes_skew = idx->rows2.as<uint4>();
@@ -1235,7 +1266,7 @@ static int range_batch(const knhip_index* idx, Workspace* ws, const float* d_q, 
         wt.items = ws->items.as<KnItem>();
         wt.nitems = ws->nitems.as<int64_t>();
         wt.scan_bytes = idx->scan_bytes_dev.as<double>();
-        HIP_TRY(launch_build_worktable(ws->keys.as<int64_t>(), nq, nprobe, nlist, qg, idx->d_list_len.as<int64_t>(),
+        HIP_TRY(launch_build_worktable(ws->keys.as<int64_t>(), nq, nprobe, nlist, qg, qg, idx->d_list_len.as<int64_t>(),
                                        idx->code_size, wt, s));
         SqScanArgs a{};
         a.rows = idx->rows.as<uint4>();

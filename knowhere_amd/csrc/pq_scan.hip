@@ -42,7 +42,7 @@
 // Work item = (list, 1 or 2 (query, probe-rank) pairs).  Items are sorted by list and mapped
 // XCD-aware, so a list's codes are read from HBM about once per XCD and then from its L2; the
 // scan is LDS/VALU-issue bound, not HBM bound (DESIGN.md section 4 has the cycle budget).
-#include "common.cuh"
+#include "common.h"
 #include "kernels.h"
 
 #include <cstdlib>

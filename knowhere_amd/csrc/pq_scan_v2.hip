@@ -31,7 +31,7 @@
 //
 // Per-step budget (2 queries, 128 lookups): 1 VOP2 (address) + 2 v_pk_add_f32 + 1 ds_read_b64 (+3 SALU)
 // = ~10 VALU-issue cycles per SIMD and 2 LDS cycles per wave -- both near their limits at 4 waves/SIMD.
-#include "common.cuh"
+#include "common.h"
 #include "kernels.h"
 
 #include <cstdlib>
@@ -40,16 +40,7 @@ namespace knhip {
 
 constexpr int P2_KSUB = 256;
 constexpr int P2_M = 32;
-#ifndef P2_NWAVES
-#define P2_NWAVES 8
-#endif
-constexpr int P2_WAVES = P2_NWAVES;
-// lanes l and l ^ 1 share a stagger phase when P2_PHASE_SHIFT = 1: 16 phases instead of 32, so only the
-// first 15 steps of a window have lanes on two different vectors (EXEC flips + second accumulate), at the
-// price of a 2-way LDS bank conflict on every lookup
-#ifndef P2_PHASE_SHIFT
-#define P2_PHASE_SHIFT 1
-#endif
+constexpr int P2_WAVES = 8;
 constexpr int P2_THREADS = P2_WAVES * KN_WAVE;
 
 typedef float p2_f32x2 __attribute__((ext_vector_type(2)));
@@ -71,7 +62,7 @@ __global__ void pq_stream16_kernel(const uint8_t* __restrict__ codes, const int6
          t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t blk = t / 64;
         const int L = (int)(t % 64);
-        const int lo = (L & 31) >> P2_PHASE_SHIFT;
+        const int lo = pq_stream_phase(L);
         uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int s = 0; s < 8; s++) {
@@ -100,47 +91,42 @@ int64_t pq_stream16_blocks(int64_t len) {
     return (ngroups * 32 + 32) / 8 + 16;
 }
 
-// ---- 8 steps of accumulate, J0 = index of the first step inside the 32-step window ------------------
-// EXEC is restored to all-ones before the block ends; the compiler never sees it changed.
-#ifndef P2_ABLATE
-#define P2_ABLATE 0
-#endif
-#if P2_ABLATE == 1 /* timing experiment only (wrong results): no EXEC flips */
-#define P2_STEP(J, LUT)                                                   \
-    "v_pk_add_f32 %0, %0, " LUT "\n\t"                                    \
+// ---- 8 steps of accumulate ---------------------------------------------------------------------------
+// Split steps (window steps 0..14: lanes of the later phases still finish the previous vector) carry the EXEC
+// mask of the lanes already on the new vector (pq_stream_mask, kernels.h) as an immediate.  EXEC is restored
+// to all-ones before a block ends; the compiler never sees it changed.
+// operands: %0 = new sums, %1 = old sums, %2..%9 = the 8 LUT pairs, %10..%17 = the 8 masks
+#define P2_SPLIT(MK, LUT)                                                 \
+    "s_mov_b32 exec_lo, " MK "\n\t"                                      \
+    "s_mov_b32 exec_hi, " MK "\n\t"                                      \
+    "v_pk_add_f32 %0, %0, " LUT "\n\t"                                   \
+    "s_not_b64 exec, exec\n\t"                                           \
     "v_pk_add_f32 %1, %1, " LUT "\n\t"
-#else
-#define P2_STEP(J, LUT)                                                   \
-    "s_mov_b32 exec_lo, " #J "\n\t"                                       \
-    "s_mov_b32 exec_hi, " #J "\n\t"                                       \
-    "v_pk_add_f32 %0, %0, " LUT "\n\t"                                    \
-    "s_not_b64 exec, exec\n\t"                                            \
-    "v_pk_add_f32 %1, %1, " LUT "\n\t"
-#endif
-
 #define P2_PLAIN(LUT) "v_pk_add_f32 %0, %0, " LUT "\n\t"
 
 template <int Q>
 __device__ __forceinline__ void p2_accum8(p2_f32x2& an, p2_f32x2& ao, const p2_f32x2 (&v)[8]);
 
-#if P2_PHASE_SHIFT == 1
-// 16 phases: lanes with (l & 31) >> 1 <= j are on the new vector at step j -> mask 4^(j+1) - 1; from step 15
-// on every lane is
 template <>
 __device__ __forceinline__ void p2_accum8<0>(p2_f32x2& an, p2_f32x2& ao, const p2_f32x2 (&v)[8]) {
-    asm volatile(P2_STEP(0x3, "%2") P2_STEP(0xf, "%3") P2_STEP(0x3f, "%4") P2_STEP(0xff, "%5")
-                 P2_STEP(0x3ff, "%6") P2_STEP(0xfff, "%7") P2_STEP(0x3fff, "%8") P2_STEP(0xffff, "%9")
+    asm volatile(P2_SPLIT("%10", "%2") P2_SPLIT("%11", "%3") P2_SPLIT("%12", "%4") P2_SPLIT("%13", "%5")
+                 P2_SPLIT("%14", "%6") P2_SPLIT("%15", "%7") P2_SPLIT("%16", "%8") P2_SPLIT("%17", "%9")
                  "s_mov_b64 exec, -1\n\t"
                  : "+v"(an), "+v"(ao)
-                 : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+                 : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]),
+                   "i"(pq_stream_mask(0)), "i"(pq_stream_mask(1)), "i"(pq_stream_mask(2)), "i"(pq_stream_mask(3)),
+                   "i"(pq_stream_mask(4)), "i"(pq_stream_mask(5)), "i"(pq_stream_mask(6)), "i"(pq_stream_mask(7)));
 }
 template <>
 __device__ __forceinline__ void p2_accum8<1>(p2_f32x2& an, p2_f32x2& ao, const p2_f32x2 (&v)[8]) {
-    asm volatile(P2_STEP(0x3ffff, "%2") P2_STEP(0xfffff, "%3") P2_STEP(0x3fffff, "%4") P2_STEP(0xffffff, "%5")
-                 P2_STEP(0x3ffffff, "%6") P2_STEP(0xfffffff, "%7") P2_STEP(0x3fffffff, "%8")
+    static_assert(PQ_STREAM_PHASES == 16, "steps 15.. of a window have every lane on the new vector");
+    asm volatile(P2_SPLIT("%10", "%2") P2_SPLIT("%11", "%3") P2_SPLIT("%12", "%4") P2_SPLIT("%13", "%5")
+                 P2_SPLIT("%14", "%6") P2_SPLIT("%15", "%7") P2_SPLIT("%16", "%8")
                  "s_mov_b64 exec, -1\n\t" P2_PLAIN("%9")
                  : "+v"(an), "+v"(ao)
-                 : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+                 : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]),
+                   "i"(pq_stream_mask(8)), "i"(pq_stream_mask(9)), "i"(pq_stream_mask(10)), "i"(pq_stream_mask(11)),
+                   "i"(pq_stream_mask(12)), "i"(pq_stream_mask(13)), "i"(pq_stream_mask(14)), "i"(0));
 }
 template <>
 __device__ __forceinline__ void p2_accum8<2>(p2_f32x2& an, p2_f32x2& ao, const p2_f32x2 (&v)[8]) {
@@ -153,44 +139,6 @@ template <>
 __device__ __forceinline__ void p2_accum8<3>(p2_f32x2& an, p2_f32x2& ao, const p2_f32x2 (&v)[8]) {
     p2_accum8<2>(an, ao, v);
 }
-#else
-template <>
-__device__ __forceinline__ void p2_accum8<0>(p2_f32x2& an, p2_f32x2& ao, const p2_f32x2 (&v)[8]) {
-    asm volatile(P2_STEP(0x1, "%2") P2_STEP(0x3, "%3") P2_STEP(0x7, "%4") P2_STEP(0xf, "%5")
-                 P2_STEP(0x1f, "%6") P2_STEP(0x3f, "%7") P2_STEP(0x7f, "%8") P2_STEP(0xff, "%9")
-                 "s_mov_b64 exec, -1\n\t"
-                 : "+v"(an), "+v"(ao)
-                 : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
-}
-template <>
-__device__ __forceinline__ void p2_accum8<1>(p2_f32x2& an, p2_f32x2& ao, const p2_f32x2 (&v)[8]) {
-    asm volatile(P2_STEP(0x1ff, "%2") P2_STEP(0x3ff, "%3") P2_STEP(0x7ff, "%4") P2_STEP(0xfff, "%5")
-                 P2_STEP(0x1fff, "%6") P2_STEP(0x3fff, "%7") P2_STEP(0x7fff, "%8") P2_STEP(0xffff, "%9")
-                 "s_mov_b64 exec, -1\n\t"
-                 : "+v"(an), "+v"(ao)
-                 : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
-}
-template <>
-__device__ __forceinline__ void p2_accum8<2>(p2_f32x2& an, p2_f32x2& ao, const p2_f32x2 (&v)[8]) {
-    asm volatile(P2_STEP(0x1ffff, "%2") P2_STEP(0x3ffff, "%3") P2_STEP(0x7ffff, "%4") P2_STEP(0xfffff, "%5")
-                 P2_STEP(0x1fffff, "%6") P2_STEP(0x3fffff, "%7") P2_STEP(0x7fffff, "%8") P2_STEP(0xffffff, "%9")
-                 "s_mov_b64 exec, -1\n\t"
-                 : "+v"(an), "+v"(ao)
-                 : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
-}
-template <>
-__device__ __forceinline__ void p2_accum8<3>(p2_f32x2& an, p2_f32x2& ao, const p2_f32x2 (&v)[8]) {
-    asm volatile(P2_STEP(0x1ffffff, "%2") P2_STEP(0x3ffffff, "%3") P2_STEP(0x7ffffff, "%4")
-                 P2_STEP(0xfffffff, "%5") P2_STEP(0x1fffffff, "%6") P2_STEP(0x3fffffff, "%7")
-                 P2_STEP(0x7fffffff, "%8")
-                 // step 31: every lane is on the new vector
-                 "s_mov_b64 exec, -1\n\t"
-                 "v_pk_add_f32 %0, %0, %9\n\t"
-                 : "+v"(an), "+v"(ao)
-                 : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
-}
-
-#endif
 
 template <bool IS_L2>
 __device__ __forceinline__ float p2_prefilter(float kd, float dis0) {
@@ -264,14 +212,10 @@ __device__ __forceinline__ void p2_process_item(const PqScanArgs& a, unsigned ch
 #pragma unroll
         for (int u = 0; u < NU; u++) {
             const int e4 = tid + u * P2_THREADS;
-#if P2_ABLATE == 4 /* timing experiment only: no table loads */
-            xa[u] = xb[u] = pp[u] = make_float4(1.f, 2.f, 3.f, (float)e4);
-#else
             const bool in = (NSLOT4 % P2_THREADS == 0) || e4 < NSLOT4;
             xa[u] = in ? ta[e4] : make_float4(0.f, 0.f, 0.f, 0.f);
             xb[u] = in ? tb[e4] : make_float4(0.f, 0.f, 0.f, 0.f);
             pp[u] = (pre && in) ? pt[e4] : make_float4(0.f, 0.f, 0.f, 0.f);
-#endif
         }
         float4* l4 = reinterpret_cast<float4*>(lut);
 #pragma unroll
@@ -349,11 +293,7 @@ __device__ __forceinline__ void p2_process_item(const PqScanArgs& a, unsigned ch
     typedef __attribute__((address_space(3))) const p2_f32x2 lds_f2;
     auto lut_read = [&](uint32_t word, int half) -> p2_f32x2 {
         const uint32_t addr = half ? (word >> 16) : (word & 0xffffu);
-#if P2_ABLATE == 2 /* timing experiment only (wrong results): no LDS lookups */
-        return p2_f32x2{__uint_as_float(addr), __uint_as_float(addr + 1)};
-#else
         return *reinterpret_cast<lds_f2*>(addr);
-#endif
     };
     // 8 lookups of one code block (uint4 = 8 x u16 addresses)
     auto issue8 = [&](const uint4 w, p2_f32x2 (&v)[8]) {
@@ -365,11 +305,7 @@ __device__ __forceinline__ void p2_process_item(const PqScanArgs& a, unsigned ch
 
     if (nwin > 0) {
         const uint4* cbase = a.codes_skew + (sblk0 + G0 * 4) * 64 + lane; // 4 blocks of 8 steps per window
-#if P2_ABLATE == 5 /* timing experiment only: every code load hits the same (L1-resident) block */
-        auto load_blk = [&](int64_t b) { return cbase[(b & 3) * 64]; };
-#else
         auto load_blk = [&](int64_t b) { return cbase[b * 64]; };      // past-the-end blocks exist (slack)
-#endif
         p2_f32x2 an = {0.f, 0.f}, ao = {0.f, 0.f};
         // LUT reads run one block (8 steps) ahead of the accumulate that consumes them (two value
         // buffers); the code stream runs TWO WINDOWS ahead of its first use (three register sets of
@@ -434,7 +370,7 @@ __device__ __forceinline__ void p2_process_item(const PqScanArgs& a, unsigned ch
                         }
                     }
                 }
-            } else if (w > 0 && P2_ABLATE != 3) {
+            } else if (w > 0) {
                 // fast path: two compares against the (possibly stale, i.e. looser) prefilter and one
                 // "did a shared threshold move" test; everything else only when one of them fires
                 const unsigned long long vmask = (G0 + w - 1 == last_group) ? tail_mask : ~0ull;
@@ -568,7 +504,7 @@ __device__ __forceinline__ void p2_process_item(const PqScanArgs& a, unsigned ch
 
 // ---- one workgroup per work item (grid = item bound), XCD-aware block -> item mapping ---------------------
 template <bool IS_L2, int R, bool DUMP>
-__global__ __launch_bounds__(P2_THREADS, (P2_NWAVES >= 10 ? 5 : P2_NWAVES >= 8 ? 4 : 2)) void pq_scan_v2_kernel(PqScanArgs a) {
+__global__ __launch_bounds__(P2_THREADS, 4) void pq_scan_v2_kernel(PqScanArgs a) {
     constexpr int QG = 2;
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = lane_id();
@@ -602,74 +538,6 @@ __global__ __launch_bounds__(P2_THREADS, (P2_NWAVES >= 10 ? 5 : P2_NWAVES >= 8 ?
                                     dis0);
 }
 
-// ---- PERSISTENT variant (experimental, KNHIP_PERSISTENT=1): the grid is the number of co-resident workgroups;
-// workgroup b walks the items (b % 8) * per + (b / 8), + gridDim / 8, ... of "its" XCD's contiguous eighth, reading
-// one flat 64-byte record per item (p2_prepare_kernel) instead of the item -> pair -> list-metadata chain.
-__global__ void p2_prepare_kernel(PqScanArgs a, int64_t nrec) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nrec) {
-        return;
-    }
-    P2Rec rec{};
-    const int64_t item_lo = a.item_lo ? *a.item_lo : 0;
-    const int64_t nitems = *a.item_hi - item_lo;
-    if (r < nitems) {
-        const KnItem it = a.items[item_lo + r];
-        const int npair = it.npair < 2 ? it.npair : 2;
-        rec.list = it.list;
-        rec.npair = npair;
-        rec.len = a.list_len[it.list];
-        rec.sblk0 = a.list_sblk_off[it.list];
-        rec.row_off = a.list_row_off[it.list];
-        for (int j = 0; j < 2; j++) {
-            const KnPair p = a.pairs[it.pair0 + (j < npair ? j : npair - 1)];
-            rec.q[j] = p.q;
-            rec.slot[j] = p.slot;
-            rec.dis0[j] = (a.lut_mode == PQ_LUT_RESIDUAL) ? 0.f : a.coarse_dis[(int64_t)p.q * a.nslot + p.slot];
-        }
-    }
-    a.recs[r] = rec;
-}
-
-template <bool IS_L2, int R>
-__global__ __launch_bounds__(P2_THREADS, 4) void pq_scan_v2_persistent_kernel(PqScanArgs a) {
-    constexpr int QG = 2;
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int lane = lane_id();
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / KN_WAVE);
-    const int64_t item_lo = a.item_lo ? *a.item_lo : 0;
-    const int64_t nitems = *a.item_hi - item_lo;
-    const int64_t per = (nitems + 7) / 8;
-    const int64_t xcd = blockIdx.x % 8, wg_in_xcd = blockIdx.x / 8, wgs_per_xcd = gridDim.x / 8;
-    for (int64_t n = 0;; n++) {
-        const int64_t local = n * wgs_per_xcd + wg_in_xcd;
-        const int64_t idx = xcd * per + local;
-        if (local >= per || idx >= nitems) {
-            break;
-        }
-        // opaque per iteration: nothing derived from the lane / thread id is hoisted out of the item loop (the
-        // hoisted addresses cost 26 VGPRs and a spill otherwise)
-        int lane_i = lane, tid_i = (int)threadIdx.x;
-        asm volatile("" : "+v"(lane_i), "+v"(tid_i));
-        // every field is wave-uniform; say so (readfirstlane), or lengths and offsets live in VGPRs and the window
-        // loop control turns into EXEC-masked vector code
-        const P2Rec rec = a.recs[idx];
-        auto sc32 = [](int32_t v) { return __builtin_amdgcn_readfirstlane(v); };
-        auto sc64 = [](int64_t v) {
-            const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(uint32_t)v);
-            const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(uint32_t)((uint64_t)v >> 32));
-            return (int64_t)(((uint64_t)hi << 32) | lo);
-        };
-        auto scf = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
-        const int32_t q_of[QG] = {sc32(rec.q[0]), sc32(rec.q[1])};
-        const int32_t slot_of[QG] = {sc32(rec.slot[0]), sc32(rec.slot[1])};
-        const float dis0[QG] = {scf(rec.dis0[0]), scf(rec.dis0[1])};
-        p2_process_item<IS_L2, R, false>(a, smem, lane_i, wave, tid_i, sc32(rec.npair), sc32(rec.list), sc64(rec.len),
-                                         sc64(rec.sblk0), sc64(rec.row_off), q_of, slot_of, dis0);
-        __syncthreads(); // the merge scratch aliases the next item's LUT
-    }
-}
-
 template <bool IS_L2, int R, bool DUMP>
 static hipError_t launch_v2_r(const PqScanArgs& a, int64_t grid, hipStream_t s) {
     const size_t lut_bytes = (size_t)P2_KSUB * 256;
@@ -680,19 +548,6 @@ static hipError_t launch_v2_r(const PqScanArgs& a, int64_t grid, hipStream_t s) 
                                        (int)sm);
     if (e != hipSuccess) {
         return e;
-    }
-    if (!DUMP && a.recs != nullptr) {
-        auto pk = pq_scan_v2_persistent_kernel<IS_L2, R>;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-        if (e != hipSuccess) {
-            return e;
-        }
-        hipLaunchKernelGGL(p2_prepare_kernel, dim3((unsigned)((grid + 255) / 256)), dim3(256), 0, s, a, grid);
-        // a few workgroups per resident slot (2 slots per CU): semi-persistent, independent of how the runtime
-        // counts compute units, still ~300 items per workgroup at the contract shape
-        const int64_t wgs = std::max<int64_t>(8, std::min<int64_t>(2048, ((grid + 7) / 8) * 8));
-        hipLaunchKernelGGL(pk, dim3((unsigned)wgs), dim3(P2_THREADS), sm, s, a);
-        return hipGetLastError();
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(P2_THREADS), sm, s, a);
     return hipGetLastError();

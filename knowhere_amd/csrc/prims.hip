@@ -15,7 +15,7 @@
 // Row-major y is the ABI's layout (as in the reference); each wave stages a 64-row x 64-column
 // tile through LDS with coalesced global loads, then lane r walks row r sequentially (row pitch
 // 65 words: conflict-free column access).
-#include "common.cuh"
+#include "common.h"
 #include "kernels.h"
 
 namespace knhip {

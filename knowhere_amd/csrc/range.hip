@@ -12,7 +12,7 @@
 //   range_count  : hits per (query, probe rank)                      one workgroup per pair
 //   range_plan   : early-stop cut + running offsets per query       one thread per query (nprobe steps)
 //   range_emit   : ordered compaction of the surviving lists         one workgroup per pair
-#include "common.cuh"
+#include "common.h"
 #include "kernels.h"
 
 namespace knhip {

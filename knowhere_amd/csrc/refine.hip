@@ -9,7 +9,7 @@
 // are bit-equal to the CPU refine.  288 GB of HBM3E holds the raw vectors of a 100M x 128 index
 // (51 GB) next to its codes, so refine is a ~0.5 GB random gather per 10k-query batch: noise
 // next to the scan, and what lifts PQ32 recall@10 past 0.95.
-#include "common.cuh"
+#include "common.h"
 #include "kernels.h"
 
 namespace knhip {

@@ -18,7 +18,7 @@
 // 16c..16c+15 of row 64b+r, so a lane reads 16 dims of its own row per 16-byte coalesced load.
 // Work item = (list, up to QG queries that probe it): the codes are decoded once for the QG
 // queries.  Algorithmic bytes per item = rows * d * npair.
-#include "common.cuh"
+#include "common.h"
 #include "kernels.h"
 
 namespace knhip {

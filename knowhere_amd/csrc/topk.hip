@@ -9,7 +9,7 @@
 //                    thirdparty/faiss/faiss/utils/distances.cpp:834-875).
 // Both return the canonical order of heap_reorder (L2: dist asc, id asc; IP: dist desc, id desc)
 // and pad missing results with id -1 / the neutral distance (utils/Heap.h:338-341).
-#include "common.cuh"
+#include "common.h"
 #include "kernels.h"
 
 namespace knhip {

@@ -10,7 +10,7 @@
 // query's partial-result row, so the final merge is independent of this regrouping.
 //
 // Everything stays on the device: no host synchronisation between coarse search and scan.
-#include "common.cuh"
+#include "common.h"
 #include "kernels.h"
 
 namespace knhip {
@@ -31,7 +31,7 @@ __global__ void wt_zero_kernel(int32_t* list_count, int32_t* list_cursor, int64_
 // Virtual list id: the rank-0 probe of every query (its closest list) goes to virtual lists
 // [0, nlist), all other probes to [nlist, 2*nlist).  Items are emitted in virtual-list order, so
 // the scans most likely to contain a query's true neighbours are dispatched first and publish a
-// tight per-query threshold (common.cuh gthr_*) before the bulk of the probes run.  Pure
+// tight per-query threshold (common.h gthr_*) before the bulk of the probes run.  Pure
 // scheduling: results do not depend on it.
 __device__ __forceinline__ int64_t wt_vlist(int64_t key, int64_t slot, int64_t nlist) {
     return key + (slot != 0 ? nlist : 0);
@@ -55,7 +55,7 @@ __global__ void wt_count_kernel(const int64_t* __restrict__ keys, int64_t npairs
 constexpr int WT_SCAN_THREADS = 1024;
 __global__ __launch_bounds__(WT_SCAN_THREADS) void wt_scan_kernel(
         const int32_t* __restrict__ list_count, const int64_t* __restrict__ list_len, int64_t nlist,
-        int64_t nreal, int qg, int64_t code_size, int64_t* list_pair_off, int64_t* list_item_off,
+        int64_t nreal, int qg0, int qg1, int64_t code_size, int64_t* list_pair_off, int64_t* list_item_off,
         int64_t* nitems, double* scan_bytes) {
     __shared__ int64_t s_pairs[WT_SCAN_THREADS];
     __shared__ int64_t s_items[WT_SCAN_THREADS];
@@ -69,6 +69,7 @@ __global__ __launch_bounds__(WT_SCAN_THREADS) void wt_scan_kernel(
     double nb = 0.0, nb0 = 0.0;
     for (int64_t l = l0; l < l1; l++) {
         const int64_t c = list_count[l];
+        const int qg = l < nreal ? qg0 : qg1;
         np += c;
         ni += (c + qg - 1) / qg;
         const double b = (double)c * (double)list_len[l % nreal] * (double)code_size;
@@ -101,6 +102,7 @@ __global__ __launch_bounds__(WT_SCAN_THREADS) void wt_scan_kernel(
     int64_t ii = s_items[tid] - ni;
     for (int64_t l = l0; l < l1; l++) {
         const int64_t c = list_count[l];
+        const int qg = l < nreal ? qg0 : qg1;
         list_pair_off[l] = pp;
         list_item_off[l] = ii;
         pp += c;
@@ -145,11 +147,12 @@ __global__ void wt_scatter_kernel(const int64_t* __restrict__ keys, int64_t npai
 __global__ void wt_items_kernel(const int32_t* __restrict__ list_count,
                                 const int64_t* __restrict__ list_pair_off,
                                 const int64_t* __restrict__ list_item_off, int64_t nlist,
-                                int64_t nreal, int qg, KnItem* items) {
+                                int64_t nreal, int qg0, int qg1, KnItem* items) {
     const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= nlist) {
         return;
     }
+    const int qg = l < nreal ? qg0 : qg1;
     const int64_t c = list_count[l];
     const int64_t p0 = list_pair_off[l];
     int64_t it = list_item_off[l];
@@ -162,7 +165,9 @@ __global__ void wt_items_kernel(const int32_t* __restrict__ list_count,
     }
 }
 
-hipError_t launch_build_worktable(const int64_t* keys, int64_t nq, int nprobe, int64_t nlist, int qg,
+// qg0: queries per item of the rank-0 virtual lists, qg1: of all other probes (the two phases of the IVF-PQ
+// search may run different kernels)
+hipError_t launch_build_worktable(const int64_t* keys, int64_t nq, int nprobe, int64_t nlist, int qg0, int qg1,
                                   const int64_t* list_len, int64_t code_size, const WorkTable& wt,
                                   hipStream_t s) {
     const int64_t npairs = nq * nprobe;
@@ -176,14 +181,14 @@ hipError_t launch_build_worktable(const int64_t* keys, int64_t nq, int nprobe, i
                            wt.list_count);
     }
     hipLaunchKernelGGL(wt_scan_kernel, dim3(1), dim3(WT_SCAN_THREADS), 0, s, wt.list_count, list_len,
-                       nvl, nlist, qg, code_size, wt.list_pair_off, wt.list_item_off, wt.nitems,
+                       nvl, nlist, qg0, qg1, code_size, wt.list_pair_off, wt.list_item_off, wt.nitems,
                        wt.scan_bytes);
     if (npairs > 0) {
         hipLaunchKernelGGL(wt_scatter_kernel, dim3(gp), dim3(256), 0, s, keys, npairs, nprobe, nlist, list_len,
                            wt.list_pair_off, wt.list_cursor, wt.pairs, wt.empty_mark, wt.k);
     }
     hipLaunchKernelGGL(wt_items_kernel, dim3(gl), dim3(256), 0, s, wt.list_count, wt.list_pair_off,
-                       wt.list_item_off, nvl, nlist, qg, wt.items);
+                       wt.list_item_off, nvl, nlist, qg0, qg1, wt.items);
     return hipGetLastError();
 }
 

@@ -409,15 +409,62 @@ def test_search_preassigned_equals_search(torch_cuda, port, kind, M):
     assert torch.equal(I1, I3)
 
 
-def test_persistent_scan_variant_matches(torch_cuda, port, monkeypatch):
-    """KNHIP_PERSISTENT=1 (experimental persistent-workgroup form of the bulk IVF-PQ scan) returns
-    exactly what the default one-workgroup-per-item launch returns"""
-    nb, nq, d, nlist, nprobe, k = 60000, 200, 128, 128, 32, 100
+@pytest.mark.parametrize("metric", [ob.L2, ob.IP])
+def test_q4_scan_matches_v2_and_oracle(torch_cuda, port, monkeypatch, metric):
+    """pq_scan_q4 (persistent workgroups, 4 queries per item, LUT computed in-kernel; d = 128, m = 32) returns
+    exactly what the oracle and the 2-query kernel return: k = 10 (bulk launch only), k = 100 (rank-0 dump +
+    select by pq_scan_v2, bulk by pq_scan_q4), bitset, ragged item tails (nq not a multiple of 4)"""
+    nb, nq, d, nlist, nprobe = 60000, 203, 128, 128, 32
     xb, xq = gen_data(nb, d, 42), gen_data(nq, d, 44)
-    ix = finish_ivfpq(port, ob.make_index(port, ob.IVF_PQ, ob.L2, xb, nlist=nlist, M=32, nbits=8))
-    D0, I0 = _gpu(ix).search(xq, k, nprobe)
-    monkeypatch.setenv("KNHIP_PERSISTENT", "1")  # read when the lists are attached
-    D1, I1 = _gpu(ix).search(xq, k, nprobe)
-    assert np.array_equal(I0, I1) and np.array_equal(D0.view(np.uint32), D1.view(np.uint32))
-    Do, Io = port.search(ix, xq, k, nprobe)
-    assert_parity(Do, Io, D1, I1, ob.L2, "persistent variant vs oracle")
+    ix = finish_ivfpq(port, ob.make_index(port, ob.IVF_PQ, metric, xb, nlist=nlist, M=32, nbits=8))
+    bs = _bitset(nb, 0.4, 1)
+    monkeypatch.setenv("KNHIP_Q4", "0")  # read when the lists are attached
+    g2 = _gpu(ix)
+    monkeypatch.setenv("KNHIP_Q4", "1")
+    g4 = _gpu(ix)
+    for k, np_, use_bs in ((10, nprobe, False), (100, nprobe, False), (10, 1, False), (64, 128, False), (10, nprobe, True),
+                           (100, 8, True)):
+        b, nbits = (bs, nb) if use_bs else (None, 0)
+        Do, Io = port.search(ix, xq, k, np_, b, nbits)
+        D2, I2 = g2.search(xq, k, np_, b, nbits)
+        D4, I4 = g4.search(xq, k, np_, b, nbits)
+        assert_parity(Do, Io, D4, I4, metric, f"q4 vs oracle k={k} nprobe={np_} bitset={use_bs}")
+        assert np.array_equal(I2, I4) and np.array_equal(D2.view(np.uint32), D4.view(np.uint32))
+    # few queries: most items hold fewer than 4 pairs
+    for nq_small in (1, 3, 5):
+        Do, Io = port.search(ix, xq[:nq_small], 10, nprobe)
+        D4, I4 = g4.search(xq[:nq_small], 10, nprobe)
+        assert_parity(Do, Io, D4, I4, metric, f"q4 nq={nq_small}")
+    g2.close()
+    g4.close()
+
+
+def test_q4_scan_residual_tables_and_ragged_lists(torch_cuda, port, monkeypatch):
+    """pq_scan_q4 with per-list residual tables (precomputed table over the limit) and with empty / tiny lists"""
+    monkeypatch.setenv("KNHIP_Q4", "1")
+    nb, d = 30000, 128
+    xb, xq = gen_data(nb, d, 42), gen_data(50, d, 44)
+    ix = ob.make_index(port, ob.IVF_PQ, ob.L2, xb, nlist=64, M=32)
+    ix.use_precomputed_table = 0
+    ix.precomputed_table = None
+    g = _gpu(ix, precomputed_table_max_bytes=1024)
+    assert g.uses_precomputed_table == 0
+    for k, nprobe in ((10, 8), (100, 64)):
+        Do, Io = port.search(ix, xq, k, nprobe)
+        D, I = g.search(xq, k, nprobe)
+        assert_parity(Do, Io, D, I, ob.L2, "q4 residual tables")
+    g.close()
+    xb = gen_data(700, d, 42)
+    xb[100:140] = xb[5]  # exact duplicates: distance ties
+    ids = np.random.default_rng(5).permutation(700).astype(np.int64) * 3 + 1
+    ix = finish_ivfpq(port, ob.make_index(port, ob.IVF_PQ, ob.L2, xb, nlist=17, M=32, ids=ids))
+    # lists emptied by hand: work items must skip them
+    for l in (0, 3):
+        ix.list_codes[l] = ix.list_codes[l][:0]
+        ix.list_ids[l] = ix.list_ids[l][:0]
+    g = _gpu(ix)
+    for k, nprobe in ((10, 17), (128, 17), (3, 1)):
+        Do, Io = port.search(ix, xq, k, nprobe)
+        D, I = g.search(xq, k, nprobe)
+        assert_parity(Do, Io, D, I, ob.L2, f"q4 ragged k={k} nprobe={nprobe}")
+    g.close()
