@@ -227,18 +227,23 @@ __device__ __forceinline__ float gthr_load(const float* p) {
 }
 template <bool IS_L2>
 __device__ __forceinline__ void gthr_publish(float* p, float v) {
-    // called by one lane; CAS loop on the bit pattern (rare: only when a local list tightens)
+    // called by one lane.  min (L2) / max (IP) of floats as ONE fire-and-forget integer atomic -- no value comes
+    // back, the wave never waits for the round trip to the L2: for v >= 0 the bit pattern orders like a signed
+    // int, for v < 0 it orders inversely as an unsigned int.  (-0.0f takes the signed branch as INT_MIN: the bound
+    // is then simply not tightened, which is always valid.)  NaN never reaches here.
+    int* ip = reinterpret_cast<int*>(p);
     unsigned int* up = reinterpret_cast<unsigned int*>(p);
-    unsigned int old = __hip_atomic_load(up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (true) {
-        const float cur = __uint_as_float(old);
-        if (IS_L2 ? !(v < cur) : !(v > cur)) {
-            return;
+    if (IS_L2) {
+        if (v >= 0.f) {
+            (void)__hip_atomic_fetch_min(ip, __float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            (void)__hip_atomic_fetch_max(up, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        const unsigned int want = __float_as_uint(v);
-        if (__hip_atomic_compare_exchange_strong(up, &old, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT)) {
-            return;
+    } else {
+        if (v >= 0.f) {
+            (void)__hip_atomic_fetch_max(ip, __float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            (void)__hip_atomic_fetch_min(up, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }

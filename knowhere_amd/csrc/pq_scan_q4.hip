@@ -114,28 +114,23 @@ __global__ void p4_prepare_kernel(PqScanArgs a, int64_t nrec) {
     "v_pk_add_f32 %1, %1, " Y "\n\t"
 #define P4_VALS(v)                                                                                         \
     "v"(__builtin_shufflevector(v[0], v[0], 0, 1)), "v"(__builtin_shufflevector(v[0], v[0], 2, 3)),         \
-    "v"(__builtin_shufflevector(v[1], v[1], 0, 1)), "v"(__builtin_shufflevector(v[1], v[1], 2, 3)),         \
-    "v"(__builtin_shufflevector(v[2], v[2], 0, 1)), "v"(__builtin_shufflevector(v[2], v[2], 2, 3)),         \
-    "v"(__builtin_shufflevector(v[3], v[3], 0, 1)), "v"(__builtin_shufflevector(v[3], v[3], 2, 3))
+    "v"(__builtin_shufflevector(v[1], v[1], 0, 1)), "v"(__builtin_shufflevector(v[1], v[1], 2, 3))
 
-// B = index of the 4-step block inside the 32-step window
-template <int B>
-__device__ __forceinline__ void p4_accum4(p4_f32x2& n01, p4_f32x2& n23, p4_f32x2& o01, p4_f32x2& o23,
-                                          const p4_f32x4 (&v)[4]) {
+// U = index of the 2-step unit inside the 32-step window (steps 2U, 2U + 1)
+template <int U>
+__device__ __forceinline__ void p4_accum2(p4_f32x2& n01, p4_f32x2& n23, p4_f32x2& o01, p4_f32x2& o23,
+                                          const p4_f32x4 (&v)[2]) {
     static_assert(PQ_STREAM_PHASES == 16, "window steps 15..31 have every lane on the new vector");
-    if constexpr (B < 3) {
-        asm volatile(P4_SPLIT("%12", "%4", "%5") P4_SPLIT("%13", "%6", "%7") P4_SPLIT("%14", "%8", "%9")
-                     P4_SPLIT("%15", "%10", "%11") "s_mov_b64 exec, -1\n\t"
+    if constexpr (U < 7) {
+        asm volatile(P4_SPLIT("%8", "%4", "%5") P4_SPLIT("%9", "%6", "%7") "s_mov_b64 exec, -1\n\t"
                      : "+v"(n01), "+v"(n23), "+v"(o01), "+v"(o23)
-                     : P4_VALS(v), "i"(pq_stream_mask(4 * B)), "i"(pq_stream_mask(4 * B + 1)),
-                       "i"(pq_stream_mask(4 * B + 2)), "i"(pq_stream_mask(4 * B + 3)));
-    } else if constexpr (B == 3) {
-        asm volatile(P4_SPLIT("%12", "%4", "%5") P4_SPLIT("%13", "%6", "%7") P4_SPLIT("%14", "%8", "%9")
-                     "s_mov_b64 exec, -1\n\t" P4_PLAIN("%10", "%11")
+                     : P4_VALS(v), "i"(pq_stream_mask(2 * U)), "i"(pq_stream_mask(2 * U + 1)));
+    } else if constexpr (U == 7) {
+        asm volatile(P4_SPLIT("%8", "%4", "%5") "s_mov_b64 exec, -1\n\t" P4_PLAIN("%6", "%7")
                      : "+v"(n01), "+v"(n23), "+v"(o01), "+v"(o23)
-                     : P4_VALS(v), "i"(pq_stream_mask(12)), "i"(pq_stream_mask(13)), "i"(pq_stream_mask(14)), "i"(0));
+                     : P4_VALS(v), "i"(pq_stream_mask(14)));
     } else {
-        asm volatile(P4_PLAIN("%4", "%5") P4_PLAIN("%6", "%7") P4_PLAIN("%8", "%9") P4_PLAIN("%10", "%11")
+        asm volatile(P4_PLAIN("%4", "%5") P4_PLAIN("%6", "%7")
                      : "+v"(n01), "+v"(n23), "+v"(o01), "+v"(o23)
                      : P4_VALS(v));
     }
@@ -148,6 +143,19 @@ __device__ __forceinline__ float p4_prefilter(float kd, float dis0) {
 }
 
 __device__ __forceinline__ int p4_sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// s_setprio takes an immediate: wave-uniform switch
+__device__ __forceinline__ void p4_setprio(int p) {
+    if (p == 0) {
+        __builtin_amdgcn_s_setprio(0);
+    } else if (p == 1) {
+        __builtin_amdgcn_s_setprio(1);
+    } else if (p == 2) {
+        __builtin_amdgcn_s_setprio(2);
+    } else {
+        __builtin_amdgcn_s_setprio(3);
+    }
+}
 
 // token (low / high half of a code word) -> LDS byte address of the 16-byte LUT entry: one SDWA shift
 __device__ __forceinline__ uint32_t p4_addr_lo(uint32_t w, uint32_t one) {
@@ -165,33 +173,95 @@ __device__ __forceinline__ uint32_t p4_addr_hi(uint32_t w, uint32_t one) {
     return a;
 }
 
+// ---- LUT[c][m][query] of one work item ------------------------------------------------------------------------
+// thread (wave, lane): m = lane & 31, c = 16 * wave + 2 * u + (lane >> 5), u = 0..7: every global load is a
+// contiguous 1 KiB (codebook) / 256 B (table row) per wave, every LDS store a contiguous 1 KiB.  All 20 loads are
+// requested in two batches; the arithmetic is the reference's: inner product / squared distance accumulated
+// in dimension order from 0 with one rounding per operation (fvec_inner_product / fvec_L2sqr scalar forms,
+// src/simd/distances_ref.cc:21-37), then LUT = precomp + (-2) * ip (fvec_madd, IVFPQ_QueryTables.cpp:140-145).
+template <int MODE>
+__device__ __forceinline__ void p4_build_lut(const PqScanArgs& a, unsigned char* smem, const int wave, const int lane_i,
+                                             const int64_t list, const int32_t (&q_of)[P4_Q]) {
+    const int m = lane_i & 31;
+    const int c0 = 16 * wave + (lane_i >> 5);
+    const float4* cbp = a.cb_t + c0 * P4_M + m;
+    float4* l4 = reinterpret_cast<float4*>(smem) + c0 * P4_M + m;
+    float4 x[P4_Q];
+#pragma unroll
+    for (int j = 0; j < P4_Q; j++) {
+        x[j] = *reinterpret_cast<const float4*>(a.queries + (int64_t)q_of[j] * a.d + m * P4_DSUB);
+    }
+    if (MODE == PQ_LUT_RESIDUAL) { // residual tables: ||(q - c_list)_m - cb[m][c]||^2
+        const float4 cl = *reinterpret_cast<const float4*>(a.centroids + list * a.d + m * P4_DSUB);
+#pragma unroll
+        for (int j = 0; j < P4_Q; j++) {
+            x[j] = make_float4(fsub_x(x[j].x, cl.x), fsub_x(x[j].y, cl.y), fsub_x(x[j].z, cl.z), fsub_x(x[j].w, cl.w));
+        }
+    }
+    const float* pt = a.precomp_t + list * (int64_t)(P4_KSUB * P4_M) + c0 * P4_M + m;
+    // two passes of 4 entries keep the register peak of this phase below the scan loop's
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        float4 y[4];
+        float p[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            y[u] = cbp[(h * 4 + u) * 2 * P4_M];
+            p[u] = MODE == PQ_LUT_PRECOMP ? pt[(h * 4 + u) * 2 * P4_M] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            float o[P4_Q];
+#pragma unroll
+            for (int j = 0; j < P4_Q; j++) {
+                float t;
+                if (MODE == PQ_LUT_RESIDUAL) {
+                    t = l2_step(0.f, x[j].x, y[u].x);
+                    t = l2_step(t, x[j].y, y[u].y);
+                    t = l2_step(t, x[j].z, y[u].z);
+                    t = l2_step(t, x[j].w, y[u].w);
+                } else {
+                    t = ip_step(0.f, x[j].x, y[u].x);
+                    t = ip_step(t, x[j].y, y[u].y);
+                    t = ip_step(t, x[j].z, y[u].z);
+                    t = ip_step(t, x[j].w, y[u].w);
+                    if (MODE == PQ_LUT_PRECOMP) {
+                        t = fadd_x(p[u], fmul_x(-2.0f, t));
+                    }
+                }
+                o[j] = t;
+            }
+            l4[(h * 4 + u) * 2 * P4_M] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
 // Phase timers (profiling build only: make prof -> libknhip_prof.so, never shipped): wave 0 of every workgroup
 // sums the shader cycles it spends per phase of an item; printed per launch by launch_q4_r.
 #ifdef KNHIP_PHASE_TIMERS
 #define P4_T(i)                                                         \
     do {                                                                \
         const unsigned long long t_ = __builtin_amdgcn_s_memtime();     \
-        if (wave == P4_TIMER_WAVE) {                                    \
-            tacc[i] += t_ - tlast;                                      \
-        }                                                               \
+        tacc[i] += t_ - tlast;                                          \
         tlast = t_;                                                     \
     } while (0)
-#ifndef P4_TIMER_WAVE
-#define P4_TIMER_WAVE 0
-#endif
-__device__ unsigned long long g_p4_prof[16];
+#define P4_COUNT(i, n) tacc[i] += (unsigned long long)(n)
+__device__ unsigned long long g_p4_prof[16 * 10];
 #else
 #define P4_T(i)
+#define P4_COUNT(i, n)
 #endif
 
 template <bool IS_L2, int R>
 __global__ __launch_bounds__(P4_THREADS) void pq_scan_q4_kernel(PqScanArgs a) {
     constexpr int QG = P4_Q;
 #ifdef KNHIP_PHASE_TIMERS
-    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = __builtin_amdgcn_s_memtime();
 #endif
     extern __shared__ __align__(16) unsigned char smem[];
+    // mailbox behind the LUT: [0] = index of the next item, [1] = "some wave holds a candidate" flag of the
+    // current item, [8..32) = the next item's 96-byte record
     int* ctl = reinterpret_cast<int*>(smem + P4_LUT_BYTES);
     const int lane = lane_id();
     const int wave = p4_sgpr((int)(threadIdx.x / KN_WAVE)); // wave-uniform: scalar loop control
@@ -224,7 +294,6 @@ __global__ __launch_bounds__(P4_THREADS) void pq_scan_q4_kernel(PqScanArgs a) {
         }
         return -1;
     };
-    // mailbox behind the LUT: [0] = index of the next item, [8..32) = its 96-byte record
     constexpr int REC_WORDS = (int)(sizeof(P4Rec) / 4);
     if (wave == 0) {
         int first = -1;
@@ -237,11 +306,13 @@ __global__ __launch_bounds__(P4_THREADS) void pq_scan_q4_kernel(PqScanArgs a) {
         }
         if (lane == 0) {
             ctl[0] = first;
+            ctl[1] = 0;
         }
     }
     __syncthreads();
     int cur = p4_sgpr(ctl[0]);
     const uint32_t one = 1u;
+    const int k = a.k;
 
     while (cur >= 0) {
         P4_T(7);
@@ -271,109 +342,99 @@ __global__ __launch_bounds__(P4_THREADS) void pq_scan_q4_kernel(PqScanArgs a) {
         const int64_t sblk0 = (int64_t)(((uint64_t)rl(17) << 32) | rl(16));
         const int64_t row_off = (int64_t)(((uint64_t)rl(19) << 32) | rl(18));
 
-        // candidate histogram of this item's queries: wave j refreshes query j's bound from it; the row is
-        // requested here so that its latency hides behind the LUT build
-        uint32_t h_lo[QG], h_shift[QG];
+        // ---- everything the scan will wait for is requested NOW, so that its latency hides behind the LUT build:
+        // the shared thresholds, this wave's first code blocks, the candidate histogram row -----------------------
+        float gt[QG];
 #pragma unroll
         for (int j = 0; j < QG; j++) {
-            h_lo[j] = 0;
-            h_shift[j] = KN_HIST_OFF;
-            if (a.ghist != nullptr) {
-                const uint2 mt = a.gmeta[q_of[j]];
-                h_lo[j] = mt.x;
-                h_shift[j] = mt.y;
-            }
+            gt[j] = gthr_load<IS_L2>(a.gthr + q_of[j]);
         }
+        // this wave's groups of 64 vectors: as even as possible (the slowest wave sets the item's time)
+        const int ngroups = (int)((len + 63) / 64);
+        const int gbase = ngroups / P4_WAVES, grem = ngroups % P4_WAVES;
+        const int G0 = wave * gbase + min(wave, grem);
+        const int G1 = G0 + gbase + (wave < grem ? 1 : 0);
+        const int nwin = G1 > G0 ? (G1 - G0 + 1) : 0; // one extra (half) window drains the stagger
+        const uint4* cbase = a.codes_skew + (sblk0 + (int64_t)G0 * 4) * 64 + lane_i; // 4 blocks per window
+        auto load_blk = [&](int b) { return cbase[(int64_t)b * 64]; };                // past-the-end blocks exist (slack)
+        // candidate histogram of this item's queries: wave j refreshes query j's bound from it
         int32_t h_q = q_of[0];
-        uint32_t h_lo_w = h_lo[0], h_shift_w = h_shift[0];
 #pragma unroll
         for (int j = 1; j < QG; j++) {
-            if (wave == j) {
-                h_q = q_of[j];
-                h_lo_w = h_lo[j];
-                h_shift_w = h_shift[j];
-            }
+            h_q = wave == j ? q_of[j] : h_q;
         }
-        const bool h_mine = wave < npair && h_shift_w != KN_HIST_OFF;
-        uint32_t h_cnt = 0;
-        if (h_mine) {
+        uint32_t h_lo_w = 0, h_shift_w = KN_HIST_OFF, h_cnt = 0;
+        const bool h_on = a.ghist != nullptr;
+        if (h_on && wave < npair) {
+            const uint2 mt = a.gmeta[h_q];
+            h_lo_w = mt.x;
+            h_shift_w = mt.y;
             h_cnt = __hip_atomic_load(a.ghist + (int64_t)h_q * KN_HIST_BINS + lane_i, __ATOMIC_RELAXED,
                                       __HIP_MEMORY_SCOPE_AGENT);
         }
 
         // ---- LUT[c][m][query] built in LDS from the codebook (+ the list's precomputed-table row) ---------------
-        // thread (wave, lane): m = lane & 31, c = 16 * wave + 2 * u + (lane >> 5), u = 0..7: every global load is
-        // a contiguous 1 KiB (codebook) / 256 B (table row) per wave, every LDS store a contiguous 1 KiB
-        {
-            const int m = lane_i & 31;
-            const int c0 = 16 * wave + (lane_i >> 5);
-            const float4* cbp = a.cb_t + c0 * P4_M + m;
-            float4 y[8];
+        if (a.lut_mode == PQ_LUT_PRECOMP) {
+            p4_build_lut<PQ_LUT_PRECOMP>(a, smem, wave, lane_i, list, q_of);
+        } else if (a.lut_mode == PQ_LUT_IP) {
+            p4_build_lut<PQ_LUT_IP>(a, smem, wave, lane_i, list, q_of);
+        } else {
+            p4_build_lut<PQ_LUT_RESIDUAL>(a, smem, wave, lane_i, list, q_of);
+        }
+
+        // this wave's first code blocks: requested before the top-k / histogram set-up and the LUT barrier
+        uint4 U0 = make_uint4(0, 0, 0, 0), U1 = U0, U2 = U0, U3 = U0;
+        if (nwin > 0) {
+            U0 = load_blk(0);
+            U1 = load_blk(1);
+            U2 = load_blk(2);
+            U3 = load_blk(3);
+        }
+        WaveTopK<IS_L2, R, int32_t> top[QG];
+        float kd[QG], pre[QG];
+        int32_t ki[QG];
+        int ncand[QG];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                y[u] = cbp[u * 2 * P4_M];
+        for (int j = 0; j < QG; j++) {
+            ncand[j] = 0;
+            top[j].init(k);
+            kd[j] = worst_dist<IS_L2>();
+            ki[j] = -1;
+        }
+        if (h_shift_w != KN_HIST_OFF) {
+            // inclusive prefix sum of the 64 bins across the wave; first bin where k vectors are reached
+            uint32_t cum = h_cnt;
+#pragma unroll
+            for (int dlt = 1; dlt < KN_WAVE; dlt <<= 1) {
+                const uint32_t up = __shfl_up(cum, dlt, KN_WAVE);
+                cum += lane_i >= dlt ? up : 0u;
             }
-            float4 x[QG];
+            const unsigned long long reach = __ballot(cum >= (uint32_t)k);
+            const int b = reach ? __ffsll((long long)reach) - 1 : KN_HIST_BINS;
+            if (b < KN_HIST_BINS - 1) { // (the last bin also collects everything beyond the range)
+                const unsigned long long edge =
+                        (unsigned long long)h_lo_w + (((unsigned long long)b + 1ull) << h_shift_w) - 1ull;
+                if (edge < 0xffffffffull) {
+                    const float bound = dist_key_inv<IS_L2>((uint32_t)edge);
+                    if (bound == bound && fabsf(bound) < FLT_MAX) {
+                        bool better_bound = false;
 #pragma unroll
-            for (int j = 0; j < QG; j++) {
-                x[j] = *reinterpret_cast<const float4*>(a.queries + (int64_t)q_of[j] * a.d + m * P4_DSUB);
-            }
-            float4* l4 = reinterpret_cast<float4*>(smem) + c0 * P4_M + m;
-            if (a.lut_mode == PQ_LUT_PRECOMP) {
-                const float* pt = a.precomp_t + list * (int64_t)(P4_KSUB * P4_M) + c0 * P4_M + m;
-                float p[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    p[u] = pt[u * 2 * P4_M];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    float o[QG];
-#pragma unroll
-                    for (int j = 0; j < QG; j++) {
-                        float t = ip_step(0.f, x[j].x, y[u].x);
-                        t = ip_step(t, x[j].y, y[u].y);
-                        t = ip_step(t, x[j].z, y[u].z);
-                        t = ip_step(t, x[j].w, y[u].w);
-                        o[j] = fadd_x(p[u], fmul_x(-2.0f, t));
+                        for (int j = 0; j < QG; j++) {
+                            if (j == wave) {
+                                better_bound = IS_L2 ? bound < gt[j] : bound > gt[j];
+                                gt[j] = tighter<IS_L2>(gt[j], bound);
+                            }
+                        }
+                        if (better_bound && lane_i == 0) {
+                            gthr_publish<IS_L2>(a.gthr + h_q, bound);
+                        }
                     }
-                    l4[u * 2 * P4_M] = make_float4(o[0], o[1], o[2], o[3]);
-                }
-            } else if (a.lut_mode == PQ_LUT_IP) {
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    float o[QG];
-#pragma unroll
-                    for (int j = 0; j < QG; j++) {
-                        float t = ip_step(0.f, x[j].x, y[u].x);
-                        t = ip_step(t, x[j].y, y[u].y);
-                        t = ip_step(t, x[j].z, y[u].z);
-                        t = ip_step(t, x[j].w, y[u].w);
-                        o[j] = t;
-                    }
-                    l4[u * 2 * P4_M] = make_float4(o[0], o[1], o[2], o[3]);
-                }
-            } else { // residual tables: ||(q - c_list)_m - cb[m][c]||^2
-                const float4 cl = *reinterpret_cast<const float4*>(a.centroids + list * a.d + m * P4_DSUB);
-#pragma unroll
-                for (int j = 0; j < QG; j++) {
-                    x[j] = make_float4(fsub_x(x[j].x, cl.x), fsub_x(x[j].y, cl.y), fsub_x(x[j].z, cl.z),
-                                       fsub_x(x[j].w, cl.w));
-                }
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    float o[QG];
-#pragma unroll
-                    for (int j = 0; j < QG; j++) {
-                        float t = l2_step(0.f, x[j].x, y[u].x);
-                        t = l2_step(t, x[j].y, y[u].y);
-                        t = l2_step(t, x[j].z, y[u].z);
-                        t = l2_step(t, x[j].w, y[u].w);
-                        o[j] = t;
-                    }
-                    l4[u * 2 * P4_M] = make_float4(o[0], o[1], o[2], o[3]);
                 }
             }
+        }
+#pragma unroll
+        for (int j = 0; j < QG; j++) {
+            pre[j] = p4_prefilter<IS_L2>(tighter<IS_L2>(kd[j], gt[j]), dis0[j]);
         }
         P4_T(0); // record + LUT build
         __syncthreads();
@@ -399,126 +460,62 @@ __global__ __launch_bounds__(P4_THREADS) void pq_scan_q4_kernel(PqScanArgs a) {
             }
         }
 
-        // ---- this wave's groups ----------------------------------------------------------------------------------
-        const int ngroups = (int)((len + 63) / 64);
-        const int gpw = (ngroups + P4_WAVES - 1) / P4_WAVES;
-        const int G0 = wave * gpw;
-        const int G1 = min(G0 + gpw, ngroups);
-        const int nwin = G1 > G0 ? (G1 - G0 + 1) : 0; // one extra window drains the stagger
-
-        WaveTopK<IS_L2, R, int32_t> top[QG];
-        float kd[QG], pre[QG], gt[QG];
-        int32_t ki[QG];
-        int ncand[QG];
-#pragma unroll
-        for (int j = 0; j < QG; j++) {
-            ncand[j] = 0;
-            top[j].init(a.k);
-            kd[j] = worst_dist<IS_L2>();
-            ki[j] = -1;
-            gt[j] = gthr_load<IS_L2>(a.gthr + q_of[j]);
-            pre[j] = p4_prefilter<IS_L2>(tighter<IS_L2>(kd[j], gt[j]), dis0[j]);
-        }
-
-        if (h_mine) {
-            // inclusive prefix sum of the 64 bins across the wave; first bin where k vectors are reached
-            uint32_t cum = h_cnt;
-#pragma unroll
-            for (int dlt = 1; dlt < KN_WAVE; dlt <<= 1) {
-                const uint32_t up = __shfl_up(cum, dlt, KN_WAVE);
-                cum += lane_i >= dlt ? up : 0u;
-            }
-            const unsigned long long reach = __ballot(cum >= (uint32_t)a.k);
-            const int b = reach ? __ffsll((long long)reach) - 1 : KN_HIST_BINS;
-            if (b < KN_HIST_BINS - 1) { // (the last bin also collects everything beyond the range)
-                const unsigned long long edge =
-                        (unsigned long long)h_lo_w + (((unsigned long long)b + 1ull) << h_shift_w) - 1ull;
-                if (edge < 0xffffffffull) {
-                    const float bound = dist_key_inv<IS_L2>((uint32_t)edge);
-                    if (bound == bound && fabsf(bound) < FLT_MAX) {
-#pragma unroll
-                        for (int j = 0; j < QG; j++) {
-                            if (j == wave) {
-                                gt[j] = tighter<IS_L2>(gt[j], bound);
-                                pre[j] = p4_prefilter<IS_L2>(tighter<IS_L2>(kd[j], gt[j]), dis0[j]);
-                            }
-                        }
-                        if (lane_i == 0) {
-                            gthr_publish<IS_L2>(a.gthr + h_q, bound);
-                        }
-                    }
-                }
-            }
-        }
-
         typedef __attribute__((address_space(3))) const p4_f32x4 lds_f4;
         auto lut_read = [&](uint32_t addr) -> p4_f32x4 { return *reinterpret_cast<lds_f4*>(addr); };
-        // 4 lookups from one half of a code block (two words = 4 tokens)
-        auto issue4 = [&](uint32_t w0, uint32_t w1, p4_f32x4 (&v)[4]) {
+        // 2 lookups from one code word (two tokens)
+        auto issue2 = [&](uint32_t w0, p4_f32x4 (&v)[2]) {
             v[0] = lut_read(p4_addr_lo(w0, one));
             v[1] = lut_read(p4_addr_hi(w0, one));
-            v[2] = lut_read(p4_addr_lo(w1, one));
-            v[3] = lut_read(p4_addr_hi(w1, one));
         };
 
+        P4_T(2); // set-up of the scan
         if (nwin > 0) {
-            const uint4* cbase = a.codes_skew + (sblk0 + (int64_t)G0 * 4) * 64 + lane_i; // 4 blocks per window
-            auto load_blk = [&](int b) { return cbase[(int64_t)b * 64]; }; // past-the-end blocks exist (slack)
             p4_f32x2 n01 = {0.f, 0.f}, n23 = {0.f, 0.f}, o01 = {0.f, 0.f}, o23 = {0.f, 0.f};
-            // The four code registers hold blocks 4w .. 4w+3 of the stream; each is reloaded with block +4 as soon
-            // as its second half has been turned into LUT reads (about 7/8 of a window ahead of its next use).
-            // LUT reads run one 4-step block ahead of the accumulate that consumes them (two value buffers).
-            uint4 U0 = load_blk(0), U1 = load_blk(1), U2 = load_blk(2), U3 = load_blk(3);
-            p4_f32x4 va[4], vb[4];
-            issue4(U0.x, U0.y, va);
+            // LUT reads run FOUR 2-step units (8 lookups per lane) ahead of the accumulate that consumes them: four
+            // value buffers, each refilled right after it has been consumed, so a wave keeps 6-8 ds_read_b128 in
+            // flight at all times.  Code registers: at the top of window w, U0 = block 4w+4 (the NEXT window's first
+            // block: its tokens feed the reads issued in units 12..15), U1..U3 = blocks 4w+1..4w+3; each register is
+            // reloaded with block +4 as soon as its last word has been turned into LUT reads (3/4 of a window ahead
+            // of its next use).
+            p4_f32x4 B0[2], B1[2], B2[2], B3[2];
+            issue2(U0.x, B0);
+            issue2(U0.y, B1);
+            issue2(U0.z, B2);
+            issue2(U0.w, B3);
+            U0 = load_blk(4);
             const int last_group = ngroups - 1;
             const unsigned long long tail_mask = (len & 63) ? ((1ull << (len & 63)) - 1ull) : ~0ull;
 
-            for (int w = 0; w < nwin; w++) {
-                // thresholds published by other workgroups meanwhile (consumed at the end of this window)
+#define P4_UNIT(U, BUF, WORD)                                      \
+    __builtin_amdgcn_sched_barrier(0);                             \
+    p4_accum2<U>(n01, n23, o01, o23, BUF);                         \
+    __builtin_amdgcn_sched_barrier(0);                             \
+    issue2(WORD, BUF);
+
+            for (int w = 0;; w++) {
+                // The SIMD arbitrates its 4 waves by priority, then age: with equal priorities the oldest wave of a
+                // SIMD runs ~1.8x faster than the youngest and idles at the item's barrier.  Rotating the priority
+                // every window (waves w, w + 4, w + 8, w + 12 share a SIMD) gives all four the same average speed.
+                p4_setprio((w + (wave >> 2)) & 3);
+                // thresholds published by other workgroups meanwhile (consumed in the middle of this window)
                 float gnext[QG];
 #pragma unroll
                 for (int qi = 0; qi < QG; qi++) {
                     gnext[qi] = gthr_load<IS_L2>(a.gthr + q_of[qi]);
                 }
-                issue4(U0.z, U0.w, vb);
-                U0 = load_blk(4 * w + 4);
-                __builtin_amdgcn_sched_barrier(0);
-                p4_accum4<0>(n01, n23, o01, o23, va);
-                __builtin_amdgcn_sched_barrier(0);
-                issue4(U1.x, U1.y, va);
-                __builtin_amdgcn_sched_barrier(0);
-                p4_accum4<1>(n01, n23, o01, o23, vb);
-                __builtin_amdgcn_sched_barrier(0);
-                issue4(U1.z, U1.w, vb);
+                P4_UNIT(0, B0, U1.x)
+                P4_UNIT(1, B1, U1.y)
+                P4_UNIT(2, B2, U1.z)
+                P4_UNIT(3, B3, U1.w)
                 U1 = load_blk(4 * w + 5);
-                __builtin_amdgcn_sched_barrier(0);
-                p4_accum4<2>(n01, n23, o01, o23, va);
-                __builtin_amdgcn_sched_barrier(0);
-                issue4(U2.x, U2.y, va);
-                __builtin_amdgcn_sched_barrier(0);
-                p4_accum4<3>(n01, n23, o01, o23, vb);
-                __builtin_amdgcn_sched_barrier(0);
-                issue4(U2.z, U2.w, vb);
+                P4_UNIT(4, B0, U2.x)
+                P4_UNIT(5, B1, U2.y)
+                P4_UNIT(6, B2, U2.z)
+                P4_UNIT(7, B3, U2.w)
                 U2 = load_blk(4 * w + 6);
                 __builtin_amdgcn_sched_barrier(0);
-                p4_accum4<4>(n01, n23, o01, o23, va);
-                __builtin_amdgcn_sched_barrier(0);
-                issue4(U3.x, U3.y, va);
-                __builtin_amdgcn_sched_barrier(0);
-                p4_accum4<5>(n01, n23, o01, o23, vb);
-                __builtin_amdgcn_sched_barrier(0);
-                issue4(U3.z, U3.w, vb);
-                U3 = load_blk(4 * w + 7);
-                __builtin_amdgcn_sched_barrier(0);
-                p4_accum4<6>(n01, n23, o01, o23, va);
-                __builtin_amdgcn_sched_barrier(0);
-                issue4(U0.x, U0.y, va); // first block of the next window
-                __builtin_amdgcn_sched_barrier(0);
-                p4_accum4<7>(n01, n23, o01, o23, vb);
-                __builtin_amdgcn_sched_barrier(0);
 
-                // ---- window end: o01 / o23 hold the finished sums of group G0 + w - 1 in every lane --------------
+                // ---- step 15 passed: o01 / o23 hold the FINISHED sums of group G0 + w - 1 in every lane ----------
                 if (w > 0) {
                     const float Y[QG] = {o01.x, o01.y, o23.x, o23.y};
                     // fast path: one compare per query against the (possibly stale, i.e. looser) prefilter and
@@ -533,6 +530,7 @@ __global__ __launch_bounds__(P4_THREADS) void pq_scan_q4_kernel(PqScanArgs a) {
                     }
                     any &= vmask;
                     if (any != 0 || __ballot(moved) != 0) {
+                        P4_COUNT(9, 1);
                         const int32_t vbase = (G0 + w - 1) * 64;
 #pragma unroll
                         for (int qi = 0; qi < QG; qi++) {
@@ -559,10 +557,13 @@ __global__ __launch_bounds__(P4_THREADS) void pq_scan_q4_kernel(PqScanArgs a) {
                                     kd[qi] = top[qi].kth_dist();
                                     ki[qi] = top[qi].kth_idx();
                                     tightened = true;
-                                    if (h_shift[qi] != KN_HIST_OFF && lane_i == 0) { // one more vector at this distance
-                                        atomicAdd(a.ghist + (int64_t)q_of[qi] * KN_HIST_BINS +
-                                                          hist_bin(dist_key<IS_L2>(dis), h_lo[qi], h_shift[qi]),
-                                                  1u);
+                                    if (h_on && lane_i == 0) { // one more vector at this distance
+                                        const uint2 mt = a.gmeta[q_of[qi]];
+                                        if (mt.y != KN_HIST_OFF) {
+                                            atomicAdd(a.ghist + (int64_t)q_of[qi] * KN_HIST_BINS +
+                                                              hist_bin(dist_key<IS_L2>(dis), mt.x, mt.y),
+                                                      1u);
+                                        }
                                     }
                                 }
                                 if (tightened && ki[qi] >= 0 && lane_i == 0) {
@@ -573,112 +574,135 @@ __global__ __launch_bounds__(P4_THREADS) void pq_scan_q4_kernel(PqScanArgs a) {
                         }
                     }
                 }
+                if (w == nwin - 1) {
+                    break; // the drain window ends here: every lane's last vector is finished
+                }
+                P4_UNIT(8, B0, U3.x)
+                P4_UNIT(9, B1, U3.y)
+                P4_UNIT(10, B2, U3.z)
+                P4_UNIT(11, B3, U3.w)
+                U3 = load_blk(4 * w + 7);
+                P4_UNIT(12, B0, U0.x)
+                P4_UNIT(13, B1, U0.y)
+                P4_UNIT(14, B2, U0.z)
+                P4_UNIT(15, B3, U0.w)
+                U0 = load_blk(4 * w + 8);
+                __builtin_amdgcn_sched_barrier(0);
                 o01 = n01;
                 o23 = n23;
                 n01 = p4_f32x2{0.f, 0.f};
                 n23 = p4_f32x2{0.f, 0.f};
             }
+#undef P4_UNIT
+            __builtin_amdgcn_s_setprio(0);
         }
+        P4_T(3); // window loop
+        P4_COUNT(6, nwin);
 
-        P4_T(2); // set-up of the scan + window loop
-#ifdef KNHIP_PHASE_TIMERS
-        if (wave == P4_TIMER_WAVE) {
-            tacc[6] += (unsigned long long)nwin;
-        }
-#endif
-        uint32_t warm = 0;
-        if (wave == 0) {
-            // park the next item and warm the L2 with the query slices its LUT build will read
+        if (wave == 0) { // park the next item
             if (lane_i < REC_WORDS) {
                 ctl[8 + lane_i] = (int)rw_next;
             }
             if (lane_i == 0) {
                 ctl[0] = nxt;
             }
-            if (nxt >= 0 && lane_i < 4 * QG) { // 4 x 512 B = 16 lines of 128 B
-                const int32_t qn = __shfl((int)rw_next, 2 + (lane_i >> 2), KN_WAVE);
-                warm = __float_as_uint(a.queries[(int64_t)qn * a.d + (lane_i & 3) * 32]);
-            }
+        }
+        const int nc_any = ncand[0] | ncand[1] | ncand[2] | ncand[3];
+        if (nc_any != 0 && lane_i == 0) {
+            ctl[1] = 1; // (same value from every writer)
         }
         // ---- merge the waves' lists; wave qi finishes query qi ----------------------------------------------------
         // Partial lists are written SENTINEL-TERMINATED: entries [0, n) and, if n < k, one id = -1 behind them
         // (merge_partials never reads past the first sentinel of a slot).  In the bulk phase most (query, list)
-        // pairs contribute nothing.
-        __syncthreads(); // LUT is dead
-        P4_T(3); // wait for the slowest wave's scan
-        const int k = a.k;
-        int* s_cnt = reinterpret_cast<int*>(smem); // [QG][P4_WAVES]
-        float* md = reinterpret_cast<float*>(smem + 256);
-        int32_t* mi = reinterpret_cast<int32_t*>(smem + 256 + (size_t)QG * P4_WAVES * k * 4);
+        // pairs contribute nothing: such an item ends with ONE barrier and an 8-byte store per query.
+        __syncthreads(); // LUT is dead, every wave's flag write has landed
+        P4_T(4);         // wait for the slowest wave's scan
+        const bool any_cand = ctl[1] != 0;
+        if (!any_cand) {
+            if (wave < npair && lane_i == 0) {
 #pragma unroll
-        for (int qi = 0; qi < QG; qi++) {
-            const int n = ncand[qi] < k ? ncand[qi] : k;
-            if (lane_i == 0) {
-                s_cnt[qi * P4_WAVES + wave] = n;
+                for (int qi = 0; qi < QG; qi++) {
+                    if (wave == qi) {
+                        const int64_t po = ((int64_t)q_of[qi] * a.nslot + slot_of[qi]) * k;
+                        a.partial_d[po] = worst_dist<IS_L2>();
+                        a.partial_i[po] = -1;
+                    }
+                }
             }
-            if (n > 0) {
-                top[qi].store(md + (qi * P4_WAVES + wave) * k, mi + (qi * P4_WAVES + wave) * k);
-            }
-        }
-        __syncthreads();
+        } else {
+            int* s_cnt = reinterpret_cast<int*>(smem); // [QG][P4_WAVES]
+            float* md = reinterpret_cast<float*>(smem + 256);
+            int32_t* mi = reinterpret_cast<int32_t*>(smem + 256 + (size_t)QG * P4_WAVES * k * 4);
 #pragma unroll
-        for (int qi = 0; qi < QG; qi++) {
-            if (qi < npair && wave == qi) {
-                for (int w = 1; w < P4_WAVES; w++) {
-                    const int ow = (wave + w) % P4_WAVES;
-                    const int on = s_cnt[qi * P4_WAVES + ow];
-                    const float* od = md + (qi * P4_WAVES + ow) * k;
-                    const int32_t* oi = mi + (qi * P4_WAVES + ow) * k;
-                    for (int e = 0; e < on; e++) {
-                        const float cd = od[e];
-                        const int32_t ci = oi[e];
-                        if (ci < 0 || !top[qi].admits(cd, ci, kd[qi], ki[qi])) {
-                            break;
+            for (int qi = 0; qi < QG; qi++) {
+                const int n = ncand[qi] < k ? ncand[qi] : k;
+                if (lane_i == 0) {
+                    s_cnt[qi * P4_WAVES + wave] = n;
+                }
+                if (n > 0) {
+                    top[qi].store(md + (qi * P4_WAVES + wave) * k, mi + (qi * P4_WAVES + wave) * k);
+                }
+            }
+            __syncthreads();
+            if (wave == 0 && lane_i == 0) {
+                ctl[1] = 0; // (read by everyone before the barrier above)
+            }
+#pragma unroll
+            for (int qi = 0; qi < QG; qi++) {
+                if (qi < npair && wave == qi) {
+                    // the other waves' list lengths in one read; only non-empty lists are walked
+                    const int on_l = lane_i < P4_WAVES ? s_cnt[qi * P4_WAVES + lane_i] : 0;
+                    unsigned long long nz = __ballot(on_l > 0 && lane_i != wave);
+                    while (nz) {
+                        const int ow = __ffsll((long long)nz) - 1;
+                        nz &= nz - 1;
+                        const int on = __builtin_amdgcn_readlane(on_l, ow);
+                        const float* od = md + (qi * P4_WAVES + ow) * k;
+                        const int32_t* oi = mi + (qi * P4_WAVES + ow) * k;
+                        for (int e = 0; e < on; e++) {
+                            const float cd = od[e];
+                            const int32_t ci = oi[e];
+                            if (ci < 0 || !top[qi].admits(cd, ci, kd[qi], ki[qi])) {
+                                break;
+                            }
+                            top[qi].insert(cd, ci);
+                            kd[qi] = top[qi].kth_dist();
+                            ki[qi] = top[qi].kth_idx();
                         }
-                        top[qi].insert(cd, ci);
-                        kd[qi] = top[qi].kth_dist();
-                        ki[qi] = top[qi].kth_idx();
                     }
-                }
-                if (ki[qi] >= 0 && lane_i == 0) {
-                    gthr_publish<IS_L2>(a.gthr + q_of[qi], kd[qi]);
-                }
-                int nvalid = 0; // the list is sorted with its empty entries at the tail
+                    if (ki[qi] >= 0 && lane_i == 0) {
+                        gthr_publish<IS_L2>(a.gthr + q_of[qi], kd[qi]);
+                    }
+                    int nvalid = 0; // the list is sorted with its empty entries at the tail
 #pragma unroll
-                for (int r = 0; r < R; r++) {
-                    nvalid += __popcll(__ballot(r * KN_WAVE + lane_i < k && top[qi].i[r] >= 0));
-                }
-                float* pd = a.partial_d + ((int64_t)q_of[qi] * a.nslot + slot_of[qi]) * k;
-                int64_t* pi = a.partial_i + ((int64_t)q_of[qi] * a.nslot + slot_of[qi]) * k;
+                    for (int r = 0; r < R; r++) {
+                        nvalid += __popcll(__ballot(r * KN_WAVE + lane_i < k && top[qi].i[r] >= 0));
+                    }
+                    float* pd = a.partial_d + ((int64_t)q_of[qi] * a.nslot + slot_of[qi]) * k;
+                    int64_t* pi = a.partial_i + ((int64_t)q_of[qi] * a.nslot + slot_of[qi]) * k;
 #pragma unroll
-                for (int r = 0; r < R; r++) {
-                    const int e = r * KN_WAVE + lane_i;
-                    if (e < nvalid) {
-                        pd[e] = top[qi].d[r];
-                        pi[e] = a.ids[row_off + (int64_t)top[qi].i[r]];
-                    } else if (e == nvalid && e < k) {
-                        pd[e] = worst_dist<IS_L2>();
-                        pi[e] = -1;
+                    for (int r = 0; r < R; r++) {
+                        const int e = r * KN_WAVE + lane_i;
+                        if (e < nvalid) {
+                            pd[e] = top[qi].d[r];
+                            pi[e] = a.ids[row_off + (int64_t)top[qi].i[r]];
+                        } else if (e == nvalid && e < k) {
+                            pd[e] = worst_dist<IS_L2>();
+                            pi[e] = -1;
+                        }
                     }
                 }
             }
+            __syncthreads(); // the merge scratch aliases the next item's LUT
         }
-        if (warm == 0x7fc0dead && a.k < 0) { // never true: keeps the warming loads alive without waiting on them early
-            ctl[4] = 1;
-        }
-        __syncthreads(); // the merge scratch aliases the next item's LUT
-        P4_T(4); // merge + result write
-#ifdef KNHIP_PHASE_TIMERS
-        if (wave == P4_TIMER_WAVE) {
-            tacc[5] += 1;
-        }
-#endif
+        P4_T(5); // merge + result write
+        P4_COUNT(8, 1);
         cur = p4_sgpr(ctl[0]);
     }
 #ifdef KNHIP_PHASE_TIMERS
-    if (wave == P4_TIMER_WAVE && lane == 0) {
-        for (int i = 0; i < 8; i++) {
-            atomicAdd(&g_p4_prof[i], tacc[i]);
+    if (lane == 0) {
+        for (int i = 0; i < 10; i++) {
+            atomicAdd(&g_p4_prof[wave * 10 + i], tacc[i]);
         }
     }
 #endif
@@ -705,19 +729,21 @@ static hipError_t launch_q4_r(const PqScanArgs& a, int64_t items_bound, hipStrea
     // one resident workgroup per CU (128 KB of LDS each); never more workgroups than items
     const int64_t wgs = std::max<int64_t>(1, std::min<int64_t>(ncu, items_bound));
 #ifdef KNHIP_PHASE_TIMERS
-    unsigned long long zero[16] = {0};
+    static unsigned long long zero[160] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_p4_prof), zero, sizeof(zero));
 #endif
     hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(P4_THREADS), sm, s, a);
 #ifdef KNHIP_PHASE_TIMERS
     (void)hipStreamSynchronize(s);
-    unsigned long long h[16];
+    unsigned long long h[160];
     (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_p4_prof), sizeof(h));
-    const double n = h[5] ? (double)h[5] : 1.0;
-    fprintf(stderr,
-            "[p4 timers, wave %d] items %llu windows/item %.2f | ticks per item: lut %.0f wait1 %.0f scan %.0f wait2 %.0f "
-            "merge %.0f loop-top %.0f\n",
-            P4_TIMER_WAVE, h[5], h[6] / n, h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[7] / n);
+    fprintf(stderr, "[p4 timers] ticks per item: wave | lut wait1 setup windows wait2 merge top | windows/item slow-ends/item\n");
+    for (int w = 0; w < 16; w++) {
+        const unsigned long long* r = h + w * 10;
+        const double n = r[8] ? (double)r[8] : 1.0;
+        fprintf(stderr, "[p4 timers] %2d | %6.0f %6.0f %6.0f %6.0f %6.0f %6.0f %5.0f | %.2f %.3f   (items %llu)\n", w, r[0] / n,
+                r[1] / n, r[2] / n, r[3] / n, r[4] / n, r[5] / n, r[7] / n, r[6] / n, r[9] / n, r[8]);
+    }
 #endif
     return hipGetLastError();
 }

@@ -1,0 +1,145 @@
+// tools/ubench/adc_loop.hip -- issue-rate microbenchmark of the pq_scan_q4 window loop in isolation:
+// one 16-wave workgroup per CU, 128 KB LUT in LDS, random tokens held in registers, no global traffic.
+// Modes knock out one ingredient at a time to show which unit bounds the loop.
+//   0 full (SDWA + ds_read_b128 + split/plain accumulates)      1 no EXEC flips (every step plain)
+//   2 no LDS reads (values = registers)                          3 no SDWA (addresses precomputed)
+//   4 only ds_read_b128 (no accumulate)                          5 only accumulates (plain + split), no LDS/SDWA
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include "../../knowhere_amd/csrc/kernels.h"
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+using knhip::pq_stream_mask;
+
+#define SPLIT(MK, X, Y) "s_mov_b32 exec_lo, " MK "\n s_mov_b32 exec_hi, " MK "\n v_pk_add_f32 %0, %0, " X "\n v_pk_add_f32 %1, %1, " Y "\n s_not_b64 exec, exec\n v_pk_add_f32 %2, %2, " X "\n v_pk_add_f32 %3, %3, " Y "\n"
+#define PLAIN(X, Y) "v_pk_add_f32 %0, %0, " X "\n v_pk_add_f32 %1, %1, " Y "\n"
+#define VALS(v) "v"(__builtin_shufflevector(v[0], v[0], 0, 1)), "v"(__builtin_shufflevector(v[0], v[0], 2, 3)), "v"(__builtin_shufflevector(v[1], v[1], 0, 1)), "v"(__builtin_shufflevector(v[1], v[1], 2, 3))
+
+template <int U, bool FLIP>
+__device__ __forceinline__ void accum2(f2& n01, f2& n23, f2& o01, f2& o23, const f4 (&v)[2]) {
+    if constexpr (FLIP && U < 7) {
+        asm volatile(SPLIT("%8", "%4", "%5") SPLIT("%9", "%6", "%7") "s_mov_b64 exec, -1\n"
+                     : "+v"(n01), "+v"(n23), "+v"(o01), "+v"(o23) : VALS(v), "i"(pq_stream_mask(2 * U)), "i"(pq_stream_mask(2 * U + 1)));
+    } else if constexpr (FLIP && U == 7) {
+        asm volatile(SPLIT("%8", "%4", "%5") "s_mov_b64 exec, -1\n" PLAIN("%6", "%7")
+                     : "+v"(n01), "+v"(n23), "+v"(o01), "+v"(o23) : VALS(v), "i"(pq_stream_mask(14)));
+    } else {
+        asm volatile(PLAIN("%4", "%5") PLAIN("%6", "%7") : "+v"(n01), "+v"(n23), "+v"(o01), "+v"(o23) : VALS(v));
+    }
+}
+
+__device__ __forceinline__ uint32_t addr_lo(uint32_t w, uint32_t one) {
+    uint32_t a;
+    asm("v_lshlrev_b32_sdwa %0, %2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(a) : "v"(w), "s"(one));
+    return a;
+}
+__device__ __forceinline__ uint32_t addr_hi(uint32_t w, uint32_t one) {
+    uint32_t a;
+    asm("v_lshlrev_b32_sdwa %0, %2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(a) : "v"(w), "s"(one));
+    return a;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(1024) void k(float* out, const uint32_t* tok, int nwin, unsigned long long* cyc) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    float* lut = reinterpret_cast<float*>(smem);
+    for (int i = threadIdx.x; i < 32768; i += 1024) lut[i] = (float)(i & 1023) * 0.001f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    // 16 token words per lane: code random, m = (step - phase) mod 32 as in the real stream
+    uint32_t T[16];
+    for (int i = 0; i < 16; i++) T[i] = tok[(blockIdx.x * 1024 + threadIdx.x) * 16 + i];
+    const uint32_t one = 1;
+    typedef __attribute__((address_space(3))) const f4 lds_f4;
+    f2 n01 = {0, 0}, n23 = {0, 0}, o01 = {0, 0}, o23 = {0, 0};
+    f4 B0[2], B1[2], B2[2], B3[2];
+    auto rd = [&](uint32_t a) -> f4 {
+        if (MODE == 2 || MODE == 5) return f4{__uint_as_float(a), 1.f, 2.f, 3.f};
+        return *reinterpret_cast<lds_f4*>(a);
+    };
+    auto issue2 = [&](uint32_t w, f4 (&v)[2]) {
+        if (MODE == 3 || MODE == 5) {
+            v[0] = rd(w & 0x1fff0u);
+            v[1] = rd((w >> 15) & 0x1fff0u);
+        } else {
+            v[0] = rd(addr_lo(w, one));
+            v[1] = rd(addr_hi(w, one));
+        }
+    };
+    if (MODE == 3 || MODE == 5) {
+        // addresses precomputed once: (mode 3 keeps the ds_reads, drops the per-step VALU address op)
+    }
+    issue2(T[0], B0); issue2(T[1], B1); issue2(T[2], B2); issue2(T[3], B3);
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#define UNIT(U, BUF, WORD)                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                       \
+    if (MODE != 4) accum2<U, MODE != 1>(n01, n23, o01, o23, BUF);            \
+    else asm volatile("" :: "v"(BUF[0]), "v"(BUF[1]));                       \
+    __builtin_amdgcn_sched_barrier(0);                                       \
+    issue2(WORD, BUF);
+    for (int w = 0; w < nwin; w++) {
+        UNIT(0, B0, T[4]) UNIT(1, B1, T[5]) UNIT(2, B2, T[6]) UNIT(3, B3, T[7])
+        UNIT(4, B0, T[8]) UNIT(5, B1, T[9]) UNIT(6, B2, T[10]) UNIT(7, B3, T[11])
+        UNIT(8, B0, T[12]) UNIT(9, B1, T[13]) UNIT(10, B2, T[14]) UNIT(11, B3, T[15])
+        UNIT(12, B0, T[0]) UNIT(13, B1, T[1]) UNIT(14, B2, T[2]) UNIT(15, B3, T[3])
+        __builtin_amdgcn_sched_barrier(0);
+        o01 = n01; o23 = n23;
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    out[blockIdx.x * 1024 + threadIdx.x] = n01.x + n01.y + n23.x + n23.y + o01.x + o23.y + B0[0].x + B1[0].x + B2[0].x + B3[0].x;
+    if (lane == 0) atomicAdd(cyc + (threadIdx.x >> 6), t1 - t0);
+}
+
+template <int MODE>
+void run(const char* name, const uint32_t* dtok, float* out, unsigned long long* dcyc) {
+    const int nwin = 2000, blocks = 256;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    hipMemset(dcyc, 0, 16 * 8);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(1024), 131072, 0, out, dtok, 10, dcyc);
+    hipDeviceSynchronize();
+    hipMemset(dcyc, 0, 16 * 8);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(1024), 131072, 0, out, dtok, nwin, dcyc);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long h[16];
+    hipMemcpy(h, dcyc, sizeof(h), hipMemcpyDeviceToHost);
+    // per CU: 16 waves x nwin windows; lookups per window per wave = 64 lanes x 32 steps x 4 queries
+    const double lookups = 256.0 * 16 * nwin * 64 * 32 * 4;
+    printf("%-34s %8.3f ms  %6.1f ns per window-round (16 waves)  %5.1f lookups/ns/CU (LDS peak 64/clk)  ticks/window: w0 %.0f w15 %.0f\n", name, ms,
+           ms * 1e6 / nwin, lookups / 256 / (ms * 1e6), (double)h[0] / blocks / nwin, (double)h[15] / blocks / nwin);
+}
+
+int main() {
+    const size_t n = (size_t)256 * 1024 * 16;
+    uint32_t* htok = (uint32_t*)malloc(n * 4);
+    srand(1);
+    for (size_t t = 0; t < (size_t)256 * 1024; t++) {
+        const int lane = t & 63;
+        const int ph = knhip::pq_stream_phase(lane);
+        for (int i = 0; i < 16; i++) {
+            uint32_t w = 0;
+            for (int h = 0; h < 2; h++) {
+                const int step = 2 * i + h;
+                const uint32_t m = (uint32_t)((step - ph) & 31), code = rand() & 255;
+                w |= ((code << 8) | (m << 3)) << (16 * h);
+            }
+            htok[t * 16 + i] = w;
+        }
+    }
+    uint32_t* dtok; float* out; unsigned long long* dcyc;
+    hipMalloc(&dtok, n * 4); hipMalloc(&out, 256 * 1024 * 4); hipMalloc(&dcyc, 16 * 8);
+    hipMemcpy(dtok, htok, n * 4, hipMemcpyHostToDevice);
+    run<0>("full", dtok, out, dcyc);
+    run<1>("no exec flips", dtok, out, dcyc);
+    run<2>("no LDS reads", dtok, out, dcyc);
+    run<3>("no SDWA (and+shift addresses)", dtok, out, dcyc);
+    run<4>("only SDWA + ds_read_b128", dtok, out, dcyc);
+    run<5>("only accumulates", dtok, out, dcyc);
+    return 0;
+}
