@@ -1,24 +1,30 @@
 #!/usr/bin/env python
 """bench.py -- contract benchmark.
 
-Metric (BASELINE.json): QPS at recall@10 >= 0.95, IVF-PQ m=32 x 8 bit, 100M x d=128 fp32,
-nlist=16384, nprobe=128, batch = 10k queries, k=10, on 1/2/4/8 MI355X.
+Default (= BASELINE.json's metric, config "C3"): QPS at recall@10 >= 0.95, IVF-PQ m=32 x 8 bit,
+100M x d=128 fp32, nlist=16384, nprobe=128, batch = 10k queries, k=10, on 1/2/4/8 MI355X.
+`--config C2` (IVF-Flat L2 10M x 128, nlist 4096, nprobe 64) and `--config C5` (IVF-SQ8 IP 100M x 768 int8-valued,
+nlist 65536, nprobe 256) run BASELINE.json's other single-GPU configurations through the same harness.
 
-One "step" = one Search() of the whole 10k-query batch: coarse quantizer -> PQ query tables ->
-per-list ADC scan -> per-query merge of the top-`refine_k` PQ candidates -> exact fp32 re-rank
-(Knowhere's `refine`, IndexRefine) -> top-10.  Queries, index and raw vectors are resident in HBM
-when the timed region starts; nothing is cached between steps (every step recomputes everything).
+One "step" = one Search() of the whole 10k-query batch: coarse quantizer -> (PQ tables) -> per-list scan ->
+per-query merge [-> exact fp32 re-rank of the top-`refine_k` PQ candidates (Knowhere's `refine`, IndexRefine)]
+-> top-10.  `value` is measured with queries, index and raw vectors resident in HBM when the timed region starts;
+nothing is cached between steps.  The same step driven across the HOST boundary (pageable host queries in, host
+results out: what IndexNode::Search does, H2D + D2H inside the timed region) is timed too and reported as
+`host_boundary` -- SURVEY.md 8(d) quotes the reference's GPU path that way.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): STRONG scaling on the same 100M
-index.  Inverted lists are partitioned across ranks (size-balanced), the coarse quantizer and PQ
-codebooks are replicated, every rank sees the full query batch and scans only the probes it owns;
-the per-rank partial top-`refine_k` are exchanged with ONE all-gather (RCCL over xGMI) and merged
-on device; each rank re-ranks the candidates whose raw vectors it owns and a second small
-all-gather + merge yields the final top-10 (bit-identical to the single-GPU result).
+N > 1 (launched by torch.distributed.run, one rank per GPU): STRONG scaling on the same index.  Inverted lists
+are partitioned across ranks (size-balanced); every rank builds, encodes and keeps ONLY the rows of the lists it
+owns (codes and raw vectors), the coarse quantizer and codebooks are trained on rank 0 and broadcast.  Per step
+the coarse quantizer is sharded by queries (one packed all-gather of the (nq, nprobe) assignment), every rank
+scans the probes it owns; one packed all-gather of the per-rank (distance, id) partial top-`refine_k` over RCCL/xGMI
++ a device merge gives the global PQ candidates, every rank re-ranks the candidates whose raw vectors it holds,
+and a second small packed all-gather + merge yields the final top-10 -- bit-identical to the single-GPU result
+(IndexRefine semantics: the global top-`refine_k` by PQ distance is what gets re-ranked).
 
-Extra JSON objects: "roofline" (dominant kernel = the ADC scan, algorithmic bytes of SURVEY.md 8d
-/ HIP-event time measured here) and "cpu_baseline" (the reference's own FAISS, or the oracle port,
-timed on this box's host cores on a bounded sample of the same workload).
+Extra JSON objects: "roofline" (dominant kernel; for the ADC scan the binding unit is the LDS gather, HBM
+fractions are kept beside it) and "cpu_baseline" (the reference's own FAISS, AVX2 dynamic-dispatch build where it
+loads, timed on this box's host cores on a bounded sample of the same workload, checked bitwise against the GPU).
 """
 import argparse
 import json
@@ -37,7 +43,25 @@ from knowhere_amd import build as kb  # noqa: E402
 from knowhere_amd import index as kidx  # noqa: E402
 from knowhere_amd import sharded  # noqa: E402
 
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+# /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBPS = 8000.0                 # HBM3E spec peak
+LDS_PEAK_GBPS = 256 * 256 * 2.4        # 256 B/clk/CU (conflict-free ds_read_b64/b128) x 256 CUs x 2.4 GHz
+VALU_PEAK_TFLOPS = 157.3               # fp32 vector peak (FMA = 2 flop)
+MFMA_F32_PEAK_TFLOPS = 157.3           # fp32 matrix peak (coarse quantizer)
+
+CONFIGS = {
+    # BASELINE.json configs[1]
+    "C2": dict(kind="ivfflat", metric="l2", nb=10_000_000, d=128, nlist=4096, nprobe=64, nq=10000, k=10, m=0,
+               refine_k=0, data="mixture", train_per_centroid=256, niter=25),
+    # BASELINE.json configs[2]: the metric's configuration
+    "C3": dict(kind="ivfpq", metric="l2", nb=100_000_000, d=128, nlist=16384, nprobe=128, nq=10000, k=10, m=32,
+               refine_k=100, data="mixture", train_per_centroid=256, niter=25),
+    # BASELINE.json configs[4]; 65536 x 768 centroids: fewer training points / iterations keep the build in minutes
+    "C5": dict(kind="ivfsq8", metric="ip", nb=100_000_000, d=768, nlist=65536, nprobe=256, nq=10000, k=10, m=0,
+               refine_k=0, data="int8", train_per_centroid=32, niter=10),
+}
+KINDS = {"ivfflat": kidx.IVF_FLAT, "ivfpq": kidx.IVF_PQ, "ivfsq8": kidx.IVF_SQ8}
+KIND_LABEL = {"ivfflat": "IVF-Flat", "ivfpq": "IVF-PQ", "ivfsq8": "IVF-SQ8"}
 
 
 def parse():
@@ -45,23 +69,29 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--nb", type=int, default=100_000_000)
-    ap.add_argument("--d", type=int, default=128)
-    ap.add_argument("--nlist", type=int, default=16384)
-    ap.add_argument("--nprobe", type=int, default=128)
-    ap.add_argument("--nq", type=int, default=10000)
-    ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--m", type=int, default=32)
-    ap.add_argument("--refine-k", type=int, default=100, help="PQ candidates re-ranked per query (0 = no refine)")
-    ap.add_argument("--data", default="mixture", choices=["mixture", "uniform"])
+    ap.add_argument("--config", default="C3", choices=sorted(CONFIGS), help="BASELINE.json configuration")
+    for name, typ in (("nb", int), ("d", int), ("nlist", int), ("nprobe", int), ("nq", int), ("k", int), ("m", int),
+                      ("refine_k", int), ("train_per_centroid", int), ("niter", int)):
+        ap.add_argument("--" + name.replace("_", "-"), type=typ, default=None, help="override the configuration")
+    ap.add_argument("--data", default=None, choices=["mixture", "uniform", "int8"])
     ap.add_argument("--sigma", type=float, default=0.35)
     ap.add_argument("--ncenter", type=int, default=0, help="mixture components (0 = nb/160 rounded to a power of two)")
     ap.add_argument("--latent", type=int, default=0, help="intrinsic dimension of a component (0 = isotropic)")
     ap.add_argument("--gt-queries", type=int, default=1000, help="queries used for the recall measurement")
-    ap.add_argument("--cpu-queries", type=int, default=192, help="queries of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-queries", type=int, default=-1,
+                    help="queries of the CPU baseline sample (-1 = 8 per host thread, 0 = skip)")
+    ap.add_argument("--host-steps", type=int, default=3, help="steps of the host-boundary timing (0 = skip)")
     ap.add_argument("--backend", default=None, help="nccl (default for N>1) | gloo (single-GPU debugging)")
     ap.add_argument("--verbose", action="store_true")
-    return ap.parse_args()
+    a = ap.parse_args()
+    cfg = dict(CONFIGS[a.config])
+    for key in list(cfg):
+        v = getattr(a, key, None)
+        if v is not None:
+            cfg[key] = v
+    for key, v in cfg.items():
+        setattr(a, key, v)
+    return a
 
 
 def log(rank, *a):
@@ -86,41 +116,60 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=dev if backend == "nccl" else None)
         comm = sharded.Comm(dev)
+    kind = KINDS[a.kind]
+    metric = kidx.L2 if a.metric == "l2" else kidx.IP
+    refine = a.refine_k > 0
 
     # ---------------------------------------------------------------- build
     t_build = time.time()
     if a.ncenter <= 0:
         a.ncenter = 1 << max(4, int(round(np.log2(max(a.nb / 160.0, 16.0)))))
     spec = kb.DataSpec(a.nb, a.d, kind=a.data, seed=42, ncenter=a.ncenter, sigma=a.sigma, latent=a.latent)
-    cen = cb = None
+    cen = cb = sq = None
+    own_row = None
     if world > 1:
-        # rank 0 trains; centroids and codebooks are broadcast so every shard quantises identically
+        # rank 0 trains; centroids and codec parameters are broadcast so every shard quantises identically
         if rank == 0:
-            tmp = kb.build_ivf(spec, kidx.IVF_PQ, kidx.L2, a.nlist, a.m, device=str(dev), train_only=True,
-                               verbose=a.verbose)
-            cen, cb = tmp.centroids, tmp.codebooks
+            tmp = kb.build_ivf(spec, kind, metric, a.nlist, a.m, device=str(dev), train_only=True,
+                               train_per_centroid=a.train_per_centroid, niter=a.niter, verbose=a.verbose)
+            cen, cb, sq = tmp.centroids, tmp.codebooks, tmp.sq_trained
         else:
             cen = torch.empty((a.nlist, a.d), device=dev)
-            cb = torch.empty((a.m, 256, a.d // a.m), device=dev)
+            cb = torch.empty((a.m, 256, a.d // a.m), device=dev) if kind == kidx.IVF_PQ else None
+            sq = torch.empty((2 * a.d,), device=dev) if kind == kidx.IVF_SQ8 else None
         cen = comm.broadcast(cen)
-        cb = comm.broadcast(cb)
-    built = kb.build_ivf(spec, kidx.IVF_PQ, kidx.L2, a.nlist, a.m, device=str(dev), centroids=cen, codebooks=cb,
-                         verbose=a.verbose and rank == 0, keep_vectors=a.refine_k > 0)
-    sizes = built.list_offsets[1:] - built.list_offsets[:-1]
-    owned = sharded.partition_lists(sizes, world)[rank] if world > 1 else None
-    g = built.to_gpu_index(device=dev_id, owned_lists=owned)
-    vectors = getattr(built, "vectors", None)  # [nb, d] fp32, row = id
-    own_row = None
-    if world > 1 and vectors is not None:
-        # a rank re-ranks only candidates whose raw vector it owns (owner = owner of the id's list)
-        own_row = sharded.owned_id_mask(built, owned)
+        cb = comm.broadcast(cb) if cb is not None else None
+        sq = comm.broadcast(sq) if sq is not None else None
+        # list ownership needs the list sizes: one cheap assignment pass per rank over its slice of the rows, summed
+        sizes = sharded.global_list_sizes(comm, spec, cen, metric, rank, world, dev)
+        owned = sharded.partition_lists(sizes, world)[rank]
+        built = kb.build_ivf(spec, kind, metric, a.nlist, a.m, device=str(dev), centroids=cen, codebooks=cb,
+                             sq_trained=sq, owned_lists=owned, verbose=a.verbose and rank == 0, keep_vectors=refine)
+        g = built.to_gpu_index(device=dev_id)
+    else:
+        built = kb.build_ivf(spec, kind, metric, a.nlist, a.m, device=str(dev), verbose=a.verbose,
+                             keep_vectors=refine, train_per_centroid=a.train_per_centroid, niter=a.niter)
+        g = built.to_gpu_index(device=dev_id)
+    vectors = getattr(built, "vectors", None)        # raw fp32 rows this rank holds (row r <-> id vector_ids[r])
+    vector_ids = getattr(built, "vector_ids", None)  # None: row r <-> id r
     xq = kb.queries(spec, a.nq, dev)
     torch.cuda.synchronize()
     build_s = time.time() - t_build
-    log(rank, f"build {build_s:.1f}s {built.timings} index {g.device_bytes / 1e9:.2f} GB/rank, "
+    log(rank, f"build {build_s:.1f}s {built.timings} index {g.device_bytes / 1e9:.2f} GB/rank"
+              f"{', raw vectors %.1f GB/rank' % (vectors.numel() * 4 / 1e9) if vectors is not None else ''}, "
               f"precomputed_table={g.uses_precomputed_table}")
+    if built.codes is not None and built.codes.numel() > (16 << 30):
+        built.codes = None  # (C5: 76.8 GB of list-sorted codes; the index holds its own layout, the CPU leg is skipped)
+    kbase = a.refine_k if refine else a.k
+    row_of_id = sharded.row_lookup(vector_ids, a.nb, dev) if (refine and vector_ids is not None) else None
 
-    kbase = a.refine_k if a.refine_k > 0 else a.k
+    def rerank(Ip):
+        """exact fp32 re-rank of the PQ candidates whose raw vectors this rank holds"""
+        if row_of_id is None:
+            return kidx.refine_device(metric, vectors, xq, Ip, a.k)
+        rows = sharded.ids_to_rows(Ip, row_of_id)          # -1 where the vector lives on another rank
+        D, R = kidx.refine_device(metric, vectors, xq, rows, a.k)
+        return D, sharded.rows_to_ids(R, vector_ids)
 
     # N > 1: the coarse quantizer is sharded by QUERIES (each rank assigns nq / N of them, one all-gather of the
     # (nq, nprobe) assignment), the scan by LISTS (knhip_search_preassigned_device = IndexIVF::search_preassigned)
@@ -129,22 +178,31 @@ def main():
             keys, cdis = sharded.sharded_coarse(comm, lambda lo, hi: g.coarse_search_device(xq[lo:hi], a.nprobe),
                                                 a.nq, a.nprobe, device=dev)
             Dp, Ip = g.search_preassigned_device(xq, kbase, keys, cdis)
-            Dp, Ip = comm.allgather_merge(kidx.L2, Dp, Ip)
-        else:
-            Dp, Ip = g.search_device(xq, kbase, a.nprobe)
-        if a.refine_k > 0:
-            cand = Ip if own_row is None else sharded.mask_unowned(Ip, own_row)
-            D, I = kidx.refine_device(kidx.L2, vectors, xq, cand, a.k)
-            if world > 1:
-                D, I = comm.allgather_merge(kidx.L2, D, I)
-            return D, I
-        return Dp[:, :a.k].contiguous(), Ip[:, :a.k].contiguous()
+            Dp, Ip = comm.allgather_merge(metric, Dp, Ip)  # global top-kbase by PQ distance, identical on every rank
+            if not refine:
+                return Dp, Ip
+            D, I = rerank(Ip)  # only the candidates whose raw vectors live here (the others are marked "skip")
+            return comm.allgather_merge(metric, D, I)
+        Dp, Ip = g.search_device(xq, kbase, a.nprobe)
+        if refine:
+            return rerank(Ip)
+        return Dp, Ip
+
+    # the same step across the host boundary (single GPU): pageable host queries in, host results out
+    xq_host = xq.cpu().numpy()
+
+    def host_step():
+        q = torch.from_numpy(xq_host).to(dev)                      # H2D
+        Dp, Ip = g.search_device(q, kbase, a.nprobe)
+        if refine:
+            Dp, Ip = kidx.refine_device(metric, vectors, q, Ip, a.k)
+        return Dp.cpu().numpy(), Ip.cpu().numpy()                  # D2H (synchronises)
 
     # ---------------------------------------------------------------- recall gate
     D, I = step()
     torch.cuda.synchronize()
     ngt = min(a.gt_queries, a.nq)
-    _, gt = kb.ground_truth(spec, xq[:ngt], a.k, device=str(dev))
+    _, gt = kb.ground_truth(spec, xq[:ngt], a.k, metric=metric, device=str(dev))
     hits = (I[:ngt].unsqueeze(2) == gt.unsqueeze(1)).any(dim=2).float().sum().item()
     rec = hits / (ngt * a.k)
     log(rank, f"recall@{a.k} = {rec:.4f} over {ngt} queries (refine_k={a.refine_k})")
@@ -160,14 +218,10 @@ def main():
         step()
     g.profile_enable(True)
     g.profile_reset()
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
     barrier()
     t0 = time.perf_counter()
-    ev0.record()
     for _ in range(a.steps):
         step()
-    ev1.record()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -177,39 +231,54 @@ def main():
     ms_per_step = dt / a.steps * 1e3
     qps = a.nq * a.steps / dt
 
-    # dominant kernel: the ADC scan.  achieved = algorithmic bytes / mean launch time, both per launch
-    # (the bulk launch over probes 1..nprobe-1; the rank-0 probes run in a separate dump + radix-select
-    # phase whose time is reported as stage "scan_rank0" and whose bytes are excluded here)
-    nlaunch = max(prof["launches"][kidx._lib.STAGE_SCAN], 1)
-    scan_ms = prof["ms"][kidx._lib.STAGE_SCAN] / nlaunch
-    scan_bytes = (prof["scan_bytes"] - prof["scan_bytes_rank0"]) / nlaunch
-    achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": "knhip::pq_scan_v2_kernel<true, 2, false>", "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "traffic": pmc_traffic(a, world),
-                "algorithmic_bytes_per_launch": scan_bytes, "ms_per_launch": round(scan_ms, 3),
-                "stage_ms_per_step": {n: round(prof["ms"][i] / a.steps, 3) for i, n in
-                                      enumerate(["coarse", "group", "lut", "scan", "merge", "other", "scan_rank0"])}}
+    host = None
+    if world == 1 and a.host_steps > 0:
+        Dh, Ih = host_step()
+        same = bool((Ih == I.cpu().numpy()).all() and (Dh.view(np.uint32) == D.cpu().numpy().view(np.uint32)).all())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.host_steps):
+            host_step()
+        torch.cuda.synchronize()
+        dth = (time.perf_counter() - t0) / a.host_steps
+        host = {"value": round(a.nq / dth, 1), "unit": "queries/s", "ms_per_step": round(dth * 1e3, 3),
+                "steps": a.host_steps, "h2d_bytes": int(xq_host.nbytes), "d2h_bytes": int(a.nq * a.k * 12),
+                "identical_to_device_path": same,
+                "note": "pageable host queries in, host (ids, distances) out; H2D + D2H inside the timed region"}
+
+    roofline = make_roofline(a, kind, prof, world)
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N == 1)
     cpu = None
-    if rank == 0 and world == 1 and a.cpu_queries > 0:
-        cpu = cpu_baseline(a, built, vectors, xq, I, log)
+    if rank == 0 and world == 1 and a.cpu_queries != 0:
+        try:
+            cpu = cpu_baseline(a, kind, metric, built, vectors, xq, D, I, g, log)
+        except Exception as e:  # the baseline is a reported side number: never lose the bench line over it
+            log(0, f"cpu baseline failed: {e!r}")
 
     if rank == 0:
+        label = KIND_LABEL[a.kind]
+        gate = a.config == "C3"
         out = {
-            "metric": f"QPS at recall@{a.k}>=0.95, IVF-PQ {a.nb // 1_000_000}M x d={a.d} batch={a.nq // 1000}k",
+            "metric": (f"QPS at recall@{a.k}>=0.95, {label} {a.nb // 1_000_000}M x d={a.d} batch={a.nq // 1000}k" if gate
+                       else f"QPS, {label} {a.nb // 1_000_000}M x d={a.d} batch={a.nq // 1000}k"),
             "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "recall_at_10": round(rec, 4), "recall_gate_met": bool(rec >= 0.95),
-            "config": {"workload": f"IVF-PQ m={a.m} nbits=8, {a.nb} x d={a.d} fp32, nlist={a.nlist} "
-                                   f"nprobe={a.nprobe}, batch={a.nq}, k={a.k}, refine_k={a.refine_k} (fp32 re-rank)",
+            "recall_at_10": round(rec, 4), "recall_gate_met": bool(rec >= 0.95) if gate else None,
+            "config": {"name": a.config,
+                       "workload": f"{label}{' m=%d nbits=8' % a.m if kind == kidx.IVF_PQ else ''} {a.metric.upper()}, "
+                                   f"{a.nb} x d={a.d} fp32{' (int8-valued)' if a.data == 'int8' else ''}, "
+                                   f"nlist={a.nlist} nprobe={a.nprobe}, batch={a.nq}, k={a.k}"
+                                   f"{', refine_k=%d (fp32 re-rank)' % a.refine_k if refine else ''}",
                        "data_generator": f"{a.data} ncenter={a.ncenter} sigma={a.sigma} latent={a.latent} seed=42/44",
                        "parallelism": f"list-sharded x{world}" if world > 1 else "single GPU",
+                       "training": f"{a.niter} k-means iterations, {a.train_per_centroid} points per centroid",
                        "build_s": round(build_s, 1)},
             "roofline": roofline,
         }
+        if host is not None:
+            out["host_boundary"] = host
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
@@ -217,72 +286,147 @@ def main():
         dist.destroy_process_group()
 
 
+def make_roofline(a, kind, prof, world):
+    """dominant kernel = the list scan.  achieved = algorithmic work per launch / mean launch time (HIP events on the
+    launch stream, inside the library; the rocprofv3 average of the same kernel is under profiles/)."""
+    S = kidx._lib
+    nlaunch = max(prof["launches"][S.STAGE_SCAN], 1)
+    scan_ms = prof["ms"][S.STAGE_SCAN] / nlaunch
+    # (IVF-PQ: the bulk launch over probes 1..nprobe-1; the rank-0 probes run in a separate dump + radix-select
+    # phase whose time is stage "scan_rank0" and whose bytes are excluded here)
+    scan_bytes = (prof["scan_bytes"] - prof["scan_bytes_rank0"]) / nlaunch
+    sec = scan_ms * 1e-3
+    stages = {n: round(prof["ms"][i] / a.steps, 3) for i, n in
+              enumerate(["coarse", "group", "lut", "scan", "merge", "other", "scan_rank0"])}
+    traffic = pmc_traffic(a, world)
+    hbm_algo = scan_bytes / sec / 1e9 if sec > 0 else 0.0
+    common = {"algorithmic_bytes_per_launch": scan_bytes, "ms_per_launch": round(scan_ms, 3), "traffic": traffic,
+              "hbm_algorithmic_GBps": round(hbm_algo, 1), "hbm_algorithmic_frac": round(hbm_algo / HBM_PEAK_GBPS, 4),
+              "hbm_measured_frac": round(traffic / sec / 1e9 / HBM_PEAK_GBPS, 4) if (traffic and sec > 0) else None,
+              "stage_ms_per_step": stages}
+    cf = prof["coarse_flops"] / max(prof["launches"][S.STAGE_COARSE], 1)
+    if stages["coarse"] > 0 and cf > 0:
+        common["coarse_stage"] = {"bound": "mfma", "flops": cf, "ms": stages["coarse"],
+                                  "achieved_TFLOPs_whole_stage": round(cf / (stages["coarse"] * 1e-3) / 1e12, 2),
+                                  "peak": MFMA_F32_PEAK_TFLOPS}
+    if kind == kidx.IVF_PQ:
+        # one 4-byte table lookup per code byte: the LDS gather is the unit that binds (round-1 PMC: HBM traffic
+        # is 0.03-0.14 x the algorithmic bytes, LDS ~ busy); SURVEY 8(d)'s no-reuse HBM model is kept beside it
+        lds = scan_bytes * 4.0 / sec / 1e9 if sec > 0 else 0.0
+        return dict({"bound": "lds", "kernel": "knhip::pq_scan_q4_kernel<true, 2>", "achieved": round(lds, 1),
+                     "peak": round(LDS_PEAK_GBPS, 1), "unit": "GB/s", "frac": round(lds / LDS_PEAK_GBPS, 4),
+                     "note": "achieved = 4 B x code bytes scanned / launch time; peak = 256 B/clk/CU x 256 CU x 2.4 GHz"},
+                    **common)
+    # exact row scans: lane = row, the queries of a work item share each row fetch -> VALU-bound by construction:
+    # per (row, query, dim) L2 = sub, mul, add; IP = mul, add (+ SQ8: decode fma per (row, dim))
+    code_size = a.d * 4 if kind == kidx.IVF_FLAT else a.d
+    pairs_dims = scan_bytes / code_size * a.d
+    flop = pairs_dims * (3.0 if a.metric == "l2" else 2.0)
+    tf = flop / sec / 1e12 if sec > 0 else 0.0
+    name = "knhip::flat_scan_kernel" if kind == kidx.IVF_FLAT else "knhip::sq_scan_kernel"
+    return dict({"bound": "valu", "kernel": name, "achieved": round(tf, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                 "frac": round(tf / VALU_PEAK_TFLOPS, 4),
+                 "note": "separately rounded sub/mul/add per (row, query, dim) counted as 1 flop each; "
+                         "peak = fp32 vector peak (an FMA counts 2)"}, **common)
+
+
 def pmc_traffic(a, world):
     """HBM bytes per launch of the scan kernel from the PMC counters.  Counters cannot be collected
     inside a timed run: they come from separate rocprofv3 --pmc passes of this same command
-    (tools/profile_bench.sh), stored under profiles/; returned only if the workload matches."""
+    (tools/profile_bench.sh), stored under profiles/ with the commit they were taken at; returned only if the
+    workload matches."""
     path = os.path.join(ROOT, "profiles", "bench_pmc_traffic.json")
     try:
         t = json.load(open(path))
     except Exception:
         return None
-    key = f"nb={a.nb},nlist={a.nlist},nprobe={a.nprobe},nq={a.nq},m={a.m},refine_k={a.refine_k},gpus={world}"
+    key = (f"config={a.config},nb={a.nb},nlist={a.nlist},nprobe={a.nprobe},nq={a.nq},m={a.m},"
+           f"refine_k={a.refine_k},gpus={world}")
     return t.get(key, {}).get("hbm_bytes_per_launch")
 
 
-def cpu_baseline(a, built, vectors, xq, I_gpu, log):
-    """Time the reference's FAISS (oracle/_ref) -- or the oracle port where _ref cannot load -- on
-    the host cores over a bounded sample of the same batch, Knowhere-style (one query per task)."""
+def cpu_baseline(a, kind, metric, built, vectors, xq, D_gpu, I_gpu, g, log):
+    """Time the reference's FAISS (oracle/_ref; the AVX2 dynamic-dispatch build when it loads, else the scalar
+    build, else the oracle port) on the host cores over a bounded sample of the same batch, Knowhere-style (one
+    query per task), on the same index bytes; compare its result with the GPU's bit for bit."""
     from oracle import binding as ob  # checker / baseline only
     nth = os.cpu_count() or 1
-    nqs = min(a.cpu_queries, a.nq)
+    nqs = a.cpu_queries if a.cpu_queries > 0 else 8 * nth
+    nqs = min(nqs, a.nq)
+    if built.codes is None:
+        log(0, "cpu baseline skipped: the list-sorted codes were released (index too large for the host leg)")
+        return None
     t0 = time.time()
     ix = built.export(ob.IndexData)
     q = xq[:nqs].cpu().numpy()
     kbase = a.refine_k if a.refine_k > 0 else a.k
-    kind = "port"
+    variants = []
     try:
+        if ob.Ref.available("avx2"):
+            variants.append(("reference", "avx2"))
         if ob.Ref.available():
-            kind = "reference"
+            variants.append(("reference", "scalar"))
     except Exception:
-        kind = "port"
-    if kind == "reference":
-        ref = ob.Ref()
+        pass
+    res = {}
+    simd_used = None
+    for kindname, simd in variants:
+        ref = ob.Ref(simd)
         h = ref.from_data(ix)
-        log(0, f"cpu baseline: reference index rebuilt on host in {time.time() - t0:.1f}s")
+        Dw, Iw = ref.search(h, q[:min(nqs, nth)], kbase, a.nprobe, nthreads=nth)  # warm (page-in, thread pool)
         t1 = time.time()
         Dc, Ic = ref.search(h, q, kbase, a.nprobe, nthreads=nth)
-        dt = time.time() - t1
-        cores = nth
-    else:
+        res[simd] = (time.time() - t1, Dc, Ic)
+        if simd_used is None:
+            simd_used = simd
+        ref.free(h)
+    if not res:
         port = ob.Port()
-        ix.use_precomputed_table = 1
-        ix.precomputed_table = port.pq_precompute_table(ix.d, ix.M, 8, ix.centroids, ix.pq_centroids)
+        if kind == kidx.IVF_PQ and metric == kidx.L2:
+            ix.use_precomputed_table = 1
+            ix.precomputed_table = port.pq_precompute_table(ix.d, ix.M, 8, ix.centroids, ix.pq_centroids)
+        nqs = min(nqs, 64)
+        q = q[:nqs]
         t1 = time.time()
         Dc, Ic = port.search(ix, q, kbase, a.nprobe)
-        dt = time.time() - t1
-        cores = 1
+        res["port"] = (time.time() - t1, Dc, Ic)
+        simd_used = "port"
+    log(0, f"cpu baseline: index on host in {time.time() - t0:.1f}s; " +
+        ", ".join(f"{s}: {nqs} queries in {r[0]:.2f}s" for s, r in res.items()))
+    dt = res[simd_used][0]
+    # parity of the first stage (bit-exact bar) against the scalar reference where present, else the timed variant
+    chk = "scalar" if "scalar" in res else simd_used
+    Dg1, Ig1 = g.search_device(xq[:nqs], kbase, a.nprobe)
+    torch.cuda.synchronize()
+    Dg1, Ig1 = Dg1.cpu().numpy(), Ig1.cpu().numpy()
+    _, Dc, Ic = res[chk]  # every comparison below is against the scalar build where present (the parity bar)
+    dist_equal = float((Dc.view(np.uint32) == Dg1.view(np.uint32)).mean())
+    id_equal = float((Ic == Ig1).mean())
+    cores = nth if simd_used != "port" else 1
     if a.refine_k > 0 and vectors is not None:
         port = ob.Port()
         t2 = time.time()
-        # gather only the candidate rows (the 51 GB base never leaves HBM)
-        uniq, inv = np.unique(Ic[Ic >= 0], return_inverse=True)
+        uniq, inv = np.unique(Ic[Ic >= 0], return_inverse=True)  # gather only the candidate rows (the base stays in HBM)
         rows = vectors[torch.from_numpy(uniq).to(vectors.device)].cpu().numpy()
         remap = np.full(Ic.shape, -1, np.int64)
         remap[Ic >= 0] = inv
-        Dr, Ir = port.refine(ob.L2, rows, q, remap, a.k)
-        Ir = np.where(Ir >= 0, uniq[np.clip(Ir, 0, None)], -1)
-        dt += (time.time() - t2) / (cores if kind == "reference" else 1)
-        Ic = Ir
+        Dr2, Ir2 = port.refine(metric, rows, q, remap, a.k)
+        Ir2 = np.where(Ir2 >= 0, uniq[np.clip(Ir2, 0, None)], -1)
+        dt += (time.time() - t2) / cores  # (the re-rank runs single-threaded here; charged as if spread over the cores)
+        final_id = float((Ir2 == I_gpu[:nqs].cpu().numpy()).mean())
+        final_dist = float((Dr2.view(np.uint32) == D_gpu[:nqs].cpu().numpy().view(np.uint32)).mean())
     else:
-        Ic = Ic[:, :a.k]
-    agree = float((Ic == I_gpu[:nqs].cpu().numpy()).mean())
-    log(0, f"cpu baseline ({kind}): {nqs} queries in {dt:.2f}s on {cores} thread(s); "
-           f"id agreement with the GPU result {agree:.4f}")
-    return {"value": round(nqs / dt, 2), "unit": "queries/s", "cores": cores, "kind": kind,
-            "sample": f"first {nqs} of the {a.nq} queries, same index bytes, one query per task, "
-                      f"scalar (SIMDLevel::NONE) FAISS build, omp=1 inside each task",
-            "gpu_id_agreement_on_sample": round(agree, 4)}
+        final_id = float((Ic[:, :a.k] == I_gpu[:nqs].cpu().numpy()).mean())
+        final_dist = float((Dc[:, :a.k].view(np.uint32) == D_gpu[:nqs].cpu().numpy().view(np.uint32)).mean())
+    return {"value": round(nqs / dt, 2), "unit": "queries/s", "cores": cores,
+            "kind": "reference" if simd_used != "port" else "port",
+            "simd": {"avx2": "AVX2 (dynamic dispatch build, cmake/libs/libfaiss.cmake:388-463 shape, -O3)",
+                     "scalar": "none (SIMDLevel::NONE build, -O2)", "port": "none (oracle.c)"}[simd_used],
+            "sample": f"first {nqs} of the {a.nq} queries ({nqs / max(cores, 1):.1f} per thread), same index bytes, "
+                      f"one query per task, omp=1 inside each task",
+            "gpu_vs_scalar_reference_first_stage": {"checked_against": chk, "ids_equal": round(id_equal, 6),
+                                                    "distances_bit_equal": round(dist_equal, 6)},
+            "gpu_final_ids_equal": round(final_id, 6), "gpu_final_distances_bit_equal": round(final_dist, 6)}
 
 
 if __name__ == "__main__":

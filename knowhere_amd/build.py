@@ -67,7 +67,15 @@ class DataSpec:
         which = torch.randint(0, self.ncenter, (m,), device=device, generator=g)
         x = self._component(m, device, g)
         x += cen[which]
+        if self.kind == "int8":
+            x = self._to_int8_valued(x)
         return x
+
+    @staticmethod
+    def _to_int8_valued(x):
+        """"int8" inputs in Knowhere are int8 vectors converted to fp32 before training / SQ8 encoding
+        (reference include/knowhere/index/index_factory.h:144-145): integer-valued fp32 in [-128, 127]"""
+        return torch.round(x * 32.0).clamp_(-128.0, 127.0)
 
     def nchunks(self):
         return (self.n + CHUNK - 1) // CHUNK
@@ -108,16 +116,24 @@ def queries(spec, nq, device, seed=44):
         return torch.rand((nq, spec.d), device=device, generator=g) * 100.0
     cen = spec.centers(device)
     which = torch.randint(0, spec.ncenter, (nq,), device=device, generator=g)
-    return (spec._component(nq, device, g) + cen[which]).contiguous()
+    x = spec._component(nq, device, g) + cen[which]
+    if spec.kind == "int8":
+        x = spec._to_int8_valued(x)
+    return x.contiguous()
 
 
 # ---- nearest centroid (L2) in row blocks --------------------------------------------------------
-def _assign_l2(x, cen, cen_sq, block=1 << 17):
+def _assign_l2(x, cen, cen_sq, block=1 << 17, metric=0):
+    """nearest centroid: L2 (metric 0) or largest inner product (metric 1: the coarse quantizer of an IP index is
+    an IndexFlatIP, reference src/index/ivf/ivf.cc:592, 613, 641)"""
     out = torch.empty(x.shape[0], dtype=torch.int64, device=x.device)
     for lo in range(0, x.shape[0], block):
         xb = x[lo:lo + block]
-        dist = torch.addmm(cen_sq.unsqueeze(0), xb, cen.t(), beta=1.0, alpha=-2.0)  # ||c||^2 - 2 x.c
-        out[lo:lo + block] = dist.argmin(dim=1)
+        if metric == 1:
+            out[lo:lo + block] = (xb @ cen.t()).argmax(dim=1)
+        else:
+            dist = torch.addmm(cen_sq.unsqueeze(0), xb, cen.t(), beta=1.0, alpha=-2.0)  # ||c||^2 - 2 x.c
+            out[lo:lo + block] = dist.argmin(dim=1)
     return out
 
 
@@ -228,8 +244,8 @@ class BuiltIndex:
 
 
 def build_ivf(spec, kind, metric, nlist, M=32, device="cuda:0", train_per_centroid=256, niter=25,
-              pq_train=1 << 20, centroids=None, codebooks=None, row_range=None, verbose=False,
-              keep_vectors=False, train_only=False):
+              pq_train=1 << 20, centroids=None, codebooks=None, sq_trained=None, row_range=None, verbose=False,
+              keep_vectors=False, train_only=False, owned_lists=None):
     """Train (unless centroids/codebooks are given, e.g. broadcast from rank 0) and encode
     rows [row_range) of the synthetic data set.  Returns a BuiltIndex on `device`.
     Clustering defaults are the reference's: 25 iterations, at most 256 training points per centroid
@@ -254,13 +270,15 @@ def build_ivf(spec, kind, metric, nlist, M=32, device="cuda:0", train_per_centro
     t0 = time.time()
     if kind == IVF_PQ and codebooks is None:
         xt = spec.sample(min(spec.n, pq_train), dev, seed=4321)
-        a = _assign_l2(xt, centroids, cen_sq)
+        a = _assign_l2(xt, centroids, cen_sq, metric=metric)
         codebooks = train_pq(xt - centroids[a], M, niter=niter)
         del xt, a
     out.codebooks = codebooks
-    if kind == IVF_SQ8:
+    if kind == IVF_SQ8 and sq_trained is not None:
+        out.sq_trained = sq_trained
+    elif kind == IVF_SQ8:
         xt = spec.sample(min(spec.n, pq_train), dev, seed=4321)
-        a = _assign_l2(xt, centroids, cen_sq)
+        a = _assign_l2(xt, centroids, cen_sq, metric=metric)
         r = xt - centroids[a]
         vmin = r.min(0).values
         vdiff = r.max(0).values - vmin  # RS_minmax, rangestat_arg 0 (ScalarQuantizer.h:67-74)
@@ -272,8 +290,9 @@ def build_ivf(spec, kind, metric, nlist, M=32, device="cuda:0", train_per_centro
         return out
     t0 = time.time()
     lo, hi = row_range if row_range is not None else (0, spec.n)
-    assign_parts, code_parts = [], []
-    vectors = torch.empty((hi - lo, d), device=dev) if keep_vectors else None
+    assign_parts, code_parts, id_parts, vec_parts = [], [], [], []
+    own_t = torch.from_numpy(np.asarray(owned_lists, bool)).to(dev) if owned_lists is not None else None
+    vectors = torch.empty((hi - lo, d), device=dev) if (keep_vectors and own_t is None) else None
     vpos = 0
     c0, c1 = lo // CHUNK, (hi + CHUNK - 1) // CHUNK
     for c in range(c0, c1):
@@ -281,8 +300,13 @@ def build_ivf(spec, kind, metric, nlist, M=32, device="cuda:0", train_per_centro
         a_lo = max(lo - c * CHUNK, 0)
         a_hi = min(hi - c * CHUNK, x.shape[0])
         x = x[a_lo:a_hi]
-        a = _assign_l2(x, centroids, cen_sq)
+        a = _assign_l2(x, centroids, cen_sq, metric=metric)
+        rid = torch.arange(c * CHUNK + a_lo, c * CHUNK + a_hi, device=dev, dtype=torch.int64)
+        if own_t is not None:
+            keep = own_t[a]
+            x, a, rid = x[keep], a[keep], rid[keep]
         assign_parts.append(a.to(torch.int32))
+        id_parts.append(rid)
         if kind == IVF_PQ:
             code_parts.append(pq_encode(x - centroids[a], codebooks))
         elif kind == IVF_SQ8:
@@ -293,25 +317,34 @@ def build_ivf(spec, kind, metric, nlist, M=32, device="cuda:0", train_per_centro
         else:
             code_parts.append(x.contiguous().view(torch.uint8).reshape(x.shape[0], d * 4))
         if keep_vectors:
-            vectors[vpos:vpos + x.shape[0]] = x
-            vpos += x.shape[0]
+            if own_t is None:
+                vectors[vpos:vpos + x.shape[0]] = x
+                vpos += x.shape[0]
+            else:
+                vec_parts.append(x.contiguous())
         if verbose and (c - c0) % 16 == 0:
             print(f"  encoded chunk {c - c0 + 1}/{c1 - c0}", flush=True)
     assign = torch.cat(assign_parts).to(torch.int64)
     del assign_parts
     codes = torch.cat(code_parts)
     del code_parts
+    row_ids = torch.cat(id_parts)
+    del id_parts
     torch.cuda.synchronize(dev)
     out.timings["encode_s"] = time.time() - t0
     t0 = time.time()
     order = torch.sort(assign, stable=True).indices  # stable: ids stay ascending inside a list
     out.codes = codes[order].contiguous()
     del codes
-    out.ids = (order + lo).contiguous()
+    out.ids = row_ids[order].contiguous()
     counts = torch.bincount(assign, minlength=nlist).cpu().numpy().astype(np.int64)
     out.list_offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
-    if keep_vectors:
+    if keep_vectors and own_t is not None:
+        out.vectors = torch.cat(vec_parts) if vec_parts else torch.empty((0, d), device=dev)
+        out.vector_ids = row_ids  # ascending: rows were visited in id order
+    elif keep_vectors:
         out.vectors = vectors  # row r <-> id lo + r
+        out.vector_ids = None if lo == 0 else row_ids
     torch.cuda.synchronize(dev)
     out.timings["sort_s"] = time.time() - t0
     return out

@@ -25,6 +25,19 @@ def _t_ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+def _bitset_nbits(bitset, nbits):
+    """a bitset without a bit count covers all its bytes (the C side ignores a bitset whose nbits <= 0, which
+    would silently return filtered ids)"""
+    if bitset is None:
+        return 0
+    n = int(bitset.numel() if hasattr(bitset, "numel") else bitset.size)
+    if nbits is None or nbits <= 0:
+        return 8 * n
+    if nbits > 8 * n:
+        raise ValueError(f"bitset of {n} bytes cannot hold {nbits} bits")
+    return int(nbits)
+
+
 class GpuIndex:
     def __init__(self, kind, metric, dim, nlist=0, pq_m=0, pq_nbits=8, device=0,
                  precomputed_table_max_bytes=0):
@@ -132,6 +145,7 @@ class GpuIndex:
         D = np.empty((nq, k), np.float32)
         I = np.empty((nq, k), np.int64)
         bs = None if bitset is None else np.ascontiguousarray(bitset, np.uint8)
+        nbits = _bitset_nbits(bs, nbits)
         check(self.L.knhip_search(self.h, _np_ptr(xq), nq, k, nprobe, _np_ptr(bs), nbits, _np_ptr(I), _np_ptr(D)))
         return D, I
 
@@ -142,6 +156,7 @@ class GpuIndex:
         lims = np.zeros(nq + 1, np.int64)
         pi, pd = C.POINTER(C.c_int64)(), C.POINTER(C.c_float)()
         bs = None if bitset is None else np.ascontiguousarray(bitset, np.uint8)
+        nbits = _bitset_nbits(bs, nbits)
         check(self.L.knhip_range_search(self.h, _np_ptr(xq), nq, float(radius), int(max_empty_result_buckets),
                                         _np_ptr(bs), nbits, _np_ptr(lims), C.byref(pi), C.byref(pd)))
         n = int(lims[-1])
@@ -160,6 +175,7 @@ class GpuIndex:
         else:
             D, I = out
         s = torch.cuda.current_stream(xq_t.device).cuda_stream if stream is None else stream
+        nbits = _bitset_nbits(bitset_t, nbits)
         check(self.L.knhip_search_device(self.h, _t_ptr(xq_t), nq, k, nprobe, _t_ptr(bitset_t), nbits,
                                          _t_ptr(I), _t_ptr(D), C.c_void_p(s)))
         return D, I
@@ -172,6 +188,7 @@ class GpuIndex:
         D = torch.empty((nq, k), dtype=torch.float32, device=xq_t.device)
         I = torch.empty((nq, k), dtype=torch.int64, device=xq_t.device)
         s = torch.cuda.current_stream(xq_t.device).cuda_stream if stream is None else stream
+        nbits = _bitset_nbits(bitset_t, nbits)
         check(self.L.knhip_search_preassigned_device(self.h, _t_ptr(xq_t), nq, k, nprobe, _t_ptr(keys_t), _t_ptr(cdis_t),
                                                      _t_ptr(bitset_t), nbits, _t_ptr(I), _t_ptr(D), C.c_void_p(s)))
         return D, I

@@ -11,8 +11,11 @@ the top-k of the union of per-shard top-k.
   * inverted lists: partitioned by a size-balanced deal (longest list first to the lightest rank)
   * every rank receives the full query batch, runs the same coarse search, scans only the probes
     whose lists it owns (unowned lists are simply empty in its knhip_index)
-  * ONE collective on the data path: all-gather of the per-rank (nq, k) partial (distance, id)
-    pairs -- 12 bytes per entry, 1.2 MB per rank at nq=10^4, k=10 -- then knhip_merge_topk_device.
+  * every rank builds, encodes and keeps ONLY the rows of the lists it owns -- codes, ids and (for `refine`)
+    the raw fp32 vectors: a PQ candidate found in a rank's lists is re-ranked against that rank's own rows
+  * collectives on the data path: one all-gather of the query-sharded coarse assignment (keys + distances in one
+    packed buffer) and ONE all-gather of the per-rank final (nq, k) partial (distance, id) pairs, packed in one
+    12-byte-per-entry buffer -- 1.2 MB per rank at nq=10^4, k=10 -- then knhip_merge_topk_device.
     xGMI is point-to-point; at this size the all-gather is latency-bound, not link-bound.
 """
 import numpy as np
@@ -35,22 +38,36 @@ def partition_lists(sizes, world):
     return [owner == r for r in range(world)]
 
 
-def owned_id_mask(built, owned):
-    """boolean device tensor over ids: True where the id's list is owned by this rank"""
-    off = built.list_offsets
-    keep = torch.from_numpy(np.repeat(np.asarray(owned, bool), off[1:] - off[:-1])).to(built.ids.device)
-    n = int(built.ids.max().item()) + 1 if built.ids.numel() else 0
-    mask = torch.zeros(n, dtype=torch.bool, device=built.ids.device)
-    mask[built.ids[keep]] = True
-    return mask
+def global_list_sizes(comm, spec, centroids, metric, rank, world, device):
+    """sizes of all inverted lists: every rank assigns its 1/world slice of the rows, one all-reduce sums the counts"""
+    from . import build as kb
+    nlist = centroids.shape[0]
+    cnt = torch.zeros(nlist, dtype=torch.int64, device=device)
+    cen_sq = (centroids * centroids).sum(1)
+    nch = spec.nchunks()
+    for c in range(rank, nch, world):
+        a = kb._assign_l2(spec.chunk(c, device), centroids, cen_sq, metric=metric)
+        cnt += torch.bincount(a, minlength=nlist)
+    return comm.allreduce_sum(cnt).cpu().numpy()
 
 
-def mask_unowned(cand_ids, own_mask):
-    """candidate ids this rank cannot re-rank become -2 (= skip; -1 still ends the row)"""
+def row_lookup(vector_ids, nb, device):
+    """sorted ids of the raw vectors this rank holds (device int64)"""
+    return vector_ids.to(device).contiguous()
+
+
+def ids_to_rows(cand_ids, sorted_ids):
+    """candidate ids -> rows of this rank's raw-vector block; ids it does not hold become -2 (= skip; -1 still
+    ends a candidate row)"""
     valid = cand_ids >= 0
-    safe = cand_ids.clamp(min=0)
-    own = own_mask[safe] & valid
-    return torch.where(own, cand_ids, torch.where(valid, torch.full_like(cand_ids, -2), cand_ids))
+    pos = torch.searchsorted(sorted_ids, cand_ids.clamp(min=0))
+    pos_c = pos.clamp(max=max(sorted_ids.numel() - 1, 0))
+    hit = valid & (sorted_ids[pos_c] == cand_ids) if sorted_ids.numel() else torch.zeros_like(valid)
+    return torch.where(hit, pos_c, torch.where(valid, torch.full_like(cand_ids, -2), cand_ids))
+
+
+def rows_to_ids(rows, sorted_ids):
+    return torch.where(rows >= 0, sorted_ids[rows.clamp(min=0)], rows)
 
 
 class Comm:
@@ -90,10 +107,28 @@ class Comm:
         dist.all_gather_into_tensor(out, s) if self.backend != "gloo" else dist.all_gather(list(out.unbind(0)), s)
         return out.to(t.device) if out.device != t.device else out
 
+    def allreduce_sum(self, t):
+        s = self._stage(t)
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        return s.to(t.device) if s.device != t.device else s
+
+    @staticmethod
+    def pack(D, I):
+        """(float32, int64) [n, k] -> one int32 [n, k, 3] buffer: 12 bytes per entry, ONE collective"""
+        buf = torch.empty(D.shape + (3,), dtype=torch.int32, device=D.device)
+        buf[..., 0] = D.contiguous().view(torch.int32)
+        buf[..., 1:] = I.contiguous().view(torch.int32).reshape(I.shape + (2,))
+        return buf
+
+    @staticmethod
+    def unpack(buf):
+        D = buf[..., 0].contiguous().view(torch.float32)
+        I = buf[..., 1:].contiguous().view(torch.int64).reshape(buf.shape[:-1])
+        return D, I
+
     def allgather_merge(self, metric, D, I):
-        """per-rank partial (nq, k) results -> global (nq, k), identical on every rank"""
-        Dp = self.allgather(D)
-        Ip = self.allgather(I)
+        """per-rank partial (nq, k) results -> global (nq, k), identical on every rank; one packed all-gather"""
+        Dp, Ip = self.unpack(self.allgather(self.pack(D, I)))
         if D.is_cuda:
             return kidx.merge_topk_device(metric, Dp, Ip)
         Dm, Im = kidx.merge_topk_host(metric, Dp.numpy(), Ip.numpy())
@@ -101,7 +136,7 @@ class Comm:
 
 
 def sharded_coarse(comm, coarse_fn, nq, nprobe, device=None):
-    """Coarse quantizer sharded by QUERIES: rank r assigns queries [r * per, (r + 1) * per), one all-gather each of the
+    """Coarse quantizer sharded by QUERIES: rank r assigns queries [r * per, (r + 1) * per), one packed all-gather of the
     keys and the coarse distances gives every rank the full (nq, nprobe) assignment for
     knhip_search_preassigned_device (= IndexIVF::search_preassigned).
     coarse_fn(lo, hi) -> (coarse_dis [hi - lo, nprobe] float32, keys [hi - lo, nprobe] int64) tensors."""
@@ -113,6 +148,5 @@ def sharded_coarse(comm, coarse_fn, nq, nprobe, device=None):
         cd, ck = coarse_fn(lo, hi)
         keys_loc[:hi - lo] = ck
         cdis_loc[:hi - lo] = cd
-    keys = comm.allgather(keys_loc).reshape(-1, nprobe)[:nq].contiguous()
-    cdis = comm.allgather(cdis_loc).reshape(-1, nprobe)[:nq].contiguous()
-    return keys, cdis
+    cdis, keys = comm.unpack(comm.allgather(comm.pack(cdis_loc, keys_loc)))  # one packed collective
+    return keys.reshape(-1, nprobe)[:nq].contiguous(), cdis.reshape(-1, nprobe)[:nq].contiguous()

@@ -322,23 +322,26 @@ def make_index(port, kind, metric, xb, nlist=16, M=8, nbits=8, seed=123, ids=Non
 
 
 class Ref:
-    """oracle/_ref/libknowhere_ref.so -- the reference's own FAISS, driven Knowhere-style."""
+    """oracle/_ref/libknowhere_ref*.so -- the reference's own FAISS, driven Knowhere-style.
+    simd = "scalar": the SIMDLevel::NONE build every parity pin uses; "avx2": the dynamic-dispatch AVX2 build
+    (oracle/Makefile ref_avx2), used ONLY as the timed cpu_baseline of bench.py."""
 
     @staticmethod
-    def path():
-        return os.path.join(_HERE, "_ref", "libknowhere_ref.so")
+    def path(simd="scalar"):
+        name = "libknowhere_ref.so" if simd == "scalar" else f"libknowhere_ref_{simd}.so"
+        return os.path.join(_HERE, "_ref", name)
 
     @staticmethod
-    def available():
-        if not os.path.exists(Ref.path()):
+    def available(simd="scalar"):
+        if not os.path.exists(Ref.path(simd)):
             return False
         try:
-            Ref()
+            Ref(simd)
             return True
         except OSError:
             return False
 
-    def __init__(self):
+    def __init__(self, simd="scalar"):
         # libmkl_rt picks its threading layer at load time
         os.environ.setdefault("MKL_THREADING_LAYER", "GNU")
         # the .so was linked against MKL by full path (oracle/Makefile); preload it the same way so
@@ -348,7 +351,10 @@ class Ref:
             if os.path.exists(mkl):
                 C.CDLL(mkl, mode=C.RTLD_GLOBAL)
                 break
-        self.lib = L = C.CDLL(Ref.path(), mode=C.RTLD_GLOBAL)
+        # local + deep binding: the scalar and the AVX2 build define the same faiss symbols and may live in one
+        # process; each must call its own
+        self.simd = simd
+        self.lib = L = C.CDLL(Ref.path(simd), mode=os.RTLD_LOCAL | os.RTLD_DEEPBIND | os.RTLD_NOW)
         L.ref_create.restype = C.c_void_p
         L.ref_deserialize.restype = C.c_void_p
         L.ref_serialize.restype = C.c_int64
@@ -358,6 +364,9 @@ class Ref:
         L.ref_fvec_L2sqr.restype = C.c_float
         L.ref_fvec_inner_product.restype = C.c_float
         L.ref_fvec_norm_L2sqr.restype = C.c_float
+
+    def free(self, h):
+        self.destroy(h)
 
     def _chk(self, rc):
         if rc != 0:

@@ -645,11 +645,11 @@ int orc_refine(int metric, int d, const float* base, int64_t nbase, int64_t id_b
         orc_heap_heapify(is_max, (size_t)k, simi, idxi);
         for (int64_t j = 0; j < k_base; j++) {
             const int64_t id = cand_ids[i * k_base + j];
-            if (id < 0) {
+            if (id == -1) {
                 break; /* entries after the first -1 are all -1 (sentinel tail): nothing to add */
             }
             if (id - id_base < 0 || id - id_base >= nbase) {
-                continue;
+                continue; /* (also any other negative id: a candidate another shard re-ranks) */
             }
             const float* y = base + (id - id_base) * (int64_t)d;
             const float dis = is_max ? orc_fvec_L2sqr(q, y, (size_t)d)

@@ -60,21 +60,42 @@ def _worker(rank, world, port_no, ret):
     b = torch.full((3,), float(rank))
     comm.broadcast(b, 0)
     assert (b == 0).all()
-    # refine ownership masking: -1 ends a row, unowned -> -2
-    own = torch.zeros(10, dtype=torch.bool)
-    own[[1, 3]] = True
-    m = sharded.mask_unowned(torch.tensor([[1, 2, 3, -1]]), own)
-    assert m.tolist() == [[1, -2, 3, -1]]
+    # refine ownership (bench.py's N > 1 step): the global top-kbase PQ candidates (all-gather + merge) are re-ranked
+    # by the rank that holds their raw vectors (kept only for owned lists); a second packed all-gather + merge ==
+    # the monolithic IndexRefine result, bit for bit
+    kbase, k = 40, 10
+    own_ids = np.sort(np.concatenate([i for l, i in enumerate(ix.list_ids) if masks[rank][l]] or
+                                     [np.empty(0, np.int64)]))
+    own_rows = xb[own_ids]
+    Dc, Ic = port.ivf_search_preassigned(sub, xq2, kbase, keys.numpy(), cdis.numpy())
+    Dcu, Icu = comm.allgather_merge(ob.L2, torch.from_numpy(Dc), torch.from_numpy(Ic))
+    Dc0, Ic0 = port.search(ix, xq2, kbase, 8)
+    assert_parity(Dc0, Ic0, Dcu.numpy(), Icu.numpy(), ob.L2, "first stage union == monolithic")
+    rows = sharded.ids_to_rows(Icu, torch.from_numpy(own_ids))
+    Dr, Rr = port.refine(ob.L2, own_rows, xq2, rows.numpy(), k)
+    Ir = sharded.rows_to_ids(torch.from_numpy(Rr), torch.from_numpy(own_ids))
+    D3, I3 = comm.allgather_merge(ob.L2, torch.from_numpy(Dr), Ir)
+    D30, I30 = port.refine(ob.L2, xb, xq2, Icu.numpy(), k)
+    assert_parity(D30, I30, D3.numpy(), I3.numpy(), ob.L2, f"rank {rank}: owner-side refine == monolithic refine")
+    # ids this rank does not hold -> -2 (skipped by the re-rank), -1 still ends a row
+    m = sharded.ids_to_rows(torch.tensor([[1, 2, 3, -1]]), torch.tensor([1, 3, 7]))
+    assert m.tolist() == [[0, -2, 1, -1]]
+    assert sharded.rows_to_ids(m, torch.tensor([1, 3, 7])).tolist() == [[1, -2, 3, -1]]
+    # the packed buffer round-trips (float32, int64) exactly
+    Dx, Ix = comm.unpack(comm.pack(torch.from_numpy(Dl), torch.from_numpy(Il)))
+    assert torch.equal(Dx.view(torch.int32), torch.from_numpy(Dl).view(torch.int32)) and torch.equal(Ix, torch.from_numpy(Il))
+    s = comm.allreduce_sum(torch.tensor([rank + 1]))
+    assert int(s.item()) == world * (world + 1) // 2
     dist.barrier()
     dist.destroy_process_group()
     ret[rank] = 1
 
 
-def test_list_sharding_allgather_merge_world2():
-    world = 2
+@pytest.mark.parametrize("world", [2, 4])
+def test_list_sharding_allgather_merge(world):
     mgr = mp.Manager()
     ret = mgr.dict()
-    port_no = 29500 + (os.getpid() % 2000)
+    port_no = 29500 + (os.getpid() % 2000) + world
     mp.spawn(_worker, args=(world, port_no, ret), nprocs=world, join=True)
     assert len(ret) == world
 
