@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define KNHIP_ABI_VERSION 1
+#define KNHIP_ABI_VERSION 2
 
 typedef struct knhip_index knhip_index;
 
@@ -119,6 +119,49 @@ int knhip_index_set_lists_device(knhip_index* idx, const int64_t* list_offsets,
                                  const uint8_t* d_codes, const int64_t* d_ids);
 int knhip_index_add_vectors_device(knhip_index* idx, int64_t n, const float* d_x,
                                    const int64_t* d_ids, int64_t id_offset);
+
+/* ---- GPU build: Train / Add on the device ------------------------------------------------------------
+ * Replaces the arithmetic of IvfIndexNode::Train / Add (reference src/index/ivf/ivf.cc:547-844):
+ *   knhip_index_train*   IndexIVF::train (thirdparty/faiss/faiss/IndexIVF.cpp:1175-1270) = Level1Quantizer::train_q1
+ *                        (:55-121, Clustering::train with the index's own exact search as the assigner,
+ *                        Clustering.cpp:95-380, impl/ClusteringHelpers.cpp:36-240) + train_encoder:
+ *                        ProductQuantizer::train (impl/ProductQuantizer.cpp:130-215, one 256-centroid k-means per
+ *                        sub-space on residuals) / ScalarQuantizer::train (QT_8bit, RS_minmax).  Same sub-sampling
+ *                        draws (rand_perm with the reference's seeds), same initial centroids, same update and
+ *                        empty-cluster split arithmetic; the assignment is the exact sequential search (the
+ *                        reference switches to a BLAS expansion above its batch threshold: near-ties may differ).
+ *                        Coarse centroids already set (knhip_index_set_coarse*) are kept.
+ *   knhip_index_add*     IndexIVF::add_core (IndexIVF.cpp:212-287): quantizer->assign, encode_vectors
+ *                        (compute_residual + ProductQuantizer::compute_code / SQ8 encode_vector), append to the
+ *                        inverted lists.  May be called repeatedly; ids NULL => running numbers continuing the
+ *                        current count (what Knowhere passes), otherwise ascending ids larger than the stored ones.
+ *                        Codes and assignments are bit-equal to the scalar reference (oracle.c orc_pq_encode ...).
+ *   knhip_kmeans_device  the Clustering restatement alone (k-means of device rows).
+ * params NULL or zero fields => the reference defaults (25 iterations, 256 points per centroid, seed 1234). */
+typedef struct knhip_train_params {
+    int32_t niter;
+    int32_t max_points_per_centroid;
+    int64_t seed;
+} knhip_train_params;
+int knhip_kmeans_device(int32_t metric, int32_t dim, int64_t n, const float* d_x, int64_t k,
+                        const knhip_train_params* params, float* d_centroids, int32_t device);
+int knhip_index_train(knhip_index* idx, int64_t n, const float* x, const knhip_train_params* params);
+int knhip_index_train_device(knhip_index* idx, int64_t n, const float* d_x, const knhip_train_params* params);
+int knhip_index_add(knhip_index* idx, int64_t n, const float* x, const int64_t* ids);
+int knhip_index_add_device(knhip_index* idx, int64_t n, const float* d_x, const int64_t* d_ids);
+/* assignment + codes of n device rows without adding them: d_assign [n] int64, d_codes [n][code_size] */
+int knhip_index_encode_device(const knhip_index* idx, int64_t n, const float* d_x, int64_t* d_assign, uint8_t* d_codes,
+                              void* stream);
+/* read the trained state / the inverted lists back (host buffers): Serialize needs the faiss objects
+ * (src/index/ivf/ivf.cc:1717-1744).  get_lists: codes [count][code_size] and ids [count], list after list
+ * (get_list_sizes gives the split); BRUTE_FORCE: codes = the raw fp32 rows, ids unused */
+int knhip_index_get_coarse(const knhip_index* idx, float* centroids);
+int knhip_index_get_pq(const knhip_index* idx, float* codebooks);
+int knhip_index_get_sq(const knhip_index* idx, float* vmin, float* vdiff);
+int knhip_index_get_list_sizes(const knhip_index* idx, int64_t* sizes);
+int knhip_index_get_lists(const knhip_index* idx, uint8_t* codes, int64_t* ids);
+/* BRUTE_FORCE: device pointer to the resident raw rows [count][dim] (valid until the next Add / destroy) */
+int knhip_index_get_vectors_device(const knhip_index* idx, const float** d_rows);
 
 int64_t knhip_index_count(const knhip_index* idx);         /* stored vectors */
 int64_t knhip_index_device_bytes(const knhip_index* idx);  /* HBM held by the index */

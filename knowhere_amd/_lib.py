@@ -44,7 +44,15 @@ SYMBOLS = [
     "knhip_fvec_norms_L2sqr", "knhip_fvec_madd", "knhip_int8_vec_L2sqr_ny",
     "knhip_int8_vec_inner_products_ny", "knhip_profile_enable", "knhip_profile_reset",
     "knhip_profile_get", "knhip_stage_kernel_name", "knhip_range_search", "knhip_free", "knhip_search_preassigned_device",
+    "knhip_kmeans_device", "knhip_index_train", "knhip_index_train_device", "knhip_index_add", "knhip_index_add_device",
+    "knhip_index_encode_device", "knhip_index_get_coarse", "knhip_index_get_pq", "knhip_index_get_sq",
+    "knhip_index_get_list_sizes", "knhip_index_get_lists", "knhip_index_get_vectors_device",
 ]
+
+
+class TrainParams(C.Structure):
+    _fields_ = [("niter", C.c_int32), ("max_points_per_centroid", C.c_int32), ("seed", C.c_int64)]
+
 
 _lib = None
 
@@ -95,6 +103,19 @@ def load():
         getattr(L, f).argtypes = [vp, vp, vp, i64, i64, vp]
     L.knhip_fvec_norms_L2sqr.argtypes = [vp, vp, i64, i64, vp]
     L.knhip_fvec_madd.argtypes = [i64, vp, C.c_float, vp, vp, vp]
+    tpp = C.POINTER(TrainParams)
+    L.knhip_kmeans_device.argtypes = [i32, i32, i64, vp, i64, tpp, vp, i32]
+    L.knhip_index_train.argtypes = [vp, i64, vp, tpp]
+    L.knhip_index_train_device.argtypes = [vp, i64, vp, tpp]
+    L.knhip_index_add.argtypes = [vp, i64, vp, vp]
+    L.knhip_index_add_device.argtypes = [vp, i64, vp, vp]
+    L.knhip_index_encode_device.argtypes = [vp, i64, vp, vp, vp, vp]
+    L.knhip_index_get_coarse.argtypes = [vp, vp]
+    L.knhip_index_get_pq.argtypes = [vp, vp]
+    L.knhip_index_get_sq.argtypes = [vp, vp, vp]
+    L.knhip_index_get_list_sizes.argtypes = [vp, vp]
+    L.knhip_index_get_lists.argtypes = [vp, vp, vp]
+    L.knhip_index_get_vectors_device.argtypes = [vp, C.POINTER(vp)]
     L.knhip_profile_enable.argtypes = [vp, C.c_int]
     L.knhip_profile_reset.argtypes = [vp]
     L.knhip_profile_get.argtypes = [vp, C.POINTER(StageTimes)]

@@ -1,0 +1,385 @@
+// knowhere_amd/csrc/build.hip -- Train / Add on the device: the kernels behind knhip_index_train* / knhip_index_add*.
+//
+// What they restate (reference, all under thirdparty/faiss/faiss unless noted):
+//   k-means            Clustering::train_encoded (Clustering.cpp:150-380): assignment by the index's own exact search
+//                      (k = 1), detail::compute_centroids (impl/ClusteringHelpers.cpp:101-171: members summed in
+//                      index order, then scaled by 1 / count), detail::split_clusters (:177-240, on the host).
+//   residual           Index::compute_residual (Index.cpp): x - centroid, element-wise.
+//   PQ encode          ProductQuantizer::compute_code (impl/ProductQuantizer.cpp:230-299) ->
+//                      fvec_L2sqr_ny_nearest (utils/distances_simd.cpp:106-125): exact squared L2 to the 256 entries of
+//                      sub-quantizer m in scalar order, FIRST minimum wins.
+//   SQ8 encode         QuantizerTemplate<Codec8bit, NON_UNIFORM>::encode_vector (impl/scalar_quantizer/quantizers.h:
+//                      108-146) + Codec8bit::encode_component (codecs.h:26-35): xi = (x - vmin) / vdiff clamped to
+//                      [0, 1] (0 when vdiff == 0), code = (int)(255 * xi).
+//   SQ8 training       train_NonUniform / train_Uniform with RS_minmax, rangestat_arg = 0 (impl/ScalarQuantizer.cpp,
+//                      trained = vmin[d], vdiff[d]).
+// Every distance is the scalar sequential form with one rounding per operation (common.h), so codes and assignments are
+// bit-equal to the scalar reference given the same codebooks / centroids (tests/test_gpu_build.py vs oracle.c).
+#include "common.h"
+#include "kernels.h"
+
+#include <hipcub/hipcub.hpp>
+
+namespace knhip {
+
+__global__ void gather_rows_kernel(const float* __restrict__ x, const int64_t* __restrict__ rows, int64_t n, int d,
+                                   float* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * d) {
+        return;
+    }
+    const int64_t i = t / d;
+    const int j = (int)(t % d);
+    out[t] = x[rows[i] * d + j];
+}
+
+hipError_t launch_gather_rows(const float* x, const int64_t* rows, int64_t n, int d, float* out, hipStream_t s) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n * d + 255) / 256)), dim3(256), 0, s, x, rows, n, d, out);
+    return hipGetLastError();
+}
+
+__global__ void residual_kernel(const float* __restrict__ x, const float* __restrict__ cen,
+                                const int64_t* __restrict__ assign, int64_t n, int d, float* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * d) {
+        return;
+    }
+    const int64_t i = t / d;
+    const int j = (int)(t % d);
+    const int64_t a = assign[i];
+    out[t] = a >= 0 ? fsub_x(x[t], cen[a * d + j]) : x[t];
+}
+
+hipError_t launch_residual(const float* x, const float* cen, const int64_t* assign, int64_t n, int d, float* out,
+                           hipStream_t s) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(residual_kernel, dim3((unsigned)((n * d + 255) / 256)), dim3(256), 0, s, x, cen, assign, n, d, out);
+    return hipGetLastError();
+}
+
+// ---- nearest of a small codebook (<= 1024 entries x dsub dims, in LDS): one thread per vector ----------------------
+// x rows have leading dimension ld, the sub-vector starts at column off.  grid.y walks `nbook` codebooks laid out
+// [nbook][ksub][dsub] with sub-vector offsets off + y * dsub and output column y (PQ encode); nbook = 1 otherwise.
+template <class OutT>
+__global__ __launch_bounds__(256) void nearest_small_kernel(const float* __restrict__ x, int64_t n, int64_t ld, int off,
+                                                            int dsub, const float* __restrict__ cb, int ksub,
+                                                            OutT* __restrict__ out, int64_t out_ld) {
+    extern __shared__ float s_cb[]; // [ksub][dsub]
+    const int book = blockIdx.y;
+    const float* cbm = cb + (int64_t)book * ksub * dsub;
+    for (int e = threadIdx.x; e < ksub * dsub; e += blockDim.x) {
+        s_cb[e] = cbm[e];
+    }
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) {
+        return;
+    }
+    const float* xi = x + i * ld + off + (int64_t)book * dsub;
+    int best = 0;
+    float best_d = HUGE_VALF;
+    if (dsub <= 8) {
+        float xr[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            xr[t] = t < dsub ? xi[t] : 0.f;
+        }
+        for (int c = 0; c < ksub; c++) {
+            const float* y = s_cb + c * dsub;
+            float res = 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                if (t < dsub) {
+                    res = l2_step(res, xr[t], y[t]);
+                }
+            }
+            if (res < best_d) {
+                best_d = res;
+                best = c;
+            }
+        }
+    } else {
+        for (int c = 0; c < ksub; c++) {
+            const float* y = s_cb + c * dsub;
+            float res = 0.f;
+            for (int t = 0; t < dsub; t++) {
+                res = l2_step(res, xi[t], y[t]);
+            }
+            if (res < best_d) {
+                best_d = res;
+                best = c;
+            }
+        }
+    }
+    out[i * out_ld + book] = (OutT)best;
+}
+
+hipError_t launch_nearest_small(const float* x, int64_t n, int64_t ld, int off, int dsub, const float* cb, int ksub,
+                                int32_t* out_idx, hipStream_t s) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    const size_t sm = (size_t)ksub * dsub * sizeof(float);
+    auto kern = nearest_small_kernel<int32_t>;
+    if (sm > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)sm);
+        if (e != hipSuccess) {
+            return e;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)((n + 255) / 256), 1), dim3(256), sm, s, x, n, ld, off, dsub, cb, ksub, out_idx,
+                       (int64_t)1);
+    return hipGetLastError();
+}
+
+hipError_t launch_pq_encode(const float* resid, int64_t n, int d, int M, const float* cb, uint8_t* codes, hipStream_t s) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    const int dsub = d / M;
+    const size_t sm = (size_t)256 * dsub * sizeof(float);
+    auto kern = nearest_small_kernel<uint8_t>;
+    if (sm > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)sm);
+        if (e != hipSuccess) {
+            return e;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)((n + 255) / 256), (unsigned)M), dim3(256), sm, s, resid, n, (int64_t)d, 0, dsub,
+                       cb, 256, codes, (int64_t)M);
+    return hipGetLastError();
+}
+
+__global__ void sq8_encode_kernel(const float* __restrict__ r, int64_t n, int d, const float* __restrict__ trained,
+                                  uint8_t* __restrict__ codes) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * d) {
+        return;
+    }
+    const int j = (int)(t % d);
+    const float vmin = trained[j], vdiff = trained[d + j];
+    float xi = 0.f;
+    if (vdiff != 0.f) {
+        xi = __fdiv_rn(fsub_x(r[t], vmin), vdiff);
+        if (xi < 0.f) {
+            xi = 0.f;
+        }
+        if (xi > 1.0f) {
+            xi = 1.0f;
+        }
+    }
+    codes[t] = (uint8_t)(int)fmul_x(255.f, xi);
+}
+
+hipError_t launch_sq8_encode(const float* resid, int64_t n, int d, const float* trained, uint8_t* codes, hipStream_t s) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(sq8_encode_kernel, dim3((unsigned)((n * d + 255) / 256)), dim3(256), 0, s, resid, n, d, trained, codes);
+    return hipGetLastError();
+}
+
+// per column min / max over n rows: one workgroup per 64 columns, rows strided over waves (order independent)
+__global__ __launch_bounds__(256) void col_minmax_kernel(const float* __restrict__ x, int64_t n, int d, float* vmin,
+                                                         float* vmax) {
+    __shared__ float s_lo[4][64], s_hi[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int w = threadIdx.x >> 6;
+    float lo = HUGE_VALF, hi = -HUGE_VALF;
+    if (col < d) {
+        for (int64_t i = w; i < n; i += 4) {
+            const float v = x[i * d + col];
+            lo = fminf(lo, v);
+            hi = fmaxf(hi, v);
+        }
+    }
+    s_lo[w][threadIdx.x & 63] = lo;
+    s_hi[w][threadIdx.x & 63] = hi;
+    __syncthreads();
+    if (w == 0 && col < d) {
+        for (int u = 1; u < 4; u++) {
+            lo = fminf(lo, s_lo[u][threadIdx.x]);
+            hi = fmaxf(hi, s_hi[u][threadIdx.x]);
+        }
+        vmin[col] = lo;
+        vmax[col] = hi;
+    }
+}
+
+hipError_t launch_col_minmax(const float* x, int64_t n, int d, float* vmin, float* vmax, hipStream_t s) {
+    hipLaunchKernelGGL(col_minmax_kernel, dim3((unsigned)((d + 63) / 64)), dim3(256), 0, s, x, n, d, vmin, vmax);
+    return hipGetLastError();
+}
+
+// ---- k-means update ------------------------------------------------------------------------------------------------
+__global__ void keys_to_i32_kernel(const int64_t* __restrict__ keys, int64_t n, int32_t* __restrict__ out,
+                                   int32_t* __restrict__ iota, int32_t* counts) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) {
+        return;
+    }
+    const int32_t k = (int32_t)keys[t];
+    out[t] = k;
+    iota[t] = (int32_t)t;
+    if (counts != nullptr && k >= 0) {
+        atomicAdd(&counts[k], 1);
+    }
+}
+
+__global__ void iota_count_kernel(const int32_t* __restrict__ keys, int64_t n, int32_t* __restrict__ iota, int32_t* counts) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) {
+        return;
+    }
+    iota[t] = (int32_t)t;
+    const int32_t k = keys[t];
+    if (k >= 0) {
+        atomicAdd(&counts[k], 1);
+    }
+}
+
+size_t group_rows_tmp_bytes(int64_t n, int64_t k) {
+    size_t sort_b = 0, scan_b = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_b, (const int32_t*)nullptr, (int32_t*)nullptr,
+                                             (const int32_t*)nullptr, (int32_t*)nullptr, (int)n);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_b, (const int32_t*)nullptr, (int64_t*)nullptr, (int)(k + 1));
+    // layout: [keys32 n][iota n][keys_sorted n][counts k+1] + cub scratch
+    return (size_t)n * 12 + (size_t)(k + 1) * 4 + 256 + std::max(sort_b, scan_b) + 256;
+}
+
+// keys (int64 [n], or int32 if keys32 != nullptr) in [0, k) -> rows grouped by key, ascending row number inside a
+// group (stable sort), seg_off[k + 1]
+hipError_t group_rows_by_key(const int64_t* keys64, const int32_t* keys32_in, int64_t n, int64_t k, int32_t* sorted_rows,
+                             int64_t* seg_off, void* tmp, size_t tmp_bytes, hipStream_t s) {
+    if (n >= (int64_t)1 << 31 || k >= (int64_t)1 << 31) {
+        return hipErrorInvalidValue;
+    }
+    char* p = static_cast<char*>(tmp);
+    int32_t* keys32 = reinterpret_cast<int32_t*>(p);
+    int32_t* iota = keys32 + n;
+    int32_t* keys_sorted = iota + n;
+    int32_t* counts = keys_sorted + n;
+    char* cub_tmp = reinterpret_cast<char*>(((uintptr_t)(counts + k + 1) + 255) & ~(uintptr_t)255);
+    size_t cub_bytes = tmp_bytes - (size_t)(cub_tmp - p);
+    hipError_t e = hipMemsetAsync(counts, 0, (size_t)(k + 1) * 4, s);
+    if (e != hipSuccess) {
+        return e;
+    }
+    const unsigned g = (unsigned)((n + 255) / 256);
+    if (n > 0) {
+        if (keys32_in != nullptr) {
+            hipLaunchKernelGGL(iota_count_kernel, dim3(g), dim3(256), 0, s, keys32_in, n, iota, counts);
+        } else {
+            hipLaunchKernelGGL(keys_to_i32_kernel, dim3(g), dim3(256), 0, s, keys64, n, keys32, iota, counts);
+        }
+    }
+    int bits = 1;
+    while (((int64_t)1 << bits) < k) {
+        bits++;
+    }
+    size_t b = cub_bytes;
+    e = hipcub::DeviceRadixSort::SortPairs(cub_tmp, b, keys32_in != nullptr ? keys32_in : keys32, keys_sorted, iota,
+                                           sorted_rows, (int)n, 0, bits, s);
+    if (e != hipSuccess) {
+        return e;
+    }
+    b = cub_bytes;
+    return hipcub::DeviceScan::ExclusiveSum(cub_tmp, b, counts, seg_off, (int)(k + 1), s);
+}
+
+// one thread per (centroid, dim): members summed in row order, then scaled by 1 / count (compute_centroids)
+__global__ void centroid_update_kernel(const float* __restrict__ x, int64_t ld, int off, int dsub,
+                                       const int32_t* __restrict__ sorted_rows, const int64_t* __restrict__ seg_off,
+                                       int64_t k, float* __restrict__ centroids, float* __restrict__ hassign) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= k * dsub) {
+        return;
+    }
+    const int64_t c = t / dsub;
+    const int j = (int)(t % dsub);
+    const int64_t b = seg_off[c], e = seg_off[c + 1];
+    float acc = 0.f;
+    for (int64_t u = b; u < e; u++) {
+        acc = fadd_x(acc, x[(int64_t)sorted_rows[u] * ld + off + j]);
+    }
+    const float cnt = (float)(e - b);
+    if (e > b) {
+        acc = fmul_x(acc, __fdiv_rn(1.0f, cnt));
+    }
+    centroids[t] = acc;
+    if (j == 0) {
+        hassign[c] = cnt;
+    }
+}
+
+hipError_t launch_centroid_update(const float* x, int64_t ld, int off, int dsub, const int32_t* sorted_rows,
+                                  const int64_t* seg_off, int64_t k, float* centroids, float* hassign, hipStream_t s) {
+    hipLaunchKernelGGL(centroid_update_kernel, dim3((unsigned)((k * dsub + 255) / 256)), dim3(256), 0, s, x, ld, off, dsub,
+                       sorted_rows, seg_off, k, centroids, hassign);
+    return hipGetLastError();
+}
+
+// ---- list append: old list-sorted (codes, ids) + a batch grouped by list -> new list-sorted arrays ------------------
+// one thread per output entry; entry e of list l comes from the old list when e < old_len[l]
+__global__ void merge_lists_kernel(const uint8_t* __restrict__ old_codes, const int64_t* __restrict__ old_ids,
+                                   const int64_t* __restrict__ old_off, const uint8_t* __restrict__ new_codes,
+                                   const int64_t* __restrict__ new_ids, const int32_t* __restrict__ new_rows,
+                                   const int64_t* __restrict__ new_seg, const int64_t* __restrict__ out_off, int64_t nlist,
+                                   int64_t code_size, uint8_t* __restrict__ out_codes, int64_t* __restrict__ out_ids) {
+    const int64_t l = blockIdx.x;
+    const int64_t o0 = out_off[l], o1 = out_off[l + 1];
+    const int64_t nold = old_off != nullptr ? old_off[l + 1] - old_off[l] : 0;
+    for (int64_t e = threadIdx.x; e < o1 - o0; e += blockDim.x) {
+        const uint8_t* src;
+        int64_t id;
+        if (e < nold) {
+            src = old_codes + (old_off[l] + e) * code_size;
+            id = old_ids[old_off[l] + e];
+        } else {
+            const int64_t r = new_rows[new_seg[l] + (e - nold)];
+            src = new_codes + r * code_size;
+            id = new_ids[r];
+        }
+        uint8_t* dst = out_codes + (o0 + e) * code_size;
+        for (int64_t b = 0; b < code_size; b++) {
+            dst[b] = src[b];
+        }
+        out_ids[o0 + e] = id;
+    }
+}
+
+hipError_t launch_merge_lists(const uint8_t* old_codes, const int64_t* old_ids, const int64_t* old_off,
+                              const uint8_t* new_codes, const int64_t* new_ids, const int32_t* new_rows,
+                              const int64_t* new_seg, const int64_t* out_off, int64_t nlist, int64_t code_size,
+                              uint8_t* out_codes, int64_t* out_ids, hipStream_t s) {
+    if (nlist <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(merge_lists_kernel, dim3((unsigned)nlist), dim3(256), 0, s, old_codes, old_ids, old_off, new_codes,
+                       new_ids, new_rows, new_seg, out_off, nlist, code_size, out_codes, out_ids);
+    return hipGetLastError();
+}
+
+__global__ void iota_i64_kernel(int64_t* out, int64_t n, int64_t base) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) {
+        out[t] = base + t;
+    }
+}
+
+hipError_t launch_iota_i64(int64_t* out, int64_t n, int64_t base, hipStream_t s) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(iota_i64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, n, base);
+    return hipGetLastError();
+}
+
+} // namespace knhip

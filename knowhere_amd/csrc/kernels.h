@@ -282,6 +282,26 @@ hipError_t launch_refine(const float* base, int64_t nbase, int64_t id_base, int 
                          int64_t nq, const int64_t* cand, int kbase, int k, bool is_l2, float* out_d,
                          int64_t* out_i, hipStream_t s);
 
+// ---- build.hip: Train / Add on the device ----
+hipError_t launch_gather_rows(const float* x, const int64_t* rows, int64_t n, int d, float* out, hipStream_t s);
+hipError_t launch_residual(const float* x, const float* cen, const int64_t* assign, int64_t n, int d, float* out,
+                           hipStream_t s);
+hipError_t launch_nearest_small(const float* x, int64_t n, int64_t ld, int off, int dsub, const float* cb, int ksub,
+                                int32_t* out_idx, hipStream_t s);
+hipError_t launch_pq_encode(const float* resid, int64_t n, int d, int M, const float* cb, uint8_t* codes, hipStream_t s);
+hipError_t launch_sq8_encode(const float* resid, int64_t n, int d, const float* trained, uint8_t* codes, hipStream_t s);
+hipError_t launch_col_minmax(const float* x, int64_t n, int d, float* vmin, float* vmax, hipStream_t s);
+size_t group_rows_tmp_bytes(int64_t n, int64_t k);
+hipError_t group_rows_by_key(const int64_t* keys64, const int32_t* keys32, int64_t n, int64_t k, int32_t* sorted_rows,
+                             int64_t* seg_off, void* tmp, size_t tmp_bytes, hipStream_t s);
+hipError_t launch_centroid_update(const float* x, int64_t ld, int off, int dsub, const int32_t* sorted_rows,
+                                  const int64_t* seg_off, int64_t k, float* centroids, float* hassign, hipStream_t s);
+hipError_t launch_merge_lists(const uint8_t* old_codes, const int64_t* old_ids, const int64_t* old_off,
+                              const uint8_t* new_codes, const int64_t* new_ids, const int32_t* new_rows,
+                              const int64_t* new_seg, const int64_t* out_off, int64_t nlist, int64_t code_size,
+                              uint8_t* out_codes, int64_t* out_ids, hipStream_t s);
+hipError_t launch_iota_i64(int64_t* out, int64_t n, int64_t base, hipStream_t s);
+
 // ---- prims.hip ----
 hipError_t launch_fvec_ny(float* out, const float* x, const float* y, int64_t d, int64_t ny,
                           bool is_l2, hipStream_t s);

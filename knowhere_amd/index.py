@@ -125,6 +125,68 @@ class GpuIndex:
         assert x_t.is_cuda and x_t.is_contiguous()
         check(self.L.knhip_index_add_vectors_device(self.h, x_t.shape[0], _t_ptr(x_t), None, id_offset))
 
+    # ---- GPU build: Train / Add on the device (knhip_index_train* / knhip_index_add*) ----
+    @staticmethod
+    def _tp(niter, max_points, seed):
+        if niter is None and max_points is None and seed is None:
+            return None
+        return C.byref(_lib.TrainParams(niter or 0, max_points or 0, seed or 0))
+
+    def train(self, x, niter=None, max_points=None, seed=None):
+        """x: host numpy [n, dim] or a device tensor"""
+        if hasattr(x, "data_ptr"):
+            assert x.is_cuda and x.is_contiguous()
+            check(self.L.knhip_index_train_device(self.h, x.shape[0], _t_ptr(x), self._tp(niter, max_points, seed)))
+        else:
+            x = np.ascontiguousarray(x, np.float32)
+            check(self.L.knhip_index_train(self.h, x.shape[0], _np_ptr(x), self._tp(niter, max_points, seed)))
+
+    def add(self, x, ids=None):
+        if hasattr(x, "data_ptr"):
+            assert x.is_cuda and x.is_contiguous()
+            check(self.L.knhip_index_add_device(self.h, x.shape[0], _t_ptr(x), _t_ptr(ids)))
+        else:
+            x = np.ascontiguousarray(x, np.float32)
+            i = None if ids is None else np.ascontiguousarray(ids, np.int64)
+            check(self.L.knhip_index_add(self.h, x.shape[0], _np_ptr(x), _np_ptr(i)))
+
+    def encode_device(self, x_t):
+        """-> (assign int64 [n], codes uint8 [n, code_size]) device tensors"""
+        import torch
+        n = x_t.shape[0]
+        cs = {IVF_FLAT: 4 * self.dim, IVF_PQ: self.pq_m, IVF_SQ8: self.dim}[self.kind]
+        a = torch.empty(n, dtype=torch.int64, device=x_t.device)
+        c = torch.empty((n, cs), dtype=torch.uint8, device=x_t.device)
+        s = torch.cuda.current_stream(x_t.device).cuda_stream
+        check(self.L.knhip_index_encode_device(self.h, n, _t_ptr(x_t), _t_ptr(a), _t_ptr(c), C.c_void_p(s)))
+        return a, c
+
+    def get_coarse(self):
+        out = np.empty((self.nlist, self.dim), np.float32)
+        check(self.L.knhip_index_get_coarse(self.h, _np_ptr(out)))
+        return out
+
+    def get_pq(self):
+        out = np.empty((self.pq_m, 256, self.dim // self.pq_m), np.float32)
+        check(self.L.knhip_index_get_pq(self.h, _np_ptr(out)))
+        return out
+
+    def get_sq(self):
+        out = np.empty(2 * self.dim, np.float32)
+        check(self.L.knhip_index_get_sq(self.h, _np_ptr(out), C.c_void_p(out.ctypes.data + 4 * self.dim)))
+        return out
+
+    def get_lists(self):
+        """-> (sizes [nlist], codes [count, code_size] uint8, ids [count]) list after list"""
+        sizes = np.zeros(self.nlist, np.int64)
+        check(self.L.knhip_index_get_list_sizes(self.h, _np_ptr(sizes)))
+        n = int(sizes.sum())
+        cs = {IVF_FLAT: 4 * self.dim, IVF_PQ: self.pq_m, IVF_SQ8: self.dim}[self.kind]
+        codes = np.empty((n, cs), np.uint8)
+        ids = np.empty(n, np.int64)
+        check(self.L.knhip_index_get_lists(self.h, _np_ptr(codes), _np_ptr(ids)))
+        return sizes, codes, ids
+
     # ---- info ----
     @property
     def count(self):
@@ -215,6 +277,18 @@ class GpuIndex:
         return {"ms": list(st.ms), "launches": list(st.launches), "scan_bytes": st.scan_bytes,
                 "coarse_flops": st.coarse_flops, "scan_items": st.scan_items,
                 "coarse_fallback_queries": st.coarse_fallback_queries, "scan_bytes_rank0": st.scan_bytes_rank0}
+
+
+def kmeans_device(metric, x_t, k, niter=None, max_points=None, seed=None):
+    """faiss Clustering restated on the device (knhip_kmeans_device): x_t [n, d] device tensor -> centroids [k, d]"""
+    import torch
+    L = _lib.load()
+    cen = torch.empty((k, x_t.shape[1]), dtype=torch.float32, device=x_t.device)
+    tp = None if (niter is None and max_points is None and seed is None) else C.byref(
+        _lib.TrainParams(niter or 0, max_points or 0, seed or 0))
+    check(L.knhip_kmeans_device(metric, x_t.shape[1], x_t.shape[0], _t_ptr(x_t), k, tp, _t_ptr(cen),
+                                x_t.device.index or 0))
+    return cen
 
 
 def merge_topk_host(metric, D_parts, I_parts):

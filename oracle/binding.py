@@ -257,6 +257,34 @@ class Port:
                                          _p(centroids, _f32p), _p(cb, _f32p), _p(out, _f32p))
         return out
 
+    # -- training restatements (Clustering / IndexIVF::train) --
+    def rand_perm(self, n, seed):
+        out = np.empty(n, np.int64)
+        self.lib.orc_rand_perm(_p(out, _i64p), C.c_int64(n), C.c_int64(seed))
+        return out
+
+    def kmeans(self, metric, x, k, niter=25, max_points=256, seed=1234, ld=None, off=0, d=None):
+        x = np.ascontiguousarray(x, np.float32)
+        ld = x.shape[1] if ld is None else ld
+        d = x.shape[1] if d is None else d
+        cen = np.empty((k, d), np.float32)
+        self.lib.orc_kmeans(C.c_int(metric), C.c_int(d), C.c_int64(x.shape[0]), _p(x, _f32p), C.c_int64(ld), C.c_int(off),
+                            C.c_int64(k), C.c_int(niter), C.c_int(max_points), C.c_int64(seed), _p(cen, _f32p))
+        return cen
+
+    def train_ivf(self, kind, metric, x, nlist, M=0, niter=25, max_points=256, seed=1234, centroids=None):
+        """-> (centroids, pq_centroids or None, sq_trained or None)"""
+        x = np.ascontiguousarray(x, np.float32)
+        n, d = x.shape
+        given = centroids is not None
+        cen = np.ascontiguousarray(centroids, np.float32).copy() if given else np.empty((nlist, d), np.float32)
+        pq = np.empty((max(M, 1), 256, d // max(M, 1)), np.float32) if kind == IVF_PQ else None
+        sq = np.empty(2 * d, np.float32) if kind == IVF_SQ8 else None
+        self.lib.orc_train_ivf(C.c_int(kind), C.c_int(metric), C.c_int(d), C.c_int64(nlist), C.c_int(max(M, 1)),
+                               C.c_int64(n), _p(x, _f32p), C.c_int(niter), C.c_int(max_points), C.c_int64(seed),
+                               C.c_int(1 if given else 0), _p(cen, _f32p), _p(pq, _f32p), _p(sq, _f32p))
+        return cen, pq, sq
+
     # -- build helpers (restated add path) --
     def assign(self, metric, centroids, x):
         out = np.empty(x.shape[0], np.int64)
@@ -367,6 +395,14 @@ class Ref:
 
     def free(self, h):
         self.destroy(h)
+
+    def kmeans(self, metric, x, k, niter=25, max_points=256, seed=1234):
+        x = np.ascontiguousarray(x, np.float32)
+        cen = np.empty((k, x.shape[1]), np.float32)
+        self._chk(self.lib.ref_kmeans(C.c_int(metric), C.c_int(x.shape[1]), C.c_int64(x.shape[0]), _p(x, _f32p),
+                                      C.c_int64(k), C.c_int(niter), C.c_int(max_points), C.c_int64(seed),
+                                      _p(cen, _f32p)))
+        return cen
 
     def _chk(self, rc):
         if rc != 0:

@@ -761,3 +761,212 @@ void orc_sq8_decode(int d, const float* trained, const uint8_t* code, float* x) 
         x[i] = sq8_component(trained, d, code, i);
     }
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Training restatements (pinned against knhip_index_train* / knhip_kmeans_device on the GPU)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* std::mt19937 (the generator behind faiss::RandomGenerator, T:utils/random.cpp:35-55) */
+typedef struct {
+    uint32_t s[624];
+    int i;
+} orc_mt;
+static void mt_seed(orc_mt* m, uint32_t seed) {
+    m->s[0] = seed;
+    for (int i = 1; i < 624; i++) {
+        m->s[i] = 1812433253u * (m->s[i - 1] ^ (m->s[i - 1] >> 30)) + (uint32_t)i;
+    }
+    m->i = 624;
+}
+static uint32_t mt_next(orc_mt* m) {
+    if (m->i >= 624) {
+        for (int k = 0; k < 624; k++) {
+            const uint32_t y = (m->s[k] & 0x80000000u) | (m->s[(k + 1) % 624] & 0x7fffffffu);
+            m->s[k] = m->s[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        m->i = 0;
+    }
+    uint32_t y = m->s[m->i++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+/* T:utils/random.cpp:188-199 rand_perm */
+void orc_rand_perm(int64_t* perm, int64_t n, int64_t seed) {
+    for (int64_t i = 0; i < n; i++) {
+        perm[i] = i;
+    }
+    orc_mt mt;
+    mt_seed(&mt, (uint32_t)seed);
+    for (int64_t i = 0; i + 1 < n; i++) {
+        const int64_t i2 = i + (int64_t)(mt_next(&mt) % (uint32_t)(n - i));
+        const int64_t t = perm[i];
+        perm[i] = perm[i2];
+        perm[i2] = t;
+    }
+}
+
+/* T:Clustering.cpp:95-380 Clustering::train_encoded (nredo 1, RANDOM init, no weights, no early stop) with an exact
+ * k = 1 search as the assigner; T:impl/ClusteringHelpers.cpp:36-240 subsample_training_set / compute_centroids /
+ * split_clusters.  x: n rows of leading dimension ld, the clustered vector = columns [off, off + d). */
+void orc_kmeans(int metric, int d, int64_t n, const float* x, int64_t ld, int off, int64_t k, int niter,
+                int max_points, int64_t seed, float* centroids) {
+    int64_t nx = n;
+    int64_t* perm = (int64_t*)malloc(sizeof(int64_t) * (size_t)n);
+    if (n > k * (int64_t)max_points) {
+        orc_rand_perm(perm, n, seed);
+        nx = k * (int64_t)max_points;
+    } else {
+        for (int64_t i = 0; i < n; i++) {
+            perm[i] = i;
+        }
+    }
+    float* xs = (float*)malloc(sizeof(float) * (size_t)nx * (size_t)d);
+    for (int64_t i = 0; i < nx; i++) {
+        memcpy(xs + i * d, x + perm[i] * ld + off, sizeof(float) * (size_t)d);
+    }
+    if (nx == k) {
+        memcpy(centroids, xs, sizeof(float) * (size_t)k * (size_t)d);
+        free(xs);
+        free(perm);
+        return;
+    }
+    int64_t* p2 = (int64_t*)malloc(sizeof(int64_t) * (size_t)nx);
+    orc_rand_perm(p2, nx, seed + 1);
+    for (int64_t i = 0; i < k; i++) {
+        memcpy(centroids + i * d, xs + p2[i] * d, sizeof(float) * (size_t)d);
+    }
+    free(p2);
+    int64_t* assign = (int64_t*)malloc(sizeof(int64_t) * (size_t)nx);
+    float* hassign = (float*)malloc(sizeof(float) * (size_t)k);
+    for (int it = 0; it < niter; it++) {
+        orc_assign(metric, d, k, centroids, nx, xs, assign);
+        /* compute_centroids: members summed in index order, scaled by 1 / count */
+        memset(centroids, 0, sizeof(float) * (size_t)k * (size_t)d);
+        memset(hassign, 0, sizeof(float) * (size_t)k);
+        for (int64_t i = 0; i < nx; i++) {
+            float* c = centroids + assign[i] * d;
+            hassign[assign[i]] += 1.0f;
+            for (int j = 0; j < d; j++) {
+                c[j] += xs[i * d + j];
+            }
+        }
+        int any_empty = 0;
+        for (int64_t ci = 0; ci < k; ci++) {
+            if (hassign[ci] == 0) {
+                any_empty = 1;
+                continue;
+            }
+            const float norm = 1 / hassign[ci];
+            for (int j = 0; j < d; j++) {
+                centroids[ci * d + j] *= norm;
+            }
+        }
+        if (any_empty) { /* split_clusters */
+            const float EPS = 1.f / 1024.f;
+            orc_mt mt;
+            mt_seed(&mt, 1234u);
+            for (int64_t ci = 0; ci < k; ci++) {
+                if (hassign[ci] != 0) {
+                    continue;
+                }
+                int64_t cj = 0, n_tries = 0;
+                const int64_t max_tries = 10 * k;
+                int found = 0;
+                for (cj = 0; n_tries < max_tries; cj = (cj + 1) % k) {
+                    const float p = (float)((hassign[cj] - 1.0) / (float)(nx - k));
+                    const float r = mt_next(&mt) / (float)4294967295u;
+                    if (r < p) {
+                        found = 1;
+                        break;
+                    }
+                    n_tries++;
+                }
+                if (!found) {
+                    cj = 0;
+                    for (int64_t j = 1; j < k; j++) {
+                        if (hassign[j] > hassign[cj]) {
+                            cj = j;
+                        }
+                    }
+                }
+                memcpy(centroids + ci * d, centroids + cj * d, sizeof(float) * (size_t)d);
+                for (int j = 0; j < d; j++) {
+                    if (j % 2 == 0) {
+                        centroids[ci * d + j] *= 1 + EPS;
+                        centroids[cj * d + j] *= 1 - EPS;
+                    } else {
+                        centroids[ci * d + j] *= 1 - EPS;
+                        centroids[cj * d + j] *= 1 + EPS;
+                    }
+                }
+                hassign[ci] = hassign[cj] / 2;
+                hassign[cj] -= hassign[ci];
+            }
+        }
+    }
+    free(hassign);
+    free(assign);
+    free(xs);
+    free(perm);
+}
+
+/* T:IndexIVF.cpp:1175-1270 IndexIVF::train for IVF_PQ / IVF_SQ8 / IVF_FLAT with by_residual: coarse k-means, encoder
+ * sub-sample (first rows of rand_perm(n, 1234)), residuals, then T:impl/ProductQuantizer.cpp:130-215 (one k-means per
+ * sub-space, 25 iterations, seed 1234) or RS_minmax ranges (trained = vmin[d], vdiff[d]).
+ * kind: 1 IVF_FLAT, 2 IVF_PQ, 3 IVF_SQ8.  coarse_given != 0: centroids are an input. */
+void orc_train_ivf(int kind, int metric, int d, int64_t nlist, int M, int64_t n, const float* x, int niter,
+                   int max_points, int64_t seed, int coarse_given, float* centroids, float* pq_centroids,
+                   float* sq_trained) {
+    if (!coarse_given) {
+        orc_kmeans(metric, d, n, x, d, 0, nlist, niter, max_points, seed, centroids);
+    }
+    if (kind == 1) {
+        return;
+    }
+    const int64_t max_nt = kind == 2 ? 65536 : 100000;
+    int64_t nt = n;
+    int64_t* perm = (int64_t*)malloc(sizeof(int64_t) * (size_t)n);
+    if (n > max_nt) {
+        orc_rand_perm(perm, n, 1234);
+        nt = max_nt;
+    } else {
+        for (int64_t i = 0; i < n; i++) {
+            perm[i] = i;
+        }
+    }
+    float* xt = (float*)malloc(sizeof(float) * (size_t)nt * (size_t)d);
+    for (int64_t i = 0; i < nt; i++) {
+        memcpy(xt + i * d, x + perm[i] * d, sizeof(float) * (size_t)d);
+    }
+    int64_t* assign = (int64_t*)malloc(sizeof(int64_t) * (size_t)nt);
+    orc_assign(metric, d, nlist, centroids, nt, xt, assign);
+    for (int64_t i = 0; i < nt; i++) {
+        for (int j = 0; j < d; j++) {
+            xt[i * d + j] = xt[i * d + j] - centroids[assign[i] * d + j];
+        }
+    }
+    if (kind == 2) {
+        const int dsub = d / M;
+        for (int m = 0; m < M; m++) {
+            orc_kmeans(ORC_L2, dsub, nt, xt, d, m * dsub, 256, 25, 256, 1234, pq_centroids + (size_t)m * 256 * dsub);
+        }
+    } else {
+        for (int j = 0; j < d; j++) {
+            float lo = HUGE_VALF, hi = -HUGE_VALF;
+            for (int64_t i = 0; i < nt; i++) {
+                const float v = xt[i * d + j];
+                if (v < lo) lo = v;
+                if (v > hi) hi = v;
+            }
+            sq_trained[j] = lo;
+            sq_trained[d + j] = hi - lo;
+        }
+    }
+    free(assign);
+    free(xt);
+    free(perm);
+}

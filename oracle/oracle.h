@@ -116,6 +116,14 @@ void orc_pq_compute_code(int d, int M, int nbits, const float* pq_centroids, con
 void orc_sq8_encode(int d, const float* trained, const float* x, uint8_t* code);
 void orc_sq8_decode(int d, const float* trained, const uint8_t* code, float* x);
 
+/* training restatements (Clustering / IndexIVF::train), see oracle.c */
+void orc_rand_perm(int64_t* perm, int64_t n, int64_t seed);
+void orc_kmeans(int metric, int d, int64_t n, const float* x, int64_t ld, int off, int64_t k, int niter,
+                int max_points, int64_t seed, float* centroids);
+void orc_train_ivf(int kind, int metric, int d, int64_t nlist, int M, int64_t n, const float* x, int niter,
+                   int max_points, int64_t seed, int coarse_given, float* centroids, float* pq_centroids,
+                   float* sq_trained);
+
 #ifdef __cplusplus
 }
 #endif

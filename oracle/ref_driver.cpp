@@ -13,6 +13,7 @@
 // Used by tests/ to pin oracle.c (the plain-C restatement) and, as "kind":"reference",
 // by bench.py's cpu_baseline leg.
 
+#include <faiss/Clustering.h>
 #include <faiss/IndexFlat.h>
 #include <faiss/IndexIVF.h>
 #include <faiss/IndexIVFFlat.h>
@@ -117,6 +118,24 @@ void ref_destroy(void* hv) {
     h->index.reset();  // index does not own the quantizer (own_fields=false)
     h->quantizer.reset();
     delete h;
+}
+
+// the reference's own k-means (faiss::Clustering with an IndexFlat of the metric as the assigner): pins oracle.c's
+// orc_kmeans.  Bit-reproducible only while the assigner stays on its sequential path (fewer than
+// distance_compute_blas_threshold = 20 training points), which is what the pin test uses.
+int ref_kmeans(int metric, int d, int64_t n, const float* x, int64_t k, int niter, int max_points, int64_t seed,
+               float* centroids) {
+    return guarded([&] {
+        faiss::ClusteringParameters cp;
+        cp.niter = niter;
+        cp.max_points_per_centroid = max_points;
+        cp.min_points_per_centroid = 1;
+        cp.seed = (int)seed;
+        faiss::Clustering clus(d, (int)k, cp);
+        faiss::IndexFlat index(d, metric == 0 ? faiss::METRIC_L2 : faiss::METRIC_INNER_PRODUCT);
+        clus.train(n, x, index);
+        std::memcpy(centroids, clus.centroids.data(), sizeof(float) * (size_t)k * d);
+    });
 }
 
 int ref_train(void* hv, int64_t n, const float* x) {

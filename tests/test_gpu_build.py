@@ -1,0 +1,128 @@
+"""GPU build tests (-m gpu): knhip_kmeans_device / knhip_index_train* / knhip_index_add* against the oracle's
+restatements of faiss::Clustering and IndexIVF::train / add_core (oracle.c: orc_kmeans is pinned bit-for-bit against
+the reference's own Clustering in tests/test_oracle.py).  Bar: centroids, codebooks, SQ ranges, assignments and codes
+bit-equal; a search on the GPU-built index == the oracle's search on the same index bytes."""
+import numpy as np
+import pytest
+
+from conftest import assert_parity, gen_data
+from helpers import finish_ivfpq
+from oracle import binding as ob
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    return torch
+
+
+@pytest.mark.parametrize("n,d,k,metric,maxpts", [(3000, 16, 32, ob.L2, 256),   # LDS codebook path
+                                                  (9000, 4, 256, ob.L2, 256),   # the PQ sub-quantizer shape
+                                                  (6000, 128, 40, ob.L2, 256),  # coarse-quantizer path (d > 64)
+                                                  (5000, 32, 24, ob.IP, 256),   # inner-product assigner
+                                                  (4000, 96, 10, ob.L2, 64)])   # sub-sampled training set
+def test_kmeans_equals_reference_restatement(torch_cuda, port, n, d, k, metric, maxpts):
+    torch = torch_cuda
+    from knowhere_amd.index import kmeans_device
+    x = gen_data(n, d, 42, -3.0, 7.0)
+    cen = kmeans_device(metric, torch.from_numpy(x).cuda(), k, niter=12, max_points=maxpts)
+    torch.cuda.synchronize()
+    co = port.kmeans(metric, x, k, niter=12, max_points=maxpts)
+    assert cen.cpu().numpy().tobytes() == co.tobytes(), f"k-means centroids differ (n={n} d={d} k={k})"
+
+
+def test_kmeans_empty_cluster_split(torch_cuda, port):
+    """duplicated points leave clusters empty: split_clusters (donor pick by the reference's RNG) must match"""
+    torch = torch_cuda
+    from knowhere_amd.index import kmeans_device
+    base = gen_data(12, 8, 1)
+    x = np.repeat(base, 40, axis=0)  # 480 points, 12 distinct: k = 32 forces empty clusters
+    cen = kmeans_device(ob.L2, torch.from_numpy(x).cuda(), 32, niter=6)
+    torch.cuda.synchronize()
+    assert cen.cpu().numpy().tobytes() == port.kmeans(ob.L2, x, 32, niter=6).tobytes()
+
+
+@pytest.mark.parametrize("kind,M,metric", [(ob.IVF_PQ, 8, ob.L2), (ob.IVF_PQ, 32, ob.L2), (ob.IVF_PQ, 16, ob.IP),
+                                           (ob.IVF_SQ8, 0, ob.L2), (ob.IVF_SQ8, 0, ob.IP), (ob.IVF_FLAT, 0, ob.L2)])
+def test_train_add_search_pipeline(torch_cuda, port, kind, M, metric):
+    """Train + two Adds on the device == the restated reference pipeline; Search on the result == oracle search"""
+    from knowhere_amd import GpuIndex
+    nb, d, nlist = 9000, 64 if M != 32 else 128, 24
+    xb, xq = gen_data(nb, d, 42), gen_data(33, d, 44)
+    g = GpuIndex(kind, metric, d, nlist=nlist, pq_m=M)
+    g.train(xb[:6000], niter=8)
+    cen, pq, sq = port.train_ivf(kind, metric, xb[:6000], nlist, M=M, niter=8)
+    assert g.get_coarse().tobytes() == cen.tobytes(), "coarse centroids"
+    if kind == ob.IVF_PQ:
+        assert g.get_pq().tobytes() == pq.tobytes(), "PQ codebooks"
+    if kind == ob.IVF_SQ8:
+        assert g.get_sq().tobytes() == sq.tobytes(), "SQ8 ranges"
+    g.add(xb[:5000])        # host rows
+    import torch
+    g.add(torch.from_numpy(xb[5000:]).cuda())  # device rows, second Add appends
+    assert g.count == nb
+    sizes, codes, ids = g.get_lists()
+    # the same index built by the restated add path
+    ix = ob.IndexData(kind, metric, d, nlist, M, 8)
+    ix.centroids, ix.pq_centroids, ix.sq_trained = cen, pq, sq
+    assign = port.assign(metric, cen, xb)
+    resid = xb - cen[assign]
+    if kind == ob.IVF_PQ:
+        oc = port.pq_encode(d, M, 8, pq, np.ascontiguousarray(resid))
+    elif kind == ob.IVF_SQ8:
+        oc = port.sq8_encode(sq, np.ascontiguousarray(resid))
+    else:
+        oc = xb.view(np.uint8).reshape(nb, d * 4)
+    ix.list_codes = [np.ascontiguousarray(oc[assign == l]) for l in range(nlist)]
+    ix.list_ids = [np.nonzero(assign == l)[0].astype(np.int64) for l in range(nlist)]
+    assert (sizes == np.array([len(i) for i in ix.list_ids])).all(), "list sizes (assignment)"
+    assert (ids == np.concatenate(ix.list_ids)).all(), "ids"
+    assert codes.tobytes() == np.concatenate(ix.list_codes).tobytes(), "codes"
+    if kind == ob.IVF_PQ and metric == ob.L2:
+        ix.use_precomputed_table = 1
+        finish_ivfpq(port, ix)
+    for k, nprobe in ((10, 8), (100, nlist)):
+        Do, Io = port.search(ix, xq, k, nprobe)
+        D, I = g.search(xq, k, nprobe)
+        assert_parity(Do, Io, D, I, metric, f"search on the GPU-built index kind={kind} k={k}")
+    g.close()
+
+
+def test_encode_device_matches_add(torch_cuda, port):
+    torch = torch_cuda
+    from knowhere_amd import GpuIndex
+    xb = gen_data(7000, 128, 42)
+    ix = ob.make_index(port, ob.IVF_PQ, ob.L2, xb, nlist=32, M=32)
+    g = GpuIndex.from_data(ix, device=0)
+    a, c = g.encode_device(torch.from_numpy(xb[:2000]).cuda())
+    torch.cuda.synchronize()
+    ao = port.assign(ob.L2, ix.centroids, xb[:2000])
+    co = port.pq_encode(128, 32, 8, ix.pq_centroids, np.ascontiguousarray(xb[:2000] - ix.centroids[ao]))
+    assert (a.cpu().numpy() == ao).all() and c.cpu().numpy().tobytes() == co.tobytes()
+    g.close()
+
+
+def test_brute_force_repeated_add(torch_cuda, port):
+    from knowhere_amd import GpuIndex
+    xb, xq = gen_data(5000, 32, 42), gen_data(20, 32, 44)
+    g = GpuIndex(0, ob.L2, 32)
+    g.add(xb[:1234])
+    g.add(xb[1234:])
+    ix = ob.make_index(port, ob.FLAT, ob.L2, xb)
+    Do, Io = port.search(ix, xq, 10)
+    D, I = g.search(xq, 10)
+    assert_parity(Do, Io, D, I, ob.L2, "brute force after two Adds")
+    g.close()
+
+
+def test_train_errors(torch_cuda):
+    from knowhere_amd import GpuIndex, KnhipError
+    g = GpuIndex(ob.IVF_PQ, ob.L2, 32, nlist=64, pq_m=8)
+    with pytest.raises(KnhipError):
+        g.add(gen_data(10, 32, 1))  # not trained
+    with pytest.raises(KnhipError):
+        g.train(gen_data(20, 32, 1))  # fewer training vectors than centroids
+    g.close()
