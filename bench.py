@@ -126,7 +126,6 @@ def main():
         a.ncenter = 1 << max(4, int(round(np.log2(max(a.nb / 160.0, 16.0)))))
     spec = kb.DataSpec(a.nb, a.d, kind=a.data, seed=42, ncenter=a.ncenter, sigma=a.sigma, latent=a.latent)
     cen = cb = sq = None
-    own_row = None
     if world > 1:
         # rank 0 trains; centroids and codec parameters are broadcast so every shard quantises identically
         if rank == 0:
@@ -141,7 +140,11 @@ def main():
         cb = comm.broadcast(cb) if cb is not None else None
         sq = comm.broadcast(sq) if sq is not None else None
         # list ownership needs the list sizes: one cheap assignment pass per rank over its slice of the rows, summed
-        sizes = sharded.global_list_sizes(comm, spec, cen, metric, rank, world, dev)
+        ga = kidx.GpuIndex(kidx.IVF_FLAT, metric, a.d, nlist=a.nlist, device=dev_id)
+        ga.set_coarse_device(cen)
+        sizes = sharded.global_list_sizes(comm, spec, lambda x: ga.coarse_search_device(x.contiguous(), 1)[1][:, 0],
+                                          a.nlist, rank, world, dev)
+        ga.close()
         owned = sharded.partition_lists(sizes, world)[rank]
         built = kb.build_ivf(spec, kind, metric, a.nlist, a.m, device=str(dev), centroids=cen, codebooks=cb,
                              sq_trained=sq, owned_lists=owned, verbose=a.verbose and rank == 0, keep_vectors=refine)

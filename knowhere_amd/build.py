@@ -2,10 +2,12 @@
 
 Build-side counterpart of the reference's Train/Add (reference src/index/ivf/ivf.cc:547-844,
 thirdparty/faiss/faiss/IndexIVF.cpp:55-121 train_q1, 212-287 add_core; Clustering.h:24-77).  The
-hot path of this project is Search(); building is "next" scope, so this
-module is plain PyTorch (rocBLAS GEMMs) -- plumbing, not product kernels.  It produces exactly the
-objects the C ABI ingests: coarse centroids, PQ codebooks / SQ ranges, and list-sorted codes + ids.
-Search parity is defined on the index BYTES, so the oracle is handed the same arrays.
+arithmetic -- k-means, PQ / SQ8 training, nearest-centroid assignment, residual encoding -- runs in the product's
+HIP kernels through the C ABI (knhip_index_train_device / knhip_index_encode_device, csrc/build.hip: the
+reference's Clustering / IndexIVF::train / add_core restated, bit-equal to the scalar reference).  What stays here is
+plumbing: the synthetic data generator, chunking, the owner filter of the list-sharded build and the final grouping
+of the encoded rows by list (torch.sort).  It produces exactly the objects the C ABI ingests, so the oracle can be
+handed the same index BYTES.
 
 Synthetic data: a counter-style generator keyed by (seed, chunk) so any rank can
 regenerate any slice without storing the 51 GB of raw vectors.
@@ -122,80 +124,6 @@ def queries(spec, nq, device, seed=44):
     return x.contiguous()
 
 
-# ---- nearest centroid (L2) in row blocks --------------------------------------------------------
-def _assign_l2(x, cen, cen_sq, block=1 << 17, metric=0):
-    """nearest centroid: L2 (metric 0) or largest inner product (metric 1: the coarse quantizer of an IP index is
-    an IndexFlatIP, reference src/index/ivf/ivf.cc:592, 613, 641)"""
-    out = torch.empty(x.shape[0], dtype=torch.int64, device=x.device)
-    for lo in range(0, x.shape[0], block):
-        xb = x[lo:lo + block]
-        if metric == 1:
-            out[lo:lo + block] = (xb @ cen.t()).argmax(dim=1)
-        else:
-            dist = torch.addmm(cen_sq.unsqueeze(0), xb, cen.t(), beta=1.0, alpha=-2.0)  # ||c||^2 - 2 x.c
-            out[lo:lo + block] = dist.argmin(dim=1)
-    return out
-
-
-def kmeans(x, k, niter=10, seed=1234, verbose=False):
-    """Lloyd k-means (L2), random-sample init, empty clusters re-seeded from the largest ones
-    (spirit of faiss Clustering::train, thirdparty/faiss/faiss/Clustering.cpp)."""
-    n, d = x.shape
-    g = torch.Generator(device=x.device).manual_seed(seed)
-    cen = x[torch.randperm(n, device=x.device, generator=g)[:k]].clone()
-    for it in range(niter):
-        cen_sq = (cen * cen).sum(1)
-        a = _assign_l2(x, cen, cen_sq)
-        cnt = torch.bincount(a, minlength=k).to(x.dtype)
-        s = torch.zeros_like(cen).index_add_(0, a, x)
-        nz = cnt > 0
-        cen[nz] = s[nz] / cnt[nz].unsqueeze(1)
-        nempty = int((~nz).sum().item())
-        if nempty:
-            big = torch.argsort(cnt, descending=True)[:nempty]
-            cen[~nz] = cen[big] * (1 + 1e-4)
-        if verbose:
-            print(f"  kmeans it {it}: empty {nempty}", flush=True)
-    return cen.contiguous()
-
-
-def train_pq(resid, M, niter=10, seed=1234):
-    """per-sub-space k-means with 256 codewords, batched over the M sub-spaces"""
-    n, d = resid.shape
-    dsub = d // M
-    xs = resid.view(n, M, dsub).permute(1, 0, 2).contiguous()  # [M, n, dsub]
-    g = torch.Generator(device=resid.device).manual_seed(seed)
-    sel = torch.randperm(n, device=resid.device, generator=g)[:256]
-    cb = xs[:, sel, :].clone()  # [M, 256, dsub]
-    for _ in range(niter):
-        a = _pq_assign(xs, cb)  # [M, n]
-        for m in range(M):
-            cnt = torch.bincount(a[m], minlength=256).to(xs.dtype)
-            s = torch.zeros((256, dsub), device=xs.device, dtype=xs.dtype).index_add_(0, a[m], xs[m])
-            nz = cnt > 0
-            cb[m][nz] = s[nz] / cnt[nz].unsqueeze(1)
-    return cb.contiguous()
-
-
-def _pq_assign(xs, cb, block=1 << 18):
-    """xs [M, n, dsub], cb [M, 256, dsub] -> nearest codeword [M, n]"""
-    M, n, _ = xs.shape
-    out = torch.empty((M, n), dtype=torch.int64, device=xs.device)
-    cb_sq = (cb * cb).sum(2)  # [M, 256]
-    for lo in range(0, n, block):
-        xb = xs[:, lo:lo + block, :]
-        dist = cb_sq.unsqueeze(1) - 2.0 * torch.bmm(xb, cb.transpose(1, 2))  # [M, b, 256]
-        out[:, lo:lo + block] = dist.argmin(dim=2)
-    return out
-
-
-def pq_encode(resid, cb):
-    n, d = resid.shape
-    M = cb.shape[0]
-    xs = resid.view(n, M, d // M).permute(1, 0, 2).contiguous()
-    return _pq_assign(xs, cb).t().contiguous().to(torch.uint8)  # [n, M]
-
-
 class BuiltIndex:
     """device-resident build result + export to the plain arrays the oracle understands"""
 
@@ -204,19 +132,23 @@ class BuiltIndex:
         self.centroids = self.codebooks = self.sq_trained = None
         self.codes = self.ids = None       # list-sorted, ids ascending inside a list
         self.list_offsets = None           # numpy int64 [nlist+1]
+        self.gpu = None                    # the GpuIndex trained by build_ivf (lists are attached by to_gpu_index)
         self.timings = {}
 
     def to_gpu_index(self, device=0, owned_lists=None):
-        """owned_lists: optional boolean numpy mask [nlist]; lists not owned are left empty
-        (multi-GPU list sharding: each rank holds only its own lists)."""
+        """the GpuIndex that was trained on the device, with the inverted lists attached.
+        owned_lists: optional boolean numpy mask [nlist]; lists not owned are left empty."""
         from .index import GpuIndex, IVF_PQ, IVF_SQ8
-        g = GpuIndex(self.kind, self.metric, self.d, nlist=self.nlist, pq_m=self.M or 0, device=device)
-        g.set_coarse_device(self.centroids)
-        if self.kind == IVF_PQ:
-            g.set_pq(self.codebooks.cpu().numpy())
-        if self.kind == IVF_SQ8:
-            t = self.sq_trained.cpu().numpy()
-            g.set_sq(t[:self.d], t[self.d:])
+        g = self.gpu if owned_lists is None else None
+        self.gpu = None  # handed out at most once (the caller owns and closes it); further calls build a new handle
+        if g is None or g.h is None or g.device != device:
+            g = GpuIndex(self.kind, self.metric, self.d, nlist=self.nlist, pq_m=self.M or 0, device=device)
+            g.set_coarse_device(self.centroids)
+            if self.kind == IVF_PQ:
+                g.set_pq(self.codebooks.cpu().numpy())
+            if self.kind == IVF_SQ8:
+                t = self.sq_trained.cpu().numpy()
+                g.set_sq(t[:self.d], t[self.d:])
         if owned_lists is None:
             g.set_lists_device(self.list_offsets, self.codes, self.ids)
         else:
@@ -253,75 +185,83 @@ def build_ivf(spec, kind, metric, nlist, M=32, device="cuda:0", train_per_centro
     100M / 16384 lists: size-biased mean list length 1.43x the mean vs 1.83x with 10 iterations on
     64 points per centroid -- i.e. 22 % fewer bytes scanned at the same recall)."""
     import time
-    from .index import IVF_FLAT, IVF_PQ, IVF_SQ8
+    from .index import GpuIndex, IVF_FLAT, IVF_PQ, IVF_SQ8
     dev = torch.device(device)
     d = spec.d
     out = BuiltIndex()
     out.kind, out.metric, out.d, out.nlist, out.M = kind, metric, d, nlist, (M if kind == IVF_PQ else 0)
-    t0 = time.time()
-    if centroids is None:
-        xt = spec.sample(min(spec.n, train_per_centroid * nlist), dev)
-        centroids = kmeans(xt, nlist, niter=niter, verbose=verbose)
-        del xt
-    out.centroids = centroids.contiguous()
-    cen_sq = (centroids * centroids).sum(1)
-    torch.cuda.synchronize(dev)
-    out.timings["train_coarse_s"] = time.time() - t0
-    t0 = time.time()
-    if kind == IVF_PQ and codebooks is None:
-        xt = spec.sample(min(spec.n, pq_train), dev, seed=4321)
-        a = _assign_l2(xt, centroids, cen_sq, metric=metric)
-        codebooks = train_pq(xt - centroids[a], M, niter=niter)
-        del xt, a
-    out.codebooks = codebooks
-    if kind == IVF_SQ8 and sq_trained is not None:
-        out.sq_trained = sq_trained
-    elif kind == IVF_SQ8:
-        xt = spec.sample(min(spec.n, pq_train), dev, seed=4321)
-        a = _assign_l2(xt, centroids, cen_sq, metric=metric)
-        r = xt - centroids[a]
-        vmin = r.min(0).values
-        vdiff = r.max(0).values - vmin  # RS_minmax, rangestat_arg 0 (ScalarQuantizer.h:67-74)
-        out.sq_trained = torch.cat([vmin, vdiff]).contiguous()
-        del xt, a, r
-    torch.cuda.synchronize(dev)
-    out.timings["train_codec_s"] = time.time() - t0
-    if train_only:
-        return out
+    g = GpuIndex(kind, metric, d, nlist=nlist, pq_m=out.M, device=dev.index or 0)
+    out.gpu = g
     t0 = time.time()
     lo, hi = row_range if row_range is not None else (0, spec.n)
-    assign_parts, code_parts, id_parts, vec_parts = [], [], [], []
-    own_t = torch.from_numpy(np.asarray(owned_lists, bool)).to(dev) if owned_lists is not None else None
-    vectors = torch.empty((hi - lo, d), device=dev) if (keep_vectors and own_t is None) else None
-    vpos = 0
     c0, c1 = lo // CHUNK, (hi + CHUNK - 1) // CHUNK
+    own_t = torch.from_numpy(np.asarray(owned_lists, bool)).to(dev) if owned_lists is not None else None
+    # the raw rows when they are kept whole (single-GPU refine): generated once, used for training AND encoding
+    vectors = None
+    if keep_vectors and own_t is None and not train_only:
+        vectors = torch.empty((hi - lo, d), device=dev)
+        vpos = 0
+        for c in range(c0, c1):
+            x = spec.chunk(c, dev)
+            x = x[max(lo - c * CHUNK, 0):min(hi - c * CHUNK, x.shape[0])]
+            vectors[vpos:vpos + x.shape[0]] = x
+            vpos += x.shape[0]
+    # ---- training on the device (knhip_index_train_device): the reference trains on the data set it is given and
+    # sub-samples internally (<= train_per_centroid rows per centroid); where the rows are not resident a sample is
+    if centroids is not None:
+        g.set_coarse_device(centroids.contiguous())
+    need_codec = (kind == IVF_PQ and codebooks is None) or (kind == IVF_SQ8 and sq_trained is None)
+    if centroids is None or need_codec:
+        if vectors is not None and vectors.shape[0] < (1 << 31):
+            xt = vectors
+        else:
+            xt = spec.sample(min(spec.n, max(train_per_centroid * nlist, pq_train)), dev)
+        if kind == IVF_PQ and codebooks is not None:
+            g.set_pq(codebooks.cpu().numpy())
+        if kind == IVF_SQ8 and sq_trained is not None:
+            t = sq_trained.cpu().numpy()
+            g.set_sq(t[:d], t[d:])
+        if centroids is None or need_codec:
+            g.train(xt, niter=niter, max_points=train_per_centroid)
+        del xt
+    else:
+        if kind == IVF_PQ:
+            g.set_pq(codebooks.cpu().numpy())
+        if kind == IVF_SQ8:
+            t = sq_trained.cpu().numpy()
+            g.set_sq(t[:d], t[d:])
+    out.centroids = torch.from_numpy(g.get_coarse()).to(dev)
+    if kind == IVF_PQ:
+        out.codebooks = torch.from_numpy(g.get_pq()).to(dev)
+    if kind == IVF_SQ8:
+        out.sq_trained = torch.from_numpy(g.get_sq()).to(dev)
+    torch.cuda.synchronize(dev)
+    out.timings["train_s"] = time.time() - t0
+    if train_only:
+        return out
+    # ---- assignment + encoding on the device (knhip_index_encode_device), chunk by chunk
+    t0 = time.time()
+    assign_parts, code_parts, id_parts, vec_parts = [], [], [], []
+    vpos = 0
     for c in range(c0, c1):
-        x = spec.chunk(c, dev)
         a_lo = max(lo - c * CHUNK, 0)
-        a_hi = min(hi - c * CHUNK, x.shape[0])
-        x = x[a_lo:a_hi]
-        a = _assign_l2(x, centroids, cen_sq, metric=metric)
-        rid = torch.arange(c * CHUNK + a_lo, c * CHUNK + a_hi, device=dev, dtype=torch.int64)
+        if vectors is not None:
+            n_c = min(hi - c * CHUNK, CHUNK) - a_lo
+            x = vectors[vpos:vpos + n_c]
+            vpos += n_c
+        else:
+            x = spec.chunk(c, dev)
+            x = x[a_lo:min(hi - c * CHUNK, x.shape[0])].contiguous()
+        a, codes_c = g.encode_device(x)
+        rid = torch.arange(c * CHUNK + a_lo, c * CHUNK + a_lo + x.shape[0], device=dev, dtype=torch.int64)
         if own_t is not None:
             keep = own_t[a]
-            x, a, rid = x[keep], a[keep], rid[keep]
+            a, codes_c, rid = a[keep], codes_c[keep], rid[keep]
+            if keep_vectors:
+                vec_parts.append(x[keep].contiguous())
         assign_parts.append(a.to(torch.int32))
+        code_parts.append(codes_c)
         id_parts.append(rid)
-        if kind == IVF_PQ:
-            code_parts.append(pq_encode(x - centroids[a], codebooks))
-        elif kind == IVF_SQ8:
-            r = x - centroids[a]
-            vmin, vdiff = out.sq_trained[:d], out.sq_trained[d:]
-            xi = torch.where(vdiff != 0, (r - vmin) / vdiff, torch.zeros_like(r)).clamp_(0, 1)
-            code_parts.append((255 * xi).to(torch.int32).clamp_(0, 255).to(torch.uint8))
-        else:
-            code_parts.append(x.contiguous().view(torch.uint8).reshape(x.shape[0], d * 4))
-        if keep_vectors:
-            if own_t is None:
-                vectors[vpos:vpos + x.shape[0]] = x
-                vpos += x.shape[0]
-            else:
-                vec_parts.append(x.contiguous())
         if verbose and (c - c0) % 16 == 0:
             print(f"  encoded chunk {c - c0 + 1}/{c1 - c0}", flush=True)
     assign = torch.cat(assign_parts).to(torch.int64)

@@ -38,16 +38,12 @@ def partition_lists(sizes, world):
     return [owner == r for r in range(world)]
 
 
-def global_list_sizes(comm, spec, centroids, metric, rank, world, device):
-    """sizes of all inverted lists: every rank assigns its 1/world slice of the rows, one all-reduce sums the counts"""
-    from . import build as kb
-    nlist = centroids.shape[0]
+def global_list_sizes(comm, spec, assign_fn, nlist, rank, world, device):
+    """sizes of all inverted lists: every rank assigns its 1/world slice of the chunks (assign_fn: device rows ->
+    int64 list ids, the index's own exact coarse search), one all-reduce sums the counts"""
     cnt = torch.zeros(nlist, dtype=torch.int64, device=device)
-    cen_sq = (centroids * centroids).sum(1)
-    nch = spec.nchunks()
-    for c in range(rank, nch, world):
-        a = kb._assign_l2(spec.chunk(c, device), centroids, cen_sq, metric=metric)
-        cnt += torch.bincount(a, minlength=nlist)
+    for c in range(rank, spec.nchunks(), world):
+        cnt += torch.bincount(assign_fn(spec.chunk(c, device)), minlength=nlist)
     return comm.allreduce_sum(cnt).cpu().numpy()
 
 
