@@ -191,10 +191,21 @@ void knhip_free(void* p);
  * NULL => none; out_ids[nq*k] int64 / out_dist[nq*k] fp32 host, best-first; missing results
  * id = -1, dist = +FLT_MAX (L2) / -FLT_MAX (IP) (thirdparty/faiss/faiss/utils/Heap.h:338-341).
  * nprobe is clamped to nlist (thirdparty/faiss/faiss/IndexIVF.cpp:321-322); ignored for
- * BRUTE_FORCE.  Thread-safe for concurrent calls on one index. */
+ * BRUTE_FORCE.  Thread-safe for concurrent calls on one index (every call takes its own scratch and stream).
+ * The *_device entry points below share one scratch per stream: calls on the SAME stream are serialised inside
+ * the library while they enqueue. */
 int knhip_search(const knhip_index* idx, const float* queries, int64_t nq, int32_t k,
                  int32_t nprobe, const uint8_t* bitset, int64_t bitset_nbits, int64_t* out_ids,
                  float* out_dist);
+/* Search k_base candidates, re-rank them exactly against the raw fp32 rows held by `raw` (a BRUTE_FORCE knhip_index on
+ * the same device whose row r is vector id r + id_offset) and return the k best: faiss::IndexRefine::search
+ * (thirdparty/faiss/faiss/IndexRefine.cpp:61-140), Knowhere's build-time `refine` + search-time `refine_k`
+ * (src/index/ivf/ivf.cc:673-700, 1073-1103).  Queries go up once, candidates never leave the device. */
+int knhip_search_refine(const knhip_index* idx, const knhip_index* raw, const float* queries, int64_t nq, int32_t k,
+                        int32_t k_base, int32_t nprobe, const uint8_t* bitset, int64_t bitset_nbits, int64_t* out_ids,
+                        float* out_dist);
+/* rows of a BRUTE_FORCE index by id (IndexNode::GetVectorByIds); out [n][dim] host */
+int knhip_index_get_vectors(const knhip_index* idx, int64_t n, const int64_t* ids, float* out);
 /* Same with every buffer already in HBM; enqueued on `stream` (hipStream_t, NULL = default
  * stream) and NOT synchronised. */
 int knhip_search_device(const knhip_index* idx, const float* d_queries, int64_t nq, int32_t k,

@@ -46,7 +46,8 @@ SYMBOLS = [
     "knhip_profile_get", "knhip_stage_kernel_name", "knhip_range_search", "knhip_free", "knhip_search_preassigned_device",
     "knhip_kmeans_device", "knhip_index_train", "knhip_index_train_device", "knhip_index_add", "knhip_index_add_device",
     "knhip_index_encode_device", "knhip_index_get_coarse", "knhip_index_get_pq", "knhip_index_get_sq",
-    "knhip_index_get_list_sizes", "knhip_index_get_lists", "knhip_index_get_vectors_device",
+    "knhip_index_get_list_sizes", "knhip_index_get_lists", "knhip_index_get_vectors_device", "knhip_search_refine",
+    "knhip_index_get_vectors",
 ]
 
 
@@ -116,6 +117,8 @@ def load():
     L.knhip_index_get_list_sizes.argtypes = [vp, vp]
     L.knhip_index_get_lists.argtypes = [vp, vp, vp]
     L.knhip_index_get_vectors_device.argtypes = [vp, C.POINTER(vp)]
+    L.knhip_search_refine.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp, i64, vp, vp]
+    L.knhip_index_get_vectors.argtypes = [vp, i64, vp, vp]
     L.knhip_profile_enable.argtypes = [vp, C.c_int]
     L.knhip_profile_reset.argtypes = [vp]
     L.knhip_profile_get.argtypes = [vp, C.POINTER(StageTimes)]

@@ -124,8 +124,8 @@ struct Workspace {
     DevBuf gmeta;        // [qb] {first-bin key, shift}
     DevBuf list_count, list_pair_off, list_item_off, list_cursor, pairs, items, nitems;
     // host-boundary staging
-    DevBuf h_queries, h_bitset, h_out_d, h_out_i;
-    bool busy = false;
+    DevBuf h_queries, h_bitset, h_out_d, h_out_i, h_ref_d, h_ref_i;
+    std::mutex mu;  // held while a *_device entry point enqueues on this (per-stream) workspace
 };
 
 struct PendingEvent {
@@ -576,7 +576,10 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         HIP_TRY(launch_build_worktable(keys_p, nq, nprobe, nlist, qg_rank0, qg_bulk,
                                        idx->d_list_len.as<int64_t>(), idx->code_size, wt, s));
     }
-    idx->last_items_bound = items_bound;
+    {
+        std::lock_guard<std::mutex> lk(idx->mu);
+        idx->last_items_bound = items_bound;
+    }
 
     if (kind == KNHIP_IVF_FLAT) {
         FlatScanArgs a{};
@@ -1079,6 +1082,7 @@ int knhip_search_device(const knhip_index* idx, const float* d_queries, int64_t 
     DeviceGuard g(idx->desc.device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     Workspace* ws = acquire_ws(idx, stream, true);
+    std::lock_guard<std::mutex> ws_lock(ws->mu);  // two host threads enqueueing on one stream share this scratch
     const int64_t qb = query_batch(idx, nq, k, nprobe);
     if (idx->desc.kind != KNHIP_BRUTE_FORCE) {
         idx->coarse_flops += 2.0 * (double)nq * (double)idx->nlist * (double)idx->d;
@@ -1115,6 +1119,7 @@ int knhip_search_preassigned_device(const knhip_index* idx, const float* d_queri
     DeviceGuard g(idx->desc.device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     Workspace* ws = acquire_ws(idx, stream, true);
+    std::lock_guard<std::mutex> ws_lock(ws->mu);  // two host threads enqueueing on one stream share this scratch
     const int64_t qb = query_batch(idx, nq, k, nprobe);
     for (int64_t q0 = 0; q0 < nq; q0 += qb) {
         const int64_t n = std::min(qb, nq - q0);
@@ -1127,10 +1132,21 @@ int knhip_search_preassigned_device(const knhip_index* idx, const float* d_queri
     return KNHIP_OK;
 }
 
-int knhip_search(const knhip_index* idx, const float* queries, int64_t nq, int32_t k, int32_t nprobe,
-                 const uint8_t* bitset, int64_t bitset_nbits, int64_t* out_ids, float* out_dist) {
+// host boundary of Search(): queries up, (search [+ exact re-rank against the raw rows of `raw`]), results down
+static int search_host_impl(const knhip_index* idx, const knhip_index* raw, const float* queries, int64_t nq, int32_t k,
+                            int32_t k_base, int32_t nprobe, const uint8_t* bitset, int64_t bitset_nbits,
+                            int64_t* out_ids, float* out_dist) {
     if (int rc = check_index(idx)) return rc;
-    if (int rc = validate_search(idx, nq, k, nprobe)) return rc;
+    const int32_t ks = raw ? k_base : k; // what the index is searched for
+    if (raw && (k <= 0 || k_base < k)) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "search_refine: need k_base >= k > 0");
+    }
+    if (int rc = validate_search(idx, nq, ks, nprobe)) return rc;
+    if (raw && (raw->desc.kind != KNHIP_BRUTE_FORCE || raw->d != idx->d || raw->desc.device != idx->desc.device ||
+                !raw->has_data)) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "search_refine: `raw` must be a filled brute-force index of the same "
+                                            "dimension on the same device");
+    }
     if (nq == 0) {
         return KNHIP_OK;
     }
@@ -1145,8 +1161,8 @@ int knhip_search(const knhip_index* idx, const float* queries, int64_t nq, int32
     auto run = [&]() -> int {
         const size_t qbytes = (size_t)nq * idx->d * sizeof(float);
         HIP_TRY(ws->h_queries.reserve(qbytes));
-        HIP_TRY(ws->h_out_d.reserve((size_t)nq * k * sizeof(float)));
-        HIP_TRY(ws->h_out_i.reserve((size_t)nq * k * sizeof(int64_t)));
+        HIP_TRY(ws->h_out_d.reserve((size_t)nq * ks * sizeof(float)));
+        HIP_TRY(ws->h_out_i.reserve((size_t)nq * ks * sizeof(int64_t)));
         HIP_TRY(hipMemcpyAsync(ws->h_queries.p, queries, qbytes, hipMemcpyHostToDevice, s));
         const uint8_t* d_bitset = nullptr;
         if (bitset && bitset_nbits > 0) {
@@ -1155,20 +1171,32 @@ int knhip_search(const knhip_index* idx, const float* queries, int64_t nq, int32
             HIP_TRY(hipMemcpyAsync(ws->h_bitset.p, bitset, bb, hipMemcpyHostToDevice, s));
             d_bitset = ws->h_bitset.as<uint8_t>();
         }
-        const int64_t qb = query_batch(idx, nq, k, nprobe);
+        const int64_t qb = query_batch(idx, nq, ks, nprobe);
         if (idx->desc.kind != KNHIP_BRUTE_FORCE) {
+            std::lock_guard<std::mutex> lk(idx->mu);
             idx->coarse_flops += 2.0 * (double)nq * (double)idx->nlist * (double)idx->d;
         }
         for (int64_t q0 = 0; q0 < nq; q0 += qb) {
             const int64_t n = std::min(qb, nq - q0);
-            if (int r = search_batch(idx, ws, ws->h_queries.as<float>() + q0 * idx->d, n, k, nprobe, d_bitset,
-                                     bitset_nbits, ws->h_out_i.as<int64_t>() + q0 * k,
-                                     ws->h_out_d.as<float>() + q0 * k, s)) {
+            if (int r = search_batch(idx, ws, ws->h_queries.as<float>() + q0 * idx->d, n, ks, nprobe, d_bitset,
+                                     bitset_nbits, ws->h_out_i.as<int64_t>() + q0 * ks,
+                                     ws->h_out_d.as<float>() + q0 * ks, s)) {
                 return r;
             }
         }
-        HIP_TRY(hipMemcpyAsync(out_dist, ws->h_out_d.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(out_ids, ws->h_out_i.p, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        const float* res_d = ws->h_out_d.as<float>();
+        const int64_t* res_i = ws->h_out_i.as<int64_t>();
+        if (raw) { // IndexRefine::search second stage, on the device-resident raw rows
+            HIP_TRY(ws->h_ref_d.reserve((size_t)nq * k * sizeof(float)));
+            HIP_TRY(ws->h_ref_i.reserve((size_t)nq * k * sizeof(int64_t)));
+            HIP_TRY(launch_refine(raw->codes_aos.as<float>(), raw->ntotal, raw->id_offset, idx->d,
+                                  ws->h_queries.as<float>(), nq, res_i, k_base, k, idx->is_l2, ws->h_ref_d.as<float>(),
+                                  ws->h_ref_i.as<int64_t>(), s));
+            res_d = ws->h_ref_d.as<float>();
+            res_i = ws->h_ref_i.as<int64_t>();
+        }
+        HIP_TRY(hipMemcpyAsync(out_dist, res_d, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(out_ids, res_i, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         return KNHIP_OK;
     };
@@ -1179,6 +1207,45 @@ int knhip_search(const knhip_index* idx, const float* queries, int64_t nq, int32
     release_ws(idx, ws);
     (void)hipStreamDestroy(s);
     return rc;
+}
+
+int knhip_search(const knhip_index* idx, const float* queries, int64_t nq, int32_t k, int32_t nprobe,
+                 const uint8_t* bitset, int64_t bitset_nbits, int64_t* out_ids, float* out_dist) {
+    return search_host_impl(idx, nullptr, queries, nq, k, k, nprobe, bitset, bitset_nbits, out_ids, out_dist);
+}
+
+int knhip_search_refine(const knhip_index* idx, const knhip_index* raw, const float* queries, int64_t nq, int32_t k,
+                        int32_t k_base, int32_t nprobe, const uint8_t* bitset, int64_t bitset_nbits, int64_t* out_ids,
+                        float* out_dist) {
+    if (!raw) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "search_refine: null raw-vector index");
+    }
+    return search_host_impl(idx, raw, queries, nq, k, k_base, nprobe, bitset, bitset_nbits, out_ids, out_dist);
+}
+
+// rows of a brute-force index by id (GetVectorByIds): ids are row + id_offset
+int knhip_index_get_vectors(const knhip_index* idx, int64_t n, const int64_t* ids, float* out) {
+    if (int rc = check_index(idx)) return rc;
+    if (idx->desc.kind != KNHIP_BRUTE_FORCE || n < 0 || (n > 0 && (!ids || !out))) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "get_vectors: brute-force index, ids and output required");
+    }
+    if (n == 0) {
+        return KNHIP_OK;
+    }
+    std::vector<int64_t> rows((size_t)n);
+    for (int64_t i = 0; i < n; i++) {
+        rows[(size_t)i] = ids[i] - idx->id_offset;
+        if (rows[(size_t)i] < 0 || rows[(size_t)i] >= idx->ntotal) {
+            return fail(KNHIP_ERR_INVALID_ARGS, "get_vectors: id out of range");
+        }
+    }
+    DeviceGuard g(idx->desc.device);
+    DevBuf dr, dout;
+    if (int rc = upload(dr, rows.data(), rows.size() * sizeof(int64_t))) return rc;
+    HIP_TRY(dout.alloc((size_t)n * idx->d * sizeof(float)));
+    HIP_TRY(launch_gather_rows(idx->codes_aos.as<float>(), dr.as<int64_t>(), n, idx->d, dout.as<float>(), nullptr));
+    HIP_TRY(hipMemcpy(out, dout.p, (size_t)n * idx->d * sizeof(float), hipMemcpyDeviceToHost));
+    return KNHIP_OK;
 }
 
 // ---- range search ----------------------------------------------------------------------------------------
@@ -1502,6 +1569,7 @@ int knhip_coarse_search_device(const knhip_index* idx, const float* d_queries, i
     DeviceGuard g(idx->desc.device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     Workspace* ws = acquire_ws(idx, stream, true);
+    std::lock_guard<std::mutex> ws_lock(ws->mu);  // two host threads enqueueing on one stream share this scratch
     const int64_t qb = std::max<int64_t>(1, std::min<int64_t>(nq, (int64_t)((4.0 * 1024 * 1024 * 1024) / (idx->nlist * 4.0))));
     for (int64_t q0 = 0; q0 < nq; q0 += qb) {
         const int64_t n = std::min(qb, nq - q0);

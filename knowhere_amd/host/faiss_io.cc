@@ -175,11 +175,17 @@ void WriteIvfHeader(Writer& w, const FaissIndexData& x) {
 
 void ReadBody(Reader& r, uint32_t h, FaissIndexData& x) {
     x.fourcc = h;
-    if (IsFlat(h)) {
+    if (IsFlat(h) || h == FourCC("IxF9")) {
         FaissFlat f;
         ReadFlatBody(r, f);
         x.hdr = f.hdr;
         x.xb = std::move(f.xb);
+        // Knowhere's cosine flat index: "IxF9", or "IxFI" with the is_cosine header byte, carries the L2 norms of
+        // the (raw) rows behind them (cppcontrib/knowhere/impl/index_write.cpp:539-546, index_read.cpp:784-831)
+        if (h == FourCC("IxF9") || x.hdr.is_cosine()) {
+            r.vec(x.flat_norms);
+            if ((int64_t)x.flat_norms.size() != x.hdr.ntotal) throw std::runtime_error("flat cosine norms size mismatch");
+        }
     } else if (h == FourCC("IwFl")) {
         ReadIvfHeader(r, x);
         x.code_size = (uint64_t)x.hdr.d * 4;
@@ -216,9 +222,10 @@ void ReadBody(Reader& r, uint32_t h, FaissIndexData& x) {
 
 void WriteBody(Writer& w, const FaissIndexData& x) {
     w.one<uint32_t>(x.fourcc);
-    if (IsFlat(x.fourcc)) {
+    if (IsFlat(x.fourcc) || x.fourcc == FourCC("IxF9")) {
         WriteHeader(w, x.hdr);
         w.vec(x.xb);
+        if (x.fourcc == FourCC("IxF9") || x.hdr.is_cosine()) w.vec(x.flat_norms);
     } else if (x.fourcc == FourCC("IwFl")) {
         WriteIvfHeader(w, x);
         WriteInvertedLists(w, x);

@@ -11,6 +11,8 @@
 //                                                  quantizer index; direct map}
 //   impl/index_write.cpp:451-463   direct map    {char type; vector<int64> array; [hashtable pairs]}
 //   impl/index_write.cpp:489-499   "IxF2"/"IxFI" {index header; xb as vector of 4-byte units}
+//   cppcontrib/knowhere/impl/index_write.cpp:539-546  "IxF9" (IndexFlatCosine) {index header; xb; vector<float> L2 norms};
+//                                                  read side also accepts "IxFI" + is_cosine byte + norms (index_read.cpp:813-831)
 //   impl/index_write.cpp:738-744   "IwFl"        {IVF header; inverted lists}
 //   impl/index_write.cpp:745-753   "IwSq"        {IVF header; ScalarQuantizer; size_t code_size;
 //                                                  bool by_residual; inverted lists}
@@ -65,8 +67,9 @@ struct FaissIndexData {
 
     uint32_t fourcc = 0;  // IwFl / IwSq / IwPQ / IxF2 / IxFI
     FaissHeader hdr;
-    // flat
+    // flat ("IxF9" / cosine "IxFI": the L2 norms of the rows follow them)
     std::vector<float> xb;
+    std::vector<float> flat_norms;
     // IVF header
     uint64_t nlist = 0, nprobe = 1;
     FaissFlat quantizer;

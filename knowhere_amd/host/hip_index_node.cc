@@ -1,46 +1,49 @@
 // knowhere_amd/host/hip_index_node.cc -- the Knowhere IndexNode of the MI355X backend.
 //
-// Modelled on GpuCuvsIndexNode (reference src/index/gpu_cuvs/gpu_cuvs.h:73-324) and registered
-// the same way (src/index/gpu_cuvs/gpu_cuvs_ivf_pq.cc:27-63) under NEW index names:
+// Modelled on GpuCuvsIndexNode (reference src/index/gpu_cuvs/gpu_cuvs.h:73-324) and registered the same way
+// (src/index/gpu_cuvs/gpu_cuvs_ivf_pq.cc:27-63: KNOWHERE_REGISTER_GLOBAL_WITH_THREAD_POOL, IndexNodeThreadPoolWrapper
+// bounding the searches in flight) under NEW index names:
 //     GPU_HIP_BRUTE_FORCE, GPU_HIP_IVF_FLAT, GPU_HIP_IVF_PQ, GPU_HIP_IVF_SQ8
-// It owns no arithmetic: everything numeric goes through the C ABI of libknhip.so
-// (include/knhip.h).  Mapping to the reference:
-//   Train   IvfIndexNode::Train (src/index/ivf/ivf.cc:547-807): MatchNlist (>= 39 points per
-//           centroid, :478-489), k-means for the coarse quantizer, PQ codebooks on residuals
-//           (faiss IndexIVFPQ::train_encoder), SQ8 min/max ranges (RS_minmax).  Lloyd iterations run
-//           on the host; the expensive step -- nearest-centroid assignment -- is a GPU brute-force
-//           search (k = 1) through the same C ABI.
-//   Add     IvfIndexNode::Add (ivf.cc:811-844) -> IndexIVF::add_core: assign, encode the residual,
-//           append (code, id) to the list; ids are the running row numbers.
-//   Search  GpuCuvsIndexNode::Search (gpu_cuvs.h:121-190): config -> knhip_search -> GenResultDataSet
-//           (takes ownership of two new[] arrays) ; `refine` / `refine_k` as IvfIndexNode::Search
-//           does with IndexRefine (ivf.cc:1073-1103).
-//   RangeSearch  IvfIndexNode::RangeSearch (ivf.cc:1231-1497) -> knhip_range_search (brute force, IVF_FLAT,
-//           IVF_SQ8, IVF_PQ m = 32; other m and nlist > 4096 report not_implemented).  GetIndexMeta: not_implemented,
-//           as the cuVS node (gpu_cuvs.h:192-201).
-//   COSINE  base normalised at Train/Add, query copied + normalised per Search, metric -> IP
-//           (ivf.cc:559-565, 1068-1071).
-//   Serialize / Deserialize: one named blob (Type()) in a BinarySet (ivf.cc:1717-1834) in the FAISS
-//           byte format the CPU nodes write (IxF2/IxFI, IwFl, IwSq, IwPQ, IxRF around the latter two
-//           when built with `refine`; faiss_io.h), so a CPU-built index loads here unchanged and back.
-//   refine  build-time `refine` keeps the fp32 rows (IndexRefineFlat, ivf.cc:673-700); search-time
-//           `refine_k` re-ranks only if they are there (ivf.cc:1073-1103).
-#include "knowhere_shim.h"
-#include "faiss_io.h"
+// Virtuals are signature-identical to include/knowhere/index/index_node.h:100-400 (shared_ptr / unique_ptr<Config>,
+// milvus::OpContext*, use_knowhere_build_pool).  The node owns NO arithmetic and holds NO host copy of the base:
+// everything numeric goes through the C ABI of libknhip.so (include/knhip.h) and lives in HBM.  Mapping:
+//   Train   IvfIndexNode::Train (src/index/ivf/ivf.cc:547-807): MatchNlist (>= 39 points per centroid, :478-489),
+//           then knhip_index_train = faiss IndexIVF::train restated on the device (k-means, PQ codebooks on residuals,
+//           SQ8 ranges).  COSINE: rows normalised first (ivf.cc:559-565, NormalizeVec src/common/utils.cc:60-82).
+//   Add     IvfIndexNode::Add (ivf.cc:811-844) -> knhip_index_add = IndexIVF::add_core (assign, encode the residual,
+//           append); ids are the running row numbers; may be called repeatedly.  Build-time `refine` keeps the raw fp32
+//           rows in a second device-resident store (IndexRefineFlat, ivf.cc:673-700).
+//   Search  GpuCuvsIndexNode::Search (gpu_cuvs.h:121-190): typed config, out-id bitset materialisation (:143-162),
+//           all-filtered shortcut (:163-173), knhip_search -> GenResultDataSet (takes ownership of two new[] arrays),
+//           MapSearchResultIdsToOutIds.  `refine_k` = IndexRefine k_factor (ivf.cc:1080-1092): the base index is searched
+//           for k * refine_k candidates, re-ranked exactly on the device (knhip_search_refine).
+//   RangeSearch  IvfIndexNode::RangeSearch (ivf.cc:1231-1497) -> knhip_range_search; range_filter applied here
+//           (src/common/range_util.cc:27-48).  GetIndexMeta: not_implemented, as the cuVS node (gpu_cuvs.h:192-201).
+//   Serialize / Deserialize: one named blob (Type()) in a BinarySet (ivf.cc:1717-1834) in the FAISS byte format the
+//           CPU nodes write (IxF2/IxFI/IxF9, IwFl, IwSq, IwPQ, IxRF; faiss_io.h), so a CPU-built index loads here and back.
+#include "hip_index_node.h"
 
 #include "../../include/knhip.h"
+#include "faiss_io.h"
 
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <numeric>
-#include <random>
+#include <shared_mutex>
 
 namespace knowhere {
 
+size_t
+HipSearchPoolSize() {
+    const int n = knhip_device_count();
+    return (size_t)std::max(n, 1) * hip_concurrent_size_per_device;
+}
+
 namespace {
 
-Status ToStatus(int rc) {
+Status
+ToStatus(int rc) {
     switch (rc) {
         case KNHIP_OK: return Status::success;
         case KNHIP_ERR_INVALID_ARGS: return Status::invalid_args;
@@ -52,327 +55,225 @@ Status ToStatus(int rc) {
     }
 }
 
-struct HipConfig {  // IvfPqConfig / GpuCuvsIvfPqConfig fields this path consumes (ivf_config.h:33-135)
-    int64_t dim = 0, k = 10, nlist = 128, nprobe = 8, m = 32, nbits = 8, refine_k = 0;
-    bool refine = false;
-    std::string metric = metric::L2;
-};
-
-Status LoadConfig(const Json& j, HipConfig& c, bool for_search, std::string* msg) {
-    auto get_int = [&](const char* key, int64_t& dst, int64_t lo, int64_t hi) -> Status {
-        if (!j.contains(key)) return Status::success;
-        const JsonValue& v = j.at(key);
-        if (!v.is_number()) {
-            *msg = std::string("type conflict for ") + key;
-            return Status::type_conflict_in_json;
-        }
-        const int64_t x = v.as_int();
-        if (x < lo || x > hi) {
-            *msg = std::string("out of range: ") + key;
-            return Status::out_of_range_in_json;
-        }
-        dst = x;
-        return Status::success;
-    };
-    Status s;
-    if ((s = get_int(meta::DIM, c.dim, 1, 32768)) != Status::success) return s;
-    if ((s = get_int(meta::TOPK, c.k, 1, 1024)) != Status::success) return s;  // gpu_cuvs_ivf_pq_config.h:49-53
-    if ((s = get_int(indexparam::NLIST, c.nlist, 1, 65536)) != Status::success) return s;
-    if ((s = get_int(indexparam::NPROBE, c.nprobe, 1, 65536)) != Status::success) return s;
-    int64_t m = c.m;
-    if ((s = get_int(indexparam::M, m, 0, 65536)) != Status::success) return s;
-    c.m = m;
-    if ((s = get_int(indexparam::NBITS, c.nbits, 1, 24)) != Status::success) return s;
-    if ((s = get_int(indexparam::REFINE_K, c.refine_k, 0, 1024)) != Status::success) return s;
-    if (j.contains(indexparam::REFINE)) {
-        if (!j.at(indexparam::REFINE).is_boolean()) return Status::type_conflict_in_json;
-        c.refine = j.at(indexparam::REFINE).as_bool();
+// NormalizeVec (src/common/utils.cc:60-82): norm^2 by the scalar fvec_norm_L2sqr (src/simd/distances_ref.cc:39-46),
+// rows whose norm^2 is 0 or within FloatAccuracy (1e-5) of 1 are left alone, the others divided by sqrt(norm^2)
+float
+NormalizeRow(float* x, int64_t d) {
+    float n2 = 0.f;
+    for (int64_t i = 0; i < d; i++) n2 += x[i] * x[i];
+    if (n2 > 0 && std::abs(1.0f - n2) > 0.00001f) {
+        const float n = std::sqrt(n2);
+        for (int64_t i = 0; i < d; i++) x[i] = x[i] / n;
+        return n;
     }
-    if (j.contains(meta::METRIC_TYPE)) {
-        if (!j.at(meta::METRIC_TYPE).is_string()) return Status::type_conflict_in_json;
-        c.metric = j.at(meta::METRIC_TYPE).as_string();
-    }
-    if (c.metric != metric::L2 && c.metric != metric::IP && c.metric != metric::COSINE) {
-        *msg = "metric type " + c.metric + " not supported";
-        return Status::invalid_metric_type;
-    }
-    (void)for_search;
-    return Status::success;
+    return 1.0f;
 }
-
-void NormalizeRows(float* x, int64_t n, int64_t d) {  // CopyAndNormalizeVecs
-    for (int64_t i = 0; i < n; i++) {
-        float* v = x + i * d;
-        double s = 0;
-        for (int64_t t = 0; t < d; t++) s += (double)v[t] * v[t];
-        const float inv = s > 0 ? (float)(1.0 / std::sqrt(s)) : 0.f;
-        for (int64_t t = 0; t < d; t++) v[t] *= inv;
-    }
+void
+NormalizeRows(float* x, int64_t n, int64_t d) {
+    for (int64_t i = 0; i < n; i++) NormalizeRow(x + i * d, d);
 }
 
 struct KnhipHandle {
     knhip_index* p = nullptr;
     ~KnhipHandle() { knhip_index_destroy(p); }
-};
-
-// nearest centroid (L2) of every row through a temporary brute-force knhip index
-Status AssignGpu(const float* cen, int64_t ncen, const float* x, int64_t n, int d, std::vector<int64_t>& out) {
-    knhip_desc desc{};
-    desc.kind = KNHIP_BRUTE_FORCE;
-    desc.metric = KNHIP_L2;
-    desc.dim = d;
-    KnhipHandle h;
-    int rc = knhip_index_create(&desc, &h.p);
-    if (rc) return ToStatus(rc);
-    if ((rc = knhip_index_add_vectors(h.p, ncen, cen, nullptr, 0))) return ToStatus(rc);
-    out.resize(n);
-    std::vector<float> dist(n);
-    rc = knhip_search(h.p, x, n, 1, 1, nullptr, 0, out.data(), dist.data());
-    return ToStatus(rc);
-}
-
-// Lloyd k-means; assignment on the GPU, update on the host (Clustering.h:24-77 defaults: seed 1234)
-Status KMeans(const float* x, int64_t n, int d, int64_t k, int niter, std::vector<float>& cen) {
-    std::mt19937_64 rng(1234);
-    std::vector<int64_t> perm(n);
-    std::iota(perm.begin(), perm.end(), 0);
-    std::shuffle(perm.begin(), perm.end(), rng);
-    cen.resize((size_t)k * d);
-    for (int64_t c = 0; c < k; c++) std::memcpy(&cen[c * d], x + perm[c % n] * d, sizeof(float) * d);
-    std::vector<int64_t> a;
-    std::vector<double> sum((size_t)k * d);
-    std::vector<int64_t> cnt(k);
-    for (int it = 0; it < niter; it++) {
-        Status s = AssignGpu(cen.data(), k, x, n, d, a);
-        if (s != Status::success) return s;
-        std::fill(sum.begin(), sum.end(), 0.0);
-        std::fill(cnt.begin(), cnt.end(), 0);
-        for (int64_t i = 0; i < n; i++) {
-            const int64_t c = a[i];
-            cnt[c]++;
-            for (int t = 0; t < d; t++) sum[c * d + t] += x[i * d + t];
-        }
-        for (int64_t c = 0; c < k; c++) {
-            if (cnt[c] == 0) {  // re-seed an empty cluster from a random point
-                std::memcpy(&cen[c * d], x + perm[(c * 7919 + it) % n] * d, sizeof(float) * d);
-                continue;
-            }
-            for (int t = 0; t < d; t++) cen[c * d + t] = (float)(sum[c * d + t] / cnt[c]);
-        }
+    void reset() {
+        knhip_index_destroy(p);
+        p = nullptr;
     }
-    return Status::success;
-}
+};
 
 }  // namespace
 
+template <typename DataType, int Kind>
 class HipIndexNode : public IndexNode {
- public:
-    HipIndexNode(int32_t /*version*/, int kind) : kind_(kind) {}
-    ~HipIndexNode() override { knhip_index_destroy(idx_); }
+    static_assert(std::is_same_v<DataType, fp32>, "fp16 / bf16 / int8 come through the reference's mock wrapper "
+                                                  "(KNOWHERE_MOCK_REGISTER_GLOBAL, index_factory.h:95-103)");
 
-    Status Train(const DataSetPtr dataset, const Json& cfg) override {
-        if (!dataset || !dataset->GetTensor()) return Status::invalid_args;
-        if (idx_) return Status::index_already_trained;
-        std::string msg;
-        Status s = LoadConfig(cfg, cfg_, false, &msg);
-        if (s != Status::success) return s;
+ public:
+    using knowhere_config_type =
+        std::conditional_t<Kind == KNHIP_BRUTE_FORCE, HipBruteForceConfig,
+                           std::conditional_t<Kind == KNHIP_IVF_FLAT, HipIvfFlatConfig,
+                                              std::conditional_t<Kind == KNHIP_IVF_PQ, HipIvfPqConfig, HipIvfSqConfig>>>;
+
+    HipIndexNode(const int32_t& /*version*/, const Object& /*object*/) {}
+    ~HipIndexNode() override = default;
+
+    bool
+    NeedBitsetExactCount() const override {
+        return true;  // the all-filtered shortcut needs the exact projected count (gpu_cuvs.h:82-85)
+    }
+
+    Status
+    Train(const DataSetPtr dataset, std::shared_ptr<Config> cfg, bool /*use_knowhere_build_pool*/) override {
+        if (!dataset || !dataset->GetTensor() || !cfg) return Status::invalid_args;
+        if (idx_.p) return Status::index_already_trained;
+        const auto& c = static_cast<const knowhere_config_type&>(*cfg);
         const int64_t rows = dataset->GetRows();
         dim_ = dataset->GetDim();
-        if (cfg_.dim != 0 && cfg_.dim != dim_) return Status::invalid_args;
-        cosine_ = cfg_.metric == metric::COSINE;
-        metric_ = (cfg_.metric == metric::L2) ? KNHIP_L2 : KNHIP_IP;
-        if (kind_ == KNHIP_BRUTE_FORCE) {
-            return Status::success;  // nothing to train
+        if (c.dim.has_value() && c.dim.value() != dim_) return Status::invalid_args;
+        const std::string metric = c.metric_type.value_or(metric::L2);
+        cosine_ = IsMetricType(metric, metric::COSINE);
+        metric_ = IsMetricType(metric, metric::L2) ? KNHIP_L2 : KNHIP_IP;
+        metric_name_ = cosine_ ? metric::COSINE : (metric_ == KNHIP_L2 ? metric::L2 : metric::IP);
+        knhip_desc desc{};
+        desc.kind = Kind;
+        desc.metric = metric_;
+        desc.dim = (int32_t)dim_;
+        if constexpr (Kind != KNHIP_BRUTE_FORCE) {
+            // MatchNlist: silently shrink nlist so that nlist * 39 <= rows (ivf.cc:478-489)
+            nlist_ = c.nlist.value();
+            if (nlist_ * 39 > rows) nlist_ = std::max<int64_t>(1, rows / 39);
+            desc.nlist = nlist_;
+            default_nprobe_ = c.nprobe.value_or(8);
         }
-        // MatchNlist: silently shrink nlist so that nlist * 39 <= rows (ivf.cc:478-489)
-        nlist_ = cfg_.nlist;
-        if (nlist_ * 39 > rows) nlist_ = std::max<int64_t>(1, rows / 39);
-        if (kind_ == KNHIP_IVF_PQ) {
-            if (cfg_.nbits != 8) return Status::invalid_args;
-            // m = 0: let the backend pick, as cuVS does for pq_dim = 0 (about dim / 2): the largest
-            // supported m that leaves sub-vectors of at least 2 dims
-            m_ = cfg_.m == 0 ? std::min<int64_t>(64, dim_ / 2) : cfg_.m;
+        if constexpr (Kind == KNHIP_IVF_PQ) {
+            // m = 0: the backend picks, as cuVS does for pq_dim = 0 (about dim / 2): the largest supported m that
+            // leaves sub-vectors of at least 2 dims
+            m_ = c.m.value_or(0) == 0 ? std::min<int64_t>(64, dim_ / 2) : c.m.value();
             while (m_ > 1 && (dim_ % m_ != 0 || !(m_ == 8 || m_ == 16 || m_ == 32 || m_ == 64))) m_--;
             if (dim_ % m_ != 0 || !(m_ == 8 || m_ == 16 || m_ == 32 || m_ == 64)) return Status::invalid_args;
+            desc.pq_m = (int32_t)m_;
+            desc.pq_nbits = 8;
         }
-        std::vector<float> x((const float*)dataset->GetTensor(), (const float*)dataset->GetTensor() + rows * dim_);
-        if (cosine_) NormalizeRows(x.data(), rows, dim_);
-        // train on at most 256 points per centroid (Clustering.h:46)
-        const int64_t ntrain = std::min<int64_t>(rows, 256 * nlist_);
-        s = KMeans(x.data(), ntrain, (int)dim_, nlist_, 10, centroids_);
-        if (s != Status::success) return s;
-        std::vector<int64_t> a;
-        if ((s = AssignGpu(centroids_.data(), nlist_, x.data(), ntrain, (int)dim_, a)) != Status::success) return s;
-        std::vector<float> resid((size_t)ntrain * dim_);
-        for (int64_t i = 0; i < ntrain; i++)
-            for (int64_t t = 0; t < dim_; t++) resid[i * dim_ + t] = x[i * dim_ + t] - centroids_[a[i] * dim_ + t];
-        if (kind_ == KNHIP_IVF_PQ) {
-            const int64_t dsub = dim_ / m_;
-            codebooks_.assign((size_t)256 * dim_, 0.f);
-            std::vector<float> sub((size_t)ntrain * dsub), cb;
-            for (int64_t m = 0; m < m_; m++) {
-                for (int64_t i = 0; i < ntrain; i++)
-                    std::memcpy(&sub[i * dsub], &resid[i * dim_ + m * dsub], sizeof(float) * dsub);
-                if ((s = KMeans(sub.data(), ntrain, (int)dsub, 256, 10, cb)) != Status::success) return s;
-                std::memcpy(&codebooks_[(size_t)m * 256 * dsub], cb.data(), sizeof(float) * 256 * dsub);
-            }
-        } else if (kind_ == KNHIP_IVF_SQ8) {
-            sq_trained_.assign(2 * dim_, 0.f);
-            for (int64_t t = 0; t < dim_; t++) {
-                float lo = FLT_MAX, hi = -FLT_MAX;
-                for (int64_t i = 0; i < ntrain; i++) {
-                    lo = std::min(lo, resid[i * dim_ + t]);
-                    hi = std::max(hi, resid[i * dim_ + t]);
-                }
-                sq_trained_[t] = lo;
-                sq_trained_[dim_ + t] = hi - lo;
-            }
+        if constexpr (Kind == KNHIP_IVF_PQ || Kind == KNHIP_IVF_SQ8) {
+            has_refine_ = c.refine.value_or(false);
         }
-        has_refine_ = cfg_.refine && (kind_ == KNHIP_IVF_PQ || kind_ == KNHIP_IVF_SQ8);
-        trained_ = true;
+        int rc = knhip_index_create(&desc, &idx_.p);
+        if (rc) return ToStatus(rc);
+        if constexpr (Kind == KNHIP_BRUTE_FORCE) {
+            return Status::success;  // nothing to train
+        }
+        const float* x = (const float*)dataset->GetTensor();
+        std::vector<float> xn;
+        if (cosine_) {
+            xn.assign(x, x + rows * dim_);
+            NormalizeRows(xn.data(), rows, dim_);
+            x = xn.data();
+        }
+        rc = knhip_index_train(idx_.p, rows, x, nullptr);  // the reference's clustering defaults
+        if (rc) {
+            idx_.reset();
+            return ToStatus(rc);
+        }
         return Status::success;
     }
 
-    Status Add(const DataSetPtr dataset, const Json& /*cfg*/) override {
+    // thread safe against concurrent Search (index_node.h:141-145): the index object serialises layout changes
+    Status
+    Add(const DataSetPtr dataset, std::shared_ptr<Config> /*cfg*/, bool /*use_knowhere_build_pool*/) override {
         if (!dataset || !dataset->GetTensor()) return Status::invalid_args;
-        if (kind_ != KNHIP_BRUTE_FORCE && !trained_) return Status::index_not_trained;
-        if (idx_) return Status::not_implemented;  // one Add per index for now (the cuVS node's Add is a no-op)
-        const int64_t rows = dataset->GetRows();
+        if (!idx_.p) return Kind == KNHIP_BRUTE_FORCE ? Status::empty_index : Status::index_not_trained;
         if (dataset->GetDim() != dim_) return Status::invalid_args;
-        raw_.assign((const float*)dataset->GetTensor(), (const float*)dataset->GetTensor() + rows * dim_);
-        if (cosine_) NormalizeRows(raw_.data(), rows, dim_);
-        knhip_desc desc{};
-        desc.kind = kind_;
-        desc.metric = metric_;
-        desc.dim = (int32_t)dim_;
-        desc.nlist = nlist_;
-        desc.pq_m = (int32_t)m_;
-        desc.pq_nbits = 8;
-        int rc = knhip_index_create(&desc, &idx_);
-        if (rc) return ToStatus(rc);
-        count_ = rows;
-        if (kind_ == KNHIP_BRUTE_FORCE) {
-            return ToStatus(knhip_index_add_vectors(idx_, rows, raw_.data(), nullptr, 0));
+        const int64_t rows = dataset->GetRows();
+        const float* x = (const float*)dataset->GetTensor();
+        std::vector<float> xn;
+        if (cosine_) {
+            xn.assign(x, x + rows * dim_);
+            NormalizeRows(xn.data(), rows, dim_);
+            x = xn.data();
         }
-        std::vector<int64_t> a;
-        Status s = AssignGpu(centroids_.data(), nlist_, raw_.data(), rows, (int)dim_, a);
-        if (s != Status::success) return s;
-        const int64_t cs = kind_ == KNHIP_IVF_FLAT ? dim_ * 4 : (kind_ == KNHIP_IVF_PQ ? m_ : dim_);
-        std::vector<uint8_t> codes((size_t)rows * cs);
-        if (kind_ == KNHIP_IVF_FLAT) {
-            std::memcpy(codes.data(), raw_.data(), codes.size());
-        } else {
-            std::vector<float> resid((size_t)rows * dim_);
-            for (int64_t i = 0; i < rows; i++)
-                for (int64_t t = 0; t < dim_; t++) resid[i * dim_ + t] = raw_[i * dim_ + t] - centroids_[a[i] * dim_ + t];
-            if (kind_ == KNHIP_IVF_PQ) {
-                const int64_t dsub = dim_ / m_;
-                std::vector<float> sub((size_t)rows * dsub);
-                std::vector<int64_t> code;
-                for (int64_t m = 0; m < m_; m++) {
-                    for (int64_t i = 0; i < rows; i++)
-                        std::memcpy(&sub[i * dsub], &resid[i * dim_ + m * dsub], sizeof(float) * dsub);
-                    s = AssignGpu(&codebooks_[(size_t)m * 256 * dsub], 256, sub.data(), rows, (int)dsub, code);
-                    if (s != Status::success) return s;
-                    for (int64_t i = 0; i < rows; i++) codes[i * cs + m] = (uint8_t)code[i];
+        std::unique_lock<std::shared_mutex> lk(rw_);
+        int rc = knhip_index_add(idx_.p, rows, x, nullptr);
+        if (rc) return ToStatus(rc);
+        if (NeedRawStore()) {
+            if (!raw_.p) {
+                knhip_desc rd{};
+                rd.kind = KNHIP_BRUTE_FORCE;
+                rd.metric = metric_;
+                rd.dim = (int32_t)dim_;
+                if ((rc = knhip_index_create(&rd, &raw_.p))) return ToStatus(rc);
+            }
+            if ((rc = knhip_index_add(raw_.p, rows, x, nullptr))) return ToStatus(rc);
+        }
+        return Status::success;
+    }
+
+    expected<DataSetPtr>
+    Search(const DataSetPtr dataset, std::unique_ptr<Config> cfg, const BitsetView& bitset,
+           milvus::OpContext* op_context) const override {
+        if (!idx_.p || Count() == 0) return expected<DataSetPtr>::Err(Status::empty_index, "index not built");
+        if (!dataset || !dataset->GetTensor() || !cfg)
+            return expected<DataSetPtr>::Err(Status::invalid_args, "null dataset / config");
+        if (dataset->GetDim() != dim_) return expected<DataSetPtr>::Err(Status::invalid_args, "dim mismatch");
+        const auto& c = static_cast<const knowhere_config_type&>(*cfg);
+        const int64_t nq = dataset->GetRows();
+        const int64_t k = c.k.value();
+        int64_t nprobe = 1;
+        if constexpr (Kind != KNHIP_BRUTE_FORCE) nprobe = c.nprobe.value_or(default_nprobe_);
+        checkCancellation(op_context);
+        const float* q = (const float*)dataset->GetTensor();
+        std::vector<float> qn;
+        if (cosine_) {  // CopyAndNormalizeVecs (ivf.cc:1068-1071)
+            qn.assign(q, q + nq * dim_);
+            NormalizeRows(qn.data(), nq, dim_);
+            q = qn.data();
+        }
+        // bitset in the searched (internal) id domain: materialise an installed out-id view (gpu_cuvs.h:143-162)
+        std::vector<uint8_t> in_bitset;
+        const uint8_t* bits = nullptr;
+        int64_t nbits = 0;
+        const bool has_bitset = bitset.data() != nullptr && bitset.num_bits() != 0;
+        if (has_bitset && bitset.has_out_ids()) {
+            const size_t n_in = bitset.out_ids_count();
+            in_bitset.assign((n_in + 7) / 8, 0);
+            for (size_t i = 0; i < n_in; i++) {
+                if (bitset.test((int64_t)i)) in_bitset[i >> 3] |= (uint8_t)(1u << (i & 7));
+            }
+            bits = in_bitset.data();
+            nbits = (int64_t)n_in;
+        } else if (has_bitset) {
+            bits = bitset.data();
+            nbits = (int64_t)bitset.num_bits();
+        }
+        // every row filtered: ids -1, distances +inf, like gpu_cuvs.h:163-173
+        if (has_bitset && bitset.has_known_count() && bitset.count() >= bitset.size() && (int64_t)bitset.size() >= Count()) {
+            auto ids = std::make_unique<int64_t[]>(nq * k);
+            auto dis = std::make_unique<float[]>(nq * k);
+            std::fill_n(ids.get(), nq * k, (int64_t)-1);
+            std::fill_n(dis.get(), nq * k, std::numeric_limits<float>::infinity());
+            return GenResultDataSet(nq, k, ids.release(), dis.release());
+        }
+        auto ids = std::make_unique<int64_t[]>(nq * k);
+        auto dis = std::make_unique<float[]>(nq * k);
+        int rc;
+        {
+            std::shared_lock<std::shared_mutex> lk(rw_);
+            // use_refine = the index carries a refine index (ivf.cc:1080-1092); k_factor = refine_k
+            int64_t kbase = k;
+            if constexpr (Kind == KNHIP_IVF_PQ || Kind == KNHIP_IVF_SQ8) {
+                if (has_refine_ && raw_.p && c.refine_k.has_value()) {
+                    kbase = std::min<int64_t>(1024, std::max<int64_t>(k, (int64_t)(k * c.refine_k.value())));
                 }
-            } else {  // SQ8: quantizers.h:118-133 + codecs.h:29-35
-                for (int64_t i = 0; i < rows; i++)
-                    for (int64_t t = 0; t < dim_; t++) {
-                        const float vmin = sq_trained_[t], vdiff = sq_trained_[dim_ + t];
-                        float xi = 0;
-                        if (vdiff != 0) {
-                            xi = (resid[i * dim_ + t] - vmin) / vdiff;
-                            xi = std::min(1.0f, std::max(0.0f, xi));
-                        }
-                        codes[i * cs + t] = (uint8_t)(int)(255 * xi);
-                    }
+            }
+            if (kbase > k) {
+                rc = knhip_search_refine(idx_.p, raw_.p, q, nq, (int32_t)k, (int32_t)kbase, (int32_t)nprobe, bits, nbits,
+                                         ids.get(), dis.get());
+            } else {
+                rc = knhip_search(idx_.p, q, nq, (int32_t)k, (int32_t)nprobe, bits, nbits, ids.get(), dis.get());
             }
         }
-        // bucket into ArrayInvertedLists layout
-        list_codes_.assign(nlist_, {});
-        list_ids_.assign(nlist_, {});
-        for (int64_t i = 0; i < rows; i++) {
-            auto& lc = list_codes_[a[i]];
-            lc.insert(lc.end(), codes.begin() + i * cs, codes.begin() + (i + 1) * cs);
-            list_ids_[a[i]].push_back(i);
-        }
-        s = Upload();
-        if (!has_refine_ && (kind_ == KNHIP_IVF_PQ || kind_ == KNHIP_IVF_SQ8)) std::vector<float>().swap(raw_);
-        return s;
-    }
-
-    expected<DataSetPtr> Search(const DataSetPtr dataset, const Json& cfg, const BitsetView& bitset) const override {
-        if (!idx_) return expected<DataSetPtr>::Err(Status::empty_index, "index not built");
-        if (!dataset || !dataset->GetTensor()) return expected<DataSetPtr>::Err(Status::invalid_args, "null dataset");
-        HipConfig c = cfg_;
-        std::string msg;
-        Status s = LoadConfig(cfg, c, true, &msg);
-        if (s != Status::success) return expected<DataSetPtr>::Err(s, msg);
-        const int64_t nq = dataset->GetRows();
-        if (dataset->GetDim() != dim_) return expected<DataSetPtr>::Err(Status::invalid_args, "dim mismatch");
-        const float* q = (const float*)dataset->GetTensor();
-        std::vector<float> qn;
-        if (cosine_) {
-            qn.assign(q, q + nq * dim_);
-            NormalizeRows(qn.data(), nq, dim_);
-            q = qn.data();
-        }
-        const int64_t k = c.k;
-        // every row filtered: ids -1, distances +inf, like gpu_cuvs.h:163-173
-        if (!bitset.empty() && bitset.count() >= (size_t)count_) {
-            auto* ids = new int64_t[nq * k];
-            auto* dis = new float[nq * k];
-            std::fill(ids, ids + nq * k, -1);
-            std::fill(dis, dis + nq * k, std::numeric_limits<float>::infinity());
-            return GenResultDataSet(nq, k, ids, dis);
-        }
-        // use_refine = the index carries a refine index; enabled by a search-time refine_k (ivf.cc:1080-1092)
-        const bool refine = has_refine_ && cfg.contains(indexparam::REFINE_K);
-        const int64_t kbase = refine ? std::min<int64_t>(1024, std::max<int64_t>(k, c.refine_k > 0 ? c.refine_k : k)) : k;
-        std::unique_ptr<int64_t[]> ids(new int64_t[nq * kbase]);
-        std::unique_ptr<float[]> dis(new float[nq * kbase]);
-        int rc = knhip_search(idx_, q, nq, (int32_t)kbase, (int32_t)c.nprobe, bitset.empty() ? nullptr : bitset.data(),
-                              (int64_t)bitset.size(), ids.get(), dis.get());
         if (rc) return expected<DataSetPtr>::Err(ToStatus(rc), knhip_last_error());
-        if (refine && kbase > k) {
-            // IndexRefine second stage on the host-resident raw copy (device-resident variant:
-            // knhip_refine_device, used by bench.py)
-            std::unique_ptr<int64_t[]> rid(new int64_t[nq * k]);
-            std::unique_ptr<float[]> rdis(new float[nq * k]);
-            RefineHost(q, nq, kbase, ids.get(), k, rid.get(), rdis.get());
-            ids = std::move(rid);
-            dis = std::move(rdis);
-        }
-        return GenResultDataSet(nq, k, ids.release(), dis.release());
+        auto res = GenResultDataSet(nq, k, ids.release(), dis.release());
+        this->MapSearchResultIdsToOutIds(res);
+        return res;
     }
 
-    // IvfIndexNode::RangeSearch (ivf.cc:1231-1497): radius / range_filter / max_empty_result_buckets from the
-    // config, every list a candidate, results filtered to [range_filter, radius) (L2) or (radius, range_filter]
-    // (IP, COSINE) (range_util.h:22-25) and returned as lims + flat arrays.
-    expected<DataSetPtr> RangeSearch(const DataSetPtr dataset, const Json& cfg, const BitsetView& bitset) const override {
-        if (!idx_) return expected<DataSetPtr>::Err(Status::empty_index, "index not built");
-        if (!dataset || !dataset->GetTensor()) return expected<DataSetPtr>::Err(Status::invalid_args, "null dataset");
+    // IvfIndexNode::RangeSearch (ivf.cc:1231-1497): radius / range_filter / max_empty_result_buckets from the config,
+    // every list a candidate, results filtered to [range_filter, radius) (L2) or (radius, range_filter] (IP, COSINE)
+    // (range_util.h:22-25) and returned as lims + flat arrays.
+    expected<DataSetPtr>
+    RangeSearch(const DataSetPtr dataset, std::unique_ptr<Config> cfg, const BitsetView& bitset,
+                milvus::OpContext* op_context) const override {
+        if (!idx_.p || Count() == 0) return expected<DataSetPtr>::Err(Status::empty_index, "index not built");
+        if (!dataset || !dataset->GetTensor() || !cfg)
+            return expected<DataSetPtr>::Err(Status::invalid_args, "null dataset / config");
         if (dataset->GetDim() != dim_) return expected<DataSetPtr>::Err(Status::invalid_args, "dim mismatch");
-        auto get_f = [&](const char* key, float dflt, float& dst) -> bool {
-            dst = dflt;
-            if (!cfg.contains(key)) return true;
-            if (!cfg.at(key).is_number()) return false;
-            dst = (float)cfg.at(key).as_double();
-            return true;
-        };
-        float radius = 0.f, range_filter = 0.f;
-        const float default_range_filter = std::numeric_limits<float>::infinity();  // config.h:583
-        if (!get_f(meta::RADIUS, 0.0f, radius) || !get_f(meta::RANGE_FILTER, default_range_filter, range_filter))
-            return expected<DataSetPtr>::Err(Status::type_conflict_in_json, "radius / range_filter must be numbers");
-        int64_t max_empty = 2;  // ivf_config.h:53-59
-        if (cfg.contains(indexparam::MAX_EMPTY_RESULT_BUCKETS)) {
-            if (!cfg.at(indexparam::MAX_EMPTY_RESULT_BUCKETS).is_number())
-                return expected<DataSetPtr>::Err(Status::type_conflict_in_json, "max_empty_result_buckets");
-            max_empty = cfg.at(indexparam::MAX_EMPTY_RESULT_BUCKETS).as_int();
-            if (max_empty < 0 || max_empty > 65536)
-                return expected<DataSetPtr>::Err(Status::out_of_range_in_json, "max_empty_result_buckets");
-        }
+        const auto& c = static_cast<const knowhere_config_type&>(*cfg);
+        const float radius = c.radius.value();
+        const float range_filter = c.range_filter.value();
+        int64_t max_empty = 2;
+        if constexpr (Kind != KNHIP_BRUTE_FORCE) max_empty = c.max_empty_result_buckets.value_or(2);
+        checkCancellation(op_context);
         const int64_t nq = dataset->GetRows();
         const float* q = (const float*)dataset->GetTensor();
         std::vector<float> qn;
@@ -380,23 +281,42 @@ class HipIndexNode : public IndexNode {
             qn.assign(q, q + nq * dim_);
             NormalizeRows(qn.data(), nq, dim_);
             q = qn.data();
+        }
+        std::vector<uint8_t> in_bitset;
+        const uint8_t* bits = nullptr;
+        int64_t nbits = 0;
+        const bool has_bitset = bitset.data() != nullptr && bitset.num_bits() != 0;
+        if (has_bitset && bitset.has_out_ids()) {
+            const size_t n_in = bitset.out_ids_count();
+            in_bitset.assign((n_in + 7) / 8, 0);
+            for (size_t i = 0; i < n_in; i++) {
+                if (bitset.test((int64_t)i)) in_bitset[i >> 3] |= (uint8_t)(1u << (i & 7));
+            }
+            bits = in_bitset.data();
+            nbits = (int64_t)n_in;
+        } else if (has_bitset) {
+            bits = bitset.data();
+            nbits = (int64_t)bitset.num_bits();
         }
         std::vector<int64_t> lims(nq + 1);
         int64_t* ids = nullptr;
         float* dis = nullptr;
-        int rc = knhip_range_search(idx_, q, nq, radius, (int32_t)max_empty, bitset.empty() ? nullptr : bitset.data(),
-                                    (int64_t)bitset.size(), lims.data(), &ids, &dis);
+        int rc;
+        {
+            std::shared_lock<std::shared_mutex> lk(rw_);
+            rc = knhip_range_search(idx_.p, q, nq, radius, (int32_t)max_empty, bits, nbits, lims.data(), &ids, &dis);
+        }
         if (rc) return expected<DataSetPtr>::Err(ToStatus(rc), knhip_last_error());
         const bool is_ip = metric_ != KNHIP_L2;
-        auto* out_lims = new size_t[nq + 1];
-        auto* out_ids = new int64_t[std::max<int64_t>(lims[nq], 1)];
-        auto* out_dis = new float[std::max<int64_t>(lims[nq], 1)];
+        auto out_lims = std::make_unique<size_t[]>(nq + 1);
+        auto out_ids = std::make_unique<int64_t[]>(std::max<int64_t>(lims[nq], 1));
+        auto out_dis = std::make_unique<float[]>(std::max<int64_t>(lims[nq], 1));
         size_t n = 0;
         out_lims[0] = 0;
         for (int64_t i = 0; i < nq; i++) {
             for (int64_t j = lims[i]; j < lims[i + 1]; j++) {
                 const float v = dis[j];
-                const bool keep = range_filter == default_range_filter ||
+                const bool keep = range_filter == defaultRangeFilter ||
                                   (is_ip ? (radius < v && v <= range_filter) : (range_filter <= v && v < radius));
                 if (keep) {
                     out_ids[n] = ids[j];
@@ -408,93 +328,122 @@ class HipIndexNode : public IndexNode {
         }
         knhip_free(ids);
         knhip_free(dis);
-        return GenRangeResultDataSet(nq, out_lims, out_ids, out_dis);
+        auto res = GenResultDataSet(nq, out_ids.release(), out_dis.release(), out_lims.release());
+        this->MapSearchResultIdsToOutIds(res);
+        return res;
     }
-    expected<DataSetPtr> GetVectorByIds(const DataSetPtr dataset) const override {
-        if (!HasRawData(cfg_.metric) || raw_.empty())
-            return expected<DataSetPtr>::Err(Status::not_implemented, "no raw data");
+
+    expected<DataSetPtr>
+    GetVectorByIds(const DataSetPtr dataset, milvus::OpContext* /*op_context*/) const override {
+        if (!dataset || !dataset->GetIds()) return expected<DataSetPtr>::Err(Status::invalid_args, "null ids");
+        if (!HasRawData(metric_name_)) return expected<DataSetPtr>::Err(Status::not_implemented, "no raw data");
+        const knhip_index* store = Kind == KNHIP_BRUTE_FORCE ? idx_.p : raw_.p;
+        if (!store) return expected<DataSetPtr>::Err(Status::empty_index, "index not built");
         const int64_t n = dataset->GetRows();
-        const int64_t* ids = dataset->GetIds();
-        auto* out = new float[n * dim_];
-        for (int64_t i = 0; i < n; i++) {
-            if (ids[i] < 0 || ids[i] >= count_) {
-                delete[] out;
-                return expected<DataSetPtr>::Err(Status::invalid_args, "id out of range");
-            }
-            std::memcpy(out + i * dim_, &raw_[ids[i] * dim_], sizeof(float) * dim_);
-        }
-        auto ds = GenDataSet(n, dim_, out);
-        ds->SetIsOwner(true);
-        return ds;
+        auto out = std::make_unique<float[]>(std::max<int64_t>(n * dim_, 1));
+        std::shared_lock<std::shared_mutex> lk(rw_);
+        const int rc = knhip_index_get_vectors(store, n, dataset->GetIds(), out.get());
+        if (rc) return expected<DataSetPtr>::Err(ToStatus(rc), knhip_last_error());
+        return GenResultDataSet(n, dim_, (const void*)out.release());
     }
-    bool HasRawData(const std::string& metric_type) const override {
-        // cosine stores normalised vectors (ivf.cc StaticHasRawData semantics)
-        return (kind_ == KNHIP_BRUTE_FORCE || kind_ == KNHIP_IVF_FLAT) && metric_type != metric::COSINE;
+
+    static bool
+    StaticHasRawData(const knowhere::BaseConfig& config, const IndexVersion& /*version*/) {
+        // cosine stores normalised vectors (IvfIndexNode::StaticHasRawData semantics, ivf.cc:142-160)
+        const bool cosine = config.metric_type.has_value() && IsMetricType(config.metric_type.value(), metric::COSINE);
+        return (Kind == KNHIP_BRUTE_FORCE || Kind == KNHIP_IVF_FLAT) && !cosine;
     }
-    expected<DataSetPtr> GetIndexMeta(const Json&) const override {
+    bool
+    HasRawData(const std::string& metric_type) const override {
+        return (Kind == KNHIP_BRUTE_FORCE || Kind == KNHIP_IVF_FLAT) && !IsMetricType(metric_type, metric::COSINE);
+    }
+
+    expected<DataSetPtr>
+    GetIndexMeta(std::unique_ptr<Config> /*cfg*/) const override {
         return expected<DataSetPtr>::Err(Status::not_implemented, "GetIndexMeta not implemented");
     }
 
-    // One named blob in the BinarySet (ivf.cc:1717-1744), holding the FAISS byte format the CPU nodes
-    // write (faiss_io.h): IxF2/IxFI, IwFl, IwSq, IwPQ, wrapped in IxRF when built with refine.
-    Status Serialize(BinarySet& binset) const override {
-        if (!idx_) return Status::empty_index;
+    // One named blob in the BinarySet (ivf.cc:1717-1744), holding the FAISS byte format the CPU nodes write
+    // (faiss_io.h): IxF2/IxFI (IxF9 for cosine), IwFl, IwSq, IwPQ, wrapped in IxRF when built with refine.  The trained
+    // state and the inverted lists are read back from the device.
+    Status
+    Serialize(BinarySet& binset) const override {
+        if (!idx_.p) return Status::empty_index;
         using namespace knhip_host;
+        std::shared_lock<std::shared_mutex> lk(rw_);
+        const int64_t count = knhip_index_count(idx_.p);
         FaissIndexData x;
-        auto fill_hdr = [&](FaissHeader& h, int64_t ntotal) {
+        auto fill_hdr = [&](FaissHeader& h, int64_t ntotal, bool cosine_byte) {
             h.d = (int32_t)dim_;
             h.ntotal = ntotal;
-            h.dummy[0] = cosine_ ? 1 : 0;  // Knowhere's is_cosine byte (cppcontrib/knowhere/impl/index_write.cpp:84-88)
+            h.dummy[0] = cosine_byte ? 1 : 0;  // Knowhere's is_cosine byte (cppcontrib/knowhere/impl/index_write.cpp:84-88)
             h.is_trained = true;
             h.metric = metric_ == KNHIP_L2 ? 1 : 0;
         };
         const uint32_t flat_cc = metric_ == KNHIP_L2 ? FourCC("IxF2") : FourCC("IxFI");
-        fill_hdr(x.hdr, count_);
-        if (kind_ == KNHIP_BRUTE_FORCE) {
-            x.fourcc = flat_cc;
-            x.xb = raw_;
+        fill_hdr(x.hdr, count, cosine_);
+        int rc = 0;
+        if constexpr (Kind == KNHIP_BRUTE_FORCE) {
+            x.xb.resize((size_t)count * dim_);
+            if ((rc = knhip_index_get_lists(idx_.p, (uint8_t*)x.xb.data(), nullptr))) return ToStatus(rc);
+            if (cosine_) {  // IndexFlatCosine: "IxF9" = header, rows, L2 norms (index_write.cpp:539-546); the rows held
+                x.fourcc = FourCC("IxF9");  // here are already normalised, so every stored norm is 1
+                x.flat_norms.assign((size_t)count, 1.0f);
+            } else {
+                x.fourcc = flat_cc;
+            }
         } else {
-            x.fourcc = kind_ == KNHIP_IVF_FLAT ? FourCC("IwFl") : kind_ == KNHIP_IVF_PQ ? FourCC("IwPQ") : FourCC("IwSq");
+            x.fourcc = Kind == KNHIP_IVF_FLAT ? FourCC("IwFl") : Kind == KNHIP_IVF_PQ ? FourCC("IwPQ") : FourCC("IwSq");
             x.nlist = (uint64_t)nlist_;
-            x.nprobe = (uint64_t)cfg_.nprobe;
+            x.nprobe = (uint64_t)default_nprobe_;
             x.quantizer.fourcc = flat_cc;
-            fill_hdr(x.quantizer.hdr, nlist_);
-            x.quantizer.hdr.dummy[0] = 0;
-            x.quantizer.xb = centroids_;
+            fill_hdr(x.quantizer.hdr, nlist_, false);
+            x.quantizer.xb.resize((size_t)nlist_ * dim_);
+            if ((rc = knhip_index_get_coarse(idx_.p, x.quantizer.xb.data()))) return ToStatus(rc);
             x.by_residual = true;
             x.code_size = (uint64_t)CodeSize();
-            if (kind_ == KNHIP_IVF_PQ) {
-                x.pq_d = (uint64_t)dim_; x.pq_M = (uint64_t)m_; x.pq_nbits = 8;
-                x.pq_centroids = codebooks_;
-            } else if (kind_ == KNHIP_IVF_SQ8) {
+            if constexpr (Kind == KNHIP_IVF_PQ) {
+                x.pq_d = (uint64_t)dim_;
+                x.pq_M = (uint64_t)m_;
+                x.pq_nbits = 8;
+                x.pq_centroids.resize((size_t)256 * dim_);
+                if ((rc = knhip_index_get_pq(idx_.p, x.pq_centroids.data()))) return ToStatus(rc);
+            } else if constexpr (Kind == KNHIP_IVF_SQ8) {
                 x.sq_qtype = 0;      // ScalarQuantizer::QT_8bit
                 x.sq_rangestat = 0;  // RS_minmax
-                x.sq_d = (uint64_t)dim_; x.sq_code_size = (uint64_t)dim_;
-                x.sq_trained = sq_trained_;
+                x.sq_d = (uint64_t)dim_;
+                x.sq_code_size = (uint64_t)dim_;
+                x.sq_trained.resize((size_t)2 * dim_);
+                if ((rc = knhip_index_get_sq(idx_.p, x.sq_trained.data(), x.sq_trained.data() + dim_))) return ToStatus(rc);
             }
-            x.codes = list_codes_;
-            x.ids = list_ids_;
+            std::vector<int64_t> sizes((size_t)nlist_);
+            if ((rc = knhip_index_get_list_sizes(idx_.p, sizes.data()))) return ToStatus(rc);
+            std::vector<uint8_t> codes((size_t)count * CodeSize());
+            std::vector<int64_t> ids((size_t)count);
+            if ((rc = knhip_index_get_lists(idx_.p, codes.data(), ids.data()))) return ToStatus(rc);
+            x.codes.assign(nlist_, {});
+            x.ids.assign(nlist_, {});
             size_t non0 = 0;
-            for (auto& l : list_ids_) non0 += !l.empty();
+            int64_t pos = 0;
+            for (int64_t l = 0; l < nlist_; l++) {
+                x.codes[l].assign(codes.begin() + pos * CodeSize(), codes.begin() + (pos + sizes[l]) * CodeSize());
+                x.ids[l].assign(ids.begin() + pos, ids.begin() + pos + sizes[l]);
+                pos += sizes[l];
+                non0 += sizes[l] != 0;
+            }
             x.lists_sparse = !(non0 > (size_t)nlist_ / 2);  // index_write.cpp:309-316
-            if (kind_ == KNHIP_IVF_FLAT && cosine_) {       // Knowhere cosine IVF-Flat carries the row norms
+            if (Kind == KNHIP_IVF_FLAT && cosine_) {        // Knowhere cosine IVF-Flat carries the row norms
                 x.with_norm = true;
                 x.norms.assign(nlist_, {});
-                for (int64_t l = 0; l < nlist_; l++)
-                    for (size_t i = 0; i < list_ids_[l].size(); i++) {
-                        const float* v = (const float*)&list_codes_[l][i * dim_ * 4];
-                        float s = 0;
-                        for (int64_t t = 0; t < dim_; t++) s += v[t] * v[t];
-                        x.norms[l].push_back(std::sqrt(s));
-                    }
+                for (int64_t l = 0; l < nlist_; l++) x.norms[l].assign((size_t)sizes[l], 1.0f);  // rows are normalised
             }
-            if (has_refine_) {  // IndexRefineFlat (ivf.cc:673-700)
+            if (has_refine_ && raw_.p) {  // IndexRefineFlat (ivf.cc:673-700)
                 x.has_refine = true;
-                fill_hdr(x.refine_hdr, count_);
+                fill_hdr(x.refine_hdr, count, cosine_);
                 x.refine_index.fourcc = flat_cc;
-                fill_hdr(x.refine_index.hdr, count_);
-                x.refine_index.hdr.dummy[0] = 0;
-                x.refine_index.xb = raw_;
+                fill_hdr(x.refine_index.hdr, count, false);
+                x.refine_index.xb.resize((size_t)count * dim_);
+                if ((rc = knhip_index_get_lists(raw_.p, (uint8_t*)x.refine_index.xb.data(), nullptr))) return ToStatus(rc);
                 x.k_factor = 1.f;
             }
         }
@@ -507,169 +456,243 @@ class HipIndexNode : public IndexNode {
         return Status::success;
     }
 
-    // Accepts the blob of this node AND of the CPU node of the same kind (FLAT / IVF_FLAT / IVF_PQ /
-    // IVF_SQ8, or the knowhere-1.x name "IVF", ivf.cc:1750-1757): same bytes.
-    Status Deserialize(const BinarySet& binset, const Json& cfg) override {
+    // Accepts the blob of this node AND of the CPU node of the same kind (FLAT / IVF_FLAT / IVF_PQ / IVF_SQ8, or the
+    // knowhere-1.x name "IVF", ivf.cc:1750-1757): same bytes.  Every length and cross-field relation is checked before a
+    // pointer is handed to the C ABI: a corrupted BinarySet yields invalid_serialized_index_type, never a wild read.
+    Status
+    Deserialize(const BinarySet& binset, std::shared_ptr<Config> cfg) override {
         using namespace knhip_host;
         static const char* cpu_names[] = {"FLAT", "IVF_FLAT", "IVF_PQ", "IVF_SQ8"};
         BinaryPtr b = binset.GetByName(Type());
-        if (!b) b = binset.GetByName(cpu_names[kind_ == KNHIP_BRUTE_FORCE ? 0 : kind_ == KNHIP_IVF_FLAT ? 1
-                                               : kind_ == KNHIP_IVF_PQ    ? 2 : 3]);
-        if (!b && kind_ != KNHIP_BRUTE_FORCE) b = binset.GetByName("IVF");
+        if (!b) b = binset.GetByName(cpu_names[Kind]);
+        if (!b && Kind != KNHIP_BRUTE_FORCE) b = binset.GetByName("IVF");
         if (!b) return Status::invalid_binary_set;
         FaissIndexData x;
         std::string err;
         if (!ParseFaissIndex(b->data.get(), (size_t)b->size, &x, &err)) return Status::invalid_serialized_index_type;
-        const bool flat = x.fourcc == FourCC("IxF2") || x.fourcc == FourCC("IxFI");
-        const bool kind_ok = (kind_ == KNHIP_BRUTE_FORCE && flat) || (kind_ == KNHIP_IVF_FLAT && x.fourcc == FourCC("IwFl")) ||
-                             (kind_ == KNHIP_IVF_PQ && x.fourcc == FourCC("IwPQ")) ||
-                             (kind_ == KNHIP_IVF_SQ8 && x.fourcc == FourCC("IwSq"));
+        const bool flat = x.fourcc == FourCC("IxF2") || x.fourcc == FourCC("IxFI") || x.fourcc == FourCC("IxF9");
+        const bool kind_ok = (Kind == KNHIP_BRUTE_FORCE && flat) || (Kind == KNHIP_IVF_FLAT && x.fourcc == FourCC("IwFl")) ||
+                             (Kind == KNHIP_IVF_PQ && x.fourcc == FourCC("IwPQ")) ||
+                             (Kind == KNHIP_IVF_SQ8 && x.fourcc == FourCC("IwSq"));
         if (!kind_ok) return Status::invalid_serialized_index_type;
         if (x.hdr.metric != 0 && x.hdr.metric != 1) return Status::invalid_metric_type;
-        if (!flat && x.quantizer.hdr.metric != x.hdr.metric) return Status::not_implemented;
-        if (kind_ == KNHIP_IVF_PQ &&
-            (x.pq_nbits != 8 || !x.by_residual || !(x.pq_M == 8 || x.pq_M == 16 || x.pq_M == 32 || x.pq_M == 64)))
-            return Status::not_implemented;
-        if (kind_ == KNHIP_IVF_SQ8 && (x.sq_qtype != 0 || !x.by_residual || x.sq_trained.size() != 2 * (size_t)x.hdr.d))
-            return Status::not_implemented;
-        metric_ = x.hdr.metric == 1 ? KNHIP_L2 : KNHIP_IP;
-        cosine_ = x.hdr.is_cosine();
-        if (cfg.contains(meta::METRIC_TYPE) && cfg.at(meta::METRIC_TYPE).is_string())
-            cosine_ = cosine_ || cfg.at(meta::METRIC_TYPE).as_string() == metric::COSINE;
-        cfg_.metric = cosine_ ? metric::COSINE : (metric_ == KNHIP_L2 ? metric::L2 : metric::IP);
-        dim_ = x.hdr.d;
-        count_ = x.hdr.ntotal;
-        nlist_ = (int64_t)x.nlist;
-        if (x.nprobe >= 1 && x.nprobe <= 65536) cfg_.nprobe = (int64_t)x.nprobe;  // the index's default nprobe
-        m_ = (int64_t)x.pq_M;
-        centroids_ = std::move(x.quantizer.xb);
-        codebooks_ = std::move(x.pq_centroids);
-        sq_trained_ = std::move(x.sq_trained);
-        list_codes_ = std::move(x.codes);
-        list_ids_ = std::move(x.ids);
-        has_refine_ = x.has_refine;
-        raw_.clear();
-        if (kind_ == KNHIP_BRUTE_FORCE) {
-            raw_ = std::move(x.xb);
-        } else if (x.has_refine) {
-            if (x.refine_index.hdr.ntotal != count_) return Status::invalid_serialized_index_type;
-            raw_ = std::move(x.refine_index.xb);
-        } else if (kind_ == KNHIP_IVF_FLAT) {  // raw rows back in id order (make_direct_map, ivf.cc:1815-1828)
-            raw_.assign((size_t)count_ * dim_, 0.f);
-            for (int64_t l = 0; l < nlist_; l++)
-                for (size_t i = 0; i < list_ids_[l].size(); i++) {
-                    const int64_t id = list_ids_[l][i];
-                    if (id < 0 || id >= count_) { raw_.clear(); l = nlist_; break; }
-                    std::memcpy(&raw_[id * dim_], &list_codes_[l][i * dim_ * 4], sizeof(float) * dim_);
+        const int64_t d = x.hdr.d, ntotal = x.hdr.ntotal;
+        if (d <= 0 || d > 65536 || ntotal < 0) return Status::invalid_serialized_index_type;
+        if (flat) {
+            if (x.xb.size() != (size_t)ntotal * d) return Status::invalid_serialized_index_type;
+            if (!x.flat_norms.empty() && x.flat_norms.size() != (size_t)ntotal) return Status::invalid_serialized_index_type;
+        } else {
+            if (x.quantizer.hdr.metric != x.hdr.metric) return Status::not_implemented;
+            if (x.nlist == 0 || x.nlist > 65536 * 16 || x.quantizer.hdr.d != d ||
+                x.quantizer.xb.size() != (size_t)x.nlist * d || x.codes.size() != x.nlist || x.ids.size() != x.nlist)
+                return Status::invalid_serialized_index_type;
+            const uint64_t want_cs = Kind == KNHIP_IVF_FLAT ? (uint64_t)d * 4 : Kind == KNHIP_IVF_PQ ? x.pq_M : (uint64_t)d;
+            if (Kind == KNHIP_IVF_PQ &&
+                (x.pq_nbits != 8 || !x.by_residual || !(x.pq_M == 8 || x.pq_M == 16 || x.pq_M == 32 || x.pq_M == 64)))
+                return Status::not_implemented;
+            if (Kind == KNHIP_IVF_PQ && (x.pq_d != (uint64_t)d || d % (int64_t)x.pq_M != 0 ||
+                                          x.pq_centroids.size() != (size_t)256 * d))
+                return Status::invalid_serialized_index_type;
+            if (Kind == KNHIP_IVF_SQ8 && (x.sq_qtype != 0 || !x.by_residual)) return Status::not_implemented;
+            if (Kind == KNHIP_IVF_SQ8 && (x.sq_d != (uint64_t)d || x.sq_code_size != (uint64_t)d ||
+                                           x.sq_trained.size() != 2 * (size_t)d))
+                return Status::invalid_serialized_index_type;
+            if (Kind != KNHIP_IVF_FLAT && x.code_size != want_cs) return Status::invalid_serialized_index_type;
+            int64_t sum = 0;
+            for (uint64_t l = 0; l < x.nlist; l++) {
+                const size_t n = x.ids[l].size();
+                if (x.codes[l].size() != n * want_cs) return Status::invalid_serialized_index_type;
+                if (x.with_norm && (x.norms.size() != x.nlist || x.norms[l].size() != n))
+                    return Status::invalid_serialized_index_type;
+                sum += (int64_t)n;
+            }
+            if (sum != ntotal) return Status::invalid_serialized_index_type;
+            if (x.has_refine) {
+                if (x.refine_index.hdr.ntotal != ntotal || x.refine_index.hdr.d != d ||
+                    x.refine_index.xb.size() != (size_t)ntotal * d)
+                    return Status::invalid_serialized_index_type;
+                for (uint64_t l = 0; l < x.nlist; l++) {
+                    for (int64_t id : x.ids[l]) {
+                        if (id < 0 || id >= ntotal) return Status::invalid_serialized_index_type;
+                    }
                 }
+            }
         }
-        knhip_index_destroy(idx_);
-        idx_ = nullptr;
+        metric_ = x.hdr.metric == 1 ? KNHIP_L2 : KNHIP_IP;
+        cosine_ = x.hdr.is_cosine() || x.fourcc == FourCC("IxF9") || x.with_norm;
+        if (cfg) {
+            const auto& c = static_cast<const BaseConfig&>(*cfg);
+            if (c.metric_type.has_value() && IsMetricType(c.metric_type.value(), metric::COSINE) && metric_ == KNHIP_IP)
+                cosine_ = true;
+        }
+        metric_name_ = cosine_ ? metric::COSINE : (metric_ == KNHIP_L2 ? metric::L2 : metric::IP);
+        dim_ = d;
+        nlist_ = (int64_t)x.nlist;
+        if (x.nprobe >= 1 && x.nprobe <= 65536) default_nprobe_ = (int64_t)x.nprobe;  // the index's default nprobe
+        m_ = (int64_t)x.pq_M;
+        has_refine_ = x.has_refine;
+        // The CPU cosine indexes keep the RAW rows plus their L2 norms and score ip / norm
+        // (cppcontrib/knowhere/IndexIVFFlat.cpp:199-210, utils/distances.cpp:344-353); this backend scores ip on
+        // normalised rows: divide each row by its stored norm once, here.
+        auto scale_rows = [&](float* rows, const float* norms, size_t n) {
+            for (size_t i = 0; i < n; i++) {
+                const float nr = norms[i];
+                if (nr > 0 && nr != 1.0f) {
+                    for (int64_t t = 0; t < d; t++) rows[i * d + t] = rows[i * d + t] / nr;
+                }
+            }
+        };
+        if (flat && !x.flat_norms.empty()) scale_rows(x.xb.data(), x.flat_norms.data(), (size_t)ntotal);
+        if (Kind == KNHIP_IVF_FLAT && x.with_norm) {
+            for (uint64_t l = 0; l < x.nlist; l++)
+                scale_rows((float*)x.codes[l].data(), x.norms[l].data(), x.ids[l].size());
+        }
+        std::unique_lock<std::shared_mutex> lk(rw_);
+        idx_.reset();
+        raw_.reset();
         knhip_desc desc{};
-        desc.kind = kind_; desc.metric = metric_; desc.dim = (int32_t)dim_; desc.nlist = nlist_;
-        desc.pq_m = (int32_t)m_; desc.pq_nbits = 8;
-        int rc = knhip_index_create(&desc, &idx_);
+        desc.kind = Kind;
+        desc.metric = metric_;
+        desc.dim = (int32_t)dim_;
+        desc.nlist = nlist_;
+        desc.pq_m = (int32_t)m_;
+        desc.pq_nbits = 8;
+        int rc = knhip_index_create(&desc, &idx_.p);
         if (rc) return ToStatus(rc);
-        trained_ = true;
-        if (kind_ == KNHIP_BRUTE_FORCE) return ToStatus(knhip_index_add_vectors(idx_, count_, raw_.data(), nullptr, 0));
-        return Upload();
+        if constexpr (Kind == KNHIP_BRUTE_FORCE) {
+            return ToStatus(knhip_index_add(idx_.p, ntotal, x.xb.data(), nullptr));
+        }
+        if ((rc = knhip_index_set_coarse(idx_.p, x.quantizer.xb.data()))) return ToStatus(rc);
+        if (Kind == KNHIP_IVF_PQ && (rc = knhip_index_set_pq(idx_.p, x.pq_centroids.data()))) return ToStatus(rc);
+        if (Kind == KNHIP_IVF_SQ8 && (rc = knhip_index_set_sq(idx_.p, x.sq_trained.data(), x.sq_trained.data() + dim_)))
+            return ToStatus(rc);
+        std::vector<int64_t> sizes(nlist_);
+        std::vector<const uint8_t*> cp(nlist_);
+        std::vector<const int64_t*> ip(nlist_);
+        for (int64_t l = 0; l < nlist_; l++) {
+            sizes[l] = (int64_t)x.ids[l].size();
+            cp[l] = x.codes[l].data();
+            ip[l] = x.ids[l].data();
+        }
+        if ((rc = knhip_index_add_lists(idx_.p, sizes.data(), cp.data(), ip.data()))) return ToStatus(rc);
+        // raw rows for refine / GetVectorByIds, back in id order
+        if (x.has_refine || (Kind == KNHIP_IVF_FLAT && !cosine_)) {
+            std::vector<float> rows;
+            if (x.has_refine) {
+                rows = std::move(x.refine_index.xb);
+            } else {
+                rows.assign((size_t)ntotal * d, 0.f);
+                bool dense = true;
+                for (int64_t l = 0; l < nlist_ && dense; l++) {
+                    for (size_t i = 0; i < x.ids[l].size(); i++) {
+                        const int64_t id = x.ids[l][i];
+                        if (id < 0 || id >= ntotal) {
+                            dense = false;  // custom ids: no direct map (make_direct_map needs 0..n-1, ivf.cc:1815-1828)
+                            break;
+                        }
+                        std::memcpy(&rows[(size_t)id * d], &x.codes[l][i * d * 4], sizeof(float) * d);
+                    }
+                }
+                if (!dense) rows.clear();
+            }
+            if (!rows.empty()) {
+                knhip_desc rd{};
+                rd.kind = KNHIP_BRUTE_FORCE;
+                rd.metric = metric_;
+                rd.dim = (int32_t)dim_;
+                if ((rc = knhip_index_create(&rd, &raw_.p))) return ToStatus(rc);
+                if ((rc = knhip_index_add(raw_.p, ntotal, rows.data(), nullptr))) return ToStatus(rc);
+            }
+        }
+        return Status::success;
     }
-    Status DeserializeFromFile(const std::string&, const Json&) override {
+
+    Status
+    DeserializeFromFile(const std::string& /*filename*/, std::shared_ptr<Config> /*config*/) override {
         return Status::not_implemented;  // as the cuVS node (gpu_cuvs.h:250-253)
     }
 
-    int64_t Dim() const override { return dim_; }
-    int64_t Size() const override { return idx_ ? knhip_index_device_bytes(idx_) : 0; }
-    int64_t Count() const override { return count_; }
-    std::string Type() const override {
-        switch (kind_) {
+    static std::unique_ptr<BaseConfig>
+    StaticCreateConfig() {
+        return std::make_unique<knowhere_config_type>();
+    }
+    std::unique_ptr<BaseConfig>
+    CreateConfig() const override {
+        return StaticCreateConfig();
+    }
+    static Status
+    StaticConfigCheck(const knowhere::BaseConfig& config, PARAM_TYPE paramType, std::string& msg) {
+        // what the typed config cannot express: this backend needs at least one visible device
+        if (paramType == PARAM_TYPE::TRAIN && knhip_device_count() <= 0) {
+            msg = "no HIP device available for " + std::string(TypeName());
+            return Status::cuda_runtime_error;
+        }
+        return Status::success;
+    }
+
+    int64_t
+    Dim() const override {
+        return dim_;
+    }
+    int64_t
+    Size() const override {
+        return (idx_.p ? knhip_index_device_bytes(idx_.p) : 0) + (raw_.p ? knhip_index_device_bytes(raw_.p) : 0);
+    }
+    int64_t
+    Count() const override {
+        return idx_.p ? knhip_index_count(idx_.p) : 0;
+    }
+    static const char*
+    TypeName() {
+        switch (Kind) {
             case KNHIP_BRUTE_FORCE: return IndexEnum::INDEX_HIP_BRUTEFORCE;
             case KNHIP_IVF_FLAT: return IndexEnum::INDEX_HIP_IVFFLAT;
             case KNHIP_IVF_PQ: return IndexEnum::INDEX_HIP_IVFPQ;
             default: return IndexEnum::INDEX_HIP_IVFSQ8;
         }
     }
+    std::string
+    Type() const override {
+        return TypeName();
+    }
 
  private:
-    int64_t CodeSize() const { return kind_ == KNHIP_IVF_FLAT ? dim_ * 4 : (kind_ == KNHIP_IVF_PQ ? m_ : dim_); }
-
-    Status Upload() {
-        int rc = knhip_index_set_coarse(idx_, centroids_.data());
-        if (rc) return ToStatus(rc);
-        if (kind_ == KNHIP_IVF_PQ && (rc = knhip_index_set_pq(idx_, codebooks_.data()))) return ToStatus(rc);
-        if (kind_ == KNHIP_IVF_SQ8 &&
-            (rc = knhip_index_set_sq(idx_, sq_trained_.data(), sq_trained_.data() + dim_)))
-            return ToStatus(rc);
-        std::vector<int64_t> sizes(nlist_);
-        std::vector<const uint8_t*> cp(nlist_);
-        std::vector<const int64_t*> ip(nlist_);
-        for (int64_t l = 0; l < nlist_; l++) {
-            sizes[l] = (int64_t)list_ids_[l].size();
-            cp[l] = list_codes_[l].data();
-            ip[l] = list_ids_[l].data();
-        }
-        return ToStatus(knhip_index_add_lists(idx_, sizes.data(), cp.data(), ip.data()));
+    int64_t
+    CodeSize() const {
+        return Kind == KNHIP_IVF_FLAT ? dim_ * 4 : (Kind == KNHIP_IVF_PQ ? m_ : dim_);
+    }
+    // a second device-resident store of the raw rows: IndexRefineFlat, and the direct map of IVF_FLAT (GetVectorByIds)
+    bool
+    NeedRawStore() const {
+        return ((Kind == KNHIP_IVF_PQ || Kind == KNHIP_IVF_SQ8) && has_refine_) || (Kind == KNHIP_IVF_FLAT && !cosine_);
     }
 
-    // exact re-rank in the reference's scalar order (IndexRefine.cpp:108-140)
-    void RefineHost(const float* q, int64_t nq, int64_t kbase, const int64_t* cand, int64_t k, int64_t* oi,
-                    float* od) const {
-        const bool l2 = metric_ == KNHIP_L2;
-        std::vector<std::pair<float, int64_t>> v;
-        for (int64_t i = 0; i < nq; i++) {
-            v.clear();
-            for (int64_t j = 0; j < kbase; j++) {
-                const int64_t id = cand[i * kbase + j];
-                if (id < 0) break;
-                const float* y = &raw_[id * dim_];
-                const float* x = q + i * dim_;
-                float acc = 0;
-                for (int64_t t = 0; t < dim_; t++) {
-                    if (l2) {
-                        const float d = x[t] - y[t];
-                        acc += d * d;
-                    } else {
-                        acc += x[t] * y[t];
-                    }
-                }
-                v.emplace_back(acc, id);
-            }
-            std::sort(v.begin(), v.end(), [l2](const auto& a, const auto& b) {
-                return l2 ? (a.first < b.first || (a.first == b.first && a.second < b.second))
-                          : (a.first > b.first || (a.first == b.first && a.second > b.second));
-            });
-            for (int64_t j = 0; j < k; j++) {
-                oi[i * k + j] = j < (int64_t)v.size() ? v[j].second : -1;
-                od[i * k + j] = j < (int64_t)v.size() ? v[j].first : (l2 ? FLT_MAX : -FLT_MAX);
-            }
-        }
-    }
-
-    int kind_;
     int metric_ = KNHIP_L2;
-    bool cosine_ = false, trained_ = false, has_refine_ = false;
-    int64_t dim_ = 0, nlist_ = 0, m_ = 0, count_ = 0;
-    HipConfig cfg_;
-    knhip_index* idx_ = nullptr;
-    std::vector<float> centroids_, codebooks_, sq_trained_, raw_;
-    std::vector<std::vector<uint8_t>> list_codes_;
-    std::vector<std::vector<int64_t>> list_ids_;
+    bool cosine_ = false, has_refine_ = false;
+    std::string metric_name_ = metric::L2;
+    int64_t dim_ = 0, nlist_ = 0, m_ = 0, default_nprobe_ = 8;
+    KnhipHandle idx_, raw_;
+    mutable std::shared_mutex rw_;  // Add / Deserialize (exclusive) vs Search / Serialize (shared)
 };
 
-// static-init registration, as every node's translation unit does (index_factory.h:75-77)
-KNOWHERE_HIP_REGISTER_GLOBAL(GPU_HIP_BRUTE_FORCE, HipIndexNode, KNHIP_BRUTE_FORCE);
-KNOWHERE_HIP_REGISTER_GLOBAL(GPU_HIP_IVF_FLAT, HipIndexNode, KNHIP_IVF_FLAT);
-KNOWHERE_HIP_REGISTER_GLOBAL(GPU_HIP_IVF_PQ, HipIndexNode, KNHIP_IVF_PQ);
-KNOWHERE_HIP_REGISTER_GLOBAL(GPU_HIP_IVF_SQ8, HipIndexNode, KNHIP_IVF_SQ8);
+template <typename DataType>
+using HipBruteForceIndexNode = HipIndexNode<DataType, KNHIP_BRUTE_FORCE>;
+template <typename DataType>
+using HipIvfFlatIndexNode = HipIndexNode<DataType, KNHIP_IVF_FLAT>;
+template <typename DataType>
+using HipIvfPqIndexNode = HipIndexNode<DataType, KNHIP_IVF_PQ>;
+template <typename DataType>
+using HipIvfSqIndexNode = HipIndexNode<DataType, KNHIP_IVF_SQ8>;
 
-// BruteForce::Search<fp32> (include/knowhere/comp/brute_force.h:27-31) through the same kernels
-template <>
-expected<DataSetPtr> BruteForce::Search<fp32>(const DataSetPtr base, const DataSetPtr query, const Json& config,
-                                              const BitsetView& bitset) {
-    HipIndexNode node(Version::GetCurrentVersion(), KNHIP_BRUTE_FORCE);
-    Status s = node.Build(base, config);
-    if (s != Status::success) return expected<DataSetPtr>::Err(s, "brute force build failed");
-    return node.Search(query, config, bitset);
-}
+// static-init registration, as src/index/gpu_cuvs/gpu_cuvs_ivf_pq.cc:27-63 does (fp16 / bf16 / int8: add the matching
+// KNOWHERE_MOCK_REGISTER_GLOBAL lines)
+KNOWHERE_REGISTER_GLOBAL_WITH_THREAD_POOL(GPU_HIP_BRUTE_FORCE, HipBruteForceIndexNode, fp32,
+                                          knowhere::feature::GPU_KNN_FLOAT_INDEX, HipSearchPoolSize());
+KNOWHERE_REGISTER_GLOBAL_WITH_THREAD_POOL(GPU_HIP_IVF_FLAT, HipIvfFlatIndexNode, fp32,
+                                          knowhere::feature::GPU_ANN_FLOAT_INDEX, HipSearchPoolSize());
+KNOWHERE_REGISTER_GLOBAL_WITH_THREAD_POOL(GPU_HIP_IVF_PQ, HipIvfPqIndexNode, fp32,
+                                          knowhere::feature::GPU_ANN_FLOAT_INDEX, HipSearchPoolSize());
+KNOWHERE_REGISTER_GLOBAL_WITH_THREAD_POOL(GPU_HIP_IVF_SQ8, HipIvfSqIndexNode, fp32,
+                                          knowhere::feature::GPU_ANN_FLOAT_INDEX, HipSearchPoolSize());
 
 }  // namespace knowhere

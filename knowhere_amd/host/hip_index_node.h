@@ -1,0 +1,131 @@
+// knowhere_amd/host/hip_index_node.h -- index names and Config classes of the MI355X backend.
+//
+// Written against the REAL Knowhere interface: with -DKNHIP_WITH_KNOWHERE_HEADERS it includes the reference's own
+// headers (this is how it is built inside a Knowhere tree, and how tests/test_node_contract.py compile-checks it against
+// /root/reference/include); without it, knowhere_shim.h supplies the same names (same signatures) so the node also
+// builds and runs where the reference tree and its third-party dependencies are absent.
+#pragma once
+
+#if defined(KNHIP_WITH_KNOWHERE_HEADERS)
+#include "index/flat/flat_config.h"
+#include "index/ivf/ivf_config.h"
+#include "knowhere/config.h"
+#include "knowhere/context.h"
+#include "knowhere/index/index_factory.h"
+#include "knowhere/index/index_node.h"
+#include "knowhere/index/index_node_thread_pool_wrapper.h"
+#else
+#include "knowhere_shim.h"
+#endif
+
+namespace knowhere {
+
+// new index types, next to INDEX_CUVS_* / INDEX_GPU_* (include/knowhere/comp/index_param.h:42-55); the same pairs go
+// into the legal-index table (include/knowhere/index/index_table.h:73-84)
+namespace IndexEnum {
+inline constexpr const char* INDEX_HIP_BRUTEFORCE = "GPU_HIP_BRUTE_FORCE";
+inline constexpr const char* INDEX_HIP_IVFFLAT = "GPU_HIP_IVF_FLAT";
+inline constexpr const char* INDEX_HIP_IVFPQ = "GPU_HIP_IVF_PQ";
+inline constexpr const char* INDEX_HIP_IVFSQ8 = "GPU_HIP_IVF_SQ8";
+}  // namespace IndexEnum
+
+// ---- configs: the CPU index's config + the limits of this backend, in the style of
+// src/index/gpu_cuvs/gpu_cuvs_ivf_pq_config.h:27-95 (k <= 1024 as the cuVS configs, :49-53) -------------------------
+inline Status
+HipCheckMetric(const BaseConfig& cfg, PARAM_TYPE param_type, std::string* err_msg) {
+    if (param_type == PARAM_TYPE::TRAIN && cfg.metric_type.has_value()) {
+        const std::string& m = cfg.metric_type.value();
+        if (!IsMetricType(m, metric::L2) && !IsMetricType(m, metric::IP) && !IsMetricType(m, metric::COSINE)) {
+            if (err_msg) *err_msg = "metric type " + m + " not found or not supported, supported: [L2 IP COSINE]";
+            return Status::invalid_metric_type;
+        }
+    }
+    return Status::success;
+}
+
+struct HipBruteForceConfig : public FlatConfig {
+    KNOWHERE_DECLARE_CONFIG(HipBruteForceConfig) {
+        KNOWHERE_CONFIG_DECLARE_FIELD(k)
+            .set_default(10)
+            .description("search for top k similar vector.")
+            .set_range(1, 1024)
+            .for_search();
+    }
+    Status
+    CheckAndAdjust(PARAM_TYPE param_type, std::string* err_msg) override {
+        return HipCheckMetric(*this, param_type, err_msg);
+    }
+};
+
+struct HipIvfFlatConfig : public IvfFlatConfig {
+    KNOWHERE_DECLARE_CONFIG(HipIvfFlatConfig) {
+        KNOWHERE_CONFIG_DECLARE_FIELD(k)
+            .set_default(10)
+            .description("search for top k similar vector.")
+            .set_range(1, 1024)
+            .for_search();
+    }
+    Status
+    CheckAndAdjust(PARAM_TYPE param_type, std::string* err_msg) override {
+        return HipCheckMetric(*this, param_type, err_msg);
+    }
+};
+
+struct HipIvfPqConfig : public IvfPqConfig {
+    KNOWHERE_DECLARE_CONFIG(HipIvfPqConfig) {
+        KNOWHERE_CONFIG_DECLARE_FIELD(k)
+            .set_default(10)
+            .description("search for top k similar vector.")
+            .set_range(1, 1024)
+            .for_search();
+        // m = 0: the backend picks (about dim / 2 sub-quantizers, as cuVS does for pq_dim = 0)
+        KNOWHERE_CONFIG_DECLARE_FIELD(m).set_default(0).description("m").set_range(0, 65536).for_train();
+        // the ADC kernels index 256-entry tables: 8-bit codes only (the cuVS config accepts 4..8)
+        KNOWHERE_CONFIG_DECLARE_FIELD(nbits).set_default(8).description("nbits").set_range(8, 8).for_train();
+    }
+    Status
+    CheckAndAdjust(PARAM_TYPE param_type, std::string* err_msg) override {
+        RETURN_IF_ERROR(HipCheckMetric(*this, param_type, err_msg));
+        if (param_type == PARAM_TYPE::TRAIN && m.has_value() && m.value() != 0) {
+            const int mv = m.value();
+            if (!(mv == 8 || mv == 16 || mv == 32 || mv == 64)) {
+                if (err_msg) *err_msg = "GPU_HIP_IVF_PQ supports m in {0 (auto), 8, 16, 32, 64}";
+                return Status::invalid_args;
+            }
+            if (dim.has_value() && dim.value() % mv != 0) {
+                if (err_msg) *err_msg = "The dimension of a vector (dim) should be a multiple of the number of subquantizers (m)";
+                return Status::invalid_args;
+            }
+        }
+        return Status::success;
+    }
+};
+
+struct HipIvfSqConfig : public IvfSqConfig {
+    KNOWHERE_DECLARE_CONFIG(HipIvfSqConfig) {
+        KNOWHERE_CONFIG_DECLARE_FIELD(k)
+            .set_default(10)
+            .description("search for top k similar vector.")
+            .set_range(1, 1024)
+            .for_search();
+    }
+    Status
+    CheckAndAdjust(PARAM_TYPE param_type, std::string* err_msg) override {
+        RETURN_IF_ERROR(HipCheckMetric(*this, param_type, err_msg));
+        if (param_type == PARAM_TYPE::TRAIN && sq_type.has_value()) {
+            std::string t = sq_type.value();
+            for (auto& c : t) c = (char)std::toupper((unsigned char)c);
+            if (t != "SQ8") {
+                if (err_msg) *err_msg = "GPU_HIP_IVF_SQ8 supports sq_type SQ8 only";
+                return Status::invalid_args;
+            }
+        }
+        return Status::success;
+    }
+};
+
+// bounded in-flight searches per device, as the cuVS nodes (src/index/gpu_cuvs/gpu_cuvs.h:48)
+auto static constexpr hip_concurrent_size_per_device = std::uint32_t{4};
+size_t HipSearchPoolSize();
+
+}  // namespace knowhere

@@ -2,7 +2,7 @@
 // Search / Serialize / Deserialize), so that non-C++ hosts and the Python tests can drive the plugin
 // exactly as Knowhere callers do.  Config is passed as "key=value;key=value" with the reference's key
 // names (include/knowhere/comp/index_param.h:100-180): integers, true/false, or strings.
-#include "knowhere_shim.h"
+#include "hip_index_node.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -51,7 +51,7 @@ const char* knhip_node_last_error() { return g_err.c_str(); }
 
 // IndexFactory::Instance().Create<fp32>(name, version); nullptr if the name is not registered
 void* knhip_node_create(const char* name) {
-    auto r = IndexFactory::Instance().Create<fp32>(name, 0);
+    auto r = IndexFactory::Instance().Create<fp32>(name, Version::GetCurrentVersion().VersionNumber());
     if (!r.has_value()) {
         g_err = r.what();
         return nullptr;

@@ -5,14 +5,17 @@
 // 42 / 44, same generators and the same bars: self-search ids[i]==i, recall vs BruteForce::Search
 // >= 0.999 / 0.95 / 0.75 for brute force / IVF-Flat / IVF-PQ, bitset at 40 % and 98 % filtered with
 // recall floors 0.7 / 0.4, k in {5, 25, 100}, serialize round trip) and tests/ut/test_bruteforce.cc
-// :70-76 (self-hit distance exactly 0).  Catch2 is absent from this image, hence the tiny harness.
+// :70-76 (self-hit distance exactly 0); plus the node contract: static functions (index_static.h), the thread-pool
+// wrapper, id-map out ids, repeated Add, GetVectorByIds, cancellation, Deserialize of damaged blobs.
+// Catch2 is absent from this image, hence the tiny harness.
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <random>
 #include <set>
+#include <thread>
 
-#include "../../knowhere_amd/host/knowhere_shim.h"
+#include "hip_index_node.h"
 
 static int g_fail = 0, g_checks = 0;
 #define REQUIRE(cond)                                                              \
@@ -67,7 +70,7 @@ static std::vector<uint8_t> BitsetRandom(size_t n, size_t t) {
 int main() {
     using namespace knowhere;
     const int64_t nb = 10000, nq = 1000, dim = 128, seed = 42;
-    auto version = Version::GetCurrentVersion();
+    auto version = Version::GetCurrentVersion().VersionNumber();
     auto base_gen = [=]() {
         Json json;
         json[meta::DIM] = dim;
@@ -136,7 +139,7 @@ int main() {
         }
         Json bad = rcfg;
         bad[meta::RADIUS] = "far";
-        REQUIRE(idx.RangeSearch(query_ds, bad, nullptr).error() == Status::type_conflict_in_json);
+        REQUIRE(idx.RangeSearch(query_ds, bad, nullptr).error() == Status::invalid_value_in_json);
     };
 
     for (auto& c : cases) {
@@ -215,7 +218,7 @@ int main() {
             cfg[meta::TOPK] = 10;
             auto plain = idx.Search(query_ds, cfg, nullptr);
             Json scfg = cfg;
-            scfg[indexparam::REFINE_K] = 100;
+            scfg[indexparam::REFINE_K] = 10.0f;  // a k factor: k_base = k * refine_k (ivf.cc:1081)
             auto noop = idx.Search(query_ds, scfg, nullptr);
             REQUIRE(plain.has_value() && noop.has_value());
             int diff = 0;
@@ -229,7 +232,7 @@ int main() {
             auto g = BruteForce::Search<fp32>(train_ds, query_ds, cfg, nullptr);
             REQUIRE(refined.has_value() && g.has_value());
             float r0 = GetKNNRecall(*g.value(), *plain.value()), r1 = GetKNNRecall(*g.value(), *refined.value());
-            std::printf("   recall@10 plain %.4f refined(100) %.4f\n", r0, r1);
+            std::printf("   recall@10 plain %.4f refined(k x 10) %.4f\n", r0, r1);
             REQUIRE(r1 > r0 && r1 > 0.9f);
             // the refine index travels with the blob ("IxRF" wrapper) and keeps working after a reload
             BinarySet rbs;
@@ -273,8 +276,142 @@ int main() {
         bad[meta::TOPK] = 100000;
         REQUIRE(idx.Search(query_ds, bad, nullptr).error() == Status::out_of_range_in_json);
         bad = c.cfg;
+        bad[meta::TOPK] = 0;
+        REQUIRE(idx.Search(query_ds, bad, nullptr).error() == Status::out_of_range_in_json);
+        bad = c.cfg;
         bad[meta::METRIC_TYPE] = "HAMMING";
-        REQUIRE(idx.Search(query_ds, bad, nullptr).error() == Status::invalid_metric_type);
+        {
+            auto hidx = IndexFactory::Instance().Create<fp32>(c.name, version).value();
+            REQUIRE(hidx.Build(train_ds, bad) == Status::invalid_metric_type);
+            std::string msg;
+            REQUIRE(IndexStaticFaced<fp32>::ConfigCheck(c.name, version, bad, msg) == Status::invalid_metric_type);
+            REQUIRE(!msg.empty());
+        }
+        // 8. the static functions Milvus calls without an index instance (index_static.h:54-90)
+        {
+            std::string msg;
+            REQUIRE(IndexStaticFaced<fp32>::ConfigCheck(c.name, version, c.cfg, msg) == Status::success);
+            auto scfg = IndexStaticFaced<fp32>::CreateConfig(c.name, version);
+            REQUIRE(scfg != nullptr);
+            const bool raw = IndexStaticFaced<fp32>::HasRawData(c.name, version, c.cfg);
+            const bool flat = std::string(c.name) == IndexEnum::INDEX_HIP_BRUTEFORCE ||
+                              std::string(c.name) == IndexEnum::INDEX_HIP_IVFFLAT;
+            REQUIRE(raw == flat);
+            REQUIRE(idx.HasRawData(metric::L2) == flat);
+        }
+        // 9. GetVectorByIds on the kinds that keep the rows
+        {
+            const int64_t want[3] = {7, 4242, nb - 1};
+            auto ids_ds = GenIdsDataSet(3, want);
+            auto gv = idx.GetVectorByIds(ids_ds);
+            if (idx.HasRawData(metric::L2)) {
+                REQUIRE(gv.has_value());
+                if (gv.has_value()) {
+                    const float* got = static_cast<const float*>(gv.value()->GetTensor());
+                    const float* base = static_cast<const float*>(train_ds->GetTensor());
+                    int bad_rows = 0;
+                    for (int r = 0; r < 3; r++) bad_rows += std::memcmp(got + r * dim, base + want[r] * dim, sizeof(float) * dim) != 0;
+                    REQUIRE(bad_rows == 0);
+                }
+            } else {
+                REQUIRE(!gv.has_value());
+            }
+        }
+        // 10. cancellation (include/knowhere/context.h:24-29): a cancelled OpContext aborts the search
+        {
+            milvus::OpContext ctx;
+            ctx.cancelled = true;
+            REQUIRE(idx.Search(query_ds, c.cfg, nullptr, &ctx).error() == Status::timeout);
+            milvus::OpContext live;
+            REQUIRE(idx.Search(query_ds, c.cfg, nullptr, &live).has_value());
+        }
+        // 11. repeated Add (IndexNode::Add appends; ids continue at Count()): the second half is found under its ids
+        {
+            auto aidx = IndexFactory::Instance().Create<fp32>(c.name, version).value();
+            const float* base = static_cast<const float*>(train_ds->GetTensor());
+            auto first = knowhere::GenDataSet(nb / 2, dim, base);
+            auto second = knowhere::GenDataSet(nb - nb / 2, dim, base + (nb / 2) * dim);
+            first->SetIsOwner(false);
+            second->SetIsOwner(false);
+            REQUIRE(aidx.Train(train_ds, c.cfg) == Status::success);
+            REQUIRE(aidx.Add(first, c.cfg) == Status::success);
+            REQUIRE(aidx.Count() == nb / 2);
+            REQUIRE(aidx.Add(second, c.cfg) == Status::success);
+            REQUIRE(aidx.Count() == nb);
+            auto r = aidx.Search(query_ds, c.cfg, nullptr);
+            REQUIRE(r.has_value());
+            int diff = 0;  // same training set, same rows: identical to the one-shot Build
+            for (int64_t i = 0; i < nq; i++) diff += r.value()->GetIds()[i] != results.value()->GetIds()[i];
+            REQUIRE(diff == 0);
+        }
+        // 12. id map (include/knowhere/index/index_node.h:292-318, id_map.h): the bitset is in public ids, results come
+        //     back in public ids
+        {
+            auto midx = IndexFactory::Instance().Create<fp32>(c.name, version).value();
+            REQUIRE(midx.Build(train_ds, c.cfg) == Status::success);
+            std::vector<int64_t> in_to_out(nb);
+            for (int64_t i = 0; i < nb; i++) in_to_out[i] = nb - 1 - i;  // storage id i is public id nb-1-i
+            midx.Node()->GetIdMap().SetInToOut(in_to_out);
+            auto r = midx.Search(query_ds, c.cfg, nullptr);
+            REQUIRE(r.has_value());
+            int diff = 0;
+            for (int64_t i = 0; i < nq; i++) diff += r.value()->GetIds()[i] != nb - 1 - results.value()->GetIds()[i];
+            REQUIRE(diff == 0);
+            // filter the public ids of the first 40 % of storage rows' mirror: public id p filtered <=> p < 0.4 nb
+            auto bits = BitsetFirst(nb, (size_t)(0.4 * nb));
+            BitsetView bv(bits.data(), nb);
+            auto rf = midx.Search(query_ds, c.cfg, bv);
+            REQUIRE(rf.has_value());
+            int leaked = 0;
+            for (int64_t i = 0; i < nq; i++) leaked += rf.value()->GetIds()[i] >= 0 && bv.test(rf.value()->GetIds()[i]);
+            REQUIRE(leaked == 0);
+            // the same filter expressed in storage ids on the unmapped index gives the mirrored result
+            std::vector<uint8_t> sbits((nb + 7) / 8, 0);
+            for (int64_t i = 0; i < nb; i++) {
+                if (bv.test(nb - 1 - i)) sbits[i >> 3] |= (1 << (i & 7));
+            }
+            auto rs = idx.Search(query_ds, c.cfg, BitsetView(sbits.data(), nb));
+            REQUIRE(rs.has_value());
+            diff = 0;
+            for (int64_t i = 0; i < nq; i++) {
+                const int64_t a = rf.value()->GetIds()[i], b = rs.value()->GetIds()[i];
+                diff += a != (b < 0 ? b : nb - 1 - b);
+            }
+            REQUIRE(diff == 0);
+        }
+        // 13. the thread-pool wrapper bounds the searches in flight (index_node_thread_pool_wrapper.h; gpu_cuvs.h:48)
+        {
+            auto* wrapper = dynamic_cast<IndexNodeThreadPoolWrapper*>(idx.Node());
+            REQUIRE(wrapper != nullptr);
+            if (wrapper) {
+                std::vector<std::thread> th;
+                std::atomic<int> okc{0};
+                for (int t = 0; t < 12; t++) {
+                    th.emplace_back([&] {
+                        for (int rep = 0; rep < 3; rep++) okc += idx.Search(query_ds, c.cfg, nullptr).has_value();
+                    });
+                }
+                for (auto& t : th) t.join();
+                REQUIRE(okc == 36);
+                REQUIRE(wrapper->MaxInFlightSeen() >= 1 && wrapper->MaxInFlightSeen() <= wrapper->PoolSize());
+                std::printf("   thread pool: size %zu, max in flight %zu\n", wrapper->PoolSize(), wrapper->MaxInFlightSeen());
+            }
+        }
+        // 14. damaged blobs are rejected, not loaded (Deserialize cross-field validation)
+        {
+            auto blob = bs.GetByName(c.name);
+            for (int64_t cut : {(int64_t)3, (int64_t)40, blob->size / 2, blob->size - 1}) {
+                BinarySet tb;
+                std::shared_ptr<uint8_t[]> copy(new uint8_t[cut]);
+                std::memcpy(copy.get(), blob->data.get(), (size_t)cut);
+                tb.Append(c.name, copy, cut);
+                auto didx = IndexFactory::Instance().Create<fp32>(c.name, version).value();
+                REQUIRE(didx.Deserialize(tb) != Status::success);
+            }
+            BinarySet empty;
+            auto didx = IndexFactory::Instance().Create<fp32>(c.name, version).value();
+            REQUIRE(didx.Deserialize(empty) == Status::invalid_binary_set);
+        }
     }
 
     {   // IVF_PQ with m = 32: the range search path of the headline kernel
@@ -285,18 +422,75 @@ int main() {
         check_range(idx, cfg);
     }
 
-    {   // COSINE == normalised IP
-        Json cfg = ivfflat_gen();
+    // COSINE (a12): self-search hits itself at ~1, results agree with the brute-force node, and the blob round-trips
+    // (IxF9 for the flat index, IwFl + cosine inverted lists for IVF_FLAT: the stored norms travel)
+    for (const char* name : {IndexEnum::INDEX_HIP_BRUTEFORCE, IndexEnum::INDEX_HIP_IVFFLAT, IndexEnum::INDEX_HIP_IVFPQ,
+                             IndexEnum::INDEX_HIP_IVFSQ8}) {
+        Json cfg = std::string(name) == IndexEnum::INDEX_HIP_IVFPQ ? ivfpq_gen() : ivfflat_gen();
         cfg[meta::METRIC_TYPE] = metric::COSINE;
         cfg[meta::TOPK] = 5;
-        auto idx = IndexFactory::Instance().Create<fp32>(IndexEnum::INDEX_HIP_IVFFLAT, version).value();
+        auto idx = IndexFactory::Instance().Create<fp32>(name, version).value();
         REQUIRE(idx.Build(train_ds, cfg) == Status::success);
         auto r = idx.Search(train_ds, cfg, nullptr);
         REQUIRE(r.has_value());
+        if (!r.has_value()) continue;
         int bad = 0;
         for (int i = 0; i < nq; i++) bad += r.value()->GetIds()[i * 5] != i;
-        REQUIRE(bad == 0);
-        REQUIRE(std::abs(r.value()->GetDistance()[0] - 1.0f) < 1e-5f);
+        REQUIRE(bad <= (std::string(name) == IndexEnum::INDEX_HIP_IVFPQ ? nq / 20 : 0));
+        if (std::string(name) != IndexEnum::INDEX_HIP_IVFPQ && std::string(name) != IndexEnum::INDEX_HIP_IVFSQ8) {
+            REQUIRE(std::abs(r.value()->GetDistance()[0] - 1.0f) < 1e-5f);
+        }
+        auto q = idx.Search(query_ds, cfg, nullptr);
+        auto g = BruteForce::Search<fp32>(train_ds, query_ds, cfg, nullptr);
+        REQUIRE(q.has_value() && g.has_value());
+        float rc = GetKNNRecall(*g.value(), *q.value());
+        std::printf("== %s COSINE recall@5 %.4f\n", name, rc);
+        REQUIRE(rc >= (std::string(name) == IndexEnum::INDEX_HIP_IVFPQ ? 0.5f : 0.9f));
+        BinarySet bs;
+        REQUIRE(idx.Serialize(bs) == Status::success);
+        if (std::string(name) == IndexEnum::INDEX_HIP_BRUTEFORCE) {
+            REQUIRE(std::memcmp(bs.GetByName(name)->data.get(), "IxF9", 4) == 0);
+        }
+        auto idx2 = IndexFactory::Instance().Create<fp32>(name, version).value();
+        REQUIRE(idx2.Deserialize(bs, cfg) == Status::success);
+        auto q2 = idx2.Search(query_ds, cfg, nullptr);
+        REQUIRE(q2.has_value());
+        if (q2.has_value()) {
+            int diff = 0;
+            for (int64_t i = 0; i < nq * 5; i++) {
+                diff += q2.value()->GetIds()[i] != q.value()->GetIds()[i];
+                diff += q2.value()->GetDistance()[i] != q.value()->GetDistance()[i];
+            }
+            REQUIRE(diff == 0);
+        }
+    }
+
+    {   // config limits of the backend (hip_index_node.h): m outside {0, 8, 16, 32, 64}, dim % m, nbits != 8, sq_type
+        std::string msg;
+        Json cfg = ivfpq_gen();
+        cfg[indexparam::M] = 12;
+        REQUIRE(IndexStaticFaced<fp32>::ConfigCheck(IndexEnum::INDEX_HIP_IVFPQ, version, cfg, msg) == Status::invalid_args);
+        cfg[indexparam::M] = 64;
+        cfg[meta::DIM] = 96;
+        REQUIRE(IndexStaticFaced<fp32>::ConfigCheck(IndexEnum::INDEX_HIP_IVFPQ, version, cfg, msg) == Status::invalid_args);
+        cfg = ivfpq_gen();
+        cfg[indexparam::NBITS] = 4;
+        REQUIRE(IndexStaticFaced<fp32>::ConfigCheck(IndexEnum::INDEX_HIP_IVFPQ, version, cfg, msg) ==
+                Status::out_of_range_in_json);
+        cfg = ivfflat_gen();
+        cfg[indexparam::SQ_TYPE] = "FP16";
+        REQUIRE(IndexStaticFaced<fp32>::ConfigCheck(IndexEnum::INDEX_HIP_IVFSQ8, version, cfg, msg) == Status::invalid_args);
+        cfg[indexparam::SQ_TYPE] = "sq8";
+        REQUIRE(IndexStaticFaced<fp32>::ConfigCheck(IndexEnum::INDEX_HIP_IVFSQ8, version, cfg, msg) == Status::success);
+        REQUIRE(IndexStaticFaced<fp32>::ConfigCheck("NO_SUCH_INDEX", version, cfg, msg) == Status::invalid_index_error);
+        // string-typed numbers are accepted as Milvus sends them (Config::FormatAndCheck)
+        cfg = ivfflat_gen();
+        cfg[indexparam::NLIST] = "20";
+        cfg[meta::DIM] = "128";
+        REQUIRE(IndexStaticFaced<fp32>::ConfigCheck(IndexEnum::INDEX_HIP_IVFFLAT, version, cfg, msg) == Status::success);
+        cfg[indexparam::NLIST] = "twenty";
+        REQUIRE(IndexStaticFaced<fp32>::ConfigCheck(IndexEnum::INDEX_HIP_IVFFLAT, version, cfg, msg) ==
+                Status::invalid_value_in_json);
     }
 
     std::printf("%s: %d checks, %d failed\n", g_fail ? "FAILED" : "PASSED", g_checks, g_fail);
