@@ -163,6 +163,7 @@ def main():
               f"precomputed_table={g.uses_precomputed_table}")
     if built.codes is not None and built.codes.numel() > (16 << 30):
         built.codes = None  # (C5: 76.8 GB of list-sorted codes; the index holds its own layout, the CPU leg is skipped)
+        torch.cuda.empty_cache()
     kbase = a.refine_k if refine else a.k
     row_of_id = sharded.row_lookup(vector_ids, a.nb, dev) if (refine and vector_ids is not None) else None
 

@@ -263,6 +263,48 @@ int knhip_int8_vec_L2sqr_ny(float* d_dis, const int8_t* d_x, const int8_t* d_y, 
 int knhip_int8_vec_inner_products_ny(float* d_ip, const int8_t* d_x, const int8_t* d_y, int64_t d,
                                      int64_t ny, void* stream);
 
+/* ---- the rest of the hook table (src/simd/hook.h:33-123; scalar definitions src/simd/distances_ref.cc) ----
+ * Same conventions: device pointers, the reference's scalar operation order, results bit-equal to the *_ref functions.
+ * Scalar-valued hooks (one x against one y) are the ny = 1 case of the row entries. */
+/* dis[i] = sum_j |x_j - y_ij|                          (fvec_L1,   hook.h:42; distances_ref.cc:39-46) */
+int knhip_fvec_L1_ny(float* d_dis, const float* d_x, const float* d_y, int64_t d, int64_t ny, void* stream);
+/* dis[i] = max_j |x_j - y_ij|                          (fvec_Linf, hook.h:45; distances_ref.cc:48-55) */
+int knhip_fvec_Linf_ny(float* d_dis, const float* d_x, const float* d_y, int64_t d, int64_t ny, void* stream);
+/* out[i] = ||x_i||^2, float products summed in a double (fvec_norm_L2sqr_ref, distances_ref.cc:57-64; the entry above,
+ * knhip_fvec_norms_L2sqr, is the float-accumulator form the FAISS tables use) */
+int knhip_fvec_norms_L2sqr_ref(float* d_out, const float* d_x, int64_t d, int64_t n, void* stream);
+/* y transposed: vector i is column i of y[d][d_offset]; dis[i] = ||x||^2 + y_sqlen[i] - 2 <x, y_i>
+ *                                                      (fvec_L2sqr_ny_transposed, hook.h:66; distances_ref.cc:84-101) */
+int knhip_fvec_L2sqr_ny_transposed(float* d_dis, const float* d_x, const float* d_y, const float* d_y_sqlen, int64_t d,
+                                   int64_t d_offset, int64_t ny, void* stream);
+/* distances into d_dis_tmp[ny] and *d_nearest = first index of the minimum (0 if ny == 0 or nothing below +inf)
+ *                                                      (fvec_L2sqr_ny_nearest, hook.h:72; distances_ref.cc:106-121) */
+int knhip_fvec_L2sqr_ny_nearest(float* d_dis_tmp, const float* d_x, const float* d_y, int64_t d, int64_t ny,
+                                int64_t* d_nearest, void* stream);
+/*                                                      (fvec_L2sqr_ny_nearest_y_transposed, hook.h:80; :128-145) */
+int knhip_fvec_L2sqr_ny_nearest_y_transposed(float* d_dis_tmp, const float* d_x, const float* d_y,
+                                             const float* d_y_sqlen, int64_t d, int64_t d_offset, int64_t ny,
+                                             int64_t* d_nearest, void* stream);
+/* c = a + bf * b and *d_imin = first index of the minimum of c below 1e20, -1 if none
+ *                                                      (fvec_madd_and_argmin, hook.h:84; distances_ref.cc:154-168) */
+int knhip_fvec_madd_and_argmin(int64_t n, const float* d_a, float bf, const float* d_b, float* d_c, int64_t* d_imin,
+                               void* stream);
+/* four rows sharing x, d_out4[r] = dist(x, y_r)        (fvec_inner_product_batch_4 / fvec_L2sqr_batch_4, hook.h:89-97) */
+int knhip_fvec_batch_4(int32_t metric, const float* d_x, const float* d_y0, const float* d_y1, const float* d_y2,
+                       const float* d_y3, int64_t d, float* d_out4, void* stream);
+/* typed operands (include/knowhere/operands.h): fp16 / bf16 as 16-bit patterns, int8.
+ * op 0: *_vec_L2sqr, 1: *_vec_inner_product, 2: *_vec_norm_L2sqr (x unused), one x against ny rows
+ *                                                      (hook.h:104-123; distances_ref.cc:236-262, 311-337, 386-412) */
+enum { KNHIP_DT_FP16 = 0, KNHIP_DT_BF16 = 1, KNHIP_DT_INT8 = 2 };
+int knhip_typed_vec_ny(int32_t dtype, int32_t op, float* d_out, const void* d_x, const void* d_y, int64_t d,
+                       int64_t ny, void* stream);
+/*                                                      (*_vec_{inner_product,L2sqr}_batch_4) */
+int knhip_typed_vec_batch_4(int32_t dtype, int32_t metric, const void* d_x, const void* d_y0, const void* d_y1,
+                            const void* d_y2, const void* d_y3, int64_t d, float* d_out4, void* stream);
+/* int32 results                                        (ivec_inner_product / ivec_L2sqr, hook.h:100-101) */
+int knhip_ivec_ny(int32_t metric, int32_t* d_out, const int8_t* d_x, const int8_t* d_y, int64_t d, int64_t ny,
+                  void* stream);
+
 /* ---- profiling hooks (bench.py / rocprof cross-check) ---- */
 #define KNHIP_NSTAGE 8
 typedef struct knhip_stage_times {

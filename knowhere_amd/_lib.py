@@ -48,6 +48,9 @@ SYMBOLS = [
     "knhip_index_encode_device", "knhip_index_get_coarse", "knhip_index_get_pq", "knhip_index_get_sq",
     "knhip_index_get_list_sizes", "knhip_index_get_lists", "knhip_index_get_vectors_device", "knhip_search_refine",
     "knhip_index_get_vectors",
+    "knhip_fvec_L1_ny", "knhip_fvec_Linf_ny", "knhip_fvec_norms_L2sqr_ref", "knhip_fvec_L2sqr_ny_transposed",
+    "knhip_fvec_L2sqr_ny_nearest", "knhip_fvec_L2sqr_ny_nearest_y_transposed", "knhip_fvec_madd_and_argmin",
+    "knhip_fvec_batch_4", "knhip_typed_vec_ny", "knhip_typed_vec_batch_4", "knhip_ivec_ny",
 ]
 
 
@@ -103,6 +106,17 @@ def load():
               "knhip_int8_vec_inner_products_ny"):
         getattr(L, f).argtypes = [vp, vp, vp, i64, i64, vp]
     L.knhip_fvec_norms_L2sqr.argtypes = [vp, vp, i64, i64, vp]
+    L.knhip_fvec_norms_L2sqr_ref.argtypes = [vp, vp, i64, i64, vp]
+    L.knhip_fvec_L1_ny.argtypes = [vp, vp, vp, i64, i64, vp]
+    L.knhip_fvec_Linf_ny.argtypes = [vp, vp, vp, i64, i64, vp]
+    L.knhip_fvec_L2sqr_ny_transposed.argtypes = [vp, vp, vp, vp, i64, i64, i64, vp]
+    L.knhip_fvec_L2sqr_ny_nearest.argtypes = [vp, vp, vp, i64, i64, vp, vp]
+    L.knhip_fvec_L2sqr_ny_nearest_y_transposed.argtypes = [vp, vp, vp, vp, i64, i64, i64, vp, vp]
+    L.knhip_fvec_madd_and_argmin.argtypes = [i64, vp, C.c_float, vp, vp, vp, vp]
+    L.knhip_fvec_batch_4.argtypes = [i32, vp, vp, vp, vp, vp, i64, vp, vp]
+    L.knhip_typed_vec_ny.argtypes = [i32, i32, vp, vp, vp, i64, i64, vp]
+    L.knhip_typed_vec_batch_4.argtypes = [i32, i32, vp, vp, vp, vp, vp, i64, vp, vp]
+    L.knhip_ivec_ny.argtypes = [i32, vp, vp, vp, i64, i64, vp]
     L.knhip_fvec_madd.argtypes = [i64, vp, C.c_float, vp, vp, vp]
     tpp = C.POINTER(TrainParams)
     L.knhip_kmeans_device.argtypes = [i32, i32, i64, vp, i64, tpp, vp, i32]

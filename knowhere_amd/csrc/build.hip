@@ -382,4 +382,56 @@ hipError_t launch_iota_i64(int64_t* out, int64_t n, int64_t base, hipStream_t s)
     return hipGetLastError();
 }
 
+// ---- interleaved list blocks (flat: float4, SQ8: uint4 -- both are "16 bytes of row r, chunk c" at
+// blk[(blk_off + b) * nchunk + c][r]) -> canonical list-sorted AoS rows [ntotal][code_size].  The inverse of
+// interleave_lists_kernel / sq_interleave_kernel: lets the index drop its AoS copy of large flat / SQ8 lists (a further
+// Add, Serialize or GetVectorByIds rebuilds it on demand).
+__global__ void deinterleave_lists_kernel(const uint4* __restrict__ rows, const int64_t* __restrict__ list_row_off,
+                                          const int64_t* __restrict__ list_len,
+                                          const int64_t* __restrict__ list_blk_off, int64_t nlist, int64_t code_size,
+                                          int nchunk, uint8_t* __restrict__ dst) {
+    const int64_t l = blockIdx.y + (int64_t)blockIdx.z * gridDim.y;
+    if (l >= nlist) {
+        return;
+    }
+    const int64_t len = list_len[l];
+    const int64_t nblk = (len + 63) / 64;
+    const int64_t row_off = list_row_off[l];
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nblk * nchunk * 64;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = t / ((int64_t)nchunk * 64);
+        const int rem = (int)(t % ((int64_t)nchunk * 64));
+        const int c = rem / 64, r = rem % 64;
+        const int64_t row = b * 64 + r;
+        if (row >= len) {
+            continue;
+        }
+        const uint4 w = rows[(list_blk_off[l] + b) * (int64_t)nchunk * 64 + rem];
+        uint8_t* o = dst + (row_off + row) * code_size + (int64_t)c * 16;
+        const int64_t nbytes = min((int64_t)16, code_size - (int64_t)c * 16);
+        if (nbytes == 16 && (code_size & 15) == 0) {
+            *reinterpret_cast<uint4*>(o) = w;
+        } else {
+            const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+            for (int e = 0; e < (int)nbytes; e++) {
+                o[e] = (uint8_t)(ww[e >> 2] >> (8 * (e & 3)));
+            }
+        }
+    }
+}
+
+hipError_t launch_deinterleave_lists(const uint4* rows, const int64_t* list_row_off, const int64_t* list_len,
+                                     const int64_t* list_blk_off, int64_t nlist, int64_t code_size, uint8_t* dst,
+                                     hipStream_t s) {
+    if (nlist <= 0) {
+        return hipSuccess;
+    }
+    const int nchunk = (int)((code_size + 15) / 16);
+    const unsigned gy = (unsigned)std::min<int64_t>(nlist, 32768);
+    const unsigned gz = (unsigned)((nlist + gy - 1) / gy);
+    hipLaunchKernelGGL(deinterleave_lists_kernel, dim3(8, gy, gz), dim3(256), 0, s, rows, list_row_off, list_len,
+                       list_blk_off, nlist, code_size, nchunk, dst);
+    return hipGetLastError();
+}
+
 } // namespace knhip

@@ -165,6 +165,7 @@ struct SqScanArgs {
 
 // ---- flat_scan.hip ----
 int flat_scan_qg(int k);
+int sq_scan_qg(int k);
 hipError_t launch_flat_scan(const FlatScanArgs& a, bool is_l2, bool dense, int64_t grid, hipStream_t s);
 hipError_t launch_flat_full(const FlatScanArgs& a, bool is_l2, float* out, const int32_t* q_subset,
                             int64_t nq_subset, const int32_t* row_flags, hipStream_t s);
@@ -303,6 +304,9 @@ hipError_t launch_merge_lists(const uint8_t* old_codes, const int64_t* old_ids, 
 hipError_t launch_iota_i64(int64_t* out, int64_t n, int64_t base, hipStream_t s);
 
 // ---- prims.hip ----
+hipError_t launch_deinterleave_lists(const uint4* rows, const int64_t* list_row_off, const int64_t* list_len,
+                                     const int64_t* list_blk_off, int64_t nlist, int64_t code_size, uint8_t* dst,
+                                     hipStream_t s);
 hipError_t launch_fvec_ny(float* out, const float* x, const float* y, int64_t d, int64_t ny,
                           bool is_l2, hipStream_t s);
 hipError_t launch_fvec_norms(float* out, const float* x, int64_t d, int64_t n, hipStream_t s);
@@ -310,5 +314,20 @@ hipError_t launch_fvec_madd(int64_t n, const float* a, float bf, const float* b,
                             hipStream_t s);
 hipError_t launch_int8_ny(float* out, const int8_t* x, const int8_t* y, int64_t d, int64_t ny,
                           bool is_l2, hipStream_t s);
+// op: 0 L2sqr, 1 inner product, 2 norm (faiss float accumulator), 3 L1, 4 Linf, 5 norm (_ref: double accumulator)
+hipError_t launch_fvec_rows(int op, float* out, const float* x, const float* y, int64_t d, int64_t ny, hipStream_t s);
+// dtype 0 fp16, 1 bf16, 2 int8; op 0 L2sqr, 1 inner product, 2 norm_L2sqr
+hipError_t launch_typed_rows(int dtype, int op, float* out, const void* x, const void* y, int64_t d, int64_t ny,
+                             hipStream_t s);
+hipError_t launch_ivec_ny(int32_t* out, const int8_t* x, const int8_t* y, int64_t d, int64_t ny, bool is_l2,
+                          hipStream_t s);
+hipError_t launch_argmin(const float* v, int64_t n, float limit, int64_t none_value, int64_t* d_idx, hipStream_t s);
+hipError_t launch_fvec_madd_and_argmin(int64_t n, const float* a, float bf, const float* b, float* c, int64_t* d_imin,
+                                       hipStream_t s);
+hipError_t launch_l2_transposed(float* dis, const float* x, const float* y, const float* y_sqlen, int64_t d,
+                                int64_t d_offset, int64_t ny, hipStream_t s);
+// dtype -1 fp32, 0 fp16, 1 bf16, 2 int8
+hipError_t launch_batch4(int dtype, bool is_l2, const void* x, const void* y0, const void* y1, const void* y2,
+                         const void* y3, int64_t d, float* out, hipStream_t s);
 
 } // namespace knhip

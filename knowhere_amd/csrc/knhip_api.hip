@@ -167,6 +167,8 @@ struct knhip_index {
     DevBuf ids;
     DevBuf codes_aos;     // canonical list-sorted codes [ntotal][code_size] (faiss ArrayInvertedLists bytes): what a
                           // further Add merges into and Serialize reads back (BRUTE_FORCE: the raw rows)
+    mutable bool aos_ready = false;  // IVF_FLAT / IVF_SQ8 drop the AoS copy of large lists (the interleaved `rows` hold the
+                                     // same bytes); ensure_aos() rebuilds it when a further Add / Serialize needs it
     std::vector<int64_t> h_list_off;  // [nlist + 1]
     DevBuf rows;          // kind specific layout
     DevBuf rows2;         // IVF_PQ m=32: stream16 layout for the staggered scan (pq_scan_v2.hip)
@@ -348,6 +350,16 @@ int build_pq_skew(const knhip_index* cidx) {
     return KNHIP_OK;
 }
 
+// flat / SQ8 indexes above this many code bytes keep only the interleaved layout (KNHIP_AOS_KEEP_MB overrides; tests
+// set it to 0 to exercise the rebuild path)
+size_t aos_keep_limit() {
+    const char* e = getenv("KNHIP_AOS_KEEP_MB");
+    if (e && *e) {
+        return (size_t)std::max<long long>(0, atoll(e)) << 20;
+    }
+    return (size_t)8 << 30;
+}
+
 // lay the lists out from device-resident, list-sorted AoS codes + ids
 int build_list_layout(knhip_index* idx, const std::vector<int64_t>& list_off, const uint8_t* d_codes,
                       const int64_t* d_ids) {
@@ -394,12 +406,20 @@ int build_list_layout(knhip_index* idx, const std::vector<int64_t>& list_off, co
             HIP_TRY(hipMemcpy(idx->ids.p, d_ids, (size_t)ntotal * sizeof(int64_t), hipMemcpyDeviceToDevice));
         }
     }
+    // the canonical AoS bytes stay resident for IVF_PQ (they feed the lazily built layouts; 32 B / row) and for small
+    // flat / SQ8 indexes; large flat / SQ8 lists keep only the interleaved layout (C5: 76.8 GB of codes once, not twice)
+    const size_t aos_bytes = (size_t)ntotal * idx->code_size;
+    const bool keep_aos = kind == KNHIP_IVF_PQ || aos_bytes <= aos_keep_limit();
     if (idx->codes_aos.p != d_codes) {
-        HIP_TRY(idx->codes_aos.alloc((size_t)ntotal * idx->code_size));
-        if (ntotal) {
-            HIP_TRY(hipMemcpy(idx->codes_aos.p, d_codes, (size_t)ntotal * idx->code_size, hipMemcpyDeviceToDevice));
+        idx->codes_aos.release();
+        if (keep_aos) {
+            HIP_TRY(idx->codes_aos.alloc(aos_bytes));
+            if (ntotal) {
+                HIP_TRY(hipMemcpy(idx->codes_aos.p, d_codes, aos_bytes, hipMemcpyDeviceToDevice));
+            }
         }
     }
+    idx->aos_ready = keep_aos;
     const int64_t total_blk = blk_off[nlist];
     if (kind == KNHIP_IVF_FLAT) {
         const int nchunk = (idx->d + 3) / 4;
@@ -437,7 +457,25 @@ int build_list_layout(knhip_index* idx, const std::vector<int64_t>& list_off, co
         return fail(KNHIP_ERR_INVALID_ARGS, "lists on a brute-force index");
     }
     HIP_TRY(hipDeviceSynchronize());
+    if (!keep_aos) {
+        idx->codes_aos.release(); // (d_codes may have been this buffer: the layout above was built from it first)
+    }
     idx->has_data = true;
+    return KNHIP_OK;
+}
+
+// canonical list-sorted AoS codes of a flat / SQ8 index that dropped them: rebuilt from the interleaved blocks
+int ensure_aos(const knhip_index* cidx) {
+    knhip_index* idx = const_cast<knhip_index*>(cidx);
+    if (idx->aos_ready || !idx->has_data || idx->desc.kind == KNHIP_BRUTE_FORCE) {
+        return KNHIP_OK;
+    }
+    HIP_TRY(idx->codes_aos.alloc((size_t)std::max<int64_t>(idx->ntotal, 1) * idx->code_size));
+    HIP_TRY(launch_deinterleave_lists(idx->rows.as<uint4>(), idx->d_list_row_off.as<int64_t>(),
+                                      idx->d_list_len.as<int64_t>(), idx->d_list_blk_off.as<int64_t>(), idx->nlist,
+                                      idx->code_size, idx->codes_aos.as<uint8_t>(), nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    idx->aos_ready = true;
     return KNHIP_OK;
 }
 
@@ -529,7 +567,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
     }
     // 2. group
     const int qg = (kind == KNHIP_IVF_PQ) ? pq_scan_qg(idx->desc.pq_m)
-                 : (kind == KNHIP_IVF_SQ8) ? 8
+                 : (kind == KNHIP_IVF_SQ8) ? sq_scan_qg(k)
                                            : flat_scan_qg(k);
     const int64_t npairs = nq * nprobe;
     // IVF-PQ m = 32: which kernels run the two phases (rank-0 dump + select, bulk) and how many queries they
@@ -763,9 +801,6 @@ int validate_search(const knhip_index* idx, int64_t nq, int32_t k, int32_t& npro
     }
     if ((size_t)nprobe > row_select_max_k()) {
         return fail(KNHIP_ERR_NOT_IMPLEMENTED, "nprobe > 4096 is not supported yet");
-    }
-    if (kind == KNHIP_IVF_SQ8 && k > 128) {
-        return fail(KNHIP_ERR_NOT_IMPLEMENTED, "IVF_SQ8 supports k <= 128");
     }
     return KNHIP_OK;
 }
@@ -1647,6 +1682,98 @@ int knhip_refine_device(int32_t metric, int32_t dim, const float* d_base, int64_
 }
 
 // ---- primitives ------------------------------------------------------------------------------------
+static int prim_args_ok(const void* out, const void* a, const void* b, int64_t d, int64_t n) {
+    if (d < 0 || n < 0 || (n > 0 && (!out || !a || !b))) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "primitive: null pointer or negative size");
+    }
+    if (n >= ((int64_t)1 << 32)) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "primitive: more than 2^32 - 1 rows");
+    }
+    return KNHIP_OK;
+}
+int knhip_fvec_L1_ny(float* d_dis, const float* d_x, const float* d_y, int64_t d, int64_t ny, void* stream) {
+    if (int rc = prim_args_ok(d_dis, d_x, d_y, d, ny)) return rc;
+    HIP_TRY(launch_fvec_rows(3, d_dis, d_x, d_y, d, ny, static_cast<hipStream_t>(stream)));
+    return KNHIP_OK;
+}
+int knhip_fvec_Linf_ny(float* d_dis, const float* d_x, const float* d_y, int64_t d, int64_t ny, void* stream) {
+    if (int rc = prim_args_ok(d_dis, d_x, d_y, d, ny)) return rc;
+    HIP_TRY(launch_fvec_rows(4, d_dis, d_x, d_y, d, ny, static_cast<hipStream_t>(stream)));
+    return KNHIP_OK;
+}
+int knhip_fvec_norms_L2sqr_ref(float* d_out, const float* d_x, int64_t d, int64_t n, void* stream) {
+    if (int rc = prim_args_ok(d_out, d_x, d_x, d, n)) return rc;
+    HIP_TRY(launch_fvec_rows(5, d_out, nullptr, d_x, d, n, static_cast<hipStream_t>(stream)));
+    return KNHIP_OK;
+}
+int knhip_fvec_L2sqr_ny_transposed(float* d_dis, const float* d_x, const float* d_y, const float* d_y_sqlen, int64_t d,
+                                   int64_t d_offset, int64_t ny, void* stream) {
+    if (int rc = prim_args_ok(d_dis, d_x, d_y, d, ny)) return rc;
+    if (ny > 0 && (!d_y_sqlen || d_offset < ny)) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "L2sqr_ny_transposed: need y_sqlen and d_offset >= ny");
+    }
+    HIP_TRY(launch_l2_transposed(d_dis, d_x, d_y, d_y_sqlen, d, d_offset, ny, static_cast<hipStream_t>(stream)));
+    return KNHIP_OK;
+}
+int knhip_fvec_L2sqr_ny_nearest(float* d_dis_tmp, const float* d_x, const float* d_y, int64_t d, int64_t ny,
+                                int64_t* d_nearest, void* stream) {
+    if (int rc = prim_args_ok(d_dis_tmp, d_x, d_y, d, ny)) return rc;
+    if (!d_nearest) return fail(KNHIP_ERR_INVALID_ARGS, "L2sqr_ny_nearest: null output");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(launch_fvec_ny(d_dis_tmp, d_x, d_y, d, ny, true, s));
+    HIP_TRY(launch_argmin(d_dis_tmp, ny, HUGE_VALF, 0, d_nearest, s));
+    return KNHIP_OK;
+}
+int knhip_fvec_L2sqr_ny_nearest_y_transposed(float* d_dis_tmp, const float* d_x, const float* d_y,
+                                             const float* d_y_sqlen, int64_t d, int64_t d_offset, int64_t ny,
+                                             int64_t* d_nearest, void* stream) {
+    if (!d_nearest) return fail(KNHIP_ERR_INVALID_ARGS, "L2sqr_ny_nearest_y_transposed: null output");
+    if (int rc = knhip_fvec_L2sqr_ny_transposed(d_dis_tmp, d_x, d_y, d_y_sqlen, d, d_offset, ny, stream)) return rc;
+    HIP_TRY(launch_argmin(d_dis_tmp, ny, HUGE_VALF, 0, d_nearest, static_cast<hipStream_t>(stream)));
+    return KNHIP_OK;
+}
+int knhip_fvec_madd_and_argmin(int64_t n, const float* d_a, float bf, const float* d_b, float* d_c, int64_t* d_imin,
+                               void* stream) {
+    if (int rc = prim_args_ok(d_c, d_a, d_b, 0, n)) return rc;
+    if (!d_imin) return fail(KNHIP_ERR_INVALID_ARGS, "madd_and_argmin: null output");
+    HIP_TRY(launch_fvec_madd_and_argmin(n, d_a, bf, d_b, d_c, d_imin, static_cast<hipStream_t>(stream)));
+    return KNHIP_OK;
+}
+int knhip_fvec_batch_4(int32_t metric, const float* d_x, const float* d_y0, const float* d_y1, const float* d_y2,
+                       const float* d_y3, int64_t d, float* d_out4, void* stream) {
+    if (d < 0 || !d_out4 || (d > 0 && (!d_x || !d_y0 || !d_y1 || !d_y2 || !d_y3)) ||
+        (metric != KNHIP_L2 && metric != KNHIP_IP)) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "batch_4: bad arguments");
+    }
+    HIP_TRY(launch_batch4(-1, metric == KNHIP_L2, d_x, d_y0, d_y1, d_y2, d_y3, d, d_out4, static_cast<hipStream_t>(stream)));
+    return KNHIP_OK;
+}
+int knhip_typed_vec_ny(int32_t dtype, int32_t op, float* d_out, const void* d_x, const void* d_y, int64_t d,
+                       int64_t ny, void* stream) {
+    if (dtype < KNHIP_DT_FP16 || dtype > KNHIP_DT_INT8 || op < 0 || op > 2) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "typed_vec_ny: dtype in {fp16, bf16, int8}, op in {L2sqr, ip, norm}");
+    }
+    if (int rc = prim_args_ok(d_out, op == 2 ? d_y : d_x, d_y, d, ny)) return rc;
+    HIP_TRY(launch_typed_rows(dtype, op, d_out, d_x, d_y, d, ny, static_cast<hipStream_t>(stream)));
+    return KNHIP_OK;
+}
+int knhip_typed_vec_batch_4(int32_t dtype, int32_t metric, const void* d_x, const void* d_y0, const void* d_y1,
+                            const void* d_y2, const void* d_y3, int64_t d, float* d_out4, void* stream) {
+    if (dtype < KNHIP_DT_FP16 || dtype > KNHIP_DT_INT8 || d < 0 || !d_out4 ||
+        (d > 0 && (!d_x || !d_y0 || !d_y1 || !d_y2 || !d_y3)) || (metric != KNHIP_L2 && metric != KNHIP_IP)) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "typed batch_4: bad arguments");
+    }
+    HIP_TRY(launch_batch4(dtype, metric == KNHIP_L2, d_x, d_y0, d_y1, d_y2, d_y3, d, d_out4,
+                          static_cast<hipStream_t>(stream)));
+    return KNHIP_OK;
+}
+int knhip_ivec_ny(int32_t metric, int32_t* d_out, const int8_t* d_x, const int8_t* d_y, int64_t d, int64_t ny,
+                  void* stream) {
+    if (metric != KNHIP_L2 && metric != KNHIP_IP) return fail(KNHIP_ERR_INVALID_ARGS, "ivec_ny: metric");
+    if (int rc = prim_args_ok(d_out, d_x, d_y, d, ny)) return rc;
+    HIP_TRY(launch_ivec_ny(d_out, d_x, d_y, d, ny, metric == KNHIP_L2, static_cast<hipStream_t>(stream)));
+    return KNHIP_OK;
+}
 int knhip_fvec_L2sqr_ny(float* d_dis, const float* d_x, const float* d_y, int64_t d, int64_t ny, void* stream) {
     HIP_TRY(launch_fvec_ny(d_dis, d_x, d_y, d, ny, true, static_cast<hipStream_t>(stream)));
     return KNHIP_OK;
@@ -1983,6 +2110,9 @@ int add_device_impl(knhip_index* idx, int64_t n, const float* d_x, const int64_t
     if (n0) {
         if (int rc = upload(old_off, idx->h_list_off.data(), idx->h_list_off.size() * sizeof(int64_t))) return rc;
     }
+    if (n0) {
+        if (int rc = ensure_aos(idx)) return rc;
+    }
     HIP_TRY(out_codes.alloc((size_t)(n0 + n) * cs));
     HIP_TRY(out_ids.alloc((size_t)(n0 + n) * sizeof(int64_t)));
     HIP_TRY(launch_merge_lists(n0 ? idx->codes_aos.as<uint8_t>() : nullptr, n0 ? idx->ids.as<int64_t>() : nullptr,
@@ -2217,7 +2347,9 @@ int knhip_index_get_lists(const knhip_index* idx, uint8_t* codes, int64_t* ids) 
         return KNHIP_OK;
     }
     DeviceGuard g(idx->desc.device);
+    std::lock_guard<std::mutex> add_lk(const_cast<knhip_index*>(idx)->add_mu);  // (not while an Add rebuilds the lists)
     if (codes) {
+        if (int rc = ensure_aos(idx)) return rc;
         const size_t b = idx->desc.kind == KNHIP_BRUTE_FORCE ? (size_t)idx->ntotal * idx->d * sizeof(float)
                                                              : (size_t)idx->ntotal * idx->code_size;
         HIP_TRY(hipMemcpy(codes, idx->codes_aos.p, b, hipMemcpyDeviceToHost));

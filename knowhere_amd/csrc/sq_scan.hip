@@ -25,11 +25,14 @@ namespace knhip {
 
 constexpr int SQ_WAVES = 4;
 constexpr int SQ_THREADS = SQ_WAVES * KN_WAVE;
-constexpr int SQ_QG = 8;
+// queries per work item: the per-query top-k state is R = ceil(k / 64) (distance, position) registers per lane,
+// so the group shrinks as k grows (same schedule as the flat scan; refine asks for k x refine_k candidates)
+int sq_scan_qg(int k) {
+    return k <= 128 ? 8 : (k <= 256 ? 4 : (k <= 512 ? 2 : 1));
+}
 
-template <bool IS_L2, int R>
+template <bool IS_L2, int QG, int R>
 __global__ __launch_bounds__(SQ_THREADS) void sq_scan_kernel(SqScanArgs a) {
-    constexpr int QG = SQ_QG;
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ float tab[256]; // (c + 0.5f) / 255.0f, correctly rounded
     const int lane = lane_id();
@@ -262,16 +265,17 @@ hipError_t launch_sq_scan(const SqScanArgs& a, bool is_l2, int64_t grid, hipStre
     }
     const int dpad = a.nchunk16 * 16;
     const int k = a.k;
-    if (k > 128) {
-        return hipErrorInvalidValue; // QG=8 register budget; larger k goes through batches of lists
+    if (k > KN_MAX_K) {
+        return hipErrorInvalidValue;
     }
-    const size_t ybytes = (size_t)(SQ_QG + 2) * dpad * 4;
-    const int qr = std::max(1, std::min(SQ_QG, (int)(48 * 1024 / (SQ_WAVES * k * 12))));
-    const size_t mbytes = (((size_t)qr * SQ_WAVES * k * 4 + 7) & ~(size_t)7) + (size_t)qr * SQ_WAVES * k * 8;
-    const size_t sm = std::max(ybytes, mbytes);
-#define SQ_LAUNCH(L2_, R_)                                                                         \
+#define SQ_LAUNCH(L2_, QG_, R_)                                                                    \
     do {                                                                                           \
-        auto kern = sq_scan_kernel<L2_, R_>;                                                       \
+        const size_t ybytes = (size_t)(QG_ + 2) * dpad * 4;                                        \
+        const int qr = std::max(1, std::min(QG_, (int)(48 * 1024 / (SQ_WAVES * k * 12))));         \
+        const size_t mbytes =                                                                      \
+            (((size_t)qr * SQ_WAVES * k * 4 + 7) & ~(size_t)7) + (size_t)qr * SQ_WAVES * k * 8;    \
+        const size_t sm = std::max(ybytes, mbytes);                                                \
+        auto kern = sq_scan_kernel<L2_, QG_, R_>;                                                  \
         if (sm > 48 * 1024) {                                                                      \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); \
@@ -279,11 +283,20 @@ hipError_t launch_sq_scan(const SqScanArgs& a, bool is_l2, int64_t grid, hipStre
         }                                                                                          \
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(SQ_THREADS), sm, s, a);                \
     } while (0)
+#define SQ_BY_K(L2_)                                                                               \
+    do {                                                                                           \
+        if (k <= 64) SQ_LAUNCH(L2_, 8, 1);                                                         \
+        else if (k <= 128) SQ_LAUNCH(L2_, 8, 2);                                                   \
+        else if (k <= 256) SQ_LAUNCH(L2_, 4, 4);                                                   \
+        else if (k <= 512) SQ_LAUNCH(L2_, 2, 8);                                                   \
+        else SQ_LAUNCH(L2_, 1, 16);                                                                \
+    } while (0)
     if (is_l2) {
-        if (k <= 64) SQ_LAUNCH(true, 1); else SQ_LAUNCH(true, 2);
+        SQ_BY_K(true);
     } else {
-        if (k <= 64) SQ_LAUNCH(false, 1); else SQ_LAUNCH(false, 2);
+        SQ_BY_K(false);
     }
+#undef SQ_BY_K
 #undef SQ_LAUNCH
     return hipGetLastError();
 }

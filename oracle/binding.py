@@ -33,7 +33,7 @@ def build(ref=True):
     """(Re)build liboracle.so and, when the reference tree is present, _ref."""
     subprocess.check_call(["make", "-s", "-C", _HERE, "port"])
     if ref and os.path.isdir("/root/reference/thirdparty/faiss/faiss"):
-        subprocess.check_call(["make", "-s", "-j8", "-C", _HERE, "ref"])
+        subprocess.check_call(["make", "-s", "-j8", "-C", _HERE, "ref", "kref"])
 
 
 class _OrcIndex(C.Structure):
@@ -43,7 +43,7 @@ class _OrcIndex(C.Structure):
         ("nlist", C.c_int64), ("code_size", C.c_int64),
         ("centroids", _f32p), ("pq_centroids", _f32p), ("precomputed_table", _f32p),
         ("sq_trained", _f32p), ("list_sizes", _i64p),
-        ("list_codes", C.POINTER(_u8p)), ("list_ids", C.POINTER(_i64p)),
+        ("list_codes", C.POINTER(_u8p)), ("list_ids", C.POINTER(_i64p)), ("list_norms", C.POINTER(_f32p)),
     ]
 
 
@@ -60,6 +60,7 @@ class IndexData:
         self.list_codes = []         # per list uint8 [len, code_size]
         self.list_ids = []           # per list int64 [len]
         self.base = None             # FLAT: [n, d] f32
+        self.list_norms = None       # IVF_FLAT + COSINE: per list float32 [len] (rows stay raw)
 
     @property
     def code_size(self):
@@ -72,8 +73,105 @@ class IndexData:
         return int(sum(len(i) for i in self.list_ids))
 
 
-class Port:
+class _SimdTable:
+    """The src/simd hook table (reference src/simd/hook.h:33-123) as exposed by either checker: Port = the restatement
+    in oracle.c, Ref = the reference's own distances_ref.cc through oracle/ref_simd.cpp.  Same call shapes for both so
+    tests can compare them entry by entry.  Typed operands: numpy float16, uint16 bit patterns (bf16) or int8."""
+    _PORT_PLAIN = ("fvec_inner_product", "fvec_L2sqr", "fvec_L2sqr_ny", "fvec_inner_products_ny", "fvec_madd")
+
+    def _sfn(self, name, restype=None):
+        if self._simd_prefix == "orc_simd_" and name in self._PORT_PLAIN:
+            fn = getattr(self.lib, "orc_" + name)
+        else:
+            fn = getattr(self.lib, self._simd_prefix + name)
+        fn.restype = restype
+        return fn
+
+    @staticmethod
+    def _typed(a):
+        a = np.ascontiguousarray(a)
+        t = {np.dtype(np.float16): 0, np.dtype(np.uint16): 1, np.dtype(np.int8): 2}[a.dtype]
+        return t, a, C.c_void_p(a.ctypes.data)
+
+    def simd_scalar(self, name, x, y=None):
+        """fvec_inner_product | fvec_L2sqr | fvec_L1 | fvec_Linf | fvec_norm_L2sqr"""
+        x = np.ascontiguousarray(x, np.float32)
+        fn = self._sfn(name, C.c_float)
+        if name == "fvec_norm_L2sqr":
+            return np.float32(fn(_p(x, _f32p), C.c_int64(x.size)))
+        y = np.ascontiguousarray(y, np.float32)
+        return np.float32(fn(_p(x, _f32p), _p(y, _f32p), C.c_int64(x.size)))
+
+    def simd_ny(self, name, x, y):
+        """fvec_L2sqr_ny | fvec_inner_products_ny : x [d], y [ny, d]"""
+        ny, d = y.shape
+        out = np.empty(ny, np.float32)
+        self._sfn(name)(_p(out, _f32p), _p(x, _f32p), _p(y, _f32p), C.c_int64(d), C.c_int64(ny))
+        return out
+
+    def simd_ny_transposed(self, x, yt, y_sqlen, ny, nearest=False):
+        """fvec_L2sqr_ny_transposed (+ _nearest_y_transposed): yt [d, d_offset] with vector i in column i"""
+        d, d_offset = yt.shape
+        out = np.empty(ny, np.float32)
+        if nearest:
+            idx = self._sfn("fvec_L2sqr_ny_nearest_y_transposed", C.c_int64)(
+                _p(out, _f32p), _p(x, _f32p), _p(yt, _f32p), _p(y_sqlen, _f32p), C.c_int64(d), C.c_int64(d_offset),
+                C.c_int64(ny))
+            return int(idx), out
+        self._sfn("fvec_L2sqr_ny_transposed")(_p(out, _f32p), _p(x, _f32p), _p(yt, _f32p), _p(y_sqlen, _f32p),
+                                              C.c_int64(d), C.c_int64(d_offset), C.c_int64(ny))
+        return out
+
+    def simd_ny_nearest(self, x, y):
+        ny, d = y.shape
+        out = np.empty(ny, np.float32)
+        idx = self._sfn("fvec_L2sqr_ny_nearest", C.c_int64)(_p(out, _f32p), _p(x, _f32p), _p(y, _f32p), C.c_int64(d),
+                                                            C.c_int64(ny))
+        return int(idx), out
+
+    def simd_madd(self, a, bf, b, argmin=False):
+        c = np.empty_like(a)
+        if argmin:
+            i = self._sfn("fvec_madd_and_argmin", C.c_int)(C.c_int64(a.size), _p(a, _f32p), C.c_float(bf), _p(b, _f32p),
+                                                           _p(c, _f32p))
+            return int(i), c
+        self._sfn("fvec_madd")(C.c_int64(a.size), _p(a, _f32p), C.c_float(bf), _p(b, _f32p), _p(c, _f32p))
+        return c
+
+    def simd_batch_4(self, is_l2, x, ys):
+        """fvec_/fp16_vec_/bf16_vec_/int8_vec_ {L2sqr, inner_product}_batch_4: ys = four rows of x's dtype"""
+        out = np.empty(4, np.float32)
+        if x.dtype == np.float32:
+            rows = [np.ascontiguousarray(r, np.float32) for r in ys]
+            self._sfn("fvec_batch_4")(C.c_int(int(is_l2)), _p(x, _f32p), *[_p(r, _f32p) for r in rows],
+                                      C.c_int64(x.size), _p(out, _f32p))
+            return out
+        t, xa, xp = self._typed(x)
+        rows = [self._typed(r) for r in ys]
+        self._sfn("typed_batch_4")(C.c_int(t), C.c_int(int(is_l2)), xp, *[r[2] for r in rows], C.c_int64(xa.size),
+                                   _p(out, _f32p))
+        return out
+
+    def simd_typed(self, op, x, y=None):
+        """{fp16,bf16,int8}_vec_{L2sqr (op 0), inner_product (1), norm_L2sqr (2)}"""
+        t, xa, xp = self._typed(x)
+        yp = self._typed(y)[2] if y is not None else None
+        if y is not None:
+            keep = np.ascontiguousarray(y)  # keep the buffer alive across the call
+            yp = C.c_void_p(keep.ctypes.data)
+        return np.float32(self._sfn("typed", C.c_float)(C.c_int(t), C.c_int(op), xp, yp, C.c_int64(xa.size)))
+
+    def simd_ivec(self, is_l2, x, y):
+        i8p = C.POINTER(C.c_int8)
+        if self._simd_prefix == "orc_simd_":
+            return int(self._sfn("ivec", C.c_int32)(C.c_int(int(is_l2)), _p(x, i8p), _p(y, i8p), C.c_int64(x.size)))
+        name = "ivec_L2sqr" if is_l2 else "ivec_inner_product"
+        return int(self._sfn(name, C.c_int32)(_p(x, i8p), _p(y, i8p), C.c_int64(x.size)))
+
+
+class Port(_SimdTable):
     """oracle.c through ctypes."""
+    _simd_prefix = "orc_simd_"
 
     def __init__(self, path=None):
         path = path or os.path.join(_HERE, "liboracle.so")
@@ -145,7 +243,43 @@ class Port:
         s.list_codes = codes
         s.list_ids = ids
         keep += [sizes, codes, ids]
+        if getattr(ix, "list_norms", None) is not None:
+            norms = (_f32p * ix.nlist)()
+            for l in range(ix.nlist):
+                v = np.ascontiguousarray(ix.list_norms[l], np.float32)
+                keep.append(v)
+                norms[l] = _p(v, _f32p) if v.size else None
+            s.list_norms = norms
+            keep.append(norms)
         return s, keep
+
+    # -- cosine --
+    def normalize(self, x):
+        """knowhere::NormalizeVecs on a copy -> (normalised rows, norms)"""
+        x = np.array(x, np.float32, order="C", copy=True)
+        norms = np.empty(x.shape[0], np.float32)
+        self.lib.orc_normalize_vecs(_p(x, _f32p), C.c_int64(x.shape[0]), C.c_int(x.shape[1]), _p(norms, _f32p))
+        return x, norms
+
+    def inverse_l2_norms(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        inv = np.empty(x.shape[0], np.float32)
+        self.lib.orc_inverse_l2_norms(_p(x, _f32p), C.c_int64(x.shape[0]), C.c_int(x.shape[1]), _p(inv, _f32p))
+        return inv
+
+    def flat_cosine_search(self, xb, xq, k, bitset=None):
+        """FLAT + COSINE as FlatIndexNode: raw queries in (normalised here, as the node does)"""
+        xb = np.ascontiguousarray(xb, np.float32)
+        qn, _ = self.normalize(xq)
+        inv = self.inverse_l2_norms(xb)
+        nb, d = xb.shape
+        nq = qn.shape[0]
+        D = np.empty((nq, k), np.float32)
+        I = np.empty((nq, k), np.int64)
+        self.lib.orc_flat_cosine_search(C.c_int(d), C.c_int64(nb), _p(xb, _f32p), _p(inv, _f32p), C.c_int64(nq),
+                                        _p(qn, _f32p), C.c_int64(k), _p(bitset, _u8p),
+                                        C.c_int64(0 if bitset is None else nb), _p(D, _f32p), _p(I, _i64p))
+        return D, I
 
     # -- searches --
     def flat_search(self, metric, xb, xq, k, bitset=None):
@@ -349,7 +483,9 @@ def make_index(port, kind, metric, xb, nlist=16, M=8, nbits=8, seed=123, ids=Non
     return ix
 
 
-class Ref:
+class Ref(_SimdTable):
+    _simd_prefix = "ref_simd_"
+
     """oracle/_ref/libknowhere_ref*.so -- the reference's own FAISS, driven Knowhere-style.
     simd = "scalar": the SIMDLevel::NONE build every parity pin uses; "avx2": the dynamic-dispatch AVX2 build
     (oracle/Makefile ref_avx2), used ONLY as the timed cpu_baseline of bench.py."""
@@ -557,3 +693,120 @@ class Ref:
 
     def fvec_norm_L2sqr(self, x):
         return float(self.lib.ref_fvec_norm_L2sqr(_p(x, _f32p), C.c_int64(x.size)))
+
+
+class KRef:
+    """oracle/_ref/libknowhere_kref.so -- the index classes Knowhere's nodes instantiate for COSINE (the reference's FAISS
+    fork + src/common/utils.cc + the scalar hook table), driven as the nodes drive them (oracle/kref_driver.cpp)."""
+
+    @staticmethod
+    def path():
+        return os.path.join(_HERE, "_ref", "libknowhere_kref.so")
+
+    @staticmethod
+    def available():
+        if not os.path.exists(KRef.path()):
+            return False
+        try:
+            KRef()
+            return True
+        except OSError:
+            return False
+
+    def __init__(self):
+        os.environ.setdefault("MKL_THREADING_LAYER", "GNU")
+        for mkl in ("/opt/conda/lib/libmkl_rt.so.1", "/opt/conda/lib/libmkl_rt.so"):
+            if os.path.exists(mkl):
+                C.CDLL(mkl, mode=C.RTLD_GLOBAL)
+        # the fork and the baseline FAISS objects of libknowhere_ref*.so share symbol names: keep this copy private
+        self.lib = L = C.CDLL(KRef.path(), mode=C.RTLD_LOCAL | getattr(os, "RTLD_DEEPBIND", 0))
+        L.kref_last_error.restype = C.c_char_p
+        L.kref_ivfflat_cosine_create.restype = C.c_void_p
+        L.kref_ivfflat_cosine_list_size.restype = C.c_int64
+        L.kref_ivfflat_cosine_serialize.restype = C.c_int64
+        L.kref_flat_cosine_serialize.restype = C.c_int64
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise RuntimeError(self.lib.kref_last_error().decode())
+
+    def normalize(self, x):
+        x = np.array(x, np.float32, order="C", copy=True)
+        norms = np.empty(x.shape[0], np.float32)
+        self._chk(self.lib.kref_normalize(_p(x, _f32p), C.c_int64(x.shape[0]), C.c_int(x.shape[1]), _p(norms, _f32p)))
+        return x, norms
+
+    def flat_cosine_search(self, xb, xq, k, bitset=None):
+        xb = np.ascontiguousarray(xb, np.float32)
+        xq = np.ascontiguousarray(xq, np.float32)
+        nb, d = xb.shape
+        nq = xq.shape[0]
+        D = np.empty((nq, k), np.float32)
+        I = np.empty((nq, k), np.int64)
+        inv = np.empty(nb, np.float32)
+        self._chk(self.lib.kref_flat_cosine_search(C.c_int(d), C.c_int64(nb), _p(xb, _f32p), C.c_int64(nq), _p(xq, _f32p),
+                                                   C.c_int64(k), _p(bitset, _u8p),
+                                                   C.c_int64(0 if bitset is None else nb), _p(D, _f32p), _p(I, _i64p),
+                                                   _p(inv, _f32p)))
+        return D, I, inv
+
+    def flat_cosine_blob(self, xb):
+        xb = np.ascontiguousarray(xb, np.float32)
+        nb, d = xb.shape
+        cap = nb * d * 4 + nb * 4 + 4096
+        out = np.empty(cap, np.uint8)
+        n = self.lib.kref_flat_cosine_serialize(C.c_int(d), C.c_int64(nb), _p(xb, _f32p), _p(out, _u8p), C.c_int64(cap))
+        assert 0 < n <= cap, self.lib.kref_last_error().decode()
+        return out[:n].copy()
+
+    # IVF_FLAT + COSINE
+    def ivfflat_create(self, d, nlist):
+        h = self.lib.kref_ivfflat_cosine_create(C.c_int(d), C.c_int64(nlist))
+        if not h:
+            raise RuntimeError(self.lib.kref_last_error().decode())
+        return C.c_void_p(h)
+
+    def ivfflat_destroy(self, h):
+        self.lib.kref_ivfflat_cosine_destroy(h)
+
+    def ivfflat_train(self, h, x, niter=0, seed=-1):
+        x = np.ascontiguousarray(x, np.float32)
+        self._chk(self.lib.kref_ivfflat_cosine_train(h, C.c_int64(x.shape[0]), _p(x, _f32p), C.c_int(niter), C.c_int(seed)))
+
+    def ivfflat_centroids(self, h, d, nlist):
+        out = np.empty((nlist, d), np.float32)
+        self._chk(self.lib.kref_ivfflat_cosine_get_centroids(h, _p(out, _f32p)))
+        return out
+
+    def ivfflat_add(self, h, x):
+        x = np.ascontiguousarray(x, np.float32)
+        self._chk(self.lib.kref_ivfflat_cosine_add(h, C.c_int64(x.shape[0]), _p(x, _f32p)))
+
+    def ivfflat_lists(self, h, d, nlist):
+        codes, ids, norms = [], [], []
+        for l in range(nlist):
+            n = int(self.lib.kref_ivfflat_cosine_list_size(h, C.c_int64(l)))
+            c = np.empty((n, d * 4), np.uint8)
+            i = np.empty(n, np.int64)
+            v = np.empty(n, np.float32)
+            if n:
+                self._chk(self.lib.kref_ivfflat_cosine_get_list(h, C.c_int64(l), _p(c, _u8p), _p(i, _i64p), _p(v, _f32p)))
+            codes.append(c)
+            ids.append(i)
+            norms.append(v)
+        return codes, ids, norms
+
+    def ivfflat_search(self, h, xq, k, nprobe, bitset=None, nbits=0):
+        xq = np.ascontiguousarray(xq, np.float32)
+        nq = xq.shape[0]
+        D = np.empty((nq, k), np.float32)
+        I = np.empty((nq, k), np.int64)
+        self._chk(self.lib.kref_ivfflat_cosine_search(h, C.c_int64(nq), _p(xq, _f32p), C.c_int64(k), C.c_int64(nprobe),
+                                                      _p(bitset, _u8p), C.c_int64(nbits), _p(D, _f32p), _p(I, _i64p)))
+        return D, I
+
+    def ivfflat_blob(self, h, cap):
+        out = np.empty(cap, np.uint8)
+        n = self.lib.kref_ivfflat_cosine_serialize(h, _p(out, _u8p), C.c_int64(cap))
+        assert 0 < n <= cap, self.lib.kref_last_error().decode()
+        return out[:n].copy()

@@ -97,6 +97,189 @@ int32_t orc_int8_vec_L2sqr(const int8_t* x, const int8_t* y, size_t d) {
 }
 
 /* ------------------------------------------------------------------------------------------
+ * The rest of the src/simd hook table (reference src/simd/hook.h:33-123), restated from the scalar
+ * definitions in src/simd/distances_ref.cc.  Pinned against the reference's own *_ref functions
+ * (oracle/ref_simd.cpp over distances_ref.cc compiled where it lies) in tests/test_oracle.py.
+ * fp16 / bf16 operands are raw 16-bit patterns (include/knowhere/operands.h:53-160).
+ * ---------------------------------------------------------------------------------------- */
+#include <math.h>
+
+/* distances_ref.cc:39-55 */
+float orc_simd_fvec_L1(const float* x, const float* y, size_t d) {
+    float res = 0;
+    for (size_t i = 0; i < d; i++) {
+        res += fabsf(x[i] - y[i]);
+    }
+    return res;
+}
+float orc_simd_fvec_Linf(const float* x, const float* y, size_t d) {
+    float res = 0;
+    for (size_t i = 0; i < d; i++) {
+        res = fmaxf(res, fabsf(x[i] - y[i]));
+    }
+    return res;
+}
+/* distances_ref.cc:57-64: float products summed in a DOUBLE, rounded once on return */
+float orc_simd_fvec_norm_L2sqr(const float* x, size_t d) {
+    double res = 0;
+    for (size_t i = 0; i < d; i++) {
+        const float p = x[i] * x[i];
+        res += (double)p;
+    }
+    return (float)res;
+}
+/* distances_ref.cc:84-101: y is [d][d_offset] (column i = vector i); expanded form */
+void orc_simd_fvec_L2sqr_ny_transposed(float* dis, const float* x, const float* y, const float* y_sqlen,
+                                       size_t d, size_t d_offset, size_t ny) {
+    float x_sqlen = 0;
+    for (size_t j = 0; j < d; j++) {
+        x_sqlen += x[j] * x[j];
+    }
+    for (size_t i = 0; i < ny; i++) {
+        float dp = 0;
+        for (size_t j = 0; j < d; j++) {
+            dp += x[j] * y[i + j * d_offset];
+        }
+        const float s = x_sqlen + y_sqlen[i];
+        const float t = 2 * dp;
+        dis[i] = s - t;
+    }
+}
+/* distances_ref.cc:106-121 / :128-145: first strict minimum below +inf, 0 if none */
+static size_t orc_first_min(const float* dis, size_t ny) {
+    size_t best = 0;
+    float vmin = HUGE_VALF;
+    for (size_t i = 0; i < ny; i++) {
+        if (dis[i] < vmin) {
+            vmin = dis[i];
+            best = i;
+        }
+    }
+    return best;
+}
+size_t orc_simd_fvec_L2sqr_ny_nearest(float* tmp, const float* x, const float* y, size_t d, size_t ny) {
+    orc_fvec_L2sqr_ny(tmp, x, y, d, ny);
+    return orc_first_min(tmp, ny);
+}
+size_t orc_simd_fvec_L2sqr_ny_nearest_y_transposed(float* tmp, const float* x, const float* y,
+                                                   const float* y_sqlen, size_t d, size_t d_offset, size_t ny) {
+    orc_simd_fvec_L2sqr_ny_transposed(tmp, x, y, y_sqlen, d, d_offset, ny);
+    return orc_first_min(tmp, ny);
+}
+/* distances_ref.cc:154-168: c = a + bf * b and the first index whose c is below 1e20 and minimal (-1 if none) */
+int orc_simd_fvec_madd_and_argmin(size_t n, const float* a, float bf, const float* b, float* c) {
+    float vmin = 1e20f;
+    int imin = -1;
+    for (size_t i = 0; i < n; i++) {
+        c[i] = a[i] + bf * b[i];
+        if (c[i] < vmin) {
+            vmin = c[i];
+            imin = (int)i;
+        }
+    }
+    return imin;
+}
+/* distances_ref.cc:170-210: four independent sequential sums sharing x */
+void orc_simd_fvec_batch_4(int is_l2, const float* x, const float* y0, const float* y1, const float* y2,
+                           const float* y3, size_t d, float* out4) {
+    const float* ys[4] = {y0, y1, y2, y3};
+    for (int r = 0; r < 4; r++) {
+        out4[r] = is_l2 ? orc_fvec_L2sqr(x, ys[r], d) : orc_fvec_inner_product(x, ys[r], d);
+    }
+}
+
+/* IEEE binary16 -> binary32 (exact); operands.h:73-100 */
+static float orc_half_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    const uint32_t exp = (h >> 10) & 0x1fu;
+    uint32_t man = h & 0x3ffu;
+    uint32_t bits;
+    if (exp == 0) {
+        if (man == 0) {
+            bits = sign;
+        } else { /* subnormal: renormalise */
+            int e = -1;
+            do {
+                man <<= 1;
+                e++;
+            } while (!(man & 0x400u));
+            bits = sign | ((uint32_t)(112 - e) << 23) | ((man & 0x3ffu) << 13);
+        }
+    } else if (exp == 31) {
+        bits = sign | 0x7f800000u | (man << 13);
+    } else {
+        bits = sign | ((exp + 112) << 23) | (man << 13);
+    }
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+/* bfloat16 -> binary32: the pattern is the high half (operands.h:141-147) */
+static float orc_bf16_to_float(uint16_t h) {
+    const uint32_t bits = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+static float orc_typed_at(int type, const void* p, size_t i) {
+    if (type == 0) return orc_half_to_float(((const uint16_t*)p)[i]);
+    if (type == 1) return orc_bf16_to_float(((const uint16_t*)p)[i]);
+    return (float)((const int8_t*)p)[i];
+}
+/* type 0 fp16, 1 bf16, 2 int8; op 0 L2sqr, 1 inner product, 2 norm_L2sqr.
+ * fp16 / bf16: convert each element to float, float arithmetic, sequential (distances_ref.cc:236-262, :311-337;
+ * the norm sums float products in a double); int8: int32 accumulate then cast (distances_ref.cc:386-412). */
+float orc_simd_typed(int type, int op, const void* x, const void* y, size_t d) {
+    if (type == 2) {
+        int32_t res = 0;
+        const int8_t* a = (const int8_t*)x;
+        const int8_t* b = (const int8_t*)y;
+        for (size_t i = 0; i < d; i++) {
+            if (op == 0) {
+                const int32_t t = (int32_t)a[i] - (int32_t)b[i];
+                res += t * t;
+            } else if (op == 1) {
+                res += (int32_t)a[i] * (int32_t)b[i];
+            } else {
+                res += (int32_t)a[i] * (int32_t)a[i];
+            }
+        }
+        return (float)res;
+    }
+    if (op == 2) {
+        double res = 0;
+        for (size_t i = 0; i < d; i++) {
+            const float v = orc_typed_at(type, x, i);
+            const float p = v * v;
+            res += (double)p;
+        }
+        return (float)res;
+    }
+    float res = 0;
+    for (size_t i = 0; i < d; i++) {
+        const float a = orc_typed_at(type, x, i), b = orc_typed_at(type, y, i);
+        if (op == 0) {
+            const float t = a - b;
+            res += t * t;
+        } else {
+            res += a * b;
+        }
+    }
+    return res;
+}
+void orc_simd_typed_batch_4(int type, int is_l2, const void* x, const void* y0, const void* y1, const void* y2,
+                            const void* y3, size_t d, float* o) {
+    const void* ys[4] = {y0, y1, y2, y3};
+    for (int r = 0; r < 4; r++) {
+        o[r] = orc_simd_typed(type, is_l2 ? 0 : 1, x, ys[r], d);
+    }
+}
+/* distances_ref.cc:217-233 (ivec_*: the obsolete hnsw-sq entries, int32 results) */
+int32_t orc_simd_ivec(int is_l2, const int8_t* x, const int8_t* y, size_t d) {
+    return is_l2 ? orc_int8_vec_L2sqr(x, y, d) : orc_int8_vec_inner_product(x, y, d);
+}
+
+/* ------------------------------------------------------------------------------------------
  * Top-k heap: T:utils/Heap.h:112-151 (heap_replace_top), :45-75 (heap_pop), :318-343
  * (heap_heapify), :427-457 (heap_reorder); comparators T:utils/ordered_key_value.h:43-83.
  * is_max=1 is CMax (keeps the k SMALLEST, L2); is_max=0 is CMin (keeps the k LARGEST, IP).
@@ -262,6 +445,59 @@ int orc_flat_search(int metric, int d, int64_t nb, const float* xb, int64_t nq, 
             heap_add(is_max, (size_t)k, simi, idxi, dis, j);
         }
         orc_heap_reorder(is_max, (size_t)k, simi, idxi);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * COSINE.  reference src/common/utils.cc:60-93 NormalizeVec: the squared norm comes from the fvec_norm_L2sqr hook
+ * (scalar level = distances_ref.cc:57-64, float products summed in a double); a row is divided by sqrt(norm^2)
+ * only when norm^2 > 0 and |1 - norm^2| > 1e-5; the returned norm is that divisor, else 1.
+ * ---------------------------------------------------------------------------------------- */
+void orc_normalize_vecs(float* x, int64_t n, int d, float* norms) {
+    for (int64_t i = 0; i < n; i++) {
+        float* v = x + i * (int64_t)d;
+        const float ns = orc_simd_fvec_norm_L2sqr(v, (size_t)d);
+        float norm = 1.0f;
+        if (ns > 0 && fabsf(1.0f - ns) > 0.00001f) {
+            norm = sqrtf(ns);
+            for (int j = 0; j < d; j++) {
+                v[j] = v[j] / norm;
+            }
+        }
+        if (norms) {
+            norms[i] = norm;
+        }
+    }
+}
+
+/* T:cppcontrib/knowhere/IndexCosine.cpp:236-250 */
+void orc_inverse_l2_norms(const float* x, int64_t n, int d, float* inv) {
+    for (int64_t i = 0; i < n; i++) {
+        const float ns = orc_simd_fvec_norm_L2sqr(x + i * (int64_t)d, (size_t)d);
+        inv[i] = (ns == 0.0f) ? 1.0f : (1.0f / sqrtf(ns));
+    }
+}
+
+/* FLAT + COSINE: FlatIndexNode::Search (reference src/index/flat/flat.cc:98-122) -> IndexFlatCosine::search
+ * (IndexCosine.cpp:303-312) -> knn_cosine -> exhaustive_cosine_seq_impl (cppcontrib/knowhere/utils/distances.cpp
+ * :367-409): similarity = clamp(<q, y_j> * inv_norm_j, -1, 1), larger is better, heap for k < 100 */
+int orc_flat_cosine_search(int d, int64_t nb, const float* xb, const float* inv_norms, int64_t nq, const float* xq,
+                           int64_t k, const uint8_t* bitset, int64_t nbits, float* D, int64_t* I) {
+    for (int64_t i = 0; i < nq; i++) {
+        const float* x = xq + i * (int64_t)d;
+        float* simi = D + i * k;
+        int64_t* idxi = I + i * k;
+        orc_heap_heapify(0, (size_t)k, simi, idxi);
+        for (int64_t j = 0; j < nb; j++) {
+            if (filtered_out(bitset, nbits, j)) {
+                continue;
+            }
+            float dis = orc_fvec_inner_product(x, xb + j * (int64_t)d, (size_t)d) * inv_norms[j];
+            dis = dis < -1.0f ? -1.0f : (dis > 1.0f ? 1.0f : dis);
+            heap_add(0, (size_t)k, simi, idxi, dis, j);
+        }
+        orc_heap_reorder(0, (size_t)k, simi, idxi);
     }
     return 0;
 }
@@ -441,6 +677,10 @@ static void scan_one_list(const orc_index* idx, orc_scan_state* st, const float*
             }
             const float* y = (const float*)(codes + j * idx->code_size);
             float dis = is_max ? orc_fvec_L2sqr(q, y, (size_t)d) : orc_fvec_inner_product(q, y, (size_t)d);
+            if (idx->list_norms != NULL && idx->list_norms[key] != NULL) {
+                /* IndexIVFFlatCosine: T:cppcontrib/knowhere/IndexIVFFlat.cpp:199-213 dis = ip(q, raw row) / norm[j] */
+                dis = dis / idx->list_norms[key][j];
+            }
             sink_add(sk, dis, ids[j]);
         }
     } else if (idx->kind == ORC_IVF_PQ) {

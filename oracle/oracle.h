@@ -43,6 +43,7 @@ typedef struct orc_index {
     const int64_t* list_sizes;     /* [nlist] */
     const uint8_t* const* list_codes; /* [nlist] -> [len][code_size] */
     const int64_t* const* list_ids;   /* [nlist] -> [len] */
+    const float* const* list_norms;   /* IVF_FLAT + COSINE: [nlist] -> [len] stored L2 norms (NULL otherwise) */
 } orc_index;
 
 /* ---- distance primitives (reference src/simd/distances_ref.cc:21-76) ---- */
@@ -56,6 +57,34 @@ void orc_fvec_L2sqr_batch_4(const float* x, const float* y0, const float* y1, co
                             const float* y3, size_t d, float* d0, float* d1, float* d2, float* d3);
 int32_t orc_int8_vec_inner_product(const int8_t* x, const int8_t* y, size_t d);
 int32_t orc_int8_vec_L2sqr(const int8_t* x, const int8_t* y, size_t d);
+
+/* ---- rest of the src/simd hook table (src/simd/hook.h:33-123; scalar definitions distances_ref.cc) ----
+ * typed operands: type 0 fp16, 1 bf16 (raw uint16 patterns), 2 int8; op 0 L2sqr, 1 inner product, 2 norm_L2sqr */
+float orc_simd_fvec_L1(const float* x, const float* y, size_t d);
+float orc_simd_fvec_Linf(const float* x, const float* y, size_t d);
+float orc_simd_fvec_norm_L2sqr(const float* x, size_t d);
+void orc_simd_fvec_L2sqr_ny_transposed(float* dis, const float* x, const float* y, const float* y_sqlen,
+                                       size_t d, size_t d_offset, size_t ny);
+size_t orc_simd_fvec_L2sqr_ny_nearest(float* tmp, const float* x, const float* y, size_t d, size_t ny);
+size_t orc_simd_fvec_L2sqr_ny_nearest_y_transposed(float* tmp, const float* x, const float* y,
+                                                   const float* y_sqlen, size_t d, size_t d_offset, size_t ny);
+int orc_simd_fvec_madd_and_argmin(size_t n, const float* a, float bf, const float* b, float* c);
+void orc_simd_fvec_batch_4(int is_l2, const float* x, const float* y0, const float* y1, const float* y2,
+                           const float* y3, size_t d, float* out4);
+float orc_simd_typed(int type, int op, const void* x, const void* y, size_t d);
+void orc_simd_typed_batch_4(int type, int is_l2, const void* x, const void* y0, const void* y1, const void* y2,
+                            const void* y3, size_t d, float* out4);
+int32_t orc_simd_ivec(int is_l2, const int8_t* x, const int8_t* y, size_t d);
+
+/* ---- COSINE (a12).  Queries passed to the cosine searches are already normalised (orc_normalize_vecs), as the
+ * nodes do with CopyAndNormalizeVecs (src/index/flat/flat.cc:113-117, src/index/ivf/ivf.cc:946-950). ---- */
+/* knowhere::NormalizeVecs, src/common/utils.cc:60-93: rows normalised in place, norms[i] = the divisor (1 if skipped) */
+void orc_normalize_vecs(float* x, int64_t n, int d, float* norms);
+/* L2NormsStorage::add, cppcontrib/knowhere/IndexCosine.cpp:236-250: inv[i] = 1 / sqrt(||x_i||^2), 1 for a zero row */
+void orc_inverse_l2_norms(const float* x, int64_t n, int d, float* inv);
+/* IndexFlatCosine::search -> knn_cosine (cppcontrib/knowhere/utils/distances.cpp:367-409): clamp(<q, y_j> * inv_j) */
+int orc_flat_cosine_search(int d, int64_t nb, const float* xb, const float* inv_norms, int64_t nq, const float* xq,
+                           int64_t k, const uint8_t* bitset, int64_t nbits, float* D, int64_t* I);
 
 /* ---- top-k heap (T:utils/Heap.h) ---- */
 void orc_heap_heapify(int is_max, size_t k, float* val, int64_t* ids);

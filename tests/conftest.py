@@ -27,6 +27,14 @@ def ref():
     return ob.Ref()
 
 
+@pytest.fixture(scope="session")
+def kref():
+    from oracle import binding as ob
+    if not ob.KRef.available():
+        pytest.skip("oracle/_ref/libknowhere_kref.so not built (needs /root/reference)")
+    return ob.KRef()
+
+
 def gen_data(n, d, seed, lo=0.0, hi=100.0):
     """reference fixture: tests/ut/utils.h:41-50 GenDataSet = uniform_real(0, 100), seeded"""
     r = np.random.default_rng(seed)

@@ -58,3 +58,19 @@ def finish_ivfpq(port, ix):
     if ix.kind == ob.IVF_PQ and ix.metric == ob.L2 and ix.use_precomputed_table == 1 and ix.precomputed_table is None:
         ix.precomputed_table = port.pq_precompute_table(ix.d, ix.M, ix.nbits, ix.centroids, ix.pq_centroids)
     return ix
+
+
+def load_cosine_golden():
+    """tests/golden/cosine/*.npz (tests/golden/make_cosine_golden.py): flat fixture, IVF_FLAT fixture as IndexData"""
+    zf = np.load(os.path.join(GOLDEN, "cosine", "flat.npz"))
+    zi = np.load(os.path.join(GOLDEN, "cosine", "ivfflat.npz"))
+    d = zf["xb"].shape[1]
+    sizes = zi["list_sizes"]
+    nlist = len(sizes)
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    ix = ob.IndexData(ob.IVF_FLAT, ob.IP, d, nlist)
+    ix.centroids = zi["centroids"]
+    ix.list_codes = [np.ascontiguousarray(zi["codes"][off[l]:off[l + 1]]) for l in range(nlist)]
+    ix.list_ids = [np.ascontiguousarray(zi["ids"][off[l]:off[l + 1]]) for l in range(nlist)]
+    ix.list_norms = [np.ascontiguousarray(zi["norms"][off[l]:off[l + 1]]) for l in range(nlist)]
+    return zf, zi, ix

@@ -163,7 +163,7 @@ def test_cpu_built_index_loads_into_the_hip_node(node, path):
         D, I = _search(node, h, xq, f"k={k};nprobe={nprobe}", k)
         assert_parity(z["D"], z["I"], D, I, metric, "cpu blob -> hip node")
         if "Dr" in z.files:  # IndexRefine, k_factor 4 (refine_k = 4k)
-            D, I = _search(node, h, xq, f"k={k};nprobe={nprobe};refine_k={4 * k}", k)
+            D, I = _search(node, h, xq, f"k={k};nprobe={nprobe};refine_k=4", k)
             assert_parity(z["Dr"], z["Ir"], D, I, metric, "cpu blob -> hip node, refine")
         # and the node writes the same kind of bytes back: identical up to the 16 reserved header bytes
         n = node.knhip_node_serialize(C.c_void_p(h), None, C.c_int64(0))
@@ -205,7 +205,7 @@ def test_hip_built_index_is_read_by_the_reference(node, ref, kind, metric):
         assert_parity(Dr, Ir, D, I, m, "hip blob -> reference")
         if refine:
             assert np.array_equal(raw, xb)
-            D2, I2 = _search(node, h, xq, f"k={k};nprobe={nprobe};refine_k={4 * k}", k)
+            D2, I2 = _search(node, h, xq, f"k={k};nprobe={nprobe};refine_k=4", k)
             Dr2, Ir2 = ref.search_refine(h2, raw, xq, k, 4.0, nprobe)
             assert_parity(Dr2, Ir2, D2, I2, m, "hip blob -> reference, refine")
         ref.destroy(h2)

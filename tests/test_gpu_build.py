@@ -118,6 +118,36 @@ def test_brute_force_repeated_add(torch_cuda, port):
     g.close()
 
 
+@pytest.mark.parametrize("kind,d", [(ob.IVF_SQ8, 20), (ob.IVF_SQ8, 64), (ob.IVF_FLAT, 6), (ob.IVF_FLAT, 32)])
+def test_large_lists_drop_the_aos_copy_and_rebuild_it(torch_cuda, port, monkeypatch, kind, d):
+    """flat / SQ8 indexes above KNHIP_AOS_KEEP_MB keep only the interleaved layout; get_lists (Serialize) and a further
+    Add rebuild the canonical bytes from it: same bytes, same search results (d not a multiple of 16 / 4 included)"""
+    from knowhere_amd import GpuIndex
+    monkeypatch.setenv("KNHIP_AOS_KEEP_MB", "0")
+    nb, nlist = 7000, 16
+    xb, xq = gen_data(nb, d, 42), gen_data(25, d, 44)
+    g = GpuIndex(kind, ob.L2, d, nlist=nlist)
+    g.train(xb[:4000], niter=5)
+    g.add(xb[:3000])
+    sizes0, codes0, ids0 = g.get_lists()       # rebuilt from the interleaved blocks
+    g.add(xb[3000:])                           # merge needs the old canonical bytes again
+    sizes, codes, ids = g.get_lists()
+    monkeypatch.setenv("KNHIP_AOS_KEEP_MB", "100000")
+    h = GpuIndex(kind, ob.L2, d, nlist=nlist)  # same build with the copy resident
+    h.train(xb[:4000], niter=5)
+    h.add(xb[:3000])
+    s0, c0, i0 = h.get_lists()
+    h.add(xb[3000:])
+    s1, c1, i1 = h.get_lists()
+    assert (sizes0 == s0).all() and codes0.tobytes() == c0.tobytes() and (ids0 == i0).all()
+    assert (sizes == s1).all() and codes.tobytes() == c1.tobytes() and (ids == i1).all()
+    D, I = g.search(xq, 10, 8)
+    D2, I2 = h.search(xq, 10, 8)
+    assert D.tobytes() == D2.tobytes() and (I == I2).all()
+    g.close()
+    h.close()
+
+
 def test_train_errors(torch_cuda):
     from knowhere_amd import GpuIndex, KnhipError
     g = GpuIndex(ob.IVF_PQ, ob.L2, 32, nlist=64, pq_m=8)

@@ -99,8 +99,7 @@ def test_ivf(torch_cuda, port, kind, M, metric):
     xb, xq = gen_data(nb, d, 42), gen_data(45, d, 44)
     ix = ob.make_index(port, kind, metric, xb, nlist=nlist, M=max(M, 1))
     g = _gpu(ix)
-    ks = (1, 10, 100) if kind == ob.IVF_SQ8 else (1, 10, 100, 200)
-    for k in ks:
+    for k in (1, 10, 100, 200):
         for nprobe in (1, 8, nlist):
             Do, Io = port.search(ix, xq, k, nprobe)
             D, I = g.search(xq, k, nprobe)
@@ -113,6 +112,26 @@ def test_ivf(torch_cuda, port, kind, M, metric):
     Do, Io = port.search(ix, xq, 10, nlist, bs, nb)
     D, I = g.search(xq, 10, nlist, bs, nb)
     assert_parity(Do, Io, D, I, metric, "bitset 98%")
+    g.close()
+
+
+@pytest.mark.parametrize("kind", [ob.IVF_FLAT, ob.IVF_SQ8])
+@pytest.mark.parametrize("metric", [ob.L2, ob.IP])
+def test_large_k_row_scans(torch_cuda, port, kind, metric):
+    """k up to 1024 on the row scans (refine asks IVF_SQ8 for k x refine_k candidates, ivf.cc:1073-1103): the
+    per-item query group shrinks as k grows (8 / 4 / 2 / 1)"""
+    nb, d, nlist = 9000, 48, 12
+    xb, xq = gen_data(nb, d, 42), gen_data(21, d, 44)
+    ix = ob.make_index(port, kind, metric, xb, nlist=nlist)
+    g = _gpu(ix)
+    for k, nprobe in ((129, 3), (256, 12), (400, 5), (512, 12), (1000, 7), (1024, 12)):
+        Do, Io = port.search(ix, xq, k, nprobe)
+        D, I = g.search(xq, k, nprobe)
+        assert_parity(Do, Io, D, I, metric, f"kind={kind} k={k} nprobe={nprobe}")
+    bs = _bitset(nb, 0.7, 3)
+    Do, Io = port.search(ix, xq, 600, 12, bs, nb)
+    D, I = g.search(xq, 600, 12, bs, nb)
+    assert_parity(Do, Io, D, I, metric, "large k + bitset (fewer survivors than k in places)")
     g.close()
 
 
