@@ -47,7 +47,8 @@ from knowhere_amd import sharded  # noqa: E402
 HBM_PEAK_GBPS = 8000.0                 # HBM3E spec peak
 LDS_PEAK_GBPS = 256 * 256 * 2.4        # 256 B/clk/CU (conflict-free ds_read_b64/b128) x 256 CUs x 2.4 GHz
 VALU_PEAK_TFLOPS = 157.3               # fp32 vector peak (FMA = 2 flop)
-MFMA_F32_PEAK_TFLOPS = 157.3           # fp32 matrix peak (coarse quantizer)
+MFMA_F32_PEAK_TFLOPS = 157.3           # fp32 matrix peak (coarse quantizer, fp32 row prefilter)
+MFMA_F16_PEAK_TFLOPS = 2500.0          # dense f16 / bf16 matrix peak (SQ8 prefilter)
 
 CONFIGS = {
     # BASELINE.json configs[1]
@@ -321,6 +322,36 @@ def make_roofline(a, kind, prof, world):
                      "peak": round(LDS_PEAK_GBPS, 1), "unit": "GB/s", "frac": round(lds / LDS_PEAK_GBPS, 4),
                      "note": "achieved = 4 B x code bytes scanned / launch time; peak = 256 B/clk/CU x 256 CU x 2.4 GHz"},
                     **common)
+    if prof.get("mscan_queries", 0) > 0:
+        # MFMA prefilter + exact finish (mfma_scan.hip): the dominant kernel is a grouped (rows of a list) x (queries
+        # that probe it) x d contraction; every unit streams its list once for up to 64 (fp32 rows) / 32 (SQ8) queries.
+        code_size = a.d * 4 if kind == kidx.IVF_FLAT else a.d
+        macs = scan_bytes / code_size * a.d
+        stream = prof["mscan_stream_bytes"] / nlaunch
+        stream_gbps = stream / sec / 1e9 if sec > 0 else 0.0
+        if kind == kidx.IVF_FLAT:
+            flop, peak, kname, unit_note = 2.0 * macs, MFMA_F32_PEAK_TFLOPS, "knhip::mscan_flat_kernel", \
+                "2 flop per (row, query, dim) on v_mfma_f32_32x32x2_f32; peak = fp32 matrix peak"
+        else:
+            flop, peak, kname, unit_note = 4.0 * macs, MFMA_F16_PEAK_TFLOPS, "knhip::mscan_sq8_kernel", \
+                "4 flop per (row, query, dim): the query operand is split into two halves (hi + lo) on " \
+                "v_mfma_f32_32x32x16_f16; peak = dense f16 matrix peak"
+        tf = flop / sec / 1e12 if sec > 0 else 0.0
+        mfma_frac, hbm_frac = tf / peak, stream_gbps / HBM_PEAK_GBPS
+        steps = max(a.steps, 1)
+        extra = {"mfma": {"achieved_TFLOPs": round(tf, 2), "peak_TFLOPs": peak, "frac": round(mfma_frac, 4)},
+                 "stream": {"bytes_per_launch": stream, "GBps": round(stream_gbps, 1), "frac_of_hbm_peak": round(hbm_frac, 4),
+                            "note": "bytes the kernel reads if every unit streams its list once (L2 hits between "
+                                    "concurrent units of one list make the HBM traffic smaller)"},
+                 "mscan": {"queries_per_step": prof["mscan_queries"] / steps,
+                           "overflow_queries_per_step": prof["mscan_overflow_queries"] / steps,
+                           "candidates_per_query": round(prof["mscan_candidates"] / max(prof["mscan_queries"], 1), 1)}}
+        if mfma_frac >= hbm_frac:
+            return dict({"bound": "mfma", "kernel": kname, "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(mfma_frac, 4), "note": unit_note}, **common, **extra)
+        return dict({"bound": "hbm", "kernel": kname, "achieved": round(stream_gbps, 1), "peak": HBM_PEAK_GBPS,
+                     "unit": "GB/s", "frac": round(hbm_frac, 4),
+                     "note": "achieved = bytes streamed by the units / launch time"}, **common, **extra)
     # exact row scans: lane = row, the queries of a work item share each row fetch -> VALU-bound by construction:
     # per (row, query, dim) L2 = sub, mul, add; IP = mul, add (+ SQ8: decode fma per (row, dim))
     code_size = a.d * 4 if kind == kidx.IVF_FLAT else a.d

@@ -59,7 +59,11 @@ __global__ __launch_bounds__(FS_THREADS) void flat_scan_kernel(FlatScanArgs a) {
             slot_of[j] = (int32_t)chunk;
         }
     } else {
-        const int64_t nitems = *a.nitems_dev;
+        if (a.q_only != nullptr && a.q_only[a.nq] == 0) {
+            return; // no query was flagged: nothing to redo
+        }
+        const int64_t item_lo = a.item_lo_dev ? *a.item_lo_dev : 0;
+        const int64_t nitems = *a.nitems_dev - item_lo;
         if ((int64_t)blockIdx.x >= ((nitems + 7) / 8) * 8) {
             return;
         }
@@ -67,7 +71,7 @@ __global__ __launch_bounds__(FS_THREADS) void flat_scan_kernel(FlatScanArgs a) {
         if (item >= nitems) {
             return;
         }
-        const KnItem it = a.items[item];
+        const KnItem it = a.items[item_lo + item];
         npair = it.npair;
         blk0 = a.list_blk_off[it.list];
         len = a.list_len[it.list];
@@ -78,6 +82,17 @@ __global__ __launch_bounds__(FS_THREADS) void flat_scan_kernel(FlatScanArgs a) {
             q_of[j] = p.q;
             slot_of[j] = p.slot;
         }
+    }
+    // query subset (fallback of the MFMA prefilter): pairs of unflagged queries are left alone
+    bool act[QG];
+    bool any_act = false;
+#pragma unroll
+    for (int j = 0; j < QG; j++) {
+        act[j] = j < npair && (DENSE || a.q_only == nullptr || a.q_only[q_of[j]] != 0);
+        any_act |= act[j];
+    }
+    if (!any_act) {
+        return;
     }
 
     // ---- stage the QG queries in LDS (zero padded to dpad) --------------------------------
@@ -141,7 +156,7 @@ __global__ __launch_bounds__(FS_THREADS) void flat_scan_kernel(FlatScanArgs a) {
         //      (lists are stored sorted by id; DENSE ids are row + offset) ----------------
 #pragma unroll
         for (int j = 0; j < QG; j++) {
-            if (j < npair) {
+            if (act[j]) {
                 bool pass = valid && within_gthr<IS_L2>(acc[j], gt[j]) &&
                             top[j].admits(acc[j], row, kd[j], ki[j]);
                 unsigned long long m = __ballot(pass);
@@ -182,7 +197,7 @@ __global__ __launch_bounds__(FS_THREADS) void flat_scan_kernel(FlatScanArgs a) {
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < QG; j++) {
-            if (j >= j0 && j < j0 + qr && j < npair && (j % FS_WAVES) == wave) {
+            if (j >= j0 && j < j0 + qr && act[j] && (j % FS_WAVES) == wave) {
                 // start from this wave's own list, fold in the other three
                 for (int w = 1; w < FS_WAVES; w++) {
                     const int ow = (wave + w) % FS_WAVES;

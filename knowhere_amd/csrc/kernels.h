@@ -88,6 +88,10 @@ struct FlatScanArgs {
     float* gthr;                 // [nq] shared per-query threshold (see common.h gthr_*)
     int32_t nslot;
     int32_t k;
+    // TABLE: optional work-item range [*item_lo_dev, *nitems_dev) (null = 0) and optional query subset: only pairs
+    // whose query has q_only[q] != 0 are scanned; q_only[nq] != 0 iff any query is flagged (mfma_scan.hip fallback)
+    const int64_t* item_lo_dev;
+    const int32_t* q_only;
 };
 
 enum PqLutMode { PQ_LUT_PRECOMP = 0, PQ_LUT_IP = 1, PQ_LUT_RESIDUAL = 2 };
@@ -161,6 +165,42 @@ struct SqScanArgs {
     // range search: non-null = write every distance to dump[q * dump_stride + storage position], no top-k
     float* dump;
     int64_t dump_stride;
+    // optional work-item range / query subset, as in FlatScanArgs
+    const int64_t* item_lo_dev;
+    const int32_t* q_only;
+    int64_t nq;
+};
+
+// ---- mfma_scan.hip: MFMA prefilter + exact finish for the IVF-Flat / IVF-SQ8 list scans ----
+struct MScanArgs {
+    const void* rows;            // interleaved blocks (float4 / uint4), as FlatScanArgs / SqScanArgs
+    const float* xnorm;          // [total blocks * 64] ||x||^2 per stored row position (L2)
+    float xnorm_max;             // fp32 rows: max ||x||^2 (error bound)
+    const int64_t* list_blk_off;
+    const int64_t* list_len;
+    const int64_t* list_row_off;
+    const int64_t* ids;
+    const float* trained;        // SQ8: vmin[d], vdiff[d]
+    const float* centroids;      // SQ8 L2: query residual
+    int32_t d;
+    int32_t nchunk;              // fp32: ceil(d / 4) float4 chunks; SQ8: ceil(d / 16) code chunks
+    int32_t nstep;               // fp32: ceil(nchunk / 4) steps of 16 dims; SQ8: ceil(nchunk / 2) steps of 32 dims
+    const float* queries;
+    const float* qnorm;          // [nq] ||q||^2 (fp32 rows)
+    const float* coarse_dis;     // [nq][nslot] (SQ8 IP: accu0)
+    int64_t nq;
+    int32_t nslot;
+    const KnItem* units;         // (list, pair range) units of the bulk probes
+    const KnPair* pairs;
+    const int64_t* nunits_dev;
+    const float* gthr;           // [nq] exact k-th distance of the rank-0 list (or the neutral value)
+    float eps_scale;
+    const uint8_t* bitset;
+    int64_t bitset_nbits;
+    int32_t* cand_cnt;           // [nq]
+    int64_t* cand;               // [nq][cap]: slot << 32 | row position in the list
+    int32_t cap;
+    int32_t* overflow;           // [nq + 1]: per-query flag, [nq] = any
 };
 
 // ---- flat_scan.hip ----
@@ -204,6 +244,24 @@ hipError_t launch_pq_stream16(const uint8_t* codes, const int64_t* list_row_off,
 bool pq_scan_q4_supports(int M, int d, int k);
 hipError_t launch_pq_scan_q4(const PqScanArgs& a, bool is_l2, int64_t items_bound, hipStream_t s);
 hipError_t launch_pq_cb_transpose(const float* cb, int M, int dsub, float4* cb_t, hipStream_t s);
+
+// ---- mfma_scan.hip ----
+int mscan_queries_per_unit(int kind);
+size_t mscan_flat_smem(int nstep);
+size_t mscan_sq8_smem(int nstep);
+int mscan_finish_pmax(int cap, int k);
+hipError_t launch_ms_block_norms(const float4* rows, int64_t total_blk, int nchunk, float* out, float* out_max,
+                                 hipStream_t s);
+hipError_t launch_ms_sq8_norms(const uint4* rows, int64_t total_blk, int nchunk16, int d, const float* trained,
+                               float* out, hipStream_t s);
+hipError_t launch_ms_units(const int32_t* list_count, const int64_t* list_pair_off, int64_t nlist, int qt,
+                           int64_t* unit_off, int64_t* nunits, KnItem* units, const int64_t* list_len,
+                           int64_t code_size, double* unit_bytes, hipStream_t s);
+hipError_t launch_mscan_flat(const MScanArgs& a, bool is_l2, int64_t units_bound, hipStream_t s);
+hipError_t launch_mscan_sq8(const MScanArgs& a, bool is_l2, int64_t units_bound, hipStream_t s);
+hipError_t launch_mscan_finish(const MScanArgs& a, int kind, bool is_l2, const int64_t* keys, const float* coarse_dis,
+                               int nprobe, const float* partial_d, const int64_t* partial_i, int k, float* out_d,
+                               int64_t* out_i, unsigned long long* counters, hipStream_t s);
 
 // ---- sq_scan.hip ----
 hipError_t launch_sq_scan(const SqScanArgs& a, bool is_l2, int64_t grid, hipStream_t s);
@@ -258,7 +316,7 @@ hipError_t launch_range_emit(const RangeArgs& a, int64_t nq, bool is_l2, const i
 // list (q, slot) starts at q * q_stride + slot * slot_stride (elements)
 hipError_t launch_merge_partials(const float* partial_d, const int64_t* partial_i, int64_t nq,
                                  int nslot, int k, int64_t q_stride, int64_t slot_stride, bool is_l2,
-                                 float* out_d, int64_t* out_i, hipStream_t s);
+                                 float* out_d, int64_t* out_i, hipStream_t s, const int32_t* q_only = nullptr);
 // per row: the k best of n values (index = column), canonical order; out_keys int64, out_d float
 hipError_t launch_row_select(const float* vals, int64_t nrows, int64_t n, int k, bool is_l2,
                              int64_t* out_keys, float* out_d, const int32_t* row_flags, hipStream_t s);

@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -123,6 +124,8 @@ struct Workspace {
     DevBuf ghist;        // [qb][64] per-query candidate histogram (pq_scan_v2 after a rank-0 phase)
     DevBuf gmeta;        // [qb] {first-bin key, shift}
     DevBuf list_count, list_pair_off, list_item_off, list_cursor, pairs, items, nitems;
+    // MFMA prefilter of the IVF-Flat / IVF-SQ8 scans (mfma_scan.hip)
+    DevBuf ms_units, ms_unit_off, ms_nunits, ms_cand, ms_cand_cnt;  // ms_cand_cnt: [qb] counters + [qb + 1] overflow flags
     // host-boundary staging
     DevBuf h_queries, h_bitset, h_out_d, h_out_i, h_ref_d, h_ref_i;
     std::mutex mu;  // held while a *_device entry point enqueues on this (per-stream) workspace
@@ -180,6 +183,13 @@ struct knhip_index {
     bool cand_hist = true;     // KNHIP_HIST=0 switches the per-query candidate histogram off
     mutable bool rank0_phase_used = false;
     int64_t max_list_len = 0;
+    // MFMA prefilter (mfma_scan.hip): KNHIP_MSCAN = 0 never, 1 whenever the shape allows, 2 (default) when the lists
+    // are shared by enough queries of the batch
+    int mscan = 2;
+    mutable bool xnorm_ready = false;
+    mutable DevBuf xnorm;        // [total blocks * 64] ||x||^2 per stored row position, built on first use
+    mutable float xnorm_max = 0.f;
+    int64_t total_blk = 0;       // 64-row blocks of the interleaved layout
     // scratch
     mutable std::mutex mu;
     std::mutex add_mu;     // serialises Add / Train
@@ -376,6 +386,9 @@ int build_list_layout(knhip_index* idx, const std::vector<int64_t>& list_off, co
         idx->cand_hist = !(h && h[0] == '0');
         const char* q4 = getenv("KNHIP_Q4");
         idx->pq_q4 = (q4 && q4[0] >= '0' && q4[0] <= '2') ? q4[0] - '0' : 2;
+        const char* ms = getenv("KNHIP_MSCAN");
+        idx->mscan = (ms && ms[0] >= '0' && ms[0] <= '2') ? ms[0] - '0' : 2;
+        idx->xnorm_ready = false;
     }
     for (int64_t l = 0; l < nlist; l++) {
         idx->h_list_len[l] = list_off[l + 1] - list_off[l];
@@ -421,6 +434,7 @@ int build_list_layout(knhip_index* idx, const std::vector<int64_t>& list_off, co
     }
     idx->aos_ready = keep_aos;
     const int64_t total_blk = blk_off[nlist];
+    idx->total_blk = total_blk;
     if (kind == KNHIP_IVF_FLAT) {
         const int nchunk = (idx->d + 3) / 4;
         HIP_TRY(idx->rows.alloc((size_t)total_blk * nchunk * 64 * sizeof(float4)));
@@ -476,6 +490,30 @@ int ensure_aos(const knhip_index* cidx) {
                                       idx->code_size, idx->codes_aos.as<uint8_t>(), nullptr));
     HIP_TRY(hipDeviceSynchronize());
     idx->aos_ready = true;
+    return KNHIP_OK;
+}
+
+// ||x||^2 per stored row (fp32 rows: any metric, for the error bound; SQ8: L2 only), built on first use
+int ensure_mscan_norms(const knhip_index* idx) {
+    const int64_t total_blk = idx->total_blk;
+    std::lock_guard<std::mutex> lk(idx->mu);
+    if (idx->xnorm_ready) {
+        return KNHIP_OK;
+    }
+    HIP_TRY(idx->xnorm.alloc((size_t)std::max<int64_t>(total_blk, 1) * 64 * sizeof(float) + 16));
+    float* xn = idx->xnorm.as<float>();
+    float* xmax = xn + std::max<int64_t>(total_blk, 1) * 64;
+    if (idx->desc.kind == KNHIP_IVF_FLAT) {
+        HIP_TRY(launch_ms_block_norms(idx->rows.as<float4>(), total_blk, (idx->d + 3) / 4, xn, xmax, nullptr));
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(&idx->xnorm_max, xmax, sizeof(float), hipMemcpyDeviceToHost));
+    } else {
+        HIP_TRY(launch_ms_sq8_norms(idx->rows.as<uint4>(), total_blk, (idx->d + 15) / 16, idx->d,
+                                    idx->sq_trained.as<float>(), xn, nullptr));
+        HIP_TRY(hipDeviceSynchronize());
+        idx->xnorm_max = 0.f;
+    }
+    idx->xnorm_ready = true;
     return KNHIP_OK;
 }
 
@@ -587,6 +625,29 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             qg_rank0 = pq_rank0 ? qg : 4;
         }
     }
+    // IVF-Flat / IVF-SQ8: MFMA prefilter + exact finish (mfma_scan.hip) when the lists are shared by enough queries
+    bool use_ms = false;
+    int ms_cap = 0, ms_nchunk = 0, ms_nstep = 0;
+    if ((kind == KNHIP_IVF_FLAT || kind == KNHIP_IVF_SQ8) && idx->mscan != 0 && nprobe >= 2) {
+        size_t lds;
+        if (kind == KNHIP_IVF_FLAT) {
+            ms_nchunk = (d + 3) / 4;
+            ms_nstep = (ms_nchunk + 3) / 4;
+            lds = mscan_flat_smem(ms_nstep);
+        } else {
+            ms_nchunk = (d + 15) / 16;
+            ms_nstep = (ms_nchunk + 1) / 2;
+            lds = mscan_sq8_smem(ms_nstep);
+        }
+        // candidate capacity per query: the finish kernel sorts cap + k entries in LDS (a power of two)
+        int P = 512;
+        while (P < (int64_t)nprobe * k + k && P < 8192) {
+            P <<= 1;
+        }
+        ms_cap = P - k;
+        use_ms = lds <= 160 * 1024 - 1024 && ms_cap >= 2 * k &&
+                (idx->mscan == 1 || npairs >= 8 * nlist);
+    }
     const int64_t items_bound =
             round_up(npairs / std::min(qg_rank0, qg_bulk) + std::min<int64_t>(2 * nlist, npairs) + 1, 8);
     HIP_TRY(ws->list_count.reserve((size_t)2 * nlist * sizeof(int32_t)));
@@ -619,6 +680,89 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         idx->last_items_bound = items_bound;
     }
 
+    // phases 2-4 of the MFMA prefilter path; `exact_bulk` re-runs the exact kernel over the bulk items for the
+    // flagged (overflowed) queries only
+    auto run_mscan = [&](const std::function<int(const int64_t*, const int64_t*, const int32_t*, int64_t)>& exact_scan)
+            -> int {
+        if (int rc = ensure_mscan_norms(idx)) return rc;
+        const int qt = mscan_queries_per_unit(kind);
+        const int64_t units_bound = round_up(npairs / qt + std::min<int64_t>(nlist, npairs) + 1, 8);
+        HIP_TRY(ws->ms_units.reserve((size_t)units_bound * sizeof(KnItem)));
+        HIP_TRY(ws->ms_unit_off.reserve((size_t)(nlist + 1) * sizeof(int64_t)));
+        HIP_TRY(ws->ms_nunits.reserve(sizeof(int64_t)));
+        HIP_TRY(ws->ms_cand.reserve((size_t)nq * ms_cap * sizeof(int64_t)));
+        HIP_TRY(ws->ms_cand_cnt.reserve((size_t)(2 * nq + 1) * sizeof(int32_t)));
+        int32_t* cand_cnt = ws->ms_cand_cnt.as<int32_t>();
+        int32_t* overflow = cand_cnt + nq;
+        {
+            // phase 1: the closest list of every query, exact (rank-0 virtual lists come first in the item array)
+            StageTimer t(idx, s, KNHIP_STAGE_SCAN_RANK0);
+            const int64_t bound0 = round_up(nq / qg + std::min<int64_t>(nlist, nq) + 1, 8);
+            if (int rc = exact_scan(nullptr, wt.list_item_off + nlist, nullptr, bound0)) return rc;
+            HIP_TRY(hipMemsetAsync(cand_cnt, 0, (size_t)(2 * nq + 1) * sizeof(int32_t), s));
+            HIP_TRY(launch_ms_units(wt.list_count, wt.list_pair_off, nlist, qt, ws->ms_unit_off.as<int64_t>(),
+                                    ws->ms_nunits.as<int64_t>(), ws->ms_units.as<KnItem>(),
+                                    idx->d_list_len.as<int64_t>(), idx->code_size,
+                                    idx->scan_bytes_dev.as<double>() + 2, s));
+            if (kind == KNHIP_IVF_FLAT) {
+                HIP_TRY(ws->qnorm.reserve((size_t)nq * sizeof(float)));
+                HIP_TRY(launch_row_norms(d_q, nq, d, ws->qnorm.as<float>(), s));
+            }
+        }
+        idx->rank0_phase_used = true;
+        MScanArgs m{};
+        m.rows = idx->rows.p;
+        m.xnorm = idx->xnorm.as<float>();
+        m.xnorm_max = idx->xnorm_max;
+        m.list_blk_off = idx->d_list_blk_off.as<int64_t>();
+        m.list_len = idx->d_list_len.as<int64_t>();
+        m.list_row_off = idx->d_list_row_off.as<int64_t>();
+        m.ids = idx->ids.as<int64_t>();
+        m.trained = idx->sq_trained.as<float>();
+        m.centroids = idx->centroids.as<float>();
+        m.d = d;
+        m.nchunk = ms_nchunk;
+        m.nstep = ms_nstep;
+        m.queries = d_q;
+        m.qnorm = ws->qnorm.as<float>();
+        m.coarse_dis = cdis_p;
+        m.nq = nq;
+        m.nslot = nprobe;
+        m.units = ws->ms_units.as<KnItem>();
+        m.pairs = wt.pairs;
+        m.nunits_dev = ws->ms_nunits.as<int64_t>();
+        m.gthr = ws->gthr.as<float>();
+        // |approx - exact| <= eps_scale * magnitude: see mfma_scan.hip
+        m.eps_scale = (kind == KNHIP_IVF_FLAT ? 16.0f : 32.0f) * (float)d * 5.9604645e-8f;
+        m.bitset = d_bitset;
+        m.bitset_nbits = nbits;
+        m.cand_cnt = cand_cnt;
+        m.cand = ws->ms_cand.as<int64_t>();
+        m.cap = ms_cap;
+        m.overflow = overflow;
+        {
+            // phase 2: every other probe on the matrix cores
+            StageTimer t(idx, s, KNHIP_STAGE_SCAN);
+            if (kind == KNHIP_IVF_FLAT) {
+                HIP_TRY(launch_mscan_flat(m, is_l2, units_bound, s));
+            } else {
+                HIP_TRY(launch_mscan_sq8(m, is_l2, units_bound, s));
+            }
+        }
+        {
+            // phase 3: exact distances of the candidates + slot 0 -> final top-k; phase 4: overflowed queries (normally
+            // none: the kernels below return at once) through the exact kernels and the ordinary merge
+            StageTimer t(idx, s, KNHIP_STAGE_MERGE);
+            HIP_TRY(launch_mscan_finish(m, kind, is_l2, keys_p, cdis_p, nprobe, ws->partial_d.as<float>(),
+                                        ws->partial_i.as<int64_t>(), k, d_out_d, d_out_i,
+                                        idx->coarse_fail_dev.as<unsigned long long>() + 1, s));
+            if (int rc = exact_scan(wt.list_item_off + nlist, wt.nitems, overflow, items_bound)) return rc;
+            HIP_TRY(launch_merge_partials(ws->partial_d.as<float>(), ws->partial_i.as<int64_t>(), nq, nprobe, k,
+                                          (int64_t)nprobe * k, k, is_l2, d_out_d, d_out_i, s, overflow));
+        }
+        return KNHIP_OK;
+    };
+
     if (kind == KNHIP_IVF_FLAT) {
         FlatScanArgs a{};
         a.rows = idx->rows.as<float4>();
@@ -640,6 +784,16 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         a.gthr = ws->gthr.as<float>();
         a.nslot = nprobe;
         a.k = k;
+        if (use_ms) {
+            return run_mscan([&](const int64_t* lo, const int64_t* hi, const int32_t* q_only, int64_t grid) -> int {
+                FlatScanArgs b = a;
+                b.item_lo_dev = lo;
+                b.nitems_dev = hi;
+                b.q_only = q_only;
+                HIP_TRY(launch_flat_scan(b, is_l2, false, grid, s));
+                return KNHIP_OK;
+            });
+        }
         StageTimer t(idx, s, KNHIP_STAGE_SCAN);
         HIP_TRY(launch_flat_scan(a, is_l2, false, items_bound, s));
     } else if (kind == KNHIP_IVF_PQ) {
@@ -756,6 +910,17 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         a.gthr = ws->gthr.as<float>();
         a.nslot = nprobe;
         a.k = k;
+        a.nq = nq;
+        if (use_ms) {
+            return run_mscan([&](const int64_t* lo, const int64_t* hi, const int32_t* q_only, int64_t grid) -> int {
+                SqScanArgs b = a;
+                b.item_lo_dev = lo;
+                b.nitems_dev = hi;
+                b.q_only = q_only;
+                HIP_TRY(launch_sq_scan(b, is_l2, grid, s));
+                return KNHIP_OK;
+            });
+        }
         StageTimer t(idx, s, KNHIP_STAGE_SCAN);
         HIP_TRY(launch_sq_scan(a, is_l2, items_bound, s));
     }
@@ -901,10 +1066,10 @@ int knhip_index_create(const knhip_desc* desc, knhip_index** out) {
             idx->code_size = desc->dim;
     }
     DeviceGuard g(desc->device);
-    HIP_TRY(idx->scan_bytes_dev.alloc(2 * sizeof(double)));
-    HIP_TRY(hipMemset(idx->scan_bytes_dev.p, 0, 2 * sizeof(double)));
-    HIP_TRY(idx->coarse_fail_dev.alloc(sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(idx->coarse_fail_dev.p, 0, sizeof(unsigned long long)));
+    HIP_TRY(idx->scan_bytes_dev.alloc(3 * sizeof(double)));
+    HIP_TRY(hipMemset(idx->scan_bytes_dev.p, 0, 3 * sizeof(double)));
+    HIP_TRY(idx->coarse_fail_dev.alloc(4 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(idx->coarse_fail_dev.p, 0, 4 * sizeof(unsigned long long)));
     *out = idx.release();
     return KNHIP_OK;
 }
@@ -977,6 +1142,7 @@ int knhip_index_set_sq(knhip_index* idx, const float* vmin, const float* vdiff) 
     std::memcpy(t.data() + idx->d, vdiff, sizeof(float) * idx->d);
     if (int rc = upload(idx->sq_trained, t.data(), t.size() * sizeof(float))) return rc;
     idx->has_sq = true;
+    idx->xnorm_ready = false;
     return KNHIP_OK;
 }
 
@@ -2399,8 +2565,8 @@ int knhip_profile_reset(knhip_index* idx) {
     std::memset(&idx->times, 0, sizeof(idx->times));
     idx->coarse_flops = 0;
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemset(idx->scan_bytes_dev.p, 0, 2 * sizeof(double)));
-    HIP_TRY(hipMemset(idx->coarse_fail_dev.p, 0, sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(idx->scan_bytes_dev.p, 0, 3 * sizeof(double)));
+    HIP_TRY(hipMemset(idx->coarse_fail_dev.p, 0, 4 * sizeof(unsigned long long)));
     return KNHIP_OK;
 }
 
@@ -2412,16 +2578,20 @@ int knhip_profile_get(const knhip_index* idx, knhip_stage_times* out) {
     DeviceGuard g(idx->desc.device);
     HIP_TRY(hipDeviceSynchronize());
     drain_pending(idx);
-    double sb[2] = {0, 0};
-    HIP_TRY(hipMemcpy(sb, idx->scan_bytes_dev.p, 2 * sizeof(double), hipMemcpyDeviceToHost));
+    double sb[3] = {0, 0, 0};
+    HIP_TRY(hipMemcpy(sb, idx->scan_bytes_dev.p, 3 * sizeof(double), hipMemcpyDeviceToHost));
     *out = idx->times;
     out->scan_bytes = sb[0];
     out->scan_bytes_rank0 = idx->rank0_phase_used ? sb[1] : 0.0;
     out->coarse_flops = idx->coarse_flops;
     out->scan_items = idx->last_items_bound;
-    unsigned long long nf = 0;
-    HIP_TRY(hipMemcpy(&nf, idx->coarse_fail_dev.p, sizeof(nf), hipMemcpyDeviceToHost));
-    out->coarse_fallback_queries = (int64_t)nf;
+    unsigned long long nf[4] = {0, 0, 0, 0}; // coarse certificate failures; mscan: finished / overflowed queries, candidates
+    HIP_TRY(hipMemcpy(nf, idx->coarse_fail_dev.p, sizeof(nf), hipMemcpyDeviceToHost));
+    out->coarse_fallback_queries = (int64_t)nf[0];
+    out->mscan_queries = (int64_t)nf[1];
+    out->mscan_overflow_queries = (int64_t)nf[2];
+    out->mscan_candidates = (int64_t)nf[3];
+    out->mscan_stream_bytes = sb[2];
     return KNHIP_OK;
 }
 

@@ -1,0 +1,907 @@
+// knowhere_amd/csrc/mfma_scan.hip -- IVF-Flat / IVF-SQ8 list scan as an MFMA PREFILTER + exact finish (gfx950).
+//
+// The exact row scans (flat_scan.hip, sq_scan.hip) reproduce the reference's scalar arithmetic for EVERY
+// (row, query, dim) triple: 2-3 separately rounded VALU operations each, so they are VALU-bound by construction
+// (BASELINE config C2: 36 ms per 10k-query batch at 0.19 of the fp32 vector peak; C5: 3.2 s).  But a (rows of one
+// list) x (queries that probe it) x d block is a dense contraction, and only the k best rows of a query need the
+// reference's exact arithmetic.  So, exactly as the coarse quantizer does (coarse_gemm.hip):
+//
+//   1. rank-0 phase   the closest list of every query is scanned by the exact kernel (flat_scan / sq_scan,
+//                     work items of the rank-0 virtual lists): partial slot 0 and tau_q = the exact k-th distance
+//                     in that list -- an upper bound of the query's final k-th distance.
+//   2. mscan_*_kernel every other (query, list) pair: approximate distances on the matrix cores
+//                     (v_mfma_f32_32x32x2_f32 for fp32 rows; v_mfma_f32_32x32x16_f16 for SQ8 codes), one
+//                     compare per (row, query) against tau_q widened by a rigorous error bound eps; rows that
+//                     pass are appended to the query's candidate list.  Every row whose EXACT distance is <=
+//                     tau_q passes (|approx - exact| <= eps), in particular every row of the final top-k.
+//   3. mscan_finish   per query: exact reference-order distances of its candidates (the same l2_step / ip_step /
+//                     SQ8 decode sequence as the exact kernels), merged with partial slot 0, canonical sort,
+//                     top-k.  Bit-equal to the exact scan: candidates are a superset of the true top-k and their
+//                     distances are the reference's.
+//   4. overflow       a query whose candidate list overflows (tau_q unknown: closest list shorter than k / heavily
+//                     filtered, or a very loose bound) is flagged and redone by the exact kernels, restricted on the
+//                     device to the flagged queries.  Exactness never depends on the capacity being "big enough".
+//
+// Reference semantics replaced: IVFFlatScanner::scan_codes (thirdparty/faiss/faiss/cppcontrib/knowhere/
+// IndexIVFFlat.cpp:193-236), BaselineIVFSQScannerIP/L2::scan_codes (.../IndexScalarQuantizer.cpp:196-400), the
+// per-query heap (impl/ResultHandler.h:258-279).
+//
+// Layout notes.  fp32 rows: the interleaved blocks of flat_scan.hip (float4 blk[chunk][64 rows]).  A wave takes a
+// block of 64 rows = two 32-row MFMA tiles; for the K-slab of 8 dims made of chunks (2s, 2s+1) lane l loads
+// chunk 2s + (l >> 5) of row (l & 31): each half-wave reads 512 contiguous bytes.  The four components of that
+// float4 feed four v_mfma_f32_32x32x2_f32 (k = 0 <-> lanes 0-31, k = 1 <-> lanes 32-63; any assignment of dims to
+// k is fine as long as the query operand uses the same one).  Queries (B operand, lane l = query l & 31) sit in LDS
+// as [query][d] rows padded to an odd number of 16-byte quads, so the ds_read_b128 of a slab is conflict-free.
+// D layout: lane l holds query l & 31 and the 16 rows (r & 3) + 8 (r >> 2) + 4 (l >> 5): one threshold per lane.
+// L2: the accumulator starts at -||x||^2 / 2 (one extra MFMA with A = ||x||^2, B = -0.5), so that
+//   ||q||^2 + ||x||^2 - 2 q.x <= tau + eps   <=>   acc >= (||q||^2 - tau - eps) / 2  =: t_q,
+// and IP is acc >= tau - eps: the epilogue is one compare per element in both metrics.
+#include "common.h"
+#include "kernels.h"
+
+namespace knhip {
+
+typedef float ms_f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 ms_f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int MS_WAVES = 4;
+constexpr int MS_THREADS = MS_WAVES * KN_WAVE;
+constexpr int MS_NQT = 2;          // query tiles of 32 per unit (fp32 rows)
+constexpr int MS_QT = 32 * MS_NQT; // queries per unit
+
+// ---- ||x||^2 per stored row position (padded block layout), and the maximum ----------------------------------
+__global__ void ms_block_norms_kernel(const float4* __restrict__ rows, int64_t total_blk, int nchunk,
+                                      float* __restrict__ out, float* __restrict__ out_max) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float acc = 0.f;
+    if (t < total_blk * 64) {
+        const int64_t b = t >> 6;
+        const int r = (int)(t & 63);
+        const float4* p = rows + b * (int64_t)nchunk * 64 + r;
+        for (int c = 0; c < nchunk; c++) {
+            const float4 v = p[(int64_t)c * 64];
+            acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+        out[t] = acc;
+    }
+    // norms are >= 0: their bit patterns order like ints
+    float m = acc;
+    for (int off = 32; off > 0; off >>= 1) {
+        m = fmaxf(m, __shfl_xor(m, off, KN_WAVE));
+    }
+    if (lane_id() == 0 && m > 0.f) {
+        atomicMax(reinterpret_cast<int*>(out_max), __float_as_int(m));
+    }
+}
+
+hipError_t launch_ms_block_norms(const float4* rows, int64_t total_blk, int nchunk, float* out, float* out_max,
+                                 hipStream_t s) {
+    hipError_t e = hipMemsetAsync(out_max, 0, sizeof(float), s);
+    if (e != hipSuccess || total_blk <= 0) {
+        return e;
+    }
+    hipLaunchKernelGGL(ms_block_norms_kernel, dim3((unsigned)((total_blk * 64 + 255) / 256)), dim3(256), 0, s, rows,
+                       total_blk, nchunk, out, out_max);
+    return hipGetLastError();
+}
+
+// ---- units: (bulk virtual list, group of up to qt of its pairs) -----------------------------------------------
+// single workgroup: exclusive scan of ceil(count / qt) over the bulk virtual lists [nlist, 2 nlist)
+constexpr int MS_SCAN_THREADS = 1024;
+__global__ __launch_bounds__(MS_SCAN_THREADS) void ms_unit_scan_kernel(const int32_t* __restrict__ list_count,
+                                                                       int64_t nlist, int qt,
+                                                                       int64_t* __restrict__ unit_off,
+                                                                       int64_t* __restrict__ nunits) {
+    __shared__ int64_t s_n[MS_SCAN_THREADS];
+    const int tid = threadIdx.x;
+    const int64_t per = (nlist + MS_SCAN_THREADS - 1) / MS_SCAN_THREADS;
+    const int64_t l0 = (int64_t)tid * per, l1 = min(l0 + per, nlist);
+    int64_t n = 0;
+    for (int64_t l = l0; l < l1; l++) {
+        n += (list_count[nlist + l] + qt - 1) / qt;
+    }
+    s_n[tid] = n;
+    __syncthreads();
+    for (int off = 1; off < MS_SCAN_THREADS; off <<= 1) {
+        int64_t a = 0;
+        if (tid >= off) {
+            a = s_n[tid - off];
+        }
+        __syncthreads();
+        s_n[tid] += a;
+        __syncthreads();
+    }
+    int64_t u = s_n[tid] - n;
+    for (int64_t l = l0; l < l1; l++) {
+        unit_off[l] = u;
+        u += (list_count[nlist + l] + qt - 1) / qt;
+    }
+    if (tid == MS_SCAN_THREADS - 1) {
+        unit_off[nlist] = s_n[tid];
+        *nunits = s_n[tid];
+    }
+}
+
+__global__ void ms_units_kernel(const int32_t* __restrict__ list_count, const int64_t* __restrict__ list_pair_off,
+                                const int64_t* __restrict__ unit_off, int64_t nlist, int qt, KnItem* __restrict__ units,
+                                const int64_t* __restrict__ list_len, int64_t code_size, double* unit_bytes) {
+    const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= nlist) {
+        return;
+    }
+    const int64_t c = list_count[nlist + l];
+    if (c > 0 && unit_bytes != nullptr) {
+        // bytes the prefilter streams: every unit reads its list once for up to qt queries
+        atomicAdd(unit_bytes, (double)((c + qt - 1) / qt) * (double)list_len[l] * (double)code_size);
+    }
+    const int64_t p0 = list_pair_off[nlist + l];
+    int64_t u = unit_off[l];
+    for (int64_t i = 0; i < c; i += qt, u++) {
+        KnItem x;
+        x.list = (int32_t)l;
+        x.npair = (int32_t)min((int64_t)qt, c - i);
+        x.pair0 = p0 + i;
+        units[u] = x;
+    }
+}
+
+hipError_t launch_ms_units(const int32_t* list_count, const int64_t* list_pair_off, int64_t nlist, int qt,
+                           int64_t* unit_off, int64_t* nunits, KnItem* units, const int64_t* list_len,
+                           int64_t code_size, double* unit_bytes, hipStream_t s) {
+    hipLaunchKernelGGL(ms_unit_scan_kernel, dim3(1), dim3(MS_SCAN_THREADS), 0, s, list_count, nlist, qt, unit_off,
+                       nunits);
+    hipLaunchKernelGGL(ms_units_kernel, dim3((unsigned)((nlist + 255) / 256)), dim3(256), 0, s, list_count,
+                       list_pair_off, unit_off, nlist, qt, units, list_len, code_size, unit_bytes);
+    return hipGetLastError();
+}
+
+// ---- candidate append (slow path of the epilogue) ---------------------------------------------------------------
+__device__ __forceinline__ void ms_emit(const MScanArgs& a, int32_t q, int32_t slot, int64_t row_off, int64_t pos) {
+    if (a.bitset != nullptr && bitset_filtered(a.bitset, a.bitset_nbits, a.ids[row_off + pos])) {
+        return;
+    }
+    const int n = atomicAdd(a.cand_cnt + q, 1);
+    if (n < a.cap) {
+        a.cand[(int64_t)q * a.cap + n] = ((int64_t)slot << 32) | (int64_t)(uint32_t)pos;
+    } else {
+        a.overflow[q] = 1;
+        a.overflow[a.nq] = 1; // "some query overflowed": the fallback kernels exit at once while this stays 0
+    }
+}
+
+// per-pair set-up shared by the kernels: query index, slot and the acceptance threshold on the accumulator
+template <bool IS_L2>
+__device__ __forceinline__ float ms_threshold_flat(const MScanArgs& a, int32_t q) {
+    const float tau = a.gthr[q];
+    if (tau == worst_dist<IS_L2>()) {
+        // no bound yet (closest list shorter than k or filtered away): every row would pass -> exact fallback
+        a.overflow[q] = 1;
+        a.overflow[a.nq] = 1;
+        return INFINITY;
+    }
+    const float qn = a.qnorm[q];
+    if (IS_L2) {
+        const float eps = a.eps_scale * (qn + a.xnorm_max) + 1e-30f;
+        return (qn - tau - eps) * 0.5f;
+    }
+    const float eps = a.eps_scale * sqrtf(qn * a.xnorm_max) + 1e-30f;
+    return tau - eps;
+}
+
+// ---- fp32 rows --------------------------------------------------------------------------------------------------
+template <bool IS_L2>
+__global__ __launch_bounds__(MS_THREADS, 4) void mscan_flat_kernel(MScanArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = lane_id();
+    const int wave = threadIdx.x / KN_WAVE;
+    const int64_t nunits = *a.nunits_dev;
+    if ((int64_t)blockIdx.x >= ((nunits + 7) / 8) * 8) {
+        return;
+    }
+    const int64_t u = xcd_item(blockIdx.x, nunits);
+    if (u >= nunits) {
+        return;
+    }
+    const KnItem it = a.units[u];
+    const int npair = it.npair;
+    const int64_t list = it.list;
+    const int64_t len = a.list_len[list];
+    const int64_t blk0 = a.list_blk_off[list];
+    const int64_t row_off = a.list_row_off[list];
+    const int nchunk = a.nchunk;
+    const int nstep = a.nstep;      // steps of 16 dims (4 chunks)
+    const int ldq = nstep * 16 + 4; // floats per query row in LDS: an odd number of 16-byte quads
+
+    float* sQ = reinterpret_cast<float*>(smem);            // [MS_QT][ldq]
+    float* sT = sQ + MS_QT * ldq;                          // [MS_QT] accumulator thresholds
+    int32_t* sPq = reinterpret_cast<int32_t*>(sT + MS_QT); // [MS_QT] query of the pair
+    int32_t* sPs = sPq + MS_QT;                            // [MS_QT] slot of the pair
+    if (threadIdx.x < MS_QT) {
+        const int j = threadIdx.x;
+        float t = INFINITY;
+        int32_t q = 0, slot = 0;
+        if (j < npair) {
+            const KnPair p = a.pairs[it.pair0 + j];
+            q = p.q;
+            slot = p.slot;
+            t = ms_threshold_flat<IS_L2>(a, q);
+        }
+        sT[j] = t;
+        sPq[j] = q;
+        sPs[j] = slot;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < MS_QT * nstep * 4; t += MS_THREADS) {
+        const int j = t / (nstep * 4), c = t % (nstep * 4);
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (j < npair) {
+            const float* src = a.queries + (int64_t)sPq[j] * a.d + c * 4;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                if (c * 4 + e < a.d) {
+                    v[e] = src[e];
+                }
+            }
+        }
+        *reinterpret_cast<float4*>(sQ + j * ldq + c * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    __syncthreads();
+
+    const int hi = lane >> 5, lr = lane & 31;
+    const int64_t nblk = (len + 63) >> 6;
+    const float4* rows = reinterpret_cast<const float4*>(a.rows) + blk0 * (int64_t)nchunk * 64;
+    // A operand of one step (16 dims): [row tile][8-dim slab]: chunk 4 s + 2 slab + hi of row tile * 32 + lr
+    auto load_step = [&](int64_t b, int s, float4 (&A)[2][2]) {
+#pragma unroll
+        for (int sl = 0; sl < 2; sl++) {
+            const int c = 4 * s + 2 * sl + hi;
+            if (b < nblk && c < nchunk) {
+                const float4* p = rows + (b * nchunk + c) * 64 + lr;
+                A[0][sl] = p[0];
+                A[1][sl] = p[32];
+            } else {
+                A[0][sl] = make_float4(0.f, 0.f, 0.f, 0.f);
+                A[1][sl] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    float4 Acur[2][2], Anxt[2][2];
+    int64_t nb = wave; // position of the next load
+    int ns = 0;
+    load_step(nb, ns, Acur);
+    if (++ns == nstep) {
+        ns = 0;
+        nb += MS_WAVES;
+    }
+    for (int64_t b = wave; b < nblk; b += MS_WAVES) {
+        ms_f32x16 acc[2][MS_NQT];
+        {
+            // L2: acc = -||x||^2 / 2 for the tile's rows (k = 0 carries the norm, k = 1 nothing)
+            float xn0 = 0.f, xn1 = 0.f;
+            if (IS_L2 && hi == 0) {
+                xn0 = a.xnorm[(blk0 + b) * 64 + lr];
+                xn1 = a.xnorm[(blk0 + b) * 64 + 32 + lr];
+            }
+            const float mh = (IS_L2 && hi == 0) ? -0.5f : 0.f;
+            ms_f32x16 z;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                z[r] = 0.f;
+            }
+            ms_f32x16 i0 = z, i1 = z;
+            if (IS_L2) {
+                i0 = __builtin_amdgcn_mfma_f32_32x32x2f32(xn0, mh, z, 0, 0, 0);
+                i1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xn1, mh, z, 0, 0, 0);
+            }
+#pragma unroll
+            for (int qt = 0; qt < MS_NQT; qt++) {
+                acc[0][qt] = i0;
+                acc[1][qt] = i1;
+            }
+        }
+        for (int s = 0; s < nstep; s++) {
+            load_step(nb, ns, Anxt); // one step ahead (crosses into this wave's next block)
+            if (++ns == nstep) {
+                ns = 0;
+                nb += MS_WAVES;
+            }
+#pragma unroll
+            for (int sl = 0; sl < 2; sl++) {
+                float4 B[MS_NQT];
+#pragma unroll
+                for (int qt = 0; qt < MS_NQT; qt++) {
+                    B[qt] = *reinterpret_cast<const float4*>(sQ + (qt * 32 + lr) * ldq + (2 * s + sl) * 8 + 4 * hi);
+                }
+#pragma unroll
+                for (int qt = 0; qt < MS_NQT; qt++) {
+#pragma unroll
+                    for (int t = 0; t < 2; t++) {
+                        acc[t][qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Acur[t][sl].x, B[qt].x, acc[t][qt], 0, 0, 0);
+                        acc[t][qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Acur[t][sl].y, B[qt].y, acc[t][qt], 0, 0, 0);
+                        acc[t][qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Acur[t][sl].z, B[qt].z, acc[t][qt], 0, 0, 0);
+                        acc[t][qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Acur[t][sl].w, B[qt].w, acc[t][qt], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+#pragma unroll
+                for (int sl = 0; sl < 2; sl++) {
+                    Acur[t][sl] = Anxt[t][sl];
+                }
+            }
+        }
+        // ---- epilogue: one compare per (row, query); the slow path only where something passes -------------------
+#pragma unroll
+        for (int qt = 0; qt < MS_NQT; qt++) {
+            const float thr = sT[qt * 32 + lr];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                float m = acc[t][qt][0];
+#pragma unroll
+                for (int r = 1; r < 16; r++) {
+                    m = fmaxf(m, acc[t][qt][r]);
+                }
+                if (__ballot(m >= thr) != 0ull) {
+                    if (m >= thr) {
+                        const int32_t q = sPq[qt * 32 + lr], slot = sPs[qt * 32 + lr];
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const int64_t pos = b * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                            if (acc[t][qt][r] >= thr && pos < len) {
+                                ms_emit(a, q, slot, row_off, pos);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- SQ8 codes -------------------------------------------------------------------------------------------------
+// Decoded component (reference codecs.h:37-41, quantizers.h:139-145): x_i = vmin_i + vdiff_i (c_i + 0.5) / 255, so with
+// y = q (IP) or q - centroid (L2, by_residual) and y'_i = y_i vdiff_i / 255:
+//     <y, x> = A + sum_i y'_i c_i,        A = sum_i y_i (vmin_i + 0.5 vdiff_i / 255).
+// The code bytes go to the matrix cores as f16 WITHOUT a convert: the bit pattern 0x6400 | c is the half 1024 + c
+// exactly (one v_perm_b32 per two codes), y' is scaled by a power of two so that max |y'| lands in [2^9, 2^10) and is
+// split into two halves hi + lo (22 significant bits), and v_mfma_f32_32x32x16_f16 accumulates
+//     S = sum_i (hi_i + lo_i) (1024 + c_i)            (fp32 accumulate)
+// so that  sum_i y'_i c_i = (S - 1024 sum_i (hi_i + lo_i)) / scale  up to the error bound eps below.
+// One unit = (list, up to 32 pairs); a wave takes 64 rows = two 32-row tiles; step = 32 dims: lane l loads the 16 codes
+// of chunk 2 s + (l >> 5) of row (l & 31) (one coalesced 16-byte load) = the A operands of two MFMAs.
+// Acceptance on the accumulator (one compare per element):
+//   IP: dis0 + A + (S - off) / sc >= tau - eps                  <=>  S >= sc (tau - eps - dis0 - A) + off
+//   L2: ||y||^2 + ||x||^2 - 2 (A + (S - off) / sc) <= tau + eps <=>  S - sc ||x||^2 / 2 >= sc (||y||^2 - 2 A - tau - eps) / 2 + off
+// (the -sc ||x||^2 / 2 term is the accumulator's start value: one fp32 MFMA with A = ||x||^2, B = -sc / 2).
+// eps = eps_scale * sum_i |y_i| (|vmin_i| + 6 |vdiff_i|), eps_scale = 32 d 2^-24: the fp32 roundings of the exact
+// sequence, of A, off and y', the 2^-22 relative split error, and the fp32 accumulation of terms of magnitude
+// |y'_i| (1024 + 255) are each below d 2^-24 times that sum.
+constexpr int MQ_WAVES = 8;
+constexpr int MQ_THREADS = MQ_WAVES * KN_WAVE;
+constexpr int MQ_QT = 32;
+
+__global__ void ms_sq8_norms_kernel(const uint4* __restrict__ rows, int64_t total_blk, int nchunk16, int d,
+                                    const float* __restrict__ trained, float* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total_blk * 64) {
+        return;
+    }
+    const int64_t b = t >> 6;
+    const int r = (int)(t & 63);
+    const uint4* p = rows + b * (int64_t)nchunk16 * 64 + r;
+    float acc = 0.f;
+    for (int c = 0; c < nchunk16; c++) {
+        const uint4 w = p[(int64_t)c * 64];
+        const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int i = c * 16 + e;
+            if (i < d) {
+                const float code = (float)((ww[e >> 2] >> (8 * (e & 3))) & 0xffu);
+                const float x = trained[i] + trained[d + i] * ((code + 0.5f) / 255.0f);
+                acc += x * x;
+            }
+        }
+    }
+    out[t] = acc;
+}
+
+hipError_t launch_ms_sq8_norms(const uint4* rows, int64_t total_blk, int nchunk16, int d, const float* trained,
+                               float* out, hipStream_t s) {
+    if (total_blk <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(ms_sq8_norms_kernel, dim3((unsigned)((total_blk * 64 + 255) / 256)), dim3(256), 0, s, rows,
+                       total_blk, nchunk16, d, trained, out);
+    return hipGetLastError();
+}
+
+__device__ __forceinline__ float ms_wave_sum(float v) {
+    for (int off = 32; off > 0; off >>= 1) {
+        v += __shfl_xor(v, off, KN_WAVE);
+    }
+    return v;
+}
+
+// 16 code bytes -> two f16x8 operands (1024 + code)
+__device__ __forceinline__ void ms_codes_to_f16(const uint4 w, ms_f16x8& lo8, ms_f16x8& hi8) {
+    const uint32_t k64 = 0x64646464u;
+    union {
+        uint32_t u[4];
+        ms_f16x8 v;
+    } a, b;
+    a.u[0] = __builtin_amdgcn_perm(k64, w.x, 0x04010400u);
+    a.u[1] = __builtin_amdgcn_perm(k64, w.x, 0x04030402u);
+    a.u[2] = __builtin_amdgcn_perm(k64, w.y, 0x04010400u);
+    a.u[3] = __builtin_amdgcn_perm(k64, w.y, 0x04030402u);
+    b.u[0] = __builtin_amdgcn_perm(k64, w.z, 0x04010400u);
+    b.u[1] = __builtin_amdgcn_perm(k64, w.z, 0x04030402u);
+    b.u[2] = __builtin_amdgcn_perm(k64, w.w, 0x04010400u);
+    b.u[3] = __builtin_amdgcn_perm(k64, w.w, 0x04030402u);
+    lo8 = a.v;
+    hi8 = b.v;
+}
+
+template <bool IS_L2>
+__global__ __launch_bounds__(MQ_THREADS, 4) void mscan_sq8_kernel(MScanArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = lane_id();
+    const int wave = threadIdx.x / KN_WAVE;
+    const int64_t nunits = *a.nunits_dev;
+    if ((int64_t)blockIdx.x >= ((nunits + 7) / 8) * 8) {
+        return;
+    }
+    const int64_t u = xcd_item(blockIdx.x, nunits);
+    if (u >= nunits) {
+        return;
+    }
+    const KnItem it = a.units[u];
+    const int npair = it.npair;
+    const int64_t list = it.list;
+    const int64_t len = a.list_len[list];
+    const int64_t blk0 = a.list_blk_off[list];
+    const int64_t row_off = a.list_row_off[list];
+    const int d = a.d;
+    const int nchunk = a.nchunk; // 16-code chunks
+    const int nstep = a.nstep;   // steps of 32 dims
+    const int ldh = nstep * 32 + 8; // halves per query row: an odd number of 16-byte quads
+
+    _Float16* sH = reinterpret_cast<_Float16*>(smem);      // [32][ldh]
+    _Float16* sL = sH + MQ_QT * ldh;                       // [32][ldh]
+    float* sT = reinterpret_cast<float*>(sL + MQ_QT * ldh); // [32] accumulator thresholds
+    float* sSc = sT + MQ_QT;                               // [32] -scale / 2 (L2 start value)
+    int32_t* sPq = reinterpret_cast<int32_t*>(sSc + MQ_QT);
+    int32_t* sPs = sPq + MQ_QT;
+    const float* vmin = a.trained;
+    const float* vdiff = a.trained + d;
+    const float* cen = a.centroids + list * d;
+    // ---- per pair: y' scaled + split into LDS, acceptance threshold -------------------------------------------------
+    for (int j = wave; j < MQ_QT; j += MQ_WAVES) {
+        float thr = INFINITY, nsc = 0.f;
+        int32_t q = 0, slot = 0;
+        if (j < npair) {
+            const KnPair p = a.pairs[it.pair0 + j];
+            q = p.q;
+            slot = p.slot;
+            const float* qv = a.queries + (int64_t)q * d;
+            float mx = 0.f;
+            for (int i = lane; i < d; i += KN_WAVE) {
+                const float y = IS_L2 ? (qv[i] - cen[i]) : qv[i];
+                mx = fmaxf(mx, fabsf(y * vdiff[i] * (1.0f / 255.0f)));
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                mx = fmaxf(mx, __shfl_xor(mx, off, KN_WAVE));
+            }
+            int ex = 0;
+            if (mx > 0.f && mx < INFINITY) {
+                ex = 9 - ilogbf(mx);
+                ex = max(-60, min(60, ex));
+            }
+            const float sc = ldexpf(1.0f, ex);
+            float sA = 0.f, sW = 0.f, sHL = 0.f, sR = 0.f;
+            for (int i = lane; i < nstep * 32; i += KN_WAVE) {
+                _Float16 h = (_Float16)0.f, l = (_Float16)0.f;
+                if (i < d) {
+                    const float y = IS_L2 ? (qv[i] - cen[i]) : qv[i];
+                    const float yp = y * vdiff[i] * (1.0f / 255.0f) * sc;
+                    h = (_Float16)yp;
+                    l = (_Float16)(yp - (float)h);
+                    sA += y * (vmin[i] + 0.5f * vdiff[i] * (1.0f / 255.0f));
+                    sW += fabsf(y) * (fabsf(vmin[i]) + 6.0f * fabsf(vdiff[i]));
+                    sHL += (float)h + (float)l;
+                    sR += y * y;
+                }
+                sH[j * ldh + i] = h;
+                sL[j * ldh + i] = l;
+            }
+            sA = ms_wave_sum(sA);
+            sW = ms_wave_sum(sW);
+            sHL = ms_wave_sum(sHL);
+            sR = ms_wave_sum(sR);
+            const float tau = a.gthr[q];
+            if (tau == worst_dist<IS_L2>() || !(mx < INFINITY)) {
+                if (lane == 0) {
+                    a.overflow[q] = 1;
+                    a.overflow[a.nq] = 1;
+                }
+            } else {
+                const float eps = a.eps_scale * sW + 1e-30f;
+                const float off = 1024.0f * sHL;
+                if (IS_L2) {
+                    thr = sc * ((sR - 2.0f * sA - tau - eps) * 0.5f) + off;
+                } else {
+                    const float dis0 = a.coarse_dis[(int64_t)q * a.nslot + slot];
+                    thr = sc * (tau - eps - dis0 - sA) + off;
+                }
+                // the threshold itself is rounded: widen it by a few ulp of the magnitudes it was formed from
+                thr -= 8.0f * 5.9604645e-8f * (fabsf(off) + fabsf(thr));
+                nsc = -0.5f * sc;
+            }
+        } else {
+            for (int i = lane; i < nstep * 32; i += KN_WAVE) {
+                sH[j * ldh + i] = (_Float16)0.f;
+                sL[j * ldh + i] = (_Float16)0.f;
+            }
+        }
+        if (lane == 0) {
+            sT[j] = thr;
+            sSc[j] = nsc;
+            sPq[j] = q;
+            sPs[j] = slot;
+        }
+    }
+    __syncthreads();
+
+    const int hi = lane >> 5, lr = lane & 31;
+    const int64_t nblk = (len + 63) >> 6;
+    const uint4* rows = reinterpret_cast<const uint4*>(a.rows) + blk0 * (int64_t)nchunk * 64;
+    auto load_step = [&](int64_t b, int s, uint4 (&A)[2]) {
+        const int c = 2 * s + hi;
+        if (b < nblk && c < nchunk) {
+            const uint4* p = rows + (b * nchunk + c) * 64 + lr;
+            A[0] = p[0];
+            A[1] = p[32];
+        } else {
+            A[0] = make_uint4(0, 0, 0, 0);
+            A[1] = make_uint4(0, 0, 0, 0);
+        }
+    };
+    // code loads run three steps ahead of the MFMAs that consume them (one workgroup per CU at d = 768: the loads
+    // in flight per wave are what covers the HBM latency)
+    uint4 A0[2], A1[2], A2[2], A3[2];
+    int64_t nb = wave;
+    int ns = 0;
+    auto advance = [&]() {
+        if (++ns == nstep) {
+            ns = 0;
+            nb += MQ_WAVES;
+        }
+    };
+    load_step(nb, ns, A0);
+    advance();
+    load_step(nb, ns, A1);
+    advance();
+    load_step(nb, ns, A2);
+    advance();
+    const float thr = sT[lr];
+    for (int64_t b = wave; b < nblk; b += MQ_WAVES) {
+        ms_f32x16 acc[2];
+        {
+            ms_f32x16 z;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                z[r] = 0.f;
+            }
+            acc[0] = z;
+            acc[1] = z;
+            if (IS_L2) {
+                float xn0 = 0.f, xn1 = 0.f, bs = 0.f;
+                if (hi == 0) {
+                    xn0 = a.xnorm[(blk0 + b) * 64 + lr];
+                    xn1 = a.xnorm[(blk0 + b) * 64 + 32 + lr];
+                    bs = sSc[lr];
+                }
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xn0, bs, z, 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xn1, bs, z, 0, 0, 0);
+            }
+        }
+        for (int s = 0; s < nstep; s++) {
+            load_step(nb, ns, A3);
+            advance();
+            ms_f16x8 Bh[2], Bl[2];
+#pragma unroll
+            for (int e8 = 0; e8 < 2; e8++) {
+                Bh[e8] = *reinterpret_cast<const ms_f16x8*>(sH + lr * ldh + 32 * s + 16 * hi + 8 * e8);
+                Bl[e8] = *reinterpret_cast<const ms_f16x8*>(sL + lr * ldh + 32 * s + 16 * hi + 8 * e8);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                ms_f16x8 Af[2];
+                ms_codes_to_f16(A0[t], Af[0], Af[1]);
+#pragma unroll
+                for (int e8 = 0; e8 < 2; e8++) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[e8], Bh[e8], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[e8], Bl[e8], acc[t], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                A0[t] = A1[t];
+                A1[t] = A2[t];
+                A2[t] = A3[t];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            float m = acc[t][0];
+#pragma unroll
+            for (int r = 1; r < 16; r++) {
+                m = fmaxf(m, acc[t][r]);
+            }
+            if (__ballot(m >= thr) != 0ull) {
+                if (m >= thr) {
+                    const int32_t q = sPq[lr], slot = sPs[lr];
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int64_t pos = b * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        if (acc[t][r] >= thr && pos < len) {
+                            ms_emit(a, q, slot, row_off, pos);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- exact finish ---------------------------------------------------------------------------------------------
+// One workgroup per query: exact distances of the candidates (thread per candidate, reference operation order),
+// together with the rank-0 partial list, bitonic sort by (distance key, id tie key), first k out.
+constexpr int MF_THREADS = 256;
+
+template <bool IS_L2, int KIND> // KIND 1: fp32 rows, 3: SQ8
+__global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, const int64_t* __restrict__ keys,
+                                                                  const float* __restrict__ coarse_dis, int nprobe,
+                                                                  const float* __restrict__ partial_d,
+                                                                  const int64_t* __restrict__ partial_i, int k,
+                                                                  int P_max, float* __restrict__ out_d,
+                                                                  int64_t* __restrict__ out_i,
+                                                                  unsigned long long* __restrict__ counters) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ int s_first_end;
+    __shared__ float tab[256];
+    const int64_t q = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (a.overflow[q] != 0) {
+        if (tid == 0) {
+            atomicAdd(counters + 1, 1ull);
+        }
+        return; // redone by the exact kernels
+    }
+    const int d = a.d;
+    const int n = min(a.cand_cnt[q], a.cap);
+    if (tid == 0) {
+        atomicAdd(counters, 1ull);
+        atomicAdd(counters + 2, (unsigned long long)n);
+    }
+    int P = 2;
+    while (P < n + k) {
+        P <<= 1;
+    }
+    // LDS: tie[P_max] (u64) | key[P_max] (u32) | query [dq] floats (| vmin, vdiff for SQ8)
+    unsigned long long* tie = reinterpret_cast<unsigned long long*>(smem);
+    uint32_t* key = reinterpret_cast<uint32_t*>(smem + (size_t)P_max * 8);
+    float* sq = reinterpret_cast<float*>(smem + (size_t)P_max * 12);
+    const int dq = KIND == 1 ? a.nchunk * 4 : a.nchunk * 16;
+    float* svmin = sq + dq;
+    float* svdiff = svmin + dq;
+    for (int i = tid; i < dq; i += MF_THREADS) {
+        sq[i] = (i < d) ? a.queries[q * d + i] : 0.f;
+        if (KIND == 3) {
+            svmin[i] = (i < d) ? a.trained[i] : 0.f;
+            svdiff[i] = (i < d) ? a.trained[d + i] : 0.f;
+        }
+    }
+    if (KIND == 3 && tid < 256) {
+        tab[tid] = __fdiv_rn((float)tid + 0.5f, 255.0f); // Codec8bit::decode_component
+    }
+    if (tid == 0) {
+        s_first_end = k;
+    }
+    __syncthreads();
+    // the rank-0 partial list is sentinel-terminated: nothing behind its first id < 0 is defined
+    const float* p0d = partial_d + q * (int64_t)nprobe * k;
+    const int64_t* p0i = partial_i + q * (int64_t)nprobe * k;
+    for (int r = tid; r < k; r += MF_THREADS) {
+        if (p0i[r] < 0) {
+            atomicMin(&s_first_end, r);
+        }
+    }
+    __syncthreads();
+    const int first_end = s_first_end;
+    for (int e = tid; e < P; e += MF_THREADS) {
+        uint32_t kk = 0xffffffffu;
+        unsigned long long tt = ~0ull;
+        if (e < n) {
+            const int64_t c = a.cand[q * (int64_t)a.cap + e];
+            const int slot = (int)(c >> 32);
+            const int64_t pos = (int64_t)(uint32_t)c;
+            const int64_t list = keys[q * nprobe + slot];
+            const int64_t blk = a.list_blk_off[list] + (pos >> 6);
+            const int r = (int)(pos & 63);
+            float acc = 0.f;
+            if (KIND == 1) {
+                const float4* p = reinterpret_cast<const float4*>(a.rows) + blk * (int64_t)a.nchunk * 64 + r;
+                for (int c4 = 0; c4 < a.nchunk; c4++) {
+                    const float4 y = p[(int64_t)c4 * 64];
+                    const float4 x = *reinterpret_cast<const float4*>(sq + c4 * 4);
+                    if (IS_L2) {
+                        acc = l2_step(acc, x.x, y.x);
+                        acc = l2_step(acc, x.y, y.y);
+                        acc = l2_step(acc, x.z, y.z);
+                        acc = l2_step(acc, x.w, y.w);
+                    } else {
+                        acc = ip_step(acc, x.x, y.x);
+                        acc = ip_step(acc, x.y, y.y);
+                        acc = ip_step(acc, x.z, y.z);
+                        acc = ip_step(acc, x.w, y.w);
+                    }
+                }
+            } else {
+                const uint4* p = reinterpret_cast<const uint4*>(a.rows) + blk * (int64_t)a.nchunk * 64 + r;
+                const float* cen = a.centroids + list * d;
+                for (int c16 = 0; c16 < a.nchunk; c16++) {
+                    const uint4 w = p[(int64_t)c16 * 64];
+                    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                    for (int e2 = 0; e2 < 16; e2++) {
+                        const int i = c16 * 16 + e2;
+                        const uint32_t code = (ww[e2 >> 2] >> (8 * (e2 & 3))) & 0xffu;
+                        const float x = fadd_x(svmin[i], fmul_x(tab[code], svdiff[i]));
+                        if (IS_L2) {
+                            // padded dims: y = 0 - 0, x = 0: they add exactly +0
+                            const float y = (i < d) ? fsub_x(sq[i], cen[i]) : 0.f;
+                            acc = l2_step(acc, y, x);
+                        } else {
+                            acc = ip_step(acc, sq[i], x);
+                        }
+                    }
+                }
+                if (!IS_L2) {
+                    acc = fadd_x(coarse_dis[q * nprobe + slot], acc);
+                }
+            }
+            const int64_t id = a.ids[a.list_row_off[list] + pos];
+            kk = dist_key<IS_L2>(acc);
+            tt = IS_L2 ? (unsigned long long)id : ~(unsigned long long)id;
+        } else if (e < n + k) {
+            const int r = e - n;
+            if (r < first_end) {
+                const int64_t id = p0i[r];
+                kk = dist_key<IS_L2>(p0d[r]);
+                tt = IS_L2 ? (unsigned long long)id : ~(unsigned long long)id;
+            }
+        }
+        key[e] = kk;
+        tie[e] = tt;
+    }
+    __syncthreads();
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < P / 2; t += MF_THREADS) {
+                const int lo = (t / stride) * stride * 2 + (t % stride);
+                const int hi = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const uint32_t ka = key[lo], kb = key[hi];
+                const unsigned long long ta = tie[lo], tb = tie[hi];
+                const bool gt = (ka > kb) || (ka == kb && ta > tb);
+                if (gt == up) {
+                    key[lo] = kb;
+                    key[hi] = ka;
+                    tie[lo] = tb;
+                    tie[hi] = ta;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int e = tid; e < k; e += MF_THREADS) {
+        float dd = worst_dist<IS_L2>();
+        int64_t ii = -1;
+        if (e < P && !(key[e] == 0xffffffffu && tie[e] == ~0ull)) {
+            dd = dist_key_inv<IS_L2>(key[e]);
+            ii = (int64_t)(IS_L2 ? tie[e] : ~tie[e]);
+        }
+        out_d[q * k + e] = dd;
+        out_i[q * k + e] = ii;
+    }
+}
+
+// ---- host launchers ---------------------------------------------------------------------------------------------
+int mscan_queries_per_unit(int kind) {
+    return kind == 1 ? MS_QT : MQ_QT;
+}
+
+size_t mscan_sq8_smem(int nstep) {
+    return (size_t)2 * MQ_QT * (nstep * 32 + 8) * 2 + (size_t)MQ_QT * 16;
+}
+
+hipError_t launch_mscan_sq8(const MScanArgs& a, bool is_l2, int64_t units_bound, hipStream_t s) {
+    if (units_bound <= 0) {
+        return hipSuccess;
+    }
+    const size_t sm = mscan_sq8_smem(a.nstep);
+    auto kern = is_l2 ? mscan_sq8_kernel<true> : mscan_sq8_kernel<false>;
+    if (sm > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        if (e != hipSuccess) {
+            return e;
+        }
+    }
+    const int64_t grid = ((units_bound + 7) / 8) * 8;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(MQ_THREADS), sm, s, a);
+    return hipGetLastError();
+}
+
+size_t mscan_flat_smem(int nstep) {
+    return (size_t)MS_QT * (nstep * 16 + 4) * 4 + (size_t)MS_QT * 12;
+}
+
+hipError_t launch_mscan_flat(const MScanArgs& a, bool is_l2, int64_t units_bound, hipStream_t s) {
+    if (units_bound <= 0) {
+        return hipSuccess;
+    }
+    const size_t sm = mscan_flat_smem(a.nstep);
+    auto kern = is_l2 ? mscan_flat_kernel<true> : mscan_flat_kernel<false>;
+    if (sm > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        if (e != hipSuccess) {
+            return e;
+        }
+    }
+    const int64_t grid = ((units_bound + 7) / 8) * 8;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(MS_THREADS), sm, s, a);
+    return hipGetLastError();
+}
+
+int mscan_finish_pmax(int cap, int k) {
+    int P = 2;
+    while (P < cap + k) {
+        P <<= 1;
+    }
+    return P;
+}
+
+hipError_t launch_mscan_finish(const MScanArgs& a, int kind, bool is_l2, const int64_t* keys, const float* coarse_dis,
+                               int nprobe, const float* partial_d, const int64_t* partial_i, int k, float* out_d,
+                               int64_t* out_i, unsigned long long* counters, hipStream_t s) {
+    if (a.nq <= 0) {
+        return hipSuccess;
+    }
+    const int P_max = mscan_finish_pmax(a.cap, k);
+    const int dq = kind == 1 ? a.nchunk * 4 : a.nchunk * 16;
+    const size_t sm = (size_t)P_max * 12 + (size_t)dq * 4 * (kind == 1 ? 1 : 3);
+#define MF_LAUNCH(L2_, KIND_)                                                                                   \
+    do {                                                                                                        \
+        auto kern = mscan_finish_kernel<L2_, KIND_>;                                                            \
+        if (sm > 48 * 1024) {                                                                                   \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                             \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);            \
+            if (e != hipSuccess) return e;                                                                      \
+        }                                                                                                       \
+        hipLaunchKernelGGL(kern, dim3((unsigned)a.nq), dim3(MF_THREADS), sm, s, a, keys, coarse_dis, nprobe,    \
+                           partial_d, partial_i, k, P_max, out_d, out_i, counters);                             \
+    } while (0)
+    if (kind == 1) {
+        if (is_l2) MF_LAUNCH(true, 1); else MF_LAUNCH(false, 1);
+    } else {
+        if (is_l2) MF_LAUNCH(true, 3); else MF_LAUNCH(false, 3);
+    }
+#undef MF_LAUNCH
+    return hipGetLastError();
+}
+
+} // namespace knhip

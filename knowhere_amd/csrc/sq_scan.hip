@@ -39,7 +39,11 @@ __global__ __launch_bounds__(SQ_THREADS) void sq_scan_kernel(SqScanArgs a) {
     const int wave = threadIdx.x / KN_WAVE;
     const int dpad = a.nchunk16 * 16;
 
-    const int64_t nitems = *a.nitems_dev;
+    if (a.q_only != nullptr && a.q_only[a.nq] == 0) {
+        return; // no query was flagged: nothing to redo
+    }
+    const int64_t item_lo = a.item_lo_dev ? *a.item_lo_dev : 0;
+    const int64_t nitems = *a.nitems_dev - item_lo;
     if ((int64_t)blockIdx.x >= ((nitems + 7) / 8) * 8) {
         return;
     }
@@ -47,7 +51,7 @@ __global__ __launch_bounds__(SQ_THREADS) void sq_scan_kernel(SqScanArgs a) {
     if (item >= nitems) {
         return;
     }
-    const KnItem it = a.items[item];
+    const KnItem it = a.items[item_lo + item];
     const int npair = it.npair;
     const int64_t list = it.list;
     const int64_t blk0 = a.list_blk_off[list];
@@ -61,6 +65,17 @@ __global__ __launch_bounds__(SQ_THREADS) void sq_scan_kernel(SqScanArgs a) {
         q_of[j] = p.q;
         slot_of[j] = p.slot;
         accu0[j] = IS_L2 ? 0.f : a.coarse_dis[(int64_t)p.q * a.nslot + p.slot];
+    }
+    // query subset (fallback of the MFMA prefilter): pairs of unflagged queries are left alone
+    bool act[QG];
+    bool any_act = false;
+#pragma unroll
+    for (int j = 0; j < QG; j++) {
+        act[j] = j < npair && (a.q_only == nullptr || a.q_only[q_of[j]] != 0);
+        any_act |= act[j];
+    }
+    if (!any_act) {
+        return;
     }
 
     // LDS: y[QG][dpad] (query, or query residual for L2), vmin[dpad], vdiff[dpad]
@@ -138,13 +153,13 @@ __global__ __launch_bounds__(SQ_THREADS) void sq_scan_kernel(SqScanArgs a) {
         }
 #pragma unroll
         for (int j = 0; j < QG; j++) {
-            if (j < npair && a.dump != nullptr) {
+            if (act[j] && a.dump != nullptr) {
                 // range search: every distance of the list, filtered rows as the sentinel
                 if (row < len) {
                     const float dis = IS_L2 ? acc[j] : fadd_x(accu0[j], acc[j]);
                     a.dump[(int64_t)q_of[j] * a.dump_stride + row_off + row] = valid ? dis : worst_dist<IS_L2>();
                 }
-            } else if (j < npair) {
+            } else if (act[j]) {
                 const float dis = IS_L2 ? acc[j] : fadd_x(accu0[j], acc[j]);
                 const bool pass = valid && within_gthr<IS_L2>(dis, gt[j]) &&
                                   top[j].admits(dis, row, kd[j], ki[j]);
@@ -188,7 +203,7 @@ __global__ __launch_bounds__(SQ_THREADS) void sq_scan_kernel(SqScanArgs a) {
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < QG; j++) {
-            if (j >= j0 && j < j0 + qr && j < npair && (j % SQ_WAVES) == wave) {
+            if (j >= j0 && j < j0 + qr && act[j] && (j % SQ_WAVES) == wave) {
                 for (int w = 1; w < SQ_WAVES; w++) {
                     const int ow = (wave + w) % SQ_WAVES;
                     const float* od = md + ((j - j0) * SQ_WAVES + ow) * k;

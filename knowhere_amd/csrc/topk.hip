@@ -23,11 +23,15 @@ __global__ __launch_bounds__(256) void merge_partials_kernel(const float* __rest
                                                              int64_t nq, int nslot, int k,
                                                              int64_t q_stride, int64_t slot_stride,
                                                              float* __restrict__ out_d,
-                                                             int64_t* __restrict__ out_i) {
+                                                             int64_t* __restrict__ out_i,
+                                                             const int32_t* __restrict__ q_only) {
     const int lane = lane_id();
     const int64_t q = (int64_t)blockIdx.x * (blockDim.x / KN_WAVE) + threadIdx.x / KN_WAVE;
     if (q >= nq) {
         return;
+    }
+    if (q_only != nullptr && (q_only[nq] == 0 || q_only[q] == 0)) {
+        return; // (mfma_scan.hip fallback: only the flagged queries are merged)
     }
     WaveTopK<IS_L2, R> top;
     top.init(k);
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(256) void merge_partials_kernel(const float* __rest
 
 hipError_t launch_merge_partials(const float* partial_d, const int64_t* partial_i, int64_t nq,
                                  int nslot, int k, int64_t q_stride, int64_t slot_stride, bool is_l2,
-                                 float* out_d, int64_t* out_i, hipStream_t s) {
+                                 float* out_d, int64_t* out_i, hipStream_t s, const int32_t* q_only) {
     if (nq <= 0) {
         return hipSuccess;
     }
@@ -114,10 +118,10 @@ hipError_t launch_merge_partials(const float* partial_d, const int64_t* partial_
     KN_DISPATCH_R(k, {
         if (is_l2) {
             hipLaunchKernelGGL((merge_partials_kernel<true, R_>), dim3(grid), dim3(256), 0, s,
-                               partial_d, partial_i, nq, nslot, k, q_stride, slot_stride, out_d, out_i);
+                               partial_d, partial_i, nq, nslot, k, q_stride, slot_stride, out_d, out_i, q_only);
         } else {
             hipLaunchKernelGGL((merge_partials_kernel<false, R_>), dim3(grid), dim3(256), 0, s,
-                               partial_d, partial_i, nq, nslot, k, q_stride, slot_stride, out_d, out_i);
+                               partial_d, partial_i, nq, nslot, k, q_stride, slot_stride, out_d, out_i, q_only);
         }
     });
     return hipGetLastError();
