@@ -54,7 +54,10 @@ __global__ __launch_bounds__(256) void row_norms_kernel(const float* __restrict_
 // (w >> 1, w & 1) as 2 x 2 MFMA tiles of 32 x 32.  K is consumed in slabs of 32 staged in LDS
 // k-major (sA[k][row]) so the A/B operand fetch -- lane l needs A[row0 + (l & 31)][k + (l >> 5)] --
 // is a conflict-free ds_read_b32.
-constexpr int CG_BM = 128, CG_BN = 128, CG_BK = 32, CG_LD = 132;
+// LD = 129 (= 1 mod 32): the staging stores of a 32-lane group -- 8 k-quads x 4 rows, element e of each -- hit the
+// banks 4 * quad + row + e: conflict-free ds_write_b32 (LD = 132 made them 4-way conflicts: half of the kernel's LDS
+// cycles in the round-2 PMC pass); the operand reads walk 32 consecutive rows of one k and stay conflict-free.
+constexpr int CG_BM = 128, CG_BN = 128, CG_BK = 32, CG_LD = 129;
 
 template <bool IS_L2>
 __global__ __launch_bounds__(256) void coarse_gemm_kernel(const float* __restrict__ Q,
@@ -90,44 +93,58 @@ __global__ __launch_bounds__(256) void coarse_gemm_kernel(const float* __restric
     }
     const int lrow = tid >> 3; // 0..31 (+32 per pass)
     const int lkq = tid & 7;   // which float4 of the 32-wide k slab
-    for (int k0 = 0; k0 < d; k0 += CG_BK) {
+    const bool vec_ok = (d & 3) == 0;
+    // one k slab of both operands in registers: the loads of slab s + 1 are in flight while slab s is multiplied
+    float4 va[4], vb[4];
+    auto fetch = [&](int k0) {
+        const int kk = k0 + lkq * 4;
 #pragma unroll
         for (int pass = 0; pass < 4; pass++) {
             const int row = lrow + pass * 32;
-            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
-            const int kk = k0 + lkq * 4;
+            va[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
+            vb[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (q0 + row < nq) {
                 const float* p = Q + (q0 + row) * d + kk;
-                if (kk + 3 < d && (d & 3) == 0) {
-                    va = *reinterpret_cast<const float4*>(p);
+                if (kk + 3 < d && vec_ok) {
+                    va[pass] = *reinterpret_cast<const float4*>(p);
                 } else {
-                    if (kk + 0 < d) va.x = p[0];
-                    if (kk + 1 < d) va.y = p[1];
-                    if (kk + 2 < d) va.z = p[2];
-                    if (kk + 3 < d) va.w = p[3];
+                    if (kk + 0 < d) va[pass].x = p[0];
+                    if (kk + 1 < d) va[pass].y = p[1];
+                    if (kk + 2 < d) va[pass].z = p[2];
+                    if (kk + 3 < d) va[pass].w = p[3];
                 }
             }
             if (c0 + row < nlist) {
                 const float* p = Cm + (c0 + row) * d + kk;
-                if (kk + 3 < d && (d & 3) == 0) {
-                    vb = *reinterpret_cast<const float4*>(p);
+                if (kk + 3 < d && vec_ok) {
+                    vb[pass] = *reinterpret_cast<const float4*>(p);
                 } else {
-                    if (kk + 0 < d) vb.x = p[0];
-                    if (kk + 1 < d) vb.y = p[1];
-                    if (kk + 2 < d) vb.z = p[2];
-                    if (kk + 3 < d) vb.w = p[3];
+                    if (kk + 0 < d) vb[pass].x = p[0];
+                    if (kk + 1 < d) vb[pass].y = p[1];
+                    if (kk + 2 < d) vb[pass].z = p[2];
+                    if (kk + 3 < d) vb[pass].w = p[3];
                 }
             }
-            sA[(lkq * 4 + 0) * CG_LD + row] = va.x;
-            sA[(lkq * 4 + 1) * CG_LD + row] = va.y;
-            sA[(lkq * 4 + 2) * CG_LD + row] = va.z;
-            sA[(lkq * 4 + 3) * CG_LD + row] = va.w;
-            sB[(lkq * 4 + 0) * CG_LD + row] = vb.x;
-            sB[(lkq * 4 + 1) * CG_LD + row] = vb.y;
-            sB[(lkq * 4 + 2) * CG_LD + row] = vb.z;
-            sB[(lkq * 4 + 3) * CG_LD + row] = vb.w;
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < d; k0 += CG_BK) {
+#pragma unroll
+        for (int pass = 0; pass < 4; pass++) {
+            const int row = lrow + pass * 32;
+            sA[(lkq * 4 + 0) * CG_LD + row] = va[pass].x;
+            sA[(lkq * 4 + 1) * CG_LD + row] = va[pass].y;
+            sA[(lkq * 4 + 2) * CG_LD + row] = va[pass].z;
+            sA[(lkq * 4 + 3) * CG_LD + row] = va[pass].w;
+            sB[(lkq * 4 + 0) * CG_LD + row] = vb[pass].x;
+            sB[(lkq * 4 + 1) * CG_LD + row] = vb[pass].y;
+            sB[(lkq * 4 + 2) * CG_LD + row] = vb[pass].z;
+            sB[(lkq * 4 + 3) * CG_LD + row] = vb[pass].w;
         }
         __syncthreads();
+        if (k0 + CG_BK < d) {
+            fetch(k0 + CG_BK);
+        }
 #pragma unroll
         for (int k = 0; k < CG_BK; k += 2) {
             const int kr = k + (lane >> 5);

@@ -28,9 +28,10 @@ constexpr int FS_WAVES = 4;
 constexpr int FS_THREADS = FS_WAVES * KN_WAVE;
 
 
+// one work item (TABLE: `item_or_block` is the item when a.item_loop is set, else the block index that xcd_item
+// maps to an item; DENSE: the block index).  Every exit is workgroup-uniform.
 template <bool IS_L2, int QG, int R, bool DENSE>
-__global__ __launch_bounds__(FS_THREADS) void flat_scan_kernel(FlatScanArgs a) {
-    extern __shared__ __align__(16) unsigned char smem[];
+__device__ __forceinline__ void flat_scan_item(const FlatScanArgs& a, const int64_t item_or_block, unsigned char* smem) {
     const int lane = lane_id();
     const int wave = threadIdx.x / KN_WAVE;
     const int dpad = a.nchunk * 4;
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(FS_THREADS) void flat_scan_kernel(FlatScanArgs a) {
     int32_t slot_of[QG];
     int64_t row_base = 0; // DENSE: first row of the chunk
     if (DENSE) {
-        item = blockIdx.x;
+        item = item_or_block;
         if (item >= a.nitems_dense) {
             return;
         }
@@ -59,19 +60,19 @@ __global__ __launch_bounds__(FS_THREADS) void flat_scan_kernel(FlatScanArgs a) {
             slot_of[j] = (int32_t)chunk;
         }
     } else {
-        if (a.q_only != nullptr && a.q_only[a.nq] == 0) {
-            return; // no query was flagged: nothing to redo
+        const int64_t nitems = *a.nitems_dev;
+        if (a.item_loop) {
+            item = item_or_block;
+        } else {
+            if (item_or_block >= ((nitems + 7) / 8) * 8) {
+                return;
+            }
+            item = xcd_item(item_or_block, nitems);
         }
-        const int64_t item_lo = a.item_lo_dev ? *a.item_lo_dev : 0;
-        const int64_t nitems = *a.nitems_dev - item_lo;
-        if ((int64_t)blockIdx.x >= ((nitems + 7) / 8) * 8) {
-            return;
-        }
-        item = xcd_item(blockIdx.x, nitems);
         if (item >= nitems) {
             return;
         }
-        const KnItem it = a.items[item_lo + item];
+        const KnItem it = a.items[item];
         npair = it.npair;
         blk0 = a.list_blk_off[it.list];
         len = a.list_len[it.list];
@@ -82,17 +83,6 @@ __global__ __launch_bounds__(FS_THREADS) void flat_scan_kernel(FlatScanArgs a) {
             q_of[j] = p.q;
             slot_of[j] = p.slot;
         }
-    }
-    // query subset (fallback of the MFMA prefilter): pairs of unflagged queries are left alone
-    bool act[QG];
-    bool any_act = false;
-#pragma unroll
-    for (int j = 0; j < QG; j++) {
-        act[j] = j < npair && (DENSE || a.q_only == nullptr || a.q_only[q_of[j]] != 0);
-        any_act |= act[j];
-    }
-    if (!any_act) {
-        return;
     }
 
     // ---- stage the QG queries in LDS (zero padded to dpad) --------------------------------
@@ -156,7 +146,7 @@ __global__ __launch_bounds__(FS_THREADS) void flat_scan_kernel(FlatScanArgs a) {
         //      (lists are stored sorted by id; DENSE ids are row + offset) ----------------
 #pragma unroll
         for (int j = 0; j < QG; j++) {
-            if (act[j]) {
+            if (j < npair) {
                 bool pass = valid && within_gthr<IS_L2>(acc[j], gt[j]) &&
                             top[j].admits(acc[j], row, kd[j], ki[j]);
                 unsigned long long m = __ballot(pass);
@@ -197,7 +187,7 @@ __global__ __launch_bounds__(FS_THREADS) void flat_scan_kernel(FlatScanArgs a) {
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < QG; j++) {
-            if (j >= j0 && j < j0 + qr && act[j] && (j % FS_WAVES) == wave) {
+            if (j >= j0 && j < j0 + qr && j < npair && (j % FS_WAVES) == wave) {
                 // start from this wave's own list, fold in the other three
                 for (int w = 1; w < FS_WAVES; w++) {
                     const int ow = (wave + w) % FS_WAVES;
@@ -239,6 +229,21 @@ __global__ __launch_bounds__(FS_THREADS) void flat_scan_kernel(FlatScanArgs a) {
         }
         __syncthreads();
     }
+}
+
+template <bool IS_L2, int QG, int R, bool DENSE>
+__global__ __launch_bounds__(FS_THREADS) void flat_scan_kernel(FlatScanArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    if (!DENSE && a.item_loop) {
+        // a fixed grid walks an item table whose size only the device knows (mfma_scan.hip fallback)
+        const int64_t nitems = *a.nitems_dev;
+        for (int64_t item = blockIdx.x; item < nitems; item += gridDim.x) {
+            flat_scan_item<IS_L2, QG, R, DENSE>(a, item, smem);
+            __syncthreads();
+        }
+        return;
+    }
+    flat_scan_item<IS_L2, QG, R, DENSE>(a, blockIdx.x, smem);
 }
 
 // ---- all-pairs exact distances (coarse quantizer, exact mode / fallback) ----------------------
@@ -397,7 +402,7 @@ int flat_scan_qg(int k) {
 }
 
 template <bool IS_L2, bool DENSE>
-static hipError_t launch_flat_scan_t(const FlatScanArgs& a, int64_t grid, hipStream_t s) {
+static hipError_t launch_flat_scan_t(const FlatScanArgs& a, int64_t grid, hipStream_t s, int qg_override) {
     const int dpad = a.nchunk * 4;
     const int k = a.k;
 #define FS_LAUNCH(QG_, R_)                                                                         \
@@ -411,7 +416,19 @@ static hipError_t launch_flat_scan_t(const FlatScanArgs& a, int64_t grid, hipStr
         }                                                                                          \
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(FS_THREADS), sm, s, a);                \
     } while (0)
-    if (k <= 64) {
+    if (!DENSE && qg_override == 1) { // one query per item: the compact table of the MFMA prefilter's fallback
+        if (k <= 64) {
+            FS_LAUNCH(1, 1);
+        } else if (k <= 128) {
+            FS_LAUNCH(1, 2);
+        } else if (k <= 256) {
+            FS_LAUNCH(1, 4);
+        } else if (k <= 512) {
+            FS_LAUNCH(1, 8);
+        } else {
+            FS_LAUNCH(1, 16);
+        }
+    } else if (k <= 64) {
         FS_LAUNCH(8, 1);
     } else if (k <= 128) {
         FS_LAUNCH(8, 2);
@@ -427,16 +444,16 @@ static hipError_t launch_flat_scan_t(const FlatScanArgs& a, int64_t grid, hipStr
 }
 
 hipError_t launch_flat_scan(const FlatScanArgs& a, bool is_l2, bool dense, int64_t grid,
-                            hipStream_t s) {
+                            hipStream_t s, int qg_override) {
     if (grid <= 0) {
         return hipSuccess;
     }
     if (is_l2) {
-        return dense ? launch_flat_scan_t<true, true>(a, grid, s)
-                     : launch_flat_scan_t<true, false>(a, grid, s);
+        return dense ? launch_flat_scan_t<true, true>(a, grid, s, 0)
+                     : launch_flat_scan_t<true, false>(a, grid, s, qg_override);
     }
-    return dense ? launch_flat_scan_t<false, true>(a, grid, s)
-                 : launch_flat_scan_t<false, false>(a, grid, s);
+    return dense ? launch_flat_scan_t<false, true>(a, grid, s, 0)
+                 : launch_flat_scan_t<false, false>(a, grid, s, qg_override);
 }
 
 hipError_t launch_flat_full(const FlatScanArgs& a, bool is_l2, float* out, const int32_t* q_subset,

@@ -88,10 +88,7 @@ struct FlatScanArgs {
     float* gthr;                 // [nq] shared per-query threshold (see common.h gthr_*)
     int32_t nslot;
     int32_t k;
-    // TABLE: optional work-item range [*item_lo_dev, *nitems_dev) (null = 0) and optional query subset: only pairs
-    // whose query has q_only[q] != 0 are scanned; q_only[nq] != 0 iff any query is flagged (mfma_scan.hip fallback)
-    const int64_t* item_lo_dev;
-    const int32_t* q_only;
+    int32_t item_loop;           // TABLE: 1 = the (fixed) grid walks items blockIdx.x, + gridDim.x, ... < *nitems_dev
 };
 
 enum PqLutMode { PQ_LUT_PRECOMP = 0, PQ_LUT_IP = 1, PQ_LUT_RESIDUAL = 2 };
@@ -165,10 +162,7 @@ struct SqScanArgs {
     // range search: non-null = write every distance to dump[q * dump_stride + storage position], no top-k
     float* dump;
     int64_t dump_stride;
-    // optional work-item range / query subset, as in FlatScanArgs
-    const int64_t* item_lo_dev;
-    const int32_t* q_only;
-    int64_t nq;
+    int32_t item_loop;           // 1 = the (fixed) grid walks items blockIdx.x, + gridDim.x, ... < *nitems_dev
 };
 
 // ---- mfma_scan.hip: MFMA prefilter + exact finish for the IVF-Flat / IVF-SQ8 list scans ----
@@ -201,12 +195,16 @@ struct MScanArgs {
     int64_t* cand;               // [nq][cap]: slot << 32 | row position in the list
     int32_t cap;
     int32_t* overflow;           // [nq + 1]: per-query flag, [nq] = any
+    // sample pass (non-null = DUMP mode): pessimistic distance of (query, row) -> dump[q * dump_stride + row]
+    float* dump;
+    int64_t dump_stride;
 };
 
 // ---- flat_scan.hip ----
 int flat_scan_qg(int k);
 int sq_scan_qg(int k);
-hipError_t launch_flat_scan(const FlatScanArgs& a, bool is_l2, bool dense, int64_t grid, hipStream_t s);
+hipError_t launch_flat_scan(const FlatScanArgs& a, bool is_l2, bool dense, int64_t grid, hipStream_t s,
+                            int qg_override = 0);
 hipError_t launch_flat_full(const FlatScanArgs& a, bool is_l2, float* out, const int32_t* q_subset,
                             int64_t nq_subset, const int32_t* row_flags, hipStream_t s);
 hipError_t launch_interleave_rows(const float* src, int64_t n, int d, float4* dst, int64_t dst_blk0,
@@ -249,22 +247,28 @@ hipError_t launch_pq_cb_transpose(const float* cb, int M, int dsub, float4* cb_t
 int mscan_queries_per_unit(int kind);
 size_t mscan_flat_smem(int nstep);
 size_t mscan_sq8_smem(int nstep);
-int mscan_finish_pmax(int cap, int k);
+int mscan_finish_pmax(int cap);
+int mscan_sample_rows();
 hipError_t launch_ms_block_norms(const float4* rows, int64_t total_blk, int nchunk, float* out, float* out_max,
                                  hipStream_t s);
 hipError_t launch_ms_sq8_norms(const uint4* rows, int64_t total_blk, int nchunk16, int d, const float* trained,
                                float* out, hipStream_t s);
-hipError_t launch_ms_units(const int32_t* list_count, const int64_t* list_pair_off, int64_t nlist, int qt,
+// units from one virtual-list range of the work table (`*_v` = the table's arrays offset to that range)
+hipError_t launch_ms_units(const int32_t* list_count_v, const int64_t* list_pair_off_v, int64_t nlist, int qt,
                            int64_t* unit_off, int64_t* nunits, KnItem* units, const int64_t* list_len,
                            int64_t code_size, double* unit_bytes, hipStream_t s);
 hipError_t launch_mscan_flat(const MScanArgs& a, bool is_l2, int64_t units_bound, hipStream_t s);
 hipError_t launch_mscan_sq8(const MScanArgs& a, bool is_l2, int64_t units_bound, hipStream_t s);
+hipError_t launch_ms_tau(const float* sel_d, int64_t nq, int k, float* gthr, hipStream_t s);
 hipError_t launch_mscan_finish(const MScanArgs& a, int kind, bool is_l2, const int64_t* keys, const float* coarse_dis,
-                               int nprobe, const float* partial_d, const int64_t* partial_i, int k, float* out_d,
-                               int64_t* out_i, unsigned long long* counters, hipStream_t s);
+                               int nprobe, int k, float* out_d, int64_t* out_i, unsigned long long* counters,
+                               hipStream_t s);
+hipError_t launch_ms_flag_pairs(const int32_t* overflow, const int64_t* keys, int64_t nq, int nprobe, int64_t nlist,
+                                const int64_t* list_len, int k, KnItem* items, KnPair* pairs, int64_t* nitems,
+                                int64_t* empty_mark, hipStream_t s);
 
 // ---- sq_scan.hip ----
-hipError_t launch_sq_scan(const SqScanArgs& a, bool is_l2, int64_t grid, hipStream_t s);
+hipError_t launch_sq_scan(const SqScanArgs& a, bool is_l2, int64_t grid, hipStream_t s, int qg_override = 0);
 hipError_t launch_sq_interleave(const uint8_t* codes, const int64_t* list_row_off,
                                 const int64_t* list_len, const int64_t* list_blk_off, int64_t nlist,
                                 int d, uint4* out, hipStream_t s);
@@ -287,7 +291,7 @@ struct WorkTable {
 };
 hipError_t launch_build_worktable(const int64_t* keys, int64_t nq, int nprobe, int64_t nlist, int qg0, int qg1,
                                   const int64_t* list_len, int64_t code_size, const WorkTable& wt,
-                                  hipStream_t s);
+                                  hipStream_t s, int rank0_slot = 0);
 hipError_t launch_fill_f32(float* p, int64_t n, float v, hipStream_t s);
 
 // ---- range.hip: range search epilogue over a dumped distance matrix ----
@@ -323,7 +327,7 @@ hipError_t launch_row_select(const float* vals, int64_t nrows, int64_t n, int k,
 // rows of different length: row r has n = list_len[keys[r * key_stride]] values at vals + r * stride
 hipError_t launch_row_select_var(const float* vals, int64_t stride, const int64_t* keys, int key_stride,
                                  const int64_t* list_len, int64_t nrows, int k, bool is_l2, int64_t* out_keys,
-                                 float* out_d, hipStream_t s);
+                                 float* out_d, hipStream_t s, int64_t n_cap = 0);
 size_t row_select_max_k();
 
 // ---- coarse_gemm.hip: fp32 MFMA prefilter for the coarse quantizer ----

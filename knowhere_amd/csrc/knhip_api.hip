@@ -639,12 +639,11 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             ms_nstep = (ms_nchunk + 1) / 2;
             lds = mscan_sq8_smem(ms_nstep);
         }
-        // candidate capacity per query: the finish kernel sorts cap + k entries in LDS (a power of two)
-        int P = 512;
-        while (P < (int64_t)nprobe * k + k && P < 8192) {
-            P <<= 1;
+        // candidate capacity per query: the finish kernel sorts them in LDS (a power of two entries)
+        ms_cap = 512;
+        while (ms_cap < (int64_t)nprobe * k && ms_cap < 8192) {
+            ms_cap <<= 1;
         }
-        ms_cap = P - k;
         use_ms = lds <= 160 * 1024 - 1024 && ms_cap >= 2 * k &&
                 (idx->mscan == 1 || npairs >= 8 * nlist);
     }
@@ -680,36 +679,25 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         idx->last_items_bound = items_bound;
     }
 
-    // phases 2-4 of the MFMA prefilter path; `exact_bulk` re-runs the exact kernel over the bulk items for the
-    // flagged (overflowed) queries only
-    auto run_mscan = [&](const std::function<int(const int64_t*, const int64_t*, const int32_t*, int64_t)>& exact_scan)
+    // The MFMA prefilter path (mfma_scan.hip): sample -> tau_q, filter, exact finish; `exact_one` runs the exact kernel
+    // over a compact table of one-query items (the overflowed queries; normally none, the kernels then return at once)
+    auto run_mscan = [&](const std::function<int(const KnItem*, const KnPair*, const int64_t*, int64_t)>& exact_one)
             -> int {
         if (int rc = ensure_mscan_norms(idx)) return rc;
         const int qt = mscan_queries_per_unit(kind);
         const int64_t units_bound = round_up(npairs / qt + std::min<int64_t>(nlist, npairs) + 1, 8);
+        const int64_t sample = mscan_sample_rows();
         HIP_TRY(ws->ms_units.reserve((size_t)units_bound * sizeof(KnItem)));
         HIP_TRY(ws->ms_unit_off.reserve((size_t)(nlist + 1) * sizeof(int64_t)));
-        HIP_TRY(ws->ms_nunits.reserve(sizeof(int64_t)));
+        HIP_TRY(ws->ms_nunits.reserve(sizeof(int64_t) + 2 * sizeof(double)));
         HIP_TRY(ws->ms_cand.reserve((size_t)nq * ms_cap * sizeof(int64_t)));
         HIP_TRY(ws->ms_cand_cnt.reserve((size_t)(2 * nq + 1) * sizeof(int32_t)));
+        HIP_TRY(ws->dump.reserve((size_t)nq * sample * sizeof(float)));
+        HIP_TRY(ws->sel_keys.reserve((size_t)nq * k * sizeof(int64_t)));
+        HIP_TRY(ws->sel_d.reserve((size_t)nq * k * sizeof(float)));
+        HIP_TRY(ws->items.reserve((size_t)std::max<int64_t>(npairs, items_bound) * sizeof(KnItem)));
         int32_t* cand_cnt = ws->ms_cand_cnt.as<int32_t>();
         int32_t* overflow = cand_cnt + nq;
-        {
-            // phase 1: the closest list of every query, exact (rank-0 virtual lists come first in the item array)
-            StageTimer t(idx, s, KNHIP_STAGE_SCAN_RANK0);
-            const int64_t bound0 = round_up(nq / qg + std::min<int64_t>(nlist, nq) + 1, 8);
-            if (int rc = exact_scan(nullptr, wt.list_item_off + nlist, nullptr, bound0)) return rc;
-            HIP_TRY(hipMemsetAsync(cand_cnt, 0, (size_t)(2 * nq + 1) * sizeof(int32_t), s));
-            HIP_TRY(launch_ms_units(wt.list_count, wt.list_pair_off, nlist, qt, ws->ms_unit_off.as<int64_t>(),
-                                    ws->ms_nunits.as<int64_t>(), ws->ms_units.as<KnItem>(),
-                                    idx->d_list_len.as<int64_t>(), idx->code_size,
-                                    idx->scan_bytes_dev.as<double>() + 2, s));
-            if (kind == KNHIP_IVF_FLAT) {
-                HIP_TRY(ws->qnorm.reserve((size_t)nq * sizeof(float)));
-                HIP_TRY(launch_row_norms(d_q, nq, d, ws->qnorm.as<float>(), s));
-            }
-        }
-        idx->rank0_phase_used = true;
         MScanArgs m{};
         m.rows = idx->rows.p;
         m.xnorm = idx->xnorm.as<float>();
@@ -740,8 +728,46 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         m.cand = ws->ms_cand.as<int64_t>();
         m.cap = ms_cap;
         m.overflow = overflow;
+        idx->rank0_phase_used = false;
         {
-            // phase 2: every other probe on the matrix cores
+            // phase 1: tau_q from a sample of the closest list (units of the rank-0 virtual lists [0, nlist), DUMP mode)
+            StageTimer t(idx, s, KNHIP_STAGE_SCAN_RANK0);
+            HIP_TRY(hipMemsetAsync(cand_cnt, 0, (size_t)(2 * nq + 1) * sizeof(int32_t), s));
+            if (kind == KNHIP_IVF_FLAT) {
+                HIP_TRY(ws->qnorm.reserve((size_t)nq * sizeof(float)));
+                m.qnorm = ws->qnorm.as<float>();
+                HIP_TRY(launch_row_norms(d_q, nq, d, ws->qnorm.as<float>(), s));
+            }
+            HIP_TRY(launch_ms_units(wt.list_count, wt.list_pair_off, nlist, qt, ws->ms_unit_off.as<int64_t>(),
+                                    ws->ms_nunits.as<int64_t>(), ws->ms_units.as<KnItem>(),
+                                    idx->d_list_len.as<int64_t>(), idx->code_size, nullptr, s));
+            MScanArgs ds = m;
+            ds.dump = ws->dump.as<float>();
+            ds.dump_stride = sample;
+            const int64_t bound0 = round_up(nq / qt + std::min<int64_t>(nlist, nq) + 1, 8);
+            if (kind == KNHIP_IVF_FLAT) {
+                HIP_TRY(launch_mscan_flat(ds, is_l2, bound0, s));
+            } else {
+                HIP_TRY(launch_mscan_sq8(ds, is_l2, bound0, s));
+            }
+            HIP_TRY(launch_row_select_var(ws->dump.as<float>(), sample, keys_p, nprobe, idx->d_list_len.as<int64_t>(),
+                                          nq, k, is_l2, ws->sel_keys.as<int64_t>(), ws->sel_d.as<float>(), s, sample));
+            HIP_TRY(launch_ms_tau(ws->sel_d.as<float>(), nq, k, ws->gthr.as<float>(), s));
+        }
+        {
+            // all probes of a list together: the work table again without the rank-0 split, its pairs cut into units
+            StageTimer t(idx, s, KNHIP_STAGE_GROUP);
+            WorkTable w2 = wt;
+            w2.scan_bytes = reinterpret_cast<double*>(ws->ms_nunits.as<int64_t>() + 1); // (bytes were counted above)
+            HIP_TRY(launch_build_worktable(keys_p, nq, nprobe, nlist, qg, qg, idx->d_list_len.as<int64_t>(),
+                                           idx->code_size, w2, s, /*rank0_slot=*/-1));
+            HIP_TRY(launch_ms_units(wt.list_count + nlist, wt.list_pair_off + nlist, nlist, qt,
+                                    ws->ms_unit_off.as<int64_t>(), ws->ms_nunits.as<int64_t>(),
+                                    ws->ms_units.as<KnItem>(), idx->d_list_len.as<int64_t>(), idx->code_size,
+                                    idx->scan_bytes_dev.as<double>() + 2, s));
+        }
+        {
+            // phase 2: every (query, list) pair on the matrix cores
             StageTimer t(idx, s, KNHIP_STAGE_SCAN);
             if (kind == KNHIP_IVF_FLAT) {
                 HIP_TRY(launch_mscan_flat(m, is_l2, units_bound, s));
@@ -750,13 +776,16 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             }
         }
         {
-            // phase 3: exact distances of the candidates + slot 0 -> final top-k; phase 4: overflowed queries (normally
-            // none: the kernels below return at once) through the exact kernels and the ordinary merge
+            // phase 3: exact distances of the candidates -> final top-k; phase 4: overflowed queries through the exact
+            // kernels (one-query items) and the ordinary merge
             StageTimer t(idx, s, KNHIP_STAGE_MERGE);
-            HIP_TRY(launch_mscan_finish(m, kind, is_l2, keys_p, cdis_p, nprobe, ws->partial_d.as<float>(),
-                                        ws->partial_i.as<int64_t>(), k, d_out_d, d_out_i,
+            HIP_TRY(launch_mscan_finish(m, kind, is_l2, keys_p, cdis_p, nprobe, k, d_out_d, d_out_i,
                                         idx->coarse_fail_dev.as<unsigned long long>() + 1, s));
-            if (int rc = exact_scan(wt.list_item_off + nlist, wt.nitems, overflow, items_bound)) return rc;
+            HIP_TRY(launch_ms_flag_pairs(overflow, keys_p, nq, nprobe, nlist, idx->d_list_len.as<int64_t>(), k,
+                                         ws->items.as<KnItem>(), wt.pairs, wt.nitems, ws->partial_i.as<int64_t>(), s));
+            if (int rc = exact_one(ws->items.as<KnItem>(), wt.pairs, wt.nitems, std::min<int64_t>(npairs, 4096))) {
+                return rc;
+            }
             HIP_TRY(launch_merge_partials(ws->partial_d.as<float>(), ws->partial_i.as<int64_t>(), nq, nprobe, k,
                                           (int64_t)nprobe * k, k, is_l2, d_out_d, d_out_i, s, overflow));
         }
@@ -785,12 +814,13 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         a.nslot = nprobe;
         a.k = k;
         if (use_ms) {
-            return run_mscan([&](const int64_t* lo, const int64_t* hi, const int32_t* q_only, int64_t grid) -> int {
+            return run_mscan([&](const KnItem* items, const KnPair* pairs, const int64_t* nitems, int64_t grid) -> int {
                 FlatScanArgs b = a;
-                b.item_lo_dev = lo;
-                b.nitems_dev = hi;
-                b.q_only = q_only;
-                HIP_TRY(launch_flat_scan(b, is_l2, false, grid, s));
+                b.items = items;
+                b.pairs = pairs;
+                b.nitems_dev = nitems;
+                b.item_loop = 1;
+                HIP_TRY(launch_flat_scan(b, is_l2, false, grid, s, /*qg_override=*/1));
                 return KNHIP_OK;
             });
         }
@@ -910,14 +940,14 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         a.gthr = ws->gthr.as<float>();
         a.nslot = nprobe;
         a.k = k;
-        a.nq = nq;
         if (use_ms) {
-            return run_mscan([&](const int64_t* lo, const int64_t* hi, const int32_t* q_only, int64_t grid) -> int {
+            return run_mscan([&](const KnItem* items, const KnPair* pairs, const int64_t* nitems, int64_t grid) -> int {
                 SqScanArgs b = a;
-                b.item_lo_dev = lo;
-                b.nitems_dev = hi;
-                b.q_only = q_only;
-                HIP_TRY(launch_sq_scan(b, is_l2, grid, s));
+                b.items = items;
+                b.pairs = pairs;
+                b.nitems_dev = nitems;
+                b.item_loop = 1;
+                HIP_TRY(launch_sq_scan(b, is_l2, grid, s, /*qg_override=*/1));
                 return KNHIP_OK;
             });
         }
@@ -980,6 +1010,9 @@ int64_t query_batch(const knhip_index* idx, int64_t nq, int k, int nprobe) {
         per_q = (double)nchunks * k * 12.0;
     } else {
         per_q = (double)idx->nlist * 4.0 + (double)nprobe * (12.0 + 8.0 + (double)k * 12.0);
+        if ((idx->desc.kind == KNHIP_IVF_FLAT || idx->desc.kind == KNHIP_IVF_SQ8) && idx->mscan != 0) {
+            per_q += 4.0 * mscan_sample_rows() + 8.0 * 8192.0; // sample dump + candidate list (mfma_scan.hip)
+        }
         if (idx->desc.kind == KNHIP_IVF_PQ) {
             per_q += 256.0 * idx->desc.pq_m * 4.0;
         }

@@ -6,21 +6,23 @@
 // list) x (queries that probe it) x d block is a dense contraction, and only the k best rows of a query need the
 // reference's exact arithmetic.  So, exactly as the coarse quantizer does (coarse_gemm.hip):
 //
-//   1. rank-0 phase   the closest list of every query is scanned by the exact kernel (flat_scan / sq_scan,
-//                     work items of the rank-0 virtual lists): partial slot 0 and tau_q = the exact k-th distance
-//                     in that list -- an upper bound of the query's final k-th distance.
-//   2. mscan_*_kernel every other (query, list) pair: approximate distances on the matrix cores
+//   1. sample         the first min(len, MS_SAMPLE) rows of every query's CLOSEST list go through the same MFMA kernel in
+//                     DUMP mode: it writes a pessimistic distance (approx widened by the error bound eps, filtered rows
+//                     as the neutral value) per (query, row); row_select picks the k-th best per query = tau_q.  k
+//                     unfiltered rows are provably at least that good, so tau_q bounds the query's final k-th distance.
+//   2. mscan_*_kernel every (query, list) pair: approximate distances on the matrix cores
 //                     (v_mfma_f32_32x32x2_f32 for fp32 rows; v_mfma_f32_32x32x16_f16 for SQ8 codes), one
-//                     compare per (row, query) against tau_q widened by a rigorous error bound eps; rows that
-//                     pass are appended to the query's candidate list.  Every row whose EXACT distance is <=
-//                     tau_q passes (|approx - exact| <= eps), in particular every row of the final top-k.
+//                     compare per (row, query) against tau_q widened by eps; rows that pass are appended to the
+//                     query's candidate list.  Every row whose EXACT distance is <= tau_q passes
+//                     (|approx - exact| <= eps), in particular every row of the final top-k.
 //   3. mscan_finish   per query: exact reference-order distances of its candidates (the same l2_step / ip_step /
-//                     SQ8 decode sequence as the exact kernels), merged with partial slot 0, canonical sort,
-//                     top-k.  Bit-equal to the exact scan: candidates are a superset of the true top-k and their
-//                     distances are the reference's.
-//   4. overflow       a query whose candidate list overflows (tau_q unknown: closest list shorter than k / heavily
-//                     filtered, or a very loose bound) is flagged and redone by the exact kernels, restricted on the
-//                     device to the flagged queries.  Exactness never depends on the capacity being "big enough".
+//                     SQ8 decode sequence as the exact kernels), canonical sort, top-k.  Bit-equal to the exact
+//                     scan: the candidates are a superset of the true top-k and their distances are the reference's.
+//   4. overflow       a query whose candidate list overflows (no bound: fewer than k unfiltered rows in the sample;
+//                     or a very loose one) is flagged; its (query, list) pairs are compacted into one-query work
+//                     items and scanned by the exact kernels (flat_scan / sq_scan), then merged as usual.  Exactness
+//                     never depends on the capacity being "big enough"; with no flagged query these kernels return
+//                     at once.
 //
 // Reference semantics replaced: IVFFlatScanner::scan_codes (thirdparty/faiss/faiss/cppcontrib/knowhere/
 // IndexIVFFlat.cpp:193-236), BaselineIVFSQScannerIP/L2::scan_codes (.../IndexScalarQuantizer.cpp:196-400), the
@@ -48,6 +50,7 @@ constexpr int MS_WAVES = 4;
 constexpr int MS_THREADS = MS_WAVES * KN_WAVE;
 constexpr int MS_NQT = 2;          // query tiles of 32 per unit (fp32 rows)
 constexpr int MS_QT = 32 * MS_NQT; // queries per unit
+constexpr int MS_SAMPLE = 4096;    // rows of the closest list that feed tau_q (a multiple of 64, <= row_select's limit)
 
 // ---- ||x||^2 per stored row position (padded block layout), and the maximum ----------------------------------
 __global__ void ms_block_norms_kernel(const float4* __restrict__ rows, int64_t total_blk, int nchunk,
@@ -86,9 +89,11 @@ hipError_t launch_ms_block_norms(const float4* rows, int64_t total_blk, int nchu
 }
 
 // ---- units: (bulk virtual list, group of up to qt of its pairs) -----------------------------------------------
-// single workgroup: exclusive scan of ceil(count / qt) over the bulk virtual lists [nlist, 2 nlist)
+// (`*_v` arrays are the work table's, offset to the virtual-list range the units are made from: [0, nlist) = the
+// rank-0 probes, [nlist, 2 nlist) = the others)
+// single workgroup: exclusive scan of ceil(count / qt) over the lists
 constexpr int MS_SCAN_THREADS = 1024;
-__global__ __launch_bounds__(MS_SCAN_THREADS) void ms_unit_scan_kernel(const int32_t* __restrict__ list_count,
+__global__ __launch_bounds__(MS_SCAN_THREADS) void ms_unit_scan_kernel(const int32_t* __restrict__ list_count_v,
                                                                        int64_t nlist, int qt,
                                                                        int64_t* __restrict__ unit_off,
                                                                        int64_t* __restrict__ nunits) {
@@ -98,7 +103,7 @@ __global__ __launch_bounds__(MS_SCAN_THREADS) void ms_unit_scan_kernel(const int
     const int64_t l0 = (int64_t)tid * per, l1 = min(l0 + per, nlist);
     int64_t n = 0;
     for (int64_t l = l0; l < l1; l++) {
-        n += (list_count[nlist + l] + qt - 1) / qt;
+        n += (list_count_v[l] + qt - 1) / qt;
     }
     s_n[tid] = n;
     __syncthreads();
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(MS_SCAN_THREADS) void ms_unit_scan_kernel(const int
     int64_t u = s_n[tid] - n;
     for (int64_t l = l0; l < l1; l++) {
         unit_off[l] = u;
-        u += (list_count[nlist + l] + qt - 1) / qt;
+        u += (list_count_v[l] + qt - 1) / qt;
     }
     if (tid == MS_SCAN_THREADS - 1) {
         unit_off[nlist] = s_n[tid];
@@ -122,19 +127,19 @@ __global__ __launch_bounds__(MS_SCAN_THREADS) void ms_unit_scan_kernel(const int
     }
 }
 
-__global__ void ms_units_kernel(const int32_t* __restrict__ list_count, const int64_t* __restrict__ list_pair_off,
+__global__ void ms_units_kernel(const int32_t* __restrict__ list_count_v, const int64_t* __restrict__ list_pair_off_v,
                                 const int64_t* __restrict__ unit_off, int64_t nlist, int qt, KnItem* __restrict__ units,
                                 const int64_t* __restrict__ list_len, int64_t code_size, double* unit_bytes) {
     const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= nlist) {
         return;
     }
-    const int64_t c = list_count[nlist + l];
+    const int64_t c = list_count_v[l];
     if (c > 0 && unit_bytes != nullptr) {
         // bytes the prefilter streams: every unit reads its list once for up to qt queries
         atomicAdd(unit_bytes, (double)((c + qt - 1) / qt) * (double)list_len[l] * (double)code_size);
     }
-    const int64_t p0 = list_pair_off[nlist + l];
+    const int64_t p0 = list_pair_off_v[l];
     int64_t u = unit_off[l];
     for (int64_t i = 0; i < c; i += qt, u++) {
         KnItem x;
@@ -145,13 +150,13 @@ __global__ void ms_units_kernel(const int32_t* __restrict__ list_count, const in
     }
 }
 
-hipError_t launch_ms_units(const int32_t* list_count, const int64_t* list_pair_off, int64_t nlist, int qt,
+hipError_t launch_ms_units(const int32_t* list_count_v, const int64_t* list_pair_off_v, int64_t nlist, int qt,
                            int64_t* unit_off, int64_t* nunits, KnItem* units, const int64_t* list_len,
                            int64_t code_size, double* unit_bytes, hipStream_t s) {
-    hipLaunchKernelGGL(ms_unit_scan_kernel, dim3(1), dim3(MS_SCAN_THREADS), 0, s, list_count, nlist, qt, unit_off,
+    hipLaunchKernelGGL(ms_unit_scan_kernel, dim3(1), dim3(MS_SCAN_THREADS), 0, s, list_count_v, nlist, qt, unit_off,
                        nunits);
-    hipLaunchKernelGGL(ms_units_kernel, dim3((unsigned)((nlist + 255) / 256)), dim3(256), 0, s, list_count,
-                       list_pair_off, unit_off, nlist, qt, units, list_len, code_size, unit_bytes);
+    hipLaunchKernelGGL(ms_units_kernel, dim3((unsigned)((nlist + 255) / 256)), dim3(256), 0, s, list_count_v,
+                       list_pair_off_v, unit_off, nlist, qt, units, list_len, code_size, unit_bytes);
     return hipGetLastError();
 }
 
@@ -169,27 +174,22 @@ __device__ __forceinline__ void ms_emit(const MScanArgs& a, int32_t q, int32_t s
     }
 }
 
-// per-pair set-up shared by the kernels: query index, slot and the acceptance threshold on the accumulator
-template <bool IS_L2>
-__device__ __forceinline__ float ms_threshold_flat(const MScanArgs& a, int32_t q) {
-    const float tau = a.gthr[q];
-    if (tau == worst_dist<IS_L2>()) {
-        // no bound yet (closest list shorter than k or filtered away): every row would pass -> exact fallback
-        a.overflow[q] = 1;
-        a.overflow[a.nq] = 1;
-        return INFINITY;
+// 64-bit mask of the block's rows that take part (inside the list, not filtered): lane = row
+__device__ __forceinline__ unsigned long long ms_valid_rows(const MScanArgs& a, int64_t b, int64_t len, int64_t row_off) {
+    const int64_t row = b * 64 + lane_id();
+    bool v = row < len;
+    if (v && a.bitset != nullptr) {
+        v = !bitset_filtered(a.bitset, a.bitset_nbits, a.ids[row_off + row]);
     }
-    const float qn = a.qnorm[q];
-    if (IS_L2) {
-        const float eps = a.eps_scale * (qn + a.xnorm_max) + 1e-30f;
-        return (qn - tau - eps) * 0.5f;
-    }
-    const float eps = a.eps_scale * sqrtf(qn * a.xnorm_max) + 1e-30f;
-    return tau - eps;
+    return __ballot(v);
 }
 
 // ---- fp32 rows --------------------------------------------------------------------------------------------------
-template <bool IS_L2>
+// DUMP = false: filter mode (candidates).  DUMP = true: the sample pass over the closest lists, every (query, row)
+// of the first min(len, MS_SAMPLE) rows gets its pessimistic distance written to dump[q * dump_stride + row].
+// Per-pair constant in LDS (sT): filter: the accumulator threshold t; dump: c with value = c - 2 acc (L2: c = ||q||^2
+// + eps) or value = acc - c (IP: c = eps).
+template <bool IS_L2, bool DUMP>
 __global__ __launch_bounds__(MS_THREADS, 4) void mscan_flat_kernel(MScanArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = lane_id();
@@ -213,18 +213,31 @@ __global__ __launch_bounds__(MS_THREADS, 4) void mscan_flat_kernel(MScanArgs a) 
     const int ldq = nstep * 16 + 4; // floats per query row in LDS: an odd number of 16-byte quads
 
     float* sQ = reinterpret_cast<float*>(smem);            // [MS_QT][ldq]
-    float* sT = sQ + MS_QT * ldq;                          // [MS_QT] accumulator thresholds
+    float* sT = sQ + MS_QT * ldq;                          // [MS_QT] per-pair constant (see above)
     int32_t* sPq = reinterpret_cast<int32_t*>(sT + MS_QT); // [MS_QT] query of the pair
     int32_t* sPs = sPq + MS_QT;                            // [MS_QT] slot of the pair
     if (threadIdx.x < MS_QT) {
         const int j = threadIdx.x;
         float t = INFINITY;
-        int32_t q = 0, slot = 0;
+        int32_t q = -1, slot = 0;
         if (j < npair) {
             const KnPair p = a.pairs[it.pair0 + j];
             q = p.q;
             slot = p.slot;
-            t = ms_threshold_flat<IS_L2>(a, q);
+            const float qn = a.qnorm[q];
+            const float eps = a.eps_scale * (IS_L2 ? (qn + a.xnorm_max) : sqrtf(qn * a.xnorm_max)) + 1e-30f;
+            if (DUMP) {
+                t = IS_L2 ? qn + eps : eps;
+            } else {
+                const float tau = a.gthr[q];
+                if (tau == worst_dist<IS_L2>()) {
+                    // no bound (fewer than k unfiltered rows in the sample): every row would pass -> exact fallback
+                    a.overflow[q] = 1;
+                    a.overflow[a.nq] = 1;
+                } else {
+                    t = IS_L2 ? (qn - tau - eps) * 0.5f : tau - eps;
+                }
+            }
         }
         sT[j] = t;
         sPq[j] = q;
@@ -248,7 +261,10 @@ __global__ __launch_bounds__(MS_THREADS, 4) void mscan_flat_kernel(MScanArgs a) 
     __syncthreads();
 
     const int hi = lane >> 5, lr = lane & 31;
-    const int64_t nblk = (len + 63) >> 6;
+    int64_t nblk = (len + 63) >> 6;
+    if (DUMP) {
+        nblk = min(nblk, (int64_t)(MS_SAMPLE / 64));
+    }
     const float4* rows = reinterpret_cast<const float4*>(a.rows) + blk0 * (int64_t)nchunk * 64;
     // A operand of one step (16 dims): [row tile][8-dim slab]: chunk 4 s + 2 slab + hi of row tile * 32 + lr
     auto load_step = [&](int64_t b, int s, float4 (&A)[2][2]) {
@@ -330,6 +346,30 @@ __global__ __launch_bounds__(MS_THREADS, 4) void mscan_flat_kernel(MScanArgs a) 
                     Acur[t][sl] = Anxt[t][sl];
                 }
             }
+        }
+        if (DUMP) {
+            // ---- sample pass: the pessimistic distance of every (query, row), filtered rows as the neutral value ----
+            const unsigned long long vmask = ms_valid_rows(a, b, len, row_off);
+#pragma unroll
+            for (int qt = 0; qt < MS_NQT; qt++) {
+                const float c = sT[qt * 32 + lr];
+                const int32_t q = sPq[qt * 32 + lr];
+                if (q >= 0) {
+                    float* drow = a.dump + (int64_t)q * a.dump_stride + b * 64;
+#pragma unroll
+                    for (int t = 0; t < 2; t++) {
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const int i = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                            if (b * 64 + i < len) {
+                                const float v = IS_L2 ? c - 2.0f * acc[t][qt][r] : acc[t][qt][r] - c;
+                                drow[i] = ((vmask >> i) & 1ull) ? v : worst_dist<IS_L2>();
+                            }
+                        }
+                    }
+                }
+            }
+            continue;
         }
         // ---- epilogue: one compare per (row, query); the slow path only where something passes -------------------
 #pragma unroll
@@ -443,7 +483,8 @@ __device__ __forceinline__ void ms_codes_to_f16(const uint4 w, ms_f16x8& lo8, ms
     hi8 = b.v;
 }
 
-template <bool IS_L2>
+// DUMP: as in mscan_flat_kernel; the pessimistic distance is u0 + v (acc - off) with the per-pair constants below.
+template <bool IS_L2, bool DUMP>
 __global__ __launch_bounds__(MQ_THREADS, 4) void mscan_sq8_kernel(MScanArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = lane_id();
@@ -471,15 +512,18 @@ __global__ __launch_bounds__(MQ_THREADS, 4) void mscan_sq8_kernel(MScanArgs a) {
     _Float16* sL = sH + MQ_QT * ldh;                       // [32][ldh]
     float* sT = reinterpret_cast<float*>(sL + MQ_QT * ldh); // [32] accumulator thresholds
     float* sSc = sT + MQ_QT;                               // [32] -scale / 2 (L2 start value)
-    int32_t* sPq = reinterpret_cast<int32_t*>(sSc + MQ_QT);
+    float* sU0 = sSc + MQ_QT;                              // [32] dump: value = u0 + v (acc - off)
+    float* sV = sU0 + MQ_QT;
+    float* sOff = sV + MQ_QT;
+    int32_t* sPq = reinterpret_cast<int32_t*>(sOff + MQ_QT);
     int32_t* sPs = sPq + MQ_QT;
     const float* vmin = a.trained;
     const float* vdiff = a.trained + d;
     const float* cen = a.centroids + list * d;
     // ---- per pair: y' scaled + split into LDS, acceptance threshold -------------------------------------------------
     for (int j = wave; j < MQ_QT; j += MQ_WAVES) {
-        float thr = INFINITY, nsc = 0.f;
-        int32_t q = 0, slot = 0;
+        float thr = INFINITY, nsc = 0.f, u0 = 0.f, vv = 0.f, offv = 0.f;
+        int32_t q = -1, slot = 0;
         if (j < npair) {
             const KnPair p = a.pairs[it.pair0 + j];
             q = p.q;
@@ -519,24 +563,31 @@ __global__ __launch_bounds__(MQ_THREADS, 4) void mscan_sq8_kernel(MScanArgs a) {
             sW = ms_wave_sum(sW);
             sHL = ms_wave_sum(sHL);
             sR = ms_wave_sum(sR);
-            const float tau = a.gthr[q];
-            if (tau == worst_dist<IS_L2>() || !(mx < INFINITY)) {
-                if (lane == 0) {
-                    a.overflow[q] = 1;
-                    a.overflow[a.nq] = 1;
-                }
+            const float dis0 = IS_L2 ? 0.f : a.coarse_dis[(int64_t)q * a.nslot + slot];
+            // (the constants below are themselves rounded: a few ulp of the magnitudes they are formed from go on top)
+            const float eps = a.eps_scale * sW + 1e-6f * (fabsf(dis0) + fabsf(sA) + sR) + 1e-30f;
+            const float off = 1024.0f * sHL;
+            nsc = -0.5f * sc;
+            offv = off;
+            if (DUMP) {
+                u0 = IS_L2 ? (sR - 2.0f * sA + eps) : (dis0 + sA - eps);
+                vv = IS_L2 ? -2.0f / sc : 1.0f / sc;
             } else {
-                const float eps = a.eps_scale * sW + 1e-30f;
-                const float off = 1024.0f * sHL;
-                if (IS_L2) {
-                    thr = sc * ((sR - 2.0f * sA - tau - eps) * 0.5f) + off;
+                const float tau = a.gthr[q];
+                if (tau == worst_dist<IS_L2>() || !(mx < INFINITY)) {
+                    // no bound (fewer than k unfiltered rows in the sample): every row would pass -> exact fallback
+                    if (lane == 0) {
+                        a.overflow[q] = 1;
+                        a.overflow[a.nq] = 1;
+                    }
                 } else {
-                    const float dis0 = a.coarse_dis[(int64_t)q * a.nslot + slot];
-                    thr = sc * (tau - eps - dis0 - sA) + off;
+                    if (IS_L2) {
+                        thr = sc * ((sR - 2.0f * sA - tau - eps) * 0.5f) + off;
+                    } else {
+                        thr = sc * (tau - eps - dis0 - sA) + off;
+                    }
+                    thr -= 8.0f * 5.9604645e-8f * (fabsf(off) + fabsf(thr));
                 }
-                // the threshold itself is rounded: widen it by a few ulp of the magnitudes it was formed from
-                thr -= 8.0f * 5.9604645e-8f * (fabsf(off) + fabsf(thr));
-                nsc = -0.5f * sc;
             }
         } else {
             for (int i = lane; i < nstep * 32; i += KN_WAVE) {
@@ -547,6 +598,9 @@ __global__ __launch_bounds__(MQ_THREADS, 4) void mscan_sq8_kernel(MScanArgs a) {
         if (lane == 0) {
             sT[j] = thr;
             sSc[j] = nsc;
+            sU0[j] = u0;
+            sV[j] = vv;
+            sOff[j] = offv;
             sPq[j] = q;
             sPs[j] = slot;
         }
@@ -554,7 +608,10 @@ __global__ __launch_bounds__(MQ_THREADS, 4) void mscan_sq8_kernel(MScanArgs a) {
     __syncthreads();
 
     const int hi = lane >> 5, lr = lane & 31;
-    const int64_t nblk = (len + 63) >> 6;
+    int64_t nblk = (len + 63) >> 6;
+    if (DUMP) {
+        nblk = min(nblk, (int64_t)(MS_SAMPLE / 64));
+    }
     const uint4* rows = reinterpret_cast<const uint4*>(a.rows) + blk0 * (int64_t)nchunk * 64;
     auto load_step = [&](int64_t b, int s, uint4 (&A)[2]) {
         const int c = 2 * s + hi;
@@ -632,6 +689,26 @@ __global__ __launch_bounds__(MQ_THREADS, 4) void mscan_sq8_kernel(MScanArgs a) {
                 A2[t] = A3[t];
             }
         }
+        if (DUMP) {
+            const unsigned long long vmask = ms_valid_rows(a, b, len, row_off);
+            const int32_t q = sPq[lr];
+            if (q >= 0) {
+                const float u0 = sU0[lr], vv = sV[lr], off = sOff[lr];
+                float* drow = a.dump + (int64_t)q * a.dump_stride + b * 64;
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int i = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        if (b * 64 + i < len) {
+                            const float v = u0 + vv * (acc[t][r] - off);
+                            drow[i] = ((vmask >> i) & 1ull) ? v : worst_dist<IS_L2>();
+                        }
+                    }
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int t = 0; t < 2; t++) {
             float m = acc[t][0];
@@ -655,21 +732,34 @@ __global__ __launch_bounds__(MQ_THREADS, 4) void mscan_sq8_kernel(MScanArgs a) {
     }
 }
 
+// ---- tau_q from the sample selection ---------------------------------------------------------------------------
+__global__ void ms_tau_kernel(const float* __restrict__ sel_d, int64_t nq, int k, float* __restrict__ gthr) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nq) {
+        gthr[q] = sel_d[q * k + k - 1]; // the neutral value when the sample holds fewer than k unfiltered rows
+    }
+}
+
+hipError_t launch_ms_tau(const float* sel_d, int64_t nq, int k, float* gthr, hipStream_t s) {
+    if (nq <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(ms_tau_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, sel_d, nq, k, gthr);
+    return hipGetLastError();
+}
+
 // ---- exact finish ---------------------------------------------------------------------------------------------
 // One workgroup per query: exact distances of the candidates (thread per candidate, reference operation order),
-// together with the rank-0 partial list, bitonic sort by (distance key, id tie key), first k out.
+// bitonic sort by (distance key, id tie key), first k out.
 constexpr int MF_THREADS = 256;
 
 template <bool IS_L2, int KIND> // KIND 1: fp32 rows, 3: SQ8
 __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, const int64_t* __restrict__ keys,
                                                                   const float* __restrict__ coarse_dis, int nprobe,
-                                                                  const float* __restrict__ partial_d,
-                                                                  const int64_t* __restrict__ partial_i, int k,
-                                                                  int P_max, float* __restrict__ out_d,
+                                                                  int k, int P_max, float* __restrict__ out_d,
                                                                   int64_t* __restrict__ out_i,
                                                                   unsigned long long* __restrict__ counters) {
     extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ int s_first_end;
     __shared__ float tab[256];
     const int64_t q = blockIdx.x;
     const int tid = threadIdx.x;
@@ -686,7 +776,7 @@ __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, c
         atomicAdd(counters + 2, (unsigned long long)n);
     }
     int P = 2;
-    while (P < n + k) {
+    while (P < n) {
         P <<= 1;
     }
     // LDS: tie[P_max] (u64) | key[P_max] (u32) | query [dq] floats (| vmin, vdiff for SQ8)
@@ -706,20 +796,7 @@ __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, c
     if (KIND == 3 && tid < 256) {
         tab[tid] = __fdiv_rn((float)tid + 0.5f, 255.0f); // Codec8bit::decode_component
     }
-    if (tid == 0) {
-        s_first_end = k;
-    }
     __syncthreads();
-    // the rank-0 partial list is sentinel-terminated: nothing behind its first id < 0 is defined
-    const float* p0d = partial_d + q * (int64_t)nprobe * k;
-    const int64_t* p0i = partial_i + q * (int64_t)nprobe * k;
-    for (int r = tid; r < k; r += MF_THREADS) {
-        if (p0i[r] < 0) {
-            atomicMin(&s_first_end, r);
-        }
-    }
-    __syncthreads();
-    const int first_end = s_first_end;
     for (int e = tid; e < P; e += MF_THREADS) {
         uint32_t kk = 0xffffffffu;
         unsigned long long tt = ~0ull;
@@ -760,7 +837,7 @@ __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, c
                         const uint32_t code = (ww[e2 >> 2] >> (8 * (e2 & 3))) & 0xffu;
                         const float x = fadd_x(svmin[i], fmul_x(tab[code], svdiff[i]));
                         if (IS_L2) {
-                            // padded dims: y = 0 - 0, x = 0: they add exactly +0
+                            // padded dims: y = 0, x = 0: they add exactly +0
                             const float y = (i < d) ? fsub_x(sq[i], cen[i]) : 0.f;
                             acc = l2_step(acc, y, x);
                         } else {
@@ -775,13 +852,6 @@ __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, c
             const int64_t id = a.ids[a.list_row_off[list] + pos];
             kk = dist_key<IS_L2>(acc);
             tt = IS_L2 ? (unsigned long long)id : ~(unsigned long long)id;
-        } else if (e < n + k) {
-            const int r = e - n;
-            if (r < first_end) {
-                const int64_t id = p0i[r];
-                kk = dist_key<IS_L2>(p0d[r]);
-                tt = IS_L2 ? (unsigned long long)id : ~(unsigned long long)id;
-            }
         }
         key[e] = kk;
         tie[e] = tt;
@@ -809,7 +879,7 @@ __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, c
     for (int e = tid; e < k; e += MF_THREADS) {
         float dd = worst_dist<IS_L2>();
         int64_t ii = -1;
-        if (e < P && !(key[e] == 0xffffffffu && tie[e] == ~0ull)) {
+        if (e < n) { // (entries [n, P) are padding and sort behind every candidate)
             dd = dist_key_inv<IS_L2>(key[e]);
             ii = (int64_t)(IS_L2 ? tie[e] : ~tie[e]);
         }
@@ -818,13 +888,60 @@ __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, c
     }
 }
 
+// ---- overflowed queries -> compact one-query work items for the exact kernels ------------------------------------
+// thread per (query, slot): pairs of flagged queries become items {list, 1 pair}; pairs of empty / invalid lists get
+// their partial slot marked empty (as the work table does).  *nitems must be 0 on entry.
+__global__ void ms_flag_pairs_kernel(const int32_t* __restrict__ overflow, const int64_t* __restrict__ keys, int64_t nq,
+                                     int nprobe, int64_t nlist, const int64_t* __restrict__ list_len, int k,
+                                     KnItem* __restrict__ items, KnPair* __restrict__ pairs, int64_t* __restrict__ nitems,
+                                     int64_t* __restrict__ empty_mark) {
+    if (overflow[nq] == 0) {
+        return;
+    }
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nq * nprobe) {
+        return;
+    }
+    const int64_t q = t / nprobe;
+    if (overflow[q] == 0) {
+        return;
+    }
+    const int64_t key = keys[t];
+    if (key < 0 || key >= nlist || list_len[key] == 0) {
+        empty_mark[t * k] = -1;
+        return;
+    }
+    const int64_t pos = (int64_t)atomicAdd(reinterpret_cast<unsigned long long*>(nitems), 1ull);
+    KnPair p;
+    p.q = (int32_t)q;
+    p.slot = (int32_t)(t % nprobe);
+    pairs[pos] = p;
+    KnItem it;
+    it.list = (int32_t)key;
+    it.npair = 1;
+    it.pair0 = pos;
+    items[pos] = it;
+}
+
+hipError_t launch_ms_flag_pairs(const int32_t* overflow, const int64_t* keys, int64_t nq, int nprobe, int64_t nlist,
+                                const int64_t* list_len, int k, KnItem* items, KnPair* pairs, int64_t* nitems,
+                                int64_t* empty_mark, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(nitems, 0, sizeof(int64_t), s);
+    if (e != hipSuccess || nq <= 0) {
+        return e;
+    }
+    hipLaunchKernelGGL(ms_flag_pairs_kernel, dim3((unsigned)((nq * nprobe + 255) / 256)), dim3(256), 0, s, overflow, keys,
+                       nq, nprobe, nlist, list_len, k, items, pairs, nitems, empty_mark);
+    return hipGetLastError();
+}
+
 // ---- host launchers ---------------------------------------------------------------------------------------------
 int mscan_queries_per_unit(int kind) {
     return kind == 1 ? MS_QT : MQ_QT;
 }
 
 size_t mscan_sq8_smem(int nstep) {
-    return (size_t)2 * MQ_QT * (nstep * 32 + 8) * 2 + (size_t)MQ_QT * 16;
+    return (size_t)2 * MQ_QT * (nstep * 32 + 8) * 2 + (size_t)MQ_QT * 28;
 }
 
 hipError_t launch_mscan_sq8(const MScanArgs& a, bool is_l2, int64_t units_bound, hipStream_t s) {
@@ -832,7 +949,9 @@ hipError_t launch_mscan_sq8(const MScanArgs& a, bool is_l2, int64_t units_bound,
         return hipSuccess;
     }
     const size_t sm = mscan_sq8_smem(a.nstep);
-    auto kern = is_l2 ? mscan_sq8_kernel<true> : mscan_sq8_kernel<false>;
+    const bool dump = a.dump != nullptr;
+    auto kern = is_l2 ? (dump ? mscan_sq8_kernel<true, true> : mscan_sq8_kernel<true, false>)
+                      : (dump ? mscan_sq8_kernel<false, true> : mscan_sq8_kernel<false, false>);
     if (sm > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
@@ -849,12 +968,18 @@ size_t mscan_flat_smem(int nstep) {
     return (size_t)MS_QT * (nstep * 16 + 4) * 4 + (size_t)MS_QT * 12;
 }
 
+int mscan_sample_rows() {
+    return MS_SAMPLE;
+}
+
 hipError_t launch_mscan_flat(const MScanArgs& a, bool is_l2, int64_t units_bound, hipStream_t s) {
     if (units_bound <= 0) {
         return hipSuccess;
     }
     const size_t sm = mscan_flat_smem(a.nstep);
-    auto kern = is_l2 ? mscan_flat_kernel<true> : mscan_flat_kernel<false>;
+    const bool dump = a.dump != nullptr;
+    auto kern = is_l2 ? (dump ? mscan_flat_kernel<true, true> : mscan_flat_kernel<true, false>)
+                      : (dump ? mscan_flat_kernel<false, true> : mscan_flat_kernel<false, false>);
     if (sm > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
@@ -867,21 +992,21 @@ hipError_t launch_mscan_flat(const MScanArgs& a, bool is_l2, int64_t units_bound
     return hipGetLastError();
 }
 
-int mscan_finish_pmax(int cap, int k) {
+int mscan_finish_pmax(int cap) {
     int P = 2;
-    while (P < cap + k) {
+    while (P < cap) {
         P <<= 1;
     }
     return P;
 }
 
 hipError_t launch_mscan_finish(const MScanArgs& a, int kind, bool is_l2, const int64_t* keys, const float* coarse_dis,
-                               int nprobe, const float* partial_d, const int64_t* partial_i, int k, float* out_d,
-                               int64_t* out_i, unsigned long long* counters, hipStream_t s) {
+                               int nprobe, int k, float* out_d, int64_t* out_i, unsigned long long* counters,
+                               hipStream_t s) {
     if (a.nq <= 0) {
         return hipSuccess;
     }
-    const int P_max = mscan_finish_pmax(a.cap, k);
+    const int P_max = mscan_finish_pmax(a.cap);
     const int dq = kind == 1 ? a.nchunk * 4 : a.nchunk * 16;
     const size_t sm = (size_t)P_max * 12 + (size_t)dq * 4 * (kind == 1 ? 1 : 3);
 #define MF_LAUNCH(L2_, KIND_)                                                                                   \
@@ -892,8 +1017,8 @@ hipError_t launch_mscan_finish(const MScanArgs& a, int kind, bool is_l2, const i
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);            \
             if (e != hipSuccess) return e;                                                                      \
         }                                                                                                       \
-        hipLaunchKernelGGL(kern, dim3((unsigned)a.nq), dim3(MF_THREADS), sm, s, a, keys, coarse_dis, nprobe,    \
-                           partial_d, partial_i, k, P_max, out_d, out_i, counters);                             \
+        hipLaunchKernelGGL(kern, dim3((unsigned)a.nq), dim3(MF_THREADS), sm, s, a, keys, coarse_dis, nprobe, k, \
+                           P_max, out_d, out_i, counters);                                                      \
     } while (0)
     if (kind == 1) {
         if (is_l2) MF_LAUNCH(true, 1); else MF_LAUNCH(false, 1);

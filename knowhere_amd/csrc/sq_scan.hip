@@ -31,27 +31,29 @@ int sq_scan_qg(int k) {
     return k <= 128 ? 8 : (k <= 256 ? 4 : (k <= 512 ? 2 : 1));
 }
 
+// one work item (`item_or_block` is the item when a.item_loop is set, else the block index that xcd_item maps to an
+// item).  Every exit is workgroup-uniform.
 template <bool IS_L2, int QG, int R>
-__global__ __launch_bounds__(SQ_THREADS) void sq_scan_kernel(SqScanArgs a) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ float tab[256]; // (c + 0.5f) / 255.0f, correctly rounded
+__device__ __forceinline__ void sq_scan_item(const SqScanArgs& a, const int64_t item_or_block, unsigned char* smem,
+                                             float* tab) {
     const int lane = lane_id();
     const int wave = threadIdx.x / KN_WAVE;
     const int dpad = a.nchunk16 * 16;
 
-    if (a.q_only != nullptr && a.q_only[a.nq] == 0) {
-        return; // no query was flagged: nothing to redo
+    const int64_t nitems = *a.nitems_dev;
+    int64_t item;
+    if (a.item_loop) {
+        item = item_or_block;
+    } else {
+        if (item_or_block >= ((nitems + 7) / 8) * 8) {
+            return;
+        }
+        item = xcd_item(item_or_block, nitems);
     }
-    const int64_t item_lo = a.item_lo_dev ? *a.item_lo_dev : 0;
-    const int64_t nitems = *a.nitems_dev - item_lo;
-    if ((int64_t)blockIdx.x >= ((nitems + 7) / 8) * 8) {
-        return;
-    }
-    const int64_t item = xcd_item(blockIdx.x, nitems);
     if (item >= nitems) {
         return;
     }
-    const KnItem it = a.items[item_lo + item];
+    const KnItem it = a.items[item];
     const int npair = it.npair;
     const int64_t list = it.list;
     const int64_t blk0 = a.list_blk_off[list];
@@ -65,17 +67,6 @@ __global__ __launch_bounds__(SQ_THREADS) void sq_scan_kernel(SqScanArgs a) {
         q_of[j] = p.q;
         slot_of[j] = p.slot;
         accu0[j] = IS_L2 ? 0.f : a.coarse_dis[(int64_t)p.q * a.nslot + p.slot];
-    }
-    // query subset (fallback of the MFMA prefilter): pairs of unflagged queries are left alone
-    bool act[QG];
-    bool any_act = false;
-#pragma unroll
-    for (int j = 0; j < QG; j++) {
-        act[j] = j < npair && (a.q_only == nullptr || a.q_only[q_of[j]] != 0);
-        any_act |= act[j];
-    }
-    if (!any_act) {
-        return;
     }
 
     // LDS: y[QG][dpad] (query, or query residual for L2), vmin[dpad], vdiff[dpad]
@@ -153,13 +144,13 @@ __global__ __launch_bounds__(SQ_THREADS) void sq_scan_kernel(SqScanArgs a) {
         }
 #pragma unroll
         for (int j = 0; j < QG; j++) {
-            if (act[j] && a.dump != nullptr) {
+            if (j < npair && a.dump != nullptr) {
                 // range search: every distance of the list, filtered rows as the sentinel
                 if (row < len) {
                     const float dis = IS_L2 ? acc[j] : fadd_x(accu0[j], acc[j]);
                     a.dump[(int64_t)q_of[j] * a.dump_stride + row_off + row] = valid ? dis : worst_dist<IS_L2>();
                 }
-            } else if (act[j]) {
+            } else if (j < npair) {
                 const float dis = IS_L2 ? acc[j] : fadd_x(accu0[j], acc[j]);
                 const bool pass = valid && within_gthr<IS_L2>(dis, gt[j]) &&
                                   top[j].admits(dis, row, kd[j], ki[j]);
@@ -203,7 +194,7 @@ __global__ __launch_bounds__(SQ_THREADS) void sq_scan_kernel(SqScanArgs a) {
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < QG; j++) {
-            if (j >= j0 && j < j0 + qr && act[j] && (j % SQ_WAVES) == wave) {
+            if (j >= j0 && j < j0 + qr && j < npair && (j % SQ_WAVES) == wave) {
                 for (int w = 1; w < SQ_WAVES; w++) {
                     const int ow = (wave + w) % SQ_WAVES;
                     const float* od = md + ((j - j0) * SQ_WAVES + ow) * k;
@@ -241,6 +232,22 @@ __global__ __launch_bounds__(SQ_THREADS) void sq_scan_kernel(SqScanArgs a) {
     }
 }
 
+template <bool IS_L2, int QG, int R>
+__global__ __launch_bounds__(SQ_THREADS) void sq_scan_kernel(SqScanArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ float tab[256]; // (c + 0.5f) / 255.0f, correctly rounded
+    if (a.item_loop) {
+        // a fixed grid walks an item table whose size only the device knows (mfma_scan.hip fallback)
+        const int64_t nitems = *a.nitems_dev;
+        for (int64_t item = blockIdx.x; item < nitems; item += gridDim.x) {
+            sq_scan_item<IS_L2, QG, R>(a, item, smem, tab);
+            __syncthreads();
+        }
+        return;
+    }
+    sq_scan_item<IS_L2, QG, R>(a, blockIdx.x, smem, tab);
+}
+
 // AoS codes [len][d] (sorted by list) -> interleaved blocks
 __global__ void sq_interleave_kernel(const uint8_t* __restrict__ codes,
                                      const int64_t* __restrict__ list_row_off,
@@ -274,7 +281,7 @@ __global__ void sq_interleave_kernel(const uint8_t* __restrict__ codes,
     }
 }
 
-hipError_t launch_sq_scan(const SqScanArgs& a, bool is_l2, int64_t grid, hipStream_t s) {
+hipError_t launch_sq_scan(const SqScanArgs& a, bool is_l2, int64_t grid, hipStream_t s, int qg_override) {
     if (grid <= 0) {
         return hipSuccess;
     }
@@ -300,6 +307,13 @@ hipError_t launch_sq_scan(const SqScanArgs& a, bool is_l2, int64_t grid, hipStre
     } while (0)
 #define SQ_BY_K(L2_)                                                                               \
     do {                                                                                           \
+        if (qg_override == 1) { /* one query per item: the compact table of the MFMA prefilter's fallback */ \
+            if (k <= 64) SQ_LAUNCH(L2_, 1, 1);                                                     \
+            else if (k <= 128) SQ_LAUNCH(L2_, 1, 2);                                               \
+            else if (k <= 256) SQ_LAUNCH(L2_, 1, 4);                                               \
+            else if (k <= 512) SQ_LAUNCH(L2_, 1, 8);                                               \
+            else SQ_LAUNCH(L2_, 1, 16);                                                            \
+        } else                                                                                     \
         if (k <= 64) SQ_LAUNCH(L2_, 8, 1);                                                         \
         else if (k <= 128) SQ_LAUNCH(L2_, 8, 2);                                                   \
         else if (k <= 256) SQ_LAUNCH(L2_, 4, 4);                                                   \
