@@ -123,7 +123,10 @@ __device__ __forceinline__ void flat_scan_item(const FlatScanArgs& a, const int6
         for (int j = 0; j < QG; j++) {
             acc[j] = 0.f;
         }
-#pragma unroll 2
+        // (one- and two-query items keep 8 row loads in flight: with so little arithmetic per load the scan is
+        // latency-bound otherwise)
+        constexpr int UF = QG <= 2 ? 8 : 2;
+#pragma unroll UF
         for (int c = 0; c < a.nchunk; c++) {
             const float4 y = p[(int64_t)c * 64];
 #pragma unroll

@@ -198,6 +198,10 @@ struct MScanArgs {
     // sample pass (non-null = DUMP mode): pessimistic distance of (query, row) -> dump[q * dump_stride + row]
     float* dump;
     int64_t dump_stride;
+    // per-query candidate histogram (null = off): ghist[q][64], gmeta[q] = {key of the first bin, bin shift | KN_HIST_OFF}
+    uint32_t* ghist;
+    const uint2* gmeta;
+    int32_t k;
 };
 
 // ---- flat_scan.hip ----
@@ -244,7 +248,7 @@ hipError_t launch_pq_scan_q4(const PqScanArgs& a, bool is_l2, int64_t items_boun
 hipError_t launch_pq_cb_transpose(const float* cb, int M, int dsub, float4* cb_t, hipStream_t s);
 
 // ---- mfma_scan.hip ----
-int mscan_queries_per_unit(int kind);
+int mscan_queries_per_unit(int kind, bool sample);
 size_t mscan_flat_smem(int nstep);
 size_t mscan_sq8_smem(int nstep);
 int mscan_finish_pmax(int cap);
@@ -259,7 +263,7 @@ hipError_t launch_ms_units(const int32_t* list_count_v, const int64_t* list_pair
                            int64_t code_size, double* unit_bytes, hipStream_t s);
 hipError_t launch_mscan_flat(const MScanArgs& a, bool is_l2, int64_t units_bound, hipStream_t s);
 hipError_t launch_mscan_sq8(const MScanArgs& a, bool is_l2, int64_t units_bound, hipStream_t s);
-hipError_t launch_ms_tau(const float* sel_d, int64_t nq, int k, float* gthr, hipStream_t s);
+hipError_t launch_ms_tau(const float* sel_d, int64_t nq, int k, bool is_l2, float* gthr, uint2* gmeta, hipStream_t s);
 hipError_t launch_mscan_finish(const MScanArgs& a, int kind, bool is_l2, const int64_t* keys, const float* coarse_dis,
                                int nprobe, int k, float* out_d, int64_t* out_i, unsigned long long* counters,
                                hipStream_t s);

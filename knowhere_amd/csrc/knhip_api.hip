@@ -640,8 +640,8 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             lds = mscan_sq8_smem(ms_nstep);
         }
         // candidate capacity per query: the finish kernel sorts them in LDS (a power of two entries)
-        ms_cap = 512;
-        while (ms_cap < (int64_t)nprobe * k && ms_cap < 8192) {
+        ms_cap = 1024;
+        while (ms_cap < (int64_t)4 * nprobe * k && ms_cap < 8192) {
             ms_cap <<= 1;
         }
         use_ms = lds <= 160 * 1024 - 1024 && ms_cap >= 2 * k &&
@@ -654,7 +654,8 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
     HIP_TRY(ws->list_pair_off.reserve((size_t)(2 * nlist + 1) * sizeof(int64_t)));
     HIP_TRY(ws->list_item_off.reserve((size_t)(2 * nlist + 1) * sizeof(int64_t)));
     HIP_TRY(ws->pairs.reserve((size_t)npairs * sizeof(KnPair)));
-    HIP_TRY(ws->items.reserve((size_t)items_bound * sizeof(KnItem)));
+    // (the MFMA prefilter's fallback compacts the pairs of overflowed queries into one-query items: up to npairs)
+    HIP_TRY(ws->items.reserve((size_t)(use_ms ? std::max<int64_t>(npairs, items_bound) : items_bound) * sizeof(KnItem)));
     HIP_TRY(ws->nitems.reserve(sizeof(int64_t)));
     WorkTable wt{};
     wt.list_count = ws->list_count.as<int32_t>();
@@ -684,7 +685,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
     auto run_mscan = [&](const std::function<int(const KnItem*, const KnPair*, const int64_t*, int64_t)>& exact_one)
             -> int {
         if (int rc = ensure_mscan_norms(idx)) return rc;
-        const int qt = mscan_queries_per_unit(kind);
+        const int qt = mscan_queries_per_unit(kind, false), qt0 = mscan_queries_per_unit(kind, true);
         const int64_t units_bound = round_up(npairs / qt + std::min<int64_t>(nlist, npairs) + 1, 8);
         const int64_t sample = mscan_sample_rows();
         HIP_TRY(ws->ms_units.reserve((size_t)units_bound * sizeof(KnItem)));
@@ -695,7 +696,8 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         HIP_TRY(ws->dump.reserve((size_t)nq * sample * sizeof(float)));
         HIP_TRY(ws->sel_keys.reserve((size_t)nq * k * sizeof(int64_t)));
         HIP_TRY(ws->sel_d.reserve((size_t)nq * k * sizeof(float)));
-        HIP_TRY(ws->items.reserve((size_t)std::max<int64_t>(npairs, items_bound) * sizeof(KnItem)));
+        HIP_TRY(ws->ghist.reserve((size_t)nq * 64 * sizeof(uint32_t)));
+        HIP_TRY(ws->gmeta.reserve((size_t)nq * sizeof(uint2)));
         int32_t* cand_cnt = ws->ms_cand_cnt.as<int32_t>();
         int32_t* overflow = cand_cnt + nq;
         MScanArgs m{};
@@ -728,6 +730,11 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         m.cand = ws->ms_cand.as<int64_t>();
         m.cap = ms_cap;
         m.overflow = overflow;
+        m.k = k;
+        if (idx->cand_hist) {
+            m.ghist = ws->ghist.as<uint32_t>();
+            m.gmeta = ws->gmeta.as<uint2>();
+        }
         idx->rank0_phase_used = false;
         {
             // phase 1: tau_q from a sample of the closest list (units of the rank-0 virtual lists [0, nlist), DUMP mode)
@@ -738,13 +745,15 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
                 m.qnorm = ws->qnorm.as<float>();
                 HIP_TRY(launch_row_norms(d_q, nq, d, ws->qnorm.as<float>(), s));
             }
-            HIP_TRY(launch_ms_units(wt.list_count, wt.list_pair_off, nlist, qt, ws->ms_unit_off.as<int64_t>(),
+            HIP_TRY(hipMemsetAsync(ws->ghist.p, 0, (size_t)nq * 64 * sizeof(uint32_t), s));
+            HIP_TRY(launch_ms_units(wt.list_count, wt.list_pair_off, nlist, qt0, ws->ms_unit_off.as<int64_t>(),
                                     ws->ms_nunits.as<int64_t>(), ws->ms_units.as<KnItem>(),
                                     idx->d_list_len.as<int64_t>(), idx->code_size, nullptr, s));
             MScanArgs ds = m;
             ds.dump = ws->dump.as<float>();
             ds.dump_stride = sample;
-            const int64_t bound0 = round_up(nq / qt + std::min<int64_t>(nlist, nq) + 1, 8);
+            ds.ghist = nullptr;
+            const int64_t bound0 = round_up(nq / qt0 + std::min<int64_t>(nlist, nq) + 1, 8);
             if (kind == KNHIP_IVF_FLAT) {
                 HIP_TRY(launch_mscan_flat(ds, is_l2, bound0, s));
             } else {
@@ -752,7 +761,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             }
             HIP_TRY(launch_row_select_var(ws->dump.as<float>(), sample, keys_p, nprobe, idx->d_list_len.as<int64_t>(),
                                           nq, k, is_l2, ws->sel_keys.as<int64_t>(), ws->sel_d.as<float>(), s, sample));
-            HIP_TRY(launch_ms_tau(ws->sel_d.as<float>(), nq, k, ws->gthr.as<float>(), s));
+            HIP_TRY(launch_ms_tau(ws->sel_d.as<float>(), nq, k, is_l2, ws->gthr.as<float>(), ws->gmeta.as<uint2>(), s));
         }
         {
             // all probes of a list together: the work table again without the rank-0 split, its pairs cut into units

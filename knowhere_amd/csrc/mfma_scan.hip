@@ -161,7 +161,13 @@ hipError_t launch_ms_units(const int32_t* list_count_v, const int64_t* list_pair
 }
 
 // ---- candidate append (slow path of the epilogue) ---------------------------------------------------------------
-__device__ __forceinline__ void ms_emit(const MScanArgs& a, int32_t q, int32_t slot, int64_t row_off, int64_t pos) {
+// `pess` is the candidate's pessimistic distance (approx widened by eps: the exact distance is at least as good).
+// It feeds the query's candidate histogram (64 bins over the key range [best, k-th] of the sample): a unit that
+// starts later and finds cum(bins <= b) >= k knows that k unfiltered rows are at least as good as the upper edge of
+// bin b -- a valid and ever tightening bound on the final k-th distance (the scheme of pq_scan_v2.hip).
+template <bool IS_L2>
+__device__ __forceinline__ void ms_emit(const MScanArgs& a, int32_t q, int32_t slot, int64_t row_off, int64_t pos,
+                                        float pess) {
     if (a.bitset != nullptr && bitset_filtered(a.bitset, a.bitset_nbits, a.ids[row_off + pos])) {
         return;
     }
@@ -170,8 +176,48 @@ __device__ __forceinline__ void ms_emit(const MScanArgs& a, int32_t q, int32_t s
         a.cand[(int64_t)q * a.cap + n] = ((int64_t)slot << 32) | (int64_t)(uint32_t)pos;
     } else {
         a.overflow[q] = 1;
-        a.overflow[a.nq] = 1; // "some query overflowed": the fallback kernels exit at once while this stays 0
+        a.overflow[a.nq] = 1; // "some query overflowed": the fallback kernels return at once while this stays 0
     }
+    if (a.ghist != nullptr) {
+        const uint2 mt = a.gmeta[q];
+        if (mt.y != KN_HIST_OFF) {
+            atomicAdd(a.ghist + (int64_t)q * KN_HIST_BINS + hist_bin(dist_key<IS_L2>(pess), mt.x, mt.y), 1u);
+        }
+    }
+}
+
+// bound on the query's final k-th distance from its candidate histogram (full wave: lane = bin); the neutral value
+// when the histogram is off or k candidates have not been seen yet
+template <bool IS_L2>
+__device__ __forceinline__ float ms_hist_bound(const MScanArgs& a, int32_t q, int k) {
+    float bound = worst_dist<IS_L2>();
+    if (a.ghist == nullptr || q < 0) {
+        return bound;
+    }
+    const uint2 mt = a.gmeta[q];
+    if (mt.y == KN_HIST_OFF) {
+        return bound;
+    }
+    const int lane = lane_id();
+    uint32_t cum = __hip_atomic_load(a.ghist + (int64_t)q * KN_HIST_BINS + lane, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int dlt = 1; dlt < KN_WAVE; dlt <<= 1) {
+        const uint32_t up = __shfl_up(cum, dlt, KN_WAVE);
+        cum += lane >= dlt ? up : 0u;
+    }
+    const unsigned long long reach = __ballot(cum >= (uint32_t)k);
+    const int b = reach ? __ffsll((long long)reach) - 1 : KN_HIST_BINS;
+    if (b < KN_HIST_BINS - 1) { // (the last bin also collects everything beyond the range)
+        const unsigned long long edge = (unsigned long long)mt.x + (((unsigned long long)b + 1ull) << mt.y) - 1ull;
+        if (edge < 0xffffffffull) {
+            const float e = dist_key_inv<IS_L2>((uint32_t)edge);
+            if (e == e && fabsf(e) < FLT_MAX) {
+                bound = e;
+            }
+        }
+    }
+    return bound;
 }
 
 // 64-bit mask of the block's rows that take part (inside the list, not filtered): lane = row
@@ -189,8 +235,10 @@ __device__ __forceinline__ unsigned long long ms_valid_rows(const MScanArgs& a, 
 // of the first min(len, MS_SAMPLE) rows gets its pessimistic distance written to dump[q * dump_stride + row].
 // Per-pair constant in LDS (sT): filter: the accumulator threshold t; dump: c with value = c - 2 acc (L2: c = ||q||^2
 // + eps) or value = acc - c (IP: c = eps).
-template <bool IS_L2, bool DUMP>
+// NQT = query tiles of 32 per unit (2 in filter mode; 1 in the sample pass, whose units hold few queries).
+template <bool IS_L2, bool DUMP, int NQT>
 __global__ __launch_bounds__(MS_THREADS, 4) void mscan_flat_kernel(MScanArgs a) {
+    constexpr int QT = 32 * NQT;
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = lane_id();
     const int wave = threadIdx.x / KN_WAVE;
@@ -212,13 +260,13 @@ __global__ __launch_bounds__(MS_THREADS, 4) void mscan_flat_kernel(MScanArgs a) 
     const int nstep = a.nstep;      // steps of 16 dims (4 chunks)
     const int ldq = nstep * 16 + 4; // floats per query row in LDS: an odd number of 16-byte quads
 
-    float* sQ = reinterpret_cast<float*>(smem);            // [MS_QT][ldq]
-    float* sT = sQ + MS_QT * ldq;                          // [MS_QT] per-pair constant (see above)
-    int32_t* sPq = reinterpret_cast<int32_t*>(sT + MS_QT); // [MS_QT] query of the pair
-    int32_t* sPs = sPq + MS_QT;                            // [MS_QT] slot of the pair
-    if (threadIdx.x < MS_QT) {
-        const int j = threadIdx.x;
-        float t = INFINITY;
+    float* sQ = reinterpret_cast<float*>(smem);          // [QT][ldq]
+    float* sT = sQ + QT * ldq;                           // [QT] filter: accumulator threshold
+    float* sC = sT + QT;                                 // [QT] pessimistic distance = c - 2 acc (L2) / acc - c (IP)
+    int32_t* sPq = reinterpret_cast<int32_t*>(sC + QT);  // [QT] query of the pair (-1: none)
+    int32_t* sPs = sPq + QT;                             // [QT] slot of the pair
+    for (int j = wave; j < QT; j += MS_WAVES) {
+        float t = INFINITY, c = 0.f;
         int32_t q = -1, slot = 0;
         if (j < npair) {
             const KnPair p = a.pairs[it.pair0 + j];
@@ -226,25 +274,30 @@ __global__ __launch_bounds__(MS_THREADS, 4) void mscan_flat_kernel(MScanArgs a) 
             slot = p.slot;
             const float qn = a.qnorm[q];
             const float eps = a.eps_scale * (IS_L2 ? (qn + a.xnorm_max) : sqrtf(qn * a.xnorm_max)) + 1e-30f;
-            if (DUMP) {
-                t = IS_L2 ? qn + eps : eps;
-            } else {
-                const float tau = a.gthr[q];
+            c = IS_L2 ? qn + eps : eps;
+            if (!DUMP) {
+                float tau = a.gthr[q];
+                tau = tighter<IS_L2>(tau, ms_hist_bound<IS_L2>(a, q, a.k));
                 if (tau == worst_dist<IS_L2>()) {
                     // no bound (fewer than k unfiltered rows in the sample): every row would pass -> exact fallback
-                    a.overflow[q] = 1;
-                    a.overflow[a.nq] = 1;
+                    if (lane == 0) {
+                        a.overflow[q] = 1;
+                        a.overflow[a.nq] = 1;
+                    }
                 } else {
                     t = IS_L2 ? (qn - tau - eps) * 0.5f : tau - eps;
                 }
             }
         }
-        sT[j] = t;
-        sPq[j] = q;
-        sPs[j] = slot;
+        if (lane == 0) {
+            sT[j] = t;
+            sC[j] = c;
+            sPq[j] = q;
+            sPs[j] = slot;
+        }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < MS_QT * nstep * 4; t += MS_THREADS) {
+    for (int t = threadIdx.x; t < QT * nstep * 4; t += MS_THREADS) {
         const int j = t / (nstep * 4), c = t % (nstep * 4);
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         if (j < npair) {
@@ -290,7 +343,7 @@ __global__ __launch_bounds__(MS_THREADS, 4) void mscan_flat_kernel(MScanArgs a) 
         nb += MS_WAVES;
     }
     for (int64_t b = wave; b < nblk; b += MS_WAVES) {
-        ms_f32x16 acc[2][MS_NQT];
+        ms_f32x16 acc[2][NQT];
         {
             // L2: acc = -||x||^2 / 2 for the tile's rows (k = 0 carries the norm, k = 1 nothing)
             float xn0 = 0.f, xn1 = 0.f;
@@ -310,7 +363,7 @@ __global__ __launch_bounds__(MS_THREADS, 4) void mscan_flat_kernel(MScanArgs a) 
                 i1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xn1, mh, z, 0, 0, 0);
             }
 #pragma unroll
-            for (int qt = 0; qt < MS_NQT; qt++) {
+            for (int qt = 0; qt < NQT; qt++) {
                 acc[0][qt] = i0;
                 acc[1][qt] = i1;
             }
@@ -323,13 +376,13 @@ __global__ __launch_bounds__(MS_THREADS, 4) void mscan_flat_kernel(MScanArgs a) 
             }
 #pragma unroll
             for (int sl = 0; sl < 2; sl++) {
-                float4 B[MS_NQT];
+                float4 B[NQT];
 #pragma unroll
-                for (int qt = 0; qt < MS_NQT; qt++) {
+                for (int qt = 0; qt < NQT; qt++) {
                     B[qt] = *reinterpret_cast<const float4*>(sQ + (qt * 32 + lr) * ldq + (2 * s + sl) * 8 + 4 * hi);
                 }
 #pragma unroll
-                for (int qt = 0; qt < MS_NQT; qt++) {
+                for (int qt = 0; qt < NQT; qt++) {
 #pragma unroll
                     for (int t = 0; t < 2; t++) {
                         acc[t][qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Acur[t][sl].x, B[qt].x, acc[t][qt], 0, 0, 0);
@@ -351,8 +404,8 @@ __global__ __launch_bounds__(MS_THREADS, 4) void mscan_flat_kernel(MScanArgs a) 
             // ---- sample pass: the pessimistic distance of every (query, row), filtered rows as the neutral value ----
             const unsigned long long vmask = ms_valid_rows(a, b, len, row_off);
 #pragma unroll
-            for (int qt = 0; qt < MS_NQT; qt++) {
-                const float c = sT[qt * 32 + lr];
+            for (int qt = 0; qt < NQT; qt++) {
+                const float c = sC[qt * 32 + lr];
                 const int32_t q = sPq[qt * 32 + lr];
                 if (q >= 0) {
                     float* drow = a.dump + (int64_t)q * a.dump_stride + b * 64;
@@ -373,7 +426,7 @@ __global__ __launch_bounds__(MS_THREADS, 4) void mscan_flat_kernel(MScanArgs a) 
         }
         // ---- epilogue: one compare per (row, query); the slow path only where something passes -------------------
 #pragma unroll
-        for (int qt = 0; qt < MS_NQT; qt++) {
+        for (int qt = 0; qt < NQT; qt++) {
             const float thr = sT[qt * 32 + lr];
 #pragma unroll
             for (int t = 0; t < 2; t++) {
@@ -385,11 +438,13 @@ __global__ __launch_bounds__(MS_THREADS, 4) void mscan_flat_kernel(MScanArgs a) 
                 if (__ballot(m >= thr) != 0ull) {
                     if (m >= thr) {
                         const int32_t q = sPq[qt * 32 + lr], slot = sPs[qt * 32 + lr];
+                        const float c = sC[qt * 32 + lr];
 #pragma unroll
                         for (int r = 0; r < 16; r++) {
                             const int64_t pos = b * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                             if (acc[t][qt][r] >= thr && pos < len) {
-                                ms_emit(a, q, slot, row_off, pos);
+                                ms_emit<IS_L2>(a, q, slot, row_off, pos,
+                                               IS_L2 ? c - 2.0f * acc[t][qt][r] : acc[t][qt][r] - c);
                             }
                         }
                     }
@@ -569,11 +624,11 @@ __global__ __launch_bounds__(MQ_THREADS, 4) void mscan_sq8_kernel(MScanArgs a) {
             const float off = 1024.0f * sHL;
             nsc = -0.5f * sc;
             offv = off;
-            if (DUMP) {
-                u0 = IS_L2 ? (sR - 2.0f * sA + eps) : (dis0 + sA - eps);
-                vv = IS_L2 ? -2.0f / sc : 1.0f / sc;
-            } else {
-                const float tau = a.gthr[q];
+            u0 = IS_L2 ? (sR - 2.0f * sA + eps) : (dis0 + sA - eps);
+            vv = IS_L2 ? -2.0f / sc : 1.0f / sc;
+            if (!DUMP) {
+                float tau = a.gthr[q];
+                tau = tighter<IS_L2>(tau, ms_hist_bound<IS_L2>(a, q, a.k));
                 if (tau == worst_dist<IS_L2>() || !(mx < INFINITY)) {
                     // no bound (fewer than k unfiltered rows in the sample): every row would pass -> exact fallback
                     if (lane == 0) {
@@ -719,11 +774,12 @@ __global__ __launch_bounds__(MQ_THREADS, 4) void mscan_sq8_kernel(MScanArgs a) {
             if (__ballot(m >= thr) != 0ull) {
                 if (m >= thr) {
                     const int32_t q = sPq[lr], slot = sPs[lr];
+                    const float u0 = sU0[lr], vv = sV[lr], off = sOff[lr];
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
                         const int64_t pos = b * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                         if (acc[t][r] >= thr && pos < len) {
-                            ms_emit(a, q, slot, row_off, pos);
+                            ms_emit<IS_L2>(a, q, slot, row_off, pos, u0 + vv * (acc[t][r] - off));
                         }
                     }
                 }
@@ -732,19 +788,41 @@ __global__ __launch_bounds__(MQ_THREADS, 4) void mscan_sq8_kernel(MScanArgs a) {
     }
 }
 
-// ---- tau_q from the sample selection ---------------------------------------------------------------------------
-__global__ void ms_tau_kernel(const float* __restrict__ sel_d, int64_t nq, int k, float* __restrict__ gthr) {
+// ---- tau_q and the candidate histogram's range from the sample selection ---------------------------------------
+template <bool IS_L2>
+__global__ void ms_tau_kernel(const float* __restrict__ sel_d, int64_t nq, int k, float* __restrict__ gthr,
+                              uint2* __restrict__ gmeta) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q < nq) {
-        gthr[q] = sel_d[q * k + k - 1]; // the neutral value when the sample holds fewer than k unfiltered rows
+    if (q >= nq) {
+        return;
+    }
+    const float kth = sel_d[q * k + k - 1]; // the neutral value when the sample holds fewer than k unfiltered rows
+    gthr[q] = kth;
+    if (gmeta != nullptr) {
+        uint32_t lo = 0, shift = KN_HIST_OFF;
+        if (kth != worst_dist<IS_L2>() && kth == kth) {
+            lo = dist_key<IS_L2>(sel_d[q * k]);
+            const uint32_t range = dist_key<IS_L2>(kth) - lo;
+            shift = 0;
+            while ((range >> shift) >= (uint32_t)(KN_HIST_BINS - 1)) {
+                shift++;
+            }
+        }
+        gmeta[q] = make_uint2(lo, shift);
     }
 }
 
-hipError_t launch_ms_tau(const float* sel_d, int64_t nq, int k, float* gthr, hipStream_t s) {
+hipError_t launch_ms_tau(const float* sel_d, int64_t nq, int k, bool is_l2, float* gthr, uint2* gmeta, hipStream_t s) {
     if (nq <= 0) {
         return hipSuccess;
     }
-    hipLaunchKernelGGL(ms_tau_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, sel_d, nq, k, gthr);
+    if (is_l2) {
+        hipLaunchKernelGGL(ms_tau_kernel<true>, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, sel_d, nq, k, gthr,
+                           gmeta);
+    } else {
+        hipLaunchKernelGGL(ms_tau_kernel<false>, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, sel_d, nq, k, gthr,
+                           gmeta);
+    }
     return hipGetLastError();
 }
 
@@ -936,8 +1014,9 @@ hipError_t launch_ms_flag_pairs(const int32_t* overflow, const int64_t* keys, in
 }
 
 // ---- host launchers ---------------------------------------------------------------------------------------------
-int mscan_queries_per_unit(int kind) {
-    return kind == 1 ? MS_QT : MQ_QT;
+// queries per unit: filter pass / sample pass
+int mscan_queries_per_unit(int kind, bool sample) {
+    return kind == 1 ? (sample ? 32 : MS_QT) : MQ_QT;
 }
 
 size_t mscan_sq8_smem(int nstep) {
@@ -965,7 +1044,7 @@ hipError_t launch_mscan_sq8(const MScanArgs& a, bool is_l2, int64_t units_bound,
 }
 
 size_t mscan_flat_smem(int nstep) {
-    return (size_t)MS_QT * (nstep * 16 + 4) * 4 + (size_t)MS_QT * 12;
+    return (size_t)MS_QT * (nstep * 16 + 4) * 4 + (size_t)MS_QT * 16;
 }
 
 int mscan_sample_rows() {
@@ -976,10 +1055,10 @@ hipError_t launch_mscan_flat(const MScanArgs& a, bool is_l2, int64_t units_bound
     if (units_bound <= 0) {
         return hipSuccess;
     }
-    const size_t sm = mscan_flat_smem(a.nstep);
     const bool dump = a.dump != nullptr;
-    auto kern = is_l2 ? (dump ? mscan_flat_kernel<true, true> : mscan_flat_kernel<true, false>)
-                      : (dump ? mscan_flat_kernel<false, true> : mscan_flat_kernel<false, false>);
+    const size_t sm = dump ? (size_t)32 * (a.nstep * 16 + 4) * 4 + (size_t)32 * 16 : mscan_flat_smem(a.nstep);
+    auto kern = is_l2 ? (dump ? mscan_flat_kernel<true, true, 1> : mscan_flat_kernel<true, false, MS_NQT>)
+                      : (dump ? mscan_flat_kernel<false, true, 1> : mscan_flat_kernel<false, false, MS_NQT>);
     if (sm > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);

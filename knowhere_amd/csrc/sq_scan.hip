@@ -122,6 +122,8 @@ __device__ __forceinline__ void sq_scan_item(const SqScanArgs& a, const int64_t 
         for (int j = 0; j < QG; j++) {
             acc[j] = 0.f;
         }
+        constexpr int UF = QG <= 2 ? 4 : 1; // (few-query items: keep several code loads in flight)
+#pragma unroll UF
         for (int c = 0; c < a.nchunk16; c++) {
             const uint4 w = p[(int64_t)c * 64];
             const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
