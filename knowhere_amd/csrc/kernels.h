@@ -251,7 +251,7 @@ hipError_t launch_pq_cb_transpose(const float* cb, int M, int dsub, float4* cb_t
 int mscan_queries_per_unit(int kind, bool sample);
 size_t mscan_flat_smem(int nstep);
 size_t mscan_sq8_smem(int nstep);
-int mscan_finish_pmax(int cap);
+int mscan_finish_pmax(int cap, int k);
 int mscan_sample_rows();
 hipError_t launch_ms_block_norms(const float4* rows, int64_t total_blk, int nchunk, float* out, float* out_max,
                                  hipStream_t s);

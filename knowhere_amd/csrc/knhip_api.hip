@@ -640,9 +640,15 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             lds = mscan_sq8_smem(ms_nstep);
         }
         // candidate capacity per query: the finish kernel sorts them in LDS (a power of two entries)
-        ms_cap = 1024;
-        while (ms_cap < (int64_t)4 * nprobe * k && ms_cap < 8192) {
+        // candidate capacity per query (the finish kernel takes any number, in chunks): generous -- a query whose sample
+        // gave a loose bound collects thousands of rows before its histogram tightens it, and their exact distances
+        // cost far less than the exact scan of all its lists -- within ~3 GB of scratch per batch
+        ms_cap = 4096;
+        while (ms_cap < (int64_t)4 * nprobe * k && ms_cap < 32768) {
             ms_cap <<= 1;
+        }
+        while (ms_cap > 1024 && (double)ms_cap * (double)nq * 8.0 > 3.0e9) {
+            ms_cap >>= 1;
         }
         use_ms = lds <= 160 * 1024 - 1024 && ms_cap >= 2 * k &&
                 (idx->mscan == 1 || npairs >= 8 * nlist);
@@ -1020,7 +1026,7 @@ int64_t query_batch(const knhip_index* idx, int64_t nq, int k, int nprobe) {
     } else {
         per_q = (double)idx->nlist * 4.0 + (double)nprobe * (12.0 + 8.0 + (double)k * 12.0);
         if ((idx->desc.kind == KNHIP_IVF_FLAT || idx->desc.kind == KNHIP_IVF_SQ8) && idx->mscan != 0) {
-            per_q += 4.0 * mscan_sample_rows() + 8.0 * 8192.0; // sample dump + candidate list (mfma_scan.hip)
+            per_q += 4.0 * mscan_sample_rows() + 8.0 * 32768.0; // sample dump + candidate list (mfma_scan.hip)
         }
         if (idx->desc.kind == KNHIP_IVF_PQ) {
             per_q += 256.0 * idx->desc.pq_m * 4.0;

@@ -472,7 +472,7 @@ __global__ __launch_bounds__(MS_THREADS, 4) void mscan_flat_kernel(MScanArgs a) 
 // eps = eps_scale * sum_i |y_i| (|vmin_i| + 6 |vdiff_i|), eps_scale = 32 d 2^-24: the fp32 roundings of the exact
 // sequence, of A, off and y', the 2^-22 relative split error, and the fp32 accumulation of terms of magnitude
 // |y'_i| (1024 + 255) are each below d 2^-24 times that sum.
-constexpr int MQ_WAVES = 8;
+constexpr int MQ_WAVES = 16;
 constexpr int MQ_THREADS = MQ_WAVES * KN_WAVE;
 constexpr int MQ_QT = 32;
 
@@ -540,7 +540,7 @@ __device__ __forceinline__ void ms_codes_to_f16(const uint4 w, ms_f16x8& lo8, ms
 
 // DUMP: as in mscan_flat_kernel; the pessimistic distance is u0 + v (acc - off) with the per-pair constants below.
 template <bool IS_L2, bool DUMP>
-__global__ __launch_bounds__(MQ_THREADS, 4) void mscan_sq8_kernel(MScanArgs a) {
+__global__ __launch_bounds__(MQ_THREADS) void mscan_sq8_kernel(MScanArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = lane_id();
     const int wave = threadIdx.x / KN_WAVE;
@@ -679,71 +679,63 @@ __global__ __launch_bounds__(MQ_THREADS, 4) void mscan_sq8_kernel(MScanArgs a) {
             A[1] = make_uint4(0, 0, 0, 0);
         }
     };
-    // code loads run three steps ahead of the MFMAs that consume them (one workgroup per CU at d = 768: the loads
-    // in flight per wave are what covers the HBM latency)
-    uint4 A0[2], A1[2], A2[2], A3[2];
-    int64_t nb = wave;
-    int ns = 0;
-    auto advance = [&]() {
-        if (++ns == nstep) {
-            ns = 0;
-            nb += MQ_WAVES;
+    // Code loads run THREE steps ahead of the MFMAs that consume them, in four statically rotating register sets
+    // (the step loop is flattened over this wave's blocks and unrolled by four: a copy-rotation would make every
+    // step wait for the newest load).  At d = 768 one workgroup fills a CU's LDS, so its 16 waves x 3 x 2 KiB in
+    // flight are what covers the HBM latency.
+    uint4 A[4][2];
+    int64_t lb = wave; // load cursor
+    int ls = 0;
+    auto issue = [&](uint4 (&dst)[2]) {
+        load_step(lb, ls, dst);
+        if (++ls == nstep) {
+            ls = 0;
+            lb += MQ_WAVES;
         }
     };
-    load_step(nb, ns, A0);
-    advance();
-    load_step(nb, ns, A1);
-    advance();
-    load_step(nb, ns, A2);
-    advance();
+    issue(A[0]);
+    issue(A[1]);
+    issue(A[2]);
     const float thr = sT[lr];
-    for (int64_t b = wave; b < nblk; b += MQ_WAVES) {
-        ms_f32x16 acc[2];
-        {
-            ms_f32x16 z;
+    ms_f32x16 acc[2];
+    auto init_acc = [&](int64_t b) {
+        ms_f32x16 z;
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                z[r] = 0.f;
-            }
-            acc[0] = z;
-            acc[1] = z;
-            if (IS_L2) {
-                float xn0 = 0.f, xn1 = 0.f, bs = 0.f;
-                if (hi == 0) {
-                    xn0 = a.xnorm[(blk0 + b) * 64 + lr];
-                    xn1 = a.xnorm[(blk0 + b) * 64 + 32 + lr];
-                    bs = sSc[lr];
-                }
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xn0, bs, z, 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xn1, bs, z, 0, 0, 0);
-            }
+        for (int r = 0; r < 16; r++) {
+            z[r] = 0.f;
         }
-        for (int s = 0; s < nstep; s++) {
-            load_step(nb, ns, A3);
-            advance();
-            ms_f16x8 Bh[2], Bl[2];
+        acc[0] = z;
+        acc[1] = z;
+        if (IS_L2 && b < nblk) {
+            float xn0 = 0.f, xn1 = 0.f, bs = 0.f;
+            if (hi == 0) {
+                xn0 = a.xnorm[(blk0 + b) * 64 + lr];
+                xn1 = a.xnorm[(blk0 + b) * 64 + 32 + lr];
+                bs = sSc[lr];
+            }
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xn0, bs, z, 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xn1, bs, z, 0, 0, 0);
+        }
+    };
+    auto compute = [&](const uint4 (&Ac)[2], int s) {
+        ms_f16x8 Bh[2], Bl[2];
+#pragma unroll
+        for (int e8 = 0; e8 < 2; e8++) {
+            Bh[e8] = *reinterpret_cast<const ms_f16x8*>(sH + lr * ldh + 32 * s + 16 * hi + 8 * e8);
+            Bl[e8] = *reinterpret_cast<const ms_f16x8*>(sL + lr * ldh + 32 * s + 16 * hi + 8 * e8);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            ms_f16x8 Af[2];
+            ms_codes_to_f16(Ac[t], Af[0], Af[1]);
 #pragma unroll
             for (int e8 = 0; e8 < 2; e8++) {
-                Bh[e8] = *reinterpret_cast<const ms_f16x8*>(sH + lr * ldh + 32 * s + 16 * hi + 8 * e8);
-                Bl[e8] = *reinterpret_cast<const ms_f16x8*>(sL + lr * ldh + 32 * s + 16 * hi + 8 * e8);
-            }
-#pragma unroll
-            for (int t = 0; t < 2; t++) {
-                ms_f16x8 Af[2];
-                ms_codes_to_f16(A0[t], Af[0], Af[1]);
-#pragma unroll
-                for (int e8 = 0; e8 < 2; e8++) {
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[e8], Bh[e8], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[e8], Bl[e8], acc[t], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < 2; t++) {
-                A0[t] = A1[t];
-                A1[t] = A2[t];
-                A2[t] = A3[t];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[e8], Bh[e8], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[e8], Bl[e8], acc[t], 0, 0, 0);
             }
         }
+    };
+    auto epilogue = [&](int64_t b) {
         if (DUMP) {
             const unsigned long long vmask = ms_valid_rows(a, b, len, row_off);
             const int32_t q = sPq[lr];
@@ -762,7 +754,7 @@ __global__ __launch_bounds__(MQ_THREADS, 4) void mscan_sq8_kernel(MScanArgs a) {
                     }
                 }
             }
-            continue;
+            return;
         }
 #pragma unroll
         for (int t = 0; t < 2; t++) {
@@ -782,6 +774,26 @@ __global__ __launch_bounds__(MQ_THREADS, 4) void mscan_sq8_kernel(MScanArgs a) {
                             ms_emit<IS_L2>(a, q, slot, row_off, pos, u0 + vv * (acc[t][r] - off));
                         }
                     }
+                }
+            }
+        }
+    };
+    int64_t b = wave; // compute cursor
+    int s = 0;
+    const int64_t nbw = nblk > wave ? (nblk - wave + MQ_WAVES - 1) / MQ_WAVES : 0;
+    const int64_t G = nbw * nstep;
+    init_acc(b);
+    for (int64_t g = 0; g < G; g += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (g + u < G) {
+                issue(A[(u + 3) & 3]);
+                compute(A[u], s);
+                if (++s == nstep) {
+                    epilogue(b);
+                    s = 0;
+                    b += MQ_WAVES;
+                    init_acc(b);
                 }
             }
         }
@@ -827,8 +839,9 @@ hipError_t launch_ms_tau(const float* sel_d, int64_t nq, int k, bool is_l2, floa
 }
 
 // ---- exact finish ---------------------------------------------------------------------------------------------
-// One workgroup per query: exact distances of the candidates (thread per candidate, reference operation order),
-// bitonic sort by (distance key, id tie key), first k out.
+// One workgroup per query: exact distances of the candidates (thread per candidate, reference operation order) and a
+// running top-k kept through chunks: LDS slots [0, k) hold the best so far, slots [k, P) the next chunk of candidates;
+// bitonic sort by (distance key, id tie key); repeat.  Any number of candidates, canonical order throughout.
 constexpr int MF_THREADS = 256;
 
 template <bool IS_L2, int KIND> // KIND 1: fp32 rows, 3: SQ8
@@ -854,9 +867,10 @@ __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, c
         atomicAdd(counters + 2, (unsigned long long)n);
     }
     int P = 2;
-    while (P < n) {
+    while (P < n + k && P < P_max) {
         P <<= 1;
     }
+    const int chunk = P - k; // candidates per round (P_max >= 2 k)
     // LDS: tie[P_max] (u64) | key[P_max] (u32) | query [dq] floats (| vmin, vdiff for SQ8)
     unsigned long long* tie = reinterpret_cast<unsigned long long*>(smem);
     uint32_t* key = reinterpret_cast<uint32_t*>(smem + (size_t)P_max * 8);
@@ -874,90 +888,97 @@ __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, c
     if (KIND == 3 && tid < 256) {
         tab[tid] = __fdiv_rn((float)tid + 0.5f, 255.0f); // Codec8bit::decode_component
     }
-    __syncthreads();
-    for (int e = tid; e < P; e += MF_THREADS) {
-        uint32_t kk = 0xffffffffu;
-        unsigned long long tt = ~0ull;
-        if (e < n) {
-            const int64_t c = a.cand[q * (int64_t)a.cap + e];
-            const int slot = (int)(c >> 32);
-            const int64_t pos = (int64_t)(uint32_t)c;
-            const int64_t list = keys[q * nprobe + slot];
-            const int64_t blk = a.list_blk_off[list] + (pos >> 6);
-            const int r = (int)(pos & 63);
-            float acc = 0.f;
-            if (KIND == 1) {
-                const float4* p = reinterpret_cast<const float4*>(a.rows) + blk * (int64_t)a.nchunk * 64 + r;
-                for (int c4 = 0; c4 < a.nchunk; c4++) {
-                    const float4 y = p[(int64_t)c4 * 64];
-                    const float4 x = *reinterpret_cast<const float4*>(sq + c4 * 4);
-                    if (IS_L2) {
-                        acc = l2_step(acc, x.x, y.x);
-                        acc = l2_step(acc, x.y, y.y);
-                        acc = l2_step(acc, x.z, y.z);
-                        acc = l2_step(acc, x.w, y.w);
-                    } else {
-                        acc = ip_step(acc, x.x, y.x);
-                        acc = ip_step(acc, x.y, y.y);
-                        acc = ip_step(acc, x.z, y.z);
-                        acc = ip_step(acc, x.w, y.w);
-                    }
-                }
-            } else {
-                const uint4* p = reinterpret_cast<const uint4*>(a.rows) + blk * (int64_t)a.nchunk * 64 + r;
-                const float* cen = a.centroids + list * d;
-                for (int c16 = 0; c16 < a.nchunk; c16++) {
-                    const uint4 w = p[(int64_t)c16 * 64];
-                    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-                    for (int e2 = 0; e2 < 16; e2++) {
-                        const int i = c16 * 16 + e2;
-                        const uint32_t code = (ww[e2 >> 2] >> (8 * (e2 & 3))) & 0xffu;
-                        const float x = fadd_x(svmin[i], fmul_x(tab[code], svdiff[i]));
-                        if (IS_L2) {
-                            // padded dims: y = 0, x = 0: they add exactly +0
-                            const float y = (i < d) ? fsub_x(sq[i], cen[i]) : 0.f;
-                            acc = l2_step(acc, y, x);
-                        } else {
-                            acc = ip_step(acc, sq[i], x);
-                        }
-                    }
-                }
-                if (!IS_L2) {
-                    acc = fadd_x(coarse_dis[q * nprobe + slot], acc);
-                }
-            }
-            const int64_t id = a.ids[a.list_row_off[list] + pos];
-            kk = dist_key<IS_L2>(acc);
-            tt = IS_L2 ? (unsigned long long)id : ~(unsigned long long)id;
-        }
-        key[e] = kk;
-        tie[e] = tt;
+    for (int e = tid; e < k; e += MF_THREADS) { // the running top-k starts empty
+        key[e] = 0xffffffffu;
+        tie[e] = ~0ull;
     }
     __syncthreads();
-    for (int size = 2; size <= P; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = tid; t < P / 2; t += MF_THREADS) {
-                const int lo = (t / stride) * stride * 2 + (t % stride);
-                const int hi = lo + stride;
-                const bool up = ((lo & size) == 0);
-                const uint32_t ka = key[lo], kb = key[hi];
-                const unsigned long long ta = tie[lo], tb = tie[hi];
-                const bool gt = (ka > kb) || (ka == kb && ta > tb);
-                if (gt == up) {
-                    key[lo] = kb;
-                    key[hi] = ka;
-                    tie[lo] = tb;
-                    tie[hi] = ta;
+    for (int base = 0; base < n || base == 0; base += chunk) {
+        for (int e = k + tid; e < P; e += MF_THREADS) {
+            uint32_t kk = 0xffffffffu;
+            unsigned long long tt = ~0ull;
+            const int ci = base + (e - k);
+            if (ci < n) {
+                const int64_t c = a.cand[q * (int64_t)a.cap + ci];
+                const int slot = (int)(c >> 32);
+                const int64_t pos = (int64_t)(uint32_t)c;
+                const int64_t list = keys[q * nprobe + slot];
+                const int64_t blk = a.list_blk_off[list] + (pos >> 6);
+                const int r = (int)(pos & 63);
+                float acc = 0.f;
+                if (KIND == 1) {
+                    const float4* p = reinterpret_cast<const float4*>(a.rows) + blk * (int64_t)a.nchunk * 64 + r;
+                    for (int c4 = 0; c4 < a.nchunk; c4++) {
+                        const float4 y = p[(int64_t)c4 * 64];
+                        const float4 x = *reinterpret_cast<const float4*>(sq + c4 * 4);
+                        if (IS_L2) {
+                            acc = l2_step(acc, x.x, y.x);
+                            acc = l2_step(acc, x.y, y.y);
+                            acc = l2_step(acc, x.z, y.z);
+                            acc = l2_step(acc, x.w, y.w);
+                        } else {
+                            acc = ip_step(acc, x.x, y.x);
+                            acc = ip_step(acc, x.y, y.y);
+                            acc = ip_step(acc, x.z, y.z);
+                            acc = ip_step(acc, x.w, y.w);
+                        }
+                    }
+                } else {
+                    const uint4* p = reinterpret_cast<const uint4*>(a.rows) + blk * (int64_t)a.nchunk * 64 + r;
+                    const float* cen = a.centroids + list * d;
+                    for (int c16 = 0; c16 < a.nchunk; c16++) {
+                        const uint4 w = p[(int64_t)c16 * 64];
+                        const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                        for (int e2 = 0; e2 < 16; e2++) {
+                            const int i = c16 * 16 + e2;
+                            const uint32_t code = (ww[e2 >> 2] >> (8 * (e2 & 3))) & 0xffu;
+                            const float x = fadd_x(svmin[i], fmul_x(tab[code], svdiff[i]));
+                            if (IS_L2) {
+                                // padded dims: y = 0, x = 0: they add exactly +0
+                                const float y = (i < d) ? fsub_x(sq[i], cen[i]) : 0.f;
+                                acc = l2_step(acc, y, x);
+                            } else {
+                                acc = ip_step(acc, sq[i], x);
+                            }
+                        }
+                    }
+                    if (!IS_L2) {
+                        acc = fadd_x(coarse_dis[q * nprobe + slot], acc);
+                    }
                 }
+                const int64_t id = a.ids[a.list_row_off[list] + pos];
+                kk = dist_key<IS_L2>(acc);
+                tt = IS_L2 ? (unsigned long long)id : ~(unsigned long long)id;
             }
-            __syncthreads();
+            key[e] = kk;
+            tie[e] = tt;
+        }
+        __syncthreads();
+        for (int size = 2; size <= P; size <<= 1) {
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int t = tid; t < P / 2; t += MF_THREADS) {
+                    const int lo = (t / stride) * stride * 2 + (t % stride);
+                    const int hi = lo + stride;
+                    const bool up = ((lo & size) == 0);
+                    const uint32_t ka = key[lo], kb = key[hi];
+                    const unsigned long long ta = tie[lo], tb = tie[hi];
+                    const bool gt = (ka > kb) || (ka == kb && ta > tb);
+                    if (gt == up) {
+                        key[lo] = kb;
+                        key[hi] = ka;
+                        tie[lo] = tb;
+                        tie[hi] = ta;
+                    }
+                }
+                __syncthreads();
+            }
         }
     }
     for (int e = tid; e < k; e += MF_THREADS) {
         float dd = worst_dist<IS_L2>();
         int64_t ii = -1;
-        if (e < n) { // (entries [n, P) are padding and sort behind every candidate)
+        if (!(key[e] == 0xffffffffu && tie[e] == ~0ull)) {
             dd = dist_key_inv<IS_L2>(key[e]);
             ii = (int64_t)(IS_L2 ? tie[e] : ~tie[e]);
         }
@@ -1071,11 +1092,13 @@ hipError_t launch_mscan_flat(const MScanArgs& a, bool is_l2, int64_t units_bound
     return hipGetLastError();
 }
 
-int mscan_finish_pmax(int cap) {
-    int P = 2;
-    while (P < cap) {
+// LDS entries of the finish kernel's sort: k running best + a chunk of candidates
+int mscan_finish_pmax(int cap, int k) {
+    int P = 1024;
+    while (P < 2 * k) {
         P <<= 1;
     }
+    (void)cap;
     return P;
 }
 
@@ -1085,7 +1108,7 @@ hipError_t launch_mscan_finish(const MScanArgs& a, int kind, bool is_l2, const i
     if (a.nq <= 0) {
         return hipSuccess;
     }
-    const int P_max = mscan_finish_pmax(a.cap);
+    const int P_max = mscan_finish_pmax(a.cap, k);
     const int dq = kind == 1 ? a.nchunk * 4 : a.nchunk * 16;
     const size_t sm = (size_t)P_max * 12 + (size_t)dq * 4 * (kind == 1 ? 1 : 3);
 #define MF_LAUNCH(L2_, KIND_)                                                                                   \
