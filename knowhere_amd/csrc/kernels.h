@@ -202,6 +202,8 @@ struct MScanArgs {
     uint32_t* ghist;
     const uint2* gmeta;
     int32_t k;
+    // sample plan: first dump column of pair (q, slot), or -1 when the pair is not part of the sample
+    const int32_t* sample_off;
 };
 
 // ---- flat_scan.hip ----
@@ -263,6 +265,8 @@ hipError_t launch_ms_units(const int32_t* list_count_v, const int64_t* list_pair
                            int64_t code_size, double* unit_bytes, hipStream_t s);
 hipError_t launch_mscan_flat(const MScanArgs& a, bool is_l2, int64_t units_bound, hipStream_t s);
 hipError_t launch_mscan_sq8(const MScanArgs& a, bool is_l2, int64_t units_bound, hipStream_t s);
+hipError_t launch_ms_sample_plan(const int64_t* keys, int64_t nq, int nprobe, int64_t nlist, const int64_t* list_len,
+                                 int smin, int32_t* sample_off, int32_t* n_row, hipStream_t s);
 hipError_t launch_ms_tau(const float* sel_d, int64_t nq, int k, bool is_l2, float* gthr, uint2* gmeta, hipStream_t s);
 hipError_t launch_mscan_finish(const MScanArgs& a, int kind, bool is_l2, const int64_t* keys, const float* coarse_dis,
                                int nprobe, int k, float* out_d, int64_t* out_i, unsigned long long* counters,
@@ -295,7 +299,7 @@ struct WorkTable {
 };
 hipError_t launch_build_worktable(const int64_t* keys, int64_t nq, int nprobe, int64_t nlist, int qg0, int qg1,
                                   const int64_t* list_len, int64_t code_size, const WorkTable& wt,
-                                  hipStream_t s, int rank0_slot = 0);
+                                  hipStream_t s, int rank0_slot = 0, const int32_t* cls = nullptr);
 hipError_t launch_fill_f32(float* p, int64_t n, float v, hipStream_t s);
 
 // ---- range.hip: range search epilogue over a dumped distance matrix ----
@@ -331,7 +335,7 @@ hipError_t launch_row_select(const float* vals, int64_t nrows, int64_t n, int k,
 // rows of different length: row r has n = list_len[keys[r * key_stride]] values at vals + r * stride
 hipError_t launch_row_select_var(const float* vals, int64_t stride, const int64_t* keys, int key_stride,
                                  const int64_t* list_len, int64_t nrows, int k, bool is_l2, int64_t* out_keys,
-                                 float* out_d, hipStream_t s, int64_t n_cap = 0);
+                                 float* out_d, hipStream_t s, int64_t n_cap = 0, const int32_t* n_row = nullptr);
 size_t row_select_max_k();
 
 // ---- coarse_gemm.hip: fp32 MFMA prefilter for the coarse quantizer ----

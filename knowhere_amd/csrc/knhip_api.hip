@@ -126,6 +126,7 @@ struct Workspace {
     DevBuf list_count, list_pair_off, list_item_off, list_cursor, pairs, items, nitems;
     // MFMA prefilter of the IVF-Flat / IVF-SQ8 scans (mfma_scan.hip)
     DevBuf ms_units, ms_unit_off, ms_nunits, ms_cand, ms_cand_cnt;  // ms_cand_cnt: [qb] counters + [qb + 1] overflow flags
+    DevBuf ms_sample_off, ms_nrow;                                   // sample plan: [qb][nprobe] dump columns, [qb] rows
     // host-boundary staging
     DevBuf h_queries, h_bitset, h_out_d, h_out_i, h_ref_d, h_ref_i;
     std::mutex mu;  // held while a *_device entry point enqueues on this (per-stream) workspace
@@ -678,8 +679,19 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
     wt.k = k;
     {
         StageTimer t(idx, s, KNHIP_STAGE_GROUP);
+        const int32_t* cls = nullptr;
+        if (use_ms) {
+            // the first class of the split = the pairs whose rows feed tau_q (mfma_scan.hip sample plan): the probes in
+            // coarse order until max(1024, 8 k) rows are covered
+            HIP_TRY(ws->ms_sample_off.reserve((size_t)npairs * sizeof(int32_t)));
+            HIP_TRY(ws->ms_nrow.reserve((size_t)nq * sizeof(int32_t)));
+            HIP_TRY(launch_ms_sample_plan(keys_p, nq, nprobe, nlist, idx->d_list_len.as<int64_t>(),
+                                          std::max(1024, 8 * k), ws->ms_sample_off.as<int32_t>(),
+                                          ws->ms_nrow.as<int32_t>(), s));
+            cls = ws->ms_sample_off.as<int32_t>();
+        }
         HIP_TRY(launch_build_worktable(keys_p, nq, nprobe, nlist, qg_rank0, qg_bulk,
-                                       idx->d_list_len.as<int64_t>(), idx->code_size, wt, s));
+                                       idx->d_list_len.as<int64_t>(), idx->code_size, wt, s, 0, cls));
     }
     {
         std::lock_guard<std::mutex> lk(idx->mu);
@@ -694,7 +706,10 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         const int qt = mscan_queries_per_unit(kind, false), qt0 = mscan_queries_per_unit(kind, true);
         const int64_t units_bound = round_up(npairs / qt + std::min<int64_t>(nlist, npairs) + 1, 8);
         const int64_t sample = mscan_sample_rows();
-        HIP_TRY(ws->ms_units.reserve((size_t)units_bound * sizeof(KnItem)));
+        // (a query samples at most `sample` rows of non-empty lists: at most that many pairs)
+        const int64_t np0 = std::min<int64_t>(npairs, nq * std::min<int64_t>(nprobe, sample));
+        const int64_t bound0 = round_up(np0 / qt0 + std::min<int64_t>(nlist, np0) + 1, 8);
+        HIP_TRY(ws->ms_units.reserve((size_t)std::max(units_bound, bound0) * sizeof(KnItem)));
         HIP_TRY(ws->ms_unit_off.reserve((size_t)(nlist + 1) * sizeof(int64_t)));
         HIP_TRY(ws->ms_nunits.reserve(sizeof(int64_t) + 2 * sizeof(double)));
         HIP_TRY(ws->ms_cand.reserve((size_t)nq * ms_cap * sizeof(int64_t)));
@@ -759,14 +774,15 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             ds.dump = ws->dump.as<float>();
             ds.dump_stride = sample;
             ds.ghist = nullptr;
-            const int64_t bound0 = round_up(nq / qt0 + std::min<int64_t>(nlist, nq) + 1, 8);
+            ds.sample_off = ws->ms_sample_off.as<int32_t>();
             if (kind == KNHIP_IVF_FLAT) {
                 HIP_TRY(launch_mscan_flat(ds, is_l2, bound0, s));
             } else {
                 HIP_TRY(launch_mscan_sq8(ds, is_l2, bound0, s));
             }
             HIP_TRY(launch_row_select_var(ws->dump.as<float>(), sample, keys_p, nprobe, idx->d_list_len.as<int64_t>(),
-                                          nq, k, is_l2, ws->sel_keys.as<int64_t>(), ws->sel_d.as<float>(), s, sample));
+                                          nq, k, is_l2, ws->sel_keys.as<int64_t>(), ws->sel_d.as<float>(), s, sample,
+                                          ws->ms_nrow.as<int32_t>()));
             HIP_TRY(launch_ms_tau(ws->sel_d.as<float>(), nq, k, is_l2, ws->gthr.as<float>(), ws->gmeta.as<uint2>(), s));
         }
         {

@@ -275,6 +275,9 @@ __global__ __launch_bounds__(MS_THREADS, 4) void mscan_flat_kernel(MScanArgs a) 
             const float qn = a.qnorm[q];
             const float eps = a.eps_scale * (IS_L2 ? (qn + a.xnorm_max) : sqrtf(qn * a.xnorm_max)) + 1e-30f;
             c = IS_L2 ? qn + eps : eps;
+            if (DUMP) {
+                slot = a.sample_off[(int64_t)q * a.nslot + slot]; // (sPs then holds the pair's first dump column)
+            }
             if (!DUMP) {
                 float tau = a.gthr[q];
                 tau = tighter<IS_L2>(tau, ms_hist_bound<IS_L2>(a, q, a.k));
@@ -318,88 +321,83 @@ __global__ __launch_bounds__(MS_THREADS, 4) void mscan_flat_kernel(MScanArgs a) 
     if (DUMP) {
         nblk = min(nblk, (int64_t)(MS_SAMPLE / 64));
     }
+    if (nblk <= 0) {
+        return;
+    }
     const float4* rows = reinterpret_cast<const float4*>(a.rows) + blk0 * (int64_t)nchunk * 64;
     // A operand of one step (16 dims): [row tile][8-dim slab]: chunk 4 s + 2 slab + hi of row tile * 32 + lr
+    // Branch-free on purpose: a load inside a conditional makes the compiler wait for it at the join (vmcnt(0) right
+    // behind the load: no prefetch at all).  A prefetch past this wave's last block re-reads that block (never used);
+    // a chunk past the last one (odd chunk counts) re-reads the last chunk, whose query operand is zero-padded in LDS.
     auto load_step = [&](int64_t b, int s, float4 (&A)[2][2]) {
+        const int64_t bb = min(b, nblk - 1);
 #pragma unroll
         for (int sl = 0; sl < 2; sl++) {
-            const int c = 4 * s + 2 * sl + hi;
-            if (b < nblk && c < nchunk) {
-                const float4* p = rows + (b * nchunk + c) * 64 + lr;
-                A[0][sl] = p[0];
-                A[1][sl] = p[32];
-            } else {
-                A[0][sl] = make_float4(0.f, 0.f, 0.f, 0.f);
-                A[1][sl] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            const int c = min(4 * s + 2 * sl + hi, nchunk - 1);
+            const float4* p = rows + (bb * nchunk + c) * 64 + lr;
+            A[0][sl] = p[0];
+            A[1][sl] = p[32];
         }
     };
-    float4 Acur[2][2], Anxt[2][2];
-    int64_t nb = wave; // position of the next load
-    int ns = 0;
-    load_step(nb, ns, Acur);
-    if (++ns == nstep) {
-        ns = 0;
-        nb += MS_WAVES;
-    }
-    for (int64_t b = wave; b < nblk; b += MS_WAVES) {
-        ms_f32x16 acc[2][NQT];
-        {
-            // L2: acc = -||x||^2 / 2 for the tile's rows (k = 0 carries the norm, k = 1 nothing)
-            float xn0 = 0.f, xn1 = 0.f;
-            if (IS_L2 && hi == 0) {
-                xn0 = a.xnorm[(blk0 + b) * 64 + lr];
-                xn1 = a.xnorm[(blk0 + b) * 64 + 32 + lr];
-            }
-            const float mh = (IS_L2 && hi == 0) ? -0.5f : 0.f;
-            ms_f32x16 z;
+    // Two statically rotating row buffers: the loads of step g + 1 are issued (and pinned there: sched_barrier) before
+    // the 32 MFMAs of step g.  The step loop is flattened over this wave's blocks and unrolled by two; both
+    // sub-steps are unconditional (a load behind a branch is waited for at its join).
+    float4 A[2][2][2];
+    int64_t lb = wave; // load cursor
+    int ls = 0;
+    auto issue = [&](float4 (&dst)[2][2]) {
+        load_step(lb, ls, dst);
+        if (++ls == nstep) {
+            ls = 0;
+            lb += MS_WAVES;
+        }
+    };
+    ms_f32x16 acc[2][NQT];
+    auto init_acc = [&](int64_t b) {
+        // L2: acc = -||x||^2 / 2 for the tile's rows (k = 0 carries the norm, k = 1 nothing)
+        ms_f32x16 z;
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                z[r] = 0.f;
-            }
-            ms_f32x16 i0 = z, i1 = z;
-            if (IS_L2) {
-                i0 = __builtin_amdgcn_mfma_f32_32x32x2f32(xn0, mh, z, 0, 0, 0);
-                i1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xn1, mh, z, 0, 0, 0);
+        for (int r = 0; r < 16; r++) {
+            z[r] = 0.f;
+        }
+        ms_f32x16 i0 = z, i1 = z;
+        if (IS_L2) {
+            const int64_t bb = min(b, nblk - 1);
+            float xn0 = a.xnorm[(blk0 + bb) * 64 + lr];
+            float xn1 = a.xnorm[(blk0 + bb) * 64 + 32 + lr];
+            xn0 = hi == 0 ? xn0 : 0.f;
+            xn1 = hi == 0 ? xn1 : 0.f;
+            const float mh = hi == 0 ? -0.5f : 0.f;
+            i0 = __builtin_amdgcn_mfma_f32_32x32x2f32(xn0, mh, z, 0, 0, 0);
+            i1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xn1, mh, z, 0, 0, 0);
+        }
+#pragma unroll
+        for (int qt = 0; qt < NQT; qt++) {
+            acc[0][qt] = i0;
+            acc[1][qt] = i1;
+        }
+    };
+    auto compute = [&](const float4 (&Ac)[2][2], int s) {
+#pragma unroll
+        for (int sl = 0; sl < 2; sl++) {
+            float4 B[NQT];
+#pragma unroll
+            for (int qt = 0; qt < NQT; qt++) {
+                B[qt] = *reinterpret_cast<const float4*>(sQ + (qt * 32 + lr) * ldq + (2 * s + sl) * 8 + 4 * hi);
             }
 #pragma unroll
             for (int qt = 0; qt < NQT; qt++) {
-                acc[0][qt] = i0;
-                acc[1][qt] = i1;
-            }
-        }
-        for (int s = 0; s < nstep; s++) {
-            load_step(nb, ns, Anxt); // one step ahead (crosses into this wave's next block)
-            if (++ns == nstep) {
-                ns = 0;
-                nb += MS_WAVES;
-            }
 #pragma unroll
-            for (int sl = 0; sl < 2; sl++) {
-                float4 B[NQT];
-#pragma unroll
-                for (int qt = 0; qt < NQT; qt++) {
-                    B[qt] = *reinterpret_cast<const float4*>(sQ + (qt * 32 + lr) * ldq + (2 * s + sl) * 8 + 4 * hi);
-                }
-#pragma unroll
-                for (int qt = 0; qt < NQT; qt++) {
-#pragma unroll
-                    for (int t = 0; t < 2; t++) {
-                        acc[t][qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Acur[t][sl].x, B[qt].x, acc[t][qt], 0, 0, 0);
-                        acc[t][qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Acur[t][sl].y, B[qt].y, acc[t][qt], 0, 0, 0);
-                        acc[t][qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Acur[t][sl].z, B[qt].z, acc[t][qt], 0, 0, 0);
-                        acc[t][qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Acur[t][sl].w, B[qt].w, acc[t][qt], 0, 0, 0);
-                    }
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < 2; t++) {
-#pragma unroll
-                for (int sl = 0; sl < 2; sl++) {
-                    Acur[t][sl] = Anxt[t][sl];
+                for (int t = 0; t < 2; t++) {
+                    acc[t][qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[t][sl].x, B[qt].x, acc[t][qt], 0, 0, 0);
+                    acc[t][qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[t][sl].y, B[qt].y, acc[t][qt], 0, 0, 0);
+                    acc[t][qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[t][sl].z, B[qt].z, acc[t][qt], 0, 0, 0);
+                    acc[t][qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[t][sl].w, B[qt].w, acc[t][qt], 0, 0, 0);
                 }
             }
         }
+    };
+    auto epilogue = [&](int64_t b) {
         if (DUMP) {
             // ---- sample pass: the pessimistic distance of every (query, row), filtered rows as the neutral value ----
             const unsigned long long vmask = ms_valid_rows(a, b, len, row_off);
@@ -408,13 +406,15 @@ __global__ __launch_bounds__(MS_THREADS, 4) void mscan_flat_kernel(MScanArgs a) 
                 const float c = sC[qt * 32 + lr];
                 const int32_t q = sPq[qt * 32 + lr];
                 if (q >= 0) {
-                    float* drow = a.dump + (int64_t)q * a.dump_stride + b * 64;
+                    const int32_t off = sPs[qt * 32 + lr];
+                    const int64_t lim = min(len, (int64_t)(MS_SAMPLE - off));
+                    float* drow = a.dump + (int64_t)q * a.dump_stride + off + b * 64;
 #pragma unroll
                     for (int t = 0; t < 2; t++) {
 #pragma unroll
                         for (int r = 0; r < 16; r++) {
                             const int i = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                            if (b * 64 + i < len) {
+                            if (b * 64 + i < lim) {
                                 const float v = IS_L2 ? c - 2.0f * acc[t][qt][r] : acc[t][qt][r] - c;
                                 drow[i] = ((vmask >> i) & 1ull) ? v : worst_dist<IS_L2>();
                             }
@@ -422,9 +422,9 @@ __global__ __launch_bounds__(MS_THREADS, 4) void mscan_flat_kernel(MScanArgs a) 
                     }
                 }
             }
-            continue;
+            return;
         }
-        // ---- epilogue: one compare per (row, query); the slow path only where something passes -------------------
+        // ---- filter: one compare per (row, query); the slow path only where something passes ----------------------
 #pragma unroll
         for (int qt = 0; qt < NQT; qt++) {
             const float thr = sT[qt * 32 + lr];
@@ -449,6 +449,28 @@ __global__ __launch_bounds__(MS_THREADS, 4) void mscan_flat_kernel(MScanArgs a) 
                         }
                     }
                 }
+            }
+        }
+    };
+    issue(A[0]);
+    int64_t b = wave; // compute cursor
+    int s = 0;
+    const int64_t nbw = nblk > wave ? (nblk - wave + MS_WAVES - 1) / MS_WAVES : 0;
+    const int64_t G = nbw * nstep;
+    init_acc(b);
+    for (int64_t g = 0; g < G; g += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            issue(A[u ^ 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(A[u], s);
+            if (++s == nstep) {
+                if (b < nblk) {
+                    epilogue(b);
+                }
+                s = 0;
+                b += MS_WAVES;
+                init_acc(b);
             }
         }
     }
@@ -583,6 +605,10 @@ __global__ __launch_bounds__(MQ_THREADS) void mscan_sq8_kernel(MScanArgs a) {
             const KnPair p = a.pairs[it.pair0 + j];
             q = p.q;
             slot = p.slot;
+            const int32_t slot_in = slot;
+            if (DUMP) {
+                slot = a.sample_off[(int64_t)q * a.nslot + slot]; // (sPs then holds the pair's first dump column)
+            }
             const float* qv = a.queries + (int64_t)q * d;
             float mx = 0.f;
             for (int i = lane; i < d; i += KN_WAVE) {
@@ -618,7 +644,7 @@ __global__ __launch_bounds__(MQ_THREADS) void mscan_sq8_kernel(MScanArgs a) {
             sW = ms_wave_sum(sW);
             sHL = ms_wave_sum(sHL);
             sR = ms_wave_sum(sR);
-            const float dis0 = IS_L2 ? 0.f : a.coarse_dis[(int64_t)q * a.nslot + slot];
+            const float dis0 = IS_L2 ? 0.f : a.coarse_dis[(int64_t)q * a.nslot + slot_in];
             // (the constants below are themselves rounded: a few ulp of the magnitudes they are formed from go on top)
             const float eps = a.eps_scale * sW + 1e-6f * (fabsf(dis0) + fabsf(sA) + sR) + 1e-30f;
             const float off = 1024.0f * sHL;
@@ -667,17 +693,17 @@ __global__ __launch_bounds__(MQ_THREADS) void mscan_sq8_kernel(MScanArgs a) {
     if (DUMP) {
         nblk = min(nblk, (int64_t)(MS_SAMPLE / 64));
     }
+    if (nblk <= 0) {
+        return;
+    }
     const uint4* rows = reinterpret_cast<const uint4*>(a.rows) + blk0 * (int64_t)nchunk * 64;
+    // branch-free (see mscan_flat_kernel): clamped re-reads instead of conditionals around the loads
     auto load_step = [&](int64_t b, int s, uint4 (&A)[2]) {
-        const int c = 2 * s + hi;
-        if (b < nblk && c < nchunk) {
-            const uint4* p = rows + (b * nchunk + c) * 64 + lr;
-            A[0] = p[0];
-            A[1] = p[32];
-        } else {
-            A[0] = make_uint4(0, 0, 0, 0);
-            A[1] = make_uint4(0, 0, 0, 0);
-        }
+        const int64_t bb = min(b, nblk - 1);
+        const int c = min(2 * s + hi, nchunk - 1);
+        const uint4* p = rows + (bb * nchunk + c) * 64 + lr;
+        A[0] = p[0];
+        A[1] = p[32];
     };
     // Code loads run THREE steps ahead of the MFMAs that consume them, in four statically rotating register sets
     // (the step loop is flattened over this wave's blocks and unrolled by four: a copy-rotation would make every
@@ -698,7 +724,16 @@ __global__ __launch_bounds__(MQ_THREADS) void mscan_sq8_kernel(MScanArgs a) {
     issue(A[2]);
     const float thr = sT[lr];
     ms_f32x16 acc[2];
-    auto init_acc = [&](int64_t b) {
+    // L2: ||x||^2 of the NEXT block's rows is fetched a block ahead (a wait for it would drain the code prefetch)
+    float xn_next0 = 0.f, xn_next1 = 0.f;
+    auto fetch_xn = [&](int64_t b) {
+        if (IS_L2) {
+            const int64_t bb = min(b, nblk - 1);
+            xn_next0 = a.xnorm[(blk0 + bb) * 64 + lr];
+            xn_next1 = a.xnorm[(blk0 + bb) * 64 + 32 + lr];
+        }
+    };
+    auto init_acc = [&]() {
         ms_f32x16 z;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
@@ -706,15 +741,10 @@ __global__ __launch_bounds__(MQ_THREADS) void mscan_sq8_kernel(MScanArgs a) {
         }
         acc[0] = z;
         acc[1] = z;
-        if (IS_L2 && b < nblk) {
-            float xn0 = 0.f, xn1 = 0.f, bs = 0.f;
-            if (hi == 0) {
-                xn0 = a.xnorm[(blk0 + b) * 64 + lr];
-                xn1 = a.xnorm[(blk0 + b) * 64 + 32 + lr];
-                bs = sSc[lr];
-            }
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xn0, bs, z, 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xn1, bs, z, 0, 0, 0);
+        if (IS_L2) {
+            const float bs = hi == 0 ? sSc[lr] : 0.f;
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(hi == 0 ? xn_next0 : 0.f, bs, z, 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(hi == 0 ? xn_next1 : 0.f, bs, z, 0, 0, 0);
         }
     };
     auto compute = [&](const uint4 (&Ac)[2], int s) {
@@ -741,13 +771,15 @@ __global__ __launch_bounds__(MQ_THREADS) void mscan_sq8_kernel(MScanArgs a) {
             const int32_t q = sPq[lr];
             if (q >= 0) {
                 const float u0 = sU0[lr], vv = sV[lr], off = sOff[lr];
-                float* drow = a.dump + (int64_t)q * a.dump_stride + b * 64;
+                const int32_t col0 = sPs[lr];
+                const int64_t lim = min(len, (int64_t)(MS_SAMPLE - col0));
+                float* drow = a.dump + (int64_t)q * a.dump_stride + col0 + b * 64;
 #pragma unroll
                 for (int t = 0; t < 2; t++) {
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
                         const int i = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        if (b * 64 + i < len) {
+                        if (b * 64 + i < lim) {
                             const float v = u0 + vv * (acc[t][r] - off);
                             drow[i] = ((vmask >> i) & 1ull) ? v : worst_dist<IS_L2>();
                         }
@@ -782,22 +814,64 @@ __global__ __launch_bounds__(MQ_THREADS) void mscan_sq8_kernel(MScanArgs a) {
     int s = 0;
     const int64_t nbw = nblk > wave ? (nblk - wave + MQ_WAVES - 1) / MQ_WAVES : 0;
     const int64_t G = nbw * nstep;
-    init_acc(b);
+    fetch_xn(b);
+    init_acc();
+    fetch_xn(b + MQ_WAVES);
+    // (the four sub-steps are unconditional -- loads behind a branch would be waited for at its join; up to three
+    // steps past the end multiply garbage into an accumulator nobody reads)
     for (int64_t g = 0; g < G; g += 4) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            if (g + u < G) {
-                issue(A[(u + 3) & 3]);
-                compute(A[u], s);
-                if (++s == nstep) {
+            issue(A[(u + 3) & 3]);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(A[u], s);
+            if (++s == nstep) {
+                if (b < nblk) {
                     epilogue(b);
-                    s = 0;
-                    b += MQ_WAVES;
-                    init_acc(b);
                 }
+                s = 0;
+                b += MQ_WAVES;
+                init_acc();
+                fetch_xn(b + MQ_WAVES);
             }
         }
     }
+}
+
+// ---- sample plan ---------------------------------------------------------------------------------------------------
+// Which (query, slot) pairs feed tau_q: the probes in coarse order until `smin` rows are covered (one list when the
+// closest list is long enough, several when it is short or empty -- inner-product clusterings have many tiny lists),
+// at most MS_SAMPLE rows in all.  sample_off[q][slot] = first dump column of the pair, -1 = not sampled;
+// n_row[q] = columns used.
+__global__ void ms_sample_plan_kernel(const int64_t* __restrict__ keys, int64_t nq, int nprobe, int64_t nlist,
+                                      const int64_t* __restrict__ list_len, int smin, int32_t* __restrict__ sample_off,
+                                      int32_t* __restrict__ n_row) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) {
+        return;
+    }
+    int cum = 0;
+    for (int slot = 0; slot < nprobe; slot++) {
+        const int64_t key = keys[q * nprobe + slot];
+        const int64_t len = (key >= 0 && key < nlist) ? list_len[key] : 0;
+        int32_t off = -1;
+        if (len > 0 && cum < smin && cum < MS_SAMPLE) {
+            off = cum;
+            cum += (int)min(len, (int64_t)(MS_SAMPLE - cum));
+        }
+        sample_off[q * nprobe + slot] = off;
+    }
+    n_row[q] = cum;
+}
+
+hipError_t launch_ms_sample_plan(const int64_t* keys, int64_t nq, int nprobe, int64_t nlist, const int64_t* list_len,
+                                 int smin, int32_t* sample_off, int32_t* n_row, hipStream_t s) {
+    if (nq <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(ms_sample_plan_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, keys, nq, nprobe, nlist,
+                       list_len, smin, sample_off, n_row);
+    return hipGetLastError();
 }
 
 // ---- tau_q and the candidate histogram's range from the sample selection ---------------------------------------

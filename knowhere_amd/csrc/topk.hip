@@ -158,7 +158,7 @@ __global__ __launch_bounds__(RS_THREADS) void row_select_kernel(const float* __r
                                                                 const int64_t* __restrict__ var_keys,
                                                                 int key_stride,
                                                                 const int64_t* __restrict__ var_len,
-                                                                int64_t n_cap) {
+                                                                int64_t n_cap, const int32_t* __restrict__ n_row) {
     extern __shared__ __align__(16) unsigned char smem[];
     int64_t n = n_fixed;
     if (row_flags != nullptr && row_flags[blockIdx.x] == 0) {
@@ -170,6 +170,9 @@ __global__ __launch_bounds__(RS_THREADS) void row_select_kernel(const float* __r
         if (n_cap > 0) {
             n = min(n, n_cap); // (only the first n_cap values of a row were written: mfma_scan.hip sample)
         }
+    }
+    if (n_row != nullptr) {
+        n = n_row[blockIdx.x]; // row lengths given directly
     }
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(smem); // [kp]
     __shared__ uint32_t hist[256];
@@ -359,17 +362,17 @@ hipError_t launch_row_select(const float* vals, int64_t nrows, int64_t n, int k,
     const size_t sm = (size_t)kp * 8;
     if (is_l2) {
         hipLaunchKernelGGL((row_select_kernel<true>), dim3((unsigned)nrows), dim3(RS_THREADS), sm, s,
-                           vals, n, k, kp, out_keys, out_d, row_flags, (int64_t)0, nullptr, 0, nullptr, (int64_t)0);
+                           vals, n, k, kp, out_keys, out_d, row_flags, (int64_t)0, nullptr, 0, nullptr, (int64_t)0, nullptr);
     } else {
         hipLaunchKernelGGL((row_select_kernel<false>), dim3((unsigned)nrows), dim3(RS_THREADS), sm, s,
-                           vals, n, k, kp, out_keys, out_d, row_flags, (int64_t)0, nullptr, 0, nullptr, (int64_t)0);
+                           vals, n, k, kp, out_keys, out_d, row_flags, (int64_t)0, nullptr, 0, nullptr, (int64_t)0, nullptr);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_row_select_var(const float* vals, int64_t stride, const int64_t* keys, int key_stride,
                                  const int64_t* list_len, int64_t nrows, int k, bool is_l2, int64_t* out_keys,
-                                 float* out_d, hipStream_t s, int64_t n_cap) {
+                                 float* out_d, hipStream_t s, int64_t n_cap, const int32_t* n_row) {
     if (nrows <= 0 || k <= 0) {
         return hipSuccess;
     }
@@ -383,10 +386,10 @@ hipError_t launch_row_select_var(const float* vals, int64_t stride, const int64_
     const size_t sm = (size_t)kp * 8;
     if (is_l2) {
         hipLaunchKernelGGL((row_select_kernel<true>), dim3((unsigned)nrows), dim3(RS_THREADS), sm, s, vals,
-                           (int64_t)0, k, kp, out_keys, out_d, nullptr, stride, keys, key_stride, list_len, n_cap);
+                           (int64_t)0, k, kp, out_keys, out_d, nullptr, stride, keys, key_stride, list_len, n_cap, n_row);
     } else {
         hipLaunchKernelGGL((row_select_kernel<false>), dim3((unsigned)nrows), dim3(RS_THREADS), sm, s, vals,
-                           (int64_t)0, k, kp, out_keys, out_d, nullptr, stride, keys, key_stride, list_len, n_cap);
+                           (int64_t)0, k, kp, out_keys, out_d, nullptr, stride, keys, key_stride, list_len, n_cap, n_row);
     }
     return hipGetLastError();
 }

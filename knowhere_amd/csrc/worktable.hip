@@ -34,22 +34,25 @@ __global__ void wt_zero_kernel(int32_t* list_count, int32_t* list_cursor, int64_
 // tight per-query threshold (common.h gthr_*) before the bulk of the probes run.  Pure
 // scheduling: results do not depend on it.
 // rank0_slot = -1: no split, every pair goes to [nlist, 2*nlist) (mfma_scan.hip scans all probes of a list together).
-__device__ __forceinline__ int64_t wt_vlist(int64_t key, int64_t slot, int64_t nlist, int rank0_slot) {
-    return key + (slot != rank0_slot ? nlist : 0);
+// cls != nullptr: the first class is given per pair instead (cls[t] >= 0: mfma_scan.hip's sample pairs).
+__device__ __forceinline__ int64_t wt_vlist(int64_t key, int64_t t, int nprobe, int64_t nlist, int rank0_slot,
+                                            const int32_t* cls) {
+    const bool first = cls != nullptr ? cls[t] >= 0 : (t % nprobe) == rank0_slot;
+    return key + (first ? 0 : nlist);
 }
 
 // Pairs whose list is empty on this device (always the case for the lists another rank owns when the index
 // is list-sharded) produce no work item at all: their partial slot is just marked empty by wt_scatter_kernel.
 __global__ void wt_count_kernel(const int64_t* __restrict__ keys, int64_t npairs, int nprobe,
                                 int64_t nlist, const int64_t* __restrict__ list_len, int32_t* list_count,
-                                int rank0_slot) {
+                                int rank0_slot, const int32_t* __restrict__ cls) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= npairs) {
         return;
     }
     const int64_t key = keys[t];
     if (key >= 0 && key < nlist && list_len[key] > 0) {
-        atomicAdd(&list_count[wt_vlist(key, t % nprobe, nlist, rank0_slot)], 1);
+        atomicAdd(&list_count[wt_vlist(key, t, nprobe, nlist, rank0_slot, cls)], 1);
     }
 }
 
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(WT_SCAN_THREADS) void wt_scan_kernel(
 __global__ void wt_scatter_kernel(const int64_t* __restrict__ keys, int64_t npairs, int nprobe,
                                   int64_t nlist, const int64_t* __restrict__ list_len,
                                   const int64_t* __restrict__ list_pair_off, int32_t* list_cursor, KnPair* pairs,
-                                  int64_t* empty_mark, int k, int rank0_slot) {
+                                  int64_t* empty_mark, int k, int rank0_slot, const int32_t* __restrict__ cls) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= npairs) {
         return;
@@ -138,7 +141,7 @@ __global__ void wt_scatter_kernel(const int64_t* __restrict__ keys, int64_t npai
         }
         return;
     }
-    const int64_t vl = wt_vlist(key, t % nprobe, nlist, rank0_slot);
+    const int64_t vl = wt_vlist(key, t, nprobe, nlist, rank0_slot, cls);
     const int64_t pos = list_pair_off[vl] + atomicAdd(&list_cursor[vl], 1);
     KnPair p;
     p.q = (int32_t)(t / nprobe);
@@ -171,7 +174,7 @@ __global__ void wt_items_kernel(const int32_t* __restrict__ list_count,
 // search may run different kernels)
 hipError_t launch_build_worktable(const int64_t* keys, int64_t nq, int nprobe, int64_t nlist, int qg0, int qg1,
                                   const int64_t* list_len, int64_t code_size, const WorkTable& wt,
-                                  hipStream_t s, int rank0_slot) {
+                                  hipStream_t s, int rank0_slot, const int32_t* cls) {
     const int64_t npairs = nq * nprobe;
     const int64_t nvl = 2 * nlist; // virtual lists, see wt_vlist
     const unsigned gl = (unsigned)((nvl + 255) / 256);
@@ -180,14 +183,14 @@ hipError_t launch_build_worktable(const int64_t* keys, int64_t nq, int nprobe, i
                        wt.scan_bytes, wt.nitems);
     if (npairs > 0) {
         hipLaunchKernelGGL(wt_count_kernel, dim3(gp), dim3(256), 0, s, keys, npairs, nprobe, nlist, list_len,
-                           wt.list_count, rank0_slot);
+                           wt.list_count, rank0_slot, cls);
     }
     hipLaunchKernelGGL(wt_scan_kernel, dim3(1), dim3(WT_SCAN_THREADS), 0, s, wt.list_count, list_len,
                        nvl, nlist, qg0, qg1, code_size, wt.list_pair_off, wt.list_item_off, wt.nitems,
                        wt.scan_bytes);
     if (npairs > 0) {
         hipLaunchKernelGGL(wt_scatter_kernel, dim3(gp), dim3(256), 0, s, keys, npairs, nprobe, nlist, list_len,
-                           wt.list_pair_off, wt.list_cursor, wt.pairs, wt.empty_mark, wt.k, rank0_slot);
+                           wt.list_pair_off, wt.list_cursor, wt.pairs, wt.empty_mark, wt.k, rank0_slot, cls);
     }
     hipLaunchKernelGGL(wt_items_kernel, dim3(gl), dim3(256), 0, s, wt.list_count, wt.list_pair_off,
                        wt.list_item_off, nvl, nlist, qg0, qg1, wt.items);
