@@ -258,7 +258,7 @@ int mscan_sample_rows();
 hipError_t launch_ms_block_norms(const float4* rows, int64_t total_blk, int nchunk, float* out, float* out_max,
                                  hipStream_t s);
 hipError_t launch_ms_sq8_norms(const uint4* rows, int64_t total_blk, int nchunk16, int d, const float* trained,
-                               float* out, hipStream_t s);
+                               float* out, float* out_max, hipStream_t s);
 // units from one virtual-list range of the work table (`*_v` = the table's arrays offset to that range)
 hipError_t launch_ms_units(const int32_t* list_count_v, const int64_t* list_pair_off_v, int64_t nlist, int qt,
                            int64_t* unit_off, int64_t* nunits, KnItem* units, const int64_t* list_len,

@@ -510,9 +510,9 @@ int ensure_mscan_norms(const knhip_index* idx) {
         HIP_TRY(hipMemcpy(&idx->xnorm_max, xmax, sizeof(float), hipMemcpyDeviceToHost));
     } else {
         HIP_TRY(launch_ms_sq8_norms(idx->rows.as<uint4>(), total_blk, (idx->d + 15) / 16, idx->d,
-                                    idx->sq_trained.as<float>(), xn, nullptr));
+                                    idx->sq_trained.as<float>(), xn, xmax, nullptr));
         HIP_TRY(hipDeviceSynchronize());
-        idx->xnorm_max = 0.f;
+        HIP_TRY(hipMemcpy(&idx->xnorm_max, xmax, sizeof(float), hipMemcpyDeviceToHost));
     }
     idx->xnorm_ready = true;
     return KNHIP_OK;

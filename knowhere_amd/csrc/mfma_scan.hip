@@ -265,22 +265,64 @@ __global__ __launch_bounds__(MS_THREADS, 4) void mscan_flat_kernel(MScanArgs a) 
     float* sC = sT + QT;                                 // [QT] pessimistic distance = c - 2 acc (L2) / acc - c (IP)
     int32_t* sPq = reinterpret_cast<int32_t*>(sC + QT);  // [QT] query of the pair (-1: none)
     int32_t* sPs = sPq + QT;                             // [QT] slot of the pair
-    for (int j = wave; j < QT; j += MS_WAVES) {
+    // Each wave sets up QT / 4 pairs.  All loads of a level are issued together (pair records -> per-query words and the
+    // histogram row, lane = bin): two round trips per unit instead of three per pair.
+    constexpr int PW = QT / MS_WAVES;
+    KnPair pp[PW];
+#pragma unroll
+    for (int i = 0; i < PW; i++) {
+        pp[i] = a.pairs[it.pair0 + min(wave + i * MS_WAVES, npair - 1)];
+    }
+    float qn_[PW], tau_[PW];
+    uint32_t hc_[PW];
+    uint2 mt_[PW];
+    const bool hist_on = !DUMP && a.ghist != nullptr;
+#pragma unroll
+    for (int i = 0; i < PW; i++) {
+        const int32_t q = pp[i].q;
+        qn_[i] = a.qnorm[q];
+        tau_[i] = DUMP ? 0.f : a.gthr[q];
+        mt_[i] = hist_on ? a.gmeta[q] : make_uint2(0u, KN_HIST_OFF);
+        hc_[i] = hist_on ? __hip_atomic_load(a.ghist + (int64_t)q * KN_HIST_BINS + lane, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT)
+                         : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < PW; i++) {
+        const int j = wave + i * MS_WAVES;
         float t = INFINITY, c = 0.f;
         int32_t q = -1, slot = 0;
         if (j < npair) {
-            const KnPair p = a.pairs[it.pair0 + j];
-            q = p.q;
-            slot = p.slot;
-            const float qn = a.qnorm[q];
+            q = pp[i].q;
+            slot = pp[i].slot;
+            const float qn = qn_[i];
             const float eps = a.eps_scale * (IS_L2 ? (qn + a.xnorm_max) : sqrtf(qn * a.xnorm_max)) + 1e-30f;
             c = IS_L2 ? qn + eps : eps;
             if (DUMP) {
                 slot = a.sample_off[(int64_t)q * a.nslot + slot]; // (sPs then holds the pair's first dump column)
-            }
-            if (!DUMP) {
-                float tau = a.gthr[q];
-                tau = tighter<IS_L2>(tau, ms_hist_bound<IS_L2>(a, q, a.k));
+            } else {
+                float tau = tau_[i];
+                if (mt_[i].y != KN_HIST_OFF) {
+                    // bound from the candidate histogram: first bin where k candidates are reached (see ms_hist_bound)
+                    uint32_t cum = hc_[i];
+#pragma unroll
+                    for (int dlt = 1; dlt < KN_WAVE; dlt <<= 1) {
+                        const uint32_t up = __shfl_up(cum, dlt, KN_WAVE);
+                        cum += lane >= dlt ? up : 0u;
+                    }
+                    const unsigned long long reach = __ballot(cum >= (uint32_t)a.k);
+                    const int bin = reach ? __ffsll((long long)reach) - 1 : KN_HIST_BINS;
+                    if (bin < KN_HIST_BINS - 1) {
+                        const unsigned long long edge =
+                                (unsigned long long)mt_[i].x + (((unsigned long long)bin + 1ull) << mt_[i].y) - 1ull;
+                        if (edge < 0xffffffffull) {
+                            const float e = dist_key_inv<IS_L2>((uint32_t)edge);
+                            if (e == e && fabsf(e) < FLT_MAX) {
+                                tau = tighter<IS_L2>(tau, e);
+                            }
+                        }
+                    }
+                }
                 if (tau == worst_dist<IS_L2>()) {
                     // no bound (fewer than k unfiltered rows in the sample): every row would pass -> exact fallback
                     if (lane == 0) {
@@ -491,24 +533,21 @@ __global__ __launch_bounds__(MS_THREADS, 4) void mscan_flat_kernel(MScanArgs a) 
 //   IP: dis0 + A + (S - off) / sc >= tau - eps                  <=>  S >= sc (tau - eps - dis0 - A) + off
 //   L2: ||y||^2 + ||x||^2 - 2 (A + (S - off) / sc) <= tau + eps <=>  S - sc ||x||^2 / 2 >= sc (||y||^2 - 2 A - tau - eps) / 2 + off
 // (the -sc ||x||^2 / 2 term is the accumulator's start value: one fp32 MFMA with A = ||x||^2, B = -sc / 2).
-// eps = eps_scale * sum_i |y_i| (|vmin_i| + 6 |vdiff_i|), eps_scale = 32 d 2^-24: the fp32 roundings of the exact
-// sequence, of A, off and y', the 2^-22 relative split error, and the fp32 accumulation of terms of magnitude
-// |y'_i| (1024 + 255) are each below d 2^-24 times that sum.
+// eps: see the bound spelled out where the thresholds are formed (worst-case rounding analysis, factor 2 on top).
 constexpr int MQ_WAVES = 16;
 constexpr int MQ_THREADS = MQ_WAVES * KN_WAVE;
 constexpr int MQ_QT = 32;
 
 __global__ void ms_sq8_norms_kernel(const uint4* __restrict__ rows, int64_t total_blk, int nchunk16, int d,
-                                    const float* __restrict__ trained, float* __restrict__ out) {
+                                    const float* __restrict__ trained, float* __restrict__ out,
+                                    float* __restrict__ out_max) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total_blk * 64) {
-        return;
-    }
-    const int64_t b = t >> 6;
+    float acc = 0.f;
+    const bool live = t < total_blk * 64;
+    const int64_t b = live ? (t >> 6) : 0;
     const int r = (int)(t & 63);
     const uint4* p = rows + b * (int64_t)nchunk16 * 64 + r;
-    float acc = 0.f;
-    for (int c = 0; c < nchunk16; c++) {
+    for (int c = 0; live && c < nchunk16; c++) {
         const uint4 w = p[(int64_t)c * 64];
         const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
@@ -521,16 +560,26 @@ __global__ void ms_sq8_norms_kernel(const uint4* __restrict__ rows, int64_t tota
             }
         }
     }
-    out[t] = acc;
+    if (live) {
+        out[t] = acc;
+    }
+    float m = acc; // (norms are >= 0: their bit patterns order like ints)
+    for (int off = 32; off > 0; off >>= 1) {
+        m = fmaxf(m, __shfl_xor(m, off, KN_WAVE));
+    }
+    if (lane_id() == 0 && m > 0.f) {
+        atomicMax(reinterpret_cast<int*>(out_max), __float_as_int(m));
+    }
 }
 
 hipError_t launch_ms_sq8_norms(const uint4* rows, int64_t total_blk, int nchunk16, int d, const float* trained,
-                               float* out, hipStream_t s) {
-    if (total_blk <= 0) {
-        return hipSuccess;
+                               float* out, float* out_max, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(out_max, 0, sizeof(float), s);
+    if (e != hipSuccess || total_blk <= 0) {
+        return e;
     }
     hipLaunchKernelGGL(ms_sq8_norms_kernel, dim3((unsigned)((total_blk * 64 + 255) / 256)), dim3(256), 0, s, rows,
-                       total_blk, nchunk16, d, trained, out);
+                       total_blk, nchunk16, d, trained, out, out_max);
     return hipGetLastError();
 }
 
@@ -624,7 +673,7 @@ __global__ __launch_bounds__(MQ_THREADS) void mscan_sq8_kernel(MScanArgs a) {
                 ex = max(-60, min(60, ex));
             }
             const float sc = ldexpf(1.0f, ex);
-            float sA = 0.f, sW = 0.f, sHL = 0.f, sR = 0.f;
+            float sA = 0.f, sW = 0.f, sYp = 0.f, sHL = 0.f, sR = 0.f;
             for (int i = lane; i < nstep * 32; i += KN_WAVE) {
                 _Float16 h = (_Float16)0.f, l = (_Float16)0.f;
                 if (i < d) {
@@ -633,7 +682,8 @@ __global__ __launch_bounds__(MQ_THREADS) void mscan_sq8_kernel(MScanArgs a) {
                     h = (_Float16)yp;
                     l = (_Float16)(yp - (float)h);
                     sA += y * (vmin[i] + 0.5f * vdiff[i] * (1.0f / 255.0f));
-                    sW += fabsf(y) * (fabsf(vmin[i]) + 6.0f * fabsf(vdiff[i]));
+                    sW += fabsf(y) * (fabsf(vmin[i]) + fabsf(vdiff[i])); // >= sum |y_i x_i|
+                    sYp += fabsf(y * vdiff[i] * (1.0f / 255.0f));          // sum |y'_i| (unscaled)
                     sHL += (float)h + (float)l;
                     sR += y * y;
                 }
@@ -642,11 +692,23 @@ __global__ __launch_bounds__(MQ_THREADS) void mscan_sq8_kernel(MScanArgs a) {
             }
             sA = ms_wave_sum(sA);
             sW = ms_wave_sum(sW);
+            sYp = ms_wave_sum(sYp);
             sHL = ms_wave_sum(sHL);
             sR = ms_wave_sum(sR);
             const float dis0 = IS_L2 ? 0.f : a.coarse_dis[(int64_t)q * a.nslot + slot_in];
             // (the constants below are themselves rounded: a few ulp of the magnitudes they are formed from go on top)
-            const float eps = a.eps_scale * sW + 1e-6f * (fabsf(dis0) + fabsf(sA) + sR) + 1e-30f;
+            // Error bound, every term with a factor 2 on top of the standard worst-case analysis (u = 2^-24):
+            //   matrix cores   (2 d + 64) u * 1279 sum |y'_i|   every product of S = sum (hi+lo)(1024+c) counted as one
+            //                                                    rounded fp32 addition of magnitude <= 1279 |y'_i|
+            //   split, y', A, off, tree sums, threshold forming   32 u (|A| + 1024 sum |y'| + |dis0| + ||y||^2)
+            //   the exact sequence itself   IP: (d + 8) u sum |y_i| (|vmin_i| + |vdiff_i|) >= gamma_d sum |y_i x_i|
+            //                               L2: (2 d + 16) u * 2 (||y||^2 + max ||x||^2) >= gamma sum (y_i - x_i)^2, and
+            //                               the inner-product part enters twice
+            const float u = 5.9604645e-8f;
+            const float e_mfma = (2.0f * (float)d + 64.0f) * u * 1279.0f * sYp;
+            const float e_misc = 32.0f * u * (fabsf(sA) + 1024.0f * sYp + fabsf(dis0) + sR);
+            const float eps = 2.0f * (IS_L2 ? 2.0f * (e_mfma + e_misc) + (2.0f * (float)d + 16.0f) * u * 2.0f * (sR + a.xnorm_max)
+                                            : e_mfma + e_misc + ((float)d + 8.0f) * u * sW) + 1e-30f;
             const float off = 1024.0f * sHL;
             nsc = -0.5f * sc;
             offv = off;

@@ -91,15 +91,27 @@ def test_mscan_ragged_dims_empty_lists_and_ties(torch_cuda, port, monkeypatch, k
 
 
 def test_mscan_overflow_goes_through_the_exact_kernels(torch_cuda, port, monkeypatch):
-    """lists of ~12 rows and k = 100: no rank-0 list holds k rows, every query has no bound -> all of them are
-    flagged and redone exactly; the result is still the oracle's"""
+    """no bound for a query = fewer than k unfiltered rows in its sample (the probes in coarse order until enough rows
+    are covered): with 99.7 % of the ids filtered every query is flagged, its (query, list) pairs are compacted into
+    one-query items for the exact kernels, and the result is still the oracle's.  Tiny lists alone (12 rows each) are
+    NOT such a case: the sample then spans several lists."""
     nb, d = 3000, 32
     xb, xq = gen_data(nb, d, 42), gen_data(40, d, 44)
     ix = ob.make_index(port, ob.IVF_FLAT, ob.L2, xb, nlist=250)
     g0, g1 = _pair(monkeypatch, ix)
     p = _check(port, ix, g0, g1, xq, 100, 64, ob.L2, "tiny lists")
+    assert p["mscan_queries"] > 0
+    _check(port, ix, g0, g1, xq, 2, 64, ob.L2, "tiny lists, small k")
+    bs = _bitset(nb, 0.997, 7)
+    p = _check(port, ix, g0, g1, xq, 10, 250, ob.L2, "99.7 % filtered", bs, nb)
     assert p["mscan_overflow_queries"] == len(xq)
-    p = _check(port, ix, g0, g1, xq, 2, 64, ob.L2, "tiny lists, small k")
+    for kind, metric in ((ob.IVF_SQ8, ob.IP), (ob.IVF_SQ8, ob.L2), (ob.IVF_FLAT, ob.IP)):
+        ix2 = ob.make_index(port, kind, metric, xb, nlist=250)
+        h0, h1 = _pair(monkeypatch, ix2)
+        p = _check(port, ix2, h0, h1, xq, 10, 250, metric, f"99.7 % filtered kind={kind} metric={metric}", bs, nb)
+        assert p["mscan_overflow_queries"] == len(xq)
+        h0.close()
+        h1.close()
     g0.close()
     g1.close()
 
