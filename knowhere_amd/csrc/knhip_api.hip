@@ -645,7 +645,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         // gave a loose bound collects thousands of rows before its histogram tightens it, and their exact distances
         // cost far less than the exact scan of all its lists -- within ~3 GB of scratch per batch
         ms_cap = 4096;
-        while (ms_cap < (int64_t)4 * nprobe * k && ms_cap < 32768) {
+        while (ms_cap < (int64_t)16 * nprobe * k && ms_cap < 32768) {
             ms_cap <<= 1;
         }
         while (ms_cap > 1024 && (double)ms_cap * (double)nq * 8.0 > 3.0e9) {
