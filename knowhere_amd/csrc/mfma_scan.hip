@@ -265,64 +265,21 @@ __global__ __launch_bounds__(MS_THREADS, 4) void mscan_flat_kernel(MScanArgs a) 
     float* sC = sT + QT;                                 // [QT] pessimistic distance = c - 2 acc (L2) / acc - c (IP)
     int32_t* sPq = reinterpret_cast<int32_t*>(sC + QT);  // [QT] query of the pair (-1: none)
     int32_t* sPs = sPq + QT;                             // [QT] slot of the pair
-    // Each wave sets up QT / 4 pairs.  All loads of a level are issued together (pair records -> per-query words and the
-    // histogram row, lane = bin): two round trips per unit instead of three per pair.
-    constexpr int PW = QT / MS_WAVES;
-    KnPair pp[PW];
-#pragma unroll
-    for (int i = 0; i < PW; i++) {
-        pp[i] = a.pairs[it.pair0 + min(wave + i * MS_WAVES, npair - 1)];
-    }
-    float qn_[PW], tau_[PW];
-    uint32_t hc_[PW];
-    uint2 mt_[PW];
-    const bool hist_on = !DUMP && a.ghist != nullptr;
-#pragma unroll
-    for (int i = 0; i < PW; i++) {
-        const int32_t q = pp[i].q;
-        qn_[i] = a.qnorm[q];
-        tau_[i] = DUMP ? 0.f : a.gthr[q];
-        mt_[i] = hist_on ? a.gmeta[q] : make_uint2(0u, KN_HIST_OFF);
-        hc_[i] = hist_on ? __hip_atomic_load(a.ghist + (int64_t)q * KN_HIST_BINS + lane, __ATOMIC_RELAXED,
-                                             __HIP_MEMORY_SCOPE_AGENT)
-                         : 0u;
-    }
-#pragma unroll
-    for (int i = 0; i < PW; i++) {
-        const int j = wave + i * MS_WAVES;
+    for (int j = wave; j < QT; j += MS_WAVES) { // wave per pair: the histogram row is read lane = bin
         float t = INFINITY, c = 0.f;
         int32_t q = -1, slot = 0;
         if (j < npair) {
-            q = pp[i].q;
-            slot = pp[i].slot;
-            const float qn = qn_[i];
+            const KnPair p = a.pairs[it.pair0 + j];
+            q = p.q;
+            slot = p.slot;
+            const float qn = a.qnorm[q];
             const float eps = a.eps_scale * (IS_L2 ? (qn + a.xnorm_max) : sqrtf(qn * a.xnorm_max)) + 1e-30f;
             c = IS_L2 ? qn + eps : eps;
             if (DUMP) {
                 slot = a.sample_off[(int64_t)q * a.nslot + slot]; // (sPs then holds the pair's first dump column)
             } else {
-                float tau = tau_[i];
-                if (mt_[i].y != KN_HIST_OFF) {
-                    // bound from the candidate histogram: first bin where k candidates are reached (see ms_hist_bound)
-                    uint32_t cum = hc_[i];
-#pragma unroll
-                    for (int dlt = 1; dlt < KN_WAVE; dlt <<= 1) {
-                        const uint32_t up = __shfl_up(cum, dlt, KN_WAVE);
-                        cum += lane >= dlt ? up : 0u;
-                    }
-                    const unsigned long long reach = __ballot(cum >= (uint32_t)a.k);
-                    const int bin = reach ? __ffsll((long long)reach) - 1 : KN_HIST_BINS;
-                    if (bin < KN_HIST_BINS - 1) {
-                        const unsigned long long edge =
-                                (unsigned long long)mt_[i].x + (((unsigned long long)bin + 1ull) << mt_[i].y) - 1ull;
-                        if (edge < 0xffffffffull) {
-                            const float e = dist_key_inv<IS_L2>((uint32_t)edge);
-                            if (e == e && fabsf(e) < FLT_MAX) {
-                                tau = tighter<IS_L2>(tau, e);
-                            }
-                        }
-                    }
-                }
+                float tau = a.gthr[q];
+                tau = tighter<IS_L2>(tau, ms_hist_bound<IS_L2>(a, q, a.k));
                 if (tau == worst_dist<IS_L2>()) {
                     // no bound (fewer than k unfiltered rows in the sample): every row would pass -> exact fallback
                     if (lane == 0) {
