@@ -337,21 +337,25 @@ def make_roofline(a, kind, prof, world):
                 "4 flop per (row, query, dim): the query operand is split into two halves (hi + lo) on " \
                 "v_mfma_f32_32x32x16_f16; peak = dense f16 matrix peak"
         tf = flop / sec / 1e12 if sec > 0 else 0.0
-        mfma_frac, hbm_frac = tf / peak, stream_gbps / HBM_PEAK_GBPS
+        # HBM side: the measured traffic (PMC pass of this workload, profiles/bench_pmc_traffic.json) where there is one;
+        # the bytes the units stream are an upper bound of it (units of one list share it through L2)
+        hbm_gbps = (traffic / sec / 1e9) if (traffic and sec > 0) else stream_gbps
+        mfma_frac, hbm_frac = tf / peak, hbm_gbps / HBM_PEAK_GBPS
         steps = max(a.steps, 1)
         extra = {"mfma": {"achieved_TFLOPs": round(tf, 2), "peak_TFLOPs": peak, "frac": round(mfma_frac, 4)},
-                 "stream": {"bytes_per_launch": stream, "GBps": round(stream_gbps, 1), "frac_of_hbm_peak": round(hbm_frac, 4),
-                            "note": "bytes the kernel reads if every unit streams its list once (L2 hits between "
-                                    "concurrent units of one list make the HBM traffic smaller)"},
+                 "stream": {"bytes_per_launch": stream, "GBps": round(stream_gbps, 1),
+                            "note": "bytes the units read (L2 + HBM); `traffic` is the part that came from HBM "
+                                    "(FETCH_SIZE pass), null when no PMC pass of this workload is on file"},
                  "mscan": {"queries_per_step": prof["mscan_queries"] / steps,
                            "overflow_queries_per_step": prof["mscan_overflow_queries"] / steps,
                            "candidates_per_query": round(prof["mscan_candidates"] / max(prof["mscan_queries"], 1), 1)}}
         if mfma_frac >= hbm_frac:
             return dict({"bound": "mfma", "kernel": kname, "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(mfma_frac, 4), "note": unit_note}, **common, **extra)
-        return dict({"bound": "hbm", "kernel": kname, "achieved": round(stream_gbps, 1), "peak": HBM_PEAK_GBPS,
+        return dict({"bound": "hbm", "kernel": kname, "achieved": round(hbm_gbps, 1), "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": round(hbm_frac, 4),
-                     "note": "achieved = bytes streamed by the units / launch time"}, **common, **extra)
+                     "note": "achieved = HBM bytes per launch (PMC traffic where on file, else the bytes the units "
+                             "stream) / launch time"}, **common, **extra)
     # exact row scans: lane = row, the queries of a work item share each row fetch -> VALU-bound by construction:
     # per (row, query, dim) L2 = sub, mul, add; IP = mul, add (+ SQ8: decode fma per (row, dim))
     code_size = a.d * 4 if kind == kidx.IVF_FLAT else a.d

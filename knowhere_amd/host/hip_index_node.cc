@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdio>
 #include <numeric>
 #include <shared_mutex>
 
@@ -608,8 +609,27 @@ class HipIndexNode : public IndexNode {
     }
 
     Status
-    DeserializeFromFile(const std::string& /*filename*/, std::shared_ptr<Config> /*config*/) override {
-        return Status::not_implemented;  // as the cuVS node (gpu_cuvs.h:250-253)
+    // IvfIndexNode::DeserializeFromFile (ivf.cc:1838-1916) reads the faiss index bytes from a file
+    // (faiss::read_index(filename, io_flags); enable_mmap only changes how the CPU node keeps them): the file holds
+    // exactly the blob Serialize puts into the BinarySet, so it is read once and handed to Deserialize -- the lists go
+    // to HBM either way.  (The cuVS node returns not_implemented here, gpu_cuvs.h:250-253.)
+    DeserializeFromFile(const std::string& filename, std::shared_ptr<Config> config) override {
+        FILE* f = std::fopen(filename.c_str(), "rb");
+        if (f == nullptr) return Status::disk_file_error;
+        std::fseek(f, 0, SEEK_END);
+        const long size = std::ftell(f);
+        std::fseek(f, 0, SEEK_SET);
+        if (size <= 0) {
+            std::fclose(f);
+            return Status::invalid_serialized_index_type;
+        }
+        std::shared_ptr<uint8_t[]> data(new uint8_t[(size_t)size]);
+        const size_t got = std::fread(data.get(), 1, (size_t)size, f);
+        std::fclose(f);
+        if (got != (size_t)size) return Status::disk_file_error;
+        BinarySet binset;
+        binset.Append(Type(), data, (int64_t)size);
+        return Deserialize(binset, std::move(config));
     }
 
     static std::unique_ptr<BaseConfig>

@@ -74,7 +74,7 @@ enum class Status {
     hnsw_inner_error = 12,
     malloc_error = 13,
     diskann_inner_error = 14,
-    diskann_file_error = 15,
+    disk_file_error = 15,
     invalid_value_in_json = 16,
     arithmetic_overflow = 17,
     cuvs_inner_error = 18,
@@ -1100,6 +1100,16 @@ class Index {
             std::string msg;
             RETURN_IF_ERROR(LoadConfig(static_cast<BaseConfig*>(cfg.get()), json, PARAM_TYPE::DESERIALIZE, &msg));
             return node_->Deserialize(binset, cfg);
+        });
+    }
+    // index.h:220 / src/index/index.cc:462-495
+    Status
+    DeserializeFromFile(const std::string& filename, const Json& json = {}) noexcept {
+        return Guard([&] {
+            std::shared_ptr<Config> cfg = node_->CreateConfig();
+            std::string msg;
+            RETURN_IF_ERROR(LoadConfig(static_cast<BaseConfig*>(cfg.get()), json, PARAM_TYPE::DESERIALIZE, &msg));
+            return node_->DeserializeFromFile(filename, cfg);
         });
     }
     int64_t Dim() const { return node_->Dim(); }

@@ -265,6 +265,28 @@ int main() {
             for (int64_t i = 0; i < nq; i++) diff += r2.value()->GetIds()[i] != results.value()->GetIds()[i];
             REQUIRE(diff == 0);
         }
+        {   // 6b. the same bytes from a file (Index::DeserializeFromFile, src/index/index.cc:462-495 ->
+            //     IvfIndexNode::DeserializeFromFile, ivf.cc:1838-1916: faiss::read_index(filename))
+            const std::string path = std::string("/tmp/knhip_test_") + c.name + ".faiss";
+            FILE* f = std::fopen(path.c_str(), "wb");
+            REQUIRE(f != nullptr);
+            auto blob = bs.GetByName(c.name);
+            REQUIRE(std::fwrite(blob->data.get(), 1, (size_t)blob->size, f) == (size_t)blob->size);
+            std::fclose(f);
+            auto idx3 = IndexFactory::Instance().Create<fp32>(c.name, version).value();
+            REQUIRE(idx3.DeserializeFromFile(path) == Status::success);
+            REQUIRE(idx3.Count() == idx.Count());
+            auto r3 = idx3.Search(query_ds, c.cfg, nullptr);
+            REQUIRE(r3.has_value());
+            if (r3.has_value()) {
+                int diff = 0;
+                for (int64_t i = 0; i < nq; i++) diff += r3.value()->GetIds()[i] != results.value()->GetIds()[i];
+                REQUIRE(diff == 0);
+            }
+            std::remove(path.c_str());
+            auto idx4 = IndexFactory::Instance().Create<fp32>(c.name, version).value();
+            REQUIRE(idx4.DeserializeFromFile("/tmp/knhip_no_such_file") == Status::disk_file_error);
+        }
         // 7. range search: brute force, IVF_FLAT, IVF_SQ8 here, IVF_PQ (m = 32) below; other m: not_implemented
         if (std::string(c.name) == IndexEnum::INDEX_HIP_IVFPQ) {
             REQUIRE(idx.RangeSearch(query_ds, c.cfg, nullptr).error() == Status::not_implemented);

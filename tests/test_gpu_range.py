@@ -32,11 +32,11 @@ def _same(a, b, what):
     assert np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32)), f"{what}: distances differ bitwise"
 
 
-@pytest.mark.parametrize("path", [p for p in __import__("helpers").golden_files() if "ivfpq" not in p],
+@pytest.mark.parametrize("path", [p for p in __import__("helpers").golden_files() if "ivfpq" not in p or "ivfpq32" in p],
                          ids=lambda p: __import__("os").path.basename(p)[:-4])
 def test_golden_range(path):
-    """the committed range results of the reference's own FAISS (tests/golden/make_golden.py); the golden IVF-PQ
-    index has m = 8, outside the range path"""
+    """the committed range results of the reference's own FAISS (tests/golden/make_golden.py); the small golden IVF-PQ
+    index has m = 8, outside the range path -- the d = 128, m = 32 fixtures (h128_ivfpq32_*) are inside it"""
     from helpers import load_golden, load_golden_range
     ix, xq, _ = load_golden(path)
     g = _gpu(ix)
