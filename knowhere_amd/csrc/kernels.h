@@ -204,6 +204,11 @@ struct MScanArgs {
     int32_t k;
     // sample plan: first dump column of pair (q, slot), or -1 when the pair is not part of the sample
     const int32_t* sample_off;
+    // SQ8 inner product: query operands prepared once per batch (ms_sq8_query_prep; null = computed per unit):
+    // qh / ql [nq][nstep * 32] halves, qs [nq][8] = {scale, A, W, sum |y'|, sum (hi + lo), finite, -, -}
+    const void* qh;
+    const void* ql;
+    const float* qs;
 };
 
 // ---- flat_scan.hip ----
@@ -267,6 +272,8 @@ hipError_t launch_mscan_flat(const MScanArgs& a, bool is_l2, int64_t units_bound
 hipError_t launch_mscan_sq8(const MScanArgs& a, bool is_l2, int64_t units_bound, hipStream_t s);
 hipError_t launch_ms_sample_plan(const int64_t* keys, int64_t nq, int nprobe, int64_t nlist, const int64_t* list_len,
                                  int smin, int32_t* sample_off, int32_t* n_row, hipStream_t s);
+hipError_t launch_ms_sq8_query_prep(const float* queries, int64_t nq, int d, int ldq, const float* trained, void* qh,
+                                    void* ql, float* qs, hipStream_t s);
 hipError_t launch_ms_tau(const float* sel_d, int64_t nq, int k, bool is_l2, float* gthr, uint2* gmeta, hipStream_t s);
 hipError_t launch_mscan_finish(const MScanArgs& a, int kind, bool is_l2, const int64_t* keys, const float* coarse_dis,
                                int nprobe, int k, float* out_d, int64_t* out_i, unsigned long long* counters,

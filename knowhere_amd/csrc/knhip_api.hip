@@ -127,6 +127,7 @@ struct Workspace {
     // MFMA prefilter of the IVF-Flat / IVF-SQ8 scans (mfma_scan.hip)
     DevBuf ms_units, ms_unit_off, ms_nunits, ms_cand, ms_cand_cnt;  // ms_cand_cnt: [qb] counters + [qb + 1] overflow flags
     DevBuf ms_sample_off, ms_nrow;                                   // sample plan: [qb][nprobe] dump columns, [qb] rows
+    DevBuf ms_qh, ms_ql, ms_qs;                                      // SQ8 IP: prepared query operands (halves) + sums
     // host-boundary staging
     DevBuf h_queries, h_bitset, h_out_d, h_out_i, h_ref_d, h_ref_i;
     std::mutex mu;  // held while a *_device entry point enqueues on this (per-stream) workspace
@@ -765,6 +766,17 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
                 HIP_TRY(ws->qnorm.reserve((size_t)nq * sizeof(float)));
                 m.qnorm = ws->qnorm.as<float>();
                 HIP_TRY(launch_row_norms(d_q, nq, d, ws->qnorm.as<float>(), s));
+            } else if (!is_l2) {
+                // inner product: the query operand (scaled, split into two halves) is the same for every list
+                const int ldq = ms_nstep * 32;
+                HIP_TRY(ws->ms_qh.reserve((size_t)nq * ldq * 2));
+                HIP_TRY(ws->ms_ql.reserve((size_t)nq * ldq * 2));
+                HIP_TRY(ws->ms_qs.reserve((size_t)nq * 8 * sizeof(float)));
+                HIP_TRY(launch_ms_sq8_query_prep(d_q, nq, d, ldq, idx->sq_trained.as<float>(), ws->ms_qh.p, ws->ms_ql.p,
+                                                 ws->ms_qs.as<float>(), s));
+                m.qh = ws->ms_qh.p;
+                m.ql = ws->ms_ql.p;
+                m.qs = ws->ms_qs.as<float>();
             }
             HIP_TRY(hipMemsetAsync(ws->ghist.p, 0, (size_t)nq * 64 * sizeof(uint32_t), s));
             HIP_TRY(launch_ms_units(wt.list_count, wt.list_pair_off, nlist, qt0, ws->ms_unit_off.as<int64_t>(),

@@ -566,6 +566,79 @@ __device__ __forceinline__ void ms_codes_to_f16(const uint4 w, ms_f16x8& lo8, ms
     hi8 = b.v;
 }
 
+// ---- inner product: the query operand does not depend on the list -> prepared once per batch -----------------------
+// (by_residual IP: dis = coarse_dis + <q, x>; L2 needs q - centroid per (query, list) and keeps the in-kernel path.)
+// One wave per query: y' = q vdiff / 255 scaled by sc = 2^ex (max |y'| sc in [2^9, 2^10)) and split into halves hi + lo
+// -> qh / ql [nq][ldq] (zero padded to the step multiple); qs[q] = {sc, A, W, sum |y'|, sum (hi + lo), finite?, 0, 0}.
+// The same arithmetic as the in-kernel prologue below.
+__global__ __launch_bounds__(256) void ms_sq8_query_prep_kernel(const float* __restrict__ queries, int64_t nq, int d,
+                                                                int ldq, const float* __restrict__ trained,
+                                                                _Float16* __restrict__ qh, _Float16* __restrict__ ql,
+                                                                float* __restrict__ qs) {
+    const int lane = lane_id();
+    const int64_t q = (int64_t)blockIdx.x * (blockDim.x / KN_WAVE) + threadIdx.x / KN_WAVE;
+    if (q >= nq) {
+        return;
+    }
+    const float* vmin = trained;
+    const float* vdiff = trained + d;
+    const float* qv = queries + q * d;
+    float mx = 0.f;
+    for (int i = lane; i < d; i += KN_WAVE) {
+        mx = fmaxf(mx, fabsf(qv[i] * vdiff[i] * (1.0f / 255.0f)));
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        mx = fmaxf(mx, __shfl_xor(mx, off, KN_WAVE));
+    }
+    int ex = 0;
+    if (mx > 0.f && mx < INFINITY) {
+        ex = 9 - ilogbf(mx);
+        ex = max(-60, min(60, ex));
+    }
+    const float sc = ldexpf(1.0f, ex);
+    float sA = 0.f, sW = 0.f, sYp = 0.f, sHL = 0.f;
+    for (int i = lane; i < ldq; i += KN_WAVE) {
+        _Float16 h = (_Float16)0.f, l = (_Float16)0.f;
+        if (i < d) {
+            const float y = qv[i];
+            const float yp = y * vdiff[i] * (1.0f / 255.0f) * sc;
+            h = (_Float16)yp;
+            l = (_Float16)(yp - (float)h);
+            sA += y * (vmin[i] + 0.5f * vdiff[i] * (1.0f / 255.0f));
+            sW += fabsf(y) * (fabsf(vmin[i]) + fabsf(vdiff[i]));
+            sYp += fabsf(y * vdiff[i] * (1.0f / 255.0f));
+            sHL += (float)h + (float)l;
+        }
+        qh[q * ldq + i] = h;
+        ql[q * ldq + i] = l;
+    }
+    sA = ms_wave_sum(sA);
+    sW = ms_wave_sum(sW);
+    sYp = ms_wave_sum(sYp);
+    sHL = ms_wave_sum(sHL);
+    if (lane == 0) {
+        float* o = qs + q * 8;
+        o[0] = sc;
+        o[1] = sA;
+        o[2] = sW;
+        o[3] = sYp;
+        o[4] = sHL;
+        o[5] = (mx < INFINITY) ? 1.f : 0.f;
+        o[6] = 0.f;
+        o[7] = 0.f;
+    }
+}
+
+hipError_t launch_ms_sq8_query_prep(const float* queries, int64_t nq, int d, int ldq, const float* trained, void* qh,
+                                    void* ql, float* qs, hipStream_t s) {
+    if (nq <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(ms_sq8_query_prep_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, queries, nq, d, ldq,
+                       trained, reinterpret_cast<_Float16*>(qh), reinterpret_cast<_Float16*>(ql), qs);
+    return hipGetLastError();
+}
+
 // DUMP: as in mscan_flat_kernel; the pessimistic distance is u0 + v (acc - off) with the per-pair constants below.
 template <bool IS_L2, bool DUMP>
 __global__ __launch_bounds__(MQ_THREADS) void mscan_sq8_kernel(MScanArgs a) {
@@ -616,8 +689,9 @@ __global__ __launch_bounds__(MQ_THREADS) void mscan_sq8_kernel(MScanArgs a) {
                 slot = a.sample_off[(int64_t)q * a.nslot + slot]; // (sPs then holds the pair's first dump column)
             }
             const float* qv = a.queries + (int64_t)q * d;
+            const bool prepared = !IS_L2 && a.qs != nullptr; // (IP: hi / lo rows and sums come from ms_sq8_query_prep)
             float mx = 0.f;
-            for (int i = lane; i < d; i += KN_WAVE) {
+            for (int i = lane; !prepared && i < d; i += KN_WAVE) {
                 const float y = IS_L2 ? (qv[i] - cen[i]) : qv[i];
                 mx = fmaxf(mx, fabsf(y * vdiff[i] * (1.0f / 255.0f)));
             }
@@ -629,9 +703,18 @@ __global__ __launch_bounds__(MQ_THREADS) void mscan_sq8_kernel(MScanArgs a) {
                 ex = 9 - ilogbf(mx);
                 ex = max(-60, min(60, ex));
             }
-            const float sc = ldexpf(1.0f, ex);
+            float sc = ldexpf(1.0f, ex);
             float sA = 0.f, sW = 0.f, sYp = 0.f, sHL = 0.f, sR = 0.f;
-            for (int i = lane; i < nstep * 32; i += KN_WAVE) {
+            if (prepared) {
+                const float* o = a.qs + (int64_t)q * 8;
+                sc = o[0];
+                sA = o[1];
+                sW = o[2];
+                sYp = o[3];
+                sHL = o[4];
+                mx = o[5] != 0.f ? 0.f : INFINITY;
+            }
+            for (int i = lane; !prepared && i < nstep * 32; i += KN_WAVE) {
                 _Float16 h = (_Float16)0.f, l = (_Float16)0.f;
                 if (i < d) {
                     const float y = IS_L2 ? (qv[i] - cen[i]) : qv[i];
@@ -647,11 +730,13 @@ __global__ __launch_bounds__(MQ_THREADS) void mscan_sq8_kernel(MScanArgs a) {
                 sH[j * ldh + i] = h;
                 sL[j * ldh + i] = l;
             }
-            sA = ms_wave_sum(sA);
-            sW = ms_wave_sum(sW);
-            sYp = ms_wave_sum(sYp);
-            sHL = ms_wave_sum(sHL);
-            sR = ms_wave_sum(sR);
+            if (!prepared) {
+                sA = ms_wave_sum(sA);
+                sW = ms_wave_sum(sW);
+                sYp = ms_wave_sum(sYp);
+                sHL = ms_wave_sum(sHL);
+                sR = ms_wave_sum(sR);
+            }
             const float dis0 = IS_L2 ? 0.f : a.coarse_dis[(int64_t)q * a.nslot + slot_in];
             // (the constants below are themselves rounded: a few ulp of the magnitudes they are formed from go on top)
             // Error bound, every term with a factor 2 on top of the standard worst-case analysis (u = 2^-24):
@@ -689,7 +774,7 @@ __global__ __launch_bounds__(MQ_THREADS) void mscan_sq8_kernel(MScanArgs a) {
                     thr -= 8.0f * 5.9604645e-8f * (fabsf(off) + fabsf(thr));
                 }
             }
-        } else {
+        } else if (IS_L2 || a.qs == nullptr) {
             for (int i = lane; i < nstep * 32; i += KN_WAVE) {
                 sH[j * ldh + i] = (_Float16)0.f;
                 sL[j * ldh + i] = (_Float16)0.f;
@@ -706,6 +791,24 @@ __global__ __launch_bounds__(MQ_THREADS) void mscan_sq8_kernel(MScanArgs a) {
         }
     }
     __syncthreads();
+    if (!IS_L2 && a.qs != nullptr) {
+        // prepared query operands: the 32 pairs' hi / lo rows are copied into LDS, 16 bytes per thread and turn
+        const int nv = nstep * 4; // 16-byte pieces per row (nstep * 32 halves)
+        const uint4* gh = reinterpret_cast<const uint4*>(a.qh);
+        const uint4* gl = reinterpret_cast<const uint4*>(a.ql);
+        for (int t = threadIdx.x; t < MQ_QT * nv; t += MQ_THREADS) {
+            const int j = t / nv, v = t % nv;
+            const int32_t q = sPq[j];
+            uint4 h = make_uint4(0, 0, 0, 0), l = h;
+            if (q >= 0) {
+                h = gh[(int64_t)q * nv + v];
+                l = gl[(int64_t)q * nv + v];
+            }
+            *reinterpret_cast<uint4*>(sH + j * ldh + v * 8) = h;
+            *reinterpret_cast<uint4*>(sL + j * ldh + v * 8) = l;
+        }
+        __syncthreads();
+    }
 
     const int hi = lane >> 5, lr = lane & 31;
     int64_t nblk = (len + 63) >> 6;
@@ -936,6 +1039,7 @@ hipError_t launch_ms_tau(const float* sel_d, int64_t nq, int k, bool is_l2, floa
 // running top-k kept through chunks: LDS slots [0, k) hold the best so far, slots [k, P) the next chunk of candidates;
 // bitonic sort by (distance key, id tie key); repeat.  Any number of candidates, canonical order throughout.
 constexpr int MF_THREADS = 256;
+constexpr int MF_MLP = 8; // row pieces requested at a time per candidate
 
 template <bool IS_L2, int KIND> // KIND 1: fp32 rows, 3: SQ8
 __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, const int64_t* __restrict__ keys,
@@ -999,40 +1103,63 @@ __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, c
                 const int64_t blk = a.list_blk_off[list] + (pos >> 6);
                 const int r = (int)(pos & 63);
                 float acc = 0.f;
+                // A candidate's row is gathered in 16-byte pieces 1 KiB apart (interleaved blocks): MF_MLP of them are
+                // requested at a time -- one dependent load per piece made this stage latency-bound (C5: 25 ms).
                 if (KIND == 1) {
                     const float4* p = reinterpret_cast<const float4*>(a.rows) + blk * (int64_t)a.nchunk * 64 + r;
-                    for (int c4 = 0; c4 < a.nchunk; c4++) {
-                        const float4 y = p[(int64_t)c4 * 64];
-                        const float4 x = *reinterpret_cast<const float4*>(sq + c4 * 4);
-                        if (IS_L2) {
-                            acc = l2_step(acc, x.x, y.x);
-                            acc = l2_step(acc, x.y, y.y);
-                            acc = l2_step(acc, x.z, y.z);
-                            acc = l2_step(acc, x.w, y.w);
-                        } else {
-                            acc = ip_step(acc, x.x, y.x);
-                            acc = ip_step(acc, x.y, y.y);
-                            acc = ip_step(acc, x.z, y.z);
-                            acc = ip_step(acc, x.w, y.w);
+                    for (int c0 = 0; c0 < a.nchunk; c0 += MF_MLP) {
+                        float4 yy[MF_MLP];
+#pragma unroll
+                        for (int u = 0; u < MF_MLP; u++) {
+                            yy[u] = p[(int64_t)min(c0 + u, a.nchunk - 1) * 64];
+                        }
+#pragma unroll
+                        for (int u = 0; u < MF_MLP; u++) {
+                            const int c4 = c0 + u;
+                            if (c4 < a.nchunk) {
+                                const float4 y = yy[u];
+                                const float4 x = *reinterpret_cast<const float4*>(sq + c4 * 4);
+                                if (IS_L2) {
+                                    acc = l2_step(acc, x.x, y.x);
+                                    acc = l2_step(acc, x.y, y.y);
+                                    acc = l2_step(acc, x.z, y.z);
+                                    acc = l2_step(acc, x.w, y.w);
+                                } else {
+                                    acc = ip_step(acc, x.x, y.x);
+                                    acc = ip_step(acc, x.y, y.y);
+                                    acc = ip_step(acc, x.z, y.z);
+                                    acc = ip_step(acc, x.w, y.w);
+                                }
+                            }
                         }
                     }
                 } else {
                     const uint4* p = reinterpret_cast<const uint4*>(a.rows) + blk * (int64_t)a.nchunk * 64 + r;
                     const float* cen = a.centroids + list * d;
-                    for (int c16 = 0; c16 < a.nchunk; c16++) {
-                        const uint4 w = p[(int64_t)c16 * 64];
-                        const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+                    for (int c0 = 0; c0 < a.nchunk; c0 += MF_MLP) {
+                        uint4 wv[MF_MLP];
 #pragma unroll
-                        for (int e2 = 0; e2 < 16; e2++) {
-                            const int i = c16 * 16 + e2;
-                            const uint32_t code = (ww[e2 >> 2] >> (8 * (e2 & 3))) & 0xffu;
-                            const float x = fadd_x(svmin[i], fmul_x(tab[code], svdiff[i]));
-                            if (IS_L2) {
-                                // padded dims: y = 0, x = 0: they add exactly +0
-                                const float y = (i < d) ? fsub_x(sq[i], cen[i]) : 0.f;
-                                acc = l2_step(acc, y, x);
-                            } else {
-                                acc = ip_step(acc, sq[i], x);
+                        for (int u = 0; u < MF_MLP; u++) {
+                            wv[u] = p[(int64_t)min(c0 + u, a.nchunk - 1) * 64];
+                        }
+#pragma unroll
+                        for (int u = 0; u < MF_MLP; u++) {
+                            const int c16 = c0 + u;
+                            if (c16 < a.nchunk) {
+                                const uint32_t ww[4] = {wv[u].x, wv[u].y, wv[u].z, wv[u].w};
+#pragma unroll
+                                for (int e2 = 0; e2 < 16; e2++) {
+                                    const int i = c16 * 16 + e2;
+                                    const uint32_t code = (ww[e2 >> 2] >> (8 * (e2 & 3))) & 0xffu;
+                                    const float x = fadd_x(svmin[i], fmul_x(tab[code], svdiff[i]));
+                                    if (IS_L2) {
+                                        // padded dims: y = 0, x = 0: they add exactly +0
+                                        const float y = (i < d) ? fsub_x(sq[i], cen[i]) : 0.f;
+                                        acc = l2_step(acc, y, x);
+                                    } else {
+                                        acc = ip_step(acc, sq[i], x);
+                                    }
+                                }
                             }
                         }
                     }
