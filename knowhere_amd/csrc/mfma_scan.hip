@@ -6,15 +6,18 @@
 // list) x (queries that probe it) x d block is a dense contraction, and only the k best rows of a query need the
 // reference's exact arithmetic.  So, exactly as the coarse quantizer does (coarse_gemm.hip):
 //
-//   1. sample         the first min(len, MS_SAMPLE) rows of every query's CLOSEST list go through the same MFMA kernel in
-//                     DUMP mode: it writes a pessimistic distance (approx widened by the error bound eps, filtered rows
-//                     as the neutral value) per (query, row); row_select picks the k-th best per query = tau_q.  k
-//                     unfiltered rows are provably at least that good, so tau_q bounds the query's final k-th distance.
+//   1. sample         the rows of a query's first probes, in coarse order until max(1024, 8 k) rows are covered (one list
+//                     when the closest list is long enough, several when it is short or empty), at most MS_SAMPLE in
+//                     all, go through the same MFMA kernel in DUMP mode: it writes a pessimistic distance (approx
+//                     widened by the error bound eps, filtered rows as the neutral value) per (query, row);
+//                     row_select picks the k-th best per query = tau_q.  k unfiltered rows are provably at least that
+//                     good, so tau_q bounds the query's final k-th distance.
 //   2. mscan_*_kernel every (query, list) pair: approximate distances on the matrix cores
 //                     (v_mfma_f32_32x32x2_f32 for fp32 rows; v_mfma_f32_32x32x16_f16 for SQ8 codes), one
 //                     compare per (row, query) against tau_q widened by eps; rows that pass are appended to the
-//                     query's candidate list.  Every row whose EXACT distance is <= tau_q passes
-//                     (|approx - exact| <= eps), in particular every row of the final top-k.
+//                     query's candidate list and counted in its 64-bin histogram, which units starting later read
+//                     to tighten tau_q.  Every row whose EXACT distance is <= tau_q passes (|approx - exact| <= eps),
+//                     in particular every row of the final top-k.
 //   3. mscan_finish   per query: exact reference-order distances of its candidates (the same l2_step / ip_step /
 //                     SQ8 decode sequence as the exact kernels), canonical sort, top-k.  Bit-equal to the exact
 //                     scan: the candidates are a superset of the true top-k and their distances are the reference's.
@@ -50,7 +53,7 @@ constexpr int MS_WAVES = 4;
 constexpr int MS_THREADS = MS_WAVES * KN_WAVE;
 constexpr int MS_NQT = 2;          // query tiles of 32 per unit (fp32 rows)
 constexpr int MS_QT = 32 * MS_NQT; // queries per unit
-constexpr int MS_SAMPLE = 4096;    // rows of the closest list that feed tau_q (a multiple of 64, <= row_select's limit)
+constexpr int MS_SAMPLE = 4096;    // rows that feed tau_q, at most (a multiple of 64, <= row_select's limit)
 
 // ---- ||x||^2 per stored row position (padded block layout), and the maximum ----------------------------------
 __global__ void ms_block_norms_kernel(const float4* __restrict__ rows, int64_t total_blk, int nchunk,
