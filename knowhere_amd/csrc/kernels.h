@@ -209,6 +209,8 @@ struct MScanArgs {
     const void* qh;
     const void* ql;
     const float* qs;
+    int32_t unit_loop;           // 1 = the (fixed) grid walks units blockIdx.x, + gridDim.x, ... < *nunits_dev
+    float* gthr_rw;              // = gthr, written by the finish kernel's retry preparation
 };
 
 // ---- flat_scan.hip ----
@@ -276,11 +278,11 @@ hipError_t launch_ms_sq8_query_prep(const float* queries, int64_t nq, int d, int
                                     void* ql, float* qs, hipStream_t s);
 hipError_t launch_ms_tau(const float* sel_d, int64_t nq, int k, bool is_l2, float* gthr, uint2* gmeta, hipStream_t s);
 hipError_t launch_mscan_finish(const MScanArgs& a, int kind, bool is_l2, const int64_t* keys, const float* coarse_dis,
-                               int nprobe, int k, float* out_d, int64_t* out_i, unsigned long long* counters,
+                               int nprobe, int k, float* out_d, int64_t* out_i, unsigned long long* counters, int pass,
                                hipStream_t s);
-hipError_t launch_ms_flag_pairs(const int32_t* overflow, const int64_t* keys, int64_t nq, int nprobe, int64_t nlist,
-                                const int64_t* list_len, int k, KnItem* items, KnPair* pairs, int64_t* nitems,
-                                int64_t* empty_mark, hipStream_t s);
+hipError_t launch_ms_flag_pairs(const int32_t* overflow, int want, const int64_t* keys, int64_t nq, int nprobe,
+                                int64_t nlist, const int64_t* list_len, int k, KnItem* items, KnPair* pairs,
+                                int64_t* nitems, int64_t* empty_mark, hipStream_t s);
 
 // ---- sq_scan.hip ----
 hipError_t launch_sq_scan(const SqScanArgs& a, bool is_l2, int64_t grid, hipStream_t s, int qg_override = 0);

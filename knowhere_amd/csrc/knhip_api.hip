@@ -188,6 +188,7 @@ struct knhip_index {
     // MFMA prefilter (mfma_scan.hip): KNHIP_MSCAN = 0 never, 1 whenever the shape allows, 2 (default) when the lists
     // are shared by enough queries of the batch
     int mscan = 2;
+    int mscan_cap = 0;           // KNHIP_MSCAN_CAP: candidate capacity per query (0 = automatic; tests force the retry round)
     mutable bool xnorm_ready = false;
     mutable DevBuf xnorm;        // [total blocks * 64] ||x||^2 per stored row position, built on first use
     mutable float xnorm_max = 0.f;
@@ -390,6 +391,8 @@ int build_list_layout(knhip_index* idx, const std::vector<int64_t>& list_off, co
         idx->pq_q4 = (q4 && q4[0] >= '0' && q4[0] <= '2') ? q4[0] - '0' : 2;
         const char* ms = getenv("KNHIP_MSCAN");
         idx->mscan = (ms && ms[0] >= '0' && ms[0] <= '2') ? ms[0] - '0' : 2;
+        const char* mc = getenv("KNHIP_MSCAN_CAP");
+        idx->mscan_cap = (mc && *mc) ? std::max(0, atoi(mc)) : 0;
         idx->xnorm_ready = false;
     }
     for (int64_t l = 0; l < nlist; l++) {
@@ -652,6 +655,9 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         while (ms_cap > 1024 && (double)ms_cap * (double)nq * 8.0 > 3.0e9) {
             ms_cap >>= 1;
         }
+        if (idx->mscan_cap > 0) {
+            ms_cap = idx->mscan_cap;
+        }
         use_ms = lds <= 160 * 1024 - 1024 && ms_cap >= 2 * k &&
                 (idx->mscan == 1 || npairs >= 8 * nlist);
     }
@@ -752,6 +758,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         m.cand = ws->ms_cand.as<int64_t>();
         m.cap = ms_cap;
         m.overflow = overflow;
+        m.gthr_rw = ws->gthr.as<float>();
         m.k = k;
         if (idx->cand_hist) {
             m.ghist = ws->ghist.as<uint32_t>();
@@ -819,12 +826,28 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             }
         }
         {
-            // phase 3: exact distances of the candidates -> final top-k; phase 4: overflowed queries through the exact
-            // kernels (one-query items) and the ordinary merge
+            // phase 3: exact distances of the candidates -> final top-k.  phase 4: overflowed queries.  First a RETRY
+            // (the exact k-th of the candidates a query gathered before it overflowed is a tight bound: its pairs are
+            // filtered once more as one-query units, then finished); whatever overflows again, or had no bound and no
+            // candidates, goes through the exact kernels (one-query items) and the ordinary merge.
             StageTimer t(idx, s, KNHIP_STAGE_MERGE);
-            HIP_TRY(launch_mscan_finish(m, kind, is_l2, keys_p, cdis_p, nprobe, k, d_out_d, d_out_i,
-                                        idx->coarse_fail_dev.as<unsigned long long>() + 1, s));
-            HIP_TRY(launch_ms_flag_pairs(overflow, keys_p, nq, nprobe, nlist, idx->d_list_len.as<int64_t>(), k,
+            unsigned long long* counters = idx->coarse_fail_dev.as<unsigned long long>() + 1;
+            HIP_TRY(launch_mscan_finish(m, kind, is_l2, keys_p, cdis_p, nprobe, k, d_out_d, d_out_i, counters, 1, s));
+            HIP_TRY(launch_ms_flag_pairs(overflow, 2, keys_p, nq, nprobe, nlist, idx->d_list_len.as<int64_t>(), k,
+                                         ws->items.as<KnItem>(), wt.pairs, wt.nitems, nullptr, s));
+            MScanArgs r = m;
+            r.units = ws->items.as<KnItem>();
+            r.nunits_dev = wt.nitems;
+            r.unit_loop = 1;
+            r.ghist = nullptr; // (the retried rows were counted once already: counting them again would fake k candidates)
+            r.gmeta = nullptr;
+            if (kind == KNHIP_IVF_FLAT) {
+                HIP_TRY(launch_mscan_flat(r, is_l2, npairs, s));
+            } else {
+                HIP_TRY(launch_mscan_sq8(r, is_l2, npairs, s));
+            }
+            HIP_TRY(launch_mscan_finish(m, kind, is_l2, keys_p, cdis_p, nprobe, k, d_out_d, d_out_i, counters, 2, s));
+            HIP_TRY(launch_ms_flag_pairs(overflow, 1, keys_p, nq, nprobe, nlist, idx->d_list_len.as<int64_t>(), k,
                                          ws->items.as<KnItem>(), wt.pairs, wt.nitems, ws->partial_i.as<int64_t>(), s));
             if (int rc = exact_one(ws->items.as<KnItem>(), wt.pairs, wt.nitems, std::min<int64_t>(npairs, 4096))) {
                 return rc;

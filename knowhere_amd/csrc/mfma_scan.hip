@@ -240,19 +240,10 @@ __device__ __forceinline__ unsigned long long ms_valid_rows(const MScanArgs& a, 
 // + eps) or value = acc - c (IP: c = eps).
 // NQT = query tiles of 32 per unit (2 in filter mode; 1 in the sample pass, whose units hold few queries).
 template <bool IS_L2, bool DUMP, int NQT>
-__global__ __launch_bounds__(MS_THREADS, 4) void mscan_flat_kernel(MScanArgs a) {
+__device__ __forceinline__ void mscan_flat_unit(const MScanArgs a, const int64_t u, unsigned char* smem) {
     constexpr int QT = 32 * NQT;
-    extern __shared__ __align__(16) unsigned char smem[];
     const int lane = lane_id();
     const int wave = threadIdx.x / KN_WAVE;
-    const int64_t nunits = *a.nunits_dev;
-    if ((int64_t)blockIdx.x >= ((nunits + 7) / 8) * 8) {
-        return;
-    }
-    const int64_t u = xcd_item(blockIdx.x, nunits);
-    if (u >= nunits) {
-        return;
-    }
     const KnItem it = a.units[u];
     const int npair = it.npair;
     const int64_t list = it.list;
@@ -478,6 +469,29 @@ __global__ __launch_bounds__(MS_THREADS, 4) void mscan_flat_kernel(MScanArgs a) 
     }
 }
 
+// One unit per workgroup in XCD-aware order; a.unit_loop: a fixed grid walks a unit table whose size only the device
+// knows (the retry round of overflowed queries).  Every exit inside a unit is workgroup-uniform.
+template <bool IS_L2, bool DUMP, int NQT, bool LOOP>
+__global__ __launch_bounds__(MS_THREADS, 4) void mscan_flat_kernel(MScanArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int64_t nunits = *a.nunits_dev;
+    if (LOOP) {
+        for (int64_t u = blockIdx.x; u < nunits; u += gridDim.x) {
+            mscan_flat_unit<IS_L2, DUMP, NQT>(a, u, smem);
+            __syncthreads();
+        }
+    } else {
+        if ((int64_t)blockIdx.x >= ((nunits + 7) / 8) * 8) {
+            return;
+        }
+        const int64_t u = xcd_item(blockIdx.x, nunits);
+        if (u >= nunits) {
+            return;
+        }
+        mscan_flat_unit<IS_L2, DUMP, NQT>(a, u, smem);
+    }
+}
+
 // ---- SQ8 codes -------------------------------------------------------------------------------------------------
 // Decoded component (reference codecs.h:37-41, quantizers.h:139-145): x_i = vmin_i + vdiff_i (c_i + 0.5) / 255, so with
 // y = q (IP) or q - centroid (L2, by_residual) and y'_i = y_i vdiff_i / 255:
@@ -644,18 +658,9 @@ hipError_t launch_ms_sq8_query_prep(const float* queries, int64_t nq, int d, int
 
 // DUMP: as in mscan_flat_kernel; the pessimistic distance is u0 + v (acc - off) with the per-pair constants below.
 template <bool IS_L2, bool DUMP>
-__global__ __launch_bounds__(MQ_THREADS) void mscan_sq8_kernel(MScanArgs a) {
-    extern __shared__ __align__(16) unsigned char smem[];
+__device__ __forceinline__ void mscan_sq8_unit(const MScanArgs a, const int64_t u, unsigned char* smem) {
     const int lane = lane_id();
     const int wave = threadIdx.x / KN_WAVE;
-    const int64_t nunits = *a.nunits_dev;
-    if ((int64_t)blockIdx.x >= ((nunits + 7) / 8) * 8) {
-        return;
-    }
-    const int64_t u = xcd_item(blockIdx.x, nunits);
-    if (u >= nunits) {
-        return;
-    }
     const KnItem it = a.units[u];
     const int npair = it.npair;
     const int64_t list = it.list;
@@ -963,6 +968,27 @@ __global__ __launch_bounds__(MQ_THREADS) void mscan_sq8_kernel(MScanArgs a) {
     }
 }
 
+template <bool IS_L2, bool DUMP, bool LOOP>
+__global__ __launch_bounds__(MQ_THREADS) void mscan_sq8_kernel(MScanArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int64_t nunits = *a.nunits_dev;
+    if (LOOP) { // (see mscan_flat_kernel)
+        for (int64_t u = blockIdx.x; u < nunits; u += gridDim.x) {
+            mscan_sq8_unit<IS_L2, DUMP>(a, u, smem);
+            __syncthreads();
+        }
+    } else {
+        if ((int64_t)blockIdx.x >= ((nunits + 7) / 8) * 8) {
+            return;
+        }
+        const int64_t u = xcd_item(blockIdx.x, nunits);
+        if (u >= nunits) {
+            return;
+        }
+        mscan_sq8_unit<IS_L2, DUMP>(a, u, smem);
+    }
+}
+
 // ---- sample plan ---------------------------------------------------------------------------------------------------
 // Which (query, slot) pairs feed tau_q: the probes in coarse order until `smin` rows are covered (one list when the
 // closest list is long enough, several when it is short or empty -- inner-product clusterings have many tiny lists),
@@ -1049,20 +1075,32 @@ __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, c
                                                                   const float* __restrict__ coarse_dis, int nprobe,
                                                                   int k, int P_max, float* __restrict__ out_d,
                                                                   int64_t* __restrict__ out_i,
-                                                                  unsigned long long* __restrict__ counters) {
+                                                                  unsigned long long* __restrict__ counters, int pass) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ float tab[256];
     const int64_t q = blockIdx.x;
     const int tid = threadIdx.x;
-    if (a.overflow[q] != 0) {
-        if (tid == 0) {
-            atomicAdd(counters + 1, 1ull);
+    // pass 1: queries that did not overflow are finished; an overflowed query (flag 1) with candidates gets a RETRY:
+    //         the exact k-th of the candidates gathered so far is a tight bound (k unfiltered rows are at least that
+    //         good) -> gthr, its list is emptied, flag 2; its pairs are then filtered again as one-query units.
+    // pass 2: the retried queries (flag 2) are finished; one that overflowed again carries flag 1 (exact kernels).
+    const int flag = a.overflow[q];
+    const bool retry_prep = pass == 1 && flag == 1;
+    if ((pass == 1 && flag != 0 && flag != 1) || (pass == 2 && flag != 2)) {
+        if (pass == 2 && flag == 1 && tid == 0 && a.cand_cnt[q] >= a.cap) {
+            atomicAdd(counters + 1, 1ull); // overflowed again in the retry round: the exact kernels
         }
-        return; // redone by the exact kernels
+        return;
     }
     const int d = a.d;
     const int n = min(a.cand_cnt[q], a.cap);
-    if (tid == 0) {
+    if (retry_prep && n < k) {
+        if (tid == 0) {
+            atomicAdd(counters + 1, 1ull);
+        }
+        return; // no bound and nothing gathered: the exact kernels
+    }
+    if (tid == 0 && !retry_prep) {
         atomicAdd(counters, 1ull);
         atomicAdd(counters + 2, (unsigned long long)n);
     }
@@ -1198,6 +1236,18 @@ __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, c
             }
         }
     }
+    if (retry_prep) {
+        if (tid == 0) {
+            if (!(key[k - 1] == 0xffffffffu && tie[k - 1] == ~0ull)) {
+                a.gthr_rw[q] = dist_key_inv<IS_L2>(key[k - 1]);
+                a.cand_cnt[q] = 0;
+                a.overflow[q] = 2;
+            } else {
+                atomicAdd(counters + 1, 1ull); // (stays flagged 1: the exact kernels)
+            }
+        }
+        return;
+    }
     for (int e = tid; e < k; e += MF_THREADS) {
         float dd = worst_dist<IS_L2>();
         int64_t ii = -1;
@@ -1208,13 +1258,17 @@ __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, c
         out_d[q * k + e] = dd;
         out_i[q * k + e] = ii;
     }
+    if (pass == 2 && tid == 0) {
+        a.overflow[q] = 0; // finished: not part of the exact fallback's merge
+    }
 }
 
 // ---- overflowed queries -> compact one-query work items for the exact kernels ------------------------------------
-// thread per (query, slot): pairs of flagged queries become items {list, 1 pair}; pairs of empty / invalid lists get
-// their partial slot marked empty (as the work table does).  *nitems must be 0 on entry.
-__global__ void ms_flag_pairs_kernel(const int32_t* __restrict__ overflow, const int64_t* __restrict__ keys, int64_t nq,
-                                     int nprobe, int64_t nlist, const int64_t* __restrict__ list_len, int k,
+// thread per (query, slot): pairs of the queries whose flag == want become items {list, 1 pair} (= one-query units of
+// the filter kernels for the retry round, want = 2; items of the exact kernels, want = 1); pairs of empty / invalid
+// lists get their partial slot marked empty where asked (as the work table does).  *nitems is zeroed first.
+__global__ void ms_flag_pairs_kernel(const int32_t* __restrict__ overflow, int want, const int64_t* __restrict__ keys,
+                                     int64_t nq, int nprobe, int64_t nlist, const int64_t* __restrict__ list_len, int k,
                                      KnItem* __restrict__ items, KnPair* __restrict__ pairs, int64_t* __restrict__ nitems,
                                      int64_t* __restrict__ empty_mark) {
     if (overflow[nq] == 0) {
@@ -1225,12 +1279,14 @@ __global__ void ms_flag_pairs_kernel(const int32_t* __restrict__ overflow, const
         return;
     }
     const int64_t q = t / nprobe;
-    if (overflow[q] == 0) {
+    if (overflow[q] != want) {
         return;
     }
     const int64_t key = keys[t];
     if (key < 0 || key >= nlist || list_len[key] == 0) {
-        empty_mark[t * k] = -1;
+        if (empty_mark != nullptr) {
+            empty_mark[t * k] = -1;
+        }
         return;
     }
     const int64_t pos = (int64_t)atomicAdd(reinterpret_cast<unsigned long long*>(nitems), 1ull);
@@ -1245,15 +1301,15 @@ __global__ void ms_flag_pairs_kernel(const int32_t* __restrict__ overflow, const
     items[pos] = it;
 }
 
-hipError_t launch_ms_flag_pairs(const int32_t* overflow, const int64_t* keys, int64_t nq, int nprobe, int64_t nlist,
-                                const int64_t* list_len, int k, KnItem* items, KnPair* pairs, int64_t* nitems,
-                                int64_t* empty_mark, hipStream_t s) {
+hipError_t launch_ms_flag_pairs(const int32_t* overflow, int want, const int64_t* keys, int64_t nq, int nprobe,
+                                int64_t nlist, const int64_t* list_len, int k, KnItem* items, KnPair* pairs,
+                                int64_t* nitems, int64_t* empty_mark, hipStream_t s) {
     hipError_t e = hipMemsetAsync(nitems, 0, sizeof(int64_t), s);
     if (e != hipSuccess || nq <= 0) {
         return e;
     }
-    hipLaunchKernelGGL(ms_flag_pairs_kernel, dim3((unsigned)((nq * nprobe + 255) / 256)), dim3(256), 0, s, overflow, keys,
-                       nq, nprobe, nlist, list_len, k, items, pairs, nitems, empty_mark);
+    hipLaunchKernelGGL(ms_flag_pairs_kernel, dim3((unsigned)((nq * nprobe + 255) / 256)), dim3(256), 0, s, overflow, want,
+                       keys, nq, nprobe, nlist, list_len, k, items, pairs, nitems, empty_mark);
     return hipGetLastError();
 }
 
@@ -1273,8 +1329,11 @@ hipError_t launch_mscan_sq8(const MScanArgs& a, bool is_l2, int64_t units_bound,
     }
     const size_t sm = mscan_sq8_smem(a.nstep);
     const bool dump = a.dump != nullptr;
-    auto kern = is_l2 ? (dump ? mscan_sq8_kernel<true, true> : mscan_sq8_kernel<true, false>)
-                      : (dump ? mscan_sq8_kernel<false, true> : mscan_sq8_kernel<false, false>);
+    auto kern = is_l2 ? (dump ? mscan_sq8_kernel<true, true, false> : mscan_sq8_kernel<true, false, false>)
+                      : (dump ? mscan_sq8_kernel<false, true, false> : mscan_sq8_kernel<false, false, false>);
+    if (a.unit_loop && !dump) { // the retry round's one-query units
+        kern = is_l2 ? mscan_sq8_kernel<true, false, true> : mscan_sq8_kernel<false, false, true>;
+    }
     if (sm > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
@@ -1282,7 +1341,7 @@ hipError_t launch_mscan_sq8(const MScanArgs& a, bool is_l2, int64_t units_bound,
             return e;
         }
     }
-    const int64_t grid = ((units_bound + 7) / 8) * 8;
+    const int64_t grid = a.unit_loop ? std::min<int64_t>(units_bound, 1024) : ((units_bound + 7) / 8) * 8;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(MQ_THREADS), sm, s, a);
     return hipGetLastError();
 }
@@ -1301,8 +1360,11 @@ hipError_t launch_mscan_flat(const MScanArgs& a, bool is_l2, int64_t units_bound
     }
     const bool dump = a.dump != nullptr;
     const size_t sm = dump ? (size_t)32 * (a.nstep * 16 + 4) * 4 + (size_t)32 * 16 : mscan_flat_smem(a.nstep);
-    auto kern = is_l2 ? (dump ? mscan_flat_kernel<true, true, 1> : mscan_flat_kernel<true, false, MS_NQT>)
-                      : (dump ? mscan_flat_kernel<false, true, 1> : mscan_flat_kernel<false, false, MS_NQT>);
+    auto kern = is_l2 ? (dump ? mscan_flat_kernel<true, true, 1, false> : mscan_flat_kernel<true, false, MS_NQT, false>)
+                      : (dump ? mscan_flat_kernel<false, true, 1, false> : mscan_flat_kernel<false, false, MS_NQT, false>);
+    if (a.unit_loop && !dump) { // the retry round's one-query units
+        kern = is_l2 ? mscan_flat_kernel<true, false, MS_NQT, true> : mscan_flat_kernel<false, false, MS_NQT, true>;
+    }
     if (sm > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
@@ -1310,7 +1372,7 @@ hipError_t launch_mscan_flat(const MScanArgs& a, bool is_l2, int64_t units_bound
             return e;
         }
     }
-    const int64_t grid = ((units_bound + 7) / 8) * 8;
+    const int64_t grid = a.unit_loop ? std::min<int64_t>(units_bound, 2048) : ((units_bound + 7) / 8) * 8;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(MS_THREADS), sm, s, a);
     return hipGetLastError();
 }
@@ -1326,7 +1388,7 @@ int mscan_finish_pmax(int cap, int k) {
 }
 
 hipError_t launch_mscan_finish(const MScanArgs& a, int kind, bool is_l2, const int64_t* keys, const float* coarse_dis,
-                               int nprobe, int k, float* out_d, int64_t* out_i, unsigned long long* counters,
+                               int nprobe, int k, float* out_d, int64_t* out_i, unsigned long long* counters, int pass,
                                hipStream_t s) {
     if (a.nq <= 0) {
         return hipSuccess;
@@ -1343,7 +1405,7 @@ hipError_t launch_mscan_finish(const MScanArgs& a, int kind, bool is_l2, const i
             if (e != hipSuccess) return e;                                                                      \
         }                                                                                                       \
         hipLaunchKernelGGL(kern, dim3((unsigned)a.nq), dim3(MF_THREADS), sm, s, a, keys, coarse_dis, nprobe, k, \
-                           P_max, out_d, out_i, counters);                                                      \
+                           P_max, out_d, out_i, counters, pass);                                                \
     } while (0)
     if (kind == 1) {
         if (is_l2) MF_LAUNCH(true, 1); else MF_LAUNCH(false, 1);

@@ -136,3 +136,23 @@ def test_mscan_config_shapes(torch_cuda, port, monkeypatch):
             p = _check(port, ix, g0, g1, xq, k, nprobe, metric, f"SQ8 d=768 metric={metric} k={k}")
         g0.close()
         g1.close()
+
+
+@pytest.mark.parametrize("kind,metric", [(ob.IVF_FLAT, ob.L2), (ob.IVF_FLAT, ob.IP), (ob.IVF_SQ8, ob.IP), (ob.IVF_SQ8, ob.L2)],
+                         ids=["flat-l2", "flat-ip", "sq8-ip", "sq8-l2"])
+def test_mscan_retry_round(torch_cuda, port, monkeypatch, kind, metric):
+    """a tiny candidate capacity (KNHIP_MSCAN_CAP) makes most queries overflow with candidates in hand: they are retried
+    with the exact k-th of those candidates as their bound (one-query units of the filter kernel) and finished from the
+    second, short candidate list; only what overflows again reaches the exact kernels.  Results stay the oracle's."""
+    nb, d, nlist = 30000, 64, 40
+    xb, xq = gen_data(nb, d, 42), gen_data(90, d, 44)
+    ix = ob.make_index(port, kind, metric, xb, nlist=nlist)
+    monkeypatch.setenv("KNHIP_MSCAN_CAP", "24")
+    g0, g1 = _pair(monkeypatch, ix)
+    for k, nprobe in ((10, 16), (3, nlist), (12, 8)):
+        p = _check(port, ix, g0, g1, xq, k, nprobe, metric, f"retry kind={kind} metric={metric} k={k} nprobe={nprobe}")
+        assert p["mscan_queries"] + p["mscan_overflow_queries"] == len(xq)
+    bs = _bitset(nb, 0.4, 1)
+    _check(port, ix, g0, g1, xq, 10, 16, metric, "retry + bitset", bs, nb)
+    g0.close()
+    g1.close()
