@@ -318,10 +318,23 @@ def make_roofline(a, kind, prof, world):
         # one 4-byte table lookup per code byte: the LDS gather is the unit that binds (round-1 PMC: HBM traffic
         # is 0.03-0.14 x the algorithmic bytes, LDS ~ busy); SURVEY 8(d)'s no-reuse HBM model is kept beside it
         lds = scan_bytes * 4.0 / sec / 1e9 if sec > 0 else 0.0
-        return dict({"bound": "lds", "kernel": "knhip::pq_scan_q4_kernel<true, 2>", "achieved": round(lds, 1),
-                     "peak": round(LDS_PEAK_GBPS, 1), "unit": "GB/s", "frac": round(lds / LDS_PEAK_GBPS, 4),
-                     "note": "achieved = 4 B x code bytes scanned / launch time; peak = 256 B/clk/CU x 256 CU x 2.4 GHz"},
-                    **common)
+        out = dict({"bound": "lds", "kernel": "knhip::pq_scan_q4_kernel<true, 2>", "achieved": round(lds, 1),
+                    "peak": round(LDS_PEAK_GBPS, 1), "unit": "GB/s", "frac": round(lds / LDS_PEAK_GBPS, 4),
+                    "note": "achieved = 4 B x code bytes scanned / launch time; peak = 256 B/clk/CU x 256 CU x 2.4 GHz"},
+                   **common)
+        try:
+            sq = pmc_counters(a, world)
+        except Exception:
+            sq = None
+        if sq and sec > 0 and all(k in sq for k in ("SQ_INSTS_VALU", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE")):
+            # the loop is co-limited by VALU issue: the instruction counts of the PMC pass on file against
+            # this run's launch time; 4 cycles per instruction is the measured issue cost of the forms the loop uses
+            # (v_pk_add_f32 4.95, SDWA 4.2, plain VOP2 2.5: tools/ubench/valu_rates), 1024 SIMDs
+            out["valu_issue"] = {"SQ_INSTS_VALU_per_launch": sq["SQ_INSTS_VALU"], "cycles_per_inst_assumed": 4.0,
+                                 "frac_of_simd_cycles_at_2.4GHz": round(sq["SQ_INSTS_VALU"] * 4.0 / 1024 / 2.4e9 / sec, 4),
+                                 "lds_bank_conflict_frac": round(sq["SQ_LDS_BANK_CONFLICT"] / sq["SQ_LDS_IDX_ACTIVE"], 5),
+                                 "source": sq.get("source")}
+        return out
     if prof.get("mscan_queries", 0) > 0:
         # MFMA prefilter + exact finish (mfma_scan.hip): the dominant kernel is a grouped (rows of a list) x (queries
         # that probe it) x d contraction; every unit streams its list once for up to 64 (fp32 rows) / 32 (SQ8) queries.
@@ -367,6 +380,18 @@ def make_roofline(a, kind, prof, world):
                  "frac": round(tf / VALU_PEAK_TFLOPS, 4),
                  "note": "separately rounded sub/mul/add per (row, query, dim) counted as 1 flop each; "
                          "peak = fp32 vector peak (an FMA counts 2)"}, **common)
+
+
+def pmc_counters(a, world):
+    """SQ counters of the dominant kernel from the PMC passes on file (same key as pmc_traffic), or None"""
+    path = os.path.join(ROOT, "profiles", "bench_pmc_traffic.json")
+    try:
+        t = json.load(open(path))
+    except Exception:
+        return None
+    key = (f"config={a.config},nb={a.nb},nlist={a.nlist},nprobe={a.nprobe},nq={a.nq},m={a.m},"
+           f"refine_k={a.refine_k},gpus={world}")
+    return t.get(key, {}).get("sq")
 
 
 def pmc_traffic(a, world):
