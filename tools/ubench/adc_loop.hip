@@ -4,6 +4,9 @@
 //   0 full (SDWA + ds_read_b128 + split/plain accumulates)      1 no EXEC flips (every step plain)
 //   2 no LDS reads (values = registers)                          3 no SDWA (addresses precomputed)
 //   4 only ds_read_b128 (no accumulate)                          5 only accumulates (plain + split), no LDS/SDWA
+//   6 f16 table, 8 queries per ds_read_b128, 4 v_pk_add_f16 per lookup, no EXEC flips: the loop an approximate
+//     (prefilter) ADC pass could run -- lanes rotated through m instead of delayed, half the LDS bytes per query
+//   7 the same with v_pk_add_f16 only (no LDS, no SDWA): its VALU floor
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -28,6 +31,14 @@ __device__ __forceinline__ void accum2(f2& n01, f2& n23, f2& o01, f2& o23, const
     } else {
         asm volatile(PLAIN("%4", "%5") PLAIN("%6", "%7") : "+v"(n01), "+v"(n23), "+v"(o01), "+v"(o23) : VALS(v));
     }
+}
+
+// modes 6 / 7: the 16 bytes of a lookup are 8 half-precision table values (8 queries); four packed accumulators
+__device__ __forceinline__ void accum2_h(uint32_t& h0, uint32_t& h1, uint32_t& h2, uint32_t& h3, const f4 (&v)[2]) {
+    asm volatile("v_pk_add_f16 %0, %0, %4\n v_pk_add_f16 %1, %1, %5\n v_pk_add_f16 %2, %2, %6\n v_pk_add_f16 %3, %3, %7\n"
+                 "v_pk_add_f16 %0, %0, %8\n v_pk_add_f16 %1, %1, %9\n v_pk_add_f16 %2, %2, %10\n v_pk_add_f16 %3, %3, %11\n"
+                 : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3)
+                 : "v"(v[0].x), "v"(v[0].y), "v"(v[0].z), "v"(v[0].w), "v"(v[1].x), "v"(v[1].y), "v"(v[1].z), "v"(v[1].w));
 }
 
 __device__ __forceinline__ uint32_t addr_lo(uint32_t w, uint32_t one) {
@@ -55,12 +66,13 @@ __global__ __launch_bounds__(1024) void k(float* out, const uint32_t* tok, int n
     typedef __attribute__((address_space(3))) const f4 lds_f4;
     f2 n01 = {0, 0}, n23 = {0, 0}, o01 = {0, 0}, o23 = {0, 0};
     f4 B0[2], B1[2], B2[2], B3[2];
+    uint32_t h0 = 0, h1 = 0, h2 = 0, h3 = 0;
     auto rd = [&](uint32_t a) -> f4 {
-        if (MODE == 2 || MODE == 5) return f4{__uint_as_float(a), 1.f, 2.f, 3.f};
+        if (MODE == 2 || MODE == 5 || MODE == 7) return f4{__uint_as_float(a), 1.f, 2.f, 3.f};
         return *reinterpret_cast<lds_f4*>(a);
     };
     auto issue2 = [&](uint32_t w, f4 (&v)[2]) {
-        if (MODE == 3 || MODE == 5) {
+        if (MODE == 3 || MODE == 5 || MODE == 7) {
             v[0] = rd(w & 0x1fff0u);
             v[1] = rd((w >> 15) & 0x1fff0u);
         } else {
@@ -75,7 +87,8 @@ __global__ __launch_bounds__(1024) void k(float* out, const uint32_t* tok, int n
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #define UNIT(U, BUF, WORD)                                                   \
     __builtin_amdgcn_sched_barrier(0);                                       \
-    if (MODE != 4) accum2<U, MODE != 1>(n01, n23, o01, o23, BUF);            \
+    if (MODE == 6 || MODE == 7) accum2_h(h0, h1, h2, h3, BUF);               \
+    else if (MODE != 4) accum2<U, MODE != 1>(n01, n23, o01, o23, BUF);       \
     else asm volatile("" :: "v"(BUF[0]), "v"(BUF[1]));                       \
     __builtin_amdgcn_sched_barrier(0);                                       \
     issue2(WORD, BUF);
@@ -88,7 +101,8 @@ __global__ __launch_bounds__(1024) void k(float* out, const uint32_t* tok, int n
         o01 = n01; o23 = n23;
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-    out[blockIdx.x * 1024 + threadIdx.x] = n01.x + n01.y + n23.x + n23.y + o01.x + o23.y + B0[0].x + B1[0].x + B2[0].x + B3[0].x;
+    out[blockIdx.x * 1024 + threadIdx.x] = n01.x + n01.y + n23.x + n23.y + o01.x + o23.y + B0[0].x + B1[0].x + B2[0].x + B3[0].x +
+                                           __uint_as_float(h0 ^ h1 ^ h2 ^ h3);
     if (lane == 0) atomicAdd(cyc + (threadIdx.x >> 6), t1 - t0);
 }
 
@@ -109,8 +123,8 @@ void run(const char* name, const uint32_t* dtok, float* out, unsigned long long*
     float ms; hipEventElapsedTime(&ms, e0, e1);
     unsigned long long h[16];
     hipMemcpy(h, dcyc, sizeof(h), hipMemcpyDeviceToHost);
-    // per CU: 16 waves x nwin windows; lookups per window per wave = 64 lanes x 32 steps x 4 queries
-    const double lookups = 256.0 * 16 * nwin * 64 * 32 * 4;
+    // per CU: 16 waves x nwin windows; lookups per window per wave = 64 lanes x 32 steps x 4 queries (8 in the f16 modes)
+    const double lookups = 256.0 * 16 * nwin * 64 * 32 * ((MODE == 6 || MODE == 7) ? 8 : 4);
     printf("%-34s %8.3f ms  %6.1f ns per window-round (16 waves)  %5.1f lookups/ns/CU (LDS peak 64/clk)  ticks/window: w0 %.0f w15 %.0f\n", name, ms,
            ms * 1e6 / nwin, lookups / 256 / (ms * 1e6), (double)h[0] / blocks / nwin, (double)h[15] / blocks / nwin);
 }
@@ -141,5 +155,7 @@ int main() {
     run<3>("no SDWA (and+shift addresses)", dtok, out, dcyc);
     run<4>("only SDWA + ds_read_b128", dtok, out, dcyc);
     run<5>("only accumulates", dtok, out, dcyc);
+    run<6>("f16 table, 8 queries, no flips", dtok, out, dcyc);
+    run<7>("f16: only v_pk_add_f16", dtok, out, dcyc);
     return 0;
 }
