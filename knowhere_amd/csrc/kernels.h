@@ -58,6 +58,19 @@ struct P4Rec {
 };
 static_assert(sizeof(P4Rec) == 96, "P4Rec layout");
 
+// flat work record of the half-precision ADC prefilter (pq_filter.hip), one per unit of (list, <= 8 pairs)
+struct P8Rec {
+    int32_t list;
+    int32_t npair;
+    int32_t q[8];
+    int32_t slot[8];  // filter: probe slot; sample pass: first dump column of the pair
+    float dis0[8];
+    int64_t len;      // rows to scan (sample pass: capped at the dump width)
+    int64_t sblk0;    // first block of the list in the rotated token stream
+    int64_t row_off;
+};
+static_assert(sizeof(P8Rec) == 128, "P8Rec layout");
+
 struct FlatScanArgs {
     // rows
     const float4* rows;          // interleaved blocks
@@ -211,7 +224,32 @@ struct MScanArgs {
     const float* qs;
     int32_t unit_loop;           // 1 = the (fixed) grid walks units blockIdx.x, + gridDim.x, ... < *nunits_dev
     float* gthr_rw;              // = gthr, written by the finish kernel's retry preparation
+    // IVF-PQ half-precision prefilter (pq_filter.hip; M = 32, dsub = 4)
+    const uint4* pq_codes_r;       // rotated token stream (pq_stream16r_kernel)
+    const int64_t* pq_sblk_off_r;  // [nlist + 1] first block of each list in it
+    const float* pq_psum;          // per stream position: sum_m term2[list][m][code_m] (L2; unused for IP)
+    const void* pq_qh;             // [nq][64][16][4][2] halves: per-query tables (pqf_query_table_kernel)
+    const float* pq_qs;            // [nq][4] = {scale, 1 / scale, eps_base, A}
+    const float4* pq_cb_t;         // [256][32] c-major codebook (exact finish)
+    const float* pq_precomp_t;     // [nlist][256][32] (exact finish, PQ_LUT_PRECOMP)
+    const uint8_t* pq_codes;       // canonical AoS codes [ntotal][32] (exact finish)
+    int32_t pq_lut_mode;           // PqLutMode
+    P8Rec* pq_recs;                // [unit bound]
+    int32_t* pq_ctr;               // [8 * 16] one unit counter per XCD, 64 B apart
 };
+
+// ---- pq_filter.hip ----
+int64_t pq_stream16r_blocks(int64_t len);
+hipError_t launch_pq_stream16r(const uint8_t* codes, const int64_t* list_row_off, const int64_t* list_len,
+                               const int64_t* list_sblk_off, int64_t nlist, uint4* out, hipStream_t s);
+hipError_t launch_pq_psum(const uint8_t* codes, const int64_t* list_row_off, const int64_t* list_len,
+                          const int64_t* list_sblk_off, int64_t nlist, const float* precomp_t, float* psum,
+                          uint32_t* pabs_max_bits, hipStream_t s);
+hipError_t launch_pqf_query_table(const float* queries, const float4* cb_t, int d, int64_t nq, bool is_l2, float pabs_max,
+                                  void* qh, float* qs, hipStream_t s);
+size_t pqf_smem();
+bool pqf_supports(int M, int d);
+hipError_t launch_pqf(const MScanArgs& a, bool is_l2, int64_t units_bound, hipStream_t s);
 
 // ---- flat_scan.hip ----
 int flat_scan_qg(int k);

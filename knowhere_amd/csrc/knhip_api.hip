@@ -128,6 +128,8 @@ struct Workspace {
     DevBuf ms_units, ms_unit_off, ms_nunits, ms_cand, ms_cand_cnt;  // ms_cand_cnt: [qb] counters + [qb + 1] overflow flags
     DevBuf ms_sample_off, ms_nrow;                                   // sample plan: [qb][nprobe] dump columns, [qb] rows
     DevBuf ms_qh, ms_ql, ms_qs;                                      // SQ8 IP: prepared query operands (halves) + sums
+                                                                     // (IVF-PQ prefilter: ms_qh = half tables, ms_qs = scales)
+    DevBuf pq_recs, pq_ctr;                                          // pq_filter.hip: unit records, per-XCD counters
     // host-boundary staging
     DevBuf h_queries, h_bitset, h_out_d, h_out_i, h_ref_d, h_ref_i;
     std::mutex mu;  // held while a *_device entry point enqueues on this (per-stream) workspace
@@ -193,6 +195,14 @@ struct knhip_index {
     mutable DevBuf xnorm;        // [total blocks * 64] ||x||^2 per stored row position, built on first use
     mutable float xnorm_max = 0.f;
     int64_t total_blk = 0;       // 64-row blocks of the interleaved layout
+    // IVF-PQ half-precision prefilter (pq_filter.hip): KNHIP_PQF = 1 switches it on (default off: not yet validated on
+    // hardware).  Its layouts are built on first use.
+    int pqf = 0;
+    mutable bool pqf_ready = false;
+    mutable DevBuf rows_r;           // rotated token stream (stream16r)
+    mutable DevBuf d_list_blk_off_r; // [nlist + 1]
+    mutable DevBuf psum;             // per stream position: sum_m term2 (L2)
+    mutable float pabs_max = 0.f;    // max over vectors of sum_m |term2|
     // scratch
     mutable std::mutex mu;
     std::mutex add_mu;     // serialises Add / Train
@@ -394,6 +404,11 @@ int build_list_layout(knhip_index* idx, const std::vector<int64_t>& list_off, co
         const char* mc = getenv("KNHIP_MSCAN_CAP");
         idx->mscan_cap = (mc && *mc) ? std::max(0, atoi(mc)) : 0;
         idx->xnorm_ready = false;
+        const char* pf = getenv("KNHIP_PQF");
+        idx->pqf = (pf && pf[0] == '1') ? 1 : 0;
+        idx->pqf_ready = false;
+        idx->rows_r.release();
+        idx->psum.release();
     }
     for (int64_t l = 0; l < nlist; l++) {
         idx->h_list_len[l] = list_off[l + 1] - list_off[l];
@@ -522,6 +537,40 @@ int ensure_mscan_norms(const knhip_index* idx) {
     return KNHIP_OK;
 }
 
+// IVF-PQ half-precision prefilter: rotated token stream + per-vector term-2 sums, from the canonical AoS codes
+int ensure_pqf(const knhip_index* idx) {
+    std::lock_guard<std::mutex> lk(idx->mu);
+    if (idx->pqf_ready) {
+        return KNHIP_OK;
+    }
+    const int64_t nlist = idx->nlist;
+    std::vector<int64_t> off(nlist + 1, 0);
+    for (int64_t l = 0; l < nlist; l++) {
+        off[l + 1] = off[l] + pq_stream16r_blocks(idx->h_list_len[l]);
+    }
+    HIP_TRY(idx->d_list_blk_off_r.alloc((size_t)(nlist + 1) * sizeof(int64_t)));
+    HIP_TRY(hipMemcpy(idx->d_list_blk_off_r.p, off.data(), (size_t)(nlist + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    HIP_TRY(idx->rows_r.alloc((size_t)std::max<int64_t>(off[nlist], 1) * 64 * sizeof(uint4)));
+    HIP_TRY(launch_pq_stream16r(idx->codes_aos.as<uint8_t>(), idx->d_list_row_off.as<int64_t>(),
+                                idx->d_list_len.as<int64_t>(), idx->d_list_blk_off_r.as<int64_t>(), nlist,
+                                idx->rows_r.as<uint4>(), nullptr));
+    idx->pabs_max = 0.f;
+    if (idx->is_l2) {
+        const size_t npos = (size_t)std::max<int64_t>(off[nlist] / 4, 1) * 64;
+        HIP_TRY(idx->psum.alloc((npos + 4) * sizeof(float)));
+        HIP_TRY(hipMemset(idx->psum.p, 0, (npos + 4) * sizeof(float)));
+        uint32_t* bits = reinterpret_cast<uint32_t*>(idx->psum.as<float>() + npos);
+        HIP_TRY(launch_pq_psum(idx->codes_aos.as<uint8_t>(), idx->d_list_row_off.as<int64_t>(),
+                               idx->d_list_len.as<int64_t>(), idx->d_list_blk_off_r.as<int64_t>(), nlist,
+                               idx->precomp_t.as<float>(), idx->psum.as<float>(), bits, nullptr));
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(&idx->pabs_max, bits, sizeof(float), hipMemcpyDeviceToHost));
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    idx->pqf_ready = true;
+    return KNHIP_OK;
+}
+
 Workspace* acquire_ws(const knhip_index* idx, void* stream_key, bool pooled_by_stream) {
     std::lock_guard<std::mutex> lk(idx->mu);
     if (pooled_by_stream) {
@@ -630,12 +679,20 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             qg_rank0 = pq_rank0 ? qg : 4;
         }
     }
-    // IVF-Flat / IVF-SQ8: MFMA prefilter + exact finish (mfma_scan.hip) when the lists are shared by enough queries
+    // IVF-Flat / IVF-SQ8: MFMA prefilter + exact finish (mfma_scan.hip) when the lists are shared by enough queries.
+    // IVF-PQ m = 32 with KNHIP_PQF=1: the half-precision ADC prefilter (pq_filter.hip) through the same machinery; its
+    // exact fallback is the 4-query kernel.
     bool use_ms = false;
     int ms_cap = 0, ms_nchunk = 0, ms_nstep = 0;
-    if ((kind == KNHIP_IVF_FLAT || kind == KNHIP_IVF_SQ8) && idx->mscan != 0 && nprobe >= 2) {
+    const bool pqf_shape = kind == KNHIP_IVF_PQ && idx->pqf == 1 && pq_use_v2 && idx->cb_t.p != nullptr &&
+            pqf_supports(idx->desc.pq_m, d) && pq_scan_q4_supports(idx->desc.pq_m, d, k) &&
+            (!is_l2 || idx->use_precomp); // (residual tables: see pq_psum_kernel)
+    if ((kind == KNHIP_IVF_FLAT || kind == KNHIP_IVF_SQ8 || pqf_shape) && (idx->mscan != 0 || pqf_shape) && nprobe >= 2) {
         size_t lds;
-        if (kind == KNHIP_IVF_FLAT) {
+        if (kind == KNHIP_IVF_PQ) {
+            ms_nchunk = d / 4;
+            lds = pqf_smem();
+        } else if (kind == KNHIP_IVF_FLAT) {
             ms_nchunk = (d + 3) / 4;
             ms_nstep = (ms_nchunk + 3) / 4;
             lds = mscan_flat_smem(ms_nstep);
@@ -659,7 +716,13 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             ms_cap = idx->mscan_cap;
         }
         use_ms = lds <= 160 * 1024 - 1024 && ms_cap >= 2 * k &&
-                (idx->mscan == 1 || npairs >= 8 * nlist);
+                (idx->mscan == 1 || pqf_shape || npairs >= 8 * nlist);
+    }
+    if (use_ms && kind == KNHIP_IVF_PQ) { // (no rank-0 dump phase: the sample pass of the prefilter gives the bounds)
+        pq_rank0 = false;
+        pq_use_q4 = true;
+        qg_bulk = 4;
+        qg_rank0 = 4;
     }
     const int64_t items_bound =
             round_up(npairs / std::min(qg_rank0, qg_bulk) + std::min<int64_t>(2 * nlist, npairs) + 1, 8);
@@ -709,7 +772,11 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
     // over a compact table of one-query items (the overflowed queries; normally none, the kernels then return at once)
     auto run_mscan = [&](const std::function<int(const KnItem*, const KnPair*, const int64_t*, int64_t)>& exact_one)
             -> int {
-        if (int rc = ensure_mscan_norms(idx)) return rc;
+        if (kind == KNHIP_IVF_PQ) {
+            if (int rc = ensure_pqf(idx)) return rc;
+        } else {
+            if (int rc = ensure_mscan_norms(idx)) return rc;
+        }
         const int qt = mscan_queries_per_unit(kind, false), qt0 = mscan_queries_per_unit(kind, true);
         const int64_t units_bound = round_up(npairs / qt + std::min<int64_t>(nlist, npairs) + 1, 8);
         const int64_t sample = mscan_sample_rows();
@@ -764,12 +831,40 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             m.ghist = ws->ghist.as<uint32_t>();
             m.gmeta = ws->gmeta.as<uint2>();
         }
+        if (kind == KNHIP_IVF_PQ) {
+            // (retry round: one-query units, up to one per pair)
+            HIP_TRY(ws->pq_recs.reserve((size_t)std::max<int64_t>(std::max(units_bound, bound0), npairs) * sizeof(P8Rec)));
+            HIP_TRY(ws->pq_ctr.reserve(8 * 16 * sizeof(int32_t)));
+            m.list_blk_off = nullptr;
+            m.pq_codes_r = idx->rows_r.as<uint4>();
+            m.pq_sblk_off_r = idx->d_list_blk_off_r.as<int64_t>();
+            m.pq_psum = idx->psum.as<float>();
+            m.pq_cb_t = idx->cb_t.as<float4>();
+            m.pq_precomp_t = idx->precomp_t.as<float>();
+            m.pq_codes = idx->codes_aos.as<uint8_t>();
+            m.pq_lut_mode = !is_l2 ? PQ_LUT_IP : (idx->use_precomp ? PQ_LUT_PRECOMP : PQ_LUT_RESIDUAL);
+            m.pq_recs = ws->pq_recs.as<P8Rec>();
+            m.pq_ctr = ws->pq_ctr.as<int32_t>();
+        }
+        auto launch_filter = [&](const MScanArgs& x, int64_t bound) -> hipError_t {
+            return kind == KNHIP_IVF_FLAT ? launch_mscan_flat(x, is_l2, bound, s)
+                 : kind == KNHIP_IVF_SQ8  ? launch_mscan_sq8(x, is_l2, bound, s)
+                                          : launch_pqf(x, is_l2, bound, s);
+        };
         idx->rank0_phase_used = false;
         {
             // phase 1: tau_q from a sample of the closest list (units of the rank-0 virtual lists [0, nlist), DUMP mode)
             StageTimer t(idx, s, KNHIP_STAGE_SCAN_RANK0);
             HIP_TRY(hipMemsetAsync(cand_cnt, 0, (size_t)(2 * nq + 1) * sizeof(int32_t), s));
-            if (kind == KNHIP_IVF_FLAT) {
+            if (kind == KNHIP_IVF_PQ) {
+                // the queries' half tables + scales (one pass over the codebook per query)
+                HIP_TRY(ws->ms_qh.reserve((size_t)nq * 256 * 32 * 2));
+                HIP_TRY(ws->ms_qs.reserve((size_t)nq * 4 * sizeof(float)));
+                HIP_TRY(launch_pqf_query_table(d_q, idx->cb_t.as<float4>(), d, nq, is_l2, idx->pabs_max, ws->ms_qh.p,
+                                               ws->ms_qs.as<float>(), s));
+                m.pq_qh = ws->ms_qh.p;
+                m.pq_qs = ws->ms_qs.as<float>();
+            } else if (kind == KNHIP_IVF_FLAT) {
                 HIP_TRY(ws->qnorm.reserve((size_t)nq * sizeof(float)));
                 m.qnorm = ws->qnorm.as<float>();
                 HIP_TRY(launch_row_norms(d_q, nq, d, ws->qnorm.as<float>(), s));
@@ -794,11 +889,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             ds.dump_stride = sample;
             ds.ghist = nullptr;
             ds.sample_off = ws->ms_sample_off.as<int32_t>();
-            if (kind == KNHIP_IVF_FLAT) {
-                HIP_TRY(launch_mscan_flat(ds, is_l2, bound0, s));
-            } else {
-                HIP_TRY(launch_mscan_sq8(ds, is_l2, bound0, s));
-            }
+            HIP_TRY(launch_filter(ds, bound0));
             HIP_TRY(launch_row_select_var(ws->dump.as<float>(), sample, keys_p, nprobe, idx->d_list_len.as<int64_t>(),
                                           nq, k, is_l2, ws->sel_keys.as<int64_t>(), ws->sel_d.as<float>(), s, sample,
                                           ws->ms_nrow.as<int32_t>()));
@@ -819,11 +910,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         {
             // phase 2: every (query, list) pair on the matrix cores
             StageTimer t(idx, s, KNHIP_STAGE_SCAN);
-            if (kind == KNHIP_IVF_FLAT) {
-                HIP_TRY(launch_mscan_flat(m, is_l2, units_bound, s));
-            } else {
-                HIP_TRY(launch_mscan_sq8(m, is_l2, units_bound, s));
-            }
+            HIP_TRY(launch_filter(m, units_bound));
         }
         {
             // phase 3: exact distances of the candidates -> final top-k.  phase 4: overflowed queries.  First a RETRY
@@ -841,11 +928,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             r.unit_loop = 1;
             r.ghist = nullptr; // (the retried rows were counted once already: counting them again would fake k candidates)
             r.gmeta = nullptr;
-            if (kind == KNHIP_IVF_FLAT) {
-                HIP_TRY(launch_mscan_flat(r, is_l2, npairs, s));
-            } else {
-                HIP_TRY(launch_mscan_sq8(r, is_l2, npairs, s));
-            }
+            HIP_TRY(launch_filter(r, npairs));
             HIP_TRY(launch_mscan_finish(m, kind, is_l2, keys_p, cdis_p, nprobe, k, d_out_d, d_out_i, counters, 2, s));
             HIP_TRY(launch_ms_flag_pairs(overflow, 1, keys_p, nq, nprobe, nlist, idx->d_list_len.as<int64_t>(), k,
                                          ws->items.as<KnItem>(), wt.pairs, wt.nitems, ws->partial_i.as<int64_t>(), s));
@@ -924,6 +1007,27 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         a.gthr = ws->gthr.as<float>();
         a.nslot = nprobe;
         a.k = k;
+        if (use_ms) {
+            // half-precision prefilter + exact finish (pq_filter.hip); the queries that overflow twice take the exact
+            // 4-query kernel over one-pair items
+            a.codes_skew = idx->rows2.as<uint4>();
+            a.list_sblk_off = idx->d_list_blk_off2.as<int64_t>();
+            a.cb_t = idx->cb_t.as<float4>();
+            return run_mscan([&](const KnItem* items, const KnPair* pairs, const int64_t* nitems, int64_t) -> int {
+                PqScanArgs b = a;
+                b.items = items;
+                b.pairs = pairs;
+                b.nitems_dev = nitems;
+                b.item_lo = nullptr;
+                b.item_hi = nitems;
+                HIP_TRY(ws->recs4.reserve((size_t)npairs * sizeof(P4Rec)));
+                HIP_TRY(ws->q4_ctr.reserve(8 * 16 * sizeof(int32_t)));
+                b.recs4 = ws->recs4.as<P4Rec>();
+                b.q4_ctr = ws->q4_ctr.as<int32_t>();
+                HIP_TRY(launch_pq_scan_q4(b, is_l2, npairs, s));
+                return KNHIP_OK;
+            });
+        }
         if (pq_use_v2) {
             a.codes_skew = idx->rows2.as<uint4>();
             a.list_sblk_off = idx->d_list_blk_off2.as<int64_t>();
@@ -1078,6 +1182,10 @@ int64_t query_batch(const knhip_index* idx, int64_t nq, int k, int nprobe) {
         per_q = (double)idx->nlist * 4.0 + (double)nprobe * (12.0 + 8.0 + (double)k * 12.0);
         if ((idx->desc.kind == KNHIP_IVF_FLAT || idx->desc.kind == KNHIP_IVF_SQ8) && idx->mscan != 0) {
             per_q += 4.0 * mscan_sample_rows() + 8.0 * 32768.0; // sample dump + candidate list (mfma_scan.hip)
+        }
+        if (idx->desc.kind == KNHIP_IVF_PQ && idx->pqf == 1) {
+            // sample dump + candidate list + half table + one-pair records of the fallbacks (pq_filter.hip)
+            per_q += 4.0 * mscan_sample_rows() + 8.0 * 32768.0 + 16384.0 + (double)nprobe * (128.0 + 96.0);
         }
         if (idx->desc.kind == KNHIP_IVF_PQ) {
             per_q += 256.0 * idx->desc.pq_m * 4.0;

@@ -43,6 +43,7 @@
 // and IP is acc >= tau - eps: the epilogue is one compare per element in both metrics.
 #include "common.h"
 #include "kernels.h"
+#include "ms_common.h"
 
 namespace knhip {
 
@@ -161,76 +162,6 @@ hipError_t launch_ms_units(const int32_t* list_count_v, const int64_t* list_pair
     hipLaunchKernelGGL(ms_units_kernel, dim3((unsigned)((nlist + 255) / 256)), dim3(256), 0, s, list_count_v,
                        list_pair_off_v, unit_off, nlist, qt, units, list_len, code_size, unit_bytes);
     return hipGetLastError();
-}
-
-// ---- candidate append (slow path of the epilogue) ---------------------------------------------------------------
-// `pess` is the candidate's pessimistic distance (approx widened by eps: the exact distance is at least as good).
-// It feeds the query's candidate histogram (64 bins over the key range [best, k-th] of the sample): a unit that
-// starts later and finds cum(bins <= b) >= k knows that k unfiltered rows are at least as good as the upper edge of
-// bin b -- a valid and ever tightening bound on the final k-th distance (the scheme of pq_scan_v2.hip).
-template <bool IS_L2>
-__device__ __forceinline__ void ms_emit(const MScanArgs& a, int32_t q, int32_t slot, int64_t row_off, int64_t pos,
-                                        float pess) {
-    if (a.bitset != nullptr && bitset_filtered(a.bitset, a.bitset_nbits, a.ids[row_off + pos])) {
-        return;
-    }
-    const int n = atomicAdd(a.cand_cnt + q, 1);
-    if (n < a.cap) {
-        a.cand[(int64_t)q * a.cap + n] = ((int64_t)slot << 32) | (int64_t)(uint32_t)pos;
-    } else {
-        a.overflow[q] = 1;
-        a.overflow[a.nq] = 1; // "some query overflowed": the fallback kernels return at once while this stays 0
-    }
-    if (a.ghist != nullptr) {
-        const uint2 mt = a.gmeta[q];
-        if (mt.y != KN_HIST_OFF) {
-            atomicAdd(a.ghist + (int64_t)q * KN_HIST_BINS + hist_bin(dist_key<IS_L2>(pess), mt.x, mt.y), 1u);
-        }
-    }
-}
-
-// bound on the query's final k-th distance from its candidate histogram (full wave: lane = bin); the neutral value
-// when the histogram is off or k candidates have not been seen yet
-template <bool IS_L2>
-__device__ __forceinline__ float ms_hist_bound(const MScanArgs& a, int32_t q, int k) {
-    float bound = worst_dist<IS_L2>();
-    if (a.ghist == nullptr || q < 0) {
-        return bound;
-    }
-    const uint2 mt = a.gmeta[q];
-    if (mt.y == KN_HIST_OFF) {
-        return bound;
-    }
-    const int lane = lane_id();
-    uint32_t cum = __hip_atomic_load(a.ghist + (int64_t)q * KN_HIST_BINS + lane, __ATOMIC_RELAXED,
-                                     __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-    for (int dlt = 1; dlt < KN_WAVE; dlt <<= 1) {
-        const uint32_t up = __shfl_up(cum, dlt, KN_WAVE);
-        cum += lane >= dlt ? up : 0u;
-    }
-    const unsigned long long reach = __ballot(cum >= (uint32_t)k);
-    const int b = reach ? __ffsll((long long)reach) - 1 : KN_HIST_BINS;
-    if (b < KN_HIST_BINS - 1) { // (the last bin also collects everything beyond the range)
-        const unsigned long long edge = (unsigned long long)mt.x + (((unsigned long long)b + 1ull) << mt.y) - 1ull;
-        if (edge < 0xffffffffull) {
-            const float e = dist_key_inv<IS_L2>((uint32_t)edge);
-            if (e == e && fabsf(e) < FLT_MAX) {
-                bound = e;
-            }
-        }
-    }
-    return bound;
-}
-
-// 64-bit mask of the block's rows that take part (inside the list, not filtered): lane = row
-__device__ __forceinline__ unsigned long long ms_valid_rows(const MScanArgs& a, int64_t b, int64_t len, int64_t row_off) {
-    const int64_t row = b * 64 + lane_id();
-    bool v = row < len;
-    if (v && a.bitset != nullptr) {
-        v = !bitset_filtered(a.bitset, a.bitset_nbits, a.ids[row_off + row]);
-    }
-    return __ballot(v);
 }
 
 // ---- fp32 rows --------------------------------------------------------------------------------------------------
@@ -1070,7 +1001,7 @@ hipError_t launch_ms_tau(const float* sel_d, int64_t nq, int k, bool is_l2, floa
 constexpr int MF_THREADS = 256;
 constexpr int MF_MLP = 8; // row pieces requested at a time per candidate
 
-template <bool IS_L2, int KIND> // KIND 1: fp32 rows, 3: SQ8
+template <bool IS_L2, int KIND> // KIND 1: fp32 rows, 2: PQ codes (M = 32, dsub = 4; pq_filter.hip), 3: SQ8
 __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, const int64_t* __restrict__ keys,
                                                                   const float* __restrict__ coarse_dis, int nprobe,
                                                                   int k, int P_max, float* __restrict__ out_d,
@@ -1113,7 +1044,7 @@ __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, c
     unsigned long long* tie = reinterpret_cast<unsigned long long*>(smem);
     uint32_t* key = reinterpret_cast<uint32_t*>(smem + (size_t)P_max * 8);
     float* sq = reinterpret_cast<float*>(smem + (size_t)P_max * 12);
-    const int dq = KIND == 1 ? a.nchunk * 4 : a.nchunk * 16;
+    const int dq = KIND == 3 ? a.nchunk * 16 : a.nchunk * 4;
     float* svmin = sq + dq;
     float* svdiff = svmin + dq;
     for (int i = tid; i < dq; i += MF_THREADS) {
@@ -1141,7 +1072,7 @@ __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, c
                 const int slot = (int)(c >> 32);
                 const int64_t pos = (int64_t)(uint32_t)c;
                 const int64_t list = keys[q * nprobe + slot];
-                const int64_t blk = a.list_blk_off[list] + (pos >> 6);
+                const int64_t blk = KIND == 2 ? 0 : a.list_blk_off[list] + (pos >> 6);
                 const int r = (int)(pos & 63);
                 float acc = 0.f;
                 // A candidate's row is gathered in 16-byte pieces 1 KiB apart (interleaved blocks): MF_MLP of them are
@@ -1173,6 +1104,43 @@ __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, c
                                 }
                             }
                         }
+                    }
+                } else if (KIND == 2) {
+                    // ADC in the reference's order (pq_scan_q4.hip header): table entry = term2 + (-2) <q_m, cb> (L2,
+                    // precomputed table) / <q_m, cb> (IP) / ||(q - c_list)_m - cb||^2 (L2, residual tables), inner
+                    // products and squared distances accumulated from 0 in dimension order, the entries summed from 0
+                    // in m order, the coarse term added last
+                    const uint4* cp = reinterpret_cast<const uint4*>(a.pq_codes + (a.list_row_off[list] + pos) * 32);
+                    const uint4 cw[2] = {cp[0], cp[1]};
+                    const uint32_t ww[8] = {cw[0].x, cw[0].y, cw[0].z, cw[0].w, cw[1].x, cw[1].y, cw[1].z, cw[1].w};
+                    const float* pt = a.pq_precomp_t + list * (int64_t)(256 * 32);
+                    const float* cen = a.centroids + list * d;
+#pragma unroll 8
+                    for (int m = 0; m < 32; m++) {
+                        const int code = (int)((ww[m >> 2] >> (8 * (m & 3))) & 0xffu);
+                        const float4 y = a.pq_cb_t[code * 32 + m];
+                        float4 x = *reinterpret_cast<const float4*>(sq + m * 4);
+                        float t;
+                        if (a.pq_lut_mode == PQ_LUT_RESIDUAL) {
+                            const float4 cl = *reinterpret_cast<const float4*>(cen + m * 4);
+                            x = make_float4(fsub_x(x.x, cl.x), fsub_x(x.y, cl.y), fsub_x(x.z, cl.z), fsub_x(x.w, cl.w));
+                            t = l2_step(0.f, x.x, y.x);
+                            t = l2_step(t, x.y, y.y);
+                            t = l2_step(t, x.z, y.z);
+                            t = l2_step(t, x.w, y.w);
+                        } else {
+                            t = ip_step(0.f, x.x, y.x);
+                            t = ip_step(t, x.y, y.y);
+                            t = ip_step(t, x.z, y.z);
+                            t = ip_step(t, x.w, y.w);
+                            if (a.pq_lut_mode == PQ_LUT_PRECOMP) {
+                                t = fadd_x(pt[code * 32 + m], fmul_x(-2.0f, t));
+                            }
+                        }
+                        acc = fadd_x(acc, t);
+                    }
+                    if (a.pq_lut_mode != PQ_LUT_RESIDUAL) {
+                        acc = fadd_x(coarse_dis[q * nprobe + slot], acc);
                     }
                 } else {
                     const uint4* p = reinterpret_cast<const uint4*>(a.rows) + blk * (int64_t)a.nchunk * 64 + r;
@@ -1316,7 +1284,7 @@ hipError_t launch_ms_flag_pairs(const int32_t* overflow, int want, const int64_t
 // ---- host launchers ---------------------------------------------------------------------------------------------
 // queries per unit: filter pass / sample pass
 int mscan_queries_per_unit(int kind, bool sample) {
-    return kind == 1 ? (sample ? 32 : MS_QT) : MQ_QT;
+    return kind == 1 ? (sample ? 32 : MS_QT) : kind == 2 ? 8 : MQ_QT; // (kind 2: pq_filter.hip, 8 queries per LUT)
 }
 
 size_t mscan_sq8_smem(int nstep) {
@@ -1394,8 +1362,8 @@ hipError_t launch_mscan_finish(const MScanArgs& a, int kind, bool is_l2, const i
         return hipSuccess;
     }
     const int P_max = mscan_finish_pmax(a.cap, k);
-    const int dq = kind == 1 ? a.nchunk * 4 : a.nchunk * 16;
-    const size_t sm = (size_t)P_max * 12 + (size_t)dq * 4 * (kind == 1 ? 1 : 3);
+    const int dq = kind == 3 ? a.nchunk * 16 : a.nchunk * 4;
+    const size_t sm = (size_t)P_max * 12 + (size_t)dq * 4 * (kind == 3 ? 3 : 1);
 #define MF_LAUNCH(L2_, KIND_)                                                                                   \
     do {                                                                                                        \
         auto kern = mscan_finish_kernel<L2_, KIND_>;                                                            \
@@ -1409,6 +1377,8 @@ hipError_t launch_mscan_finish(const MScanArgs& a, int kind, bool is_l2, const i
     } while (0)
     if (kind == 1) {
         if (is_l2) MF_LAUNCH(true, 1); else MF_LAUNCH(false, 1);
+    } else if (kind == 2) {
+        if (is_l2) MF_LAUNCH(true, 2); else MF_LAUNCH(false, 2);
     } else {
         if (is_l2) MF_LAUNCH(true, 3); else MF_LAUNCH(false, 3);
     }

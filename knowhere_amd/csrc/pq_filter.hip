@@ -1,0 +1,667 @@
+// knowhere_amd/csrc/pq_filter.hip -- IVF-PQ (M = 32 x 8 bit, dsub = 4) ADC scan as a HALF-PRECISION PREFILTER.
+//
+// STATUS: written at the end of round 2 without access to a GPU (the round's GPU minutes were spent).  It compiles for
+// gfx950, is OFF unless KNHIP_PQF=1, and has never run on hardware.  See DESIGN.md section 7.
+//
+// Why: the exact ADC scan (pq_scan_q4.hip) is bound by VALU issue: per 256 lookups of a wave one ds_read_b128, one SDWA
+// address shift and 2..4 v_pk_add_f32 (EXEC flips on the staggered steps).  tools/ubench/adc_loop measured a loop
+// with the table in half precision, EIGHT queries per 16-byte entry, 4 v_pk_add_f16 per step and no EXEC flips at
+// 191 lookups/ns/CU against 90 for the exact loop.  Half-precision sums cannot be returned (the reference's distances
+// are fp32 sums in m order), but they can FILTER, as mfma_scan.hip does for fp32 rows and SQ8 codes:
+//
+//   approx(q, v) = dis0 + psum[v] + (1 / sc_q) * sum_m Qh_q[m][code_m(v)]                                  (L2)
+//       psum[v]  = sum_m term2[list][m][code_m(v)]     per stored vector, fp32, computed when the layout is built
+//                  (term2 = ||cb||^2 + 2 <c_list,m, cb>: IVFPQ_QueryTables.cpp:50-108; no query in it)
+//       Qh_q     = half(sc_q * -2 <q_m, cb[m][c]>)     per query, sc_q a power of two that brings
+//                  A_q = sum_m max_c |2 <q_m, cb>| into [2^13, 2^14): no partial sum can overflow
+//   approx(q, v) = dis0 + (1 / sc_q) * sum_m half(sc_q <q_m, cb>)                                           (IP)
+//
+//   |approx - exact| <= eps = 34 * 2^-11 * A_q + 64 * 2^-24 * (|dis0| + max_v sum_m |term2| + A_q + |tau|)
+//                             + 33 * 2^-25 / sc_q:
+//   32 table entries rounded to half (relative 2^-11 each, sum of magnitudes <= A_q; absolute 2^-25 where the scaled
+//   entry is a half subnormal), 31 half additions whose results are bounded by A_q (2^-11 relative each), the fp32
+//   roundings of both sides (~70 operations of relative 2^-24 on quantities bounded by the bracket).
+//   tests/test_pq_filter_bound.py replays the arithmetic on the CPU.
+//
+// A row whose approx is within eps of the query's bound tau_q goes to the query's candidate list; the finish kernel
+// (mfma_scan.hip, KIND 2) recomputes the candidates in the reference's exact order and keeps the canonical top-k --
+// the returned values never see half precision.  Bound, sample pass, candidate histogram, retry round and exact
+// fallback are the machinery of mfma_scan.hip (MScanArgs).
+//
+// Lanes never split a vector between windows here.  Half additions may run in any order, so lane L walks the 32
+// sub-quantizers of ITS vector rotated: at step T of a window it handles m = (T + pq_stream_phase(L)) & 31.  The 16
+// lanes an LDS gather is serviced together for sit on 16 consecutive m = 16 different bank quads of LUT[c][m][8 q]
+// (16-byte entries): no bank conflict for any code values, no stagger, no EXEC flips, no drain window.  That needs its
+// own token stream (`stream16r`: same 16-bit tokens code << 8 | m << 3 as stream16, rotated instead of delayed).
+#include "common.h"
+#include "kernels.h"
+#include "ms_common.h"
+
+#include <algorithm>
+
+namespace knhip {
+
+constexpr int PF_KSUB = 256;
+constexpr int PF_M = 32;
+constexpr int PF_DSUB = 4;
+constexpr int PF_Q = 8;
+constexpr int PF_WAVES = 16;
+constexpr int PF_THREADS = PF_WAVES * KN_WAVE;
+constexpr int PF_LUT_BYTES = PF_KSUB * PF_M * PF_Q * 2; // 131072
+// behind the LUT: [0] next unit, [8..8+34) next record, [64 + 8 j ..) per-pair constants of the current unit
+constexpr int PF_CTL_BYTES = 1024;
+constexpr int PF_SAMPLE = 4096; // = MS_SAMPLE (mfma_scan.hip): dump columns per query
+constexpr float PF_U = 5.9604645e-8f;        // 2^-24
+constexpr float PF_UH = 4.8828125e-4f;       // 2^-11
+
+typedef _Float16 pf_h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 pf_h8 __attribute__((ext_vector_type(8))); // one LUT entry: the 8 queries' halves
+
+// ---- AoS codes [len][32] -> rotated token stream ----------------------------------------------------------------
+// uint4 out[blk][lane], 8 steps per block, 4 blocks per group of 64 vectors
+int64_t pq_stream16r_blocks(int64_t len) {
+    // + two windows of slack: every wave's code prefetch runs two windows ahead of its last group
+    return ((len + 63) / 64) * 4 + 8;
+}
+
+__global__ void pq_stream16r_kernel(const uint8_t* __restrict__ codes, const int64_t* __restrict__ list_row_off,
+                                    const int64_t* __restrict__ list_len, const int64_t* __restrict__ list_sblk_off,
+                                    int64_t nlist, uint4* __restrict__ out) {
+    const int64_t l = blockIdx.y + (int64_t)blockIdx.z * gridDim.y;
+    if (l >= nlist) {
+        return;
+    }
+    const int64_t len = list_len[l];
+    const int64_t nblk = list_sblk_off[l + 1] - list_sblk_off[l];
+    const int64_t row_off = list_row_off[l];
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nblk * 64;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t blk = t / 64;
+        const int L = (int)(t % 64);
+        const int ph = pq_stream_phase(L);
+        const int64_t v = (blk >> 2) * 64 + L;
+        uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            const int T = (int)(blk & 3) * 8 + s;
+            const int m = (T + ph) & 31;
+            uint32_t code = 0;
+            if (v < len) {
+                code = codes[(row_off + v) * PF_M + m];
+            }
+            const uint32_t val = (code << 8) | ((uint32_t)m << 3);
+            w[s >> 1] |= val << (16 * (s & 1));
+        }
+        out[(list_sblk_off[l] + blk) * 64 + L] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+hipError_t launch_pq_stream16r(const uint8_t* codes, const int64_t* list_row_off, const int64_t* list_len,
+                               const int64_t* list_sblk_off, int64_t nlist, uint4* out, hipStream_t s) {
+    if (nlist <= 0) {
+        return hipSuccess;
+    }
+    const unsigned gy = (unsigned)std::min<int64_t>(nlist, 65535);
+    const unsigned gz = (unsigned)((nlist + gy - 1) / gy);
+    hipLaunchKernelGGL(pq_stream16r_kernel, dim3(8, gy, gz), dim3(256), 0, s, codes, list_row_off, list_len, list_sblk_off,
+                       nlist, out);
+    return hipGetLastError();
+}
+
+// ---- per stored vector: psum = sum_m term2[list][m][code_m], |.| bound -------------------------------------------
+// psum[(list_sblk_off[l] / 4) * 64 + v]: one float per vector position of the rotated stream (slack positions 0).
+// term2 = the entries of the index's precomputed table, i.e. the very values the exact scan adds (an index that
+// searches with residual tables -- table over precomputed_table_max_bytes -- does not take this path: without the
+// stored entries both sides of the bound would round differently).  pabs_max: max over vectors of sum_m |term2|.
+__global__ void pq_psum_kernel(const uint8_t* __restrict__ codes, const int64_t* __restrict__ list_row_off,
+                               const int64_t* __restrict__ list_len, const int64_t* __restrict__ list_sblk_off,
+                               int64_t nlist, const float* __restrict__ precomp_t, float* __restrict__ psum,
+                               uint32_t* __restrict__ pabs_max_bits) {
+    const int64_t l = blockIdx.y + (int64_t)blockIdx.z * gridDim.y;
+    if (l >= nlist) {
+        return;
+    }
+    const int64_t len = list_len[l];
+    const int64_t npos = (list_sblk_off[l + 1] - list_sblk_off[l]) / 4 * 64;
+    const int64_t base = list_sblk_off[l] / 4 * 64;
+    const int64_t row_off = list_row_off[l];
+    float amax = 0.f;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < npos; v += (int64_t)gridDim.x * blockDim.x) {
+        float sum = 0.f, sabs = 0.f;
+        if (v < len) {
+            const uint8_t* cv = codes + (row_off + v) * PF_M;
+            for (int m = 0; m < PF_M; m++) {
+                const int c = cv[m];
+                const float t2 = precomp_t[(l * PF_KSUB + c) * PF_M + m];
+                sum += t2;
+                sabs += fabsf(t2);
+            }
+        }
+        psum[base + v] = sum;
+        amax = fmaxf(amax, sabs);
+    }
+    if (amax > 0.f) {
+        atomicMax(pabs_max_bits, __float_as_uint(amax)); // (non-negative floats order as their bit patterns)
+    }
+}
+
+hipError_t launch_pq_psum(const uint8_t* codes, const int64_t* list_row_off, const int64_t* list_len,
+                          const int64_t* list_sblk_off, int64_t nlist, const float* precomp_t, float* psum,
+                          uint32_t* pabs_max_bits, hipStream_t s) {
+    if (nlist <= 0 || precomp_t == nullptr) {
+        return hipSuccess;
+    }
+    const unsigned gy = (unsigned)std::min<int64_t>(nlist, 65535);
+    const unsigned gz = (unsigned)((nlist + gy - 1) / gy);
+    hipLaunchKernelGGL(pq_psum_kernel, dim3(4, gy, gz), dim3(256), 0, s, codes, list_row_off, list_len, list_sblk_off,
+                       nlist, precomp_t, psum, pabs_max_bits);
+    return hipGetLastError();
+}
+
+// ---- per-query half table ------------------------------------------------------------------------------------------
+// One workgroup per query, thread = centroid index c.  qs[q] = {sc, 1 / sc, eps_base, A}.
+// Table layout (halves): qh[q][c >> 2][m & 15][c & 3][m >> 4] -- the 16-byte piece thread t = (c >> 2) * 16 + (m & 15)
+// of the filter kernel reads holds, for each of its 8 (c, m) cells, this query's entry; the cells of 16 consecutive
+// threads at the same piece index are 16 consecutive m of one c: their LUT stores are a contiguous 256 bytes.
+template <bool IS_L2>
+__global__ __launch_bounds__(PF_KSUB) void pqf_query_table_kernel(const float* __restrict__ queries,
+                                                                  const float4* __restrict__ cb_t, int d, float pabs_max,
+                                                                  uint32_t* __restrict__ qh, float* __restrict__ qs) {
+    __shared__ float sq[PF_M * PF_DSUB];
+    __shared__ float smax[PF_M][PF_KSUB / KN_WAVE];
+    __shared__ float s_sc;
+    const int64_t q = blockIdx.x;
+    const int c = threadIdx.x;
+    const int wave = c / KN_WAVE;
+    if (c < PF_M * PF_DSUB) {
+        sq[c] = queries[q * d + c];
+    }
+    __syncthreads();
+    float v[PF_M];
+#pragma unroll
+    for (int m = 0; m < PF_M; m++) {
+        const float4 y = cb_t[c * PF_M + m];
+        const float4 x = *reinterpret_cast<const float4*>(sq + m * PF_DSUB);
+        float t = ip_step(0.f, x.x, y.x);
+        t = ip_step(t, x.y, y.y);
+        t = ip_step(t, x.z, y.z);
+        t = ip_step(t, x.w, y.w);
+        v[m] = IS_L2 ? fmul_x(-2.0f, t) : t;
+        float a = fabsf(v[m]);
+        a = (a == a) ? a : INFINITY; // NaN -> "no bound": the query takes the exact kernels
+#pragma unroll
+        for (int dlt = KN_WAVE / 2; dlt > 0; dlt >>= 1) {
+            a = fmaxf(a, __shfl_xor(a, dlt, KN_WAVE));
+        }
+        if (lane_id() == 0) {
+            smax[m][wave] = a;
+        }
+    }
+    __syncthreads();
+    if (c == 0) {
+        float A = 0.f;
+        for (int m = 0; m < PF_M; m++) {
+            float a = smax[m][0];
+            for (int w = 1; w < PF_KSUB / KN_WAVE; w++) {
+                a = fmaxf(a, smax[m][w]);
+            }
+            A += a;
+        }
+        float sc = 1.0f, eps = INFINITY;
+        if (A < INFINITY) {
+            int ex = 0;
+            if (A > 0.f) {
+                (void)frexpf(A, &ex); // A = f * 2^ex, f in [0.5, 1)
+            } else {
+                ex = 14;
+            }
+            int e = 14 - ex;          // A * 2^e in [2^13, 2^14)
+            e = e < -100 ? -100 : (e > 100 ? 100 : e);
+            sc = ldexpf(1.0f, e);
+            // (last term: a scaled entry below the half normal range 2^-14 is rounded to a multiple of 2^-24 instead
+            // of relative 2^-11; additions of such values are exact)
+            eps = 34.0f * PF_UH * A + 64.0f * PF_U * (pabs_max + A) + 33.0f * 2.9802322e-8f / sc;
+        }
+        s_sc = sc;
+        qs[q * 4 + 0] = sc;
+        qs[q * 4 + 1] = 1.0f / sc;
+        qs[q * 4 + 2] = eps;
+        qs[q * 4 + 3] = A;
+    }
+    __syncthreads();
+    const float sc = s_sc;
+    uint32_t* out = qh + q * (PF_KSUB * PF_M / 2);
+#pragma unroll
+    for (int l16 = 0; l16 < 16; l16++) {
+        pf_h2 h;
+        h.x = (_Float16)(v[l16] * sc);      // (power-of-two scale: exact unless the half goes subnormal)
+        h.y = (_Float16)(v[l16 + 16] * sc);
+        out[((c >> 2) * 16 + l16) * 4 + (c & 3)] = __builtin_bit_cast(uint32_t, h);
+    }
+}
+
+hipError_t launch_pqf_query_table(const float* queries, const float4* cb_t, int d, int64_t nq, bool is_l2, float pabs_max,
+                                  void* qh, float* qs, hipStream_t s) {
+    if (nq <= 0) {
+        return hipSuccess;
+    }
+    if (is_l2) {
+        hipLaunchKernelGGL(pqf_query_table_kernel<true>, dim3((unsigned)nq), dim3(PF_KSUB), 0, s, queries, cb_t, d,
+                           pabs_max, static_cast<uint32_t*>(qh), qs);
+    } else {
+        hipLaunchKernelGGL(pqf_query_table_kernel<false>, dim3((unsigned)nq), dim3(PF_KSUB), 0, s, queries, cb_t, d,
+                           pabs_max, static_cast<uint32_t*>(qh), qs);
+    }
+    return hipGetLastError();
+}
+
+// ---- flat unit records + counter reset ------------------------------------------------------------------------------
+__global__ void pqf_prepare_kernel(MScanArgs a, int64_t nrec) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < 8 * 16) {
+        a.pq_ctr[r] = 0;
+    }
+    if (r >= nrec || r >= *a.nunits_dev) {
+        return;
+    }
+    const bool dump = a.dump != nullptr;
+    P8Rec rec{};
+    const KnItem it = a.units[r];
+    const int npair = it.npair < PF_Q ? it.npair : PF_Q;
+    rec.list = it.list;
+    rec.npair = npair;
+    const int64_t len = a.list_len[it.list];
+    rec.len = dump ? (len < PF_SAMPLE ? len : PF_SAMPLE) : len;
+    rec.sblk0 = a.pq_sblk_off_r[it.list];
+    rec.row_off = a.list_row_off[it.list];
+    for (int j = 0; j < PF_Q; j++) {
+        const KnPair p = a.pairs[it.pair0 + (j < npair ? j : npair - 1)];
+        rec.q[j] = p.q;
+        rec.slot[j] = dump ? a.sample_off[(int64_t)p.q * a.nslot + p.slot] : p.slot;
+        rec.dis0[j] = a.coarse_dis[(int64_t)p.q * a.nslot + p.slot];
+    }
+    a.pq_recs[r] = rec;
+}
+
+__device__ __forceinline__ int pf_sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float pf_sgpr_f(float v) {
+    return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v)));
+}
+
+__device__ __forceinline__ void pf_setprio(int p) {
+    if (p == 0) {
+        __builtin_amdgcn_s_setprio(0);
+    } else if (p == 1) {
+        __builtin_amdgcn_s_setprio(1);
+    } else if (p == 2) {
+        __builtin_amdgcn_s_setprio(2);
+    } else {
+        __builtin_amdgcn_s_setprio(3);
+    }
+}
+
+// token (low / high half of a code word) -> LDS byte address of the 16-byte LUT entry: one SDWA shift
+__device__ __forceinline__ uint32_t pf_addr_lo(uint32_t w, uint32_t one) {
+    uint32_t a;
+    asm("v_lshlrev_b32_sdwa %0, %2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
+        : "=v"(a)
+        : "v"(w), "s"(one));
+    return a;
+}
+__device__ __forceinline__ uint32_t pf_addr_hi(uint32_t w, uint32_t one) {
+    uint32_t a;
+    asm("v_lshlrev_b32_sdwa %0, %2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+        : "=v"(a)
+        : "v"(w), "s"(one));
+    return a;
+}
+
+// ---- the filter / sample kernel -----------------------------------------------------------------------------------
+// Persistent: one workgroup of 16 waves per CU (128 KB of LUT), units pulled in list order from the XCD's counter as
+// pq_scan_q4.hip does.  Per unit: per-pair constants (waves 0..7, one pair each: bound from gthr and the candidate
+// histogram), LUT[c][m][8 queries] transposed from the queries' half tables, then every wave scans its share of the
+// list's groups of 64 vectors: 32 steps of {SDWA shift, ds_read_b128, 4 v_pk_add_f16} per group, one compare per
+// (vector, query) at the end of the window.
+template <bool IS_L2, bool DUMP>
+__global__ __launch_bounds__(PF_THREADS) void pqf_kernel(MScanArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    int* ctl = reinterpret_cast<int*>(smem + PF_LUT_BYTES);
+    float* pc = reinterpret_cast<float*>(smem + PF_LUT_BYTES + 256); // [8][4] = {t, sc, pess const, 1 / sc}
+    const int lane = lane_id();
+    const int wave = pf_sgpr((int)(threadIdx.x / KN_WAVE));
+    if ((uint32_t)(size_t)((__attribute__((address_space(3))) unsigned char*)smem) != 0u) {
+        __builtin_trap(); // the 16-bit tokens assume the LUT at LDS offset 0
+    }
+    const int nunits = (int)*a.nunits_dev;
+    const int per = (nunits + 7) / 8;
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const int xcd = (int)(xcc & 7u);
+    int fetch_t = 0; // thread 0: counters [xcd, xcd + fetch_t) are known to be exhausted
+    auto fetch_slow = [&]() -> int {
+        while (fetch_t < 8) {
+            const int x = (xcd + fetch_t) & 7;
+            const int base = x * per;
+            const int cnt = min(per, nunits - base);
+            if (cnt > 0) {
+                const int i = atomicAdd(a.pq_ctr + x * 16, 1);
+                if (i < cnt) {
+                    return base + i;
+                }
+            }
+            fetch_t++;
+        }
+        return -1;
+    };
+    constexpr int REC_WORDS = (int)(sizeof(P8Rec) / 4);
+    static_assert(REC_WORDS <= KN_WAVE, "one lane per record word");
+    if (wave == 0) {
+        int first = -1;
+        if (lane == 0) {
+            first = fetch_slow();
+        }
+        first = __builtin_amdgcn_readlane(first, 0);
+        if (lane < REC_WORDS && first >= 0) {
+            ctl[8 + lane] = (int)reinterpret_cast<const uint32_t*>(a.pq_recs + first)[lane];
+        }
+        if (lane == 0) {
+            ctl[0] = first;
+        }
+    }
+    __syncthreads();
+    int cur = pf_sgpr(ctl[0]);
+    const uint32_t one = 1u;
+    const uint4* qh4 = reinterpret_cast<const uint4*>(a.pq_qh);
+
+    while (cur >= 0) {
+        int lane_i = lane;
+        asm volatile("" : "+v"(lane_i)); // nothing lane-derived is hoisted out of the unit loop
+        int f_x = 0, f_i = 0;
+        if (wave == 0 && lane_i == 0 && fetch_t < 8) {
+            f_x = (xcd + fetch_t) & 7;
+            f_i = atomicAdd(a.pq_ctr + f_x * 16, 1);
+        }
+        // ---- the unit's record (mailbox), fields broadcast to SGPRs ----------------------------------------------
+        const uint32_t rw = lane_i < REC_WORDS ? (uint32_t)ctl[8 + lane_i] : 0u;
+        auto rl = [&](int i) { return (uint32_t)__builtin_amdgcn_readlane((int)rw, i); };
+        const int npair = (int)rl(1);
+        int32_t q_of[PF_Q], slot_of[PF_Q];
+#pragma unroll
+        for (int j = 0; j < PF_Q; j++) {
+            q_of[j] = (int32_t)rl(2 + j);
+            slot_of[j] = (int32_t)rl(10 + j);
+        }
+        const int64_t len = (int64_t)(((uint64_t)rl(27) << 32) | rl(26));
+        const int64_t sblk0 = (int64_t)(((uint64_t)rl(29) << 32) | rl(28));
+        const int64_t row_off = (int64_t)(((uint64_t)rl(31) << 32) | rl(30));
+
+        // ---- the 8 queries' table pieces: requested first, transposed into the LUT below -----------------------------
+        uint4 tp[PF_Q];
+#pragma unroll
+        for (int j = 0; j < PF_Q; j++) {
+            tp[j] = qh4[(int64_t)q_of[j] * (PF_KSUB * PF_M / 8) + (wave * KN_WAVE + lane_i)];
+        }
+        // this wave's groups of 64 vectors and its first code blocks
+        const int ngroups = (int)((len + 63) / 64);
+        const int gbase = ngroups / PF_WAVES, grem = ngroups % PF_WAVES;
+        const int G0 = wave * gbase + min(wave, grem);
+        const int G1 = G0 + gbase + (wave < grem ? 1 : 0);
+        const int nwin = G1 - G0;
+        const uint4* cbase = a.pq_codes_r + (sblk0 + (int64_t)G0 * 4) * 64 + lane_i; // 4 blocks per window
+        auto load_blk = [&](int b) { return cbase[(int64_t)b * 64]; };                // past-the-end blocks exist (slack)
+        const float* psb = a.pq_psum + (sblk0 / 4 + G0) * 64 + lane_i;
+        uint4 U0 = make_uint4(0, 0, 0, 0), U1 = U0, U2 = U0, U3 = U0;
+        float ps_next = 0.f;
+        if (nwin > 0) {
+            U0 = load_blk(0);
+            U1 = load_blk(1);
+            U2 = load_blk(2);
+            U3 = load_blk(3);
+            if (IS_L2) {
+                ps_next = psb[0];
+            }
+        }
+        // ---- per-pair constants: wave j < 8 prepares pair j ---------------------------------------------------------
+        if (wave < PF_Q) {
+            int32_t q = q_of[0];
+            float dis0 = __uint_as_float(rl(18));
+#pragma unroll
+            for (int j = 1; j < PF_Q; j++) {
+                q = wave == j ? q_of[j] : q;
+                dis0 = wave == j ? __uint_as_float(rl(18 + j)) : dis0;
+            }
+            const float4 s4 = *reinterpret_cast<const float4*>(a.pq_qs + (int64_t)q * 4);
+            // pass-nothing defaults (missing pair, no bound, non-finite query)
+            float t = IS_L2 ? -INFINITY : INFINITY, pcst = 0.f;
+            if (wave < npair) {
+                if (DUMP) {
+                    const float eps = s4.z + 64.0f * PF_U * fabsf(dis0);
+                    pcst = IS_L2 ? dis0 + eps : dis0 - eps; // (a non-finite eps dumps the neutral side: no bound from it)
+                } else {
+                    float tau = a.gthr[q];
+                    tau = tighter<IS_L2>(tau, ms_hist_bound<IS_L2>(a, q, a.k));
+                    const float eps = s4.z + 64.0f * PF_U * (fabsf(dis0) + fabsf(tau));
+                    if (tau == worst_dist<IS_L2>() || !(eps < INFINITY)) {
+                        // no bound (fewer than k unfiltered rows in the sample) or a query the half table cannot hold:
+                        // nothing passes here, the query goes through the exact kernels
+                        if (lane_i == 0) {
+                            a.overflow[q] = 1;
+                            a.overflow[a.nq] = 1;
+                        }
+                    } else {
+                        t = IS_L2 ? ((tau + eps) - dis0) * s4.x : ((tau - eps) - dis0) * s4.x;
+                        pcst = IS_L2 ? dis0 + eps : dis0 - eps;
+                    }
+                }
+            }
+            if (lane_i == 0) {
+                *reinterpret_cast<float4*>(pc + wave * 4) = make_float4(t, s4.x, pcst, s4.y);
+            }
+        }
+        // ---- LUT[c][m][query]: 8 x 8 halves transposed in registers, 8 conflict-free 16-byte stores ------------------
+        {
+            const int t = wave * KN_WAVE + lane_i;
+            const int c4 = t >> 4, l16 = t & 15;
+            const uint32_t r[PF_Q][4] = {{tp[0].x, tp[0].y, tp[0].z, tp[0].w}, {tp[1].x, tp[1].y, tp[1].z, tp[1].w},
+                                         {tp[2].x, tp[2].y, tp[2].z, tp[2].w}, {tp[3].x, tp[3].y, tp[3].z, tp[3].w},
+                                         {tp[4].x, tp[4].y, tp[4].z, tp[4].w}, {tp[5].x, tp[5].y, tp[5].z, tp[5].w},
+                                         {tp[6].x, tp[6].y, tp[6].z, tp[6].w}, {tp[7].x, tp[7].y, tp[7].z, tp[7].w}};
+            uint4* lut = reinterpret_cast<uint4*>(smem);
+#pragma unroll
+            for (int e = 0; e < 8; e++) { // cell e of the piece: c = 4 c4 + (e >> 1), m = l16 + 16 (e & 1); word e >> 1
+                const int cc = e >> 1, h = e & 1;
+                const uint32_t sel = h ? 0x07060302u : 0x05040100u;
+                uint4 o;
+                o.x = __builtin_amdgcn_perm(r[1][cc], r[0][cc], sel);
+                o.y = __builtin_amdgcn_perm(r[3][cc], r[2][cc], sel);
+                o.z = __builtin_amdgcn_perm(r[5][cc], r[4][cc], sel);
+                o.w = __builtin_amdgcn_perm(r[7][cc], r[6][cc], sel);
+                lut[(c4 * 4 + cc) * PF_M + l16 + 16 * h] = o;
+            }
+        }
+        __syncthreads();
+        // ---- next unit: index now (the atomic was issued at the top), record requested, parked after the scan ---------
+        int nxt = -1;
+        uint32_t rw_next = 0;
+        if (wave == 0) {
+            if (lane_i == 0) {
+                if (fetch_t < 8) {
+                    const int base = f_x * per;
+                    const int cnt = min(per, nunits - base);
+                    if (f_i < cnt) {
+                        nxt = base + f_i;
+                    } else {
+                        fetch_t++;
+                        nxt = fetch_slow();
+                    }
+                }
+            }
+            nxt = __builtin_amdgcn_readlane(nxt, 0);
+            if (lane_i < REC_WORDS && nxt >= 0) {
+                rw_next = reinterpret_cast<const uint32_t*>(a.pq_recs + nxt)[lane_i];
+            }
+        }
+        // the pairs' constants -> SGPRs
+        float thr[PF_Q], scq[PF_Q], pcs[PF_Q], isc[PF_Q];
+#pragma unroll
+        for (int j = 0; j < PF_Q; j++) {
+            const float4 c4v = *reinterpret_cast<const float4*>(pc + j * 4);
+            thr[j] = pf_sgpr_f(c4v.x);
+            scq[j] = pf_sgpr_f(c4v.y);
+            pcs[j] = pf_sgpr_f(c4v.z);
+            isc[j] = pf_sgpr_f(c4v.w);
+        }
+
+        typedef __attribute__((address_space(3))) const pf_h8 lds_h8;
+        auto lut_read = [&](uint32_t addr) -> pf_h8 { return *reinterpret_cast<lds_h8*>(addr); };
+        auto issue2 = [&](uint32_t w0, pf_h8 (&v)[2]) {
+            v[0] = lut_read(pf_addr_lo(w0, one));
+            v[1] = lut_read(pf_addr_hi(w0, one));
+        };
+
+        if (nwin > 0) {
+            const _Float16 h0 = (_Float16)0.f;
+            const pf_h8 hz = {h0, h0, h0, h0, h0, h0, h0, h0};
+            pf_h8 acc = hz; // 8 half sums: 4 v_pk_add_f16 per LUT entry
+            // LUT reads run four 2-step units ahead of the additions that consume them (four value buffers); code
+            // registers as in pq_scan_q4: at the top of window w, U0 = block 4w + 4, U1..U3 = blocks 4w + 1..4w + 3.
+            pf_h8 B0[2], B1[2], B2[2], B3[2];
+            issue2(U0.x, B0);
+            issue2(U0.y, B1);
+            issue2(U0.z, B2);
+            issue2(U0.w, B3);
+            U0 = load_blk(4);
+            const int last_group = ngroups - 1;
+            const unsigned long long tail_mask = (len & 63) ? ((1ull << (len & 63)) - 1ull) : ~0ull;
+
+#define PF_UNIT(BUF, WORD)                 \
+    __builtin_amdgcn_sched_barrier(0);     \
+    acc += BUF[0];                         \
+    acc += BUF[1];                         \
+    __builtin_amdgcn_sched_barrier(0);     \
+    issue2(WORD, BUF);
+
+            for (int w = 0; w < nwin; w++) {
+                pf_setprio((w + (wave >> 2)) & 3); // (see pq_scan_q4.hip: equal average speed for a SIMD's four waves)
+                const float ps = ps_next;
+                if (IS_L2) {
+                    ps_next = psb[(int64_t)(w + 1) * 64]; // (the slack groups behind a list exist)
+                }
+                PF_UNIT(B0, U1.x)
+                PF_UNIT(B1, U1.y)
+                PF_UNIT(B2, U1.z)
+                PF_UNIT(B3, U1.w)
+                U1 = load_blk(4 * w + 5);
+                PF_UNIT(B0, U2.x)
+                PF_UNIT(B1, U2.y)
+                PF_UNIT(B2, U2.z)
+                PF_UNIT(B3, U2.w)
+                U2 = load_blk(4 * w + 6);
+                PF_UNIT(B0, U3.x)
+                PF_UNIT(B1, U3.y)
+                PF_UNIT(B2, U3.z)
+                PF_UNIT(B3, U3.w)
+                U3 = load_blk(4 * w + 7);
+                PF_UNIT(B0, U0.x)
+                PF_UNIT(B1, U0.y)
+                PF_UNIT(B2, U0.z)
+                PF_UNIT(B3, U0.w)
+                U0 = load_blk(4 * w + 8);
+                __builtin_amdgcn_sched_barrier(0);
+
+                // ---- the window's 64 vectors are finished in every lane ------------------------------------------------
+                const float f[PF_Q] = {(float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3],
+                                       (float)acc[4], (float)acc[5], (float)acc[6], (float)acc[7]};
+                acc = hz;
+                const int G = G0 + w;
+                const int64_t pos = (int64_t)G * 64 + lane_i;
+                if (DUMP) {
+                    const unsigned long long vmask = ms_valid_rows(a, G, len, row_off);
+                    const bool ok = (vmask >> lane_i) & 1ull;
+#pragma unroll
+                    for (int j = 0; j < PF_Q; j++) {
+                        if (j < npair) {
+                            const int32_t off = slot_of[j]; // (sample pass: the pair's first dump column)
+                            if (pos < len && pos < (int64_t)(PF_SAMPLE - off)) {
+                                const float v = IS_L2 ? __fmaf_rn(f[j], isc[j], pcs[j] + ps) : __fmaf_rn(f[j], isc[j], pcs[j]);
+                                a.dump[(int64_t)q_of[j] * a.dump_stride + off + pos] =
+                                        (ok && v == v) ? v : worst_dist<IS_L2>();
+                            }
+                        }
+                    }
+                } else {
+                    bool hit[PF_Q];
+                    bool any = false;
+#pragma unroll
+                    for (int j = 0; j < PF_Q; j++) {
+                        // L2: ps sc + f <= t;  IP: f >= t   (t = -inf / +inf: nothing passes)
+                        hit[j] = IS_L2 ? (__fmaf_rn(ps, scq[j], f[j]) <= thr[j]) : (f[j] >= thr[j]);
+                        any |= hit[j];
+                    }
+                    const unsigned long long vmask = (G == last_group) ? tail_mask : ~0ull;
+                    if ((__ballot(any) & vmask) != 0ull) {
+                        if (any && ((vmask >> lane_i) & 1ull)) {
+#pragma unroll
+                            for (int j = 0; j < PF_Q; j++) {
+                                if (hit[j]) {
+                                    const float pess = IS_L2 ? __fmaf_rn(f[j], isc[j], pcs[j] + ps)
+                                                             : __fmaf_rn(f[j], isc[j], pcs[j]);
+                                    ms_emit<IS_L2>(a, q_of[j], slot_of[j], row_off, pos, pess);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+#undef PF_UNIT
+            __builtin_amdgcn_s_setprio(0);
+        }
+        if (wave == 0) { // park the next unit
+            if (lane_i < REC_WORDS) {
+                ctl[8 + lane_i] = (int)rw_next;
+            }
+            if (lane_i == 0) {
+                ctl[0] = nxt;
+            }
+        }
+        __syncthreads(); // the LUT and the pair constants are dead, the mailbox is visible
+        cur = pf_sgpr(ctl[0]);
+    }
+}
+
+size_t pqf_smem() {
+    return (size_t)PF_LUT_BYTES + PF_CTL_BYTES;
+}
+
+bool pqf_supports(int M, int d) {
+    return M == PF_M && d == PF_M * PF_DSUB;
+}
+
+// units_bound: upper bound of *a.nunits_dev (sizes pq_recs)
+hipError_t launch_pqf(const MScanArgs& a, bool is_l2, int64_t units_bound, hipStream_t s) {
+    if (units_bound <= 0) {
+        return hipSuccess;
+    }
+    const bool dump = a.dump != nullptr;
+    auto kern = is_l2 ? (dump ? pqf_kernel<true, true> : pqf_kernel<true, false>)
+                      : (dump ? pqf_kernel<false, true> : pqf_kernel<false, false>);
+    const size_t sm = pqf_smem();
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)sm);
+    if (e != hipSuccess) {
+        return e;
+    }
+    hipLaunchKernelGGL(pqf_prepare_kernel, dim3((unsigned)((std::max<int64_t>(units_bound, 128) + 255) / 256)), dim3(256),
+                       0, s, a, units_bound);
+    int dev = 0, ncu = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (ncu <= 0) {
+        ncu = 256;
+    }
+    const int64_t wgs = std::max<int64_t>(1, std::min<int64_t>(ncu, units_bound));
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(PF_THREADS), sm, s, a);
+    return hipGetLastError();
+}
+
+} // namespace knhip
