@@ -1165,7 +1165,7 @@ int validate_search(const knhip_index* idx, int64_t nq, int32_t k, int32_t& npro
         nprobe = (int32_t)idx->nlist; // IndexIVF.cpp:321-322
     }
     if ((size_t)nprobe > row_select_max_k()) {
-        return fail(KNHIP_ERR_NOT_IMPLEMENTED, "nprobe > 4096 is not supported yet");
+        return fail(KNHIP_ERR_NOT_IMPLEMENTED, "nprobe > 16384 is not supported yet");
     }
     return KNHIP_OK;
 }
@@ -1871,7 +1871,7 @@ int knhip_range_search(const knhip_index* idx, const float* queries, int64_t nq,
         return fail(KNHIP_ERR_NOT_IMPLEMENTED, "range search on IVF_PQ needs m = 32 (stream16 layout)");
     }
     if (kind != KNHIP_BRUTE_FORCE && (size_t)idx->nlist > row_select_max_k()) {
-        return fail(KNHIP_ERR_NOT_IMPLEMENTED, "range search probes every list: nlist > 4096 is not supported yet");
+        return fail(KNHIP_ERR_NOT_IMPLEMENTED, "range search probes every list: nlist > 16384 is not supported yet");
     }
     DeviceGuard g(idx->desc.device);
     hipStream_t s = nullptr;

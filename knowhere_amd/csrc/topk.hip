@@ -132,7 +132,7 @@ hipError_t launch_merge_partials(const float* partial_d, const int64_t* partial_
 // for the k-th key, gather, bitonic sort of the survivors in LDS.
 // ---------------------------------------------------------------------------------------------
 constexpr int RS_THREADS = 256;
-constexpr int RS_MAX_K = 4096;
+constexpr int RS_MAX_K = 16384; // the selected keys are sorted in LDS: 8 bytes each, 128 KB of the CU's 160
 
 // order-preserving map float -> uint32 such that "better" == smaller key
 template <bool IS_L2>
@@ -347,6 +347,16 @@ size_t row_select_max_k() {
     return RS_MAX_K;
 }
 
+// more than 48 KB of dynamic LDS (k > 4096) has to be allowed per kernel
+static hipError_t rs_allow_smem(size_t sm, bool is_l2) {
+    if (sm <= 48 * 1024) {
+        return hipSuccess;
+    }
+    const void* kern = is_l2 ? reinterpret_cast<const void*>(row_select_kernel<true>)
+                             : reinterpret_cast<const void*>(row_select_kernel<false>);
+    return hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+}
+
 hipError_t launch_row_select(const float* vals, int64_t nrows, int64_t n, int k, bool is_l2,
                              int64_t* out_keys, float* out_d, const int32_t* row_flags, hipStream_t s) {
     if (nrows <= 0 || k <= 0) {
@@ -360,6 +370,9 @@ hipError_t launch_row_select(const float* vals, int64_t nrows, int64_t n, int k,
         kp <<= 1;
     }
     const size_t sm = (size_t)kp * 8;
+    if (hipError_t e = rs_allow_smem(sm, is_l2); e != hipSuccess) {
+        return e;
+    }
     if (is_l2) {
         hipLaunchKernelGGL((row_select_kernel<true>), dim3((unsigned)nrows), dim3(RS_THREADS), sm, s,
                            vals, n, k, kp, out_keys, out_d, row_flags, (int64_t)0, nullptr, 0, nullptr, (int64_t)0, nullptr);
@@ -384,6 +397,9 @@ hipError_t launch_row_select_var(const float* vals, int64_t stride, const int64_
         kp <<= 1;
     }
     const size_t sm = (size_t)kp * 8;
+    if (hipError_t e = rs_allow_smem(sm, is_l2); e != hipSuccess) {
+        return e;
+    }
     if (is_l2) {
         hipLaunchKernelGGL((row_select_kernel<true>), dim3((unsigned)nrows), dim3(RS_THREADS), sm, s, vals,
                            (int64_t)0, k, kp, out_keys, out_d, nullptr, stride, keys, key_stride, list_len, n_cap, n_row);

@@ -1,0 +1,53 @@
+"""GPU parity tests (-m gpu) of the shapes opened by the larger row selection (topk.hip RS_MAX_K 4096 -> 16384):
+nprobe above 4096 and range search on indexes with more than 4096 lists, against the oracle, bit for bit.
+
+The change was made at the end of round 2 after the round's GPU minutes were spent (the selection kernel itself is
+unchanged; only its LDS allowance and the limits moved), so these tests are skipped unless KNHIP_TEST_UNVALIDATED=1.
+Next round:  KNHIP_TEST_UNVALIDATED=1 python -m pytest tests/test_gpu_limits.py -m gpu -x -q"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import assert_parity, gen_data
+from oracle import binding as ob
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("KNHIP_TEST_UNVALIDATED") != "1",
+                                 reason="not validated on hardware yet (set KNHIP_TEST_UNVALIDATED=1)")]
+
+
+def _gpu(ix):
+    from knowhere_amd import GpuIndex
+    return GpuIndex.from_data(ix, device=0)
+
+
+@pytest.mark.parametrize("kind", [ob.IVF_FLAT, ob.IVF_SQ8], ids=["ivfflat", "ivfsq8"])
+@pytest.mark.parametrize("metric", [ob.L2, ob.IP], ids=["l2", "ip"])
+def test_nprobe_above_4096(port, kind, metric):
+    nb, d, nlist = 30000, 16, 6000
+    xb, xq = gen_data(nb, d, 42), gen_data(12, d, 44)
+    ix = ob.make_index(port, kind, metric, xb, nlist=nlist)
+    g = _gpu(ix)
+    for k, nprobe in ((10, 5000), (100, nlist), (3, 4097)):
+        Do, Io = port.search(ix, xq, k, nprobe)
+        D, I = g.search(xq, k, nprobe)
+        assert_parity(Do, Io, D, I, metric, f"kind={kind} k={k} nprobe={nprobe}")
+    g.close()
+
+
+@pytest.mark.parametrize("metric", [ob.L2, ob.IP], ids=["l2", "ip"])
+def test_range_search_above_4096_lists(port, metric):
+    nb, d, nlist = 30000, 16, 5000
+    xb, xq = gen_data(nb, d, 42), gen_data(10, d, 44)
+    ix = ob.make_index(port, ob.IVF_FLAT, metric, xb, nlist=nlist)
+    g = _gpu(ix)
+    D, _ = port.search(ix, xq, 40, nlist)
+    for radius in (float(np.median(D[:, 5])), float(np.median(D[:, 39]))):
+        for max_empty in (0, 2):
+            exp = port.range_search(ix, xq, radius, max_empty)
+            got = g.range_search(xq, np.float32(radius), max_empty)
+            assert np.array_equal(exp[0], got[0]), "lims differ"
+            assert np.array_equal(exp[1], got[1]), "ids differ (or are in a different order)"
+            assert np.array_equal(exp[2].view(np.uint32), got[2].view(np.uint32)), "distances differ bitwise"
+    g.close()
