@@ -218,7 +218,8 @@ struct knhip_index {
 
     int64_t device_bytes() const {
         const DevBuf* all[] = {&centroids, &centroids_il, &cb, &precomp_t, &sq_trained, &d_list_len,
-                               &d_list_row_off, &d_list_blk_off, &ids, &rows, &rows2, &d_list_blk_off2, &cb_t, &codes_aos};
+                               &d_list_row_off, &d_list_blk_off, &ids, &rows, &rows2, &d_list_blk_off2, &cb_t, &codes_aos,
+                               &rows_r, &d_list_blk_off_r, &psum};
         int64_t t = 0;
         for (auto* b : all) {
             t += (int64_t)b->bytes;
