@@ -38,6 +38,7 @@
 #include "ms_common.h"
 
 #include <algorithm>
+#include <cstdio>
 
 namespace knhip {
 
@@ -316,6 +317,22 @@ __device__ __forceinline__ uint32_t pf_addr_hi(uint32_t w, uint32_t one) {
     return a;
 }
 
+// Phase timers (profiling build only: make prof -> libknhip_prof.so, never shipped): wave 0 of every workgroup sums
+// the shader cycles it spends per phase of a unit; printed per launch by launch_pqf.
+#ifdef KNHIP_PHASE_TIMERS
+#define PF_T(i)                                                         \
+    do {                                                                \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();     \
+        tacc[i] += t_ - tlast;                                          \
+        tlast = t_;                                                     \
+    } while (0)
+#define PF_COUNT(i, n) tacc[i] += (unsigned long long)(n)
+__device__ unsigned long long g_pf_prof[16 * 8];
+#else
+#define PF_T(i)
+#define PF_COUNT(i, n)
+#endif
+
 // ---- the filter / sample kernel -----------------------------------------------------------------------------------
 // Persistent: one workgroup of 16 waves per CU (128 KB of LUT), units pulled in list order from the XCD's counter as
 // pq_scan_q4.hip does.  Per unit: per-pair constants (waves 0..7, one pair each: bound from gthr and the candidate
@@ -324,6 +341,10 @@ __device__ __forceinline__ uint32_t pf_addr_hi(uint32_t w, uint32_t one) {
 // (vector, query) at the end of the window.
 template <bool IS_L2, bool DUMP>
 __global__ __launch_bounds__(PF_THREADS) void pqf_kernel(MScanArgs a) {
+#ifdef KNHIP_PHASE_TIMERS
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_amdgcn_s_memtime();
+#endif
     extern __shared__ __align__(16) unsigned char smem[];
     int* ctl = reinterpret_cast<int*>(smem + PF_LUT_BYTES);
     float* pc = reinterpret_cast<float*>(smem + PF_LUT_BYTES + 256); // [8][4] = {t, sc, pess const, 1 / sc}
@@ -374,6 +395,7 @@ __global__ __launch_bounds__(PF_THREADS) void pqf_kernel(MScanArgs a) {
     const uint4* qh4 = reinterpret_cast<const uint4*>(a.pq_qh);
 
     while (cur >= 0) {
+        PF_T(5); // (loop top: the mailbox read of the previous iteration's end)
         int lane_i = lane;
         asm volatile("" : "+v"(lane_i)); // nothing lane-derived is hoisted out of the unit loop
         int f_x = 0, f_i = 0;
@@ -479,7 +501,9 @@ __global__ __launch_bounds__(PF_THREADS) void pqf_kernel(MScanArgs a) {
                 lut[(c4 * 4 + cc) * PF_M + l16 + 16 * h] = o;
             }
         }
+        PF_T(0); // record, pair constants, table loads + LUT stores
         __syncthreads();
+        PF_T(1); // wait for the other waves' LUT parts
         // ---- next unit: index now (the atomic was issued at the top), record requested, parked after the scan ---------
         int nxt = -1;
         uint32_t rw_next = 0;
@@ -519,6 +543,7 @@ __global__ __launch_bounds__(PF_THREADS) void pqf_kernel(MScanArgs a) {
             v[1] = lut_read(pf_addr_hi(w0, one));
         };
 
+        PF_T(2); // set-up of the scan
         if (nwin > 0) {
             const _Float16 h0 = (_Float16)0.f;
             const pf_h8 hz = {h0, h0, h0, h0, h0, h0, h0, h0};
@@ -616,6 +641,8 @@ __global__ __launch_bounds__(PF_THREADS) void pqf_kernel(MScanArgs a) {
 #undef PF_UNIT
             __builtin_amdgcn_s_setprio(0);
         }
+        PF_T(3); // window loop
+        PF_COUNT(6, nwin);
         if (wave == 0) { // park the next unit
             if (lane_i < REC_WORDS) {
                 ctl[8 + lane_i] = (int)rw_next;
@@ -625,8 +652,17 @@ __global__ __launch_bounds__(PF_THREADS) void pqf_kernel(MScanArgs a) {
             }
         }
         __syncthreads(); // the LUT and the pair constants are dead, the mailbox is visible
+        PF_T(4);         // wait for the slowest wave's scan
+        PF_COUNT(7, 1);
         cur = pf_sgpr(ctl[0]);
     }
+#ifdef KNHIP_PHASE_TIMERS
+    if (lane == 0) {
+        for (int i = 0; i < 8; i++) {
+            atomicAdd(&g_pf_prof[wave * 8 + i], tacc[i]);
+        }
+    }
+#endif
 }
 
 size_t pqf_smem() {
@@ -660,7 +696,24 @@ hipError_t launch_pqf(const MScanArgs& a, bool is_l2, int64_t units_bound, hipSt
         ncu = 256;
     }
     const int64_t wgs = std::max<int64_t>(1, std::min<int64_t>(ncu, units_bound));
+#ifdef KNHIP_PHASE_TIMERS
+    static unsigned long long zero[128] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pf_prof), zero, sizeof(zero));
+#endif
     hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(PF_THREADS), sm, s, a);
+#ifdef KNHIP_PHASE_TIMERS
+    (void)hipStreamSynchronize(s);
+    unsigned long long h[128];
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pf_prof), sizeof(h));
+    fprintf(stderr, "[pqf timers] %s ticks per unit: wave | lut wait1 setup windows wait2 top | windows/unit\n",
+            dump ? "sample" : "filter");
+    for (int w = 0; w < 16; w++) {
+        const unsigned long long* r = h + w * 8;
+        const double n = r[7] ? (double)r[7] : 1.0;
+        fprintf(stderr, "[pqf timers] %2d | %6.0f %6.0f %6.0f %6.0f %6.0f %5.0f | %.2f   (units %llu)\n", w, r[0] / n, r[1] / n,
+                r[2] / n, r[3] / n, r[4] / n, r[5] / n, r[6] / n, r[7]);
+    }
+#endif
     return hipGetLastError();
 }
 
