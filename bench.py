@@ -317,6 +317,20 @@ def make_roofline(a, kind, prof, world):
     if kind == kidx.IVF_PQ:
         # one 4-byte table lookup per code byte: the LDS gather is the unit that binds (round-1 PMC: HBM traffic
         # is 0.03-0.14 x the algorithmic bytes, LDS ~ busy); SURVEY 8(d)'s no-reuse HBM model is kept beside it
+        if prof.get("mscan_queries", 0) > 0:
+            # KNHIP_PQF=1: the half-precision prefilter (pq_filter.hip) is the dominant kernel: one 2-byte table lookup
+            # per code byte and query (16-byte entries hold 8 queries), survivors recomputed by the exact finish
+            lds = scan_bytes * 2.0 / sec / 1e9 if sec > 0 else 0.0
+            steps = max(a.steps, 1)
+            return dict({"bound": "lds", "kernel": "knhip::pqf_kernel<true, false>", "achieved": round(lds, 1),
+                         "peak": round(LDS_PEAK_GBPS, 1), "unit": "GB/s", "frac": round(lds / LDS_PEAK_GBPS, 4),
+                         "note": "achieved = 2 B x code bytes scanned / launch time (half-precision table, 8 queries "
+                                 "per ds_read_b128); peak = 256 B/clk/CU x 256 CU x 2.4 GHz",
+                         "lookups_per_ns_per_cu": round(scan_bytes / sec / 1e9 / 256.0, 1) if sec > 0 else None,
+                         "mscan": {"queries_per_step": prof["mscan_queries"] / steps,
+                                   "overflow_queries_per_step": prof["mscan_overflow_queries"] / steps,
+                                   "candidates_per_query": round(prof["mscan_candidates"] /
+                                                                 max(prof["mscan_queries"], 1), 1)}}, **common)
         lds = scan_bytes * 4.0 / sec / 1e9 if sec > 0 else 0.0
         out = dict({"bound": "lds", "kernel": "knhip::pq_scan_q4_kernel<true, 2>", "achieved": round(lds, 1),
                     "peak": round(LDS_PEAK_GBPS, 1), "unit": "GB/s", "frac": round(lds / LDS_PEAK_GBPS, 4),
