@@ -305,7 +305,8 @@ int coarse_stage(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
     c.nq = nq;
     const int margin = std::max(32, nprobe / 4);
     const int64_t ncand = (int64_t)nprobe + margin;
-    if (!idx->coarse_gemm || ncand >= nlist || (size_t)ncand > row_select_max_k()) {
+    // (the MFMA prefilter + exact re-rank is validated for up to 4096 candidates per query; above, the exact kernel)
+    if (!idx->coarse_gemm || ncand >= nlist || ncand > 4096) {
         HIP_TRY(launch_flat_full(c, is_l2, ws->coarse_full.as<float>(), nullptr, 0, nullptr, s));
         HIP_TRY(launch_row_select(ws->coarse_full.as<float>(), nq, nlist, nprobe, is_l2, keys, cdis, nullptr, s));
         return KNHIP_OK;
