@@ -38,6 +38,7 @@
 #include "ms_common.h"
 
 #include <algorithm>
+#include <cstddef>
 #include <cstdio>
 
 namespace knhip {
@@ -376,6 +377,10 @@ __global__ __launch_bounds__(PF_THREADS) void pqf_kernel(MScanArgs a) {
     };
     constexpr int REC_WORDS = (int)(sizeof(P8Rec) / 4);
     static_assert(REC_WORDS <= KN_WAVE, "one lane per record word");
+    // (the word indices read back from the mailbox below)
+    static_assert(offsetof(P8Rec, npair) == 4 && offsetof(P8Rec, q) == 8 && offsetof(P8Rec, slot) == 40 &&
+                  offsetof(P8Rec, dis0) == 72 && offsetof(P8Rec, len) == 104 && offsetof(P8Rec, sblk0) == 112 &&
+                  offsetof(P8Rec, row_off) == 120, "P8Rec layout");
     if (wave == 0) {
         int first = -1;
         if (lane == 0) {
@@ -679,6 +684,9 @@ hipError_t launch_pqf(const MScanArgs& a, bool is_l2, int64_t units_bound, hipSt
         return hipSuccess;
     }
     const bool dump = a.dump != nullptr;
+    if (dump && a.dump_stride != PF_SAMPLE) {
+        return hipErrorInvalidValue; // (the sample pass writes at most PF_SAMPLE columns per query)
+    }
     auto kern = is_l2 ? (dump ? pqf_kernel<true, true> : pqf_kernel<true, false>)
                       : (dump ? pqf_kernel<false, true> : pqf_kernel<false, false>);
     const size_t sm = pqf_smem();
