@@ -1,0 +1,79 @@
+"""tests/hipemu/emu_build.py -- build the host stand-in of selected kernel files (test infrastructure only).
+
+Copies knowhere_amd/csrc/{pq_filter,mfma_scan}.hip into tests/hipemu/_build/ with the few hardware-specific lines
+rewritten (LDS-offset addressing, inline ISA, dynamic LDS declarations), and compiles them with the host clang++ against
+tests/hipemu/hip/hip_runtime.h into _build/libpqf_emu.so.  Every rewrite asserts how often its pattern occurs, so a
+change of the kernel source that the emulation does not cover fails here instead of passing silently."""
+import os
+import re
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "knowhere_amd", "csrc")
+BUILD = os.path.join(HERE, "_build")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+DYN_SMEM = "extern __shared__ __align__(16) unsigned char smem[];"
+DYN_SMEM_EMU = "unsigned char* smem = hipemu::tl.g->smem;"
+
+
+def _sub(s, pattern, repl, count, flags=0, what=""):
+    out, n = re.subn(pattern, repl, s, flags=flags)
+    assert n == count, f"emu patch '{what or pattern[:40]}': expected {count} match(es), found {n}"
+    return out
+
+
+def patch_pq_filter(s):
+    s = _sub(s, re.escape(DYN_SMEM), DYN_SMEM_EMU, 1, what="dynamic LDS")
+    # the LDS-offset-0 assertion of the token addressing
+    s = _sub(s, r"    if \(\(uint32_t\)\(size_t\)\(\(__attribute__\(\(address_space\(3\)\)\) unsigned char\*\)smem\) != 0u\) \{\n"
+                r"        __builtin_trap\(\);[^\n]*\n    \}\n", "", 1, what="LDS offset check")
+    # token -> LDS byte address: the SDWA shift, restated
+    s = _sub(s, r'    asm\("v_lshlrev_b32_sdwa %0, %2, %1 [^"]*src1_sel:WORD_0"\n\s*: "=v"\(a\)\n\s*: "v"\(w\), "s"\(one\)\);\n',
+             "    a = (w & 0xffffu) << one;\n", 1, what="sdwa lo")
+    s = _sub(s, r'    asm\("v_lshlrev_b32_sdwa %0, %2, %1 [^"]*src1_sel:WORD_1"\n\s*: "=v"\(a\)\n\s*: "v"\(w\), "s"\(one\)\);\n',
+             "    a = (w >> 16) << one;\n", 1, what="sdwa hi")
+    # LDS reads by byte offset
+    s = _sub(s, r"        typedef __attribute__\(\(address_space\(3\)\)\) const pf_h8 lds_h8;\n"
+                r"        auto lut_read = \[&\]\(uint32_t addr\) -> pf_h8 \{ return \*reinterpret_cast<lds_h8\*>\(addr\); \};\n",
+             "        auto lut_read = [&](uint32_t addr) -> pf_h8 { return *reinterpret_cast<const pf_h8*>(smem + addr); };\n",
+             1, what="lut_read")
+    s = _sub(s, r'    asm volatile\("s_getreg_b32 %0, hwreg\(HW_REG_XCC_ID\)" : "=s"\(xcc\)\);\n',
+             "    xcc = (uint32_t)blockIdx.x;\n", 1, what="xcc id")
+    s = _sub(s, r'        asm volatile\("" : "\+v"\(lane_i\)\);[^\n]*\n', "", 1, what="lane launder")
+    return s
+
+
+def patch_mfma_scan(s):
+    n = s.count(DYN_SMEM)
+    assert n >= 1
+    s = s.replace(DYN_SMEM, DYN_SMEM_EMU)
+    return s
+
+
+def build(force=False):
+    os.makedirs(BUILD, exist_ok=True)
+    so = os.path.join(BUILD, "libpqf_emu.so")
+    srcs = [os.path.join(CSRC, f) for f in ("pq_filter.hip", "mfma_scan.hip", "common.h", "kernels.h", "ms_common.h")]
+    srcs += [os.path.join(HERE, f) for f in ("emu_runtime.cpp", "harness.cpp", "emu_build.py", "hip/hip_runtime.h")]
+    if not force and os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(p) for p in srcs):
+        return so
+    for name, fn in (("pq_filter.hip", patch_pq_filter), ("mfma_scan.hip", patch_mfma_scan)):
+        with open(os.path.join(CSRC, name)) as f:
+            src = fn(f.read())
+        with open(os.path.join(BUILD, name.replace(".hip", "_emu.cpp")), "w") as f:
+            f.write(src)
+    cmd = [CLANG, "-std=c++20", "-O1", "-g", "-fPIC", "-shared", "-pthread", "-ffp-contract=off",
+           "-Xclang", "-ffloat16-excess-precision=none", "-Wno-unused-value", "-Wno-unknown-pragmas", "-Wno-pass-failed",
+           "-I", HERE, "-I", CSRC, "-I", os.path.join(ROOT, "include"),
+           os.path.join(BUILD, "pq_filter_emu.cpp"), os.path.join(BUILD, "mfma_scan_emu.cpp"),
+           os.path.join(HERE, "emu_runtime.cpp"), os.path.join(HERE, "harness.cpp"), "-o", so]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("emulation build failed:\n" + r.stdout[-3000:] + r.stderr[-6000:])
+    return so
+
+
+if __name__ == "__main__":
+    print(build(force=True))

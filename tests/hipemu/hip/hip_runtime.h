@@ -1,0 +1,235 @@
+// tests/hipemu/hip/hip_runtime.h -- a HOST stand-in for <hip/hip_runtime.h>, test infrastructure only.
+//
+// Purpose: run the *source* of selected kernels (knowhere_amd/csrc/pq_filter.hip, the finish kernel of mfma_scan.hip)
+// on the CPU when no GPU is at hand, to check their index arithmetic, work protocol and epilogues against the numpy
+// model of tests/test_pqf_model.py.  It is NOT a product path and nothing under knowhere_amd/ includes it: the test
+// compiles a patched copy of the kernel files against this directory (tests/hipemu/emu_build.py).
+//
+// Execution model: a workgroup = blockDim.x OS threads running the kernel body; workgroups run one after another
+// (function-local `__shared__` arrays are plain statics, valid for one workgroup at a time).
+//   __syncthreads()                      -> barrier over the workgroup's live threads (a thread that returns drops out)
+//   __shfl / __shfl_up / __shfl_xor / __ballot / readlane / readfirstlane
+//                                        -> exchange through a per-wave buffer + barrier over the wave's 64 threads.
+//     They are only valid where all 64 lanes of the wave take part (wave-uniform control flow) -- which is how the
+//     kernels under test use them.
+//   atomics                              -> GCC/Clang __atomic builtins on host memory
+// What it cannot model: the hardware's memory model and LDS hazards, EXEC-masked cross-lane operations, instruction
+// scheduling.  Hardware-specific lines (LDS offset addressing, inline ISA) are rewritten by emu_build.py.
+#pragma once
+#include <atomic>
+#include <barrier>
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <thread>
+#include <vector>
+
+// ---- qualifiers ---------------------------------------------------------------------------------------------------
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ static
+#define __align__(n) alignas(n)
+#define HIP_SYMBOL(x) x
+#define __HIP_MEMORY_SCOPE_AGENT 0
+
+// ---- vector types ---------------------------------------------------------------------------------------------------
+struct alignas(8) uint2 { uint32_t x, y; };
+struct alignas(16) uint4 { uint32_t x, y, z, w; };
+struct alignas(8) float2 { float x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
+inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
+inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
+inline float2 make_float2(float x, float y) { return float2{x, y}; }
+inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+// ---- runtime API subset -----------------------------------------------------------------------------------------------
+typedef int hipError_t;
+typedef void* hipStream_t;
+constexpr hipError_t hipSuccess = 0;
+constexpr hipError_t hipErrorInvalidValue = 1;
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+namespace hipemu { extern int g_ncu; }
+inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = hipemu::g_ncu; return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { std::memset(p, v, n); return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+
+// ---- execution model ------------------------------------------------------------------------------------------------
+namespace hipemu {
+
+struct Wave {
+    std::barrier<> bar;
+    uint64_t x[2][64];
+    explicit Wave(int n) : bar(n) {}
+};
+struct Group {
+    std::barrier<> bar;
+    std::vector<std::unique_ptr<Wave>> waves;
+    unsigned char* smem = nullptr;
+    explicit Group(int n) : bar(n) {}
+};
+struct Ctx {
+    dim3 tid, bid, bdim, gdim;
+    Group* g = nullptr;
+    Wave* w = nullptr;
+    int lane = 0;
+    unsigned op = 0;
+};
+extern thread_local Ctx tl;
+
+inline uint64_t xchg(uint64_t v, int src) { // every lane of the wave calls this; returns lane `src`'s value
+    Wave& w = *tl.w;
+    const unsigned k = tl.op++ & 1u;
+    w.x[k][tl.lane] = v;
+    w.bar.arrive_and_wait();
+    return w.x[k][src & 63];
+}
+inline unsigned long long ballot(bool p) {
+    Wave& w = *tl.w;
+    const unsigned k = tl.op++ & 1u;
+    w.x[k][tl.lane] = p ? 1u : 0u;
+    w.bar.arrive_and_wait();
+    unsigned long long m = 0;
+    for (int i = 0; i < 64; i++) {
+        m |= (unsigned long long)(w.x[k][i] & 1u) << i;
+    }
+    return m;
+}
+template <class T>
+inline uint64_t to_bits(T v) {
+    uint64_t b = 0;
+    static_assert(sizeof(T) <= 8, "shuffle payload");
+    std::memcpy(&b, &v, sizeof(T));
+    return b;
+}
+template <class T>
+inline T from_bits(uint64_t b) {
+    T v;
+    std::memcpy(&v, &b, sizeof(T));
+    return v;
+}
+
+// run one kernel launch: workgroups in sequence, threads of a workgroup concurrently
+void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()>& body);
+
+} // namespace hipemu
+
+#define threadIdx (hipemu::tl.tid)
+#define blockIdx (hipemu::tl.bid)
+#define blockDim (hipemu::tl.bdim)
+#define gridDim (hipemu::tl.gdim)
+#define hipLaunchKernelGGL(kern, grid, block, smem, stream, ...) \
+    hipemu::launch((grid), (block), (size_t)(smem), [&]() { (kern)(__VA_ARGS__); })
+
+inline void __syncthreads() { hipemu::tl.g->bar.arrive_and_wait(); }
+
+// ---- cross-lane ---------------------------------------------------------------------------------------------------
+template <class T>
+inline T __shfl(T v, int src, int = 64) { return hipemu::from_bits<T>(hipemu::xchg(hipemu::to_bits(v), src)); }
+template <class T>
+inline T __shfl_up(T v, unsigned d, int = 64) {
+    const int l = hipemu::tl.lane;
+    const T o = hipemu::from_bits<T>(hipemu::xchg(hipemu::to_bits(v), l >= (int)d ? l - (int)d : l));
+    return l >= (int)d ? o : v;
+}
+template <class T>
+inline T __shfl_xor(T v, int m, int = 64) { return hipemu::from_bits<T>(hipemu::xchg(hipemu::to_bits(v), hipemu::tl.lane ^ m)); }
+inline unsigned long long __ballot(bool p) { return hipemu::ballot(p); }
+#define __builtin_amdgcn_readlane(v, l) ((int)hipemu::xchg((uint64_t)(uint32_t)(v), (l)))
+#define __builtin_amdgcn_readfirstlane(v) ((int)hipemu::xchg((uint64_t)(uint32_t)(v), 0))
+#define __builtin_amdgcn_update_dpp(...) (std::abort(), 0)
+inline uint32_t hipemu_perm(uint32_t s0, uint32_t s1, uint32_t sel) { // v_perm_b32: bytes 0..3 = S1, 4..7 = S0
+    const uint64_t src = ((uint64_t)s0 << 32) | s1;
+    uint32_t out = 0;
+    for (int i = 0; i < 4; i++) {
+        const uint32_t c = (sel >> (8 * i)) & 0xffu;
+        uint32_t b;
+        if (c <= 7) {
+            b = (uint32_t)(src >> (8 * c)) & 0xffu;
+        } else if (c == 0x0c) {
+            b = 0;
+        } else {
+            std::abort(); // (selector forms the kernels do not use)
+        }
+        out |= b << (8 * i);
+    }
+    return out;
+}
+#define __builtin_amdgcn_perm(a, b, sel) hipemu_perm((a), (b), (sel))
+// matrix-core builtins: present so that files holding MFMA kernels compile; those kernels are not run here
+template <class A, class B, class C>
+inline C hipemu_mfma_stub(A, B, C c, int, int, int) {
+    std::abort();
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(...) hipemu_mfma_stub(__VA_ARGS__)
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(...) hipemu_mfma_stub(__VA_ARGS__)
+#define __builtin_amdgcn_s_setprio(p) ((void)0)
+#define __builtin_amdgcn_sched_barrier(m) ((void)0)
+#define __builtin_amdgcn_s_memtime() 0ull
+#define __builtin_amdgcn_s_sleep(n) ((void)0)
+
+// ---- scalar helpers ---------------------------------------------------------------------------------------------------
+inline float __fadd_rn(float a, float b) { return a + b; }
+inline float __fsub_rn(float a, float b) { return a - b; }
+inline float __fmul_rn(float a, float b) { return a * b; }
+inline float __fdiv_rn(float a, float b) { return a / b; }
+inline float __fmaf_rn(float a, float b, float c) { return std::fmaf(a, b, c); }
+inline uint32_t __float_as_uint(float f) { return hipemu::from_bits<uint32_t>(hipemu::to_bits(f)); }
+inline int __float_as_int(float f) { return (int)__float_as_uint(f); }
+inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+inline float __int_as_float(int u) { float f; std::memcpy(&f, &u, 4); return f; }
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
+template <class T>
+inline T min(T a, T b) { return a < b ? a : b; }
+template <class T>
+inline T max(T a, T b) { return a > b ? a : b; }
+inline int64_t min(int64_t a, int b) { return a < b ? a : (int64_t)b; }
+inline int64_t min(int a, int64_t b) { return a < b ? (int64_t)a : b; }
+inline int64_t max(int64_t a, int b) { return a > b ? a : (int64_t)b; }
+
+// ---- atomics -----------------------------------------------------------------------------------------------------------
+template <class T>
+inline T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline unsigned atomicAdd(unsigned* p, int v) { return __atomic_fetch_add(p, (unsigned)v, __ATOMIC_RELAXED); }
+inline unsigned long long atomicAdd(unsigned long long* p, int v) { return __atomic_fetch_add(p, (unsigned long long)v, __ATOMIC_RELAXED); }
+template <class T>
+inline T atomicMax(T* p, T v) {
+    T o = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (o < v && !__atomic_compare_exchange_n(p, &o, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+    }
+    return o;
+}
+template <class T>
+inline T atomicMin(T* p, T v) {
+    T o = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (o > v && !__atomic_compare_exchange_n(p, &o, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+    }
+    return o;
+}
+template <class T>
+inline T hipemu_aload(const T* p) {
+    T v;
+    __atomic_load(const_cast<T*>(p), &v, __ATOMIC_RELAXED);
+    return v;
+}
+#define __hip_atomic_load(p, order, scope) hipemu_aload(p)
+#define __hip_atomic_fetch_min(p, v, order, scope) atomicMin((p), (v))
+#define __hip_atomic_fetch_max(p, v, order, scope) atomicMax((p), (v))

@@ -1,0 +1,107 @@
+"""The SOURCE of the half-precision ADC prefilter kernels (knowhere_amd/csrc/pq_filter.hip) and of the sample-plan / tau /
+exact-finish kernels of mfma_scan.hip, executed on the CPU through the host stand-in of tests/hipemu (one OS thread
+per GPU thread, barriers for __syncthreads and for the cross-lane operations), against the oracle.
+
+Why: the kernels were written when no GPU was at hand.  The numpy model (tests/test_pqf_model.py) pins the layouts and
+formulas; this test runs the kernel files themselves -- their index arithmetic, the persistent unit protocol (per-XCD
+counters, mailbox, barriers), the per-pair constants, window loop, epilogues, candidate lists and the exact finish --
+with only the hardware-specific lines rewritten (tests/hipemu/emu_build.py lists them: LDS byte-offset addressing, the
+SDWA shift, dynamic LDS declarations).  It cannot see hardware hazards; it does catch wrong indices, protocol
+deadlocks and wrong arithmetic.  Results must equal the oracle's bit for bit for every query that did not overflow its
+candidate list."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import gen_data
+from oracle import binding as ob
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu"))
+
+pytestmark = pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"), reason="needs the host clang++")
+
+M, KSUB, DSUB = 32, 256, 4
+
+
+@pytest.fixture(scope="module")
+def emu():
+    import emu_build
+    lib = C.CDLL(emu_build.build())
+    lib.emu_pqf_search.restype = C.c_int
+    return lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def run_emulated(lib, port, ix, xq, k, nprobe, cap=4096, bitset=None, use_hist=1):
+    is_l2 = ix.metric == ob.L2
+    nq = xq.shape[0]
+    cdis, keys = port.coarse_search(ix, xq, nprobe)
+    lens = np.array([len(c) for c in ix.list_codes], np.int64)
+    row_off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+    codes = np.ascontiguousarray(np.concatenate([c.reshape(-1, M) for c in ix.list_codes]).astype(np.uint8))
+    ids = np.ascontiguousarray(np.concatenate(ix.list_ids).astype(np.int64))
+    pre = np.ascontiguousarray(ix.precomputed_table, np.float32) if is_l2 else None
+    cb = np.ascontiguousarray(ix.pq_centroids, np.float32)
+    cen = np.ascontiguousarray(ix.centroids, np.float32)
+    xq = np.ascontiguousarray(xq, np.float32)
+    keys = np.ascontiguousarray(keys, np.int64)
+    cdis = np.ascontiguousarray(cdis, np.float32)
+    D = np.zeros((nq, k), np.float32)
+    I = np.zeros((nq, k), np.int64)
+    cnt = np.zeros(nq, np.int32)
+    ovf = np.zeros(nq, np.int32)
+    tau = np.zeros(nq, np.float32)
+    nunits = np.zeros(1, np.int64)
+    nbits = 0 if bitset is None else int(lens.sum())
+    rc = lib.emu_pqf_search(C.c_int64(ix.nlist), _p(lens, C.c_int64), _p(row_off, C.c_int64), _p(codes, C.c_uint8),
+                            _p(ids, C.c_int64), _p(pre, C.c_float), _p(cb, C.c_float), _p(cen, C.c_float),
+                            _p(xq, C.c_float), C.c_int64(nq), C.c_int(nprobe), _p(keys, C.c_int64), _p(cdis, C.c_float),
+                            C.c_int(k), C.c_int(1 if is_l2 else 0), C.c_int(cap), _p(bitset, C.c_uint8), C.c_int64(nbits),
+                            C.c_int(use_hist), _p(D, C.c_float), _p(I, C.c_int64), _p(cnt, C.c_int32), _p(ovf, C.c_int32),
+                            _p(tau, C.c_float), _p(nunits, C.c_int64))
+    assert rc == 0, f"emulated pipeline failed at stage {rc}"
+    return D, I, cnt, ovf, tau, int(nunits[0])
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("metric", [ob.L2, ob.IP], ids=["l2", "ip"])
+def test_emulated_kernels_return_the_oracles_bits(emu, port, metric):
+    nb, d, nlist, nq, k, nprobe = 2600, 128, 5, 11, 10, 3  # 11 queries: units of 8 and ragged ones, two "CUs"
+    xb, xq = gen_data(nb, d, 42), gen_data(nq, d, 44)
+    ix = ob.make_index(port, ob.IVF_PQ, metric, xb, nlist=nlist, M=32)
+    Do, Io = port.search(ix, xq, k, nprobe)
+    D, I, cnt, ovf, tau, nunits = run_emulated(emu, port, ix, xq, k, nprobe)
+    assert nunits >= nlist - 1
+    assert not ovf.any(), (ovf, cnt)
+    assert np.array_equal(I, Io), (I, Io)
+    assert np.array_equal(D.view(np.uint32), Do.view(np.uint32))
+    scanned = sum(len(c) for c in ix.list_codes) * nprobe / nlist
+    assert 0 < cnt.max() < 0.6 * scanned, (cnt, scanned)
+
+
+@pytest.mark.timeout(1500)
+def test_emulated_bitset_and_overflow_flags(emu, port):
+    nb, d, nlist, nq, k, nprobe = 2000, 128, 4, 6, 5, 2
+    xb, xq = gen_data(nb, d, 52), gen_data(nq, d, 54)
+    ix = ob.make_index(port, ob.IVF_PQ, ob.L2, xb, nlist=nlist, M=32)
+    filt = np.random.default_rng(3).random(nb) < 0.4
+    bs = np.packbits(filt, bitorder="little")
+    Do, Io = port.search(ix, xq, k, nprobe, bs, nb)
+    D, I, cnt, ovf, tau, _ = run_emulated(emu, port, ix, xq, k, nprobe, bitset=bs, use_hist=0)
+    assert not ovf.any()
+    assert np.array_equal(I, Io) and np.array_equal(D.view(np.uint32), Do.view(np.uint32))
+    # a capacity of 8 candidates: a query that gathers more is flagged 1 by the filter kernel; the finish kernel's first
+    # pass then prepares its RETRY (flag 2, candidate list emptied, bound = exact k-th of the 8 gathered rows -- the
+    # retry and exact rounds themselves belong to the product's orchestration, not to this harness); the queries that
+    # stayed within the capacity still equal the oracle
+    D2, I2, cnt2, ovf2, _, _ = run_emulated(emu, port, ix, xq, k, nprobe, cap=8, bitset=bs, use_hist=0)
+    assert (ovf2 == 2).sum() >= 1 and set(ovf2.tolist()) <= {0, 2}, ovf2
+    assert (cnt2[ovf2 == 2] == 0).all()
+    ok = ovf2 == 0
+    assert np.array_equal(I2[ok], Io[ok])
