@@ -55,7 +55,7 @@ extern "C" int emu_pqf_search(int64_t nlist, const int64_t* list_len, const int6
                               const int64_t* ids, const float* precomp /* [nlist][32][256] or null */,
                               const float* cb /* [32][256][4] */, const float* centroids, const float* xq, int64_t nq,
                               int nprobe, const int64_t* keys, const float* cdis, int k, int is_l2, int cap,
-                              const uint8_t* bitset, int64_t nbits, int use_hist, float* out_d, int64_t* out_i,
+                              const uint8_t* bitset, int64_t nbits, int use_hist, int do_retry, float* out_d, int64_t* out_i,
                               int32_t* cand_cnt_out, int32_t* overflow_out, float* tau_out, int64_t* nunits_out) {
     const int d = 128, M = 32;
     const bool l2 = is_l2 != 0;
@@ -185,9 +185,55 @@ extern "C" int emu_pqf_search(int64_t nlist, const int64_t* list_len, const int6
     // ---- phase 3: exact finish of the candidates ---------------------------------------------------------------------------
     unsigned long long counters[4] = {0, 0, 0, 0};
     if (launch_mscan_finish(m, 2, l2, keys, cdis, nprobe, k, out_d, out_i, counters, 1, nullptr) != hipSuccess) return 8;
+    // ---- phase 4: the retry round of the queries whose list overflowed (flag 2 after pass 1): one-pair units of all
+    // their probes, no histogram (the rows were counted once already), second pass of the finish kernel ---------------
+    if (do_retry) {
+        const int32_t* flag = cand_cnt.data() + nq;
+        pairs.clear();
+        units.clear();
+        for (int64_t q = 0; q < nq; q++) {
+            if (flag[q] != 2) {
+                continue;
+            }
+            for (int s = 0; s < nprobe; s++) {
+                const int64_t l = keys[q * nprobe + s];
+                if (l < 0 || l >= nlist || list_len[l] == 0) {
+                    continue;
+                }
+                KnItem it;
+                it.list = (int32_t)l;
+                it.npair = 1;
+                it.pair0 = (int64_t)pairs.size();
+                units.push_back(it);
+                pairs.push_back(KnPair{(int32_t)q, (int32_t)s});
+            }
+        }
+        nunits = (int64_t)units.size();
+        MScanArgs r = m;
+        r.units = units.data();
+        r.pairs = pairs.data();
+        r.unit_loop = 1;
+        r.ghist = nullptr;
+        r.gmeta = nullptr;
+        if (nunits > 0 && launch_pqf(r, l2, nunits, nullptr) != hipSuccess) return 9;
+        if (launch_mscan_finish(m, 2, l2, keys, cdis, nprobe, k, out_d, out_i, counters, 2, nullptr) != hipSuccess) return 10;
+    }
     for (int64_t q = 0; q < nq; q++) {
         cand_cnt_out[q] = cand_cnt[(size_t)q];
         overflow_out[q] = cand_cnt[(size_t)nq + q];
     }
     return 0;
+}
+
+// row selection (topk.hip) as emulated kernel source: the k best of each row, canonical order
+extern "C" int emu_row_select(const float* vals, int64_t nrows, int64_t n, int k, int is_l2, int64_t* out_keys, float* out_d) {
+    return launch_row_select(vals, nrows, n, k, is_l2 != 0, out_keys, out_d, nullptr, nullptr) == hipSuccess ? 0 : 1;
+}
+
+extern "C" int emu_merge_partials(const float* pd, const int64_t* pi, int64_t nq, int nslot, int k, int is_l2, float* out_d,
+                                  int64_t* out_i) {
+    return launch_merge_partials(pd, pi, nq, nslot, k, (int64_t)nslot * k, k, is_l2 != 0, out_d, out_i, nullptr, nullptr) ==
+                           hipSuccess
+                   ? 0
+                   : 1;
 }

@@ -152,7 +152,17 @@ inline T __shfl_xor(T v, int m, int = 64) { return hipemu::from_bits<T>(hipemu::
 inline unsigned long long __ballot(bool p) { return hipemu::ballot(p); }
 #define __builtin_amdgcn_readlane(v, l) ((int)hipemu::xchg((uint64_t)(uint32_t)(v), (l)))
 #define __builtin_amdgcn_readfirstlane(v) ((int)hipemu::xchg((uint64_t)(uint32_t)(v), 0))
-#define __builtin_amdgcn_update_dpp(...) (std::abort(), 0)
+// DPP: only wave_shr:1 (control 0x138, no bound control) is used by the kernels: lane i takes lane i - 1's value,
+// lane 0 keeps `old`
+inline int hipemu_update_dpp(int old, int src, int ctrl, int, int, bool) {
+    if (ctrl != 0x138) {
+        std::abort();
+    }
+    const int l = hipemu::tl.lane;
+    const int v = (int)hipemu::xchg((uint64_t)(uint32_t)src, l > 0 ? l - 1 : 0);
+    return l > 0 ? v : old;
+}
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) hipemu_update_dpp((old), (src), (ctrl), (rm), (bm), (bc))
 inline uint32_t hipemu_perm(uint32_t s0, uint32_t s1, uint32_t sel) { // v_perm_b32: bytes 0..3 = S1, 4..7 = S0
     const uint64_t src = ((uint64_t)s0 << 32) | s1;
     uint32_t out = 0;

@@ -38,7 +38,7 @@ def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
 
 
-def run_emulated(lib, port, ix, xq, k, nprobe, cap=4096, bitset=None, use_hist=1):
+def run_emulated(lib, port, ix, xq, k, nprobe, cap=4096, bitset=None, use_hist=1, retry=0):
     is_l2 = ix.metric == ob.L2
     nq = xq.shape[0]
     cdis, keys = port.coarse_search(ix, xq, nprobe)
@@ -63,7 +63,7 @@ def run_emulated(lib, port, ix, xq, k, nprobe, cap=4096, bitset=None, use_hist=1
                             _p(ids, C.c_int64), _p(pre, C.c_float), _p(cb, C.c_float), _p(cen, C.c_float),
                             _p(xq, C.c_float), C.c_int64(nq), C.c_int(nprobe), _p(keys, C.c_int64), _p(cdis, C.c_float),
                             C.c_int(k), C.c_int(1 if is_l2 else 0), C.c_int(cap), _p(bitset, C.c_uint8), C.c_int64(nbits),
-                            C.c_int(use_hist), _p(D, C.c_float), _p(I, C.c_int64), _p(cnt, C.c_int32), _p(ovf, C.c_int32),
+                            C.c_int(use_hist), C.c_int(retry), _p(D, C.c_float), _p(I, C.c_int64), _p(cnt, C.c_int32), _p(ovf, C.c_int32),
                             _p(tau, C.c_float), _p(nunits, C.c_int64))
     assert rc == 0, f"emulated pipeline failed at stage {rc}"
     return D, I, cnt, ovf, tau, int(nunits[0])
@@ -105,3 +105,52 @@ def test_emulated_bitset_and_overflow_flags(emu, port):
     assert (cnt2[ovf2 == 2] == 0).all()
     ok = ovf2 == 0
     assert np.array_equal(I2[ok], Io[ok])
+    # ... and with the retry round (one-query units under the tightened bound, second finish pass): a capacity of 64
+    # overflows in the first round and fits in the second -- every query ends with the oracle's result
+    D3, I3, cnt3, ovf3, _, _ = run_emulated(emu, port, ix, xq, k, nprobe, cap=64, bitset=bs, use_hist=0, retry=1)
+    assert not ovf3.any(), (ovf3, cnt3)
+    assert np.array_equal(I3, Io) and np.array_equal(D3.view(np.uint32), Do.view(np.uint32))
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("metric", [ob.L2, ob.IP], ids=["l2", "ip"])
+def test_emulated_ragged_lists_and_k(emu, port, metric):
+    """an empty list, a list shorter than one group of 64, one of exactly 128 rows, ids that are not row numbers;
+    k = 1 and k above a wave; every list probed"""
+    nb, d, nlist, nq = 1500, 128, 6, 9
+    xb, xq = gen_data(nb, d, 62), gen_data(nq, d, 64)
+    ids = np.random.default_rng(5).permutation(nb).astype(np.int64) * 3 + 1
+    ix = ob.make_index(port, ob.IVF_PQ, metric, xb, nlist=nlist, M=32, ids=ids)
+    ix.list_codes[1], ix.list_ids[1] = ix.list_codes[1][:0], ix.list_ids[1][:0]
+    ix.list_codes[2], ix.list_ids[2] = ix.list_codes[2][:17], ix.list_ids[2][:17]
+    ix.list_codes[3], ix.list_ids[3] = ix.list_codes[3][:128], ix.list_ids[3][:128]
+    for k, nprobe in ((1, 2), (70, nlist), (10, 4)):
+        Do, Io = port.search(ix, xq, k, nprobe)
+        D, I, cnt, ovf, tau, _ = run_emulated(emu, port, ix, xq, k, nprobe)
+        ok = ovf == 0
+        assert ok.all(), (k, nprobe, ovf, cnt)
+        assert np.array_equal(I, Io), (k, nprobe)
+        assert np.array_equal(D.view(np.uint32), Do.view(np.uint32)), (k, nprobe)
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("is_l2", [True, False], ids=["l2", "ip"])
+def test_emulated_row_select_above_4096_keys(emu, is_l2):
+    """topk.hip::row_select_kernel with k up to 16384 (the sort of the selected keys fills 128 KB of LDS): the shapes
+    behind nprobe > 4096 and range search on more than 4096 lists.  Canonical order with ties on the value."""
+    emu.emu_row_select.restype = C.c_int
+    rng = np.random.default_rng(9)
+    for n, k in ((6000, 5000), (16384, 16384), (20000, 4097), (300, 10)):
+        vals = rng.standard_normal((2, n)).astype(np.float32)
+        vals[0, ::7] = vals[0, 3]  # ties on the value: broken by the column index
+        keys = np.zeros((2, k), np.int64)
+        dist = np.zeros((2, k), np.float32)
+        rc = emu.emu_row_select(_p(vals, C.c_float), C.c_int64(2), C.c_int64(n), C.c_int(k), C.c_int(1 if is_l2 else 0),
+                                _p(keys, C.c_int64), _p(dist, C.c_float))
+        assert rc == 0
+        for r in range(2):
+            idx = np.arange(n)
+            order = np.lexsort((idx, vals[r])) if is_l2 else np.lexsort((-idx, -vals[r]))
+            kk = min(k, n)
+            assert np.array_equal(keys[r, :kk], order[:kk]), (n, k, r)
+            assert np.array_equal(dist[r, :kk].view(np.uint32), vals[r][order[:kk]].view(np.uint32))
