@@ -178,7 +178,7 @@ int knhip_index_uses_precomputed_table(const knhip_index* idx);
  * Host pointers.  lims[nq + 1] receives the per-query offsets; *out_ids / *out_dist receive malloc'ed arrays
  * of lims[nq] entries (release with knhip_free) in the reference's emission order: list by list in coarse
  * order, storage order inside a list.  Distances are bit-equal to the scalar reference.
- * Supported: KNHIP_BRUTE_FORCE, KNHIP_IVF_FLAT, KNHIP_IVF_SQ8, KNHIP_IVF_PQ with m = 32; nlist <= 16384.
+ * Supported: KNHIP_BRUTE_FORCE, KNHIP_IVF_FLAT, KNHIP_IVF_SQ8, KNHIP_IVF_PQ with m = 32; nlist <= 65536.
  * Others return KNHIP_ERR_NOT_IMPLEMENTED. */
 int knhip_range_search(const knhip_index* idx, const float* queries, int64_t nq, float radius,
                        int32_t max_empty_result_buckets, const uint8_t* bitset, int64_t bitset_nbits, int64_t* lims,

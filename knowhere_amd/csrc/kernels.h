@@ -377,8 +377,12 @@ hipError_t launch_merge_partials(const float* partial_d, const int64_t* partial_
                                  int nslot, int k, int64_t q_stride, int64_t slot_stride, bool is_l2,
                                  float* out_d, int64_t* out_i, hipStream_t s, const int32_t* q_only = nullptr);
 // per row: the k best of n values (index = column), canonical order; out_keys int64, out_d float
+// k above row_select_lds_max_k() (up to row_select_max_k()): the selected keys are sorted in `sort_scratch`
+// ([nrows][next power of two >= k] u64, caller's memory) instead of the LDS
 hipError_t launch_row_select(const float* vals, int64_t nrows, int64_t n, int k, bool is_l2,
-                             int64_t* out_keys, float* out_d, const int32_t* row_flags, hipStream_t s);
+                             int64_t* out_keys, float* out_d, const int32_t* row_flags, hipStream_t s,
+                             unsigned long long* sort_scratch = nullptr);
+size_t row_select_lds_max_k();
 // rows of different length: row r has n = list_len[keys[r * key_stride]] values at vals + r * stride
 hipError_t launch_row_select_var(const float* vals, int64_t stride, const int64_t* keys, int key_stride,
                                  const int64_t* list_len, int64_t nrows, int k, bool is_l2, int64_t* out_keys,

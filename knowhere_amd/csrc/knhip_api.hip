@@ -130,6 +130,7 @@ struct Workspace {
     DevBuf ms_qh, ms_ql, ms_qs;                                      // SQ8 IP: prepared query operands (halves) + sums
                                                                      // (IVF-PQ prefilter: ms_qh = half tables, ms_qs = scales)
     DevBuf pq_recs, pq_ctr;                                          // pq_filter.hip: unit records, per-XCD counters
+    DevBuf rs_sort;                                                  // row selection of more than 16384 keys: sort scratch
     // host-boundary staging
     DevBuf h_queries, h_bitset, h_out_d, h_out_i, h_ref_d, h_ref_i;
     std::mutex mu;  // held while a *_device entry point enqueues on this (per-stream) workspace
@@ -308,7 +309,17 @@ int coarse_stage(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
     // (the MFMA prefilter + exact re-rank is validated for up to 4096 candidates per query; above, the exact kernel)
     if (!idx->coarse_gemm || ncand >= nlist || ncand > 4096) {
         HIP_TRY(launch_flat_full(c, is_l2, ws->coarse_full.as<float>(), nullptr, 0, nullptr, s));
-        HIP_TRY(launch_row_select(ws->coarse_full.as<float>(), nq, nlist, nprobe, is_l2, keys, cdis, nullptr, s));
+        unsigned long long* sort_scratch = nullptr;
+        if ((size_t)nprobe > row_select_lds_max_k()) { // (more keys than the LDS sorts: a scratch row per query)
+            int64_t kp = 2;
+            while (kp < nprobe) {
+                kp <<= 1;
+            }
+            HIP_TRY(ws->rs_sort.reserve((size_t)nq * kp * sizeof(unsigned long long)));
+            sort_scratch = ws->rs_sort.as<unsigned long long>();
+        }
+        HIP_TRY(launch_row_select(ws->coarse_full.as<float>(), nq, nlist, nprobe, is_l2, keys, cdis, nullptr, s,
+                                  sort_scratch));
         return KNHIP_OK;
     }
     HIP_TRY(ws->qnorm.reserve((size_t)nq * sizeof(float)));
@@ -1167,7 +1178,7 @@ int validate_search(const knhip_index* idx, int64_t nq, int32_t k, int32_t& npro
         nprobe = (int32_t)idx->nlist; // IndexIVF.cpp:321-322
     }
     if ((size_t)nprobe > row_select_max_k()) {
-        return fail(KNHIP_ERR_NOT_IMPLEMENTED, "nprobe > 16384 is not supported yet");
+        return fail(KNHIP_ERR_NOT_IMPLEMENTED, "nprobe > 65536 is not supported");
     }
     return KNHIP_OK;
 }
@@ -1182,6 +1193,9 @@ int64_t query_batch(const knhip_index* idx, int64_t nq, int k, int nprobe) {
         per_q = (double)nchunks * k * 12.0;
     } else {
         per_q = (double)idx->nlist * 4.0 + (double)nprobe * (12.0 + 8.0 + (double)k * 12.0);
+        if ((size_t)nprobe > row_select_lds_max_k()) {
+            per_q += 16.0 * nprobe; // sort scratch of the row selection (next power of two of nprobe, 8 bytes each)
+        }
         if ((idx->desc.kind == KNHIP_IVF_FLAT || idx->desc.kind == KNHIP_IVF_SQ8) && idx->mscan != 0) {
             per_q += 4.0 * mscan_sample_rows() + 8.0 * 32768.0; // sample dump + candidate list (mfma_scan.hip)
         }
@@ -1873,7 +1887,7 @@ int knhip_range_search(const knhip_index* idx, const float* queries, int64_t nq,
         return fail(KNHIP_ERR_NOT_IMPLEMENTED, "range search on IVF_PQ needs m = 32 (stream16 layout)");
     }
     if (kind != KNHIP_BRUTE_FORCE && (size_t)idx->nlist > row_select_max_k()) {
-        return fail(KNHIP_ERR_NOT_IMPLEMENTED, "range search probes every list: nlist > 16384 is not supported yet");
+        return fail(KNHIP_ERR_NOT_IMPLEMENTED, "range search probes every list: nlist > 65536 is not supported");
     }
     DeviceGuard g(idx->desc.device);
     hipStream_t s = nullptr;

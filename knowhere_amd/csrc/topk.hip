@@ -129,10 +129,12 @@ hipError_t launch_merge_partials(const float* partial_d, const int64_t* partial_
 
 // ---------------------------------------------------------------------------------------------
 // row_select: one 256-thread workgroup per row; radix select (4 x 8-bit digits, LDS histogram)
-// for the k-th key, gather, bitonic sort of the survivors in LDS.
+// for the k-th key, gather, bitonic sort of the survivors in LDS (GSORT: in a global scratch row, for
+// k above what the LDS holds -- nprobe / range search on indexes with up to 65536 lists).
 // ---------------------------------------------------------------------------------------------
 constexpr int RS_THREADS = 256;
-constexpr int RS_MAX_K = 16384; // the selected keys are sorted in LDS: 8 bytes each, 128 KB of the CU's 160
+constexpr int RS_LDS_MAX_K = 16384; // the selected keys are sorted in LDS: 8 bytes each, 128 KB of the CU's 160
+constexpr int RS_MAX_K = 65536;     // above RS_LDS_MAX_K the sort runs in global memory (slow path, rare shapes)
 
 // order-preserving map float -> uint32 such that "better" == smaller key
 template <bool IS_L2>
@@ -148,7 +150,7 @@ __device__ __forceinline__ float rs_unkey(uint32_t key) {
     return __uint_as_float(b);
 }
 
-template <bool IS_L2>
+template <bool IS_L2, bool GSORT = false>
 __global__ __launch_bounds__(RS_THREADS) void row_select_kernel(const float* __restrict__ vals,
                                                                 int64_t n_fixed, int k, int kp,
                                                                 int64_t* __restrict__ out_keys,
@@ -158,7 +160,8 @@ __global__ __launch_bounds__(RS_THREADS) void row_select_kernel(const float* __r
                                                                 const int64_t* __restrict__ var_keys,
                                                                 int key_stride,
                                                                 const int64_t* __restrict__ var_len,
-                                                                int64_t n_cap, const int32_t* __restrict__ n_row) {
+                                                                int64_t n_cap, const int32_t* __restrict__ n_row,
+                                                                unsigned long long* __restrict__ sort_scratch) {
     extern __shared__ __align__(16) unsigned char smem[];
     int64_t n = n_fixed;
     if (row_flags != nullptr && row_flags[blockIdx.x] == 0) {
@@ -174,7 +177,8 @@ __global__ __launch_bounds__(RS_THREADS) void row_select_kernel(const float* __r
     if (n_row != nullptr) {
         n = n_row[blockIdx.x]; // row lengths given directly
     }
-    unsigned long long* cand = reinterpret_cast<unsigned long long*>(smem); // [kp]
+    unsigned long long* cand = GSORT ? sort_scratch + (int64_t)blockIdx.x * kp
+                                     : reinterpret_cast<unsigned long long*>(smem); // [kp]
     __shared__ uint32_t hist[256];
     __shared__ uint32_t s_prefix, s_need, s_count, s_wave_tot[RS_THREADS / KN_WAVE], s_taken;
     const int tid = threadIdx.x;
@@ -347,6 +351,10 @@ size_t row_select_max_k() {
     return RS_MAX_K;
 }
 
+size_t row_select_lds_max_k() {
+    return RS_LDS_MAX_K;
+}
+
 // more than 48 KB of dynamic LDS (k > 4096) has to be allowed per kernel
 static hipError_t rs_allow_smem(size_t sm, bool is_l2) {
     if (sm <= 48 * 1024) {
@@ -358,7 +366,8 @@ static hipError_t rs_allow_smem(size_t sm, bool is_l2) {
 }
 
 hipError_t launch_row_select(const float* vals, int64_t nrows, int64_t n, int k, bool is_l2,
-                             int64_t* out_keys, float* out_d, const int32_t* row_flags, hipStream_t s) {
+                             int64_t* out_keys, float* out_d, const int32_t* row_flags, hipStream_t s,
+                             unsigned long long* sort_scratch) {
     if (nrows <= 0 || k <= 0) {
         return hipSuccess;
     }
@@ -369,16 +378,31 @@ hipError_t launch_row_select(const float* vals, int64_t nrows, int64_t n, int k,
     while (kp < k) {
         kp <<= 1;
     }
+    if (k > RS_LDS_MAX_K) { // the selected keys do not fit the LDS: sorted in the caller's scratch ([nrows][kp] u64)
+        if (sort_scratch == nullptr) {
+            return hipErrorInvalidValue;
+        }
+        if (is_l2) {
+            hipLaunchKernelGGL((row_select_kernel<true, true>), dim3((unsigned)nrows), dim3(RS_THREADS), 0, s, vals, n, k, kp,
+                               out_keys, out_d, row_flags, (int64_t)0, nullptr, 0, nullptr, (int64_t)0, nullptr, sort_scratch);
+        } else {
+            hipLaunchKernelGGL((row_select_kernel<false, true>), dim3((unsigned)nrows), dim3(RS_THREADS), 0, s, vals, n, k, kp,
+                               out_keys, out_d, row_flags, (int64_t)0, nullptr, 0, nullptr, (int64_t)0, nullptr, sort_scratch);
+        }
+        return hipGetLastError();
+    }
     const size_t sm = (size_t)kp * 8;
     if (hipError_t e = rs_allow_smem(sm, is_l2); e != hipSuccess) {
         return e;
     }
     if (is_l2) {
         hipLaunchKernelGGL((row_select_kernel<true>), dim3((unsigned)nrows), dim3(RS_THREADS), sm, s,
-                           vals, n, k, kp, out_keys, out_d, row_flags, (int64_t)0, nullptr, 0, nullptr, (int64_t)0, nullptr);
+                           vals, n, k, kp, out_keys, out_d, row_flags, (int64_t)0, nullptr, 0, nullptr, (int64_t)0, nullptr,
+                           nullptr);
     } else {
         hipLaunchKernelGGL((row_select_kernel<false>), dim3((unsigned)nrows), dim3(RS_THREADS), sm, s,
-                           vals, n, k, kp, out_keys, out_d, row_flags, (int64_t)0, nullptr, 0, nullptr, (int64_t)0, nullptr);
+                           vals, n, k, kp, out_keys, out_d, row_flags, (int64_t)0, nullptr, 0, nullptr, (int64_t)0, nullptr,
+                           nullptr);
     }
     return hipGetLastError();
 }
@@ -389,7 +413,7 @@ hipError_t launch_row_select_var(const float* vals, int64_t stride, const int64_
     if (nrows <= 0 || k <= 0) {
         return hipSuccess;
     }
-    if (k > RS_MAX_K) {
+    if (k > RS_LDS_MAX_K) {
         return hipErrorInvalidValue;
     }
     int kp = 2;
@@ -402,10 +426,12 @@ hipError_t launch_row_select_var(const float* vals, int64_t stride, const int64_
     }
     if (is_l2) {
         hipLaunchKernelGGL((row_select_kernel<true>), dim3((unsigned)nrows), dim3(RS_THREADS), sm, s, vals,
-                           (int64_t)0, k, kp, out_keys, out_d, nullptr, stride, keys, key_stride, list_len, n_cap, n_row);
+                           (int64_t)0, k, kp, out_keys, out_d, nullptr, stride, keys, key_stride, list_len, n_cap, n_row,
+                           nullptr);
     } else {
         hipLaunchKernelGGL((row_select_kernel<false>), dim3((unsigned)nrows), dim3(RS_THREADS), sm, s, vals,
-                           (int64_t)0, k, kp, out_keys, out_d, nullptr, stride, keys, key_stride, list_len, n_cap, n_row);
+                           (int64_t)0, k, kp, out_keys, out_d, nullptr, stride, keys, key_stride, list_len, n_cap, n_row,
+                           nullptr);
     }
     return hipGetLastError();
 }

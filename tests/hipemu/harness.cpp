@@ -227,7 +227,12 @@ extern "C" int emu_pqf_search(int64_t nlist, const int64_t* list_len, const int6
 
 // row selection (topk.hip) as emulated kernel source: the k best of each row, canonical order
 extern "C" int emu_row_select(const float* vals, int64_t nrows, int64_t n, int k, int is_l2, int64_t* out_keys, float* out_d) {
-    return launch_row_select(vals, nrows, n, k, is_l2 != 0, out_keys, out_d, nullptr, nullptr) == hipSuccess ? 0 : 1;
+    int64_t kp = 2;
+    while (kp < k) {
+        kp <<= 1;
+    }
+    std::vector<unsigned long long> scratch((size_t)k > row_select_lds_max_k() ? (size_t)nrows * kp : 1);
+    return launch_row_select(vals, nrows, n, k, is_l2 != 0, out_keys, out_d, nullptr, nullptr, scratch.data()) == hipSuccess ? 0 : 1;
 }
 
 extern "C" int emu_merge_partials(const float* pd, const int64_t* pi, int64_t nq, int nslot, int k, int is_l2, float* out_d,

@@ -1,5 +1,6 @@
-"""GPU parity tests (-m gpu) of the shapes opened by the larger row selection (topk.hip RS_MAX_K 4096 -> 16384):
-nprobe above 4096 and range search on indexes with more than 4096 lists, against the oracle, bit for bit.
+"""GPU parity tests (-m gpu) of the shapes opened by the larger row selection (topk.hip: up to 16384 keys sorted in LDS,
+up to 65536 in a global scratch row; was 4096): nprobe above 4096 and range search on indexes with more than 4096
+lists, against the oracle, bit for bit.
 
 The change was made at the end of round 2 after the round's GPU minutes were spent (the selection kernel itself is
 unchanged; only its LDS allowance and the limits moved), so these tests are skipped unless KNHIP_TEST_UNVALIDATED=1.
@@ -50,4 +51,23 @@ def test_range_search_above_4096_lists(port, metric):
             assert np.array_equal(exp[0], got[0]), "lims differ"
             assert np.array_equal(exp[1], got[1]), "ids differ (or are in a different order)"
             assert np.array_equal(exp[2].view(np.uint32), got[2].view(np.uint32)), "distances differ bitwise"
+    g.close()
+
+
+def test_nprobe_and_range_above_16384_lists(port):
+    """more keys than the LDS sorts: the global-scratch sort of the row selection"""
+    nb, d, nlist = 40000, 8, 20000
+    xb, xq = gen_data(nb, d, 42), gen_data(6, d, 44)
+    ix = ob.make_index(port, ob.IVF_FLAT, ob.L2, xb, nlist=nlist)
+    g = _gpu(ix)
+    for k, nprobe in ((10, 17000), (5, nlist)):
+        Do, Io = port.search(ix, xq, k, nprobe)
+        D, I = g.search(xq, k, nprobe)
+        assert_parity(Do, Io, D, I, ob.L2, f"k={k} nprobe={nprobe}")
+    D, _ = port.search(ix, xq, 40, nlist)
+    radius = float(np.median(D[:, 20]))
+    exp = port.range_search(ix, xq, radius, 2)
+    got = g.range_search(xq, np.float32(radius), 2)
+    assert np.array_equal(exp[0], got[0]) and np.array_equal(exp[1], got[1])
+    assert np.array_equal(exp[2].view(np.uint32), got[2].view(np.uint32))
     g.close()

@@ -136,11 +136,12 @@ def test_emulated_ragged_lists_and_k(emu, port, metric):
 @pytest.mark.timeout(1500)
 @pytest.mark.parametrize("is_l2", [True, False], ids=["l2", "ip"])
 def test_emulated_row_select_above_4096_keys(emu, is_l2):
-    """topk.hip::row_select_kernel with k up to 16384 (the sort of the selected keys fills 128 KB of LDS): the shapes
-    behind nprobe > 4096 and range search on more than 4096 lists.  Canonical order with ties on the value."""
+    """topk.hip::row_select_kernel with k up to 16384 (the sort of the selected keys fills 128 KB of LDS) and, sorted in
+    a global scratch row, up to 65536: the shapes behind nprobe > 4096 and range search on more than 4096 lists.
+    Canonical order with ties on the value."""
     emu.emu_row_select.restype = C.c_int
     rng = np.random.default_rng(9)
-    for n, k in ((6000, 5000), (16384, 16384), (20000, 4097), (300, 10)):
+    for n, k in ((6000, 5000), (16384, 16384), (20000, 4097), (300, 10), (40000, 16385), (65536, 65536)):
         vals = rng.standard_normal((2, n)).astype(np.float32)
         vals[0, ::7] = vals[0, 3]  # ties on the value: broken by the column index
         keys = np.zeros((2, k), np.int64)
