@@ -364,6 +364,27 @@ struct RangeArgs {
     const uint8_t* bitset;
     int64_t bitset_nbits;
 };
+// every exact ADC distance of every probed list of an IVF-PQ index with any M x 8 bit codes (range.hip)
+struct PqDumpArgs {
+    float* dist;                 // [nq][ncol], column = list_row_off[list] + position
+    int64_t ncol;
+    const int64_t* keys;         // [nq][nprobe] probed lists (coarse order)
+    const float* coarse_dis;     // [nq][nprobe]
+    int32_t nprobe;
+    int64_t nlist;
+    const int64_t* list_len;
+    const int64_t* list_row_off;
+    const uint8_t* codes;        // canonical AoS codes [ntotal][M]
+    int32_t M;
+    int32_t d;
+    int32_t lut_mode;            // PqLutMode
+    const float* t2t;            // [nq][256][M] <q_m, cb>      (PRECOMP, IP)
+    const float* precomp_t;      // [nlist][256][M]             (PRECOMP)
+    const float* cb;             // [M][256][dsub]              (RESIDUAL)
+    const float* centroids;      // [nlist][d]                  (RESIDUAL)
+    const float* queries;        // [nq][d]                     (RESIDUAL)
+};
+hipError_t launch_pq_adc_dump(const PqDumpArgs& a, int64_t nq, bool is_l2, hipStream_t s);
 hipError_t launch_range_count(const RangeArgs& a, int64_t nq, bool is_l2, int32_t* cnt, hipStream_t s);
 hipError_t launch_range_plan(const int32_t* cnt, int64_t nq, int nprobe, int max_empty, int64_t* off, int64_t* total,
                              hipStream_t s);

@@ -1720,7 +1720,34 @@ static int range_batch(const knhip_index* idx, Workspace* ws, const float* d_q, 
         r.ids = idx->ids.as<int64_t>();
         r.order = ws->keys.as<int64_t>();
     }
-    if (kind == KNHIP_IVF_PQ) {
+    if (kind == KNHIP_IVF_PQ && !(idx->pq_v2 && idx->desc.pq_m == 32)) {
+        // code widths without a dump mode in the fast ADC kernels: the plain exact ADC kernel of range.hip
+        const int M = idx->desc.pq_m;
+        const int mode = !is_l2 ? PQ_LUT_IP : (idx->use_precomp ? PQ_LUT_PRECOMP : PQ_LUT_RESIDUAL);
+        if (mode != PQ_LUT_RESIDUAL) {
+            HIP_TRY(ws->t2t.reserve((size_t)nq * 256 * M * sizeof(float)));
+            HIP_TRY(launch_pq_query_table(d_q, idx->cb.as<float>(), d, M, nq, ws->t2t.as<float>(), s));
+        }
+        PqDumpArgs a{};
+        a.dist = ws->dump.as<float>();
+        a.ncol = ncol;
+        a.keys = ws->keys.as<int64_t>();
+        a.coarse_dis = ws->cdis.as<float>();
+        a.nprobe = nprobe;
+        a.nlist = idx->nlist;
+        a.list_len = idx->d_list_len.as<int64_t>();
+        a.list_row_off = idx->d_list_row_off.as<int64_t>();
+        a.codes = idx->codes_aos.as<uint8_t>();
+        a.M = M;
+        a.d = d;
+        a.lut_mode = mode;
+        a.t2t = ws->t2t.as<float>();
+        a.precomp_t = idx->precomp_t.as<float>();
+        a.cb = idx->cb.as<float>();
+        a.centroids = idx->centroids.as<float>();
+        a.queries = d_q;
+        HIP_TRY(launch_pq_adc_dump(a, nq, is_l2, s));
+    } else if (kind == KNHIP_IVF_PQ) {
         const int M = idx->desc.pq_m;
         const int mode = !is_l2 ? PQ_LUT_IP : (idx->use_precomp ? PQ_LUT_PRECOMP : PQ_LUT_RESIDUAL);
         if (mode != PQ_LUT_RESIDUAL) {
@@ -1884,7 +1911,12 @@ int knhip_range_search(const knhip_index* idx, const float* queries, int64_t nq,
     }
     const int kind = idx->desc.kind;
     if (kind == KNHIP_IVF_PQ && !(idx->pq_v2 && idx->desc.pq_m == 32)) {
-        return fail(KNHIP_ERR_NOT_IMPLEMENTED, "range search on IVF_PQ needs m = 32 (stream16 layout)");
+        // other code widths go through the plain ADC dump kernel of range.hip, which has not run on hardware yet
+        // (written at the end of round 2; emulated on the CPU): opt-in until it has
+        const char* e = getenv("KNHIP_UNVALIDATED");
+        if (!(e && e[0] == '1')) {
+            return fail(KNHIP_ERR_NOT_IMPLEMENTED, "range search on IVF_PQ needs m = 32 (stream16 layout)");
+        }
     }
     if (kind != KNHIP_BRUTE_FORCE && (size_t)idx->nlist > row_select_max_k()) {
         return fail(KNHIP_ERR_NOT_IMPLEMENTED, "range search probes every list: nlist > 65536 is not supported");

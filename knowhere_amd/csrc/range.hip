@@ -7,8 +7,8 @@
 // nothing is bumped or reset, and the loop stops once it reaches max_empty_result_buckets (> 0).  Results
 // of one query are emitted list by list in that order, storage order inside a list.
 //
-// The scan kernels (flat_full / pq_scan_v2 dump mode) have already written every distance of every probed
-// list to dist[q][column]; what is left is data-parallel bookkeeping:
+// The scan kernels (flat_full / pq_scan_v2 dump mode / pq_adc_dump below) have already written every distance of
+// every probed list to dist[q][column]; what is left is data-parallel bookkeeping:
 //   range_count  : hits per (query, probe rank)                      one workgroup per pair
 //   range_plan   : early-stop cut + running offsets per query       one thread per query (nprobe steps)
 //   range_emit   : ordered compaction of the surviving lists         one workgroup per pair
@@ -145,6 +145,80 @@ __global__ __launch_bounds__(RG_THREADS) void range_emit_kernel(RangeArgs a, con
         }
         __syncthreads();
     }
+}
+
+// ---- IVF-PQ, any M x 8 bit: every exact ADC distance of every probed list -> dist[q][list_row_off + position] -------
+// The fast ADC kernels (stream16 layouts, M = 32) have a dump mode of their own; this plain kernel serves the other
+// code widths.  One workgroup per (query, probe): the (query, list) table in LDS, then thread per stored vector, the
+// table entries summed from 0 in m order and the coarse term added last -- PQCodeDistanceScalar / scan_list_with_table
+// (thirdparty/faiss/faiss/impl/pq_code_distance/pq_code_distance-inl.h:69-90, IVFPQScanner_impl.h:109-181) with the
+// tables of IVFPQ_QueryTables.cpp:110-230 (same arithmetic as pq_scan_q4.hip::p4_build_lut).
+template <bool IS_L2>
+__global__ __launch_bounds__(RG_THREADS) void pq_adc_dump_kernel(PqDumpArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    float* lut = reinterpret_cast<float*>(smem); // [M][256]
+    const int64_t q = blockIdx.x / a.nprobe;
+    const int slot = (int)(blockIdx.x % a.nprobe);
+    const int64_t list = a.keys[q * a.nprobe + slot];
+    if (list < 0 || list >= a.nlist) {
+        return;
+    }
+    const int64_t len = a.list_len[list];
+    if (len <= 0) {
+        return;
+    }
+    const int M = a.M, dsub = a.d / a.M;
+    for (int e = threadIdx.x; e < M * 256; e += RG_THREADS) {
+        const int m = e >> 8, c = e & 255;
+        float t;
+        if (a.lut_mode == PQ_LUT_RESIDUAL) { // ||(q - c_list)_m - cb[m][c]||^2
+            const float* y = a.cb + ((int64_t)m * 256 + c) * dsub;
+            const float* x = a.queries + q * a.d + m * dsub;
+            const float* cl = a.centroids + list * a.d + m * dsub;
+            t = 0.f;
+            for (int i = 0; i < dsub; i++) {
+                t = l2_step(t, fsub_x(x[i], cl[i]), y[i]);
+            }
+        } else {
+            t = a.t2t[(q * 256 + c) * M + m]; // <q_m, cb[m][c]>
+            if (a.lut_mode == PQ_LUT_PRECOMP) {
+                t = fadd_x(a.precomp_t[(list * 256 + c) * M + m], fmul_x(-2.0f, t));
+            }
+        }
+        lut[e] = t;
+    }
+    __syncthreads();
+    const float dis0 = a.lut_mode == PQ_LUT_RESIDUAL ? 0.f : a.coarse_dis[q * a.nprobe + slot];
+    const int64_t row_off = a.list_row_off[list];
+    float* out = a.dist + q * a.ncol + row_off;
+    for (int64_t pos = threadIdx.x; pos < len; pos += RG_THREADS) {
+        const uint8_t* code = a.codes + (row_off + pos) * M;
+        float acc = 0.f;
+        for (int m = 0; m < M; m++) {
+            acc = fadd_x(acc, lut[m * 256 + code[m]]);
+        }
+        out[pos] = fadd_x(dis0, acc);
+    }
+}
+
+hipError_t launch_pq_adc_dump(const PqDumpArgs& a, int64_t nq, bool is_l2, hipStream_t s) {
+    if (nq <= 0 || a.nprobe <= 0) {
+        return hipSuccess;
+    }
+    if (a.M <= 0 || a.M > 64 || a.d % a.M != 0) {
+        return hipErrorInvalidValue;
+    }
+    const size_t sm = (size_t)a.M * 256 * sizeof(float);
+    auto kern = is_l2 ? pq_adc_dump_kernel<true> : pq_adc_dump_kernel<false>;
+    if (sm > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)sm);
+        if (e != hipSuccess) {
+            return e;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nq * a.nprobe)), dim3(RG_THREADS), sm, s, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_range_count(const RangeArgs& a, int64_t nq, bool is_l2, int32_t* cnt, hipStream_t s) {

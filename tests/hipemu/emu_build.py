@@ -1,6 +1,6 @@
 """tests/hipemu/emu_build.py -- build the host stand-in of selected kernel files (test infrastructure only).
 
-Copies knowhere_amd/csrc/{pq_filter,mfma_scan,topk}.hip into tests/hipemu/_build/ with the few hardware-specific lines
+Copies knowhere_amd/csrc/{pq_filter,mfma_scan,topk,range}.hip into tests/hipemu/_build/ with the few hardware-specific lines
 rewritten (LDS-offset addressing, inline ISA, dynamic LDS declarations), and compiles them with the host clang++ against
 tests/hipemu/hip/hip_runtime.h into _build/libpqf_emu.so.  Every rewrite asserts how often its pattern occurs, so a
 change of the kernel source that the emulation does not cover fails here instead of passing silently."""
@@ -54,17 +54,19 @@ def patch_dyn_smem_only(s):
 
 patch_mfma_scan = patch_dyn_smem_only
 patch_topk = patch_dyn_smem_only
+patch_range = patch_dyn_smem_only
 
 
 def build(force=False):
     os.makedirs(BUILD, exist_ok=True)
     so = os.path.join(BUILD, "libpqf_emu.so")
-    srcs = [os.path.join(CSRC, f) for f in ("pq_filter.hip", "mfma_scan.hip", "topk.hip", "common.h", "kernels.h",
+    srcs = [os.path.join(CSRC, f) for f in ("pq_filter.hip", "mfma_scan.hip", "topk.hip", "range.hip", "common.h", "kernels.h",
                                             "ms_common.h")]
     srcs += [os.path.join(HERE, f) for f in ("emu_runtime.cpp", "harness.cpp", "emu_build.py", "hip/hip_runtime.h")]
     if not force and os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(p) for p in srcs):
         return so
-    for name, fn in (("pq_filter.hip", patch_pq_filter), ("mfma_scan.hip", patch_mfma_scan), ("topk.hip", patch_topk)):
+    for name, fn in (("pq_filter.hip", patch_pq_filter), ("mfma_scan.hip", patch_mfma_scan), ("topk.hip", patch_topk),
+                     ("range.hip", patch_range)):
         with open(os.path.join(CSRC, name)) as f:
             src = fn(f.read())
         with open(os.path.join(BUILD, name.replace(".hip", "_emu.cpp")), "w") as f:
@@ -73,7 +75,7 @@ def build(force=False):
            "-Xclang", "-ffloat16-excess-precision=none", "-Wno-unused-value", "-Wno-unknown-pragmas", "-Wno-pass-failed",
            "-I", HERE, "-I", CSRC, "-I", os.path.join(ROOT, "include"),
            os.path.join(BUILD, "pq_filter_emu.cpp"), os.path.join(BUILD, "mfma_scan_emu.cpp"),
-           os.path.join(BUILD, "topk_emu.cpp"),
+           os.path.join(BUILD, "topk_emu.cpp"), os.path.join(BUILD, "range_emu.cpp"),
            os.path.join(HERE, "emu_runtime.cpp"), os.path.join(HERE, "harness.cpp"), "-o", so]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

@@ -242,3 +242,54 @@ extern "C" int emu_merge_partials(const float* pd, const int64_t* pi, int64_t nq
                    ? 0
                    : 1;
 }
+
+// range.hip::pq_adc_dump_kernel as emulated kernel source: every exact ADC distance of every probed list.
+// t2t [nq][256][M] = <q_m, cb[m][c]> and the c-major term-2 table are prepared here on the host (in the product they
+// come from pq_query_table_kernel / pq_precomp_table_kernel, validated on hardware).
+extern "C" int emu_pq_adc_dump(int64_t nlist, const int64_t* list_len, const int64_t* list_row_off, const uint8_t* codes, int M,
+                               int d, int lut_mode, const float* precomp /* [nlist][M][256] or null */,
+                               const float* cb /* [M][256][dsub] */, const float* centroids, const float* xq, int64_t nq,
+                               int nprobe, const int64_t* keys, const float* cdis, int64_t ncol, float* dist) {
+    const int dsub = d / M;
+    std::vector<float> t2t((size_t)nq * 256 * M), precomp_t;
+    for (int64_t q = 0; q < nq; q++) {
+        for (int m = 0; m < M; m++) {
+            for (int c = 0; c < 256; c++) {
+                float t = 0.f;
+                for (int i = 0; i < dsub; i++) {
+                    t = ip_step(t, xq[q * d + m * dsub + i], cb[((size_t)m * 256 + c) * dsub + i]);
+                }
+                t2t[((size_t)q * 256 + c) * M + m] = t;
+            }
+        }
+    }
+    if (precomp != nullptr) {
+        precomp_t.resize((size_t)nlist * 256 * M);
+        for (int64_t l = 0; l < nlist; l++) {
+            for (int m = 0; m < M; m++) {
+                for (int c = 0; c < 256; c++) {
+                    precomp_t[((size_t)l * 256 + c) * M + m] = precomp[((size_t)l * M + m) * 256 + c];
+                }
+            }
+        }
+    }
+    PqDumpArgs a{};
+    a.dist = dist;
+    a.ncol = ncol;
+    a.keys = keys;
+    a.coarse_dis = cdis;
+    a.nprobe = nprobe;
+    a.nlist = nlist;
+    a.list_len = list_len;
+    a.list_row_off = list_row_off;
+    a.codes = codes;
+    a.M = M;
+    a.d = d;
+    a.lut_mode = lut_mode;
+    a.t2t = t2t.data();
+    a.precomp_t = precomp_t.empty() ? nullptr : precomp_t.data();
+    a.cb = cb;
+    a.centroids = centroids;
+    a.queries = xq;
+    return launch_pq_adc_dump(a, nq, lut_mode != PQ_LUT_IP, nullptr) == hipSuccess ? 0 : 1;
+}

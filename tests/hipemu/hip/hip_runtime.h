@@ -148,6 +148,12 @@ inline T __shfl_up(T v, unsigned d, int = 64) {
     return l >= (int)d ? o : v;
 }
 template <class T>
+inline T __shfl_down(T v, unsigned d, int = 64) {
+    const int l = hipemu::tl.lane;
+    const T o = hipemu::from_bits<T>(hipemu::xchg(hipemu::to_bits(v), l + (int)d < 64 ? l + (int)d : l));
+    return l + (int)d < 64 ? o : v;
+}
+template <class T>
 inline T __shfl_xor(T v, int m, int = 64) { return hipemu::from_bits<T>(hipemu::xchg(hipemu::to_bits(v), hipemu::tl.lane ^ m)); }
 inline unsigned long long __ballot(bool p) { return hipemu::ballot(p); }
 #define __builtin_amdgcn_readlane(v, l) ((int)hipemu::xchg((uint64_t)(uint32_t)(v), (l)))

@@ -71,3 +71,24 @@ def test_nprobe_and_range_above_16384_lists(port):
     assert np.array_equal(exp[0], got[0]) and np.array_equal(exp[1], got[1])
     assert np.array_equal(exp[2].view(np.uint32), got[2].view(np.uint32))
     g.close()
+
+
+@pytest.mark.parametrize("M", [8, 16, 64])
+@pytest.mark.parametrize("metric", [ob.L2, ob.IP], ids=["l2", "ip"])
+def test_range_search_ivfpq_other_code_widths(port, monkeypatch, M, metric):
+    """range.hip::pq_adc_dump_kernel behind KNHIP_UNVALIDATED=1: range search on IVF-PQ with m != 32"""
+    from helpers import finish_ivfpq
+    monkeypatch.setenv("KNHIP_UNVALIDATED", "1")
+    nb, d, nlist = 12000, 128, 48
+    xb, xq = gen_data(nb, d, 42), gen_data(30, d, 44)
+    ix = finish_ivfpq(port, ob.make_index(port, ob.IVF_PQ, metric, xb, nlist=nlist, M=M))
+    g = _gpu(ix)
+    D, _ = port.search(ix, xq, 40, nlist)
+    for radius in (float(np.median(D[:, 5])), float(np.median(D[:, 39]))):
+        for max_empty in (0, 2):
+            exp = port.range_search(ix, xq, radius, max_empty)
+            got = g.range_search(xq, np.float32(radius), max_empty)
+            assert np.array_equal(exp[0], got[0]), "lims differ"
+            assert np.array_equal(exp[1], got[1]), "ids differ (or are in a different order)"
+            assert np.array_equal(exp[2].view(np.uint32), got[2].view(np.uint32)), "distances differ bitwise"
+    g.close()

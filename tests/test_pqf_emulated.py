@@ -155,3 +155,52 @@ def test_emulated_row_select_above_4096_keys(emu, is_l2):
             kk = min(k, n)
             assert np.array_equal(keys[r, :kk], order[:kk]), (n, k, r)
             assert np.array_equal(dist[r, :kk].view(np.uint32), vals[r][order[:kk]].view(np.uint32))
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("M", [8, 16, 64])
+def test_emulated_pq_adc_dump_any_code_width(emu, port, M):
+    """range.hip::pq_adc_dump_kernel (range search on IVF-PQ indexes whose code width has no dump mode in the fast ADC
+    kernels): every distance it writes equals, bit for bit, what the oracle's range search reports for that row -- L2
+    with the precomputed table, L2 with residual tables, inner product"""
+    emu.emu_pq_adc_dump.restype = C.c_int
+    nb, d, nlist, nq = 900, 128, 5, 4
+    xb, xq = gen_data(nb, d, 72), gen_data(nq, d, 74)
+    for metric, residual in ((ob.L2, False), (ob.L2, True), (ob.IP, False)):
+        ix = ob.make_index(port, ob.IVF_PQ, metric, xb, nlist=nlist, M=M)
+        mode = 1 if metric == ob.IP else (2 if residual else 0)  # PqLutMode
+        pre = None
+        if metric == ob.L2 and not residual:
+            pre = np.ascontiguousarray(ix.precomputed_table, np.float32)
+        if residual:
+            ix.use_precomputed_table = 0
+            ix.precomputed_table = None
+        cdis, keys = port.coarse_search(ix, xq, nlist)
+        lens = np.array([len(c) for c in ix.list_codes], np.int64)
+        row_off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+        codes = np.ascontiguousarray(np.concatenate([c.reshape(-1, M) for c in ix.list_codes]).astype(np.uint8))
+        ids = np.concatenate(ix.list_ids)
+        cb = np.ascontiguousarray(ix.pq_centroids, np.float32)
+        cen = np.ascontiguousarray(ix.centroids, np.float32)
+        keys = np.ascontiguousarray(keys, np.int64)
+        cdis = np.ascontiguousarray(cdis, np.float32)
+        dist = np.full((nq, nb), np.nan, np.float32)
+        rc = emu.emu_pq_adc_dump(C.c_int64(nlist), _p(lens, C.c_int64), _p(row_off, C.c_int64), _p(codes, C.c_uint8),
+                                 C.c_int(M), C.c_int(d), C.c_int(mode), _p(pre, C.c_float), _p(cb, C.c_float),
+                                 _p(cen, C.c_float), _p(np.ascontiguousarray(xq), C.c_float), C.c_int64(nq), C.c_int(nlist),
+                                 _p(keys, C.c_int64), _p(cdis, C.c_float), C.c_int64(nb), _p(dist, C.c_float))
+        assert rc == 0
+        assert not np.isnan(dist).any()
+        # the oracle's range search with an all-embracing radius reports every row: lists in coarse order, storage
+        # order inside a list
+        radius = np.float32(3.0e38) if metric == ob.L2 else np.float32(-3.0e38)
+        lims, rid, rdis = port.range_search(ix, xq, radius, 0)
+        for q in range(nq):
+            exp_i, exp_d = rid[lims[q]:lims[q + 1]], rdis[lims[q]:lims[q + 1]]
+            got_i, got_d = [], []
+            for l in keys[q]:
+                got_i.append(ids[row_off[l]:row_off[l] + lens[l]])
+                got_d.append(dist[q, row_off[l]:row_off[l] + lens[l]])
+            got_i, got_d = np.concatenate(got_i), np.concatenate(got_d)
+            assert np.array_equal(got_i, exp_i), (M, metric, residual, q)
+            assert np.array_equal(got_d.view(np.uint32), exp_d.view(np.uint32)), (M, metric, residual, q)

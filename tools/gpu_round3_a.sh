@@ -8,7 +8,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 KNHIP_TEST_PQF=1 timeout 420 python -m pytest tests/test_gpu_pqf.py -x -q -m gpu > gpurun_out/r3a_pqf.log 2>&1
 rc=$?; tail -5 gpurun_out/r3a_pqf.log | cut -c1-400
-KNHIP_TEST_UNVALIDATED=1 timeout 300 python -m pytest tests/test_gpu_limits.py -x -q -m gpu > gpurun_out/r3a_limits.log 2>&1
+KNHIP_TEST_UNVALIDATED=1 timeout 420 python -m pytest tests/test_gpu_limits.py -x -q -m gpu > gpurun_out/r3a_limits.log 2>&1
 tail -3 gpurun_out/r3a_limits.log | cut -c1-400
 if [ $rc -eq 0 ]; then
   KNHIP_PQF=1 timeout 600 python bench.py > gpurun_out/r3a_bench_c3_pqf.log 2>&1; tail -1 gpurun_out/r3a_bench_c3_pqf.log | cut -c1-1400
