@@ -396,6 +396,16 @@ def make_roofline(a, kind, prof, world):
                          "peak = fp32 vector peak (an FMA counts 2)"}, **common)
 
 
+def pmc_key(a, world):
+    """key of a workload in profiles/bench_pmc_traffic.json (a PMC pass belongs to one kernel path: the half-precision
+    IVF-PQ prefilter, KNHIP_PQF=1, is a different dominant kernel than the exact ADC scan)"""
+    key = (f"config={a.config},nb={a.nb},nlist={a.nlist},nprobe={a.nprobe},nq={a.nq},m={a.m},"
+           f"refine_k={a.refine_k},gpus={world}")
+    if os.environ.get("KNHIP_PQF") == "1":
+        key += ",pqf=1"
+    return key
+
+
 def pmc_counters(a, world):
     """SQ counters of the dominant kernel from the PMC passes on file (same key as pmc_traffic), or None"""
     path = os.path.join(ROOT, "profiles", "bench_pmc_traffic.json")
@@ -403,8 +413,7 @@ def pmc_counters(a, world):
         t = json.load(open(path))
     except Exception:
         return None
-    key = (f"config={a.config},nb={a.nb},nlist={a.nlist},nprobe={a.nprobe},nq={a.nq},m={a.m},"
-           f"refine_k={a.refine_k},gpus={world}")
+    key = pmc_key(a, world)
     return t.get(key, {}).get("sq")
 
 
@@ -418,8 +427,7 @@ def pmc_traffic(a, world):
         t = json.load(open(path))
     except Exception:
         return None
-    key = (f"config={a.config},nb={a.nb},nlist={a.nlist},nprobe={a.nprobe},nq={a.nq},m={a.m},"
-           f"refine_k={a.refine_k},gpus={world}")
+    key = pmc_key(a, world)
     return t.get(key, {}).get("hbm_bytes_per_launch")
 
 
