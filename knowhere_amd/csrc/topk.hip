@@ -108,6 +108,107 @@ __global__ __launch_bounds__(256) void merge_partials_kernel(const float* __rest
     top.store(out_d + q * k, out_i + q * k);
 }
 
+// merge_partials for more than 4096 slots (nprobe above 4096): the kernel above tracks its exhausted slots in one
+// 64-bit word per lane (bit g = slot 64 g + lane), which holds 64 x 64 slots; this copy keeps the bits in LDS.  (A
+// separate kernel so that the one every search runs stays exactly as validated.)
+constexpr int MP_BIG_GROUPS = 1024; // 65536 slots
+template <bool IS_L2, int R>
+__global__ __launch_bounds__(256) void merge_partials_big_kernel(const float* __restrict__ pd,
+                                                             const int64_t* __restrict__ pi,
+                                                             int64_t nq, int nslot, int k,
+                                                             int64_t q_stride, int64_t slot_stride,
+                                                             float* __restrict__ out_d,
+                                                             int64_t* __restrict__ out_i,
+                                                             const int32_t* __restrict__ q_only) {
+    const int lane = lane_id();
+    const int64_t q = (int64_t)blockIdx.x * (blockDim.x / KN_WAVE) + threadIdx.x / KN_WAVE;
+    if (q >= nq) {
+        return;
+    }
+    if (q_only != nullptr && (q_only[nq] == 0 || q_only[q] == 0)) {
+        return; // (mfma_scan.hip fallback: only the flagged queries are merged)
+    }
+    // exhausted-slot bits of this wave, word g = the 64 lanes' bits of slots [64 g, 64 g + 64): wave-private (written
+    // by lane 0 and read by the whole wave in program order)
+    __shared__ unsigned long long s_done_all[4 * MP_BIG_GROUPS];
+    volatile unsigned long long* s_done = s_done_all + (threadIdx.x / KN_WAVE) * MP_BIG_GROUPS;
+    for (int g = lane; g < MP_BIG_GROUPS; g += KN_WAVE) {
+        s_done[g] = 0ull;
+    }
+    WaveTopK<IS_L2, R> top;
+    top.init(k);
+    float kd = worst_dist<IS_L2>();
+    int64_t ki = -1;
+    const float* qd = pd + q * q_stride;
+    const int64_t* qi = pi + q * q_stride;
+    // Slot lists are sorted best-first and SENTINEL-TERMINATED: nothing behind the first id < 0 of a slot is
+    // defined (the scan kernels stop writing there).
+    // Slot 0 (the closest list / first shard) usually supplies a large share of the result: load it straight
+    // into the wave-resident list (element e -> lane e % 64, register e / 64) so that the rank loop below can
+    // stop early.
+    int first_end = k;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int e = r * KN_WAVE + lane;
+        int64_t id0 = -1;
+        float d0 = worst_dist<IS_L2>();
+        if (e < k && e < first_end) {
+            id0 = qi[e];
+            if (id0 >= 0) {
+                d0 = qd[e];
+            }
+        }
+        const unsigned long long endm = __ballot(e < k && e < first_end && id0 < 0);
+        if (endm) {
+            first_end = min(first_end, r * KN_WAVE + __ffsll((long long)endm) - 1);
+        }
+        const bool ok = e < first_end && id0 >= 0;
+        top.d[r] = ok ? d0 : worst_dist<IS_L2>();
+        top.i[r] = ok ? id0 : -1;
+    }
+    kd = top.kth_dist();
+    ki = top.kth_idx();
+    // a slot is exhausted once its sentinel was seen or an entry could not enter (every later one of that slot is
+    // worse and the bound only tightens)
+    for (int r = 0; r < k; r++) {
+        bool any = false;
+        int g = 0;
+        for (int s0 = 0; s0 < nslot; s0 += KN_WAVE, g++) {
+            const int s = s0 + lane;
+            float cd = worst_dist<IS_L2>();
+            int64_t ci = -1;
+            const bool live = s < nslot && s > 0 && !((s_done[g] >> lane) & 1ull);
+            if (live) {
+                ci = qi[(int64_t)s * slot_stride + r];
+                if (ci >= 0) {
+                    cd = qd[(int64_t)s * slot_stride + r];
+                }
+            }
+            const bool pass = (ci >= 0) && top.admits(cd, ci, kd, ki);
+            unsigned long long m = __ballot(pass);
+            if (lane == 0) {
+                s_done[g] = s_done[g] | ~m;
+            }
+            any |= (m != 0);
+            while (m) {
+                const int l = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const float xd = __shfl(cd, l, KN_WAVE);
+                const int64_t xi = shfl_i64(ci, l);
+                if (top.admits(xd, xi, kd, ki)) {
+                    top.insert(xd, xi);
+                    kd = top.kth_dist();
+                    ki = top.kth_idx();
+                }
+            }
+        }
+        if (!any) {
+            break; // every slot is sorted best-first: deeper ranks cannot enter either
+        }
+    }
+    top.store(out_d + q * k, out_i + q * k);
+}
+
 hipError_t launch_merge_partials(const float* partial_d, const int64_t* partial_i, int64_t nq,
                                  int nslot, int k, int64_t q_stride, int64_t slot_stride, bool is_l2,
                                  float* out_d, int64_t* out_i, hipStream_t s, const int32_t* q_only) {
@@ -115,6 +216,21 @@ hipError_t launch_merge_partials(const float* partial_d, const int64_t* partial_
         return hipSuccess;
     }
     const unsigned grid = (unsigned)((nq + 3) / 4);
+    if (nslot > KN_WAVE * MP_BIG_GROUPS) {
+        return hipErrorInvalidValue;
+    }
+    if (nslot > KN_WAVE * KN_WAVE) {
+        KN_DISPATCH_R(k, {
+            if (is_l2) {
+                hipLaunchKernelGGL((merge_partials_big_kernel<true, R_>), dim3(grid), dim3(256), 0, s, partial_d, partial_i,
+                                   nq, nslot, k, q_stride, slot_stride, out_d, out_i, q_only);
+            } else {
+                hipLaunchKernelGGL((merge_partials_big_kernel<false, R_>), dim3(grid), dim3(256), 0, s, partial_d, partial_i,
+                                   nq, nslot, k, q_stride, slot_stride, out_d, out_i, q_only);
+            }
+        });
+        return hipGetLastError();
+    }
     KN_DISPATCH_R(k, {
         if (is_l2) {
             hipLaunchKernelGGL((merge_partials_kernel<true, R_>), dim3(grid), dim3(256), 0, s,

@@ -68,6 +68,42 @@ namespace hipemu { extern int g_ncu; }
 inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = hipemu::g_ncu; return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { std::memset(p, v, n); return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+// memory / streams / events of the orchestration (knhip_api.hip): "device" memory is host memory, everything is synchronous
+constexpr hipError_t hipErrorOutOfMemory = 2;
+typedef void* hipEvent_t;
+enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
+constexpr unsigned hipStreamNonBlocking = 1;
+inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : "emulated error"; }
+inline hipError_t hipMalloc(void** p, size_t n) {
+    // (slack behind every allocation: kernels prefetch past the end by design; filled with a pattern, not zero)
+    *p = std::aligned_alloc(256, ((n + 255) / 256) * 256 + 4096);
+    if (*p == nullptr) {
+        return hipErrorOutOfMemory;
+    }
+    std::memset(*p, 0xcd, ((n + 255) / 256) * 256 + 4096);
+    return hipSuccess;
+}
+template <class T>
+inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc(reinterpret_cast<void**>(p), n); }
+inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemset(void* p, int v, size_t n) { std::memset(p, v, n); return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+inline hipError_t hipMemGetInfo(size_t* f, size_t* t) { *f = (size_t)64 << 30; *t = (size_t)64 << 30; return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+[[noreturn]] inline void hipemu_unreachable() { // stands in for inline ISA (kernels that hold it are not run here)
+    std::fprintf(stderr, "hipemu: reached inline ISA that the emulation does not model\n");
+    std::abort();
+}
 
 // ---- execution model ------------------------------------------------------------------------------------------------
 namespace hipemu {

@@ -1,0 +1,80 @@
+"""tests/hipemu/run_api.py -- one emulated end-to-end search through the product's own ctypes harness and C ABI.
+
+Run as a subprocess by tests/test_pqf_emulated.py with KNHIP_LIB = the emulated library (the binding reads it at import),
+KNHIP_COARSE=exact (the MFMA coarse prefilter is not emulated) and, for the IVF-PQ prefilter, KNHIP_PQF=1.
+usage: python run_api.py <case>     prints "OK <case> ..." or raises"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, os.path.dirname(HERE))
+
+from conftest import gen_data  # noqa: E402
+from oracle import binding as ob  # noqa: E402
+
+
+def same(Do, Io, D, I, what):
+    assert np.array_equal(I, Io), f"{what}: ids differ\n{I}\n{Io}"
+    assert np.array_equal(D.view(np.uint32), Do.view(np.uint32)), f"{what}: distances differ"
+
+
+def main():
+    case = sys.argv[1]
+    assert os.environ.get("KNHIP_LIB", "").endswith("libknhip_emu.so")
+    from knowhere_amd import GpuIndex
+    port = ob.Port()
+    if case in ("pqf_l2", "pqf_ip"):
+        metric = ob.L2 if case == "pqf_l2" else ob.IP
+        assert os.environ.get("KNHIP_PQF") == "1"
+        nb, d, nlist, nq = 2400, 128, 5, 11
+        xb, xq = gen_data(nb, d, 42), gen_data(nq, d, 44)
+        ix = ob.make_index(port, ob.IVF_PQ, metric, xb, nlist=nlist, M=32)
+        g = GpuIndex.from_data(ix, device=0)
+        g.profile_enable(True)
+        for k, nprobe in ((10, 3), (4, nlist)):
+            g.profile_reset()
+            Do, Io = port.search(ix, xq, k, nprobe)
+            D, I = g.search(xq, k, nprobe)
+            p = g.profile_get()
+            same(Do, Io, D, I, f"{case} k={k} nprobe={nprobe}")
+            assert p["mscan_queries"] == nq and p["mscan_overflow_queries"] == 0, p
+        bs = np.packbits(np.random.default_rng(3).random(nb) < 0.4, bitorder="little")
+        Do, Io = port.search(ix, xq, 10, 3, bs, nb)
+        D, I = g.search(xq, 10, 3, bs, nb)
+        same(Do, Io, D, I, f"{case} bitset")
+        g.close()
+    elif case == "limits":
+        # nprobe above what the LDS sorts (the global-scratch row selection) through the whole search path
+        nb, d, nlist, nq = 9000, 8, 4500, 3
+        xb, xq = gen_data(nb, d, 42), gen_data(nq, d, 44)
+        ix = ob.make_index(port, ob.IVF_FLAT, ob.L2, xb, nlist=nlist)
+        g = GpuIndex.from_data(ix, device=0)
+        Do, Io = port.search(ix, xq, 5, 4200)
+        D, I = g.search(xq, 5, 4200)
+        same(Do, Io, D, I, "nprobe=4200")
+        g.close()
+    elif case == "range_pq16":
+        assert os.environ.get("KNHIP_UNVALIDATED") == "1"
+        nb, d, nlist, nq = 1500, 128, 6, 5
+        xb, xq = gen_data(nb, d, 42), gen_data(nq, d, 44)
+        for metric in (ob.L2, ob.IP):
+            ix = ob.make_index(port, ob.IVF_PQ, metric, xb, nlist=nlist, M=16)
+            g = GpuIndex.from_data(ix, device=0)
+            D, _ = port.search(ix, xq, 40, nlist)
+            radius = float(np.median(D[:, 20]))
+            for max_empty in (0, 2):
+                exp = port.range_search(ix, xq, radius, max_empty)
+                got = g.range_search(xq, np.float32(radius), max_empty)
+                assert np.array_equal(exp[0], got[0]) and np.array_equal(exp[1], got[1])
+                assert np.array_equal(exp[2].view(np.uint32), got[2].view(np.uint32))
+            g.close()
+    else:
+        raise SystemExit(f"unknown case {case}")
+    print("OK", case)
+
+
+if __name__ == "__main__":
+    main()

@@ -141,7 +141,8 @@ def test_emulated_row_select_above_4096_keys(emu, is_l2):
     Canonical order with ties on the value."""
     emu.emu_row_select.restype = C.c_int
     rng = np.random.default_rng(9)
-    for n, k in ((6000, 5000), (16384, 16384), (20000, 4097), (300, 10), (40000, 16385), (65536, 65536)):
+    shapes = ((6000, 5000), (20000, 4097), (300, 10), (40000, 16385)) if is_l2 else ((16384, 16384), (65536, 65536))
+    for n, k in shapes:
         vals = rng.standard_normal((2, n)).astype(np.float32)
         vals[0, ::7] = vals[0, 3]  # ties on the value: broken by the column index
         keys = np.zeros((2, k), np.int64)
@@ -204,3 +205,77 @@ def test_emulated_pq_adc_dump_any_code_width(emu, port, M):
             got_i, got_d = np.concatenate(got_i), np.concatenate(got_d)
             assert np.array_equal(got_i, exp_i), (M, metric, residual, q)
             assert np.array_equal(got_d.view(np.uint32), exp_d.view(np.uint32)), (M, metric, residual, q)
+
+
+def _run_api_case(case, **env):
+    """one end-to-end search through the product's ctypes harness, C ABI and orchestration (knhip_api.hip) on the
+    emulated library, in a subprocess (the binding reads KNHIP_LIB at import)"""
+    import subprocess
+    import emu_build
+    e = dict(os.environ)
+    e.update({"KNHIP_LIB": emu_build.build_api(), "KNHIP_COARSE": "exact"})  # (the MFMA coarse prefilter is not emulated)
+    e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(emu_build.__file__), "run_api.py"), case], env=e,
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and f"OK {case}" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("case", ["pqf_l2", "pqf_ip"])
+def test_emulated_api_ivfpq_prefilter(case):
+    """KNHIP_PQF=1 through knhip_index_* / knhip_search: layouts built on first use, exact coarse stage, work table with
+    the sample split, sample pass, row selection, tau, filter, finish passes, (empty) retry and exact rounds, merge --
+    every query finished by the prefilter path, results equal to the oracle's bit for bit, with and without a bitset"""
+    _run_api_case(case, KNHIP_PQF="1")
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.skipif(os.environ.get("KNHIP_TEST_EMU_FULL") != "1", reason="10 minutes of emulation (KNHIP_TEST_EMU_FULL=1); "
+                    "the kernels it exercises have their own quick tests above and below")
+def test_emulated_api_nprobe_above_4096():
+    """IVF-Flat with nprobe = 4200 of 4500 lists: the larger row selection AND the partial-list merge over more than
+    4096 slots (merge_partials_big_kernel: the emulation found the 64 x 64 slot limit of the original kernel's
+    exhausted-slot mask)"""
+    _run_api_case("limits")
+
+
+@pytest.mark.timeout(1800)
+def test_emulated_api_range_search_pq16():
+    _run_api_case("range_pq16", KNHIP_UNVALIDATED="1")
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("is_l2", [True, False], ids=["l2", "ip"])
+def test_emulated_merge_of_more_than_4096_partial_lists(emu, is_l2):
+    """topk.hip::merge_partials_big_kernel: per query the k best of nslot sentinel-terminated sorted partial lists with
+    nslot above 64 x 64 (the slot count the original kernel's per-lane exhausted mask holds), and the original kernel
+    just below that limit"""
+    emu.emu_merge_partials.restype = C.c_int
+    rng = np.random.default_rng(11)
+    for nslot, k in ((4200, 4), (4096, 3)):
+        nq = 1
+        pd = np.zeros((nq, nslot, k), np.float32)
+        pi = np.full((nq, nslot, k), -1, np.int64)
+        allv = []
+        for q in range(nq):
+            cand = []
+            for s in range(nslot):
+                n = int(rng.integers(0, k + 1)) if s % 3 else 0   # a third of the slots are empty
+                v = np.sort(rng.standard_normal(n).astype(np.float32))
+                if s >= 4096:  # the best entries sit in the slots behind the old limit
+                    v = (v - np.float32(10.0)).astype(np.float32)
+                if not is_l2:
+                    v = (-v).astype(np.float32)
+                ids = np.sort(rng.choice(1000, n, replace=False)).astype(np.int64) + s * 1000
+                pd[q, s, :n], pi[q, s, :n] = v, ids
+                cand += list(zip(v.tolist(), ids.tolist()))
+            cand.sort(key=(lambda t: (t[0], t[1])) if is_l2 else (lambda t: (-t[0], -t[1])))
+            allv.append(cand[:k])
+        out_d = np.zeros((nq, k), np.float32)
+        out_i = np.zeros((nq, k), np.int64)
+        rc = emu.emu_merge_partials(_p(pd, C.c_float), _p(pi, C.c_int64), C.c_int64(nq), C.c_int(nslot), C.c_int(k),
+                                    C.c_int(1 if is_l2 else 0), _p(out_d, C.c_float), _p(out_i, C.c_int64))
+        assert rc == 0
+        for q in range(nq):
+            assert out_i[q].tolist() == [c[1] for c in allv[q]], (nslot, k, q)
+            assert np.array_equal(out_d[q], np.array([c[0] for c in allv[q]], np.float32))
