@@ -50,7 +50,8 @@ constexpr int PF_Q = 8;
 constexpr int PF_WAVES = 16;
 constexpr int PF_THREADS = PF_WAVES * KN_WAVE;
 constexpr int PF_LUT_BYTES = PF_KSUB * PF_M * PF_Q * 2; // 131072
-// behind the LUT: [0] next unit, [8..8+34) next record, [64 + 8 j ..) per-pair constants of the current unit
+// behind the LUT (ints): [0], [1] unit index of mailbox slot 0 / 1, [8 + 32 s ..) the record of slot s (the current unit
+// and the one after it), [128 + 4 j ..) per-pair constants of the current unit
 constexpr int PF_CTL_BYTES = 1024;
 constexpr int PF_SAMPLE = 4096; // = MS_SAMPLE (mfma_scan.hip): dump columns per query
 constexpr float PF_U = 5.9604645e-8f;        // 2^-24
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(PF_THREADS) void pqf_kernel(MScanArgs a) {
 #endif
     extern __shared__ __align__(16) unsigned char smem[];
     int* ctl = reinterpret_cast<int*>(smem + PF_LUT_BYTES);
-    float* pc = reinterpret_cast<float*>(smem + PF_LUT_BYTES + 256); // [8][4] = {t, sc, pess const, 1 / sc}
+    float* pc = reinterpret_cast<float*>(smem + PF_LUT_BYTES + 512); // [8][4] = {t, sc, pess const, 1 / sc}
     const int lane = lane_id();
     const int wave = pf_sgpr((int)(threadIdx.x / KN_WAVE));
     if ((uint32_t)(size_t)((__attribute__((address_space(3))) unsigned char*)smem) != 0u) {
@@ -381,23 +382,51 @@ __global__ __launch_bounds__(PF_THREADS) void pqf_kernel(MScanArgs a) {
     static_assert(offsetof(P8Rec, npair) == 4 && offsetof(P8Rec, q) == 8 && offsetof(P8Rec, slot) == 40 &&
                   offsetof(P8Rec, dis0) == 72 && offsetof(P8Rec, len) == 104 && offsetof(P8Rec, sblk0) == 112 &&
                   offsetof(P8Rec, row_off) == 120, "P8Rec layout");
+    static_assert(REC_WORDS == 32, "mailbox slots of 32 words");
+    // Two-deep mailbox: slot `par` holds the current unit's record, slot `par ^ 1` the next unit's.  Knowing the next
+    // unit before the scan lets every wave request ITS pieces of the next unit's 8 query tables (128 KB per unit, mostly
+    // from HBM: the tables of a batch exceed the caches) before the scan loop, which hides their latency.
     if (wave == 0) {
-        int first = -1;
+        int u0 = -1, u1 = -1;
         if (lane == 0) {
-            first = fetch_slow();
+            u0 = fetch_slow();
+            u1 = u0 >= 0 ? fetch_slow() : -1;
         }
-        first = __builtin_amdgcn_readlane(first, 0);
-        if (lane < REC_WORDS && first >= 0) {
-            ctl[8 + lane] = (int)reinterpret_cast<const uint32_t*>(a.pq_recs + first)[lane];
+        u0 = __builtin_amdgcn_readlane(u0, 0);
+        u1 = __builtin_amdgcn_readlane(u1, 0);
+        if (lane < REC_WORDS && u0 >= 0) {
+            ctl[8 + lane] = (int)reinterpret_cast<const uint32_t*>(a.pq_recs + u0)[lane];
+        }
+        if (lane < REC_WORDS && u1 >= 0) {
+            ctl[8 + REC_WORDS + lane] = (int)reinterpret_cast<const uint32_t*>(a.pq_recs + u1)[lane];
         }
         if (lane == 0) {
-            ctl[0] = first;
+            ctl[0] = u0;
+            ctl[1] = u1;
         }
     }
     __syncthreads();
     int cur = pf_sgpr(ctl[0]);
+    int par = 0;
     const uint32_t one = 1u;
     const uint4* qh4 = reinterpret_cast<const uint4*>(a.pq_qh);
+    // this thread's 16-byte piece of the 8 query tables of the unit in mailbox slot `slot`
+    auto load_tables = [&](int slot, uint4 (&t)[PF_Q], int lane_i) {
+        const uint32_t rq = lane_i < REC_WORDS ? (uint32_t)ctl[8 + slot * REC_WORDS + lane_i] : 0u;
+#pragma unroll
+        for (int j = 0; j < PF_Q; j++) {
+            const int64_t q = (int64_t)(int32_t)__builtin_amdgcn_readlane((int)rq, 2 + j);
+            t[j] = qh4[q * (PF_KSUB * PF_M / 8) + (wave * KN_WAVE + lane_i)];
+        }
+    };
+    uint4 tp[PF_Q];
+#pragma unroll
+    for (int j = 0; j < PF_Q; j++) {
+        tp[j] = make_uint4(0, 0, 0, 0);
+    }
+    if (cur >= 0) {
+        load_tables(0, tp, lane);
+    }
 
     while (cur >= 0) {
         PF_T(5); // (loop top: the mailbox read of the previous iteration's end)
@@ -409,7 +438,8 @@ __global__ __launch_bounds__(PF_THREADS) void pqf_kernel(MScanArgs a) {
             f_i = atomicAdd(a.pq_ctr + f_x * 16, 1);
         }
         // ---- the unit's record (mailbox), fields broadcast to SGPRs ----------------------------------------------
-        const uint32_t rw = lane_i < REC_WORDS ? (uint32_t)ctl[8 + lane_i] : 0u;
+        const uint32_t rw = lane_i < REC_WORDS ? (uint32_t)ctl[8 + par * REC_WORDS + lane_i] : 0u;
+        const int nxt_unit = pf_sgpr(ctl[par ^ 1]); // (-1: this is the last unit of the workgroup)
         auto rl = [&](int i) { return (uint32_t)__builtin_amdgcn_readlane((int)rw, i); };
         const int npair = (int)rl(1);
         int32_t q_of[PF_Q], slot_of[PF_Q];
@@ -422,12 +452,7 @@ __global__ __launch_bounds__(PF_THREADS) void pqf_kernel(MScanArgs a) {
         const int64_t sblk0 = (int64_t)(((uint64_t)rl(29) << 32) | rl(28));
         const int64_t row_off = (int64_t)(((uint64_t)rl(31) << 32) | rl(30));
 
-        // ---- the 8 queries' table pieces: requested first, transposed into the LUT below -----------------------------
-        uint4 tp[PF_Q];
-#pragma unroll
-        for (int j = 0; j < PF_Q; j++) {
-            tp[j] = qh4[(int64_t)q_of[j] * (PF_KSUB * PF_M / 8) + (wave * KN_WAVE + lane_i)];
-        }
+        // (the 8 queries' table pieces `tp` were requested one unit ago; they are transposed into the LUT below)
         // this wave's groups of 64 vectors and its first code blocks
         const int ngroups = (int)((len + 63) / 64);
         const int gbase = ngroups / PF_WAVES, grem = ngroups % PF_WAVES;
@@ -509,12 +534,13 @@ __global__ __launch_bounds__(PF_THREADS) void pqf_kernel(MScanArgs a) {
         PF_T(0); // record, pair constants, table loads + LUT stores
         __syncthreads();
         PF_T(1); // wait for the other waves' LUT parts
-        // ---- next unit: index now (the atomic was issued at the top), record requested, parked after the scan ---------
+        // ---- the unit after the next: index now (the atomic was issued at the top), record requested, parked after the
+        // scan in the mailbox slot this unit occupies (every wave has read it) --------------------------------------------
         int nxt = -1;
         uint32_t rw_next = 0;
         if (wave == 0) {
             if (lane_i == 0) {
-                if (fetch_t < 8) {
+                if (fetch_t < 8 && nxt_unit >= 0) {
                     const int base = f_x * per;
                     const int cnt = min(per, nunits - base);
                     if (f_i < cnt) {
@@ -529,6 +555,15 @@ __global__ __launch_bounds__(PF_THREADS) void pqf_kernel(MScanArgs a) {
             if (lane_i < REC_WORDS && nxt >= 0) {
                 rw_next = reinterpret_cast<const uint32_t*>(a.pq_recs + nxt)[lane_i];
             }
+        }
+        // the next unit's table pieces: in flight during the scan
+        uint4 tpn[PF_Q];
+#pragma unroll
+        for (int j = 0; j < PF_Q; j++) {
+            tpn[j] = make_uint4(0, 0, 0, 0);
+        }
+        if (nxt_unit >= 0) {
+            load_tables(par ^ 1, tpn, lane_i);
         }
         // the pairs' constants -> SGPRs
         float thr[PF_Q], scq[PF_Q], pcs[PF_Q], isc[PF_Q];
@@ -648,18 +683,23 @@ __global__ __launch_bounds__(PF_THREADS) void pqf_kernel(MScanArgs a) {
         }
         PF_T(3); // window loop
         PF_COUNT(6, nwin);
-        if (wave == 0) { // park the next unit
+        if (wave == 0) { // park the unit after the next
             if (lane_i < REC_WORDS) {
-                ctl[8 + lane_i] = (int)rw_next;
+                ctl[8 + par * REC_WORDS + lane_i] = (int)rw_next;
             }
             if (lane_i == 0) {
-                ctl[0] = nxt;
+                ctl[par] = nxt;
             }
         }
         __syncthreads(); // the LUT and the pair constants are dead, the mailbox is visible
         PF_T(4);         // wait for the slowest wave's scan
         PF_COUNT(7, 1);
-        cur = pf_sgpr(ctl[0]);
+        cur = nxt_unit;
+        par ^= 1;
+#pragma unroll
+        for (int j = 0; j < PF_Q; j++) {
+            tp[j] = tpn[j];
+        }
     }
 #ifdef KNHIP_PHASE_TIMERS
     if (lane == 0) {
