@@ -29,7 +29,7 @@ def main():
     if case in ("pqf_l2", "pqf_ip"):
         metric = ob.L2 if case == "pqf_l2" else ob.IP
         assert os.environ.get("KNHIP_PQF") == "1"
-        nb, d, nlist, nq = 2400, 128, 5, 11
+        nb, d, nlist, nq = 1800, 128, 5, 10
         xb, xq = gen_data(nb, d, 42), gen_data(nq, d, 44)
         ix = ob.make_index(port, ob.IVF_PQ, metric, xb, nlist=nlist, M=32)
         g = GpuIndex.from_data(ix, device=0)
