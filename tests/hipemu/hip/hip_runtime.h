@@ -111,6 +111,7 @@ namespace hipemu {
 struct Wave {
     std::barrier<> bar;
     uint64_t x[2][64];
+    alignas(16) unsigned char wide[2][64][32]; // 32-byte payloads (matrix-core operands)
     explicit Wave(int n) : bar(n) {}
 };
 struct Group {
@@ -145,6 +146,14 @@ inline unsigned long long ballot(bool p) {
         m |= (unsigned long long)(w.x[k][i] & 1u) << i;
     }
     return m;
+}
+// every lane publishes n <= 32 bytes; returns the wave's 64 payloads (valid until this lane's next-but-one exchange)
+inline const unsigned char (*xchg_wide(const void* p, size_t n))[32] {
+    Wave& w = *tl.w;
+    const unsigned k = tl.op++ & 1u;
+    std::memcpy(w.wide[k][tl.lane], p, n);
+    w.bar.arrive_and_wait();
+    return w.wide[k];
 }
 template <class T>
 inline uint64_t to_bits(T v) {
@@ -223,14 +232,54 @@ inline uint32_t hipemu_perm(uint32_t s0, uint32_t s1, uint32_t sel) { // v_perm_
     return out;
 }
 #define __builtin_amdgcn_perm(a, b, sel) hipemu_perm((a), (b), (sel))
-// matrix-core builtins: present so that files holding MFMA kernels compile; those kernels are not run here
-template <class A, class B, class C>
-inline C hipemu_mfma_stub(A, B, C c, int, int, int) {
-    std::abort();
+// matrix cores, 32x32 output tile of a wave: lane l supplies A[i = l % 32][k-slab l / 32] and B[k-slab l / 32][j = l % 32]
+// and holds, in element r of its 16 accumulators, D[i = (r & 3) + 8 (r >> 2) + 4 (l / 32)][j = l % 32].
+// v_mfma_f32_32x32x2_f32: one fp32 per lane and operand (K = 2).  v_mfma_f32_32x32x16_f16: 8 halves per lane and operand
+// (K = 16, slab = 8 consecutive k).  Products are added to the fp32 accumulator one by one here; the hardware rounds
+// differently inside -- the kernels use these results only as a prefilter, never as a returned value.
+template <class C>
+inline C hipemu_mfma_32x32x2_f32(float a, float b, C c, int, int, int) {
+    const float ab[2] = {a, b};
+    const unsigned char (*all)[32] = hipemu::xchg_wide(ab, sizeof(ab));
+    const int l = hipemu::tl.lane, j = l & 31, hi = l >> 5;
+    for (int r = 0; r < 16; r++) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c[r];
+        for (int kk = 0; kk < 2; kk++) {
+            float av, bv;
+            std::memcpy(&av, all[i + 32 * kk], 4);
+            std::memcpy(&bv, all[j + 32 * kk] + 4, 4);
+            acc += av * bv;
+        }
+        c[r] = acc;
+    }
     return c;
 }
-#define __builtin_amdgcn_mfma_f32_32x32x2f32(...) hipemu_mfma_stub(__VA_ARGS__)
-#define __builtin_amdgcn_mfma_f32_32x32x16_f16(...) hipemu_mfma_stub(__VA_ARGS__)
+template <class H8, class C>
+inline C hipemu_mfma_32x32x16_f16(H8 a, H8 b, C c, int, int, int) {
+    static_assert(sizeof(H8) == 16, "8 halves per lane");
+    unsigned char ab[32];
+    std::memcpy(ab, &a, 16);
+    std::memcpy(ab + 16, &b, 16);
+    const unsigned char (*all)[32] = hipemu::xchg_wide(ab, 32);
+    const int l = hipemu::tl.lane, j = l & 31, hi = l >> 5;
+    for (int r = 0; r < 16; r++) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c[r];
+        for (int kk = 0; kk < 2; kk++) {
+            _Float16 av[8], bv[8];
+            std::memcpy(av, all[i + 32 * kk], 16);
+            std::memcpy(bv, all[j + 32 * kk] + 16, 16);
+            for (int e = 0; e < 8; e++) {
+                acc += (float)av[e] * (float)bv[e];
+            }
+        }
+        c[r] = acc;
+    }
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(...) hipemu_mfma_32x32x2_f32(__VA_ARGS__)
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(...) hipemu_mfma_32x32x16_f16(__VA_ARGS__)
 #define __builtin_amdgcn_s_setprio(p) ((void)0)
 #define __builtin_amdgcn_sched_barrier(m) ((void)0)
 #define __builtin_amdgcn_s_memtime() 0ull

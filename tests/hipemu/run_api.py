@@ -46,6 +46,24 @@ def main():
         D, I = g.search(xq, 10, 3, bs, nb)
         same(Do, Io, D, I, f"{case} bitset")
         g.close()
+    elif case in ("ms_flat_l2", "ms_sq8_ip", "ms_sq8_l2", "ms_flat_ip"):
+        # the MFMA paths (hardware-validated) under the matrix-core emulation: coarse GEMM prefilter + re-rank +
+        # certificate, fp32 / f16 list prefilter + exact finish -- a regression net for changes made without a GPU
+        assert os.environ.get("KNHIP_MSCAN") == "1" and os.environ.get("KNHIP_COARSE") is None
+        kind = ob.IVF_FLAT if "flat" in case else ob.IVF_SQ8
+        metric = ob.L2 if case.endswith("l2") else ob.IP
+        nb, d, nlist, nq = 2400, 48, 36, 40
+        xb, xq = gen_data(nb, d, 42), gen_data(nq, d, 44)
+        ix = ob.make_index(port, kind, metric, xb, nlist=nlist)
+        g = GpuIndex.from_data(ix, device=0)
+        g.profile_enable(True)
+        Do, Io = port.search(ix, xq, 10, 8)
+        D, I = g.search(xq, 10, 8)
+        p = g.profile_get()
+        same(Do, Io, D, I, case)
+        assert p["mscan_queries"] == nq and p["coarse_fallback_queries"] == 0, p
+        assert p["mscan_candidates"] < 40 * nq, p  # (a wrong operand layout would flood the candidate lists)
+        g.close()
     elif case == "limits":
         # nprobe above what the LDS sorts (the global-scratch row selection) through the whole search path
         nb, d, nlist, nq = 9000, 8, 4500, 3

@@ -216,8 +216,9 @@ def _run_api_case(case, **env):
     import subprocess
     import emu_build
     e = dict(os.environ)
-    e.update({"KNHIP_LIB": emu_build.build_api(), "KNHIP_COARSE": "exact"})  # (the MFMA coarse prefilter is not emulated)
+    e.update({"KNHIP_LIB": emu_build.build_api(), "KNHIP_COARSE": "exact"})  # (exact coarse stage: less to emulate)
     e.update(env)
+    e = {k: v for k, v in e.items() if v is not None}
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(emu_build.__file__), "run_api.py"), case], env=e,
                        capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and f"OK {case}" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
@@ -282,3 +283,18 @@ def test_emulated_merge_of_more_than_4096_partial_lists(emu, is_l2):
         for q in range(nq):
             assert out_i[q].tolist() == [c[1] for c in allv[q]], (nslot, k, q)
             assert np.array_equal(out_d[q], np.array([c[0] for c in allv[q]], np.float32))
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("case", ["ms_flat_l2",
+                                  pytest.param("ms_sq8_ip", marks=pytest.mark.skipif(
+                                      os.environ.get("KNHIP_TEST_EMU_FULL") != "1", reason="KNHIP_TEST_EMU_FULL=1")),
+                                  pytest.param("ms_sq8_l2", marks=pytest.mark.skipif(
+                                      os.environ.get("KNHIP_TEST_EMU_FULL") != "1", reason="KNHIP_TEST_EMU_FULL=1")),
+                                  pytest.param("ms_flat_ip", marks=pytest.mark.skipif(
+                                      os.environ.get("KNHIP_TEST_EMU_FULL") != "1", reason="KNHIP_TEST_EMU_FULL=1"))])
+def test_emulated_api_mfma_paths(case):
+    """the matrix-core paths with v_mfma_f32_32x32x2_f32 / v_mfma_f32_32x32x16_f16 emulated (operand and accumulator
+    layouts of hip/hip_runtime.h): coarse GEMM prefilter + exact re-rank + certificate, list prefilter + exact finish.
+    These kernels are validated on hardware; the emulated run is the safety net for changes made without a GPU."""
+    _run_api_case(case, KNHIP_MSCAN="1", KNHIP_COARSE=None)
