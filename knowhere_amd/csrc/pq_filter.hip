@@ -424,7 +424,7 @@ __global__ __launch_bounds__(PF_THREADS) void pqf_kernel(MScanArgs a) {
     for (int j = 0; j < PF_Q; j++) {
         tp[j] = make_uint4(0, 0, 0, 0);
     }
-    if (cur >= 0) {
+    if (!DUMP && cur >= 0) {
         load_tables(0, tp, lane);
     }
 
@@ -452,7 +452,11 @@ __global__ __launch_bounds__(PF_THREADS) void pqf_kernel(MScanArgs a) {
         const int64_t sblk0 = (int64_t)(((uint64_t)rl(29) << 32) | rl(28));
         const int64_t row_off = (int64_t)(((uint64_t)rl(31) << 32) | rl(30));
 
-        // (the 8 queries' table pieces `tp` were requested one unit ago; they are transposed into the LUT below)
+        // (filter mode: the 8 queries' table pieces `tp` were requested one unit ago; they are transposed into the LUT
+        // below.  The sample pass -- few, short units -- requests them here instead and keeps 32 registers free)
+        if (DUMP) {
+            load_tables(par, tp, lane_i);
+        }
         // this wave's groups of 64 vectors and its first code blocks
         const int ngroups = (int)((len + 63) / 64);
         const int gbase = ngroups / PF_WAVES, grem = ngroups % PF_WAVES;
@@ -562,7 +566,7 @@ __global__ __launch_bounds__(PF_THREADS) void pqf_kernel(MScanArgs a) {
         for (int j = 0; j < PF_Q; j++) {
             tpn[j] = make_uint4(0, 0, 0, 0);
         }
-        if (nxt_unit >= 0) {
+        if (!DUMP && nxt_unit >= 0) {
             load_tables(par ^ 1, tpn, lane_i);
         }
         // the pairs' constants -> SGPRs

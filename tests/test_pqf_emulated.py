@@ -127,7 +127,7 @@ def test_emulated_ragged_lists_and_k(emu, port, metric):
     ix.list_codes[1], ix.list_ids[1] = ix.list_codes[1][:0], ix.list_ids[1][:0]
     ix.list_codes[2], ix.list_ids[2] = ix.list_codes[2][:17], ix.list_ids[2][:17]
     ix.list_codes[3], ix.list_ids[3] = ix.list_codes[3][:128], ix.list_ids[3][:128]
-    for k, nprobe in ((1, 2), (70, nlist), (10, 4)):
+    for k, nprobe in (((1, 2), (70, nlist)) if metric == ob.L2 else ((10, 4),)):
         Do, Io = port.search(ix, xq, k, nprobe)
         D, I, cnt, ovf, tau, _ = run_emulated(emu, port, ix, xq, k, nprobe)
         ok = ovf == 0
@@ -225,7 +225,8 @@ def _run_api_case(case, **env):
 
 
 @pytest.mark.timeout(1800)
-@pytest.mark.parametrize("case", ["pqf_l2", "pqf_ip"])
+@pytest.mark.parametrize("case", ["pqf_l2", pytest.param("pqf_ip", marks=pytest.mark.skipif(
+    os.environ.get("KNHIP_TEST_EMU_FULL") != "1", reason="KNHIP_TEST_EMU_FULL=1"))])
 def test_emulated_api_ivfpq_prefilter(case):
     """KNHIP_PQF=1 through knhip_index_* / knhip_search: layouts built on first use, exact coarse stage, work table with
     the sample split, sample pass, row selection, tau, filter, finish passes, (empty) retry and exact rounds, merge --
