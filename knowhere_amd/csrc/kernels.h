@@ -247,6 +247,10 @@ hipError_t launch_pq_psum(const uint8_t* codes, const int64_t* list_row_off, con
                           uint32_t* pabs_max_bits, hipStream_t s);
 hipError_t launch_pqf_query_table(const float* queries, const float4* cb_t, int d, int64_t nq, bool is_l2, float pabs_max,
                                   void* qh, float* qs, hipStream_t s);
+// selectivity guard: *poor = queries whose predicted candidate count exceeds half the capacity
+hipError_t launch_pqf_predict(const float* dump, int64_t stride, const int32_t* n_row, const float* gthr, const float* qs,
+                              const int64_t* keys, int nprobe, int64_t nlist, const int64_t* list_len, int64_t nq, int cap,
+                              bool is_l2, int32_t* poor, hipStream_t s);
 size_t pqf_smem();
 bool pqf_supports(int M, int d);
 hipError_t launch_pqf(const MScanArgs& a, bool is_l2, int64_t units_bound, hipStream_t s);

@@ -550,6 +550,8 @@ int ensure_mscan_norms(const knhip_index* idx) {
     return KNHIP_OK;
 }
 
+constexpr int KNHIP_PQF_ABANDONED = 1; // (not an error: the selectivity guard sent the batch to the exact kernel)
+
 // IVF-PQ half-precision prefilter: rotated token stream + per-vector term-2 sums, from the canonical AoS codes
 int ensure_pqf(const knhip_index* idx) {
     std::lock_guard<std::mutex> lk(idx->mu);
@@ -800,7 +802,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         HIP_TRY(ws->ms_unit_off.reserve((size_t)(nlist + 1) * sizeof(int64_t)));
         HIP_TRY(ws->ms_nunits.reserve(sizeof(int64_t) + 2 * sizeof(double)));
         HIP_TRY(ws->ms_cand.reserve((size_t)nq * ms_cap * sizeof(int64_t)));
-        HIP_TRY(ws->ms_cand_cnt.reserve((size_t)(2 * nq + 1) * sizeof(int32_t)));
+        HIP_TRY(ws->ms_cand_cnt.reserve((size_t)(2 * nq + 2) * sizeof(int32_t))); // counters, flags, any-flag, guard counter
         HIP_TRY(ws->dump.reserve((size_t)nq * sample * sizeof(float)));
         HIP_TRY(ws->sel_keys.reserve((size_t)nq * k * sizeof(int64_t)));
         HIP_TRY(ws->sel_d.reserve((size_t)nq * k * sizeof(float)));
@@ -907,6 +909,20 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
                                           nq, k, is_l2, ws->sel_keys.as<int64_t>(), ws->sel_d.as<float>(), s, sample,
                                           ws->ms_nrow.as<int32_t>()));
             HIP_TRY(launch_ms_tau(ws->sel_d.as<float>(), nq, k, is_l2, ws->gthr.as<float>(), ws->gmeta.as<uint2>(), s));
+            if (kind == KNHIP_IVF_PQ) {
+                // selectivity guard (pq_filter.hip): on data where the half-precision bound lets through a few percent of
+                // the rows the exact finish costs more than the exact scan: such a batch takes the 4-query kernel
+                int32_t* poor = ws->ms_cand_cnt.as<int32_t>() + 2 * nq + 1;
+                HIP_TRY(launch_pqf_predict(ws->dump.as<float>(), sample, ws->ms_nrow.as<int32_t>(), ws->gthr.as<float>(),
+                                           ws->ms_qs.as<float>(), keys_p, nprobe, nlist, idx->d_list_len.as<int64_t>(), nq,
+                                           ms_cap, is_l2, poor, s));
+                int32_t h_poor = 0;
+                HIP_TRY(hipMemcpyAsync(&h_poor, poor, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                if ((int64_t)h_poor * 4 > nq) {
+                    return KNHIP_PQF_ABANDONED;
+                }
+            }
         }
         {
             // all probes of a list together: the work table again without the rank-0 split, its pairs cut into units
@@ -1026,7 +1042,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             a.codes_skew = idx->rows2.as<uint4>();
             a.list_sblk_off = idx->d_list_blk_off2.as<int64_t>();
             a.cb_t = idx->cb_t.as<float4>();
-            return run_mscan([&](const KnItem* items, const KnPair* pairs, const int64_t* nitems, int64_t) -> int {
+            const int rc_ms = run_mscan([&](const KnItem* items, const KnPair* pairs, const int64_t* nitems, int64_t) -> int {
                 PqScanArgs b = a;
                 b.items = items;
                 b.pairs = pairs;
@@ -1040,6 +1056,11 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
                 HIP_TRY(launch_pq_scan_q4(b, is_l2, npairs, s));
                 return KNHIP_OK;
             });
+            if (rc_ms != KNHIP_PQF_ABANDONED) {
+                return rc_ms;
+            }
+            // (the guard found the batch poorly selective: the exact 4-query kernel over the work table built above -- both
+            // classes of the sample split are ordinary items of 4 pairs; gthr holds the sample's bounds, which are valid)
         }
         if (pq_use_v2) {
             a.codes_skew = idx->rows2.as<uint4>();

@@ -714,6 +714,68 @@ __global__ __launch_bounds__(PF_THREADS) void pqf_kernel(MScanArgs a) {
 #endif
 }
 
+// ---- selectivity guard -----------------------------------------------------------------------------------------
+// The filter is only as selective as eps against the spread of the distances: on clustered data 0.1 % of the scanned
+// rows pass, on isotropic data 10 %, and at a few percent the exact finish (32 global gathers per candidate) costs more
+// than the exact scan it replaces.  The sample pass holds the estimate: the share of a query's sample rows whose
+// pessimistic distance is within tau + 2 eps (what the filter lets through) times the rows of its probed lists.  One
+// wave per query; *poor counts the queries predicted to gather more than half their capacity.  The host abandons the
+// prefilter for the batch when more than a quarter of its queries are (knhip_api.hip).
+template <bool IS_L2>
+__global__ __launch_bounds__(256) void pqf_predict_kernel(const float* __restrict__ dump, int64_t stride,
+                                                          const int32_t* __restrict__ n_row, const float* __restrict__ gthr,
+                                                          const float* __restrict__ qs, const int64_t* __restrict__ keys,
+                                                          int nprobe, int64_t nlist, const int64_t* __restrict__ list_len,
+                                                          int64_t nq, int cap, int32_t* __restrict__ poor) {
+    const int lane = lane_id();
+    const int64_t q = (int64_t)blockIdx.x * (blockDim.x / KN_WAVE) + threadIdx.x / KN_WAVE;
+    if (q >= nq) {
+        return;
+    }
+    const float tau = gthr[q];
+    const int n = n_row[q];
+    if (tau == worst_dist<IS_L2>() || n <= 0) {
+        return; // (no bound: the query takes the exact kernels on its own)
+    }
+    const float eps = qs[q * 4 + 2] + 64.0f * PF_U * fabsf(tau);
+    const float lim = IS_L2 ? tau + 2.0f * eps : tau - 2.0f * eps;
+    float cnt = 0.f, rows = 0.f;
+    for (int i = lane; i < n; i += KN_WAVE) {
+        const float v = dump[q * stride + i];
+        cnt += (IS_L2 ? v <= lim : v >= lim) ? 1.f : 0.f;
+    }
+    for (int sl = lane; sl < nprobe; sl += KN_WAVE) {
+        const int64_t key = keys[q * nprobe + sl];
+        rows += (key >= 0 && key < nlist) ? (float)list_len[key] : 0.f;
+    }
+#pragma unroll
+    for (int dlt = KN_WAVE / 2; dlt > 0; dlt >>= 1) {
+        cnt += __shfl_xor(cnt, dlt, KN_WAVE);
+        rows += __shfl_xor(rows, dlt, KN_WAVE);
+    }
+    if (lane == 0 && cnt / (float)n * rows > 0.5f * (float)cap) {
+        atomicAdd(poor, 1);
+    }
+}
+
+hipError_t launch_pqf_predict(const float* dump, int64_t stride, const int32_t* n_row, const float* gthr, const float* qs,
+                              const int64_t* keys, int nprobe, int64_t nlist, const int64_t* list_len, int64_t nq, int cap,
+                              bool is_l2, int32_t* poor, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(poor, 0, sizeof(int32_t), s);
+    if (e != hipSuccess || nq <= 0) {
+        return e;
+    }
+    const unsigned grid = (unsigned)((nq + 3) / 4);
+    if (is_l2) {
+        hipLaunchKernelGGL(pqf_predict_kernel<true>, dim3(grid), dim3(256), 0, s, dump, stride, n_row, gthr, qs, keys, nprobe,
+                           nlist, list_len, nq, cap, poor);
+    } else {
+        hipLaunchKernelGGL(pqf_predict_kernel<false>, dim3(grid), dim3(256), 0, s, dump, stride, n_row, gthr, qs, keys, nprobe,
+                           nlist, list_len, nq, cap, poor);
+    }
+    return hipGetLastError();
+}
+
 size_t pqf_smem() {
     return (size_t)PF_LUT_BYTES + PF_CTL_BYTES;
 }

@@ -56,7 +56,7 @@ extern "C" int emu_pqf_search(int64_t nlist, const int64_t* list_len, const int6
                               const float* cb /* [32][256][4] */, const float* centroids, const float* xq, int64_t nq,
                               int nprobe, const int64_t* keys, const float* cdis, int k, int is_l2, int cap,
                               const uint8_t* bitset, int64_t nbits, int use_hist, int do_retry, float* out_d, int64_t* out_i,
-                              int32_t* cand_cnt_out, int32_t* overflow_out, float* tau_out, int64_t* nunits_out) {
+                              int32_t* cand_cnt_out, int32_t* overflow_out, float* tau_out, int64_t* nunits_out, int32_t* poor_out) {
     const int d = 128, M = 32;
     const bool l2 = is_l2 != 0;
     // ---- index side: c-major codebook, transposed term-2 table, rotated stream, per-vector sums ----------------------
@@ -170,6 +170,12 @@ extern "C" int emu_pqf_search(int64_t nlist, const int64_t* list_len, const int6
     if (launch_ms_tau(sel_d.data(), nq, k, l2, gthr.data(), gmeta.data(), nullptr) != hipSuccess) return 6;
     for (int64_t q = 0; q < nq; q++) {
         tau_out[q] = gthr[(size_t)q];
+    }
+    {   // the selectivity guard's prediction (the product abandons the prefilter for a batch on it; here it is reported)
+        int32_t poor = 0;
+        if (launch_pqf_predict(dump.data(), sample, n_row.data(), gthr.data(), qs.data(), keys, nprobe, nlist, list_len, nq, cap,
+                               l2, &poor, nullptr) != hipSuccess) return 11;
+        *poor_out = poor;
     }
     if (use_hist) {
         m.ghist = ghist.data();

@@ -58,14 +58,16 @@ def run_emulated(lib, port, ix, xq, k, nprobe, cap=4096, bitset=None, use_hist=1
     ovf = np.zeros(nq, np.int32)
     tau = np.zeros(nq, np.float32)
     nunits = np.zeros(1, np.int64)
+    poor = np.zeros(1, np.int32)
     nbits = 0 if bitset is None else int(lens.sum())
     rc = lib.emu_pqf_search(C.c_int64(ix.nlist), _p(lens, C.c_int64), _p(row_off, C.c_int64), _p(codes, C.c_uint8),
                             _p(ids, C.c_int64), _p(pre, C.c_float), _p(cb, C.c_float), _p(cen, C.c_float),
                             _p(xq, C.c_float), C.c_int64(nq), C.c_int(nprobe), _p(keys, C.c_int64), _p(cdis, C.c_float),
                             C.c_int(k), C.c_int(1 if is_l2 else 0), C.c_int(cap), _p(bitset, C.c_uint8), C.c_int64(nbits),
                             C.c_int(use_hist), C.c_int(retry), _p(D, C.c_float), _p(I, C.c_int64), _p(cnt, C.c_int32), _p(ovf, C.c_int32),
-                            _p(tau, C.c_float), _p(nunits, C.c_int64))
+                            _p(tau, C.c_float), _p(nunits, C.c_int64), _p(poor, C.c_int32))
     assert rc == 0, f"emulated pipeline failed at stage {rc}"
+    run_emulated.poor = int(poor[0])
     return D, I, cnt, ovf, tau, int(nunits[0])
 
 
@@ -83,6 +85,11 @@ def test_emulated_kernels_return_the_oracles_bits(emu, port, metric):
     assert np.array_equal(D.view(np.uint32), Do.view(np.uint32))
     scanned = sum(len(c) for c in ix.list_codes) * nprobe / nlist
     assert 0 < cnt.max() < 0.6 * scanned, (cnt, scanned)
+    # the selectivity guard: with room for 4096 candidates no query is predicted to need more than half of it; with
+    # room for 16 every one is (the prediction, sample share x rows probed, is within a factor 2 of what was gathered)
+    assert run_emulated.poor == 0
+    run_emulated(emu, port, ix, xq, k, nprobe, cap=16)
+    assert run_emulated.poor == nq, run_emulated.poor
 
 
 @pytest.mark.timeout(1500)
