@@ -199,6 +199,7 @@ struct knhip_index {
     // IVF-PQ half-precision prefilter (pq_filter.hip): KNHIP_PQF = 1 switches it on (default off: not yet validated on
     // hardware).  Its layouts are built on first use.
     int pqf = 0;
+    bool pqf_guard = true;           // KNHIP_PQF_GUARD=0 switches the selectivity guard off (tests of the overflow rounds)
     mutable bool pqf_ready = false;
     mutable DevBuf rows_r;           // rotated token stream (stream16r)
     mutable DevBuf d_list_blk_off_r; // [nlist + 1]
@@ -419,6 +420,8 @@ int build_list_layout(knhip_index* idx, const std::vector<int64_t>& list_off, co
         idx->xnorm_ready = false;
         const char* pf = getenv("KNHIP_PQF");
         idx->pqf = (pf && pf[0] == '1') ? 1 : 0;
+        const char* pg = getenv("KNHIP_PQF_GUARD");
+        idx->pqf_guard = !(pg && pg[0] == '0');
         idx->pqf_ready = false;
         idx->rows_r.release();
         idx->psum.release();
@@ -909,7 +912,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
                                           nq, k, is_l2, ws->sel_keys.as<int64_t>(), ws->sel_d.as<float>(), s, sample,
                                           ws->ms_nrow.as<int32_t>()));
             HIP_TRY(launch_ms_tau(ws->sel_d.as<float>(), nq, k, is_l2, ws->gthr.as<float>(), ws->gmeta.as<uint2>(), s));
-            if (kind == KNHIP_IVF_PQ) {
+            if (kind == KNHIP_IVF_PQ && idx->pqf_guard) {
                 // selectivity guard (pq_filter.hip): on data where the half-precision bound lets through a few percent of
                 // the rows the exact finish costs more than the exact scan: such a batch takes the 4-query kernel
                 int32_t* poor = ws->ms_cand_cnt.as<int32_t>() + 2 * nq + 1;
