@@ -12,15 +12,16 @@
 //   approx(q, v) = dis0 + psum[v] + (1 / sc_q) * sum_m Qh_q[m][code_m(v)]                                  (L2)
 //       psum[v]  = sum_m term2[list][m][code_m(v)]     per stored vector, fp32, computed when the layout is built
 //                  (term2 = ||cb||^2 + 2 <c_list,m, cb>: IVFPQ_QueryTables.cpp:50-108; no query in it)
-//       Qh_q     = half(sc_q * -2 <q_m, cb[m][c]>)     per query, sc_q a power of two that brings
-//                  A_q = sum_m max_c |2 <q_m, cb>| into [2^13, 2^14): no partial sum can overflow
-//   approx(q, v) = dis0 + (1 / sc_q) * sum_m half(sc_q <q_m, cb>)                                           (IP)
+//       Qh_q     = rint(sc_q * -2 <q_m, cb[m][c]>)     per query, an INTEGER table: sc_q = 2032 / A_q with
+//                  A_q = sum_m max_c |2 <q_m, cb>|, so that every partial sum of a vector's 32 entries is an
+//                  integer of magnitude <= 2048 -- exactly representable in half precision: the additions are exact
+//   approx(q, v) = dis0 + (1 / sc_q) * sum_m rint(sc_q <q_m, cb>)                                           (IP)
 //
-//   |approx - exact| <= eps = 34 * 2^-11 * A_q + 64 * 2^-24 * (|dis0| + max_v sum_m |term2| + A_q + |tau|)
-//                             + 33 * 2^-25 / sc_q:
-//   32 table entries rounded to half (relative 2^-11 each, sum of magnitudes <= A_q; absolute 2^-25 where the scaled
-//   entry is a half subnormal), 31 half additions whose results are bounded by A_q (2^-11 relative each), the fp32
-//   roundings of both sides (~70 operations of relative 2^-24 on quantities bounded by the bracket).
+//   |approx - exact| <= eps = 16.5 / sc_q + 64 * 2^-24 * (|dis0| + max_v sum_m |term2| + A_q + |tau|)
+//                           = 0.0081 A_q + ...:
+//   32 table entries rounded to integers (half a unit each; the half additions add nothing), the fp32 roundings of both
+//   sides (~70 operations of relative 2^-24 on quantities bounded by the bracket).  (Rounding the entries to half
+//   precision instead and letting the additions round costs 34 * 2^-11 A_q = 0.0166 A_q: twice as loose.)
 //   tests/test_pq_filter_bound.py replays the arithmetic on the CPU.
 //
 // A row whose approx is within eps of the query's bound tau_q goes to the query's candidate list; the finish kernel
@@ -55,7 +56,6 @@ constexpr int PF_LUT_BYTES = PF_KSUB * PF_M * PF_Q * 2; // 131072
 constexpr int PF_CTL_BYTES = 1024;
 constexpr int PF_SAMPLE = 4096; // = MS_SAMPLE (mfma_scan.hip): dump columns per query
 constexpr float PF_U = 5.9604645e-8f;        // 2^-24
-constexpr float PF_UH = 4.8828125e-4f;       // 2^-11
 
 typedef _Float16 pf_h2 __attribute__((ext_vector_type(2)));
 typedef _Float16 pf_h8 __attribute__((ext_vector_type(8))); // one LUT entry: the 8 queries' halves
@@ -210,20 +210,18 @@ __global__ __launch_bounds__(PF_KSUB) void pqf_query_table_kernel(const float* _
             }
             A += a;
         }
+        // INTEGER table: entries rint(Qf * sc) with sc = 2032 / A.  The per-m maxima of the rounded entries sum to at
+        // most 2032 + 32 * 0.5 = 2048, so every partial sum of a vector's 32 entries is an integer of magnitude <= 2048:
+        // exactly representable in half precision -- the 32 half additions are EXACT, in any order.  What is left is the
+        // rounding of the entries themselves: half a unit each, 16 units in all (+ the fp32 roundings of Qf * sc, < 0.01).
         float sc = 1.0f, eps = INFINITY;
         if (A < INFINITY) {
-            int ex = 0;
-            if (A > 0.f) {
-                (void)frexpf(A, &ex); // A = f * 2^ex, f in [0.5, 1)
+            sc = A > 0.f ? 2032.0f / A : 1.0f;
+            if (sc < INFINITY) {
+                eps = 16.5f / sc + 64.0f * PF_U * (pabs_max + A);
             } else {
-                ex = 14;
+                sc = 1.0f; // (a table of subnormal magnitude: no bound, the query takes the exact kernels)
             }
-            int e = 14 - ex;          // A * 2^e in [2^13, 2^14)
-            e = e < -100 ? -100 : (e > 100 ? 100 : e);
-            sc = ldexpf(1.0f, e);
-            // (last term: a scaled entry below the half normal range 2^-14 is rounded to a multiple of 2^-24 instead
-            // of relative 2^-11; additions of such values are exact)
-            eps = 34.0f * PF_UH * A + 64.0f * PF_U * (pabs_max + A) + 33.0f * 2.9802322e-8f / sc;
         }
         s_sc = sc;
         qs[q * 4 + 0] = sc;
@@ -237,8 +235,8 @@ __global__ __launch_bounds__(PF_KSUB) void pqf_query_table_kernel(const float* _
 #pragma unroll
     for (int l16 = 0; l16 < 16; l16++) {
         pf_h2 h;
-        h.x = (_Float16)(v[l16] * sc);      // (power-of-two scale: exact unless the half goes subnormal)
-        h.y = (_Float16)(v[l16 + 16] * sc);
+        h.x = (_Float16)rintf(v[l16] * sc); // (an integer of magnitude <= 2033: exact in half precision)
+        h.y = (_Float16)rintf(v[l16 + 16] * sc);
         out[((c >> 2) * 16 + l16) * 4 + (c & 3)] = __builtin_bit_cast(uint32_t, h);
     }
 }

@@ -65,15 +65,13 @@ def query_table(q, cb, is_l2, pabs_max):
     A = f32(0)
     for m in range(M):
         A = f32(A + np.abs(Qf[m]).max())
-    ex = np.frexp(A)[1] if A > 0 else 14
-    e = int(np.clip(14 - ex, -100, 100))
-    sc = f32(np.ldexp(1.0, e))
-    eps = f32(f32(34.0) * UH * A + f32(64.0) * U * f32(pabs_max + A) + f32(33.0) * f32(2.0 ** -25) / sc)
+    sc = f32(f32(2032.0) / A) if A > 0 else f32(1.0)
+    eps = f32(f32(16.5) / sc + f32(64.0) * U * f32(pabs_max + A))
     qh = np.zeros((KSUB // 4, 16, 4, 2), f16)
     for c in range(KSUB):
         for l16 in range(16):
-            qh[c >> 2, l16, c & 3, 0] = f16(f32(Qf[l16, c] * sc))
-            qh[c >> 2, l16, c & 3, 1] = f16(f32(Qf[l16 + 16, c] * sc))
+            qh[c >> 2, l16, c & 3, 0] = f16(np.rint(f32(Qf[l16, c] * sc)))
+            qh[c >> 2, l16, c & 3, 1] = f16(np.rint(f32(Qf[l16 + 16, c] * sc)))
     return qh, sc, f32(1.0) / sc, eps, T
 
 
@@ -225,7 +223,7 @@ def test_lut_transposition_matches_the_tables():
         q = rng.standard_normal(M * DSUB).astype(f32)
         qh, sc, _, _, T = query_table(q, cb, True, f32(0))
         tabs.append(qh)
-        plain.append(((f32(-2.0) * T).astype(f32) * sc).astype(f32).astype(f16))  # [m][c]
+        plain.append(np.rint(((f32(-2.0) * T).astype(f32) * sc).astype(f32)).astype(f16))  # [m][c]
     lds = build_lut(tabs).view(f16).reshape(KSUB, M, 8)
     for j in range(8):
         assert np.array_equal(lds[:, :, j].view(np.uint16), plain[j].T.view(np.uint16))

@@ -2,7 +2,8 @@
 
 DESIGN.md section 7 item 2: an approximate ADC pass (per-query table -2<q_m, cb> in f16, 32 v_pk_add_f16 per vector,
 per-vector constant sum_m precomp[list][m][c_m]) runs the loop 2.1x faster (tools/ubench/adc_loop), but its error
-bound is ~33 * 2^-11 * sum_m max_c |table_m|.  This script builds a real IVF-PQ index through the product ABI, replays
+bound is ~33 * 2^-11 * sum_m max_c |table_m|  (the kernel written afterwards uses an integer table whose half additions
+are exact: half that bound -- the counts below are therefore upper bounds of what it lets through).  This script builds a real IVF-PQ index through the product ABI, replays
 both the exact (fp32, reference order) and the f16 sums with torch for a sample of queries, and reports
   * the observed |approx - exact| against the bound,
   * rows with approx <= tau + bound (what the filter would hand to the exact finish) vs k, tau = exact k-th distance.
