@@ -53,10 +53,10 @@ MFMA_F16_PEAK_TFLOPS = 2500.0          # dense f16 / bf16 matrix peak (SQ8 prefi
 CONFIGS = {
     # BASELINE.json configs[1]
     "C2": dict(kind="ivfflat", metric="l2", nb=10_000_000, d=128, nlist=4096, nprobe=64, nq=10000, k=10, m=0,
-               refine_k=0, data="mixture", train_per_centroid=256, niter=25),
+               refine_k=0, data="mixture", train_per_centroid=256, niter=10),
     # BASELINE.json configs[2]: the metric's configuration
     "C3": dict(kind="ivfpq", metric="l2", nb=100_000_000, d=128, nlist=16384, nprobe=128, nq=10000, k=10, m=32,
-               refine_k=100, data="mixture", train_per_centroid=256, niter=25),
+               refine_k=100, data="mixture", train_per_centroid=256, niter=10),
     # BASELINE.json configs[4]; 65536 x 768 centroids: fewer training points / iterations keep the build in minutes
     "C5": dict(kind="ivfsq8", metric="ip", nb=100_000_000, d=768, nlist=65536, nprobe=256, nq=10000, k=10, m=0,
                refine_k=0, data="int8", train_per_centroid=32, niter=10),

@@ -128,8 +128,14 @@ int knhip_index_add_vectors_device(knhip_index* idx, int64_t n, const float* d_x
  *                        ProductQuantizer::train (impl/ProductQuantizer.cpp:130-215, one 256-centroid k-means per
  *                        sub-space on residuals) / ScalarQuantizer::train (QT_8bit, RS_minmax).  Same sub-sampling
  *                        draws (rand_perm with the reference's seeds), same initial centroids, same update and
- *                        empty-cluster split arithmetic; the assignment is the exact sequential search (the
- *                        reference switches to a BLAS expansion above its batch threshold: near-ties may differ).
+ *                        empty-cluster split arithmetic, spherical k-means (Clustering::post_process_centroids ->
+ *                        fvec_renorm_L2, Clustering.cpp:35-38) for the inner product as IndexIVF's constructor sets
+ *                        it (IndexIVF.cpp:178-181), 10 iterations for the level-1 quantizer (IndexIVF.cpp:44) and 25
+ *                        for the PQ codebooks; the assignment is the exact sequential search (the reference switches
+ *                        to a BLAS expansion above its batch threshold: near-ties may differ).  Pinned:
+ *                        tests/test_oracle.py::test_train_add_restatement_equals_reference (oracle.c == the
+ *                        reference's own IndexIVF::train + add, bit for bit, L2 and IP, default parameters) and
+ *                        tests/test_gpu_build.py (this library == oracle.c and == reference-generated goldens).
  *                        Coarse centroids already set (knhip_index_set_coarse*) are kept.
  *   knhip_index_add*     IndexIVF::add_core (IndexIVF.cpp:212-287): quantizer->assign, encode_vectors
  *                        (compute_residual + ProductQuantizer::compute_code / SQ8 encode_vector), append to the
@@ -137,11 +143,17 @@ int knhip_index_add_vectors_device(knhip_index* idx, int64_t n, const float* d_x
  *                        current count (what Knowhere passes), otherwise ascending ids larger than the stored ones.
  *                        Codes and assignments are bit-equal to the scalar reference (oracle.c orc_pq_encode ...).
  *   knhip_kmeans_device  the Clustering restatement alone (k-means of device rows).
- * params NULL or zero fields => the reference defaults (25 iterations, 256 points per centroid, seed 1234). */
+ * params NULL or zero fields => the reference defaults: 256 points per centroid, seed 1234; iterations 10 for the
+ * level-1 quantizer of knhip_index_train* (Level1Quantizer, IndexIVF.cpp:44) and 25 for knhip_kmeans_device
+ * (ClusteringParameters); spherical 0 = what the reference does (on for an inner-product index's level-1 quantizer,
+ * off for knhip_kmeans_device), 1 = on, 2 = off.  niter applies to the level-1 quantizer only: the PQ codebooks always
+ * train with the ClusteringParameters defaults, as ProductQuantizer::train does. */
 typedef struct knhip_train_params {
     int32_t niter;
     int32_t max_points_per_centroid;
     int64_t seed;
+    int32_t spherical;
+    int32_t reserved;
 } knhip_train_params;
 int knhip_kmeans_device(int32_t metric, int32_t dim, int64_t n, const float* d_x, int64_t k,
                         const knhip_train_params* params, float* d_centroids, int32_t device);

@@ -56,7 +56,8 @@ SYMBOLS = [
 
 
 class TrainParams(C.Structure):
-    _fields_ = [("niter", C.c_int32), ("max_points_per_centroid", C.c_int32), ("seed", C.c_int64)]
+    _fields_ = [("niter", C.c_int32), ("max_points_per_centroid", C.c_int32), ("seed", C.c_int64),
+                ("spherical", C.c_int32), ("reserved", C.c_int32)]
 
 
 _lib = None

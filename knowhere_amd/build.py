@@ -175,7 +175,7 @@ class BuiltIndex:
         return ix
 
 
-def build_ivf(spec, kind, metric, nlist, M=32, device="cuda:0", train_per_centroid=256, niter=25,
+def build_ivf(spec, kind, metric, nlist, M=32, device="cuda:0", train_per_centroid=256, niter=None,
               pq_train=1 << 20, centroids=None, codebooks=None, sq_trained=None, row_range=None, verbose=False,
               keep_vectors=False, train_only=False, owned_lists=None):
     """Train (unless centroids/codebooks are given, e.g. broadcast from rank 0) and encode

@@ -3,7 +3,9 @@
 // What they restate (reference, all under thirdparty/faiss/faiss unless noted):
 //   k-means            Clustering::train_encoded (Clustering.cpp:150-380): assignment by the index's own exact search
 //                      (k = 1), detail::compute_centroids (impl/ClusteringHelpers.cpp:101-171: members summed in
-//                      index order, then scaled by 1 / count), detail::split_clusters (:177-240, on the host).
+//                      index order, then scaled by 1 / count), detail::split_clusters (:177-240, on the host),
+//                      post_process_centroids (Clustering.cpp:35-38: spherical renormalisation, what IndexIVF turns
+//                      on for the inner product, IndexIVF.cpp:178-181).
 //   residual           Index::compute_residual (Index.cpp): x - centroid, element-wise.
 //   PQ encode          ProductQuantizer::compute_code (impl/ProductQuantizer.cpp:230-299) ->
 //                      fvec_L2sqr_ny_nearest (utils/distances_simd.cpp:106-125): exact squared L2 to the 256 entries of
@@ -323,6 +325,39 @@ hipError_t launch_centroid_update(const float* x, int64_t ld, int off, int dsub,
                                   const int64_t* seg_off, int64_t k, float* centroids, float* hassign, hipStream_t s) {
     hipLaunchKernelGGL(centroid_update_kernel, dim3((unsigned)((k * dsub + 255) / 256)), dim3(256), 0, s, x, ld, off, dsub,
                        sorted_rows, seg_off, k, centroids, hassign);
+    return hipGetLastError();
+}
+
+// spherical k-means (Clustering::post_process_centroids, Clustering.cpp:35-38 -> fvec_renorm_L2, utils/distances.cpp:
+// 238-275): every row of non-zero squared norm (sequential float sum) is scaled by (float)(1.0 / sqrtf(norm2)).
+// One thread per row for the norm (k <= 65536 rows), then one thread per element.
+__global__ void row_inv_norm_kernel(const float* __restrict__ x, int64_t k, int d, float* __restrict__ inv) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= k) {
+        return;
+    }
+    const float* xi = x + c * d;
+    float nr = 0.f;
+    for (int j = 0; j < d; j++) {
+        nr = fadd_x(nr, fmul_x(xi[j], xi[j]));
+    }
+    inv[c] = nr > 0.f ? (float)__ddiv_rn(1.0, (double)__fsqrt_rn(nr)) : 1.0f;
+}
+
+__global__ void row_scale_kernel(float* __restrict__ x, int64_t k, int d, const float* __restrict__ inv) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= k * d) {
+        return;
+    }
+    const float f = inv[t / d];
+    if (f != 1.0f) {  // (a zero row keeps its bits; x * 1.0f is the identity anyway)
+        x[t] = fmul_x(x[t], f);
+    }
+}
+
+hipError_t launch_renorm_rows(float* x, int64_t k, int d, float* inv_tmp, hipStream_t s) {
+    hipLaunchKernelGGL(row_inv_norm_kernel, dim3((unsigned)((k + 63) / 64)), dim3(64), 0, s, x, k, d, inv_tmp);
+    hipLaunchKernelGGL(row_scale_kernel, dim3((unsigned)((k * d + 255) / 256)), dim3(256), 0, s, x, k, d, inv_tmp);
     return hipGetLastError();
 }
 

@@ -2316,17 +2316,25 @@ int split_clusters_host(int d, int64_t k, int64_t n, std::vector<float>& hassign
 }
 
 struct TrainParams {
-    int niter = 25;
+    int niter = 25;          // ClusteringParameters default (Clustering.h); the level-1 quantizer overrides it with 10
     int max_points = 256;
     int64_t seed = 1234;
+    bool spherical = false;  // Clustering::post_process_centroids renormalises the centroids
 };
 
-TrainParams resolve(const knhip_train_params* p) {
+// default_niter: 25 for a plain Clustering (PQ codebooks, knhip_kmeans_device), 10 for the level-1 quantizer of an IVF
+// index (Level1Quantizer's constructor, IndexIVF.cpp:44).  default_spherical: what the caller's metric implies
+// (IndexIVF's constructor switches it on for the inner product, IndexIVF.cpp:178-181).
+TrainParams resolve(const knhip_train_params* p, int default_niter, bool default_spherical) {
     TrainParams t;
+    t.niter = default_niter;
+    t.spherical = default_spherical;
     if (p) {
         if (p->niter > 0) t.niter = p->niter;
         if (p->max_points_per_centroid > 0) t.max_points = p->max_points_per_centroid;
         if (p->seed != 0) t.seed = p->seed;
+        if (p->spherical == 1) t.spherical = true;
+        if (p->spherical == 2) t.spherical = false;
     }
     return t;
 }
@@ -2341,7 +2349,8 @@ int kmeans_impl(int device, int metric, int d, int64_t n, const float* d_x, int6
     if (n < k || k <= 0 || d <= 0) {
         return fail(KNHIP_ERR_INVALID_ARGS, "k-means needs at least as many training vectors as centroids");
     }
-    const bool small = k <= 1024 && d <= 64 && metric == KNHIP_L2;
+    // (the LDS codebook kernel keeps k x d floats in one workgroup's LDS: 160 KB on gfx950, 8 KB left for the compiler)
+    const bool small = k <= 1024 && d <= 64 && metric == KNHIP_L2 && (size_t)k * d * sizeof(float) <= 152 * 1024;
     if (!small && (ld != d || off != 0)) {
         return fail(KNHIP_ERR_INVALID_ARGS, "k-means: strided input only with a small codebook");
     }
@@ -2392,7 +2401,14 @@ int kmeans_impl(int device, int metric, int d, int64_t n, const float* d_x, int6
         HIP_TRY(launch_gather_rows(xs, pb.as<int64_t>(), k, d, d_cen, nullptr));
         HIP_TRY(hipDeviceSynchronize());
     }
-    // -- iterations
+    DevBuf inv_norm;
+    if (tp.spherical) { // post_process_centroids after the initialisation (Clustering.cpp:251)
+        HIP_TRY(inv_norm.alloc((size_t)k * sizeof(float)));
+        HIP_TRY(launch_renorm_rows(d_cen, k, d, inv_norm.as<float>(), nullptr));
+    }
+    // -- iterations.  (The reference leaves the loop when the objective repeats bit for bit, Clustering.cpp:362-377 with
+    // early_stop_threshold 0: that is the fixed point of this deterministic loop, where further iterations reproduce
+    // the same centroids -- running them changes nothing.)
     DevBuf keys64, dist, keys32, sorted_rows, seg_off, tmp, hassign_d;
     HIP_TRY(sorted_rows.alloc((size_t)nx * sizeof(int32_t)));
     HIP_TRY(seg_off.alloc((size_t)(k + 1) * sizeof(int64_t)));
@@ -2442,6 +2458,9 @@ int kmeans_impl(int device, int metric, int d, int64_t n, const float* d_x, int6
             HIP_TRY(hipMemcpy(cen_h.data(), d_cen, cen_h.size() * sizeof(float), hipMemcpyDeviceToHost));
             split_clusters_host(d, k, nx, hassign, cen_h);
             HIP_TRY(hipMemcpy(d_cen, cen_h.data(), cen_h.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
+        if (tp.spherical) { // post_process_centroids after the update and the split (Clustering.cpp:347)
+            HIP_TRY(launch_renorm_rows(d_cen, k, d, inv_norm.as<float>(), nullptr));
         }
     }
     HIP_TRY(hipDeviceSynchronize());
@@ -2581,7 +2600,7 @@ int train_device_impl(knhip_index* idx, int64_t n, const float* d_x, const knhip
     if (n <= 0 || !d_x) {
         return fail(KNHIP_ERR_INVALID_ARGS, "train: no training vectors");
     }
-    const TrainParams tp = resolve(p);
+    const TrainParams tp = resolve(p, 10, idx->desc.metric == KNHIP_IP);
     const int d = idx->d;
     const int64_t nlist = idx->nlist;
     const int dev = idx->desc.device;
@@ -2659,7 +2678,7 @@ int knhip_kmeans_device(int32_t metric, int32_t dim, int64_t n, const float* d_x
     if (!d_x || !d_centroids || (metric != KNHIP_L2 && metric != KNHIP_IP)) {
         return fail(KNHIP_ERR_INVALID_ARGS, "kmeans: bad arguments");
     }
-    return kmeans_impl(device, metric, dim, n, d_x, dim, 0, k, resolve(params), d_centroids);
+    return kmeans_impl(device, metric, dim, n, d_x, dim, 0, k, resolve(params, 25, false), d_centroids);
 }
 
 int knhip_index_train_device(knhip_index* idx, int64_t n, const float* d_x, const knhip_train_params* params) {
@@ -2679,7 +2698,7 @@ int knhip_index_train(knhip_index* idx, int64_t n, const float* x, const knhip_t
     // Only the rows k-means and the encoder can use are uploaded: the reference subsamples to
     // max(nlist * max_points_per_centroid, train_encoder_num_vectors) rows of two rand_perm draws; both draws index
     // the SAME caller array, so upload the union once is not possible without changing the draws -> upload all rows
-    // when they fit a quarter of the free HBM, otherwise fail loudly (stream in slices via knhip_index_train_device).
+    // when they fit half of the free HBM, otherwise fail loudly (stream in slices via knhip_index_train_device).
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     const size_t bytes = (size_t)n * idx->d * sizeof(float);

@@ -281,13 +281,13 @@ class GpuIndex:
                 "mscan_candidates": st.mscan_candidates, "mscan_stream_bytes": st.mscan_stream_bytes}
 
 
-def kmeans_device(metric, x_t, k, niter=None, max_points=None, seed=None):
+def kmeans_device(metric, x_t, k, niter=None, max_points=None, seed=None, spherical=False):
     """faiss Clustering restated on the device (knhip_kmeans_device): x_t [n, d] device tensor -> centroids [k, d]"""
     import torch
     L = _lib.load()
     cen = torch.empty((k, x_t.shape[1]), dtype=torch.float32, device=x_t.device)
-    tp = None if (niter is None and max_points is None and seed is None) else C.byref(
-        _lib.TrainParams(niter or 0, max_points or 0, seed or 0))
+    tp = None if (niter is None and max_points is None and seed is None and not spherical) else C.byref(
+        _lib.TrainParams(niter or 0, max_points or 0, seed or 0, 1 if spherical else 0, 0))
     check(L.knhip_kmeans_device(metric, x_t.shape[1], x_t.shape[0], _t_ptr(x_t), k, tp, _t_ptr(cen),
                                 x_t.device.index or 0))
     return cen

@@ -397,17 +397,18 @@ class Port(_SimdTable):
         self.lib.orc_rand_perm(_p(out, _i64p), C.c_int64(n), C.c_int64(seed))
         return out
 
-    def kmeans(self, metric, x, k, niter=25, max_points=256, seed=1234, ld=None, off=0, d=None):
+    def kmeans(self, metric, x, k, niter=25, max_points=256, seed=1234, ld=None, off=0, d=None, spherical=False):
         x = np.ascontiguousarray(x, np.float32)
         ld = x.shape[1] if ld is None else ld
         d = x.shape[1] if d is None else d
         cen = np.empty((k, d), np.float32)
         self.lib.orc_kmeans(C.c_int(metric), C.c_int(d), C.c_int64(x.shape[0]), _p(x, _f32p), C.c_int64(ld), C.c_int(off),
-                            C.c_int64(k), C.c_int(niter), C.c_int(max_points), C.c_int64(seed), _p(cen, _f32p))
+                            C.c_int64(k), C.c_int(niter), C.c_int(max_points), C.c_int64(seed),
+                            C.c_int(1 if spherical else 0), _p(cen, _f32p))
         return cen
 
-    def train_ivf(self, kind, metric, x, nlist, M=0, niter=25, max_points=256, seed=1234, centroids=None):
-        """-> (centroids, pq_centroids or None, sq_trained or None)"""
+    def train_ivf(self, kind, metric, x, nlist, M=0, niter=0, max_points=256, seed=1234, centroids=None):
+        """-> (centroids, pq_centroids or None, sq_trained or None); niter 0 = the level-1 quantizer's default (10)"""
         x = np.ascontiguousarray(x, np.float32)
         n, d = x.shape
         given = centroids is not None
@@ -532,12 +533,12 @@ class Ref(_SimdTable):
     def free(self, h):
         self.destroy(h)
 
-    def kmeans(self, metric, x, k, niter=25, max_points=256, seed=1234):
+    def kmeans(self, metric, x, k, niter=25, max_points=256, seed=1234, spherical=False):
         x = np.ascontiguousarray(x, np.float32)
         cen = np.empty((k, x.shape[1]), np.float32)
         self._chk(self.lib.ref_kmeans(C.c_int(metric), C.c_int(x.shape[1]), C.c_int64(x.shape[0]), _p(x, _f32p),
                                       C.c_int64(k), C.c_int(niter), C.c_int(max_points), C.c_int64(seed),
-                                      _p(cen, _f32p)))
+                                      C.c_int(1 if spherical else 0), _p(cen, _f32p)))
         return cen
 
     def _chk(self, rc):

@@ -932,8 +932,8 @@ int orc_merge_topk(int metric, int64_t nq, int64_t k, int nshard, const float* D
  * Build-side helpers (restated add path), used to make test indexes on boxes without _ref.
  * ---------------------------------------------------------------------------------------- */
 /* IndexFlat::assign == search with k=1: first strict improvement wins */
-void orc_assign(int metric, int d, int64_t nlist, const float* centroids, int64_t n, const float* x,
-                int64_t* out) {
+void orc_assign_dis(int metric, int d, int64_t nlist, const float* centroids, int64_t n, const float* x,
+                    int64_t* out, float* out_dis) {
     for (int64_t i = 0; i < n; i++) {
         const float* xi = x + i * (int64_t)d;
         int64_t best = -1;
@@ -955,7 +955,15 @@ void orc_assign(int metric, int d, int64_t nlist, const float* centroids, int64_
             }
         }
         out[i] = best;
+        if (out_dis) {
+            out_dis[i] = bd;
+        }
     }
+}
+
+void orc_assign(int metric, int d, int64_t nlist, const float* centroids, int64_t n, const float* x,
+                int64_t* out) {
+    orc_assign_dis(metric, d, nlist, centroids, n, x, out, NULL);
 }
 
 /* T:impl/ProductQuantizer.cpp:250-280 compute_1_code (nbits = 8): per sub-vector the nearest
@@ -1052,8 +1060,26 @@ void orc_rand_perm(int64_t* perm, int64_t n, int64_t seed) {
 /* T:Clustering.cpp:95-380 Clustering::train_encoded (nredo 1, RANDOM init, no weights, no early stop) with an exact
  * k = 1 search as the assigner; T:impl/ClusteringHelpers.cpp:36-240 subsample_training_set / compute_centroids /
  * split_clusters.  x: n rows of leading dimension ld, the clustered vector = columns [off, off + d). */
+/* T:utils/distances.cpp:238-275 fvec_renorm_L2: rows of non-zero norm scaled by (float)(1.0 / sqrtf(norm2)) */
+void orc_renorm_L2(int d, int64_t n, float* x) {
+    for (int64_t i = 0; i < n; i++) {
+        float* xi = x + i * d;
+        const float nr = orc_fvec_norm_L2sqr(xi, (size_t)d);
+        if (nr > 0) {
+            const float inv_nr = (float)(1.0 / sqrtf(nr));
+            for (int j = 0; j < d; j++) {
+                xi[j] *= inv_nr;
+            }
+        }
+    }
+}
+
+/* spherical != 0: Clustering::post_process_centroids (T:Clustering.cpp:35-38) renormalises the centroids after the
+ * initialisation (:251) and after every update (:347) -- what IndexIVF switches on for the inner product
+ * (T:IndexIVF.cpp:178-181).  The iteration loop ends early when the objective (sum of the assignment distances, float,
+ * in row order) repeats bit for bit (early_stop_threshold 0: T:Clustering.cpp:362-377, src/index/clustering_config.h:34). */
 void orc_kmeans(int metric, int d, int64_t n, const float* x, int64_t ld, int off, int64_t k, int niter,
-                int max_points, int64_t seed, float* centroids) {
+                int max_points, int64_t seed, int spherical, float* centroids) {
     int64_t nx = n;
     int64_t* perm = (int64_t*)malloc(sizeof(int64_t) * (size_t)n);
     if (n > k * (int64_t)max_points) {
@@ -1080,10 +1106,19 @@ void orc_kmeans(int metric, int d, int64_t n, const float* x, int64_t ld, int of
         memcpy(centroids + i * d, xs + p2[i] * d, sizeof(float) * (size_t)d);
     }
     free(p2);
+    if (spherical) {
+        orc_renorm_L2(d, k, centroids);
+    }
     int64_t* assign = (int64_t*)malloc(sizeof(int64_t) * (size_t)nx);
+    float* adis = (float*)malloc(sizeof(float) * (size_t)nx);
     float* hassign = (float*)malloc(sizeof(float) * (size_t)k);
+    float prev_obj = 0;
     for (int it = 0; it < niter; it++) {
-        orc_assign(metric, d, k, centroids, nx, xs, assign);
+        orc_assign_dis(metric, d, k, centroids, nx, xs, assign, adis);
+        float obj = 0;
+        for (int64_t i = 0; i < nx; i++) {
+            obj += adis[i];
+        }
         /* compute_centroids: members summed in index order, scaled by 1 / count */
         memset(centroids, 0, sizeof(float) * (size_t)k * (size_t)d);
         memset(hassign, 0, sizeof(float) * (size_t)k);
@@ -1147,8 +1182,19 @@ void orc_kmeans(int metric, int d, int64_t n, const float* x, int64_t ld, int of
                 hassign[cj] -= hassign[ci];
             }
         }
+        if (spherical) {
+            orc_renorm_L2(d, k, centroids);
+        }
+        if (it > 0) {
+            const double change = (prev_obj == 0) ? DBL_MAX : fabs((double)(prev_obj - obj)) / fabs((double)prev_obj);
+            if (change <= 0.0) {
+                break;
+            }
+        }
+        prev_obj = obj;
     }
     free(hassign);
+    free(adis);
     free(assign);
     free(xs);
     free(perm);
@@ -1162,7 +1208,9 @@ void orc_train_ivf(int kind, int metric, int d, int64_t nlist, int M, int64_t n,
                    int max_points, int64_t seed, int coarse_given, float* centroids, float* pq_centroids,
                    float* sq_trained) {
     if (!coarse_given) {
-        orc_kmeans(metric, d, n, x, d, 0, nlist, niter, max_points, seed, centroids);
+        /* level-1 quantizer: cp.niter = 10 unless the caller overrides it (T:IndexIVF.cpp:44), spherical for the inner
+         * product (T:IndexIVF.cpp:178-181) */
+        orc_kmeans(metric, d, n, x, d, 0, nlist, niter > 0 ? niter : 10, max_points, seed, metric == ORC_IP, centroids);
     }
     if (kind == 1) {
         return;
@@ -1192,7 +1240,7 @@ void orc_train_ivf(int kind, int metric, int d, int64_t nlist, int M, int64_t n,
     if (kind == 2) {
         const int dsub = d / M;
         for (int m = 0; m < M; m++) {
-            orc_kmeans(ORC_L2, dsub, nt, xt, d, m * dsub, 256, 25, 256, 1234, pq_centroids + (size_t)m * 256 * dsub);
+            orc_kmeans(ORC_L2, dsub, nt, xt, d, m * dsub, 256, 25, 256, 1234, 0, pq_centroids + (size_t)m * 256 * dsub);
         }
     } else {
         for (int j = 0; j < d; j++) {

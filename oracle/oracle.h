@@ -138,6 +138,8 @@ int orc_merge_topk(int metric, int64_t nq, int64_t k, int nshard, const float* D
 /* nearest centroid by the metric (IndexFlat::assign) */
 void orc_assign(int metric, int d, int64_t nlist, const float* centroids, int64_t n, const float* x,
                 int64_t* out);
+void orc_assign_dis(int metric, int d, int64_t nlist, const float* centroids, int64_t n, const float* x,
+                    int64_t* out, float* out_dis);
 /* PQ encode one (residual) vector: T:impl/ProductQuantizer.cpp:282-299 compute_code */
 void orc_pq_compute_code(int d, int M, int nbits, const float* pq_centroids, const float* x,
                          uint8_t* code);
@@ -147,8 +149,11 @@ void orc_sq8_decode(int d, const float* trained, const uint8_t* code, float* x);
 
 /* training restatements (Clustering / IndexIVF::train), see oracle.c */
 void orc_rand_perm(int64_t* perm, int64_t n, int64_t seed);
+void orc_renorm_L2(int d, int64_t n, float* x);
 void orc_kmeans(int metric, int d, int64_t n, const float* x, int64_t ld, int off, int64_t k, int niter,
-                int max_points, int64_t seed, float* centroids);
+                int max_points, int64_t seed, int spherical, float* centroids);
+/* niter <= 0: the level-1 quantizer's own default (10, T:IndexIVF.cpp:44); the PQ codebooks always train with the
+ * ClusteringParameters default (25).  The coarse k-means is spherical for the inner product (T:IndexIVF.cpp:178-181) */
 void orc_train_ivf(int kind, int metric, int d, int64_t nlist, int M, int64_t n, const float* x, int niter,
                    int max_points, int64_t seed, int coarse_given, float* centroids, float* pq_centroids,
                    float* sq_trained);

@@ -124,13 +124,14 @@ void ref_destroy(void* hv) {
 // orc_kmeans.  Bit-reproducible only while the assigner stays on its sequential path (fewer than
 // distance_compute_blas_threshold = 20 training points), which is what the pin test uses.
 int ref_kmeans(int metric, int d, int64_t n, const float* x, int64_t k, int niter, int max_points, int64_t seed,
-               float* centroids) {
+               int spherical, float* centroids) {
     return guarded([&] {
         faiss::ClusteringParameters cp;
         cp.niter = niter;
         cp.max_points_per_centroid = max_points;
         cp.min_points_per_centroid = 1;
         cp.seed = (int)seed;
+        cp.spherical = spherical != 0;
         faiss::Clustering clus(d, (int)k, cp);
         faiss::IndexFlat index(d, metric == 0 ? faiss::METRIC_L2 : faiss::METRIC_INNER_PRODUCT);
         clus.train(n, x, index);

@@ -34,6 +34,62 @@ def test_kmeans_equals_reference_restatement(torch_cuda, port, n, d, k, metric, 
     assert cen.cpu().numpy().tobytes() == co.tobytes(), f"k-means centroids differ (n={n} d={d} k={k})"
 
 
+def test_spherical_kmeans(torch_cuda, port):
+    """Clustering::post_process_centroids with spherical = true (what IndexIVF sets for the inner product)"""
+    torch = torch_cuda
+    from knowhere_amd.index import kmeans_device
+    for n, d, k in ((5000, 32, 24), (6000, 128, 40)):
+        x = gen_data(n, d, 42, -3.0, 7.0)
+        cen = kmeans_device(ob.IP, torch.from_numpy(x).cuda(), k, niter=7, spherical=True)
+        torch.cuda.synchronize()
+        co = port.kmeans(ob.IP, x, k, niter=7, spherical=True)
+        assert cen.cpu().numpy().tobytes() == co.tobytes()
+        assert np.allclose(np.linalg.norm(co, axis=1), 1.0, atol=1e-5)
+
+
+def test_kmeans_codebook_larger_than_lds(torch_cuda, port):
+    """k x d floats above the 160 KB of one workgroup's LDS (d = 64, k = 1024) take the coarse-quantizer path"""
+    torch = torch_cuda
+    from knowhere_amd.index import kmeans_device
+    x = gen_data(5000, 64, 42, -3.0, 7.0)
+    cen = kmeans_device(ob.L2, torch.from_numpy(x).cuda(), 1024, niter=3)
+    torch.cuda.synchronize()
+    assert cen.cpu().numpy().tobytes() == port.kmeans(ob.L2, x, 1024, niter=3).tobytes()
+
+
+def _ivf_goldens():
+    import os
+    from helpers import golden_files
+    from test_oracle import BLAS_NEAR_TIE  # (two fixtures whose reference training flips a near-tie inside sgemm)
+    return [p for p in golden_files() if not os.path.basename(p).startswith("flat_")
+            and os.path.basename(p)[:-4] not in BLAS_NEAR_TIE]
+
+
+@pytest.mark.parametrize("path", _ivf_goldens(), ids=lambda p: p.split("/")[-1][:-4])
+def test_train_add_rebuilds_the_reference_built_goldens(torch_cuda, path):
+    """knhip_index_train + knhip_index_add at DEFAULT parameters on gen(nb, d, 42) == the bytes of the index the
+    reference's own IndexIVF::train + add built from the same rows (tests/golden/make_golden.py): centroids (spherical
+    for the inner product, 10 level-1 iterations), PQ codebooks, SQ8 ranges, list sizes, ids and codes"""
+    from helpers import load_golden
+    from knowhere_amd import GpuIndex
+    ix, _, _ = load_golden(path)
+    nb = int(np.load(path)["nb"])
+    xb = gen_data(nb, ix.d, 42)
+    g = GpuIndex(ix.kind, ix.metric, ix.d, nlist=ix.nlist, pq_m=ix.M)
+    g.train(xb)
+    assert g.get_coarse().tobytes() == ix.centroids.tobytes(), "coarse centroids"
+    if ix.kind == ob.IVF_PQ:
+        assert g.get_pq().tobytes() == ix.pq_centroids.tobytes(), "PQ codebooks"
+    if ix.kind == ob.IVF_SQ8:
+        assert g.get_sq().tobytes() == ix.sq_trained.tobytes(), "SQ8 ranges"
+    g.add(xb)
+    sizes, codes, ids = g.get_lists()
+    assert (sizes == np.array([len(i) for i in ix.list_ids])).all(), "list sizes"
+    assert (ids == np.concatenate(ix.list_ids)).all(), "ids"
+    assert codes.tobytes() == np.concatenate([c.reshape(len(c), -1) for c in ix.list_codes]).tobytes(), "codes"
+    g.close()
+
+
 def test_kmeans_empty_cluster_split(torch_cuda, port):
     """duplicated points leave clusters empty: split_clusters (donor pick by the reference's RNG) must match"""
     torch = torch_cuda
@@ -46,7 +102,8 @@ def test_kmeans_empty_cluster_split(torch_cuda, port):
 
 
 @pytest.mark.parametrize("kind,M,metric", [(ob.IVF_PQ, 8, ob.L2), (ob.IVF_PQ, 32, ob.L2), (ob.IVF_PQ, 16, ob.IP),
-                                           (ob.IVF_SQ8, 0, ob.L2), (ob.IVF_SQ8, 0, ob.IP), (ob.IVF_FLAT, 0, ob.L2)])
+                                           (ob.IVF_SQ8, 0, ob.L2), (ob.IVF_SQ8, 0, ob.IP), (ob.IVF_FLAT, 0, ob.L2),
+                                           (ob.IVF_FLAT, 0, ob.IP)])
 def test_train_add_search_pipeline(torch_cuda, port, kind, M, metric):
     """Train + two Adds on the device == the restated reference pipeline; Search on the result == oracle search"""
     from knowhere_amd import GpuIndex

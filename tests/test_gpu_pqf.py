@@ -110,7 +110,10 @@ def test_pqf_overflow_goes_through_the_exact_kernel(torch_cuda, port, monkeypatc
     assert p["mscan_queries"] > 0
     bs = _bitset(nb, 0.997, 7)
     p = _check(port, ix, g0, g1, xq, 10, 100, ob.L2, "99.7 % filtered", bs, nb)
-    assert p["mscan_overflow_queries"] == len(xq)
+    # (18 unfiltered rows in all: a query whose sample happens to hold k of them gets a bound and is finished by the
+    # prefilter path; on hardware that is 1 query of 40)
+    assert p["mscan_overflow_queries"] >= len(xq) - 4
+    assert p["mscan_queries"] + p["mscan_overflow_queries"] == len(xq)
     g0.close()
     g1.close()
 
