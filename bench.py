@@ -303,12 +303,26 @@ def make_roofline(a, kind, prof, world):
     sec = scan_ms * 1e-3
     stages = {n: round(prof["ms"][i] / a.steps, 3) for i, n in
               enumerate(["coarse", "group", "lut", "scan", "merge", "other", "scan_rank0"])}
-    traffic = pmc_traffic(a, world)
     hbm_algo = scan_bytes / sec / 1e9 if sec > 0 else 0.0
-    common = {"algorithmic_bytes_per_launch": scan_bytes, "ms_per_launch": round(scan_ms, 3), "traffic": traffic,
+    common = {"algorithmic_bytes_per_launch": scan_bytes, "ms_per_launch": round(scan_ms, 3), "traffic": None,
               "hbm_algorithmic_GBps": round(hbm_algo, 1), "hbm_algorithmic_frac": round(hbm_algo / HBM_PEAK_GBPS, 4),
-              "hbm_measured_frac": round(traffic / sec / 1e9 / HBM_PEAK_GBPS, 4) if (traffic and sec > 0) else None,
-              "stage_ms_per_step": stages}
+              "hbm_measured_frac": None, "stage_ms_per_step": stages}
+
+    def with_pmc(out):
+        """attach the PMC evidence on file for the run's dominant kernel (or say that there is none)"""
+        e = pmc_entry(a, world, out["kernel"])
+        if e is None:
+            out["traffic_note"] = "no PMC pass on file for this workload and kernel (profiles/bench_pmc_traffic.json)"
+            return out
+        out["traffic"] = e.get("hbm_bytes_per_launch")
+        if out["traffic"] and sec > 0:
+            out["hbm_measured_frac"] = round(out["traffic"] / sec / 1e9 / HBM_PEAK_GBPS, 4)
+        out["traffic_source"] = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at commit {e.get('commit')}"
+        ub = unit_busy(e, sec)
+        if ub:
+            out["unit_busy"] = ub
+        return out
+
     cf = prof["coarse_flops"] / max(prof["launches"][S.STAGE_COARSE], 1)
     if stages["coarse"] > 0 and cf > 0:
         common["coarse_stage"] = {"bound": "mfma", "flops": cf, "ms": stages["coarse"],
@@ -318,37 +332,31 @@ def make_roofline(a, kind, prof, world):
         # one 4-byte table lookup per code byte: the LDS gather is the unit that binds (round-1 PMC: HBM traffic
         # is 0.03-0.14 x the algorithmic bytes, LDS ~ busy); SURVEY 8(d)'s no-reuse HBM model is kept beside it
         if prof.get("mscan_queries", 0) > 0:
-            # KNHIP_PQF=1: the half-precision prefilter (pq_filter.hip) is the dominant kernel: one 2-byte table lookup
-            # per code byte and query (16-byte entries hold 8 queries), survivors recomputed by the exact finish
+            # the matrix-core prefilter (pq_filter.hip) is the dominant kernel: one 2-byte table lookup per code byte and
+            # query (16-byte entries hold 8 queries; one ds_read_b128 feeds one v_mfma_f32_16x16x32_f16 = 512 lookups:
+            # the LDS gather at 4 cycles per wave-instruction and the matrix pipe at 16 cycles per instruction and SIMD
+            # bind at the same 128 lookups/clk/CU), survivors recomputed by the exact finish
             lds = scan_bytes * 2.0 / sec / 1e9 if sec > 0 else 0.0
             steps = max(a.steps, 1)
-            return dict({"bound": "lds", "kernel": "knhip::pqf_kernel<true, false>", "achieved": round(lds, 1),
+            kn = "knhip::pqf_kernel<true, false>" if a.metric == "l2" else "knhip::pqf_kernel<false, false>"
+            return with_pmc(dict({"bound": "lds", "kernel": kn, "achieved": round(lds, 1),
                          "peak": round(LDS_PEAK_GBPS, 1), "unit": "GB/s", "frac": round(lds / LDS_PEAK_GBPS, 4),
                          "note": "achieved = 2 B x code bytes scanned / launch time (half-precision table, 8 queries "
-                                 "per ds_read_b128); peak = 256 B/clk/CU x 256 CU x 2.4 GHz",
+                                 "per ds_read_b128 = one v_mfma_f32_16x16x32_f16); peak = 256 B/clk/CU x 256 CU x 2.4 GHz "
+                                 "(the matrix pipe binds at the same rate: 512 lookups per 16 cycles and SIMD)",
                          "lookups_per_ns_per_cu": round(scan_bytes / sec / 1e9 / 256.0, 1) if sec > 0 else None,
                          "mscan": {"queries_per_step": prof["mscan_queries"] / steps,
                                    "overflow_queries_per_step": prof["mscan_overflow_queries"] / steps,
                                    "candidates_per_query": round(prof["mscan_candidates"] /
-                                                                 max(prof["mscan_queries"], 1), 1)}}, **common)
+                                                                 max(prof["mscan_queries"], 1), 1)}}, **common))
         lds = scan_bytes * 4.0 / sec / 1e9 if sec > 0 else 0.0
         out = dict({"bound": "lds", "kernel": "knhip::pq_scan_q4_kernel<true, 2>", "achieved": round(lds, 1),
                     "peak": round(LDS_PEAK_GBPS, 1), "unit": "GB/s", "frac": round(lds / LDS_PEAK_GBPS, 4),
                     "note": "achieved = 4 B x code bytes scanned / launch time; peak = 256 B/clk/CU x 256 CU x 2.4 GHz"},
                    **common)
-        try:
-            sq = pmc_counters(a, world)
-        except Exception:
-            sq = None
-        if sq and sec > 0 and all(k in sq for k in ("SQ_INSTS_VALU", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE")):
-            # the loop is co-limited by VALU issue: the instruction counts of the PMC pass on file against
-            # this run's launch time; 4 cycles per instruction is the measured issue cost of the forms the loop uses
-            # (v_pk_add_f32 4.95, SDWA 4.2, plain VOP2 2.5: tools/ubench/valu_rates), 1024 SIMDs
-            out["valu_issue"] = {"SQ_INSTS_VALU_per_launch": sq["SQ_INSTS_VALU"], "cycles_per_inst_assumed": 4.0,
-                                 "frac_of_simd_cycles_at_2.4GHz": round(sq["SQ_INSTS_VALU"] * 4.0 / 1024 / 2.4e9 / sec, 4),
-                                 "lds_bank_conflict_frac": round(sq["SQ_LDS_BANK_CONFLICT"] / sq["SQ_LDS_IDX_ACTIVE"], 5),
-                                 "source": sq.get("source")}
-        return out
+        # (the loop is co-limited by VALU issue, DESIGN 4.2: unit_busy carries the LDS-array and VALU-issue fractions of the
+        # PMC passes on file for this kernel)
+        return with_pmc(out)
     if prof.get("mscan_queries", 0) > 0:
         # MFMA prefilter + exact finish (mfma_scan.hip): the dominant kernel is a grouped (rows of a list) x (queries
         # that probe it) x d contraction; every unit streams its list once for up to 64 (fp32 rows) / 32 (SQ8) queries.
@@ -366,6 +374,8 @@ def make_roofline(a, kind, prof, world):
         tf = flop / sec / 1e12 if sec > 0 else 0.0
         # HBM side: the measured traffic (PMC pass of this workload, profiles/bench_pmc_traffic.json) where there is one;
         # the bytes the units stream are an upper bound of it (units of one list share it through L2)
+        e = pmc_entry(a, world, kname)
+        traffic = e.get("hbm_bytes_per_launch") if e else None
         hbm_gbps = (traffic / sec / 1e9) if (traffic and sec > 0) else stream_gbps
         mfma_frac, hbm_frac = tf / peak, hbm_gbps / HBM_PEAK_GBPS
         steps = max(a.steps, 1)
@@ -377,12 +387,12 @@ def make_roofline(a, kind, prof, world):
                            "overflow_queries_per_step": prof["mscan_overflow_queries"] / steps,
                            "candidates_per_query": round(prof["mscan_candidates"] / max(prof["mscan_queries"], 1), 1)}}
         if mfma_frac >= hbm_frac:
-            return dict({"bound": "mfma", "kernel": kname, "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(mfma_frac, 4), "note": unit_note}, **common, **extra)
-        return dict({"bound": "hbm", "kernel": kname, "achieved": round(hbm_gbps, 1), "peak": HBM_PEAK_GBPS,
-                     "unit": "GB/s", "frac": round(hbm_frac, 4),
-                     "note": "achieved = HBM bytes per launch (PMC traffic where on file, else the bytes the units "
-                             "stream) / launch time"}, **common, **extra)
+            return with_pmc(dict({"bound": "mfma", "kernel": kname, "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
+                                  "frac": round(mfma_frac, 4), "note": unit_note}, **common, **extra))
+        return with_pmc(dict({"bound": "hbm", "kernel": kname, "achieved": round(hbm_gbps, 1), "peak": HBM_PEAK_GBPS,
+                              "unit": "GB/s", "frac": round(hbm_frac, 4),
+                              "note": "achieved = HBM bytes per launch (PMC traffic where on file, else the bytes the units "
+                                      "stream) / launch time"}, **common, **extra))
     # exact row scans: lane = row, the queries of a work item share each row fetch -> VALU-bound by construction:
     # per (row, query, dim) L2 = sub, mul, add; IP = mul, add (+ SQ8: decode fma per (row, dim))
     code_size = a.d * 4 if kind == kidx.IVF_FLAT else a.d
@@ -396,39 +406,55 @@ def make_roofline(a, kind, prof, world):
                          "peak = fp32 vector peak (an FMA counts 2)"}, **common)
 
 
-def pmc_key(a, world):
-    """key of a workload in profiles/bench_pmc_traffic.json (a PMC pass belongs to one kernel path: the half-precision
-    IVF-PQ prefilter, KNHIP_PQF=1, is a different dominant kernel than the exact ADC scan)"""
+def pmc_key(a, world, kernel):
+    """key of a workload in profiles/bench_pmc_traffic.json (a PMC pass belongs to one kernel path: the IVF-PQ prefilter is
+    a different dominant kernel than the exact ADC scan)"""
     key = (f"config={a.config},nb={a.nb},nlist={a.nlist},nprobe={a.nprobe},nq={a.nq},m={a.m},"
            f"refine_k={a.refine_k},gpus={world}")
-    if os.environ.get("KNHIP_PQF") == "1":
+    if "pqf_kernel" in kernel:
         key += ",pqf=1"
     return key
 
 
-def pmc_counters(a, world):
-    """SQ counters of the dominant kernel from the PMC passes on file (same key as pmc_traffic), or None"""
+def pmc_entry(a, world, kernel):
+    """The PMC evidence on file for this workload AND this dominant kernel, or None.  Counters cannot be collected inside a
+    timed run: they come from separate rocprofv3 --pmc passes of this same command (tools/profile_bench.sh ->
+    tools/pmc_traffic.py), stored under profiles/ with the commit they were taken at.  An entry whose kernel is not
+    the kernel this run was dominated by is refused (a stale file must not dress up a different kernel)."""
     path = os.path.join(ROOT, "profiles", "bench_pmc_traffic.json")
     try:
         t = json.load(open(path))
     except Exception:
         return None
-    key = pmc_key(a, world)
-    return t.get(key, {}).get("sq")
-
-
-def pmc_traffic(a, world):
-    """HBM bytes per launch of the scan kernel from the PMC counters.  Counters cannot be collected
-    inside a timed run: they come from separate rocprofv3 --pmc passes of this same command
-    (tools/profile_bench.sh), stored under profiles/ with the commit they were taken at; returned only if the
-    workload matches."""
-    path = os.path.join(ROOT, "profiles", "bench_pmc_traffic.json")
-    try:
-        t = json.load(open(path))
-    except Exception:
+    e = t.get(pmc_key(a, world, kernel))
+    if not e:
         return None
-    key = pmc_key(a, world)
-    return t.get(key, {}).get("hbm_bytes_per_launch")
+    short = kernel.split("::")[-1].split("<")[0]
+    if short not in e.get("kernel", ""):
+        return None
+    return e
+
+
+def unit_busy(e, sec):
+    """busy fractions of the dominant kernel's units from the PMC passes on file: counter / (GRBM_GUI_ACTIVE / 8 XCDs =
+    the kernel's cycles, from the same passes -- no assumed clock)"""
+    sq = (e or {}).get("sq") or {}
+    cyc = sq.get("GRBM_GUI_ACTIVE", 0) / 8.0
+    if cyc <= 0:
+        return None
+    out = {"kernel_cycles": cyc, "effective_clock_GHz_in_the_pmc_pass": None, "source": sq.get("source"),
+           "commit": e.get("commit")}
+    if "SQ_LDS_IDX_ACTIVE" in sq:
+        out["lds_array_busy"] = round(sq["SQ_LDS_IDX_ACTIVE"] / 256.0 / cyc, 4)
+    if "SQ_LDS_BANK_CONFLICT" in sq and sq.get("SQ_LDS_IDX_ACTIVE"):
+        out["lds_bank_conflict_frac"] = round(sq["SQ_LDS_BANK_CONFLICT"] / sq["SQ_LDS_IDX_ACTIVE"], 5)
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in sq:
+        out["mfma_pipe_busy"] = round(sq["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / cyc, 4)
+    if "SQ_ACTIVE_INST_VALU" in sq:  # (quad-cycles a wave spent issuing VALU, summed over waves)
+        out["valu_issue_busy"] = round(sq["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / cyc, 4)
+    if "SQ_WAIT_ANY" in sq and sq.get("SQ_WAVE_CYCLES"):
+        out["wave_cycles_waiting"] = round(sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"], 4)
+    return out
 
 
 def cpu_baseline(a, kind, metric, built, vectors, xq, D_gpu, I_gpu, g, log):

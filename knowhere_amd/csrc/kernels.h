@@ -250,7 +250,7 @@ hipError_t launch_pqf_query_table(const float* queries, const float4* cb_t, int 
 // selectivity guard: *poor = queries whose predicted candidate count exceeds half the capacity
 hipError_t launch_pqf_predict(const float* dump, int64_t stride, const int32_t* n_row, const float* gthr, const float* qs,
                               const int64_t* keys, int nprobe, int64_t nlist, const int64_t* list_len, int64_t nq, int cap,
-                              bool is_l2, int32_t* poor, hipStream_t s);
+                              int k, bool is_l2, int32_t* poor, hipStream_t s);
 size_t pqf_smem();
 bool pqf_supports(int M, int d);
 hipError_t launch_pqf(const MScanArgs& a, bool is_l2, int64_t units_bound, hipStream_t s);

@@ -196,9 +196,9 @@ struct knhip_index {
     mutable DevBuf xnorm;        // [total blocks * 64] ||x||^2 per stored row position, built on first use
     mutable float xnorm_max = 0.f;
     int64_t total_blk = 0;       // 64-row blocks of the interleaved layout
-    // IVF-PQ half-precision prefilter (pq_filter.hip): KNHIP_PQF = 1 switches it on (default off: not yet validated on
-    // hardware).  Its layouts are built on first use.
-    int pqf = 0;
+    // IVF-PQ matrix-core ADC prefilter (pq_filter.hip): 1 = when the lists are shared by enough queries (default),
+    // 2 = whenever the shape allows (KNHIP_PQF=1: tests), 0 = never (KNHIP_PQF=0).  Its layouts are built on first use.
+    int pqf = 1;
     bool pqf_guard = true;           // KNHIP_PQF_GUARD=0 switches the selectivity guard off (tests of the overflow rounds)
     mutable bool pqf_ready = false;
     mutable DevBuf rows_r;           // rotated token stream (stream16r)
@@ -419,7 +419,7 @@ int build_list_layout(knhip_index* idx, const std::vector<int64_t>& list_off, co
         idx->mscan_cap = (mc && *mc) ? std::max(0, atoi(mc)) : 0;
         idx->xnorm_ready = false;
         const char* pf = getenv("KNHIP_PQF");
-        idx->pqf = (pf && pf[0] == '1') ? 1 : 0;
+        idx->pqf = (pf && pf[0] == '1') ? 2 : (pf && pf[0] == '0') ? 0 : 1;
         const char* pg = getenv("KNHIP_PQF_GUARD");
         idx->pqf_guard = !(pg && pg[0] == '0');
         idx->pqf_ready = false;
@@ -574,7 +574,7 @@ int ensure_pqf(const knhip_index* idx) {
                                 idx->rows_r.as<uint4>(), nullptr));
     idx->pabs_max = 0.f;
     if (idx->is_l2) {
-        const size_t npos = (size_t)std::max<int64_t>(off[nlist] / 4, 1) * 64;
+        const size_t npos = (size_t)std::max<int64_t>(off[nlist], 1) * 16; // 16 vector positions per block
         HIP_TRY(idx->psum.alloc((npos + 4) * sizeof(float)));
         HIP_TRY(hipMemset(idx->psum.p, 0, (npos + 4) * sizeof(float)));
         uint32_t* bits = reinterpret_cast<uint32_t*>(idx->psum.as<float>() + npos);
@@ -698,11 +698,12 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         }
     }
     // IVF-Flat / IVF-SQ8: MFMA prefilter + exact finish (mfma_scan.hip) when the lists are shared by enough queries.
-    // IVF-PQ m = 32 with KNHIP_PQF=1: the half-precision ADC prefilter (pq_filter.hip) through the same machinery; its
-    // exact fallback is the 4-query kernel.
+    // IVF-PQ m = 32: the matrix-core ADC prefilter (pq_filter.hip) through the same machinery, when the lists are shared by
+    // enough queries for its units of (list, 8 queries) -- 4 pairs per list on average --; its exact fallback is the
+    // 4-query kernel.
     bool use_ms = false;
     int ms_cap = 0, ms_nchunk = 0, ms_nstep = 0;
-    const bool pqf_shape = kind == KNHIP_IVF_PQ && idx->pqf == 1 && pq_use_v2 && idx->cb_t.p != nullptr &&
+    const bool pqf_shape = kind == KNHIP_IVF_PQ && idx->pqf != 0 && pq_use_v2 && idx->cb_t.p != nullptr &&
             pqf_supports(idx->desc.pq_m, d) && pq_scan_q4_supports(idx->desc.pq_m, d, k) &&
             (!is_l2 || idx->use_precomp); // (residual tables: see pq_psum_kernel)
     if ((kind == KNHIP_IVF_FLAT || kind == KNHIP_IVF_SQ8 || pqf_shape) && (idx->mscan != 0 || pqf_shape) && nprobe >= 2) {
@@ -734,7 +735,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             ms_cap = idx->mscan_cap;
         }
         use_ms = lds <= 160 * 1024 - 1024 && ms_cap >= 2 * k &&
-                (idx->mscan == 1 || pqf_shape || npairs >= 8 * nlist);
+                (kind == KNHIP_IVF_PQ ? (idx->pqf == 2 || npairs >= 4 * nlist) : (idx->mscan == 1 || npairs >= 8 * nlist));
     }
     if (use_ms && kind == KNHIP_IVF_PQ) { // (no rank-0 dump phase: the sample pass of the prefilter gives the bounds)
         pq_rank0 = false;
@@ -918,7 +919,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
                 int32_t* poor = ws->ms_cand_cnt.as<int32_t>() + 2 * nq + 1;
                 HIP_TRY(launch_pqf_predict(ws->dump.as<float>(), sample, ws->ms_nrow.as<int32_t>(), ws->gthr.as<float>(),
                                            ws->ms_qs.as<float>(), keys_p, nprobe, nlist, idx->d_list_len.as<int64_t>(), nq,
-                                           ms_cap, is_l2, poor, s));
+                                           ms_cap, k, is_l2, poor, s));
                 int32_t h_poor = 0;
                 HIP_TRY(hipMemcpyAsync(&h_poor, poor, sizeof(int32_t), hipMemcpyDeviceToHost, s));
                 HIP_TRY(hipStreamSynchronize(s));
@@ -1934,14 +1935,7 @@ int knhip_range_search(const knhip_index* idx, const float* queries, int64_t nq,
         return fail(KNHIP_ERR_EMPTY_INDEX, "index holds no vectors");
     }
     const int kind = idx->desc.kind;
-    if (kind == KNHIP_IVF_PQ && !(idx->pq_v2 && idx->desc.pq_m == 32)) {
-        // other code widths go through the plain ADC dump kernel of range.hip, which has not run on hardware yet
-        // (written at the end of round 2; emulated on the CPU): opt-in until it has
-        const char* e = getenv("KNHIP_UNVALIDATED");
-        if (!(e && e[0] == '1')) {
-            return fail(KNHIP_ERR_NOT_IMPLEMENTED, "range search on IVF_PQ needs m = 32 (stream16 layout)");
-        }
-    }
+    // (IVF_PQ: m = 32 dumps through the stream16 scan, other code widths through the plain ADC dump kernel of range.hip)
     if (kind != KNHIP_BRUTE_FORCE && (size_t)idx->nlist > row_select_max_k()) {
         return fail(KNHIP_ERR_NOT_IMPLEMENTED, "range search probes every list: nlist > 65536 is not supported");
     }

@@ -1,39 +1,43 @@
-// knowhere_amd/csrc/pq_filter.hip -- IVF-PQ (M = 32 x 8 bit, dsub = 4) ADC scan as a HALF-PRECISION PREFILTER.
-//
-// STATUS: written at the end of round 2 without access to a GPU (the round's GPU minutes were spent).  It compiles for
-// gfx950, is OFF unless KNHIP_PQF=1, and has never run on hardware.  See DESIGN.md section 7.
+// knowhere_amd/csrc/pq_filter.hip -- IVF-PQ (M = 32 x 8 bit, dsub = 4) ADC scan as a PREFILTER on the matrix cores.
 //
 // Why: the exact ADC scan (pq_scan_q4.hip) is bound by VALU issue: per 256 lookups of a wave one ds_read_b128, one SDWA
-// address shift and 2..4 v_pk_add_f32 (EXEC flips on the staggered steps).  tools/ubench/adc_loop measured a loop
-// with the table in half precision, EIGHT queries per 16-byte entry, 4 v_pk_add_f16 per step and no EXEC flips at
-// 191 lookups/ns/CU against 90 for the exact loop.  Half-precision sums cannot be returned (the reference's distances
-// are fp32 sums in m order), but they can FILTER, as mfma_scan.hip does for fp32 rows and SQ8 codes:
+// address shift and 2..4 v_pk_add_f32 (EXEC flips on the staggered steps).  Sums that only FILTER need neither the
+// reference's summation order nor its precision, as mfma_scan.hip shows for fp32 rows and SQ8 codes:
 //
 //   approx(q, v) = dis0 + psum[v] + (1 / sc_q) * sum_m Qh_q[m][code_m(v)]                                  (L2)
 //       psum[v]  = sum_m term2[list][m][code_m(v)]     per stored vector, fp32, computed when the layout is built
 //                  (term2 = ||cb||^2 + 2 <c_list,m, cb>: IVFPQ_QueryTables.cpp:50-108; no query in it)
-//       Qh_q     = rint(sc_q * -2 <q_m, cb[m][c]>)     per query, an INTEGER table: sc_q = 2032 / A_q with
-//                  A_q = sum_m max_c |2 <q_m, cb>|, so that every partial sum of a vector's 32 entries is an
-//                  integer of magnitude <= 2048 -- exactly representable in half precision: the additions are exact
-//   approx(q, v) = dis0 + (1 / sc_q) * sum_m rint(sc_q <q_m, cb>)                                           (IP)
+//       Qh_q     = half(sc_q * -2 <q_m, cb[m][c]>)     per query; sc_q = the power of two that puts the table's largest
+//                  magnitude into [2^14, 2^15): the scaling is exact, every entry keeps 11 significant bits
+//   approx(q, v) = dis0 + (1 / sc_q) * sum_m half(sc_q <q_m, cb>)                                           (IP)
 //
-//   |approx - exact| <= eps = 16.5 / sc_q + 64 * 2^-24 * (|dis0| + max_v sum_m |term2| + A_q + |tau|)
-//                           = 0.0081 A_q + ...:
-//   32 table entries rounded to integers (half a unit each; the half additions add nothing), the fp32 roundings of both
-//   sides (~70 operations of relative 2^-24 on quantities bounded by the bracket).  (Rounding the entries to half
-//   precision instead and letting the additions round costs 34 * 2^-11 A_q = 0.0166 A_q: twice as loose.)
-//   tests/test_pq_filter_bound.py replays the arithmetic on the CPU.
+// The additions run on the MATRIX CORES (round 3; the first version of this file added 8 packed halves per lookup on
+// the VALU and had to scale the table to integers <= 2048 to keep those additions exact: eps = 0.0081 A_q).  One LUT
+// entry = the 8 queries' halves of one (m, code) = the 16 bytes a lane fetches with one ds_read_b128 = the B operand
+// of one v_mfma_f32_16x16x32_f16.  Lane L = (kb = L >> 4, n = L & 15) fetches for vector 16 (kb >> 1) + n of a group
+// of 32 vectors, sub-quantizer half kb & 1; the A operand is a constant selector (row i < 8 sums the k blocks 0, 1
+// element i, row i >= 8 the k blocks 2, 3 element i - 8), so D[i][n] accumulates in FP32, over the 16 steps of a
+// group, query (i & 7)'s 32 table entries of vector 16 (i >> 3) + n: 512 lookups per instruction, no VALU on the data
+// path (one SDWA shift per lookup for the address), 240 against 198 lookups/ns/CU in tools/ubench/adc_loop
+// (profiles/r03_ubench_adc_loop_mfma.log) -- and, because the accumulator is fp32, the only approximation left is the
+// half rounding of the entries themselves:
+//
+//   |approx - exact| <= eps = 2^-11 A_q (1 + 2^-10) + 2^-20 / sc_q + 128 * 2^-24 * (max_v sum_m |term2| + A_q)
+//                              + 64 * 2^-24 * (|dis0| + |tau|),        A_q = sum_m max_c |Qf_q[m][c]|
+//   (32 entries rounded to 11 bits: 2^-11 relative each, 2^-25 absolute for the subnormal ones in scaled units; the
+//   matrix core's fp32 additions of 32 exact products, in any order and rounding: 64 * 2^-24 of the magnitudes; the
+//   fp32 roundings of both sides).  16x tighter than the integer table: the filter passes ~k rows per query instead
+//   of ~10 k, on isotropic data a fraction of a percent instead of 10 %.  tests/test_pq_filter_bound.py replays it.
 //
 // A row whose approx is within eps of the query's bound tau_q goes to the query's candidate list; the finish kernel
 // (mfma_scan.hip, KIND 2) recomputes the candidates in the reference's exact order and keeps the canonical top-k --
 // the returned values never see half precision.  Bound, sample pass, candidate histogram, retry round and exact
 // fallback are the machinery of mfma_scan.hip (MScanArgs).
 //
-// Lanes never split a vector between windows here.  Half additions may run in any order, so lane L walks the 32
-// sub-quantizers of ITS vector rotated: at step T of a window it handles m = (T + pq_stream_phase(L)) & 31.  The 16
-// lanes an LDS gather is serviced together for sit on 16 consecutive m = 16 different bank quads of LUT[c][m][8 q]
-// (16-byte entries): no bank conflict for any code values, no stagger, no EXEC flips, no drain window.  That needs its
-// own token stream (`stream16r`: same 16-bit tokens code << 8 | m << 3 as stream16, rotated instead of delayed).
+// Token stream `stream16m`: the same 16-bit tokens code << 8 | m << 3 as stream16 (token << 1 = LDS byte address of
+// LUT[code][m][8 queries], 16-byte entries), laid out for the lane map above: at step s of a group lane L handles
+// m = 16 (kb & 1) + ((pq_stream_phase(L) + s) & 15).  The 16 lanes an LDS gather is serviced together for (kernels.h:
+// pq_stream_phase) sit on 16 different m mod 16 = 16 different bank quads: no bank conflict for any code values.
 #include "common.h"
 #include "kernels.h"
 #include "ms_common.h"
@@ -56,16 +60,21 @@ constexpr int PF_LUT_BYTES = PF_KSUB * PF_M * PF_Q * 2; // 131072
 constexpr int PF_CTL_BYTES = 1024;
 constexpr int PF_SAMPLE = 4096; // = MS_SAMPLE (mfma_scan.hip): dump columns per query
 constexpr float PF_U = 5.9604645e-8f;        // 2^-24
+constexpr float PF_UH = 4.8828125e-4f;       // 2^-11: unit roundoff of half precision
 
 typedef _Float16 pf_h2 __attribute__((ext_vector_type(2)));
 typedef _Float16 pf_h8 __attribute__((ext_vector_type(8))); // one LUT entry: the 8 queries' halves
 
-// ---- AoS codes [len][32] -> rotated token stream ----------------------------------------------------------------
-// uint4 out[blk][lane], 8 steps per block, 4 blocks per group of 64 vectors
+// ---- AoS codes [len][32] -> token stream of the matrix-core scan ---------------------------------------------------
+// uint4 out[blk][lane]: 8 steps per block, 2 blocks per group of 32 vectors (16 vector positions per block)
 int64_t pq_stream16r_blocks(int64_t len) {
-    // + two windows of slack: every wave's code prefetch runs two windows ahead of its last group
-    return ((len + 63) / 64) * 4 + 8;
+    // + four groups of slack: every wave's code prefetch runs two window pairs ahead of its last group
+    return ((len + 31) / 32) * 2 + 8;
 }
+
+// lane L of a wave -> (vector within the group of 32, sub-quantizer at step s)
+__host__ __device__ constexpr int pf_lane_vec(int L) { return 16 * (L >> 5) + (L & 15); }
+__host__ __device__ constexpr int pf_lane_m(int L, int s) { return 16 * ((L >> 4) & 1) + ((pq_stream_phase(L) + s) & 15); }
 
 __global__ void pq_stream16r_kernel(const uint8_t* __restrict__ codes, const int64_t* __restrict__ list_row_off,
                                     const int64_t* __restrict__ list_len, const int64_t* __restrict__ list_sblk_off,
@@ -81,13 +90,11 @@ __global__ void pq_stream16r_kernel(const uint8_t* __restrict__ codes, const int
          t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t blk = t / 64;
         const int L = (int)(t % 64);
-        const int ph = pq_stream_phase(L);
-        const int64_t v = (blk >> 2) * 64 + L;
+        const int64_t v = (blk >> 1) * 32 + pf_lane_vec(L);
         uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int s = 0; s < 8; s++) {
-            const int T = (int)(blk & 3) * 8 + s;
-            const int m = (T + ph) & 31;
+            const int m = pf_lane_m(L, (int)(blk & 1) * 8 + s);
             uint32_t code = 0;
             if (v < len) {
                 code = codes[(row_off + v) * PF_M + m];
@@ -112,7 +119,7 @@ hipError_t launch_pq_stream16r(const uint8_t* codes, const int64_t* list_row_off
 }
 
 // ---- per stored vector: psum = sum_m term2[list][m][code_m], |.| bound -------------------------------------------
-// psum[(list_sblk_off[l] / 4) * 64 + v]: one float per vector position of the rotated stream (slack positions 0).
+// psum[list_sblk_off[l] * 16 + v]: one float per vector position of the token stream (slack positions 0).
 // term2 = the entries of the index's precomputed table, i.e. the very values the exact scan adds (an index that
 // searches with residual tables -- table over precomputed_table_max_bytes -- does not take this path: without the
 // stored entries both sides of the bound would round differently).  pabs_max: max over vectors of sum_m |term2|.
@@ -125,8 +132,8 @@ __global__ void pq_psum_kernel(const uint8_t* __restrict__ codes, const int64_t*
         return;
     }
     const int64_t len = list_len[l];
-    const int64_t npos = (list_sblk_off[l + 1] - list_sblk_off[l]) / 4 * 64;
-    const int64_t base = list_sblk_off[l] / 4 * 64;
+    const int64_t npos = (list_sblk_off[l + 1] - list_sblk_off[l]) * 16;
+    const int64_t base = list_sblk_off[l] * 16;
     const int64_t row_off = list_row_off[l];
     float amax = 0.f;
     for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < npos; v += (int64_t)gridDim.x * blockDim.x) {
@@ -202,26 +209,29 @@ __global__ __launch_bounds__(PF_KSUB) void pqf_query_table_kernel(const float* _
     }
     __syncthreads();
     if (c == 0) {
-        float A = 0.f;
+        float A = 0.f, gmax = 0.f;
         for (int m = 0; m < PF_M; m++) {
             float a = smax[m][0];
             for (int w = 1; w < PF_KSUB / KN_WAVE; w++) {
                 a = fmaxf(a, smax[m][w]);
             }
             A += a;
+            gmax = fmaxf(gmax, a);
         }
-        // INTEGER table: entries rint(Qf * sc) with sc = 2032 / A.  The per-m maxima of the rounded entries sum to at
-        // most 2032 + 32 * 0.5 = 2048, so every partial sum of a vector's 32 entries is an integer of magnitude <= 2048:
-        // exactly representable in half precision -- the 32 half additions are EXACT, in any order.  What is left is the
-        // rounding of the entries themselves: half a unit each, 16 units in all (+ the fp32 roundings of Qf * sc, < 0.01).
+        // HALF table: entries half(Qf * sc), sc = the power of two that puts the largest magnitude into [2^14, 2^15)
+        // (exact scaling, no overflow of the half range); every entry keeps 11 significant bits: relative error 2^-11,
+        // absolute 2^-25 (scaled units) for the subnormal ones.  The additions are fp32 (matrix cores).
         float sc = 1.0f, eps = INFINITY;
         if (A < INFINITY) {
-            sc = A > 0.f ? 2032.0f / A : 1.0f;
-            if (sc < INFINITY) {
-                eps = 16.5f / sc + 64.0f * PF_U * (pabs_max + A);
-            } else {
-                sc = 1.0f; // (a table of subnormal magnitude: no bound, the query takes the exact kernels)
+            if (gmax > 0.f) {
+                int e = 0;
+                (void)frexpf(gmax, &e); // gmax = f * 2^e, f in [0.5, 1)
+                int p2 = 15 - e;
+                p2 = p2 > 126 ? 126 : (p2 < -126 ? -126 : p2);
+                sc = ldexpf(1.0f, p2);
             }
+            const float isc = 1.0f / sc; // (a power of two in [2^-126, 2^126]: exact)
+            eps = PF_UH * A * 1.001f + 9.5367431640625e-7f * isc + 128.0f * PF_U * (pabs_max + A);
         }
         s_sc = sc;
         qs[q * 4 + 0] = sc;
@@ -235,8 +245,8 @@ __global__ __launch_bounds__(PF_KSUB) void pqf_query_table_kernel(const float* _
 #pragma unroll
     for (int l16 = 0; l16 < 16; l16++) {
         pf_h2 h;
-        h.x = (_Float16)rintf(v[l16] * sc); // (an integer of magnitude <= 2033: exact in half precision)
-        h.y = (_Float16)rintf(v[l16 + 16] * sc);
+        h.x = (_Float16)(v[l16] * sc); // (|.| < 2^15: no overflow; round to nearest even)
+        h.y = (_Float16)(v[l16 + 16] * sc);
         out[((c >> 2) * 16 + l16) * 4 + (c & 3)] = __builtin_bit_cast(uint32_t, h);
     }
 }
@@ -337,8 +347,10 @@ __device__ unsigned long long g_pf_prof[16 * 8];
 // Persistent: one workgroup of 16 waves per CU (128 KB of LUT), units pulled in list order from the XCD's counter as
 // pq_scan_q4.hip does.  Per unit: per-pair constants (waves 0..7, one pair each: bound from gthr and the candidate
 // histogram), LUT[c][m][8 queries] transposed from the queries' half tables, then every wave scans its share of the
-// list's groups of 64 vectors: 32 steps of {SDWA shift, ds_read_b128, 4 v_pk_add_f16} per group, one compare per
-// (vector, query) at the end of the window.
+// list's groups of 32 vectors: 16 steps of {SDWA shift, ds_read_b128, v_mfma_f32_16x16x32_f16} per group, one fma +
+// compare per (vector, query) at the end of the group.
+typedef float pf_f4 __attribute__((ext_vector_type(4)));
+
 template <bool IS_L2, bool DUMP>
 __global__ __launch_bounds__(PF_THREADS) void pqf_kernel(MScanArgs a) {
 #ifdef KNHIP_PHASE_TIMERS
@@ -347,7 +359,8 @@ __global__ __launch_bounds__(PF_THREADS) void pqf_kernel(MScanArgs a) {
 #endif
     extern __shared__ __align__(16) unsigned char smem[];
     int* ctl = reinterpret_cast<int*>(smem + PF_LUT_BYTES);
-    float* pc = reinterpret_cast<float*>(smem + PF_LUT_BYTES + 512); // [8][4] = {t, sc, pess const, 1 / sc}
+    float* pc = reinterpret_cast<float*>(smem + PF_LUT_BYTES + 512); // [8][4] = {t, 1 / sc, pess const, -}
+    int* pqs = reinterpret_cast<int*>(smem + PF_LUT_BYTES + 640);    // [8][2] = {query, slot / dump column} of the pairs
     const int lane = lane_id();
     const int wave = pf_sgpr((int)(threadIdx.x / KN_WAVE));
     if ((uint32_t)(size_t)((__attribute__((address_space(3))) unsigned char*)smem) != 0u) {
@@ -440,48 +453,44 @@ __global__ __launch_bounds__(PF_THREADS) void pqf_kernel(MScanArgs a) {
         const int nxt_unit = pf_sgpr(ctl[par ^ 1]); // (-1: this is the last unit of the workgroup)
         auto rl = [&](int i) { return (uint32_t)__builtin_amdgcn_readlane((int)rw, i); };
         const int npair = (int)rl(1);
-        int32_t q_of[PF_Q], slot_of[PF_Q];
-#pragma unroll
-        for (int j = 0; j < PF_Q; j++) {
-            q_of[j] = (int32_t)rl(2 + j);
-            slot_of[j] = (int32_t)rl(10 + j);
-        }
         const int64_t len = (int64_t)(((uint64_t)rl(27) << 32) | rl(26));
         const int64_t sblk0 = (int64_t)(((uint64_t)rl(29) << 32) | rl(28));
         const int64_t row_off = (int64_t)(((uint64_t)rl(31) << 32) | rl(30));
 
         // (filter mode: the 8 queries' table pieces `tp` were requested one unit ago; they are transposed into the LUT
-        // below.  The sample pass -- few, short units -- requests them here instead and keeps 32 registers free)
+        // below.  The sample pass -- few, short units -- requests them here instead)
         if (DUMP) {
             load_tables(par, tp, lane_i);
         }
-        // this wave's groups of 64 vectors and its first code blocks
-        const int ngroups = (int)((len + 63) / 64);
+        // this wave's groups of 32 vectors and its first code blocks (2 blocks per group)
+        const int ngroups = (int)((len + 31) / 32);
         const int gbase = ngroups / PF_WAVES, grem = ngroups % PF_WAVES;
         const int G0 = wave * gbase + min(wave, grem);
         const int G1 = G0 + gbase + (wave < grem ? 1 : 0);
         const int nwin = G1 - G0;
-        const uint4* cbase = a.pq_codes_r + (sblk0 + (int64_t)G0 * 4) * 64 + lane_i; // 4 blocks per window
-        auto load_blk = [&](int b) { return cbase[(int64_t)b * 64]; };                // past-the-end blocks exist (slack)
-        const float* psb = a.pq_psum + (sblk0 / 4 + G0) * 64 + lane_i;
+        const uint4* cbase = a.pq_codes_r + (sblk0 + (int64_t)G0 * 2) * 64 + lane_i;
+        auto load_blk = [&](int b) { return cbase[(int64_t)b * 64]; }; // past-the-end blocks exist (slack)
+        const float* psb = a.pq_psum + sblk0 * 16 + (int64_t)G0 * 32 + pf_lane_vec(lane_i);
         uint4 U0 = make_uint4(0, 0, 0, 0), U1 = U0, U2 = U0, U3 = U0;
-        float ps_next = 0.f;
+        float psa_next = 0.f, psb_next = 0.f;
         if (nwin > 0) {
             U0 = load_blk(0);
             U1 = load_blk(1);
             U2 = load_blk(2);
             U3 = load_blk(3);
             if (IS_L2) {
-                ps_next = psb[0];
+                psa_next = psb[0];
+                psb_next = psb[32];
             }
         }
         // ---- per-pair constants: wave j < 8 prepares pair j ---------------------------------------------------------
         if (wave < PF_Q) {
-            int32_t q = q_of[0];
+            int32_t q = (int32_t)rl(2), slot = (int32_t)rl(10);
             float dis0 = __uint_as_float(rl(18));
 #pragma unroll
             for (int j = 1; j < PF_Q; j++) {
-                q = wave == j ? q_of[j] : q;
+                q = wave == j ? (int32_t)rl(2 + j) : q;
+                slot = wave == j ? (int32_t)rl(10 + j) : slot;
                 dis0 = wave == j ? __uint_as_float(rl(18 + j)) : dis0;
             }
             const float4 s4 = *reinterpret_cast<const float4*>(a.pq_qs + (int64_t)q * 4);
@@ -503,13 +512,15 @@ __global__ __launch_bounds__(PF_THREADS) void pqf_kernel(MScanArgs a) {
                             a.overflow[a.nq] = 1;
                         }
                     } else {
-                        t = IS_L2 ? ((tau + eps) - dis0) * s4.x : ((tau - eps) - dis0) * s4.x;
+                        t = IS_L2 ? (tau + eps) - dis0 : (tau - eps) - dis0;
                         pcst = IS_L2 ? dis0 + eps : dis0 - eps;
                     }
                 }
             }
             if (lane_i == 0) {
-                *reinterpret_cast<float4*>(pc + wave * 4) = make_float4(t, s4.x, pcst, s4.y);
+                *reinterpret_cast<float4*>(pc + wave * 4) = make_float4(t, s4.y, pcst, 0.f);
+                pqs[wave * 2] = q;
+                pqs[wave * 2 + 1] = slot;
             }
         }
         // ---- LUT[c][m][query]: 8 x 8 halves transposed in registers, 8 conflict-free 16-byte stores ------------------
@@ -567,15 +578,24 @@ __global__ __launch_bounds__(PF_THREADS) void pqf_kernel(MScanArgs a) {
         if (!DUMP && nxt_unit >= 0) {
             load_tables(par ^ 1, tpn, lane_i);
         }
-        // the pairs' constants -> SGPRs
-        float thr[PF_Q], scq[PF_Q], pcs[PF_Q], isc[PF_Q];
+        // this lane's 4 accumulator rows are the queries 4 hb + r of its vector: their constants -> VGPRs
+        const int hb = (lane_i >> 4) & 1;
+        float thr[4], isc[4];
 #pragma unroll
-        for (int j = 0; j < PF_Q; j++) {
-            const float4 c4v = *reinterpret_cast<const float4*>(pc + j * 4);
-            thr[j] = pf_sgpr_f(c4v.x);
-            scq[j] = pf_sgpr_f(c4v.y);
-            pcs[j] = pf_sgpr_f(c4v.z);
-            isc[j] = pf_sgpr_f(c4v.w);
+        for (int r = 0; r < 4; r++) {
+            const float4 c4v = *reinterpret_cast<const float4*>(pc + (4 * hb + r) * 4);
+            thr[r] = c4v.x;
+            isc[r] = c4v.y;
+        }
+        // the selector operand: row i = lane & 15 takes element i & 7 of the k blocks 2 (i >> 3), 2 (i >> 3) + 1
+        pf_h8 sel;
+        {
+            const int i = lane_i & 15, kb = lane_i >> 4;
+            const bool on = (kb >> 1) == (i >> 3);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                sel[e] = (on && (i & 7) == e) ? (_Float16)1.0f : (_Float16)0.0f;
+            }
         }
 
         typedef __attribute__((address_space(3))) const pf_h8 lds_h8;
@@ -587,99 +607,113 @@ __global__ __launch_bounds__(PF_THREADS) void pqf_kernel(MScanArgs a) {
 
         PF_T(2); // set-up of the scan
         if (nwin > 0) {
-            const _Float16 h0 = (_Float16)0.f;
-            const pf_h8 hz = {h0, h0, h0, h0, h0, h0, h0, h0};
-            pf_h8 acc = hz; // 8 half sums: 4 v_pk_add_f16 per LUT entry
-            // LUT reads run four 2-step units ahead of the additions that consume them (four value buffers); code
-            // registers as in pq_scan_q4: at the top of window w, U0 = block 4w + 4, U1..U3 = blocks 4w + 1..4w + 3.
-            pf_h8 B0[2], B1[2], B2[2], B3[2];
-            issue2(U0.x, B0);
-            issue2(U0.y, B1);
-            issue2(U0.z, B2);
-            issue2(U0.w, B3);
-            U0 = load_blk(4);
-            const int last_group = ngroups - 1;
-            const unsigned long long tail_mask = (len & 63) ? ((1ull << (len & 63)) - 1ull) : ~0ull;
+            const pf_f4 fz = {0.f, 0.f, 0.f, 0.f};
+            // LUT reads run four 2-step units ahead of the matrix instructions that consume them (four value buffers);
+            // code registers: at the top of window pair i, U0 = block 4 i + 4, U1..U3 = blocks 4 i + 1..4 i + 3.
+            pf_h8 B0[2], B1[2];
+            uint4 W0 = U0; // block 4 i at the top of pair i (its first two words are in flight)
+            issue2(W0.x, B0);
+            issue2(W0.y, B1);
+            pf_f4 e0 = fz, e1 = fz, o0 = fz, o1 = fz; // even / odd window of a pair, even / odd step
+            const int vec = pf_lane_vec(lane_i);
 
-#define PF_UNIT(BUF, WORD)                 \
-    __builtin_amdgcn_sched_barrier(0);     \
-    acc += BUF[0];                         \
-    acc += BUF[1];                         \
-    __builtin_amdgcn_sched_barrier(0);     \
+#define PF_UNIT(A0, A1, C0, C1, BUF, WORD)                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    A0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(sel, BUF[0], C0, 0, 0, 0);                   \
+    A1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(sel, BUF[1], C1, 0, 0, 0);                   \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
     issue2(WORD, BUF);
 
-            for (int w = 0; w < nwin; w++) {
-                pf_setprio((w + (wave >> 2)) & 3); // (see pq_scan_q4.hip: equal average speed for a SIMD's four waves)
-                const float ps = ps_next;
-                if (IS_L2) {
-                    ps_next = psb[(int64_t)(w + 1) * 64]; // (the slack groups behind a list exist)
-                }
-                PF_UNIT(B0, U1.x)
-                PF_UNIT(B1, U1.y)
-                PF_UNIT(B2, U1.z)
-                PF_UNIT(B3, U1.w)
-                U1 = load_blk(4 * w + 5);
-                PF_UNIT(B0, U2.x)
-                PF_UNIT(B1, U2.y)
-                PF_UNIT(B2, U2.z)
-                PF_UNIT(B3, U2.w)
-                U2 = load_blk(4 * w + 6);
-                PF_UNIT(B0, U3.x)
-                PF_UNIT(B1, U3.y)
-                PF_UNIT(B2, U3.z)
-                PF_UNIT(B3, U3.w)
-                U3 = load_blk(4 * w + 7);
-                PF_UNIT(B0, U0.x)
-                PF_UNIT(B1, U0.y)
-                PF_UNIT(B2, U0.z)
-                PF_UNIT(B3, U0.w)
-                U0 = load_blk(4 * w + 8);
-                __builtin_amdgcn_sched_barrier(0);
-
-                // ---- the window's 64 vectors are finished in every lane ------------------------------------------------
-                const float f[PF_Q] = {(float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3],
-                                       (float)acc[4], (float)acc[5], (float)acc[6], (float)acc[7]};
-                acc = hz;
-                const int G = G0 + w;
-                const int64_t pos = (int64_t)G * 64 + lane_i;
+            // ---- the 32 vectors of group G are finished: 4 sums per lane (queries 4 hb .. 4 hb + 3 of vector `vec`) ----
+            auto finish = [&](const pf_f4& x0, const pf_f4& x1, int G, float ps) {
+                const float f[4] = {x0[0] + x1[0], x0[1] + x1[1], x0[2] + x1[2], x0[3] + x1[3]};
+                const int64_t pos = (int64_t)G * 32 + vec;
+                const bool inside = G < G1 && pos < len;
                 if (DUMP) {
-                    const unsigned long long vmask = ms_valid_rows(a, G, len, row_off);
-                    const bool ok = (vmask >> lane_i) & 1ull;
+                    bool ok = inside;
+                    if (ok && a.bitset != nullptr) {
+                        ok = !bitset_filtered(a.bitset, a.bitset_nbits, a.ids[row_off + pos]);
+                    }
 #pragma unroll
-                    for (int j = 0; j < PF_Q; j++) {
+                    for (int r = 0; r < 4; r++) {
+                        const int j = 4 * hb + r;
                         if (j < npair) {
-                            const int32_t off = slot_of[j]; // (sample pass: the pair's first dump column)
-                            if (pos < len && pos < (int64_t)(PF_SAMPLE - off)) {
-                                const float v = IS_L2 ? __fmaf_rn(f[j], isc[j], pcs[j] + ps) : __fmaf_rn(f[j], isc[j], pcs[j]);
-                                a.dump[(int64_t)q_of[j] * a.dump_stride + off + pos] =
+                            const int32_t off = pqs[j * 2 + 1]; // (sample pass: the pair's first dump column)
+                            if (inside && pos < (int64_t)(PF_SAMPLE - off)) {
+                                const float pcs = pc[j * 4 + 2];
+                                const float v = IS_L2 ? __fmaf_rn(f[r], isc[r], pcs + ps) : __fmaf_rn(f[r], isc[r], pcs);
+                                a.dump[(int64_t)pqs[j * 2] * a.dump_stride + off + pos] =
                                         (ok && v == v) ? v : worst_dist<IS_L2>();
                             }
                         }
                     }
                 } else {
-                    bool hit[PF_Q];
+                    bool hit[4];
                     bool any = false;
 #pragma unroll
-                    for (int j = 0; j < PF_Q; j++) {
-                        // L2: ps sc + f <= t;  IP: f >= t   (t = -inf / +inf: nothing passes)
-                        hit[j] = IS_L2 ? (__fmaf_rn(ps, scq[j], f[j]) <= thr[j]) : (f[j] >= thr[j]);
-                        any |= hit[j];
+                    for (int r = 0; r < 4; r++) {
+                        // L2: ps + f / sc <= t;  IP: f / sc >= t   (t = -inf / +inf: nothing passes)
+                        const float v = __fmaf_rn(f[r], isc[r], IS_L2 ? ps : 0.f);
+                        hit[r] = IS_L2 ? (v <= thr[r]) : (v >= thr[r]);
+                        any |= hit[r];
                     }
-                    const unsigned long long vmask = (G == last_group) ? tail_mask : ~0ull;
-                    if ((__ballot(any) & vmask) != 0ull) {
-                        if (any && ((vmask >> lane_i) & 1ull)) {
+                    any = any && inside;
+                    if (__ballot(any) != 0ull) {
+                        if (any) {
 #pragma unroll
-                            for (int j = 0; j < PF_Q; j++) {
-                                if (hit[j]) {
-                                    const float pess = IS_L2 ? __fmaf_rn(f[j], isc[j], pcs[j] + ps)
-                                                             : __fmaf_rn(f[j], isc[j], pcs[j]);
-                                    ms_emit<IS_L2>(a, q_of[j], slot_of[j], row_off, pos, pess);
+                            for (int r = 0; r < 4; r++) {
+                                if (hit[r]) {
+                                    const int j = 4 * hb + r;
+                                    const float pcs = pc[j * 4 + 2];
+                                    const float pess = IS_L2 ? __fmaf_rn(f[r], isc[r], pcs + ps)
+                                                             : __fmaf_rn(f[r], isc[r], pcs);
+                                    ms_emit<IS_L2>(a, pqs[j * 2], pqs[j * 2 + 1], row_off, pos, pess);
                                 }
                             }
                         }
                     }
                 }
+            };
+
+            const int npairs_w = (nwin + 1) >> 1;
+            float psb_prev = 0.f;
+            for (int i = 0; i < npairs_w; i++) {
+                pf_setprio((i + (wave >> 2)) & 3); // (see pq_scan_q4.hip: equal average speed for a SIMD's four waves)
+                const float psa = psa_next, psb2 = psb_next;
+                if (IS_L2) {
+                    psa_next = psb[(int64_t)(2 * i + 2) * 32]; // (the slack groups behind a list exist)
+                    psb_next = psb[(int64_t)(2 * i + 3) * 32];
+                }
+                // even window of the pair: blocks 4 i, 4 i + 1 (in flight at the top: the first two words of block 4 i)
+                PF_UNIT(e0, e1, fz, fz, B0, W0.z)
+                PF_UNIT(e0, e1, e0, e1, B1, W0.w)
+                if (i > 0) { // (the odd window of the previous pair: its last matrix instructions have retired by now)
+                    finish(o0, o1, G0 + 2 * i - 1, psb_prev);
+                }
+                PF_UNIT(e0, e1, e0, e1, B0, U1.x)
+                PF_UNIT(e0, e1, e0, e1, B1, U1.y)
+                W0 = load_blk(4 * i + 4);
+                PF_UNIT(e0, e1, e0, e1, B0, U1.z)
+                PF_UNIT(e0, e1, e0, e1, B1, U1.w)
+                PF_UNIT(e0, e1, e0, e1, B0, U2.x)
+                PF_UNIT(e0, e1, e0, e1, B1, U2.y)
+                U1 = load_blk(4 * i + 5);
+                // odd window: blocks 4 i + 2, 4 i + 3
+                PF_UNIT(o0, o1, fz, fz, B0, U2.z)
+                PF_UNIT(o0, o1, o0, o1, B1, U2.w)
+                finish(e0, e1, G0 + 2 * i, psa);
+                PF_UNIT(o0, o1, o0, o1, B0, U3.x)
+                PF_UNIT(o0, o1, o0, o1, B1, U3.y)
+                U2 = load_blk(4 * i + 6);
+                PF_UNIT(o0, o1, o0, o1, B0, U3.z)
+                PF_UNIT(o0, o1, o0, o1, B1, U3.w)
+                PF_UNIT(o0, o1, o0, o1, B0, W0.x)
+                PF_UNIT(o0, o1, o0, o1, B1, W0.y)
+                U3 = load_blk(4 * i + 7);
+                __builtin_amdgcn_sched_barrier(0);
+                psb_prev = psb2;
             }
+            finish(o0, o1, G0 + 2 * npairs_w - 1, psb_prev);
 #undef PF_UNIT
             __builtin_amdgcn_s_setprio(0);
         }
@@ -713,18 +747,21 @@ __global__ __launch_bounds__(PF_THREADS) void pqf_kernel(MScanArgs a) {
 }
 
 // ---- selectivity guard -----------------------------------------------------------------------------------------
-// The filter is only as selective as eps against the spread of the distances: on clustered data 0.1 % of the scanned
-// rows pass, on isotropic data 10 %, and at a few percent the exact finish (32 global gathers per candidate) costs more
-// than the exact scan it replaces.  The sample pass holds the estimate: the share of a query's sample rows whose
-// pessimistic distance is within tau + 2 eps (what the filter lets through) times the rows of its probed lists.  One
-// wave per query; *poor counts the queries predicted to gather more than half their capacity.  The host abandons the
-// prefilter for the batch when more than a quarter of its queries are (knhip_api.hip).
+// The filter is only as selective as eps against the spread of the distances.  With the fp32-accumulated half table
+// eps is 2^-11 of the table magnitude and a few times k rows per query pass on every data set tried; should a data set
+// exist where a few percent of the rows pass, the exact finish (32 global gathers per candidate) would cost more than
+// the exact scan it replaces.  The sample pass holds an estimate: the share of a query's sample rows whose pessimistic
+// distance lies in the band (tau, tau + 2 eps] -- rows that pass only because of eps -- times the rows of its probed
+// lists, plus the k rows below tau.  (The band, not everything below tau + 2 eps: the sample is the query's CLOSEST
+// list, whose k best rows say nothing about the other lists.)  One wave per query; *poor counts the queries predicted
+// to gather more than half their capacity.  The host abandons the prefilter for the batch when more than a quarter of
+// its queries are (knhip_api.hip).
 template <bool IS_L2>
 __global__ __launch_bounds__(256) void pqf_predict_kernel(const float* __restrict__ dump, int64_t stride,
                                                           const int32_t* __restrict__ n_row, const float* __restrict__ gthr,
                                                           const float* __restrict__ qs, const int64_t* __restrict__ keys,
                                                           int nprobe, int64_t nlist, const int64_t* __restrict__ list_len,
-                                                          int64_t nq, int cap, int32_t* __restrict__ poor) {
+                                                          int64_t nq, int cap, int k, int32_t* __restrict__ poor) {
     const int lane = lane_id();
     const int64_t q = (int64_t)blockIdx.x * (blockDim.x / KN_WAVE) + threadIdx.x / KN_WAVE;
     if (q >= nq) {
@@ -740,7 +777,7 @@ __global__ __launch_bounds__(256) void pqf_predict_kernel(const float* __restric
     float cnt = 0.f, rows = 0.f;
     for (int i = lane; i < n; i += KN_WAVE) {
         const float v = dump[q * stride + i];
-        cnt += (IS_L2 ? v <= lim : v >= lim) ? 1.f : 0.f;
+        cnt += (IS_L2 ? (v > tau && v <= lim) : (v < tau && v >= lim)) ? 1.f : 0.f;
     }
     for (int sl = lane; sl < nprobe; sl += KN_WAVE) {
         const int64_t key = keys[q * nprobe + sl];
@@ -751,14 +788,14 @@ __global__ __launch_bounds__(256) void pqf_predict_kernel(const float* __restric
         cnt += __shfl_xor(cnt, dlt, KN_WAVE);
         rows += __shfl_xor(rows, dlt, KN_WAVE);
     }
-    if (lane == 0 && cnt / (float)n * rows > 0.5f * (float)cap) {
+    if (lane == 0 && (float)k + cnt / (float)n * rows > 0.5f * (float)cap) {
         atomicAdd(poor, 1);
     }
 }
 
 hipError_t launch_pqf_predict(const float* dump, int64_t stride, const int32_t* n_row, const float* gthr, const float* qs,
                               const int64_t* keys, int nprobe, int64_t nlist, const int64_t* list_len, int64_t nq, int cap,
-                              bool is_l2, int32_t* poor, hipStream_t s) {
+                              int k, bool is_l2, int32_t* poor, hipStream_t s) {
     hipError_t e = hipMemsetAsync(poor, 0, sizeof(int32_t), s);
     if (e != hipSuccess || nq <= 0) {
         return e;
@@ -766,10 +803,10 @@ hipError_t launch_pqf_predict(const float* dump, int64_t stride, const int32_t* 
     const unsigned grid = (unsigned)((nq + 3) / 4);
     if (is_l2) {
         hipLaunchKernelGGL(pqf_predict_kernel<true>, dim3(grid), dim3(256), 0, s, dump, stride, n_row, gthr, qs, keys, nprobe,
-                           nlist, list_len, nq, cap, poor);
+                           nlist, list_len, nq, cap, k, poor);
     } else {
         hipLaunchKernelGGL(pqf_predict_kernel<false>, dim3(grid), dim3(256), 0, s, dump, stride, n_row, gthr, qs, keys, nprobe,
-                           nlist, list_len, nq, cap, poor);
+                           nlist, list_len, nq, cap, k, poor);
     }
     return hipGetLastError();
 }

@@ -84,7 +84,7 @@ extern "C" int emu_pqf_search(int64_t nlist, const int64_t* list_len, const int6
     }
     std::vector<uint4> rows_r((size_t)std::max<int64_t>(sblk[(size_t)nlist], 1) * 64);
     if (launch_pq_stream16r(codes, list_row_off, list_len, sblk.data(), nlist, rows_r.data(), nullptr) != hipSuccess) return 1;
-    const size_t npos = (size_t)std::max<int64_t>(sblk[(size_t)nlist] / 4, 1) * 64;
+    const size_t npos = (size_t)std::max<int64_t>(sblk[(size_t)nlist], 1) * 16;
     std::vector<float> psum(npos + 4, 0.f);
     float pabs_max = 0.f;
     if (l2) {
@@ -174,7 +174,7 @@ extern "C" int emu_pqf_search(int64_t nlist, const int64_t* list_len, const int6
     {   // the selectivity guard's prediction (the product abandons the prefilter for a batch on it; here it is reported)
         int32_t poor = 0;
         if (launch_pqf_predict(dump.data(), sample, n_row.data(), gthr.data(), qs.data(), keys, nprobe, nlist, list_len, nq, cap,
-                               l2, &poor, nullptr) != hipSuccess) return 11;
+                               k, l2, &poor, nullptr) != hipSuccess) return 11;
         *poor_out = poor;
     }
     if (use_hist) {

@@ -278,6 +278,33 @@ inline C hipemu_mfma_32x32x16_f16(H8 a, H8 b, C c, int, int, int) {
     }
     return c;
 }
+// v_mfma_f32_16x16x32_f16: A lane l holds row i = l & 15, k block l >> 4 (8 halves); B lane l column n = l & 15, k
+// block l >> 4; D lane l, register r = D[4 (l >> 4) + r][l & 15].  Element e of k block kb of A meets element e of k
+// block kb of B -- which k index that is does not matter to a sum over k.
+template <class H8, class C>
+inline C hipemu_mfma_16x16x32_f16(H8 a, H8 b, C c, int, int, int) {
+    static_assert(sizeof(H8) == 16, "8 halves per lane");
+    unsigned char ab[32];
+    std::memcpy(ab, &a, 16);
+    std::memcpy(ab + 16, &b, 16);
+    const unsigned char (*all)[32] = hipemu::xchg_wide(ab, 32);
+    const int l = hipemu::tl.lane, n = l & 15;
+    for (int r = 0; r < 4; r++) {
+        const int i = 4 * (l >> 4) + r;
+        float acc = c[r];
+        for (int kb = 0; kb < 4; kb++) {
+            _Float16 av[8], bv[8];
+            std::memcpy(av, all[i + 16 * kb], 16);
+            std::memcpy(bv, all[n + 16 * kb] + 16, 16);
+            for (int e = 0; e < 8; e++) {
+                acc += (float)av[e] * (float)bv[e];
+            }
+        }
+        c[r] = acc;
+    }
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_f16(...) hipemu_mfma_16x16x32_f16(__VA_ARGS__)
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(...) hipemu_mfma_32x32x2_f32(__VA_ARGS__)
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(...) hipemu_mfma_32x32x16_f16(__VA_ARGS__)
 #define __builtin_amdgcn_s_setprio(p) ((void)0)

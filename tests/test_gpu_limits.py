@@ -2,9 +2,7 @@
 up to 65536 in a global scratch row; was 4096): nprobe above 4096 and range search on indexes with more than 4096
 lists, against the oracle, bit for bit.
 
-The change was made at the end of round 2 after the round's GPU minutes were spent (the selection kernel itself is
-unchanged; only its LDS allowance and the limits moved), so these tests are skipped unless KNHIP_TEST_UNVALIDATED=1.
-Next round:  KNHIP_TEST_UNVALIDATED=1 python -m pytest tests/test_gpu_limits.py -m gpu -x -q"""
+First run on hardware in round 3 (13 cases green)."""
 import os
 
 import numpy as np
@@ -13,9 +11,7 @@ import pytest
 from conftest import assert_parity, gen_data
 from oracle import binding as ob
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("KNHIP_TEST_UNVALIDATED") != "1",
-                                 reason="not validated on hardware yet (set KNHIP_TEST_UNVALIDATED=1)")]
+pytestmark = pytest.mark.gpu
 
 
 def _gpu(ix):
@@ -76,9 +72,8 @@ def test_nprobe_and_range_above_16384_lists(port):
 @pytest.mark.parametrize("M", [8, 16, 64])
 @pytest.mark.parametrize("metric", [ob.L2, ob.IP], ids=["l2", "ip"])
 def test_range_search_ivfpq_other_code_widths(port, monkeypatch, M, metric):
-    """range.hip::pq_adc_dump_kernel behind KNHIP_UNVALIDATED=1: range search on IVF-PQ with m != 32"""
+    """range.hip::pq_adc_dump_kernel: range search on IVF-PQ with m != 32"""
     from helpers import finish_ivfpq
-    monkeypatch.setenv("KNHIP_UNVALIDATED", "1")
     nb, d, nlist = 12000, 128, 48
     xb, xq = gen_data(nb, d, 42), gen_data(30, d, 44)
     ix = finish_ivfpq(port, ob.make_index(port, ob.IVF_PQ, metric, xb, nlist=nlist, M=M))

@@ -1,10 +1,6 @@
-"""GPU parity tests (-m gpu) of the half-precision ADC prefilter + exact finish of the IVF-PQ scan
-(knowhere_amd/csrc/pq_filter.hip, KNHIP_PQF=1): the prefilter path, the exact kernels (KNHIP_PQF unset) and the
-oracle must agree bit for bit -- distances AND ids.
-
-The kernel was written at the end of round 2 after the round's GPU minutes were spent: it has not run on hardware yet,
-so these tests are skipped unless KNHIP_TEST_PQF=1 (the product switch KNHIP_PQF is off by default as well).  First
-thing to run in the next round:  KNHIP_TEST_PQF=1 python -m pytest tests/test_gpu_pqf.py -m gpu -x -q"""
+"""GPU parity tests (-m gpu) of the matrix-core ADC prefilter + exact finish of the IVF-PQ scan
+(knowhere_amd/csrc/pq_filter.hip): the prefilter path (KNHIP_PQF=1: whenever the shape allows), the exact kernels
+(KNHIP_PQF=0) and the oracle must agree bit for bit -- distances AND ids."""
 import os
 
 import numpy as np
@@ -14,9 +10,7 @@ from conftest import assert_parity, gen_data
 from helpers import finish_ivfpq
 from oracle import binding as ob
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("KNHIP_TEST_PQF") != "1",
-                                 reason="pq_filter.hip is not validated on hardware yet (set KNHIP_TEST_PQF=1)")]
+pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
@@ -37,7 +31,7 @@ def _bitset(n, frac, seed):
 
 
 def _pair(monkeypatch, ix, guard=True):
-    monkeypatch.delenv("KNHIP_PQF", raising=False)  # read when the lists are attached
+    monkeypatch.setenv("KNHIP_PQF", "0")  # read when the lists are attached
     g0 = _gpu(ix)
     monkeypatch.setenv("KNHIP_PQF", "1")
     monkeypatch.setenv("KNHIP_PQF_GUARD", "1" if guard else "0")

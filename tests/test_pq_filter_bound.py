@@ -1,12 +1,13 @@
-"""CPU check of the error bound the half-precision ADC prefilter relies on (knowhere_amd/csrc/pq_filter.hip).
+"""CPU check of the error bound the matrix-core ADC prefilter relies on (knowhere_amd/csrc/pq_filter.hip).
 
 The prefilter never decides a result: it only has to let every row through whose EXACT distance (the reference's fp32
 sum in m order) is within the query's bound, which holds as long as |approx - exact| <= eps.  Here the kernel's
-arithmetic is replayed in numpy: per-query table scaled to integers of at most 2048 in all, 32 (exact) half additions in
-the rotated order a lane walks (any start phase), the per-vector term-2 sum in fp32, the final fp32 combination; exact is
-the reference's sequence; eps is the kernel's formula.  The bound must hold with room to spare on random and on
-adversarial inputs (one-signed tables whose partial sums reach A_q, tiny and huge value scales, entries far below the
-half range of the scaled table)."""
+arithmetic is replayed in numpy: per-query table scaled by a power of two and rounded to half precision, 32 products
+with 1.0 accumulated in fp32 under the least favourable treatment the matrix core could give them (every addition
+rounded on its own, in the lane's k-block order and in reverse), the per-vector term-2 sum in fp32, the final fp32
+combination; exact is the reference's sequence; eps is the kernel's formula.  The bound must hold with room to spare on
+random and on adversarial inputs (one-signed tables whose partial sums reach A_q, tiny and huge value scales, entries
+far below the half range of the scaled table)."""
 import numpy as np
 import pytest
 
@@ -34,16 +35,23 @@ def _tables(q, cb, is_l2):
 
 
 def _query_prep(Qf, pabs_max):
-    """pqf_query_table_kernel: A = sum_m max_c |Qf|, sc = 2032 / A, integer table rint(Qf sc), eps_base"""
+    """pqf_query_table_kernel: A = sum_m max_c |Qf|, sc = 2^(15 - e) with max |Qf| = f 2^e, table half(Qf sc), eps_base"""
     A = f32(0)
+    gmax = f32(0)
     for m in range(M):
-        A = f32(A + np.abs(Qf[m]).max())
-    with np.errstate(over="ignore", divide="ignore"):
-        sc = f32(f32(2032.0) / A) if A > 0 else f32(1.0)
-    if not np.isfinite(sc):
+        a = np.abs(Qf[m]).max()
+        A = f32(A + a)
+        gmax = max(gmax, a)
+    if not np.isfinite(A):
         return A, f32(1.0), np.zeros_like(Qf, dtype=f16), f32(np.inf)  # (no bound: the exact kernels)
-    Qh = np.rint((Qf * sc).astype(f32)).astype(f16)
-    eps_base = f32(f32(16.5) / sc + f32(64.0) * U * f32(pabs_max + A))
+    sc = f32(1.0)
+    if gmax > 0:
+        _, e = np.frexp(gmax)
+        sc = f32(np.ldexp(1.0, int(np.clip(15 - e, -126, 126))))
+    isc = f32(1.0) / sc
+    with np.errstate(over="ignore", under="ignore"):
+        Qh = (Qf * sc).astype(f32).astype(f16)
+    eps_base = f32(f32(UH * A) * f32(1.001) + f32(2.0 ** -20) * isc + f32(128.0) * U * f32(pabs_max + A))
     return A, sc, Qh, eps_base
 
 
@@ -91,62 +99,72 @@ def test_half_adc_bound_holds_with_margin(is_l2, scale, mode):
             lut = f32(P[m, row[m]] + Qf[m, row[m]]) if is_l2 else Qf[m, row[m]]
             acc = f32(acc + lut)
         exact = f32(dis0 + acc)
-        # approx: half additions in a lane's rotated order, start phase = any of the 16
-        for ph in (0, 5, 15):
-            h = f16(0)
-            for t in range(M):
-                m = (t + ph) & 31
-                h = f16(h + Qh[m, row[m]])
-            assert np.isfinite(f32(h))
+        # approx: the 32 halves (exact products with 1.0) added in fp32, one rounding per addition, in several orders
+        for order in (list(range(M)), list(range(M - 1, -1, -1)), [(5 * t + 3) % M for t in range(M)]):
+            h = f32(0)
+            for m in order:
+                h = f32(h + f32(Qh[m, row[m]]))
             ps = f32(0)
             for m in range(M):
                 ps = f32(ps + P[m, row[m]])
-            approx = f32(f32(h) * isc + f32(dis0 + ps)) if is_l2 else f32(f32(h) * isc + dis0)
+            # kernel: L2 fma(h, isc, ps) <= (tau + eps) - dis0;  pessimistic value fma(h, isc, (dis0 +- eps) + ps)
+            approx = f32(f32(h * isc + ps) + dis0) if is_l2 else f32(f32(h * isc) + dis0)
             err = abs(float(approx) - float(exact))
             assert err <= float(eps), (err, float(eps))
             worst = max(worst, err / float(eps))
     assert worst < 0.75, f"the bound holds but with little room: {worst:.3f} of eps"
 
 
-def test_integer_table_makes_the_half_additions_exact():
-    """the per-m maxima of the rounded entries sum to at most 2048, every entry is an integer: every partial sum of a
-    vector's 32 entries is an integer of magnitude <= 2048, which half precision represents exactly -- the half sum
-    equals the integer sum for any order of the additions"""
+def test_scaled_half_table_keeps_eleven_bits():
+    """the power-of-two scale puts the largest magnitude into [2^14, 2^15): no entry overflows half precision and every
+    normal entry is within 2^-11 relative of the fp32 value (2^-25 absolute, scaled, for the subnormal ones)"""
     rng = np.random.default_rng(3)
     for scale in (1e-15, 1e-3, 1.0, 1e6, 1e15):
-        for mode in ("one_signed", "random"):
+        for mode in ("one_signed", "random", "mixed_magnitudes"):
             q, cb = _case(rng, scale, mode)
             Qf = _tables(q, cb, True)
             A, sc, Qh, eps = _query_prep(Qf, f32(0))
             assert np.isfinite(eps)
-            Qi = Qh.astype(np.float64)
-            assert np.array_equal(Qi, np.rint(Qi)) and np.abs(Qi).max(1).sum() <= 2048
-            codes = rng.integers(0, KSUB, (20, M))
-            codes[0] = np.abs(Qf).argmax(1)
-            for row in codes:
-                exact_int = int(Qi[np.arange(M), row].sum())
-                for ph in (0, 7):
-                    h = f16(0)
-                    for t in range(M):
-                        m = (t + ph) & 31
-                        h = f16(h + Qh[m, row[m]])
-                    assert float(h) == exact_int
+            big = np.abs(Qh.astype(np.float64)).max()
+            assert 2.0 ** 14 <= big <= 2.0 ** 15
+            x = Qf.astype(np.float64) * float(sc)
+            err = np.abs(Qh.astype(np.float64) - x)
+            assert (err <= np.maximum(np.abs(x) * 2.0 ** -11, 2.0 ** -25)).all()
 
 
-def test_token_rotation_covers_every_subquantizer_once():
-    """a lane's 32 steps of a window visit each m exactly once, and the 16 lanes an LDS gather is serviced together for
+def test_lane_map_covers_every_subquantizer_once_without_bank_conflicts():
+    """pq_filter.hip::pf_lane_vec / pf_lane_m: the two lanes (k blocks 2 v, 2 v + 1) that fetch for one vector of a group
+    visit its 32 sub-quantizers exactly once over the 16 steps, and the 16 lanes an LDS gather is serviced together for
     sit on 16 different bank quads (m mod 16) at every step -- the phase map of kernels.h::pq_stream_phase"""
     def phase(lane):
         l = lane & 31
         return l if l < 4 else l + 4 if l < 12 else l - 8 if l < 16 else l - 16 if l < 20 else l - 12 if l < 28 else l - 24
+
+    def lane_vec(L):
+        return 16 * (L >> 5) + (L & 15)
+
+    def lane_m(L, s):
+        return 16 * ((L >> 4) & 1) + ((phase(L) + s) & 15)
     groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27],
               [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
-    for lane in range(64):
-        assert sorted((t + phase(lane)) & 31 for t in range(32)) == list(range(32))
-    for t in range(32):
+    seen = {}
+    for L in range(64):
+        for s_ in range(16):
+            seen.setdefault(lane_vec(L), []).append(lane_m(L, s_))
+    assert sorted(seen) == list(range(32))
+    for v, ms in seen.items():
+        assert sorted(ms) == list(range(32)), v
+    for s_ in range(16):
         for g in groups:
             for base in (0, 32):
-                quads = {((t + phase(base + l)) & 31) & 15 for l in g}
-                assert len(quads) == 16
+                assert len({lane_m(base + l, s_) & 15 for l in g}) == 16
         for g0 in range(0, 64, 16):  # (also conflict-free for contiguous sixteenths)
-            assert len({((t + phase(l)) & 31) & 15 for l in range(g0, g0 + 16)}) == 16
+            assert len({lane_m(l, s_) & 15 for l in range(g0, g0 + 16)}) == 16
+    # selector operand: accumulator row i of column n sums element i & 7 of the k blocks 2 (i >> 3), 2 (i >> 3) + 1 -- the
+    # lanes that fetch for vector 16 (i >> 3) + n
+    for i in range(16):
+        for kb in range(4):
+            on = (kb >> 1) == (i >> 3)
+            for n in range(16):
+                L = 16 * kb + n
+                assert (lane_vec(L) == 16 * (i >> 3) + n) == on

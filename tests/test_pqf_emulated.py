@@ -103,20 +103,24 @@ def test_emulated_bitset_and_overflow_flags(emu, port):
     D, I, cnt, ovf, tau, _ = run_emulated(emu, port, ix, xq, k, nprobe, bitset=bs, use_hist=0)
     assert not ovf.any()
     assert np.array_equal(I, Io) and np.array_equal(D.view(np.uint32), Do.view(np.uint32))
-    # a capacity of 8 candidates: a query that gathers more is flagged 1 by the filter kernel; the finish kernel's first
+    # a small capacity: a query that gathers more is flagged 1 by the filter kernel; the finish kernel's first
     # pass then prepares its RETRY (flag 2, candidate list emptied, bound = exact k-th of the 8 gathered rows -- the
     # retry and exact rounds themselves belong to the product's orchestration, not to this harness); the queries that
     # stayed within the capacity still equal the oracle
-    D2, I2, cnt2, ovf2, _, _ = run_emulated(emu, port, ix, xq, k, nprobe, cap=8, bitset=bs, use_hist=0)
+    # (the capacity is taken one below the largest candidate count of the first run: the matrix-core filter passes little
+    # more than k rows per query)
+    small = int(cnt.max()) - 1
+    assert small >= k
+    D2, I2, cnt2, ovf2, _, _ = run_emulated(emu, port, ix, xq, k, nprobe, cap=small, bitset=bs, use_hist=0)
     assert (ovf2 == 2).sum() >= 1 and set(ovf2.tolist()) <= {0, 2}, ovf2
     assert (cnt2[ovf2 == 2] == 0).all()
     ok = ovf2 == 0
     assert np.array_equal(I2[ok], Io[ok])
-    # ... and with the retry round (one-query units under the tightened bound, second finish pass): a capacity of 64
+    # ... and with the retry round (one-query units under the tightened bound, second finish pass): the small capacity
     # overflows in the first round; in the second the bound is the exact k-th of whichever 64 rows got in first (thread
     # timing), so a query may overflow again (flag 1: the product's exact round) -- every query that finished here ends
     # with the oracle's result, and most do
-    D3, I3, cnt3, ovf3, _, _ = run_emulated(emu, port, ix, xq, k, nprobe, cap=64, bitset=bs, use_hist=0, retry=1)
+    D3, I3, cnt3, ovf3, _, _ = run_emulated(emu, port, ix, xq, k, nprobe, cap=small, bitset=bs, use_hist=0, retry=1)
     ok3 = ovf3 == 0
     assert set(ovf3.tolist()) <= {0, 1} and ok3.sum() >= nq - 2, (ovf3, cnt3)
     assert np.array_equal(I3[ok3], Io[ok3]) and np.array_equal(D3[ok3].view(np.uint32), Do[ok3].view(np.uint32))

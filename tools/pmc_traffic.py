@@ -1,9 +1,15 @@
-"""tools/pmc_traffic.py -- HBM bytes per launch of the dominant scan kernel from the FETCH_SIZE / WRITE_SIZE passes of
-tools/profile_bench.sh -> profiles/bench_pmc_traffic.json (key = the bench workload, value stamped with the commit).
-usage: python tools/pmc_traffic.py <fetch.json> <write.json> <key> <kernel-substring> [commit]"""
+"""tools/pmc_traffic.py -- the PMC evidence of the dominant scan kernel from the passes of tools/profile_bench.sh ->
+profiles/bench_pmc_traffic.json (key = the bench workload [+ kernel path], value stamped with the commit): HBM bytes per
+launch from FETCH_SIZE / WRITE_SIZE, and -- when the sq / lds / mfma summaries are given -- the issue counters bench.py
+turns into unit-busy fractions (SQ_LDS_IDX_ACTIVE, SQ_INSTS_VALU, SQ_VALU_MFMA_BUSY_CYCLES against GRBM_GUI_ACTIVE / 8).
+usage: python tools/pmc_traffic.py <fetch.json> <write.json> <key> <kernel-substring> [commit] [sq.json lds.json mfma.json]"""
 import json, os, subprocess, sys
 fetch, write, key, kern = sys.argv[1:5]
-commit = sys.argv[5] if len(sys.argv) > 5 else subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+commit = sys.argv[5] if len(sys.argv) > 5 and sys.argv[5] else subprocess.run(
+    ["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+extra = sys.argv[6:]
+
+
 def mean(path, counter):
     d = json.load(open(path))
     best = None
@@ -13,6 +19,8 @@ def mean(path, counter):
             if best is None or c["mean"] > best[0]:
                 best = (c["mean"], k, c["dispatches"])
     return best
+
+
 f, w = mean(fetch, "FETCH_SIZE"), mean(write, "WRITE_SIZE")
 # gfx950: FETCH_SIZE (KB) reports half of a wide coalesced read (MI355X_MICROARCH.md, HBM section); WRITE_SIZE uncalibrated
 bytes_ = f[0] * 1024 * 2 + (w[0] * 1024 if w else 0)
@@ -24,5 +32,15 @@ except Exception:
     t = {}
 t[key] = {"hbm_bytes_per_launch": bytes_, "kernel": f[1], "fetch_size_kb": f[0], "write_size_kb": w[0] if w else None,
           "dispatches": f[2], "commit": commit, "correction": "FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024"}
+if extra:
+    sq = {}
+    for p in extra:
+        d = json.load(open(p))
+        for k, v in d.items():
+            if k == f[1]:
+                for c, cv in v.get("counters", {}).items():
+                    sq[c] = cv["mean"]
+    sq["source"] = ", ".join(os.path.basename(p) for p in extra) + f" (separate --pmc passes of the bench, commit {commit})"
+    t[key]["sq"] = sq
 json.dump(t, open(path, "w"), indent=1)
 print(key, bytes_)

@@ -7,6 +7,12 @@
 //   6 f16 table, 8 queries per ds_read_b128, 4 v_pk_add_f16 per lookup, no EXEC flips: the loop an approximate
 //     (prefilter) ADC pass could run -- lanes rotated through m instead of delayed, half the LDS bytes per query
 //   7 the same with v_pk_add_f16 only (no LDS, no SDWA): its VALU floor
+//   8 f16 table, the additions on the matrix cores: every ds_read_b128 result (8 halves per lane) is the B operand of one
+//     v_mfma_f32_16x16x32_f16 whose A operand is a constant selector (A[i][k] = [i == k mod 8]): fp32 accumulation of
+//     512 lookups per instruction, no VALU on the data path (two accumulators alternate)
+//   9 the same with a single accumulator (dependent MFMAs back to back)
+//  10 mode 8 without the LDS reads (MFMA + SDWA only)
+//  11 mode 8 with two value buffers (4 reads in flight instead of 8): what pq_filter.hip's registers allow
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -41,6 +47,16 @@ __device__ __forceinline__ void accum2_h(uint32_t& h0, uint32_t& h1, uint32_t& h
                  : "v"(v[0].x), "v"(v[0].y), "v"(v[0].z), "v"(v[0].w), "v"(v[1].x), "v"(v[1].y), "v"(v[1].z), "v"(v[1].w));
 }
 
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void accum2_mfma(f4& a0, f4& a1, const h8 sel, const f4 (&v)[2], bool one_acc) {
+    a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(sel, __builtin_bit_cast(h8, v[0]), a0, 0, 0, 0);
+    if (one_acc) {
+        a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(sel, __builtin_bit_cast(h8, v[1]), a0, 0, 0, 0);
+    } else {
+        a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(sel, __builtin_bit_cast(h8, v[1]), a1, 0, 0, 0);
+    }
+}
+
 __device__ __forceinline__ uint32_t addr_lo(uint32_t w, uint32_t one) {
     uint32_t a;
     asm("v_lshlrev_b32_sdwa %0, %2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(a) : "v"(w), "s"(one));
@@ -67,8 +83,11 @@ __global__ __launch_bounds__(1024) void k(float* out, const uint32_t* tok, int n
     f2 n01 = {0, 0}, n23 = {0, 0}, o01 = {0, 0}, o23 = {0, 0};
     f4 B0[2], B1[2], B2[2], B3[2];
     uint32_t h0 = 0, h1 = 0, h2 = 0, h3 = 0;
+    f4 m0 = {0, 0, 0, 0}, m1 = {0, 0, 0, 0};
+    h8 sel;
+    for (int e = 0; e < 8; e++) sel[e] = (_Float16)(((lane & 15) == e) ? 1.0f : 0.0f);
     auto rd = [&](uint32_t a) -> f4 {
-        if (MODE == 2 || MODE == 5 || MODE == 7) return f4{__uint_as_float(a), 1.f, 2.f, 3.f};
+        if (MODE == 2 || MODE == 5 || MODE == 7 || MODE == 10) return f4{__uint_as_float(a), 1.f, 2.f, 3.f};
         return *reinterpret_cast<lds_f4*>(a);
     };
     auto issue2 = [&](uint32_t w, f4 (&v)[2]) {
@@ -87,11 +106,21 @@ __global__ __launch_bounds__(1024) void k(float* out, const uint32_t* tok, int n
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #define UNIT(U, BUF, WORD)                                                   \
     __builtin_amdgcn_sched_barrier(0);                                       \
-    if (MODE == 6 || MODE == 7) accum2_h(h0, h1, h2, h3, BUF);               \
+    if (MODE >= 8) accum2_mfma(m0, m1, sel, BUF, MODE == 9);                 \
+    else if (MODE == 6 || MODE == 7) accum2_h(h0, h1, h2, h3, BUF);          \
     else if (MODE != 4) accum2<U, MODE != 1>(n01, n23, o01, o23, BUF);       \
     else asm volatile("" :: "v"(BUF[0]), "v"(BUF[1]));                       \
     __builtin_amdgcn_sched_barrier(0);                                       \
     issue2(WORD, BUF);
+    if (MODE == 11) {
+        for (int w = 0; w < nwin; w++) {
+            UNIT(0, B0, T[2]) UNIT(1, B1, T[3]) UNIT(2, B0, T[4]) UNIT(3, B1, T[5])
+            UNIT(4, B0, T[6]) UNIT(5, B1, T[7]) UNIT(6, B0, T[8]) UNIT(7, B1, T[9])
+            UNIT(8, B0, T[10]) UNIT(9, B1, T[11]) UNIT(10, B0, T[12]) UNIT(11, B1, T[13])
+            UNIT(12, B0, T[14]) UNIT(13, B1, T[15]) UNIT(14, B0, T[0]) UNIT(15, B1, T[1])
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else
     for (int w = 0; w < nwin; w++) {
         UNIT(0, B0, T[4]) UNIT(1, B1, T[5]) UNIT(2, B2, T[6]) UNIT(3, B3, T[7])
         UNIT(4, B0, T[8]) UNIT(5, B1, T[9]) UNIT(6, B2, T[10]) UNIT(7, B3, T[11])
@@ -102,7 +131,7 @@ __global__ __launch_bounds__(1024) void k(float* out, const uint32_t* tok, int n
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     out[blockIdx.x * 1024 + threadIdx.x] = n01.x + n01.y + n23.x + n23.y + o01.x + o23.y + B0[0].x + B1[0].x + B2[0].x + B3[0].x +
-                                           __uint_as_float(h0 ^ h1 ^ h2 ^ h3);
+                                           __uint_as_float(h0 ^ h1 ^ h2 ^ h3) + m0.x + m0.y + m0.z + m0.w + m1.x + m1.y + m1.z + m1.w;
     if (lane == 0) atomicAdd(cyc + (threadIdx.x >> 6), t1 - t0);
 }
 
@@ -124,7 +153,7 @@ void run(const char* name, const uint32_t* dtok, float* out, unsigned long long*
     unsigned long long h[16];
     hipMemcpy(h, dcyc, sizeof(h), hipMemcpyDeviceToHost);
     // per CU: 16 waves x nwin windows; lookups per window per wave = 64 lanes x 32 steps x 4 queries (8 in the f16 modes)
-    const double lookups = 256.0 * 16 * nwin * 64 * 32 * ((MODE == 6 || MODE == 7) ? 8 : 4);
+    const double lookups = 256.0 * 16 * nwin * 64 * 32 * ((MODE >= 6) ? 8 : 4);
     printf("%-34s %8.3f ms  %6.1f ns per window-round (16 waves)  %5.1f lookups/ns/CU (LDS peak 64/clk)  ticks/window: w0 %.0f w15 %.0f\n", name, ms,
            ms * 1e6 / nwin, lookups / 256 / (ms * 1e6), (double)h[0] / blocks / nwin, (double)h[15] / blocks / nwin);
 }
@@ -157,5 +186,9 @@ int main() {
     run<5>("only accumulates", dtok, out, dcyc);
     run<6>("f16 table, 8 queries, no flips", dtok, out, dcyc);
     run<7>("f16: only v_pk_add_f16", dtok, out, dcyc);
+    run<8>("f16 table, MFMA 16x16x32 adds", dtok, out, dcyc);
+    run<9>("f16 table, MFMA adds, one acc", dtok, out, dcyc);
+    run<10>("MFMA adds + SDWA, no LDS", dtok, out, dcyc);
+    run<11>("MFMA adds, 4 reads in flight", dtok, out, dcyc);
     return 0;
 }
