@@ -328,6 +328,69 @@ hipError_t launch_centroid_update(const float* x, int64_t ld, int off, int dsub,
     return hipGetLastError();
 }
 
+// ---- IndexFlat::assign under the inner product: exact ties ---------------------------------------------------------
+// The reference's k = 1 search keeps the FIRST centroid that reaches the maximum (strict improvement, IndexFlat.cpp ->
+// exhaustive_inner_product_seq / the heap's strict admission); the library's coarse search returns ties in canonical
+// order, which for the inner product is the HIGHEST id first.  Exact ties are not rare in training: split_clusters
+// (impl/ClusteringHelpers.cpp:177-240) makes two centroids that differ by a factor 1 +- 1/1024 per dimension, and after the
+// spherical renormalisation their products with a row can round to the same float.  One wave per row: rows whose two
+// best candidates tie bit for bit are rescanned over all centroids (sequential exact products, lowest index of the
+// maximum); every other row keeps its best candidate.
+__global__ __launch_bounds__(256) void assign_first_max_ip_kernel(const float* __restrict__ x, int64_t n, int d,
+                                                                  const float* __restrict__ cen, int64_t nlist,
+                                                                  const int64_t* __restrict__ top2_keys,
+                                                                  const float* __restrict__ top2_dis,
+                                                                  int64_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+    if (i >= n) {
+        return;
+    }
+    const int64_t k0 = top2_keys[2 * i];
+    if (!(top2_dis[2 * i] == top2_dis[2 * i + 1]) || top2_keys[2 * i + 1] < 0) {
+        if (lane == 0) {
+            out[i] = k0;
+        }
+        return;
+    }
+    const float* xi = x + i * d;
+    float best = -INFINITY;
+    int64_t bi = INT64_MAX;
+    for (int64_t c = lane; c < nlist; c += 64) {
+        const float* cc = cen + c * d;
+        float t = 0.f;
+        for (int j = 0; j < d; j++) {
+            t = ip_step(t, xi[j], cc[j]);
+        }
+        if (t > best) { // (c ascends within a lane: the first maximum stays)
+            best = t;
+            bi = c;
+        }
+    }
+#pragma unroll
+    for (int dlt = 32; dlt > 0; dlt >>= 1) {
+        const float ob = __shfl_xor(best, dlt, 64);
+        const int64_t oi = __shfl_xor(bi, dlt, 64);
+        if (ob > best || (ob == best && oi < bi)) {
+            best = ob;
+            bi = oi;
+        }
+    }
+    if (lane == 0) {
+        out[i] = bi == INT64_MAX ? k0 : bi;
+    }
+}
+
+hipError_t launch_assign_first_max_ip(const float* x, int64_t n, int d, const float* cen, int64_t nlist,
+                                      const int64_t* top2_keys, const float* top2_dis, int64_t* out, hipStream_t s) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(assign_first_max_ip_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, x, n, d, cen, nlist,
+                       top2_keys, top2_dis, out);
+    return hipGetLastError();
+}
+
 // spherical k-means (Clustering::post_process_centroids, Clustering.cpp:35-38 -> fvec_renorm_L2, utils/distances.cpp:
 // 238-275): every row of non-zero squared norm (sequential float sum) is scaled by (float)(1.0 / sqrtf(norm2)).
 // One thread per row for the norm (k <= 65536 rows), then one thread per element.
@@ -341,7 +404,10 @@ __global__ void row_inv_norm_kernel(const float* __restrict__ x, int64_t k, int 
     for (int j = 0; j < d; j++) {
         nr = fadd_x(nr, fmul_x(xi[j], xi[j]));
     }
-    inv[c] = nr > 0.f ? (float)__ddiv_rn(1.0, (double)__fsqrt_rn(nr)) : 1.0f;
+    // sqrtf, not __fsqrt_rn: the intrinsic compiles to the bare v_sqrt_f32 (1 ulp), sqrtf to the correctly rounded
+    // sequence -- what the host's sqrtf returns.  (float)(1.0 / (double)s) == 1.0f / s: a double quotient rounded to
+    // float is the correctly rounded float quotient
+    inv[c] = nr > 0.f ? (float)(1.0 / (double)sqrtf(nr)) : 1.0f;
 }
 
 __global__ void row_scale_kernel(float* __restrict__ x, int64_t k, int d, const float* __restrict__ inv) {

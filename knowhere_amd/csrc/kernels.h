@@ -448,6 +448,9 @@ hipError_t launch_merge_lists(const uint8_t* old_codes, const int64_t* old_ids, 
                               const int64_t* new_seg, const int64_t* out_off, int64_t nlist, int64_t code_size,
                               uint8_t* out_codes, int64_t* out_ids, hipStream_t s);
 hipError_t launch_iota_i64(int64_t* out, int64_t n, int64_t base, hipStream_t s);
+// k = 1 assignment under the inner product with the reference's first-maximum tie rule (see build.hip)
+hipError_t launch_assign_first_max_ip(const float* x, int64_t n, int d, const float* cen, int64_t nlist,
+                                      const int64_t* top2_keys, const float* top2_dis, int64_t* out, hipStream_t s);
 // fvec_renorm_L2 of k rows in place; inv_tmp: k floats of scratch
 hipError_t launch_renorm_rows(float* x, int64_t k, int d, float* inv_tmp, hipStream_t s);
 

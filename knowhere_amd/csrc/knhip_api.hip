@@ -2309,6 +2309,30 @@ int split_clusters_host(int d, int64_t k, int64_t n, std::vector<float>& hassign
     return nsplit;
 }
 
+// IndexFlat::assign (k = 1 search, first best centroid wins) of n device rows.  L2: the coarse search's canonical order
+// (distance, then id ascending) is the reference's answer.  Inner product: canonical ties come highest id first, the
+// reference keeps the lowest -- rows whose two best candidates tie are rescanned (build.hip).
+int assign_rows(const knhip_index* idx, const float* d_x, int64_t n, int64_t* d_assign, hipStream_t s) {
+    if (n <= 0) {
+        return KNHIP_OK;
+    }
+    DevBuf dist;
+    if (idx->desc.metric != KNHIP_IP || idx->nlist < 2) {
+        HIP_TRY(dist.alloc((size_t)n * sizeof(float)));
+        if (int rc = knhip_coarse_search_device(idx, d_x, n, 1, d_assign, dist.as<float>(), s)) return rc;
+        HIP_TRY(hipStreamSynchronize(s)); // (the scratch is freed on return)
+        return KNHIP_OK;
+    }
+    DevBuf keys2;
+    HIP_TRY(dist.alloc((size_t)n * 2 * sizeof(float)));
+    HIP_TRY(keys2.alloc((size_t)n * 2 * sizeof(int64_t)));
+    if (int rc = knhip_coarse_search_device(idx, d_x, n, 2, keys2.as<int64_t>(), dist.as<float>(), s)) return rc;
+    HIP_TRY(launch_assign_first_max_ip(d_x, n, idx->d, idx->centroids.as<float>(), idx->nlist, keys2.as<int64_t>(),
+                                       dist.as<float>(), d_assign, s));
+    HIP_TRY(hipStreamSynchronize(s)); // (the scratch above is freed on return)
+    return KNHIP_OK;
+}
+
 struct TrainParams {
     int niter = 25;          // ClusteringParameters default (Clustering.h); the level-1 quantizer overrides it with 10
     int max_points = 256;
@@ -2403,7 +2427,7 @@ int kmeans_impl(int device, int metric, int d, int64_t n, const float* d_x, int6
     // -- iterations.  (The reference leaves the loop when the objective repeats bit for bit, Clustering.cpp:362-377 with
     // early_stop_threshold 0: that is the fixed point of this deterministic loop, where further iterations reproduce
     // the same centroids -- running them changes nothing.)
-    DevBuf keys64, dist, keys32, sorted_rows, seg_off, tmp, hassign_d;
+    DevBuf keys64, keys32, sorted_rows, seg_off, tmp, hassign_d;
     HIP_TRY(sorted_rows.alloc((size_t)nx * sizeof(int32_t)));
     HIP_TRY(seg_off.alloc((size_t)(k + 1) * sizeof(int64_t)));
     const size_t tmp_bytes = group_rows_tmp_bytes(nx, k);
@@ -2418,7 +2442,6 @@ int kmeans_impl(int device, int metric, int d, int64_t n, const float* d_x, int6
         HIP_TRY(keys32.alloc((size_t)nx * sizeof(int32_t)));
     } else {
         HIP_TRY(keys64.alloc((size_t)nx * sizeof(int64_t)));
-        HIP_TRY(dist.alloc((size_t)nx * sizeof(float)));
         knhip_desc desc{};
         desc.kind = KNHIP_IVF_FLAT;
         desc.metric = metric;
@@ -2435,8 +2458,7 @@ int kmeans_impl(int device, int metric, int d, int64_t n, const float* d_x, int6
                                       seg_off.as<int64_t>(), tmp.p, tmp_bytes, nullptr));
         } else {
             if (int rc = knhip_index_set_coarse_device(assigner, d_cen)) return rc;
-            if (int rc = knhip_coarse_search_device(assigner, xs, nx, 1, keys64.as<int64_t>(), dist.as<float>(), nullptr))
-                return rc;
+            if (int rc = assign_rows(assigner, xs, nx, keys64.as<int64_t>(), nullptr)) return rc;
             HIP_TRY(group_rows_by_key(keys64.as<int64_t>(), nullptr, nx, k, sorted_rows.as<int32_t>(),
                                       seg_off.as<int64_t>(), tmp.p, tmp_bytes, nullptr));
         }
@@ -2478,9 +2500,8 @@ int set_pq_device(knhip_index* idx, const float* d_cb) {
 // assignment (k = 1 exact coarse search) + codes of n device rows; d_assign [n] int64, d_codes [n][code_size]
 int encode_rows(const knhip_index* idx, int64_t n, const float* d_x, int64_t* d_assign, uint8_t* d_codes, hipStream_t s) {
     const int d = idx->d;
-    DevBuf dist, resid;
-    HIP_TRY(dist.alloc((size_t)std::max<int64_t>(n, 1) * sizeof(float)));
-    if (int rc = knhip_coarse_search_device(idx, d_x, n, 1, d_assign, dist.as<float>(), s)) return rc;
+    DevBuf resid;
+    if (int rc = assign_rows(idx, d_x, n, d_assign, s)) return rc;
     if (idx->desc.kind == KNHIP_IVF_FLAT) {
         HIP_TRY(hipMemcpyAsync(d_codes, d_x, (size_t)n * d * sizeof(float), hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipStreamSynchronize(s));
@@ -2629,11 +2650,10 @@ int train_device_impl(knhip_index* idx, int64_t n, const float* d_x, const knhip
         HIP_TRY(hipDeviceSynchronize());
         xt = xt_buf.as<float>();
     }
-    DevBuf assign, dist, resid;
+    DevBuf assign, resid;
     HIP_TRY(assign.alloc((size_t)nt * sizeof(int64_t)));
-    HIP_TRY(dist.alloc((size_t)nt * sizeof(float)));
     HIP_TRY(resid.alloc((size_t)nt * d * sizeof(float)));
-    if (int rc = knhip_coarse_search_device(idx, xt, nt, 1, assign.as<int64_t>(), dist.as<float>(), nullptr)) return rc;
+    if (int rc = assign_rows(idx, xt, nt, assign.as<int64_t>(), nullptr)) return rc;
     HIP_TRY(launch_residual(xt, idx->centroids.as<float>(), assign.as<int64_t>(), nt, d, resid.as<float>(), nullptr));
     HIP_TRY(hipDeviceSynchronize());
     if (kind == KNHIP_IVF_PQ) {
