@@ -348,7 +348,9 @@ def make_roofline(a, kind, prof, world):
                          "mscan": {"queries_per_step": prof["mscan_queries"] / steps,
                                    "overflow_queries_per_step": prof["mscan_overflow_queries"] / steps,
                                    "candidates_per_query": round(prof["mscan_candidates"] /
-                                                                 max(prof["mscan_queries"], 1), 1)}}, **common))
+                                                                 max(prof["mscan_queries"], 1), 1),
+                                   "exact_recomputations_per_query": round(prof.get("mscan_recomputed", 0) /
+                                                                           max(prof["mscan_queries"], 1), 1)}}, **common))
         lds = scan_bytes * 4.0 / sec / 1e9 if sec > 0 else 0.0
         out = dict({"bound": "lds", "kernel": "knhip::pq_scan_q4_kernel<true, 2>", "achieved": round(lds, 1),
                     "peak": round(LDS_PEAK_GBPS, 1), "unit": "GB/s", "frac": round(lds / LDS_PEAK_GBPS, 4),

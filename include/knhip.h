@@ -329,12 +329,13 @@ typedef struct knhip_stage_times {
     int64_t scan_items;   /* work items launched by the scan kernel */
     int64_t coarse_fallback_queries; /* queries whose MFMA-prefilter certificate failed (exact redo) */
     double scan_bytes_rank0; /* part of scan_bytes handled by the rank-0 (dump + select / exact) phase */
-    /* IVF_FLAT / IVF_SQ8 MFMA prefilter (mfma_scan.hip): queries finished from their candidate lists, queries whose
-       candidate list overflowed (redone by the exact kernels), candidates that got an exact distance */
+    /* prefilter paths (mfma_scan.hip, pq_filter.hip): queries finished from their candidate lists, queries whose
+       candidate list overflowed (redone by the exact kernels), candidates the filter passed */
     int64_t mscan_queries;
     int64_t mscan_overflow_queries;
     int64_t mscan_candidates;
     double mscan_stream_bytes; /* bytes the prefilter streams: sum over its units of len(list) * code_size */
+    int64_t mscan_recomputed;  /* candidates that got an exact distance (IVF_PQ: after the finish kernel's pruning) */
 } knhip_stage_times;
 /* stage indices */
 enum {

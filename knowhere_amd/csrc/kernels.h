@@ -206,6 +206,8 @@ struct MScanArgs {
     int64_t bitset_nbits;
     int32_t* cand_cnt;           // [nq]
     int64_t* cand;               // [nq][cap]: slot << 32 | row position in the list
+    float* cand_pess;            // [nq][cap] pessimistic distance of each candidate (null = not kept): the finish kernel
+                                 // drops the candidates that cannot beat the k-th best of them before it recomputes any
     int32_t cap;
     int32_t* overflow;           // [nq + 1]: per-query flag, [nq] = any
     // sample pass (non-null = DUMP mode): pessimistic distance of (query, row) -> dump[q * dump_stride + row]

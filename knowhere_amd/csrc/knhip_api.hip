@@ -125,6 +125,7 @@ struct Workspace {
     DevBuf gmeta;        // [qb] {first-bin key, shift}
     DevBuf list_count, list_pair_off, list_item_off, list_cursor, pairs, items, nitems;
     // MFMA prefilter of the IVF-Flat / IVF-SQ8 scans (mfma_scan.hip)
+    DevBuf ms_cand_pess;                                             // [qb][cap] pessimistic distances of the candidates (IVF-PQ)
     DevBuf ms_units, ms_unit_off, ms_nunits, ms_cand, ms_cand_cnt;  // ms_cand_cnt: [qb] counters + [qb + 1] overflow flags
     DevBuf ms_sample_off, ms_nrow;                                   // sample plan: [qb][nprobe] dump columns, [qb] rows
     DevBuf ms_qh, ms_ql, ms_qs;                                      // SQ8 IP: prepared query operands (halves) + sums
@@ -806,6 +807,9 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         HIP_TRY(ws->ms_unit_off.reserve((size_t)(nlist + 1) * sizeof(int64_t)));
         HIP_TRY(ws->ms_nunits.reserve(sizeof(int64_t) + 2 * sizeof(double)));
         HIP_TRY(ws->ms_cand.reserve((size_t)nq * ms_cap * sizeof(int64_t)));
+        if (kind == KNHIP_IVF_PQ) {
+            HIP_TRY(ws->ms_cand_pess.reserve((size_t)nq * ms_cap * sizeof(float)));
+        }
         HIP_TRY(ws->ms_cand_cnt.reserve((size_t)(2 * nq + 2) * sizeof(int32_t))); // counters, flags, any-flag, guard counter
         HIP_TRY(ws->dump.reserve((size_t)nq * sample * sizeof(float)));
         HIP_TRY(ws->sel_keys.reserve((size_t)nq * k * sizeof(int64_t)));
@@ -842,6 +846,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         m.bitset_nbits = nbits;
         m.cand_cnt = cand_cnt;
         m.cand = ws->ms_cand.as<int64_t>();
+        m.cand_pess = kind == KNHIP_IVF_PQ ? ws->ms_cand_pess.as<float>() : nullptr;
         m.cap = ms_cap;
         m.overflow = overflow;
         m.gthr_rw = ws->gthr.as<float>();
@@ -1226,7 +1231,7 @@ int64_t query_batch(const knhip_index* idx, int64_t nq, int k, int nprobe) {
         }
         if (idx->desc.kind == KNHIP_IVF_PQ && idx->pqf == 1) {
             // sample dump + candidate list + half table + one-pair records of the fallbacks (pq_filter.hip)
-            per_q += 4.0 * mscan_sample_rows() + 8.0 * 32768.0 + 16384.0 + (double)nprobe * (128.0 + 96.0);
+            per_q += 4.0 * mscan_sample_rows() + 12.0 * 32768.0 + 16384.0 + (double)nprobe * (128.0 + 96.0);
         }
         if (idx->desc.kind == KNHIP_IVF_PQ) {
             per_q += 256.0 * idx->desc.pq_m * 4.0;
@@ -1316,8 +1321,8 @@ int knhip_index_create(const knhip_desc* desc, knhip_index** out) {
     DeviceGuard g(desc->device);
     HIP_TRY(idx->scan_bytes_dev.alloc(3 * sizeof(double)));
     HIP_TRY(hipMemset(idx->scan_bytes_dev.p, 0, 3 * sizeof(double)));
-    HIP_TRY(idx->coarse_fail_dev.alloc(4 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(idx->coarse_fail_dev.p, 0, 4 * sizeof(unsigned long long)));
+    HIP_TRY(idx->coarse_fail_dev.alloc(8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(idx->coarse_fail_dev.p, 0, 8 * sizeof(unsigned long long)));
     *out = idx.release();
     return KNHIP_OK;
 }
@@ -2878,7 +2883,7 @@ int knhip_profile_reset(knhip_index* idx) {
     idx->coarse_flops = 0;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemset(idx->scan_bytes_dev.p, 0, 3 * sizeof(double)));
-    HIP_TRY(hipMemset(idx->coarse_fail_dev.p, 0, 4 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(idx->coarse_fail_dev.p, 0, 8 * sizeof(unsigned long long)));
     return KNHIP_OK;
 }
 
@@ -2897,12 +2902,14 @@ int knhip_profile_get(const knhip_index* idx, knhip_stage_times* out) {
     out->scan_bytes_rank0 = idx->rank0_phase_used ? sb[1] : 0.0;
     out->coarse_flops = idx->coarse_flops;
     out->scan_items = idx->last_items_bound;
-    unsigned long long nf[4] = {0, 0, 0, 0}; // coarse certificate failures; mscan: finished / overflowed queries, candidates
+    // coarse certificate failures; prefilter paths: finished / overflowed queries, candidates, exact recomputations
+    unsigned long long nf[5] = {0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpy(nf, idx->coarse_fail_dev.p, sizeof(nf), hipMemcpyDeviceToHost));
     out->coarse_fallback_queries = (int64_t)nf[0];
     out->mscan_queries = (int64_t)nf[1];
     out->mscan_overflow_queries = (int64_t)nf[2];
     out->mscan_candidates = (int64_t)nf[3];
+    out->mscan_recomputed = (int64_t)nf[4];
     out->mscan_stream_bytes = sb[2];
     return KNHIP_OK;
 }

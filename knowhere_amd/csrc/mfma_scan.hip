@@ -1024,7 +1024,98 @@ __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, c
         return;
     }
     const int d = a.d;
-    const int n = min(a.cand_cnt[q], a.cap);
+    int n = min(a.cand_cnt[q], a.cap);
+    const int n_filter = n;
+    // ---- prune (PQ prefilter): every candidate came with its pessimistic distance (exact <= pess).  The k-th best of
+    // those values bounds the final k-th distance, and a candidate whose OPTIMISTIC distance (>= pess - 2 eps_max) is
+    // beyond it cannot enter: only the rest is recomputed exactly (32 dependent gathers each).  The k-th value comes from
+    // a binary search over the order-preserving integer keys, the candidates sit in registers meanwhile.
+    constexpr int MF_PRUNE_PER_THREAD = 16;
+    if (KIND == 2 && a.cand_pess != nullptr && !retry_prep && n >= 2 * k && n <= MF_THREADS * MF_PRUNE_PER_THREAD) {
+        __shared__ int s_cnt;
+        __shared__ float s_red[MF_THREADS / KN_WAVE];
+        // eps_max: the per-query part + the fp32 roundings at the largest |dis0| of the query's probes and its bound
+        float cmax = 0.f;
+        for (int sl = tid; sl < nprobe; sl += MF_THREADS) {
+            cmax = fmaxf(cmax, fabsf(coarse_dis[q * nprobe + sl]));
+        }
+#pragma unroll
+        for (int dlt = KN_WAVE / 2; dlt > 0; dlt >>= 1) {
+            cmax = fmaxf(cmax, __shfl_xor(cmax, dlt, KN_WAVE));
+        }
+        if ((tid & (KN_WAVE - 1)) == 0) {
+            s_red[tid / KN_WAVE] = cmax;
+        }
+        __syncthreads();
+        cmax = s_red[0];
+        for (int w = 1; w < MF_THREADS / KN_WAVE; w++) {
+            cmax = fmaxf(cmax, s_red[w]);
+        }
+        const float eps_max = a.pq_qs[q * 4 + 2] + 64.0f * 5.9604645e-8f * (cmax + fabsf(a.gthr[q]));
+        uint32_t pk[MF_PRUNE_PER_THREAD];
+        int64_t pc[MF_PRUNE_PER_THREAD];
+        float pp[MF_PRUNE_PER_THREAD];
+#pragma unroll
+        for (int u = 0; u < MF_PRUNE_PER_THREAD; u++) {
+            const int ci = tid + u * MF_THREADS;
+            pk[u] = 0xffffffffu;
+            pc[u] = 0;
+            pp[u] = worst_dist<IS_L2>();
+            if (ci < n) {
+                pc[u] = a.cand[q * (int64_t)a.cap + ci];
+                pp[u] = a.cand_pess[q * (int64_t)a.cap + ci];
+                pk[u] = dist_key<IS_L2>(pp[u]);
+            }
+        }
+        // smallest key K with count(keys <= K) >= k
+        uint32_t lo = 0u, hi = 0xffffffffu;
+        while (lo < hi) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (tid == 0) {
+                s_cnt = 0;
+            }
+            __syncthreads();
+            int c = 0;
+#pragma unroll
+            for (int u = 0; u < MF_PRUNE_PER_THREAD; u++) {
+                c += pk[u] <= mid ? 1 : 0;
+            }
+#pragma unroll
+            for (int dlt = KN_WAVE / 2; dlt > 0; dlt >>= 1) {
+                c += __shfl_xor(c, dlt, KN_WAVE);
+            }
+            if ((tid & (KN_WAVE - 1)) == 0 && c) {
+                atomicAdd(&s_cnt, c);
+            }
+            __syncthreads();
+            const int tot = s_cnt;
+            __syncthreads();
+            if (tot >= k) {
+                hi = mid;
+            } else {
+                lo = mid + 1;
+            }
+        }
+        const float tau2 = dist_key_inv<IS_L2>(lo);
+        if (eps_max < INFINITY && tau2 == tau2 && fabsf(tau2) < FLT_MAX) {
+            if (tid == 0) {
+                s_cnt = 0;
+            }
+            __syncthreads(); // (every candidate is in registers: the list is rewritten in place)
+#pragma unroll
+            for (int u = 0; u < MF_PRUNE_PER_THREAD; u++) {
+                const int ci = tid + u * MF_THREADS;
+                const bool keep = ci < n && (IS_L2 ? (pp[u] - 2.0f * eps_max <= tau2) : (pp[u] + 2.0f * eps_max >= tau2));
+                if (keep) {
+                    const int j = atomicAdd(&s_cnt, 1);
+                    a.cand[q * (int64_t)a.cap + j] = pc[u];
+                }
+            }
+            __syncthreads();
+            n = s_cnt;
+            __syncthreads();
+        }
+    }
     if (retry_prep && n < k) {
         if (tid == 0) {
             atomicAdd(counters + 1, 1ull);
@@ -1033,7 +1124,8 @@ __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, c
     }
     if (tid == 0 && !retry_prep) {
         atomicAdd(counters, 1ull);
-        atomicAdd(counters + 2, (unsigned long long)n);
+        atomicAdd(counters + 2, (unsigned long long)n_filter);
+        atomicAdd(counters + 3, (unsigned long long)n);
     }
     int P = 2;
     while (P < n + k && P < P_max) {

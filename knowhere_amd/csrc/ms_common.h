@@ -20,6 +20,9 @@ __device__ __forceinline__ void ms_emit(const MScanArgs& a, int32_t q, int32_t s
     const int n = atomicAdd(a.cand_cnt + q, 1);
     if (n < a.cap) {
         a.cand[(int64_t)q * a.cap + n] = ((int64_t)slot << 32) | (int64_t)(uint32_t)pos;
+        if (a.cand_pess != nullptr) {
+            a.cand_pess[(int64_t)q * a.cap + n] = pess;
+        }
     } else {
         a.overflow[q] = 1;
         a.overflow[a.nq] = 1; // "some query overflowed": the fallback kernels return at once while this stays 0
