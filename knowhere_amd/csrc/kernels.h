@@ -71,6 +71,20 @@ struct P8Rec {
 };
 static_assert(sizeof(P8Rec) == 128, "P8Rec layout");
 
+// ... and of its 16-query integer form (pq_filter.hip, pqi_kernel): one unit of (list, <= 16 pairs)
+struct P16Rec {
+    int32_t list;
+    int32_t npair;
+    int32_t q[16];
+    int32_t slot[16];
+    float dis0[16];
+    int64_t len;
+    int64_t sblk0;    // first block of the list in the token stream (same block offsets as the half-precision form)
+    int64_t row_off;
+    int64_t pad[4];
+};
+static_assert(sizeof(P16Rec) == 256, "P16Rec layout");
+
 struct FlatScanArgs {
     // rows
     const float4* rows;          // interleaved blocks
@@ -237,6 +251,11 @@ struct MScanArgs {
     const uint8_t* pq_codes;       // canonical AoS codes [ntotal][32] (exact finish)
     int32_t pq_lut_mode;           // PqLutMode
     P8Rec* pq_recs;                // [unit bound]
+    // ... its 16-query integer form (pqi_kernel): int8 tables, units of (list, <= 16 pairs)
+    const uint4* pq_codes_i;       // token stream of the integer form (pq_stream16i_kernel), block offsets = pq_sblk_off_r
+    const void* pq_qi;             // [nq][64][16][4][2] int8: per-query tables (pqi_query_table_kernel)
+    const float* pq_qis;           // [nq][4] = {step, sum of the per-m offsets, eps_base, A}
+    P16Rec* pq_recs16;             // [unit bound]
     int32_t* pq_ctr;               // [8 * 16] one unit counter per XCD, 64 B apart
 };
 
@@ -254,6 +273,13 @@ hipError_t launch_pqf_predict(const float* dump, int64_t stride, const int32_t* 
                               const int64_t* keys, int nprobe, int64_t nlist, const int64_t* list_len, int64_t nq, int cap,
                               int k, bool is_l2, int32_t* poor, hipStream_t s);
 size_t pqf_smem();
+// integer form: 16 queries per unit, int8 tables, v_mfma_i32_16x16x64_i8
+hipError_t launch_pq_stream16i(const uint8_t* codes, const int64_t* list_row_off, const int64_t* list_len,
+                               const int64_t* list_sblk_off, int64_t nlist, uint4* out, hipStream_t s);
+hipError_t launch_pqi_query_table(const float* queries, const float4* cb_t, int d, int64_t nq, bool is_l2, float pabs_max,
+                                  void* qi, float* qis, hipStream_t s);
+hipError_t launch_pqi(const MScanArgs& a, bool is_l2, int64_t units_bound, hipStream_t s);
+
 bool pqf_supports(int M, int d);
 hipError_t launch_pqf(const MScanArgs& a, bool is_l2, int64_t units_bound, hipStream_t s);
 

@@ -125,6 +125,7 @@ struct Workspace {
     DevBuf gmeta;        // [qb] {first-bin key, shift}
     DevBuf list_count, list_pair_off, list_item_off, list_cursor, pairs, items, nitems;
     // MFMA prefilter of the IVF-Flat / IVF-SQ8 scans (mfma_scan.hip)
+    DevBuf ms_qi, ms_qis, pq_recs16;                                 // integer form: tables, {step, mu sum, eps, A}, records
     DevBuf ms_cand_pess;                                             // [qb][cap] pessimistic distances of the candidates (IVF-PQ)
     DevBuf ms_units, ms_unit_off, ms_nunits, ms_cand, ms_cand_cnt;  // ms_cand_cnt: [qb] counters + [qb + 1] overflow flags
     DevBuf ms_sample_off, ms_nrow;                                   // sample plan: [qb][nprobe] dump columns, [qb] rows
@@ -201,7 +202,10 @@ struct knhip_index {
     // 2 = whenever the shape allows (KNHIP_PQF=1: tests), 0 = never (KNHIP_PQF=0).  Its layouts are built on first use.
     int pqf = 1;
     bool pqf_guard = true;           // KNHIP_PQF_GUARD=0 switches the selectivity guard off (tests of the overflow rounds)
+    int pqf_form = 0;                // KNHIP_PQF_FORM: 0 = chosen per batch by the guard, 1 = half precision, 2 = int8
     mutable bool pqf_ready = false;
+    mutable bool pqi_ready = false;
+    mutable DevBuf rows_i;           // token stream of the integer form (stream16i)
     mutable DevBuf rows_r;           // rotated token stream (stream16r)
     mutable DevBuf d_list_blk_off_r; // [nlist + 1]
     mutable DevBuf psum;             // per stream position: sum_m term2 (L2)
@@ -423,7 +427,11 @@ int build_list_layout(knhip_index* idx, const std::vector<int64_t>& list_off, co
         idx->pqf = (pf && pf[0] == '1') ? 2 : (pf && pf[0] == '0') ? 0 : 1;
         const char* pg = getenv("KNHIP_PQF_GUARD");
         idx->pqf_guard = !(pg && pg[0] == '0');
+        const char* pm = getenv("KNHIP_PQF_FORM");
+        idx->pqf_form = (pm && pm[0] == 'h') ? 1 : (pm && pm[0] == 'i') ? 2 : 0;
         idx->pqf_ready = false;
+        idx->pqi_ready = false;
+        idx->rows_i.release();
         idx->rows_r.release();
         idx->psum.release();
     }
@@ -587,6 +595,23 @@ int ensure_pqf(const knhip_index* idx) {
     }
     HIP_TRY(hipDeviceSynchronize());
     idx->pqf_ready = true;
+    return KNHIP_OK;
+}
+
+// token stream of the integer form of the prefilter (same block offsets as the half-precision stream)
+int ensure_pqi(const knhip_index* idx) {
+    if (int rc = ensure_pqf(idx)) return rc;
+    std::lock_guard<std::mutex> lk(idx->mu);
+    if (idx->pqi_ready) {
+        return KNHIP_OK;
+    }
+    const int64_t nblk = idx->rows_r.bytes / (64 * sizeof(uint4));
+    HIP_TRY(idx->rows_i.alloc((size_t)std::max<int64_t>(nblk, 1) * 64 * sizeof(uint4)));
+    HIP_TRY(launch_pq_stream16i(idx->codes_aos.as<uint8_t>(), idx->d_list_row_off.as<int64_t>(),
+                                idx->d_list_len.as<int64_t>(), idx->d_list_blk_off_r.as<int64_t>(), idx->nlist,
+                                idx->rows_i.as<uint4>(), nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    idx->pqi_ready = true;
     return KNHIP_OK;
 }
 
@@ -797,7 +822,8 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         } else {
             if (int rc = ensure_mscan_norms(idx)) return rc;
         }
-        const int qt = mscan_queries_per_unit(kind, false), qt0 = mscan_queries_per_unit(kind, true);
+        int qt = mscan_queries_per_unit(kind, false);
+        const int qt0 = mscan_queries_per_unit(kind, true);
         const int64_t units_bound = round_up(npairs / qt + std::min<int64_t>(nlist, npairs) + 1, 8);
         const int64_t sample = mscan_sample_rows();
         // (a query samples at most `sample` rows of non-empty lists: at most that many pairs)
@@ -810,7 +836,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         if (kind == KNHIP_IVF_PQ) {
             HIP_TRY(ws->ms_cand_pess.reserve((size_t)nq * ms_cap * sizeof(float)));
         }
-        HIP_TRY(ws->ms_cand_cnt.reserve((size_t)(2 * nq + 2) * sizeof(int32_t))); // counters, flags, any-flag, guard counter
+        HIP_TRY(ws->ms_cand_cnt.reserve((size_t)(2 * nq + 4) * sizeof(int32_t))); // counters, flags, any-flag, guard counters
         HIP_TRY(ws->dump.reserve((size_t)nq * sample * sizeof(float)));
         HIP_TRY(ws->sel_keys.reserve((size_t)nq * k * sizeof(int64_t)));
         HIP_TRY(ws->sel_d.reserve((size_t)nq * k * sizeof(float)));
@@ -870,10 +896,12 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             m.pq_recs = ws->pq_recs.as<P8Rec>();
             m.pq_ctr = ws->pq_ctr.as<int32_t>();
         }
+        bool pq_i8 = false; // IVF-PQ: the integer form of the filter (chosen after the sample pass)
         auto launch_filter = [&](const MScanArgs& x, int64_t bound) -> hipError_t {
             return kind == KNHIP_IVF_FLAT ? launch_mscan_flat(x, is_l2, bound, s)
                  : kind == KNHIP_IVF_SQ8  ? launch_mscan_sq8(x, is_l2, bound, s)
-                                          : launch_pqf(x, is_l2, bound, s);
+                 : (pq_i8 && x.dump == nullptr) ? launch_pqi(x, is_l2, bound, s)
+                                                : launch_pqf(x, is_l2, bound, s);
         };
         idx->rank0_phase_used = false;
         {
@@ -918,18 +946,46 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
                                           nq, k, is_l2, ws->sel_keys.as<int64_t>(), ws->sel_d.as<float>(), s, sample,
                                           ws->ms_nrow.as<int32_t>()));
             HIP_TRY(launch_ms_tau(ws->sel_d.as<float>(), nq, k, is_l2, ws->gthr.as<float>(), ws->gmeta.as<uint2>(), s));
-            if (kind == KNHIP_IVF_PQ && idx->pqf_guard) {
-                // selectivity guard (pq_filter.hip): on data where the half-precision bound lets through a few percent of
-                // the rows the exact finish costs more than the exact scan: such a batch takes the 4-query kernel
-                int32_t* poor = ws->ms_cand_cnt.as<int32_t>() + 2 * nq + 1;
-                HIP_TRY(launch_pqf_predict(ws->dump.as<float>(), sample, ws->ms_nrow.as<int32_t>(), ws->gthr.as<float>(),
-                                           ws->ms_qs.as<float>(), keys_p, nprobe, nlist, idx->d_list_len.as<int64_t>(), nq,
-                                           ms_cap, k, is_l2, poor, s));
-                int32_t h_poor = 0;
-                HIP_TRY(hipMemcpyAsync(&h_poor, poor, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-                HIP_TRY(hipStreamSynchronize(s));
-                if ((int64_t)h_poor * 4 > nq) {
-                    return KNHIP_PQF_ABANDONED;
+            if (kind == KNHIP_IVF_PQ) {
+                // The integer form of the filter (int8 tables, 16 queries per unit: twice the lookups per step) has an eps
+                // 8 .. 20 x that of the half-precision form.  Selectivity guard (pq_filter.hip): the sample dump predicts
+                // each query's candidate count under either eps; the batch takes the integer form when that is small,
+                // else the half-precision form, else -- data where even that lets a few percent of the rows through,
+                // so that the exact finish would cost more than the exact scan -- the exact 4-query kernel.
+                const bool want_i8 = idx->pqf_form != 1;
+                if (want_i8) {
+                    HIP_TRY(ws->ms_qi.reserve((size_t)nq * 256 * 32));
+                    HIP_TRY(ws->ms_qis.reserve((size_t)nq * 4 * sizeof(float)));
+                    HIP_TRY(launch_pqi_query_table(d_q, idx->cb_t.as<float4>(), d, nq, is_l2, idx->pabs_max, ws->ms_qi.p,
+                                                   ws->ms_qis.as<float>(), s));
+                }
+                int32_t h_poor[2] = {0, 0};
+                if (idx->pqf_guard) {
+                    int32_t* poor = ws->ms_cand_cnt.as<int32_t>() + 2 * nq + 1;
+                    HIP_TRY(launch_pqf_predict(ws->dump.as<float>(), sample, ws->ms_nrow.as<int32_t>(),
+                                               ws->gthr.as<float>(), ws->ms_qs.as<float>(), keys_p, nprobe, nlist,
+                                               idx->d_list_len.as<int64_t>(), nq, ms_cap, k, is_l2, poor, s));
+                    if (want_i8) {
+                        HIP_TRY(launch_pqf_predict(ws->dump.as<float>(), sample, ws->ms_nrow.as<int32_t>(),
+                                                   ws->gthr.as<float>(), ws->ms_qis.as<float>(), keys_p, nprobe, nlist,
+                                                   idx->d_list_len.as<int64_t>(), nq, ms_cap, k, is_l2, poor + 1, s));
+                    }
+                    HIP_TRY(hipMemcpyAsync(h_poor, poor, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+                    HIP_TRY(hipStreamSynchronize(s));
+                    if ((int64_t)h_poor[0] * 4 > nq) {
+                        return KNHIP_PQF_ABANDONED;
+                    }
+                }
+                pq_i8 = want_i8 && (idx->pqf_form == 2 || !idx->pqf_guard || (int64_t)h_poor[1] * 4 <= nq);
+                if (pq_i8) {
+                    if (int rc = ensure_pqi(idx)) return rc;
+                    qt = 16;
+                    HIP_TRY(ws->pq_recs16.reserve((size_t)std::max<int64_t>(std::max(units_bound, bound0), npairs) *
+                                                  sizeof(P16Rec)));
+                    m.pq_codes_i = idx->rows_i.as<uint4>();
+                    m.pq_qi = ws->ms_qi.p;
+                    m.pq_qis = ws->ms_qis.as<float>();
+                    m.pq_recs16 = ws->pq_recs16.as<P16Rec>();
                 }
             }
         }
@@ -957,7 +1013,11 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             // candidates, goes through the exact kernels (one-query items) and the ordinary merge.
             StageTimer t(idx, s, KNHIP_STAGE_MERGE);
             unsigned long long* counters = idx->coarse_fail_dev.as<unsigned long long>() + 1;
-            HIP_TRY(launch_mscan_finish(m, kind, is_l2, keys_p, cdis_p, nprobe, k, d_out_d, d_out_i, counters, 1, s));
+            MScanArgs mf = m;
+            if (pq_i8) {
+                mf.pq_qs = m.pq_qis; // (the finish kernel's pruning reads eps_base at [q][2] of either)
+            }
+            HIP_TRY(launch_mscan_finish(mf, kind, is_l2, keys_p, cdis_p, nprobe, k, d_out_d, d_out_i, counters, 1, s));
             HIP_TRY(launch_ms_flag_pairs(overflow, 2, keys_p, nq, nprobe, nlist, idx->d_list_len.as<int64_t>(), k,
                                          ws->items.as<KnItem>(), wt.pairs, wt.nitems, nullptr, s));
             MScanArgs r = m;
@@ -967,7 +1027,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             r.ghist = nullptr; // (the retried rows were counted once already: counting them again would fake k candidates)
             r.gmeta = nullptr;
             HIP_TRY(launch_filter(r, npairs));
-            HIP_TRY(launch_mscan_finish(m, kind, is_l2, keys_p, cdis_p, nprobe, k, d_out_d, d_out_i, counters, 2, s));
+            HIP_TRY(launch_mscan_finish(mf, kind, is_l2, keys_p, cdis_p, nprobe, k, d_out_d, d_out_i, counters, 2, s));
             HIP_TRY(launch_ms_flag_pairs(overflow, 1, keys_p, nq, nprobe, nlist, idx->d_list_len.as<int64_t>(), k,
                                          ws->items.as<KnItem>(), wt.pairs, wt.nitems, ws->partial_i.as<int64_t>(), s));
             if (int rc = exact_one(ws->items.as<KnItem>(), wt.pairs, wt.nitems, std::min<int64_t>(npairs, 4096))) {
@@ -1231,7 +1291,7 @@ int64_t query_batch(const knhip_index* idx, int64_t nq, int k, int nprobe) {
         }
         if (idx->desc.kind == KNHIP_IVF_PQ && idx->pqf == 1) {
             // sample dump + candidate list + half table + one-pair records of the fallbacks (pq_filter.hip)
-            per_q += 4.0 * mscan_sample_rows() + 12.0 * 32768.0 + 16384.0 + (double)nprobe * (128.0 + 96.0);
+            per_q += 4.0 * mscan_sample_rows() + 12.0 * 32768.0 + 16384.0 + 8192.0 + (double)nprobe * (256.0 + 96.0);
         }
         if (idx->desc.kind == KNHIP_IVF_PQ) {
             per_q += 256.0 * idx->desc.pq_m * 4.0;

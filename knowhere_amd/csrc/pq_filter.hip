@@ -59,6 +59,12 @@ constexpr int PF_LUT_BYTES = PF_KSUB * PF_M * PF_Q * 2; // 131072
 // and the one after it), [128 + 4 j ..) per-pair constants of the current unit
 constexpr int PF_CTL_BYTES = 1024;
 constexpr int PF_SAMPLE = 4096; // = MS_SAMPLE (mfma_scan.hip): dump columns per query
+// Candidate staging behind the control block: a hit costs an LDS atomic and one 16-byte LDS store inside the scan loop;
+// the global side of ms_emit (bitset test, atomic on the query's counter with its returned slot, candidate store,
+// histogram) waited 1 .. 2 us per hit in the loop -- with ~10^7 hits per batch a fifth of the kernel (round-3 experiment:
+// profiles/r03_pqi_experiments.md).  The staged records are written out by all 1024 threads at the end of the unit.
+constexpr int PF_STAGE_CAP = 1792;
+constexpr int PF_STAGE_BYTES = PF_STAGE_CAP * 16 + 16; // records + two counters (unit parity)
 constexpr float PF_U = 5.9604645e-8f;        // 2^-24
 constexpr float PF_UH = 4.8828125e-4f;       // 2^-11: unit roundoff of half precision
 
@@ -343,6 +349,30 @@ __device__ unsigned long long g_pf_prof[16 * 8];
 #define PF_COUNT(i, n)
 #endif
 
+// staged candidate records {query, slot, position, pessimistic distance} + flush (see PF_STAGE_CAP)
+template <bool IS_L2>
+__device__ __forceinline__ void pf_stage_emit(const MScanArgs& a, unsigned char* smem, int par, int32_t q, int32_t slot,
+                                              int64_t row_off, int64_t pos, float pess) {
+    int* cnt = reinterpret_cast<int*>(smem + PF_LUT_BYTES + PF_CTL_BYTES + PF_STAGE_CAP * 16);
+    const int n = atomicAdd(cnt + par, 1);
+    if (n < PF_STAGE_CAP) {
+        *reinterpret_cast<uint4*>(smem + PF_LUT_BYTES + PF_CTL_BYTES + n * 16) =
+                make_uint4((uint32_t)q, (uint32_t)slot, (uint32_t)pos, __float_as_uint(pess));
+    } else {
+        ms_emit<IS_L2>(a, q, slot, row_off, pos, pess); // (staging full: straight to the candidate list)
+    }
+}
+
+template <bool IS_L2>
+__device__ __forceinline__ void pf_stage_flush(const MScanArgs& a, unsigned char* smem, int par, int64_t row_off) {
+    const int* cnt = reinterpret_cast<const int*>(smem + PF_LUT_BYTES + PF_CTL_BYTES + PF_STAGE_CAP * 16);
+    const int n = min(cnt[par], PF_STAGE_CAP);
+    for (int i = (int)threadIdx.x; i < n; i += PF_THREADS) {
+        const uint4 r = *reinterpret_cast<const uint4*>(smem + PF_LUT_BYTES + PF_CTL_BYTES + i * 16);
+        ms_emit<IS_L2>(a, (int32_t)r.x, (int32_t)r.y, row_off, (int64_t)r.z, __uint_as_float(r.w));
+    }
+}
+
 // ---- the filter / sample kernel -----------------------------------------------------------------------------------
 // Persistent: one workgroup of 16 waves per CU (128 KB of LUT), units pulled in list order from the XCD's counter as
 // pq_scan_q4.hip does.  Per unit: per-pair constants (waves 0..7, one pair each: bound from gthr and the candidate
@@ -414,6 +444,9 @@ __global__ __launch_bounds__(PF_THREADS) void pqf_kernel(MScanArgs a) {
         if (lane == 0) {
             ctl[0] = u0;
             ctl[1] = u1;
+            int* scnt = reinterpret_cast<int*>(smem + PF_LUT_BYTES + PF_CTL_BYTES + PF_STAGE_CAP * 16);
+            scnt[0] = 0;
+            scnt[1] = 0;
         }
     }
     __syncthreads();
@@ -547,6 +580,9 @@ __global__ __launch_bounds__(PF_THREADS) void pqf_kernel(MScanArgs a) {
         PF_T(0); // record, pair constants, table loads + LUT stores
         __syncthreads();
         PF_T(1); // wait for the other waves' LUT parts
+        if (!DUMP && threadIdx.x == 0) { // the NEXT unit's staging counter (its last user's flush ended before this barrier)
+            reinterpret_cast<int*>(smem + PF_LUT_BYTES + PF_CTL_BYTES + PF_STAGE_CAP * 16)[par ^ 1] = 0;
+        }
         // ---- the unit after the next: index now (the atomic was issued at the top), record requested, parked after the
         // scan in the mailbox slot this unit occupies (every wave has read it) --------------------------------------------
         int nxt = -1;
@@ -648,26 +684,25 @@ __global__ __launch_bounds__(PF_THREADS) void pqf_kernel(MScanArgs a) {
                         }
                     }
                 } else {
-                    bool hit[4];
-                    bool any = false;
+                    // fast path: 4 fma + 4 compares per lane, the lane masks OR-ed on the scalar unit; whether the row
+                    // exists at all (tail of the list, groups of the next wave) is only looked at when something passed
+                    unsigned long long mk[4];
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         // L2: ps + f / sc <= t;  IP: f / sc >= t   (t = -inf / +inf: nothing passes)
                         const float v = __fmaf_rn(f[r], isc[r], IS_L2 ? ps : 0.f);
-                        hit[r] = IS_L2 ? (v <= thr[r]) : (v >= thr[r]);
-                        any |= hit[r];
+                        mk[r] = __ballot(IS_L2 ? (v <= thr[r]) : (v >= thr[r]));
                     }
-                    any = any && inside;
-                    if (__ballot(any) != 0ull) {
-                        if (any) {
+                    if (__builtin_expect((mk[0] | mk[1] | mk[2] | mk[3]) != 0ull, 0)) { // (out of line: the hot path falls through)
+                        if (inside) {
 #pragma unroll
                             for (int r = 0; r < 4; r++) {
-                                if (hit[r]) {
+                                if ((mk[r] >> lane_i) & 1ull) {
                                     const int j = 4 * hb + r;
                                     const float pcs = pc[j * 4 + 2];
                                     const float pess = IS_L2 ? __fmaf_rn(f[r], isc[r], pcs + ps)
                                                              : __fmaf_rn(f[r], isc[r], pcs);
-                                    ms_emit<IS_L2>(a, pqs[j * 2], pqs[j * 2 + 1], row_off, pos, pess);
+                                    pf_stage_emit<IS_L2>(a, smem, par, pqs[j * 2], pqs[j * 2 + 1], row_off, pos, pess);
                                 }
                             }
                         }
@@ -729,6 +764,9 @@ __global__ __launch_bounds__(PF_THREADS) void pqf_kernel(MScanArgs a) {
         }
         __syncthreads(); // the LUT and the pair constants are dead, the mailbox is visible
         PF_T(4);         // wait for the slowest wave's scan
+        if (!DUMP) {
+            pf_stage_flush<IS_L2>(a, smem, par, row_off);
+        }
         PF_COUNT(7, 1);
         cur = nxt_unit;
         par ^= 1;
@@ -811,9 +849,628 @@ hipError_t launch_pqf_predict(const float* dump, int64_t stride, const int32_t* 
     return hipGetLastError();
 }
 
-size_t pqf_smem() {
-    return (size_t)PF_LUT_BYTES + PF_CTL_BYTES;
+// =====================================================================================================================
+// The INTEGER form: int8 tables, 16 queries per LUT entry, v_mfma_i32_16x16x64_i8 (round 3).
+//
+// The LDS gather (one ds_read_b128 per lane and step, 4 cycles per wave-instruction) and the matrix pipe (16 cycles per
+// instruction and SIMD) bind the half-precision form at the same 128 lookups/clk/CU.  Both move 16 bytes per lane and
+// step whatever those bytes mean: with ONE byte per query an entry holds 16 queries, the instruction K = 64 bytes, and
+// every step delivers twice the lookups -- a unit is (list, <= 16 queries), half as many units per batch.
+//
+//   Qi_q[m][c] = rint((Qf_q[m][c] - mu_q[m]) / s_q) in [-127, 127],  mu_q[m] = midrange of Qf_q[m][.],
+//                s_q = max_m (range of Qf_q[m][.]) / 254            (one step per query: the sums share one accumulator)
+//   approx(q, v) = dis0 + psum[v] + sum_m mu_q[m] + s_q * sum_m Qi_q[m][code_m(v)]          (int32 accumulation: exact)
+//   |approx - exact| <= eps = 16.4 s_q + 128 * 2^-24 * (max_v sum_m |term2| + A_q) + 64 * 2^-24 * (|dis0| + |tau| + |mu|)
+//   (32 entries half a step each, + 2 % for the fp32 roundings of the quantisation itself)
+// That is 8 .. 20 x looser than the half-precision form (and 2 x tighter than round 2's integer-scaled half table), so
+// this form is chosen per batch by the selectivity guard: the sample pass always runs in half precision, and its dump
+// predicts the candidate count under either eps (knhip_api.hip): integer form when that is small, else the half
+// form, else the exact kernel.
+//
+// Lane L = (kb = L >> 4, n = L & 15) fetches for vector n of a group of 16, eight steps per group; at step s it handles
+// m = 16 (kb >> 1) + ((pi(n) + 8 (kb & 1) + s) & 15), pi(n) = n ^ 4 for n < 8, n otherwise: the four lanes of a vector
+// cover its 32 sub-quantizers once, and the 16 lanes of an LDS service group -- in the documented grouping
+// {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} as well as in contiguous sixteenths -- sit on 16 different bank quads.
+// The selector A[i][kb][e] = [e == i] sums the four k blocks: D[i][n] = query i's 32 entries of vector n after 8 steps.
+constexpr int PI_Q = 16;
+typedef int pf_i4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ constexpr int pi_lane_m(int L, int s) {
+    const int n = L & 15, kb = L >> 4;
+    const int pn = n < 8 ? (n ^ 4) : n;
+    return 16 * (kb >> 1) + ((pn + 8 * (kb & 1) + s) & 15);
 }
+
+// uint4 out[blk][lane]: 8 steps = one group of 16 vectors per block; block offsets shared with the half-precision stream
+__global__ void pq_stream16i_kernel(const uint8_t* __restrict__ codes, const int64_t* __restrict__ list_row_off,
+                                    const int64_t* __restrict__ list_len, const int64_t* __restrict__ list_sblk_off,
+                                    int64_t nlist, uint4* __restrict__ out) {
+    const int64_t l = blockIdx.y + (int64_t)blockIdx.z * gridDim.y;
+    if (l >= nlist) {
+        return;
+    }
+    const int64_t len = list_len[l];
+    const int64_t nblk = list_sblk_off[l + 1] - list_sblk_off[l];
+    const int64_t row_off = list_row_off[l];
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nblk * 64;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t blk = t / 64;
+        const int L = (int)(t % 64);
+        const int64_t v = blk * 16 + (L & 15);
+        uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            const int m = pi_lane_m(L, s);
+            uint32_t code = 0;
+            if (v < len) {
+                code = codes[(row_off + v) * PF_M + m];
+            }
+            const uint32_t val = (code << 8) | ((uint32_t)m << 3);
+            w[s >> 1] |= val << (16 * (s & 1));
+        }
+        out[(list_sblk_off[l] + blk) * 64 + L] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+hipError_t launch_pq_stream16i(const uint8_t* codes, const int64_t* list_row_off, const int64_t* list_len,
+                               const int64_t* list_sblk_off, int64_t nlist, uint4* out, hipStream_t s) {
+    if (nlist <= 0) {
+        return hipSuccess;
+    }
+    const unsigned gy = (unsigned)std::min<int64_t>(nlist, 65535);
+    const unsigned gz = (unsigned)((nlist + gy - 1) / gy);
+    hipLaunchKernelGGL(pq_stream16i_kernel, dim3(8, gy, gz), dim3(256), 0, s, codes, list_row_off, list_len, list_sblk_off,
+                       nlist, out);
+    return hipGetLastError();
+}
+
+// One workgroup per query, thread = centroid index c.  qis[q] = {s, sum_m mu, eps_base, A}.
+// Table layout (bytes): qi[q][c >> 2][m & 15][c & 3][m >> 4]: the 8-byte piece thread t = (c >> 2) * 16 + (m & 15) of the
+// filter kernel reads holds this query's entries of its 8 (c, m) cells.
+template <bool IS_L2>
+__global__ __launch_bounds__(PF_KSUB) void pqi_query_table_kernel(const float* __restrict__ queries,
+                                                                  const float4* __restrict__ cb_t, int d, float pabs_max,
+                                                                  uint32_t* __restrict__ qi, float* __restrict__ qis) {
+    __shared__ float sq[PF_M * PF_DSUB];
+    __shared__ float smax[PF_M][PF_KSUB / KN_WAVE];
+    __shared__ float smin[PF_M][PF_KSUB / KN_WAVE];
+    __shared__ float smu[PF_M];
+    __shared__ float s_inv;
+    const int64_t q = blockIdx.x;
+    const int c = threadIdx.x;
+    const int wave = c / KN_WAVE;
+    if (c < PF_M * PF_DSUB) {
+        sq[c] = queries[q * d + c];
+    }
+    __syncthreads();
+    float v[PF_M];
+#pragma unroll
+    for (int m = 0; m < PF_M; m++) {
+        const float4 y = cb_t[c * PF_M + m];
+        const float4 x = *reinterpret_cast<const float4*>(sq + m * PF_DSUB);
+        float t = ip_step(0.f, x.x, y.x);
+        t = ip_step(t, x.y, y.y);
+        t = ip_step(t, x.z, y.z);
+        t = ip_step(t, x.w, y.w);
+        v[m] = IS_L2 ? fmul_x(-2.0f, t) : t;
+        const bool fin = fabsf(v[m]) < INFINITY; // (false for NaN too: "no bound", the query takes the exact kernels)
+        float hi = fin ? v[m] : INFINITY, lo = fin ? v[m] : -INFINITY;
+#pragma unroll
+        for (int dlt = KN_WAVE / 2; dlt > 0; dlt >>= 1) {
+            hi = fmaxf(hi, __shfl_xor(hi, dlt, KN_WAVE));
+            lo = fminf(lo, __shfl_xor(lo, dlt, KN_WAVE));
+        }
+        if (lane_id() == 0) {
+            smax[m][wave] = hi;
+            smin[m][wave] = lo;
+        }
+    }
+    __syncthreads();
+    if (c == 0) {
+        float A = 0.f, R = 0.f, musum = 0.f;
+        for (int m = 0; m < PF_M; m++) {
+            float hi = smax[m][0], lo = smin[m][0];
+            for (int w = 1; w < PF_KSUB / KN_WAVE; w++) {
+                hi = fmaxf(hi, smax[m][w]);
+                lo = fminf(lo, smin[m][w]);
+            }
+            const float mu = 0.5f * hi + 0.5f * lo;
+            smu[m] = mu;
+            musum += mu;
+            A += fmaxf(fabsf(hi), fabsf(lo));
+            R = fmaxf(R, hi - lo);
+        }
+        float step = 1.0f, eps = INFINITY;
+        if (A < INFINITY && R < INFINITY) {
+            step = R > 0.f ? R / 254.0f : 1.0f;
+            if (!(step > 1e-30f)) {
+                step = 1e-30f; // (keeps 1 / step finite; the clamp below holds whatever the step)
+            }
+            eps = 16.4f * step + 128.0f * PF_U * (pabs_max + A) + 64.0f * PF_U * fabsf(musum);
+        }
+        s_inv = 1.0f / step;
+        qis[q * 4 + 0] = step;
+        qis[q * 4 + 1] = musum;
+        qis[q * 4 + 2] = eps;
+        qis[q * 4 + 3] = A;
+    }
+    __syncthreads();
+    const float inv = s_inv;
+    uint32_t* out = qi + q * (PF_KSUB * PF_M / 4);
+    // word (c >> 2, l16, w): bytes = cells (c & 3 = 2 w, h = 0), (2 w, 1), (2 w + 1, 0), (2 w + 1, 1): thread c owns byte
+    // pairs; the four threads of a c >> 2 group combine through LDS-free shuffles: c & 3 = 0..3 are neighbouring lanes
+#pragma unroll
+    for (int l16 = 0; l16 < 16; l16++) {
+        float x0 = rintf((v[l16] - smu[l16]) * inv), x1 = rintf((v[l16 + 16] - smu[l16 + 16]) * inv);
+        x0 = fminf(fmaxf(x0, -127.0f), 127.0f);
+        x1 = fminf(fmaxf(x1, -127.0f), 127.0f);
+        x0 = (x0 == x0) ? x0 : 0.f;
+        x1 = (x1 == x1) ? x1 : 0.f;
+        const uint32_t pair = ((uint32_t)(int)x0 & 0xffu) | (((uint32_t)(int)x1 & 0xffu) << 8); // (h = 0, h = 1) of cell c
+        const uint32_t other = (uint32_t)__shfl_xor((int)pair, 1, KN_WAVE);                      // the cell c ^ 1
+        if ((c & 1) == 0) {
+            out[((c >> 2) * 16 + l16) * 2 + ((c >> 1) & 1)] = pair | (other << 16);
+        }
+    }
+}
+
+hipError_t launch_pqi_query_table(const float* queries, const float4* cb_t, int d, int64_t nq, bool is_l2, float pabs_max,
+                                  void* qi, float* qis, hipStream_t s) {
+    if (nq <= 0) {
+        return hipSuccess;
+    }
+    if (is_l2) {
+        hipLaunchKernelGGL(pqi_query_table_kernel<true>, dim3((unsigned)nq), dim3(PF_KSUB), 0, s, queries, cb_t, d,
+                           pabs_max, static_cast<uint32_t*>(qi), qis);
+    } else {
+        hipLaunchKernelGGL(pqi_query_table_kernel<false>, dim3((unsigned)nq), dim3(PF_KSUB), 0, s, queries, cb_t, d,
+                           pabs_max, static_cast<uint32_t*>(qi), qis);
+    }
+    return hipGetLastError();
+}
+
+__global__ void pqi_prepare_kernel(MScanArgs a, int64_t nrec) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < 8 * 16) {
+        a.pq_ctr[r] = 0;
+    }
+    if (r >= nrec || r >= *a.nunits_dev) {
+        return;
+    }
+    P16Rec rec{};
+    const KnItem it = a.units[r];
+    const int npair = it.npair < PI_Q ? it.npair : PI_Q;
+    rec.list = it.list;
+    rec.npair = npair;
+    rec.len = a.list_len[it.list];
+    rec.sblk0 = a.pq_sblk_off_r[it.list];
+    rec.row_off = a.list_row_off[it.list];
+    for (int j = 0; j < PI_Q; j++) {
+        const KnPair p = a.pairs[it.pair0 + (j < npair ? j : npair - 1)];
+        rec.q[j] = p.q;
+        rec.slot[j] = p.slot;
+        rec.dis0[j] = a.coarse_dis[(int64_t)p.q * a.nslot + p.slot];
+    }
+    a.pq_recs16[r] = rec;
+}
+
+// The filter kernel of the integer form.  Same persistent structure as pqf_kernel (two-deep mailbox, the next unit's
+// table pieces in flight during the scan); no sample mode (the sample pass stays in half precision).
+template <bool IS_L2>
+__global__ __launch_bounds__(PF_THREADS) void pqi_kernel(MScanArgs a) {
+#ifdef KNHIP_PHASE_TIMERS
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_amdgcn_s_memtime();
+#endif
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int REC_WORDS = (int)(sizeof(P16Rec) / 4);
+    static_assert(REC_WORDS == 64, "mailbox slots of 64 words, one lane per word");
+    static_assert(offsetof(P16Rec, npair) == 4 && offsetof(P16Rec, q) == 8 && offsetof(P16Rec, slot) == 72 &&
+                  offsetof(P16Rec, dis0) == 136 && offsetof(P16Rec, len) == 200 && offsetof(P16Rec, sblk0) == 208 &&
+                  offsetof(P16Rec, row_off) == 216, "P16Rec layout");
+    // behind the LUT: ints [0], [1] unit index of mailbox slot 0 / 1, [8 + 64 s ..) the record of slot s;
+    // bytes 576..831 per-pair constants [16][4] = {t, step, pess const, -}; bytes 832..959 [16][2] = {query, slot}
+    int* ctl = reinterpret_cast<int*>(smem + PF_LUT_BYTES);
+    float* pc = reinterpret_cast<float*>(smem + PF_LUT_BYTES + 576);
+    int* pqs = reinterpret_cast<int*>(smem + PF_LUT_BYTES + 832);
+    static_assert(8 * 4 + 2 * REC_WORDS * 4 <= 576 && 832 + PI_Q * 8 <= PF_CTL_BYTES, "control block layout");
+    const int lane = lane_id();
+    const int wave = pf_sgpr((int)(threadIdx.x / KN_WAVE));
+    if ((uint32_t)(size_t)((__attribute__((address_space(3))) unsigned char*)smem) != 0u) {
+        __builtin_trap(); // the 16-bit tokens assume the LUT at LDS offset 0
+    }
+    const int nunits = (int)*a.nunits_dev;
+    const int per = (nunits + 7) / 8;
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const int xcd = (int)(xcc & 7u);
+    int fetch_t = 0; // thread 0: counters [xcd, xcd + fetch_t) are known to be exhausted
+    auto fetch_slow = [&]() -> int {
+        while (fetch_t < 8) {
+            const int x = (xcd + fetch_t) & 7;
+            const int base = x * per;
+            const int cnt = min(per, nunits - base);
+            if (cnt > 0) {
+                const int i = atomicAdd(a.pq_ctr + x * 16, 1);
+                if (i < cnt) {
+                    return base + i;
+                }
+            }
+            fetch_t++;
+        }
+        return -1;
+    };
+    if (wave == 0) {
+        int u0 = -1, u1 = -1;
+        if (lane == 0) {
+            u0 = fetch_slow();
+            u1 = u0 >= 0 ? fetch_slow() : -1;
+        }
+        u0 = __builtin_amdgcn_readlane(u0, 0);
+        u1 = __builtin_amdgcn_readlane(u1, 0);
+        if (u0 >= 0) {
+            ctl[8 + lane] = (int)reinterpret_cast<const uint32_t*>(a.pq_recs16 + u0)[lane];
+        }
+        if (u1 >= 0) {
+            ctl[8 + REC_WORDS + lane] = (int)reinterpret_cast<const uint32_t*>(a.pq_recs16 + u1)[lane];
+        }
+        if (lane == 0) {
+            ctl[0] = u0;
+            ctl[1] = u1;
+            int* scnt = reinterpret_cast<int*>(smem + PF_LUT_BYTES + PF_CTL_BYTES + PF_STAGE_CAP * 16);
+            scnt[0] = 0;
+            scnt[1] = 0;
+        }
+    }
+    __syncthreads();
+    int cur = pf_sgpr(ctl[0]);
+    int par = 0;
+    const uint32_t one = 1u;
+    const uint2* qi2 = reinterpret_cast<const uint2*>(a.pq_qi);
+    // this thread's 8-byte piece of the 16 query tables of the unit in mailbox slot `slot`
+    auto load_tables = [&](int slot, uint2 (&t)[PI_Q], int lane_i) {
+        const uint32_t rq = (uint32_t)ctl[8 + slot * REC_WORDS + lane_i];
+#pragma unroll
+        for (int j = 0; j < PI_Q; j++) {
+            const int64_t q = (int64_t)(int32_t)__builtin_amdgcn_readlane((int)rq, 2 + j);
+            t[j] = qi2[q * (PF_KSUB * PF_M / 8) + (wave * KN_WAVE + lane_i)];
+        }
+    };
+    uint2 tp[PI_Q];
+#pragma unroll
+    for (int j = 0; j < PI_Q; j++) {
+        tp[j] = make_uint2(0, 0);
+    }
+    if (cur >= 0) {
+        load_tables(0, tp, lane);
+    }
+
+    while (cur >= 0) {
+        PF_T(5);
+        int lane_i = lane;
+        asm volatile("" : "+v"(lane_i)); // nothing lane-derived is hoisted out of the unit loop
+        int f_x = 0, f_i = 0;
+        if (wave == 0 && lane_i == 0 && fetch_t < 8) {
+            f_x = (xcd + fetch_t) & 7;
+            f_i = atomicAdd(a.pq_ctr + f_x * 16, 1);
+        }
+        const uint32_t rw = (uint32_t)ctl[8 + par * REC_WORDS + lane_i];
+        const int nxt_unit = pf_sgpr(ctl[par ^ 1]);
+        auto rl = [&](int i) { return (uint32_t)__builtin_amdgcn_readlane((int)rw, i); };
+        const int npair = (int)rl(1);
+        const int64_t len = (int64_t)(((uint64_t)rl(51) << 32) | rl(50));
+        const int64_t sblk0 = (int64_t)(((uint64_t)rl(53) << 32) | rl(52));
+        const int64_t row_off = (int64_t)(((uint64_t)rl(55) << 32) | rl(54));
+        // this wave's groups of 16 vectors (one code block each)
+        const int ngroups = (int)((len + 15) / 16);
+        const int gbase = ngroups / PF_WAVES, grem = ngroups % PF_WAVES;
+        const int G0 = wave * gbase + min(wave, grem);
+        const int G1 = G0 + gbase + (wave < grem ? 1 : 0);
+        const int nwin = G1 - G0;
+        const uint4* cbase = a.pq_codes_i + (sblk0 + (int64_t)G0) * 64 + lane_i;
+        auto load_blk = [&](int b) { return cbase[(int64_t)b * 64]; }; // past-the-end blocks exist (slack)
+        const float* psb = a.pq_psum + sblk0 * 16 + (int64_t)G0 * 16 + (lane_i & 15);
+        uint4 U0 = make_uint4(0, 0, 0, 0), U1 = U0, U2 = U0, U3 = U0;
+        if (nwin > 0) {
+            U0 = load_blk(0);
+            U1 = load_blk(1);
+            U2 = load_blk(2);
+            U3 = load_blk(3);
+        }
+        // ---- per-pair constants: wave j prepares pair j -----------------------------------------------------------
+        {
+            int32_t q = (int32_t)rl(2), slot = (int32_t)rl(18);
+            float dis0 = __uint_as_float(rl(34));
+#pragma unroll
+            for (int j = 1; j < PI_Q; j++) {
+                q = wave == j ? (int32_t)rl(2 + j) : q;
+                slot = wave == j ? (int32_t)rl(18 + j) : slot;
+                dis0 = wave == j ? __uint_as_float(rl(34 + j)) : dis0;
+            }
+            const float4 s4 = *reinterpret_cast<const float4*>(a.pq_qis + (int64_t)q * 4);
+            float t = IS_L2 ? -INFINITY : INFINITY, pcst = 0.f; // pass-nothing defaults
+            if (wave < npair) {
+                float tau = a.gthr[q];
+                tau = tighter<IS_L2>(tau, ms_hist_bound<IS_L2>(a, q, a.k));
+                const float eps = s4.z + 64.0f * PF_U * (fabsf(dis0) + fabsf(tau) + fabsf(s4.y));
+                if (tau == worst_dist<IS_L2>() || !(eps < INFINITY)) {
+                    if (lane_i == 0) {
+                        a.overflow[q] = 1;
+                        a.overflow[a.nq] = 1;
+                    }
+                } else {
+                    t = IS_L2 ? ((tau + eps) - dis0) - s4.y : ((tau - eps) - dis0) - s4.y;
+                    pcst = IS_L2 ? (dis0 + s4.y) + eps : (dis0 + s4.y) - eps;
+                }
+            }
+            if (lane_i == 0) {
+                *reinterpret_cast<float4*>(pc + wave * 4) = make_float4(t, s4.x, pcst, 0.f);
+                pqs[wave * 2] = q;
+                pqs[wave * 2 + 1] = slot;
+            }
+        }
+        // ---- LUT[c][m][16 queries]: 16 x 8 bytes transposed in registers, 8 conflict-free 16-byte stores ------------
+        {
+            const int t = wave * KN_WAVE + lane_i;
+            const int c4 = t >> 4, l16 = t & 15;
+            uint4* lut = reinterpret_cast<uint4*>(smem);
+#pragma unroll
+            for (int w = 0; w < 2; w++) { // word w of a piece: cells (cc = 2 w, h = 0), (2 w, 1), (2 w + 1, 0), (2 w + 1, 1)
+                uint32_t r[PI_Q];
+#pragma unroll
+                for (int j = 0; j < PI_Q; j++) {
+                    r[j] = w ? tp[j].y : tp[j].x;
+                }
+                // level 1: queries (2 i, 2 i + 1) -> bytes {b0 q, b0 q', b1 q, b1 q'} and {b2 q, b2 q', b3 q, b3 q'}
+                uint32_t lo[8], hi[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    lo[i] = __builtin_amdgcn_perm(r[2 * i + 1], r[2 * i], 0x05010400u);
+                    hi[i] = __builtin_amdgcn_perm(r[2 * i + 1], r[2 * i], 0x07030602u);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; e++) { // byte e of the word = cell (cc = 2 w + (e >> 1), h = e & 1)
+                    const uint32_t sel = (e & 1) ? 0x07060302u : 0x05040100u;
+                    const uint32_t* src = (e & 2) ? hi : lo;
+                    uint4 o;
+                    o.x = __builtin_amdgcn_perm(src[1], src[0], sel);
+                    o.y = __builtin_amdgcn_perm(src[3], src[2], sel);
+                    o.z = __builtin_amdgcn_perm(src[5], src[4], sel);
+                    o.w = __builtin_amdgcn_perm(src[7], src[6], sel);
+                    const int cc = 2 * w + (e >> 1), h = e & 1;
+                    lut[(c4 * 4 + cc) * PF_M + l16 + 16 * h] = o;
+                }
+            }
+        }
+        PF_T(0);
+        __syncthreads();
+        PF_T(1);
+        if (threadIdx.x == 0) { // the NEXT unit's staging counter (its last user's flush ended before this barrier)
+            reinterpret_cast<int*>(smem + PF_LUT_BYTES + PF_CTL_BYTES + PF_STAGE_CAP * 16)[par ^ 1] = 0;
+        }
+        int nxt = -1;
+        uint32_t rw_next = 0;
+        if (wave == 0) {
+            if (lane_i == 0) {
+                if (fetch_t < 8 && nxt_unit >= 0) {
+                    const int base = f_x * per;
+                    const int cnt = min(per, nunits - base);
+                    if (f_i < cnt) {
+                        nxt = base + f_i;
+                    } else {
+                        fetch_t++;
+                        nxt = fetch_slow();
+                    }
+                }
+            }
+            nxt = __builtin_amdgcn_readlane(nxt, 0);
+            if (nxt >= 0) {
+                rw_next = reinterpret_cast<const uint32_t*>(a.pq_recs16 + nxt)[lane_i];
+            }
+        }
+        uint2 tpn[PI_Q];
+#pragma unroll
+        for (int j = 0; j < PI_Q; j++) {
+            tpn[j] = make_uint2(0, 0);
+        }
+        if (nxt_unit >= 0) {
+            load_tables(par ^ 1, tpn, lane_i);
+        }
+        // this lane's 4 accumulator rows are the queries 4 (lane >> 4) + r of vector lane & 15
+        const int qb = 4 * (lane_i >> 4);
+        float thr[4], stp[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float4 c4v = *reinterpret_cast<const float4*>(pc + (qb + r) * 4);
+            thr[r] = c4v.x;
+            stp[r] = c4v.y;
+        }
+        // selector: row i = lane & 15 takes byte i of every k block
+        pf_i4 sel;
+        {
+            const int i = lane_i & 15;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                sel[w] = (i >> 2) == w ? (int)(1u << (8 * (i & 3))) : 0;
+            }
+        }
+        typedef __attribute__((address_space(3))) const pf_i4 lds_i4;
+        auto lut_read = [&](uint32_t addr) -> pf_i4 { return *reinterpret_cast<lds_i4*>(addr); };
+        auto issue2 = [&](uint32_t w0, pf_i4 (&v)[2]) {
+            v[0] = lut_read(pf_addr_lo(w0, one));
+            v[1] = lut_read(pf_addr_hi(w0, one));
+        };
+        PF_T(2);
+        if (nwin > 0) {
+            const pf_i4 iz = {0, 0, 0, 0};
+            pf_i4 B0[2], B1[2];
+            uint4 W0 = U0; // block 4 i at the top of iteration i (its first two words are in flight)
+            issue2(W0.x, B0);
+            issue2(W0.y, B1);
+            pf_i4 e0 = iz, e1 = iz, o0 = iz, o1 = iz; // even / odd windows, even / odd steps
+            const int vec = lane_i & 15;
+            float ps_cur[4] = {0.f, 0.f, 0.f, 0.f}, ps_prev = 0.f;
+            if (IS_L2) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    ps_cur[u] = psb[u * 16];
+                }
+            }
+
+#define PI_UNIT(A0, A1, C0, C1, BUF, WORD)                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    A0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(sel, BUF[0], C0, 0, 0, 0);                    \
+    A1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(sel, BUF[1], C1, 0, 0, 0);                    \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    issue2(WORD, BUF);
+
+            auto finish = [&](const pf_i4& x0, const pf_i4& x1, int G, float ps) {
+                const float f[4] = {(float)(x0[0] + x1[0]), (float)(x0[1] + x1[1]), (float)(x0[2] + x1[2]),
+                                    (float)(x0[3] + x1[3])};
+                // fast path: 4 (add, convert, fma, compare) per lane, the lane masks OR-ed on the scalar unit; whether the
+                // row exists at all is only looked at when something passed
+                unsigned long long mk[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    // L2: ps + s S <= t;  IP: s S >= t   (t = -inf / +inf: nothing passes)
+                    const float v = __fmaf_rn(f[r], stp[r], IS_L2 ? ps : 0.f);
+                    mk[r] = __ballot(IS_L2 ? (v <= thr[r]) : (v >= thr[r]));
+                }
+                if (__builtin_expect((mk[0] | mk[1] | mk[2] | mk[3]) != 0ull, 0)) { // (out of line: the hot path falls through)
+                    const int64_t pos = (int64_t)G * 16 + vec;
+                    if (G < G1 && pos < len) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            if ((mk[r] >> lane_i) & 1ull) {
+                                const int j = qb + r;
+                                const float pcs = pc[j * 4 + 2];
+                                const float pess = IS_L2 ? __fmaf_rn(f[r], stp[r], pcs + ps) : __fmaf_rn(f[r], stp[r], pcs);
+                                pf_stage_emit<IS_L2>(a, smem, par, pqs[j * 2], pqs[j * 2 + 1], row_off, pos, pess);
+                            }
+                        }
+                    }
+                }
+            };
+
+            const int niter = (nwin + 3) >> 2;
+            for (int i = 0; i < niter; i++) {
+                pf_setprio((i + (wave >> 2)) & 3);
+                const float ps0 = ps_cur[0], ps1 = ps_cur[1], ps2 = ps_cur[2], ps3 = ps_cur[3];
+                if (IS_L2) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        ps_cur[u] = psb[(int64_t)(4 * i + 4 + u) * 16]; // (the slack groups behind a list exist)
+                    }
+                }
+                // window 4 i (block W0)
+                PI_UNIT(e0, e1, iz, iz, B0, W0.z)
+                PI_UNIT(e0, e1, e0, e1, B1, W0.w)
+                if (i > 0) { // (window 4 i - 1: its last matrix instructions have retired by now)
+                    finish(o0, o1, G0 + 4 * i - 1, ps_prev);
+                }
+                PI_UNIT(e0, e1, e0, e1, B0, U1.x)
+                PI_UNIT(e0, e1, e0, e1, B1, U1.y)
+                W0 = load_blk(4 * i + 4);
+                // window 4 i + 1 (block U1)
+                PI_UNIT(o0, o1, iz, iz, B0, U1.z)
+                PI_UNIT(o0, o1, o0, o1, B1, U1.w)
+                finish(e0, e1, G0 + 4 * i, ps0);
+                PI_UNIT(o0, o1, o0, o1, B0, U2.x)
+                PI_UNIT(o0, o1, o0, o1, B1, U2.y)
+                U1 = load_blk(4 * i + 5);
+                // window 4 i + 2 (block U2)
+                PI_UNIT(e0, e1, iz, iz, B0, U2.z)
+                PI_UNIT(e0, e1, e0, e1, B1, U2.w)
+                finish(o0, o1, G0 + 4 * i + 1, ps1);
+                PI_UNIT(e0, e1, e0, e1, B0, U3.x)
+                PI_UNIT(e0, e1, e0, e1, B1, U3.y)
+                U2 = load_blk(4 * i + 6);
+                // window 4 i + 3 (block U3)
+                PI_UNIT(o0, o1, iz, iz, B0, U3.z)
+                PI_UNIT(o0, o1, o0, o1, B1, U3.w)
+                finish(e0, e1, G0 + 4 * i + 2, ps2);
+                PI_UNIT(o0, o1, o0, o1, B0, W0.x)
+                PI_UNIT(o0, o1, o0, o1, B1, W0.y)
+                U3 = load_blk(4 * i + 7);
+                __builtin_amdgcn_sched_barrier(0);
+                ps_prev = ps3;
+            }
+            finish(o0, o1, G0 + 4 * niter - 1, ps_prev);
+#undef PI_UNIT
+            __builtin_amdgcn_s_setprio(0);
+        }
+        PF_T(3);
+        PF_COUNT(6, nwin);
+        if (wave == 0) { // park the unit after the next
+            ctl[8 + par * REC_WORDS + lane_i] = (int)rw_next;
+            if (lane_i == 0) {
+                ctl[par] = nxt;
+            }
+        }
+        __syncthreads();
+        PF_T(4);
+        pf_stage_flush<IS_L2>(a, smem, par, row_off);
+        PF_COUNT(7, 1);
+        cur = nxt_unit;
+        par ^= 1;
+#pragma unroll
+        for (int j = 0; j < PI_Q; j++) {
+            tp[j] = tpn[j];
+        }
+    }
+#ifdef KNHIP_PHASE_TIMERS
+    if (lane == 0) {
+        for (int i = 0; i < 8; i++) {
+            atomicAdd(&g_pf_prof[wave * 8 + i], tacc[i]);
+        }
+    }
+#endif
+}
+
+hipError_t launch_pqi(const MScanArgs& a, bool is_l2, int64_t units_bound, hipStream_t s) {
+    if (units_bound <= 0) {
+        return hipSuccess;
+    }
+    auto kern = is_l2 ? pqi_kernel<true> : pqi_kernel<false>;
+    const size_t sm = pqf_smem();
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)sm);
+    if (e != hipSuccess) {
+        return e;
+    }
+    hipLaunchKernelGGL(pqi_prepare_kernel, dim3((unsigned)((std::max<int64_t>(units_bound, 128) + 255) / 256)), dim3(256),
+                       0, s, a, units_bound);
+    int dev = 0, ncu = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (ncu <= 0) {
+        ncu = 256;
+    }
+    const int64_t wgs = std::max<int64_t>(1, std::min<int64_t>(ncu, units_bound));
+#ifdef KNHIP_PHASE_TIMERS
+    static unsigned long long zero[128] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pf_prof), zero, sizeof(zero));
+#endif
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(PF_THREADS), sm, s, a);
+#ifdef KNHIP_PHASE_TIMERS
+    (void)hipStreamSynchronize(s);
+    unsigned long long h[128];
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pf_prof), sizeof(h));
+    fprintf(stderr, "[pqf timers] int8 filter ticks per unit: wave | lut wait1 setup windows wait2 top | windows/unit\n");
+    for (int w = 0; w < 16; w++) {
+        const unsigned long long* r = h + w * 8;
+        const double n = r[7] ? (double)r[7] : 1.0;
+        fprintf(stderr, "[pqf timers] %2d | %6.0f %6.0f %6.0f %6.0f %6.0f %5.0f | %.2f   (units %llu)\n", w, r[0] / n, r[1] / n,
+                r[2] / n, r[3] / n, r[4] / n, r[5] / n, r[6] / n, r[7]);
+    }
+#endif
+    return hipGetLastError();
+}
+
+size_t pqf_smem() {
+    return (size_t)PF_LUT_BYTES + PF_CTL_BYTES + PF_STAGE_BYTES;
+}
+static_assert(PF_LUT_BYTES + PF_CTL_BYTES + PF_STAGE_BYTES <= 160 * 1024, "LDS of one workgroup");
 
 bool pqf_supports(int M, int d) {
     return M == PF_M && d == PF_M * PF_DSUB;

@@ -25,10 +25,10 @@ def _sub(s, pattern, repl, count, flags=0, what=""):
 
 
 def patch_pq_filter(s):
-    s = _sub(s, re.escape(DYN_SMEM), DYN_SMEM_EMU, 1, what="dynamic LDS")
+    s = _sub(s, re.escape(DYN_SMEM), DYN_SMEM_EMU, 2, what="dynamic LDS")
     # the LDS-offset-0 assertion of the token addressing
     s = _sub(s, r"    if \(\(uint32_t\)\(size_t\)\(\(__attribute__\(\(address_space\(3\)\)\) unsigned char\*\)smem\) != 0u\) \{\n"
-                r"        __builtin_trap\(\);[^\n]*\n    \}\n", "", 1, what="LDS offset check")
+                r"        __builtin_trap\(\);[^\n]*\n    \}\n", "", 2, what="LDS offset check")
     # token -> LDS byte address: the SDWA shift, restated
     s = _sub(s, r'    asm\("v_lshlrev_b32_sdwa %0, %2, %1 [^"]*src1_sel:WORD_0"\n\s*: "=v"\(a\)\n\s*: "v"\(w\), "s"\(one\)\);\n',
              "    a = (w & 0xffffu) << one;\n", 1, what="sdwa lo")
@@ -39,9 +39,13 @@ def patch_pq_filter(s):
                 r"        auto lut_read = \[&\]\(uint32_t addr\) -> pf_h8 \{ return \*reinterpret_cast<lds_h8\*>\(addr\); \};\n",
              "        auto lut_read = [&](uint32_t addr) -> pf_h8 { return *reinterpret_cast<const pf_h8*>(smem + addr); };\n",
              1, what="lut_read")
+    s = _sub(s, r"        typedef __attribute__\(\(address_space\(3\)\)\) const pf_i4 lds_i4;\n"
+                r"        auto lut_read = \[&\]\(uint32_t addr\) -> pf_i4 \{ return \*reinterpret_cast<lds_i4\*>\(addr\); \};\n",
+             "        auto lut_read = [&](uint32_t addr) -> pf_i4 { return *reinterpret_cast<const pf_i4*>(smem + addr); };\n",
+             1, what="lut_read i8")
     s = _sub(s, r'    asm volatile\("s_getreg_b32 %0, hwreg\(HW_REG_XCC_ID\)" : "=s"\(xcc\)\);\n',
-             "    xcc = (uint32_t)blockIdx.x;\n", 1, what="xcc id")
-    s = _sub(s, r'        asm volatile\("" : "\+v"\(lane_i\)\);[^\n]*\n', "", 1, what="lane launder")
+             "    xcc = (uint32_t)blockIdx.x;\n", 2, what="xcc id")
+    s = _sub(s, r'        asm volatile\("" : "\+v"\(lane_i\)\);[^\n]*\n', "", 2, what="lane launder")
     return s
 
 

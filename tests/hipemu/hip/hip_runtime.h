@@ -304,6 +304,30 @@ inline C hipemu_mfma_16x16x32_f16(H8 a, H8 b, C c, int, int, int) {
     }
     return c;
 }
+// v_mfma_i32_16x16x64_i8: 16 signed bytes per lane and operand, int32 accumulator; same lane maps
+template <class I4>
+inline I4 hipemu_mfma_i32_16x16x64_i8(I4 a, I4 b, I4 c, int, int, int) {
+    static_assert(sizeof(I4) == 16, "16 bytes per lane");
+    unsigned char ab[32];
+    std::memcpy(ab, &a, 16);
+    std::memcpy(ab + 16, &b, 16);
+    const unsigned char (*all)[32] = hipemu::xchg_wide(ab, 32);
+    const int l = hipemu::tl.lane, n = l & 15;
+    for (int r = 0; r < 4; r++) {
+        const int i = 4 * (l >> 4) + r;
+        int acc = c[r];
+        for (int kb = 0; kb < 4; kb++) {
+            const signed char* av = reinterpret_cast<const signed char*>(all[i + 16 * kb]);
+            const signed char* bv = reinterpret_cast<const signed char*>(all[n + 16 * kb] + 16);
+            for (int e = 0; e < 16; e++) {
+                acc += (int)av[e] * (int)bv[e];
+            }
+        }
+        c[r] = acc;
+    }
+    return c;
+}
+#define __builtin_amdgcn_mfma_i32_16x16x64_i8(...) hipemu_mfma_i32_16x16x64_i8(__VA_ARGS__)
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16(...) hipemu_mfma_16x16x32_f16(__VA_ARGS__)
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(...) hipemu_mfma_32x32x2_f32(__VA_ARGS__)
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(...) hipemu_mfma_32x32x16_f16(__VA_ARGS__)

@@ -75,7 +75,6 @@ def main():
         same(Do, Io, D, I, "nprobe=4200")
         g.close()
     elif case == "range_pq16":
-        assert os.environ.get("KNHIP_UNVALIDATED") == "1"
         nb, d, nlist, nq = 1500, 128, 6, 5
         xb, xq = gen_data(nb, d, 42), gen_data(nq, d, 44)
         for metric in (ob.L2, ob.IP):

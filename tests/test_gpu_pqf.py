@@ -30,14 +30,27 @@ def _bitset(n, frac, seed):
     return np.packbits(filt, bitorder="little")
 
 
+FORM = {"v": "half"}  # the filter form the module's tests run with (fixture below)
+
+
+@pytest.fixture(autouse=True, params=["half", "int8"])
+def form(request):
+    """KNHIP_PQF_FORM: half = half-precision tables, 8 queries per unit (v_mfma_f32_16x16x32_f16); int8 = integer tables,
+    16 queries per unit (v_mfma_i32_16x16x64_i8).  Both must return the exact kernels' and the oracle's bits."""
+    FORM["v"] = request.param
+    return request.param
+
+
 def _pair(monkeypatch, ix, guard=True):
     monkeypatch.setenv("KNHIP_PQF", "0")  # read when the lists are attached
     g0 = _gpu(ix)
     monkeypatch.setenv("KNHIP_PQF", "1")
     monkeypatch.setenv("KNHIP_PQF_GUARD", "1" if guard else "0")
+    monkeypatch.setenv("KNHIP_PQF_FORM", FORM["v"])
     g1 = _gpu(ix)
     monkeypatch.delenv("KNHIP_PQF", raising=False)
     monkeypatch.delenv("KNHIP_PQF_GUARD", raising=False)
+    monkeypatch.delenv("KNHIP_PQF_FORM", raising=False)
     return g0, g1
 
 

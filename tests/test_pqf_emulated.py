@@ -236,13 +236,14 @@ def _run_api_case(case, **env):
 
 
 @pytest.mark.timeout(1800)
+@pytest.mark.parametrize("form", ["half", "int8"])
 @pytest.mark.parametrize("case", ["pqf_l2", pytest.param("pqf_ip", marks=pytest.mark.skipif(
     os.environ.get("KNHIP_TEST_EMU_FULL") != "1", reason="KNHIP_TEST_EMU_FULL=1"))])
-def test_emulated_api_ivfpq_prefilter(case):
+def test_emulated_api_ivfpq_prefilter(case, form):
     """KNHIP_PQF=1 through knhip_index_* / knhip_search: layouts built on first use, exact coarse stage, work table with
     the sample split, sample pass, row selection, tau, filter, finish passes, (empty) retry and exact rounds, merge --
     every query finished by the prefilter path, results equal to the oracle's bit for bit, with and without a bitset"""
-    _run_api_case(case, KNHIP_PQF="1")
+    _run_api_case(case, KNHIP_PQF="1", KNHIP_PQF_FORM=form)
 
 
 @pytest.mark.timeout(1800)
@@ -257,7 +258,7 @@ def test_emulated_api_nprobe_above_4096():
 
 @pytest.mark.timeout(1800)
 def test_emulated_api_range_search_pq16():
-    _run_api_case("range_pq16", KNHIP_UNVALIDATED="1")
+    _run_api_case("range_pq16")
 
 
 @pytest.mark.timeout(1500)

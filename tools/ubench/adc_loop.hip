@@ -13,6 +13,8 @@
 //   9 the same with a single accumulator (dependent MFMAs back to back)
 //  10 mode 8 without the LDS reads (MFMA + SDWA only)
 //  11 mode 8 with two value buffers (4 reads in flight instead of 8): what pq_filter.hip's registers allow
+//  12 int8 table, 16 queries per entry: one v_mfma_i32_16x16x64_i8 per ds_read_b128 (1024 lookups per instruction)
+//  13 int8 table, one v_smfmac_i32_16x16x128_i8 (2:4-sparse selector) per TWO ds_read_b128 (2048 lookups per instruction)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -57,6 +59,18 @@ __device__ __forceinline__ void accum2_mfma(f4& a0, f4& a1, const h8 sel, const 
     }
 }
 
+typedef int i4v __attribute__((ext_vector_type(4)));
+typedef int i8v __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void accum2_i8(i4v& a0, i4v& a1, const i4v sel, const f4 (&v)[2]) {
+    a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(sel, __builtin_bit_cast(i4v, v[0]), a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(sel, __builtin_bit_cast(i4v, v[1]), a1, 0, 0, 0);
+}
+__device__ __forceinline__ void accum2_smfmac(i4v& a0, const i4v sel, int idx, const f4 (&v)[2]) {
+    const i4v lo = __builtin_bit_cast(i4v, v[0]), hi = __builtin_bit_cast(i4v, v[1]);
+    const i8v b = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    a0 = __builtin_amdgcn_smfmac_i32_16x16x128_i8(sel, b, a0, idx, 0, 0);
+}
+
 __device__ __forceinline__ uint32_t addr_lo(uint32_t w, uint32_t one) {
     uint32_t a;
     asm("v_lshlrev_b32_sdwa %0, %2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(a) : "v"(w), "s"(one));
@@ -84,6 +98,8 @@ __global__ __launch_bounds__(1024) void k(float* out, const uint32_t* tok, int n
     f4 B0[2], B1[2], B2[2], B3[2];
     uint32_t h0 = 0, h1 = 0, h2 = 0, h3 = 0;
     f4 m0 = {0, 0, 0, 0}, m1 = {0, 0, 0, 0};
+    i4v im0 = {0, 0, 0, 0}, im1 = {0, 0, 0, 0}, isel = {lane & 1, (lane >> 1) & 1, 0, 1};
+    const int iidx = 0x44444444 ^ (lane & 3);
     h8 sel;
     for (int e = 0; e < 8; e++) sel[e] = (_Float16)(((lane & 15) == e) ? 1.0f : 0.0f);
     auto rd = [&](uint32_t a) -> f4 {
@@ -106,7 +122,9 @@ __global__ __launch_bounds__(1024) void k(float* out, const uint32_t* tok, int n
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #define UNIT(U, BUF, WORD)                                                   \
     __builtin_amdgcn_sched_barrier(0);                                       \
-    if (MODE >= 8) accum2_mfma(m0, m1, sel, BUF, MODE == 9);                 \
+    if (MODE == 12) accum2_i8(im0, im1, isel, BUF);                          \
+    else if (MODE == 13) accum2_smfmac(im0, isel, iidx, BUF);                \
+    else if (MODE >= 8) accum2_mfma(m0, m1, sel, BUF, MODE == 9);            \
     else if (MODE == 6 || MODE == 7) accum2_h(h0, h1, h2, h3, BUF);          \
     else if (MODE != 4) accum2<U, MODE != 1>(n01, n23, o01, o23, BUF);       \
     else asm volatile("" :: "v"(BUF[0]), "v"(BUF[1]));                       \
@@ -131,7 +149,8 @@ __global__ __launch_bounds__(1024) void k(float* out, const uint32_t* tok, int n
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     out[blockIdx.x * 1024 + threadIdx.x] = n01.x + n01.y + n23.x + n23.y + o01.x + o23.y + B0[0].x + B1[0].x + B2[0].x + B3[0].x +
-                                           __uint_as_float(h0 ^ h1 ^ h2 ^ h3) + m0.x + m0.y + m0.z + m0.w + m1.x + m1.y + m1.z + m1.w;
+                                           __uint_as_float(h0 ^ h1 ^ h2 ^ h3) + m0.x + m0.y + m0.z + m0.w + m1.x + m1.y + m1.z + m1.w +
+                                           (float)(im0[0] + im0[1] + im0[2] + im0[3] + im1[0] + im1[1] + im1[2] + im1[3]);
     if (lane == 0) atomicAdd(cyc + (threadIdx.x >> 6), t1 - t0);
 }
 
@@ -153,7 +172,7 @@ void run(const char* name, const uint32_t* dtok, float* out, unsigned long long*
     unsigned long long h[16];
     hipMemcpy(h, dcyc, sizeof(h), hipMemcpyDeviceToHost);
     // per CU: 16 waves x nwin windows; lookups per window per wave = 64 lanes x 32 steps x 4 queries (8 in the f16 modes)
-    const double lookups = 256.0 * 16 * nwin * 64 * 32 * ((MODE >= 6) ? 8 : 4);
+    const double lookups = 256.0 * 16 * nwin * 64 * 32 * ((MODE >= 12) ? 16 : (MODE >= 6) ? 8 : 4);
     printf("%-34s %8.3f ms  %6.1f ns per window-round (16 waves)  %5.1f lookups/ns/CU (LDS peak 64/clk)  ticks/window: w0 %.0f w15 %.0f\n", name, ms,
            ms * 1e6 / nwin, lookups / 256 / (ms * 1e6), (double)h[0] / blocks / nwin, (double)h[15] / blocks / nwin);
 }
@@ -190,5 +209,7 @@ int main() {
     run<9>("f16 table, MFMA adds, one acc", dtok, out, dcyc);
     run<10>("MFMA adds + SDWA, no LDS", dtok, out, dcyc);
     run<11>("MFMA adds, 4 reads in flight", dtok, out, dcyc);
+    run<12>("int8 table, MFMA i8 16x16x64", dtok, out, dcyc);
+    run<13>("int8 table, SMFMAC i8 16x16x128", dtok, out, dcyc);
     return 0;
 }
