@@ -336,14 +336,26 @@ def make_roofline(a, kind, prof, world):
             # query (16-byte entries hold 8 queries; one ds_read_b128 feeds one v_mfma_f32_16x16x32_f16 = 512 lookups:
             # the LDS gather at 4 cycles per wave-instruction and the matrix pipe at 16 cycles per instruction and SIMD
             # bind at the same 128 lookups/clk/CU), survivors recomputed by the exact finish
-            lds = scan_bytes * 2.0 / sec / 1e9 if sec > 0 else 0.0
             steps = max(a.steps, 1)
-            kn = "knhip::pqf_kernel<true, false>" if a.metric == "l2" else "knhip::pqf_kernel<false, false>"
+            i8 = prof.get("pq_filter_form", 1) == 2
+            l2s = "true" if a.metric == "l2" else "false"
+            if i8:
+                # integer form: 1 byte per (lookup, query): an entry holds 16 queries, one ds_read_b128 feeds one
+                # v_mfma_i32_16x16x64_i8 = 1024 lookups; LDS gather and matrix pipe bind at 256 lookups/clk/CU
+                lds = scan_bytes * 1.0 / sec / 1e9 if sec > 0 else 0.0
+                kn = f"knhip::pqi_kernel<{l2s}>"
+                note = ("achieved = 1 B x code bytes scanned / launch time (int8 table, 16 queries per ds_read_b128 = one "
+                        "v_mfma_i32_16x16x64_i8); peak = 256 B/clk/CU x 256 CU x 2.4 GHz (the matrix pipe binds at the same "
+                        "rate: 1024 lookups per 16 cycles and SIMD)")
+            else:
+                lds = scan_bytes * 2.0 / sec / 1e9 if sec > 0 else 0.0
+                kn = f"knhip::pqf_kernel<{l2s}, false>"
+                note = ("achieved = 2 B x code bytes scanned / launch time (half-precision table, 8 queries per ds_read_b128 "
+                        "= one v_mfma_f32_16x16x32_f16); peak = 256 B/clk/CU x 256 CU x 2.4 GHz (the matrix pipe binds at "
+                        "the same rate: 512 lookups per 16 cycles and SIMD)")
             return with_pmc(dict({"bound": "lds", "kernel": kn, "achieved": round(lds, 1),
                          "peak": round(LDS_PEAK_GBPS, 1), "unit": "GB/s", "frac": round(lds / LDS_PEAK_GBPS, 4),
-                         "note": "achieved = 2 B x code bytes scanned / launch time (half-precision table, 8 queries "
-                                 "per ds_read_b128 = one v_mfma_f32_16x16x32_f16); peak = 256 B/clk/CU x 256 CU x 2.4 GHz "
-                                 "(the matrix pipe binds at the same rate: 512 lookups per 16 cycles and SIMD)",
+                         "note": note, "filter_form": "int8 x 16 queries" if i8 else "half x 8 queries",
                          "lookups_per_ns_per_cu": round(scan_bytes / sec / 1e9 / 256.0, 1) if sec > 0 else None,
                          "mscan": {"queries_per_step": prof["mscan_queries"] / steps,
                                    "overflow_queries_per_step": prof["mscan_overflow_queries"] / steps,
@@ -415,6 +427,8 @@ def pmc_key(a, world, kernel):
            f"refine_k={a.refine_k},gpus={world}")
     if "pqf_kernel" in kernel:
         key += ",pqf=1"
+    if "pqi_kernel" in kernel:
+        key += ",pqi=1"
     return key
 
 

@@ -336,6 +336,7 @@ typedef struct knhip_stage_times {
     int64_t mscan_candidates;
     double mscan_stream_bytes; /* bytes the prefilter streams: sum over its units of len(list) * code_size */
     int64_t mscan_recomputed;  /* candidates that got an exact distance (IVF_PQ: after the finish kernel's pruning) */
+    int64_t pq_filter_form;    /* IVF_PQ prefilter of the last search: 0 none (exact kernels), 1 half precision, 2 int8 */
 } knhip_stage_times;
 /* stage indices */
 enum {

@@ -31,7 +31,7 @@ class StageTimes(C.Structure):
     _fields_ = [("ms", C.c_float * NSTAGE), ("launches", C.c_int64 * NSTAGE), ("scan_bytes", C.c_double),
                 ("coarse_flops", C.c_double), ("scan_items", C.c_int64), ("coarse_fallback_queries", C.c_int64), ("scan_bytes_rank0", C.c_double),
                 ("mscan_queries", C.c_int64), ("mscan_overflow_queries", C.c_int64), ("mscan_candidates", C.c_int64), ("mscan_stream_bytes", C.c_double),
-                ("mscan_recomputed", C.c_int64)]
+                ("mscan_recomputed", C.c_int64), ("pq_filter_form", C.c_int64)]
 
 
 # every symbol include/knhip.h declares (tests check the .so exports all of them)

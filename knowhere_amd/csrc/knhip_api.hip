@@ -205,6 +205,7 @@ struct knhip_index {
     int pqf_form = 0;                // KNHIP_PQF_FORM: 0 = chosen per batch by the guard, 1 = half precision, 2 = int8
     mutable bool pqf_ready = false;
     mutable bool pqi_ready = false;
+    mutable int last_pq_form = 0;    // prefilter form of the last search: 0 none (exact kernels), 1 half precision, 2 int8
     mutable DevBuf rows_i;           // token stream of the integer form (stream16i)
     mutable DevBuf rows_r;           // rotated token stream (stream16r)
     mutable DevBuf d_list_blk_off_r; // [nlist + 1]
@@ -904,6 +905,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
                                                 : launch_pqf(x, is_l2, bound, s);
         };
         idx->rank0_phase_used = false;
+        idx->last_pq_form = 0;
         {
             // phase 1: tau_q from a sample of the closest list (units of the rank-0 virtual lists [0, nlist), DUMP mode)
             StageTimer t(idx, s, KNHIP_STAGE_SCAN_RANK0);
@@ -977,6 +979,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
                     }
                 }
                 pq_i8 = want_i8 && (idx->pqf_form == 2 || !idx->pqf_guard || (int64_t)h_poor[1] * 4 <= nq);
+                idx->last_pq_form = pq_i8 ? 2 : 1;
                 if (pq_i8) {
                     if (int rc = ensure_pqi(idx)) return rc;
                     qt = 16;
@@ -2970,6 +2973,7 @@ int knhip_profile_get(const knhip_index* idx, knhip_stage_times* out) {
     out->mscan_overflow_queries = (int64_t)nf[2];
     out->mscan_candidates = (int64_t)nf[3];
     out->mscan_recomputed = (int64_t)nf[4];
+    out->pq_filter_form = idx->last_pq_form;
     out->mscan_stream_bytes = sb[2];
     return KNHIP_OK;
 }

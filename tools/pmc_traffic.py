@@ -16,8 +16,10 @@ def mean(path, counter):
     for k, v in d.items():
         if kern in k and counter in v.get("counters", {}):
             c = v["counters"][counter]
-            if best is None or c["mean"] > best[0]:
-                best = (c["mean"], k, c["dispatches"])
+            # (max over the dispatches: the prefilter kernels are launched a second time per step for the -- normally
+            # empty -- retry round; the mean would halve the main launch's traffic)
+            if best is None or c["max"] > best[0]:
+                best = (c["max"], k, c["dispatches"])
     return best
 
 
@@ -31,7 +33,7 @@ try:
 except Exception:
     t = {}
 t[key] = {"hbm_bytes_per_launch": bytes_, "kernel": f[1], "fetch_size_kb": f[0], "write_size_kb": w[0] if w else None,
-          "dispatches": f[2], "commit": commit, "correction": "FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024"}
+          "dispatches": f[2], "commit": commit, "correction": "FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 (largest dispatch)"}
 if extra:
     sq = {}
     for p in extra:
