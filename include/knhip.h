@@ -101,6 +101,16 @@ int knhip_index_set_coarse(knhip_index* idx, const float* centroids);
 int knhip_index_set_pq(knhip_index* idx, const float* codebooks);
 /* SQ8 trained params: vmin[dim], vdiff[dim] (ScalarQuantizer::trained) */
 int knhip_index_set_sq(knhip_index* idx, const float* vmin, const float* vdiff);
+/* COSINE with stored norms, as the CPU nodes keep it for FLAT and IVF_FLAT: raw rows + one float per row, applied to the
+ * finished inner product of every scanned row (Search and RangeSearch):
+ *   mode 1: dis = <q, y> / scale      IVFFlatScanner with code norms (cppcontrib/knowhere/IndexIVFFlat.cpp:199-210),
+ *                                      scale = the row's L2 norm as knowhere::NormalizeVecs returns it
+ *   mode 2: dis = clamp(<q, y> * scale, -1, 1)   IndexFlatCosine -> exhaustive_cosine_seq_impl
+ *                                      (cppcontrib/knowhere/utils/distances.cpp:367-409), scale = inverse L2 norm
+ * scale: one float per stored entry in the canonical order of knhip_index_get_lists (BRUTE_FORCE: row order); NULL or
+ * mode 0 switches it off.  Inner-product BRUTE_FORCE / IVF_FLAT indexes only; the values belong to the current
+ * contents: set them again after an Add.  Queries are normalised by the caller (the node), as in the reference. */
+int knhip_index_set_row_scale(knhip_index* idx, const float* scale, int32_t mode);
 /* inverted lists in faiss ArrayInvertedLists layout: list_sizes[nlist],
  * codes[l] -> uint8[len][code_size] (IVF_FLAT: the fp32 rows), ids[l] -> int64[len].
  * Replaces any previous content.  codes[l]/ids[l] may be NULL when list_sizes[l] == 0. */
@@ -161,6 +171,10 @@ int knhip_index_train(knhip_index* idx, int64_t n, const float* x, const knhip_t
 int knhip_index_train_device(knhip_index* idx, int64_t n, const float* d_x, const knhip_train_params* params);
 int knhip_index_add(knhip_index* idx, int64_t n, const float* x, const int64_t* ids);
 int knhip_index_add_device(knhip_index* idx, int64_t n, const float* d_x, const int64_t* d_ids);
+/* IVF_FLAT: rows x_store appended to the lists their companions x_assign are assigned to -- IndexIVFFlatCosine::
+ * add_with_ids (cppcontrib/knowhere/IndexIVFFlat.cpp:516-524) assigns by the normalised row and stores the raw one */
+int knhip_index_add_assigned_by(knhip_index* idx, int64_t n, const float* x_store, const float* x_assign,
+                                const int64_t* ids);
 /* assignment + codes of n device rows without adding them: d_assign [n] int64, d_codes [n][code_size] */
 int knhip_index_encode_device(const knhip_index* idx, int64_t n, const float* d_x, int64_t* d_assign, uint8_t* d_codes,
                               void* stream);

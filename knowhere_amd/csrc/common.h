@@ -32,6 +32,15 @@ __device__ __forceinline__ float ip_step(float res, float x, float y) {
     return fadd_x(res, fmul_x(x, y));
 }
 
+// COSINE with stored norms: mode 1 = <q, y> / norm (one IEEE division), mode 2 = clamp(<q, y> * inverse norm, -1, 1)
+__device__ __forceinline__ float cosine_finish(float ip, float scale, int mode) {
+    if (mode == 1) {
+        return __fdiv_rn(ip, scale);
+    }
+    const float v = __fmul_rn(ip, scale);
+    return v < -1.0f ? -1.0f : (v > 1.0f ? 1.0f : v);
+}
+
 // ---- canonical ordering ----------------------------------------------------------------------
 // IS_L2: "a is better than b"  <=>  (da < db) || (da == db && ia < ib)
 // IP   :                         (da > db) || (da == db && ia > ib)

@@ -145,6 +145,13 @@ __device__ __forceinline__ void flat_scan_item(const FlatScanArgs& a, const int6
                 }
             }
         }
+        if (!IS_L2 && a.cos_mode != 0) { // COSINE with stored norms (FlatScanArgs)
+            const float sc = a.row_scale[(blk0 + b) * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < QG; j++) {
+                acc[j] = cosine_finish(acc[j], sc, a.cos_mode);
+            }
+        }
         // ---- candidates: ties are ordered by the row position, which is the id order
         //      (lists are stored sorted by id; DENSE ids are row + offset) ----------------
 #pragma unroll
@@ -317,6 +324,13 @@ __global__ __launch_bounds__(FS_THREADS) void flat_full_kernel(FlatScanArgs a, f
                     acc[j] = ip_step(acc[j], q.z, y.z);
                     acc[j] = ip_step(acc[j], q.w, y.w);
                 }
+            }
+        }
+        if (!IS_L2 && a.cos_mode != 0 && row < len) {
+            const float sc = a.row_scale[row_base + row];
+#pragma unroll
+            for (int j = 0; j < QG; j++) {
+                acc[j] = cosine_finish(acc[j], sc, a.cos_mode);
             }
         }
         if (row < len) {

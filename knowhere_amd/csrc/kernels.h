@@ -116,6 +116,11 @@ struct FlatScanArgs {
     int32_t nslot;
     int32_t k;
     int32_t item_loop;           // TABLE: 1 = the (fixed) grid walks items blockIdx.x, + gridDim.x, ... < *nitems_dev
+    // COSINE with stored norms (inner product only): one float per stored row position, applied to the finished product
+    // sum.  cos_mode 1: dis = ip / scale (IVF-Flat: cppcontrib/knowhere/IndexIVFFlat.cpp:199-210);
+    // 2: dis = clamp(ip * scale, -1, 1) (flat: cppcontrib/knowhere/utils/distances.cpp:367-409); 0: off
+    const float* row_scale;
+    int32_t cos_mode;
 };
 
 enum PqLutMode { PQ_LUT_PRECOMP = 0, PQ_LUT_IP = 1, PQ_LUT_RESIDUAL = 2 };

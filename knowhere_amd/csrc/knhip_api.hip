@@ -198,6 +198,9 @@ struct knhip_index {
     mutable DevBuf xnorm;        // [total blocks * 64] ||x||^2 per stored row position, built on first use
     mutable float xnorm_max = 0.f;
     int64_t total_blk = 0;       // 64-row blocks of the interleaved layout
+    DevBuf row_scale;            // COSINE with stored norms: one float per stored row position (knhip_index_set_row_scale)
+    int cos_mode = 0;            // 0 off, 1 ip / norm (IVF-Flat), 2 clamp(ip * inverse norm) (flat)
+    std::vector<int64_t> h_list_blk_off; // [nlist + 1] first 64-row block of each list
     // IVF-PQ matrix-core ADC prefilter (pq_filter.hip): 1 = when the lists are shared by enough queries (default),
     // 2 = whenever the shape allows (KNHIP_PQF=1: tests), 0 = never (KNHIP_PQF=0).  Its layouts are built on first use.
     int pqf = 1;
@@ -409,6 +412,8 @@ int build_list_layout(knhip_index* idx, const std::vector<int64_t>& list_off, co
     const int64_t nlist = idx->nlist;
     const int64_t ntotal = list_off[nlist];
     idx->ntotal = ntotal;
+    idx->row_scale.release(); // (stored norms belong to one layout: the caller sets them again after an Add)
+    idx->cos_mode = 0;
     idx->h_list_len.resize(nlist);
     idx->h_list_row_off.assign(list_off.begin(), list_off.begin() + nlist);
     idx->max_list_len = 0;
@@ -481,6 +486,7 @@ int build_list_layout(knhip_index* idx, const std::vector<int64_t>& list_off, co
     idx->aos_ready = keep_aos;
     const int64_t total_blk = blk_off[nlist];
     idx->total_blk = total_blk;
+    idx->h_list_blk_off = blk_off;
     if (kind == KNHIP_IVF_FLAT) {
         const int nchunk = (idx->d + 3) / 4;
         HIP_TRY(idx->rows.alloc((size_t)total_blk * nchunk * 64 * sizeof(float4)));
@@ -675,6 +681,8 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         a.gthr = ws->gthr.as<float>();
         a.nslot = (int)nchunks;
         a.k = k;
+        a.row_scale = idx->row_scale.as<float>();
+        a.cos_mode = idx->cos_mode;
         {
             StageTimer t(idx, s, KNHIP_STAGE_SCAN);
             HIP_TRY(launch_flat_scan(a, is_l2, true, a.nitems_dense, s));
@@ -733,7 +741,9 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
     const bool pqf_shape = kind == KNHIP_IVF_PQ && idx->pqf != 0 && pq_use_v2 && idx->cb_t.p != nullptr &&
             pqf_supports(idx->desc.pq_m, d) && pq_scan_q4_supports(idx->desc.pq_m, d, k) &&
             (!is_l2 || idx->use_precomp); // (residual tables: see pq_psum_kernel)
-    if ((kind == KNHIP_IVF_FLAT || kind == KNHIP_IVF_SQ8 || pqf_shape) && (idx->mscan != 0 || pqf_shape) && nprobe >= 2) {
+    // (COSINE with stored norms takes the exact kernels: the prefilter's bound does not carry the per-row division)
+    if ((kind == KNHIP_IVF_FLAT || kind == KNHIP_IVF_SQ8 || pqf_shape) && (idx->mscan != 0 || pqf_shape) && nprobe >= 2 &&
+        idx->cos_mode == 0) {
         size_t lds;
         if (kind == KNHIP_IVF_PQ) {
             ms_nchunk = d / 4;
@@ -1063,6 +1073,8 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         a.gthr = ws->gthr.as<float>();
         a.nslot = nprobe;
         a.k = k;
+        a.row_scale = idx->row_scale.as<float>();
+        a.cos_mode = idx->cos_mode;
         if (use_ms) {
             return run_mscan([&](const KnItem* items, const KnPair* pairs, const int64_t* nitems, int64_t grid) -> int {
                 FlatScanArgs b = a;
@@ -1462,6 +1474,41 @@ int knhip_index_set_sq(knhip_index* idx, const float* vmin, const float* vdiff) 
     return KNHIP_OK;
 }
 
+int knhip_index_set_row_scale(knhip_index* idx, const float* scale, int32_t mode) {
+    if (int rc = check_index(idx)) return rc;
+    const int kind = idx->desc.kind;
+    if (!scale || mode == 0) {
+        idx->row_scale.release();
+        idx->cos_mode = 0;
+        return KNHIP_OK;
+    }
+    if ((kind != KNHIP_BRUTE_FORCE && kind != KNHIP_IVF_FLAT) || idx->desc.metric != KNHIP_IP || (mode != 1 && mode != 2)) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "set_row_scale: inner-product BRUTE_FORCE / IVF_FLAT indexes, mode 1 or 2");
+    }
+    if (!idx->has_data) {
+        return fail(KNHIP_ERR_EMPTY_INDEX, "set_row_scale: the index holds no vectors");
+    }
+    DeviceGuard g(idx->desc.device);
+    // canonical entry order -> stored row positions (lists start at 64-row block boundaries); padding rows get 1
+    std::vector<float> pos;
+    if (kind == KNHIP_BRUTE_FORCE) {
+        pos.assign((size_t)round_up(idx->ntotal, 64) + 2048, 1.0f);
+        std::memcpy(pos.data(), scale, (size_t)idx->ntotal * sizeof(float));
+    } else {
+        pos.assign((size_t)idx->total_blk * 64 + 64, 1.0f);
+        for (int64_t l = 0; l < idx->nlist; l++) {
+            const int64_t len = idx->h_list_len[(size_t)l];
+            if (len > 0) {
+                std::memcpy(pos.data() + idx->h_list_blk_off[(size_t)l] * 64, scale + idx->h_list_row_off[(size_t)l],
+                            (size_t)len * sizeof(float));
+            }
+        }
+    }
+    if (int rc = upload(idx->row_scale, pos.data(), pos.size() * sizeof(float))) return rc;
+    idx->cos_mode = mode;
+    return KNHIP_OK;
+}
+
 int knhip_index_add_lists(knhip_index* idx, const int64_t* list_sizes, const uint8_t* const* codes,
                           const int64_t* const* ids) {
     if (int rc = check_index(idx)) return rc;
@@ -1534,6 +1581,8 @@ static int add_vectors_common(knhip_index* idx, int64_t n, const float* d_x, con
                               int64_t id_offset) {
     const int nchunk = (idx->d + 3) / 4;
     const int64_t nblk = (n + 63) / 64;
+    idx->row_scale.release();
+    idx->cos_mode = 0;
     HIP_TRY(idx->rows.alloc((size_t)nblk * nchunk * 64 * sizeof(float4)));
     HIP_TRY(launch_interleave_rows(d_x, n, idx->d, idx->rows.as<float4>(), 0, nullptr));
     if (idx->codes_aos.p != d_x) { // the raw rows stay resident: further Adds append to them, GetVectorByIds reads them
@@ -1797,6 +1846,8 @@ static int range_batch(const knhip_index* idx, Workspace* ws, const float* d_q, 
         c.nchunk = (d + 3) / 4;
         c.queries = d_q;
         c.nq = nq;
+        c.row_scale = idx->row_scale.as<float>();
+        c.cos_mode = idx->cos_mode;
         HIP_TRY(launch_flat_full(c, is_l2, ws->dump.as<float>(), nullptr, 0, nullptr, s));
     }
     if (kind == KNHIP_BRUTE_FORCE) {
@@ -2566,10 +2617,13 @@ int set_pq_device(knhip_index* idx, const float* d_cb) {
 }
 
 // assignment (k = 1 exact coarse search) + codes of n device rows; d_assign [n] int64, d_codes [n][code_size]
-int encode_rows(const knhip_index* idx, int64_t n, const float* d_x, int64_t* d_assign, uint8_t* d_codes, hipStream_t s) {
+// d_x_assign: rows the assignment is taken from when they differ from the stored ones (COSINE IVF-Flat: assigned by the
+// normalised row, stored raw -- IndexIVFFlatCosine::add_with_ids, cppcontrib/knowhere/IndexIVFFlat.cpp:516-524)
+int encode_rows(const knhip_index* idx, int64_t n, const float* d_x, int64_t* d_assign, uint8_t* d_codes, hipStream_t s,
+                const float* d_x_assign = nullptr) {
     const int d = idx->d;
     DevBuf resid;
-    if (int rc = assign_rows(idx, d_x, n, d_assign, s)) return rc;
+    if (int rc = assign_rows(idx, d_x_assign ? d_x_assign : d_x, n, d_assign, s)) return rc;
     if (idx->desc.kind == KNHIP_IVF_FLAT) {
         HIP_TRY(hipMemcpyAsync(d_codes, d_x, (size_t)n * d * sizeof(float), hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipStreamSynchronize(s));
@@ -2604,7 +2658,8 @@ int check_trained_for_add(const knhip_index* idx) {
     return KNHIP_OK;
 }
 
-int add_device_impl(knhip_index* idx, int64_t n, const float* d_x, const int64_t* d_ids) {
+int add_device_impl(knhip_index* idx, int64_t n, const float* d_x, const int64_t* d_ids,
+                    const float* d_x_assign = nullptr) {
     if (n == 0) {
         return KNHIP_OK;
     }
@@ -2632,7 +2687,7 @@ int add_device_impl(knhip_index* idx, int64_t n, const float* d_x, const int64_t
     DevBuf assign, codes, ids_new, sorted_rows, seg_off, tmp;
     HIP_TRY(assign.alloc((size_t)n * sizeof(int64_t)));
     HIP_TRY(codes.alloc((size_t)n * cs));
-    if (int rc = encode_rows(idx, n, d_x, assign.as<int64_t>(), codes.as<uint8_t>(), nullptr)) return rc;
+    if (int rc = encode_rows(idx, n, d_x, assign.as<int64_t>(), codes.as<uint8_t>(), nullptr, d_x_assign)) return rc;
     const int64_t* new_ids = d_ids;
     if (!d_ids) { // Knowhere ids are the running row numbers (IvfIndexNode::Add -> add_core without xids)
         HIP_TRY(ids_new.alloc((size_t)n * sizeof(int64_t)));
@@ -2829,6 +2884,26 @@ int knhip_index_add(knhip_index* idx, int64_t n, const float* x, const int64_t* 
         if (int rc = add_device_impl(idx, m, dx.as<float>(), ids ? di.as<int64_t>() : nullptr)) return rc;
     }
     return KNHIP_OK;
+}
+
+int knhip_index_add_assigned_by(knhip_index* idx, int64_t n, const float* x_store, const float* x_assign,
+                                const int64_t* ids) {
+    if (int rc = check_index(idx)) return rc;
+    if (idx->desc.kind != KNHIP_IVF_FLAT || n < 0 || (n > 0 && (!x_store || !x_assign))) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "add_assigned_by: IVF_FLAT index, two row arrays");
+    }
+    if (n == 0) {
+        return KNHIP_OK;
+    }
+    DeviceGuard g(idx->desc.device);
+    std::lock_guard<std::mutex> lk(idx->add_mu);
+    DevBuf dx, da, di;
+    if (int rc = upload(dx, x_store, (size_t)n * idx->d * sizeof(float))) return rc;
+    if (int rc = upload(da, x_assign, (size_t)n * idx->d * sizeof(float))) return rc;
+    if (ids) {
+        if (int rc = upload(di, ids, (size_t)n * sizeof(int64_t))) return rc;
+    }
+    return add_device_impl(idx, n, dx.as<float>(), ids ? di.as<int64_t>() : nullptr, da.as<float>());
 }
 
 int knhip_index_encode_device(const knhip_index* idx, int64_t n, const float* d_x, int64_t* d_assign, uint8_t* d_codes,

@@ -56,12 +56,23 @@ ToStatus(int rc) {
     }
 }
 
-// NormalizeVec (src/common/utils.cc:60-82): norm^2 by the scalar fvec_norm_L2sqr (src/simd/distances_ref.cc:39-46),
-// rows whose norm^2 is 0 or within FloatAccuracy (1e-5) of 1 are left alone, the others divided by sqrt(norm^2)
+// fvec_norm_L2sqr at the scalar level of the hook table (src/simd/distances_ref.cc:57-64: float products summed in a
+// DOUBLE, rounded once on return)
+float
+NormL2Sqr(const float* x, int64_t d) {
+    double res = 0;
+    for (int64_t i = 0; i < d; i++) {
+        const float p = x[i] * x[i];
+        res += (double)p;
+    }
+    return (float)res;
+}
+
+// NormalizeVec (src/common/utils.cc:60-82): rows whose norm^2 is 0 or within FloatAccuracy (1e-5) of 1 are left alone,
+// the others divided by sqrt(norm^2); returns the divisor (1 when the row was left alone)
 float
 NormalizeRow(float* x, int64_t d) {
-    float n2 = 0.f;
-    for (int64_t i = 0; i < d; i++) n2 += x[i] * x[i];
+    const float n2 = NormL2Sqr(x, d);
     if (n2 > 0 && std::abs(1.0f - n2) > 0.00001f) {
         const float n = std::sqrt(n2);
         for (int64_t i = 0; i < d; i++) x[i] = x[i] / n;
@@ -70,8 +81,17 @@ NormalizeRow(float* x, int64_t d) {
     return 1.0f;
 }
 void
-NormalizeRows(float* x, int64_t n, int64_t d) {
-    for (int64_t i = 0; i < n; i++) NormalizeRow(x + i * d, d);
+NormalizeRows(float* x, int64_t n, int64_t d, float* norms = nullptr) {
+    for (int64_t i = 0; i < n; i++) {
+        const float nr = NormalizeRow(x + i * d, d);
+        if (norms) norms[i] = nr;
+    }
+}
+// L2NormsStorage::add (cppcontrib/knowhere/IndexCosine.cpp:236-245): what IndexFlatCosine multiplies by
+float
+InverseL2Norm(const float* x, int64_t d) {
+    const float n2 = NormL2Sqr(x, d);
+    return n2 == 0.0f ? 1.0f : (1.0f / std::sqrt(n2));
 }
 
 struct KnhipHandle {
@@ -168,6 +188,28 @@ class HipIndexNode : public IndexNode {
         const int64_t rows = dataset->GetRows();
         const float* x = (const float*)dataset->GetTensor();
         std::vector<float> xn;
+        if (StoredNormCosine()) {
+            // FLAT / IVF_FLAT keep the RAW rows and one float per row beside them, as IndexFlatCosine (inverse norms,
+            // IndexCosine.cpp:236-245) and IndexIVFFlatCosine (norms, IndexIVFFlat.cpp:516-524: assigned by the
+            // normalised row) do: the scores are then the CPU node's floats
+            std::unique_lock<std::shared_mutex> lk(rw_);
+            const size_t n0 = row_scale_by_id_.size();
+            row_scale_by_id_.resize(n0 + (size_t)rows);
+            int rc = 0;
+            if constexpr (Kind == KNHIP_BRUTE_FORCE) {
+                for (int64_t i = 0; i < rows; i++) row_scale_by_id_[n0 + i] = InverseL2Norm(x + i * dim_, dim_);
+                rc = knhip_index_add(idx_.p, rows, x, nullptr);
+            } else {
+                xn.assign(x, x + rows * dim_);
+                NormalizeRows(xn.data(), rows, dim_, row_scale_by_id_.data() + n0);
+                rc = knhip_index_add_assigned_by(idx_.p, rows, x, xn.data(), nullptr);
+            }
+            if (rc) {
+                row_scale_by_id_.resize(n0);
+                return ToStatus(rc);
+            }
+            return PushRowScale();
+        }
         if (cosine_) {
             xn.assign(x, x + rows * dim_);
             NormalizeRows(xn.data(), rows, dim_);
@@ -387,9 +429,10 @@ class HipIndexNode : public IndexNode {
         if constexpr (Kind == KNHIP_BRUTE_FORCE) {
             x.xb.resize((size_t)count * dim_);
             if ((rc = knhip_index_get_lists(idx_.p, (uint8_t*)x.xb.data(), nullptr))) return ToStatus(rc);
-            if (cosine_) {  // IndexFlatCosine: "IxF9" = header, rows, L2 norms (index_write.cpp:539-546); the rows held
-                x.fourcc = FourCC("IxF9");  // here are already normalised, so every stored norm is 1
-                x.flat_norms.assign((size_t)count, 1.0f);
+            if (cosine_) {  // IndexFlatCosine: "IxF9" = header, raw rows, L2 norms = 1 / inverse norm
+                x.fourcc = FourCC("IxF9");  // (index_write.cpp:539-546, L2NormsStorage::as_l2_norms IndexCosine.cpp:261-268)
+                x.flat_norms.resize((size_t)count);
+                for (int64_t i = 0; i < count; i++) x.flat_norms[(size_t)i] = 1.0f / row_scale_by_id_[(size_t)i];
             } else {
                 x.fourcc = flat_cc;
             }
@@ -436,7 +479,10 @@ class HipIndexNode : public IndexNode {
             if (Kind == KNHIP_IVF_FLAT && cosine_) {        // Knowhere cosine IVF-Flat carries the row norms
                 x.with_norm = true;
                 x.norms.assign(nlist_, {});
-                for (int64_t l = 0; l < nlist_; l++) x.norms[l].assign((size_t)sizes[l], 1.0f);  // rows are normalised
+                for (int64_t l = 0; l < nlist_; l++) {
+                    x.norms[l].resize((size_t)sizes[l]);
+                    for (int64_t j = 0; j < sizes[l]; j++) x.norms[l][(size_t)j] = row_scale_by_id_[(size_t)x.ids[l][(size_t)j]];
+                }
             }
             if (has_refine_ && raw_.p) {  // IndexRefineFlat (ivf.cc:673-700)
                 x.has_refine = true;
@@ -532,25 +578,38 @@ class HipIndexNode : public IndexNode {
         if (x.nprobe >= 1 && x.nprobe <= 65536) default_nprobe_ = (int64_t)x.nprobe;  // the index's default nprobe
         m_ = (int64_t)x.pq_M;
         has_refine_ = x.has_refine;
-        // The CPU cosine indexes keep the RAW rows plus their L2 norms and score ip / norm
-        // (cppcontrib/knowhere/IndexIVFFlat.cpp:199-210, utils/distances.cpp:344-353); this backend scores ip on
-        // normalised rows: divide each row by its stored norm once, here.
-        auto scale_rows = [&](float* rows, const float* norms, size_t n) {
-            for (size_t i = 0; i < n; i++) {
-                const float nr = norms[i];
-                if (nr > 0 && nr != 1.0f) {
-                    for (int64_t t = 0; t < d; t++) rows[i * d + t] = rows[i * d + t] / nr;
+        // The CPU cosine indexes keep the RAW rows plus their L2 norms (FLAT: the wire carries the norms, the index
+        // multiplies by their inverses, L2NormsStorage::add_l2_norms IndexCosine.cpp:247-255; IVF_FLAT: ip / norm,
+        // cppcontrib/knowhere/IndexIVFFlat.cpp:199-210): kept exactly so, per row id
+        std::vector<float> scale_by_id;
+        if (cosine_ && flat) {
+            if (x.flat_norms.size() != (size_t)ntotal) return Status::invalid_serialized_index_type;
+            scale_by_id.resize((size_t)ntotal);
+            for (int64_t i = 0; i < ntotal; i++) {
+                const float nr = x.flat_norms[(size_t)i];
+                scale_by_id[(size_t)i] = nr == 0.0f ? 1.0f : (1.0f / nr);
+            }
+        }
+        if (cosine_ && Kind == KNHIP_IVF_FLAT) {
+            if (!x.with_norm) return Status::invalid_serialized_index_type;
+            int64_t max_id = -1;
+            for (uint64_t l = 0; l < x.nlist; l++) {
+                if (x.norms[l].size() != x.ids[l].size()) return Status::invalid_serialized_index_type;
+                for (int64_t id : x.ids[l]) {
+                    if (id < 0) return Status::invalid_serialized_index_type;
+                    max_id = std::max(max_id, id);
                 }
             }
-        };
-        if (flat && !x.flat_norms.empty()) scale_rows(x.xb.data(), x.flat_norms.data(), (size_t)ntotal);
-        if (Kind == KNHIP_IVF_FLAT && x.with_norm) {
-            for (uint64_t l = 0; l < x.nlist; l++)
-                scale_rows((float*)x.codes[l].data(), x.norms[l].data(), x.ids[l].size());
+            if (max_id >= 4 * std::max<int64_t>(ntotal, 1) + 1024) return Status::invalid_serialized_index_type;
+            scale_by_id.assign((size_t)(max_id + 1), 1.0f);
+            for (uint64_t l = 0; l < x.nlist; l++) {
+                for (size_t j = 0; j < x.ids[l].size(); j++) scale_by_id[(size_t)x.ids[l][j]] = x.norms[l][j];
+            }
         }
         std::unique_lock<std::shared_mutex> lk(rw_);
         idx_.reset();
         raw_.reset();
+        row_scale_by_id_ = std::move(scale_by_id);
         knhip_desc desc{};
         desc.kind = Kind;
         desc.metric = metric_;
@@ -561,7 +620,8 @@ class HipIndexNode : public IndexNode {
         int rc = knhip_index_create(&desc, &idx_.p);
         if (rc) return ToStatus(rc);
         if constexpr (Kind == KNHIP_BRUTE_FORCE) {
-            return ToStatus(knhip_index_add(idx_.p, ntotal, x.xb.data(), nullptr));
+            if ((rc = knhip_index_add(idx_.p, ntotal, x.xb.data(), nullptr))) return ToStatus(rc);
+            return StoredNormCosine() ? PushRowScale() : Status::success;
         }
         if ((rc = knhip_index_set_coarse(idx_.p, x.quantizer.xb.data()))) return ToStatus(rc);
         if (Kind == KNHIP_IVF_PQ && (rc = knhip_index_set_pq(idx_.p, x.pq_centroids.data()))) return ToStatus(rc);
@@ -576,6 +636,10 @@ class HipIndexNode : public IndexNode {
             ip[l] = x.ids[l].data();
         }
         if ((rc = knhip_index_add_lists(idx_.p, sizes.data(), cp.data(), ip.data()))) return ToStatus(rc);
+        if (StoredNormCosine()) {
+            const Status st = PushRowScale();
+            if (st != Status::success) return st;
+        }
         // raw rows for refine / GetVectorByIds, back in id order
         if (x.has_refine || (Kind == KNHIP_IVF_FLAT && !cosine_)) {
             std::vector<float> rows;
@@ -687,8 +751,34 @@ class HipIndexNode : public IndexNode {
         return ((Kind == KNHIP_IVF_PQ || Kind == KNHIP_IVF_SQ8) && has_refine_) || (Kind == KNHIP_IVF_FLAT && !cosine_);
     }
 
+    // COSINE on FLAT / IVF_FLAT: raw rows + one float per row (inverse norm / norm), see Add
+    bool
+    StoredNormCosine() const {
+        return cosine_ && (Kind == KNHIP_BRUTE_FORCE || Kind == KNHIP_IVF_FLAT);
+    }
+    // row_scale_by_id_ (ids are the running row numbers) -> the index's canonical entry order -> knhip_index_set_row_scale
+    Status
+    PushRowScale() {
+        const int64_t count = knhip_index_count(idx_.p);
+        if (count <= 0) return Status::success;
+        std::vector<float> canon((size_t)count);
+        if constexpr (Kind == KNHIP_BRUTE_FORCE) {
+            if ((int64_t)row_scale_by_id_.size() != count) return Status::invalid_args;
+            canon = row_scale_by_id_;
+        } else {
+            std::vector<int64_t> ids((size_t)count);
+            if (int rc = knhip_index_get_lists(idx_.p, nullptr, ids.data())) return ToStatus(rc);
+            for (int64_t i = 0; i < count; i++) {
+                if (ids[i] < 0 || ids[i] >= (int64_t)row_scale_by_id_.size()) return Status::invalid_args;
+                canon[i] = row_scale_by_id_[(size_t)ids[i]];
+            }
+        }
+        return ToStatus(knhip_index_set_row_scale(idx_.p, canon.data(), Kind == KNHIP_BRUTE_FORCE ? 2 : 1));
+    }
+
     int metric_ = KNHIP_L2;
     bool cosine_ = false, has_refine_ = false;
+    std::vector<float> row_scale_by_id_;  // StoredNormCosine(): FLAT inverse L2 norms, IVF_FLAT L2 norms, by row id
     std::string metric_name_ = metric::L2;
     int64_t dim_ = 0, nlist_ = 0, m_ = 0, default_nprobe_ = 8;
     KnhipHandle idx_, raw_;
@@ -716,3 +806,12 @@ KNOWHERE_REGISTER_GLOBAL_WITH_THREAD_POOL(GPU_HIP_IVF_SQ8, HipIvfSqIndexNode, fp
                                           knowhere::feature::GPU_ANN_FLOAT_INDEX, HipSearchPoolSize());
 
 }  // namespace knowhere
+
+// test hook (node_capi.cc): the node's NormalizeVec restatement
+extern "C" void
+knhip_host_normalize_rows(float* x, int64_t n, int64_t d, float* norms) {
+    for (int64_t i = 0; i < n; i++) {
+        const float nr = knowhere::NormalizeRow(x + i * d, d);
+        if (norms) norms[i] = nr;
+    }
+}

@@ -9,6 +9,8 @@
 
 using namespace knowhere;
 
+extern "C" void knhip_host_normalize_rows(float* x, int64_t n, int64_t d, float* norms);  // hip_index_node.cc
+
 namespace {
 thread_local std::string g_err;
 
@@ -122,6 +124,10 @@ int knhip_node_range_search(void* h, const float* q, int64_t nq, int64_t dim, co
     std::memcpy(*dist, r.value()->GetDistance(), sizeof(float) * n);
     return 0;
 }
+
+// the node's NormalizeVec restatement on n rows in place (norms may be null): test hook for the bitwise check against
+// knowhere::NormalizeVecs (src/common/utils.cc:60-93)
+void knhip_node_normalize_rows(float* x, int64_t n, int64_t d, float* norms) { knhip_host_normalize_rows(x, n, d, norms); }
 
 int64_t knhip_node_count(void* h) { return static_cast<Handle*>(h)->idx.Count(); }
 int64_t knhip_node_dim(void* h) { return static_cast<Handle*>(h)->idx.Dim(); }

@@ -76,6 +76,15 @@ class GpuIndex:
         b = np.ascontiguousarray(vdiff, np.float32)
         check(self.L.knhip_index_set_sq(self.h, _np_ptr(a), _np_ptr(b)))
 
+    def set_row_scale(self, scale, mode):
+        """COSINE with stored norms (knhip_index_set_row_scale): one float per entry in canonical order; mode 1 = ip / norm
+        (IVF_FLAT), 2 = clamp(ip * inverse norm) (FLAT); None switches it off"""
+        if scale is None:
+            check(self.L.knhip_index_set_row_scale(self.h, None, 0))
+            return
+        a = np.ascontiguousarray(scale, np.float32)
+        check(self.L.knhip_index_set_row_scale(self.h, _np_ptr(a), mode))
+
     def add_lists(self, list_codes, list_ids):
         nlist = self.nlist
         sizes = np.array([len(i) for i in list_ids], np.int64)
@@ -109,6 +118,9 @@ class GpuIndex:
         if kind == IVF_SQ8:
             g.set_sq(ix.sq_trained[:ix.d], ix.sq_trained[ix.d:])
         g.add_lists(ix.list_codes, ix.list_ids)
+        norms = getattr(ix, "list_norms", None)
+        if kind == IVF_FLAT and norms:  # COSINE with stored norms (IndexIVFFlatCosine): dis = ip / norm
+            g.set_row_scale(np.concatenate([np.asarray(n, np.float32) for n in norms]), 1)
         return g
 
     # ---- contents (device tensors, GPU build path) ----

@@ -254,3 +254,67 @@ def test_node_range_search_equals_the_reference_on_the_same_bytes(node, ref, kin
         ref.destroy(h2)
     finally:
         node.knhip_node_destroy(C.c_void_p(h))
+
+
+# ------------------------------------------------------------------------------------------ COSINE (a12)
+def test_node_normalize_is_the_references_normalizevec(node):
+    """hip_index_node.cc::NormalizeRow == knowhere::NormalizeVecs (src/common/utils.cc:60-93; norm^2 from the scalar hook,
+    float products summed in a double) on the fixture the reference itself normalised: rows and returned norms, bit for
+    bit, incl. the zero row and the already-unit row that are left alone"""
+    from helpers import load_cosine_golden
+    zf, _, _ = load_cosine_golden()
+    x = np.array(zf["xb"], np.float32, order="C", copy=True)
+    norms = np.empty(x.shape[0], np.float32)
+    node.knhip_node_normalize_rows(x.ctypes.data_as(C.POINTER(C.c_float)), C.c_int64(x.shape[0]), C.c_int64(x.shape[1]),
+                                   norms.ctypes.data_as(C.POINTER(C.c_float)))
+    assert x.tobytes() == zf["normalized"].tobytes() and norms.tobytes() == zf["norms"].tobytes()
+
+
+@pytest.mark.gpu
+def test_cpu_built_cosine_blobs_load_into_the_hip_node(node):
+    """the "IxF9" (IndexFlatCosine: raw rows + L2 norms) and stored-norm "IwFl" (IndexIVFFlatCosine) blobs written by the
+    reference's own classes (tests/golden/make_cosine_golden.py): Deserialize under the CPU node's key, Search with
+    metric COSINE (the node normalises the query) == the reference's results bit for bit; Serialize writes the bytes back"""
+    from helpers import load_cosine_golden
+    zf, zi, _ = load_cosine_golden()
+    xq = np.ascontiguousarray(zf["xq"])
+    for kind, blob, cases in ((ob.FLAT, zf["flat_blob"], [(k, 1, zf[f"flat_D_{k}"], zf[f"flat_I_{k}"]) for k in (1, 10, 120)]),
+                              (ob.IVF_FLAT, zi["blob"], [(k, p, zi[f"D_{k}_{p}"], zi[f"I_{k}_{p}"])
+                                                         for k, p in ((1, 1), (10, 4), (10, 16), (120, 16))])):
+        blob = np.ascontiguousarray(blob)
+        h = node.knhip_node_create(GPU_NAME[kind].encode())
+        assert h
+        try:
+            rc = node.knhip_node_deserialize(C.c_void_p(h), CPU_NAME[kind].encode(), _u8(blob), C.c_int64(blob.size),
+                                             b"metric_type=COSINE")
+            assert rc == 0, node.knhip_node_last_error().decode()
+            for k, nprobe, De, Ie in cases:
+                D, I = _search(node, h, xq, f"metric_type=COSINE;k={k};nprobe={nprobe}", k)
+                assert_parity(De, Ie, D, I, ob.IP, f"cosine blob kind={kind} k={k} nprobe={nprobe}")
+            n = node.knhip_node_serialize(C.c_void_p(h), None, C.c_int64(0))
+            out = np.empty(n, np.uint8)
+            assert node.knhip_node_serialize(C.c_void_p(h), _u8(out), C.c_int64(n)) == n
+            assert n == blob.size and bytes(out[:4]) == bytes(blob[:4])
+            diff = np.nonzero(out != blob)[0]
+            assert len(diff) <= 8, (kind, len(diff))  # (reserved header bytes only)
+        finally:
+            node.knhip_node_destroy(C.c_void_p(h))
+
+
+@pytest.mark.gpu
+def test_hip_built_cosine_index_equals_the_reference(node, kref):
+    """Build FLAT / IVF_FLAT with COSINE through the plugin API on the GPU: FLAT == IndexFlatCosine on the same rows; the
+    IVF_FLAT blob the node writes is read back by the reference's IndexIVFFlatCosine and searched there: same results"""
+    r = np.random.default_rng(5)
+    d, nb, nq, k = 32, 3000, 12, 10
+    xb = (r.random((nb, d), dtype=np.float32) * 10 - 3).astype(np.float32)
+    xq = (r.random((nq, d), dtype=np.float32) * 2 - 1).astype(np.float32)
+    h = node.knhip_node_create(GPU_NAME[ob.FLAT].encode())
+    try:
+        assert node.knhip_node_build(C.c_void_p(h), xb.ctypes.data_as(C.POINTER(C.c_float)), C.c_int64(nb), C.c_int64(d),
+                                     b"metric_type=COSINE") == 0
+        D, I = _search(node, h, xq, f"metric_type=COSINE;k={k}", k)
+        De, Ie, _ = kref.flat_cosine_search(xb, xq, k)
+        assert_parity(De, Ie, D, I, ob.IP, "hip-built FLAT cosine vs IndexFlatCosine")
+    finally:
+        node.knhip_node_destroy(C.c_void_p(h))
