@@ -150,8 +150,11 @@ class HipIndexNode : public IndexNode {
         if constexpr (Kind == KNHIP_IVF_PQ) {
             // m = 0: the backend picks, as cuVS does for pq_dim = 0 (about dim / 2): the largest supported m that
             // leaves sub-vectors of at least 2 dims
-            m_ = c.m.value_or(0) == 0 ? std::min<int64_t>(64, dim_ / 2) : c.m.value();
-            while (m_ > 1 && (dim_ % m_ != 0 || !(m_ == 8 || m_ == 16 || m_ == 32 || m_ == 64))) m_--;
+            // leaves sub-vectors of at least 2 dims.  An explicit m is honoured or refused, never rewritten (the reference
+            // honours any m that divides dim; this backend has kernels for 8, 16, 32 and 64 sub-quantizers)
+            const bool auto_m = c.m.value_or(0) == 0;
+            m_ = auto_m ? std::min<int64_t>(64, dim_ / 2) : c.m.value();
+            while (auto_m && m_ > 1 && (dim_ % m_ != 0 || !(m_ == 8 || m_ == 16 || m_ == 32 || m_ == 64))) m_--;
             if (dim_ % m_ != 0 || !(m_ == 8 || m_ == 16 || m_ == 32 || m_ == 64)) return Status::invalid_args;
             desc.pq_m = (int32_t)m_;
             desc.pq_nbits = 8;

@@ -41,6 +41,18 @@ def gen_data(n, d, seed, lo=0.0, hi=100.0):
     return (r.random((n, d), dtype=np.float32) * (hi - lo) + lo).astype(np.float32)
 
 
+# how often the one licensed deviation (ties at the k-th distance: first-scanned vs canonical-first) was actually used
+PARITY_STATS = {"comparisons": 0, "ids_compared": 0, "licensed_id_mismatches": 0, "comparisons_with_licensed_mismatches": 0}
+
+
+def pytest_terminal_summary(terminalreporter):
+    if PARITY_STATS["comparisons"]:
+        terminalreporter.write_line(
+            f"assert_parity: {PARITY_STATS['comparisons']} comparisons, {PARITY_STATS['ids_compared']} ids; licensed k-th-"
+            f"boundary tie mismatches: {PARITY_STATS['licensed_id_mismatches']} ids in "
+            f"{PARITY_STATS['comparisons_with_licensed_mismatches']} comparisons")
+
+
 def assert_parity(Do, Io, Dg, Ig, metric, what=""):
     """Parity bar (BASELINE.json north_star): distances bit-equal (tolerance 0 -- far inside the
     1e-4 relative bound), ids equal in canonical order.  The only licensed difference: entries whose
@@ -53,9 +65,13 @@ def assert_parity(Do, Io, Dg, Ig, metric, what=""):
     assert not db.any(), (f"{what}: {db.sum()} distances differ bitwise; first at {np.argwhere(db)[0]}: "
                           f"oracle {Do[db][0]!r} gpu {Dg[db][0]!r}")
     bad = Io != Ig
+    PARITY_STATS["comparisons"] += 1
+    PARITY_STATS["ids_compared"] += int(Io.size)
     if bad.any():
         kth = Do[:, -1:]
         licensed = bad & (Do == kth)
+        PARITY_STATS["licensed_id_mismatches"] += int(licensed.sum())
+        PARITY_STATS["comparisons_with_licensed_mismatches"] += 1
         # within a run of equal distances the same id multiset must appear unless it touches the k-th
         assert (bad == licensed).all(), (f"{what}: {int((bad & ~licensed).sum())} id mismatches that are not "
                                          f"k-th-boundary ties; first at {np.argwhere(bad & ~licensed)[0]}")

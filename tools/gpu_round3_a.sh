@@ -13,6 +13,6 @@ tail -3 gpurun_out/r3a_limits.log | cut -c1-400
 if [ $rc -eq 0 ]; then
   timeout 600 python bench.py > gpurun_out/r3a_bench_c3_q4.log 2>&1; tail -1 gpurun_out/r3a_bench_c3_q4.log | cut -c1-1400
   KNHIP_PQF=1 timeout 600 python bench.py > gpurun_out/r3a_bench_c3_pqf.log 2>&1; tail -1 gpurun_out/r3a_bench_c3_pqf.log | cut -c1-1400
-  KNHIP_PQF=1 KNHIP_LIB=knowhere_amd/libknhip_prof.so timeout 600 python bench.py --steps 2 --warmup 1 > gpurun_out/r3a_bench_c3_pqf_prof.log 2>&1
+  KNHIP_PQF=1 KNHIP_LIB=tools/prof/libknhip_prof.so timeout 600 python bench.py --steps 2 --warmup 1 > gpurun_out/r3a_bench_c3_pqf_prof.log 2>&1
   grep "pqf timers" gpurun_out/r3a_bench_c3_pqf_prof.log | tail -40 | cut -c1-200
 fi
