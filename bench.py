@@ -423,8 +423,10 @@ def make_roofline(a, kind, prof, world):
 def pmc_key(a, world, kernel):
     """key of a workload in profiles/bench_pmc_traffic.json (a PMC pass belongs to one kernel path: the IVF-PQ prefilter is
     a different dominant kernel than the exact ADC scan)"""
+    # (build=r3: indexes trained as the reference trains them -- 10 level-1 iterations, spherical k-means for the inner
+    # product -- since round 3; the traffic of a kernel depends on the index it scans, entries of older builds are not used)
     key = (f"config={a.config},nb={a.nb},nlist={a.nlist},nprobe={a.nprobe},nq={a.nq},m={a.m},"
-           f"refine_k={a.refine_k},gpus={world}")
+           f"refine_k={a.refine_k},gpus={world},data={a.data},latent={a.latent},build=r3")
     if "pqf_kernel" in kernel:
         key += ",pqf=1"
     if "pqi_kernel" in kernel:
