@@ -437,6 +437,11 @@ hipError_t launch_merge_partials(const float* partial_d, const int64_t* partial_
 // per row: the k best of n values (index = column), canonical order; out_keys int64, out_d float
 // k above row_select_lds_max_k() (up to row_select_max_k()): the selected keys are sorted in `sort_scratch`
 // ([nrows][next power of two >= k] u64, caller's memory) instead of the LDS
+// two-pass selection for k << n (topk.hip: group minima -> bound -> candidates); rows it cannot take are flagged in
+// ovf_flags for launch_row_select
+bool row_select_thr_supports(int64_t n, int k);
+hipError_t launch_row_select_thr(const float* vals, int64_t nrows, int64_t n, int k, bool is_l2, int64_t* out_keys,
+                                 float* out_d, int32_t* ovf_flags, hipStream_t s);
 hipError_t launch_row_select(const float* vals, int64_t nrows, int64_t n, int k, bool is_l2,
                              int64_t* out_keys, float* out_d, const int32_t* row_flags, hipStream_t s,
                              unsigned long long* sort_scratch = nullptr);

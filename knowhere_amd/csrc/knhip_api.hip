@@ -126,6 +126,7 @@ struct Workspace {
     DevBuf list_count, list_pair_off, list_item_off, list_cursor, pairs, items, nitems;
     // MFMA prefilter of the IVF-Flat / IVF-SQ8 scans (mfma_scan.hip)
     DevBuf ms_qi, ms_qis, pq_recs16;                                 // integer form: tables, {step, mu sum, eps, A}, records
+    DevBuf rs_ovf;                                                    // coarse stage: rows the two-pass selection left to the radix select
     DevBuf ms_cand_pess;                                             // [qb][cap] pessimistic distances of the candidates (IVF-PQ)
     DevBuf ms_units, ms_unit_off, ms_nunits, ms_cand, ms_cand_cnt;  // ms_cand_cnt: [qb] counters + [qb + 1] overflow flags
     DevBuf ms_sample_off, ms_nrow;                                   // sample plan: [qb][nprobe] dump columns, [qb] rows
@@ -339,8 +340,18 @@ int coarse_stage(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
     HIP_TRY(launch_row_norms(d_q, nq, d, ws->qnorm.as<float>(), s));
     HIP_TRY(launch_coarse_gemm(d_q, ws->qnorm.as<float>(), idx->centroids.as<float>(), idx->cnorm.as<float>(), nq,
                                nlist, d, is_l2, ws->coarse_full.as<float>(), s));
-    HIP_TRY(launch_row_select(ws->coarse_full.as<float>(), nq, nlist, (int)ncand, is_l2,
-                              ws->cand_keys.as<int64_t>(), ws->cand_approx.as<float>(), nullptr, s));
+    if (row_select_thr_supports(nlist, (int)ncand)) {
+        // two passes over the row (group minima -> bound -> candidates); rows with masses of equal values fall to the radix
+        // select through the flags
+        HIP_TRY(ws->rs_ovf.reserve((size_t)nq * sizeof(int32_t)));
+        HIP_TRY(launch_row_select_thr(ws->coarse_full.as<float>(), nq, nlist, (int)ncand, is_l2,
+                                      ws->cand_keys.as<int64_t>(), ws->cand_approx.as<float>(), ws->rs_ovf.as<int32_t>(), s));
+        HIP_TRY(launch_row_select(ws->coarse_full.as<float>(), nq, nlist, (int)ncand, is_l2,
+                                  ws->cand_keys.as<int64_t>(), ws->cand_approx.as<float>(), ws->rs_ovf.as<int32_t>(), s));
+    } else {
+        HIP_TRY(launch_row_select(ws->coarse_full.as<float>(), nq, nlist, (int)ncand, is_l2,
+                                  ws->cand_keys.as<int64_t>(), ws->cand_approx.as<float>(), nullptr, s));
+    }
     HIP_TRY(launch_coarse_rerank(d_q, idx->centroids.as<float>(), d, nq, nlist, (int)ncand,
                                  ws->cand_keys.as<int64_t>(), ws->cand_approx.as<float>(), nprobe, is_l2,
                                  ws->qnorm.as<float>(), idx->cnorm_max, keys, cdis, ws->fail_flags.as<int32_t>(),

@@ -463,6 +463,228 @@ __global__ __launch_bounds__(RS_THREADS) void row_select_kernel(const float* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// row_select_thr: the same selection (the k best of a row of n values, canonical order) for k << n, in two passes
+// over the row instead of the six of the radix select, and without its contended LDS histogram (distance rows fall
+// into two or three bins of the upper digits).  The row is cut into G >= 2 k disjoint groups (group g = the elements
+// i with i mod G == g); the k-th smallest of the G group minima is an upper bound of the row's k-th smallest value --
+// k groups hold an element at least that good -- so every element <= that bound is a candidate (expected
+// ~ k ln(1 / (1 - k / G)) n / (n / G ...) ~ 1.2 .. 1.6 k of them); they are compacted into LDS (wave-aggregated) and
+// sorted canonically.  Rows whose candidates do not fit RT_CAP (masses of equal values) are flagged for the radix
+// kernel.  Round 3: the coarse stage spent 0.93 of its 1.68 ms (C3) / 5.4 of 17.8 ms (C5) in the radix select.
+// ---------------------------------------------------------------------------------------------
+constexpr int RT_THREADS = 256;
+constexpr int RT_CAP = 2048;    // candidates per row (LDS: 16 KB)
+constexpr int RT_GMAX = 2048;   // group minima per row (LDS: 8 KB)
+
+template <bool IS_L2>
+__global__ __launch_bounds__(RT_THREADS) void row_select_thr_kernel(const float* __restrict__ vals, int64_t n, int k,
+                                                                    int kp, int G, int64_t* __restrict__ out_keys,
+                                                                    float* __restrict__ out_d,
+                                                                    int32_t* __restrict__ ovf_flags) {
+    __shared__ unsigned long long cand[RT_CAP];
+    __shared__ uint32_t gmin[RT_GMAX];
+    __shared__ uint32_t s_count;
+    const int tid = threadIdx.x;
+    const float* row = vals + (int64_t)blockIdx.x * n;
+    // ---- pass 1: group minima (thread t owns the groups g with g mod RT_THREADS == t: all its elements) ----
+    const int gper = G / RT_THREADS; // groups per thread (G is a multiple of RT_THREADS)
+    uint32_t lm[RT_GMAX / RT_THREADS];
+#pragma unroll
+    for (int u = 0; u < RT_GMAX / RT_THREADS; u++) {
+        lm[u] = 0xffffffffu;
+    }
+    // 16-byte loads, four in flight: thread t takes the float4 pieces t, t + 256, ...; piece number `it` of a thread goes
+    // to its group it mod gper (any disjoint cut of the row into G groups serves the bound)
+    const int64_t n4 = n >> 2; // (rows are 16-byte aligned when n is a multiple of 4; the tail goes element by element)
+    const bool vec = (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(row) & 15) == 0);
+    if (vec) {
+        const float4* row4 = reinterpret_cast<const float4*>(row);
+        int it = 0;
+#pragma unroll 4
+        for (int64_t j = tid; j < n4; j += RT_THREADS, it++) {
+            const float4 v = row4[j];
+            const uint32_t key = min(min(rs_key<IS_L2>(v.x), rs_key<IS_L2>(v.y)), min(rs_key<IS_L2>(v.z), rs_key<IS_L2>(v.w)));
+            const int u = it % gper;
+#pragma unroll
+            for (int uu = 0; uu < RT_GMAX / RT_THREADS; uu++) {
+                if (uu == u) {
+                    lm[uu] = min(lm[uu], key);
+                }
+            }
+        }
+    } else {
+        int it = 0;
+        for (int64_t i = tid; i < n; i += RT_THREADS, it++) {
+            const uint32_t key = rs_key<IS_L2>(row[i]);
+            const int u = it % gper;
+#pragma unroll
+            for (int uu = 0; uu < RT_GMAX / RT_THREADS; uu++) {
+                if (uu == u) {
+                    lm[uu] = min(lm[uu], key);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < RT_GMAX / RT_THREADS; u++) {
+        if (u < gper) {
+            gmin[u * RT_THREADS + tid] = lm[u];
+        }
+    }
+    if (tid == 0) {
+        s_count = 0;
+    }
+    __syncthreads();
+    // ---- the k-th smallest group minimum: bitonic sort of G keys ----
+    for (int size = 2; size <= G; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < G / 2; t += RT_THREADS) {
+                const int lo = (t / stride) * stride * 2 + (t % stride);
+                const int hi = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const uint32_t a = gmin[lo], b = gmin[hi];
+                if ((a > b) == up) {
+                    gmin[lo] = b;
+                    gmin[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const uint32_t theta = gmin[k - 1];
+    __syncthreads();
+    // ---- pass 2: everything <= theta (the row is L2-resident from pass 1) ----
+    const int lane = tid & (KN_WAVE - 1);
+    auto take = [&](bool hit, uint32_t key, int64_t i) {
+        const unsigned long long bal = __ballot(hit);
+        if (bal != 0ull) {
+            uint32_t base = 0;
+            if (lane == 0) {
+                base = atomicAdd(&s_count, (uint32_t)__popcll(bal));
+            }
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (hit) {
+                const uint32_t pos = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                if (pos < RT_CAP) {
+                    const uint32_t tie = IS_L2 ? (uint32_t)i : ~(uint32_t)i;
+                    cand[pos] = ((unsigned long long)key << 32) | tie;
+                }
+            }
+        }
+    };
+    if (vec) {
+        const float4* row4 = reinterpret_cast<const float4*>(row);
+#pragma unroll 4
+        for (int64_t j0 = 0; j0 < n4; j0 += RT_THREADS) {
+            const int64_t j = j0 + tid;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool in = j < n4;
+            if (in) {
+                v = row4[j];
+            }
+            const uint32_t k0 = rs_key<IS_L2>(v.x), k1 = rs_key<IS_L2>(v.y), k2 = rs_key<IS_L2>(v.z), k3 = rs_key<IS_L2>(v.w);
+            const bool any = in && (min(min(k0, k1), min(k2, k3)) <= theta);
+            if (__ballot(any) != 0ull) { // (most pieces hold no candidate: one ballot instead of four)
+                take(in && k0 <= theta, k0, 4 * j);
+                take(in && k1 <= theta, k1, 4 * j + 1);
+                take(in && k2 <= theta, k2, 4 * j + 2);
+                take(in && k3 <= theta, k3, 4 * j + 3);
+            }
+        }
+    } else {
+        for (int64_t i0 = 0; i0 < n; i0 += RT_THREADS) {
+            const int64_t i = i0 + tid;
+            uint32_t key = 0xffffffffu;
+            bool hit = false;
+            if (i < n) {
+                key = rs_key<IS_L2>(row[i]);
+                hit = key <= theta;
+            }
+            take(hit, key, i);
+        }
+    }
+    __syncthreads();
+    const uint32_t C = s_count;
+    if (C > RT_CAP) { // (masses of equal values: the radix kernel takes the row)
+        if (tid == 0) {
+            ovf_flags[blockIdx.x] = 1;
+        }
+        return;
+    }
+    if (tid == 0) {
+        ovf_flags[blockIdx.x] = 0;
+    }
+    int P = kp;
+    while (P < (int)C) {
+        P <<= 1;
+    }
+    for (int i = (int)C + tid; i < P; i += RT_THREADS) {
+        cand[i] = ~0ull;
+    }
+    __syncthreads();
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < P / 2; t += RT_THREADS) {
+                const int lo = (t / stride) * stride * 2 + (t % stride);
+                const int hi = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const unsigned long long a = cand[lo], b = cand[hi];
+                if ((a > b) == up) {
+                    cand[lo] = b;
+                    cand[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    int64_t* ok = out_keys + (int64_t)blockIdx.x * k;
+    float* od = out_d + (int64_t)blockIdx.x * k;
+    for (int e = tid; e < k; e += RT_THREADS) {
+        const unsigned long long c = cand[e];
+        const uint32_t key = (uint32_t)(c >> 32);
+        const uint32_t tie = (uint32_t)c;
+        ok[e] = IS_L2 ? (int64_t)tie : (int64_t)(~tie);
+        od[e] = rs_unkey<IS_L2>(key);
+    }
+}
+
+// true when the two-pass selection applies: k candidates of n with 2 k groups of at least 8 elements each
+bool row_select_thr_supports(int64_t n, int k) {
+    int G = RT_THREADS;
+    while (G < 2 * k) {
+        G <<= 1;
+    }
+    return k >= 1 && k <= RT_CAP / 2 && G <= RT_GMAX && n >= (int64_t)G * 8 && n <= 0x7fffffffll;
+}
+
+// ovf_flags [nrows]: 1 = the row was left to the radix kernel (launch_row_select with these flags afterwards)
+hipError_t launch_row_select_thr(const float* vals, int64_t nrows, int64_t n, int k, bool is_l2, int64_t* out_keys,
+                                 float* out_d, int32_t* ovf_flags, hipStream_t s) {
+    if (nrows <= 0) {
+        return hipSuccess;
+    }
+    if (!row_select_thr_supports(n, k) || ovf_flags == nullptr) {
+        return hipErrorInvalidValue;
+    }
+    int G = RT_THREADS;
+    while (G < 2 * k) {
+        G <<= 1;
+    }
+    int kp = 2;
+    while (kp < k) {
+        kp <<= 1;
+    }
+    if (is_l2) {
+        hipLaunchKernelGGL(row_select_thr_kernel<true>, dim3((unsigned)nrows), dim3(RT_THREADS), 0, s, vals, n, k, kp, G,
+                           out_keys, out_d, ovf_flags);
+    } else {
+        hipLaunchKernelGGL(row_select_thr_kernel<false>, dim3((unsigned)nrows), dim3(RT_THREADS), 0, s, vals, n, k, kp, G,
+                           out_keys, out_d, ovf_flags);
+    }
+    return hipGetLastError();
+}
+
 size_t row_select_max_k() {
     return RS_MAX_K;
 }
