@@ -189,6 +189,7 @@ int knhip_index_get_lists(const knhip_index* idx, uint8_t* codes, int64_t* ids);
 /* BRUTE_FORCE: device pointer to the resident raw rows [count][dim] (valid until the next Add / destroy) */
 int knhip_index_get_vectors_device(const knhip_index* idx, const float** d_rows);
 
+int knhip_index_get_desc(const knhip_index* idx, knhip_desc* out);  /* the descriptor the index was created with */
 int64_t knhip_index_count(const knhip_index* idx);         /* stored vectors */
 int64_t knhip_index_device_bytes(const knhip_index* idx);  /* HBM held by the index */
 int knhip_index_uses_precomputed_table(const knhip_index* idx);

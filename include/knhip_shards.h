@@ -1,0 +1,42 @@
+/* include/knhip_shards.h -- C ABI of the list-sharded multi-GPU search.
+ *
+ * Replaces what faiss does host-side for sharded indexes -- IndexShards::search + merge_knn_results
+ * (/root/reference/thirdparty/faiss/faiss/IndexShards.cpp:247-256, utils/Heap.h:636) -- with one step per query batch:
+ *   every GPU scans the inverted lists it owns (knhip_search_device on its own index: centroids, codebooks / SQ ranges
+ *   replicated, the lists of the other GPUs empty), ONE all-gather of the per-GPU (nq, k) partial results over RCCL /
+ *   xGMI (packed 12 bytes per entry: distance + id), one merge kernel per GPU (knhip_merge_topk_device), rank 0's copy
+ *   is returned.  Candidates of different lists are disjoint, so the result is bit-identical to the single-GPU search of
+ *   the whole index (tests/test_gpu_shards.py).
+ * The host side is C++ (knowhere_amd/host/shard_group.cc): one worker thread per GPU inside one process,
+ * ncclCommInitAll over device_ids[] -- the shape a Knowhere node owning several devices would use.  transport:
+ *   KNHIP_SHARDS_RCCL    ncclAllGather on the workers' streams (needs distinct devices)
+ *   KNHIP_SHARDS_STAGED  the same protocol with the all-gather done by device-to-device copies through rank 0's
+ *                        buffer: any device list, also several ranks on ONE device (how the protocol is tested on a
+ *                        single-GPU box). */
+#ifndef KNHIP_SHARDS_H
+#define KNHIP_SHARDS_H
+#include "knhip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct knhip_shard_group knhip_shard_group;
+enum { KNHIP_SHARDS_RCCL = 0, KNHIP_SHARDS_STAGED = 1 };
+
+/* n_devices ranks; rank r works on device_ids[r].  RCCL transport: the communicators are created here. */
+int knhip_shard_group_create(int32_t n_devices, const int32_t* device_ids, int32_t transport, knhip_shard_group** out);
+void knhip_shard_group_destroy(knhip_shard_group* g);
+/* rank r's index: created on device_ids[r] by the caller, holding the lists rank r owns (not owned by the group) */
+int knhip_shard_group_set_index(knhip_shard_group* g, int32_t rank, const knhip_index* idx);
+/* one Search() of the whole (sharded) index: host queries [nq][dim] in, host ids / distances [nq][k] out.
+ * stage_ms (may be NULL): [n_devices][4] = per rank {search, all-gather, merge, total} milliseconds of this call. */
+int knhip_shard_group_search(knhip_shard_group* g, const float* queries, int64_t nq, int32_t k, int32_t nprobe,
+                             const uint8_t* bitset, int64_t bitset_nbits, int64_t* out_ids, float* out_dist,
+                             float* stage_ms);
+int32_t knhip_shard_group_size(const knhip_shard_group* g);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

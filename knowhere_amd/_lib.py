@@ -37,7 +37,7 @@ class StageTimes(C.Structure):
 # every symbol include/knhip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
     "knhip_abi_version", "knhip_device_count", "knhip_last_error", "knhip_index_create",
-    "knhip_index_destroy", "knhip_index_set_coarse", "knhip_index_set_pq", "knhip_index_set_sq", "knhip_index_set_row_scale", "knhip_index_add_assigned_by",
+    "knhip_index_destroy", "knhip_index_set_coarse", "knhip_index_set_pq", "knhip_index_set_sq", "knhip_index_set_row_scale", "knhip_index_add_assigned_by", "knhip_index_get_desc",
     "knhip_index_add_lists", "knhip_index_add_vectors", "knhip_index_set_coarse_device",
     "knhip_index_set_lists_device", "knhip_index_add_vectors_device", "knhip_index_count",
     "knhip_index_device_bytes", "knhip_index_uses_precomputed_table", "knhip_search",

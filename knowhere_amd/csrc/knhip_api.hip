@@ -1637,6 +1637,15 @@ int64_t knhip_index_count(const knhip_index* idx) {
     return idx ? idx->ntotal : 0;
 }
 
+int knhip_index_get_desc(const knhip_index* idx, knhip_desc* out) {
+    if (int rc = check_index(idx)) return rc;
+    if (!out) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "get_desc: null output");
+    }
+    *out = idx->desc;
+    return KNHIP_OK;
+}
+
 int64_t knhip_index_device_bytes(const knhip_index* idx) {
     return idx ? idx->device_bytes() : 0;
 }

@@ -1,0 +1,338 @@
+// knowhere_amd/host/shard_group.cc -- C++ host of the list-sharded multi-GPU search (include/knhip_shards.h).
+//
+// One worker thread per GPU inside one process; per Search(): every worker uploads the batch, runs knhip_search_device on
+// its own index (the lists it owns), packs its (nq, k) partial result into 12-byte entries, ONE all-gather
+// (ncclAllGather over the RCCL communicators of ncclCommInitAll, or staged device copies), knhip_merge_topk_device,
+// rank 0 downloads.  Replaces faiss IndexShards::search + merge_knn_results (IndexShards.cpp:247-256).
+#include "knhip_shards.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+struct Barrier {  // reusable barrier of n threads
+    explicit Barrier(int n) : n_(n) {}
+    void wait() {
+        std::unique_lock<std::mutex> lk(mu_);
+        const int gen = gen_;
+        if (++count_ == n_) {
+            count_ = 0;
+            gen_++;
+            cv_.notify_all();
+        } else {
+            cv_.wait(lk, [&] { return gen != gen_; });
+        }
+    }
+    int n_, count_ = 0, gen_ = 0;
+    std::mutex mu_;
+    std::condition_variable cv_;
+};
+
+struct DevMem {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int dev = 0;
+    hipError_t reserve(size_t b) {
+        if (b <= bytes) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        hipError_t e = hipMalloc(&p, b);
+        if (e == hipSuccess) bytes = b;
+        return e;
+    }
+    ~DevMem() {
+        if (p) {
+            (void)hipSetDevice(dev);
+            (void)hipFree(p);
+        }
+    }
+};
+
+struct Rank {
+    int dev = 0;
+    const knhip_index* idx = nullptr;
+    hipStream_t stream = nullptr;
+    ncclComm_t comm = nullptr;
+    DevMem q, bits, part_d, part_i, packed, gathered, all_d, all_i, out_d, out_i;
+};
+
+}  // namespace
+
+struct knhip_shard_group {
+    int n = 0;
+    int transport = KNHIP_SHARDS_RCCL;
+    std::vector<Rank> ranks;
+    std::mutex call_mu;  // one Search() at a time per group
+};
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& m) {
+    g_err = m;
+    return code;
+}
+
+// pack (dist, id) -> 12-byte entries and back: tiny kernels, compiled as HIP in this TU
+__global__ void pack_kernel(const float* d, const int64_t* i, int64_t n, uint32_t* out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    out[3 * t] = __float_as_uint(d[t]);
+    out[3 * t + 1] = (uint32_t)(uint64_t)i[t];
+    out[3 * t + 2] = (uint32_t)((uint64_t)i[t] >> 32);
+}
+__global__ void unpack_kernel(const uint32_t* in, int64_t n, float* d, int64_t* i) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    d[t] = __uint_as_float(in[3 * t]);
+    i[t] = (int64_t)((uint64_t)in[3 * t + 1] | ((uint64_t)in[3 * t + 2] << 32));
+}
+
+#define SG_HIP(call)                                                                     \
+    do {                                                                                 \
+        hipError_t e_ = (call);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            err = std::string(#call) + ": " + hipGetErrorString(e_);                     \
+            rc = KNHIP_ERR_HIP_RUNTIME;                                                  \
+            return;                                                                      \
+        }                                                                                \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int knhip_shard_group_create(int32_t n_devices, const int32_t* device_ids, int32_t transport, knhip_shard_group** out) {
+    if (n_devices <= 0 || !device_ids || !out || (transport != KNHIP_SHARDS_RCCL && transport != KNHIP_SHARDS_STAGED)) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "shard_group_create: bad arguments");
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        return fail(KNHIP_ERR_HIP_RUNTIME, "no HIP device");
+    }
+    auto* g = new knhip_shard_group();
+    g->n = n_devices;
+    g->transport = transport;
+    g->ranks.resize(n_devices);
+    for (int r = 0; r < n_devices; r++) {
+        if (device_ids[r] < 0 || device_ids[r] >= ndev) {
+            delete g;
+            return fail(KNHIP_ERR_INVALID_ARGS, "shard_group_create: device id out of range");
+        }
+        Rank& k = g->ranks[r];
+        k.dev = device_ids[r];
+        for (DevMem* m : {&k.q, &k.bits, &k.part_d, &k.part_i, &k.packed, &k.gathered, &k.all_d, &k.all_i, &k.out_d, &k.out_i}) {
+            m->dev = k.dev;
+        }
+        (void)hipSetDevice(k.dev);
+        if (hipStreamCreateWithFlags(&k.stream, hipStreamNonBlocking) != hipSuccess) {
+            delete g;
+            return fail(KNHIP_ERR_HIP_RUNTIME, "stream creation failed");
+        }
+    }
+    if (transport == KNHIP_SHARDS_RCCL) {
+        for (int a = 0; a < n_devices; a++) {
+            for (int b = a + 1; b < n_devices; b++) {
+                if (device_ids[a] == device_ids[b]) {
+                    delete g;
+                    return fail(KNHIP_ERR_INVALID_ARGS, "RCCL transport needs distinct devices (use KNHIP_SHARDS_STAGED)");
+                }
+            }
+        }
+        std::vector<ncclComm_t> comms(n_devices);
+        std::vector<int> devs(device_ids, device_ids + n_devices);
+        const ncclResult_t nr = ncclCommInitAll(comms.data(), n_devices, devs.data());
+        if (nr != ncclSuccess) {
+            delete g;
+            return fail(KNHIP_ERR_HIP_RUNTIME, std::string("ncclCommInitAll: ") + ncclGetErrorString(nr));
+        }
+        for (int r = 0; r < n_devices; r++) {
+            int cnt = 0;
+            (void)ncclCommCount(comms[r], &cnt);
+            if (cnt != n_devices) {  // the communicator really spans the group
+                delete g;
+                return fail(KNHIP_ERR_HIP_RUNTIME, "RCCL communicator does not span the device list");
+            }
+            g->ranks[r].comm = comms[r];
+        }
+    }
+    *out = g;
+    return KNHIP_OK;
+}
+
+void knhip_shard_group_destroy(knhip_shard_group* g) {
+    if (!g) return;
+    for (Rank& k : g->ranks) {
+        (void)hipSetDevice(k.dev);
+        if (k.comm) (void)ncclCommDestroy(k.comm);
+        if (k.stream) (void)hipStreamDestroy(k.stream);
+    }
+    delete g;
+}
+
+int32_t knhip_shard_group_size(const knhip_shard_group* g) { return g ? g->n : 0; }
+
+int knhip_shard_group_set_index(knhip_shard_group* g, int32_t rank, const knhip_index* idx) {
+    if (!g || rank < 0 || rank >= g->n || !idx) return fail(KNHIP_ERR_INVALID_ARGS, "shard_group_set_index: bad arguments");
+    g->ranks[rank].idx = idx;
+    return KNHIP_OK;
+}
+
+int knhip_shard_group_search(knhip_shard_group* g, const float* queries, int64_t nq, int32_t k, int32_t nprobe,
+                             const uint8_t* bitset, int64_t bitset_nbits, int64_t* out_ids, float* out_dist,
+                             float* stage_ms) {
+    if (!g || !queries || nq <= 0 || k <= 0 || !out_ids || !out_dist) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "shard_group_search: bad arguments");
+    }
+    for (const Rank& r : g->ranks) {
+        if (!r.idx) return fail(KNHIP_ERR_INVALID_ARGS, "shard_group_search: a rank has no index");
+    }
+    std::lock_guard<std::mutex> call_lk(g->call_mu);
+    const int W = g->n;
+    knhip_desc desc{};
+    if (int drc = knhip_index_get_desc(g->ranks[0].idx, &desc)) return fail(drc, knhip_last_error());
+    const int32_t dim = desc.dim;
+    const int32_t metric = desc.metric;
+    const int64_t ne = nq * (int64_t)k;  // entries per rank
+    Barrier bar(W);
+    std::vector<int> rcs(W, KNHIP_OK);
+    std::vector<std::string> errs(W);
+    std::vector<std::thread> th;
+    Rank* R = g->ranks.data();
+    auto worker = [&](int r) {
+        int& rc = rcs[r];
+        std::string& err = errs[r];
+        Rank& me = R[r];
+        bool alive = true;  // (a failed rank still walks through every barrier)
+        hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+        auto body = [&]() {
+            SG_HIP(hipSetDevice(me.dev));
+            for (auto& e : ev) SG_HIP(hipEventCreate(&e));
+            SG_HIP(me.q.reserve((size_t)nq * dim * sizeof(float)));
+            SG_HIP(me.part_d.reserve((size_t)ne * sizeof(float)));
+            SG_HIP(me.part_i.reserve((size_t)ne * sizeof(int64_t)));
+            SG_HIP(me.packed.reserve((size_t)ne * 12));
+            SG_HIP(me.gathered.reserve((size_t)ne * 12 * W));
+            SG_HIP(me.all_d.reserve((size_t)ne * W * sizeof(float)));
+            SG_HIP(me.all_i.reserve((size_t)ne * W * sizeof(int64_t)));
+            SG_HIP(me.out_d.reserve((size_t)ne * sizeof(float)));
+            SG_HIP(me.out_i.reserve((size_t)ne * sizeof(int64_t)));
+            SG_HIP(hipMemcpyAsync(me.q.p, queries, (size_t)nq * dim * sizeof(float), hipMemcpyHostToDevice, me.stream));
+            const uint8_t* d_bits = nullptr;
+            if (bitset && bitset_nbits > 0) {
+                const size_t bb = (size_t)((bitset_nbits + 7) / 8);
+                SG_HIP(me.bits.reserve(bb));
+                SG_HIP(hipMemcpyAsync(me.bits.p, bitset, bb, hipMemcpyHostToDevice, me.stream));
+                d_bits = static_cast<const uint8_t*>(me.bits.p);
+            }
+            SG_HIP(hipEventRecord(ev[0], me.stream));
+            const int src = knhip_search_device(me.idx, static_cast<const float*>(me.q.p), nq, k, nprobe, d_bits,
+                                                d_bits ? bitset_nbits : 0, static_cast<int64_t*>(me.part_i.p),
+                                                static_cast<float*>(me.part_d.p), me.stream);
+            if (src != KNHIP_OK) {
+                err = std::string("knhip_search_device: ") + knhip_last_error();
+                rc = src;
+                return;
+            }
+            hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, me.stream,
+                               static_cast<const float*>(me.part_d.p), static_cast<const int64_t*>(me.part_i.p), ne,
+                               static_cast<uint32_t*>(me.packed.p));
+            SG_HIP(hipEventRecord(ev[1], me.stream));
+        };
+        body();
+        alive = rc == KNHIP_OK;
+        // ---- the one exchange step: all-gather of the packed partials ----
+        if (g->transport == KNHIP_SHARDS_RCCL) {
+            if (alive) {
+                const ncclResult_t nr = ncclAllGather(me.packed.p, me.gathered.p, (size_t)ne * 12, ncclChar, me.comm, me.stream);
+                if (nr != ncclSuccess) {
+                    err = std::string("ncclAllGather: ") + ncclGetErrorString(nr);
+                    rc = KNHIP_ERR_HIP_RUNTIME;
+                    alive = false;
+                }
+            }
+            bar.wait();
+        } else {
+            if (alive && hipStreamSynchronize(me.stream) != hipSuccess) {
+                rc = KNHIP_ERR_HIP_RUNTIME;
+                err = "stream synchronize failed";
+                alive = false;
+            }
+            bar.wait();  // every rank's packed partial is complete
+            bool all_ok = true;
+            for (int o = 0; o < W; o++) all_ok = all_ok && rcs[o] == KNHIP_OK;
+            if (alive && all_ok) {
+                for (int o = 0; o < W && alive; o++) {  // pull every rank's block (peer copies; same device: plain copies)
+                    const hipError_t e = hipMemcpyPeerAsync(static_cast<char*>(me.gathered.p) + (size_t)o * ne * 12, me.dev,
+                                                            R[o].packed.p, R[o].dev, (size_t)ne * 12, me.stream);
+                    if (e != hipSuccess) {
+                        rc = KNHIP_ERR_HIP_RUNTIME;
+                        err = std::string("hipMemcpyPeerAsync: ") + hipGetErrorString(e);
+                        alive = false;
+                    }
+                }
+                if (alive && hipStreamSynchronize(me.stream) != hipSuccess) {
+                    rc = KNHIP_ERR_HIP_RUNTIME;
+                    alive = false;
+                }
+            }
+            bar.wait();  // nobody's packed buffer is overwritten before everyone has read it
+        }
+        bool all_ok = true;
+        for (int o = 0; o < W; o++) all_ok = all_ok && rcs[o] == KNHIP_OK;
+        auto tail = [&]() {
+            SG_HIP(hipEventRecord(ev[2], me.stream));
+            hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)((ne * W + 255) / 256)), dim3(256), 0, me.stream,
+                               static_cast<const uint32_t*>(me.gathered.p), ne * W, static_cast<float*>(me.all_d.p),
+                               static_cast<int64_t*>(me.all_i.p));
+            const int mrc = knhip_merge_topk_device(metric, nq, k, W, static_cast<const float*>(me.all_d.p),
+                                                    static_cast<const int64_t*>(me.all_i.p), static_cast<float*>(me.out_d.p),
+                                                    static_cast<int64_t*>(me.out_i.p), me.stream);
+            if (mrc != KNHIP_OK) {
+                err = std::string("knhip_merge_topk_device: ") + knhip_last_error();
+                rc = mrc;
+                return;
+            }
+            SG_HIP(hipEventRecord(ev[3], me.stream));
+            if (r == 0) {
+                SG_HIP(hipMemcpyAsync(out_dist, me.out_d.p, (size_t)ne * sizeof(float), hipMemcpyDeviceToHost, me.stream));
+                SG_HIP(hipMemcpyAsync(out_ids, me.out_i.p, (size_t)ne * sizeof(int64_t), hipMemcpyDeviceToHost, me.stream));
+            }
+            SG_HIP(hipStreamSynchronize(me.stream));
+            if (stage_ms) {
+                float a = 0, b = 0, c = 0;
+                (void)hipEventElapsedTime(&a, ev[0], ev[1]);
+                (void)hipEventElapsedTime(&b, ev[1], ev[2]);
+                (void)hipEventElapsedTime(&c, ev[2], ev[3]);
+                stage_ms[4 * r + 0] = a;
+                stage_ms[4 * r + 1] = b;
+                stage_ms[4 * r + 2] = c;
+                stage_ms[4 * r + 3] = a + b + c;
+            }
+        };
+        if (alive && all_ok) tail();
+        for (auto& e : ev) {
+            if (e) (void)hipEventDestroy(e);
+        }
+    };
+    for (int r = 0; r < W; r++) th.emplace_back(worker, r);
+    for (auto& t : th) t.join();
+    for (int r = 0; r < W; r++) {
+        if (rcs[r] != KNHIP_OK) return fail(rcs[r], "rank " + std::to_string(r) + ": " + errs[r]);
+    }
+    return KNHIP_OK;
+}
+
+const char* knhip_shard_group_last_error() { return g_err.c_str(); }
+
+}  // extern "C"

@@ -31,6 +31,23 @@ def test_exports_match_header():
     assert set(_lib().SYMBOLS) == declared
 
 
+def test_shard_library_exports_match_header():
+    """include/knhip_shards.h (the C++ multi-GPU host, knowhere_amd/host/shard_group.cc): every declared entry point is
+    exported by libknhip_shards.so; without a device the group refuses loudly"""
+    hdr = open(os.path.join(ROOT, "include", "knhip_shards.h")).read()
+    declared = set(re.findall(r"\b(knhip_shard_group_[a-zA-Z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 5
+    _lib().load()
+    L = C.CDLL(os.path.join(ROOT, "knowhere_amd", "libknhip_shards.so"))
+    missing = [s for s in sorted(declared) if not hasattr(L, s)]
+    assert not missing, f"libknhip_shards.so does not export: {missing}"
+    import torch
+    if not torch.cuda.is_available():
+        g = C.c_void_p()
+        dev = (C.c_int32 * 1)(0)
+        assert L.knhip_shard_group_create(C.c_int32(1), dev, C.c_int32(1), C.byref(g)) != 0
+
+
 def test_no_gpu_fails_loudly():
     import torch
     if torch.cuda.is_available():

@@ -1,0 +1,123 @@
+"""(e) multi-GPU, C++ host (-m gpu): knowhere_amd/host/shard_group.cc behind include/knhip_shards.h -- one worker thread per
+rank, every rank scans the lists it owns, ONE all-gather of the packed (nq, k) partials, knhip_merge_topk_device.
+On a single-GPU box the protocol runs with several ranks on device 0 through the STAGED transport (device copies instead of
+ncclAllGather, everything else identical); the RCCL transport itself is exercised at world 1 (ncclCommInitAll +
+ncclAllGather on hardware) and, when the box has more GPUs, at world = all of them.  Bar: bit-identical to the
+single-GPU search of the whole index."""
+import copy
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import assert_parity, gen_data
+from helpers import finish_ivfpq
+from oracle import binding as ob
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "knowhere_amd", "libknhip_shards.so")
+
+
+@pytest.fixture(scope="module")
+def shards():
+    assert os.path.exists(SO), "build with __graft_entry__.build()"
+    from knowhere_amd import _lib
+    _lib.load()  # libknhip.so first (the shard library links it)
+    L = C.CDLL(SO)
+    L.knhip_shard_group_last_error.restype = C.c_char_p
+    return L
+
+
+def _split(ix, world):
+    """rank r's index: the lists dealt to it by the size-balanced deal, every other list empty"""
+    from knowhere_amd.sharded import partition_lists
+    masks = partition_lists(np.array([len(i) for i in ix.list_ids]), world)
+    parts = []
+    for r in range(world):
+        p = copy.copy(ix)
+        p.list_codes = [c if masks[r][l] else c[:0] for l, c in enumerate(ix.list_codes)]
+        p.list_ids = [i if masks[r][l] else i[:0] for l, i in enumerate(ix.list_ids)]
+        parts.append(p)
+    return parts
+
+
+def _group_search(L, gpus, devices, transport, xq, k, nprobe, bitset=None, nbits=0):
+    W = len(gpus)
+    g = C.c_void_p()
+    dev = (C.c_int32 * W)(*devices)
+    rc = L.knhip_shard_group_create(C.c_int32(W), dev, C.c_int32(transport), C.byref(g))
+    assert rc == 0, L.knhip_shard_group_last_error().decode()
+    try:
+        for r, gi in enumerate(gpus):
+            assert L.knhip_shard_group_set_index(g, C.c_int32(r), gi.h) == 0
+        nq = xq.shape[0]
+        I = np.empty((nq, k), np.int64)
+        D = np.empty((nq, k), np.float32)
+        ms = np.zeros((W, 4), np.float32)
+        bs = None if bitset is None else np.ascontiguousarray(bitset, np.uint8)
+        rc = L.knhip_shard_group_search(g, xq.ctypes.data_as(C.c_void_p), C.c_int64(nq), C.c_int32(k), C.c_int32(nprobe),
+                                        None if bs is None else bs.ctypes.data_as(C.c_void_p), C.c_int64(nbits),
+                                        I.ctypes.data_as(C.c_void_p), D.ctypes.data_as(C.c_void_p),
+                                        ms.ctypes.data_as(C.c_void_p))
+        assert rc == 0, L.knhip_shard_group_last_error().decode()
+        return D, I, ms
+    finally:
+        L.knhip_shard_group_destroy(g)
+
+
+@pytest.mark.parametrize("kind,metric", [(ob.IVF_PQ, ob.L2), (ob.IVF_FLAT, ob.IP), (ob.IVF_SQ8, ob.L2)],
+                         ids=["ivfpq_l2", "ivfflat_ip", "ivfsq8_l2"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_search_equals_the_single_index(shards, port, kind, metric, world):
+    from knowhere_amd import GpuIndex
+    nb, d, nlist, nq = 30000, 128, 40, 50
+    xb, xq = gen_data(nb, d, 42), gen_data(nq, d, 44)
+    ix = finish_ivfpq(port, ob.make_index(port, kind, metric, xb, nlist=nlist, M=32))
+    whole = GpuIndex.from_data(ix, device=0)
+    parts = [GpuIndex.from_data(p, device=0) for p in _split(ix, world)]
+    try:
+        for k, nprobe in ((10, 8), (100, nlist), (1, 3)):
+            Dw, Iw = whole.search(xq, k, nprobe)
+            Do, Io = port.search(ix, xq, k, nprobe)
+            D, I, ms = _group_search(shards, parts, [0] * world, 1, xq, k, nprobe)
+            assert np.array_equal(I, Iw) and np.array_equal(D.view(np.uint32), Dw.view(np.uint32)), (kind, k, nprobe)
+            assert_parity(Do, Io, D, I, metric, f"sharded world={world} kind={kind} k={k}")
+            assert (ms[:, 3] > 0).all()
+        bs = np.packbits(np.random.default_rng(1).random(nb) < 0.4, bitorder="little")
+        Dw, Iw = whole.search(xq, 10, 8, bs, nb)
+        D, I, _ = _group_search(shards, parts, [0] * world, 1, xq, 10, 8, bs, nb)
+        assert np.array_equal(I, Iw) and np.array_equal(D.view(np.uint32), Dw.view(np.uint32))
+    finally:
+        whole.close()
+        for p in parts:
+            p.close()
+
+
+def test_rccl_transport_on_the_devices_present(shards, port):
+    """ncclCommInitAll + ncclAllGather on hardware: world = every GPU of the box (1 on the test box: the collective is
+    then a copy, but communicator creation, the rank-count check and the call path are the real ones)"""
+    import torch
+    from knowhere_amd import GpuIndex
+    world = torch.cuda.device_count()
+    nb, d, nlist, nq = 20000, 128, 32, 40
+    xb, xq = gen_data(nb, d, 42), gen_data(nq, d, 44)
+    ix = finish_ivfpq(port, ob.make_index(port, ob.IVF_PQ, ob.L2, xb, nlist=nlist, M=32))
+    whole = GpuIndex.from_data(ix, device=0)
+    parts = [GpuIndex.from_data(p, device=r) for r, p in enumerate(_split(ix, world))]
+    try:
+        Dw, Iw = whole.search(xq, 10, 8)
+        D, I, ms = _group_search(shards, parts, list(range(world)), 0, xq, 10, 8)
+        assert np.array_equal(I, Iw) and np.array_equal(D.view(np.uint32), Dw.view(np.uint32))
+    finally:
+        whole.close()
+        for p in parts:
+            p.close()
+
+
+def test_rccl_transport_refuses_one_device_twice(shards):
+    g = C.c_void_p()
+    dev = (C.c_int32 * 2)(0, 0)
+    assert shards.knhip_shard_group_create(C.c_int32(2), dev, C.c_int32(0), C.byref(g)) != 0
+    assert b"distinct devices" in shards.knhip_shard_group_last_error()
