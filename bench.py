@@ -83,6 +83,9 @@ def parse():
                     help="queries of the CPU baseline sample (-1 = 8 per host thread, 0 = skip)")
     ap.add_argument("--host-steps", type=int, default=3, help="steps of the host-boundary timing (0 = skip)")
     ap.add_argument("--backend", default=None, help="nccl (default for N>1) | gloo (single-GPU debugging)")
+    ap.add_argument("--coarse-mode", default="auto", choices=["auto", "replicate", "shard"],
+                    help="N > 1: coarse quantizer replicated on every rank (no collective) or sharded by queries (one "
+                         "all-gather of the assignment); auto = replicate below 1e11 flop per batch")
     ap.add_argument("--verbose", action="store_true")
     a = ap.parse_args()
     cfg = dict(CONFIGS[a.config])
@@ -117,6 +120,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=dev if backend == "nccl" else None)
         comm = sharded.Comm(dev)
+        assert comm.world == world == a.gpus and comm.backend == backend, (comm.world, world, comm.backend)
+        if backend == "nccl":
+            assert ndev >= world or os.environ.get("KNHIP_ALLOW_SHARED_GPU") == "1", \
+                f"{world} RCCL ranks need {world} GPUs (found {ndev})"
     kind = KINDS[a.kind]
     metric = kidx.L2 if a.metric == "l2" else kidx.IP
     refine = a.refine_k > 0
@@ -178,11 +185,18 @@ def main():
 
     # N > 1: the coarse quantizer is sharded by QUERIES (each rank assigns nq / N of them, one all-gather of the
     # (nq, nprobe) assignment), the scan by LISTS (knhip_search_preassigned_device = IndexIVF::search_preassigned)
+    # (the coarse stage is replicated when it is small -- no collective, <= ~1 ms at C3 -- and sharded by queries, one
+    # all-gather of the assignment, when it is a TFLOP as at C5)
+    coarse_replicated = a.coarse_mode == "replicate" or (a.coarse_mode == "auto" and 2.0 * a.nq * a.nlist * a.d < 1e11)
+
     def step():
         if world > 1:
-            keys, cdis = sharded.sharded_coarse(comm, lambda lo, hi: g.coarse_search_device(xq[lo:hi], a.nprobe),
-                                                a.nq, a.nprobe, device=dev)
-            Dp, Ip = g.search_preassigned_device(xq, kbase, keys, cdis)
+            if coarse_replicated:
+                Dp, Ip = g.search_device(xq, kbase, a.nprobe)  # coarse + the lists this rank owns
+            else:
+                keys, cdis = sharded.sharded_coarse(comm, lambda lo, hi: g.coarse_search_device(xq[lo:hi], a.nprobe),
+                                                    a.nq, a.nprobe, device=dev)
+                Dp, Ip = g.search_preassigned_device(xq, kbase, keys, cdis)
             Dp, Ip = comm.allgather_merge(metric, Dp, Ip)  # global top-kbase by PQ distance, identical on every rank
             if not refine:
                 return Dp, Ip
@@ -233,6 +247,31 @@ def main():
         dt = comm.max_float(dt)
     prof = g.profile_get()
     g.profile_enable(False)
+    multi = None
+    if world > 1:
+        # per-rank evidence for the scaling curve, taken in a separate pass of the same steps (the events around the
+        # collectives stay out of the timed region): stage times of every rank, time inside the collectives
+        comm.timed = True
+        n0 = comm.ncollectives
+        g.profile_enable(True)
+        g.profile_reset()
+        barrier()
+        for _ in range(a.steps):
+            step()
+        barrier()
+        coll_ms = comm.collective_ms() / a.steps
+        pr = g.profile_get()
+        g.profile_enable(False)
+        comm.timed = False
+        mine = {"rank": rank, "device": dev_id, "collective_ms_per_step": round(coll_ms, 3),
+                "collectives_per_step": (comm.ncollectives - n0) // a.steps,
+                "stage_ms_per_step": {n: round(pr["ms"][i] / a.steps, 3) for i, n in
+                                      enumerate(["coarse", "group", "lut", "scan", "merge", "other", "scan_rank0"])},
+                "scan_bytes_per_step": pr["scan_bytes"] / a.steps}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        multi = {"backend": comm.backend, "world": comm.world, "coarse": "replicated" if coarse_replicated else "sharded by queries",
+                 "ranks": gathered}
     ms_per_step = dt / a.steps * 1e3
     qps = a.nq * a.steps / dt
 
@@ -282,6 +321,8 @@ def main():
                        "build_s": round(build_s, 1)},
             "roofline": roofline,
         }
+        if multi is not None:
+            out["multi_gpu"] = multi
         if host is not None:
             out["host_boundary"] = host
         if cpu is not None:

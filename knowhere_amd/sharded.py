@@ -75,6 +75,19 @@ class Comm:
         self.rank = dist.get_rank()
         self.backend = dist.get_backend()
         self.device = device
+        # time spent in the collectives (device events around each one; read with collective_ms())
+        self.timed = False
+        self._events = []
+        self.ncollectives = 0
+
+    def collective_ms(self):
+        """milliseconds between the recorded event pairs since the last call (synchronises the device)"""
+        if not self._events:
+            return 0.0
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self._events)
+        self._events = []
+        return ms
 
     def _stage(self, t):
         return t.cpu() if self.backend == "gloo" and t.is_cuda else t
@@ -100,8 +113,17 @@ class Comm:
         """[...] -> [world, ...] on t's device"""
         s = self._stage(t.contiguous())
         out = torch.empty((self.world,) + tuple(s.shape), dtype=s.dtype, device=s.device)
+        ev = None
+        if self.timed and t.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         dist.all_gather_into_tensor(out, s) if self.backend != "gloo" else dist.all_gather(list(out.unbind(0)), s)
-        return out.to(t.device) if out.device != t.device else out
+        self.ncollectives += 1
+        out = out.to(t.device) if out.device != t.device else out
+        if ev is not None:
+            ev[1].record()
+            self._events.append(ev)
+        return out
 
     def allreduce_sum(self, t):
         s = self._stage(t)
