@@ -978,7 +978,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
                 const bool want_i8 = idx->pqf_form != 1;
                 if (want_i8) {
                     HIP_TRY(ws->ms_qi.reserve((size_t)nq * 256 * 32));
-                    HIP_TRY(ws->ms_qis.reserve((size_t)nq * 4 * sizeof(float)));
+                    HIP_TRY(ws->ms_qis.reserve(((size_t)nq * 4 + 4) * sizeof(float))); // (+ the batch record)
                     HIP_TRY(launch_pqi_query_table(d_q, idx->cb_t.as<float4>(), d, nq, is_l2, idx->pabs_max, ws->ms_qi.p,
                                                    ws->ms_qis.as<float>(), s));
                 }

@@ -36,20 +36,35 @@ __device__ __forceinline__ void ms_emit(const MScanArgs& a, int32_t q, int32_t s
 }
 
 // bound on the query's final k-th distance from its candidate histogram (full wave: lane = bin); the neutral value
-// when the histogram is off or k candidates have not been seen yet
+// when the histogram is off or k candidates have not been seen yet.  Two halves, so that a caller can issue the loads
+// (ms_hist_load) together with its other loads and evaluate (ms_hist_eval) when they are back.
+struct MsHist {
+    bool on;      // (wave-uniform) the other fields are loaded; they stay unset otherwise (no merge, no early wait)
+    uint2 mt;     // the query's histogram origin and shift (shift == KN_HIST_OFF: no histogram)
+    uint32_t cum; // this lane's bin
+};
+
+__device__ __forceinline__ void ms_hist_load(const MScanArgs& a, int32_t q, MsHist& h) {
+    h.on = a.ghist != nullptr && q >= 0;
+    if (h.on) {
+        h.mt = a.gmeta[q];
+        h.cum = __hip_atomic_load(a.ghist + (int64_t)q * KN_HIST_BINS + lane_id(), __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 template <bool IS_L2>
-__device__ __forceinline__ float ms_hist_bound(const MScanArgs& a, int32_t q, int k) {
+__device__ __forceinline__ float ms_hist_eval(const MsHist& h, int k) {
     float bound = worst_dist<IS_L2>();
-    if (a.ghist == nullptr || q < 0) {
+    if (!h.on) {
         return bound;
     }
-    const uint2 mt = a.gmeta[q];
+    const uint2 mt = h.mt;
     if (mt.y == KN_HIST_OFF) {
         return bound;
     }
     const int lane = lane_id();
-    uint32_t cum = __hip_atomic_load(a.ghist + (int64_t)q * KN_HIST_BINS + lane, __ATOMIC_RELAXED,
-                                     __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t cum = h.cum;
 #pragma unroll
     for (int dlt = 1; dlt < KN_WAVE; dlt <<= 1) {
         const uint32_t up = __shfl_up(cum, dlt, KN_WAVE);
@@ -67,6 +82,13 @@ __device__ __forceinline__ float ms_hist_bound(const MScanArgs& a, int32_t q, in
         }
     }
     return bound;
+}
+
+template <bool IS_L2>
+__device__ __forceinline__ float ms_hist_bound(const MScanArgs& a, int32_t q, int k) {
+    MsHist h;
+    ms_hist_load(a, q, h);
+    return ms_hist_eval<IS_L2>(h, k);
 }
 
 // 64-bit mask of the block's rows that take part (inside the list, not filtered): lane = row

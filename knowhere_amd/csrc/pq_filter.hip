@@ -57,7 +57,7 @@ constexpr int PF_THREADS = PF_WAVES * KN_WAVE;
 constexpr int PF_LUT_BYTES = PF_KSUB * PF_M * PF_Q * 2; // 131072
 // behind the LUT (ints): [0], [1] unit index of mailbox slot 0 / 1, [8 + 32 s ..) the record of slot s (the current unit
 // and the one after it), [128 + 4 j ..) per-pair constants of the current unit
-constexpr int PF_CTL_BYTES = 1024;
+constexpr int PF_CTL_BYTES = 1536; // (the integer form keeps its per-pair constants per unit parity: pqi_kernel)
 constexpr int PF_SAMPLE = 4096; // = MS_SAMPLE (mfma_scan.hip): dump columns per query
 // Candidate staging behind the control block: a hit costs an LDS atomic and one 16-byte LDS store inside the scan loop;
 // the global side of ms_emit (bitset test, atomic on the query's counter with its returned slot, candidate store,
@@ -924,26 +924,26 @@ hipError_t launch_pq_stream16i(const uint8_t* codes, const int64_t* list_row_off
     return hipGetLastError();
 }
 
-// One workgroup per query, thread = centroid index c.  qis[q] = {s, sum_m mu, eps_base, A}.
-// Table layout (bytes): qi[q][c >> 2][m & 15][c & 3][m >> 4]: the 8-byte piece thread t = (c >> 2) * 16 + (m & 15) of the
-// filter kernel reads holds this query's entries of its 8 (c, m) cells.
+// Steps on a lattice.  s_q = w_q * s0 with an integer weight 1 <= w_q <= 127 and ONE power of two s0 = 2^E0 per batch
+// (from the largest table range of the batch: pqi_query_range_kernel).  The weight goes into the selector operand
+// (A[i][kb][e] = w_i [e == i], negated for inner product), so the matrix instruction delivers Y = w_q * sum_m Qi in units
+// of s0 for every query of a unit, and the filter's fast path is integer: with the accumulator started at -T_q,
+//   pass  <=>  min_i (Y_i - T_i) <= ceil(-psum[v] / s0)                                (pqi_kernel, finish()).
+// Rounding a step up to the lattice costs <= 1 / w_q of eps (w_q >= 64 for the widest query of the batch).
+// qis[q] = {s_q, sum_m mu, eps_base, A}; qis[nq] = {bits of the batch's largest range (atomic max), s0, 1 / s0, -}.
+constexpr float PI_INT_LIM = 536870912.0f; // 2^29: |psum| / s0 stays below it (else: no bound, the exact kernels)
+
+// v[m] = this thread's (centroid c) table entries of query q; smax / smin[m][wave] = their extrema over the wave
 template <bool IS_L2>
-__global__ __launch_bounds__(PF_KSUB) void pqi_query_table_kernel(const float* __restrict__ queries,
-                                                                  const float4* __restrict__ cb_t, int d, float pabs_max,
-                                                                  uint32_t* __restrict__ qi, float* __restrict__ qis) {
-    __shared__ float sq[PF_M * PF_DSUB];
-    __shared__ float smax[PF_M][PF_KSUB / KN_WAVE];
-    __shared__ float smin[PF_M][PF_KSUB / KN_WAVE];
-    __shared__ float smu[PF_M];
-    __shared__ float s_inv;
-    const int64_t q = blockIdx.x;
+__device__ __forceinline__ void pqi_table_values(const float* __restrict__ queries, const float4* __restrict__ cb_t, int d,
+                                                 int64_t q, float* sq, float (*smax)[PF_KSUB / KN_WAVE],
+                                                 float (*smin)[PF_KSUB / KN_WAVE], float (&v)[PF_M]) {
     const int c = threadIdx.x;
     const int wave = c / KN_WAVE;
     if (c < PF_M * PF_DSUB) {
         sq[c] = queries[q * d + c];
     }
     __syncthreads();
-    float v[PF_M];
 #pragma unroll
     for (int m = 0; m < PF_M; m++) {
         const float4 y = cb_t[c * PF_M + m];
@@ -966,7 +966,69 @@ __global__ __launch_bounds__(PF_KSUB) void pqi_query_table_kernel(const float* _
         }
     }
     __syncthreads();
+}
+
+// the power of two s0 with 127 s0 >= (largest range of the batch) / 254
+__device__ __forceinline__ float pqi_base_step(float rmax) {
+    if (!(rmax > 0.f) || !(rmax < INFINITY)) {
+        return 1.0f;
+    }
+    int e;
+    (void)frexpf(rmax / (254.0f * 127.0f), &e); // value = f 2^e, f in [0.5, 1)
+    e = e < -100 ? -100 : e;
+    return ldexpf(1.0f, e);
+}
+
+// pass 1: the batch's largest finite table range -> gl[0] (bits of a non-negative float: integer order = float order)
+template <bool IS_L2>
+__global__ __launch_bounds__(PF_KSUB) void pqi_query_range_kernel(const float* __restrict__ queries,
+                                                                  const float4* __restrict__ cb_t, int d,
+                                                                  uint32_t* __restrict__ gl) {
+    __shared__ float sq[PF_M * PF_DSUB];
+    __shared__ float smax[PF_M][PF_KSUB / KN_WAVE];
+    __shared__ float smin[PF_M][PF_KSUB / KN_WAVE];
+    float v[PF_M];
+    pqi_table_values<IS_L2>(queries, cb_t, d, blockIdx.x, sq, smax, smin, v);
+    if (threadIdx.x == 0) {
+        float R = 0.f;
+        for (int m = 0; m < PF_M; m++) {
+            float hi = smax[m][0], lo = smin[m][0];
+            for (int w = 1; w < PF_KSUB / KN_WAVE; w++) {
+                hi = fmaxf(hi, smax[m][w]);
+                lo = fminf(lo, smin[m][w]);
+            }
+            R = fmaxf(R, hi - lo);
+        }
+        if (R > 0.f && R < INFINITY) {
+            atomicMax(gl, __float_as_uint(R));
+        }
+    }
+}
+
+// pass 2: one workgroup per query, thread = centroid index c.
+// Table layout (bytes): qi[q][c >> 2][m & 15][c & 3][m >> 4]: the 8-byte piece thread t = (c >> 2) * 16 + (m & 15) of the
+// filter kernel reads holds this query's entries of its 8 (c, m) cells.
+template <bool IS_L2>
+__global__ __launch_bounds__(PF_KSUB) void pqi_query_table_kernel(const float* __restrict__ queries,
+                                                                  const float4* __restrict__ cb_t, int d, float pabs_max,
+                                                                  int64_t nq, uint32_t* __restrict__ qi,
+                                                                  float* __restrict__ qis) {
+    __shared__ float sq[PF_M * PF_DSUB];
+    __shared__ float smax[PF_M][PF_KSUB / KN_WAVE];
+    __shared__ float smin[PF_M][PF_KSUB / KN_WAVE];
+    __shared__ float smu[PF_M];
+    __shared__ float s_inv;
+    const int64_t q = blockIdx.x;
+    const int c = threadIdx.x;
+    float v[PF_M];
+    pqi_table_values<IS_L2>(queries, cb_t, d, q, sq, smax, smin, v);
     if (c == 0) {
+        const float s0 = pqi_base_step(__uint_as_float(reinterpret_cast<const uint32_t*>(qis)[nq * 4]));
+        const float inv0 = 1.0f / s0; // (a power of two: exact)
+        if (q == 0) {
+            qis[nq * 4 + 1] = s0;
+            qis[nq * 4 + 2] = inv0;
+        }
         float A = 0.f, R = 0.f, musum = 0.f;
         for (int m = 0; m < PF_M; m++) {
             float hi = smax[m][0], lo = smin[m][0];
@@ -980,12 +1042,11 @@ __global__ __launch_bounds__(PF_KSUB) void pqi_query_table_kernel(const float* _
             A += fmaxf(fabsf(hi), fabsf(lo));
             R = fmaxf(R, hi - lo);
         }
-        float step = 1.0f, eps = INFINITY;
-        if (A < INFINITY && R < INFINITY) {
-            step = R > 0.f ? R / 254.0f : 1.0f;
-            if (!(step > 1e-30f)) {
-                step = 1e-30f; // (keeps 1 / step finite; the clamp below holds whatever the step)
-            }
+        float step = s0, eps = INFINITY;
+        if (A < INFINITY && R < INFINITY && pabs_max * inv0 < PI_INT_LIM) {
+            // the smallest lattice step >= R / 254 (w = 1 for a constant table; R <= the batch's largest range => w <= 127)
+            const float w = fminf(fmaxf(ceilf((R / 254.0f) * inv0), 1.0f), 127.0f);
+            step = w * s0;
             eps = 16.4f * step + 128.0f * PF_U * (pabs_max + A) + 64.0f * PF_U * fabsf(musum);
         }
         s_inv = 1.0f / step;
@@ -1014,17 +1075,25 @@ __global__ __launch_bounds__(PF_KSUB) void pqi_query_table_kernel(const float* _
     }
 }
 
+// qis: nq * 4 + 4 floats (the batch record behind the per-query records)
 hipError_t launch_pqi_query_table(const float* queries, const float4* cb_t, int d, int64_t nq, bool is_l2, float pabs_max,
                                   void* qi, float* qis, hipStream_t s) {
     if (nq <= 0) {
         return hipSuccess;
     }
+    hipError_t e = hipMemsetAsync(qis + nq * 4, 0, 4 * sizeof(float), s);
+    if (e != hipSuccess) {
+        return e;
+    }
+    uint32_t* gl = reinterpret_cast<uint32_t*>(qis + nq * 4);
     if (is_l2) {
+        hipLaunchKernelGGL(pqi_query_range_kernel<true>, dim3((unsigned)nq), dim3(PF_KSUB), 0, s, queries, cb_t, d, gl);
         hipLaunchKernelGGL(pqi_query_table_kernel<true>, dim3((unsigned)nq), dim3(PF_KSUB), 0, s, queries, cb_t, d,
-                           pabs_max, static_cast<uint32_t*>(qi), qis);
+                           pabs_max, nq, static_cast<uint32_t*>(qi), qis);
     } else {
+        hipLaunchKernelGGL(pqi_query_range_kernel<false>, dim3((unsigned)nq), dim3(PF_KSUB), 0, s, queries, cb_t, d, gl);
         hipLaunchKernelGGL(pqi_query_table_kernel<false>, dim3((unsigned)nq), dim3(PF_KSUB), 0, s, queries, cb_t, d,
-                           pabs_max, static_cast<uint32_t*>(qi), qis);
+                           pabs_max, nq, static_cast<uint32_t*>(qi), qis);
     }
     return hipGetLastError();
 }
@@ -1054,8 +1123,125 @@ __global__ void pqi_prepare_kernel(MScanArgs a, int64_t nrec) {
     a.pq_recs16[r] = rec;
 }
 
-// The filter kernel of the integer form.  Same persistent structure as pqf_kernel (two-deep mailbox, the next unit's
-// table pieces in flight during the scan); no sample mode (the sample pass stays in half precision).
+// Integer form: a hit inside the scan loop only parks the lane's raw accumulators (32-byte record, one LDS atomic per
+// wave); the fp32 re-test, the pessimistic distance and the global side happen here, spread over all 16 waves, at the
+// START of the next unit -- behind that unit's table loads, whose latency covers the atomics' round trips.
+constexpr int PI_STAGE_CAP = PF_STAGE_CAP / 2; // records of 32 bytes: {x[4], psum, position, first query of the lane}
+constexpr int PI_PC_OFF = 576;                 // control block: per-pair constants [parity][16][4], then {query, slot}
+constexpr int PI_PC_STRIDE = 384;              // 256 bytes of constants + 128 bytes of (query, slot) per parity
+static_assert(PI_PC_OFF + 2 * PI_PC_STRIDE <= PF_CTL_BYTES, "control block layout");
+
+template <bool IS_L2>
+__device__ __forceinline__ void pqi_emit_raw(const MScanArgs& a, const float* pcp, const int* pqsp, const int (&x)[4],
+                                             float ps, int64_t pos, int qb, float s0, float inv0, int64_t row_off) {
+    const int negp = IS_L2 ? (int)ceilf(-ps * inv0) : 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        if (x[r] <= negp) {
+            // the fp32 test of the half-precision form, bit for bit: s_q S = s0 Y (both products are exact)
+            const int j = qb + r;
+            const int T = __float_as_int(pcp[j * 4 + 3]);
+            const int y = IS_L2 ? x[r] + T : -(x[r] + T);
+            const float f = (float)y;
+            const float v = __fmaf_rn(f, s0, IS_L2 ? ps : 0.f);
+            const float th = pcp[j * 4];
+            if (IS_L2 ? (v <= th) : (v >= th)) {
+                const float pcs = pcp[j * 4 + 2];
+                const float pess = IS_L2 ? __fmaf_rn(f, s0, pcs + ps) : __fmaf_rn(f, s0, pcs);
+                ms_emit<IS_L2>(a, pqsp[j * 2], pqsp[j * 2 + 1], row_off, pos, pess);
+            }
+        }
+    }
+}
+
+// One parked record per thread (PI_STAGE_CAP < PF_THREADS), in two halves: pqi_flush_issue re-tests the record and issues
+// the returning atomics on the queries' candidate counters (+ the loads of their histogram origins); pqi_flush_complete
+// stores the candidates once those are back.  In between the caller does everything else a unit's start needs, so the
+// round trips overlap.  Together they are ms_emit (ms_common.h) of every hit of the record.
+struct PiFlush { // the first hit of the thread's record (further hits of a record are rare: written out at once)
+    int has;
+    int32_t q, slot, n;
+    float pess;
+    uint2 mt;
+    uint32_t pos;
+};
+
+template <bool IS_L2>
+__device__ __forceinline__ void pqi_flush_issue(const MScanArgs& a, unsigned char* smem, int pp, int64_t row_off, float s0,
+                                                float inv0, int wave, int lane, PiFlush& fl) {
+    static_assert(PI_STAGE_CAP <= PF_THREADS, "one parked record per thread");
+    fl.has = 0;
+    const int* cnt = reinterpret_cast<const int*>(smem + PF_LUT_BYTES + PF_CTL_BYTES + PF_STAGE_CAP * 16);
+    const int n = min(cnt[pp], PI_STAGE_CAP);
+    const int i = wave + PF_WAVES * lane; // (record i -> wave i % 16: every wave takes a share)
+    if (i >= n) {
+        return;
+    }
+    const float* pcp = reinterpret_cast<const float*>(smem + PF_LUT_BYTES + PI_PC_OFF + pp * PI_PC_STRIDE);
+    const int* pqsp = reinterpret_cast<const int*>(pcp + 64);
+    const uint4 r0 = *reinterpret_cast<const uint4*>(smem + PF_LUT_BYTES + PF_CTL_BYTES + i * 32);
+    const uint4 r1 = *reinterpret_cast<const uint4*>(smem + PF_LUT_BYTES + PF_CTL_BYTES + i * 32 + 16);
+    const int x[4] = {(int)r0.x, (int)r0.y, (int)r0.z, (int)r0.w};
+    const float ps = __uint_as_float(r1.x);
+    const int qb = (int)r1.z;
+    fl.pos = r1.y;
+    const int negp = IS_L2 ? (int)ceilf(-ps * inv0) : 0;
+    if (a.bitset != nullptr && bitset_filtered(a.bitset, a.bitset_nbits, a.ids[row_off + (int64_t)fl.pos])) {
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        if (x[r] <= negp) {
+            const int j = qb + r;
+            const int T = __float_as_int(pcp[j * 4 + 3]);
+            const int y = IS_L2 ? x[r] + T : -(x[r] + T);
+            const float f = (float)y;
+            const float v = __fmaf_rn(f, s0, IS_L2 ? ps : 0.f);
+            const float th = pcp[j * 4];
+            if (IS_L2 ? (v <= th) : (v >= th)) {
+                const float pcs = pcp[j * 4 + 2];
+                const float pess = IS_L2 ? __fmaf_rn(f, s0, pcs + ps) : __fmaf_rn(f, s0, pcs);
+                const int32_t q = pqsp[j * 2], slot = pqsp[j * 2 + 1];
+                if (!fl.has) {
+                    fl.has = 1;
+                    fl.q = q;
+                    fl.slot = slot;
+                    fl.pess = pess;
+                    fl.n = atomicAdd(a.cand_cnt + q, 1);
+                    fl.mt = a.ghist != nullptr ? a.gmeta[q] : make_uint2(0u, KN_HIST_OFF);
+                } else {
+                    MScanArgs b = a;
+                    b.bitset = nullptr; // (tested above)
+                    ms_emit<IS_L2>(b, q, slot, row_off, (int64_t)fl.pos, pess);
+                }
+            }
+        }
+    }
+}
+
+template <bool IS_L2>
+__device__ __forceinline__ void pqi_flush_complete(const MScanArgs& a, const PiFlush& fl) {
+    if (!fl.has) {
+        return;
+    }
+    const int32_t q = fl.q;
+    if (fl.n < a.cap) {
+        a.cand[(int64_t)q * a.cap + fl.n] = ((int64_t)fl.slot << 32) | (int64_t)fl.pos;
+        if (a.cand_pess != nullptr) {
+            a.cand_pess[(int64_t)q * a.cap + fl.n] = fl.pess;
+        }
+    } else {
+        a.overflow[q] = 1;
+        a.overflow[a.nq] = 1;
+    }
+    if (fl.mt.y != KN_HIST_OFF) {
+        atomicAdd(a.ghist + (int64_t)q * KN_HIST_BINS + hist_bin(dist_key<IS_L2>(fl.pess), fl.mt.x, fl.mt.y), 1u);
+    }
+}
+
+// The filter kernel of the integer form.  Same persistent structure as pqf_kernel (two-deep mailbox); the unit's table
+// pieces are fetched at its start (L2 hits) so that the scan keeps eight gathers per wave in flight; no sample mode
+// (the sample pass stays in half precision).
 template <bool IS_L2>
 __global__ __launch_bounds__(PF_THREADS) void pqi_kernel(MScanArgs a) {
 #ifdef KNHIP_PHASE_TIMERS
@@ -1069,11 +1255,12 @@ __global__ __launch_bounds__(PF_THREADS) void pqi_kernel(MScanArgs a) {
                   offsetof(P16Rec, dis0) == 136 && offsetof(P16Rec, len) == 200 && offsetof(P16Rec, sblk0) == 208 &&
                   offsetof(P16Rec, row_off) == 216, "P16Rec layout");
     // behind the LUT: ints [0], [1] unit index of mailbox slot 0 / 1, [8 + 64 s ..) the record of slot s;
-    // bytes 576..831 per-pair constants [16][4] = {t, step, pess const, -}; bytes 832..959 [16][2] = {query, slot}
+    // from byte PI_PC_OFF, per unit parity: per-pair constants [16][4] = {t, step, pess const, bits of the integer
+    // threshold T}, then [16][2] = {query, slot} (the previous unit's are read by its flush while this unit's are written)
     int* ctl = reinterpret_cast<int*>(smem + PF_LUT_BYTES);
-    float* pc = reinterpret_cast<float*>(smem + PF_LUT_BYTES + 576);
-    int* pqs = reinterpret_cast<int*>(smem + PF_LUT_BYTES + 832);
-    static_assert(8 * 4 + 2 * REC_WORDS * 4 <= 576 && 832 + PI_Q * 8 <= PF_CTL_BYTES, "control block layout");
+    static_assert(8 * 4 + 2 * REC_WORDS * 4 <= PI_PC_OFF, "control block layout");
+    const float s0 = pf_sgpr_f(a.pq_qis[(int64_t)a.nq * 4 + 1]); // the batch's base step (a power of two) and 1 / s0
+    const float inv0 = pf_sgpr_f(a.pq_qis[(int64_t)a.nq * 4 + 2]);
     const int lane = lane_id();
     const int wave = pf_sgpr((int)(threadIdx.x / KN_WAVE));
     if ((uint32_t)(size_t)((__attribute__((address_space(3))) unsigned char*)smem) != 0u) {
@@ -1136,14 +1323,8 @@ __global__ __launch_bounds__(PF_THREADS) void pqi_kernel(MScanArgs a) {
             t[j] = qi2[q * (PF_KSUB * PF_M / 8) + (wave * KN_WAVE + lane_i)];
         }
     };
-    uint2 tp[PI_Q];
-#pragma unroll
-    for (int j = 0; j < PI_Q; j++) {
-        tp[j] = make_uint2(0, 0);
-    }
-    if (cur >= 0) {
-        load_tables(0, tp, lane);
-    }
+
+    int64_t prev_row_off = -1; // row offset of the unit whose parked hits are still to be written out
 
     while (cur >= 0) {
         PF_T(5);
@@ -1161,6 +1342,11 @@ __global__ __launch_bounds__(PF_THREADS) void pqi_kernel(MScanArgs a) {
         const int64_t len = (int64_t)(((uint64_t)rl(51) << 32) | rl(50));
         const int64_t sblk0 = (int64_t)(((uint64_t)rl(53) << 32) | rl(52));
         const int64_t row_off = (int64_t)(((uint64_t)rl(55) << 32) | rl(54));
+        // (the registers hold four value buffers in the scan, not the next unit's tables: round 3 experiments)
+        uint2 tp[PI_Q];
+        load_tables(par, tp, lane_i);
+        float* pc = reinterpret_cast<float*>(smem + PF_LUT_BYTES + PI_PC_OFF + par * PI_PC_STRIDE);
+        int* pqs = reinterpret_cast<int*>(pc + 64);
         // this wave's groups of 16 vectors (one code block each)
         const int ngroups = (int)((len + 15) / 16);
         const int gbase = ngroups / PF_WAVES, grem = ngroups % PF_WAVES;
@@ -1177,21 +1363,35 @@ __global__ __launch_bounds__(PF_THREADS) void pqi_kernel(MScanArgs a) {
             U2 = load_blk(2);
             U3 = load_blk(3);
         }
-        // ---- per-pair constants: wave j prepares pair j -----------------------------------------------------------
-        {
-            int32_t q = (int32_t)rl(2), slot = (int32_t)rl(18);
-            float dis0 = __uint_as_float(rl(34));
+        // ---- everything this unit's start waits for is issued first: table pieces and code blocks (above), the pair's
+        // constants, the atomics of the previous unit's parked hits -- one round trip instead of five in a row
+        int32_t pq_q = (int32_t)rl(2), pq_slot = (int32_t)rl(18);
+        float pq_dis0 = __uint_as_float(rl(34)); // wave j prepares pair j
 #pragma unroll
-            for (int j = 1; j < PI_Q; j++) {
-                q = wave == j ? (int32_t)rl(2 + j) : q;
-                slot = wave == j ? (int32_t)rl(18 + j) : slot;
-                dis0 = wave == j ? __uint_as_float(rl(34 + j)) : dis0;
-            }
-            const float4 s4 = *reinterpret_cast<const float4*>(a.pq_qis + (int64_t)q * 4);
+        for (int j = 1; j < PI_Q; j++) {
+            pq_q = wave == j ? (int32_t)rl(2 + j) : pq_q;
+            pq_slot = wave == j ? (int32_t)rl(18 + j) : pq_slot;
+            pq_dis0 = wave == j ? __uint_as_float(rl(34 + j)) : pq_dis0;
+        }
+        int32_t pq_qv = pq_q; // (in a vector register: the loads below stay vector loads whose results nobody reads early)
+        asm volatile("" : "+v"(pq_qv));
+        const float4 s4 = *reinterpret_cast<const float4*>(a.pq_qis + (int64_t)pq_qv * 4);
+        float tau_g = a.gthr[pq_qv];
+        MsHist hst;
+        ms_hist_load(a, pq_qv, hst);
+        PiFlush fl;
+        fl.has = 0;
+        if (prev_row_off >= 0) {
+            pqi_flush_issue<IS_L2>(a, smem, par ^ 1, prev_row_off, s0, inv0, wave, lane_i, fl);
+        }
+        asm volatile("" : "+v"(tau_g)::"memory"); // (the loaded constants are looked at below this line)
+        // ---- per-pair constants -------------------------------------------------------------------------------------
+        {
+            const int32_t q = pq_q, slot = pq_slot;
+            const float dis0 = pq_dis0;
             float t = IS_L2 ? -INFINITY : INFINITY, pcst = 0.f; // pass-nothing defaults
             if (wave < npair) {
-                float tau = a.gthr[q];
-                tau = tighter<IS_L2>(tau, ms_hist_bound<IS_L2>(a, q, a.k));
+                const float tau = tighter<IS_L2>(tau_g, ms_hist_eval<IS_L2>(hst, a.k));
                 const float eps = s4.z + 64.0f * PF_U * (fabsf(dis0) + fabsf(tau) + fabsf(s4.y));
                 if (tau == worst_dist<IS_L2>() || !(eps < INFINITY)) {
                     if (lane_i == 0) {
@@ -1203,8 +1403,17 @@ __global__ __launch_bounds__(PF_THREADS) void pqi_kernel(MScanArgs a) {
                     pcst = IS_L2 ? (dis0 + s4.y) + eps : (dis0 + s4.y) - eps;
                 }
             }
+            // integer threshold in units of s0: whatever passes `ps + s Y <= t` (L2; IP: `s Y >= t`) in fp32 also
+            // satisfies Y + floor(ps / s0) <= T (IP: -Y <= T): 2^-22 |t| covers the one rounding of the fp32 form
+            int T;
+            {
+                const float tt = IS_L2 ? t : -t;
+                float x = floorf((tt + 2.384185791015625e-7f * fabsf(tt)) * inv0) + 2.0f;
+                x = fminf(fmaxf(x, -2.0f * PI_INT_LIM), 2.0f * PI_INT_LIM); // (NaN -> the lower clamp: nothing passes)
+                T = (int)x;
+            }
             if (lane_i == 0) {
-                *reinterpret_cast<float4*>(pc + wave * 4) = make_float4(t, s4.x, pcst, 0.f);
+                *reinterpret_cast<float4*>(pc + wave * 4) = make_float4(t, s4.x, pcst, __int_as_float(T));
                 pqs[wave * 2] = q;
                 pqs[wave * 2 + 1] = slot;
             }
@@ -1242,6 +1451,7 @@ __global__ __launch_bounds__(PF_THREADS) void pqi_kernel(MScanArgs a) {
                 }
             }
         }
+        pqi_flush_complete<IS_L2>(a, fl);
         PF_T(0);
         __syncthreads();
         PF_T(1);
@@ -1268,30 +1478,23 @@ __global__ __launch_bounds__(PF_THREADS) void pqi_kernel(MScanArgs a) {
                 rw_next = reinterpret_cast<const uint32_t*>(a.pq_recs16 + nxt)[lane_i];
             }
         }
-        uint2 tpn[PI_Q];
-#pragma unroll
-        for (int j = 0; j < PI_Q; j++) {
-            tpn[j] = make_uint2(0, 0);
-        }
-        if (nxt_unit >= 0) {
-            load_tables(par ^ 1, tpn, lane_i);
-        }
         // this lane's 4 accumulator rows are the queries 4 (lane >> 4) + r of vector lane & 15
         const int qb = 4 * (lane_i >> 4);
-        float thr[4], stp[4];
+        pf_i4 negT; // every group's accumulator starts at -T of the lane's four queries
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const float4 c4v = *reinterpret_cast<const float4*>(pc + (qb + r) * 4);
-            thr[r] = c4v.x;
-            stp[r] = c4v.y;
+            negT[r] = -__float_as_int(pc[(qb + r) * 4 + 3]);
         }
-        // selector: row i = lane & 15 takes byte i of every k block
+        // selector: row i = lane & 15 takes byte i of every k block, times the query's step weight (negated for IP:
+        // the accumulator then holds -Y and "small is good" holds for both metrics)
         pf_i4 sel;
         {
             const int i = lane_i & 15;
+            const int wq = (int)rintf(pc[i * 4 + 1] * inv0); // s_q / s0: an integer 1 .. 127 by construction
+            const uint32_t wb = (uint32_t)(IS_L2 ? wq : -wq) & 0xffu;
 #pragma unroll
             for (int w = 0; w < 4; w++) {
-                sel[w] = (i >> 2) == w ? (int)(1u << (8 * (i & 3))) : 0;
+                sel[w] = (i >> 2) == w ? (int)(wb << (8 * (i & 3))) : 0;
             }
         }
         typedef __attribute__((address_space(3))) const pf_i4 lds_i4;
@@ -1302,12 +1505,17 @@ __global__ __launch_bounds__(PF_THREADS) void pqi_kernel(MScanArgs a) {
         };
         PF_T(2);
         if (nwin > 0) {
-            const pf_i4 iz = {0, 0, 0, 0};
-            pf_i4 B0[2], B1[2];
-            uint4 W0 = U0; // block 4 i at the top of iteration i (its first two words are in flight)
-            issue2(W0.x, B0);
+            pf_i4 B0[2], B1[2], B2[2], B3[2];
+            uint4 W0 = U0;
+            issue2(W0.x, B0); // (in this order: the loop's first unit waits for the oldest two reads only)
+            __builtin_amdgcn_sched_barrier(0);
             issue2(W0.y, B1);
-            pf_i4 e0 = iz, e1 = iz, o0 = iz, o1 = iz; // even / odd windows, even / odd steps
+            __builtin_amdgcn_sched_barrier(0);
+            issue2(W0.z, B2);
+            __builtin_amdgcn_sched_barrier(0);
+            issue2(W0.w, B3);
+            __builtin_amdgcn_sched_barrier(0);
+            pf_i4 e0 = negT, o0 = negT; // even / odd windows: one accumulator chain each, started at -T
             const int vec = lane_i & 15;
             float ps_cur[4] = {0.f, 0.f, 0.f, 0.f}, ps_prev = 0.f;
             if (IS_L2) {
@@ -1317,36 +1525,41 @@ __global__ __launch_bounds__(PF_THREADS) void pqi_kernel(MScanArgs a) {
                 }
             }
 
-#define PI_UNIT(A0, A1, C0, C1, BUF, WORD)                                                  \
+#define PI_UNIT(ACC, CIN, BUF, WORD)                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                      \
-    A0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(sel, BUF[0], C0, 0, 0, 0);                    \
-    A1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(sel, BUF[1], C1, 0, 0, 0);                    \
+    ACC = __builtin_amdgcn_mfma_i32_16x16x64_i8(sel, BUF[0], CIN, 0, 0, 0);                  \
+    ACC = __builtin_amdgcn_mfma_i32_16x16x64_i8(sel, BUF[1], ACC, 0, 0, 0);                  \
     __builtin_amdgcn_sched_barrier(0);                                                      \
     issue2(WORD, BUF);
 
-            auto finish = [&](const pf_i4& x0, const pf_i4& x1, int G, float ps) {
-                const float f[4] = {(float)(x0[0] + x1[0]), (float)(x0[1] + x1[1]), (float)(x0[2] + x1[2]),
-                                    (float)(x0[3] + x1[3])};
-                // fast path: 4 (add, convert, fma, compare) per lane, the lane masks OR-ed on the scalar unit; whether the
-                // row exists at all is only looked at when something passed
-                unsigned long long mk[4];
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    // L2: ps + s S <= t;  IP: s S >= t   (t = -inf / +inf: nothing passes)
-                    const float v = __fmaf_rn(f[r], stp[r], IS_L2 ? ps : 0.f);
-                    mk[r] = __ballot(IS_L2 ? (v <= thr[r]) : (v >= thr[r]));
-                }
-                if (__builtin_expect((mk[0] | mk[1] | mk[2] | mk[3]) != 0ull, 0)) { // (out of line: the hot path falls through)
+            auto finish = [&](const pf_i4& x, int G, float ps) {
+#ifdef KNHIP_EXPERIMENT_NOFINISH
+                asm volatile("" ::"v"(x), "v"(ps));
+                return;
+#endif
+                // fast path, integer: x[r] = (+-)Y_r - T_r in units of s0; something passes iff the smallest of the lane's
+                // four is <= ceil(-ps / s0) (a superset of the fp32 test below: see the per-pair constants).  Whether the
+                // row exists at all is only looked at when something passed.
+                const int negp = IS_L2 ? (int)ceilf(-ps * inv0) : 0;
+                const int mn = min(min(x[0], x[1]), min(x[2], x[3]));
+                if (__builtin_expect(__ballot(mn <= negp) != 0ull, 0)) { // (out of line: the hot path falls through)
+#ifdef KNHIP_EXPERIMENT_NOSLOW
+                    asm volatile("s_nop 0");
+                    return;
+#endif
                     const int64_t pos = (int64_t)G * 16 + vec;
-                    if (G < G1 && pos < len) {
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            if ((mk[r] >> lane_i) & 1ull) {
-                                const int j = qb + r;
-                                const float pcs = pc[j * 4 + 2];
-                                const float pess = IS_L2 ? __fmaf_rn(f[r], stp[r], pcs + ps) : __fmaf_rn(f[r], stp[r], pcs);
-                                pf_stage_emit<IS_L2>(a, smem, par, pqs[j * 2], pqs[j * 2 + 1], row_off, pos, pess);
-                            }
+                    if (G < G1 && mn <= negp && pos < len) {
+                        int* cnt = reinterpret_cast<int*>(smem + PF_LUT_BYTES + PF_CTL_BYTES + PF_STAGE_CAP * 16);
+                        const int n = atomicAdd(cnt + par, 1); // (one LDS atomic per wave: the compiler aggregates)
+                        if (n < PI_STAGE_CAP) {
+                            unsigned char* rec = smem + PF_LUT_BYTES + PF_CTL_BYTES + n * 32;
+                            *reinterpret_cast<uint4*>(rec) = make_uint4((uint32_t)x[0], (uint32_t)x[1], (uint32_t)x[2],
+                                                                        (uint32_t)x[3]);
+                            *reinterpret_cast<uint4*>(rec + 16) = make_uint4(__float_as_uint(ps), (uint32_t)pos,
+                                                                             (uint32_t)qb, 0u);
+                        } else { // (staging full: straight to the candidate list)
+                            const int xs[4] = {x[0], x[1], x[2], x[3]};
+                            pqi_emit_raw<IS_L2>(a, pc, pqs, xs, ps, pos, qb, s0, inv0, row_off);
                         }
                     }
                 }
@@ -1362,40 +1575,37 @@ __global__ __launch_bounds__(PF_THREADS) void pqi_kernel(MScanArgs a) {
                         ps_cur[u] = psb[(int64_t)(4 * i + 4 + u) * 16]; // (the slack groups behind a list exist)
                     }
                 }
-                // window 4 i (block W0)
-                PI_UNIT(e0, e1, iz, iz, B0, W0.z)
-                PI_UNIT(e0, e1, e0, e1, B1, W0.w)
-                if (i > 0) { // (window 4 i - 1: its last matrix instructions have retired by now)
-                    finish(o0, o1, G0 + 4 * i - 1, ps_prev);
+                // four value buffers: a read is consumed four units (eight steps) after it was issued
+                PI_UNIT(e0, negT, B0, U1.x)
+                PI_UNIT(e0, e0, B1, U1.y)
+                if (i > 0) {
+                    finish(o0, G0 + 4 * i - 1, ps_prev);
                 }
-                PI_UNIT(e0, e1, e0, e1, B0, U1.x)
-                PI_UNIT(e0, e1, e0, e1, B1, U1.y)
+                PI_UNIT(e0, e0, B2, U1.z)
+                PI_UNIT(e0, e0, B3, U1.w)
                 W0 = load_blk(4 * i + 4);
-                // window 4 i + 1 (block U1)
-                PI_UNIT(o0, o1, iz, iz, B0, U1.z)
-                PI_UNIT(o0, o1, o0, o1, B1, U1.w)
-                finish(e0, e1, G0 + 4 * i, ps0);
-                PI_UNIT(o0, o1, o0, o1, B0, U2.x)
-                PI_UNIT(o0, o1, o0, o1, B1, U2.y)
+                PI_UNIT(o0, negT, B0, U2.x)
+                PI_UNIT(o0, o0, B1, U2.y)
+                finish(e0, G0 + 4 * i, ps0);
+                PI_UNIT(o0, o0, B2, U2.z)
+                PI_UNIT(o0, o0, B3, U2.w)
                 U1 = load_blk(4 * i + 5);
-                // window 4 i + 2 (block U2)
-                PI_UNIT(e0, e1, iz, iz, B0, U2.z)
-                PI_UNIT(e0, e1, e0, e1, B1, U2.w)
-                finish(o0, o1, G0 + 4 * i + 1, ps1);
-                PI_UNIT(e0, e1, e0, e1, B0, U3.x)
-                PI_UNIT(e0, e1, e0, e1, B1, U3.y)
+                PI_UNIT(e0, negT, B0, U3.x)
+                PI_UNIT(e0, e0, B1, U3.y)
+                finish(o0, G0 + 4 * i + 1, ps1);
+                PI_UNIT(e0, e0, B2, U3.z)
+                PI_UNIT(e0, e0, B3, U3.w)
                 U2 = load_blk(4 * i + 6);
-                // window 4 i + 3 (block U3)
-                PI_UNIT(o0, o1, iz, iz, B0, U3.z)
-                PI_UNIT(o0, o1, o0, o1, B1, U3.w)
-                finish(e0, e1, G0 + 4 * i + 2, ps2);
-                PI_UNIT(o0, o1, o0, o1, B0, W0.x)
-                PI_UNIT(o0, o1, o0, o1, B1, W0.y)
+                PI_UNIT(o0, negT, B0, W0.x)
+                PI_UNIT(o0, o0, B1, W0.y)
+                finish(e0, G0 + 4 * i + 2, ps2);
+                PI_UNIT(o0, o0, B2, W0.z)
+                PI_UNIT(o0, o0, B3, W0.w)
                 U3 = load_blk(4 * i + 7);
                 __builtin_amdgcn_sched_barrier(0);
                 ps_prev = ps3;
             }
-            finish(o0, o1, G0 + 4 * niter - 1, ps_prev);
+            finish(o0, G0 + 4 * niter - 1, ps_prev);
 #undef PI_UNIT
             __builtin_amdgcn_s_setprio(0);
         }
@@ -1409,14 +1619,15 @@ __global__ __launch_bounds__(PF_THREADS) void pqi_kernel(MScanArgs a) {
         }
         __syncthreads();
         PF_T(4);
-        pf_stage_flush<IS_L2>(a, smem, par, row_off);
         PF_COUNT(7, 1);
+        prev_row_off = row_off; // (its parked hits go out at the start of the next unit, or below)
         cur = nxt_unit;
         par ^= 1;
-#pragma unroll
-        for (int j = 0; j < PI_Q; j++) {
-            tp[j] = tpn[j];
-        }
+    }
+    if (prev_row_off >= 0) { // the last unit's parked hits
+        PiFlush fl;
+        pqi_flush_issue<IS_L2>(a, smem, par ^ 1, prev_row_off, s0, inv0, wave, lane, fl);
+        pqi_flush_complete<IS_L2>(a, fl);
     }
 #ifdef KNHIP_PHASE_TIMERS
     if (lane == 0) {

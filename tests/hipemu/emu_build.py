@@ -46,6 +46,8 @@ def patch_pq_filter(s):
     s = _sub(s, r'    asm volatile\("s_getreg_b32 %0, hwreg\(HW_REG_XCC_ID\)" : "=s"\(xcc\)\);\n',
              "    xcc = (uint32_t)blockIdx.x;\n", 2, what="xcc id")
     s = _sub(s, r'        asm volatile\("" : "\+v"\(lane_i\)\);[^\n]*\n', "", 2, what="lane launder")
+    s = _sub(s, r'        asm volatile\("" : "\+v"\(tau_g\)[^\n]*\n', "", 1, what="load-order fence")
+    s = _sub(s, r'        asm volatile\("" : "\+v"\(pq_qv\)\);\n', "", 1, what="query index launder")
     return s
 
 
