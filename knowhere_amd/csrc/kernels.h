@@ -271,7 +271,7 @@ hipError_t launch_pq_stream16r(const uint8_t* codes, const int64_t* list_row_off
 hipError_t launch_pq_psum(const uint8_t* codes, const int64_t* list_row_off, const int64_t* list_len,
                           const int64_t* list_sblk_off, int64_t nlist, const float* precomp_t, float* psum,
                           uint32_t* pabs_max_bits, hipStream_t s);
-hipError_t launch_pqf_query_table(const float* queries, const float4* cb_t, int d, int64_t nq, bool is_l2, float pabs_max,
+hipError_t launch_pqf_query_table(const float* queries, const float4* cb_m, int d, int64_t nq, bool is_l2, float pabs_max,
                                   void* qh, float* qs, hipStream_t s);
 // selectivity guard: *poor = queries whose predicted candidate count exceeds half the capacity
 hipError_t launch_pqf_predict(const float* dump, int64_t stride, const int32_t* n_row, const float* gthr, const float* qs,
@@ -281,8 +281,13 @@ size_t pqf_smem();
 // integer form: 16 queries per unit, int8 tables, v_mfma_i32_16x16x64_i8
 hipError_t launch_pq_stream16i(const uint8_t* codes, const int64_t* list_row_off, const int64_t* list_len,
                                const int64_t* list_sblk_off, int64_t nlist, uint4* out, hipStream_t s);
-hipError_t launch_pqi_query_table(const float* queries, const float4* cb_t, int d, int64_t nq, bool is_l2, float pabs_max,
-                                  void* qi, float* qis, hipStream_t s);
+// cb_m: the codebook in FAISS order [m][256][4]; qis: nq * 4 + 4 floats; qmu: nq * 32 floats of scratch
+hipError_t launch_pqi_query_table(const float* queries, const float4* cb_m, int d, int64_t nq, bool is_l2, float pabs_max,
+                                  void* qi, float* qis, float* qmu, bool stats_done, hipStream_t s);
+// the sample pass of the IVF-PQ prefilter, one workgroup per query (no units, no work table): dump + n_row, the half
+// form's qs records, and (qis / qmu non-null) pass 1 of the integer form
+hipError_t launch_pq_sample(const MScanArgs& a, const int64_t* keys, const float4* cb_m, int64_t nlist, int smin,
+                            float pabs_max, bool is_l2, int32_t* n_row, float* qs, float* qis, float* qmu, hipStream_t s);
 hipError_t launch_pqi(const MScanArgs& a, bool is_l2, int64_t units_bound, hipStream_t s);
 
 bool pqf_supports(int M, int d);

@@ -125,7 +125,7 @@ struct Workspace {
     DevBuf gmeta;        // [qb] {first-bin key, shift}
     DevBuf list_count, list_pair_off, list_item_off, list_cursor, pairs, items, nitems;
     // MFMA prefilter of the IVF-Flat / IVF-SQ8 scans (mfma_scan.hip)
-    DevBuf ms_qi, ms_qis, pq_recs16;                                 // integer form: tables, {step, mu sum, eps, A}, records
+    DevBuf ms_qi, ms_qis, ms_qmu, pq_recs16;                                 // integer form: tables, {step, mu sum, eps, A}, records
     DevBuf rs_ovf;                                                    // coarse stage: rows the two-pass selection left to the radix select
     DevBuf ms_cand_pess;                                             // [qb][cap] pessimistic distances of the candidates (IVF-PQ)
     DevBuf ms_units, ms_unit_off, ms_nunits, ms_cand, ms_cand_cnt;  // ms_cand_cnt: [qb] counters + [qb + 1] overflow flags
@@ -814,7 +814,10 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
     HIP_TRY(ws->partial_i.reserve((size_t)npairs * k * sizeof(int64_t)));
     wt.empty_mark = ws->partial_i.as<int64_t>();
     wt.k = k;
-    {
+    // The IVF-PQ prefilter samples per query (pq_filter.hip, pq_sample_kernel) and groups all probes of a list together
+    // afterwards: it needs this table -- split by the sample plan -- only when its guard abandons the batch.
+    const bool wt1_lazy = use_ms && kind == KNHIP_IVF_PQ;
+    auto build_wt1 = [&]() -> int {
         StageTimer t(idx, s, KNHIP_STAGE_GROUP);
         const int32_t* cls = nullptr;
         if (use_ms) {
@@ -829,6 +832,10 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         }
         HIP_TRY(launch_build_worktable(keys_p, nq, nprobe, nlist, qg_rank0, qg_bulk,
                                        idx->d_list_len.as<int64_t>(), idx->code_size, wt, s, 0, cls));
+        return KNHIP_OK;
+    };
+    if (!wt1_lazy) {
+        if (int rc = build_wt1()) return rc;
     }
     {
         std::lock_guard<std::mutex> lk(idx->mu);
@@ -931,14 +938,17 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             // phase 1: tau_q from a sample of the closest list (units of the rank-0 virtual lists [0, nlist), DUMP mode)
             StageTimer t(idx, s, KNHIP_STAGE_SCAN_RANK0);
             HIP_TRY(hipMemsetAsync(cand_cnt, 0, (size_t)(2 * nq + 1) * sizeof(int32_t), s));
+            const bool want_i8 = kind == KNHIP_IVF_PQ && idx->pqf_form != 1;
             if (kind == KNHIP_IVF_PQ) {
-                // the queries' half tables + scales (one pass over the codebook per query)
-                HIP_TRY(ws->ms_qh.reserve((size_t)nq * 256 * 32 * 2));
+                // (the sample pass below computes the queries' table statistics; the tables themselves follow the guard)
                 HIP_TRY(ws->ms_qs.reserve((size_t)nq * 4 * sizeof(float)));
-                HIP_TRY(launch_pqf_query_table(d_q, idx->cb_t.as<float4>(), d, nq, is_l2, idx->pabs_max, ws->ms_qh.p,
-                                               ws->ms_qs.as<float>(), s));
-                m.pq_qh = ws->ms_qh.p;
+                HIP_TRY(ws->ms_nrow.reserve((size_t)nq * sizeof(int32_t)));
                 m.pq_qs = ws->ms_qs.as<float>();
+                if (want_i8) {
+                    HIP_TRY(ws->ms_qi.reserve((size_t)nq * 256 * 32));
+                    HIP_TRY(ws->ms_qis.reserve(((size_t)nq * 4 + 4) * sizeof(float))); // (+ the batch record)
+                    HIP_TRY(ws->ms_qmu.reserve((size_t)nq * 32 * sizeof(float)));
+                }
             } else if (kind == KNHIP_IVF_FLAT) {
                 HIP_TRY(ws->qnorm.reserve((size_t)nq * sizeof(float)));
                 m.qnorm = ws->qnorm.as<float>();
@@ -956,15 +966,23 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
                 m.qs = ws->ms_qs.as<float>();
             }
             HIP_TRY(hipMemsetAsync(ws->ghist.p, 0, (size_t)nq * 64 * sizeof(uint32_t), s));
-            HIP_TRY(launch_ms_units(wt.list_count, wt.list_pair_off, nlist, qt0, ws->ms_unit_off.as<int64_t>(),
-                                    ws->ms_nunits.as<int64_t>(), ws->ms_units.as<KnItem>(),
-                                    idx->d_list_len.as<int64_t>(), idx->code_size, nullptr, s));
             MScanArgs ds = m;
             ds.dump = ws->dump.as<float>();
             ds.dump_stride = sample;
             ds.ghist = nullptr;
-            ds.sample_off = ws->ms_sample_off.as<int32_t>();
-            HIP_TRY(launch_filter(ds, bound0));
+            if (kind == KNHIP_IVF_PQ) {
+                // one workgroup per query: plan, fp32 table, sampled rows, and the statistics of both table forms
+                HIP_TRY(launch_pq_sample(ds, keys_p, idx->cb.as<float4>(), nlist, std::max(1024, 8 * k), idx->pabs_max,
+                                         is_l2, ws->ms_nrow.as<int32_t>(), ws->ms_qs.as<float>(),
+                                         want_i8 ? ws->ms_qis.as<float>() : nullptr,
+                                         want_i8 ? ws->ms_qmu.as<float>() : nullptr, s));
+            } else {
+                HIP_TRY(launch_ms_units(wt.list_count, wt.list_pair_off, nlist, qt0, ws->ms_unit_off.as<int64_t>(),
+                                        ws->ms_nunits.as<int64_t>(), ws->ms_units.as<KnItem>(),
+                                        idx->d_list_len.as<int64_t>(), idx->code_size, nullptr, s));
+                ds.sample_off = ws->ms_sample_off.as<int32_t>();
+                HIP_TRY(launch_filter(ds, bound0));
+            }
             HIP_TRY(launch_row_select_var(ws->dump.as<float>(), sample, keys_p, nprobe, idx->d_list_len.as<int64_t>(),
                                           nq, k, is_l2, ws->sel_keys.as<int64_t>(), ws->sel_d.as<float>(), s, sample,
                                           ws->ms_nrow.as<int32_t>()));
@@ -975,12 +993,10 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
                 // each query's candidate count under either eps; the batch takes the integer form when that is small,
                 // else the half-precision form, else -- data where even that lets a few percent of the rows through,
                 // so that the exact finish would cost more than the exact scan -- the exact 4-query kernel.
-                const bool want_i8 = idx->pqf_form != 1;
-                if (want_i8) {
-                    HIP_TRY(ws->ms_qi.reserve((size_t)nq * 256 * 32));
-                    HIP_TRY(ws->ms_qis.reserve(((size_t)nq * 4 + 4) * sizeof(float))); // (+ the batch record)
-                    HIP_TRY(launch_pqi_query_table(d_q, idx->cb_t.as<float4>(), d, nq, is_l2, idx->pabs_max, ws->ms_qi.p,
-                                                   ws->ms_qis.as<float>(), s));
+                if (want_i8) { // (pass 1 -- ranges, midranges -- was part of the sample pass)
+                    HIP_TRY(launch_pqi_query_table(d_q, idx->cb.as<float4>(), d, nq, is_l2, idx->pabs_max, ws->ms_qi.p,
+                                                   ws->ms_qis.as<float>(), ws->ms_qmu.as<float>(), /*stats_done=*/true,
+                                                   s));
                 }
                 int32_t h_poor[2] = {0, 0};
                 if (idx->pqf_guard) {
@@ -1001,6 +1017,13 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
                 }
                 pq_i8 = want_i8 && (idx->pqf_form == 2 || !idx->pqf_guard || (int64_t)h_poor[1] * 4 <= nq);
                 idx->last_pq_form = pq_i8 ? 2 : 1;
+                if (!pq_i8) {
+                    // the queries' half tables + scales (the same records the sample pass wrote)
+                    HIP_TRY(ws->ms_qh.reserve((size_t)nq * 256 * 32 * 2));
+                    HIP_TRY(launch_pqf_query_table(d_q, idx->cb.as<float4>(), d, nq, is_l2, idx->pabs_max, ws->ms_qh.p,
+                                                   ws->ms_qs.as<float>(), s));
+                    m.pq_qh = ws->ms_qh.p;
+                }
                 if (pq_i8) {
                     if (int rc = ensure_pqi(idx)) return rc;
                     qt = 16;
@@ -1017,7 +1040,9 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             // all probes of a list together: the work table again without the rank-0 split, its pairs cut into units
             StageTimer t(idx, s, KNHIP_STAGE_GROUP);
             WorkTable w2 = wt;
-            w2.scan_bytes = reinterpret_cast<double*>(ws->ms_nunits.as<int64_t>() + 1); // (bytes were counted above)
+            if (!wt1_lazy) {
+                w2.scan_bytes = reinterpret_cast<double*>(ws->ms_nunits.as<int64_t>() + 1); // (bytes were counted above)
+            }
             HIP_TRY(launch_build_worktable(keys_p, nq, nprobe, nlist, qg, qg, idx->d_list_len.as<int64_t>(),
                                            idx->code_size, w2, s, /*rank0_slot=*/-1));
             HIP_TRY(launch_ms_units(wt.list_count + nlist, wt.list_pair_off + nlist, nlist, qt,
@@ -1154,6 +1179,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             if (rc_ms != KNHIP_PQF_ABANDONED) {
                 return rc_ms;
             }
+            if (int rc = build_wt1()) return rc;
             // (the guard found the batch poorly selective: the exact 4-query kernel over the work table built above -- both
             // classes of the sample split are ordinary items of 4 pairs; gthr holds the sample's bounds, which are valid)
         }

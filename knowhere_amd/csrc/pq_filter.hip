@@ -174,6 +174,49 @@ hipError_t launch_pq_psum(const uint8_t* codes, const int64_t* list_row_off, con
     return hipGetLastError();
 }
 
+// ---- per-query tables: shared pieces ---------------------------------------------------------------------------------
+// Thread c of a 256-thread workgroup holds the query's 32 table entries of centroid c.  The codebook is read in FAISS's
+// own order cb[m][c][4] (a wave reads 1 KB contiguous per m; the c-major copy the scan kernels use made every lane of
+// such a load touch its own cache line: 10 GB of L2 -> L1 traffic per 10^4 queries, round 3 profile).
+template <bool IS_L2>
+__device__ __forceinline__ void pq_table_values(const float* sq, const float4* __restrict__ cb_m, int c, float (&v)[PF_M]) {
+#pragma unroll
+    for (int m = 0; m < PF_M; m++) {
+        const float4 y = cb_m[m * PF_KSUB + c];
+        const float4 x = *reinterpret_cast<const float4*>(sq + m * PF_DSUB);
+        float t = ip_step(0.f, x.x, y.x);
+        t = ip_step(t, x.y, y.y);
+        t = ip_step(t, x.z, y.z);
+        t = ip_step(t, x.w, y.w);
+        v[m] = IS_L2 ? fmul_x(-2.0f, t) : t;
+    }
+}
+
+// Reduction of a[m] over the 64 lanes of a wave for all 32 m at once (`a` is consumed): halving exchanges -- 16 + 8 + 4 +
+// 2 + 1 + 1 = 32 shuffles instead of 32 x 6.  Returns the reduced value of m = (lane >> 1) & 31.
+template <int W, typename Op>
+__device__ __forceinline__ void pf_reduce_step(float (&a)[PF_M], Op op, int lane) {
+    constexpr int BIT = 2 * W; // partner = lane ^ BIT; lanes with the bit set keep the upper half
+    const bool up = (lane & BIT) != 0;
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+        const float send = up ? a[i] : a[i + W];
+        const float keep = up ? a[i + W] : a[i];
+        a[i] = op(keep, __shfl_xor(send, BIT, KN_WAVE));
+    }
+}
+
+template <typename Op>
+__device__ __forceinline__ float pf_reduce32(float (&a)[PF_M], Op op) {
+    const int lane = lane_id();
+    pf_reduce_step<16>(a, op, lane);
+    pf_reduce_step<8>(a, op, lane);
+    pf_reduce_step<4>(a, op, lane);
+    pf_reduce_step<2>(a, op, lane);
+    pf_reduce_step<1>(a, op, lane);
+    return op(a[0], __shfl_xor(a[0], 1, KN_WAVE));
+}
+
 // ---- per-query half table ------------------------------------------------------------------------------------------
 // One workgroup per query, thread = centroid index c.  qs[q] = {sc, 1 / sc, eps_base, A}.
 // Table layout (halves): qh[q][c >> 2][m & 15][c & 3][m >> 4] -- the 16-byte piece thread t = (c >> 2) * 16 + (m & 15)
@@ -181,7 +224,7 @@ hipError_t launch_pq_psum(const uint8_t* codes, const int64_t* list_row_off, con
 // threads at the same piece index are 16 consecutive m of one c: their LUT stores are a contiguous 256 bytes.
 template <bool IS_L2>
 __global__ __launch_bounds__(PF_KSUB) void pqf_query_table_kernel(const float* __restrict__ queries,
-                                                                  const float4* __restrict__ cb_t, int d, float pabs_max,
+                                                                  const float4* __restrict__ cb_m, int d, float pabs_max,
                                                                   uint32_t* __restrict__ qh, float* __restrict__ qs) {
     __shared__ float sq[PF_M * PF_DSUB];
     __shared__ float smax[PF_M][PF_KSUB / KN_WAVE];
@@ -194,23 +237,17 @@ __global__ __launch_bounds__(PF_KSUB) void pqf_query_table_kernel(const float* _
     }
     __syncthreads();
     float v[PF_M];
+    pq_table_values<IS_L2>(sq, cb_m, c, v);
+    {
+        float a[PF_M];
 #pragma unroll
-    for (int m = 0; m < PF_M; m++) {
-        const float4 y = cb_t[c * PF_M + m];
-        const float4 x = *reinterpret_cast<const float4*>(sq + m * PF_DSUB);
-        float t = ip_step(0.f, x.x, y.x);
-        t = ip_step(t, x.y, y.y);
-        t = ip_step(t, x.z, y.z);
-        t = ip_step(t, x.w, y.w);
-        v[m] = IS_L2 ? fmul_x(-2.0f, t) : t;
-        float a = fabsf(v[m]);
-        a = (a == a) ? a : INFINITY; // NaN -> "no bound": the query takes the exact kernels
-#pragma unroll
-        for (int dlt = KN_WAVE / 2; dlt > 0; dlt >>= 1) {
-            a = fmaxf(a, __shfl_xor(a, dlt, KN_WAVE));
+        for (int m = 0; m < PF_M; m++) {
+            const float x = fabsf(v[m]);
+            a[m] = (x == x) ? x : INFINITY; // NaN -> "no bound": the query takes the exact kernels
         }
-        if (lane_id() == 0) {
-            smax[m][wave] = a;
+        const float r = pf_reduce32(a, [](float x, float y) { return fmaxf(x, y); });
+        if ((lane_id() & 1) == 0) {
+            smax[(lane_id() >> 1) & 31][wave] = r;
         }
     }
     __syncthreads();
@@ -257,16 +294,17 @@ __global__ __launch_bounds__(PF_KSUB) void pqf_query_table_kernel(const float* _
     }
 }
 
-hipError_t launch_pqf_query_table(const float* queries, const float4* cb_t, int d, int64_t nq, bool is_l2, float pabs_max,
+// cb_m: the codebook in FAISS order [m][256][4]
+hipError_t launch_pqf_query_table(const float* queries, const float4* cb_m, int d, int64_t nq, bool is_l2, float pabs_max,
                                   void* qh, float* qs, hipStream_t s) {
     if (nq <= 0) {
         return hipSuccess;
     }
     if (is_l2) {
-        hipLaunchKernelGGL(pqf_query_table_kernel<true>, dim3((unsigned)nq), dim3(PF_KSUB), 0, s, queries, cb_t, d,
+        hipLaunchKernelGGL(pqf_query_table_kernel<true>, dim3((unsigned)nq), dim3(PF_KSUB), 0, s, queries, cb_m, d,
                            pabs_max, static_cast<uint32_t*>(qh), qs);
     } else {
-        hipLaunchKernelGGL(pqf_query_table_kernel<false>, dim3((unsigned)nq), dim3(PF_KSUB), 0, s, queries, cb_t, d,
+        hipLaunchKernelGGL(pqf_query_table_kernel<false>, dim3((unsigned)nq), dim3(PF_KSUB), 0, s, queries, cb_m, d,
                            pabs_max, static_cast<uint32_t*>(qh), qs);
     }
     return hipGetLastError();
@@ -933,41 +971,6 @@ hipError_t launch_pq_stream16i(const uint8_t* codes, const int64_t* list_row_off
 // qis[q] = {s_q, sum_m mu, eps_base, A}; qis[nq] = {bits of the batch's largest range (atomic max), s0, 1 / s0, -}.
 constexpr float PI_INT_LIM = 536870912.0f; // 2^29: |psum| / s0 stays below it (else: no bound, the exact kernels)
 
-// v[m] = this thread's (centroid c) table entries of query q; smax / smin[m][wave] = their extrema over the wave
-template <bool IS_L2>
-__device__ __forceinline__ void pqi_table_values(const float* __restrict__ queries, const float4* __restrict__ cb_t, int d,
-                                                 int64_t q, float* sq, float (*smax)[PF_KSUB / KN_WAVE],
-                                                 float (*smin)[PF_KSUB / KN_WAVE], float (&v)[PF_M]) {
-    const int c = threadIdx.x;
-    const int wave = c / KN_WAVE;
-    if (c < PF_M * PF_DSUB) {
-        sq[c] = queries[q * d + c];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int m = 0; m < PF_M; m++) {
-        const float4 y = cb_t[c * PF_M + m];
-        const float4 x = *reinterpret_cast<const float4*>(sq + m * PF_DSUB);
-        float t = ip_step(0.f, x.x, y.x);
-        t = ip_step(t, x.y, y.y);
-        t = ip_step(t, x.z, y.z);
-        t = ip_step(t, x.w, y.w);
-        v[m] = IS_L2 ? fmul_x(-2.0f, t) : t;
-        const bool fin = fabsf(v[m]) < INFINITY; // (false for NaN too: "no bound", the query takes the exact kernels)
-        float hi = fin ? v[m] : INFINITY, lo = fin ? v[m] : -INFINITY;
-#pragma unroll
-        for (int dlt = KN_WAVE / 2; dlt > 0; dlt >>= 1) {
-            hi = fmaxf(hi, __shfl_xor(hi, dlt, KN_WAVE));
-            lo = fminf(lo, __shfl_xor(lo, dlt, KN_WAVE));
-        }
-        if (lane_id() == 0) {
-            smax[m][wave] = hi;
-            smin[m][wave] = lo;
-        }
-    }
-    __syncthreads();
-}
-
 // the power of two s0 with 127 s0 >= (largest range of the batch) / 254
 __device__ __forceinline__ float pqi_base_step(float rmax) {
     if (!(rmax > 0.f) || !(rmax < INFINITY)) {
@@ -979,49 +982,89 @@ __device__ __forceinline__ float pqi_base_step(float rmax) {
     return ldexpf(1.0f, e);
 }
 
-// pass 1: the batch's largest finite table range -> gl[0] (bits of a non-negative float: integer order = float order)
+// pass 1, one workgroup per query, thread = centroid index c: the per-m midranges mu[q][m], qis[q] = {R (largest range),
+// sum_m mu, -, A}, and the batch's largest finite range -> gl[0] (bits of a non-negative float: integer order = float
+// order)
 template <bool IS_L2>
-__global__ __launch_bounds__(PF_KSUB) void pqi_query_range_kernel(const float* __restrict__ queries,
-                                                                  const float4* __restrict__ cb_t, int d,
+__global__ __launch_bounds__(PF_KSUB) void pqi_query_stats_kernel(const float* __restrict__ queries,
+                                                                  const float4* __restrict__ cb_m, int d,
+                                                                  float* __restrict__ qmu, float* __restrict__ qis,
                                                                   uint32_t* __restrict__ gl) {
     __shared__ float sq[PF_M * PF_DSUB];
     __shared__ float smax[PF_M][PF_KSUB / KN_WAVE];
     __shared__ float smin[PF_M][PF_KSUB / KN_WAVE];
-    float v[PF_M];
-    pqi_table_values<IS_L2>(queries, cb_t, d, blockIdx.x, sq, smax, smin, v);
-    if (threadIdx.x == 0) {
-        float R = 0.f;
-        for (int m = 0; m < PF_M; m++) {
-            float hi = smax[m][0], lo = smin[m][0];
-            for (int w = 1; w < PF_KSUB / KN_WAVE; w++) {
-                hi = fmaxf(hi, smax[m][w]);
-                lo = fminf(lo, smin[m][w]);
-            }
-            R = fmaxf(R, hi - lo);
+    __shared__ float s_mu[PF_M], s_a[PF_M], s_r[PF_M];
+    const int64_t q = blockIdx.x;
+    const int c = threadIdx.x;
+    const int wave = c / KN_WAVE;
+    if (c < PF_M * PF_DSUB) {
+        sq[c] = queries[q * d + c];
+    }
+    __syncthreads();
+    float hi[PF_M], lo[PF_M];
+    pq_table_values<IS_L2>(sq, cb_m, c, hi);
+#pragma unroll
+    for (int m = 0; m < PF_M; m++) {
+        const bool fin = fabsf(hi[m]) < INFINITY; // (false for NaN too: "no bound", the query takes the exact kernels)
+        lo[m] = fin ? hi[m] : -INFINITY;
+        hi[m] = fin ? hi[m] : INFINITY;
+    }
+    const float rh = pf_reduce32(hi, [](float x, float y) { return fmaxf(x, y); });
+    const float rl = pf_reduce32(lo, [](float x, float y) { return fminf(x, y); });
+    if ((lane_id() & 1) == 0) {
+        smax[(lane_id() >> 1) & 31][wave] = rh;
+        smin[(lane_id() >> 1) & 31][wave] = rl;
+    }
+    __syncthreads();
+    if (c < PF_M) {
+        float h = smax[c][0], l = smin[c][0];
+        for (int w = 1; w < PF_KSUB / KN_WAVE; w++) {
+            h = fmaxf(h, smax[c][w]);
+            l = fminf(l, smin[c][w]);
         }
+        const float mu = 0.5f * h + 0.5f * l;
+        s_mu[c] = mu;
+        s_a[c] = fmaxf(fabsf(h), fabsf(l));
+        s_r[c] = h - l;
+        qmu[q * PF_M + c] = mu;
+    }
+    __syncthreads();
+    if (c == 0) {
+        float A = 0.f, R = 0.f, musum = 0.f;
+        for (int m = 0; m < PF_M; m++) { // (in this order: the sums are part of the bound's definition)
+            musum += s_mu[m];
+            A += s_a[m];
+            R = fmaxf(R, s_r[m]);
+        }
+        qis[q * 4 + 0] = R;
+        qis[q * 4 + 1] = musum;
+        qis[q * 4 + 2] = INFINITY;
+        qis[q * 4 + 3] = A;
         if (R > 0.f && R < INFINITY) {
             atomicMax(gl, __float_as_uint(R));
         }
     }
 }
 
-// pass 2: one workgroup per query, thread = centroid index c.
+// pass 2: step on the batch's lattice, eps, the quantised table.
 // Table layout (bytes): qi[q][c >> 2][m & 15][c & 3][m >> 4]: the 8-byte piece thread t = (c >> 2) * 16 + (m & 15) of the
 // filter kernel reads holds this query's entries of its 8 (c, m) cells.
 template <bool IS_L2>
 __global__ __launch_bounds__(PF_KSUB) void pqi_query_table_kernel(const float* __restrict__ queries,
-                                                                  const float4* __restrict__ cb_t, int d, float pabs_max,
-                                                                  int64_t nq, uint32_t* __restrict__ qi,
-                                                                  float* __restrict__ qis) {
+                                                                  const float4* __restrict__ cb_m, int d, float pabs_max,
+                                                                  int64_t nq, const float* __restrict__ qmu,
+                                                                  uint32_t* __restrict__ qi, float* __restrict__ qis) {
     __shared__ float sq[PF_M * PF_DSUB];
-    __shared__ float smax[PF_M][PF_KSUB / KN_WAVE];
-    __shared__ float smin[PF_M][PF_KSUB / KN_WAVE];
     __shared__ float smu[PF_M];
     __shared__ float s_inv;
     const int64_t q = blockIdx.x;
     const int c = threadIdx.x;
-    float v[PF_M];
-    pqi_table_values<IS_L2>(queries, cb_t, d, q, sq, smax, smin, v);
+    if (c < PF_M * PF_DSUB) {
+        sq[c] = queries[q * d + c];
+    }
+    if (c < PF_M) {
+        smu[c] = qmu[q * PF_M + c];
+    }
     if (c == 0) {
         const float s0 = pqi_base_step(__uint_as_float(reinterpret_cast<const uint32_t*>(qis)[nq * 4]));
         const float inv0 = 1.0f / s0; // (a power of two: exact)
@@ -1029,19 +1072,7 @@ __global__ __launch_bounds__(PF_KSUB) void pqi_query_table_kernel(const float* _
             qis[nq * 4 + 1] = s0;
             qis[nq * 4 + 2] = inv0;
         }
-        float A = 0.f, R = 0.f, musum = 0.f;
-        for (int m = 0; m < PF_M; m++) {
-            float hi = smax[m][0], lo = smin[m][0];
-            for (int w = 1; w < PF_KSUB / KN_WAVE; w++) {
-                hi = fmaxf(hi, smax[m][w]);
-                lo = fminf(lo, smin[m][w]);
-            }
-            const float mu = 0.5f * hi + 0.5f * lo;
-            smu[m] = mu;
-            musum += mu;
-            A += fmaxf(fabsf(hi), fabsf(lo));
-            R = fmaxf(R, hi - lo);
-        }
+        const float R = qis[q * 4 + 0], musum = qis[q * 4 + 1], A = qis[q * 4 + 3];
         float step = s0, eps = INFINITY;
         if (A < INFINITY && R < INFINITY && pabs_max * inv0 < PI_INT_LIM) {
             // the smallest lattice step >= R / 254 (w = 1 for a constant table; R <= the batch's largest range => w <= 127)
@@ -1051,11 +1082,11 @@ __global__ __launch_bounds__(PF_KSUB) void pqi_query_table_kernel(const float* _
         }
         s_inv = 1.0f / step;
         qis[q * 4 + 0] = step;
-        qis[q * 4 + 1] = musum;
         qis[q * 4 + 2] = eps;
-        qis[q * 4 + 3] = A;
     }
     __syncthreads();
+    float v[PF_M];
+    pq_table_values<IS_L2>(sq, cb_m, c, v);
     const float inv = s_inv;
     uint32_t* out = qi + q * (PF_KSUB * PF_M / 4);
     // word (c >> 2, l16, w): bytes = cells (c & 3 = 2 w, h = 0), (2 w, 1), (2 w + 1, 0), (2 w + 1, 1): thread c owns byte
@@ -1075,25 +1106,202 @@ __global__ __launch_bounds__(PF_KSUB) void pqi_query_table_kernel(const float* _
     }
 }
 
-// qis: nq * 4 + 4 floats (the batch record behind the per-query records)
-hipError_t launch_pqi_query_table(const float* queries, const float4* cb_t, int d, int64_t nq, bool is_l2, float pabs_max,
-                                  void* qi, float* qis, hipStream_t s) {
+// cb_m: the codebook in FAISS order [m][256][4]; qis: nq * 4 + 4 floats (the batch record behind the per-query
+// records); qmu: nq * 32 floats (the midranges between the two passes).  stats_done: pass 1 was part of the sample pass
+// (pq_sample_kernel) -- only the tables are written.
+hipError_t launch_pqi_query_table(const float* queries, const float4* cb_m, int d, int64_t nq, bool is_l2, float pabs_max,
+                                  void* qi, float* qis, float* qmu, bool stats_done, hipStream_t s) {
     if (nq <= 0) {
         return hipSuccess;
     }
-    hipError_t e = hipMemsetAsync(qis + nq * 4, 0, 4 * sizeof(float), s);
-    if (e != hipSuccess) {
-        return e;
-    }
     uint32_t* gl = reinterpret_cast<uint32_t*>(qis + nq * 4);
+    if (!stats_done) {
+        hipError_t e = hipMemsetAsync(qis + nq * 4, 0, 4 * sizeof(float), s);
+        if (e != hipSuccess) {
+            return e;
+        }
+        if (is_l2) {
+            hipLaunchKernelGGL(pqi_query_stats_kernel<true>, dim3((unsigned)nq), dim3(PF_KSUB), 0, s, queries, cb_m, d,
+                               qmu, qis, gl);
+        } else {
+            hipLaunchKernelGGL(pqi_query_stats_kernel<false>, dim3((unsigned)nq), dim3(PF_KSUB), 0, s, queries, cb_m, d,
+                               qmu, qis, gl);
+        }
+    }
     if (is_l2) {
-        hipLaunchKernelGGL(pqi_query_range_kernel<true>, dim3((unsigned)nq), dim3(PF_KSUB), 0, s, queries, cb_t, d, gl);
-        hipLaunchKernelGGL(pqi_query_table_kernel<true>, dim3((unsigned)nq), dim3(PF_KSUB), 0, s, queries, cb_t, d,
-                           pabs_max, nq, static_cast<uint32_t*>(qi), qis);
+        hipLaunchKernelGGL(pqi_query_table_kernel<true>, dim3((unsigned)nq), dim3(PF_KSUB), 0, s, queries, cb_m, d,
+                           pabs_max, nq, qmu, static_cast<uint32_t*>(qi), qis);
     } else {
-        hipLaunchKernelGGL(pqi_query_range_kernel<false>, dim3((unsigned)nq), dim3(PF_KSUB), 0, s, queries, cb_t, d, gl);
-        hipLaunchKernelGGL(pqi_query_table_kernel<false>, dim3((unsigned)nq), dim3(PF_KSUB), 0, s, queries, cb_t, d,
-                           pabs_max, nq, static_cast<uint32_t*>(qi), qis);
+        hipLaunchKernelGGL(pqi_query_table_kernel<false>, dim3((unsigned)nq), dim3(PF_KSUB), 0, s, queries, cb_m, d,
+                           pabs_max, nq, qmu, static_cast<uint32_t*>(qi), qis);
+    }
+    return hipGetLastError();
+}
+
+// ---- the sample pass, direct ---------------------------------------------------------------------------------------
+// tau_q comes from the closest list(s) of each query alone: ~10^4 (query, list) pairs with one query each.  As units of
+// the filter kernel every one of them paid a 128 KB LUT for a few thousand rows (0.43 ms per 10^4 queries, plus a work
+// table, units and a sample plan built just for it: ~1 ms per batch in the round-3 profile).  Here one workgroup per
+// query builds the query's fp32 table once in LDS (32 KB) and walks the sampled rows with plain fp32 lookups, the plan
+// (probes in coarse order until `smin` rows, at most PF_SAMPLE) evaluated on the way.  The same pass over the table
+// yields the statistics both table forms need, so it also writes qs[q] = {sc, 1 / sc, eps_base, A} (half form) and, when
+// asked, qis[q] = {R, sum mu, -, A}, qmu and the batch's largest range (integer form, pass 1: pqi_query_stats_kernel).
+// dump[q][col] = fp32 ADC distance made pessimistic by its own rounding bound (no table quantisation: tighter than the
+// half-precision sample it replaces); filtered rows dump the neutral value.
+template <bool IS_L2>
+__global__ __launch_bounds__(PF_KSUB) void pq_sample_kernel(MScanArgs a, const int64_t* __restrict__ keys,
+                                                            const float4* __restrict__ cb_m, int64_t nlist, int smin,
+                                                            float pabs_max, int32_t* __restrict__ n_row,
+                                                            float* __restrict__ qs, float* __restrict__ qis,
+                                                            float* __restrict__ qmu, uint32_t* __restrict__ gl) {
+    __shared__ float lut[PF_M * PF_KSUB]; // [m][c]
+    __shared__ float sq[PF_M * PF_DSUB];
+    __shared__ float smax[PF_M][PF_KSUB / KN_WAVE];
+    __shared__ float smin_[PF_M][PF_KSUB / KN_WAVE];
+    __shared__ float s_mu[PF_M], s_a[PF_M], s_r[PF_M];
+    __shared__ float s_A;
+    const int64_t q = blockIdx.x;
+    const int c = threadIdx.x;
+    const int wave = c / KN_WAVE;
+    if (c < PF_M * PF_DSUB) {
+        sq[c] = a.queries[q * a.d + c];
+    }
+    __syncthreads();
+    {
+        float v[PF_M], hi[PF_M], lo[PF_M];
+        pq_table_values<IS_L2>(sq, cb_m, c, v);
+#pragma unroll
+        for (int m = 0; m < PF_M; m++) {
+            lut[m * PF_KSUB + c] = v[m];
+            const bool fin = fabsf(v[m]) < INFINITY; // (false for NaN too: "no bound", the query takes the exact kernels)
+            hi[m] = fin ? v[m] : INFINITY;
+            lo[m] = fin ? v[m] : -INFINITY;
+        }
+        const float rh = pf_reduce32(hi, [](float x, float y) { return fmaxf(x, y); });
+        const float rl = pf_reduce32(lo, [](float x, float y) { return fminf(x, y); });
+        if ((lane_id() & 1) == 0) {
+            smax[(lane_id() >> 1) & 31][wave] = rh;
+            smin_[(lane_id() >> 1) & 31][wave] = rl;
+        }
+    }
+    __syncthreads();
+    if (c < PF_M) {
+        float h = smax[c][0], l = smin_[c][0];
+        for (int w = 1; w < PF_KSUB / KN_WAVE; w++) {
+            h = fmaxf(h, smax[c][w]);
+            l = fminf(l, smin_[c][w]);
+        }
+        const float mu = 0.5f * h + 0.5f * l;
+        s_mu[c] = mu;
+        s_a[c] = fmaxf(fabsf(h), fabsf(l));
+        s_r[c] = h - l;
+        if (qmu != nullptr) {
+            qmu[q * PF_M + c] = mu;
+        }
+    }
+    __syncthreads();
+    if (c == 0) {
+        float A = 0.f, R = 0.f, musum = 0.f, gmax = 0.f;
+        for (int m = 0; m < PF_M; m++) { // (in this order: the sums are part of the bounds' definitions)
+            musum += s_mu[m];
+            A += s_a[m];
+            R = fmaxf(R, s_r[m]);
+            gmax = fmaxf(gmax, s_a[m]);
+        }
+        s_A = A;
+        // half form: the record pqf_query_table_kernel writes
+        float sc = 1.0f, eps = INFINITY;
+        if (A < INFINITY) {
+            if (gmax > 0.f) {
+                int e = 0;
+                (void)frexpf(gmax, &e);
+                int p2 = 15 - e;
+                p2 = p2 > 126 ? 126 : (p2 < -126 ? -126 : p2);
+                sc = ldexpf(1.0f, p2);
+            }
+            const float isc = 1.0f / sc;
+            eps = PF_UH * A * 1.001f + 9.5367431640625e-7f * isc + 128.0f * PF_U * (pabs_max + A);
+        }
+        qs[q * 4 + 0] = sc;
+        qs[q * 4 + 1] = 1.0f / sc;
+        qs[q * 4 + 2] = eps;
+        qs[q * 4 + 3] = A;
+        if (qis != nullptr) { // integer form, pass 1
+            qis[q * 4 + 0] = R;
+            qis[q * 4 + 1] = musum;
+            qis[q * 4 + 2] = INFINITY;
+            qis[q * 4 + 3] = A;
+            if (R > 0.f && R < INFINITY) {
+                atomicMax(gl, __float_as_uint(R));
+            }
+        }
+    }
+    __syncthreads();
+    const float A = s_A;
+    // ---- the sampled rows ------------------------------------------------------------------------------------------
+    int cum = 0;
+    for (int slot = 0; slot < a.nslot && cum < smin && cum < PF_SAMPLE; slot++) {
+        const int64_t key = keys[q * a.nslot + slot];
+        const int64_t len = (key >= 0 && key < nlist) ? a.list_len[key] : 0;
+        if (len <= 0) {
+            continue;
+        }
+        const int off = cum;
+        const int rows = (int)min(len, (int64_t)(PF_SAMPLE - cum));
+        cum += rows;
+        const float dis0 = a.coarse_dis[q * a.nslot + slot];
+        const int64_t row_off = a.list_row_off[key];
+        const float* ps = a.pq_psum + a.pq_sblk_off_r[key] * 16;
+        const float slack0 = 128.0f * PF_U * (pabs_max + A) + 64.0f * PF_U * fabsf(dis0);
+        for (int pos = c; pos < rows; pos += PF_KSUB) {
+            const uint4* cp = reinterpret_cast<const uint4*>(a.pq_codes + (row_off + pos) * PF_M);
+            const uint4 c0 = cp[0], c1 = cp[1];
+            const uint32_t w[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+            float acc = 0.f;
+#pragma unroll
+            for (int m = 0; m < PF_M; m++) {
+                acc += lut[m * PF_KSUB + ((w[m >> 2] >> (8 * (m & 3))) & 0xffu)];
+            }
+            float val = IS_L2 ? (dis0 + ps[pos]) + acc : dis0 + acc;
+            const float slack = slack0 + 64.0f * PF_U * fabsf(val);
+            val = IS_L2 ? val + slack : val - slack;
+            if (!(slack < INFINITY) || val != val) {
+                val = worst_dist<IS_L2>(); // (no bound from this row)
+            }
+            if (a.bitset != nullptr && bitset_filtered(a.bitset, a.bitset_nbits, a.ids[row_off + pos])) {
+                val = worst_dist<IS_L2>();
+            }
+            a.dump[q * a.dump_stride + off + pos] = val;
+        }
+    }
+    if (c == 0) {
+        n_row[q] = cum;
+    }
+}
+
+// qis / qmu null: the integer form is off (no pass-1 record).  With qis: its batch record qis[nq * 4 ..) is reset here.
+hipError_t launch_pq_sample(const MScanArgs& a, const int64_t* keys, const float4* cb_m, int64_t nlist, int smin,
+                            float pabs_max, bool is_l2, int32_t* n_row, float* qs, float* qis, float* qmu, hipStream_t s) {
+    if (a.nq <= 0) {
+        return hipSuccess;
+    }
+    if (a.dump == nullptr || a.dump_stride < PF_SAMPLE) {
+        return hipErrorInvalidValue;
+    }
+    uint32_t* gl = nullptr;
+    if (qis != nullptr) {
+        hipError_t e = hipMemsetAsync(qis + a.nq * 4, 0, 4 * sizeof(float), s);
+        if (e != hipSuccess) {
+            return e;
+        }
+        gl = reinterpret_cast<uint32_t*>(qis + a.nq * 4);
+    }
+    if (is_l2) {
+        hipLaunchKernelGGL(pq_sample_kernel<true>, dim3((unsigned)a.nq), dim3(PF_KSUB), 0, s, a, keys, cb_m, nlist, smin,
+                           pabs_max, n_row, qs, qis, qmu, gl);
+    } else {
+        hipLaunchKernelGGL(pq_sample_kernel<false>, dim3((unsigned)a.nq), dim3(PF_KSUB), 0, s, a, keys, cb_m, nlist, smin,
+                           pabs_max, n_row, qs, qis, qmu, gl);
     }
     return hipGetLastError();
 }

@@ -95,7 +95,7 @@ extern "C" int emu_pqf_search(int64_t nlist, const int64_t* list_len, const int6
     // ---- per query: half tables ----------------------------------------------------------------------------------
     std::vector<uint16_t> qh((size_t)nq * 256 * 32);
     std::vector<float> qs((size_t)nq * 4);
-    if (launch_pqf_query_table(xq, cb_t.data(), d, nq, l2, pabs_max, qh.data(), qs.data(), nullptr) != hipSuccess) return 3;
+    if (launch_pqf_query_table(xq, reinterpret_cast<const float4*>(cb), d, nq, l2, pabs_max, qh.data(), qs.data(), nullptr) != hipSuccess) return 3;
     // ---- sample plan (emulated kernel), units of the sampled pairs -----------------------------------------------------
     const int sample = mscan_sample_rows();
     std::vector<int32_t> sample_off((size_t)nq * nprobe), n_row((size_t)nq);
