@@ -1205,7 +1205,10 @@ __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, c
                     const uint4* cp = reinterpret_cast<const uint4*>(a.pq_codes + (a.list_row_off[list] + pos) * 32);
                     const uint4 cw[2] = {cp[0], cp[1]};
                     const uint32_t ww[8] = {cw[0].x, cw[0].y, cw[0].z, cw[0].w, cw[1].x, cw[1].y, cw[1].z, cw[1].w};
-                    const float* pt = a.pq_precomp_t + list * (int64_t)(256 * 32);
+                    // The term-2 entry PT[list][code][m] = ||cb||^2 + 2 <c_list,m , cb> is recomputed here with the very
+                    // operations of pq_precomp_table_kernel (pq_scan.hip) from the list's centroid -- 512 contiguous
+                    // bytes per candidate -- instead of 32 four-byte gathers out of the list's 32 KB table (a cache
+                    // line each: the finish was bound by them, round-3 profile).  Same bits as the stored table.
                     const float* cen = a.centroids + list * d;
 #pragma unroll 8
                     for (int m = 0; m < 32; m++) {
@@ -1226,7 +1229,17 @@ __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, c
                             t = ip_step(t, x.z, y.z);
                             t = ip_step(t, x.w, y.w);
                             if (a.pq_lut_mode == PQ_LUT_PRECOMP) {
-                                t = fadd_x(pt[code * 32 + m], fmul_x(-2.0f, t));
+                                const float4 cl = *reinterpret_cast<const float4*>(cen + m * 4);
+                                float nrm = ip_step(0.f, y.x, y.x);
+                                nrm = ip_step(nrm, y.y, y.y);
+                                nrm = ip_step(nrm, y.z, y.z);
+                                nrm = ip_step(nrm, y.w, y.w);
+                                float ipc = ip_step(0.f, cl.x, y.x);
+                                ipc = ip_step(ipc, cl.y, y.y);
+                                ipc = ip_step(ipc, cl.z, y.z);
+                                ipc = ip_step(ipc, cl.w, y.w);
+                                const float t2 = fadd_x(nrm, fmul_x(2.0f, ipc));
+                                t = fadd_x(t2, fmul_x(-2.0f, t));
                             }
                         }
                         acc = fadd_x(acc, t);

@@ -1149,7 +1149,7 @@ hipError_t launch_pqi_query_table(const float* queries, const float4* cb_m, int 
 // dump[q][col] = fp32 ADC distance made pessimistic by its own rounding bound (no table quantisation: tighter than the
 // half-precision sample it replaces); filtered rows dump the neutral value.
 template <bool IS_L2>
-__global__ __launch_bounds__(PF_KSUB) void pq_sample_kernel(MScanArgs a, const int64_t* __restrict__ keys,
+__global__ __launch_bounds__(PF_KSUB, 4) void pq_sample_kernel(MScanArgs a, const int64_t* __restrict__ keys,
                                                             const float4* __restrict__ cb_m, int64_t nlist, int smin,
                                                             float pabs_max, int32_t* __restrict__ n_row,
                                                             float* __restrict__ qs, float* __restrict__ qis,
@@ -1168,14 +1168,14 @@ __global__ __launch_bounds__(PF_KSUB) void pq_sample_kernel(MScanArgs a, const i
     }
     __syncthreads();
     {
-        float v[PF_M], hi[PF_M], lo[PF_M];
-        pq_table_values<IS_L2>(sq, cb_m, c, v);
+        float hi[PF_M], lo[PF_M];
+        pq_table_values<IS_L2>(sq, cb_m, c, hi);
 #pragma unroll
         for (int m = 0; m < PF_M; m++) {
-            lut[m * PF_KSUB + c] = v[m];
-            const bool fin = fabsf(v[m]) < INFINITY; // (false for NaN too: "no bound", the query takes the exact kernels)
-            hi[m] = fin ? v[m] : INFINITY;
-            lo[m] = fin ? v[m] : -INFINITY;
+            lut[m * PF_KSUB + c] = hi[m];
+            const bool fin = fabsf(hi[m]) < INFINITY; // (false for NaN too: "no bound", the query takes the exact kernels)
+            lo[m] = fin ? hi[m] : -INFINITY;
+            hi[m] = fin ? hi[m] : INFINITY;
         }
         const float rh = pf_reduce32(hi, [](float x, float y) { return fmaxf(x, y); });
         const float rl = pf_reduce32(lo, [](float x, float y) { return fminf(x, y); });
@@ -1253,25 +1253,40 @@ __global__ __launch_bounds__(PF_KSUB) void pq_sample_kernel(MScanArgs a, const i
         const int64_t row_off = a.list_row_off[key];
         const float* ps = a.pq_psum + a.pq_sblk_off_r[key] * 16;
         const float slack0 = 128.0f * PF_U * (pabs_max + A) + 64.0f * PF_U * fabsf(dis0);
-        for (int pos = c; pos < rows; pos += PF_KSUB) {
-            const uint4* cp = reinterpret_cast<const uint4*>(a.pq_codes + (row_off + pos) * PF_M);
-            const uint4 c0 = cp[0], c1 = cp[1];
-            const uint32_t w[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-            float acc = 0.f;
+        // four rows per thread and round: their loads are in flight together (the loop is latency-bound otherwise)
+        for (int pos0 = c; pos0 < rows; pos0 += 4 * PF_KSUB) {
+            uint4 c0[4], c1[4];
+            float psv[4];
 #pragma unroll
-            for (int m = 0; m < PF_M; m++) {
-                acc += lut[m * PF_KSUB + ((w[m >> 2] >> (8 * (m & 3))) & 0xffu)];
+            for (int u = 0; u < 4; u++) {
+                const int pos = min(pos0 + u * PF_KSUB, rows - 1); // (clamped: a valid row, its result is dropped)
+                const uint4* cp = reinterpret_cast<const uint4*>(a.pq_codes + (row_off + pos) * PF_M);
+                c0[u] = cp[0];
+                c1[u] = cp[1];
+                psv[u] = IS_L2 ? ps[pos] : 0.f;
             }
-            float val = IS_L2 ? (dis0 + ps[pos]) + acc : dis0 + acc;
-            const float slack = slack0 + 64.0f * PF_U * fabsf(val);
-            val = IS_L2 ? val + slack : val - slack;
-            if (!(slack < INFINITY) || val != val) {
-                val = worst_dist<IS_L2>(); // (no bound from this row)
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int pos = pos0 + u * PF_KSUB;
+                const uint32_t w[8] = {c0[u].x, c0[u].y, c0[u].z, c0[u].w, c1[u].x, c1[u].y, c1[u].z, c1[u].w};
+                float acc = 0.f;
+#pragma unroll
+                for (int m = 0; m < PF_M; m++) {
+                    acc += lut[m * PF_KSUB + ((w[m >> 2] >> (8 * (m & 3))) & 0xffu)];
+                }
+                float val = IS_L2 ? (dis0 + psv[u]) + acc : dis0 + acc;
+                const float slack = slack0 + 64.0f * PF_U * fabsf(val);
+                val = IS_L2 ? val + slack : val - slack;
+                if (!(slack < INFINITY) || val != val) {
+                    val = worst_dist<IS_L2>(); // (no bound from this row)
+                }
+                if (pos < rows) {
+                    if (a.bitset != nullptr && bitset_filtered(a.bitset, a.bitset_nbits, a.ids[row_off + pos])) {
+                        val = worst_dist<IS_L2>();
+                    }
+                    a.dump[q * a.dump_stride + off + pos] = val;
+                }
             }
-            if (a.bitset != nullptr && bitset_filtered(a.bitset, a.bitset_nbits, a.ids[row_off + pos])) {
-                val = worst_dist<IS_L2>();
-            }
-            a.dump[q * a.dump_stride + off + pos] = val;
         }
     }
     if (c == 0) {

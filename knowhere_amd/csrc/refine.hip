@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ b
                                                      const int64_t* __restrict__ cand, int kbase, int k,
                                                      float* __restrict__ out_d,
                                                      int64_t* __restrict__ out_i) {
-    extern __shared__ float sq[]; // [4][d]
+    extern __shared__ __align__(16) float sq[]; // [4][d]
     const int lane = lane_id();
     const int wave = threadIdx.x / KN_WAVE;
     const int64_t q = (int64_t)blockIdx.x * 4 + wave;
@@ -58,7 +58,32 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ b
         float acc = 0.f;
         if (ok) {
             const float* y = base + (id - id_base) * d;
-            for (int i = 0; i < d; i++) {
+            int i = 0;
+            if ((d & 3) == 0 && (reinterpret_cast<uintptr_t>(base) & 15) == 0) {
+                // 16-byte loads, eight in flight per lane (every lane reads its own row: scalar loads made each of them a
+                // 64-line request); the accumulation order stays i = 0, 1, 2, ... (reference order)
+                const float4* y4 = reinterpret_cast<const float4*>(y);
+                const float4* q4 = reinterpret_cast<const float4*>(myq);
+                const int n4 = d >> 2;
+                int j = 0;
+                for (; j + 8 <= n4; j += 8) {
+                    float4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        v[u] = y4[j + u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const float4 x = q4[j + u];
+                        acc = IS_L2 ? l2_step(acc, x.x, v[u].x) : ip_step(acc, x.x, v[u].x);
+                        acc = IS_L2 ? l2_step(acc, x.y, v[u].y) : ip_step(acc, x.y, v[u].y);
+                        acc = IS_L2 ? l2_step(acc, x.z, v[u].z) : ip_step(acc, x.z, v[u].z);
+                        acc = IS_L2 ? l2_step(acc, x.w, v[u].w) : ip_step(acc, x.w, v[u].w);
+                    }
+                }
+                i = j * 4;
+            }
+            for (; i < d; i++) {
                 acc = IS_L2 ? l2_step(acc, myq[i], y[i]) : ip_step(acc, myq[i], y[i]);
             }
         }
