@@ -972,8 +972,12 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             ds.ghist = nullptr;
             if (kind == KNHIP_IVF_PQ) {
                 // one workgroup per query: plan, fp32 table, sampled rows, and the statistics of both table forms
-                HIP_TRY(launch_pq_sample(ds, keys_p, idx->cb.as<float4>(), nlist, std::max(1024, 8 * k), idx->pabs_max,
-                                         is_l2, ws->ms_nrow.as<int32_t>(), ws->ms_qs.as<float>(),
+                int scap = (int)sample;
+                if (const char* e = getenv("KNHIP_PQ_SAMPLE_ROWS")) { // (experiments: rows of the sample, at most)
+                    scap = std::max(64, std::min((int)sample, atoi(e)));
+                }
+                HIP_TRY(launch_pq_sample(ds, keys_p, idx->cb.as<float4>(), nlist, std::max(1024, 8 * k), scap,
+                                         idx->pabs_max, is_l2, ws->ms_nrow.as<int32_t>(), ws->ms_qs.as<float>(),
                                          want_i8 ? ws->ms_qis.as<float>() : nullptr,
                                          want_i8 ? ws->ms_qmu.as<float>() : nullptr, s));
             } else {

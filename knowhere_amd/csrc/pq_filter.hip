@@ -1151,7 +1151,7 @@ hipError_t launch_pqi_query_table(const float* queries, const float4* cb_m, int 
 template <bool IS_L2>
 __global__ __launch_bounds__(PF_KSUB, 4) void pq_sample_kernel(MScanArgs a, const int64_t* __restrict__ keys,
                                                             const float4* __restrict__ cb_m, int64_t nlist, int smin,
-                                                            float pabs_max, int32_t* __restrict__ n_row,
+                                                            int scap, float pabs_max, int32_t* __restrict__ n_row,
                                                             float* __restrict__ qs, float* __restrict__ qis,
                                                             float* __restrict__ qmu, uint32_t* __restrict__ gl) {
     __shared__ float lut[PF_M * PF_KSUB]; // [m][c]
@@ -1240,14 +1240,14 @@ __global__ __launch_bounds__(PF_KSUB, 4) void pq_sample_kernel(MScanArgs a, cons
     const float A = s_A;
     // ---- the sampled rows ------------------------------------------------------------------------------------------
     int cum = 0;
-    for (int slot = 0; slot < a.nslot && cum < smin && cum < PF_SAMPLE; slot++) {
+    for (int slot = 0; slot < a.nslot && cum < smin && cum < scap; slot++) {
         const int64_t key = keys[q * a.nslot + slot];
         const int64_t len = (key >= 0 && key < nlist) ? a.list_len[key] : 0;
         if (len <= 0) {
             continue;
         }
         const int off = cum;
-        const int rows = (int)min(len, (int64_t)(PF_SAMPLE - cum));
+        const int rows = (int)min(len, (int64_t)(scap - cum));
         cum += rows;
         const float dis0 = a.coarse_dis[q * a.nslot + slot];
         const int64_t row_off = a.list_row_off[key];
@@ -1296,11 +1296,12 @@ __global__ __launch_bounds__(PF_KSUB, 4) void pq_sample_kernel(MScanArgs a, cons
 
 // qis / qmu null: the integer form is off (no pass-1 record).  With qis: its batch record qis[nq * 4 ..) is reset here.
 hipError_t launch_pq_sample(const MScanArgs& a, const int64_t* keys, const float4* cb_m, int64_t nlist, int smin,
-                            float pabs_max, bool is_l2, int32_t* n_row, float* qs, float* qis, float* qmu, hipStream_t s) {
+                            int scap, float pabs_max, bool is_l2, int32_t* n_row, float* qs, float* qis, float* qmu,
+                            hipStream_t s) {
     if (a.nq <= 0) {
         return hipSuccess;
     }
-    if (a.dump == nullptr || a.dump_stride < PF_SAMPLE) {
+    if (a.dump == nullptr || scap < 1 || scap > PF_SAMPLE || a.dump_stride < scap) {
         return hipErrorInvalidValue;
     }
     uint32_t* gl = nullptr;
@@ -1313,10 +1314,10 @@ hipError_t launch_pq_sample(const MScanArgs& a, const int64_t* keys, const float
     }
     if (is_l2) {
         hipLaunchKernelGGL(pq_sample_kernel<true>, dim3((unsigned)a.nq), dim3(PF_KSUB), 0, s, a, keys, cb_m, nlist, smin,
-                           pabs_max, n_row, qs, qis, qmu, gl);
+                           scap, pabs_max, n_row, qs, qis, qmu, gl);
     } else {
         hipLaunchKernelGGL(pq_sample_kernel<false>, dim3((unsigned)a.nq), dim3(PF_KSUB), 0, s, a, keys, cb_m, nlist, smin,
-                           pabs_max, n_row, qs, qis, qmu, gl);
+                           scap, pabs_max, n_row, qs, qis, qmu, gl);
     }
     return hipGetLastError();
 }
@@ -1588,14 +1589,9 @@ __global__ __launch_bounds__(PF_THREADS) void pqi_kernel(MScanArgs a) {
         }
         // ---- everything this unit's start waits for is issued first: table pieces and code blocks (above), the pair's
         // constants, the atomics of the previous unit's parked hits -- one round trip instead of five in a row
-        int32_t pq_q = (int32_t)rl(2), pq_slot = (int32_t)rl(18);
-        float pq_dis0 = __uint_as_float(rl(34)); // wave j prepares pair j
-#pragma unroll
-        for (int j = 1; j < PI_Q; j++) {
-            pq_q = wave == j ? (int32_t)rl(2 + j) : pq_q;
-            pq_slot = wave == j ? (int32_t)rl(18 + j) : pq_slot;
-            pq_dis0 = wave == j ? __uint_as_float(rl(34 + j)) : pq_dis0;
-        }
+        // wave j prepares pair j (the lane index of a readlane may be a scalar register)
+        const int32_t pq_q = (int32_t)rl(2 + wave), pq_slot = (int32_t)rl(18 + wave);
+        const float pq_dis0 = __uint_as_float(rl(34 + wave));
         int32_t pq_qv = pq_q; // (in a vector register: the loads below stay vector loads whose results nobody reads early)
         asm volatile("" : "+v"(pq_qv));
         const float4 s4 = *reinterpret_cast<const float4*>(a.pq_qis + (int64_t)pq_qv * 4);
