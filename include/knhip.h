@@ -205,11 +205,14 @@ int knhip_index_uses_precomputed_table(const knhip_index* idx);
  * Host pointers.  lims[nq + 1] receives the per-query offsets; *out_ids / *out_dist receive malloc'ed arrays
  * of lims[nq] entries (release with knhip_free) in the reference's emission order: list by list in coarse
  * order, storage order inside a list.  Distances are bit-equal to the scalar reference.
- * Supported: KNHIP_BRUTE_FORCE, KNHIP_IVF_FLAT, KNHIP_IVF_SQ8, KNHIP_IVF_PQ with m = 32; nlist <= 65536.
- * Others return KNHIP_ERR_NOT_IMPLEMENTED. */
+ * Supported: KNHIP_BRUTE_FORCE, KNHIP_IVF_FLAT, KNHIP_IVF_SQ8, KNHIP_IVF_PQ (any m x 8 bit); nlist <= 65536. */
 int knhip_range_search(const knhip_index* idx, const float* queries, int64_t nq, float radius,
                        int32_t max_empty_result_buckets, const uint8_t* bitset, int64_t bitset_nbits, int64_t* lims,
                        int64_t** out_ids, float** out_dist);
+/* Coarse ranks the last knhip_range_search on this index scanned per query (its last batch): the IVF kinds probe in
+ * waves of ranks (64, 128, 256, ...) and stop once every query has met the reference's early stop, so the cost follows
+ * max_empty_result_buckets instead of nlist.  nlist when every list was scanned (max_empty = 0, or nlist <= 128). */
+int64_t knhip_index_last_range_ranks(const knhip_index* idx);
 void knhip_free(void* p);
 
 /* ---- search ---- */

@@ -40,7 +40,7 @@ SYMBOLS = [
     "knhip_index_destroy", "knhip_index_set_coarse", "knhip_index_set_pq", "knhip_index_set_sq", "knhip_index_set_row_scale", "knhip_index_add_assigned_by", "knhip_index_get_desc",
     "knhip_index_add_lists", "knhip_index_add_vectors", "knhip_index_set_coarse_device",
     "knhip_index_set_lists_device", "knhip_index_add_vectors_device", "knhip_index_count",
-    "knhip_index_device_bytes", "knhip_index_uses_precomputed_table", "knhip_search",
+    "knhip_index_device_bytes", "knhip_index_uses_precomputed_table", "knhip_index_last_range_ranks", "knhip_search",
     "knhip_search_device", "knhip_coarse_search_device", "knhip_merge_topk_device",
     "knhip_merge_topk_host", "knhip_refine_device", "knhip_fvec_L2sqr_ny", "knhip_fvec_inner_products_ny",
     "knhip_fvec_norms_L2sqr", "knhip_fvec_madd", "knhip_int8_vec_L2sqr_ny",
@@ -100,6 +100,8 @@ def load():
     L.knhip_index_count.argtypes = [vp]
     L.knhip_index_device_bytes.argtypes = [vp]
     L.knhip_index_uses_precomputed_table.argtypes = [vp]
+    L.knhip_index_last_range_ranks.argtypes = [vp]
+    L.knhip_index_last_range_ranks.restype = C.c_int64
     L.knhip_search.argtypes = [vp, vp, i64, i32, i32, vp, i64, vp, vp]
     L.knhip_search_device.argtypes = [vp, vp, i64, i32, i32, vp, i64, vp, vp, vp]
     L.knhip_coarse_search_device.argtypes = [vp, vp, i64, i32, vp, vp, vp]

@@ -429,7 +429,18 @@ struct PqDumpArgs {
     const float* queries;        // [nq][d]                     (RESIDUAL)
 };
 hipError_t launch_pq_adc_dump(const PqDumpArgs& a, int64_t nq, bool is_l2, hipStream_t s);
-hipError_t launch_range_count(const RangeArgs& a, int64_t nq, bool is_l2, int32_t* cnt, hipStream_t s);
+// (rank0, nrank >= 0: one wave of ranks; qstate: queries with qstate[q][1] != 0 are skipped)
+hipError_t launch_range_count(const RangeArgs& a, int64_t nq, bool is_l2, int32_t* cnt, hipStream_t s, int rank0 = 0,
+                              int nrank = -1, const int32_t* qstate = nullptr);
+// rank waves of the range search (range.hip): the wave's lists of the running queries, the early-stop state, and the
+// IVF-Flat dump of a wave
+hipError_t launch_range_wave_gather(const int64_t* keys, const float* cdis, int64_t nq, int nprobe, int r0, int W,
+                                    const int32_t* qstate, int64_t* keys_w, float* cdis_w, hipStream_t s);
+hipError_t launch_range_wave_state(const int32_t* cnt, int64_t nq, int nprobe, int r0, int r1, int max_empty,
+                                   int32_t* qstate, int32_t* alive, hipStream_t s);
+hipError_t launch_range_flat_dump(const FlatScanArgs& a, const int64_t* keys_w, int64_t nq, int W, int64_t nlist,
+                                  const int64_t* seg_col, const int64_t* seg_len, float* dist, int64_t ncol, bool is_l2,
+                                  hipStream_t s);
 hipError_t launch_range_plan(const int32_t* cnt, int64_t nq, int nprobe, int max_empty, int64_t* off, int64_t* total,
                              hipStream_t s);
 hipError_t launch_range_emit(const RangeArgs& a, int64_t nq, bool is_l2, const int64_t* off, const int64_t* qbase,

@@ -119,6 +119,7 @@ struct Workspace {
     DevBuf sel_keys;     // [qb][k]
     DevBuf sel_d;        // [qb][k]
     DevBuf rg_seg, rg_cnt, rg_off, rg_tot, rg_out_i, rg_out_d;  // range search scratch
+    DevBuf rg_state, rg_keys_w, rg_cdis_w;                       // rank waves: {empty run, stopped} per query, the wave's lists
     DevBuf recs4;        // [items] flat work records of the persistent 4-query scan (pq_scan_q4)
     DevBuf q4_ctr;       // [8 * 16] per-XCD item counters
     DevBuf ghist;        // [qb][64] per-query candidate histogram (pq_scan_v2 after a rank-0 phase)
@@ -209,6 +210,7 @@ struct knhip_index {
     int pqf_form = 0;                // KNHIP_PQF_FORM: 0 = chosen per batch by the guard, 1 = half precision, 2 = int8
     mutable bool pqf_ready = false;
     mutable bool pqi_ready = false;
+    mutable int64_t last_range_ranks = 0; // coarse ranks the last range search scanned per query (rank waves)
     mutable int last_pq_form = 0;    // prefilter form of the last search: 0 none (exact kernels), 1 half precision, 2 int8
     mutable DevBuf rows_i;           // token stream of the integer form (stream16i)
     mutable DevBuf rows_r;           // rotated token stream (stream16r)
@@ -1680,6 +1682,10 @@ int64_t knhip_index_device_bytes(const knhip_index* idx) {
     return idx ? idx->device_bytes() : 0;
 }
 
+int64_t knhip_index_last_range_ranks(const knhip_index* idx) {
+    return idx ? idx->last_range_ranks : -1;
+}
+
 int knhip_index_uses_precomputed_table(const knhip_index* idx) {
     return idx ? idx->use_precomp : 0;
 }
@@ -1887,20 +1893,20 @@ static int range_batch(const knhip_index* idx, Workspace* ws, const float* d_q, 
     r.radius = radius;
     r.bitset = d_bitset;
     r.bitset_nbits = nbits;
+    FlatScanArgs fc{};
     if (kind == KNHIP_BRUTE_FORCE || kind == KNHIP_IVF_FLAT) {
-        FlatScanArgs c{};
-        c.rows = idx->rows.as<float4>();
-        c.nrows = ncol;
-        c.chunk_rows = std::max<int64_t>(1024, round_up((ncol + 1023) / 1024, 64));
-        c.d = d;
-        c.nchunk = (d + 3) / 4;
-        c.queries = d_q;
-        c.nq = nq;
-        c.row_scale = idx->row_scale.as<float>();
-        c.cos_mode = idx->cos_mode;
-        HIP_TRY(launch_flat_full(c, is_l2, ws->dump.as<float>(), nullptr, 0, nullptr, s));
+        fc.rows = idx->rows.as<float4>();
+        fc.nrows = ncol;
+        fc.chunk_rows = std::max<int64_t>(1024, round_up((ncol + 1023) / 1024, 64));
+        fc.d = d;
+        fc.nchunk = (d + 3) / 4;
+        fc.queries = d_q;
+        fc.nq = nq;
+        fc.row_scale = idx->row_scale.as<float>();
+        fc.cos_mode = idx->cos_mode;
     }
     if (kind == KNHIP_BRUTE_FORCE) {
+        HIP_TRY(launch_flat_full(fc, is_l2, ws->dump.as<float>(), nullptr, 0, nullptr, s));
         r.ids = nullptr;
         r.id_offset = idx->id_offset;
         r.order = nullptr;
@@ -1914,43 +1920,46 @@ static int range_batch(const knhip_index* idx, Workspace* ws, const float* d_q, 
         r.ids = idx->ids.as<int64_t>();
         r.order = ws->keys.as<int64_t>();
     }
-    if (kind == KNHIP_IVF_PQ && !(idx->pq_v2 && idx->desc.pq_m == 32)) {
-        // code widths without a dump mode in the fast ADC kernels: the plain exact ADC kernel of range.hip
-        const int M = idx->desc.pq_m;
-        const int mode = !is_l2 ? PQ_LUT_IP : (idx->use_precomp ? PQ_LUT_PRECOMP : PQ_LUT_RESIDUAL);
-        if (mode != PQ_LUT_RESIDUAL) {
-            HIP_TRY(ws->t2t.reserve((size_t)nq * 256 * M * sizeof(float)));
-            HIP_TRY(launch_pq_query_table(d_q, idx->cb.as<float>(), d, M, nq, ws->t2t.as<float>(), s));
+    // every distance of the lists keys_w[q][0 .. W) (-1: none) -> dump[q][column]
+    auto scan_dump = [&](const int64_t* keys_w, const float* cdis_w, int W) -> int {
+        if (kind == KNHIP_IVF_FLAT) {
+            if (W == nprobe) {
+                // all lists of every query: the dense all-pairs kernel (rows shared by eight queries)
+                HIP_TRY(launch_flat_full(fc, is_l2, ws->dump.as<float>(), nullptr, 0, nullptr, s));
+            } else {
+                HIP_TRY(launch_range_flat_dump(fc, keys_w, nq, W, idx->nlist, r.seg_col, r.seg_len, ws->dump.as<float>(),
+                                               ncol, is_l2, s));
+            }
+            return KNHIP_OK;
         }
-        PqDumpArgs a{};
-        a.dist = ws->dump.as<float>();
-        a.ncol = ncol;
-        a.keys = ws->keys.as<int64_t>();
-        a.coarse_dis = ws->cdis.as<float>();
-        a.nprobe = nprobe;
-        a.nlist = idx->nlist;
-        a.list_len = idx->d_list_len.as<int64_t>();
-        a.list_row_off = idx->d_list_row_off.as<int64_t>();
-        a.codes = idx->codes_aos.as<uint8_t>();
-        a.M = M;
-        a.d = d;
-        a.lut_mode = mode;
-        a.t2t = ws->t2t.as<float>();
-        a.precomp_t = idx->precomp_t.as<float>();
-        a.cb = idx->cb.as<float>();
-        a.centroids = idx->centroids.as<float>();
-        a.queries = d_q;
-        HIP_TRY(launch_pq_adc_dump(a, nq, is_l2, s));
-    } else if (kind == KNHIP_IVF_PQ) {
-        const int M = idx->desc.pq_m;
-        const int mode = !is_l2 ? PQ_LUT_IP : (idx->use_precomp ? PQ_LUT_PRECOMP : PQ_LUT_RESIDUAL);
-        if (mode != PQ_LUT_RESIDUAL) {
-            HIP_TRY(ws->t2t.reserve((size_t)nq * 256 * M * sizeof(float)));
-            HIP_TRY(launch_pq_query_table(d_q, idx->cb.as<float>(), d, M, nq, ws->t2t.as<float>(), s));
-        }
-        const int qg = pq_scan_qg(M);
         const int64_t nlist = idx->nlist;
-        const int64_t npairs = nq * nprobe;
+        const int64_t npairs = nq * W;
+        if (kind == KNHIP_IVF_PQ && !(idx->pq_v2 && idx->desc.pq_m == 32)) {
+            // code widths without a dump mode in the fast ADC kernels: the plain exact ADC kernel of range.hip
+            const int M = idx->desc.pq_m;
+            const int mode = !is_l2 ? PQ_LUT_IP : (idx->use_precomp ? PQ_LUT_PRECOMP : PQ_LUT_RESIDUAL);
+            PqDumpArgs a{};
+            a.dist = ws->dump.as<float>();
+            a.ncol = ncol;
+            a.keys = keys_w;
+            a.coarse_dis = cdis_w;
+            a.nprobe = W;
+            a.nlist = nlist;
+            a.list_len = idx->d_list_len.as<int64_t>();
+            a.list_row_off = idx->d_list_row_off.as<int64_t>();
+            a.codes = idx->codes_aos.as<uint8_t>();
+            a.M = M;
+            a.d = d;
+            a.lut_mode = mode;
+            a.t2t = ws->t2t.as<float>();
+            a.precomp_t = idx->precomp_t.as<float>();
+            a.cb = idx->cb.as<float>();
+            a.centroids = idx->centroids.as<float>();
+            a.queries = d_q;
+            HIP_TRY(launch_pq_adc_dump(a, nq, is_l2, s));
+            return KNHIP_OK;
+        }
+        const int qg = kind == KNHIP_IVF_PQ ? pq_scan_qg(idx->desc.pq_m) : 8;
         const int64_t items_bound = round_up(npairs / qg + std::min<int64_t>(2 * nlist, npairs) + 1, 8);
         HIP_TRY(ws->list_count.reserve((size_t)2 * nlist * sizeof(int32_t)));
         HIP_TRY(ws->list_cursor.reserve((size_t)2 * nlist * sizeof(int32_t)));
@@ -1970,91 +1979,116 @@ static int range_batch(const knhip_index* idx, Workspace* ws, const float* d_q, 
         wt.items = ws->items.as<KnItem>();
         wt.nitems = ws->nitems.as<int64_t>();
         wt.scan_bytes = idx->scan_bytes_dev.as<double>();
-        HIP_TRY(launch_build_worktable(ws->keys.as<int64_t>(), nq, nprobe, nlist, qg, qg, idx->d_list_len.as<int64_t>(),
-                                       idx->code_size, wt, s));
-        PqScanArgs a{};
-        a.codes_skew = idx->rows2.as<uint4>();
-        a.list_sblk_off = idx->d_list_blk_off2.as<int64_t>();
-        a.list_len = idx->d_list_len.as<int64_t>();
-        a.list_row_off = idx->d_list_row_off.as<int64_t>();
-        a.ids = idx->ids.as<int64_t>();
-        a.precomp_t = idx->precomp_t.as<float>();
-        a.cb = idx->cb.as<float>();
-        a.centroids = idx->centroids.as<float>();
-        a.d = d;
-        a.lut_mode = mode;
-        a.queries = d_q;
-        a.t2t = ws->t2t.as<float>();
-        a.coarse_dis = ws->cdis.as<float>();
-        a.items = wt.items;
-        a.pairs = wt.pairs;
-        a.nitems_dev = wt.nitems;
-        a.bitset = d_bitset;
-        a.bitset_nbits = nbits;
-        a.gthr = ws->gthr.as<float>();
-        a.nslot = nprobe;
-        a.k = 1;
-        a.item_lo = nullptr;
-        a.item_hi = wt.nitems;
-        a.dump = ws->dump.as<float>();
-        a.dump_stride = ncol;
-        a.dump_by_row = 1;
-        HIP_TRY(launch_pq_scan_v2(a, is_l2, true, items_bound, s));
+        HIP_TRY(launch_build_worktable(keys_w, nq, W, nlist, qg, qg, idx->d_list_len.as<int64_t>(), idx->code_size, wt, s));
+        if (kind == KNHIP_IVF_PQ) {
+            const int mode = !is_l2 ? PQ_LUT_IP : (idx->use_precomp ? PQ_LUT_PRECOMP : PQ_LUT_RESIDUAL);
+            PqScanArgs a{};
+            a.codes_skew = idx->rows2.as<uint4>();
+            a.list_sblk_off = idx->d_list_blk_off2.as<int64_t>();
+            a.list_len = idx->d_list_len.as<int64_t>();
+            a.list_row_off = idx->d_list_row_off.as<int64_t>();
+            a.ids = idx->ids.as<int64_t>();
+            a.precomp_t = idx->precomp_t.as<float>();
+            a.cb = idx->cb.as<float>();
+            a.centroids = idx->centroids.as<float>();
+            a.d = d;
+            a.lut_mode = mode;
+            a.queries = d_q;
+            a.t2t = ws->t2t.as<float>();
+            a.coarse_dis = cdis_w;
+            a.items = wt.items;
+            a.pairs = wt.pairs;
+            a.nitems_dev = wt.nitems;
+            a.bitset = d_bitset;
+            a.bitset_nbits = nbits;
+            a.gthr = ws->gthr.as<float>();
+            a.nslot = W;
+            a.k = 1;
+            a.item_lo = nullptr;
+            a.item_hi = wt.nitems;
+            a.dump = ws->dump.as<float>();
+            a.dump_stride = ncol;
+            a.dump_by_row = 1;
+            HIP_TRY(launch_pq_scan_v2(a, is_l2, true, items_bound, s));
+        } else {
+            SqScanArgs a{};
+            a.rows = idx->rows.as<uint4>();
+            a.list_blk_off = idx->d_list_blk_off.as<int64_t>();
+            a.list_len = idx->d_list_len.as<int64_t>();
+            a.list_row_off = idx->d_list_row_off.as<int64_t>();
+            a.ids = idx->ids.as<int64_t>();
+            a.trained = idx->sq_trained.as<float>();
+            a.centroids = idx->centroids.as<float>();
+            a.d = d;
+            a.nchunk16 = (d + 15) / 16;
+            a.queries = d_q;
+            a.coarse_dis = cdis_w;
+            a.items = wt.items;
+            a.pairs = wt.pairs;
+            a.nitems_dev = wt.nitems;
+            a.bitset = d_bitset;
+            a.bitset_nbits = nbits;
+            a.gthr = ws->gthr.as<float>();
+            a.nslot = W;
+            a.k = 1;
+            a.dump = ws->dump.as<float>();
+            a.dump_stride = ncol;
+            HIP_TRY(launch_sq_scan(a, is_l2, items_bound, s));
+        }
+        return KNHIP_OK;
+    };
+    HIP_TRY(ws->rg_cnt.reserve((size_t)nq * nprobe * sizeof(int32_t)));
+    if (kind == KNHIP_IVF_PQ) {
+        const int M = idx->desc.pq_m;
+        const int mode = !is_l2 ? PQ_LUT_IP : (idx->use_precomp ? PQ_LUT_PRECOMP : PQ_LUT_RESIDUAL);
+        if (mode != PQ_LUT_RESIDUAL) {
+            HIP_TRY(ws->t2t.reserve((size_t)nq * 256 * M * sizeof(float)));
+            HIP_TRY(launch_pq_query_table(d_q, idx->cb.as<float>(), d, M, nq, ws->t2t.as<float>(), s));
+        }
     }
-    if (kind == KNHIP_IVF_SQ8) {
-        const int qg = 8;
-        const int64_t nlist = idx->nlist;
-        const int64_t npairs = nq * nprobe;
-        const int64_t items_bound = round_up(npairs / qg + std::min<int64_t>(2 * nlist, npairs) + 1, 8);
-        HIP_TRY(ws->list_count.reserve((size_t)2 * nlist * sizeof(int32_t)));
-        HIP_TRY(ws->list_cursor.reserve((size_t)2 * nlist * sizeof(int32_t)));
-        HIP_TRY(ws->list_pair_off.reserve((size_t)(2 * nlist + 1) * sizeof(int64_t)));
-        HIP_TRY(ws->list_item_off.reserve((size_t)(2 * nlist + 1) * sizeof(int64_t)));
-        HIP_TRY(ws->pairs.reserve((size_t)npairs * sizeof(KnPair)));
-        HIP_TRY(ws->items.reserve((size_t)items_bound * sizeof(KnItem)));
-        HIP_TRY(ws->nitems.reserve(sizeof(int64_t)));
-        HIP_TRY(ws->gthr.reserve((size_t)nq * sizeof(float)));
-        HIP_TRY(launch_fill_f32(ws->gthr.as<float>(), nq, is_l2 ? FLT_MAX : -FLT_MAX, s));
-        WorkTable wt{};
-        wt.list_count = ws->list_count.as<int32_t>();
-        wt.list_cursor = ws->list_cursor.as<int32_t>();
-        wt.list_pair_off = ws->list_pair_off.as<int64_t>();
-        wt.list_item_off = ws->list_item_off.as<int64_t>();
-        wt.pairs = ws->pairs.as<KnPair>();
-        wt.items = ws->items.as<KnItem>();
-        wt.nitems = ws->nitems.as<int64_t>();
-        wt.scan_bytes = idx->scan_bytes_dev.as<double>();
-        HIP_TRY(launch_build_worktable(ws->keys.as<int64_t>(), nq, nprobe, nlist, qg, qg, idx->d_list_len.as<int64_t>(),
-                                       idx->code_size, wt, s));
-        SqScanArgs a{};
-        a.rows = idx->rows.as<uint4>();
-        a.list_blk_off = idx->d_list_blk_off.as<int64_t>();
-        a.list_len = idx->d_list_len.as<int64_t>();
-        a.list_row_off = idx->d_list_row_off.as<int64_t>();
-        a.ids = idx->ids.as<int64_t>();
-        a.trained = idx->sq_trained.as<float>();
-        a.centroids = idx->centroids.as<float>();
-        a.d = d;
-        a.nchunk16 = (d + 15) / 16;
-        a.queries = d_q;
-        a.coarse_dis = ws->cdis.as<float>();
-        a.items = wt.items;
-        a.pairs = wt.pairs;
-        a.nitems_dev = wt.nitems;
-        a.bitset = d_bitset;
-        a.bitset_nbits = nbits;
-        a.gthr = ws->gthr.as<float>();
-        a.nslot = nprobe;
-        a.k = 1;
-        a.dump = ws->dump.as<float>();
-        a.dump_stride = ncol;
-        HIP_TRY(launch_sq_scan(a, is_l2, items_bound, s));
+    bool counted = false;
+    if (kind != KNHIP_BRUTE_FORCE) {
+        const bool waves = max_empty > 0 && nprobe > 128 && getenv("KNHIP_RANGE_NO_WAVES") == nullptr;
+        if (!waves) {
+            if (int rc = scan_dump(ws->keys.as<int64_t>(), ws->cdis.as<float>(), nprobe)) return rc;
+            idx->last_range_ranks = nprobe;
+        } else {
+            // rank waves: 64 coarse ranks first, doubling; a query leaves once its run of empty lists reaches max_empty
+            HIP_TRY(ws->rg_state.reserve(((size_t)nq * 2 + 1) * sizeof(int32_t)));
+            HIP_TRY(hipMemsetAsync(ws->rg_state.p, 0, ((size_t)nq * 2 + 1) * sizeof(int32_t), s));
+            HIP_TRY(hipMemsetAsync(ws->rg_cnt.p, 0, (size_t)nq * nprobe * sizeof(int32_t), s));
+            int32_t* qstate = ws->rg_state.as<int32_t>();
+            int32_t* alive = qstate + 2 * nq;
+            int r0 = 0, W = std::max(64, 2 * max_empty);
+            while (r0 < nprobe) {
+                const int Wc = std::min(W, nprobe - r0);
+                HIP_TRY(ws->rg_keys_w.reserve((size_t)nq * Wc * sizeof(int64_t)));
+                HIP_TRY(ws->rg_cdis_w.reserve((size_t)nq * Wc * sizeof(float)));
+                HIP_TRY(launch_range_wave_gather(ws->keys.as<int64_t>(), ws->cdis.as<float>(), nq, nprobe, r0, Wc, qstate,
+                                                 ws->rg_keys_w.as<int64_t>(), ws->rg_cdis_w.as<float>(), s));
+                if (int rc = scan_dump(ws->rg_keys_w.as<int64_t>(), ws->rg_cdis_w.as<float>(), Wc)) return rc;
+                HIP_TRY(launch_range_count(r, nq, is_l2, ws->rg_cnt.as<int32_t>(), s, r0, Wc, qstate));
+                HIP_TRY(launch_range_wave_state(ws->rg_cnt.as<int32_t>(), nq, nprobe, r0, r0 + Wc, max_empty, qstate, alive,
+                                                s));
+                int32_t h_alive = 0;
+                HIP_TRY(hipMemcpyAsync(&h_alive, alive, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                r0 += Wc;
+                W *= 2;
+                if (h_alive == 0) {
+                    break;
+                }
+            }
+            idx->last_range_ranks = r0;
+            counted = true;
+        }
     }
     // count -> plan -> (host: totals, bases) -> emit
-    HIP_TRY(ws->rg_cnt.reserve((size_t)nq * nprobe * sizeof(int32_t)));
     HIP_TRY(ws->rg_off.reserve((size_t)nq * nprobe * sizeof(int64_t)));
     HIP_TRY(ws->rg_tot.reserve((size_t)nq * 2 * sizeof(int64_t)));
-    HIP_TRY(launch_range_count(r, nq, is_l2, ws->rg_cnt.as<int32_t>(), s));
+    if (!counted) {
+        HIP_TRY(launch_range_count(r, nq, is_l2, ws->rg_cnt.as<int32_t>(), s));
+    }
     HIP_TRY(launch_range_plan(ws->rg_cnt.as<int32_t>(), nq, nprobe, max_empty, ws->rg_off.as<int64_t>(),
                               ws->rg_tot.as<int64_t>(), s));
     std::vector<int64_t> tot((size_t)nq), base((size_t)nq);

@@ -12,6 +12,12 @@
 //   range_count  : hits per (query, probe rank)                      one workgroup per pair
 //   range_plan   : early-stop cut + running offsets per query       one thread per query (nprobe steps)
 //   range_emit   : ordered compaction of the surviving lists         one workgroup per pair
+//
+// Rank waves (IVF kinds with max_empty_result_buckets > 0): range search probes all nlist lists, but the reference stops
+// a query after max_empty consecutive lists without a hit -- usually a few dozen ranks in.  The probes are therefore
+// scanned in waves of coarse ranks [r0, r1) (64 ranks first, doubling): range_wave_gather compacts the wave's lists of
+// the queries still running, the scan kernels dump only those, range_count counts them, range_wave_state advances each
+// query's run of empty lists exactly as the plan kernel will.  The cost follows the early stop instead of nlist.
 #include "common.h"
 #include "kernels.h"
 
@@ -43,10 +49,15 @@ __device__ __forceinline__ bool range_segment(const RangeArgs& a, int64_t q, int
     return *len > 0;
 }
 
+// (rank0, nrank): the ranks counted by this launch -- all of them, or one wave
 template <bool IS_L2>
-__global__ __launch_bounds__(RG_THREADS) void range_count_kernel(RangeArgs a, int32_t* __restrict__ cnt) {
-    const int64_t q = blockIdx.x / a.nprobe;
-    const int rank = (int)(blockIdx.x % a.nprobe);
+__global__ __launch_bounds__(RG_THREADS) void range_count_kernel(RangeArgs a, int32_t* __restrict__ cnt, int rank0,
+                                                                 int nrank, const int32_t* __restrict__ qstate) {
+    const int64_t q = blockIdx.x / nrank;
+    const int rank = rank0 + (int)(blockIdx.x % nrank);
+    if (qstate != nullptr && qstate[q * 2 + 1] != 0) {
+        return; // (stopped before this wave: its lists were not scanned; cnt stays 0 behind the cut)
+    }
     __shared__ int s_tot;
     if (threadIdx.x == 0) {
         s_tot = 0;
@@ -69,7 +80,101 @@ __global__ __launch_bounds__(RG_THREADS) void range_count_kernel(RangeArgs a, in
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        cnt[blockIdx.x] = s_tot;
+        cnt[q * a.nprobe + rank] = s_tot;
+    }
+}
+
+// keys_w[q][j] = list at rank r0 + j of query q (-1: the query has stopped, or the rank does not exist), cdis_w alike
+__global__ void range_wave_gather_kernel(const int64_t* __restrict__ keys, const float* __restrict__ cdis, int64_t nq,
+                                         int nprobe, int r0, int W, const int32_t* __restrict__ qstate,
+                                         int64_t* __restrict__ keys_w, float* __restrict__ cdis_w) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nq * W) {
+        return;
+    }
+    const int64_t q = t / W;
+    const int r = r0 + (int)(t % W);
+    const bool live = r < nprobe && qstate[q * 2 + 1] == 0;
+    keys_w[t] = live ? keys[q * nprobe + r] : -1;
+    cdis_w[t] = live ? cdis[q * nprobe + r] : 0.f;
+}
+
+// qstate[q] = {consecutive empty lists so far, stopped}: the recurrence of range_plan_kernel over ranks [r0, r1);
+// *alive = queries still running after the wave
+__global__ void range_wave_state_kernel(const int32_t* __restrict__ cnt, int64_t nq, int nprobe, int r0, int r1,
+                                        int max_empty, int32_t* __restrict__ qstate, int32_t* __restrict__ alive) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) {
+        return;
+    }
+    int ndup = qstate[q * 2];
+    bool stopped = qstate[q * 2 + 1] != 0;
+    for (int r = r0; r < r1 && !stopped; r++) {
+        const int c = cnt[q * nprobe + r];
+        ndup = c == 0 ? ndup + 1 : 0;
+        stopped = ndup >= max_empty;
+    }
+    qstate[q * 2] = ndup;
+    qstate[q * 2 + 1] = stopped ? 1 : 0;
+    if (!stopped) {
+        atomicAdd(alive, 1);
+    }
+}
+
+// ---- IVF-Flat: exact distances of the wave's lists -> dist[q][column] (the arithmetic of flat_full_kernel, one
+// workgroup per (query, rank of the wave); column = padded position of the row in the interleaved store) --------------
+template <bool IS_L2>
+__global__ __launch_bounds__(RG_THREADS) void range_flat_dump_kernel(FlatScanArgs a, const int64_t* __restrict__ keys_w,
+                                                                     int W, int64_t nlist,
+                                                                     const int64_t* __restrict__ seg_col,
+                                                                     const int64_t* __restrict__ seg_len,
+                                                                     float* __restrict__ dist, int64_t ncol) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int64_t q = blockIdx.x / W;
+    const int64_t key = keys_w[blockIdx.x];
+    if (key < 0 || key >= nlist) {
+        return;
+    }
+    const int64_t len = seg_len[key];
+    if (len <= 0) {
+        return;
+    }
+    const int64_t col0 = seg_col[key]; // (a multiple of 64: lists start on a block)
+    const int dpad = a.nchunk * 4;
+    float* sq = reinterpret_cast<float*>(smem);
+    for (int i = threadIdx.x; i < dpad; i += RG_THREADS) {
+        sq[i] = (i < a.d) ? a.queries[q * a.d + i] : 0.f;
+    }
+    __syncthreads();
+    const int lane = lane_id();
+    const int wave = threadIdx.x / KN_WAVE;
+    const int64_t nblk = (len + 63) / 64;
+    for (int64_t b = wave; b < nblk; b += RG_THREADS / KN_WAVE) {
+        const int64_t row = b * 64 + lane;
+        const float4* p = a.rows + (col0 / 64 + b) * (int64_t)a.nchunk * 64 + lane;
+        float acc = 0.f;
+#pragma unroll 4
+        for (int c = 0; c < a.nchunk; c++) {
+            const float4 y = p[(int64_t)c * 64];
+            const float4 x = *reinterpret_cast<const float4*>(sq + c * 4);
+            if (IS_L2) {
+                acc = l2_step(acc, x.x, y.x);
+                acc = l2_step(acc, x.y, y.y);
+                acc = l2_step(acc, x.z, y.z);
+                acc = l2_step(acc, x.w, y.w);
+            } else {
+                acc = ip_step(acc, x.x, y.x);
+                acc = ip_step(acc, x.y, y.y);
+                acc = ip_step(acc, x.z, y.z);
+                acc = ip_step(acc, x.w, y.w);
+            }
+        }
+        if (row < len) {
+            if (!IS_L2 && a.cos_mode != 0) {
+                acc = cosine_finish(acc, a.row_scale[col0 + row], a.cos_mode);
+            }
+            dist[q * ncol + col0 + row] = acc;
+        }
     }
 }
 
@@ -221,16 +326,66 @@ hipError_t launch_pq_adc_dump(const PqDumpArgs& a, int64_t nq, bool is_l2, hipSt
     return hipGetLastError();
 }
 
-hipError_t launch_range_count(const RangeArgs& a, int64_t nq, bool is_l2, int32_t* cnt, hipStream_t s) {
-    if (nq <= 0 || a.nprobe <= 0) {
+hipError_t launch_range_count(const RangeArgs& a, int64_t nq, bool is_l2, int32_t* cnt, hipStream_t s, int rank0,
+                              int nrank, const int32_t* qstate) {
+    if (nrank < 0) {
+        rank0 = 0;
+        nrank = a.nprobe;
+    }
+    nrank = std::min(nrank, a.nprobe - rank0);
+    if (nq <= 0 || nrank <= 0) {
         return hipSuccess;
     }
-    const unsigned grid = (unsigned)(nq * a.nprobe);
+    const unsigned grid = (unsigned)(nq * nrank);
     if (is_l2) {
-        hipLaunchKernelGGL((range_count_kernel<true>), dim3(grid), dim3(RG_THREADS), 0, s, a, cnt);
+        hipLaunchKernelGGL((range_count_kernel<true>), dim3(grid), dim3(RG_THREADS), 0, s, a, cnt, rank0, nrank, qstate);
     } else {
-        hipLaunchKernelGGL((range_count_kernel<false>), dim3(grid), dim3(RG_THREADS), 0, s, a, cnt);
+        hipLaunchKernelGGL((range_count_kernel<false>), dim3(grid), dim3(RG_THREADS), 0, s, a, cnt, rank0, nrank, qstate);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_range_wave_gather(const int64_t* keys, const float* cdis, int64_t nq, int nprobe, int r0, int W,
+                                    const int32_t* qstate, int64_t* keys_w, float* cdis_w, hipStream_t s) {
+    if (nq <= 0 || W <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(range_wave_gather_kernel, dim3((unsigned)((nq * W + 255) / 256)), dim3(256), 0, s, keys, cdis, nq,
+                       nprobe, r0, W, qstate, keys_w, cdis_w);
+    return hipGetLastError();
+}
+
+hipError_t launch_range_wave_state(const int32_t* cnt, int64_t nq, int nprobe, int r0, int r1, int max_empty,
+                                   int32_t* qstate, int32_t* alive, hipStream_t s) {
+    if (nq <= 0) {
+        return hipSuccess;
+    }
+    hipError_t e = hipMemsetAsync(alive, 0, sizeof(int32_t), s);
+    if (e != hipSuccess) {
+        return e;
+    }
+    hipLaunchKernelGGL(range_wave_state_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, s, cnt, nq, nprobe, r0,
+                       std::min(r1, nprobe), max_empty, qstate, alive);
+    return hipGetLastError();
+}
+
+hipError_t launch_range_flat_dump(const FlatScanArgs& a, const int64_t* keys_w, int64_t nq, int W, int64_t nlist,
+                                  const int64_t* seg_col, const int64_t* seg_len, float* dist, int64_t ncol, bool is_l2,
+                                  hipStream_t s) {
+    if (nq <= 0 || W <= 0) {
+        return hipSuccess;
+    }
+    const size_t sm = (size_t)a.nchunk * 4 * sizeof(float);
+    auto kern = is_l2 ? range_flat_dump_kernel<true> : range_flat_dump_kernel<false>;
+    if (sm > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        if (e != hipSuccess) {
+            return e;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nq * W)), dim3(RG_THREADS), sm, s, a, keys_w, W, nlist, seg_col, seg_len,
+                       dist, ncol);
     return hipGetLastError();
 }
 

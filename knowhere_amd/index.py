@@ -223,6 +223,10 @@ class GpuIndex:
         check(self.L.knhip_search(self.h, _np_ptr(xq), nq, k, nprobe, _np_ptr(bs), nbits, _np_ptr(I), _np_ptr(D)))
         return D, I
 
+    def last_range_ranks(self):
+        """coarse ranks per query the last range_search scanned (rank waves: knhip_index_last_range_ranks)"""
+        return int(self.L.knhip_index_last_range_ranks(self.h))
+
     def range_search(self, xq, radius, max_empty_result_buckets=2, bitset=None, nbits=0):
         """-> (lims[nq + 1], ids, distances) in the reference's emission order (include/knhip.h)"""
         xq = np.ascontiguousarray(xq, np.float32)

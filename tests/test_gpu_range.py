@@ -106,6 +106,41 @@ def test_ivf_range_early_stop_changes_the_result(port):
         assert set(one[1][one[0][q]:one[0][q + 1]].tolist()) <= set(full[1][full[0][q]:full[0][q + 1]].tolist())
 
 
+@pytest.mark.parametrize("kind,M,d", [(ob.IVF_FLAT, 0, 24), (ob.IVF_SQ8, 0, 40), (ob.IVF_PQ, 32, 128), (ob.IVF_PQ, 8, 32)],
+                         ids=["ivfflat", "ivfsq8", "ivfpq32", "ivfpq8"])
+@pytest.mark.parametrize("metric", [ob.L2, ob.IP], ids=["l2", "ip"])
+def test_ivf_range_rank_waves(port, kind, M, d, metric, monkeypatch):
+    """nlist > 128: the probes go in waves of coarse ranks (64, 128, ...) and the scan stops once every query has met
+    the early stop.  Same lims / ids / order / bits as the oracle (which walks all nlist ranks), the same as the
+    one-wave path, and -- for a small max_empty -- far fewer ranks scanned than nlist."""
+    nb, nq, nlist = 30000, 37, 600
+    xb, xq = gen_data(nb, d, 42), gen_data(nq, d, 44)
+    ix = finish_ivfpq(port, ob.make_index(port, kind, metric, xb, nlist=nlist, M=max(M, 1), nbits=8))
+    g = _gpu(ix)
+    bs = _bitset(nb, 0.4, 7)
+    radii = _radii(port, ix, xq, metric, nlist)
+    total = 0
+    for radius in radii[1:]:
+        for max_empty in (1, 2, 40, 0):
+            for bitset in (None, bs):
+                nbits = nb if bitset is not None else 0
+                exp = port.range_search(ix, xq, radius, max_empty, bitset, nbits)
+                got = g.range_search(xq, radius, max_empty, bitset, nbits)
+                ranks = g.last_range_ranks()
+                _same(exp, got, f"kind={kind} radius={radius} max_empty={max_empty} bitset={bitset is not None}")
+                total += int(exp[0][-1])
+                if max_empty == 0:
+                    assert ranks == nlist  # (no early stop: one pass over every list)
+                elif max_empty <= 2:
+                    assert ranks < nlist, f"max_empty={max_empty}: all {ranks} ranks were scanned"
+                monkeypatch.setenv("KNHIP_RANGE_NO_WAVES", "1")
+                one = g.range_search(xq, radius, max_empty, bitset, nbits)
+                monkeypatch.delenv("KNHIP_RANGE_NO_WAVES")
+                assert g.last_range_ranks() == nlist or max_empty == 0
+                _same(one, got, "waves vs one pass")
+    assert total > 0
+
+
 def test_range_unsupported_and_edge_cases(port):
     nb, d = 3000, 16
     xb, xq = gen_data(nb, d, 1), gen_data(5, d, 2)
