@@ -273,8 +273,11 @@ __global__ __launch_bounds__(256) void coarse_rerank_kernel(
             }
         }
         fail_flags[q] = fail;
-        if (fail && nfail != nullptr) {
-            atomicAdd(nfail, 1ull);
+        if (fail) {
+            fail_flags[gridDim.x] = 1; // (summary entry [nq]: the fallback kernel returns at once while it is 0)
+            if (nfail != nullptr) {
+                atomicAdd(nfail, 1ull);
+            }
         }
     }
 }
@@ -325,6 +328,10 @@ hipError_t launch_coarse_rerank(const float* queries, const float* centroids, in
         if (e != hipSuccess) {
             return e;
         }
+    }
+    hipError_t e0 = hipMemsetAsync(fail_flags + nq, 0, sizeof(int32_t), s); // fail_flags: [nq + 1], the last = any flag
+    if (e0 != hipSuccess) {
+        return e0;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nq), dim3(256), sm, s, queries, centroids, d, nlist, ncand, kp,
                        cand_keys, cand_approx, nprobe, qnorm, cnorm_max, out_keys, out_d, fail_flags, nfail);

@@ -269,7 +269,15 @@ __global__ __launch_bounds__(FS_THREADS) void flat_full_kernel(FlatScanArgs a, f
     const int dpad = a.nchunk * 4;
     const int64_t nq = q_subset ? nq_subset : a.nq;
     const int64_t ngroups = (nq + QG - 1) / QG;
-    const int64_t item = blockIdx.x;
+    // With row flags (the exact fallback of the MFMA prefilter) the grid is small and walks the items: row_flags[a.nq] is
+    // the "any query flagged" summary -- normally 0, and the launch then costs a few hundred workgroups that return at once
+    // instead of one per item (0.16 ms of the C3 coarse stage in the round-2 profile).
+    if (row_flags != nullptr && row_flags[a.nq] == 0) {
+        return;
+    }
+    const int64_t nitems = ngroups * ((a.nrows + a.chunk_rows - 1) / a.chunk_rows);
+    for (int64_t item = blockIdx.x; item < nitems; item += gridDim.x) {
+    __syncthreads(); // (the query tile in LDS is rewritten per item)
     const int64_t chunk = item / ngroups;
     const int64_t g = item % ngroups;
     const int64_t row_base = chunk * a.chunk_rows;
@@ -289,7 +297,7 @@ __global__ __launch_bounds__(FS_THREADS) void flat_full_kernel(FlatScanArgs a, f
             any |= (j < npair) && row_flags[q_of[j]] != 0;
         }
         if (!any) {
-            return;
+            continue;
         }
     }
     float* sq = reinterpret_cast<float*>(smem);
@@ -342,6 +350,7 @@ __global__ __launch_bounds__(FS_THREADS) void flat_full_kernel(FlatScanArgs a, f
             }
         }
     }
+    } // items
 }
 
 // ---- row-major [n][d] -> interleaved blocks -------------------------------------------------
@@ -489,8 +498,9 @@ hipError_t launch_flat_full(const FlatScanArgs& a, bool is_l2, float* out, const
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(ngroups * nchunks)), dim3(FS_THREADS), sm, s, a, out,
-                       q_subset, nq_subset, row_flags);
+    // (row_flags: [nq + 1], the last entry = any flag set; the grid then walks the items)
+    const int64_t grid = row_flags != nullptr ? std::min<int64_t>(ngroups * nchunks, 512) : ngroups * nchunks;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(FS_THREADS), sm, s, a, out, q_subset, nq_subset, row_flags);
     return hipGetLastError();
 }
 

@@ -338,7 +338,7 @@ int coarse_stage(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
     HIP_TRY(ws->qnorm.reserve((size_t)nq * sizeof(float)));
     HIP_TRY(ws->cand_keys.reserve((size_t)nq * ncand * sizeof(int64_t)));
     HIP_TRY(ws->cand_approx.reserve((size_t)nq * ncand * sizeof(float)));
-    HIP_TRY(ws->fail_flags.reserve((size_t)nq * sizeof(int32_t)));
+    HIP_TRY(ws->fail_flags.reserve(((size_t)nq + 1) * sizeof(int32_t))); // (+ the "any flag" summary)
     HIP_TRY(launch_row_norms(d_q, nq, d, ws->qnorm.as<float>(), s));
     HIP_TRY(launch_coarse_gemm(d_q, ws->qnorm.as<float>(), idx->centroids.as<float>(), idx->cnorm.as<float>(), nq,
                                nlist, d, is_l2, ws->coarse_full.as<float>(), s));

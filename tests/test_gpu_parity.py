@@ -89,6 +89,29 @@ def test_coarse(torch_cuda, port, metric):
     g.close()
 
 
+@pytest.mark.parametrize("metric", [ob.L2, ob.IP])
+def test_coarse_certificate_fallback(torch_cuda, port, metric):
+    """many identical centroids: the nprobe-th and the (nprobe + margin)-th prefilter values tie, the certificate of the
+    MFMA prefilter cannot hold, and the flagged queries go through the exact fallback (flat_full restricted by the flags
+    + their "any flag" summary).  Same keys and distances as the oracle; the fallback really ran."""
+    torch = torch_cuda
+    rng = np.random.default_rng(3)
+    xb = gen_data(6000, 64, 42)
+    xb[:4500] = xb[rng.integers(4500, 4502, 4500)]  # three quarters of the rows are copies of two vectors: ~110 of
+    # the 300 sampled centroids are copies of each -- more than nprobe + margin
+    xq = np.concatenate([xb[4500:4502] + 0.01 * gen_data(2, 64, 45), gen_data(30, 64, 44)]).astype(np.float32)
+    ix = ob.make_index(port, ob.IVF_FLAT, metric, xb, nlist=300)
+    g = _gpu(ix)
+    g.profile_reset()
+    for nprobe in (8, 32, 64, 128):
+        Do, Io = port.coarse_search(ix, xq, nprobe)
+        D, I = g.coarse_search_device(torch.from_numpy(xq).cuda(), nprobe)
+        torch.cuda.synchronize()
+        assert_parity(Do, Io, D.cpu().numpy(), I.cpu().numpy(), metric, f"coarse ties nprobe={nprobe}")
+    assert g.profile_get()["coarse_fallback_queries"] > 0
+    g.close()
+
+
 KINDS = [(ob.IVF_FLAT, 0), (ob.IVF_PQ, 8), (ob.IVF_PQ, 16), (ob.IVF_PQ, 32), (ob.IVF_PQ, 64), (ob.IVF_SQ8, 0)]
 
 
