@@ -275,8 +275,8 @@ hipError_t launch_pqf_query_table(const float* queries, const float4* cb_m, int 
                                   void* qh, float* qs, hipStream_t s);
 // selectivity guard: *poor = queries whose predicted candidate count exceeds half the capacity
 hipError_t launch_pqf_predict(const float* dump, int64_t stride, const int32_t* n_row, const float* gthr, const float* qs,
-                              const int64_t* keys, int nprobe, int64_t nlist, const int64_t* list_len, int64_t nq, int cap,
-                              int k, bool is_l2, int32_t* poor, hipStream_t s);
+                              const float* qs2, const int64_t* keys, int nprobe, int64_t nlist, const int64_t* list_len,
+                              int64_t nq, int cap, int k, bool is_l2, int32_t* poor, hipStream_t s);
 size_t pqf_smem();
 // integer form: 16 queries per unit, int8 tables, v_mfma_i32_16x16x64_i8
 hipError_t launch_pq_stream16i(const uint8_t* codes, const int64_t* list_row_off, const int64_t* list_len,

@@ -1054,13 +1054,9 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
                 if (idx->pqf_guard) {
                     int32_t* poor = ws->ms_cand_cnt.as<int32_t>() + 2 * nq + 1;
                     HIP_TRY(launch_pqf_predict(ws->dump.as<float>(), sample, ws->ms_nrow.as<int32_t>(),
-                                               ws->gthr.as<float>(), ws->ms_qs.as<float>(), keys_p, nprobe, nlist,
+                                               ws->gthr.as<float>(), ws->ms_qs.as<float>(),
+                                               want_i8 ? ws->ms_qis.as<float>() : nullptr, keys_p, nprobe, nlist,
                                                idx->d_list_len.as<int64_t>(), nq, ms_cap, k, is_l2, poor, s));
-                    if (want_i8) {
-                        HIP_TRY(launch_pqf_predict(ws->dump.as<float>(), sample, ws->ms_nrow.as<int32_t>(),
-                                                   ws->gthr.as<float>(), ws->ms_qis.as<float>(), keys_p, nprobe, nlist,
-                                                   idx->d_list_len.as<int64_t>(), nq, ms_cap, k, is_l2, poor + 1, s));
-                    }
                     HIP_TRY(hipMemcpyAsync(h_poor, poor, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
                     HIP_TRY(hipStreamSynchronize(s));
                     if ((int64_t)h_poor[0] * 4 > nq) {

@@ -835,9 +835,10 @@ __global__ __launch_bounds__(PF_THREADS) void pqf_kernel(MScanArgs a) {
 template <bool IS_L2>
 __global__ __launch_bounds__(256) void pqf_predict_kernel(const float* __restrict__ dump, int64_t stride,
                                                           const int32_t* __restrict__ n_row, const float* __restrict__ gthr,
-                                                          const float* __restrict__ qs, const int64_t* __restrict__ keys,
-                                                          int nprobe, int64_t nlist, const int64_t* __restrict__ list_len,
-                                                          int64_t nq, int cap, int k, int32_t* __restrict__ poor) {
+                                                          const float* __restrict__ qs, const float* __restrict__ qs2,
+                                                          const int64_t* __restrict__ keys, int nprobe, int64_t nlist,
+                                                          const int64_t* __restrict__ list_len, int64_t nq, int cap, int k,
+                                                          int32_t* __restrict__ poor) {
     const int lane = lane_id();
     const int64_t q = (int64_t)blockIdx.x * (blockDim.x / KN_WAVE) + threadIdx.x / KN_WAVE;
     if (q >= nq) {
@@ -848,12 +849,16 @@ __global__ __launch_bounds__(256) void pqf_predict_kernel(const float* __restric
     if (tau == worst_dist<IS_L2>() || n <= 0) {
         return; // (no bound: the query takes the exact kernels on its own)
     }
+    // one pass over the query's sample for both forms (qs: half precision -> poor[0]; qs2, when given: integer -> poor[1])
     const float eps = qs[q * 4 + 2] + 64.0f * PF_U * fabsf(tau);
     const float lim = IS_L2 ? tau + 2.0f * eps : tau - 2.0f * eps;
-    float cnt = 0.f, rows = 0.f;
+    const float eps2 = qs2 != nullptr ? qs2[q * 4 + 2] + 64.0f * PF_U * fabsf(tau) : 0.f;
+    const float lim2 = IS_L2 ? tau + 2.0f * eps2 : tau - 2.0f * eps2;
+    float cnt = 0.f, cnt2 = 0.f, rows = 0.f;
     for (int i = lane; i < n; i += KN_WAVE) {
         const float v = dump[q * stride + i];
         cnt += (IS_L2 ? (v > tau && v <= lim) : (v < tau && v >= lim)) ? 1.f : 0.f;
+        cnt2 += (IS_L2 ? (v > tau && v <= lim2) : (v < tau && v >= lim2)) ? 1.f : 0.f;
     }
     for (int sl = lane; sl < nprobe; sl += KN_WAVE) {
         const int64_t key = keys[q * nprobe + sl];
@@ -862,27 +867,35 @@ __global__ __launch_bounds__(256) void pqf_predict_kernel(const float* __restric
 #pragma unroll
     for (int dlt = KN_WAVE / 2; dlt > 0; dlt >>= 1) {
         cnt += __shfl_xor(cnt, dlt, KN_WAVE);
+        cnt2 += __shfl_xor(cnt2, dlt, KN_WAVE);
         rows += __shfl_xor(rows, dlt, KN_WAVE);
     }
-    if (lane == 0 && (float)k + cnt / (float)n * rows > 0.5f * (float)cap) {
-        atomicAdd(poor, 1);
+    if (lane == 0) {
+        if ((float)k + cnt / (float)n * rows > 0.5f * (float)cap) {
+            atomicAdd(poor, 1);
+        }
+        if (qs2 != nullptr && (float)k + cnt2 / (float)n * rows > 0.5f * (float)cap) {
+            atomicAdd(poor + 1, 1);
+        }
     }
 }
 
+// poor[0]: queries the half-precision form (records qs) would overflow; poor[1]: the same for the records qs2 (integer
+// form; nullptr: not evaluated, poor[1] = 0)
 hipError_t launch_pqf_predict(const float* dump, int64_t stride, const int32_t* n_row, const float* gthr, const float* qs,
-                              const int64_t* keys, int nprobe, int64_t nlist, const int64_t* list_len, int64_t nq, int cap,
-                              int k, bool is_l2, int32_t* poor, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(poor, 0, sizeof(int32_t), s);
+                              const float* qs2, const int64_t* keys, int nprobe, int64_t nlist, const int64_t* list_len,
+                              int64_t nq, int cap, int k, bool is_l2, int32_t* poor, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(poor, 0, 2 * sizeof(int32_t), s);
     if (e != hipSuccess || nq <= 0) {
         return e;
     }
     const unsigned grid = (unsigned)((nq + 3) / 4);
     if (is_l2) {
-        hipLaunchKernelGGL(pqf_predict_kernel<true>, dim3(grid), dim3(256), 0, s, dump, stride, n_row, gthr, qs, keys, nprobe,
-                           nlist, list_len, nq, cap, k, poor);
+        hipLaunchKernelGGL(pqf_predict_kernel<true>, dim3(grid), dim3(256), 0, s, dump, stride, n_row, gthr, qs, qs2, keys,
+                           nprobe, nlist, list_len, nq, cap, k, poor);
     } else {
-        hipLaunchKernelGGL(pqf_predict_kernel<false>, dim3(grid), dim3(256), 0, s, dump, stride, n_row, gthr, qs, keys, nprobe,
-                           nlist, list_len, nq, cap, k, poor);
+        hipLaunchKernelGGL(pqf_predict_kernel<false>, dim3(grid), dim3(256), 0, s, dump, stride, n_row, gthr, qs, qs2, keys,
+                           nprobe, nlist, list_len, nq, cap, k, poor);
     }
     return hipGetLastError();
 }

@@ -172,10 +172,10 @@ extern "C" int emu_pqf_search(int64_t nlist, const int64_t* list_len, const int6
         tau_out[q] = gthr[(size_t)q];
     }
     {   // the selectivity guard's prediction (the product abandons the prefilter for a batch on it; here it is reported)
-        int32_t poor = 0;
-        if (launch_pqf_predict(dump.data(), sample, n_row.data(), gthr.data(), qs.data(), keys, nprobe, nlist, list_len, nq, cap,
-                               k, l2, &poor, nullptr) != hipSuccess) return 11;
-        *poor_out = poor;
+        int32_t poor[2] = {0, 0};
+        if (launch_pqf_predict(dump.data(), sample, n_row.data(), gthr.data(), qs.data(), nullptr, keys, nprobe, nlist, list_len,
+                               nq, cap, k, l2, poor, nullptr) != hipSuccess) return 11;
+        *poor_out = poor[0];
     }
     if (use_hist) {
         m.ghist = ghist.data();
