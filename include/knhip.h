@@ -234,7 +234,9 @@ int knhip_search(const knhip_index* idx, const float* queries, int64_t nq, int32
 int knhip_search_refine(const knhip_index* idx, const knhip_index* raw, const float* queries, int64_t nq, int32_t k,
                         int32_t k_base, int32_t nprobe, const uint8_t* bitset, int64_t bitset_nbits, int64_t* out_ids,
                         float* out_dist);
-/* rows of a BRUTE_FORCE index by id (IndexNode::GetVectorByIds); out [n][dim] host */
+/* rows by id (IndexNode::GetVectorByIds); out [n][dim] host.  BRUTE_FORCE: row = id - id_offset.  IVF_FLAT: through a
+ * direct map built on first use from the index's own ids (16 bytes per vector in HBM; the reference's
+ * make_direct_map / reconstruct, thirdparty/faiss/faiss/IndexIVF.cpp); an id that is not stored is an error. */
 int knhip_index_get_vectors(const knhip_index* idx, int64_t n, const int64_t* ids, float* out);
 /* Same with every buffer already in HBM; enqueued on `stream` (hipStream_t, NULL = default
  * stream) and NOT synchronised at the end.  One exception inside: an IVF_PQ m = 32 batch that takes the matrix-core

@@ -43,6 +43,95 @@ hipError_t launch_gather_rows(const float* x, const int64_t* rows, int64_t n, in
     return hipGetLastError();
 }
 
+// ---- direct map of an IVF-Flat index: id -> column of the interleaved store (GetVectorByIds) ------------------------
+// col[p] for storage position p (list-sorted order): 64 * first block of its list + offset inside the list
+__global__ void idmap_cols_kernel(const int64_t* __restrict__ list_row_off, const int64_t* __restrict__ list_blk_off,
+                                  int64_t nlist, int64_t ntotal, int64_t* __restrict__ col) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= ntotal) {
+        return;
+    }
+    int64_t lo = 0, hi = nlist - 1; // the last list whose first row is <= p (empty lists share their successor's offset)
+    while (lo < hi) {
+        const int64_t mid = (lo + hi + 1) >> 1;
+        if (list_row_off[mid] <= p) {
+            lo = mid;
+        } else {
+            hi = mid - 1;
+        }
+    }
+    col[p] = list_blk_off[lo] * 64 + (p - list_row_off[lo]);
+}
+
+// one thread per (requested id, chunk of 4 dims): binary search in the sorted ids, then the 16-byte piece of the row
+__global__ void idmap_gather_kernel(const int64_t* __restrict__ want, int64_t n, const int64_t* __restrict__ ids_sorted,
+                                    const int64_t* __restrict__ col_sorted, int64_t ntotal,
+                                    const float4* __restrict__ rows, int d, int nchunk, float* __restrict__ out,
+                                    int32_t* __restrict__ missing) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * nchunk) {
+        return;
+    }
+    const int64_t i = t / nchunk;
+    const int c = (int)(t % nchunk);
+    const int64_t id = want[i];
+    int64_t lo = 0, hi = ntotal;
+    while (lo < hi) { // first entry >= id
+        const int64_t mid = (lo + hi) >> 1;
+        if (ids_sorted[mid] < id) {
+            lo = mid + 1;
+        } else {
+            hi = mid;
+        }
+    }
+    if (lo >= ntotal || ids_sorted[lo] != id) {
+        if (c == 0) {
+            atomicAdd(missing, 1);
+        }
+        return;
+    }
+    const int64_t col = col_sorted[lo];
+    const float4 v = rows[(col >> 6) * (int64_t)nchunk * 64 + (int64_t)c * 64 + (col & 63)];
+    const float e[4] = {v.x, v.y, v.z, v.w};
+    for (int j = 0; j < 4 && c * 4 + j < d; j++) {
+        out[i * d + c * 4 + j] = e[j];
+    }
+}
+
+size_t idmap_sort_tmp_bytes(int64_t n) {
+    size_t b = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b, (const int64_t*)nullptr, (int64_t*)nullptr, (const int64_t*)nullptr,
+                                             (int64_t*)nullptr, (int)n);
+    return b + 256;
+}
+
+// ids [ntotal] (storage order) -> ids_sorted / col_sorted; col_tmp [ntotal] and tmp are scratch
+hipError_t launch_idmap_build(const int64_t* ids, const int64_t* list_row_off, const int64_t* list_blk_off, int64_t nlist,
+                              int64_t ntotal, int64_t* col_tmp, int64_t* ids_sorted, int64_t* col_sorted, void* tmp,
+                              size_t tmp_bytes, hipStream_t s) {
+    if (ntotal <= 0) {
+        return hipSuccess;
+    }
+    if (ntotal >= ((int64_t)1 << 31)) {
+        return hipErrorInvalidValue;
+    }
+    hipLaunchKernelGGL(idmap_cols_kernel, dim3((unsigned)((ntotal + 255) / 256)), dim3(256), 0, s, list_row_off,
+                       list_blk_off, nlist, ntotal, col_tmp);
+    size_t b = tmp_bytes;
+    return hipcub::DeviceRadixSort::SortPairs(tmp, b, ids, ids_sorted, col_tmp, col_sorted, (int)ntotal, 0, 64, s);
+}
+
+hipError_t launch_idmap_gather(const int64_t* want, int64_t n, const int64_t* ids_sorted, const int64_t* col_sorted,
+                               int64_t ntotal, const float4* rows, int d, float* out, int32_t* missing, hipStream_t s) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    const int nchunk = (d + 3) / 4;
+    hipLaunchKernelGGL(idmap_gather_kernel, dim3((unsigned)((n * nchunk + 255) / 256)), dim3(256), 0, s, want, n,
+                       ids_sorted, col_sorted, ntotal, rows, d, nchunk, out, missing);
+    return hipGetLastError();
+}
+
 __global__ void residual_kernel(const float* __restrict__ x, const float* __restrict__ cen,
                                 const int64_t* __restrict__ assign, int64_t n, int d, float* __restrict__ out) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -486,6 +486,13 @@ hipError_t launch_refine(const float* base, int64_t nbase, int64_t id_base, int 
                          int64_t* out_i, hipStream_t s);
 
 // ---- build.hip: Train / Add on the device ----
+// direct map of an IVF-Flat index (GetVectorByIds): ids sorted with the columns of their rows in the interleaved store
+size_t idmap_sort_tmp_bytes(int64_t n);
+hipError_t launch_idmap_build(const int64_t* ids, const int64_t* list_row_off, const int64_t* list_blk_off, int64_t nlist,
+                              int64_t ntotal, int64_t* col_tmp, int64_t* ids_sorted, int64_t* col_sorted, void* tmp,
+                              size_t tmp_bytes, hipStream_t s);
+hipError_t launch_idmap_gather(const int64_t* want, int64_t n, const int64_t* ids_sorted, const int64_t* col_sorted,
+                               int64_t ntotal, const float4* rows, int d, float* out, int32_t* missing, hipStream_t s);
 hipError_t launch_gather_rows(const float* x, const int64_t* rows, int64_t n, int d, float* out, hipStream_t s);
 hipError_t launch_residual(const float* x, const float* cen, const int64_t* assign, int64_t n, int d, float* out,
                            hipStream_t s);

@@ -236,6 +236,8 @@ struct knhip_index {
     int pqf_form = 0;                // KNHIP_PQF_FORM: 0 = chosen per batch by the guard, 1 = half precision, 2 = int8
     mutable bool pqf_ready = false;
     mutable bool pqi_ready = false;
+    mutable bool idmap_ready = false; // IVF-Flat direct map (knhip_index_get_vectors): built on first use
+    mutable DevBuf idmap_ids, idmap_col;
     mutable int64_t last_range_ranks = 0; // coarse ranks the last range search scanned per query (rank waves)
     mutable int last_pq_form = 0;    // prefilter form of the last search: 0 none (exact kernels), 1 half precision, 2 int8
     mutable DevBuf rows_i;           // token stream of the integer form (stream16i)
@@ -259,7 +261,7 @@ struct knhip_index {
     int64_t device_bytes() const {
         const DevBuf* all[] = {&centroids, &centroids_il, &cb, &precomp_t, &sq_trained, &d_list_len,
                                &d_list_row_off, &d_list_blk_off, &ids, &rows, &rows2, &d_list_blk_off2, &cb_t, &codes_aos,
-                               &rows_r, &d_list_blk_off_r, &psum};
+                               &rows_r, &d_list_blk_off_r, &psum, &rows_i, &idmap_ids, &idmap_col};
         int64_t t = 0;
         for (auto* b : all) {
             t += (int64_t)b->bytes;
@@ -476,6 +478,9 @@ int build_list_layout(knhip_index* idx, const std::vector<int64_t>& list_off, co
         idx->pqf_form = (pm && pm[0] == 'h') ? 1 : (pm && pm[0] == 'i') ? 2 : 0;
         idx->pqf_ready = false;
         idx->pqi_ready = false;
+        idx->idmap_ready = false;
+        idx->idmap_ids.release();
+        idx->idmap_col.release();
         idx->rows_i.release();
         idx->rows_r.release();
         idx->psum.release();
@@ -1892,12 +1897,57 @@ int knhip_search_refine(const knhip_index* idx, const knhip_index* raw, const fl
 }
 
 // rows of a brute-force index by id (GetVectorByIds): ids are row + id_offset
+// IVF-Flat: ids sorted once with the column of their row in the interleaved store (16 bytes per vector, against the
+// 4 d bytes of a second copy of the raw rows the node used to keep for this call: ADVICE round 2)
+static int ensure_idmap(const knhip_index* cidx) {
+    knhip_index* idx = const_cast<knhip_index*>(cidx);
+    std::lock_guard<std::mutex> lk(idx->mu);
+    if (idx->idmap_ready) {
+        return KNHIP_OK;
+    }
+    const int64_t n = idx->ntotal;
+    if (n > 0) {
+        DevBuf col_tmp, tmp;
+        const size_t tb = idmap_sort_tmp_bytes(n);
+        HIP_TRY(col_tmp.alloc((size_t)n * sizeof(int64_t)));
+        HIP_TRY(tmp.alloc(tb));
+        HIP_TRY(idx->idmap_ids.alloc((size_t)n * sizeof(int64_t)));
+        HIP_TRY(idx->idmap_col.alloc((size_t)n * sizeof(int64_t)));
+        HIP_TRY(launch_idmap_build(idx->ids.as<int64_t>(), idx->d_list_row_off.as<int64_t>(),
+                                   idx->d_list_blk_off.as<int64_t>(), idx->nlist, n, col_tmp.as<int64_t>(),
+                                   idx->idmap_ids.as<int64_t>(), idx->idmap_col.as<int64_t>(), tmp.p, tb, nullptr));
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    idx->idmap_ready = true;
+    return KNHIP_OK;
+}
+
 int knhip_index_get_vectors(const knhip_index* idx, int64_t n, const int64_t* ids, float* out) {
     if (int rc = check_index(idx)) return rc;
-    if (idx->desc.kind != KNHIP_BRUTE_FORCE || n < 0 || (n > 0 && (!ids || !out))) {
-        return fail(KNHIP_ERR_INVALID_ARGS, "get_vectors: brute-force index, ids and output required");
+    const int kind = idx->desc.kind;
+    if ((kind != KNHIP_BRUTE_FORCE && kind != KNHIP_IVF_FLAT) || n < 0 || (n > 0 && (!ids || !out))) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "get_vectors: brute-force or IVF-Flat index, ids and output required");
     }
     if (n == 0) {
+        return KNHIP_OK;
+    }
+    DeviceGuard g(idx->desc.device);
+    if (kind == KNHIP_IVF_FLAT) {
+        if (int rc = ensure_idmap(idx)) return rc;
+        DevBuf dw, dout, dmiss;
+        if (int rc = upload(dw, ids, (size_t)n * sizeof(int64_t))) return rc;
+        HIP_TRY(dout.alloc((size_t)n * idx->d * sizeof(float)));
+        HIP_TRY(dmiss.alloc(sizeof(int32_t)));
+        HIP_TRY(hipMemset(dmiss.p, 0, sizeof(int32_t)));
+        HIP_TRY(launch_idmap_gather(dw.as<int64_t>(), n, idx->idmap_ids.as<int64_t>(), idx->idmap_col.as<int64_t>(),
+                                    idx->ntotal, idx->rows.as<float4>(), idx->d, dout.as<float>(), dmiss.as<int32_t>(),
+                                    nullptr));
+        int32_t miss = 0;
+        HIP_TRY(hipMemcpy(&miss, dmiss.p, sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (miss != 0) {
+            return fail(KNHIP_ERR_INVALID_ARGS, "get_vectors: id not in the index");
+        }
+        HIP_TRY(hipMemcpy(out, dout.p, (size_t)n * idx->d * sizeof(float), hipMemcpyDeviceToHost));
         return KNHIP_OK;
     }
     std::vector<int64_t> rows((size_t)n);
@@ -1907,7 +1957,6 @@ int knhip_index_get_vectors(const knhip_index* idx, int64_t n, const int64_t* id
             return fail(KNHIP_ERR_INVALID_ARGS, "get_vectors: id out of range");
         }
     }
-    DeviceGuard g(idx->desc.device);
     DevBuf dr, dout;
     if (int rc = upload(dr, rows.data(), rows.size() * sizeof(int64_t))) return rc;
     HIP_TRY(dout.alloc((size_t)n * idx->d * sizeof(float)));

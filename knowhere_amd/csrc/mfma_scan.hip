@@ -1067,14 +1067,16 @@ __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, c
                 pk[u] = dist_key<IS_L2>(pp[u]);
             }
         }
-        // smallest key K with count(keys <= K) >= k
+        // smallest key K with count(keys <= K) >= k: bisection, one counter and ONE barrier per step (the counters of all
+        // 32 steps are zeroed up front; the loop runs exactly 32 times for every thread: the interval halves each step)
+        __shared__ int s_step[32];
+        if (tid < 32) {
+            s_step[tid] = 0;
+        }
+        __syncthreads();
         uint32_t lo = 0u, hi = 0xffffffffu;
-        while (lo < hi) {
+        for (int it = 0; it < 32; it++) {
             const uint32_t mid = lo + ((hi - lo) >> 1);
-            if (tid == 0) {
-                s_cnt = 0;
-            }
-            __syncthreads();
             int c = 0;
 #pragma unroll
             for (int u = 0; u < MF_PRUNE_PER_THREAD; u++) {
@@ -1085,15 +1087,16 @@ __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, c
                 c += __shfl_xor(c, dlt, KN_WAVE);
             }
             if ((tid & (KN_WAVE - 1)) == 0 && c) {
-                atomicAdd(&s_cnt, c);
+                atomicAdd(&s_step[it], c);
             }
             __syncthreads();
-            const int tot = s_cnt;
-            __syncthreads();
-            if (tot >= k) {
-                hi = mid;
-            } else {
-                lo = mid + 1;
+            const int tot = s_step[it];
+            if (lo < hi) {
+                if (tot >= k) {
+                    hi = mid;
+                } else {
+                    lo = mid + 1;
+                }
             }
         }
         const float tau2 = dist_key_inv<IS_L2>(lo);

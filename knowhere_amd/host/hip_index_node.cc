@@ -383,7 +383,8 @@ class HipIndexNode : public IndexNode {
     GetVectorByIds(const DataSetPtr dataset, milvus::OpContext* /*op_context*/) const override {
         if (!dataset || !dataset->GetIds()) return expected<DataSetPtr>::Err(Status::invalid_args, "null ids");
         if (!HasRawData(metric_name_)) return expected<DataSetPtr>::Err(Status::not_implemented, "no raw data");
-        const knhip_index* store = Kind == KNHIP_BRUTE_FORCE ? idx_.p : raw_.p;
+        // (IVF_FLAT: the index's own rows through its direct map -- no second copy of the raw vectors)
+        const knhip_index* store = idx_.p;
         if (!store) return expected<DataSetPtr>::Err(Status::empty_index, "index not built");
         const int64_t n = dataset->GetRows();
         auto out = std::make_unique<float[]>(std::max<int64_t>(n * dim_, 1));
@@ -643,34 +644,14 @@ class HipIndexNode : public IndexNode {
             const Status st = PushRowScale();
             if (st != Status::success) return st;
         }
-        // raw rows for refine / GetVectorByIds, back in id order
-        if (x.has_refine || (Kind == KNHIP_IVF_FLAT && !cosine_)) {
-            std::vector<float> rows;
-            if (x.has_refine) {
-                rows = std::move(x.refine_index.xb);
-            } else {
-                rows.assign((size_t)ntotal * d, 0.f);
-                bool dense = true;
-                for (int64_t l = 0; l < nlist_ && dense; l++) {
-                    for (size_t i = 0; i < x.ids[l].size(); i++) {
-                        const int64_t id = x.ids[l][i];
-                        if (id < 0 || id >= ntotal) {
-                            dense = false;  // custom ids: no direct map (make_direct_map needs 0..n-1, ivf.cc:1815-1828)
-                            break;
-                        }
-                        std::memcpy(&rows[(size_t)id * d], &x.codes[l][i * d * 4], sizeof(float) * d);
-                    }
-                }
-                if (!dense) rows.clear();
-            }
-            if (!rows.empty()) {
-                knhip_desc rd{};
-                rd.kind = KNHIP_BRUTE_FORCE;
-                rd.metric = metric_;
-                rd.dim = (int32_t)dim_;
-                if ((rc = knhip_index_create(&rd, &raw_.p))) return ToStatus(rc);
-                if ((rc = knhip_index_add(raw_.p, ntotal, rows.data(), nullptr))) return ToStatus(rc);
-            }
+        // raw rows for refine, in id order
+        if (x.has_refine && !x.refine_index.xb.empty()) {
+            knhip_desc rd{};
+            rd.kind = KNHIP_BRUTE_FORCE;
+            rd.metric = metric_;
+            rd.dim = (int32_t)dim_;
+            if ((rc = knhip_index_create(&rd, &raw_.p))) return ToStatus(rc);
+            if ((rc = knhip_index_add(raw_.p, ntotal, x.refine_index.xb.data(), nullptr))) return ToStatus(rc);
         }
         return Status::success;
     }
@@ -748,10 +729,11 @@ class HipIndexNode : public IndexNode {
     CodeSize() const {
         return Kind == KNHIP_IVF_FLAT ? dim_ * 4 : (Kind == KNHIP_IVF_PQ ? m_ : dim_);
     }
-    // a second device-resident store of the raw rows: IndexRefineFlat, and the direct map of IVF_FLAT (GetVectorByIds)
+    // a second device-resident store of the raw rows: IndexRefineFlat only (GetVectorByIds of IVF_FLAT is served from the
+    // index's own rows through knhip_index_get_vectors' direct map)
     bool
     NeedRawStore() const {
-        return ((Kind == KNHIP_IVF_PQ || Kind == KNHIP_IVF_SQ8) && has_refine_) || (Kind == KNHIP_IVF_FLAT && !cosine_);
+        return (Kind == KNHIP_IVF_PQ || Kind == KNHIP_IVF_SQ8) && has_refine_;
     }
 
     // COSINE on FLAT / IVF_FLAT: raw rows + one float per row (inverse norm / norm), see Add

@@ -223,6 +223,13 @@ class GpuIndex:
         check(self.L.knhip_search(self.h, _np_ptr(xq), nq, k, nprobe, _np_ptr(bs), nbits, _np_ptr(I), _np_ptr(D)))
         return D, I
 
+    def get_vectors(self, ids):
+        """stored fp32 rows by id (knhip_index_get_vectors: BRUTE_FORCE, or IVF_FLAT through its direct map)"""
+        ids = np.ascontiguousarray(ids, np.int64)
+        out = np.empty((len(ids), self.dim), np.float32)
+        check(self.L.knhip_index_get_vectors(self.h, len(ids), _np_ptr(ids), _np_ptr(out)))
+        return out
+
     def last_range_ranks(self):
         """coarse ranks per query the last range_search scanned (rank waves: knhip_index_last_range_ranks)"""
         return int(self.L.knhip_index_last_range_ranks(self.h))

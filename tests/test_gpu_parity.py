@@ -112,6 +112,23 @@ def test_coarse_certificate_fallback(torch_cuda, port, metric):
     g.close()
 
 
+def test_ivfflat_get_vectors_direct_map(torch_cuda, port):
+    """GetVectorByIds of IVF_FLAT from the index's own rows (knhip_index_get_vectors' direct map, built on first use):
+    custom non-monotone ids, ragged and empty lists, an id that is not stored"""
+    from knowhere_amd import KnhipError
+    nb, d = 5000, 36
+    xb = gen_data(nb, d, 42)
+    ids = np.random.default_rng(5).permutation(nb).astype(np.int64) * 7 + 3
+    ix = ob.make_index(port, ob.IVF_FLAT, ob.L2, xb, nlist=300, ids=ids)
+    g = _gpu(ix)
+    pick = np.random.default_rng(6).integers(0, nb, 257)
+    got = g.get_vectors(ids[pick])
+    assert np.array_equal(got.view(np.uint32), xb[pick].view(np.uint32))
+    with pytest.raises(KnhipError):
+        g.get_vectors(np.array([ids[0], 1], np.int64))  # 1 is not of the form 7 i + 3
+    g.close()
+
+
 KINDS = [(ob.IVF_FLAT, 0), (ob.IVF_PQ, 8), (ob.IVF_PQ, 16), (ob.IVF_PQ, 32), (ob.IVF_PQ, 64), (ob.IVF_SQ8, 0)]
 
 
