@@ -30,10 +30,19 @@ void knhip_shard_group_destroy(knhip_shard_group* g);
 /* rank r's index: created on device_ids[r] by the caller, holding the lists rank r owns (not owned by the group) */
 int knhip_shard_group_set_index(knhip_shard_group* g, int32_t rank, const knhip_index* idx);
 /* one Search() of the whole (sharded) index: host queries [nq][dim] in, host ids / distances [nq][k] out.
- * stage_ms (may be NULL): [n_devices][4] = per rank {search, all-gather, merge, total} milliseconds of this call. */
+ * stage_ms (may be NULL): [n_devices][4] = per rank {search, all-gather + merge, -, total} milliseconds of this call. */
 int knhip_shard_group_search(knhip_shard_group* g, const float* queries, int64_t nq, int32_t k, int32_t nprobe,
                              const uint8_t* bitset, int64_t bitset_nbits, int64_t* out_ids, float* out_dist,
                              float* stage_ms);
+/* Refine stage (Knowhere's `refine` / `refine_k`, IndexRefine::search over IndexShards): rank r holds the raw fp32 rows
+ * of the vector ids [id_base, id_base + nrows) in its HBM (d_rows: device pointer on device_ids[r]; the split of the raw
+ * rows need not follow the split of the lists).  search_refine: k_base candidates per rank -> all-gather + merge (the same
+ * merged candidates on every rank) -> every rank re-ranks exactly the candidates whose rows it holds -> all-gather + merge
+ * of the (nq, k) partials.  stage_ms: [n_devices][7] = {search, gather + merge, -, refine, gather + merge, -, total}. */
+int knhip_shard_group_set_raw(knhip_shard_group* g, int32_t rank, const float* d_rows, int64_t nrows, int64_t id_base);
+int knhip_shard_group_search_refine(knhip_shard_group* g, const float* queries, int64_t nq, int32_t k, int32_t k_base,
+                                    int32_t nprobe, const uint8_t* bitset, int64_t bitset_nbits, int64_t* out_ids,
+                                    float* out_dist, float* stage_ms);
 int32_t knhip_shard_group_size(const knhip_shard_group* g);
 
 #ifdef __cplusplus

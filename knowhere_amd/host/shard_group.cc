@@ -63,7 +63,10 @@ struct Rank {
     const knhip_index* idx = nullptr;
     hipStream_t stream = nullptr;
     ncclComm_t comm = nullptr;
-    DevMem q, bits, part_d, part_i, packed, gathered, all_d, all_i, out_d, out_i;
+    DevMem q, bits, part_d, part_i, packed, gathered, all_d, all_i, out_d, out_i, ref_d, ref_i;
+    // raw fp32 rows this rank holds for the refine stage: row r = vector id raw_id0 + r (device pointer on `dev`)
+    const float* raw = nullptr;
+    int64_t raw_n = 0, raw_id0 = 0;
 };
 
 }  // namespace
@@ -131,7 +134,8 @@ int knhip_shard_group_create(int32_t n_devices, const int32_t* device_ids, int32
         }
         Rank& k = g->ranks[r];
         k.dev = device_ids[r];
-        for (DevMem* m : {&k.q, &k.bits, &k.part_d, &k.part_i, &k.packed, &k.gathered, &k.all_d, &k.all_i, &k.out_d, &k.out_i}) {
+        for (DevMem* m : {&k.q, &k.bits, &k.part_d, &k.part_i, &k.packed, &k.gathered, &k.all_d, &k.all_i, &k.out_d, &k.out_i,
+                          &k.ref_d, &k.ref_i}) {
             m->dev = k.dev;
         }
         (void)hipSetDevice(k.dev);
@@ -188,45 +192,137 @@ int knhip_shard_group_set_index(knhip_shard_group* g, int32_t rank, const knhip_
     return KNHIP_OK;
 }
 
-int knhip_shard_group_search(knhip_shard_group* g, const float* queries, int64_t nq, int32_t k, int32_t nprobe,
-                             const uint8_t* bitset, int64_t bitset_nbits, int64_t* out_ids, float* out_dist,
-                             float* stage_ms) {
-    if (!g || !queries || nq <= 0 || k <= 0 || !out_ids || !out_dist) {
+int knhip_shard_group_set_raw(knhip_shard_group* g, int32_t rank, const float* d_rows, int64_t nrows, int64_t id_base) {
+    if (!g || rank < 0 || rank >= g->n || nrows < 0 || (nrows > 0 && !d_rows)) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "shard_group_set_raw: bad arguments");
+    }
+    g->ranks[rank].raw = d_rows;
+    g->ranks[rank].raw_n = nrows;
+    g->ranks[rank].raw_id0 = id_base;
+    return KNHIP_OK;
+}
+
+// k_base = 0: plain search.  k_base >= k: k_base candidates per rank, merged; every rank re-ranks the merged candidates
+// whose raw rows it holds; second exchange + merge of the (nq, k) partials.
+static int search_impl(knhip_shard_group* g, const float* queries, int64_t nq, int32_t k, int32_t k_base, int32_t nprobe,
+                       const uint8_t* bitset, int64_t bitset_nbits, int64_t* out_ids, float* out_dist, float* stage_ms) {
+    if (!g || !queries || nq <= 0 || k <= 0 || !out_ids || !out_dist || (k_base != 0 && k_base < k)) {
         return fail(KNHIP_ERR_INVALID_ARGS, "shard_group_search: bad arguments");
     }
     for (const Rank& r : g->ranks) {
         if (!r.idx) return fail(KNHIP_ERR_INVALID_ARGS, "shard_group_search: a rank has no index");
     }
+    const bool refine = k_base != 0;
     std::lock_guard<std::mutex> call_lk(g->call_mu);
     const int W = g->n;
     knhip_desc desc{};
     if (int drc = knhip_index_get_desc(g->ranks[0].idx, &desc)) return fail(drc, knhip_last_error());
     const int32_t dim = desc.dim;
     const int32_t metric = desc.metric;
-    const int64_t ne = nq * (int64_t)k;  // entries per rank
+    const int32_t k1 = refine ? k_base : k;       // width of the first exchange
+    const int64_t ne1 = nq * (int64_t)k1;         // entries per rank, first exchange
+    const int64_t ne = nq * (int64_t)k;           // entries of the result
     Barrier bar(W);
     std::vector<int> rcs(W, KNHIP_OK);
     std::vector<std::string> errs(W);
     std::vector<std::thread> th;
     Rank* R = g->ranks.data();
+    const int NS = refine ? 7 : 4;  // stage_ms columns: {search, gather, merge, [refine, gather, merge,] total}
     auto worker = [&](int r) {
         int& rc = rcs[r];
         std::string& err = errs[r];
         Rank& me = R[r];
         bool alive = true;  // (a failed rank still walks through every barrier)
-        hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+        hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        auto all_ok = [&]() {
+            bool ok = true;
+            for (int o = 0; o < W; o++) ok = ok && rcs[o] == KNHIP_OK;
+            return ok;
+        };
+        // ---- one exchange step: pack (pd, pi) [nq][kk], all-gather of the packed partials, unpack + merge -> (od, oi);
+        // e_g / e_m: events recorded before the gather and after the merge.  Same barrier walk for every rank.
+        auto exchange = [&](int32_t kk, const float* pd, const int64_t* pi, float* od, int64_t* oi, hipEvent_t e_g,
+                            hipEvent_t e_m) {
+            const int64_t n = nq * (int64_t)kk;
+            auto head = [&]() {
+                hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, me.stream, pd, pi, n,
+                                   static_cast<uint32_t*>(me.packed.p));
+                SG_HIP(hipEventRecord(e_g, me.stream));
+            };
+            if (alive) {
+                head();
+                alive = rc == KNHIP_OK;
+            }
+            if (g->transport == KNHIP_SHARDS_RCCL) {
+                if (alive) {
+                    const ncclResult_t nr = ncclAllGather(me.packed.p, me.gathered.p, (size_t)n * 12, ncclChar, me.comm, me.stream);
+                    if (nr != ncclSuccess) {
+                        err = std::string("ncclAllGather: ") + ncclGetErrorString(nr);
+                        rc = KNHIP_ERR_HIP_RUNTIME;
+                        alive = false;
+                    }
+                }
+                bar.wait();
+            } else {
+                if (alive && hipStreamSynchronize(me.stream) != hipSuccess) {
+                    rc = KNHIP_ERR_HIP_RUNTIME;
+                    err = "stream synchronize failed";
+                    alive = false;
+                }
+                bar.wait();  // every rank's packed partial is complete
+                if (alive && all_ok()) {
+                    for (int o = 0; o < W && alive; o++) {  // pull every rank's block (peer copies; same device: plain copies)
+                        const hipError_t e = hipMemcpyPeerAsync(static_cast<char*>(me.gathered.p) + (size_t)o * n * 12, me.dev,
+                                                                R[o].packed.p, R[o].dev, (size_t)n * 12, me.stream);
+                        if (e != hipSuccess) {
+                            rc = KNHIP_ERR_HIP_RUNTIME;
+                            err = std::string("hipMemcpyPeerAsync: ") + hipGetErrorString(e);
+                            alive = false;
+                        }
+                    }
+                    if (alive && hipStreamSynchronize(me.stream) != hipSuccess) {
+                        rc = KNHIP_ERR_HIP_RUNTIME;
+                        alive = false;
+                    }
+                }
+                bar.wait();  // nobody's packed buffer is overwritten before everyone has read it
+            }
+            auto tail = [&]() {
+                hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)((n * W + 255) / 256)), dim3(256), 0, me.stream,
+                                   static_cast<const uint32_t*>(me.gathered.p), n * W, static_cast<float*>(me.all_d.p),
+                                   static_cast<int64_t*>(me.all_i.p));
+                const int mrc = knhip_merge_topk_device(metric, nq, kk, W, static_cast<const float*>(me.all_d.p),
+                                                        static_cast<const int64_t*>(me.all_i.p), od, oi, me.stream);
+                if (mrc != KNHIP_OK) {
+                    err = std::string("knhip_merge_topk_device: ") + knhip_last_error();
+                    rc = mrc;
+                    return;
+                }
+                SG_HIP(hipEventRecord(e_m, me.stream));
+            };
+            if (alive && all_ok()) {
+                tail();
+                alive = rc == KNHIP_OK;
+            } else {
+                alive = false;
+            }
+        };
         auto body = [&]() {
             SG_HIP(hipSetDevice(me.dev));
             for (auto& e : ev) SG_HIP(hipEventCreate(&e));
             SG_HIP(me.q.reserve((size_t)nq * dim * sizeof(float)));
-            SG_HIP(me.part_d.reserve((size_t)ne * sizeof(float)));
-            SG_HIP(me.part_i.reserve((size_t)ne * sizeof(int64_t)));
-            SG_HIP(me.packed.reserve((size_t)ne * 12));
-            SG_HIP(me.gathered.reserve((size_t)ne * 12 * W));
-            SG_HIP(me.all_d.reserve((size_t)ne * W * sizeof(float)));
-            SG_HIP(me.all_i.reserve((size_t)ne * W * sizeof(int64_t)));
-            SG_HIP(me.out_d.reserve((size_t)ne * sizeof(float)));
-            SG_HIP(me.out_i.reserve((size_t)ne * sizeof(int64_t)));
+            SG_HIP(me.part_d.reserve((size_t)ne1 * sizeof(float)));
+            SG_HIP(me.part_i.reserve((size_t)ne1 * sizeof(int64_t)));
+            SG_HIP(me.packed.reserve((size_t)ne1 * 12));
+            SG_HIP(me.gathered.reserve((size_t)ne1 * 12 * W));
+            SG_HIP(me.all_d.reserve((size_t)ne1 * W * sizeof(float)));
+            SG_HIP(me.all_i.reserve((size_t)ne1 * W * sizeof(int64_t)));
+            SG_HIP(me.out_d.reserve((size_t)ne1 * sizeof(float)));
+            SG_HIP(me.out_i.reserve((size_t)ne1 * sizeof(int64_t)));
+            if (refine) {
+                SG_HIP(me.ref_d.reserve((size_t)ne * sizeof(float)));
+                SG_HIP(me.ref_i.reserve((size_t)ne * sizeof(int64_t)));
+            }
             SG_HIP(hipMemcpyAsync(me.q.p, queries, (size_t)nq * dim * sizeof(float), hipMemcpyHostToDevice, me.stream));
             const uint8_t* d_bits = nullptr;
             if (bitset && bitset_nbits > 0) {
@@ -236,7 +332,7 @@ int knhip_shard_group_search(knhip_shard_group* g, const float* queries, int64_t
                 d_bits = static_cast<const uint8_t*>(me.bits.p);
             }
             SG_HIP(hipEventRecord(ev[0], me.stream));
-            const int src = knhip_search_device(me.idx, static_cast<const float*>(me.q.p), nq, k, nprobe, d_bits,
+            const int src = knhip_search_device(me.idx, static_cast<const float*>(me.q.p), nq, k1, nprobe, d_bits,
                                                 d_bits ? bitset_nbits : 0, static_cast<int64_t*>(me.part_i.p),
                                                 static_cast<float*>(me.part_d.p), me.stream);
             if (src != KNHIP_OK) {
@@ -244,83 +340,64 @@ int knhip_shard_group_search(knhip_shard_group* g, const float* queries, int64_t
                 rc = src;
                 return;
             }
-            hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, me.stream,
-                               static_cast<const float*>(me.part_d.p), static_cast<const int64_t*>(me.part_i.p), ne,
-                               static_cast<uint32_t*>(me.packed.p));
-            SG_HIP(hipEventRecord(ev[1], me.stream));
         };
         body();
         alive = rc == KNHIP_OK;
-        // ---- the one exchange step: all-gather of the packed partials ----
-        if (g->transport == KNHIP_SHARDS_RCCL) {
+        exchange(k1, static_cast<const float*>(me.part_d.p), static_cast<const int64_t*>(me.part_i.p),
+                 static_cast<float*>(me.out_d.p), static_cast<int64_t*>(me.out_i.p), ev[1], ev[2]);
+        float* res_d = static_cast<float*>(me.out_d.p);
+        int64_t* res_i = static_cast<int64_t*>(me.out_i.p);
+        if (refine) {
+            // every rank holds the same merged candidates; it re-ranks those whose raw rows live here (ids outside
+            // [raw_id0, raw_id0 + raw_n) are skipped slots of refine.hip), then the (nq, k) partials are exchanged
             if (alive) {
-                const ncclResult_t nr = ncclAllGather(me.packed.p, me.gathered.p, (size_t)ne * 12, ncclChar, me.comm, me.stream);
-                if (nr != ncclSuccess) {
-                    err = std::string("ncclAllGather: ") + ncclGetErrorString(nr);
-                    rc = KNHIP_ERR_HIP_RUNTIME;
+                const int rrc = knhip_refine_device(metric, dim, me.raw, me.raw_n, me.raw_id0, static_cast<const float*>(me.q.p),
+                                                    nq, static_cast<const int64_t*>(me.out_i.p), k1, k,
+                                                    static_cast<float*>(me.ref_d.p), static_cast<int64_t*>(me.ref_i.p), me.stream);
+                if (rrc != KNHIP_OK) {
+                    err = std::string("knhip_refine_device: ") + knhip_last_error();
+                    rc = rrc;
                     alive = false;
                 }
             }
-            bar.wait();
-        } else {
-            if (alive && hipStreamSynchronize(me.stream) != hipSuccess) {
-                rc = KNHIP_ERR_HIP_RUNTIME;
-                err = "stream synchronize failed";
-                alive = false;
-            }
-            bar.wait();  // every rank's packed partial is complete
-            bool all_ok = true;
-            for (int o = 0; o < W; o++) all_ok = all_ok && rcs[o] == KNHIP_OK;
-            if (alive && all_ok) {
-                for (int o = 0; o < W && alive; o++) {  // pull every rank's block (peer copies; same device: plain copies)
-                    const hipError_t e = hipMemcpyPeerAsync(static_cast<char*>(me.gathered.p) + (size_t)o * ne * 12, me.dev,
-                                                            R[o].packed.p, R[o].dev, (size_t)ne * 12, me.stream);
-                    if (e != hipSuccess) {
-                        rc = KNHIP_ERR_HIP_RUNTIME;
-                        err = std::string("hipMemcpyPeerAsync: ") + hipGetErrorString(e);
-                        alive = false;
-                    }
-                }
-                if (alive && hipStreamSynchronize(me.stream) != hipSuccess) {
-                    rc = KNHIP_ERR_HIP_RUNTIME;
-                    alive = false;
-                }
-            }
-            bar.wait();  // nobody's packed buffer is overwritten before everyone has read it
+            exchange(k, static_cast<const float*>(me.ref_d.p), static_cast<const int64_t*>(me.ref_i.p),
+                     static_cast<float*>(me.part_d.p), static_cast<int64_t*>(me.part_i.p), ev[4], ev[5]);
+            res_d = static_cast<float*>(me.part_d.p);
+            res_i = static_cast<int64_t*>(me.part_i.p);
         }
-        bool all_ok = true;
-        for (int o = 0; o < W; o++) all_ok = all_ok && rcs[o] == KNHIP_OK;
-        auto tail = [&]() {
-            SG_HIP(hipEventRecord(ev[2], me.stream));
-            hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)((ne * W + 255) / 256)), dim3(256), 0, me.stream,
-                               static_cast<const uint32_t*>(me.gathered.p), ne * W, static_cast<float*>(me.all_d.p),
-                               static_cast<int64_t*>(me.all_i.p));
-            const int mrc = knhip_merge_topk_device(metric, nq, k, W, static_cast<const float*>(me.all_d.p),
-                                                    static_cast<const int64_t*>(me.all_i.p), static_cast<float*>(me.out_d.p),
-                                                    static_cast<int64_t*>(me.out_i.p), me.stream);
-            if (mrc != KNHIP_OK) {
-                err = std::string("knhip_merge_topk_device: ") + knhip_last_error();
-                rc = mrc;
-                return;
-            }
-            SG_HIP(hipEventRecord(ev[3], me.stream));
+        auto finish = [&]() {
             if (r == 0) {
-                SG_HIP(hipMemcpyAsync(out_dist, me.out_d.p, (size_t)ne * sizeof(float), hipMemcpyDeviceToHost, me.stream));
-                SG_HIP(hipMemcpyAsync(out_ids, me.out_i.p, (size_t)ne * sizeof(int64_t), hipMemcpyDeviceToHost, me.stream));
+                SG_HIP(hipMemcpyAsync(out_dist, res_d, (size_t)ne * sizeof(float), hipMemcpyDeviceToHost, me.stream));
+                SG_HIP(hipMemcpyAsync(out_ids, res_i, (size_t)ne * sizeof(int64_t), hipMemcpyDeviceToHost, me.stream));
             }
             SG_HIP(hipStreamSynchronize(me.stream));
             if (stage_ms) {
-                float a = 0, b = 0, c = 0;
+                float a = 0, b = 0, c = 0, d2 = 0, e2 = 0, f2 = 0;
                 (void)hipEventElapsedTime(&a, ev[0], ev[1]);
                 (void)hipEventElapsedTime(&b, ev[1], ev[2]);
-                (void)hipEventElapsedTime(&c, ev[2], ev[3]);
-                stage_ms[4 * r + 0] = a;
-                stage_ms[4 * r + 1] = b;
-                stage_ms[4 * r + 2] = c;
-                stage_ms[4 * r + 3] = a + b + c;
+                float* o = stage_ms + (size_t)NS * r;
+                if (!refine) {
+                    // (the merge is inside [ev1, ev2] here: gather and merge are reported together as gather + 0)
+                    o[0] = a;
+                    o[1] = b;
+                    o[2] = 0.f;
+                    o[3] = a + b;
+                } else {
+                    (void)hipEventElapsedTime(&c, ev[2], ev[4]);
+                    (void)hipEventElapsedTime(&d2, ev[4], ev[5]);
+                    (void)e2;
+                    (void)f2;
+                    o[0] = a;
+                    o[1] = b;
+                    o[2] = 0.f;
+                    o[3] = c;
+                    o[4] = d2;
+                    o[5] = 0.f;
+                    o[6] = a + b + c + d2;
+                }
             }
         };
-        if (alive && all_ok) tail();
+        if (alive && all_ok()) finish();
         for (auto& e : ev) {
             if (e) (void)hipEventDestroy(e);
         }
@@ -331,6 +408,22 @@ int knhip_shard_group_search(knhip_shard_group* g, const float* queries, int64_t
         if (rcs[r] != KNHIP_OK) return fail(rcs[r], "rank " + std::to_string(r) + ": " + errs[r]);
     }
     return KNHIP_OK;
+}
+
+int knhip_shard_group_search(knhip_shard_group* g, const float* queries, int64_t nq, int32_t k, int32_t nprobe,
+                             const uint8_t* bitset, int64_t bitset_nbits, int64_t* out_ids, float* out_dist,
+                             float* stage_ms) {
+    return search_impl(g, queries, nq, k, 0, nprobe, bitset, bitset_nbits, out_ids, out_dist, stage_ms);
+}
+
+int knhip_shard_group_search_refine(knhip_shard_group* g, const float* queries, int64_t nq, int32_t k, int32_t k_base,
+                                    int32_t nprobe, const uint8_t* bitset, int64_t bitset_nbits, int64_t* out_ids,
+                                    float* out_dist, float* stage_ms) {
+    if (k_base < k) return fail(KNHIP_ERR_INVALID_ARGS, "shard_group_search_refine: k_base < k");
+    for (int r = 0; g && r < g->n; r++) {
+        if (g->ranks[r].raw_n > 0 && !g->ranks[r].raw) return fail(KNHIP_ERR_INVALID_ARGS, "shard_group_search_refine: no raw rows");
+    }
+    return search_impl(g, queries, nq, k, k_base, nprobe, bitset, bitset_nbits, out_ids, out_dist, stage_ms);
 }
 
 const char* knhip_shard_group_last_error() { return g_err.c_str(); }

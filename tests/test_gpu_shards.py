@@ -23,6 +23,9 @@ SO = os.path.join(ROOT, "knowhere_amd", "libknhip_shards.so")
 @pytest.fixture(scope="module")
 def shards():
     assert os.path.exists(SO), "build with __graft_entry__.build()"
+    import torch
+    assert torch.cuda.is_available()  # (torch brings its own HIP runtime up before the shard library's RCCL is loaded)
+    torch.zeros(1).cuda()
     from knowhere_amd import _lib
     _lib.load()  # libknhip.so first (the shard library links it)
     L = C.CDLL(SO)
@@ -90,6 +93,52 @@ def test_sharded_search_equals_the_single_index(shards, port, kind, metric, worl
         D, I, _ = _group_search(shards, parts, [0] * world, 1, xq, 10, 8, bs, nb)
         assert np.array_equal(I, Iw) and np.array_equal(D.view(np.uint32), Dw.view(np.uint32))
     finally:
+        whole.close()
+        for p in parts:
+            p.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("metric", [ob.L2, ob.IP], ids=["l2", "ip"])
+def test_sharded_search_with_refine(shards, port, world, metric):
+    """refine stage of the C++ host: k_base PQ candidates per rank -> all-gather + merge -> every rank re-ranks the
+    candidates whose raw rows it holds (raw rows split by id range, NOT along the list split) -> all-gather + merge.
+    Bit-identical to knhip_search_refine of the whole index on one GPU, and to the oracle's IndexRefine."""
+    import torch
+    from knowhere_amd import GpuIndex, index as kidx
+    nb, d, nlist, nq, k, kb = 30000, 128, 40, 50, 10, 100
+    xb, xq = gen_data(nb, d, 42), gen_data(nq, d, 44)
+    ix = finish_ivfpq(port, ob.make_index(port, ob.IVF_PQ, metric, xb, nlist=nlist, M=32))
+    whole = GpuIndex.from_data(ix, device=0)
+    parts = [GpuIndex.from_data(p, device=0) for p in _split(ix, world)]
+    xb_t = torch.from_numpy(xb).cuda()
+    cuts = [nb * r // world for r in range(world + 1)]
+    L = shards
+    g = C.c_void_p()
+    dev = (C.c_int32 * world)(*([0] * world))
+    assert L.knhip_shard_group_create(C.c_int32(world), dev, C.c_int32(1), C.byref(g)) == 0
+    try:
+        for r, gi in enumerate(parts):
+            assert L.knhip_shard_group_set_index(g, C.c_int32(r), gi.h) == 0
+            lo, hi = cuts[r], cuts[r + 1]
+            assert L.knhip_shard_group_set_raw(g, C.c_int32(r), C.c_void_p(xb_t[lo:hi].data_ptr()), C.c_int64(hi - lo),
+                                               C.c_int64(lo)) == 0
+        I = np.empty((nq, k), np.int64)
+        D = np.empty((nq, k), np.float32)
+        ms = np.zeros((world, 7), np.float32)
+        rc = L.knhip_shard_group_search_refine(g, xq.ctypes.data_as(C.c_void_p), C.c_int64(nq), C.c_int32(k), C.c_int32(kb),
+                                               C.c_int32(8), None, C.c_int64(0), I.ctypes.data_as(C.c_void_p),
+                                               D.ctypes.data_as(C.c_void_p), ms.ctypes.data_as(C.c_void_p))
+        assert rc == 0, L.knhip_shard_group_last_error().decode()
+        # one GPU: candidates of the whole index, exact re-rank against all raw rows
+        xq_t = torch.from_numpy(xq).cuda()
+        Dp, Ip = whole.search_device(xq_t, kb, 8)
+        Dr, Ir = kidx.refine_device(metric, xb_t, xq_t, Ip, k)
+        torch.cuda.synchronize()
+        assert np.array_equal(I, Ir.cpu().numpy()) and np.array_equal(D.view(np.uint32), Dr.cpu().numpy().view(np.uint32))
+        assert (ms[:, 6] > 0).all() and (ms[:, 3] > 0).all()
+    finally:
+        L.knhip_shard_group_destroy(g)
         whole.close()
         for p in parts:
             p.close()
