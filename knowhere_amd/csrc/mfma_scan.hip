@@ -1213,7 +1213,7 @@ __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, c
                     // bytes per candidate -- instead of 32 four-byte gathers out of the list's 32 KB table (a cache
                     // line each: the finish was bound by them, round-3 profile).  Same bits as the stored table.
                     const float* cen = a.centroids + list * d;
-#pragma unroll 8
+#pragma unroll 16
                     for (int m = 0; m < 32; m++) {
                         const int code = (int)((ww[m >> 2] >> (8 * (m & 3))) & 0xffu);
                         const float4 y = a.pq_cb_t[code * 32 + m];

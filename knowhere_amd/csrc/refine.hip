@@ -60,26 +60,34 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ b
             const float* y = base + (id - id_base) * d;
             int i = 0;
             if ((d & 3) == 0 && (reinterpret_cast<uintptr_t>(base) & 15) == 0) {
-                // 16-byte loads, eight in flight per lane (every lane reads its own row: scalar loads made each of them a
+                // 16-byte loads, sixteen in flight per lane (every lane reads its own row: scalar loads made each of them a
                 // 64-line request); the accumulation order stays i = 0, 1, 2, ... (reference order)
                 const float4* y4 = reinterpret_cast<const float4*>(y);
                 const float4* q4 = reinterpret_cast<const float4*>(myq);
                 const int n4 = d >> 2;
                 int j = 0;
-                for (; j + 8 <= n4; j += 8) {
-                    float4 v[8];
+                for (; j + 16 <= n4; j += 16) {
+                    float4 v[16];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) {
+                    for (int u = 0; u < 16; u++) {
                         v[u] = y4[j + u];
                     }
 #pragma unroll
-                    for (int u = 0; u < 8; u++) {
+                    for (int u = 0; u < 16; u++) {
                         const float4 x = q4[j + u];
                         acc = IS_L2 ? l2_step(acc, x.x, v[u].x) : ip_step(acc, x.x, v[u].x);
                         acc = IS_L2 ? l2_step(acc, x.y, v[u].y) : ip_step(acc, x.y, v[u].y);
                         acc = IS_L2 ? l2_step(acc, x.z, v[u].z) : ip_step(acc, x.z, v[u].z);
                         acc = IS_L2 ? l2_step(acc, x.w, v[u].w) : ip_step(acc, x.w, v[u].w);
                     }
+                }
+                for (; j < n4; j++) { // (the last n4 mod 16 pieces)
+                    const float4 v1 = y4[j];
+                    const float4 x = q4[j];
+                    acc = IS_L2 ? l2_step(acc, x.x, v1.x) : ip_step(acc, x.x, v1.x);
+                    acc = IS_L2 ? l2_step(acc, x.y, v1.y) : ip_step(acc, x.y, v1.y);
+                    acc = IS_L2 ? l2_step(acc, x.z, v1.z) : ip_step(acc, x.z, v1.z);
+                    acc = IS_L2 ? l2_step(acc, x.w, v1.w) : ip_step(acc, x.w, v1.w);
                 }
                 i = j * 4;
             }

@@ -501,7 +501,7 @@ __global__ __launch_bounds__(RT_THREADS) void row_select_thr_kernel(const float*
     if (vec) {
         const float4* row4 = reinterpret_cast<const float4*>(row);
         int it = 0;
-#pragma unroll 4
+#pragma unroll 8
         for (int64_t j = tid; j < n4; j += RT_THREADS, it++) {
             const float4 v = row4[j];
             const uint32_t key = min(min(rs_key<IS_L2>(v.x), rs_key<IS_L2>(v.y)), min(rs_key<IS_L2>(v.z), rs_key<IS_L2>(v.w)));
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(RT_THREADS) void row_select_thr_kernel(const float*
     };
     if (vec) {
         const float4* row4 = reinterpret_cast<const float4*>(row);
-#pragma unroll 4
+#pragma unroll 8
         for (int64_t j0 = 0; j0 < n4; j0 += RT_THREADS) {
             const int64_t j = j0 + tid;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
