@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-3 evidence refresh after the integer fast path / per-query sample: full GPU suite, smoke, the contract bench (with
+# evidence refresh (run on the GPU box from the repo root): full GPU suite, smoke, the contract bench (with
 # the CPU baseline leg), then the rocprofv3 passes of the same command (stats + PMC, tools/profile_bench.sh)
 mkdir -p gpurun_out
 export TMPDIR=/tmp
