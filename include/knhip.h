@@ -240,9 +240,11 @@ int knhip_search_refine(const knhip_index* idx, const knhip_index* raw, const fl
 int knhip_index_get_vectors(const knhip_index* idx, int64_t n, const int64_t* ids, float* out);
 /* Same with every buffer already in HBM; enqueued on `stream` (hipStream_t, NULL = default
  * stream) and NOT synchronised at the end.  One exception inside: an IVF_PQ m = 32 batch that takes the matrix-core
- * prefilter (pq_filter.hip) waits once on `stream` in the middle of the batch -- the selectivity guard reads two
- * counters back to choose between the integer form, the half-precision form and the exact kernel -- so such a call is
- * not capturable into a hipGraph; KNHIP_PQF_GUARD=0 or KNHIP_PQF=0 removes the wait. */
+ * prefilter (pq_filter.hip) waits once on `stream` in the middle of the batch the FIRST time a (k, nprobe) pair is seen
+ * on this index, and every 64th time after: the selectivity guard reads two counters back to choose between the integer
+ * form, the half-precision form and the exact kernels.  All other batches take the decision from the previous batch's
+ * counters (pinned buffer + event, polled, never waited for).  The decision only picks kernels -- results do not depend
+ * on it.  KNHIP_PQF_GUARD=0 or KNHIP_PQF=0 removes the wait altogether (graph capture). */
 int knhip_search_device(const knhip_index* idx, const float* d_queries, int64_t nq, int32_t k,
                         int32_t nprobe, const uint8_t* d_bitset, int64_t bitset_nbits,
                         int64_t* d_out_ids, float* d_out_dist, void* stream);

@@ -236,6 +236,18 @@ struct knhip_index {
     int pqf_form = 0;                // KNHIP_PQF_FORM: 0 = chosen per batch by the guard, 1 = half precision, 2 = int8
     mutable bool pqf_ready = false;
     mutable bool pqi_ready = false;
+    // The selectivity guard of the IVF-PQ prefilter decides per (k, nprobe): synchronously the first time (and every 64th),
+    // from the PREVIOUS batch's counters otherwise -- they arrive through a pinned buffer and an event, nothing waits.  The
+    // decision only picks kernels; results do not depend on it.
+    struct GuardEntry {
+        int form = -1;            // -1 not decided yet, 0 exact kernels (abandon), 1 half form, 2 integer form
+        int32_t* h_poor = nullptr; // pinned [2]
+        hipEvent_t ev = nullptr;
+        bool pending = false;
+        int64_t pending_nq = 0;
+        int age = 0;
+    };
+    mutable std::map<std::pair<int, int>, GuardEntry> guard_cache; // (under mu)
     mutable bool idmap_ready = false; // IVF-Flat direct map (knhip_index_get_vectors): built on first use
     mutable DevBuf idmap_ids, idmap_col;
     mutable int64_t last_range_ranks = 0; // coarse ranks the last range search scanned per query (rank waves)
@@ -1055,20 +1067,60 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
                                                    ws->ms_qis.as<float>(), ws->ms_qmu.as<float>(), /*stats_done=*/true,
                                                    s));
                 }
-                int32_t h_poor[2] = {0, 0};
+                auto decide = [&](const int32_t* poor_h, int64_t n) -> int {
+                    if ((int64_t)poor_h[0] * 4 > n) {
+                        return 0;
+                    }
+                    return (want_i8 && (idx->pqf_form == 2 || (int64_t)poor_h[1] * 4 <= n)) ? 2 : 1;
+                };
+                int form = want_i8 ? 2 : 1; // (guard off: the form asked for)
                 if (idx->pqf_guard) {
                     int32_t* poor = ws->ms_cand_cnt.as<int32_t>() + 2 * nq + 1;
                     HIP_TRY(launch_pqf_predict(ws->dump.as<float>(), sample, ws->ms_nrow.as<int32_t>(),
                                                ws->gthr.as<float>(), ws->ms_qs.as<float>(),
                                                want_i8 ? ws->ms_qis.as<float>() : nullptr, keys_p, nprobe, nlist,
                                                idx->d_list_len.as<int64_t>(), nq, ms_cap, k, is_l2, poor, s));
-                    HIP_TRY(hipMemcpyAsync(h_poor, poor, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-                    HIP_TRY(hipStreamSynchronize(s));
-                    if ((int64_t)h_poor[0] * 4 > nq) {
+                    bool sync_now = true;
+                    {
+                        std::lock_guard<std::mutex> lk(idx->mu);
+                        knhip_index::GuardEntry& e = idx->guard_cache[{k, nprobe}];
+                        if (e.pending && hipEventQuery(e.ev) == hipSuccess) { // the previous batch's counters are in
+                            e.pending = false;
+                            e.form = decide(e.h_poor, e.pending_nq);
+                        }
+                        e.age++;
+                        static const bool always_sync = getenv("KNHIP_PQF_GUARD_SYNC") != nullptr;
+                        if (e.form > 0 && !always_sync && (e.age & 63) != 0) {
+                            sync_now = false;
+                            form = e.form;
+                            if (!e.pending) {
+                                if (e.h_poor == nullptr) {
+                                    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e.h_poor), 2 * sizeof(int32_t)));
+                                    HIP_TRY(hipEventCreateWithFlags(&e.ev, hipEventDisableTiming));
+                                }
+                                HIP_TRY(hipMemcpyAsync(e.h_poor, poor, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+                                HIP_TRY(hipEventRecord(e.ev, s));
+                                e.pending = true;
+                                e.pending_nq = nq;
+                            }
+                        }
+                    }
+                    if (sync_now) {
+                        int32_t h_poor[2] = {0, 0};
+                        HIP_TRY(hipMemcpyAsync(h_poor, poor, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+                        HIP_TRY(hipStreamSynchronize(s));
+                        form = decide(h_poor, nq);
+                        std::lock_guard<std::mutex> lk(idx->mu);
+                        knhip_index::GuardEntry& e = idx->guard_cache[{k, nprobe}];
+                        if (!e.pending) {
+                            e.form = form;
+                        }
+                    }
+                    if (form == 0) {
                         return KNHIP_PQF_ABANDONED;
                     }
                 }
-                pq_i8 = want_i8 && (idx->pqf_form == 2 || !idx->pqf_guard || (int64_t)h_poor[1] * 4 <= nq);
+                pq_i8 = form == 2;
                 idx->last_pq_form = pq_i8 ? 2 : 1;
                 if (!pq_i8) {
                     // the queries' half tables + scales (the same records the sample pass wrote)
@@ -1505,6 +1557,10 @@ void knhip_index_destroy(knhip_index* idx) {
     for (auto& p : idx->pending) {
         (void)hipEventDestroy(p.e0);
         (void)hipEventDestroy(p.e1);
+    }
+    for (auto& kv : idx->guard_cache) {
+        if (kv.second.ev) (void)hipEventDestroy(kv.second.ev);
+        if (kv.second.h_poor) (void)hipHostFree(kv.second.h_poor);
     }
     delete idx;
 }

@@ -101,6 +101,9 @@ inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 constexpr unsigned hipEventDisableTiming = 2;
 inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; } // (launches run in order)
+inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; } // (everything enqueued has already run)
+inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = std::malloc(n); return *p ? hipSuccess : hipErrorOutOfMemory; }
+inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 [[noreturn]] inline void hipemu_unreachable() { // stands in for inline ISA (kernels that hold it are not run here)
