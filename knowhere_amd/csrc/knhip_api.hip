@@ -974,7 +974,6 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         // IVF-PQ: the pairs are grouped by list (work table: four small, latency-bound kernels, ~0.25 ms per 10^4 queries at
         // C3) on a side stream while this stream runs the sample pass; only the cut into units waits for the form.
         SideJoin sj{ws, s};
-        const int qg_units = 1; // (the work table's own items are not used by the prefilter: units are cut below)
         if (wt1_lazy && getenv("KNHIP_NO_SIDE_STREAM") == nullptr) {
             if (ws->side == nullptr) {
                 HIP_TRY(hipStreamCreateWithFlags(&ws->side, hipStreamNonBlocking));
@@ -989,7 +988,6 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             HIP_TRY(hipEventRecord(ws->ev_join, ws->side));
             sj.forked = true;
         }
-        (void)qg_units;
         const bool wt2_done = sj.forked;
         auto launch_filter = [&](const MScanArgs& x, int64_t bound) -> hipError_t {
             return kind == KNHIP_IVF_FLAT ? launch_mscan_flat(x, is_l2, bound, s)
