@@ -88,6 +88,24 @@ def main():
                 assert np.array_equal(exp[0], got[0]) and np.array_equal(exp[1], got[1])
                 assert np.array_equal(exp[2].view(np.uint32), got[2].view(np.uint32))
             g.close()
+    elif case == "range_waves":
+        # nlist > 128 with an early stop: the probes go in waves of coarse ranks (range.hip); IVF-Flat and IVF-SQ8
+        nb, d, nlist, nq = 2500, 8, 200, 4
+        xb, xq = gen_data(nb, d, 42), gen_data(nq, d, 44)
+        for kind in (ob.IVF_FLAT, ob.IVF_SQ8):
+            ix = ob.make_index(port, kind, ob.L2, xb, nlist=nlist)
+            g = GpuIndex.from_data(ix, device=0)
+            D, _ = port.search(ix, xq, 40, nlist)
+            radius = float(np.median(D[:, 20]))
+            for max_empty in (1, 3, 0):
+                exp = port.range_search(ix, xq, radius, max_empty)
+                got = g.range_search(xq, np.float32(radius), max_empty)
+                assert np.array_equal(exp[0], got[0]) and np.array_equal(exp[1], got[1]), (kind, max_empty)
+                assert np.array_equal(exp[2].view(np.uint32), got[2].view(np.uint32))
+                ranks = g.last_range_ranks()
+                assert ranks == nlist if max_empty == 0 else ranks <= nlist, (kind, max_empty, ranks)
+                assert exp[0][-1] > 0
+            g.close()
     else:
         raise SystemExit(f"unknown case {case}")
     print("OK", case)

@@ -261,6 +261,13 @@ def test_emulated_api_range_search_pq16():
     _run_api_case("range_pq16")
 
 
+@pytest.mark.timeout(1800)
+def test_emulated_api_range_search_rank_waves():
+    """range search with nlist > 128 and an early stop: wave gather, the list-based dump kernels, per-wave counts and the
+    early-stop state kernel, all emulated; lims / ids / order / bits equal to the oracle's walk over every rank"""
+    _run_api_case("range_waves")
+
+
 @pytest.mark.timeout(1500)
 @pytest.mark.parametrize("is_l2", [True, False], ids=["l2", "ip"])
 def test_emulated_merge_of_more_than_4096_partial_lists(emu, is_l2):
