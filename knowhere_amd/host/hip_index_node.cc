@@ -288,7 +288,12 @@ class HipIndexNode : public IndexNode {
             int64_t kbase = k;
             if constexpr (Kind == KNHIP_IVF_PQ || Kind == KNHIP_IVF_SQ8) {
                 if (has_refine_ && raw_.p && c.refine_k.has_value()) {
-                    kbase = std::min<int64_t>(1024, std::max<int64_t>(k, (int64_t)(k * c.refine_k.value())));
+                    const int64_t want = std::max<int64_t>(k, (int64_t)(k * c.refine_k.value()));
+                    kbase = std::min<int64_t>(1024, want);
+                    if (kbase < want) {  // (the first stage returns at most 1024 candidates per query: said, not hidden)
+                        LOG_KNOWHERE_WARNING_ << "GPU_HIP refine: k * refine_k = " << want << " clamped to " << kbase
+                                              << (kbase <= k ? " (refine stage skipped)" : "");
+                    }
                 }
             }
             if (kbase > k) {
