@@ -794,8 +794,12 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
     // 4-query kernel.
     bool use_ms = false;
     int ms_cap = 0, ms_nchunk = 0, ms_nstep = 0;
-    const bool pqf_shape = kind == KNHIP_IVF_PQ && idx->pqf != 0 && pq_use_v2 && idx->cb_t.p != nullptr &&
-            pqf_supports(idx->desc.pq_m, d) && pq_scan_q4_supports(idx->desc.pq_m, d, k) &&
+    // (k <= 128: the exact fallback of its overflowed queries is the 4-query kernel; 128 < k <= 1024 -- Knowhere's refine
+    // asks for k * refine_k candidates -- it is the systolic kernel over one-pair items: the filter, the sample and the
+    // finish take any k)
+    const bool pq_q4_ok = kind == KNHIP_IVF_PQ && pq_scan_q4_supports(idx->desc.pq_m, d, k);
+    const bool pqf_shape = kind == KNHIP_IVF_PQ && idx->pqf != 0 && idx->pq_v2 && idx->cb_t.p != nullptr &&
+            pqf_supports(idx->desc.pq_m, d) && k <= 1024 && (pq_q4_ok || pq_scan_supported_m(idx->desc.pq_m)) &&
             (!is_l2 || idx->use_precomp); // (residual tables: see pq_psum_kernel)
     // (COSINE with stored norms takes the exact kernels: the prefilter's bound does not carry the per-row division)
     if ((kind == KNHIP_IVF_FLAT || kind == KNHIP_IVF_SQ8 || pqf_shape) && (idx->mscan != 0 || pqf_shape) && nprobe >= 2 &&
@@ -832,9 +836,9 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
     }
     if (use_ms && kind == KNHIP_IVF_PQ) { // (no rank-0 dump phase: the sample pass of the prefilter gives the bounds)
         pq_rank0 = false;
-        pq_use_q4 = true;
-        qg_bulk = 4;
-        qg_rank0 = 4;
+        pq_use_q4 = pq_q4_ok;
+        qg_bulk = pq_q4_ok ? 4 : qg;
+        qg_rank0 = pq_q4_ok ? 4 : qg;
     }
     const int64_t items_bound =
             round_up(npairs / std::min(qg_rank0, qg_bulk) + std::min<int64_t>(2 * nlist, npairs) + 1, 8);
@@ -1266,9 +1270,11 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         if (use_ms) {
             // half-precision prefilter + exact finish (pq_filter.hip); the queries that overflow twice take the exact
             // 4-query kernel over one-pair items
-            a.codes_skew = idx->rows2.as<uint4>();
-            a.list_sblk_off = idx->d_list_blk_off2.as<int64_t>();
-            a.cb_t = idx->cb_t.as<float4>();
+            if (pq_q4_ok) {
+                a.codes_skew = idx->rows2.as<uint4>();
+                a.list_sblk_off = idx->d_list_blk_off2.as<int64_t>();
+                a.cb_t = idx->cb_t.as<float4>();
+            }
             const int rc_ms = run_mscan([&](const KnItem* items, const KnPair* pairs, const int64_t* nitems, int64_t) -> int {
                 PqScanArgs b = a;
                 b.items = items;
@@ -1276,6 +1282,17 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
                 b.nitems_dev = nitems;
                 b.item_lo = nullptr;
                 b.item_hi = nitems;
+                if (!pq_q4_ok) {
+                    // k > 128: the systolic kernel, one workgroup per one-pair item (normally none: the workgroups of
+                    // the launch read the item count and return)
+                    if (!idx->skew_ready) {
+                        if (int rc = build_pq_skew(idx)) return rc;
+                    }
+                    b.codes_skew = idx->rows.as<uint4>();
+                    b.list_sblk_off = idx->d_list_blk_off.as<int64_t>();
+                    HIP_TRY(launch_pq_scan(b, is_l2, M, npairs, s));
+                    return KNHIP_OK;
+                }
                 HIP_TRY(ws->recs4.reserve((size_t)npairs * sizeof(P4Rec)));
                 HIP_TRY(ws->q4_ctr.reserve(8 * 16 * sizeof(int32_t)));
                 b.recs4 = ws->recs4.as<P4Rec>();

@@ -126,6 +126,28 @@ def test_pqf_overflow_goes_through_the_exact_kernel(torch_cuda, port, monkeypatc
 
 
 @pytest.mark.parametrize("metric", [ob.L2, ob.IP], ids=["l2", "ip"])
+def test_pqf_large_k(torch_cuda, port, monkeypatch, metric):
+    """128 < k <= 1024 (Knowhere's refine asks the first stage for k * refine_k candidates): sample, filter and finish
+    take any k; the queries that overflow are redone by the systolic exact kernel over one-pair items.  Bits equal to the
+    exact kernels and the oracle, with the prefilter really used, and with the overflow fallback forced by a bitset."""
+    nb, d, nlist = 60000, 128, 48
+    xb, xq = gen_data(nb, d, 42), gen_data(70, d, 44)
+    ix = finish_ivfpq(port, ob.make_index(port, ob.IVF_PQ, metric, xb, nlist=nlist, M=32))
+    g0, g1 = _pair(monkeypatch, ix, guard=False)
+    used = 0
+    for k, nprobe in ((200, 8), (1000, 4), (1024, nlist), (129, 2)):
+        p = _check(port, ix, g0, g1, xq, k, nprobe, metric, f"large k metric={metric} k={k} nprobe={nprobe}")
+        assert p["mscan_queries"] + p["mscan_overflow_queries"] == len(xq)
+        used += p["mscan_queries"]
+    assert used > 0
+    bs = _bitset(nb, 0.995, 7)  # ~300 unfiltered rows: no query finds 200 of them in its sample
+    p = _check(port, ix, g0, g1, xq, 200, nlist, metric, "large k, 99.5 % filtered", bs, nb)
+    assert p["mscan_overflow_queries"] > 0
+    g0.close()
+    g1.close()
+
+
+@pytest.mark.parametrize("metric", [ob.L2, ob.IP], ids=["l2", "ip"])
 def test_pqf_retry_round(torch_cuda, port, monkeypatch, metric):
     """a tiny candidate capacity makes most queries overflow with candidates in hand: retried as one-query units with the
     exact k-th of those candidates as their bound"""
