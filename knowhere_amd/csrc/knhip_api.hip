@@ -1083,7 +1083,14 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
                                                want_i8 ? ws->ms_qis.as<float>() : nullptr, keys_p, nprobe, nlist,
                                                idx->d_list_len.as<int64_t>(), nq, ms_cap, k, is_l2, poor, s));
                     bool sync_now = true;
+                    // (at most 64 (k, nprobe) pairs are remembered -- an entry owns a pinned buffer and an event; a caller
+                    // that keeps inventing new pairs gets the synchronous decision)
+                    bool cached = false;
                     {
+                        std::lock_guard<std::mutex> lk(idx->mu);
+                        cached = idx->guard_cache.size() < 64 || idx->guard_cache.count({k, nprobe}) != 0;
+                    }
+                    if (cached) {
                         std::lock_guard<std::mutex> lk(idx->mu);
                         knhip_index::GuardEntry& e = idx->guard_cache[{k, nprobe}];
                         if (e.pending && hipEventQuery(e.ev) == hipSuccess) { // the previous batch's counters are in
@@ -1112,10 +1119,12 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
                         HIP_TRY(hipMemcpyAsync(h_poor, poor, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
                         HIP_TRY(hipStreamSynchronize(s));
                         form = decide(h_poor, nq);
-                        std::lock_guard<std::mutex> lk(idx->mu);
-                        knhip_index::GuardEntry& e = idx->guard_cache[{k, nprobe}];
-                        if (!e.pending) {
-                            e.form = form;
+                        if (cached) {
+                            std::lock_guard<std::mutex> lk(idx->mu);
+                            knhip_index::GuardEntry& e = idx->guard_cache[{k, nprobe}];
+                            if (!e.pending) {
+                                e.form = form;
+                            }
                         }
                     }
                     if (form == 0) {
