@@ -387,13 +387,17 @@ def make_roofline(a, kind, prof, world):
                 kn = f"knhip::pqi_kernel<{l2s}>"
                 note = ("achieved = 1 B x code bytes scanned / launch time (int8 table, 16 queries per ds_read_b128 = one "
                         "v_mfma_i32_16x16x64_i8); peak = 256 B/clk/CU x 256 CU x 2.4 GHz (the matrix pipe binds at the same "
-                        "rate: 1024 lookups per 16 cycles and SIMD)")
+                        "rate: 1024 lookups per 16 cycles and SIMD); the kernel is launched twice per step -- the scan and the "
+                        "normally empty retry round (~5 us) -- so rocprofv3's per-kernel AVERAGE is half of ms_per_launch, its "
+                        "MAX is the scan launch (profiles/r03_c3_pqi_stats.json)")
             else:
                 lds = scan_bytes * 2.0 / sec / 1e9 if sec > 0 else 0.0
                 kn = f"knhip::pqf_kernel<{l2s}, false>"
                 note = ("achieved = 2 B x code bytes scanned / launch time (half-precision table, 8 queries per ds_read_b128 "
                         "= one v_mfma_f32_16x16x32_f16); peak = 256 B/clk/CU x 256 CU x 2.4 GHz (the matrix pipe binds at "
-                        "the same rate: 512 lookups per 16 cycles and SIMD)")
+                        "the same rate: 512 lookups per 16 cycles and SIMD); the kernel is launched twice per step -- the scan "
+                        "and the normally empty retry round -- so rocprofv3's per-kernel AVERAGE is half of ms_per_launch, its "
+                        "MAX is the scan launch")
             return with_pmc(dict({"bound": "lds", "kernel": kn, "achieved": round(lds, 1),
                          "peak": round(LDS_PEAK_GBPS, 1), "unit": "GB/s", "frac": round(lds / LDS_PEAK_GBPS, 4),
                          "note": note, "filter_form": "int8 x 16 queries" if i8 else "half x 8 queries",
