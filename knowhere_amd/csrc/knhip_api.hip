@@ -2234,7 +2234,7 @@ static int range_batch(const knhip_index* idx, Workspace* ws, const float* d_q, 
             HIP_TRY(hipMemsetAsync(ws->rg_cnt.p, 0, (size_t)nq * nprobe * sizeof(int32_t), s));
             int32_t* qstate = ws->rg_state.as<int32_t>();
             int32_t* alive = qstate + 2 * nq;
-            int r0 = 0, W = std::max(64, 2 * max_empty);
+            int r0 = 0, W = std::max(64, 2 * std::min(max_empty, nprobe));
             while (r0 < nprobe) {
                 const int Wc = std::min(W, nprobe - r0);
                 HIP_TRY(ws->rg_keys_w.reserve((size_t)nq * Wc * sizeof(int64_t)));
@@ -2249,7 +2249,7 @@ static int range_batch(const knhip_index* idx, Workspace* ws, const float* d_q, 
                 HIP_TRY(hipMemcpyAsync(&h_alive, alive, sizeof(int32_t), hipMemcpyDeviceToHost, s));
                 HIP_TRY(hipStreamSynchronize(s));
                 r0 += Wc;
-                W *= 2;
+                W = W < nprobe ? W * 2 : W;
                 if (h_alive == 0) {
                     break;
                 }
