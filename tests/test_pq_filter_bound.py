@@ -168,3 +168,69 @@ def test_lane_map_covers_every_subquantizer_once_without_bank_conflicts():
             for n in range(16):
                 L = 16 * kb + n
                 assert (lane_vec(L) == 16 * (i >> 3) + n) == on
+
+
+# ---- integer form: the integer fast path is a superset of the fp32 test ------------------------------------------------
+def _int_threshold(t, inv0, is_l2):
+    """pqi_kernel, per-pair constants: T in units of s0 (the float arithmetic of the kernel, step by step)"""
+    tt = f32(t) if is_l2 else f32(-f32(t))
+    with np.errstate(all="ignore"):  # (inf - inf / inf * x on the pass-nothing thresholds: NaN, clamped below as fmaxf does)
+        x = f32(np.floor(f32(f32(tt + f32(f32(2.384185791015625e-7) * f32(abs(tt)))) * inv0)) + f32(2.0))
+    lim = f32(2.0 * 536870912.0)
+    if np.isnan(x):
+        x = -lim  # fmaxf(NaN, lo) = lo
+    x = min(max(x, -lim), lim)
+    return int(x)
+
+
+@pytest.mark.parametrize("is_l2", [True, False], ids=["l2", "ip"])
+def test_integer_fast_path_is_a_superset_of_the_fp32_test(is_l2):
+    """pq_filter.hip, integer form: with s_q = w s0 (s0 a power of two, w an integer weight in the selector operand) and the
+    accumulator started at -T, the per-group test `w S - T <= ceil(-ps / s0)` (IP: `-w S - T <= 0`) must pass every
+    (S, ps, t) the fp32 test `fma(S, s_q, ps) <= t` (IP: `S s_q >= t`) passes -- else a candidate would be lost.  Random and
+    edge inputs over twelve orders of magnitude of the step; also: T stays inside the clamp, and the fp32 value rebuilt
+    in the slow path from the integer accumulator equals the fma of the first version bit for bit."""
+    rng = np.random.default_rng(7)
+    n_pass = 0
+    for trial in range(60000):
+        e0 = int(rng.integers(-40, 20))
+        s0 = f32(2.0 ** e0)
+        inv0 = f32(1.0) / s0
+        w = int(rng.integers(1, 128))
+        s_q = f32(f32(w) * s0)  # exact: w < 2^7
+        S = int(rng.integers(-4064, 4065))  # sum of 32 int8 entries
+        scale = float(s_q) * 4064.0
+        kind = trial % 6
+        ps = f32(rng.normal(0.0, scale)) if is_l2 and kind != 0 else f32(0.0)
+        if is_l2 and kind == 1:
+            ps = f32(rng.normal(0.0, scale * 1e3))  # term-2 sums far above the table part
+        # thresholds around the decision boundary, exactly on it, and far away
+        val = np.float32(np.float64(S) * np.float64(s_q) + np.float64(ps))
+        t = f32(val + f32(rng.normal(0.0, 1.0)) * f32(scale * 1e-3)) if kind < 4 else (
+            f32(val) if kind == 4 else f32(rng.normal(0.0, scale * 10)))
+        if abs(float(ps)) * float(inv0) >= 2.0 ** 29:  # (the table kernel refuses such batches: eps = inf)
+            continue
+        # fp32 test of the kernel's slow path: one fused multiply-add, then the compare
+        v = np.float32(np.float64(f32(S)) * np.float64(s_q) + np.float64(ps))  # fma: one rounding
+        passes_f = (v <= t) if is_l2 else (np.float32(np.float64(f32(S)) * np.float64(s_q)) >= t)
+        # integer test
+        T = _int_threshold(t, inv0, is_l2)
+        assert abs(T) <= 2 ** 30
+        Y = w * S
+        negp = int(np.ceil(f32(f32(-ps) * inv0))) if is_l2 else 0
+        x = (Y - T) if is_l2 else (-Y - T)
+        passes_i = x <= negp
+        if passes_f:
+            n_pass += 1
+            assert passes_i, (trial, e0, w, S, float(ps), float(t), T, negp)
+        # the slow path's rebuilt operand: y = x + T (L2) / -(x + T) (IP) is w S exactly, and fma(y, s0, ps) == fma(S, s_q, ps)
+        y = (x + T) if is_l2 else -(x + T)
+        assert y == Y
+        v2 = np.float32(np.float64(f32(y)) * np.float64(s0) + np.float64(ps if is_l2 else f32(0)))
+        v1 = np.float32(np.float64(f32(S)) * np.float64(s_q) + np.float64(ps if is_l2 else f32(0)))
+        assert v1.view(np.uint32) == v2.view(np.uint32)
+    assert n_pass > 5000  # (the boundary cases really were exercised)
+    # pass-nothing and NaN thresholds: nothing may pass the integer test by accident of the conversion
+    for t in (-np.inf, np.nan) if is_l2 else (np.inf, np.nan):
+        T = _int_threshold(f32(t), f32(1.0), is_l2)
+        assert T == -2 ** 30
