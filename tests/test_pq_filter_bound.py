@@ -234,3 +234,75 @@ def test_integer_fast_path_is_a_superset_of_the_fp32_test(is_l2):
     for t in (-np.inf, np.nan) if is_l2 else (np.inf, np.nan):
         T = _int_threshold(f32(t), f32(1.0), is_l2)
         assert T == -2 ** 30
+
+
+def _int8_prep(Qf, s0, pabs_max):
+    """pqi_query_stats_kernel + pqi_query_table_kernel: per-m midranges, the lattice step w s0 >= R / 254, int8 table, eps"""
+    hi, lo = Qf.max(1), Qf.min(1)
+    mu = (f32(0.5) * hi + f32(0.5) * lo).astype(f32)
+    A = f32(0)
+    musum = f32(0)
+    R = f32(0)
+    for m in range(M):
+        musum = f32(musum + mu[m])
+        A = f32(A + max(abs(hi[m]), abs(lo[m])))
+        R = max(R, f32(hi[m] - lo[m]))
+    inv0 = f32(1.0) / s0
+    w = f32(min(max(np.ceil(f32(f32(R / f32(254.0)) * inv0)), 1.0), 127.0))
+    step = f32(w * s0)
+    eps = f32(f32(16.4) * step + f32(128.0) * U * f32(pabs_max + A) + f32(64.0) * U * abs(musum))
+    inv = f32(1.0) / step
+    Qi = np.clip(np.rint(((Qf - mu[:, None]).astype(f32) * inv).astype(f32)), -127, 127).astype(np.int32)
+    return int(w), step, musum, A, R, eps, Qi
+
+
+def _base_step(rmax):
+    """pqi_base_step: the power of two s0 with 127 s0 >= rmax / 254"""
+    _, e = np.frexp(f32(rmax / f32(254.0 * 127.0)))
+    return f32(np.ldexp(1.0, int(max(e, -100))))
+
+
+@pytest.mark.parametrize("is_l2", [True, False], ids=["l2", "ip"])
+@pytest.mark.parametrize("scale", [1e-3, 1.0, 300.0])
+@pytest.mark.parametrize("mode", ["random", "one_signed", "mixed_magnitudes"])
+def test_int8_adc_bound_holds_on_lattice_steps(is_l2, scale, mode):
+    """integer form: |approx - exact| <= eps = 16.4 s_q + fp32 terms with s_q rounded UP to the batch's lattice (w s0); the
+    batch's largest range comes from another query of up to 40 x the magnitude, so small weights (coarse lattice points)
+    are exercised; the weight is an integer in [1, 127] and the table stays inside int8"""
+    rng = np.random.default_rng(int(scale * 11) % 1000 + len(mode) + (5 if is_l2 else 0))
+    q, cb = _case(rng, scale, mode)
+    Qf = _tables(q, cb, is_l2)
+    cen = (rng.standard_normal(M * DSUB) * scale).astype(f32)
+    P = np.zeros((M, KSUB), f32)
+    if is_l2:
+        for m in range(M):
+            P[m] = (cb[m] * cb[m]).sum(1) + f32(2) * (cb[m] * cen[m * DSUB:(m + 1) * DSUB]).sum(1)
+    codes = rng.integers(0, KSUB, (48, M))
+    codes[0] = (Qf - Qf.min(1, keepdims=True)).argmax(1)  # every entry at its column maximum
+    ar = np.arange(M)
+    pabs_max = f32(np.abs(P[ar, codes]).astype(f32).sum(1, dtype=f32).max()) if is_l2 else f32(0)
+    R_q = f32((Qf.max(1) - Qf.min(1)).max())
+    for blow in (1.0, 3.7, 40.0):  # the batch's widest query relative to this one
+        s0 = _base_step(f32(R_q * f32(blow)))
+        w, step, musum, A, R, eps_base, Qi = _int8_prep(Qf, s0, pabs_max)
+        assert 1 <= w <= 127 and float(step) >= float(R) / 254.0 and np.abs(Qi).max() <= 127
+        dis0 = f32(abs(rng.standard_normal()) * scale * scale * 40)
+        eps = f32(eps_base + f32(64.0) * U * f32(abs(dis0) + abs(dis0) + abs(musum)))
+        worst = 0.0
+        for row in codes:
+            acc = f32(0)
+            for m in range(M):
+                lut = f32(P[m, row[m]] + Qf[m, row[m]]) if is_l2 else Qf[m, row[m]]
+                acc = f32(acc + lut)
+            exact = f32(dis0 + acc)
+            S = int(Qi[ar, row].sum())  # int32 accumulation: exact
+            ps = f32(0)
+            for m in range(M):
+                ps = f32(ps + P[m, row[m]])
+            # kernel: fma(S, s_q, ps) against ((tau + eps) - dis0) - musum; pessimistic value fma(S, s_q, (dis0 + musum) + ps)
+            v = np.float32(np.float64(f32(S)) * np.float64(step) + np.float64(ps if is_l2 else f32(0)))
+            approx = f32(f32(v + musum) + dis0)
+            err = abs(float(approx) - float(exact))
+            assert err <= float(eps), (blow, err, float(eps))
+            worst = max(worst, err / float(eps))
+        assert worst < 0.75, f"the bound holds but with little room: {worst:.3f} of eps (blow {blow})"
