@@ -306,3 +306,48 @@ def test_int8_adc_bound_holds_on_lattice_steps(is_l2, scale, mode):
             assert err <= float(eps), (blow, err, float(eps))
             worst = max(worst, err / float(eps))
         assert worst < 0.75, f"the bound holds but with little room: {worst:.3f} of eps (blow {blow})"
+
+
+@pytest.mark.parametrize("is_l2", [True, False], ids=["l2", "ip"])
+@pytest.mark.parametrize("scale", [1e-3, 1.0, 300.0])
+@pytest.mark.parametrize("mode", ["random", "one_signed", "mixed_magnitudes"])
+def test_sample_pass_value_is_pessimistic(is_l2, scale, mode):
+    """pq_sample_kernel: dump = ((dis0 + psum) + sum_m Qf[m][code]) made pessimistic by
+    slack = 128 u (pabs_max + A) + 64 u |dis0| + 64 u |value|: it must never be BETTER than the reference's exact distance
+    (tau_q, the k-th best dump value, has to bound the k-th exact distance from the safe side), and it should stay close."""
+    rng = np.random.default_rng(int(scale * 13) % 1000 + len(mode) + (7 if is_l2 else 0))
+    q, cb = _case(rng, scale, mode)
+    Qf = _tables(q, cb, is_l2)
+    cen = (rng.standard_normal(M * DSUB) * scale).astype(f32)
+    P = np.zeros((M, KSUB), f32)
+    if is_l2:
+        for m in range(M):
+            P[m] = (cb[m] * cb[m]).sum(1) + f32(2) * (cb[m] * cen[m * DSUB:(m + 1) * DSUB]).sum(1)
+    codes = rng.integers(0, KSUB, (64, M))
+    ar = np.arange(M)
+    pabs_max = f32(np.abs(P[ar, codes]).astype(f32).sum(1, dtype=f32).max()) if is_l2 else f32(0)
+    A = f32(0)
+    for m in range(M):
+        A = f32(A + np.abs(Qf[m]).max())
+    dis0 = f32(abs(rng.standard_normal()) * scale * scale * 40)
+    slack0 = f32(f32(128.0) * U * f32(pabs_max + A) + f32(64.0) * U * abs(dis0))
+    for row in codes:
+        acc = f32(0)
+        for m in range(M):
+            lut = f32(P[m, row[m]] + Qf[m, row[m]]) if is_l2 else Qf[m, row[m]]
+            acc = f32(acc + lut)
+        exact = f32(dis0 + acc)
+        ps = f32(0)
+        for m in range(M):
+            ps = f32(ps + P[m, row[m]])
+        t = f32(0)
+        for m in range(M):
+            t = f32(t + Qf[m, row[m]])
+        val = f32(f32(dis0 + ps) + t) if is_l2 else f32(dis0 + t)
+        slack = f32(slack0 + f32(64.0) * U * abs(val))
+        pess = f32(val + slack) if is_l2 else f32(val - slack)
+        if is_l2:
+            assert float(pess) >= float(exact), (float(pess), float(exact))
+        else:
+            assert float(pess) <= float(exact), (float(pess), float(exact))
+        assert abs(float(pess) - float(exact)) <= 2.5 * float(slack) + 1e-30
