@@ -46,7 +46,9 @@
 extern "C" {
 #endif
 
-#define KNHIP_ABI_VERSION 3
+/* 4: knhip_train_params gained spherical/reserved, knhip_stage_times its prefilter counters.
+ * Callers compare knhip_abi_version() with the header they were built against. */
+#define KNHIP_ABI_VERSION 4
 
 typedef struct knhip_index knhip_index;
 

@@ -38,12 +38,16 @@ int knhip_shard_group_search(knhip_shard_group* g, const float* queries, int64_t
  * of the vector ids [id_base, id_base + nrows) in its HBM (d_rows: device pointer on device_ids[r]; the split of the raw
  * rows need not follow the split of the lists).  search_refine: k_base candidates per rank -> all-gather + merge (the same
  * merged candidates on every rank) -> every rank re-ranks exactly the candidates whose rows it holds -> all-gather + merge
- * of the (nq, k) partials.  stage_ms: [n_devices][7] = {search, gather + merge, -, refine, gather + merge, -, total}. */
+ * of the (nq, k) partials.  A rank with nrows = 0 holds no raw rows and contributes an empty partial.  A failure on any
+ * rank before a collective makes EVERY rank skip it (agreement under a host barrier); a failure of the collective's own
+ * enqueue marks the group unusable (later calls fail at once; destroy aborts the communicators).  stage_ms: [n_devices][7] = {search, gather + merge, -, refine, gather + merge, -, total}. */
 int knhip_shard_group_set_raw(knhip_shard_group* g, int32_t rank, const float* d_rows, int64_t nrows, int64_t id_base);
 int knhip_shard_group_search_refine(knhip_shard_group* g, const float* queries, int64_t nq, int32_t k, int32_t k_base,
                                     int32_t nprobe, const uint8_t* bitset, int64_t bitset_nbits, int64_t* out_ids,
                                     float* out_dist, float* stage_ms);
 int32_t knhip_shard_group_size(const knhip_shard_group* g);
+/* message of the last failed knhip_shard_group_* call on this thread (the per-rank text: "rank r: ...") */
+const char* knhip_shard_group_last_error(void);
 
 #ifdef __cplusplus
 }

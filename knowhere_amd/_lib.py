@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("KNHIP_LIB") or os.path.join(_HERE, "libknhip.so")  # 
 BRUTE_FORCE, IVF_FLAT, IVF_PQ, IVF_SQ8 = 0, 1, 2, 3
 L2, IP = 0, 1
 NSTAGE = 8
+ABI_VERSION = 4  # KNHIP_ABI_VERSION of include/knhip.h
 STAGE_COARSE, STAGE_GROUP, STAGE_LUT, STAGE_SCAN, STAGE_MERGE, STAGE_OTHER, STAGE_SCAN_RANK0 = range(7)
 
 
@@ -75,6 +76,8 @@ def load():
             "(python -c 'import __graft_entry__ as g; g.build()' or make -C knowhere_amd/csrc). "
             "knowhere_amd has no CPU fallback.")
     L = C.CDLL(LIB_PATH)
+    if L.knhip_abi_version() != ABI_VERSION:  # the structures below mirror include/knhip.h at this version
+        raise ImportError(f"{LIB_PATH} speaks ABI {L.knhip_abi_version()}, this binding {ABI_VERSION}: rebuild the library")
     vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int32
     L.knhip_last_error.restype = C.c_char_p
     L.knhip_stage_kernel_name.restype = C.c_char_p

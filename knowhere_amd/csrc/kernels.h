@@ -262,6 +262,7 @@ struct MScanArgs {
     const float* pq_qis;           // [nq][4] = {step, sum of the per-m offsets, eps_base, A}
     P16Rec* pq_recs16;             // [unit bound]
     int32_t* pq_ctr;               // [8 * 16] one unit counter per XCD, 64 B apart
+    int32_t pq_prune_mu;           // finish kernel: pq_qs is the integer form's record ([q][1] = sum of the per-m offsets)
 };
 
 // ---- pq_filter.hip ----

@@ -1185,6 +1185,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             MScanArgs mf = m;
             if (pq_i8) {
                 mf.pq_qs = m.pq_qis; // (the finish kernel's pruning reads eps_base at [q][2] of either)
+                mf.pq_prune_mu = 1;  // (... and the integer form's emission eps carries |sum of the per-m offsets|)
             }
             HIP_TRY(launch_mscan_finish(mf, kind, is_l2, keys_p, cdis_p, nprobe, k, d_out_d, d_out_i, counters, 1, s));
             HIP_TRY(launch_ms_flag_pairs(overflow, 2, keys_p, nq, nprobe, nlist, idx->d_list_len.as<int64_t>(), k,
@@ -1474,7 +1475,7 @@ int64_t query_batch(const knhip_index* idx, int64_t nq, int k, int nprobe) {
         if ((idx->desc.kind == KNHIP_IVF_FLAT || idx->desc.kind == KNHIP_IVF_SQ8) && idx->mscan != 0) {
             per_q += 4.0 * mscan_sample_rows() + 8.0 * 32768.0; // sample dump + candidate list (mfma_scan.hip)
         }
-        if (idx->desc.kind == KNHIP_IVF_PQ && idx->pqf == 1) {
+        if (idx->desc.kind == KNHIP_IVF_PQ && idx->pqf != 0) {
             // sample dump + candidate list + half table + one-pair records of the fallbacks (pq_filter.hip)
             per_q += 4.0 * mscan_sample_rows() + 12.0 * 32768.0 + 16384.0 + 8192.0 + (double)nprobe * (256.0 + 96.0);
         }
@@ -3156,13 +3157,19 @@ int knhip_index_add_assigned_by(knhip_index* idx, int64_t n, const float* x_stor
     }
     DeviceGuard g(idx->desc.device);
     std::lock_guard<std::mutex> lk(idx->add_mu);
-    DevBuf dx, da, di;
-    if (int rc = upload(dx, x_store, (size_t)n * idx->d * sizeof(float))) return rc;
-    if (int rc = upload(da, x_assign, (size_t)n * idx->d * sizeof(float))) return rc;
-    if (ids) {
-        if (int rc = upload(di, ids, (size_t)n * sizeof(int64_t))) return rc;
+    // slices of at most 1 GiB per row array keep the staging buffers bounded, as knhip_index_add does
+    const int64_t step = std::max<int64_t>(1, ((int64_t)1 << 30) / ((int64_t)idx->d * 4));
+    for (int64_t i0 = 0; i0 < n; i0 += step) {
+        const int64_t m = std::min(step, n - i0);
+        DevBuf dx, da, di;
+        if (int rc = upload(dx, x_store + i0 * idx->d, (size_t)m * idx->d * sizeof(float))) return rc;
+        if (int rc = upload(da, x_assign + i0 * idx->d, (size_t)m * idx->d * sizeof(float))) return rc;
+        if (ids) {
+            if (int rc = upload(di, ids + i0, (size_t)m * sizeof(int64_t))) return rc;
+        }
+        if (int rc = add_device_impl(idx, m, dx.as<float>(), ids ? di.as<int64_t>() : nullptr, da.as<float>())) return rc;
     }
-    return add_device_impl(idx, n, dx.as<float>(), ids ? di.as<int64_t>() : nullptr, da.as<float>());
+    return KNHIP_OK;
 }
 
 int knhip_index_encode_device(const knhip_index* idx, int64_t n, const float* d_x, int64_t* d_assign, uint8_t* d_codes,

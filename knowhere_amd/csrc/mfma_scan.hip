@@ -1051,7 +1051,9 @@ __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, c
         for (int w = 1; w < MF_THREADS / KN_WAVE; w++) {
             cmax = fmaxf(cmax, s_red[w]);
         }
-        const float eps_max = a.pq_qs[q * 4 + 2] + 64.0f * 5.9604645e-8f * (cmax + fabsf(a.gthr[q]));
+        // (completed below, once tau2 is known: the emission's eps used |tau| of a bound between gthr and tau2)
+        const float eps_q = a.pq_qs[q * 4 + 2], eps_mu = a.pq_prune_mu ? fabsf(a.pq_qs[q * 4 + 1]) : 0.f;
+        const float gthr_abs = fabsf(a.gthr[q]);
         uint32_t pk[MF_PRUNE_PER_THREAD];
         int64_t pc[MF_PRUNE_PER_THREAD];
         float pp[MF_PRUNE_PER_THREAD];
@@ -1100,6 +1102,11 @@ __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, c
             }
         }
         const float tau2 = dist_key_inv<IS_L2>(lo);
+        // eps_max dominates the eps of EVERY emission of this query (pq_filter.hip: eps_base + 64 u (|dis0| + |tau| [+ |mu|])):
+        // |dis0| <= cmax; the emission's tau lies between the sample bound gthr and the final k-th pessimistic distance
+        // tau2 (a histogram edge is only read once k candidates sit below it), so |tau| <= max(|gthr|, |tau2|); the
+        // integer form's per-query offset sum rides in [q][1] of its record
+        const float eps_max = eps_q + 64.0f * 5.9604645e-8f * (cmax + fmaxf(gthr_abs, fabsf(tau2)) + eps_mu);
         if (eps_max < INFINITY && tau2 == tau2 && fabsf(tau2) < FLT_MAX) {
             if (tid == 0) {
                 s_cnt = 0;

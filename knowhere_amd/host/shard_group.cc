@@ -76,6 +76,9 @@ struct knhip_shard_group {
     int transport = KNHIP_SHARDS_RCCL;
     std::vector<Rank> ranks;
     std::mutex call_mu;  // one Search() at a time per group
+    // RCCL transport: a collective that some ranks enqueued and others did not can never complete; the group is then
+    // unusable (every later call fails at once, destroy aborts the communicators instead of draining them)
+    std::atomic<bool> dead{false};
 };
 
 namespace {
@@ -93,6 +96,12 @@ __global__ void pack_kernel(const float* d, const int64_t* i, int64_t n, uint32_
     out[3 * t] = __float_as_uint(d[t]);
     out[3 * t + 1] = (uint32_t)(uint64_t)i[t];
     out[3 * t + 2] = (uint32_t)((uint64_t)i[t] >> 32);
+}
+__global__ void fill_empty_kernel(float* d, int64_t* i, int64_t n, float worst) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    d[t] = worst;
+    i[t] = -1;
 }
 __global__ void unpack_kernel(const uint32_t* in, int64_t n, float* d, int64_t* i) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -178,7 +187,7 @@ void knhip_shard_group_destroy(knhip_shard_group* g) {
     if (!g) return;
     for (Rank& k : g->ranks) {
         (void)hipSetDevice(k.dev);
-        if (k.comm) (void)ncclCommDestroy(k.comm);
+        if (k.comm) (void)(g->dead.load() ? ncclCommAbort(k.comm) : ncclCommDestroy(k.comm));
         if (k.stream) (void)hipStreamDestroy(k.stream);
     }
     delete g;
@@ -214,6 +223,9 @@ static int search_impl(knhip_shard_group* g, const float* queries, int64_t nq, i
     }
     const bool refine = k_base != 0;
     std::lock_guard<std::mutex> call_lk(g->call_mu);
+    if (g->dead.load()) {
+        return fail(KNHIP_ERR_HIP_RUNTIME, "shard group is unusable after a failed collective: destroy and recreate it");
+    }
     const int W = g->n;
     knhip_desc desc{};
     if (int drc = knhip_index_get_desc(g->ranks[0].idx, &desc)) return fail(drc, knhip_last_error());
@@ -223,20 +235,24 @@ static int search_impl(knhip_shard_group* g, const float* queries, int64_t nq, i
     const int64_t ne1 = nq * (int64_t)k1;         // entries per rank, first exchange
     const int64_t ne = nq * (int64_t)k;           // entries of the result
     Barrier bar(W);
-    std::vector<int> rcs(W, KNHIP_OK);
+    std::vector<std::atomic<int>> rcs(W);  // (read by the peers between barriers)
+    for (auto& a : rcs) a.store(KNHIP_OK);
     std::vector<std::string> errs(W);
     std::vector<std::thread> th;
     Rank* R = g->ranks.data();
     const int NS = refine ? 7 : 4;  // stage_ms columns: {search, gather, merge, [refine, gather, merge,] total}
     auto worker = [&](int r) {
-        int& rc = rcs[r];
+        int rc = KNHIP_OK;  // published to rcs[r] by post() before every barrier the peers look behind
         std::string& err = errs[r];
+        auto post = [&]() {
+            if (rc != KNHIP_OK) rcs[r].store(rc);
+        };
         Rank& me = R[r];
         bool alive = true;  // (a failed rank still walks through every barrier)
         hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         auto all_ok = [&]() {
             bool ok = true;
-            for (int o = 0; o < W; o++) ok = ok && rcs[o] == KNHIP_OK;
+            for (int o = 0; o < W; o++) ok = ok && rcs[o].load() == KNHIP_OK;
             return ok;
         };
         // ---- one exchange step: pack (pd, pi) [nq][kk], all-gather of the packed partials, unpack + merge -> (od, oi);
@@ -254,14 +270,26 @@ static int search_impl(knhip_shard_group* g, const float* queries, int64_t nq, i
                 alive = rc == KNHIP_OK;
             }
             if (g->transport == KNHIP_SHARDS_RCCL) {
-                if (alive) {
+                // agreement BEFORE the collective: every rank posts its status, all read the same verdict, and only
+                // then does anyone enqueue -- a rank that failed earlier (allocation, search, merge) makes every rank skip
+                // the all-gather instead of leaving the others' streams behind a collective that never completes
+                post();
+                bar.wait();
+                const bool go = all_ok();
+                bar.wait();  // (nobody posts a new status before everyone has read the verdict)
+                if (!go) {
+                    alive = false;
+                } else {
                     const ncclResult_t nr = ncclAllGather(me.packed.p, me.gathered.p, (size_t)n * 12, ncclChar, me.comm, me.stream);
                     if (nr != ncclSuccess) {
+                        // the peers may have enqueued theirs: nothing can be salvaged on these communicators
                         err = std::string("ncclAllGather: ") + ncclGetErrorString(nr);
                         rc = KNHIP_ERR_HIP_RUNTIME;
                         alive = false;
+                        g->dead.store(true);
                     }
                 }
+                post();
                 bar.wait();
             } else {
                 if (alive && hipStreamSynchronize(me.stream) != hipSuccess) {
@@ -269,6 +297,7 @@ static int search_impl(knhip_shard_group* g, const float* queries, int64_t nq, i
                     err = "stream synchronize failed";
                     alive = false;
                 }
+                post();
                 bar.wait();  // every rank's packed partial is complete
                 if (alive && all_ok()) {
                     for (int o = 0; o < W && alive; o++) {  // pull every rank's block (peer copies; same device: plain copies)
@@ -285,6 +314,7 @@ static int search_impl(knhip_shard_group* g, const float* queries, int64_t nq, i
                         alive = false;
                     }
                 }
+                post();
                 bar.wait();  // nobody's packed buffer is overwritten before everyone has read it
             }
             auto tail = [&]() {
@@ -350,7 +380,12 @@ static int search_impl(knhip_shard_group* g, const float* queries, int64_t nq, i
         if (refine) {
             // every rank holds the same merged candidates; it re-ranks those whose raw rows live here (ids outside
             // [raw_id0, raw_id0 + raw_n) are skipped slots of refine.hip), then the (nq, k) partials are exchanged
-            if (alive) {
+            if (alive && me.raw_n == 0) {
+                // this rank holds no raw rows (the raw split need not follow the list split): an all-empty partial
+                hipLaunchKernelGGL(fill_empty_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, me.stream,
+                                   static_cast<float*>(me.ref_d.p), static_cast<int64_t*>(me.ref_i.p), ne,
+                                   metric == KNHIP_L2 ? 3.402823466e+38f : -3.402823466e+38f);
+            } else if (alive) {
                 const int rrc = knhip_refine_device(metric, dim, me.raw, me.raw_n, me.raw_id0, static_cast<const float*>(me.q.p),
                                                     nq, static_cast<const int64_t*>(me.out_i.p), k1, k,
                                                     static_cast<float*>(me.ref_d.p), static_cast<int64_t*>(me.ref_i.p), me.stream);
@@ -397,7 +432,10 @@ static int search_impl(knhip_shard_group* g, const float* queries, int64_t nq, i
                 }
             }
         };
+        post();
+        bar.wait();
         if (alive && all_ok()) finish();
+        post();
         for (auto& e : ev) {
             if (e) (void)hipEventDestroy(e);
         }
@@ -405,7 +443,7 @@ static int search_impl(knhip_shard_group* g, const float* queries, int64_t nq, i
     for (int r = 0; r < W; r++) th.emplace_back(worker, r);
     for (auto& t : th) t.join();
     for (int r = 0; r < W; r++) {
-        if (rcs[r] != KNHIP_OK) return fail(rcs[r], "rank " + std::to_string(r) + ": " + errs[r]);
+        if (rcs[r].load() != KNHIP_OK) return fail(rcs[r].load(), "rank " + std::to_string(r) + ": " + errs[r]);
     }
     return KNHIP_OK;
 }

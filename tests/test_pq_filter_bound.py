@@ -351,3 +351,110 @@ def test_sample_pass_value_is_pessimistic(is_l2, scale, mode):
         else:
             assert float(pess) <= float(exact), (float(pess), float(exact))
         assert abs(float(pess) - float(exact)) <= 2.5 * float(slack) + 1e-30
+
+
+# ---- the finish kernel's prune (mfma_scan.hip, KIND 2): its eps_max must dominate the eps of every emission --------------
+@pytest.mark.parametrize("is_l2", [True, False], ids=["l2", "ip"])
+@pytest.mark.parametrize("form", ["half", "int8"])
+@pytest.mark.parametrize("mode", ["random", "one_signed", "mixed_magnitudes"])
+def test_finish_prune_bound_dominates_every_emission(is_l2, form, mode):
+    """mscan_finish_kernel prunes a candidate when its OPTIMISTIC distance `pess -+ 2 eps_max` is beyond the k-th best
+    pessimistic distance tau2.  That is only sound while `exact >= pess - 2 eps_max` (L2; IP mirrored) for EVERY
+    emitted candidate: the candidate's pess was built with the emission's own eps = eps_base + 64 u (|dis0| + |tau|
+    [+ |sum mu|, integer form]) where dis0 is the probe's coarse distance (any sign for the inner product, the farthest
+    probe has |dis0| = cmax) and tau is whatever bound the unit read -- the sample bound gthr or a tighter histogram
+    edge, never beyond tau2.  Replay: several probes per query, tau swept over [gthr, tau2], pess as the kernel builds
+    it, eps_max by the finish kernel's formula; the inequality must hold for each, and a candidate the prune DROPS
+    must be strictly worse than k exact distances."""
+    rng = np.random.default_rng(101 + 7 * len(mode) + (3 if is_l2 else 0) + (11 if form == "int8" else 0))
+    scale = 30.0
+    q, cb = _case(rng, scale, mode)
+    Qf = _tables(q, cb, is_l2)
+    ar = np.arange(M)
+    nprobe, rows, k = 6, 40, 5
+    # coarse distances: L2 positive and growing, IP of either sign with a large positive head (positive-score IP)
+    dis0s = (np.sort(np.abs(rng.standard_normal(nprobe))) * scale * scale * 60).astype(f32)
+    if not is_l2:
+        dis0s = (dis0s[::-1] - f32(scale * scale * 20)).astype(f32)
+    cmax = f32(np.abs(dis0s).max())
+    P_all, codes_all = [], []
+    for p in range(nprobe):
+        cen = (rng.standard_normal(M * DSUB) * scale).astype(f32)
+        P = np.zeros((M, KSUB), f32)
+        if is_l2:
+            for m in range(M):
+                P[m] = (cb[m] * cb[m]).sum(1) + f32(2) * (cb[m] * cen[m * DSUB:(m + 1) * DSUB]).sum(1)
+        P_all.append(P)
+        codes_all.append(rng.integers(0, KSUB, (rows, M)))
+    pabs_max = f32(max(np.abs(P_all[p][ar, c]).astype(f32).sum(dtype=f32) for p in range(nprobe) for c in codes_all[p])) \
+        if is_l2 else f32(0)
+    if form == "half":
+        A, sc, Qh, eps_base = _query_prep(Qf, pabs_max)
+        isc = f32(1.0) / sc
+        musum = f32(0)
+    else:
+        R_q = f32((Qf.max(1) - Qf.min(1)).max())
+        s0 = _base_step(f32(R_q * f32(3.7)))
+        w, step, musum, A, R, eps_base, Qi = _int8_prep(Qf, s0, pabs_max)
+    # exact distances of everything (the reference's sequence)
+    exact = np.zeros((nprobe, rows), f32)
+    for p in range(nprobe):
+        for r, row in enumerate(codes_all[p]):
+            acc = f32(0)
+            for m in range(M):
+                lut = f32(P_all[p][m, row[m]] + Qf[m, row[m]]) if is_l2 else Qf[m, row[m]]
+                acc = f32(acc + lut)
+            exact[p, r] = f32(dis0s[p] + acc)
+    flat = np.sort(exact.ravel())
+    kth = flat[k - 1] if is_l2 else flat[-k]
+    # gthr: a loose sample bound; the emission's tau anywhere between it and (about) the final k-th value
+    gthr = f32(kth + f32(abs(kth)) * f32(0.5) + f32(scale * scale)) if is_l2 else f32(kth - f32(abs(kth)) * f32(0.5) - f32(scale * scale))
+    def emit(tau_of):
+        pess_all, exact_all, eps_all = [], [], []
+        for p in range(nprobe):
+            dis0 = dis0s[p]
+            for r, row in enumerate(codes_all[p]):
+                tau = tau_of()
+                eps = f32(eps_base + f32(64.0) * U * f32(f32(abs(dis0) + abs(tau)) + (abs(musum) if form == "int8" else f32(0))))
+                ps = f32(0)
+                for m in range(M):
+                    ps = f32(ps + P_all[p][m, row[m]])
+                if form == "half":
+                    h = f32(0)
+                    for m in range(M):
+                        h = f32(h + f32(Qh[m, row[m]]))
+                    pcs = f32(dis0 + eps) if is_l2 else f32(dis0 - eps)
+                    pess = np.float32(np.float64(h) * np.float64(isc) + np.float64(f32(pcs + ps) if is_l2 else pcs))
+                else:
+                    S = int(Qi[ar, row].sum())
+                    pcs = f32(f32(dis0 + musum) + eps) if is_l2 else f32(f32(dis0 + musum) - eps)
+                    pess = np.float32(np.float64(f32(S)) * np.float64(step) + np.float64(f32(pcs + ps) if is_l2 else pcs))
+                pess_all.append(pess)
+                exact_all.append(exact[p, r])
+                eps_all.append(eps)
+        return np.array(pess_all, f32), np.array(exact_all, f32), np.array(eps_all, f32)
+
+    # the loosest emission (every unit read the sample bound) gives a provisional k-th pessimistic value; a histogram edge
+    # a unit can read lies between the sample bound and that value (k candidates must sit below it), and tightening tau
+    # only moves the final tau2 further to the good side
+    p0, _, _ = emit(lambda: gthr)
+    s0_ = np.sort(p0)
+    tau2_0 = s0_[k - 1] if is_l2 else s0_[-k]
+    pess_all, exact_all, eps_all = emit(lambda: f32(gthr + (tau2_0 - gthr) * f32(rng.random())))
+    # every candidate's pess is on the safe side of its exact distance
+    assert ((pess_all >= exact_all) if is_l2 else (pess_all <= exact_all)).all()
+    srt = np.sort(pess_all)
+    tau2 = srt[k - 1] if is_l2 else srt[-k]
+    # the finish kernel's formula
+    eps_max = f32(eps_base + f32(64.0) * f32(5.9604645e-8) *
+                  f32(f32(cmax + max(f32(abs(gthr)), f32(abs(tau2)))) + (abs(musum) if form == "int8" else f32(0))))
+    opt = (pess_all - f32(2.0) * eps_max) if is_l2 else (pess_all + f32(2.0) * eps_max)
+    assert ((opt <= exact_all) if is_l2 else (opt >= exact_all)).all(), "optimistic bound is not below the exact distance"
+    dropped = (opt > tau2) if is_l2 else (opt < tau2)
+    assert ((exact_all[dropped] > kth) if is_l2 else (exact_all[dropped] < kth)).all(), "the prune dropped a top-k row"
+    # ... and it dominates the eps each emission used (what the prune's `2 eps_max` stands for)
+    assert (eps_all <= eps_max).all()
+    # the first version's formula (no |sum mu| term, |gthr| only) does NOT dominate them on the integer form
+    eps_old = f32(eps_base + f32(64.0) * f32(5.9604645e-8) * f32(cmax + f32(abs(gthr))))
+    if form == "int8" and abs(float(musum)) > 0:
+        assert (eps_all > eps_old).any()
