@@ -223,6 +223,19 @@ class GpuIndex:
         check(self.L.knhip_search(self.h, _np_ptr(xq), nq, k, nprobe, _np_ptr(bs), nbits, _np_ptr(I), _np_ptr(D)))
         return D, I
 
+    def search_refine(self, raw, xq, k, k_base, nprobe=1, bitset=None, nbits=0):
+        """knhip_search_refine across the HOST boundary: k_base candidates from this index, re-ranked exactly against the
+        rows of `raw` (a BRUTE_FORCE GpuIndex on the same device), k best returned -- what the node's Search() calls"""
+        xq = np.ascontiguousarray(xq, np.float32)
+        nq = xq.shape[0]
+        D = np.empty((nq, k), np.float32)
+        I = np.empty((nq, k), np.int64)
+        bs = None if bitset is None else np.ascontiguousarray(bitset, np.uint8)
+        nbits = _bitset_nbits(bs, nbits)
+        check(self.L.knhip_search_refine(self.h, raw.h, _np_ptr(xq), nq, k, k_base, nprobe, _np_ptr(bs), nbits,
+                                         _np_ptr(I), _np_ptr(D)))
+        return D, I
+
     def get_vectors(self, ids):
         """stored fp32 rows by id (knhip_index_get_vectors: BRUTE_FORCE, or IVF_FLAT through its direct map)"""
         ids = np.ascontiguousarray(ids, np.int64)
