@@ -92,6 +92,9 @@ typedef struct knhip_desc {
 int knhip_abi_version(void);
 int knhip_device_count(void);
 const char* knhip_last_error(void);
+/* free / total HBM of a device: what cuvs_knowhere_index::deserialize looks at to place a loaded index on the device
+ * with the most free memory (src/common/cuvs/integration/cuvs_knowhere_index.cuh:678-690) */
+int knhip_device_memory(int32_t device, int64_t* free_bytes, int64_t* total_bytes);
 
 /* ---- index lifetime and contents (all pointers below are HOST pointers) ---- */
 int knhip_index_create(const knhip_desc* desc, knhip_index** out);
@@ -177,6 +180,10 @@ int knhip_index_add_device(knhip_index* idx, int64_t n, const float* d_x, const 
  * add_with_ids (cppcontrib/knowhere/IndexIVFFlat.cpp:516-524) assigns by the normalised row and stores the raw one */
 int knhip_index_add_assigned_by(knhip_index* idx, int64_t n, const float* x_store, const float* x_assign,
                                 const int64_t* ids);
+/* quantizer->assign of n HOST rows (IndexIVF::add_core's first step, IndexIVF.cpp:236): assign [n] int64, the list every
+ * row would be appended to (first maximum for the inner product, as IndexFlat::assign).  What a node that deals its
+ * inverted lists over several devices needs to route a row to the device owning its list. */
+int knhip_index_assign(const knhip_index* idx, int64_t n, const float* x, int64_t* assign);
 /* assignment + codes of n device rows without adding them: d_assign [n] int64, d_codes [n][code_size] */
 int knhip_index_encode_device(const knhip_index* idx, int64_t n, const float* d_x, int64_t* d_assign, uint8_t* d_codes,
                               void* stream);
@@ -240,6 +247,10 @@ int knhip_search_refine(const knhip_index* idx, const knhip_index* raw, const fl
  * direct map built on first use from the index's own ids (16 bytes per vector in HBM; the reference's
  * make_direct_map / reconstruct, thirdparty/faiss/faiss/IndexIVF.cpp); an id that is not stored is an error. */
 int knhip_index_get_vectors(const knhip_index* idx, int64_t n, const int64_t* ids, float* out);
+/* the tolerant form for an index that holds only part of the id space (one shard of a list-sharded IVF_FLAT, one row
+ * range of a sharded FLAT): found[i] = 1 and out row i written where id i is stored here, found[i] = 0 and the row left
+ * untouched otherwise; never an error for an absent id. */
+int knhip_index_find_vectors(const knhip_index* idx, int64_t n, const int64_t* ids, float* out, uint8_t* found);
 /* Same with every buffer already in HBM; enqueued on `stream` (hipStream_t, NULL = default
  * stream) and NOT synchronised at the end.  One exception inside: an IVF_PQ m = 32 batch that takes the matrix-core
  * prefilter (pq_filter.hip) waits once on `stream` in the middle of the batch the FIRST time a (k, nprobe) pair is seen

@@ -50,7 +50,7 @@ SYMBOLS = [
     "knhip_kmeans_device", "knhip_index_train", "knhip_index_train_device", "knhip_index_add", "knhip_index_add_device",
     "knhip_index_encode_device", "knhip_index_get_coarse", "knhip_index_get_pq", "knhip_index_get_sq",
     "knhip_index_get_list_sizes", "knhip_index_get_lists", "knhip_index_get_vectors_device", "knhip_search_refine",
-    "knhip_index_get_vectors",
+    "knhip_index_get_vectors", "knhip_index_find_vectors", "knhip_index_assign", "knhip_device_memory",
     "knhip_fvec_L1_ny", "knhip_fvec_Linf_ny", "knhip_fvec_norms_L2sqr_ref", "knhip_fvec_L2sqr_ny_transposed",
     "knhip_fvec_L2sqr_ny_nearest", "knhip_fvec_L2sqr_ny_nearest_y_transposed", "knhip_fvec_madd_and_argmin",
     "knhip_fvec_batch_4", "knhip_typed_vec_ny", "knhip_typed_vec_batch_4", "knhip_ivec_ny",
@@ -143,6 +143,9 @@ def load():
     L.knhip_index_get_vectors_device.argtypes = [vp, C.POINTER(vp)]
     L.knhip_search_refine.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp, i64, vp, vp]
     L.knhip_index_get_vectors.argtypes = [vp, i64, vp, vp]
+    L.knhip_index_find_vectors.argtypes = [vp, i64, vp, vp, vp]
+    L.knhip_index_assign.argtypes = [vp, i64, vp, vp]
+    L.knhip_device_memory.argtypes = [i32, vp, vp]
     L.knhip_profile_enable.argtypes = [vp, C.c_int]
     L.knhip_profile_reset.argtypes = [vp]
     L.knhip_profile_get.argtypes = [vp, C.POINTER(StageTimes)]

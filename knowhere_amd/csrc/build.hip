@@ -67,7 +67,7 @@ __global__ void idmap_cols_kernel(const int64_t* __restrict__ list_row_off, cons
 __global__ void idmap_gather_kernel(const int64_t* __restrict__ want, int64_t n, const int64_t* __restrict__ ids_sorted,
                                     const int64_t* __restrict__ col_sorted, int64_t ntotal,
                                     const float4* __restrict__ rows, int d, int nchunk, float* __restrict__ out,
-                                    int32_t* __restrict__ missing) {
+                                    int32_t* __restrict__ missing, uint8_t* __restrict__ found) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n * nchunk) {
         return;
@@ -87,8 +87,14 @@ __global__ void idmap_gather_kernel(const int64_t* __restrict__ want, int64_t n,
     if (lo >= ntotal || ids_sorted[lo] != id) {
         if (c == 0) {
             atomicAdd(missing, 1);
+            if (found) {
+                found[i] = 0;
+            }
         }
         return;
+    }
+    if (c == 0 && found) {
+        found[i] = 1;
     }
     const int64_t col = col_sorted[lo];
     const float4 v = rows[(col >> 6) * (int64_t)nchunk * 64 + (int64_t)c * 64 + (col & 63)];
@@ -122,13 +128,14 @@ hipError_t launch_idmap_build(const int64_t* ids, const int64_t* list_row_off, c
 }
 
 hipError_t launch_idmap_gather(const int64_t* want, int64_t n, const int64_t* ids_sorted, const int64_t* col_sorted,
-                               int64_t ntotal, const float4* rows, int d, float* out, int32_t* missing, hipStream_t s) {
+                               int64_t ntotal, const float4* rows, int d, float* out, int32_t* missing, hipStream_t s,
+                               uint8_t* found) {
     if (n <= 0) {
         return hipSuccess;
     }
     const int nchunk = (d + 3) / 4;
     hipLaunchKernelGGL(idmap_gather_kernel, dim3((unsigned)((n * nchunk + 255) / 256)), dim3(256), 0, s, want, n,
-                       ids_sorted, col_sorted, ntotal, rows, d, nchunk, out, missing);
+                       ids_sorted, col_sorted, ntotal, rows, d, nchunk, out, missing, found);
     return hipGetLastError();
 }
 

@@ -493,7 +493,8 @@ hipError_t launch_idmap_build(const int64_t* ids, const int64_t* list_row_off, c
                               int64_t ntotal, int64_t* col_tmp, int64_t* ids_sorted, int64_t* col_sorted, void* tmp,
                               size_t tmp_bytes, hipStream_t s);
 hipError_t launch_idmap_gather(const int64_t* want, int64_t n, const int64_t* ids_sorted, const int64_t* col_sorted,
-                               int64_t ntotal, const float4* rows, int d, float* out, int32_t* missing, hipStream_t s);
+                               int64_t ntotal, const float4* rows, int d, float* out, int32_t* missing, hipStream_t s,
+                               uint8_t* found = nullptr); // found [n] (optional): 1 = the id is stored here, its row was written
 hipError_t launch_gather_rows(const float* x, const int64_t* rows, int64_t n, int d, float* out, hipStream_t s);
 hipError_t launch_residual(const float* x, const float* cen, const int64_t* assign, int64_t n, int d, float* out,
                            hipStream_t s);

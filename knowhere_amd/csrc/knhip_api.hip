@@ -1497,6 +1497,19 @@ int64_t query_batch(const knhip_index* idx, int64_t nq, int k, int nprobe) {
 // =================================================================================================
 extern "C" {
 
+int knhip_device_memory(int32_t device, int64_t* free_bytes, int64_t* total_bytes) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "device_memory: no such device");
+    }
+    DeviceGuard g(device);
+    size_t f = 0, t = 0;
+    HIP_TRY(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = (int64_t)f;
+    if (total_bytes) *total_bytes = (int64_t)t;
+    return KNHIP_OK;
+}
+
 int knhip_abi_version(void) {
     return KNHIP_ABI_VERSION;
 }
@@ -2043,6 +2056,69 @@ int knhip_index_get_vectors(const knhip_index* idx, int64_t n, const int64_t* id
     HIP_TRY(dout.alloc((size_t)n * idx->d * sizeof(float)));
     HIP_TRY(launch_gather_rows(idx->codes_aos.as<float>(), dr.as<int64_t>(), n, idx->d, dout.as<float>(), nullptr));
     HIP_TRY(hipMemcpy(out, dout.p, (size_t)n * idx->d * sizeof(float), hipMemcpyDeviceToHost));
+    return KNHIP_OK;
+}
+
+int knhip_index_find_vectors(const knhip_index* idx, int64_t n, const int64_t* ids, float* out, uint8_t* found) {
+    if (int rc = check_index(idx)) return rc;
+    const int kind = idx->desc.kind;
+    if ((kind != KNHIP_BRUTE_FORCE && kind != KNHIP_IVF_FLAT) || n < 0 || (n > 0 && (!ids || !out || !found))) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "find_vectors: brute-force or IVF-Flat index, ids, output and flags required");
+    }
+    if (n == 0) {
+        return KNHIP_OK;
+    }
+    DeviceGuard g(idx->desc.device);
+    const int d = idx->d;
+    if (kind == KNHIP_BRUTE_FORCE) {
+        // rows by id range: gather the ones that live here
+        std::vector<int64_t> rows, where;
+        for (int64_t i = 0; i < n; i++) {
+            const int64_t r = ids[i] - idx->id_offset;
+            found[i] = (r >= 0 && r < idx->ntotal) ? 1 : 0;
+            if (found[i]) {
+                rows.push_back(r);
+                where.push_back(i);
+            }
+        }
+        if (rows.empty()) {
+            return KNHIP_OK;
+        }
+        DevBuf dr, dout;
+        if (int rc = upload(dr, rows.data(), rows.size() * sizeof(int64_t))) return rc;
+        HIP_TRY(dout.alloc(rows.size() * d * sizeof(float)));
+        HIP_TRY(launch_gather_rows(idx->codes_aos.as<float>(), dr.as<int64_t>(), (int64_t)rows.size(), d, dout.as<float>(),
+                                   nullptr));
+        std::vector<float> tmp(rows.size() * (size_t)d);
+        HIP_TRY(hipMemcpy(tmp.data(), dout.p, tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (size_t j = 0; j < rows.size(); j++) {
+            std::memcpy(out + where[j] * d, tmp.data() + j * d, (size_t)d * sizeof(float));
+        }
+        return KNHIP_OK;
+    }
+    if (idx->ntotal == 0) {
+        std::memset(found, 0, (size_t)n);
+        return KNHIP_OK;
+    }
+    if (int rc = ensure_idmap(idx)) return rc;
+    DevBuf dw, dout, dmiss, dfound;
+    if (int rc = upload(dw, ids, (size_t)n * sizeof(int64_t))) return rc;
+    HIP_TRY(dout.alloc((size_t)n * d * sizeof(float)));
+    HIP_TRY(dmiss.alloc(sizeof(int32_t)));
+    HIP_TRY(dfound.alloc((size_t)n));
+    HIP_TRY(hipMemset(dmiss.p, 0, sizeof(int32_t)));
+    HIP_TRY(hipMemset(dfound.p, 0, (size_t)n));
+    HIP_TRY(launch_idmap_gather(dw.as<int64_t>(), n, idx->idmap_ids.as<int64_t>(), idx->idmap_col.as<int64_t>(), idx->ntotal,
+                                idx->rows.as<float4>(), d, dout.as<float>(), dmiss.as<int32_t>(), nullptr,
+                                dfound.as<uint8_t>()));
+    std::vector<float> tmp((size_t)n * d);
+    HIP_TRY(hipMemcpy(found, dfound.p, (size_t)n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(tmp.data(), dout.p, tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < n; i++) {
+        if (found[i]) {
+            std::memcpy(out + i * d, tmp.data() + (size_t)i * d, (size_t)d * sizeof(float));
+        }
+    }
     return KNHIP_OK;
 }
 
@@ -3168,6 +3244,28 @@ int knhip_index_add_assigned_by(knhip_index* idx, int64_t n, const float* x_stor
             if (int rc = upload(di, ids + i0, (size_t)m * sizeof(int64_t))) return rc;
         }
         if (int rc = add_device_impl(idx, m, dx.as<float>(), ids ? di.as<int64_t>() : nullptr, da.as<float>())) return rc;
+    }
+    return KNHIP_OK;
+}
+
+int knhip_index_assign(const knhip_index* idx, int64_t n, const float* x, int64_t* assign) {
+    if (int rc = check_index(idx)) return rc;
+    if (idx->desc.kind == KNHIP_BRUTE_FORCE || n < 0 || (n > 0 && (!x || !assign))) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "assign: IVF index, rows and output required");
+    }
+    if (!idx->has_coarse) {
+        return fail(KNHIP_ERR_NOT_TRAINED, "coarse centroids not set");
+    }
+    DeviceGuard g(idx->desc.device);
+    const int64_t step = std::max<int64_t>(1, ((int64_t)1 << 30) / ((int64_t)idx->d * 4));
+    for (int64_t i0 = 0; i0 < n; i0 += step) {
+        const int64_t m = std::min(step, n - i0);
+        DevBuf dx, da;
+        if (int rc = upload(dx, x + i0 * idx->d, (size_t)m * idx->d * sizeof(float))) return rc;
+        HIP_TRY(da.alloc((size_t)m * sizeof(int64_t)));
+        if (int rc = assign_rows(idx, dx.as<float>(), m, da.as<int64_t>(), nullptr)) return rc;
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(assign + i0, da.p, (size_t)m * sizeof(int64_t), hipMemcpyDeviceToHost));
     }
     return KNHIP_OK;
 }

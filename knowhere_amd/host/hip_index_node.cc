@@ -19,19 +19,27 @@
 //           for k * refine_k candidates, re-ranked exactly on the device (knhip_search_refine).
 //   RangeSearch  IvfIndexNode::RangeSearch (ivf.cc:1231-1497) -> knhip_range_search; range_filter applied here
 //           (src/common/range_util.cc:27-48).  GetIndexMeta: not_implemented, as the cuVS node (gpu_cuvs.h:192-201).
+//   Devices cuvs_knowhere_index (src/common/cuvs/integration/cuvs_knowhere_index.cuh): every index instance owns a device --
+//           round-robin over the visible ones at Train (select_device_id, :414-426), the one with the most free
+//           memory at Deserialize (:678-690) -- or the `gpu_id` of the config.  `gpu_ids` with several ordinals deals
+//           the inverted lists (FLAT: the rows) over those devices: one knhip_index per device, Search() through
+//           knhip_shard_group_* (include/knhip_shards.h), bit-identical to the single-device index.
 //   Serialize / Deserialize: one named blob (Type()) in a BinarySet (ivf.cc:1717-1834) in the FAISS byte format the
 //           CPU nodes write (IxF2/IxFI/IxF9, IwFl, IwSq, IwPQ, IxRF; faiss_io.h), so a CPU-built index loads here and back.
 #include "hip_index_node.h"
 
 #include "../../include/knhip.h"
+#include "../../include/knhip_shards.h"
 #include "faiss_io.h"
 
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <atomic>
 #include <numeric>
 #include <shared_mutex>
+#include <thread>
 
 namespace knowhere {
 
@@ -96,12 +104,90 @@ InverseL2Norm(const float* x, int64_t d) {
 
 struct KnhipHandle {
     knhip_index* p = nullptr;
+    KnhipHandle() = default;
+    KnhipHandle(const KnhipHandle&) = delete;
+    KnhipHandle& operator=(const KnhipHandle&) = delete;
+    KnhipHandle(KnhipHandle&& o) noexcept : p(o.p) { o.p = nullptr; }
+    KnhipHandle& operator=(KnhipHandle&& o) noexcept {
+        if (this != &o) {
+            knhip_index_destroy(p);
+            p = o.p;
+            o.p = nullptr;
+        }
+        return *this;
+    }
     ~KnhipHandle() { knhip_index_destroy(p); }
     void reset() {
         knhip_index_destroy(p);
         p = nullptr;
     }
 };
+
+// one device's part of an index: everything (single device) or the inverted lists / row range this device owns
+struct Shard {
+    int32_t device = 0;
+    KnhipHandle idx;
+    KnhipHandle raw;       // refine rows (IndexRefineFlat) whose ids are [raw_base, raw_base + count(raw))
+    int64_t raw_base = 0;
+    int64_t row_base = 0;  // sharded FLAT: id of this shard's first row
+};
+
+struct GroupHandle {
+    knhip_shard_group* p = nullptr;
+    ~GroupHandle() { knhip_shard_group_destroy(p); }
+    void reset() {
+        knhip_shard_group_destroy(p);
+        p = nullptr;
+    }
+};
+
+// test hook: the devices the last Train / Deserialize on this thread placed its index on (node_capi.cc)
+thread_local std::vector<int32_t> g_last_placement;
+
+// select_device_id() of the cuVS integration (cuvs_knowhere_index.cuh:414-426): one counter for every index of the process
+int32_t
+RoundRobinDevice(int ndev) {
+    static std::atomic<int> index_counter{0};
+    return (int32_t)(index_counter.fetch_add(1) % std::max(ndev, 1));
+}
+// ... and of its deserialize (:678-690): the device with the most free memory
+int32_t
+MostFreeDevice(int ndev) {
+    int32_t best = 0;
+    int64_t best_free = -1;
+    for (int i = 0; i < ndev; i++) {
+        int64_t f = 0, t = 0;
+        if (knhip_device_memory(i, &f, &t) == KNHIP_OK && f > best_free) {
+            best_free = f;
+            best = i;
+        }
+    }
+    return best;
+}
+
+// size-balanced deal of the inverted lists (longest-processing-time-first as knowhere_amd/sharded.py::
+// partition_lists): lists sorted by length (longest first, ties by list number), each dealt to the currently lightest
+// shard (ties: the shard with fewer lists, then the lowest -- empty lists spread out instead of piling up on shard 0)
+std::vector<int32_t>
+DealLists(const std::vector<int64_t>& sizes, int W) {
+    const int64_t nlist = (int64_t)sizes.size();
+    std::vector<int64_t> order((size_t)nlist);
+    std::iota(order.begin(), order.end(), (int64_t)0);
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return sizes[a] > sizes[b]; });
+    std::vector<int64_t> load((size_t)W, 0);
+    std::vector<int64_t> cnt((size_t)W, 0);
+    std::vector<int32_t> owner((size_t)nlist, 0);
+    for (int64_t l : order) {
+        int best = 0;
+        for (int r = 1; r < W; r++) {
+            if (load[r] < load[best] || (load[r] == load[best] && cnt[r] < cnt[best])) best = r;
+        }
+        owner[(size_t)l] = best;
+        load[best] += sizes[l];
+        cnt[best]++;
+    }
+    return owner;
+}
 
 }  // namespace
 
@@ -127,7 +213,8 @@ class HipIndexNode : public IndexNode {
     Status
     Train(const DataSetPtr dataset, std::shared_ptr<Config> cfg, bool /*use_knowhere_build_pool*/) override {
         if (!dataset || !dataset->GetTensor() || !cfg) return Status::invalid_args;
-        if (idx_.p) return Status::index_already_trained;
+        if (Built()) return Status::index_already_trained;
+        if (knhip_abi_version() != KNHIP_ABI_VERSION) return Status::cuda_runtime_error;  // header / library mismatch
         const auto& c = static_cast<const knowhere_config_type&>(*cfg);
         const int64_t rows = dataset->GetRows();
         dim_ = dataset->GetDim();
@@ -136,34 +223,39 @@ class HipIndexNode : public IndexNode {
         cosine_ = IsMetricType(metric, metric::COSINE);
         metric_ = IsMetricType(metric, metric::L2) ? KNHIP_L2 : KNHIP_IP;
         metric_name_ = cosine_ ? metric::COSINE : (metric_ == KNHIP_L2 ? metric::L2 : metric::IP);
-        knhip_desc desc{};
-        desc.kind = Kind;
-        desc.metric = metric_;
-        desc.dim = (int32_t)dim_;
         if constexpr (Kind != KNHIP_BRUTE_FORCE) {
             // MatchNlist: silently shrink nlist so that nlist * 39 <= rows (ivf.cc:478-489)
             nlist_ = c.nlist.value();
             if (nlist_ * 39 > rows) nlist_ = std::max<int64_t>(1, rows / 39);
-            desc.nlist = nlist_;
             default_nprobe_ = c.nprobe.value_or(8);
         }
         if constexpr (Kind == KNHIP_IVF_PQ) {
             // m = 0: the backend picks, as cuVS does for pq_dim = 0 (about dim / 2): the largest supported m that
-            // leaves sub-vectors of at least 2 dims
             // leaves sub-vectors of at least 2 dims.  An explicit m is honoured or refused, never rewritten (the reference
             // honours any m that divides dim; this backend has kernels for 8, 16, 32 and 64 sub-quantizers)
             const bool auto_m = c.m.value_or(0) == 0;
             m_ = auto_m ? std::min<int64_t>(64, dim_ / 2) : c.m.value();
             while (auto_m && m_ > 1 && (dim_ % m_ != 0 || !(m_ == 8 || m_ == 16 || m_ == 32 || m_ == 64))) m_--;
             if (dim_ % m_ != 0 || !(m_ == 8 || m_ == 16 || m_ == 32 || m_ == 64)) return Status::invalid_args;
-            desc.pq_m = (int32_t)m_;
-            desc.pq_nbits = 8;
         }
         if constexpr (Kind == KNHIP_IVF_PQ || Kind == KNHIP_IVF_SQ8) {
             has_refine_ = c.refine.value_or(false);
+            // refine_type (ivf_config.h:113-135, refine_utils.cc:38-58): the raw-row store of this backend is fp32
+            // (is_flat_refine: unset / "fp32" / "flat"); the quantised stores (SQ6 / SQ8 / FP16 / BF16) are refused, not
+            // silently replaced by a bigger one
+            if (has_refine_ && c.refine_type.has_value()) {
+                std::string t = c.refine_type.value();
+                for (auto& ch : t) ch = (char)std::tolower((unsigned char)ch);
+                if (t != "fp32" && t != "flat") {
+                    LOG_KNOWHERE_ERROR_ << TypeName() << ": refine_type " << c.refine_type.value()
+                                        << " is not supported (fp32 rows only)";
+                    return Status::invalid_args;
+                }
+            }
         }
-        int rc = knhip_index_create(&desc, &idx_.p);
-        if (rc) return ToStatus(rc);
+        std::vector<int32_t> devs;
+        if (Status st = SelectDevices(c, /*deserialize=*/false, &devs); st != Status::success) return st;
+        if (Status st = CreateShards(devs); st != Status::success) return st;
         if constexpr (Kind == KNHIP_BRUTE_FORCE) {
             return Status::success;  // nothing to train
         }
@@ -174,9 +266,11 @@ class HipIndexNode : public IndexNode {
             NormalizeRows(xn.data(), rows, dim_);
             x = xn.data();
         }
-        rc = knhip_index_train(idx_.p, rows, x, nullptr);  // the reference's clustering defaults
+        // the reference's clustering defaults, on the first device; the trained state is replicated on the others
+        int rc = knhip_index_train(sh_[0].idx.p, rows, x, nullptr);
+        if (rc == KNHIP_OK && sh_.size() > 1) rc = ReplicateTrainedState();
         if (rc) {
-            idx_.reset();
+            DropShards();
             return ToStatus(rc);
         }
         return Status::success;
@@ -186,50 +280,66 @@ class HipIndexNode : public IndexNode {
     Status
     Add(const DataSetPtr dataset, std::shared_ptr<Config> /*cfg*/, bool /*use_knowhere_build_pool*/) override {
         if (!dataset || !dataset->GetTensor()) return Status::invalid_args;
-        if (!idx_.p) return Kind == KNHIP_BRUTE_FORCE ? Status::empty_index : Status::index_not_trained;
+        if (!Built()) return Kind == KNHIP_BRUTE_FORCE ? Status::empty_index : Status::index_not_trained;
         if (dataset->GetDim() != dim_) return Status::invalid_args;
         const int64_t rows = dataset->GetRows();
         const float* x = (const float*)dataset->GetTensor();
         std::vector<float> xn;
+        std::unique_lock<std::shared_mutex> lk(rw_);
+        const int64_t n0 = CountLocked();
+        const int W = (int)sh_.size();
+        // what is assigned / encoded (cosine on PQ / SQ8: the normalised rows) and, for the stored-norm cosine kinds
+        // (FLAT / IVF_FLAT keep the RAW rows and one float per row beside them, as IndexFlatCosine -- inverse norms,
+        // IndexCosine.cpp:236-245 -- and IndexIVFFlatCosine -- norms, IndexIVFFlat.cpp:516-524: assigned by the
+        // normalised row -- do), what is stored
+        const float* x_store = x;
+        const float* x_assign = x;
+        const size_t scale0 = row_scale_by_id_.size();
         if (StoredNormCosine()) {
-            // FLAT / IVF_FLAT keep the RAW rows and one float per row beside them, as IndexFlatCosine (inverse norms,
-            // IndexCosine.cpp:236-245) and IndexIVFFlatCosine (norms, IndexIVFFlat.cpp:516-524: assigned by the
-            // normalised row) do: the scores are then the CPU node's floats
-            std::unique_lock<std::shared_mutex> lk(rw_);
-            const size_t n0 = row_scale_by_id_.size();
-            row_scale_by_id_.resize(n0 + (size_t)rows);
-            int rc = 0;
+            row_scale_by_id_.resize(scale0 + (size_t)rows);
             if constexpr (Kind == KNHIP_BRUTE_FORCE) {
-                for (int64_t i = 0; i < rows; i++) row_scale_by_id_[n0 + i] = InverseL2Norm(x + i * dim_, dim_);
-                rc = knhip_index_add(idx_.p, rows, x, nullptr);
+                for (int64_t i = 0; i < rows; i++) row_scale_by_id_[scale0 + i] = InverseL2Norm(x + i * dim_, dim_);
             } else {
                 xn.assign(x, x + rows * dim_);
-                NormalizeRows(xn.data(), rows, dim_, row_scale_by_id_.data() + n0);
-                rc = knhip_index_add_assigned_by(idx_.p, rows, x, xn.data(), nullptr);
+                NormalizeRows(xn.data(), rows, dim_, row_scale_by_id_.data() + scale0);
+                x_assign = xn.data();
             }
-            if (rc) {
-                row_scale_by_id_.resize(n0);
-                return ToStatus(rc);
-            }
-            return PushRowScale();
-        }
-        if (cosine_) {
+        } else if (cosine_) {
             xn.assign(x, x + rows * dim_);
             NormalizeRows(xn.data(), rows, dim_);
-            x = xn.data();
+            x_store = x_assign = xn.data();
         }
-        std::unique_lock<std::shared_mutex> lk(rw_);
-        int rc = knhip_index_add(idx_.p, rows, x, nullptr);
-        if (rc) return ToStatus(rc);
+        int rc = KNHIP_OK;
+        if constexpr (Kind == KNHIP_BRUTE_FORCE) {
+            rc = AddRowRanges(&Shard::idx, /*bases=*/&Shard::row_base, n0, rows, x_store);
+        } else if (W == 1) {
+            rc = StoredNormCosine() ? knhip_index_add_assigned_by(sh_[0].idx.p, rows, x_store, x_assign, nullptr)
+                                    : knhip_index_add(sh_[0].idx.p, rows, x_store, nullptr);
+        } else {
+            rc = AddSharded(n0, rows, x_store, x_assign);
+        }
+        if (rc) {
+            row_scale_by_id_.resize(scale0);
+            return ToStatus(rc);
+        }
+        if (StoredNormCosine()) {
+            if (Status st = PushRowScale(); st != Status::success) return st;
+        }
         if (NeedRawStore()) {
-            if (!raw_.p) {
-                knhip_desc rd{};
-                rd.kind = KNHIP_BRUTE_FORCE;
-                rd.metric = metric_;
-                rd.dim = (int32_t)dim_;
-                if ((rc = knhip_index_create(&rd, &raw_.p))) return ToStatus(rc);
+            for (auto& s : sh_) {
+                if (!s.raw.p) {
+                    knhip_desc rd{};
+                    rd.kind = KNHIP_BRUTE_FORCE;
+                    rd.metric = metric_;
+                    rd.dim = (int32_t)dim_;
+                    rd.device = s.device;
+                    if ((rc = knhip_index_create(&rd, &s.raw.p))) return ToStatus(rc);
+                }
             }
-            if ((rc = knhip_index_add(raw_.p, rows, x, nullptr))) return ToStatus(rc);
+            if ((rc = AddRowRanges(&Shard::raw, &Shard::raw_base, n0, rows, x_store))) return ToStatus(rc);
+            if (W > 1) {
+                if (Status st = AttachRawToGroup(); st != Status::success) return st;
+            }
         }
         return Status::success;
     }
@@ -237,7 +347,7 @@ class HipIndexNode : public IndexNode {
     expected<DataSetPtr>
     Search(const DataSetPtr dataset, std::unique_ptr<Config> cfg, const BitsetView& bitset,
            milvus::OpContext* op_context) const override {
-        if (!idx_.p || Count() == 0) return expected<DataSetPtr>::Err(Status::empty_index, "index not built");
+        if (!Built() || Count() == 0) return expected<DataSetPtr>::Err(Status::empty_index, "index not built");
         if (!dataset || !dataset->GetTensor() || !cfg)
             return expected<DataSetPtr>::Err(Status::invalid_args, "null dataset / config");
         if (dataset->GetDim() != dim_) return expected<DataSetPtr>::Err(Status::invalid_args, "dim mismatch");
@@ -258,19 +368,7 @@ class HipIndexNode : public IndexNode {
         std::vector<uint8_t> in_bitset;
         const uint8_t* bits = nullptr;
         int64_t nbits = 0;
-        const bool has_bitset = bitset.data() != nullptr && bitset.num_bits() != 0;
-        if (has_bitset && bitset.has_out_ids()) {
-            const size_t n_in = bitset.out_ids_count();
-            in_bitset.assign((n_in + 7) / 8, 0);
-            for (size_t i = 0; i < n_in; i++) {
-                if (bitset.test((int64_t)i)) in_bitset[i >> 3] |= (uint8_t)(1u << (i & 7));
-            }
-            bits = in_bitset.data();
-            nbits = (int64_t)n_in;
-        } else if (has_bitset) {
-            bits = bitset.data();
-            nbits = (int64_t)bitset.num_bits();
-        }
+        const bool has_bitset = MaterialiseBitset(bitset, &in_bitset, &bits, &nbits);
         // every row filtered: ids -1, distances +inf, like gpu_cuvs.h:163-173
         if (has_bitset && bitset.has_known_count() && bitset.count() >= bitset.size() && (int64_t)bitset.size() >= Count()) {
             auto ids = std::make_unique<int64_t[]>(nq * k);
@@ -282,12 +380,13 @@ class HipIndexNode : public IndexNode {
         auto ids = std::make_unique<int64_t[]>(nq * k);
         auto dis = std::make_unique<float[]>(nq * k);
         int rc;
+        const char* err_text = nullptr;
         {
             std::shared_lock<std::shared_mutex> lk(rw_);
             // use_refine = the index carries a refine index (ivf.cc:1080-1092); k_factor = refine_k
             int64_t kbase = k;
             if constexpr (Kind == KNHIP_IVF_PQ || Kind == KNHIP_IVF_SQ8) {
-                if (has_refine_ && raw_.p && c.refine_k.has_value()) {
+                if (has_refine_ && sh_[0].raw.p && c.refine_k.has_value()) {
                     const int64_t want = std::max<int64_t>(k, (int64_t)(k * c.refine_k.value()));
                     kbase = std::min<int64_t>(1024, want);
                     if (kbase < want) {  // (the first stage returns at most 1024 candidates per query: said, not hidden)
@@ -296,14 +395,25 @@ class HipIndexNode : public IndexNode {
                     }
                 }
             }
-            if (kbase > k) {
-                rc = knhip_search_refine(idx_.p, raw_.p, q, nq, (int32_t)k, (int32_t)kbase, (int32_t)nprobe, bits, nbits,
-                                         ids.get(), dis.get());
+            if (sh_.size() > 1) {
+                // list-sharded: every device scans the lists it owns, one all-gather of the partial top-k, device merge
+                // (include/knhip_shards.h); with refine every device re-ranks the candidates whose rows it holds
+                if (kbase > k) {
+                    rc = knhip_shard_group_search_refine(group_.p, q, nq, (int32_t)k, (int32_t)kbase, (int32_t)nprobe, bits,
+                                                         nbits, ids.get(), dis.get(), nullptr);
+                } else {
+                    rc = knhip_shard_group_search(group_.p, q, nq, (int32_t)k, (int32_t)nprobe, bits, nbits, ids.get(),
+                                                  dis.get(), nullptr);
+                }
+                if (rc) err_text = knhip_shard_group_last_error();
+            } else if (kbase > k) {
+                rc = knhip_search_refine(sh_[0].idx.p, sh_[0].raw.p, q, nq, (int32_t)k, (int32_t)kbase, (int32_t)nprobe, bits,
+                                         nbits, ids.get(), dis.get());
             } else {
-                rc = knhip_search(idx_.p, q, nq, (int32_t)k, (int32_t)nprobe, bits, nbits, ids.get(), dis.get());
+                rc = knhip_search(sh_[0].idx.p, q, nq, (int32_t)k, (int32_t)nprobe, bits, nbits, ids.get(), dis.get());
             }
         }
-        if (rc) return expected<DataSetPtr>::Err(ToStatus(rc), knhip_last_error());
+        if (rc) return expected<DataSetPtr>::Err(ToStatus(rc), err_text ? err_text : knhip_last_error());
         auto res = GenResultDataSet(nq, k, ids.release(), dis.release());
         this->MapSearchResultIdsToOutIds(res);
         return res;
@@ -315,7 +425,7 @@ class HipIndexNode : public IndexNode {
     expected<DataSetPtr>
     RangeSearch(const DataSetPtr dataset, std::unique_ptr<Config> cfg, const BitsetView& bitset,
                 milvus::OpContext* op_context) const override {
-        if (!idx_.p || Count() == 0) return expected<DataSetPtr>::Err(Status::empty_index, "index not built");
+        if (!Built() || Count() == 0) return expected<DataSetPtr>::Err(Status::empty_index, "index not built");
         if (!dataset || !dataset->GetTensor() || !cfg)
             return expected<DataSetPtr>::Err(Status::invalid_args, "null dataset / config");
         if (dataset->GetDim() != dim_) return expected<DataSetPtr>::Err(Status::invalid_args, "dim mismatch");
@@ -324,6 +434,14 @@ class HipIndexNode : public IndexNode {
         const float range_filter = c.range_filter.value();
         int64_t max_empty = 2;
         if constexpr (Kind != KNHIP_BRUTE_FORCE) max_empty = c.max_empty_result_buckets.value_or(2);
+        if (Kind != KNHIP_BRUTE_FORCE && sh_.size() > 1) {
+            // the reference's early stop counts CONSECUTIVE lists without a hit in coarse order over all lists
+            // (IndexIVF.cpp:917-933); a shard only sees its own: the per-(query, rank) hit counts would have to be summed
+            // over the devices between the count and the stop.  Not built; refused rather than answered differently
+            // (the cuVS nodes implement no RangeSearch at all, gpu_cuvs.h:192-196).
+            return expected<DataSetPtr>::Err(Status::not_implemented,
+                                             "RangeSearch on a list-sharded index (gpu_ids with several devices)");
+        }
         checkCancellation(op_context);
         const int64_t nq = dataset->GetRows();
         const float* q = (const float*)dataset->GetTensor();
@@ -336,49 +454,55 @@ class HipIndexNode : public IndexNode {
         std::vector<uint8_t> in_bitset;
         const uint8_t* bits = nullptr;
         int64_t nbits = 0;
-        const bool has_bitset = bitset.data() != nullptr && bitset.num_bits() != 0;
-        if (has_bitset && bitset.has_out_ids()) {
-            const size_t n_in = bitset.out_ids_count();
-            in_bitset.assign((n_in + 7) / 8, 0);
-            for (size_t i = 0; i < n_in; i++) {
-                if (bitset.test((int64_t)i)) in_bitset[i >> 3] |= (uint8_t)(1u << (i & 7));
-            }
-            bits = in_bitset.data();
-            nbits = (int64_t)n_in;
-        } else if (has_bitset) {
-            bits = bitset.data();
-            nbits = (int64_t)bitset.num_bits();
-        }
-        std::vector<int64_t> lims(nq + 1);
-        int64_t* ids = nullptr;
-        float* dis = nullptr;
-        int rc;
+        MaterialiseBitset(bitset, &in_bitset, &bits, &nbits);
+        // one result per shard (FLAT row ranges: ascending ids, so the concatenation per query is IndexFlat's row order)
+        const int W = (int)sh_.size();
+        std::vector<std::vector<int64_t>> lims((size_t)W, std::vector<int64_t>((size_t)nq + 1));
+        std::vector<int64_t*> ids((size_t)W, nullptr);
+        std::vector<float*> dis((size_t)W, nullptr);
+        int rc = KNHIP_OK;
         {
             std::shared_lock<std::shared_mutex> lk(rw_);
-            rc = knhip_range_search(idx_.p, q, nq, radius, (int32_t)max_empty, bits, nbits, lims.data(), &ids, &dis);
+            for (int r = 0; r < W && rc == KNHIP_OK; r++) {
+                if (knhip_index_count(sh_[r].idx.p) == 0) continue;  // (an empty row range: lims stay 0)
+                rc = knhip_range_search(sh_[r].idx.p, q, nq, radius, (int32_t)max_empty, bits, nbits, lims[r].data(), &ids[r],
+                                        &dis[r]);
+            }
         }
-        if (rc) return expected<DataSetPtr>::Err(ToStatus(rc), knhip_last_error());
+        auto free_all = [&]() {
+            for (int r = 0; r < W; r++) {
+                knhip_free(ids[r]);
+                knhip_free(dis[r]);
+            }
+        };
+        if (rc) {
+            free_all();
+            return expected<DataSetPtr>::Err(ToStatus(rc), knhip_last_error());
+        }
+        int64_t total = 0;
+        for (int r = 0; r < W; r++) total += lims[r][(size_t)nq];
         const bool is_ip = metric_ != KNHIP_L2;
         auto out_lims = std::make_unique<size_t[]>(nq + 1);
-        auto out_ids = std::make_unique<int64_t[]>(std::max<int64_t>(lims[nq], 1));
-        auto out_dis = std::make_unique<float[]>(std::max<int64_t>(lims[nq], 1));
+        auto out_ids = std::make_unique<int64_t[]>(std::max<int64_t>(total, 1));
+        auto out_dis = std::make_unique<float[]>(std::max<int64_t>(total, 1));
         size_t n = 0;
         out_lims[0] = 0;
         for (int64_t i = 0; i < nq; i++) {
-            for (int64_t j = lims[i]; j < lims[i + 1]; j++) {
-                const float v = dis[j];
-                const bool keep = range_filter == defaultRangeFilter ||
-                                  (is_ip ? (radius < v && v <= range_filter) : (range_filter <= v && v < radius));
-                if (keep) {
-                    out_ids[n] = ids[j];
-                    out_dis[n] = v;
-                    n++;
+            for (int r = 0; r < W; r++) {
+                for (int64_t j = lims[r][(size_t)i]; j < lims[r][(size_t)i + 1]; j++) {
+                    const float v = dis[r][j];
+                    const bool keep = range_filter == defaultRangeFilter ||
+                                      (is_ip ? (radius < v && v <= range_filter) : (range_filter <= v && v < radius));
+                    if (keep) {
+                        out_ids[n] = ids[r][j];
+                        out_dis[n] = v;
+                        n++;
+                    }
                 }
             }
             out_lims[i + 1] = n;
         }
-        knhip_free(ids);
-        knhip_free(dis);
+        free_all();
         auto res = GenResultDataSet(nq, out_ids.release(), out_dis.release(), out_lims.release());
         this->MapSearchResultIdsToOutIds(res);
         return res;
@@ -389,13 +513,25 @@ class HipIndexNode : public IndexNode {
         if (!dataset || !dataset->GetIds()) return expected<DataSetPtr>::Err(Status::invalid_args, "null ids");
         if (!HasRawData(metric_name_)) return expected<DataSetPtr>::Err(Status::not_implemented, "no raw data");
         // (IVF_FLAT: the index's own rows through its direct map -- no second copy of the raw vectors)
-        const knhip_index* store = idx_.p;
-        if (!store) return expected<DataSetPtr>::Err(Status::empty_index, "index not built");
+        if (!Built()) return expected<DataSetPtr>::Err(Status::empty_index, "index not built");
         const int64_t n = dataset->GetRows();
         auto out = std::make_unique<float[]>(std::max<int64_t>(n * dim_, 1));
         std::shared_lock<std::shared_mutex> lk(rw_);
-        const int rc = knhip_index_get_vectors(store, n, dataset->GetIds(), out.get());
-        if (rc) return expected<DataSetPtr>::Err(ToStatus(rc), knhip_last_error());
+        if (sh_.size() == 1) {
+            const int rc = knhip_index_get_vectors(sh_[0].idx.p, n, dataset->GetIds(), out.get());
+            if (rc) return expected<DataSetPtr>::Err(ToStatus(rc), knhip_last_error());
+        } else {
+            // every shard fills the rows it stores; an id stored nowhere is an error, as on one device
+            std::vector<uint8_t> found((size_t)n, 0), f((size_t)n);
+            for (const auto& s : sh_) {
+                const int rc = knhip_index_find_vectors(s.idx.p, n, dataset->GetIds(), out.get(), f.data());
+                if (rc) return expected<DataSetPtr>::Err(ToStatus(rc), knhip_last_error());
+                for (int64_t i = 0; i < n; i++) found[(size_t)i] |= f[(size_t)i];
+            }
+            for (int64_t i = 0; i < n; i++) {
+                if (!found[(size_t)i]) return expected<DataSetPtr>::Err(Status::invalid_args, "get_vectors: id not in the index");
+            }
+        }
         return GenResultDataSet(n, dim_, (const void*)out.release());
     }
 
@@ -417,13 +553,14 @@ class HipIndexNode : public IndexNode {
 
     // One named blob in the BinarySet (ivf.cc:1717-1744), holding the FAISS byte format the CPU nodes write
     // (faiss_io.h): IxF2/IxFI (IxF9 for cosine), IwFl, IwSq, IwPQ, wrapped in IxRF when built with refine.  The trained
-    // state and the inverted lists are read back from the device.
+    // state and the inverted lists are read back from the device(s); a sharded index writes the SAME bytes as a
+    // single-device one (every list comes from the device that owns it).
     Status
     Serialize(BinarySet& binset) const override {
-        if (!idx_.p) return Status::empty_index;
+        if (!Built()) return Status::empty_index;
         using namespace knhip_host;
         std::shared_lock<std::shared_mutex> lk(rw_);
-        const int64_t count = knhip_index_count(idx_.p);
+        const int64_t count = CountLocked();
         FaissIndexData x;
         auto fill_hdr = [&](FaissHeader& h, int64_t ntotal, bool cosine_byte) {
             h.d = (int32_t)dim_;
@@ -435,9 +572,22 @@ class HipIndexNode : public IndexNode {
         const uint32_t flat_cc = metric_ == KNHIP_L2 ? FourCC("IxF2") : FourCC("IxFI");
         fill_hdr(x.hdr, count, cosine_);
         int rc = 0;
+        // rows kept in per-shard id ranges (FLAT base, refine store) -> one array in id order
+        auto read_rows = [&](KnhipHandle Shard::*which, std::vector<float>* out) -> int {
+            out->resize((size_t)count * dim_);
+            size_t pos = 0;
+            for (const auto& s : sh_) {
+                const knhip_index* h = (s.*which).p;
+                const int64_t n = h ? knhip_index_count(h) : 0;
+                if (n == 0) continue;
+                if (pos + (size_t)n * dim_ > out->size()) return KNHIP_ERR_INVALID_ARGS;
+                if (int e = knhip_index_get_lists(h, (uint8_t*)(out->data() + pos), nullptr)) return e;
+                pos += (size_t)n * dim_;
+            }
+            return pos == out->size() ? KNHIP_OK : KNHIP_ERR_INVALID_ARGS;
+        };
         if constexpr (Kind == KNHIP_BRUTE_FORCE) {
-            x.xb.resize((size_t)count * dim_);
-            if ((rc = knhip_index_get_lists(idx_.p, (uint8_t*)x.xb.data(), nullptr))) return ToStatus(rc);
+            if ((rc = read_rows(&Shard::idx, &x.xb))) return ToStatus(rc);
             if (cosine_) {  // IndexFlatCosine: "IxF9" = header, raw rows, L2 norms = 1 / inverse norm
                 x.fourcc = FourCC("IxF9");  // (index_write.cpp:539-546, L2NormsStorage::as_l2_norms IndexCosine.cpp:261-268)
                 x.flat_norms.resize((size_t)count);
@@ -452,7 +602,8 @@ class HipIndexNode : public IndexNode {
             x.quantizer.fourcc = flat_cc;
             fill_hdr(x.quantizer.hdr, nlist_, false);
             x.quantizer.xb.resize((size_t)nlist_ * dim_);
-            if ((rc = knhip_index_get_coarse(idx_.p, x.quantizer.xb.data()))) return ToStatus(rc);
+            const knhip_index* first = sh_[0].idx.p;  // (the trained state is the same on every shard)
+            if ((rc = knhip_index_get_coarse(first, x.quantizer.xb.data()))) return ToStatus(rc);
             x.by_residual = true;
             x.code_size = (uint64_t)CodeSize();
             if constexpr (Kind == KNHIP_IVF_PQ) {
@@ -460,46 +611,53 @@ class HipIndexNode : public IndexNode {
                 x.pq_M = (uint64_t)m_;
                 x.pq_nbits = 8;
                 x.pq_centroids.resize((size_t)256 * dim_);
-                if ((rc = knhip_index_get_pq(idx_.p, x.pq_centroids.data()))) return ToStatus(rc);
+                if ((rc = knhip_index_get_pq(first, x.pq_centroids.data()))) return ToStatus(rc);
             } else if constexpr (Kind == KNHIP_IVF_SQ8) {
                 x.sq_qtype = 0;      // ScalarQuantizer::QT_8bit
                 x.sq_rangestat = 0;  // RS_minmax
                 x.sq_d = (uint64_t)dim_;
                 x.sq_code_size = (uint64_t)dim_;
                 x.sq_trained.resize((size_t)2 * dim_);
-                if ((rc = knhip_index_get_sq(idx_.p, x.sq_trained.data(), x.sq_trained.data() + dim_))) return ToStatus(rc);
+                if ((rc = knhip_index_get_sq(first, x.sq_trained.data(), x.sq_trained.data() + dim_))) return ToStatus(rc);
             }
-            std::vector<int64_t> sizes((size_t)nlist_);
-            if ((rc = knhip_index_get_list_sizes(idx_.p, sizes.data()))) return ToStatus(rc);
-            std::vector<uint8_t> codes((size_t)count * CodeSize());
-            std::vector<int64_t> ids((size_t)count);
-            if ((rc = knhip_index_get_lists(idx_.p, codes.data(), ids.data()))) return ToStatus(rc);
             x.codes.assign(nlist_, {});
             x.ids.assign(nlist_, {});
-            size_t non0 = 0;
-            int64_t pos = 0;
-            for (int64_t l = 0; l < nlist_; l++) {
-                x.codes[l].assign(codes.begin() + pos * CodeSize(), codes.begin() + (pos + sizes[l]) * CodeSize());
-                x.ids[l].assign(ids.begin() + pos, ids.begin() + pos + sizes[l]);
-                pos += sizes[l];
-                non0 += sizes[l] != 0;
+            std::vector<int64_t> all_sizes((size_t)nlist_, 0);
+            for (const auto& s : sh_) {
+                const int64_t cnt = knhip_index_count(s.idx.p);
+                if (cnt == 0) continue;
+                std::vector<int64_t> sizes((size_t)nlist_);
+                if ((rc = knhip_index_get_list_sizes(s.idx.p, sizes.data()))) return ToStatus(rc);
+                std::vector<uint8_t> codes((size_t)cnt * CodeSize());
+                std::vector<int64_t> ids((size_t)cnt);
+                if ((rc = knhip_index_get_lists(s.idx.p, codes.data(), ids.data()))) return ToStatus(rc);
+                int64_t pos = 0;
+                for (int64_t l = 0; l < nlist_; l++) {
+                    if (sizes[l] == 0) continue;
+                    if (all_sizes[l] != 0) return Status::faiss_inner_error;  // (a list lives on exactly one shard)
+                    x.codes[l].assign(codes.begin() + pos * CodeSize(), codes.begin() + (pos + sizes[l]) * CodeSize());
+                    x.ids[l].assign(ids.begin() + pos, ids.begin() + pos + sizes[l]);
+                    all_sizes[l] = sizes[l];
+                    pos += sizes[l];
+                }
             }
+            size_t non0 = 0;
+            for (int64_t l = 0; l < nlist_; l++) non0 += all_sizes[l] != 0;
             x.lists_sparse = !(non0 > (size_t)nlist_ / 2);  // index_write.cpp:309-316
             if (Kind == KNHIP_IVF_FLAT && cosine_) {        // Knowhere cosine IVF-Flat carries the row norms
                 x.with_norm = true;
                 x.norms.assign(nlist_, {});
                 for (int64_t l = 0; l < nlist_; l++) {
-                    x.norms[l].resize((size_t)sizes[l]);
-                    for (int64_t j = 0; j < sizes[l]; j++) x.norms[l][(size_t)j] = row_scale_by_id_[(size_t)x.ids[l][(size_t)j]];
+                    x.norms[l].resize((size_t)all_sizes[l]);
+                    for (int64_t j = 0; j < all_sizes[l]; j++) x.norms[l][(size_t)j] = row_scale_by_id_[(size_t)x.ids[l][(size_t)j]];
                 }
             }
-            if (has_refine_ && raw_.p) {  // IndexRefineFlat (ivf.cc:673-700)
+            if (has_refine_ && sh_[0].raw.p) {  // IndexRefineFlat (ivf.cc:673-700)
                 x.has_refine = true;
                 fill_hdr(x.refine_hdr, count, cosine_);
                 x.refine_index.fourcc = flat_cc;
                 fill_hdr(x.refine_index.hdr, count, false);
-                x.refine_index.xb.resize((size_t)count * dim_);
-                if ((rc = knhip_index_get_lists(raw_.p, (uint8_t*)x.refine_index.xb.data(), nullptr))) return ToStatus(rc);
+                if ((rc = read_rows(&Shard::raw, &x.refine_index.xb))) return ToStatus(rc);
                 x.k_factor = 1.f;
             }
         }
@@ -523,6 +681,7 @@ class HipIndexNode : public IndexNode {
         if (!b) b = binset.GetByName(cpu_names[Kind]);
         if (!b && Kind != KNHIP_BRUTE_FORCE) b = binset.GetByName("IVF");
         if (!b) return Status::invalid_binary_set;
+        if (knhip_abi_version() != KNHIP_ABI_VERSION) return Status::cuda_runtime_error;
         FaissIndexData x;
         std::string err;
         if (!ParseFaissIndex(b->data.get(), (size_t)b->size, &x, &err)) return Status::invalid_serialized_index_type;
@@ -574,24 +733,23 @@ class HipIndexNode : public IndexNode {
                 }
             }
         }
-        metric_ = x.hdr.metric == 1 ? KNHIP_L2 : KNHIP_IP;
-        cosine_ = x.hdr.is_cosine() || x.fourcc == FourCC("IxF9") || x.with_norm;
+        const int new_metric = x.hdr.metric == 1 ? KNHIP_L2 : KNHIP_IP;
+        bool new_cosine = x.hdr.is_cosine() || x.fourcc == FourCC("IxF9") || x.with_norm;
+        std::vector<int32_t> devs;
         if (cfg) {
-            const auto& c = static_cast<const BaseConfig&>(*cfg);
-            if (c.metric_type.has_value() && IsMetricType(c.metric_type.value(), metric::COSINE) && metric_ == KNHIP_IP)
-                cosine_ = true;
+            const auto& c = static_cast<const knowhere_config_type&>(*cfg);
+            if (c.metric_type.has_value() && IsMetricType(c.metric_type.value(), metric::COSINE) && new_metric == KNHIP_IP)
+                new_cosine = true;
+            if (Status st = SelectDevices(c, /*deserialize=*/true, &devs); st != Status::success) return st;
+        } else {
+            knowhere_config_type none;
+            if (Status st = SelectDevices(none, /*deserialize=*/true, &devs); st != Status::success) return st;
         }
-        metric_name_ = cosine_ ? metric::COSINE : (metric_ == KNHIP_L2 ? metric::L2 : metric::IP);
-        dim_ = d;
-        nlist_ = (int64_t)x.nlist;
-        if (x.nprobe >= 1 && x.nprobe <= 65536) default_nprobe_ = (int64_t)x.nprobe;  // the index's default nprobe
-        m_ = (int64_t)x.pq_M;
-        has_refine_ = x.has_refine;
         // The CPU cosine indexes keep the RAW rows plus their L2 norms (FLAT: the wire carries the norms, the index
         // multiplies by their inverses, L2NormsStorage::add_l2_norms IndexCosine.cpp:247-255; IVF_FLAT: ip / norm,
         // cppcontrib/knowhere/IndexIVFFlat.cpp:199-210): kept exactly so, per row id
         std::vector<float> scale_by_id;
-        if (cosine_ && flat) {
+        if (new_cosine && flat) {
             if (x.flat_norms.size() != (size_t)ntotal) return Status::invalid_serialized_index_type;
             scale_by_id.resize((size_t)ntotal);
             for (int64_t i = 0; i < ntotal; i++) {
@@ -599,7 +757,7 @@ class HipIndexNode : public IndexNode {
                 scale_by_id[(size_t)i] = nr == 0.0f ? 1.0f : (1.0f / nr);
             }
         }
-        if (cosine_ && Kind == KNHIP_IVF_FLAT) {
+        if (new_cosine && Kind == KNHIP_IVF_FLAT) {
             if (!x.with_norm) return Status::invalid_serialized_index_type;
             int64_t max_id = -1;
             for (uint64_t l = 0; l < x.nlist; l++) {
@@ -616,47 +774,68 @@ class HipIndexNode : public IndexNode {
             }
         }
         std::unique_lock<std::shared_mutex> lk(rw_);
-        idx_.reset();
-        raw_.reset();
+        DropShards();
+        metric_ = new_metric;
+        cosine_ = new_cosine;
+        metric_name_ = cosine_ ? metric::COSINE : (metric_ == KNHIP_L2 ? metric::L2 : metric::IP);
+        dim_ = d;
+        nlist_ = (int64_t)x.nlist;
+        if (x.nprobe >= 1 && x.nprobe <= 65536) default_nprobe_ = (int64_t)x.nprobe;  // the index's default nprobe
+        m_ = (int64_t)x.pq_M;
+        has_refine_ = x.has_refine;
         row_scale_by_id_ = std::move(scale_by_id);
-        knhip_desc desc{};
-        desc.kind = Kind;
-        desc.metric = metric_;
-        desc.dim = (int32_t)dim_;
-        desc.nlist = nlist_;
-        desc.pq_m = (int32_t)m_;
-        desc.pq_nbits = 8;
-        int rc = knhip_index_create(&desc, &idx_.p);
-        if (rc) return ToStatus(rc);
+        if (Status st = CreateShards(devs); st != Status::success) return st;
+        const int W = (int)sh_.size();
+        int rc = KNHIP_OK;
+        auto bail = [&](int e) {
+            DropShards();
+            return ToStatus(e);
+        };
         if constexpr (Kind == KNHIP_BRUTE_FORCE) {
-            if ((rc = knhip_index_add(idx_.p, ntotal, x.xb.data(), nullptr))) return ToStatus(rc);
-            return StoredNormCosine() ? PushRowScale() : Status::success;
+            if ((rc = AddRowRanges(&Shard::idx, &Shard::row_base, 0, ntotal, x.xb.data()))) return bail(rc);
+            if (StoredNormCosine()) {
+                if (Status st = PushRowScale(); st != Status::success) return st;
+            }
+            return Status::success;
         }
-        if ((rc = knhip_index_set_coarse(idx_.p, x.quantizer.xb.data()))) return ToStatus(rc);
-        if (Kind == KNHIP_IVF_PQ && (rc = knhip_index_set_pq(idx_.p, x.pq_centroids.data()))) return ToStatus(rc);
-        if (Kind == KNHIP_IVF_SQ8 && (rc = knhip_index_set_sq(idx_.p, x.sq_trained.data(), x.sq_trained.data() + dim_)))
-            return ToStatus(rc);
         std::vector<int64_t> sizes(nlist_);
-        std::vector<const uint8_t*> cp(nlist_);
-        std::vector<const int64_t*> ip(nlist_);
-        for (int64_t l = 0; l < nlist_; l++) {
-            sizes[l] = (int64_t)x.ids[l].size();
-            cp[l] = x.codes[l].data();
-            ip[l] = x.ids[l].data();
+        for (int64_t l = 0; l < nlist_; l++) sizes[l] = (int64_t)x.ids[l].size();
+        if (W > 1) owner_ = DealLists(sizes, W);
+        for (int r = 0; r < W; r++) {
+            knhip_index* h = sh_[r].idx.p;
+            if ((rc = knhip_index_set_coarse(h, x.quantizer.xb.data()))) return bail(rc);
+            if (Kind == KNHIP_IVF_PQ && (rc = knhip_index_set_pq(h, x.pq_centroids.data()))) return bail(rc);
+            if (Kind == KNHIP_IVF_SQ8 && (rc = knhip_index_set_sq(h, x.sq_trained.data(), x.sq_trained.data() + dim_)))
+                return bail(rc);
+            std::vector<int64_t> sz(nlist_, 0);
+            std::vector<const uint8_t*> cp(nlist_, nullptr);
+            std::vector<const int64_t*> ip(nlist_, nullptr);
+            for (int64_t l = 0; l < nlist_; l++) {
+                if (W > 1 && owner_[(size_t)l] != r) continue;
+                sz[l] = sizes[l];
+                cp[l] = x.codes[l].data();
+                ip[l] = x.ids[l].data();
+            }
+            if ((rc = knhip_index_add_lists(h, sz.data(), cp.data(), ip.data()))) return bail(rc);
         }
-        if ((rc = knhip_index_add_lists(idx_.p, sizes.data(), cp.data(), ip.data()))) return ToStatus(rc);
         if (StoredNormCosine()) {
             const Status st = PushRowScale();
             if (st != Status::success) return st;
         }
         // raw rows for refine, in id order
         if (x.has_refine && !x.refine_index.xb.empty()) {
-            knhip_desc rd{};
-            rd.kind = KNHIP_BRUTE_FORCE;
-            rd.metric = metric_;
-            rd.dim = (int32_t)dim_;
-            if ((rc = knhip_index_create(&rd, &raw_.p))) return ToStatus(rc);
-            if ((rc = knhip_index_add(raw_.p, ntotal, x.refine_index.xb.data(), nullptr))) return ToStatus(rc);
+            for (auto& s : sh_) {
+                knhip_desc rd{};
+                rd.kind = KNHIP_BRUTE_FORCE;
+                rd.metric = metric_;
+                rd.dim = (int32_t)dim_;
+                rd.device = s.device;
+                if ((rc = knhip_index_create(&rd, &s.raw.p))) return bail(rc);
+            }
+            if ((rc = AddRowRanges(&Shard::raw, &Shard::raw_base, 0, ntotal, x.refine_index.xb.data()))) return bail(rc);
+            if (W > 1) {
+                if (Status st = AttachRawToGroup(); st != Status::success) return st;
+            }
         }
         return Status::success;
     }
@@ -695,10 +874,24 @@ class HipIndexNode : public IndexNode {
     }
     static Status
     StaticConfigCheck(const knowhere::BaseConfig& config, PARAM_TYPE paramType, std::string& msg) {
-        // what the typed config cannot express: this backend needs at least one visible device
-        if (paramType == PARAM_TYPE::TRAIN && knhip_device_count() <= 0) {
-            msg = "no HIP device available for " + std::string(TypeName());
-            return Status::cuda_runtime_error;
+        // what the typed config cannot express: this backend needs at least one visible device, and a device list that
+        // names devices that exist
+        if (paramType == PARAM_TYPE::TRAIN || paramType == PARAM_TYPE::DESERIALIZE) {
+            const int ndev = knhip_device_count();
+            if (ndev <= 0) {
+                msg = "no HIP device available for " + std::string(TypeName());
+                return Status::cuda_runtime_error;
+            }
+            const auto* c = dynamic_cast<const knowhere_config_type*>(&config);
+            if (c && c->gpu_ids.has_value() && HipParseGpuIds(c->gpu_ids.value(), ndev).empty()) {
+                msg = "gpu_ids \"" + c->gpu_ids.value() + "\": comma separated device ordinals below " + std::to_string(ndev) +
+                      ", or \"all\"";
+                return Status::invalid_args;
+            }
+            if (c && c->gpu_id.has_value() && c->gpu_id.value() >= ndev) {
+                msg = "gpu_id " + std::to_string(c->gpu_id.value()) + ": " + std::to_string(ndev) + " device(s) visible";
+                return Status::invalid_args;
+            }
         }
         return Status::success;
     }
@@ -709,11 +902,15 @@ class HipIndexNode : public IndexNode {
     }
     int64_t
     Size() const override {
-        return (idx_.p ? knhip_index_device_bytes(idx_.p) : 0) + (raw_.p ? knhip_index_device_bytes(raw_.p) : 0);
+        int64_t b = 0;
+        for (const auto& s : sh_) {
+            b += (s.idx.p ? knhip_index_device_bytes(s.idx.p) : 0) + (s.raw.p ? knhip_index_device_bytes(s.raw.p) : 0);
+        }
+        return b;
     }
     int64_t
     Count() const override {
-        return idx_.p ? knhip_index_count(idx_.p) : 0;
+        return CountLocked();
     }
     static const char*
     TypeName() {
@@ -729,7 +926,25 @@ class HipIndexNode : public IndexNode {
         return TypeName();
     }
 
+    // the devices this index lives on, in shard order (tests; Milvus would log it)
+    std::vector<int32_t>
+    Devices() const {
+        std::vector<int32_t> d;
+        for (const auto& s : sh_) d.push_back(s.device);
+        return d;
+    }
+
  private:
+    bool
+    Built() const {
+        return !sh_.empty() && sh_[0].idx.p != nullptr;
+    }
+    int64_t
+    CountLocked() const {
+        int64_t n = 0;
+        for (const auto& s : sh_) n += s.idx.p ? knhip_index_count(s.idx.p) : 0;
+        return n;
+    }
     int64_t
     CodeSize() const {
         return Kind == KNHIP_IVF_FLAT ? dim_ * 4 : (Kind == KNHIP_IVF_PQ ? m_ : dim_);
@@ -740,30 +955,233 @@ class HipIndexNode : public IndexNode {
     NeedRawStore() const {
         return (Kind == KNHIP_IVF_PQ || Kind == KNHIP_IVF_SQ8) && has_refine_;
     }
-
     // COSINE on FLAT / IVF_FLAT: raw rows + one float per row (inverse norm / norm), see Add
     bool
     StoredNormCosine() const {
         return cosine_ && (Kind == KNHIP_BRUTE_FORCE || Kind == KNHIP_IVF_FLAT);
     }
-    // row_scale_by_id_ (ids are the running row numbers) -> the index's canonical entry order -> knhip_index_set_row_scale
+
+    static bool
+    MaterialiseBitset(const BitsetView& bitset, std::vector<uint8_t>* store, const uint8_t** bits, int64_t* nbits) {
+        const bool has_bitset = bitset.data() != nullptr && bitset.num_bits() != 0;
+        if (has_bitset && bitset.has_out_ids()) {
+            const size_t n_in = bitset.out_ids_count();
+            store->assign((n_in + 7) / 8, 0);
+            for (size_t i = 0; i < n_in; i++) {
+                if (bitset.test((int64_t)i)) (*store)[i >> 3] |= (uint8_t)(1u << (i & 7));
+            }
+            *bits = store->data();
+            *nbits = (int64_t)n_in;
+        } else if (has_bitset) {
+            *bits = bitset.data();
+            *nbits = (int64_t)bitset.num_bits();
+        }
+        return has_bitset;
+    }
+
+    // ---- devices ---------------------------------------------------------------------------------------------------
+    // gpu_ids (several: sharded) > gpu_id > the reference's placement rule
+    static Status
+    SelectDevices(const knowhere_config_type& c, bool deserialize, std::vector<int32_t>* out) {
+        const int ndev = knhip_device_count();
+        if (ndev <= 0) return Status::cuda_runtime_error;
+        out->clear();
+        if (c.gpu_ids.has_value()) {
+            *out = HipParseGpuIds(c.gpu_ids.value(), ndev);
+            if (out->empty()) {
+                LOG_KNOWHERE_ERROR_ << TypeName() << ": gpu_ids \"" << c.gpu_ids.value() << "\" names no valid device list ("
+                                    << ndev << " visible)";
+                return Status::invalid_args;
+            }
+            if (out->size() > 64) return Status::invalid_args;
+            return Status::success;
+        }
+        if (c.gpu_id.has_value()) {
+            if (c.gpu_id.value() < 0 || c.gpu_id.value() >= ndev) return Status::invalid_args;
+            out->push_back(c.gpu_id.value());
+            return Status::success;
+        }
+        out->push_back(deserialize ? MostFreeDevice(ndev) : RoundRobinDevice(ndev));
+        return Status::success;
+    }
+
+    void
+    DropShards() {
+        group_.reset();
+        sh_.clear();
+        owner_.clear();
+    }
+
+    // one knhip_index per device (empty, untrained) + the shard group when there are several
     Status
-    PushRowScale() {
-        const int64_t count = knhip_index_count(idx_.p);
-        if (count <= 0) return Status::success;
-        std::vector<float> canon((size_t)count);
-        if constexpr (Kind == KNHIP_BRUTE_FORCE) {
-            if ((int64_t)row_scale_by_id_.size() != count) return Status::invalid_args;
-            canon = row_scale_by_id_;
-        } else {
-            std::vector<int64_t> ids((size_t)count);
-            if (int rc = knhip_index_get_lists(idx_.p, nullptr, ids.data())) return ToStatus(rc);
-            for (int64_t i = 0; i < count; i++) {
-                if (ids[i] < 0 || ids[i] >= (int64_t)row_scale_by_id_.size()) return Status::invalid_args;
-                canon[i] = row_scale_by_id_[(size_t)ids[i]];
+    CreateShards(const std::vector<int32_t>& devs) {
+        DropShards();
+        sh_.resize(devs.size());
+        for (size_t r = 0; r < devs.size(); r++) {
+            sh_[r].device = devs[r];
+            knhip_desc desc{};
+            desc.kind = Kind;
+            desc.metric = metric_;
+            desc.dim = (int32_t)dim_;
+            desc.device = devs[r];
+            if constexpr (Kind != KNHIP_BRUTE_FORCE) desc.nlist = nlist_;
+            if constexpr (Kind == KNHIP_IVF_PQ) {
+                desc.pq_m = (int32_t)m_;
+                desc.pq_nbits = 8;
+            }
+            if (int rc = knhip_index_create(&desc, &sh_[r].idx.p)) {
+                DropShards();
+                return ToStatus(rc);
             }
         }
-        return ToStatus(knhip_index_set_row_scale(idx_.p, canon.data(), Kind == KNHIP_BRUTE_FORCE ? 2 : 1));
+        g_last_placement = devs;
+        if (devs.size() > 1) {
+            bool distinct = true;
+            for (size_t a = 0; a < devs.size(); a++) {
+                for (size_t b = a + 1; b < devs.size(); b++) distinct = distinct && devs[a] != devs[b];
+            }
+            // RCCL over xGMI between distinct devices; shards sharing a device exchange by device copies
+            const int rc = knhip_shard_group_create((int32_t)devs.size(), devs.data(),
+                                                    distinct ? KNHIP_SHARDS_RCCL : KNHIP_SHARDS_STAGED, &group_.p);
+            if (rc) {
+                LOG_KNOWHERE_ERROR_ << TypeName() << ": shard group: " << knhip_shard_group_last_error();
+                DropShards();
+                return ToStatus(rc);
+            }
+            for (size_t r = 0; r < devs.size(); r++) {
+                if (int e = knhip_shard_group_set_index(group_.p, (int32_t)r, sh_[r].idx.p)) {
+                    DropShards();
+                    return ToStatus(e);
+                }
+            }
+        }
+        return Status::success;
+    }
+
+    // centroids / codebooks / SQ ranges of shard 0 -> every other shard (every device quantises identically)
+    int
+    ReplicateTrainedState() {
+        std::vector<float> cen((size_t)nlist_ * dim_), aux;
+        if (int rc = knhip_index_get_coarse(sh_[0].idx.p, cen.data())) return rc;
+        if constexpr (Kind == KNHIP_IVF_PQ) {
+            aux.resize((size_t)256 * dim_);
+            if (int rc = knhip_index_get_pq(sh_[0].idx.p, aux.data())) return rc;
+        } else if constexpr (Kind == KNHIP_IVF_SQ8) {
+            aux.resize((size_t)2 * dim_);
+            if (int rc = knhip_index_get_sq(sh_[0].idx.p, aux.data(), aux.data() + dim_)) return rc;
+        }
+        for (size_t r = 1; r < sh_.size(); r++) {
+            knhip_index* h = sh_[r].idx.p;
+            if (int rc = knhip_index_set_coarse(h, cen.data())) return rc;
+            if constexpr (Kind == KNHIP_IVF_PQ) {
+                if (int rc = knhip_index_set_pq(h, aux.data())) return rc;
+            } else if constexpr (Kind == KNHIP_IVF_SQ8) {
+                if (int rc = knhip_index_set_sq(h, aux.data(), aux.data() + dim_)) return rc;
+            }
+        }
+        return KNHIP_OK;
+    }
+
+    // rows kept by id range (the FLAT base, the refine store): the first batch is cut into one contiguous range per
+    // shard; later batches extend the LAST shard's range (a BRUTE_FORCE knhip_index is one id range: row + offset)
+    int
+    AddRowRanges(KnhipHandle Shard::*which, int64_t Shard::*base, int64_t n0, int64_t rows, const float* x) {
+        const int W = (int)sh_.size();
+        if (n0 == 0) {
+            if (rows < W && which == &Shard::idx) return KNHIP_ERR_INVALID_ARGS;  // (fewer rows than devices)
+            for (int r = 0; r < W; r++) {
+                const int64_t lo = rows * r / W, hi = rows * (r + 1) / W;
+                if (hi == lo) continue;  // (an empty range of the refine store: the group skips it)
+                sh_[r].*base = lo;
+                if (int rc = knhip_index_add_vectors((sh_[r].*which).p, hi - lo, x + lo * dim_, nullptr, lo)) return rc;
+            }
+            return KNHIP_OK;
+        }
+        return knhip_index_add((sh_[W - 1].*which).p, rows, x, nullptr);
+    }
+
+    Status
+    AttachRawToGroup() {
+        for (size_t r = 0; r < sh_.size(); r++) {
+            const float* d_rows = nullptr;
+            const int64_t n = sh_[r].raw.p ? knhip_index_count(sh_[r].raw.p) : 0;
+            if (n > 0) {
+                if (int rc = knhip_index_get_vectors_device(sh_[r].raw.p, &d_rows)) return ToStatus(rc);
+            }
+            if (int rc = knhip_shard_group_set_raw(group_.p, (int32_t)r, d_rows, n, sh_[r].raw_base)) return ToStatus(rc);
+        }
+        return Status::success;
+    }
+
+    // IVF kinds over several devices: quantizer->assign once (knhip_index_assign on the first device), the first batch
+    // fixes the owner of every list (size-balanced deal), every row goes to the device that owns its list with its id
+    // (the running row number), the devices encode and append their rows concurrently.
+    int
+    AddSharded(int64_t n0, int64_t rows, const float* x_store, const float* x_assign) {
+        const int W = (int)sh_.size();
+        std::vector<int64_t> assign((size_t)rows);
+        if (int rc = knhip_index_assign(sh_[0].idx.p, rows, x_assign, assign.data())) return rc;
+        if (owner_.empty()) {
+            std::vector<int64_t> sizes((size_t)nlist_, 0);
+            for (int64_t i = 0; i < rows; i++) {
+                if (assign[(size_t)i] >= 0 && assign[(size_t)i] < nlist_) sizes[(size_t)assign[(size_t)i]]++;
+            }
+            owner_ = DealLists(sizes, W);
+        }
+        std::vector<std::vector<float>> xs((size_t)W), xa((size_t)W);
+        std::vector<std::vector<int64_t>> ids((size_t)W);
+        const bool two = x_assign != x_store;
+        for (int64_t i = 0; i < rows; i++) {
+            const int64_t l = assign[(size_t)i];
+            if (l < 0 || l >= nlist_) return KNHIP_ERR_INVALID_ARGS;  // (a NaN row: IndexIVF::add_core skips it; refused here)
+            const int r = owner_[(size_t)l];
+            xs[r].insert(xs[r].end(), x_store + i * dim_, x_store + (i + 1) * dim_);
+            if (two) xa[r].insert(xa[r].end(), x_assign + i * dim_, x_assign + (i + 1) * dim_);
+            ids[r].push_back(n0 + i);
+        }
+        std::vector<int> rcs((size_t)W, KNHIP_OK);
+        std::vector<std::string> errs((size_t)W);
+        std::vector<std::thread> th;
+        for (int r = 0; r < W; r++) {
+            th.emplace_back([&, r]() {
+                const int64_t n = (int64_t)ids[r].size();
+                if (n == 0) return;
+                rcs[r] = two ? knhip_index_add_assigned_by(sh_[r].idx.p, n, xs[r].data(), xa[r].data(), ids[r].data())
+                             : knhip_index_add(sh_[r].idx.p, n, xs[r].data(), ids[r].data());
+                if (rcs[r]) errs[r] = knhip_last_error();  // (thread-local text: fetched on the thread that failed)
+            });
+        }
+        for (auto& t : th) t.join();
+        for (int r = 0; r < W; r++) {
+            if (rcs[r]) {
+                LOG_KNOWHERE_ERROR_ << TypeName() << ": add on device " << sh_[r].device << ": " << errs[r];
+                return rcs[r];
+            }
+        }
+        return KNHIP_OK;
+    }
+
+    // row_scale_by_id_ (ids are the running row numbers) -> every shard's canonical entry order -> knhip_index_set_row_scale
+    Status
+    PushRowScale() {
+        for (auto& s : sh_) {
+            const int64_t count = knhip_index_count(s.idx.p);
+            if (count <= 0) continue;
+            std::vector<float> canon((size_t)count);
+            if constexpr (Kind == KNHIP_BRUTE_FORCE) {
+                if (s.row_base < 0 || s.row_base + count > (int64_t)row_scale_by_id_.size()) return Status::invalid_args;
+                std::copy_n(row_scale_by_id_.begin() + s.row_base, count, canon.begin());
+            } else {
+                std::vector<int64_t> ids((size_t)count);
+                if (int rc = knhip_index_get_lists(s.idx.p, nullptr, ids.data())) return ToStatus(rc);
+                for (int64_t i = 0; i < count; i++) {
+                    if (ids[i] < 0 || ids[i] >= (int64_t)row_scale_by_id_.size()) return Status::invalid_args;
+                    canon[i] = row_scale_by_id_[(size_t)ids[i]];
+                }
+            }
+            if (int rc = knhip_index_set_row_scale(s.idx.p, canon.data(), Kind == KNHIP_BRUTE_FORCE ? 2 : 1)) return ToStatus(rc);
+        }
+        return Status::success;
     }
 
     int metric_ = KNHIP_L2;
@@ -771,7 +1189,9 @@ class HipIndexNode : public IndexNode {
     std::vector<float> row_scale_by_id_;  // StoredNormCosine(): FLAT inverse L2 norms, IVF_FLAT L2 norms, by row id
     std::string metric_name_ = metric::L2;
     int64_t dim_ = 0, nlist_ = 0, m_ = 0, default_nprobe_ = 8;
-    KnhipHandle idx_, raw_;
+    std::vector<Shard> sh_;        // one entry: the whole index on one device; several: list- (FLAT: row-) sharded
+    GroupHandle group_;            // several shards: the exchange + merge host (include/knhip_shards.h)
+    std::vector<int32_t> owner_;   // several shards, IVF kinds: list -> shard
     mutable std::shared_mutex rw_;  // Add / Deserialize (exclusive) vs Search / Serialize (shared)
 };
 
@@ -796,6 +1216,14 @@ KNOWHERE_REGISTER_GLOBAL_WITH_THREAD_POOL(GPU_HIP_IVF_SQ8, HipIvfSqIndexNode, fp
                                           knowhere::feature::GPU_ANN_FLOAT_INDEX, HipSearchPoolSize());
 
 }  // namespace knowhere
+
+// test hook (node_capi.cc): where the last index built / loaded on this thread lives
+extern "C" int32_t
+knhip_host_last_placement(int32_t* out, int32_t cap) {
+    const auto& d = knowhere::g_last_placement;
+    for (int32_t i = 0; i < (int32_t)d.size() && i < cap; i++) out[i] = d[(size_t)i];
+    return (int32_t)d.size();
+}
 
 // test hook (node_capi.cc): the node's NormalizeVec restatement
 extern "C" void

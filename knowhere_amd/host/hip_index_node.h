@@ -18,6 +18,11 @@
 #include "knowhere_shim.h"
 #endif
 
+#include <cctype>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
 namespace knowhere {
 
 // new index types, next to INDEX_CUVS_* / INDEX_GPU_* (include/knowhere/comp/index_param.h:42-55); the same pairs go
@@ -43,8 +48,64 @@ HipCheckMetric(const BaseConfig& cfg, PARAM_TYPE param_type, std::string* err_ms
     return Status::success;
 }
 
+// Device placement, the same keys in all four configs (the reference's GPU configs carry `gpu_id`,
+// src/index/gpu/ivf_gpu/ivf_gpu_config.h:18-20; its cuVS nodes place every new index round-robin and a loaded one on the
+// device with the most free memory, src/common/cuvs/integration/cuvs_knowhere_index.cuh:414-426, 678-690):
+//   gpu_id   one device ordinal.                      unset = round-robin over the visible devices at Train, the device
+//                                                     with the most free HBM at Deserialize -- as the cuVS nodes.
+//   gpu_ids  "0,1,2,3" or "all": the inverted lists (FLAT: the rows) are dealt over these devices and every Search() is
+//            served by all of them (include/knhip_shards.h: one all-gather of the per-device top-k over RCCL / xGMI).
+//            The reference's config system has no list type (include/knowhere/config.h:37-58), hence a string.  A
+//            device may be named twice ("0,0"): the shards then share it and exchange by device copies (tests on a
+//            one-GPU box).
+#define KNHIP_DEVICE_CONFIG_MEMBERS \
+    CFG_INT gpu_id;                 \
+    CFG_STRING gpu_ids;
+#define KNHIP_DEVICE_CONFIG_FIELDS()                                                                        \
+    KNOWHERE_CONFIG_DECLARE_FIELD(gpu_id)                                                                   \
+        .description("device ordinal of the index (unset: round-robin / most free memory)")                \
+        .allow_empty_without_default()                                                                      \
+        .set_range(0, 1023)                                                                                 \
+        .for_train()                                                                                        \
+        .for_deserialize()                                                                                  \
+        .for_deserialize_from_file();                                                                       \
+    KNOWHERE_CONFIG_DECLARE_FIELD(gpu_ids)                                                                  \
+        .description("devices the index is sharded over: comma separated ordinals or \"all\"")             \
+        .allow_empty_without_default()                                                                      \
+        .for_train()                                                                                        \
+        .for_deserialize()                                                                                  \
+        .for_deserialize_from_file()
+
+// "0,2,3" / "all" -> ordinals; empty on a syntax error or an ordinal outside [0, ndev)
+inline std::vector<int32_t>
+HipParseGpuIds(const std::string& s, int ndev) {
+    std::vector<int32_t> out;
+    std::string t;
+    for (char c : s) {
+        if (!std::isspace((unsigned char)c)) t.push_back((char)std::tolower((unsigned char)c));
+    }
+    if (t == "all") {
+        for (int i = 0; i < ndev; i++) out.push_back(i);
+        return out;
+    }
+    size_t pos = 0;
+    while (pos <= t.size()) {
+        const size_t e = t.find(',', pos);
+        const std::string tok = t.substr(pos, e == std::string::npos ? std::string::npos : e - pos);
+        if (tok.empty() || tok.size() > 4 || tok.find_first_not_of("0123456789") != std::string::npos) return {};
+        const int v = std::atoi(tok.c_str());
+        if (v < 0 || v >= ndev) return {};
+        out.push_back(v);
+        if (e == std::string::npos) break;
+        pos = e + 1;
+    }
+    return out;
+}
+
 struct HipBruteForceConfig : public FlatConfig {
+    KNHIP_DEVICE_CONFIG_MEMBERS
     KNOWHERE_DECLARE_CONFIG(HipBruteForceConfig) {
+        KNHIP_DEVICE_CONFIG_FIELDS();
         KNOWHERE_CONFIG_DECLARE_FIELD(k)
             .set_default(10)
             .description("search for top k similar vector.")
@@ -58,7 +119,9 @@ struct HipBruteForceConfig : public FlatConfig {
 };
 
 struct HipIvfFlatConfig : public IvfFlatConfig {
+    KNHIP_DEVICE_CONFIG_MEMBERS
     KNOWHERE_DECLARE_CONFIG(HipIvfFlatConfig) {
+        KNHIP_DEVICE_CONFIG_FIELDS();
         KNOWHERE_CONFIG_DECLARE_FIELD(k)
             .set_default(10)
             .description("search for top k similar vector.")
@@ -72,7 +135,9 @@ struct HipIvfFlatConfig : public IvfFlatConfig {
 };
 
 struct HipIvfPqConfig : public IvfPqConfig {
+    KNHIP_DEVICE_CONFIG_MEMBERS
     KNOWHERE_DECLARE_CONFIG(HipIvfPqConfig) {
+        KNHIP_DEVICE_CONFIG_FIELDS();
         KNOWHERE_CONFIG_DECLARE_FIELD(k)
             .set_default(10)
             .description("search for top k similar vector.")
@@ -102,7 +167,9 @@ struct HipIvfPqConfig : public IvfPqConfig {
 };
 
 struct HipIvfSqConfig : public IvfSqConfig {
+    KNHIP_DEVICE_CONFIG_MEMBERS
     KNOWHERE_DECLARE_CONFIG(HipIvfSqConfig) {
+        KNHIP_DEVICE_CONFIG_FIELDS();
         KNOWHERE_CONFIG_DECLARE_FIELD(k)
             .set_default(10)
             .description("search for top k similar vector.")

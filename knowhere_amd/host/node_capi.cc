@@ -10,6 +10,7 @@
 using namespace knowhere;
 
 extern "C" void knhip_host_normalize_rows(float* x, int64_t n, int64_t d, float* norms);  // hip_index_node.cc
+extern "C" int32_t knhip_host_last_placement(int32_t* out, int32_t cap);                  // hip_index_node.cc
 
 namespace {
 thread_local std::string g_err;
@@ -128,6 +129,31 @@ int knhip_node_range_search(void* h, const float* q, int64_t nq, int64_t dim, co
 // the node's NormalizeVec restatement on n rows in place (norms may be null): test hook for the bitwise check against
 // knowhere::NormalizeVecs (src/common/utils.cc:60-93)
 void knhip_node_normalize_rows(float* x, int64_t n, int64_t d, float* norms) { knhip_host_normalize_rows(x, n, d, norms); }
+
+// Index::Train / Index::Add separately (Build = both): repeated Add is how a growing segment is fed
+int knhip_node_train(void* h, const float* x, int64_t rows, int64_t dim, const char* cfg) {
+    auto ds = GenDataSet(rows, dim, x);
+    return (int)static_cast<Handle*>(h)->idx.Train(ds, ParseConfig(cfg));
+}
+int knhip_node_add(void* h, const float* x, int64_t rows, int64_t dim, const char* cfg) {
+    auto ds = GenDataSet(rows, dim, x);
+    return (int)static_cast<Handle*>(h)->idx.Add(ds, ParseConfig(cfg));
+}
+
+// Index::GetVectorByIds: out receives n * dim floats
+int knhip_node_get_vectors(void* h, const int64_t* ids, int64_t n, int64_t dim, float* out) {
+    auto ds = GenIdsDataSet(n, ids);
+    auto r = static_cast<Handle*>(h)->idx.GetVectorByIds(ds);
+    if (!r.has_value()) {
+        g_err = r.what();
+        return (int)r.error();
+    }
+    std::memcpy(out, r.value()->GetTensor(), sizeof(float) * (size_t)(n * dim));
+    return 0;
+}
+
+// where the index built / loaded last on the calling thread was placed (device ordinals in shard order): test hook
+int32_t knhip_node_last_placement(int32_t* out, int32_t cap) { return knhip_host_last_placement(out, cap); }
 
 int64_t knhip_node_count(void* h) { return static_cast<Handle*>(h)->idx.Count(); }
 int64_t knhip_node_dim(void* h) { return static_cast<Handle*>(h)->idx.Dim(); }

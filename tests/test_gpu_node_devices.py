@@ -1,0 +1,277 @@
+"""GPU tests (-m gpu) of device ownership in the Knowhere IndexNode (knowhere_amd/host/hip_index_node.cc), driven through
+IndexFactory::Create / Index::Build / Search / Serialize (node_capi.cc), as a Knowhere caller would:
+
+* placement: an index lives on the device the config names (`gpu_id`), else round-robin over the visible devices at
+  Train and on the device with the most free memory at Deserialize -- the cuVS integration's rule
+  (reference src/common/cuvs/integration/cuvs_knowhere_index.cuh:414-426, 678-690);
+* `gpu_ids` with several entries deals the inverted lists (FLAT: the rows) over those devices; Search() goes through the
+  shard group (include/knhip_shards.h) and must be BIT-IDENTICAL to the single-device node -- ids, distances, and the
+  serialized bytes.  On a one-GPU box the shards share device 0 ("0,0": staged transport), which exercises the whole
+  protocol but the RCCL transport; with >= 2 devices the same test runs over RCCL on distinct devices."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, gen_data
+
+pytestmark = pytest.mark.gpu
+NODE_SO = os.path.join(ROOT, "knowhere_amd", "libknowhere_hip_node.so")
+F = C.POINTER(C.c_float)
+I64 = C.POINTER(C.c_int64)
+U8 = C.POINTER(C.c_uint8)
+
+
+@pytest.fixture(scope="module")
+def node():
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    L = C.CDLL(NODE_SO)
+    L.knhip_node_create.restype = C.c_void_p
+    L.knhip_node_serialize.restype = C.c_int64
+    L.knhip_node_last_error.restype = C.c_char_p
+    L.knhip_node_count.restype = C.c_int64
+    return L
+
+
+def ndev():
+    import torch
+    return torch.cuda.device_count()
+
+
+class Node:
+    def __init__(self, L, name):
+        self.L, self.name = L, name
+        self.h = L.knhip_node_create(name.encode())
+        assert self.h, L.knhip_node_last_error().decode()
+
+    def close(self):
+        if self.h:
+            self.L.knhip_node_destroy(C.c_void_p(self.h))
+            self.h = None
+
+    def build(self, xb, cfg):
+        return self.L.knhip_node_build(C.c_void_p(self.h), xb.ctypes.data_as(F), C.c_int64(xb.shape[0]), C.c_int64(xb.shape[1]),
+                                       cfg.encode())
+
+    def train(self, xb, cfg):
+        return self.L.knhip_node_train(C.c_void_p(self.h), xb.ctypes.data_as(F), C.c_int64(xb.shape[0]), C.c_int64(xb.shape[1]),
+                                       cfg.encode())
+
+    def add(self, xb, cfg=""):
+        return self.L.knhip_node_add(C.c_void_p(self.h), xb.ctypes.data_as(F), C.c_int64(xb.shape[0]), C.c_int64(xb.shape[1]),
+                                     cfg.encode())
+
+    def search(self, xq, cfg, k, bitset=None, nbits=0):
+        nq, d = xq.shape
+        ids, dis = np.empty((nq, k), np.int64), np.empty((nq, k), np.float32)
+        rc = self.L.knhip_node_search(C.c_void_p(self.h), xq.ctypes.data_as(F), C.c_int64(nq), C.c_int64(d), cfg.encode(),
+                                      None if bitset is None else bitset.ctypes.data_as(U8), C.c_int64(nbits), C.c_int64(k),
+                                      ids.ctypes.data_as(I64), dis.ctypes.data_as(F))
+        assert rc == 0, (rc, self.L.knhip_node_last_error().decode())
+        return dis, ids
+
+    def range_search(self, xq, cfg):
+        nq, d = xq.shape
+        lims = np.zeros(nq + 1, np.int64)
+        pi, pd = I64(), F()
+        rc = self.L.knhip_node_range_search(C.c_void_p(self.h), xq.ctypes.data_as(F), C.c_int64(nq), C.c_int64(d), cfg.encode(),
+                                            None, C.c_int64(0), lims.ctypes.data_as(I64), C.byref(pi), C.byref(pd))
+        if rc != 0:
+            return rc, None, None, None
+        n = int(lims[nq])
+        ids = np.ctypeslib.as_array(pi, shape=(max(n, 1),))[:n].copy()
+        dis = np.ctypeslib.as_array(pd, shape=(max(n, 1),))[:n].copy()
+        libc = C.CDLL(None)
+        libc.free(pi)
+        libc.free(pd)
+        return 0, lims, ids, dis
+
+    def blob(self):
+        n = self.L.knhip_node_serialize(C.c_void_p(self.h), None, C.c_int64(0))
+        assert n > 0, n
+        out = np.empty(n, np.uint8)
+        assert self.L.knhip_node_serialize(C.c_void_p(self.h), out.ctypes.data_as(U8), C.c_int64(n)) == n
+        return out
+
+    def load(self, key, blob, cfg=""):
+        return self.L.knhip_node_deserialize(C.c_void_p(self.h), key.encode(), blob.ctypes.data_as(U8), C.c_int64(blob.size),
+                                             cfg.encode())
+
+    def get_vectors(self, ids, d):
+        ids = np.ascontiguousarray(ids, np.int64)
+        out = np.empty((len(ids), d), np.float32)
+        rc = self.L.knhip_node_get_vectors(C.c_void_p(self.h), ids.ctypes.data_as(I64), C.c_int64(len(ids)), C.c_int64(d),
+                                           out.ctypes.data_as(F))
+        return rc, out
+
+    def count(self):
+        return int(self.L.knhip_node_count(C.c_void_p(self.h)))
+
+    def placement(self):
+        buf = (C.c_int32 * 64)()
+        n = self.L.knhip_node_last_placement(buf, C.c_int32(64))
+        return [int(buf[i]) for i in range(n)]
+
+
+def shard_ids(world):
+    """distinct devices where the box has them (RCCL transport), else every shard on device 0 (staged transport)"""
+    n = ndev()
+    return ",".join(str(r if n >= world else 0) for r in range(world))
+
+
+def same(a, b):
+    return np.array_equal(a[1], b[1]) and np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+
+
+KINDS = [("GPU_HIP_IVF_PQ", "nlist=64;m=32;nbits=8", "nprobe=12"), ("GPU_HIP_IVF_FLAT", "nlist=64", "nprobe=12"),
+         ("GPU_HIP_IVF_SQ8", "nlist=64", "nprobe=12"), ("GPU_HIP_BRUTE_FORCE", "", "")]
+
+
+@pytest.mark.parametrize("name,train_cfg,search_cfg", KINDS, ids=[k[0] for k in KINDS])
+@pytest.mark.parametrize("metric", ["L2", "IP", "COSINE"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_node_is_bit_identical_to_the_single_device_node(node, name, train_cfg, search_cfg, metric, world):
+    nb, d, nq = 20000, 128, 200
+    xb, xq = gen_data(nb, d, 42), gen_data(nq, d, 44)
+    base = f"metric_type={metric};dim={d};{train_cfg}"
+    one, many = Node(node, name), Node(node, name)
+    try:
+        assert one.build(xb, base + ";gpu_id=0") == 0, node.knhip_node_last_error().decode()
+        assert one.placement() == [0]
+        assert many.build(xb, base + f";gpu_ids={shard_ids(world)}") == 0, node.knhip_node_last_error().decode()
+        assert many.placement() == [int(t) for t in shard_ids(world).split(",")]
+        assert one.count() == many.count() == nb
+        for k in (10, 1, 100):
+            cfg = f"k={k};{search_cfg}"
+            assert same(one.search(xq, cfg, k), many.search(xq, cfg, k)), (name, metric, k)
+        # a delete-bitset (bit set = filtered out), 40 % of the rows
+        bs = np.packbits(np.random.default_rng(3).random(nb) < 0.4, bitorder="little")
+        cfg = f"k=10;{search_cfg}"
+        assert same(one.search(xq, cfg, 10, bs, nb), many.search(xq, cfg, 10, bs, nb)), (name, metric, "bitset")
+        # the serialized bytes do not depend on where the lists live
+        b1, bm = one.blob(), many.blob()
+        assert np.array_equal(b1, bm), (name, metric, "blob")
+        # ... and load back onto any device list
+        again = Node(node, name)
+        try:
+            assert again.load(name, b1, f"metric_type={metric};gpu_ids={shard_ids(3)}") == 0
+            assert again.count() == nb and len(again.placement()) == 3
+            assert same(one.search(xq, cfg, 10), again.search(xq, cfg, 10)), (name, metric, "reloaded on 3 shards")
+        finally:
+            again.close()
+        if name in ("GPU_HIP_IVF_FLAT", "GPU_HIP_BRUTE_FORCE") and metric != "COSINE":
+            want = np.array([0, nb - 1, 17, nb // 2, 4242], np.int64)
+            rc1, v1 = one.get_vectors(want, d)
+            rcm, vm = many.get_vectors(want, d)
+            assert rc1 == 0 and rcm == 0 and np.array_equal(v1, vm) and np.array_equal(v1, xb[want])
+            rcm, _ = many.get_vectors(np.array([nb + 5], np.int64), d)
+            assert rcm != 0  # an id stored on no shard is an error, as on one device
+        # RangeSearch: FLAT shards by rows and answers; the IVF kinds refuse (the early stop needs every list's hit count)
+        radius = float(np.median(one.search(xq[:8], cfg, 10)[0][:, 5]))
+        rcfg = f"radius={radius!r};{search_cfg}"
+        r1 = one.range_search(xq[:8], rcfg)
+        rm = many.range_search(xq[:8], rcfg)
+        assert r1[0] == 0
+        if name == "GPU_HIP_BRUTE_FORCE":
+            assert rm[0] == 0 and np.array_equal(r1[1], rm[1])
+            for q in range(8):  # (same hits per query; the emission order of IndexFlat::range_search is the row order)
+                a, b = slice(r1[1][q], r1[1][q + 1]), slice(rm[1][q], rm[1][q + 1])
+                o1, om = np.argsort(r1[2][a], kind="stable"), np.argsort(rm[2][b], kind="stable")
+                assert np.array_equal(r1[2][a][o1], rm[2][b][om])
+                assert np.array_equal(r1[3][a][o1].view(np.uint32), rm[3][b][om].view(np.uint32))
+        else:
+            assert rm[0] == 3, rm[0]  # Status::not_implemented
+    finally:
+        one.close()
+        many.close()
+
+
+@pytest.mark.parametrize("metric", ["L2", "IP"])
+def test_sharded_refine_through_the_node(node, metric):
+    """build-time `refine` + search-time `refine_k` (IndexRefineFlat, ivf.cc:673-700, 1073-1103) on a sharded IVF_PQ index:
+    every device re-ranks the candidates whose raw rows it holds; bit-identical to the single-device node"""
+    nb, d, nq = 20000, 128, 120
+    xb, xq = gen_data(nb, d, 42), gen_data(nq, d, 44)
+    base = f"metric_type={metric};dim={d};nlist=64;m=32;nbits=8;refine=true;refine_type=fp32"
+    one, many = Node(node, "GPU_HIP_IVF_PQ"), Node(node, "GPU_HIP_IVF_PQ")
+    try:
+        assert one.build(xb, base + ";gpu_id=0") == 0
+        assert many.build(xb, base + f";gpu_ids={shard_ids(2)}") == 0
+        for k, rk in ((10, 8), (5, 20)):
+            cfg = f"k={k};nprobe=16;refine_k={rk}"
+            assert same(one.search(xq, cfg, k), many.search(xq, cfg, k)), (metric, k, rk)
+        assert np.array_equal(one.blob(), many.blob())
+        # a quantised refine store is refused, never silently replaced by another one
+        bad = Node(node, "GPU_HIP_IVF_PQ")
+        try:
+            assert bad.build(xb, base.replace("refine_type=fp32", "refine_type=sq8")) != 0
+        finally:
+            bad.close()
+    finally:
+        one.close()
+        many.close()
+
+
+@pytest.mark.parametrize("name,train_cfg,search_cfg", KINDS[:2] + KINDS[3:], ids=[k[0] for k in KINDS[:2] + KINDS[3:]])
+def test_repeated_add_on_a_sharded_node(node, name, train_cfg, search_cfg):
+    """Add may be called again and again (index_node.h:141-145): the first batch fixes the owner of every list, later rows
+    follow their list; the result equals the single-device node fed the same batches"""
+    nb, d, nq = 24000, 128, 100
+    xb, xq = gen_data(nb, d, 42), gen_data(nq, d, 44)
+    base = f"metric_type=L2;dim={d};{train_cfg}"
+    one, many = Node(node, name), Node(node, name)
+    try:
+        for nd, extra in ((one, ";gpu_id=0"), (many, f";gpu_ids={shard_ids(2)}")):
+            assert nd.train(xb, base + extra) == 0
+            for lo, hi in ((0, 10000), (10000, 17000), (17000, nb)):
+                assert nd.add(np.ascontiguousarray(xb[lo:hi]), base + extra) == 0
+            assert nd.count() == nb
+        cfg = f"k=10;{search_cfg}"
+        assert same(one.search(xq, cfg, 10), many.search(xq, cfg, 10))
+        assert np.array_equal(one.blob(), many.blob())
+    finally:
+        one.close()
+        many.close()
+
+
+def test_placement_follows_the_reference_rule(node):
+    """no gpu_id: consecutive indexes go round-robin over the visible devices at Train (select_device_id) -- on a box with
+    two or more devices two nodes built one after the other land on different devices; an explicit gpu_id is honoured
+    or refused; a loaded index goes to the device with the most free memory"""
+    nb, d = 4000, 32
+    xb = gen_data(nb, d, 42)
+    n = ndev()
+    placed = []
+    nodes = [Node(node, "GPU_HIP_IVF_FLAT") for _ in range(3)]
+    try:
+        for nd in nodes:
+            assert nd.build(xb, f"metric_type=L2;dim={d};nlist=16") == 0
+            p = nd.placement()
+            assert len(p) == 1 and 0 <= p[0] < n
+            placed.append(p[0])
+        if n >= 2:
+            assert placed[0] != placed[1], placed  # round-robin: neighbours differ
+            assert placed[1] == (placed[0] + 1) % n and placed[2] == (placed[0] + 2) % n
+        else:
+            assert placed == [0, 0, 0]
+        blob = nodes[0].blob()
+        loaded = Node(node, "GPU_HIP_IVF_FLAT")
+        try:
+            assert loaded.load("GPU_HIP_IVF_FLAT", blob, "metric_type=L2") == 0
+            assert len(loaded.placement()) == 1 and 0 <= loaded.placement()[0] < n
+            assert loaded.load("GPU_HIP_IVF_FLAT", blob, f"metric_type=L2;gpu_id={n - 1}") == 0
+            assert loaded.placement() == [n - 1]
+        finally:
+            loaded.close()
+        refused = Node(node, "GPU_HIP_IVF_FLAT")
+        try:
+            assert refused.build(xb, f"metric_type=L2;dim={d};nlist=16;gpu_id={n}") != 0      # no such device
+            assert refused.build(xb, f"metric_type=L2;dim={d};nlist=16;gpu_ids=0,{n}") != 0   # one bad entry spoils the list
+            assert refused.build(xb, f"metric_type=L2;dim={d};nlist=16;gpu_ids=zero") != 0
+        finally:
+            refused.close()
+    finally:
+        for nd in nodes:
+            nd.close()
