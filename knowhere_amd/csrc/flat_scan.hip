@@ -114,7 +114,7 @@ __device__ __forceinline__ void flat_scan_item(const FlatScanArgs& a, const int6
         bool valid = row < len;
         int64_t id_for_filter = -1;
         if (a.bitset != nullptr && valid) {
-            id_for_filter = DENSE ? (row_base + row) : a.ids[row_off + row];
+            id_for_filter = DENSE ? (row_base + row + a.id_offset) : a.ids[row_off + row]; // (the bitset lives in the id domain)
             valid = !bitset_filtered(a.bitset, a.bitset_nbits, id_for_filter);
         }
         const float4* p = a.rows + (blk0 + b) * (int64_t)a.nchunk * 64 + lane;

@@ -182,7 +182,7 @@ def test_sharded_node_is_bit_identical_to_the_single_device_node(node, name, tra
                 assert np.array_equal(r1[2][a][o1], rm[2][b][om])
                 assert np.array_equal(r1[3][a][o1].view(np.uint32), rm[3][b][om].view(np.uint32))
         else:
-            assert rm[0] == 3, rm[0]  # Status::not_implemented
+            assert rm[0] == 7, rm[0]  # Status::not_implemented
     finally:
         one.close()
         many.close()

@@ -15,6 +15,9 @@
 //  11 mode 8 with two value buffers (4 reads in flight instead of 8): what pq_filter.hip's registers allow
 //  12 int8 table, 16 queries per entry: one v_mfma_i32_16x16x64_i8 per ds_read_b128 (1024 lookups per instruction)
 //  13 int8 table, one v_smfmac_i32_16x16x128_i8 (2:4-sparse selector) per TWO ds_read_b128 (2048 lookups per instruction)
+//  14 int8 table, EIGHT queries per entry (8 bytes, 64 KB LUT): two ds_read_b64 (plain and / shift addresses: the 16-bit
+//     token IS the byte address) feed one v_mfma_i32_16x16x64_i8 -- the loop of two 8-wave workgroups per CU, each with
+//     its own 64 KB LUT (one can rebuild its LUT while the other scans); run as 512 blocks x 512 threads
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -80,6 +83,66 @@ __device__ __forceinline__ uint32_t addr_hi(uint32_t w, uint32_t one) {
     uint32_t a;
     asm("v_lshlrev_b32_sdwa %0, %2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(a) : "v"(w), "s"(one));
     return a;
+}
+
+// mode 14: 8 waves, 64 KB LUT of 8-byte entries; per token word two ds_read_b64 and one MFMA
+typedef int i2v __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(512) void k14(float* out, const uint32_t* tok, int nwin, unsigned long long* cyc) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    float* lut = reinterpret_cast<float*>(smem);
+    for (int i = threadIdx.x; i < 16384; i += 512) lut[i] = (float)(i & 1023) * 0.001f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    uint32_t T[16];
+    for (int i = 0; i < 16; i++) T[i] = tok[((blockIdx.x & 255) * 1024 + threadIdx.x) * 16 + i];
+    typedef __attribute__((address_space(3))) const i2v lds_i2;
+    i4v im0 = {0, 0, 0, 0}, im1 = {0, 0, 0, 0}, isel = {lane & 1, (lane >> 1) & 1, 0, 1};
+    i4v B0, B1, B2, B3, B4, B5, B6, B7;
+    auto issue = [&](uint32_t w, i4v& v) {
+        const i2v lo = *reinterpret_cast<lds_i2*>(w & 0xffffu);
+        const i2v hi = *reinterpret_cast<lds_i2*>(w >> 16);
+        v = i4v{lo[0], lo[1], hi[0], hi[1]};
+    };
+    issue(T[0], B0); issue(T[1], B1); issue(T[2], B2); issue(T[3], B3);
+    issue(T[4], B4); issue(T[5], B5); issue(T[6], B6); issue(T[7], B7);
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#define U14(ACC, BUF, WORD)                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                               \
+    ACC = __builtin_amdgcn_mfma_i32_16x16x64_i8(isel, BUF, ACC, 0, 0, 0);            \
+    __builtin_amdgcn_sched_barrier(0);                                               \
+    issue(WORD, BUF);
+    for (int w = 0; w < nwin; w++) {
+        U14(im0, B0, T[8]) U14(im1, B1, T[9]) U14(im0, B2, T[10]) U14(im1, B3, T[11])
+        U14(im0, B4, T[12]) U14(im1, B5, T[13]) U14(im0, B6, T[14]) U14(im1, B7, T[15])
+        U14(im0, B0, T[0]) U14(im1, B1, T[1]) U14(im0, B2, T[2]) U14(im1, B3, T[3])
+        U14(im0, B4, T[4]) U14(im1, B5, T[5]) U14(im0, B6, T[6]) U14(im1, B7, T[7])
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    out[(blockIdx.x & 255) * 1024 + threadIdx.x] = (float)(im0[0] + im0[1] + im0[2] + im0[3] + im1[0] + im1[1] + im1[2] + im1[3] +
+                                                          B0[0] + B1[0] + B2[0] + B3[0] + B4[0] + B5[0] + B6[0] + B7[0]);
+    if (lane == 0) atomicAdd(cyc + (threadIdx.x >> 6), t1 - t0);
+}
+
+void run14(const uint32_t* dtok, float* out, unsigned long long* dcyc, int blocks) {
+    const int nwin = 2000;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k14), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k14, dim3(blocks), dim3(512), 65536, 0, out, dtok, 10, dcyc);
+    hipDeviceSynchronize();
+    hipMemset(dcyc, 0, 16 * 8);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k14, dim3(blocks), dim3(512), 65536, 0, out, dtok, nwin, dcyc);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long h[16];
+    hipMemcpy(h, dcyc, sizeof(h), hipMemcpyDeviceToHost);
+    // per workgroup: 8 waves x nwin windows x 16 MFMAs x 1024 lookups
+    const double lookups = (double)blocks * 8 * nwin * 16 * 1024;
+    printf("int8 x 8 queries, 2 x ds_read_b64 per MFMA, %d blocks of 8 waves  %8.3f ms  %5.1f lookups/ns/CU  ticks/window: w0 %.0f w7 %.0f\n",
+           blocks, ms, lookups / 256 / (ms * 1e6), (double)h[0] / blocks / nwin, (double)h[7] / blocks / nwin);
 }
 
 template <int MODE>
@@ -211,5 +274,22 @@ int main() {
     run<11>("MFMA adds, 4 reads in flight", dtok, out, dcyc);
     run<12>("int8 table, MFMA i8 16x16x64", dtok, out, dcyc);
     run<13>("int8 table, SMFMAC i8 16x16x128", dtok, out, dcyc);
+    // mode 14 tokens: lane (kb = L >> 4, n = L & 15) walks m = 16 (kb & 1) + ((n + step) & 15): the 32 lanes of either half
+    // of the wave touch 32 different sub-quantizers = 32 different bank pairs of the 8-byte entries at every step
+    for (size_t t = 0; t < (size_t)256 * 1024; t++) {
+        const int L = t & 63;
+        for (int i = 0; i < 16; i++) {
+            uint32_t w = 0;
+            for (int h = 0; h < 2; h++) {
+                const int step = 2 * i + h;
+                const uint32_t m = (uint32_t)(16 * ((L >> 4) & 1) + ((L + step) & 15)), code = rand() & 255;
+                w |= ((code << 8) | (m << 3)) << (16 * h);
+            }
+            htok[t * 16 + i] = w;
+        }
+    }
+    hipMemcpy(dtok, htok, n * 4, hipMemcpyHostToDevice);
+    run14(dtok, out, dcyc, 512);  // two workgroups per CU
+    run14(dtok, out, dcyc, 256);  // one workgroup per CU (half the waves): what one scans at while the other builds its LUT
     return 0;
 }
