@@ -46,9 +46,9 @@
 extern "C" {
 #endif
 
-/* 4: knhip_train_params gained spherical/reserved, knhip_stage_times its prefilter counters.
+/* 4: knhip_train_params gained spherical/reserved, knhip_stage_times its prefilter counters.  5: tie_queries.
  * Callers compare knhip_abi_version() with the header they were built against. */
-#define KNHIP_ABI_VERSION 4
+#define KNHIP_ABI_VERSION 5
 
 typedef struct knhip_index knhip_index;
 
@@ -375,6 +375,8 @@ typedef struct knhip_stage_times {
     double mscan_stream_bytes; /* bytes the prefilter streams: sum over its units of len(list) * code_size */
     int64_t mscan_recomputed;  /* candidates that got an exact distance (IVF_PQ: after the finish kernel's pruning) */
     int64_t pq_filter_form;    /* IVF_PQ prefilter of the last search: 0 none (exact kernels), 1 half precision, 2 int8 */
+    int64_t tie_queries;       /* queries with candidates tied at their k-th distance beyond the k-th place, resolved by the
+                                  reference's first-come admission rule (scan order) instead of the canonical order */
 } knhip_stage_times;
 /* stage indices */
 enum {

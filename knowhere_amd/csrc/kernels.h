@@ -408,7 +408,14 @@ struct RangeArgs {
     float radius;
     const uint8_t* bitset;
     int64_t bitset_nbits;
+    // tie resolution of Search() (knhip_api.hip, search_batch_ties): one radius per query and the bound itself is a hit
+    const float* radius_q;    // [nq], nullptr: `radius` for every query
+    int32_t inclusive;        // 1: dist <= radius (L2) / dist >= radius (IP)
 };
+// k-th-boundary ties (ResultHandler.h:258-279): rows of kk = k + 1 canonical results -> the first k to (out_d, out_i); a
+// query whose (k + 1)-th entry exists with the k-th distance is appended to flagged[] (count in *nflag)
+hipError_t launch_tie_detect(const float* d, const int64_t* i, int64_t nq, int k, float* out_d, int64_t* out_i,
+                             int32_t* flagged, int32_t* nflag, hipStream_t s);
 // every exact ADC distance of every probed list of an IVF-PQ index with any M x 8 bit codes (range.hip)
 struct PqDumpArgs {
     float* dist;                 // [nq][ncol], column = list_row_off[list] + position

@@ -137,6 +137,7 @@ struct Workspace {
     DevBuf rs_sort;                                                  // row selection of more than 16384 keys: sort scratch
     // host-boundary staging
     DevBuf h_queries, h_bitset, h_out_d, h_out_i, h_ref_d, h_ref_i;
+    DevBuf tie_d, tie_i, tie_flag, tie_q, tie_r, tie_keys, tie_cdis; // search_batch_ties: k + 1 results, flagged queries
     std::mutex mu;  // held while a *_device entry point enqueues on this (per-stream) workspace
     // side stream of the IVF-PQ prefilter: the grouping of the pairs by list (work table) runs beside the sample pass
     hipStream_t side = nullptr;
@@ -268,6 +269,7 @@ struct knhip_index {
     mutable knhip_stage_times times{};
     DevBuf scan_bytes_dev; // double accumulator
     mutable double coarse_flops = 0;
+    mutable int64_t tie_queries = 0;  // queries resolved by the reference's admission rule (search_batch_ties)
     mutable int64_t last_items_bound = 0;
 
     int64_t device_bytes() const {
@@ -1835,6 +1837,11 @@ int knhip_index_uses_precomputed_table(const knhip_index* idx) {
     return idx ? idx->use_precomp : 0;
 }
 
+// (defined behind the range pass it reuses)
+static int search_batch_ties(const knhip_index* idx, Workspace* ws, const float* d_q, int64_t nq, int k, int nprobe,
+                             const uint8_t* d_bitset, int64_t nbits, int64_t* d_out_i, float* d_out_d, hipStream_t s,
+                             const int64_t* pre_keys, const float* pre_cdis);
+
 int knhip_search_device(const knhip_index* idx, const float* d_queries, int64_t nq, int32_t k,
                         int32_t nprobe, const uint8_t* d_bitset, int64_t bitset_nbits,
                         int64_t* d_out_ids, float* d_out_dist, void* stream) {
@@ -1856,8 +1863,8 @@ int knhip_search_device(const knhip_index* idx, const float* d_queries, int64_t 
     }
     for (int64_t q0 = 0; q0 < nq; q0 += qb) {
         const int64_t n = std::min(qb, nq - q0);
-        if (int rc = search_batch(idx, ws, d_queries + q0 * idx->d, n, k, nprobe, d_bitset, bitset_nbits,
-                                  d_out_ids + q0 * k, d_out_dist + q0 * k, s)) {
+        if (int rc = search_batch_ties(idx, ws, d_queries + q0 * idx->d, n, k, nprobe, d_bitset, bitset_nbits,
+                                       d_out_ids + q0 * k, d_out_dist + q0 * k, s, nullptr, nullptr)) {
             return rc;
         }
     }
@@ -1890,9 +1897,9 @@ int knhip_search_preassigned_device(const knhip_index* idx, const float* d_queri
     const int64_t qb = query_batch(idx, nq, k, nprobe);
     for (int64_t q0 = 0; q0 < nq; q0 += qb) {
         const int64_t n = std::min(qb, nq - q0);
-        if (int rc = search_batch(idx, ws, d_queries + q0 * idx->d, n, k, nprobe, d_bitset, bitset_nbits,
-                                  d_out_ids + q0 * k, d_out_dist + q0 * k, s, d_keys + q0 * nprobe,
-                                  d_coarse_dis + q0 * nprobe)) {
+        if (int rc = search_batch_ties(idx, ws, d_queries + q0 * idx->d, n, k, nprobe, d_bitset, bitset_nbits,
+                                       d_out_ids + q0 * k, d_out_dist + q0 * k, s, d_keys + q0 * nprobe,
+                                       d_coarse_dis + q0 * nprobe)) {
             return rc;
         }
     }
@@ -1945,9 +1952,9 @@ static int search_host_impl(const knhip_index* idx, const knhip_index* raw, cons
         }
         for (int64_t q0 = 0; q0 < nq; q0 += qb) {
             const int64_t n = std::min(qb, nq - q0);
-            if (int r = search_batch(idx, ws, ws->h_queries.as<float>() + q0 * idx->d, n, ks, nprobe, d_bitset,
-                                     bitset_nbits, ws->h_out_i.as<int64_t>() + q0 * ks,
-                                     ws->h_out_d.as<float>() + q0 * ks, s)) {
+            if (int r = search_batch_ties(idx, ws, ws->h_queries.as<float>() + q0 * idx->d, n, ks, nprobe, d_bitset,
+                                          bitset_nbits, ws->h_out_i.as<int64_t>() + q0 * ks,
+                                          ws->h_out_d.as<float>() + q0 * ks, s, nullptr, nullptr)) {
                 return r;
             }
         }
@@ -2126,14 +2133,20 @@ int knhip_index_find_vectors(const knhip_index* idx, int64_t n, const int64_t* i
 // Every probed list is scanned in dump mode (all distances -> dist[q][column]); range.hip then counts the
 // hits per (query, probe rank), applies the reference's early stop and compacts the survivors in the
 // reference's emission order.  One batch of queries (device pointers); results appended to host vectors.
+// Tie resolution of Search() reuses this pass (search_batch_ties): d_radius_q = one (inclusive) radius per query,
+// nprobe_limit = the search's nprobe (the lists of ranks [0, nprobe_limit) only, no early stop), pre_keys / pre_cdis =
+// a given coarse assignment [nq][nprobe_limit] (search_preassigned) -- the hits then come out in the reference's SCAN
+// order (probe rank, storage position), which is what its first-come admission depends on.
 static int range_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_t nq, float radius,
                        int max_empty, const uint8_t* d_bitset, int64_t nbits, const int64_t* d_seg /*3 x nseg*/,
                        int64_t nseg, int64_t ncol, int64_t* h_lims /*nq + 1, relative*/, std::vector<int64_t>& out_i,
-                       std::vector<float>& out_d, hipStream_t s) {
+                       std::vector<float>& out_d, hipStream_t s, const float* d_radius_q = nullptr,
+                       int nprobe_limit = 0, const int64_t* pre_keys = nullptr, const float* pre_cdis = nullptr) {
     const int kind = idx->desc.kind;
     const bool is_l2 = idx->is_l2;
     const int d = idx->d;
-    const int nprobe = (int)nseg;
+    const int nprobe = (nprobe_limit > 0 && kind != KNHIP_BRUTE_FORCE) ? std::min<int64_t>(nprobe_limit, nseg) : (int)nseg;
+    const bool all_lists = nprobe == (int)nseg;
     HIP_TRY(ws->dump.reserve((size_t)nq * ncol * sizeof(float)));
     RangeArgs r{};
     r.dist = ws->dump.as<float>();
@@ -2143,6 +2156,8 @@ static int range_batch(const knhip_index* idx, Workspace* ws, const float* d_q, 
     r.seg_len = d_seg + 2 * nseg;
     r.nprobe = nprobe;
     r.radius = radius;
+    r.radius_q = d_radius_q;
+    r.inclusive = d_radius_q != nullptr ? 1 : 0;
     r.bitset = d_bitset;
     r.bitset_nbits = nbits;
     FlatScanArgs fc{};
@@ -2166,7 +2181,10 @@ static int range_batch(const knhip_index* idx, Workspace* ws, const float* d_q, 
     } else {
         HIP_TRY(ws->keys.reserve((size_t)nq * nprobe * sizeof(int64_t)));
         HIP_TRY(ws->cdis.reserve((size_t)nq * nprobe * sizeof(float)));
-        if (int rc = coarse_stage(idx, ws, d_q, nq, nprobe, ws->keys.as<int64_t>(), ws->cdis.as<float>(), s)) {
+        if (pre_keys != nullptr) {
+            HIP_TRY(hipMemcpyAsync(ws->keys.p, pre_keys, (size_t)nq * nprobe * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+            HIP_TRY(hipMemcpyAsync(ws->cdis.p, pre_cdis, (size_t)nq * nprobe * sizeof(float), hipMemcpyDeviceToDevice, s));
+        } else if (int rc = coarse_stage(idx, ws, d_q, nq, nprobe, ws->keys.as<int64_t>(), ws->cdis.as<float>(), s)) {
             return rc;
         }
         r.ids = idx->ids.as<int64_t>();
@@ -2175,7 +2193,7 @@ static int range_batch(const knhip_index* idx, Workspace* ws, const float* d_q, 
     // every distance of the lists keys_w[q][0 .. W) (-1: none) -> dump[q][column]
     auto scan_dump = [&](const int64_t* keys_w, const float* cdis_w, int W) -> int {
         if (kind == KNHIP_IVF_FLAT) {
-            if (W == nprobe) {
+            if (W == nprobe && all_lists) {
                 // all lists of every query: the dense all-pairs kernel (rows shared by eight queries)
                 HIP_TRY(launch_flat_full(fc, is_l2, ws->dump.as<float>(), nullptr, 0, nullptr, s));
             } else {
@@ -2300,10 +2318,12 @@ static int range_batch(const knhip_index* idx, Workspace* ws, const float* d_q, 
     }
     bool counted = false;
     if (kind != KNHIP_BRUTE_FORCE) {
-        const bool waves = max_empty > 0 && nprobe > 128 && getenv("KNHIP_RANGE_NO_WAVES") == nullptr;
+        const bool waves = all_lists && max_empty > 0 && nprobe > 128 && getenv("KNHIP_RANGE_NO_WAVES") == nullptr;
         if (!waves) {
             if (int rc = scan_dump(ws->keys.as<int64_t>(), ws->cdis.as<float>(), nprobe)) return rc;
-            idx->last_range_ranks = nprobe;
+            if (all_lists) {
+                idx->last_range_ranks = nprobe;
+            }
         } else {
             // rank waves: 64 coarse ranks first, doubling; a query leaves once its run of empty lists reaches max_empty
             HIP_TRY(ws->rg_state.reserve(((size_t)nq * 2 + 1) * sizeof(int32_t)));
@@ -2370,6 +2390,193 @@ static int range_batch(const knhip_index* idx, Workspace* ws, const float* d_q, 
     return KNHIP_OK;
 }
 
+// segments of the distance matrix range_batch works on -> ws->rg_seg (3 x nseg: column of the first row, position of the
+// first id, length): the inverted lists, or 8192-row pieces of a brute-force base
+static int range_segments(const knhip_index* idx, Workspace* ws, hipStream_t s, int64_t* nseg_out, int64_t* ncol_out) {
+    const int kind = idx->desc.kind;
+    std::vector<int64_t> seg;
+    int64_t nseg = 0, ncol = 0;
+    if (kind == KNHIP_BRUTE_FORCE) {
+        const int64_t SEG = 8192;
+        ncol = idx->ntotal;
+        nseg = (ncol + SEG - 1) / SEG;
+        seg.resize((size_t)3 * nseg);
+        for (int64_t i = 0; i < nseg; i++) {
+            seg[i] = seg[nseg + i] = i * SEG;
+            seg[2 * nseg + i] = std::min(SEG, ncol - i * SEG);
+        }
+    } else {
+        nseg = idx->nlist;
+        seg.resize((size_t)3 * nseg);
+        int64_t blk = 0;
+        for (int64_t l = 0; l < nseg; l++) {
+            seg[l] = kind == KNHIP_IVF_FLAT ? blk * 64 : idx->h_list_row_off[l];
+            seg[nseg + l] = idx->h_list_row_off[l];
+            seg[2 * nseg + l] = idx->h_list_len[l];
+            blk += (idx->h_list_len[l] + 63) / 64;
+        }
+        ncol = kind == KNHIP_IVF_FLAT ? blk * 64 : idx->ntotal;
+    }
+    HIP_TRY(ws->rg_seg.reserve(seg.size() * sizeof(int64_t)));
+    HIP_TRY(hipMemcpyAsync(ws->rg_seg.p, seg.data(), seg.size() * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s)); // (the host vector is released on return)
+    *nseg_out = nseg;
+    *ncol_out = ncol;
+    return KNHIP_OK;
+}
+
+// ---- Search() with the reference's admission rule at the k-th boundary ---------------------------------------------------
+// The reference keeps its k best in a heap with STRICT-improve admission (HeapResultHandler::add_result,
+// thirdparty/faiss/faiss/impl/ResultHandler.h:258-279: a candidate enters only if it beats the current k-th) and
+// replaces the heap's top, which among equal distances is the one heap_replace_top's cmp2 order puts there
+// (utils/Heap.h:113-151, utils/ordered_key_value.h:51, 74: the largest id for L2 / CMax, the smallest for IP / CMin);
+// candidates arrive in scan order = probe rank, then storage position (IndexIVF.cpp:642-655; IndexFlat: row order).  With
+// v the final k-th distance this is equivalent to (tests/test_tie_rule.py replays the heap against it):
+//     a candidate tied with v is ELIGIBLE iff it is among the first k arrivals with distance <= v (L2; >= v for IP);
+//     result = canonical top-k of {every candidate better than v} U {eligible ties}.
+// The canonical pipeline already has v and every better candidate; it is run for k + 1 results, and only a query whose
+// (k + 1)-th entry ties with its k-th (a tied candidate was left out) needs the arrival order: its probed lists are
+// scanned once more in dump mode (range_batch with the query's own radius v, inclusive), which emits the hits in
+// scan order; the first k of them decide.  One 4-byte read-back per batch tells whether any query is flagged
+// (KNHIP_TIES=canonical: no read-back, the canonical answer -- the licensed deviation of include/knhip.h).
+// Not covered: k = 1024 (no room for the (k + 1)-th result), brute force with k >= 100 (the reference switches to a
+// reservoir, ResultHandler.h:719-728, whose boundary ties depend on its partition steps), lists sharded over several
+// indexes (every shard resolves its own candidates; the merge is canonical).
+static bool ties_reference_mode() {
+    const char* t = getenv("KNHIP_TIES");
+    return !(t && (t[0] == 'c' || t[0] == 'C' || t[0] == '0'));
+}
+
+static int search_batch_ties(const knhip_index* idx, Workspace* ws, const float* d_q, int64_t nq, int k, int nprobe,
+                             const uint8_t* d_bitset, int64_t nbits, int64_t* d_out_i, float* d_out_d, hipStream_t s,
+                             const int64_t* pre_keys, const float* pre_cdis) {
+    const int kind = idx->desc.kind;
+    const bool reservoir = kind == KNHIP_BRUTE_FORCE && k >= 100;
+    if (!ties_reference_mode() || reservoir || k + 1 > KN_MAX_K) {
+        return search_batch(idx, ws, d_q, nq, k, nprobe, d_bitset, nbits, d_out_i, d_out_d, s, pre_keys, pre_cdis);
+    }
+    const int kk = k + 1;
+    const bool is_l2 = idx->is_l2;
+    HIP_TRY(ws->tie_d.reserve((size_t)nq * kk * sizeof(float)));
+    HIP_TRY(ws->tie_i.reserve((size_t)nq * kk * sizeof(int64_t)));
+    HIP_TRY(ws->tie_flag.reserve(((size_t)nq + 1) * sizeof(int32_t)));
+    if (int rc = search_batch(idx, ws, d_q, nq, kk, nprobe, d_bitset, nbits, ws->tie_i.as<int64_t>(), ws->tie_d.as<float>(), s,
+                              pre_keys, pre_cdis)) {
+        return rc;
+    }
+    int32_t* flagged = ws->tie_flag.as<int32_t>();
+    int32_t* nflag_dev = flagged + nq;
+    HIP_TRY(hipMemsetAsync(nflag_dev, 0, sizeof(int32_t), s));
+    HIP_TRY(launch_tie_detect(ws->tie_d.as<float>(), ws->tie_i.as<int64_t>(), nq, k, d_out_d, d_out_i, flagged, nflag_dev, s));
+    int32_t nflag = 0;
+    HIP_TRY(hipMemcpyAsync(&nflag, nflag_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (nflag <= 0) {
+        return KNHIP_OK;
+    }
+    // ---- flagged queries: canonical rows to the host, arrivals with distance <= v in scan order from a dump pass --------
+    std::vector<int32_t> fl((size_t)nflag);
+    HIP_TRY(hipMemcpy(fl.data(), flagged, (size_t)nflag * sizeof(int32_t), hipMemcpyDeviceToHost));
+    std::sort(fl.begin(), fl.end()); // (the detect kernel appends in any order)
+    std::vector<float> cd((size_t)nflag * kk);
+    std::vector<int64_t> ci((size_t)nflag * kk);
+    for (int32_t f = 0; f < nflag; f++) {
+        HIP_TRY(hipMemcpyAsync(cd.data() + (size_t)f * kk, ws->tie_d.as<float>() + (size_t)fl[f] * kk, (size_t)kk * sizeof(float),
+                               hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(ci.data() + (size_t)f * kk, ws->tie_i.as<int64_t>() + (size_t)fl[f] * kk,
+                               (size_t)kk * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    }
+    int64_t nseg = 0, ncol = 0;
+    if (int rc = range_segments(idx, ws, s, &nseg, &ncol)) return rc; // (synchronises: the rows above have arrived)
+    const int np = kind == KNHIP_BRUTE_FORCE ? 0 : nprobe;
+    // queries per round: the dump matrix [round][ncol] stays below 2 GiB
+    int64_t qb = std::max<int64_t>(1, (int64_t)((2ull << 30) / ((size_t)std::max<int64_t>(ncol, 1) * 4)));
+    qb = std::max<int64_t>(1, std::min<int64_t>(qb, (int64_t)0x7fffffff / std::max<int64_t>(nseg, 1)));
+    std::vector<float> new_d((size_t)nflag * k);
+    std::vector<int64_t> new_i((size_t)nflag * k);
+    for (int64_t f0 = 0; f0 < nflag; f0 += qb) {
+        const int64_t n = std::min<int64_t>(qb, nflag - f0);
+        HIP_TRY(ws->tie_q.reserve((size_t)n * idx->d * sizeof(float)));
+        HIP_TRY(ws->tie_r.reserve((size_t)n * sizeof(float)));
+        std::vector<float> rad((size_t)n);
+        for (int64_t j = 0; j < n; j++) {
+            const int64_t q = fl[(size_t)(f0 + j)];
+            HIP_TRY(hipMemcpyAsync(ws->tie_q.as<float>() + j * idx->d, d_q + q * idx->d, (size_t)idx->d * sizeof(float),
+                                   hipMemcpyDeviceToDevice, s));
+            rad[(size_t)j] = cd[(size_t)(f0 + j) * kk + k - 1]; // v: the k-th distance
+        }
+        HIP_TRY(hipMemcpyAsync(ws->tie_r.p, rad.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice, s));
+        const int64_t* pk = nullptr;
+        const float* pc = nullptr;
+        if (pre_keys != nullptr) { // the given assignment of these queries
+            HIP_TRY(ws->tie_keys.reserve((size_t)n * nprobe * sizeof(int64_t)));
+            HIP_TRY(ws->tie_cdis.reserve((size_t)n * nprobe * sizeof(float)));
+            for (int64_t j = 0; j < n; j++) {
+                const int64_t q = fl[(size_t)(f0 + j)];
+                HIP_TRY(hipMemcpyAsync(ws->tie_keys.as<int64_t>() + j * nprobe, pre_keys + q * nprobe,
+                                       (size_t)nprobe * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+                HIP_TRY(hipMemcpyAsync(ws->tie_cdis.as<float>() + j * nprobe, pre_cdis + q * nprobe,
+                                       (size_t)nprobe * sizeof(float), hipMemcpyDeviceToDevice, s));
+            }
+            pk = ws->tie_keys.as<int64_t>();
+            pc = ws->tie_cdis.as<float>();
+        }
+        HIP_TRY(hipStreamSynchronize(s)); // (rad is a host temporary)
+        std::vector<int64_t> lims((size_t)n + 1), hit_i;
+        std::vector<float> hit_d;
+        if (int rc = range_batch(idx, ws, ws->tie_q.as<float>(), n, 0.f, 0, d_bitset, nbits, ws->rg_seg.as<int64_t>(), nseg, ncol,
+                                 lims.data(), hit_i, hit_d, s, ws->tie_r.as<float>(), np, pk, pc)) {
+            return rc;
+        }
+        for (int64_t j = 0; j < n; j++) {
+            const size_t f = (size_t)(f0 + j);
+            const float v = cd[f * kk + k - 1];
+            // every candidate better than v is in the canonical row; a tie is eligible iff it is among the first k arrivals
+            std::vector<std::pair<float, int64_t>> pool;
+            for (int e = 0; e < k; e++) {
+                if (ci[f * kk + e] >= 0 && cd[f * kk + e] != v) {
+                    pool.emplace_back(cd[f * kk + e], ci[f * kk + e]);
+                }
+            }
+            const int64_t a0 = lims[(size_t)j], a1 = lims[(size_t)j + 1];
+            for (int64_t a = a0; a < a1 && a < a0 + k; a++) {
+                if (hit_d[(size_t)a] == v) {
+                    pool.emplace_back(v, hit_i[(size_t)a]);
+                }
+            }
+            std::sort(pool.begin(), pool.end(), [&](const std::pair<float, int64_t>& x, const std::pair<float, int64_t>& y) {
+                if (x.first != y.first) return is_l2 ? x.first < y.first : x.first > y.first;
+                return is_l2 ? x.second < y.second : x.second > y.second;
+            });
+            if ((int64_t)pool.size() < k) {
+                // (cannot happen: the first k arrivals and the better candidates together hold at least k entries; keep the
+                // canonical row rather than invent one)
+                for (int e = 0; e < k; e++) {
+                    new_d[f * k + e] = cd[f * kk + e];
+                    new_i[f * k + e] = ci[f * kk + e];
+                }
+                continue;
+            }
+            for (int e = 0; e < k; e++) {
+                new_d[f * k + e] = pool[(size_t)e].first;
+                new_i[f * k + e] = pool[(size_t)e].second;
+            }
+        }
+    }
+    for (int32_t f = 0; f < nflag; f++) {
+        HIP_TRY(hipMemcpyAsync(d_out_d + (size_t)fl[f] * k, new_d.data() + (size_t)f * k, (size_t)k * sizeof(float),
+                               hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_out_i + (size_t)fl[f] * k, new_i.data() + (size_t)f * k, (size_t)k * sizeof(int64_t),
+                               hipMemcpyHostToDevice, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    {
+        std::lock_guard<std::mutex> lk(idx->mu);
+        idx->tie_queries += nflag;
+    }
+    return KNHIP_OK;
+}
+
 int knhip_range_search(const knhip_index* idx, const float* queries, int64_t nq, float radius,
                        int32_t max_empty_result_buckets, const uint8_t* bitset, int64_t bitset_nbits, int64_t* lims,
                        int64_t** out_ids, float** out_dist) {
@@ -2401,32 +2608,8 @@ int knhip_range_search(const knhip_index* idx, const float* queries, int64_t nq,
     std::vector<int64_t> res_i;
     std::vector<float> res_d;
     auto run = [&]() -> int {
-        // segments: column of the first row, position of the first id, length
-        std::vector<int64_t> seg;
         int64_t nseg = 0, ncol = 0;
-        if (kind == KNHIP_BRUTE_FORCE) {
-            const int64_t SEG = 8192;
-            ncol = idx->ntotal;
-            nseg = (ncol + SEG - 1) / SEG;
-            seg.resize((size_t)3 * nseg);
-            for (int64_t i = 0; i < nseg; i++) {
-                seg[i] = seg[nseg + i] = i * SEG;
-                seg[2 * nseg + i] = std::min(SEG, ncol - i * SEG);
-            }
-        } else {
-            nseg = idx->nlist;
-            seg.resize((size_t)3 * nseg);
-            int64_t blk = 0;
-            for (int64_t l = 0; l < nseg; l++) {
-                seg[l] = kind == KNHIP_IVF_FLAT ? blk * 64 : idx->h_list_row_off[l];
-                seg[nseg + l] = idx->h_list_row_off[l];
-                seg[2 * nseg + l] = idx->h_list_len[l];
-                blk += (idx->h_list_len[l] + 63) / 64;
-            }
-            ncol = kind == KNHIP_IVF_FLAT ? blk * 64 : idx->ntotal;
-        }
-        HIP_TRY(ws->rg_seg.reserve(seg.size() * sizeof(int64_t)));
-        HIP_TRY(hipMemcpyAsync(ws->rg_seg.p, seg.data(), seg.size() * sizeof(int64_t), hipMemcpyHostToDevice, s));
+        if (int r = range_segments(idx, ws, s, &nseg, &ncol)) return r;
         const size_t qbytes = (size_t)nq * idx->d * sizeof(float);
         HIP_TRY(ws->h_queries.reserve(qbytes));
         HIP_TRY(hipMemcpyAsync(ws->h_queries.p, queries, qbytes, hipMemcpyHostToDevice, s));
@@ -3383,6 +3566,7 @@ int knhip_profile_reset(knhip_index* idx) {
     drain_pending(idx);
     std::memset(&idx->times, 0, sizeof(idx->times));
     idx->coarse_flops = 0;
+    idx->tie_queries = 0;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemset(idx->scan_bytes_dev.p, 0, 3 * sizeof(double)));
     HIP_TRY(hipMemset(idx->coarse_fail_dev.p, 0, 8 * sizeof(unsigned long long)));
@@ -3403,6 +3587,7 @@ int knhip_profile_get(const knhip_index* idx, knhip_stage_times* out) {
     out->scan_bytes = sb[0];
     out->scan_bytes_rank0 = idx->rank0_phase_used ? sb[1] : 0.0;
     out->coarse_flops = idx->coarse_flops;
+    out->tie_queries = idx->tie_queries;
     out->scan_items = idx->last_items_bound;
     // coarse certificate failures; prefilter paths: finished / overflowed queries, candidates, exact recomputations
     unsigned long long nf[5] = {0, 0, 0, 0, 0};

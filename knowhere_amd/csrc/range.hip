@@ -29,7 +29,12 @@ template <bool IS_L2>
 __device__ __forceinline__ bool range_hit(const RangeArgs& a, int64_t q, int64_t col, int64_t id_pos, float* dis) {
     const float v = a.dist[q * a.ncol + col];
     *dis = v;
-    if (!(IS_L2 ? (v < a.radius) : (v > a.radius))) {
+    const float rad = a.radius_q ? a.radius_q[q] : a.radius;
+    if (a.inclusive) {
+        if (!(IS_L2 ? (v <= rad) : (v >= rad))) {
+            return false;
+        }
+    } else if (!(IS_L2 ? (v < rad) : (v > rad))) {
         return false;
     }
     const int64_t id = a.ids ? a.ids[id_pos] : id_pos + a.id_offset;
@@ -396,6 +401,40 @@ hipError_t launch_range_plan(const int32_t* cnt, int64_t nq, int nprobe, int max
     }
     hipLaunchKernelGGL(range_plan_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, s, cnt, nq, nprobe, max_empty,
                        off, total);
+    return hipGetLastError();
+}
+
+// ---- k-th-boundary ties: the search ran with kk = k + 1 results per query; the (k + 1)-th tells whether the k-th distance
+// is shared by a candidate that did not make the canonical top-k -- only then can the reference's first-come admission
+// (ResultHandler.h:258-279, Heap.h:113-151) differ from the canonical answer, and only those queries are resolved
+__global__ void tie_detect_kernel(const float* __restrict__ d, const int64_t* __restrict__ i, int64_t nq, int k,
+                                  float* __restrict__ out_d, int64_t* __restrict__ out_i, int32_t* __restrict__ flagged,
+                                  int32_t* __restrict__ nflag) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int kk = k + 1;
+    if (t < nq * k) {
+        const int64_t q = t / k;
+        const int j = (int)(t % k);
+        out_d[t] = d[q * kk + j];
+        out_i[t] = i[q * kk + j];
+    }
+    if (t < nq) {
+        const bool tie = i[t * kk + k] >= 0 && i[t * kk + k - 1] >= 0 &&
+                         __float_as_uint(d[t * kk + k]) == __float_as_uint(d[t * kk + k - 1]);
+        if (tie) {
+            flagged[atomicAdd(nflag, 1)] = (int32_t)t;
+        }
+    }
+}
+
+hipError_t launch_tie_detect(const float* d, const int64_t* i, int64_t nq, int k, float* out_d, int64_t* out_i,
+                             int32_t* flagged, int32_t* nflag, hipStream_t s) {
+    if (nq <= 0) {
+        return hipSuccess;
+    }
+    const int64_t n = nq * (int64_t)k;
+    hipLaunchKernelGGL(tie_detect_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d, i, nq, k, out_d, out_i,
+                       flagged, nflag);
     return hipGetLastError();
 }
 

@@ -4,7 +4,11 @@
 // thirdparty/faiss/faiss/IndexRefine.cpp:104-140; Knowhere wraps IVF_PQ / IVF_SQ8 in it when
 // `refine` is set: src/index/ivf/ivf.cc:1073-1103, src/index/refine/refine_utils.cc:99):
 //   for each candidate label (in order, stopping at the first -1): dis = metric(q, base[label])
-//   then the k best of the k_base re-scored candidates, canonical order.
+//   then the k best of the k_base re-scored candidates: reorder_2_heaps (utils/Heap.h:657) pushes them IN CANDIDATE ORDER
+//   through a heap with strict-improve admission (Heap.cpp addn_with_ids -> heap_replace_top), so among candidates tied
+//   at the k-th distance v the ones kept are decided by arrival: a tie is eligible iff it is among the first k
+//   candidates with distance <= v (knhip_api.hip, search_batch_ties states the equivalence), and the result is the
+//   canonical top-k of {better than v} U {eligible ties}.  Applied here whenever more than k candidates reach v.
 // Distances use the reference's sequential fp32 order (fvec_L2sqr / fvec_inner_product), so they
 // are bit-equal to the CPU refine.  288 GB of HBM3E holds the raw vectors of a 100M x 128 index
 // (51 GB) next to its codes, so refine is a ~0.5 GB random gather per 10k-query batch: noise
@@ -21,12 +25,13 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ b
                                                      const int64_t* __restrict__ cand, int kbase, int k,
                                                      float* __restrict__ out_d,
                                                      int64_t* __restrict__ out_i) {
-    extern __shared__ __align__(16) float sq[]; // [4][d]
+    extern __shared__ __align__(16) float sq[]; // [4][d] queries, then [4][kbase] the candidates' distances
     const int lane = lane_id();
     const int wave = threadIdx.x / KN_WAVE;
     const int64_t q = (int64_t)blockIdx.x * 4 + wave;
     const bool live = q < nq;
     float* myq = sq + wave * d;
+    float* mydis = sq + 4 * d + wave * kbase;
     if (live) {
         for (int i = lane; i < d; i += KN_WAVE) {
             myq[i] = queries[q * d + i];
@@ -41,6 +46,8 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ b
     float kd = worst_dist<IS_L2>();
     int64_t ki = -1;
     bool ended = false; // a -1 label ends the candidate list (IndexRefine.cpp:119-121)
+    bool skipped = false; // a slot whose row lives on another shard: its distance is unknown here
+    int nend = kbase;     // candidates before the end of the list
     for (int c0 = 0; c0 < kbase && !ended; c0 += KN_WAVE) {
         const int c = c0 + lane;
         int64_t id = -1;
@@ -53,8 +60,10 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ b
         if (neg) {
             nvalid = __ffsll((long long)neg) - 1;
             ended = true;
+            nend = c0 + nvalid;
         }
         const bool ok = lane < nvalid && id >= 0 && (id - id_base) >= 0 && (id - id_base) < nbase;
+        skipped = skipped || __ballot(lane < nvalid && !ok) != 0ull;
         float acc = 0.f;
         if (ok) {
             const float* y = base + (id - id_base) * d;
@@ -95,6 +104,9 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ b
                 acc = IS_L2 ? l2_step(acc, myq[i], y[i]) : ip_step(acc, myq[i], y[i]);
             }
         }
+        if (c < kbase) {
+            mydis[c] = acc;
+        }
         unsigned long long m = __ballot(ok && top.admits(acc, id, kd, ki));
         while (m) {
             const int l = __ffsll((long long)m) - 1;
@@ -108,6 +120,44 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ b
             }
         }
     }
+    // ---- the reference's admission at the k-th boundary (see the header): only when a full list leaves tied candidates out
+    if (ki >= 0 && !skipped) {
+        const float v = kd;
+        int nqual = 0;
+        for (int c0 = 0; c0 < nend; c0 += KN_WAVE) {
+            const int c = c0 + lane;
+            const float dis = c < nend ? mydis[c] : 0.f;
+            nqual += __popcll(__ballot(c < nend && (IS_L2 ? dis <= v : dis >= v)));
+        }
+        if (nqual > k) {
+            top.init(k);
+            kd = worst_dist<IS_L2>();
+            ki = -1;
+            int seen = 0;
+            for (int c0 = 0; c0 < nend; c0 += KN_WAVE) {
+                const int c = c0 + lane;
+                const float dis = c < nend ? mydis[c] : 0.f;
+                const int64_t id = c < nend ? cand[q * kbase + c] : -1;
+                const bool qual = c < nend && (IS_L2 ? dis <= v : dis >= v);
+                const unsigned long long qm = __ballot(qual);
+                const int rank = seen + __popcll(qm & ((1ull << lane) - 1ull)); // arrivals with distance <= v before this one
+                seen += __popcll(qm);
+                const bool elig = qual && (dis != v || rank < k);
+                unsigned long long m = __ballot(elig && top.admits(dis, id, kd, ki));
+                while (m) {
+                    const int l = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const float cd = readlane_f(dis, l);
+                    const int64_t ci = readlane_i64(id, l);
+                    if (top.admits(cd, ci, kd, ki)) {
+                        top.insert(cd, ci);
+                        kd = top.kth_dist();
+                        ki = top.kth_idx();
+                    }
+                }
+            }
+        }
+    }
     top.store(out_d + q * k, out_i + q * k);
 }
 
@@ -118,7 +168,7 @@ hipError_t launch_refine(const float* base, int64_t nbase, int64_t id_base, int 
         return hipSuccess;
     }
     const unsigned grid = (unsigned)((nq + 3) / 4);
-    const size_t sm = (size_t)4 * d * sizeof(float);
+    const size_t sm = ((size_t)4 * d + (size_t)4 * kbase) * sizeof(float);
     KN_DISPATCH_R(k, {
         if (is_l2) {
             hipLaunchKernelGGL((refine_kernel<true, R_>), dim3(grid), dim3(256), sm, s, base, nbase, id_base,

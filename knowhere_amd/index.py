@@ -315,7 +315,8 @@ class GpuIndex:
                 "coarse_fallback_queries": st.coarse_fallback_queries, "scan_bytes_rank0": st.scan_bytes_rank0,
                 "mscan_queries": st.mscan_queries, "mscan_overflow_queries": st.mscan_overflow_queries,
                 "mscan_candidates": st.mscan_candidates, "mscan_stream_bytes": st.mscan_stream_bytes,
-                "mscan_recomputed": st.mscan_recomputed, "pq_filter_form": st.pq_filter_form}
+                "mscan_recomputed": st.mscan_recomputed, "pq_filter_form": st.pq_filter_form,
+                "tie_queries": st.tie_queries}
 
 
 def kmeans_device(metric, x_t, k, niter=None, max_points=None, seed=None, spherical=False):

@@ -86,7 +86,7 @@ def test_sharded_search_equals_the_single_index(shards, port, kind, metric, worl
             Do, Io = port.search(ix, xq, k, nprobe)
             D, I, ms = _group_search(shards, parts, [0] * world, 1, xq, k, nprobe)
             assert np.array_equal(I, Iw) and np.array_equal(D.view(np.uint32), Dw.view(np.uint32)), (kind, k, nprobe)
-            assert_parity(Do, Io, D, I, metric, f"sharded world={world} kind={kind} k={k}")
+            assert_parity(Do, Io, D, I, metric, f"sharded world={world} kind={kind} k={k}", licensed_ties=True)
             assert (ms[:, 3] > 0).all()
         bs = np.packbits(np.random.default_rng(1).random(nb) < 0.4, bitorder="little")
         Dw, Iw = whole.search(xq, 10, 8, bs, nb)

@@ -39,7 +39,7 @@ def _worker(rank, world, port_no, ret):
     comm = sharded.Comm()
     D, I = comm.allgather_merge(ob.L2, torch.from_numpy(Dl), torch.from_numpy(Il))
     D0, I0 = port.search(ix, xq, 10, 8)
-    assert_parity(D0, I0, D.numpy(), I.numpy(), ob.L2, f"rank {rank}: sharded == monolithic")
+    assert_parity(D0, I0, D.numpy(), I.numpy(), ob.L2, f"rank {rank}: sharded == monolithic", licensed_ties=True)
     # the coarse quantizer sharded by queries + search_preassigned over the owned lists (bench.py's N > 1 step):
     # 41 queries over 2 ranks exercises the padded last slice
     xq2 = gen_data(41, 32, 45)
@@ -54,7 +54,7 @@ def _worker(rank, world, port_no, ret):
     Dl2, Il2 = port.ivf_search_preassigned(sub, xq2, 10, keys.numpy(), cdis.numpy())
     D2, I2 = comm.allgather_merge(ob.L2, torch.from_numpy(Dl2), torch.from_numpy(Il2))
     D20, I20 = port.search(ix, xq2, 10, 8)
-    assert_parity(D20, I20, D2.numpy(), I2.numpy(), ob.L2, f"rank {rank}: query-sharded coarse + list-sharded scan")
+    assert_parity(D20, I20, D2.numpy(), I2.numpy(), ob.L2, f"rank {rank}: query-sharded coarse + list-sharded scan", licensed_ties=True)
     t = comm.max_float(float(rank))
     assert t == world - 1
     b = torch.full((3,), float(rank))
@@ -70,13 +70,13 @@ def _worker(rank, world, port_no, ret):
     Dc, Ic = port.ivf_search_preassigned(sub, xq2, kbase, keys.numpy(), cdis.numpy())
     Dcu, Icu = comm.allgather_merge(ob.L2, torch.from_numpy(Dc), torch.from_numpy(Ic))
     Dc0, Ic0 = port.search(ix, xq2, kbase, 8)
-    assert_parity(Dc0, Ic0, Dcu.numpy(), Icu.numpy(), ob.L2, "first stage union == monolithic")
+    assert_parity(Dc0, Ic0, Dcu.numpy(), Icu.numpy(), ob.L2, "first stage union == monolithic", licensed_ties=True)
     rows = sharded.ids_to_rows(Icu, torch.from_numpy(own_ids))
     Dr, Rr = port.refine(ob.L2, own_rows, xq2, rows.numpy(), k)
     Ir = sharded.rows_to_ids(torch.from_numpy(Rr), torch.from_numpy(own_ids))
     D3, I3 = comm.allgather_merge(ob.L2, torch.from_numpy(Dr), Ir)
     D30, I30 = port.refine(ob.L2, xb, xq2, Icu.numpy(), k)
-    assert_parity(D30, I30, D3.numpy(), I3.numpy(), ob.L2, f"rank {rank}: owner-side refine == monolithic refine")
+    assert_parity(D30, I30, D3.numpy(), I3.numpy(), ob.L2, f"rank {rank}: owner-side refine == monolithic refine", licensed_ties=True)
     # ids this rank does not hold -> -2 (skipped by the re-rank), -1 still ends a row
     m = sharded.ids_to_rows(torch.tensor([[1, 2, 3, -1]]), torch.tensor([1, 3, 7]))
     assert m.tolist() == [[0, -2, 1, -1]]
