@@ -32,9 +32,19 @@
  * reference's scalar operation order, one IEEE rounding per operation (no FMA contraction),
  * so returned distances are bit-equal to the scalar reference; returned ids are the k best
  * in canonical order (L2: distance asc, id asc; IP: distance desc, id desc -- the order
- * heap_reorder produces, thirdparty/faiss/faiss/utils/Heap.h:427-457).  The only licensed
- * deviation: among candidates whose distance EQUALS the k-th distance bit-for-bit, the
- * reference keeps first-scanned, this library keeps canonical-first.
+ * heap_reorder produces, thirdparty/faiss/faiss/utils/Heap.h:427-457).
+ * Candidates TIED at the k-th distance: the reference's heap admits first-come (strict improve,
+ * impl/ResultHandler.h:258-279) and evicts by id (heap_replace_top / cmp2, utils/Heap.h:113-151), so which of them
+ * is returned depends on the scan order (probe rank, then storage position).  The library returns the same ones
+ * (knhip_search*, knhip_search_preassigned_device, knhip_search_refine, knhip_refine_device): the search runs for
+ * k + 1 canonical results, a query whose (k + 1)-th ties with its k-th has its probed lists scanned once more in
+ * scan order and the rule applied (one 4-byte read-back per batch tells whether there is such a query;
+ * KNHIP_TIES=canonical skips it and returns the canonical k: graph capture, or callers that do not care).
+ * Conditions: the ids of every list ascend in storage order -- what IvfIndexNode::Add produces (ids are the running
+ * row numbers); knhip_index_add_lists re-sorts a list that does not, and ties inside it are then taken in id order.
+ * Not covered (canonical answer): k = 1024; BRUTE_FORCE with k >= 100 (the reference switches to a reservoir,
+ * impl/ResultHandler.h:719-728); results merged from several indexes (knhip_merge_topk_*, knhip_shard_group_*: every
+ * shard resolves its own candidates).
  */
 #ifndef KNHIP_H
 #define KNHIP_H

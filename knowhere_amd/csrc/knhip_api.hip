@@ -2476,7 +2476,10 @@ static int search_batch_ties(const knhip_index* idx, Workspace* ws, const float*
     }
     // ---- flagged queries: canonical rows to the host, arrivals with distance <= v in scan order from a dump pass --------
     std::vector<int32_t> fl((size_t)nflag);
-    HIP_TRY(hipMemcpy(fl.data(), flagged, (size_t)nflag * sizeof(int32_t), hipMemcpyDeviceToHost));
+    // (never the null stream: a legacy-default-stream copy waits for every blocking stream of the process, other shards'
+    // included -- three shards on one device deadlocked on it)
+    HIP_TRY(hipMemcpyAsync(fl.data(), flagged, (size_t)nflag * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
     std::sort(fl.begin(), fl.end()); // (the detect kernel appends in any order)
     std::vector<float> cd((size_t)nflag * kk);
     std::vector<int64_t> ci((size_t)nflag * kk);

@@ -74,3 +74,17 @@ def load_cosine_golden():
     ix.list_ids = [np.ascontiguousarray(zi["ids"][off[l]:off[l + 1]]) for l in range(nlist)]
     ix.list_norms = [np.ascontiguousarray(zi["norms"][off[l]:off[l + 1]]) for l in range(nlist)]
     return zf, zi, ix
+
+
+def sort_lists_by_id(ix):
+    """every inverted list in ascending id order (codes follow): the storage order Knowhere's own Add produces (ids are the
+    running row numbers, appended), and the order the library keeps its lists in -- which candidate of several tied at
+    the k-th distance is returned depends on the scan order (conftest.assert_parity), so a fixture with shuffled ids is
+    brought to that order on BOTH sides before it is compared"""
+    for l in range(len(ix.list_ids)):
+        o = np.argsort(ix.list_ids[l], kind="stable")
+        ix.list_ids[l] = np.ascontiguousarray(ix.list_ids[l][o])
+        ix.list_codes[l] = np.ascontiguousarray(ix.list_codes[l][o])
+        if getattr(ix, "list_norms", None):
+            ix.list_norms[l] = np.ascontiguousarray(ix.list_norms[l][o])
+    return ix

@@ -106,6 +106,28 @@ def main():
                 assert ranks == nlist if max_empty == 0 else ranks <= nlist, (kind, max_empty, ranks)
                 assert exp[0][-1] > 0
             g.close()
+    elif case in ("ties_flat", "ties_ivfflat", "ties_ivfsq8", "ties_ivfpq"):
+        # duplicates of a few rows: more candidates at the k-th distance than places -> the reference's admission rule
+        # (knhip_api.hip, search_batch_ties: k + 1 results, detect, dump pass in scan order, closed form of the heap)
+        rng = np.random.default_rng(17)
+        d = 32
+        proto = (rng.integers(-3, 4, (30, d)) * 7.0).astype(np.float32)
+        xb = np.ascontiguousarray(proto[rng.integers(0, 30, 1500)])
+        xq = np.ascontiguousarray((proto[rng.integers(0, 30, 12)] + rng.integers(0, 2, (12, d))).astype(np.float32))
+        kind = {"ties_flat": ob.FLAT, "ties_ivfflat": ob.IVF_FLAT, "ties_ivfsq8": ob.IVF_SQ8, "ties_ivfpq": ob.IVF_PQ}[case]
+        for metric in (ob.L2, ob.IP):
+            ix = ob.make_index(port, kind, metric, xb, nlist=8, M=8)
+            g = GpuIndex.from_data(ix, device=0)
+            g.profile_enable(True)
+            g.profile_reset()
+            bs = np.packbits(np.random.default_rng(3).random(len(xb)) < 0.3, bitorder="little")
+            for k in (1, 6, 25):
+                for b, nb_ in ((None, 0), (bs, len(xb))):
+                    Do, Io = port.search(ix, xq, k, 4, b, nb_)
+                    D, I = g.search(xq, k, 4, b, nb_)
+                    same(Do, Io, D, I, f"{case} metric={metric} k={k} bitset={b is not None}")
+            assert g.profile_get()["tie_queries"] > 0
+            g.close()
     else:
         raise SystemExit(f"unknown case {case}")
     print("OK", case)

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 from conftest import assert_parity, gen_data
+from helpers import sort_lists_by_id
 from oracle import binding as ob
 
 pytestmark = pytest.mark.gpu
@@ -79,7 +80,7 @@ def test_mscan_ragged_dims_empty_lists_and_ties(torch_cuda, port, monkeypatch, k
         xb, xq = gen_data(nb, d, 42), gen_data(70, d, 44)
         xb[100:160] = xb[7]  # exact duplicates: distance ties, broken by id
         ids = np.random.default_rng(5).permutation(nb).astype(np.int64) * 3 + 1
-        ix = ob.make_index(port, kind, ob.L2, xb, nlist=23, ids=ids)
+        ix = sort_lists_by_id(ob.make_index(port, kind, ob.L2, xb, nlist=23, ids=ids))  # (shuffled ids, stored in id order)
         for l in (0, 4):  # lists emptied by hand
             ix.list_codes[l] = ix.list_codes[l][:0]
             ix.list_ids[l] = ix.list_ids[l][:0]
@@ -147,7 +148,7 @@ def test_mscan_retry_round(torch_cuda, port, monkeypatch, kind, metric):
     nb, d, nlist = 30000, 64, 40
     xb, xq = gen_data(nb, d, 42), gen_data(90, d, 44)
     ix = ob.make_index(port, kind, metric, xb, nlist=nlist)
-    monkeypatch.setenv("KNHIP_MSCAN_CAP", "24")
+    monkeypatch.setenv("KNHIP_MSCAN_CAP", "26")  # (>= 2 (k + 1): the search runs for k + 1 results, conftest.assert_parity)
     g0, g1 = _pair(monkeypatch, ix)
     for k, nprobe in ((10, 16), (3, nlist), (12, 8)):
         p = _check(port, ix, g0, g1, xq, k, nprobe, metric, f"retry kind={kind} metric={metric} k={k} nprobe={nprobe}")

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from conftest import assert_parity, gen_data
-from helpers import finish_ivfpq
+from helpers import finish_ivfpq, sort_lists_by_id
 from oracle import binding as ob
 
 pytestmark = pytest.mark.gpu
@@ -95,7 +95,7 @@ def test_pqf_empty_lists_ties_and_ids(torch_cuda, port, monkeypatch):
     xb, xq = gen_data(nb, d, 42), gen_data(70, d, 44)
     xb[100:160] = xb[7]  # exact duplicates: distance ties, broken by id
     ids = np.random.default_rng(5).permutation(nb).astype(np.int64) * 3 + 1
-    ix = finish_ivfpq(port, ob.make_index(port, ob.IVF_PQ, ob.L2, xb, nlist=23, M=32, ids=ids))
+    ix = sort_lists_by_id(finish_ivfpq(port, ob.make_index(port, ob.IVF_PQ, ob.L2, xb, nlist=23, M=32, ids=ids)))
     for l in (0, 4):  # lists emptied by hand
         ix.list_codes[l] = ix.list_codes[l][:0]
         ix.list_ids[l] = ix.list_ids[l][:0]
