@@ -101,7 +101,7 @@ def parse():
     ap.add_argument("--backend", default=None, help="nccl (default for N>1) | gloo (single-GPU debugging)")
     ap.add_argument("--coarse-mode", default="auto", choices=["auto", "replicate", "shard"],
                     help="N > 1: coarse quantizer replicated on every rank (no collective) or sharded by queries (one "
-                         "all-gather of the assignment); auto = replicate below 1e11 flop per batch")
+                         "all-gather of the assignment); auto = shard")
     ap.add_argument("--verbose", action="store_true")
     a = ap.parse_args()
     a.overridden = [key for key in SHAPE_KEYS if getattr(a, key, None) is not None] + (["data"] if a.data else [])
@@ -285,10 +285,9 @@ def run_config(a, rank, world, dev, dev_id, comm):
 
     # N > 1: the coarse quantizer is sharded by QUERIES (each rank assigns nq / N of them, one all-gather of the
     # (nq, nprobe) assignment), the scan by LISTS (knhip_search_preassigned_device = IndexIVF::search_preassigned)
-    # (the coarse stage is replicated when it is small -- no collective, <= ~1 ms at C3 -- and sharded by queries, one
-    # all-gather of the assignment, when it is a TFLOP as at C5)
-    coarse_replicated = kind == kidx.BRUTE_FORCE or a.coarse_mode == "replicate" or \
-        (a.coarse_mode == "auto" and 2.0 * a.nq * a.nlist * a.d < 1e11)
+    # (auto = sharded: the replicated coarse stage -- 1.1 ms per rank at C3 -- is the first thing Amdahl charges a
+    # list-sharded step for; the packed assignment is 15 MB per step at C3)
+    coarse_replicated = kind == kidx.BRUTE_FORCE or a.coarse_mode == "replicate"
 
     def step(b=0):
         q = xqs[b % len(xqs)]

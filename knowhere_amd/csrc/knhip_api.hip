@@ -2455,7 +2455,9 @@ static int search_batch_ties(const knhip_index* idx, Workspace* ws, const float*
     if (!ties_reference_mode() || reservoir || k + 1 > KN_MAX_K) {
         return search_batch(idx, ws, d_q, nq, k, nprobe, d_bitset, nbits, d_out_i, d_out_d, s, pre_keys, pre_cdis);
     }
+    const bool trace = getenv("KNHIP_TIES_TRACE") != nullptr;
     const int kk = k + 1;
+    if (trace) fprintf(stderr, "[ties] search nq=%lld k=%d nprobe=%d kind=%d\n", (long long)nq, k, nprobe, kind);
     const bool is_l2 = idx->is_l2;
     HIP_TRY(ws->tie_d.reserve((size_t)nq * kk * sizeof(float)));
     HIP_TRY(ws->tie_i.reserve((size_t)nq * kk * sizeof(int64_t)));
@@ -2464,6 +2466,7 @@ static int search_batch_ties(const knhip_index* idx, Workspace* ws, const float*
                               pre_keys, pre_cdis)) {
         return rc;
     }
+    if (trace) fprintf(stderr, "[ties] searched\n");
     int32_t* flagged = ws->tie_flag.as<int32_t>();
     int32_t* nflag_dev = flagged + nq;
     HIP_TRY(hipMemsetAsync(nflag_dev, 0, sizeof(int32_t), s));
@@ -2471,6 +2474,7 @@ static int search_batch_ties(const knhip_index* idx, Workspace* ws, const float*
     int32_t nflag = 0;
     HIP_TRY(hipMemcpyAsync(&nflag, nflag_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    if (trace) fprintf(stderr, "[ties] flagged %d\n", nflag);
     if (nflag <= 0) {
         return KNHIP_OK;
     }
@@ -2525,12 +2529,14 @@ static int search_batch_ties(const knhip_index* idx, Workspace* ws, const float*
             pc = ws->tie_cdis.as<float>();
         }
         HIP_TRY(hipStreamSynchronize(s)); // (rad is a host temporary)
+        if (trace) fprintf(stderr, "[ties] round f0=%lld n=%lld ncol=%lld nseg=%lld np=%d\n", (long long)f0, (long long)n, (long long)ncol, (long long)nseg, np);
         std::vector<int64_t> lims((size_t)n + 1), hit_i;
         std::vector<float> hit_d;
         if (int rc = range_batch(idx, ws, ws->tie_q.as<float>(), n, 0.f, 0, d_bitset, nbits, ws->rg_seg.as<int64_t>(), nseg, ncol,
                                  lims.data(), hit_i, hit_d, s, ws->tie_r.as<float>(), np, pk, pc)) {
             return rc;
         }
+        if (trace) fprintf(stderr, "[ties] dumped: %lld hits\n", (long long)hit_i.size());
         for (int64_t j = 0; j < n; j++) {
             const size_t f = (size_t)(f0 + j);
             const float v = cd[f * kk + k - 1];
@@ -2573,6 +2579,7 @@ static int search_batch_ties(const knhip_index* idx, Workspace* ws, const float*
                                hipMemcpyHostToDevice, s));
     }
     HIP_TRY(hipStreamSynchronize(s));
+    if (trace) fprintf(stderr, "[ties] patched\n");
     {
         std::lock_guard<std::mutex> lk(idx->mu);
         idx->tie_queries += nflag;

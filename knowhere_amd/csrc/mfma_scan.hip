@@ -1138,10 +1138,10 @@ __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, c
         atomicAdd(counters + 3, (unsigned long long)n);
     }
     int P = 2;
-    while (P < n + k && P < P_max) {
-        P <<= 1;
+    while ((P < n + k || P <= k) && P < P_max) { // (P > k always: a query without candidates and a power-of-two k left
+        P <<= 1;                                   //  P == k, chunk 0 and the round loop below spinning for ever)
     }
-    const int chunk = P - k; // candidates per round (P_max >= 2 k)
+    const int chunk = P - k; // candidates per round, >= 1 (P_max >= 2 k)
     // LDS: tie[P_max] (u64) | key[P_max] (u32) | query [dq] floats (| vmin, vdiff for SQ8)
     unsigned long long* tie = reinterpret_cast<unsigned long long*>(smem);
     uint32_t* key = reinterpret_cast<uint32_t*>(smem + (size_t)P_max * 8);

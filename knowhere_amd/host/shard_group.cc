@@ -1,7 +1,10 @@
 // knowhere_amd/host/shard_group.cc -- C++ host of the list-sharded multi-GPU search (include/knhip_shards.h).
 //
-// One worker thread per GPU inside one process; per Search(): every worker uploads the batch, runs knhip_search_device on
-// its own index (the lists it owns), packs its (nq, k) partial result into 12-byte entries, ONE all-gather
+// One worker thread per GPU inside one process; per Search(): every worker uploads the batch; the coarse quantizer is
+// SHARDED BY QUERIES (rank r assigns nq / W of them with knhip_coarse_search_device, one packed all-gather gives every rank
+// the whole (nq, nprobe) assignment: the replicated stage that would otherwise bound the scaling), then every
+// worker scans the lists it owns (knhip_search_preassigned_device = IndexIVF::search_preassigned), packs its (nq, k)
+// partial result into 12-byte entries, ONE all-gather
 // (ncclAllGather over the RCCL communicators of ncclCommInitAll, or staged device copies), knhip_merge_topk_device,
 // rank 0 downloads.  Replaces faiss IndexShards::search + merge_knn_results (IndexShards.cpp:247-256).
 #include "knhip_shards.h"
@@ -9,8 +12,10 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -63,7 +68,7 @@ struct Rank {
     const knhip_index* idx = nullptr;
     hipStream_t stream = nullptr;
     ncclComm_t comm = nullptr;
-    DevMem q, bits, part_d, part_i, packed, gathered, all_d, all_i, out_d, out_i, ref_d, ref_i;
+    DevMem q, bits, part_d, part_i, packed, gathered, all_d, all_i, out_d, out_i, ref_d, ref_i, ck, cd, keys, cdis;
     // raw fp32 rows this rank holds for the refine stage: row r = vector id raw_id0 + r (device pointer on `dev`)
     const float* raw = nullptr;
     int64_t raw_n = 0, raw_id0 = 0;
@@ -144,7 +149,7 @@ int knhip_shard_group_create(int32_t n_devices, const int32_t* device_ids, int32
         Rank& k = g->ranks[r];
         k.dev = device_ids[r];
         for (DevMem* m : {&k.q, &k.bits, &k.part_d, &k.part_i, &k.packed, &k.gathered, &k.all_d, &k.all_i, &k.out_d, &k.out_i,
-                          &k.ref_d, &k.ref_i}) {
+                          &k.ref_d, &k.ref_i, &k.ck, &k.cd, &k.keys, &k.cdis}) {
             m->dev = k.dev;
         }
         (void)hipSetDevice(k.dev);
@@ -234,6 +239,13 @@ static int search_impl(knhip_shard_group* g, const float* queries, int64_t nq, i
     const int32_t k1 = refine ? k_base : k;       // width of the first exchange
     const int64_t ne1 = nq * (int64_t)k1;         // entries per rank, first exchange
     const int64_t ne = nq * (int64_t)k;           // entries of the result
+    // coarse quantizer sharded by queries (IVF kinds, several ranks): rank r assigns rows [r per, (r + 1) per)
+    const char* cmode = getenv("KNHIP_SHARDS_COARSE");  // "replicate": every rank assigns every query (no extra collective)
+    const bool shard_coarse = W > 1 && desc.kind != KNHIP_BRUTE_FORCE && !(cmode && cmode[0] == 'r');
+    const int32_t np = desc.kind == KNHIP_BRUTE_FORCE ? 1 : (int32_t)std::min<int64_t>(nprobe, desc.nlist);
+    const int64_t per = (nq + W - 1) / W;
+    const int64_t nec = shard_coarse ? per * (int64_t)np : 0;  // entries per rank of the coarse exchange
+    const int64_t nemax = std::max(ne1, nec);
     Barrier bar(W);
     std::vector<std::atomic<int>> rcs(W);  // (read by the peers between barriers)
     for (auto& a : rcs) a.store(KNHIP_OK);
@@ -249,6 +261,7 @@ static int search_impl(knhip_shard_group* g, const float* queries, int64_t nq, i
         };
         Rank& me = R[r];
         bool alive = true;  // (a failed rank still walks through every barrier)
+        const uint8_t* me_bits = nullptr;
         hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         auto all_ok = [&]() {
             bool ok = true;
@@ -257,9 +270,11 @@ static int search_impl(knhip_shard_group* g, const float* queries, int64_t nq, i
         };
         // ---- one exchange step: pack (pd, pi) [nq][kk], all-gather of the packed partials, unpack + merge -> (od, oi);
         // e_g / e_m: events recorded before the gather and after the merge.  Same barrier walk for every rank.
+        // merge = false: the gathered (float, int64) entries are only unpacked into (all_d, all_i) -- the coarse assignment;
+        // rows = entries per rank / kk
         auto exchange = [&](int32_t kk, const float* pd, const int64_t* pi, float* od, int64_t* oi, hipEvent_t e_g,
-                            hipEvent_t e_m) {
-            const int64_t n = nq * (int64_t)kk;
+                            hipEvent_t e_m, bool merge = true, int64_t rows = -1) {
+            const int64_t n = (rows < 0 ? nq : rows) * (int64_t)kk;
             auto head = [&]() {
                 hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, me.stream, pd, pi, n,
                                    static_cast<uint32_t*>(me.packed.p));
@@ -321,12 +336,14 @@ static int search_impl(knhip_shard_group* g, const float* queries, int64_t nq, i
                 hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)((n * W + 255) / 256)), dim3(256), 0, me.stream,
                                    static_cast<const uint32_t*>(me.gathered.p), n * W, static_cast<float*>(me.all_d.p),
                                    static_cast<int64_t*>(me.all_i.p));
-                const int mrc = knhip_merge_topk_device(metric, nq, kk, W, static_cast<const float*>(me.all_d.p),
-                                                        static_cast<const int64_t*>(me.all_i.p), od, oi, me.stream);
-                if (mrc != KNHIP_OK) {
-                    err = std::string("knhip_merge_topk_device: ") + knhip_last_error();
-                    rc = mrc;
-                    return;
+                if (merge) {
+                    const int mrc = knhip_merge_topk_device(metric, nq, kk, W, static_cast<const float*>(me.all_d.p),
+                                                            static_cast<const int64_t*>(me.all_i.p), od, oi, me.stream);
+                    if (mrc != KNHIP_OK) {
+                        err = std::string("knhip_merge_topk_device: ") + knhip_last_error();
+                        rc = mrc;
+                        return;
+                    }
                 }
                 SG_HIP(hipEventRecord(e_m, me.stream));
             };
@@ -343,10 +360,16 @@ static int search_impl(knhip_shard_group* g, const float* queries, int64_t nq, i
             SG_HIP(me.q.reserve((size_t)nq * dim * sizeof(float)));
             SG_HIP(me.part_d.reserve((size_t)ne1 * sizeof(float)));
             SG_HIP(me.part_i.reserve((size_t)ne1 * sizeof(int64_t)));
-            SG_HIP(me.packed.reserve((size_t)ne1 * 12));
-            SG_HIP(me.gathered.reserve((size_t)ne1 * 12 * W));
-            SG_HIP(me.all_d.reserve((size_t)ne1 * W * sizeof(float)));
-            SG_HIP(me.all_i.reserve((size_t)ne1 * W * sizeof(int64_t)));
+            SG_HIP(me.packed.reserve((size_t)nemax * 12));
+            SG_HIP(me.gathered.reserve((size_t)nemax * 12 * W));
+            SG_HIP(me.all_d.reserve((size_t)nemax * W * sizeof(float)));
+            SG_HIP(me.all_i.reserve((size_t)nemax * W * sizeof(int64_t)));
+            if (shard_coarse) {
+                SG_HIP(me.ck.reserve((size_t)nec * sizeof(int64_t)));
+                SG_HIP(me.cd.reserve((size_t)nec * sizeof(float)));
+                SG_HIP(me.keys.reserve((size_t)nec * W * sizeof(int64_t)));
+                SG_HIP(me.cdis.reserve((size_t)nec * W * sizeof(float)));
+            }
             SG_HIP(me.out_d.reserve((size_t)ne1 * sizeof(float)));
             SG_HIP(me.out_i.reserve((size_t)ne1 * sizeof(int64_t)));
             if (refine) {
@@ -361,18 +384,55 @@ static int search_impl(knhip_shard_group* g, const float* queries, int64_t nq, i
                 SG_HIP(hipMemcpyAsync(me.bits.p, bitset, bb, hipMemcpyHostToDevice, me.stream));
                 d_bits = static_cast<const uint8_t*>(me.bits.p);
             }
+            me_bits = d_bits;
             SG_HIP(hipEventRecord(ev[0], me.stream));
-            const int src = knhip_search_device(me.idx, static_cast<const float*>(me.q.p), nq, k1, nprobe, d_bits,
-                                                d_bits ? bitset_nbits : 0, static_cast<int64_t*>(me.part_i.p),
-                                                static_cast<float*>(me.part_d.p), me.stream);
+            if (shard_coarse) {
+                // my slice of the queries -> (keys, coarse distances); rows past nq stay "no list"
+                const int64_t lo = std::min<int64_t>(nq, r * per), hi = std::min<int64_t>(nq, (r + 1) * per);
+                SG_HIP(hipMemsetAsync(me.ck.p, 0xff, (size_t)nec * sizeof(int64_t), me.stream));  // -1
+                SG_HIP(hipMemsetAsync(me.cd.p, 0, (size_t)nec * sizeof(float), me.stream));
+                if (hi > lo) {
+                    const int crc = knhip_coarse_search_device(me.idx, static_cast<const float*>(me.q.p) + lo * dim, hi - lo, np,
+                                                               static_cast<int64_t*>(me.ck.p), static_cast<float*>(me.cd.p),
+                                                               me.stream);
+                    if (crc != KNHIP_OK) {
+                        err = std::string("knhip_coarse_search_device: ") + knhip_last_error();
+                        rc = crc;
+                        return;
+                    }
+                }
+            }
+        };
+        auto search = [&]() {
+            int src;
+            if (shard_coarse) {
+                // (all_d, all_i) hold the W blocks of `per` rows in rank order = the assignment of rows [0, W per) >= nq
+                SG_HIP(hipMemcpyAsync(me.cdis.p, me.all_d.p, (size_t)nec * W * sizeof(float), hipMemcpyDeviceToDevice, me.stream));
+                SG_HIP(hipMemcpyAsync(me.keys.p, me.all_i.p, (size_t)nec * W * sizeof(int64_t), hipMemcpyDeviceToDevice, me.stream));
+                src = knhip_search_preassigned_device(me.idx, static_cast<const float*>(me.q.p), nq, k1, np,
+                                                      static_cast<const int64_t*>(me.keys.p), static_cast<const float*>(me.cdis.p),
+                                                      me_bits, me_bits ? bitset_nbits : 0, static_cast<int64_t*>(me.part_i.p),
+                                                      static_cast<float*>(me.part_d.p), me.stream);
+            } else {
+                src = knhip_search_device(me.idx, static_cast<const float*>(me.q.p), nq, k1, nprobe, me_bits,
+                                          me_bits ? bitset_nbits : 0, static_cast<int64_t*>(me.part_i.p),
+                                          static_cast<float*>(me.part_d.p), me.stream);
+            }
             if (src != KNHIP_OK) {
-                err = std::string("knhip_search_device: ") + knhip_last_error();
+                err = std::string(shard_coarse ? "knhip_search_preassigned_device: " : "knhip_search_device: ") + knhip_last_error();
                 rc = src;
-                return;
             }
         };
         body();
         alive = rc == KNHIP_OK;
+        if (shard_coarse) {
+            exchange(np, static_cast<const float*>(me.cd.p), static_cast<const int64_t*>(me.ck.p), nullptr, nullptr, ev[3], ev[6],
+                     /*merge=*/false, /*rows=*/per);
+        }
+        if (alive) {
+            search();
+            alive = rc == KNHIP_OK;
+        }
         exchange(k1, static_cast<const float*>(me.part_d.p), static_cast<const int64_t*>(me.part_i.p),
                  static_cast<float*>(me.out_d.p), static_cast<int64_t*>(me.out_i.p), ev[1], ev[2]);
         float* res_d = static_cast<float*>(me.out_d.p);

@@ -85,7 +85,7 @@ def test_mscan_ragged_dims_empty_lists_and_ties(torch_cuda, port, monkeypatch, k
             ix.list_codes[l] = ix.list_codes[l][:0]
             ix.list_ids[l] = ix.list_ids[l][:0]
         g0, g1 = _pair(monkeypatch, ix)
-        for k, nprobe in ((10, 23), (64, 6), (3, 2)):
+        for k, nprobe in ((10, 23), (64, 6), (3, 2), (4, 2), (8, 1), (2, 1)):  # (2^n with all probed lists empty: see mscan_finish_kernel)
             _check(port, ix, g0, g1, xq, k, nprobe, ob.L2, f"kind={kind} d={d} k={k} nprobe={nprobe}")
         g0.close()
         g1.close()
