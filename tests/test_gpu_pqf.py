@@ -154,7 +154,7 @@ def test_pqf_retry_round(torch_cuda, port, monkeypatch, metric):
     nb, d, nlist = 40000, 128, 40
     xb, xq = gen_data(nb, d, 42), gen_data(90, d, 44)
     ix = finish_ivfpq(port, ob.make_index(port, ob.IVF_PQ, metric, xb, nlist=nlist, M=32))
-    monkeypatch.setenv("KNHIP_MSCAN_CAP", "24")
+    monkeypatch.setenv("KNHIP_MSCAN_CAP", "26")  # (>= 2 (k + 1): the search runs for k + 1 results)
     g0, g1 = _pair(monkeypatch, ix, guard=False)  # (the selectivity guard would hand these batches to the exact kernel)
     for k, nprobe in ((10, 16), (3, nlist), (12, 8)):
         p = _check(port, ix, g0, g1, xq, k, nprobe, metric, f"retry metric={metric} k={k} nprobe={nprobe}")

@@ -90,7 +90,8 @@ def test_canonical_mode_is_the_old_licensed_answer(torch_cuda, port, monkeypatch
     monkeypatch.delenv("KNHIP_TIES")
     assert g.profile_get()["tie_queries"] == 0
     assert_parity(Do, Io, D, I, metric, "canonical ties", licensed_ties=True)
-    assert (I != Io).any(), "this data has ambiguous boundaries: the canonical answer differs from the reference's somewhere"
+    if metric == ob.IP:  # (L2: canonical = ascending ids = storage order: the first arrivals ARE the canonical ties here)
+        assert (I != Io).any(), "ambiguous boundaries: the canonical answer differs from the reference's somewhere"
     # the canonical answer is the (distance, id) order: L2 smallest ids first, IP largest
     for q in range(len(xq)):
         tied = D[q] == D[q, -1]
