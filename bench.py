@@ -464,7 +464,8 @@ def make_roofline(a, kind, prof, world):
     stages = {n: round(prof["ms"][i] / a.steps, 3) for i, n in
               enumerate(["coarse", "group", "lut", "scan", "merge", "other", "scan_rank0"])}
     hbm_algo = scan_bytes / sec / 1e9 if sec > 0 else 0.0
-    common = {"algorithmic_bytes_per_launch": scan_bytes, "ms_per_launch": round(scan_ms, 3), "traffic": None,
+    common = {"tie_queries_per_step": round(prof.get("tie_queries", 0) / max(a.steps, 1), 2),
+              "algorithmic_bytes_per_launch": scan_bytes, "ms_per_launch": round(scan_ms, 3), "traffic": None,
               "hbm_algorithmic_GBps": round(hbm_algo, 1), "hbm_algorithmic_frac": round(hbm_algo / HBM_PEAK_GBPS, 4),
               "hbm_measured_frac": None, "stage_ms_per_step": stages}
 

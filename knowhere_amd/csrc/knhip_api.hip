@@ -270,6 +270,8 @@ struct knhip_index {
     DevBuf scan_bytes_dev; // double accumulator
     mutable double coarse_flops = 0;
     mutable int64_t tie_queries = 0;  // queries resolved by the reference's admission rule (search_batch_ties)
+    mutable DevBuf rg_seg_dev;        // range_segments(): the segment table of the current lists, built on first use
+    mutable int64_t rg_seg_nseg = -1, rg_seg_ncol = 0;
     mutable int64_t last_items_bound = 0;
 
     int64_t device_bytes() const {
@@ -493,6 +495,7 @@ int build_list_layout(knhip_index* idx, const std::vector<int64_t>& list_off, co
         idx->pqf_ready = false;
         idx->pqi_ready = false;
         idx->idmap_ready = false;
+        idx->rg_seg_nseg = -1;
         idx->idmap_ids.release();
         idx->idmap_col.release();
         idx->rows_i.release();
@@ -1783,6 +1786,7 @@ static int add_vectors_common(knhip_index* idx, int64_t n, const float* d_x, con
     idx->ntotal = n;
     idx->id_offset = id_offset;
     idx->has_data = n > 0;
+    idx->rg_seg_nseg = -1; // (the segment table of range_segments belongs to the old row count)
     return KNHIP_OK;
 }
 
@@ -2392,7 +2396,15 @@ static int range_batch(const knhip_index* idx, Workspace* ws, const float* d_q, 
 
 // segments of the distance matrix range_batch works on -> ws->rg_seg (3 x nseg: column of the first row, position of the
 // first id, length): the inverted lists, or 8192-row pieces of a brute-force base
-static int range_segments(const knhip_index* idx, Workspace* ws, hipStream_t s, int64_t* nseg_out, int64_t* ncol_out) {
+static int range_segments(const knhip_index* idx, hipStream_t s, const int64_t** d_seg_out, int64_t* nseg_out,
+                          int64_t* ncol_out) {
+    std::lock_guard<std::mutex> lk(idx->mu);
+    if (idx->rg_seg_nseg >= 0 && idx->rg_seg_dev.p != nullptr) { // (built once per list layout)
+        *d_seg_out = idx->rg_seg_dev.as<int64_t>();
+        *nseg_out = idx->rg_seg_nseg;
+        *ncol_out = idx->rg_seg_ncol;
+        return KNHIP_OK;
+    }
     const int kind = idx->desc.kind;
     std::vector<int64_t> seg;
     int64_t nseg = 0, ncol = 0;
@@ -2417,9 +2429,12 @@ static int range_segments(const knhip_index* idx, Workspace* ws, hipStream_t s, 
         }
         ncol = kind == KNHIP_IVF_FLAT ? blk * 64 : idx->ntotal;
     }
-    HIP_TRY(ws->rg_seg.reserve(seg.size() * sizeof(int64_t)));
-    HIP_TRY(hipMemcpyAsync(ws->rg_seg.p, seg.data(), seg.size() * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(idx->rg_seg_dev.reserve(std::max<size_t>(seg.size(), 1) * sizeof(int64_t)));
+    HIP_TRY(hipMemcpyAsync(idx->rg_seg_dev.p, seg.data(), seg.size() * sizeof(int64_t), hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s)); // (the host vector is released on return)
+    idx->rg_seg_nseg = nseg;
+    idx->rg_seg_ncol = ncol;
+    *d_seg_out = idx->rg_seg_dev.as<int64_t>();
     *nseg_out = nseg;
     *ncol_out = ncol;
     return KNHIP_OK;
@@ -2494,13 +2509,30 @@ static int search_batch_ties(const knhip_index* idx, Workspace* ws, const float*
                                (size_t)kk * sizeof(int64_t), hipMemcpyDeviceToHost, s));
     }
     int64_t nseg = 0, ncol = 0;
-    if (int rc = range_segments(idx, ws, s, &nseg, &ncol)) return rc; // (synchronises: the rows above have arrived)
+    const int64_t* d_seg = nullptr;
+    if (int rc = range_segments(idx, s, &d_seg, &nseg, &ncol)) return rc;
+    HIP_TRY(hipStreamSynchronize(s)); // (the rows above have arrived)
     const int np = kind == KNHIP_BRUTE_FORCE ? 0 : nprobe;
     // queries per round: the dump matrix [round][ncol] stays below 2 GiB
     int64_t qb = std::max<int64_t>(1, (int64_t)((2ull << 30) / ((size_t)std::max<int64_t>(ncol, 1) * 4)));
     qb = std::max<int64_t>(1, std::min<int64_t>(qb, (int64_t)0x7fffffff / std::max<int64_t>(nseg, 1)));
     std::vector<float> new_d((size_t)nflag * k);
     std::vector<int64_t> new_i((size_t)nflag * k);
+    // the assignment the search used for the flagged queries: the given one, or the one search_batch left in ws->keys /
+    // ws->cdis -- gathered for ALL of them before the first dump pass reuses those buffers (no second coarse stage)
+    const int64_t* src_keys = pre_keys != nullptr ? pre_keys : (kind != KNHIP_BRUTE_FORCE ? ws->keys.as<int64_t>() : nullptr);
+    const float* src_cdis = pre_cdis != nullptr ? pre_cdis : (kind != KNHIP_BRUTE_FORCE ? ws->cdis.as<float>() : nullptr);
+    const bool all_keys = src_keys != nullptr && src_cdis != nullptr;
+    if (all_keys) {
+        HIP_TRY(ws->tie_keys.reserve((size_t)nflag * nprobe * sizeof(int64_t)));
+        HIP_TRY(ws->tie_cdis.reserve((size_t)nflag * nprobe * sizeof(float)));
+        for (int32_t f = 0; f < nflag; f++) {
+            HIP_TRY(hipMemcpyAsync(ws->tie_keys.as<int64_t>() + (size_t)f * nprobe, src_keys + (size_t)fl[f] * nprobe,
+                                   (size_t)nprobe * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+            HIP_TRY(hipMemcpyAsync(ws->tie_cdis.as<float>() + (size_t)f * nprobe, src_cdis + (size_t)fl[f] * nprobe,
+                                   (size_t)nprobe * sizeof(float), hipMemcpyDeviceToDevice, s));
+        }
+    }
     for (int64_t f0 = 0; f0 < nflag; f0 += qb) {
         const int64_t n = std::min<int64_t>(qb, nflag - f0);
         HIP_TRY(ws->tie_q.reserve((size_t)n * idx->d * sizeof(float)));
@@ -2513,26 +2545,13 @@ static int search_batch_ties(const knhip_index* idx, Workspace* ws, const float*
             rad[(size_t)j] = cd[(size_t)(f0 + j) * kk + k - 1]; // v: the k-th distance
         }
         HIP_TRY(hipMemcpyAsync(ws->tie_r.p, rad.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice, s));
-        const int64_t* pk = nullptr;
-        const float* pc = nullptr;
-        if (pre_keys != nullptr) { // the given assignment of these queries
-            HIP_TRY(ws->tie_keys.reserve((size_t)n * nprobe * sizeof(int64_t)));
-            HIP_TRY(ws->tie_cdis.reserve((size_t)n * nprobe * sizeof(float)));
-            for (int64_t j = 0; j < n; j++) {
-                const int64_t q = fl[(size_t)(f0 + j)];
-                HIP_TRY(hipMemcpyAsync(ws->tie_keys.as<int64_t>() + j * nprobe, pre_keys + q * nprobe,
-                                       (size_t)nprobe * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
-                HIP_TRY(hipMemcpyAsync(ws->tie_cdis.as<float>() + j * nprobe, pre_cdis + q * nprobe,
-                                       (size_t)nprobe * sizeof(float), hipMemcpyDeviceToDevice, s));
-            }
-            pk = ws->tie_keys.as<int64_t>();
-            pc = ws->tie_cdis.as<float>();
-        }
+        const int64_t* pk = all_keys ? ws->tie_keys.as<int64_t>() + f0 * nprobe : nullptr;
+        const float* pc = all_keys ? ws->tie_cdis.as<float>() + f0 * nprobe : nullptr;
         HIP_TRY(hipStreamSynchronize(s)); // (rad is a host temporary)
         if (trace) fprintf(stderr, "[ties] round f0=%lld n=%lld ncol=%lld nseg=%lld np=%d\n", (long long)f0, (long long)n, (long long)ncol, (long long)nseg, np);
         std::vector<int64_t> lims((size_t)n + 1), hit_i;
         std::vector<float> hit_d;
-        if (int rc = range_batch(idx, ws, ws->tie_q.as<float>(), n, 0.f, 0, d_bitset, nbits, ws->rg_seg.as<int64_t>(), nseg, ncol,
+        if (int rc = range_batch(idx, ws, ws->tie_q.as<float>(), n, 0.f, 0, d_bitset, nbits, d_seg, nseg, ncol,
                                  lims.data(), hit_i, hit_d, s, ws->tie_r.as<float>(), np, pk, pc)) {
             return rc;
         }
@@ -2619,7 +2638,8 @@ int knhip_range_search(const knhip_index* idx, const float* queries, int64_t nq,
     std::vector<float> res_d;
     auto run = [&]() -> int {
         int64_t nseg = 0, ncol = 0;
-        if (int r = range_segments(idx, ws, s, &nseg, &ncol)) return r;
+        const int64_t* d_seg = nullptr;
+        if (int r = range_segments(idx, s, &d_seg, &nseg, &ncol)) return r;
         const size_t qbytes = (size_t)nq * idx->d * sizeof(float);
         HIP_TRY(ws->h_queries.reserve(qbytes));
         HIP_TRY(hipMemcpyAsync(ws->h_queries.p, queries, qbytes, hipMemcpyHostToDevice, s));
@@ -2638,7 +2658,7 @@ int knhip_range_search(const knhip_index* idx, const float* queries, int64_t nq,
         for (int64_t q0 = 0; q0 < nq; q0 += qb) {
             const int64_t n = std::min(qb, nq - q0);
             if (int r = range_batch(idx, ws, ws->h_queries.as<float>() + q0 * idx->d, n, radius, max_empty_result_buckets,
-                                    d_bitset, bitset_nbits, ws->rg_seg.as<int64_t>(), nseg, ncol, rel.data(), res_i,
+                                    d_bitset, bitset_nbits, d_seg, nseg, ncol, rel.data(), res_i,
                                     res_d, s)) {
                 return r;
             }
