@@ -560,12 +560,15 @@ def make_roofline(a, kind, prof, world):
         steps = max(a.steps, 1)
         extra = {"mfma": {"achieved_TFLOPs": round(tf, 2), "peak_TFLOPs": peak, "frac": round(mfma_frac, 4)},
                  "stream": {"bytes_per_launch": stream, "GBps": round(stream_gbps, 1),
+                            "hbm_frac_upper_bound": round(stream_gbps / HBM_PEAK_GBPS, 4),
                             "note": "bytes the units read (L2 + HBM); `traffic` is the part that came from HBM "
                                     "(FETCH_SIZE pass), null when no PMC pass of this workload is on file"},
                  "mscan": {"queries_per_step": prof["mscan_queries"] / steps,
                            "overflow_queries_per_step": prof["mscan_overflow_queries"] / steps,
                            "candidates_per_query": round(prof["mscan_candidates"] / max(prof["mscan_queries"], 1), 1)}}
-        if mfma_frac >= hbm_frac:
+        # without a PMC pass of this workload the HBM share is unknown (the bytes the units stream include every L2 hit): the
+        # matrix-core fraction is then the one number that is measured, and the stream rate is listed as an upper bound only
+        if mfma_frac >= hbm_frac or not traffic:
             return with_pmc(dict({"bound": "mfma", "kernel": kname, "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
                                   "frac": round(mfma_frac, 4), "note": unit_note}, **common, **extra))
         return with_pmc(dict({"bound": "hbm", "kernel": kname, "achieved": round(hbm_gbps, 1), "peak": HBM_PEAK_GBPS,

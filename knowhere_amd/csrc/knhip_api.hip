@@ -2715,6 +2715,7 @@ int knhip_coarse_search_device(const knhip_index* idx, const float* d_queries, i
     const int64_t qb = std::max<int64_t>(1, std::min<int64_t>(nq, (int64_t)((4.0 * 1024 * 1024 * 1024) / (idx->nlist * 4.0))));
     for (int64_t q0 = 0; q0 < nq; q0 += qb) {
         const int64_t n = std::min(qb, nq - q0);
+        StageTimer t(idx, s, KNHIP_STAGE_COARSE); // (a query-sharded coarse stage shows up in the rank's profile)
         if (int rc = coarse_stage(idx, ws, d_queries + q0 * idx->d, n, nprobe, d_out_keys + q0 * nprobe,
                                   d_out_dist + q0 * nprobe, s)) {
             return rc;
