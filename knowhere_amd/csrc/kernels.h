@@ -288,9 +288,10 @@ hipError_t launch_pqi_query_table(const float* queries, const float4* cb_m, int 
 // the sample pass of the IVF-PQ prefilter, one workgroup per query (no units, no work table): dump + n_row, the half
 // form's qs records, and (qis / qmu non-null) pass 1 of the integer form
 // (smin: rows the plan wants at least; scap <= 4096: rows it takes at most)
+// gthr_out / gmeta_out non-null: tau_q (the ksel-th best sampled value) and the histogram range are selected in the kernel
 hipError_t launch_pq_sample(const MScanArgs& a, const int64_t* keys, const float4* cb_m, int64_t nlist, int smin,
                             int scap, float pabs_max, bool is_l2, int32_t* n_row, float* qs, float* qis, float* qmu,
-                            hipStream_t s);
+                            hipStream_t s, float* gthr_out = nullptr, uint2* gmeta_out = nullptr, int ksel = 0);
 hipError_t launch_pqi(const MScanArgs& a, bool is_l2, int64_t units_bound, hipStream_t s);
 
 bool pqf_supports(int M, int d);

@@ -1051,7 +1051,8 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
                 HIP_TRY(launch_pq_sample(ds, keys_p, idx->cb.as<float4>(), nlist, std::max(1024, 8 * k), scap,
                                          idx->pabs_max, is_l2, ws->ms_nrow.as<int32_t>(), ws->ms_qs.as<float>(),
                                          want_i8 ? ws->ms_qis.as<float>() : nullptr,
-                                         want_i8 ? ws->ms_qmu.as<float>() : nullptr, s));
+                                         want_i8 ? ws->ms_qmu.as<float>() : nullptr, s, ws->gthr.as<float>(),
+                                         ws->gmeta.as<uint2>(), k)); // (tau_q and the histogram range come out of it too)
             } else {
                 HIP_TRY(launch_ms_units(wt.list_count, wt.list_pair_off, nlist, qt0, ws->ms_unit_off.as<int64_t>(),
                                         ws->ms_nunits.as<int64_t>(), ws->ms_units.as<KnItem>(),
@@ -1059,10 +1060,12 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
                 ds.sample_off = ws->ms_sample_off.as<int32_t>();
                 HIP_TRY(launch_filter(ds, bound0));
             }
-            HIP_TRY(launch_row_select_var(ws->dump.as<float>(), sample, keys_p, nprobe, idx->d_list_len.as<int64_t>(),
-                                          nq, k, is_l2, ws->sel_keys.as<int64_t>(), ws->sel_d.as<float>(), s, sample,
-                                          ws->ms_nrow.as<int32_t>()));
-            HIP_TRY(launch_ms_tau(ws->sel_d.as<float>(), nq, k, is_l2, ws->gthr.as<float>(), ws->gmeta.as<uint2>(), s));
+            if (kind != KNHIP_IVF_PQ) {
+                HIP_TRY(launch_row_select_var(ws->dump.as<float>(), sample, keys_p, nprobe, idx->d_list_len.as<int64_t>(),
+                                              nq, k, is_l2, ws->sel_keys.as<int64_t>(), ws->sel_d.as<float>(), s, sample,
+                                              ws->ms_nrow.as<int32_t>()));
+                HIP_TRY(launch_ms_tau(ws->sel_d.as<float>(), nq, k, is_l2, ws->gthr.as<float>(), ws->gmeta.as<uint2>(), s));
+            }
             if (kind == KNHIP_IVF_PQ) {
                 // The integer form of the filter (int8 tables, 16 queries per unit: twice the lookups per step) has an eps
                 // 8 .. 20 x that of the half-precision form.  Selectivity guard (pq_filter.hip): the sample dump predicts

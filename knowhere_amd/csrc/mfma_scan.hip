@@ -54,7 +54,7 @@ constexpr int MS_WAVES = 4;
 constexpr int MS_THREADS = MS_WAVES * KN_WAVE;
 constexpr int MS_NQT = 2;          // query tiles of 32 per unit (fp32 rows)
 constexpr int MS_QT = 32 * MS_NQT; // queries per unit
-constexpr int MS_SAMPLE = 4096;    // rows that feed tau_q, at most (a multiple of 64, <= row_select's limit)
+constexpr int MS_SAMPLE = 8192;    // rows that feed tau_q, at most (a multiple of 64, <= row_select's limit)
 
 // ---- ||x||^2 per stored row position (padded block layout), and the maximum ----------------------------------
 __global__ void ms_block_norms_kernel(const float4* __restrict__ rows, int64_t total_blk, int nchunk,

@@ -58,7 +58,7 @@ constexpr int PF_LUT_BYTES = PF_KSUB * PF_M * PF_Q * 2; // 131072
 // behind the LUT (ints): [0], [1] unit index of mailbox slot 0 / 1, [8 + 32 s ..) the record of slot s (the current unit
 // and the one after it), [128 + 4 j ..) per-pair constants of the current unit
 constexpr int PF_CTL_BYTES = 1536; // (the integer form keeps its per-pair constants per unit parity: pqi_kernel)
-constexpr int PF_SAMPLE = 4096; // = MS_SAMPLE (mfma_scan.hip): dump columns per query
+constexpr int PF_SAMPLE = 8192; // = MS_SAMPLE (mfma_scan.hip): dump columns per query
 // Candidate staging behind the control block: a hit costs an LDS atomic and one 16-byte LDS store inside the scan loop;
 // the global side of ms_emit (bitset test, atomic on the query's counter with its returned slot, candidate store,
 // histogram) waited 1 .. 2 us per hit in the loop -- with ~10^7 hits per batch a fifth of the kernel (round-3 experiment:
@@ -1166,7 +1166,9 @@ __global__ __launch_bounds__(PF_KSUB, 4) void pq_sample_kernel(MScanArgs a, cons
                                                             const float4* __restrict__ cb_m, int64_t nlist, int smin,
                                                             int scap, float pabs_max, int32_t* __restrict__ n_row,
                                                             float* __restrict__ qs, float* __restrict__ qis,
-                                                            float* __restrict__ qmu, uint32_t* __restrict__ gl) {
+                                                            float* __restrict__ qmu, uint32_t* __restrict__ gl,
+                                                            float* __restrict__ gthr_out, uint2* __restrict__ gmeta_out,
+                                                            int ksel) {
     __shared__ float lut[PF_M * PF_KSUB]; // [m][c]
     __shared__ float sq[PF_M * PF_DSUB];
     __shared__ float smax[PF_M][PF_KSUB / KN_WAVE];
@@ -1305,12 +1307,89 @@ __global__ __launch_bounds__(PF_KSUB, 4) void pq_sample_kernel(MScanArgs a, cons
     if (c == 0) {
         n_row[q] = cum;
     }
+    if (gthr_out == nullptr) {
+        return;
+    }
+    // ---- tau_q = the ksel-th best dump value, and the candidate histogram's range [best, tau] (what a radix select of the
+    // dump + ms_tau_kernel produced in round 3: 0.3 ms per batch for a value this workgroup has at hand).  The values are
+    // read back into registers (this workgroup wrote them: L1 / L2 hits) as order-preserving integer keys; the ksel-th
+    // smallest key comes from a bisection with one counter and one barrier per step.
+    __syncthreads();
+    constexpr int PER = PF_SAMPLE / PF_KSUB;
+    uint32_t key[PER];
+    uint32_t mn = 0xffffffffu;
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const int i = c + u * PF_KSUB;
+        key[u] = i < cum ? dist_key<IS_L2>(a.dump[q * a.dump_stride + i]) : 0xffffffffu;
+        mn = min(mn, key[u]);
+    }
+    __shared__ int s_step[32];
+    __shared__ uint32_t s_mn[PF_KSUB / KN_WAVE];
+#pragma unroll
+    for (int dlt = KN_WAVE / 2; dlt > 0; dlt >>= 1) {
+        mn = min(mn, (uint32_t)__shfl_xor((int)mn, dlt, KN_WAVE));
+    }
+    if (lane_id() == 0) {
+        s_mn[wave] = mn;
+    }
+    if (c < 32) {
+        s_step[c] = 0;
+    }
+    __syncthreads();
+    uint32_t lo = 0u, hi = 0xffffffffu;
+    for (int it = 0; it < 32; it++) { // (exactly 32 steps for every thread: the interval halves each time)
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        int cnt = 0;
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            cnt += key[u] <= mid ? 1 : 0;
+        }
+#pragma unroll
+        for (int dlt = KN_WAVE / 2; dlt > 0; dlt >>= 1) {
+            cnt += __shfl_xor(cnt, dlt, KN_WAVE);
+        }
+        if (lane_id() == 0 && cnt) {
+            atomicAdd(&s_step[it], cnt);
+        }
+        __syncthreads();
+        const int tot = s_step[it];
+        if (lo < hi) {
+            if (tot >= ksel) {
+                hi = mid;
+            } else {
+                lo = mid + 1;
+            }
+        }
+    }
+    if (c == 0) {
+        // fewer than ksel sampled rows (padding keys counted): no bound, exactly as a selection of ksel values would say
+        const float kth = cum >= ksel ? dist_key_inv<IS_L2>(lo) : worst_dist<IS_L2>();
+        gthr_out[q] = kth;
+        if (gmeta_out != nullptr) {
+            uint32_t best = s_mn[0];
+            for (int w = 1; w < PF_KSUB / KN_WAVE; w++) {
+                best = min(best, s_mn[w]);
+            }
+            uint32_t glo = 0, shift = KN_HIST_OFF;
+            if (kth != worst_dist<IS_L2>() && kth == kth) { // (ms_tau_kernel's rule)
+                glo = best;
+                const uint32_t range = dist_key<IS_L2>(kth) - glo;
+                shift = 0;
+                while ((range >> shift) >= (uint32_t)(KN_HIST_BINS - 1)) {
+                    shift++;
+                }
+            }
+            gmeta_out[q] = make_uint2(glo, shift);
+        }
+    }
 }
 
 // qis / qmu null: the integer form is off (no pass-1 record).  With qis: its batch record qis[nq * 4 ..) is reset here.
+// gthr_out (+ gmeta_out) non-null: the kernel also selects tau_q = the ksel-th best sampled value itself.
 hipError_t launch_pq_sample(const MScanArgs& a, const int64_t* keys, const float4* cb_m, int64_t nlist, int smin,
                             int scap, float pabs_max, bool is_l2, int32_t* n_row, float* qs, float* qis, float* qmu,
-                            hipStream_t s) {
+                            hipStream_t s, float* gthr_out, uint2* gmeta_out, int ksel) {
     if (a.nq <= 0) {
         return hipSuccess;
     }
@@ -1327,10 +1406,10 @@ hipError_t launch_pq_sample(const MScanArgs& a, const int64_t* keys, const float
     }
     if (is_l2) {
         hipLaunchKernelGGL(pq_sample_kernel<true>, dim3((unsigned)a.nq), dim3(PF_KSUB), 0, s, a, keys, cb_m, nlist, smin,
-                           scap, pabs_max, n_row, qs, qis, qmu, gl);
+                           scap, pabs_max, n_row, qs, qis, qmu, gl, gthr_out, gmeta_out, ksel);
     } else {
         hipLaunchKernelGGL(pq_sample_kernel<false>, dim3((unsigned)a.nq), dim3(PF_KSUB), 0, s, a, keys, cb_m, nlist, smin,
-                           scap, pabs_max, n_row, qs, qis, qmu, gl);
+                           scap, pabs_max, n_row, qs, qis, qmu, gl, gthr_out, gmeta_out, ksel);
     }
     return hipGetLastError();
 }
