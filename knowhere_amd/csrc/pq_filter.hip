@@ -1317,49 +1317,72 @@ __global__ __launch_bounds__(PF_KSUB, 4) void pq_sample_kernel(MScanArgs a, cons
     __syncthreads();
     constexpr int PER = PF_SAMPLE / PF_KSUB;
     uint32_t key[PER];
-    uint32_t mn = 0xffffffffu;
+    uint32_t mn = 0xffffffffu, mx = 0u;
 #pragma unroll
     for (int u = 0; u < PER; u++) {
         const int i = c + u * PF_KSUB;
         key[u] = i < cum ? dist_key<IS_L2>(a.dump[q * a.dump_stride + i]) : 0xffffffffu;
         mn = min(mn, key[u]);
+        mx = i < cum ? max(mx, key[u]) : mx;
     }
-    __shared__ int s_step[32];
-    __shared__ uint32_t s_mn[PF_KSUB / KN_WAVE];
+    constexpr int NSTEP = 18; // 2 bits of the interval per step (16 cover the key space; two spare for the rounding of the cuts)
+    __shared__ int s_step[NSTEP][3];
+    __shared__ uint32_t s_mn[PF_KSUB / KN_WAVE], s_mx[PF_KSUB / KN_WAVE];
 #pragma unroll
     for (int dlt = KN_WAVE / 2; dlt > 0; dlt >>= 1) {
         mn = min(mn, (uint32_t)__shfl_xor((int)mn, dlt, KN_WAVE));
+        mx = max(mx, (uint32_t)__shfl_xor((int)mx, dlt, KN_WAVE));
     }
     if (lane_id() == 0) {
         s_mn[wave] = mn;
+        s_mx[wave] = mx;
     }
-    if (c < 32) {
-        s_step[c] = 0;
+    if (c < NSTEP * 3) {
+        (&s_step[0][0])[c] = 0;
     }
     __syncthreads();
-    uint32_t lo = 0u, hi = 0xffffffffu;
-    for (int it = 0; it < 32; it++) { // (exactly 32 steps for every thread: the interval halves each time)
-        const uint32_t mid = lo + ((hi - lo) >> 1);
-        int cnt = 0;
+    uint32_t lo = s_mn[0], hi = s_mx[0];
+    for (int w = 1; w < PF_KSUB / KN_WAVE; w++) {
+        lo = min(lo, s_mn[w]);
+        hi = max(hi, s_mx[w]);
+    }
+    const uint32_t best = lo;
+    // the ksel-th smallest key lies in [lo, hi] (when cum >= ksel): the interval is cut in four per step -- three counters,
+    // one barrier -- until it is a point; the number of steps depends on the spread of the sample only (distances of one
+    // sample share their exponent: ~12 steps, against 32 for a bisection of the whole key space)
+    for (int it = 0; it < NSTEP && lo < hi; it++) { // (lo, hi are the same in every thread: uniform trip count)
+        const uint32_t span = hi - lo;
+        const uint32_t q1 = lo + (span >> 2), q2 = lo + (span >> 1), q3 = lo + (span >> 2) + (span >> 1); // lo <= q1 <= q2 <= q3 < hi
+        int c1 = 0, c2 = 0, c3 = 0;
 #pragma unroll
         for (int u = 0; u < PER; u++) {
-            cnt += key[u] <= mid ? 1 : 0;
+            c1 += key[u] <= q1 ? 1 : 0;
+            c2 += key[u] <= q2 ? 1 : 0;
+            c3 += key[u] <= q3 ? 1 : 0;
         }
 #pragma unroll
         for (int dlt = KN_WAVE / 2; dlt > 0; dlt >>= 1) {
-            cnt += __shfl_xor(cnt, dlt, KN_WAVE);
+            c1 += __shfl_xor(c1, dlt, KN_WAVE);
+            c2 += __shfl_xor(c2, dlt, KN_WAVE);
+            c3 += __shfl_xor(c3, dlt, KN_WAVE);
         }
-        if (lane_id() == 0 && cnt) {
-            atomicAdd(&s_step[it], cnt);
+        if (lane_id() == 0) {
+            if (c1) atomicAdd(&s_step[it][0], c1);
+            if (c2) atomicAdd(&s_step[it][1], c2);
+            if (c3) atomicAdd(&s_step[it][2], c3);
         }
         __syncthreads();
-        const int tot = s_step[it];
-        if (lo < hi) {
-            if (tot >= ksel) {
-                hi = mid;
-            } else {
-                lo = mid + 1;
-            }
+        const int t1 = s_step[it][0], t2 = s_step[it][1], t3 = s_step[it][2];
+        if (t1 >= ksel) {
+            hi = q1;
+        } else if (t2 >= ksel) {
+            lo = q1 + 1;
+            hi = q2;
+        } else if (t3 >= ksel) {
+            lo = q2 + 1;
+            hi = q3;
+        } else {
+            lo = q3 + 1;
         }
     }
     if (c == 0) {
@@ -1367,10 +1390,6 @@ __global__ __launch_bounds__(PF_KSUB, 4) void pq_sample_kernel(MScanArgs a, cons
         const float kth = cum >= ksel ? dist_key_inv<IS_L2>(lo) : worst_dist<IS_L2>();
         gthr_out[q] = kth;
         if (gmeta_out != nullptr) {
-            uint32_t best = s_mn[0];
-            for (int w = 1; w < PF_KSUB / KN_WAVE; w++) {
-                best = min(best, s_mn[w]);
-            }
             uint32_t glo = 0, shift = KN_HIST_OFF;
             if (kth != worst_dist<IS_L2>() && kth == kth) { // (ms_tau_kernel's rule)
                 glo = best;

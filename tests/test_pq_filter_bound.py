@@ -458,3 +458,48 @@ def test_finish_prune_bound_dominates_every_emission(is_l2, form, mode):
     eps_old = f32(eps_base + f32(64.0) * f32(5.9604645e-8) * f32(cmax + f32(abs(gthr))))
     if form == "int8" and abs(float(musum)) > 0:
         assert (eps_all > eps_old).any()
+
+
+def test_sample_kernel_selection_finds_the_kth_smallest_key():
+    """pq_sample_kernel selects tau_q itself: the ksel-th smallest of the dumped values as order-preserving integer keys, by
+    cutting the interval [min, max] in four per step (three counters, one barrier).  The cut arithmetic replayed on integer
+    sets with heavy ties, tiny and full-width spreads: the result is the ksel-th order statistic and the interval closes
+    within the kernel's 18 steps."""
+    rng = np.random.default_rng(77)
+    worst_steps = 0
+    for trial in range(3000):
+        n = int(rng.integers(1, 400))
+        kind = trial % 5
+        if kind == 0:
+            keys = rng.integers(0, 2 ** 32, n, dtype=np.uint64)
+        elif kind == 1:
+            keys = (np.uint64(0x42000000) + rng.integers(0, 2 ** 22, n, dtype=np.uint64))   # one exponent
+        elif kind == 2:
+            keys = (np.uint64(7) + rng.integers(0, 3, n, dtype=np.uint64))                 # ties everywhere
+        elif kind == 3:
+            keys = np.full(n, np.uint64(0xfffffffe))
+        else:
+            keys = np.concatenate([[0, 0xffffffff], rng.integers(0, 2 ** 32, max(n - 2, 0), dtype=np.uint64)]).astype(np.uint64)
+        keys = keys.astype(np.uint64)
+        n = len(keys)
+        k = int(rng.integers(1, n + 1))
+        lo, hi = int(keys.min()), int(keys.max())
+        steps = 0
+        while lo < hi:
+            span = hi - lo
+            q1, q2, q3 = lo + (span >> 2), lo + (span >> 1), lo + (span >> 2) + (span >> 1)
+            assert lo <= q1 <= q2 <= q3 < hi
+            t1, t2, t3 = int((keys <= q1).sum()), int((keys <= q2).sum()), int((keys <= q3).sum())
+            if t1 >= k:
+                hi = q1
+            elif t2 >= k:
+                lo, hi = q1 + 1, q2
+            elif t3 >= k:
+                lo, hi = q2 + 1, q3
+            else:
+                lo = q3 + 1
+            steps += 1
+            assert steps <= 18
+        worst_steps = max(worst_steps, steps)
+        assert lo == int(np.sort(keys)[k - 1]), (trial, k)
+    assert worst_steps >= 14  # (the full-width cases really need most of the steps)
