@@ -417,6 +417,12 @@ struct RangeArgs {
 // query whose (k + 1)-th entry exists with the k-th distance is appended to flagged[] (count in *nflag)
 hipError_t launch_tie_detect(const float* d, const int64_t* i, int64_t nq, int k, float* out_d, int64_t* out_i,
                              int32_t* flagged, int32_t* nflag, hipStream_t s);
+// ... and the resolve itself: the flagged queries' rows gathered, then (after the dump pass over their probed lists) the
+// reference's rule applied per query, the result written over its row of (out_d, out_i) -- no host round trip
+hipError_t launch_tie_gather(const int32_t* flagged, int nflag, const float* q, int d, const int64_t* keys, const float* cdis,
+                             int nprobe, float* q_out, int64_t* keys_out, float* cdis_out, hipStream_t s);
+hipError_t launch_tie_apply(const RangeArgs& a, const int32_t* flagged, int nflag, const float* can_d, const int64_t* can_i,
+                            int k, bool is_l2, float* out_d, int64_t* out_i, hipStream_t s);
 // every exact ADC distance of every probed list of an IVF-PQ index with any M x 8 bit codes (range.hip)
 struct PqDumpArgs {
     float* dist;                 // [nq][ncol], column = list_row_off[list] + position

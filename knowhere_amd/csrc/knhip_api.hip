@@ -2148,7 +2148,8 @@ static int range_batch(const knhip_index* idx, Workspace* ws, const float* d_q, 
                        int max_empty, const uint8_t* d_bitset, int64_t nbits, const int64_t* d_seg /*3 x nseg*/,
                        int64_t nseg, int64_t ncol, int64_t* h_lims /*nq + 1, relative*/, std::vector<int64_t>& out_i,
                        std::vector<float>& out_d, hipStream_t s, const float* d_radius_q = nullptr,
-                       int nprobe_limit = 0, const int64_t* pre_keys = nullptr, const float* pre_cdis = nullptr) {
+                       int nprobe_limit = 0, const int64_t* pre_keys = nullptr, const float* pre_cdis = nullptr,
+                       RangeArgs* dump_only_out = nullptr) {
     const int kind = idx->desc.kind;
     const bool is_l2 = idx->is_l2;
     const int d = idx->d;
@@ -2362,6 +2363,10 @@ static int range_batch(const knhip_index* idx, Workspace* ws, const float* d_q, 
             counted = true;
         }
     }
+    if (dump_only_out != nullptr) { // (the caller walks the dump itself: search_batch_ties)
+        *dump_only_out = r;
+        return KNHIP_OK;
+    }
     // count -> plan -> (host: totals, bases) -> emit
     HIP_TRY(ws->rg_off.reserve((size_t)nq * nprobe * sizeof(int64_t)));
     HIP_TRY(ws->rg_tot.reserve((size_t)nq * 2 * sizeof(int64_t)));
@@ -2454,9 +2459,11 @@ static int range_segments(const knhip_index* idx, hipStream_t s, const int64_t**
 //     result = canonical top-k of {every candidate better than v} U {eligible ties}.
 // The canonical pipeline already has v and every better candidate; it is run for k + 1 results, and only a query whose
 // (k + 1)-th entry ties with its k-th (a tied candidate was left out) needs the arrival order: its probed lists are
-// scanned once more in dump mode (range_batch with the query's own radius v, inclusive), which emits the hits in
-// scan order; the first k of them decide.  One 4-byte read-back per batch tells whether any query is flagged
-// (KNHIP_TIES=canonical: no read-back, the canonical answer -- the licensed deviation of include/knhip.h).
+// scanned once more in dump mode (the dump pass of range_batch over the search's own coarse assignment), one workgroup
+// per query walks the dump in scan order, keeps the ties among the first k arrivals and writes the rule's answer over
+// the query's row (range.hip::tie_apply_kernel) -- all on the device.  The host reads ONE 4-byte count per batch (how
+// many queries are flagged: it sizes the dump) -- KNHIP_TIES=canonical skips even that and returns the canonical answer
+// (the licensed deviation of include/knhip.h).
 // Not covered: k = 1024 (no room for the (k + 1)-th result), brute force with k >= 100 (the reference switches to a
 // reservoir, ResultHandler.h:719-728, whose boundary ties depend on its partition steps), lists sharded over several
 // indexes (every shard resolves its own candidates; the merge is canonical).
@@ -2496,112 +2503,42 @@ static int search_batch_ties(const knhip_index* idx, Workspace* ws, const float*
     if (nflag <= 0) {
         return KNHIP_OK;
     }
-    // ---- flagged queries: canonical rows to the host, arrivals with distance <= v in scan order from a dump pass --------
-    std::vector<int32_t> fl((size_t)nflag);
-    // (never the null stream: a legacy-default-stream copy waits for every blocking stream of the process, other shards'
-    // included -- three shards on one device deadlocked on it)
-    HIP_TRY(hipMemcpyAsync(fl.data(), flagged, (size_t)nflag * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    std::sort(fl.begin(), fl.end()); // (the detect kernel appends in any order)
-    std::vector<float> cd((size_t)nflag * kk);
-    std::vector<int64_t> ci((size_t)nflag * kk);
-    for (int32_t f = 0; f < nflag; f++) {
-        HIP_TRY(hipMemcpyAsync(cd.data() + (size_t)f * kk, ws->tie_d.as<float>() + (size_t)fl[f] * kk, (size_t)kk * sizeof(float),
-                               hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(ci.data() + (size_t)f * kk, ws->tie_i.as<int64_t>() + (size_t)fl[f] * kk,
-                               (size_t)kk * sizeof(int64_t), hipMemcpyDeviceToHost, s));
-    }
+    // ---- flagged queries, on the device: their rows gathered (queries + the coarse assignment the search used -- the given
+    // one, or the one search_batch left in ws->keys / ws->cdis -- before the dump pass reuses those buffers), every distance
+    // of their probed lists dumped by the range-search pass, then one workgroup per query walks the dump in scan order and
+    // writes the reference's answer over the query's row of the output.  Nothing comes back to the host.
     int64_t nseg = 0, ncol = 0;
     const int64_t* d_seg = nullptr;
     if (int rc = range_segments(idx, s, &d_seg, &nseg, &ncol)) return rc;
-    HIP_TRY(hipStreamSynchronize(s)); // (the rows above have arrived)
     const int np = kind == KNHIP_BRUTE_FORCE ? 0 : nprobe;
+    const int64_t* src_keys = pre_keys != nullptr ? pre_keys : (kind != KNHIP_BRUTE_FORCE ? ws->keys.as<int64_t>() : nullptr);
+    const float* src_cdis = pre_cdis != nullptr ? pre_cdis : (kind != KNHIP_BRUTE_FORCE ? ws->cdis.as<float>() : nullptr);
+    HIP_TRY(ws->tie_q.reserve((size_t)nflag * idx->d * sizeof(float)));
+    if (src_keys != nullptr) {
+        HIP_TRY(ws->tie_keys.reserve((size_t)nflag * nprobe * sizeof(int64_t)));
+        HIP_TRY(ws->tie_cdis.reserve((size_t)nflag * nprobe * sizeof(float)));
+    }
+    HIP_TRY(launch_tie_gather(flagged, nflag, d_q, idx->d, src_keys, src_cdis, nprobe, ws->tie_q.as<float>(),
+                              ws->tie_keys.as<int64_t>(), ws->tie_cdis.as<float>(), s));
     // queries per round: the dump matrix [round][ncol] stays below 2 GiB
     int64_t qb = std::max<int64_t>(1, (int64_t)((2ull << 30) / ((size_t)std::max<int64_t>(ncol, 1) * 4)));
     qb = std::max<int64_t>(1, std::min<int64_t>(qb, (int64_t)0x7fffffff / std::max<int64_t>(nseg, 1)));
-    std::vector<float> new_d((size_t)nflag * k);
-    std::vector<int64_t> new_i((size_t)nflag * k);
-    // the assignment the search used for the flagged queries: the given one, or the one search_batch left in ws->keys /
-    // ws->cdis -- gathered for ALL of them before the first dump pass reuses those buffers (no second coarse stage)
-    const int64_t* src_keys = pre_keys != nullptr ? pre_keys : (kind != KNHIP_BRUTE_FORCE ? ws->keys.as<int64_t>() : nullptr);
-    const float* src_cdis = pre_cdis != nullptr ? pre_cdis : (kind != KNHIP_BRUTE_FORCE ? ws->cdis.as<float>() : nullptr);
-    const bool all_keys = src_keys != nullptr && src_cdis != nullptr;
-    if (all_keys) {
-        HIP_TRY(ws->tie_keys.reserve((size_t)nflag * nprobe * sizeof(int64_t)));
-        HIP_TRY(ws->tie_cdis.reserve((size_t)nflag * nprobe * sizeof(float)));
-        for (int32_t f = 0; f < nflag; f++) {
-            HIP_TRY(hipMemcpyAsync(ws->tie_keys.as<int64_t>() + (size_t)f * nprobe, src_keys + (size_t)fl[f] * nprobe,
-                                   (size_t)nprobe * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
-            HIP_TRY(hipMemcpyAsync(ws->tie_cdis.as<float>() + (size_t)f * nprobe, src_cdis + (size_t)fl[f] * nprobe,
-                                   (size_t)nprobe * sizeof(float), hipMemcpyDeviceToDevice, s));
-        }
-    }
     for (int64_t f0 = 0; f0 < nflag; f0 += qb) {
         const int64_t n = std::min<int64_t>(qb, nflag - f0);
-        HIP_TRY(ws->tie_q.reserve((size_t)n * idx->d * sizeof(float)));
-        HIP_TRY(ws->tie_r.reserve((size_t)n * sizeof(float)));
-        std::vector<float> rad((size_t)n);
-        for (int64_t j = 0; j < n; j++) {
-            const int64_t q = fl[(size_t)(f0 + j)];
-            HIP_TRY(hipMemcpyAsync(ws->tie_q.as<float>() + j * idx->d, d_q + q * idx->d, (size_t)idx->d * sizeof(float),
-                                   hipMemcpyDeviceToDevice, s));
-            rad[(size_t)j] = cd[(size_t)(f0 + j) * kk + k - 1]; // v: the k-th distance
-        }
-        HIP_TRY(hipMemcpyAsync(ws->tie_r.p, rad.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice, s));
-        const int64_t* pk = all_keys ? ws->tie_keys.as<int64_t>() + f0 * nprobe : nullptr;
-        const float* pc = all_keys ? ws->tie_cdis.as<float>() + f0 * nprobe : nullptr;
-        HIP_TRY(hipStreamSynchronize(s)); // (rad is a host temporary)
         if (trace) fprintf(stderr, "[ties] round f0=%lld n=%lld ncol=%lld nseg=%lld np=%d\n", (long long)f0, (long long)n, (long long)ncol, (long long)nseg, np);
-        std::vector<int64_t> lims((size_t)n + 1), hit_i;
-        std::vector<float> hit_d;
-        if (int rc = range_batch(idx, ws, ws->tie_q.as<float>(), n, 0.f, 0, d_bitset, nbits, d_seg, nseg, ncol,
-                                 lims.data(), hit_i, hit_d, s, ws->tie_r.as<float>(), np, pk, pc)) {
+        std::vector<int64_t> lims_unused((size_t)n + 1), hi_unused;
+        std::vector<float> hd_unused;
+        RangeArgs r{};
+        if (int rc = range_batch(idx, ws, ws->tie_q.as<float>() + f0 * idx->d, n, 0.f, 0, d_bitset, nbits, d_seg, nseg, ncol,
+                                 lims_unused.data(), hi_unused, hd_unused, s, nullptr, np,
+                                 src_keys ? ws->tie_keys.as<int64_t>() + f0 * nprobe : nullptr,
+                                 src_keys ? ws->tie_cdis.as<float>() + f0 * nprobe : nullptr, &r)) {
             return rc;
         }
-        if (trace) fprintf(stderr, "[ties] dumped: %lld hits\n", (long long)hit_i.size());
-        for (int64_t j = 0; j < n; j++) {
-            const size_t f = (size_t)(f0 + j);
-            const float v = cd[f * kk + k - 1];
-            // every candidate better than v is in the canonical row; a tie is eligible iff it is among the first k arrivals
-            std::vector<std::pair<float, int64_t>> pool;
-            for (int e = 0; e < k; e++) {
-                if (ci[f * kk + e] >= 0 && cd[f * kk + e] != v) {
-                    pool.emplace_back(cd[f * kk + e], ci[f * kk + e]);
-                }
-            }
-            const int64_t a0 = lims[(size_t)j], a1 = lims[(size_t)j + 1];
-            for (int64_t a = a0; a < a1 && a < a0 + k; a++) {
-                if (hit_d[(size_t)a] == v) {
-                    pool.emplace_back(v, hit_i[(size_t)a]);
-                }
-            }
-            std::sort(pool.begin(), pool.end(), [&](const std::pair<float, int64_t>& x, const std::pair<float, int64_t>& y) {
-                if (x.first != y.first) return is_l2 ? x.first < y.first : x.first > y.first;
-                return is_l2 ? x.second < y.second : x.second > y.second;
-            });
-            if ((int64_t)pool.size() < k) {
-                // (cannot happen: the first k arrivals and the better candidates together hold at least k entries; keep the
-                // canonical row rather than invent one)
-                for (int e = 0; e < k; e++) {
-                    new_d[f * k + e] = cd[f * kk + e];
-                    new_i[f * k + e] = ci[f * kk + e];
-                }
-                continue;
-            }
-            for (int e = 0; e < k; e++) {
-                new_d[f * k + e] = pool[(size_t)e].first;
-                new_i[f * k + e] = pool[(size_t)e].second;
-            }
-        }
+        HIP_TRY(launch_tie_apply(r, flagged + f0, (int)n, ws->tie_d.as<float>(), ws->tie_i.as<int64_t>(), k, is_l2, d_out_d,
+                                 d_out_i, s));
     }
-    for (int32_t f = 0; f < nflag; f++) {
-        HIP_TRY(hipMemcpyAsync(d_out_d + (size_t)fl[f] * k, new_d.data() + (size_t)f * k, (size_t)k * sizeof(float),
-                               hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(d_out_i + (size_t)fl[f] * k, new_i.data() + (size_t)f * k, (size_t)k * sizeof(int64_t),
-                               hipMemcpyHostToDevice, s));
-    }
-    HIP_TRY(hipStreamSynchronize(s));
-    if (trace) fprintf(stderr, "[ties] patched\n");
+    if (trace) fprintf(stderr, "[ties] applied\n");
     {
         std::lock_guard<std::mutex> lk(idx->mu);
         idx->tie_queries += nflag;

@@ -438,6 +438,159 @@ hipError_t launch_tie_detect(const float* d, const int64_t* i, int64_t nq, int k
     return hipGetLastError();
 }
 
+// ---- k-th-boundary ties, resolved on the device (knhip_api.hip, search_batch_ties) -----------------------------------------
+// gather the flagged queries (rows of the batch's queries, coarse keys and coarse distances) into dense arrays
+__global__ void tie_gather_kernel(const int32_t* __restrict__ flagged, int nflag, const float* __restrict__ q, int d,
+                                  const int64_t* __restrict__ keys, const float* __restrict__ cdis, int nprobe,
+                                  float* __restrict__ q_out, int64_t* __restrict__ keys_out, float* __restrict__ cdis_out) {
+    const int f = blockIdx.x;
+    if (f >= nflag) {
+        return;
+    }
+    const int64_t src = flagged[f];
+    for (int i = threadIdx.x; i < d; i += blockDim.x) {
+        q_out[(int64_t)f * d + i] = q[src * d + i];
+    }
+    if (keys != nullptr) {
+        for (int i = threadIdx.x; i < nprobe; i += blockDim.x) {
+            keys_out[(int64_t)f * nprobe + i] = keys[src * nprobe + i];
+            cdis_out[(int64_t)f * nprobe + i] = cdis[src * nprobe + i];
+        }
+    }
+}
+
+// One workgroup per flagged query.  a.dist holds every distance of its probed lists (dump pass), a.order its lists in
+// coarse order.  Phase 1 walks them in the reference's SCAN order (rank, then storage position) and keeps the first k
+// arrivals with distance <= v (>= v for IP) that the bitset lets through -- v = the canonical k-th distance.  Phase 2: the
+// result = canonical top-k of {canonical entries better than v} U {ties among those first k arrivals} (the closed form of
+// the reference's heap, tests/test_tie_rule.py), written over the query's row of the output.
+template <bool IS_L2>
+__global__ __launch_bounds__(RG_THREADS) void tie_apply_kernel(RangeArgs a, const int32_t* __restrict__ flagged,
+                                                               const float* __restrict__ can_d,
+                                                               const int64_t* __restrict__ can_i, int k,
+                                                               float* __restrict__ out_d, int64_t* __restrict__ out_i) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    float* pool_d = reinterpret_cast<float*>(smem);                         // [2 k]
+    int64_t* pool_i = reinterpret_cast<int64_t*>(smem + (size_t)2 * k * 4); // [2 k] (2 k * 4 is a multiple of 8)
+    __shared__ int s_wave[RG_THREADS / KN_WAVE];
+    __shared__ int s_n;
+    const int64_t f = blockIdx.x;          // row of the dump / the gathered keys
+    const int64_t q = flagged[f];          // row of the batch
+    const int kk = k + 1;
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid / KN_WAVE;
+    const float v = can_d[q * kk + k - 1];
+    // the canonical entries better than v open the pool
+    int nbetter = 0;
+    for (int e = 0; e < k; e++) { // (sorted best-first: the better ones are a prefix)
+        if (can_d[q * kk + e] == v) {
+            break;
+        }
+        nbetter++;
+    }
+    for (int e = tid; e < nbetter; e += RG_THREADS) {
+        pool_d[e] = can_d[q * kk + e];
+        pool_i[e] = can_i[q * kk + e];
+    }
+    if (tid == 0) {
+        s_n = 0;
+    }
+    __syncthreads();
+    // phase 1: arrivals in scan order; `seen` counts those with distance <= v, ties among the first k join the pool
+    int seen = 0, nt = 0; // (uniform over the workgroup)
+    for (int rank = 0; rank < a.nprobe && seen < k; rank++) {
+        int64_t col0, idp0, len;
+        if (!range_segment(a, f, rank, &col0, &idp0, &len)) {
+            continue;
+        }
+        for (int64_t i0 = 0; i0 < len && seen < k; i0 += RG_THREADS) {
+            const int64_t i = i0 + tid;
+            float dis = 0.f;
+            bool hit = false;
+            if (i < len) {
+                dis = a.dist[f * a.ncol + col0 + i];
+                hit = IS_L2 ? (dis <= v) : (dis >= v);
+                if (hit) {
+                    const int64_t id = a.ids ? a.ids[idp0 + i] : idp0 + i + a.id_offset;
+                    hit = !bitset_filtered(a.bitset, a.bitset_nbits, id);
+                }
+            }
+            const unsigned long long m = __ballot(hit);
+            if (lane == 0) {
+                s_wave[wave] = __popcll(m);
+            }
+            __syncthreads();
+            int before = __popcll(m & ((1ull << lane) - 1ull)), tot = 0;
+            for (int w = 0; w < RG_THREADS / KN_WAVE; w++) {
+                if (w < wave) {
+                    before += s_wave[w];
+                }
+                tot += s_wave[w];
+            }
+            // arrival number of this hit = seen + before; a TIE among the first k arrivals is eligible
+            const bool elig = hit && dis == v && seen + before < k;
+            const unsigned long long em = __ballot(elig);
+            __syncthreads(); // (s_wave is reused for the eligible counts)
+            if (lane == 0) {
+                s_wave[wave] = __popcll(em);
+            }
+            __syncthreads();
+            int ebefore = __popcll(em & ((1ull << lane) - 1ull)), etot = 0;
+            for (int w = 0; w < RG_THREADS / KN_WAVE; w++) {
+                if (w < wave) {
+                    ebefore += s_wave[w];
+                }
+                etot += s_wave[w];
+            }
+            if (elig) {
+                pool_d[nbetter + nt + ebefore] = dis;
+                pool_i[nbetter + nt + ebefore] = a.ids ? a.ids[idp0 + i] : idp0 + i + a.id_offset;
+            }
+            nt += etot;
+            seen += tot;
+            __syncthreads();
+        }
+    }
+    // phase 2: canonical order of the pool by counting (n <= 2 k - 1 entries, all ids distinct); the first k go out
+    const int n = nbetter + nt;
+    for (int e = tid; e < n; e += RG_THREADS) {
+        const float de = pool_d[e];
+        const int64_t ie = pool_i[e];
+        int rank = 0;
+        for (int o = 0; o < n; o++) {
+            rank += better<IS_L2>(pool_d[o], pool_i[o], de, ie) ? 1 : 0;
+        }
+        if (rank < k) {
+            out_d[q * k + rank] = de;
+            out_i[q * k + rank] = ie;
+        }
+    }
+    // (n >= k whenever the query was flagged: the canonical row itself holds k entries at or below v, and they arrive)
+}
+
+hipError_t launch_tie_gather(const int32_t* flagged, int nflag, const float* q, int d, const int64_t* keys, const float* cdis,
+                             int nprobe, float* q_out, int64_t* keys_out, float* cdis_out, hipStream_t s) {
+    if (nflag <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(tie_gather_kernel, dim3((unsigned)nflag), dim3(128), 0, s, flagged, nflag, q, d, keys, cdis, nprobe,
+                       q_out, keys_out, cdis_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_tie_apply(const RangeArgs& a, const int32_t* flagged, int nflag, const float* can_d, const int64_t* can_i,
+                            int k, bool is_l2, float* out_d, int64_t* out_i, hipStream_t s) {
+    if (nflag <= 0) {
+        return hipSuccess;
+    }
+    const size_t sm = (size_t)2 * k * 12;
+    auto kern = is_l2 ? tie_apply_kernel<true> : tie_apply_kernel<false>;
+    if (sm > 48 * 1024) {
+        return hipErrorInvalidValue; // (k <= 1023: 24 KB)
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nflag), dim3(RG_THREADS), sm, s, a, flagged, can_d, can_i, k, out_d, out_i);
+    return hipGetLastError();
+}
+
 hipError_t launch_range_emit(const RangeArgs& a, int64_t nq, bool is_l2, const int64_t* off, const int64_t* qbase,
                              int64_t* out_ids, float* out_dis, hipStream_t s) {
     if (nq <= 0 || a.nprobe <= 0) {
