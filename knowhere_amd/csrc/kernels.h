@@ -420,9 +420,11 @@ hipError_t launch_tie_detect(const float* d, const int64_t* i, int64_t nq, int k
 // ... and the resolve itself: the flagged queries' rows gathered, then (after the dump pass over their probed lists) the
 // reference's rule applied per query, the result written over its row of (out_d, out_i) -- no host round trip
 hipError_t launch_tie_gather(const int32_t* flagged, int nflag, const float* q, int d, const int64_t* keys, const float* cdis,
-                             int nprobe, float* q_out, int64_t* keys_out, float* cdis_out, hipStream_t s);
-hipError_t launch_tie_apply(const RangeArgs& a, const int32_t* flagged, int nflag, const float* can_d, const int64_t* can_i,
-                            int k, bool is_l2, float* out_d, int64_t* out_i, hipStream_t s);
+                             int nprobe, float* q_out, int64_t* keys_out, float* cdis_out, const float* can_d, int k,
+                             float* rad_out, hipStream_t s);
+hipError_t launch_tie_apply(const int32_t* flagged, int nflag, const float* can_d, const int64_t* can_i, int k, bool is_l2,
+                            const float* hit_d, const int64_t* hit_i, const int64_t* total, float* out_d, int64_t* out_i,
+                            hipStream_t s);
 // every exact ADC distance of every probed list of an IVF-PQ index with any M x 8 bit codes (range.hip)
 struct PqDumpArgs {
     float* dist;                 // [nq][ncol], column = list_row_off[list] + position
@@ -459,7 +461,7 @@ hipError_t launch_range_flat_dump(const FlatScanArgs& a, const int64_t* keys_w, 
 hipError_t launch_range_plan(const int32_t* cnt, int64_t nq, int nprobe, int max_empty, int64_t* off, int64_t* total,
                              hipStream_t s);
 hipError_t launch_range_emit(const RangeArgs& a, int64_t nq, bool is_l2, const int64_t* off, const int64_t* qbase,
-                             int64_t* out_ids, float* out_dis, hipStream_t s);
+                             int64_t* out_ids, float* out_dis, hipStream_t s, int64_t cap = 0);
 
 // ---- topk.hip: selection kernels ----
 // per query: k best of nslot sorted partial lists -> out (canonical order, sentinel padded);

@@ -2518,8 +2518,10 @@ static int search_batch_ties(const knhip_index* idx, Workspace* ws, const float*
         HIP_TRY(ws->tie_keys.reserve((size_t)nflag * nprobe * sizeof(int64_t)));
         HIP_TRY(ws->tie_cdis.reserve((size_t)nflag * nprobe * sizeof(float)));
     }
+    HIP_TRY(ws->tie_r.reserve((size_t)nflag * sizeof(float)));
     HIP_TRY(launch_tie_gather(flagged, nflag, d_q, idx->d, src_keys, src_cdis, nprobe, ws->tie_q.as<float>(),
-                              ws->tie_keys.as<int64_t>(), ws->tie_cdis.as<float>(), s));
+                              ws->tie_keys.as<int64_t>(), ws->tie_cdis.as<float>(), ws->tie_d.as<float>(), k,
+                              ws->tie_r.as<float>(), s));
     // queries per round: the dump matrix [round][ncol] stays below 2 GiB
     int64_t qb = std::max<int64_t>(1, (int64_t)((2ull << 30) / ((size_t)std::max<int64_t>(ncol, 1) * 4)));
     qb = std::max<int64_t>(1, std::min<int64_t>(qb, (int64_t)0x7fffffff / std::max<int64_t>(nseg, 1)));
@@ -2535,7 +2537,21 @@ static int search_batch_ties(const knhip_index* idx, Workspace* ws, const float*
                                  src_keys ? ws->tie_cdis.as<float>() + f0 * nprobe : nullptr, &r)) {
             return rc;
         }
-        HIP_TRY(launch_tie_apply(r, flagged + f0, (int)n, ws->tie_d.as<float>(), ws->tie_i.as<int64_t>(), k, is_l2, d_out_d,
+        // the first k arrivals with distance <= v of every flagged query, in scan order: count per (query, rank) -> offsets
+        // -> capped emit (all parallel over the ranks), then one workgroup per query applies the rule to its row
+        r.radius_q = ws->tie_r.as<float>() + f0;
+        r.inclusive = 1;
+        HIP_TRY(ws->rg_cnt.reserve((size_t)n * r.nprobe * sizeof(int32_t)));
+        HIP_TRY(ws->rg_off.reserve((size_t)n * r.nprobe * sizeof(int64_t)));
+        HIP_TRY(ws->rg_tot.reserve((size_t)n * 2 * sizeof(int64_t)));
+        HIP_TRY(ws->rg_out_i.reserve((size_t)n * k * sizeof(int64_t)));
+        HIP_TRY(ws->rg_out_d.reserve((size_t)n * k * sizeof(float)));
+        HIP_TRY(launch_range_count(r, n, is_l2, ws->rg_cnt.as<int32_t>(), s));
+        HIP_TRY(launch_range_plan(ws->rg_cnt.as<int32_t>(), n, r.nprobe, 0, ws->rg_off.as<int64_t>(), ws->rg_tot.as<int64_t>(), s));
+        HIP_TRY(launch_range_emit(r, n, is_l2, ws->rg_off.as<int64_t>(), nullptr, ws->rg_out_i.as<int64_t>(),
+                                  ws->rg_out_d.as<float>(), s, k));
+        HIP_TRY(launch_tie_apply(flagged + f0, (int)n, ws->tie_d.as<float>(), ws->tie_i.as<int64_t>(), k, is_l2,
+                                 ws->rg_out_d.as<float>(), ws->rg_out_i.as<int64_t>(), ws->rg_tot.as<int64_t>(), d_out_d,
                                  d_out_i, s));
     }
     if (trace) fprintf(stderr, "[ties] applied\n");

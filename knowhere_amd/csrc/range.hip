@@ -209,23 +209,26 @@ __global__ void range_plan_kernel(const int32_t* __restrict__ cnt, int64_t nq, i
     total[q] = run;
 }
 
+// cap > 0: only the first `cap` hits of a query are kept, at out[q * cap + position] (qbase unused): the tie rule needs the
+// first k arrivals only
 template <bool IS_L2>
 __global__ __launch_bounds__(RG_THREADS) void range_emit_kernel(RangeArgs a, const int64_t* __restrict__ off,
                                                                 const int64_t* __restrict__ qbase,
                                                                 int64_t* __restrict__ out_ids,
-                                                                float* __restrict__ out_dis) {
+                                                                float* __restrict__ out_dis, int64_t cap) {
     const int64_t q = blockIdx.x / a.nprobe;
     const int rank = (int)(blockIdx.x % a.nprobe);
     const int64_t o = off[blockIdx.x];
     int64_t col0, idp0, len;
-    if (o < 0 || !range_segment(a, q, rank, &col0, &idp0, &len)) {
+    if (o < 0 || (cap > 0 && o >= cap) || !range_segment(a, q, rank, &col0, &idp0, &len)) {
         return;
     }
     __shared__ int s_wave[RG_THREADS / KN_WAVE];
     __shared__ int64_t s_base;
     const int lane = lane_id(), wave = threadIdx.x / KN_WAVE;
+    const int64_t qb0 = cap > 0 ? q * cap : qbase[q];
     if (threadIdx.x == 0) {
-        s_base = qbase[q] + o;
+        s_base = qb0 + o;
     }
     __syncthreads();
     for (int64_t i0 = 0; i0 < len; i0 += RG_THREADS) {
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(RG_THREADS) void range_emit_kernel(RangeArgs a, con
             tot += s_wave[w];
         }
         const int64_t base = s_base;
-        if (hit) {
+        if (hit && (cap <= 0 || base + before - qb0 < cap)) {
             out_ids[base + before] = a.ids ? a.ids[idp0 + i] : idp0 + i + a.id_offset;
             out_dis[base + before] = dis;
         }
@@ -442,12 +445,16 @@ hipError_t launch_tie_detect(const float* d, const int64_t* i, int64_t nq, int k
 // gather the flagged queries (rows of the batch's queries, coarse keys and coarse distances) into dense arrays
 __global__ void tie_gather_kernel(const int32_t* __restrict__ flagged, int nflag, const float* __restrict__ q, int d,
                                   const int64_t* __restrict__ keys, const float* __restrict__ cdis, int nprobe,
-                                  float* __restrict__ q_out, int64_t* __restrict__ keys_out, float* __restrict__ cdis_out) {
+                                  float* __restrict__ q_out, int64_t* __restrict__ keys_out, float* __restrict__ cdis_out,
+                                  const float* __restrict__ can_d, int k, float* __restrict__ rad_out) {
     const int f = blockIdx.x;
     if (f >= nflag) {
         return;
     }
     const int64_t src = flagged[f];
+    if (threadIdx.x == 0) {
+        rad_out[f] = can_d[src * (k + 1) + k - 1]; // v: the query's k-th distance = its (inclusive) radius
+    }
     for (int i = threadIdx.x; i < d; i += blockDim.x) {
         q_out[(int64_t)f * d + i] = q[src * d + i];
     }
@@ -459,99 +466,54 @@ __global__ void tie_gather_kernel(const int32_t* __restrict__ flagged, int nflag
     }
 }
 
-// One workgroup per flagged query.  a.dist holds every distance of its probed lists (dump pass), a.order its lists in
-// coarse order.  Phase 1 walks them in the reference's SCAN order (rank, then storage position) and keeps the first k
-// arrivals with distance <= v (>= v for IP) that the bitset lets through -- v = the canonical k-th distance.  Phase 2: the
-// result = canonical top-k of {canonical entries better than v} U {ties among those first k arrivals} (the closed form of
-// the reference's heap, tests/test_tie_rule.py), written over the query's row of the output.
+// One workgroup per flagged query.  hits[f][0 .. min(k, total[f])) = the first arrivals with distance <= v (>= v for IP) in
+// the reference's SCAN order (range_count / range_plan / range_emit over the dump of its probed lists, capped at k), v =
+// the canonical k-th distance.  The result = canonical top-k of {canonical entries better than v} U {ties among those
+// arrivals} (the closed form of the reference's heap, tests/test_tie_rule.py), written over the query's output row.
 template <bool IS_L2>
-__global__ __launch_bounds__(RG_THREADS) void tie_apply_kernel(RangeArgs a, const int32_t* __restrict__ flagged,
+__global__ __launch_bounds__(RG_THREADS) void tie_apply_kernel(const int32_t* __restrict__ flagged,
                                                                const float* __restrict__ can_d,
                                                                const int64_t* __restrict__ can_i, int k,
+                                                               const float* __restrict__ hit_d,
+                                                               const int64_t* __restrict__ hit_i,
+                                                               const int64_t* __restrict__ total,
                                                                float* __restrict__ out_d, int64_t* __restrict__ out_i) {
     extern __shared__ __align__(16) unsigned char smem[];
     float* pool_d = reinterpret_cast<float*>(smem);                         // [2 k]
     int64_t* pool_i = reinterpret_cast<int64_t*>(smem + (size_t)2 * k * 4); // [2 k] (2 k * 4 is a multiple of 8)
-    __shared__ int s_wave[RG_THREADS / KN_WAVE];
     __shared__ int s_n;
-    const int64_t f = blockIdx.x;          // row of the dump / the gathered keys
-    const int64_t q = flagged[f];          // row of the batch
+    const int64_t f = blockIdx.x; // row of the hits
+    const int64_t q = flagged[f]; // row of the batch
     const int kk = k + 1;
-    const int tid = threadIdx.x, lane = lane_id(), wave = tid / KN_WAVE;
+    const int tid = threadIdx.x;
     const float v = can_d[q * kk + k - 1];
-    // the canonical entries better than v open the pool
-    int nbetter = 0;
-    for (int e = 0; e < k; e++) { // (sorted best-first: the better ones are a prefix)
-        if (can_d[q * kk + e] == v) {
-            break;
-        }
-        nbetter++;
-    }
-    for (int e = tid; e < nbetter; e += RG_THREADS) {
-        pool_d[e] = can_d[q * kk + e];
-        pool_i[e] = can_i[q * kk + e];
-    }
     if (tid == 0) {
         s_n = 0;
     }
     __syncthreads();
-    // phase 1: arrivals in scan order; `seen` counts those with distance <= v, ties among the first k join the pool
-    int seen = 0, nt = 0; // (uniform over the workgroup)
-    for (int rank = 0; rank < a.nprobe && seen < k; rank++) {
-        int64_t col0, idp0, len;
-        if (!range_segment(a, f, rank, &col0, &idp0, &len)) {
-            continue;
+    // the canonical entries better than v, and the ties among the first k arrivals, in any order (ranked below)
+    const int narr = (int)min((int64_t)k, total[f]);
+    for (int e = tid; e < k + narr; e += RG_THREADS) {
+        float de;
+        int64_t ie;
+        bool take;
+        if (e < k) {
+            de = can_d[q * kk + e];
+            ie = can_i[q * kk + e];
+            take = ie >= 0 && de != v;
+        } else {
+            de = hit_d[f * k + (e - k)];
+            ie = hit_i[f * k + (e - k)];
+            take = de == v;
         }
-        for (int64_t i0 = 0; i0 < len && seen < k; i0 += RG_THREADS) {
-            const int64_t i = i0 + tid;
-            float dis = 0.f;
-            bool hit = false;
-            if (i < len) {
-                dis = a.dist[f * a.ncol + col0 + i];
-                hit = IS_L2 ? (dis <= v) : (dis >= v);
-                if (hit) {
-                    const int64_t id = a.ids ? a.ids[idp0 + i] : idp0 + i + a.id_offset;
-                    hit = !bitset_filtered(a.bitset, a.bitset_nbits, id);
-                }
-            }
-            const unsigned long long m = __ballot(hit);
-            if (lane == 0) {
-                s_wave[wave] = __popcll(m);
-            }
-            __syncthreads();
-            int before = __popcll(m & ((1ull << lane) - 1ull)), tot = 0;
-            for (int w = 0; w < RG_THREADS / KN_WAVE; w++) {
-                if (w < wave) {
-                    before += s_wave[w];
-                }
-                tot += s_wave[w];
-            }
-            // arrival number of this hit = seen + before; a TIE among the first k arrivals is eligible
-            const bool elig = hit && dis == v && seen + before < k;
-            const unsigned long long em = __ballot(elig);
-            __syncthreads(); // (s_wave is reused for the eligible counts)
-            if (lane == 0) {
-                s_wave[wave] = __popcll(em);
-            }
-            __syncthreads();
-            int ebefore = __popcll(em & ((1ull << lane) - 1ull)), etot = 0;
-            for (int w = 0; w < RG_THREADS / KN_WAVE; w++) {
-                if (w < wave) {
-                    ebefore += s_wave[w];
-                }
-                etot += s_wave[w];
-            }
-            if (elig) {
-                pool_d[nbetter + nt + ebefore] = dis;
-                pool_i[nbetter + nt + ebefore] = a.ids ? a.ids[idp0 + i] : idp0 + i + a.id_offset;
-            }
-            nt += etot;
-            seen += tot;
-            __syncthreads();
+        if (take) {
+            const int p = atomicAdd(&s_n, 1);
+            pool_d[p] = de;
+            pool_i[p] = ie;
         }
     }
-    // phase 2: canonical order of the pool by counting (n <= 2 k - 1 entries, all ids distinct); the first k go out
-    const int n = nbetter + nt;
+    __syncthreads();
+    const int n = s_n; // (>= k whenever the query was flagged: k entries at or below v exist and arrive)
     for (int e = tid; e < n; e += RG_THREADS) {
         const float de = pool_d[e];
         const int64_t ie = pool_i[e];
@@ -564,21 +526,22 @@ __global__ __launch_bounds__(RG_THREADS) void tie_apply_kernel(RangeArgs a, cons
             out_i[q * k + rank] = ie;
         }
     }
-    // (n >= k whenever the query was flagged: the canonical row itself holds k entries at or below v, and they arrive)
 }
 
 hipError_t launch_tie_gather(const int32_t* flagged, int nflag, const float* q, int d, const int64_t* keys, const float* cdis,
-                             int nprobe, float* q_out, int64_t* keys_out, float* cdis_out, hipStream_t s) {
+                             int nprobe, float* q_out, int64_t* keys_out, float* cdis_out, const float* can_d, int k,
+                             float* rad_out, hipStream_t s) {
     if (nflag <= 0) {
         return hipSuccess;
     }
     hipLaunchKernelGGL(tie_gather_kernel, dim3((unsigned)nflag), dim3(128), 0, s, flagged, nflag, q, d, keys, cdis, nprobe,
-                       q_out, keys_out, cdis_out);
+                       q_out, keys_out, cdis_out, can_d, k, rad_out);
     return hipGetLastError();
 }
 
-hipError_t launch_tie_apply(const RangeArgs& a, const int32_t* flagged, int nflag, const float* can_d, const int64_t* can_i,
-                            int k, bool is_l2, float* out_d, int64_t* out_i, hipStream_t s) {
+hipError_t launch_tie_apply(const int32_t* flagged, int nflag, const float* can_d, const int64_t* can_i, int k, bool is_l2,
+                            const float* hit_d, const int64_t* hit_i, const int64_t* total, float* out_d, int64_t* out_i,
+                            hipStream_t s) {
     if (nflag <= 0) {
         return hipSuccess;
     }
@@ -587,22 +550,23 @@ hipError_t launch_tie_apply(const RangeArgs& a, const int32_t* flagged, int nfla
     if (sm > 48 * 1024) {
         return hipErrorInvalidValue; // (k <= 1023: 24 KB)
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nflag), dim3(RG_THREADS), sm, s, a, flagged, can_d, can_i, k, out_d, out_i);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nflag), dim3(RG_THREADS), sm, s, flagged, can_d, can_i, k, hit_d, hit_i, total,
+                       out_d, out_i);
     return hipGetLastError();
 }
 
 hipError_t launch_range_emit(const RangeArgs& a, int64_t nq, bool is_l2, const int64_t* off, const int64_t* qbase,
-                             int64_t* out_ids, float* out_dis, hipStream_t s) {
+                             int64_t* out_ids, float* out_dis, hipStream_t s, int64_t cap) {
     if (nq <= 0 || a.nprobe <= 0) {
         return hipSuccess;
     }
     const unsigned grid = (unsigned)(nq * a.nprobe);
     if (is_l2) {
         hipLaunchKernelGGL((range_emit_kernel<true>), dim3(grid), dim3(RG_THREADS), 0, s, a, off, qbase, out_ids,
-                           out_dis);
+                           out_dis, cap);
     } else {
         hipLaunchKernelGGL((range_emit_kernel<false>), dim3(grid), dim3(RG_THREADS), 0, s, a, off, qbase, out_ids,
-                           out_dis);
+                           out_dis, cap);
     }
     return hipGetLastError();
 }
