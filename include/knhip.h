@@ -56,9 +56,9 @@
 extern "C" {
 #endif
 
-/* 4: knhip_train_params gained spherical/reserved, knhip_stage_times its prefilter counters.  5: tie_queries.
+/* 4: knhip_train_params gained spherical/reserved, knhip_stage_times its prefilter counters.  5: tie_queries.  6: the quantised refine store (knhip_rows_*, knhip_search_refine_rows).
  * Callers compare knhip_abi_version() with the header they were built against. */
-#define KNHIP_ABI_VERSION 5
+#define KNHIP_ABI_VERSION 6
 
 typedef struct knhip_index knhip_index;
 
@@ -253,6 +253,32 @@ int knhip_search(const knhip_index* idx, const float* queries, int64_t nq, int32
 int knhip_search_refine(const knhip_index* idx, const knhip_index* raw, const float* queries, int64_t nq, int32_t k,
                         int32_t k_base, int32_t nprobe, const uint8_t* bitset, int64_t bitset_nbits, int64_t* out_ids,
                         float* out_dist);
+/* ---- quantised refine store: Knowhere's `refine_type` = fp16 / bf16 / sq8 (src/index/ivf/ivf_config.h:113-135,
+ * src/index/refine/refine_utils.cc:99-160: the refine index is a faiss::IndexScalarQuantizer(d, QT_fp16 / QT_bf16 /
+ * QT_8bit, metric) instead of IndexFlat).  knhip_rows keeps the encoded rows in HBM (row r = vector id r):
+ *   fp16: IEEE half, round to nearest even (utils/fp16.h encode_fp16);  bf16: (bits + 0x8000) >> 16 (utils/bf16.h:27-32);
+ *   sq8:  per-dimension ranges trained over ALL training rows (ScalarQuantizer::train, RS_minmax, rangestat_arg 0),
+ *         code_i = (int)(255 * clamp((x_i - vmin_i) / vdiff_i, 0, 1)), x_i = vmin_i + vdiff_i * ((code_i + 0.5) / 255)
+ *         (impl/scalar_quantizer/quantizers.h:108-146, codecs.h:26-41).
+ * knhip_search_refine_rows = knhip_search_refine with the second stage reading this store through the scalar quantizer's
+ * distance computer (sequential: decode x_i, then (q_i - x_i)^2 / q_i * x_i added in order): bit-equal to the reference.
+ * get_codes / add_codes move the faiss code bytes (Serialize / Deserialize: "IxSQ" inside "IxRF"). */
+typedef struct knhip_rows knhip_rows;
+enum { KNHIP_ROWS_FP16 = 1, KNHIP_ROWS_BF16 = 2, KNHIP_ROWS_SQ8 = 3 };
+int knhip_rows_create(int32_t device, int32_t dim, int32_t row_type, knhip_rows** out);
+void knhip_rows_destroy(knhip_rows* rows);
+int knhip_rows_train(knhip_rows* rows, int64_t n, const float* x);                 /* sq8 ranges; a no-op for the 16-bit types */
+int knhip_rows_set_trained(knhip_rows* rows, const float* vmin, const float* vdiff);
+int knhip_rows_get_trained(const knhip_rows* rows, float* vmin, float* vdiff);
+int knhip_rows_add(knhip_rows* rows, int64_t n, const float* x);                   /* encode + append (host fp32 rows) */
+int knhip_rows_add_codes(knhip_rows* rows, int64_t n, const uint8_t* codes);       /* append already encoded rows */
+int knhip_rows_get_codes(const knhip_rows* rows, uint8_t* out);                    /* [count][code_size] host */
+int64_t knhip_rows_count(const knhip_rows* rows);
+int64_t knhip_rows_code_size(const knhip_rows* rows);
+int64_t knhip_rows_device_bytes(const knhip_rows* rows);
+int knhip_search_refine_rows(const knhip_index* idx, const knhip_rows* rows, const float* queries, int64_t nq, int32_t k,
+                             int32_t k_base, int32_t nprobe, const uint8_t* bitset, int64_t bitset_nbits, int64_t* out_ids,
+                             float* out_dist);
 /* rows by id (IndexNode::GetVectorByIds); out [n][dim] host.  BRUTE_FORCE: row = id - id_offset.  IVF_FLAT: through a
  * direct map built on first use from the index's own ids (16 bytes per vector in HBM; the reference's
  * make_direct_map / reconstruct, thirdparty/faiss/faiss/IndexIVF.cpp); an id that is not stored is an error. */

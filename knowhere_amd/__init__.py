@@ -6,4 +6,4 @@ thin harness the tests and ``bench.py`` drive it through: ctypes bindings, torch
 memory / streams / ``torch.distributed`` plumbing, and the GPU index builder.
 """
 from . import _lib  # noqa: F401
-from .index import GpuIndex, KnhipError  # noqa: F401
+from .index import GpuIndex, KnhipError, RowStore  # noqa: F401

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("KNHIP_LIB") or os.path.join(_HERE, "libknhip.so")  # 
 BRUTE_FORCE, IVF_FLAT, IVF_PQ, IVF_SQ8 = 0, 1, 2, 3
 L2, IP = 0, 1
 NSTAGE = 8
-ABI_VERSION = 5  # KNHIP_ABI_VERSION of include/knhip.h
+ABI_VERSION = 6  # KNHIP_ABI_VERSION of include/knhip.h
 STAGE_COARSE, STAGE_GROUP, STAGE_LUT, STAGE_SCAN, STAGE_MERGE, STAGE_OTHER, STAGE_SCAN_RANK0 = range(7)
 
 
@@ -51,6 +51,9 @@ SYMBOLS = [
     "knhip_index_encode_device", "knhip_index_get_coarse", "knhip_index_get_pq", "knhip_index_get_sq",
     "knhip_index_get_list_sizes", "knhip_index_get_lists", "knhip_index_get_vectors_device", "knhip_search_refine",
     "knhip_index_get_vectors", "knhip_index_find_vectors", "knhip_index_assign", "knhip_device_memory",
+    "knhip_rows_create", "knhip_rows_destroy", "knhip_rows_train", "knhip_rows_set_trained", "knhip_rows_get_trained",
+    "knhip_rows_add", "knhip_rows_add_codes", "knhip_rows_get_codes", "knhip_rows_count", "knhip_rows_code_size",
+    "knhip_rows_device_bytes", "knhip_search_refine_rows",
     "knhip_fvec_L1_ny", "knhip_fvec_Linf_ny", "knhip_fvec_norms_L2sqr_ref", "knhip_fvec_L2sqr_ny_transposed",
     "knhip_fvec_L2sqr_ny_nearest", "knhip_fvec_L2sqr_ny_nearest_y_transposed", "knhip_fvec_madd_and_argmin",
     "knhip_fvec_batch_4", "knhip_typed_vec_ny", "knhip_typed_vec_batch_4", "knhip_ivec_ny",
@@ -146,6 +149,19 @@ def load():
     L.knhip_index_find_vectors.argtypes = [vp, i64, vp, vp, vp]
     L.knhip_index_assign.argtypes = [vp, i64, vp, vp]
     L.knhip_device_memory.argtypes = [i32, vp, vp]
+    L.knhip_rows_create.argtypes = [i32, i32, i32, C.POINTER(vp)]
+    L.knhip_rows_destroy.argtypes = [vp]
+    L.knhip_rows_destroy.restype = None
+    L.knhip_rows_train.argtypes = [vp, i64, vp]
+    L.knhip_rows_set_trained.argtypes = [vp, vp, vp]
+    L.knhip_rows_get_trained.argtypes = [vp, vp, vp]
+    L.knhip_rows_add.argtypes = [vp, i64, vp]
+    L.knhip_rows_add_codes.argtypes = [vp, i64, vp]
+    L.knhip_rows_get_codes.argtypes = [vp, vp]
+    for f in ("knhip_rows_count", "knhip_rows_code_size", "knhip_rows_device_bytes"):
+        getattr(L, f).argtypes = [vp]
+        getattr(L, f).restype = i64
+    L.knhip_search_refine_rows.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp, i64, vp, vp]
     L.knhip_profile_enable.argtypes = [vp, C.c_int]
     L.knhip_profile_reset.argtypes = [vp]
     L.knhip_profile_get.argtypes = [vp, C.POINTER(StageTimes)]

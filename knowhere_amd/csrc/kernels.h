@@ -446,6 +446,36 @@ struct PqDumpArgs {
     const float* queries;        // [nq][d]                     (RESIDUAL)
 };
 hipError_t launch_pq_adc_dump(const PqDumpArgs& a, int64_t nq, bool is_l2, hipStream_t s);
+
+// ---- pq_scan_any.hip: exact IVF-PQ top-k scan for any number of 8-bit sub-quantizers (the widths the fast kernels do not
+// take).  One workgroup per (query, probe); its four waves write four sorted partial lists:
+// partial slot = 4 * probe rank + wave, so merge_partials runs over 4 * nprobe slots
+struct PqAnyArgs {
+    const int64_t* keys;         // [nq][nprobe] probed lists (coarse order; < 0: none)
+    const float* coarse_dis;     // [nq][nprobe]
+    int32_t nprobe;
+    int64_t nlist;
+    const int64_t* list_len;
+    const int64_t* list_row_off;
+    const uint8_t* codes;        // canonical list-sorted AoS codes [ntotal][M]
+    const int64_t* ids;          // [ntotal]
+    int32_t M;
+    int32_t d;
+    int32_t lut_mode;            // PqLutMode
+    const float* t2t;            // [nq][256][M]     (PRECOMP, IP)
+    const float* precomp_t;      // [nlist][256][M]  (PRECOMP)
+    const float* cb;             // [M][256][dsub]   (RESIDUAL)
+    const float* centroids;      // [nlist][d]       (RESIDUAL)
+    const float* queries;        // [nq][d]          (RESIDUAL)
+    const uint8_t* bitset;
+    int64_t bitset_nbits;
+    float* partial_d;            // [nq][nprobe * 4][k]
+    int64_t* partial_i;
+    int32_t k;
+};
+constexpr int PQ_ANY_PARTS = 4;  // partial lists per (query, probe)
+int pq_scan_any_supports(int M, int d);
+hipError_t launch_pq_scan_any(const PqAnyArgs& a, int64_t nq, bool is_l2, hipStream_t s);
 // (rank0, nrank >= 0: one wave of ranks; qstate: queries with qstate[q][1] != 0 are skipped)
 hipError_t launch_range_count(const RangeArgs& a, int64_t nq, bool is_l2, int32_t* cnt, hipStream_t s, int rank0 = 0,
                               int nrank = -1, const int32_t* qstate = nullptr);
@@ -498,9 +528,12 @@ hipError_t launch_coarse_rerank(const float* queries, const float* centroids, in
                                 unsigned long long* nfail, hipStream_t s);
 
 // ---- refine.hip ----
+// row_type: 0 fp32 rows (base), 1 fp16, 2 bf16, 3 per-dimension 8-bit codes with sq_trained = vmin[d], vdiff[d] (base is
+// then the byte / half-word array, row r = id id_base + r)
 hipError_t launch_refine(const float* base, int64_t nbase, int64_t id_base, int d, const float* queries,
                          int64_t nq, const int64_t* cand, int kbase, int k, bool is_l2, float* out_d,
-                         int64_t* out_i, hipStream_t s);
+                         int64_t* out_i, hipStream_t s, int row_type = 0, const float* sq_trained = nullptr);
+hipError_t launch_rows_encode16(const float* x, int64_t n_elems, bool bf16, uint16_t* out, hipStream_t s);
 
 // ---- build.hip: Train / Add on the device ----
 // direct map of an IVF-Flat index (GetVectorByIds): ids sorted with the columns of their rows in the interleaved store

@@ -561,7 +561,9 @@ int build_list_layout(knhip_index* idx, const std::vector<int64_t>& list_off, co
         idx->pq_v2 = (M == 32) && !(v1 && v1[0] == '1');
         idx->rows.release();
         idx->skew_ready = false;
-        if (!idx->pq_v2) { // (m = 32 searches on the stream16 layout; its skewed copy is built on first use: k > 128)
+        if (!idx->pq_v2 && pq_scan_supported_m(M)) {
+            // (m = 32 searches on the stream16 layout; its skewed copy is built on first use: k > 128.  Widths without a
+            // systolic kernel -- pq_scan_any.hip -- read the canonical AoS codes)
             if (int rc2 = build_pq_skew(idx)) return rc2;
         }
         if (idx->pq_v2) {
@@ -770,6 +772,48 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         }
         keys_p = ws->keys.as<int64_t>();
         cdis_p = ws->cdis.as<float>();
+    }
+    if (kind == KNHIP_IVF_PQ && !pq_scan_supported_m(idx->desc.pq_m)) {
+        // any other number of sub-quantizers: the plain exact kernel, one workgroup per (query, probe), no work table
+        const int M = idx->desc.pq_m;
+        const int mode = !is_l2 ? PQ_LUT_IP : (idx->use_precomp ? PQ_LUT_PRECOMP : PQ_LUT_RESIDUAL);
+        if (mode != PQ_LUT_RESIDUAL) {
+            HIP_TRY(ws->t2t.reserve((size_t)nq * 256 * M * sizeof(float)));
+            StageTimer t(idx, s, KNHIP_STAGE_LUT);
+            HIP_TRY(launch_pq_query_table(d_q, idx->cb.as<float>(), d, M, nq, ws->t2t.as<float>(), s));
+        }
+        const int64_t nparts = (int64_t)nprobe * PQ_ANY_PARTS;
+        HIP_TRY(ws->partial_d.reserve((size_t)nq * nparts * k * sizeof(float)));
+        HIP_TRY(ws->partial_i.reserve((size_t)nq * nparts * k * sizeof(int64_t)));
+        PqAnyArgs a{};
+        a.keys = keys_p;
+        a.coarse_dis = cdis_p;
+        a.nprobe = nprobe;
+        a.nlist = nlist;
+        a.list_len = idx->d_list_len.as<int64_t>();
+        a.list_row_off = idx->d_list_row_off.as<int64_t>();
+        a.codes = idx->codes_aos.as<uint8_t>();
+        a.ids = idx->ids.as<int64_t>();
+        a.M = M;
+        a.d = d;
+        a.lut_mode = mode;
+        a.t2t = ws->t2t.as<float>();
+        a.precomp_t = idx->precomp_t.as<float>();
+        a.cb = idx->cb.as<float>();
+        a.centroids = idx->centroids.as<float>();
+        a.queries = d_q;
+        a.bitset = d_bitset;
+        a.bitset_nbits = nbits;
+        a.partial_d = ws->partial_d.as<float>();
+        a.partial_i = ws->partial_i.as<int64_t>();
+        a.k = k;
+        {
+            StageTimer t(idx, s, KNHIP_STAGE_SCAN);
+            HIP_TRY(launch_pq_scan_any(a, nq, is_l2, s));
+        }
+        StageTimer t(idx, s, KNHIP_STAGE_MERGE);
+        HIP_TRY(launch_merge_partials(a.partial_d, a.partial_i, nq, (int)nparts, k, nparts * k, k, is_l2, d_out_d, d_out_i, s));
+        return KNHIP_OK;
     }
     // 2. group
     const int qg = (kind == KNHIP_IVF_PQ) ? pq_scan_qg(idx->desc.pq_m)
@@ -1489,6 +1533,9 @@ int64_t query_batch(const knhip_index* idx, int64_t nq, int k, int nprobe) {
         }
         if (idx->desc.kind == KNHIP_IVF_PQ) {
             per_q += 256.0 * idx->desc.pq_m * 4.0;
+            if (!pq_scan_supported_m(idx->desc.pq_m)) { // (pq_scan_any.hip: four partial lists per probe)
+                per_q += (double)nprobe * (PQ_ANY_PARTS - 1) * (double)k * 12.0;
+            }
         }
     }
     const double budget = 8.0 * 1024 * 1024 * 1024;
@@ -1558,8 +1605,9 @@ int knhip_index_create(const knhip_desc* desc, knhip_index** out) {
         if (desc->pq_m <= 0 || desc->dim % desc->pq_m != 0) {
             return fail(KNHIP_ERR_INVALID_ARGS, "pq_m must divide dim");
         }
-        if (!pq_scan_supported_m(desc->pq_m)) {
-            return fail(KNHIP_ERR_NOT_IMPLEMENTED, "pq_m must be one of 8, 16, 32, 64");
+        // (8, 16, 32, 64: the fast kernels; every other width: pq_scan_any.hip)
+        if (!pq_scan_supported_m(desc->pq_m) && !pq_scan_any_supports(desc->pq_m, desc->dim)) {
+            return fail(KNHIP_ERR_NOT_IMPLEMENTED, "pq_m above 128, or sub-vectors of more than 144 dimensions");
         }
     }
     int ndev = knhip_device_count();
@@ -1914,7 +1962,15 @@ int knhip_search_preassigned_device(const knhip_index* idx, const float* d_queri
 }
 
 // host boundary of Search(): queries up, (search [+ exact re-rank against the raw rows of `raw`]), results down
-static int search_host_impl(const knhip_index* idx, const knhip_index* raw, const float* queries, int64_t nq, int32_t k,
+// the rows the second stage of knhip_search_refine* reads: fp32 rows of a BRUTE_FORCE index, or a quantised knhip_rows store
+struct RefineStore {
+    const void* rows = nullptr;   // device: [n][d] fp32 / 16-bit / 8-bit codes
+    int64_t n = 0, id0 = 0;
+    int row_type = 0;             // 0 fp32, 1 fp16, 2 bf16, 3 sq8
+    const float* sq = nullptr;    // device: vmin[d], vdiff[d] (sq8)
+};
+
+static int search_host_impl(const knhip_index* idx, const RefineStore* raw, const float* queries, int64_t nq, int32_t k,
                             int32_t k_base, int32_t nprobe, const uint8_t* bitset, int64_t bitset_nbits,
                             int64_t* out_ids, float* out_dist) {
     if (int rc = check_index(idx)) return rc;
@@ -1923,11 +1979,6 @@ static int search_host_impl(const knhip_index* idx, const knhip_index* raw, cons
         return fail(KNHIP_ERR_INVALID_ARGS, "search_refine: need k_base >= k > 0");
     }
     if (int rc = validate_search(idx, nq, ks, nprobe)) return rc;
-    if (raw && (raw->desc.kind != KNHIP_BRUTE_FORCE || raw->d != idx->d || raw->desc.device != idx->desc.device ||
-                !raw->has_data)) {
-        return fail(KNHIP_ERR_INVALID_ARGS, "search_refine: `raw` must be a filled brute-force index of the same "
-                                            "dimension on the same device");
-    }
     if (nq == 0) {
         return KNHIP_OK;
     }
@@ -1970,9 +2021,9 @@ static int search_host_impl(const knhip_index* idx, const knhip_index* raw, cons
         if (raw) { // IndexRefine::search second stage, on the device-resident raw rows
             HIP_TRY(ws->h_ref_d.reserve((size_t)nq * k * sizeof(float)));
             HIP_TRY(ws->h_ref_i.reserve((size_t)nq * k * sizeof(int64_t)));
-            HIP_TRY(launch_refine(raw->codes_aos.as<float>(), raw->ntotal, raw->id_offset, idx->d,
+            HIP_TRY(launch_refine(static_cast<const float*>(raw->rows), raw->n, raw->id0, idx->d,
                                   ws->h_queries.as<float>(), nq, res_i, k_base, k, idx->is_l2, ws->h_ref_d.as<float>(),
-                                  ws->h_ref_i.as<int64_t>(), s));
+                                  ws->h_ref_i.as<int64_t>(), s, raw->row_type, raw->sq));
             res_d = ws->h_ref_d.as<float>();
             res_i = ws->h_ref_i.as<int64_t>();
         }
@@ -2001,7 +2052,206 @@ int knhip_search_refine(const knhip_index* idx, const knhip_index* raw, const fl
     if (!raw) {
         return fail(KNHIP_ERR_INVALID_ARGS, "search_refine: null raw-vector index");
     }
-    return search_host_impl(idx, raw, queries, nq, k, k_base, nprobe, bitset, bitset_nbits, out_ids, out_dist);
+    if (int rc = check_index(idx)) return rc;
+    if (raw->desc.kind != KNHIP_BRUTE_FORCE || raw->d != idx->d || raw->desc.device != idx->desc.device || !raw->has_data) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "search_refine: `raw` must be a filled brute-force index of the same "
+                                            "dimension on the same device");
+    }
+    RefineStore st;
+    st.rows = raw->codes_aos.p;
+    st.n = raw->ntotal;
+    st.id0 = raw->id_offset;
+    return search_host_impl(idx, &st, queries, nq, k, k_base, nprobe, bitset, bitset_nbits, out_ids, out_dist);
+}
+
+// ---- quantised refine store (Knowhere's refine_type = fp16 / bf16 / sq8: the refine index is a faiss::IndexScalarQuantizer,
+// reference src/index/refine/refine_utils.cc:99-160) ---------------------------------------------------------------------
+} // extern "C"
+
+struct knhip_rows {
+    int device = 0, d = 0, row_type = KNHIP_ROWS_FP16;
+    int64_t n = 0;
+    bool trained = false;
+    DevBuf codes;      // [n][code_size]
+    DevBuf sq;         // vmin[d], vdiff[d] (sq8)
+    std::mutex mu;
+    int64_t code_size() const { return row_type == KNHIP_ROWS_SQ8 ? d : 2 * (int64_t)d; }
+};
+
+extern "C" {
+
+int knhip_rows_create(int32_t device, int32_t dim, int32_t row_type, knhip_rows** out) {
+    if (!out || dim <= 0 || (row_type != KNHIP_ROWS_FP16 && row_type != KNHIP_ROWS_BF16 && row_type != KNHIP_ROWS_SQ8)) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "rows_create: dim > 0 and row type fp16 / bf16 / sq8");
+    }
+    if (device < 0 || device >= knhip_device_count()) {
+        return fail(KNHIP_ERR_HIP_RUNTIME, "rows_create: no such HIP device");
+    }
+    auto* r = new knhip_rows();
+    r->device = device;
+    r->d = dim;
+    r->row_type = row_type;
+    r->trained = row_type != KNHIP_ROWS_SQ8; // (the 16-bit types have nothing to train)
+    *out = r;
+    return KNHIP_OK;
+}
+
+void knhip_rows_destroy(knhip_rows* r) {
+    if (r) {
+        DeviceGuard g(r->device);
+        delete r;
+    }
+}
+
+int64_t knhip_rows_count(const knhip_rows* r) { return r ? r->n : 0; }
+int64_t knhip_rows_code_size(const knhip_rows* r) { return r ? r->code_size() : 0; }
+int64_t knhip_rows_device_bytes(const knhip_rows* r) { return r ? (int64_t)(r->codes.bytes + r->sq.bytes) : 0; }
+
+int knhip_rows_set_trained(knhip_rows* r, const float* vmin, const float* vdiff) {
+    if (!r || r->row_type != KNHIP_ROWS_SQ8 || !vmin || !vdiff) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "rows_set_trained: an sq8 store and two arrays of dim floats");
+    }
+    DeviceGuard g(r->device);
+    std::lock_guard<std::mutex> lk(r->mu);
+    HIP_TRY(r->sq.reserve((size_t)2 * r->d * sizeof(float)));
+    HIP_TRY(hipMemcpy(r->sq.p, vmin, (size_t)r->d * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(r->sq.as<float>() + r->d, vdiff, (size_t)r->d * sizeof(float), hipMemcpyHostToDevice));
+    r->trained = true;
+    return KNHIP_OK;
+}
+
+int knhip_rows_get_trained(const knhip_rows* r, float* vmin, float* vdiff) {
+    if (!r || r->row_type != KNHIP_ROWS_SQ8 || !r->trained || !vmin || !vdiff) {
+        return fail(KNHIP_ERR_NOT_TRAINED, "rows_get_trained: a trained sq8 store");
+    }
+    DeviceGuard g(r->device);
+    HIP_TRY(hipMemcpy(vmin, r->sq.p, (size_t)r->d * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(vdiff, r->sq.as<float>() + r->d, (size_t)r->d * sizeof(float), hipMemcpyDeviceToHost));
+    return KNHIP_OK;
+}
+
+// ScalarQuantizer::train, QT_8bit, RS_minmax with rangestat_arg 0 (impl/ScalarQuantizer.cpp train_NonUniform): vmin = column
+// minimum, vdiff = column maximum - vmin over ALL n rows (no sub-sampling for RS_minmax)
+int knhip_rows_train(knhip_rows* r, int64_t n, const float* x) {
+    if (!r || n < 0 || (n > 0 && !x)) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "rows_train: bad arguments");
+    }
+    if (r->row_type != KNHIP_ROWS_SQ8) {
+        return KNHIP_OK;
+    }
+    if (n == 0) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "rows_train: no training rows");
+    }
+    DeviceGuard g(r->device);
+    const int d = r->d;
+    std::vector<float> lo((size_t)d, INFINITY), hi((size_t)d, -INFINITY), a((size_t)d), b((size_t)d);
+    DevBuf dx, mm;
+    HIP_TRY(mm.alloc((size_t)2 * d * sizeof(float)));
+    const int64_t step = std::max<int64_t>(1, ((int64_t)1 << 30) / ((int64_t)d * 4));
+    for (int64_t i0 = 0; i0 < n; i0 += step) { // (min / max are order independent: slices of at most 1 GiB)
+        const int64_t m = std::min(step, n - i0);
+        if (int rc = upload(dx, x + i0 * d, (size_t)m * d * sizeof(float))) return rc;
+        HIP_TRY(launch_col_minmax(dx.as<float>(), m, d, mm.as<float>(), mm.as<float>() + d, nullptr));
+        HIP_TRY(hipMemcpy(a.data(), mm.p, (size_t)d * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(b.data(), mm.as<float>() + d, (size_t)d * sizeof(float), hipMemcpyDeviceToHost));
+        for (int j = 0; j < d; j++) {
+            lo[(size_t)j] = std::min(lo[(size_t)j], a[(size_t)j]);
+            hi[(size_t)j] = std::max(hi[(size_t)j], b[(size_t)j]);
+        }
+    }
+    for (int j = 0; j < d; j++) {
+        hi[(size_t)j] = hi[(size_t)j] - lo[(size_t)j];
+    }
+    return knhip_rows_set_trained(r, lo.data(), hi.data());
+}
+
+static int rows_append(knhip_rows* r, int64_t n, const void* d_new_codes) {
+    DevBuf all;
+    const size_t cs = (size_t)r->code_size();
+    HIP_TRY(all.alloc((size_t)(r->n + n) * cs));
+    if (r->n) {
+        HIP_TRY(hipMemcpy(all.p, r->codes.p, (size_t)r->n * cs, hipMemcpyDeviceToDevice));
+    }
+    HIP_TRY(hipMemcpy(static_cast<char*>(all.p) + (size_t)r->n * cs, d_new_codes, (size_t)n * cs, hipMemcpyDeviceToDevice));
+    std::swap(r->codes.p, all.p);
+    std::swap(r->codes.bytes, all.bytes);
+    r->n += n;
+    return KNHIP_OK;
+}
+
+// encode (ScalarQuantizer::compute_codes) and append: row r of the store is vector id r
+int knhip_rows_add(knhip_rows* r, int64_t n, const float* x) {
+    if (!r || n < 0 || (n > 0 && !x)) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "rows_add: bad arguments");
+    }
+    if (!r->trained) {
+        return fail(KNHIP_ERR_NOT_TRAINED, "rows_add: the sq8 ranges are not trained");
+    }
+    if (n == 0) {
+        return KNHIP_OK;
+    }
+    DeviceGuard g(r->device);
+    std::lock_guard<std::mutex> lk(r->mu);
+    const int d = r->d;
+    const int64_t step = std::max<int64_t>(1, ((int64_t)1 << 30) / ((int64_t)d * 4));
+    for (int64_t i0 = 0; i0 < n; i0 += step) {
+        const int64_t m = std::min(step, n - i0);
+        DevBuf dx, dc;
+        if (int rc = upload(dx, x + i0 * d, (size_t)m * d * sizeof(float))) return rc;
+        HIP_TRY(dc.alloc((size_t)m * r->code_size()));
+        if (r->row_type == KNHIP_ROWS_SQ8) {
+            HIP_TRY(launch_sq8_encode(dx.as<float>(), m, d, r->sq.as<float>(), dc.as<uint8_t>(), nullptr));
+        } else {
+            HIP_TRY(launch_rows_encode16(dx.as<float>(), m * d, r->row_type == KNHIP_ROWS_BF16, dc.as<uint16_t>(), nullptr));
+        }
+        HIP_TRY(hipDeviceSynchronize());
+        if (int rc = rows_append(r, m, dc.p)) return rc;
+    }
+    return KNHIP_OK;
+}
+
+int knhip_rows_add_codes(knhip_rows* r, int64_t n, const uint8_t* codes) {
+    if (!r || n < 0 || (n > 0 && !codes)) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "rows_add_codes: bad arguments");
+    }
+    if (n == 0) {
+        return KNHIP_OK;
+    }
+    DeviceGuard g(r->device);
+    std::lock_guard<std::mutex> lk(r->mu);
+    DevBuf dc;
+    if (int rc = upload(dc, codes, (size_t)n * r->code_size())) return rc;
+    return rows_append(r, n, dc.p);
+}
+
+int knhip_rows_get_codes(const knhip_rows* r, uint8_t* out) {
+    if (!r || !out) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "rows_get_codes: bad arguments");
+    }
+    DeviceGuard g(r->device);
+    if (r->n) {
+        HIP_TRY(hipMemcpy(out, r->codes.p, (size_t)r->n * r->code_size(), hipMemcpyDeviceToHost));
+    }
+    return KNHIP_OK;
+}
+
+int knhip_search_refine_rows(const knhip_index* idx, const knhip_rows* rows, const float* queries, int64_t nq, int32_t k,
+                             int32_t k_base, int32_t nprobe, const uint8_t* bitset, int64_t bitset_nbits, int64_t* out_ids,
+                             float* out_dist) {
+    if (!rows) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "search_refine_rows: null row store");
+    }
+    if (int rc = check_index(idx)) return rc;
+    if (rows->d != idx->d || rows->device != idx->desc.device || rows->n <= 0 || !rows->trained) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "search_refine_rows: a filled store of the same dimension on the same device");
+    }
+    RefineStore st;
+    st.rows = rows->codes.p;
+    st.n = rows->n;
+    st.id0 = 0;
+    st.row_type = rows->row_type;
+    st.sq = rows->row_type == KNHIP_ROWS_SQ8 ? rows->sq.as<float>() : nullptr;
+    return search_host_impl(idx, &st, queries, nq, k, k_base, nprobe, bitset, bitset_nbits, out_ids, out_dist);
 }
 
 // rows of a brute-force index by id (GetVectorByIds): ids are row + id_offset

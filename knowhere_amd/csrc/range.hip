@@ -318,7 +318,7 @@ hipError_t launch_pq_adc_dump(const PqDumpArgs& a, int64_t nq, bool is_l2, hipSt
     if (nq <= 0 || a.nprobe <= 0) {
         return hipSuccess;
     }
-    if (a.M <= 0 || a.M > 64 || a.d % a.M != 0) {
+    if (a.M <= 0 || a.M > 128 || a.d % a.M != 0) {
         return hipErrorInvalidValue;
     }
     const size_t sm = (size_t)a.M * 256 * sizeof(float);

@@ -9,22 +9,45 @@
 //   at the k-th distance v the ones kept are decided by arrival: a tie is eligible iff it is among the first k
 //   candidates with distance <= v (knhip_api.hip, search_batch_ties states the equivalence), and the result is the
 //   canonical top-k of {better than v} U {eligible ties}.  Applied here whenever more than k candidates reach v.
+// Quantised refine stores (Knowhere's `refine_type`, src/index/refine/refine_utils.cc:38-160: the refine index is an
+// IndexScalarQuantizer instead of IndexFlat): rows kept as fp16 / bf16 / per-dimension 8-bit codes; the distance is the
+// scalar quantizer's DistanceComputer (impl/scalar_quantizer/distance_computers.h, SIMDLevel::NONE): for i = 0 .. d - 1:
+// x_i = reconstruct_component(code, i), L2: tmp = q_i - x_i, accu += tmp * tmp; IP: accu += q_i * x_i -- the same
+// sequential sum with the decode in front (fp16: IEEE half -> float; bf16: bits << 16; 8 bit: vmin_i + vdiff_i *
+// ((code_i + 0.5) / 255), quantizers.h:139-145, codecs.h:37-41).
 // Distances use the reference's sequential fp32 order (fvec_L2sqr / fvec_inner_product), so they
 // are bit-equal to the CPU refine.  288 GB of HBM3E holds the raw vectors of a 100M x 128 index
 // (51 GB) next to its codes, so refine is a ~0.5 GB random gather per 10k-query batch: noise
 // next to the scan, and what lifts PQ32 recall@10 past 0.95.
+
 #include "common.h"
 #include "kernels.h"
 
 namespace knhip {
 
-template <bool IS_L2, int R>
+// ROWT: 0 fp32 rows, 1 fp16, 2 bf16, 3 per-dimension 8-bit codes (sq = vmin[d], vdiff[d])
+template <int ROWT>
+__device__ __forceinline__ float refine_row_value(const void* row, int i, const float* __restrict__ sq, int d) {
+    if (ROWT == 1) {
+        return (float)reinterpret_cast<const _Float16*>(row)[i]; // (exact: decode_fp16, utils/fp16-inl.h:88-108)
+    }
+    if (ROWT == 2) {
+        return __uint_as_float((uint32_t)reinterpret_cast<const uint16_t*>(row)[i] << 16);
+    }
+    if (ROWT == 3) {
+        const float xi = __fdiv_rn(fadd_x((float)reinterpret_cast<const uint8_t*>(row)[i], 0.5f), 255.0f);
+        return fadd_x(sq[i], fmul_x(xi, sq[d + i]));
+    }
+    return reinterpret_cast<const float*>(row)[i];
+}
+
+template <bool IS_L2, int R, int ROWT>
 __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ base, int64_t nbase,
                                                      int64_t id_base, int d,
                                                      const float* __restrict__ queries, int64_t nq,
                                                      const int64_t* __restrict__ cand, int kbase, int k,
                                                      float* __restrict__ out_d,
-                                                     int64_t* __restrict__ out_i) {
+                                                     int64_t* __restrict__ out_i, const float* __restrict__ sq_trained) {
     extern __shared__ __align__(16) float sq[]; // [4][d] queries, then [4][kbase] the candidates' distances
     const int lane = lane_id();
     const int wave = threadIdx.x / KN_WAVE;
@@ -65,7 +88,50 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ b
         const bool ok = lane < nvalid && id >= 0 && (id - id_base) >= 0 && (id - id_base) < nbase;
         skipped = skipped || __ballot(lane < nvalid && !ok) != 0ull;
         float acc = 0.f;
-        if (ok) {
+        if (ok && ROWT != 0) {
+            // quantised rows: decode + accumulate, element by element in the reference's order
+            constexpr int ESZ = ROWT == 3 ? 1 : 2;
+            constexpr int EPC = 16 / ESZ; // elements per 16-byte piece
+            const unsigned char* y = reinterpret_cast<const unsigned char*>(base) + (id - id_base) * (int64_t)d * ESZ;
+            int i = 0;
+            if (((d * ESZ) & 15) == 0 && (reinterpret_cast<uintptr_t>(base) & 15) == 0) {
+                // 16-byte loads, eight in flight per lane (as the fp32 rows below); decoded and added in element order
+                const uint4* y4 = reinterpret_cast<const uint4*>(y);
+                const int n16 = (d * ESZ) >> 4;
+                for (int j = 0; j < n16; j += 8) {
+                    uint4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        v[u] = j + u < n16 ? y4[j + u] : make_uint4(0u, 0u, 0u, 0u);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        if (j + u < n16) {
+                            const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                            for (int e = 0; e < EPC; e++) {
+                                const int col = (j + u) * EPC + e;
+                                float x;
+                                if (ROWT == 3) {
+                                    const float xi = __fdiv_rn(fadd_x((float)((w[e >> 2] >> (8 * (e & 3))) & 0xffu), 0.5f), 255.0f);
+                                    x = fadd_x(sq_trained[col], fmul_x(xi, sq_trained[d + col]));
+                                } else {
+                                    const uint32_t hb = (w[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+                                    x = ROWT == 1 ? (float)__builtin_bit_cast(_Float16, (uint16_t)hb) : __uint_as_float(hb << 16);
+                                }
+                                acc = IS_L2 ? l2_step(acc, myq[col], x) : ip_step(acc, myq[col], x);
+                            }
+                        }
+                    }
+                }
+                i = d;
+            }
+            for (; i < d; i++) {
+                const float x = refine_row_value<ROWT>(y, i, sq_trained, d);
+                acc = IS_L2 ? l2_step(acc, myq[i], x) : ip_step(acc, myq[i], x);
+            }
+        }
+        if (ok && ROWT == 0) {
             const float* y = base + (id - id_base) * d;
             int i = 0;
             if ((d & 3) == 0 && (reinterpret_cast<uintptr_t>(base) & 15) == 0) {
@@ -163,21 +229,73 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ b
 
 hipError_t launch_refine(const float* base, int64_t nbase, int64_t id_base, int d, const float* queries,
                          int64_t nq, const int64_t* cand, int kbase, int k, bool is_l2, float* out_d,
-                         int64_t* out_i, hipStream_t s) {
+                         int64_t* out_i, hipStream_t s, int row_type, const float* sq_trained) {
     if (nq <= 0) {
         return hipSuccess;
     }
+    if (row_type < 0 || row_type > 3 || (row_type == 3 && sq_trained == nullptr)) {
+        return hipErrorInvalidValue;
+    }
     const unsigned grid = (unsigned)((nq + 3) / 4);
     const size_t sm = ((size_t)4 * d + (size_t)4 * kbase) * sizeof(float);
-    KN_DISPATCH_R(k, {
-        if (is_l2) {
-            hipLaunchKernelGGL((refine_kernel<true, R_>), dim3(grid), dim3(256), sm, s, base, nbase, id_base,
-                               d, queries, nq, cand, kbase, k, out_d, out_i);
-        } else {
-            hipLaunchKernelGGL((refine_kernel<false, R_>), dim3(grid), dim3(256), sm, s, base, nbase, id_base,
-                               d, queries, nq, cand, kbase, k, out_d, out_i);
-        }
-    });
+#define KN_REFINE_LAUNCH(ROWT_)                                                                                       \
+    KN_DISPATCH_R(k, {                                                                                                \
+        if (is_l2) {                                                                                                  \
+            hipLaunchKernelGGL((refine_kernel<true, R_, ROWT_>), dim3(grid), dim3(256), sm, s, base, nbase, id_base,  \
+                               d, queries, nq, cand, kbase, k, out_d, out_i, sq_trained);                            \
+        } else {                                                                                                      \
+            hipLaunchKernelGGL((refine_kernel<false, R_, ROWT_>), dim3(grid), dim3(256), sm, s, base, nbase, id_base, \
+                               d, queries, nq, cand, kbase, k, out_d, out_i, sq_trained);                            \
+        }                                                                                                             \
+    })
+    switch (row_type) {
+        case 1: KN_REFINE_LAUNCH(1); break;
+        case 2: KN_REFINE_LAUNCH(2); break;
+        case 3: KN_REFINE_LAUNCH(3); break;
+        default: KN_REFINE_LAUNCH(0); break;
+    }
+#undef KN_REFINE_LAUNCH
+    return hipGetLastError();
+}
+
+// ---- encoders of the quantised refine stores (ScalarQuantizer::compute_codes: QuantizerFP16 / QuantizerBF16) -------------
+// bf16: utils/bf16.h:28-33 encode_bf16 = (bits + 0x8000) >> 16.
+// fp16: the reference's scalar encode_fp16 (utils/fp16-inl.h:32-86, what SIMDLevel::NONE code is built with): the low 12 bits
+// are masked off, the value is rescaled by 2^-112 in fp32 (half subnormals become fp32 subnormals), half a unit is added and
+// bits 13.. are taken -- round HALF UP of the 11-bit truncation, not round-to-nearest-even (exact ties go up, so
+// __float2half_rn would differ there).  Integer form of the same arithmetic (no dependence on the fp32 denormal mode);
+// proven equal to the reference's on all 2^20 classes in tests/test_refine_rows.py.
+__device__ __forceinline__ uint16_t encode_fp16_ref(float f) {
+    const uint32_t bits = __float_as_uint(f), sign = (bits >> 16) & 0x8000u, fint = bits & 0x7fffffffu;
+    if (fint >= 0x7f800000u) {
+        return (uint16_t)(sign | (fint > 0x7f800000u ? 0x7e00u : 0x7c00u));
+    }
+    const uint32_t t = fint & ~0xfffu, E = t >> 23;
+    uint32_t b;
+    if (E >= 113u) {
+        b = t - (112u << 23);
+    } else {
+        const uint32_t sh = 113u - E;
+        b = sh <= 12u ? (((t & 0x7fffffu) | (E ? 0x800000u : 0u)) >> sh) : 0u; // (the shift is exact: 12 zero low bits)
+    }
+    b = min(b, (31u << 23) - 0x1000u);
+    return (uint16_t)(sign | ((b + 0x1000u) >> 13));
+}
+
+__global__ void rows_encode16_kernel(const float* __restrict__ x, int64_t n, int bf16, uint16_t* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) {
+        return;
+    }
+    out[t] = bf16 ? (uint16_t)((__float_as_uint(x[t]) + 0x8000u) >> 16) : encode_fp16_ref(x[t]);
+}
+
+hipError_t launch_rows_encode16(const float* x, int64_t n_elems, bool bf16, uint16_t* out, hipStream_t s) {
+    if (n_elems <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(rows_encode16_kernel, dim3((unsigned)((n_elems + 255) / 256)), dim3(256), 0, s, x, n_elems, bf16 ? 1 : 0,
+                       out);
     return hipGetLastError();
 }
 

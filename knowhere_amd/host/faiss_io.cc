@@ -265,9 +265,28 @@ bool ParseFaissIndex(const uint8_t* data, size_t size, FaissIndexData* out, std:
             out->has_refine = true;
             ReadHeader(r, out->refine_hdr);
             ReadBody(r, r.one<uint32_t>(), *out);
-            out->refine_index.fourcc = r.one<uint32_t>();
-            if (!IsFlat(out->refine_index.fourcc)) throw std::runtime_error("refine index is not a flat fp32 index");
-            ReadFlatBody(r, out->refine_index);
+            const uint32_t rcc = r.one<uint32_t>();
+            if (rcc == FourCC("IxSQ")) {
+                FaissSQFlat& q = out->refine_sq;
+                out->refine_is_sq = true;
+                ReadHeader(r, q.hdr);
+                q.qtype = r.one<int32_t>();
+                q.rangestat = r.one<int32_t>();
+                q.rangestat_arg = r.one<float>();
+                q.d = r.one<uint64_t>();
+                q.code_size = r.one<uint64_t>();
+                r.vec(q.trained);
+                r.vec(q.codes);
+                const uint64_t want = q.qtype == 0 ? q.d : (q.qtype == 4 || q.qtype == 7) ? 2 * q.d : 0;
+                if (want == 0) throw std::runtime_error("refine scalar quantizer type is not fp16 / bf16 / sq8");
+                if (q.d != (uint64_t)q.hdr.d || q.code_size != want || q.codes.size() != (uint64_t)q.hdr.ntotal * want ||
+                    q.trained.size() != (q.qtype == 0 ? 2 * q.d : 0))
+                    throw std::runtime_error("refine scalar quantizer shape mismatch");
+            } else {
+                out->refine_index.fourcc = rcc;
+                if (!IsFlat(rcc)) throw std::runtime_error("refine index is neither flat fp32 nor a scalar quantizer store");
+                ReadFlatBody(r, out->refine_index);
+            }
             out->k_factor = r.one<float>();
         } else {
             ReadBody(r, h, *out);
@@ -288,7 +307,20 @@ bool WriteFaissIndex(const FaissIndexData& in, std::vector<uint8_t>* out, std::s
             w.one<uint32_t>(FourCC("IxRF"));
             WriteHeader(w, in.refine_hdr);
             WriteBody(w, in);
-            WriteFlat(w, in.refine_index);
+            if (in.refine_is_sq) {
+                const FaissSQFlat& q = in.refine_sq;
+                w.one<uint32_t>(FourCC("IxSQ"));
+                WriteHeader(w, q.hdr);
+                w.one<int32_t>(q.qtype);
+                w.one<int32_t>(q.rangestat);
+                w.one<float>(q.rangestat_arg);
+                w.one<uint64_t>(q.d);
+                w.one<uint64_t>(q.code_size);
+                w.vec(q.trained);
+                w.vec(q.codes);
+            } else {
+                WriteFlat(w, in.refine_index);
+            }
             w.one<float>(in.k_factor);
         } else {
             WriteBody(w, in);

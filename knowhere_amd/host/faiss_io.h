@@ -26,6 +26,7 @@
 //                                                  [, float norms for Knowhere's cosine IVF-Flat,
 //                                                  cppcontrib/knowhere/impl/index_write.cpp:299-306]}
 //   impl/index_write.cpp:849-858   "IxRF"        {index header; base index; refine index; float k_factor}
+//   impl/index_write.cpp:692-699   "IxSQ"        {index header; scalar quantizer; codes} (a quantised refine index)
 // vector<T> = {size_t n; T[n]}.  Everything little-endian, unaligned.
 //
 // Parse() followed by Write() reproduces the input bytes exactly (tests/test_faiss_io.py).
@@ -58,11 +59,23 @@ struct FaissFlat {  // "IxF2" / "IxFI"
     std::vector<float> xb;
 };
 
+struct FaissSQFlat {  // "IxSQ": faiss::IndexScalarQuantizer (impl/index_write.cpp:692-699, write_ScalarQuantizer :262-269)
+    FaissHeader hdr;
+    int32_t qtype = 0, rangestat = 0;  // QuantizerType: 0 QT_8bit, 4 QT_fp16, 7 QT_bf16; RangeStat 0 = RS_minmax
+    float rangestat_arg = 0.f;
+    uint64_t d = 0, code_size = 0;
+    std::vector<float> trained;
+    std::vector<uint8_t> codes;       // [ntotal][code_size]
+};
+
 struct FaissIndexData {
-    // outer IndexRefine wrapper ("IxRF"), present when an IVF-PQ / IVF-SQ8 index was built with refine
+    // outer IndexRefine wrapper ("IxRF"), present when an IVF-PQ / IVF-SQ8 index was built with refine; the refine index
+    // is flat fp32 (refine_index) or, for refine_type = fp16 / bf16 / sq8, a scalar quantizer store (refine_sq)
     bool has_refine = false;
+    bool refine_is_sq = false;
     FaissHeader refine_hdr;
     FaissFlat refine_index;
+    FaissSQFlat refine_sq;
     float k_factor = 1.f;
 
     uint32_t fourcc = 0;  // IwFl / IwSq / IwPQ / IxF2 / IxFI

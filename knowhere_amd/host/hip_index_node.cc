@@ -123,11 +123,25 @@ struct KnhipHandle {
     }
 };
 
+struct RowsHandle {
+    knhip_rows* p = nullptr;
+    RowsHandle() = default;
+    RowsHandle(const RowsHandle&) = delete;
+    RowsHandle& operator=(const RowsHandle&) = delete;
+    RowsHandle(RowsHandle&& o) noexcept : p(o.p) { o.p = nullptr; }
+    RowsHandle& operator=(RowsHandle&& o) noexcept {
+        std::swap(p, o.p);
+        return *this;
+    }
+    ~RowsHandle() { knhip_rows_destroy(p); }
+};
+
 // one device's part of an index: everything (single device) or the inverted lists / row range this device owns
 struct Shard {
     int32_t device = 0;
     KnhipHandle idx;
     KnhipHandle raw;       // refine rows (IndexRefineFlat) whose ids are [raw_base, raw_base + count(raw))
+    RowsHandle rows;       // quantised refine rows (refine_type fp16 / bf16 / sq8: IndexScalarQuantizer), single device
     int64_t raw_base = 0;
     int64_t row_base = 0;  // sharded FLAT: id of this shard's first row
 };
@@ -230,31 +244,55 @@ class HipIndexNode : public IndexNode {
             default_nprobe_ = c.nprobe.value_or(8);
         }
         if constexpr (Kind == KNHIP_IVF_PQ) {
-            // m = 0: the backend picks, as cuVS does for pq_dim = 0 (about dim / 2): the largest supported m that
-            // leaves sub-vectors of at least 2 dims.  An explicit m is honoured or refused, never rewritten (the reference
-            // honours any m that divides dim; this backend has kernels for 8, 16, 32 and 64 sub-quantizers)
+            // m = 0: the backend picks, as cuVS does for pq_dim = 0 (about dim / 2): the largest m with a fast kernel (8,
+            // 16, 32, 64) that divides dim and leaves sub-vectors of at least 2 dims, else the largest divisor of dim up to
+            // min(128, dim / 2).  An explicit m is honoured (any divisor of dim up to 128 with sub-vectors of at most 144
+            // dims, as the reference honours any divisor) or refused, never rewritten
             const bool auto_m = c.m.value_or(0) == 0;
-            m_ = auto_m ? std::min<int64_t>(64, dim_ / 2) : c.m.value();
-            while (auto_m && m_ > 1 && (dim_ % m_ != 0 || !(m_ == 8 || m_ == 16 || m_ == 32 || m_ == 64))) m_--;
-            if (dim_ % m_ != 0 || !(m_ == 8 || m_ == 16 || m_ == 32 || m_ == 64)) return Status::invalid_args;
+            auto fast = [](int64_t m) { return m == 8 || m == 16 || m == 32 || m == 64; };
+            auto fits = [&](int64_t m) { return m >= 1 && m <= 128 && dim_ % m == 0 && dim_ / m <= 144; };
+            if (auto_m) {
+                m_ = 0;
+                for (int64_t m = std::min<int64_t>(64, dim_ / 2); m >= 8 && m_ == 0; m--) {
+                    if (fast(m) && fits(m)) m_ = m;
+                }
+                for (int64_t m = std::min<int64_t>(128, std::max<int64_t>(1, dim_ / 2)); m >= 1 && m_ == 0; m--) {
+                    if (fits(m)) m_ = m;
+                }
+            } else {
+                m_ = c.m.value();
+            }
+            if (!fits(m_)) return Status::invalid_args;
         }
         if constexpr (Kind == KNHIP_IVF_PQ || Kind == KNHIP_IVF_SQ8) {
-            has_refine_ = c.refine.value_or(false);
-            // refine_type (ivf_config.h:113-135, refine_utils.cc:38-58): the raw-row store of this backend is fp32
-            // (is_flat_refine: unset / "fp32" / "flat"); the quantised stores (SQ6 / SQ8 / FP16 / BF16) are refused, not
-            // silently replaced by a bigger one
-            if (has_refine_ && c.refine_type.has_value()) {
+            // a refine index is built iff `refine` AND `refine_type` are given (ivf_wrapper.cc:170, :214).  refine_type
+            // (ivf_config.h:64-76, refine_utils.cc:20-58): fp32 / flat = IndexRefineFlat over the raw rows; fp16 / bf16 / sq8
+            // = IndexRefine over an IndexScalarQuantizer store of the rows (knhip_rows); sq6 is refused, not replaced
+            has_refine_ = c.refine.value_or(false) && c.refine_type.has_value();
+            refine_rows_type_ = 0;
+            if (has_refine_) {
                 std::string t = c.refine_type.value();
                 for (auto& ch : t) ch = (char)std::tolower((unsigned char)ch);
-                if (t != "fp32" && t != "flat") {
+                if (t == "fp16") {
+                    refine_rows_type_ = KNHIP_ROWS_FP16;
+                } else if (t == "bf16") {
+                    refine_rows_type_ = KNHIP_ROWS_BF16;
+                } else if (t == "sq8") {
+                    refine_rows_type_ = KNHIP_ROWS_SQ8;
+                } else if (t != "fp32" && t != "flat") {
                     LOG_KNOWHERE_ERROR_ << TypeName() << ": refine_type " << c.refine_type.value()
-                                        << " is not supported (fp32 rows only)";
+                                        << " is not supported (fp32 / flat / fp16 / bf16 / sq8)";
                     return Status::invalid_args;
                 }
             }
         }
         std::vector<int32_t> devs;
         if (Status st = SelectDevices(c, /*deserialize=*/false, &devs); st != Status::success) return st;
+        if (refine_rows_type_ != 0 && devs.size() > 1) {
+            LOG_KNOWHERE_ERROR_ << TypeName() << ": a quantised refine store (refine_type fp16 / bf16 / sq8) lives on one "
+                                << "device; gpu_ids asks for " << devs.size();
+            return Status::invalid_args;
+        }
         if (Status st = CreateShards(devs); st != Status::success) return st;
         if constexpr (Kind == KNHIP_BRUTE_FORCE) {
             return Status::success;  // nothing to train
@@ -269,6 +307,11 @@ class HipIndexNode : public IndexNode {
         // the reference's clustering defaults, on the first device; the trained state is replicated on the others
         int rc = knhip_index_train(sh_[0].idx.p, rows, x, nullptr);
         if (rc == KNHIP_OK && sh_.size() > 1) rc = ReplicateTrainedState();
+        if (rc == KNHIP_OK && refine_rows_type_ != 0) {
+            // IndexRefine::train trains the refine index on the same rows (IndexRefine.cpp:47-51): the sq8 ranges
+            rc = knhip_rows_create(sh_[0].device, (int32_t)dim_, refine_rows_type_, &sh_[0].rows.p);
+            if (rc == KNHIP_OK) rc = knhip_rows_train(sh_[0].rows.p, rows, x);
+        }
         if (rc) {
             DropShards();
             return ToStatus(rc);
@@ -325,7 +368,10 @@ class HipIndexNode : public IndexNode {
         if (StoredNormCosine()) {
             if (Status st = PushRowScale(); st != Status::success) return st;
         }
-        if (NeedRawStore()) {
+        if (NeedRawStore() && refine_rows_type_ != 0) {
+            if (!sh_[0].rows.p) return Status::index_not_trained;
+            if ((rc = knhip_rows_add(sh_[0].rows.p, rows, x_store))) return ToStatus(rc);
+        } else if (NeedRawStore()) {
             for (auto& s : sh_) {
                 if (!s.raw.p) {
                     knhip_desc rd{};
@@ -384,21 +430,24 @@ class HipIndexNode : public IndexNode {
         {
             std::shared_lock<std::shared_mutex> lk(rw_);
             // use_refine = the index carries a refine index (ivf.cc:1080-1092); k_factor = refine_k
+            // with k_factor 1 (the default refine_k) the reference still re-scores the k results against the refine index
+            // and re-sorts them (IndexRefine::search, k_base == k): so does this node
             int64_t kbase = k;
+            bool use_refine = false;
             if constexpr (Kind == KNHIP_IVF_PQ || Kind == KNHIP_IVF_SQ8) {
-                if (has_refine_ && sh_[0].raw.p && c.refine_k.has_value()) {
+                if (has_refine_ && (sh_[0].raw.p || sh_[0].rows.p) && c.refine_k.has_value()) {
+                    use_refine = true;
                     const int64_t want = std::max<int64_t>(k, (int64_t)(k * c.refine_k.value()));
                     kbase = std::min<int64_t>(1024, want);
                     if (kbase < want) {  // (the first stage returns at most 1024 candidates per query: said, not hidden)
-                        LOG_KNOWHERE_WARNING_ << "GPU_HIP refine: k * refine_k = " << want << " clamped to " << kbase
-                                              << (kbase <= k ? " (refine stage skipped)" : "");
+                        LOG_KNOWHERE_WARNING_ << "GPU_HIP refine: k * refine_k = " << want << " clamped to " << kbase;
                     }
                 }
             }
             if (sh_.size() > 1) {
                 // list-sharded: every device scans the lists it owns, one all-gather of the partial top-k, device merge
                 // (include/knhip_shards.h); with refine every device re-ranks the candidates whose rows it holds
-                if (kbase > k) {
+                if (use_refine) {
                     rc = knhip_shard_group_search_refine(group_.p, q, nq, (int32_t)k, (int32_t)kbase, (int32_t)nprobe, bits,
                                                          nbits, ids.get(), dis.get(), nullptr);
                 } else {
@@ -406,7 +455,10 @@ class HipIndexNode : public IndexNode {
                                                   dis.get(), nullptr);
                 }
                 if (rc) err_text = knhip_shard_group_last_error();
-            } else if (kbase > k) {
+            } else if (use_refine && sh_[0].rows.p) {
+                rc = knhip_search_refine_rows(sh_[0].idx.p, sh_[0].rows.p, q, nq, (int32_t)k, (int32_t)kbase, (int32_t)nprobe,
+                                              bits, nbits, ids.get(), dis.get());
+            } else if (use_refine) {
                 rc = knhip_search_refine(sh_[0].idx.p, sh_[0].raw.p, q, nq, (int32_t)k, (int32_t)kbase, (int32_t)nprobe, bits,
                                          nbits, ids.get(), dis.get());
             } else {
@@ -652,7 +704,25 @@ class HipIndexNode : public IndexNode {
                     for (int64_t j = 0; j < all_sizes[l]; j++) x.norms[l][(size_t)j] = row_scale_by_id_[(size_t)x.ids[l][(size_t)j]];
                 }
             }
-            if (has_refine_ && sh_[0].raw.p) {  // IndexRefineFlat (ivf.cc:673-700)
+            if (has_refine_ && sh_[0].rows.p) {  // IndexRefine over an IndexScalarQuantizer ("IxSQ", refine_utils.cc:150-185)
+                const knhip_rows* rs = sh_[0].rows.p;
+                if (knhip_rows_count(rs) != count) return Status::invalid_index_error;
+                x.has_refine = x.refine_is_sq = true;
+                fill_hdr(x.refine_hdr, count, cosine_);
+                FaissSQFlat& sq = x.refine_sq;
+                fill_hdr(sq.hdr, count, false);
+                sq.qtype = refine_rows_type_ == KNHIP_ROWS_FP16 ? 4 : (refine_rows_type_ == KNHIP_ROWS_BF16 ? 7 : 0);
+                sq.rangestat = 0;  // RS_minmax, rangestat_arg 0: the ScalarQuantizer defaults
+                sq.d = (uint64_t)dim_;
+                sq.code_size = (uint64_t)knhip_rows_code_size(rs);
+                if (refine_rows_type_ == KNHIP_ROWS_SQ8) {
+                    sq.trained.resize((size_t)2 * dim_);
+                    if ((rc = knhip_rows_get_trained(rs, sq.trained.data(), sq.trained.data() + dim_))) return ToStatus(rc);
+                }
+                sq.codes.resize((size_t)count * sq.code_size);
+                if ((rc = knhip_rows_get_codes(rs, sq.codes.data()))) return ToStatus(rc);
+                x.k_factor = 1.f;
+            } else if (has_refine_ && sh_[0].raw.p) {  // IndexRefineFlat (ivf.cc:673-700)
                 x.has_refine = true;
                 fill_hdr(x.refine_hdr, count, cosine_);
                 x.refine_index.fourcc = flat_cc;
@@ -703,7 +773,7 @@ class HipIndexNode : public IndexNode {
                 return Status::invalid_serialized_index_type;
             const uint64_t want_cs = Kind == KNHIP_IVF_FLAT ? (uint64_t)d * 4 : Kind == KNHIP_IVF_PQ ? x.pq_M : (uint64_t)d;
             if (Kind == KNHIP_IVF_PQ &&
-                (x.pq_nbits != 8 || !x.by_residual || !(x.pq_M == 8 || x.pq_M == 16 || x.pq_M == 32 || x.pq_M == 64)))
+                (x.pq_nbits != 8 || !x.by_residual || x.pq_M < 1 || x.pq_M > 128 || (uint64_t)d / x.pq_M > 144))
                 return Status::not_implemented;
             if (Kind == KNHIP_IVF_PQ && (x.pq_d != (uint64_t)d || d % (int64_t)x.pq_M != 0 ||
                                           x.pq_centroids.size() != (size_t)256 * d))
@@ -723,8 +793,9 @@ class HipIndexNode : public IndexNode {
             }
             if (sum != ntotal) return Status::invalid_serialized_index_type;
             if (x.has_refine) {
-                if (x.refine_index.hdr.ntotal != ntotal || x.refine_index.hdr.d != d ||
-                    x.refine_index.xb.size() != (size_t)ntotal * d)
+                if (x.refine_is_sq ? (x.refine_sq.hdr.ntotal != ntotal || x.refine_sq.hdr.d != d)
+                                   : (x.refine_index.hdr.ntotal != ntotal || x.refine_index.hdr.d != d ||
+                                      x.refine_index.xb.size() != (size_t)ntotal * d))
                     return Status::invalid_serialized_index_type;
                 for (uint64_t l = 0; l < x.nlist; l++) {
                     for (int64_t id : x.ids[l]) {
@@ -783,6 +854,14 @@ class HipIndexNode : public IndexNode {
         if (x.nprobe >= 1 && x.nprobe <= 65536) default_nprobe_ = (int64_t)x.nprobe;  // the index's default nprobe
         m_ = (int64_t)x.pq_M;
         has_refine_ = x.has_refine;
+        refine_rows_type_ = !(x.has_refine && x.refine_is_sq) ? 0
+                            : x.refine_sq.qtype == 4          ? KNHIP_ROWS_FP16
+                            : x.refine_sq.qtype == 7          ? KNHIP_ROWS_BF16
+                                                              : KNHIP_ROWS_SQ8;
+        if (refine_rows_type_ != 0 && devs.size() > 1) {
+            LOG_KNOWHERE_ERROR_ << TypeName() << ": a quantised refine store lives on one device; gpu_ids asks for " << devs.size();
+            return Status::invalid_args;
+        }
         row_scale_by_id_ = std::move(scale_by_id);
         if (Status st = CreateShards(devs); st != Status::success) return st;
         const int W = (int)sh_.size();
@@ -821,6 +900,15 @@ class HipIndexNode : public IndexNode {
         if (StoredNormCosine()) {
             const Status st = PushRowScale();
             if (st != Status::success) return st;
+        }
+        if (x.has_refine && x.refine_is_sq) {
+            const FaissSQFlat& sq = x.refine_sq;
+            if ((rc = knhip_rows_create(sh_[0].device, (int32_t)dim_, refine_rows_type_, &sh_[0].rows.p))) return bail(rc);
+            if (refine_rows_type_ == KNHIP_ROWS_SQ8 &&
+                (rc = knhip_rows_set_trained(sh_[0].rows.p, sq.trained.data(), sq.trained.data() + dim_)))
+                return bail(rc);
+            if ((rc = knhip_rows_add_codes(sh_[0].rows.p, ntotal, sq.codes.data()))) return bail(rc);
+            return Status::success;
         }
         // raw rows for refine, in id order
         if (x.has_refine && !x.refine_index.xb.empty()) {
@@ -904,7 +992,8 @@ class HipIndexNode : public IndexNode {
     Size() const override {
         int64_t b = 0;
         for (const auto& s : sh_) {
-            b += (s.idx.p ? knhip_index_device_bytes(s.idx.p) : 0) + (s.raw.p ? knhip_index_device_bytes(s.raw.p) : 0);
+            b += (s.idx.p ? knhip_index_device_bytes(s.idx.p) : 0) + (s.raw.p ? knhip_index_device_bytes(s.raw.p) : 0) +
+                 (s.rows.p ? knhip_rows_device_bytes(s.rows.p) : 0);
         }
         return b;
     }
@@ -1186,6 +1275,7 @@ class HipIndexNode : public IndexNode {
 
     int metric_ = KNHIP_L2;
     bool cosine_ = false, has_refine_ = false;
+    int32_t refine_rows_type_ = 0;  // 0: fp32 rows (IndexRefineFlat); KNHIP_ROWS_*: a quantised store (single device)
     std::vector<float> row_scale_by_id_;  // StoredNormCosine(): FLAT inverse L2 norms, IVF_FLAT L2 norms, by row id
     std::string metric_name_ = metric::L2;
     int64_t dim_ = 0, nlist_ = 0, m_ = 0, default_nprobe_ = 8;

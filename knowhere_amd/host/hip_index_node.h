@@ -153,12 +153,18 @@ struct HipIvfPqConfig : public IvfPqConfig {
         RETURN_IF_ERROR(HipCheckMetric(*this, param_type, err_msg));
         if (param_type == PARAM_TYPE::TRAIN && m.has_value() && m.value() != 0) {
             const int mv = m.value();
-            if (!(mv == 8 || mv == 16 || mv == 32 || mv == 64)) {
-                if (err_msg) *err_msg = "GPU_HIP_IVF_PQ supports m in {0 (auto), 8, 16, 32, 64}";
+            // (the reference takes any m that divides dim, ivf_config.h:118, :138-147; here 8, 16, 32, 64 run on the fast
+            // kernels and every other m up to 128 on the plain exact one, sub-vectors of at most 144 dimensions)
+            if (mv < 0 || mv > 128) {
+                if (err_msg) *err_msg = "GPU_HIP_IVF_PQ supports m in 0 (auto), 1 ... 128";
                 return Status::invalid_args;
             }
             if (dim.has_value() && dim.value() % mv != 0) {
                 if (err_msg) *err_msg = "The dimension of a vector (dim) should be a multiple of the number of subquantizers (m)";
+                return Status::invalid_args;
+            }
+            if (dim.has_value() && dim.value() / mv > 144) {
+                if (err_msg) *err_msg = "GPU_HIP_IVF_PQ: sub-vectors (dim / m) of more than 144 dimensions are not supported";
                 return Status::invalid_args;
             }
         }

@@ -236,6 +236,19 @@ class GpuIndex:
                                          _np_ptr(I), _np_ptr(D)))
         return D, I
 
+    def search_refine_rows(self, rows, xq, k, k_base, nprobe=1, bitset=None, nbits=0):
+        """knhip_search_refine_rows: as search_refine with the second stage reading a quantised RowStore (refine_type =
+        fp16 / bf16 / sq8)"""
+        xq = np.ascontiguousarray(xq, np.float32)
+        nq = xq.shape[0]
+        D = np.empty((nq, k), np.float32)
+        I = np.empty((nq, k), np.int64)
+        bs = None if bitset is None else np.ascontiguousarray(bitset, np.uint8)
+        nbits = _bitset_nbits(bs, nbits)
+        check(self.L.knhip_search_refine_rows(self.h, rows.h, _np_ptr(xq), nq, k, k_base, nprobe, _np_ptr(bs), nbits,
+                                              _np_ptr(I), _np_ptr(D)))
+        return D, I
+
     def get_vectors(self, ids):
         """stored fp32 rows by id (knhip_index_get_vectors: BRUTE_FORCE, or IVF_FLAT through its direct map)"""
         ids = np.ascontiguousarray(ids, np.int64)
@@ -366,3 +379,60 @@ def refine_device(metric, base_t, xq_t, cand_ids_t, k, id_base=0, stream=None):
     check(L.knhip_refine_device(metric, base_t.shape[1], _t_ptr(base_t), base_t.shape[0], id_base, _t_ptr(xq_t), nq,
                                 _t_ptr(cand_ids_t), kbase, k, _t_ptr(D), _t_ptr(I), C.c_void_p(s)))
     return D, I
+
+
+ROWS_FP16, ROWS_BF16, ROWS_SQ8 = 1, 2, 3
+
+
+class RowStore:
+    """knhip_rows: the encoded raw vectors a quantised refine reads (include/knhip.h; the reference's
+    faiss::IndexScalarQuantizer refine index, src/index/refine/refine_utils.cc:150-185).  Row r = vector id r."""
+
+    def __init__(self, row_type, dim, device=0):
+        self.L = _lib.load()
+        self.row_type, self.dim = row_type, dim
+        h = C.c_void_p()
+        check(self.L.knhip_rows_create(device, dim, row_type, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.L.knhip_rows_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def train(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        check(self.L.knhip_rows_train(self.h, x.shape[0], _np_ptr(x)))
+
+    def set_trained(self, trained):
+        t = np.ascontiguousarray(trained, np.float32)
+        check(self.L.knhip_rows_set_trained(self.h, _np_ptr(t[:self.dim]), _np_ptr(np.ascontiguousarray(t[self.dim:]))))
+
+    def trained(self):
+        t = np.empty(2 * self.dim, np.float32)
+        lo, hi = t[:self.dim], np.empty(self.dim, np.float32)
+        check(self.L.knhip_rows_get_trained(self.h, _np_ptr(lo), _np_ptr(hi)))
+        t[self.dim:] = hi
+        return t
+
+    def add(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        check(self.L.knhip_rows_add(self.h, x.shape[0], _np_ptr(x)))
+
+    def add_codes(self, codes):
+        c = np.ascontiguousarray(codes, np.uint8)
+        check(self.L.knhip_rows_add_codes(self.h, c.shape[0], _np_ptr(c)))
+
+    def count(self):
+        return int(self.L.knhip_rows_count(self.h))
+
+    def codes(self):
+        out = np.empty((self.count(), int(self.L.knhip_rows_code_size(self.h))), np.uint8)
+        check(self.L.knhip_rows_get_codes(self.h, _np_ptr(out)))
+        return out

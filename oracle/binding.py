@@ -384,6 +384,41 @@ class Port(_SimdTable):
                             C.c_int64(k), _p(D, _f32p), _p(I, _i64p))
         return D, I
 
+    # ---- quantised refine store (row_type 1 fp16, 2 bf16, 3 sq8)
+    def rows_train(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        tr = np.empty(2 * x.shape[1], np.float32)
+        self.lib.orc_rows_train(C.c_int(x.shape[1]), C.c_int64(x.shape[0]), _p(x, _f32p), _p(tr, _f32p))
+        return tr
+
+    def rows_encode(self, row_type, x, trained=None):
+        x = np.ascontiguousarray(x, np.float32)
+        n, d = x.shape
+        cs = d if row_type == 3 else 2 * d
+        codes = np.empty((n, cs), np.uint8)
+        self.lib.orc_rows_encode(C.c_int(row_type), C.c_int(d), C.c_int64(n), _p(x, _f32p), _p(trained, _f32p),
+                                 _p(codes, _u8p))
+        return codes
+
+    def rows_decode(self, row_type, d, codes, trained=None):
+        codes = np.ascontiguousarray(codes, np.uint8)
+        x = np.empty((codes.shape[0], d), np.float32)
+        self.lib.orc_rows_decode(C.c_int(row_type), C.c_int(d), C.c_int64(codes.shape[0]), _p(codes, _u8p),
+                                 _p(trained, _f32p), _p(x, _f32p))
+        return x
+
+    def refine_rows(self, metric, row_type, d, codes, trained, xq, cand_ids, k):
+        codes = np.ascontiguousarray(codes, np.uint8)
+        xq = np.ascontiguousarray(xq, np.float32)
+        cand = np.ascontiguousarray(cand_ids, np.int64)
+        nq, kb = cand.shape
+        D = np.empty((nq, k), np.float32)
+        I = np.empty((nq, k), np.int64)
+        self.lib.orc_refine_rows(C.c_int(metric), C.c_int(d), C.c_int(row_type), _p(codes, _u8p), _p(trained, _f32p),
+                                 C.c_int64(codes.shape[0]), C.c_int64(nq), _p(xq, _f32p), C.c_int64(kb), _p(cand, _i64p),
+                                 C.c_int64(k), _p(D, _f32p), _p(I, _i64p))
+        return D, I
+
     def pq_precompute_table(self, d, M, nbits, centroids, cb):
         nlist = centroids.shape[0]
         out = np.empty((nlist, M * (1 << nbits)), np.float32)
@@ -523,6 +558,8 @@ class Ref(_SimdTable):
         L.ref_create.restype = C.c_void_p
         L.ref_deserialize.restype = C.c_void_p
         L.ref_serialize.restype = C.c_int64
+        if hasattr(L, "ref_serialize_sq"):
+            L.ref_serialize_sq.restype = C.c_int64
         L.ref_last_error.restype = C.c_char_p
         for f in ("ref_ntotal", "ref_nlist", "ref_code_size", "ref_list_size", "ref_get_precomputed_table"):
             getattr(L, f).restype = C.c_int64
@@ -676,6 +713,50 @@ class Ref(_SimdTable):
         self._chk(self.lib.ref_search_refine(h, C.c_int64(xb.shape[0]), _p(xb, _f32p), C.c_int64(nq), _p(xq, _f32p),
                                              C.c_int64(k), C.c_float(k_factor), C.c_int64(nprobe), _p(D, _f32p),
                                              _p(I, _i64p)))
+        return D, I
+
+    def sq_rows(self, row_type, metric, xb):
+        """(codes, trained) of the IndexScalarQuantizer Knowhere builds as the refine index for fp16 / bf16 / sq8"""
+        xb = np.ascontiguousarray(xb, np.float32)
+        n, d = xb.shape
+        codes = np.empty((n, d if row_type == 3 else 2 * d), np.uint8)
+        tr = np.zeros(2 * d, np.float32)
+        self._chk(self.lib.ref_sq_rows(C.c_int(row_type), C.c_int(metric), C.c_int(d), C.c_int64(n), _p(xb, _f32p),
+                                       _p(codes, _u8p), _p(tr, _f32p)))
+        return codes, tr
+
+    def search_refine_sq(self, h, row_type, xb, xq, k, k_factor, nprobe):
+        """IndexRefine(base = h, refine = IndexScalarQuantizer(xb)).search, one query per call"""
+        xb = np.ascontiguousarray(xb, np.float32)
+        xq = np.ascontiguousarray(xq, np.float32)
+        nq = xq.shape[0]
+        D = np.empty((nq, k), np.float32)
+        I = np.empty((nq, k), np.int64)
+        self._chk(self.lib.ref_search_refine_sq(h, C.c_int(row_type), C.c_int64(xb.shape[0]), _p(xb, _f32p), C.c_int64(nq),
+                                                _p(xq, _f32p), C.c_int64(k), C.c_float(k_factor), C.c_int64(nprobe),
+                                                _p(D, _f32p), _p(I, _i64p)))
+        return D, I
+
+    def serialize_sq(self, h, row_type, xb):
+        xb = np.ascontiguousarray(xb, np.float32)
+        a = (h, C.c_int(row_type), C.c_int64(xb.shape[0]), _p(xb, _f32p))
+        n = self.lib.ref_serialize_sq(*a, None, C.c_int64(0))
+        if n < 0:
+            raise RuntimeError(self.lib.ref_last_error().decode())
+        out = np.empty(n, np.uint8)
+        assert self.lib.ref_serialize_sq(*a, _p(out, _u8p), C.c_int64(n)) == n
+        return out
+
+    def blob_search_refine(self, blob, xq, k, k_factor, nprobe):
+        """read_index(blob) must be an IndexRefine; search through it, one query per call"""
+        blob = np.ascontiguousarray(blob, np.uint8)
+        xq = np.ascontiguousarray(xq, np.float32)
+        nq = xq.shape[0]
+        D = np.empty((nq, k), np.float32)
+        I = np.empty((nq, k), np.int64)
+        self._chk(self.lib.ref_blob_search_refine(_p(blob, _u8p), C.c_int64(blob.size), C.c_int64(nq), _p(xq, _f32p),
+                                                  C.c_int64(k), C.c_float(k_factor), C.c_int64(nprobe), _p(D, _f32p),
+                                                  _p(I, _i64p)))
         return D, I
 
     def coarse(self, h, xq, nprobe):

@@ -902,6 +902,180 @@ int orc_refine(int metric, int d, const float* base, int64_t nbase, int64_t id_b
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Quantised refine store: Knowhere's refine_type = fp16 / bf16 / sq8 makes the refine index a
+ * faiss::IndexScalarQuantizer (R:src/index/refine/refine_utils.cc:150-185).  Row types:
+ * 1 QT_fp16, 2 QT_bf16, 3 QT_8bit.  Restated from the SIMDLevel::NONE classes:
+ *   train   T:impl/scalar_quantizer/training.cpp train_NonUniform, RS_minmax, rangestat_arg 0
+ *           (vmin = column minimum, vdiff = column maximum - vmin, over all rows)
+ *   encode  T:impl/scalar_quantizer/quantizers.h:108-127 + codecs.h Codec8bit::encode_component
+ *           (int)(255 * x); QuantizerFP16 -> encode_fp16 (fp16-inl.h: ties round UP, see orc_encode_fp16),
+ *           QuantizerBF16 -> encode_bf16 = (bits + 0x8000) >> 16 (T:utils/bf16.h:28-33)
+ *   decode  reconstruct_component: vmin[i] + ((code + 0.5f) / 255.0f) * vdiff[i]
+ *   dis     DCTemplate<Quantizer, Similarity, NONE>::compute_distance: one accumulator, i ascending,
+ *           L2: tmp = q[i] - x_i, accu += tmp * tmp; IP: accu += q[i] * x_i
+ *           (T:impl/scalar_quantizer/similarities.h, distance_computers.h)
+ * ---------------------------------------------------------------------------------------- */
+static uint16_t orc_encode_fp16(float f) {
+    /* T:utils/fp16-inl.h:32-86 (the build without F16C, which is what SIMDLevel::NONE code sees): keep 11 mantissa bits,
+     * rescale by 2^-112 in fp32 (half subnormals come out as fp32 subnormals), add half a unit, take bits 13.. -- i.e.
+     * round HALF UP after truncating to 11 bits, NOT round-to-nearest-even: exact ties go up.  Restated literally. */
+    uint32_t fint, sign;
+    memcpy(&fint, &f, 4);
+    sign = fint & 0x80000000u;
+    fint ^= sign;
+    const uint32_t f32infty = 255u << 23, round_mask = ~0xfffu, magic = 15u << 23, capb = (31u << 23) - 0x1000u;
+    int32_t o = (fint > f32infty) ? 0x7e00 : 0x7c00;
+    const uint32_t tb = fint & round_mask;
+    float t, mg, cap;
+    memcpy(&t, &tb, 4);
+    memcpy(&mg, &magic, 4);
+    memcpy(&cap, &capb, 4);
+    volatile float fscale = t * mg; /* (volatile: one rounding to fp32, subnormals kept) */
+    float fs = fscale;
+    if (cap < fs) {
+        fs = cap;
+    }
+    uint32_t fb;
+    memcpy(&fb, &fs, 4);
+    const int32_t fint2 = (int32_t)(fb - round_mask);
+    if (fint < f32infty) {
+        o = fint2 >> 13;
+    }
+    return (uint16_t)(o | (sign >> 16));
+}
+
+static float orc_decode_fp16(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    const uint32_t e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+    uint32_t x;
+    if (e == 0) {
+        if (m == 0) {
+            x = sign;
+        } else {
+            const float v = (float)m * 5.9604644775390625e-08f; /* m * 2^-24, exact */
+            memcpy(&x, &v, 4);
+            x |= sign;
+        }
+    } else if (e == 31) {
+        x = sign | 0x7f800000u | (m << 13);
+    } else {
+        x = sign | ((e + 112u) << 23) | (m << 13);
+    }
+    float f;
+    memcpy(&f, &x, 4);
+    return f;
+}
+
+int64_t orc_rows_code_size(int row_type, int d) {
+    return row_type == 3 ? d : 2 * (int64_t)d;
+}
+
+void orc_rows_train(int d, int64_t n, const float* x, float* trained) {
+    for (int j = 0; j < d; j++) {
+        float lo = HUGE_VALF, hi = -HUGE_VALF;
+        for (int64_t i = 0; i < n; i++) {
+            const float v = x[i * d + j];
+            if (v < lo) lo = v;
+            if (v > hi) hi = v;
+        }
+        const float vexp = (hi - lo) * 0.0f; /* rangestat_arg */
+        lo -= vexp;
+        hi += vexp;
+        trained[j] = lo;
+        trained[d + j] = hi - lo;
+    }
+}
+
+void orc_rows_encode(int row_type, int d, int64_t n, const float* x, const float* trained, uint8_t* codes) {
+    for (int64_t r = 0; r < n; r++) {
+        const float* xr = x + r * d;
+        if (row_type == 3) {
+            uint8_t* c = codes + r * d;
+            for (int i = 0; i < d; i++) {
+                float xi = 0;
+                if (trained[d + i] != 0) {
+                    xi = (xr[i] - trained[i]) / trained[d + i];
+                    if (xi < 0) xi = 0;
+                    if (xi > 1.0) xi = 1.0;
+                }
+                c[i] = (uint8_t)(int)(255 * xi);
+            }
+        } else {
+            uint16_t* c = (uint16_t*)(codes + r * 2 * (int64_t)d);
+            for (int i = 0; i < d; i++) {
+                if (row_type == 1) {
+                    c[i] = orc_encode_fp16(xr[i]);
+                } else {
+                    uint32_t b;
+                    memcpy(&b, &xr[i], 4);
+                    c[i] = (uint16_t)((b + 0x8000u) >> 16);
+                }
+            }
+        }
+    }
+}
+
+static float rows_component(int row_type, int d, const uint8_t* code, const float* trained, int i) {
+    if (row_type == 3) {
+        const float xi = (code[i] + 0.5f) / 255.0f;
+        return trained[i] + xi * trained[d + i];
+    }
+    const uint16_t v = ((const uint16_t*)code)[i];
+    if (row_type == 1) {
+        return orc_decode_fp16(v);
+    }
+    const uint32_t b = (uint32_t)v << 16;
+    float f;
+    memcpy(&f, &b, 4);
+    return f;
+}
+
+void orc_rows_decode(int row_type, int d, int64_t n, const uint8_t* codes, const float* trained, float* x) {
+    const int64_t cs = orc_rows_code_size(row_type, d);
+    for (int64_t r = 0; r < n; r++) {
+        for (int i = 0; i < d; i++) {
+            x[r * d + i] = rows_component(row_type, d, codes + r * cs, trained, i);
+        }
+    }
+}
+
+/* IndexRefine::search over an IndexScalarQuantizer refine index (candidates as orc_refine) */
+int orc_refine_rows(int metric, int d, int row_type, const uint8_t* codes, const float* trained, int64_t nbase, int64_t nq,
+                    const float* xq, int64_t k_base, const int64_t* cand_ids, int64_t k, float* D, int64_t* I) {
+    const int is_max = (metric == ORC_L2);
+    const int64_t cs = orc_rows_code_size(row_type, d);
+    for (int64_t i = 0; i < nq; i++) {
+        const float* q = xq + i * (int64_t)d;
+        float* simi = D + i * k;
+        int64_t* idxi = I + i * k;
+        orc_heap_heapify(is_max, (size_t)k, simi, idxi);
+        for (int64_t j = 0; j < k_base; j++) {
+            const int64_t id = cand_ids[i * k_base + j];
+            if (id == -1) {
+                break;
+            }
+            if (id < 0 || id >= nbase) {
+                continue;
+            }
+            const uint8_t* code = codes + id * cs;
+            float accu = 0;
+            for (int c = 0; c < d; c++) {
+                const float xi = rows_component(row_type, d, code, trained, c);
+                if (is_max) {
+                    const float tmp = q[c] - xi;
+                    accu += tmp * tmp;
+                } else {
+                    accu += q[c] * xi;
+                }
+            }
+            heap_add(is_max, (size_t)k, simi, idxi, accu, id);
+        }
+        orc_heap_reorder(is_max, (size_t)k, simi, idxi);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
  * Shard merge.  The k best of the union of per-shard results; the reference proves the
  * property in tests/ut/test_bruteforce.cc:128-181 (heaps.addn_with_ids over partitions) and
  * T:utils/Heap.h:636 merge_knn_results.  Restated with the same heap.

@@ -380,6 +380,115 @@ int ref_search_refine(
     });
 }
 
+static faiss::ScalarQuantizer::QuantizerType row_qtype(int row_type) {
+    switch (row_type) {
+        case 1: return faiss::ScalarQuantizer::QT_fp16;
+        case 2: return faiss::ScalarQuantizer::QT_bf16;
+        case 3: return faiss::ScalarQuantizer::QT_8bit;
+        default: throw std::runtime_error("row type: 1 fp16, 2 bf16, 3 sq8");
+    }
+}
+
+/// The refine index Knowhere builds for refine_type = fp16 / bf16 / sq8: faiss::IndexScalarQuantizer(d, qtype, metric),
+/// trained and filled with the raw vectors (reference src/index/refine/refine_utils.cc:150-185).  codes_out
+/// [nb][code_size] and trained_out (2*d floats for sq8) receive its state if non-null.
+int ref_sq_rows(int row_type, int metric, int d, int64_t nb, const float* xb, uint8_t* codes_out, float* trained_out) {
+    return guarded([&] {
+        faiss::IndexScalarQuantizer sq(d, row_qtype(row_type), metric == 0 ? faiss::METRIC_L2 : faiss::METRIC_INNER_PRODUCT);
+        sq.train(nb, xb);
+        sq.add(nb, xb);
+        if (codes_out) {
+            std::memcpy(codes_out, sq.codes.data(), sq.codes.size());
+        }
+        if (trained_out && !sq.sq.trained.empty()) {
+            std::memcpy(trained_out, sq.sq.trained.data(), sizeof(float) * sq.sq.trained.size());
+        }
+    });
+}
+
+/// IndexRefine(base = h, refine = IndexScalarQuantizer(xb)).search, one query per call
+int ref_search_refine_sq(
+        void* hv,
+        int row_type,
+        int64_t nb,
+        const float* xb,
+        int64_t nq,
+        const float* q,
+        int64_t k,
+        float k_factor,
+        int64_t nprobe,
+        float* D,
+        int64_t* I) {
+    auto* h = static_cast<RefIndex*>(hv);
+    return guarded([&] {
+        faiss::MetricType mt = h->metric == 0 ? faiss::METRIC_L2 : faiss::METRIC_INNER_PRODUCT;
+        faiss::IndexScalarQuantizer sq(h->d, row_qtype(row_type), mt);
+        sq.train(nb, xb);
+        sq.add(nb, xb);
+        faiss::IndexRefine refine(h->index.get(), &sq);
+        refine.ntotal = h->index->ntotal;
+        faiss::IVFSearchParameters ivfp;
+        ivfp.nprobe = nprobe;
+        faiss::IndexRefineSearchParameters rp;
+        rp.k_factor = k_factor;
+        rp.base_index_params = &ivfp;
+        for (int64_t i = 0; i < nq; i++) {
+            refine.search(1, q + i * h->d, k, D + i * k, I + i * k, &rp);
+        }
+    });
+}
+
+/// write_index(IndexRefine(base, IndexScalarQuantizer(xb))) -- what the node serialises with a quantised refine_type
+int64_t ref_serialize_sq(void* hv, int row_type, int64_t nb, const float* xb, uint8_t* out, int64_t cap) {
+    auto* h = static_cast<RefIndex*>(hv);
+    int64_t n = -1;
+    int rc = guarded([&] {
+        faiss::MetricType mt = h->metric == 0 ? faiss::METRIC_L2 : faiss::METRIC_INNER_PRODUCT;
+        faiss::IndexScalarQuantizer sq(h->d, row_qtype(row_type), mt);
+        sq.train(nb, xb);
+        sq.add(nb, xb);
+        faiss::IndexRefine refine(h->index.get(), &sq);
+        refine.ntotal = h->index->ntotal;
+        faiss::VectorIOWriter w;
+        faiss::write_index(&refine, &w);
+        n = (int64_t)w.data.size();
+        if (n <= cap) {
+            std::memcpy(out, w.data.data(), w.data.size());
+        }
+    });
+    return rc == 0 ? n : -1;
+}
+
+/// read_index of ANY serialized IndexRefine (bytes written by the HIP node) and search through it, one query per call
+int ref_blob_search_refine(
+        const uint8_t* data,
+        int64_t size,
+        int64_t nq,
+        const float* q,
+        int64_t k,
+        float k_factor,
+        int64_t nprobe,
+        float* D,
+        int64_t* I) {
+    return guarded([&] {
+        faiss::VectorIOReader r;
+        r.data.assign(data, data + size);
+        std::unique_ptr<faiss::Index> idx(faiss::read_index(&r));
+        auto* rf = dynamic_cast<faiss::IndexRefine*>(idx.get());
+        if (!rf) {
+            throw std::runtime_error("not an IndexRefine");
+        }
+        faiss::IVFSearchParameters ivfp;
+        ivfp.nprobe = nprobe;
+        faiss::IndexRefineSearchParameters rp;
+        rp.k_factor = k_factor;
+        rp.base_index_params = &ivfp;
+        for (int64_t i = 0; i < nq; i++) {
+            rf->search(1, q + i * idx->d, k, D + i * k, I + i * k, &rp);
+        }
+    });
+}
+
 /// faiss::write_index into memory -- the bytes IvfIndexNode::SerializeImpl puts into the BinarySet
 /// (reference src/index/ivf/ivf.cc:1717-1744).  With nb_refine > 0 the index is first wrapped the
 /// way Knowhere's `refine` build option does: IndexRefine(base, IndexFlat(raw vectors))
@@ -421,13 +530,13 @@ void* ref_deserialize(const uint8_t* data, int64_t size, int64_t* nb_refine, flo
         }
         if (auto* rf = dynamic_cast<faiss::IndexRefine*>(idx.get())) {
             auto* flat = dynamic_cast<faiss::IndexFlat*>(rf->refine_index);
-            if (!flat) {
-                throw std::runtime_error("refine index is not flat");
+            if (!flat && !dynamic_cast<faiss::IndexScalarQuantizer*>(rf->refine_index)) {
+                throw std::runtime_error("refine index is neither flat nor a scalar quantizer");
             }
-            if (nb_refine) {
+            if (flat && nb_refine) {  // (a quantised refine index is dropped: *nb_refine stays 0)
                 *nb_refine = flat->ntotal;
             }
-            if (xb_refine) {
+            if (flat && xb_refine) {
                 std::memcpy(xb_refine, flat->get_xb(), sizeof(float) * flat->ntotal * flat->d);
             }
             faiss::Index* base = rf->base_index;

@@ -11,6 +11,15 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a GPU selection: torch (which carries its own HIP runtime) must meet the device before libknhip.so's runtime does, or
+    # torch.cuda reports no device for the rest of the process -- whatever subset of the test files was asked for
+    expr = config.getoption("markexpr", "") or ""
+    if "gpu" in expr and "not gpu" not in expr:
+        try:
+            import torch
+            torch.cuda.is_available()
+        except ImportError:
+            pass
 
 
 @pytest.fixture(scope="session")

@@ -224,27 +224,43 @@ int main() {
             int diff = 0;
             for (int64_t i = 0; i < nq * 10; i++) diff += plain.value()->GetIds()[i] != noop.value()->GetIds()[i];
             REQUIRE(diff == 0);
-            Json bcfg = c.cfg;
-            bcfg[indexparam::REFINE] = true;
-            auto ridx = IndexFactory::Instance().Create<fp32>(c.name, version).value();
-            REQUIRE(ridx.Build(train_ds, bcfg) == Status::success);
-            auto refined = ridx.Search(query_ds, scfg, nullptr);
             auto g = BruteForce::Search<fp32>(train_ds, query_ds, cfg, nullptr);
-            REQUIRE(refined.has_value() && g.has_value());
-            float r0 = GetKNNRecall(*g.value(), *plain.value()), r1 = GetKNNRecall(*g.value(), *refined.value());
-            std::printf("   recall@10 plain %.4f refined(k x 10) %.4f\n", r0, r1);
-            REQUIRE(r1 > r0 && r1 > 0.9f);
-            // the refine index travels with the blob ("IxRF" wrapper) and keeps working after a reload
-            BinarySet rbs;
-            REQUIRE(ridx.Serialize(rbs) == Status::success);
-            REQUIRE(std::memcmp(rbs.GetByName(c.name)->data.get(), "IxRF", 4) == 0);
-            auto ridx2 = IndexFactory::Instance().Create<fp32>(c.name, version).value();
-            REQUIRE(ridx2.Deserialize(rbs) == Status::success);
-            auto refined2 = ridx2.Search(query_ds, scfg, nullptr);
-            REQUIRE(refined2.has_value());
-            diff = 0;
-            for (int64_t i = 0; i < nq * 10; i++) diff += refined.value()->GetIds()[i] != refined2.value()->GetIds()[i];
-            REQUIRE(diff == 0);
+            REQUIRE(g.has_value());
+            const float r0 = GetKNNRecall(*g.value(), *plain.value());
+            // refine_type: fp32 / flat = IndexRefineFlat, fp16 / bf16 / sq8 = IndexRefine over an IndexScalarQuantizer
+            // (refine_utils.cc:99-185); both `refine` and `refine_type` are needed for a refine index (ivf_wrapper.cc:170)
+            for (const char* rtype : {"fp32", "fp16", "bf16", "sq8"}) {
+                Json bcfg = c.cfg;
+                bcfg[indexparam::REFINE] = true;
+                bcfg[indexparam::REFINE_TYPE] = rtype;
+                auto ridx = IndexFactory::Instance().Create<fp32>(c.name, version).value();
+                REQUIRE(ridx.Build(train_ds, bcfg) == Status::success);
+                auto refined = ridx.Search(query_ds, scfg, nullptr);
+                REQUIRE(refined.has_value());
+                const float r1 = GetKNNRecall(*g.value(), *refined.value());
+                std::printf("   recall@10 plain %.4f refined(k x 10, %s) %.4f\n", r0, rtype, r1);
+                REQUIRE(r1 > r0 && r1 > 0.9f);
+                // the refine index travels with the blob ("IxRF" wrapper) and keeps working after a reload
+                BinarySet rbs;
+                REQUIRE(ridx.Serialize(rbs) == Status::success);
+                REQUIRE(std::memcmp(rbs.GetByName(c.name)->data.get(), "IxRF", 4) == 0);
+                auto ridx2 = IndexFactory::Instance().Create<fp32>(c.name, version).value();
+                REQUIRE(ridx2.Deserialize(rbs) == Status::success);
+                auto refined2 = ridx2.Search(query_ds, scfg, nullptr);
+                REQUIRE(refined2.has_value());
+                diff = 0;
+                for (int64_t i = 0; i < nq * 10; i++) diff += refined.value()->GetIds()[i] != refined2.value()->GetIds()[i];
+                REQUIRE(diff == 0);
+            }
+            {   // `refine` alone builds no refine index
+                Json bcfg = c.cfg;
+                bcfg[indexparam::REFINE] = true;
+                auto nidx = IndexFactory::Instance().Create<fp32>(c.name, version).value();
+                REQUIRE(nidx.Build(train_ds, bcfg) == Status::success);
+                BinarySet nbs;
+                REQUIRE(nidx.Serialize(nbs) == Status::success);
+                REQUIRE(std::memcmp(nbs.GetByName(c.name)->data.get(), "IwPQ", 4) == 0);
+            }
         }
         // 6. serialize round trip (test_gpu_search.cc:280-314)
         BinarySet bs;

@@ -14,6 +14,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 
 from conftest import gen_data  # noqa: E402
 from oracle import binding as ob  # noqa: E402
+from helpers import finish_ivfpq  # noqa: E402
 
 
 def same(Do, Io, D, I, what):
@@ -64,6 +65,91 @@ def main():
         assert p["mscan_queries"] == nq and p["coarse_fallback_queries"] == 0, p
         assert p["mscan_candidates"] < 40 * nq, p  # (a wrong operand layout would flood the candidate lists)
         g.close()
+    elif case == "pq_any":
+        # numbers of sub-quantizers without a fast kernel (pq_scan_any.hip): m = 12 (word loads, precomputed tables, bitset,
+        # range search), m = 3 (byte loads, residual tables), m = 6 (inner product, boundary ties).  Small on purpose: an
+        # emulated search takes ~15 s; the GPU suite sweeps the widths (tests/test_gpu_pq_any.py)
+        nq, nb = 4, 600
+        for M, d, nlist, metric, resid in ((12, 48, 4, ob.L2, False), (3, 24, 3, ob.L2, True)):
+            xb, xq = gen_data(nb, d, 42 + M), gen_data(nq, d, 44)
+            ix = ob.make_index(port, ob.IVF_PQ, metric, xb, nlist=nlist, M=M)
+            if resid:
+                ix.use_precomputed_table = 0
+                ix.precomputed_table = None
+            else:
+                finish_ivfpq(port, ix)
+            g = GpuIndex.from_data(ix, device=0, precomputed_table_max_bytes=1024 if resid else 0)
+            Do, Io = port.search(ix, xq, 10, 3)
+            D, I = g.search(xq, 10, 3)
+            same(Do, Io, D, I, f"pq_any M={M} resid={resid}")
+            if M == 12:
+                bs = np.packbits(np.random.default_rng(3).random(nb) < 0.4, bitorder="little")
+                Do, Io = port.search(ix, xq, 70, nlist, bs, nb)
+                D, I = g.search(xq, 70, nlist, bs, nb)
+                same(Do, Io, D, I, f"pq_any M={M} k=70 bitset")
+                D40, _ = port.search(ix, xq, 40, nlist)
+                radius = float(np.median(D40[:, 20]))
+                exp = port.range_search(ix, xq, radius, 2)
+                got = g.range_search(xq, np.float32(radius), 2)
+                assert np.array_equal(exp[0], got[0]) and np.array_equal(exp[1], got[1])
+                assert np.array_equal(exp[2].view(np.uint32), got[2].view(np.uint32))
+            g.close()
+        # duplicated rows: more candidates at the k-th distance than places (the reference's first-come admission)
+        rng = np.random.default_rng(7)
+        proto = (rng.integers(-3, 4, (20, 24)) * 7.0).astype(np.float32)
+        xb = np.ascontiguousarray(proto[rng.integers(0, 20, nb)])
+        xq = np.ascontiguousarray(proto[rng.integers(0, 20, nq)] + rng.integers(0, 2, (nq, 24)).astype(np.float32))
+        ix = finish_ivfpq(port, ob.make_index(port, ob.IVF_PQ, ob.IP, xb, nlist=4, M=6))
+        g = GpuIndex.from_data(ix, device=0)
+        g.profile_enable(True)
+        g.profile_reset()
+        Do, Io = port.search(ix, xq, 7, 3)
+        D, I = g.search(xq, 7, 3)
+        same(Do, Io, D, I, "pq_any ties")
+        assert g.profile_get()["tie_queries"] > 0
+        g.close()
+    elif case == "refine_rows":
+        # quantised refine stores: train / encode / append on the device == the oracle's restatement (pinned against
+        # IndexScalarQuantizer), and knhip_search_refine_rows == IndexRefine over it
+        from knowhere_amd import RowStore
+        nb, nlist, nq = 700, 4, 6
+        # d = 24: sq8 rows are not a multiple of 16 bytes (element loads); d = 32: every row type takes the 16-byte loads
+        for metric, d in ((ob.L2, 24), (ob.IP, 32)):
+            xb, xq = gen_data(nb, d, 42, -40.0, 60.0), gen_data(nq, d, 44, -40.0, 60.0)
+            xb[5, :4] = [1 + 2.0 ** -11, 2.0 ** -25, 65520.0, -(1 + 3 * 2.0 ** -11)]  # fp16 ties / subnormal / overflow
+            ix = ob.make_index(port, ob.IVF_SQ8, metric, xb, nlist=nlist)
+            g = GpuIndex.from_data(ix, device=0)
+            for rt in (1, 2, 3):
+                rows = RowStore(rt, d, device=0)
+                tr = port.rows_train(xb) if rt == 3 else None
+                codes = port.rows_encode(rt, xb, tr)
+                if rt == 3:  # (build.hip -- column ranges, sq8 encoder -- is not part of the emulated library: GPU tests)
+                    rows.set_trained(tr)
+                    assert rows.trained().tobytes() == tr.tobytes()
+                    rows.add_codes(codes[:300])
+                    rows.add_codes(codes[300:])
+                else:
+                    rows.train(xb)
+                    rows.add(xb[:300])
+                    rows.add(xb[300:])
+                assert rows.count() == nb and rows.codes().tobytes() == codes.tobytes(), f"row type {rt}: code bytes"
+                for k, kb, nprobe in ((5, 20, 3), (10, 10, 4)):
+                    _, Ib = port.search(ix, xq, kb, nprobe)
+                    Do, Io = port.refine_rows(metric, rt, d, codes, tr, xq, Ib, k)
+                    D, I = g.search_refine_rows(rows, xq, k, kb, nprobe)
+                    same(Do, Io, D, I, f"refine_rows metric={metric} type={rt} k={k}")
+                # a store filled from code bytes (Deserialize) behaves the same
+                r2 = RowStore(rt, d, device=0)
+                if rt == 3:
+                    r2.set_trained(tr)
+                r2.add_codes(codes)
+                if rt != 3:  # (the sq8 store above was itself filled from code bytes)
+                    D1, I1 = g.search_refine_rows(rows, xq, 5, 20, 3)
+                    D2, I2 = g.search_refine_rows(r2, xq, 5, 20, 3)
+                    same(D1, I1, D2, I2, "store from codes")
+                r2.close()
+                rows.close()
+            g.close()
     elif case == "limits":
         # nprobe above what the LDS sorts (the global-scratch row selection) through the whole search path
         nb, d, nlist, nq = 9000, 8, 4500, 3

@@ -96,6 +96,33 @@ def test_live_reference_bytes_roundtrip(node, ref):
             ref.destroy(h)
 
 
+@pytest.mark.parametrize("rt", [1, 2, 3], ids=["fp16", "bf16", "sq8"])
+def test_live_reference_quantised_refine_bytes_roundtrip(node, ref, rt):
+    """IndexRefine(base, IndexScalarQuantizer) as the reference writes it ("IxRF" ... "IxSQ" ... k_factor): parsed and
+    re-emitted byte-identically; truncations and a wrong quantizer type are rejected"""
+    d = 8
+    xb = gen_data(400, d, 5)
+    for kind in (ob.IVF_PQ, ob.IVF_SQ8):
+        h = ref.create(kind, ob.IP, d, 4, 4, 8)
+        ref.train_add(h, xb)
+        blob = ref.serialize_sq(h, rt, xb)
+        ref.destroy(h)
+        assert bytes(blob[:4]) == b"IxRF"
+        assert np.array_equal(roundtrip(node, blob), blob)
+        i = info(node, blob)
+        assert i["has_refine"] and i["ntotal"] == 400
+        for bad in (blob[:-1], blob[:-5], np.concatenate([blob, np.zeros(1, np.uint8)])):
+            with pytest.raises(ValueError):
+                roundtrip(node, bad)
+        pos = blob.tobytes().rindex(b"IxSQ")
+        hdr = 4 + 4 + 8 + 16 + 1 + 4  # fourcc, d, ntotal, 2 reserved int64, is_trained, metric
+        assert int(np.frombuffer(blob[pos + hdr:pos + hdr + 4].tobytes(), np.int32)[0]) == {1: 4, 2: 7, 3: 0}[rt]
+        wrong = blob.copy()
+        wrong[pos + hdr] = 6  # QT_6bit: not a store this backend reads
+        with pytest.raises(ValueError, match="fp16 / bf16 / sq8"):
+            roundtrip(node, wrong)
+
+
 def test_malformed_blobs_are_rejected(node):
     blob = np.load(golden_blobs()[0])["blob"]
     pq = np.load([p for p in golden_blobs() if "ivfpq_l2.npz" in p][0])["blob"]
@@ -161,10 +188,19 @@ def test_cpu_built_index_loads_into_the_hip_node(node, path):
         assert rc == 0
         assert node.knhip_node_count(C.c_void_p(h)) == int(z["nb"])
         D, I = _search(node, h, xq, f"k={k};nprobe={nprobe}", k)
-        assert_parity(z["D"], z["I"], D, I, metric, "cpu blob -> hip node")
-        if "Dr" in z.files:  # IndexRefine, k_factor 4 (refine_k = 4k)
-            D, I = _search(node, h, xq, f"k={k};nprobe={nprobe};refine_k=4", k)
+        if "Dr" in z.files:
+            # an index that carries a refine index is searched THROUGH it, also with the default refine_k = 1 (ivf.cc:
+            # 1076-1098: refine_k always has a value): the k results of the base index re-scored against the raw rows and
+            # re-sorted (IndexRefine::search with k_base == k).  The raw rows are the tail of the blob (IxRF: ... "IxF2" /
+            # "IxFI", header, vector<float>, float k_factor)
+            nb, d = int(z["nb"]), xq.shape[1]
+            raw = np.frombuffer(blob[-(4 + nb * d * 4):-4].tobytes(), np.float32).reshape(nb, d)
+            D1, I1 = ob.Port().refine(metric, raw, xq, z["I"], k)
+            assert_parity(D1, I1, D, I, metric, "cpu blob -> hip node, refine index with the default refine_k")
+            D, I = _search(node, h, xq, f"k={k};nprobe={nprobe};refine_k=4", k)  # k_factor 4
             assert_parity(z["Dr"], z["Ir"], D, I, metric, "cpu blob -> hip node, refine")
+        else:
+            assert_parity(z["D"], z["I"], D, I, metric, "cpu blob -> hip node")
         # and the node writes the same kind of bytes back: identical up to the 16 reserved header bytes
         n = node.knhip_node_serialize(C.c_void_p(h), None, C.c_int64(0))
         out = np.empty(n, np.uint8)
@@ -189,7 +225,7 @@ def test_hip_built_index_is_read_by_the_reference(node, ref, kind, metric):
     h = node.knhip_node_create(GPU_NAME[kind].encode())
     try:
         refine = kind in (ob.IVF_PQ, ob.IVF_SQ8)
-        cfg = f"metric_type={metric};nlist=32;m=8;nbits=8" + (";refine=true" if refine else "")
+        cfg = f"metric_type={metric};nlist=32;m=8;nbits=8" + (";refine=true;refine_type=fp32" if refine else "")
         rc = node.knhip_node_build(C.c_void_p(h), xb.ctypes.data_as(C.POINTER(C.c_float)), C.c_int64(nb), C.c_int64(d),
                                    cfg.encode())
         assert rc == 0
@@ -201,7 +237,10 @@ def test_hip_built_index_is_read_by_the_reference(node, ref, kind, metric):
                                                            ob.IVF_FLAT: b"IwFl"}[kind])
         h2, raw = ref.deserialize(blob, d)
         m = ob.L2 if metric == "L2" else ob.IP
-        Dr, Ir = ref.search(h2, xq, k, nprobe)
+        if refine:  # (searched through the refine index, k_factor = the default refine_k = 1)
+            Dr, Ir = ref.search_refine(h2, raw, xq, k, 1.0, nprobe)
+        else:
+            Dr, Ir = ref.search(h2, xq, k, nprobe)
         assert_parity(Dr, Ir, D, I, m, "hip blob -> reference")
         if refine:
             assert np.array_equal(raw, xb)
@@ -318,3 +357,90 @@ def test_hip_built_cosine_index_equals_the_reference(node, kref):
         assert_parity(De, Ie, D, I, ob.IP, "hip-built FLAT cosine vs IndexFlatCosine")
     finally:
         node.knhip_node_destroy(C.c_void_p(h))
+
+
+ROW_TYPES = [("fp16", 1), ("bf16", 2), ("sq8", 3)]
+
+
+def _node_blob(node, h):
+    n = node.knhip_node_serialize(C.c_void_p(h), None, C.c_int64(0))
+    blob = np.empty(n, np.uint8)
+    assert node.knhip_node_serialize(C.c_void_p(h), _u8(blob), C.c_int64(n)) == n
+    return blob
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rt_name,rt", ROW_TYPES, ids=[r[0] for r in ROW_TYPES])
+@pytest.mark.parametrize("kind", [ob.IVF_PQ, ob.IVF_SQ8], ids=["ivfpq", "ivfsq8"])
+@pytest.mark.parametrize("metric", ["L2", "IP"])
+def test_quantised_refine_store_round_trips_with_the_reference(node, ref, port, kind, metric, rt_name, rt):
+    """refine_type = fp16 / bf16 / sq8 (IndexRefine over faiss::IndexScalarQuantizer, refine_utils.cc:150-185):
+    node-built -> the reference reads the bytes ("IxRF" ... "IxSQ") and searches through ITS IndexRefine: the node's
+    results; the refine store's code bytes and sq8 ranges are the reference's for the same rows; and a blob the
+    reference wrote loads into the node and answers like the reference."""
+    nb, nq, d, k, nprobe = 4000, 32, 32, 10, 8
+    xb, xq = gen_data(nb, d, 42), gen_data(nq, d, 44)
+    m = ob.L2 if metric == "L2" else ob.IP
+    h = node.knhip_node_create(GPU_NAME[kind].encode())
+    h3 = node.knhip_node_create(GPU_NAME[kind].encode())
+    try:
+        cfg = f"metric_type={metric};nlist=32;m=8;nbits=8;refine=true;refine_type={rt_name}"
+        rc = node.knhip_node_build(C.c_void_p(h), xb.ctypes.data_as(C.POINTER(C.c_float)), C.c_int64(nb), C.c_int64(d),
+                                   cfg.encode())
+        assert rc == 0, node.knhip_node_last_error().decode()
+        blob = _node_blob(node, h)
+        assert bytes(blob[:4]) == b"IxRF" and b"IxSQ" in blob.tobytes()
+        for kf in (1, 4):
+            D, I = _search(node, h, xq, f"k={k};nprobe={nprobe}" + (f";refine_k={kf}" if kf != 1 else ""), k)
+            Dr, Ir = ref.blob_search_refine(blob, xq, k, float(kf), nprobe)
+            assert_parity(Dr, Ir, D, I, m, f"hip blob ({rt_name}) -> reference, k_factor {kf}")
+        # the store inside the blob = the reference's IndexScalarQuantizer over the same rows: same tail bytes
+        codes_r, tr_r = ref.sq_rows(rt, m, xb)
+        tail = codes_r.tobytes() + np.float32(1.0).tobytes()
+        assert blob.tobytes().endswith(tail), "code bytes of the refine store"
+        if rt == 3:
+            assert tr_r.tobytes() in blob.tobytes(), "sq8 ranges"
+        # reference-written bytes -> node
+        h2, _ = ref.deserialize(blob, d)
+        blob_r = ref.serialize_sq(h2, rt, xb)
+        ref.destroy(h2)
+        rc = node.knhip_node_deserialize(C.c_void_p(h3), CPU_NAME[kind].encode(), _u8(blob_r), C.c_int64(blob_r.size), b"")
+        assert rc == 0, node.knhip_node_last_error().decode()
+        D3, I3 = _search(node, h3, xq, f"k={k};nprobe={nprobe};refine_k=4", k)
+        Dr, Ir = ref.blob_search_refine(blob_r, xq, k, 4.0, nprobe)
+        assert_parity(Dr, Ir, D3, I3, m, f"reference blob ({rt_name}) -> hip node")
+        out = _node_blob(node, h3)
+        assert out.size == blob_r.size
+        diff = np.nonzero(out != blob_r)[0]
+        assert len(diff) <= 12 and all(blob_r[i] == 0x10 for i in diff)  # (the reserved header bytes, as above)
+    finally:
+        node.knhip_node_destroy(C.c_void_p(h))
+        node.knhip_node_destroy(C.c_void_p(h3))
+
+
+@pytest.mark.gpu
+def test_refine_needs_refine_type_and_one_device_for_quantised_stores(node):
+    """`refine = true` without `refine_type` builds NO refine index (ivf_wrapper.cc:170: both are needed); sq6 is refused;
+    a quantised store with several gpu_ids is refused"""
+    nb, d = 3000, 32
+    xb = gen_data(nb, d, 42)
+    name = GPU_NAME[ob.IVF_PQ].encode()
+
+    def build(cfg):
+        h = node.knhip_node_create(name)
+        rc = node.knhip_node_build(C.c_void_p(h), xb.ctypes.data_as(C.POINTER(C.c_float)), C.c_int64(nb), C.c_int64(d),
+                                   ("metric_type=L2;nlist=16;m=8;nbits=8;" + cfg).encode())
+        return h, rc
+
+    h, rc = build("refine=true")
+    assert rc == 0 and bytes(_node_blob(node, h)[:4]) == b"IwPQ"
+    node.knhip_node_destroy(C.c_void_p(h))
+    h, rc = build("refine=true;refine_type=sq6")
+    assert rc != 0
+    node.knhip_node_destroy(C.c_void_p(h))
+    h, rc = build("refine=true;refine_type=fp16;gpu_ids=0,0")
+    assert rc != 0
+    node.knhip_node_destroy(C.c_void_p(h))
+    h, rc = build("refine=true;refine_type=FP16")
+    assert rc == 0 and bytes(_node_blob(node, h)[:4]) == b"IxRF"
+    node.knhip_node_destroy(C.c_void_p(h))

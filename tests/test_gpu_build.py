@@ -102,6 +102,7 @@ def test_kmeans_empty_cluster_split(torch_cuda, port):
 
 
 @pytest.mark.parametrize("kind,M,metric", [(ob.IVF_PQ, 8, ob.L2), (ob.IVF_PQ, 32, ob.L2), (ob.IVF_PQ, 16, ob.IP),
+                                           (ob.IVF_PQ, 4, ob.L2), (ob.IVF_PQ, 2, ob.IP),  # (widths of pq_scan_any.hip)
                                            (ob.IVF_SQ8, 0, ob.L2), (ob.IVF_SQ8, 0, ob.IP), (ob.IVF_FLAT, 0, ob.L2),
                                            (ob.IVF_FLAT, 0, ob.IP)])
 def test_train_add_search_pipeline(torch_cuda, port, kind, M, metric):

@@ -199,16 +199,19 @@ def test_sharded_refine_through_the_node(node, metric):
     try:
         assert one.build(xb, base + ";gpu_id=0") == 0
         assert many.build(xb, base + f";gpu_ids={shard_ids(2)}") == 0
-        for k, rk in ((10, 8), (5, 20)):
-            cfg = f"k={k};nprobe=16;refine_k={rk}"
+        for k, rk in ((10, 8), (5, 20), (10, 1)):  # (refine_k = 1, the default: the k results re-scored and re-sorted)
+            cfg = f"k={k};nprobe=16" + (f";refine_k={rk}" if rk != 1 else "")
             assert same(one.search(xq, cfg, k), many.search(xq, cfg, k)), (metric, k, rk)
         assert np.array_equal(one.blob(), many.blob())
-        # a quantised refine store is refused, never silently replaced by another one
-        bad = Node(node, "GPU_HIP_IVF_PQ")
-        try:
-            assert bad.build(xb, base.replace("refine_type=fp32", "refine_type=sq8")) != 0
-        finally:
-            bad.close()
+        # a quantised refine store (one device) with several gpu_ids is refused, never silently replaced by another one;
+        # sq6 is not a store this backend has
+        for cfg in (base.replace("refine_type=fp32", "refine_type=sq8") + f";gpu_ids={shard_ids(2)}",
+                    base.replace("refine_type=fp32", "refine_type=sq6") + ";gpu_id=0"):
+            bad = Node(node, "GPU_HIP_IVF_PQ")
+            try:
+                assert bad.build(xb, cfg) != 0
+            finally:
+                bad.close()
     finally:
         one.close()
         many.close()

@@ -1,0 +1,140 @@
+"""GPU tests (-m gpu): the quantised refine store (knhip_rows; Knowhere's refine_type = fp16 / bf16 / sq8).
+
+The reference re-ranks the first stage's candidates against a faiss::IndexScalarQuantizer of the raw rows (reference
+src/index/refine/refine_utils.cc:150-185, thirdparty/faiss/faiss/cppcontrib/knowhere/IndexRefine.cpp:66-165).  The oracle's
+restatement is pinned against the reference in tests/test_refine_rows.py; here the device side -- range training, the three
+encoders, append, and knhip_search_refine_rows -- must equal it bit for bit."""
+import numpy as np
+import pytest
+
+from conftest import assert_parity, gen_data
+from helpers import finish_ivfpq
+from oracle import binding as ob
+from test_refine_rows import ROW_TYPES, _nasty
+
+pytestmark = pytest.mark.gpu
+
+
+def _store(rt, xb, chunks=1):
+    from knowhere_amd import RowStore
+    rows = RowStore(rt, xb.shape[1], device=0)
+    rows.train(xb)
+    for part in np.array_split(xb, chunks):
+        rows.add(part)
+    return rows
+
+
+@pytest.mark.parametrize("row_type,name", ROW_TYPES, ids=[r[1] for r in ROW_TYPES])
+def test_device_encoders_write_the_reference_code_bytes(port, row_type, name):
+    d = 24
+    for x in (gen_data(5000, d, 5), gen_data(300, d, 6, -3.0, 3.0), _nasty(d, 7)):
+        if row_type == 3:
+            x = np.ascontiguousarray(x[np.isfinite(x).all(1)])
+        rows = _store(row_type, x, chunks=3)
+        tr = port.rows_train(x) if row_type == 3 else None
+        if row_type == 3:
+            assert rows.trained().tobytes() == tr.tobytes(), "sq8 ranges (column minimum / maximum - minimum)"
+        assert rows.count() == len(x)
+        assert rows.codes().tobytes() == port.rows_encode(row_type, x, tr).tobytes(), f"{name} code bytes"
+        rows.close()
+
+
+def test_sq8_store_constant_column_and_rows_outside_the_trained_range(port):
+    from knowhere_amd import RowStore
+    d = 8
+    x = gen_data(200, d, 3)
+    x[:, 2] = 7.5
+    rows = RowStore(3, d, device=0)
+    rows.train(x)
+    tr = port.rows_train(x)
+    assert rows.trained().tobytes() == tr.tobytes()
+    wide = gen_data(50, d, 4, -100.0, 300.0)
+    rows.add(wide)  # (Add after Train with rows the ranges have not seen: clamped to 0 / 255)
+    assert rows.codes().tobytes() == port.rows_encode(3, wide, tr).tobytes()
+    rows.close()
+
+
+def test_store_contract_errors():
+    from knowhere_amd import KnhipError, RowStore
+    with pytest.raises(KnhipError):
+        RowStore(9, 8, device=0)
+    rows = RowStore(3, 8, device=0)
+    with pytest.raises(KnhipError):  # sq8 before its ranges are trained
+        rows.add(gen_data(4, 8, 1))
+    rows.close()
+
+
+KINDS = [(ob.IVF_PQ, "ivfpq", dict(nlist=24, M=8)), (ob.IVF_SQ8, "ivfsq8", dict(nlist=24)), (ob.IVF_FLAT, "ivfflat", dict(nlist=24))]
+
+
+@pytest.mark.parametrize("row_type,name", ROW_TYPES, ids=[r[1] for r in ROW_TYPES])
+@pytest.mark.parametrize("metric", [ob.L2, ob.IP], ids=["l2", "ip"])
+@pytest.mark.parametrize("kind,kname,kw", KINDS, ids=[k[1] for k in KINDS])
+def test_search_refine_rows_equals_index_refine_over_a_scalar_quantizer(port, kind, kname, kw, metric, row_type, name):
+    from knowhere_amd import GpuIndex
+    nb, nq, d = 6000, 64, 32
+    xb, xq = gen_data(nb, d, 42, -20.0, 80.0), gen_data(nq, d, 44, -20.0, 80.0)
+    ix = ob.make_index(port, kind, metric, xb, **kw)
+    if kind == ob.IVF_PQ:
+        finish_ivfpq(port, ix)
+    g = GpuIndex.from_data(ix, device=0)
+    rows = _store(row_type, xb, chunks=2)
+    tr = port.rows_train(xb) if row_type == 3 else None
+    codes = port.rows_encode(row_type, xb, tr)
+    bs = np.packbits(np.random.default_rng(5).random(nb) < 0.3, bitorder="little")
+    for k, kb, nprobe in ((10, 40, 8), (1, 16, 3), (7, 7, 9), (20, 200, 24)):
+        for bitset, nbits in ((None, 0), (bs, nb)):
+            _, Ib = port.search(ix, xq, kb, nprobe, bitset, nbits)
+            Do, Io = port.refine_rows(metric, row_type, d, codes, tr, xq, Ib, k)
+            D, I = g.search_refine_rows(rows, xq, k, kb, nprobe, bitset, nbits)
+            assert_parity(Do, Io, D, I, metric, f"{kname} {name} k={k} k_base={kb} bitset={bitset is not None}")
+    rows.close()
+    g.close()
+
+
+@pytest.mark.parametrize("row_type,name", ROW_TYPES, ids=[r[1] for r in ROW_TYPES])
+@pytest.mark.parametrize("metric", [ob.L2, ob.IP], ids=["l2", "ip"])
+def test_refine_rows_ties_follow_reorder_2_heaps(port, metric, row_type, name):
+    """duplicated raw rows encode to the same code and tie exactly after the re-rank: which of them are returned depends on
+    where they stood in the first stage's result (reorder_2_heaps) -- as for the fp32 store (tests/test_gpu_ties.py)"""
+    from knowhere_amd import GpuIndex
+    from test_gpu_ties import _dup_data
+    xb, xq = _dup_data(6000, 32, 40, 11)
+    ix = ob.make_index(port, ob.IVF_SQ8, metric, xb, nlist=24)
+    g = GpuIndex.from_data(ix, device=0)
+    rows = _store(row_type, xb)
+    tr = port.rows_train(xb) if row_type == 3 else None
+    codes = port.rows_encode(row_type, xb, tr)
+    kbase, k, nprobe = 60, 6, 9
+    _, Ib = port.search(ix, xq, kbase, nprobe)
+    Do, Io = port.refine_rows(metric, row_type, 32, codes, tr, xq, Ib, k)
+    D, I = g.search_refine_rows(rows, xq, k, kbase, nprobe)
+    assert_parity(Do, Io, D, I, metric, f"{name} refine over duplicates")
+    rows.close()
+    g.close()
+
+
+def test_refine_rows_at_scale_properties(port):
+    """100k x 128 rows, batch 2000: (a) every returned id is among the first stage's candidates, (b) the distances are the
+    decoded rows' distances recomputed on the host, sorted, (c) equal to the oracle on a sample of the queries"""
+    from knowhere_amd import GpuIndex
+    nb, nq, d, k, kb, nprobe = 100_000, 2000, 128, 10, 100, 16
+    xb, xq = gen_data(nb, d, 1, -1.0, 1.0), gen_data(nq, d, 2, -1.0, 1.0)
+    ix = ob.make_index(port, ob.IVF_PQ, ob.L2, xb, nlist=256, M=32)
+    finish_ivfpq(port, ix)
+    g = GpuIndex.from_data(ix, device=0)
+    for rt in (1, 3):
+        rows = _store(rt, xb, chunks=4)
+        tr = rows.trained() if rt == 3 else None
+        codes = rows.codes()
+        _, Ib = g.search(xq, kb, nprobe)
+        D, I = g.search_refine_rows(rows, xq, k, kb, nprobe)
+        assert all(set(I[q][I[q] >= 0]) <= set(Ib[q]) for q in range(0, nq, 37))
+        assert (np.diff(D, axis=1) >= 0).all()
+        dec = port.rows_decode(rt, d, codes[I[:50].ravel()], tr).reshape(50, k, d)
+        ref_d = ((xq[:50, None, :].astype(np.float64) - dec) ** 2).sum(-1)
+        assert np.allclose(D[:50], ref_d, rtol=1e-4)
+        Do, Io = port.refine_rows(ob.L2, rt, d, codes, tr, xq[:100], Ib[:100], k)
+        assert_parity(Do, Io, D[:100], I[:100], ob.L2, f"row type {rt} at scale")
+        rows.close()
+    g.close()

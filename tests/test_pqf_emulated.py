@@ -257,6 +257,20 @@ def test_emulated_api_nprobe_above_4096():
 
 
 @pytest.mark.timeout(1800)
+def test_emulated_api_any_number_of_sub_quantizers():
+    """IVF-PQ with m outside {8, 16, 32, 64} (pq_scan_any.hip, the reference takes any m that divides dim): m = 12, 6, 3, 1,
+    precomputed / residual / inner-product tables, bitset, boundary ties, range search -- the oracle's results"""
+    _run_api_case("pq_any")
+
+
+@pytest.mark.timeout(1800)
+def test_emulated_api_quantised_refine_stores():
+    """knhip_rows (fp16 / bf16 / sq8 refine stores): device training, encoding and append give the oracle's bytes, and
+    knhip_search_refine_rows the oracle's IndexRefine-over-IndexScalarQuantizer results, both metrics"""
+    _run_api_case("refine_rows")
+
+
+@pytest.mark.timeout(1800)
 def test_emulated_api_range_search_pq16():
     _run_api_case("range_pq16")
 

@@ -1,0 +1,130 @@
+"""Quantised refine store (refine_type = fp16 / bf16 / sq8): the oracle's restatement pinned against the reference.
+
+Knowhere builds IndexRefine(base, faiss::IndexScalarQuantizer(d, QT_fp16 / QT_bf16 / QT_8bit, metric)) for these refine
+types (reference src/index/refine/refine_utils.cc:150-185).  oracle.c restates the quantizer (train / encode / decode) and
+the refine distance computer; here the restatement must produce the reference's code bytes, trained ranges and search
+results bit for bit (oracle/_ref = the reference's own sources, SIMDLevel::NONE)."""
+import numpy as np
+import pytest
+
+from conftest import gen_data
+from oracle import binding as ob
+
+ROW_TYPES = [(1, "fp16"), (2, "bf16"), (3, "sq8")]
+
+
+def _nasty(d, seed):
+    """values that exercise the rounding rules: half ulps (ties), subnormal halves, overflow to inf, signed zeros"""
+    rng = np.random.default_rng(seed)
+    v = [0.0, -0.0, 1.0, -1.0, 65504.0, 65519.9, 65520.0, 70000.0, -70000.0, 1e-8, 2.0 ** -25, 2.0 ** -24, 3 * 2.0 ** -25,
+         2.0 ** -14, 2.0 ** -14 - 2.0 ** -25, 1 + 2.0 ** -11, 1 + 3 * 2.0 ** -11, 1 + 2.0 ** -11 + 2.0 ** -20, 1 + 2.0 ** -8,
+         1 + 3 * 2.0 ** -8, 3.3895314e38, 1e-40, -1e-40, 1234.5678, np.pi]
+    x = np.concatenate([np.array(v, np.float32), (rng.standard_normal(4000) * 10 ** rng.uniform(-9, 5, 4000)).astype(np.float32)])
+    n = (len(x) + d - 1) // d * d
+    x = np.concatenate([x, np.zeros(n - len(x), np.float32)])
+    return np.ascontiguousarray(x.reshape(-1, d))
+
+
+@pytest.mark.parametrize("row_type,name", ROW_TYPES, ids=[r[1] for r in ROW_TYPES])
+def test_rows_encode_equals_the_reference(port, ref, row_type, name):
+    d = 24
+    for x in (gen_data(700, d, 5), gen_data(300, d, 6, -3.0, 3.0), _nasty(d, 7)):
+        if row_type == 3:
+            x = x[np.isfinite(x).all(1)]
+        codes_r, tr_r = ref.sq_rows(row_type, ob.L2, x)
+        tr = port.rows_train(x) if row_type == 3 else None
+        if row_type == 3:
+            assert tr.tobytes() == tr_r.tobytes(), "sq8 ranges"
+        codes = port.rows_encode(row_type, x, tr)
+        assert codes.tobytes() == codes_r.tobytes(), f"{name} code bytes"
+
+
+def test_sq8_constant_column_and_clamp(port, ref):
+    """vdiff == 0 encodes 0; rows outside the trained range clamp (encode with ranges trained on OTHER rows)"""
+    d = 8
+    x = gen_data(200, d, 3)
+    x[:, 2] = 7.5
+    codes_r, tr_r = ref.sq_rows(3, ob.L2, x)
+    tr = port.rows_train(x)
+    assert tr.tobytes() == tr_r.tobytes() and tr[d + 2] == 0
+    assert port.rows_encode(3, x, tr).tobytes() == codes_r.tobytes()
+    wide = gen_data(50, d, 4, -100.0, 300.0)
+    c = port.rows_encode(3, wide, tr)
+    assert c.min() == 0 and c.max() == 255
+    back = port.rows_decode(3, d, c, tr)
+    assert (back[:, 2] == 7.5).all()
+
+
+@pytest.mark.parametrize("row_type,name", ROW_TYPES, ids=[r[1] for r in ROW_TYPES])
+@pytest.mark.parametrize("metric", [ob.L2, ob.IP], ids=["l2", "ip"])
+@pytest.mark.parametrize("kind", [ob.IVF_PQ, ob.IVF_SQ8], ids=["ivfpq", "ivfsq8"])
+def test_refine_rows_equals_index_refine_over_a_scalar_quantizer(port, ref, kind, metric, row_type, name):
+    nb, nq, d, nlist, M = 2500, 24, 48, 20, 12
+    xb, xq = gen_data(nb, d, 42), gen_data(nq, d, 44)
+    h = ref.create(kind, metric, d, nlist, M, 8)
+    try:
+        ref.train_add(h, xb)
+        ix = ref.export(h, kind, metric, d, nlist, M, 8)
+        tr = port.rows_train(xb) if row_type == 3 else None
+        codes = port.rows_encode(row_type, xb, tr)
+        for k, kf, nprobe in ((5, 4.0, 18), (1, 8.0, 3), (10, 1.0, 20)):
+            Dr, Ir = ref.search_refine_sq(h, row_type, xb, xq, k, kf, nprobe)
+            kb = int(k * kf)
+            _, Ib = port.search(ix, xq, kb, nprobe)
+            Dp, Ip = port.refine_rows(metric, row_type, d, codes, tr, xq, Ib, k)
+            assert Dr.tobytes() == Dp.tobytes(), f"{name} k={k} k_factor={kf}: distances"
+            assert (Ir == Ip).all(), f"{name} k={k} k_factor={kf}: ids"
+    finally:
+        ref.destroy(h)
+
+
+@pytest.mark.parametrize("row_type,name", ROW_TYPES, ids=[r[1] for r in ROW_TYPES])
+def test_decode_round_trip_properties(port, row_type, name):
+    d = 16
+    x = gen_data(500, d, 9, -50.0, 50.0)
+    tr = port.rows_train(x) if row_type == 3 else None
+    c = port.rows_encode(row_type, x, tr)
+    y = port.rows_decode(row_type, d, c, tr)
+    # idempotence: re-encoding the decoded rows gives the same codes
+    assert port.rows_encode(row_type, y, tr).tobytes() == c.tobytes()
+    if row_type == 1:
+        # the reference's scalar encode_fp16 rounds exact ties UP; everywhere else it is IEEE round-to-nearest (= numpy's half)
+        rne = x.astype(np.float16).astype(np.float32)
+        tie = (x.view(np.uint32) & 0x1fff) == 0x1000
+        assert np.array_equal(y[~tie], rne[~tie])
+        assert (np.abs(y) >= np.abs(rne)).all()
+    elif row_type == 2:
+        assert np.abs(y - x).max() <= np.abs(x).max() * 2.0 ** -8
+    else:
+        assert (np.abs(y - x) <= tr[d:] / 255.0 * 0.5001 + 1e-6).all()
+
+
+def _encode_fp16_int(bits):
+    """the kernel's integer form of the reference's scalar encode_fp16 (refine.hip rows_encode16_kernel), in numpy"""
+    bits = bits.astype(np.int64)
+    sign = (bits >> 16) & 0x8000
+    fint = bits & 0x7fffffff
+    t = fint & 0xfffff000
+    E = t >> 23
+    mant = (t & 0x7fffff) | np.where(E > 0, 0x800000, 0)
+    s = np.clip(113 - E, 0, 62)
+    sub = np.where(s <= 12, mant >> s, 0)
+    b = np.where(E >= 113, t - (112 << 23), sub)
+    b = np.minimum(b, (31 << 23) - 0x1000)
+    o = (b + 0x1000) >> 13
+    o = np.where(fint > 0x7f800000, 0x7e00, np.where(fint == 0x7f800000, 0x7c00, o))
+    return (o | sign).astype(np.uint16)
+
+
+def test_fp16_encode_integer_form_is_exhaustively_the_reference(port):
+    """encode_fp16 depends on the top 20 bits of |x| only (the low 12 are masked first): all 2^19 classes x both signs,
+    with the low bits clear, set and random"""
+    hi = np.arange(1 << 19, dtype=np.uint32) << 12
+    rng = np.random.default_rng(1)
+    for low in (0, 0xfff, rng.integers(0, 0x1000, hi.size, dtype=np.uint32)):
+        for sgn in (0, 0x80000000):
+            bits = (hi | low | sgn).astype(np.uint32)
+            x = bits.view(np.float32).reshape(-1, 64)
+            want = port.rows_encode(1, x, None).view(np.uint16).ravel()
+            got = _encode_fp16_int(bits)
+            assert np.array_equal(want, got)
