@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-/* 4: knhip_train_params gained spherical/reserved, knhip_stage_times its prefilter counters.  5: tie_queries.  6: the quantised refine store (knhip_rows_*, knhip_search_refine_rows).
+/* 4: knhip_train_params gained spherical/reserved, knhip_stage_times its prefilter counters.  5: tie_queries.  6: the quantised refine store (knhip_rows_*, knhip_search_refine_rows), knhip_range_search_ranked.
  * Callers compare knhip_abi_version() with the header they were built against. */
 #define KNHIP_ABI_VERSION 6
 
@@ -228,6 +228,16 @@ int knhip_index_uses_precomputed_table(const knhip_index* idx);
 int knhip_range_search(const knhip_index* idx, const float* queries, int64_t nq, float radius,
                        int32_t max_empty_result_buckets, const uint8_t* bitset, int64_t bitset_nbits, int64_t* lims,
                        int64_t** out_ids, float** out_dist);
+/* The same search over EVERY list (no early stop) that also returns how many hits each coarse rank contributed:
+ * (*out_rank_counts)[q * nlist + r] = hits of query q in its r-th nearest list (malloc'ed, nq * nlist entries, release with
+ * knhip_free).  What a list-sharded deployment needs to apply the reference's early stop ACROSS shards: every shard holds
+ * all centroids (so it ranks the lists like every other shard) but only the entries of the lists it owns; the host sums
+ * the counts over the shards per (query, rank), walks the ranks with the rule of IndexIVF::range_search_preassigned
+ * (IndexIVF.cpp:917-933: stop after max_empty_result_buckets consecutive lists without a hit) and takes each rank's hits
+ * from the shard that owns the list (knowhere_amd/host/hip_index_node.cc, RangeSearch).  IVF kinds only. */
+int knhip_range_search_ranked(const knhip_index* idx, const float* queries, int64_t nq, float radius, const uint8_t* bitset,
+                              int64_t bitset_nbits, int64_t* lims, int64_t** out_ids, float** out_dist,
+                              int32_t** out_rank_counts);
 /* Coarse ranks the last knhip_range_search on this index scanned per query (its last batch): the IVF kinds probe in
  * waves of ranks (64, 128, 256, ...) and stop once every query has met the reference's early stop, so the cost follows
  * max_empty_result_buckets instead of nlist.  nlist when every list was scanned (max_empty = 0, or nlist <= 128). */
@@ -279,6 +289,12 @@ int64_t knhip_rows_device_bytes(const knhip_rows* rows);
 int knhip_search_refine_rows(const knhip_index* idx, const knhip_rows* rows, const float* queries, int64_t nq, int32_t k,
                              int32_t k_base, int32_t nprobe, const uint8_t* bitset, int64_t bitset_nbits, int64_t* out_ids,
                              float* out_dist);
+/* the second stage alone, device pointers (knhip_refine_device over a quantised store): row r of `rows` = vector id
+ * id_base + r; candidates outside the store are skipped slots -- what a rank of a sharded deployment runs on the part
+ * of the store it holds (include/knhip_shards.h) */
+int knhip_refine_rows_device(int32_t metric, const knhip_rows* rows, int64_t id_base, const float* d_queries, int64_t nq,
+                             const int64_t* d_cand_ids, int32_t k_base, int32_t k, float* d_out_dist, int64_t* d_out_ids,
+                             void* stream);
 /* rows by id (IndexNode::GetVectorByIds); out [n][dim] host.  BRUTE_FORCE: row = id - id_offset.  IVF_FLAT: through a
  * direct map built on first use from the index's own ids (16 bytes per vector in HBM; the reference's
  * make_direct_map / reconstruct, thirdparty/faiss/faiss/IndexIVF.cpp); an id that is not stored is an error. */

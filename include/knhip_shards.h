@@ -42,6 +42,10 @@ int knhip_shard_group_search(knhip_shard_group* g, const float* queries, int64_t
  * rank before a collective makes EVERY rank skip it (agreement under a host barrier); a failure of the collective's own
  * enqueue marks the group unusable (later calls fail at once; destroy aborts the communicators).  stage_ms: [n_devices][7] = {search, gather + merge, -, refine, gather + merge, -, total}. */
 int knhip_shard_group_set_raw(knhip_shard_group* g, int32_t rank, const float* d_rows, int64_t nrows, int64_t id_base);
+/* the same with a quantised refine store (knhip_rows: refine_type fp16 / bf16 / sq8): row r of `rows` = vector id
+ * id_base + r; every rank's store must carry the same sq8 ranges.  NULL clears it.  A rank uses this store if set, else
+ * its fp32 rows. */
+int knhip_shard_group_set_raw_rows(knhip_shard_group* g, int32_t rank, const knhip_rows* rows, int64_t id_base);
 int knhip_shard_group_search_refine(knhip_shard_group* g, const float* queries, int64_t nq, int32_t k, int32_t k_base,
                                     int32_t nprobe, const uint8_t* bitset, int64_t bitset_nbits, int64_t* out_ids,
                                     float* out_dist, float* stage_ms);

@@ -46,14 +46,14 @@ SYMBOLS = [
     "knhip_merge_topk_host", "knhip_refine_device", "knhip_fvec_L2sqr_ny", "knhip_fvec_inner_products_ny",
     "knhip_fvec_norms_L2sqr", "knhip_fvec_madd", "knhip_int8_vec_L2sqr_ny",
     "knhip_int8_vec_inner_products_ny", "knhip_profile_enable", "knhip_profile_reset",
-    "knhip_profile_get", "knhip_stage_kernel_name", "knhip_range_search", "knhip_free", "knhip_search_preassigned_device",
+    "knhip_profile_get", "knhip_stage_kernel_name", "knhip_range_search", "knhip_range_search_ranked", "knhip_free", "knhip_search_preassigned_device",
     "knhip_kmeans_device", "knhip_index_train", "knhip_index_train_device", "knhip_index_add", "knhip_index_add_device",
     "knhip_index_encode_device", "knhip_index_get_coarse", "knhip_index_get_pq", "knhip_index_get_sq",
     "knhip_index_get_list_sizes", "knhip_index_get_lists", "knhip_index_get_vectors_device", "knhip_search_refine",
     "knhip_index_get_vectors", "knhip_index_find_vectors", "knhip_index_assign", "knhip_device_memory",
     "knhip_rows_create", "knhip_rows_destroy", "knhip_rows_train", "knhip_rows_set_trained", "knhip_rows_get_trained",
     "knhip_rows_add", "knhip_rows_add_codes", "knhip_rows_get_codes", "knhip_rows_count", "knhip_rows_code_size",
-    "knhip_rows_device_bytes", "knhip_search_refine_rows",
+    "knhip_rows_device_bytes", "knhip_search_refine_rows", "knhip_refine_rows_device",
     "knhip_fvec_L1_ny", "knhip_fvec_Linf_ny", "knhip_fvec_norms_L2sqr_ref", "knhip_fvec_L2sqr_ny_transposed",
     "knhip_fvec_L2sqr_ny_nearest", "knhip_fvec_L2sqr_ny_nearest_y_transposed", "knhip_fvec_madd_and_argmin",
     "knhip_fvec_batch_4", "knhip_typed_vec_ny", "knhip_typed_vec_batch_4", "knhip_ivec_ny",
@@ -91,6 +91,8 @@ def load():
     L.knhip_index_destroy.restype = None
     L.knhip_range_search.argtypes = [vp, vp, i64, C.c_float, i32, vp, i64, vp, C.POINTER(C.POINTER(C.c_int64)),
                                      C.POINTER(C.POINTER(C.c_float))]
+    L.knhip_range_search_ranked.argtypes = [vp, vp, i64, C.c_float, vp, i64, vp, C.POINTER(C.POINTER(C.c_int64)),
+                                            C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_int32))]
     L.knhip_free.argtypes = [vp]
     L.knhip_free.restype = None
     L.knhip_index_set_coarse.argtypes = [vp, vp]
@@ -162,6 +164,7 @@ def load():
         getattr(L, f).argtypes = [vp]
         getattr(L, f).restype = i64
     L.knhip_search_refine_rows.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp, i64, vp, vp]
+    L.knhip_refine_rows_device.argtypes = [i32, vp, i64, vp, i64, vp, i32, i32, vp, vp, vp]
     L.knhip_profile_enable.argtypes = [vp, C.c_int]
     L.knhip_profile_reset.argtypes = [vp]
     L.knhip_profile_get.argtypes = [vp, C.POINTER(StageTimes)]

@@ -2166,15 +2166,18 @@ int knhip_rows_train(knhip_rows* r, int64_t n, const float* x) {
 }
 
 static int rows_append(knhip_rows* r, int64_t n, const void* d_new_codes) {
-    DevBuf all;
     const size_t cs = (size_t)r->code_size();
-    HIP_TRY(all.alloc((size_t)(r->n + n) * cs));
-    if (r->n) {
-        HIP_TRY(hipMemcpy(all.p, r->codes.p, (size_t)r->n * cs, hipMemcpyDeviceToDevice));
+    const size_t need = (size_t)(r->n + n) * cs;
+    if (need > r->codes.bytes) { // grow by half: repeated Adds copy the store O(log) times (a search in flight must not
+        DevBuf all;              // race an Add: the node's reader / writer lock, as for every other index state)
+        HIP_TRY(all.alloc(std::max(need, r->codes.bytes + r->codes.bytes / 2)));
+        if (r->n) {
+            HIP_TRY(hipMemcpy(all.p, r->codes.p, (size_t)r->n * cs, hipMemcpyDeviceToDevice));
+        }
+        std::swap(r->codes.p, all.p);
+        std::swap(r->codes.bytes, all.bytes);
     }
-    HIP_TRY(hipMemcpy(static_cast<char*>(all.p) + (size_t)r->n * cs, d_new_codes, (size_t)n * cs, hipMemcpyDeviceToDevice));
-    std::swap(r->codes.p, all.p);
-    std::swap(r->codes.bytes, all.bytes);
+    HIP_TRY(hipMemcpy(static_cast<char*>(r->codes.p) + (size_t)r->n * cs, d_new_codes, (size_t)n * cs, hipMemcpyDeviceToDevice));
     r->n += n;
     return KNHIP_OK;
 }
@@ -2399,7 +2402,7 @@ static int range_batch(const knhip_index* idx, Workspace* ws, const float* d_q, 
                        int64_t nseg, int64_t ncol, int64_t* h_lims /*nq + 1, relative*/, std::vector<int64_t>& out_i,
                        std::vector<float>& out_d, hipStream_t s, const float* d_radius_q = nullptr,
                        int nprobe_limit = 0, const int64_t* pre_keys = nullptr, const float* pre_cdis = nullptr,
-                       RangeArgs* dump_only_out = nullptr) {
+                       RangeArgs* dump_only_out = nullptr, std::vector<int32_t>* out_cnt = nullptr) {
     const int kind = idx->desc.kind;
     const bool is_l2 = idx->is_l2;
     const int d = idx->d;
@@ -2627,6 +2630,12 @@ static int range_batch(const knhip_index* idx, Workspace* ws, const float* d_q, 
                               ws->rg_tot.as<int64_t>(), s));
     std::vector<int64_t> tot((size_t)nq), base((size_t)nq);
     HIP_TRY(hipMemcpyAsync(tot.data(), ws->rg_tot.p, (size_t)nq * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    if (out_cnt != nullptr) { // hits per (query, coarse rank): knhip_range_search_ranked
+        const size_t o = out_cnt->size();
+        out_cnt->resize(o + (size_t)nq * nprobe);
+        HIP_TRY(hipMemcpyAsync(out_cnt->data() + o, ws->rg_cnt.p, (size_t)nq * nprobe * sizeof(int32_t),
+                               hipMemcpyDeviceToHost, s));
+    }
     HIP_TRY(hipStreamSynchronize(s));
     int64_t run = 0;
     h_lims[0] = 0;
@@ -2812,10 +2821,13 @@ static int search_batch_ties(const knhip_index* idx, Workspace* ws, const float*
     return KNHIP_OK;
 }
 
-int knhip_range_search(const knhip_index* idx, const float* queries, int64_t nq, float radius,
-                       int32_t max_empty_result_buckets, const uint8_t* bitset, int64_t bitset_nbits, int64_t* lims,
-                       int64_t** out_ids, float** out_dist) {
+static int range_search_impl(const knhip_index* idx, const float* queries, int64_t nq, float radius,
+                             int32_t max_empty_result_buckets, const uint8_t* bitset, int64_t bitset_nbits, int64_t* lims,
+                             int64_t** out_ids, float** out_dist, int32_t** out_rank_counts) {
     if (int rc = check_index(idx)) return rc;
+    if (out_rank_counts) {
+        *out_rank_counts = nullptr;
+    }
     if (nq < 0 || max_empty_result_buckets < 0 || !lims || !out_ids || !out_dist) {
         return fail(KNHIP_ERR_INVALID_ARGS, "bad range search arguments");
     }
@@ -2842,6 +2854,7 @@ int knhip_range_search(const knhip_index* idx, const float* queries, int64_t nq,
     Workspace* ws = acquire_ws(idx, nullptr, false);
     std::vector<int64_t> res_i;
     std::vector<float> res_d;
+    std::vector<int32_t> res_cnt;
     auto run = [&]() -> int {
         int64_t nseg = 0, ncol = 0;
         const int64_t* d_seg = nullptr;
@@ -2865,7 +2878,7 @@ int knhip_range_search(const knhip_index* idx, const float* queries, int64_t nq,
             const int64_t n = std::min(qb, nq - q0);
             if (int r = range_batch(idx, ws, ws->h_queries.as<float>() + q0 * idx->d, n, radius, max_empty_result_buckets,
                                     d_bitset, bitset_nbits, d_seg, nseg, ncol, rel.data(), res_i,
-                                    res_d, s)) {
+                                    res_d, s, nullptr, 0, nullptr, nullptr, nullptr, out_rank_counts ? &res_cnt : nullptr)) {
                 return r;
             }
             for (int64_t i = 0; i < n; i++) {
@@ -2895,7 +2908,38 @@ int knhip_range_search(const knhip_index* idx, const float* queries, int64_t nq,
     }
     std::memcpy(*out_ids, res_i.data(), sizeof(int64_t) * n);
     std::memcpy(*out_dist, res_d.data(), sizeof(float) * n);
+    if (out_rank_counts) {
+        *out_rank_counts = static_cast<int32_t*>(std::malloc(sizeof(int32_t) * (res_cnt.size() + 1)));
+        if (!*out_rank_counts) {
+            std::free(*out_ids);
+            std::free(*out_dist);
+            *out_ids = nullptr;
+            *out_dist = nullptr;
+            return fail(KNHIP_ERR_OUT_OF_MEMORY, "host allocation of the range result failed");
+        }
+        std::memcpy(*out_rank_counts, res_cnt.data(), sizeof(int32_t) * res_cnt.size());
+    }
     return KNHIP_OK;
+}
+
+int knhip_range_search(const knhip_index* idx, const float* queries, int64_t nq, float radius,
+                       int32_t max_empty_result_buckets, const uint8_t* bitset, int64_t bitset_nbits, int64_t* lims,
+                       int64_t** out_ids, float** out_dist) {
+    return range_search_impl(idx, queries, nq, radius, max_empty_result_buckets, bitset, bitset_nbits, lims, out_ids, out_dist,
+                             nullptr);
+}
+
+int knhip_range_search_ranked(const knhip_index* idx, const float* queries, int64_t nq, float radius, const uint8_t* bitset,
+                              int64_t bitset_nbits, int64_t* lims, int64_t** out_ids, float** out_dist,
+                              int32_t** out_rank_counts) {
+    if (!out_rank_counts) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "range_search_ranked: null count pointer");
+    }
+    if (int rc = check_index(idx)) return rc;
+    if (idx->desc.kind == KNHIP_BRUTE_FORCE) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "range_search_ranked: an IVF index (a brute-force base has no coarse ranks)");
+    }
+    return range_search_impl(idx, queries, nq, radius, 0, bitset, bitset_nbits, lims, out_ids, out_dist, out_rank_counts);
 }
 
 void knhip_free(void* p) {
@@ -2992,6 +3036,19 @@ int knhip_refine_device(int32_t metric, int32_t dim, const float* d_base, int64_
     }
     HIP_TRY(launch_refine(d_base, nbase, id_base, dim, d_queries, nq, d_cand_ids, k_base, k, metric == KNHIP_L2,
                           d_out_dist, d_out_ids, static_cast<hipStream_t>(stream)));
+    return KNHIP_OK;
+}
+
+int knhip_refine_rows_device(int32_t metric, const knhip_rows* rows, int64_t id_base, const float* d_queries, int64_t nq,
+                             const int64_t* d_cand_ids, int32_t k_base, int32_t k, float* d_out_dist, int64_t* d_out_ids,
+                             void* stream) {
+    if (!rows || !rows->trained || rows->n <= 0 || nq < 0 || k <= 0 || k > KN_MAX_K || k_base < k || !d_queries ||
+        !d_cand_ids || !d_out_dist || !d_out_ids || (metric != KNHIP_L2 && metric != KNHIP_IP)) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "refine_rows: bad arguments");
+    }
+    HIP_TRY(launch_refine(static_cast<const float*>(rows->codes.p), rows->n, id_base, rows->d, d_queries, nq, d_cand_ids, k_base,
+                          k, metric == KNHIP_L2, d_out_dist, d_out_ids, static_cast<hipStream_t>(stream), rows->row_type,
+                          rows->row_type == KNHIP_ROWS_SQ8 ? rows->sq.as<float>() : nullptr));
     return KNHIP_OK;
 }
 

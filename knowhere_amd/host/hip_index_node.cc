@@ -141,7 +141,7 @@ struct Shard {
     int32_t device = 0;
     KnhipHandle idx;
     KnhipHandle raw;       // refine rows (IndexRefineFlat) whose ids are [raw_base, raw_base + count(raw))
-    RowsHandle rows;       // quantised refine rows (refine_type fp16 / bf16 / sq8: IndexScalarQuantizer), single device
+    RowsHandle rows;       // quantised refine rows (refine_type fp16 / bf16 / sq8: IndexScalarQuantizer): ids [raw_base, ..)
     int64_t raw_base = 0;
     int64_t row_base = 0;  // sharded FLAT: id of this shard's first row
 };
@@ -288,11 +288,6 @@ class HipIndexNode : public IndexNode {
         }
         std::vector<int32_t> devs;
         if (Status st = SelectDevices(c, /*deserialize=*/false, &devs); st != Status::success) return st;
-        if (refine_rows_type_ != 0 && devs.size() > 1) {
-            LOG_KNOWHERE_ERROR_ << TypeName() << ": a quantised refine store (refine_type fp16 / bf16 / sq8) lives on one "
-                                << "device; gpu_ids asks for " << devs.size();
-            return Status::invalid_args;
-        }
         if (Status st = CreateShards(devs); st != Status::success) return st;
         if constexpr (Kind == KNHIP_BRUTE_FORCE) {
             return Status::success;  // nothing to train
@@ -308,9 +303,11 @@ class HipIndexNode : public IndexNode {
         int rc = knhip_index_train(sh_[0].idx.p, rows, x, nullptr);
         if (rc == KNHIP_OK && sh_.size() > 1) rc = ReplicateTrainedState();
         if (rc == KNHIP_OK && refine_rows_type_ != 0) {
-            // IndexRefine::train trains the refine index on the same rows (IndexRefine.cpp:47-51): the sq8 ranges
-            rc = knhip_rows_create(sh_[0].device, (int32_t)dim_, refine_rows_type_, &sh_[0].rows.p);
+            // IndexRefine::train trains the refine index on the same rows (IndexRefine.cpp:47-51): the sq8 ranges, on the
+            // first device, copied to the stores of the others
+            rc = CreateRowStores();
             if (rc == KNHIP_OK) rc = knhip_rows_train(sh_[0].rows.p, rows, x);
+            if (rc == KNHIP_OK) rc = ReplicateRowRanges();
         }
         if (rc) {
             DropShards();
@@ -370,7 +367,20 @@ class HipIndexNode : public IndexNode {
         }
         if (NeedRawStore() && refine_rows_type_ != 0) {
             if (!sh_[0].rows.p) return Status::index_not_trained;
-            if ((rc = knhip_rows_add(sh_[0].rows.p, rows, x_store))) return ToStatus(rc);
+            // id ranges as for the fp32 rows: the first batch cut into one range per device, later batches extend the last
+            if (n0 == 0) {
+                for (int r = 0; r < W && rc == KNHIP_OK; r++) {
+                    const int64_t lo = rows * r / W, hi = rows * (r + 1) / W;
+                    sh_[r].raw_base = lo;
+                    if (hi > lo) rc = knhip_rows_add(sh_[r].rows.p, hi - lo, x_store + lo * dim_);
+                }
+            } else {
+                rc = knhip_rows_add(sh_[W - 1].rows.p, rows, x_store);
+            }
+            if (rc) return ToStatus(rc);
+            if (W > 1) {
+                if (Status st = AttachRawToGroup(); st != Status::success) return st;
+            }
         } else if (NeedRawStore()) {
             for (auto& s : sh_) {
                 if (!s.raw.p) {
@@ -486,14 +496,6 @@ class HipIndexNode : public IndexNode {
         const float range_filter = c.range_filter.value();
         int64_t max_empty = 2;
         if constexpr (Kind != KNHIP_BRUTE_FORCE) max_empty = c.max_empty_result_buckets.value_or(2);
-        if (Kind != KNHIP_BRUTE_FORCE && sh_.size() > 1) {
-            // the reference's early stop counts CONSECUTIVE lists without a hit in coarse order over all lists
-            // (IndexIVF.cpp:917-933); a shard only sees its own: the per-(query, rank) hit counts would have to be summed
-            // over the devices between the count and the stop.  Not built; refused rather than answered differently
-            // (the cuVS nodes implement no RangeSearch at all, gpu_cuvs.h:192-196).
-            return expected<DataSetPtr>::Err(Status::not_implemented,
-                                             "RangeSearch on a list-sharded index (gpu_ids with several devices)");
-        }
         checkCancellation(op_context);
         const int64_t nq = dataset->GetRows();
         const float* q = (const float*)dataset->GetTensor();
@@ -507,54 +509,96 @@ class HipIndexNode : public IndexNode {
         const uint8_t* bits = nullptr;
         int64_t nbits = 0;
         MaterialiseBitset(bitset, &in_bitset, &bits, &nbits);
-        // one result per shard (FLAT row ranges: ascending ids, so the concatenation per query is IndexFlat's row order)
+        // one result per shard.  FLAT row ranges: ascending ids, so the concatenation per query is IndexFlat's row order.
+        // List-sharded IVF kinds: every shard visits ALL of its lists and reports its hits per coarse rank
+        // (knhip_range_search_ranked: each shard holds every centroid, so all rank the lists alike); the reference's early
+        // stop counts CONSECUTIVE lists without a hit in coarse order over all lists (IndexIVF.cpp:917-933), so the counts
+        // are summed over the shards per (query, rank), the ranks walked with that rule here, and each rank's hits taken
+        // from the shard that owns the list -- the emission order and the stop of one device.  (What is lost is the
+        // saving of the early stop: every list is scanned.)  Queries go in slices that bound the count arrays.
         const int W = (int)sh_.size();
-        std::vector<std::vector<int64_t>> lims((size_t)W, std::vector<int64_t>((size_t)nq + 1));
-        std::vector<int64_t*> ids((size_t)W, nullptr);
-        std::vector<float*> dis((size_t)W, nullptr);
-        int rc = KNHIP_OK;
-        {
-            std::shared_lock<std::shared_mutex> lk(rw_);
-            for (int r = 0; r < W && rc == KNHIP_OK; r++) {
-                if (knhip_index_count(sh_[r].idx.p) == 0) continue;  // (an empty row range: lims stay 0)
-                rc = knhip_range_search(sh_[r].idx.p, q, nq, radius, (int32_t)max_empty, bits, nbits, lims[r].data(), &ids[r],
-                                        &dis[r]);
-            }
-        }
-        auto free_all = [&]() {
-            for (int r = 0; r < W; r++) {
-                knhip_free(ids[r]);
-                knhip_free(dis[r]);
-            }
-        };
-        if (rc) {
-            free_all();
-            return expected<DataSetPtr>::Err(ToStatus(rc), knhip_last_error());
-        }
-        int64_t total = 0;
-        for (int r = 0; r < W; r++) total += lims[r][(size_t)nq];
+        const bool ranked = Kind != KNHIP_BRUTE_FORCE && W > 1;
+        const int64_t slice = ranked ? std::max<int64_t>(1, ((int64_t)16 << 20) / std::max<int64_t>(nlist_, 1)) : nq;
         const bool is_ip = metric_ != KNHIP_L2;
-        auto out_lims = std::make_unique<size_t[]>(nq + 1);
-        auto out_ids = std::make_unique<int64_t[]>(std::max<int64_t>(total, 1));
-        auto out_dis = std::make_unique<float[]>(std::max<int64_t>(total, 1));
-        size_t n = 0;
-        out_lims[0] = 0;
-        for (int64_t i = 0; i < nq; i++) {
-            for (int r = 0; r < W; r++) {
-                for (int64_t j = lims[r][(size_t)i]; j < lims[r][(size_t)i + 1]; j++) {
-                    const float v = dis[r][j];
-                    const bool keep = range_filter == defaultRangeFilter ||
-                                      (is_ip ? (radius < v && v <= range_filter) : (range_filter <= v && v < radius));
-                    if (keep) {
-                        out_ids[n] = ids[r][j];
-                        out_dis[n] = v;
-                        n++;
-                    }
+        std::vector<size_t> res_lims((size_t)nq + 1, 0);
+        std::vector<int64_t> res_ids;
+        std::vector<float> res_dis;
+        auto keep = [&](float v) {
+            return range_filter == defaultRangeFilter ||
+                   (is_ip ? (radius < v && v <= range_filter) : (range_filter <= v && v < radius));
+        };
+        for (int64_t q0 = 0; q0 < nq; q0 += slice) {
+            const int64_t n = std::min(slice, nq - q0);
+            std::vector<std::vector<int64_t>> lims((size_t)W, std::vector<int64_t>((size_t)n + 1, 0));
+            std::vector<int64_t*> ids((size_t)W, nullptr);
+            std::vector<float*> dis((size_t)W, nullptr);
+            std::vector<int32_t*> cnt((size_t)W, nullptr);
+            int rc = KNHIP_OK;
+            {
+                std::shared_lock<std::shared_mutex> lk(rw_);
+                for (int r = 0; r < W && rc == KNHIP_OK; r++) {
+                    if (knhip_index_count(sh_[r].idx.p) == 0) continue;  // (an empty shard: lims stay 0, no counts)
+                    rc = ranked ? knhip_range_search_ranked(sh_[r].idx.p, q + q0 * dim_, n, radius, bits, nbits,
+                                                            lims[r].data(), &ids[r], &dis[r], &cnt[r])
+                                : knhip_range_search(sh_[r].idx.p, q + q0 * dim_, n, radius, (int32_t)max_empty, bits, nbits,
+                                                     lims[r].data(), &ids[r], &dis[r]);
                 }
             }
-            out_lims[i + 1] = n;
+            auto free_all = [&]() {
+                for (int r = 0; r < W; r++) {
+                    knhip_free(ids[r]);
+                    knhip_free(dis[r]);
+                    knhip_free(cnt[r]);
+                }
+            };
+            if (rc) {
+                free_all();
+                return expected<DataSetPtr>::Err(ToStatus(rc), knhip_last_error());
+            }
+            for (int64_t i = 0; i < n; i++) {
+                if (!ranked) {
+                    for (int r = 0; r < W; r++) {
+                        for (int64_t j = lims[r][(size_t)i]; j < lims[r][(size_t)i + 1]; j++) {
+                            if (keep(dis[r][j])) {
+                                res_ids.push_back(ids[r][j]);
+                                res_dis.push_back(dis[r][j]);
+                            }
+                        }
+                    }
+                } else {
+                    std::vector<int64_t> ptr((size_t)W);
+                    for (int r = 0; r < W; r++) ptr[(size_t)r] = lims[r][(size_t)i];
+                    int64_t nempty = 0;
+                    for (int64_t rank = 0; rank < nlist_; rank++) {
+                        int64_t hits = 0;
+                        for (int r = 0; r < W; r++) {
+                            const int64_t c = cnt[r] ? cnt[r][i * nlist_ + rank] : 0;
+                            for (int64_t j = ptr[(size_t)r]; j < ptr[(size_t)r] + c; j++) {
+                                if (keep(dis[r][j])) {
+                                    res_ids.push_back(ids[r][j]);
+                                    res_dis.push_back(dis[r][j]);
+                                }
+                            }
+                            ptr[(size_t)r] += c;
+                            hits += c;
+                        }
+                        if (max_empty > 0) {  // (the rule of range.hip::range_plan_kernel, i.e. of the reference)
+                            nempty = hits == 0 ? nempty + 1 : 0;
+                            if (nempty >= max_empty) break;
+                        }
+                    }
+                }
+                res_lims[(size_t)(q0 + i) + 1] = res_ids.size();
+            }
+            free_all();
         }
-        free_all();
+        const size_t total = res_ids.size();
+        auto out_lims = std::make_unique<size_t[]>(nq + 1);
+        auto out_ids = std::make_unique<int64_t[]>(std::max<size_t>(total, 1));
+        auto out_dis = std::make_unique<float[]>(std::max<size_t>(total, 1));
+        std::copy(res_lims.begin(), res_lims.end(), out_lims.get());
+        std::copy(res_ids.begin(), res_ids.end(), out_ids.get());
+        std::copy(res_dis.begin(), res_dis.end(), out_dis.get());
         auto res = GenResultDataSet(nq, out_ids.release(), out_dis.release(), out_lims.release());
         this->MapSearchResultIdsToOutIds(res);
         return res;
@@ -706,7 +750,9 @@ class HipIndexNode : public IndexNode {
             }
             if (has_refine_ && sh_[0].rows.p) {  // IndexRefine over an IndexScalarQuantizer ("IxSQ", refine_utils.cc:150-185)
                 const knhip_rows* rs = sh_[0].rows.p;
-                if (knhip_rows_count(rs) != count) return Status::invalid_index_error;
+                int64_t have = 0;
+                for (const auto& sd : sh_) have += sd.rows.p ? knhip_rows_count(sd.rows.p) : 0;
+                if (have != count) return Status::invalid_index_error;
                 x.has_refine = x.refine_is_sq = true;
                 fill_hdr(x.refine_hdr, count, cosine_);
                 FaissSQFlat& sq = x.refine_sq;
@@ -720,7 +766,12 @@ class HipIndexNode : public IndexNode {
                     if ((rc = knhip_rows_get_trained(rs, sq.trained.data(), sq.trained.data() + dim_))) return ToStatus(rc);
                 }
                 sq.codes.resize((size_t)count * sq.code_size);
-                if ((rc = knhip_rows_get_codes(rs, sq.codes.data()))) return ToStatus(rc);
+                for (const auto& sd : sh_) {  // (id ranges in shard order: raw_base ascending)
+                    if (!sd.rows.p || knhip_rows_count(sd.rows.p) == 0) continue;
+                    if (sd.raw_base < 0 || sd.raw_base + knhip_rows_count(sd.rows.p) > count) return Status::invalid_index_error;
+                    if ((rc = knhip_rows_get_codes(sd.rows.p, sq.codes.data() + (size_t)sd.raw_base * sq.code_size)))
+                        return ToStatus(rc);
+                }
                 x.k_factor = 1.f;
             } else if (has_refine_ && sh_[0].raw.p) {  // IndexRefineFlat (ivf.cc:673-700)
                 x.has_refine = true;
@@ -858,10 +909,6 @@ class HipIndexNode : public IndexNode {
                             : x.refine_sq.qtype == 4          ? KNHIP_ROWS_FP16
                             : x.refine_sq.qtype == 7          ? KNHIP_ROWS_BF16
                                                               : KNHIP_ROWS_SQ8;
-        if (refine_rows_type_ != 0 && devs.size() > 1) {
-            LOG_KNOWHERE_ERROR_ << TypeName() << ": a quantised refine store lives on one device; gpu_ids asks for " << devs.size();
-            return Status::invalid_args;
-        }
         row_scale_by_id_ = std::move(scale_by_id);
         if (Status st = CreateShards(devs); st != Status::success) return st;
         const int W = (int)sh_.size();
@@ -903,11 +950,19 @@ class HipIndexNode : public IndexNode {
         }
         if (x.has_refine && x.refine_is_sq) {
             const FaissSQFlat& sq = x.refine_sq;
-            if ((rc = knhip_rows_create(sh_[0].device, (int32_t)dim_, refine_rows_type_, &sh_[0].rows.p))) return bail(rc);
-            if (refine_rows_type_ == KNHIP_ROWS_SQ8 &&
-                (rc = knhip_rows_set_trained(sh_[0].rows.p, sq.trained.data(), sq.trained.data() + dim_)))
-                return bail(rc);
-            if ((rc = knhip_rows_add_codes(sh_[0].rows.p, ntotal, sq.codes.data()))) return bail(rc);
+            if ((rc = CreateRowStores())) return bail(rc);
+            for (int r = 0; r < W; r++) {
+                if (refine_rows_type_ == KNHIP_ROWS_SQ8 &&
+                    (rc = knhip_rows_set_trained(sh_[r].rows.p, sq.trained.data(), sq.trained.data() + dim_)))
+                    return bail(rc);
+                const int64_t lo = ntotal * r / W, hi = ntotal * (r + 1) / W;
+                sh_[r].raw_base = lo;
+                if (hi > lo && (rc = knhip_rows_add_codes(sh_[r].rows.p, hi - lo, sq.codes.data() + (size_t)lo * sq.code_size)))
+                    return bail(rc);
+            }
+            if (W > 1) {
+                if (Status st = AttachRawToGroup(); st != Status::success) return st;
+            }
             return Status::success;
         }
         // raw rows for refine, in id order
@@ -1189,8 +1244,36 @@ class HipIndexNode : public IndexNode {
         return knhip_index_add((sh_[W - 1].*which).p, rows, x, nullptr);
     }
 
+    // one quantised refine store per device
+    int
+    CreateRowStores() {
+        for (auto& sd : sh_) {
+            if (int rc = knhip_rows_create(sd.device, (int32_t)dim_, refine_rows_type_, &sd.rows.p)) return rc;
+        }
+        return KNHIP_OK;
+    }
+    // the sq8 ranges trained on the first device -> every other store (all devices decode alike)
+    int
+    ReplicateRowRanges() {
+        if (refine_rows_type_ != KNHIP_ROWS_SQ8 || sh_.size() < 2) return KNHIP_OK;
+        std::vector<float> tr((size_t)2 * dim_);
+        if (int rc = knhip_rows_get_trained(sh_[0].rows.p, tr.data(), tr.data() + dim_)) return rc;
+        for (size_t r = 1; r < sh_.size(); r++) {
+            if (int rc = knhip_rows_set_trained(sh_[r].rows.p, tr.data(), tr.data() + dim_)) return rc;
+        }
+        return KNHIP_OK;
+    }
+
     Status
     AttachRawToGroup() {
+        if (refine_rows_type_ != 0) {
+            for (size_t r = 0; r < sh_.size(); r++) {
+                const bool any = sh_[r].rows.p && knhip_rows_count(sh_[r].rows.p) > 0;
+                if (int rc = knhip_shard_group_set_raw_rows(group_.p, (int32_t)r, any ? sh_[r].rows.p : nullptr, sh_[r].raw_base))
+                    return ToStatus(rc);
+            }
+            return Status::success;
+        }
         for (size_t r = 0; r < sh_.size(); r++) {
             const float* d_rows = nullptr;
             const int64_t n = sh_[r].raw.p ? knhip_index_count(sh_[r].raw.p) : 0;

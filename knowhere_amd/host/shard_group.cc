@@ -72,6 +72,7 @@ struct Rank {
     // raw fp32 rows this rank holds for the refine stage: row r = vector id raw_id0 + r (device pointer on `dev`)
     const float* raw = nullptr;
     int64_t raw_n = 0, raw_id0 = 0;
+    const knhip_rows* rows = nullptr;  // ... or a quantised store of them (refine_type fp16 / bf16 / sq8)
 };
 
 }  // namespace
@@ -212,6 +213,17 @@ int knhip_shard_group_set_raw(knhip_shard_group* g, int32_t rank, const float* d
     }
     g->ranks[rank].raw = d_rows;
     g->ranks[rank].raw_n = nrows;
+    g->ranks[rank].raw_id0 = id_base;
+    return KNHIP_OK;
+}
+
+int knhip_shard_group_set_raw_rows(knhip_shard_group* g, int32_t rank, const knhip_rows* rows, int64_t id_base) {
+    if (!g || rank < 0 || rank >= g->n) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "shard_group_set_raw_rows: bad arguments");
+    }
+    g->ranks[rank].rows = rows;
+    g->ranks[rank].raw = nullptr;
+    g->ranks[rank].raw_n = rows ? knhip_rows_count(rows) : 0;
     g->ranks[rank].raw_id0 = id_base;
     return KNHIP_OK;
 }
@@ -446,9 +458,13 @@ static int search_impl(knhip_shard_group* g, const float* queries, int64_t nq, i
                                    static_cast<float*>(me.ref_d.p), static_cast<int64_t*>(me.ref_i.p), ne,
                                    metric == KNHIP_L2 ? 3.402823466e+38f : -3.402823466e+38f);
             } else if (alive) {
-                const int rrc = knhip_refine_device(metric, dim, me.raw, me.raw_n, me.raw_id0, static_cast<const float*>(me.q.p),
-                                                    nq, static_cast<const int64_t*>(me.out_i.p), k1, k,
-                                                    static_cast<float*>(me.ref_d.p), static_cast<int64_t*>(me.ref_i.p), me.stream);
+                const int rrc = me.rows
+                        ? knhip_refine_rows_device(metric, me.rows, me.raw_id0, static_cast<const float*>(me.q.p), nq,
+                                                   static_cast<const int64_t*>(me.out_i.p), k1, k,
+                                                   static_cast<float*>(me.ref_d.p), static_cast<int64_t*>(me.ref_i.p), me.stream)
+                        : knhip_refine_device(metric, dim, me.raw, me.raw_n, me.raw_id0, static_cast<const float*>(me.q.p),
+                                              nq, static_cast<const int64_t*>(me.out_i.p), k1, k,
+                                              static_cast<float*>(me.ref_d.p), static_cast<int64_t*>(me.ref_i.p), me.stream);
                 if (rrc != KNHIP_OK) {
                     err = std::string("knhip_refine_device: ") + knhip_last_error();
                     rc = rrc;
@@ -519,7 +535,7 @@ int knhip_shard_group_search_refine(knhip_shard_group* g, const float* queries, 
                                     float* out_dist, float* stage_ms) {
     if (k_base < k) return fail(KNHIP_ERR_INVALID_ARGS, "shard_group_search_refine: k_base < k");
     for (int r = 0; g && r < g->n; r++) {
-        if (g->ranks[r].raw_n > 0 && !g->ranks[r].raw) return fail(KNHIP_ERR_INVALID_ARGS, "shard_group_search_refine: no raw rows");
+        if (g->ranks[r].raw_n > 0 && !g->ranks[r].raw && !g->ranks[r].rows) return fail(KNHIP_ERR_INVALID_ARGS, "shard_group_search_refine: no raw rows");
     }
     return search_impl(g, queries, nq, k, k_base, nprobe, bitset, bitset_nbits, out_ids, out_dist, stage_ms);
 }

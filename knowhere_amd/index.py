@@ -277,6 +277,25 @@ class GpuIndex:
         self.L.knhip_free(pd)
         return lims, ids, dis
 
+    def range_search_ranked(self, xq, radius, bitset=None, nbits=0):
+        """knhip_range_search_ranked -> (lims, ids, distances, counts[nq][nlist]): every list visited, hits per coarse rank"""
+        xq = np.ascontiguousarray(xq, np.float32)
+        nq = xq.shape[0]
+        lims = np.zeros(nq + 1, np.int64)
+        pi, pd, pc = C.POINTER(C.c_int64)(), C.POINTER(C.c_float)(), C.POINTER(C.c_int32)()
+        bs = None if bitset is None else np.ascontiguousarray(bitset, np.uint8)
+        nbits = _bitset_nbits(bs, nbits)
+        check(self.L.knhip_range_search_ranked(self.h, _np_ptr(xq), nq, float(radius), _np_ptr(bs), nbits, _np_ptr(lims),
+                                               C.byref(pi), C.byref(pd), C.byref(pc)))
+        n = int(lims[-1])
+        ids = np.ctypeslib.as_array(pi, shape=(n,)).copy() if n else np.empty(0, np.int64)
+        dis = np.ctypeslib.as_array(pd, shape=(n,)).copy() if n else np.empty(0, np.float32)
+        cnt = np.ctypeslib.as_array(pc, shape=(nq * self.nlist,)).copy().reshape(nq, self.nlist) if nq else \
+            np.empty((0, self.nlist), np.int32)
+        for p in (pi, pd, pc):
+            self.L.knhip_free(p)
+        return lims, ids, dis, cnt
+
     def search_device(self, xq_t, k, nprobe=1, bitset_t=None, nbits=0, out=None, stream=None):
         import torch
         nq = xq_t.shape[0]

@@ -421,7 +421,7 @@ def test_quantised_refine_store_round_trips_with_the_reference(node, ref, port, 
 @pytest.mark.gpu
 def test_refine_needs_refine_type_and_one_device_for_quantised_stores(node):
     """`refine = true` without `refine_type` builds NO refine index (ivf_wrapper.cc:170: both are needed); sq6 is refused;
-    a quantised store with several gpu_ids is refused"""
+    the type name is case-insensitive (str_to_lower, refine_utils.cc:28)"""
     nb, d = 3000, 32
     xb = gen_data(nb, d, 42)
     name = GPU_NAME[ob.IVF_PQ].encode()
@@ -436,9 +436,6 @@ def test_refine_needs_refine_type_and_one_device_for_quantised_stores(node):
     assert rc == 0 and bytes(_node_blob(node, h)[:4]) == b"IwPQ"
     node.knhip_node_destroy(C.c_void_p(h))
     h, rc = build("refine=true;refine_type=sq6")
-    assert rc != 0
-    node.knhip_node_destroy(C.c_void_p(h))
-    h, rc = build("refine=true;refine_type=fp16;gpu_ids=0,0")
     assert rc != 0
     node.knhip_node_destroy(C.c_void_p(h))
     h, rc = build("refine=true;refine_type=FP16")

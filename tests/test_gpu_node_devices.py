@@ -72,12 +72,13 @@ class Node:
         assert rc == 0, (rc, self.L.knhip_node_last_error().decode())
         return dis, ids
 
-    def range_search(self, xq, cfg):
+    def range_search(self, xq, cfg, bitset=None, nbits=0):
         nq, d = xq.shape
         lims = np.zeros(nq + 1, np.int64)
         pi, pd = I64(), F()
+        bp = None if bitset is None else bitset.ctypes.data_as(U8)
         rc = self.L.knhip_node_range_search(C.c_void_p(self.h), xq.ctypes.data_as(F), C.c_int64(nq), C.c_int64(d), cfg.encode(),
-                                            None, C.c_int64(0), lims.ctypes.data_as(I64), C.byref(pi), C.byref(pd))
+                                            bp, C.c_int64(nbits), lims.ctypes.data_as(I64), C.byref(pi), C.byref(pd))
         if rc != 0:
             return rc, None, None, None
         n = int(lims[nq])
@@ -168,12 +169,24 @@ def test_sharded_node_is_bit_identical_to_the_single_device_node(node, name, tra
             assert rc1 == 0 and rcm == 0 and np.array_equal(v1, vm) and np.array_equal(v1, xb[want])
             rcm, _ = many.get_vectors(np.array([nb + 5], np.int64), d)
             assert rcm != 0  # an id stored on no shard is an error, as on one device
-        # RangeSearch: FLAT shards by rows and answers; the IVF kinds refuse (the early stop needs every list's hit count)
+        # RangeSearch: FLAT shards by rows; the IVF kinds sum the hits per (query, coarse rank) over the shards and apply
+        # the reference's early stop to the sums: the single-device answer, in its emission order, for every stop setting
         radius = float(np.median(one.search(xq[:8], cfg, 10)[0][:, 5]))
         rcfg = f"radius={radius!r};{search_cfg}"
         r1 = one.range_search(xq[:8], rcfg)
         rm = many.range_search(xq[:8], rcfg)
         assert r1[0] == 0
+        if name != "GPU_HIP_BRUTE_FORCE":
+            for extra in ("", ";max_empty_result_buckets=1", ";max_empty_result_buckets=0", ";max_empty_result_buckets=7"):
+                a, b = one.range_search(xq[:24], rcfg + extra), many.range_search(xq[:24], rcfg + extra)
+                assert a[0] == 0 and b[0] == 0, (name, metric, extra, b[0])
+                assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), (name, metric, extra)
+                assert np.array_equal(a[3].view(np.uint32), b[3].view(np.uint32)), (name, metric, extra)
+            assert one.range_search(xq[:24], rcfg + ";max_empty_result_buckets=1")[1][-1] <= \
+                one.range_search(xq[:24], rcfg + ";max_empty_result_buckets=0")[1][-1]
+            bs = np.packbits(np.random.default_rng(3).random(nb) < 0.4, bitorder="little")
+            a, b = one.range_search(xq[:24], rcfg, bs, nb), many.range_search(xq[:24], rcfg, bs, nb)
+            assert a[0] == 0 and b[0] == 0 and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
         if name == "GPU_HIP_BRUTE_FORCE":
             assert rm[0] == 0 and np.array_equal(r1[1], rm[1])
             for q in range(8):  # (same hits per query; the emission order of IndexFlat::range_search is the row order)
@@ -181,8 +194,6 @@ def test_sharded_node_is_bit_identical_to_the_single_device_node(node, name, tra
                 o1, om = np.argsort(r1[2][a], kind="stable"), np.argsort(rm[2][b], kind="stable")
                 assert np.array_equal(r1[2][a][o1], rm[2][b][om])
                 assert np.array_equal(r1[3][a][o1].view(np.uint32), rm[3][b][om].view(np.uint32))
-        else:
-            assert rm[0] == 7, rm[0]  # Status::not_implemented
     finally:
         one.close()
         many.close()
@@ -203,18 +214,45 @@ def test_sharded_refine_through_the_node(node, metric):
             cfg = f"k={k};nprobe=16" + (f";refine_k={rk}" if rk != 1 else "")
             assert same(one.search(xq, cfg, k), many.search(xq, cfg, k)), (metric, k, rk)
         assert np.array_equal(one.blob(), many.blob())
-        # a quantised refine store (one device) with several gpu_ids is refused, never silently replaced by another one;
-        # sq6 is not a store this backend has
-        for cfg in (base.replace("refine_type=fp32", "refine_type=sq8") + f";gpu_ids={shard_ids(2)}",
-                    base.replace("refine_type=fp32", "refine_type=sq6") + ";gpu_id=0"):
-            bad = Node(node, "GPU_HIP_IVF_PQ")
-            try:
-                assert bad.build(xb, cfg) != 0
-            finally:
-                bad.close()
+        # sq6 is not a store this backend has: refused, never silently replaced by another one
+        bad = Node(node, "GPU_HIP_IVF_PQ")
+        try:
+            assert bad.build(xb, base.replace("refine_type=fp32", "refine_type=sq6") + ";gpu_id=0") != 0
+        finally:
+            bad.close()
     finally:
         one.close()
         many.close()
+
+
+@pytest.mark.parametrize("rtype", ["fp16", "bf16", "sq8"])
+@pytest.mark.parametrize("metric", ["L2", "IP"])
+def test_sharded_quantised_refine_through_the_node(node, metric, rtype):
+    """refine_type = fp16 / bf16 / sq8 on a sharded index: the store is cut into one id range per device (the sq8 ranges
+    trained once, copied to every device), every device re-ranks the candidates whose rows it holds
+    (knhip_shard_group_set_raw_rows); results, bytes, repeated Add and reload equal the single-device node's"""
+    nb, d, nq = 20000, 64, 100
+    xb, xq = gen_data(nb, d, 42), gen_data(nq, d, 44)
+    base = f"metric_type={metric};dim={d};nlist=64;m=16;nbits=8;refine=true;refine_type={rtype}"
+    one, many, again = Node(node, "GPU_HIP_IVF_PQ"), Node(node, "GPU_HIP_IVF_PQ"), Node(node, "GPU_HIP_IVF_PQ")
+    try:
+        for nd, extra in ((one, ";gpu_id=0"), (many, f";gpu_ids={shard_ids(3)}")):
+            assert nd.train(xb, base + extra) == 0, node.knhip_node_last_error().decode()
+            for lo, hi in ((0, 12000), (12000, nb)):
+                assert nd.add(np.ascontiguousarray(xb[lo:hi]), base + extra) == 0
+            assert nd.count() == nb
+        for k, rk in ((10, 8), (5, 20), (10, 1)):
+            cfg = f"k={k};nprobe=16" + (f";refine_k={rk}" if rk != 1 else "")
+            assert same(one.search(xq, cfg, k), many.search(xq, cfg, k)), (metric, rtype, k, rk)
+        b1 = one.blob()
+        assert np.array_equal(b1, many.blob())
+        assert again.load("GPU_HIP_IVF_PQ", b1, f"metric_type={metric};gpu_ids={shard_ids(2)}") == 0
+        cfg = "k=10;nprobe=16;refine_k=8"
+        assert same(one.search(xq, cfg, 10), again.search(xq, cfg, 10)), (metric, rtype, "reloaded on 2 shards")
+    finally:
+        one.close()
+        many.close()
+        again.close()
 
 
 @pytest.mark.parametrize("name,train_cfg,search_cfg", KINDS[:2] + KINDS[3:], ids=[k[0] for k in KINDS[:2] + KINDS[3:]])

@@ -160,3 +160,60 @@ def test_range_unsupported_and_edge_cases(port):
     assert lims.tolist() == [0] * 6 and ids.size == 0
     lims, ids, dis = g.range_search(xq, 3.0e38, 0)  # everything is
     assert lims[-1] == 5 * nb
+
+
+@pytest.mark.parametrize("kind,M,d", [(ob.IVF_FLAT, 0, 32), (ob.IVF_SQ8, 0, 32), (ob.IVF_PQ, 32, 128), (ob.IVF_PQ, 12, 48)],
+                         ids=["ivfflat", "ivfsq8", "ivfpq32", "ivfpq12"])
+@pytest.mark.parametrize("metric", [ob.L2, ob.IP], ids=["l2", "ip"])
+def test_ranked_range_search_counts_rebuild_every_early_stop(port, kind, M, d, metric):
+    """knhip_range_search_ranked (what a list-sharded deployment merges by): every list visited, hits per coarse rank.
+    The counts add up to the per-query totals, and walking them with the reference's rule reproduces the oracle's result
+    for every max_empty_result_buckets -- here with the lists dealt to two "shards" whose results are merged the way
+    the node does (knowhere_amd/host/hip_index_node.cc, RangeSearch)"""
+    from knowhere_amd import GpuIndex
+    nb, nq, nlist = 6000, 24, 48
+    xb, xq = gen_data(nb, d, 42), gen_data(nq, d, 44)
+    ix = ob.make_index(port, kind, metric, xb, nlist=nlist, M=M or 8)
+    if kind == ob.IVF_PQ:
+        finish_ivfpq(port, ix)
+    g = GpuIndex.from_data(ix, device=0)
+    D40, _ = port.search(ix, xq, 40, nlist)
+    radius = float(np.median(D40[:, 12]))
+    lims, ids, dis, cnt = g.range_search_ranked(xq, np.float32(radius))
+    assert cnt.shape == (nq, nlist) and np.array_equal(cnt.sum(1), np.diff(lims))
+    full = g.range_search(xq, np.float32(radius), 0)
+    assert np.array_equal(full[0], lims) and np.array_equal(full[1], ids)
+    # two shards: the same centroids, the lists dealt alternately
+    import copy
+    parts = []
+    for s in range(2):
+        sub = copy.copy(ix)
+        sub.list_codes = [c if l % 2 == s else c[:0] for l, c in enumerate(ix.list_codes)]
+        sub.list_ids = [i if l % 2 == s else i[:0] for l, i in enumerate(ix.list_ids)]
+        gs = GpuIndex.from_data(sub, device=0)
+        parts.append(gs.range_search_ranked(xq, np.float32(radius)))
+        gs.close()
+    assert np.array_equal(parts[0][3] + parts[1][3], cnt), "every shard ranks the lists alike"
+    for max_empty in (0, 1, 2, 5):
+        exp = port.range_search(ix, xq, radius, max_empty)
+        got_i, got_d = [], []
+        for q in range(nq):
+            ptr = [p[0][q] for p in parts]
+            nempty = 0
+            for r in range(nlist):
+                hits = 0
+                for s, p in enumerate(parts):
+                    c = int(p[3][q, r])
+                    got_i.append(p[1][ptr[s]:ptr[s] + c])
+                    got_d.append(p[2][ptr[s]:ptr[s] + c])
+                    ptr[s] += c
+                    hits += c
+                if max_empty > 0:
+                    nempty = nempty + 1 if hits == 0 else 0
+                    if nempty >= max_empty:
+                        break
+        ii = np.concatenate(got_i) if got_i else np.empty(0, np.int64)
+        dd = np.concatenate(got_d) if got_d else np.empty(0, np.float32)
+        assert np.array_equal(ii, exp[1]), (max_empty,)
+        assert np.array_equal(dd.view(np.uint32), exp[2].view(np.uint32)), (max_empty,)
+    g.close()
