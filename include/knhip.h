@@ -266,7 +266,9 @@ int knhip_search_refine(const knhip_index* idx, const knhip_index* raw, const fl
 /* ---- quantised refine store: Knowhere's `refine_type` = fp16 / bf16 / sq8 (src/index/ivf/ivf_config.h:113-135,
  * src/index/refine/refine_utils.cc:99-160: the refine index is a faiss::IndexScalarQuantizer(d, QT_fp16 / QT_bf16 /
  * QT_8bit, metric) instead of IndexFlat).  knhip_rows keeps the encoded rows in HBM (row r = vector id r):
- *   fp16: IEEE half, round to nearest even (utils/fp16.h encode_fp16);  bf16: (bits + 0x8000) >> 16 (utils/bf16.h:27-32);
+ *   fp16: the reference's scalar encode_fp16 (utils/fp16-inl.h:32-86: 11 mantissa bits kept, then round half UP -- IEEE
+ *         round-to-nearest except that exact ties go up; builds with F16C round ties to even there);
+ *   bf16: (bits + 0x8000) >> 16 (utils/bf16.h:27-32);
  *   sq8:  per-dimension ranges trained over ALL training rows (ScalarQuantizer::train, RS_minmax, rangestat_arg 0),
  *         code_i = (int)(255 * clamp((x_i - vmin_i) / vdiff_i, 0, 1)), x_i = vmin_i + vdiff_i * ((code_i + 0.5) / 255)
  *         (impl/scalar_quantizer/quantizers.h:108-146, codecs.h:26-41).

@@ -448,8 +448,8 @@ struct PqDumpArgs {
 hipError_t launch_pq_adc_dump(const PqDumpArgs& a, int64_t nq, bool is_l2, hipStream_t s);
 
 // ---- pq_scan_any.hip: exact IVF-PQ top-k scan for any number of 8-bit sub-quantizers (the widths the fast kernels do not
-// take).  One workgroup per (query, probe); its four waves write four sorted partial lists:
-// partial slot = 4 * probe rank + wave, so merge_partials runs over 4 * nprobe slots
+// take).  One workgroup per (query, probe) writing pq_scan_any_parts(k) sorted partial lists (k <= 64: one per wave,
+// partial slot = 4 * probe rank + wave; larger k: one), so merge_partials runs over parts * nprobe slots
 struct PqAnyArgs {
     const int64_t* keys;         // [nq][nprobe] probed lists (coarse order; < 0: none)
     const float* coarse_dis;     // [nq][nprobe]
@@ -469,11 +469,11 @@ struct PqAnyArgs {
     const float* queries;        // [nq][d]          (RESIDUAL)
     const uint8_t* bitset;
     int64_t bitset_nbits;
-    float* partial_d;            // [nq][nprobe * 4][k]
+    float* partial_d;            // [nq][nprobe * parts][k]
     int64_t* partial_i;
     int32_t k;
 };
-constexpr int PQ_ANY_PARTS = 4;  // partial lists per (query, probe)
+int pq_scan_any_parts(int k);    // partial lists per (query, probe): 4 (one per wave, k <= 64) or 1 (block selection)
 int pq_scan_any_supports(int M, int d);
 hipError_t launch_pq_scan_any(const PqAnyArgs& a, int64_t nq, bool is_l2, hipStream_t s);
 // (rank0, nrank >= 0: one wave of ranks; qstate: queries with qstate[q][1] != 0 are skipped)

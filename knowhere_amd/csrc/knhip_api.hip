@@ -782,7 +782,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             StageTimer t(idx, s, KNHIP_STAGE_LUT);
             HIP_TRY(launch_pq_query_table(d_q, idx->cb.as<float>(), d, M, nq, ws->t2t.as<float>(), s));
         }
-        const int64_t nparts = (int64_t)nprobe * PQ_ANY_PARTS;
+        const int64_t nparts = (int64_t)nprobe * pq_scan_any_parts(k);
         HIP_TRY(ws->partial_d.reserve((size_t)nq * nparts * k * sizeof(float)));
         HIP_TRY(ws->partial_i.reserve((size_t)nq * nparts * k * sizeof(int64_t)));
         PqAnyArgs a{};
@@ -1534,7 +1534,7 @@ int64_t query_batch(const knhip_index* idx, int64_t nq, int k, int nprobe) {
         if (idx->desc.kind == KNHIP_IVF_PQ) {
             per_q += 256.0 * idx->desc.pq_m * 4.0;
             if (!pq_scan_supported_m(idx->desc.pq_m)) { // (pq_scan_any.hip: four partial lists per probe)
-                per_q += (double)nprobe * (PQ_ANY_PARTS - 1) * (double)k * 12.0;
+                per_q += (double)nprobe * (pq_scan_any_parts(k) - 1) * (double)k * 12.0;
             }
         }
     }

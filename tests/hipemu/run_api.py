@@ -107,19 +107,22 @@ def main():
         D, I = g.search(xq, 7, 3)
         same(Do, Io, D, I, "pq_any ties")
         assert g.profile_get()["tie_queries"] > 0
+        Do, Io = port.search(ix, xq, 70, 3)  # k > 64: the block selection, its boundary tied (the second bisection)
+        D, I = g.search(xq, 70, 3)
+        same(Do, Io, D, I, "pq_any ties, block selection")
         g.close()
     elif case == "refine_rows":
         # quantised refine stores: train / encode / append on the device == the oracle's restatement (pinned against
         # IndexScalarQuantizer), and knhip_search_refine_rows == IndexRefine over it
         from knowhere_amd import RowStore
-        nb, nlist, nq = 700, 4, 6
+        nb, nlist, nq = 500, 4, 4
         # d = 24: sq8 rows are not a multiple of 16 bytes (element loads); d = 32: every row type takes the 16-byte loads
-        for metric, d in ((ob.L2, 24), (ob.IP, 32)):
+        for metric, d, types in ((ob.L2, 24, (1, 3)), (ob.IP, 32, (2, 3))):
             xb, xq = gen_data(nb, d, 42, -40.0, 60.0), gen_data(nq, d, 44, -40.0, 60.0)
             xb[5, :4] = [1 + 2.0 ** -11, 2.0 ** -25, 65520.0, -(1 + 3 * 2.0 ** -11)]  # fp16 ties / subnormal / overflow
             ix = ob.make_index(port, ob.IVF_SQ8, metric, xb, nlist=nlist)
             g = GpuIndex.from_data(ix, device=0)
-            for rt in (1, 2, 3):
+            for rt in types:
                 rows = RowStore(rt, d, device=0)
                 tr = port.rows_train(xb) if rt == 3 else None
                 codes = port.rows_encode(rt, xb, tr)
@@ -178,12 +181,13 @@ def main():
         # nlist > 128 with an early stop: the probes go in waves of coarse ranks (range.hip); IVF-Flat and IVF-SQ8
         nb, d, nlist, nq = 2500, 8, 200, 4
         xb, xq = gen_data(nb, d, 42), gen_data(nq, d, 44)
-        for kind in (ob.IVF_FLAT, ob.IVF_SQ8):
+        full = os.environ.get("KNHIP_TEST_EMU_FULL") == "1"  # (the default run: one kind, two stop settings -- ~50 s)
+        for kind in ((ob.IVF_FLAT, ob.IVF_SQ8) if full else (ob.IVF_FLAT,)):
             ix = ob.make_index(port, kind, ob.L2, xb, nlist=nlist)
             g = GpuIndex.from_data(ix, device=0)
             D, _ = port.search(ix, xq, 40, nlist)
             radius = float(np.median(D[:, 20]))
-            for max_empty in (1, 3, 0):
+            for max_empty in ((1, 3, 0) if full else (3, 0)):
                 exp = port.range_search(ix, xq, radius, max_empty)
                 got = g.range_search(xq, np.float32(radius), max_empty)
                 assert np.array_equal(exp[0], got[0]) and np.array_equal(exp[1], got[1]), (kind, max_empty)

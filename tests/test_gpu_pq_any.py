@@ -78,6 +78,27 @@ def test_any_m_boundary_ties_and_range_search(port, M, d, metric):
     g.close()
 
 
+@pytest.mark.parametrize("metric", [ob.L2, ob.IP], ids=["l2", "ip"])
+def test_any_m_long_lists_and_large_k(port, metric):
+    """k > 64 takes the block selection (pq_scan_any_block_kernel): lists longer than its 4096-row tile (the carried list),
+    k up to 1024, a bitset, and duplicated rows that tie at the boundary of the tile selection"""
+    from test_gpu_ties import _dup_data
+    M, d = 12, 48
+    for xb, xq, what in ((gen_data(14000, d, 42), gen_data(24, d, 44), "random"), (*_dup_data(14000, d, 60, 5), "duplicates")):
+        nb = len(xb)
+        ix = finish_ivfpq(port, ob.make_index(port, ob.IVF_PQ, metric, xb, nlist=3, M=M))
+        assert max(len(i) for i in ix.list_ids) > 4096
+        g = _gpu(ix)
+        bs = np.packbits(np.random.default_rng(5).random(nb) < 0.5, bitorder="little")
+        for k, nprobe in ((65, 3), (100, 2), (1000, 3), (1024, 1)):
+            for bitset, nbits in ((None, 0), (bs, nb)):
+                Do, Io = port.search(ix, xq, k, nprobe, bitset, nbits)
+                D, I = g.search(xq, k, nprobe, bitset, nbits)
+                assert_parity(Do, Io, D, I, metric, f"{what} k={k} nprobe={nprobe} bitset={bitset is not None}",
+                              licensed_ties=(k == 1024))  # (k + 1 results are not available at k = 1024: canonical ties)
+        g.close()
+
+
 def test_unsupported_shapes_are_refused():
     from knowhere_amd import GpuIndex, KnhipError
     for M, d in ((129, 258), (256, 256), (5, 32), (1, 200)):  # above 128; does not divide; sub-vectors above 144 dims
