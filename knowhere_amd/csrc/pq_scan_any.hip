@@ -8,14 +8,15 @@
 //              arithmetic as pq_scan.hip's LUT build and range.hip::pq_adc_dump_kernel
 //   * distance PQCodeDistanceScalar::distance_single_code (pq_code_distance-inl.h:69-90): the m table values summed from 0
 //              in m order, then dis0 + sum (IVFPQScanner_impl.h:109-181)
-//   * top-k    per wave a canonical (distance, id) top-k; the four waves of a workgroup write four sorted partial lists
-//              (partial slot = 4 * probe rank + wave), merged by topk.hip::merge_partials -- boundary ties are then
-//              resolved like for every other kernel (knhip_api.hip::search_batch_ties)
+//   * top-k    canonical (distance, id) partial lists, merged by topk.hip::merge_partials -- boundary ties are then
+//              resolved like for every other kernel (knhip_api.hip::search_batch_ties).  k <= 64: one list per wave built
+//              by sorting (pq_scan_any_kernel, partial slot = 4 * probe rank + wave); k > 64: one list per workgroup by
+//              block-wide selection (pq_scan_any_block_kernel)
 // One workgroup per (query, probed list): the (query, list) table [m][256] fp32 in LDS (m KB; 160 KB LDS holds m = 128),
 // one thread per stored vector reading its m code bytes from the list-sorted AoS codes.  Not a tuned kernel: LDS
 // gathers with random bank conflicts, a table build per (query, list); it is the completeness path, the headline
-// shapes never reach it.  (Round 4, 10M x 96, m = 24, nprobe 64, batch 10k: 109 ms with sequential top-k insertion --
-// 143 ms of insertion in a 165 ms variant --; the sorted list build below removed most of it.)
+// shapes never reach it.  (Round 4, 10M x 96, m = 24, nprobe 64, batch 10k: sequential top-k insertion took 109 ms at
+// k = 101, of which tables + distances are 22; now 38 ms there and 30 ms at k = 11: DESIGN.md section 7.)
 #include "common.h"
 #include "kernels.h"
 
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(PA_THREADS) void pq_scan_any_block_kernel(PqAnyArgs
     }
 }
 
-template <bool IS_L2, int R>
+template <bool IS_L2>
 __global__ __launch_bounds__(PA_THREADS) void pq_scan_any_kernel(PqAnyArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     float* lut = reinterpret_cast<float*>(smem); // [M][256]
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(PA_THREADS) void pq_scan_any_kernel(PqAnyArgs a) {
     const int slot = (int)(blockIdx.x % a.nprobe);
     float* pd = a.partial_d + ((q * a.nprobe + slot) * PA_WAVES + wave) * (int64_t)a.k;
     int64_t* pi = a.partial_i + ((q * a.nprobe + slot) * PA_WAVES + wave) * (int64_t)a.k;
-    WaveTopK<IS_L2, R> top;
+    WaveTopK<IS_L2, 1> top; // k <= 64: one list entry per lane
     top.init(a.k);
     const int64_t list = a.keys[q * a.nprobe + slot];
     const int64_t len = (list >= 0 && list < a.nlist) ? a.list_len[list] : 0;
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(PA_THREADS) void pq_scan_any_kernel(PqAnyArgs a) {
         dis = fadd_x(dis0, acc);
         return true;
     };
-    // candidates of one row per lane through the sequential insertion (k > 64, and the stragglers of the sorted path)
+    // candidates of one row per lane through the sequential insertion (the stragglers of the sorted path)
     auto insert_passing = [&](bool pass, float dis, int64_t id) {
         unsigned long long mk = __ballot(pass && top.admits(dis, id, kd, ki));
         while (mk) {
@@ -462,8 +463,8 @@ __global__ __launch_bounds__(PA_THREADS) void pq_scan_any_kernel(PqAnyArgs a) {
             }
         }
     };
-    if (R == 1) {
-        // ---- k <= 64: one list entry per lane, built by sorting (see the helpers above) ----
+    {
+        // ---- one list entry per lane, built by sorting (see the helpers above) ----
         const int k = a.k;
         int cnt = 0; // valid entries of the list (wave-uniform)
         for (int64_t b0 = (int64_t)wave * KN_WAVE * PA_S; b0 < len; b0 += (int64_t)PA_THREADS * PA_S) {
@@ -547,13 +548,6 @@ __global__ __launch_bounds__(PA_THREADS) void pq_scan_any_kernel(PqAnyArgs a) {
                 cnt = __popcll(__ballot(top.i[0] >= 0));
             }
         }
-    } else {
-        for (int64_t p0 = (int64_t)wave * KN_WAVE; p0 < len; p0 += PA_THREADS) {
-            float dis;
-            int64_t id;
-            const bool ok = row_distance(p0 + lane, dis, id);
-            insert_passing(ok, dis, id);
-        }
     }
     top.store(pd, pi);
 }
@@ -584,7 +578,7 @@ hipError_t launch_pq_scan_any(const PqAnyArgs& a, int64_t nq, bool is_l2, hipStr
         return hipGetLastError();
     }
     const size_t sm = (size_t)a.M * 256 * sizeof(float);
-    auto kern = is_l2 ? pq_scan_any_kernel<true, 1> : pq_scan_any_kernel<false, 1>;
+    auto kern = is_l2 ? pq_scan_any_kernel<true> : pq_scan_any_kernel<false>;
     if (sm > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)sm);
