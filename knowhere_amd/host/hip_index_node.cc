@@ -207,8 +207,9 @@ DealLists(const std::vector<int64_t>& sizes, int W) {
 
 template <typename DataType, int Kind>
 class HipIndexNode : public IndexNode {
-    static_assert(std::is_same_v<DataType, fp32>, "fp16 / bf16 / int8 come through the reference's mock wrapper "
-                                                  "(KNOWHERE_MOCK_REGISTER_GLOBAL, index_factory.h:95-103)");
+    // (instantiated for fp16 / bf16 / int8 too, for the static registry entries -- StaticCreateConfig and friends, as
+    // KNOWHERE_REGISTER_STATIC wants them --; an OBJECT exists for fp32 only: the other vector types come through the
+    // reference's conversion wrapper, see the registrations at the end of the file)
 
  public:
     using knowhere_config_type =
@@ -216,7 +217,9 @@ class HipIndexNode : public IndexNode {
                            std::conditional_t<Kind == KNHIP_IVF_FLAT, HipIvfFlatConfig,
                                               std::conditional_t<Kind == KNHIP_IVF_PQ, HipIvfPqConfig, HipIvfSqConfig>>>;
 
-    HipIndexNode(const int32_t& /*version*/, const Object& /*object*/) {}
+    HipIndexNode(const int32_t& /*version*/, const Object& /*object*/) {
+        static_assert(std::is_same_v<DataType, fp32>, "fp16 / bf16 / int8 datasets are converted by IndexNodeDataMockWrapper");
+    }
     ~HipIndexNode() override = default;
 
     bool
@@ -1377,8 +1380,7 @@ using HipIvfPqIndexNode = HipIndexNode<DataType, KNHIP_IVF_PQ>;
 template <typename DataType>
 using HipIvfSqIndexNode = HipIndexNode<DataType, KNHIP_IVF_SQ8>;
 
-// static-init registration, as src/index/gpu_cuvs/gpu_cuvs_ivf_pq.cc:27-63 does (fp16 / bf16 / int8: add the matching
-// KNOWHERE_MOCK_REGISTER_GLOBAL lines)
+// static-init registration, as src/index/gpu_cuvs/gpu_cuvs_ivf_pq.cc:27-63 does (fp16 / bf16 / int8: below)
 KNOWHERE_REGISTER_GLOBAL_WITH_THREAD_POOL(GPU_HIP_BRUTE_FORCE, HipBruteForceIndexNode, fp32,
                                           knowhere::feature::GPU_KNN_FLOAT_INDEX, HipSearchPoolSize());
 KNOWHERE_REGISTER_GLOBAL_WITH_THREAD_POOL(GPU_HIP_IVF_FLAT, HipIvfFlatIndexNode, fp32,
@@ -1387,6 +1389,38 @@ KNOWHERE_REGISTER_GLOBAL_WITH_THREAD_POOL(GPU_HIP_IVF_PQ, HipIvfPqIndexNode, fp3
                                           knowhere::feature::GPU_ANN_FLOAT_INDEX, HipSearchPoolSize());
 KNOWHERE_REGISTER_GLOBAL_WITH_THREAD_POOL(GPU_HIP_IVF_SQ8, HipIvfSqIndexNode, fp32,
                                           knowhere::feature::GPU_ANN_FLOAT_INDEX, HipSearchPoolSize());
+
+
+#if defined(KNHIP_WITH_KNOWHERE_HEADERS)
+// fp16 / bf16 / int8 vectors, as the CPU IVF nodes take them (KNOWHERE_MOCK_REGISTER_DENSE_FLOAT_ALL_GLOBAL /
+// _DENSE_INT_GLOBAL, ivf.cc:1924-1966): the reference's own IndexNodeDataMockWrapper (index_node_data_mock_wrapper.h: the
+// dataset is converted to fp32 on the host, results converted back where vectors are returned) in front of the fp32
+// node, inside the GPU nodes' thread-pool wrapper -- KNOWHERE_MOCK_REGISTER_GLOBAL (index_factory.h:95-103) with the pool
+// of KNOWHERE_REGISTER_GLOBAL_WITH_THREAD_POOL (:157-165).  Only in a Knowhere tree: the wrapper is the reference's
+// code (src/index/index_node_data_mock_wrapper.cc), not restated in the stand-alone shim build.
+#define KNHIP_MOCK_REGISTER_WITH_THREAD_POOL(name, index_node, data_type, features, thread_size)                          \
+    KNOWHERE_REGISTER_STATIC(name, index_node, data_type)                                                                  \
+    KNOWHERE_REGISTER_GLOBAL(                                                                                              \
+        name,                                                                                                              \
+        [](const int32_t& version, const Object& object) {                                                                 \
+            return (Index<IndexNodeThreadPoolWrapper>::Create(                                                             \
+                std::make_unique<IndexNodeDataMockWrapper<data_type>>(                                                     \
+                    std::make_unique<index_node<MockData<data_type>::type>>(version, object)),                             \
+                thread_size));                                                                                             \
+        },                                                                                                                 \
+        data_type, typeCheck<data_type>(features), features)
+#define KNHIP_MOCK_REGISTER_TYPES(name, index_node)                                                                         \
+    KNHIP_MOCK_REGISTER_WITH_THREAD_POOL(name, index_node, fp16, knowhere::feature::GPU | knowhere::feature::FP16,         \
+                                         HipSearchPoolSize());                                                             \
+    KNHIP_MOCK_REGISTER_WITH_THREAD_POOL(name, index_node, bf16, knowhere::feature::GPU | knowhere::feature::BF16,         \
+                                         HipSearchPoolSize());                                                             \
+    KNHIP_MOCK_REGISTER_WITH_THREAD_POOL(name, index_node, int8, knowhere::feature::GPU | knowhere::feature::INT8,         \
+                                         HipSearchPoolSize());
+KNHIP_MOCK_REGISTER_TYPES(GPU_HIP_BRUTE_FORCE, HipBruteForceIndexNode)
+KNHIP_MOCK_REGISTER_TYPES(GPU_HIP_IVF_FLAT, HipIvfFlatIndexNode)
+KNHIP_MOCK_REGISTER_TYPES(GPU_HIP_IVF_PQ, HipIvfPqIndexNode)
+KNHIP_MOCK_REGISTER_TYPES(GPU_HIP_IVF_SQ8, HipIvfSqIndexNode)
+#endif
 
 }  // namespace knowhere
 

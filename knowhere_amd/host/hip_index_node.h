@@ -13,6 +13,7 @@
 #include "knowhere/context.h"
 #include "knowhere/index/index_factory.h"
 #include "knowhere/index/index_node.h"
+#include "knowhere/index/index_node_data_mock_wrapper.h"
 #include "knowhere/index/index_node_thread_pool_wrapper.h"
 #else
 #include "knowhere_shim.h"

@@ -60,3 +60,22 @@ def test_shim_names_match_reference_macros():
     for fn in ("StaticCreateConfig", "StaticHasRawData", "StaticConfigCheck", "checkCancellation",
                "MapSearchResultIdsToOutIds"):
         assert fn in src, fn
+    # fp16 / bf16 / int8: the reference's conversion wrapper in front of the fp32 node, one line per index type (compiled
+    # by the two tests above: the block is active with the reference's headers)
+    assert src.count("KNHIP_MOCK_REGISTER_TYPES(GPU_HIP_") == 4
+    assert "IndexNodeDataMockWrapper<data_type>" in src and "MockData<data_type>::type" in src
+
+
+@needs_ref
+def test_typed_registrations_expand_to_the_reference_wrapper():
+    """preprocessed with the reference's headers: twelve typed factory entries (4 index types x fp16 / bf16 / int8), each
+    building IndexNodeThreadPoolWrapper(IndexNodeDataMockWrapper<T>(node<fp32>))"""
+    cmd = ["g++", "-std=c++17", "-E", "-P", "-DKNHIP_WITH_KNOWHERE_HEADERS", f"-I{REF}/include", f"-I{REF}/src", f"-I{REF}",
+           f"-I{REF}/thirdparty/faiss", f"-I{ROOT}/tests/cpp/ref_stubs", f"-I{ROOT}/include",
+           os.path.join(ROOT, "knowhere_amd", "host", "hip_index_node.cc")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = r.stdout.replace(" ", "").replace("\n", "")
+    for t in ("fp16", "bf16", "int8"):
+        assert out.count(f"std::make_unique<IndexNodeDataMockWrapper<{t}>>(") == 4, t
+        assert out.count(f"MockData<{t}>::type>>(version,object)") == 4, t
