@@ -128,3 +128,32 @@ def test_fp16_encode_integer_form_is_exhaustively_the_reference(port):
             want = port.rows_encode(1, x, None).view(np.uint16).ravel()
             got = _encode_fp16_int(bits)
             assert np.array_equal(want, got)
+
+
+@pytest.mark.parametrize("row_type,name", ROW_TYPES, ids=[r[1] for r in ROW_TYPES])
+@pytest.mark.parametrize("metric", [ob.L2, ob.IP], ids=["l2", "ip"])
+def test_refine_rows_ties_equal_the_reference(port, ref, metric, row_type, name):
+    """duplicated raw rows encode to the same code and tie exactly after the re-rank: which of them the reference returns
+    depends on where they stood in the first stage's result (reorder_2_heaps pushes them in candidate order) -- the
+    restatement must make the same choice"""
+    rng = np.random.default_rng(11)
+    d, nb, nq = 24, 3000, 40
+    proto = (rng.integers(-3, 4, (30, d)) * 7.0).astype(np.float32)
+    xb = np.ascontiguousarray(proto[rng.integers(0, 30, nb)])
+    xq = np.ascontiguousarray(proto[rng.integers(0, 30, nq)] + rng.integers(0, 2, (nq, d)).astype(np.float32))
+    h = ref.create(ob.IVF_SQ8, metric, d, 16, 0, 8)
+    try:
+        ref.train_add(h, xb)
+        ix = ref.export(h, ob.IVF_SQ8, metric, d, 16, 0, 8)
+        tr = port.rows_train(xb) if row_type == 3 else None
+        codes = port.rows_encode(row_type, xb, tr)
+        ties = 0
+        for k, kf, nprobe in ((6, 10.0, 9), (10, 3.0, 16), (4, 1.0, 5)):
+            Dr, Ir = ref.search_refine_sq(h, row_type, xb, xq, k, kf, nprobe)
+            _, Ib = port.search(ix, xq, int(k * kf), nprobe)
+            Dp, Ip = port.refine_rows(metric, row_type, d, codes, tr, xq, Ib, k)
+            assert Dr.tobytes() == Dp.tobytes() and (Ir == Ip).all(), f"{name} k={k} k_factor={kf}"
+            ties += int((Dr[:, :-1] == Dr[:, 1:]).sum())
+        assert ties > 0, "no tied distances in the results: the data tests nothing"
+    finally:
+        ref.destroy(h)
