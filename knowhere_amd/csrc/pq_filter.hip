@@ -45,6 +45,7 @@
 #include <algorithm>
 #include <cstddef>
 #include <cstdio>
+#include <cstdlib>
 
 namespace knhip {
 
@@ -1654,8 +1655,10 @@ __global__ __launch_bounds__(PF_THREADS) void pqi_kernel(MScanArgs a) {
         const uint32_t rq = (uint32_t)ctl[8 + slot * REC_WORDS + lane_i];
 #pragma unroll
         for (int j = 0; j < PI_Q; j++) {
+            // (a scalar base per table + one 32-bit lane offset: saddr loads, no 64-bit address arithmetic per table)
             const int64_t q = (int64_t)(int32_t)__builtin_amdgcn_readlane((int)rq, 2 + j);
-            t[j] = qi2[q * (PF_KSUB * PF_M / 8) + (wave * KN_WAVE + lane_i)];
+            const unsigned char* tq = reinterpret_cast<const unsigned char*>(qi2) + q * (PF_KSUB * PF_M);
+            t[j] = *reinterpret_cast<const uint2*>(tq + (size_t)((uint32_t)(wave * KN_WAVE + lane_i) * 8u));
         }
     };
 
@@ -1968,11 +1971,13 @@ __global__ __launch_bounds__(PF_THREADS) void pqi_kernel(MScanArgs a) {
 #endif
 }
 
+
 hipError_t launch_pqi(const MScanArgs& a, bool is_l2, int64_t units_bound, hipStream_t s) {
     if (units_bound <= 0) {
         return hipSuccess;
     }
     auto kern = is_l2 ? pqi_kernel<true> : pqi_kernel<false>;
+    const int nthreads = PF_THREADS;
     const size_t sm = pqf_smem();
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)sm);
@@ -1992,13 +1997,13 @@ hipError_t launch_pqi(const MScanArgs& a, bool is_l2, int64_t units_bound, hipSt
     static unsigned long long zero[128] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pf_prof), zero, sizeof(zero));
 #endif
-    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(PF_THREADS), sm, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(nthreads), sm, s, a);
 #ifdef KNHIP_PHASE_TIMERS
     (void)hipStreamSynchronize(s);
     unsigned long long h[128];
     (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pf_prof), sizeof(h));
     fprintf(stderr, "[pqf timers] int8 filter ticks per unit: wave | lut wait1 setup windows wait2 top | windows/unit\n");
-    for (int w = 0; w < 16; w++) {
+    for (int w = 0; w < nthreads / KN_WAVE; w++) {
         const unsigned long long* r = h + w * 8;
         const double n = r[7] ? (double)r[7] : 1.0;
         fprintf(stderr, "[pqf timers] %2d | %6.0f %6.0f %6.0f %6.0f %6.0f %5.0f | %.2f   (units %llu)\n", w, r[0] / n, r[1] / n,

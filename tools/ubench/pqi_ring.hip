@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -250,7 +251,56 @@ void run_scan(const char* name, const uint32_t* dtok, float* out, const uint2* t
     printf("\n");
 }
 
+// v_cvt_flr_i32_f32 (one instruction) against (int)floorf(x): pqi8_kernel's group test relies on it
+__global__ void kflr(const float* x, int* o, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        int r;
+        asm("v_cvt_flr_i32_f32_e32 %0, %1" : "=v"(r) : "v"(x[i]));
+        o[i] = r;
+    }
+}
+
+static void check_flr() {
+    std::vector<float> h;
+    for (int i = -4100; i <= 4100; i++) {
+        for (float f : {0.0f, 0.25f, 0.5f, 0.75f, 0.99999994f}) {
+            h.push_back((float)i + f);
+            h.push_back(((float)i + f) * 65536.0f);
+        }
+    }
+    for (float f : {536870912.0f, -536870912.0f, 536870880.0f, -536870880.0f, 1e-30f, -1e-30f, -0.0f}) {
+        h.push_back(f);
+    }
+    srand(7);
+    for (int i = 0; i < 200000; i++) {
+        h.push_back(((float)rand() / RAND_MAX - 0.5f) * 1.0e9f);
+        h.push_back(((float)rand() / RAND_MAX - 0.5f) * 3.0e3f);
+    }
+    const int n = (int)h.size();
+    float* dx;
+    int* dout;
+    CK(hipMalloc(&dx, n * 4));
+    CK(hipMalloc(&dout, n * 4));
+    CK(hipMemcpy(dx, h.data(), n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(kflr, dim3((n + 255) / 256), dim3(256), 0, 0, dx, dout, n);
+    std::vector<int> o(n);
+    CK(hipMemcpy(o.data(), dout, n * 4, hipMemcpyDeviceToHost));
+    int bad = 0;
+    for (int i = 0; i < n; i++) {
+        const int want = (int)floorf(h[i]);
+        if (o[i] != want) {
+            if (bad < 5) {
+                printf("  v_cvt_flr_i32_f32(%.9g) = %d, floorf -> %d\n", h[i], o[i], want);
+            }
+            bad++;
+        }
+    }
+    printf("v_cvt_flr_i32_f32 == (int)floorf on %d values (|x| < 2^29.9): %d mismatches\n", n, bad);
+}
+
 int main() {
+    check_flr();
     // tokens as adc_loop.hip: code random, m from the stream's phase (any conflict-free pattern does for a rate test)
     const size_t n = (size_t)256 * 1024 * 16;
     std::vector<uint32_t> htok(n);
