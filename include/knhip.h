@@ -57,8 +57,9 @@ extern "C" {
 #endif
 
 /* 4: knhip_train_params gained spherical/reserved, knhip_stage_times its prefilter counters.  5: tie_queries.  6: the quantised refine store (knhip_rows_*, knhip_search_refine_rows), knhip_range_search_ranked.
+ * 7: sixteen profiling stages (sample / tables / refine / ties itemised), tie_anomalies.
  * Callers compare knhip_abi_version() with the header they were built against. */
-#define KNHIP_ABI_VERSION 6
+#define KNHIP_ABI_VERSION 7
 
 typedef struct knhip_index knhip_index;
 
@@ -410,7 +411,7 @@ int knhip_ivec_ny(int32_t metric, int32_t* d_out, const int8_t* d_x, const int8_
                   void* stream);
 
 /* ---- profiling hooks (bench.py / rocprof cross-check) ---- */
-#define KNHIP_NSTAGE 8
+#define KNHIP_NSTAGE 16
 typedef struct knhip_stage_times {
     /* accumulated HIP-event milliseconds per stage since the last reset, and launch counts */
     float ms[KNHIP_NSTAGE];
@@ -431,6 +432,8 @@ typedef struct knhip_stage_times {
     int64_t pq_filter_form;    /* IVF_PQ prefilter of the last search: 0 none (exact kernels), 1 half precision, 2 int8 */
     int64_t tie_queries;       /* queries with candidates tied at their k-th distance beyond the k-th place, resolved by the
                                   reference's first-come admission rule (scan order) instead of the canonical order */
+    int64_t tie_anomalies;     /* ... of those, rows the resolution left at their canonical copy because its dump pass found
+                                  fewer entries than the row holds (expected 0: counted so that it cannot go unnoticed) */
 } knhip_stage_times;
 /* stage indices */
 enum {
@@ -440,7 +443,12 @@ enum {
     KNHIP_STAGE_SCAN = 3,     /* per-list code scan (ADC / flat / SQ8) -- the dominant kernel */
     KNHIP_STAGE_MERGE = 4,    /* per-query merge of per-probe partial top-k */
     KNHIP_STAGE_OTHER = 5,
-    KNHIP_STAGE_SCAN_RANK0 = 6 /* IVF_PQ: rank-0 probes in dump mode + radix select (pq_scan_v2.hip) */
+    KNHIP_STAGE_SCAN_RANK0 = 6, /* exact IVF_PQ kernels: rank-0 probes in dump mode + radix select (pq_scan_v2.hip);
+                                   prefilter paths: the SAMPLE pass (tau_q from each query's closest lists) */
+    KNHIP_STAGE_TABLES = 7,   /* prefilter paths: the queries' tables / operands of the filter + the selectivity guard */
+    KNHIP_STAGE_REFINE = 8,   /* exact re-rank of the first stage's candidates (knhip_search_refine*, knhip_refine*_device
+                                 when given the index) */
+    KNHIP_STAGE_TIES = 9      /* k-th-boundary ties: detection, read-back, dump pass and rule of the flagged queries */
 };
 int knhip_profile_enable(knhip_index* idx, int on);
 int knhip_profile_reset(knhip_index* idx);

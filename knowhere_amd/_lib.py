@@ -11,9 +11,11 @@ LIB_PATH = os.environ.get("KNHIP_LIB") or os.path.join(_HERE, "libknhip.so")  # 
 
 BRUTE_FORCE, IVF_FLAT, IVF_PQ, IVF_SQ8 = 0, 1, 2, 3
 L2, IP = 0, 1
-NSTAGE = 8
-ABI_VERSION = 6  # KNHIP_ABI_VERSION of include/knhip.h
-STAGE_COARSE, STAGE_GROUP, STAGE_LUT, STAGE_SCAN, STAGE_MERGE, STAGE_OTHER, STAGE_SCAN_RANK0 = range(7)
+NSTAGE = 16
+ABI_VERSION = 7  # KNHIP_ABI_VERSION of include/knhip.h
+(STAGE_COARSE, STAGE_GROUP, STAGE_LUT, STAGE_SCAN, STAGE_MERGE, STAGE_OTHER, STAGE_SCAN_RANK0, STAGE_TABLES, STAGE_REFINE,
+ STAGE_TIES) = range(10)
+STAGE_NAMES = ["coarse", "group", "lut", "scan", "merge", "other", "scan_rank0", "tables", "refine", "ties"]
 
 
 class KnhipError(RuntimeError):
@@ -32,7 +34,8 @@ class StageTimes(C.Structure):
     _fields_ = [("ms", C.c_float * NSTAGE), ("launches", C.c_int64 * NSTAGE), ("scan_bytes", C.c_double),
                 ("coarse_flops", C.c_double), ("scan_items", C.c_int64), ("coarse_fallback_queries", C.c_int64), ("scan_bytes_rank0", C.c_double),
                 ("mscan_queries", C.c_int64), ("mscan_overflow_queries", C.c_int64), ("mscan_candidates", C.c_int64), ("mscan_stream_bytes", C.c_double),
-                ("mscan_recomputed", C.c_int64), ("pq_filter_form", C.c_int64), ("tie_queries", C.c_int64)]
+                ("mscan_recomputed", C.c_int64), ("pq_filter_form", C.c_int64), ("tie_queries", C.c_int64),
+                ("tie_anomalies", C.c_int64)]
 
 
 # every symbol include/knhip.h declares (tests check the .so exports all of them)

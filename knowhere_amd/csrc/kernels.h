@@ -323,7 +323,7 @@ hipError_t launch_pq_skew_codes(const uint8_t* codes, const int64_t* list_row_of
                                 const int64_t* list_len, const int64_t* list_sblk_off, int64_t nlist,
                                 int M, uint4* out, hipStream_t s);
 
-// ---- pq_scan_v2.hip (M = 32, k <= 128: lane-stationary staggered ADC on the stream16 layout) ----
+// ---- pq_scan_v2.hip (M = 32, k <= 192: lane-stationary staggered ADC on the stream16 layout) ----
 bool pq_scan_v2_supports(int M, int k);
 int64_t pq_stream16_blocks(int64_t len);
 hipError_t launch_pq_scan_v2(const PqScanArgs& a, bool is_l2, bool dump, int64_t grid, hipStream_t s);
@@ -335,7 +335,7 @@ hipError_t launch_rank0_select(const float* dump, int64_t dump_stride, const int
 hipError_t launch_pq_stream16(const uint8_t* codes, const int64_t* list_row_off, const int64_t* list_len,
                               const int64_t* list_sblk_off, int64_t nlist, uint4* out, hipStream_t s);
 
-// ---- pq_scan_q4.hip (M = 32, dsub = 4, k <= 128: persistent 4-query staggered ADC, LUT built in-kernel) ----
+// ---- pq_scan_q4.hip (M = 32, dsub = 4, k <= 192: persistent 4-query staggered ADC, LUT built in-kernel) ----
 bool pq_scan_q4_supports(int M, int d, int k);
 hipError_t launch_pq_scan_q4(const PqScanArgs& a, bool is_l2, int64_t items_bound, hipStream_t s);
 hipError_t launch_pq_cb_transpose(const float* cb, int M, int dsub, float4* cb_t, hipStream_t s);
@@ -424,7 +424,7 @@ hipError_t launch_tie_gather(const int32_t* flagged, int nflag, const float* q, 
                              float* rad_out, hipStream_t s);
 hipError_t launch_tie_apply(const int32_t* flagged, int nflag, const float* can_d, const int64_t* can_i, int k, bool is_l2,
                             const float* hit_d, const int64_t* hit_i, const int64_t* total, float* out_d, int64_t* out_i,
-                            hipStream_t s);
+                            int32_t* anomalies, hipStream_t s);
 // every exact ADC distance of every probed list of an IVF-PQ index with any M x 8 bit codes (range.hip)
 struct PqDumpArgs {
     float* dist;                 // [nq][ncol], column = list_row_off[list] + position

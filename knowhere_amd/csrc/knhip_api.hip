@@ -1110,6 +1110,10 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
                                               ws->ms_nrow.as<int32_t>()));
                 HIP_TRY(launch_ms_tau(ws->sel_d.as<float>(), nq, k, is_l2, ws->gthr.as<float>(), ws->gmeta.as<uint2>(), s));
             }
+        }
+        {
+            StageTimer t(idx, s, KNHIP_STAGE_TABLES); // (IVF_PQ: the filter's query tables + the selectivity guard)
+            const bool want_i8 = kind == KNHIP_IVF_PQ && idx->pqf_form != 1;
             if (kind == KNHIP_IVF_PQ) {
                 // The integer form of the filter (int8 tables, 16 queries per unit: twice the lookups per step) has an eps
                 // 8 .. 20 x that of the half-precision form.  Selectivity guard (pq_filter.hip): the sample dump predicts
@@ -2021,6 +2025,7 @@ static int search_host_impl(const knhip_index* idx, const RefineStore* raw, cons
         if (raw) { // IndexRefine::search second stage, on the device-resident raw rows
             HIP_TRY(ws->h_ref_d.reserve((size_t)nq * k * sizeof(float)));
             HIP_TRY(ws->h_ref_i.reserve((size_t)nq * k * sizeof(int64_t)));
+            StageTimer t(idx, s, KNHIP_STAGE_REFINE);
             HIP_TRY(launch_refine(static_cast<const float*>(raw->rows), raw->n, raw->id0, idx->d,
                                   ws->h_queries.as<float>(), nq, res_i, k_base, k, idx->is_l2, ws->h_ref_d.as<float>(),
                                   ws->h_ref_i.as<int64_t>(), s, raw->row_type, raw->sq));
@@ -2751,6 +2756,7 @@ static int search_batch_ties(const knhip_index* idx, Workspace* ws, const float*
         return rc;
     }
     if (trace) fprintf(stderr, "[ties] searched\n");
+    StageTimer t_ties(idx, s, KNHIP_STAGE_TIES); // (detection, read-back and -- for the flagged queries -- dump pass + rule)
     int32_t* flagged = ws->tie_flag.as<int32_t>();
     int32_t* nflag_dev = flagged + nq;
     HIP_TRY(hipMemsetAsync(nflag_dev, 0, sizeof(int32_t), s));
@@ -2811,7 +2817,7 @@ static int search_batch_ties(const knhip_index* idx, Workspace* ws, const float*
                                   ws->rg_out_d.as<float>(), s, k));
         HIP_TRY(launch_tie_apply(flagged + f0, (int)n, ws->tie_d.as<float>(), ws->tie_i.as<int64_t>(), k, is_l2,
                                  ws->rg_out_d.as<float>(), ws->rg_out_i.as<int64_t>(), ws->rg_tot.as<int64_t>(), d_out_d,
-                                 d_out_i, s));
+                                 d_out_i, reinterpret_cast<int32_t*>(idx->coarse_fail_dev.as<unsigned long long>() + 5), s));
     }
     if (trace) fprintf(stderr, "[ties] applied\n");
     {
@@ -3884,8 +3890,9 @@ int knhip_profile_get(const knhip_index* idx, knhip_stage_times* out) {
     out->tie_queries = idx->tie_queries;
     out->scan_items = idx->last_items_bound;
     // coarse certificate failures; prefilter paths: finished / overflowed queries, candidates, exact recomputations
-    unsigned long long nf[5] = {0, 0, 0, 0, 0};
+    unsigned long long nf[6] = {0, 0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpy(nf, idx->coarse_fail_dev.p, sizeof(nf), hipMemcpyDeviceToHost));
+    out->tie_anomalies = (int64_t)(nf[5] & 0xffffffffull);
     out->coarse_fallback_queries = (int64_t)nf[0];
     out->mscan_queries = (int64_t)nf[1];
     out->mscan_overflow_queries = (int64_t)nf[2];

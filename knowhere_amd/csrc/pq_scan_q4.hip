@@ -748,8 +748,11 @@ static hipError_t launch_q4_r(const PqScanArgs& a, int64_t items_bound, hipStrea
     return hipGetLastError();
 }
 
+// k <= 192 (R = 1, 2, 3).  R = 3 exists for ONE case that matters: the k-th-boundary tie rule searches for k + 1 results
+// (knhip_api.hip, search_batch_ties), and a caller's k = 128 must not fall off this kernel onto the systolic one and its
+// second copy of the codes.
 bool pq_scan_q4_supports(int M, int d, int k) {
-    return M == P4_M && d == P4_M * P4_DSUB && k <= 128;
+    return M == P4_M && d == P4_M * P4_DSUB && k <= 192;
 }
 
 hipError_t launch_pq_scan_q4(const PqScanArgs& a, bool is_l2, int64_t items_bound, hipStream_t s) {
@@ -759,7 +762,10 @@ hipError_t launch_pq_scan_q4(const PqScanArgs& a, bool is_l2, int64_t items_boun
     if (a.k <= 64) {
         return is_l2 ? launch_q4_r<true, 1>(a, items_bound, s) : launch_q4_r<false, 1>(a, items_bound, s);
     }
-    return is_l2 ? launch_q4_r<true, 2>(a, items_bound, s) : launch_q4_r<false, 2>(a, items_bound, s);
+    if (a.k <= 128) {
+        return is_l2 ? launch_q4_r<true, 2>(a, items_bound, s) : launch_q4_r<false, 2>(a, items_bound, s);
+    }
+    return is_l2 ? launch_q4_r<true, 3>(a, items_bound, s) : launch_q4_r<false, 3>(a, items_bound, s);
 }
 
 } // namespace knhip

@@ -553,9 +553,10 @@ static hipError_t launch_v2_r(const PqScanArgs& a, int64_t grid, hipStream_t s) 
     return hipGetLastError();
 }
 
-// k <= 128 only (R = 1, 2); larger k stays on the systolic kernel and its layout
+// k <= 192 (R = 1, 2, 3; R = 3 for the tie rule's k + 1 at a caller's k = 128: see pq_scan_q4_supports); larger k stays on
+// the systolic kernel and its layout
 bool pq_scan_v2_supports(int M, int k) {
-    return M == P2_M && k <= 128;
+    return M == P2_M && k <= 192;
 }
 
 hipError_t launch_pq_scan_v2(const PqScanArgs& a, bool is_l2, bool dump, int64_t grid, hipStream_t s) {
@@ -568,7 +569,10 @@ hipError_t launch_pq_scan_v2(const PqScanArgs& a, bool is_l2, bool dump, int64_t
     if (a.k <= 64) {
         return is_l2 ? launch_v2_r<true, 1, false>(a, grid, s) : launch_v2_r<false, 1, false>(a, grid, s);
     }
-    return is_l2 ? launch_v2_r<true, 2, false>(a, grid, s) : launch_v2_r<false, 2, false>(a, grid, s);
+    if (a.k <= 128) {
+        return is_l2 ? launch_v2_r<true, 2, false>(a, grid, s) : launch_v2_r<false, 2, false>(a, grid, s);
+    }
+    return is_l2 ? launch_v2_r<true, 3, false>(a, grid, s) : launch_v2_r<false, 3, false>(a, grid, s);
 }
 
 // ---- rank-0 epilogue: list offsets -> ids, partial slot 0, shared threshold -------------------------------

@@ -477,11 +477,12 @@ __global__ __launch_bounds__(RG_THREADS) void tie_apply_kernel(const int32_t* __
                                                                const float* __restrict__ hit_d,
                                                                const int64_t* __restrict__ hit_i,
                                                                const int64_t* __restrict__ total,
-                                                               float* __restrict__ out_d, int64_t* __restrict__ out_i) {
+                                                               float* __restrict__ out_d, int64_t* __restrict__ out_i,
+                                                               int32_t* __restrict__ anomalies) {
     extern __shared__ __align__(16) unsigned char smem[];
     float* pool_d = reinterpret_cast<float*>(smem);                         // [2 k]
     int64_t* pool_i = reinterpret_cast<int64_t*>(smem + (size_t)2 * k * 4); // [2 k] (2 k * 4 is a multiple of 8)
-    __shared__ int s_n;
+    __shared__ int s_n, s_valid;
     const int64_t f = blockIdx.x; // row of the hits
     const int64_t q = flagged[f]; // row of the batch
     const int kk = k + 1;
@@ -489,6 +490,7 @@ __global__ __launch_bounds__(RG_THREADS) void tie_apply_kernel(const int32_t* __
     const float v = can_d[q * kk + k - 1];
     if (tid == 0) {
         s_n = 0;
+        s_valid = 0;
     }
     __syncthreads();
     // the canonical entries better than v, and the ties among the first k arrivals, in any order (ranked below)
@@ -501,6 +503,9 @@ __global__ __launch_bounds__(RG_THREADS) void tie_apply_kernel(const int32_t* __
             de = can_d[q * kk + e];
             ie = can_i[q * kk + e];
             take = ie >= 0 && de != v;
+            if (ie >= 0) {
+                atomicAdd(&s_valid, 1);
+            }
         } else {
             de = hit_d[f * k + (e - k)];
             ie = hit_i[f * k + (e - k)];
@@ -514,6 +519,15 @@ __global__ __launch_bounds__(RG_THREADS) void tie_apply_kernel(const int32_t* __
     }
     __syncthreads();
     const int n = s_n; // (>= k whenever the query was flagged: k entries at or below v exist and arrive)
+    if (n < s_valid) {
+        // Fewer entries than the canonical row holds: the dump pass did not reproduce a tied distance bit for bit (it runs
+        // through other kernels than the search) or the bitset / k + 1 interplay left fewer than k arrivals.  The row keeps
+        // its canonical copy (written by tie_detect) -- a partial overwrite would return duplicate or misordered ids.
+        if (tid == 0 && anomalies != nullptr) {
+            atomicAdd(anomalies, 1);
+        }
+        return;
+    }
     for (int e = tid; e < n; e += RG_THREADS) {
         const float de = pool_d[e];
         const int64_t ie = pool_i[e];
@@ -541,7 +555,7 @@ hipError_t launch_tie_gather(const int32_t* flagged, int nflag, const float* q, 
 
 hipError_t launch_tie_apply(const int32_t* flagged, int nflag, const float* can_d, const int64_t* can_i, int k, bool is_l2,
                             const float* hit_d, const int64_t* hit_i, const int64_t* total, float* out_d, int64_t* out_i,
-                            hipStream_t s) {
+                            int32_t* anomalies, hipStream_t s) {
     if (nflag <= 0) {
         return hipSuccess;
     }
@@ -551,7 +565,7 @@ hipError_t launch_tie_apply(const int32_t* flagged, int nflag, const float* can_
         return hipErrorInvalidValue; // (k <= 1023: 24 KB)
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nflag), dim3(RG_THREADS), sm, s, flagged, can_d, can_i, k, hit_d, hit_i, total,
-                       out_d, out_i);
+                       out_d, out_i, anomalies);
     return hipGetLastError();
 }
 

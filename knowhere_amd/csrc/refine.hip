@@ -238,14 +238,29 @@ hipError_t launch_refine(const float* base, int64_t nbase, int64_t id_base, int 
     }
     const unsigned grid = (unsigned)((nq + 3) / 4);
     const size_t sm = ((size_t)4 * d + (size_t)4 * kbase) * sizeof(float);
+    if (sm > 160 * 1024) {
+        return hipErrorInvalidValue; // (four queries + their candidates' distances do not fit the CU's LDS)
+    }
+    // (above the default dynamic-LDS limit -- d >= ~3 k with k_base up to 1024 -- the limit is raised per instantiation)
+#define KN_REFINE_ONE(L2_, ROWT_)                                                                                     \
+    {                                                                                                                 \
+        auto kern_ = refine_kernel<L2_, R_, ROWT_>;                                                                   \
+        if (sm > 48 * 1024) {                                                                                         \
+            const hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kern_),                           \
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);           \
+            if (e_ != hipSuccess) {                                                                                   \
+                return e_;                                                                                            \
+            }                                                                                                         \
+        }                                                                                                             \
+        hipLaunchKernelGGL(kern_, dim3(grid), dim3(256), sm, s, base, nbase, id_base, d, queries, nq, cand, kbase, k, \
+                           out_d, out_i, sq_trained);                                                                 \
+    }
 #define KN_REFINE_LAUNCH(ROWT_)                                                                                       \
     KN_DISPATCH_R(k, {                                                                                                \
         if (is_l2) {                                                                                                  \
-            hipLaunchKernelGGL((refine_kernel<true, R_, ROWT_>), dim3(grid), dim3(256), sm, s, base, nbase, id_base,  \
-                               d, queries, nq, cand, kbase, k, out_d, out_i, sq_trained);                            \
+            KN_REFINE_ONE(true, ROWT_)                                                                                \
         } else {                                                                                                      \
-            hipLaunchKernelGGL((refine_kernel<false, R_, ROWT_>), dim3(grid), dim3(256), sm, s, base, nbase, id_base, \
-                               d, queries, nq, cand, kbase, k, out_d, out_i, sq_trained);                            \
+            KN_REFINE_ONE(false, ROWT_)                                                                               \
         }                                                                                                             \
     })
     switch (row_type) {
@@ -255,6 +270,7 @@ hipError_t launch_refine(const float* base, int64_t nbase, int64_t id_base, int 
         default: KN_REFINE_LAUNCH(0); break;
     }
 #undef KN_REFINE_LAUNCH
+#undef KN_REFINE_ONE
     return hipGetLastError();
 }
 

@@ -361,15 +361,26 @@ class HipIndexNode : public IndexNode {
         } else {
             rc = AddSharded(n0, rows, x_store, x_assign);
         }
+        // A failure from here on may have left some shard with rows the others (or the norms / the refine store / the
+        // group) do not have: Count, ids and the stores would disagree for ever after.  The node drops the index and
+        // reports the error -- a caller can rebuild, it cannot be handed half an Add.
+        auto broken = [&](Status st) {
+            LOG_KNOWHERE_ERROR_ << TypeName() << ": Add failed after rows were appended; the index is dropped";
+            DropShards();
+            row_scale_by_id_.clear();
+            return st;
+        };
         if (rc) {
             row_scale_by_id_.resize(scale0);
-            return ToStatus(rc);
+            // one device, or a failure before anything was appended (assignment, routing): the index is unchanged
+            if (W == 1 || CountLocked() == n0) return ToStatus(rc);
+            return broken(ToStatus(rc));
         }
         if (StoredNormCosine()) {
-            if (Status st = PushRowScale(); st != Status::success) return st;
+            if (Status st = PushRowScale(); st != Status::success) return broken(st);
         }
         if (NeedRawStore() && refine_rows_type_ != 0) {
-            if (!sh_[0].rows.p) return Status::index_not_trained;
+            if (!sh_[0].rows.p) return broken(Status::index_not_trained);
             // id ranges as for the fp32 rows: the first batch cut into one range per device, later batches extend the last
             if (n0 == 0) {
                 for (int r = 0; r < W && rc == KNHIP_OK; r++) {
@@ -380,9 +391,9 @@ class HipIndexNode : public IndexNode {
             } else {
                 rc = knhip_rows_add(sh_[W - 1].rows.p, rows, x_store);
             }
-            if (rc) return ToStatus(rc);
+            if (rc) return broken(ToStatus(rc));
             if (W > 1) {
-                if (Status st = AttachRawToGroup(); st != Status::success) return st;
+                if (Status st = AttachRawToGroup(); st != Status::success) return broken(st);
             }
         } else if (NeedRawStore()) {
             for (auto& s : sh_) {
@@ -392,12 +403,12 @@ class HipIndexNode : public IndexNode {
                     rd.metric = metric_;
                     rd.dim = (int32_t)dim_;
                     rd.device = s.device;
-                    if ((rc = knhip_index_create(&rd, &s.raw.p))) return ToStatus(rc);
+                    if ((rc = knhip_index_create(&rd, &s.raw.p))) return broken(ToStatus(rc));
                 }
             }
-            if ((rc = AddRowRanges(&Shard::raw, &Shard::raw_base, n0, rows, x_store))) return ToStatus(rc);
+            if ((rc = AddRowRanges(&Shard::raw, &Shard::raw_base, n0, rows, x_store))) return broken(ToStatus(rc));
             if (W > 1) {
-                if (Status st = AttachRawToGroup(); st != Status::success) return st;
+                if (Status st = AttachRawToGroup(); st != Status::success) return broken(st);
             }
         }
         return Status::success;
@@ -920,10 +931,14 @@ class HipIndexNode : public IndexNode {
             DropShards();
             return ToStatus(e);
         };
+        auto bail_st = [&](Status st) { // (a post-step failed: the half-loaded index is dropped, as for every other step)
+            DropShards();
+            return st;
+        };
         if constexpr (Kind == KNHIP_BRUTE_FORCE) {
             if ((rc = AddRowRanges(&Shard::idx, &Shard::row_base, 0, ntotal, x.xb.data()))) return bail(rc);
             if (StoredNormCosine()) {
-                if (Status st = PushRowScale(); st != Status::success) return st;
+                if (Status st = PushRowScale(); st != Status::success) return bail_st(st);
             }
             return Status::success;
         }
@@ -949,7 +964,7 @@ class HipIndexNode : public IndexNode {
         }
         if (StoredNormCosine()) {
             const Status st = PushRowScale();
-            if (st != Status::success) return st;
+            if (st != Status::success) return bail_st(st);
         }
         if (x.has_refine && x.refine_is_sq) {
             const FaissSQFlat& sq = x.refine_sq;
@@ -964,7 +979,7 @@ class HipIndexNode : public IndexNode {
                     return bail(rc);
             }
             if (W > 1) {
-                if (Status st = AttachRawToGroup(); st != Status::success) return st;
+                if (Status st = AttachRawToGroup(); st != Status::success) return bail_st(st);
             }
             return Status::success;
         }
@@ -980,7 +995,7 @@ class HipIndexNode : public IndexNode {
             }
             if ((rc = AddRowRanges(&Shard::raw, &Shard::raw_base, 0, ntotal, x.refine_index.xb.data()))) return bail(rc);
             if (W > 1) {
-                if (Status st = AttachRawToGroup(); st != Status::success) return st;
+                if (Status st = AttachRawToGroup(); st != Status::success) return bail_st(st);
             }
         }
         return Status::success;
@@ -1320,7 +1335,19 @@ class HipIndexNode : public IndexNode {
         for (int r = 0; r < W; r++) {
             th.emplace_back([&, r]() {
                 const int64_t n = (int64_t)ids[r].size();
-                if (n == 0) return;
+                if (n == 0) {
+                    // A shard that has received nothing yet still needs an (empty) list layout: without one it answers
+                    // Search() with "empty index" and fails the whole group (fewer non-empty lists than devices: small
+                    // segments, nlist shrunk to rows / 39, a skewed first batch).  Same call Deserialize makes.
+                    if (knhip_index_count(sh_[r].idx.p) == 0) {
+                        const std::vector<int64_t> zero((size_t)nlist_, 0);
+                        const std::vector<const uint8_t*> cp((size_t)nlist_, nullptr);
+                        const std::vector<const int64_t*> ip((size_t)nlist_, nullptr);
+                        rcs[r] = knhip_index_add_lists(sh_[r].idx.p, zero.data(), cp.data(), ip.data());
+                        if (rcs[r]) errs[r] = knhip_last_error();
+                    }
+                    return;
+                }
                 rcs[r] = two ? knhip_index_add_assigned_by(sh_[r].idx.p, n, xs[r].data(), xa[r].data(), ids[r].data())
                              : knhip_index_add(sh_[r].idx.p, n, xs[r].data(), ids[r].data());
                 if (rcs[r]) errs[r] = knhip_last_error();  // (thread-local text: fetched on the thread that failed)

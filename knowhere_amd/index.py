@@ -348,7 +348,7 @@ class GpuIndex:
                 "mscan_queries": st.mscan_queries, "mscan_overflow_queries": st.mscan_overflow_queries,
                 "mscan_candidates": st.mscan_candidates, "mscan_stream_bytes": st.mscan_stream_bytes,
                 "mscan_recomputed": st.mscan_recomputed, "pq_filter_form": st.pq_filter_form,
-                "tie_queries": st.tie_queries}
+                "tie_queries": st.tie_queries, "tie_anomalies": st.tie_anomalies}
 
 
 def kmeans_device(metric, x_t, k, niter=None, max_points=None, seed=None, spherical=False):

@@ -277,6 +277,31 @@ def test_repeated_add_on_a_sharded_node(node, name, train_cfg, search_cfg):
         many.close()
 
 
+@pytest.mark.parametrize("name,train_cfg,search_cfg",
+                         [("GPU_HIP_IVF_FLAT", "nlist=2", "nprobe=2"), ("GPU_HIP_IVF_SQ8", "nlist=2", "nprobe=2")],
+                         ids=["ivfflat", "ivfsq8"])
+def test_sharded_node_with_fewer_lists_than_devices(node, name, train_cfg, search_cfg):
+    """fewer non-empty lists than devices (small segments; nlist shrunk to rows / 39, ivf.cc:478-489; a skewed first batch):
+    a shard that owns nothing must still answer -- an empty partial --, not fail the whole Search with `empty index`
+    (ADVICE round 4).  Three shards, two lists: at least one shard holds no row."""
+    nb, d, nq = 400, 32, 50
+    xb, xq = gen_data(nb, d, 42), gen_data(nq, d, 44)
+    base = f"metric_type=L2;dim={d};{train_cfg}"
+    one, many = Node(node, name), Node(node, name)
+    try:
+        assert one.build(xb, base + ";gpu_id=0") == 0
+        assert many.train(xb, base + f";gpu_ids={shard_ids(3)}") == 0
+        assert many.add(np.ascontiguousarray(xb[:250]), base) == 0, node.knhip_node_last_error().decode()
+        assert many.add(np.ascontiguousarray(xb[250:]), base) == 0
+        assert many.count() == nb
+        cfg = f"k=10;{search_cfg}"
+        assert same(one.search(xq, cfg, 10), many.search(xq, cfg, 10))
+        assert np.array_equal(one.blob(), many.blob())
+    finally:
+        one.close()
+        many.close()
+
+
 def test_placement_follows_the_reference_rule(node):
     """no gpu_id: consecutive indexes go round-robin over the visible devices at Train (select_device_id) -- on a box with
     two or more devices two nodes built one after the other land on different devices; an explicit gpu_id is honoured

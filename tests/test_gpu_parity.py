@@ -484,8 +484,12 @@ def test_q4_scan_matches_v2_and_oracle(torch_cuda, port, monkeypatch, metric):
     g2 = _gpu(ix)
     monkeypatch.setenv("KNHIP_Q4", "1")
     g4 = _gpu(ix)
+    g4.search(xq, 100, nprobe)  # (layouts built on first use are built now)
+    bytes4 = g4.device_bytes
+    # k = 128: the tie rule searches for 129 results -- R = 3 of both kernels (a caller's k = 128 must stay
+    # on these kernels, not fall onto the systolic one and its second copy of the codes); k = 150: plain R = 3
     for k, np_, use_bs in ((10, nprobe, False), (100, nprobe, False), (10, 1, False), (64, 128, False), (10, nprobe, True),
-                           (100, 8, True)):
+                           (100, 8, True), (128, nprobe, False), (128, 8, True), (150, nprobe, False)):
         b, nbits = (bs, nb) if use_bs else (None, 0)
         Do, Io = port.search(ix, xq, k, np_, b, nbits)
         D2, I2 = g2.search(xq, k, np_, b, nbits)
@@ -497,6 +501,7 @@ def test_q4_scan_matches_v2_and_oracle(torch_cuda, port, monkeypatch, metric):
         Do, Io = port.search(ix, xq[:nq_small], 10, nprobe)
         D4, I4 = g4.search(xq[:nq_small], 10, nprobe)
         assert_parity(Do, Io, D4, I4, metric, f"q4 nq={nq_small}")
+    assert g4.device_bytes == bytes4, "a k = 128 search built another copy of the codes"
     g2.close()
     g4.close()
 
