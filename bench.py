@@ -55,6 +55,8 @@ LDS_PEAK_GBPS = 256 * 256 * 2.4        # 256 B/clk/CU (conflict-free ds_read_b64
 VALU_PEAK_TFLOPS = 157.3               # fp32 vector peak (FMA = 2 flop)
 MFMA_F32_PEAK_TFLOPS = 157.3           # fp32 matrix peak (coarse quantizer, fp32 row prefilter)
 MFMA_F16_PEAK_TFLOPS = 2500.0          # dense f16 / bf16 matrix peak (SQ8 prefilter)
+MFMA_I8_PEAK_TOPS = 1024 * 2048 * 2.4 / 1e3  # v_mfma_i32_16x16x64_i8: 32768 ops per 16 cycles and SIMD x 1024 SIMDs x 2.4 GHz
+#                                        = 5033 TOP/s (the guide lists >= 3944 TOP/s measured for this instruction)
 
 CONFIGS = {
     # BASELINE.json configs[0]: the reference's own CPU-runnable plumbing case, here on the GPU through the same ABI
@@ -69,7 +71,21 @@ CONFIGS = {
     # BASELINE.json configs[4]; 65536 x 768 centroids: fewer training points / iterations keep the build in minutes
     "C5": dict(kind="ivfsq8", metric="ip", nb=100_000_000, d=768, nlist=65536, nprobe=256, nq=10000, k=10, m=0,
                refine_k=0, data="int8", train_per_centroid=32, niter=10),
+    # a SLICE of C5 for the default driver line (the full configuration builds for minutes and its 76.8 GB of codes do not
+    # fit the host for the reference cross-check): a tenth of the rows and of the lists -- the same mean list length
+    # (1526 rows), nprobe and row size, hence the same code bytes per query; the coarse stage is ten times smaller
+    "C5s": dict(kind="ivfsq8", metric="ip", nb=10_000_000, d=768, nlist=6554, nprobe=256, nq=10000, k=10, m=0,
+                refine_k=0, data="int8", train_per_centroid=32, niter=10),
+    # the metric's configuration on data where the selectivity guard takes other decisions (driver-visible data dependence):
+    # uniform [0, 100) (the reference's own test fixture; PQ32 cannot separate it: no recall gate) and mixture components
+    # of intrinsic dimension 16
+    "C3u": dict(kind="ivfpq", metric="l2", nb=100_000_000, d=128, nlist=16384, nprobe=128, nq=10000, k=10, m=32,
+                refine_k=100, data="uniform", train_per_centroid=256, niter=10),
+    "C3l": dict(kind="ivfpq", metric="l2", nb=100_000_000, d=128, nlist=16384, nprobe=128, nq=10000, k=10, m=32,
+                refine_k=100, data="mixture", train_per_centroid=256, niter=10, latent=16),
 }
+CONFIG_NOTE = {"C5s": "slice of C5: 1/10 of the rows and lists, same list length / nprobe / row size",
+               "C3u": "C3 on uniform [0, 100) data", "C3l": "C3 on mixture components of intrinsic dimension 16"}
 KINDS = {"flat": kidx.BRUTE_FORCE, "ivfflat": kidx.IVF_FLAT, "ivfpq": kidx.IVF_PQ, "ivfsq8": kidx.IVF_SQ8}
 KIND_LABEL = {"flat": "BruteForce (FLAT)", "ivfflat": "IVF-Flat", "ivfpq": "IVF-PQ", "ivfsq8": "IVF-SQ8"}
 SHAPE_KEYS = ("nb", "d", "nlist", "nprobe", "nq", "k", "m", "refine_k", "train_per_centroid", "niter")
@@ -93,11 +109,11 @@ def parse():
                     help="queries of the CPU baseline sample (-1 = 32 per host thread, 0 = skip)")
     ap.add_argument("--query-batches", type=int, default=3, help="distinct query batches the timed loop rotates through")
     ap.add_argument("--extra", default="auto",
-                    help="further configurations run after the main one and reported under extra_configs: auto (= C2 "
-                         "for the default C3 run on one GPU), none, or a comma-separated list")
+                    help="further configurations run after the main one and reported under extra_configs: auto (= C1, C2, "
+                         "C5s, C3u, C3l for the default C3 run on one GPU), none, or a comma-separated list")
     ap.add_argument("--dry-launch", action="store_true",
                     help="only bring the process group up and print its size (tests the --gpus N self-launch without a GPU)")
-    ap.add_argument("--host-steps", type=int, default=3, help="steps of the host-boundary timing (0 = skip)")
+    ap.add_argument("--host-steps", type=int, default=-1, help="steps of the host-boundary timing (-1 = --steps, 0 = skip)")
     ap.add_argument("--backend", default=None, help="nccl (default for N>1) | gloo (single-GPU debugging)")
     ap.add_argument("--coarse-mode", default="auto", choices=["auto", "replicate", "shard"],
                     help="N > 1: coarse quantizer replicated on every rank (no collective) or sharded by queries (one "
@@ -111,10 +127,14 @@ def parse():
 
 def apply_config(a, name, keep_overrides):
     cfg = dict(CONFIGS[name])
+    user_latent = getattr(a, "latent", 0) or 0
     for key in list(cfg):
+        if key == "latent":
+            continue
         v = getattr(a, key, None)
         if keep_overrides and v is not None:
             cfg[key] = v
+    cfg["latent"] = user_latent if (keep_overrides and user_latent) else cfg.get("latent", 0)
     for key, v in cfg.items():
         setattr(a, key, v)
     a.config = name
@@ -190,7 +210,7 @@ def main():
     out = run_config(a, rank, world, dev, dev_id, comm)
     extra = []
     if a.extra == "auto":
-        extra = ["C2"] if (a.config == "C3" and world == 1 and not a.overridden) else []
+        extra = ["C1", "C2", "C5s", "C3u", "C3l"] if (a.config == "C3" and world == 1 and not a.overridden) else []
     elif a.extra != "none":
         extra = [e for e in a.extra.split(",") if e]
     for name in extra:
@@ -198,6 +218,8 @@ def main():
         import copy
         b = apply_config(copy.copy(a), name, keep_overrides=False)
         b.ncenter = 0
+        if name in ("C3u", "C3l"):
+            b.cpu_queries = 0  # (the same index kind and kernels as the main run: no second reference leg)
         torch.cuda.empty_cache()
         sub = run_config(b, rank, world, dev, dev_id, comm)
         if rank == 0:
@@ -275,8 +297,20 @@ def run_config(a, rank, world, dev, dev_id, comm):
     kbase = a.refine_k if refine else a.k
     row_of_id = sharded.row_lookup(vector_ids, a.nb, dev) if (refine and vector_ids is not None) else None
 
+    refine_ev = {"on": False, "ev": []}  # (event pairs around the re-rank: its stage time, itemised like the library's)
+
     def rerank(q, Ip):
         """exact fp32 re-rank of the PQ candidates whose raw vectors this rank holds"""
+        if refine_ev["on"]:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = rerank_inner(q, Ip)
+            e1.record()
+            refine_ev["ev"].append((e0, e1))
+            return out
+        return rerank_inner(q, Ip)
+
+    def rerank_inner(q, Ip):
         if row_of_id is None:
             return kidx.refine_device(metric, vectors, q, Ip, a.k)
         rows = sharded.ids_to_rows(Ip, row_of_id)          # -1 where the vector lives on another rank
@@ -338,15 +372,19 @@ def run_config(a, rank, world, dev, dev_id, comm):
         step(b)
     g.profile_enable(True)
     g.profile_reset()
+    refine_ev["on"] = True
     barrier()
     t0 = time.perf_counter()
     for b in range(a.steps):
         step(a.warmup + b)
     barrier()
     dt = time.perf_counter() - t0
+    refine_ev["on"] = False
     if world > 1:
         dt = comm.max_float(dt)
     prof = g.profile_get()
+    prof["bench_refine_ms"] = sum(e0.elapsed_time(e1) for e0, e1 in refine_ev["ev"])
+    refine_ev["ev"] = []
     g.profile_enable(False)
     multi = None
     if world > 1:
@@ -366,8 +404,7 @@ def run_config(a, rank, world, dev, dev_id, comm):
         comm.timed = False
         mine = {"rank": rank, "device": dev_id, "collective_ms_per_step": round(coll_ms, 3),
                 "collectives_per_step": (comm.ncollectives - n0) // a.steps,
-                "stage_ms_per_step": {n: round(pr["ms"][i] / a.steps, 3) for i, n in
-                                      enumerate(["coarse", "group", "lut", "scan", "merge", "other", "scan_rank0"])},
+                "stage_ms_per_step": stage_table(a, kind, pr),
                 "scan_bytes_per_step": pr["scan_bytes"] / a.steps}
         gathered = [None] * world
         dist.all_gather_object(gathered, mine)
@@ -375,9 +412,11 @@ def run_config(a, rank, world, dev, dev_id, comm):
                  "ranks": gathered}
     ms_per_step = dt / a.steps * 1e3
     qps = a.nq * a.steps / dt
+    prof["bench_ms_per_step"] = ms_per_step
 
     host = None
-    if world == 1 and a.host_steps > 0:
+    host_steps = a.steps if a.host_steps < 0 else a.host_steps
+    if world == 1 and host_steps > 0:
         if refine:
             # the refine store knhip_search_refine reads: a BRUTE_FORCE index over the raw rows (a transient second copy here;
             # the node holds its rows in such an index from the start)
@@ -386,15 +425,18 @@ def run_config(a, rank, world, dev, dev_id, comm):
         Dh, Ih = host_step()
         same = bool((Ih == I.cpu().numpy()).all() and (Dh.view(np.uint32) == D.cpu().numpy().view(np.uint32)).all())
         t0 = time.perf_counter()
-        for _ in range(a.host_steps):
+        for _ in range(host_steps):
             host_step()
-        dth = (time.perf_counter() - t0) / a.host_steps
+        dth = (time.perf_counter() - t0) / host_steps
         host = {"value": round(a.nq / dth, 1), "unit": "queries/s", "ms_per_step": round(dth * 1e3, 3),
-                "steps": a.host_steps, "h2d_bytes": int(xq_host.nbytes), "d2h_bytes": int(a.nq * a.k * 12),
+                "steps": host_steps, "h2d_bytes": int(xq_host.nbytes), "d2h_bytes": int(a.nq * a.k * 12),
                 "identical_to_device_path": same,
                 "entry_point": "knhip_search_refine" if refine else "knhip_search",
-                "note": "host pointers through the C ABI entry point the IndexNode's Search() calls: pageable host queries "
-                        "in, host (ids, distances) out; H2D, D2H, scratch and stream set-up inside the timed region"}
+                "note": "SURVEY 8(d)'s form of the metric (one Search() of the batch across the HOST boundary): host pointers "
+                        "through the C ABI entry point the IndexNode's Search() calls, pageable host queries in, host (ids, "
+                        "distances) out; H2D, D2H, scratch and stream set-up inside the timed region; the same query batch "
+                        "every step.  `value` of the line is the device-resident step, as the harness contract asks "
+                        "(inputs resident in HBM when the timed region starts)"}
         if raw_bf is not None:
             raw_bf.close()
             raw_bf = None
@@ -451,6 +493,31 @@ def run_config(a, rank, world, dev, dev_id, comm):
     return out
 
 
+def stage_table(a, kind, prof):
+    """HIP-event time of every stage of a step (ms, mean over the timed steps), itemised so that the rows add up to the
+    step: library stages (include/knhip.h, knhip_stage_times) + the re-rank this harness calls + what no event pair covers
+    (launch gaps, the tie rule's 4-byte read-back, host time between the calls)."""
+    S = kidx._lib
+    n = max(a.steps, 1)
+    ms = prof["ms"]
+    prefilter = prof.get("mscan_queries", 0) > 0
+    t = {"coarse": ms[S.STAGE_COARSE], "group": ms[S.STAGE_GROUP], "query_tables": ms[S.STAGE_LUT] + ms[S.STAGE_TABLES],
+         ("sample" if prefilter else "scan_rank0"): ms[S.STAGE_SCAN_RANK0],
+         ("filter" if prefilter else "scan"): ms[S.STAGE_SCAN],
+         ("finish" if prefilter else "merge"): ms[S.STAGE_MERGE], "ties": ms[S.STAGE_TIES],
+         "refine": ms[S.STAGE_REFINE] + prof.get("bench_refine_ms", 0.0), "other": ms[S.STAGE_OTHER]}
+    out = {k: round(v / n, 3) for k, v in t.items()}
+    if "bench_ms_per_step" in prof:
+        out["not_in_any_stage"] = round(prof["bench_ms_per_step"] - sum(out.values()), 3)
+        out["sum"] = round(prof["bench_ms_per_step"], 3)
+    if prefilter and kind == kidx.IVF_PQ:
+        out["note"] = ("query_tables = the filter's int8 / half tables + the selectivity guard; sample = tau_q from each "
+                       "query's closest lists; ties = k + 1-th result, detection, read-back, rule; the work table (group) "
+                       "is built on a side stream beside the sample pass: its time overlaps and is not part of the sum's "
+                       "critical path")
+    return out
+
+
 def make_roofline(a, kind, prof, world):
     """dominant kernel = the list scan.  achieved = algorithmic work per launch / mean launch time (HIP events on the
     launch stream, inside the library; the rocprofv3 average of the same kernel is under profiles/)."""
@@ -461,8 +528,7 @@ def make_roofline(a, kind, prof, world):
     # phase whose time is stage "scan_rank0" and whose bytes are excluded here)
     scan_bytes = (prof["scan_bytes"] - prof["scan_bytes_rank0"]) / nlaunch
     sec = scan_ms * 1e-3
-    stages = {n: round(prof["ms"][i] / a.steps, 3) for i, n in
-              enumerate(["coarse", "group", "lut", "scan", "merge", "other", "scan_rank0"])}
+    stages = stage_table(a, kind, prof)
     hbm_algo = scan_bytes / sec / 1e9 if sec > 0 else 0.0
     common = {"tie_queries_per_step": round(prof.get("tie_queries", 0) / max(a.steps, 1), 2),
               "algorithmic_bytes_per_launch": scan_bytes, "ms_per_launch": round(scan_ms, 3), "traffic": None,
@@ -518,8 +584,16 @@ def make_roofline(a, kind, prof, world):
                         "the same rate: 512 lookups per 16 cycles and SIMD); the kernel is launched twice per step -- the scan "
                         "and the normally empty retry round -- so rocprofv3's per-kernel AVERAGE is half of ms_per_launch, its "
                         "MAX is the scan launch")
-            return with_pmc(dict({"bound": "lds", "kernel": kn, "achieved": round(lds, 1),
-                         "peak": round(LDS_PEAK_GBPS, 1), "unit": "GB/s", "frac": round(lds / LDS_PEAK_GBPS, 4),
+            # What binds the filter is the matrix pipe and -- at the very same rate -- the LDS gather that feeds it (one
+            # ds_read_b128 per matrix instruction): `bound` names the matrix pipe, the LDS view of the same number is kept
+            # beside it, the HBM side (measured traffic of the PMC passes on file) under hbm_*.  32 integer (half: floating
+            # point) operations per (lookup, query): a 16x16x64 (16x16x32) instruction = 32768 (16384) for 1024 (512) pairs.
+            tops = scan_bytes * 32.0 / sec / 1e12 if sec > 0 else 0.0
+            peak = MFMA_I8_PEAK_TOPS if i8 else MFMA_F16_PEAK_TFLOPS
+            return with_pmc(dict({"bound": "mfma", "kernel": kn, "achieved": round(tops, 1), "peak": round(peak, 1),
+                         "unit": "TOP/s" if i8 else "TFLOP/s", "frac": round(tops / peak, 4),
+                         "lds_gather": {"achieved_GBps": round(lds, 1), "peak_GBps": round(LDS_PEAK_GBPS, 1),
+                                        "frac": round(lds / LDS_PEAK_GBPS, 4)},
                          "note": note, "filter_form": "int8 x 16 queries" if i8 else "half x 8 queries",
                          "lookups_per_ns_per_cu": round(scan_bytes / sec / 1e9 / 256.0, 1) if sec > 0 else None,
                          "mscan": {"queries_per_step": prof["mscan_queries"] / steps,
