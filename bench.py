@@ -18,9 +18,10 @@ are partitioned across ranks (size-balanced); every rank builds, encodes and kee
 owns (codes and raw vectors), the coarse quantizer and codebooks are trained on rank 0 and broadcast.  Per step
 the coarse quantizer is sharded by queries (one packed all-gather of the (nq, nprobe) assignment), every rank
 scans the probes it owns; one packed all-gather of the per-rank (distance, id) partial top-`refine_k` over RCCL/xGMI
-+ a device merge gives the global PQ candidates, every rank re-ranks the candidates whose raw vectors it holds,
-and a second small packed all-gather + merge yields the final top-10 -- bit-identical to the single-GPU result
-(IndexRefine semantics: the global top-`refine_k` by PQ distance is what gets re-ranked).
++ a device merge gives the global PQ candidates, every rank computes the exact distances of the candidates whose raw
+vectors it holds, one all-gather of the distance arrays and ONE selection yield the final top-10
+-- bit-identical to the single-GPU result, candidates tied at a k-th distance included (the reference's first-come
+admission rule is applied once, after the merge: knowhere_amd/sharded.py::search_sharded / refine_sharded).
 
 `python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run (one rank per GPU on
 127.0.0.1) and fails loudly when fewer than N GPUs are visible; `n_gpus` in the line is the size of the process group
@@ -326,17 +327,26 @@ def run_config(a, rank, world, dev, dev_id, comm):
     def step(b=0):
         q = xqs[b % len(xqs)]
         if world > 1:
-            if coarse_replicated:
-                Dp, Ip = g.search_device(q, kbase, a.nprobe)  # coarse + the lists this rank owns
-            else:
-                keys, cdis = sharded.sharded_coarse(comm, lambda lo, hi: g.coarse_search_device(q[lo:hi], a.nprobe),
-                                                    a.nq, a.nprobe, device=dev)
-                Dp, Ip = g.search_preassigned_device(q, kbase, keys, cdis)
-            Dp, Ip = comm.allgather_merge(metric, Dp, Ip)  # global top-kbase by PQ distance, identical on every rank
+            # every rank contributes CANONICAL partials; the reference's admission rule at the k-th boundary is applied once,
+            # after the merge, over all ranks' candidates (sharded.search_sharded): the single-GPU answer, ties included
+            keys = cdis = None
+            if kind != kidx.BRUTE_FORCE:
+                if coarse_replicated:
+                    cdis, keys = g.coarse_search_device(q, a.nprobe)
+                else:
+                    keys, cdis = sharded.sharded_coarse(comm, lambda lo, hi: g.coarse_search_device(q[lo:hi], a.nprobe),
+                                                        a.nq, a.nprobe, device=dev)
+            Dp, Ip = sharded.search_sharded(
+                comm, metric, kbase, lambda kk: g.search_canonical_device(q, kk, a.nprobe, keys, cdis),
+                lambda fl, can: g.tie_arrivals_device(q, fl, can, kbase, a.nprobe, keys, cdis,
+                                                      key_base=(a.nb * rank // world) if kind == kidx.BRUTE_FORCE else 0))
             if not refine:
                 return Dp, Ip
-            D, I = rerank(q, Ip)  # only the candidates whose raw vectors live here (the others are marked "skip")
-            return comm.allgather_merge(metric, D, I)
+            # second stage: distances where the rows are (the others marked "not here"), one all-gather, ONE selection
+            def held():
+                rows = Ip if row_of_id is None else sharded.ids_to_rows(Ip, row_of_id)
+                return kidx.refine_distances_device(metric, vectors, q, rows)
+            return sharded.refine_sharded(comm, metric, a.k, Ip, held)
         Dp, Ip = g.search_device(q, kbase, a.nprobe)
         if refine:
             return rerank(q, Ip)

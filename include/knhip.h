@@ -43,8 +43,10 @@
  * Conditions: the ids of every list ascend in storage order -- what IvfIndexNode::Add produces (ids are the running
  * row numbers); knhip_index_add_lists re-sorts a list that does not, and ties inside it are then taken in id order.
  * Not covered (canonical answer): k = 1024; BRUTE_FORCE with k >= 100 (the reference switches to a reservoir,
- * impl/ResultHandler.h:719-728); results merged from several indexes (knhip_merge_topk_*, knhip_shard_group_*: every
- * shard resolves its own candidates).
+ * impl/ResultHandler.h:719-728).  A list-sharded index returns the same answer as one index: the rule is applied once, after
+ * the merge, over all shards' candidates (knhip_search_canonical_device .. knhip_tie_resolve_device below,
+ * knhip_shard_group_*); only a caller that merges tie-resolved per-shard results itself (knhip_merge_topk_*) gets the
+ * canonical choice among the shards' survivors.
  */
 #ifndef KNHIP_H
 #define KNHIP_H
@@ -57,7 +59,8 @@ extern "C" {
 #endif
 
 /* 4: knhip_train_params gained spherical/reserved, knhip_stage_times its prefilter counters.  5: tie_queries.  6: the quantised refine store (knhip_rows_*, knhip_search_refine_rows), knhip_range_search_ranked.
- * 7: sixteen profiling stages (sample / tables / refine / ties itemised), tie_anomalies.
+ * 7: sixteen profiling stages (sample / tables / refine / ties itemised), tie_anomalies; the tie rule for list-sharded
+ * indexes (knhip_search_canonical_device, knhip_tie_*, knhip_refine_distances / _combine / _select).
  * Callers compare knhip_abi_version() with the header they were built against. */
 #define KNHIP_ABI_VERSION 7
 
@@ -339,6 +342,66 @@ int knhip_coarse_search_device(const knhip_index* idx, const float* d_queries, i
 int knhip_refine_device(int32_t metric, int32_t dim, const float* d_base, int64_t nbase,
                         int64_t id_base, const float* d_queries, int64_t nq, const int64_t* d_cand_ids,
                         int32_t k_base, int32_t k, float* d_out_dist, int64_t* d_out_ids, void* stream);
+
+/* ---- multi-GPU: the reference's answer from a list-sharded index, ties at the k-th distance included ----
+ * The reference's own sharding contract is ids-equal (tests/ut/test_bruteforce.cc:128-181; faiss IndexShards merges
+ * per-shard heaps, IndexShards.cpp:247-256 -- whose tie behaviour is that of each shard's heap).  Here every shard resolves
+ * nothing on its own: the rule of the header comment is applied ONCE, after the merge, over all shards' candidates:
+ *   1. every shard: knhip_search_canonical_device for k + 1 results (no tie rule: the canonical order only);
+ *   2. exchange + knhip_merge_topk_device of the (nq, k + 1) partials: the global canonical top-(k + 1) on every shard;
+ *   3. knhip_tie_flag_device: the first k of every row -> the result; queries whose (k + 1)-th entry ties with the k-th are
+ *      flagged (ascending list, identical on every shard; one 4-byte read-back);
+ *   4. only if any is flagged: every shard knhip_tie_arrivals_device (its first k arrivals at or below the k-th distance, each
+ *      with its place in the global scan order), exchange, knhip_tie_resolve_device writes the rule's answer over the rows.
+ * include/knhip_shards.h does exactly this (C++ host); knowhere_amd/sharded.py does it over torch.distributed.
+ * BRUTE_FORCE with k >= 100 and k = 1024 stay canonical, as on one index. */
+/* canonical top-k, no tie rule.  d_keys / d_coarse_dis: the coarse assignment [nq][nprobe] (IndexIVF::search_preassigned;
+ * both NULL: assigned inside; BRUTE_FORCE: NULL) */
+int knhip_search_canonical_device(const knhip_index* idx, const float* d_queries, int64_t nq, int32_t k, int32_t nprobe,
+                                  const int64_t* d_keys, const float* d_coarse_dis, const uint8_t* d_bitset,
+                                  int64_t bitset_nbits, int64_t* d_out_ids, float* d_out_dist, void* stream);
+/* rows of k + 1 canonical results -> the first k to (d_out_dist, d_out_ids) [nq][k]; d_flagged: int32 [2 nq + 1] scratch whose
+ * first *nflag_out entries are the flagged queries in ascending order.  Synchronises the stream (reads the count back). */
+int knhip_tie_flag_device(const float* d_can_dist, const int64_t* d_can_ids, int64_t nq, int32_t k, float* d_out_dist,
+                          int64_t* d_out_ids, int32_t* d_flagged, int32_t* nflag_out, void* stream);
+/* this index's first k arrivals with distance <= the query's k-th distance (>= for IP) in scan order, for the flagged
+ * queries: d_arr_dist / d_arr_ids / d_arr_key [nflag][k], d_arr_n [nflag] (arrivals found; min(k, .) are stored).
+ * d_queries, d_keys, d_coarse_dis, d_can_dist ([.][k + 1]) are the whole batch's arrays (rows = d_flagged entries).
+ * key: (probe rank << 40 | position in the list) for the IVF kinds; key_base + row for BRUTE_FORCE (key_base = the number
+ * of rows held by the shards in front of this one). */
+int knhip_tie_arrivals_device(const knhip_index* idx, const float* d_queries, const int32_t* d_flagged, int32_t nflag,
+                              const float* d_can_dist, int32_t k, int32_t nprobe, const int64_t* d_keys,
+                              const float* d_coarse_dis, const uint8_t* d_bitset, int64_t bitset_nbits, int64_t key_base,
+                              float* d_arr_dist, int64_t* d_arr_ids, int64_t* d_arr_key, int64_t* d_arr_n, void* stream);
+/* arrivals of all shards [nshards][nflag][k] (+ [nshards][nflag]) -> the rule's answer over the flagged rows of
+ * (d_out_dist, d_out_ids) [nq][k] */
+int knhip_tie_resolve_device(int32_t metric, int32_t nshards, const int32_t* d_flagged, int32_t nflag, int32_t k,
+                             const float* d_can_dist, const int64_t* d_can_ids, const float* d_arr_dist,
+                             const int64_t* d_arr_ids, const int64_t* d_arr_key, const int64_t* d_arr_n, float* d_out_dist,
+                             int64_t* d_out_ids, void* stream);
+/* host forms (results merged on the CPU: knhip_merge_topk_host's companions): flagged [nq] 0 / 1; the arrival arrays are
+ * [nshards][nq][k] / [nshards][nq], rows of unflagged queries are not read */
+int knhip_tie_flag_host(const float* can_dist, const int64_t* can_ids, int64_t nq, int32_t k, float* out_dist,
+                        int64_t* out_ids, uint8_t* flagged_out);
+int knhip_tie_resolve_host(int32_t metric, int32_t nshards, int64_t nq, int32_t k, const uint8_t* flagged,
+                           const float* can_dist, const int64_t* can_ids, const float* arr_dist, const int64_t* arr_ids,
+                           const int64_t* arr_key, const int64_t* arr_n, float* out_dist, int64_t* out_ids);
+/* Sharded refine (the rows cut into one id range per shard).  IndexRefine pushes the re-scored candidates through its heap in
+ * CANDIDATE order whoever holds their rows, so the selection needs every candidate's distance: every shard computes the
+ * distances of the candidates it holds ([nq][k_base]; the all-ones pattern elsewhere), the arrays are exchanged and combined
+ * (every candidate is held once), and ONE selection -- the single index's, tie rule included -- runs on the result. */
+int knhip_refine_distances_device(int32_t metric, int32_t dim, const float* d_base, int64_t nbase, int64_t id_base,
+                                  const float* d_queries, int64_t nq, const int64_t* d_cand_ids, int32_t k_base,
+                                  float* d_out_dist, void* stream);
+int knhip_refine_rows_distances_device(int32_t metric, const knhip_rows* rows, int64_t id_base, const float* d_queries,
+                                       int64_t nq, const int64_t* d_cand_ids, int32_t k_base, float* d_out_dist,
+                                       void* stream);
+int knhip_refine_combine_device(int32_t nshards, int64_t n, const float* d_parts /*[nshards][n]*/, float* d_out, void* stream);
+int knhip_refine_select_device(int32_t metric, int64_t nq, const int64_t* d_cand_ids, const float* d_dist, int32_t k_base,
+                               int32_t k, float* d_out_dist, int64_t* d_out_ids, void* stream);
+/* host form of the selection (distances already combined) */
+int knhip_refine_select_host(int32_t metric, int64_t nq, const int64_t* cand_ids, const float* dist, int32_t k_base, int32_t k,
+                             float* out_dist, int64_t* out_ids);
 
 /* ---- multi-GPU: merge of per-shard partial top-k ----
  * parts laid out [nshard][nq][k]; ids < 0 are empty slots. */

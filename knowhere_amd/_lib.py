@@ -46,6 +46,9 @@ SYMBOLS = [
     "knhip_index_set_lists_device", "knhip_index_add_vectors_device", "knhip_index_count",
     "knhip_index_device_bytes", "knhip_index_uses_precomputed_table", "knhip_index_last_range_ranks", "knhip_search",
     "knhip_search_device", "knhip_coarse_search_device", "knhip_merge_topk_device",
+    "knhip_search_canonical_device", "knhip_tie_flag_device", "knhip_tie_arrivals_device", "knhip_tie_resolve_device",
+    "knhip_tie_flag_host", "knhip_tie_resolve_host", "knhip_refine_distances_device", "knhip_refine_rows_distances_device",
+    "knhip_refine_combine_device", "knhip_refine_select_device", "knhip_refine_select_host",
     "knhip_merge_topk_host", "knhip_refine_device", "knhip_fvec_L2sqr_ny", "knhip_fvec_inner_products_ny",
     "knhip_fvec_norms_L2sqr", "knhip_fvec_madd", "knhip_int8_vec_L2sqr_ny",
     "knhip_int8_vec_inner_products_ny", "knhip_profile_enable", "knhip_profile_reset",
@@ -120,6 +123,17 @@ def load():
     L.knhip_merge_topk_device.argtypes = [i32, i64, i32, i32, vp, vp, vp, vp, vp]
     L.knhip_merge_topk_host.argtypes = [i32, i64, i32, i32, vp, vp, vp, vp]
     L.knhip_refine_device.argtypes = [i32, i32, vp, i64, i64, vp, i64, vp, i32, i32, vp, vp, vp]
+    L.knhip_search_canonical_device.argtypes = [vp, vp, i64, i32, i32, vp, vp, vp, i64, vp, vp, vp]
+    L.knhip_tie_flag_device.argtypes = [vp, vp, i64, i32, vp, vp, vp, C.POINTER(C.c_int32), vp]
+    L.knhip_tie_arrivals_device.argtypes = [vp, vp, vp, i32, vp, i32, i32, vp, vp, vp, i64, i64, vp, vp, vp, vp, vp]
+    L.knhip_tie_resolve_device.argtypes = [i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.knhip_tie_flag_host.argtypes = [vp, vp, i64, i32, vp, vp, vp]
+    L.knhip_tie_resolve_host.argtypes = [i32, i32, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.knhip_refine_distances_device.argtypes = [i32, i32, vp, i64, i64, vp, i64, vp, i32, vp, vp]
+    L.knhip_refine_rows_distances_device.argtypes = [i32, vp, i64, vp, i64, vp, i32, vp, vp]
+    L.knhip_refine_combine_device.argtypes = [i32, i64, vp, vp, vp]
+    L.knhip_refine_select_device.argtypes = [i32, i64, vp, vp, i32, i32, vp, vp, vp]
+    L.knhip_refine_select_host.argtypes = [i32, i64, vp, vp, i32, i32, vp, vp]
     for f in ("knhip_fvec_L2sqr_ny", "knhip_fvec_inner_products_ny", "knhip_int8_vec_L2sqr_ny",
               "knhip_int8_vec_inner_products_ny"):
         getattr(L, f).argtypes = [vp, vp, vp, i64, i64, vp]

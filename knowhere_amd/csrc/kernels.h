@@ -422,9 +422,13 @@ hipError_t launch_tie_detect(const float* d, const int64_t* i, int64_t nq, int k
 hipError_t launch_tie_gather(const int32_t* flagged, int nflag, const float* q, int d, const int64_t* keys, const float* cdis,
                              int nprobe, float* q_out, int64_t* keys_out, float* cdis_out, const float* can_d, int k,
                              float* rad_out, hipStream_t s);
-hipError_t launch_tie_apply(const int32_t* flagged, int nflag, const float* can_d, const int64_t* can_i, int k, bool is_l2,
-                            const float* hit_d, const int64_t* hit_i, const int64_t* total, float* out_d, int64_t* out_i,
-                            int32_t* anomalies, hipStream_t s);
+hipError_t launch_tie_sort_flags(const int32_t* in, int n, int32_t* out, hipStream_t s);
+hipError_t launch_refine_combine(const float* parts, int nsh, int64_t n, float* out, hipStream_t s);
+// (nsh shards' arrival lists [nsh][nflag][k] with their scan-order keys; nsh = 1: the index's own, keys optional)
+hipError_t launch_tie_resolve(const int32_t* flagged, int nflag, int nsh, const float* can_d, const int64_t* can_i, int k,
+                              bool is_l2, const float* arr_d, const int64_t* arr_i, const int64_t* arr_key,
+                              const int64_t* arr_n, int64_t arr_n_stride, float* out_d, int64_t* out_i, int32_t* anomalies,
+                              hipStream_t s);
 // every exact ADC distance of every probed list of an IVF-PQ index with any M x 8 bit codes (range.hip)
 struct PqDumpArgs {
     float* dist;                 // [nq][ncol], column = list_row_off[list] + position
@@ -491,7 +495,8 @@ hipError_t launch_range_flat_dump(const FlatScanArgs& a, const int64_t* keys_w, 
 hipError_t launch_range_plan(const int32_t* cnt, int64_t nq, int nprobe, int max_empty, int64_t* off, int64_t* total,
                              hipStream_t s);
 hipError_t launch_range_emit(const RangeArgs& a, int64_t nq, bool is_l2, const int64_t* off, const int64_t* qbase,
-                             int64_t* out_ids, float* out_dis, hipStream_t s, int64_t cap = 0);
+                             int64_t* out_ids, float* out_dis, hipStream_t s, int64_t cap = 0, int64_t* out_key = nullptr,
+                             int64_t key_base = 0);
 
 // ---- topk.hip: selection kernels ----
 // per query: k best of nslot sorted partial lists -> out (canonical order, sentinel padded);
@@ -532,7 +537,8 @@ hipError_t launch_coarse_rerank(const float* queries, const float* centroids, in
 // then the byte / half-word array, row r = id id_base + r)
 hipError_t launch_refine(const float* base, int64_t nbase, int64_t id_base, int d, const float* queries,
                          int64_t nq, const int64_t* cand, int kbase, int k, bool is_l2, float* out_d,
-                         int64_t* out_i, hipStream_t s, int row_type = 0, const float* sq_trained = nullptr);
+                         int64_t* out_i, hipStream_t s, int row_type = 0, const float* sq_trained = nullptr,
+                         const float* dist_in = nullptr, float* dist_out = nullptr);
 hipError_t launch_rows_encode16(const float* x, int64_t n_elems, bool bf16, uint16_t* out, hipStream_t s);
 
 // ---- build.hip: Train / Add on the device ----

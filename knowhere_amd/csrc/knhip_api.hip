@@ -138,6 +138,7 @@ struct Workspace {
     // host-boundary staging
     DevBuf h_queries, h_bitset, h_out_d, h_out_i, h_ref_d, h_ref_i;
     DevBuf tie_d, tie_i, tie_flag, tie_q, tie_r, tie_keys, tie_cdis; // search_batch_ties: k + 1 results, flagged queries
+    DevBuf tie_arr_d, tie_arr_i, tie_arr_n;                          // ... their first k arrivals
     std::mutex mu;  // held while a *_device entry point enqueues on this (per-stream) workspace
     // side stream of the IVF-PQ prefilter: the grouping of the pairs by list (work table) runs beside the sample pass
     hipStream_t side = nullptr;
@@ -2736,6 +2737,62 @@ static bool ties_reference_mode() {
     return !(t && (t[0] == 'c' || t[0] == 'C' || t[0] == '0'));
 }
 
+// The first k arrivals with distance <= v (>= v for IP) of every flagged query, in THIS index's scan order (probe rank, then
+// storage position; brute force: row order): arr_d / arr_i [nflag][k], arr_n [nflag] (how many arrived: only min(k, .) are
+// stored), arr_key [nflag][k] (optional) = each arrival's place in the scan order, comparable across the shards of a group.
+// flagged[f] = row of the query in (d_q, src_keys, src_cdis, can_d [.][k + 1]); v = can_d[row][k - 1].
+static int tie_arrivals(const knhip_index* idx, Workspace* ws, const float* d_q, const int32_t* flagged, int32_t nflag,
+                        const float* can_d, int k, int nprobe, const int64_t* src_keys, const float* src_cdis,
+                        const uint8_t* d_bitset, int64_t nbits, int64_t key_base, float* arr_d, int64_t* arr_i,
+                        int64_t* arr_key, int64_t* arr_n, hipStream_t s) {
+    const int kind = idx->desc.kind;
+    const bool is_l2 = idx->is_l2;
+    const bool trace = getenv("KNHIP_TIES_TRACE") != nullptr;
+    int64_t nseg = 0, ncol = 0;
+    const int64_t* d_seg = nullptr;
+    if (int rc = range_segments(idx, s, &d_seg, &nseg, &ncol)) return rc;
+    const int np = kind == KNHIP_BRUTE_FORCE ? 0 : nprobe;
+    if (kind != KNHIP_BRUTE_FORCE && (src_keys == nullptr || src_cdis == nullptr)) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "tie arrivals: the coarse assignment of the search is needed");
+    }
+    HIP_TRY(ws->tie_q.reserve((size_t)nflag * idx->d * sizeof(float)));
+    if (src_keys != nullptr) {
+        HIP_TRY(ws->tie_keys.reserve((size_t)nflag * nprobe * sizeof(int64_t)));
+        HIP_TRY(ws->tie_cdis.reserve((size_t)nflag * nprobe * sizeof(float)));
+    }
+    HIP_TRY(ws->tie_r.reserve((size_t)nflag * sizeof(float)));
+    HIP_TRY(launch_tie_gather(flagged, nflag, d_q, idx->d, src_keys, src_cdis, nprobe, ws->tie_q.as<float>(),
+                              ws->tie_keys.as<int64_t>(), ws->tie_cdis.as<float>(), can_d, k, ws->tie_r.as<float>(), s));
+    // queries per round: the dump matrix [round][ncol] stays below 2 GiB
+    int64_t qb = std::max<int64_t>(1, (int64_t)((2ull << 30) / ((size_t)std::max<int64_t>(ncol, 1) * 4)));
+    qb = std::max<int64_t>(1, std::min<int64_t>(qb, (int64_t)0x7fffffff / std::max<int64_t>(nseg, 1)));
+    for (int64_t f0 = 0; f0 < nflag; f0 += qb) {
+        const int64_t n = std::min<int64_t>(qb, nflag - f0);
+        if (trace) fprintf(stderr, "[ties] round f0=%lld n=%lld ncol=%lld nseg=%lld np=%d\n", (long long)f0, (long long)n, (long long)ncol, (long long)nseg, np);
+        std::vector<int64_t> lims_unused((size_t)n + 1), hi_unused;
+        std::vector<float> hd_unused;
+        RangeArgs r{};
+        if (int rc = range_batch(idx, ws, ws->tie_q.as<float>() + f0 * idx->d, n, 0.f, 0, d_bitset, nbits, d_seg, nseg, ncol,
+                                 lims_unused.data(), hi_unused, hd_unused, s, nullptr, np,
+                                 src_keys ? ws->tie_keys.as<int64_t>() + f0 * nprobe : nullptr,
+                                 src_keys ? ws->tie_cdis.as<float>() + f0 * nprobe : nullptr, &r)) {
+            return rc;
+        }
+        // count per (query, rank) -> offsets -> capped emit (all parallel over the ranks)
+        r.radius_q = ws->tie_r.as<float>() + f0;
+        r.inclusive = 1;
+        HIP_TRY(ws->rg_cnt.reserve((size_t)n * r.nprobe * sizeof(int32_t)));
+        HIP_TRY(ws->rg_off.reserve((size_t)n * r.nprobe * sizeof(int64_t)));
+        HIP_TRY(ws->rg_tot.reserve((size_t)n * 2 * sizeof(int64_t)));
+        HIP_TRY(launch_range_count(r, n, is_l2, ws->rg_cnt.as<int32_t>(), s));
+        HIP_TRY(launch_range_plan(ws->rg_cnt.as<int32_t>(), n, r.nprobe, 0, ws->rg_off.as<int64_t>(), ws->rg_tot.as<int64_t>(), s));
+        HIP_TRY(launch_range_emit(r, n, is_l2, ws->rg_off.as<int64_t>(), nullptr, arr_i + f0 * k, arr_d + f0 * k, s, k,
+                                  arr_key != nullptr ? arr_key + f0 * k : nullptr, key_base));
+        HIP_TRY(hipMemcpyAsync(arr_n + f0, ws->rg_tot.as<int64_t>(), (size_t)n * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+    }
+    return KNHIP_OK;
+}
+
 static int search_batch_ties(const knhip_index* idx, Workspace* ws, const float* d_q, int64_t nq, int k, int nprobe,
                              const uint8_t* d_bitset, int64_t nbits, int64_t* d_out_i, float* d_out_d, hipStream_t s,
                              const int64_t* pre_keys, const float* pre_cdis) {
@@ -2768,61 +2825,321 @@ static int search_batch_ties(const knhip_index* idx, Workspace* ws, const float*
     if (nflag <= 0) {
         return KNHIP_OK;
     }
-    // ---- flagged queries, on the device: their rows gathered (queries + the coarse assignment the search used -- the given
-    // one, or the one search_batch left in ws->keys / ws->cdis -- before the dump pass reuses those buffers), every distance
-    // of their probed lists dumped by the range-search pass, then one workgroup per query walks the dump in scan order and
-    // writes the reference's answer over the query's row of the output.  Nothing comes back to the host.
-    int64_t nseg = 0, ncol = 0;
-    const int64_t* d_seg = nullptr;
-    if (int rc = range_segments(idx, s, &d_seg, &nseg, &ncol)) return rc;
-    const int np = kind == KNHIP_BRUTE_FORCE ? 0 : nprobe;
+    // ---- flagged queries, on the device: every distance of their probed lists dumped by the range-search pass, the first
+    // k arrivals with distance <= v taken in scan order (tie_arrivals), then one workgroup per query writes the reference's
+    // answer over the query's row of the output.  Nothing comes back to the host.
     const int64_t* src_keys = pre_keys != nullptr ? pre_keys : (kind != KNHIP_BRUTE_FORCE ? ws->keys.as<int64_t>() : nullptr);
     const float* src_cdis = pre_cdis != nullptr ? pre_cdis : (kind != KNHIP_BRUTE_FORCE ? ws->cdis.as<float>() : nullptr);
-    HIP_TRY(ws->tie_q.reserve((size_t)nflag * idx->d * sizeof(float)));
-    if (src_keys != nullptr) {
-        HIP_TRY(ws->tie_keys.reserve((size_t)nflag * nprobe * sizeof(int64_t)));
-        HIP_TRY(ws->tie_cdis.reserve((size_t)nflag * nprobe * sizeof(float)));
+    HIP_TRY(ws->tie_arr_d.reserve((size_t)nflag * k * sizeof(float)));
+    HIP_TRY(ws->tie_arr_i.reserve((size_t)nflag * k * sizeof(int64_t)));
+    HIP_TRY(ws->tie_arr_n.reserve((size_t)nflag * sizeof(int64_t)));
+    if (int rc = tie_arrivals(idx, ws, d_q, flagged, nflag, ws->tie_d.as<float>(), k, nprobe, src_keys, src_cdis, d_bitset,
+                              nbits, 0, ws->tie_arr_d.as<float>(), ws->tie_arr_i.as<int64_t>(), nullptr,
+                              ws->tie_arr_n.as<int64_t>(), s)) {
+        return rc;
     }
-    HIP_TRY(ws->tie_r.reserve((size_t)nflag * sizeof(float)));
-    HIP_TRY(launch_tie_gather(flagged, nflag, d_q, idx->d, src_keys, src_cdis, nprobe, ws->tie_q.as<float>(),
-                              ws->tie_keys.as<int64_t>(), ws->tie_cdis.as<float>(), ws->tie_d.as<float>(), k,
-                              ws->tie_r.as<float>(), s));
-    // queries per round: the dump matrix [round][ncol] stays below 2 GiB
-    int64_t qb = std::max<int64_t>(1, (int64_t)((2ull << 30) / ((size_t)std::max<int64_t>(ncol, 1) * 4)));
-    qb = std::max<int64_t>(1, std::min<int64_t>(qb, (int64_t)0x7fffffff / std::max<int64_t>(nseg, 1)));
-    for (int64_t f0 = 0; f0 < nflag; f0 += qb) {
-        const int64_t n = std::min<int64_t>(qb, nflag - f0);
-        if (trace) fprintf(stderr, "[ties] round f0=%lld n=%lld ncol=%lld nseg=%lld np=%d\n", (long long)f0, (long long)n, (long long)ncol, (long long)nseg, np);
-        std::vector<int64_t> lims_unused((size_t)n + 1), hi_unused;
-        std::vector<float> hd_unused;
-        RangeArgs r{};
-        if (int rc = range_batch(idx, ws, ws->tie_q.as<float>() + f0 * idx->d, n, 0.f, 0, d_bitset, nbits, d_seg, nseg, ncol,
-                                 lims_unused.data(), hi_unused, hd_unused, s, nullptr, np,
-                                 src_keys ? ws->tie_keys.as<int64_t>() + f0 * nprobe : nullptr,
-                                 src_keys ? ws->tie_cdis.as<float>() + f0 * nprobe : nullptr, &r)) {
-            return rc;
-        }
-        // the first k arrivals with distance <= v of every flagged query, in scan order: count per (query, rank) -> offsets
-        // -> capped emit (all parallel over the ranks), then one workgroup per query applies the rule to its row
-        r.radius_q = ws->tie_r.as<float>() + f0;
-        r.inclusive = 1;
-        HIP_TRY(ws->rg_cnt.reserve((size_t)n * r.nprobe * sizeof(int32_t)));
-        HIP_TRY(ws->rg_off.reserve((size_t)n * r.nprobe * sizeof(int64_t)));
-        HIP_TRY(ws->rg_tot.reserve((size_t)n * 2 * sizeof(int64_t)));
-        HIP_TRY(ws->rg_out_i.reserve((size_t)n * k * sizeof(int64_t)));
-        HIP_TRY(ws->rg_out_d.reserve((size_t)n * k * sizeof(float)));
-        HIP_TRY(launch_range_count(r, n, is_l2, ws->rg_cnt.as<int32_t>(), s));
-        HIP_TRY(launch_range_plan(ws->rg_cnt.as<int32_t>(), n, r.nprobe, 0, ws->rg_off.as<int64_t>(), ws->rg_tot.as<int64_t>(), s));
-        HIP_TRY(launch_range_emit(r, n, is_l2, ws->rg_off.as<int64_t>(), nullptr, ws->rg_out_i.as<int64_t>(),
-                                  ws->rg_out_d.as<float>(), s, k));
-        HIP_TRY(launch_tie_apply(flagged + f0, (int)n, ws->tie_d.as<float>(), ws->tie_i.as<int64_t>(), k, is_l2,
-                                 ws->rg_out_d.as<float>(), ws->rg_out_i.as<int64_t>(), ws->rg_tot.as<int64_t>(), d_out_d,
-                                 d_out_i, reinterpret_cast<int32_t*>(idx->coarse_fail_dev.as<unsigned long long>() + 5), s));
-    }
+    HIP_TRY(launch_tie_resolve(flagged, nflag, 1, ws->tie_d.as<float>(), ws->tie_i.as<int64_t>(), k, is_l2,
+                               ws->tie_arr_d.as<float>(), ws->tie_arr_i.as<int64_t>(), nullptr, ws->tie_arr_n.as<int64_t>(),
+                               nflag, d_out_d, d_out_i,
+                               reinterpret_cast<int32_t*>(idx->coarse_fail_dev.as<unsigned long long>() + 5), s));
     if (trace) fprintf(stderr, "[ties] applied\n");
     {
         std::lock_guard<std::mutex> lk(idx->mu);
         idx->tie_queries += nflag;
+    }
+    return KNHIP_OK;
+}
+
+// ---- the same rule for a list-sharded index: the pieces a shard host strings together (include/knhip.h) ---------------------
+int knhip_search_canonical_device(const knhip_index* idx, const float* d_queries, int64_t nq, int32_t k, int32_t nprobe,
+                                  const int64_t* d_keys, const float* d_coarse_dis, const uint8_t* d_bitset,
+                                  int64_t bitset_nbits, int64_t* d_out_ids, float* d_out_dist, void* stream) {
+    if (int rc = check_index(idx)) return rc;
+    const int32_t nprobe_in = nprobe;
+    if (int rc = validate_search(idx, nq, k, nprobe)) return rc;
+    const bool pre = d_keys != nullptr || d_coarse_dis != nullptr;
+    if (pre && (idx->desc.kind == KNHIP_BRUTE_FORCE || !d_keys || !d_coarse_dis || nprobe != nprobe_in)) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "search_canonical: a coarse assignment needs an IVF index, both arrays and nprobe <= nlist");
+    }
+    if (nq == 0) {
+        return KNHIP_OK;
+    }
+    if (!d_queries || !d_out_ids || !d_out_dist) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "null query/output pointer");
+    }
+    DeviceGuard g(idx->desc.device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Workspace* ws = acquire_ws(idx, stream, true);
+    std::lock_guard<std::mutex> ws_lock(ws->mu);
+    const int64_t qb = query_batch(idx, nq, k, nprobe);
+    for (int64_t q0 = 0; q0 < nq; q0 += qb) {
+        const int64_t n = std::min(qb, nq - q0);
+        if (int rc = search_batch(idx, ws, d_queries + q0 * idx->d, n, k, nprobe, d_bitset, bitset_nbits, d_out_ids + q0 * k,
+                                  d_out_dist + q0 * k, s, pre ? d_keys + q0 * nprobe : nullptr,
+                                  pre ? d_coarse_dis + q0 * nprobe : nullptr)) {
+            return rc;
+        }
+    }
+    return KNHIP_OK;
+}
+
+int knhip_tie_flag_device(const float* d_can_dist, const int64_t* d_can_ids, int64_t nq, int32_t k, float* d_out_dist,
+                          int64_t* d_out_ids, int32_t* d_flagged, int32_t* nflag_out, void* stream) {
+    if (nq < 0 || k <= 0 || k + 1 > KN_MAX_K || !d_can_dist || !d_can_ids || !d_out_dist || !d_out_ids || !d_flagged ||
+        !nflag_out) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "tie_flag: bad arguments");
+    }
+    *nflag_out = 0;
+    if (nq == 0) {
+        return KNHIP_OK;
+    }
+    if (nq > 0x3fffffff) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "tie_flag: too many queries");
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // d_flagged [2 nq + 1]: the sorted list, the raw (atomic-order) list behind it, the count
+    int32_t* raw = d_flagged + nq;
+    int32_t* cnt = d_flagged + 2 * nq;
+    HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int32_t), s));
+    HIP_TRY(launch_tie_detect(d_can_dist, d_can_ids, nq, k, d_out_dist, d_out_ids, raw, cnt, s));
+    int32_t nflag = 0;
+    HIP_TRY(hipMemcpyAsync(&nflag, cnt, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(launch_tie_sort_flags(raw, nflag, d_flagged, s));
+    *nflag_out = nflag;
+    return KNHIP_OK;
+}
+
+int knhip_tie_arrivals_device(const knhip_index* idx, const float* d_queries, const int32_t* d_flagged, int32_t nflag,
+                              const float* d_can_dist, int32_t k, int32_t nprobe, const int64_t* d_keys,
+                              const float* d_coarse_dis, const uint8_t* d_bitset, int64_t bitset_nbits, int64_t key_base,
+                              float* d_arr_dist, int64_t* d_arr_ids, int64_t* d_arr_key, int64_t* d_arr_n, void* stream) {
+    if (int rc = check_index(idx)) return rc;
+    if (nflag < 0 || k <= 0 || k + 1 > KN_MAX_K || !d_queries || !d_flagged || !d_can_dist || !d_arr_dist || !d_arr_ids ||
+        !d_arr_key || !d_arr_n) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "tie_arrivals: bad arguments");
+    }
+    if (nflag == 0) {
+        return KNHIP_OK;
+    }
+    DeviceGuard g(idx->desc.device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!idx->has_data || idx->ntotal == 0) { // (a shard without rows: nothing arrives)
+        HIP_TRY(hipMemsetAsync(d_arr_n, 0, (size_t)nflag * sizeof(int64_t), s));
+        return KNHIP_OK;
+    }
+    int32_t np = nprobe;
+    if (idx->desc.kind != KNHIP_BRUTE_FORCE) {
+        if (np <= 0 || np > idx->nlist) {
+            return fail(KNHIP_ERR_INVALID_ARGS, "tie_arrivals: nprobe out of range");
+        }
+    }
+    Workspace* ws = acquire_ws(idx, stream, true);
+    std::lock_guard<std::mutex> ws_lock(ws->mu);
+    return tie_arrivals(idx, ws, d_queries, d_flagged, nflag, d_can_dist, k, np, d_keys, d_coarse_dis, d_bitset, bitset_nbits,
+                        key_base, d_arr_dist, d_arr_ids, d_arr_key, d_arr_n, s);
+}
+
+int knhip_tie_resolve_device(int32_t metric, int32_t nshards, const int32_t* d_flagged, int32_t nflag, int32_t k,
+                             const float* d_can_dist, const int64_t* d_can_ids, const float* d_arr_dist,
+                             const int64_t* d_arr_ids, const int64_t* d_arr_key, const int64_t* d_arr_n, float* d_out_dist,
+                             int64_t* d_out_ids, void* stream) {
+    if (nshards <= 0 || nflag < 0 || k <= 0 || k + 1 > KN_MAX_K || (metric != KNHIP_L2 && metric != KNHIP_IP) ||
+        !d_flagged || !d_can_dist || !d_can_ids || !d_arr_dist || !d_arr_ids || !d_arr_key || !d_arr_n || !d_out_dist ||
+        !d_out_ids) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "tie_resolve: bad arguments");
+    }
+    HIP_TRY(launch_tie_resolve(d_flagged, nflag, nshards, d_can_dist, d_can_ids, k, metric == KNHIP_L2, d_arr_dist, d_arr_ids,
+                               d_arr_key, d_arr_n, nflag, d_out_dist, d_out_ids, nullptr, static_cast<hipStream_t>(stream)));
+    return KNHIP_OK;
+}
+
+// host form of flag + resolve (results merged on the CPU: knhip_merge_topk_host's companion).  arr_* [nshards][nq][k] /
+// arr_n [nshards][nq] indexed by the QUERY (rows of unflagged queries are not read); flagged_out (nullable) [nq] 0 / 1.
+int knhip_tie_flag_host(const float* can_dist, const int64_t* can_ids, int64_t nq, int32_t k, float* out_dist,
+                        int64_t* out_ids, uint8_t* flagged_out) {
+    if (nq < 0 || k <= 0 || !can_dist || !can_ids || !out_dist || !out_ids) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "tie_flag_host: bad arguments");
+    }
+    const int kk = k + 1;
+    for (int64_t q = 0; q < nq; q++) {
+        for (int j = 0; j < k; j++) {
+            out_dist[q * k + j] = can_dist[q * kk + j];
+            out_ids[q * k + j] = can_ids[q * kk + j];
+        }
+        uint32_t a, b;
+        std::memcpy(&a, &can_dist[q * kk + k], 4);
+        std::memcpy(&b, &can_dist[q * kk + k - 1], 4);
+        if (flagged_out) {
+            flagged_out[q] = (can_ids[q * kk + k] >= 0 && can_ids[q * kk + k - 1] >= 0 && a == b) ? 1 : 0;
+        }
+    }
+    return KNHIP_OK;
+}
+
+int knhip_tie_resolve_host(int32_t metric, int32_t nshards, int64_t nq, int32_t k, const uint8_t* flagged,
+                           const float* can_dist, const int64_t* can_ids, const float* arr_dist, const int64_t* arr_ids,
+                           const int64_t* arr_key, const int64_t* arr_n, float* out_dist, int64_t* out_ids) {
+    if (nshards <= 0 || nq < 0 || k <= 0 || (metric != KNHIP_L2 && metric != KNHIP_IP) || !flagged || !can_dist || !can_ids ||
+        !arr_dist || !arr_ids || !arr_key || !arr_n || !out_dist || !out_ids) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "tie_resolve_host: bad arguments");
+    }
+    const bool l2 = metric == KNHIP_L2;
+    const int kk = k + 1;
+    struct Arr {
+        int64_t key;
+        float d;
+        int64_t id;
+    };
+    std::vector<Arr> arr;
+    std::vector<std::pair<float, int64_t>> pool;
+    for (int64_t q = 0; q < nq; q++) {
+        if (!flagged[q]) {
+            continue;
+        }
+        const float v = can_dist[q * kk + k - 1];
+        pool.clear();
+        size_t nvalid = 0;
+        for (int j = 0; j < k; j++) {
+            if (can_ids[q * kk + j] >= 0) {
+                nvalid++;
+                if (can_dist[q * kk + j] != v) {
+                    pool.emplace_back(can_dist[q * kk + j], can_ids[q * kk + j]);
+                }
+            }
+        }
+        arr.clear();
+        for (int sh = 0; sh < nshards; sh++) {
+            const int64_t cnt = std::min<int64_t>(k, arr_n[(int64_t)sh * nq + q]);
+            const int64_t at = ((int64_t)sh * nq + q) * k;
+            for (int64_t e = 0; e < cnt; e++) {
+                arr.push_back({arr_key[at + e], arr_dist[at + e], arr_ids[at + e]});
+            }
+        }
+        std::stable_sort(arr.begin(), arr.end(), [](const Arr& a, const Arr& b) { return a.key < b.key; });
+        for (size_t e = 0; e < arr.size() && e < (size_t)k; e++) { // the first k arrivals overall
+            if (arr[e].d == v) {
+                pool.emplace_back(v, arr[e].id);
+            }
+        }
+        if (pool.size() < nvalid) {
+            continue; // (as the device kernel: the canonical row stays)
+        }
+        std::sort(pool.begin(), pool.end(), [l2](const std::pair<float, int64_t>& a, const std::pair<float, int64_t>& b) {
+            if (l2) {
+                return a.first < b.first || (a.first == b.first && a.second < b.second);
+            }
+            return a.first > b.first || (a.first == b.first && a.second > b.second);
+        });
+        for (int j = 0; j < k && (size_t)j < pool.size(); j++) {
+            out_dist[q * k + j] = pool[j].first;
+            out_ids[q * k + j] = pool[j].second;
+        }
+    }
+    return KNHIP_OK;
+}
+
+// ---- sharded refine: distances where the rows are, ONE selection over all of them --------------------------------------------
+int knhip_refine_distances_device(int32_t metric, int32_t dim, const float* d_base, int64_t nbase, int64_t id_base,
+                                  const float* d_queries, int64_t nq, const int64_t* d_cand_ids, int32_t k_base,
+                                  float* d_out_dist, void* stream) {
+    if (dim <= 0 || nbase < 0 || nq < 0 || k_base <= 0 || k_base > KN_MAX_K || (nbase > 0 && !d_base) || !d_queries ||
+        !d_cand_ids || !d_out_dist || (metric != KNHIP_L2 && metric != KNHIP_IP)) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "refine_distances: bad arguments");
+    }
+    HIP_TRY(launch_refine(d_base, nbase, id_base, dim, d_queries, nq, d_cand_ids, k_base, 1, metric == KNHIP_L2, nullptr,
+                          nullptr, static_cast<hipStream_t>(stream), 0, nullptr, nullptr, d_out_dist));
+    return KNHIP_OK;
+}
+
+int knhip_refine_rows_distances_device(int32_t metric, const knhip_rows* rows, int64_t id_base, const float* d_queries,
+                                       int64_t nq, const int64_t* d_cand_ids, int32_t k_base, float* d_out_dist,
+                                       void* stream) {
+    if (!rows || !rows->trained || nq < 0 || k_base <= 0 || k_base > KN_MAX_K || !d_queries || !d_cand_ids || !d_out_dist ||
+        (metric != KNHIP_L2 && metric != KNHIP_IP)) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "refine_rows_distances: bad arguments");
+    }
+    HIP_TRY(launch_refine(static_cast<const float*>(rows->codes.p), rows->n, id_base, rows->d, d_queries, nq, d_cand_ids, k_base,
+                          1, metric == KNHIP_L2, nullptr, nullptr, static_cast<hipStream_t>(stream), rows->row_type,
+                          rows->row_type == KNHIP_ROWS_SQ8 ? rows->sq.as<float>() : nullptr, nullptr, d_out_dist));
+    return KNHIP_OK;
+}
+
+int knhip_refine_combine_device(int32_t nshards, int64_t n, const float* d_parts, float* d_out, void* stream) {
+    if (nshards <= 0 || n < 0 || !d_parts || !d_out) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "refine_combine: bad arguments");
+    }
+    HIP_TRY(launch_refine_combine(d_parts, nshards, n, d_out, static_cast<hipStream_t>(stream)));
+    return KNHIP_OK;
+}
+
+int knhip_refine_select_device(int32_t metric, int64_t nq, const int64_t* d_cand_ids, const float* d_dist, int32_t k_base,
+                               int32_t k, float* d_out_dist, int64_t* d_out_ids, void* stream) {
+    if (nq < 0 || k <= 0 || k > KN_MAX_K || k_base < k || !d_cand_ids || !d_dist || !d_out_dist || !d_out_ids ||
+        (metric != KNHIP_L2 && metric != KNHIP_IP)) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "refine_select: bad arguments");
+    }
+    HIP_TRY(launch_refine(nullptr, 0, 0, 4, nullptr, nq, d_cand_ids, k_base, k, metric == KNHIP_L2, d_out_dist, d_out_ids,
+                          static_cast<hipStream_t>(stream), 0, nullptr, d_dist, nullptr));
+    return KNHIP_OK;
+}
+
+// host form of the selection (a CPU-side merge of sharded refine results): the closed form of IndexRefine's reorder_2_heaps
+// (Heap.h:657: the re-scored candidates pass a heap with strict-improve admission IN CANDIDATE ORDER) -- candidates up to the
+// first -1 label, slots marked "not here" skipped
+int knhip_refine_select_host(int32_t metric, int64_t nq, const int64_t* cand_ids, const float* dist, int32_t k_base, int32_t k,
+                             float* out_dist, int64_t* out_ids) {
+    if (nq < 0 || k <= 0 || k_base < k || !cand_ids || !dist || !out_dist || !out_ids || (metric != KNHIP_L2 && metric != KNHIP_IP)) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "refine_select_host: bad arguments");
+    }
+    const bool l2 = metric == KNHIP_L2;
+    auto before = [l2](const std::pair<float, int64_t>& a, const std::pair<float, int64_t>& b) {
+        if (l2) {
+            return a.first < b.first || (a.first == b.first && a.second < b.second);
+        }
+        return a.first > b.first || (a.first == b.first && a.second > b.second);
+    };
+    std::vector<std::pair<float, int64_t>> arr, pool;
+    for (int64_t q = 0; q < nq; q++) {
+        arr.clear();
+        for (int c = 0; c < k_base; c++) {
+            const int64_t id = cand_ids[q * k_base + c];
+            if (id == -1) {
+                break;
+            }
+            uint32_t bits;
+            std::memcpy(&bits, &dist[q * k_base + c], 4);
+            if (id >= 0 && bits != 0xffffffffu) {
+                arr.emplace_back(dist[q * k_base + c], id);
+            }
+        }
+        pool = arr;
+        std::sort(pool.begin(), pool.end(), before);
+        if ((int64_t)pool.size() > k) {
+            const float v = pool[(size_t)k - 1].first;
+            pool.clear();
+            int seen = 0; // arrivals with distance <= v so far
+            for (const auto& a : arr) {
+                const bool qual = l2 ? a.first <= v : a.first >= v;
+                if (!qual) {
+                    continue;
+                }
+                if (a.first != v || seen < k) {
+                    pool.push_back(a);
+                }
+                seen++;
+            }
+            std::sort(pool.begin(), pool.end(), before);
+        }
+        for (int j = 0; j < k; j++) {
+            if ((size_t)j < pool.size()) {
+                out_dist[q * k + j] = pool[(size_t)j].first;
+                out_ids[q * k + j] = pool[(size_t)j].second;
+            } else {
+                out_dist[q * k + j] = l2 ? FLT_MAX : -FLT_MAX;
+                out_ids[q * k + j] = -1;
+            }
+        }
     }
     return KNHIP_OK;
 }

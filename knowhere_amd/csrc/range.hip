@@ -215,7 +215,8 @@ template <bool IS_L2>
 __global__ __launch_bounds__(RG_THREADS) void range_emit_kernel(RangeArgs a, const int64_t* __restrict__ off,
                                                                 const int64_t* __restrict__ qbase,
                                                                 int64_t* __restrict__ out_ids,
-                                                                float* __restrict__ out_dis, int64_t cap) {
+                                                                float* __restrict__ out_dis, int64_t cap,
+                                                                int64_t* __restrict__ out_key, int64_t key_base) {
     const int64_t q = blockIdx.x / a.nprobe;
     const int rank = (int)(blockIdx.x % a.nprobe);
     const int64_t o = off[blockIdx.x];
@@ -251,6 +252,12 @@ __global__ __launch_bounds__(RG_THREADS) void range_emit_kernel(RangeArgs a, con
         if (hit && (cap <= 0 || base + before - qb0 < cap)) {
             out_ids[base + before] = a.ids ? a.ids[idp0 + i] : idp0 + i + a.id_offset;
             out_dis[base + before] = dis;
+            if (out_key != nullptr) {
+                // the arrival's place in the reference's scan order, comparable ACROSS shards: (probe rank, position in the
+                // list) for the IVF kinds -- every shard ranks the lists alike --, the row number for brute force
+                // (key_base = the shard's first row)
+                out_key[base + before] = a.order != nullptr ? (((int64_t)rank << 40) | i) : key_base + idp0 + i;
+            }
         }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -441,6 +448,53 @@ hipError_t launch_tie_detect(const float* d, const int64_t* i, int64_t nq, int k
     return hipGetLastError();
 }
 
+// flagged[] comes out of tie_detect in atomic order; the shards of a group must walk the same list in the same order:
+// ascending (the entries are distinct query numbers: an entry's place = how many are smaller)
+__global__ void tie_sort_flags_kernel(const int32_t* __restrict__ in, int n, int32_t* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) {
+        return;
+    }
+    const int32_t v = in[t];
+    int r = 0;
+    for (int o = 0; o < n; o++) {
+        r += in[o] < v ? 1 : 0;
+    }
+    out[r] = v;
+}
+
+hipError_t launch_tie_sort_flags(const int32_t* in, int n, int32_t* out, hipStream_t s) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(tie_sort_flags_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, n, out);
+    return hipGetLastError();
+}
+
+// sharded refine: every candidate's distance from the one shard that holds its row (parts [nsh][n]; REFINE_NOT_HERE = the
+// all-ones pattern elsewhere, kept when no shard holds it)
+__global__ void refine_combine_kernel(const uint32_t* __restrict__ parts, int nsh, int64_t n, uint32_t* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) {
+        return;
+    }
+    uint32_t v = 0xffffffffu;
+    for (int sh = 0; sh < nsh; sh++) {
+        const uint32_t x = parts[(int64_t)sh * n + t];
+        v = x != 0xffffffffu ? x : v;
+    }
+    out[t] = v;
+}
+
+hipError_t launch_refine_combine(const float* parts, int nsh, int64_t n, float* out, hipStream_t s) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(refine_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                       reinterpret_cast<const uint32_t*>(parts), nsh, n, reinterpret_cast<uint32_t*>(out));
+    return hipGetLastError();
+}
+
 // ---- k-th-boundary ties, resolved on the device (knhip_api.hip, search_batch_ties) -----------------------------------------
 // gather the flagged queries (rows of the batch's queries, coarse keys and coarse distances) into dense arrays
 __global__ void tie_gather_kernel(const int32_t* __restrict__ flagged, int nflag, const float* __restrict__ q, int d,
@@ -466,24 +520,31 @@ __global__ void tie_gather_kernel(const int32_t* __restrict__ flagged, int nflag
     }
 }
 
-// One workgroup per flagged query.  hits[f][0 .. min(k, total[f])) = the first arrivals with distance <= v (>= v for IP) in
-// the reference's SCAN order (range_count / range_plan / range_emit over the dump of its probed lists, capped at k), v =
-// the canonical k-th distance.  The result = canonical top-k of {canonical entries better than v} U {ties among those
-// arrivals} (the closed form of the reference's heap, tests/test_tie_rule.py), written over the query's output row.
+// One workgroup per flagged query.  Shard s (nsh = 1: the index itself) reports arr_*[s][f][0 .. min(k, arr_n[s][f])) = ITS
+// first arrivals with distance <= v (>= v for IP) in the reference's scan order (range_count / range_plan / range_emit over
+// the dump of the probed lists it holds, capped at k), v = the canonical k-th distance, each with its place in the GLOBAL
+// scan order (arr_key: (probe rank, position) -- every shard ranks the lists alike -- or the row number for brute force).
+// The first k arrivals overall are among these (a shard's (k + 1)-th arrival has k earlier ones in its own shard), so:
+//   eligible tie = an arrival with distance v that fewer than k arrivals precede (by key, over all shards);
+//   result = canonical top-k of {canonical entries better than v} U {eligible ties}
+// -- the closed form of the reference's heap (tests/test_tie_rule.py) --, written over the query's output row.  With one
+// shard the arrivals are in order already (arr_key may be null).  The reference's own sharding contract is ids-equal
+// (tests/ut/test_bruteforce.cc:128-181): this is what makes a list-sharded search return the single index's answer.
 template <bool IS_L2>
-__global__ __launch_bounds__(RG_THREADS) void tie_apply_kernel(const int32_t* __restrict__ flagged,
-                                                               const float* __restrict__ can_d,
-                                                               const int64_t* __restrict__ can_i, int k,
-                                                               const float* __restrict__ hit_d,
-                                                               const int64_t* __restrict__ hit_i,
-                                                               const int64_t* __restrict__ total,
-                                                               float* __restrict__ out_d, int64_t* __restrict__ out_i,
-                                                               int32_t* __restrict__ anomalies) {
+__global__ __launch_bounds__(RG_THREADS) void tie_resolve_kernel(const int32_t* __restrict__ flagged, int nflag, int nsh,
+                                                                 const float* __restrict__ can_d,
+                                                                 const int64_t* __restrict__ can_i, int k,
+                                                                 const float* __restrict__ arr_d,
+                                                                 const int64_t* __restrict__ arr_i,
+                                                                 const int64_t* __restrict__ arr_key,
+                                                                 const int64_t* __restrict__ arr_n, int64_t arr_n_stride,
+                                                                 float* __restrict__ out_d, int64_t* __restrict__ out_i,
+                                                                 int32_t* __restrict__ anomalies) {
     extern __shared__ __align__(16) unsigned char smem[];
     float* pool_d = reinterpret_cast<float*>(smem);                         // [2 k]
     int64_t* pool_i = reinterpret_cast<int64_t*>(smem + (size_t)2 * k * 4); // [2 k] (2 k * 4 is a multiple of 8)
     __shared__ int s_n, s_valid;
-    const int64_t f = blockIdx.x; // row of the hits
+    const int64_t f = blockIdx.x; // row of the arrivals
     const int64_t q = flagged[f]; // row of the batch
     const int kk = k + 1;
     const int tid = threadIdx.x;
@@ -493,28 +554,57 @@ __global__ __launch_bounds__(RG_THREADS) void tie_apply_kernel(const int32_t* __
         s_valid = 0;
     }
     __syncthreads();
-    // the canonical entries better than v, and the ties among the first k arrivals, in any order (ranked below)
-    const int narr = (int)min((int64_t)k, total[f]);
-    for (int e = tid; e < k + narr; e += RG_THREADS) {
-        float de;
-        int64_t ie;
-        bool take;
-        if (e < k) {
-            de = can_d[q * kk + e];
-            ie = can_i[q * kk + e];
-            take = ie >= 0 && de != v;
-            if (ie >= 0) {
-                atomicAdd(&s_valid, 1);
+    // the canonical entries better than v ...
+    for (int e = tid; e < k; e += RG_THREADS) {
+        const float de = can_d[q * kk + e];
+        const int64_t ie = can_i[q * kk + e];
+        if (ie >= 0) {
+            atomicAdd(&s_valid, 1);
+            if (de != v) {
+                const int p = atomicAdd(&s_n, 1);
+                pool_d[p] = de;
+                pool_i[p] = ie;
             }
-        } else {
-            de = hit_d[f * k + (e - k)];
-            ie = hit_i[f * k + (e - k)];
-            take = de == v;
         }
-        if (take) {
+    }
+    // ... and the ties among the first k arrivals (flattened index a = s * k + e over the shards' lists)
+    const int na = nsh * k;
+    for (int a = tid; a < na; a += RG_THREADS) {
+        const int sh = a / k, e = a - sh * k;
+        const int64_t cnt = min((int64_t)k, arr_n[(int64_t)sh * arr_n_stride + f]);
+        if (e >= cnt) {
+            continue;
+        }
+        const int64_t at = ((int64_t)sh * nflag + f) * k + e;
+        if (arr_d[at] != v) {
+            continue;
+        }
+        int before = e; // arrivals of this shard in front of it
+        if (nsh > 1) {
+            const int64_t key = arr_key[at];
+            for (int o = 0; o < nsh && before < k; o++) {
+                if (o == sh) {
+                    continue;
+                }
+                const int64_t ocnt = min((int64_t)k, arr_n[(int64_t)o * arr_n_stride + f]);
+                const int64_t* okey = arr_key + ((int64_t)o * nflag + f) * k;
+                // (a shard's arrivals are in key order: count by bisection)
+                int lo = 0, hi = (int)ocnt;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (okey[mid] < key) {
+                        lo = mid + 1;
+                    } else {
+                        hi = mid;
+                    }
+                }
+                before += lo;
+            }
+        }
+        if (before < k) {
             const int p = atomicAdd(&s_n, 1);
-            pool_d[p] = de;
-            pool_i[p] = ie;
+            pool_d[p] = v;
+            pool_i[p] = arr_i[at];
         }
     }
     __syncthreads();
@@ -553,34 +643,39 @@ hipError_t launch_tie_gather(const int32_t* flagged, int nflag, const float* q, 
     return hipGetLastError();
 }
 
-hipError_t launch_tie_apply(const int32_t* flagged, int nflag, const float* can_d, const int64_t* can_i, int k, bool is_l2,
-                            const float* hit_d, const int64_t* hit_i, const int64_t* total, float* out_d, int64_t* out_i,
-                            int32_t* anomalies, hipStream_t s) {
+hipError_t launch_tie_resolve(const int32_t* flagged, int nflag, int nsh, const float* can_d, const int64_t* can_i, int k,
+                              bool is_l2, const float* arr_d, const int64_t* arr_i, const int64_t* arr_key,
+                              const int64_t* arr_n, int64_t arr_n_stride, float* out_d, int64_t* out_i, int32_t* anomalies,
+                              hipStream_t s) {
     if (nflag <= 0) {
         return hipSuccess;
     }
+    if (nsh <= 0 || (nsh > 1 && arr_key == nullptr)) {
+        return hipErrorInvalidValue;
+    }
     const size_t sm = (size_t)2 * k * 12;
-    auto kern = is_l2 ? tie_apply_kernel<true> : tie_apply_kernel<false>;
+    auto kern = is_l2 ? tie_resolve_kernel<true> : tie_resolve_kernel<false>;
     if (sm > 48 * 1024) {
         return hipErrorInvalidValue; // (k <= 1023: 24 KB)
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nflag), dim3(RG_THREADS), sm, s, flagged, can_d, can_i, k, hit_d, hit_i, total,
-                       out_d, out_i, anomalies);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nflag), dim3(RG_THREADS), sm, s, flagged, nflag, nsh, can_d, can_i, k, arr_d, arr_i,
+                       arr_key, arr_n, arr_n_stride, out_d, out_i, anomalies);
     return hipGetLastError();
 }
 
 hipError_t launch_range_emit(const RangeArgs& a, int64_t nq, bool is_l2, const int64_t* off, const int64_t* qbase,
-                             int64_t* out_ids, float* out_dis, hipStream_t s, int64_t cap) {
+                             int64_t* out_ids, float* out_dis, hipStream_t s, int64_t cap, int64_t* out_key,
+                             int64_t key_base) {
     if (nq <= 0 || a.nprobe <= 0) {
         return hipSuccess;
     }
     const unsigned grid = (unsigned)(nq * a.nprobe);
     if (is_l2) {
         hipLaunchKernelGGL((range_emit_kernel<true>), dim3(grid), dim3(RG_THREADS), 0, s, a, off, qbase, out_ids,
-                           out_dis, cap);
+                           out_dis, cap, out_key, key_base);
     } else {
         hipLaunchKernelGGL((range_emit_kernel<false>), dim3(grid), dim3(RG_THREADS), 0, s, a, off, qbase, out_ids,
-                           out_dis, cap);
+                           out_dis, cap, out_key, key_base);
     }
     return hipGetLastError();
 }

@@ -25,6 +25,8 @@
 
 namespace knhip {
 
+constexpr uint32_t REFINE_NOT_HERE = 0xffffffffu; // a NaN pattern no arithmetic produces: "this shard does not hold the row"
+
 // ROWT: 0 fp32 rows, 1 fp16, 2 bf16, 3 per-dimension 8-bit codes (sq = vmin[d], vdiff[d])
 template <int ROWT>
 __device__ __forceinline__ float refine_row_value(const void* row, int i, const float* __restrict__ sq, int d) {
@@ -47,7 +49,12 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ b
                                                      const float* __restrict__ queries, int64_t nq,
                                                      const int64_t* __restrict__ cand, int kbase, int k,
                                                      float* __restrict__ out_d,
-                                                     int64_t* __restrict__ out_i, const float* __restrict__ sq_trained) {
+                                                     int64_t* __restrict__ out_i, const float* __restrict__ sq_trained,
+                                                     const float* __restrict__ dist_in, float* __restrict__ dist_out) {
+    // Sharded refine (the raw rows cut into one id range per shard): the re-scored candidates pass the reference's heap in
+    // CANDIDATE order whoever holds their rows, so the selection needs every candidate's distance.  dist_out != nullptr:
+    // only the distances of the candidates held here are written ([nq][kbase]; REFINE_NOT_HERE elsewhere), nothing is
+    // selected; dist_in != nullptr: the distances are given (the shards' arrays combined), only the selection runs.
     extern __shared__ __align__(16) float sq[]; // [4][d] queries, then [4][kbase] the candidates' distances
     const int lane = lane_id();
     const int wave = threadIdx.x / KN_WAVE;
@@ -55,7 +62,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ b
     const bool live = q < nq;
     float* myq = sq + wave * d;
     float* mydis = sq + 4 * d + wave * kbase;
-    if (live) {
+    if (live && dist_in == nullptr) {
         for (int i = lane; i < d; i += KN_WAVE) {
             myq[i] = queries[q * d + i];
         }
@@ -85,10 +92,14 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ b
             ended = true;
             nend = c0 + nvalid;
         }
-        const bool ok = lane < nvalid && id >= 0 && (id - id_base) >= 0 && (id - id_base) < nbase;
-        skipped = skipped || __ballot(lane < nvalid && !ok) != 0ull;
+        bool ok = lane < nvalid && id >= 0 && (id - id_base) >= 0 && (id - id_base) < nbase;
         float acc = 0.f;
-        if (ok && ROWT != 0) {
+        if (dist_in != nullptr) {
+            acc = c < kbase ? dist_in[q * kbase + c] : 0.f;
+            ok = lane < nvalid && id >= 0 && __float_as_uint(acc) != REFINE_NOT_HERE; // (held by no shard: skipped)
+        }
+        skipped = skipped || __ballot(lane < nvalid && !ok) != 0ull;
+        if (ok && ROWT != 0 && dist_in == nullptr) {
             // quantised rows: decode + accumulate, element by element in the reference's order
             constexpr int ESZ = ROWT == 3 ? 1 : 2;
             constexpr int EPC = 16 / ESZ; // elements per 16-byte piece
@@ -131,7 +142,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ b
                 acc = IS_L2 ? l2_step(acc, myq[i], x) : ip_step(acc, myq[i], x);
             }
         }
-        if (ok && ROWT == 0) {
+        if (ok && ROWT == 0 && dist_in == nullptr) {
             const float* y = base + (id - id_base) * d;
             int i = 0;
             if ((d & 3) == 0 && (reinterpret_cast<uintptr_t>(base) & 15) == 0) {
@@ -173,6 +184,12 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ b
         if (c < kbase) {
             mydis[c] = acc;
         }
+        if (dist_out != nullptr) {
+            if (c < kbase) {
+                dist_out[q * kbase + c] = ok ? acc : __uint_as_float(REFINE_NOT_HERE);
+            }
+            continue;
+        }
         unsigned long long m = __ballot(ok && top.admits(acc, id, kd, ki));
         while (m) {
             const int l = __ffsll((long long)m) - 1;
@@ -185,6 +202,13 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ b
                 ki = top.kth_idx();
             }
         }
+    }
+    if (dist_out != nullptr) {
+        // (slots behind the end of the candidate list)
+        for (int c = nend + lane; c < kbase; c += KN_WAVE) {
+            dist_out[q * kbase + c] = __uint_as_float(REFINE_NOT_HERE);
+        }
+        return;
     }
     // ---- the reference's admission at the k-th boundary (see the header): only when a full list leaves tied candidates out
     if (ki >= 0 && !skipped) {
@@ -229,11 +253,13 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ b
 
 hipError_t launch_refine(const float* base, int64_t nbase, int64_t id_base, int d, const float* queries,
                          int64_t nq, const int64_t* cand, int kbase, int k, bool is_l2, float* out_d,
-                         int64_t* out_i, hipStream_t s, int row_type, const float* sq_trained) {
+                         int64_t* out_i, hipStream_t s, int row_type, const float* sq_trained, const float* dist_in,
+                         float* dist_out) {
     if (nq <= 0) {
         return hipSuccess;
     }
-    if (row_type < 0 || row_type > 3 || (row_type == 3 && sq_trained == nullptr)) {
+    if (row_type < 0 || row_type > 3 || (row_type == 3 && sq_trained == nullptr && dist_in == nullptr) ||
+        (dist_in != nullptr && dist_out != nullptr)) {
         return hipErrorInvalidValue;
     }
     const unsigned grid = (unsigned)((nq + 3) / 4);
@@ -253,7 +279,7 @@ hipError_t launch_refine(const float* base, int64_t nbase, int64_t id_base, int 
             }                                                                                                         \
         }                                                                                                             \
         hipLaunchKernelGGL(kern_, dim3(grid), dim3(256), sm, s, base, nbase, id_base, d, queries, nq, cand, kbase, k, \
-                           out_d, out_i, sq_trained);                                                                 \
+                           out_d, out_i, sq_trained, dist_in, dist_out);                                              \
     }
 #define KN_REFINE_LAUNCH(ROWT_)                                                                                       \
     KN_DISPATCH_R(k, {                                                                                                \

@@ -3,10 +3,14 @@
 // One worker thread per GPU inside one process; per Search(): every worker uploads the batch; the coarse quantizer is
 // SHARDED BY QUERIES (rank r assigns nq / W of them with knhip_coarse_search_device, one packed all-gather gives every rank
 // the whole (nq, nprobe) assignment: the replicated stage that would otherwise bound the scaling), then every
-// worker scans the lists it owns (knhip_search_preassigned_device = IndexIVF::search_preassigned), packs its (nq, k)
-// partial result into 12-byte entries, ONE all-gather
-// (ncclAllGather over the RCCL communicators of ncclCommInitAll, or staged device copies), knhip_merge_topk_device,
-// rank 0 downloads.  Replaces faiss IndexShards::search + merge_knn_results (IndexShards.cpp:247-256).
+// worker scans the lists it owns (knhip_search_canonical_device over the given assignment = IndexIVF::search_preassigned,
+// k + 1 CANONICAL results, no tie rule), packs its partial result into 12-byte entries, ONE all-gather
+// (ncclAllGather over the RCCL communicators of ncclCommInitAll, or staged device copies), knhip_merge_topk_device; the
+// reference's admission rule at the k-th boundary is then applied ONCE over all shards' candidates (knhip_tie_flag_device;
+// for the flagged queries every shard's first k arrivals, one more small all-gather, knhip_tie_resolve_device), so the
+// group returns the single index's answer, ties included.  Refine: every rank computes the distances of the merged
+// candidates whose rows it holds, one all-gather of the distance arrays, ONE selection (knhip_refine_select_device).
+// Rank 0 downloads.  Replaces faiss IndexShards::search + merge_knn_results (IndexShards.cpp:247-256).
 #include "knhip_shards.h"
 
 #include <hip/hip_runtime.h>
@@ -69,6 +73,7 @@ struct Rank {
     hipStream_t stream = nullptr;
     ncclComm_t comm = nullptr;
     DevMem q, bits, part_d, part_i, packed, gathered, all_d, all_i, out_d, out_i, ref_d, ref_i, ck, cd, keys, cdis;
+    DevMem res_d, res_i, flags, arr_d, arr_i, arr_k, arr_n, all_ad, all_ai, all_ak, all_an, rdist, rdist_all;
     // raw fp32 rows this rank holds for the refine stage: row r = vector id raw_id0 + r (device pointer on `dev`)
     const float* raw = nullptr;
     int64_t raw_n = 0, raw_id0 = 0;
@@ -116,6 +121,44 @@ __global__ void unpack_kernel(const uint32_t* in, int64_t n, float* d, int64_t* 
     i[t] = (int64_t)((uint64_t)in[3 * t + 1] | ((uint64_t)in[3 * t + 2] << 32));
 }
 
+// a rank's arrivals of the flagged queries as ONE block of `stride` bytes (a multiple of 8):
+// [ids nflag k int64][keys nflag k int64][counts nflag int64][distances nflag k float]
+__global__ void pack_arrivals_kernel(const float* ad, const int64_t* ai, const int64_t* ak, const int64_t* an, int64_t nflag,
+                                     int k, unsigned char* out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t ne = nflag * k;
+    int64_t* oi = reinterpret_cast<int64_t*>(out);
+    int64_t* ok = oi + ne;
+    int64_t* on = ok + ne;
+    float* od = reinterpret_cast<float*>(on + nflag);
+    if (t < ne) {
+        oi[t] = ai[t];
+        ok[t] = ak[t];
+        od[t] = ad[t];
+    }
+    if (t < nflag) {
+        on[t] = an[t];
+    }
+}
+__global__ void unpack_arrivals_kernel(const unsigned char* in, int64_t stride, int W, int64_t nflag, int k, float* ad,
+                                       int64_t* ai, int64_t* ak, int64_t* an) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t ne = nflag * k;
+    if (t >= (int64_t)W * ne) return;
+    const int o = (int)(t / ne);
+    const int64_t e = t - (int64_t)o * ne;
+    const int64_t* bi = reinterpret_cast<const int64_t*>(in + (size_t)o * stride);
+    const int64_t* bk = bi + ne;
+    const int64_t* bn = bk + ne;
+    const float* bd = reinterpret_cast<const float*>(bn + nflag);
+    ai[t] = bi[e];
+    ak[t] = bk[e];
+    ad[t] = bd[e];
+    if (e < nflag) {
+        an[(int64_t)o * nflag + e] = bn[e];
+    }
+}
+
 #define SG_HIP(call)                                                                     \
     do {                                                                                 \
         hipError_t e_ = (call);                                                          \
@@ -150,7 +193,8 @@ int knhip_shard_group_create(int32_t n_devices, const int32_t* device_ids, int32
         Rank& k = g->ranks[r];
         k.dev = device_ids[r];
         for (DevMem* m : {&k.q, &k.bits, &k.part_d, &k.part_i, &k.packed, &k.gathered, &k.all_d, &k.all_i, &k.out_d, &k.out_i,
-                          &k.ref_d, &k.ref_i, &k.ck, &k.cd, &k.keys, &k.cdis}) {
+                          &k.ref_d, &k.ref_i, &k.ck, &k.cd, &k.keys, &k.cdis, &k.res_d, &k.res_i, &k.flags, &k.arr_d, &k.arr_i,
+                          &k.arr_k, &k.arr_n, &k.all_ad, &k.all_ai, &k.all_ak, &k.all_an, &k.rdist, &k.rdist_all}) {
             m->dev = k.dev;
         }
         (void)hipSetDevice(k.dev);
@@ -248,19 +292,33 @@ static int search_impl(knhip_shard_group* g, const float* queries, int64_t nq, i
     if (int drc = knhip_index_get_desc(g->ranks[0].idx, &desc)) return fail(drc, knhip_last_error());
     const int32_t dim = desc.dim;
     const int32_t metric = desc.metric;
-    const int32_t k1 = refine ? k_base : k;       // width of the first exchange
-    const int64_t ne1 = nq * (int64_t)k1;         // entries per rank, first exchange
+    const int32_t k1 = refine ? k_base : k;       // results of the first stage
+    // the tie rule needs the (k1 + 1)-th canonical result; not covered (canonical answer, as on one index): k1 = 1024,
+    // brute force with k1 >= 100 (the reference's reservoir)
+    const bool ties1 = k1 + 1 <= 1024 && !(desc.kind == KNHIP_BRUTE_FORCE && k1 >= 100);
+    const int32_t kk1 = ties1 ? k1 + 1 : k1;      // width of the first exchange
+    const int64_t ne1 = nq * (int64_t)kk1;        // entries per rank, first exchange
     const int64_t ne = nq * (int64_t)k;           // entries of the result
     // coarse quantizer sharded by queries (IVF kinds, several ranks): rank r assigns rows [r per, (r + 1) per)
     const char* cmode = getenv("KNHIP_SHARDS_COARSE");  // "replicate": every rank assigns every query (no extra collective)
-    const bool shard_coarse = W > 1 && desc.kind != KNHIP_BRUTE_FORCE && !(cmode && cmode[0] == 'r');
-    const int32_t np = desc.kind == KNHIP_BRUTE_FORCE ? 1 : (int32_t)std::min<int64_t>(nprobe, desc.nlist);
+    const bool ivf = desc.kind != KNHIP_BRUTE_FORCE;
+    const bool shard_coarse = W > 1 && ivf && !(cmode && cmode[0] == 'r');
+    const int32_t np = !ivf ? 1 : (int32_t)std::min<int64_t>(nprobe, desc.nlist);
     const int64_t per = (nq + W - 1) / W;
     const int64_t nec = shard_coarse ? per * (int64_t)np : 0;  // entries per rank of the coarse exchange
-    const int64_t nemax = std::max(ne1, nec);
+    // bytes a rank sends in one exchange, at most: packed partials / coarse slice, a block of arrivals, refine distances
+    const size_t arr_stride_max = (((size_t)nq * ((size_t)k1 * 20 + 8)) + 7) & ~(size_t)7;
+    const size_t send_max = std::max<size_t>({(size_t)std::max(ne1, nec) * 12, ties1 ? arr_stride_max : 0,
+                                              refine ? (size_t)nq * k1 * 4 : 0});
+    // brute force: the arrival keys are row numbers; a rank's rows follow those of the ranks in front of it
+    std::vector<int64_t> row_base(W, 0);
+    if (!ivf) {
+        for (int r = 1; r < W; r++) row_base[r] = row_base[r - 1] + knhip_index_count(g->ranks[r - 1].idx);
+    }
     Barrier bar(W);
     std::vector<std::atomic<int>> rcs(W);  // (read by the peers between barriers)
     for (auto& a : rcs) a.store(KNHIP_OK);
+    std::atomic<int> shared_nflag{-1};     // flagged queries of the batch: the same number on every rank that got that far
     std::vector<std::string> errs(W);
     std::vector<std::thread> th;
     Rank* R = g->ranks.data();
@@ -280,22 +338,9 @@ static int search_impl(knhip_shard_group* g, const float* queries, int64_t nq, i
             for (int o = 0; o < W; o++) ok = ok && rcs[o].load() == KNHIP_OK;
             return ok;
         };
-        // ---- one exchange step: pack (pd, pi) [nq][kk], all-gather of the packed partials, unpack + merge -> (od, oi);
-        // e_g / e_m: events recorded before the gather and after the merge.  Same barrier walk for every rank.
-        // merge = false: the gathered (float, int64) entries are only unpacked into (all_d, all_i) -- the coarse assignment;
-        // rows = entries per rank / kk
-        auto exchange = [&](int32_t kk, const float* pd, const int64_t* pi, float* od, int64_t* oi, hipEvent_t e_g,
-                            hipEvent_t e_m, bool merge = true, int64_t rows = -1) {
-            const int64_t n = (rows < 0 ? nq : rows) * (int64_t)kk;
-            auto head = [&]() {
-                hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, me.stream, pd, pi, n,
-                                   static_cast<uint32_t*>(me.packed.p));
-                SG_HIP(hipEventRecord(e_g, me.stream));
-            };
-            if (alive) {
-                head();
-                alive = rc == KNHIP_OK;
-            }
+        // ---- the collective: every rank's `bytes` at `src` -> W blocks in rank order at `dst` (both on the rank's device).
+        // Same barrier walk for every rank, alive or not.
+        auto allgather_bytes = [&](const void* src, void* dst, size_t bytes) {
             if (g->transport == KNHIP_SHARDS_RCCL) {
                 // agreement BEFORE the collective: every rank posts its status, all read the same verdict, and only
                 // then does anyone enqueue -- a rank that failed earlier (allocation, search, merge) makes every rank skip
@@ -307,7 +352,7 @@ static int search_impl(knhip_shard_group* g, const float* queries, int64_t nq, i
                 if (!go) {
                     alive = false;
                 } else {
-                    const ncclResult_t nr = ncclAllGather(me.packed.p, me.gathered.p, (size_t)n * 12, ncclChar, me.comm, me.stream);
+                    const ncclResult_t nr = ncclAllGather(src, dst, bytes, ncclChar, me.comm, me.stream);
                     if (nr != ncclSuccess) {
                         // the peers may have enqueued theirs: nothing can be salvaged on these communicators
                         err = std::string("ncclAllGather: ") + ncclGetErrorString(nr);
@@ -325,11 +370,11 @@ static int search_impl(knhip_shard_group* g, const float* queries, int64_t nq, i
                     alive = false;
                 }
                 post();
-                bar.wait();  // every rank's packed partial is complete
+                bar.wait();  // every rank's block is complete
                 if (alive && all_ok()) {
                     for (int o = 0; o < W && alive; o++) {  // pull every rank's block (peer copies; same device: plain copies)
-                        const hipError_t e = hipMemcpyPeerAsync(static_cast<char*>(me.gathered.p) + (size_t)o * n * 12, me.dev,
-                                                                R[o].packed.p, R[o].dev, (size_t)n * 12, me.stream);
+                        const hipError_t e = hipMemcpyPeerAsync(static_cast<char*>(dst) + (size_t)o * bytes, me.dev,
+                                                                R[o].packed.p, R[o].dev, bytes, me.stream);
                         if (e != hipSuccess) {
                             rc = KNHIP_ERR_HIP_RUNTIME;
                             err = std::string("hipMemcpyPeerAsync: ") + hipGetErrorString(e);
@@ -342,8 +387,26 @@ static int search_impl(knhip_shard_group* g, const float* queries, int64_t nq, i
                     }
                 }
                 post();
-                bar.wait();  // nobody's packed buffer is overwritten before everyone has read it
+                bar.wait();  // nobody's send buffer is overwritten before everyone has read it
             }
+            if (!(alive && all_ok())) alive = false;
+        };
+        // ---- one exchange step: pack (pd, pi) [rows][kk], all-gather of the packed partials, unpack + merge -> (od, oi);
+        // e_g / e_m: events recorded before the gather and after the merge.  merge = false: the gathered (float, int64)
+        // entries are only unpacked into (all_d, all_i) -- the coarse assignment; rows = entries per rank / kk
+        auto exchange = [&](int32_t kk, const float* pd, const int64_t* pi, float* od, int64_t* oi, hipEvent_t e_g,
+                            hipEvent_t e_m, bool merge = true, int64_t rows = -1) {
+            const int64_t n = (rows < 0 ? nq : rows) * (int64_t)kk;
+            auto head = [&]() {
+                hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, me.stream, pd, pi, n,
+                                   static_cast<uint32_t*>(me.packed.p));
+                SG_HIP(hipEventRecord(e_g, me.stream));
+            };
+            if (alive) {
+                head();
+                alive = rc == KNHIP_OK;
+            }
+            allgather_bytes(me.packed.p, me.gathered.p, (size_t)n * 12);
             auto tail = [&]() {
                 hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)((n * W + 255) / 256)), dim3(256), 0, me.stream,
                                    static_cast<const uint32_t*>(me.gathered.p), n * W, static_cast<float*>(me.all_d.p),
@@ -359,11 +422,9 @@ static int search_impl(knhip_shard_group* g, const float* queries, int64_t nq, i
                 }
                 SG_HIP(hipEventRecord(e_m, me.stream));
             };
-            if (alive && all_ok()) {
+            if (alive) {
                 tail();
                 alive = rc == KNHIP_OK;
-            } else {
-                alive = false;
             }
         };
         auto body = [&]() {
@@ -372,21 +433,28 @@ static int search_impl(knhip_shard_group* g, const float* queries, int64_t nq, i
             SG_HIP(me.q.reserve((size_t)nq * dim * sizeof(float)));
             SG_HIP(me.part_d.reserve((size_t)ne1 * sizeof(float)));
             SG_HIP(me.part_i.reserve((size_t)ne1 * sizeof(int64_t)));
-            SG_HIP(me.packed.reserve((size_t)nemax * 12));
-            SG_HIP(me.gathered.reserve((size_t)nemax * 12 * W));
-            SG_HIP(me.all_d.reserve((size_t)nemax * W * sizeof(float)));
-            SG_HIP(me.all_i.reserve((size_t)nemax * W * sizeof(int64_t)));
+            SG_HIP(me.packed.reserve(send_max));
+            SG_HIP(me.gathered.reserve(send_max * W));
+            SG_HIP(me.all_d.reserve((size_t)std::max(ne1, nec) * W * sizeof(float)));
+            SG_HIP(me.all_i.reserve((size_t)std::max(ne1, nec) * W * sizeof(int64_t)));
+            if (ivf) {
+                SG_HIP(me.keys.reserve((size_t)std::max<int64_t>(nec * W, nq * (int64_t)np) * sizeof(int64_t)));
+                SG_HIP(me.cdis.reserve((size_t)std::max<int64_t>(nec * W, nq * (int64_t)np) * sizeof(float)));
+            }
             if (shard_coarse) {
                 SG_HIP(me.ck.reserve((size_t)nec * sizeof(int64_t)));
                 SG_HIP(me.cd.reserve((size_t)nec * sizeof(float)));
-                SG_HIP(me.keys.reserve((size_t)nec * W * sizeof(int64_t)));
-                SG_HIP(me.cdis.reserve((size_t)nec * W * sizeof(float)));
             }
             SG_HIP(me.out_d.reserve((size_t)ne1 * sizeof(float)));
             SG_HIP(me.out_i.reserve((size_t)ne1 * sizeof(int64_t)));
+            SG_HIP(me.res_d.reserve((size_t)nq * k1 * sizeof(float)));
+            SG_HIP(me.res_i.reserve((size_t)nq * k1 * sizeof(int64_t)));
+            if (ties1) SG_HIP(me.flags.reserve(((size_t)2 * nq + 1) * sizeof(int32_t)));
             if (refine) {
                 SG_HIP(me.ref_d.reserve((size_t)ne * sizeof(float)));
                 SG_HIP(me.ref_i.reserve((size_t)ne * sizeof(int64_t)));
+                SG_HIP(me.rdist.reserve((size_t)nq * k1 * sizeof(float)));
+                SG_HIP(me.rdist_all.reserve((size_t)nq * k1 * W * sizeof(float)));
             }
             SG_HIP(hipMemcpyAsync(me.q.p, queries, (size_t)nq * dim * sizeof(float), hipMemcpyHostToDevice, me.stream));
             const uint8_t* d_bits = nullptr;
@@ -413,25 +481,33 @@ static int search_impl(knhip_shard_group* g, const float* queries, int64_t nq, i
                         return;
                     }
                 }
+            } else if (ivf) {
+                // replicated coarse stage: every rank assigns every query (the assignment is needed explicitly: the tie
+                // rule's arrival pass walks the same probes)
+                const int crc = knhip_coarse_search_device(me.idx, static_cast<const float*>(me.q.p), nq, np,
+                                                           static_cast<int64_t*>(me.keys.p), static_cast<float*>(me.cdis.p),
+                                                           me.stream);
+                if (crc != KNHIP_OK) {
+                    err = std::string("knhip_coarse_search_device: ") + knhip_last_error();
+                    rc = crc;
+                    return;
+                }
             }
         };
         auto search = [&]() {
-            int src;
             if (shard_coarse) {
                 // (all_d, all_i) hold the W blocks of `per` rows in rank order = the assignment of rows [0, W per) >= nq
                 SG_HIP(hipMemcpyAsync(me.cdis.p, me.all_d.p, (size_t)nec * W * sizeof(float), hipMemcpyDeviceToDevice, me.stream));
                 SG_HIP(hipMemcpyAsync(me.keys.p, me.all_i.p, (size_t)nec * W * sizeof(int64_t), hipMemcpyDeviceToDevice, me.stream));
-                src = knhip_search_preassigned_device(me.idx, static_cast<const float*>(me.q.p), nq, k1, np,
-                                                      static_cast<const int64_t*>(me.keys.p), static_cast<const float*>(me.cdis.p),
-                                                      me_bits, me_bits ? bitset_nbits : 0, static_cast<int64_t*>(me.part_i.p),
-                                                      static_cast<float*>(me.part_d.p), me.stream);
-            } else {
-                src = knhip_search_device(me.idx, static_cast<const float*>(me.q.p), nq, k1, nprobe, me_bits,
-                                          me_bits ? bitset_nbits : 0, static_cast<int64_t*>(me.part_i.p),
-                                          static_cast<float*>(me.part_d.p), me.stream);
             }
+            // canonical partials, no tie rule on the shard: the rule is applied once, after the merge
+            const int src = knhip_search_canonical_device(me.idx, static_cast<const float*>(me.q.p), nq, kk1, ivf ? np : nprobe,
+                                                          ivf ? static_cast<const int64_t*>(me.keys.p) : nullptr,
+                                                          ivf ? static_cast<const float*>(me.cdis.p) : nullptr, me_bits,
+                                                          me_bits ? bitset_nbits : 0, static_cast<int64_t*>(me.part_i.p),
+                                                          static_cast<float*>(me.part_d.p), me.stream);
             if (src != KNHIP_OK) {
-                err = std::string(shard_coarse ? "knhip_search_preassigned_device: " : "knhip_search_device: ") + knhip_last_error();
+                err = std::string("knhip_search_canonical_device: ") + knhip_last_error();
                 rc = src;
             }
         };
@@ -445,36 +521,136 @@ static int search_impl(knhip_shard_group* g, const float* queries, int64_t nq, i
             search();
             alive = rc == KNHIP_OK;
         }
-        exchange(k1, static_cast<const float*>(me.part_d.p), static_cast<const int64_t*>(me.part_i.p),
+        exchange(kk1, static_cast<const float*>(me.part_d.p), static_cast<const int64_t*>(me.part_i.p),
                  static_cast<float*>(me.out_d.p), static_cast<int64_t*>(me.out_i.p), ev[1], ev[2]);
         float* res_d = static_cast<float*>(me.out_d.p);
         int64_t* res_i = static_cast<int64_t*>(me.out_i.p);
-        if (refine) {
-            // every rank holds the same merged candidates; it re-ranks those whose raw rows live here (ids outside
-            // [raw_id0, raw_id0 + raw_n) are skipped slots of refine.hip), then the (nq, k) partials are exchanged
-            if (alive && me.raw_n == 0) {
-                // this rank holds no raw rows (the raw split need not follow the list split): an all-empty partial
-                hipLaunchKernelGGL(fill_empty_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, me.stream,
-                                   static_cast<float*>(me.ref_d.p), static_cast<int64_t*>(me.ref_i.p), ne,
-                                   metric == KNHIP_L2 ? 3.402823466e+38f : -3.402823466e+38f);
-            } else if (alive) {
-                const int rrc = me.rows
-                        ? knhip_refine_rows_device(metric, me.rows, me.raw_id0, static_cast<const float*>(me.q.p), nq,
-                                                   static_cast<const int64_t*>(me.out_i.p), k1, k,
-                                                   static_cast<float*>(me.ref_d.p), static_cast<int64_t*>(me.ref_i.p), me.stream)
-                        : knhip_refine_device(metric, dim, me.raw, me.raw_n, me.raw_id0, static_cast<const float*>(me.q.p),
-                                              nq, static_cast<const int64_t*>(me.out_i.p), k1, k,
-                                              static_cast<float*>(me.ref_d.p), static_cast<int64_t*>(me.ref_i.p), me.stream);
-                if (rrc != KNHIP_OK) {
-                    err = std::string("knhip_refine_device: ") + knhip_last_error();
-                    rc = rrc;
+        if (ties1) {
+            // ---- the reference's admission rule at the k1-th boundary, once, over all shards' candidates -----------------
+            int32_t nflag = 0;
+            if (alive) {
+                const int frc = knhip_tie_flag_device(static_cast<const float*>(me.out_d.p), static_cast<const int64_t*>(me.out_i.p),
+                                                      nq, k1, static_cast<float*>(me.res_d.p), static_cast<int64_t*>(me.res_i.p),
+                                                      static_cast<int32_t*>(me.flags.p), &nflag, me.stream);
+                if (frc != KNHIP_OK) {
+                    err = std::string("knhip_tie_flag_device: ") + knhip_last_error();
+                    rc = frc;
                     alive = false;
+                } else {
+                    shared_nflag.store(nflag);  // (the merged rows are the same on every rank: so is the count)
                 }
             }
-            exchange(k, static_cast<const float*>(me.ref_d.p), static_cast<const int64_t*>(me.ref_i.p),
-                     static_cast<float*>(me.part_d.p), static_cast<int64_t*>(me.part_i.p), ev[4], ev[5]);
-            res_d = static_cast<float*>(me.part_d.p);
-            res_i = static_cast<int64_t*>(me.part_i.p);
+            post();
+            bar.wait();
+            nflag = shared_nflag.load();
+            res_d = static_cast<float*>(me.res_d.p);
+            res_i = static_cast<int64_t*>(me.res_i.p);
+            if (nflag > 0) {  // (every rank takes this branch or none does)
+                const size_t stride = (((size_t)nflag * ((size_t)k1 * 20 + 8)) + 7) & ~(size_t)7;
+                auto arrivals = [&]() {
+                    SG_HIP(me.arr_d.reserve((size_t)nflag * k1 * sizeof(float)));
+                    SG_HIP(me.arr_i.reserve((size_t)nflag * k1 * sizeof(int64_t)));
+                    SG_HIP(me.arr_k.reserve((size_t)nflag * k1 * sizeof(int64_t)));
+                    SG_HIP(me.arr_n.reserve((size_t)nflag * sizeof(int64_t)));
+                    SG_HIP(me.all_ad.reserve((size_t)W * nflag * k1 * sizeof(float)));
+                    SG_HIP(me.all_ai.reserve((size_t)W * nflag * k1 * sizeof(int64_t)));
+                    SG_HIP(me.all_ak.reserve((size_t)W * nflag * k1 * sizeof(int64_t)));
+                    SG_HIP(me.all_an.reserve((size_t)W * nflag * sizeof(int64_t)));
+                    const int arc = knhip_tie_arrivals_device(
+                            me.idx, static_cast<const float*>(me.q.p), static_cast<const int32_t*>(me.flags.p), nflag,
+                            static_cast<const float*>(me.out_d.p), k1, ivf ? np : nprobe,
+                            ivf ? static_cast<const int64_t*>(me.keys.p) : nullptr, ivf ? static_cast<const float*>(me.cdis.p) : nullptr,
+                            me_bits, me_bits ? bitset_nbits : 0, row_base[r], static_cast<float*>(me.arr_d.p),
+                            static_cast<int64_t*>(me.arr_i.p), static_cast<int64_t*>(me.arr_k.p), static_cast<int64_t*>(me.arr_n.p),
+                            me.stream);
+                    if (arc != KNHIP_OK) {
+                        err = std::string("knhip_tie_arrivals_device: ") + knhip_last_error();
+                        rc = arc;
+                        return;
+                    }
+                    const int64_t nt = (int64_t)nflag * k1;
+                    hipLaunchKernelGGL(pack_arrivals_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, me.stream,
+                                       static_cast<const float*>(me.arr_d.p), static_cast<const int64_t*>(me.arr_i.p),
+                                       static_cast<const int64_t*>(me.arr_k.p), static_cast<const int64_t*>(me.arr_n.p),
+                                       (int64_t)nflag, (int)k1, static_cast<unsigned char*>(me.packed.p));
+                };
+                if (alive) {
+                    arrivals();
+                    alive = rc == KNHIP_OK;
+                }
+                allgather_bytes(me.packed.p, me.gathered.p, stride);
+                auto resolve = [&]() {
+                    const int64_t nt = (int64_t)W * nflag * k1;
+                    hipLaunchKernelGGL(unpack_arrivals_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, me.stream,
+                                       static_cast<const unsigned char*>(me.gathered.p), (int64_t)stride, W, (int64_t)nflag, (int)k1,
+                                       static_cast<float*>(me.all_ad.p), static_cast<int64_t*>(me.all_ai.p),
+                                       static_cast<int64_t*>(me.all_ak.p), static_cast<int64_t*>(me.all_an.p));
+                    const int rrc = knhip_tie_resolve_device(
+                            metric, W, static_cast<const int32_t*>(me.flags.p), nflag, k1, static_cast<const float*>(me.out_d.p),
+                            static_cast<const int64_t*>(me.out_i.p), static_cast<const float*>(me.all_ad.p),
+                            static_cast<const int64_t*>(me.all_ai.p), static_cast<const int64_t*>(me.all_ak.p),
+                            static_cast<const int64_t*>(me.all_an.p), res_d, res_i, me.stream);
+                    if (rrc != KNHIP_OK) {
+                        err = std::string("knhip_tie_resolve_device: ") + knhip_last_error();
+                        rc = rrc;
+                    }
+                };
+                if (alive) {
+                    resolve();
+                    alive = rc == KNHIP_OK;
+                }
+            }
+            if (alive) (void)hipEventRecord(ev[2], me.stream);  // (the first stage ends behind the rule)
+        }
+        if (refine) {
+            // every rank holds the same merged candidates (res_i [nq][k1]); it computes the distances of those whose raw
+            // rows live here (the others marked "not here"), the arrays are exchanged and every rank runs the single
+            // index's selection -- candidate order, tie rule included -- on the combined distances
+            auto dists = [&]() {
+                if (me.raw_n == 0) {
+                    SG_HIP(hipMemsetAsync(me.rdist.p, 0xff, (size_t)nq * k1 * sizeof(float), me.stream));  // "not here"
+                    return;
+                }
+                const int rrc = me.rows
+                        ? knhip_refine_rows_distances_device(metric, me.rows, me.raw_id0, static_cast<const float*>(me.q.p), nq,
+                                                             res_i, k1, static_cast<float*>(me.rdist.p), me.stream)
+                        : knhip_refine_distances_device(metric, dim, me.raw, me.raw_n, me.raw_id0,
+                                                        static_cast<const float*>(me.q.p), nq, res_i, k1,
+                                                        static_cast<float*>(me.rdist.p), me.stream);
+                if (rrc != KNHIP_OK) {
+                    err = std::string("knhip_refine_distances_device: ") + knhip_last_error();
+                    rc = rrc;
+                }
+            };
+            if (alive) {
+                dists();
+                alive = rc == KNHIP_OK;
+                if (alive) {
+                    (void)hipMemcpyAsync(me.packed.p, me.rdist.p, (size_t)nq * k1 * sizeof(float), hipMemcpyDeviceToDevice, me.stream);
+                    (void)hipEventRecord(ev[4], me.stream);
+                }
+            }
+            allgather_bytes(me.packed.p, me.rdist_all.p, (size_t)nq * k1 * sizeof(float));
+            auto select = [&]() {
+                int src = knhip_refine_combine_device(W, nq * (int64_t)k1, static_cast<const float*>(me.rdist_all.p),
+                                                      static_cast<float*>(me.rdist.p), me.stream);
+                if (src == KNHIP_OK) {
+                    src = knhip_refine_select_device(metric, nq, res_i, static_cast<const float*>(me.rdist.p), k1, k,
+                                                     static_cast<float*>(me.ref_d.p), static_cast<int64_t*>(me.ref_i.p), me.stream);
+                }
+                if (src != KNHIP_OK) {
+                    err = std::string("knhip_refine_select_device: ") + knhip_last_error();
+                    rc = src;
+                    return;
+                }
+                SG_HIP(hipEventRecord(ev[5], me.stream));
+            };
+            if (alive) {
+                select();
+                alive = rc == KNHIP_OK;
+            }
+            res_d = static_cast<float*>(me.ref_d.p);
+            res_i = static_cast<int64_t*>(me.ref_i.p);
         }
         auto finish = [&]() {
             if (r == 0) {
@@ -483,12 +659,12 @@ static int search_impl(knhip_shard_group* g, const float* queries, int64_t nq, i
             }
             SG_HIP(hipStreamSynchronize(me.stream));
             if (stage_ms) {
-                float a = 0, b = 0, c = 0, d2 = 0, e2 = 0, f2 = 0;
+                float a = 0, b = 0, c = 0, d2 = 0;
                 (void)hipEventElapsedTime(&a, ev[0], ev[1]);
                 (void)hipEventElapsedTime(&b, ev[1], ev[2]);
                 float* o = stage_ms + (size_t)NS * r;
                 if (!refine) {
-                    // (the merge is inside [ev1, ev2] here: gather and merge are reported together as gather + 0)
+                    // (merge and tie rule are inside [ev1, ev2] here: reported together as gather + 0)
                     o[0] = a;
                     o[1] = b;
                     o[2] = 0.f;
@@ -496,8 +672,6 @@ static int search_impl(knhip_shard_group* g, const float* queries, int64_t nq, i
                 } else {
                     (void)hipEventElapsedTime(&c, ev[2], ev[4]);
                     (void)hipEventElapsedTime(&d2, ev[4], ev[5]);
-                    (void)e2;
-                    (void)f2;
                     o[0] = a;
                     o[1] = b;
                     o[2] = 0.f;

@@ -323,6 +323,37 @@ class GpuIndex:
                                                      _t_ptr(bitset_t), nbits, _t_ptr(I), _t_ptr(D), C.c_void_p(s)))
         return D, I
 
+    def search_canonical_device(self, xq_t, k, nprobe, keys_t=None, cdis_t=None, bitset_t=None, nbits=0, stream=None):
+        """canonical top-k, no tie rule (knhip_search_canonical_device): what a shard contributes to a list-sharded
+        search; keys_t / cdis_t: the coarse assignment [nq][nprobe] (None: assigned inside / BRUTE_FORCE)"""
+        import torch
+        nq = xq_t.shape[0]
+        D = torch.empty((nq, k), dtype=torch.float32, device=xq_t.device)
+        I = torch.empty((nq, k), dtype=torch.int64, device=xq_t.device)
+        s = torch.cuda.current_stream(xq_t.device).cuda_stream if stream is None else stream
+        nbits = _bitset_nbits(bitset_t, nbits)
+        check(self.L.knhip_search_canonical_device(self.h, _t_ptr(xq_t), nq, k, nprobe, _t_ptr(keys_t), _t_ptr(cdis_t),
+                                                   _t_ptr(bitset_t), nbits, _t_ptr(I), _t_ptr(D), C.c_void_p(s)))
+        return D, I
+
+    def tie_arrivals_device(self, xq_t, flagged_t, can_d_t, k, nprobe, keys_t=None, cdis_t=None, bitset_t=None, nbits=0,
+                            key_base=0, stream=None):
+        """this index's first k arrivals at or below the k-th distance of the flagged queries (knhip_tie_arrivals_device):
+        -> (arr_d [nflag, k], arr_i, arr_key, arr_n [nflag])"""
+        import torch
+        nflag = int(flagged_t.numel())
+        dev = xq_t.device
+        arr_d = torch.zeros((nflag, k), dtype=torch.float32, device=dev)
+        arr_i = torch.full((nflag, k), -1, dtype=torch.int64, device=dev)
+        arr_key = torch.zeros((nflag, k), dtype=torch.int64, device=dev)
+        arr_n = torch.zeros((nflag,), dtype=torch.int64, device=dev)
+        s = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+        nbits = _bitset_nbits(bitset_t, nbits)
+        check(self.L.knhip_tie_arrivals_device(self.h, _t_ptr(xq_t), _t_ptr(flagged_t), nflag, _t_ptr(can_d_t), k, nprobe,
+                                               _t_ptr(keys_t), _t_ptr(cdis_t), _t_ptr(bitset_t), nbits, C.c_int64(key_base),
+                                               _t_ptr(arr_d), _t_ptr(arr_i), _t_ptr(arr_key), _t_ptr(arr_n), C.c_void_p(s)))
+        return arr_d, arr_i, arr_key, arr_n
+
     def coarse_search_device(self, xq_t, nprobe, stream=None):
         import torch
         nq = xq_t.shape[0]
@@ -384,6 +415,97 @@ def merge_topk_device(metric, D_parts_t, I_parts_t, stream=None):
     s = torch.cuda.current_stream(D_parts_t.device).cuda_stream if stream is None else stream
     check(L.knhip_merge_topk_device(metric, nq, k, nshard, _t_ptr(D_parts_t), _t_ptr(I_parts_t), _t_ptr(D),
                                     _t_ptr(I), C.c_void_p(s)))
+    return D, I
+
+
+def tie_flag(can_d_t, can_i_t, k):
+    """rows of k + 1 canonical results -> (D [nq, k], I [nq, k], flagged: ascending int32 query numbers whose (k + 1)-th
+    entry ties with the k-th).  Device tensors: knhip_tie_flag_device (one 4-byte read-back); CPU tensors: the host form."""
+    import torch
+    L = _lib.load()
+    nq = can_d_t.shape[0]
+    assert can_d_t.shape[1] == k + 1 and can_d_t.is_contiguous() and can_i_t.is_contiguous()
+    D = torch.empty((nq, k), dtype=torch.float32, device=can_d_t.device)
+    I = torch.empty((nq, k), dtype=torch.int64, device=can_d_t.device)
+    if can_d_t.is_cuda:
+        fl = torch.empty((2 * nq + 1,), dtype=torch.int32, device=can_d_t.device)
+        n = C.c_int32(0)
+        s = torch.cuda.current_stream(can_d_t.device).cuda_stream
+        check(L.knhip_tie_flag_device(_t_ptr(can_d_t), _t_ptr(can_i_t), nq, k, _t_ptr(D), _t_ptr(I), _t_ptr(fl), C.byref(n),
+                                      C.c_void_p(s)))
+        return D, I, fl[:n.value].contiguous()
+    fl = torch.zeros((nq,), dtype=torch.uint8)
+    check(L.knhip_tie_flag_host(_t_ptr(can_d_t), _t_ptr(can_i_t), nq, k, _t_ptr(D), _t_ptr(I), _t_ptr(fl)))
+    return D, I, torch.nonzero(fl)[:, 0].to(torch.int32).contiguous()
+
+
+def tie_resolve(metric, flagged_t, k, can_d_t, can_i_t, arr_d_t, arr_i_t, arr_key_t, arr_n_t, D_t, I_t):
+    """the reference's admission rule over ALL shards' arrivals ([nshards, nflag, k] / [nshards, nflag]) written over the
+    flagged rows of (D_t, I_t) in place"""
+    import torch
+    L = _lib.load()
+    nsh, nflag = arr_n_t.shape
+    if nflag == 0:
+        return D_t, I_t
+    if can_d_t.is_cuda:
+        s = torch.cuda.current_stream(can_d_t.device).cuda_stream
+        check(L.knhip_tie_resolve_device(metric, nsh, _t_ptr(flagged_t), nflag, k, _t_ptr(can_d_t), _t_ptr(can_i_t),
+                                         _t_ptr(arr_d_t.contiguous()), _t_ptr(arr_i_t.contiguous()),
+                                         _t_ptr(arr_key_t.contiguous()), _t_ptr(arr_n_t.contiguous()), _t_ptr(D_t), _t_ptr(I_t),
+                                         C.c_void_p(s)))
+        return D_t, I_t
+    # host form: arrival arrays indexed by the query
+    nq = can_d_t.shape[0]
+    fl = torch.zeros((nq,), dtype=torch.uint8)
+    idx = flagged_t.long()
+    fl[idx] = 1
+    fd = torch.zeros((nsh, nq, k), dtype=torch.float32)
+    fi = torch.full((nsh, nq, k), -1, dtype=torch.int64)
+    fk = torch.zeros((nsh, nq, k), dtype=torch.int64)
+    fn = torch.zeros((nsh, nq), dtype=torch.int64)
+    fd[:, idx], fi[:, idx], fk[:, idx], fn[:, idx] = arr_d_t, arr_i_t, arr_key_t, arr_n_t
+    check(L.knhip_tie_resolve_host(metric, nsh, nq, k, _t_ptr(fl), _t_ptr(can_d_t), _t_ptr(can_i_t), _t_ptr(fd), _t_ptr(fi),
+                                   _t_ptr(fk), _t_ptr(fn), _t_ptr(D_t), _t_ptr(I_t)))
+    return D_t, I_t
+
+
+def refine_distances_device(metric, base_t, xq_t, cand_ids_t, id_base=0, stream=None):
+    """distances of the candidates whose rows live in base_t (row r = id id_base + r); the all-ones pattern elsewhere
+    (knhip_refine_distances_device): a shard's share of a sharded refine"""
+    import torch
+    L = _lib.load()
+    nq, kbase = cand_ids_t.shape
+    D = torch.empty((nq, kbase), dtype=torch.float32, device=xq_t.device)
+    s = torch.cuda.current_stream(xq_t.device).cuda_stream if stream is None else stream
+    check(L.knhip_refine_distances_device(metric, xq_t.shape[1], _t_ptr(base_t), base_t.shape[0], id_base, _t_ptr(xq_t), nq,
+                                          _t_ptr(cand_ids_t), kbase, _t_ptr(D), C.c_void_p(s)))
+    return D
+
+
+def refine_select_device(metric, cand_ids_t, dist_parts_t, k, stream=None):
+    """the shards' distance arrays [nshards, nq, k_base] combined (every candidate is held once) and the single index's
+    selection -- tie rule in candidate order included -- run on them"""
+    import torch
+    L = _lib.load()
+    nsh, nq, kbase = dist_parts_t.shape
+    dev = cand_ids_t.device
+    if not cand_ids_t.is_cuda:  # results combined on the CPU (gloo): the host form of the same selection
+        bits = dist_parts_t.contiguous().view(torch.int32)
+        held = bits != -1
+        first = held.to(torch.int8).argmax(dim=0, keepdim=True)
+        dist = torch.where(held.any(dim=0), torch.gather(bits, 0, first)[0], torch.full((nq, kbase), -1, dtype=torch.int32))
+        dist = dist.contiguous().view(torch.float32)
+        D = torch.empty((nq, k), dtype=torch.float32)
+        I = torch.empty((nq, k), dtype=torch.int64)
+        check(L.knhip_refine_select_host(metric, nq, _t_ptr(cand_ids_t), _t_ptr(dist), kbase, k, _t_ptr(D), _t_ptr(I)))
+        return D, I
+    dist = torch.empty((nq, kbase), dtype=torch.float32, device=dev)
+    D = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    I = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    s = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+    check(L.knhip_refine_combine_device(nsh, nq * kbase, _t_ptr(dist_parts_t.contiguous()), _t_ptr(dist), C.c_void_p(s)))
+    check(L.knhip_refine_select_device(metric, nq, _t_ptr(cand_ids_t), _t_ptr(dist), kbase, k, _t_ptr(D), _t_ptr(I),
+                                       C.c_void_p(s)))
     return D, I
 
 

@@ -153,6 +153,48 @@ class Comm:
         return torch.from_numpy(Dm), torch.from_numpy(Im)
 
 
+def search_sharded(comm, metric, k, partial_fn, arrivals_fn):
+    """List-sharded Search() with the reference's admission rule at the k-th boundary applied ONCE, after the merge, over all
+    shards' candidates (include/knhip.h, "multi-GPU: the reference's answer from a list-sharded index").
+      partial_fn(kk)              -> this shard's CANONICAL top-kk (D [nq, kk], I), no tie rule
+      arrivals_fn(flagged, can_d) -> this shard's first k arrivals at or below the flagged queries' k-th distance:
+                                     (arr_d [nflag, k], arr_i, arr_key, arr_n [nflag]) -- GpuIndex.tie_arrivals_device
+    Collectives: one packed all-gather of the (nq, k + 1) partials; a second, small one (20 bytes per arrival) only when
+    some query of the batch is flagged (the flags are computed from the merged rows: identical on every rank)."""
+    kk = k + 1
+    if kk > 1024:  # (no room for the (k + 1)-th result: canonical, as on one index)
+        Dp, Ip = partial_fn(k)
+        return comm.allgather_merge(metric, Dp, Ip)
+    Dp, Ip = partial_fn(kk)
+    Dm, Im = comm.allgather_merge(metric, Dp, Ip)
+    Dm, Im = Dm.contiguous(), Im.contiguous()
+    D, I, flagged = kidx.tie_flag(Dm, Im, k)
+    if flagged.numel() == 0:
+        return D, I
+    arr_d, arr_i, arr_key, arr_n = arrivals_fn(flagged, Dm)
+    # one collective: distances, ids, keys and counts of a rank's arrivals in one int32 buffer [nflag, 5 k + 2]
+    nflag = flagged.numel()
+    buf = torch.empty((nflag, 5 * k + 2), dtype=torch.int32, device=arr_d.device)
+    buf[:, :k] = arr_d.contiguous().view(torch.int32)
+    buf[:, k:3 * k] = arr_i.contiguous().view(torch.int32).reshape(nflag, 2 * k)
+    buf[:, 3 * k:5 * k] = arr_key.contiguous().view(torch.int32).reshape(nflag, 2 * k)
+    buf[:, 5 * k:] = arr_n.contiguous().view(torch.int32).reshape(nflag, 2)
+    g = comm.allgather(buf)  # [world, nflag, 5 k + 2]
+    gd = g[..., :k].contiguous().view(torch.float32)
+    gi = g[..., k:3 * k].contiguous().view(torch.int64).reshape(comm.world, nflag, k)
+    gk = g[..., 3 * k:5 * k].contiguous().view(torch.int64).reshape(comm.world, nflag, k)
+    gn = g[..., 5 * k:].contiguous().view(torch.int64).reshape(comm.world, nflag)
+    return kidx.tie_resolve(metric, flagged, k, Dm, Im, gd, gi, gk, gn, D, I)
+
+
+def refine_sharded(comm, metric, k, cand_ids, dist_fn):
+    """Sharded second stage of IndexRefine: every rank computes the distances of the candidates whose rows it holds
+    (dist_fn() -> [nq, k_base], the all-ones pattern elsewhere), ONE all-gather of those arrays, and the single index's
+    selection (tie rule in candidate order included) on every rank."""
+    parts = comm.allgather(dist_fn().contiguous())  # [world, nq, k_base]
+    return kidx.refine_select_device(metric, cand_ids.contiguous(), parts, k)
+
+
 def sharded_coarse(comm, coarse_fn, nq, nprobe, device=None):
     """Coarse quantizer sharded by QUERIES: rank r assigns queries [r * per, (r + 1) * per), one packed all-gather of the
     keys and the coarse distances gives every rank the full (nq, nprobe) assignment for

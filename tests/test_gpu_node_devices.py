@@ -278,6 +278,40 @@ def test_repeated_add_on_a_sharded_node(node, name, train_cfg, search_cfg):
 
 
 @pytest.mark.parametrize("name,train_cfg,search_cfg",
+                         [("GPU_HIP_IVF_FLAT", "nlist=24", "nprobe=8"), ("GPU_HIP_BRUTE_FORCE", "", ""),
+                          ("GPU_HIP_IVF_PQ", "nlist=24;m=4;nbits=8;refine=true;refine_type=fp32", "nprobe=8;refine_k=6")],
+                         ids=["ivfflat", "flat", "ivfpq_refine"])
+@pytest.mark.parametrize("metric", ["L2", "IP"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_node_ties_equal_the_single_device_node(node, name, train_cfg, search_cfg, metric, world):
+    """exact ties at the k-th distance across shards (integer coordinates: every distance an integer): the sharded node must
+    return the single-device node's ids -- the reference's first-come choice --, first stage and refine stage alike; until
+    round 5 every shard resolved its own candidates and the merge was canonical"""
+    nb, d, nq = 12000, 16, 80
+    rng = np.random.default_rng(42)
+    xb = rng.integers(0, 4, (nb, d)).astype(np.float32)
+    xq = np.random.default_rng(44).integers(0, 4, (nq, d)).astype(np.float32)
+    base = f"metric_type={metric};dim={d};{train_cfg}"
+    one, many = Node(node, name), Node(node, name)
+    try:
+        assert one.build(xb, base + ";gpu_id=0") == 0, node.knhip_node_last_error().decode()
+        assert many.build(xb, base + f";gpu_ids={shard_ids(world)}") == 0, node.knhip_node_last_error().decode()
+        tied = 0
+        for k in (10, 1, 37, 64):
+            cfg = f"k={k};{search_cfg}"
+            a, b = one.search(xq, cfg, k), many.search(xq, cfg, k)
+            assert same(a, b), (name, metric, world, k, int((a[1] != b[1]).sum()))
+            tied += int(((a[0][:, -1:] == a[0]).sum(axis=1) > 1).sum())
+        assert tied > 0, "the fixture produced no tie at any k-th boundary"
+        bs = np.packbits(np.random.default_rng(3).random(nb) < 0.4, bitorder="little")
+        cfg = f"k=10;{search_cfg}"
+        assert same(one.search(xq, cfg, 10, bs, nb), many.search(xq, cfg, 10, bs, nb)), (name, metric, "bitset")
+    finally:
+        one.close()
+        many.close()
+
+
+@pytest.mark.parametrize("name,train_cfg,search_cfg",
                          [("GPU_HIP_IVF_FLAT", "nlist=2", "nprobe=2"), ("GPU_HIP_IVF_SQ8", "nlist=2", "nprobe=2")],
                          ids=["ivfflat", "ivfsq8"])
 def test_sharded_node_with_fewer_lists_than_devices(node, name, train_cfg, search_cfg):

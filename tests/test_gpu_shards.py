@@ -86,7 +86,7 @@ def test_sharded_search_equals_the_single_index(shards, port, kind, metric, worl
             Do, Io = port.search(ix, xq, k, nprobe)
             D, I, ms = _group_search(shards, parts, [0] * world, 1, xq, k, nprobe)
             assert np.array_equal(I, Iw) and np.array_equal(D.view(np.uint32), Dw.view(np.uint32)), (kind, k, nprobe)
-            assert_parity(Do, Io, D, I, metric, f"sharded world={world} kind={kind} k={k}", licensed_ties=True)
+            assert_parity(Do, Io, D, I, metric, f"sharded world={world} kind={kind} k={k}")
             assert (ms[:, 3] > 0).all()
         bs = np.packbits(np.random.default_rng(1).random(nb) < 0.4, bitorder="little")
         Dw, Iw = whole.search(xq, 10, 8, bs, nb)
@@ -137,6 +137,125 @@ def test_sharded_search_with_refine(shards, port, world, metric):
         torch.cuda.synchronize()
         assert np.array_equal(I, Ir.cpu().numpy()) and np.array_equal(D.view(np.uint32), Dr.cpu().numpy().view(np.uint32))
         assert (ms[:, 6] > 0).all() and (ms[:, 3] > 0).all()
+    finally:
+        L.knhip_shard_group_destroy(g)
+        whole.close()
+        for p in parts:
+            p.close()
+
+
+def _int_data(n, d, seed, hi=4):
+    """small integer coordinates: every distance is an exactly representable integer, so exact ties are everywhere -- also
+    between rows of different lists, i.e. of different shards"""
+    return np.random.default_rng(seed).integers(0, hi, (n, d)).astype(np.float32)
+
+
+def _untie_coarse(port, ix):
+    """integer centroids tie with each other at a query's nprobe-th place, and the coarse quantizer's own boundary is not
+    part of the rule under test (include/knhip.h): tiny distinct offsets make every coarse distance unique.  The lists
+    keep their contents -- an index is valid whatever its centroids are."""
+    ix.centroids = (ix.centroids + np.random.default_rng(9).random(ix.centroids.shape).astype(np.float32) * 1e-3).astype(np.float32)
+    ix.precomputed_table = None
+    return finish_ivfpq(port, ix)
+
+
+@pytest.mark.parametrize("kind,metric", [(ob.IVF_FLAT, ob.L2), (ob.IVF_FLAT, ob.IP), (ob.IVF_PQ, ob.L2), (ob.FLAT, ob.L2),
+                                         (ob.FLAT, ob.IP)],
+                         ids=["ivfflat_l2", "ivfflat_ip", "ivfpq_l2", "flat_l2", "flat_ip"])
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_sharded_ties_follow_the_reference(shards, port, kind, metric, world):
+    """candidates tied at the k-th distance ACROSS shards: the group applies the reference's first-come admission rule once,
+    after the merge, over all shards' candidates (knhip_tie_flag / _arrivals / _resolve) -- the answer of the single index
+    and of the reference, with no licence (the reference's own sharding contract is ids-equal,
+    tests/ut/test_bruteforce.cc:128-181)"""
+    from knowhere_amd import GpuIndex
+    from knowhere_amd.index import BRUTE_FORCE, L2 as KL2, IP as KIP
+    nb, d, nlist, nq = 12000, 16, 24, 60
+    xb, xq = _int_data(nb, d, 42), _int_data(nq, d, 44)
+    if kind == ob.IVF_PQ:
+        # (PQ distances carry the list's centroid: ties come from equal codes in one list -- copies of a row -- while the
+        # better candidates of the query sit on other shards)
+        xb[6000:6300] = xb[:300]
+        xb[9000:9300] = xb[:300]
+        xq = np.ascontiguousarray(xb[:nq])
+    if kind == ob.FLAT:
+        ix = ob.IndexData(ob.FLAT, metric, d)
+        ix.base = xb
+        whole = GpuIndex.from_data(ix, device=0)
+        parts = []
+        for r in range(world):
+            lo, hi = nb * r // world, nb * (r + 1) // world
+            g = GpuIndex(BRUTE_FORCE, KL2 if metric == ob.L2 else KIP, d, device=0)
+            g.add_vectors(np.ascontiguousarray(xb[lo:hi]), id_offset=lo)
+            parts.append(g)
+        cases = ((10, 1), (37, 1), (1, 1), (99, 1))
+    else:
+        ix = _untie_coarse(port, ob.make_index(port, kind, metric, xb, nlist=nlist, M=4))
+        whole = GpuIndex.from_data(ix, device=0)
+        parts = [GpuIndex.from_data(p, device=0) for p in _split(ix, world)]
+        cases = ((10, 8), (100, nlist), (1, 3), (64, 5), (2, 8))
+    try:
+        ntie = 0
+        for k, nprobe in cases:
+            Dw, Iw = whole.search(xq, k, nprobe)
+            Do, Io = port.search(ix, xq, k, nprobe)
+            D, I, _ = _group_search(shards, parts, [0] * world, 1, xq, k, nprobe)
+            assert_parity(Do, Io, D, I, metric, f"sharded ties world={world} kind={kind} k={k}")
+            assert np.array_equal(I, Iw) and np.array_equal(D.view(np.uint32), Dw.view(np.uint32)), (kind, k, nprobe)
+            # (how many rows really sit on a tie: the canonical choice -- smallest ids -- would differ on some of them)
+            ntie += int((Do[:, -1:] == Do).sum(axis=1).max() > 1)
+        assert ntie > 0, "the fixture produced no tie at any k-th boundary"
+        bs = np.packbits(np.random.default_rng(1).random(nb) < 0.4, bitorder="little")
+        Do, Io = port.search(ix, xq, 10, cases[0][1], bs, nb)
+        D, I, _ = _group_search(shards, parts, [0] * world, 1, xq, 10, cases[0][1], bs, nb)
+        assert_parity(Do, Io, D, I, metric, f"sharded ties + bitset world={world} kind={kind}")
+    finally:
+        whole.close()
+        for p in parts:
+            p.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("metric", [ob.L2, ob.IP], ids=["l2", "ip"])
+def test_sharded_refine_ties_follow_the_reference(shards, port, world, metric):
+    """refine over shards with exact ties among the re-scored candidates (integer rows): IndexRefine pushes them through its
+    heap in CANDIDATE order whoever holds their rows; the group exchanges the distances and runs ONE selection --
+    bit-identical to knhip_search_refine on one GPU and to the oracle's IndexRefine"""
+    import torch
+    from knowhere_amd import GpuIndex
+    nb, d, nlist, nq, k, kb = 12000, 16, 24, 60, 5, 60
+    xb, xq = _int_data(nb, d, 42), _int_data(nq, d, 44)
+    ix = _untie_coarse(port, ob.make_index(port, ob.IVF_PQ, metric, xb, nlist=nlist, M=4))
+    whole = GpuIndex.from_data(ix, device=0)
+    parts = [GpuIndex.from_data(p, device=0) for p in _split(ix, world)]
+    xb_t = torch.from_numpy(xb).cuda()
+    cuts = [nb * r // world for r in range(world + 1)]
+    L = shards
+    g = C.c_void_p()
+    dev = (C.c_int32 * world)(*([0] * world))
+    assert L.knhip_shard_group_create(C.c_int32(world), dev, C.c_int32(1), C.byref(g)) == 0
+    try:
+        for r, gi in enumerate(parts):
+            assert L.knhip_shard_group_set_index(g, C.c_int32(r), gi.h) == 0
+            lo, hi = cuts[r], cuts[r + 1]
+            assert L.knhip_shard_group_set_raw(g, C.c_int32(r), C.c_void_p(xb_t[lo:hi].data_ptr()), C.c_int64(hi - lo),
+                                               C.c_int64(lo)) == 0
+        I = np.empty((nq, k), np.int64)
+        D = np.empty((nq, k), np.float32)
+        rc = L.knhip_shard_group_search_refine(g, xq.ctypes.data_as(C.c_void_p), C.c_int64(nq), C.c_int32(k), C.c_int32(kb),
+                                               C.c_int32(8), None, C.c_int64(0), I.ctypes.data_as(C.c_void_p),
+                                               D.ctypes.data_as(C.c_void_p), None)
+        assert rc == 0, L.knhip_shard_group_last_error().decode()
+        from knowhere_amd.index import BRUTE_FORCE
+        raw = GpuIndex(BRUTE_FORCE, metric, d, device=0)  # the store of the raw rows knhip_search_refine reads
+        raw.add_vectors(xb)
+        Dg, Ig = whole.search_refine(raw, xq, k, kb, 8)
+        raw.close()
+        assert np.array_equal(I, Ig) and np.array_equal(D.view(np.uint32), Dg.view(np.uint32))
+        Dc, Ic = port.search(ix, xq, kb, 8)
+        Dr, Ir = port.refine(metric, xb, xq, Ic, k)
+        assert_parity(Dr, Ir, D, I, metric, f"sharded refine ties world={world}")
+        assert int(((Dr[:, -1:] == Dr).sum(axis=1) > 1).sum()) > 0, "no tie at any k-th boundary of the refine stage"
     finally:
         L.knhip_shard_group_destroy(g)
         whole.close()
