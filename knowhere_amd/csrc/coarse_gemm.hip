@@ -181,6 +181,266 @@ __global__ __launch_bounds__(256) void coarse_gemm_kernel(const float* __restric
     }
 }
 
+// ---- round 5: the same prefilter on the bf16 matrix pipe, selection fused, no distance matrix ------------------------
+// The certificate + exact re-rank make the GEMM a prefilter: it needs a bounded error, not fp32 products.  Every operand is
+// split into two bf16 terms (x = hi + lo + r, |r| <= 2^-18 |x|: v_cvt_pk_bf16_f32 rounds to nearest) and the product taken
+// as hi hi + hi lo + lo hi on v_mfma_f32_32x32x16_bf16 (fp32 accumulation): three instructions of a pipe sixteen times as
+// fast as the fp32 one, |dot - exact| <= (4 * 2^-18 + 3 d 2^-24) ||q|| ||c||.  And the nq x nlist matrix (655 MB at C3, written
+// once and read twice by the select) is never written: the GEMM runs TWICE with different epilogues --
+//   pass 1: the minimum over every group of 32 centroids (one MFMA tile's rows: in the C layout a lane = a query, its 16
+//           registers + the partner lane's = the group) -> gmin[group][query]; the ncand-th smallest group minimum B_q
+//           bounds the row's ncand-th value (ncand groups hold a value <= B_q);
+//   pass 2: every centroid with approx <= B_q is appended to the query's candidate list (~1.2 ncand of them).
+// Everything unselected has approx > B_q: B_q is the certificate's T.  M = centroids, N = queries (A = centroids).
+// order-preserving float <-> uint32 keys ("better" = smaller key): used by the bound selection above the re-rank kernel's own
+template <bool IS_L2>
+__device__ __forceinline__ uint32_t cr_key_fwd(float f) {
+    const uint32_t b = __float_as_uint(f);
+    const uint32_t asc = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    return IS_L2 ? asc : ~asc;
+}
+template <bool IS_L2>
+__device__ __forceinline__ float cr_unkey_fwd(uint32_t key) {
+    const uint32_t asc = IS_L2 ? key : ~key;
+    const uint32_t b = (asc & 0x80000000u) ? (asc & 0x7fffffffu) : ~asc;
+    return __uint_as_float(b);
+}
+
+typedef __bf16 cg_bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 cg_bf4 __attribute__((ext_vector_type(4)));
+constexpr int CB_BM = 128, CB_BN = 128, CB_BK = 32;
+constexpr int CB_ROW = 144; // bytes per staged row: 32 hi + 32 lo bf16 + 16 of padding (16 rows -> 16 different bank quads)
+
+// fp32 rows [n][d] -> the split operand rows the GEMM stages without touching them: per row and k slab of 32 dimensions
+// 32 hi then 32 lo bf16 (128 bytes; dimensions past d are zero).  The centroids' copy is built once with the index
+// (8 MB at C3, 201 MB at C5), the queries' once per batch.
+__global__ void cb_split_rows_kernel(const float* __restrict__ x, int64_t n, int d, int nslab, unsigned char* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; // one thread per (row, slab, group of 4 dimensions)
+    const int64_t total = n * nslab * 8;
+    if (t >= total) {
+        return;
+    }
+    const int g4 = (int)(t & 7);
+    const int64_t rs = t >> 3;
+    const int slab = (int)(rs % nslab);
+    const int64_t row = rs / nslab;
+    const int k = slab * CB_BK + g4 * 4;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        v[e] = k + e < d ? x[row * d + k + e] : 0.f;
+    }
+    cg_bf4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const __bf16 h = (__bf16)v[e];
+        hi[e] = h;
+        lo[e] = (__bf16)(v[e] - (float)h); // (inf / NaN inputs give NaN here: nothing is selected, the query falls back)
+    }
+    unsigned char* o = out + (row * nslab + slab) * 128 + g4 * 8;
+    *reinterpret_cast<cg_bf4*>(o) = hi;
+    *reinterpret_cast<cg_bf4*>(o + 64) = lo;
+}
+
+// MODE 1: gmin[query][group] group minima (maxima for IP).  MODE 2: candidates appended where approx <= bound.
+template <bool IS_L2, int MODE>
+__global__ __launch_bounds__(256) void coarse_bf16_kernel(const unsigned char* __restrict__ Qs, const float* __restrict__ qn,
+                                                          const unsigned char* __restrict__ Cs, const float* __restrict__ cn,
+                                                          int64_t nq, int64_t nlist, int nslab, int64_t tiles_q,
+                                                          int64_t ntiles, float* __restrict__ gmin, int G,
+                                                          const float* __restrict__ bound, int32_t* __restrict__ cand_cnt,
+                                                          int64_t* __restrict__ cand, int cap) {
+    __shared__ __align__(16) unsigned char sA[CB_BM * CB_ROW];
+    __shared__ __align__(16) unsigned char sB[CB_BN * CB_ROW];
+    __shared__ float s_cn[CB_BM];
+    __shared__ float s_gm[4][CB_BN];
+    // XCD-aware tile order: consecutive tile ids share the centroid panel
+    const int64_t per = (ntiles + 7) / 8;
+    const int64_t tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    if (tile >= ntiles) {
+        return;
+    }
+    const int64_t tc = tile / tiles_q, tq = tile % tiles_q;
+    const int64_t c0 = tc * CB_BM, q0 = tq * CB_BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    if (IS_L2 && tid < CB_BM) {
+        s_cn[tid] = c0 + tid < nlist ? cn[c0 + tid] : 0.f;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                acc[i][j][r] = 0.f;
+            }
+        }
+    }
+    // staging: 1024 pieces of 16 bytes per operand and slab, four per thread; rows past the end are zero
+    uint4 va[4], vb[4];
+    auto fetch = [&](int slab) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int p = tid + 256 * j, row = p >> 3, piece = p & 7;
+            va[j] = make_uint4(0u, 0u, 0u, 0u);
+            vb[j] = make_uint4(0u, 0u, 0u, 0u);
+            if (c0 + row < nlist) {
+                va[j] = *reinterpret_cast<const uint4*>(Cs + ((c0 + row) * nslab + slab) * 128 + piece * 16);
+            }
+            if (q0 + row < nq) {
+                vb[j] = *reinterpret_cast<const uint4*>(Qs + ((q0 + row) * nslab + slab) * 128 + piece * 16);
+            }
+        }
+    };
+    fetch(0);
+    for (int slab = 0; slab < nslab; slab++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int p = tid + 256 * j, row = p >> 3, piece = p & 7;
+            *reinterpret_cast<uint4*>(sA + row * CB_ROW + piece * 16) = va[j];
+            *reinterpret_cast<uint4*>(sB + row * CB_ROW + piece * 16) = vb[j];
+        }
+        __syncthreads();
+        if (slab + 1 < nslab) {
+            fetch(slab + 1);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) { // two k steps of 16: lane (row = lane & 31, k half = lane >> 5) holds 8 consecutive k
+            const int ko = (ks * 16 + (lane >> 5) * 8) * 2;
+            cg_bf8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const unsigned char* pa = sA + (wm + i * 32 + (lane & 31)) * CB_ROW + ko;
+                ah[i] = *reinterpret_cast<const cg_bf8*>(pa);
+                al[i] = *reinterpret_cast<const cg_bf8*>(pa + 64);
+                const unsigned char* pb = sB + (wn + i * 32 + (lane & 31)) * CB_ROW + ko;
+                bh[i] = *reinterpret_cast<const cg_bf8*>(pb);
+                bl[i] = *reinterpret_cast<const cg_bf8*>(pb + 64);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // epilogue: C/D layout col (query) = lane & 31, row (centroid) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int64_t query = q0 + wn + j * 32 + (lane & 31);
+        const bool qok = query < nq;
+        const float qnv = (IS_L2 && qok) ? qn[query] : 0.f;
+        float bnd = 0.f;
+        if (MODE == 2) {
+            bnd = qok ? bound[query] : (IS_L2 ? -INFINITY : INFINITY);
+        }
+        uint32_t hit[2] = {0u, 0u}; // MODE 2: which of the lane's 2 x 16 values pass (bit r of block i)
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            float best = IS_L2 ? INFINITY : -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int rowl = wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int64_t cen = c0 + rowl;
+                float v = acc[i][j][r];
+                if (IS_L2) {
+                    v = qnv + s_cn[rowl] - 2.0f * v;
+                }
+                if (cen >= nlist) {
+                    v = IS_L2 ? INFINITY : -INFINITY;
+                }
+                if (MODE == 1) {
+                    best = IS_L2 ? fminf(best, v) : fmaxf(best, v);
+                } else if (qok && (IS_L2 ? v <= bnd : v >= bnd)) {
+                    hit[i] |= 1u << r;
+                }
+            }
+            if (MODE == 1) {
+                const float other = __shfl_xor(best, 32, KN_WAVE);
+                best = IS_L2 ? fminf(best, other) : fmaxf(best, other);
+                if (lane < 32) {
+                    s_gm[(wm >> 5) + i][wn + j * 32 + lane] = best;
+                }
+            }
+        }
+        if (MODE == 2) {
+            // ONE returning atomic per lane for all its hits of this query block (a returning atomic per hit made the wave
+            // wait a memory round trip ~40 times per tile: 465 us of the stage at C3), then the ids go to their slots
+            const int nh = __popc(hit[0]) + __popc(hit[1]);
+            if (nh > 0) {
+                int n = atomicAdd(cand_cnt + query, nh);
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    uint32_t m = hit[i];
+                    while (m != 0u) {
+                        const int r = __ffs((int)m) - 1;
+                        m &= m - 1u;
+                        if (n < cap) {
+                            cand[query * cap + n] = c0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        }
+                        n++;
+                    }
+                }
+            }
+        }
+    }
+    if (MODE == 1) {
+        // the tile's 128 queries x 4 groups: one 16-byte store per query (gmin [nq][G]: a row per query for the bound kernel)
+        __syncthreads();
+        if (tid < CB_BN && q0 + tid < nq) {
+            const float4 o = make_float4(s_gm[0][tid], s_gm[1][tid], s_gm[2][tid], s_gm[3][tid]);
+            *reinterpret_cast<float4*>(gmin + (q0 + tid) * G + c0 / 32) = o;
+        }
+    }
+}
+
+// B_q = the ncand-th best of the query's G group minima (gmin [nq][G]): one wave per query, the row in registers,
+// bisection over the order-preserving integer keys with ballot counts.  G <= 4096.
+template <bool IS_L2>
+__global__ __launch_bounds__(256) void coarse_bound_kernel(const float* __restrict__ gmin, int G, int64_t nq, int ncand,
+                                                           float* __restrict__ bound) {
+    constexpr int RMAX = 4096 / KN_WAVE;
+    const int lane = lane_id();
+    const int64_t q = (int64_t)blockIdx.x * (blockDim.x / KN_WAVE) + threadIdx.x / KN_WAVE;
+    if (q >= nq) {
+        return;
+    }
+    uint32_t key[RMAX];
+    const int nreg = (G + KN_WAVE - 1) / KN_WAVE;
+#pragma unroll
+    for (int r = 0; r < RMAX; r++) {
+        const int g = r * KN_WAVE + lane;
+        key[r] = (r < nreg && g < G) ? cr_key_fwd<IS_L2>(gmin[q * G + g]) : 0xffffffffu;
+    }
+    // smallest key x with count(key <= x) >= ncand; keys ascend with "better"
+    uint32_t lo = 0u, hi = 0xffffffffu;
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        int cnt = 0;
+#pragma unroll
+        for (int r = 0; r < RMAX; r++) {
+            if (r < nreg) {
+                cnt += __popcll(__ballot(key[r] <= mid));
+            }
+        }
+        if (cnt >= ncand) {
+            hi = mid;
+        } else {
+            lo = mid + 1;
+        }
+    }
+    if (lane == 0) {
+        bound[q] = cr_unkey_fwd<IS_L2>(lo);
+    }
+}
+
 // ---- exact re-rank of the candidates + certificate ----------------------------------------------
 // one 256-thread workgroup per query; ncand <= 4096
 template <bool IS_L2>
@@ -201,7 +461,10 @@ __global__ __launch_bounds__(256) void coarse_rerank_kernel(
         const float* __restrict__ queries, const float* __restrict__ centroids, int d, int64_t nlist,
         int ncand, int kp, const int64_t* __restrict__ cand_keys, const float* __restrict__ cand_approx,
         int nprobe, const float* __restrict__ qnorm, float cnorm_max, int64_t* __restrict__ out_keys,
-        float* __restrict__ out_d, int32_t* __restrict__ fail_flags, unsigned long long* __restrict__ nfail) {
+        float* __restrict__ out_d, int32_t* __restrict__ fail_flags, unsigned long long* __restrict__ nfail,
+        const int32_t* __restrict__ cand_cnt, const float* __restrict__ bound, float eps_rel) {
+    // cand_cnt / bound non-null (the bf16 prefilter): the row holds cand_cnt[q] unordered candidates (capacity ncand: more
+    // is an overflow -> exact fallback) = EVERY centroid with approx <= bound[q], so bound[q] is the certificate's T
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(smem); // [kp]
     float* sq = reinterpret_cast<float*>(smem + (size_t)kp * 8);           // [d]
@@ -214,14 +477,40 @@ __global__ __launch_bounds__(256) void coarse_rerank_kernel(
         cand[i] = ~0ull;
     }
     __syncthreads();
-    for (int c = tid; c < ncand; c += 256) {
+    const int nc = cand_cnt != nullptr ? min(cand_cnt[q], ncand) : ncand;
+    for (int c = tid; c < nc; c += 256) {
         const int64_t key = cand_keys[q * ncand + c];
         if (key < 0) {
             continue;
         }
         const float* y = centroids + key * d;
         float acc = 0.f;
-        for (int i = 0; i < d; i++) {
+        int i = 0;
+        if ((d & 3) == 0 && (reinterpret_cast<uintptr_t>(centroids) & 15) == 0) {
+            // 16-byte loads, eight in flight per lane (every lane reads its own row: 4-byte loads were one cache-line request
+            // per element -- 2.6 ms of the stage at C5); the accumulation order stays i = 0, 1, 2, ... (reference order)
+            const float4* y4 = reinterpret_cast<const float4*>(y);
+            const float4* q4 = reinterpret_cast<const float4*>(sq);
+            const int n4 = d >> 2;
+            int j = 0;
+            for (; j + 8 <= n4; j += 8) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    v[u] = y4[j + u];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const float4 x = q4[j + u];
+                    acc = IS_L2 ? l2_step(acc, x.x, v[u].x) : ip_step(acc, x.x, v[u].x);
+                    acc = IS_L2 ? l2_step(acc, x.y, v[u].y) : ip_step(acc, x.y, v[u].y);
+                    acc = IS_L2 ? l2_step(acc, x.z, v[u].z) : ip_step(acc, x.z, v[u].z);
+                    acc = IS_L2 ? l2_step(acc, x.w, v[u].w) : ip_step(acc, x.w, v[u].w);
+                }
+            }
+            i = j * 4;
+        }
+        for (; i < d; i++) {
             acc = IS_L2 ? l2_step(acc, sq[i], y[i]) : ip_step(acc, sq[i], y[i]);
         }
         const uint32_t tie = IS_L2 ? (uint32_t)key : ~(uint32_t)key;
@@ -257,14 +546,15 @@ __global__ __launch_bounds__(256) void coarse_rerank_kernel(
     if (tid == 0) {
         int fail = 0;
         if ((int64_t)ncand < nlist) {
-            // T = worst selected approx (row_select output is sorted best-first)
-            const float T = cand_approx[q * ncand + ncand - 1];
+            // T = worst selected approx (row_select output is sorted best-first) / the bound everything selected is under
+            const float T = bound != nullptr ? bound[q] : cand_approx[q * ncand + ncand - 1];
             const unsigned long long c = cand[nprobe - 1];
             const float en = cr_unkey<IS_L2>((uint32_t)(c >> 32));
-            // |approx - exact| <= eps, gamma_d = d * 2^-24 with a 8x safety factor
+            // |approx - exact| <= eps = eps_rel * magnitude (fp32 GEMM: gamma_d = d * 2^-24 with a 8x safety factor; the
+            // bf16 split adds 2^-15)
             const float scale = IS_L2 ? (qnorm[q] + cnorm_max) : sqrtf(qnorm[q] * cnorm_max);
-            const float eps = 8.0f * (float)d * 5.9604645e-8f * scale + 1e-30f;
-            if (c == ~0ull) {
+            const float eps = eps_rel * scale + 1e-30f;
+            if (c == ~0ull || (cand_cnt != nullptr && cand_cnt[q] > ncand) || !(eps < INFINITY)) {
                 fail = 1;
             } else if (IS_L2) {
                 fail = !(T - eps > en);
@@ -312,10 +602,11 @@ hipError_t launch_coarse_rerank(const float* queries, const float* centroids, in
                                 int64_t nlist, int ncand, const int64_t* cand_keys,
                                 const float* cand_approx, int nprobe, bool is_l2, const float* qnorm,
                                 float cnorm_max, int64_t* out_keys, float* out_d, int32_t* fail_flags,
-                                unsigned long long* nfail, hipStream_t s) {
+                                unsigned long long* nfail, hipStream_t s, const int32_t* cand_cnt, const float* bound) {
     if (nq <= 0) {
         return hipSuccess;
     }
+    const float eps_rel = 8.0f * (float)d * 5.9604645e-8f + (bound != nullptr ? 3.0517578125e-5f : 0.f);
     int kp = 2;
     while (kp < ncand) {
         kp <<= 1;
@@ -334,8 +625,68 @@ hipError_t launch_coarse_rerank(const float* queries, const float* centroids, in
         return e0;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nq), dim3(256), sm, s, queries, centroids, d, nlist, ncand, kp,
-                       cand_keys, cand_approx, nprobe, qnorm, cnorm_max, out_keys, out_d, fail_flags, nfail);
+                       cand_keys, cand_approx, nprobe, qnorm, cnorm_max, out_keys, out_d, fail_flags, nfail, cand_cnt, bound,
+                       eps_rel);
     return hipGetLastError();
+}
+
+// the bf16 prefilter: group minima -> bound per query -> candidates under the bound (see coarse_bf16_kernel)
+bool coarse_bf16_supports(int64_t nlist, int ncand) {
+    const int64_t G = (nlist + 31) / 32;
+    return nlist >= 2048 && G >= 2 * (int64_t)ncand && G <= 4096; // (enough groups for a tight bound)
+}
+
+int coarse_bf16_slabs(int d) {
+    return (d + CB_BK - 1) / CB_BK;
+}
+
+// split operand rows of n fp32 rows (coarse_bf16_slabs(d) * 128 bytes per row)
+hipError_t launch_coarse_bf16_split(const float* x, int64_t n, int d, void* out, hipStream_t s) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    const int nslab = coarse_bf16_slabs(d);
+    const int64_t total = n * nslab * 8;
+    hipLaunchKernelGGL(cb_split_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, n, d, nslab,
+                       static_cast<unsigned char*>(out));
+    return hipGetLastError();
+}
+
+hipError_t launch_coarse_bf16(const void* q_split, const float* qnorm, const void* c_split, const float* cnorm, int64_t nq,
+                              int64_t nlist, int d, bool is_l2, int ncand, int cap, float* gmin, float* bound,
+                              int32_t* cand_cnt, int64_t* cand, hipStream_t s) {
+    if (nq <= 0 || nlist <= 0) {
+        return hipSuccess;
+    }
+    const int64_t tc = (nlist + CB_BM - 1) / CB_BM, tq = (nq + CB_BN - 1) / CB_BN;
+    const int64_t ntiles = tc * tq;
+    const unsigned grid = (unsigned)(((ntiles + 7) / 8) * 8);
+    const int G = (int)(tc * (CB_BM / 32)); // (groups of the padded tiles: the padding's minima are the neutral value)
+    const int nslab = coarse_bf16_slabs(d);
+    const unsigned char* Qs = static_cast<const unsigned char*>(q_split);
+    const unsigned char* Cs = static_cast<const unsigned char*>(c_split);
+    hipError_t e = hipMemsetAsync(cand_cnt, 0, (size_t)nq * sizeof(int32_t), s);
+    if (e != hipSuccess) {
+        return e;
+    }
+    if (is_l2) {
+        hipLaunchKernelGGL((coarse_bf16_kernel<true, 1>), dim3(grid), dim3(256), 0, s, Qs, qnorm, Cs, cnorm, nq, nlist, nslab, tq,
+                           ntiles, gmin, G, nullptr, nullptr, nullptr, 0);
+        hipLaunchKernelGGL((coarse_bound_kernel<true>), dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, gmin, G, nq, ncand, bound);
+        hipLaunchKernelGGL((coarse_bf16_kernel<true, 2>), dim3(grid), dim3(256), 0, s, Qs, qnorm, Cs, cnorm, nq, nlist, nslab, tq,
+                           ntiles, nullptr, G, bound, cand_cnt, cand, cap);
+    } else {
+        hipLaunchKernelGGL((coarse_bf16_kernel<false, 1>), dim3(grid), dim3(256), 0, s, Qs, qnorm, Cs, cnorm, nq, nlist, nslab, tq,
+                           ntiles, gmin, G, nullptr, nullptr, nullptr, 0);
+        hipLaunchKernelGGL((coarse_bound_kernel<false>), dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, gmin, G, nq, ncand, bound);
+        hipLaunchKernelGGL((coarse_bf16_kernel<false, 2>), dim3(grid), dim3(256), 0, s, Qs, qnorm, Cs, cnorm, nq, nlist, nslab, tq,
+                           ntiles, nullptr, G, bound, cand_cnt, cand, cap);
+    }
+    return hipGetLastError();
+}
+
+int64_t coarse_bf16_groups(int64_t nlist) {
+    return ((nlist + CB_BM - 1) / CB_BM) * (CB_BM / 32);
 }
 
 } // namespace knhip

@@ -119,6 +119,7 @@ struct Workspace {
     DevBuf sel_keys;     // [qb][k]
     DevBuf sel_d;        // [qb][k]
     DevBuf rg_seg, rg_cnt, rg_off, rg_tot, rg_out_i, rg_out_d;  // range search scratch
+    DevBuf cg_gmin, cg_bound, cg_cnt, cg_qs;                    // coarse prefilter on the bf16 pipe: group minima, bounds, counts, split queries
     DevBuf rg_state, rg_keys_w, rg_cdis_w;                       // rank waves: {empty run, stopped} per query, the wave's lists
     DevBuf recs4;        // [items] flat work records of the persistent 4-query scan (pq_scan_q4)
     DevBuf q4_ctr;       // [8 * 16] per-XCD item counters
@@ -185,8 +186,9 @@ struct knhip_index {
     DevBuf centroids;     // [nlist][d] row major
     DevBuf centroids_il;  // interleaved 64-row blocks
     DevBuf cnorm;         // [nlist] ||c||^2
+    DevBuf centroids_bs;  // split bf16 operand rows of the coarse prefilter (coarse_gemm.hip: hi | lo per k slab of 32)
     float cnorm_max = 0.f;
-    bool coarse_gemm = true;  // KNHIP_COARSE=exact switches the MFMA prefilter off
+    int coarse_gemm = 2;      // KNHIP_COARSE=exact: no MFMA prefilter; =fp32: the round-1 fp32 GEMM + select; default 2: bf16
     DevBuf coarse_fail_dev;   // unsigned long long: queries that took the exact fallback
     // PQ
     bool has_pq = false;
@@ -276,7 +278,7 @@ struct knhip_index {
     mutable int64_t last_items_bound = 0;
 
     int64_t device_bytes() const {
-        const DevBuf* all[] = {&centroids, &centroids_il, &cb, &precomp_t, &sq_trained, &d_list_len,
+        const DevBuf* all[] = {&centroids, &centroids_il, &centroids_bs, &cb, &precomp_t, &sq_trained, &d_list_len,
                                &d_list_row_off, &d_list_blk_off, &ids, &rows, &rows2, &d_list_blk_off2, &cb_t, &codes_aos,
                                &rows_r, &d_list_blk_off_r, &psum, &rows_i, &idmap_ids, &idmap_col};
         int64_t t = 0;
@@ -338,12 +340,15 @@ int build_coarse_layout(knhip_index* idx) {
                                    idx->centroids_il.as<float4>(), 0, nullptr));
     HIP_TRY(idx->cnorm.alloc((size_t)idx->nlist * sizeof(float)));
     HIP_TRY(launch_row_norms(idx->centroids.as<float>(), idx->nlist, idx->d, idx->cnorm.as<float>(), nullptr));
+    // the centroids as split bf16 operand rows of the coarse prefilter (coarse_gemm.hip)
+    HIP_TRY(idx->centroids_bs.alloc((size_t)idx->nlist * coarse_bf16_slabs(idx->d) * 128));
+    HIP_TRY(launch_coarse_bf16_split(idx->centroids.as<float>(), idx->nlist, idx->d, idx->centroids_bs.p, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     std::vector<float> cn((size_t)idx->nlist);
     HIP_TRY(hipMemcpy(cn.data(), idx->cnorm.p, cn.size() * sizeof(float), hipMemcpyDeviceToHost));
     idx->cnorm_max = cn.empty() ? 0.f : *std::max_element(cn.begin(), cn.end());
     const char* e = getenv("KNHIP_COARSE");
-    idx->coarse_gemm = !(e && std::string(e) == "exact");
+    idx->coarse_gemm = (e && std::string(e) == "exact") ? 0 : ((e && std::string(e) == "fp32") ? 1 : 2);
     return KNHIP_OK;
 }
 
@@ -385,6 +390,31 @@ int coarse_stage(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
     HIP_TRY(ws->cand_approx.reserve((size_t)nq * ncand * sizeof(float)));
     HIP_TRY(ws->fail_flags.reserve(((size_t)nq + 1) * sizeof(int32_t))); // (+ the "any flag" summary)
     HIP_TRY(launch_row_norms(d_q, nq, d, ws->qnorm.as<float>(), s));
+    if (idx->coarse_gemm == 2 && coarse_bf16_supports(nlist, (int)ncand)) {
+        // bf16 matrix pipe, selection fused, no nq x nlist matrix (coarse_gemm.hip, round 5)
+        int cap = 256;
+        while (cap < 2 * ncand) {
+            cap <<= 1;
+        }
+        HIP_TRY(ws->cg_gmin.reserve((size_t)coarse_bf16_groups(nlist) * nq * sizeof(float)));
+        HIP_TRY(ws->cg_bound.reserve((size_t)nq * sizeof(float)));
+        HIP_TRY(ws->cg_cnt.reserve((size_t)nq * sizeof(int32_t)));
+        HIP_TRY(ws->cand_keys.reserve((size_t)nq * cap * sizeof(int64_t)));
+        HIP_TRY(ws->cg_qs.reserve((size_t)nq * coarse_bf16_slabs(d) * 128));
+        HIP_TRY(launch_coarse_bf16_split(d_q, nq, d, ws->cg_qs.p, s));
+        HIP_TRY(launch_coarse_bf16(ws->cg_qs.p, ws->qnorm.as<float>(), idx->centroids_bs.p, idx->cnorm.as<float>(), nq, nlist,
+                                   d, is_l2, (int)ncand, cap, ws->cg_gmin.as<float>(), ws->cg_bound.as<float>(),
+                                   ws->cg_cnt.as<int32_t>(), ws->cand_keys.as<int64_t>(), s));
+        HIP_TRY(launch_coarse_rerank(d_q, idx->centroids.as<float>(), d, nq, nlist, cap, ws->cand_keys.as<int64_t>(), nullptr,
+                                     nprobe, is_l2, ws->qnorm.as<float>(), idx->cnorm_max, keys, cdis,
+                                     ws->fail_flags.as<int32_t>(), idx->coarse_fail_dev.as<unsigned long long>(), s,
+                                     ws->cg_cnt.as<int32_t>(), ws->cg_bound.as<float>()));
+        // exact fallback, restricted on the device to the flagged queries (normally none)
+        HIP_TRY(launch_flat_full(c, is_l2, ws->coarse_full.as<float>(), nullptr, 0, ws->fail_flags.as<int32_t>(), s));
+        HIP_TRY(launch_row_select(ws->coarse_full.as<float>(), nq, nlist, nprobe, is_l2, keys, cdis,
+                                  ws->fail_flags.as<int32_t>(), s));
+        return KNHIP_OK;
+    }
     HIP_TRY(launch_coarse_gemm(d_q, ws->qnorm.as<float>(), idx->centroids.as<float>(), idx->cnorm.as<float>(), nq,
                                nlist, d, is_l2, ws->coarse_full.as<float>(), s));
     if (row_select_thr_supports(nlist, (int)ncand)) {
@@ -4223,7 +4253,7 @@ int knhip_profile_get(const knhip_index* idx, knhip_stage_times* out) {
 const char* knhip_stage_kernel_name(int stage, int kind) {
     switch (stage) {
         case KNHIP_STAGE_COARSE:
-            return "coarse_gemm_kernel+row_select_kernel+coarse_rerank_kernel";
+            return "coarse_bf16_kernel (two passes)+coarse_bound_kernel+coarse_rerank_kernel";
         case KNHIP_STAGE_GROUP:
             return "wt_*_kernel";
         case KNHIP_STAGE_LUT:

@@ -90,6 +90,50 @@ def test_coarse(torch_cuda, port, metric):
 
 
 @pytest.mark.parametrize("metric", [ob.L2, ob.IP])
+@pytest.mark.parametrize("d", [32, 100])
+def test_coarse_bf16_prefilter(torch_cuda, port, metric, d):
+    """the coarse prefilter on the bf16 matrix pipe with the selection fused (coarse_gemm.hip, round 5: nlist >= 2048 with
+    enough groups of 32 centroids): keys and coarse distances bit-equal to the reference's, whatever the prefilter's
+    arithmetic -- and (second half) centroids tied in masses make its certificate fail and the exact fallback answer"""
+    torch = torch_cuda
+    from knowhere_amd import GpuIndex
+    from knowhere_amd.index import IVF_FLAT
+    nlist, nq = 4096 + 40, 333  # (neither a multiple of the 128 x 128 tile)
+    rng = np.random.default_rng(5)
+    cen = (rng.random((nlist, d), dtype=np.float32) * 100).astype(np.float32)
+    xq = (rng.random((nq, d), dtype=np.float32) * 100).astype(np.float32)
+    ix = ob.IndexData(ob.IVF_FLAT, metric, d, nlist, 0, 8)
+    ix.centroids = cen
+    ix.list_codes = [np.empty((0, d * 4), np.uint8)] * nlist  # (only the coarse quantizer is asked)
+    ix.list_ids = [np.empty(0, np.int64)] * nlist
+    g = GpuIndex(IVF_FLAT, metric, d, nlist=nlist, device=0)
+    g.set_coarse_device(torch.from_numpy(cen).cuda())
+    xq_t = torch.from_numpy(xq).cuda()
+    g.profile_reset()
+    for nprobe in (1, 8, 40, 64):
+        Do, Io = port.coarse_search(ix, xq, nprobe)
+        D, I = g.coarse_search_device(xq_t, nprobe)
+        torch.cuda.synchronize()
+        assert_parity(Do, Io, D.cpu().numpy(), I.cpu().numpy(), metric, f"bf16 coarse prefilter d={d} nprobe={nprobe}")
+    assert g.profile_get()["coarse_fallback_queries"] == 0, "well separated centroids must not need the exact fallback"
+    g.close()
+    cen2 = cen.copy()
+    cen2[:3000] = cen2[rng.integers(3000, 3002, 3000)]  # most centroids are copies of two
+    xq2 = np.concatenate([cen2[3000:3002] + 0.01, xq[:20]]).astype(np.float32)
+    ix.centroids = cen2
+    g = GpuIndex(IVF_FLAT, metric, d, nlist=nlist, device=0)
+    g.set_coarse_device(torch.from_numpy(cen2).cuda())
+    g.profile_reset()
+    for nprobe in (8, 40):
+        Do, Io = port.coarse_search(ix, xq2, nprobe)
+        D, I = g.coarse_search_device(torch.from_numpy(xq2).cuda(), nprobe)
+        torch.cuda.synchronize()
+        assert_parity(Do, Io, D.cpu().numpy(), I.cpu().numpy(), metric, f"bf16 coarse ties nprobe={nprobe}", licensed_ties=True)
+    assert g.profile_get()["coarse_fallback_queries"] > 0
+    g.close()
+
+
+@pytest.mark.parametrize("metric", [ob.L2, ob.IP])
 def test_coarse_certificate_fallback(torch_cuda, port, metric):
     """many identical centroids: the nprobe-th and the (nprobe + margin)-th prefilter values tie, the certificate of the
     MFMA prefilter cannot hold, and the flagged queries go through the exact fallback (flat_full restricted by the flags

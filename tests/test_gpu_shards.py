@@ -284,6 +284,57 @@ def test_rccl_transport_on_the_devices_present(shards, port):
             p.close()
 
 
+def test_rccl_transport_world2_on_two_devices(shards, port):
+    """RCCL with more than one rank: runs whenever the box has two GPUs (skipped, loudly, on a one-GPU box -- no round's test
+    box has had two so far, so the first multi-GPU box is where ncclAllGather at world 2 first executes).  The communicator
+    must span exactly the two devices (a rank-count mismatch fails the group's creation: shard_group.cc checks
+    ncclCommCount); results -- ties at the k-th boundary and the refine stage included -- equal the single index's."""
+    import torch
+    from knowhere_amd import GpuIndex
+    from knowhere_amd.index import BRUTE_FORCE
+    if torch.cuda.device_count() < 2:
+        pytest.skip(f"RCCL at world 2 needs two GPUs; this box has {torch.cuda.device_count()}")
+    world, nb, d, nlist, nq, k, kb = 2, 12000, 16, 24, 60, 5, 60
+    xb, xq = _int_data(nb, d, 42), _int_data(nq, d, 44)
+    for kind, metric in ((ob.IVF_FLAT, ob.L2), (ob.IVF_PQ, ob.IP)):
+        ix = _untie_coarse(port, ob.make_index(port, kind, metric, xb, nlist=nlist, M=4))
+        parts = [GpuIndex.from_data(p, device=r) for r, p in enumerate(_split(ix, world))]
+        try:
+            for kk_, nprobe in ((10, 8), (1, 3), (64, 5)):
+                Do, Io = port.search(ix, xq, kk_, nprobe)
+                D, I, _ = _group_search(shards, parts, [0, 1], 0, xq, kk_, nprobe)
+                assert_parity(Do, Io, D, I, metric, f"RCCL world 2 kind={kind} k={kk_}")
+            if kind == ob.IVF_PQ:
+                g = C.c_void_p()
+                dev = (C.c_int32 * world)(0, 1)
+                assert shards.knhip_shard_group_create(C.c_int32(world), dev, C.c_int32(0), C.byref(g)) == 0, \
+                    shards.knhip_shard_group_last_error().decode()
+                assert shards.knhip_shard_group_size(g) == world
+                raws = []
+                try:
+                    for r, gi in enumerate(parts):
+                        assert shards.knhip_shard_group_set_index(g, C.c_int32(r), gi.h) == 0
+                        lo, hi = nb * r // world, nb * (r + 1) // world
+                        t = torch.from_numpy(xb[lo:hi]).to(f"cuda:{r}")
+                        raws.append(t)
+                        assert shards.knhip_shard_group_set_raw(g, C.c_int32(r), C.c_void_p(t.data_ptr()), C.c_int64(hi - lo),
+                                                                C.c_int64(lo)) == 0
+                    I = np.empty((nq, k), np.int64)
+                    D = np.empty((nq, k), np.float32)
+                    rc = shards.knhip_shard_group_search_refine(g, xq.ctypes.data_as(C.c_void_p), C.c_int64(nq), C.c_int32(k),
+                                                                C.c_int32(kb), C.c_int32(8), None, C.c_int64(0),
+                                                                I.ctypes.data_as(C.c_void_p), D.ctypes.data_as(C.c_void_p), None)
+                    assert rc == 0, shards.knhip_shard_group_last_error().decode()
+                    Dc, Ic = port.search(ix, xq, kb, 8)
+                    Dr, Ir = port.refine(metric, xb, xq, Ic, k)
+                    assert_parity(Dr, Ir, D, I, metric, "RCCL world 2 refine")
+                finally:
+                    shards.knhip_shard_group_destroy(g)
+        finally:
+            for p in parts:
+                p.close()
+
+
 def test_rccl_transport_refuses_one_device_twice(shards):
     g = C.c_void_p()
     dev = (C.c_int32 * 2)(0, 0)
