@@ -250,8 +250,8 @@ __global__ __launch_bounds__(256) void coarse_bf16_kernel(const unsigned char* _
                                                           int64_t ntiles, float* __restrict__ gmin, int G,
                                                           const float* __restrict__ bound, int32_t* __restrict__ cand_cnt,
                                                           int64_t* __restrict__ cand, int cap) {
-    __shared__ __align__(16) unsigned char sA[CB_BM * CB_ROW];
-    __shared__ __align__(16) unsigned char sB[CB_BN * CB_ROW];
+    __align__(16) __shared__ unsigned char sA[CB_BM * CB_ROW];
+    __align__(16) __shared__ unsigned char sB[CB_BN * CB_ROW];
     __shared__ float s_cn[CB_BM];
     __shared__ float s_gm[4][CB_BN];
     // XCD-aware tile order: consecutive tile ids share the centroid panel

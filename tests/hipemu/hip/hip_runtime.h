@@ -284,6 +284,36 @@ inline C hipemu_mfma_32x32x16_f16(H8 a, H8 b, C c, int, int, int) {
     }
     return c;
 }
+// v_mfma_f32_32x32x16_bf16: the same lane maps with 8 bf16 per lane and operand
+template <class B8, class C>
+inline C hipemu_mfma_32x32x16_bf16(B8 a, B8 b, C c, int, int, int) {
+    static_assert(sizeof(B8) == 16, "8 bf16 per lane");
+    unsigned char ab[32];
+    std::memcpy(ab, &a, 16);
+    std::memcpy(ab + 16, &b, 16);
+    const unsigned char (*all)[32] = hipemu::xchg_wide(ab, 32);
+    const int l = hipemu::tl.lane, j = l & 31, hi = l >> 5;
+    auto widen = [](uint16_t h) {
+        const uint32_t u = (uint32_t)h << 16;
+        float f;
+        std::memcpy(&f, &u, 4);
+        return f;
+    };
+    for (int r = 0; r < 16; r++) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c[r];
+        for (int kk = 0; kk < 2; kk++) {
+            uint16_t av[8], bv[8];
+            std::memcpy(av, all[i + 32 * kk], 16);
+            std::memcpy(bv, all[j + 32 * kk] + 16, 16);
+            for (int e = 0; e < 8; e++) {
+                acc += widen(av[e]) * widen(bv[e]);
+            }
+        }
+        c[r] = acc;
+    }
+    return c;
+}
 // v_mfma_f32_16x16x32_f16: A lane l holds row i = l & 15, k block l >> 4 (8 halves); B lane l column n = l & 15, k
 // block l >> 4; D lane l, register r = D[4 (l >> 4) + r][l & 15].  Element e of k block kb of A meets element e of k
 // block kb of B -- which k index that is does not matter to a sum over k.
@@ -337,6 +367,7 @@ inline I4 hipemu_mfma_i32_16x16x64_i8(I4 a, I4 b, I4 c, int, int, int) {
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16(...) hipemu_mfma_16x16x32_f16(__VA_ARGS__)
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(...) hipemu_mfma_32x32x2_f32(__VA_ARGS__)
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(...) hipemu_mfma_32x32x16_f16(__VA_ARGS__)
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(...) hipemu_mfma_32x32x16_bf16(__VA_ARGS__)
 #define __builtin_amdgcn_s_setprio(p) ((void)0)
 #define __builtin_amdgcn_sched_barrier(m) ((void)0)
 #define __builtin_amdgcn_s_memtime() 0ull
@@ -353,6 +384,8 @@ inline int __float_as_int(float f) { return (int)__float_as_uint(f); }
 inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 inline float __int_as_float(int u) { float f; std::memcpy(&f, &u, 4); return f; }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __popc(unsigned int v) { return __builtin_popcount(v); }
+inline int __ffs(int v) { return __builtin_ffs(v); }
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 template <class T>
