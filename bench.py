@@ -627,9 +627,14 @@ def make_roofline(a, kind, prof, world):
         macs = scan_bytes / code_size * a.d
         stream = prof["mscan_stream_bytes"] / nlaunch
         stream_gbps = stream / sec / 1e9 if sec > 0 else 0.0
-        if kind == kidx.IVF_FLAT:
+        if kind == kidx.IVF_FLAT and os.environ.get("KNHIP_MSCAN_FLAT") == "fp32":
             flop, peak, kname, unit_note = 2.0 * macs, MFMA_F32_PEAK_TFLOPS, "knhip::mscan_flat_kernel", \
                 "2 flop per (row, query, dim) on v_mfma_f32_32x32x2_f32; peak = fp32 matrix peak"
+        elif kind == kidx.IVF_FLAT:
+            flop, peak, kname, unit_note = 6.0 * macs, MFMA_F16_PEAK_TFLOPS, "knhip::mscan_flatb_kernel", \
+                "6 flop per (row, query, dim): both operands split into two bf16 terms, hi hi + hi lo + lo hi on " \
+                "v_mfma_f32_32x32x16_bf16 (mfma_scan_bf16.hip); peak = dense bf16 matrix peak; the algorithmic 2 flop per " \
+                "(row, query, dim) are a third of `achieved`"
         else:
             flop, peak, kname, unit_note = 4.0 * macs, MFMA_F16_PEAK_TFLOPS, "knhip::mscan_sq8_kernel", \
                 "4 flop per (row, query, dim): the query operand is split into two halves (hi + lo) on " \

@@ -183,9 +183,11 @@ __global__ __launch_bounds__(256) void coarse_gemm_kernel(const float* __restric
 
 // ---- round 5: the same prefilter on the bf16 matrix pipe, selection fused, no distance matrix ------------------------
 // The certificate + exact re-rank make the GEMM a prefilter: it needs a bounded error, not fp32 products.  Every operand is
-// split into two bf16 terms (x = hi + lo + r, |r| <= 2^-18 |x|: v_cvt_pk_bf16_f32 rounds to nearest) and the product taken
-// as hi hi + hi lo + lo hi on v_mfma_f32_32x32x16_bf16 (fp32 accumulation): three instructions of a pipe sixteen times as
-// fast as the fp32 one, |dot - exact| <= (4 * 2^-18 + 3 d 2^-24) ||q|| ||c||.  And the nq x nlist matrix (655 MB at C3, written
+// split into two bf16 terms (bf16 carries 8 significant bits, v_cvt_pk_bf16_f32 rounds to nearest: |x - hi| <= 2^-8 |x|,
+// x = hi + lo + r with |r| <= 2^-16 |x|) and the product taken as hi hi + hi lo + lo hi on v_mfma_f32_32x32x16_bf16 (the
+// bf16 products are exact in fp32, fp32 accumulation): three instructions of a pipe sixteen times as fast as the fp32
+// one.  What is dropped is lo lo + r_q c + q r_c: |dot - exact| <= (3 * 2^-16 + 3 d 2^-24) ||q|| ||c||; the certificate's
+// eps takes 2^-14 (||q||^2 + max ||c||^2) (L2: twice the dot's error, 2 ab <= a^2 + b^2) / 2^-14 ||q|| max ||c|| (IP).  And the nq x nlist matrix (655 MB at C3, written
 // once and read twice by the select) is never written: the GEMM runs TWICE with different epilogues --
 //   pass 1: the minimum over every group of 32 centroids (one MFMA tile's rows: in the C layout a lane = a query, its 16
 //           registers + the partner lane's = the group) -> gmin[group][query]; the ncand-th smallest group minimum B_q
@@ -551,7 +553,7 @@ __global__ __launch_bounds__(256) void coarse_rerank_kernel(
             const unsigned long long c = cand[nprobe - 1];
             const float en = cr_unkey<IS_L2>((uint32_t)(c >> 32));
             // |approx - exact| <= eps = eps_rel * magnitude (fp32 GEMM: gamma_d = d * 2^-24 with a 8x safety factor; the
-            // bf16 split adds 2^-15)
+            // bf16 split adds 2^-14 >= 3 * 2^-16, see coarse_bf16_kernel)
             const float scale = IS_L2 ? (qnorm[q] + cnorm_max) : sqrtf(qnorm[q] * cnorm_max);
             const float eps = eps_rel * scale + 1e-30f;
             if (c == ~0ull || (cand_cnt != nullptr && cand_cnt[q] > ncand) || !(eps < INFINITY)) {
@@ -606,7 +608,7 @@ hipError_t launch_coarse_rerank(const float* queries, const float* centroids, in
     if (nq <= 0) {
         return hipSuccess;
     }
-    const float eps_rel = 8.0f * (float)d * 5.9604645e-8f + (bound != nullptr ? 3.0517578125e-5f : 0.f);
+    const float eps_rel = 8.0f * (float)d * 5.9604645e-8f + (bound != nullptr ? 6.103515625e-5f : 0.f);
     int kp = 2;
     while (kp < ncand) {
         kp <<= 1;

@@ -355,6 +355,11 @@ hipError_t launch_ms_units(const int32_t* list_count_v, const int64_t* list_pair
                            int64_t* unit_off, int64_t* nunits, KnItem* units, const int64_t* list_len,
                            int64_t code_size, double* unit_bytes, hipStream_t s);
 hipError_t launch_mscan_flat(const MScanArgs& a, bool is_l2, int64_t units_bound, hipStream_t s);
+// ... its filter pass on the bf16 matrix pipe (mfma_scan_bf16.hip): queries per unit for this shape (0 = not served), LDS
+// bytes per workgroup, launch (a.dump must be null; units cut for mscan_flat_bf16_qt(a.nstep) queries)
+int mscan_flat_bf16_qt(int nstep);
+size_t mscan_flat_bf16_smem(int nstep);
+hipError_t launch_mscan_flat_bf16(const MScanArgs& a, bool is_l2, int64_t units_bound, hipStream_t s);
 hipError_t launch_mscan_sq8(const MScanArgs& a, bool is_l2, int64_t units_bound, hipStream_t s);
 hipError_t launch_ms_sample_plan(const int64_t* keys, int64_t nq, int nprobe, int64_t nlist, const int64_t* list_len,
                                  int smin, int32_t* sample_off, int32_t* n_row, hipStream_t s);

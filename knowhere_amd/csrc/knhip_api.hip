@@ -225,6 +225,7 @@ struct knhip_index {
     // MFMA prefilter (mfma_scan.hip): KNHIP_MSCAN = 0 never, 1 whenever the shape allows, 2 (default) when the lists
     // are shared by enough queries of the batch
     int mscan = 2;
+    bool flat_bf16 = true;    // KNHIP_MSCAN_FLAT=fp32: the IVF-Flat filter pass on the fp32 matrix instruction (round 2)
     int mscan_cap = 0;           // KNHIP_MSCAN_CAP: candidate capacity per query (0 = automatic; tests force the retry round)
     mutable bool xnorm_ready = false;
     mutable DevBuf xnorm;        // [total blocks * 64] ||x||^2 per stored row position, built on first use
@@ -514,6 +515,8 @@ int build_list_layout(knhip_index* idx, const std::vector<int64_t>& list_off, co
         idx->pq_q4 = (q4 && q4[0] >= '0' && q4[0] <= '2') ? q4[0] - '0' : 2;
         const char* ms = getenv("KNHIP_MSCAN");
         idx->mscan = (ms && ms[0] >= '0' && ms[0] <= '2') ? ms[0] - '0' : 2;
+        const char* mf = getenv("KNHIP_MSCAN_FLAT");
+        idx->flat_bf16 = !(mf && std::string(mf) == "fp32");
         const char* mc = getenv("KNHIP_MSCAN_CAP");
         idx->mscan_cap = (mc && *mc) ? std::max(0, atoi(mc)) : 0;
         idx->xnorm_ready = false;
@@ -981,6 +984,12 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             if (int rc = ensure_mscan_norms(idx)) return rc;
         }
         int qt = mscan_queries_per_unit(kind, false);
+        // IVF-Flat: the filter pass on the bf16 matrix pipe (mfma_scan_bf16.hip: up to 128 queries per unit); the sample
+        // pass stays on the fp32 kernel (its units hold one or two queries: bound by the rows it reads, not by the products)
+        const bool flat_b = kind == KNHIP_IVF_FLAT && idx->flat_bf16 && mscan_flat_bf16_qt(ms_nstep) > 0;
+        if (flat_b) {
+            qt = mscan_flat_bf16_qt(ms_nstep);
+        }
         const int qt0 = mscan_queries_per_unit(kind, true);
         const int64_t units_bound = round_up(npairs / qt + std::min<int64_t>(nlist, npairs) + 1, 8);
         const int64_t sample = mscan_sample_rows();
@@ -1025,7 +1034,9 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         m.nunits_dev = ws->ms_nunits.as<int64_t>();
         m.gthr = ws->gthr.as<float>();
         // |approx - exact| <= eps_scale * magnitude: see mfma_scan.hip
-        m.eps_scale = (kind == KNHIP_IVF_FLAT ? 16.0f : 32.0f) * (float)d * 5.9604645e-8f;
+        const float eps_fp32 = (kind == KNHIP_IVF_FLAT ? 16.0f : 32.0f) * (float)d * 5.9604645e-8f;
+        // (split-bf16 products drop lo lo + r_q x + q r_x <= 3 * 2^-16 ||q|| ||x||: mfma_scan_bf16.hip)
+        m.eps_scale = eps_fp32 + (flat_b ? 6.103515625e-5f : 0.f);
         m.bitset = d_bitset;
         m.bitset_nbits = nbits;
         m.cand_cnt = cand_cnt;
@@ -1074,7 +1085,8 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         }
         const bool wt2_done = sj.forked;
         auto launch_filter = [&](const MScanArgs& x, int64_t bound) -> hipError_t {
-            return kind == KNHIP_IVF_FLAT ? launch_mscan_flat(x, is_l2, bound, s)
+            return kind == KNHIP_IVF_FLAT ? ((flat_b && x.dump == nullptr) ? launch_mscan_flat_bf16(x, is_l2, bound, s)
+                                                                            : launch_mscan_flat(x, is_l2, bound, s))
                  : kind == KNHIP_IVF_SQ8  ? launch_mscan_sq8(x, is_l2, bound, s)
                  : (pq_i8 && x.dump == nullptr) ? launch_pqi(x, is_l2, bound, s)
                                                 : launch_pqf(x, is_l2, bound, s);
@@ -1114,6 +1126,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             }
             HIP_TRY(hipMemsetAsync(ws->ghist.p, 0, (size_t)nq * 64 * sizeof(uint32_t), s));
             MScanArgs ds = m;
+            ds.eps_scale = eps_fp32; // (the sample pass runs the fp32 kernel)
             ds.dump = ws->dump.as<float>();
             ds.dump_stride = sample;
             ds.ghist = nullptr;

@@ -1162,8 +1162,39 @@ hipError_t launch_pqi_query_table(const float* queries, const float4* cb_m, int 
 // asked, qis[q] = {R, sum mu, -, A}, qmu and the batch's largest range (integer form, pass 1: pqi_query_stats_kernel).
 // dump[q][col] = fp32 ADC distance made pessimistic by its own rounding bound (no table quantisation: tighter than the
 // half-precision sample it replaces); filtered rows dump the neutral value.
+// Round 5: PS_THREADS = 512.  The walk is bound by the latency of its table lookups (round-4 PMC pass: LDS array 58 %
+// busy, vector issue 47 %, 60 % of the wave cycles waiting), and the 32 KB table caps the CU at four workgroups whatever
+// their size: eight waves per workgroup double the waves that cover each other's lookups.  The table is built by the
+// first 256 threads (thread = code).  The selection of tau_q no longer bisects over all 8192 keys (as many vector
+// instructions as the walk itself): the ksel-th smallest of the PS_THREADS per-thread minima bounds the ksel-th
+// smallest key, the few keys under the bound are compacted into LDS and ONE wave bisects over them with ballots -- no
+// barriers, no atomics in the steps; same value bit for bit.  (ksel > PS_THREADS, or more than PS_CAND keys under the
+// bound -- masses of equal values --: the block-wide interval cuts of round 4.)
+constexpr int PS_THREADS = 512;
+constexpr int PS_WAVES = PS_THREADS / KN_WAVE;
+constexpr int PS_CAND = 1024;
+constexpr int PS_ROWS = 2;
+// the r-th smallest (r >= 1) of the keys a wave holds in v[] (lane-strided; padding = 0xffffffff), known to lie in [l, h]:
+// plain bisection, the counts are ballots (scalar unit), no barrier.  (mid < h <= 0xffffffff: padding is never counted.)
+template <int NV>
+__device__ __forceinline__ uint32_t ps_wave_select(const uint32_t (&v)[NV], int r, uint32_t l, uint32_t h) {
+    while (l < h) {
+        const uint32_t mid = l + ((h - l) >> 1);
+        int cnt = 0;
+#pragma unroll
+        for (int u = 0; u < NV; u++) {
+            cnt += __popcll(__ballot(v[u] <= mid));
+        }
+        if (cnt >= r) {
+            h = mid;
+        } else {
+            l = mid + 1;
+        }
+    }
+    return l;
+}
 template <bool IS_L2>
-__global__ __launch_bounds__(PF_KSUB, 4) void pq_sample_kernel(MScanArgs a, const int64_t* __restrict__ keys,
+__global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void pq_sample_kernel(MScanArgs a, const int64_t* __restrict__ keys,
                                                             const float4* __restrict__ cb_m, int64_t nlist, int smin,
                                                             int scap, float pabs_max, int32_t* __restrict__ n_row,
                                                             float* __restrict__ qs, float* __restrict__ qis,
@@ -1172,8 +1203,6 @@ __global__ __launch_bounds__(PF_KSUB, 4) void pq_sample_kernel(MScanArgs a, cons
                                                             int ksel) {
     __shared__ float lut[PF_M * PF_KSUB]; // [m][c]
     __shared__ float sq[PF_M * PF_DSUB];
-    __shared__ float smax[PF_M][PF_KSUB / KN_WAVE];
-    __shared__ float smin_[PF_M][PF_KSUB / KN_WAVE];
     __shared__ float s_mu[PF_M], s_a[PF_M], s_r[PF_M];
     __shared__ float s_A;
     const int64_t q = blockIdx.x;
@@ -1184,40 +1213,54 @@ __global__ __launch_bounds__(PF_KSUB, 4) void pq_sample_kernel(MScanArgs a, cons
     }
     __syncthreads();
     {
-        float hi[PF_M], lo[PF_M];
-        pq_table_values<IS_L2>(sq, cb_m, c, hi);
+        // the table: thread = (half of the sub-quantizers, code); the operations of pq_table_values
+        const int cc = c & (PF_KSUB - 1), m0 = (c / PF_KSUB) * (PF_M / 2);
 #pragma unroll
-        for (int m = 0; m < PF_M; m++) {
-            lut[m * PF_KSUB + c] = hi[m];
-            const bool fin = fabsf(hi[m]) < INFINITY; // (false for NaN too: "no bound", the query takes the exact kernels)
-            lo[m] = fin ? hi[m] : -INFINITY;
-            hi[m] = fin ? hi[m] : INFINITY;
-        }
-        const float rh = pf_reduce32(hi, [](float x, float y) { return fmaxf(x, y); });
-        const float rl = pf_reduce32(lo, [](float x, float y) { return fminf(x, y); });
-        if ((lane_id() & 1) == 0) {
-            smax[(lane_id() >> 1) & 31][wave] = rh;
-            smin_[(lane_id() >> 1) & 31][wave] = rl;
+        for (int j = 0; j < PF_M / 2; j++) {
+            const int m = m0 + j;
+            const float4 y = cb_m[m * PF_KSUB + cc];
+            const float4 x = *reinterpret_cast<const float4*>(sq + m * PF_DSUB);
+            float t = ip_step(0.f, x.x, y.x);
+            t = ip_step(t, x.y, y.y);
+            t = ip_step(t, x.z, y.z);
+            t = ip_step(t, x.w, y.w);
+            lut[m * PF_KSUB + cc] = IS_L2 ? fmul_x(-2.0f, t) : t;
         }
     }
     __syncthreads();
-    if (c < PF_M) {
-        float h = smax[c][0], l = smin_[c][0];
-        for (int w = 1; w < PF_KSUB / KN_WAVE; w++) {
-            h = fmaxf(h, smax[c][w]);
-            l = fminf(l, smin_[c][w]);
-        }
-        const float mu = 0.5f * h + 0.5f * l;
-        s_mu[c] = mu;
-        s_a[c] = fmaxf(fabsf(h), fabsf(l));
-        s_r[c] = h - l;
-        if (qmu != nullptr) {
-            qmu[q * PF_M + c] = mu;
+    {
+        // per-m extrema: wave w takes m = 4 w .. 4 w + 3, four entries per lane (max / min do not depend on the order)
+#pragma unroll
+        for (int j = 0; j < PF_M / PS_WAVES; j++) {
+            const int m = wave * (PF_M / PS_WAVES) + j;
+            float h = -INFINITY, l = INFINITY;
+#pragma unroll
+            for (int e = 0; e < PF_KSUB / KN_WAVE; e++) {
+                const float v = lut[m * PF_KSUB + lane_id() + e * KN_WAVE];
+                const bool fin = fabsf(v) < INFINITY; // (false for NaN too: "no bound", the query takes the exact kernels)
+                h = fmaxf(h, fin ? v : INFINITY);
+                l = fminf(l, fin ? v : -INFINITY);
+            }
+#pragma unroll
+            for (int dlt = KN_WAVE / 2; dlt > 0; dlt >>= 1) {
+                h = fmaxf(h, __shfl_xor(h, dlt, KN_WAVE));
+                l = fminf(l, __shfl_xor(l, dlt, KN_WAVE));
+            }
+            if (lane_id() == 0) {
+                const float mu = 0.5f * h + 0.5f * l;
+                s_mu[m] = mu;
+                s_a[m] = fmaxf(fabsf(h), fabsf(l));
+                s_r[m] = h - l;
+                if (qmu != nullptr) {
+                    qmu[q * PF_M + m] = mu;
+                }
+            }
         }
     }
     __syncthreads();
     if (c == 0) {
         float A = 0.f, R = 0.f, musum = 0.f, gmax = 0.f;
+#pragma unroll 4
         for (int m = 0; m < PF_M; m++) { // (in this order: the sums are part of the bounds' definitions)
             musum += s_mu[m];
             A += s_a[m];
@@ -1269,21 +1312,21 @@ __global__ __launch_bounds__(PF_KSUB, 4) void pq_sample_kernel(MScanArgs a, cons
         const int64_t row_off = a.list_row_off[key];
         const float* ps = a.pq_psum + a.pq_sblk_off_r[key] * 16;
         const float slack0 = 128.0f * PF_U * (pabs_max + A) + 64.0f * PF_U * fabsf(dis0);
-        // four rows per thread and round: their loads are in flight together (the loop is latency-bound otherwise)
-        for (int pos0 = c; pos0 < rows; pos0 += 4 * PF_KSUB) {
-            uint4 c0[4], c1[4];
-            float psv[4];
+        // PS_ROWS rows per thread and round: their loads are in flight together (64 registers per thread: eight waves per SIMD)
+        for (int pos0 = c; pos0 < rows; pos0 += PS_ROWS * PS_THREADS) {
+            uint4 c0[PS_ROWS], c1[PS_ROWS];
+            float psv[PS_ROWS];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int pos = min(pos0 + u * PF_KSUB, rows - 1); // (clamped: a valid row, its result is dropped)
+            for (int u = 0; u < PS_ROWS; u++) {
+                const int pos = min(pos0 + u * PS_THREADS, rows - 1); // (clamped: a valid row, its result is dropped)
                 const uint4* cp = reinterpret_cast<const uint4*>(a.pq_codes + (row_off + pos) * PF_M);
                 c0[u] = cp[0];
                 c1[u] = cp[1];
                 psv[u] = IS_L2 ? ps[pos] : 0.f;
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int pos = pos0 + u * PF_KSUB;
+            for (int u = 0; u < PS_ROWS; u++) {
+                const int pos = pos0 + u * PS_THREADS;
                 const uint32_t w[8] = {c0[u].x, c0[u].y, c0[u].z, c0[u].w, c1[u].x, c1[u].y, c1[u].z, c1[u].w};
                 float acc = 0.f;
 #pragma unroll
@@ -1316,19 +1359,24 @@ __global__ __launch_bounds__(PF_KSUB, 4) void pq_sample_kernel(MScanArgs a, cons
     // read back into registers (this workgroup wrote them: L1 / L2 hits) as order-preserving integer keys; the ksel-th
     // smallest key comes from a bisection with one counter and one barrier per step.
     __syncthreads();
-    constexpr int PER = PF_SAMPLE / PF_KSUB;
+    constexpr int PER = PF_SAMPLE / PS_THREADS;
     uint32_t key[PER];
     uint32_t mn = 0xffffffffu, mx = 0u;
 #pragma unroll
     for (int u = 0; u < PER; u++) {
-        const int i = c + u * PF_KSUB;
+        const int i = c + u * PS_THREADS;
         key[u] = i < cum ? dist_key<IS_L2>(a.dump[q * a.dump_stride + i]) : 0xffffffffu;
         mn = min(mn, key[u]);
         mx = i < cum ? max(mx, key[u]) : mx;
     }
     constexpr int NSTEP = 18; // 2 bits of the interval per step (16 cover the key space; two spare for the rounding of the cuts)
     __shared__ int s_step[NSTEP][3];
-    __shared__ uint32_t s_mn[PF_KSUB / KN_WAVE], s_mx[PF_KSUB / KN_WAVE];
+    __shared__ uint32_t s_mn[PS_WAVES], s_mx[PS_WAVES];
+    __shared__ uint32_t s_tmin[PS_THREADS];
+    __shared__ uint32_t s_cand[PS_CAND];
+    __shared__ uint32_t s_bound, s_kth;
+    __shared__ int s_ncand;
+    s_tmin[c] = mn; // (this thread's minimum, before the reduction below)
 #pragma unroll
     for (int dlt = KN_WAVE / 2; dlt > 0; dlt >>= 1) {
         mn = min(mn, (uint32_t)__shfl_xor((int)mn, dlt, KN_WAVE));
@@ -1341,13 +1389,67 @@ __global__ __launch_bounds__(PF_KSUB, 4) void pq_sample_kernel(MScanArgs a, cons
     if (c < NSTEP * 3) {
         (&s_step[0][0])[c] = 0;
     }
+    if (c == 0) {
+        s_ncand = 0;
+    }
     __syncthreads();
     uint32_t lo = s_mn[0], hi = s_mx[0];
-    for (int w = 1; w < PF_KSUB / KN_WAVE; w++) {
+    for (int w = 1; w < PS_WAVES; w++) {
         lo = min(lo, s_mn[w]);
         hi = max(hi, s_mx[w]);
     }
     const uint32_t best = lo;
+    bool fast = ksel <= PS_THREADS && cum >= ksel && lo < hi; // (uniform)
+    if (fast) {
+        // 1. the bound: ksel threads hold a key <= the ksel-th smallest thread minimum, so the ksel-th smallest key is
+        //    <= it (cum >= ksel keys are spread over min(cum, PS_THREADS) >= ksel threads)
+        if (wave == 0) {
+            uint32_t v[PS_THREADS / KN_WAVE];
+#pragma unroll
+            for (int u = 0; u < PS_THREADS / KN_WAVE; u++) {
+                v[u] = s_tmin[lane_id() + u * KN_WAVE];
+            }
+            const uint32_t b = ps_wave_select(v, ksel, lo, hi);
+            if (lane_id() == 0) {
+                s_bound = b;
+            }
+        }
+        __syncthreads();
+        // 2. the keys under the bound (a few more than ksel)
+        const uint32_t bound = s_bound;
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            if (key[u] <= bound) {
+                const int at = atomicAdd(&s_ncand, 1);
+                if (at < PS_CAND) {
+                    s_cand[at] = key[u];
+                }
+            }
+        }
+        __syncthreads();
+        const int nc = s_ncand;
+        if (nc <= PS_CAND) {
+            // 3. one wave: the ksel-th smallest of them
+            if (wave == 0) {
+                uint32_t v[PS_CAND / KN_WAVE];
+#pragma unroll
+                for (int u = 0; u < PS_CAND / KN_WAVE; u++) {
+                    const int i = lane_id() + u * KN_WAVE;
+                    v[u] = i < nc ? s_cand[i] : 0xffffffffu;
+                }
+                const uint32_t kk = ps_wave_select(v, ksel, lo, bound);
+                if (lane_id() == 0) {
+                    s_kth = kk;
+                }
+            }
+            __syncthreads();
+            lo = s_kth;
+            hi = lo;
+        } else {
+            hi = bound; // (the ksel-th smallest is <= the bound: the block-wide cuts start from there)
+            fast = false;
+        }
+    }
     // the ksel-th smallest key lies in [lo, hi] (when cum >= ksel): the interval is cut in four per step -- three counters,
     // one barrier -- until it is a point; the number of steps depends on the spread of the sample only (distances of one
     // sample share their exponent: ~12 steps, against 32 for a bisection of the whole key space)
@@ -1425,10 +1527,10 @@ hipError_t launch_pq_sample(const MScanArgs& a, const int64_t* keys, const float
         gl = reinterpret_cast<uint32_t*>(qis + a.nq * 4);
     }
     if (is_l2) {
-        hipLaunchKernelGGL(pq_sample_kernel<true>, dim3((unsigned)a.nq), dim3(PF_KSUB), 0, s, a, keys, cb_m, nlist, smin,
+        hipLaunchKernelGGL(pq_sample_kernel<true>, dim3((unsigned)a.nq), dim3(PS_THREADS), 0, s, a, keys, cb_m, nlist, smin,
                            scap, pabs_max, n_row, qs, qis, qmu, gl, gthr_out, gmeta_out, ksel);
     } else {
-        hipLaunchKernelGGL(pq_sample_kernel<false>, dim3((unsigned)a.nq), dim3(PF_KSUB), 0, s, a, keys, cb_m, nlist, smin,
+        hipLaunchKernelGGL(pq_sample_kernel<false>, dim3((unsigned)a.nq), dim3(PS_THREADS), 0, s, a, keys, cb_m, nlist, smin,
                            scap, pabs_max, n_row, qs, qis, qmu, gl, gthr_out, gmeta_out, ksel);
     }
     return hipGetLastError();

@@ -24,6 +24,10 @@ def _sub(s, pattern, repl, count, flags=0, what=""):
     return out
 
 
+# occupancy hints of the device compiler
+WAVES_PER_EU = re.compile(r"__attribute__\(\(amdgpu_waves_per_eu\(\d+, \d+\)\)\) ")
+
+
 def patch_pq_filter(s):
     s = _sub(s, re.escape(DYN_SMEM), DYN_SMEM_EMU, 2, what="dynamic LDS")
     # the LDS-offset-0 assertion of the token addressing
@@ -48,7 +52,7 @@ def patch_pq_filter(s):
     s = _sub(s, r'        asm volatile\("" : "\+v"\(lane_i\)\);[^\n]*\n', "", 2, what="lane launder")
     s = _sub(s, r'        asm volatile\("" : "\+v"\(tau_g\)[^\n]*\n', "", 1, what="load-order fence")
     s = _sub(s, r'        asm volatile\("" : "\+v"\(pq_qv\)\);\n', "", 1, what="query index launder")
-    return s
+    return WAVES_PER_EU.sub("", s)
 
 
 def patch_dyn_smem_only(s):
@@ -102,13 +106,13 @@ def patch_generic(s):
     # "the LUT sits at LDS offset 0" assertions of the token-addressed kernels (host pointers are never 0)
     s = re.sub(r"    if \(\(uint32_t\)\(size_t\)\(\(__attribute__\(\(address_space\(3\)\)\) unsigned char\*\)smem\) != 0u\) \{\n"
                r"        __builtin_trap\(\);[^\n]*\n    \}\n", "", s)
-    return s.replace("__attribute__((address_space(3)))", "")
+    return WAVES_PER_EU.sub("", s).replace("__attribute__((address_space(3)))", "")
 
 
 # the whole library (C ABI + orchestration + kernels) for API-level emulation; prims.hip / build.hip stay out (their
 # entry points resolve to aborting stubs generated from the link's undefined symbols)
 API_FILES = ["knhip_api.hip", "flat_scan.hip", "sq_scan.hip", "topk.hip", "worktable.hip", "coarse_gemm.hip", "refine.hip",
-             "range.hip", "mfma_scan.hip", "pq_filter.hip", "pq_scan.hip", "pq_scan_v2.hip", "pq_scan_q4.hip", "pq_scan_any.hip"]
+             "range.hip", "mfma_scan.hip", "mfma_scan_bf16.hip", "pq_filter.hip", "pq_scan.hip", "pq_scan_v2.hip", "pq_scan_q4.hip", "pq_scan_any.hip"]
 
 
 def build_api(force=False):

@@ -157,3 +157,34 @@ def test_mscan_retry_round(torch_cuda, port, monkeypatch, kind, metric):
     _check(port, ix, g0, g1, xq, 10, 16, metric, "retry + bitset", bs, nb)
     g0.close()
     g1.close()
+
+
+@pytest.mark.parametrize("metric", [ob.L2, ob.IP], ids=["l2", "ip"])
+@pytest.mark.parametrize("d", [128, 320, 36], ids=["d128", "d320", "d36"])
+def test_mscan_flat_filter_on_the_bf16_pipe(torch_cuda, port, monkeypatch, d, metric):
+    """the IVF-Flat filter pass on split-bf16 operands (mfma_scan_bf16.hip; round 5) against the fp32 filter
+    (KNHIP_MSCAN_FLAT=fp32) and the oracle: units of 128 queries in full, partly filled and one-tile units (300 queries
+    probing every list), the 64-query form of wide rows (d = 320), a ragged dimension, a bitset, and rows of
+    different magnitudes."""
+    nb, nlist, nq = 24000, 24, 300
+    xb, xq = gen_data(nb, d, 42), gen_data(nq, d, 44)
+    xb[::97] *= 3.0  # a few rows longer than the rest (the bound scales with the LARGEST row norm of the index)
+    ix = ob.make_index(port, ob.IVF_FLAT, metric, xb, nlist=nlist)
+    monkeypatch.setenv("KNHIP_MSCAN", "1")
+    monkeypatch.setenv("KNHIP_MSCAN_FLAT", "fp32")
+    g32 = _gpu(ix)
+    monkeypatch.delenv("KNHIP_MSCAN_FLAT")
+    gb = _gpu(ix)
+    bs = _bitset(nb, 0.5, 3)
+    for k, nprobe, b, nbits in ((10, nlist, None, 0), (100, 8, None, 0), (1, 3, None, 0), (10, nlist, bs, nb)):
+        Do, Io = port.search(ix, xq, k, nprobe, b, nbits)
+        D0, I0 = g32.search(xq, k, nprobe, b, nbits)
+        gb.profile_enable(True)
+        gb.profile_reset()
+        D1, I1 = gb.search(xq, k, nprobe, b, nbits)
+        p = gb.profile_get()
+        assert p["mscan_queries"] + p["mscan_overflow_queries"] == nq and p["mscan_queries"] > 0
+        assert_parity(Do, Io, D1, I1, metric, f"bf16 filter d={d} k={k} nprobe={nprobe} bitset={b is not None}")
+        assert np.array_equal(I0, I1) and np.array_equal(D0.view(np.uint32), D1.view(np.uint32))
+    g32.close()
+    gb.close()
