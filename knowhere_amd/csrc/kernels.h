@@ -232,6 +232,7 @@ struct MScanArgs {
     // sample pass (non-null = DUMP mode): pessimistic distance of (query, row) -> dump[q * dump_stride + row]
     float* dump;
     int64_t dump_stride;
+    int32_t sample_cap;          // rows of a query's sample, at most (<= dump_stride; the plan's `cap`)
     // per-query candidate histogram (null = off): ghist[q][64], gmeta[q] = {key of the first bin, bin shift | KN_HIST_OFF}
     uint32_t* ghist;
     const uint2* gmeta;
@@ -362,7 +363,7 @@ size_t mscan_flat_bf16_smem(int nstep);
 hipError_t launch_mscan_flat_bf16(const MScanArgs& a, bool is_l2, int64_t units_bound, hipStream_t s);
 hipError_t launch_mscan_sq8(const MScanArgs& a, bool is_l2, int64_t units_bound, hipStream_t s);
 hipError_t launch_ms_sample_plan(const int64_t* keys, int64_t nq, int nprobe, int64_t nlist, const int64_t* list_len,
-                                 int smin, int32_t* sample_off, int32_t* n_row, hipStream_t s);
+                                 int smin, int cap, int32_t* sample_off, int32_t* n_row, hipStream_t s);
 hipError_t launch_ms_sq8_query_prep(const float* queries, int64_t nq, int d, int ldq, const float* trained, void* qh,
                                     void* ql, float* qs, hipStream_t s);
 hipError_t launch_ms_tau(const float* sel_d, int64_t nq, int k, bool is_l2, float* gthr, uint2* gmeta, hipStream_t s);

@@ -933,6 +933,14 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
     // (the MFMA prefilter's fallback compacts the pairs of overflowed queries into one-query items: up to npairs)
     HIP_TRY(ws->items.reserve((size_t)(use_ms ? std::max<int64_t>(npairs, items_bound) : items_bound) * sizeof(KnItem)));
     HIP_TRY(ws->nitems.reserve(sizeof(int64_t)));
+    // rows of a query's sample (IVF-Flat / IVF-SQ8 prefilter), at most: the first max(1024, 8 k) rows of its closest
+    // list(s) -- the pass is bound by the rows it reads (C2: every list is somebody's closest: the whole index once per
+    // batch when a list was sampled in full), and tau from 1024 rows lets only a few dozen more candidates through.
+    // KNHIP_MS_SAMPLE_ROWS=n overrides (tests / experiments; 8192 = whole lists as in rounds 2-4)
+    int ms_sample_cap = std::min<int>(mscan_sample_rows(), (std::max(1024, 8 * k) + 63) / 64 * 64);
+    if (const char* e = getenv("KNHIP_MS_SAMPLE_ROWS")) {
+        ms_sample_cap = std::max(64, std::min(mscan_sample_rows(), atoi(e) / 64 * 64));
+    }
     WorkTable wt{};
     wt.list_count = ws->list_count.as<int32_t>();
     wt.list_cursor = ws->list_cursor.as<int32_t>();
@@ -958,7 +966,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             HIP_TRY(ws->ms_sample_off.reserve((size_t)npairs * sizeof(int32_t)));
             HIP_TRY(ws->ms_nrow.reserve((size_t)nq * sizeof(int32_t)));
             HIP_TRY(launch_ms_sample_plan(keys_p, nq, nprobe, nlist, idx->d_list_len.as<int64_t>(),
-                                          std::max(1024, 8 * k), ws->ms_sample_off.as<int32_t>(),
+                                          std::max(1024, 8 * k), ms_sample_cap, ws->ms_sample_off.as<int32_t>(),
                                           ws->ms_nrow.as<int32_t>(), s));
             cls = ws->ms_sample_off.as<int32_t>();
         }
@@ -1000,7 +1008,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         HIP_TRY(ws->ms_unit_off.reserve((size_t)(nlist + 1) * sizeof(int64_t)));
         HIP_TRY(ws->ms_nunits.reserve(sizeof(int64_t) + 2 * sizeof(double)));
         HIP_TRY(ws->ms_cand.reserve((size_t)nq * ms_cap * sizeof(int64_t)));
-        if (kind == KNHIP_IVF_PQ) {
+        if (kind == KNHIP_IVF_PQ || kind == KNHIP_IVF_FLAT) {
             HIP_TRY(ws->ms_cand_pess.reserve((size_t)nq * ms_cap * sizeof(float)));
         }
         HIP_TRY(ws->ms_cand_cnt.reserve((size_t)(2 * nq + 4) * sizeof(int32_t))); // counters, flags, any-flag, guard counters
@@ -1041,7 +1049,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         m.bitset_nbits = nbits;
         m.cand_cnt = cand_cnt;
         m.cand = ws->ms_cand.as<int64_t>();
-        m.cand_pess = kind == KNHIP_IVF_PQ ? ws->ms_cand_pess.as<float>() : nullptr;
+        m.cand_pess = (kind == KNHIP_IVF_PQ || kind == KNHIP_IVF_FLAT) ? ws->ms_cand_pess.as<float>() : nullptr;
         m.cap = ms_cap;
         m.overflow = overflow;
         m.gthr_rw = ws->gthr.as<float>();
@@ -1129,6 +1137,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             ds.eps_scale = eps_fp32; // (the sample pass runs the fp32 kernel)
             ds.dump = ws->dump.as<float>();
             ds.dump_stride = sample;
+            ds.sample_cap = ms_sample_cap;
             ds.ghist = nullptr;
             if (kind == KNHIP_IVF_PQ) {
                 // one workgroup per query: plan, fp32 table, sampled rows, and the statistics of both table forms

@@ -243,7 +243,7 @@ __device__ __forceinline__ void mscan_flat_unit(const MScanArgs a, const int64_t
     const int hi = lane >> 5, lr = lane & 31;
     int64_t nblk = (len + 63) >> 6;
     if (DUMP) {
-        nblk = min(nblk, (int64_t)(MS_SAMPLE / 64));
+        nblk = min(nblk, (int64_t)((a.sample_cap + 63) / 64));
     }
     if (nblk <= 0) {
         return;
@@ -331,7 +331,7 @@ __device__ __forceinline__ void mscan_flat_unit(const MScanArgs a, const int64_t
                 const int32_t q = sPq[qt * 32 + lr];
                 if (q >= 0) {
                     const int32_t off = sPs[qt * 32 + lr];
-                    const int64_t lim = min(len, (int64_t)(MS_SAMPLE - off));
+                    const int64_t lim = min(len, (int64_t)(a.sample_cap - off));
                     float* drow = a.dump + (int64_t)q * a.dump_stride + off + b * 64;
 #pragma unroll
                     for (int t = 0; t < 2; t++) {
@@ -752,7 +752,7 @@ __device__ __forceinline__ void mscan_sq8_unit(const MScanArgs a, const int64_t 
     const int hi = lane >> 5, lr = lane & 31;
     int64_t nblk = (len + 63) >> 6;
     if (DUMP) {
-        nblk = min(nblk, (int64_t)(MS_SAMPLE / 64));
+        nblk = min(nblk, (int64_t)((a.sample_cap + 63) / 64));
     }
     if (nblk <= 0) {
         return;
@@ -833,7 +833,7 @@ __device__ __forceinline__ void mscan_sq8_unit(const MScanArgs a, const int64_t 
             if (q >= 0) {
                 const float u0 = sU0[lr], vv = sV[lr], off = sOff[lr];
                 const int32_t col0 = sPs[lr];
-                const int64_t lim = min(len, (int64_t)(MS_SAMPLE - col0));
+                const int64_t lim = min(len, (int64_t)(a.sample_cap - col0));
                 float* drow = a.dump + (int64_t)q * a.dump_stride + col0 + b * 64;
 #pragma unroll
                 for (int t = 0; t < 2; t++) {
@@ -923,11 +923,11 @@ __global__ __launch_bounds__(MQ_THREADS) void mscan_sq8_kernel(MScanArgs a) {
 // ---- sample plan ---------------------------------------------------------------------------------------------------
 // Which (query, slot) pairs feed tau_q: the probes in coarse order until `smin` rows are covered (one list when the
 // closest list is long enough, several when it is short or empty -- inner-product clusterings have many tiny lists),
-// at most MS_SAMPLE rows in all.  sample_off[q][slot] = first dump column of the pair, -1 = not sampled;
+// at most `cap` (<= MS_SAMPLE) rows in all -- a long list gives its first cap - cum rows.  sample_off[q][slot] = first dump column of the pair, -1 = not sampled;
 // n_row[q] = columns used.
 __global__ void ms_sample_plan_kernel(const int64_t* __restrict__ keys, int64_t nq, int nprobe, int64_t nlist,
-                                      const int64_t* __restrict__ list_len, int smin, int32_t* __restrict__ sample_off,
-                                      int32_t* __restrict__ n_row) {
+                                      const int64_t* __restrict__ list_len, int smin, int cap,
+                                      int32_t* __restrict__ sample_off, int32_t* __restrict__ n_row) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) {
         return;
@@ -937,9 +937,9 @@ __global__ void ms_sample_plan_kernel(const int64_t* __restrict__ keys, int64_t 
         const int64_t key = keys[q * nprobe + slot];
         const int64_t len = (key >= 0 && key < nlist) ? list_len[key] : 0;
         int32_t off = -1;
-        if (len > 0 && cum < smin && cum < MS_SAMPLE) {
+        if (len > 0 && cum < smin && cum < cap) {
             off = cum;
-            cum += (int)min(len, (int64_t)(MS_SAMPLE - cum));
+            cum += (int)min(len, (int64_t)(cap - cum));
         }
         sample_off[q * nprobe + slot] = off;
     }
@@ -947,12 +947,15 @@ __global__ void ms_sample_plan_kernel(const int64_t* __restrict__ keys, int64_t 
 }
 
 hipError_t launch_ms_sample_plan(const int64_t* keys, int64_t nq, int nprobe, int64_t nlist, const int64_t* list_len,
-                                 int smin, int32_t* sample_off, int32_t* n_row, hipStream_t s) {
+                                 int smin, int cap, int32_t* sample_off, int32_t* n_row, hipStream_t s) {
     if (nq <= 0) {
         return hipSuccess;
     }
+    if (cap < 1 || cap > MS_SAMPLE) {
+        return hipErrorInvalidValue;
+    }
     hipLaunchKernelGGL(ms_sample_plan_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, keys, nq, nprobe, nlist,
-                       list_len, smin, sample_off, n_row);
+                       list_len, smin, cap, sample_off, n_row);
     return hipGetLastError();
 }
 
@@ -1026,17 +1029,24 @@ __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, c
     const int d = a.d;
     int n = min(a.cand_cnt[q], a.cap);
     const int n_filter = n;
-    // ---- prune (PQ prefilter): every candidate came with its pessimistic distance (exact <= pess).  The k-th best of
+    // ---- prune (PQ prefilter; fp32 rows since round 5: a loose tau from a short sample gives a few queries thousands of
+    // candidates, and they were the stage's tail): every candidate came with its pessimistic distance (exact <= pess).  The k-th best of
     // those values bounds the final k-th distance, and a candidate whose OPTIMISTIC distance (>= pess - 2 eps_max) is
     // beyond it cannot enter: only the rest is recomputed exactly (32 dependent gathers each).  The k-th value comes from
     // a binary search over the order-preserving integer keys, the candidates sit in registers meanwhile.
     constexpr int MF_PRUNE_PER_THREAD = 16;
-    if (KIND == 2 && a.cand_pess != nullptr && !retry_prep && n >= 2 * k && n <= MF_THREADS * MF_PRUNE_PER_THREAD) {
+    // fp32 rows: any number of candidates -- the bound comes from the first MF_THREADS * MF_PRUNE_PER_THREAD of them (the
+    // k-th best of ANY k candidates is a valid bound; the eps of this kind does not depend on it), the rest is streamed
+    // through the same test.  (A query whose sample was unlucky can arrive with the full capacity of candidates: without
+    // this it alone took 16 rounds of 1013 exact distances + a 1024-entry sort, the tail of the whole stage.)
+    const int n_head = KIND == 1 ? min(n, MF_THREADS * MF_PRUNE_PER_THREAD) : n;
+    if ((KIND == 2 || KIND == 1) && a.cand_pess != nullptr && !retry_prep && n >= 2 * k &&
+        n_head <= MF_THREADS * MF_PRUNE_PER_THREAD) {
         __shared__ int s_cnt;
         __shared__ float s_red[MF_THREADS / KN_WAVE];
         // eps_max: the per-query part + the fp32 roundings at the largest |dis0| of the query's probes and its bound
         float cmax = 0.f;
-        for (int sl = tid; sl < nprobe; sl += MF_THREADS) {
+        for (int sl = tid; KIND == 2 && sl < nprobe; sl += MF_THREADS) {
             cmax = fmaxf(cmax, fabsf(coarse_dis[q * nprobe + sl]));
         }
 #pragma unroll
@@ -1052,7 +1062,11 @@ __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, c
             cmax = fmaxf(cmax, s_red[w]);
         }
         // (completed below, once tau2 is known: the emission's eps used |tau| of a bound between gthr and tau2)
-        const float eps_q = a.pq_qs[q * 4 + 2], eps_mu = a.pq_prune_mu ? fabsf(a.pq_qs[q * 4 + 1]) : 0.f;
+        float eps_q = 0.f, eps_mu = 0.f;
+        if (KIND == 2) {
+            eps_q = a.pq_qs[q * 4 + 2];
+            eps_mu = a.pq_prune_mu ? fabsf(a.pq_qs[q * 4 + 1]) : 0.f;
+        }
         const float gthr_abs = fabsf(a.gthr[q]);
         uint32_t pk[MF_PRUNE_PER_THREAD];
         int64_t pc[MF_PRUNE_PER_THREAD];
@@ -1063,7 +1077,7 @@ __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, c
             pk[u] = 0xffffffffu;
             pc[u] = 0;
             pp[u] = worst_dist<IS_L2>();
-            if (ci < n) {
+            if (ci < n_head) {
                 pc[u] = a.cand[q * (int64_t)a.cap + ci];
                 pp[u] = a.cand_pess[q * (int64_t)a.cap + ci];
                 pk[u] = dist_key<IS_L2>(pp[u]);
@@ -1106,7 +1120,12 @@ __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, c
         // |dis0| <= cmax; the emission's tau lies between the sample bound gthr and the final k-th pessimistic distance
         // tau2 (a histogram edge is only read once k candidates sit below it), so |tau| <= max(|gthr|, |tau2|); the
         // integer form's per-query offset sum rides in [q][1] of its record
-        const float eps_max = eps_q + 64.0f * 5.9604645e-8f * (cmax + fmaxf(gthr_abs, fabsf(tau2)) + eps_mu);
+        float eps_max = eps_q + 64.0f * 5.9604645e-8f * (cmax + fmaxf(gthr_abs, fabsf(tau2)) + eps_mu);
+        if (KIND == 1) {
+            // fp32 rows: every emission of this query used the one eps of mscan_flat*_unit (pess = approx widened by it)
+            const float qn = a.qnorm[q];
+            eps_max = a.eps_scale * (IS_L2 ? (qn + a.xnorm_max) : sqrtf(qn * a.xnorm_max)) + 1e-30f;
+        }
         if (eps_max < INFINITY && tau2 == tau2 && fabsf(tau2) < FLT_MAX) {
             if (tid == 0) {
                 s_cnt = 0;
@@ -1115,10 +1134,26 @@ __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, c
 #pragma unroll
             for (int u = 0; u < MF_PRUNE_PER_THREAD; u++) {
                 const int ci = tid + u * MF_THREADS;
-                const bool keep = ci < n && (IS_L2 ? (pp[u] - 2.0f * eps_max <= tau2) : (pp[u] + 2.0f * eps_max >= tau2));
+                const bool keep = ci < n_head && (IS_L2 ? (pp[u] - 2.0f * eps_max <= tau2) : (pp[u] + 2.0f * eps_max >= tau2));
                 if (keep) {
                     const int j = atomicAdd(&s_cnt, 1);
                     a.cand[q * (int64_t)a.cap + j] = pc[u];
+                }
+            }
+            // the candidates past the head: kept ones land below everything still to be read (s_cnt <= candidates seen)
+#pragma unroll 1
+            for (int ci0 = n_head; ci0 < n; ci0 += MF_THREADS) {
+                const int ci = ci0 + tid;
+                int64_t c = 0;
+                float p = worst_dist<IS_L2>();
+                if (ci < n) {
+                    c = a.cand[q * (int64_t)a.cap + ci];
+                    p = a.cand_pess[q * (int64_t)a.cap + ci];
+                }
+                __syncthreads(); // (this row of candidates is in registers before any thread may overwrite part of it)
+                if (ci < n && (IS_L2 ? (p - 2.0f * eps_max <= tau2) : (p + 2.0f * eps_max >= tau2))) {
+                    const int j = atomicAdd(&s_cnt, 1);
+                    a.cand[q * (int64_t)a.cap + j] = c;
                 }
             }
             __syncthreads();

@@ -188,3 +188,30 @@ def test_mscan_flat_filter_on_the_bf16_pipe(torch_cuda, port, monkeypatch, d, me
         assert np.array_equal(I0, I1) and np.array_equal(D0.view(np.uint32), D1.view(np.uint32))
     g32.close()
     gb.close()
+
+
+def test_mscan_flat_finish_prunes_a_long_candidate_list(torch_cuda, port, monkeypatch):
+    """an unlucky sample: seven of eight rows among the first 1024 of every list are filtered, so tau comes from 128 rows per
+    list and ~9 % of the 100k rows pass the filter -- more candidates per query than the finish kernel's pruning holds in
+    registers (4096): the bound comes from the head of the list, the rest is streamed through the same test."""
+    nb, d, nlist, nq = 100_000, 32, 4, 40
+    xb, xq = gen_data(nb, d, 42), gen_data(nq, d, 44)
+    ix = sort_lists_by_id(ob.make_index(port, ob.IVF_FLAT, ob.L2, xb, nlist=nlist))
+    filt = np.zeros(nb, bool)
+    for l in range(nlist):
+        head = np.asarray(ix.list_ids[l][:1024])
+        filt[head[np.arange(head.size) % 8 != 0]] = True
+    bs = np.packbits(filt, bitorder="little")
+    monkeypatch.setenv("KNHIP_MSCAN", "1")
+    monkeypatch.setenv("KNHIP_MSCAN_CAP", "16384")
+    g = _gpu(ix)
+    for k in (10, 100):
+        Do, Io = port.search(ix, xq, k, nlist, bs, nb)
+        g.profile_enable(True)
+        g.profile_reset()
+        D, I = g.search(xq, k, nlist, bs, nb)
+        p = g.profile_get()
+        assert_parity(Do, Io, D, I, ob.L2, f"long candidate lists k={k}")
+        if k == 10:
+            assert p["mscan_queries"] == nq and p["mscan_candidates"] > 4096 * nq, p
+    g.close()

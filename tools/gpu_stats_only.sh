@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pb_stats
 (timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb_stats -- python $R/bench.py $ARGS) > /tmp/pb_stats.log 2>&1
 python $R/tools/pmc_summary.py /tmp/pb_stats $R/gpurun_out/${TAG}.json
-tail -1 /tmp/pb_stats.log | cut -c1-200
+grep -v "output_stream.cpp\|simple_timer" /tmp/pb_stats.log | tail -12 | cut -c1-300
 python - <<PY
 import json
 d=json.load(open("$R/gpurun_out/${TAG}.json"))["__kernel_stats__"]
