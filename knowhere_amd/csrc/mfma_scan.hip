@@ -1039,7 +1039,8 @@ __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, c
     // k-th best of ANY k candidates is a valid bound; the eps of this kind does not depend on it), the rest is streamed
     // through the same test.  (A query whose sample was unlucky can arrive with the full capacity of candidates: without
     // this it alone took 16 rounds of 1013 exact distances + a 1024-entry sort, the tail of the whole stage.)
-    const int n_head = KIND == 1 ? min(n, MF_THREADS * MF_PRUNE_PER_THREAD) : n;
+    // (PQ codes: the same; the |tau| its eps carries is then bounded through the histogram's origin, see eps_max below)
+    const int n_head = (KIND == 1 || KIND == 2) ? min(n, MF_THREADS * MF_PRUNE_PER_THREAD) : n;
     if ((KIND == 2 || KIND == 1) && a.cand_pess != nullptr && !retry_prep && n >= 2 * k &&
         n_head <= MF_THREADS * MF_PRUNE_PER_THREAD) {
         __shared__ int s_cnt;
@@ -1090,8 +1091,31 @@ __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, c
             s_step[tid] = 0;
         }
         __syncthreads();
-        uint32_t lo = 0u, hi = 0xffffffffu;
-        for (int it = 0; it < 32; it++) {
+        // (the interval starts at the block's own key range: pessimistic distances of one query share their exponent, ~22
+        // steps instead of 32; lo, hi are the same in every thread, so the trip count is uniform)
+        __shared__ uint32_t s_kmin[MF_THREADS / KN_WAVE], s_kmax[MF_THREADS / KN_WAVE];
+        uint32_t kmn = 0xffffffffu, kmx = 0u;
+#pragma unroll
+        for (int u = 0; u < MF_PRUNE_PER_THREAD; u++) {
+            kmn = min(kmn, pk[u]);
+            kmx = (tid + u * MF_THREADS < n_head) ? max(kmx, pk[u]) : kmx;
+        }
+#pragma unroll
+        for (int dlt = KN_WAVE / 2; dlt > 0; dlt >>= 1) {
+            kmn = min(kmn, (uint32_t)__shfl_xor((int)kmn, dlt, KN_WAVE));
+            kmx = max(kmx, (uint32_t)__shfl_xor((int)kmx, dlt, KN_WAVE));
+        }
+        if ((tid & (KN_WAVE - 1)) == 0) {
+            s_kmin[tid / KN_WAVE] = kmn;
+            s_kmax[tid / KN_WAVE] = kmx;
+        }
+        __syncthreads();
+        uint32_t lo = s_kmin[0], hi = s_kmax[0];
+        for (int w = 1; w < MF_THREADS / KN_WAVE; w++) {
+            lo = min(lo, s_kmin[w]);
+            hi = max(hi, s_kmax[w]);
+        }
+        for (int it = 0; it < 32 && lo < hi; it++) {
             const uint32_t mid = lo + ((hi - lo) >> 1);
             int c = 0;
 #pragma unroll
@@ -1120,7 +1144,16 @@ __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, c
         // |dis0| <= cmax; the emission's tau lies between the sample bound gthr and the final k-th pessimistic distance
         // tau2 (a histogram edge is only read once k candidates sit below it), so |tau| <= max(|gthr|, |tau2|); the
         // integer form's per-query offset sum rides in [q][1] of its record
-        float eps_max = eps_q + 64.0f * 5.9604645e-8f * (cmax + fmaxf(gthr_abs, fabsf(tau2)) + eps_mu);
+        float tau_abs = fmaxf(gthr_abs, fabsf(tau2));
+        if (KIND == 2 && n_head < n && a.gmeta != nullptr) {
+            // (tau2 then comes from the head only and may lie above the full list's: every threshold a unit used is gthr or
+            // a histogram edge, and the edges start at the sample's best key)
+            const uint2 mt = a.gmeta[q];
+            if (mt.y != KN_HIST_OFF) {
+                tau_abs = fmaxf(tau_abs, fabsf(dist_key_inv<IS_L2>(mt.x)));
+            }
+        }
+        float eps_max = eps_q + 64.0f * 5.9604645e-8f * (cmax + tau_abs + eps_mu);
         if (KIND == 1) {
             // fp32 rows: every emission of this query used the one eps of mscan_flat*_unit (pess = approx widened by it)
             const float qn = a.qnorm[q];

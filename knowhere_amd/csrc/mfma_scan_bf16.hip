@@ -33,6 +33,7 @@ typedef __bf16 mb_bf4 __attribute__((ext_vector_type(4)));
 
 constexpr int MB_WAVES = 4;
 constexpr int MB_THREADS = MB_WAVES * KN_WAVE;
+constexpr int MB_HITS = 448; // parked hits per unit (7 KB of LDS; more are appended on the spot)
 
 // bytes of one query's split row in LDS: per step of 16 dimensions 16 hi + 16 lo bf16, + 16 bytes so that the rows of
 // consecutive queries start an odd number of 16-byte quads apart (conflict-free ds_read_b128 across a query tile)
@@ -71,7 +72,15 @@ __device__ __forceinline__ void mscan_flatb_unit(const MScanArgs a, const int64_
     float* sC = sT + QT;                                             // [QT] pessimistic distance = c - 2 acc (L2) / acc - c (IP)
     int32_t* sPq = reinterpret_cast<int32_t*>(sC + QT);              // [QT] query of the pair (-1: none)
     int32_t* sPs = sPq + QT;                                         // [QT] slot of the pair
-    for (int j = wave; j < 32 * ntq; j += MB_WAVES) { // wave per pair: the histogram row is read lane = bin
+    int4* sHit = reinterpret_cast<int4*>(sPs + QT);                  // [MB_HITS] parked hits {pair, position, value bits, -}
+    int32_t* sNhit = reinterpret_cast<int32_t*>(sHit + MB_HITS);
+    if (threadIdx.x == 0) {
+        *sNhit = 0;
+    }
+    // thread per pair (32 ntq <= 128 of them): every pair's record, norm, tau and histogram row are requested together --
+    // with a wave per pair, as the fp32 kernel has it, the 32 pairs a wave walks cost a memory round trip each, one
+    // after the other: longer than the unit's scan on this pipe
+    for (int j = threadIdx.x; j < 32 * ntq; j += MB_THREADS) {
         float t = INFINITY, c = 0.f;
         int32_t q = -1, slot = 0;
         if (j < npair) {
@@ -82,35 +91,43 @@ __device__ __forceinline__ void mscan_flatb_unit(const MScanArgs a, const int64_
             const float eps = a.eps_scale * (IS_L2 ? (qn + a.xnorm_max) : sqrtf(qn * a.xnorm_max)) + 1e-30f;
             c = IS_L2 ? qn + eps : eps;
             float tau = a.gthr[q];
-            tau = tighter<IS_L2>(tau, ms_hist_bound<IS_L2>(a, q, a.k));
+            tau = tighter<IS_L2>(tau, ms_hist_bound_lane<IS_L2>(a, q, a.k));
             if (tau == worst_dist<IS_L2>()) {
                 // no bound (fewer than k unfiltered rows in the sample): every row would pass -> exact fallback
-                if (lane == 0) {
-                    a.overflow[q] = 1;
-                    a.overflow[a.nq] = 1;
-                }
+                a.overflow[q] = 1;
+                a.overflow[a.nq] = 1;
             } else {
                 t = IS_L2 ? (qn - tau - eps) * 0.5f : tau - eps;
             }
         }
-        if (lane == 0) {
-            sT[j] = t;
-            sC[j] = c;
-            sPq[j] = q;
-            sPs[j] = slot;
-        }
+        sT[j] = t;
+        sC[j] = c;
+        sPq[j] = q;
+        sPs[j] = slot;
     }
     __syncthreads();
     // the queries, split: thread = (pair, chunk of 4 dims); dims past d and pairs past npair are zero
+    const bool vec4 = (a.d & 3) == 0 && (reinterpret_cast<uintptr_t>(a.queries) & 15) == 0; // (one load per chunk)
+#pragma unroll 4
     for (int t = threadIdx.x; t < 32 * ntq * nstep * 4; t += MB_THREADS) {
         const int j = t / (nstep * 4), c = t % (nstep * 4);
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         if (j < npair) {
             const float* src = a.queries + (int64_t)sPq[j] * a.d + c * 4;
+            if (vec4) {
+                if (c * 4 < a.d) {
+                    const float4 f = *reinterpret_cast<const float4*>(src);
+                    v[0] = f.x;
+                    v[1] = f.y;
+                    v[2] = f.z;
+                    v[3] = f.w;
+                }
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                if (c * 4 + e < a.d) {
-                    v[e] = src[e];
+                for (int e = 0; e < 4; e++) {
+                    if (c * 4 + e < a.d) {
+                        v[e] = src[e];
+                    }
                 }
             }
         }
@@ -146,7 +163,7 @@ __device__ __forceinline__ void mscan_flatb_unit(const MScanArgs a, const int64_
             A[1][e] = p[32];
         }
     };
-    float4 A[2][2][2];
+    float4 A[2][2][2]; // two statically rotating row buffers
     int64_t lb = wave; // load cursor
     int ls = 0;
     auto issue = [&](float4 (&dst)[2][2]) {
@@ -236,7 +253,14 @@ __device__ __forceinline__ void mscan_flatb_unit(const MScanArgs a, const int64_
                                 }
                                 const int64_t pos = b * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                                 if (pos < len) {
-                                    ms_emit<IS_L2>(a, q, slot, row_off, pos, IS_L2 ? c - 2.0f * v : v - c);
+                                    // parked: the append's global atomics (a round trip each, with the wave waiting) run at
+                                    // the unit's end, all in flight together
+                                    const int at = atomicAdd(sNhit, 1);
+                                    if (at < MB_HITS) {
+                                        sHit[at] = make_int4(qt * 32 + lr, (int)pos, __float_as_int(v), 0);
+                                    } else {
+                                        ms_emit<IS_L2>(a, q, slot, row_off, pos, IS_L2 ? c - 2.0f * v : v - c);
+                                    }
                                 }
                             }
                         }
@@ -245,6 +269,8 @@ __device__ __forceinline__ void mscan_flatb_unit(const MScanArgs a, const int64_
             }
         }
     };
+    // (loads one step ahead.  Two steps ahead -- three buffers, 240 registers -- was measured and changes nothing: 2.845
+    // against 2.815 ms at C2; the bytes in flight are not what limits the kernel)
     issue(A[0]);
     int64_t b = wave; // compute cursor
     int s = 0;
@@ -266,6 +292,13 @@ __device__ __forceinline__ void mscan_flatb_unit(const MScanArgs a, const int64_
                 init_acc(b);
             }
         }
+    }
+    __syncthreads();
+    const int nhit = min(*sNhit, MB_HITS);
+    for (int i = threadIdx.x; i < nhit; i += MB_THREADS) {
+        const int4 h = sHit[i];
+        const float v = __int_as_float(h.z), c = sC[h.x];
+        ms_emit<IS_L2>(a, sPq[h.x], sPs[h.x], row_off, (int64_t)h.y, IS_L2 ? c - 2.0f * v : v - c);
     }
 }
 
@@ -295,7 +328,7 @@ __global__ __launch_bounds__(MB_THREADS, 2) void mscan_flatb_kernel(MScanArgs a)
 // queries per unit: 128 while two workgroups' split queries fit a CU's LDS side by side with room to spare, else 64;
 // 0 = the shape is not served (the fp32 kernel's own limit, d <= 608)
 int mscan_flat_bf16_qt(int nstep) {
-    auto bytes = [&](int qt) { return (size_t)qt * mb_pitch(nstep) + (size_t)qt * 16; };
+    auto bytes = [&](int qt) { return (size_t)qt * mb_pitch(nstep) + (size_t)qt * 16 + (size_t)MB_HITS * 16 + 16; };
     if (bytes(128) <= 80 * 1024) {
         return 128;
     }
@@ -304,7 +337,7 @@ int mscan_flat_bf16_qt(int nstep) {
 
 size_t mscan_flat_bf16_smem(int nstep) {
     const int qt = mscan_flat_bf16_qt(nstep);
-    return (size_t)qt * mb_pitch(nstep) + (size_t)qt * 16;
+    return (size_t)qt * mb_pitch(nstep) + (size_t)qt * 16 + (size_t)MB_HITS * 16 + 16;
 }
 
 template <int NQT>

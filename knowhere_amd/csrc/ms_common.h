@@ -91,6 +91,47 @@ __device__ __forceinline__ float ms_hist_bound(const MScanArgs& a, int32_t q, in
     return ms_hist_eval<IS_L2>(h, k);
 }
 
+// The same bound evaluated by ONE lane for its own query (a unit's prologue: one thread per pair, every pair's loads in
+// flight together, instead of one wave per pair and a memory round trip per pair one after the other).  64-bit relaxed
+// atomic loads at agent scope, like ms_hist_load: counts that other CUs bumped a moment ago are seen (a stale row would
+// only loosen the bound).
+template <bool IS_L2>
+__device__ __forceinline__ float ms_hist_bound_lane(const MScanArgs& a, int32_t q, int k) {
+    float bound = worst_dist<IS_L2>();
+    if (a.ghist == nullptr || q < 0) {
+        return bound;
+    }
+    const uint2 mt = a.gmeta[q];
+    if (mt.y == KN_HIST_OFF) {
+        return bound;
+    }
+    const unsigned long long* hp = reinterpret_cast<const unsigned long long*>(a.ghist + (int64_t)q * KN_HIST_BINS);
+    unsigned long long w[KN_HIST_BINS / 2];
+#pragma unroll
+    for (int i = 0; i < KN_HIST_BINS / 2; i++) {
+        w[i] = __hip_atomic_load(hp + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    uint32_t cum = 0;
+    int b = KN_HIST_BINS;
+#pragma unroll
+    for (int i = 0; i < KN_HIST_BINS / 2; i++) {
+        cum += (uint32_t)w[i];
+        b = (b == KN_HIST_BINS && cum >= (uint32_t)k) ? 2 * i : b;
+        cum += (uint32_t)(w[i] >> 32);
+        b = (b == KN_HIST_BINS && cum >= (uint32_t)k) ? 2 * i + 1 : b;
+    }
+    if (b < KN_HIST_BINS - 1) { // (the last bin also collects everything beyond the range)
+        const unsigned long long edge = (unsigned long long)mt.x + (((unsigned long long)b + 1ull) << mt.y) - 1ull;
+        if (edge < 0xffffffffull) {
+            const float e = dist_key_inv<IS_L2>((uint32_t)edge);
+            if (e == e && fabsf(e) < FLT_MAX) {
+                bound = e;
+            }
+        }
+    }
+    return bound;
+}
+
 // 64-bit mask of the block's rows that take part (inside the list, not filtered): lane = row
 __device__ __forceinline__ unsigned long long ms_valid_rows(const MScanArgs& a, int64_t b, int64_t len, int64_t row_off) {
     const int64_t row = b * 64 + lane_id();

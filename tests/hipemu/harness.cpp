@@ -99,7 +99,7 @@ extern "C" int emu_pqf_search(int64_t nlist, const int64_t* list_len, const int6
     // ---- sample plan (emulated kernel), units of the sampled pairs -----------------------------------------------------
     const int sample = mscan_sample_rows();
     std::vector<int32_t> sample_off((size_t)nq * nprobe), n_row((size_t)nq);
-    if (launch_ms_sample_plan(keys, nq, nprobe, nlist, list_len, std::max(1024, 8 * k), sample_off.data(), n_row.data(), nullptr) != hipSuccess) return 4;
+    if (launch_ms_sample_plan(keys, nq, nprobe, nlist, list_len, std::max(1024, 8 * k), sample, sample_off.data(), n_row.data(), nullptr) != hipSuccess) return 4;
     std::vector<KnPair> pairs;
     std::vector<KnItem> units;
     make_units(keys, sample_off.data(), nq, nprobe, nlist, list_len, true, pairs, units);
