@@ -72,7 +72,7 @@ __device__ __forceinline__ void mscan_flatb_unit(const MScanArgs a, const int64_
     float* sC = sT + QT;                                             // [QT] pessimistic distance = c - 2 acc (L2) / acc - c (IP)
     int32_t* sPq = reinterpret_cast<int32_t*>(sC + QT);              // [QT] query of the pair (-1: none)
     int32_t* sPs = sPq + QT;                                         // [QT] slot of the pair
-    int4* sHit = reinterpret_cast<int4*>(sPs + QT);                  // [MB_HITS] parked hits {pair, position, value bits, -}
+    uint4* sHit = reinterpret_cast<uint4*>(sPs + QT);                  // [MB_HITS] parked hits {pair, position, value bits, -}
     int32_t* sNhit = reinterpret_cast<int32_t*>(sHit + MB_HITS);
     if (threadIdx.x == 0) {
         *sNhit = 0;
@@ -257,7 +257,7 @@ __device__ __forceinline__ void mscan_flatb_unit(const MScanArgs a, const int64_
                                     // the unit's end, all in flight together
                                     const int at = atomicAdd(sNhit, 1);
                                     if (at < MB_HITS) {
-                                        sHit[at] = make_int4(qt * 32 + lr, (int)pos, __float_as_int(v), 0);
+                                        sHit[at] = make_uint4((uint32_t)(qt * 32 + lr), (uint32_t)pos, __float_as_uint(v), 0u);
                                     } else {
                                         ms_emit<IS_L2>(a, q, slot, row_off, pos, IS_L2 ? c - 2.0f * v : v - c);
                                     }
@@ -296,8 +296,8 @@ __device__ __forceinline__ void mscan_flatb_unit(const MScanArgs a, const int64_
     __syncthreads();
     const int nhit = min(*sNhit, MB_HITS);
     for (int i = threadIdx.x; i < nhit; i += MB_THREADS) {
-        const int4 h = sHit[i];
-        const float v = __int_as_float(h.z), c = sC[h.x];
+        const uint4 h = sHit[i];
+        const float v = __uint_as_float(h.z), c = sC[h.x];
         ms_emit<IS_L2>(a, sPq[h.x], sPs[h.x], row_off, (int64_t)h.y, IS_L2 ? c - 2.0f * v : v - c);
     }
 }
