@@ -275,15 +275,22 @@ int knhip_search_refine(const knhip_index* idx, const knhip_index* raw, const fl
  *   bf16: (bits + 0x8000) >> 16 (utils/bf16.h:27-32);
  *   sq8:  per-dimension ranges trained over ALL training rows (ScalarQuantizer::train, RS_minmax, rangestat_arg 0),
  *         code_i = (int)(255 * clamp((x_i - vmin_i) / vdiff_i, 0, 1)), x_i = vmin_i + vdiff_i * ((code_i + 0.5) / 255)
- *         (impl/scalar_quantizer/quantizers.h:108-146, codecs.h:26-41).
+ *         (impl/scalar_quantizer/quantizers.h:108-146, codecs.h:26-41);
+ *   sq6:  (round 5) the same ranges, 6-bit codes, four per three bytes: code_i = (int)((double)xi * 63.0),
+ *         x_i = vmin_i + vdiff_i * ((code_i + 0.5) / 63) (Codec6bit, codecs.h:63-118); code_size = (6 d + 7) / 8;
+ *   int8: (round 5) QT_8bit_direct_signed, Knowhere's int8 data format: code_i = (uint8_t)(x_i + 128) for values in
+ *         [-128, 127], x_i = code_i - 128 (quantizers.h:350-379); nothing to train.  Distances through the float-domain
+ *         distance computer (SIMDLevel::NONE; AVX2 / AVX-512 builds of the reference switch to an integer-domain computer
+ *         that truncates the QUERY to bytes, sq-dispatch.h:543-560 -- not restated).
+ * `sq4u` (QT_4bit_uniform with quantile-trained ranges for L2) is the one refine type of refine_utils.cc:20-26 without a store.
  * knhip_search_refine_rows = knhip_search_refine with the second stage reading this store through the scalar quantizer's
  * distance computer (sequential: decode x_i, then (q_i - x_i)^2 / q_i * x_i added in order): bit-equal to the reference.
  * get_codes / add_codes move the faiss code bytes (Serialize / Deserialize: "IxSQ" inside "IxRF"). */
 typedef struct knhip_rows knhip_rows;
-enum { KNHIP_ROWS_FP16 = 1, KNHIP_ROWS_BF16 = 2, KNHIP_ROWS_SQ8 = 3 };
+enum { KNHIP_ROWS_FP16 = 1, KNHIP_ROWS_BF16 = 2, KNHIP_ROWS_SQ8 = 3, KNHIP_ROWS_SQ6 = 4, KNHIP_ROWS_INT8 = 5 };
 int knhip_rows_create(int32_t device, int32_t dim, int32_t row_type, knhip_rows** out);
 void knhip_rows_destroy(knhip_rows* rows);
-int knhip_rows_train(knhip_rows* rows, int64_t n, const float* x);                 /* sq8 ranges; a no-op for the 16-bit types */
+int knhip_rows_train(knhip_rows* rows, int64_t n, const float* x);                 /* sq8 / sq6 ranges; a no-op otherwise */
 int knhip_rows_set_trained(knhip_rows* rows, const float* vmin, const float* vdiff);
 int knhip_rows_get_trained(const knhip_rows* rows, float* vmin, float* vdiff);
 int knhip_rows_add(knhip_rows* rows, int64_t n, const float* x);                   /* encode + append (host fp32 rows) */

@@ -556,6 +556,8 @@ hipError_t launch_refine(const float* base, int64_t nbase, int64_t id_base, int 
                          int64_t* out_i, hipStream_t s, int row_type = 0, const float* sq_trained = nullptr,
                          const float* dist_in = nullptr, float* dist_out = nullptr);
 hipError_t launch_rows_encode16(const float* x, int64_t n_elems, bool bf16, uint16_t* out, hipStream_t s);
+hipError_t launch_rows_encode6(const float* x, int64_t n, int d, const float* trained, uint8_t* out, hipStream_t s);
+hipError_t launch_rows_encode_i8(const float* x, int64_t n_elems, uint8_t* out, hipStream_t s);
 
 // ---- build.hip: Train / Add on the device ----
 // direct map of an IVF-Flat index (GetVectorByIds): ids sorted with the columns of their rows in the interleaved store

@@ -2133,13 +2133,17 @@ struct knhip_rows {
     DevBuf codes;      // [n][code_size]
     DevBuf sq;         // vmin[d], vdiff[d] (sq8)
     std::mutex mu;
-    int64_t code_size() const { return row_type == KNHIP_ROWS_SQ8 ? d : 2 * (int64_t)d; }
+    bool ranged() const { return row_type == KNHIP_ROWS_SQ8 || row_type == KNHIP_ROWS_SQ6; } // per-dimension vmin / vdiff
+    int64_t code_size() const {
+        return row_type == KNHIP_ROWS_SQ6 ? ((int64_t)d * 6 + 7) / 8
+             : (row_type == KNHIP_ROWS_SQ8 || row_type == KNHIP_ROWS_INT8) ? (int64_t)d : 2 * (int64_t)d;
+    }
 };
 
 extern "C" {
 
 int knhip_rows_create(int32_t device, int32_t dim, int32_t row_type, knhip_rows** out) {
-    if (!out || dim <= 0 || (row_type != KNHIP_ROWS_FP16 && row_type != KNHIP_ROWS_BF16 && row_type != KNHIP_ROWS_SQ8)) {
+    if (!out || dim <= 0 || row_type < KNHIP_ROWS_FP16 || row_type > KNHIP_ROWS_INT8) {
         return fail(KNHIP_ERR_INVALID_ARGS, "rows_create: dim > 0 and row type fp16 / bf16 / sq8");
     }
     if (device < 0 || device >= knhip_device_count()) {
@@ -2149,7 +2153,7 @@ int knhip_rows_create(int32_t device, int32_t dim, int32_t row_type, knhip_rows*
     r->device = device;
     r->d = dim;
     r->row_type = row_type;
-    r->trained = row_type != KNHIP_ROWS_SQ8; // (the 16-bit types have nothing to train)
+    r->trained = !r->ranged(); // (fp16 / bf16 / int8 have nothing to train)
     *out = r;
     return KNHIP_OK;
 }
@@ -2166,8 +2170,8 @@ int64_t knhip_rows_code_size(const knhip_rows* r) { return r ? r->code_size() : 
 int64_t knhip_rows_device_bytes(const knhip_rows* r) { return r ? (int64_t)(r->codes.bytes + r->sq.bytes) : 0; }
 
 int knhip_rows_set_trained(knhip_rows* r, const float* vmin, const float* vdiff) {
-    if (!r || r->row_type != KNHIP_ROWS_SQ8 || !vmin || !vdiff) {
-        return fail(KNHIP_ERR_INVALID_ARGS, "rows_set_trained: an sq8 store and two arrays of dim floats");
+    if (!r || !r->ranged() || !vmin || !vdiff) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "rows_set_trained: an sq8 / sq6 store and two arrays of dim floats");
     }
     DeviceGuard g(r->device);
     std::lock_guard<std::mutex> lk(r->mu);
@@ -2179,8 +2183,8 @@ int knhip_rows_set_trained(knhip_rows* r, const float* vmin, const float* vdiff)
 }
 
 int knhip_rows_get_trained(const knhip_rows* r, float* vmin, float* vdiff) {
-    if (!r || r->row_type != KNHIP_ROWS_SQ8 || !r->trained || !vmin || !vdiff) {
-        return fail(KNHIP_ERR_NOT_TRAINED, "rows_get_trained: a trained sq8 store");
+    if (!r || !r->ranged() || !r->trained || !vmin || !vdiff) {
+        return fail(KNHIP_ERR_NOT_TRAINED, "rows_get_trained: a trained sq8 / sq6 store");
     }
     DeviceGuard g(r->device);
     HIP_TRY(hipMemcpy(vmin, r->sq.p, (size_t)r->d * sizeof(float), hipMemcpyDeviceToHost));
@@ -2188,13 +2192,13 @@ int knhip_rows_get_trained(const knhip_rows* r, float* vmin, float* vdiff) {
     return KNHIP_OK;
 }
 
-// ScalarQuantizer::train, QT_8bit, RS_minmax with rangestat_arg 0 (impl/ScalarQuantizer.cpp train_NonUniform): vmin = column
+// ScalarQuantizer::train, QT_8bit / QT_6bit, RS_minmax with rangestat_arg 0 (impl/ScalarQuantizer.cpp train_NonUniform): vmin = column
 // minimum, vdiff = column maximum - vmin over ALL n rows (no sub-sampling for RS_minmax)
 int knhip_rows_train(knhip_rows* r, int64_t n, const float* x) {
     if (!r || n < 0 || (n > 0 && !x)) {
         return fail(KNHIP_ERR_INVALID_ARGS, "rows_train: bad arguments");
     }
-    if (r->row_type != KNHIP_ROWS_SQ8) {
+    if (!r->ranged()) {
         return KNHIP_OK;
     }
     if (n == 0) {
@@ -2246,7 +2250,7 @@ int knhip_rows_add(knhip_rows* r, int64_t n, const float* x) {
         return fail(KNHIP_ERR_INVALID_ARGS, "rows_add: bad arguments");
     }
     if (!r->trained) {
-        return fail(KNHIP_ERR_NOT_TRAINED, "rows_add: the sq8 ranges are not trained");
+        return fail(KNHIP_ERR_NOT_TRAINED, "rows_add: the ranges are not trained");
     }
     if (n == 0) {
         return KNHIP_OK;
@@ -2262,6 +2266,10 @@ int knhip_rows_add(knhip_rows* r, int64_t n, const float* x) {
         HIP_TRY(dc.alloc((size_t)m * r->code_size()));
         if (r->row_type == KNHIP_ROWS_SQ8) {
             HIP_TRY(launch_sq8_encode(dx.as<float>(), m, d, r->sq.as<float>(), dc.as<uint8_t>(), nullptr));
+        } else if (r->row_type == KNHIP_ROWS_SQ6) {
+            HIP_TRY(launch_rows_encode6(dx.as<float>(), m, d, r->sq.as<float>(), dc.as<uint8_t>(), nullptr));
+        } else if (r->row_type == KNHIP_ROWS_INT8) {
+            HIP_TRY(launch_rows_encode_i8(dx.as<float>(), m * d, dc.as<uint8_t>(), nullptr));
         } else {
             HIP_TRY(launch_rows_encode16(dx.as<float>(), m * d, r->row_type == KNHIP_ROWS_BF16, dc.as<uint16_t>(), nullptr));
         }
@@ -2311,7 +2319,7 @@ int knhip_search_refine_rows(const knhip_index* idx, const knhip_rows* rows, con
     st.n = rows->n;
     st.id0 = 0;
     st.row_type = rows->row_type;
-    st.sq = rows->row_type == KNHIP_ROWS_SQ8 ? rows->sq.as<float>() : nullptr;
+    st.sq = rows->ranged() ? rows->sq.as<float>() : nullptr;
     return search_host_impl(idx, &st, queries, nq, k, k_base, nprobe, bitset, bitset_nbits, out_ids, out_dist);
 }
 
@@ -3113,7 +3121,7 @@ int knhip_refine_rows_distances_device(int32_t metric, const knhip_rows* rows, i
     }
     HIP_TRY(launch_refine(static_cast<const float*>(rows->codes.p), rows->n, id_base, rows->d, d_queries, nq, d_cand_ids, k_base,
                           1, metric == KNHIP_L2, nullptr, nullptr, static_cast<hipStream_t>(stream), rows->row_type,
-                          rows->row_type == KNHIP_ROWS_SQ8 ? rows->sq.as<float>() : nullptr, nullptr, d_out_dist));
+                          rows->ranged() ? rows->sq.as<float>() : nullptr, nullptr, d_out_dist));
     return KNHIP_OK;
 }
 
@@ -3423,7 +3431,7 @@ int knhip_refine_rows_device(int32_t metric, const knhip_rows* rows, int64_t id_
     }
     HIP_TRY(launch_refine(static_cast<const float*>(rows->codes.p), rows->n, id_base, rows->d, d_queries, nq, d_cand_ids, k_base,
                           k, metric == KNHIP_L2, d_out_dist, d_out_ids, static_cast<hipStream_t>(stream), rows->row_type,
-                          rows->row_type == KNHIP_ROWS_SQ8 ? rows->sq.as<float>() : nullptr));
+                          rows->ranged() ? rows->sq.as<float>() : nullptr));
     return KNHIP_OK;
 }
 

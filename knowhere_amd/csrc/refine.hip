@@ -27,7 +27,8 @@ namespace knhip {
 
 constexpr uint32_t REFINE_NOT_HERE = 0xffffffffu; // a NaN pattern no arithmetic produces: "this shard does not hold the row"
 
-// ROWT: 0 fp32 rows, 1 fp16, 2 bf16, 3 per-dimension 8-bit codes (sq = vmin[d], vdiff[d])
+// ROWT: 0 fp32 rows, 1 fp16, 2 bf16, 3 per-dimension 8-bit codes (sq = vmin[d], vdiff[d]), 4 per-dimension 6-bit codes (four
+// per three bytes: Codec6bit, codecs.h:63-118), 5 signed bytes stored + 128 (Quantizer8bitDirectSigned, quantizers.h:350-379)
 template <int ROWT>
 __device__ __forceinline__ float refine_row_value(const void* row, int i, const float* __restrict__ sq, int d) {
     if (ROWT == 1) {
@@ -40,7 +41,27 @@ __device__ __forceinline__ float refine_row_value(const void* row, int i, const 
         const float xi = __fdiv_rn(fadd_x((float)reinterpret_cast<const uint8_t*>(row)[i], 0.5f), 255.0f);
         return fadd_x(sq[i], fmul_x(xi, sq[d + i]));
     }
+    if (ROWT == 4) {
+        const uint8_t* g = reinterpret_cast<const uint8_t*>(row) + (i >> 2) * 3;
+        uint32_t bits;
+        switch (i & 3) {
+            case 0: bits = g[0] & 0x3fu; break;
+            case 1: bits = ((uint32_t)g[0] >> 6) | (((uint32_t)g[1] & 0xfu) << 2); break;
+            case 2: bits = ((uint32_t)g[1] >> 4) | (((uint32_t)g[2] & 3u) << 4); break;
+            default: bits = (uint32_t)g[2] >> 2; break;
+        }
+        const float xi = __fdiv_rn(fadd_x((float)bits, 0.5f), 63.0f);
+        return fadd_x(sq[i], fmul_x(xi, sq[d + i]));
+    }
+    if (ROWT == 5) {
+        return (float)((int)reinterpret_cast<const uint8_t*>(row)[i] - 128);
+    }
     return reinterpret_cast<const float*>(row)[i];
+}
+
+// bytes of one stored row
+__host__ __device__ inline int64_t refine_row_bytes(int row_type, int d) {
+    return row_type == 4 ? ((int64_t)d * 6 + 7) / 8 : (row_type == 3 || row_type == 5) ? (int64_t)d : row_type == 0 ? 4 * (int64_t)d : 2 * (int64_t)d;
 }
 
 template <bool IS_L2, int R, int ROWT>
@@ -101,11 +122,12 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ b
         skipped = skipped || __ballot(lane < nvalid && !ok) != 0ull;
         if (ok && ROWT != 0 && dist_in == nullptr) {
             // quantised rows: decode + accumulate, element by element in the reference's order
-            constexpr int ESZ = ROWT == 3 ? 1 : 2;
+            constexpr int ESZ = (ROWT == 3 || ROWT == 5) ? 1 : 2;
             constexpr int EPC = 16 / ESZ; // elements per 16-byte piece
-            const unsigned char* y = reinterpret_cast<const unsigned char*>(base) + (id - id_base) * (int64_t)d * ESZ;
+            const unsigned char* y = reinterpret_cast<const unsigned char*>(base) + (id - id_base) * refine_row_bytes(ROWT, d);
             int i = 0;
-            if (((d * ESZ) & 15) == 0 && (reinterpret_cast<uintptr_t>(base) & 15) == 0) {
+            // (6-bit codes straddle bytes: the element loop below)
+            if (ROWT != 4 && ((d * ESZ) & 15) == 0 && (reinterpret_cast<uintptr_t>(base) & 15) == 0) {
                 // 16-byte loads, eight in flight per lane (as the fp32 rows below); decoded and added in element order
                 const uint4* y4 = reinterpret_cast<const uint4*>(y);
                 const int n16 = (d * ESZ) >> 4;
@@ -126,6 +148,8 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ b
                                 if (ROWT == 3) {
                                     const float xi = __fdiv_rn(fadd_x((float)((w[e >> 2] >> (8 * (e & 3))) & 0xffu), 0.5f), 255.0f);
                                     x = fadd_x(sq_trained[col], fmul_x(xi, sq_trained[d + col]));
+                                } else if (ROWT == 5) {
+                                    x = (float)((int)((w[e >> 2] >> (8 * (e & 3))) & 0xffu) - 128);
                                 } else {
                                     const uint32_t hb = (w[e >> 1] >> (16 * (e & 1))) & 0xffffu;
                                     x = ROWT == 1 ? (float)__builtin_bit_cast(_Float16, (uint16_t)hb) : __uint_as_float(hb << 16);
@@ -258,7 +282,7 @@ hipError_t launch_refine(const float* base, int64_t nbase, int64_t id_base, int 
     if (nq <= 0) {
         return hipSuccess;
     }
-    if (row_type < 0 || row_type > 3 || (row_type == 3 && sq_trained == nullptr && dist_in == nullptr) ||
+    if (row_type < 0 || row_type > 5 || ((row_type == 3 || row_type == 4) && sq_trained == nullptr && dist_in == nullptr) ||
         (dist_in != nullptr && dist_out != nullptr)) {
         return hipErrorInvalidValue;
     }
@@ -293,6 +317,8 @@ hipError_t launch_refine(const float* base, int64_t nbase, int64_t id_base, int 
         case 1: KN_REFINE_LAUNCH(1); break;
         case 2: KN_REFINE_LAUNCH(2); break;
         case 3: KN_REFINE_LAUNCH(3); break;
+        case 4: KN_REFINE_LAUNCH(4); break;
+        case 5: KN_REFINE_LAUNCH(5); break;
         default: KN_REFINE_LAUNCH(0); break;
     }
 #undef KN_REFINE_LAUNCH
@@ -338,6 +364,71 @@ hipError_t launch_rows_encode16(const float* x, int64_t n_elems, bool bf16, uint
     }
     hipLaunchKernelGGL(rows_encode16_kernel, dim3((unsigned)((n_elems + 255) / 256)), dim3(256), 0, s, x, n_elems, bf16 ? 1 : 0,
                        out);
+    return hipGetLastError();
+}
+
+// QT_6bit (QuantizerTemplate<Codec6bit, NON_UNIFORM>::encode_vector, quantizers.h:124-137): xi = (x - vmin) / vdiff clamped to
+// [0, 1] (0 where vdiff == 0), bits = (int)(xi * 63.0) -- a DOUBLE product in the reference, exact for a float in [0, 1], so
+// the truncation never sees a rounded-up product --, four codes packed into three bytes.  Thread per group of four dimensions.
+__global__ void rows_encode6_kernel(const float* __restrict__ x, int64_t n, int d, const float* __restrict__ trained,
+                                    uint8_t* __restrict__ out) {
+    const int ngrp = (d + 3) >> 2;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * ngrp) {
+        return;
+    }
+    const int64_t r = t / ngrp;
+    const int g = (int)(t % ngrp);
+    const int64_t cs = ((int64_t)d * 6 + 7) / 8;
+    uint32_t b[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const int i = 4 * g + e;
+        if (i < d) {
+            float xi = 0.f;
+            const float vd = trained[d + i];
+            if (vd != 0.f) {
+                xi = __fdiv_rn(fsub_x(x[r * d + i], trained[i]), vd);
+                xi = xi < 0.f ? 0.f : xi;
+                xi = xi > 1.0f ? 1.0f : xi;
+            }
+            b[e] = (uint32_t)(int)((double)xi * 63.0);
+        }
+    }
+    const uint32_t w = b[0] | (b[1] << 6) | (b[2] << 12) | (b[3] << 18);
+    uint8_t* o = out + r * cs + (int64_t)g * 3;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        if ((int64_t)g * 3 + j < cs) { // (a ragged last group owns fewer than three bytes)
+            o[j] = (uint8_t)(w >> (8 * j));
+        }
+    }
+}
+
+// QT_8bit_direct_signed (Quantizer8bitDirectSigned::encode_vector, quantizers.h:362-366): code = (uint8_t)(x + 128); defined
+// for values in [-128, 127]
+__global__ void rows_encode_i8_kernel(const float* __restrict__ x, int64_t n, uint8_t* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) {
+        return;
+    }
+    out[t] = (uint8_t)(int)fadd_x(x[t], 128.0f);
+}
+
+hipError_t launch_rows_encode6(const float* x, int64_t n, int d, const float* trained, uint8_t* out, hipStream_t s) {
+    const int64_t nt = n * ((d + 3) >> 2);
+    if (nt <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(rows_encode6_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, x, n, d, trained, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_rows_encode_i8(const float* x, int64_t n_elems, uint8_t* out, hipStream_t s) {
+    if (n_elems <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(rows_encode_i8_kernel, dim3((unsigned)((n_elems + 255) / 256)), dim3(256), 0, s, x, n_elems, out);
     return hipGetLastError();
 }
 

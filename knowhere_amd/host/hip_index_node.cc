@@ -270,7 +270,8 @@ class HipIndexNode : public IndexNode {
         if constexpr (Kind == KNHIP_IVF_PQ || Kind == KNHIP_IVF_SQ8) {
             // a refine index is built iff `refine` AND `refine_type` are given (ivf_wrapper.cc:170, :214).  refine_type
             // (ivf_config.h:64-76, refine_utils.cc:20-58): fp32 / flat = IndexRefineFlat over the raw rows; fp16 / bf16 / sq8
-            // = IndexRefine over an IndexScalarQuantizer store of the rows (knhip_rows); sq6 is refused, not replaced
+            // / sq6 / int8 = IndexRefine over an IndexScalarQuantizer store of the rows (knhip_rows); sq4u (quantile-trained
+            // uniform range) is refused, not replaced
             has_refine_ = c.refine.value_or(false) && c.refine_type.has_value();
             refine_rows_type_ = 0;
             if (has_refine_) {
@@ -282,9 +283,13 @@ class HipIndexNode : public IndexNode {
                     refine_rows_type_ = KNHIP_ROWS_BF16;
                 } else if (t == "sq8") {
                     refine_rows_type_ = KNHIP_ROWS_SQ8;
+                } else if (t == "sq6") {
+                    refine_rows_type_ = KNHIP_ROWS_SQ6;
+                } else if (t == "int8") {
+                    refine_rows_type_ = KNHIP_ROWS_INT8;
                 } else if (t != "fp32" && t != "flat") {
                     LOG_KNOWHERE_ERROR_ << TypeName() << ": refine_type " << c.refine_type.value()
-                                        << " is not supported (fp32 / flat / fp16 / bf16 / sq8)";
+                                        << " is not supported (fp32 / flat / fp16 / bf16 / sq8 / sq6 / int8)";
                     return Status::invalid_args;
                 }
             }
@@ -771,11 +776,17 @@ class HipIndexNode : public IndexNode {
                 fill_hdr(x.refine_hdr, count, cosine_);
                 FaissSQFlat& sq = x.refine_sq;
                 fill_hdr(sq.hdr, count, false);
-                sq.qtype = refine_rows_type_ == KNHIP_ROWS_FP16 ? 4 : (refine_rows_type_ == KNHIP_ROWS_BF16 ? 7 : 0);
+                // (ScalarQuantizer::QuantizerType, impl/ScalarQuantizer.h:27-40: QT_8bit 0, QT_fp16 4, QT_6bit 6, QT_bf16 7,
+                // QT_8bit_direct_signed 8)
+                sq.qtype = refine_rows_type_ == KNHIP_ROWS_FP16   ? 4
+                           : refine_rows_type_ == KNHIP_ROWS_BF16 ? 7
+                           : refine_rows_type_ == KNHIP_ROWS_SQ6  ? 6
+                           : refine_rows_type_ == KNHIP_ROWS_INT8 ? 8
+                                                                  : 0;
                 sq.rangestat = 0;  // RS_minmax, rangestat_arg 0: the ScalarQuantizer defaults
                 sq.d = (uint64_t)dim_;
                 sq.code_size = (uint64_t)knhip_rows_code_size(rs);
-                if (refine_rows_type_ == KNHIP_ROWS_SQ8) {
+                if (RowsRanged()) {
                     sq.trained.resize((size_t)2 * dim_);
                     if ((rc = knhip_rows_get_trained(rs, sq.trained.data(), sq.trained.data() + dim_))) return ToStatus(rc);
                 }
@@ -922,6 +933,8 @@ class HipIndexNode : public IndexNode {
         refine_rows_type_ = !(x.has_refine && x.refine_is_sq) ? 0
                             : x.refine_sq.qtype == 4          ? KNHIP_ROWS_FP16
                             : x.refine_sq.qtype == 7          ? KNHIP_ROWS_BF16
+                            : x.refine_sq.qtype == 6          ? KNHIP_ROWS_SQ6
+                            : x.refine_sq.qtype == 8          ? KNHIP_ROWS_INT8
                                                               : KNHIP_ROWS_SQ8;
         row_scale_by_id_ = std::move(scale_by_id);
         if (Status st = CreateShards(devs); st != Status::success) return st;
@@ -970,7 +983,7 @@ class HipIndexNode : public IndexNode {
             const FaissSQFlat& sq = x.refine_sq;
             if ((rc = CreateRowStores())) return bail(rc);
             for (int r = 0; r < W; r++) {
-                if (refine_rows_type_ == KNHIP_ROWS_SQ8 &&
+                if (RowsRanged() &&
                     (rc = knhip_rows_set_trained(sh_[r].rows.p, sq.trained.data(), sq.trained.data() + dim_)))
                     return bail(rc);
                 const int64_t lo = ntotal * r / W, hi = ntotal * (r + 1) / W;
@@ -1270,10 +1283,15 @@ class HipIndexNode : public IndexNode {
         }
         return KNHIP_OK;
     }
-    // the sq8 ranges trained on the first device -> every other store (all devices decode alike)
+    // refine stores with per-dimension ranges (sq8, sq6)
+    bool
+    RowsRanged() const {
+        return refine_rows_type_ == KNHIP_ROWS_SQ8 || refine_rows_type_ == KNHIP_ROWS_SQ6;
+    }
+    // the ranges trained on the first device -> every other store (all devices decode alike)
     int
     ReplicateRowRanges() {
-        if (refine_rows_type_ != KNHIP_ROWS_SQ8 || sh_.size() < 2) return KNHIP_OK;
+        if (!RowsRanged() || sh_.size() < 2) return KNHIP_OK;
         std::vector<float> tr((size_t)2 * dim_);
         if (int rc = knhip_rows_get_trained(sh_[0].rows.p, tr.data(), tr.data() + dim_)) return rc;
         for (size_t r = 1; r < sh_.size(); r++) {

@@ -522,7 +522,7 @@ def refine_device(metric, base_t, xq_t, cand_ids_t, k, id_base=0, stream=None):
     return D, I
 
 
-ROWS_FP16, ROWS_BF16, ROWS_SQ8 = 1, 2, 3
+ROWS_FP16, ROWS_BF16, ROWS_SQ8, ROWS_SQ6, ROWS_INT8 = 1, 2, 3, 4, 5
 
 
 class RowStore:

@@ -23,6 +23,11 @@ _i64p = C.POINTER(C.c_int64)
 _u8p = C.POINTER(C.c_uint8)
 
 
+def rows_code_size(row_type, d):
+    """bytes per row of a quantised refine store: 1 fp16, 2 bf16 (2 d); 3 sq8, 5 int8 (d); 4 sq6 (four values per 3 bytes)"""
+    return (d * 6 + 7) // 8 if row_type == 4 else (d if row_type in (3, 5) else 2 * d)
+
+
 def _p(a, t):
     if a is None:
         return None
@@ -384,7 +389,7 @@ class Port(_SimdTable):
                             C.c_int64(k), _p(D, _f32p), _p(I, _i64p))
         return D, I
 
-    # ---- quantised refine store (row_type 1 fp16, 2 bf16, 3 sq8)
+    # ---- quantised refine store (row_type 1 fp16, 2 bf16, 3 sq8, 4 sq6, 5 int8 = QT_8bit_direct_signed)
     def rows_train(self, x):
         x = np.ascontiguousarray(x, np.float32)
         tr = np.empty(2 * x.shape[1], np.float32)
@@ -394,7 +399,7 @@ class Port(_SimdTable):
     def rows_encode(self, row_type, x, trained=None):
         x = np.ascontiguousarray(x, np.float32)
         n, d = x.shape
-        cs = d if row_type == 3 else 2 * d
+        cs = rows_code_size(row_type, d)
         codes = np.empty((n, cs), np.uint8)
         self.lib.orc_rows_encode(C.c_int(row_type), C.c_int(d), C.c_int64(n), _p(x, _f32p), _p(trained, _f32p),
                                  _p(codes, _u8p))
@@ -719,7 +724,7 @@ class Ref(_SimdTable):
         """(codes, trained) of the IndexScalarQuantizer Knowhere builds as the refine index for fp16 / bf16 / sq8"""
         xb = np.ascontiguousarray(xb, np.float32)
         n, d = xb.shape
-        codes = np.empty((n, d if row_type == 3 else 2 * d), np.uint8)
+        codes = np.empty((n, rows_code_size(row_type, d)), np.uint8)
         tr = np.zeros(2 * d, np.float32)
         self._chk(self.lib.ref_sq_rows(C.c_int(row_type), C.c_int(metric), C.c_int(d), C.c_int64(n), _p(xb, _f32p),
                                        _p(codes, _u8p), _p(tr, _f32p)))

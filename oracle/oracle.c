@@ -966,8 +966,13 @@ static float orc_decode_fp16(uint16_t h) {
     return f;
 }
 
+/* row types: 1 fp16, 2 bf16, 3 QT_8bit, 4 QT_6bit, 5 QT_8bit_direct_signed (ScalarQuantizer::set_derived_sizes,
+ * T:impl/ScalarQuantizer.cpp: code_size = d for the 8-bit types, (d * 6 + 7) / 8 for QT_6bit, 2 d for the 16-bit ones) */
 int64_t orc_rows_code_size(int row_type, int d) {
-    return row_type == 3 ? d : 2 * (int64_t)d;
+    if (row_type == 4) {
+        return ((int64_t)d * 6 + 7) / 8;
+    }
+    return (row_type == 3 || row_type == 5) ? d : 2 * (int64_t)d;
 }
 
 void orc_rows_train(int d, int64_t n, const float* x, float* trained) {
@@ -1000,6 +1005,36 @@ void orc_rows_encode(int row_type, int d, int64_t n, const float* x, const float
                 }
                 c[i] = (uint8_t)(int)(255 * xi);
             }
+        } else if (row_type == 4) {
+            /* QuantizerTemplate<Codec6bit, NON_UNIFORM>::encode_vector (T:impl/scalar_quantizer/quantizers.h:124-137) over
+             * Codec6bit::encode_component (codecs.h:66-90): the codes are OR-ed into a zeroed row, four 6-bit values per
+             * three bytes; `x * 63.0` is a DOUBLE product (exact for a float in [0, 1]) truncated to int */
+            const int64_t cs = orc_rows_code_size(4, d);
+            uint8_t* c = codes + r * cs;
+            memset(c, 0, (size_t)cs);
+            for (int i = 0; i < d; i++) {
+                float xi = 0;
+                if (trained[d + i] != 0) {
+                    xi = (xr[i] - trained[i]) / trained[d + i];
+                    if (xi < 0) xi = 0;
+                    if (xi > 1.0) xi = 1.0;
+                }
+                const int bits = (int)(xi * 63.0);
+                uint8_t* g = c + (i >> 2) * 3;
+                switch (i & 3) {
+                    case 0: g[0] |= (uint8_t)bits; break;
+                    case 1: g[0] |= (uint8_t)(bits << 6); g[1] |= (uint8_t)(bits >> 2); break;
+                    case 2: g[1] |= (uint8_t)(bits << 4); g[2] |= (uint8_t)(bits >> 4); break;
+                    default: g[2] |= (uint8_t)(bits << 2); break;
+                }
+            }
+        } else if (row_type == 5) {
+            /* Quantizer8bitDirectSigned::encode_vector (quantizers.h:362-366): code = (uint8_t)(x + 128) -- defined for
+             * values in [-128, 127] (Knowhere's int8 data format); the conversion truncates */
+            uint8_t* c = codes + r * d;
+            for (int i = 0; i < d; i++) {
+                c[i] = (uint8_t)(int)(xr[i] + 128);
+            }
         } else {
             uint16_t* c = (uint16_t*)(codes + r * 2 * (int64_t)d);
             for (int i = 0; i < d; i++) {
@@ -1019,6 +1054,21 @@ static float rows_component(int row_type, int d, const uint8_t* code, const floa
     if (row_type == 3) {
         const float xi = (code[i] + 0.5f) / 255.0f;
         return trained[i] + xi * trained[d + i];
+    }
+    if (row_type == 4) { /* Codec6bit::decode_component (codecs.h:92-118) inside QuantizerTemplate::reconstruct_component */
+        const uint8_t* g = code + (i >> 2) * 3;
+        uint8_t bits;
+        switch (i & 3) {
+            case 0: bits = g[0] & 0x3f; break;
+            case 1: bits = (uint8_t)(g[0] >> 6); bits |= (uint8_t)((g[1] & 0xf) << 2); break;
+            case 2: bits = (uint8_t)(g[1] >> 4); bits |= (uint8_t)((g[2] & 3) << 4); break;
+            default: bits = (uint8_t)(g[2] >> 2); break;
+        }
+        const float xi = (bits + 0.5f) / 63.0f;
+        return trained[i] + xi * trained[d + i];
+    }
+    if (row_type == 5) { /* Quantizer8bitDirectSigned::reconstruct_component (quantizers.h:374-378) */
+        return (float)(code[i] - 128);
     }
     const uint16_t v = ((const uint16_t*)code)[i];
     if (row_type == 1) {

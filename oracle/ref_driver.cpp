@@ -385,7 +385,9 @@ static faiss::ScalarQuantizer::QuantizerType row_qtype(int row_type) {
         case 1: return faiss::ScalarQuantizer::QT_fp16;
         case 2: return faiss::ScalarQuantizer::QT_bf16;
         case 3: return faiss::ScalarQuantizer::QT_8bit;
-        default: throw std::runtime_error("row type: 1 fp16, 2 bf16, 3 sq8");
+        case 4: return faiss::ScalarQuantizer::QT_6bit;
+        case 5: return faiss::ScalarQuantizer::QT_8bit_direct_signed;
+        default: throw std::runtime_error("row type: 1 fp16, 2 bf16, 3 sq8, 4 sq6, 5 int8");
     }
 }
 

@@ -117,14 +117,15 @@ def main():
         from knowhere_amd import RowStore
         nb, nlist, nq = 500, 4, 4
         # d = 24: sq8 rows are not a multiple of 16 bytes (element loads); d = 32: every row type takes the 16-byte loads
-        for metric, d, types in ((ob.L2, 24, (1, 3)), (ob.IP, 32, (2, 3))):
+        # d = 22 with sq6: a ragged last group of 6-bit codes (17 bytes per row)
+        for metric, d, types in ((ob.L2, 24, (1, 3, 4, 5)), (ob.IP, 32, (2, 3, 4)), (ob.L2, 22, (4,))):
             xb, xq = gen_data(nb, d, 42, -40.0, 60.0), gen_data(nq, d, 44, -40.0, 60.0)
             xb[5, :4] = [1 + 2.0 ** -11, 2.0 ** -25, 65520.0, -(1 + 3 * 2.0 ** -11)]  # fp16 ties / subnormal / overflow
             ix = ob.make_index(port, ob.IVF_SQ8, metric, xb, nlist=nlist)
             g = GpuIndex.from_data(ix, device=0)
             for rt in types:
                 rows = RowStore(rt, d, device=0)
-                tr = port.rows_train(xb) if rt == 3 else None
+                tr = port.rows_train(xb) if rt in (3, 4) else None
                 codes = port.rows_encode(rt, xb, tr)
                 if rt == 3:  # (build.hip -- column ranges, sq8 encoder -- is not part of the emulated library: GPU tests)
                     rows.set_trained(tr)
@@ -132,7 +133,10 @@ def main():
                     rows.add_codes(codes[:300])
                     rows.add_codes(codes[300:])
                 else:
-                    rows.train(xb)
+                    if rt == 4:  # (ranges from the oracle: the column min / max kernel lives in build.hip; the encoder runs here)
+                        rows.set_trained(tr)
+                    else:
+                        rows.train(xb)
                     rows.add(xb[:300])
                     rows.add(xb[300:])
                 assert rows.count() == nb and rows.codes().tobytes() == codes.tobytes(), f"row type {rt}: code bytes"
@@ -143,7 +147,7 @@ def main():
                     same(Do, Io, D, I, f"refine_rows metric={metric} type={rt} k={k}")
                 # a store filled from code bytes (Deserialize) behaves the same
                 r2 = RowStore(rt, d, device=0)
-                if rt == 3:
+                if rt in (3, 4):
                     r2.set_trained(tr)
                 r2.add_codes(codes)
                 if rt != 3:  # (the sq8 store above was itself filled from code bytes)

@@ -1,8 +1,8 @@
-"""GPU tests (-m gpu): the quantised refine store (knhip_rows; Knowhere's refine_type = fp16 / bf16 / sq8).
+"""GPU tests (-m gpu): the quantised refine store (knhip_rows; Knowhere's refine_type = fp16 / bf16 / sq8 / sq6 / int8).
 
 The reference re-ranks the first stage's candidates against a faiss::IndexScalarQuantizer of the raw rows (reference
 src/index/refine/refine_utils.cc:150-185, thirdparty/faiss/faiss/cppcontrib/knowhere/IndexRefine.cpp:66-165).  The oracle's
-restatement is pinned against the reference in tests/test_refine_rows.py; here the device side -- range training, the three
+restatement is pinned against the reference in tests/test_refine_rows.py; here the device side -- range training, the five
 encoders, append, and knhip_search_refine_rows -- must equal it bit for bit."""
 import numpy as np
 import pytest
@@ -10,7 +10,7 @@ import pytest
 from conftest import assert_parity, gen_data
 from helpers import finish_ivfpq
 from oracle import binding as ob
-from test_refine_rows import ROW_TYPES, _nasty
+from test_refine_rows import ROW_TYPES, TRAINED, _data, _nasty
 
 pytestmark = pytest.mark.gpu
 
@@ -27,13 +27,14 @@ def _store(rt, xb, chunks=1):
 @pytest.mark.parametrize("row_type,name", ROW_TYPES, ids=[r[1] for r in ROW_TYPES])
 def test_device_encoders_write_the_reference_code_bytes(port, row_type, name):
     d = 24
-    for x in (gen_data(5000, d, 5), gen_data(300, d, 6, -3.0, 3.0), _nasty(d, 7)):
-        if row_type == 3:
+    sets = (_data(row_type, 5000, d, 5), _data(row_type, 300, d, 6, -3.0, 3.0)) + (() if row_type == 5 else (_nasty(d, 7),))
+    for x in sets:
+        if row_type in TRAINED:
             x = np.ascontiguousarray(x[np.isfinite(x).all(1)])
         rows = _store(row_type, x, chunks=3)
-        tr = port.rows_train(x) if row_type == 3 else None
-        if row_type == 3:
-            assert rows.trained().tobytes() == tr.tobytes(), "sq8 ranges (column minimum / maximum - minimum)"
+        tr = port.rows_train(x) if row_type in TRAINED else None
+        if row_type in TRAINED:
+            assert rows.trained().tobytes() == tr.tobytes(), "ranges (column minimum / maximum - minimum)"
         assert rows.count() == len(x)
         assert rows.codes().tobytes() == port.rows_encode(row_type, x, tr).tobytes(), f"{name} code bytes"
         rows.close()
@@ -73,13 +74,13 @@ KINDS = [(ob.IVF_PQ, "ivfpq", dict(nlist=24, M=8)), (ob.IVF_SQ8, "ivfsq8", dict(
 def test_search_refine_rows_equals_index_refine_over_a_scalar_quantizer(port, kind, kname, kw, metric, row_type, name):
     from knowhere_amd import GpuIndex
     nb, nq, d = 6000, 64, 32
-    xb, xq = gen_data(nb, d, 42, -20.0, 80.0), gen_data(nq, d, 44, -20.0, 80.0)
+    xb, xq = _data(row_type, nb, d, 42, -20.0, 80.0), _data(row_type, nq, d, 44, -20.0, 80.0)
     ix = ob.make_index(port, kind, metric, xb, **kw)
     if kind == ob.IVF_PQ:
         finish_ivfpq(port, ix)
     g = GpuIndex.from_data(ix, device=0)
     rows = _store(row_type, xb, chunks=2)
-    tr = port.rows_train(xb) if row_type == 3 else None
+    tr = port.rows_train(xb) if row_type in TRAINED else None
     codes = port.rows_encode(row_type, xb, tr)
     bs = np.packbits(np.random.default_rng(5).random(nb) < 0.3, bitorder="little")
     for k, kb, nprobe in ((10, 40, 8), (1, 16, 3), (7, 7, 9), (20, 200, 24)):
@@ -103,7 +104,7 @@ def test_refine_rows_ties_follow_reorder_2_heaps(port, metric, row_type, name):
     ix = ob.make_index(port, ob.IVF_SQ8, metric, xb, nlist=24)
     g = GpuIndex.from_data(ix, device=0)
     rows = _store(row_type, xb)
-    tr = port.rows_train(xb) if row_type == 3 else None
+    tr = port.rows_train(xb) if row_type in TRAINED else None
     codes = port.rows_encode(row_type, xb, tr)
     kbase, k, nprobe = 60, 6, 9
     _, Ib = port.search(ix, xq, kbase, nprobe)
@@ -138,3 +139,46 @@ def test_refine_rows_at_scale_properties(port):
         assert_parity(Do, Io, D[:100], I[:100], ob.L2, f"row type {rt} at scale")
         rows.close()
     g.close()
+
+
+def test_sq6_ragged_dimension_and_boundary_values(port):
+    """d = 10 (the last group of codes owns two of its three bytes), d = 7; values right below each of the 63 cell
+    boundaries (the encoder's product is a double one: tests/test_refine_rows.py); a constant column; rows outside the
+    trained range; then a refine over the store with d not a multiple of four"""
+    from knowhere_amd import GpuIndex, RowStore
+    for d in (10, 7):
+        x = gen_data(600, d, 13, -5.0, 5.0)
+        x[:, 3] = -2.25
+        rows = _store(4, x, chunks=2)
+        tr = port.rows_train(x)
+        assert rows.trained().tobytes() == tr.tobytes()
+        assert rows.codes().tobytes() == port.rows_encode(4, x, tr).tobytes()
+        wide = gen_data(60, d, 14, -100.0, 100.0)
+        r2 = RowStore(4, d, device=0)
+        r2.set_trained(tr)
+        r2.add(wide)
+        assert r2.codes().tobytes() == port.rows_encode(4, wide, tr).tobytes()
+        r2.close()
+        rows.close()
+    j = np.arange(1, 64, dtype=np.float64)
+    below = np.nextafter((j / 63.0).astype(np.float32), np.float32(0))
+    col = np.concatenate([[0.0, 1.0], below, (j / 63.0).astype(np.float32)]).astype(np.float32)
+    xx = np.zeros((col.size, 4), np.float32)
+    xx[:, 0] = col
+    rows = _store(4, xx)
+    assert rows.codes().tobytes() == port.rows_encode(4, xx, port.rows_train(xx)).tobytes()
+    rows.close()
+    nb, nq, d = 4000, 40, 10
+    xb, xq = gen_data(nb, d, 42, -20.0, 80.0), gen_data(nq, d, 44, -20.0, 80.0)
+    for metric in (ob.L2, ob.IP):
+        ix = ob.make_index(port, ob.IVF_FLAT, metric, xb, nlist=16)
+        g = GpuIndex.from_data(ix, device=0)
+        rows = _store(4, xb)
+        tr = port.rows_train(xb)
+        codes = port.rows_encode(4, xb, tr)
+        _, Ib = port.search(ix, xq, 50, 8)
+        Do, Io = port.refine_rows(metric, 4, d, codes, tr, xq, Ib, 10)
+        D, I = g.search_refine_rows(rows, xq, 10, 50, 8)
+        assert_parity(Do, Io, D, I, metric, "sq6 d=10")
+        rows.close()
+        g.close()

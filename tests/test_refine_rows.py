@@ -1,6 +1,7 @@
-"""Quantised refine store (refine_type = fp16 / bf16 / sq8): the oracle's restatement pinned against the reference.
+"""Quantised refine store (refine_type = fp16 / bf16 / sq8 / sq6 / int8): the oracle's restatement pinned against the reference.
 
-Knowhere builds IndexRefine(base, faiss::IndexScalarQuantizer(d, QT_fp16 / QT_bf16 / QT_8bit, metric)) for these refine
+Knowhere builds IndexRefine(base, faiss::IndexScalarQuantizer(d, QT_fp16 / QT_bf16 / QT_8bit / QT_6bit /
+QT_8bit_direct_signed, metric)) for these refine
 types (reference src/index/refine/refine_utils.cc:150-185).  oracle.c restates the quantizer (train / encode / decode) and
 the refine distance computer; here the restatement must produce the reference's code bytes, trained ranges and search
 results bit for bit (oracle/_ref = the reference's own sources, SIMDLevel::NONE)."""
@@ -10,7 +11,16 @@ import pytest
 from conftest import gen_data
 from oracle import binding as ob
 
-ROW_TYPES = [(1, "fp16"), (2, "bf16"), (3, "sq8")]
+ROW_TYPES = [(1, "fp16"), (2, "bf16"), (3, "sq8"), (4, "sq6"), (5, "int8")]
+TRAINED = (3, 4)  # types with per-dimension ranges
+
+
+def _data(row_type, *a, **kw):
+    """int8 stores hold integer values in [-128, 127] (Knowhere's int8 data format); everything else takes the floats"""
+    x = gen_data(*a, **kw)
+    if row_type == 5:
+        x = np.clip(np.rint((x - x.mean()) / (x.std() + 1e-9) * 40.0), -128, 127).astype(np.float32)
+    return x
 
 
 def _nasty(d, seed):
@@ -28,13 +38,14 @@ def _nasty(d, seed):
 @pytest.mark.parametrize("row_type,name", ROW_TYPES, ids=[r[1] for r in ROW_TYPES])
 def test_rows_encode_equals_the_reference(port, ref, row_type, name):
     d = 24
-    for x in (gen_data(700, d, 5), gen_data(300, d, 6, -3.0, 3.0), _nasty(d, 7)):
-        if row_type == 3:
+    sets = (_data(row_type, 700, d, 5), _data(row_type, 300, d, 6, -3.0, 3.0)) + (() if row_type == 5 else (_nasty(d, 7),))
+    for x in sets:
+        if row_type in TRAINED:
             x = x[np.isfinite(x).all(1)]
         codes_r, tr_r = ref.sq_rows(row_type, ob.L2, x)
-        tr = port.rows_train(x) if row_type == 3 else None
-        if row_type == 3:
-            assert tr.tobytes() == tr_r.tobytes(), "sq8 ranges"
+        tr = port.rows_train(x) if row_type in TRAINED else None
+        if row_type in TRAINED:
+            assert tr.tobytes() == tr_r.tobytes(), f"{name} ranges"
         codes = port.rows_encode(row_type, x, tr)
         assert codes.tobytes() == codes_r.tobytes(), f"{name} code bytes"
 
@@ -60,12 +71,12 @@ def test_sq8_constant_column_and_clamp(port, ref):
 @pytest.mark.parametrize("kind", [ob.IVF_PQ, ob.IVF_SQ8], ids=["ivfpq", "ivfsq8"])
 def test_refine_rows_equals_index_refine_over_a_scalar_quantizer(port, ref, kind, metric, row_type, name):
     nb, nq, d, nlist, M = 2500, 24, 48, 20, 12
-    xb, xq = gen_data(nb, d, 42), gen_data(nq, d, 44)
+    xb, xq = _data(row_type, nb, d, 42), _data(row_type, nq, d, 44)
     h = ref.create(kind, metric, d, nlist, M, 8)
     try:
         ref.train_add(h, xb)
         ix = ref.export(h, kind, metric, d, nlist, M, 8)
-        tr = port.rows_train(xb) if row_type == 3 else None
+        tr = port.rows_train(xb) if row_type in TRAINED else None
         codes = port.rows_encode(row_type, xb, tr)
         for k, kf, nprobe in ((5, 4.0, 18), (1, 8.0, 3), (10, 1.0, 20)):
             Dr, Ir = ref.search_refine_sq(h, row_type, xb, xq, k, kf, nprobe)
@@ -81,8 +92,8 @@ def test_refine_rows_equals_index_refine_over_a_scalar_quantizer(port, ref, kind
 @pytest.mark.parametrize("row_type,name", ROW_TYPES, ids=[r[1] for r in ROW_TYPES])
 def test_decode_round_trip_properties(port, row_type, name):
     d = 16
-    x = gen_data(500, d, 9, -50.0, 50.0)
-    tr = port.rows_train(x) if row_type == 3 else None
+    x = _data(row_type, 500, d, 9, -50.0, 50.0)
+    tr = port.rows_train(x) if row_type in TRAINED else None
     c = port.rows_encode(row_type, x, tr)
     y = port.rows_decode(row_type, d, c, tr)
     # idempotence: re-encoding the decoded rows gives the same codes
@@ -95,8 +106,11 @@ def test_decode_round_trip_properties(port, row_type, name):
         assert (np.abs(y) >= np.abs(rne)).all()
     elif row_type == 2:
         assert np.abs(y - x).max() <= np.abs(x).max() * 2.0 ** -8
+    elif row_type == 5:
+        assert np.array_equal(y, x)  # (integer values in range: lossless)
     else:
-        assert (np.abs(y - x) <= tr[d:] / 255.0 * 0.5001 + 1e-6).all()
+        levels = 255.0 if row_type == 3 else 63.0
+        assert (np.abs(y - x) <= tr[d:] / levels * 0.5001 + 1e-6).all()
 
 
 def _encode_fp16_int(bits):
@@ -145,7 +159,7 @@ def test_refine_rows_ties_equal_the_reference(port, ref, metric, row_type, name)
     try:
         ref.train_add(h, xb)
         ix = ref.export(h, ob.IVF_SQ8, metric, d, 16, 0, 8)
-        tr = port.rows_train(xb) if row_type == 3 else None
+        tr = port.rows_train(xb) if row_type in TRAINED else None
         codes = port.rows_encode(row_type, xb, tr)
         ties = 0
         for k, kf, nprobe in ((6, 10.0, 9), (10, 3.0, 16), (4, 1.0, 5)):
@@ -157,3 +171,33 @@ def test_refine_rows_ties_equal_the_reference(port, ref, metric, row_type, name)
         assert ties > 0, "no tied distances in the results: the data tests nothing"
     finally:
         ref.destroy(h)
+
+
+def test_sq6_packing_and_the_double_product(port, ref):
+    """four 6-bit codes per three bytes, a ragged last group (d = 10: 8 bytes), clamping, a constant column; and the
+    encoder's `x * 63.0` is a double product: values whose float product would round up to the next integer keep the
+    lower code"""
+    d = 10
+    x = gen_data(400, d, 13, -5.0, 5.0)
+    x[:, 3] = -2.25
+    codes_r, tr_r = ref.sq_rows(4, ob.L2, x)
+    tr = port.rows_train(x)
+    assert tr.tobytes() == tr_r.tobytes() and tr[d + 3] == 0
+    c = port.rows_encode(4, x, tr)
+    assert c.shape == (400, 8) and c.tobytes() == codes_r.tobytes()
+    y = port.rows_decode(4, d, c, tr)
+    assert (y[:, 3] == -2.25).all()
+    wide = gen_data(60, d, 14, -100.0, 100.0)
+    back = port.rows_decode(4, d, port.rows_encode(4, wide, tr), tr)
+    # (a code decodes to the middle of its cell: the top code lands half a cell above the trained maximum)
+    assert (back >= tr[:d] - 1e-6).all() and (back <= tr[:d] + tr[d:] * (63.5 / 63.0) + 1e-5).all()
+    # one column with range exactly [0, 1]: xi = x; the largest floats below j / 63 must encode to j - 1
+    j = np.arange(1, 64, dtype=np.float64)
+    below = np.nextafter((j / 63.0).astype(np.float32), np.float32(0))
+    col = np.concatenate([[0.0, 1.0], below, (j / 63.0).astype(np.float32)]).astype(np.float32)
+    xx = np.zeros((col.size, 4), np.float32)
+    xx[:, 0] = col
+    cr, trr = ref.sq_rows(4, ob.L2, xx)
+    t2 = port.rows_train(xx)
+    assert t2.tobytes() == trr.tobytes() and t2[0] == 0 and t2[4] == 1
+    assert port.rows_encode(4, xx, t2).tobytes() == cr.tobytes()
