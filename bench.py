@@ -676,7 +676,7 @@ def make_roofline(a, kind, prof, world):
     pairs_dims = scan_bytes / code_size * a.d
     flop = pairs_dims * (3.0 if a.metric == "l2" else 2.0)
     tf = flop / sec / 1e12 if sec > 0 else 0.0
-    name = "knhip::flat_scan_kernel" if kind == kidx.IVF_FLAT else "knhip::sq_scan_kernel"
+    name = "knhip::flat_scan_kernel" if kind in (kidx.IVF_FLAT, kidx.BRUTE_FORCE) else "knhip::sq_scan_kernel"
     return dict({"bound": "valu", "kernel": name, "achieved": round(tf, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                  "frac": round(tf / VALU_PEAK_TFLOPS, 4),
                  "note": "separately rounded sub/mul/add per (row, query, dim) counted as 1 flop each; "

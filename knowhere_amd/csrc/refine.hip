@@ -25,6 +25,7 @@
 
 namespace knhip {
 
+constexpr int RF_PITCH = 17 * 16; // bytes per staged row piece set (16 pieces + one of padding)
 constexpr uint32_t REFINE_NOT_HERE = 0xffffffffu; // a NaN pattern no arithmetic produces: "this shard does not hold the row"
 
 // ROWT: 0 fp32 rows, 1 fp16, 2 bf16, 3 per-dimension 8-bit codes (sq = vmin[d], vdiff[d]), 4 per-dimension 6-bit codes (four
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ b
                                                      const int64_t* __restrict__ cand, int kbase, int k,
                                                      float* __restrict__ out_d,
                                                      int64_t* __restrict__ out_i, const float* __restrict__ sq_trained,
-                                                     const float* __restrict__ dist_in, float* __restrict__ dist_out) {
+                                                     const float* __restrict__ dist_in, float* __restrict__ dist_out, int coop) {
     // Sharded refine (the raw rows cut into one id range per shard): the re-scored candidates pass the reference's heap in
     // CANDIDATE order whoever holds their rows, so the selection needs every candidate's distance.  dist_out != nullptr:
     // only the distances of the candidates held here are written ([nq][kbase]; REFINE_NOT_HERE elsewhere), nothing is
@@ -166,7 +167,52 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ b
                 acc = IS_L2 ? l2_step(acc, myq[i], x) : ip_step(acc, myq[i], x);
             }
         }
-        if (ok && ROWT == 0 && dist_in == nullptr) {
+        if (ROWT == 0 && dist_in == nullptr && coop) {
+            // fp32 rows, gathered by the wave TOGETHER: 16 lanes read 256 contiguous bytes of one row, an instruction covers
+            // four rows (four pages) instead of 64 -- with lane = row every wave-level load touched 64 pages, and the random
+            // 512-byte rows of a 51 GB array came in at 1.2 TB/s against 4.9 TB/s for whole-row requests
+            // (tools/ubench/row_gather.hip, profiles/r05_ubench_row_gather.log): the translations, not the bytes.  The pieces
+            // go through a per-wave LDS staging area (row pitch 17 x 16 bytes: conflict-free when lane = row reads them back)
+            // and are accumulated by the candidate's own lane in dimension order, as before.
+            const int64_t myrow = ok ? (id - id_base) : 0; // (a lane without a candidate names row 0: read, never used)
+            const float4* b4 = reinterpret_cast<const float4*>(base);
+            const float4* q4 = reinterpret_cast<const float4*>(myq);
+            const int n4 = d >> 2;
+            unsigned char* st = reinterpret_cast<unsigned char*>(sq + 4 * d + 4 * kbase) + wave * (KN_WAVE * RF_PITCH);
+            const int sub = lane >> 4, pl = lane & 15;
+            for (int p0 = 0; p0 < n4; p0 += 16) { // 16 pieces = 64 dimensions of every row
+                float4 v[16];
+                const int piece = min(p0 + pl, n4 - 1);
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    const int64_t rr = __shfl(myrow, 4 * u + sub, KN_WAVE);
+                    v[u] = 4 * u < nvalid ? b4[rr * n4 + piece] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    *reinterpret_cast<float4*>(st + (4 * u + sub) * RF_PITCH + pl * 16) = v[u];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const float4* mine = reinterpret_cast<const float4*>(st + lane * RF_PITCH);
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    if (p0 + e < n4) {
+                        const float4 y = mine[e];
+                        const float4 x = q4[p0 + e];
+                        acc = IS_L2 ? l2_step(acc, x.x, y.x) : ip_step(acc, x.x, y.x);
+                        acc = IS_L2 ? l2_step(acc, x.y, y.y) : ip_step(acc, x.y, y.y);
+                        acc = IS_L2 ? l2_step(acc, x.z, y.z) : ip_step(acc, x.z, y.z);
+                        acc = IS_L2 ? l2_step(acc, x.w, y.w) : ip_step(acc, x.w, y.w);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier(); // (the next chunk overwrites the staging area)
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            acc = ok ? acc : 0.f;
+        } else if (ok && ROWT == 0 && dist_in == nullptr) {
             const float* y = base + (id - id_base) * d;
             int i = 0;
             if ((d & 3) == 0 && (reinterpret_cast<uintptr_t>(base) & 15) == 0) {
@@ -287,7 +333,9 @@ hipError_t launch_refine(const float* base, int64_t nbase, int64_t id_base, int 
         return hipErrorInvalidValue;
     }
     const unsigned grid = (unsigned)((nq + 3) / 4);
-    const size_t sm = ((size_t)4 * d + (size_t)4 * kbase) * sizeof(float);
+    // fp32 rows of 16-byte multiples are gathered cooperatively through a per-wave staging area (refine_kernel)
+    const int coop = (row_type == 0 && dist_in == nullptr && (d & 3) == 0 && (reinterpret_cast<uintptr_t>(base) & 15) == 0) ? 1 : 0;
+    const size_t sm = ((size_t)4 * d + (size_t)4 * kbase) * sizeof(float) + (coop ? (size_t)4 * KN_WAVE * RF_PITCH : 0);
     if (sm > 160 * 1024) {
         return hipErrorInvalidValue; // (four queries + their candidates' distances do not fit the CU's LDS)
     }
@@ -303,7 +351,7 @@ hipError_t launch_refine(const float* base, int64_t nbase, int64_t id_base, int 
             }                                                                                                         \
         }                                                                                                             \
         hipLaunchKernelGGL(kern_, dim3(grid), dim3(256), sm, s, base, nbase, id_base, d, queries, nq, cand, kbase, k, \
-                           out_d, out_i, sq_trained, dist_in, dist_out);                                              \
+                           out_d, out_i, sq_trained, dist_in, dist_out, coop);                                        \
     }
 #define KN_REFINE_LAUNCH(ROWT_)                                                                                       \
     KN_DISPATCH_R(k, {                                                                                                \

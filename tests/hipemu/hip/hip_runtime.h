@@ -369,6 +369,10 @@ inline I4 hipemu_mfma_i32_16x16x64_i8(I4 a, I4 b, I4 c, int, int, int) {
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(...) hipemu_mfma_32x32x16_f16(__VA_ARGS__)
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(...) hipemu_mfma_32x32x16_bf16(__VA_ARGS__)
 #define __builtin_amdgcn_s_setprio(p) ((void)0)
+// a wave runs in lockstep on the hardware: LDS traffic between its lanes needs only the compiler's attention there.  Here the
+// lanes are separate threads of execution: the wave barrier is a real rendezvous (an exchange every lane takes part in)
+#define __builtin_amdgcn_wave_barrier() ((void)hipemu::xchg(0ull, 0))
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_sched_barrier(m) ((void)0)
 #define __builtin_amdgcn_s_memtime() 0ull
 #define __builtin_amdgcn_s_sleep(n) ((void)0)

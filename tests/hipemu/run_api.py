@@ -123,6 +123,17 @@ def main():
             xb[5, :4] = [1 + 2.0 ** -11, 2.0 ** -25, 65520.0, -(1 + 3 * 2.0 ** -11)]  # fp16 ties / subnormal / overflow
             ix = ob.make_index(port, ob.IVF_SQ8, metric, xb, nlist=nlist)
             g = GpuIndex.from_data(ix, device=0)
+            # the fp32 store (IndexRefineFlat): rows gathered by the wave together through the LDS staging area (refine.hip;
+            # d = 24 / 32: one ragged chunk of pieces, d = 22: not a multiple of four -> the lane = row path)
+            from knowhere_amd import index as kidx
+            raw = kidx.GpuIndex(kidx.BRUTE_FORCE, metric, d, device=0)
+            raw.add_vectors(xb)
+            for k, kb, nprobe in ((5, 20, 3), (10, 70, 4)):  # (70 candidates: a second, partly filled round of 64)
+                _, Ib = port.search(ix, xq, kb, nprobe)
+                Do, Io = port.refine(metric, xb, xq, Ib, k)
+                D, I = g.search_refine(raw, xq, k, kb, nprobe)
+                same(Do, Io, D, I, f"fp32 refine metric={metric} d={d} k={k} k_base={kb}")
+            raw.close()
             for rt in types:
                 rows = RowStore(rt, d, device=0)
                 tr = port.rows_train(xb) if rt in (3, 4) else None
