@@ -933,11 +933,14 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
     // (the MFMA prefilter's fallback compacts the pairs of overflowed queries into one-query items: up to npairs)
     HIP_TRY(ws->items.reserve((size_t)(use_ms ? std::max<int64_t>(npairs, items_bound) : items_bound) * sizeof(KnItem)));
     HIP_TRY(ws->nitems.reserve(sizeof(int64_t)));
-    // rows of a query's sample (IVF-Flat / IVF-SQ8 prefilter), at most: the first max(1024, 8 k) rows of its closest
+    // rows of a query's sample (IVF-Flat prefilter), at most: the first max(1024, 8 k) rows of its closest
     // list(s) -- the pass is bound by the rows it reads (C2: every list is somebody's closest: the whole index once per
     // batch when a list was sampled in full), and tau from 1024 rows lets only a few dozen more candidates through.
     // KNHIP_MS_SAMPLE_ROWS=n overrides (tests / experiments; 8192 = whole lists as in rounds 2-4)
-    int ms_sample_cap = std::min<int>(mscan_sample_rows(), (std::max(1024, 8 * k) + 63) / 64 * 64);
+    // IVF-SQ8 keeps whole lists: its finish does not prune (the eps of an emission depends on the pair), and the looser tau
+    // of a short sample cost it more than the sample saved (C5: sample 3.3 -> 2.2 ms, finish 1.6 -> 4.3 ms)
+    int ms_sample_cap = kind == KNHIP_IVF_FLAT ? std::min<int>(mscan_sample_rows(), (std::max(1024, 8 * k) + 63) / 64 * 64)
+                                               : mscan_sample_rows();
     if (const char* e = getenv("KNHIP_MS_SAMPLE_ROWS")) {
         ms_sample_cap = std::max(64, std::min(mscan_sample_rows(), atoi(e) / 64 * 64));
     }
