@@ -225,6 +225,7 @@ struct MScanArgs {
     int64_t bitset_nbits;
     int32_t* cand_cnt;           // [nq]
     int64_t* cand;               // [nq][cap]: slot << 32 | row position in the list
+    uint32_t* eps_max;           // [nq] SQ8: bit pattern of the largest eps any unit of the query emitted with (null = off)
     float* cand_pess;            // [nq][cap] pessimistic distance of each candidate (null = not kept): the finish kernel
                                  // drops the candidates that cannot beat the k-th best of them before it recomputes any
     int32_t cap;

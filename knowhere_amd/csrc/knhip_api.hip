@@ -129,6 +129,7 @@ struct Workspace {
     // MFMA prefilter of the IVF-Flat / IVF-SQ8 scans (mfma_scan.hip)
     DevBuf ms_qi, ms_qis, ms_qmu, pq_recs16;                                 // integer form: tables, {step, mu sum, eps, A}, records
     DevBuf rs_ovf;                                                    // coarse stage: rows the two-pass selection left to the radix select
+    DevBuf ms_eps_max;                                               // [qb] SQ8: largest emission eps per query (bit pattern)
     DevBuf ms_cand_pess;                                             // [qb][cap] pessimistic distances of the candidates (IVF-PQ)
     DevBuf ms_units, ms_unit_off, ms_nunits, ms_cand, ms_cand_cnt;  // ms_cand_cnt: [qb] counters + [qb + 1] overflow flags
     DevBuf ms_sample_off, ms_nrow;                                   // sample plan: [qb][nprobe] dump columns, [qb] rows
@@ -933,14 +934,12 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
     // (the MFMA prefilter's fallback compacts the pairs of overflowed queries into one-query items: up to npairs)
     HIP_TRY(ws->items.reserve((size_t)(use_ms ? std::max<int64_t>(npairs, items_bound) : items_bound) * sizeof(KnItem)));
     HIP_TRY(ws->nitems.reserve(sizeof(int64_t)));
-    // rows of a query's sample (IVF-Flat prefilter), at most: the first max(1024, 8 k) rows of its closest
+    // rows of a query's sample (IVF-Flat / IVF-SQ8 prefilter), at most: the first max(1024, 8 k) rows of its closest
     // list(s) -- the pass is bound by the rows it reads (C2: every list is somebody's closest: the whole index once per
     // batch when a list was sampled in full), and tau from 1024 rows lets only a few dozen more candidates through.
     // KNHIP_MS_SAMPLE_ROWS=n overrides (tests / experiments; 8192 = whole lists as in rounds 2-4)
-    // IVF-SQ8 keeps whole lists: its finish does not prune (the eps of an emission depends on the pair), and the looser tau
-    // of a short sample cost it more than the sample saved (C5: sample 3.3 -> 2.2 ms, finish 1.6 -> 4.3 ms)
-    int ms_sample_cap = kind == KNHIP_IVF_FLAT ? std::min<int>(mscan_sample_rows(), (std::max(1024, 8 * k) + 63) / 64 * 64)
-                                               : mscan_sample_rows();
+    // (IVF-SQ8 too, now that its finish prunes: before that the looser tau cost C5's finish 2.7 ms for 1.1 ms saved here)
+    int ms_sample_cap = std::min<int>(mscan_sample_rows(), (std::max(1024, 8 * k) + 63) / 64 * 64);
     if (const char* e = getenv("KNHIP_MS_SAMPLE_ROWS")) {
         ms_sample_cap = std::max(64, std::min(mscan_sample_rows(), atoi(e) / 64 * 64));
     }
@@ -1011,8 +1010,10 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         HIP_TRY(ws->ms_unit_off.reserve((size_t)(nlist + 1) * sizeof(int64_t)));
         HIP_TRY(ws->ms_nunits.reserve(sizeof(int64_t) + 2 * sizeof(double)));
         HIP_TRY(ws->ms_cand.reserve((size_t)nq * ms_cap * sizeof(int64_t)));
-        if (kind == KNHIP_IVF_PQ || kind == KNHIP_IVF_FLAT) {
-            HIP_TRY(ws->ms_cand_pess.reserve((size_t)nq * ms_cap * sizeof(float)));
+        HIP_TRY(ws->ms_cand_pess.reserve((size_t)nq * ms_cap * sizeof(float)));
+        if (kind == KNHIP_IVF_SQ8) {
+            HIP_TRY(ws->ms_eps_max.reserve((size_t)nq * sizeof(uint32_t)));
+            HIP_TRY(hipMemsetAsync(ws->ms_eps_max.p, 0, (size_t)nq * sizeof(uint32_t), s));
         }
         HIP_TRY(ws->ms_cand_cnt.reserve((size_t)(2 * nq + 4) * sizeof(int32_t))); // counters, flags, any-flag, guard counters
         HIP_TRY(ws->dump.reserve((size_t)nq * sample * sizeof(float)));
@@ -1052,7 +1053,8 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         m.bitset_nbits = nbits;
         m.cand_cnt = cand_cnt;
         m.cand = ws->ms_cand.as<int64_t>();
-        m.cand_pess = (kind == KNHIP_IVF_PQ || kind == KNHIP_IVF_FLAT) ? ws->ms_cand_pess.as<float>() : nullptr;
+        m.cand_pess = ws->ms_cand_pess.as<float>();
+        m.eps_max = kind == KNHIP_IVF_SQ8 ? ws->ms_eps_max.as<uint32_t>() : nullptr;
         m.cap = ms_cap;
         m.overflow = overflow;
         m.gthr_rw = ws->gthr.as<float>();

@@ -690,6 +690,11 @@ __device__ __forceinline__ void mscan_sq8_unit(const MScanArgs a, const int64_t 
             const float e_misc = 32.0f * u * (fabsf(sA) + 1024.0f * sYp + fabsf(dis0) + sR);
             const float eps = 2.0f * (IS_L2 ? 2.0f * (e_mfma + e_misc) + (2.0f * (float)d + 16.0f) * u * 2.0f * (sR + a.xnorm_max)
                                             : e_mfma + e_misc + ((float)d + 8.0f) * u * sW) + 1e-30f;
+            if (!DUMP && a.eps_max != nullptr && lane == 0) {
+                // the finish prunes by pessimistic distances: it needs an eps that dominates every emission of the query (an
+                // infinite or NaN eps orders above every finite one as a bit pattern: the finish then does not prune)
+                atomicMax(a.eps_max + q, __float_as_uint(eps));
+            }
             const float off = 1024.0f * sHL;
             nsc = -0.5f * sc;
             offv = off;
@@ -1039,9 +1044,11 @@ __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, c
     // k-th best of ANY k candidates is a valid bound; the eps of this kind does not depend on it), the rest is streamed
     // through the same test.  (A query whose sample was unlucky can arrive with the full capacity of candidates: without
     // this it alone took 16 rounds of 1013 exact distances + a 1024-entry sort, the tail of the whole stage.)
-    // (PQ codes: the same; the |tau| its eps carries is then bounded through the histogram's origin, see eps_max below)
-    const int n_head = (KIND == 1 || KIND == 2) ? min(n, MF_THREADS * MF_PRUNE_PER_THREAD) : n;
-    if ((KIND == 2 || KIND == 1) && a.cand_pess != nullptr && !retry_prep && n >= 2 * k &&
+    // (PQ codes: the same; the |tau| its eps carries is then bounded through the histogram's origin, see eps_max below.
+    // SQ8 codes since round 5 as well: C5s spent 3.5 ms of a 3.6 ms finish on the few queries that arrived with the full
+    // capacity of 32768 candidates -- 32 rounds of 1013 exact 768-dimensional distances each)
+    const int n_head = min(n, MF_THREADS * MF_PRUNE_PER_THREAD);
+    if ((KIND != 3 || a.eps_max != nullptr) && a.cand_pess != nullptr && !retry_prep && n >= 2 * k &&
         n_head <= MF_THREADS * MF_PRUNE_PER_THREAD) {
         __shared__ int s_cnt;
         __shared__ float s_red[MF_THREADS / KN_WAVE];
@@ -1158,6 +1165,11 @@ __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, c
             // fp32 rows: every emission of this query used the one eps of mscan_flat*_unit (pess = approx widened by it)
             const float qn = a.qnorm[q];
             eps_max = a.eps_scale * (IS_L2 ? (qn + a.xnorm_max) : sqrtf(qn * a.xnorm_max)) + 1e-30f;
+        }
+        if (KIND == 3) {
+            // SQ8 codes: the eps of an emission belongs to its (query, list) pair; the units publish the largest one
+            // (mscan_sq8_unit, atomic max of the bit patterns of non-negative floats)
+            eps_max = __uint_as_float(a.eps_max[q]);
         }
         if (eps_max < INFINITY && tau2 == tau2 && fabsf(tau2) < FLT_MAX) {
             if (tid == 0) {
