@@ -190,13 +190,15 @@ def test_mscan_flat_filter_on_the_bf16_pipe(torch_cuda, port, monkeypatch, d, me
     gb.close()
 
 
-def test_mscan_flat_finish_prunes_a_long_candidate_list(torch_cuda, port, monkeypatch):
+@pytest.mark.parametrize("kind", [ob.IVF_FLAT, ob.IVF_SQ8], ids=["flat", "sq8"])
+def test_mscan_finish_prunes_a_long_candidate_list(torch_cuda, port, monkeypatch, kind):
     """an unlucky sample: seven of eight rows among the first 1024 of every list are filtered, so tau comes from 128 rows per
     list and ~9 % of the 100k rows pass the filter -- more candidates per query than the finish kernel's pruning holds in
-    registers (4096): the bound comes from the head of the list, the rest is streamed through the same test."""
+    registers (4096): the bound comes from the head of the list, the rest is streamed through the same test (SQ8: with the
+    largest emission eps the units published for the query)."""
     nb, d, nlist, nq = 100_000, 32, 4, 40
     xb, xq = gen_data(nb, d, 42), gen_data(nq, d, 44)
-    ix = sort_lists_by_id(ob.make_index(port, ob.IVF_FLAT, ob.L2, xb, nlist=nlist))
+    ix = sort_lists_by_id(ob.make_index(port, kind, ob.L2, xb, nlist=nlist))
     filt = np.zeros(nb, bool)
     for l in range(nlist):
         head = np.asarray(ix.list_ids[l][:1024])
@@ -215,3 +217,4 @@ def test_mscan_flat_finish_prunes_a_long_candidate_list(torch_cuda, port, monkey
         if k == 10:
             assert p["mscan_queries"] == nq and p["mscan_candidates"] > 4096 * nq, p
     g.close()
+
