@@ -562,9 +562,18 @@ def make_roofline(a, kind, prof, world):
 
     cf = prof["coarse_flops"] / max(prof["launches"][S.STAGE_COARSE], 1)
     if stages["coarse"] > 0 and cf > 0:
-        common["coarse_stage"] = {"bound": "mfma", "flops": cf, "ms": stages["coarse"],
-                                  "achieved_TFLOPs_whole_stage": round(cf / (stages["coarse"] * 1e-3) / 1e12, 2),
-                                  "peak": MFMA_F32_PEAK_TFLOPS}
+        # coarse_gemm.hip: where nlist >= 2048 and nlist / 32 >= 2 (nprobe + margin) the prefilter runs on the bf16 pipe --
+        # two GEMM passes (group minima -> bound; candidates under the bound) of three bf16 products each; else one fp32 GEMM
+        ncand = a.nprobe + max(32, a.nprobe // 4)
+        bf16 = (a.nlist >= 2048 and a.nlist // 32 >= 2 * ncand and a.nlist // 32 <= 4096
+                and os.environ.get("KNHIP_COARSE") is None)
+        flops, peak = (6.0 * cf, MFMA_F16_PEAK_TFLOPS) if bf16 else (cf, MFMA_F32_PEAK_TFLOPS)
+        common["coarse_stage"] = {"bound": "mfma", "kernel": "knhip::coarse_bf16_kernel (two passes x hi hi + hi lo + lo hi)"
+                                  if bf16 else "knhip::coarse_gemm_kernel (fp32)",
+                                  "algorithmic_flops": cf, "flops": flops, "ms": stages["coarse"],
+                                  "achieved_TFLOPs_whole_stage": round(flops / (stages["coarse"] * 1e-3) / 1e12, 2),
+                                  "peak": peak,
+                                  "note": "whole stage: GEMM pass(es) + bound / select + exact re-rank + certificate"}
     if kind == kidx.IVF_PQ:
         # one 4-byte table lookup per code byte: the LDS gather is the unit that binds (round-1 PMC: HBM traffic
         # is 0.03-0.14 x the algorithmic bytes, LDS ~ busy); SURVEY 8(d)'s no-reuse HBM model is kept beside it
