@@ -126,6 +126,8 @@ struct Workspace {
     DevBuf ghist;        // [qb][64] per-query candidate histogram (pq_scan_v2 after a rank-0 phase)
     DevBuf gmeta;        // [qb] {first-bin key, shift}
     DevBuf list_count, list_pair_off, list_item_off, list_cursor, pairs, items, nitems;
+    // a second work table (row-kind prefilters: the all-probes table is built on the side stream beside the sample pass)
+    DevBuf list_count2, list_pair_off2, list_item_off2, list_cursor2, pairs2, items2, nitems2;
     // MFMA prefilter of the IVF-Flat / IVF-SQ8 scans (mfma_scan.hip)
     DevBuf ms_qi, ms_qis, ms_qmu, pq_recs16;                                 // integer form: tables, {step, mu sum, eps, A}, records
     DevBuf rs_ovf;                                                    // coarse stage: rows the two-pass selection left to the radix select
@@ -1082,6 +1084,37 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         // IVF-PQ: the pairs are grouped by list (work table: four small, latency-bound kernels, ~0.25 ms per 10^4 queries at
         // C3) on a side stream while this stream runs the sample pass; only the cut into units waits for the form.
         SideJoin sj{ws, s};
+        WorkTable wside = wt; // the table the filter pass reads (its own buffers when it is built on the side stream)
+        if (!wt1_lazy && getenv("KNHIP_NO_SIDE_STREAM") == nullptr) {
+            // IVF-Flat / IVF-SQ8: the sample pass reads the split table built above; the all-probes table of the filter pass
+            // goes to a second set of buffers and is built beside the sample pass (0.35 ms per batch at C2, 1.5 ms at C5)
+            HIP_TRY(ws->list_count2.reserve((size_t)2 * nlist * sizeof(int32_t)));
+            HIP_TRY(ws->list_cursor2.reserve((size_t)2 * nlist * sizeof(int32_t)));
+            HIP_TRY(ws->list_pair_off2.reserve((size_t)(2 * nlist + 1) * sizeof(int64_t)));
+            HIP_TRY(ws->list_item_off2.reserve((size_t)(2 * nlist + 1) * sizeof(int64_t)));
+            HIP_TRY(ws->pairs2.reserve((size_t)npairs * sizeof(KnPair)));
+            HIP_TRY(ws->items2.reserve((size_t)items_bound * sizeof(KnItem)));
+            HIP_TRY(ws->nitems2.reserve(sizeof(int64_t)));
+            wside.list_count = ws->list_count2.as<int32_t>();
+            wside.list_cursor = ws->list_cursor2.as<int32_t>();
+            wside.list_pair_off = ws->list_pair_off2.as<int64_t>();
+            wside.list_item_off = ws->list_item_off2.as<int64_t>();
+            wside.pairs = ws->pairs2.as<KnPair>();
+            wside.items = ws->items2.as<KnItem>();
+            wside.nitems = ws->nitems2.as<int64_t>();
+            wside.scan_bytes = reinterpret_cast<double*>(ws->ms_nunits.as<int64_t>() + 1); // (bytes were counted above)
+            if (ws->side == nullptr) {
+                HIP_TRY(hipStreamCreateWithFlags(&ws->side, hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&ws->ev_fork, hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&ws->ev_join, hipEventDisableTiming));
+            }
+            HIP_TRY(hipEventRecord(ws->ev_fork, s));
+            HIP_TRY(hipStreamWaitEvent(ws->side, ws->ev_fork, 0));
+            HIP_TRY(launch_build_worktable(keys_p, nq, nprobe, nlist, qg, qg, idx->d_list_len.as<int64_t>(),
+                                           idx->code_size, wside, ws->side, /*rank0_slot=*/-1));
+            HIP_TRY(hipEventRecord(ws->ev_join, ws->side));
+            sj.forked = true;
+        }
         if (wt1_lazy && getenv("KNHIP_NO_SIDE_STREAM") == nullptr) {
             if (ws->side == nullptr) {
                 HIP_TRY(hipStreamCreateWithFlags(&ws->side, hipStreamNonBlocking));
@@ -1269,7 +1302,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         {
             // all probes of a list together: the work table again without the rank-0 split, its pairs cut into units
             StageTimer t(idx, s, KNHIP_STAGE_GROUP);
-            WorkTable w2 = wt;
+            WorkTable w2 = wside;
             if (!wt1_lazy) {
                 w2.scan_bytes = reinterpret_cast<double*>(ws->ms_nunits.as<int64_t>() + 1); // (bytes were counted above)
             }
@@ -1279,7 +1312,8 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
                 HIP_TRY(launch_build_worktable(keys_p, nq, nprobe, nlist, qg, qg, idx->d_list_len.as<int64_t>(),
                                                idx->code_size, w2, s, /*rank0_slot=*/-1));
             }
-            HIP_TRY(launch_ms_units(wt.list_count + nlist, wt.list_pair_off + nlist, nlist, qt,
+            m.pairs = w2.pairs;
+            HIP_TRY(launch_ms_units(w2.list_count + nlist, w2.list_pair_off + nlist, nlist, qt,
                                     ws->ms_unit_off.as<int64_t>(), ws->ms_nunits.as<int64_t>(),
                                     ws->ms_units.as<KnItem>(), idx->d_list_len.as<int64_t>(), idx->code_size,
                                     idx->scan_bytes_dev.as<double>() + 2, s));
@@ -1305,6 +1339,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             HIP_TRY(launch_ms_flag_pairs(overflow, 2, keys_p, nq, nprobe, nlist, idx->d_list_len.as<int64_t>(), k,
                                          ws->items.as<KnItem>(), wt.pairs, wt.nitems, nullptr, s));
             MScanArgs r = m;
+            r.pairs = wt.pairs; // (ms_flag_pairs wrote the retried queries' one-pair units there)
             r.units = ws->items.as<KnItem>();
             r.nunits_dev = wt.nitems;
             r.unit_loop = 1;
