@@ -225,7 +225,7 @@ def main():
         sub = run_config(b, rank, world, dev, dev_id, comm)
         if rank == 0:
             out.setdefault("extra_configs", {})[name] = {key: sub[key] for key in
-                ("metric", "value", "unit", "ms_per_step", "recall_at_10", "config", "roofline", "host_boundary", "cpu_baseline")
+                ("metric", "value", "unit", "ms_per_step", "recall_at_10", "result_crc32", "config", "roofline", "host_boundary", "cpu_baseline")
                 if key in sub}
     if rank == 0:
         print(json.dumps(out), flush=True)
@@ -258,9 +258,14 @@ def run_config(a, rank, world, dev, dev_id, comm):
     elif world > 1:
         # rank 0 trains; centroids and codec parameters are broadcast so every shard quantises identically
         if rank == 0:
-            tmp = kb.build_ivf(spec, kind, metric, a.nlist, a.m, device=str(dev), train_only=True,
+            # (keep_vectors as at N = 1: with refine the single-GPU build trains on the resident rows, else on a sample --
+            # the same input here, so that every N searches the SAME index and `result_crc32` can be compared across N)
+            tmp = kb.build_ivf(spec, kind, metric, a.nlist, a.m, device=str(dev), train_only=True, keep_vectors=refine,
                                train_per_centroid=a.train_per_centroid, niter=a.niter, verbose=a.verbose)
             cen, cb, sq = tmp.centroids, tmp.codebooks, tmp.sq_trained
+            tmp.gpu.close()
+            tmp = None
+            torch.cuda.empty_cache()
         else:
             cen = torch.empty((a.nlist, a.d), device=dev)
             cb = torch.empty((a.m, 256, a.d // a.m), device=dev) if kind == kidx.IVF_PQ else None
@@ -370,6 +375,10 @@ def run_config(a, rank, world, dev, dev_id, comm):
     hits = (I[:ngt].unsqueeze(2) == gt.unsqueeze(1)).any(dim=2).float().sum().item()
     rec = hits / (ngt * a.k)
     log(rank, f"recall@{a.k} = {rec:.4f} over {ngt} queries (refine_k={a.refine_k})")
+    # a fingerprint of batch 0's (ids, distance bits): the same for every N when the same index is searched (the sharded
+    # path returns the single GPU's answer bit for bit) -- lets the driver's N = 1, 2, 4, 8 lines be compared
+    import zlib
+    result_crc = "%08x" % (zlib.crc32(D.cpu().numpy().tobytes(), zlib.crc32(I.cpu().numpy().tobytes())) & 0xffffffff)
 
     # ---------------------------------------------------------------- timed region
     def barrier():
@@ -473,6 +482,7 @@ def run_config(a, rank, world, dev, dev_id, comm):
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "recall_at_10": round(rec, 4), "recall_gate_met": bool(rec >= 0.95) if gate else None,
+            "result_crc32": result_crc,
             "config": {"name": a.config,
                        "workload": f"{label}{' m=%d nbits=8' % a.m if kind == kidx.IVF_PQ else ''} {a.metric.upper()}, "
                                    f"{a.nb} x d={a.d} fp32{' (int8-valued)' if a.data == 'int8' else ''}, "

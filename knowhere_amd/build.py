@@ -198,7 +198,7 @@ def build_ivf(spec, kind, metric, nlist, M=32, device="cuda:0", train_per_centro
     own_t = torch.from_numpy(np.asarray(owned_lists, bool)).to(dev) if owned_lists is not None else None
     # the raw rows when they are kept whole (single-GPU refine): generated once, used for training AND encoding
     vectors = None
-    if keep_vectors and own_t is None and not train_only:
+    if keep_vectors and own_t is None:  # (also for train_only: rank 0 of a sharded build trains on what a single GPU trains on)
         vectors = torch.empty((hi - lo, d), device=dev)
         vpos = 0
         for c in range(c0, c1):
