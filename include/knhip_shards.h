@@ -2,11 +2,16 @@
  *
  * Replaces what faiss does host-side for sharded indexes -- IndexShards::search + merge_knn_results
  * (/root/reference/thirdparty/faiss/faiss/IndexShards.cpp:247-256, utils/Heap.h:636) -- with one step per query batch:
- *   every GPU scans the inverted lists it owns (knhip_search_device on its own index: centroids, codebooks / SQ ranges
- *   replicated, the lists of the other GPUs empty), ONE all-gather of the per-GPU (nq, k) partial results over RCCL /
- *   xGMI (packed 12 bytes per entry: distance + id), one merge kernel per GPU (knhip_merge_topk_device), rank 0's copy
- *   is returned.  Candidates of different lists are disjoint, so the result is bit-identical to the single-GPU search of
- *   the whole index (tests/test_gpu_shards.py).
+ *   the coarse quantizer on a slice of the queries per GPU + an all-gather of the assignment; every GPU scans the inverted
+ *   lists it owns for a CANONICAL top-(k + 1) (knhip_search_canonical_device on its own index: centroids, codebooks / SQ
+ *   ranges replicated, the lists of the other GPUs empty), ONE all-gather of the per-GPU (nq, k + 1) partials over RCCL /
+ *   xGMI (packed 12 bytes per entry: distance + id), one merge kernel per GPU (knhip_merge_topk_device); the queries whose
+ *   k-th and (k + 1)-th entries tie are resolved over ALL shards' candidates (knhip_tie_flag_device, per-shard
+ *   knhip_tie_arrivals_device, one more small all-gather, knhip_tie_resolve_device: the steps of include/knhip.h); rank
+ *   0's copy is returned.  Candidates of different lists are disjoint and the boundary rule is applied once, after the
+ *   merge, so the result is bit-identical to the single-GPU search of the whole index, including WHICH of several rows
+ *   tied at the k-th distance is returned (tests/test_gpu_shards.py: world 2 / 3 / 4, no licence).  With a refine store
+ *   (knhip_shard_group_set_raw / _set_raw_rows) the shards exchange per-candidate distances and run one selection.
  * The host side is C++ (knowhere_amd/host/shard_group.cc): one worker thread per GPU inside one process,
  * ncclCommInitAll over device_ids[] -- the shape a Knowhere node owning several devices would use.  transport:
  *   KNHIP_SHARDS_RCCL    ncclAllGather on the workers' streams (needs distinct devices)
