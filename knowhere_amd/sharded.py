@@ -14,9 +14,12 @@ the top-k of the union of per-shard top-k.
   * every rank builds, encodes and keeps ONLY the rows of the lists it owns -- codes, ids and (for `refine`)
     the raw fp32 vectors: a PQ candidate found in a rank's lists is re-ranked against that rank's own rows
   * collectives on the data path: one all-gather of the query-sharded coarse assignment (keys + distances in one
-    packed buffer) and ONE all-gather of the per-rank final (nq, k) partial (distance, id) pairs, packed in one
-    12-byte-per-entry buffer -- 1.2 MB per rank at nq=10^4, k=10 -- then knhip_merge_topk_device.
-    xGMI is point-to-point; at this size the all-gather is latency-bound, not link-bound.
+    packed buffer) and ONE all-gather of the per-rank CANONICAL (nq, k + 1) partial (distance, id) pairs, packed in one
+    12-byte-per-entry buffer, then knhip_merge_topk_device; queries whose k-th and (k + 1)-th merged entries tie are
+    resolved over ALL ranks' candidates (search_sharded: knhip_tie_flag / _arrivals / _resolve, one more small
+    all-gather, only in batches that flag something); with refine, one all-gather of per-candidate distances and one
+    selection (refine_sharded).  The answer is the single GPU's bit for bit, boundary ties included.
+    xGMI is point-to-point; at these sizes the all-gathers are latency-bound, not link-bound.
 """
 import numpy as np
 import torch
