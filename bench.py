@@ -572,10 +572,11 @@ def make_roofline(a, kind, prof, world):
 
     cf = prof["coarse_flops"] / max(prof["launches"][S.STAGE_COARSE], 1)
     if stages["coarse"] > 0 and cf > 0:
-        # coarse_gemm.hip: where nlist >= 2048 and nlist / 32 >= 2 (nprobe + margin) the prefilter runs on the bf16 pipe --
+        # coarse_gemm.hip: where nlist >= 2048 and nlist / 32 (or / 16) >= 2 (nprobe + margin) the prefilter runs on the bf16 pipe --
         # two GEMM passes (group minima -> bound; candidates under the bound) of three bf16 products each; else one fp32 GEMM
         ncand = a.nprobe + max(32, a.nprobe // 4)
-        bf16 = (a.nlist >= 2048 and a.nlist // 32 >= 2 * ncand and a.nlist // 32 <= 4096
+        g32, g16 = (a.nlist + 31) // 32, (a.nlist + 15) // 16  # (groups of 32 centroids, else of 16: coarse_bf16_group_rows)
+        bf16 = (a.nlist >= 2048 and ((g32 >= 2 * ncand and g32 <= 4096) or (g16 >= 2 * ncand and g16 <= 4096))
                 and os.environ.get("KNHIP_COARSE") is None)
         flops, peak = (6.0 * cf, MFMA_F16_PEAK_TFLOPS) if bf16 else (cf, MFMA_F32_PEAK_TFLOPS)
         common["coarse_stage"] = {"bound": "mfma", "kernel": "knhip::coarse_bf16_kernel (two passes x hi hi + hi lo + lo hi)"

@@ -251,11 +251,11 @@ __global__ __launch_bounds__(256) void coarse_bf16_kernel(const unsigned char* _
                                                           int64_t nq, int64_t nlist, int nslab, int64_t tiles_q,
                                                           int64_t ntiles, float* __restrict__ gmin, int G,
                                                           const float* __restrict__ bound, int32_t* __restrict__ cand_cnt,
-                                                          int64_t* __restrict__ cand, int cap) {
+                                                          int64_t* __restrict__ cand, int cap, int g16) {
     __align__(16) __shared__ unsigned char sA[CB_BM * CB_ROW];
     __align__(16) __shared__ unsigned char sB[CB_BN * CB_ROW];
     __shared__ float s_cn[CB_BM];
-    __shared__ float s_gm[4][CB_BN];
+    __shared__ float s_gm[8][CB_BN]; // group minima of the tile: 4 groups of 32 centroids, or 8 of 16 (g16)
     // XCD-aware tile order: consecutive tile ids share the centroid panel
     const int64_t per = (ntiles + 7) / 8;
     const int64_t tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
@@ -365,10 +365,16 @@ __global__ __launch_bounds__(256) void coarse_bf16_kernel(const unsigned char* _
                 }
             }
             if (MODE == 1) {
-                const float other = __shfl_xor(best, 32, KN_WAVE);
-                best = IS_L2 ? fminf(best, other) : fmaxf(best, other);
-                if (lane < 32) {
-                    s_gm[(wm >> 5) + i][wn + j * 32 + lane] = best;
+                if (g16) {
+                    // groups of 16: the 16 rows this lane holds of the 32-row block (any fixed partition of the centroids
+                    // serves the bound) -- twice the groups, for nlist where 32-row groups are fewer than 2 ncand
+                    s_gm[2 * ((wm >> 5) + i) + (lane >> 5)][wn + j * 32 + (lane & 31)] = best;
+                } else {
+                    const float other = __shfl_xor(best, 32, KN_WAVE);
+                    best = IS_L2 ? fminf(best, other) : fmaxf(best, other);
+                    if (lane < 32) {
+                        s_gm[(wm >> 5) + i][wn + j * 32 + lane] = best;
+                    }
                 }
             }
         }
@@ -398,7 +404,13 @@ __global__ __launch_bounds__(256) void coarse_bf16_kernel(const unsigned char* _
         __syncthreads();
         if (tid < CB_BN && q0 + tid < nq) {
             const float4 o = make_float4(s_gm[0][tid], s_gm[1][tid], s_gm[2][tid], s_gm[3][tid]);
-            *reinterpret_cast<float4*>(gmin + (q0 + tid) * G + c0 / 32) = o;
+            if (g16) {
+                const float4 o2 = make_float4(s_gm[4][tid], s_gm[5][tid], s_gm[6][tid], s_gm[7][tid]);
+                *reinterpret_cast<float4*>(gmin + (q0 + tid) * G + c0 / 16) = o;
+                *reinterpret_cast<float4*>(gmin + (q0 + tid) * G + c0 / 16 + 4) = o2;
+            } else {
+                *reinterpret_cast<float4*>(gmin + (q0 + tid) * G + c0 / 32) = o;
+            }
         }
     }
 }
@@ -633,9 +645,21 @@ hipError_t launch_coarse_rerank(const float* queries, const float* centroids, in
 }
 
 // the bf16 prefilter: group minima -> bound per query -> candidates under the bound (see coarse_bf16_kernel)
+// groups of 32 centroids where there are at least 2 ncand of them (enough for a tight bound), else groups of 16 (round 5:
+// nlist 4096 with nprobe 64 -- C2 -- has 128 groups of 32 for 96 candidates); 0: the shape is not served
+static int coarse_bf16_group_rows(int64_t nlist, int ncand) {
+    if (nlist < 2048) {
+        return 0;
+    }
+    const int64_t g32 = (nlist + 31) / 32, g16 = (nlist + 15) / 16;
+    if (g32 >= 2 * (int64_t)ncand && g32 <= 4096) {
+        return 32;
+    }
+    return (g16 >= 2 * (int64_t)ncand && g16 <= 4096) ? 16 : 0;
+}
+
 bool coarse_bf16_supports(int64_t nlist, int ncand) {
-    const int64_t G = (nlist + 31) / 32;
-    return nlist >= 2048 && G >= 2 * (int64_t)ncand && G <= 4096; // (enough groups for a tight bound)
+    return coarse_bf16_group_rows(nlist, ncand) != 0;
 }
 
 int coarse_bf16_slabs(int d) {
@@ -663,7 +687,12 @@ hipError_t launch_coarse_bf16(const void* q_split, const float* qnorm, const voi
     const int64_t tc = (nlist + CB_BM - 1) / CB_BM, tq = (nq + CB_BN - 1) / CB_BN;
     const int64_t ntiles = tc * tq;
     const unsigned grid = (unsigned)(((ntiles + 7) / 8) * 8);
-    const int G = (int)(tc * (CB_BM / 32)); // (groups of the padded tiles: the padding's minima are the neutral value)
+    const int grows = coarse_bf16_group_rows(nlist, ncand);
+    if (grows == 0) {
+        return hipErrorInvalidValue;
+    }
+    const int g16 = grows == 16 ? 1 : 0;
+    const int G = (int)(tc * (CB_BM / grows)); // (groups of the padded tiles: the padding's minima are the neutral value)
     const int nslab = coarse_bf16_slabs(d);
     const unsigned char* Qs = static_cast<const unsigned char*>(q_split);
     const unsigned char* Cs = static_cast<const unsigned char*>(c_split);
@@ -673,22 +702,23 @@ hipError_t launch_coarse_bf16(const void* q_split, const float* qnorm, const voi
     }
     if (is_l2) {
         hipLaunchKernelGGL((coarse_bf16_kernel<true, 1>), dim3(grid), dim3(256), 0, s, Qs, qnorm, Cs, cnorm, nq, nlist, nslab, tq,
-                           ntiles, gmin, G, nullptr, nullptr, nullptr, 0);
+                           ntiles, gmin, G, nullptr, nullptr, nullptr, 0, g16);
         hipLaunchKernelGGL((coarse_bound_kernel<true>), dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, gmin, G, nq, ncand, bound);
         hipLaunchKernelGGL((coarse_bf16_kernel<true, 2>), dim3(grid), dim3(256), 0, s, Qs, qnorm, Cs, cnorm, nq, nlist, nslab, tq,
-                           ntiles, nullptr, G, bound, cand_cnt, cand, cap);
+                           ntiles, nullptr, G, bound, cand_cnt, cand, cap, g16);
     } else {
         hipLaunchKernelGGL((coarse_bf16_kernel<false, 1>), dim3(grid), dim3(256), 0, s, Qs, qnorm, Cs, cnorm, nq, nlist, nslab, tq,
-                           ntiles, gmin, G, nullptr, nullptr, nullptr, 0);
+                           ntiles, gmin, G, nullptr, nullptr, nullptr, 0, g16);
         hipLaunchKernelGGL((coarse_bound_kernel<false>), dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, gmin, G, nq, ncand, bound);
         hipLaunchKernelGGL((coarse_bf16_kernel<false, 2>), dim3(grid), dim3(256), 0, s, Qs, qnorm, Cs, cnorm, nq, nlist, nslab, tq,
-                           ntiles, nullptr, G, bound, cand_cnt, cand, cap);
+                           ntiles, nullptr, G, bound, cand_cnt, cand, cap, g16);
     }
     return hipGetLastError();
 }
 
+// upper bound of the group count (the gmin scratch: [nq][groups]; groups of 16 at most)
 int64_t coarse_bf16_groups(int64_t nlist) {
-    return ((nlist + CB_BM - 1) / CB_BM) * (CB_BM / 32);
+    return ((nlist + CB_BM - 1) / CB_BM) * (CB_BM / 16);
 }
 
 } // namespace knhip

@@ -93,7 +93,7 @@ def test_coarse(torch_cuda, port, metric):
 @pytest.mark.parametrize("d", [32, 100])
 def test_coarse_bf16_prefilter(torch_cuda, port, metric, d):
     """the coarse prefilter on the bf16 matrix pipe with the selection fused (coarse_gemm.hip, round 5: nlist >= 2048 with
-    enough groups of 32 centroids): keys and coarse distances bit-equal to the reference's, whatever the prefilter's
+    enough groups of 32 -- or, nprobe 40 and 64 here, 16 -- centroids): keys and coarse distances bit-equal to the reference's, whatever the prefilter's
     arithmetic -- and (second half) centroids tied in masses make its certificate fail and the exact fallback answer"""
     torch = torch_cuda
     from knowhere_amd import GpuIndex
