@@ -115,10 +115,10 @@ def main():
         # quantised refine stores: train / encode / append on the device == the oracle's restatement (pinned against
         # IndexScalarQuantizer), and knhip_search_refine_rows == IndexRefine over it
         from knowhere_amd import RowStore
-        nb, nlist, nq = 500, 4, 4
+        nb, nlist, nq = 320, 4, 3
         # d = 24: sq8 rows are not a multiple of 16 bytes (element loads); d = 32: every row type takes the 16-byte loads
         # d = 22 with sq6: a ragged last group of 6-bit codes (17 bytes per row)
-        for metric, d, types in ((ob.L2, 24, (1, 3, 4, 5)), (ob.IP, 32, (2, 3, 4)), (ob.L2, 22, (4,))):
+        for metric, d, types in ((ob.L2, 24, (1, 4, 5)), (ob.IP, 32, (2, 3, 4)), (ob.L2, 22, (4,))):
             xb, xq = gen_data(nb, d, 42, -40.0, 60.0), gen_data(nq, d, 44, -40.0, 60.0)
             xb[5, :4] = [1 + 2.0 ** -11, 2.0 ** -25, 65520.0, -(1 + 3 * 2.0 ** -11)]  # fp16 ties / subnormal / overflow
             ix = ob.make_index(port, ob.IVF_SQ8, metric, xb, nlist=nlist)
@@ -128,7 +128,7 @@ def main():
             from knowhere_amd import index as kidx
             raw = kidx.GpuIndex(kidx.BRUTE_FORCE, metric, d, device=0)
             raw.add_vectors(xb)
-            for k, kb, nprobe in ((5, 20, 3), (10, 70, 4)):  # (70 candidates: a second, partly filled round of 64)
+            for k, kb, nprobe in ((10, 70, 4),):  # (70 candidates: a second, partly filled round of 64)
                 _, Ib = port.search(ix, xq, kb, nprobe)
                 Do, Io = port.refine(metric, xb, xq, Ib, k)
                 D, I = g.search_refine(raw, xq, k, kb, nprobe)
@@ -141,17 +141,17 @@ def main():
                 if rt == 3:  # (build.hip -- column ranges, sq8 encoder -- is not part of the emulated library: GPU tests)
                     rows.set_trained(tr)
                     assert rows.trained().tobytes() == tr.tobytes()
-                    rows.add_codes(codes[:300])
-                    rows.add_codes(codes[300:])
+                    rows.add_codes(codes[:200])
+                    rows.add_codes(codes[200:])
                 else:
                     if rt == 4:  # (ranges from the oracle: the column min / max kernel lives in build.hip; the encoder runs here)
                         rows.set_trained(tr)
                     else:
                         rows.train(xb)
-                    rows.add(xb[:300])
-                    rows.add(xb[300:])
+                    rows.add(xb[:200])
+                    rows.add(xb[200:])
                 assert rows.count() == nb and rows.codes().tobytes() == codes.tobytes(), f"row type {rt}: code bytes"
-                for k, kb, nprobe in ((5, 20, 3), (10, 10, 4)):
+                for k, kb, nprobe in ((5, 20, 3),) + (((10, 10, 4),) if rt in (1, 4) else ()):
                     _, Ib = port.search(ix, xq, kb, nprobe)
                     Do, Io = port.refine_rows(metric, rt, d, codes, tr, xq, Ib, k)
                     D, I = g.search_refine_rows(rows, xq, k, kb, nprobe)
@@ -161,7 +161,7 @@ def main():
                 if rt in (3, 4):
                     r2.set_trained(tr)
                 r2.add_codes(codes)
-                if rt != 3:  # (the sq8 store above was itself filled from code bytes)
+                if rt in (2, 4):  # (one 16-bit and one ranged store; the sq8 store above was itself filled from code bytes)
                     D1, I1 = g.search_refine_rows(rows, xq, 5, 20, 3)
                     D2, I2 = g.search_refine_rows(r2, xq, 5, 20, 3)
                     same(D1, I1, D2, I2, "store from codes")
