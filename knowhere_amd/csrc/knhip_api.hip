@@ -4321,19 +4321,29 @@ int knhip_profile_get(const knhip_index* idx, knhip_stage_times* out) {
 }
 
 const char* knhip_stage_kernel_name(int stage, int kind) {
+    // (the kernels of a large batch on the prefilter paths; small batches and fallbacks take the exact kernels named last)
     switch (stage) {
         case KNHIP_STAGE_COARSE:
-            return "coarse_bf16_kernel (two passes)+coarse_bound_kernel+coarse_rerank_kernel";
+            return "coarse_bf16_kernel (two passes)+coarse_bound_kernel+coarse_rerank_kernel | coarse_gemm_kernel+row_select_thr_kernel";
         case KNHIP_STAGE_GROUP:
-            return "wt_*_kernel";
+            return "wt_*_kernel+ms_unit*_kernel";
         case KNHIP_STAGE_LUT:
             return "pq_query_table_kernel";
         case KNHIP_STAGE_SCAN_RANK0:
-            return "pq_scan_v2_kernel<DUMP>+row_select_kernel+rank0_finalize_kernel";
+            return kind == KNHIP_IVF_PQ ? "pq_sample_kernel | pq_scan_v2_kernel<DUMP>+row_select_kernel"
+                                        : "mscan_flat_kernel<DUMP> | mscan_sq8_kernel<DUMP> +row_select_kernel+ms_tau_kernel";
+        case KNHIP_STAGE_TABLES:
+            return "pqi_query_table_kernel | pqf_query_table_kernel +pqf_predict_kernel";
         case KNHIP_STAGE_SCAN:
-            return kind == KNHIP_IVF_PQ ? "pq_scan_v2_kernel (m=32, k<=128) | pq_scan_kernel" : kind == KNHIP_IVF_SQ8 ? "sq_scan_kernel" : "flat_scan_kernel";
+            return kind == KNHIP_IVF_PQ    ? "pqi_kernel | pqf_kernel | pq_scan_q4_kernel | pq_scan_kernel | pq_scan_any_kernel"
+                   : kind == KNHIP_IVF_SQ8 ? "mscan_sq8_kernel | sq_scan_kernel"
+                                           : "mscan_flatb_kernel | mscan_flat_kernel | flat_scan_kernel";
         case KNHIP_STAGE_MERGE:
-            return "merge_partials_kernel";
+            return "mscan_finish_kernel | merge_partials_kernel";
+        case KNHIP_STAGE_REFINE:
+            return "refine_kernel";
+        case KNHIP_STAGE_TIES:
+            return "tie_detect_kernel+range dump pass+tie_resolve_kernel";
         default:
             return "other";
     }
