@@ -62,7 +62,7 @@ extern "C" {
  * 7: sixteen profiling stages (sample / tables / refine / ties itemised), tie_anomalies; the tie rule for list-sharded
  * indexes (knhip_search_canonical_device, knhip_tie_*, knhip_refine_distances / _combine / _select).
  * Callers compare knhip_abi_version() with the header they were built against. */
-#define KNHIP_ABI_VERSION 7
+#define KNHIP_ABI_VERSION 8
 
 typedef struct knhip_index knhip_index;
 
@@ -282,15 +282,22 @@ int knhip_search_refine(const knhip_index* idx, const knhip_index* raw, const fl
  *         [-128, 127], x_i = code_i - 128 (quantizers.h:350-379); nothing to train.  Distances through the float-domain
  *         distance computer (SIMDLevel::NONE; AVX2 / AVX-512 builds of the reference switch to an integer-domain computer
  *         that truncates the QUERY to bytes, sq-dispatch.h:543-560 -- not restated).
- * `sq4u` (QT_4bit_uniform with quantile-trained ranges for L2) is the one refine type of refine_utils.cc:20-26 without a store.
+ *   sq4u: (round 5) QT_4bit_uniform: ONE range for all dimensions (train_Uniform over the n * d values,
+ *         impl/scalar_quantizer/training.cpp:209-332): RS_minmax by default, RS_quantiles with argument 0.01 where Knowhere
+ *         sets it (L2: refine_utils.cc:176-180) -- knhip_rows_train_uniform(rangestat, arg); code_i = (int)((double)xi * 15.0),
+ *         two codes per byte (Codec4bit, codecs.h:43-59), x_i = vmin + vdiff * ((code_i + 0.5) / 15); trained = {vmin, vdiff}:
+ *         set_trained / get_trained move ONE float each for this type.
  * knhip_search_refine_rows = knhip_search_refine with the second stage reading this store through the scalar quantizer's
  * distance computer (sequential: decode x_i, then (q_i - x_i)^2 / q_i * x_i added in order): bit-equal to the reference.
  * get_codes / add_codes move the faiss code bytes (Serialize / Deserialize: "IxSQ" inside "IxRF"). */
 typedef struct knhip_rows knhip_rows;
-enum { KNHIP_ROWS_FP16 = 1, KNHIP_ROWS_BF16 = 2, KNHIP_ROWS_SQ8 = 3, KNHIP_ROWS_SQ6 = 4, KNHIP_ROWS_INT8 = 5 };
+enum { KNHIP_ROWS_FP16 = 1, KNHIP_ROWS_BF16 = 2, KNHIP_ROWS_SQ8 = 3, KNHIP_ROWS_SQ6 = 4, KNHIP_ROWS_INT8 = 5, KNHIP_ROWS_SQ4U = 6 };
 int knhip_rows_create(int32_t device, int32_t dim, int32_t row_type, knhip_rows** out);
 void knhip_rows_destroy(knhip_rows* rows);
-int knhip_rows_train(knhip_rows* rows, int64_t n, const float* x);                 /* sq8 / sq6 ranges; a no-op otherwise */
+int knhip_rows_train(knhip_rows* rows, int64_t n, const float* x);                 /* sq8 / sq6 / sq4u ranges; a no-op otherwise */
+/* sq4u: the one range from all n * dim values; rangestat 0 = RS_minmax (widened by arg), 2 = RS_quantiles (the arg-quantile
+ * and its mirror: ScalarQuantizer::RangeStat).  knhip_rows_train on an sq4u store = (0, 0), the ScalarQuantizer default */
+int knhip_rows_train_uniform(knhip_rows* rows, int64_t n, const float* x, int32_t rangestat, float rangestat_arg);
 int knhip_rows_set_trained(knhip_rows* rows, const float* vmin, const float* vdiff);
 int knhip_rows_get_trained(const knhip_rows* rows, float* vmin, float* vdiff);
 int knhip_rows_add(knhip_rows* rows, int64_t n, const float* x);                   /* encode + append (host fp32 rows) */

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("KNHIP_LIB") or os.path.join(_HERE, "libknhip.so")  # 
 BRUTE_FORCE, IVF_FLAT, IVF_PQ, IVF_SQ8 = 0, 1, 2, 3
 L2, IP = 0, 1
 NSTAGE = 16
-ABI_VERSION = 7  # KNHIP_ABI_VERSION of include/knhip.h
+ABI_VERSION = 8  # KNHIP_ABI_VERSION of include/knhip.h
 (STAGE_COARSE, STAGE_GROUP, STAGE_LUT, STAGE_SCAN, STAGE_MERGE, STAGE_OTHER, STAGE_SCAN_RANK0, STAGE_TABLES, STAGE_REFINE,
  STAGE_TIES) = range(10)
 STAGE_NAMES = ["coarse", "group", "lut", "scan", "merge", "other", "scan_rank0", "tables", "refine", "ties"]
@@ -57,7 +57,7 @@ SYMBOLS = [
     "knhip_index_encode_device", "knhip_index_get_coarse", "knhip_index_get_pq", "knhip_index_get_sq",
     "knhip_index_get_list_sizes", "knhip_index_get_lists", "knhip_index_get_vectors_device", "knhip_search_refine",
     "knhip_index_get_vectors", "knhip_index_find_vectors", "knhip_index_assign", "knhip_device_memory",
-    "knhip_rows_create", "knhip_rows_destroy", "knhip_rows_train", "knhip_rows_set_trained", "knhip_rows_get_trained",
+    "knhip_rows_create", "knhip_rows_destroy", "knhip_rows_train", "knhip_rows_train_uniform", "knhip_rows_set_trained", "knhip_rows_get_trained",
     "knhip_rows_add", "knhip_rows_add_codes", "knhip_rows_get_codes", "knhip_rows_count", "knhip_rows_code_size",
     "knhip_rows_device_bytes", "knhip_search_refine_rows", "knhip_refine_rows_device",
     "knhip_fvec_L1_ny", "knhip_fvec_Linf_ny", "knhip_fvec_norms_L2sqr_ref", "knhip_fvec_L2sqr_ny_transposed",
@@ -172,6 +172,7 @@ def load():
     L.knhip_rows_destroy.argtypes = [vp]
     L.knhip_rows_destroy.restype = None
     L.knhip_rows_train.argtypes = [vp, i64, vp]
+    L.knhip_rows_train_uniform.argtypes = [vp, i64, vp, i32, C.c_float]
     L.knhip_rows_set_trained.argtypes = [vp, vp, vp]
     L.knhip_rows_get_trained.argtypes = [vp, vp, vp]
     L.knhip_rows_add.argtypes = [vp, i64, vp]

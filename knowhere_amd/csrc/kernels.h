@@ -559,6 +559,10 @@ hipError_t launch_refine(const float* base, int64_t nbase, int64_t id_base, int 
 hipError_t launch_rows_encode16(const float* x, int64_t n_elems, bool bf16, uint16_t* out, hipStream_t s);
 hipError_t launch_rows_encode6(const float* x, int64_t n, int d, const float* trained, uint8_t* out, hipStream_t s);
 hipError_t launch_rows_encode_i8(const float* x, int64_t n_elems, uint8_t* out, hipStream_t s);
+hipError_t launch_rows_encode4u(const float* x, int64_t n, int d, const float* trained, uint8_t* out, hipStream_t s);
+// one pass of the radix select behind the quantile range of an sq4u store: hist[2][256] (64-bit counters, accumulated)
+hipError_t launch_rows_key_hist(const float* x, int64_t n, uint32_t mask, uint32_t prefix_lo, uint32_t prefix_hi, int shift,
+                                unsigned long long* hist, hipStream_t s);
 
 // ---- build.hip: Train / Add on the device ----
 // direct map of an IVF-Flat index (GetVectorByIds): ids sorted with the columns of their rows in the interleaved store

@@ -2173,8 +2173,13 @@ struct knhip_rows {
     DevBuf codes;      // [n][code_size]
     DevBuf sq;         // vmin[d], vdiff[d] (sq8)
     std::mutex mu;
-    bool ranged() const { return row_type == KNHIP_ROWS_SQ8 || row_type == KNHIP_ROWS_SQ6; } // per-dimension vmin / vdiff
+    // trained ranges: per-dimension vmin / vdiff (sq8, sq6: 2 d floats) or one for all dimensions (sq4u: 2 floats)
+    bool ranged() const { return row_type == KNHIP_ROWS_SQ8 || row_type == KNHIP_ROWS_SQ6 || row_type == KNHIP_ROWS_SQ4U; }
+    int nrange() const { return row_type == KNHIP_ROWS_SQ4U ? 1 : d; } // floats per half of the trained vector
     int64_t code_size() const {
+        if (row_type == KNHIP_ROWS_SQ4U) {
+            return ((int64_t)d * 4 + 7) / 8;
+        }
         return row_type == KNHIP_ROWS_SQ6 ? ((int64_t)d * 6 + 7) / 8
              : (row_type == KNHIP_ROWS_SQ8 || row_type == KNHIP_ROWS_INT8) ? (int64_t)d : 2 * (int64_t)d;
     }
@@ -2183,7 +2188,7 @@ struct knhip_rows {
 extern "C" {
 
 int knhip_rows_create(int32_t device, int32_t dim, int32_t row_type, knhip_rows** out) {
-    if (!out || dim <= 0 || row_type < KNHIP_ROWS_FP16 || row_type > KNHIP_ROWS_INT8) {
+    if (!out || dim <= 0 || row_type < KNHIP_ROWS_FP16 || row_type > KNHIP_ROWS_SQ4U) {
         return fail(KNHIP_ERR_INVALID_ARGS, "rows_create: dim > 0 and row type fp16 / bf16 / sq8");
     }
     if (device < 0 || device >= knhip_device_count()) {
@@ -2211,13 +2216,14 @@ int64_t knhip_rows_device_bytes(const knhip_rows* r) { return r ? (int64_t)(r->c
 
 int knhip_rows_set_trained(knhip_rows* r, const float* vmin, const float* vdiff) {
     if (!r || !r->ranged() || !vmin || !vdiff) {
-        return fail(KNHIP_ERR_INVALID_ARGS, "rows_set_trained: an sq8 / sq6 store and two arrays of dim floats");
+        return fail(KNHIP_ERR_INVALID_ARGS, "rows_set_trained: an sq8 / sq6 / sq4u store and two arrays of dim (sq4u: 1) floats");
     }
     DeviceGuard g(r->device);
     std::lock_guard<std::mutex> lk(r->mu);
-    HIP_TRY(r->sq.reserve((size_t)2 * r->d * sizeof(float)));
-    HIP_TRY(hipMemcpy(r->sq.p, vmin, (size_t)r->d * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(r->sq.as<float>() + r->d, vdiff, (size_t)r->d * sizeof(float), hipMemcpyHostToDevice));
+    const size_t nr = (size_t)r->nrange();
+    HIP_TRY(r->sq.reserve(2 * nr * sizeof(float)));
+    HIP_TRY(hipMemcpy(r->sq.p, vmin, nr * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(r->sq.as<float>() + nr, vdiff, nr * sizeof(float), hipMemcpyHostToDevice));
     r->trained = true;
     return KNHIP_OK;
 }
@@ -2227,8 +2233,9 @@ int knhip_rows_get_trained(const knhip_rows* r, float* vmin, float* vdiff) {
         return fail(KNHIP_ERR_NOT_TRAINED, "rows_get_trained: a trained sq8 / sq6 store");
     }
     DeviceGuard g(r->device);
-    HIP_TRY(hipMemcpy(vmin, r->sq.p, (size_t)r->d * sizeof(float), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(vdiff, r->sq.as<float>() + r->d, (size_t)r->d * sizeof(float), hipMemcpyDeviceToHost));
+    const size_t nr = (size_t)r->nrange();
+    HIP_TRY(hipMemcpy(vmin, r->sq.p, nr * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(vdiff, r->sq.as<float>() + nr, nr * sizeof(float), hipMemcpyDeviceToHost));
     return KNHIP_OK;
 }
 
@@ -2240,6 +2247,9 @@ int knhip_rows_train(knhip_rows* r, int64_t n, const float* x) {
     }
     if (!r->ranged()) {
         return KNHIP_OK;
+    }
+    if (r->row_type == KNHIP_ROWS_SQ4U) {
+        return knhip_rows_train_uniform(r, n, x, 0, 0.f); // (RS_minmax, argument 0: the ScalarQuantizer defaults)
     }
     if (n == 0) {
         return fail(KNHIP_ERR_INVALID_ARGS, "rows_train: no training rows");
@@ -2265,6 +2275,90 @@ int knhip_rows_train(knhip_rows* r, int64_t n, const float* x) {
         hi[(size_t)j] = hi[(size_t)j] - lo[(size_t)j];
     }
     return knhip_rows_set_trained(r, lo.data(), hi.data());
+}
+
+// ScalarQuantizer::train for QT_4bit_uniform: train_Uniform over the n * d values (impl/scalar_quantizer/training.cpp:209-332).
+// RS_minmax: min / max widened by arg * (max - min).  RS_quantiles: o = (idx_t)(arg * N) -- a FLOAT product, as the
+// reference forms it --, vmin = the o-th smallest value, vmax = the (N - 1 - o)-th: a radix select over the order-
+// preserving keys, eight bits per pass, the host slices re-uploaded per pass (training runs once per index).
+int knhip_rows_train_uniform(knhip_rows* r, int64_t n, const float* x, int32_t rangestat, float rangestat_arg) {
+    if (!r || r->row_type != KNHIP_ROWS_SQ4U || n <= 0 || !x || (rangestat != 0 && rangestat != 2)) {
+        return fail(KNHIP_ERR_INVALID_ARGS, "rows_train_uniform: an sq4u store, training rows, rangestat 0 (minmax) or 2 (quantiles)");
+    }
+    DeviceGuard g(r->device);
+    const int d = r->d;
+    const int64_t N = n * (int64_t)d;
+    const int64_t step = (int64_t)1 << 28; // values per slice (1 GiB)
+    float vmin = 0.f, vmax = 0.f;
+    DevBuf dx;
+    if (rangestat == 0) {
+        DevBuf mm;
+        HIP_TRY(mm.alloc((size_t)2 * d * sizeof(float)));
+        std::vector<float> ab((size_t)2 * d);
+        vmin = INFINITY;
+        vmax = -INFINITY;
+        const int64_t rstep = std::max<int64_t>(1, step / d);
+        for (int64_t r0 = 0; r0 < n; r0 += rstep) { // (column extrema per slice of rows, reduced on the host: order independent)
+            const int64_t m = std::min(rstep, n - r0);
+            if (int rc = upload(dx, x + r0 * d, (size_t)m * d * sizeof(float))) return rc;
+            HIP_TRY(launch_col_minmax(dx.as<float>(), m, d, mm.as<float>(), mm.as<float>() + d, nullptr));
+            HIP_TRY(hipMemcpy(ab.data(), mm.p, (size_t)2 * d * sizeof(float), hipMemcpyDeviceToHost));
+            for (int j = 0; j < d; j++) {
+                vmin = std::min(vmin, ab[(size_t)j]);
+                vmax = std::max(vmax, ab[(size_t)d + j]);
+            }
+        }
+        const float vexp = (vmax - vmin) * rangestat_arg;
+        vmin -= vexp;
+        vmax += vexp;
+    } else {
+        int64_t o = static_cast<int64_t>(rangestat_arg * N); // (float * idx_t: the count is converted to float)
+        if (o < 0) o = 0;
+        if (o > N - o) o = N / 2;
+        int64_t rank[2] = {o, N - 1 - o}; // 0-based ranks still to find inside the current prefixes
+        uint32_t prefix[2] = {0u, 0u}, mask = 0u;
+        DevBuf dh;
+        HIP_TRY(dh.alloc(512 * sizeof(unsigned long long)));
+        std::vector<unsigned long long> h(512);
+        const bool resident = N <= step;
+        if (resident) {
+            if (int rc = upload(dx, x, (size_t)N * sizeof(float))) return rc;
+        }
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            HIP_TRY(hipMemset(dh.p, 0, 512 * sizeof(unsigned long long)));
+            for (int64_t i0 = 0; i0 < N; i0 += step) {
+                const int64_t m = std::min(step, N - i0);
+                if (!resident) {
+                    if (int rc = upload(dx, x + i0, (size_t)m * sizeof(float))) return rc;
+                }
+                HIP_TRY(launch_rows_key_hist(dx.as<float>(), m, mask, prefix[0], prefix[1], shift,
+                                             dh.as<unsigned long long>(), nullptr));
+                HIP_TRY(hipDeviceSynchronize());
+            }
+            HIP_TRY(hipMemcpy(h.data(), dh.p, 512 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            for (int w = 0; w < 2; w++) {
+                int b = 0;
+                int64_t left = rank[w];
+                while (b < 255 && left >= (int64_t)h[(size_t)w * 256 + b]) {
+                    left -= (int64_t)h[(size_t)w * 256 + b];
+                    b++;
+                }
+                rank[w] = left;
+                prefix[w] |= (uint32_t)b << shift;
+            }
+            mask |= 0xffu << shift;
+        }
+        auto unkey = [](uint32_t key) {
+            const uint32_t bits = (key & 0x80000000u) ? (key & 0x7fffffffu) : ~key;
+            float f;
+            std::memcpy(&f, &bits, 4);
+            return f;
+        };
+        vmin = unkey(prefix[0]);
+        vmax = unkey(prefix[1]);
+    }
+    const float vdiff = vmax - vmin;
+    return knhip_rows_set_trained(r, &vmin, &vdiff);
 }
 
 static int rows_append(knhip_rows* r, int64_t n, const void* d_new_codes) {
@@ -2310,6 +2404,8 @@ int knhip_rows_add(knhip_rows* r, int64_t n, const float* x) {
             HIP_TRY(launch_rows_encode6(dx.as<float>(), m, d, r->sq.as<float>(), dc.as<uint8_t>(), nullptr));
         } else if (r->row_type == KNHIP_ROWS_INT8) {
             HIP_TRY(launch_rows_encode_i8(dx.as<float>(), m * d, dc.as<uint8_t>(), nullptr));
+        } else if (r->row_type == KNHIP_ROWS_SQ4U) {
+            HIP_TRY(launch_rows_encode4u(dx.as<float>(), m, d, r->sq.as<float>(), dc.as<uint8_t>(), nullptr));
         } else {
             HIP_TRY(launch_rows_encode16(dx.as<float>(), m * d, r->row_type == KNHIP_ROWS_BF16, dc.as<uint16_t>(), nullptr));
         }

@@ -20,6 +20,8 @@
 // (51 GB) next to its codes, so refine is a ~0.5 GB random gather per 10k-query batch: noise
 // next to the scan, and what lifts PQ32 recall@10 past 0.95.
 
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -29,7 +31,8 @@ constexpr int RF_PITCH = 17 * 16; // bytes per staged row piece set (16 pieces +
 constexpr uint32_t REFINE_NOT_HERE = 0xffffffffu; // a NaN pattern no arithmetic produces: "this shard does not hold the row"
 
 // ROWT: 0 fp32 rows, 1 fp16, 2 bf16, 3 per-dimension 8-bit codes (sq = vmin[d], vdiff[d]), 4 per-dimension 6-bit codes (four
-// per three bytes: Codec6bit, codecs.h:63-118), 5 signed bytes stored + 128 (Quantizer8bitDirectSigned, quantizers.h:350-379)
+// per three bytes: Codec6bit, codecs.h:63-118), 5 signed bytes stored + 128 (Quantizer8bitDirectSigned, quantizers.h:350-379),
+// 6 4-bit codes with ONE range for all dimensions (sq = {vmin, vdiff}; Codec4bit, codecs.h:43-59, QuantizerTemplate UNIFORM)
 template <int ROWT>
 __device__ __forceinline__ float refine_row_value(const void* row, int i, const float* __restrict__ sq, int d) {
     if (ROWT == 1) {
@@ -57,12 +60,19 @@ __device__ __forceinline__ float refine_row_value(const void* row, int i, const 
     if (ROWT == 5) {
         return (float)((int)reinterpret_cast<const uint8_t*>(row)[i] - 128);
     }
+    if (ROWT == 6) {
+        const uint32_t bits = ((uint32_t)reinterpret_cast<const uint8_t*>(row)[i >> 1] >> ((i & 1) << 2)) & 0xfu;
+        const float xi = __fdiv_rn(fadd_x((float)bits, 0.5f), 15.0f);
+        return fadd_x(sq[0], fmul_x(xi, sq[1]));
+    }
     return reinterpret_cast<const float*>(row)[i];
 }
 
 // bytes of one stored row
 __host__ __device__ inline int64_t refine_row_bytes(int row_type, int d) {
-    return row_type == 4 ? ((int64_t)d * 6 + 7) / 8 : (row_type == 3 || row_type == 5) ? (int64_t)d : row_type == 0 ? 4 * (int64_t)d : 2 * (int64_t)d;
+    return row_type == 4   ? ((int64_t)d * 6 + 7) / 8
+           : row_type == 6 ? ((int64_t)d * 4 + 7) / 8
+           : (row_type == 3 || row_type == 5) ? (int64_t)d : row_type == 0 ? 4 * (int64_t)d : 2 * (int64_t)d;
 }
 
 template <bool IS_L2, int R, int ROWT>
@@ -127,8 +137,8 @@ __global__ __launch_bounds__(256) void refine_kernel(const float* __restrict__ b
             constexpr int EPC = 16 / ESZ; // elements per 16-byte piece
             const unsigned char* y = reinterpret_cast<const unsigned char*>(base) + (id - id_base) * refine_row_bytes(ROWT, d);
             int i = 0;
-            // (6-bit codes straddle bytes: the element loop below)
-            if (ROWT != 4 && ((d * ESZ) & 15) == 0 && (reinterpret_cast<uintptr_t>(base) & 15) == 0) {
+            // (6-bit codes straddle bytes, 4-bit codes share them: the element loop below)
+            if (ROWT != 4 && ROWT != 6 && ((d * ESZ) & 15) == 0 && (reinterpret_cast<uintptr_t>(base) & 15) == 0) {
                 // 16-byte loads, eight in flight per lane (as the fp32 rows below); decoded and added in element order
                 const uint4* y4 = reinterpret_cast<const uint4*>(y);
                 const int n16 = (d * ESZ) >> 4;
@@ -328,7 +338,8 @@ hipError_t launch_refine(const float* base, int64_t nbase, int64_t id_base, int 
     if (nq <= 0) {
         return hipSuccess;
     }
-    if (row_type < 0 || row_type > 5 || ((row_type == 3 || row_type == 4) && sq_trained == nullptr && dist_in == nullptr) ||
+    if (row_type < 0 || row_type > 6 ||
+        ((row_type == 3 || row_type == 4 || row_type == 6) && sq_trained == nullptr && dist_in == nullptr) ||
         (dist_in != nullptr && dist_out != nullptr)) {
         return hipErrorInvalidValue;
     }
@@ -367,6 +378,7 @@ hipError_t launch_refine(const float* base, int64_t nbase, int64_t id_base, int 
         case 3: KN_REFINE_LAUNCH(3); break;
         case 4: KN_REFINE_LAUNCH(4); break;
         case 5: KN_REFINE_LAUNCH(5); break;
+        case 6: KN_REFINE_LAUNCH(6); break;
         default: KN_REFINE_LAUNCH(0); break;
     }
 #undef KN_REFINE_LAUNCH
@@ -461,6 +473,84 @@ __global__ void rows_encode_i8_kernel(const float* __restrict__ x, int64_t n, ui
         return;
     }
     out[t] = (uint8_t)(int)fadd_x(x[t], 128.0f);
+}
+
+// QT_4bit_uniform (QuantizerTemplate<Codec4bit, UNIFORM>::encode_vector, quantizers.h:76-90): xi = (x - vmin) / vdiff clamped
+// to [0, 1] (0 when vdiff == 0), code = (int)(xi * 15.0) -- the DOUBLE product of the reference, codecs.h:51 --, dimension i
+// in the low (even i) or high nibble of byte i / 2.  Thread per output byte.
+__global__ void rows_encode4u_kernel(const float* __restrict__ x, int64_t n, int d, const float* __restrict__ trained,
+                                     uint8_t* __restrict__ out) {
+    const int cs = (d + 1) >> 1;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * cs) {
+        return;
+    }
+    const int64_t r = t / cs;
+    const int b = (int)(t % cs);
+    const float vmin = trained[0], vdiff = trained[1];
+    uint32_t byte = 0u;
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        const int i = 2 * b + e;
+        if (i < d) {
+            float xi = 0.f;
+            if (vdiff != 0.f) {
+                xi = __fdiv_rn(fsub_x(x[r * d + i], vmin), vdiff);
+                xi = xi < 0.f ? 0.f : xi;
+                xi = xi > 1.0f ? 1.0f : xi;
+            }
+            byte |= (uint32_t)(int)((double)xi * 15.0) << (4 * e);
+        }
+    }
+    out[t] = (uint8_t)byte;
+}
+
+// train_Uniform, RS_quantiles (training.cpp:247-261): order statistics of ALL values by a radix select over their
+// order-preserving 32-bit keys, eight bits per pass.  One pass: the 256-bin histograms of the values whose key starts with
+// prefix_lo / prefix_hi (the two ranks are walked together: the o-th smallest and the (n - 1 - o)-th).
+__global__ __launch_bounds__(256) void rows_key_hist_kernel(const float* __restrict__ x, int64_t n, uint32_t mask,
+                                                            uint32_t prefix_lo, uint32_t prefix_hi, int shift,
+                                                            unsigned long long* __restrict__ hist) {
+    __shared__ uint32_t s_h[2][256];
+    s_h[0][threadIdx.x] = 0u;
+    s_h[1][threadIdx.x] = 0u;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t b = __float_as_uint(x[i]);
+        const uint32_t key = (b & 0x80000000u) ? ~b : (b | 0x80000000u); // ascending with the value
+        if ((key & mask) == prefix_lo) {
+            atomicAdd(&s_h[0][(key >> shift) & 255u], 1u);
+        }
+        if ((key & mask) == prefix_hi) {
+            atomicAdd(&s_h[1][(key >> shift) & 255u], 1u);
+        }
+    }
+    __syncthreads();
+    if (s_h[0][threadIdx.x]) {
+        atomicAdd(hist + threadIdx.x, (unsigned long long)s_h[0][threadIdx.x]);
+    }
+    if (s_h[1][threadIdx.x]) {
+        atomicAdd(hist + 256 + threadIdx.x, (unsigned long long)s_h[1][threadIdx.x]);
+    }
+}
+
+hipError_t launch_rows_key_hist(const float* x, int64_t n, uint32_t mask, uint32_t prefix_lo, uint32_t prefix_hi, int shift,
+                                unsigned long long* hist, hipStream_t s) {
+    if (n <= 0) {
+        return hipSuccess;
+    }
+    const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(rows_key_hist_kernel, dim3(grid), dim3(256), 0, s, x, n, mask, prefix_lo, prefix_hi, shift, hist);
+    return hipGetLastError();
+}
+
+hipError_t launch_rows_encode4u(const float* x, int64_t n, int d, const float* trained, uint8_t* out, hipStream_t s) {
+    const int64_t nt = n * ((d + 1) >> 1);
+    if (nt <= 0) {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(rows_encode4u_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, x, n, d, trained, out);
+    return hipGetLastError();
 }
 
 hipError_t launch_rows_encode6(const float* x, int64_t n, int d, const float* trained, uint8_t* out, hipStream_t s) {

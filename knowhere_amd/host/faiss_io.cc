@@ -277,15 +277,17 @@ bool ParseFaissIndex(const uint8_t* data, size_t size, FaissIndexData* out, std:
                 q.code_size = r.one<uint64_t>();
                 r.vec(q.trained);
                 r.vec(q.codes);
-                // QT_8bit 0, QT_fp16 4, QT_6bit 6, QT_bf16 7, QT_8bit_direct_signed 8 (impl/ScalarQuantizer.h:27-40)
+                // QT_8bit 0, QT_4bit_uniform 3, QT_fp16 4, QT_6bit 6, QT_bf16 7, QT_8bit_direct_signed 8 (impl/ScalarQuantizer.h:27-40)
                 const uint64_t want = (q.qtype == 0 || q.qtype == 8)   ? q.d
                                       : (q.qtype == 4 || q.qtype == 7) ? 2 * q.d
                                       : q.qtype == 6                   ? (q.d * 6 + 7) / 8
+                                      : q.qtype == 3                   ? (q.d * 4 + 7) / 8
                                                                        : 0;
-                if (want == 0) throw std::runtime_error("refine scalar quantizer type is not fp16 / bf16 / sq8 / sq6 / int8");
-                const bool ranged = q.qtype == 0 || q.qtype == 6;
+                if (want == 0)
+                    throw std::runtime_error("refine scalar quantizer type is not fp16 / bf16 / sq8 / sq6 / int8 / sq4u");
+                const uint64_t ntrained = (q.qtype == 0 || q.qtype == 6) ? 2 * q.d : q.qtype == 3 ? 2 : 0;
                 if (q.d != (uint64_t)q.hdr.d || q.code_size != want || q.codes.size() != (uint64_t)q.hdr.ntotal * want ||
-                    q.trained.size() != (ranged ? 2 * q.d : 0))
+                    q.trained.size() != ntrained)
                     throw std::runtime_error("refine scalar quantizer shape mismatch");
             } else {
                 out->refine_index.fourcc = rcc;

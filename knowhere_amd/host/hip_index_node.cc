@@ -270,8 +270,8 @@ class HipIndexNode : public IndexNode {
         if constexpr (Kind == KNHIP_IVF_PQ || Kind == KNHIP_IVF_SQ8) {
             // a refine index is built iff `refine` AND `refine_type` are given (ivf_wrapper.cc:170, :214).  refine_type
             // (ivf_config.h:64-76, refine_utils.cc:20-58): fp32 / flat = IndexRefineFlat over the raw rows; fp16 / bf16 / sq8
-            // / sq6 / int8 = IndexRefine over an IndexScalarQuantizer store of the rows (knhip_rows); sq4u (quantile-trained
-            // uniform range) is refused, not replaced
+            // / sq6 / int8 / sq4u = IndexRefine over an IndexScalarQuantizer store of the rows (knhip_rows): every type of
+            // get_sq_quantizer_type (refine_utils.cc:19-26)
             has_refine_ = c.refine.value_or(false) && c.refine_type.has_value();
             refine_rows_type_ = 0;
             if (has_refine_) {
@@ -287,9 +287,11 @@ class HipIndexNode : public IndexNode {
                     refine_rows_type_ = KNHIP_ROWS_SQ6;
                 } else if (t == "int8") {
                     refine_rows_type_ = KNHIP_ROWS_INT8;
+                } else if (t == "sq4u") {
+                    refine_rows_type_ = KNHIP_ROWS_SQ4U;
                 } else if (t != "fp32" && t != "flat") {
-                    LOG_KNOWHERE_ERROR_ << TypeName() << ": refine_type " << c.refine_type.value()
-                                        << " is not supported (fp32 / flat / fp16 / bf16 / sq8 / sq6 / int8)";
+                    LOG_KNOWHERE_ERROR_ << TypeName() << ": invalid refine type " << c.refine_type.value()
+                                        << " (fp32 / flat / fp16 / bf16 / sq8 / sq6 / int8 / sq4u)";
                     return Status::invalid_args;
                 }
             }
@@ -314,7 +316,13 @@ class HipIndexNode : public IndexNode {
             // IndexRefine::train trains the refine index on the same rows (IndexRefine.cpp:47-51): the sq8 ranges, on the
             // first device, copied to the stores of the others
             rc = CreateRowStores();
-            if (rc == KNHIP_OK) rc = knhip_rows_train(sh_[0].rows.p, rows, x);
+            if (rc == KNHIP_OK) {
+                // (QT_4bit_uniform + L2 takes its one range from the 1 % / 99 % quantiles: refine_utils.cc:176-180)
+                rc = refine_rows_type_ == KNHIP_ROWS_SQ4U
+                             ? knhip_rows_train_uniform(sh_[0].rows.p, rows, x, metric_ == KNHIP_L2 ? 2 : 0,
+                                                        metric_ == KNHIP_L2 ? 0.01f : 0.f)
+                             : knhip_rows_train(sh_[0].rows.p, rows, x);
+            }
             if (rc == KNHIP_OK) rc = ReplicateRowRanges();
         }
         if (rc) {
@@ -782,13 +790,19 @@ class HipIndexNode : public IndexNode {
                            : refine_rows_type_ == KNHIP_ROWS_BF16 ? 7
                            : refine_rows_type_ == KNHIP_ROWS_SQ6  ? 6
                            : refine_rows_type_ == KNHIP_ROWS_INT8 ? 8
+                           : refine_rows_type_ == KNHIP_ROWS_SQ4U ? 3
                                                                   : 0;
                 sq.rangestat = 0;  // RS_minmax, rangestat_arg 0: the ScalarQuantizer defaults
+                if (refine_rows_type_ == KNHIP_ROWS_SQ4U && metric_ == KNHIP_L2) {
+                    sq.rangestat = 2;  // RS_quantiles, as Knowhere sets it for QT_4bit_uniform + L2 (the fields are written as set)
+                    sq.rangestat_arg = 0.01f;
+                }
                 sq.d = (uint64_t)dim_;
                 sq.code_size = (uint64_t)knhip_rows_code_size(rs);
                 if (RowsRanged()) {
-                    sq.trained.resize((size_t)2 * dim_);
-                    if ((rc = knhip_rows_get_trained(rs, sq.trained.data(), sq.trained.data() + dim_))) return ToStatus(rc);
+                    const size_t nr = RowsRangeLen();
+                    sq.trained.resize(2 * nr);
+                    if ((rc = knhip_rows_get_trained(rs, sq.trained.data(), sq.trained.data() + nr))) return ToStatus(rc);
                 }
                 sq.codes.resize((size_t)count * sq.code_size);
                 for (const auto& sd : sh_) {  // (id ranges in shard order: raw_base ascending)
@@ -935,6 +949,7 @@ class HipIndexNode : public IndexNode {
                             : x.refine_sq.qtype == 7          ? KNHIP_ROWS_BF16
                             : x.refine_sq.qtype == 6          ? KNHIP_ROWS_SQ6
                             : x.refine_sq.qtype == 8          ? KNHIP_ROWS_INT8
+                            : x.refine_sq.qtype == 3          ? KNHIP_ROWS_SQ4U
                                                               : KNHIP_ROWS_SQ8;
         row_scale_by_id_ = std::move(scale_by_id);
         if (Status st = CreateShards(devs); st != Status::success) return st;
@@ -984,7 +999,7 @@ class HipIndexNode : public IndexNode {
             if ((rc = CreateRowStores())) return bail(rc);
             for (int r = 0; r < W; r++) {
                 if (RowsRanged() &&
-                    (rc = knhip_rows_set_trained(sh_[r].rows.p, sq.trained.data(), sq.trained.data() + dim_)))
+                    (rc = knhip_rows_set_trained(sh_[r].rows.p, sq.trained.data(), sq.trained.data() + RowsRangeLen())))
                     return bail(rc);
                 const int64_t lo = ntotal * r / W, hi = ntotal * (r + 1) / W;
                 sh_[r].raw_base = lo;
@@ -1283,19 +1298,24 @@ class HipIndexNode : public IndexNode {
         }
         return KNHIP_OK;
     }
-    // refine stores with per-dimension ranges (sq8, sq6)
+    // refine stores with trained ranges: per dimension (sq8, sq6) or one for all dimensions (sq4u)
     bool
     RowsRanged() const {
-        return refine_rows_type_ == KNHIP_ROWS_SQ8 || refine_rows_type_ == KNHIP_ROWS_SQ6;
+        return refine_rows_type_ == KNHIP_ROWS_SQ8 || refine_rows_type_ == KNHIP_ROWS_SQ6 || refine_rows_type_ == KNHIP_ROWS_SQ4U;
+    }
+    size_t
+    RowsRangeLen() const {  // floats per half (vmin | vdiff) of the trained vector
+        return refine_rows_type_ == KNHIP_ROWS_SQ4U ? 1 : (size_t)dim_;
     }
     // the ranges trained on the first device -> every other store (all devices decode alike)
     int
     ReplicateRowRanges() {
         if (!RowsRanged() || sh_.size() < 2) return KNHIP_OK;
-        std::vector<float> tr((size_t)2 * dim_);
-        if (int rc = knhip_rows_get_trained(sh_[0].rows.p, tr.data(), tr.data() + dim_)) return rc;
+        const size_t nr = RowsRangeLen();
+        std::vector<float> tr(2 * nr);
+        if (int rc = knhip_rows_get_trained(sh_[0].rows.p, tr.data(), tr.data() + nr)) return rc;
         for (size_t r = 1; r < sh_.size(); r++) {
-            if (int rc = knhip_rows_set_trained(sh_[r].rows.p, tr.data(), tr.data() + dim_)) return rc;
+            if (int rc = knhip_rows_set_trained(sh_[r].rows.p, tr.data(), tr.data() + nr)) return rc;
         }
         return KNHIP_OK;
     }

@@ -522,7 +522,7 @@ def refine_device(metric, base_t, xq_t, cand_ids_t, k, id_base=0, stream=None):
     return D, I
 
 
-ROWS_FP16, ROWS_BF16, ROWS_SQ8, ROWS_SQ6, ROWS_INT8 = 1, 2, 3, 4, 5
+ROWS_FP16, ROWS_BF16, ROWS_SQ8, ROWS_SQ6, ROWS_INT8, ROWS_SQ4U = 1, 2, 3, 4, 5, 6
 
 
 class RowStore:
@@ -551,16 +551,24 @@ class RowStore:
         x = np.ascontiguousarray(x, np.float32)
         check(self.L.knhip_rows_train(self.h, x.shape[0], _np_ptr(x)))
 
+    def train_uniform(self, x, rangestat=0, rangestat_arg=0.0):
+        """sq4u: the one range of all dimensions; rangestat 0 = min / max, 2 = quantiles (Knowhere: 2 with 0.01 for L2)"""
+        x = np.ascontiguousarray(x, np.float32)
+        check(self.L.knhip_rows_train_uniform(self.h, x.shape[0], _np_ptr(x), rangestat, C.c_float(rangestat_arg)))
+
+    def _nrange(self):
+        return 1 if self.row_type == ROWS_SQ4U else self.dim
+
     def set_trained(self, trained):
         t = np.ascontiguousarray(trained, np.float32)
-        check(self.L.knhip_rows_set_trained(self.h, _np_ptr(t[:self.dim]), _np_ptr(np.ascontiguousarray(t[self.dim:]))))
+        n = self._nrange()
+        check(self.L.knhip_rows_set_trained(self.h, _np_ptr(np.ascontiguousarray(t[:n])), _np_ptr(np.ascontiguousarray(t[n:]))))
 
     def trained(self):
-        t = np.empty(2 * self.dim, np.float32)
-        lo, hi = t[:self.dim], np.empty(self.dim, np.float32)
+        n = self._nrange()
+        lo, hi = np.empty(n, np.float32), np.empty(n, np.float32)
         check(self.L.knhip_rows_get_trained(self.h, _np_ptr(lo), _np_ptr(hi)))
-        t[self.dim:] = hi
-        return t
+        return np.concatenate([lo, hi])
 
     def add(self, x):
         x = np.ascontiguousarray(x, np.float32)

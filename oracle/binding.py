@@ -24,7 +24,10 @@ _u8p = C.POINTER(C.c_uint8)
 
 
 def rows_code_size(row_type, d):
-    """bytes per row of a quantised refine store: 1 fp16, 2 bf16 (2 d); 3 sq8, 5 int8 (d); 4 sq6 (four values per 3 bytes)"""
+    """bytes per row of a quantised refine store: 1 fp16, 2 bf16 (2 d); 3 sq8, 5 int8 (d); 4 sq6 (four values per 3 bytes);
+    6 sq4u (two values per byte)"""
+    if row_type == 6:
+        return (d * 4 + 7) // 8
     return (d * 6 + 7) // 8 if row_type == 4 else (d if row_type in (3, 5) else 2 * d)
 
 
@@ -396,6 +399,14 @@ class Port(_SimdTable):
         self.lib.orc_rows_train(C.c_int(x.shape[1]), C.c_int64(x.shape[0]), _p(x, _f32p), _p(tr, _f32p))
         return tr
 
+    def rows_train_uniform(self, metric, x):
+        """the one range of a QT_4bit_uniform refine store as Knowhere trains it: quantiles 1 % / 99 % for L2, min / max else"""
+        x = np.ascontiguousarray(x, np.float32)
+        tr = np.empty(2, np.float32)
+        self.lib.orc_rows_train_uniform(C.c_int(2 if metric == L2 else 0), C.c_float(0.01 if metric == L2 else 0.0),
+                                        C.c_int64(x.size), _p(x, _f32p), _p(tr, _f32p))
+        return tr
+
     def rows_encode(self, row_type, x, trained=None):
         x = np.ascontiguousarray(x, np.float32)
         n, d = x.shape
@@ -725,7 +736,7 @@ class Ref(_SimdTable):
         xb = np.ascontiguousarray(xb, np.float32)
         n, d = xb.shape
         codes = np.empty((n, rows_code_size(row_type, d)), np.uint8)
-        tr = np.zeros(2 * d, np.float32)
+        tr = np.zeros(2 * d if row_type != 6 else 2, np.float32)
         self._chk(self.lib.ref_sq_rows(C.c_int(row_type), C.c_int(metric), C.c_int(d), C.c_int64(n), _p(xb, _f32p),
                                        _p(codes, _u8p), _p(tr, _f32p)))
         return codes, tr

@@ -966,11 +966,14 @@ static float orc_decode_fp16(uint16_t h) {
     return f;
 }
 
-/* row types: 1 fp16, 2 bf16, 3 QT_8bit, 4 QT_6bit, 5 QT_8bit_direct_signed (ScalarQuantizer::set_derived_sizes,
+/* row types: 1 fp16, 2 bf16, 3 QT_8bit, 4 QT_6bit, 5 QT_8bit_direct_signed, 6 QT_4bit_uniform (ScalarQuantizer::set_derived_sizes,
  * T:impl/ScalarQuantizer.cpp: code_size = d for the 8-bit types, (d * 6 + 7) / 8 for QT_6bit, 2 d for the 16-bit ones) */
 int64_t orc_rows_code_size(int row_type, int d) {
     if (row_type == 4) {
         return ((int64_t)d * 6 + 7) / 8;
+    }
+    if (row_type == 6) { /* QT_4bit_uniform: two codes per byte */
+        return ((int64_t)d * 4 + 7) / 8;
     }
     return (row_type == 3 || row_type == 5) ? d : 2 * (int64_t)d;
 }
@@ -989,6 +992,44 @@ void orc_rows_train(int d, int64_t n, const float* x, float* trained) {
         trained[j] = lo;
         trained[d + j] = hi - lo;
     }
+}
+
+static int cmp_f32(const void* a, const void* b) {
+    const float x = *(const float*)a, y = *(const float*)b;
+    return (x > y) - (x < y);
+}
+
+/* QT_4bit_uniform (row type 6): ONE range for all dimensions, train_Uniform over the n * d values
+ * (T:impl/scalar_quantizer/training.cpp:209-332).  rangestat 0 = RS_minmax with rangestat_arg (the ScalarQuantizer default,
+ * what Knowhere keeps for the inner product), 2 = RS_quantiles (Knowhere sets it with arg 0.01 for L2,
+ * src/index/refine/refine_utils.cc:176-180): o = (idx_t)(rs_arg * n) -- a FLOAT product of the float argument and the count
+ * --, vmin = the o-th smallest value, vmax = the (n - 1 - o)-th.  trained = {vmin, vmax - vmin}. */
+void orc_rows_train_uniform(int rangestat, float rs_arg, int64_t n_values, const float* x, float* trained) {
+    float vmin, vmax;
+    if (rangestat == 2) {
+        float* c = (float*)malloc((size_t)n_values * sizeof(float));
+        memcpy(c, x, (size_t)n_values * sizeof(float));
+        qsort(c, (size_t)n_values, sizeof(float), cmp_f32);
+        int64_t o = (int64_t)(rs_arg * n_values);
+        if (o < 0) o = 0;
+        if (o > n_values - o) o = n_values / 2;
+        vmin = c[o];
+        vmax = c[n_values - 1 - o];
+        free(c);
+    } else {
+        vmin = HUGE_VALF;
+        vmax = -HUGE_VALF;
+        for (int64_t i = 0; i < n_values; i++) {
+            if (x[i] < vmin) vmin = x[i];
+            if (x[i] > vmax) vmax = x[i];
+        }
+        const float vexp = (vmax - vmin) * rs_arg;
+        vmin -= vexp;
+        vmax += vexp;
+    }
+    vmax -= vmin;
+    trained[0] = vmin;
+    trained[1] = vmax;
 }
 
 void orc_rows_encode(int row_type, int d, int64_t n, const float* x, const float* trained, uint8_t* codes) {
@@ -1028,6 +1069,22 @@ void orc_rows_encode(int row_type, int d, int64_t n, const float* x, const float
                     default: g[2] |= (uint8_t)(bits << 2); break;
                 }
             }
+        } else if (row_type == 6) {
+            /* QuantizerTemplate<Codec4bit, UNIFORM>::encode_vector (quantizers.h:76-90) over Codec4bit::encode_component
+             * (codecs.h:47-52): code[i / 2] |= (int)(xi * 15.0) << ((i & 1) << 2), a DOUBLE product, into a zeroed row */
+            const int64_t cs = orc_rows_code_size(6, d);
+            uint8_t* c = codes + r * cs;
+            memset(c, 0, (size_t)cs);
+            const float vmin = trained[0], vdiff = trained[1];
+            for (int i = 0; i < d; i++) {
+                float xi = 0;
+                if (vdiff != 0) {
+                    xi = (xr[i] - vmin) / vdiff;
+                    if (xi < 0) xi = 0;
+                    if (xi > 1.0) xi = 1.0;
+                }
+                c[i / 2] |= (uint8_t)((int)(xi * 15.0) << ((i & 1) << 2));
+            }
         } else if (row_type == 5) {
             /* Quantizer8bitDirectSigned::encode_vector (quantizers.h:362-366): code = (uint8_t)(x + 128) -- defined for
              * values in [-128, 127] (Knowhere's int8 data format); the conversion truncates */
@@ -1066,6 +1123,10 @@ static float rows_component(int row_type, int d, const uint8_t* code, const floa
         }
         const float xi = (bits + 0.5f) / 63.0f;
         return trained[i] + xi * trained[d + i];
+    }
+    if (row_type == 6) { /* Codec4bit::decode_component (codecs.h:54-58) inside the UNIFORM reconstruct_component */
+        const float xi = (((code[i / 2] >> ((i & 1) << 2)) & 0xf) + 0.5f) / 15.0f;
+        return trained[0] + xi * trained[1];
     }
     if (row_type == 5) { /* Quantizer8bitDirectSigned::reconstruct_component (quantizers.h:374-378) */
         return (float)(code[i] - 128);

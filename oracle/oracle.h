@@ -131,6 +131,7 @@ int orc_refine(int metric, int d, const float* base, int64_t nbase, int64_t id_b
 /* quantised refine store (row_type 1 fp16, 2 bf16, 3 sq8): IndexRefine over faiss::IndexScalarQuantizer */
 int64_t orc_rows_code_size(int row_type, int d);
 void orc_rows_train(int d, int64_t n, const float* x, float* trained);
+void orc_rows_train_uniform(int rangestat, float rs_arg, int64_t n_values, const float* x, float* trained);
 void orc_rows_encode(int row_type, int d, int64_t n, const float* x, const float* trained, uint8_t* codes);
 void orc_rows_decode(int row_type, int d, int64_t n, const uint8_t* codes, const float* trained, float* x);
 int orc_refine_rows(int metric, int d, int row_type, const uint8_t* codes, const float* trained, int64_t nbase, int64_t nq,

@@ -380,6 +380,15 @@ int ref_search_refine(
     });
 }
 
+/// what Knowhere does right after constructing the refine quantizer (reference src/index/refine/refine_utils.cc:176-180):
+/// QT_4bit_uniform with L2 takes its one range from the 1 % / 99 % quantiles
+static void knowhere_refine_sq_setup(faiss::IndexScalarQuantizer& sq, int row_type, bool is_l2) {
+    if (row_type == 6 && is_l2) {
+        sq.sq.rangestat = faiss::ScalarQuantizer::RS_quantiles;
+        sq.sq.rangestat_arg = 0.01;
+    }
+}
+
 static faiss::ScalarQuantizer::QuantizerType row_qtype(int row_type) {
     switch (row_type) {
         case 1: return faiss::ScalarQuantizer::QT_fp16;
@@ -387,7 +396,8 @@ static faiss::ScalarQuantizer::QuantizerType row_qtype(int row_type) {
         case 3: return faiss::ScalarQuantizer::QT_8bit;
         case 4: return faiss::ScalarQuantizer::QT_6bit;
         case 5: return faiss::ScalarQuantizer::QT_8bit_direct_signed;
-        default: throw std::runtime_error("row type: 1 fp16, 2 bf16, 3 sq8, 4 sq6, 5 int8");
+        case 6: return faiss::ScalarQuantizer::QT_4bit_uniform;
+        default: throw std::runtime_error("row type: 1 fp16, 2 bf16, 3 sq8, 4 sq6, 5 int8, 6 sq4u");
     }
 }
 
@@ -397,6 +407,7 @@ static faiss::ScalarQuantizer::QuantizerType row_qtype(int row_type) {
 int ref_sq_rows(int row_type, int metric, int d, int64_t nb, const float* xb, uint8_t* codes_out, float* trained_out) {
     return guarded([&] {
         faiss::IndexScalarQuantizer sq(d, row_qtype(row_type), metric == 0 ? faiss::METRIC_L2 : faiss::METRIC_INNER_PRODUCT);
+        knowhere_refine_sq_setup(sq, row_type, metric == 0);
         sq.train(nb, xb);
         sq.add(nb, xb);
         if (codes_out) {
@@ -425,6 +436,7 @@ int ref_search_refine_sq(
     return guarded([&] {
         faiss::MetricType mt = h->metric == 0 ? faiss::METRIC_L2 : faiss::METRIC_INNER_PRODUCT;
         faiss::IndexScalarQuantizer sq(h->d, row_qtype(row_type), mt);
+        knowhere_refine_sq_setup(sq, row_type, mt == faiss::METRIC_L2);
         sq.train(nb, xb);
         sq.add(nb, xb);
         faiss::IndexRefine refine(h->index.get(), &sq);
@@ -447,6 +459,7 @@ int64_t ref_serialize_sq(void* hv, int row_type, int64_t nb, const float* xb, ui
     int rc = guarded([&] {
         faiss::MetricType mt = h->metric == 0 ? faiss::METRIC_L2 : faiss::METRIC_INNER_PRODUCT;
         faiss::IndexScalarQuantizer sq(h->d, row_qtype(row_type), mt);
+        knowhere_refine_sq_setup(sq, row_type, mt == faiss::METRIC_L2);
         sq.train(nb, xb);
         sq.add(nb, xb);
         faiss::IndexRefine refine(h->index.get(), &sq);

@@ -118,7 +118,8 @@ def main():
         nb, nlist, nq = 320, 4, 3
         # d = 24: sq8 rows are not a multiple of 16 bytes (element loads); d = 32: every row type takes the 16-byte loads
         # d = 22 with sq6: a ragged last group of 6-bit codes (17 bytes per row)
-        for metric, d, types in ((ob.L2, 24, (1, 4, 5)), (ob.IP, 32, (2, 3, 4)), (ob.L2, 22, (4,))):
+        # sq4u (6): two codes per byte; d = 21: the last byte of a row holds one
+        for metric, d, types in ((ob.L2, 24, (1, 4, 5, 6)), (ob.IP, 32, (2, 3, 4)), (ob.L2, 22, (4,)), (ob.IP, 21, (6,))):
             xb, xq = gen_data(nb, d, 42, -40.0, 60.0), gen_data(nq, d, 44, -40.0, 60.0)
             xb[5, :4] = [1 + 2.0 ** -11, 2.0 ** -25, 65520.0, -(1 + 3 * 2.0 ** -11)]  # fp16 ties / subnormal / overflow
             ix = ob.make_index(port, ob.IVF_SQ8, metric, xb, nlist=nlist)
@@ -136,7 +137,7 @@ def main():
             raw.close()
             for rt in types:
                 rows = RowStore(rt, d, device=0)
-                tr = port.rows_train(xb) if rt in (3, 4) else None
+                tr = port.rows_train_uniform(metric, xb) if rt == 6 else (port.rows_train(xb) if rt in (3, 4) else None)
                 codes = port.rows_encode(rt, xb, tr)
                 if rt == 3:  # (build.hip -- column ranges, sq8 encoder -- is not part of the emulated library: GPU tests)
                     rows.set_trained(tr)
@@ -146,6 +147,12 @@ def main():
                 else:
                     if rt == 4:  # (ranges from the oracle: the column min / max kernel lives in build.hip; the encoder runs here)
                         rows.set_trained(tr)
+                    elif rt == 6:  # (the quantile range by the device's radix select for L2; min / max needs build.hip)
+                        if metric == ob.L2:
+                            rows.train_uniform(xb, 2, 0.01)
+                            assert rows.trained().tobytes() == tr.tobytes(), 'sq4u quantile range'
+                        else:
+                            rows.set_trained(tr)
                     else:
                         rows.train(xb)
                     rows.add(xb[:200])
@@ -158,10 +165,10 @@ def main():
                     same(Do, Io, D, I, f"refine_rows metric={metric} type={rt} k={k}")
                 # a store filled from code bytes (Deserialize) behaves the same
                 r2 = RowStore(rt, d, device=0)
-                if rt in (3, 4):
+                if rt in (3, 4, 6):
                     r2.set_trained(tr)
                 r2.add_codes(codes)
-                if rt in (2, 4):  # (one 16-bit and one ranged store; the sq8 store above was itself filled from code bytes)
+                if rt in (2, 4, 6):  # (one 16-bit and two ranged stores; the sq8 store above was itself filled from code bytes)
                     D1, I1 = g.search_refine_rows(rows, xq, 5, 20, 3)
                     D2, I2 = g.search_refine_rows(r2, xq, 5, 20, 3)
                     same(D1, I1, D2, I2, "store from codes")

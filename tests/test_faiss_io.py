@@ -96,7 +96,7 @@ def test_live_reference_bytes_roundtrip(node, ref):
             ref.destroy(h)
 
 
-@pytest.mark.parametrize("rt", [1, 2, 3, 4, 5], ids=["fp16", "bf16", "sq8", "sq6", "int8"])
+@pytest.mark.parametrize("rt", [1, 2, 3, 4, 5, 6], ids=["fp16", "bf16", "sq8", "sq6", "int8", "sq4u"])
 def test_live_reference_quantised_refine_bytes_roundtrip(node, ref, rt):
     """IndexRefine(base, IndexScalarQuantizer) as the reference writes it ("IxRF" ... "IxSQ" ... k_factor): parsed and
     re-emitted byte-identically; truncations and a wrong quantizer type are rejected"""
@@ -116,10 +116,10 @@ def test_live_reference_quantised_refine_bytes_roundtrip(node, ref, rt):
                 roundtrip(node, bad)
         pos = blob.tobytes().rindex(b"IxSQ")
         hdr = 4 + 4 + 8 + 16 + 1 + 4  # fourcc, d, ntotal, 2 reserved int64, is_trained, metric
-        assert int(np.frombuffer(blob[pos + hdr:pos + hdr + 4].tobytes(), np.int32)[0]) == {1: 4, 2: 7, 3: 0, 4: 6, 5: 8}[rt]
+        assert int(np.frombuffer(blob[pos + hdr:pos + hdr + 4].tobytes(), np.int32)[0]) == {1: 4, 2: 7, 3: 0, 4: 6, 5: 8, 6: 3}[rt]
         wrong = blob.copy()
-        wrong[pos + hdr] = 3  # QT_4bit_uniform: not a store this backend reads
-        with pytest.raises(ValueError, match="fp16 / bf16 / sq8"):
+        wrong[pos + hdr] = 1  # QT_4bit (per-dimension 4-bit ranges): not a refine type of Knowhere, not a store this backend reads
+        with pytest.raises(ValueError):
             roundtrip(node, wrong)
 
 
@@ -359,7 +359,7 @@ def test_hip_built_cosine_index_equals_the_reference(node, kref):
         node.knhip_node_destroy(C.c_void_p(h))
 
 
-ROW_TYPES = [("fp16", 1), ("bf16", 2), ("sq8", 3), ("sq6", 4), ("int8", 5)]
+ROW_TYPES = [("fp16", 1), ("bf16", 2), ("sq8", 3), ("sq6", 4), ("int8", 5), ("sq4u", 6)]
 
 
 def _node_blob(node, h):
@@ -374,7 +374,7 @@ def _node_blob(node, h):
 @pytest.mark.parametrize("kind", [ob.IVF_PQ, ob.IVF_SQ8], ids=["ivfpq", "ivfsq8"])
 @pytest.mark.parametrize("metric", ["L2", "IP"])
 def test_quantised_refine_store_round_trips_with_the_reference(node, ref, port, kind, metric, rt_name, rt):
-    """refine_type = fp16 / bf16 / sq8 / sq6 / int8 (IndexRefine over faiss::IndexScalarQuantizer, refine_utils.cc:150-185):
+    """refine_type = fp16 / bf16 / sq8 / sq6 / int8 / sq4u (IndexRefine over faiss::IndexScalarQuantizer, refine_utils.cc:150-185):
     node-built -> the reference reads the bytes ("IxRF" ... "IxSQ") and searches through ITS IndexRefine: the node's
     results; the refine store's code bytes and sq8 ranges are the reference's for the same rows; and a blob the
     reference wrote loads into the node and answers like the reference."""
@@ -398,7 +398,7 @@ def test_quantised_refine_store_round_trips_with_the_reference(node, ref, port, 
         codes_r, tr_r = ref.sq_rows(rt, m, xb)
         tail = codes_r.tobytes() + np.float32(1.0).tobytes()
         assert blob.tobytes().endswith(tail), "code bytes of the refine store"
-        if rt in (3, 4):
+        if rt in (3, 4, 6):
             assert tr_r.tobytes() in blob.tobytes(), "trained ranges"
         # reference-written bytes -> node
         h2, _ = ref.deserialize(blob, d)
@@ -420,7 +420,7 @@ def test_quantised_refine_store_round_trips_with_the_reference(node, ref, port, 
 
 @pytest.mark.gpu
 def test_refine_needs_refine_type_and_one_device_for_quantised_stores(node):
-    """`refine = true` without `refine_type` builds NO refine index (ivf_wrapper.cc:170: both are needed); sq4u is refused;
+    """`refine = true` without `refine_type` builds NO refine index (ivf_wrapper.cc:170: both are needed); an unknown type is refused;
     the type name is case-insensitive (str_to_lower, refine_utils.cc:28)"""
     nb, d = 3000, 32
     xb = gen_data(nb, d, 42)
@@ -435,7 +435,7 @@ def test_refine_needs_refine_type_and_one_device_for_quantised_stores(node):
     h, rc = build("refine=true")
     assert rc == 0 and bytes(_node_blob(node, h)[:4]) == b"IwPQ"
     node.knhip_node_destroy(C.c_void_p(h))
-    h, rc = build("refine=true;refine_type=sq4u")
+    h, rc = build("refine=true;refine_type=sq4")
     assert rc != 0
     node.knhip_node_destroy(C.c_void_p(h))
     h, rc = build("refine=true;refine_type=FP16")

@@ -214,10 +214,10 @@ def test_sharded_refine_through_the_node(node, metric):
             cfg = f"k={k};nprobe=16" + (f";refine_k={rk}" if rk != 1 else "")
             assert same(one.search(xq, cfg, k), many.search(xq, cfg, k)), (metric, k, rk)
         assert np.array_equal(one.blob(), many.blob())
-        # sq4u is not a store this backend has: refused, never silently replaced by another one
+        # an unknown refine type is refused, never silently replaced by another one
         bad = Node(node, "GPU_HIP_IVF_PQ")
         try:
-            assert bad.build(xb, base.replace("refine_type=fp32", "refine_type=sq4u") + ";gpu_id=0") != 0
+            assert bad.build(xb, base.replace("refine_type=fp32", "refine_type=sq4") + ";gpu_id=0") != 0
         finally:
             bad.close()
     finally:
@@ -225,7 +225,7 @@ def test_sharded_refine_through_the_node(node, metric):
         many.close()
 
 
-@pytest.mark.parametrize("rtype", ["fp16", "bf16", "sq8", "sq6", "int8"])
+@pytest.mark.parametrize("rtype", ["fp16", "bf16", "sq8", "sq6", "int8", "sq4u"])
 @pytest.mark.parametrize("metric", ["L2", "IP"])
 def test_sharded_quantised_refine_through_the_node(node, metric, rtype):
     """refine_type = fp16 / bf16 / sq8 / sq6 / int8 on a sharded index: the store is cut into one id range per device (the sq8 ranges

@@ -1,4 +1,4 @@
-"""GPU tests (-m gpu): the quantised refine store (knhip_rows; Knowhere's refine_type = fp16 / bf16 / sq8 / sq6 / int8).
+"""GPU tests (-m gpu): the quantised refine store (knhip_rows; Knowhere's refine_type = fp16 / bf16 / sq8 / sq6 / int8 / sq4u).
 
 The reference re-ranks the first stage's candidates against a faiss::IndexScalarQuantizer of the raw rows (reference
 src/index/refine/refine_utils.cc:150-185, thirdparty/faiss/faiss/cppcontrib/knowhere/IndexRefine.cpp:66-165).  The oracle's
@@ -10,15 +10,18 @@ import pytest
 from conftest import assert_parity, gen_data
 from helpers import finish_ivfpq
 from oracle import binding as ob
-from test_refine_rows import ROW_TYPES, TRAINED, _data, _nasty
+from test_refine_rows import ROW_TYPES, TRAINED, _data, _nasty, _train
 
 pytestmark = pytest.mark.gpu
 
 
-def _store(rt, xb, chunks=1):
+def _store(rt, xb, chunks=1, metric=ob.L2):
     from knowhere_amd import RowStore
     rows = RowStore(rt, xb.shape[1], device=0)
-    rows.train(xb)
+    if rt == 6:  # (sq4u: one range for all dimensions; Knowhere trains it from the 1 % / 99 % quantiles for L2)
+        rows.train_uniform(xb, 2 if metric == ob.L2 else 0, 0.01 if metric == ob.L2 else 0.0)
+    else:
+        rows.train(xb)
     for part in np.array_split(xb, chunks):
         rows.add(part)
     return rows
@@ -31,13 +34,14 @@ def test_device_encoders_write_the_reference_code_bytes(port, row_type, name):
     for x in sets:
         if row_type in TRAINED:
             x = np.ascontiguousarray(x[np.isfinite(x).all(1)])
-        rows = _store(row_type, x, chunks=3)
-        tr = port.rows_train(x) if row_type in TRAINED else None
-        if row_type in TRAINED:
-            assert rows.trained().tobytes() == tr.tobytes(), "ranges (column minimum / maximum - minimum)"
-        assert rows.count() == len(x)
-        assert rows.codes().tobytes() == port.rows_encode(row_type, x, tr).tobytes(), f"{name} code bytes"
-        rows.close()
+        for metric in ((ob.L2, ob.IP) if row_type == 6 else (ob.L2,)):
+            rows = _store(row_type, x, chunks=3, metric=metric)
+            tr = _train(port, row_type, x, metric)
+            if row_type in TRAINED:
+                assert rows.trained().tobytes() == tr.tobytes(), "ranges (column minimum / maximum - minimum; sq4u: quantiles)"
+            assert rows.count() == len(x)
+            assert rows.codes().tobytes() == port.rows_encode(row_type, x, tr).tobytes(), f"{name} code bytes"
+            rows.close()
 
 
 def test_sq8_store_constant_column_and_rows_outside_the_trained_range(port):
@@ -79,8 +83,8 @@ def test_search_refine_rows_equals_index_refine_over_a_scalar_quantizer(port, ki
     if kind == ob.IVF_PQ:
         finish_ivfpq(port, ix)
     g = GpuIndex.from_data(ix, device=0)
-    rows = _store(row_type, xb, chunks=2)
-    tr = port.rows_train(xb) if row_type in TRAINED else None
+    rows = _store(row_type, xb, chunks=2, metric=metric)
+    tr = _train(port, row_type, xb, metric)
     codes = port.rows_encode(row_type, xb, tr)
     bs = np.packbits(np.random.default_rng(5).random(nb) < 0.3, bitorder="little")
     for k, kb, nprobe in ((10, 40, 8), (1, 16, 3), (7, 7, 9), (20, 200, 24)):
@@ -103,8 +107,8 @@ def test_refine_rows_ties_follow_reorder_2_heaps(port, metric, row_type, name):
     xb, xq = _dup_data(6000, 32, 40, 11)
     ix = ob.make_index(port, ob.IVF_SQ8, metric, xb, nlist=24)
     g = GpuIndex.from_data(ix, device=0)
-    rows = _store(row_type, xb)
-    tr = port.rows_train(xb) if row_type in TRAINED else None
+    rows = _store(row_type, xb, metric=metric)
+    tr = _train(port, row_type, xb, metric)
     codes = port.rows_encode(row_type, xb, tr)
     kbase, k, nprobe = 60, 6, 9
     _, Ib = port.search(ix, xq, kbase, nprobe)
@@ -182,3 +186,30 @@ def test_sq6_ragged_dimension_and_boundary_values(port):
         assert_parity(Do, Io, D, I, metric, "sq6 d=10")
         rows.close()
         g.close()
+
+
+def test_sq4u_quantile_range_at_scale_and_odd_dimension(port):
+    """the radix select behind RS_quantiles on 2 x 10^7 values (ranks 2 x 10^5 from either end) against numpy's order
+    statistics; d = 7: the last byte of a row holds one code; a constant data set (vdiff = 0) encodes zeros"""
+    from knowhere_amd import RowStore
+    n, d = 156_250, 128
+    x = gen_data(n, d, 21, -3.0, 9.0)
+    rows = RowStore(6, d, device=0)
+    rows.train_uniform(x, 2, 0.01)
+    tr = rows.trained()
+    N = n * d
+    o = int(np.float32(0.01) * np.float32(N))
+    part = np.partition(x.ravel(), (o, N - 1 - o))
+    assert tr[0] == part[o] and tr[1] == np.float32(part[N - 1 - o] - part[o])
+    rows.close()
+    for dd in (7, 1):
+        y = gen_data(300, dd, 22, -1.0, 1.0)
+        r2 = _store(6, y, chunks=2, metric=ob.IP)
+        t2 = port.rows_train_uniform(ob.IP, y)
+        assert r2.trained().tobytes() == t2.tobytes()
+        assert r2.codes().shape[1] == (dd + 1) // 2 and r2.codes().tobytes() == port.rows_encode(6, y, t2).tobytes()
+        r2.close()
+    z = np.full((50, 6), 2.5, np.float32)
+    r3 = _store(6, z)
+    assert r3.trained()[1] == 0 and not r3.codes().any()
+    r3.close()

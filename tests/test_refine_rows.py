@@ -1,4 +1,4 @@
-"""Quantised refine store (refine_type = fp16 / bf16 / sq8 / sq6 / int8): the oracle's restatement pinned against the reference.
+"""Quantised refine store (refine_type = fp16 / bf16 / sq8 / sq6 / int8 / sq4u): the oracle's restatement pinned against the reference.
 
 Knowhere builds IndexRefine(base, faiss::IndexScalarQuantizer(d, QT_fp16 / QT_bf16 / QT_8bit / QT_6bit /
 QT_8bit_direct_signed, metric)) for these refine
@@ -11,8 +11,14 @@ import pytest
 from conftest import gen_data
 from oracle import binding as ob
 
-ROW_TYPES = [(1, "fp16"), (2, "bf16"), (3, "sq8"), (4, "sq6"), (5, "int8")]
-TRAINED = (3, 4)  # types with per-dimension ranges
+ROW_TYPES = [(1, "fp16"), (2, "bf16"), (3, "sq8"), (4, "sq6"), (5, "int8"), (6, "sq4u")]
+TRAINED = (3, 4, 6)  # types with trained ranges (3, 4: per dimension; 6: one for all, from quantiles for L2)
+
+
+def _train(port, row_type, x, metric=ob.L2):
+    if row_type == 6:
+        return port.rows_train_uniform(metric, x)
+    return port.rows_train(x) if row_type in TRAINED else None
 
 
 def _data(row_type, *a, **kw):
@@ -42,10 +48,12 @@ def test_rows_encode_equals_the_reference(port, ref, row_type, name):
     for x in sets:
         if row_type in TRAINED:
             x = x[np.isfinite(x).all(1)]
-        codes_r, tr_r = ref.sq_rows(row_type, ob.L2, x)
-        tr = port.rows_train(x) if row_type in TRAINED else None
-        if row_type in TRAINED:
-            assert tr.tobytes() == tr_r.tobytes(), f"{name} ranges"
+        for metric in ((ob.L2, ob.IP) if row_type == 6 else (ob.L2,)):  # (sq4u: quantile range for L2, min / max else)
+            codes_r, tr_r = ref.sq_rows(row_type, metric, x)
+            tr = _train(port, row_type, x, metric)
+            if row_type in TRAINED:
+                assert tr.tobytes() == tr_r.tobytes(), f"{name} ranges"
+            assert port.rows_encode(row_type, x, tr).tobytes() == codes_r.tobytes(), f"{name} code bytes"
         codes = port.rows_encode(row_type, x, tr)
         assert codes.tobytes() == codes_r.tobytes(), f"{name} code bytes"
 
@@ -76,7 +84,7 @@ def test_refine_rows_equals_index_refine_over_a_scalar_quantizer(port, ref, kind
     try:
         ref.train_add(h, xb)
         ix = ref.export(h, kind, metric, d, nlist, M, 8)
-        tr = port.rows_train(xb) if row_type in TRAINED else None
+        tr = _train(port, row_type, xb, metric)
         codes = port.rows_encode(row_type, xb, tr)
         for k, kf, nprobe in ((5, 4.0, 18), (1, 8.0, 3), (10, 1.0, 20)):
             Dr, Ir = ref.search_refine_sq(h, row_type, xb, xq, k, kf, nprobe)
@@ -93,7 +101,7 @@ def test_refine_rows_equals_index_refine_over_a_scalar_quantizer(port, ref, kind
 def test_decode_round_trip_properties(port, row_type, name):
     d = 16
     x = _data(row_type, 500, d, 9, -50.0, 50.0)
-    tr = port.rows_train(x) if row_type in TRAINED else None
+    tr = _train(port, row_type, x)
     c = port.rows_encode(row_type, x, tr)
     y = port.rows_decode(row_type, d, c, tr)
     # idempotence: re-encoding the decoded rows gives the same codes
@@ -108,6 +116,10 @@ def test_decode_round_trip_properties(port, row_type, name):
         assert np.abs(y - x).max() <= np.abs(x).max() * 2.0 ** -8
     elif row_type == 5:
         assert np.array_equal(y, x)  # (integer values in range: lossless)
+    elif row_type == 6:
+        inside = (x >= tr[0]) & (x <= tr[0] + tr[1])  # (2 % of the values lie outside the quantile range: clamped)
+        assert 0.97 < inside.mean() < 0.99
+        assert (np.abs(y - x)[inside] <= tr[1] / 15.0 * 0.5001 + 1e-5).all()
     else:
         levels = 255.0 if row_type == 3 else 63.0
         assert (np.abs(y - x) <= tr[d:] / levels * 0.5001 + 1e-6).all()
@@ -159,7 +171,7 @@ def test_refine_rows_ties_equal_the_reference(port, ref, metric, row_type, name)
     try:
         ref.train_add(h, xb)
         ix = ref.export(h, ob.IVF_SQ8, metric, d, 16, 0, 8)
-        tr = port.rows_train(xb) if row_type in TRAINED else None
+        tr = _train(port, row_type, xb, metric)
         codes = port.rows_encode(row_type, xb, tr)
         ties = 0
         for k, kf, nprobe in ((6, 10.0, 9), (10, 3.0, 16), (4, 1.0, 5)):
