@@ -117,9 +117,9 @@ def main():
         from knowhere_amd import RowStore
         nb, nlist, nq = 320, 4, 3
         # d = 24: sq8 rows are not a multiple of 16 bytes (element loads); d = 32: every row type takes the 16-byte loads
-        # d = 22 with sq6: a ragged last group of 6-bit codes (17 bytes per row)
-        # sq4u (6): two codes per byte; d = 21: the last byte of a row holds one
-        for metric, d, types in ((ob.L2, 24, (1, 4, 5, 6)), (ob.IP, 32, (2, 3, 4)), (ob.L2, 22, (4,)), (ob.IP, 21, (6,))):
+        # d = 21: a ragged last group of 6-bit codes (sq6: 16 bytes per row) and a last byte with one 4-bit code (sq4u);
+        # not a multiple of four: the fp32 refine takes its lane = row path there
+        for metric, d, types in ((ob.L2, 24, (1, 4, 5, 6)), (ob.IP, 32, (2, 3, 4)), (ob.IP, 21, (4, 6))):
             xb, xq = gen_data(nb, d, 42, -40.0, 60.0), gen_data(nq, d, 44, -40.0, 60.0)
             xb[5, :4] = [1 + 2.0 ** -11, 2.0 ** -25, 65520.0, -(1 + 3 * 2.0 ** -11)]  # fp16 ties / subnormal / overflow
             ix = ob.make_index(port, ob.IVF_SQ8, metric, xb, nlist=nlist)
