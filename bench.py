@@ -63,6 +63,9 @@ CONFIGS = {
     # BASELINE.json configs[0]: the reference's own CPU-runnable plumbing case, here on the GPU through the same ABI
     "C1": dict(kind="flat", metric="l2", nb=100_000, d=128, nlist=0, nprobe=1, nq=1000, k=10, m=0,
                refine_k=0, data="uniform", train_per_centroid=0, niter=0),
+    # the same scan at a size where the matrix pipe matters: 1M rows, a 10k-query batch (north_star: BruteForce Search())
+    "C1m": dict(kind="flat", metric="l2", nb=1_000_000, d=128, nlist=0, nprobe=1, nq=10000, k=10, m=0,
+                refine_k=0, data="uniform", train_per_centroid=0, niter=0),
     # BASELINE.json configs[1]
     "C2": dict(kind="ivfflat", metric="l2", nb=10_000_000, d=128, nlist=4096, nprobe=64, nq=10000, k=10, m=0,
                refine_k=0, data="mixture", train_per_centroid=256, niter=10),
@@ -209,11 +212,16 @@ def main():
             assert ndev >= world or os.environ.get("KNHIP_ALLOW_SHARED_GPU") == "1", \
                 f"{world} ranks on {ndev} GPU(s): set KNHIP_ALLOW_SHARED_GPU=1 for single-GPU debugging over gloo"
     out = run_config(a, rank, world, dev, dev_id, comm)
+    if rank == 0:
+        # (a copy for the log as soon as it exists: should a later configuration take the process down, the headline
+        # is still on stderr; stdout gets it LAST so that a tail of stdout always ends with it)
+        print("[bench-headline] " + json.dumps(slim_line(out)), file=sys.stderr, flush=True)
     extra = []
     if a.extra == "auto":
-        extra = ["C1", "C2", "C5s", "C3u", "C3l"] if (a.config == "C3" and world == 1 and not a.overridden) else []
+        extra = ["C1", "C1m", "C2", "C5s", "C3u", "C3l"] if (a.config == "C3" and world == 1 and not a.overridden) else []
     elif a.extra != "none":
         extra = [e for e in a.extra.split(",") if e]
+    full = {a.config: out}
     for name in extra:
         assert name in CONFIGS, name
         import copy
@@ -222,15 +230,88 @@ def main():
         if name in ("C3u", "C3l"):
             b.cpu_queries = 0  # (the same index kind and kernels as the main run: no second reference leg)
         torch.cuda.empty_cache()
-        sub = run_config(b, rank, world, dev, dev_id, comm)
+        try:
+            sub = run_config(b, rank, world, dev, dev_id, comm)
+        except Exception as e:  # an extra configuration never costs the headline
+            log(rank, f"extra configuration {name} failed: {e!r}")
+            continue
         if rank == 0:
-            out.setdefault("extra_configs", {})[name] = {key: sub[key] for key in
-                ("metric", "value", "unit", "ms_per_step", "recall_at_10", "result_crc32", "config", "roofline", "host_boundary", "cpu_baseline")
-                if key in sub}
+            full[name] = sub
+            # one short line per extra configuration, BEFORE the headline
+            print(json.dumps(slim_line(sub, extra=True)), flush=True)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        write_full(full)
+        print(json.dumps(slim_line(out)), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# What is printed.  The driver keeps the last ~10 kB of stdout and parses the LAST JSON line: the headline must be short
+# (round 5's 21 kB line with every extra configuration nested inside it did not parse).  stdout = one line of < 1 kB per
+# extra configuration, then the headline (< 6 kB) as the last line; everything else (prose notes, per-unit PMC fractions,
+# thread sweeps) goes to gpurun_out/bench_full.json and, where it explains a number, to DESIGN.md section 5.
+ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "algorithmic", "executed", "filter_form",
+                 "algorithmic_bytes_per_launch", "ms_per_launch", "traffic", "hbm_measured_frac", "hbm_algorithmic_frac",
+                 "stage_ms_per_step", "mscan")
+HOST_KEYS = ("value", "unit", "ms_per_step", "steps", "identical_to_device_path", "entry_point")
+CPU_KEYS = ("value", "unit", "cores", "kind", "simd", "sample", "gpu_final_ids_equal", "gpu_final_distances_bit_equal")
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d is not None and k in d}
+
+
+def slim_line(out, extra=False):
+    """the printed form of a configuration's result: the contract's keys + roofline + host boundary + CPU baseline,
+    without prose"""
+    if out is None:
+        return None
+    line = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                       "vs_baseline", "dtype", "data", "value_form", "recall_at_10", "recall_gate_met", "result_crc32"))
+    cfg = out.get("config", {})
+    line["config"] = _pick(cfg, ("name", "workload", "data_generator") + (() if extra else ("parallelism",)))
+    r = out.get("roofline")
+    if r:
+        rk = ("bound", "kernel", "achieved", "peak", "unit", "frac", "algorithmic", "ms_per_launch", "traffic",
+              "hbm_measured_frac") if extra else ROOFLINE_KEYS
+        line["roofline"] = _pick(r, rk)
+        st = line["roofline"].get("stage_ms_per_step")
+        if st:
+            line["roofline"]["stage_ms_per_step"] = {k: v for k, v in st.items() if k != "note"}
+        if r.get("unit_busy") and not extra:
+            line["roofline"]["unit_busy"] = _pick(r["unit_busy"], ("mfma_pipe_busy", "lds_array_busy", "valu_issue_busy",
+                                                                   "wave_cycles_waiting", "commit"))
+        if r.get("coarse_stage") and not extra:
+            line["roofline"]["coarse_stage"] = _pick(r["coarse_stage"], ("kernel", "algorithmic_flops", "flops", "ms",
+                                                                         "achieved_TFLOPs_whole_stage", "peak"))
+    if out.get("host_boundary"):
+        line["host_boundary"] = _pick(out["host_boundary"], ("value", "ms_per_step") if extra else HOST_KEYS)
+    if out.get("cpu_baseline"):
+        c = _pick(out["cpu_baseline"], ("value", "cores", "kind", "gpu_final_ids_equal", "gpu_final_distances_bit_equal")
+                  if extra else CPU_KEYS)
+        if "simd" in c:
+            c["simd"] = c["simd"].split(" (")[0]
+        line["cpu_baseline"] = c
+    if out.get("multi_gpu") and not extra:
+        m = out["multi_gpu"]
+        line["multi_gpu"] = {"backend": m.get("backend"), "world": m.get("world"), "coarse": m.get("coarse"),
+                             "collectives_per_step": m.get("collectives_per_step"),
+                             "ranks": [_pick(rk_, ("rank", "collective_ms_per_step", "step_ms", "filter_ms", "scan_bytes_per_step"))
+                                       for rk_ in m.get("ranks", [])]}
+    return line
+
+
+def write_full(full):
+    """every configuration's complete object (notes included) -> gpurun_out/bench_full.json (scratch; copied to profiles/
+    by hand for the runs that are cited)"""
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "bench_full.json"), "w") as f:
+            json.dump(full, f, indent=1)
+    except Exception as e:
+        print(f"[bench] could not write gpurun_out/bench_full.json: {e!r}", file=sys.stderr)
 
 
 def run_config(a, rank, world, dev, dev_id, comm):
@@ -344,7 +425,8 @@ def run_config(a, rank, world, dev, dev_id, comm):
             Dp, Ip = sharded.search_sharded(
                 comm, metric, kbase, lambda kk: g.search_canonical_device(q, kk, a.nprobe, keys, cdis),
                 lambda fl, can: g.tie_arrivals_device(q, fl, can, kbase, a.nprobe, keys, cdis,
-                                                      key_base=(a.nb * rank // world) if kind == kidx.BRUTE_FORCE else 0))
+                                                      key_base=(a.nb * rank // world) if kind == kidx.BRUTE_FORCE else 0),
+                kind=kind)
             if not refine:
                 return Dp, Ip
             # second stage: distances where the rows are (the others marked "not here"), one all-gather, ONE selection
@@ -423,12 +505,13 @@ def run_config(a, rank, world, dev, dev_id, comm):
         comm.timed = False
         mine = {"rank": rank, "device": dev_id, "collective_ms_per_step": round(coll_ms, 3),
                 "collectives_per_step": (comm.ncollectives - n0) // a.steps,
+                "filter_ms": round(pr["ms"][kidx._lib.STAGE_SCAN] / max(a.steps, 1), 3),
                 "stage_ms_per_step": stage_table(a, kind, pr),
                 "scan_bytes_per_step": pr["scan_bytes"] / a.steps}
         gathered = [None] * world
         dist.all_gather_object(gathered, mine)
         multi = {"backend": comm.backend, "world": comm.world, "coarse": "replicated" if coarse_replicated else "sharded by queries",
-                 "ranks": gathered}
+                 "collectives_per_step": mine["collectives_per_step"], "ranks": gathered}
     ms_per_step = dt / a.steps * 1e3
     qps = a.nq * a.steps / dt
     prof["bench_ms_per_step"] = ms_per_step
@@ -481,6 +564,7 @@ def run_config(a, rank, world, dev, dev_id, comm):
             "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "value_form": "device-resident step (queries, index, raw rows in HBM); SURVEY 8(d)'s host-pointer form = host_boundary",
             "recall_at_10": round(rec, 4), "recall_gate_met": bool(rec >= 0.95) if gate else None,
             "result_crc32": result_crc,
             "config": {"name": a.config,

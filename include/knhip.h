@@ -61,8 +61,11 @@ extern "C" {
 /* 4: knhip_train_params gained spherical/reserved, knhip_stage_times its prefilter counters.  5: tie_queries.  6: the quantised refine store (knhip_rows_*, knhip_search_refine_rows), knhip_range_search_ranked.
  * 7: sixteen profiling stages (sample / tables / refine / ties itemised), tie_anomalies; the tie rule for list-sharded
  * indexes (knhip_search_canonical_device, knhip_tie_*, knhip_refine_distances / _combine / _select).
+ * 8: the refine stores sq6 / int8 / sq4u (KNHIP_ROWS_SQ6 / _INT8 / _SQ4U) and knhip_rows_train_uniform.
+ * 9: knhip_ties_rule_applies (one place decides whether a search follows the reference's boundary rule: single index, shard
+ * group and the torch.distributed host agree); pq_filter_form 3 in knhip_stage_times (the decode form of the IVF-PQ prefilter).
  * Callers compare knhip_abi_version() with the header they were built against. */
-#define KNHIP_ABI_VERSION 8
+#define KNHIP_ABI_VERSION 9
 
 typedef struct knhip_index knhip_index;
 
@@ -369,6 +372,10 @@ int knhip_refine_device(int32_t metric, int32_t dim, const float* d_base, int64_
  *      with its place in the global scan order), exchange, knhip_tie_resolve_device writes the rule's answer over the rows.
  * include/knhip_shards.h does exactly this (C++ host); knowhere_amd/sharded.py does it over torch.distributed.
  * BRUTE_FORCE with k >= 100 and k = 1024 stay canonical, as on one index. */
+/* 1 when a search of this kind and k follows the reference's boundary rule (k + 1 canonical results, flag, arrivals, resolve),
+ * 0 when it returns the canonical k: KNHIP_TIES=canonical, k + 1 > 1024, BRUTE_FORCE with k >= 100 (the reference's reservoir).
+ * The hosts of a list-sharded index ask this instead of restating the conditions. */
+int knhip_ties_rule_applies(int32_t kind, int32_t k);
 /* canonical top-k, no tie rule.  d_keys / d_coarse_dis: the coarse assignment [nq][nprobe] (IndexIVF::search_preassigned;
  * both NULL: assigned inside; BRUTE_FORCE: NULL) */
 int knhip_search_canonical_device(const knhip_index* idx, const float* d_queries, int64_t nq, int32_t k, int32_t nprobe,

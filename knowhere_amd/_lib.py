@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("KNHIP_LIB") or os.path.join(_HERE, "libknhip.so")  # 
 BRUTE_FORCE, IVF_FLAT, IVF_PQ, IVF_SQ8 = 0, 1, 2, 3
 L2, IP = 0, 1
 NSTAGE = 16
-ABI_VERSION = 8  # KNHIP_ABI_VERSION of include/knhip.h
+ABI_VERSION = 9  # KNHIP_ABI_VERSION of include/knhip.h
 (STAGE_COARSE, STAGE_GROUP, STAGE_LUT, STAGE_SCAN, STAGE_MERGE, STAGE_OTHER, STAGE_SCAN_RANK0, STAGE_TABLES, STAGE_REFINE,
  STAGE_TIES) = range(10)
 STAGE_NAMES = ["coarse", "group", "lut", "scan", "merge", "other", "scan_rank0", "tables", "refine", "ties"]
@@ -46,7 +46,7 @@ SYMBOLS = [
     "knhip_index_set_lists_device", "knhip_index_add_vectors_device", "knhip_index_count",
     "knhip_index_device_bytes", "knhip_index_uses_precomputed_table", "knhip_index_last_range_ranks", "knhip_search",
     "knhip_search_device", "knhip_coarse_search_device", "knhip_merge_topk_device",
-    "knhip_search_canonical_device", "knhip_tie_flag_device", "knhip_tie_arrivals_device", "knhip_tie_resolve_device",
+    "knhip_search_canonical_device", "knhip_ties_rule_applies", "knhip_tie_flag_device", "knhip_tie_arrivals_device", "knhip_tie_resolve_device",
     "knhip_tie_flag_host", "knhip_tie_resolve_host", "knhip_refine_distances_device", "knhip_refine_rows_distances_device",
     "knhip_refine_combine_device", "knhip_refine_select_device", "knhip_refine_select_host",
     "knhip_merge_topk_host", "knhip_refine_device", "knhip_fvec_L2sqr_ny", "knhip_fvec_inner_products_ny",

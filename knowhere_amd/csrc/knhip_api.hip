@@ -2189,7 +2189,7 @@ extern "C" {
 
 int knhip_rows_create(int32_t device, int32_t dim, int32_t row_type, knhip_rows** out) {
     if (!out || dim <= 0 || row_type < KNHIP_ROWS_FP16 || row_type > KNHIP_ROWS_SQ4U) {
-        return fail(KNHIP_ERR_INVALID_ARGS, "rows_create: dim > 0 and row type fp16 / bf16 / sq8");
+        return fail(KNHIP_ERR_INVALID_ARGS, "rows_create: dim > 0 and row type fp16 / bf16 / sq8 / sq6 / int8 / sq4u");
     }
     if (device < 0 || device >= knhip_device_count()) {
         return fail(KNHIP_ERR_HIP_RUNTIME, "rows_create: no such HIP device");
@@ -2230,7 +2230,7 @@ int knhip_rows_set_trained(knhip_rows* r, const float* vmin, const float* vdiff)
 
 int knhip_rows_get_trained(const knhip_rows* r, float* vmin, float* vdiff) {
     if (!r || !r->ranged() || !r->trained || !vmin || !vdiff) {
-        return fail(KNHIP_ERR_NOT_TRAINED, "rows_get_trained: a trained sq8 / sq6 store");
+        return fail(KNHIP_ERR_NOT_TRAINED, "rows_get_trained: a trained ranged store (sq8 / sq6 / sq4u)");
     }
     DeviceGuard g(r->device);
     const size_t nr = (size_t)r->nrange();
@@ -2933,6 +2933,11 @@ static bool ties_reference_mode() {
     return !(t && (t[0] == 'c' || t[0] == 'C' || t[0] == '0'));
 }
 
+extern "C" int knhip_ties_rule_applies(int32_t kind, int32_t k) {
+    const bool reservoir = kind == KNHIP_BRUTE_FORCE && k >= 100;
+    return (ties_reference_mode() && !reservoir && k + 1 <= KN_MAX_K) ? 1 : 0;
+}
+
 // The first k arrivals with distance <= v (>= v for IP) of every flagged query, in THIS index's scan order (probe rank, then
 // storage position; brute force: row order): arr_d / arr_i [nflag][k], arr_n [nflag] (how many arrived: only min(k, .) are
 // stored), arr_key [nflag][k] (optional) = each arrival's place in the scan order, comparable across the shards of a group.
@@ -2993,8 +2998,7 @@ static int search_batch_ties(const knhip_index* idx, Workspace* ws, const float*
                              const uint8_t* d_bitset, int64_t nbits, int64_t* d_out_i, float* d_out_d, hipStream_t s,
                              const int64_t* pre_keys, const float* pre_cdis) {
     const int kind = idx->desc.kind;
-    const bool reservoir = kind == KNHIP_BRUTE_FORCE && k >= 100;
-    if (!ties_reference_mode() || reservoir || k + 1 > KN_MAX_K) {
+    if (!knhip_ties_rule_applies(kind, k)) {
         return search_batch(idx, ws, d_q, nq, k, nprobe, d_bitset, nbits, d_out_i, d_out_d, s, pre_keys, pre_cdis);
     }
     const bool trace = getenv("KNHIP_TIES_TRACE") != nullptr;

@@ -345,8 +345,17 @@ hipError_t launch_refine(const float* base, int64_t nbase, int64_t id_base, int 
     }
     const unsigned grid = (unsigned)((nq + 3) / 4);
     // fp32 rows of 16-byte multiples are gathered cooperatively through a per-wave staging area (refine_kernel)
-    const int coop = (row_type == 0 && dist_in == nullptr && (d & 3) == 0 && (reinterpret_cast<uintptr_t>(base) & 15) == 0) ? 1 : 0;
-    const size_t sm = ((size_t)4 * d + (size_t)4 * kbase) * sizeof(float) + (coop ? (size_t)4 * KN_WAVE * RF_PITCH : 0);
+    // (nbase == 0: no row exists -- the cooperative gather names row 0 for lanes without a candidate and would read it;
+    // a base pointer may legitimately be null then.  ADVICE round 5)
+    int coop = (row_type == 0 && dist_in == nullptr && nbase > 0 && base != nullptr && (d & 3) == 0 &&
+                (reinterpret_cast<uintptr_t>(base) & 15) == 0) ? 1 : 0;
+    const size_t sm_plain = ((size_t)4 * d + (size_t)4 * kbase) * sizeof(float);
+    size_t sm = sm_plain + (coop ? (size_t)4 * KN_WAVE * RF_PITCH : 0);
+    if (sm > 160 * 1024 && coop) {
+        // the staging area (69.6 KB) does not fit beside four long queries: the lane-per-row gather still does
+        coop = 0;
+        sm = sm_plain;
+    }
     if (sm > 160 * 1024) {
         return hipErrorInvalidValue; // (four queries + their candidates' distances do not fit the CU's LDS)
     }

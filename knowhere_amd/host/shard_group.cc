@@ -295,7 +295,8 @@ static int search_impl(knhip_shard_group* g, const float* queries, int64_t nq, i
     const int32_t k1 = refine ? k_base : k;       // results of the first stage
     // the tie rule needs the (k1 + 1)-th canonical result; not covered (canonical answer, as on one index): k1 = 1024,
     // brute force with k1 >= 100 (the reference's reservoir)
-    const bool ties1 = k1 + 1 <= 1024 && !(desc.kind == KNHIP_BRUTE_FORCE && k1 >= 100);
+    // (one place decides -- knhip_ties_rule_applies: KNHIP_TIES=canonical is honoured here as on one index)
+    const bool ties1 = knhip_ties_rule_applies(desc.kind, k1) != 0;
     const int32_t kk1 = ties1 ? k1 + 1 : k1;      // width of the first exchange
     const int64_t ne1 = nq * (int64_t)kk1;        // entries per rank, first exchange
     const int64_t ne = nq * (int64_t)k;           // entries of the result
@@ -338,9 +339,12 @@ static int search_impl(knhip_shard_group* g, const float* queries, int64_t nq, i
             for (int o = 0; o < W; o++) ok = ok && rcs[o].load() == KNHIP_OK;
             return ok;
         };
-        // ---- the collective: every rank's `bytes` at `src` -> W blocks in rank order at `dst` (both on the rank's device).
-        // Same barrier walk for every rank, alive or not.
-        auto allgather_bytes = [&](const void* src, void* dst, size_t bytes) {
+        // ---- the collective: the first `bytes` of every rank's send buffer (me.packed) -> W blocks in rank order at `dst`
+        // (on the rank's device).  The send buffer is fixed: the staged transport PULLS from the peers' `packed`, so a
+        // caller-chosen source would be honoured by one transport only.  Same barrier walk for every rank,
+        // alive or not.
+        auto allgather_bytes = [&](void* dst, size_t bytes) {
+            const void* src = me.packed.p;
             if (g->transport == KNHIP_SHARDS_RCCL) {
                 // agreement BEFORE the collective: every rank posts its status, all read the same verdict, and only
                 // then does anyone enqueue -- a rank that failed earlier (allocation, search, merge) makes every rank skip
@@ -406,7 +410,7 @@ static int search_impl(knhip_shard_group* g, const float* queries, int64_t nq, i
                 head();
                 alive = rc == KNHIP_OK;
             }
-            allgather_bytes(me.packed.p, me.gathered.p, (size_t)n * 12);
+            allgather_bytes(me.gathered.p, (size_t)n * 12);
             auto tail = [&]() {
                 hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)((n * W + 255) / 256)), dim3(256), 0, me.stream,
                                    static_cast<const uint32_t*>(me.gathered.p), n * W, static_cast<float*>(me.all_d.p),
@@ -578,7 +582,7 @@ static int search_impl(knhip_shard_group* g, const float* queries, int64_t nq, i
                     arrivals();
                     alive = rc == KNHIP_OK;
                 }
-                allgather_bytes(me.packed.p, me.gathered.p, stride);
+                allgather_bytes(me.gathered.p, stride);
                 auto resolve = [&]() {
                     const int64_t nt = (int64_t)W * nflag * k1;
                     hipLaunchKernelGGL(unpack_arrivals_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, me.stream,
@@ -630,7 +634,7 @@ static int search_impl(knhip_shard_group* g, const float* queries, int64_t nq, i
                     (void)hipEventRecord(ev[4], me.stream);
                 }
             }
-            allgather_bytes(me.packed.p, me.rdist_all.p, (size_t)nq * k1 * sizeof(float));
+            allgather_bytes(me.rdist_all.p, (size_t)nq * k1 * sizeof(float));
             auto select = [&]() {
                 int src = knhip_refine_combine_device(W, nq * (int64_t)k1, static_cast<const float*>(me.rdist_all.p),
                                                       static_cast<float*>(me.rdist.p), me.stream);

@@ -156,7 +156,7 @@ class Comm:
         return torch.from_numpy(Dm), torch.from_numpy(Im)
 
 
-def search_sharded(comm, metric, k, partial_fn, arrivals_fn):
+def search_sharded(comm, metric, k, partial_fn, arrivals_fn, kind=None):
     """List-sharded Search() with the reference's admission rule at the k-th boundary applied ONCE, after the merge, over all
     shards' candidates (include/knhip.h, "multi-GPU: the reference's answer from a list-sharded index").
       partial_fn(kk)              -> this shard's CANONICAL top-kk (D [nq, kk], I), no tie rule
@@ -165,7 +165,12 @@ def search_sharded(comm, metric, k, partial_fn, arrivals_fn):
     Collectives: one packed all-gather of the (nq, k + 1) partials; a second, small one (20 bytes per arrival) only when
     some query of the batch is flagged (the flags are computed from the merged rows: identical on every rank)."""
     kk = k + 1
-    if kk > 1024:  # (no room for the (k + 1)-th result: canonical, as on one index)
+    # the library decides whether this (kind, k) follows the boundary rule -- k = 1024, brute force with k >= 100 (the
+    # reference's reservoir) and KNHIP_TIES=canonical stay canonical, exactly as on one index (ADVICE round 5); kind None =
+    # an IVF kind
+    from . import _lib
+    rule = _lib.load().knhip_ties_rule_applies(int(kind) if kind is not None else kidx.IVF_FLAT, int(k))
+    if not rule:
         Dp, Ip = partial_fn(k)
         return comm.allgather_merge(metric, Dp, Ip)
     Dp, Ip = partial_fn(kk)

@@ -395,6 +395,44 @@ def test_refine(torch_cuda, port, metric):
     g.close()
 
 
+def test_refine_empty_base_and_long_rows(torch_cuda, port):
+    """(a) a shard that holds NO rows (nbase == 0, base pointer possibly null) must answer "not here" /
+    empty results instead of reading row 0 in the cooperative gather; (b) fp32 rows too long for the cooperative staging
+    area beside four queries (d >= ~5.4k) fall back to the lane-per-row gather instead of failing."""
+    torch = torch_cuda
+    import ctypes as C
+    from knowhere_amd import _lib
+    from knowhere_amd.index import refine_device, refine_distances_device
+    from knowhere_amd._lib import check
+    L = _lib.load()
+    d, nq, kbase = 64, 9, 40
+    q = torch.from_numpy(gen_data(nq, d, 44)).cuda()
+    cand = torch.randint(0, 1000, (nq, kbase), dtype=torch.int64, device="cuda")
+    empty = torch.empty((0, d), dtype=torch.float32, device="cuda")
+    D = refine_distances_device(ob.L2, empty, q, cand)
+    torch.cuda.synchronize()
+    assert (D.view(torch.int32) == -1).all()  # REFINE_NOT_HERE everywhere
+    # ... with a null base pointer, as knhip_refine_distances_device allows for nbase == 0
+    D2 = torch.zeros((nq, kbase), dtype=torch.float32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    check(L.knhip_refine_distances_device(ob.L2, d, None, 0, 0, C.c_void_p(q.data_ptr()), nq, C.c_void_p(cand.data_ptr()),
+                                          kbase, C.c_void_p(D2.data_ptr()), C.c_void_p(s)))
+    torch.cuda.synchronize()
+    assert (D2.view(torch.int32) == -1).all()
+    Ds, Is = refine_device(ob.L2, empty, q, cand, 10)
+    torch.cuda.synchronize()
+    assert (Is == -1).all()
+    # (b) d = 6000, k_base = 100: 4 d + 4 k_base floats = 97.6 KB, + 69.6 KB of staging > 160 KB
+    nb, d2, k = 300, 6000, 5
+    xb, xq = gen_data(nb, d2, 42), gen_data(6, d2, 44)
+    rng = np.random.default_rng(3)
+    ids = np.stack([rng.permutation(nb)[:100] for _ in range(6)]).astype(np.int64)
+    Dg, Ig = refine_device(ob.L2, torch.from_numpy(xb).cuda(), torch.from_numpy(xq).cuda(), torch.from_numpy(ids).cuda(), k)
+    torch.cuda.synchronize()
+    Do, Io = port.refine(ob.L2, xb, xq, ids, k)
+    assert_parity(Do, Io, Dg.cpu().numpy(), Ig.cpu().numpy(), ob.L2, "refine d=6000")
+
+
 def test_gpu_builder_index_parity_and_recall(torch_cuda, port):
     # index trained/encoded by the GPU builder (bench.py's path): same bytes to oracle and GPU
     torch = torch_cuda
