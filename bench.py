@@ -680,6 +680,24 @@ def make_roofline(a, kind, prof, world):
             steps = max(a.steps, 1)
             i8 = prof.get("pq_filter_form", 1) == 2
             l2s = "true" if a.metric == "l2" else "false"
+            mscan = {"queries_per_step": prof["mscan_queries"] / steps,
+                     "overflow_queries_per_step": prof["mscan_overflow_queries"] / steps,
+                     "candidates_per_query": round(prof["mscan_candidates"] / max(prof["mscan_queries"], 1), 1),
+                     "exact_recomputations_per_query": round(prof.get("mscan_recomputed", 0) / max(prof["mscan_queries"], 1), 1)}
+            if prof.get("pq_filter_form", 1) == 3:
+                # decode form (pq_decode.hip): rows decoded once per (list, <= 128 queries), dense half-precision contraction
+                # on v_mfma_f32_32x32x16_f16: 128 MACs = 256 flop per (row, query) -- the ALGORITHMIC work of
+                # dis = dis0 + psum - 2 <q, y> and what the kernel executes, up to the padding of its 32-query tiles
+                pairs = scan_bytes / 32.0  # (row, query) pairs: 32 code bytes per row
+                tf = pairs * 256.0 / sec / 1e12 if sec > 0 else 0.0
+                return with_pmc(dict({"bound": "mfma", "kernel": f"knhip::pqd_kernel<{l2s}, false>", "achieved": round(tf, 1),
+                                      "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F16_PEAK_TFLOPS, 4),
+                                      "algorithmic": {"flop_per_row_query": 256, "TFLOPs": round(tf, 1),
+                                                      "frac": round(tf / MFMA_F16_PEAK_TFLOPS, 4),
+                                                      "table_lookups_per_ns_per_cu": round(scan_bytes / sec / 1e9 / 256.0, 1)
+                                                      if sec > 0 else None},
+                                      "filter_form": "decode: f16 contraction, <= 128 queries per unit", "mscan": mscan},
+                                     **common))
             if i8:
                 # integer form: 1 byte per (lookup, query): an entry holds 16 queries, one ds_read_b128 feeds one
                 # v_mfma_i32_16x16x64_i8 = 1024 lookups; LDS gather and matrix pipe bind at 256 lookups/clk/CU
@@ -709,13 +727,12 @@ def make_roofline(a, kind, prof, world):
                          "lds_gather": {"achieved_GBps": round(lds, 1), "peak_GBps": round(LDS_PEAK_GBPS, 1),
                                         "frac": round(lds / LDS_PEAK_GBPS, 4)},
                          "note": note, "filter_form": "int8 x 16 queries" if i8 else "half x 8 queries",
+                         # `achieved` counts EXECUTED matrix operations (32 per lookup: the selector operand); the algorithm's
+                         # own work is one addition per lookup
+                         "executed": {"ops_per_lookup": 32, "T_ops": round(tops, 1)},
+                         "algorithmic": {"ops_per_lookup": 1, "T_ops": round(tops / 32.0, 1), "frac": round(tops / 32.0 / peak, 4)},
                          "lookups_per_ns_per_cu": round(scan_bytes / sec / 1e9 / 256.0, 1) if sec > 0 else None,
-                         "mscan": {"queries_per_step": prof["mscan_queries"] / steps,
-                                   "overflow_queries_per_step": prof["mscan_overflow_queries"] / steps,
-                                   "candidates_per_query": round(prof["mscan_candidates"] /
-                                                                 max(prof["mscan_queries"], 1), 1),
-                                   "exact_recomputations_per_query": round(prof.get("mscan_recomputed", 0) /
-                                                                           max(prof["mscan_queries"], 1), 1)}}, **common))
+                         "mscan": mscan}, **common))
         lds = scan_bytes * 4.0 / sec / 1e9 if sec > 0 else 0.0
         out = dict({"bound": "lds", "kernel": "knhip::pq_scan_q4_kernel<true, 2>", "achieved": round(lds, 1),
                     "peak": round(LDS_PEAK_GBPS, 1), "unit": "GB/s", "frac": round(lds / LDS_PEAK_GBPS, 4),
@@ -744,6 +761,7 @@ def make_roofline(a, kind, prof, world):
                 "4 flop per (row, query, dim): the query operand is split into two halves (hi + lo) on " \
                 "v_mfma_f32_32x32x16_f16; peak = dense f16 matrix peak"
         tf = flop / sec / 1e12 if sec > 0 else 0.0
+        tf_algo = 2.0 * macs / sec / 1e12 if sec > 0 else 0.0  # (2 flop per (row, query, dim): the contraction itself)
         # HBM side: the measured traffic (PMC pass of this workload, profiles/bench_pmc_traffic.json) where there is one;
         # the bytes the units stream are an upper bound of it (units of one list share it through L2)
         e = pmc_entry(a, world, kname)
@@ -752,6 +770,8 @@ def make_roofline(a, kind, prof, world):
         mfma_frac, hbm_frac = tf / peak, hbm_gbps / HBM_PEAK_GBPS
         steps = max(a.steps, 1)
         extra = {"mfma": {"achieved_TFLOPs": round(tf, 2), "peak_TFLOPs": peak, "frac": round(mfma_frac, 4)},
+                 "executed": {"flop_per_mac": round(flop / max(macs, 1.0), 1), "TFLOPs": round(tf, 2)},
+                 "algorithmic": {"flop_per_mac": 2, "TFLOPs": round(tf_algo, 2), "frac": round(tf_algo / peak, 4)},
                  "stream": {"bytes_per_launch": stream, "GBps": round(stream_gbps, 1),
                             "hbm_frac_upper_bound": round(stream_gbps / HBM_PEAK_GBPS, 4),
                             "note": "bytes the units read (L2 + HBM); `traffic` is the part that came from HBM "
@@ -798,6 +818,8 @@ def pmc_key(a, world, kernel):
         key += ",pqf=1"
     if "pqi_kernel" in kernel:
         key += ",pqi=1"
+    if "pqd_kernel" in kernel:
+        key += ",pqd=1"
     return key
 
 

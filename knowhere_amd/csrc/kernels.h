@@ -265,6 +265,12 @@ struct MScanArgs {
     P16Rec* pq_recs16;             // [unit bound]
     int32_t* pq_ctr;               // [8 * 16] one unit counter per XCD, 64 B apart
     int32_t pq_prune_mu;           // finish kernel: pq_qs is the integer form's record ([q][1] = sum of the per-m offsets)
+    // ... its DECODE form (pq_decode.hip, pqd_kernel): rows decoded once per (list, <= 128 queries), dense f16 contraction
+    const void* pq_cb16;           // [32][256][4] halves: the codebook scaled by a power of two (per index)
+    const void* pq_qh16;           // [nq][128] halves: the queries scaled by the batch's power of two
+    const float* pq_qd;            // [nq][4] = {||q||_1, B_q, eps_base, 2 B_q}
+    const float* pq_sc;            // [8] = {sc_y, 1 / sc_y, max |cb|, Ysum, sc_q, 1 / sc_q, SC, 1 / SC}: the index's scales (device)
+    const float* pq_psum_s;        // -psum SC / 2 per stream position (same offsets as pq_psum): the accumulators' start values
 };
 
 // ---- pq_filter.hip ----
@@ -295,6 +301,19 @@ hipError_t launch_pq_sample(const MScanArgs& a, const int64_t* keys, const float
                             int scap, float pabs_max, bool is_l2, int32_t* n_row, float* qs, float* qis, float* qmu,
                             hipStream_t s, float* gthr_out = nullptr, uint2* gmeta_out = nullptr, int ksel = 0);
 hipError_t launch_pqi(const MScanArgs& a, bool is_l2, int64_t units_bound, hipStream_t s);
+
+// ---- pq_decode.hip: the decode form of the IVF-PQ prefilter ----
+constexpr int PD_QT = 128; // queries per unit
+size_t pqd_smem();
+bool pqd_supports(int M, int d);
+// per index: cb (FAISS order [m][256][4]) -> cb16 (64 KB of halves) + st[8] (scales, constants); centroids: ncent floats (their
+// largest magnitude sets the query scale); psum -> psum_s (npsum floats; L2 only); scratch: one uint32
+hipError_t launch_pqd_index_prep(const float4* cb, const float* centroids, int64_t ncent, void* cb16, float* st,
+                                 uint32_t* scratch, const float* psum, int64_t npsum, float* psum_s, hipStream_t s);
+// per batch: qh16: nq * 128 halves; qd: nq * 4 floats = {||q||_1, B_q, eps_base, 2 B_q}
+hipError_t launch_pqd_query_prep(const float* queries, const float4* cb, const float* cst, int64_t nq, bool is_l2,
+                                 float pabs_max, void* qh16, float* qd, hipStream_t s);
+hipError_t launch_pqd(const MScanArgs& a, bool is_l2, int64_t units_bound, hipStream_t s);
 
 bool pqf_supports(int M, int d);
 hipError_t launch_pqf(const MScanArgs& a, bool is_l2, int64_t units_bound, hipStream_t s);

@@ -138,6 +138,7 @@ struct Workspace {
     DevBuf ms_qh, ms_ql, ms_qs;                                      // SQ8 IP: prepared query operands (halves) + sums
                                                                      // (IVF-PQ prefilter: ms_qh = half tables, ms_qs = scales)
     DevBuf pq_recs, pq_ctr;                                          // pq_filter.hip: unit records, per-XCD counters
+    DevBuf ms_qh16, ms_qd;                                           // pq_decode.hip: the queries as halves, their error records
     DevBuf rs_sort;                                                  // row selection of more than 16384 keys: sort scratch
     // host-boundary staging
     DevBuf h_queries, h_bitset, h_out_d, h_out_i, h_ref_d, h_ref_i;
@@ -241,9 +242,12 @@ struct knhip_index {
     // 2 = whenever the shape allows (KNHIP_PQF=1: tests), 0 = never (KNHIP_PQF=0).  Its layouts are built on first use.
     int pqf = 1;
     bool pqf_guard = true;           // KNHIP_PQF_GUARD=0 switches the selectivity guard off (tests of the overflow rounds)
-    int pqf_form = 0;                // KNHIP_PQF_FORM: 0 = chosen per batch by the guard, 1 = half precision, 2 = int8
-    mutable bool pqf_ready = false;
-    mutable bool pqi_ready = false;
+    int pqf_form = 0;                // KNHIP_PQF_FORM: 0 = chosen per batch by the guard (decode form, else half), 1 = half
+                                     // precision tables, 2 = int8 tables, 3 = decode form (pq_decode.hip)
+    mutable bool psum_ready = false; // psum + its offsets (every form and the sample pass)
+    mutable bool pqf_ready = false;  // ... + the half form's token stream
+    mutable bool pqi_ready = false;  // ... + the integer form's
+    mutable bool pqd_ready = false;  // ... + the decode form's half codebook, scales and start values
     // The selectivity guard of the IVF-PQ prefilter decides per (k, nprobe): synchronously the first time (and every 64th),
     // from the PREVIOUS batch's counters otherwise -- they arrive through a pinned buffer and an event, nothing waits.  The
     // decision only picks kernels; results do not depend on it.
@@ -264,6 +268,9 @@ struct knhip_index {
     mutable DevBuf rows_r;           // rotated token stream (stream16r)
     mutable DevBuf d_list_blk_off_r; // [nlist + 1]
     mutable DevBuf psum;             // per stream position: sum_m term2 (L2)
+    mutable DevBuf psum_s;           // decode form: -psum SC / 2 (the accumulators' start values)
+    mutable DevBuf pqd_cb16;         // decode form: the codebook as halves (64 KB)
+    mutable DevBuf pqd_st;           // decode form: [8] scales and constants (pq_decode.hip) + one word of scratch
     mutable float pabs_max = 0.f;    // max over vectors of sum_m |term2|
     // scratch
     mutable std::mutex mu;
@@ -284,7 +291,7 @@ struct knhip_index {
     int64_t device_bytes() const {
         const DevBuf* all[] = {&centroids, &centroids_il, &centroids_bs, &cb, &precomp_t, &sq_trained, &d_list_len,
                                &d_list_row_off, &d_list_blk_off, &ids, &rows, &rows2, &d_list_blk_off2, &cb_t, &codes_aos,
-                               &rows_r, &d_list_blk_off_r, &psum, &rows_i, &idmap_ids, &idmap_col};
+                               &rows_r, &d_list_blk_off_r, &psum, &rows_i, &idmap_ids, &idmap_col, &psum_s, &pqd_cb16, &pqd_st};
         int64_t t = 0;
         for (auto* b : all) {
             t += (int64_t)b->bytes;
@@ -528,9 +535,11 @@ int build_list_layout(knhip_index* idx, const std::vector<int64_t>& list_off, co
         const char* pg = getenv("KNHIP_PQF_GUARD");
         idx->pqf_guard = !(pg && pg[0] == '0');
         const char* pm = getenv("KNHIP_PQF_FORM");
-        idx->pqf_form = (pm && pm[0] == 'h') ? 1 : (pm && pm[0] == 'i') ? 2 : 0;
+        idx->pqf_form = (pm && pm[0] == 'h') ? 1 : (pm && pm[0] == 'i') ? 2 : (pm && pm[0] == 'd') ? 3 : 0;
+        idx->psum_ready = false;
         idx->pqf_ready = false;
         idx->pqi_ready = false;
+        idx->pqd_ready = false;
         idx->idmap_ready = false;
         idx->rg_seg_nseg = -1;
         idx->idmap_ids.release();
@@ -538,6 +547,7 @@ int build_list_layout(knhip_index* idx, const std::vector<int64_t>& list_off, co
         idx->rows_i.release();
         idx->rows_r.release();
         idx->psum.release();
+        idx->psum_s.release();
     }
     for (int64_t l = 0; l < nlist; l++) {
         idx->h_list_len[l] = list_off[l + 1] - list_off[l];
@@ -671,10 +681,11 @@ int ensure_mscan_norms(const knhip_index* idx) {
 
 constexpr int KNHIP_PQF_ABANDONED = 1; // (not an error: the selectivity guard sent the batch to the exact kernel)
 
-// IVF-PQ half-precision prefilter: rotated token stream + per-vector term-2 sums, from the canonical AoS codes
-int ensure_pqf(const knhip_index* idx) {
+// IVF-PQ prefilter, every form and the sample pass: per-vector term-2 sums (+ the block offsets they are indexed by), from the
+// canonical AoS codes
+int ensure_psum(const knhip_index* idx) {
     std::lock_guard<std::mutex> lk(idx->mu);
-    if (idx->pqf_ready) {
+    if (idx->psum_ready) {
         return KNHIP_OK;
     }
     const int64_t nlist = idx->nlist;
@@ -684,10 +695,6 @@ int ensure_pqf(const knhip_index* idx) {
     }
     HIP_TRY(idx->d_list_blk_off_r.alloc((size_t)(nlist + 1) * sizeof(int64_t)));
     HIP_TRY(hipMemcpy(idx->d_list_blk_off_r.p, off.data(), (size_t)(nlist + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
-    HIP_TRY(idx->rows_r.alloc((size_t)std::max<int64_t>(off[nlist], 1) * 64 * sizeof(uint4)));
-    HIP_TRY(launch_pq_stream16r(idx->codes_aos.as<uint8_t>(), idx->d_list_row_off.as<int64_t>(),
-                                idx->d_list_len.as<int64_t>(), idx->d_list_blk_off_r.as<int64_t>(), nlist,
-                                idx->rows_r.as<uint4>(), nullptr));
     idx->pabs_max = 0.f;
     if (idx->is_l2) {
         const size_t npos = (size_t)std::max<int64_t>(off[nlist], 1) * 16; // 16 vector positions per block
@@ -701,7 +708,51 @@ int ensure_pqf(const knhip_index* idx) {
         HIP_TRY(hipMemcpy(&idx->pabs_max, bits, sizeof(float), hipMemcpyDeviceToHost));
     }
     HIP_TRY(hipDeviceSynchronize());
+    idx->psum_ready = true;
+    return KNHIP_OK;
+}
+
+// ... the half form: + the rotated token stream
+int ensure_pqf(const knhip_index* idx) {
+    if (int rc = ensure_psum(idx)) return rc;
+    std::lock_guard<std::mutex> lk(idx->mu);
+    if (idx->pqf_ready) {
+        return KNHIP_OK;
+    }
+    const int64_t nblk = idx->nlist > 0 ? [&] {
+        int64_t t = 0;
+        for (int64_t l = 0; l < idx->nlist; l++) t += pq_stream16r_blocks(idx->h_list_len[l]);
+        return t;
+    }() : 0;
+    HIP_TRY(idx->rows_r.alloc((size_t)std::max<int64_t>(nblk, 1) * 64 * sizeof(uint4)));
+    HIP_TRY(launch_pq_stream16r(idx->codes_aos.as<uint8_t>(), idx->d_list_row_off.as<int64_t>(),
+                                idx->d_list_len.as<int64_t>(), idx->d_list_blk_off_r.as<int64_t>(), idx->nlist,
+                                idx->rows_r.as<uint4>(), nullptr));
+    HIP_TRY(hipDeviceSynchronize());
     idx->pqf_ready = true;
+    return KNHIP_OK;
+}
+
+// ... the decode form (pq_decode.hip): the codebook as halves, the index's scales, the rows' start values -psum SC / 2.  No
+// token stream: the kernel reads the canonical AoS codes as they lie
+int ensure_pqd(const knhip_index* idx) {
+    if (int rc = ensure_psum(idx)) return rc;
+    std::lock_guard<std::mutex> lk(idx->mu);
+    if (idx->pqd_ready) {
+        return KNHIP_OK;
+    }
+    HIP_TRY(idx->pqd_cb16.alloc((size_t)32 * 256 * 4 * 2));
+    HIP_TRY(idx->pqd_st.alloc(16 * sizeof(float)));
+    const int64_t npsum = idx->is_l2 ? (int64_t)(idx->psum.bytes / sizeof(float)) - 4 : 0;
+    if (npsum > 0) {
+        HIP_TRY(idx->psum_s.alloc((size_t)(npsum + 4) * sizeof(float)));
+    }
+    HIP_TRY(launch_pqd_index_prep(idx->cb.as<float4>(), idx->centroids.as<float>(), idx->nlist * (int64_t)idx->d,
+                                  idx->pqd_cb16.p, idx->pqd_st.as<float>(),
+                                  reinterpret_cast<uint32_t*>(idx->pqd_st.as<float>() + 8), idx->psum.as<float>(), npsum,
+                                  idx->psum_s.as<float>(), nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    idx->pqd_ready = true;
     return KNHIP_OK;
 }
 
@@ -991,7 +1042,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
     auto run_mscan = [&](const std::function<int(const KnItem*, const KnPair*, const int64_t*, int64_t)>& exact_one)
             -> int {
         if (kind == KNHIP_IVF_PQ) {
-            if (int rc = ensure_pqf(idx)) return rc;
+            if (int rc = ensure_psum(idx)) return rc; // (the token streams / the half codebook follow the form)
         } else {
             if (int rc = ensure_mscan_norms(idx)) return rc;
         }
@@ -1070,7 +1121,6 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             HIP_TRY(ws->pq_recs.reserve((size_t)std::max<int64_t>(std::max(units_bound, bound0), npairs) * sizeof(P8Rec)));
             HIP_TRY(ws->pq_ctr.reserve(8 * 16 * sizeof(int32_t)));
             m.list_blk_off = nullptr;
-            m.pq_codes_r = idx->rows_r.as<uint4>();
             m.pq_sblk_off_r = idx->d_list_blk_off_r.as<int64_t>();
             m.pq_psum = idx->psum.as<float>();
             m.pq_cb_t = idx->cb_t.as<float4>();
@@ -1081,6 +1131,11 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             m.pq_ctr = ws->pq_ctr.as<int32_t>();
         }
         bool pq_i8 = false; // IVF-PQ: the integer form of the filter (chosen after the sample pass)
+        bool pq_dec = false; // IVF-PQ: the decode form (pq_decode.hip)
+        // which second form the guard weighs against the half tables: the decode form (default; its eps lies between the
+        // half tables' and the int8 tables', its units hold 128 queries) or, when asked for, the int8 tables
+        const bool pqd_ok = kind == KNHIP_IVF_PQ && pqd_supports(idx->desc.pq_m, d);
+        const bool want_dec = kind == KNHIP_IVF_PQ && pqd_ok && (idx->pqf_form == 0 || idx->pqf_form == 3);
         // IVF-PQ: the pairs are grouped by list (work table: four small, latency-bound kernels, ~0.25 ms per 10^4 queries at
         // C3) on a side stream while this stream runs the sample pass; only the cut into units waits for the form.
         SideJoin sj{ws, s};
@@ -1134,8 +1189,9 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             return kind == KNHIP_IVF_FLAT ? ((flat_b && x.dump == nullptr) ? launch_mscan_flat_bf16(x, is_l2, bound, s)
                                                                             : launch_mscan_flat(x, is_l2, bound, s))
                  : kind == KNHIP_IVF_SQ8  ? launch_mscan_sq8(x, is_l2, bound, s)
-                 : (pq_i8 && x.dump == nullptr) ? launch_pqi(x, is_l2, bound, s)
-                                                : launch_pqf(x, is_l2, bound, s);
+                 : (pq_dec && x.dump == nullptr) ? launch_pqd(x, is_l2, bound, s)
+                 : (pq_i8 && x.dump == nullptr)  ? launch_pqi(x, is_l2, bound, s)
+                                                 : launch_pqf(x, is_l2, bound, s);
         };
         idx->rank0_phase_used = false;
         idx->last_pq_form = 0;
@@ -1143,7 +1199,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             // phase 1: tau_q from a sample of the closest list (units of the rank-0 virtual lists [0, nlist), DUMP mode)
             StageTimer t(idx, s, KNHIP_STAGE_SCAN_RANK0);
             HIP_TRY(hipMemsetAsync(cand_cnt, 0, (size_t)(2 * nq + 1) * sizeof(int32_t), s));
-            const bool want_i8 = kind == KNHIP_IVF_PQ && idx->pqf_form != 1;
+            const bool want_i8 = kind == KNHIP_IVF_PQ && idx->pqf_form == 2;
             if (kind == KNHIP_IVF_PQ) {
                 // (the sample pass below computes the queries' table statistics; the tables themselves follow the guard)
                 HIP_TRY(ws->ms_qs.reserve((size_t)nq * 4 * sizeof(float)));
@@ -1203,31 +1259,45 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             }
         }
         {
-            StageTimer t(idx, s, KNHIP_STAGE_TABLES); // (IVF_PQ: the filter's query tables + the selectivity guard)
-            const bool want_i8 = kind == KNHIP_IVF_PQ && idx->pqf_form != 1;
+            StageTimer t(idx, s, KNHIP_STAGE_TABLES); // (IVF_PQ: the filter's query operands / tables + the selectivity guard)
+            const bool want_i8 = kind == KNHIP_IVF_PQ && idx->pqf_form == 2;
             if (kind == KNHIP_IVF_PQ) {
-                // The integer form of the filter (int8 tables, 16 queries per unit: twice the lookups per step) has an eps
-                // 8 .. 20 x that of the half-precision form.  Selectivity guard (pq_filter.hip): the sample dump predicts
-                // each query's candidate count under either eps; the batch takes the integer form when that is small,
-                // else the half-precision form, else -- data where even that lets a few percent of the rows through,
-                // so that the exact finish would cost more than the exact scan -- the exact 4-query kernel.
+                // Three forms of the filter (pq_filter.hip, pq_decode.hip).  DECODE form: rows decoded once per (list, <= 128
+                // queries), dense f16 contraction -- eps ~ 2^-9 B_q.  HALF tables: 8 queries per unit, eps = 2^-11 A_q: the
+                // tightest.  INT8 tables: 16 queries per unit, eps 8 .. 20 x the half form's (kept for KNHIP_PQF_FORM=int8).
+                // Selectivity guard: the sample dump predicts each query's candidate count under the eps of the half form and
+                // of the second form (decode, or int8 when asked for); the batch takes the second form when that count is
+                // small, else the half form, else -- data where even that lets a few percent of the rows through, so that the
+                // exact finish would cost more than the exact scan -- the exact 4-query kernel.
                 if (want_i8) { // (pass 1 -- ranges, midranges -- was part of the sample pass)
                     HIP_TRY(launch_pqi_query_table(d_q, idx->cb.as<float4>(), d, nq, is_l2, idx->pabs_max, ws->ms_qi.p,
                                                    ws->ms_qis.as<float>(), ws->ms_qmu.as<float>(), /*stats_done=*/true,
                                                    s));
                 }
+                if (want_dec) { // the queries as halves + their error records (cheap: the guard reads the records)
+                    if (int rc = ensure_pqd(idx)) return rc;
+                    HIP_TRY(ws->ms_qh16.reserve((size_t)nq * 128 * 2));
+                    HIP_TRY(ws->ms_qd.reserve((size_t)nq * 4 * sizeof(float)));
+                    HIP_TRY(launch_pqd_query_prep(d_q, idx->cb.as<float4>(), idx->pqd_st.as<float>(), nq, is_l2, idx->pabs_max,
+                                                  ws->ms_qh16.p, ws->ms_qd.as<float>(), s));
+                }
+                const bool want2 = want_i8 || want_dec;
+                const int form2 = want_dec ? 3 : 2;
+                const float* qs2 = want_dec ? ws->ms_qd.as<float>() : want_i8 ? ws->ms_qis.as<float>() : nullptr;
                 auto decide = [&](const int32_t* poor_h, int64_t n) -> int {
+                    if (want2 && (idx->pqf_form == form2 || (int64_t)poor_h[1] * 4 <= n)) {
+                        return form2;
+                    }
                     if ((int64_t)poor_h[0] * 4 > n) {
                         return 0;
                     }
-                    return (want_i8 && (idx->pqf_form == 2 || (int64_t)poor_h[1] * 4 <= n)) ? 2 : 1;
+                    return 1;
                 };
-                int form = want_i8 ? 2 : 1; // (guard off: the form asked for)
+                int form = want2 ? form2 : 1; // (guard off: the form asked for)
                 if (idx->pqf_guard) {
                     int32_t* poor = ws->ms_cand_cnt.as<int32_t>() + 2 * nq + 1;
                     HIP_TRY(launch_pqf_predict(ws->dump.as<float>(), sample, ws->ms_nrow.as<int32_t>(),
-                                               ws->gthr.as<float>(), ws->ms_qs.as<float>(),
-                                               want_i8 ? ws->ms_qis.as<float>() : nullptr, keys_p, nprobe, nlist,
+                                               ws->gthr.as<float>(), ws->ms_qs.as<float>(), qs2, keys_p, nprobe, nlist,
                                                idx->d_list_len.as<int64_t>(), nq, ms_cap, k, is_l2, poor, s));
                     bool sync_now = true;
                     // (at most 64 (k, nprobe) pairs are remembered -- an entry owns a pinned buffer and an event; a caller
@@ -1279,9 +1349,12 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
                     }
                 }
                 pq_i8 = form == 2;
-                idx->last_pq_form = pq_i8 ? 2 : 1;
-                if (!pq_i8) {
+                pq_dec = form == 3;
+                idx->last_pq_form = form;
+                if (form == 1) {
                     // the queries' half tables + scales (the same records the sample pass wrote)
+                    if (int rc = ensure_pqf(idx)) return rc;
+                    m.pq_codes_r = idx->rows_r.as<uint4>();
                     HIP_TRY(ws->ms_qh.reserve((size_t)nq * 256 * 32 * 2));
                     HIP_TRY(launch_pqf_query_table(d_q, idx->cb.as<float4>(), d, nq, is_l2, idx->pabs_max, ws->ms_qh.p,
                                                    ws->ms_qs.as<float>(), s));
@@ -1292,10 +1365,19 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
                     qt = 16;
                     HIP_TRY(ws->pq_recs16.reserve((size_t)std::max<int64_t>(std::max(units_bound, bound0), npairs) *
                                                   sizeof(P16Rec)));
+                    m.pq_codes_r = idx->rows_r.as<uint4>();
                     m.pq_codes_i = idx->rows_i.as<uint4>();
                     m.pq_qi = ws->ms_qi.p;
                     m.pq_qis = ws->ms_qis.as<float>();
                     m.pq_recs16 = ws->pq_recs16.as<P16Rec>();
+                }
+                if (pq_dec) {
+                    qt = PD_QT;
+                    m.pq_cb16 = idx->pqd_cb16.p;
+                    m.pq_qh16 = ws->ms_qh16.p;
+                    m.pq_qd = ws->ms_qd.as<float>();
+                    m.pq_sc = idx->pqd_st.as<float>();
+                    m.pq_psum_s = idx->psum_s.as<float>();
                 }
             }
         }
@@ -1334,6 +1416,9 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             if (pq_i8) {
                 mf.pq_qs = m.pq_qis; // (the finish kernel's pruning reads eps_base at [q][2] of either)
                 mf.pq_prune_mu = 1;  // (... and the integer form's emission eps carries |sum of the per-m offsets|)
+            }
+            if (pq_dec) {
+                mf.pq_qs = m.pq_qd;  // (eps_base at [q][2], like the table forms' records)
             }
             HIP_TRY(launch_mscan_finish(mf, kind, is_l2, keys_p, cdis_p, nprobe, k, d_out_d, d_out_i, counters, 1, s));
             HIP_TRY(launch_ms_flag_pairs(overflow, 2, keys_p, nq, nprobe, nlist, idx->d_list_len.as<int64_t>(), k,

@@ -1,0 +1,618 @@
+// knowhere_amd/csrc/pq_decode.hip -- IVF-PQ (M = 32 x 8 bit, dsub = 4) ADC prefilter, DECODE form (gfx950, round 6).
+//
+// The table forms of pq_filter.hip restate the CPU's algorithm on the matrix cores: a per-query table of 8192 entries, one
+// table LOOKUP per (row, query, sub-quantizer), the additions done by a matrix instruction whose other operand is a constant
+// selector -- 16 multiply-accumulate slots spent per addition, and a 128 KB table rebuilt in LDS for every 16 queries of a
+// list.  On this machine the cheaper formulation is the other one: for L2 with the precomputed term-2 table
+//
+//     dis(q, v) = dis0(q, list) + psum[v] - 2 <q, y(v)>,      y(v) = the row's DECODED residual (its 32 codebook entries,
+//                                                              128 values), psum[v] = sum_m term2[list][m][code_m(v)]
+//                                                              (per stored row, built with the layout: pq_filter.hip)
+//     dis(q, v) = dis0 + <q, y(v)>                             (inner product)
+//
+// so the prefilter of a list is a DENSE contraction  [rows of the list] x [queries that probe it] x 128:
+//   * the codebook is STATIC: 32 x 256 entries x 4 halves = 64 KB, loaded into LDS once per workgroup (no per-unit table
+//     phase at all);
+//   * a row is decoded ONCE per (list, <= 128 queries): 16 ds_read_b64 per lane and 32-row tile (lane = (row, half of the
+//     sub-quantizers)) ARE the A operand of v_mfma_f32_32x32x16_f16 -- lane (r, h) of step s holds the entries of
+//     m = 16 h + 2 s, 16 h + 2 s + 1, i.e. dimensions 64 h + 8 s .. + 8 (the contraction does not care which dimension sits
+//     in which k slot as long as both operands agree), which are bytes 2 s, 2 s + 1 of the 16 contiguous code bytes the lane
+//     fetched: the canonical AoS codes are read as they lie, 1 KiB per wave and tile, no token stream;
+//   * the queries of the unit sit in REGISTERS (lane (n, h): query n's dimensions 64 h .. 64 h + 64 as 32 VGPRs per tile of
+//     32 queries; one wave per SIMD, 512 registers): a decoded tile is multiplied against up to four query tiles = 32
+//     matrix instructions of 32 cycles; per (row, query) 128 MACs instead of 512 MAC slots, the codes of a list read once
+//     per 128 queries instead of once per 16.
+// The accumulator starts at -psum[v] * SC / 2 (stored with the index: psum_s) and ends as SC * (<q, y> - psum / 2): one compare per (row, query) against
+// SC * (dis0 - tau - eps) / 2, survivors parked in LDS and appended to the candidate lists at the unit's end (ms_emit), the
+// exact finish (mfma_scan.hip, KIND 2) recomputes them in the reference's order: no returned value sees half precision.
+//
+// Error bound (tests/test_pq_decode_bound.py replays it).  Operands: Q = half(sc_q q), Y = half(sc_y y) with powers of two
+// sc_q, sc_y fixed per INDEX (pqd_codebook_kernel), SC = sc_q sc_y.  With
+// u = 2^-11 (half precision, round to nearest), a = 2^-14 (the bound must hold whether or not the matrix pipe flushes half
+// subnormals: an element below the normal range is off by at most the smallest normal), U = 2^-24:
+//     |acc / SC - (<q, y> - psum / 2)| <= (2 u + u^2) B_q + a (1 + u) (||y||_1 / sc_q + ||q||_1 / sc_y) + 128 a^2 / SC
+//                                          + 136 U ((1 + 3 u) B_q + pabs_max / 2)
+//     B_q = sum_m max_c sum_{i in m} |q_i| |cb[m][c][i]|  >=  sum_i |q_i| |y_i(v)| for every row v
+// (products of halves are exact in fp32; the accumulation of 128 products onto the start value, in any order and rounding, is
+// the last line).  The distance has twice that (L2) plus the reference's own fp32 roundings of its 32-term sums, as in
+// pq_filter.hip: 128 U (pabs_max + 2 B_q), and 64 U (|dis0| + |tau|) per pair for the threshold arithmetic.
+//
+// Reference semantics replaced: IVFPQScannerT::scan_list_with_table (thirdparty/faiss/faiss/impl/pq_code_distance/
+// IVFPQScanner_impl.h:109-181) -- only WHICH rows reach the exact finish.
+#include "common.h"
+#include "kernels.h"
+#include "ms_common.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace knhip {
+
+constexpr int PD_M = 32;
+constexpr int PD_KSUB = 256;
+constexpr int PD_D = 128;
+constexpr int PD_WAVES = 4;
+constexpr int PD_THREADS = PD_WAVES * KN_WAVE;
+constexpr int PD_CB_BYTES = PD_M * PD_KSUB * 8;     // 65536: [m][c][4 halves]
+constexpr int PD_HITS = 1024;                       // parked hits per unit (16 KB; more are appended on the spot)
+constexpr int PD_OFF_T = PD_CB_BYTES;               // float  [128] accumulator threshold of the pair (scaled)
+constexpr int PD_OFF_C = PD_OFF_T + PD_QT * 4;      // float  [128] dis0 +- eps
+constexpr int PD_OFF_Q = PD_OFF_C + PD_QT * 4;      // int32  [128] query of the pair (-1: none)
+constexpr int PD_OFF_S = PD_OFF_Q + PD_QT * 4;      // int32  [128] slot of the pair
+constexpr int PD_OFF_HIT = PD_OFF_S + PD_QT * 4;    // uint4  [PD_HITS] {pair, position, accumulator bits, -}
+constexpr int PD_OFF_CTL = PD_OFF_HIT + PD_HITS * 16; // int32 [16]: 0 = parked hits, 1 = current unit, 2 = next unit
+constexpr int PD_SMEM = PD_OFF_CTL + 64;
+static_assert(PD_SMEM <= 160 * 1024, "LDS of one workgroup");
+constexpr float PD_U = 5.9604645e-8f;   // 2^-24
+constexpr float PD_UH = 4.8828125e-4f;  // 2^-11
+constexpr float PD_A = 6.103515625e-5f; // 2^-14: the smallest normal half
+
+typedef _Float16 pd_h8 __attribute__((ext_vector_type(8)));
+typedef float pd_f16 __attribute__((ext_vector_type(16)));
+
+size_t pqd_smem() { return PD_SMEM; }
+
+bool pqd_supports(int M, int d) { return M == PD_M && d == PD_D; }
+
+// the power of two that puts `amax` into [2^14, 2^15) (1 for amax = 0; exponent kept within +-60 so that products of
+// two such scales and of scaled operands stay far inside the fp32 range)
+__host__ __device__ inline float pqd_scale_for(float amax) {
+    if (!(amax > 0.f) || !(amax < INFINITY)) {
+        return 1.0f;
+    }
+    int e;
+    frexpf(amax, &e); // amax = f 2^e, f in [0.5, 1)
+    int s = 15 - e;
+    s = s < -60 ? -60 : (s > 60 ? 60 : s);
+    return ldexpf(1.0f, s);
+}
+
+// ---- per index: the half-precision codebook, the scales, the scaled row constants ----------------------------------------
+// cb: FAISS order [m][256][4] fp32.  cb16: [m][256][4] halves of sc_y cb.
+// st[0..7] = {sc_y, 1 / sc_y, max |cb|, Ysum = sum_m max_c sum_i |cb[m][c][i]| (>= ||y(v)||_1 of every row),
+//             sc_q, 1 / sc_q, SC = sc_q sc_y, 1 / SC}.
+// sc_q is fixed per INDEX, not per batch: queries live where the data lives, |x_i| <= |c_i| + |y_i| <= cmax + ymax, and the
+// scale puts 4 (cmax + ymax) into [2^14, 2^15): a query up to eight times the data's largest coordinate still fits the half
+// range (a larger one gets eps = inf and takes the exact kernels); a smaller one loses nothing (floating point) until its
+// coordinates fall 2^-28 below that.  A fixed SC lets the rows' start values -psum SC / 2 be stored with the index.
+__global__ __launch_bounds__(PD_KSUB) void pqd_codebook_kernel(const float4* __restrict__ cb, const uint32_t* __restrict__ cmax_bits,
+                                                               _Float16* __restrict__ cb16, float* __restrict__ st) {
+    __shared__ float s_red[PD_KSUB];
+    __shared__ float s_bc[2];
+    const int c = threadIdx.x;
+    float amax = 0.f;
+    for (int m = 0; m < PD_M; m++) {
+        const float4 e = cb[m * PD_KSUB + c];
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(e.x), fabsf(e.y)), fmaxf(fabsf(e.z), fabsf(e.w))));
+    }
+    s_red[c] = amax;
+    __syncthreads();
+    if (c == 0) {
+        float v = 0.f;
+        for (int i = 0; i < PD_KSUB; i++) {
+            v = fmaxf(v, s_red[i]);
+        }
+        s_bc[0] = v;
+    }
+    __syncthreads();
+    const float ymax = s_bc[0];
+    const float sc = pqd_scale_for(ymax);
+    float ysum = 0.f;
+    for (int m = 0; m < PD_M; m++) {
+        const float4 e = cb[m * PD_KSUB + c];
+        _Float16* o = cb16 + ((size_t)m * PD_KSUB + c) * 4;
+        o[0] = (_Float16)(e.x * sc);
+        o[1] = (_Float16)(e.y * sc);
+        o[2] = (_Float16)(e.z * sc);
+        o[3] = (_Float16)(e.w * sc);
+        __syncthreads();
+        s_red[c] = fabsf(e.x) + fabsf(e.y) + fabsf(e.z) + fabsf(e.w);
+        __syncthreads();
+        if (c == 0) {
+            float v = 0.f;
+            for (int i = 0; i < PD_KSUB; i++) {
+                v = fmaxf(v, s_red[i]);
+            }
+            ysum += v;
+        }
+    }
+    if (c == 0) {
+        const float cmax = __uint_as_float(*cmax_bits);
+        const float sq = pqd_scale_for(4.0f * (cmax + ymax));
+        st[0] = sc;
+        st[1] = 1.0f / sc;
+        st[2] = ymax;
+        st[3] = ysum * 1.0001f;
+        st[4] = sq;
+        st[5] = 1.0f / sq;
+        st[6] = sq * sc;
+        st[7] = 1.0f / (sq * sc);
+    }
+}
+
+// largest finite |x| of an array (bit pattern of a non-negative float, atomic max; *out zeroed by the caller)
+__global__ __launch_bounds__(256) void pqd_absmax_kernel(const float* __restrict__ x, int64_t n, uint32_t* __restrict__ out) {
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = fabsf(x[i]);
+        m = v < INFINITY ? fmaxf(m, v) : m;
+    }
+#pragma unroll
+    for (int dlt = KN_WAVE / 2; dlt > 0; dlt >>= 1) {
+        m = fmaxf(m, __shfl_xor(m, dlt, KN_WAVE));
+    }
+    if (lane_id() == 0 && m > 0.f) {
+        atomicMax(out, __float_as_uint(m));
+    }
+}
+
+// psum_s[i] = -psum[i] SC / 2 (a power-of-two multiple: exact)
+__global__ __launch_bounds__(256) void pqd_scale_psum_kernel(const float* __restrict__ psum, int64_t n, const float* __restrict__ st,
+                                                             float* __restrict__ psum_s) {
+    const float f = -0.5f * st[6];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        psum_s[i] = psum[i] * f;
+    }
+}
+
+// centroids [ncent] floats; scratch: one uint32; psum / psum_s: npsum floats (L2; null / 0 for the inner product)
+hipError_t launch_pqd_index_prep(const float4* cb, const float* centroids, int64_t ncent, void* cb16, float* st,
+                                 uint32_t* scratch, const float* psum, int64_t npsum, float* psum_s, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(scratch, 0, sizeof(uint32_t), s);
+    if (e != hipSuccess) {
+        return e;
+    }
+    if (ncent > 0) {
+        const unsigned grid = (unsigned)std::min<int64_t>((ncent + 255) / 256, 1024);
+        hipLaunchKernelGGL(pqd_absmax_kernel, dim3(grid), dim3(256), 0, s, centroids, ncent, scratch);
+    }
+    hipLaunchKernelGGL(pqd_codebook_kernel, dim3(1), dim3(PD_KSUB), 0, s, cb, scratch, static_cast<_Float16*>(cb16), st);
+    if (npsum > 0 && psum != nullptr) {
+        const unsigned grid = (unsigned)std::min<int64_t>((npsum + 255) / 256, 65535);
+        hipLaunchKernelGGL(pqd_scale_psum_kernel, dim3(grid), dim3(256), 0, s, psum, npsum, st, psum_s);
+    }
+    return hipGetLastError();
+}
+
+// ---- per batch: the queries' half rows and error records ---------------------------------------------------------------
+// one workgroup per query, thread = code c.  qh16[q][128] = half(sc_q q); qd[q] = {||q||_1, B_q, eps_base, 2 B_q}.
+// cst = the index constants above; pabs_max = max_v sum_m |term2| (L2 with the precomputed table; 0 for the inner product)
+template <bool IS_L2>
+__global__ __launch_bounds__(PD_KSUB) void pqd_query_prep_kernel(const float* __restrict__ queries, const float4* __restrict__ cb,
+                                                                 const float* __restrict__ cst, float pabs_max,
+                                                                 _Float16* __restrict__ qh16, float* __restrict__ qd) {
+    __shared__ float s_q[PD_D];
+    __shared__ uint32_t s_max[PD_M];
+    const int64_t q = blockIdx.x;
+    const int c = threadIdx.x;
+    if (c < PD_D) {
+        s_q[c] = queries[q * PD_D + c];
+    }
+    if (c < PD_M) {
+        s_max[c] = 0u;
+    }
+    __syncthreads();
+    const float inv_y = cst[1], ysum = cst[3], sc_q = cst[4], inv_q = cst[5], inv_sc = cst[7];
+    if (c < PD_D) {
+        qh16[q * PD_D + c] = (_Float16)(s_q[c] * sc_q); // (out of the half range: inf here, eps = inf below -> exact path)
+    }
+    for (int m = 0; m < PD_M; m++) {
+        const float4 e = cb[m * PD_KSUB + c];
+        float v = fabsf(s_q[4 * m]) * fabsf(e.x) + fabsf(s_q[4 * m + 1]) * fabsf(e.y) + fabsf(s_q[4 * m + 2]) * fabsf(e.z) +
+                  fabsf(s_q[4 * m + 3]) * fabsf(e.w);
+#pragma unroll
+        for (int dlt = KN_WAVE / 2; dlt > 0; dlt >>= 1) {
+            v = fmaxf(v, __shfl_xor(v, dlt, KN_WAVE));
+        }
+        if (lane_id() == 0) {
+            atomicMax(&s_max[m], __float_as_uint(v)); // (a NaN query is caught by the finite test below)
+        }
+    }
+    __syncthreads();
+    if (c == 0) {
+        float B = 0.f, q1 = 0.f;
+        bool fits = true;
+        for (int m = 0; m < PD_M; m++) {
+            B += __uint_as_float(s_max[m]);
+        }
+        for (int i = 0; i < PD_D; i++) {
+            q1 += fabsf(s_q[i]);
+            fits = fits && fabsf(s_q[i]) * sc_q < 65504.0f; // (false for NaN / inf too)
+        }
+        B *= 1.0001f; // (its own fp32 summation)
+        q1 *= 1.0001f;
+        float eps = INFINITY;
+        if (fits && B < INFINITY) {
+            const float F = IS_L2 ? 2.0f : 1.0f;
+            const float e_prod = (2.0f * PD_UH + PD_UH * PD_UH) * B;
+            const float e_sub = PD_A * (1.0f + PD_UH) * (ysum * inv_q + q1 * inv_y) + 128.0f * PD_A * PD_A * inv_sc;
+            const float e_acc = 136.0f * PD_U * ((1.0f + 3.0f * PD_UH) * B + 0.5f * pabs_max);
+            eps = (F * (e_prod + e_sub + e_acc) + 128.0f * PD_U * (pabs_max + F * B)) * 1.001f;
+        }
+        qd[q * 4 + 0] = q1;
+        qd[q * 4 + 1] = B;
+        qd[q * 4 + 2] = eps;
+        qd[q * 4 + 3] = 2.0f * B;
+    }
+}
+
+hipError_t launch_pqd_query_prep(const float* queries, const float4* cb, const float* cst, int64_t nq, bool is_l2,
+                                 float pabs_max, void* qh16, float* qd, hipStream_t s) {
+    if (nq <= 0) {
+        return hipSuccess;
+    }
+    if (is_l2) {
+        hipLaunchKernelGGL(pqd_query_prep_kernel<true>, dim3((unsigned)nq), dim3(PD_KSUB), 0, s, queries, cb, cst, pabs_max,
+                           static_cast<_Float16*>(qh16), qd);
+    } else {
+        hipLaunchKernelGGL(pqd_query_prep_kernel<false>, dim3((unsigned)nq), dim3(PD_KSUB), 0, s, queries, cb, cst, 0.f,
+                           static_cast<_Float16*>(qh16), qd);
+    }
+    return hipGetLastError();
+}
+
+// ---- the scan ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float pd_max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
+// largest of the 16 accumulator values of a lane (v_max3_f32 chains)
+__device__ __forceinline__ float pd_max16(const pd_f16& v) {
+    const float a = pd_max3(v[0], v[1], v[2]), b = pd_max3(v[3], v[4], v[5]), c = pd_max3(v[6], v[7], v[8]);
+    const float d = pd_max3(v[9], v[10], v[11]), e = pd_max3(v[12], v[13], v[14]);
+    return fmaxf(pd_max3(a, b, c), pd_max3(d, e, v[15]));
+}
+
+struct PdUnit {
+    int64_t len;      // rows of the list
+    int64_t row_off;  // first row of the list in the canonical arrays (codes, ids)
+    int64_t ps_off;   // first entry of the list in psum_s
+    int ntile;        // ceil(len / 32)
+};
+
+// One unit with NTQ query tiles.  Every wave walks the 32-row tiles wave, wave + 4, ...  While tile t is multiplied (step
+// s = 16 dimensions: NTQ matrix instructions on NTQ different accumulators), step s of tile t + 4 is decoded into the operand
+// registers step s just released (its codes arrived three tiles ago).  Two tiles per trip of the loop so that the start-value
+// registers rotate statically.
+template <bool IS_L2, int NTQ>
+__device__ __forceinline__ void pqd_scan(const MScanArgs& a, unsigned char* smem, const PdUnit& un) {
+    const int lane = lane_id();
+    const int wave = threadIdx.x / KN_WAVE;
+    const int lr = lane & 31, hi = lane >> 5;
+    const float* sT = reinterpret_cast<const float*>(smem + PD_OFF_T);
+    const int32_t* sPq = reinterpret_cast<const int32_t*>(smem + PD_OFF_Q);
+    uint4* sHit = reinterpret_cast<uint4*>(smem + PD_OFF_HIT);
+    int32_t* ctl = reinterpret_cast<int32_t*>(smem + PD_OFF_CTL);
+    const int ntile = un.ntile;
+    if (wave >= ntile) {
+        return;
+    }
+
+    // the unit's queries: lane (n, h) holds query n's dimensions 64 h .. 64 h + 64 of every tile (8 steps x 8 halves)
+    pd_h8 B[NTQ][8];
+    float thr[NTQ];
+    const uint4* qh = reinterpret_cast<const uint4*>(a.pq_qh16);
+#pragma unroll
+    for (int qt = 0; qt < NTQ; qt++) {
+        const int32_t q = sPq[qt * 32 + lr];
+        thr[qt] = sT[qt * 32 + lr];
+        const uint4* src = qh + ((int64_t)(q < 0 ? 0 : q) * (PD_D / 8) + hi * 8);
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            const uint4 w = src[s];
+            B[qt][s] = __builtin_bit_cast(pd_h8, w);
+        }
+    }
+    const uint4* codes = reinterpret_cast<const uint4*>(a.pq_codes) + un.row_off * 2;
+    const int64_t last_row = un.len - 1;
+    auto load_codes = [&](int t) -> uint4 { // tile t's 16 code bytes of this lane (a tile past the list re-reads the last row)
+        const int64_t row = min((int64_t)min(t, ntile - 1) * 32 + lr, last_row);
+        return codes[row * 2 + hi];
+    };
+    const float4* ps4 = reinterpret_cast<const float4*>(a.pq_psum_s + un.ps_off);
+    auto load_init = [&](int t, pd_f16& v) { // the tile's start values: rows 8 j + 4 h .. + 4 (the padding behind a list exists)
+        if (IS_L2) {
+            const int tt = min(t, ntile - 1);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float4 p = ps4[tt * 8 + 2 * j + hi];
+                v[4 * j + 0] = p.x;
+                v[4 * j + 1] = p.y;
+                v[4 * j + 2] = p.z;
+                v[4 * j + 3] = p.w;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                v[r] = 0.f;
+            }
+        }
+    };
+    const uint32_t hbase = (uint32_t)hi * (16u * PD_KSUB * 8u);
+    // step s of a tile's operand: the entries of sub-quantizers 16 h + 2 s, + 1 = bytes 2 s, 2 s + 1 of the lane's codes
+    auto decode_step = [&](const uint4& w, int s, pd_h8& A) {
+        const uint32_t ww = s < 2 ? w.x : s < 4 ? w.y : s < 6 ? w.z : w.w;
+        const uint32_t c0 = (ww >> (16 * (s & 1))) & 0xffu, c1 = (ww >> (16 * (s & 1) + 8)) & 0xffu;
+        const uint2 e0 = *reinterpret_cast<const uint2*>(smem + (hbase + (uint32_t)(2 * s) * (PD_KSUB * 8u) + c0 * 8u));
+        const uint2 e1 = *reinterpret_cast<const uint2*>(smem + (hbase + (uint32_t)(2 * s + 1) * (PD_KSUB * 8u) + c1 * 8u));
+        const uint4 both = make_uint4(e0.x, e0.y, e1.x, e1.y);
+        A = __builtin_bit_cast(pd_h8, both);
+    };
+    // whoever passes is parked (pair, position, accumulator) and appended at the unit's end
+    auto park = [&](const pd_f16& acc, int qt, int t) {
+        float thq = thr[qt];
+        asm volatile("" : "+v"(thq)); // (the slow path's compares stay in the slow path)
+        uint32_t hits = 0;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            hits |= acc[r] >= thq ? (1u << r) : 0u;
+        }
+        while (hits != 0u) {
+            const int r = __ffs((int)hits) - 1;
+            hits &= hits - 1u;
+            float v = acc[0];
+#pragma unroll
+            for (int r2 = 1; r2 < 16; r2++) {
+                v = r == r2 ? acc[r2] : v;
+            }
+            const int64_t pos = (int64_t)t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (pos < un.len) {
+                const int at = atomicAdd(&ctl[0], 1);
+                if (at < PD_HITS) {
+                    sHit[at] = make_uint4((uint32_t)(qt * 32 + lr), (uint32_t)pos, __float_as_uint(v), 0u);
+                } else {
+                    const float c = reinterpret_cast<const float*>(smem + PD_OFF_C)[qt * 32 + lr];
+                    const float x = v * a.pq_sc[7];
+                    ms_emit<IS_L2>(a, sPq[qt * 32 + lr], reinterpret_cast<const int32_t*>(smem + PD_OFF_S)[qt * 32 + lr],
+                                   un.row_off, pos, IS_L2 ? c - 2.0f * x : c + x);
+                }
+            }
+        }
+    };
+    // one maximum per lane and query tile, one ballot; the slow path only where something passes
+    auto compare = [&](const pd_f16& acc, int qt, int t) {
+        if (__ballot(pd_max16(acc) >= thr[qt]) != 0ull) {
+            park(acc, qt, t);
+        }
+    };
+
+    pd_h8 A[8];
+    pd_f16 acc[NTQ], init0, init1;
+    // at the top of a tile: A = that tile decoded, W1 = the codes of the next tile (decoded meanwhile), W2, W3 in flight
+    uint4 W1, W2, W3;
+    {
+        const uint4 w0 = load_codes(wave);
+        W1 = load_codes(wave + PD_WAVES);
+        W2 = load_codes(wave + 2 * PD_WAVES);
+        W3 = load_codes(wave + 3 * PD_WAVES);
+        load_init(wave, init0);
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            decode_step(w0, s, A[s]);
+        }
+    }
+    // tile t: acc <- initC + A x B, step by step (NTQ matrix instructions on NTQ different accumulators per step); the
+    // operand registers of a step are refilled with tile t + 4's as soon as the step's instructions have been issued.  The
+    // accumulators of the PREVIOUS tile tp are compared one query tile at a time right before step 0 overwrites them: the
+    // compare of query tile qt + 1 runs while step 0 of query tile qt is in the matrix pipe
+    auto tile = [&](const pd_f16& initC, pd_f16& initN, int t, int tp, bool first) {
+        const uint4 wfar = load_codes(t + 4 * PD_WAVES);
+        load_init(t + PD_WAVES, initN);
+#pragma unroll
+        for (int qt = 0; qt < NTQ; qt++) {
+            if (!first) {
+                compare(acc[qt], qt, tp);
+            }
+            acc[qt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], B[qt][0], initC, 0, 0, 0);
+        }
+        decode_step(W1, 0, A[0]);
+#pragma unroll
+        for (int s = 1; s < 8; s++) {
+#pragma unroll
+            for (int qt = 0; qt < NTQ; qt++) {
+                acc[qt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s], B[qt][s], acc[qt], 0, 0, 0);
+            }
+            decode_step(W1, s, A[s]);
+        }
+        W1 = W2;
+        W2 = W3;
+        W3 = wfar;
+    };
+    int t = wave, tl = wave;
+    tile(init0, init1, t, 0, true);
+    for (t += PD_WAVES; t < ntile; t += 2 * PD_WAVES) {
+        tile(init1, init0, t, t - PD_WAVES, false);
+        tl = t;
+        if (t + PD_WAVES < ntile) {
+            tile(init0, init1, t + PD_WAVES, t, false);
+            tl = t + PD_WAVES;
+        } else {
+            break;
+        }
+    }
+#pragma unroll
+    for (int qt = 0; qt < NTQ; qt++) {
+        compare(acc[qt], qt, tl);
+    }
+}
+
+// Persistent: one workgroup per CU keeps the codebook in LDS and pulls units in list order from its XCD's counter (the
+// units of one list run on one XCD, close in time: the second one finds the codes in that L2); LOOP: a fixed grid walks a
+// unit table whose size only the device knows (the retry round's one-query units).
+template <bool IS_L2, bool LOOP>
+__global__ __launch_bounds__(PD_THREADS, 1) void pqd_kernel(MScanArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    float* sT = reinterpret_cast<float*>(smem + PD_OFF_T);
+    float* sC = reinterpret_cast<float*>(smem + PD_OFF_C);
+    int32_t* sPq = reinterpret_cast<int32_t*>(smem + PD_OFF_Q);
+    int32_t* sPs = reinterpret_cast<int32_t*>(smem + PD_OFF_S);
+    const uint4* sHit = reinterpret_cast<const uint4*>(smem + PD_OFF_HIT);
+    int32_t* ctl = reinterpret_cast<int32_t*>(smem + PD_OFF_CTL);
+    const int nunits = (int)*a.nunits_dev;
+    if (nunits <= 0) {
+        return;
+    }
+    // unit source
+    const int per = (nunits + 7) / 8;
+    uint32_t xcc = 0;
+    if (!LOOP) {
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    }
+    const int xcd = (int)(xcc & 7u);
+    int fetch_t = 0;  // thread 0: counters [xcd, xcd + fetch_t) are known to be exhausted
+    int loop_u = (int)blockIdx.x;
+    auto fetch = [&]() -> int { // (thread 0 only)
+        if (LOOP) {
+            const int u = loop_u;
+            loop_u += (int)gridDim.x;
+            return u < nunits ? u : -1;
+        }
+        while (fetch_t < 8) {
+            const int x = (xcd + fetch_t) & 7;
+            const int base = x * per;
+            const int cnt = min(per, nunits - base);
+            if (cnt > 0) {
+                const int i = atomicAdd(a.pq_ctr + x * 16, 1);
+                if (i < cnt) {
+                    return base + i;
+                }
+            }
+            fetch_t++;
+        }
+        return -1;
+    };
+    if (threadIdx.x == 0) {
+        ctl[0] = 0;
+        ctl[1] = fetch();
+    }
+    // the codebook: 64 KB, once per workgroup
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(a.pq_cb16);
+        uint4* dst = reinterpret_cast<uint4*>(smem);
+#pragma unroll 4
+        for (int i = threadIdx.x; i < PD_CB_BYTES / 16; i += PD_THREADS) {
+            dst[i] = src[i];
+        }
+    }
+    __syncthreads();
+    const float SC = a.pq_sc[6], inv_sc = a.pq_sc[7];
+    int cur = ctl[1];
+    while (cur >= 0) {
+        const KnItem it = a.units[cur];
+        const int npair = it.npair;
+        const int ntq = (npair + 31) >> 5; // query tiles in use (uniform)
+        PdUnit un;
+        un.len = a.list_len[it.list];
+        un.row_off = a.list_row_off[it.list];
+        un.ps_off = IS_L2 ? a.pq_sblk_off_r[it.list] * 16 : 0;
+        un.ntile = (int)((un.len + 31) >> 5);
+        if (threadIdx.x == 0) {
+            ctl[2] = fetch(); // the next unit: its index is here when this one ends
+        }
+        // thread per pair: record, tau (sample bound, tightened by the candidate histogram), threshold in accumulator units
+        if (threadIdx.x < 32 * ntq) {
+            const int j = threadIdx.x;
+            float t = INFINITY, c = 0.f;
+            int32_t q = -1, slot = 0;
+            if (j < npair) {
+                const KnPair p = a.pairs[it.pair0 + j];
+                q = p.q;
+                slot = p.slot;
+                const float dis0 = a.coarse_dis[(int64_t)q * a.nslot + slot];
+                float tau = a.gthr[q];
+                tau = tighter<IS_L2>(tau, ms_hist_bound_lane<IS_L2>(a, q, a.k));
+                const float eps = a.pq_qd[(int64_t)q * 4 + 2] + 64.0f * PD_U * (fabsf(dis0) + fabsf(tau));
+                if (tau == worst_dist<IS_L2>() || !(eps < INFINITY)) {
+                    // no bound (fewer than k unfiltered rows in the sample) or a query the half operands cannot hold: nothing
+                    // passes here, the query goes through the exact kernels
+                    a.overflow[q] = 1;
+                    a.overflow[a.nq] = 1;
+                } else {
+                    // L2: dis0 + psum - 2 dot <= tau + eps  <=>  dot - psum / 2 >= (dis0 - tau - eps) / 2
+                    // IP: dis0 + dot >= tau - eps            <=>  dot >= tau - eps - dis0
+                    t = IS_L2 ? SC * (((dis0 - tau) - eps) * 0.5f) : SC * ((tau - eps) - dis0);
+                    c = IS_L2 ? dis0 + eps : dis0 - eps;
+                }
+            }
+            sT[j] = t;
+            sC[j] = c;
+            sPq[j] = q;
+            sPs[j] = slot;
+        }
+        __syncthreads();
+        if (un.ntile > 0) {
+            switch (ntq) {
+                case 1: pqd_scan<IS_L2, 1>(a, smem, un); break;
+                case 2: pqd_scan<IS_L2, 2>(a, smem, un); break;
+                case 3: pqd_scan<IS_L2, 3>(a, smem, un); break;
+                default: pqd_scan<IS_L2, 4>(a, smem, un); break;
+            }
+        }
+        __syncthreads();
+        // the parked hits: one record per thread, their global atomics in flight together
+        const int nhit = min(ctl[0], PD_HITS);
+        for (int i = threadIdx.x; i < nhit; i += PD_THREADS) {
+            const uint4 h = sHit[i];
+            const float x = __uint_as_float(h.z) * inv_sc, c = sC[h.x];
+            ms_emit<IS_L2>(a, sPq[h.x], sPs[h.x], un.row_off, (int64_t)h.y, IS_L2 ? c - 2.0f * x : c + x);
+        }
+        cur = ctl[2];
+        __syncthreads(); // (everybody has read the next unit and the parked hits)
+        if (threadIdx.x == 0) {
+            ctl[0] = 0;
+        }
+    }
+}
+
+// filter pass only (no sample mode: pq_sample_kernel samples per query); the units must have been cut for PD_QT queries
+hipError_t launch_pqd(const MScanArgs& a, bool is_l2, int64_t units_bound, hipStream_t s) {
+    if (units_bound <= 0) {
+        return hipSuccess;
+    }
+    if (a.dump != nullptr || a.pq_cb16 == nullptr || a.pq_qh16 == nullptr || a.pq_qd == nullptr || a.pq_sc == nullptr ||
+        a.pq_codes == nullptr || a.pq_ctr == nullptr || (is_l2 && (a.pq_psum_s == nullptr || a.pq_sblk_off_r == nullptr))) {
+        return hipErrorInvalidValue;
+    }
+    int dev = 0, ncu = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (ncu <= 0) {
+        ncu = 256;
+    }
+    auto kern = a.unit_loop ? (is_l2 ? pqd_kernel<true, true> : pqd_kernel<false, true>)
+                            : (is_l2 ? pqd_kernel<true, false> : pqd_kernel<false, false>);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)PD_SMEM);
+    if (e != hipSuccess) {
+        return e;
+    }
+    if (!a.unit_loop) {
+        e = hipMemsetAsync(a.pq_ctr, 0, 8 * 16 * sizeof(int32_t), s);
+        if (e != hipSuccess) {
+            return e;
+        }
+    }
+    const int64_t grid = std::min<int64_t>(units_bound, ncu);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(PD_THREADS), PD_SMEM, s, a);
+    return hipGetLastError();
+}
+
+} // namespace knhip

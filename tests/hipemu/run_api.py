@@ -42,11 +42,37 @@ def main():
             p = g.profile_get()
             same(Do, Io, D, I, f"{case} k={k} nprobe={nprobe}")
             assert p["mscan_queries"] == nq and p["mscan_overflow_queries"] == 0, p
+            want = {"h": 1, "i": 2, "d": 3}.get(os.environ.get("KNHIP_PQF_FORM", " ")[0])
+            assert want is None or p["pq_filter_form"] == want, (p["pq_filter_form"], want)
+            # (a wrong operand layout or scale would flood the candidate lists -- or pass nothing and fail above)
+            assert p["mscan_candidates"] < 60 * nq, p
+            print(f"  form {p['pq_filter_form']} k={k} nprobe={nprobe}: {p['mscan_candidates'] / nq:.1f} candidates per query")
         bs = np.packbits(np.random.default_rng(3).random(nb) < 0.4, bitorder="little")
         Do, Io = port.search(ix, xq, 10, 3, bs, nb)
         D, I = g.search(xq, 10, 3, bs, nb)
         same(Do, Io, D, I, f"{case} bitset")
         g.close()
+    elif case == "pqd_wide":
+        # the decode form's wide units: 130 queries on 3 lists = one unit of 128 pairs (four query tiles) + one of 2 per
+        # list, tiles per wave odd and even (lists of ~600 rows: 19 tiles, the last one ragged); 70 queries: three tiles
+        assert os.environ.get("KNHIP_PQF") == "1" and os.environ.get("KNHIP_PQF_FORM", "")[:1] == "d"
+        nb, d, nlist = 1800, 128, 3
+        xb = gen_data(nb, d, 42)
+        for metric, nq in ((ob.L2, 130), (ob.IP, 70)):
+            xq = gen_data(nq, d, 44)
+            ix = ob.make_index(port, ob.IVF_PQ, metric, xb, nlist=nlist, M=32)
+            g = GpuIndex.from_data(ix, device=0)
+            g.profile_enable(True)
+            g.profile_reset()
+            bs = np.packbits(np.random.default_rng(3).random(nb) < 0.3, bitorder="little")
+            Do, Io = port.search(ix, xq, 10, nlist, bs, nb)
+            D, I = g.search(xq, 10, nlist, bs, nb)
+            p = g.profile_get()
+            same(Do, Io, D, I, f"{case} metric={metric} nq={nq}")
+            assert p["pq_filter_form"] == 3 and p["mscan_queries"] == nq and p["mscan_overflow_queries"] == 0, p
+            assert p["mscan_candidates"] < 80 * nq, p
+            print(f"  metric {metric} nq={nq}: {p['mscan_candidates'] / nq:.1f} candidates per query")
+            g.close()
     elif case in ("ms_flat_l2", "ms_sq8_ip", "ms_sq8_l2", "ms_flat_ip"):
         # the MFMA paths (hardware-validated) under the matrix-core emulation: coarse GEMM prefilter + re-rank +
         # certificate, fp32 / f16 list prefilter + exact finish -- a regression net for changes made without a GPU

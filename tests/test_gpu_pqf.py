@@ -1,5 +1,5 @@
 """GPU parity tests (-m gpu) of the matrix-core ADC prefilter + exact finish of the IVF-PQ scan
-(knowhere_amd/csrc/pq_filter.hip): the prefilter path (KNHIP_PQF=1: whenever the shape allows), the exact kernels
+(knowhere_amd/csrc/pq_filter.hip, pq_decode.hip): the prefilter path (KNHIP_PQF=1: whenever the shape allows), the exact kernels
 (KNHIP_PQF=0) and the oracle must agree bit for bit -- distances AND ids."""
 import os
 
@@ -33,10 +33,11 @@ def _bitset(n, frac, seed):
 FORM = {"v": "half"}  # the filter form the module's tests run with (fixture below)
 
 
-@pytest.fixture(autouse=True, params=["half", "int8"])
+@pytest.fixture(autouse=True, params=["half", "int8", "decode"])
 def form(request):
     """KNHIP_PQF_FORM: half = half-precision tables, 8 queries per unit (v_mfma_f32_16x16x32_f16); int8 = integer tables,
-    16 queries per unit (v_mfma_i32_16x16x64_i8).  Both must return the exact kernels' and the oracle's bits."""
+    16 queries per unit (v_mfma_i32_16x16x64_i8); decode = rows decoded once per (list, <= 128 queries), dense half-precision
+    contraction (pq_decode.hip, v_mfma_f32_32x32x16_f16).  All must return the exact kernels' and the oracle's bits."""
     FORM["v"] = request.param
     return request.param
 

@@ -33,7 +33,7 @@ def _bitset(n, frac, seed):
 def _forms(monkeypatch, make):
     """the same lists behind the two forms of the filter (the switches are read when the lists are attached)"""
     out = {}
-    for form in ("int8", "half"):
+    for form in ("decode", "int8", "half"):
         monkeypatch.setenv("KNHIP_PQF", "1")
         monkeypatch.setenv("KNHIP_PQF_FORM", form)
         monkeypatch.setenv("KNHIP_PQF_GUARD", "0")
@@ -80,7 +80,7 @@ def test_ivfpq_10m_prefilter_equals_the_reference_build(torch_cuda, monkeypatch)
                 g.profile_reset()
                 D, I = g.search(xq[:nq], k, nprobe, b, nbits)
                 p = g.profile_get()
-                assert p["pq_filter_form"] == (2 if form == "int8" else 1), (form, p["pq_filter_form"])
+                assert p["pq_filter_form"] == {"half": 1, "int8": 2, "decode": 3}[form], (form, p["pq_filter_form"])
                 assert p["mscan_queries"] + p["mscan_overflow_queries"] == nq
                 assert p["tie_anomalies"] == 0
                 assert_parity(Do, Io, D, I, ob.L2, f"10M IVF-PQ, {form} form, k={k}, bitset={b is not None}")

@@ -236,7 +236,7 @@ def _run_api_case(case, **env):
 
 
 @pytest.mark.timeout(1800)
-@pytest.mark.parametrize("form", ["half", "int8"])
+@pytest.mark.parametrize("form", ["half", "int8", "decode"])
 @pytest.mark.parametrize("case", ["pqf_l2", pytest.param("pqf_ip", marks=pytest.mark.skipif(
     os.environ.get("KNHIP_TEST_EMU_FULL") != "1", reason="KNHIP_TEST_EMU_FULL=1"))])
 def test_emulated_api_ivfpq_prefilter(case, form):
