@@ -63,7 +63,7 @@ extern "C" {
  * indexes (knhip_search_canonical_device, knhip_tie_*, knhip_refine_distances / _combine / _select).
  * 8: the refine stores sq6 / int8 / sq4u (KNHIP_ROWS_SQ6 / _INT8 / _SQ4U) and knhip_rows_train_uniform.
  * 9: knhip_ties_rule_applies (one place decides whether a search follows the reference's boundary rule: single index, shard
- * group and the torch.distributed host agree); pq_filter_form 3 in knhip_stage_times (the decode form of the IVF-PQ prefilter).
+ * group and the torch.distributed host agree); value 3 of the profile field pq_filter_form: the decode form of the IVF-PQ prefilter.
  * Callers compare knhip_abi_version() with the header they were built against. */
 #define KNHIP_ABI_VERSION 9
 
@@ -513,7 +513,7 @@ typedef struct knhip_stage_times {
     int64_t mscan_candidates;
     double mscan_stream_bytes; /* bytes the prefilter streams: sum over its units of len(list) * code_size */
     int64_t mscan_recomputed;  /* candidates that got an exact distance (IVF_PQ: after the finish kernel's pruning) */
-    int64_t pq_filter_form;    /* IVF_PQ prefilter of the last search: 0 none (exact kernels), 1 half precision, 2 int8 */
+    int64_t pq_filter_form;    /* IVF_PQ prefilter of the last search: 0 none (exact kernels), 1 half precision, 2 int8, 3 decode form */
     int64_t tie_queries;       /* queries with candidates tied at their k-th distance beyond the k-th place, resolved by the
                                   reference's first-come admission rule (scan order) instead of the canonical order */
     int64_t tie_anomalies;     /* ... of those, rows the resolution left at their canonical copy because its dump pass found

@@ -18,7 +18,7 @@ def _lib():
 
 def test_library_built_and_loads():
     L = _lib().load()
-    assert L.knhip_abi_version() == 8
+    assert L.knhip_abi_version() == _lib().ABI_VERSION == 9
 
 
 def test_exports_match_header():
