@@ -271,6 +271,10 @@ struct MScanArgs {
     const float* pq_qd;            // [nq][4] = {||q||_1, B_q, eps_base, 2 B_q}
     const float* pq_sc;            // [8] = {sc_y, 1 / sc_y, max |cb|, Ysum, sc_q, 1 / sc_q, SC, 1 / SC}: the index's scales (device)
     const float* pq_psum_s;        // -psum SC / 2 per stream position (same offsets as pq_psum): the accumulators' start values
+    unsigned char* pq_spill;       // [pq_spill_wgs][pq_spill_cap] records of 80 bytes: where a workgroup parks passing lanes once its
+    int32_t pq_spill_cap;          // LDS regions are full (a unit that is hot for many of its queries at once)
+    int32_t pq_spill_wgs;          // workgroups the buffer serves (the launch takes no more)
+    int32_t pq_dbg;                // tools/prof build only (KNHIP_PHASE_TIMERS): experiment switches of pqd_kernel, else 0
 };
 
 // ---- pq_filter.hip ----

@@ -138,7 +138,7 @@ struct Workspace {
     DevBuf ms_qh, ms_ql, ms_qs;                                      // SQ8 IP: prepared query operands (halves) + sums
                                                                      // (IVF-PQ prefilter: ms_qh = half tables, ms_qs = scales)
     DevBuf pq_recs, pq_ctr;                                          // pq_filter.hip: unit records, per-XCD counters
-    DevBuf ms_qh16, ms_qd;                                           // pq_decode.hip: the queries as halves, their error records
+    DevBuf ms_qh16, ms_qd, pq_spill;                                 // pq_decode.hip: the queries as halves, their error records, parked lanes beyond LDS
     DevBuf rs_sort;                                                  // row selection of more than 16384 keys: sort scratch
     // host-boundary staging
     DevBuf h_queries, h_bitset, h_out_d, h_out_i, h_ref_d, h_ref_i;
@@ -1378,6 +1378,21 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
                     m.pq_qd = ws->ms_qd.as<float>();
                     m.pq_sc = idx->pqd_st.as<float>();
                     m.pq_psum_s = idx->psum_s.as<float>();
+                    // where a workgroup parks passing lanes beyond its LDS (8192 records of 80 bytes per workgroup, 168 MB: a list that is the closest list of many queries of the batch at once passes thousands of rows -- C3: up to 3300 in one unit, 5 % of the units leave the LDS regions)
+                    m.pq_spill_cap = 8192;
+                    m.pq_spill_wgs = 512;
+                    {
+                        int dev = 0, ncu = 0;
+                        (void)hipGetDevice(&dev);
+                        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0) {
+                            m.pq_spill_wgs = ncu;
+                        }
+                    }
+                    HIP_TRY(ws->pq_spill.reserve((size_t)m.pq_spill_wgs * m.pq_spill_cap * 80));
+                    m.pq_spill = static_cast<unsigned char*>(ws->pq_spill.p);
+                    if (const char* e = getenv("KNHIP_PQD_DBG")) { // (read by the tools/prof build of the kernel only)
+                        m.pq_dbg = atoi(e);
+                    }
                 }
             }
         }

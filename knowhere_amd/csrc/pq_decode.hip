@@ -45,6 +45,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 
 namespace knhip {
 
@@ -54,21 +55,50 @@ constexpr int PD_D = 128;
 constexpr int PD_WAVES = 4;
 constexpr int PD_THREADS = PD_WAVES * KN_WAVE;
 constexpr int PD_CB_BYTES = PD_M * PD_KSUB * 8;     // 65536: [m][c][4 halves]
-constexpr int PD_HITS = 1024;                       // parked hits per unit (16 KB; more are appended on the spot)
+constexpr int PD_RING = 4;                          // tiles the loads run ahead of the decode (which runs one tile ahead)
+constexpr int PD_REC_BYTES = 80;                    // a parked lane: {pair, first row, -, -} + its 16 accumulator values
+constexpr int PD_REC_CAP = 128;                     // records per wave and unit in the wave's own region ...
+constexpr int PD_SPILL_CAP = 320;                   // ... then in a region all waves share (claimed by an LDS atomic); beyond:
+                                                    // the query's overflow route
+constexpr int PD_FLAT_CAP = 1024;                   // passing rows of a unit, sorted out of the records at its end
 constexpr int PD_OFF_T = PD_CB_BYTES;               // float  [128] accumulator threshold of the pair (scaled)
 constexpr int PD_OFF_C = PD_OFF_T + PD_QT * 4;      // float  [128] dis0 +- eps
 constexpr int PD_OFF_Q = PD_OFF_C + PD_QT * 4;      // int32  [128] query of the pair (-1: none)
 constexpr int PD_OFF_S = PD_OFF_Q + PD_QT * 4;      // int32  [128] slot of the pair
-constexpr int PD_OFF_HIT = PD_OFF_S + PD_QT * 4;    // uint4  [PD_HITS] {pair, position, accumulator bits, -}
-constexpr int PD_OFF_CTL = PD_OFF_HIT + PD_HITS * 16; // int32 [16]: 0 = parked hits, 1 = current unit, 2 = next unit
+constexpr int PD_OFF_REC = PD_OFF_S + PD_QT * 4;    // [PD_WAVES][PD_REC_CAP] parked records, a private region per wave
+constexpr int PD_OFF_SPILL = PD_OFF_REC + PD_WAVES * PD_REC_CAP * PD_REC_BYTES; // [PD_SPILL_CAP] shared records
+constexpr int PD_OFF_FLAT = PD_OFF_SPILL + PD_SPILL_CAP * PD_REC_BYTES;         // uint4 [PD_FLAT_CAP] {pair, row, value bits, -}
+constexpr int PD_OFF_CTL = PD_OFF_FLAT + PD_FLAT_CAP * 16; // int32 [16]: 1 = current unit, 2 = next unit, 4 + w = records of
+                                                           // wave w, 8 = shared records, 9 = passing rows, 10 = records in global memory
 constexpr int PD_SMEM = PD_OFF_CTL + 64;
 static_assert(PD_SMEM <= 160 * 1024, "LDS of one workgroup");
 constexpr float PD_U = 5.9604645e-8f;   // 2^-24
 constexpr float PD_UH = 4.8828125e-4f;  // 2^-11
 constexpr float PD_A = 6.103515625e-5f; // 2^-14: the smallest normal half
 
+#ifdef KNHIP_PHASE_TIMERS
+// tools/prof build only: shader-clock ticks per phase, summed per wave over the launch (printed by launch_pqd)
+#define PD_T(i)                                                         \
+    do {                                                                \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();     \
+        tacc[i] += t_ - tlast;                                          \
+        tlast = t_;                                                     \
+    } while (0)
+#define PD_COUNT(i, n) tacc[i] += (unsigned long long)(n)
+#define PD_TARG , unsigned long long (&tacc)[8], unsigned long long& tlast
+#define PD_TPASS , tacc, tlast
+__device__ unsigned long long g_pd_prof[4 * 8 + 8]; // + [32..]: high-water marks of the shared / global record regions and the flat list
+#else
+#define PD_T(i)
+#define PD_COUNT(i, n)
+#define PD_TARG
+#define PD_TPASS
+#endif
+
 typedef _Float16 pd_h8 __attribute__((ext_vector_type(8)));
 typedef float pd_f16 __attribute__((ext_vector_type(16)));
+typedef uint32_t pd_u4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t pd_rsrc;
 
 size_t pqd_smem() { return PD_SMEM; }
 
@@ -293,16 +323,20 @@ struct PdUnit {
 // registers step s just released (its codes arrived three tiles ago).  Two tiles per trip of the loop so that the start-value
 // registers rotate statically.
 template <bool IS_L2, int NTQ>
-__device__ __forceinline__ void pqd_scan(const MScanArgs& a, unsigned char* smem, const PdUnit& un) {
+__device__ __forceinline__ void pqd_scan(const MScanArgs& a, unsigned char* smem, const PdUnit& un PD_TARG) {
     const int lane = lane_id();
-    const int wave = threadIdx.x / KN_WAVE;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / KN_WAVE)); // (wave-uniform: tile arithmetic on the scalar unit)
     const int lr = lane & 31, hi = lane >> 5;
     const float* sT = reinterpret_cast<const float*>(smem + PD_OFF_T);
     const int32_t* sPq = reinterpret_cast<const int32_t*>(smem + PD_OFF_Q);
-    uint4* sHit = reinterpret_cast<uint4*>(smem + PD_OFF_HIT);
     int32_t* ctl = reinterpret_cast<int32_t*>(smem + PD_OFF_CTL);
+    unsigned char* rec = smem + PD_OFF_REC + wave * (PD_REC_CAP * PD_REC_BYTES);
     const int ntile = un.ntile;
+    int nrec = 0; // records this wave has parked (wave-uniform)
     if (wave >= ntile) {
+        if (lane == 0) {
+            ctl[4 + wave] = 0;
+        }
         return;
     }
 
@@ -321,31 +355,49 @@ __device__ __forceinline__ void pqd_scan(const MScanArgs& a, unsigned char* smem
             B[qt][s] = __builtin_bit_cast(pd_h8, w);
         }
     }
-    const uint4* codes = reinterpret_cast<const uint4*>(a.pq_codes) + un.row_off * 2;
-    const int64_t last_row = un.len - 1;
-    auto load_codes = [&](int t) -> uint4 { // tile t's 16 code bytes of this lane (a tile past the list re-reads the last row)
-        const int64_t row = min((int64_t)min(t, ntile - 1) * 32 + lr, last_row);
-        return codes[row * 2 + hi];
-    };
-    const float4* ps4 = reinterpret_cast<const float4*>(a.pq_psum_s + un.ps_off);
-    auto load_init = [&](int t, pd_f16& v) { // the tile's start values: rows 8 j + 4 h .. + 4 (the padding behind a list exists)
-        if (IS_L2) {
-            const int tt = min(t, ntile - 1);
+    // Everything loaded so far is waited for HERE: a value still in flight when the tile loop is entered makes the compiler
+    // wait for ALL outstanding loads (vmcnt(0) / lgkmcnt(0)) at its first use in every trip -- the loop-carried prefetches
+    // included (the first version stalled a full memory round trip per tile this way)
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const float4 p = ps4[tt * 8 + 2 * j + hi];
-                v[4 * j + 0] = p.x;
-                v[4 * j + 1] = p.y;
-                v[4 * j + 2] = p.z;
-                v[4 * j + 3] = p.w;
-            }
-        } else {
+    for (int qt = 0; qt < NTQ; qt++) {
+        float th = thr[qt];
+        asm volatile("" : "+v"(th));
+        thr[qt] = th;
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                v[r] = 0.f;
-            }
+        for (int s = 0; s < 8; s++) {
+            pd_h8 bq = B[qt][s];
+            asm volatile("" : "+v"(bq));
+            B[qt][s] = bq;
         }
+    }
+    // The list's codes and start values through buffer descriptors: the tile's offset rides in the scalar offset, the lane's
+    // part (row lr, half hi: 16 of the row's 32 code bytes) is a constant, and the hardware's bounds check returns zeros past
+    // the list's end (code 0: a valid table entry; those rows are never emitted) -- no address arithmetic on the vector unit,
+    // no clamps.  The start value of the tile's row `lr` is -psum SC / 2; both halves of the wave load it: the fp32 matrix
+    // instruction that spreads the values over the accumulator layout takes k = 0 from the lower half and multiplies the
+    // upper half's k = 1 by zero (finite values: no NaN from it).
+    // (every input of a descriptor through readfirstlane: the list's offsets came out of memory, and a descriptor the
+    // compiler cannot PROVE uniform is loaded through a waterfall loop per load)
+    auto uniform_ptr = [](const void* p) -> void* {
+        const uint64_t v = reinterpret_cast<uint64_t>(p);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+        const uint32_t hi2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+        return reinterpret_cast<void*>(((uint64_t)hi2 << 32) | lo);
     };
+    const int bytes_c = __builtin_amdgcn_readfirstlane((int)(un.len * PD_M));
+    const int bytes_p = __builtin_amdgcn_readfirstlane(IS_L2 ? un.ntile * 32 * 4 : 0);
+    const pd_rsrc rc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.pq_codes + un.row_off * PD_M), 0, bytes_c, 0x00020000);
+    const pd_rsrc rp = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(IS_L2 ? a.pq_psum_s + un.ps_off : a.pq_sc), 0, bytes_p,
+                                                        0x00020000);
+    const int voff_c = lr * PD_M + hi * 16, voff_p = lr * 4;
+    auto load_codes = [&](int t) -> uint4 { // tile t's 16 code bytes of this lane
+        const pd_u4 w = __builtin_amdgcn_raw_buffer_load_b128(rc, voff_c, t * (32 * PD_M), 0);
+        return make_uint4(w[0], w[1], w[2], w[3]);
+    };
+    auto load_start = [&](int t) -> float {
+        return IS_L2 ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, voff_p, t * (32 * 4), 0)) : 0.f;
+    };
+    const float one_lo = hi == 0 ? 1.0f : 0.f;
     const uint32_t hbase = (uint32_t)hi * (16u * PD_KSUB * 8u);
     // step s of a tile's operand: the entries of sub-quantizers 16 h + 2 s, + 1 = bytes 2 s, 2 s + 1 of the lane's codes
     auto decode_step = [&](const uint4& w, int s, pd_h8& A) {
@@ -356,102 +408,164 @@ __device__ __forceinline__ void pqd_scan(const MScanArgs& a, unsigned char* smem
         const uint4 both = make_uint4(e0.x, e0.y, e1.x, e1.y);
         A = __builtin_bit_cast(pd_h8, both);
     };
-    // whoever passes is parked (pair, position, accumulator) and appended at the unit's end
-    auto park = [&](const pd_f16& acc, int qt, int t) {
-        float thq = thr[qt];
-        asm volatile("" : "+v"(thq)); // (the slow path's compares stay in the slow path)
-        uint32_t hits = 0;
+#ifdef KNHIP_PHASE_TIMERS
+    const int dbg = a.pq_dbg; // 1: nothing ever passes; 2: no operand refill (no LDS gathers); 4: no loads in the loop
+#else
+    constexpr int dbg = 0;
+#endif
+    // One maximum per lane and query tile, one ballot.  A lane whose maximum passes PARKS its 16 accumulator values as they
+    // are (a record of 80 bytes in the wave's own LDS region: no atomic, no round trip -- the count is a wave-uniform
+    // register); which of the 16 rows passed is sorted out at the unit's end, one record per thread.  (The first version
+    // picked the passing values apart on the spot: 1300 cycles per entry with the matrix pipe idle, 0.6 entries per tile.)
+    auto compare = [&](const pd_f16& acc, int qt, int t) {
+        const bool p = pd_max16(acc) >= thr[qt];
+        const unsigned long long mask = __ballot(p);
+        if (__builtin_expect(mask != 0ull, 0) && !(dbg & 1)) {
+            PD_T(2);
+            const int my = nrec + __popcll(mask & ((1ull << lane) - 1ull));
+            nrec += __popcll(mask);
+            if (p) {
+                // (LDS and global memory are written through pointers of their OWN address space: a store through a pointer
+                // that may be either is a FLAT instruction, and with one of those possibly in flight the compiler waits for
+                // ALL outstanding loads and gathers -- vmcnt(0), lgkmcnt(0) -- at every join behind a compare: the first
+                // version of this path did that to every tile)
+                const uint4 hd = make_uint4((uint32_t)(qt * 32 + lr), (uint32_t)(t * 32 + 4 * hi), 0u, 0u);
+                int at = -1, at2 = -1;
+                if (my >= PD_REC_CAP) { // (rare: the wave's own region is full -> the shared one -> the workgroup's global one)
+                    at = atomicAdd(&ctl[8], 1);
+                    if (at >= PD_SPILL_CAP) {
+                        at2 = atomicAdd(&ctl[10], 1);
+                    }
+                }
+                if (at < PD_SPILL_CAP) {
+                    uint4* r = reinterpret_cast<uint4*>(at < 0 ? rec + my * PD_REC_BYTES : smem + PD_OFF_SPILL + at * PD_REC_BYTES);
+                    r[0] = hd;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            hits |= acc[r] >= thq ? (1u << r) : 0u;
-        }
-        while (hits != 0u) {
-            const int r = __ffs((int)hits) - 1;
-            hits &= hits - 1u;
-            float v = acc[0];
+                    for (int j = 0; j < 4; j++) {
+                        r[1 + j] = make_uint4(__float_as_uint(acc[4 * j]), __float_as_uint(acc[4 * j + 1]),
+                                              __float_as_uint(acc[4 * j + 2]), __float_as_uint(acc[4 * j + 3]));
+                    }
+                } else if (at2 < a.pq_spill_cap) {
+                    uint4* g = reinterpret_cast<uint4*>(a.pq_spill) + ((int64_t)blockIdx.x * a.pq_spill_cap + at2) * (PD_REC_BYTES / 16);
+                    g[0] = hd;
 #pragma unroll
-            for (int r2 = 1; r2 < 16; r2++) {
-                v = r == r2 ? acc[r2] : v;
-            }
-            const int64_t pos = (int64_t)t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            if (pos < un.len) {
-                const int at = atomicAdd(&ctl[0], 1);
-                if (at < PD_HITS) {
-                    sHit[at] = make_uint4((uint32_t)(qt * 32 + lr), (uint32_t)pos, __float_as_uint(v), 0u);
+                    for (int j = 0; j < 4; j++) {
+                        g[1 + j] = make_uint4(__float_as_uint(acc[4 * j]), __float_as_uint(acc[4 * j + 1]),
+                                              __float_as_uint(acc[4 * j + 2]), __float_as_uint(acc[4 * j + 3]));
+                    }
                 } else {
-                    const float c = reinterpret_cast<const float*>(smem + PD_OFF_C)[qt * 32 + lr];
-                    const float x = v * a.pq_sc[7];
-                    ms_emit<IS_L2>(a, sPq[qt * 32 + lr], reinterpret_cast<const int32_t*>(smem + PD_OFF_S)[qt * 32 + lr],
-                                   un.row_off, pos, IS_L2 ? c - 2.0f * x : c + x);
+                    // every region is full (thousands of parked lanes in one unit: a bound that lets a large part of the list
+                    // through): the query takes the overflow route of the candidate lists -- retried with the tighter bound
+                    // of what it has gathered, else the exact kernels.  Exactness never rests on a capacity.
+                    const int32_t q = sPq[qt * 32 + lr];
+                    a.overflow[q] = 1;
+                    a.overflow[a.nq] = 1;
                 }
             }
-        }
-    };
-    // one maximum per lane and query tile, one ballot; the slow path only where something passes
-    auto compare = [&](const pd_f16& acc, int qt, int t) {
-        if (__ballot(pd_max16(acc) >= thr[qt]) != 0ull) {
-            park(acc, qt, t);
+            PD_T(3);
+            PD_COUNT(7, 1);
         }
     };
 
+    // Loads run PD_RING tiles ahead in a ring of registers (4 code words + one start value per slot).  The ring turns by
+    // NAME, never by copying: a register copy waits for its source, i.e. for a load issued a moment ago -- the first
+    // version rotated three code registers by assignment and ran at the memory latency per tile (3200 cycles against 770
+    // of matrix work).  So the tile loop is unrolled PD_RING times with compile-time slot numbers.
     pd_h8 A[8];
-    pd_f16 acc[NTQ], init0, init1;
-    // at the top of a tile: A = that tile decoded, W1 = the codes of the next tile (decoded meanwhile), W2, W3 in flight
-    uint4 W1, W2, W3;
+    pd_f16 acc[NTQ], init;
+    uint4 W[PD_RING];
+    float P[PD_RING];
     {
         const uint4 w0 = load_codes(wave);
-        W1 = load_codes(wave + PD_WAVES);
-        W2 = load_codes(wave + 2 * PD_WAVES);
-        W3 = load_codes(wave + 3 * PD_WAVES);
-        load_init(wave, init0);
+        const float p0 = load_start(wave);
+#pragma unroll
+        for (int i = 0; i < PD_RING; i++) { // slot i <- tile (i + 1) of this wave
+            W[i] = load_codes(wave + (i + 1) * PD_WAVES);
+            P[i] = load_start(wave + (i + 1) * PD_WAVES);
+        }
 #pragma unroll
         for (int s = 0; s < 8; s++) {
             decode_step(w0, s, A[s]);
         }
+        pd_f16 z;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            z[r] = 0.f;
+        }
+        init = IS_L2 ? __builtin_amdgcn_mfma_f32_32x32x2f32(p0, one_lo, z, 0, 0, 0) : z;
     }
-    // tile t: acc <- initC + A x B, step by step (NTQ matrix instructions on NTQ different accumulators per step); the
-    // operand registers of a step are refilled with tile t + 4's as soon as the step's instructions have been issued.  The
-    // accumulators of the PREVIOUS tile tp are compared one query tile at a time right before step 0 overwrites them: the
-    // compare of query tile qt + 1 runs while step 0 of query tile qt is in the matrix pipe
-    auto tile = [&](const pd_f16& initC, pd_f16& initN, int t, int tp, bool first) {
-        const uint4 wfar = load_codes(t + 4 * PD_WAVES);
-        load_init(t + PD_WAVES, initN);
+    // tile t (SLOT = the ring slot that holds tile t + 4's codes and start value): acc <- init + A x B, step by step (NTQ
+    // matrix instructions on NTQ different accumulators per step); the operand registers of a step are refilled with tile
+    // t + 4's as soon as the step's instructions have been issued; at the end one fp32 matrix instruction spreads the next
+    // tile's start values over the accumulator layout (D[r][n] = P[r] * 1).  The accumulators of the PREVIOUS tile tp are
+    // compared one query tile at a time right before step 0 overwrites them: the compare of query tile qt + 1 runs while
+    // step 0 of query tile qt is in the matrix pipe.
+    auto tile = [&](uint4& Wslot, float& Pslot, int t, int tp, bool first) {
+        const uint4 wn = Wslot; // tile t + 4
+        const float pn = Pslot;
 #pragma unroll
         for (int qt = 0; qt < NTQ; qt++) {
             if (!first) {
                 compare(acc[qt], qt, tp);
             }
-            acc[qt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], B[qt][0], initC, 0, 0, 0);
+            acc[qt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], B[qt][0], init, 0, 0, 0);
         }
-        decode_step(W1, 0, A[0]);
+        if (!(dbg & 2)) {
+            decode_step(wn, 0, A[0]);
+        }
 #pragma unroll
         for (int s = 1; s < 8; s++) {
 #pragma unroll
             for (int qt = 0; qt < NTQ; qt++) {
                 acc[qt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[s], B[qt][s], acc[qt], 0, 0, 0);
             }
-            decode_step(W1, s, A[s]);
+            if (!(dbg & 2)) {
+                decode_step(wn, s, A[s]);
+            }
         }
-        W1 = W2;
-        W2 = W3;
-        W3 = wfar;
+        if (IS_L2) {
+            pd_f16 z;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                z[r] = 0.f;
+            }
+            // (`init` stays in ITS registers over the whole tile: without this the last matrix instruction of step 0 takes
+            // them over as its destination, the roles of the register sets rotate from tile to tile and the unrolled loop
+            // pays 32 register copies per tile to undo it)
+            asm volatile("" : "+v"(init));
+            init = __builtin_amdgcn_mfma_f32_32x32x2f32(pn, one_lo, z, 0, 0, 0);
+        }
+        // the slot is refilled only NOW, when its old content is dead: a load issued at the top of the tile needs a second
+        // register while the old content is still being decoded, and the copy back into the slot's register at the end of
+        // the tile waits for that very load (vmcnt(0): a memory round trip per tile)
+        if (!(dbg & 4)) {
+            Wslot = load_codes(t + (PD_RING + 1) * PD_WAVES);
+            Pslot = load_start(t + (PD_RING + 1) * PD_WAVES);
+        }
     };
     int t = wave, tl = wave;
-    tile(init0, init1, t, 0, true);
-    for (t += PD_WAVES; t < ntile; t += 2 * PD_WAVES) {
-        tile(init1, init0, t, t - PD_WAVES, false);
-        tl = t;
-        if (t + PD_WAVES < ntile) {
-            tile(init0, init1, t + PD_WAVES, t, false);
-            tl = t + PD_WAVES;
-        } else {
-            break;
+    bool first = true;
+    PD_T(1);
+    while (t < ntile) {
+#pragma unroll
+        for (int i = 0; i < PD_RING; i++) {
+            if (t < ntile) { // (wave-uniform)
+                tile(W[i], P[i], t, tl, first);
+                first = false;
+                tl = t;
+                t += PD_WAVES;
+                PD_COUNT(6, 1);
+            }
         }
     }
 #pragma unroll
     for (int qt = 0; qt < NTQ; qt++) {
         compare(acc[qt], qt, tl);
     }
+    if (lane == 0) {
+        ctl[4 + wave] = min(nrec, PD_REC_CAP);
+    }
+    PD_T(2);
 }
 
 // Persistent: one workgroup per CU keeps the codebook in LDS and pulls units in list order from its XCD's counter (the
@@ -459,12 +573,15 @@ __device__ __forceinline__ void pqd_scan(const MScanArgs& a, unsigned char* smem
 // unit table whose size only the device knows (the retry round's one-query units).
 template <bool IS_L2, bool LOOP>
 __global__ __launch_bounds__(PD_THREADS, 1) void pqd_kernel(MScanArgs a) {
+#ifdef KNHIP_PHASE_TIMERS
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_amdgcn_s_memtime();
+#endif
     extern __shared__ __align__(16) unsigned char smem[];
     float* sT = reinterpret_cast<float*>(smem + PD_OFF_T);
     float* sC = reinterpret_cast<float*>(smem + PD_OFF_C);
     int32_t* sPq = reinterpret_cast<int32_t*>(smem + PD_OFF_Q);
     int32_t* sPs = reinterpret_cast<int32_t*>(smem + PD_OFF_S);
-    const uint4* sHit = reinterpret_cast<const uint4*>(smem + PD_OFF_HIT);
     int32_t* ctl = reinterpret_cast<int32_t*>(smem + PD_OFF_CTL);
     const int nunits = (int)*a.nunits_dev;
     if (nunits <= 0) {
@@ -500,7 +617,6 @@ __global__ __launch_bounds__(PD_THREADS, 1) void pqd_kernel(MScanArgs a) {
         return -1;
     };
     if (threadIdx.x == 0) {
-        ctl[0] = 0;
         ctl[1] = fetch();
     }
     // the codebook: 64 KB, once per workgroup
@@ -526,6 +642,9 @@ __global__ __launch_bounds__(PD_THREADS, 1) void pqd_kernel(MScanArgs a) {
         un.ntile = (int)((un.len + 31) >> 5);
         if (threadIdx.x == 0) {
             ctl[2] = fetch(); // the next unit: its index is here when this one ends
+            ctl[8] = 0;
+            ctl[9] = 0;
+            ctl[10] = 0;
         }
         // thread per pair: record, tau (sample bound, tightened by the candidate histogram), threshold in accumulator units
         if (threadIdx.x < 32 * ntq) {
@@ -558,28 +677,97 @@ __global__ __launch_bounds__(PD_THREADS, 1) void pqd_kernel(MScanArgs a) {
             sPs[j] = slot;
         }
         __syncthreads();
+        PD_T(0);
         if (un.ntile > 0) {
             switch (ntq) {
-                case 1: pqd_scan<IS_L2, 1>(a, smem, un); break;
-                case 2: pqd_scan<IS_L2, 2>(a, smem, un); break;
-                case 3: pqd_scan<IS_L2, 3>(a, smem, un); break;
-                default: pqd_scan<IS_L2, 4>(a, smem, un); break;
+                case 1: pqd_scan<IS_L2, 1>(a, smem, un PD_TPASS); break;
+                case 2: pqd_scan<IS_L2, 2>(a, smem, un PD_TPASS); break;
+                case 3: pqd_scan<IS_L2, 3>(a, smem, un PD_TPASS); break;
+                default: pqd_scan<IS_L2, 4>(a, smem, un PD_TPASS); break;
+            }
+        }
+        PD_T(2);
+        __syncthreads();
+        PD_T(4);
+        // the parked lanes.  Phase A, one record per thread: which of its 16 rows pass -> a flat list in LDS (one LDS atomic
+        // per passing row).  Phase B, one passing row per thread: the appends (global atomics with a returned slot), all in
+        // flight together.  (Appending straight from the records made a wave walk the 16 rows with some lane appending at
+        // nearly every step: 16 global round trips one after the other, 59 k cycles per unit.)
+        uint4* flat = reinterpret_cast<uint4*>(smem + PD_OFF_FLAT);
+        for (int w = 0; w <= PD_WAVES + 1; w++) {
+            const int n = un.ntile <= 0 ? 0 : w < PD_WAVES ? ctl[4 + w] : w == PD_WAVES ? min(ctl[8], PD_SPILL_CAP)
+                                                                                     : min(ctl[10], a.pq_spill_cap);
+            const unsigned char* base = w < PD_WAVES    ? smem + PD_OFF_REC + w * PD_REC_CAP * PD_REC_BYTES
+                                        : w == PD_WAVES ? smem + PD_OFF_SPILL
+                                                        : a.pq_spill + (int64_t)blockIdx.x * a.pq_spill_cap * PD_REC_BYTES;
+            for (int i = threadIdx.x; i < n; i += PD_THREADS) {
+                const unsigned char* rp = base + i * PD_REC_BYTES;
+                uint32_t rw[PD_REC_BYTES / 4];
+                if (w <= PD_WAVES) {
+#pragma unroll
+                    for (int j = 0; j < PD_REC_BYTES / 16; j++) {
+                        const uint4 q4 = reinterpret_cast<const uint4*>(rp)[j];
+                        rw[4 * j] = q4.x;
+                        rw[4 * j + 1] = q4.y;
+                        rw[4 * j + 2] = q4.z;
+                        rw[4 * j + 3] = q4.w;
+                    }
+                } else {
+                    // records in global memory were written by other waves of this workgroup a moment ago: read past the
+                    // CU's vector cache (a line of this buffer may sit there from an earlier unit)
+#pragma unroll
+                    for (int j = 0; j < PD_REC_BYTES / 4; j++) {
+                        rw[j] = __hip_atomic_load(reinterpret_cast<const uint32_t*>(rp) + j, __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                const uint4 h = make_uint4(rw[0], rw[1], 0u, 0u);
+                const float thq = sT[h.x];
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const uint32_t pos = h.y + (uint32_t)((r & 3) + 8 * (r >> 2));
+                    const float x = __uint_as_float(rw[4 + r]);
+                    if (x >= thq && (int64_t)pos < un.len) {
+                        const int at = atomicAdd(&ctl[9], 1);
+                        if (at < PD_FLAT_CAP) {
+                            flat[at] = make_uint4(h.x, pos, __float_as_uint(x), 0u);
+                        } else { // (more passing rows than the list holds: appended on the spot)
+                            const float xs = x * inv_sc, c = sC[h.x];
+                            ms_emit<IS_L2>(a, sPq[h.x], sPs[h.x], un.row_off, (int64_t)pos, IS_L2 ? c - 2.0f * xs : c + xs);
+                        }
+                    }
+                }
             }
         }
         __syncthreads();
-        // the parked hits: one record per thread, their global atomics in flight together
-        const int nhit = min(ctl[0], PD_HITS);
-        for (int i = threadIdx.x; i < nhit; i += PD_THREADS) {
-            const uint4 h = sHit[i];
+#ifdef KNHIP_PHASE_TIMERS
+        if (threadIdx.x == 0) {
+            atomicMax(&g_pd_prof[32], (unsigned long long)ctl[8]);
+            atomicMax(&g_pd_prof[33], (unsigned long long)ctl[10]);
+            atomicMax(&g_pd_prof[34], (unsigned long long)ctl[9]);
+            atomicAdd(&g_pd_prof[35], (unsigned long long)(ctl[4] + ctl[5] + ctl[6] + ctl[7]));
+            atomicAdd(&g_pd_prof[36], (unsigned long long)ctl[9]);
+            atomicAdd(&g_pd_prof[37], (unsigned long long)(ctl[10] > 0));
+            atomicAdd(&g_pd_prof[38], (unsigned long long)(ctl[8] > 0));
+        }
+#endif
+        const int nflat = min(ctl[9], PD_FLAT_CAP);
+        for (int i = threadIdx.x; i < nflat; i += PD_THREADS) {
+            const uint4 h = flat[i];
             const float x = __uint_as_float(h.z) * inv_sc, c = sC[h.x];
             ms_emit<IS_L2>(a, sPq[h.x], sPs[h.x], un.row_off, (int64_t)h.y, IS_L2 ? c - 2.0f * x : c + x);
         }
         cur = ctl[2];
-        __syncthreads(); // (everybody has read the next unit and the parked hits)
-        if (threadIdx.x == 0) {
-            ctl[0] = 0;
+        __syncthreads(); // (everybody has read the next unit and the parked records)
+        PD_T(5);
+    }
+#ifdef KNHIP_PHASE_TIMERS
+    if (lane_id() == 0) {
+        for (int i = 0; i < 8; i++) {
+            atomicAdd(&g_pd_prof[(threadIdx.x / KN_WAVE) * 8 + i], tacc[i]);
         }
     }
+#endif
 }
 
 // filter pass only (no sample mode: pq_sample_kernel samples per query); the units must have been cut for PD_QT queries
@@ -587,7 +775,7 @@ hipError_t launch_pqd(const MScanArgs& a, bool is_l2, int64_t units_bound, hipSt
     if (units_bound <= 0) {
         return hipSuccess;
     }
-    if (a.dump != nullptr || a.pq_cb16 == nullptr || a.pq_qh16 == nullptr || a.pq_qd == nullptr || a.pq_sc == nullptr ||
+    if (a.dump != nullptr || a.pq_spill == nullptr || a.pq_spill_cap <= 0 || a.pq_cb16 == nullptr || a.pq_qh16 == nullptr || a.pq_qd == nullptr || a.pq_sc == nullptr ||
         a.pq_codes == nullptr || a.pq_ctr == nullptr || (is_l2 && (a.pq_psum_s == nullptr || a.pq_sblk_off_r == nullptr))) {
         return hipErrorInvalidValue;
     }
@@ -610,8 +798,33 @@ hipError_t launch_pqd(const MScanArgs& a, bool is_l2, int64_t units_bound, hipSt
             return e;
         }
     }
-    const int64_t grid = std::min<int64_t>(units_bound, ncu);
+    const int64_t grid = std::min<int64_t>(std::min<int64_t>(units_bound, ncu), a.pq_spill_wgs);
+#ifdef KNHIP_PHASE_TIMERS
+    static unsigned long long zero[40] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pd_prof), zero, sizeof(zero));
+#endif
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(PD_THREADS), PD_SMEM, s, a);
+#ifdef KNHIP_PHASE_TIMERS
+    (void)hipStreamSynchronize(s);
+    unsigned long long h[40];
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pd_prof), sizeof(h));
+    {
+        int64_t nu = -1;
+        (void)hipMemcpy(&nu, a.nunits_dev, sizeof(nu), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[pqd timers] launch unit_loop=%d units=%lld | max shared %llu max global %llu max flat %llu | private records %llu "
+                        "passing rows %llu | units with global %llu with shared %llu\n", (int)a.unit_loop, (long long)nu, h[32], h[33], h[34],
+                h[35], h[36], h[37], h[38]);
+    }
+    if (!a.unit_loop) {
+        fprintf(stderr, "[pqd timers] ticks per workgroup (grid %lld): wave | prologue  operands  tiles  slow-path  end-barrier  flush | "
+                        "tiles  slow entries\n", (long long)grid);
+        for (int w = 0; w < 4; w++) {
+            fprintf(stderr, "[pqd timers]   %d |", w);
+            for (int i = 0; i < 6; i++) fprintf(stderr, " %10.0f", (double)h[w * 8 + i] / (double)grid);
+            fprintf(stderr, " | %8.0f %8.0f\n", (double)h[w * 8 + 6] / (double)grid, (double)h[w * 8 + 7] / (double)grid);
+        }
+    }
+#endif
     return hipGetLastError();
 }
 

@@ -101,7 +101,7 @@ def patch_generic(s):
                lambda m: f"{m.group(1)}* {m.group(2)} = reinterpret_cast<{m.group(1)}*>(hipemu::tl.g->smem);", s)
     # the XCD id of a persistent workgroup (placement only): the workgroup index stands in
     s = re.sub(r'asm volatile\("s_getreg_b32 %0, hwreg\(HW_REG_XCC_ID\)" : "=s"\((\w+)\)\);', r"\1 = (uint32_t)blockIdx.x;", s)
-    s = re.sub(r'asm volatile\("" : "\+v"\((\w+)\)\);', "", s)  # (compiler fences on a lane value)
+    s = re.sub(r'asm volatile\("" : "\+v"\(([\w\[\]\.]+)\)\);', "", s)  # (compiler fences on a lane value)
     s = strip_inline_isa(s)
     # "the LUT sits at LDS offset 0" assertions of the token-addressed kernels (host pointers are never 0)
     s = re.sub(r"    if \(\(uint32_t\)\(size_t\)\(\(__attribute__\(\(address_space\(3\)\)\) unsigned char\*\)smem\) != 0u\) \{\n"

@@ -368,6 +368,25 @@ inline I4 hipemu_mfma_i32_16x16x64_i8(I4 a, I4 b, I4 c, int, int, int) {
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(...) hipemu_mfma_32x32x2_f32(__VA_ARGS__)
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(...) hipemu_mfma_32x32x16_f16(__VA_ARGS__)
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(...) hipemu_mfma_32x32x16_bf16(__VA_ARGS__)
+// buffer descriptors (pq_decode.hip): base + byte count, loads past the end return zeros like the hardware's bounds check
+struct hipemu_rsrc {
+    const unsigned char* base;
+    uint32_t bytes;
+};
+#define __amdgpu_buffer_rsrc_t hipemu_rsrc
+#define __builtin_amdgcn_make_buffer_rsrc(p, stride, num, flags) \
+    hipemu_rsrc{reinterpret_cast<const unsigned char*>(p), (uint32_t)(num)}
+template <class V>
+inline V hipemu_buffer_load(hipemu_rsrc r, uint32_t off) {
+    V v{};
+    if ((uint64_t)off + sizeof(V) <= r.bytes) {
+        std::memcpy(&v, r.base + off, sizeof(V));
+    }
+    return v;
+}
+typedef uint32_t hipemu_u4 __attribute__((ext_vector_type(4)));
+#define __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, aux) hipemu_buffer_load<hipemu_u4>((r), (uint32_t)((voff) + (soff)))
+#define __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, aux) hipemu_buffer_load<uint32_t>((r), (uint32_t)((voff) + (soff)))
 #define __builtin_amdgcn_s_setprio(p) ((void)0)
 // a wave runs in lockstep on the hardware: LDS traffic between its lanes needs only the compiler's attention there.  Here the
 // lanes are separate threads of execution: the wave barrier is a real rendezvous (an exchange every lane takes part in)
