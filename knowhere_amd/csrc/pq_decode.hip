@@ -46,6 +46,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <type_traits>
 
 namespace knhip {
 
@@ -311,6 +312,117 @@ __device__ __forceinline__ float pd_max16(const pd_f16& v) {
     return fmaxf(pd_max3(a, b, c), pd_max3(d, e, v[15]));
 }
 
+// ---- the ring loads: issued and waited for BY HAND ------------------------------------------------------------------------
+// The compiler's own wait insertion cannot follow a ring of loads that turns by name through an unrolled loop with exits:
+// whatever the structure tried, some body waited with vmcnt(0) or vmcnt(1) -- for the load issued a moment ago, a memory
+// round trip per tile -- where 2 (PD_RING - 1) loads may stay in flight.  And a load in inline ISA whose destination the
+// compiler manages does not work either: it believes the value is there when the instruction has been issued and moves it
+// around (seen: v_accvgpr_read of the destination right behind the load).  So the ring lives in NAMED accumulation registers
+// the compiler never sees -- a[236:255], at the far end of a file of which the kernel uses the first ~70; every statement
+// that touches them lists them as clobbered, which also puts them into the kernel's register count -- the loads are inline
+// ISA, and one statement waits (s_waitcnt vmcnt(N): at most N loads still in flight) and copies the slot into ordinary
+// registers.  Everything else in the loop that counts in vmcnt (the rare stores of the park path) is YOUNGER than the loads
+// waited for and can only make the wait longer, never shorter.  The host pass and the CPU emulation of tests/hipemu keep
+// the ring in ordinary variables and take the builtin loads.
+typedef int pd_i4 __attribute__((ext_vector_type(4)));
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PD_NO_ASM)
+#define PD_RING_CLOBBER                                                                                                      \
+    "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250",  \
+            "a251", "a252", "a253", "a254", "a255", "memory"
+struct PdRing {}; // (nothing: the slots are the named registers)
+// slot I <- 16 code bytes (+ the start value).  s_nop 4: the scalar offsets are computed right in front of this statement, and
+// a vector memory instruction that reads an SGPR needs five wait states behind the scalar instruction that wrote it -- the
+// compiler pads that for its own instructions, not for inline ISA (without the padding the loads took the PREVIOUS tile's
+// offset now and then: tiles scanned twice, tiles missed)
+template <int I, bool WITH_P>
+__device__ __forceinline__ void pd_ring_load(PdRing&, pd_i4 rc, int voff_c, int soff_c, pd_i4 rp, int voff_p, int soff_p) {
+    static_assert(I >= 0 && I < 4, "four slots");
+#define PD_LD(WREG, PREG)                                                                                                    \
+    if (WITH_P) {                                                                                                            \
+        asm volatile("s_nop 4\n\tbuffer_load_dwordx4 " WREG ", %0, %1, %2 offen\n\tbuffer_load_dword " PREG ", %3, %4, %5 offen" \
+                     :                                                                                                       \
+                     : "v"(voff_c), "s"(rc), "s"(soff_c), "v"(voff_p), "s"(rp), "s"(soff_p)                                  \
+                     : PD_RING_CLOBBER);                                                                                     \
+    } else {                                                                                                                 \
+        asm volatile("s_nop 4\n\tbuffer_load_dwordx4 " WREG ", %0, %1, %2 offen" : : "v"(voff_c), "s"(rc), "s"(soff_c) : PD_RING_CLOBBER); \
+    }
+    if (I == 0) {
+        PD_LD("a[236:239]", "a252")
+    } else if (I == 1) {
+        PD_LD("a[240:243]", "a253")
+    } else if (I == 2) {
+        PD_LD("a[244:247]", "a254")
+    } else {
+        PD_LD("a[248:251]", "a255")
+    }
+#undef PD_LD
+}
+// wait until at most N loads are in flight, then slot I -> (w, p).  s_nop 7 behind the copies: found by bisection on the
+// hardware -- without wait states between these v_accvgpr_read_b32 and the compiler's instructions that follow the statement
+// the scan lost rows (tests/test_gpu_pqf.py failed; padding in front of the loads, in front of the copies or behind the
+// loads did not help, padding behind the copies did: a hazard the compiler pads for its own instructions and cannot see
+// inside inline ISA)
+template <int I, int N, bool WITH_P>
+__device__ __forceinline__ void pd_ring_take(PdRing&, pd_u4& w, float& p) {
+    uint32_t w0, w1, w2, w3;
+    float pp = 0.f;
+#define PD_TK(W0, W1, W2, W3, PREG)                                                                                          \
+    if (WITH_P) {                                                                                                            \
+        asm volatile("s_waitcnt vmcnt(%5)\n\tv_accvgpr_read_b32 %0, " W0 "\n\tv_accvgpr_read_b32 %1, " W1                   \
+                     "\n\tv_accvgpr_read_b32 %2, " W2 "\n\tv_accvgpr_read_b32 %3, " W3 "\n\tv_accvgpr_read_b32 %4, " PREG "\n\ts_nop 7" \
+                     : "=v"(w0), "=v"(w1), "=v"(w2), "=v"(w3), "=v"(pp)                                                      \
+                     : "n"(N)                                                                                                \
+                     : PD_RING_CLOBBER);                                                                                     \
+    } else {                                                                                                                 \
+        asm volatile("s_waitcnt vmcnt(%4)\n\tv_accvgpr_read_b32 %0, " W0 "\n\tv_accvgpr_read_b32 %1, " W1                   \
+                     "\n\tv_accvgpr_read_b32 %2, " W2 "\n\tv_accvgpr_read_b32 %3, " W3 "\n\ts_nop 7"                          \
+                     : "=v"(w0), "=v"(w1), "=v"(w2), "=v"(w3)                                                                \
+                     : "n"(N)                                                                                                \
+                     : PD_RING_CLOBBER);                                                                                     \
+    }
+    if (I == 0) {
+        PD_TK("a236", "a237", "a238", "a239", "a252")
+    } else if (I == 1) {
+        PD_TK("a240", "a241", "a242", "a243", "a253")
+    } else if (I == 2) {
+        PD_TK("a244", "a245", "a246", "a247", "a254")
+    } else {
+        PD_TK("a248", "a249", "a250", "a251", "a255")
+    }
+#undef PD_TK
+    w[0] = w0;
+    w[1] = w1;
+    w[2] = w2;
+    w[3] = w3;
+    p = pp;
+}
+// nothing of the ring is in flight any more (its registers are the compiler's again)
+__device__ __forceinline__ void pd_ring_drain(PdRing&) { asm volatile("s_waitcnt vmcnt(0)" : : : PD_RING_CLOBBER); }
+#else
+struct PdRing {
+    pd_u4 w[4];
+    float p[4];
+};
+template <int I, bool WITH_P>
+__device__ __forceinline__ void pd_ring_load(PdRing& r, pd_i4 rc, int voff_c, int soff_c, pd_i4 rp, int voff_p, int soff_p) {
+    const pd_rsrc dc = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<void*>(((uint64_t)(uint32_t)rc[1] << 32) | (uint32_t)rc[0]), 0, rc[2], rc[3]);
+    r.w[I] = __builtin_amdgcn_raw_buffer_load_b128(dc, voff_c, soff_c, 0);
+    r.p[I] = 0.f;
+    if (WITH_P) {
+        const pd_rsrc dp = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<void*>(((uint64_t)(uint32_t)rp[1] << 32) | (uint32_t)rp[0]), 0, rp[2], rp[3]);
+        r.p[I] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dp, voff_p, soff_p, 0));
+    }
+}
+template <int I, int N, bool WITH_P>
+__device__ __forceinline__ void pd_ring_take(PdRing& r, pd_u4& w, float& p) {
+    w = r.w[I];
+    p = r.p[I];
+}
+__device__ __forceinline__ void pd_ring_drain(PdRing&) {}
+#endif
+
 struct PdUnit {
     int64_t len;      // rows of the list
     int64_t row_off;  // first row of the list in the canonical arrays (codes, ids)
@@ -371,37 +483,34 @@ __device__ __forceinline__ void pqd_scan(const MScanArgs& a, unsigned char* smem
         }
     }
     // The list's codes and start values through buffer descriptors: the tile's offset rides in the scalar offset, the lane's
-    // part (row lr, half hi: 16 of the row's 32 code bytes) is a constant, and the hardware's bounds check returns zeros past
-    // the list's end (code 0: a valid table entry; those rows are never emitted) -- no address arithmetic on the vector unit,
-    // no clamps.  The start value of the tile's row `lr` is -psum SC / 2; both halves of the wave load it: the fp32 matrix
-    // instruction that spreads the values over the accumulator layout takes k = 0 from the lower half and multiplies the
-    // upper half's k = 1 by zero (finite values: no NaN from it).
+    // part (row lr, half hi: 16 of the row's 32 code bytes) is a constant -- no address arithmetic on the vector unit.  A tile
+    // past the list's end re-reads the last tile (never used).  The start value of the tile's row `lr` is -psum SC / 2; both
+    // halves of the wave load it: the fp32 matrix instruction that spreads the values over the accumulator layout takes
+    // k = 0 from the lower half and multiplies the upper half's k = 1 by zero (finite values: no NaN from it).
     // (every input of a descriptor through readfirstlane: the list's offsets came out of memory, and a descriptor the
     // compiler cannot PROVE uniform is loaded through a waterfall loop per load)
-    auto uniform_ptr = [](const void* p) -> void* {
+    auto make_rsrc = [](const void* p, int bytes) -> pd_i4 {
         const uint64_t v = reinterpret_cast<uint64_t>(p);
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-        const uint32_t hi2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-        return reinterpret_cast<void*>(((uint64_t)hi2 << 32) | lo);
+        pd_i4 r;
+        r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+        r[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) & 0xffff; // (stride 0: a raw buffer)
+        r[2] = __builtin_amdgcn_readfirstlane(bytes);
+        r[3] = 0x00020000;
+        return r;
     };
-    const int bytes_c = __builtin_amdgcn_readfirstlane((int)(un.len * PD_M));
-    const int bytes_p = __builtin_amdgcn_readfirstlane(IS_L2 ? un.ntile * 32 * 4 : 0);
-    const pd_rsrc rc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(a.pq_codes + un.row_off * PD_M), 0, bytes_c, 0x00020000);
-    const pd_rsrc rp = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(IS_L2 ? a.pq_psum_s + un.ps_off : a.pq_sc), 0, bytes_p,
-                                                        0x00020000);
+    // (bounds: the whole tiles of the list -- rows past its end inside the last tile belong to the next list or to the
+    // allocation's tail and are never emitted; the codes' allocation ends with the last list, whose last tile may reach
+    // past it: the record count stops THAT)
+    const pd_i4 rc = make_rsrc(a.pq_codes + un.row_off * PD_M, (int)(un.len * PD_M));
+    const pd_i4 rp = make_rsrc(IS_L2 ? a.pq_psum_s + un.ps_off : a.pq_sc, IS_L2 ? un.ntile * 32 * 4 : 0);
     const int voff_c = lr * PD_M + hi * 16, voff_p = lr * 4;
-    auto load_codes = [&](int t) -> uint4 { // tile t's 16 code bytes of this lane
-        const pd_u4 w = __builtin_amdgcn_raw_buffer_load_b128(rc, voff_c, t * (32 * PD_M), 0);
-        return make_uint4(w[0], w[1], w[2], w[3]);
-    };
-    auto load_start = [&](int t) -> float {
-        return IS_L2 ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, voff_p, t * (32 * 4), 0)) : 0.f;
-    };
+    const int t_end = ntile - 1;
+    PdRing ring;
     const float one_lo = hi == 0 ? 1.0f : 0.f;
     const uint32_t hbase = (uint32_t)hi * (16u * PD_KSUB * 8u);
     // step s of a tile's operand: the entries of sub-quantizers 16 h + 2 s, + 1 = bytes 2 s, 2 s + 1 of the lane's codes
-    auto decode_step = [&](const uint4& w, int s, pd_h8& A) {
-        const uint32_t ww = s < 2 ? w.x : s < 4 ? w.y : s < 6 ? w.z : w.w;
+    auto decode_step = [&](const pd_u4& w, int s, pd_h8& A) {
+        const uint32_t ww = w[s >> 1];
         const uint32_t c0 = (ww >> (16 * (s & 1))) & 0xffu, c1 = (ww >> (16 * (s & 1) + 8)) & 0xffu;
         const uint2 e0 = *reinterpret_cast<const uint2*>(smem + (hbase + (uint32_t)(2 * s) * (PD_KSUB * 8u) + c0 * 8u));
         const uint2 e1 = *reinterpret_cast<const uint2*>(smem + (hbase + (uint32_t)(2 * s + 1) * (PD_KSUB * 8u) + c1 * 8u));
@@ -473,16 +582,18 @@ __device__ __forceinline__ void pqd_scan(const MScanArgs& a, unsigned char* smem
     // of matrix work).  So the tile loop is unrolled PD_RING times with compile-time slot numbers.
     pd_h8 A[8];
     pd_f16 acc[NTQ], init;
-    uint4 W[PD_RING];
-    float P[PD_RING];
+    constexpr int NLD = IS_L2 ? 2 : 1; // loads per tile
+    static_assert(PD_RING == 4, "the ring's named registers");
     {
-        const uint4 w0 = load_codes(wave);
-        const float p0 = load_start(wave);
-#pragma unroll
-        for (int i = 0; i < PD_RING; i++) { // slot i <- tile (i + 1) of this wave
-            W[i] = load_codes(wave + (i + 1) * PD_WAVES);
-            P[i] = load_start(wave + (i + 1) * PD_WAVES);
-        }
+        // tile `wave` through slot 0, taken at once; then the ring: slot i <- tile (i + 1) of this wave
+        pd_u4 w0;
+        float p0;
+        pd_ring_load<0, IS_L2>(ring, rc, voff_c, min(wave, t_end) * (32 * PD_M), rp, voff_p, min(wave, t_end) * (32 * 4));
+        pd_ring_take<0, 0, IS_L2>(ring, w0, p0);
+        pd_ring_load<0, IS_L2>(ring, rc, voff_c, min(wave + 1 * PD_WAVES, t_end) * (32 * PD_M), rp, voff_p, min(wave + 1 * PD_WAVES, t_end) * (32 * 4));
+        pd_ring_load<1, IS_L2>(ring, rc, voff_c, min(wave + 2 * PD_WAVES, t_end) * (32 * PD_M), rp, voff_p, min(wave + 2 * PD_WAVES, t_end) * (32 * 4));
+        pd_ring_load<2, IS_L2>(ring, rc, voff_c, min(wave + 3 * PD_WAVES, t_end) * (32 * PD_M), rp, voff_p, min(wave + 3 * PD_WAVES, t_end) * (32 * 4));
+        pd_ring_load<3, IS_L2>(ring, rc, voff_c, min(wave + 4 * PD_WAVES, t_end) * (32 * PD_M), rp, voff_p, min(wave + 4 * PD_WAVES, t_end) * (32 * 4));
 #pragma unroll
         for (int s = 0; s < 8; s++) {
             decode_step(w0, s, A[s]);
@@ -497,12 +608,35 @@ __device__ __forceinline__ void pqd_scan(const MScanArgs& a, unsigned char* smem
     // tile t (SLOT = the ring slot that holds tile t + 4's codes and start value): acc <- init + A x B, step by step (NTQ
     // matrix instructions on NTQ different accumulators per step); the operand registers of a step are refilled with tile
     // t + 4's as soon as the step's instructions have been issued; at the end one fp32 matrix instruction spreads the next
-    // tile's start values over the accumulator layout (D[r][n] = P[r] * 1).  The accumulators of the PREVIOUS tile tp are
-    // compared one query tile at a time right before step 0 overwrites them: the compare of query tile qt + 1 runs while
-    // step 0 of query tile qt is in the matrix pipe.
-    auto tile = [&](uint4& Wslot, float& Pslot, int t, int tp, bool first) {
-        const uint4 wn = Wslot; // tile t + 4
-        const float pn = Pslot;
+    // tile's start values over the accumulator layout (D[r][n] = P[r] * 1) and the slot is refilled with tile t + 20's.  The
+    // accumulators of the PREVIOUS tile tp are compared one query tile at a time right before step 0 overwrites them: the
+    // compare of query tile qt + 1 runs while step 0 of query tile qt is in the matrix pipe.
+    auto tile = [&](auto slot, int t, int tp, bool first) {
+        constexpr int SLOT = decltype(slot)::value;
+        pd_u4 wn;
+        float pn;
+        // behind the slot's loads sit those of the other three slots
+        pd_ring_take<SLOT, NLD * (PD_RING - 1), IS_L2>(ring, wn, pn);
+#ifdef PD_CHECK_RING
+        {   // (debug build: the same tile through the compiler's own loads)
+            const pd_rsrc dc = __builtin_amdgcn_make_buffer_rsrc(
+                    reinterpret_cast<void*>(((uint64_t)(uint32_t)rc[1] << 32) | (uint32_t)rc[0]), 0, rc[2], rc[3]);
+            const pd_rsrc dp = __builtin_amdgcn_make_buffer_rsrc(
+                    reinterpret_cast<void*>(((uint64_t)(uint32_t)rp[1] << 32) | (uint32_t)rp[0]), 0, rp[2], rp[3]);
+            const int tt = min(t + PD_WAVES, t_end);
+            const pd_u4 cw = __builtin_amdgcn_raw_buffer_load_b128(dc, voff_c, tt * (32 * PD_M), 0);
+            const float cp = IS_L2 ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dp, voff_p, tt * (32 * 4), 0)) : 0.f;
+            const bool bad = cw[0] != wn[0] || cw[1] != wn[1] || cw[2] != wn[2] || cw[3] != wn[3] ||
+                             __float_as_uint(cp) != __float_as_uint(pn);
+            if (bad) {
+                atomicAdd(&g_pd_prof[39], 1ull);
+                if (atomicAdd(&g_pd_prof[38], 0ull) == 0ull) {
+                    printf("ring mismatch: slot %d tile %d (ntile %d) lane %d: got %08x %08x %08x %08x | %g, want %08x %08x %08x %08x | %g\n",
+                           SLOT, tt, ntile, lane, wn[0], wn[1], wn[2], wn[3], pn, cw[0], cw[1], cw[2], cw[3], cp);
+                }
+            }
+        }
+#endif
 #pragma unroll
         for (int qt = 0; qt < NTQ; qt++) {
             if (!first) {
@@ -535,29 +669,44 @@ __device__ __forceinline__ void pqd_scan(const MScanArgs& a, unsigned char* smem
             asm volatile("" : "+v"(init));
             init = __builtin_amdgcn_mfma_f32_32x32x2f32(pn, one_lo, z, 0, 0, 0);
         }
-        // the slot is refilled only NOW, when its old content is dead: a load issued at the top of the tile needs a second
-        // register while the old content is still being decoded, and the copy back into the slot's register at the end of
-        // the tile waits for that very load (vmcnt(0): a memory round trip per tile)
-        if (!(dbg & 4)) {
-            Wslot = load_codes(t + (PD_RING + 1) * PD_WAVES);
-            Pslot = load_start(t + (PD_RING + 1) * PD_WAVES);
-        }
+        const int tn = min(t + (PD_RING + 1) * PD_WAVES, t_end);
+        pd_ring_load<SLOT, IS_L2>(ring, rc, voff_c, tn * (32 * PD_M), rp, voff_p, tn * (32 * 4));
+#ifdef PD_DRAIN_EACH
+        pd_ring_drain(ring);
+#endif
     };
     int t = wave, tl = wave;
     bool first = true;
     PD_T(1);
-    while (t < ntile) {
+    // (body i + 1 is reachable ONLY through body i: with every body behind its own `if (t < ntile)` the compiler must assume
+    // a path that skips the bodies in front, on which a slot's load has fewer loads behind it, and waits accordingly --
+    // vmcnt(1) instead of vmcnt(6))
+    for (;;) {
+        bool done = false;
 #pragma unroll
         for (int i = 0; i < PD_RING; i++) {
-            if (t < ntile) { // (wave-uniform)
-                tile(W[i], P[i], t, tl, first);
+            if (!done) {
+                if (i == 0) {
+                    tile(std::integral_constant<int, 0>{}, t, tl, first);
+                } else if (i == 1) {
+                    tile(std::integral_constant<int, 1>{}, t, tl, first);
+                } else if (i == 2) {
+                    tile(std::integral_constant<int, 2>{}, t, tl, first);
+                } else {
+                    tile(std::integral_constant<int, 3>{}, t, tl, first);
+                }
                 first = false;
                 tl = t;
                 t += PD_WAVES;
                 PD_COUNT(6, 1);
+                done = t >= ntile;
             }
         }
+        if (done) {
+            break;
+        }
     }
+    pd_ring_drain(ring); // (the loads still in flight -- tiles past the end -- have landed)
 #pragma unroll
     for (int qt = 0; qt < NTQ; qt++) {
         compare(acc[qt], qt, tl);
@@ -811,6 +960,7 @@ hipError_t launch_pqd(const MScanArgs& a, bool is_l2, int64_t units_bound, hipSt
     {
         int64_t nu = -1;
         (void)hipMemcpy(&nu, a.nunits_dev, sizeof(nu), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[pqd timers] ring mismatches %llu\n", h[39]);
         fprintf(stderr, "[pqd timers] launch unit_loop=%d units=%lld | max shared %llu max global %llu max flat %llu | private records %llu "
                         "passing rows %llu | units with global %llu with shared %llu\n", (int)a.unit_loop, (long long)nu, h[32], h[33], h[34],
                 h[35], h[36], h[37], h[38]);
