@@ -530,7 +530,6 @@ __device__ __forceinline__ void pqd_scan(const MScanArgs& a, unsigned char* smem
         const bool p = pd_max16(acc) >= thr[qt];
         const unsigned long long mask = __ballot(p);
         if (__builtin_expect(mask != 0ull, 0) && !(dbg & 1)) {
-            PD_T(2);
             const int my = nrec + __popcll(mask & ((1ull << lane) - 1ull));
             nrec += __popcll(mask);
             if (p) {
@@ -571,8 +570,8 @@ __device__ __forceinline__ void pqd_scan(const MScanArgs& a, unsigned char* smem
                     a.overflow[a.nq] = 1;
                 }
             }
-            PD_T(3);
-            PD_COUNT(7, 1);
+            PD_COUNT(7, 1); // (no clock reads inside the tile loop: s_memtime answers through lgkmcnt, out of order with the
+                            // LDS gathers, and every wait behind it becomes lgkmcnt(0))
         }
     };
 
@@ -839,55 +838,79 @@ __global__ __launch_bounds__(PD_THREADS, 1) void pqd_kernel(MScanArgs a) {
         __syncthreads();
         PD_T(4);
         // the parked lanes.  Phase A, one record per thread: which of its 16 rows pass -> a flat list in LDS (one LDS atomic
-        // per passing row).  Phase B, one passing row per thread: the appends (global atomics with a returned slot), all in
-        // flight together.  (Appending straight from the records made a wave walk the 16 rows with some lane appending at
-        // nearly every step: 16 global round trips one after the other, 59 k cycles per unit.)
+        // per RECORD: the thread reserves as many entries as rows pass).  Every wave sorts out its OWN region (all records
+        // through the first wave's lanes took that wave 24 k cycles per unit with the other three waiting); the shared and the
+        // global regions go over all threads.  Phase B, one passing row per thread: the appends (global atomics with a
+        // returned slot), all in flight together.  (Appending straight from the records made a wave walk the 16 rows with
+        // some lane appending at nearly every step: 16 global round trips one after the other, 59 k cycles per unit.)
         uint4* flat = reinterpret_cast<uint4*>(smem + PD_OFF_FLAT);
-        for (int w = 0; w <= PD_WAVES + 1; w++) {
-            const int n = un.ntile <= 0 ? 0 : w < PD_WAVES ? ctl[4 + w] : w == PD_WAVES ? min(ctl[8], PD_SPILL_CAP)
-                                                                                     : min(ctl[10], a.pq_spill_cap);
-            const unsigned char* base = w < PD_WAVES    ? smem + PD_OFF_REC + w * PD_REC_CAP * PD_REC_BYTES
-                                        : w == PD_WAVES ? smem + PD_OFF_SPILL
-                                                        : a.pq_spill + (int64_t)blockIdx.x * a.pq_spill_cap * PD_REC_BYTES;
-            for (int i = threadIdx.x; i < n; i += PD_THREADS) {
-                const unsigned char* rp = base + i * PD_REC_BYTES;
+        auto sort_out = [&](const uint32_t (&rw)[PD_REC_BYTES / 4]) {
+            const uint32_t pair = rw[0], row0 = rw[1];
+            const float thq = sT[pair];
+            uint32_t hm = 0;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const uint32_t pos = row0 + (uint32_t)((r & 3) + 8 * (r >> 2));
+                hm |= (__uint_as_float(rw[4 + r]) >= thq && (int64_t)pos < un.len) ? (1u << r) : 0u;
+            }
+            if (hm == 0u) {
+                return;
+            }
+            int at = atomicAdd(&ctl[9], __popc(hm));
+            while (hm != 0u) {
+                const int r = __ffs((int)hm) - 1;
+                hm &= hm - 1u;
+                uint32_t xb = rw[4];
+#pragma unroll
+                for (int r2 = 1; r2 < 16; r2++) {
+                    xb = r == r2 ? rw[4 + r2] : xb;
+                }
+                const uint32_t pos = row0 + (uint32_t)((r & 3) + 8 * (r >> 2));
+                if (at < PD_FLAT_CAP) {
+                    flat[at] = make_uint4(pair, pos, xb, 0u);
+                } else { // (more passing rows than the list holds: appended on the spot)
+                    const float xs = __uint_as_float(xb) * inv_sc, c = sC[pair];
+                    ms_emit<IS_L2>(a, sPq[pair], sPs[pair], un.row_off, (int64_t)pos, IS_L2 ? c - 2.0f * xs : c + xs);
+                }
+                at++;
+            }
+        };
+        auto read_lds = [&](const unsigned char* rp, uint32_t (&rw)[PD_REC_BYTES / 4]) {
+#pragma unroll
+            for (int j = 0; j < PD_REC_BYTES / 16; j++) {
+                const uint4 q4 = reinterpret_cast<const uint4*>(rp)[j];
+                rw[4 * j] = q4.x;
+                rw[4 * j + 1] = q4.y;
+                rw[4 * j + 2] = q4.z;
+                rw[4 * j + 3] = q4.w;
+            }
+        };
+        if (un.ntile > 0) {
+            const int wv = threadIdx.x / KN_WAVE, ln = threadIdx.x % KN_WAVE;
+            const int n_own = ctl[4 + wv], n_sh = min(ctl[8], PD_SPILL_CAP), n_gl = min(ctl[10], a.pq_spill_cap);
+            for (int i = ln; i < n_own; i += KN_WAVE) {
                 uint32_t rw[PD_REC_BYTES / 4];
-                if (w <= PD_WAVES) {
+                read_lds(smem + PD_OFF_REC + (wv * PD_REC_CAP + i) * PD_REC_BYTES, rw);
+                sort_out(rw);
+            }
+            for (int i = threadIdx.x; i < n_sh; i += PD_THREADS) {
+                uint32_t rw[PD_REC_BYTES / 4];
+                read_lds(smem + PD_OFF_SPILL + i * PD_REC_BYTES, rw);
+                sort_out(rw);
+            }
+            // records in global memory were written by other waves of this workgroup a moment ago: read past the CU's vector
+            // cache (a line of this buffer may sit there from an earlier unit)
+            const uint32_t* gl = reinterpret_cast<const uint32_t*>(a.pq_spill) + (int64_t)blockIdx.x * a.pq_spill_cap * (PD_REC_BYTES / 4);
+            for (int i = threadIdx.x; i < n_gl; i += PD_THREADS) {
+                uint32_t rw[PD_REC_BYTES / 4];
 #pragma unroll
-                    for (int j = 0; j < PD_REC_BYTES / 16; j++) {
-                        const uint4 q4 = reinterpret_cast<const uint4*>(rp)[j];
-                        rw[4 * j] = q4.x;
-                        rw[4 * j + 1] = q4.y;
-                        rw[4 * j + 2] = q4.z;
-                        rw[4 * j + 3] = q4.w;
-                    }
-                } else {
-                    // records in global memory were written by other waves of this workgroup a moment ago: read past the
-                    // CU's vector cache (a line of this buffer may sit there from an earlier unit)
-#pragma unroll
-                    for (int j = 0; j < PD_REC_BYTES / 4; j++) {
-                        rw[j] = __hip_atomic_load(reinterpret_cast<const uint32_t*>(rp) + j, __ATOMIC_RELAXED,
-                                                  __HIP_MEMORY_SCOPE_AGENT);
-                    }
+                for (int j = 0; j < PD_REC_BYTES / 4; j++) {
+                    rw[j] = __hip_atomic_load(gl + (int64_t)i * (PD_REC_BYTES / 4) + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                const uint4 h = make_uint4(rw[0], rw[1], 0u, 0u);
-                const float thq = sT[h.x];
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const uint32_t pos = h.y + (uint32_t)((r & 3) + 8 * (r >> 2));
-                    const float x = __uint_as_float(rw[4 + r]);
-                    if (x >= thq && (int64_t)pos < un.len) {
-                        const int at = atomicAdd(&ctl[9], 1);
-                        if (at < PD_FLAT_CAP) {
-                            flat[at] = make_uint4(h.x, pos, __float_as_uint(x), 0u);
-                        } else { // (more passing rows than the list holds: appended on the spot)
-                            const float xs = x * inv_sc, c = sC[h.x];
-                            ms_emit<IS_L2>(a, sPq[h.x], sPs[h.x], un.row_off, (int64_t)pos, IS_L2 ? c - 2.0f * xs : c + xs);
-                        }
-                    }
-                }
+                sort_out(rw);
             }
         }
+        PD_T(3); // (phase A)
         __syncthreads();
 #ifdef KNHIP_PHASE_TIMERS
         if (threadIdx.x == 0) {
@@ -966,7 +989,7 @@ hipError_t launch_pqd(const MScanArgs& a, bool is_l2, int64_t units_bound, hipSt
                 h[35], h[36], h[37], h[38]);
     }
     if (!a.unit_loop) {
-        fprintf(stderr, "[pqd timers] ticks per workgroup (grid %lld): wave | prologue  operands  tiles  slow-path  end-barrier  flush | "
+        fprintf(stderr, "[pqd timers] ticks per workgroup (grid %lld): wave | prologue  operands  tiles  flush-A  end-barrier  flush-B+barriers | "
                         "tiles  slow entries\n", (long long)grid);
         for (int w = 0; w < 4; w++) {
             fprintf(stderr, "[pqd timers]   %d |", w);

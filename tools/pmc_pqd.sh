@@ -1,6 +1,6 @@
 set -u
 R=$(pwd)
-TAG=r06_c3_pqd3
+TAG=r06_c3_pqd4
 ARGS="--steps 3 --warmup 1 --cpu-queries 0 --host-steps 0 --extra none --gt-queries 10"
 cd /tmp && export TMPDIR=/tmp
 run() { name=$1; shift; rm -rf /tmp/pb_$name; (timeout 900 rocprofv3 "$@" --output-format csv -d /tmp/pb_$name -- python $R/bench.py $ARGS) > /tmp/pb_$name.log 2>&1; python $R/tools/pmc_summary.py /tmp/pb_$name $R/gpurun_out/${TAG}_$name.json; }
