@@ -379,7 +379,20 @@ def run_config(a, rank, world, dev, dev_id, comm):
               f"{', raw vectors %.1f GB/rank' % (vectors.numel() * 4 / 1e9) if vectors is not None else ''}, "
               f"precomputed_table={g.uses_precomputed_table}")
     if getattr(built, "codes", None) is not None and built.codes.numel() > (16 << 30):
-        built.codes = None  # (C5: 76.8 GB of list-sorted codes; the index holds its own layout, the CPU leg is skipped)
+        # (C5: 76.8 GB of list-sorted codes: more than the host holds.  The reference leg runs on the SUB-INDEX the first
+        # queries probe -- every list they visit, complete, the others empty: those queries get the whole index's answer)
+        if rank == 0 and world == 1 and a.cpu_queries != 0:
+            from oracle import binding as ob  # checker / baseline only
+            nsub = 24
+            _, kk = g.coarse_search_device(xq[:nsub].contiguous(), a.nprobe)
+            uniq = torch.unique(kk[kk >= 0]).cpu().numpy()
+            t_sub = time.time()
+            built.sub_ix = built.export(ob.IndexData, lists=uniq)
+            built.sub_nq = nsub
+            log(rank, f"sub-index for the reference leg: {len(uniq)} lists of {a.nlist}, "
+                      f"{sum(len(c) for c in built.sub_ix.list_codes) * built.codes.shape[1] / 1e9:.1f} GB on the host in "
+                      f"{time.time() - t_sub:.1f}s")
+        built.codes = None
         torch.cuda.empty_cache()
     kbase = a.refine_k if refine else a.k
     row_of_id = sharded.row_lookup(vector_ids, a.nb, dev) if (refine and vector_ids is not None) else None
@@ -797,6 +810,17 @@ def make_roofline(a, kind, prof, world):
         common["algorithmic_bytes_per_launch"] = scan_bytes
         hbm_algo = scan_bytes / sec / 1e9 if sec > 0 else 0.0
         common["hbm_algorithmic_GBps"], common["hbm_algorithmic_frac"] = round(hbm_algo, 1), round(hbm_algo / HBM_PEAK_GBPS, 4)
+    if kind == kidx.BRUTE_FORCE and prof.get("pq_filter_form", 0) == 10:
+        # the coarse quantizer's machinery over the base rows (knhip_api.hip::bf_mfma_batch): two GEMM passes of three bf16
+        # products each + bound + exact re-rank; ALGORITHMIC work 2 nq nb d flop, executed 6 x that
+        algo = 2.0 * a.nq * (a.nb / world) * a.d
+        tf_a = algo / sec / 1e12 if sec > 0 else 0.0
+        return dict({"bound": "mfma", "kernel": "knhip::coarse_bf16_kernel (BRUTE_FORCE rows: two passes x hi hi + hi lo + lo hi)",
+                     "achieved": round(6.0 * tf_a, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(6.0 * tf_a / MFMA_F16_PEAK_TFLOPS, 4),
+                     "executed": {"flop_per_mac": 12, "TFLOPs": round(6.0 * tf_a, 2)},
+                     "algorithmic": {"flop_per_mac": 2, "TFLOPs": round(tf_a, 2), "frac": round(tf_a / MFMA_F16_PEAK_TFLOPS, 4),
+                                     "frac_of_fp32_matrix_peak": round(tf_a / MFMA_F32_PEAK_TFLOPS, 4)}}, **common)
     pairs_dims = scan_bytes / code_size * a.d
     flop = pairs_dims * (3.0 if a.metric == "l2" else 2.0)
     tf = flop / sec / 1e12 if sec > 0 else 0.0
@@ -897,13 +921,18 @@ def cpu_baseline(a, kind, metric, built, vectors, xq, D_gpu, I_gpu, g, log):
         ix.base = built.base.cpu().numpy()
         code_bytes_per_query = float(a.nb) * a.d * 4
     else:
-        if built.codes is None:
-            log(0, "cpu baseline skipped: the list-sorted codes were released (index too large for the host leg)")
-            return None
         ix = None
+        if built.codes is None:
+            ix = getattr(built, "sub_ix", None)
+            if ix is None:
+                log(0, "cpu baseline skipped: the list-sorted codes were released (index too large for the host leg)")
+                return None
         code_bytes_per_query = None
     nqs = a.cpu_queries if a.cpu_queries > 0 else 32 * nth
     nqs = min(nqs, a.nq)
+    sub = kind != kidx.BRUTE_FORCE and built.codes is None
+    if sub:
+        nqs = built.sub_nq  # (only these queries' lists are on the host)
     n_chk = min(nqs, 2048)  # the bitwise check against the scalar build runs on this prefix
     t0 = time.time()
     if ix is None:
@@ -996,8 +1025,8 @@ def cpu_baseline(a, kind, metric, built, vectors, xq, D_gpu, I_gpu, g, log):
             "simd": {"avx2": "AVX2 (dynamic dispatch build, cmake/libs/libfaiss.cmake:388-463 shape, -O3)",
                      "scalar": "none (SIMDLevel::NONE build, -O2)", "port": "none (oracle.c)"}[simd_used],
             "sample": f"first {nqs} of the {a.nq} queries ({nqs / max(cores, 1):.1f} per thread at the reported point), same "
-                      f"index bytes, one query per task, omp=1 inside each task, warm thread pool; bitwise check on the "
-                      f"first {n_chk}",
+                      f"index bytes{' (the sub-index of the lists these queries probe: the whole index does not fit the host)' if sub else ''}, "
+                      f"one query per task, omp=1 inside each task, warm thread pool; bitwise check on the first {n_chk}",
             "code_GB_scanned_per_s": round(nqs / dt * code_bytes_per_query / 1e9, 2),
             "gpu_vs_scalar_reference_first_stage": {"checked_against": chk, "ids_equal": round(id_equal, 6),
                                                     "distances_bit_equal": round(dist_equal, 6)},

@@ -513,7 +513,8 @@ typedef struct knhip_stage_times {
     int64_t mscan_candidates;
     double mscan_stream_bytes; /* bytes the prefilter streams: sum over its units of len(list) * code_size */
     int64_t mscan_recomputed;  /* candidates that got an exact distance (IVF_PQ: after the finish kernel's pruning) */
-    int64_t pq_filter_form;    /* IVF_PQ prefilter of the last search: 0 none (exact kernels), 1 half precision, 2 int8, 3 decode form */
+    int64_t pq_filter_form;    /* IVF_PQ prefilter of the last search: 0 none (exact kernels), 1 half precision, 2 int8, 3 decode form;
+                                * BRUTE_FORCE: 10 = the last search ran on the matrix cores (bf16 prefilter + exact re-rank), 0 = row scan */
     int64_t tie_queries;       /* queries with candidates tied at their k-th distance beyond the k-th place, resolved by the
                                   reference's first-come admission rule (scan order) instead of the canonical order */
     int64_t tie_anomalies;     /* ... of those, rows the resolution left at their canonical copy because its dump pass found

@@ -159,19 +159,36 @@ class BuiltIndex:
             g.set_lists_device(new_off, self.codes[keep].contiguous(), self.ids[keep].contiguous())
         return g
 
-    def export(self, IndexData, list_limit=None):
-        """-> oracle IndexData (host numpy).  Used ONLY by tests / the cpu_baseline leg."""
+    def export(self, IndexData, lists=None):
+        """-> oracle IndexData (host numpy).  Used ONLY by tests / the cpu_baseline leg.
+        lists: optional list numbers -- only those lists are filled (the others stay empty): the SUB-INDEX a set of queries
+        probes, for an index whose codes do not fit the host (C5: 76.8 GB); a search of those queries with the same nprobe
+        returns what the whole index returns, since the coarse quantizer is complete and nothing else is visited."""
         ix = IndexData({1: 1, 2: 2, 3: 3}[self.kind], self.metric, self.d, self.nlist, self.M or 0, 8)
         ix.centroids = self.centroids.cpu().numpy()
         if self.codebooks is not None:
             ix.pq_centroids = self.codebooks.cpu().numpy()
         if self.sq_trained is not None:
             ix.sq_trained = self.sq_trained.cpu().numpy()
-        codes = self.codes.cpu().numpy()
-        ids = self.ids.cpu().numpy()
         off = self.list_offsets
-        ix.list_codes = [codes[off[l]:off[l + 1]] for l in range(self.nlist)]
-        ix.list_ids = [ids[off[l]:off[l + 1]] for l in range(self.nlist)]
+        if lists is None:
+            codes = self.codes.cpu().numpy()
+            ids = self.ids.cpu().numpy()
+            ix.list_codes = [codes[off[l]:off[l + 1]] for l in range(self.nlist)]
+            ix.list_ids = [ids[off[l]:off[l + 1]] for l in range(self.nlist)]
+            return ix
+        cs = self.codes.shape[1]
+        want = np.zeros(self.nlist, bool)
+        want[np.asarray(lists, np.int64)] = True
+        e_c, e_i = np.empty((0, cs), np.uint8), np.empty(0, np.int64)
+        ix.list_codes, ix.list_ids = [], []
+        for l in range(self.nlist):
+            if want[l] and off[l + 1] > off[l]:
+                ix.list_codes.append(self.codes[off[l]:off[l + 1]].cpu().numpy())
+                ix.list_ids.append(self.ids[off[l]:off[l + 1]].cpu().numpy())
+            else:
+                ix.list_codes.append(e_c)
+                ix.list_ids.append(e_i)
         return ix
 
 

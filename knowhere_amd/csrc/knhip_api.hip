@@ -231,6 +231,13 @@ struct knhip_index {
     int mscan = 2;
     bool flat_bf16 = true;    // KNHIP_MSCAN_FLAT=fp32: the IVF-Flat filter pass on the fp32 matrix instruction (round 2)
     int mscan_cap = 0;           // KNHIP_MSCAN_CAP: candidate capacity per query (0 = automatic; tests force the retry round)
+    // BRUTE_FORCE on the matrix cores (the coarse quantizer's bf16 prefilter + exact re-rank + certificate over the base rows):
+    // split bf16 operand rows + ||x||^2 per row, built on first use.  KNHIP_BF=exact keeps the exact row scan
+    mutable bool bf_split_ready = false;
+    mutable DevBuf rows_bs, bf_norm;
+    mutable float bf_norm_max = 0.f;
+    bool bf_mfma = true;
+    mutable int last_bf_mfma = 0;    // 1: the last BRUTE_FORCE search ran on the matrix cores
     mutable bool xnorm_ready = false;
     mutable DevBuf xnorm;        // [total blocks * 64] ||x||^2 per stored row position, built on first use
     mutable float xnorm_max = 0.f;
@@ -291,7 +298,7 @@ struct knhip_index {
     int64_t device_bytes() const {
         const DevBuf* all[] = {&centroids, &centroids_il, &centroids_bs, &cb, &precomp_t, &sq_trained, &d_list_len,
                                &d_list_row_off, &d_list_blk_off, &ids, &rows, &rows2, &d_list_blk_off2, &cb_t, &codes_aos,
-                               &rows_r, &d_list_blk_off_r, &psum, &rows_i, &idmap_ids, &idmap_col, &psum_s, &pqd_cb16, &pqd_st};
+                               &rows_r, &d_list_blk_off_r, &psum, &rows_i, &idmap_ids, &idmap_col, &psum_s, &pqd_cb16, &pqd_st, &rows_bs, &bf_norm};
         int64_t t = 0;
         for (auto* b : all) {
             t += (int64_t)b->bytes;
@@ -364,14 +371,24 @@ int build_coarse_layout(knhip_index* idx) {
 }
 
 // Coarse quantizer for one batch: keys/cdis [nq][nprobe], best-first, bit-equal to the exact search.
-int coarse_stage(const knhip_index* idx, Workspace* ws, const float* d_q, int64_t nq, int nprobe,
-                 int64_t* keys, float* cdis, hipStream_t s) {
-    const int64_t nlist = idx->nlist;
+// the rows a "nearest rows of every query" stage runs over: the coarse quantizer's centroids, or a chunk of a BRUTE_FORCE base
+struct CoarseRows {
+    const float* rows;      // [n][d] row major
+    const float4* rows_il;  // interleaved 64-row blocks
+    const void* rows_bs;    // split bf16 operand rows (null: the bf16 prefilter is not available)
+    const float* norm;      // [n] ||x||^2
+    float norm_max;
+    int64_t n;
+};
+
+int coarse_rows_stage(const knhip_index* idx, Workspace* ws, const CoarseRows& R, const float* d_q, int64_t nq, int nprobe,
+                      int64_t* keys, float* cdis, hipStream_t s) {
+    const int64_t nlist = R.n;
     const int d = idx->d;
     const bool is_l2 = idx->is_l2;
     HIP_TRY(ws->coarse_full.reserve((size_t)nq * nlist * sizeof(float)));
     FlatScanArgs c{};
-    c.rows = idx->centroids_il.as<float4>();
+    c.rows = R.rows_il;
     c.nrows = nlist;
     c.chunk_rows = 1024;
     c.d = d;
@@ -401,7 +418,7 @@ int coarse_stage(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
     HIP_TRY(ws->cand_approx.reserve((size_t)nq * ncand * sizeof(float)));
     HIP_TRY(ws->fail_flags.reserve(((size_t)nq + 1) * sizeof(int32_t))); // (+ the "any flag" summary)
     HIP_TRY(launch_row_norms(d_q, nq, d, ws->qnorm.as<float>(), s));
-    if (idx->coarse_gemm == 2 && coarse_bf16_supports(nlist, (int)ncand)) {
+    if (idx->coarse_gemm == 2 && R.rows_bs != nullptr && coarse_bf16_supports(nlist, (int)ncand)) {
         // bf16 matrix pipe, selection fused, no nq x nlist matrix (coarse_gemm.hip, round 5)
         int cap = 256;
         while (cap < 2 * ncand) {
@@ -413,11 +430,11 @@ int coarse_stage(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         HIP_TRY(ws->cand_keys.reserve((size_t)nq * cap * sizeof(int64_t)));
         HIP_TRY(ws->cg_qs.reserve((size_t)nq * coarse_bf16_slabs(d) * 128));
         HIP_TRY(launch_coarse_bf16_split(d_q, nq, d, ws->cg_qs.p, s));
-        HIP_TRY(launch_coarse_bf16(ws->cg_qs.p, ws->qnorm.as<float>(), idx->centroids_bs.p, idx->cnorm.as<float>(), nq, nlist,
+        HIP_TRY(launch_coarse_bf16(ws->cg_qs.p, ws->qnorm.as<float>(), R.rows_bs, R.norm, nq, nlist,
                                    d, is_l2, (int)ncand, cap, ws->cg_gmin.as<float>(), ws->cg_bound.as<float>(),
                                    ws->cg_cnt.as<int32_t>(), ws->cand_keys.as<int64_t>(), s));
-        HIP_TRY(launch_coarse_rerank(d_q, idx->centroids.as<float>(), d, nq, nlist, cap, ws->cand_keys.as<int64_t>(), nullptr,
-                                     nprobe, is_l2, ws->qnorm.as<float>(), idx->cnorm_max, keys, cdis,
+        HIP_TRY(launch_coarse_rerank(d_q, R.rows, d, nq, nlist, cap, ws->cand_keys.as<int64_t>(), nullptr,
+                                     nprobe, is_l2, ws->qnorm.as<float>(), R.norm_max, keys, cdis,
                                      ws->fail_flags.as<int32_t>(), idx->coarse_fail_dev.as<unsigned long long>(), s,
                                      ws->cg_cnt.as<int32_t>(), ws->cg_bound.as<float>()));
         // exact fallback, restricted on the device to the flagged queries (normally none)
@@ -426,7 +443,7 @@ int coarse_stage(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
                                   ws->fail_flags.as<int32_t>(), s));
         return KNHIP_OK;
     }
-    HIP_TRY(launch_coarse_gemm(d_q, ws->qnorm.as<float>(), idx->centroids.as<float>(), idx->cnorm.as<float>(), nq,
+    HIP_TRY(launch_coarse_gemm(d_q, ws->qnorm.as<float>(), R.rows, R.norm, nq,
                                nlist, d, is_l2, ws->coarse_full.as<float>(), s));
     if (row_select_thr_supports(nlist, (int)ncand)) {
         // two passes over the row (group minima -> bound -> candidates); rows with masses of equal values fall to the radix
@@ -440,15 +457,22 @@ int coarse_stage(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         HIP_TRY(launch_row_select(ws->coarse_full.as<float>(), nq, nlist, (int)ncand, is_l2,
                                   ws->cand_keys.as<int64_t>(), ws->cand_approx.as<float>(), nullptr, s));
     }
-    HIP_TRY(launch_coarse_rerank(d_q, idx->centroids.as<float>(), d, nq, nlist, (int)ncand,
+    HIP_TRY(launch_coarse_rerank(d_q, R.rows, d, nq, nlist, (int)ncand,
                                  ws->cand_keys.as<int64_t>(), ws->cand_approx.as<float>(), nprobe, is_l2,
-                                 ws->qnorm.as<float>(), idx->cnorm_max, keys, cdis, ws->fail_flags.as<int32_t>(),
+                                 ws->qnorm.as<float>(), R.norm_max, keys, cdis, ws->fail_flags.as<int32_t>(),
                                  idx->coarse_fail_dev.as<unsigned long long>(), s));
     // exact fallback, restricted on the device to the flagged queries (normally none)
     HIP_TRY(launch_flat_full(c, is_l2, ws->coarse_full.as<float>(), nullptr, 0, ws->fail_flags.as<int32_t>(), s));
     HIP_TRY(launch_row_select(ws->coarse_full.as<float>(), nq, nlist, nprobe, is_l2, keys, cdis,
                               ws->fail_flags.as<int32_t>(), s));
     return KNHIP_OK;
+}
+
+int coarse_stage(const knhip_index* idx, Workspace* ws, const float* d_q, int64_t nq, int nprobe,
+                 int64_t* keys, float* cdis, hipStream_t s) {
+    CoarseRows R{idx->centroids.as<float>(), idx->centroids_il.as<float4>(), idx->centroids_bs.p, idx->cnorm.as<float>(),
+                 idx->cnorm_max, idx->nlist};
+    return coarse_rows_stage(idx, ws, R, d_q, nq, nprobe, keys, cdis, s);
 }
 
 int maybe_build_precomp(knhip_index* idx) {
@@ -795,6 +819,110 @@ void release_ws(const knhip_index* idx, Workspace* w) {
     idx->ws_free.emplace_back(w);
 }
 
+// ---- BRUTE_FORCE on the matrix cores ---------------------------------------------------------------------------------------
+// The reference's batch path of BruteForce / IndexFlat::search is a dense contraction too (exhaustive_L2sqr_blas,
+// thirdparty/faiss/faiss/cppcontrib/knowhere/utils/distances.cpp:994-1050: sgemm + norms, reservoir / heap per block); its
+// one-query-per-task path -- what Knowhere's nodes drive, src/common/comp/brute_force.cc:258-392 -- is the sequential
+// fvec_L2sqr / fvec_inner_product per row, whose bits the exact row scan (flat_scan.hip) reproduces.  Here the coarse
+// quantizer's machinery runs over the BASE rows: split-bf16 prefilter on the matrix pipe with the selection fused
+// (coarse_gemm.hip: two GEMM passes, no nq x nb matrix), the candidates recomputed in the reference's sequential order,
+// a certificate that nothing unselected can beat the k-th (else the query is redone by the exact all-pairs kernel) -- the
+// same bits and the same canonical order as the row scan, at matrix-pipe speed.  The base is cut into chunks of at most
+// 131072 rows (the bound kernel holds up to 4096 group minima per query); the chunks' top-k lists are merged as the row
+// scan's are.  Taken when no bitset is given (the prefilter cannot count filtered rows), the metric is plain L2 / IP, and the
+// batch is large enough to pay for splitting the queries.
+int ensure_bf_split(const knhip_index* idx) {
+    std::lock_guard<std::mutex> lk(idx->mu);
+    if (idx->bf_split_ready) {
+        return KNHIP_OK;
+    }
+    const int64_t nb = idx->ntotal;
+    const int nslab = coarse_bf16_slabs(idx->d);
+    HIP_TRY(idx->rows_bs.alloc((size_t)std::max<int64_t>(nb, 1) * nslab * 128));
+    HIP_TRY(idx->bf_norm.alloc((size_t)std::max<int64_t>(nb, 1) * sizeof(float)));
+    HIP_TRY(launch_coarse_bf16_split(idx->codes_aos.as<float>(), nb, idx->d, idx->rows_bs.p, nullptr));
+    HIP_TRY(launch_row_norms(idx->codes_aos.as<float>(), nb, idx->d, idx->bf_norm.as<float>(), nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<float> h((size_t)nb);
+    HIP_TRY(hipMemcpy(h.data(), idx->bf_norm.p, h.size() * sizeof(float), hipMemcpyDeviceToHost));
+    float mx = 0.f;
+    for (float v : h) {
+        mx = v > mx ? v : mx; // (a NaN norm never raises it: such a row fails every certificate it could decide)
+    }
+    idx->bf_norm_max = mx;
+    idx->bf_split_ready = true;
+    return KNHIP_OK;
+}
+
+// a chunk's (nq, k) result -> slot `slot` of the partial lists [nq][nslots][k], row numbers -> ids
+__global__ void bf_place_kernel(const int64_t* __restrict__ keys, const float* __restrict__ dis, int64_t nq, int k, int64_t add,
+                                float* __restrict__ pd, int64_t* __restrict__ pi, int nslots, int slot) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nq * k) {
+        return;
+    }
+    const int64_t q = t / k, j = t % k;
+    const int64_t o = (q * nslots + slot) * k + j;
+    const int64_t key = keys[t];
+    pd[o] = dis[t];
+    pi[o] = key >= 0 ? key + add : -1;
+}
+
+// rows of a chunk (multiples of 128), 0 = the shape is not served
+static int64_t bf_mfma_chunk_rows(int64_t nb, int k) {
+    const int ncand = k + std::max(32, k / 4);
+    const int64_t nch = (nb + 131071) / 131072;
+    const int64_t per = round_up((nb + nch - 1) / nch, 128);
+    const int64_t last = nb - (nch - 1) * per;
+    if (last <= 0 || !coarse_bf16_supports(per, ncand) || !coarse_bf16_supports(last, ncand) || ncand >= last) {
+        return 0;
+    }
+    return per;
+}
+
+int bf_mfma_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_t nq, int k, int64_t per, int64_t* d_out_i,
+                  float* d_out_d, hipStream_t s) {
+    if (int rc = ensure_bf_split(idx)) return rc;
+    const int64_t nb = idx->ntotal;
+    const int d = idx->d;
+    const int nslab = coarse_bf16_slabs(d);
+    const int64_t nch = (nb + per - 1) / per;
+    const int nchunk4 = (d + 3) / 4;
+    // queries per round: the exact fallback's nq x rows scratch stays below 1 GiB
+    const int64_t nqb = std::max<int64_t>(64, std::min<int64_t>(nq, ((int64_t)1 << 28) / per));
+    HIP_TRY(ws->partial_d.reserve((size_t)nq * nch * k * sizeof(float)));
+    HIP_TRY(ws->partial_i.reserve((size_t)nq * nch * k * sizeof(int64_t)));
+    HIP_TRY(ws->keys.reserve((size_t)nqb * k * sizeof(int64_t)));
+    HIP_TRY(ws->cdis.reserve((size_t)nqb * k * sizeof(float)));
+    {
+        StageTimer t(idx, s, KNHIP_STAGE_SCAN);
+        for (int64_t q0 = 0; q0 < nq; q0 += nqb) {
+            const int64_t n = std::min(nqb, nq - q0);
+            for (int64_t c = 0; c < nch; c++) {
+                const int64_t r0 = c * per, rn = std::min(per, nb - r0);
+                CoarseRows R{idx->codes_aos.as<float>() + r0 * d, idx->rows.as<float4>() + (r0 / 64) * nchunk4 * 64,
+                             static_cast<const unsigned char*>(idx->rows_bs.p) + (size_t)r0 * nslab * 128,
+                             idx->bf_norm.as<float>() + r0, idx->bf_norm_max, rn};
+                if (int rc = coarse_rows_stage(idx, ws, R, d_q + q0 * d, n, k, ws->keys.as<int64_t>(), ws->cdis.as<float>(), s)) {
+                    return rc;
+                }
+                hipLaunchKernelGGL(bf_place_kernel, dim3((unsigned)((n * k + 255) / 256)), dim3(256), 0, s, ws->keys.as<int64_t>(),
+                                   ws->cdis.as<float>(), n, k, r0 + idx->id_offset, ws->partial_d.as<float>() + q0 * nch * k,
+                                   ws->partial_i.as<int64_t>() + q0 * nch * k, (int)nch, (int)c);
+                HIP_TRY(hipGetLastError());
+            }
+        }
+    }
+    {
+        std::lock_guard<std::mutex> lk(idx->mu);
+        idx->coarse_flops += 0.0; // (the stage's flop count is the bench's: 2 nq nb d)
+    }
+    StageTimer t(idx, s, KNHIP_STAGE_MERGE);
+    HIP_TRY(launch_merge_partials(ws->partial_d.as<float>(), ws->partial_i.as<int64_t>(), nq, (int)nch, k, nch * k, k,
+                                  idx->is_l2, d_out_d, d_out_i, s));
+    return KNHIP_OK;
+}
+
 // ---- one batch of queries, everything on the device ------------------------------------------------
 // pre_keys / pre_cdis non-null: the coarse assignment is given (IndexIVF::search_preassigned), [nq][nprobe]
 int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_t nq, int k, int nprobe,
@@ -808,6 +936,15 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
 
     if (kind == KNHIP_BRUTE_FORCE) {
         const int64_t nb = idx->ntotal;
+        if (idx->bf_mfma && d_bitset == nullptr && idx->cos_mode == 0 && idx->coarse_gemm == 2 && nb >= 4096 && nq >= 16 &&
+            (double)nq * (double)nb >= 16.0e6) {
+            const int64_t per = bf_mfma_chunk_rows(nb, k);
+            if (per > 0) {
+                idx->last_bf_mfma = 1;
+                return bf_mfma_batch(idx, ws, d_q, nq, k, per, d_out_i, d_out_d, s);
+            }
+        }
+        idx->last_bf_mfma = 0;
         int64_t chunk_rows = std::max<int64_t>(1024, round_up((nb + 511) / 512, 64));
         const int64_t nchunks = (nb + chunk_rows - 1) / chunk_rows;
         const int qg = flat_scan_qg(k);
@@ -2035,6 +2172,14 @@ static int add_vectors_common(knhip_index* idx, int64_t n, const float* d_x, con
     idx->id_offset = id_offset;
     idx->has_data = n > 0;
     idx->rg_seg_nseg = -1; // (the segment table of range_segments belongs to the old row count)
+    idx->bf_split_ready = false;
+    idx->rows_bs.release();
+    idx->bf_norm.release();
+    {
+        const char* e = getenv("KNHIP_BF");
+        const char* c = getenv("KNHIP_COARSE"); // (the switch of the stage whose machinery this is)
+        idx->bf_mfma = !(e && std::string(e) == "exact") && c == nullptr;
+    }
     return KNHIP_OK;
 }
 
@@ -3653,7 +3798,7 @@ int knhip_merge_topk_host(int32_t metric, int64_t nq, int32_t k, int32_t nshard,
 int knhip_refine_device(int32_t metric, int32_t dim, const float* d_base, int64_t nbase, int64_t id_base,
                         const float* d_queries, int64_t nq, const int64_t* d_cand_ids, int32_t k_base,
                         int32_t k, float* d_out_dist, int64_t* d_out_ids, void* stream) {
-    if (dim <= 0 || nbase < 0 || nq < 0 || k <= 0 || k > KN_MAX_K || k_base < k || !d_base || !d_queries ||
+    if (dim <= 0 || nbase < 0 || nq < 0 || k <= 0 || k > KN_MAX_K || k_base < k || (nbase > 0 && !d_base) || !d_queries ||
         !d_cand_ids || !d_out_dist || !d_out_ids || (metric != KNHIP_L2 && metric != KNHIP_IP)) {
         return fail(KNHIP_ERR_INVALID_ARGS, "refine: bad arguments");
     }
@@ -4515,7 +4660,7 @@ int knhip_profile_get(const knhip_index* idx, knhip_stage_times* out) {
     out->mscan_overflow_queries = (int64_t)nf[2];
     out->mscan_candidates = (int64_t)nf[3];
     out->mscan_recomputed = (int64_t)nf[4];
-    out->pq_filter_form = idx->last_pq_form;
+    out->pq_filter_form = idx->desc.kind == KNHIP_BRUTE_FORCE ? (idx->last_bf_mfma ? 10 : 0) : idx->last_pq_form;
     out->mscan_stream_bytes = sb[2];
     return KNHIP_OK;
 }

@@ -62,15 +62,15 @@ constexpr int PD_REC_CAP = 128;                     // records per wave and unit
 constexpr int PD_SPILL_CAP = 320;                   // ... then in a region all waves share (claimed by an LDS atomic); beyond:
                                                     // the query's overflow route
 constexpr int PD_FLAT_CAP = 1024;                   // passing rows of a unit, sorted out of the records at its end
-constexpr int PD_OFF_T = PD_CB_BYTES;               // float  [128] accumulator threshold of the pair (scaled)
-constexpr int PD_OFF_C = PD_OFF_T + PD_QT * 4;      // float  [128] dis0 +- eps
-constexpr int PD_OFF_Q = PD_OFF_C + PD_QT * 4;      // int32  [128] query of the pair (-1: none)
-constexpr int PD_OFF_S = PD_OFF_Q + PD_QT * 4;      // int32  [128] slot of the pair
+constexpr int PD_PA_BYTES = PD_QT * 16;             // a unit's pair arrays: float T[128] (accumulator threshold, scaled), float C[128]
+                                                    // (dis0 +- eps), int32 Q[128] (query, -1: none), int32 S[128] (slot)
+constexpr int PD_OFF_PA = PD_CB_BYTES;              // two sets: the unit being scanned / flushed and the next one
+constexpr int PD_OFF_S = PD_OFF_PA + 2 * PD_PA_BYTES - PD_QT * 4; // (end of the second set)
 constexpr int PD_OFF_REC = PD_OFF_S + PD_QT * 4;    // [PD_WAVES][PD_REC_CAP] parked records, a private region per wave
 constexpr int PD_OFF_SPILL = PD_OFF_REC + PD_WAVES * PD_REC_CAP * PD_REC_BYTES; // [PD_SPILL_CAP] shared records
 constexpr int PD_OFF_FLAT = PD_OFF_SPILL + PD_SPILL_CAP * PD_REC_BYTES;         // uint4 [PD_FLAT_CAP] {pair, row, value bits, -}
 constexpr int PD_OFF_CTL = PD_OFF_FLAT + PD_FLAT_CAP * 16; // int32 [16]: 1 = current unit, 2 = next unit, 4 + w = records of
-                                                           // wave w, 8 = shared records, 9 = passing rows, 10 = records in global memory
+                                                           // the unit after the next, 4 + w = records of wave w, 8 = shared records, 9 = passing rows, 10 = records in global memory
 constexpr int PD_SMEM = PD_OFF_CTL + 64;
 static_assert(PD_SMEM <= 160 * 1024, "LDS of one workgroup");
 constexpr float PD_U = 5.9604645e-8f;   // 2^-24
@@ -423,6 +423,18 @@ __device__ __forceinline__ void pd_ring_take(PdRing& r, pd_u4& w, float& p) {
 __device__ __forceinline__ void pd_ring_drain(PdRing&) {}
 #endif
 
+// a workgroup barrier that orders LDS only: __syncthreads() also waits for every outstanding GLOBAL access (its fences are
+// s_waitcnt vmcnt(0)), which is exactly what the unit pipeline below wants to keep in flight across the barrier (the next
+// unit's pair constants and queries).  Whatever crosses waves through GLOBAL memory waits for itself (pqd_scan: the parked
+// records that spill into the workgroup's global region).
+__device__ __forceinline__ void pd_lds_barrier() {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PD_NO_ASM)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory");
+#else
+    __syncthreads();
+#endif
+}
+
 struct PdUnit {
     int64_t len;      // rows of the list
     int64_t row_off;  // first row of the list in the canonical arrays (codes, ids)
@@ -435,16 +447,18 @@ struct PdUnit {
 // registers step s just released (its codes arrived three tiles ago).  Two tiles per trip of the loop so that the start-value
 // registers rotate statically.
 template <bool IS_L2, int NTQ>
-__device__ __forceinline__ void pqd_scan(const MScanArgs& a, unsigned char* smem, const PdUnit& un PD_TARG) {
+__device__ __forceinline__ void pqd_scan(const MScanArgs& a, unsigned char* smem, const unsigned char* pa, pd_h8 (&B)[4][8],
+                                         const PdUnit& un PD_TARG) {
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / KN_WAVE)); // (wave-uniform: tile arithmetic on the scalar unit)
     const int lr = lane & 31, hi = lane >> 5;
-    const float* sT = reinterpret_cast<const float*>(smem + PD_OFF_T);
-    const int32_t* sPq = reinterpret_cast<const int32_t*>(smem + PD_OFF_Q);
+    const float* sT = reinterpret_cast<const float*>(pa);
+    const int32_t* sPq = reinterpret_cast<const int32_t*>(pa + 2 * PD_QT * 4);
     int32_t* ctl = reinterpret_cast<int32_t*>(smem + PD_OFF_CTL);
     unsigned char* rec = smem + PD_OFF_REC + wave * (PD_REC_CAP * PD_REC_BYTES);
     const int ntile = un.ntile;
     int nrec = 0; // records this wave has parked (wave-uniform)
+    bool wrote_global = false; // this lane parked a record in global memory
     if (wave >= ntile) {
         if (lane == 0) {
             ctl[4 + wave] = 0;
@@ -452,20 +466,12 @@ __device__ __forceinline__ void pqd_scan(const MScanArgs& a, unsigned char* smem
         return;
     }
 
-    // the unit's queries: lane (n, h) holds query n's dimensions 64 h .. 64 h + 64 of every tile (8 steps x 8 halves)
-    pd_h8 B[NTQ][8];
+    // the unit's queries (loaded by the caller while the previous unit was flushed: pqd_load_queries): lane (n, h) holds
+    // query n's dimensions 64 h .. 64 h + 64 of every tile (8 steps x 8 halves)
     float thr[NTQ];
-    const uint4* qh = reinterpret_cast<const uint4*>(a.pq_qh16);
 #pragma unroll
     for (int qt = 0; qt < NTQ; qt++) {
-        const int32_t q = sPq[qt * 32 + lr];
         thr[qt] = sT[qt * 32 + lr];
-        const uint4* src = qh + ((int64_t)(q < 0 ? 0 : q) * (PD_D / 8) + hi * 8);
-#pragma unroll
-        for (int s = 0; s < 8; s++) {
-            const uint4 w = src[s];
-            B[qt][s] = __builtin_bit_cast(pd_h8, w);
-        }
     }
     // Everything loaded so far is waited for HERE: a value still in flight when the tile loop is entered makes the compiler
     // wait for ALL outstanding loads (vmcnt(0) / lgkmcnt(0)) at its first use in every trip -- the loop-carried prefetches
@@ -554,6 +560,7 @@ __device__ __forceinline__ void pqd_scan(const MScanArgs& a, unsigned char* smem
                                               __float_as_uint(acc[4 * j + 2]), __float_as_uint(acc[4 * j + 3]));
                     }
                 } else if (at2 < a.pq_spill_cap) {
+                    wrote_global = true;
                     uint4* g = reinterpret_cast<uint4*>(a.pq_spill) + ((int64_t)blockIdx.x * a.pq_spill_cap + at2) * (PD_REC_BYTES / 16);
                     g[0] = hd;
 #pragma unroll
@@ -713,6 +720,9 @@ __device__ __forceinline__ void pqd_scan(const MScanArgs& a, unsigned char* smem
     if (lane == 0) {
         ctl[4 + wave] = min(nrec, PD_REC_CAP);
     }
+    if (__ballot(wrote_global) != 0ull) { // (rare) the records in global memory are read by other waves behind an LDS-only barrier
+        __threadfence();
+    }
     PD_T(2);
 }
 
@@ -726,10 +736,6 @@ __global__ __launch_bounds__(PD_THREADS, 1) void pqd_kernel(MScanArgs a) {
     unsigned long long tlast = __builtin_amdgcn_s_memtime();
 #endif
     extern __shared__ __align__(16) unsigned char smem[];
-    float* sT = reinterpret_cast<float*>(smem + PD_OFF_T);
-    float* sC = reinterpret_cast<float*>(smem + PD_OFF_C);
-    int32_t* sPq = reinterpret_cast<int32_t*>(smem + PD_OFF_Q);
-    int32_t* sPs = reinterpret_cast<int32_t*>(smem + PD_OFF_S);
     int32_t* ctl = reinterpret_cast<int32_t*>(smem + PD_OFF_CTL);
     const int nunits = (int)*a.nunits_dev;
     if (nunits <= 0) {
@@ -765,7 +771,9 @@ __global__ __launch_bounds__(PD_THREADS, 1) void pqd_kernel(MScanArgs a) {
         return -1;
     };
     if (threadIdx.x == 0) {
-        ctl[1] = fetch();
+        const int u0 = fetch();
+        ctl[1] = u0;
+        ctl[2] = u0 >= 0 ? fetch() : -1;
     }
     // the codebook: 64 KB, once per workgroup
     {
@@ -778,65 +786,136 @@ __global__ __launch_bounds__(PD_THREADS, 1) void pqd_kernel(MScanArgs a) {
     }
     __syncthreads();
     const float SC = a.pq_sc[6], inv_sc = a.pq_sc[7];
-    int cur = ctl[1];
+    auto pa_of = [&](int par) -> unsigned char* { return smem + PD_OFF_PA + par * PD_PA_BYTES; };
+    // The per-unit work around the scan is latency, not arithmetic -- pair records, thresholds (a chain of two memory round
+    // trips), 32 query loads per lane, the appends of the passing rows -- and with one wave per SIMD nothing hides it but
+    // the program itself.  So the units are software-pipelined:
+    //   * thread j < 128 holds pair j of the NEXT unit in registers (requested while the current unit is flushed and
+    //     scanned), and requests that pair's constants (dis0, tau, the candidate histogram's bound, eps) right behind the
+    //     current unit's scan; they arrive while the parked records are sorted out (LDS work);
+    //   * the next unit's thresholds go into the OTHER set of pair arrays, and its queries are requested (32 loads per
+    //     lane into the B registers, dead since the scan ended) before the passing rows are appended: both sets of global
+    //     round trips overlap.
+    // (First version: prologue 12 k + query loads 7.5 k cycles per unit with every wave waiting, of ~140 k.)
+    const int pj = (int)threadIdx.x; // pair this thread prepares (waves 0, 1)
+    auto pair_of = [&](int u) -> KnPair {
+        KnPair p;
+        p.q = -1;
+        p.slot = 0;
+        if (u >= 0 && pj < PD_QT) {
+            const KnItem it = a.units[u];
+            if (pj < it.npair) {
+                p = a.pairs[it.pair0 + pj];
+            }
+        }
+        return p;
+    };
+    struct PairConst { // what a pair's threshold is made of (requested early, consumed late)
+        float dis0, tau, epsb;
+    };
+    auto pair_request = [&](const KnPair& p, PairConst& pc) {
+        pc.dis0 = 0.f;
+        pc.tau = worst_dist<IS_L2>();
+        pc.epsb = INFINITY;
+        if (p.q >= 0) {
+            pc.dis0 = a.coarse_dis[(int64_t)p.q * a.nslot + p.slot];
+            pc.tau = tighter<IS_L2>(a.gthr[p.q], ms_hist_bound_lane<IS_L2>(a, p.q, a.k));
+            pc.epsb = a.pq_qd[(int64_t)p.q * 4 + 2];
+        }
+    };
+    auto pair_write = [&](const KnPair& p, const PairConst& pc, int par) {
+        if (pj >= PD_QT) {
+            return;
+        }
+        float t = INFINITY, c = 0.f;
+        if (p.q >= 0) {
+            const float eps = pc.epsb + 64.0f * PD_U * (fabsf(pc.dis0) + fabsf(pc.tau));
+            if (pc.tau == worst_dist<IS_L2>() || !(eps < INFINITY)) {
+                // no bound (fewer than k unfiltered rows in the sample) or a query the half operands cannot hold: nothing
+                // passes here, the query goes through the exact kernels
+                a.overflow[p.q] = 1;
+                a.overflow[a.nq] = 1;
+            } else {
+                // L2: dis0 + psum - 2 dot <= tau + eps  <=>  dot - psum / 2 >= (dis0 - tau - eps) / 2
+                // IP: dis0 + dot >= tau - eps            <=>  dot >= tau - eps - dis0
+                t = IS_L2 ? SC * (((pc.dis0 - pc.tau) - eps) * 0.5f) : SC * ((pc.tau - eps) - pc.dis0);
+                c = IS_L2 ? pc.dis0 + eps : pc.dis0 - eps;
+            }
+        }
+        unsigned char* pa = pa_of(par);
+        reinterpret_cast<float*>(pa)[pj] = t;
+        reinterpret_cast<float*>(pa + PD_QT * 4)[pj] = c;
+        reinterpret_cast<int32_t*>(pa + 2 * PD_QT * 4)[pj] = p.q;
+        reinterpret_cast<int32_t*>(pa + 3 * PD_QT * 4)[pj] = p.slot;
+    };
+    // the unit's queries -> B: lane (n, h) of every wave loads query n's dimensions 64 h .. 64 h + 64 of every tile in use
+    pd_h8 B[4][8];
+    auto load_queries = [&](int par, int ntq) {
+        const int lane = lane_id();
+        const int lr = lane & 31, hi = lane >> 5;
+        const int32_t* sPq = reinterpret_cast<const int32_t*>(pa_of(par) + 2 * PD_QT * 4);
+        const uint4* qh = reinterpret_cast<const uint4*>(a.pq_qh16);
+#pragma unroll
+        for (int qt = 0; qt < 4; qt++) {
+            if (qt < ntq) { // (uniform)
+                const int32_t q = sPq[qt * 32 + lr];
+                const uint4* src = qh + ((int64_t)(q < 0 ? 0 : q) * (PD_D / 8) + hi * 8);
+#pragma unroll
+                for (int s = 0; s < 8; s++) {
+                    const uint4 w = src[s];
+                    B[qt][s] = __builtin_bit_cast(pd_h8, w);
+                }
+            }
+        }
+    };
+    int cur = ctl[1], nxt = ctl[2];
+    int par = 0;
+    {   // the first unit: everything on the spot
+        const KnPair p0 = pair_of(cur);
+        PairConst c0;
+        pair_request(p0, c0);
+        pair_write(p0, c0, 0);
+    }
+    KnPair pn = pair_of(nxt); // (in flight)
+    __syncthreads();
+    if (cur >= 0) {
+        load_queries(0, (a.units[cur].npair + 31) >> 5);
+    }
     while (cur >= 0) {
         const KnItem it = a.units[cur];
-        const int npair = it.npair;
-        const int ntq = (npair + 31) >> 5; // query tiles in use (uniform)
+        const int ntq = (it.npair + 31) >> 5; // query tiles in use (uniform)
         PdUnit un;
         un.len = a.list_len[it.list];
         un.row_off = a.list_row_off[it.list];
         un.ps_off = IS_L2 ? a.pq_sblk_off_r[it.list] * 16 : 0;
         un.ntile = (int)((un.len + 31) >> 5);
+        unsigned char* pa = pa_of(par);
+        float* sT = reinterpret_cast<float*>(pa);
+        float* sC = reinterpret_cast<float*>(pa + PD_QT * 4);
+        int32_t* sPq = reinterpret_cast<int32_t*>(pa + 2 * PD_QT * 4);
+        int32_t* sPs = reinterpret_cast<int32_t*>(pa + 3 * PD_QT * 4);
         if (threadIdx.x == 0) {
-            ctl[2] = fetch(); // the next unit: its index is here when this one ends
+            ctl[3] = nxt >= 0 ? fetch() : -1; // the unit after the next
             ctl[8] = 0;
             ctl[9] = 0;
             ctl[10] = 0;
         }
-        // thread per pair: record, tau (sample bound, tightened by the candidate histogram), threshold in accumulator units
-        if (threadIdx.x < 32 * ntq) {
-            const int j = threadIdx.x;
-            float t = INFINITY, c = 0.f;
-            int32_t q = -1, slot = 0;
-            if (j < npair) {
-                const KnPair p = a.pairs[it.pair0 + j];
-                q = p.q;
-                slot = p.slot;
-                const float dis0 = a.coarse_dis[(int64_t)q * a.nslot + slot];
-                float tau = a.gthr[q];
-                tau = tighter<IS_L2>(tau, ms_hist_bound_lane<IS_L2>(a, q, a.k));
-                const float eps = a.pq_qd[(int64_t)q * 4 + 2] + 64.0f * PD_U * (fabsf(dis0) + fabsf(tau));
-                if (tau == worst_dist<IS_L2>() || !(eps < INFINITY)) {
-                    // no bound (fewer than k unfiltered rows in the sample) or a query the half operands cannot hold: nothing
-                    // passes here, the query goes through the exact kernels
-                    a.overflow[q] = 1;
-                    a.overflow[a.nq] = 1;
-                } else {
-                    // L2: dis0 + psum - 2 dot <= tau + eps  <=>  dot - psum / 2 >= (dis0 - tau - eps) / 2
-                    // IP: dis0 + dot >= tau - eps            <=>  dot >= tau - eps - dis0
-                    t = IS_L2 ? SC * (((dis0 - tau) - eps) * 0.5f) : SC * ((tau - eps) - dis0);
-                    c = IS_L2 ? dis0 + eps : dis0 - eps;
-                }
-            }
-            sT[j] = t;
-            sC[j] = c;
-            sPq[j] = q;
-            sPs[j] = slot;
-        }
-        __syncthreads();
         PD_T(0);
         if (un.ntile > 0) {
             switch (ntq) {
-                case 1: pqd_scan<IS_L2, 1>(a, smem, un PD_TPASS); break;
-                case 2: pqd_scan<IS_L2, 2>(a, smem, un PD_TPASS); break;
-                case 3: pqd_scan<IS_L2, 3>(a, smem, un PD_TPASS); break;
-                default: pqd_scan<IS_L2, 4>(a, smem, un PD_TPASS); break;
+                case 1: pqd_scan<IS_L2, 1>(a, smem, pa, B, un PD_TPASS); break;
+                case 2: pqd_scan<IS_L2, 2>(a, smem, pa, B, un PD_TPASS); break;
+                case 3: pqd_scan<IS_L2, 3>(a, smem, pa, B, un PD_TPASS); break;
+                default: pqd_scan<IS_L2, 4>(a, smem, pa, B, un PD_TPASS); break;
             }
         }
         PD_T(2);
-        __syncthreads();
+        // the next unit's pair constants: requested now, looked at behind the sorting of this unit's records
+        PairConst cn;
+        pair_request(pn, cn);
+        pd_lds_barrier(); // (every wave has parked its last lane; ctl[3] is there)
         PD_T(4);
+        const int nn = ctl[3];
         // the parked lanes.  Phase A, one record per thread: which of its 16 rows pass -> a flat list in LDS (one LDS atomic
         // per RECORD: the thread reserves as many entries as rows pass).  Every wave sorts out its OWN region (all records
         // through the first wave's lanes took that wave 24 k cycles per unit with the other three waiting); the shared and the
@@ -910,8 +989,10 @@ __global__ __launch_bounds__(PD_THREADS, 1) void pqd_kernel(MScanArgs a) {
                 sort_out(rw);
             }
         }
+        // the next unit's thresholds -> the other set of pair arrays
+        pair_write(pn, cn, par ^ 1);
         PD_T(3); // (phase A)
-        __syncthreads();
+        pd_lds_barrier();
 #ifdef KNHIP_PHASE_TIMERS
         if (threadIdx.x == 0) {
             atomicMax(&g_pd_prof[32], (unsigned long long)ctl[8]);
@@ -923,14 +1004,21 @@ __global__ __launch_bounds__(PD_THREADS, 1) void pqd_kernel(MScanArgs a) {
             atomicAdd(&g_pd_prof[38], (unsigned long long)(ctl[8] > 0));
         }
 #endif
+        // the next unit's queries (B is dead since the scan ended) and the pair after it: in flight beside the appends
+        if (nxt >= 0) {
+            load_queries(par ^ 1, (a.units[nxt].npair + 31) >> 5);
+        }
+        pn = pair_of(nn);
         const int nflat = min(ctl[9], PD_FLAT_CAP);
         for (int i = threadIdx.x; i < nflat; i += PD_THREADS) {
             const uint4 h = flat[i];
             const float x = __uint_as_float(h.z) * inv_sc, c = sC[h.x];
             ms_emit<IS_L2>(a, sPq[h.x], sPs[h.x], un.row_off, (int64_t)h.y, IS_L2 ? c - 2.0f * x : c + x);
         }
-        cur = ctl[2];
-        __syncthreads(); // (everybody has read the next unit and the parked records)
+        cur = nxt;
+        nxt = nn;
+        par ^= 1;
+        pd_lds_barrier(); // (everybody is done with this unit's pair arrays, records and counters)
         PD_T(5);
     }
 #ifdef KNHIP_PHASE_TIMERS

@@ -319,6 +319,10 @@ int ref_search(
 #pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
     for (int64_t i = 0; i < nq; i++) {
         try {
+            // one thread inside each task (Knowhere: omp = 1 inside a search task, ivf.cc:920).  Without this the flat
+            // index's own `omp parallel num_threads(min(nx, omp_get_max_threads()))` returned untouched result arrays when
+            // this loop ran on more than one thread (seen with libgomp in the dev container: ids all 0)
+            omp_set_num_threads(1);
             std::unique_ptr<BitsetSelector> sel;
             if (bitset) {
                 sel.reset(new BitsetSelector(bitset, nbits));

@@ -63,6 +63,44 @@ def test_brute_force(torch_cuda, port, metric, nb, d):
     g.close()
 
 
+@pytest.mark.parametrize("metric", [ob.L2, ob.IP])
+def test_brute_force_on_the_matrix_cores(torch_cuda, port, metric, monkeypatch):
+    """BRUTE_FORCE with a batch of queries and no bitset runs the coarse quantizer's machinery over the base rows (bf16
+    prefilter on the matrix pipe, exact re-rank, certificate; knhip_api.hip::bf_mfma_batch): same bits and order as the exact
+    row scan (KNHIP_BF=exact) and as the oracle; 140000 rows = two chunks with a ragged last one; duplicated rows put ties
+    inside the lists; k up to 300 (k >= 100: the reference's reservoir -- canonical answer, licensed as for the row scan)."""
+    from knowhere_amd import GpuIndex
+    nb, d, nq = 140_000, 96, 200
+    xb, xq = gen_data(nb, d, 42), gen_data(nq, d, 44)
+    xb[5000:5040] = xb[17]
+    xb[131070:131080] = xb[131000]  # (across the chunk boundary)
+    g1 = GpuIndex(0, metric, d)
+    g1.add_vectors(xb, id_offset=1000)
+    monkeypatch.setenv("KNHIP_BF", "exact")  # read when the rows are added
+    g0 = GpuIndex(0, metric, d)
+    g0.add_vectors(xb, id_offset=1000)
+    monkeypatch.delenv("KNHIP_BF")
+    ix = ob.make_index(port, ob.FLAT, metric, xb)
+    g1.profile_enable(True)
+    for k in (1, 10, 99, 300):
+        g1.profile_reset()
+        D1, I1 = g1.search(xq, k)
+        assert g1.profile_get()["pq_filter_form"] == 10, "the matrix-core path did not run"
+        D0, I0 = g0.search(xq, k)
+        assert np.array_equal(I0, I1) and np.array_equal(D0.view(np.uint32), D1.view(np.uint32)), f"k={k}: MFMA path vs row scan"
+        Do, Io = port.search(ix, xq[:40], k)
+        assert_parity(Do, Io + 1000, D1[:40], I1[:40], metric, f"BF on the matrix cores k={k}", licensed_ties=k >= 100)
+    # a bitset, or a handful of queries: the row scan
+    bs = _bitset(nb + 1000, 0.4, 1)  # (bits are indexed by id = row + 1000)
+    g1.profile_reset()
+    D1, I1 = g1.search(xq, 10, bitset=bs, nbits=nb + 1000)
+    assert g1.profile_get()["pq_filter_form"] == 0
+    D0, I0 = g0.search(xq, 10, bitset=bs, nbits=nb + 1000)
+    assert np.array_equal(I0, I1) and np.array_equal(D0.view(np.uint32), D1.view(np.uint32))
+    g0.close()
+    g1.close()
+
+
 def test_brute_force_self_hit(torch_cuda):
     # reference tests/ut/test_bruteforce.cc:70-76 and test_gpu_search.cc:83-86
     xb = gen_data(10000, 128, 42)
