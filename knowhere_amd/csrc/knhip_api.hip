@@ -769,7 +769,9 @@ int ensure_pqd(const knhip_index* idx) {
     HIP_TRY(idx->pqd_st.alloc(16 * sizeof(float)));
     const int64_t npsum = idx->is_l2 ? (int64_t)(idx->psum.bytes / sizeof(float)) - 4 : 0;
     if (npsum > 0) {
-        HIP_TRY(idx->psum_s.alloc((size_t)(npsum + 4) * sizeof(float)));
+        // (+ 64: the scan's last 32-row tile of the last list reads up to 16 entries past the list's 16-row blocks)
+        HIP_TRY(idx->psum_s.alloc((size_t)(npsum + 64) * sizeof(float)));
+        HIP_TRY(hipMemset(idx->psum_s.p, 0, (size_t)(npsum + 64) * sizeof(float)));
     }
     HIP_TRY(launch_pqd_index_prep(idx->cb.as<float4>(), idx->centroids.as<float>(), idx->nlist * (int64_t)idx->d,
                                   idx->pqd_cb16.p, idx->pqd_st.as<float>(),

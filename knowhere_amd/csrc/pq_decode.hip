@@ -69,8 +69,11 @@ constexpr int PD_OFF_S = PD_OFF_PA + 2 * PD_PA_BYTES - PD_QT * 4; // (end of the
 constexpr int PD_OFF_REC = PD_OFF_S + PD_QT * 4;    // [PD_WAVES][PD_REC_CAP] parked records, a private region per wave
 constexpr int PD_OFF_SPILL = PD_OFF_REC + PD_WAVES * PD_REC_CAP * PD_REC_BYTES; // [PD_SPILL_CAP] shared records
 constexpr int PD_OFF_FLAT = PD_OFF_SPILL + PD_SPILL_CAP * PD_REC_BYTES;         // uint4 [PD_FLAT_CAP] {pair, row, value bits, -}
-constexpr int PD_OFF_CTL = PD_OFF_FLAT + PD_FLAT_CAP * 16; // int32 [16]: 1 = current unit, 2 = next unit, 4 + w = records of
-                                                           // the unit after the next, 4 + w = records of wave w, 8 = shared records, 9 = passing rows, 10 = records in global memory
+constexpr int PD_OFF_CTL = PD_OFF_FLAT + PD_FLAT_CAP * 16; // int32 [16]: 1 = current unit, 2 = next unit, 3 = the unit after the
+                                                           // next, 4 + w = records of wave w; two sets of unit counters
+                                                           // (8 + 4 p: shared records, + 1: passing rows, + 2: records in global
+                                                           // memory) used by alternate units: the waves enter a unit's scan
+                                                           // without a barrier, so its counters are zeroed one unit ahead
 constexpr int PD_SMEM = PD_OFF_CTL + 64;
 static_assert(PD_SMEM <= 160 * 1024, "LDS of one workgroup");
 constexpr float PD_U = 5.9604645e-8f;   // 2^-24
@@ -447,8 +450,8 @@ struct PdUnit {
 // registers step s just released (its codes arrived three tiles ago).  Two tiles per trip of the loop so that the start-value
 // registers rotate statically.
 template <bool IS_L2, int NTQ>
-__device__ __forceinline__ void pqd_scan(const MScanArgs& a, unsigned char* smem, const unsigned char* pa, pd_h8 (&B)[4][8],
-                                         const PdUnit& un PD_TARG) {
+__device__ __forceinline__ void pqd_scan(const MScanArgs& a, unsigned char* smem, const unsigned char* pa, int32_t* cnt,
+                                         pd_h8 (&B)[4][8], const PdUnit& un PD_TARG) {
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / KN_WAVE)); // (wave-uniform: tile arithmetic on the scalar unit)
     const int lr = lane & 31, hi = lane >> 5;
@@ -546,9 +549,9 @@ __device__ __forceinline__ void pqd_scan(const MScanArgs& a, unsigned char* smem
                 const uint4 hd = make_uint4((uint32_t)(qt * 32 + lr), (uint32_t)(t * 32 + 4 * hi), 0u, 0u);
                 int at = -1, at2 = -1;
                 if (my >= PD_REC_CAP) { // (rare: the wave's own region is full -> the shared one -> the workgroup's global one)
-                    at = atomicAdd(&ctl[8], 1);
+                    at = atomicAdd(&cnt[0], 1);
                     if (at >= PD_SPILL_CAP) {
-                        at2 = atomicAdd(&ctl[10], 1);
+                        at2 = atomicAdd(&cnt[2], 1);
                     }
                 }
                 if (at < PD_SPILL_CAP) {
@@ -774,6 +777,9 @@ __global__ __launch_bounds__(PD_THREADS, 1) void pqd_kernel(MScanArgs a) {
         const int u0 = fetch();
         ctl[1] = u0;
         ctl[2] = u0 >= 0 ? fetch() : -1;
+        ctl[8] = 0; // (the first unit's counters; every later unit's are zeroed while the unit before it runs)
+        ctl[9] = 0;
+        ctl[10] = 0;
     }
     // the codebook: 64 KB, once per workgroup
     {
@@ -890,23 +896,27 @@ __global__ __launch_bounds__(PD_THREADS, 1) void pqd_kernel(MScanArgs a) {
         un.ps_off = IS_L2 ? a.pq_sblk_off_r[it.list] * 16 : 0;
         un.ntile = (int)((un.len + 31) >> 5);
         unsigned char* pa = pa_of(par);
+        int32_t* cnt = ctl + 8 + 4 * par; // this unit's counters
         float* sT = reinterpret_cast<float*>(pa);
         float* sC = reinterpret_cast<float*>(pa + PD_QT * 4);
         int32_t* sPq = reinterpret_cast<int32_t*>(pa + 2 * PD_QT * 4);
         int32_t* sPs = reinterpret_cast<int32_t*>(pa + 3 * PD_QT * 4);
         if (threadIdx.x == 0) {
+            // (the OTHER set of counters: last read before the barrier that ended the previous unit, next touched in the
+            // next unit's scan -- zeroing this unit's own here raced with waves already parking records in its scan)
+            int32_t* cz = ctl + 8 + 4 * (par ^ 1);
+            cz[0] = 0;
+            cz[1] = 0;
+            cz[2] = 0;
             ctl[3] = nxt >= 0 ? fetch() : -1; // the unit after the next
-            ctl[8] = 0;
-            ctl[9] = 0;
-            ctl[10] = 0;
         }
         PD_T(0);
         if (un.ntile > 0) {
             switch (ntq) {
-                case 1: pqd_scan<IS_L2, 1>(a, smem, pa, B, un PD_TPASS); break;
-                case 2: pqd_scan<IS_L2, 2>(a, smem, pa, B, un PD_TPASS); break;
-                case 3: pqd_scan<IS_L2, 3>(a, smem, pa, B, un PD_TPASS); break;
-                default: pqd_scan<IS_L2, 4>(a, smem, pa, B, un PD_TPASS); break;
+                case 1: pqd_scan<IS_L2, 1>(a, smem, pa, cnt, B, un PD_TPASS); break;
+                case 2: pqd_scan<IS_L2, 2>(a, smem, pa, cnt, B, un PD_TPASS); break;
+                case 3: pqd_scan<IS_L2, 3>(a, smem, pa, cnt, B, un PD_TPASS); break;
+                default: pqd_scan<IS_L2, 4>(a, smem, pa, cnt, B, un PD_TPASS); break;
             }
         }
         PD_T(2);
@@ -935,7 +945,7 @@ __global__ __launch_bounds__(PD_THREADS, 1) void pqd_kernel(MScanArgs a) {
             if (hm == 0u) {
                 return;
             }
-            int at = atomicAdd(&ctl[9], __popc(hm));
+            int at = atomicAdd(&cnt[1], __popc(hm));
             while (hm != 0u) {
                 const int r = __ffs((int)hm) - 1;
                 hm &= hm - 1u;
@@ -966,7 +976,7 @@ __global__ __launch_bounds__(PD_THREADS, 1) void pqd_kernel(MScanArgs a) {
         };
         if (un.ntile > 0) {
             const int wv = threadIdx.x / KN_WAVE, ln = threadIdx.x % KN_WAVE;
-            const int n_own = ctl[4 + wv], n_sh = min(ctl[8], PD_SPILL_CAP), n_gl = min(ctl[10], a.pq_spill_cap);
+            const int n_own = ctl[4 + wv], n_sh = min(cnt[0], PD_SPILL_CAP), n_gl = min(cnt[2], a.pq_spill_cap);
             for (int i = ln; i < n_own; i += KN_WAVE) {
                 uint32_t rw[PD_REC_BYTES / 4];
                 read_lds(smem + PD_OFF_REC + (wv * PD_REC_CAP + i) * PD_REC_BYTES, rw);
@@ -995,13 +1005,13 @@ __global__ __launch_bounds__(PD_THREADS, 1) void pqd_kernel(MScanArgs a) {
         pd_lds_barrier();
 #ifdef KNHIP_PHASE_TIMERS
         if (threadIdx.x == 0) {
-            atomicMax(&g_pd_prof[32], (unsigned long long)ctl[8]);
-            atomicMax(&g_pd_prof[33], (unsigned long long)ctl[10]);
-            atomicMax(&g_pd_prof[34], (unsigned long long)ctl[9]);
+            atomicMax(&g_pd_prof[32], (unsigned long long)cnt[0]);
+            atomicMax(&g_pd_prof[33], (unsigned long long)cnt[2]);
+            atomicMax(&g_pd_prof[34], (unsigned long long)cnt[1]);
             atomicAdd(&g_pd_prof[35], (unsigned long long)(ctl[4] + ctl[5] + ctl[6] + ctl[7]));
-            atomicAdd(&g_pd_prof[36], (unsigned long long)ctl[9]);
-            atomicAdd(&g_pd_prof[37], (unsigned long long)(ctl[10] > 0));
-            atomicAdd(&g_pd_prof[38], (unsigned long long)(ctl[8] > 0));
+            atomicAdd(&g_pd_prof[36], (unsigned long long)cnt[1]);
+            atomicAdd(&g_pd_prof[37], (unsigned long long)(cnt[2] > 0));
+            atomicAdd(&g_pd_prof[38], (unsigned long long)(cnt[0] > 0));
         }
 #endif
         // the next unit's queries (B is dead since the scan ended) and the pair after it: in flight beside the appends
@@ -1009,7 +1019,7 @@ __global__ __launch_bounds__(PD_THREADS, 1) void pqd_kernel(MScanArgs a) {
             load_queries(par ^ 1, (a.units[nxt].npair + 31) >> 5);
         }
         pn = pair_of(nn);
-        const int nflat = min(ctl[9], PD_FLAT_CAP);
+        const int nflat = min(cnt[1], PD_FLAT_CAP);
         for (int i = threadIdx.x; i < nflat; i += PD_THREADS) {
             const uint4 h = flat[i];
             const float x = __uint_as_float(h.z) * inv_sc, c = sC[h.x];
