@@ -274,7 +274,6 @@ struct MScanArgs {
     unsigned char* pq_spill;       // [pq_spill_wgs][pq_spill_cap] records of 80 bytes: where a workgroup parks passing lanes once its
     int32_t pq_spill_cap;          // LDS regions are full (a unit that is hot for many of its queries at once)
     int32_t pq_spill_wgs;          // workgroups the buffer serves (the launch takes no more)
-    int32_t pq_dbg;                // tools/prof build only (KNHIP_PHASE_TIMERS): experiment switches of pqd_kernel, else 0
 };
 
 // ---- pq_filter.hip ----

@@ -1529,9 +1529,6 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
                     }
                     HIP_TRY(ws->pq_spill.reserve((size_t)m.pq_spill_wgs * m.pq_spill_cap * 80));
                     m.pq_spill = static_cast<unsigned char*>(ws->pq_spill.p);
-                    if (const char* e = getenv("KNHIP_PQD_DBG")) { // (read by the tools/prof build of the kernel only)
-                        m.pq_dbg = atoi(e);
-                    }
                 }
             }
         }

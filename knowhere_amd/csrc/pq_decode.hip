@@ -461,6 +461,7 @@ __device__ __forceinline__ void pqd_scan(const MScanArgs& a, unsigned char* smem
     unsigned char* rec = smem + PD_OFF_REC + wave * (PD_REC_CAP * PD_REC_BYTES);
     const int ntile = un.ntile;
     int nrec = 0; // records this wave has parked (wave-uniform)
+    float sink = 0.f; // (experiment builds only)
     bool wrote_global = false; // this lane parked a record in global memory
     if (wave >= ntile) {
         if (lane == 0) {
@@ -526,19 +527,29 @@ __device__ __forceinline__ void pqd_scan(const MScanArgs& a, unsigned char* smem
         const uint4 both = make_uint4(e0.x, e0.y, e1.x, e1.y);
         A = __builtin_bit_cast(pd_h8, both);
     };
-#ifdef KNHIP_PHASE_TIMERS
-    const int dbg = a.pq_dbg; // 1: nothing ever passes; 2: no operand refill (no LDS gathers); 4: no loads in the loop
-#else
-    constexpr int dbg = 0;
+    // experiment knock-outs, COMPILE time (tools/build_pqd_variants.sh builds one library per mask; the results of such a
+    // build are wrong, its filter time says what the removed part costs): 1 = nothing ever passes; 2 = no operand refill (no
+    // LDS gathers, no address arithmetic); 4 = no loads in the loop; 8 = no compare at all; 16 = no start-value instruction
+#ifndef PD_EXP
+#define PD_EXP 0
 #endif
+    constexpr int dbg = PD_EXP;
     // One maximum per lane and query tile, one ballot.  A lane whose maximum passes PARKS its 16 accumulator values as they
     // are (a record of 80 bytes in the wave's own LDS region: no atomic, no round trip -- the count is a wave-uniform
     // register); which of the 16 rows passed is sorted out at the unit's end, one record per thread.  (The first version
     // picked the passing values apart on the spot: 1300 cycles per entry with the matrix pipe idle, 0.6 entries per tile.)
     auto compare = [&](const pd_f16& acc, int qt, int t) {
+        if (dbg & 8) { // (one operation that keeps the matrix instructions alive)
+            sink += acc[5];
+            return;
+        }
         const bool p = pd_max16(acc) >= thr[qt];
         const unsigned long long mask = __ballot(p);
-        if (__builtin_expect(mask != 0ull, 0) && !(dbg & 1)) {
+        if (dbg & 1) { // (the count keeps the compare alive)
+            nrec += __popcll(mask);
+            return;
+        }
+        if (__builtin_expect(mask != 0ull, 0)) {
             const int my = nrec + __popcll(mask & ((1ull << lane) - 1ull));
             nrec += __popcll(mask);
             if (p) {
@@ -625,7 +636,12 @@ __device__ __forceinline__ void pqd_scan(const MScanArgs& a, unsigned char* smem
         pd_u4 wn;
         float pn;
         // behind the slot's loads sit those of the other three slots
-        pd_ring_take<SLOT, NLD * (PD_RING - 1), IS_L2>(ring, wn, pn);
+        if (!(dbg & 4)) {
+            pd_ring_take<SLOT, NLD * (PD_RING - 1), IS_L2>(ring, wn, pn);
+        } else {
+            wn = pd_u4{0x01020304u * (uint32_t)(t & 31), 0x11121314u, 0x21222324u, 0x31323334u};
+            pn = 0.f;
+        }
 #ifdef PD_CHECK_RING
         {   // (debug build: the same tile through the compiler's own loads)
             const pd_rsrc dc = __builtin_amdgcn_make_buffer_rsrc(
@@ -666,7 +682,7 @@ __device__ __forceinline__ void pqd_scan(const MScanArgs& a, unsigned char* smem
                 decode_step(wn, s, A[s]);
             }
         }
-        if (IS_L2) {
+        if (IS_L2 && !(dbg & 16)) {
             pd_f16 z;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
@@ -679,7 +695,9 @@ __device__ __forceinline__ void pqd_scan(const MScanArgs& a, unsigned char* smem
             init = __builtin_amdgcn_mfma_f32_32x32x2f32(pn, one_lo, z, 0, 0, 0);
         }
         const int tn = min(t + (PD_RING + 1) * PD_WAVES, t_end);
-        pd_ring_load<SLOT, IS_L2>(ring, rc, voff_c, tn * (32 * PD_M), rp, voff_p, tn * (32 * 4));
+        if (!(dbg & 4)) {
+            pd_ring_load<SLOT, IS_L2>(ring, rc, voff_c, tn * (32 * PD_M), rp, voff_p, tn * (32 * 4));
+        }
 #ifdef PD_DRAIN_EACH
         pd_ring_drain(ring);
 #endif
@@ -721,7 +739,10 @@ __device__ __forceinline__ void pqd_scan(const MScanArgs& a, unsigned char* smem
         compare(acc[qt], qt, tl);
     }
     if (lane == 0) {
-        ctl[4 + wave] = min(nrec, PD_REC_CAP);
+        ctl[4 + wave] = (dbg & 9) ? 0 : min(nrec, PD_REC_CAP);
+    }
+    if ((dbg & 9) && (nrec == 0x7ffffff0 || sink == 1.2345e-30f)) { // (never: the experiment builds' counters stay alive)
+        a.overflow[a.nq] = 1;
     }
     if (__ballot(wrote_global) != 0ull) { // (rare) the records in global memory are read by other waves behind an LDS-only barrier
         __threadfence();
