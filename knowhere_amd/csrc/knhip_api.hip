@@ -231,6 +231,7 @@ struct knhip_index {
     int mscan = 2;
     bool flat_bf16 = true;    // KNHIP_MSCAN_FLAT=fp32: the IVF-Flat filter pass on the fp32 matrix instruction (round 2)
     int mscan_cap = 0;           // KNHIP_MSCAN_CAP: candidate capacity per query (0 = automatic; tests force the retry round)
+    int pqd_spill_cap = 0;       // KNHIP_PQD_SPILL: parked records per workgroup in global memory (0 = automatic; tests force the overflow route of pq_decode.hip)
     // BRUTE_FORCE on the matrix cores (the coarse quantizer's bf16 prefilter + exact re-rank + certificate over the base rows):
     // split bf16 operand rows + ||x||^2 per row, built on first use.  KNHIP_BF=exact keeps the exact row scan
     mutable bool bf_split_ready = false;
@@ -553,6 +554,8 @@ int build_list_layout(knhip_index* idx, const std::vector<int64_t>& list_off, co
         idx->flat_bf16 = !(mf && std::string(mf) == "fp32");
         const char* mc = getenv("KNHIP_MSCAN_CAP");
         idx->mscan_cap = (mc && *mc) ? std::max(0, atoi(mc)) : 0;
+        const char* psp = getenv("KNHIP_PQD_SPILL");
+        idx->pqd_spill_cap = (psp && *psp) ? std::max(0, atoi(psp)) : 0;
         idx->xnorm_ready = false;
         const char* pf = getenv("KNHIP_PQF");
         idx->pqf = (pf && pf[0] == '1') ? 2 : (pf && pf[0] == '0') ? 0 : 1;
@@ -1517,8 +1520,12 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
                     m.pq_qd = ws->ms_qd.as<float>();
                     m.pq_sc = idx->pqd_st.as<float>();
                     m.pq_psum_s = idx->psum_s.as<float>();
-                    // where a workgroup parks passing lanes beyond its LDS (8192 records of 80 bytes per workgroup, 168 MB: a list that is the closest list of many queries of the batch at once passes thousands of rows -- C3: up to 3300 in one unit, 5 % of the units leave the LDS regions)
-                    m.pq_spill_cap = 8192;
+                    // where a wave parks passing lanes beyond its LDS region (192 records): a list that is the closest list of many
+                    // queries of the batch at once passes thousands of rows (C3: up to 3300 in one unit)
+                    m.pq_spill_cap = 4 * 8192; // (per workgroup: 8192 records per wave, 671 MB of scratch at 256 workgroups)
+                    if (idx->pqd_spill_cap > 0) {
+                        m.pq_spill_cap = idx->pqd_spill_cap;
+                    }
                     m.pq_spill_wgs = 512;
                     {
                         int dev = 0, ncu = 0;

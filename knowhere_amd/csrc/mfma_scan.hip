@@ -1023,11 +1023,14 @@ __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, c
     //         the exact k-th of the candidates gathered so far is a tight bound (k unfiltered rows are at least that
     //         good) -> gthr, its list is emptied, flag 2; its pairs are then filtered again as one-query units.
     // pass 2: the retried queries (flag 2) are finished; one that overflowed again carries flag 1 (exact kernels).
+    // (flag 3 = flag 1 that pass 1 has counted: no candidates to retry with)
     const int flag = a.overflow[q];
     const bool retry_prep = pass == 1 && flag == 1;
     if ((pass == 1 && flag != 0 && flag != 1) || (pass == 2 && flag != 2)) {
-        if (pass == 2 && flag == 1 && tid == 0 && a.cand_cnt[q] >= a.cap) {
-            atomicAdd(counters + 1, 1ull); // overflowed again in the retry round: the exact kernels
+        if (pass == 2 && flag == 1 && tid == 0) {
+            // flagged again in the retry round (its candidate list, or the decode form's record regions, filled up once
+            // more): the exact kernels
+            atomicAdd(counters + 1, 1ull);
         }
         return;
     }
@@ -1209,6 +1212,7 @@ __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, c
     if (retry_prep && n < k) {
         if (tid == 0) {
             atomicAdd(counters + 1, 1ull);
+            a.overflow[q] = 3; // (flag 1, counted)
         }
         return; // no bound and nothing gathered: the exact kernels
     }
@@ -1406,7 +1410,8 @@ __global__ __launch_bounds__(MF_THREADS) void mscan_finish_kernel(MScanArgs a, c
                 a.cand_cnt[q] = 0;
                 a.overflow[q] = 2;
             } else {
-                atomicAdd(counters + 1, 1ull); // (stays flagged 1: the exact kernels)
+                atomicAdd(counters + 1, 1ull); // (the exact kernels; 3 = counted)
+                a.overflow[q] = 3;
             }
         }
         return;
@@ -1442,7 +1447,8 @@ __global__ void ms_flag_pairs_kernel(const int32_t* __restrict__ overflow, int w
         return;
     }
     const int64_t q = t / nprobe;
-    if (overflow[q] != want) {
+    const int flag = overflow[q];
+    if ((flag == 3 ? 1 : flag) != want) { // (3: flag 1 after the finish kernel's first pass counted it)
         return;
     }
     const int64_t key = keys[t];

@@ -56,25 +56,27 @@ constexpr int PD_D = 128;
 constexpr int PD_WAVES = 4;
 constexpr int PD_THREADS = PD_WAVES * KN_WAVE;
 constexpr int PD_CB_BYTES = PD_M * PD_KSUB * 8;     // 65536: [m][c][4 halves]
-constexpr int PD_RING = 4;                          // tiles the loads run ahead of the decode (which runs one tile ahead)
+constexpr int PD_RING = 8;                          // tiles the loads run ahead of the decode (which runs one tile ahead): the
+                                                    // loop runs at (memory latency) / PD_RING per tile or at its own pace,
+                                                    // whichever is SLOWER -- four slots held it at 1550 cycles per tile (2.6 us
+                                                    // of latency under load) against ~820 of matrix work
 constexpr int PD_REC_BYTES = 80;                    // a parked lane: {pair, first row, -, -} + its 16 accumulator values
-constexpr int PD_REC_CAP = 128;                     // records per wave and unit in the wave's own region ...
-constexpr int PD_SPILL_CAP = 320;                   // ... then in a region all waves share (claimed by an LDS atomic); beyond:
-                                                    // the query's overflow route
-constexpr int PD_FLAT_CAP = 1024;                   // passing rows of a unit, sorted out of the records at its end
+constexpr int PD_REC_CAP = 176;                     // records per wave and unit in the wave's LDS region; beyond: the wave's
+                                                    // region in global memory, beyond that the query's overflow route
+constexpr int PD_FLAT_CAP = 256;                    // passing rows of a unit, sorted out of the records at its end (more: appended on the spot)
+// LDS: the codebook, then one private area per WAVE (a wave runs its own units from start to end: no workgroup barrier
+// after the codebook is in place)
 constexpr int PD_PA_BYTES = PD_QT * 16;             // a unit's pair arrays: float T[128] (accumulator threshold, scaled), float C[128]
                                                     // (dis0 +- eps), int32 Q[128] (query, -1: none), int32 S[128] (slot)
-constexpr int PD_OFF_PA = PD_CB_BYTES;              // two sets: the unit being scanned / flushed and the next one
-constexpr int PD_OFF_S = PD_OFF_PA + 2 * PD_PA_BYTES - PD_QT * 4; // (end of the second set)
-constexpr int PD_OFF_REC = PD_OFF_S + PD_QT * 4;    // [PD_WAVES][PD_REC_CAP] parked records, a private region per wave
-constexpr int PD_OFF_SPILL = PD_OFF_REC + PD_WAVES * PD_REC_CAP * PD_REC_BYTES; // [PD_SPILL_CAP] shared records
-constexpr int PD_OFF_FLAT = PD_OFF_SPILL + PD_SPILL_CAP * PD_REC_BYTES;         // uint4 [PD_FLAT_CAP] {pair, row, value bits, -}
-constexpr int PD_OFF_CTL = PD_OFF_FLAT + PD_FLAT_CAP * 16; // int32 [16]: 1 = current unit, 2 = next unit, 3 = the unit after the
-                                                           // next, 4 + w = records of wave w; two sets of unit counters
-                                                           // (8 + 4 p: shared records, + 1: passing rows, + 2: records in global
-                                                           // memory) used by alternate units: the waves enter a unit's scan
-                                                           // without a barrier, so its counters are zeroed one unit ahead
-constexpr int PD_SMEM = PD_OFF_CTL + 64;
+constexpr int PD_W_PA = 0;                          // two sets: the unit being scanned / flushed and the next one
+constexpr int PD_W_REC = PD_W_PA + 2 * PD_PA_BYTES; // [PD_REC_CAP] parked records
+constexpr int PD_W_FLAT = PD_W_REC + PD_REC_CAP * PD_REC_BYTES; // uint4 [PD_FLAT_CAP] {pair, row, value bits, rank among the pair's rows}
+constexpr int PD_W_PCNT = PD_W_FLAT + PD_FLAT_CAP * 16;         // int32 [128] passing rows per pair, [128] the pair's first slot in its
+                                                                // query's candidate list (one reservation per pair and unit)
+constexpr int PD_W_CTL = PD_W_PCNT + 2 * PD_QT * 4;             // int32 [16]: 1 = passing rows, 2 = records in global memory
+constexpr int PD_W_BYTES = PD_W_CTL + 64;
+constexpr int PD_OFF_W = PD_CB_BYTES;
+constexpr int PD_SMEM = PD_OFF_W + PD_WAVES * PD_W_BYTES;
 static_assert(PD_SMEM <= 160 * 1024, "LDS of one workgroup");
 constexpr float PD_U = 5.9604645e-8f;   // 2^-24
 constexpr float PD_UH = 4.8828125e-4f;  // 2^-11
@@ -321,7 +323,8 @@ __device__ __forceinline__ float pd_max16(const pd_f16& v) {
 // round trip per tile -- where 2 (PD_RING - 1) loads may stay in flight.  And a load in inline ISA whose destination the
 // compiler manages does not work either: it believes the value is there when the instruction has been issued and moves it
 // around (seen: v_accvgpr_read of the destination right behind the load).  So the ring lives in NAMED accumulation registers
-// the compiler never sees -- a[236:255], at the far end of a file of which the kernel uses the first ~70; every statement
+// the compiler never sees -- a[216:255], at the far end of a file of which the kernel uses the first ~180 (checked at build
+// time: tools/check_pqd_ring.py); every statement
 // that touches them lists them as clobbered, which also puts them into the kernel's register count -- the loads are inline
 // ISA, and one statement waits (s_waitcnt vmcnt(N): at most N loads still in flight) and copies the slot into ordinary
 // registers.  Everything else in the loop that counts in vmcnt (the rare stores of the park path) is YOUNGER than the loads
@@ -329,9 +332,7 @@ __device__ __forceinline__ float pd_max16(const pd_f16& v) {
 // the ring in ordinary variables and take the builtin loads.
 typedef int pd_i4 __attribute__((ext_vector_type(4)));
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(PD_NO_ASM)
-#define PD_RING_CLOBBER                                                                                                      \
-    "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250",  \
-            "a251", "a252", "a253", "a254", "a255", "memory"
+#define PD_RING_CLOBBER "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255", "memory"
 struct PdRing {}; // (nothing: the slots are the named registers)
 // slot I <- 16 code bytes (+ the start value).  s_nop 4: the scalar offsets are computed right in front of this statement, and
 // a vector memory instruction that reads an SGPR needs five wait states behind the scalar instruction that wrote it -- the
@@ -339,7 +340,7 @@ struct PdRing {}; // (nothing: the slots are the named registers)
 // offset now and then: tiles scanned twice, tiles missed)
 template <int I, bool WITH_P>
 __device__ __forceinline__ void pd_ring_load(PdRing&, pd_i4 rc, int voff_c, int soff_c, pd_i4 rp, int voff_p, int soff_p) {
-    static_assert(I >= 0 && I < 4, "four slots");
+    static_assert(I >= 0 && I < PD_RING, "eight slots: codes a[216 + 4 I : 219 + 4 I], start value a[248 + I]");
 #define PD_LD(WREG, PREG)                                                                                                    \
     if (WITH_P) {                                                                                                            \
         asm volatile("s_nop 4\n\tbuffer_load_dwordx4 " WREG ", %0, %1, %2 offen\n\tbuffer_load_dword " PREG ", %3, %4, %5 offen" \
@@ -350,13 +351,21 @@ __device__ __forceinline__ void pd_ring_load(PdRing&, pd_i4 rc, int voff_c, int 
         asm volatile("s_nop 4\n\tbuffer_load_dwordx4 " WREG ", %0, %1, %2 offen" : : "v"(voff_c), "s"(rc), "s"(soff_c) : PD_RING_CLOBBER); \
     }
     if (I == 0) {
-        PD_LD("a[236:239]", "a252")
+        PD_LD("a[216:219]", "a248")
     } else if (I == 1) {
-        PD_LD("a[240:243]", "a253")
+        PD_LD("a[220:223]", "a249")
     } else if (I == 2) {
-        PD_LD("a[244:247]", "a254")
+        PD_LD("a[224:227]", "a250")
+    } else if (I == 3) {
+        PD_LD("a[228:231]", "a251")
+    } else if (I == 4) {
+        PD_LD("a[232:235]", "a252")
+    } else if (I == 5) {
+        PD_LD("a[236:239]", "a253")
+    } else if (I == 6) {
+        PD_LD("a[240:243]", "a254")
     } else {
-        PD_LD("a[248:251]", "a255")
+        PD_LD("a[244:247]", "a255")
     }
 #undef PD_LD
 }
@@ -384,13 +393,21 @@ __device__ __forceinline__ void pd_ring_take(PdRing&, pd_u4& w, float& p) {
                      : PD_RING_CLOBBER);                                                                                     \
     }
     if (I == 0) {
-        PD_TK("a236", "a237", "a238", "a239", "a252")
+        PD_TK("a216", "a217", "a218", "a219", "a248")
     } else if (I == 1) {
-        PD_TK("a240", "a241", "a242", "a243", "a253")
+        PD_TK("a220", "a221", "a222", "a223", "a249")
     } else if (I == 2) {
-        PD_TK("a244", "a245", "a246", "a247", "a254")
+        PD_TK("a224", "a225", "a226", "a227", "a250")
+    } else if (I == 3) {
+        PD_TK("a228", "a229", "a230", "a231", "a251")
+    } else if (I == 4) {
+        PD_TK("a232", "a233", "a234", "a235", "a252")
+    } else if (I == 5) {
+        PD_TK("a236", "a237", "a238", "a239", "a253")
+    } else if (I == 6) {
+        PD_TK("a240", "a241", "a242", "a243", "a254")
     } else {
-        PD_TK("a248", "a249", "a250", "a251", "a255")
+        PD_TK("a244", "a245", "a246", "a247", "a255")
     }
 #undef PD_TK
     w[0] = w0;
@@ -403,8 +420,8 @@ __device__ __forceinline__ void pd_ring_take(PdRing&, pd_u4& w, float& p) {
 __device__ __forceinline__ void pd_ring_drain(PdRing&) { asm volatile("s_waitcnt vmcnt(0)" : : : PD_RING_CLOBBER); }
 #else
 struct PdRing {
-    pd_u4 w[4];
-    float p[4];
+    pd_u4 w[PD_RING];
+    float p[PD_RING];
 };
 template <int I, bool WITH_P>
 __device__ __forceinline__ void pd_ring_load(PdRing& r, pd_i4 rc, int voff_c, int soff_c, pd_i4 rp, int voff_p, int soff_p) {
@@ -426,15 +443,14 @@ __device__ __forceinline__ void pd_ring_take(PdRing& r, pd_u4& w, float& p) {
 __device__ __forceinline__ void pd_ring_drain(PdRing&) {}
 #endif
 
-// a workgroup barrier that orders LDS only: __syncthreads() also waits for every outstanding GLOBAL access (its fences are
-// s_waitcnt vmcnt(0)), which is exactly what the unit pipeline below wants to keep in flight across the barrier (the next
-// unit's pair constants and queries).  Whatever crosses waves through GLOBAL memory waits for itself (pqd_scan: the parked
-// records that spill into the workgroup's global region).
-__device__ __forceinline__ void pd_lds_barrier() {
+// LDS written by lanes of a wave and read by OTHER lanes of the same wave (pair arrays, parked records, the flat list): the
+// LDS executes a wave's instructions in order, so all it takes is that the compiler keeps the order; the host pass and the
+// CPU emulation (one OS thread per lane) need a real rendezvous of the wave's lanes
+__device__ __forceinline__ void pd_wave_sync() {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(PD_NO_ASM)
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
 #else
-    __syncthreads();
+    (void)__ballot(1);
 #endif
 }
 
@@ -445,30 +461,24 @@ struct PdUnit {
     int ntile;        // ceil(len / 32)
 };
 
-// One unit with NTQ query tiles.  Every wave walks the 32-row tiles wave, wave + 4, ...  While tile t is multiplied (step
-// s = 16 dimensions: NTQ matrix instructions on NTQ different accumulators), step s of tile t + 4 is decoded into the operand
-// registers step s just released (its codes arrived three tiles ago).  Two tiles per trip of the loop so that the start-value
-// registers rotate statically.
+// One unit with NTQ query tiles: the wave walks the list's 32-row tiles 0, 1, ...  While tile t is multiplied (step
+// s = 16 dimensions: NTQ matrix instructions on NTQ different accumulators), step s of tile t + 1 is decoded into the operand
+// registers step s just released (its codes arrived three tiles ago).  Returns the number of lanes parked (wave-uniform;
+// those beyond PD_REC_CAP sit in the wave's global region, counted in ctl[2]).
 template <bool IS_L2, int NTQ>
-__device__ __forceinline__ void pqd_scan(const MScanArgs& a, unsigned char* smem, const unsigned char* pa, int32_t* cnt,
-                                         pd_h8 (&B)[4][8], const PdUnit& un PD_TARG) {
+__device__ __forceinline__ int pqd_scan(const MScanArgs& a, unsigned char* smem, unsigned char* wb, const unsigned char* pa,
+                                        int wslot, pd_h8 (&B)[4][8], const PdUnit& un PD_TARG) {
     const int lane = lane_id();
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / KN_WAVE)); // (wave-uniform: tile arithmetic on the scalar unit)
     const int lr = lane & 31, hi = lane >> 5;
     const float* sT = reinterpret_cast<const float*>(pa);
     const int32_t* sPq = reinterpret_cast<const int32_t*>(pa + 2 * PD_QT * 4);
-    int32_t* ctl = reinterpret_cast<int32_t*>(smem + PD_OFF_CTL);
-    unsigned char* rec = smem + PD_OFF_REC + wave * (PD_REC_CAP * PD_REC_BYTES);
+    int32_t* ctl = reinterpret_cast<int32_t*>(wb + PD_W_CTL);
+    unsigned char* rec = wb + PD_W_REC;
     const int ntile = un.ntile;
+    const int spill_cap = a.pq_spill_cap / PD_WAVES; // the wave's share of its workgroup's global region
     int nrec = 0; // records this wave has parked (wave-uniform)
     float sink = 0.f; // (experiment builds only)
     bool wrote_global = false; // this lane parked a record in global memory
-    if (wave >= ntile) {
-        if (lane == 0) {
-            ctl[4 + wave] = 0;
-        }
-        return;
-    }
 
     // the unit's queries (loaded by the caller while the previous unit was flushed: pqd_load_queries): lane (n, h) holds
     // query n's dimensions 64 h .. 64 h + 64 of every tile (8 steps x 8 halves)
@@ -552,30 +562,38 @@ __device__ __forceinline__ void pqd_scan(const MScanArgs& a, unsigned char* smem
         if (__builtin_expect(mask != 0ull, 0)) {
             const int my = nrec + __popcll(mask & ((1ull << lane) - 1ull));
             nrec += __popcll(mask);
-            if (p) {
+            if (__builtin_expect(nrec <= PD_REC_CAP, 1)) {
+                // (wave-uniform: every parked lane of this tile fits the LDS region -- no per-lane region logic)
+                if (p) {
+                    uint4* r = reinterpret_cast<uint4*>(rec + my * PD_REC_BYTES);
+                    r[0] = make_uint4((uint32_t)(qt * 32 + lr), (uint32_t)(t * 32 + 4 * hi), 0u, 0u);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        r[1 + j] = make_uint4(__float_as_uint(acc[4 * j]), __float_as_uint(acc[4 * j + 1]),
+                                              __float_as_uint(acc[4 * j + 2]), __float_as_uint(acc[4 * j + 3]));
+                    }
+                }
+            } else if (p) {
                 // (LDS and global memory are written through pointers of their OWN address space: a store through a pointer
                 // that may be either is a FLAT instruction, and with one of those possibly in flight the compiler waits for
                 // ALL outstanding loads and gathers -- vmcnt(0), lgkmcnt(0) -- at every join behind a compare: the first
                 // version of this path did that to every tile)
                 const uint4 hd = make_uint4((uint32_t)(qt * 32 + lr), (uint32_t)(t * 32 + 4 * hi), 0u, 0u);
-                int at = -1, at2 = -1;
-                if (my >= PD_REC_CAP) { // (rare: the wave's own region is full -> the shared one -> the workgroup's global one)
-                    at = atomicAdd(&cnt[0], 1);
-                    if (at >= PD_SPILL_CAP) {
-                        at2 = atomicAdd(&cnt[2], 1);
-                    }
+                int at2 = -1;
+                if (my >= PD_REC_CAP) { // (rare: the wave's LDS region is full -> its global one)
+                    at2 = atomicAdd(&ctl[2], 1);
                 }
-                if (at < PD_SPILL_CAP) {
-                    uint4* r = reinterpret_cast<uint4*>(at < 0 ? rec + my * PD_REC_BYTES : smem + PD_OFF_SPILL + at * PD_REC_BYTES);
+                if (at2 < 0) {
+                    uint4* r = reinterpret_cast<uint4*>(rec + my * PD_REC_BYTES);
                     r[0] = hd;
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         r[1 + j] = make_uint4(__float_as_uint(acc[4 * j]), __float_as_uint(acc[4 * j + 1]),
                                               __float_as_uint(acc[4 * j + 2]), __float_as_uint(acc[4 * j + 3]));
                     }
-                } else if (at2 < a.pq_spill_cap) {
+                } else if (at2 < spill_cap) {
                     wrote_global = true;
-                    uint4* g = reinterpret_cast<uint4*>(a.pq_spill) + ((int64_t)blockIdx.x * a.pq_spill_cap + at2) * (PD_REC_BYTES / 16);
+                    uint4* g = reinterpret_cast<uint4*>(a.pq_spill) + ((int64_t)wslot * spill_cap + at2) * (PD_REC_BYTES / 16);
                     g[0] = hd;
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
@@ -583,7 +601,7 @@ __device__ __forceinline__ void pqd_scan(const MScanArgs& a, unsigned char* smem
                                               __float_as_uint(acc[4 * j + 2]), __float_as_uint(acc[4 * j + 3]));
                     }
                 } else {
-                    // every region is full (thousands of parked lanes in one unit: a bound that lets a large part of the list
+                    // both regions are full (thousands of parked lanes in one unit: a bound that lets a large part of the list
                     // through): the query takes the overflow route of the candidate lists -- retried with the tighter bound
                     // of what it has gathered, else the exact kernels.  Exactness never rests on a capacity.
                     const int32_t q = sPq[qt * 32 + lr];
@@ -603,17 +621,21 @@ __device__ __forceinline__ void pqd_scan(const MScanArgs& a, unsigned char* smem
     pd_h8 A[8];
     pd_f16 acc[NTQ], init;
     constexpr int NLD = IS_L2 ? 2 : 1; // loads per tile
-    static_assert(PD_RING == 4, "the ring's named registers");
+    static_assert(PD_RING == 8, "the ring's named registers");
     {
-        // tile `wave` through slot 0, taken at once; then the ring: slot i <- tile (i + 1) of this wave
+        // tile 0 through slot 0, taken at once; then the ring: slot i <- tile i + 1
         pd_u4 w0;
         float p0;
-        pd_ring_load<0, IS_L2>(ring, rc, voff_c, min(wave, t_end) * (32 * PD_M), rp, voff_p, min(wave, t_end) * (32 * 4));
+        pd_ring_load<0, IS_L2>(ring, rc, voff_c, 0, rp, voff_p, 0);
         pd_ring_take<0, 0, IS_L2>(ring, w0, p0);
-        pd_ring_load<0, IS_L2>(ring, rc, voff_c, min(wave + 1 * PD_WAVES, t_end) * (32 * PD_M), rp, voff_p, min(wave + 1 * PD_WAVES, t_end) * (32 * 4));
-        pd_ring_load<1, IS_L2>(ring, rc, voff_c, min(wave + 2 * PD_WAVES, t_end) * (32 * PD_M), rp, voff_p, min(wave + 2 * PD_WAVES, t_end) * (32 * 4));
-        pd_ring_load<2, IS_L2>(ring, rc, voff_c, min(wave + 3 * PD_WAVES, t_end) * (32 * PD_M), rp, voff_p, min(wave + 3 * PD_WAVES, t_end) * (32 * 4));
-        pd_ring_load<3, IS_L2>(ring, rc, voff_c, min(wave + 4 * PD_WAVES, t_end) * (32 * PD_M), rp, voff_p, min(wave + 4 * PD_WAVES, t_end) * (32 * 4));
+        pd_ring_load<0, IS_L2>(ring, rc, voff_c, min(1, t_end) * (32 * PD_M), rp, voff_p, min(1, t_end) * (32 * 4));
+        pd_ring_load<1, IS_L2>(ring, rc, voff_c, min(2, t_end) * (32 * PD_M), rp, voff_p, min(2, t_end) * (32 * 4));
+        pd_ring_load<2, IS_L2>(ring, rc, voff_c, min(3, t_end) * (32 * PD_M), rp, voff_p, min(3, t_end) * (32 * 4));
+        pd_ring_load<3, IS_L2>(ring, rc, voff_c, min(4, t_end) * (32 * PD_M), rp, voff_p, min(4, t_end) * (32 * 4));
+        pd_ring_load<4, IS_L2>(ring, rc, voff_c, min(5, t_end) * (32 * PD_M), rp, voff_p, min(5, t_end) * (32 * 4));
+        pd_ring_load<5, IS_L2>(ring, rc, voff_c, min(6, t_end) * (32 * PD_M), rp, voff_p, min(6, t_end) * (32 * 4));
+        pd_ring_load<6, IS_L2>(ring, rc, voff_c, min(7, t_end) * (32 * PD_M), rp, voff_p, min(7, t_end) * (32 * 4));
+        pd_ring_load<7, IS_L2>(ring, rc, voff_c, min(8, t_end) * (32 * PD_M), rp, voff_p, min(8, t_end) * (32 * 4));
 #pragma unroll
         for (int s = 0; s < 8; s++) {
             decode_step(w0, s, A[s]);
@@ -625,10 +647,10 @@ __device__ __forceinline__ void pqd_scan(const MScanArgs& a, unsigned char* smem
         }
         init = IS_L2 ? __builtin_amdgcn_mfma_f32_32x32x2f32(p0, one_lo, z, 0, 0, 0) : z;
     }
-    // tile t (SLOT = the ring slot that holds tile t + 4's codes and start value): acc <- init + A x B, step by step (NTQ
+    // tile t (SLOT = the ring slot that holds tile t + 1's codes and start value): acc <- init + A x B, step by step (NTQ
     // matrix instructions on NTQ different accumulators per step); the operand registers of a step are refilled with tile
-    // t + 4's as soon as the step's instructions have been issued; at the end one fp32 matrix instruction spreads the next
-    // tile's start values over the accumulator layout (D[r][n] = P[r] * 1) and the slot is refilled with tile t + 20's.  The
+    // t + 1's as soon as the step's instructions have been issued; at the end one fp32 matrix instruction spreads the next
+    // tile's start values over the accumulator layout (D[r][n] = P[r] * 1) and the slot is refilled with tile t + 5's.  The
     // accumulators of the PREVIOUS tile tp are compared one query tile at a time right before step 0 overwrites them: the
     // compare of query tile qt + 1 runs while step 0 of query tile qt is in the matrix pipe.
     auto tile = [&](auto slot, int t, int tp, bool first) {
@@ -648,7 +670,7 @@ __device__ __forceinline__ void pqd_scan(const MScanArgs& a, unsigned char* smem
                     reinterpret_cast<void*>(((uint64_t)(uint32_t)rc[1] << 32) | (uint32_t)rc[0]), 0, rc[2], rc[3]);
             const pd_rsrc dp = __builtin_amdgcn_make_buffer_rsrc(
                     reinterpret_cast<void*>(((uint64_t)(uint32_t)rp[1] << 32) | (uint32_t)rp[0]), 0, rp[2], rp[3]);
-            const int tt = min(t + PD_WAVES, t_end);
+            const int tt = min(t + 1, t_end);
             const pd_u4 cw = __builtin_amdgcn_raw_buffer_load_b128(dc, voff_c, tt * (32 * PD_M), 0);
             const float cp = IS_L2 ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dp, voff_p, tt * (32 * 4), 0)) : 0.f;
             const bool bad = cw[0] != wn[0] || cw[1] != wn[1] || cw[2] != wn[2] || cw[3] != wn[3] ||
@@ -694,7 +716,7 @@ __device__ __forceinline__ void pqd_scan(const MScanArgs& a, unsigned char* smem
             asm volatile("" : "+v"(init));
             init = __builtin_amdgcn_mfma_f32_32x32x2f32(pn, one_lo, z, 0, 0, 0);
         }
-        const int tn = min(t + (PD_RING + 1) * PD_WAVES, t_end);
+        const int tn = min(t + PD_RING + 1, t_end);
         if (!(dbg & 4)) {
             pd_ring_load<SLOT, IS_L2>(ring, rc, voff_c, tn * (32 * PD_M), rp, voff_p, tn * (32 * 4));
         }
@@ -702,57 +724,61 @@ __device__ __forceinline__ void pqd_scan(const MScanArgs& a, unsigned char* smem
         pd_ring_drain(ring);
 #endif
     };
-    int t = wave, tl = wave;
+    int t = 0, tl = 0;
     bool first = true;
     PD_T(1);
     // (body i + 1 is reachable ONLY through body i: with every body behind its own `if (t < ntile)` the compiler must assume
     // a path that skips the bodies in front, on which a slot's load has fewer loads behind it, and waits accordingly --
     // vmcnt(1) instead of vmcnt(6))
+    // (written out: the optimizer refuses to unroll a loop of eight such bodies, and a slot number that is not a constant
+    // of the body cannot name registers)
+#define PD_TILE_BODY(I)                                        \
+    if (!done) {                                               \
+        tile(std::integral_constant<int, I>{}, t, tl, first);  \
+        first = false;                                         \
+        tl = t;                                                \
+        t += 1;                                                \
+        PD_COUNT(6, 1);                                        \
+        done = t >= ntile;                                     \
+    }
     for (;;) {
         bool done = false;
-#pragma unroll
-        for (int i = 0; i < PD_RING; i++) {
-            if (!done) {
-                if (i == 0) {
-                    tile(std::integral_constant<int, 0>{}, t, tl, first);
-                } else if (i == 1) {
-                    tile(std::integral_constant<int, 1>{}, t, tl, first);
-                } else if (i == 2) {
-                    tile(std::integral_constant<int, 2>{}, t, tl, first);
-                } else {
-                    tile(std::integral_constant<int, 3>{}, t, tl, first);
-                }
-                first = false;
-                tl = t;
-                t += PD_WAVES;
-                PD_COUNT(6, 1);
-                done = t >= ntile;
-            }
-        }
+        PD_TILE_BODY(0)
+        PD_TILE_BODY(1)
+        PD_TILE_BODY(2)
+        PD_TILE_BODY(3)
+        PD_TILE_BODY(4)
+        PD_TILE_BODY(5)
+        PD_TILE_BODY(6)
+        PD_TILE_BODY(7)
         if (done) {
             break;
         }
     }
+#undef PD_TILE_BODY
     pd_ring_drain(ring); // (the loads still in flight -- tiles past the end -- have landed)
 #pragma unroll
     for (int qt = 0; qt < NTQ; qt++) {
         compare(acc[qt], qt, tl);
     }
-    if (lane == 0) {
-        ctl[4 + wave] = (dbg & 9) ? 0 : min(nrec, PD_REC_CAP);
-    }
     if ((dbg & 9) && (nrec == 0x7ffffff0 || sink == 1.2345e-30f)) { // (never: the experiment builds' counters stay alive)
         a.overflow[a.nq] = 1;
     }
-    if (__ballot(wrote_global) != 0ull) { // (rare) the records in global memory are read by other waves behind an LDS-only barrier
+    if (__ballot(wrote_global) != 0ull) { // (rare) the records in global memory are read back by other lanes of this wave
         __threadfence();
     }
     PD_T(2);
+    return (dbg & 9) ? 0 : nrec;
 }
 
-// Persistent: one workgroup per CU keeps the codebook in LDS and pulls units in list order from its XCD's counter (the
-// units of one list run on one XCD, close in time: the second one finds the codes in that L2); LOOP: a fixed grid walks a
-// unit table whose size only the device knows (the retry round's one-query units).
+// Persistent: one workgroup per CU keeps the codebook in LDS; after that its four waves never meet again -- every WAVE
+// pulls its own units (a list x <= 128 of the queries that probe it) in list order from its XCD's counter (the units of one
+// list run on one XCD, close in time: the second one finds the codes in that L2) and takes each from its first tile to the
+// appends of its passing rows alone, with its own pair arrays, parked records and counters in LDS.  (Until the middle of round 6
+// the four waves shared a unit, tiles dealt round-robin: per unit 10 k cycles went to the wave that had parked the most
+// lanes, 15 k to barriers around the flush, and every fixed latency of a unit -- the first tile, the pair constants, the
+// queries, the appends -- was paid per 48 tiles of a wave instead of per 190.)  LOOP: a fixed grid walks a unit table whose
+// size only the device knows (the retry round's one-query units).
 template <bool IS_L2, bool LOOP>
 __global__ __launch_bounds__(PD_THREADS, 1) void pqd_kernel(MScanArgs a) {
 #ifdef KNHIP_PHASE_TIMERS
@@ -760,11 +786,15 @@ __global__ __launch_bounds__(PD_THREADS, 1) void pqd_kernel(MScanArgs a) {
     unsigned long long tlast = __builtin_amdgcn_s_memtime();
 #endif
     extern __shared__ __align__(16) unsigned char smem[];
-    int32_t* ctl = reinterpret_cast<int32_t*>(smem + PD_OFF_CTL);
     const int nunits = (int)*a.nunits_dev;
     if (nunits <= 0) {
         return;
     }
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / KN_WAVE));
+    const int wslot = (int)blockIdx.x * PD_WAVES + wave; // the wave's number in the launch (its global record region)
+    unsigned char* wb = smem + PD_OFF_W + wave * PD_W_BYTES;
+    int32_t* ctl = reinterpret_cast<int32_t*>(wb + PD_W_CTL);
     // unit source
     const int per = (nunits + 7) / 8;
     uint32_t xcc = 0;
@@ -772,36 +802,32 @@ __global__ __launch_bounds__(PD_THREADS, 1) void pqd_kernel(MScanArgs a) {
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     }
     const int xcd = (int)(xcc & 7u);
-    int fetch_t = 0;  // thread 0: counters [xcd, xcd + fetch_t) are known to be exhausted
-    int loop_u = (int)blockIdx.x;
-    auto fetch = [&]() -> int { // (thread 0 only)
+    int fetch_t = 0;  // lane 0: counters [xcd, xcd + fetch_t) are known to be exhausted
+    int loop_u = wslot;
+    auto fetch = [&]() -> int { // (wave-uniform result; lane 0 asks)
+        int u = -1;
         if (LOOP) {
-            const int u = loop_u;
-            loop_u += (int)gridDim.x;
-            return u < nunits ? u : -1;
+            u = loop_u < nunits ? loop_u : -1;
+            loop_u += (int)gridDim.x * PD_WAVES;
+            return u;
         }
-        while (fetch_t < 8) {
-            const int x = (xcd + fetch_t) & 7;
-            const int base = x * per;
-            const int cnt = min(per, nunits - base);
-            if (cnt > 0) {
-                const int i = atomicAdd(a.pq_ctr + x * 16, 1);
-                if (i < cnt) {
-                    return base + i;
+        if (lane == 0) {
+            while (fetch_t < 8) {
+                const int x = (xcd + fetch_t) & 7;
+                const int base = x * per;
+                const int cnt = min(per, nunits - base);
+                if (cnt > 0) {
+                    const int i = atomicAdd(a.pq_ctr + x * 16, 1);
+                    if (i < cnt) {
+                        u = base + i;
+                        break;
+                    }
                 }
+                fetch_t++;
             }
-            fetch_t++;
         }
-        return -1;
+        return __builtin_amdgcn_readfirstlane(u);
     };
-    if (threadIdx.x == 0) {
-        const int u0 = fetch();
-        ctl[1] = u0;
-        ctl[2] = u0 >= 0 ? fetch() : -1;
-        ctl[8] = 0; // (the first unit's counters; every later unit's are zeroed while the unit before it runs)
-        ctl[9] = 0;
-        ctl[10] = 0;
-    }
     // the codebook: 64 KB, once per workgroup
     {
         const uint4* src = reinterpret_cast<const uint4*>(a.pq_cb16);
@@ -811,74 +837,88 @@ __global__ __launch_bounds__(PD_THREADS, 1) void pqd_kernel(MScanArgs a) {
             dst[i] = src[i];
         }
     }
-    __syncthreads();
+    int cur = fetch();
+    int nxt = cur >= 0 ? fetch() : -1;
+    __syncthreads(); // (the only workgroup barrier: every wave passes it exactly once, whether or not it got a unit)
+    if (cur < 0) {
+        return;
+    }
     const float SC = a.pq_sc[6], inv_sc = a.pq_sc[7];
-    auto pa_of = [&](int par) -> unsigned char* { return smem + PD_OFF_PA + par * PD_PA_BYTES; };
+    auto pa_of = [&](int par) -> unsigned char* { return wb + PD_W_PA + par * PD_PA_BYTES; };
     // The per-unit work around the scan is latency, not arithmetic -- pair records, thresholds (a chain of two memory round
     // trips), 32 query loads per lane, the appends of the passing rows -- and with one wave per SIMD nothing hides it but
     // the program itself.  So the units are software-pipelined:
-    //   * thread j < 128 holds pair j of the NEXT unit in registers (requested while the current unit is flushed and
-    //     scanned), and requests that pair's constants (dis0, tau, the candidate histogram's bound, eps) right behind the
+    //   * lane j holds pairs j and j + 64 of the NEXT unit in registers (requested while the current unit is flushed and
+    //     scanned), and requests those pairs' constants (dis0, tau, the candidate histogram's bound, eps) right behind the
     //     current unit's scan; they arrive while the parked records are sorted out (LDS work);
     //   * the next unit's thresholds go into the OTHER set of pair arrays, and its queries are requested (32 loads per
     //     lane into the B registers, dead since the scan ended) before the passing rows are appended: both sets of global
     //     round trips overlap.
-    // (First version: prologue 12 k + query loads 7.5 k cycles per unit with every wave waiting, of ~140 k.)
-    const int pj = (int)threadIdx.x; // pair this thread prepares (waves 0, 1)
-    auto pair_of = [&](int u) -> KnPair {
-        KnPair p;
-        p.q = -1;
-        p.slot = 0;
-        if (u >= 0 && pj < PD_QT) {
+    struct Pairs2 {
+        KnPair p[2];
+    };
+    auto pair_of = [&](int u) -> Pairs2 {
+        Pairs2 r;
+        r.p[0].q = r.p[1].q = -1;
+        r.p[0].slot = r.p[1].slot = 0;
+        if (u >= 0) {
             const KnItem it = a.units[u];
-            if (pj < it.npair) {
-                p = a.pairs[it.pair0 + pj];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                if (lane + 64 * h < it.npair) {
+                    r.p[h] = a.pairs[it.pair0 + lane + 64 * h];
+                }
             }
         }
-        return p;
+        return r;
     };
     struct PairConst { // what a pair's threshold is made of (requested early, consumed late)
-        float dis0, tau, epsb;
+        float dis0[2], tau[2], epsb[2];
     };
-    auto pair_request = [&](const KnPair& p, PairConst& pc) {
-        pc.dis0 = 0.f;
-        pc.tau = worst_dist<IS_L2>();
-        pc.epsb = INFINITY;
-        if (p.q >= 0) {
-            pc.dis0 = a.coarse_dis[(int64_t)p.q * a.nslot + p.slot];
-            pc.tau = tighter<IS_L2>(a.gthr[p.q], ms_hist_bound_lane<IS_L2>(a, p.q, a.k));
-            pc.epsb = a.pq_qd[(int64_t)p.q * 4 + 2];
-        }
-    };
-    auto pair_write = [&](const KnPair& p, const PairConst& pc, int par) {
-        if (pj >= PD_QT) {
-            return;
-        }
-        float t = INFINITY, c = 0.f;
-        if (p.q >= 0) {
-            const float eps = pc.epsb + 64.0f * PD_U * (fabsf(pc.dis0) + fabsf(pc.tau));
-            if (pc.tau == worst_dist<IS_L2>() || !(eps < INFINITY)) {
-                // no bound (fewer than k unfiltered rows in the sample) or a query the half operands cannot hold: nothing
-                // passes here, the query goes through the exact kernels
-                a.overflow[p.q] = 1;
-                a.overflow[a.nq] = 1;
-            } else {
-                // L2: dis0 + psum - 2 dot <= tau + eps  <=>  dot - psum / 2 >= (dis0 - tau - eps) / 2
-                // IP: dis0 + dot >= tau - eps            <=>  dot >= tau - eps - dis0
-                t = IS_L2 ? SC * (((pc.dis0 - pc.tau) - eps) * 0.5f) : SC * ((pc.tau - eps) - pc.dis0);
-                c = IS_L2 ? pc.dis0 + eps : pc.dis0 - eps;
+    auto pair_request = [&](const Pairs2& pp, PairConst& pc) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const KnPair p = pp.p[h];
+            pc.dis0[h] = 0.f;
+            pc.tau[h] = worst_dist<IS_L2>();
+            pc.epsb[h] = INFINITY;
+            if (p.q >= 0) {
+                pc.dis0[h] = a.coarse_dis[(int64_t)p.q * a.nslot + p.slot];
+                pc.tau[h] = tighter<IS_L2>(a.gthr[p.q], ms_hist_bound_lane<IS_L2>(a, p.q, a.k));
+                pc.epsb[h] = a.pq_qd[(int64_t)p.q * 4 + 2];
             }
         }
-        unsigned char* pa = pa_of(par);
-        reinterpret_cast<float*>(pa)[pj] = t;
-        reinterpret_cast<float*>(pa + PD_QT * 4)[pj] = c;
-        reinterpret_cast<int32_t*>(pa + 2 * PD_QT * 4)[pj] = p.q;
-        reinterpret_cast<int32_t*>(pa + 3 * PD_QT * 4)[pj] = p.slot;
     };
-    // the unit's queries -> B: lane (n, h) of every wave loads query n's dimensions 64 h .. 64 h + 64 of every tile in use
+    auto pair_write = [&](const Pairs2& pp, const PairConst& pc, int par) {
+        unsigned char* pa = pa_of(par);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const KnPair p = pp.p[h];
+            const int pj = lane + 64 * h;
+            float t = INFINITY, c = 0.f;
+            if (p.q >= 0) {
+                const float eps = pc.epsb[h] + 64.0f * PD_U * (fabsf(pc.dis0[h]) + fabsf(pc.tau[h]));
+                if (pc.tau[h] == worst_dist<IS_L2>() || !(eps < INFINITY)) {
+                    // no bound (fewer than k unfiltered rows in the sample) or a query the half operands cannot hold: nothing
+                    // passes here, the query goes through the exact kernels
+                    a.overflow[p.q] = 1;
+                    a.overflow[a.nq] = 1;
+                } else {
+                    // L2: dis0 + psum - 2 dot <= tau + eps  <=>  dot - psum / 2 >= (dis0 - tau - eps) / 2
+                    // IP: dis0 + dot >= tau - eps            <=>  dot >= tau - eps - dis0
+                    t = IS_L2 ? SC * (((pc.dis0[h] - pc.tau[h]) - eps) * 0.5f) : SC * ((pc.tau[h] - eps) - pc.dis0[h]);
+                    c = IS_L2 ? pc.dis0[h] + eps : pc.dis0[h] - eps;
+                }
+            }
+            reinterpret_cast<float*>(pa)[pj] = t;
+            reinterpret_cast<float*>(pa + PD_QT * 4)[pj] = c;
+            reinterpret_cast<int32_t*>(pa + 2 * PD_QT * 4)[pj] = p.q;
+            reinterpret_cast<int32_t*>(pa + 3 * PD_QT * 4)[pj] = p.slot;
+        }
+    };
+    // the unit's queries -> B: lane (n, h) loads query n's dimensions 64 h .. 64 h + 64 of every tile in use
     pd_h8 B[4][8];
     auto load_queries = [&](int par, int ntq) {
-        const int lane = lane_id();
         const int lr = lane & 31, hi = lane >> 5;
         const int32_t* sPq = reinterpret_cast<const int32_t*>(pa_of(par) + 2 * PD_QT * 4);
         const uint4* qh = reinterpret_cast<const uint4*>(a.pq_qh16);
@@ -895,19 +935,16 @@ __global__ __launch_bounds__(PD_THREADS, 1) void pqd_kernel(MScanArgs a) {
             }
         }
     };
-    int cur = ctl[1], nxt = ctl[2];
     int par = 0;
     {   // the first unit: everything on the spot
-        const KnPair p0 = pair_of(cur);
+        const Pairs2 p0 = pair_of(cur);
         PairConst c0;
         pair_request(p0, c0);
         pair_write(p0, c0, 0);
     }
-    KnPair pn = pair_of(nxt); // (in flight)
-    __syncthreads();
-    if (cur >= 0) {
-        load_queries(0, (a.units[cur].npair + 31) >> 5);
-    }
+    Pairs2 pn = pair_of(nxt); // (in flight)
+    pd_wave_sync();
+    load_queries(0, (a.units[cur].npair + 31) >> 5);
     while (cur >= 0) {
         const KnItem it = a.units[cur];
         const int ntq = (it.npair + 31) >> 5; // query tiles in use (uniform)
@@ -917,43 +954,43 @@ __global__ __launch_bounds__(PD_THREADS, 1) void pqd_kernel(MScanArgs a) {
         un.ps_off = IS_L2 ? a.pq_sblk_off_r[it.list] * 16 : 0;
         un.ntile = (int)((un.len + 31) >> 5);
         unsigned char* pa = pa_of(par);
-        int32_t* cnt = ctl + 8 + 4 * par; // this unit's counters
         float* sT = reinterpret_cast<float*>(pa);
         float* sC = reinterpret_cast<float*>(pa + PD_QT * 4);
         int32_t* sPq = reinterpret_cast<int32_t*>(pa + 2 * PD_QT * 4);
         int32_t* sPs = reinterpret_cast<int32_t*>(pa + 3 * PD_QT * 4);
-        if (threadIdx.x == 0) {
-            // (the OTHER set of counters: last read before the barrier that ended the previous unit, next touched in the
-            // next unit's scan -- zeroing this unit's own here raced with waves already parking records in its scan)
-            int32_t* cz = ctl + 8 + 4 * (par ^ 1);
-            cz[0] = 0;
-            cz[1] = 0;
-            cz[2] = 0;
-            ctl[3] = nxt >= 0 ? fetch() : -1; // the unit after the next
+        int32_t* pcnt = reinterpret_cast<int32_t*>(wb + PD_W_PCNT);
+        int32_t* pbase = pcnt + PD_QT;
+        pcnt[lane] = 0;
+        pcnt[lane + 64] = 0;
+        if (lane == 0) {
+            ctl[1] = 0;
+            ctl[2] = 0;
         }
+        pd_wave_sync();
+        const int nn = nxt >= 0 ? fetch() : -1; // the unit after the next
         PD_T(0);
+        int nrec = 0;
         if (un.ntile > 0) {
             switch (ntq) {
-                case 1: pqd_scan<IS_L2, 1>(a, smem, pa, cnt, B, un PD_TPASS); break;
-                case 2: pqd_scan<IS_L2, 2>(a, smem, pa, cnt, B, un PD_TPASS); break;
-                case 3: pqd_scan<IS_L2, 3>(a, smem, pa, cnt, B, un PD_TPASS); break;
-                default: pqd_scan<IS_L2, 4>(a, smem, pa, cnt, B, un PD_TPASS); break;
+                case 1: nrec = pqd_scan<IS_L2, 1>(a, smem, wb, pa, wslot, B, un PD_TPASS); break;
+                case 2: nrec = pqd_scan<IS_L2, 2>(a, smem, wb, pa, wslot, B, un PD_TPASS); break;
+                case 3: nrec = pqd_scan<IS_L2, 3>(a, smem, wb, pa, wslot, B, un PD_TPASS); break;
+                default: nrec = pqd_scan<IS_L2, 4>(a, smem, wb, pa, wslot, B, un PD_TPASS); break;
             }
         }
         PD_T(2);
         // the next unit's pair constants: requested now, looked at behind the sorting of this unit's records
         PairConst cn;
         pair_request(pn, cn);
-        pd_lds_barrier(); // (every wave has parked its last lane; ctl[3] is there)
+        pd_wave_sync(); // (the last parked records are in LDS)
         PD_T(4);
-        const int nn = ctl[3];
-        // the parked lanes.  Phase A, one record per thread: which of its 16 rows pass -> a flat list in LDS (one LDS atomic
-        // per RECORD: the thread reserves as many entries as rows pass).  Every wave sorts out its OWN region (all records
-        // through the first wave's lanes took that wave 24 k cycles per unit with the other three waiting); the shared and the
-        // global regions go over all threads.  Phase B, one passing row per thread: the appends (global atomics with a
-        // returned slot), all in flight together.  (Appending straight from the records made a wave walk the 16 rows with
-        // some lane appending at nearly every step: 16 global round trips one after the other, 59 k cycles per unit.)
-        uint4* flat = reinterpret_cast<uint4*>(smem + PD_OFF_FLAT);
+        // the parked lanes.  Phase A, one record per lane: which of its 16 rows pass (and are not filtered) -> a flat list in
+        // LDS, each entry with its rank among the rows of its PAIR (LDS atomics).  Phase B: ONE reservation per pair in its
+        // query's candidate list (a global atomic with a returned slot, all pairs' in flight together, beside the loads of
+        // the rows' histogram origins), then one passing row per lane: candidate, pessimistic distance, histogram count --
+        // nothing that waits.  (One append per row -- ms_emit -- is a global round trip per 64 rows, one after the other: a
+        // unit with 460 passing rows spent 8 of them; appending straight from the records, a round trip per row.)
+        uint4* flat = reinterpret_cast<uint4*>(wb + PD_W_FLAT);
         auto sort_out = [&](const uint32_t (&rw)[PD_REC_BYTES / 4]) {
             const uint32_t pair = rw[0], row0 = rw[1];
             const float thq = sT[pair];
@@ -963,10 +1000,6 @@ __global__ __launch_bounds__(PD_THREADS, 1) void pqd_kernel(MScanArgs a) {
                 const uint32_t pos = row0 + (uint32_t)((r & 3) + 8 * (r >> 2));
                 hm |= (__uint_as_float(rw[4 + r]) >= thq && (int64_t)pos < un.len) ? (1u << r) : 0u;
             }
-            if (hm == 0u) {
-                return;
-            }
-            int at = atomicAdd(&cnt[1], __popc(hm));
             while (hm != 0u) {
                 const int r = __ffs((int)hm) - 1;
                 hm &= hm - 1u;
@@ -976,42 +1009,39 @@ __global__ __launch_bounds__(PD_THREADS, 1) void pqd_kernel(MScanArgs a) {
                     xb = r == r2 ? rw[4 + r2] : xb;
                 }
                 const uint32_t pos = row0 + (uint32_t)((r & 3) + 8 * (r >> 2));
+                if (a.bitset != nullptr && bitset_filtered(a.bitset, a.bitset_nbits, a.ids[un.row_off + (int64_t)pos])) {
+                    continue;
+                }
+                const int at = atomicAdd(&ctl[1], 1);
                 if (at < PD_FLAT_CAP) {
-                    flat[at] = make_uint4(pair, pos, xb, 0u);
+                    const int rank = atomicAdd(&pcnt[pair], 1);
+                    flat[at] = make_uint4(pair, pos, xb, (uint32_t)rank);
                 } else { // (more passing rows than the list holds: appended on the spot)
                     const float xs = __uint_as_float(xb) * inv_sc, c = sC[pair];
                     ms_emit<IS_L2>(a, sPq[pair], sPs[pair], un.row_off, (int64_t)pos, IS_L2 ? c - 2.0f * xs : c + xs);
                 }
-                at++;
             }
         };
-        auto read_lds = [&](const unsigned char* rp, uint32_t (&rw)[PD_REC_BYTES / 4]) {
+        if (nrec > 0) {
+            const int n_own = min(nrec, PD_REC_CAP), n_gl = min(ctl[2], a.pq_spill_cap / PD_WAVES);
+            for (int i = lane; i < n_own; i += KN_WAVE) {
+                uint32_t rw[PD_REC_BYTES / 4];
+                const unsigned char* rp = wb + PD_W_REC + i * PD_REC_BYTES;
 #pragma unroll
-            for (int j = 0; j < PD_REC_BYTES / 16; j++) {
-                const uint4 q4 = reinterpret_cast<const uint4*>(rp)[j];
-                rw[4 * j] = q4.x;
-                rw[4 * j + 1] = q4.y;
-                rw[4 * j + 2] = q4.z;
-                rw[4 * j + 3] = q4.w;
-            }
-        };
-        if (un.ntile > 0) {
-            const int wv = threadIdx.x / KN_WAVE, ln = threadIdx.x % KN_WAVE;
-            const int n_own = ctl[4 + wv], n_sh = min(cnt[0], PD_SPILL_CAP), n_gl = min(cnt[2], a.pq_spill_cap);
-            for (int i = ln; i < n_own; i += KN_WAVE) {
-                uint32_t rw[PD_REC_BYTES / 4];
-                read_lds(smem + PD_OFF_REC + (wv * PD_REC_CAP + i) * PD_REC_BYTES, rw);
+                for (int j = 0; j < PD_REC_BYTES / 16; j++) {
+                    const uint4 q4 = reinterpret_cast<const uint4*>(rp)[j];
+                    rw[4 * j] = q4.x;
+                    rw[4 * j + 1] = q4.y;
+                    rw[4 * j + 2] = q4.z;
+                    rw[4 * j + 3] = q4.w;
+                }
                 sort_out(rw);
             }
-            for (int i = threadIdx.x; i < n_sh; i += PD_THREADS) {
-                uint32_t rw[PD_REC_BYTES / 4];
-                read_lds(smem + PD_OFF_SPILL + i * PD_REC_BYTES, rw);
-                sort_out(rw);
-            }
-            // records in global memory were written by other waves of this workgroup a moment ago: read past the CU's vector
-            // cache (a line of this buffer may sit there from an earlier unit)
-            const uint32_t* gl = reinterpret_cast<const uint32_t*>(a.pq_spill) + (int64_t)blockIdx.x * a.pq_spill_cap * (PD_REC_BYTES / 4);
-            for (int i = threadIdx.x; i < n_gl; i += PD_THREADS) {
+            // records in global memory were written by lanes of this wave a moment ago: read past the CU's vector cache (a
+            // line of this buffer may sit there from an earlier unit)
+            const uint32_t* gl = reinterpret_cast<const uint32_t*>(a.pq_spill) +
+                                 (int64_t)wslot * (a.pq_spill_cap / PD_WAVES) * (PD_REC_BYTES / 4);
+            for (int i = lane; i < n_gl; i += KN_WAVE) {
                 uint32_t rw[PD_REC_BYTES / 4];
 #pragma unroll
                 for (int j = 0; j < PD_REC_BYTES / 4; j++) {
@@ -1023,16 +1053,14 @@ __global__ __launch_bounds__(PD_THREADS, 1) void pqd_kernel(MScanArgs a) {
         // the next unit's thresholds -> the other set of pair arrays
         pair_write(pn, cn, par ^ 1);
         PD_T(3); // (phase A)
-        pd_lds_barrier();
+        pd_wave_sync();
 #ifdef KNHIP_PHASE_TIMERS
-        if (threadIdx.x == 0) {
-            atomicMax(&g_pd_prof[32], (unsigned long long)cnt[0]);
-            atomicMax(&g_pd_prof[33], (unsigned long long)cnt[2]);
-            atomicMax(&g_pd_prof[34], (unsigned long long)cnt[1]);
-            atomicAdd(&g_pd_prof[35], (unsigned long long)(ctl[4] + ctl[5] + ctl[6] + ctl[7]));
-            atomicAdd(&g_pd_prof[36], (unsigned long long)cnt[1]);
-            atomicAdd(&g_pd_prof[37], (unsigned long long)(cnt[2] > 0));
-            atomicAdd(&g_pd_prof[38], (unsigned long long)(cnt[0] > 0));
+        if (lane == 0) {
+            atomicMax(&g_pd_prof[33], (unsigned long long)ctl[2]);
+            atomicMax(&g_pd_prof[34], (unsigned long long)ctl[1]);
+            atomicAdd(&g_pd_prof[35], (unsigned long long)nrec);
+            atomicAdd(&g_pd_prof[36], (unsigned long long)ctl[1]);
+            atomicAdd(&g_pd_prof[37], (unsigned long long)(ctl[2] > 0));
         }
 #endif
         // the next unit's queries (B is dead since the scan ended) and the pair after it: in flight beside the appends
@@ -1040,22 +1068,69 @@ __global__ __launch_bounds__(PD_THREADS, 1) void pqd_kernel(MScanArgs a) {
             load_queries(par ^ 1, (a.units[nxt].npair + 31) >> 5);
         }
         pn = pair_of(nn);
-        const int nflat = min(cnt[1], PD_FLAT_CAP);
-        for (int i = threadIdx.x; i < nflat; i += PD_THREADS) {
-            const uint4 h = flat[i];
-            const float x = __uint_as_float(h.z) * inv_sc, c = sC[h.x];
-            ms_emit<IS_L2>(a, sPq[h.x], sPs[h.x], un.row_off, (int64_t)h.y, IS_L2 ? c - 2.0f * x : c + x);
+        const int nflat = min(ctl[1], PD_FLAT_CAP);
+        if (nflat > 0) {
+            static_assert(PD_FLAT_CAP == 4 * KN_WAVE, "four rows per lane");
+            uint4 fe[4];
+            uint2 mt[4];
+#pragma unroll
+            for (int b = 0; b < 4; b++) { // the rows' histogram origins: requested first
+                const int i = lane + KN_WAVE * b;
+                fe[b] = make_uint4(0u, 0u, 0u, 0u);
+                mt[b] = make_uint2(0u, KN_HIST_OFF);
+                if (i < nflat) {
+                    fe[b] = flat[i];
+                    if (a.ghist != nullptr) {
+                        mt[b] = a.gmeta[sPq[fe[b].x]];
+                    }
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++) { // one reservation per pair
+                const int j = lane + 64 * h;
+                const int c = pcnt[j];
+                if (c > 0) {
+                    const int32_t q = sPq[j];
+                    const int base = atomicAdd(a.cand_cnt + q, c);
+                    pbase[j] = base;
+                    if (base + c > a.cap) {
+                        a.overflow[q] = 1;
+                        a.overflow[a.nq] = 1; // "some query overflowed": the fallback kernels return at once while this stays 0
+                    }
+                }
+            }
+            pd_wave_sync();
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int i = lane + KN_WAVE * b;
+                if (i < nflat) {
+                    const uint4 h = fe[b];
+                    const int32_t q = sPq[h.x];
+                    const float x = __uint_as_float(h.z) * inv_sc, c = sC[h.x];
+                    const float pess = IS_L2 ? c - 2.0f * x : c + x;
+                    const int n = pbase[h.x] + (int)h.w;
+                    if (n < a.cap) {
+                        a.cand[(int64_t)q * a.cap + n] = ((int64_t)sPs[h.x] << 32) | (int64_t)h.y;
+                        if (a.cand_pess != nullptr) {
+                            a.cand_pess[(int64_t)q * a.cap + n] = pess;
+                        }
+                    }
+                    if (mt[b].y != KN_HIST_OFF) {
+                        atomicAdd(a.ghist + (int64_t)q * KN_HIST_BINS + hist_bin(dist_key<IS_L2>(pess), mt[b].x, mt[b].y), 1u);
+                    }
+                }
+            }
         }
         cur = nxt;
         nxt = nn;
         par ^= 1;
-        pd_lds_barrier(); // (everybody is done with this unit's pair arrays, records and counters)
+        pd_wave_sync(); // (this unit's flat list and counters have been read)
         PD_T(5);
     }
 #ifdef KNHIP_PHASE_TIMERS
-    if (lane_id() == 0) {
+    if (lane == 0) {
         for (int i = 0; i < 8; i++) {
-            atomicAdd(&g_pd_prof[(threadIdx.x / KN_WAVE) * 8 + i], tacc[i]);
+            atomicAdd(&g_pd_prof[wave * 8 + i], tacc[i]);
         }
     }
 #endif
@@ -1089,7 +1164,8 @@ hipError_t launch_pqd(const MScanArgs& a, bool is_l2, int64_t units_bound, hipSt
             return e;
         }
     }
-    const int64_t grid = std::min<int64_t>(std::min<int64_t>(units_bound, ncu), a.pq_spill_wgs);
+    // (every wave runs its own units: four per workgroup)
+    const int64_t grid = std::min<int64_t>(std::min<int64_t>((units_bound + PD_WAVES - 1) / PD_WAVES, ncu), a.pq_spill_wgs);
 #ifdef KNHIP_PHASE_TIMERS
     static unsigned long long zero[40] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pd_prof), zero, sizeof(zero));
@@ -1103,9 +1179,9 @@ hipError_t launch_pqd(const MScanArgs& a, bool is_l2, int64_t units_bound, hipSt
         int64_t nu = -1;
         (void)hipMemcpy(&nu, a.nunits_dev, sizeof(nu), hipMemcpyDeviceToHost);
         fprintf(stderr, "[pqd timers] ring mismatches %llu\n", h[39]);
-        fprintf(stderr, "[pqd timers] launch unit_loop=%d units=%lld | max shared %llu max global %llu max flat %llu | private records %llu "
-                        "passing rows %llu | units with global %llu with shared %llu\n", (int)a.unit_loop, (long long)nu, h[32], h[33], h[34],
-                h[35], h[36], h[37], h[38]);
+        fprintf(stderr, "[pqd timers] launch unit_loop=%d units=%lld | max global %llu max flat %llu | parked lanes %llu "
+                        "passing rows %llu | units with global records %llu\n", (int)a.unit_loop, (long long)nu, h[33], h[34],
+                h[35], h[36], h[37]);
     }
     if (!a.unit_loop) {
         fprintf(stderr, "[pqd timers] ticks per workgroup (grid %lld): wave | prologue  operands  tiles  flush-A  end-barrier  flush-B+barriers | "

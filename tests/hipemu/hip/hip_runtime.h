@@ -188,6 +188,7 @@ void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()
     hipemu::launch((grid), (block), (size_t)(smem), [&]() { (kern)(__VA_ARGS__); })
 
 inline void __syncthreads() { hipemu::tl.g->bar.arrive_and_wait(); }
+inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 
 // ---- cross-lane ---------------------------------------------------------------------------------------------------
 template <class T>

@@ -166,6 +166,29 @@ def test_pqf_retry_round(torch_cuda, port, monkeypatch, metric):
     g1.close()
 
 
+def test_pqd_parked_records_overflow_route(torch_cuda, port, monkeypatch):
+    """decode form (pq_decode.hip): a wave parks passing lanes in 192 LDS records, then in its share of a global region; when
+    both are full the lane's query takes the overflow route (retry with the bound of what it gathered, else the exact
+    kernels).  KNHIP_PQD_SPILL=4 leaves one global record per wave, k = 100 on isotropic data with the guard off lets
+    hundreds of rows of a list pass: the route is taken by most queries and the answer stays the oracle's."""
+    if FORM["v"] != "decode":
+        pytest.skip("the decode form's record regions")
+    nb, d = 120000, 128
+    xb, xq = gen_data(nb, d, 42), gen_data(300, d, 44)
+    ix = finish_ivfpq(port, ob.make_index(port, ob.IVF_PQ, ob.L2, xb, nlist=40, M=32))
+    monkeypatch.setenv("KNHIP_PQD_SPILL", "4")
+    g0, g1 = _pair(monkeypatch, ix, guard=False)
+    monkeypatch.delenv("KNHIP_PQD_SPILL")
+    for k, nprobe in ((100, 8), (10, 4), (128, 40)):
+        p = _check(port, ix, g0, g1, xq, k, nprobe, ob.L2, f"record overflow k={k} nprobe={nprobe}")
+        assert p["mscan_queries"] + p["mscan_overflow_queries"] == len(xq)
+    assert p["mscan_overflow_queries"] > 0, "the overflow route was not taken"
+    bs = _bitset(nb, 0.5, 3)
+    _check(port, ix, g0, g1, xq, 100, 8, ob.L2, "record overflow + bitset", bs, nb)
+    g0.close()
+    g1.close()
+
+
 def test_pqf_headline_shape_long_lists(torch_cuda, port, monkeypatch):
     """d = 128, m = 32, lists of ~3000 codes (many windows per wave), batch large enough for full 8-query units"""
     nb, d = 200000, 128

@@ -1,15 +1,15 @@
 """tools/check_pqd_ring.py <pq_decode.s> -- build-time check of pq_decode.hip's hand-managed registers.
 
-The tile loop keeps its ring of loads in NAMED accumulation registers a[236:255] that only inline ISA touches (the compiler
+The tile loop keeps its ring of loads in NAMED accumulation registers a[216:255] that only inline ISA touches (the compiler
 cannot follow loads that turn by name through an unrolled loop; pq_decode.hip, "the ring loads").  Every ring statement
 lists them as clobbered, which keeps the compiler from holding a value in them ACROSS such a statement -- but nothing keeps
 it from using them for a value that lives BETWEEN two statements, which would silently destroy a slot.  It has no reason to
-while it needs fewer than 236 accumulation registers; this script makes the build fail the day it does: no instruction
-outside the inline-ISA blocks of a pqd_kernel may name a236 .. a255."""
+while it needs fewer than 216 accumulation registers; this script makes the build fail the day it does: no instruction
+outside the inline-ISA blocks of a pqd_kernel may name a216 .. a255."""
 import re
 import sys
 
-RING_LO = 236
+RING_LO = 216
 src = open(sys.argv[1]).read().split("\n")
 fn, inasm, bad, hi = None, False, [], {}
 for n, l in enumerate(src, 1):
