@@ -59,8 +59,46 @@ void run(const char* name) {
     hipFree(ticks);
 }
 
+// the same stream for several milliseconds, timed from outside: the rate a whole chip of matrix pipes SUSTAINS (ticks of
+// s_memtime follow the shader clock; wall time shows what that clock was)
+template <int NACC>
+void run_long(const char* name, int iters) {
+    float* out;
+    unsigned long long* ticks;
+    hipMalloc(&out, 256 * 256 * 4);
+    hipMalloc(&ticks, 256 * 8);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k<NACC, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    k<NACC, 0><<<256, 256, 100 * 1024>>>(out, ticks, 200); // warm
+    for (int rep = 0; rep < 3; rep++) {
+        hipEventRecord(e0);
+        k<NACC, 0><<<256, 256, 100 * 1024>>>(out, ticks, iters);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        unsigned long long h[256];
+        hipMemcpy(h, ticks, sizeof(h), hipMemcpyDeviceToHost);
+        double s = 0;
+        for (int i = 0; i < 256; i++) s += (double)h[i];
+        const double n = (double)iters * 8.0 * NACC; // matrix instructions per wave
+        printf("%s long NACC=%d: %.2f ms, %.1f ticks per MFMA, %.2f ns per MFMA = %.2f GHz at 32 cycles each, %.0f TFLOP/s on 1024 pipes\n",
+               name, NACC, ms, s / 256 / n, ms * 1e6 / n, 32.0 / (ms * 1e6 / n), 1024.0 * n * 32768.0 / (ms * 1e-3) / 1e12);
+    }
+    hipFree(out);
+    hipFree(ticks);
+}
+
 int main(int argc, char** argv) {
     const char* name = argc > 1 ? argv[1] : "?";
+    if (argc > 2) {
+        run_long<3>(name, 3000);   // ~1 ms
+        run_long<3>(name, 15000);  // ~5 ms
+        run_long<3>(name, 60000);  // ~20 ms
+        return 0;
+    }
     run<1, 0>(name);
     run<2, 0>(name);
     run<3, 0>(name);
