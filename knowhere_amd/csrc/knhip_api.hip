@@ -148,7 +148,9 @@ struct Workspace {
     // side stream of the IVF-PQ prefilter: the grouping of the pairs by list (work table) runs beside the sample pass
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int32_t* h_word = nullptr; // pinned: small counts read back inside a search (a pageable destination is staged by the runtime)
     ~Workspace() {
+        if (h_word) (void)hipHostFree(h_word);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
         if (side) (void)hipStreamDestroy(side);
@@ -3269,9 +3271,12 @@ static int search_batch_ties(const knhip_index* idx, Workspace* ws, const float*
     int32_t* nflag_dev = flagged + nq;
     HIP_TRY(hipMemsetAsync(nflag_dev, 0, sizeof(int32_t), s));
     HIP_TRY(launch_tie_detect(ws->tie_d.as<float>(), ws->tie_i.as<int64_t>(), nq, k, d_out_d, d_out_i, flagged, nflag_dev, s));
-    int32_t nflag = 0;
-    HIP_TRY(hipMemcpyAsync(&nflag, nflag_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (ws->h_word == nullptr) {
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ws->h_word), 16 * sizeof(int32_t)));
+    }
+    HIP_TRY(hipMemcpyAsync(ws->h_word, nflag_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    const int32_t nflag = ws->h_word[0];
     if (trace) fprintf(stderr, "[ties] flagged %d\n", nflag);
     if (nflag <= 0) {
         return KNHIP_OK;

@@ -72,7 +72,8 @@ class IndexData:
 
     @property
     def code_size(self):
-        return {FLAT: self.d * 4, IVF_FLAT: self.d * 4, IVF_PQ: self.M, IVF_SQ8: self.d}[self.kind]
+        # (IVF_PQ: the reference's code bytes -- M indices of nbits bits as a little-endian bit string, ProductQuantizer.cpp:69)
+        return {FLAT: self.d * 4, IVF_FLAT: self.d * 4, IVF_PQ: (self.M * self.nbits + 7) // 8, IVF_SQ8: self.d}[self.kind]
 
     @property
     def ntotal(self):
@@ -458,17 +459,18 @@ class Port(_SimdTable):
                             C.c_int(1 if spherical else 0), _p(cen, _f32p))
         return cen
 
-    def train_ivf(self, kind, metric, x, nlist, M=0, niter=0, max_points=256, seed=1234, centroids=None):
+    def train_ivf(self, kind, metric, x, nlist, M=0, niter=0, max_points=256, seed=1234, centroids=None, nbits=8):
         """-> (centroids, pq_centroids or None, sq_trained or None); niter 0 = the level-1 quantizer's default (10)"""
         x = np.ascontiguousarray(x, np.float32)
         n, d = x.shape
         given = centroids is not None
         cen = np.ascontiguousarray(centroids, np.float32).copy() if given else np.empty((nlist, d), np.float32)
-        pq = np.empty((max(M, 1), 256, d // max(M, 1)), np.float32) if kind == IVF_PQ else None
+        pq = np.empty((max(M, 1), 1 << nbits, d // max(M, 1)), np.float32) if kind == IVF_PQ else None
         sq = np.empty(2 * d, np.float32) if kind == IVF_SQ8 else None
-        self.lib.orc_train_ivf(C.c_int(kind), C.c_int(metric), C.c_int(d), C.c_int64(nlist), C.c_int(max(M, 1)),
-                               C.c_int64(n), _p(x, _f32p), C.c_int(niter), C.c_int(max_points), C.c_int64(seed),
-                               C.c_int(1 if given else 0), _p(cen, _f32p), _p(pq, _f32p), _p(sq, _f32p))
+        self.lib.orc_train_ivf_nbits(C.c_int(kind), C.c_int(metric), C.c_int(d), C.c_int64(nlist), C.c_int(max(M, 1)),
+                                     C.c_int(nbits), C.c_int64(n), _p(x, _f32p), C.c_int(niter), C.c_int(max_points),
+                                     C.c_int64(seed), C.c_int(1 if given else 0), _p(cen, _f32p), _p(pq, _f32p),
+                                     _p(sq, _f32p))
         return cen, pq, sq
 
     # -- build helpers (restated add path) --
@@ -479,12 +481,31 @@ class Port(_SimdTable):
         return out
 
     def pq_encode(self, d, M, nbits, cb, x):
-        codes = np.empty((x.shape[0], M), np.uint8)
+        """-> the reference's code bytes [n, (M nbits + 7) / 8]"""
+        cs = (M * nbits + 7) // 8
+        codes = np.empty((x.shape[0], cs), np.uint8)
+        buf = np.empty(max(M, cs), np.uint8)
         for i in range(x.shape[0]):
             self.lib.orc_pq_compute_code(C.c_int(d), C.c_int(M), C.c_int(nbits), _p(cb, _f32p),
                                          _p(np.ascontiguousarray(x[i]), _f32p),
-                                         codes[i].ctypes.data_as(_u8p))
+                                         buf.ctypes.data_as(_u8p))
+            codes[i] = buf[:cs]
         return codes
+
+    def pq_pack(self, M, nbits, idx):
+        """[n, M] byte-wide indices -> the reference's code bytes"""
+        idx = np.ascontiguousarray(idx, np.uint8)
+        out = np.empty((idx.shape[0], (M * nbits + 7) // 8), np.uint8)
+        for i in range(idx.shape[0]):
+            self.lib.orc_pq_pack(C.c_int(M), C.c_int(nbits), idx[i].ctypes.data_as(_u8p), out[i].ctypes.data_as(_u8p))
+        return out
+
+    def pq_unpack(self, M, nbits, codes):
+        codes = np.ascontiguousarray(codes, np.uint8)
+        out = np.empty((codes.shape[0], M), np.uint8)
+        for i in range(codes.shape[0]):
+            self.lib.orc_pq_unpack(C.c_int(M), C.c_int(nbits), codes[i].ctypes.data_as(_u8p), out[i].ctypes.data_as(_u8p))
+        return out
 
     def sq8_encode(self, trained, x):
         d = x.shape[1]

@@ -584,11 +584,64 @@ float orc_ivfpq_list_table(const orc_index* idx, const float* q, int64_t list_no
 /* ADC: T:impl/pq_code_distance/pq_code_distance-inl.h:73-90: result = 0; result += tab[m][c_m]
  * in m order; the caller adds dis0 in front: dis = dis0 + result
  * (T:impl/pq_code_distance/IVFPQScanner_impl.h:147-150). */
+/* Code widths other than 8 bits: T:impl/ProductQuantizer-inl.h:67-101 PQDecoderGeneric::decode / T:impl/ProductQuantizer.h:195
+ * PQEncoderGeneric -- the M indices are a little-endian bit string, index m in bits [m nbits, (m + 1) nbits), the code
+ * takes (M nbits + 7) / 8 bytes (T:impl/ProductQuantizer.cpp:69).  The scanner of such an index is the same template with
+ * the generic decoder (T:impl/pq_code_distance/pq_code_distance-inl.h:73-90): the same sequential sum. */
+static inline uint32_t pq_code_get(const uint8_t* code, int nbits, int m) {
+    const size_t bit = (size_t)m * (size_t)nbits;
+    size_t byte = bit >> 3;
+    int off = (int)(bit & 7), got = 0;
+    uint32_t v = 0;
+    while (got < nbits) {
+        const int take = (8 - off) < (nbits - got) ? (8 - off) : (nbits - got);
+        v |= (((uint32_t)code[byte] >> off) & ((1u << take) - 1u)) << got;
+        got += take;
+        off = 0;
+        byte++;
+    }
+    return v;
+}
+
+int64_t orc_pq_code_size(int M, int nbits) {
+    return ((int64_t)M * nbits + 7) / 8;
+}
+
+/* M byte-wide indices -> the reference's code bytes, and back (nbits <= 8) */
+void orc_pq_pack(int M, int nbits, const uint8_t* idx, uint8_t* code) {
+    memset(code, 0, (size_t)orc_pq_code_size(M, nbits));
+    for (int m = 0; m < M; m++) {
+        const size_t bit = (size_t)m * (size_t)nbits;
+        const uint32_t v = (uint32_t)idx[m] << (bit & 7); /* (at most 15 bits) */
+        code[bit >> 3] |= (uint8_t)v;
+        if ((bit & 7) + (size_t)nbits > 8) {
+            code[(bit >> 3) + 1] |= (uint8_t)(v >> 8);
+        }
+    }
+}
+
+void orc_pq_unpack(int M, int nbits, const uint8_t* code, uint8_t* idx) {
+    for (int m = 0; m < M; m++) {
+        idx[m] = (uint8_t)pq_code_get(code, nbits, m);
+    }
+}
+
 static inline float adc_distance(int M, size_t ksub, const float* sim_table, const uint8_t* code) {
     const float* tab = sim_table;
     float result = 0;
+    if (ksub == 256) {
+        for (int m = 0; m < M; m++) {
+            result += tab[code[m]];
+            tab += ksub;
+        }
+        return result;
+    }
+    int nbits = 0;
+    while (((size_t)1 << nbits) < ksub) {
+        nbits++;
+    }
     for (int m = 0; m < M; m++) {
-        result += tab[code[m]];
+        result += tab[pq_code_get(code, nbits, m)];
         tab += ksub;
     }
     return result;
@@ -1268,6 +1321,13 @@ void orc_pq_compute_code(int d, int M, int nbits, const float* cb, const float* 
         }
         code[m] = (uint8_t)best;
     }
+    if (nbits != 8) { /* (the caller's buffer holds max(M, code size) bytes) */
+        uint8_t tmp[4096];
+        if (M <= 4096) {
+            memcpy(tmp, code, (size_t)M);
+            orc_pq_pack(M, nbits, tmp, code);
+        }
+    }
 }
 
 /* T:impl/scalar_quantizer/quantizers.h:118-133 + codecs.h:29-35 */
@@ -1489,9 +1549,23 @@ void orc_kmeans(int metric, int d, int64_t n, const float* x, int64_t ld, int of
  * sub-sample (first rows of rand_perm(n, 1234)), residuals, then T:impl/ProductQuantizer.cpp:130-215 (one k-means per
  * sub-space, 25 iterations, seed 1234) or RS_minmax ranges (trained = vmin[d], vdiff[d]).
  * kind: 1 IVF_FLAT, 2 IVF_PQ, 3 IVF_SQ8.  coarse_given != 0: centroids are an input. */
+void orc_train_ivf_nbits(int kind, int metric, int d, int64_t nlist, int M, int nbits, int64_t n, const float* x, int niter,
+                         int max_points, int64_t seed, int coarse_given, float* centroids, float* pq_centroids,
+                         float* sq_trained);
+
 void orc_train_ivf(int kind, int metric, int d, int64_t nlist, int M, int64_t n, const float* x, int niter,
                    int max_points, int64_t seed, int coarse_given, float* centroids, float* pq_centroids,
                    float* sq_trained) {
+    orc_train_ivf_nbits(kind, metric, d, nlist, M, 8, n, x, niter, max_points, seed, coarse_given, centroids, pq_centroids,
+                        sq_trained);
+}
+
+/* nbits: the PQ code width (ksub = 2^nbits codebook entries per sub-quantizer; the encoder trains on at most 256 ksub
+ * points: T:IndexIVFPQ.cpp:97-99 train_encoder_num_vectors = max_points_per_centroid * ksub) */
+void orc_train_ivf_nbits(int kind, int metric, int d, int64_t nlist, int M, int nbits, int64_t n, const float* x, int niter,
+                         int max_points, int64_t seed, int coarse_given, float* centroids, float* pq_centroids,
+                         float* sq_trained) {
+    const int64_t ksub = (int64_t)1 << nbits;
     if (!coarse_given) {
         /* level-1 quantizer: cp.niter = 10 unless the caller overrides it (T:IndexIVF.cpp:44), spherical for the inner
          * product (T:IndexIVF.cpp:178-181) */
@@ -1500,7 +1574,7 @@ void orc_train_ivf(int kind, int metric, int d, int64_t nlist, int M, int64_t n,
     if (kind == 1) {
         return;
     }
-    const int64_t max_nt = kind == 2 ? 65536 : 100000;
+    const int64_t max_nt = kind == 2 ? 256 * ksub : 100000;
     int64_t nt = n;
     int64_t* perm = (int64_t*)malloc(sizeof(int64_t) * (size_t)n);
     if (n > max_nt) {
@@ -1525,7 +1599,7 @@ void orc_train_ivf(int kind, int metric, int d, int64_t nlist, int M, int64_t n,
     if (kind == 2) {
         const int dsub = d / M;
         for (int m = 0; m < M; m++) {
-            orc_kmeans(ORC_L2, dsub, nt, xt, d, m * dsub, 256, 25, 256, 1234, 0, pq_centroids + (size_t)m * 256 * dsub);
+            orc_kmeans(ORC_L2, dsub, nt, xt, d, m * dsub, ksub, 25, 256, 1234, 0, pq_centroids + (size_t)m * (size_t)ksub * dsub);
         }
     } else {
         for (int j = 0; j < d; j++) {
