@@ -63,7 +63,8 @@ extern "C" {
  * indexes (knhip_search_canonical_device, knhip_tie_*, knhip_refine_distances / _combine / _select).
  * 8: the refine stores sq6 / int8 / sq4u (KNHIP_ROWS_SQ6 / _INT8 / _SQ4U) and knhip_rows_train_uniform.
  * 9: knhip_ties_rule_applies (one place decides whether a search follows the reference's boundary rule: single index, shard
- * group and the torch.distributed host agree); value 3 of the profile field pq_filter_form: the decode form of the IVF-PQ prefilter.
+ * group and the torch.distributed host agree); value 3 of the profile field pq_filter_form: the decode form of the IVF-PQ prefilter;
+ * pq_nbits 1 .. 8 (host-side list codes in the reference's bit-string form).
  * Callers compare knhip_abi_version() with the header they were built against. */
 #define KNHIP_ABI_VERSION 9
 
@@ -98,7 +99,11 @@ typedef struct knhip_desc {
     int32_t device;   /* HIP device ordinal */
     int64_t nlist;    /* IVF kinds */
     int32_t pq_m;     /* IVF_PQ: sub-quantizers (must divide dim) */
-    int32_t pq_nbits; /* IVF_PQ: 8 */
+    int32_t pq_nbits; /* IVF_PQ: 1 .. 8 (ABI 9; 8 before).  Codebooks are [pq_m][2^nbits][dim / pq_m].  HOST-side list codes
+                       * (knhip_index_add_lists / knhip_index_get_lists) are the reference's code bytes: pq_m indices of nbits bits
+                       * as a little-endian bit string of (pq_m nbits + 7) / 8 bytes (faiss ProductQuantizer.cpp:69,
+                       * PQEncoderGeneric); DEVICE-side codes (knhip_index_encode_device, knhip_index_set_lists_device) are one
+                       * byte per sub-quantizer for every width */
     /* IVF_PQ + L2: precomputed term-2 table limit in bytes; 0 = the reference default 2 GiB
      * (thirdparty/faiss/faiss/IndexIVFPQ.cpp:375).  Above it the residual-table form is used,
      * as the reference does (:441-456). */

@@ -230,6 +230,9 @@ struct knhip_index {
     int64_t max_list_len = 0;
     // MFMA prefilter (mfma_scan.hip): KNHIP_MSCAN = 0 never, 1 whenever the shape allows, 2 (default) when the lists
     // are shared by enough queries of the batch
+    int ksub = 256;              // IVF_PQ: codebook entries per sub-quantizer in use (2^nbits); the layouts and kernels are those of
+                                 // 8-bit codes -- one byte per sub-quantizer, tables 256 wide, entries >= ksub copies of entry 0
+                                 // that no code refers to
     int mscan = 2;
     bool flat_bf16 = true;    // KNHIP_MSCAN_FLAT=fp32: the IVF-Flat filter pass on the fp32 matrix instruction (round 2)
     int mscan_cap = 0;           // KNHIP_MSCAN_CAP: candidate capacity per query (0 = automatic; tests force the retry round)
@@ -489,7 +492,8 @@ int maybe_build_precomp(knhip_index* idx) {
             ? (size_t)idx->desc.precomputed_table_max_bytes
             : ((size_t)1 << 31);
     const size_t table = (size_t)idx->nlist * 256 * idx->desc.pq_m * sizeof(float);
-    if (table > limit) {
+    // (the decision follows the REFERENCE's table, M x ksub x nlist floats: it selects the arithmetic of the distances)
+    if ((size_t)idx->nlist * idx->ksub * idx->desc.pq_m * sizeof(float) > limit) {
         return KNHIP_OK;
     }
     HIP_TRY(idx->precomp_t.alloc(table));
@@ -1941,8 +1945,8 @@ int knhip_index_create(const knhip_desc* desc, knhip_index** out) {
         return fail(KNHIP_ERR_INVALID_ARGS, "nlist out of range");
     }
     if (desc->kind == KNHIP_IVF_PQ) {
-        if (desc->pq_nbits != 8) {
-            return fail(KNHIP_ERR_NOT_IMPLEMENTED, "only 8-bit PQ codes are supported");
+        if (desc->pq_nbits < 1 || desc->pq_nbits > 8) {
+            return fail(KNHIP_ERR_NOT_IMPLEMENTED, "PQ codes of 1 .. 8 bits are supported");
         }
         if (desc->pq_m <= 0 || desc->dim % desc->pq_m != 0) {
             return fail(KNHIP_ERR_INVALID_ARGS, "pq_m must divide dim");
@@ -1970,7 +1974,8 @@ int knhip_index_create(const knhip_desc* desc, knhip_index** out) {
             idx->code_size = (int64_t)desc->dim * 4;
             break;
         case KNHIP_IVF_PQ:
-            idx->code_size = desc->pq_m;
+            idx->code_size = desc->pq_m; // (on the device: one byte per sub-quantizer whatever the width)
+            idx->ksub = 1 << desc->pq_nbits;
             break;
         default:
             idx->code_size = desc->dim;
@@ -2027,13 +2032,31 @@ int knhip_index_set_coarse_device(knhip_index* idx, const float* d_centroids) {
     return maybe_build_precomp(idx);
 }
 
+// [M][ksub][dsub] -> [M][256][dsub]: the entries no code refers to repeat entry 0 (the encoder takes the FIRST minimum, table
+// statistics see no value that is not a real entry's)
+static std::vector<float> pad_codebook(const float* cb, int M, int ksub, int dsub) {
+    std::vector<float> out((size_t)M * 256 * dsub);
+    for (int m = 0; m < M; m++) {
+        for (int c = 0; c < 256; c++) {
+            const float* src = cb + ((size_t)m * ksub + (c < ksub ? c : 0)) * dsub;
+            std::copy(src, src + dsub, out.begin() + ((size_t)m * 256 + c) * dsub);
+        }
+    }
+    return out;
+}
+
 int knhip_index_set_pq(knhip_index* idx, const float* codebooks) {
     if (int rc = check_index(idx)) return rc;
     if (!codebooks || idx->desc.kind != KNHIP_IVF_PQ) {
         return fail(KNHIP_ERR_INVALID_ARGS, "set_pq: not an IVF_PQ index");
     }
     DeviceGuard g(idx->desc.device);
-    if (int rc = upload(idx->cb, codebooks, (size_t)256 * idx->d * sizeof(float))) return rc;
+    if (idx->ksub == 256) {
+        if (int rc = upload(idx->cb, codebooks, (size_t)256 * idx->d * sizeof(float))) return rc;
+    } else {
+        const std::vector<float> padded = pad_codebook(codebooks, idx->desc.pq_m, idx->ksub, idx->d / idx->desc.pq_m);
+        if (int rc = upload(idx->cb, padded.data(), padded.size() * sizeof(float))) return rc;
+    }
     idx->has_pq = true;
     idx->cb_t.release();
     if (pq_scan_q4_supports(idx->desc.pq_m, idx->d, 1)) {
@@ -2104,6 +2127,22 @@ int knhip_index_add_lists(knhip_index* idx, const int64_t* list_sizes, const uin
     DeviceGuard g(idx->desc.device);
     const int64_t nlist = idx->nlist;
     const int64_t cs = idx->code_size;
+    // IVF_PQ with codes narrower than 8 bits: the caller's lists hold the reference's code bytes -- M indices of nbits bits as
+    // a little-endian bit string of (M nbits + 7) / 8 bytes (ProductQuantizer.cpp:69, PQEncoderGeneric); unpacked here to one
+    // byte per sub-quantizer
+    const int nb_pq = idx->desc.kind == KNHIP_IVF_PQ ? idx->desc.pq_nbits : 8;
+    const int64_t cs_in = nb_pq == 8 ? cs : ((int64_t)idx->desc.pq_m * nb_pq + 7) / 8;
+    auto take_code = [&](uint8_t* dst, const uint8_t* src) {
+        if (nb_pq == 8) {
+            std::memcpy(dst, src, (size_t)cs);
+            return;
+        }
+        for (int m = 0; m < (int)cs; m++) {
+            const size_t bit = (size_t)m * nb_pq;
+            const uint32_t w = (uint32_t)src[bit >> 3] | ((bit >> 3) + 1 < (size_t)cs_in ? (uint32_t)src[(bit >> 3) + 1] << 8 : 0u);
+            dst[m] = (uint8_t)((w >> (bit & 7)) & ((1u << nb_pq) - 1u));
+        }
+    };
     std::vector<int64_t> off(nlist + 1, 0);
     for (int64_t l = 0; l < nlist; l++) {
         if (list_sizes[l] < 0 || (list_sizes[l] > 0 && (!codes[l] || !ids[l]))) {
@@ -2129,8 +2168,13 @@ int knhip_index_add_lists(knhip_index* idx, const int64_t* list_sizes, const uin
                 break;
             }
         }
-        if (sorted) {
+        if (sorted && nb_pq == 8) {
             std::memcpy(hc.data() + (size_t)off[l] * cs, codes[l], (size_t)n * cs);
+            std::memcpy(hi.data() + off[l], ids[l], (size_t)n * sizeof(int64_t));
+        } else if (sorted) {
+            for (int64_t j = 0; j < n; j++) {
+                take_code(hc.data() + (size_t)(off[l] + j) * cs, codes[l] + (size_t)j * cs_in);
+            }
             std::memcpy(hi.data() + off[l], ids[l], (size_t)n * sizeof(int64_t));
         } else {
             perm.resize(n);
@@ -2138,7 +2182,7 @@ int knhip_index_add_lists(knhip_index* idx, const int64_t* list_sizes, const uin
             const int64_t* lid = ids[l];
             std::stable_sort(perm.begin(), perm.end(), [lid](int64_t a, int64_t b) { return lid[a] < lid[b]; });
             for (int64_t j = 0; j < n; j++) {
-                std::memcpy(hc.data() + (size_t)(off[l] + j) * cs, codes[l] + (size_t)perm[j] * cs, (size_t)cs);
+                take_code(hc.data() + (size_t)(off[l] + j) * cs, codes[l] + (size_t)perm[j] * cs_in);
                 hi[off[l] + j] = lid[perm[j]];
             }
         }
@@ -4349,7 +4393,7 @@ int train_device_impl(knhip_index* idx, int64_t n, const float* d_x, const knhip
     //    rows (IVF_PQ: 256 * ksub = 65536, IndexIVFPQ.cpp:97-99; IVF_SQ: 100000, IndexScalarQuantizer.cpp:159-161),
     //    the first rows of rand_perm(n, 1234) (fvecs_maybe_subsample, utils/utils.cpp:464-489); residuals to the
     //    assigned centroid (by_residual)
-    const int64_t max_nt = kind == KNHIP_IVF_PQ ? 65536 : 100000;
+    const int64_t max_nt = kind == KNHIP_IVF_PQ ? (int64_t)256 * idx->ksub : 100000;
     int64_t nt = n;
     DevBuf xt_buf;
     const float* xt = d_x;
@@ -4373,15 +4417,17 @@ int train_device_impl(knhip_index* idx, int64_t n, const float* d_x, const knhip
     HIP_TRY(hipDeviceSynchronize());
     if (kind == KNHIP_IVF_PQ) {
         // ProductQuantizer::train (impl/ProductQuantizer.cpp:130-215, Train_default): one k-means per sub-space on its
-        // slice of the residuals, 256 centroids, ClusteringParameters defaults (25 iterations, seed 1234), L2
-        const int M = idx->desc.pq_m, dsub = d / M;
+        // slice of the residuals, ksub = 2^nbits centroids, ClusteringParameters defaults (25 iterations, seed 1234), L2
+        const int M = idx->desc.pq_m, dsub = d / M, ksub = idx->ksub;
         DevBuf cb;
         HIP_TRY(cb.alloc((size_t)256 * d * sizeof(float)));
         TrainParams pq_tp;  // (the coarse quantizer's parameters do not apply to the codebooks)
         for (int m = 0; m < M; m++) {
-            if (int rc = kmeans_impl(dev, KNHIP_L2, dsub, nt, resid.as<float>(), d, m * dsub, 256, pq_tp,
-                                     cb.as<float>() + (size_t)m * 256 * dsub))
-                return rc;
+            float* cbm = cb.as<float>() + (size_t)m * 256 * dsub;
+            if (int rc = kmeans_impl(dev, KNHIP_L2, dsub, nt, resid.as<float>(), d, m * dsub, ksub, pq_tp, cbm)) return rc;
+            for (int c = ksub; c < 256; c++) { // (entries no code refers to: copies of entry 0, see pad_codebook)
+                HIP_TRY(hipMemcpy(cbm + (size_t)c * dsub, cbm, (size_t)dsub * sizeof(float), hipMemcpyDeviceToDevice));
+            }
         }
         return set_pq_device(idx, cb.as<float>());
     }
@@ -4556,7 +4602,17 @@ int knhip_index_get_pq(const knhip_index* idx, float* codebooks) {
         return fail(KNHIP_ERR_NOT_TRAINED, "PQ codebooks not set");
     }
     DeviceGuard g(idx->desc.device);
-    HIP_TRY(hipMemcpy(codebooks, idx->cb.p, (size_t)256 * idx->d * sizeof(float), hipMemcpyDeviceToHost));
+    if (idx->ksub == 256) {
+        HIP_TRY(hipMemcpy(codebooks, idx->cb.p, (size_t)256 * idx->d * sizeof(float), hipMemcpyDeviceToHost));
+        return KNHIP_OK;
+    }
+    std::vector<float> h((size_t)256 * idx->d);
+    HIP_TRY(hipMemcpy(h.data(), idx->cb.p, h.size() * sizeof(float), hipMemcpyDeviceToHost));
+    const int M = idx->desc.pq_m, dsub = idx->d / M;
+    for (int m = 0; m < M; m++) { // [M][256][dsub] -> [M][ksub][dsub]
+        std::copy(h.begin() + (size_t)m * 256 * dsub, h.begin() + ((size_t)m * 256 + idx->ksub) * dsub,
+                  codebooks + (size_t)m * idx->ksub * dsub);
+    }
     return KNHIP_OK;
 }
 
@@ -4593,7 +4649,28 @@ int knhip_index_get_lists(const knhip_index* idx, uint8_t* codes, int64_t* ids) 
         if (int rc = ensure_aos(idx)) return rc;
         const size_t b = idx->desc.kind == KNHIP_BRUTE_FORCE ? (size_t)idx->ntotal * idx->d * sizeof(float)
                                                              : (size_t)idx->ntotal * idx->code_size;
-        HIP_TRY(hipMemcpy(codes, idx->codes_aos.p, b, hipMemcpyDeviceToHost));
+        if (idx->desc.kind == KNHIP_IVF_PQ && idx->desc.pq_nbits != 8) {
+            // -> the reference's code bytes (see knhip_index_add_lists)
+            const int nb_pq = idx->desc.pq_nbits, M = idx->desc.pq_m;
+            const size_t cs_out = ((size_t)M * nb_pq + 7) / 8;
+            std::vector<uint8_t> h(b);
+            HIP_TRY(hipMemcpy(h.data(), idx->codes_aos.p, b, hipMemcpyDeviceToHost));
+            std::memset(codes, 0, (size_t)idx->ntotal * cs_out);
+            for (int64_t i = 0; i < idx->ntotal; i++) {
+                uint8_t* dst = codes + (size_t)i * cs_out;
+                const uint8_t* src = h.data() + (size_t)i * M;
+                for (int m = 0; m < M; m++) {
+                    const size_t bit = (size_t)m * nb_pq;
+                    const uint32_t v = (uint32_t)src[m] << (bit & 7);
+                    dst[bit >> 3] |= (uint8_t)v;
+                    if ((bit & 7) + (size_t)nb_pq > 8) {
+                        dst[(bit >> 3) + 1] |= (uint8_t)(v >> 8);
+                    }
+                }
+            }
+        } else {
+            HIP_TRY(hipMemcpy(codes, idx->codes_aos.p, b, hipMemcpyDeviceToHost));
+        }
     }
     if (ids && idx->desc.kind != KNHIP_BRUTE_FORCE) {
         HIP_TRY(hipMemcpy(ids, idx->ids.p, (size_t)idx->ntotal * sizeof(int64_t), hipMemcpyDeviceToHost));

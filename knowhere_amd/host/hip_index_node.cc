@@ -266,6 +266,8 @@ class HipIndexNode : public IndexNode {
                 m_ = c.m.value();
             }
             if (!fits(m_)) return Status::invalid_args;
+            nbits_ = c.nbits.value_or(8);
+            if (nbits_ < 1 || nbits_ > 8) return Status::invalid_args;
         }
         if constexpr (Kind == KNHIP_IVF_PQ || Kind == KNHIP_IVF_SQ8) {
             // a refine index is built iff `refine` AND `refine_type` are given (ivf_wrapper.cc:170, :214).  refine_type
@@ -732,8 +734,8 @@ class HipIndexNode : public IndexNode {
             if constexpr (Kind == KNHIP_IVF_PQ) {
                 x.pq_d = (uint64_t)dim_;
                 x.pq_M = (uint64_t)m_;
-                x.pq_nbits = 8;
-                x.pq_centroids.resize((size_t)256 * dim_);
+                x.pq_nbits = (uint64_t)nbits_;
+                x.pq_centroids.resize(((size_t)1 << nbits_) * dim_);
                 if ((rc = knhip_index_get_pq(first, x.pq_centroids.data()))) return ToStatus(rc);
             } else if constexpr (Kind == KNHIP_IVF_SQ8) {
                 x.sq_qtype = 0;      // ScalarQuantizer::QT_8bit
@@ -861,12 +863,14 @@ class HipIndexNode : public IndexNode {
             if (x.nlist == 0 || x.nlist > 65536 * 16 || x.quantizer.hdr.d != d ||
                 x.quantizer.xb.size() != (size_t)x.nlist * d || x.codes.size() != x.nlist || x.ids.size() != x.nlist)
                 return Status::invalid_serialized_index_type;
-            const uint64_t want_cs = Kind == KNHIP_IVF_FLAT ? (uint64_t)d * 4 : Kind == KNHIP_IVF_PQ ? x.pq_M : (uint64_t)d;
-            if (Kind == KNHIP_IVF_PQ &&
-                (x.pq_nbits != 8 || !x.by_residual || x.pq_M < 1 || x.pq_M > 128 || (uint64_t)d / x.pq_M > 144))
+            if (Kind == KNHIP_IVF_PQ && (x.pq_nbits < 1 || x.pq_nbits > 8 || !x.by_residual || x.pq_M < 1 || x.pq_M > 128 ||
+                                         (uint64_t)d / x.pq_M > 144))
                 return Status::not_implemented;
+            // (PQ codes on the wire: M indices of nbits bits as a little-endian bit string, ProductQuantizer.cpp:69)
+            const uint64_t want_cs = Kind == KNHIP_IVF_FLAT ? (uint64_t)d * 4
+                                     : Kind == KNHIP_IVF_PQ ? (x.pq_M * x.pq_nbits + 7) / 8 : (uint64_t)d;
             if (Kind == KNHIP_IVF_PQ && (x.pq_d != (uint64_t)d || d % (int64_t)x.pq_M != 0 ||
-                                          x.pq_centroids.size() != (size_t)256 * d))
+                                          x.pq_centroids.size() != ((size_t)1 << x.pq_nbits) * d))
                 return Status::invalid_serialized_index_type;
             if (Kind == KNHIP_IVF_SQ8 && (x.sq_qtype != 0 || !x.by_residual)) return Status::not_implemented;
             if (Kind == KNHIP_IVF_SQ8 && (x.sq_d != (uint64_t)d || x.sq_code_size != (uint64_t)d ||
@@ -943,6 +947,7 @@ class HipIndexNode : public IndexNode {
         nlist_ = (int64_t)x.nlist;
         if (x.nprobe >= 1 && x.nprobe <= 65536) default_nprobe_ = (int64_t)x.nprobe;  // the index's default nprobe
         m_ = (int64_t)x.pq_M;
+        nbits_ = Kind == KNHIP_IVF_PQ ? (int64_t)x.pq_nbits : 8;
         has_refine_ = x.has_refine;
         refine_rows_type_ = !(x.has_refine && x.refine_is_sq) ? 0
                             : x.refine_sq.qtype == 4          ? KNHIP_ROWS_FP16
@@ -1137,7 +1142,7 @@ class HipIndexNode : public IndexNode {
     }
     int64_t
     CodeSize() const {
-        return Kind == KNHIP_IVF_FLAT ? dim_ * 4 : (Kind == KNHIP_IVF_PQ ? m_ : dim_);
+        return Kind == KNHIP_IVF_FLAT ? dim_ * 4 : (Kind == KNHIP_IVF_PQ ? (m_ * nbits_ + 7) / 8 : dim_);
     }
     // a second device-resident store of the raw rows: IndexRefineFlat only (GetVectorByIds of IVF_FLAT is served from the
     // index's own rows through knhip_index_get_vectors' direct map)
@@ -1217,7 +1222,7 @@ class HipIndexNode : public IndexNode {
             if constexpr (Kind != KNHIP_BRUTE_FORCE) desc.nlist = nlist_;
             if constexpr (Kind == KNHIP_IVF_PQ) {
                 desc.pq_m = (int32_t)m_;
-                desc.pq_nbits = 8;
+                desc.pq_nbits = (int32_t)nbits_;
             }
             if (int rc = knhip_index_create(&desc, &sh_[r].idx.p)) {
                 DropShards();
@@ -1254,7 +1259,7 @@ class HipIndexNode : public IndexNode {
         std::vector<float> cen((size_t)nlist_ * dim_), aux;
         if (int rc = knhip_index_get_coarse(sh_[0].idx.p, cen.data())) return rc;
         if constexpr (Kind == KNHIP_IVF_PQ) {
-            aux.resize((size_t)256 * dim_);
+            aux.resize(((size_t)1 << nbits_) * dim_);
             if (int rc = knhip_index_get_pq(sh_[0].idx.p, aux.data())) return rc;
         } else if constexpr (Kind == KNHIP_IVF_SQ8) {
             aux.resize((size_t)2 * dim_);
@@ -1430,6 +1435,7 @@ class HipIndexNode : public IndexNode {
     std::vector<float> row_scale_by_id_;  // StoredNormCosine(): FLAT inverse L2 norms, IVF_FLAT L2 norms, by row id
     std::string metric_name_ = metric::L2;
     int64_t dim_ = 0, nlist_ = 0, m_ = 0, default_nprobe_ = 8;
+    int64_t nbits_ = 8;  // IVF_PQ: code width (1 .. 8)
     std::vector<Shard> sh_;        // one entry: the whole index on one device; several: list- (FLAT: row-) sharded
     GroupHandle group_;            // several shards: the exchange + merge host (include/knhip_shards.h)
     std::vector<int32_t> owner_;   // several shards, IVF kinds: list -> shard

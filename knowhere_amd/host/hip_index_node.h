@@ -146,8 +146,9 @@ struct HipIvfPqConfig : public IvfPqConfig {
             .for_search();
         // m = 0: the backend picks (about dim / 2 sub-quantizers, as cuVS does for pq_dim = 0)
         KNOWHERE_CONFIG_DECLARE_FIELD(m).set_default(0).description("m").set_range(0, 65536).for_train();
-        // the ADC kernels index 256-entry tables: 8-bit codes only (the cuVS config accepts 4..8)
-        KNOWHERE_CONFIG_DECLARE_FIELD(nbits).set_default(8).description("nbits").set_range(8, 8).for_train();
+        // codes of 1 .. 8 bits (the cuVS config accepts 4 .. 8, gpu_cuvs_ivf_pq_config.h:55-58; the CPU node up to 24): on the
+        // device every width is one byte per sub-quantizer indexing 256-entry tables of which 2^nbits are in use
+        KNOWHERE_CONFIG_DECLARE_FIELD(nbits).set_default(8).description("nbits").set_range(1, 8).for_train();
     }
     Status
     CheckAndAdjust(PARAM_TYPE param_type, std::string* err_msg) override {

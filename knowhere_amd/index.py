@@ -43,6 +43,7 @@ class GpuIndex:
                  precomputed_table_max_bytes=0):
         self.L = _lib.load()
         self.kind, self.metric, self.dim, self.nlist, self.pq_m = kind, metric, dim, nlist, pq_m
+        self.pq_nbits = pq_nbits
         self.device = device
         d = _lib.Desc(kind, metric, dim, device, nlist, pq_m, pq_nbits, precomputed_table_max_bytes)
         h = C.c_void_p()
@@ -68,7 +69,7 @@ class GpuIndex:
 
     def set_pq(self, codebooks):
         c = np.ascontiguousarray(codebooks, np.float32)
-        assert c.size == 256 * self.dim
+        assert c.size == (1 << self.pq_nbits) * self.dim  # [pq_m][2^nbits][dim / pq_m]
         check(self.L.knhip_index_set_pq(self.h, _np_ptr(c)))
 
     def set_sq(self, vmin, vdiff):
@@ -179,7 +180,7 @@ class GpuIndex:
         return out
 
     def get_pq(self):
-        out = np.empty((self.pq_m, 256, self.dim // self.pq_m), np.float32)
+        out = np.empty((self.pq_m, 1 << self.pq_nbits, self.dim // self.pq_m), np.float32)
         check(self.L.knhip_index_get_pq(self.h, _np_ptr(out)))
         return out
 
@@ -193,7 +194,9 @@ class GpuIndex:
         sizes = np.zeros(self.nlist, np.int64)
         check(self.L.knhip_index_get_list_sizes(self.h, _np_ptr(sizes)))
         n = int(sizes.sum())
-        cs = {IVF_FLAT: 4 * self.dim, IVF_PQ: self.pq_m, IVF_SQ8: self.dim}[self.kind]
+        # (IVF_PQ: the reference's code bytes -- pq_m indices of nbits bits as a little-endian bit string; the DEVICE side
+        # entry points -- encode_device, set_lists_device -- speak one byte per sub-quantizer)
+        cs = {IVF_FLAT: 4 * self.dim, IVF_PQ: (self.pq_m * self.pq_nbits + 7) // 8, IVF_SQ8: self.dim}[self.kind]
         codes = np.empty((n, cs), np.uint8)
         ids = np.empty(n, np.int64)
         check(self.L.knhip_index_get_lists(self.h, _np_ptr(codes), _np_ptr(ids)))
