@@ -419,6 +419,8 @@ struct WorkTable {
     int64_t* empty_mark;
     int32_t k;
 };
+hipError_t launch_direct_items(const int64_t* keys, int64_t nq, int nprobe, int64_t nlist, const int64_t* list_len,
+                               const WorkTable& wt, hipStream_t s);
 hipError_t launch_build_worktable(const int64_t* keys, int64_t nq, int nprobe, int64_t nlist, int qg0, int qg1,
                                   const int64_t* list_len, int64_t code_size, const WorkTable& wt,
                                   hipStream_t s, int rank0_slot = 0, const int32_t* cls = nullptr);

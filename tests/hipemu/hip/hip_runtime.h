@@ -68,8 +68,11 @@ namespace hipemu { extern int g_ncu; }
 inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = hipemu::g_ncu; return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { std::memset(p, v, n); return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }  // (launches are synchronous here)
 // memory / streams / events of the orchestration (knhip_api.hip): "device" memory is host memory, everything is synchronous
 constexpr hipError_t hipErrorOutOfMemory = 2;
+constexpr hipError_t hipErrorNotReady = 600;
+constexpr unsigned hipHostMallocMapped = 2, hipHostMallocCoherent = 0x40000000;
 typedef void* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
 constexpr unsigned hipStreamNonBlocking = 1;
@@ -189,6 +192,7 @@ void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()
 
 inline void __syncthreads() { hipemu::tl.g->bar.arrive_and_wait(); }
 inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
+inline void __threadfence_system() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 
 // ---- cross-lane ---------------------------------------------------------------------------------------------------
 template <class T>
