@@ -56,6 +56,7 @@ LDS_PEAK_GBPS = 256 * 256 * 2.4        # 256 B/clk/CU (conflict-free ds_read_b64
 VALU_PEAK_TFLOPS = 157.3               # fp32 vector peak (FMA = 2 flop)
 MFMA_F32_PEAK_TFLOPS = 157.3           # fp32 matrix peak (coarse quantizer, fp32 row prefilter)
 MFMA_F16_PEAK_TFLOPS = 2500.0          # dense f16 / bf16 matrix peak (SQ8 prefilter)
+MFMA_F16_SUSTAINED_TFLOPS = 1850.0  # measured: the 32x32x16 f16 / bf16 instruction back to back on every pipe for 1 - 6 ms (see roofline.algorithmic)
 MFMA_I8_PEAK_TOPS = 1024 * 2048 * 2.4 / 1e3  # v_mfma_i32_16x16x64_i8: 32768 ops per 16 cycles and SIMD x 1024 SIMDs x 2.4 GHz
 #                                        = 5033 TOP/s (the guide lists >= 3944 TOP/s measured for this instruction)
 
@@ -728,7 +729,12 @@ def make_roofline(a, kind, prof, world):
                                       "algorithmic": {"flop_per_row_query": 256, "TFLOPs": round(tf, 1),
                                                       "frac": round(tf / MFMA_F16_PEAK_TFLOPS, 4),
                                                       "table_lookups_per_ns_per_cu": round(scan_bytes / sec / 1e9 / 256.0, 1)
-                                                      if sec > 0 else None},
+                                                      if sec > 0 else None,
+                                                      # what 1024 matrix pipes SUSTAIN for a launch of this length (the same
+                                                      # instruction back to back, nothing else: tools/ubench/mfma_stream long,
+                                                      # profiles/r06_ubench_mfma_sustained.log: 1.67 - 1.99 PFLOP/s at 1 - 6 ms)
+                                                      "sustained_peak_measured_TFLOPs": MFMA_F16_SUSTAINED_TFLOPS,
+                                                      "frac_of_sustained_peak": round(tf / MFMA_F16_SUSTAINED_TFLOPS, 4)},
                                       "filter_form": "decode: f16 contraction, <= 128 queries per unit", "mscan": mscan},
                                      **common))
             if i8:

@@ -499,7 +499,7 @@ int main() {
         }
     }
 
-    {   // config limits of the backend (hip_index_node.h): m outside {0, 8, 16, 32, 64}, dim % m, nbits != 8, sq_type
+    {   // config limits of the backend (hip_index_node.h): m, dim % m, nbits outside 1 .. 8, sq_type
         std::string msg;
         Json cfg = ivfpq_gen();
         cfg[indexparam::M] = 12;
@@ -508,7 +508,9 @@ int main() {
         cfg[meta::DIM] = 96;
         REQUIRE(IndexStaticFaced<fp32>::ConfigCheck(IndexEnum::INDEX_HIP_IVFPQ, version, cfg, msg) == Status::invalid_args);
         cfg = ivfpq_gen();
-        cfg[indexparam::NBITS] = 4;
+        cfg[indexparam::NBITS] = 4;  // codes of 1 .. 8 bits since round 6 (the cuVS config accepts 4 .. 8)
+        REQUIRE(IndexStaticFaced<fp32>::ConfigCheck(IndexEnum::INDEX_HIP_IVFPQ, version, cfg, msg) == Status::success);
+        cfg[indexparam::NBITS] = 12;  // wider than a byte: refused by the config range
         REQUIRE(IndexStaticFaced<fp32>::ConfigCheck(IndexEnum::INDEX_HIP_IVFPQ, version, cfg, msg) ==
                 Status::out_of_range_in_json);
         cfg = ivfflat_gen();
