@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256) void coarse_rerank_kernel(
         int ncand, int kp, const int64_t* __restrict__ cand_keys, const float* __restrict__ cand_approx,
         int nprobe, const float* __restrict__ qnorm, float cnorm_max, int64_t* __restrict__ out_keys,
         float* __restrict__ out_d, int32_t* __restrict__ fail_flags, unsigned long long* __restrict__ nfail,
-        const int32_t* __restrict__ cand_cnt, const float* __restrict__ bound, float eps_rel) {
+        const int32_t* __restrict__ cand_cnt, const float* __restrict__ bound, float eps_rel, int need_kth) {
     // cand_cnt / bound non-null (the bf16 prefilter): the row holds cand_cnt[q] unordered candidates (capacity ncand: more
     // is an overflow -> exact fallback) = EVERY centroid with approx <= bound[q], so bound[q] is the certificate's T
     extern __shared__ __align__(16) unsigned char smem[];
@@ -568,7 +568,11 @@ __global__ __launch_bounds__(256) void coarse_rerank_kernel(
             // bf16 split adds 2^-14 >= 3 * 2^-16, see coarse_bf16_kernel)
             const float scale = IS_L2 ? (qnorm[q] + cnorm_max) : sqrtf(qnorm[q] * cnorm_max);
             const float eps = eps_rel * scale + 1e-30f;
-            if (c == ~0ull || (cand_cnt != nullptr && cand_cnt[q] > ncand) || !(eps < INFINITY)) {
+            if (!need_kth) {
+                // the bound came from OUTSIDE (a k-th best found elsewhere, widened by eps: coarse_ext_bound_kernel): every row
+                // that can matter is among the candidates unless they overflowed; fewer than nprobe of them is no failure
+                fail = (cand_cnt != nullptr && cand_cnt[q] > ncand) || !(eps < INFINITY) || !(T == T);
+            } else if (c == ~0ull || (cand_cnt != nullptr && cand_cnt[q] > ncand) || !(eps < INFINITY)) {
                 fail = 1;
             } else if (IS_L2) {
                 fail = !(T - eps > en);
@@ -616,7 +620,8 @@ hipError_t launch_coarse_rerank(const float* queries, const float* centroids, in
                                 int64_t nlist, int ncand, const int64_t* cand_keys,
                                 const float* cand_approx, int nprobe, bool is_l2, const float* qnorm,
                                 float cnorm_max, int64_t* out_keys, float* out_d, int32_t* fail_flags,
-                                unsigned long long* nfail, hipStream_t s, const int32_t* cand_cnt, const float* bound) {
+                                unsigned long long* nfail, hipStream_t s, const int32_t* cand_cnt, const float* bound,
+                                bool need_kth) {
     if (nq <= 0) {
         return hipSuccess;
     }
@@ -640,7 +645,7 @@ hipError_t launch_coarse_rerank(const float* queries, const float* centroids, in
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nq), dim3(256), sm, s, queries, centroids, d, nlist, ncand, kp,
                        cand_keys, cand_approx, nprobe, qnorm, cnorm_max, out_keys, out_d, fail_flags, nfail, cand_cnt, bound,
-                       eps_rel);
+                       eps_rel, need_kth ? 1 : 0);
     return hipGetLastError();
 }
 
@@ -680,7 +685,9 @@ hipError_t launch_coarse_bf16_split(const float* x, int64_t n, int d, void* out,
 
 hipError_t launch_coarse_bf16(const void* q_split, const float* qnorm, const void* c_split, const float* cnorm, int64_t nq,
                               int64_t nlist, int d, bool is_l2, int ncand, int cap, float* gmin, float* bound,
-                              int32_t* cand_cnt, int64_t* cand, hipStream_t s) {
+                              int32_t* cand_cnt, int64_t* cand, hipStream_t s, bool bound_given) {
+    // bound_given: `bound` already holds every query's selection bound (coarse_ext_bound): no group-minima pass, no bound
+    // kernel -- ONE pass over the rows
     if (nq <= 0 || nlist <= 0) {
         return hipSuccess;
     }
@@ -701,17 +708,65 @@ hipError_t launch_coarse_bf16(const void* q_split, const float* qnorm, const voi
         return e;
     }
     if (is_l2) {
-        hipLaunchKernelGGL((coarse_bf16_kernel<true, 1>), dim3(grid), dim3(256), 0, s, Qs, qnorm, Cs, cnorm, nq, nlist, nslab, tq,
-                           ntiles, gmin, G, nullptr, nullptr, nullptr, 0, g16);
-        hipLaunchKernelGGL((coarse_bound_kernel<true>), dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, gmin, G, nq, ncand, bound);
+        if (!bound_given) {
+            hipLaunchKernelGGL((coarse_bf16_kernel<true, 1>), dim3(grid), dim3(256), 0, s, Qs, qnorm, Cs, cnorm, nq, nlist, nslab, tq,
+                               ntiles, gmin, G, nullptr, nullptr, nullptr, 0, g16);
+            hipLaunchKernelGGL((coarse_bound_kernel<true>), dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, gmin, G, nq, ncand, bound);
+        }
         hipLaunchKernelGGL((coarse_bf16_kernel<true, 2>), dim3(grid), dim3(256), 0, s, Qs, qnorm, Cs, cnorm, nq, nlist, nslab, tq,
                            ntiles, nullptr, G, bound, cand_cnt, cand, cap, g16);
     } else {
-        hipLaunchKernelGGL((coarse_bf16_kernel<false, 1>), dim3(grid), dim3(256), 0, s, Qs, qnorm, Cs, cnorm, nq, nlist, nslab, tq,
-                           ntiles, gmin, G, nullptr, nullptr, nullptr, 0, g16);
-        hipLaunchKernelGGL((coarse_bound_kernel<false>), dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, gmin, G, nq, ncand, bound);
+        if (!bound_given) {
+            hipLaunchKernelGGL((coarse_bf16_kernel<false, 1>), dim3(grid), dim3(256), 0, s, Qs, qnorm, Cs, cnorm, nq, nlist, nslab, tq,
+                               ntiles, gmin, G, nullptr, nullptr, nullptr, 0, g16);
+            hipLaunchKernelGGL((coarse_bound_kernel<false>), dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, gmin, G, nq, ncand, bound);
+        }
         hipLaunchKernelGGL((coarse_bf16_kernel<false, 2>), dim3(grid), dim3(256), 0, s, Qs, qnorm, Cs, cnorm, nq, nlist, nslab, tq,
                            ntiles, nullptr, G, bound, cand_cnt, cand, cap, g16);
+    }
+    return hipGetLastError();
+}
+
+// ---- a selection bound from OUTSIDE: the best k-th distance found so far (BRUTE_FORCE: over the chunks already searched) ----
+// kth [nq]: the running k-th best EXACT distance per query (worst value: none yet).  chunk_d [nq][k] (may be null): a chunk's
+// exact result, best first -- its k-th entry, where filled, updates kth.  bound_out[q] = kth widened by the prefilter's eps
+// (the same eps_rel * magnitude the certificate uses, times 1.001): every row whose exact distance is at least as good as
+// kth has approx within the bound.
+template <bool IS_L2>
+__global__ void coarse_ext_bound_kernel(float* __restrict__ kth, const float* __restrict__ chunk_d, int k, int64_t nq,
+                                        const float* __restrict__ qnorm, float cnorm_max, float eps_rel,
+                                        float* __restrict__ bound_out) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) {
+        return;
+    }
+    float b = kth[q];
+    if (chunk_d != nullptr) {
+        const float v = chunk_d[q * k + k - 1];
+        if (v == v && fabsf(v) < FLT_MAX) {
+            b = IS_L2 ? fminf(b, v) : fmaxf(b, v);
+        }
+        kth[q] = b;
+    }
+    const float scale = IS_L2 ? (qnorm[q] + cnorm_max) : sqrtf(qnorm[q] * cnorm_max);
+    const float eps = 1.001f * (eps_rel * scale + 1e-30f);
+    bound_out[q] = IS_L2 ? b + eps : b - eps; // (no k-th yet: +-FLT_MAX stays out of reach of every approx -> everything passes
+                                              // -> the candidate lists overflow -> the exact fallback: never taken, chunk 0
+                                              // runs the two-pass form)
+}
+
+hipError_t launch_coarse_ext_bound(float* kth, const float* chunk_d, int k, int64_t nq, const float* qnorm, float cnorm_max, int d,
+                                   bool is_l2, float* bound_out, hipStream_t s) {
+    if (nq <= 0) {
+        return hipSuccess;
+    }
+    const float eps_rel = 8.0f * (float)d * 5.9604645e-8f + 6.103515625e-5f; // (launch_coarse_rerank's, bf16 form)
+    if (is_l2) {
+        hipLaunchKernelGGL(coarse_ext_bound_kernel<true>, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, kth, chunk_d, k, nq,
+                           qnorm, cnorm_max, eps_rel, bound_out);
+    } else {
+        hipLaunchKernelGGL(coarse_ext_bound_kernel<false>, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, kth, chunk_d, k, nq,
+                           qnorm, cnorm_max, eps_rel, bound_out);
     }
     return hipGetLastError();
 }

@@ -562,7 +562,8 @@ hipError_t launch_coarse_rerank(const float* queries, const float* centroids, in
                                 const float* cand_approx, int nprobe, bool is_l2, const float* qnorm,
                                 float cnorm_max, int64_t* out_keys, float* out_d, int32_t* fail_flags,
                                 unsigned long long* nfail, hipStream_t s, const int32_t* cand_cnt = nullptr,
-                                const float* bound = nullptr);
+                                const float* bound = nullptr,
+                                bool need_kth = true);
 // the coarse prefilter on the bf16 matrix pipe with the selection fused (two GEMM passes, no distance matrix): per query
 // bound[q] and cand_cnt[q] unordered candidates (capacity cap) = every centroid with approx <= bound[q]
 bool coarse_bf16_supports(int64_t nlist, int ncand);
@@ -571,7 +572,9 @@ int coarse_bf16_slabs(int d);
 hipError_t launch_coarse_bf16_split(const float* x, int64_t n, int d, void* out, hipStream_t s);
 hipError_t launch_coarse_bf16(const void* q_split, const float* qnorm, const void* c_split, const float* cnorm, int64_t nq,
                               int64_t nlist, int d, bool is_l2, int ncand, int cap, float* gmin, float* bound,
-                              int32_t* cand_cnt, int64_t* cand, hipStream_t s);
+                              int32_t* cand_cnt, int64_t* cand, hipStream_t s, bool bound_given = false);
+hipError_t launch_coarse_ext_bound(float* kth, const float* chunk_d, int k, int64_t nq, const float* qnorm, float cnorm_max, int d,
+                                   bool is_l2, float* bound_out, hipStream_t s);
 
 // ---- refine.hip ----
 // row_type: 0 fp32 rows (base), 1 fp16, 2 bf16, 3 per-dimension 8-bit codes with sq_trained = vmin[d], vdiff[d] (base is

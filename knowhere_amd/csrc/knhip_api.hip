@@ -138,6 +138,7 @@ struct Workspace {
     DevBuf ms_qh, ms_ql, ms_qs;                                      // SQ8 IP: prepared query operands (halves) + sums
                                                                      // (IVF-PQ prefilter: ms_qh = half tables, ms_qs = scales)
     DevBuf pq_recs, pq_ctr;                                          // pq_filter.hip: unit records, per-XCD counters
+    DevBuf bf_kth;                                                   // BRUTE_FORCE on the matrix cores: the running k-th best per query over the chunks searched
     DevBuf ms_qh16, ms_qd, pq_spill;                                 // pq_decode.hip: the queries as halves, their error records, parked lanes beyond LDS
     DevBuf rs_sort;                                                  // row selection of more than 16384 keys: sort scratch
     // host-boundary staging
@@ -391,8 +392,17 @@ struct CoarseRows {
     int64_t n;
 };
 
+// a search over several row sets one after the other (the chunks of a BRUTE_FORCE base): the k-th best distance found so far
+// bounds what a later chunk can contribute, so only the FIRST chunk needs the two-pass form (group minima -> bound ->
+// candidates); the others take the running k-th, widened by the prefilter's eps, as their selection bound and make ONE pass
+struct RowsRun {
+    float* kth;          // [nq] running k-th best exact distance (worst value before the first chunk)
+    bool have_bound;     // a chunk has been searched: kth bounds this one
+    bool queries_ready;  // the queries' norms and split operand rows of this batch are in the workspace already
+};
+
 int coarse_rows_stage(const knhip_index* idx, Workspace* ws, const CoarseRows& R, const float* d_q, int64_t nq, int nprobe,
-                      int64_t* keys, float* cdis, hipStream_t s) {
+                      int64_t* keys, float* cdis, hipStream_t s, RowsRun* run = nullptr) {
     const int64_t nlist = R.n;
     const int d = idx->d;
     const bool is_l2 = idx->is_l2;
@@ -427,7 +437,10 @@ int coarse_rows_stage(const knhip_index* idx, Workspace* ws, const CoarseRows& R
     HIP_TRY(ws->cand_keys.reserve((size_t)nq * ncand * sizeof(int64_t)));
     HIP_TRY(ws->cand_approx.reserve((size_t)nq * ncand * sizeof(float)));
     HIP_TRY(ws->fail_flags.reserve(((size_t)nq + 1) * sizeof(int32_t))); // (+ the "any flag" summary)
-    HIP_TRY(launch_row_norms(d_q, nq, d, ws->qnorm.as<float>(), s));
+    const bool q_ready = run != nullptr && run->queries_ready;
+    if (!q_ready) {
+        HIP_TRY(launch_row_norms(d_q, nq, d, ws->qnorm.as<float>(), s));
+    }
     if (idx->coarse_gemm == 2 && R.rows_bs != nullptr && coarse_bf16_supports(nlist, (int)ncand)) {
         // bf16 matrix pipe, selection fused, no nq x nlist matrix (coarse_gemm.hip, round 5)
         int cap = 256;
@@ -439,19 +452,36 @@ int coarse_rows_stage(const knhip_index* idx, Workspace* ws, const CoarseRows& R
         HIP_TRY(ws->cg_cnt.reserve((size_t)nq * sizeof(int32_t)));
         HIP_TRY(ws->cand_keys.reserve((size_t)nq * cap * sizeof(int64_t)));
         HIP_TRY(ws->cg_qs.reserve((size_t)nq * coarse_bf16_slabs(d) * 128));
-        HIP_TRY(launch_coarse_bf16_split(d_q, nq, d, ws->cg_qs.p, s));
+        if (!q_ready) {
+            HIP_TRY(launch_coarse_bf16_split(d_q, nq, d, ws->cg_qs.p, s));
+        }
+        const bool bound_given = run != nullptr && run->have_bound;
+        if (bound_given) {
+            HIP_TRY(launch_coarse_ext_bound(run->kth, nullptr, nprobe, nq, ws->qnorm.as<float>(), R.norm_max, d, is_l2,
+                                            ws->cg_bound.as<float>(), s));
+        }
         HIP_TRY(launch_coarse_bf16(ws->cg_qs.p, ws->qnorm.as<float>(), R.rows_bs, R.norm, nq, nlist,
                                    d, is_l2, (int)ncand, cap, ws->cg_gmin.as<float>(), ws->cg_bound.as<float>(),
-                                   ws->cg_cnt.as<int32_t>(), ws->cand_keys.as<int64_t>(), s));
+                                   ws->cg_cnt.as<int32_t>(), ws->cand_keys.as<int64_t>(), s, bound_given));
         HIP_TRY(launch_coarse_rerank(d_q, R.rows, d, nq, nlist, cap, ws->cand_keys.as<int64_t>(), nullptr,
                                      nprobe, is_l2, ws->qnorm.as<float>(), R.norm_max, keys, cdis,
                                      ws->fail_flags.as<int32_t>(), idx->coarse_fail_dev.as<unsigned long long>(), s,
-                                     ws->cg_cnt.as<int32_t>(), ws->cg_bound.as<float>()));
+                                     ws->cg_cnt.as<int32_t>(), ws->cg_bound.as<float>(), /*need_kth=*/!bound_given));
         // exact fallback, restricted on the device to the flagged queries (normally none)
         HIP_TRY(launch_flat_full(c, is_l2, ws->coarse_full.as<float>(), nullptr, 0, ws->fail_flags.as<int32_t>(), s));
         HIP_TRY(launch_row_select(ws->coarse_full.as<float>(), nq, nlist, nprobe, is_l2, keys, cdis,
                                   ws->fail_flags.as<int32_t>(), s));
+        if (run != nullptr) { // this chunk's k-th best (where it found k rows) tightens the running one
+            HIP_TRY(launch_coarse_ext_bound(run->kth, cdis, nprobe, nq, ws->qnorm.as<float>(), R.norm_max, d, is_l2,
+                                            ws->cg_bound.as<float>(), s));
+            run->have_bound = true;
+            run->queries_ready = true;
+        }
         return KNHIP_OK;
+    }
+    if (run != nullptr) {
+        run->have_bound = false; // (the other forms of the stage keep no running bound)
+        run->queries_ready = false;
     }
     HIP_TRY(launch_coarse_gemm(d_q, ws->qnorm.as<float>(), R.rows, R.norm, nq,
                                nlist, d, is_l2, ws->coarse_full.as<float>(), s));
@@ -911,14 +941,19 @@ int bf_mfma_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64
     HIP_TRY(ws->cdis.reserve((size_t)nqb * k * sizeof(float)));
     {
         StageTimer t(idx, s, KNHIP_STAGE_SCAN);
+        HIP_TRY(ws->bf_kth.reserve((size_t)nqb * sizeof(float)));
         for (int64_t q0 = 0; q0 < nq; q0 += nqb) {
             const int64_t n = std::min(nqb, nq - q0);
+            // (one pass over every chunk but the first: the k-th best of the chunks searched so far is the selection bound)
+            HIP_TRY(launch_fill_f32(ws->bf_kth.as<float>(), n, idx->is_l2 ? FLT_MAX : -FLT_MAX, s));
+            RowsRun run{ws->bf_kth.as<float>(), false, false};
             for (int64_t c = 0; c < nch; c++) {
                 const int64_t r0 = c * per, rn = std::min(per, nb - r0);
                 CoarseRows R{idx->codes_aos.as<float>() + r0 * d, idx->rows.as<float4>() + (r0 / 64) * nchunk4 * 64,
                              static_cast<const unsigned char*>(idx->rows_bs.p) + (size_t)r0 * nslab * 128,
                              idx->bf_norm.as<float>() + r0, idx->bf_norm_max, rn};
-                if (int rc = coarse_rows_stage(idx, ws, R, d_q + q0 * d, n, k, ws->keys.as<int64_t>(), ws->cdis.as<float>(), s)) {
+                if (int rc = coarse_rows_stage(idx, ws, R, d_q + q0 * d, n, k, ws->keys.as<int64_t>(), ws->cdis.as<float>(), s,
+                                               &run)) {
                     return rc;
                 }
                 hipLaunchKernelGGL(bf_place_kernel, dim3((unsigned)((n * k + 255) / 256)), dim3(256), 0, s, ws->keys.as<int64_t>(),

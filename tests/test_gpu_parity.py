@@ -99,6 +99,28 @@ def test_brute_force_on_the_matrix_cores(torch_cuda, port, metric, monkeypatch):
     assert np.array_equal(I0, I1) and np.array_equal(D0.view(np.uint32), D1.view(np.uint32))
     g0.close()
     g1.close()
+    # four chunks: every chunk but the first takes the running k-th best (widened by the prefilter's eps) as its selection
+    # bound and makes ONE pass; rows EQUAL to that k-th -- copies planted in the later chunks -- must still be found
+    nb = 400_000
+    xb = gen_data(nb, d, 43)
+    xb[150_000:150_004] = xb[9]
+    xb[390_000:390_003] = xb[9]
+    xq2 = np.concatenate([xb[9:10] + 0.001, gen_data(nq, d, 45)]).astype(np.float32)
+    g1 = GpuIndex(0, metric, d)
+    g1.add_vectors(xb)
+    monkeypatch.setenv("KNHIP_BF", "exact")
+    g0 = GpuIndex(0, metric, d)
+    g0.add_vectors(xb)
+    monkeypatch.delenv("KNHIP_BF")
+    g1.profile_enable(True)
+    for k in (5, 10, 300):
+        g1.profile_reset()
+        D1, I1 = g1.search(xq2, k)
+        assert g1.profile_get()["pq_filter_form"] == 10
+        D0, I0 = g0.search(xq2, k)
+        assert np.array_equal(I0, I1) and np.array_equal(D0.view(np.uint32), D1.view(np.uint32)), f"four chunks, k={k}"
+    g0.close()
+    g1.close()
 
 
 def test_brute_force_self_hit(torch_cuda):
