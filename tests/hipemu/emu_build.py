@@ -111,7 +111,7 @@ def patch_generic(s):
 
 # the whole library (C ABI + orchestration + kernels) for API-level emulation; prims.hip / build.hip stay out (their
 # entry points resolve to aborting stubs generated from the link's undefined symbols)
-API_FILES = ["knhip_api.hip", "flat_scan.hip", "sq_scan.hip", "topk.hip", "worktable.hip", "coarse_gemm.hip", "refine.hip",
+API_FILES = ["knhip_api.hip", "knhip_api_build.hip", "knhip_api_prims.hip", "flat_scan.hip", "sq_scan.hip", "topk.hip", "worktable.hip", "coarse_gemm.hip", "refine.hip",
              "range.hip", "mfma_scan.hip", "mfma_scan_bf16.hip", "pq_filter.hip", "pq_decode.hip", "pq_scan.hip", "pq_scan_v2.hip", "pq_scan_q4.hip", "pq_scan_any.hip"]
 
 
@@ -120,7 +120,7 @@ def build_api(force=False):
     harness (knowhere_amd/index.py) and orchestration (knhip_api.hip)"""
     os.makedirs(BUILD, exist_ok=True)
     so = os.path.join(BUILD, "libknhip_emu.so")
-    srcs = [os.path.join(CSRC, f) for f in API_FILES + ["common.h", "kernels.h", "ms_common.h"]]
+    srcs = [os.path.join(CSRC, f) for f in API_FILES + ["common.h", "kernels.h", "ms_common.h", "knhip_internal.h"]]
     srcs += [os.path.join(HERE, f) for f in ("emu_runtime.cpp", "emu_build.py", "hip/hip_runtime.h")]
     if not force and os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(p) for p in srcs):
         return so
