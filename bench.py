@@ -837,14 +837,18 @@ def make_roofline(a, kind, prof, world):
         hbm_algo = scan_bytes / sec / 1e9 if sec > 0 else 0.0
         common["hbm_algorithmic_GBps"], common["hbm_algorithmic_frac"] = round(hbm_algo, 1), round(hbm_algo / HBM_PEAK_GBPS, 4)
     if kind == kidx.BRUTE_FORCE and prof.get("pq_filter_form", 0) == 10:
-        # the coarse quantizer's machinery over the base rows (knhip_api.hip::bf_mfma_batch): two GEMM passes of three bf16
-        # products each + bound + exact re-rank; ALGORITHMIC work 2 nq nb d flop, executed 6 x that
+        # the coarse quantizer's machinery over the base rows (knhip_api.hip::bf_mfma_batch): GEMM passes of three bf16 products
+        # each + bound + exact re-rank; the base is cut into chunks of <= 131072 rows, the first chunk takes two passes (group
+        # minima -> bound -> candidates), every other chunk ONE (the running k-th best is its bound).  ALGORITHMIC work
+        # 2 nq nb d flop, executed 3 x (chunks + 1) / chunks x that
         algo = 2.0 * a.nq * (a.nb / world) * a.d
         tf_a = algo / sec / 1e12 if sec > 0 else 0.0
-        return dict({"bound": "mfma", "kernel": "knhip::coarse_bf16_kernel (BRUTE_FORCE rows: two passes x hi hi + hi lo + lo hi)",
-                     "achieved": round(6.0 * tf_a, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(6.0 * tf_a / MFMA_F16_PEAK_TFLOPS, 4),
-                     "executed": {"flop_per_mac": 12, "TFLOPs": round(6.0 * tf_a, 2)},
+        nch = max(1, -(-int(a.nb / world) // 131072))
+        ex = 3.0 * (nch + 1) / nch
+        return dict({"bound": "mfma", "kernel": f"knhip::coarse_bf16_kernel (BRUTE_FORCE rows: {nch + 1} passes over {nch} chunk(s) x hi hi + hi lo + lo hi)",
+                     "achieved": round(ex * tf_a, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(ex * tf_a / MFMA_F16_PEAK_TFLOPS, 4),
+                     "executed": {"flop_per_mac": round(2 * ex, 3), "TFLOPs": round(ex * tf_a, 2)},
                      "algorithmic": {"flop_per_mac": 2, "TFLOPs": round(tf_a, 2), "frac": round(tf_a / MFMA_F16_PEAK_TFLOPS, 4),
                                      "frac_of_fp32_matrix_peak": round(tf_a / MFMA_F32_PEAK_TFLOPS, 4)}}, **common)
     pairs_dims = scan_bytes / code_size * a.d

@@ -357,6 +357,16 @@ int build_list_layout(knhip_index* idx, const std::vector<int64_t>& list_off, co
 int ensure_aos(const knhip_index* cidx);
 Workspace* acquire_ws(const knhip_index* idx, void* stream_key, bool pooled_by_stream);
 void release_ws(const knhip_index* idx, Workspace* w);
+// one batch of queries, everything on the device (pre_keys / pre_cdis non-null: the coarse assignment is given)
+int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_t nq, int k, int nprobe, const uint8_t* d_bitset,
+                 int64_t nbits, int64_t* d_out_i, float* d_out_d, hipStream_t s, const int64_t* pre_keys = nullptr,
+                 const float* pre_cdis = nullptr);
+int validate_search(const knhip_index* idx, int64_t nq, int32_t k, int32_t& nprobe);
+int64_t query_batch(const knhip_index* idx, int64_t nq, int k, int nprobe);
+// search_batch + the reference's first-come admission at the k-th boundary (knhip_api_range.hip)
+int search_batch_ties(const knhip_index* idx, Workspace* ws, const float* d_q, int64_t nq, int k, int nprobe,
+                      const uint8_t* d_bitset, int64_t nbits, int64_t* d_out_i, float* d_out_d, hipStream_t s,
+                      const int64_t* pre_keys, const float* pre_cdis);
 // BRUTE_FORCE rows -> the interleaved blocks (knhip_index_add_vectors*; the GPU build appends through it)
 int add_vectors_common(knhip_index* idx, int64_t n, const float* d_x, const int64_t* d_ids, int64_t id_offset);
 } // namespace knhip_host

@@ -111,7 +111,7 @@ def patch_generic(s):
 
 # the whole library (C ABI + orchestration + kernels) for API-level emulation; prims.hip / build.hip stay out (their
 # entry points resolve to aborting stubs generated from the link's undefined symbols)
-API_FILES = ["knhip_api.hip", "knhip_api_build.hip", "knhip_api_prims.hip", "flat_scan.hip", "sq_scan.hip", "topk.hip", "worktable.hip", "coarse_gemm.hip", "refine.hip",
+API_FILES = ["knhip_api.hip", "knhip_api_build.hip", "knhip_api_prims.hip", "knhip_api_rows.hip", "knhip_api_range.hip", "flat_scan.hip", "sq_scan.hip", "topk.hip", "worktable.hip", "coarse_gemm.hip", "refine.hip",
              "range.hip", "mfma_scan.hip", "mfma_scan_bf16.hip", "pq_filter.hip", "pq_decode.hip", "pq_scan.hip", "pq_scan_v2.hip", "pq_scan_q4.hip", "pq_scan_any.hip"]
 
 
