@@ -1254,6 +1254,15 @@ struct BruteForce {
     static expected<DataSetPtr>
     Search(const DataSetPtr base_dataset, const DataSetPtr query_dataset, const Json& config, const BitsetView& bitset,
            milvus::OpContext* op_context = nullptr);
+    // (include/knowhere/comp/brute_force.h:41-58: the caller's result buffers / the radius search)
+    template <typename DataType>
+    static Status
+    SearchWithBuf(const DataSetPtr base_dataset, const DataSetPtr query_dataset, int64_t* ids, float* dis, const Json& config,
+                  const BitsetView& bitset, milvus::OpContext* op_context = nullptr);
+    template <typename DataType>
+    static expected<DataSetPtr>
+    RangeSearch(const DataSetPtr base_dataset, const DataSetPtr query_dataset, const Json& config, const BitsetView& bitset,
+                milvus::OpContext* op_context = nullptr);
 };
 
 }  // namespace knowhere

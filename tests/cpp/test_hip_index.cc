@@ -499,6 +499,51 @@ int main() {
         }
     }
 
+    {   // the static BruteForce functions beside Search (include/knowhere/comp/brute_force.h:41-58): SearchWithBuf fills the
+        // caller's buffers with Search's answer; RangeSearch returns every row inside the radius and nothing else (checked
+        // against the k = 64 search: a query's neighbours under the radius are exactly the prefix of its sorted list)
+        Json cfg = base_gen();
+        cfg[meta::TOPK] = 64;
+        auto g = BruteForce::Search<fp32>(train_ds, query_ds, cfg, nullptr);
+        REQUIRE(g.has_value());
+        std::vector<int64_t> bi((size_t)nq * 64);
+        std::vector<float> bd((size_t)nq * 64);
+        REQUIRE(BruteForce::SearchWithBuf<fp32>(train_ds, query_ds, bi.data(), bd.data(), cfg, nullptr) == Status::success);
+        int diff = 0;
+        for (int64_t i = 0; i < nq * 64; i++) {
+            diff += bi[i] != g.value()->GetIds()[i];
+            diff += bd[i] != g.value()->GetDistance()[i];
+        }
+        REQUIRE(diff == 0);
+        REQUIRE(BruteForce::SearchWithBuf<fp32>(train_ds, query_ds, nullptr, bd.data(), cfg, nullptr) == Status::invalid_args);
+        std::vector<float> d8(nq);
+        for (int64_t i = 0; i < nq; i++) d8[i] = g.value()->GetDistance()[i * 64 + 8];
+        std::nth_element(d8.begin(), d8.begin() + nq / 2, d8.end());
+        const float radius = d8[nq / 2];  // (about 8 neighbours per query: far inside the 64 of the search)
+        Json rcfg = base_gen();
+        rcfg[meta::RADIUS] = radius;
+        rcfg[meta::RANGE_FILTER] = 0.0f;
+        auto rr = BruteForce::RangeSearch<fp32>(train_ds, query_ds, rcfg, nullptr);
+        REQUIRE(rr.has_value());
+        if (rr.has_value()) {
+            const size_t* lims = rr.value()->GetLims();
+            int wrong = 0;
+            for (int64_t i = 0; i < nq; i++) {
+                int64_t want = 0;
+                while (want < 64 && g.value()->GetDistance()[i * 64 + want] < radius) want++;
+                if (want == 64) continue;  // (more than the search saw: not decidable from it)
+                wrong += (int64_t)(lims[i + 1] - lims[i]) != want;
+                for (size_t j = lims[i]; j < lims[i + 1]; j++) {
+                    bool found = false;
+                    for (int64_t t = 0; t < want; t++) found |= g.value()->GetIds()[i * 64 + t] == rr.value()->GetIds()[j];
+                    wrong += !found;
+                }
+            }
+            REQUIRE(wrong == 0);
+            std::printf("== BruteForce::RangeSearch: %zu results inside radius %.3f\n", lims[nq], radius);
+        }
+    }
+
     {   // config limits of the backend (hip_index_node.h): m, dim % m, nbits outside 1 .. 8, sq_type
         std::string msg;
         Json cfg = ivfpq_gen();
