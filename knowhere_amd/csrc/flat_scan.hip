@@ -474,6 +474,9 @@ hipError_t launch_flat_scan(const FlatScanArgs& a, bool is_l2, bool dense, int64
     if (grid <= 0) {
         return hipSuccess;
     }
+    if (!a.item_loop) {
+        grid = (grid + 7) / 8 * 8; // (xcd_item spreads the items over the blocks [0, round_up(nitems, 8)))
+    }
     if (is_l2) {
         return dense ? launch_flat_scan_t<true, true>(a, grid, s, 0)
                      : launch_flat_scan_t<true, false>(a, grid, s, qg_override);

@@ -580,6 +580,10 @@ hipError_t launch_pq_scan(const PqScanArgs& a, bool is_l2, int M, int64_t grid, 
     if (grid <= 0) {
         return hipSuccess;
     }
+    // xcd_item spreads the items over the blocks [0, round_up(nitems, 8)): a grid that is not a multiple of 8 leaves up to
+    // seven items of the last stretch without a block (the prefilter's exact fallback launched one block per PAIR: with
+    // 258 one-pair items, six partial lists were never written -- found by tests/test_gpu_pqd_fuzz.py, round 6)
+    grid = (grid + 7) / 8 * 8;
     switch (M) {
         case 8:
             return launch_pq_scan_m8(a, is_l2, grid, s);

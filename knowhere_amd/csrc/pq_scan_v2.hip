@@ -563,6 +563,7 @@ hipError_t launch_pq_scan_v2(const PqScanArgs& a, bool is_l2, bool dump, int64_t
     if (grid <= 0) {
         return hipSuccess;
     }
+    grid = (grid + 7) / 8 * 8; // (xcd_item: blocks [0, round_up(nitems, 8)), see launch_pq_scan)
     if (dump) {
         return is_l2 ? launch_v2_r<true, 1, true>(a, grid, s) : launch_v2_r<false, 1, true>(a, grid, s);
     }

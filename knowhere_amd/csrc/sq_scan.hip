@@ -287,6 +287,9 @@ hipError_t launch_sq_scan(const SqScanArgs& a, bool is_l2, int64_t grid, hipStre
     if (grid <= 0) {
         return hipSuccess;
     }
+    if (!a.item_loop) {
+        grid = (grid + 7) / 8 * 8; // (xcd_item spreads the items over the blocks [0, round_up(nitems, 8)))
+    }
     const int dpad = a.nchunk16 * 16;
     const int k = a.k;
     if (k > KN_MAX_K) {

@@ -1,0 +1,92 @@
+"""GPU (-m gpu): randomized shapes through the decode form of the IVF-PQ prefilter (knowhere_amd/csrc/pq_decode.hip: loads in a
+hand-managed ring of named registers, one wave per unit, parked records, per-pair reservations) against the exact ADC kernels
+on the SAME index -- ids and distance bits equal.  The exact kernels are pinned against the oracle / the reference build in
+tests/test_gpu_pqf.py, test_gpu_parity.py and test_gpu_scale_parity.py; this file only asks that no shape -- list lengths from
+empty to tens of tiles, 1 .. 4 query tiles per unit, k up to 1000, heavy filters, units that overflow their record regions --
+makes the two disagree.  The index is trained and filled on the device (fast), then attached twice."""
+import types
+
+import numpy as np
+import pytest
+
+from conftest import gen_data
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    return torch
+
+
+def _clustered(n, d, ncenter, sigma, seed):
+    r = np.random.default_rng(seed)
+    c = r.random((ncenter, d), dtype=np.float32) * 10.0
+    return (c[r.integers(0, ncenter, n)] + sigma * r.standard_normal((n, d), dtype=np.float32)).astype(np.float32)
+
+
+def _index_pair(monkeypatch, metric, xb, nlist, spill=None):
+    """one device-built IVF-PQ m = 32 index, attached as (exact kernels, decode-form prefilter)"""
+    from knowhere_amd import GpuIndex
+    d = xb.shape[1]
+    b = GpuIndex(2, metric, d, nlist, 32, 8, device=0)
+    b.train(xb)
+    b.add(xb)
+    sizes, codes, ids = b.get_lists()
+    ix = types.SimpleNamespace(kind=2, metric=metric, d=d, nlist=nlist, M=32, nbits=8, centroids=b.get_coarse(),
+                               pq_centroids=b.get_pq(), list_codes=[], list_ids=[])
+    pos = 0
+    for l in range(nlist):
+        n = int(sizes[l])
+        ix.list_codes.append(codes[pos:pos + n])
+        ix.list_ids.append(ids[pos:pos + n])
+        pos += n
+    b.close()
+    monkeypatch.setenv("KNHIP_PQF", "0")
+    g0 = GpuIndex.from_data(ix, device=0)
+    monkeypatch.setenv("KNHIP_PQF", "1")
+    monkeypatch.setenv("KNHIP_PQF_GUARD", "0")
+    monkeypatch.setenv("KNHIP_PQF_FORM", "decode")
+    if spill is not None:
+        monkeypatch.setenv("KNHIP_PQD_SPILL", str(spill))
+    g1 = GpuIndex.from_data(ix, device=0)
+    for v in ("KNHIP_PQF", "KNHIP_PQF_GUARD", "KNHIP_PQF_FORM", "KNHIP_PQD_SPILL"):
+        monkeypatch.delenv(v, raising=False)
+    return g0, g1
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_decode_form_equals_the_exact_kernels_on_random_shapes(torch_cuda, monkeypatch, seed):
+    r = np.random.default_rng(1000 + seed)
+    metric = int(r.integers(0, 2))
+    d = 128
+    nb = int(r.choice([3000, 20000, 90000, 250000]))
+    nlist = int(r.choice([4, 16, 64, 256])) if nb >= 20000 else int(r.choice([4, 16, 40]))
+    clustered = bool(r.integers(0, 2))
+    xb = _clustered(nb, d, 200, 0.4, seed) if clustered else gen_data(nb, d, seed, -5.0, 5.0)
+    if seed % 3 == 0:
+        xb[100:180] = xb[7]  # identical rows: identical codes, ties in the lists
+    g0, g1 = _index_pair(monkeypatch, metric, xb, nlist, spill=16 if seed % 6 == 5 else None)
+    g1.profile_enable(True)
+    ran = 0
+    for case in range(5):
+        nq = int(r.choice([1, 3, 40, 130, 600]))
+        k = int(r.choice([1, 10, 100, 128, 500, 1000]))
+        nprobe = int(min(nlist, r.choice([1, 2, 8, 32, 256])))
+        xq = (xb[r.integers(0, nb, nq)] + 0.05 * r.standard_normal((nq, d), dtype=np.float32)).astype(np.float32) \
+            if clustered else gen_data(nq, d, 77 + case, -5.0, 5.0)
+        frac = float(r.choice([0.0, 0.0, 0.3, 0.9, 0.995]))
+        bs = np.packbits(r.random(nb) < frac, bitorder="little") if frac > 0 else None
+        g1.profile_reset()
+        D1, I1 = g1.search(xq, k, nprobe, bs, nb if bs is not None else 0)
+        p = g1.profile_get()
+        D0, I0 = g0.search(xq, k, nprobe, bs, nb if bs is not None else 0)
+        what = f"seed={seed} case={case} metric={metric} nb={nb} nlist={nlist} nq={nq} k={k} nprobe={nprobe} filter={frac}"
+        assert np.array_equal(I0, I1), what + f": {int((I0 != I1).any(1).sum())} queries differ in ids"
+        assert np.array_equal(D0.view(np.uint32), D1.view(np.uint32)), what + ": distance bits"
+        ran += p["pq_filter_form"] == 3
+    assert ran > 0, "the decode form never ran"
+    g0.close()
+    g1.close()

@@ -189,6 +189,26 @@ def test_pqd_parked_records_overflow_route(torch_cuda, port, monkeypatch):
     g1.close()
 
 
+@pytest.mark.parametrize("nq", [127, 129, 130, 257])
+def test_pqf_exact_fallback_item_counts_off_the_multiple_of_eight(torch_cuda, port, monkeypatch, nq):
+    """k = 500, two short probed lists, 90 % of the ids filtered: no query finds k rows in its sample, every query is flagged and its (query, list)
+    pairs become one-pair items of the systolic exact kernel (k > 128) -- 2 nq items, here NOT a multiple of 8.  That kernel
+    spreads its items over the blocks [0, round_up(items, 8)) (xcd_item): launched with one block per pair, the last up to
+    seven items had no block and their partial lists stayed unwritten (whatever the freshly allocated scratch held was merged:
+    found by tests/test_gpu_pqd_fuzz.py in round 6, present since the prefilter's k > 128 fallback of round 3).  A FRESH index
+    per case: a second search of the same shape finds the first one's correct partial lists in the scratch."""
+    nb, d, nlist = 3000, 128, 40
+    xb = gen_data(nb, d, 42)
+    xq = gen_data(nq, d, 44)
+    ix = finish_ivfpq(port, ob.make_index(port, ob.IVF_PQ, ob.IP, xb, nlist=nlist, M=32))
+    bs = _bitset(nb, 0.9, 5)  # (a tenth of the rows left: no sample holds k of them -> every query is flagged)
+    g0, g1 = _pair(monkeypatch, ix, guard=False)
+    p = _check(port, ix, g0, g1, xq, 500, 2, ob.IP, f"one-pair items, nq={nq}", bs, nb)
+    assert p["mscan_overflow_queries"] >= nq - 2
+    g0.close()
+    g1.close()
+
+
 def test_pqf_headline_shape_long_lists(torch_cuda, port, monkeypatch):
     """d = 128, m = 32, lists of ~3000 codes (many windows per wave), batch large enough for full 8-query units"""
     nb, d = 200000, 128

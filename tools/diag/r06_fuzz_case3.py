@@ -1,0 +1,44 @@
+import os, sys
+import numpy as np
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import torch; torch.cuda.is_available()
+from conftest import gen_data
+from helpers import finish_ivfpq
+from oracle import binding as ob
+from knowhere_amd import GpuIndex
+port = ob.Port()
+os.environ["KNHIP_TIES"] = "canonical"
+def clustered(n, d, ncenter, sigma, seed):
+    rr = np.random.default_rng(seed)
+    c = rr.random((ncenter, d), dtype=np.float32) * 10.0
+    return (c[rr.integers(0, ncenter, n)] + sigma * rr.standard_normal((n, d), dtype=np.float32)).astype(np.float32)
+nb, d, nlist = 3000, 128, 40
+xb = clustered(nb, d, 200, 0.4, 10)
+r = np.random.default_rng(5)
+xq_all = (xb[r.integers(0, nb, 700)] + 0.05 * r.standard_normal((700, d), dtype=np.float32)).astype(np.float32)
+bs = np.packbits(r.random(nb) < 0.3, bitorder="little")
+for metric in (1, 0):
+    b = GpuIndex(2, metric, d, nlist, 32, 8, device=0); b.train(xb); b.add(xb)
+    sizes, codes, ids = b.get_lists()
+    ix = ob.IndexData(ob.IVF_PQ, metric, d, nlist, 32, 8)
+    ix.centroids, ix.pq_centroids = b.get_coarse(), b.get_pq()
+    pos = 0
+    for l in range(nlist):
+        n = int(sizes[l]); ix.list_codes.append(codes[pos:pos+n]); ix.list_ids.append(ids[pos:pos+n]); pos += n
+    if metric == ob.L2: ix.use_precomputed_table = 1
+    ix = finish_ivfpq(port, ix); b.close()
+    os.environ.update({"KNHIP_PQF": "1", "KNHIP_PQF_GUARD": "0", "KNHIP_PQF_FORM": "decode"}); g = GpuIndex.from_data(ix, device=0)
+    for v in ("KNHIP_PQF", "KNHIP_PQF_GUARD", "KNHIP_PQF_FORM"): os.environ.pop(v, None)
+    g.profile_enable(True)
+    for k, nprobe in ((500, 2), (1000, 2), (500, 3), (200, 1)):
+        for nq in (64, 127, 128, 129, 130, 200, 257, 600):
+            xq = xq_all[:nq]
+            Do, Io = port.search(ix, xq, k, nprobe, bs, nb)
+            res = []
+            for rep in range(3):
+                g.profile_reset()
+                D, I = g.search(xq, k, nprobe, bs, nb)
+                p = g.profile_get()
+                bad = np.flatnonzero((I != Io).any(1) | (D.view(np.uint32) != Do.view(np.uint32)).any(1))
+                res.append(len(bad))
+            print(f"metric {metric} k {k} nprobe {nprobe} nq {nq} pairs {nq*nprobe}: bad per run {res} (overflowed {p['mscan_overflow_queries']}) bad queries {bad[:6]}")
