@@ -4,6 +4,7 @@ on the SAME index -- ids and distance bits equal.  The exact kernels are pinned 
 tests/test_gpu_pqf.py, test_gpu_parity.py and test_gpu_scale_parity.py; this file only asks that no shape -- list lengths from
 empty to tens of tiles, 1 .. 4 query tiles per unit, k up to 1000, heavy filters, units that overflow their record regions --
 makes the two disagree.  The index is trained and filled on the device (fast), then attached twice."""
+import os
 import types
 
 import numpy as np
@@ -57,7 +58,7 @@ def _index_pair(monkeypatch, metric, xb, nlist, spill=None):
     return g0, g1
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KNHIP_FUZZ_SEEDS", "24"))))  # (KNHIP_FUZZ_SEEDS=400: a longer hunt)
 def test_decode_form_equals_the_exact_kernels_on_random_shapes(torch_cuda, monkeypatch, seed):
     r = np.random.default_rng(1000 + seed)
     metric = int(r.integers(0, 2))
@@ -88,5 +89,60 @@ def test_decode_form_equals_the_exact_kernels_on_random_shapes(torch_cuda, monke
         assert np.array_equal(D0.view(np.uint32), D1.view(np.uint32)), what + ": distance bits"
         ran += p["pq_filter_form"] == 3
     assert ran > 0, "the decode form never ran"
+    g0.close()
+    g1.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KNHIP_FUZZ_SEEDS", "16"))))
+def test_row_kind_prefilters_equal_the_exact_kernels_on_random_shapes(torch_cuda, monkeypatch, seed):
+    """the same for IVF-Flat (split-bf16 filter, mfma_scan_bf16.hip) and IVF-SQ8 (f16 filter on the code bytes, mfma_scan.hip)
+    with their pruning finish: KNHIP_MSCAN=1 (the prefilter whenever the shape allows) against KNHIP_MSCAN=0 (exact row
+    kernels) on one device-built index; dimensions off the multiples of 16, k up to 1000, heavy filters"""
+    from knowhere_amd import GpuIndex
+    r = np.random.default_rng(2000 + seed)
+    kind = 1 if seed % 2 == 0 else 3
+    metric = int(r.integers(0, 2))
+    d = int(r.choice([24, 64, 100, 128, 200]))
+    nb = int(r.choice([3000, 30000, 120000]))
+    nlist = int(r.choice([4, 16, 64, 200])) if nb >= 30000 else int(r.choice([4, 16, 40]))
+    xb = _clustered(nb, d, 150, 0.5, seed) if seed % 3 else gen_data(nb, d, seed, -3.0, 3.0)
+    if seed % 4 == 0:
+        xb[200:260] = xb[11]
+    b = GpuIndex(kind, metric, d, nlist, 0, 8, device=0)
+    b.train(xb)
+    b.add(xb)
+    sizes, codes, ids = b.get_lists()
+    ix = types.SimpleNamespace(kind=kind, metric=metric, d=d, nlist=nlist, M=0, nbits=8, centroids=b.get_coarse(),
+                               pq_centroids=None, sq_trained=b.get_sq() if kind == 3 else None, list_codes=[], list_ids=[])
+    pos = 0
+    for l in range(nlist):
+        n = int(sizes[l])
+        ix.list_codes.append(codes[pos:pos + n])
+        ix.list_ids.append(ids[pos:pos + n])
+        pos += n
+    b.close()
+    monkeypatch.setenv("KNHIP_MSCAN", "0")
+    g0 = GpuIndex.from_data(ix, device=0)
+    monkeypatch.setenv("KNHIP_MSCAN", "1")
+    g1 = GpuIndex.from_data(ix, device=0)
+    monkeypatch.delenv("KNHIP_MSCAN")
+    g1.profile_enable(True)
+    ran = 0
+    for case in range(5):
+        nq = int(r.choice([1, 5, 70, 129, 500]))
+        k = int(r.choice([1, 10, 100, 128, 500, 1000]))
+        nprobe = int(min(nlist, r.choice([1, 2, 8, 32, 200])))
+        xq = (xb[r.integers(0, nb, nq)] + 0.05 * r.standard_normal((nq, d), dtype=np.float32)).astype(np.float32)
+        frac = float(r.choice([0.0, 0.0, 0.3, 0.9, 0.995]))
+        bs = np.packbits(r.random(nb) < frac, bitorder="little") if frac > 0 else None
+        g1.profile_reset()
+        D1, I1 = g1.search(xq, k, nprobe, bs, nb if bs is not None else 0)
+        p = g1.profile_get()
+        D0, I0 = g0.search(xq, k, nprobe, bs, nb if bs is not None else 0)
+        what = f"seed={seed} case={case} kind={kind} metric={metric} d={d} nb={nb} nlist={nlist} nq={nq} k={k} nprobe={nprobe} filter={frac}"
+        assert np.array_equal(I0, I1), what + f": {int((I0 != I1).any(1).sum())} queries differ in ids"
+        assert np.array_equal(D0.view(np.uint32), D1.view(np.uint32)), what + ": distance bits"
+        ran += (p["mscan_queries"] + p["mscan_overflow_queries"]) > 0
+    assert ran > 0, "the prefilter never ran"
     g0.close()
     g1.close()
