@@ -146,3 +146,70 @@ def test_row_kind_prefilters_equal_the_exact_kernels_on_random_shapes(torch_cuda
     assert ran > 0, "the prefilter never ran"
     g0.close()
     g1.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KNHIP_FUZZ_SEEDS", "10"))))
+def test_brute_force_matrix_core_path_equals_the_row_scan_on_random_shapes(torch_cuda, monkeypatch, seed):
+    """BRUTE_FORCE: the bf16 prefilter + exact re-rank over chunks of the base (one pass per chunk behind the first, the running
+    k-th best as the bound) against the exact row scan (KNHIP_BF=exact): random dimension, row count (1 .. 5 chunks, ragged
+    last chunk), batch, k up to 400, both metrics, duplicated rows"""
+    from knowhere_amd import GpuIndex
+    r = np.random.default_rng(3000 + seed)
+    metric = int(r.integers(0, 2))
+    d = int(r.choice([16, 48, 96, 128, 256]))
+    nb = int(r.choice([40_000, 131_072, 131_073, 300_000, 600_000]))
+    nq = int(r.choice([16, 100, 700]))
+    if nq * nb < 16_000_000:
+        nq = int(16_000_000 // nb + 1)
+    xb = _clustered(nb, d, 300, 0.5, seed) if seed % 2 else gen_data(nb, d, seed, -2.0, 2.0)
+    xb[nb // 2:nb // 2 + 30] = xb[3]
+    xb[nb - 5:] = xb[3]
+    xq = np.concatenate([xb[3:4] + 0.001, xb[r.integers(0, nb, nq - 1)] + 0.1 * r.standard_normal((nq - 1, d), dtype=np.float32)]).astype(np.float32)
+    g1 = GpuIndex(0, metric, d)
+    g1.add_vectors(xb)
+    monkeypatch.setenv("KNHIP_BF", "exact")
+    g0 = GpuIndex(0, metric, d)
+    g0.add_vectors(xb)
+    monkeypatch.delenv("KNHIP_BF")
+    g1.profile_enable(True)
+    for k in (int(r.choice([1, 7, 50])), int(r.choice([99, 100, 400]))):
+        g1.profile_reset()
+        D1, I1 = g1.search(xq, k)
+        assert g1.profile_get()["pq_filter_form"] == 10, "the matrix-core path did not run"
+        D0, I0 = g0.search(xq, k)
+        what = f"seed={seed} metric={metric} d={d} nb={nb} nq={nq} k={k}"
+        assert np.array_equal(I0, I1), what + f": {int((I0 != I1).any(1).sum())} queries differ in ids"
+        assert np.array_equal(D0.view(np.uint32), D1.view(np.uint32)), what + ": distance bits"
+    g0.close()
+    g1.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KNHIP_FUZZ_SEEDS", "12"))))
+def test_ivfpq_any_width_equals_the_oracle_on_random_shapes(torch_cuda, port, seed):
+    """IVF-PQ with a random number of sub-quantizers and a random code width (1 .. 8 bits) against the ORACLE (oracle.c: generic
+    decoder, pinned against the reference build in tests/test_oracle.py): small indexes built by the oracle's helpers, so the
+    host boundary (the reference's bit strings) is part of the path"""
+    from conftest import assert_parity
+    from helpers import finish_ivfpq
+    from oracle import binding as ob
+    from knowhere_amd import GpuIndex
+    r = np.random.default_rng(4000 + seed)
+    metric = int(r.integers(0, 2))
+    d, M = [(128, 32), (128, 16), (64, 8), (96, 12), (128, 64), (48, 4)][int(r.integers(0, 6))]
+    nbits = int(r.integers(1, 9))
+    nb, nlist = int(r.choice([2000, 6000])), int(r.choice([4, 12, 30]))
+    xb = gen_data(nb, d, seed, -4.0, 4.0)
+    ix = finish_ivfpq(port, ob.make_index(port, ob.IVF_PQ, metric, xb, nlist=nlist, M=M, nbits=nbits, seed=seed))
+    g = GpuIndex.from_data(ix, device=0)
+    for case in range(3):
+        nq = int(r.choice([1, 33, 200]))
+        k = int(r.choice([1, 10, 100, 300]))
+        nprobe = int(min(nlist, r.choice([1, 3, 30])))
+        xq = gen_data(nq, d, 90 + case, -4.0, 4.0)
+        frac = float(r.choice([0.0, 0.4, 0.97]))
+        bs = np.packbits(r.random(nb) < frac, bitorder="little") if frac > 0 else None
+        Do, Io = port.search(ix, xq, k, nprobe, bs, nb if bs is not None else 0)
+        D, I = g.search(xq, k, nprobe, bs, nb if bs is not None else 0)
+        assert_parity(Do, Io, D, I, metric, f"seed={seed} d={d} m={M} nbits={nbits} nb={nb} nlist={nlist} nq={nq} k={k} "
+                                            f"nprobe={nprobe} filter={frac}")
+    g.close()
