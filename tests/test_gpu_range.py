@@ -217,3 +217,40 @@ def test_ranked_range_search_counts_rebuild_every_early_stop(port, kind, M, d, m
         assert np.array_equal(ii, exp[1]), (max_empty,)
         assert np.array_equal(dd.view(np.uint32), exp[2].view(np.uint32)), (max_empty,)
     g.close()
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("KNHIP_FUZZ_SEEDS", "10"))))
+def test_range_search_equals_the_oracle_on_random_shapes(port, seed):
+    """random kind (brute force, IVF-Flat, IVF-SQ8, IVF-PQ with m = 32 / 8 / 12 and 8 / 5-bit codes), metric, nlist above and
+    below the rank-wave limit of 128, early stop 0 .. 3, filter, radius taken from a k-th distance: lims, ids in the
+    reference's emission order and distance bits equal to the oracle's"""
+    r = np.random.default_rng(6000 + seed)
+    kind, M, d, nbits = [(ob.FLAT, 0, 40, 8), (ob.IVF_FLAT, 0, 40, 8), (ob.IVF_SQ8, 0, 72, 8), (ob.IVF_PQ, 32, 128, 8),
+                         (ob.IVF_PQ, 8, 64, 8), (ob.IVF_PQ, 12, 48, 5)][int(r.integers(0, 6))]
+    metric = int(r.integers(0, 2))
+    nb = int(r.choice([1500, 8000]))
+    nlist = int(r.choice([6, 40, 150]))
+    xb = gen_data(nb, d, seed, -2.0, 2.0)
+    ix = ob.make_index(port, kind, metric, xb, nlist=nlist, M=max(M, 1), nbits=nbits, seed=seed) if kind != ob.FLAT else \
+        ob.make_index(port, ob.FLAT, metric, xb)
+    ix = finish_ivfpq(port, ix)
+    g = _gpu(ix)
+    for case in range(3):
+        nq = int(r.choice([1, 9, 60]))
+        xq = gen_data(nq, d, 50 + case, -2.0, 2.0)
+        kk = int(r.choice([1, 20, 200]))
+        np_ = max(1, nlist // 3)
+        Dk, _ = port.search(ix, xq, kk, np_) if kind != ob.FLAT else port.search(ix, xq, kk)
+        v = Dk[:, -1]
+        v = v[np.isfinite(v) & (np.abs(v) < 1e30)]
+        if v.size == 0:
+            continue
+        radius = np.float32(np.median(v))
+        max_empty = int(r.integers(0, 4))
+        frac = float(r.choice([0.0, 0.5, 0.97]))
+        bs = _bitset(nb, frac, seed + case) if frac > 0 else None
+        exp = port.range_search(ix, xq, radius, max_empty, bs, nb if bs is not None else 0)
+        got = g.range_search(xq, radius, max_empty, bs, nb if bs is not None else 0)
+        _same(exp, got, f"seed={seed} kind={kind} m={M} nbits={nbits} metric={metric} nb={nb} nlist={nlist} nq={nq} "
+                        f"radius={radius} max_empty={max_empty} filter={frac}")
+    g.close()

@@ -340,3 +340,53 @@ def test_rccl_transport_refuses_one_device_twice(shards):
     dev = (C.c_int32 * 2)(0, 0)
     assert shards.knhip_shard_group_create(C.c_int32(2), dev, C.c_int32(0), C.byref(g)) != 0
     assert b"distinct devices" in shards.knhip_shard_group_last_error()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KNHIP_FUZZ_SEEDS", "8"))))
+def test_sharded_search_equals_the_single_index_on_random_shapes(shards, seed):
+    """random kind / metric / world 2 .. 4 / shape / k / nprobe / filter: the list-sharded group (staged transport, every rank on
+    device 0) returns the single index's ids and distance bits -- boundary ties included (duplicated rows spread over the
+    shards).  Device-built indexes; the single index is the bar (pinned against the oracle elsewhere)."""
+    import types
+    from knowhere_amd import GpuIndex
+    r = np.random.default_rng(5000 + seed)
+    kind = int(r.choice([1, 2, 3]))
+    metric = int(r.integers(0, 2))
+    world = int(r.integers(2, 5))
+    d = 128 if kind == 2 else int(r.choice([32, 96, 128]))
+    nb, nlist = int(r.choice([4000, 40000])), int(r.choice([8, 32, 100]))
+    xb = gen_data(nb, d, seed, -3.0, 3.0)
+    xb[300:340] = xb[5]
+    b = GpuIndex(kind, metric, d, nlist, 32 if kind == 2 else 0, 8, device=0)
+    b.train(xb)
+    b.add(xb)
+    sizes, codes, ids = b.get_lists()
+    ix = types.SimpleNamespace(kind=kind, metric=metric, d=d, nlist=nlist, M=32 if kind == 2 else 0, nbits=8,
+                               centroids=b.get_coarse(), pq_centroids=b.get_pq() if kind == 2 else None,
+                               sq_trained=b.get_sq() if kind == 3 else None, list_codes=[], list_ids=[])
+    pos = 0
+    for l in range(nlist):
+        n = int(sizes[l])
+        ix.list_codes.append(codes[pos:pos + n])
+        ix.list_ids.append(ids[pos:pos + n])
+        pos += n
+    b.close()
+    whole = GpuIndex.from_data(ix, device=0)
+    parts = [GpuIndex.from_data(p, device=0) for p in _split(ix, world)]
+    try:
+        for case in range(4):
+            nq = int(r.choice([1, 17, 300]))
+            k = int(r.choice([1, 10, 100, 400]))
+            nprobe = int(min(nlist, r.choice([1, 4, 100])))
+            xq = np.concatenate([xb[5:6] + 0.001, gen_data(nq, d, 70 + case, -3.0, 3.0)])[:nq].astype(np.float32)
+            frac = float(r.choice([0.0, 0.5, 0.98]))
+            bs = np.packbits(r.random(nb) < frac, bitorder="little") if frac > 0 else None
+            Dw, Iw = whole.search(xq, k, nprobe, bs, nb if bs is not None else 0)
+            D, I, _ = _group_search(shards, parts, [0] * world, 1, xq, k, nprobe, bs, nb if bs is not None else 0)
+            what = f"seed={seed} kind={kind} metric={metric} world={world} d={d} nb={nb} nlist={nlist} nq={nq} k={k} nprobe={nprobe} filter={frac}"
+            assert np.array_equal(I, Iw), what + f": {int((I != Iw).any(1).sum())} queries differ in ids"
+            assert np.array_equal(D.view(np.uint32), Dw.view(np.uint32)), what + ": distance bits"
+    finally:
+        whole.close()
+        for p in parts:
+            p.close()
