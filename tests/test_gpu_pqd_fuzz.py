@@ -28,8 +28,9 @@ def _clustered(n, d, ncenter, sigma, seed):
     return (c[r.integers(0, ncenter, n)] + sigma * r.standard_normal((n, d), dtype=np.float32)).astype(np.float32)
 
 
-def _index_pair(monkeypatch, metric, xb, nlist, spill=None):
-    """one device-built IVF-PQ m = 32 index, attached as (exact kernels, decode-form prefilter)"""
+def _index_pair(monkeypatch, metric, xb, nlist, spill=None, forced=True):
+    """one device-built IVF-PQ m = 32 index, attached as (exact kernels, decode-form prefilter -- forced, guard off; or,
+    forced=False, whatever the library's own decision logic picks: guard, form, exact kernels)"""
     from knowhere_amd import GpuIndex
     d = xb.shape[1]
     b = GpuIndex(2, metric, d, nlist, 32, 8, device=0)
@@ -47,9 +48,11 @@ def _index_pair(monkeypatch, metric, xb, nlist, spill=None):
     b.close()
     monkeypatch.setenv("KNHIP_PQF", "0")
     g0 = GpuIndex.from_data(ix, device=0)
-    monkeypatch.setenv("KNHIP_PQF", "1")
-    monkeypatch.setenv("KNHIP_PQF_GUARD", "0")
-    monkeypatch.setenv("KNHIP_PQF_FORM", "decode")
+    monkeypatch.delenv("KNHIP_PQF")
+    if forced:
+        monkeypatch.setenv("KNHIP_PQF", "1")
+        monkeypatch.setenv("KNHIP_PQF_GUARD", "0")
+        monkeypatch.setenv("KNHIP_PQF_FORM", "decode")
     if spill is not None:
         monkeypatch.setenv("KNHIP_PQD_SPILL", str(spill))
     g1 = GpuIndex.from_data(ix, device=0)
@@ -69,7 +72,8 @@ def test_decode_form_equals_the_exact_kernels_on_random_shapes(torch_cuda, monke
     xb = _clustered(nb, d, 200, 0.4, seed) if clustered else gen_data(nb, d, seed, -5.0, 5.0)
     if seed % 3 == 0:
         xb[100:180] = xb[7]  # identical rows: identical codes, ties in the lists
-    g0, g1 = _index_pair(monkeypatch, metric, xb, nlist, spill=16 if seed % 6 == 5 else None)
+    forced = seed % 4 != 3  # (every fourth shape: the library's own choice of path)
+    g0, g1 = _index_pair(monkeypatch, metric, xb, nlist, spill=16 if seed % 6 == 5 else None, forced=forced)
     g1.profile_enable(True)
     ran = 0
     for case in range(5):
@@ -88,7 +92,7 @@ def test_decode_form_equals_the_exact_kernels_on_random_shapes(torch_cuda, monke
         assert np.array_equal(I0, I1), what + f": {int((I0 != I1).any(1).sum())} queries differ in ids"
         assert np.array_equal(D0.view(np.uint32), D1.view(np.uint32)), what + ": distance bits"
         ran += p["pq_filter_form"] == 3
-    assert ran > 0, "the decode form never ran"
+    assert ran > 0 or not forced, "the decode form never ran"
     g0.close()
     g1.close()
 
