@@ -68,8 +68,11 @@ def test_decode_form_equals_the_exact_kernels_on_random_shapes(torch_cuda, monke
     d = 128
     nb = int(r.choice([3000, 20000, 90000, 250000]))
     nlist = int(r.choice([4, 16, 64, 256])) if nb >= 20000 else int(r.choice([4, 16, 40]))
+    large = os.environ.get("KNHIP_FUZZ_LARGE") == "1"  # (a one-off hunt at sizes where units span hundreds of tiles)
+    if large:
+        nb, nlist = int(r.choice([600_000, 2_000_000])), int(r.choice([128, 512, 2048]))
     clustered = bool(r.integers(0, 2))
-    xb = _clustered(nb, d, 200, 0.4, seed) if clustered else gen_data(nb, d, seed, -5.0, 5.0)
+    xb = _clustered(nb, d, 2000 if large else 200, 0.4, seed) if clustered else gen_data(nb, d, seed, -5.0, 5.0)
     if seed % 3 == 0:
         xb[100:180] = xb[7]  # identical rows: identical codes, ties in the lists
     forced = seed % 4 != 3  # (every fourth shape: the library's own choice of path)
@@ -78,6 +81,8 @@ def test_decode_form_equals_the_exact_kernels_on_random_shapes(torch_cuda, monke
     ran = 0
     for case in range(5):
         nq = int(r.choice([1, 3, 40, 130, 600]))
+        if large:
+            nq = int(r.choice([300, 2000, 5000]))
         k = int(r.choice([1, 10, 100, 128, 500, 1000]))
         nprobe = int(min(nlist, r.choice([1, 2, 8, 32, 256])))
         xq = (xb[r.integers(0, nb, nq)] + 0.05 * r.standard_normal((nq, d), dtype=np.float32)).astype(np.float32) \
