@@ -50,6 +50,9 @@
 
 namespace knhip {
 
+#ifndef PD_EXP
+#define PD_EXP 0 // experiment knock-outs (compile time): see pqd_scan
+#endif
 constexpr int PD_M = 32;
 constexpr int PD_KSUB = 256;
 constexpr int PD_D = 128;
@@ -284,6 +287,9 @@ __global__ __launch_bounds__(PD_KSUB) void pqd_query_prep_kernel(const float* __
             const float e_sub = PD_A * (1.0f + PD_UH) * (ysum * inv_q + q1 * inv_y) + 128.0f * PD_A * PD_A * inv_sc;
             const float e_acc = 136.0f * PD_U * ((1.0f + 3.0f * PD_UH) * B + 0.5f * pabs_max);
             eps = (F * (e_prod + e_sub + e_acc) + 128.0f * PD_U * (pabs_max + F * B)) * 1.001f;
+#if defined(PD_EXP) && (PD_EXP & 32)
+            eps *= 16.0f; // (experiment build: what an int8 contraction's bound would let through -- results stay exact)
+#endif
         }
         qd[q * 4 + 0] = q1;
         qd[q * 4 + 1] = B;
@@ -539,10 +545,8 @@ __device__ __forceinline__ int pqd_scan(const MScanArgs& a, unsigned char* smem,
     };
     // experiment knock-outs, COMPILE time (tools/build_pqd_variants.sh builds one library per mask; the results of such a
     // build are wrong, its filter time says what the removed part costs): 1 = nothing ever passes; 2 = no operand refill (no
-    // LDS gathers, no address arithmetic); 4 = no loads in the loop; 8 = no compare at all; 16 = no start-value instruction
-#ifndef PD_EXP
-#define PD_EXP 0
-#endif
+    // LDS gathers, no address arithmetic); 4 = no loads in the loop; 8 = no compare at all; 16 = no start-value instruction;
+    // 32 = the error bound times 16 (pqd_query_prep_kernel: what an int8 contraction would let through; results stay exact)
     constexpr int dbg = PD_EXP;
     // One maximum per lane and query tile, one ballot.  A lane whose maximum passes PARKS its 16 accumulator values as they
     // are (a record of 80 bytes in the wave's own LDS region: no atomic, no round trip -- the count is a wave-uniform
