@@ -290,6 +290,9 @@ __global__ __launch_bounds__(PD_KSUB) void pqd_query_prep_kernel(const float* __
 #if defined(PD_EXP) && (PD_EXP & 32)
             eps *= 16.0f; // (experiment build: what an int8 contraction's bound would let through -- results stay exact)
 #endif
+#if defined(PD_EXP) && (PD_EXP & 64)
+            eps *= 0.25f; // (experiment build: NOT a bound any more -- how much of the filter's time the band tau .. tau + eps is)
+#endif
         }
         qd[q * 4 + 0] = q1;
         qd[q * 4 + 1] = B;

@@ -43,10 +43,12 @@
 // ---- vector types ---------------------------------------------------------------------------------------------------
 struct alignas(8) uint2 { uint32_t x, y; };
 struct alignas(16) uint4 { uint32_t x, y, z, w; };
+struct alignas(8) int2 { int32_t x, y; };
 struct alignas(8) float2 { float x, y; };
 struct alignas(16) float4 { float x, y, z, w; };
 inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
 inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
+inline int2 make_int2(int32_t x, int32_t y) { return int2{x, y}; }
 inline float2 make_float2(float x, float y) { return float2{x, y}; }
 inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 struct dim3 {
