@@ -9,6 +9,7 @@
 // wrapper, id-map out ids, repeated Add, GetVectorByIds, cancellation, Deserialize of damaged blobs.
 // Catch2 is absent from this image, hence the tiny harness.
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <random>
@@ -49,6 +50,50 @@ static float GetKNNRecall(const knowhere::DataSet& gt, const knowhere::DataSet& 
         for (int64_t j = 0; j < res_k; j++) matched += a.count(res.GetIds()[i * res_k + j]);
     }
     return (float)matched / ((float)nq * res_k);
+}
+
+// An exhaustive scan on the HOST, in double precision, written here: the ground truth of the ground truth.  The recall bars
+// below compare the IVF indexes with BruteForce::Search, which in the standalone build is served by the device as well
+// (host/hip_brute_force.cc); this check ties that device scan to arithmetic that never touches the GPU.  Returns the number
+// of (query, rank) places where the device result is not explained by the host scan: the id must be among the host's rows
+// whose distance lies within `tol` (relative) of the host's value at that rank, and the distance must agree with the id's own.
+static int HostScanMismatches(const knowhere::DataSet& base, const knowhere::DataSet& queries, const knowhere::DataSet& res,
+                              bool is_l2, const uint8_t* bitset = nullptr, double tol = 5e-5) {
+    const int64_t nb = base.GetRows(), d = base.GetDim(), nq = queries.GetRows(), k = res.GetDim();
+    const float* xb = (const float*)base.GetTensor();
+    const float* xq = (const float*)queries.GetTensor();
+    int bad = 0;
+    std::vector<std::pair<double, int64_t>> all;
+    for (int64_t q = 0; q < nq; q++) {
+        all.clear();
+        for (int64_t i = 0; i < nb; i++) {
+            if (bitset != nullptr && (bitset[i >> 3] >> (i & 7)) & 1) continue;
+            double acc = 0.0;
+            for (int64_t j = 0; j < d; j++) {
+                const double a = xq[q * d + j], b = xb[i * d + j];
+                acc += is_l2 ? (a - b) * (a - b) : a * b;
+            }
+            all.emplace_back(is_l2 ? acc : -acc, i);  // ascending = best first for both metrics
+        }
+        std::sort(all.begin(), all.end());
+        std::vector<double> of_id(nb, 1e300);
+        for (auto& e : all) of_id[e.second] = e.first;
+        for (int64_t r = 0; r < k; r++) {
+            const int64_t id = res.GetIds()[q * k + r];
+            if (r >= (int64_t)all.size()) {
+                bad += id != -1;
+                continue;
+            }
+            const double want = all[r].first, scale = std::max(1.0, std::fabs(want));
+            if (id < 0 || id >= nb || std::fabs(of_id[id] - want) > tol * scale) {
+                bad++;
+                continue;
+            }
+            const double got = is_l2 ? res.GetDistance()[q * k + r] : -(double)res.GetDistance()[q * k + r];
+            bad += std::fabs(got - of_id[id]) > tol * scale;
+        }
+    }
+    return bad;
 }
 
 // tests/ut/utils.h GenerateBitsetWithFirstTbitsSet / RandomTbitsSet
@@ -173,6 +218,11 @@ int main() {
         REQUIRE(results.has_value());
         auto gt = BruteForce::Search<fp32>(train_ds, query_ds, c.cfg, nullptr);
         REQUIRE(gt.has_value());
+        {   // the ground truth itself against a host scan in double precision (not the device's own word for it)
+            const int bad = HostScanMismatches(*train_ds, *query_ds, *gt.value(), /*is_l2=*/true);
+            std::printf("   BruteForce::Search vs host double-precision scan: %d places differ\n", bad);
+            REQUIRE(bad == 0);
+        }
         float recall = GetKNNRecall(*gt.value(), *results.value());
         std::printf("   recall@1 %.4f (floor %.3f)\n", recall, c.min_recall);
         REQUIRE(recall >= c.min_recall);
@@ -183,6 +233,9 @@ int main() {
             auto r = idx.Search(query_ds, cfg, nullptr);
             auto g = BruteForce::Search<fp32>(train_ds, query_ds, cfg, nullptr);
             REQUIRE(r.has_value() && g.has_value());
+            if (std::string(c.name) == IndexEnum::INDEX_HIP_BRUTEFORCE) {
+                REQUIRE(HostScanMismatches(*train_ds, *query_ds, *g.value(), true) == 0);
+            }
             float rc = GetKNNRecall(*g.value(), *r.value());
             std::printf("   recall@%d %.4f\n", k, rc);
             REQUIRE(rc >= (std::string(c.name) == IndexEnum::INDEX_HIP_IVFPQ ? 0.5f : c.min_recall - 0.05f));
@@ -201,6 +254,9 @@ int main() {
                     leaked += id >= 0 && bv.test(id);
                 }
                 REQUIRE(leaked == 0);
+                if (std::string(c.name) == IndexEnum::INDEX_HIP_BRUTEFORCE) {  // (once: the same call for every index)
+                    REQUIRE(HostScanMismatches(*train_ds, *query_ds, *g.value(), true, bits.data()) == 0);
+                }
                 float rc = GetKNNRecall(*g.value(), *r.value());
                 REQUIRE(rc > (frac < 0.5f ? 0.7f : 0.4f));
             }
