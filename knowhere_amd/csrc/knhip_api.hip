@@ -37,8 +37,7 @@ int build_coarse_layout(knhip_index* idx) {
     std::vector<float> cn((size_t)idx->nlist);
     HIP_TRY(hipMemcpy(cn.data(), idx->cnorm.p, cn.size() * sizeof(float), hipMemcpyDeviceToHost));
     idx->cnorm_max = cn.empty() ? 0.f : *std::max_element(cn.begin(), cn.end());
-    const char* e = getenv("KNHIP_COARSE");
-    idx->coarse_gemm = (e && std::string(e) == "exact") ? 0 : ((e && std::string(e) == "fp32") ? 1 : 2);
+    idx->coarse_gemm = env_layout().coarse_gemm;
     return KNHIP_OK;
 }
 
@@ -223,13 +222,7 @@ int build_pq_skew(const knhip_index* cidx) {
 
 // flat / SQ8 indexes above this many code bytes keep only the interleaved layout (KNHIP_AOS_KEEP_MB overrides; tests
 // set it to 0 to exercise the rebuild path)
-size_t aos_keep_limit() {
-    const char* e = getenv("KNHIP_AOS_KEEP_MB");
-    if (e && *e) {
-        return (size_t)std::max<long long>(0, atoll(e)) << 20;
-    }
-    return (size_t)8 << 30;
-}
+size_t aos_keep_limit() { return env_layout().aos_keep_bytes; }
 
 // lay the lists out from device-resident, list-sorted AoS codes + ids
 int build_list_layout(knhip_index* idx, const std::vector<int64_t>& list_off, const uint8_t* d_codes,
@@ -243,27 +236,19 @@ int build_list_layout(knhip_index* idx, const std::vector<int64_t>& list_off, co
     idx->h_list_row_off.assign(list_off.begin(), list_off.begin() + nlist);
     idx->max_list_len = 0;
     {
-        const char* e = getenv("KNHIP_RANK0");
-        idx->rank0_select = !(e && e[0] == '0');
-        const char* h = getenv("KNHIP_HIST");
-        idx->cand_hist = !(h && h[0] == '0');
-        const char* q4 = getenv("KNHIP_Q4");
-        idx->pq_q4 = (q4 && q4[0] >= '0' && q4[0] <= '2') ? q4[0] - '0' : 2;
-        const char* ms = getenv("KNHIP_MSCAN");
-        idx->mscan = (ms && ms[0] >= '0' && ms[0] <= '2') ? ms[0] - '0' : 2;
-        const char* mf = getenv("KNHIP_MSCAN_FLAT");
-        idx->flat_bf16 = !(mf && std::string(mf) == "fp32");
-        const char* mc = getenv("KNHIP_MSCAN_CAP");
-        idx->mscan_cap = (mc && *mc) ? std::max(0, atoi(mc)) : 0;
-        const char* psp = getenv("KNHIP_PQD_SPILL");
-        idx->pqd_spill_cap = (psp && *psp) ? std::max(0, atoi(psp)) : 0;
+        const EnvLayout env = env_layout(); // (the switches an index keeps for its lifetime: knhip_env.h)
+        idx->rank0_select = env.rank0_select;
+        idx->cand_hist = env.cand_hist;
+        idx->pq_q4 = env.pq_q4;
+        idx->mscan = env.mscan;
+        idx->flat_bf16 = env.flat_bf16;
+        idx->mscan_cap = env.mscan_cap;
+        idx->pqd_spill_cap = env.pqd_spill_cap;
         idx->xnorm_ready = false;
-        const char* pf = getenv("KNHIP_PQF");
-        idx->pqf = (pf && pf[0] == '1') ? 2 : (pf && pf[0] == '0') ? 0 : 1;
-        const char* pg = getenv("KNHIP_PQF_GUARD");
-        idx->pqf_guard = !(pg && pg[0] == '0');
-        const char* pm = getenv("KNHIP_PQF_FORM");
-        idx->pqf_form = (pm && pm[0] == 'h') ? 1 : (pm && pm[0] == 'i') ? 2 : (pm && pm[0] == 'd') ? 3 : 0;
+        idx->pqf = env.pqf;
+        idx->pqf_guard = env.pqf_guard;
+        idx->pqf_form = env.pqf_form;
+        idx->pq_v1 = env.pq_v1;
         idx->psum_ready = false;
         idx->pqf_ready = false;
         idx->pqi_ready = false;
@@ -332,8 +317,7 @@ int build_list_layout(knhip_index* idx, const std::vector<int64_t>& list_off, co
                                         idx->rows.as<float4>(), nullptr));
     } else if (kind == KNHIP_IVF_PQ) {
         const int M = idx->desc.pq_m;
-        const char* v1 = getenv("KNHIP_PQ_V1");
-        idx->pq_v2 = (M == 32) && !(v1 && v1[0] == '1');
+        idx->pq_v2 = (M == 32) && !idx->pq_v1;
         idx->rows.release();
         idx->skew_ready = false;
         if (!idx->pq_v2 && pq_scan_supported_m(M)) {
@@ -841,8 +825,9 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
     // KNHIP_MS_SAMPLE_ROWS=n overrides (tests / experiments; 8192 = whole lists as in rounds 2-4)
     // (IVF-SQ8 too, now that its finish prunes: before that the looser tau cost C5's finish 2.7 ms for 1.1 ms saved here)
     int ms_sample_cap = std::min<int>(mscan_sample_rows(), (std::max(1024, 8 * k) + 63) / 64 * 64);
-    if (const char* e = getenv("KNHIP_MS_SAMPLE_ROWS")) {
-        ms_sample_cap = std::max(64, std::min(mscan_sample_rows(), atoi(e) / 64 * 64));
+    const EnvSearch env = env_search(); // (the switches every search reads: knhip_env.h)
+    if (env.ms_sample_rows > 0) {
+        ms_sample_cap = std::max(64, std::min(mscan_sample_rows(), env.ms_sample_rows / 64 * 64));
     }
     WorkTable wt{};
     wt.list_count = ws->list_count.as<int32_t>();
@@ -988,7 +973,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
         // C3) on a side stream while this stream runs the sample pass; only the cut into units waits for the form.
         SideJoin sj{ws, s};
         WorkTable wside = wt; // the table the filter pass reads (its own buffers when it is built on the side stream)
-        if (!wt1_lazy && getenv("KNHIP_NO_SIDE_STREAM") == nullptr) {
+        if (!wt1_lazy && !env.no_side_stream) {
             // IVF-Flat / IVF-SQ8: the sample pass reads the split table built above; the all-probes table of the filter pass
             // goes to a second set of buffers and is built beside the sample pass (0.35 ms per batch at C2, 1.5 ms at C5)
             HIP_TRY(ws->list_count2.reserve((size_t)2 * nlist * sizeof(int32_t)));
@@ -1018,7 +1003,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             HIP_TRY(hipEventRecord(ws->ev_join, ws->side));
             sj.forked = true;
         }
-        if (wt1_lazy && getenv("KNHIP_NO_SIDE_STREAM") == nullptr) {
+        if (wt1_lazy && !env.no_side_stream) {
             if (ws->side == nullptr) {
                 HIP_TRY(hipStreamCreateWithFlags(&ws->side, hipStreamNonBlocking));
                 HIP_TRY(hipEventCreateWithFlags(&ws->ev_fork, hipEventDisableTiming));
@@ -1084,8 +1069,8 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
             if (kind == KNHIP_IVF_PQ) {
                 // one workgroup per query: plan, fp32 table, sampled rows, and the statistics of both table forms
                 int scap = (int)sample;
-                if (const char* e = getenv("KNHIP_PQ_SAMPLE_ROWS")) { // (experiments: rows of the sample, at most)
-                    scap = std::max(64, std::min((int)sample, atoi(e)));
+                if (env.pq_sample_rows > 0) { // (experiments: rows of the sample, at most)
+                    scap = std::max(64, std::min((int)sample, env.pq_sample_rows));
                 }
                 HIP_TRY(launch_pq_sample(ds, keys_p, idx->cb.as<float4>(), nlist, std::max(1024, 8 * k), scap,
                                          idx->pabs_max, is_l2, ws->ms_nrow.as<int32_t>(), ws->ms_qs.as<float>(),
@@ -1173,7 +1158,7 @@ int search_batch(const knhip_index* idx, Workspace* ws, const float* d_q, int64_
                             e.form = decide(e.h_poor, e.pending_nq);
                         }
                         e.age++;
-                        static const bool always_sync = getenv("KNHIP_PQF_GUARD_SYNC") != nullptr;
+                        const bool always_sync = env.guard_sync;
                         if (e.form > 0 && !always_sync && (e.age & 63) != 0) {
                             sync_now = false;
                             form = e.form;
@@ -1943,9 +1928,8 @@ int add_vectors_common(knhip_index* idx, int64_t n, const float* d_x, const int6
     idx->rows_bs.release();
     idx->bf_norm.release();
     {
-        const char* e = getenv("KNHIP_BF");
-        const char* c = getenv("KNHIP_COARSE"); // (the switch of the stage whose machinery this is)
-        idx->bf_mfma = !(e && std::string(e) == "exact") && c == nullptr;
+        const EnvLayout env = env_layout(); // (KNHIP_COARSE: the switch of the stage whose machinery this is)
+        idx->bf_mfma = !env.bf_exact && !env.coarse_given;
     }
     return KNHIP_OK;
 }

@@ -200,7 +200,7 @@ static int range_batch(const knhip_index* idx, Workspace* ws, const float* d_q, 
     }
     bool counted = false;
     if (kind != KNHIP_BRUTE_FORCE) {
-        const bool waves = all_lists && max_empty > 0 && nprobe > 128 && getenv("KNHIP_RANGE_NO_WAVES") == nullptr;
+        const bool waves = all_lists && max_empty > 0 && nprobe > 128 && !env_search().range_no_waves;
         if (!waves) {
             if (int rc = scan_dump(ws->keys.as<int64_t>(), ws->cdis.as<float>(), nprobe)) return rc;
             if (all_lists) {
@@ -347,10 +347,7 @@ static int range_segments(const knhip_index* idx, hipStream_t s, const int64_t**
 // Not covered: k = 1024 (no room for the (k + 1)-th result), brute force with k >= 100 (the reference switches to a
 // reservoir, ResultHandler.h:719-728, whose boundary ties depend on its partition steps), lists sharded over several
 // indexes (every shard resolves its own candidates; the merge is canonical).
-static bool ties_reference_mode() {
-    const char* t = getenv("KNHIP_TIES");
-    return !(t && (t[0] == 'c' || t[0] == 'C' || t[0] == '0'));
-}
+static bool ties_reference_mode() { return !env_search().ties_canonical; }
 
 extern "C" int knhip_ties_rule_applies(int32_t kind, int32_t k) {
     const bool reservoir = kind == KNHIP_BRUTE_FORCE && k >= 100;
@@ -367,7 +364,7 @@ static int tie_arrivals(const knhip_index* idx, Workspace* ws, const float* d_q,
                         int64_t* arr_key, int64_t* arr_n, hipStream_t s) {
     const int kind = idx->desc.kind;
     const bool is_l2 = idx->is_l2;
-    const bool trace = getenv("KNHIP_TIES_TRACE") != nullptr;
+    const bool trace = env_search().ties_trace;
     int64_t nseg = 0, ncol = 0;
     const int64_t* d_seg = nullptr;
     if (int rc = range_segments(idx, s, &d_seg, &nseg, &ncol)) return rc;
@@ -464,7 +461,7 @@ int search_batch_ties(const knhip_index* idx, Workspace* ws, const float* d_q, i
     if (!knhip_ties_rule_applies(kind, k)) {
         return search_batch(idx, ws, d_q, nq, k, nprobe, d_bitset, nbits, d_out_i, d_out_d, s, pre_keys, pre_cdis);
     }
-    const bool trace = getenv("KNHIP_TIES_TRACE") != nullptr;
+    const bool trace = env_search().ties_trace;
     const int kk = k + 1;
     if (trace) fprintf(stderr, "[ties] search nq=%lld k=%d nprobe=%d kind=%d\n", (long long)nq, k, nprobe, kind);
     const bool is_l2 = idx->is_l2;

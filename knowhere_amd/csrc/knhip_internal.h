@@ -5,6 +5,7 @@
 #include "../../include/knhip.h"
 #include "common.h"
 #include "kernels.h"
+#include "knhip_env.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -219,6 +220,7 @@ struct knhip_index {
     int pq_q4 = 2;             // KNHIP_Q4 = 0: never, 1: whenever the shape allows, 2 (default): when lists are shared by enough queries
     bool rank0_select = true;  // KNHIP_RANK0=0 switches the dump + radix-select phase off
     bool cand_hist = true;     // KNHIP_HIST=0 switches the per-query candidate histogram off
+    bool pq_v1 = false;        // KNHIP_PQ_V1=1: m = 32 on the round-1 layout
     mutable bool rank0_phase_used = false;
     int64_t max_list_len = 0;
     // MFMA prefilter (mfma_scan.hip): KNHIP_MSCAN = 0 never, 1 whenever the shape allows, 2 (default) when the lists

@@ -44,6 +44,7 @@
 // scan is LDS/VALU-issue bound, not HBM bound (DESIGN.md section 4 has the cycle budget).
 #include "common.h"
 #include "kernels.h"
+#include "knhip_env.h"
 
 #include <cstdlib>
 
@@ -530,10 +531,7 @@ static hipError_t launch_pq_scan_rw(const PqScanArgs& a, int64_t grid, hipStream
 // R = 16 with 4 waves so the cross-wave merge area (QG * waves * k * 12 B) still fits the LDS.
 template <bool IS_L2, int M, int QG>
 static hipError_t launch_pq_scan_m(const PqScanArgs& a, int64_t grid, hipStream_t s) {
-    static const int waves = [] {
-        const char* e = getenv("KNHIP_PQ_WAVES");
-        return e ? atoi(e) : 8;
-    }();
+    static const int waves = knhip_host::env_layout().pq_waves; // (tuning knob, read once per process: knhip_env.h)
     const int k = a.k;
     if (k > 128) {
         return launch_pq_scan_rw<IS_L2, M, QG, 16, 4>(a, grid, s);

@@ -120,7 +120,7 @@ def build_api(force=False):
     harness (knowhere_amd/index.py) and orchestration (knhip_api.hip)"""
     os.makedirs(BUILD, exist_ok=True)
     so = os.path.join(BUILD, "libknhip_emu.so")
-    srcs = [os.path.join(CSRC, f) for f in API_FILES + ["common.h", "kernels.h", "ms_common.h", "knhip_internal.h"]]
+    srcs = [os.path.join(CSRC, f) for f in API_FILES + ["common.h", "kernels.h", "ms_common.h", "knhip_internal.h", "knhip_env.h"]]
     srcs += [os.path.join(HERE, f) for f in ("emu_runtime.cpp", "emu_build.py", "hip/hip_runtime.h")]
     if not force and os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(p) for p in srcs):
         return so
