@@ -210,7 +210,12 @@ __device__ __forceinline__ float cr_unkey_fwd(uint32_t key) {
 
 typedef __bf16 cg_bf8 __attribute__((ext_vector_type(8)));
 typedef __bf16 cg_bf4 __attribute__((ext_vector_type(4)));
-constexpr int CB_BM = 128, CB_BN = 128, CB_BK = 32;
+constexpr int CB_BM = 256, CB_BN = 128, CB_BK = 32; // rows (centroids) x queries per workgroup tile, dimensions per slab
+constexpr int CB_WI = 4;                            // a wave holds CB_WI x 2 MFMA tiles: rows (wave >> 1) * 128 .. + 128, queries
+                                                    // (wave & 1) * 64 .. + 64.  Round 6: 2 x 2 tiles per wave read 8 operand
+                                                    // fragments per 12 matrix instructions -- with the staging stores the LDS
+                                                    // was as busy as the matrix pipe (both at half their rate); 4 x 2 tiles read
+                                                    // 12 per 24
 constexpr int CB_ROW = 144; // bytes per staged row: 32 hi + 32 lo bf16 + 16 of padding (16 rows -> 16 different bank quads)
 
 // fp32 rows [n][d] -> the split operand rows the GEMM stages without touching them: per row and k slab of 32 dimensions
@@ -246,7 +251,7 @@ __global__ void cb_split_rows_kernel(const float* __restrict__ x, int64_t n, int
 
 // MODE 1: gmin[query][group] group minima (maxima for IP).  MODE 2: candidates appended where approx <= bound.
 template <bool IS_L2, int MODE>
-__global__ __launch_bounds__(256) void coarse_bf16_kernel(const unsigned char* __restrict__ Qs, const float* __restrict__ qn,
+__global__ __launch_bounds__(256, 2) void coarse_bf16_kernel(const unsigned char* __restrict__ Qs, const float* __restrict__ qn,
                                                           const unsigned char* __restrict__ Cs, const float* __restrict__ cn,
                                                           int64_t nq, int64_t nlist, int nslab, int64_t tiles_q,
                                                           int64_t ntiles, float* __restrict__ gmin, int G,
@@ -255,7 +260,7 @@ __global__ __launch_bounds__(256) void coarse_bf16_kernel(const unsigned char* _
     __align__(16) __shared__ unsigned char sA[CB_BM * CB_ROW];
     __align__(16) __shared__ unsigned char sB[CB_BN * CB_ROW];
     __shared__ float s_cn[CB_BM];
-    __shared__ float s_gm[8][CB_BN]; // group minima of the tile: 4 groups of 32 centroids, or 8 of 16 (g16)
+    __shared__ float s_gm[CB_BM / 16][CB_BN]; // group minima of the tile: 8 groups of 32 centroids, or 16 of 16 (g16)
     // XCD-aware tile order: consecutive tile ids share the centroid panel
     const int64_t per = (ntiles + 7) / 8;
     const int64_t tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
@@ -265,13 +270,14 @@ __global__ __launch_bounds__(256) void coarse_bf16_kernel(const unsigned char* _
     const int64_t tc = tile / tiles_q, tq = tile % tiles_q;
     const int64_t c0 = tc * CB_BM, q0 = tq * CB_BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-    if (IS_L2 && tid < CB_BM) {
+    const int wm = (wave >> 1) * (32 * CB_WI), wn = (wave & 1) * 64;
+    static_assert(CB_BM == 256 && 2 * 32 * CB_WI == CB_BM, "one s_cn entry per thread, two wave rows");
+    if (IS_L2) {
         s_cn[tid] = c0 + tid < nlist ? cn[c0 + tid] : 0.f;
     }
-    f32x16 acc[2][2];
+    f32x16 acc[CB_WI][2];
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < CB_WI; i++) {
 #pragma unroll
         for (int j = 0; j < 2; j++) {
 #pragma unroll
@@ -280,17 +286,22 @@ __global__ __launch_bounds__(256) void coarse_bf16_kernel(const unsigned char* _
             }
         }
     }
-    // staging: 1024 pieces of 16 bytes per operand and slab, four per thread; rows past the end are zero
-    uint4 va[4], vb[4];
+    // staging: 2048 + 1024 pieces of 16 bytes per slab, eight + four per thread; rows past the end are zero
+    constexpr int NA = CB_BM * 8 / 256, NB = CB_BN * 8 / 256;
+    uint4 va[NA], vb[NB];
     auto fetch = [&](int slab) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < NA; j++) {
             const int p = tid + 256 * j, row = p >> 3, piece = p & 7;
             va[j] = make_uint4(0u, 0u, 0u, 0u);
-            vb[j] = make_uint4(0u, 0u, 0u, 0u);
             if (c0 + row < nlist) {
                 va[j] = *reinterpret_cast<const uint4*>(Cs + ((c0 + row) * nslab + slab) * 128 + piece * 16);
             }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+            const int p = tid + 256 * j, row = p >> 3, piece = p & 7;
+            vb[j] = make_uint4(0u, 0u, 0u, 0u);
             if (q0 + row < nq) {
                 vb[j] = *reinterpret_cast<const uint4*>(Qs + ((q0 + row) * nslab + slab) * 128 + piece * 16);
             }
@@ -299,9 +310,13 @@ __global__ __launch_bounds__(256) void coarse_bf16_kernel(const unsigned char* _
     fetch(0);
     for (int slab = 0; slab < nslab; slab++) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < NA; j++) {
             const int p = tid + 256 * j, row = p >> 3, piece = p & 7;
             *reinterpret_cast<uint4*>(sA + row * CB_ROW + piece * 16) = va[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+            const int p = tid + 256 * j, row = p >> 3, piece = p & 7;
             *reinterpret_cast<uint4*>(sB + row * CB_ROW + piece * 16) = vb[j];
         }
         __syncthreads();
@@ -311,18 +326,21 @@ __global__ __launch_bounds__(256) void coarse_bf16_kernel(const unsigned char* _
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) { // two k steps of 16: lane (row = lane & 31, k half = lane >> 5) holds 8 consecutive k
             const int ko = (ks * 16 + (lane >> 5) * 8) * 2;
-            cg_bf8 ah[2], al[2], bh[2], bl[2];
+            cg_bf8 ah[CB_WI], al[CB_WI], bh[2], bl[2];
 #pragma unroll
-            for (int i = 0; i < 2; i++) {
+            for (int i = 0; i < CB_WI; i++) {
                 const unsigned char* pa = sA + (wm + i * 32 + (lane & 31)) * CB_ROW + ko;
                 ah[i] = *reinterpret_cast<const cg_bf8*>(pa);
                 al[i] = *reinterpret_cast<const cg_bf8*>(pa + 64);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
                 const unsigned char* pb = sB + (wn + i * 32 + (lane & 31)) * CB_ROW + ko;
                 bh[i] = *reinterpret_cast<const cg_bf8*>(pb);
                 bl[i] = *reinterpret_cast<const cg_bf8*>(pb + 64);
             }
 #pragma unroll
-            for (int i = 0; i < 2; i++) {
+            for (int i = 0; i < CB_WI; i++) {
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
@@ -343,9 +361,9 @@ __global__ __launch_bounds__(256) void coarse_bf16_kernel(const unsigned char* _
         if (MODE == 2) {
             bnd = qok ? bound[query] : (IS_L2 ? -INFINITY : INFINITY);
         }
-        uint32_t hit[2] = {0u, 0u}; // MODE 2: which of the lane's 2 x 16 values pass (bit r of block i)
+        uint32_t hit[CB_WI] = {}; // MODE 2: which of the lane's CB_WI x 16 values pass (bit r of block i)
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < CB_WI; i++) {
             float best = IS_L2 ? INFINITY : -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
@@ -381,11 +399,15 @@ __global__ __launch_bounds__(256) void coarse_bf16_kernel(const unsigned char* _
         if (MODE == 2) {
             // ONE returning atomic per lane for all its hits of this query block (a returning atomic per hit made the wave
             // wait a memory round trip ~40 times per tile: 465 us of the stage at C3), then the ids go to their slots
-            const int nh = __popc(hit[0]) + __popc(hit[1]);
+            int nh = 0;
+#pragma unroll
+            for (int i = 0; i < CB_WI; i++) {
+                nh += __popc(hit[i]);
+            }
             if (nh > 0) {
                 int n = atomicAdd(cand_cnt + query, nh);
 #pragma unroll
-                for (int i = 0; i < 2; i++) {
+                for (int i = 0; i < CB_WI; i++) {
                     uint32_t m = hit[i];
                     while (m != 0u) {
                         const int r = __ffs((int)m) - 1;
@@ -400,16 +422,13 @@ __global__ __launch_bounds__(256) void coarse_bf16_kernel(const unsigned char* _
         }
     }
     if (MODE == 1) {
-        // the tile's 128 queries x 4 groups: one 16-byte store per query (gmin [nq][G]: a row per query for the bound kernel)
+        // the tile's 128 queries x 8 (16) groups: 16-byte stores per query (gmin [nq][G]: a row per query for the bound kernel)
         __syncthreads();
         if (tid < CB_BN && q0 + tid < nq) {
-            const float4 o = make_float4(s_gm[0][tid], s_gm[1][tid], s_gm[2][tid], s_gm[3][tid]);
-            if (g16) {
-                const float4 o2 = make_float4(s_gm[4][tid], s_gm[5][tid], s_gm[6][tid], s_gm[7][tid]);
-                *reinterpret_cast<float4*>(gmin + (q0 + tid) * G + c0 / 16) = o;
-                *reinterpret_cast<float4*>(gmin + (q0 + tid) * G + c0 / 16 + 4) = o2;
-            } else {
-                *reinterpret_cast<float4*>(gmin + (q0 + tid) * G + c0 / 32) = o;
+            const int ng = g16 ? CB_BM / 16 : CB_BM / 32;
+            float* o = gmin + (q0 + tid) * G + c0 / (g16 ? 16 : 32);
+            for (int g = 0; g < ng; g += 4) {
+                *reinterpret_cast<float4*>(o + g) = make_float4(s_gm[g][tid], s_gm[g + 1][tid], s_gm[g + 2][tid], s_gm[g + 3][tid]);
             }
         }
     }

@@ -158,7 +158,7 @@ def test_coarse_bf16_prefilter(torch_cuda, port, metric, d):
     torch = torch_cuda
     from knowhere_amd import GpuIndex
     from knowhere_amd.index import IVF_FLAT
-    nlist, nq = 4096 + 40, 333  # (neither a multiple of the 128 x 128 tile)
+    nlist, nq = 4096 + 40, 333  # (neither a multiple of the 256 x 128 tile)
     rng = np.random.default_rng(5)
     cen = (rng.random((nlist, d), dtype=np.float32) * 100).astype(np.float32)
     xq = (rng.random((nq, d), dtype=np.float32) * 100).astype(np.float32)
