@@ -56,72 +56,102 @@ __global__ void wt_count_kernel(const int64_t* __restrict__ keys, int64_t npairs
     }
 }
 
-// single workgroup: exclusive scans of pair counts and item counts over the lists
+// single workgroup: exclusive scans of pair counts and item counts over the lists.  Round 6: the lists are walked in chunks of
+// 4096, four CONSECUTIVE lists per thread (16 bytes of counts per thread: coalesced), a wave scan by shuffles and 16 wave
+// totals through LDS per chunk.  (Before: every thread walked its own run of nlist / 1024 lists -- each load instruction
+// touched 1024 cache lines, twice per list: 0.31 ms at 2 x 16384 virtual lists, 0.40 ms at 2 x 65536.)
 constexpr int WT_SCAN_THREADS = 1024;
+constexpr int WT_SCAN_PER = 4;
 __global__ __launch_bounds__(WT_SCAN_THREADS) void wt_scan_kernel(
         const int32_t* __restrict__ list_count, const int64_t* __restrict__ list_len, int64_t nlist,
         int64_t nreal, int qg0, int qg1, int64_t code_size, int64_t* list_pair_off, int64_t* list_item_off,
         int64_t* nitems, double* scan_bytes) {
-    __shared__ int64_t s_pairs[WT_SCAN_THREADS];
-    __shared__ int64_t s_items[WT_SCAN_THREADS];
-    __shared__ double s_bytes[WT_SCAN_THREADS];
-    const int tid = threadIdx.x;
-    const int64_t per = (nlist + WT_SCAN_THREADS - 1) / WT_SCAN_THREADS;
-    const int64_t l0 = (int64_t)tid * per;
-    const int64_t l1 = min(l0 + per, nlist);
-    __shared__ double s_bytes0[WT_SCAN_THREADS];
-    int64_t np = 0, ni = 0;
+    constexpr int NW = WT_SCAN_THREADS / KN_WAVE;
+    __shared__ long long s_wp[NW], s_wi[NW];
+    __shared__ double s_wb[NW], s_wb0[NW];
+    const int tid = threadIdx.x, lane = tid & (KN_WAVE - 1), wave = tid / KN_WAVE;
+    long long carry_p = 0, carry_i = 0; // (the same in every thread)
     double nb = 0.0, nb0 = 0.0;
-    for (int64_t l = l0; l < l1; l++) {
-        const int64_t c = list_count[l];
-        const int qg = l < nreal ? qg0 : qg1;
-        np += c;
-        ni += (c + qg - 1) / qg;
-        const double b = (double)c * (double)list_len[l % nreal] * (double)code_size;
-        nb += b;
-        if (l < nreal) {
-            nb0 += b; // rank-0 probes (virtual lists [0, nreal))
+    for (int64_t c0 = 0; c0 < nlist; c0 += (int64_t)WT_SCAN_THREADS * WT_SCAN_PER) {
+        const int64_t l0 = c0 + (int64_t)tid * WT_SCAN_PER;
+        long long p[WT_SCAN_PER], it[WT_SCAN_PER], tp = 0, ti = 0;
+#pragma unroll
+        for (int e = 0; e < WT_SCAN_PER; e++) {
+            const int64_t l = l0 + e;
+            p[e] = 0;
+            it[e] = 0;
+            if (l < nlist) {
+                const long long c = list_count[l];
+                const int qg = l < nreal ? qg0 : qg1;
+                p[e] = c;
+                it[e] = (c + qg - 1) / qg;
+                const double b = (double)c * (double)list_len[l % nreal] * (double)code_size;
+                nb += b;
+                if (l < nreal) {
+                    nb0 += b; // rank-0 probes (virtual lists [0, nreal))
+                }
+            }
+            tp += p[e];
+            ti += it[e];
         }
+        long long ip = tp, ii = ti; // inclusive scan over the wave's lanes
+        for (int d = 1; d < KN_WAVE; d <<= 1) {
+            const long long up = __shfl_up(ip, d, KN_WAVE), ui = __shfl_up(ii, d, KN_WAVE);
+            if (lane >= d) {
+                ip += up;
+                ii += ui;
+            }
+        }
+        if (lane == KN_WAVE - 1) {
+            s_wp[wave] = ip;
+            s_wi[wave] = ii;
+        }
+        __syncthreads();
+        long long wp = 0, wi = 0, cp = 0, ci = 0;
+        for (int w = 0; w < NW; w++) {
+            const long long a = s_wp[w], b = s_wi[w];
+            if (w < wave) {
+                wp += a;
+                wi += b;
+            }
+            cp += a;
+            ci += b;
+        }
+        long long pp = carry_p + wp + (ip - tp), qq = carry_i + wi + (ii - ti); // exclusive prefixes of the thread's first list
+#pragma unroll
+        for (int e = 0; e < WT_SCAN_PER; e++) {
+            const int64_t l = l0 + e;
+            if (l < nlist) {
+                list_pair_off[l] = pp;
+                list_item_off[l] = qq;
+            }
+            pp += p[e];
+            qq += it[e];
+        }
+        carry_p += cp;
+        carry_i += ci;
+        __syncthreads(); // (the wave totals are rewritten by the next chunk)
     }
-    s_bytes0[tid] = nb0;
-    s_pairs[tid] = np;
-    s_items[tid] = ni;
-    s_bytes[tid] = nb;
+    // the byte counters: exact in double whatever the order (integers far below 2^53)
+    for (int off = KN_WAVE / 2; off > 0; off >>= 1) {
+        nb += __shfl_xor(nb, off, KN_WAVE);
+        nb0 += __shfl_xor(nb0, off, KN_WAVE);
+    }
+    if (lane == 0) {
+        s_wb[wave] = nb;
+        s_wb0[wave] = nb0;
+    }
     __syncthreads();
-    // Hillis-Steele inclusive scan over the 1024 per-thread totals
-    for (int off = 1; off < WT_SCAN_THREADS; off <<= 1) {
-        int64_t a = 0, b = 0;
-        double c = 0.0;
-        if (tid >= off) {
-            a = s_pairs[tid - off];
-            b = s_items[tid - off];
-            c = s_bytes[tid - off];
+    if (tid == 0) {
+        double t = 0.0, t0 = 0.0;
+        for (int w = 0; w < NW; w++) {
+            t += s_wb[w];
+            t0 += s_wb0[w];
         }
-        __syncthreads();
-        s_pairs[tid] += a;
-        s_items[tid] += b;
-        s_bytes[tid] += c;
-        __syncthreads();
-    }
-    int64_t pp = s_pairs[tid] - np; // exclusive prefix
-    int64_t ii = s_items[tid] - ni;
-    for (int64_t l = l0; l < l1; l++) {
-        const int64_t c = list_count[l];
-        const int qg = l < nreal ? qg0 : qg1;
-        list_pair_off[l] = pp;
-        list_item_off[l] = ii;
-        pp += c;
-        ii += (c + qg - 1) / qg;
-    }
-    if (tid == WT_SCAN_THREADS - 1) {
-        list_pair_off[nlist] = s_pairs[tid];
-        list_item_off[nlist] = s_items[tid];
-        *nitems = s_items[tid];
-        *scan_bytes += s_bytes[tid]; // accumulated across query batches; reset by the host
-        double t0 = 0.0;
-        for (int i = 0; i < WT_SCAN_THREADS; i++) {
-            t0 += s_bytes0[i];
-        }
+        list_pair_off[nlist] = carry_p;
+        list_item_off[nlist] = carry_i;
+        *nitems = carry_i;
+        scan_bytes[0] += t; // accumulated across query batches; reset by the host
         scan_bytes[1] += t0;
     }
 }
