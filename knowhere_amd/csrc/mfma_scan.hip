@@ -95,39 +95,60 @@ hipError_t launch_ms_block_norms(const float4* rows, int64_t total_blk, int nchu
 // ---- units: (bulk virtual list, group of up to qt of its pairs) -----------------------------------------------
 // (`*_v` arrays are the work table's, offset to the virtual-list range the units are made from: [0, nlist) = the
 // rank-0 probes, [nlist, 2 nlist) = the others)
-// single workgroup: exclusive scan of ceil(count / qt) over the lists
+// single workgroup: exclusive scan of ceil(count / qt) over the lists -- chunks of 4096 lists, four consecutive lists per
+// thread (coalesced), wave scans by shuffles (worktable.hip::wt_scan_kernel: the per-thread runs of the first form cost a
+// cache line per thread and load)
 constexpr int MS_SCAN_THREADS = 1024;
+constexpr int MS_SCAN_PER = 4;
 __global__ __launch_bounds__(MS_SCAN_THREADS) void ms_unit_scan_kernel(const int32_t* __restrict__ list_count_v,
                                                                        int64_t nlist, int qt,
                                                                        int64_t* __restrict__ unit_off,
                                                                        int64_t* __restrict__ nunits) {
-    __shared__ int64_t s_n[MS_SCAN_THREADS];
-    const int tid = threadIdx.x;
-    const int64_t per = (nlist + MS_SCAN_THREADS - 1) / MS_SCAN_THREADS;
-    const int64_t l0 = (int64_t)tid * per, l1 = min(l0 + per, nlist);
-    int64_t n = 0;
-    for (int64_t l = l0; l < l1; l++) {
-        n += (list_count_v[l] + qt - 1) / qt;
-    }
-    s_n[tid] = n;
-    __syncthreads();
-    for (int off = 1; off < MS_SCAN_THREADS; off <<= 1) {
-        int64_t a = 0;
-        if (tid >= off) {
-            a = s_n[tid - off];
+    constexpr int NW = MS_SCAN_THREADS / KN_WAVE;
+    __shared__ long long s_w[NW];
+    const int tid = threadIdx.x, lane = tid & (KN_WAVE - 1), wave = tid / KN_WAVE;
+    long long carry = 0; // (the same in every thread)
+    for (int64_t c0 = 0; c0 < nlist; c0 += (int64_t)MS_SCAN_THREADS * MS_SCAN_PER) {
+        const int64_t l0 = c0 + (int64_t)tid * MS_SCAN_PER;
+        long long n[MS_SCAN_PER], tn = 0;
+#pragma unroll
+        for (int e = 0; e < MS_SCAN_PER; e++) {
+            const int64_t l = l0 + e;
+            n[e] = l < nlist ? (list_count_v[l] + qt - 1) / qt : 0;
+            tn += n[e];
+        }
+        long long in = tn; // inclusive scan over the wave's lanes
+        for (int d = 1; d < KN_WAVE; d <<= 1) {
+            const long long up = __shfl_up(in, d, KN_WAVE);
+            if (lane >= d) {
+                in += up;
+            }
+        }
+        if (lane == KN_WAVE - 1) {
+            s_w[wave] = in;
         }
         __syncthreads();
-        s_n[tid] += a;
-        __syncthreads();
+        long long before = 0, total = 0;
+        for (int w = 0; w < NW; w++) {
+            const long long a = s_w[w];
+            before += w < wave ? a : 0;
+            total += a;
+        }
+        long long u = carry + before + (in - tn);
+#pragma unroll
+        for (int e = 0; e < MS_SCAN_PER; e++) {
+            const int64_t l = l0 + e;
+            if (l < nlist) {
+                unit_off[l] = u;
+            }
+            u += n[e];
+        }
+        carry += total;
+        __syncthreads(); // (the wave totals are rewritten by the next chunk)
     }
-    int64_t u = s_n[tid] - n;
-    for (int64_t l = l0; l < l1; l++) {
-        unit_off[l] = u;
-        u += (list_count_v[l] + qt - 1) / qt;
-    }
-    if (tid == MS_SCAN_THREADS - 1) {
-        unit_off[nlist] = s_n[tid];
-        *nunits = s_n[tid];
+    if (tid == 0) {
+        unit_off[nlist] = carry;
+        *nunits = carry;
     }
 }
 
